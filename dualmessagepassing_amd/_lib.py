@@ -1,0 +1,166 @@
+"""ctypes binding of libdmp_hip.so (the C ABI declared in include/dmp_hip.h).
+
+The product path has no CPU fallback: if the shared library cannot be built or
+loaded, or a tensor is not on an AMD GPU, the ops raise.
+"""
+import ctypes
+import os
+import threading
+
+from . import _build
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dmp_hip.h one to one.
+SIGNATURES = {
+    "dmp_abi_version": (c_int, []),
+    "dmp_last_hip_error": (ctypes.c_char_p, []),
+    "dmp_csr_workspace_words": (c_size, [c_i64, c_i64]),
+    "dmp_csr_build": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_incidence_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "dmp_degree_coef": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_collate": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                            c_ptr, c_ptr, c_ptr]),
+    "dmp_add_reversed_edges": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64,
+                                       c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_line_graph_count": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_line_graph_fill": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_first_edge_of_id": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "dmp_dedupe_table_words": (c_size, [c_i64]),
+    "dmp_dedupe_first": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "dmp_scan_workspace_words": (c_size, [c_i64]),
+    "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_seg_sum2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64,
+                             c_ptr]),
+    "dmp_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_gather_select": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr,
+                                  c_i64, c_ptr]),
+    "dmp_edge_combine": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                 c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_edge_combine_bwd_g": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_compgcn_agg": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
+                                c_ptr, c_i64, c_ptr]),
+    "dmp_compgcn_agg_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                    c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+}
+
+ABI_VERSION = 1
+ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
+
+
+class DmpError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load (building first if needed) libdmp_hip.so; raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if build_if_missing:
+            try:
+                path = _build.build_lib()
+            except Exception:
+                if not os.path.exists(path):
+                    raise
+        if not os.path.exists(path):
+            raise DmpError("libdmp_hip.so is missing (%s); run __graft_entry__.build()" % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dmp_abi_version() != ABI_VERSION:
+            raise DmpError("libdmp_hip.so ABI %d != binding ABI %d" % (lib.dmp_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code == 0:
+        return
+    msg = ERRORS.get(code, "error %d" % code)
+    if code == -3:
+        msg += ": " + (load().dmp_last_hip_error() or b"").decode(errors="replace")
+    raise DmpError("%s failed: %s" % (what, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or NULL for None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DmpError(
+                "dualmessagepassing_amd ops run on an AMD GPU only (tensor on %s); "
+                "there is no CPU fallback in the product path" % (t.device,))
+
+
+# ----------------------------------------------------------------------------- per-launch timing
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the launch stream (bench.py's
+    ``roofline`` numbers).  Disabled by default: zero cost in the product path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}  # name -> list of (start_event, end_event, algorithmic_bytes)
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """name -> dict(launches, avg_us, bytes, gbps); synchronises the device."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            nbytes = sum(r[2] for r in recs) / len(recs)
+            avg = sum(ms) / len(ms)
+            out[name] = {"launches": len(recs), "avg_us": avg * 1e3, "bytes": nbytes,
+                         "gbps": nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0}
+        return out
+
+
+timer = KernelTimer()
+
+
+class timed:
+    """``with timed(name, nbytes): <one kernel launch>``"""
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if timer.enabled:
+            import torch
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timer.enabled:
+            self.b.record()
+            timer.records.setdefault(self.name, []).append((self.a, self.b, self.nbytes))
+        return False

@@ -1,0 +1,660 @@
+// Aggregation kernels of the dual-message-passing hot path (gfx950 / MI355X).
+//
+// All of them are HBM-bound row movers over fp32 feature rows of H floats
+// (512 B at H = 128).  Common shape: a group of G = H/4 lanes (16, 32 or 64)
+// owns one row and moves it as one float4 (16 B) per lane, so every
+// wave-instruction moves 1 KiB in whole 128-B lines; 256-thread workgroups,
+// XCD-aware row->workgroup mapping (dmp_common.h) so the node rows a batched
+// graph's edges re-read are served by one XCD's L2.
+//
+//   seg_sum / seg_sum2   CSR segment sum by destination, atomics-free, fixed
+//                        (ascending eid) order  -> run-to-run bit-stable
+//   gather_rows          out[e] = X[idx[e]]
+//   gather_select        backward of seg_sum2
+//   edge_combine         fused DMPLayer edge pre-activation
+//   edge_combine_bwd_g   its backward w.r.t. the per-edge GEMM output
+//   compgcn_agg(+bwd)    CompGCN composition fused into the segment sum
+//
+// Reference call sites are cited in include/dmp_hip.h.
+#include "dmp_common.h"
+
+namespace dmp {
+
+static thread_local char g_last_err[256] = "";
+void set_last_hip_error(hipError_t e) {
+  const char *s = hipGetErrorString(e);
+  int i = 0;
+  for (; s && s[i] && i < 255; ++i) g_last_err[i] = s[i];
+  g_last_err[i] = 0;
+}
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void st4(float *p, const float4 &v) {
+  *reinterpret_cast<float4 *>(p) = v;
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void add4(float4 &a, const float4 &b) {
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+__device__ __forceinline__ float4 mul4(const float4 &a, float s) {
+  return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ float4 sub4(const float4 &a, const float4 &b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+__device__ __forceinline__ float4 had4(const float4 &a, const float4 &b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
+// ---------------------------------------------------------------------------
+// Segment sum.  One G-lane group per destination row.  The group's lanes first
+// fetch up to G CSR entries with one coalesced load, then the entries are
+// broadcast by shuffle and the source rows are fetched four at a time (four
+// independent 16-B loads in flight per lane) and added in CSR order.
+// ---------------------------------------------------------------------------
+template <int G, bool SPLIT, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void seg_sum_vec(
+    const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
+    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  constexpr int RPB = kBlock / G;
+  const int row = xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G;
+  const int lane = threadIdx.x % G;
+  if (row >= N) return;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  for (int c0 = 0; c0 < H; c0 += G * 4) {
+    const int c = c0 + lane * 4;
+    const bool act = c < H;
+    float4 a0 = zero4(), a1 = zero4();
+    for (int base = beg; base < end; base += G) {
+      const int cnt = min(G, end - base);
+      int my = 0;
+      float myw = 1.f;
+      if (lane < cnt) {
+        my = ent[base + lane];
+        if (WEIGHTED) myw = ew[my >> 1];
+      }
+      int j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const int e0 = __shfl(my, j, G), e1 = __shfl(my, j + 1, G);
+        const int e2 = __shfl(my, j + 2, G), e3 = __shfl(my, j + 3, G);
+        float w0 = 1.f, w1 = 1.f, w2 = 1.f, w3 = 1.f;
+        if (WEIGHTED) {
+          w0 = __shfl(myw, j, G); w1 = __shfl(myw, j + 1, G);
+          w2 = __shfl(myw, j + 2, G); w3 = __shfl(myw, j + 3, G);
+        }
+        if (act) {
+          float4 v0 = ld4(M + (int64_t)(e0 >> 1) * ldm + c);
+          float4 v1 = ld4(M + (int64_t)(e1 >> 1) * ldm + c);
+          float4 v2 = ld4(M + (int64_t)(e2 >> 1) * ldm + c);
+          float4 v3 = ld4(M + (int64_t)(e3 >> 1) * ldm + c);
+          if (WEIGHTED) { v0 = mul4(v0, w0); v1 = mul4(v1, w1); v2 = mul4(v2, w2); v3 = mul4(v3, w3); }
+          if (SPLIT) {
+            if (e0 & 1) add4(a1, v0); else add4(a0, v0);
+            if (e1 & 1) add4(a1, v1); else add4(a0, v1);
+            if (e2 & 1) add4(a1, v2); else add4(a0, v2);
+            if (e3 & 1) add4(a1, v3); else add4(a0, v3);
+          } else {
+            add4(a0, v0); add4(a0, v1); add4(a0, v2); add4(a0, v3);
+          }
+        }
+      }
+      for (; j < cnt; ++j) {
+        const int e0 = __shfl(my, j, G);
+        float w0 = 1.f;
+        if (WEIGHTED) w0 = __shfl(myw, j, G);
+        if (act) {
+          float4 v0 = ld4(M + (int64_t)(e0 >> 1) * ldm + c);
+          if (WEIGHTED) v0 = mul4(v0, w0);
+          if (SPLIT && (e0 & 1)) add4(a1, v0); else add4(a0, v0);
+        }
+      }
+    }
+    if (act) {
+      float *o = out + (int64_t)row * ldo + c;
+      if (SPLIT) {
+        st4(o, mul4(a0, s0));
+        st4(o + H, mul4(a1, s1));
+      } else {
+        st4(o, a0);
+      }
+    }
+  }
+}
+
+// Any H / any alignment: one wave per row, scalar column-strided accesses.
+template <bool SPLIT>
+__global__ __launch_bounds__(kBlock) void seg_sum_scalar(
+    const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
+    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  const int row = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (row >= N) return;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  for (int c = lane; c < H; c += kWave) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = beg; i < end; ++i) {
+      const int e = ent[i];
+      float v = M[(int64_t)(e >> 1) * ldm + c];
+      if (ew) v *= ew[e >> 1];
+      if (SPLIT && (e & 1)) a1 += v; else a0 += v;
+    }
+    float *o = out + (int64_t)row * ldo + c;
+    if (SPLIT) { o[0] = a0 * s0; o[H] = a1 * s1; } else { o[0] = a0; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-edge streaming kernels: a G-lane group per edge row, ROWS rows per group
+// (all loads of the ROWS rows are issued before the first store).
+// ---------------------------------------------------------------------------
+constexpr int kRowsPerGroup = 2;
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void gather_rows_vec(
+    const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ idx,
+    const float *__restrict__ ew, int64_t E, int H, float *__restrict__ out, int64_t ldo) {
+  constexpr int RPB = kBlock / G;
+  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  const int lane = threadIdx.x % G;
+  for (int c = lane * 4; c < H; c += G * 4) {
+    float4 v[kRowsPerGroup];
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) {
+        v[k] = ld4(X + (int64_t)idx[e] * ldx + c);
+        if (WEIGHTED) v[k] = mul4(v[k], ew[e]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) st4(out + e * ldo + c, v[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_rows_scalar(
+    const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ idx,
+    const float *__restrict__ ew, int64_t E, int H, float *__restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const float w = ew ? ew[e] : 1.f;
+  const int64_t r = idx[e];
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) out[e * ldo + c] = X[r * ldx + c] * w;
+}
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void gather_select_vec(
+    const float *__restrict__ D, int64_t ldd, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ flag, const float *__restrict__ ew, int64_t E, int H,
+    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  constexpr int RPB = kBlock / G;
+  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  const int lane = threadIdx.x % G;
+  for (int c = lane * 4; c < H; c += G * 4) {
+    float4 v[kRowsPerGroup];
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) {
+        const bool f = flag && flag[e];
+        float s = f ? s1 : s0;
+        if (WEIGHTED) s *= ew[e];
+        v[k] = mul4(ld4(D + (int64_t)dst[e] * ldd + (f ? H : 0) + c), s);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) st4(out + e * ldo + c, v[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_select_scalar(
+    const float *__restrict__ D, int64_t ldd, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ flag, const float *__restrict__ ew, int64_t E, int H,
+    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const bool f = flag && flag[e];
+  float s = f ? s1 : s0;
+  if (ew) s *= ew[e];
+  const float *d = D + (int64_t)dst[e] * ldd + (f ? H : 0);
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) out[e * ldo + c] = d[c] * s;
+}
+
+// Y[e] = ((G0 + coef*G1) + (P[a,0:H] - P[b,H:2H])) + bias     (reference order,
+// dmpnn.py:147: matmul(Z,eloop) + add + agg, then + ebias)
+template <int G>
+__global__ __launch_bounds__(kBlock) void edge_combine_vec(
+    const float *__restrict__ Gm, int64_t ldg, const float *__restrict__ P, int64_t ldp,
+    const float *__restrict__ coef, const float *__restrict__ bias,
+    const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ flag, int64_t E, int H, float *__restrict__ Y, int64_t ldy) {
+  constexpr int RPB = kBlock / G;
+  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  const int lane = threadIdx.x % G;
+  for (int c = lane * 4; c < H; c += G * 4) {
+    const float4 bi = bias ? ld4(bias + c) : zero4();
+    float4 y[kRowsPerGroup];
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) {
+        const int u = src[e], v = dst[e];
+        const bool f = flag && flag[e];
+        const float cf = coef[v];
+        const int a = f ? u : v, b = f ? v : u;
+        const float4 g0 = ld4(Gm + e * ldg + c);
+        const float4 g1 = ld4(Gm + e * ldg + H + c);
+        const float4 pa = ld4(P + (int64_t)a * ldp + c);
+        const float4 pb = ld4(P + (int64_t)b * ldp + H + c);
+        float4 t = mul4(g1, cf);
+        add4(t, g0);
+        add4(t, sub4(pa, pb));
+        add4(t, bi);
+        y[k] = t;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) st4(Y + e * ldy + c, y[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_combine_scalar(
+    const float *__restrict__ Gm, int64_t ldg, const float *__restrict__ P, int64_t ldp,
+    const float *__restrict__ coef, const float *__restrict__ bias,
+    const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+    const uint8_t *__restrict__ flag, int64_t E, int H, float *__restrict__ Y, int64_t ldy) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const int u = src[e], v = dst[e];
+  const bool f = flag && flag[e];
+  const float cf = coef[v];
+  const int64_t a = f ? u : v, b = f ? v : u;
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) {
+    float t = Gm[e * ldg + H + c] * cf;
+    t += Gm[e * ldg + c];
+    t += P[a * ldp + c] - P[b * ldp + H + c];
+    if (bias) t += bias[c];
+    Y[e * ldy + c] = t;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void edge_combine_bwd_g_vec(
+    const float *__restrict__ dY, int64_t ldy, const float *__restrict__ coef,
+    const int32_t *__restrict__ dst, int64_t E, int H, float *__restrict__ dG, int64_t ldg) {
+  constexpr int RPB = kBlock / G;
+  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  const int lane = threadIdx.x % G;
+  for (int c = lane * 4; c < H; c += G * 4) {
+    float4 v[kRowsPerGroup];
+    float cf[kRowsPerGroup];
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) { v[k] = ld4(dY + e * ldy + c); cf[k] = coef[dst[e]]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerGroup; ++k) {
+      const int64_t e = e0 + k;
+      if (e < E) {
+        st4(dG + e * ldg + c, v[k]);
+        st4(dG + e * ldg + H + c, mul4(v[k], cf[k]));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_combine_bwd_g_scalar(
+    const float *__restrict__ dY, int64_t ldy, const float *__restrict__ coef,
+    const int32_t *__restrict__ dst, int64_t E, int H, float *__restrict__ dG, int64_t ldg) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const float cf = coef[dst[e]];
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) {
+    const float v = dY[e * ldy + c];
+    dG[e * ldg + c] = v;
+    dG[e * ldg + H + c] = v * cf;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// CompGCN: out[v] = [ sum_{flag=0} n_e comp(X[src e], Z[e]) | sum_{flag=1} ... ]
+// ---------------------------------------------------------------------------
+template <int G, int COMP>
+__global__ __launch_bounds__(kBlock) void compgcn_agg_vec(
+    const float *__restrict__ X, int64_t ldx, const float *__restrict__ Z, int64_t ldz,
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ent,
+    const int32_t *__restrict__ src, const float *__restrict__ norm, int N, int H,
+    float *__restrict__ out, int64_t ldo) {
+  constexpr int RPB = kBlock / G;
+  const int row = xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G;
+  const int lane = threadIdx.x % G;
+  if (row >= N) return;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  for (int c0 = 0; c0 < H; c0 += G * 4) {
+    const int c = c0 + lane * 4;
+    const bool act = c < H;
+    float4 a0 = zero4(), a1 = zero4();
+    for (int base = beg; base < end; base += G) {
+      const int cnt = min(G, end - base);
+      int my = 0, mys = 0;
+      float myw = 1.f;
+      if (lane < cnt) {
+        my = ent[base + lane];
+        mys = src[my >> 1];
+        if (norm) myw = norm[my >> 1];
+      }
+      int j = 0;
+      for (; j + 2 <= cnt; j += 2) {
+        const int e0 = __shfl(my, j, G), e1 = __shfl(my, j + 1, G);
+        const int u0 = __shfl(mys, j, G), u1 = __shfl(mys, j + 1, G);
+        const float w0 = __shfl(myw, j, G), w1 = __shfl(myw, j + 1, G);
+        if (act) {
+          const float4 x0 = ld4(X + (int64_t)u0 * ldx + c), z0 = ld4(Z + (int64_t)(e0 >> 1) * ldz + c);
+          const float4 x1 = ld4(X + (int64_t)u1 * ldx + c), z1 = ld4(Z + (int64_t)(e1 >> 1) * ldz + c);
+          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : had4(x0, z0), w0);
+          const float4 m1 = mul4(COMP == 0 ? sub4(x1, z1) : had4(x1, z1), w1);
+          if (e0 & 1) add4(a1, m0); else add4(a0, m0);
+          if (e1 & 1) add4(a1, m1); else add4(a0, m1);
+        }
+      }
+      for (; j < cnt; ++j) {
+        const int e0 = __shfl(my, j, G), u0 = __shfl(mys, j, G);
+        const float w0 = __shfl(myw, j, G);
+        if (act) {
+          const float4 x0 = ld4(X + (int64_t)u0 * ldx + c), z0 = ld4(Z + (int64_t)(e0 >> 1) * ldz + c);
+          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : had4(x0, z0), w0);
+          if (e0 & 1) add4(a1, m0); else add4(a0, m0);
+        }
+      }
+    }
+    if (act) {
+      float *o = out + (int64_t)row * ldo + c;
+      st4(o, a0);
+      st4(o + H, a1);
+    }
+  }
+}
+
+template <int COMP>
+__global__ __launch_bounds__(kBlock) void compgcn_agg_scalar(
+    const float *__restrict__ X, int64_t ldx, const float *__restrict__ Z, int64_t ldz,
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ent,
+    const int32_t *__restrict__ src, const float *__restrict__ norm, int N, int H,
+    float *__restrict__ out, int64_t ldo) {
+  const int row = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (row >= N) return;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = beg; i < end; ++i) {
+      const int e = ent[i], eid = e >> 1;
+      const float x = X[(int64_t)src[eid] * ldx + c], z = Z[(int64_t)eid * ldz + c];
+      float m = COMP == 0 ? x - z : x * z;
+      if (norm) m *= norm[eid];
+      if (e & 1) a1 += m; else a0 += m;
+    }
+    out[(int64_t)row * ldo + c] = a0;
+    out[(int64_t)row * ldo + H + c] = a1;
+  }
+}
+
+template <int G, int COMP>
+__global__ __launch_bounds__(kBlock) void compgcn_agg_bwd_vec(
+    const float *__restrict__ D, int64_t ldd, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ Z, int64_t ldz, const int32_t *__restrict__ src,
+    const int32_t *__restrict__ dst, const uint8_t *__restrict__ flag,
+    const float *__restrict__ norm, int64_t E, int H, float *__restrict__ dZ, int64_t lddz,
+    float *__restrict__ dXe, int64_t lddxe) {
+  constexpr int RPB = kBlock / G;
+  const int64_t e = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G;
+  const int lane = threadIdx.x % G;
+  if (e >= E) return;
+  const bool f = flag && flag[e];
+  const float w = norm ? norm[e] : 1.f;
+  const int u = src[e], v = dst[e];
+  for (int c = lane * 4; c < H; c += G * 4) {
+    const float4 g = mul4(ld4(D + (int64_t)v * ldd + (f ? H : 0) + c), w);
+    if (COMP == 0) {
+      st4(dZ + e * lddz + c, mul4(g, -1.f));
+      st4(dXe + e * lddxe + c, g);
+    } else {
+      const float4 x = ld4(X + (int64_t)u * ldx + c), z = ld4(Z + e * ldz + c);
+      st4(dZ + e * lddz + c, had4(g, x));
+      st4(dXe + e * lddxe + c, had4(g, z));
+    }
+  }
+}
+
+template <int COMP>
+__global__ __launch_bounds__(kBlock) void compgcn_agg_bwd_scalar(
+    const float *__restrict__ D, int64_t ldd, const float *__restrict__ X, int64_t ldx,
+    const float *__restrict__ Z, int64_t ldz, const int32_t *__restrict__ src,
+    const int32_t *__restrict__ dst, const uint8_t *__restrict__ flag,
+    const float *__restrict__ norm, int64_t E, int H, float *__restrict__ dZ, int64_t lddz,
+    float *__restrict__ dXe, int64_t lddxe) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const bool f = flag && flag[e];
+  const float w = norm ? norm[e] : 1.f;
+  const int64_t u = src[e], v = dst[e];
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) {
+    const float g = D[v * ldd + (f ? H : 0) + c] * w;
+    if (COMP == 0) {
+      dZ[e * lddz + c] = -g;
+      dXe[e * lddxe + c] = g;
+    } else {
+      dZ[e * lddz + c] = g * X[u * ldx + c];
+      dXe[e * lddxe + c] = g * Z[e * ldz + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dispatch
+inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
+inline unsigned blocks_for(int64_t rows, int rows_per_block) {
+  return (unsigned)((rows + rows_per_block - 1) / rows_per_block);
+}
+inline bool vec_ok(int H, std::initializer_list<int64_t> lds, std::initializer_list<const void *> ps) {
+  if (H % 4) return false;
+  for (int64_t l : lds) if (l % 4) return false;
+  for (const void *p : ps) if (p && !aligned16(p)) return false;
+  return true;
+}
+constexpr int64_t kMaxRows = (int64_t)1 << 30;  // eid << 1 must fit int32
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+#define DMP_DISPATCH_G(H, ...)                                   \
+  do {                                                           \
+    const int g_ = group_lanes(H);                               \
+    if (g_ == 16) { constexpr int G = 16; __VA_ARGS__; }         \
+    else if (g_ == 32) { constexpr int G = 32; __VA_ARGS__; }    \
+    else { constexpr int G = 64; __VA_ARGS__; }                  \
+  } while (0)
+
+extern "C" {
+
+int dmp_abi_version(void) { return DMP_ABI_VERSION; }
+const char *dmp_last_hip_error(void) { return g_last_err; }
+
+static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
+                        const float *ew, int64_t N, int H, bool split, float s0, float s1,
+                        float *out, int64_t ldo, void *stream) {
+  if (N < 0 || H <= 0 || ldm < H || ldo < (split ? 2 * H : H)) return DMP_ERR_BAD_ARG;
+  if (N == 0) return DMP_OK;
+  if (!M || !rowptr || !ent || !out) return DMP_ERR_BAD_ARG;
+  if (N >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldm, ldo}, {M, out})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(N, kBlock / G);
+      if (split) {
+        if (ew) seg_sum_vec<G, true, true><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+        else seg_sum_vec<G, true, false><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+      } else {
+        if (ew) seg_sum_vec<G, false, true><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+        else seg_sum_vec<G, false, false><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+      }
+    });
+  } else {
+    const unsigned nb = blocks_for(N, kBlock / kWave);
+    if (split) seg_sum_scalar<true><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+    else seg_sum_scalar<false><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+  }
+  return check_launch();
+}
+
+int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
+                const float *edge_w, int64_t num_nodes, int H, float *out, int64_t ldo,
+                void *stream) {
+  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, false, 1.f, 1.f, out, ldo, stream);
+}
+
+int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
+                 const float *edge_w, int64_t num_nodes, int H, float s0, float s1, float *out,
+                 int64_t ldo, void *stream) {
+  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, true, s0, s1, out, ldo, stream);
+}
+
+int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx, const float *edge_w,
+                    int64_t E, int H, float *out, int64_t ldo, void *stream) {
+  if (E < 0 || H <= 0 || ldx < H || ldo < H) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!X || !idx || !out) return DMP_ERR_BAD_ARG;
+  if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldx, ldo}, {X, out})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
+      if (edge_w) gather_rows_vec<G, true><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
+      else gather_rows_vec<G, false><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
+    });
+  } else {
+    gather_rows_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
+  }
+  return check_launch();
+}
+
+int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst, const uint8_t *flag,
+                      const float *edge_w, int64_t E, int H, float s0, float s1, float *out,
+                      int64_t ldo, void *stream) {
+  if (E < 0 || H <= 0 || ldd < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!D || !dst || !out) return DMP_ERR_BAD_ARG;
+  if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldd, ldo}, {D, out})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
+      if (edge_w) gather_select_vec<G, true><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+      else gather_select_vec<G, false><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+    });
+  } else {
+    gather_select_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+  }
+  return check_launch();
+}
+
+int dmp_edge_combine(const float *Gm, int64_t ldg, const float *P, int64_t ldp, const float *coef,
+                     const float *bias, const int32_t *src, const int32_t *dst,
+                     const uint8_t *flag, int64_t E, int H, float *Y, int64_t ldy, void *stream) {
+  if (E < 0 || H <= 0 || ldg < 2 * H || ldp < 2 * H || ldy < H) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!Gm || !P || !coef || !src || !dst || !Y) return DMP_ERR_BAD_ARG;
+  if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldg, ldp, ldy}, {Gm, P, Y, bias})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
+      edge_combine_vec<G><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
+    });
+  } else {
+    edge_combine_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
+  }
+  return check_launch();
+}
+
+int dmp_edge_combine_bwd_g(const float *dY, int64_t ldy, const float *coef, const int32_t *dst,
+                           int64_t E, int H, float *dG, int64_t ldg, void *stream) {
+  if (E < 0 || H <= 0 || ldy < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!dY || !coef || !dst || !dG) return DMP_ERR_BAD_ARG;
+  if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldy, ldg}, {dY, dG})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
+      edge_combine_bwd_g_vec<G><<<nb, kBlock, 0, st>>>(dY, ldy, coef, dst, E, H, dG, ldg);
+    });
+  } else {
+    edge_combine_bwd_g_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(dY, ldy, coef, dst, E, H, dG, ldg);
+  }
+  return check_launch();
+}
+
+int dmp_compgcn_agg(const float *X, int64_t ldx, const float *Z, int64_t ldz, const int32_t *rowptr,
+                    const int32_t *ent, const int32_t *src, const float *norm, int64_t N, int H,
+                    int comp, float *out, int64_t ldo, void *stream) {
+  if (N < 0 || H <= 0 || ldx < H || ldz < H || ldo < 2 * H || (comp != 0 && comp != 1)) return DMP_ERR_BAD_ARG;
+  if (N == 0) return DMP_OK;
+  if (!X || !Z || !rowptr || !ent || !src || !out) return DMP_ERR_BAD_ARG;
+  if (N >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldx, ldz, ldo}, {X, Z, out})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(N, kBlock / G);
+      if (comp == 0) compgcn_agg_vec<G, 0><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+      else compgcn_agg_vec<G, 1><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+    });
+  } else {
+    const unsigned nb = blocks_for(N, kBlock / kWave);
+    if (comp == 0) compgcn_agg_scalar<0><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+    else compgcn_agg_scalar<1><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+  }
+  return check_launch();
+}
+
+int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X, int64_t ldx, const float *Z,
+                        int64_t ldz, const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                        const float *norm, int64_t E, int H, int comp, float *dZ, int64_t lddz,
+                        float *dXe, int64_t lddxe, void *stream) {
+  if (E < 0 || H <= 0 || ldd < 2 * H || ldx < H || ldz < H || lddz < H || lddxe < H ||
+      (comp != 0 && comp != 1))
+    return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!D || !X || !Z || !src || !dst || !dZ || !dXe) return DMP_ERR_BAD_ARG;
+  if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(H, {ldd, ldx, ldz, lddz, lddxe}, {D, X, Z, dZ, dXe})) {
+    DMP_DISPATCH_G(H, {
+      const unsigned nb = blocks_for(E, kBlock / G);
+      if (comp == 0) compgcn_agg_bwd_vec<G, 0><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+      else compgcn_agg_bwd_vec<G, 1><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+    });
+  } else {
+    const unsigned nb = blocks_for(E, kBlock / kWave);
+    if (comp == 0) compgcn_agg_bwd_scalar<0><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+    else compgcn_agg_bwd_scalar<1><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+  }
+  return check_launch();
+}
+
+}  // extern "C"

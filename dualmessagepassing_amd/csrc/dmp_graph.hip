@@ -1,0 +1,527 @@
+// Integer graph-index kernels of the dual-message-passing hot path (gfx950).
+//
+//   csr_build          counting sort of the edge list by dst (or src); rows in
+//                      ascending eid -> every later segment sum has one fixed order
+//   incidence_build    in-edges ++ out-edges (flag flipped) per node
+//   degree_coef        2(1+log2(1+out_deg))
+//   collate            dgl.batch: node-offset concatenation
+//   add_reversed_edges train.py:299-327
+//   line_graph_*       utils/graph.py:74-169 (directed line graph, emission order)
+//   scans              exclusive prefix sums (int32 / int64)
+//
+// Every result here is an integer array and must equal the reference's bit for
+// bit; nothing depends on atomic arrival order (rows are sorted after the
+// atomic fill, hash-table winners are chosen by atomicMin on the item index).
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+constexpr int kScanItems = 8;                       // items per thread
+constexpr int kScanTile = kBlock * kScanItems;      // 2048 items per workgroup
+
+// ------------------------------------------------------------------ scans
+// Three-phase exclusive scan: (A) per-tile scan + tile totals, (B) one
+// workgroup scans the tile totals, (C) add tile offsets, write the grand total.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *lds, T &total) {
+  // v: this thread's value; returns exclusive prefix within the workgroup
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  T inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    T t = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += t;
+  }
+  if (lane == kWave - 1) lds[wave] = inc;
+  __syncthreads();
+  T wave_off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    const T s = lds[w];
+    if (w < wave) wave_off += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return wave_off + inc - v;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kBlock) void scan_tiles(const TI *__restrict__ in, int64_t n,
+                                                     TO *__restrict__ out, TO *__restrict__ tile_sum) {
+  __shared__ TO lds[kBlock / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  TO v[kScanItems];
+  TO s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? (TO)in[base + k] : (TO)0;
+    s += v[k];
+  }
+  TO total;
+  TO pre = block_exclusive_scan<TO>(s, lds, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = pre;
+    pre += v[k];
+  }
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(kBlock) void scan_tile_sums(TO *__restrict__ tile_sum, int64_t ntiles,
+                                                         TO *__restrict__ grand_total) {
+  __shared__ TO lds[kBlock / kWave];
+  TO carry = 0;
+  for (int64_t base = 0; base < ntiles; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const TO v = i < ntiles ? tile_sum[i] : (TO)0;
+    TO total;
+    const TO pre = block_exclusive_scan<TO>(v, lds, total);
+    if (i < ntiles) tile_sum[i] = carry + pre;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *grand_total = carry;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(kBlock) void scan_add_offsets(TO *__restrict__ out, int64_t n,
+                                                           const TO *__restrict__ tile_sum) {
+  const TO off = tile_sum[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) out[base + k] += off;
+}
+
+// out[0..n] = exclusive scan of in[0..n-1]; tile_ws holds ceil(n/2048) entries.
+template <typename TI, typename TO>
+int exclusive_scan(const TI *in, int64_t n, TO *out, TO *tile_ws, hipStream_t st) {
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(TO), st);
+    if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
+    return DMP_OK;
+  }
+  const int64_t ntiles = (n + kScanTile - 1) / kScanTile;
+  scan_tiles<TI, TO><<<(unsigned)ntiles, kBlock, 0, st>>>(in, n, out, tile_ws);
+  scan_tile_sums<TO><<<1, kBlock, 0, st>>>(tile_ws, ntiles, out + n);
+  if (ntiles > 1) scan_add_offsets<TO><<<(unsigned)ntiles, kBlock, 0, st>>>(out, n, tile_ws);
+  return check_launch();
+}
+
+// ------------------------------------------------------------------ CSR build
+__global__ __launch_bounds__(kBlock) void csr_count(const int64_t *__restrict__ key, int64_t E,
+                                                    int64_t N, int32_t *__restrict__ cnt,
+                                                    int32_t *__restrict__ key32,
+                                                    int32_t *__restrict__ status) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t k = key[e];
+  const bool ok = k >= 0 && k < N;
+  if (key32) key32[e] = ok ? (int32_t)k : 0;
+  if (ok) atomicAdd(&cnt[k], 1);
+  else atomicOr(status, 1);
+}
+
+__global__ __launch_bounds__(kBlock) void csr_fill(const int64_t *__restrict__ key,
+                                                   const uint8_t *__restrict__ flag, int64_t E,
+                                                   int64_t N, int32_t *__restrict__ cursor,
+                                                   int32_t *__restrict__ ent) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t k = key[e];
+  if (k < 0 || k >= N) return;
+  const int pos = atomicAdd(&cursor[k], 1);
+  ent[pos] = ((int32_t)e << 1) | (flag ? (flag[e] ? 1 : 0) : 0);
+}
+
+// Restore ascending eid inside each row (the atomic fill arrives almost sorted,
+// so insertion sort is near linear); rows longer than kHeapFrom use heap sort.
+constexpr int kHeapFrom = 96;
+__device__ void sift_down(int32_t *a, int start, int end) {
+  int root = start;
+  while (2 * root + 1 <= end) {
+    int child = 2 * root + 1, sw = root;
+    if (a[sw] < a[child]) sw = child;
+    if (child + 1 <= end && a[sw] < a[child + 1]) sw = child + 1;
+    if (sw == root) return;
+    const int32_t t = a[root]; a[root] = a[sw]; a[sw] = t;
+    root = sw;
+  }
+}
+__global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restrict__ rowptr, int64_t N,
+                                                        int32_t *__restrict__ ent,
+                                                        int64_t *__restrict__ degree) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= N) return;
+  const int beg = rowptr[r], end = rowptr[r + 1];
+  const int n = end - beg;
+  if (degree) degree[r] = n;
+  int32_t *a = ent + beg;
+  if (n <= kHeapFrom) {
+    for (int i = 1; i < n; ++i) {
+      const int32_t x = a[i];
+      int j = i - 1;
+      while (j >= 0 && a[j] > x) { a[j + 1] = a[j]; --j; }
+      a[j + 1] = x;
+    }
+  } else {
+    for (int s = (n - 2) / 2; s >= 0; --s) sift_down(a, s, n - 1);
+    for (int e = n - 1; e > 0; --e) {
+      const int32_t t = a[e]; a[e] = a[0]; a[0] = t;
+      sift_down(a, 0, e - 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void copy_i32(const int32_t *__restrict__ a, int64_t n,
+                                                   int32_t *__restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+
+// ------------------------------------------------------------------ incidence
+__global__ __launch_bounds__(kBlock) void incidence_ptr(const int32_t *__restrict__ in_ptr,
+                                                        const int32_t *__restrict__ out_ptr, int64_t N,
+                                                        int32_t *__restrict__ inc_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i <= N) inc_ptr[i] = in_ptr[i] + out_ptr[i];
+}
+// one thread per incidence entry: binary search for the owning node
+__global__ __launch_bounds__(kBlock) void incidence_fill(const int32_t *__restrict__ in_ptr,
+                                                         const int32_t *__restrict__ in_ent,
+                                                         const int32_t *__restrict__ out_ptr,
+                                                         const int32_t *__restrict__ out_ent, int64_t N,
+                                                         int64_t E2, int32_t *__restrict__ inc_ent) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= E2) return;
+  // largest w with in_ptr[w] + out_ptr[w] <= i
+  int64_t lo = 0, hi = N;  // invariant: ptr[lo] <= i < ptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)in_ptr[mid] + out_ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  const int64_t w = lo;
+  const int64_t k = i - ((int64_t)in_ptr[w] + out_ptr[w]);
+  const int nin = in_ptr[w + 1] - in_ptr[w];
+  if (k < nin) inc_ent[i] = in_ent[in_ptr[w] + k];
+  else inc_ent[i] = out_ent[out_ptr[w] + (k - nin)] ^ 1;
+}
+
+__global__ __launch_bounds__(kBlock) void degree_coef_k(const int64_t *__restrict__ deg, int64_t N,
+                                                        float *__restrict__ coef) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  // dmpnn.py:144-146: d = out_deg.float(); d = (1 + d).log2(); 2 * (1 + d)
+  const float d = log2f(1.0f + (float)deg[i]);
+  coef[i] = 2.0f * (1.0f + d);
+}
+
+// ------------------------------------------------------------------ collate
+__device__ __forceinline__ int64_t upper_graph(const int64_t *off, int64_t B, int64_t i) {
+  // largest g in [0,B) with off[g] <= i   (off has B+1 entries, off[B] > i)
+  int64_t lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(kBlock) void collate_edges(const int64_t *__restrict__ ls,
+                                                        const int64_t *__restrict__ ld,
+                                                        const int64_t *__restrict__ node_off,
+                                                        const int64_t *__restrict__ edge_off, int64_t B,
+                                                        int64_t E, int64_t *__restrict__ src,
+                                                        int64_t *__restrict__ dst,
+                                                        int32_t *__restrict__ edge_graph) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t g = upper_graph(edge_off, B, e);
+  const int64_t o = node_off[g];
+  src[e] = ls[e] + o;
+  dst[e] = ld[e] + o;
+  if (edge_graph) edge_graph[e] = (int32_t)g;
+}
+__global__ __launch_bounds__(kBlock) void collate_nodes(const int64_t *__restrict__ node_off, int64_t B,
+                                                        int64_t N, int32_t *__restrict__ node_graph) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v >= N) return;
+  node_graph[v] = (int32_t)upper_graph(node_off, B, v);
+}
+
+__global__ __launch_bounds__(kBlock) void add_rev_k(
+    const int64_t *__restrict__ src, const int64_t *__restrict__ dst, const int64_t *__restrict__ eid,
+    const int64_t *__restrict__ el, const int64_t *__restrict__ edge_off, int64_t B, int64_t E,
+    int64_t max_ne, int64_t max_nel, int64_t *__restrict__ o_src, int64_t *__restrict__ o_dst,
+    int64_t *__restrict__ o_eid, int64_t *__restrict__ o_el, uint8_t *__restrict__ o_rev) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t g = upper_graph(edge_off, B, e);
+  const int64_t beg = edge_off[g], n = edge_off[g + 1] - beg, k = e - beg;
+  const int64_t f = 2 * beg + k, r = 2 * beg + n + k;
+  const int64_t u = src[e], v = dst[e];
+  o_src[f] = u; o_dst[f] = v; o_eid[f] = eid[e]; o_el[f] = el[e]; o_rev[f] = 0;
+  // train.py:307-318: add_edges(v, u, id = max_nge + arange(num_ge), label + max_ngel, rev = 1)
+  o_src[r] = v; o_dst[r] = u; o_eid[r] = max_ne + k; o_el[r] = el[e] + max_nel; o_rev[r] = 1;
+}
+
+// ------------------------------------------------------------------ line graph
+__global__ __launch_bounds__(kBlock) void lg_count(const int32_t *__restrict__ in_ptr,
+                                                   const int64_t *__restrict__ src, int64_t E,
+                                                   int64_t *__restrict__ cnt) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = src[e];
+  cnt[e] = in_ptr[s + 1] - in_ptr[s];
+}
+// one wave per primal edge e: its in-degree(src e) dual edges are written in
+// ascending eid of the in-edge = the reference's emission order (graph.py:130-133)
+__global__ __launch_bounds__(kBlock) void lg_fill(const int32_t *__restrict__ in_ptr,
+                                                  const int32_t *__restrict__ in_ent,
+                                                  const int64_t *__restrict__ src,
+                                                  const int64_t *__restrict__ off, int64_t E,
+                                                  int64_t *__restrict__ dsrc, int64_t *__restrict__ ddst,
+                                                  int64_t *__restrict__ payload) {
+  const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (e >= E) return;
+  const int64_t s = src[e];
+  const int beg = in_ptr[s], n = in_ptr[s + 1] - beg;
+  const int64_t o = off[e];
+  for (int k = threadIdx.x % kWave; k < n; k += kWave) {
+    dsrc[o + k] = in_ent[beg + k] >> 1;
+    ddst[o + k] = e;
+    payload[o + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_i64(int64_t *__restrict__ a, int64_t n, int64_t v) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void first_of_id_k(const int64_t *__restrict__ eid, int64_t E,
+                                                        int64_t K, int64_t *__restrict__ first) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t k = eid[e];
+  if (k >= 0 && k < K)
+    atomicMin(reinterpret_cast<unsigned long long *>(&first[k]), (unsigned long long)e);
+}
+__global__ __launch_bounds__(kBlock) void first_fix_k(int64_t *__restrict__ first, int64_t K) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < K && first[k] == INT64_MAX) first[k] = -1;
+}
+
+// Open-addressing table of item indices; a slot's identity is the key of the
+// item it holds, and only same-key items ever replace each other (atomicMin),
+// so the winner of every key is its lowest item index regardless of timing.
+constexpr unsigned long long kEmpty = ~0ull;
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ uint64_t key_hash(int64_t a, int64_t l, int64_t b) {
+  return mix64((uint64_t)a * 0x9E3779B97F4A7C15ULL ^ mix64((uint64_t)b + 0x7F4A7C15ULL) ^
+               mix64((uint64_t)l * 0xD6E8FEB86659FD93ULL));
+}
+__global__ __launch_bounds__(kBlock) void dedupe_insert(const int64_t *__restrict__ ka,
+                                                        const int64_t *__restrict__ kl,
+                                                        const int64_t *__restrict__ kb, int64_t M,
+                                                        unsigned long long *__restrict__ table,
+                                                        uint64_t mask) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M) return;
+  const int64_t a = ka[m], l = kl[m], b = kb[m];
+  uint64_t h = key_hash(a, l, b) & mask;
+  while (true) {
+    unsigned long long s = atomicCAS(&table[h], kEmpty, (unsigned long long)m);
+    if (s == kEmpty) return;
+    if (ka[s] == a && kl[s] == l && kb[s] == b) {
+      atomicMin(&table[h], (unsigned long long)m);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+__global__ __launch_bounds__(kBlock) void dedupe_lookup(const int64_t *__restrict__ ka,
+                                                        const int64_t *__restrict__ kl,
+                                                        const int64_t *__restrict__ kb, int64_t M,
+                                                        const unsigned long long *__restrict__ table,
+                                                        uint64_t mask, uint8_t *__restrict__ keep) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M) return;
+  const int64_t a = ka[m], l = kl[m], b = kb[m];
+  uint64_t h = key_hash(a, l, b) & mask;
+  while (true) {
+    const unsigned long long s = table[h];
+    if (s == kEmpty) { keep[m] = 1; return; }  // unreachable after insert; fail open
+    if (ka[s] == a && kl[s] == l && kb[s] == b) { keep[m] = (s == (unsigned long long)m); return; }
+    h = (h + 1) & mask;
+  }
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+inline int64_t scan_tiles_for(int64_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+inline uint64_t table_size(int64_t M) {
+  uint64_t c = 16;
+  while (c < (uint64_t)M * 2) c <<= 1;
+  return c;
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+#define DMP_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) { set_last_hip_error(e_); return DMP_ERR_HIP; } \
+  } while (0)
+
+extern "C" {
+
+size_t dmp_csr_workspace_words(int64_t N, int64_t E) {
+  (void)E;
+  if (N < 0) return 0;
+  // cnt/cursor [N] + scan tile sums
+  return (size_t)N + (size_t)scan_tiles_for(N) + 8;
+}
+
+int dmp_csr_build(const int64_t *key, const uint8_t *flag, int64_t E, int64_t N, int32_t *rowptr,
+                  int32_t *ent, int32_t *key32, int64_t *degree, int32_t *status, int32_t *ws,
+                  void *stream) {
+  if (E < 0 || N < 0 || !rowptr || !status || !ws) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!key || !ent)) return DMP_ERR_BAD_ARG;
+  if (E >= ((int64_t)1 << 30) || N >= ((int64_t)1 << 31) - 1) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *cnt = ws, *tiles = ws + N;
+  DMP_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  if (N > 0) DMP_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)N, st));
+  if (E > 0) csr_count<<<nblk(E), kBlock, 0, st>>>(key, E, N, cnt, key32, status);
+  int rc = exclusive_scan<int32_t, int32_t>(cnt, N, rowptr, tiles, st);
+  if (rc != DMP_OK) return rc;
+  if (N > 0 && E > 0) {
+    copy_i32<<<nblk(N), kBlock, 0, st>>>(rowptr, N, cnt);  // cnt becomes the fill cursor
+    csr_fill<<<nblk(E), kBlock, 0, st>>>(key, flag, E, N, cnt, ent);
+  }
+  if (N > 0) csr_sort_rows<<<nblk(N), kBlock, 0, st>>>(rowptr, N, ent, degree);
+  return check_launch();
+}
+
+int dmp_incidence_build(const int32_t *in_ptr, const int32_t *in_ent, const int32_t *out_ptr,
+                        const int32_t *out_ent, int64_t N, int64_t E, int32_t *inc_ptr,
+                        int32_t *inc_ent, void *stream) {
+  if (N < 0 || E < 0 || !in_ptr || !out_ptr || !inc_ptr) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!in_ent || !out_ent || !inc_ent)) return DMP_ERR_BAD_ARG;
+  if (E >= ((int64_t)1 << 29)) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  incidence_ptr<<<nblk(N + 1), kBlock, 0, st>>>(in_ptr, out_ptr, N, inc_ptr);
+  if (E > 0 && N > 0)
+    incidence_fill<<<nblk(2 * E), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, N, 2 * E, inc_ent);
+  return check_launch();
+}
+
+int dmp_degree_coef(const int64_t *out_deg, int64_t N, float *coef, void *stream) {
+  if (N < 0) return DMP_ERR_BAD_ARG;
+  if (N == 0) return DMP_OK;
+  if (!out_deg || !coef) return DMP_ERR_BAD_ARG;
+  degree_coef_k<<<nblk(N), kBlock, 0, (hipStream_t)stream>>>(out_deg, N, coef);
+  return check_launch();
+}
+
+size_t dmp_scan_workspace_words(int64_t n) { return n < 0 ? 0 : (size_t)scan_tiles_for(n) + 8; }
+
+int dmp_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, int64_t *ws, void *stream) {
+  if (n < 0 || !out || !ws || (n > 0 && !in)) return DMP_ERR_BAD_ARG;
+  return exclusive_scan<int64_t, int64_t>(in, n, out, ws, (hipStream_t)stream);
+}
+
+int dmp_collate(const int64_t *local_src, const int64_t *local_dst, const int64_t *num_nodes,
+                const int64_t *num_edges, int64_t B, int64_t N, int64_t E, int64_t *node_off,
+                int64_t *edge_off, int64_t *src, int64_t *dst, int32_t *edge_graph,
+                int32_t *node_graph, void *stream) {
+  if (B < 0 || N < 0 || E < 0 || !node_off || !edge_off) return DMP_ERR_BAD_ARG;
+  if (B > 0 && (!num_nodes || !num_edges)) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!local_src || !local_dst || !src || !dst || B == 0)) return DMP_ERR_BAD_ARG;
+  if (B > kScanTile) {
+    // sizes are scanned by single-tile launches below (no scratch in the signature)
+    return DMP_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    DMP_HIP_TRY(hipMemsetAsync(node_off, 0, sizeof(int64_t), st));
+    DMP_HIP_TRY(hipMemsetAsync(edge_off, 0, sizeof(int64_t), st));
+    return DMP_OK;
+  }
+  // B <= 2048: one tile each; the tile total lands in off[B] twice (harmless)
+  scan_tiles<int64_t, int64_t><<<1, kBlock, 0, st>>>(num_nodes, B, node_off, node_off + B);
+  scan_tiles<int64_t, int64_t><<<1, kBlock, 0, st>>>(num_edges, B, edge_off, edge_off + B);
+  if (E > 0)
+    collate_edges<<<nblk(E), kBlock, 0, st>>>(local_src, local_dst, node_off, edge_off, B, E, src, dst, edge_graph);
+  if (node_graph && N > 0) collate_nodes<<<nblk(N), kBlock, 0, st>>>(node_off, B, N, node_graph);
+  return check_launch();
+}
+
+int dmp_add_reversed_edges(const int64_t *src, const int64_t *dst, const int64_t *eid,
+                           const int64_t *elabel, const int64_t *edge_off, int64_t B, int64_t E,
+                           int64_t max_ne, int64_t max_nel, int64_t *o_src, int64_t *o_dst,
+                           int64_t *o_eid, int64_t *o_elabel, uint8_t *o_rev, void *stream) {
+  if (B < 0 || E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!src || !dst || !eid || !elabel || !edge_off || !o_src || !o_dst || !o_eid || !o_elabel ||
+      !o_rev || B == 0)
+    return DMP_ERR_BAD_ARG;
+  add_rev_k<<<nblk(E), kBlock, 0, (hipStream_t)stream>>>(src, dst, eid, elabel, edge_off, B, E, max_ne,
+                                                         max_nel, o_src, o_dst, o_eid, o_elabel, o_rev);
+  return check_launch();
+}
+
+int dmp_line_graph_count(const int32_t *in_ptr, const int64_t *src, int64_t E, int64_t *cnt,
+                         void *stream) {
+  if (E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!in_ptr || !src || !cnt) return DMP_ERR_BAD_ARG;
+  lg_count<<<nblk(E), kBlock, 0, (hipStream_t)stream>>>(in_ptr, src, E, cnt);
+  return check_launch();
+}
+
+int dmp_line_graph_fill(const int32_t *in_ptr, const int32_t *in_ent, const int64_t *src,
+                        const int64_t *off, int64_t E, int64_t *dual_src, int64_t *dual_dst,
+                        int64_t *payload, void *stream) {
+  if (E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!in_ptr || !in_ent || !src || !off || !dual_src || !dual_dst || !payload) return DMP_ERR_BAD_ARG;
+  lg_fill<<<(unsigned)((E + 3) / 4), kBlock, 0, (hipStream_t)stream>>>(in_ptr, in_ent, src, off, E,
+                                                                      dual_src, dual_dst, payload);
+  return check_launch();
+}
+
+int dmp_first_edge_of_id(const int64_t *eid, int64_t E, int64_t K, int64_t *first, void *stream) {
+  if (E < 0 || K < 0) return DMP_ERR_BAD_ARG;
+  if (K == 0) return DMP_OK;
+  if (!first || (E > 0 && !eid)) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  fill_i64<<<nblk(K), kBlock, 0, st>>>(first, K, INT64_MAX);
+  if (E > 0) first_of_id_k<<<nblk(E), kBlock, 0, st>>>(eid, E, K, first);
+  first_fix_k<<<nblk(K), kBlock, 0, st>>>(first, K);
+  return check_launch();
+}
+
+size_t dmp_dedupe_table_words(int64_t M) { return M < 0 ? 0 : (size_t)table_size(M); }
+
+int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l, const int64_t *key_b, int64_t M,
+                     int64_t *table, uint8_t *keep, void *stream) {
+  if (M < 0) return DMP_ERR_BAD_ARG;
+  if (M == 0) return DMP_OK;
+  if (!key_a || !key_l || !key_b || !table || !keep) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t cap = table_size(M);
+  DMP_HIP_TRY(hipMemsetAsync(table, 0xFF, sizeof(int64_t) * cap, st));
+  unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
+  dedupe_insert<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1);
+  dedupe_lookup<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1, keep);
+  return check_launch();
+}
+
+}  // extern "C"

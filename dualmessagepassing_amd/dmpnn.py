@@ -1,0 +1,257 @@
+"""DMPLayer and the DMPNN representation network on the MI355X kernels.
+
+Drop-in for ``SubgraphCountingMatching/models/dmpnn.py``: same constructor
+arguments, parameter names / shapes (``state_dict`` compatible), the same
+``forward(graph, node_feat, edge_feat) -> (node_out, edge_out)`` and the same
+``create_rep_net`` / ``get_pattern_rep`` / ``get_graph_rep`` used by
+``GraphAdjModelV2.forward`` (basemodel.py:1515,1519).
+
+How one layer runs here (math identical row by row to dmpnn.py:111-156, see
+SURVEY.md Appendix A; only the association of sums and products differs):
+
+  node side   S   = seg_sum2(Z)                 [N,2H]  one HIP kernel (the scatter-add)
+              T   = X W_nloop + S [W_in ; W_out] + b_n          (N-row GEMMs -> MFMA)
+              out = drop(nmlp(T))
+  edge side   P   = X [W_dst | W_src]           [N,2H]          (N-row GEMM)
+              G   = Z [W_eloop | W_src - W_dst] [E,2H]          (E-row GEMM)
+              Y   = edge_combine(G, P, b_e)     [E,H]   one HIP kernel
+              out = drop(emlp(Y))
+
+The reference multiplies every edge row by W_in AND W_out (and gathers node rows
+before projecting them): 10 [E,H]x[H,H] products per layer.  Summing first and
+projecting node rows first leaves 4 of them and is the same linear map.
+"""
+import torch as th
+import torch.nn as nn
+
+from . import ops
+from .act import init_module, init_weight, map_activation_str_to_layer
+from .constants import (EDGEFEAT, NODEAGG, NODEFEAT, OUTDEGREE, REVFLAG)
+from .graph import BatchedGraph
+
+
+class DMPLayer(nn.Module):
+    def __init__(
+        self,
+        input_dim,
+        hidden_dim,
+        init_neigenv=4.0,  # dmpnn.py:21-22: empirical value of triangles
+        init_eeigenv=4.0,
+        bias=True,
+        num_mlp_layers=2,
+        batch_norm=True,
+        act_func="relu",
+        dropout=0.0
+    ):
+        super(DMPLayer, self).__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+
+        # dmpnn.py:33-38 -- [in, out] layout, used as x @ W
+        self.in_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.out_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.src_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.dst_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.nloop_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.eloop_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        if bias:
+            self.nbias = nn.Parameter(th.empty(hidden_dim))
+            self.ebias = nn.Parameter(th.empty(hidden_dim))
+        else:
+            self.register_parameter("nbias", None)
+            self.register_parameter("ebias", None)
+        self.nmlp = self._make_mlp(hidden_dim, num_mlp_layers, batch_norm, act_func)
+        self.emlp = self._make_mlp(hidden_dim, num_mlp_layers, batch_norm, act_func)
+        self.act = map_activation_str_to_layer(act_func)
+        self.drop = nn.Dropout(dropout)
+
+        # dmpnn.py:64-75
+        for w in (self.in_weight, self.out_weight, self.src_weight, self.dst_weight,
+                  self.nloop_weight, self.eloop_weight):
+            init_weight(w, activation=act_func, init="uniform")
+        for module in self.nmlp.modules():
+            init_module(module, activation=act_func, init="uniform")
+        for module in self.emlp.modules():
+            init_module(module, activation=act_func, init="uniform")
+        if bias:
+            nn.init.zeros_(self.nbias)
+            nn.init.zeros_(self.ebias)
+
+        # dmpnn.py:78-85 -- re-parameterisation by the largest-eigenvalue bounds
+        with th.no_grad():
+            self.in_weight.data.div_(init_neigenv)
+            self.out_weight.data.div_(init_neigenv)
+            self.nloop_weight.data.div_(init_neigenv)
+            self.src_weight.data.div_(init_eeigenv)
+            self.dst_weight.data.div_(init_eeigenv)
+            self.eloop_weight.data.div_(init_eeigenv)
+
+    @staticmethod
+    def _make_mlp(hidden_dim, num_mlp_layers, batch_norm, act_func):
+        # dmpnn.py:45-60: Linear (-> BN) -> act between layers, plain Linear last
+        mods = []
+        for i in range(num_mlp_layers):
+            mods.append(nn.Linear(hidden_dim, hidden_dim))
+            if i != num_mlp_layers - 1:
+                if batch_norm:
+                    mods.append(nn.BatchNorm1d(hidden_dim))
+                mods.append(map_activation_str_to_layer(act_func))
+        return nn.Sequential(*mods)
+
+    def forward(self, graph, node_feat, edge_feat):
+        if not isinstance(graph, BatchedGraph):
+            raise TypeError("DMPLayer expects a dualmessagepassing_amd BatchedGraph "
+                            "(see collate.from_dgl for DGLGraph inputs)")
+        g = graph
+        # _node_init_func / _edge_init_func (dmpnn.py:96-109)
+        if node_feat is not None:
+            g.ndata[NODEFEAT] = node_feat
+        if OUTDEGREE not in g.ndata:
+            g.ndata[OUTDEGREE] = g.out_degrees()
+        if edge_feat is not None:
+            g.edata[EDGEFEAT] = edge_feat
+        x, z = g.ndata[NODEFEAT], g.edata[EDGEFEAT]
+        ix = g.index()
+        coef = ix.degree_coef(g.ndata[OUTDEGREE])
+
+        # ---- node side: _node_message_func's node_msg + fn.sum + _node_update_func
+        if REVFLAG in g.edata:
+            s = ops.seg_sum2(z, ix, None, -1.0, 1.0)                       # [-S_fwd | S_rev]
+            agg = s @ th.cat([self.in_weight, self.out_weight], dim=0)
+        else:
+            agg = ops.seg_sum(z, ix) @ (-self.in_weight)
+        g.ndata[NODEAGG] = agg
+        out = x @ self.nloop_weight + agg
+        if self.nbias is not None:
+            out = out + self.nbias
+        out = self.nmlp(out) if len(self.nmlp) > 0 else self.act(out)
+        node_out = self.drop(out)
+
+        # ---- edge side: edge_msg of _node_message_func + _edge_update_func
+        p = x @ th.cat([self.dst_weight, self.src_weight], dim=1)
+        gm = z @ th.cat([self.eloop_weight, self.src_weight - self.dst_weight], dim=1)
+        out = ops.edge_combine(gm, p, self.ebias, coef, ix)
+        out = self.emlp(out) if len(self.emlp) > 0 else self.act(out)
+        edge_out = self.drop(out)
+
+        return node_out, edge_out
+
+    def extra_repr(self):
+        return "in=%s, out=%s" % (self.input_dim, self.hidden_dim)
+
+    def get_output_dim(self):
+        return self.hidden_dim
+
+
+class DMPNNRepMixin:
+    """``create_rep_net`` / ``get_pattern_rep`` / ``get_graph_rep`` of the reference's
+    ``DMPNN`` (dmpnn.py:183-277); mixed into the model skeleton (``basemodel``) and into
+    the stand-alone ``DMPNNRep`` below.  Expects ``hid_dim``, ``share_rep_net``,
+    ``rep_residual``, ``g_rep_net`` / ``p_rep_net`` attributes."""
+
+    def create_rep_net(self, type, **kw):
+        if type == "graph":
+            num_layers = kw.get("rep_num_graph_layers", 1)
+        elif type == "pattern":
+            if self.share_rep_net:
+                return self.g_rep_net
+            num_layers = kw.get("rep_num_pattern_layers", 1)
+        else:
+            raise ValueError(type)
+        dmpnn = nn.ModuleList()
+        for i in range(num_layers):
+            dmpnn.add_module(
+                "%s_dmpnn_(%d)" % (type, i),
+                DMPLayer(
+                    self.hid_dim,
+                    self.hid_dim,
+                    init_neigenv=kw.get("init_neigenv", 4.0),
+                    init_eeigenv=kw.get("init_eeigenv", 4.0),
+                    num_mlp_layers=kw.get("rep_dmpnn_num_mlp_layers", 2),
+                    batch_norm=kw.get("rep_dmpnn_batch_norm", False),
+                    act_func=kw.get("rep_act_func", "relu"),
+                    dropout=kw.get("rep_dropout", 0.0)
+                )
+            )
+        return nn.ModuleDict({"dmpnn": dmpnn})
+
+    def get_pattern_rep(self, pattern, p_v_emb, p_e_emb, v_mask=None, e_mask=None):
+        # dmpnn.py:215-243
+        if v_mask is not None:
+            p_v_zero_mask = ~(v_mask)
+            v_outputs = [p_v_emb.masked_fill(p_v_zero_mask, 0.0)]
+        else:
+            p_v_zero_mask = None
+            v_outputs = [p_v_emb]
+        if e_mask is not None:
+            p_e_zero_mask = ~(e_mask)
+            e_outputs = [p_e_emb.masked_fill(p_e_zero_mask, 0.0)]
+        else:
+            p_e_zero_mask = None
+            e_outputs = [p_e_emb]
+
+        for layer in self.p_rep_net["dmpnn"]:
+            v, e = layer(pattern, v_outputs[-1], e_outputs[-1])
+            if p_v_zero_mask is not None:
+                v = v.masked_fill(p_v_zero_mask, 0.0)
+            if p_e_zero_mask is not None:
+                e = e.masked_fill(p_e_zero_mask, 0.0)
+            if self.rep_residual and v_outputs[-1].size() == v.size() and e_outputs[-1].size() == e.size():
+                v_outputs.append(v_outputs[-1] + v)
+                e_outputs.append(e_outputs[-1] + e)
+            else:
+                v_outputs.append(v)
+                e_outputs.append(e)
+        return v_outputs[-1], e_outputs[-1]
+
+    def get_graph_rep(self, graph, g_v_emb, g_e_emb, v_mask=None, e_mask=None, v_gate=None, e_gate=None):
+        # dmpnn.py:245-277
+        if v_mask is not None or v_gate is not None:
+            if v_gate is None:
+                v_gate = v_mask.float()
+            elif v_mask is not None:
+                v_gate = v_mask.float() * v_gate
+            v_outputs = [g_v_emb * v_gate]
+        else:
+            v_outputs = [g_v_emb]
+        if e_mask is not None or e_gate is not None:
+            if e_gate is None:
+                e_gate = e_mask.float()
+            elif e_mask is not None:
+                e_gate = e_mask.float() * e_gate
+            e_outputs = [g_e_emb * e_gate]
+        else:
+            e_outputs = [g_e_emb]
+
+        for layer in self.g_rep_net["dmpnn"]:
+            v, e = layer(graph, v_outputs[-1], e_outputs[-1])
+            if v_gate is not None:
+                v = v * v_gate
+            if e_gate is not None:
+                e = e * e_gate
+            if self.rep_residual and v_outputs[-1].size() == v.size() and e_outputs[-1].size() == e.size():
+                v_outputs.append(v_outputs[-1] + v)
+                e_outputs.append(e_outputs[-1] + e)
+            else:
+                v_outputs.append(v)
+                e_outputs.append(e)
+        return v_outputs[-1], e_outputs[-1]
+
+
+class DMPNNRep(DMPNNRepMixin, nn.Module):
+    """The representation stage of ``DMPNN`` on its own: ``g_rep_net`` / ``p_rep_net``
+    with the reference's child names (``g_rep_net.dmpnn.graph_dmpnn_(i).*``), so a
+    reference checkpoint's rep-net entries load with ``strict=False``."""
+
+    def __init__(self, **kw):
+        super(DMPNNRep, self).__init__()
+        self.hid_dim = kw.get("hid_dim", 64)
+        self.share_rep_net = kw.get("share_rep_net", True)
+        self.rep_residual = kw.get("rep_residual", True)
+        self.g_rep_net = self.create_rep_net(type="graph", **kw)
+        self.p_rep_net = self.create_rep_net(type="pattern", **kw)
+
+    def forward(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
+        p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
+        g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=v_gate, e_gate=e_gate)
+        return p_v_rep, p_e_rep, g_v_rep, g_e_rep

@@ -1,0 +1,82 @@
+"""Data parallelism over (pattern, graph) pairs: one process per GPU, gradients summed
+with ONE all-reduce of a flat fp32 buffer per step (RCCL over xGMI on the GPU box;
+``gloo`` in the CPU tests).
+
+The reference is single-device (SubgraphCountingMatching/train.py:1080-1083); pairs are
+independent in forward and backward as long as BatchNorm is off (the default,
+config.py:201-207), and the losses are means over the local batch (train.py:463-480), so
+averaging the per-rank gradients reproduces the global-batch gradient for equal shards.
+
+The payload is small (~0.6 M parameters = 2.4 MB at H=128): latency-bound, so it is sent
+as one message instead of per-parameter buckets.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_items, rank, world):
+    """Contiguous shard [lo, hi) of ``num_items`` pairs for ``rank``; sizes differ by <= 1."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatGradSync:
+    """Makes every trainable parameter's ``.grad`` a view into one contiguous buffer.
+
+    Parameters that get no gradient in a step (the reference has such: ``out_weight``
+    without REVFLAG, UNC ``nfc``/``efc``, model.py:137-138) simply keep zeros there.
+    Use ``zero()`` instead of ``optimizer.zero_grad()`` (which would drop the views).
+    """
+
+    def __init__(self, module, group=None, average=True):
+        self.group = group
+        self.average = average
+        seen, params = set(), []
+        for p in module.parameters():  # shared modules (share_rep_net) appear once
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev, dt = params[0].device, params[0].dtype
+        for p in params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("all parameters must share device and dtype")
+        self.params = params
+        self.flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def zero(self):
+        self.flat.zero_()
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+    def sync(self, async_op=False):
+        """Sum the flat gradient over ranks (and divide by the world size if ``average``)."""
+        w = self.world
+        if w == 1:
+            return None
+        if async_op:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            self.flat.div_(w)
+        return None
+
+    def finish(self, work):
+        if work is not None:
+            work.wait()
+            if self.average:
+                self.flat.div_(self.world)

@@ -1,0 +1,273 @@
+"""Batched graph object: the part of the DGLGraph surface the reference's models
+touch, backed by device arrays and the HIP index kernels.
+
+Surface mirrored (measured by attribute tracing of
+``GraphAdjModelV2.forward``, SubgraphCountingMatching/models/basemodel.py:1500-1663):
+``batch_size``, ``batch_num_nodes()``, ``batch_num_edges()``, ``number_of_nodes()``,
+``number_of_edges()``, ``ndata`` / ``edata``, ``in_degrees()``, ``out_degrees()``,
+``update_all``, ``apply_edges``, ``all_edges(form, order="eid")``, ``.to(device)``.
+Degree caching follows ``dataset.Graph.in_degrees/out_degrees``
+(SubgraphCountingMatching/dataset.py:1222-1236).
+
+Edges are kept in eid order; CSR arrays are an *index* into that order and never
+reorder features (outputs of every layer stay in eid order).
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .constants import INDEGREE, OUTDEGREE, REVFLAG
+
+
+class SumReducer:
+    """``dgl.function.sum(msg, out)`` (dmpnn.py:92)."""
+
+    def __init__(self, msg, out):
+        self.msg = msg
+        self.out = out
+
+
+class function:  # namespace mirroring ``import dgl.function as fn``
+    sum = SumReducer
+
+
+class GraphIndex:
+    """Device-resident integer index of one (batched) graph.
+
+    in_ptr/in_ent   CSR by destination, entries (eid<<1)|is_reversed, ascending eid
+    out_ptr/out_ent CSR by source
+    inc_ptr/inc_ent incidence CSR (in-edges ++ out-edges with flipped flag), lazy
+    src32/dst32     int32 endpoints in eid order; rev8 uint8 is_reversed or None
+    in_deg/out_deg  int64 degree vectors (structure-derived)
+    """
+
+    def __init__(self, src, dst, num_nodes, rev=None, validate=False):
+        lib = _lib.load()
+        _lib.require_gpu(src, dst, rev)
+        if src.dtype != torch.int64 or dst.dtype != torch.int64:
+            raise _lib.DmpError("edge endpoints must be int64 (DGL default idtype)")
+        src = src.contiguous()
+        dst = dst.contiguous()
+        dev = src.device
+        E, N = src.numel(), int(num_nodes)
+        self.num_nodes, self.num_edges, self.device = N, E, dev
+        if rev is not None:
+            if rev.dtype == torch.bool:
+                rev = rev.to(torch.uint8)
+            elif rev.dtype != torch.uint8:
+                raise _lib.DmpError("is_reversed must be bool or uint8")
+            rev = rev.contiguous().view(-1)
+            if rev.numel() != E:
+                raise _lib.DmpError("is_reversed must have one entry per edge")
+        self.rev8 = rev
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.dmp_csr_workspace_words(N, E), **i32)
+        status = torch.empty(2, **i32)
+        self.in_ptr = torch.empty(N + 1, **i32)
+        self.in_ent = torch.empty(E, **i32)
+        self.dst32 = torch.empty(E, **i32)
+        self.in_deg = torch.empty(N, dtype=torch.int64, device=dev)
+        st = stream_ptr()
+        check(lib.dmp_csr_build(ptr(dst), ptr(rev), E, N, ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32),
+                                ptr(self.in_deg), ptr(status[0:]), ptr(ws), st), "dmp_csr_build(dst)")
+        self.out_ptr = torch.empty(N + 1, **i32)
+        self.out_ent = torch.empty(E, **i32)
+        self.src32 = torch.empty(E, **i32)
+        self.out_deg = torch.empty(N, dtype=torch.int64, device=dev)
+        check(lib.dmp_csr_build(ptr(src), ptr(rev), E, N, ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32),
+                                ptr(self.out_deg), ptr(status[1:]), ptr(ws), st), "dmp_csr_build(src)")
+        self._inc = None
+        self._coef = {}
+        if validate and int(status.sum().item()) != 0:
+            raise _lib.DmpError("edge endpoint outside [0, num_nodes)")
+
+    def incidence(self):
+        if self._inc is None:
+            lib = _lib.load()
+            N, E = self.num_nodes, self.num_edges
+            inc_ptr = torch.empty(N + 1, dtype=torch.int32, device=self.device)
+            inc_ent = torch.empty(2 * E, dtype=torch.int32, device=self.device)
+            check(lib.dmp_incidence_build(ptr(self.in_ptr), ptr(self.in_ent), ptr(self.out_ptr),
+                                          ptr(self.out_ent), N, E, ptr(inc_ptr), ptr(inc_ent), stream_ptr()),
+                  "dmp_incidence_build")
+            self._inc = (inc_ptr, inc_ent)
+        return self._inc
+
+    def degree_coef(self, out_deg):
+        """2(1+log2(1+out_deg)) per node (dmpnn.py:144-146); cached per degree tensor."""
+        key = (out_deg.data_ptr(), out_deg._version)
+        c = self._coef.get(key)
+        if c is None:
+            lib = _lib.load()
+            _lib.require_gpu(out_deg)
+            if out_deg.dtype != torch.int64:
+                out_deg = out_deg.to(torch.int64)
+            out_deg = out_deg.contiguous().view(-1)
+            c = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
+            check(lib.dmp_degree_coef(ptr(out_deg), self.num_nodes, ptr(c), stream_ptr()), "dmp_degree_coef")
+            self._coef = {key: c}
+        return c
+
+
+class _Gather:
+    """``edges.src`` / ``edges.dst`` views handed to message UDFs."""
+
+    def __init__(self, graph, by_src):
+        self._g, self._by_src = graph, by_src
+
+    def __contains__(self, k):
+        return k in self._g.ndata
+
+    def __getitem__(self, k):
+        from . import ops
+        t = self._g.ndata[k]
+        ix = self._g.index()
+        if t.is_cuda and t.dtype == torch.float32 and t.dim() == 2:
+            return ops.gather_src(t, ix) if self._by_src else ops.gather_dst(t, ix)
+        idx = self._g._src if self._by_src else self._g._dst
+        return t[idx]
+
+
+class EdgeBatch:
+    def __init__(self, graph):
+        self.src = _Gather(graph, True)
+        self.dst = _Gather(graph, False)
+        self.data = graph.edata  # same dict: UDF side-effect writes persist (dmpnn.py:126)
+        self._n = graph.number_of_edges()
+
+    def __len__(self):
+        return self._n
+
+
+class NodeBatch:
+    def __init__(self, graph):
+        self.data = graph.ndata
+        self._n = graph.number_of_nodes()
+
+    def __len__(self):
+        return self._n
+
+
+class BatchedGraph:
+    """A block-diagonal batch of directed multigraphs in eid order."""
+
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, batch_num_edges=None, ndata=None,
+                 edata=None):
+        if src.dtype != torch.int64 or dst.dtype != torch.int64:
+            raise ValueError("src/dst must be int64")
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src/dst must be 1-D and of equal length")
+        self._src, self._dst = src, dst
+        self._n = int(num_nodes)
+        self._bnn = batch_num_nodes
+        self._bne = batch_num_edges
+        self.ndata = dict(ndata) if ndata else {}
+        self.edata = dict(edata) if edata else {}
+        self._index = None
+        self._index_key = None
+        self.node_graph = None  # int32 [N] owning graph of each node (set by collate)
+        self.edge_graph = None
+
+    # ---- sizes
+    @property
+    def batch_size(self):
+        return 1 if self._bnn is None else int(self._bnn.numel())
+
+    def batch_num_nodes(self, *a):
+        if self._bnn is None:
+            return torch.tensor([self._n], dtype=torch.int64, device=self._src.device)
+        return self._bnn
+
+    def batch_num_edges(self, *a):
+        if self._bne is None:
+            return torch.tensor([self._src.numel()], dtype=torch.int64, device=self._src.device)
+        return self._bne
+
+    def number_of_nodes(self):
+        return self._n
+
+    def number_of_edges(self):
+        return int(self._src.numel())
+
+    num_nodes = number_of_nodes
+    num_edges = number_of_edges
+
+    def __len__(self):
+        return self._n
+
+    @property
+    def device(self):
+        return self._src.device
+
+    # ---- structure
+    def all_edges(self, form="uv", order="eid"):
+        if order != "eid":
+            raise NotImplementedError("only order='eid' is supported")
+        if form == "uv":
+            return self._src, self._dst
+        e = torch.arange(self._src.numel(), device=self._src.device)
+        if form == "eid":
+            return e
+        if form == "all":
+            return self._src, self._dst, e
+        raise ValueError(form)
+
+    edges = all_edges
+
+    def index(self, validate=False):
+        """Build (once) and return the device index; keyed on the is_reversed tensor."""
+        rev = self.edata.get(REVFLAG)
+        key = None if rev is None else (rev.data_ptr(), rev._version)
+        if self._index is None or self._index_key != key:
+            self._index = GraphIndex(self._src, self._dst, self._n, rev, validate=validate)
+            self._index_key = key
+        return self._index
+
+    def in_degrees(self):
+        # dataset.py:1222-1228: cached in ndata["in_deg"]
+        if INDEGREE not in self.ndata:
+            self.ndata[INDEGREE] = self.index().in_deg
+        return self.ndata[INDEGREE]
+
+    def out_degrees(self):
+        # dataset.py:1230-1236
+        if OUTDEGREE not in self.ndata:
+            self.ndata[OUTDEGREE] = self.index().out_deg
+        return self.ndata[OUTDEGREE]
+
+    # ---- message passing (generic UDF path = DGL semantics, HIP kernels underneath)
+    def update_all(self, message_func, reduce_func, apply_node_func=None):
+        """DGL semantics: message UDF once on all E edges (eid order), ``fn.sum`` by
+        destination (zero rows for nodes without in-edges), apply UDF once on all N nodes."""
+        from . import ops
+        if not isinstance(reduce_func, SumReducer):
+            raise NotImplementedError("only fn.sum reduction is supported")
+        msgs = message_func(EdgeBatch(self))
+        m = msgs[reduce_func.msg]
+        shape = m.shape
+        agg = ops.seg_sum(m.reshape(shape[0], -1), self.index())
+        self.ndata[reduce_func.out] = agg.reshape((self._n,) + tuple(shape[1:]))
+        if apply_node_func is not None:
+            self.ndata.update(apply_node_func(NodeBatch(self)))
+
+    def apply_edges(self, func):
+        self.edata.update(func(EdgeBatch(self)))
+
+    def local_var(self):
+        return self
+
+    # ---- placement
+    def to(self, device):
+        device = torch.device(device) if device is not None else None
+        if device is None or device == self._src.device:
+            return self
+        g = BatchedGraph(self._src.to(device), self._dst.to(device), self._n,
+                         None if self._bnn is None else self._bnn.to(device),
+                         None if self._bne is None else self._bne.to(device),
+                         {k: v.to(device) for k, v in self.ndata.items()},
+                         {k: v.to(device) for k, v in self.edata.items()})
+        if self.node_graph is not None:
+            g.node_graph = self.node_graph.to(device)
+        if self.edge_graph is not None:
+            g.edge_graph = self.edge_graph.to(device)
+        return g

@@ -1,0 +1,266 @@
+"""torch.autograd wrappers around the C ABI of libdmp_hip.so.
+
+Each Function is one HIP kernel forward and one (or two) HIP kernels backward;
+torch is only used for memory, streams and the autograd tape.  There is no CPU
+implementation here -- CPU tensors raise (``_lib.require_gpu``).
+
+Math (reference SubgraphCountingMatching/models/dmpnn.py:111-156):
+  seg_sum        A[v]      = sum_{e: dst(e)=v} w_e M[e]                  (fn.sum, dmpnn.py:92)
+  seg_sum2       S[v]      = [s0 * sum_{flag=0} w_e M[e] | s1 * sum_{flag=1} w_e M[e]]
+  gather_rows    out[e]    = w_e X[idx[e]]                               (edges.src/dst[...])
+  edge_combine   Y[e]      = G[e,:H] + coef[dst e] G[e,H:] + b + (+-) gathered P rows
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _mat(t, min_cols=None):
+    """fp32 2-D tensor with unit inner stride; returns (tensor, leading dim)."""
+    if t.dtype != torch.float32:
+        raise _lib.DmpError("feature matrices must be float32, got %s" % t.dtype)
+    if t.dim() != 2:
+        raise _lib.DmpError("feature matrices must be 2-D, got shape %s" % (tuple(t.shape),))
+    if t.size(0) <= 1:
+        t = t.contiguous()
+        return t, max(t.size(1), 1)
+    if t.stride(1) != 1 or t.stride(0) < t.size(1):
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def _vec(t, dtype):
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        raise _lib.DmpError("expected %s tensor, got %s" % (dtype, t.dtype))
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------- raw launches
+def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0):
+    lib = _lib.load()
+    _lib.require_gpu(M, rowptr, ent, edge_w)
+    M, ldm = _mat(M)
+    H = M.size(1)
+    out = torch.empty((num_nodes, 2 * H if split else H), dtype=torch.float32, device=M.device)
+    ew = _vec(edge_w, torch.float32)
+    nent = ent.numel()
+    # algorithmic bytes: every source row once, every output row once, the CSR arrays once
+    nbytes = 4 * H * nent + 4 * out.size(1) * num_nodes + 4 * nent + 4 * (num_nodes + 1) + (4 * nent if ew is not None else 0)
+    if split:
+        with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
+            check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,
+                                   ptr(out), out.size(1), stream_ptr()), "dmp_seg_sum2")
+    else:
+        with _lib.timed("seg_sum[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
+            check(lib.dmp_seg_sum(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H,
+                                  ptr(out), out.size(1), stream_ptr()), "dmp_seg_sum")
+    return out
+
+
+def gather_rows_raw(X, idx32, edge_w=None):
+    lib = _lib.load()
+    _lib.require_gpu(X, idx32, edge_w)
+    X, ldx = _mat(X)
+    E, H = idx32.numel(), X.size(1)
+    out = torch.empty((E, H), dtype=torch.float32, device=X.device)
+    ew = _vec(edge_w, torch.float32)
+    with _lib.timed("gather_rows[H=%d,E=%d]" % (H, E), 4 * H * (E + X.size(0)) + 4 * E):
+        check(lib.dmp_gather_rows(ptr(X), ldx, ptr(idx32), ptr(ew), E, H, ptr(out), H, stream_ptr()),
+              "dmp_gather_rows")
+    return out
+
+
+def gather_select_raw(D, dst32, rev8, H, edge_w=None, s0=1.0, s1=1.0):
+    lib = _lib.load()
+    _lib.require_gpu(D, dst32, rev8, edge_w)
+    D, ldd = _mat(D)
+    E = dst32.numel()
+    out = torch.empty((E, H), dtype=torch.float32, device=D.device)
+    ew = _vec(edge_w, torch.float32)
+    with _lib.timed("gather_select[H=%d,E=%d]" % (H, E), 4 * H * (E + 2 * D.size(0)) + 5 * E):
+        check(lib.dmp_gather_select(ptr(D), ldd, ptr(dst32), ptr(rev8), ptr(ew), E, H, s0, s1, ptr(out), H,
+                                    stream_ptr()), "dmp_gather_select")
+    return out
+
+
+# ----------------------------------------------------------------------------- autograd ops
+class _SegSum(torch.autograd.Function):
+    """fn.sum by destination; backward = row gather (dmpnn.py:92,163)."""
+
+    @staticmethod
+    def forward(ctx, M, index, edge_w):
+        ctx.index = index
+        ctx.edge_w = edge_w
+        return seg_sum_raw(M, index.in_ptr, index.in_ent, index.num_nodes, edge_w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dA):
+        return gather_rows_raw(dA, ctx.index.dst32, ctx.edge_w), None, None
+
+
+class _SegSumBySrc(torch.autograd.Function):
+    """Sum of per-edge rows by *source* node; backward = gather by src."""
+
+    @staticmethod
+    def forward(ctx, M, index):
+        ctx.index = index
+        return seg_sum_raw(M, index.out_ptr, index.out_ent, index.num_nodes)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dA):
+        return gather_rows_raw(dA, ctx.index.src32), None
+
+
+class _SegSum2(torch.autograd.Function):
+    """Flag-split segment sum over the in-CSR; backward = gather_select."""
+
+    @staticmethod
+    def forward(ctx, M, index, edge_w, s0, s1):
+        ctx.index, ctx.edge_w, ctx.s0, ctx.s1, ctx.H = index, edge_w, s0, s1, M.size(1)
+        return seg_sum_raw(M, index.in_ptr, index.in_ent, index.num_nodes, edge_w, True, s0, s1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dS):
+        ix = ctx.index
+        dM = gather_select_raw(dS, ix.dst32, ix.rev8, ctx.H, ctx.edge_w, ctx.s0, ctx.s1)
+        return dM, None, None, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """edges.src[k] (by_src=True) or edges.dst[k]; backward = segment sum."""
+
+    @staticmethod
+    def forward(ctx, X, index, by_src):
+        ctx.index, ctx.by_src = index, by_src
+        return gather_rows_raw(X, index.src32 if by_src else index.dst32)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dO):
+        ix = ctx.index
+        if ctx.by_src:
+            return seg_sum_raw(dO, ix.out_ptr, ix.out_ent, ix.num_nodes), None, None
+        return seg_sum_raw(dO, ix.in_ptr, ix.in_ent, ix.num_nodes), None, None
+
+
+class _EdgeCombine(torch.autograd.Function):
+    """DMPLayer edge pre-activation, one kernel (dmpnn.py:112,120,124,142-151)."""
+
+    @staticmethod
+    def forward(ctx, G, P, bias, coef, index):
+        lib = _lib.load()
+        _lib.require_gpu(G, P, bias, coef)
+        G, ldg = _mat(G)
+        P, ldp = _mat(P)
+        E, H = G.size(0), G.size(1) // 2
+        if G.size(1) != 2 * H or P.size(1) != 2 * H or E != index.num_edges:
+            raise _lib.DmpError("edge_combine: G must be [E,2H], P [N,2H]")
+        Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
+        b = _vec(bias, torch.float32)
+        with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * P.size(0)) + 9 * E + 4 * P.size(0)):
+            check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(b), ptr(index.src32),
+                                       ptr(index.dst32), ptr(index.rev8), E, H, ptr(Y), H, stream_ptr()),
+                  "dmp_edge_combine")
+        ctx.index, ctx.coef, ctx.H = index, coef, H
+        ctx.has_bias = bias is not None
+        return Y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dY):
+        lib = _lib.load()
+        ix, H = ctx.index, ctx.H
+        dY, ldy = _mat(dY)
+        E = dY.size(0)
+        dG = dP = db = None
+        if ctx.needs_input_grad[0]:
+            dG = torch.empty((E, 2 * H), dtype=torch.float32, device=dY.device)
+            with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]" % (H, E), 4 * H * 3 * E + 4 * E + 4 * ix.num_nodes):
+                check(lib.dmp_edge_combine_bwd_g(ptr(dY), ldy, ptr(ctx.coef), ptr(ix.dst32), E, H, ptr(dG),
+                                                 2 * H, stream_ptr()), "dmp_edge_combine_bwd_g")
+        if ctx.needs_input_grad[1]:
+            inc_ptr, inc_ent = ix.incidence()
+            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dY.sum(0)
+        return dG, dP, db, None, None
+
+
+class _CompGCNAgg(torch.autograd.Function):
+    """CompGCN message + fn.sum with the W_in/W_out products moved behind the sum
+    (compgcn.py:213-238,271)."""
+
+    @staticmethod
+    def forward(ctx, X, Z, norm, index, comp):
+        lib = _lib.load()
+        _lib.require_gpu(X, Z, norm)
+        X, ldx = _mat(X)
+        Z, ldz = _mat(Z)
+        H = X.size(1)
+        out = torch.empty((index.num_nodes, 2 * H), dtype=torch.float32, device=X.device)
+        nrm = _vec(norm, torch.float32)
+        check(lib.dmp_compgcn_agg(ptr(X), ldx, ptr(Z), ldz, ptr(index.in_ptr), ptr(index.in_ent),
+                                  ptr(index.src32), ptr(nrm), index.num_nodes, H, comp, ptr(out), 2 * H,
+                                  stream_ptr()), "dmp_compgcn_agg")
+        ctx.save_for_backward(X, Z)
+        ctx.index, ctx.norm, ctx.comp = index, nrm, comp
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dS):
+        lib = _lib.load()
+        X, Z = ctx.saved_tensors
+        ix = ctx.index
+        X, ldx = _mat(X)
+        Z, ldz = _mat(Z)
+        dS, ldd = _mat(dS)
+        E, H = ix.num_edges, X.size(1)
+        dZ = torch.empty((E, H), dtype=torch.float32, device=X.device)
+        dXe = torch.empty((E, H), dtype=torch.float32, device=X.device)
+        check(lib.dmp_compgcn_agg_bwd(ptr(dS), ldd, ptr(X), ldx, ptr(Z), ldz, ptr(ix.src32), ptr(ix.dst32),
+                                      ptr(ix.rev8), ptr(ctx.norm), E, H, ctx.comp, ptr(dZ), H, ptr(dXe), H,
+                                      stream_ptr()), "dmp_compgcn_agg_bwd")
+        dX = seg_sum_raw(dXe, ix.out_ptr, ix.out_ent, ix.num_nodes)
+        return dX, dZ, None, None, None
+
+
+# ----------------------------------------------------------------------------- public functional API
+def seg_sum(M, index, edge_w=None):
+    """``out[v] = sum_{e: dst(e)=v} w_e M[e]`` -- DGL ``fn.sum`` by destination."""
+    return _SegSum.apply(M, index, edge_w)
+
+
+def seg_sum_by_src(M, index):
+    return _SegSumBySrc.apply(M, index)
+
+
+def seg_sum2(M, index, edge_w=None, s0=-1.0, s1=1.0):
+    """``[s0 * sum_{non-reversed in-edges} | s1 * sum_{reversed in-edges}]`` -> [N, 2H]."""
+    return _SegSum2.apply(M, index, edge_w, float(s0), float(s1))
+
+
+def gather_src(X, index):
+    return _GatherRows.apply(X, index, True)
+
+
+def gather_dst(X, index):
+    return _GatherRows.apply(X, index, False)
+
+
+def edge_combine(G, P, bias, coef, index):
+    return _EdgeCombine.apply(G, P, bias, coef, index)
+
+
+COMP_SUB, COMP_MULT = 0, 1
+
+
+def compgcn_agg(X, Z, norm, index, comp):
+    return _CompGCNAgg.apply(X, Z, norm, index, int(comp))

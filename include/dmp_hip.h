@@ -1,0 +1,283 @@
+/*
+ * dmp_hip.h -- C ABI of libdmp_hip.so: the MI355X (gfx950) dual-message-passing
+ * hot path.
+ *
+ * The reference (HKUST-KnowComp/DualMessagePassing) is pure Python; its "native"
+ * boundary for this path is the set of DGL calls made by the DMPNN / CompGCN
+ * layers and the dataset transforms.  Each entry point below names the
+ * reference call site (path:line under /root/reference) it replaces.  A
+ * maintainer binds them with ctypes; the shipped host side
+ * (dualmessagepassing_amd/) does exactly that.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless marked "host";
+ *  - the caller allocates every buffer, the library holds no state;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - nothing synchronises the stream, nothing allocates; safe to capture in a
+ *    hipGraph and to call from several host threads on distinct streams;
+ *  - return value: DMP_OK (0) or a negative DMP_ERR_* code; never throws.
+ *  - feature matrices are row-major fp32 with an explicit leading dimension
+ *    (`ld*`, in floats) so column slices of fused GEMM outputs can be passed
+ *    without a copy;
+ *  - graph indices are int64 at the API where the reference uses DGL's default
+ *    idtype (int64) and int32 inside the CSR index arrays built here.
+ *
+ * "ent" arrays: a CSR entry is a packed int32  (eid << 1) | flag  where flag is
+ * the edge's is_reversed bit (possibly flipped, see dmp_incidence_build).  The
+ * rows of every CSR built here list their edges in ascending eid, so every
+ * per-destination sum has a fixed order and results are run-to-run bit-stable.
+ */
+#ifndef DMP_HIP_H
+#define DMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMP_OK 0
+#define DMP_ERR_BAD_ARG (-1)     /* null pointer, negative size, bad enum          */
+#define DMP_ERR_UNSUPPORTED (-2) /* shape the kernels do not cover (e.g. E >= 2^30) */
+#define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
+
+/* ABI version of this header; bumped on any signature change. */
+#define DMP_ABI_VERSION 1
+int dmp_abi_version(void);
+/* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
+const char *dmp_last_hip_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Graph index construction (integer, bit-exact)                             */
+/* ------------------------------------------------------------------------- */
+
+/* Number of int32 words of scratch dmp_csr_build / dmp_incidence_build need. */
+size_t dmp_csr_workspace_words(int64_t num_nodes, int64_t num_edges);
+
+/*
+ * CSR by `key` (key = dst gives the in-edge lists DGL builds behind
+ * `update_all(..., fn.sum, ...)`: SubgraphCountingMatching/models/dmpnn.py:163,
+ * compgcn.py:271, UnsupervisedNodeClassification/Model/DMPNN/src/model.py:271;
+ * key = src gives the out-edge lists).  Also yields the degree vector
+ * (`graph.in_degrees()` / `graph.out_degrees()`: dmpnn.py:101,
+ * compgcn.py:180,190, dataset.py:1222-1236) as int64.
+ *
+ *   key      [E] int64  node id per edge, in eid order
+ *   flag     [E] uint8  is_reversed per edge, or NULL (all 0)
+ *   rowptr   [N+1] int32 out
+ *   ent      [E]  int32 out, (eid<<1)|flag, ascending eid inside each row
+ *   key32    [E]  int32 out, or NULL: key narrowed to int32
+ *   degree   [N]  int64 out, or NULL
+ *   status   [1]  int32 out: 0, or 1 if any key was outside [0,N)
+ *   ws       scratch, dmp_csr_workspace_words() int32 words
+ */
+int dmp_csr_build(const int64_t *key, const uint8_t *flag, int64_t num_edges,
+                  int64_t num_nodes, int32_t *rowptr, int32_t *ent,
+                  int32_t *key32, int64_t *degree, int32_t *status,
+                  int32_t *ws, void *stream);
+
+/*
+ * Incidence CSR: for node w, its in-edges (flag = is_reversed) followed by its
+ * out-edges (flag = !is_reversed).  This is the index of the backward of the
+ * implicit line-graph edge message (dmpnn.py:112,120: d/dX of
+ * X[dst]W_dst - X[src]W_src with the src/dst swap on reversed edges).
+ *
+ *   in_ptr/in_ent   CSR by dst from dmp_csr_build
+ *   out_ptr/out_ent CSR by src from dmp_csr_build
+ *   inc_ptr [N+1] int32 out, inc_ent [2E] int32 out
+ */
+int dmp_incidence_build(const int32_t *in_ptr, const int32_t *in_ent,
+                        const int32_t *out_ptr, const int32_t *out_ent,
+                        int64_t num_nodes, int64_t num_edges, int32_t *inc_ptr,
+                        int32_t *inc_ent, void *stream);
+
+/*
+ * Degree coefficient of the edge update, per node:
+ *   coef[v] = 2 * (1 + log2(1 + out_deg[v]))          (dmpnn.py:144-146)
+ * out_deg is the int64 vector the reference caches in ndata["out_deg"].
+ */
+int dmp_degree_coef(const int64_t *out_deg, int64_t num_nodes, float *coef,
+                    void *stream);
+
+/*
+ * Block-diagonal batching of B graphs (`dgl.batch` behind Graph.batch:
+ * SubgraphCountingMatching/dataset.py:1320-1328, called from
+ * GraphAdjDataset.batchify dataset.py:1604-1636).
+ *
+ *   local_src/local_dst [E] int64  per-graph local node ids, graphs
+ *                                  concatenated in list order
+ *   num_nodes/num_edges [B] int64  per-graph sizes (batch_num_nodes/edges)
+ *   node_off/edge_off   [B+1] int64 out, exclusive prefix sums
+ *   src/dst             [E] int64 out, global ids (local + node_off[graph])
+ *   edge_graph [E] int32 out or NULL, node_graph [N] int32 out or NULL:
+ *                                  owning graph of each edge / node
+ * E and N (totals) are passed by the host, which knows them from the sizes.
+ */
+int dmp_collate(const int64_t *local_src, const int64_t *local_dst,
+                const int64_t *num_nodes, const int64_t *num_edges,
+                int64_t batch, int64_t total_nodes, int64_t total_edges,
+                int64_t *node_off, int64_t *edge_off, int64_t *src,
+                int64_t *dst, int32_t *edge_graph, int32_t *node_graph,
+                void *stream);
+
+/*
+ * `add_reversed_edges` (GraphAdj branch), SubgraphCountingMatching/train.py:299-327:
+ * for one graph, append (v->u) after all (u->v) with id = max_ne + arange(E),
+ * label += max_nel, is_reversed = 1 (originals 0).  Batched over B graphs laid
+ * out back to back: graph g's E_g edges at edge_off[g] become 2*E_g edges at
+ * 2*edge_off[g] ([forward | reversed] per graph, the order the layer sees).
+ *
+ *   src/dst/eid/elabel [E] int64 in;  edge_off [B+1] int64
+ *   o_src/o_dst/o_eid/o_elabel [2E] int64 out; o_rev [2E] uint8 out
+ */
+int dmp_add_reversed_edges(const int64_t *src, const int64_t *dst,
+                           const int64_t *eid, const int64_t *elabel,
+                           const int64_t *edge_off, int64_t batch,
+                           int64_t num_edges, int64_t max_ne, int64_t max_nel,
+                           int64_t *o_src, int64_t *o_dst, int64_t *o_eid,
+                           int64_t *o_elabel, uint8_t *o_rev, void *stream);
+
+/*
+ * Directed line graph, plain branch of `convert_to_dual_graph`
+ * (SubgraphCountingMatching/utils/graph.py:126-134): for e = 0..E-1 in eid
+ * order, s = src[e], for every in-edge i of s in ascending eid emit the dual
+ * edge (i -> e) with payload s.  Two calls:
+ *   count: cnt[e] = in_degree(src[e])           (then the caller scans cnt,
+ *          or passes `off` = NULL to dmp_line_graph_fill after dmp_exclusive_scan_i64)
+ *   fill : writes dual_src/dual_dst/payload [M], M = sum(cnt) = sum_v indeg*outdeg
+ */
+int dmp_line_graph_count(const int32_t *in_ptr, const int64_t *src,
+                         int64_t num_edges, int64_t *cnt, void *stream);
+int dmp_line_graph_fill(const int32_t *in_ptr, const int32_t *in_ent,
+                        const int64_t *src, const int64_t *off,
+                        int64_t num_edges, int64_t *dual_src, int64_t *dual_dst,
+                        int64_t *payload, void *stream);
+
+/*
+ * id/label branch of `convert_to_dual_graph` (utils/graph.py:80-95,110-125,161-164):
+ * dual edges are built in edge-*id* space and only the first occurrence of a key
+ * (id[i], node_label[src], id[e]) is kept; dual nodes are the distinct edge ids,
+ * each represented by its first edge, holes removed and ids compacted.
+ *
+ *   dmp_first_edge_of_id: first[k] = min{e : eid[e] = k} or -1, k in [0,K)
+ *   dmp_dedupe_first    : keep[m] = 1 iff candidate m is the first (lowest m)
+ *                         with its (a,l,b) key.  table: scratch of
+ *                         dmp_dedupe_table_words(M) int64 words.
+ */
+int dmp_first_edge_of_id(const int64_t *eid, int64_t num_edges, int64_t num_ids,
+                         int64_t *first, void *stream);
+size_t dmp_dedupe_table_words(int64_t num_items);
+int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
+                     const int64_t *key_b, int64_t num_items, int64_t *table,
+                     uint8_t *keep, void *stream);
+
+/* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
+ * ws: scratch of dmp_scan_workspace_words(n) int64 words. */
+size_t dmp_scan_workspace_words(int64_t n);
+int dmp_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out,
+                           int64_t *ws, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Aggregation kernels (fp32, HBM-bound)                                     */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Segment sum by destination -- `fn.sum(msg, out)` inside `update_all`
+ * (dmpnn.py:92,163; compgcn.py:165,271; UNC model.py:202,271):
+ *     out[v, :] = sum_{i in [rowptr[v], rowptr[v+1])}  w_i * M[ent[i]>>1, :]
+ * with w_i = edge_w[eid] if edge_w != NULL else 1.  Atomics-free, fixed order.
+ *   M [E, ldm>=H], out [N, ldo>=H]
+ */
+int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr,
+                const int32_t *ent, const float *edge_w, int64_t num_nodes,
+                int H, float *out, int64_t ldo, void *stream);
+
+/*
+ * Flag-split segment sum: the DMPLayer node aggregation after moving the
+ * W_in / W_out products behind the sum (dmpnn.py:113,121,125 + fn.sum):
+ *     out[v, 0:H ] = s0 * sum_{i: flag=0} w_i * M[eid_i, :]
+ *     out[v, H:2H] = s1 * sum_{i: flag=1} w_i * M[eid_i, :]
+ * With the in-CSR and (s0,s1) = (-1,+1) this is [-S_fwd | S_rev] so that
+ * node_agg = out @ [W_in ; W_out].  With the incidence CSR and (+1,-1) it is the
+ * backward of dmp_edge_combine w.r.t. the projected node features.
+ *   M [E, ldm>=H], out [N, ldo>=2H]
+ */
+int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
+                 const int32_t *ent, const float *edge_w, int64_t num_nodes,
+                 int H, float s0, float s1, float *out, int64_t ldo,
+                 void *stream);
+
+/*
+ * Row gather by an int32 index -- `edges.src[k]` / `edges.dst[k]` inside the
+ * message UDFs (dmpnn.py:112,120; compgcn.py:227) and the backward of
+ * dmp_seg_sum:   out[e, :] = w_e * X[idx[e], :]
+ */
+int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx,
+                    const float *edge_w, int64_t num_edges, int H, float *out,
+                    int64_t ldo, void *stream);
+
+/*
+ * Backward of dmp_seg_sum2 over the in-CSR:
+ *     out[e, :] = w_e * (flag[e] ? s1 * D[dst[e], H:2H] : s0 * D[dst[e], 0:H])
+ *   D [N, ldd>=2H], out [E, ldo>=H], flag may be NULL (all 0)
+ */
+int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst,
+                      const uint8_t *flag, const float *edge_w,
+                      int64_t num_edges, int H, float s0, float s1, float *out,
+                      int64_t ldo, void *stream);
+
+/*
+ * DMPLayer edge pre-activation (dmpnn.py:112,120,124,142-151), project-then-gather:
+ *     Y[e] = G[e,0:H] + coef[dst e] * G[e,H:2H] + bias
+ *            + (flag[e] ? P[src e,0:H] - P[dst e,H:2H]
+ *                       : P[dst e,0:H] - P[src e,H:2H])
+ * where G = Z @ [W_eloop | W_src - W_dst]  and  P = X @ [W_dst | W_src].
+ *   G [E, ldg>=2H], P [N, ldp>=2H], coef [N], bias [H] or NULL, Y [E, ldy>=H]
+ */
+int dmp_edge_combine(const float *G, int64_t ldg, const float *P, int64_t ldp,
+                     const float *coef, const float *bias, const int32_t *src,
+                     const int32_t *dst, const uint8_t *flag,
+                     int64_t num_edges, int H, float *Y, int64_t ldy,
+                     void *stream);
+
+/*
+ * Backward of dmp_edge_combine w.r.t. G:
+ *     dG[e, 0:H] = dY[e],   dG[e, H:2H] = coef[dst e] * dY[e]
+ * (w.r.t. P it is dmp_seg_sum2 over the incidence CSR with (s0,s1) = (+1,-1);
+ *  w.r.t. bias a column sum the host side takes.)
+ */
+int dmp_edge_combine_bwd_g(const float *dY, int64_t ldy, const float *coef,
+                           const int32_t *dst, int64_t num_edges, int H,
+                           float *dG, int64_t ldg, void *stream);
+
+/*
+ * CompGCN message aggregation (compgcn.py:213-238 + fn.sum), sum moved in front
+ * of the W_in / W_out products:
+ *     m_e = norm_e * comp(X[src e], Z[e]),  comp = sub (0): x - z, mult (1): x * z
+ *     out[v, 0:H ] = sum_{e->v, flag=0} m_e ;  out[v, H:2H] = sum_{e->v, flag=1} m_e
+ * so that node_agg = out @ [W_in ; W_out].  norm may be NULL.
+ */
+int dmp_compgcn_agg(const float *X, int64_t ldx, const float *Z, int64_t ldz,
+                    const int32_t *rowptr, const int32_t *ent,
+                    const int32_t *src, const float *norm, int64_t num_nodes,
+                    int H, int comp, float *out, int64_t ldo, void *stream);
+
+/*
+ * Backward of dmp_compgcn_agg w.r.t. Z (per edge, streaming):
+ *     g_e = norm_e * D[dst e, flag ? H:2H : 0:H]
+ *     dZ[e] = sub: -g_e          mult: g_e * X[src e]
+ * and the per-edge term of dX:  dXe[e] = sub: g_e   mult: g_e * Z[e]
+ * (dX = dmp_seg_sum of dXe over the CSR by src).
+ */
+int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X,
+                        int64_t ldx, const float *Z, int64_t ldz,
+                        const int32_t *src, const int32_t *dst,
+                        const uint8_t *flag, const float *norm,
+                        int64_t num_edges, int H, int comp, float *dZ,
+                        int64_t lddz, float *dXe, int64_t lddxe, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMP_HIP_H */

@@ -1,0 +1,376 @@
+"""Emit the golden fixtures under tests/golden/ by running the REFERENCE's own code.
+
+Runs only in the development container (needs /root/reference).  The reference's
+model files are imported over the DGL/numba/igraph stand-ins of
+``oracle/ref_standin.py``; their arithmetic is the reference's own torch code.
+Outputs are data only (inputs, parameters, expected outputs/gradients) -- no
+reference source is copied.
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+Fixtures
+  dmplayer_*.npz     DMPLayer fwd+bwd (models/dmpnn.py:158-166)
+  dmpnn_rep.npz      DMPNN.get_pattern_rep / get_graph_rep, L=3, gates, residual (dmpnn.py:215-277)
+  compgcn_*.npz      CompGCNLayer fwd+bwd (models/compgcn.py:265-274)
+  linegraph_*.npz    convert_to_dual_graph (utils/graph.py:74-169)
+  addrev_*.npz       add_reversed_edges, GraphAdj branch (train.py:299-327)
+  unc_dualconv_*.npz DualGraphConv (UNC Model/DMPNN/src/model.py:117-273) -- separate interpreter
+"""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import torch as th
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, HERE)
+
+
+def er_edges(n, m, rng):
+    """m distinct ordered pairs u != v, uniformly without replacement."""
+    total = n * (n - 1)
+    pick = rng.choice(total, size=m, replace=False)
+    u = pick // (n - 1)
+    r = pick % (n - 1)
+    v = r + (r >= u)
+    return u.astype(np.int64), v.astype(np.int64)
+
+
+def named_graphs(rng):
+    g = {}
+    g["cycle3"] = (np.array([0, 1, 2]), np.array([1, 2, 0]), 3)
+    g["pair2"] = (np.array([0]), np.array([1]), 2)
+    g["star8"] = (np.arange(1, 9), np.zeros(8, dtype=np.int64), 9)
+    u, v = er_edges(8, 12, rng)
+    g["er8_12"] = (u, v, 8)
+    u, v = er_edges(64, 256, rng)
+    g["er64_256"] = (u, v, 64)
+    # multigraph with a self loop and an isolated node
+    g["multi"] = (np.array([0, 0, 1, 2, 2, 1]), np.array([1, 1, 2, 2, 0, 0]), 4)
+    return {k: (np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64), n) for k, (a, b, n) in g.items()}
+
+
+def with_rev(u, v):
+    e = len(u)
+    return np.concatenate([u, v]), np.concatenate([v, u]), np.concatenate([np.zeros(e, bool), np.ones(e, bool)])
+
+
+def t2n(d):
+    """tensors -> numpy; ``None`` entries (gradients of unused parameters) are dropped."""
+    return {k: (v.detach().numpy() if isinstance(v, th.Tensor) else np.asarray(v)) for k, v in d.items()
+            if v is not None}
+
+
+def seed_of(*key):
+    return zlib.crc32(repr(key).encode()) % (2 ** 31)
+
+
+def gen_dmplayer():
+    import dgl
+    from models.dmpnn import DMPLayer
+    rng = np.random.default_rng(1234)
+    graphs = named_graphs(rng)
+    cases = [
+        ("cycle3", 4, "relu", False, 2), ("cycle3", 4, "relu", True, 2),
+        ("pair2", 4, "leaky_relu", True, 2), ("star8", 8, "relu", True, 2),
+        ("multi", 8, "leaky_relu", True, 2), ("multi", 6, "relu", False, 0),
+        ("er8_12", 64, "relu", True, 2), ("er8_12", 64, "leaky_relu", False, 2),
+        ("er64_256", 64, "relu", True, 2), ("er64_256", 128, "leaky_relu", True, 2),
+    ]
+    for name, h, act, use_rev, nmlp in cases:
+        u, v, n = graphs[name]
+        rev = None
+        if use_rev:
+            u, v, rev = with_rev(u, v)
+        th.manual_seed(seed_of(name, h, act, use_rev))
+        layer = DMPLayer(h, h, init_neigenv=4.0, init_eeigenv=4.0, num_mlp_layers=nmlp, batch_norm=False,
+                         act_func=act, dropout=0.0)
+        with th.no_grad():  # biases are zero-initialised; make them matter
+            layer.nbias.uniform_(-0.1, 0.1)
+            layer.ebias.uniform_(-0.1, 0.1)
+            for m in list(layer.nmlp.modules()) + list(layer.emlp.modules()):
+                if isinstance(m, th.nn.Linear):
+                    m.bias.uniform_(-0.1, 0.1)
+        g = dgl.DGLGraph.from_edges(u, v, n)
+        if rev is not None:
+            g.edata["is_reversed"] = th.from_numpy(rev)
+        x = th.randn(n, h, requires_grad=True)
+        z = th.randn(len(u), h, requires_grad=True)
+        node_out, edge_out = layer(g, x, z)
+        wn = th.randn_like(node_out)
+        we = th.randn_like(edge_out)
+        ((node_out * wn).sum() + (edge_out * we).sum()).backward()
+        d = {"src": u, "dst": v, "num_nodes": n, "out_deg": g.ndata["out_deg"],
+             "x": x, "z": z, "node_out": node_out, "edge_out": edge_out, "wn": wn, "we": we,
+             "dx": x.grad, "dz": z.grad, "edge_agg": g.edata["edge_agg"], "node_agg": g.ndata["node_agg"],
+             "act_func": act, "num_mlp_layers": nmlp}
+        if rev is not None:
+            d["rev"] = rev
+        for k, p in layer.named_parameters():
+            d["p." + k] = p
+            d["g." + k] = p.grad
+        fn = "dmplayer_%s_h%d_%s_%s_m%d.npz" % (name, h, act, "rev" if use_rev else "norev", nmlp)
+        np.savez_compressed(os.path.join(OUT, fn), **t2n(d))
+        print("wrote", fn)
+
+
+def gen_dmpnn_rep():
+    """get_pattern_rep / get_graph_rep of the reference DMPNN class, called unbound on a
+    light holder object (they only touch p_rep_net / g_rep_net / rep_residual)."""
+    import dgl
+    from models.dmpnn import DMPNN, DMPLayer
+    from models.container import ModuleDict, ModuleList
+    rng = np.random.default_rng(77)
+    h, L, B = 32, 3, 4
+    th.manual_seed(5)
+
+    class Holder(th.nn.Module):
+        pass
+
+    hold = Holder()
+    hold.rep_residual = True
+    layers = ModuleList()
+    for i in range(L):
+        layers.add_module("graph_dmpnn_(%d)" % i,
+                          DMPLayer(h, h, num_mlp_layers=2, batch_norm=False, act_func="relu", dropout=0.0))
+    hold.g_rep_net = ModuleDict({"dmpnn": layers})
+    hold.p_rep_net = hold.g_rep_net  # share_rep_net (dmpnn.py:186-188)
+
+    def batch(nv, ne):
+        gs = []
+        for _ in range(B):
+            u, v = er_edges(nv, ne, rng)
+            u, v, rev = with_rev(u, v)
+            g = dgl.DGLGraph.from_edges(u, v, nv)
+            g.edata["is_reversed"] = th.from_numpy(rev)
+            g.ndata["out_deg"] = g.out_degrees()
+            gs.append(g)
+        return dgl.batch(gs)
+
+    pattern, graph = batch(4, 5), batch(16, 40)
+    d = {}
+    for tag, g in (("p", pattern), ("g", graph)):
+        n, e = g.number_of_nodes(), g.number_of_edges()
+        v_emb = th.randn(n, h, requires_grad=True)
+        e_emb = th.randn(e, h, requires_grad=True)
+        for p in hold.parameters():
+            p.grad = None
+        if tag == "p":
+            v_rep, e_rep = DMPNN.get_pattern_rep(hold, g, v_emb, e_emb)
+        else:
+            v_gate = (th.rand(n, 1) > 0.3).float()
+            e_gate = (th.rand(e, 1) > 0.3).float()
+            d["g_v_gate"], d["g_e_gate"] = v_gate, e_gate
+            v_rep, e_rep = DMPNN.get_graph_rep(hold, g, v_emb, e_emb, v_gate=v_gate, e_gate=e_gate)
+        wv, we = th.randn_like(v_rep), th.randn_like(e_rep)
+        ((v_rep * wv).sum() + (e_rep * we).sum()).backward()
+        d.update({tag + "_src": g._u, tag + "_dst": g._v, tag + "_rev": g.edata["is_reversed"],
+                  tag + "_num_nodes": n, tag + "_out_deg": g.ndata["out_deg"],
+                  tag + "_bnn": g.batch_num_nodes(), tag + "_bne": g.batch_num_edges(),
+                  tag + "_v_emb": v_emb, tag + "_e_emb": e_emb, tag + "_v_rep": v_rep, tag + "_e_rep": e_rep,
+                  tag + "_wv": wv, tag + "_we": we, tag + "_dv_emb": v_emb.grad, tag + "_de_emb": e_emb.grad})
+        for k, p in hold.g_rep_net.named_parameters():
+            d["%s_grad.%s" % (tag, k)] = p.grad.clone()
+    for k, p in hold.g_rep_net.named_parameters():
+        d["p." + k] = p
+    d["hid"], d["layers"] = h, L
+    np.savez_compressed(os.path.join(OUT, "dmpnn_rep.npz"), **t2n(d))
+    print("wrote dmpnn_rep.npz")
+
+
+def gen_compgcn():
+    import dgl
+    from models.compgcn import CompGCNLayer
+    rng = np.random.default_rng(4321)
+    graphs = named_graphs(rng)
+    cases = [("er8_12", 16, "sub", "none", True, True), ("er8_12", 16, "mult", "both", True, True),
+             ("er8_12", 16, "corr", "in", True, True), ("multi", 8, "mult", "out", True, False),
+             ("er64_256", 64, "sub", "both", True, True), ("er64_256", 64, "mult", "in", False, True),
+             ("star8", 8, "sub", "both", True, False)]
+    for name, h, comp, norm, use_rev, self_loop in cases:
+        u, v, n = graphs[name]
+        rev = None
+        if use_rev:
+            u, v, rev = with_rev(u, v)
+        th.manual_seed(seed_of(name, h, comp, norm))
+        layer = CompGCNLayer(h, h, self_loop=self_loop, comp_opt=comp, edge_norm=norm, bias=True,
+                             batch_norm=False, act_func="relu", dropout=0.0)
+        with th.no_grad():
+            layer.bias.uniform_(-0.1, 0.1)
+        g = dgl.DGLGraph.from_edges(u, v, n)
+        if rev is not None:
+            g.edata["is_reversed"] = th.from_numpy(rev)
+        x = th.randn(n, h, requires_grad=True)
+        z = th.randn(len(u), h, requires_grad=True)
+        node_out, edge_out = layer(g, x, z)
+        wn, we = th.randn_like(node_out), th.randn_like(edge_out)
+        ((node_out * wn).sum() + (edge_out * we).sum()).backward()
+        d = {"src": u, "dst": v, "num_nodes": n, "x": x, "z": z, "node_out": node_out, "edge_out": edge_out,
+             "wn": wn, "we": we, "dx": x.grad, "dz": z.grad, "comp_opt": comp, "edge_norm": norm,
+             "self_loop": self_loop}
+        if rev is not None:
+            d["rev"] = rev
+        if "norm" in g.edata:
+            d["norm"] = g.edata["norm"]
+        for k, p in layer.named_parameters():
+            d["p." + k] = p
+            d["g." + k] = p.grad
+        fn = "compgcn_%s_h%d_%s_%s_%s.npz" % (name, h, comp, norm, "rev" if use_rev else "norev")
+        np.savez_compressed(os.path.join(OUT, fn), **t2n(d))
+        print("wrote", fn)
+
+
+def gen_linegraph():
+    import dgl
+    from utils.graph import convert_to_dual_graph
+    rng = np.random.default_rng(99)
+    graphs = named_graphs(rng)
+    graphs["loop3"] = (np.array([0, 1, 1]), np.array([1, 0, 1]), 2)
+    graphs["empty"] = (np.zeros(0, np.int64), np.zeros(0, np.int64), 3)
+    u, v = er_edges(16, 60, rng)
+    graphs["er16_60"] = (u, v, 16)
+
+    def run(tag, u, v, n, ndata, edata):
+        g = dgl.DGLGraph.from_edges(u, v, n)
+        for k, val in ndata.items():
+            g.ndata[k] = th.as_tensor(val)
+        for k, val in edata.items():
+            g.edata[k] = th.as_tensor(val)
+        dg = convert_to_dual_graph(g)
+        d = {"src": u, "dst": v, "num_nodes": n, "dual_src": dg._u, "dual_dst": dg._v,
+             "dual_num_nodes": dg.number_of_nodes()}
+        for k, val in ndata.items():
+            d["ndata." + k] = np.asarray(val)
+        for k, val in edata.items():
+            d["edata." + k] = np.asarray(val)
+        for k, val in dg.ndata.items():
+            d["dual_ndata." + k] = val
+        for k, val in dg.edata.items():
+            d["dual_edata." + k] = val
+        np.savez_compressed(os.path.join(OUT, "linegraph_%s.npz" % tag), **t2n(d))
+        print("wrote linegraph_%s.npz" % tag, "dual nodes", dg.number_of_nodes(), "dual edges", dg.number_of_edges())
+
+    for name, (u, v, n) in graphs.items():
+        # plain branch: no id / label frames (graph.py:96-103,126-134)
+        run(name + "_plain", u, v, n, {}, {})
+        if len(u) == 0:
+            continue
+        # training-pipeline branch: ids = arange, labels, then add_reversed_edges' arrays
+        e = len(u)
+        nl = rng.integers(0, 4, size=n)
+        el = rng.integers(0, 3, size=e)
+        max_ne, max_nel = e + 3, 3  # holes between e and max_ne (train.py:306)
+        uu, vv, rev = with_rev(u, v)
+        run(name + "_idrev", uu, vv, n, {"id": np.arange(n), "label": nl},
+            {"id": np.concatenate([np.arange(e), max_ne + np.arange(e)]),
+             "label": np.concatenate([el, el + max_nel]), "is_reversed": rev})
+        # duplicate edge ids (merge rule graph.py:80-95) + dedupe of (uid, label, vid) keys (:110-125)
+        dup = rng.integers(0, max(1, e // 2), size=e)
+        run(name + "_dupid", u, v, n, {"id": np.arange(n), "label": nl}, {"id": dup, "label": el[dup % e]})
+
+
+def gen_addrev():
+    """add_reversed_edges on the reference's dataset.Graph class (train.py:299-327 drives
+    dataset.Graph.add_edges, dataset.py:1261-1293, which also updates cached degrees)."""
+    import dgl
+    import dataset as ref_dataset  # reference module
+    rng = np.random.default_rng(11)
+    graphs = named_graphs(rng)
+    for name in ("cycle3", "er8_12", "multi"):
+        u, v, n = graphs[name]
+        e = len(u)
+        g = ref_dataset.Graph()
+        g.add_nodes(n)
+        dgl.DGLGraph.add_edges(g, u, v)
+        g.ndata["id"] = th.arange(n)
+        g.ndata["label"] = th.from_numpy(rng.integers(0, 4, size=n))
+        g.edata["id"] = th.arange(e)
+        g.edata["label"] = th.from_numpy(rng.integers(0, 3, size=e))
+        g.ndata["in_deg"] = dgl.DGLGraph.in_degrees(g)
+        g.ndata["out_deg"] = dgl.DGLGraph.out_degrees(g)
+        max_nge, max_ngel = e + 2, 5
+        d = {"src": u, "dst": v, "num_nodes": n, "eid": g.edata["id"].clone(), "elabel": g.edata["label"].clone(),
+             "max_ne": max_nge, "max_nel": max_ngel}
+        # body of train.py:303-316 (GraphAdj branch) on this one graph
+        num_ge = g.number_of_edges()
+        uu, vv = g.all_edges(form="uv", order="eid")
+        eid = th.arange(max_nge, max_nge + num_ge)
+        g.add_edges(vv, uu, data={"id": eid, "label": g.edata["label"] + max_ngel,
+                                  "is_reversed": th.ones((num_ge,), dtype=th.bool)})
+        d.update({"o_src": g._u, "o_dst": g._v, "o_eid": g.edata["id"], "o_elabel": g.edata["label"],
+                  "o_rev": g.edata["is_reversed"], "o_in_deg": g.ndata["in_deg"], "o_out_deg": g.ndata["out_deg"]})
+        np.savez_compressed(os.path.join(OUT, "addrev_%s.npz" % name), **t2n(d))
+        print("wrote addrev_%s.npz" % name)
+
+
+UNC_SCRIPT = r'''
+import os, sys
+import numpy as np, torch as th
+sys.path.insert(0, %(here)r)
+import ref_standin
+ref_standin.install()
+sys.path.insert(0, ref_standin.REF_UNC)
+import dgl
+from model import DualGraphConv
+sys.path.insert(0, %(here)r)
+from make_golden import er_edges, t2n
+rng = np.random.default_rng(2024)
+for tag, n, m, h, act, bn_train in (("small", 12, 30, 8, None, False), ("tanh", 40, 160, 32, "tanh", False),
+                                    ("bntrain", 40, 160, 32, None, True)):
+    u, v = er_edges(n, m, rng)
+    u, v = np.concatenate([u, v]), np.concatenate([v, u])   # utils.py:486-487: forward + reversed copies
+    th.manual_seed(len(tag) * 101 + n)
+    layer = DualGraphConv(h, h, activation=(th.nn.Tanh() if act == "tanh" else None), dropout=0.0)
+    with th.no_grad():
+        layer.nbias.uniform_(-0.1, 0.1); layer.ebias.uniform_(-0.1, 0.1)
+        for seq in (layer.nmlp, layer.emlp):
+            seq[1].running_mean.uniform_(-0.2, 0.2); seq[1].running_var.uniform_(0.5, 1.5)
+            seq[1].weight.uniform_(0.5, 1.5); seq[1].bias.uniform_(-0.1, 0.1)
+    layer.train(bn_train)
+    g = dgl.DGLGraph.from_edges(u, v, n)
+    in_deg = g.in_degrees().float()
+    norm = in_deg[g._v].reciprocal().unsqueeze(-1)            # utils.py:446 (norm="in")
+    x = th.randn(n, h, requires_grad=True); z = th.randn(len(u), h, requires_grad=True)
+    bn_before = {k: b.clone() for k, b in layer.named_buffers()}
+    node_out, edge_out = layer(g, x, z, norm)
+    wn, we = th.randn_like(node_out), th.randn_like(edge_out)
+    ((node_out * wn).sum() + (edge_out * we).sum()).backward()
+    d = {"src": u, "dst": v, "num_nodes": n, "x": x, "z": z, "norm": norm, "node_out": node_out,
+         "edge_out": edge_out, "wn": wn, "we": we, "dx": x.grad, "dz": z.grad, "out_deg": g.ndata["out_deg"],
+         "activation": act or "", "bn_train": bn_train}
+    for k, p in layer.named_parameters():
+        d["p." + k] = p
+        if p.grad is not None:
+            d["g." + k] = p.grad
+    for k, b in bn_before.items():
+        d["b." + k] = b
+    for k, b in layer.named_buffers():
+        d["b_after." + k] = b
+    np.savez_compressed(os.path.join(%(out)r, "unc_dualconv_%%s.npz" %% tag), **t2n(d))
+    print("wrote unc_dualconv_%%s.npz" %% tag)
+'''
+
+
+def gen_unc():
+    # the UNC package's top-level module is also called ``utils`` -> separate interpreter
+    code = UNC_SCRIPT % {"here": HERE, "out": OUT}
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    import ref_standin
+    ref_standin.import_scm()
+    gen_dmplayer()
+    gen_dmpnn_rep()
+    gen_compgcn()
+    gen_linegraph()
+    gen_addrev()
+    gen_unc()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""GPU parity of the individual HIP kernels through the C ABI (ctypes), against numpy /
+the CPU oracle: integer results bit-exact, fp32 sums exact where the order is pinned
+(plain seg-sum in ascending eid = index_add_ order) and 1e-6-relative otherwise; plus
+size-independent properties at BASELINE config-2 size."""
+import numpy as np
+import pytest
+import torch as th
+
+import dmp_oracle as O
+from util_graphs import er_batch, skewed_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return th.from_numpy(np.asarray(a))
+
+
+def _index(src, dst, n, rev, dev):
+    from dualmessagepassing_amd.graph import GraphIndex
+    return GraphIndex(_t(src).to(dev), _t(dst).to(dev), n, None if rev is None else _t(rev).to(dev), validate=True)
+
+
+def _csr_ref(key, flag, n):
+    order = np.argsort(key, kind="stable")
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(key, minlength=n), out=ptr[1:])
+    ent = (order.astype(np.int64) << 1) | (flag[order].astype(np.int64) if flag is not None else 0)
+    return ptr.astype(np.int32), ent.astype(np.int32)
+
+
+GRAPHS = {
+    "er_batch": lambda rng: er_batch(6, 11, 20, rng)[:4],
+    "skewed": lambda rng: skewed_graph(300, 5000, rng) + (rng.random(5000) < 0.5, 300),
+    "isolated": lambda rng: (np.array([0, 0, 5]), np.array([5, 5, 0]), np.array([False, True, False]), 9),
+    "empty": lambda rng: (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, bool), 4),
+    "hub": lambda rng: (rng.integers(0, 50, 4000).astype(np.int64), np.zeros(4000, np.int64),
+                        rng.random(4000) < 0.3, 50),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRAPHS))
+def test_csr_and_incidence_build_bit_exact(name, gpu):
+    rng = np.random.default_rng(5)
+    src, dst, rev, n = GRAPHS[name](rng)
+    src, dst = np.asarray(src, np.int64), np.asarray(dst, np.int64)
+    ix = _index(src, dst, n, rev, gpu)
+    ip, ie = _csr_ref(dst, rev, n)
+    op, oe = _csr_ref(src, rev, n)
+    assert np.array_equal(ix.in_ptr.cpu().numpy(), ip) and np.array_equal(ix.in_ent.cpu().numpy(), ie)
+    assert np.array_equal(ix.out_ptr.cpu().numpy(), op) and np.array_equal(ix.out_ent.cpu().numpy(), oe)
+    assert np.array_equal(ix.in_deg.cpu().numpy(), np.bincount(dst, minlength=n))
+    assert np.array_equal(ix.out_deg.cpu().numpy(), np.bincount(src, minlength=n))
+    assert np.array_equal(ix.src32.cpu().numpy(), src.astype(np.int32))
+    assert np.array_equal(ix.dst32.cpu().numpy(), dst.astype(np.int32))
+    inc_ptr, inc_ent = ix.incidence()
+    ref_ptr = ip.astype(np.int64) + op
+    ref_ent = np.concatenate([np.concatenate([ie[ip[w]:ip[w + 1]], oe[op[w]:op[w + 1]] ^ 1]) for w in range(n)]) \
+        if n else np.zeros(0)
+    assert np.array_equal(inc_ptr.cpu().numpy(), ref_ptr.astype(np.int32))
+    assert np.array_equal(inc_ent.cpu().numpy(), ref_ent.astype(np.int32))
+
+
+def test_csr_build_flags_out_of_range_endpoint(gpu):
+    from dualmessagepassing_amd import _lib
+    from dualmessagepassing_amd.graph import GraphIndex
+    with pytest.raises(_lib.DmpError):
+        GraphIndex(th.tensor([0, 7], device=gpu), th.tensor([1, 0], device=gpu), 3, None, validate=True)
+
+
+@pytest.mark.parametrize("h", [1, 3, 4, 20, 64, 128, 256, 260, 512])
+@pytest.mark.parametrize("name", ["er_batch", "skewed", "isolated", "hub"])
+def test_seg_sum_and_gathers(name, h, gpu):
+    from dualmessagepassing_amd import ops
+    rng = np.random.default_rng(h)
+    src, dst, rev, n = GRAPHS[name](rng)
+    e = len(src)
+    ix = _index(src, dst, n, rev, gpu)
+    gen = th.Generator().manual_seed(h)
+    m = th.randn(e, h, generator=gen)
+    w = th.rand(e, generator=gen) + 0.5
+    td, ts, tr = _t(dst), _t(src), _t(rev)
+    mg = m.to(gpu)
+    # plain: same order as index_add_ -> bit-exact
+    got = ops.seg_sum_raw(mg, ix.in_ptr, ix.in_ent, n)
+    assert th.equal(got.cpu(), O.seg_sum(m, td, n))
+    # strided input (column slice of a wider matrix, the fused-GEMM-output case)
+    wide = th.randn(e, 2 * h + 4, generator=gen).to(gpu)
+    got = ops.seg_sum_raw(wide[:, 4:4 + h], ix.in_ptr, ix.in_ent, n)
+    assert th.equal(got.cpu(), O.seg_sum(wide[:, 4:4 + h].cpu(), td, n))
+    # weighted
+    got = ops.seg_sum_raw(mg, ix.in_ptr, ix.in_ent, n, w.to(gpu))
+    ref = O.seg_sum(m * w[:, None], td, n)
+    assert th.allclose(got.cpu(), ref, rtol=1e-6, atol=1e-6)
+    # split by flag with signs
+    got = ops.seg_sum_raw(mg, ix.in_ptr, ix.in_ent, n, None, True, -1.0, 1.0)
+    ref = th.cat([-O.seg_sum(m * (~tr)[:, None], td, n), O.seg_sum(m * tr[:, None], td, n)], 1)
+    assert th.equal(got.cpu(), ref)
+    # by source
+    got = ops.seg_sum_raw(mg, ix.out_ptr, ix.out_ent, n)
+    assert th.equal(got.cpu(), O.seg_sum(m, ts, n))
+    # gathers
+    x = th.randn(n, h, generator=gen)
+    assert th.equal(ops.gather_rows_raw(x.to(gpu), ix.src32).cpu(), x[ts])
+    assert th.equal(ops.gather_rows_raw(x.to(gpu), ix.dst32, w.to(gpu)).cpu(), x[td] * w[:, None])
+    d2 = th.randn(n, 2 * h, generator=gen)
+    got = ops.gather_select_raw(d2.to(gpu), ix.dst32, ix.rev8, h, None, -1.0, 1.0)
+    ref = th.where(tr[:, None], d2[td][:, h:], -d2[td][:, :h])
+    assert th.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("h", [3, 8, 64, 128, 256])
+def test_edge_combine_fwd_bwd(h, gpu):
+    from dualmessagepassing_amd import ops
+    rng = np.random.default_rng(h + 1)
+    src, dst, rev, n = GRAPHS["er_batch"](rng)
+    e = len(src)
+    ix = _index(src, dst, n, rev, gpu)
+    gen = th.Generator().manual_seed(h)
+    G = th.randn(e, 2 * h, generator=gen, dtype=th.float64)
+    P = th.randn(n, 2 * h, generator=gen, dtype=th.float64)
+    b = th.randn(h, generator=gen, dtype=th.float64)
+    wy = th.randn(e, h, generator=gen, dtype=th.float64)
+    ts, td, tr = _t(src), _t(dst), _t(rev)
+    out_deg = O.out_degrees(ts, n)
+    coef64 = 2 * (1 + (1 + out_deg.double()).log2())
+    Go, Po, bo = G.clone().requires_grad_(True), P.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    a = th.where(tr, ts, td)
+    c = th.where(tr, td, ts)
+    Y = Go[:, :h] + coef64[td][:, None] * Go[:, h:] + (Po[a][:, :h] - Po[c][:, h:]) + bo
+    (Y * wy).sum().backward()
+    Gg, Pg, bg = (t.float().to(gpu).requires_grad_(True) for t in (G, P, b))
+    coef = ix.degree_coef(ix.out_deg)
+    assert th.allclose(coef.cpu().double(), coef64, rtol=3e-7, atol=0)
+    Yg = ops.edge_combine(Gg, Pg, bg, coef, ix)
+    assert th.allclose(Yg.cpu().double(), Y.detach(), rtol=2e-6, atol=2e-6)
+    (Yg * wy.float().to(gpu)).sum().backward()
+    assert th.allclose(Gg.grad.cpu().double(), Go.grad, rtol=2e-6, atol=2e-6)
+    assert th.allclose(Pg.grad.cpu().double(), Po.grad, rtol=2e-5, atol=2e-5)
+    assert th.allclose(bg.grad.cpu().double(), bo.grad, rtol=2e-5, atol=2e-4)
+
+
+# ----------------------------------------------------------------------------- full size (config 2)
+def test_config2_size_properties(gpu):
+    """B=1024 x target(64, 256->512 edges), H=128: size-independent checks."""
+    from dualmessagepassing_amd import ops
+    rng = np.random.default_rng(2000)
+    src, dst, rev, n, _, _ = er_batch(1024, 64, 256, rng)
+    e, h = len(src), 128
+    ix = _index(src, dst, n, rev, gpu)
+    # (1) sum of all-ones rows = in-degree, split by flag; exact in fp32 (small integers)
+    ones = th.ones(e, h, device=gpu)
+    s = ops.seg_sum_raw(ones, ix.in_ptr, ix.in_ent, n, None, True, 1.0, 1.0)
+    tr, td = _t(rev).to(gpu), _t(dst).to(gpu)
+    deg0 = th.bincount(td[~tr], minlength=n).float()
+    deg1 = th.bincount(td[tr], minlength=n).float()
+    assert th.equal(s[:, :h], deg0[:, None].expand(n, h)) and th.equal(s[:, h:], deg1[:, None].expand(n, h))
+    # (2) run-to-run bitwise determinism and column-sum conservation
+    gen = th.Generator(device="cpu").manual_seed(0)
+    m = th.randn(e, h, generator=gen).to(gpu)
+    a1 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
+    a2 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
+    assert th.equal(a1, a2)
+    assert th.allclose(a1.double().sum(0), m.double().sum(0), rtol=1e-9, atol=1e-6)
+    # (3) equals torch's own index_add on device within fp32 reassociation
+    ref = th.zeros(n, h, device=gpu).index_add_(0, td, m)
+    assert th.allclose(a1, ref, rtol=1e-5, atol=1e-5)
+    # (4) linearity: seg_sum(2m + k) = 2 seg_sum(m) + k * indeg
+    a3 = ops.seg_sum_raw(2 * m + 3.0, ix.in_ptr, ix.in_ent, n)
+    assert th.allclose(a3, 2 * a1 + 3.0 * (deg0 + deg1)[:, None], rtol=1e-5, atol=1e-4)
+    # (5) gather is the transpose of seg-sum:  <seg_sum(m), y> = <m, gather(y)>
+    y = th.randn(n, h, generator=gen).to(gpu)
+    lhs = (a1.double() * y.double()).sum()
+    rhs = (m.double() * ops.gather_rows_raw(y, ix.dst32).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-7 * abs(float(lhs)) + 1e-3
