@@ -145,7 +145,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     bounded sample of the same workload: fwd+bwd of the 3-layer pattern + graph rep-nets."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dmp_oracle as O
-    cores = os.cpu_count() or 1
+    # the oracle's ops are small; past ~32 threads torch's intra-op pool only adds contention
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     B, H, L = 32, cfg["hid"], cfg["layers"]
     rng = np.random.default_rng(7)

@@ -1,0 +1,195 @@
+"""CompGCNLayer on the MI355X kernels -- drop-in for
+``SubgraphCountingMatching/models/compgcn.py:102-287`` (same constructor arguments,
+parameter names/shapes, ``forward(graph, node_feat, edge_feat) -> (node_out, edge_out)``).
+
+    msg[e]   = comp(X[src e], Z[e]) (r_e ? W_out : W_in) * norm[e]          (compgcn.py:226-238)
+    node_out = drop(act(BN?((sum_{e->v} msg[e] + comp(X, loop_rel) W_loop) * 0.3333333 + b)))
+    edge_out = Z W_rel                                                       (compgcn.py:260-263)
+
+The composition and the per-edge norm are fused into the segment sum (one HIP kernel,
+``dmp_compgcn_agg``), and the W_in / W_out products are applied to the N summed rows instead
+of the E message rows.  ``comp_opt="corr"`` (circular correlation by FFT, compgcn.py:218-222)
+runs the FFTs in torch and the flag-split segment sum on the result.
+"""
+import torch as th
+import torch.nn as nn
+
+from . import ops
+from .act import init_weight, map_activation_str_to_layer
+from .constants import (EDGEFEAT, INDEGREE, INNORM, NODEAGG, NODEFEAT, NORM, OUTDEGREE, OUTNORM, REVFLAG)
+from .dmpnn import DMPNNRepMixin
+from .graph import BatchedGraph
+
+
+class CompGCNLayer(nn.Module):
+    def __init__(
+        self,
+        input_dim,
+        hidden_dim,
+        self_loop=True,
+        comp_opt="mult",
+        edge_norm="both",
+        bias=True,
+        batch_norm=True,
+        act_func="relu",
+        dropout=0.0
+    ):
+        super(CompGCNLayer, self).__init__()
+        assert edge_norm in ["none", "in", "out", "both"]
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.edge_norm = edge_norm
+        self.num_rels = 3 if self_loop else 2
+        self.comp_opt = comp_opt
+
+        # compgcn.py:127-149 (registration order kept: it is the state_dict order)
+        if self_loop:
+            self.loop_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        else:
+            self.register_parameter("loop_weight", None)
+        if bias:
+            self.bias = nn.Parameter(th.empty(hidden_dim))
+        else:
+            self.register_parameter("bias", None)
+        self.bn = nn.BatchNorm1d(hidden_dim) if batch_norm else None
+        self.in_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.out_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        self.rel_weight = nn.Parameter(th.empty(input_dim, hidden_dim))
+        if self_loop:
+            self.loop_rel = nn.Parameter(th.empty(1, input_dim))
+        else:
+            self.register_parameter("loop_rel", None)
+        self.act = map_activation_str_to_layer(act_func)
+        self.drop = nn.Dropout(dropout)
+
+        # compgcn.py:152-160
+        init_weight(self.in_weight, activation=act_func, init="uniform")
+        init_weight(self.out_weight, activation=act_func, init="uniform")
+        init_weight(self.rel_weight, activation=act_func, init="uniform")
+        if self_loop:
+            init_weight(self.loop_weight, activation=act_func, init="uniform")
+            init_weight(self.loop_rel, activation=act_func, init="uniform")
+        if bias:
+            nn.init.zeros_(self.bias)
+
+    @property
+    def self_loop(self):
+        return hasattr(self, "loop_weight") and self.loop_weight is not None
+
+    def _comp_func(self, head, relation):
+        # compgcn.py:213-224
+        if self.comp_opt == "sub":
+            return head - relation
+        elif self.comp_opt == "mult":
+            return head * relation
+        elif self.comp_opt == "corr":
+            return th.fft.irfft(th.conj(th.fft.rfft(head, dim=-1)) * th.fft.rfft(relation, dim=-1),
+                                n=head.size(-1), dim=-1)
+        raise NotImplementedError
+
+    def _norms(self, g):
+        """compgcn.py:177-209: node norms from (cached) degrees, then the per-edge norm."""
+        if self.edge_norm in ("in", "both") and INNORM not in g.ndata:
+            in_deg = g.in_degrees()
+            if self.self_loop:
+                g.ndata[INNORM] = (in_deg + 1).reciprocal().unsqueeze(-1)
+            else:
+                g.ndata[INNORM] = in_deg.reciprocal().masked_fill_(in_deg == 0, 1.0).unsqueeze(-1)
+        if self.edge_norm in ("out", "both") and OUTNORM not in g.ndata:
+            out_deg = g.out_degrees()
+            if self.self_loop:
+                g.ndata[OUTNORM] = (out_deg + 1).reciprocal().unsqueeze(-1)
+            else:
+                g.ndata[OUTNORM] = out_deg.reciprocal().masked_fill_(out_deg == 0, 1.0).unsqueeze(-1)
+        if self.edge_norm == "none":
+            return None
+        u, v = g.all_edges(form="uv", order="eid")
+        if self.edge_norm == "in":
+            g.edata[NORM] = g.ndata[INNORM][v]
+        elif self.edge_norm == "out":
+            g.edata[NORM] = g.ndata[OUTNORM][u]
+        else:
+            g.edata[NORM] = (g.ndata[OUTNORM][u] * g.ndata[INNORM][v]) ** 0.5
+        return g.edata[NORM].reshape(-1)
+
+    def forward(self, graph, node_feat, edge_feat):
+        if not isinstance(graph, BatchedGraph):
+            raise TypeError("CompGCNLayer expects a dualmessagepassing_amd BatchedGraph")
+        g = graph
+        if node_feat is not None:
+            g.ndata[NODEFEAT] = node_feat
+        if edge_feat is not None:
+            g.edata[EDGEFEAT] = edge_feat
+        x, z = g.ndata[NODEFEAT], g.edata[EDGEFEAT]
+        norm = self._norms(g)
+        ix = g.index()
+        has_rev = REVFLAG in g.edata
+        h = self.input_dim
+
+        # _node_message_func + fn.sum (compgcn.py:226-238,271)
+        if self.comp_opt in ("sub", "mult"):
+            s = ops.compgcn_agg(x, z, norm, ix, ops.COMP_SUB if self.comp_opt == "sub" else ops.COMP_MULT)
+        else:
+            comp = self._comp_func(ops.gather_src(x, ix), z)
+            s = ops.seg_sum2(comp, ix, norm, 1.0, 1.0)
+        if has_rev:
+            agg = ops.matmul_xw(s, th.cat([self.in_weight, self.out_weight], dim=0))
+        else:
+            agg = ops.matmul_xw(s[:, :h], self.in_weight)
+        g.ndata[NODEAGG] = agg
+
+        # _node_update_func (compgcn.py:240-258)
+        if self.self_loop:
+            loop_msg = th.matmul(self._comp_func(x, self.loop_rel), self.loop_weight)
+            out = (agg + loop_msg) * 0.3333333
+        else:
+            out = agg * 0.5
+        if self.bias is not None:
+            out = out + self.bias
+        if self.bn is not None:
+            out = self.bn(out)
+        node_out = self.drop(self.act(out))
+
+        # _edge_update_func (compgcn.py:260-263)
+        edge_out = ops.matmul_xw(z, self.rel_weight)
+        return node_out, edge_out
+
+    def extra_repr(self):
+        return "\n".join([
+            "in=%s, out=%s," % (self.input_dim, self.hidden_dim),
+            "comp_opt=%s," % (self.comp_opt),
+            "edge_norm=%s, self_loop=%s, bias=%s," % (self.edge_norm, self.self_loop, self.bias is not None),
+        ])
+
+    def get_output_dim(self):
+        return self.hidden_dim
+
+
+class CompGCNRepMixin(DMPNNRepMixin):
+    """``create_rep_net`` of the reference's ``CompGCN`` model (compgcn.py:289-321); its
+    ``get_pattern_rep`` / ``get_graph_rep`` (compgcn.py:323-385) are the DMPNN loops over
+    ``rep_net["compgcn"]``."""
+
+    rep_key = "compgcn"
+
+    def create_rep_net(self, type, **kw):
+        if type == "graph":
+            num_layers = kw.get("rep_num_graph_layers", 1)
+        elif type == "pattern":
+            if self.share_rep_net:
+                return self.g_rep_net
+            num_layers = kw.get("rep_num_pattern_layers", 1)
+        else:
+            raise ValueError(type)
+        compgcn = nn.ModuleList()
+        for i in range(num_layers):
+            compgcn.add_module(
+                "%s_compgcn_(%d)" % (type, i),
+                CompGCNLayer(
+                    self.hid_dim, self.hid_dim,
+                    comp_opt=kw.get("rep_compgcn_comp_opt", "mult"),
+                    edge_norm=kw.get("rep_compgcn_edge_norm", "none"),
+                    batch_norm=kw.get("rep_compgcn_batch_norm", False),
+                    act_func=kw.get("rep_act_func", "relu"),
+                    dropout=kw.get("rep_dropout", 0.0)))
+        return nn.ModuleDict({"compgcn": compgcn})

@@ -30,6 +30,36 @@ from .constants import (EDGEFEAT, NODEAGG, NODEFEAT, OUTDEGREE, REVFLAG)
 from .graph import BatchedGraph
 
 
+def dual_message_passing(graph, x, z, in_weight, out_weight, src_weight, dst_weight, nloop_weight, eloop_weight,
+                         nbias, ebias, has_rev, edge_norm=None):
+    """The linear part of one dual-message-passing layer (dmpnn.py:111-151; UNC model.py:222-257):
+    returns ``(node_pre [N,H], edge_pre [E,H], node_agg [N,H])`` with
+
+        node_pre = X W_nloop + sum_{e->v} n_e (r_e ? Z_e W_out : -Z_e W_in) + b_n
+        edge_pre = Z W_eloop + 2(1+log2(1+outdeg[dst])) Z (W_src - W_dst) + edge_msg + b_e
+        edge_msg = r_e ? X[src] W_dst - X[dst] W_src : X[dst] W_dst - X[src] W_src
+
+    ``edge_norm`` [E] or [E,1]: per-edge scale n_e of the node messages (UNC only).
+    Two HIP kernels (seg_sum2 / edge_combine) + four GEMMs."""
+    ix = graph.index()
+    coef = ix.degree_coef(graph.ndata[OUTDEGREE])
+    ew = None if edge_norm is None else edge_norm.reshape(-1)
+    h = nloop_weight.size(1)
+    if has_rev:
+        s = ops.seg_sum2(z, ix, ew, -1.0, 1.0)                       # [-S_fwd | S_rev]
+        agg = ops.matmul_xw(s, th.cat([in_weight, out_weight], dim=0))
+    else:
+        agg = ops.matmul_xw(ops.seg_sum(z, ix, ew), -in_weight)
+    # one N-row GEMM for the three node-side projections: [X W_nloop | X W_dst | X W_src]
+    xp = ops.matmul_xw(x, th.cat([nloop_weight, dst_weight, src_weight], dim=1))
+    node_pre = xp[:, :h] + agg
+    if nbias is not None:
+        node_pre = node_pre + nbias
+    gm = ops.matmul_xw(z, th.cat([eloop_weight, src_weight - dst_weight], dim=1))
+    edge_pre = ops.edge_combine(gm, xp[:, h:], ebias, coef, ix)
+    return node_pre, edge_pre, agg
+
+
 class DMPLayer(nn.Module):
     def __init__(
         self,
@@ -111,27 +141,14 @@ class DMPLayer(nn.Module):
         if edge_feat is not None:
             g.edata[EDGEFEAT] = edge_feat
         x, z = g.ndata[NODEFEAT], g.edata[EDGEFEAT]
-        ix = g.index()
-        coef = ix.degree_coef(g.ndata[OUTDEGREE])
-
-        # ---- node side: _node_message_func's node_msg + fn.sum + _node_update_func
-        if REVFLAG in g.edata:
-            s = ops.seg_sum2(z, ix, None, -1.0, 1.0)                       # [-S_fwd | S_rev]
-            agg = s @ th.cat([self.in_weight, self.out_weight], dim=0)
-        else:
-            agg = ops.seg_sum(z, ix) @ (-self.in_weight)
+        node_pre, edge_pre, agg = dual_message_passing(
+            g, x, z, self.in_weight, self.out_weight, self.src_weight, self.dst_weight, self.nloop_weight,
+            self.eloop_weight, self.nbias, self.ebias, has_rev=REVFLAG in g.edata)
         g.ndata[NODEAGG] = agg
-        out = x @ self.nloop_weight + agg
-        if self.nbias is not None:
-            out = out + self.nbias
-        out = self.nmlp(out) if len(self.nmlp) > 0 else self.act(out)
+        # _node_update_func / _edge_update_func tails (dmpnn.py:135-140,151-156)
+        out = ops.apply_mlp(self.nmlp, node_pre) if len(self.nmlp) > 0 else self.act(node_pre)
         node_out = self.drop(out)
-
-        # ---- edge side: edge_msg of _node_message_func + _edge_update_func
-        p = x @ th.cat([self.dst_weight, self.src_weight], dim=1)
-        gm = z @ th.cat([self.eloop_weight, self.src_weight - self.dst_weight], dim=1)
-        out = ops.edge_combine(gm, p, self.ebias, coef, ix)
-        out = self.emlp(out) if len(self.emlp) > 0 else self.act(out)
+        out = ops.apply_mlp(self.emlp, edge_pre) if len(self.emlp) > 0 else self.act(edge_pre)
         edge_out = self.drop(out)
 
         return node_out, edge_out
@@ -148,6 +165,8 @@ class DMPNNRepMixin:
     ``DMPNN`` (dmpnn.py:183-277); mixed into the model skeleton (``basemodel``) and into
     the stand-alone ``DMPNNRep`` below.  Expects ``hid_dim``, ``share_rep_net``,
     ``rep_residual``, ``g_rep_net`` / ``p_rep_net`` attributes."""
+
+    rep_key = "dmpnn"
 
     def create_rep_net(self, type, **kw):
         if type == "graph":
@@ -190,7 +209,7 @@ class DMPNNRepMixin:
             p_e_zero_mask = None
             e_outputs = [p_e_emb]
 
-        for layer in self.p_rep_net["dmpnn"]:
+        for layer in self.p_rep_net[self.rep_key]:
             v, e = layer(pattern, v_outputs[-1], e_outputs[-1])
             if p_v_zero_mask is not None:
                 v = v.masked_fill(p_v_zero_mask, 0.0)
@@ -223,7 +242,7 @@ class DMPNNRepMixin:
         else:
             e_outputs = [g_e_emb]
 
-        for layer in self.g_rep_net["dmpnn"]:
+        for layer in self.g_rep_net[self.rep_key]:
             v, e = layer(graph, v_outputs[-1], e_outputs[-1])
             if v_gate is not None:
                 v = v * v_gate

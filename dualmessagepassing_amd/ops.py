@@ -264,3 +264,98 @@ COMP_SUB, COMP_MULT = 0, 1
 
 def compgcn_agg(X, Z, norm, index, comp):
     return _CompGCNAgg.apply(X, Z, norm, index, int(comp))
+
+
+# ----------------------------------------------------------------------------- dense projections
+# The [rows,H] x [H,H'] products stay on the MFMA units through torch (hipBLASLt).  What is
+# ours here is the *shape* of the weight-gradient product: dW = A^T B has K = rows (5e5 edge
+# rows) and a 128 x 256 output, which a single GEMM call runs on ~32 workgroups (16-26 TF/s
+# measured); cutting K into 4096-row slices as one batched GEMM plus a tiny reduction fills
+# the chip (115-126 TF/s measured on MI355X, scripts/mb_gemm.py).
+_SPLITK_ROWS = 4096
+
+
+def atb_splitk(a, b):
+    """``a.T @ b`` for tall-skinny a [R,K], b [R,N]."""
+    R = a.size(0)
+    if R < 4 * _SPLITK_ROWS:
+        return a.t() @ b
+    a, b = a.contiguous(), b.contiguous()
+    S = R // _SPLITK_ROWS
+    main = S * _SPLITK_ROWS
+    out = torch.bmm(a[:main].view(S, _SPLITK_ROWS, a.size(1)).transpose(1, 2),
+                    b[:main].view(S, _SPLITK_ROWS, b.size(1))).sum(0)
+    if main < R:
+        out = out + a[main:].t() @ b[main:]
+    return out
+
+
+class _MatmulXW(torch.autograd.Function):
+    """``x @ W`` with W in the reference's [in, out] layout (dmpnn.py:33-38)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return x @ W
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx = dy @ W.t() if ctx.needs_input_grad[0] else None
+        dW = atb_splitk(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dW
+
+
+class _LinearNN(torch.autograd.Function):
+    """``F.linear(x, weight, bias)`` (nn.Linear layout [out, in]) with an optional fused ReLU
+    epilogue (hipBLASLt) and the split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if relu and bias is not None:
+            y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        else:
+            y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+            if relu:
+                y = torch.relu_(y)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = atb_splitk(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def matmul_xw(x, W):
+    return _MatmulXW.apply(x, W)
+
+
+def linear_nn(x, weight, bias=None, relu=False):
+    return _LinearNN.apply(x, weight, bias, bool(relu))
+
+
+def apply_mlp(seq, x):
+    """Run an ``nn.Sequential`` of Linear / BatchNorm / activation modules (nmlp / emlp,
+    dmpnn.py:45-60) with the Linear layers on ``linear_nn`` and Linear+ReLU pairs fused."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            fuse = i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.ReLU and m.bias is not None
+            x = linear_nn(x, m.weight, m.bias, relu=fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

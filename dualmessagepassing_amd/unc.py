@@ -1,0 +1,143 @@
+"""UnsupervisedNodeClassification twin of the DMPLayer on the MI355X kernels.
+
+Drop-in for ``DualGraphConv`` (UnsupervisedNodeClassification/Model/DMPNN/src/model.py:117-281)
+plus the two graph helpers that define its inputs, ``compute_edgenorm`` and
+``build_graph_from_triplets`` (.../src/utils.py:437-453,473-491).
+
+Differences from the SCM layer, all preserved:
+  * node messages are scaled by ``edata["norm"]`` when an ``edge_norm`` is passed (model.py:234-235);
+  * frame keys are "h" / "out_deg" / "norm" / "is_rev" (model.py:207-221,228,234);
+  * MLP = Linear -> BN -> act -> Linear with act = LeakyReLU(1/5.5) unless an ``activation`` module
+    is given, which is then ALSO applied to the outputs (model.py:145-165,247-248,262-263);
+  * dropout is called but its result discarded (model.py:245,260) -> no effect;
+  * ``nfc`` / ``efc`` exist but are never used (model.py:137-138) -> their grads stay None.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .constants import OUTDEGREE, REVFLAG
+from .dmpnn import dual_message_passing
+from .graph import BatchedGraph
+
+
+class DualGraphConv(nn.Module):
+    def __init__(
+            self,
+            input_dim,
+            hidden_dim,
+            init_neigenv=4.0,
+            init_eeigenv=4.0,
+            bias=True,
+            batch_norm=True,
+            activation=None,
+            dropout=0.0
+    ):
+        super(DualGraphConv, self).__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.in_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.out_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.src_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.dst_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.nloop_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.eloop_weight = nn.Parameter(torch.empty(input_dim, hidden_dim))
+        self.nfc = nn.Linear(hidden_dim, hidden_dim)
+        self.efc = nn.Linear(hidden_dim, hidden_dim)
+        if bias:
+            self.nbias = nn.Parameter(torch.zeros((hidden_dim)))
+            self.ebias = nn.Parameter(torch.zeros((hidden_dim)))
+        else:
+            self.register_parameter("nbias", None)
+            self.register_parameter("ebias", None)
+
+        def mlp():
+            inner = nn.LeakyReLU(1 / 5.5) if activation is None else activation
+            mods = [nn.Linear(hidden_dim, hidden_dim)]
+            if batch_norm:
+                mods.append(nn.BatchNorm1d(hidden_dim))
+            mods += [inner, nn.Linear(hidden_dim, hidden_dim)]
+            return nn.Sequential(*mods)
+
+        self.nmlp = mlp()
+        self.emlp = mlp()
+        self.act = activation
+        self.drop = nn.Dropout(dropout)
+
+        # model.py:168-181
+        for w in (self.in_weight, self.out_weight, self.src_weight, self.dst_weight, self.nloop_weight,
+                  self.eloop_weight, self.nmlp[0].weight, self.nmlp[-1].weight, self.emlp[0].weight,
+                  self.emlp[-1].weight):
+            nn.init.xavier_uniform_(w)
+        for b in (self.nmlp[0].bias, self.nmlp[-1].bias, self.emlp[0].bias, self.emlp[-1].bias):
+            nn.init.zeros_(b)
+        # model.py:185-191
+        with torch.no_grad():
+            self.in_weight.data.div_(init_neigenv)
+            self.out_weight.data.div_(init_neigenv)
+            self.nloop_weight.data.div_(init_neigenv)
+            self.src_weight.data.div_(init_eeigenv)
+            self.dst_weight.data.div_(init_eeigenv)
+            self.eloop_weight.data.div_(init_eeigenv)
+
+    def forward(self, graph, node_feat, edge_feat, edge_norm=None):
+        if not isinstance(graph, BatchedGraph):
+            raise TypeError("DualGraphConv expects a dualmessagepassing_amd BatchedGraph")
+        g = graph
+        # _node_init_func / _edge_init_func (model.py:207-221)
+        g.ndata["h"] = node_feat
+        if OUTDEGREE not in g.ndata:
+            g.ndata[OUTDEGREE] = g.out_degrees()
+        g.edata["h"] = edge_feat
+        if edge_norm is not None:
+            g.edata["norm"] = edge_norm
+        if "is_rev" in g.edata and REVFLAG not in g.edata:
+            g.edata[REVFLAG] = g.edata["is_rev"]  # the index reads the flag under the SCM key
+        node_pre, edge_pre, _ = dual_message_passing(
+            g, node_feat, edge_feat, self.in_weight, self.out_weight, self.src_weight, self.dst_weight,
+            self.nloop_weight, self.eloop_weight, self.nbias, self.ebias, has_rev="is_rev" in g.edata,
+            edge_norm=g.edata.get("norm"))
+        node_out = ops.apply_mlp(self.nmlp, node_pre)
+        edge_out = ops.apply_mlp(self.emlp, edge_pre)
+        if self.act:
+            node_out = self.act(node_out)
+            edge_out = self.act(edge_out)
+        return node_out, edge_out
+
+    def extra_repr(self):
+        return "in=%s, out=%s," % (self.input_dim, self.hidden_dim)
+
+
+def compute_edgenorm(g, norm="in"):
+    """utils.py:437-453: per-edge ``1/in_deg[dst]`` (or out / both) as [E,1]; NaN and Inf
+    entries are replaced by the minimum (in that order)."""
+    in_deg = g.in_degrees().float()
+    out_deg = g.out_degrees().float()
+    u, v = g.all_edges(form="uv", order="eid")
+    if norm == "in":
+        w = in_deg[v].reciprocal().unsqueeze(-1)
+    elif norm == "out":
+        w = out_deg[u].reciprocal().unsqueeze(-1)
+    elif norm == "both":
+        w = torch.pow(out_deg[u] * in_deg[v], 0.5).reciprocal().unsqueeze(-1)
+    else:
+        raise ValueError(norm)
+    w.masked_fill_(torch.isnan(w), w.min())
+    w.masked_fill_(torch.isinf(w), w.min())
+    return w
+
+
+def build_graph_from_triplets(num_nodes, num_rels, triplets, device):
+    """utils.py:473-491: sort the (src, rel, dst) triplets by (src, dst, rel), add E forward and E
+    reversed edges, ``type`` = rel | rel + num_rels, ``norm`` = compute_edgenorm (1 / in-degree)."""
+    t = np.asarray(triplets).copy()
+    order = np.lexsort((t[:, 1], t[:, 2], t[:, 0]))  # keys: src, then dst, then rel
+    t = t[order]
+    src = np.concatenate([t[:, 0], t[:, 2]]).astype(np.int64)
+    dst = np.concatenate([t[:, 2], t[:, 0]]).astype(np.int64)
+    rel = np.concatenate([t[:, 1], t[:, 1] + num_rels]).astype(np.int64)
+    g = BatchedGraph(torch.from_numpy(src).to(device), torch.from_numpy(dst).to(device), num_nodes)
+    g.edata["type"] = torch.from_numpy(rel).to(device)
+    g.edata["norm"] = compute_edgenorm(g)
+    return g

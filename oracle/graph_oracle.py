@@ -1,0 +1,106 @@
+"""ORACLE -- TEST INFRASTRUCTURE.  numpy/ctypes front end of oracle/graph_oracle.c
+(sequential C restatement of the reference's integer graph transforms) plus the
+frame handling of ``convert_to_dual_graph`` (utils/graph.py:74-169) in numpy."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgraph_oracle.so")
+        src = os.path.join(_HERE, "graph_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_line_graph_plain.restype = ctypes.c_int64
+        _LIB.orc_line_graph_id.restype = ctypes.c_int64
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def csr_build(key, flag, n):
+    key = _i64(key)
+    e = len(key)
+    f = None if flag is None else np.ascontiguousarray(flag, dtype=np.uint8)
+    ptr = np.zeros(n + 1, np.int32)
+    ent = np.zeros(max(e, 1), np.int32)
+    lib().orc_csr_build(_p(key), _p(f), ctypes.c_int64(e), ctypes.c_int64(n), _p(ptr), _p(ent))
+    return ptr, ent[:e]
+
+
+def add_reversed_edges(src, dst, eid, el, max_ne, max_nel):
+    src, dst, eid, el = map(_i64, (src, dst, eid, el))
+    e = len(src)
+    o = [np.zeros(2 * e, np.int64) for _ in range(4)]
+    rev = np.zeros(2 * e, np.uint8)
+    lib().orc_add_reversed_edges(_p(src), _p(dst), _p(eid), _p(el), ctypes.c_int64(e), ctypes.c_int64(max_ne),
+                                 ctypes.c_int64(max_nel), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(rev))
+    return o[0], o[1], o[2], o[3], rev.astype(bool)
+
+
+def collate(local_src, local_dst, num_nodes, num_edges):
+    ls, ld, nn, ne = map(_i64, (local_src, local_dst, num_nodes, num_edges))
+    b, e, n = len(nn), len(ls), int(nn.sum())
+    node_off, edge_off = np.zeros(b + 1, np.int64), np.zeros(b + 1, np.int64)
+    src, dst = np.zeros(e, np.int64), np.zeros(e, np.int64)
+    eg, ng = np.zeros(max(e, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    lib().orc_collate(_p(ls), _p(ld), _p(nn), _p(ne), ctypes.c_int64(b), _p(node_off), _p(edge_off), _p(src),
+                      _p(dst), _p(eg), _p(ng))
+    return src, dst, node_off, edge_off, eg[:e], ng[:n]
+
+
+def eigen_bounds(src, dst, n):
+    src, dst = _i64(src), _i64(dst)
+    a, b = ctypes.c_float(), ctypes.c_float()
+    lib().orc_eigen_bounds(_p(src), _p(dst), ctypes.c_int64(len(src)), ctypes.c_int64(n), ctypes.byref(a),
+                           ctypes.byref(b))
+    return a.value, b.value
+
+
+def convert_to_dual_graph(src, dst, n, ndata, edata):
+    """One graph.  ndata / edata: dict name -> numpy array.  Returns
+    (dual_src, dual_dst, dual_num_nodes, dual_ndata, dual_edata) like the reference's
+    DGL branch (utils/graph.py:75-169)."""
+    src, dst = _i64(src), _i64(dst)
+    e = len(src)
+    cap = int((np.bincount(dst, minlength=n)[src]).sum()) if e else 0
+    dsrc, ddst, pay = (np.zeros(max(cap, 1), np.int64) for _ in range(3))
+    if "id" in edata and e > 0:
+        eid = _i64(edata["id"])
+        k = int(eid.max()) + 1
+        if "label" not in ndata:
+            raise NotImplementedError("edge ids without node labels")
+        first = np.zeros(k, np.int64)
+        nk = ctypes.c_int64()
+        m = lib().orc_line_graph_id(_p(src), _p(dst), _p(eid), _p(_i64(ndata["label"])), ctypes.c_int64(e),
+                                    ctypes.c_int64(n), ctypes.c_int64(k), _p(first), _p(dsrc), _p(ddst), _p(pay),
+                                    ctypes.byref(nk))
+        rep = first[first >= 0]
+        dual_ndata = {key: np.asarray(v)[rep] for key, v in edata.items()}   # graph.py:90-95 + :161-164
+        dn = nk.value
+    else:
+        m = lib().orc_line_graph_plain(_p(src), _p(dst), ctypes.c_int64(e), ctypes.c_int64(n), _p(dsrc), _p(ddst),
+                                       _p(pay))
+        dual_ndata = {key: np.asarray(v) for key, v in edata.items()}        # graph.py:99-101
+        if "id" not in edata:
+            dual_ndata["id"] = np.arange(e, dtype=np.int64)                  # graph.py:102-103
+        dn = e
+    dsrc, ddst, pay = dsrc[:m], ddst[:m], pay[:m]
+    dual_edata = {key: np.asarray(v)[pay] for key, v in ndata.items()}      # graph.py:139-140
+    if "id" not in ndata:
+        dual_edata["id"] = pay.copy()                                       # graph.py:141-142
+    return dsrc, ddst, dn, dual_ndata, dual_edata

@@ -1,0 +1,155 @@
+"""GPU parity (bit-exact) of the integer graph transforms: line graph, reversed edges,
+collate, degree/eigenvalue bounds -- against the reference's golden vectors and the C oracle."""
+import numpy as np
+import pytest
+import torch as th
+
+import graph_oracle as GO
+from conftest import golden_files, load_golden
+from util_graphs import er_edges
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return th.from_numpy(np.ascontiguousarray(a))
+
+
+def _frames(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def _bg(src, dst, n, ndata, edata, dev, bnn=None, bne=None):
+    from dualmessagepassing_amd.graph import BatchedGraph
+    return BatchedGraph(_t(src).to(dev), _t(dst).to(dev), n, None if bnn is None else _t(bnn).to(dev),
+                        None if bne is None else _t(bne).to(dev),
+                        {k: _t(v).to(dev) for k, v in ndata.items()}, {k: _t(v).to(dev) for k, v in edata.items()})
+
+
+@pytest.mark.parametrize("path", golden_files("linegraph_"))
+def test_line_graph_matches_reference_golden(path, gpu):
+    from dualmessagepassing_amd.linegraph import convert_to_dual_graph
+    d = load_golden(path)
+    ndata, edata = _frames(d, "ndata."), _frames(d, "edata.")
+    g = _bg(d["src"].astype(np.int64), d["dst"].astype(np.int64), int(d["num_nodes"]), ndata, edata, gpu)
+    dg = convert_to_dual_graph(g)
+    assert dg.number_of_nodes() == int(d["dual_num_nodes"])
+    u, v = dg.all_edges()
+    assert np.array_equal(u.cpu().numpy(), d["dual_src"]) and np.array_equal(v.cpu().numpy(), d["dual_dst"])
+    ref_nd, ref_ed = _frames(d, "dual_ndata."), _frames(d, "dual_edata.")
+    assert sorted(dg.ndata) == sorted(ref_nd) and sorted(dg.edata) == sorted(ref_ed)
+    for k in ref_nd:
+        assert np.array_equal(dg.ndata[k].cpu().numpy(), ref_nd[k]), k
+    for k in ref_ed:
+        assert np.array_equal(dg.edata[k].cpu().numpy().reshape(ref_ed[k].shape), ref_ed[k]), k
+
+
+@pytest.mark.parametrize("mode", ["plain", "idrev", "dupid"])
+def test_line_graph_batched_equals_per_graph_oracle(mode, gpu):
+    """A whole batch converted at once == the oracle applied graph by graph (ragged sizes,
+    one empty graph, duplicate ids, id holes)."""
+    from dualmessagepassing_amd.collate import collate_device
+    from dualmessagepassing_amd.linegraph import convert_to_dual_graph
+    rng = np.random.default_rng(8)
+    sizes = [(5, 7), (1, 0), (9, 30), (3, 6), (12, 40)]
+    per, ls, ld, nd_all, ed_all = [], [], [], {}, {}
+    for n, m in sizes:
+        u, v = er_edges(n, m, rng) if m else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        ndata, edata = {}, {}
+        if mode != "plain":
+            nl = rng.integers(0, 3, size=n)
+            el = rng.integers(0, 3, size=len(u))
+            ndata = {"id": np.arange(n), "label": nl}
+            if mode == "idrev":
+                e = len(u)
+                u, v = np.concatenate([u, v]), np.concatenate([v, u])
+                edata = {"id": np.concatenate([np.arange(e), e + 2 + np.arange(e)]), "label": np.concatenate([el, el + 3]),
+                         "is_reversed": np.concatenate([np.zeros(e, bool), np.ones(e, bool)])}
+            else:
+                edata = {"id": rng.integers(0, max(1, m // 2 + 1), size=len(u)), "label": el}
+        per.append((u, v, n, ndata, edata))
+        ls.append(u); ld.append(v)
+        for k, x in ndata.items():
+            nd_all.setdefault(k, []).append(x)
+        for k, x in edata.items():
+            ed_all.setdefault(k, []).append(x)
+    nn = np.array([p[2] for p in per], np.int64)
+    ne = np.array([len(p[0]) for p in per], np.int64)
+    g = collate_device(_t(np.concatenate(ls)).to(gpu), _t(np.concatenate(ld)).to(gpu), _t(nn).to(gpu), _t(ne).to(gpu),
+                       int(nn.sum()), int(ne.sum()),
+                       {k: _t(np.concatenate(x)).to(gpu) for k, x in nd_all.items()},
+                       {k: _t(np.concatenate(x)).to(gpu) for k, x in ed_all.items()})
+    dg = convert_to_dual_graph(g)
+    # expected: oracle per graph, then dgl.batch semantics
+    exp_s, exp_t, exp_nd, exp_ed, off, dnn, dne = [], [], {}, {}, 0, [], []
+    for u, v, n, ndata, edata in per:
+        s, t, dn, dnd, ded = GO.convert_to_dual_graph(u, v, n, ndata, edata)
+        exp_s.append(s + off); exp_t.append(t + off)
+        off += dn
+        dnn.append(dn); dne.append(len(s))
+        for k, x in dnd.items():
+            exp_nd.setdefault(k, []).append(x)
+        for k, x in ded.items():
+            exp_ed.setdefault(k, []).append(x)
+    u, v = dg.all_edges()
+    assert np.array_equal(u.cpu().numpy(), np.concatenate(exp_s)) and np.array_equal(v.cpu().numpy(), np.concatenate(exp_t))
+    assert dg.batch_num_nodes().cpu().tolist() == dnn and dg.batch_num_edges().cpu().tolist() == dne
+    for k, x in exp_nd.items():
+        assert np.array_equal(dg.ndata[k].cpu().numpy(), np.concatenate(x)), k
+    for k, x in exp_ed.items():
+        assert np.array_equal(dg.edata[k].cpu().numpy(), np.concatenate(x)), k
+    # |E_L| = sum_v indeg(v) * outdeg(v) in the plain branch
+    if mode == "plain":
+        for (uu, vv, n, _, _), m in zip(per, dne):
+            assert m == int((np.bincount(vv, minlength=n) * np.bincount(uu, minlength=n)).sum())
+
+
+@pytest.mark.parametrize("path", golden_files("addrev_"))
+def test_add_reversed_edges_matches_reference_golden(path, gpu):
+    from dualmessagepassing_amd.preprocess import add_reversed_edges
+    d = load_golden(path)
+    n = int(d["num_nodes"])
+    g = _bg(d["src"], d["dst"], n, {"id": np.arange(n)}, {"id": d["eid"], "label": d["elabel"]}, gpu)
+    g.in_degrees(); g.out_degrees()  # cached before, updated by the pass (dataset.py:1289-1293)
+    r = add_reversed_edges(g, int(d["max_ne"]), int(d["max_nel"]))
+    u, v = r.all_edges()
+    for got, key in ((u, "o_src"), (v, "o_dst"), (r.edata["id"], "o_eid"), (r.edata["label"], "o_elabel"),
+                     (r.edata["is_reversed"], "o_rev"), (r.ndata["in_deg"], "o_in_deg"), (r.ndata["out_deg"], "o_out_deg")):
+        assert np.array_equal(got.cpu().numpy(), d[key]), key
+    assert add_reversed_edges(r, 1, 1) is r  # train.py:302: no-op when REVFLAG is present
+
+
+def test_collate_addrev_degrees_batched(gpu):
+    """collate -> add_reversed_edges on a ragged batch == oracle per graph, in dgl.batch order."""
+    from dualmessagepassing_amd.collate import collate_device
+    from dualmessagepassing_amd.preprocess import add_reversed_edges, compute_largest_eigenvalues
+    rng = np.random.default_rng(21)
+    sizes = [(6, 9), (2, 1), (4, 0), (10, 33)]
+    graphs = [(er_edges(n, m, rng) if m else (np.zeros(0, np.int64), np.zeros(0, np.int64))) + (n,) for n, m in sizes]
+    ls = np.concatenate([g[0] for g in graphs]); ld = np.concatenate([g[1] for g in graphs])
+    nn = np.array([g[2] for g in graphs], np.int64); ne = np.array([len(g[0]) for g in graphs], np.int64)
+    eid = np.concatenate([np.arange(len(g[0])) for g in graphs]); el = rng.integers(0, 4, size=len(ls))
+    src, dst, no, eo, eg, ng = GO.collate(ls, ld, nn, ne)
+    g = collate_device(_t(ls).to(gpu), _t(ld).to(gpu), _t(nn).to(gpu), _t(ne).to(gpu), int(nn.sum()), int(ne.sum()),
+                       None, {"id": _t(eid).to(gpu), "label": _t(el).to(gpu)})
+    u, v = g.all_edges()
+    assert np.array_equal(u.cpu().numpy(), src) and np.array_equal(v.cpu().numpy(), dst)
+    assert np.array_equal(g.node_offsets.cpu().numpy(), no) and np.array_equal(g.edge_offsets.cpu().numpy(), eo)
+    assert np.array_equal(g.edge_graph.cpu().numpy(), eg) and np.array_equal(g.node_graph.cpu().numpy(), ng)
+    assert g.batch_size == 4 and g.batch_num_nodes().cpu().tolist() == nn.tolist()
+    r = add_reversed_edges(g, 50, 10)
+    exp = [GO.add_reversed_edges(src[eo[i]:eo[i + 1]], dst[eo[i]:eo[i + 1]], eid[eo[i]:eo[i + 1]], el[eo[i]:eo[i + 1]], 50, 10)
+           for i in range(4)]
+    u, v = r.all_edges()
+    for got, j in ((u, 0), (v, 1), (r.edata["id"], 2), (r.edata["label"], 3), (r.edata["is_reversed"], 4)):
+        assert np.array_equal(got.cpu().numpy(), np.concatenate([x[j] for x in exp]))
+    assert r.batch_num_edges().cpu().tolist() == (2 * ne).tolist()
+    # per-graph eigenvalue bounds (utils/graph.py:40-71) on the doubled graphs
+    nd, ed = compute_largest_eigenvalues(r)
+    uu, vv = u.cpu().numpy(), v.cpu().numpy()
+    for i in range(4):
+        if ne[i] == 0:
+            continue
+        sl = slice(2 * eo[i], 2 * eo[i + 1])
+        a, b = GO.eigen_bounds(uu[sl] - no[i], vv[sl] - no[i], int(nn[i]))
+        assert float(nd[i]) == a and float(ed[i]) == b

@@ -161,7 +161,8 @@ def test_config2_size_properties(gpu):
     a1 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
     a2 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
     assert th.equal(a1, a2)
-    assert th.allclose(a1.double().sum(0), m.double().sum(0), rtol=1e-9, atol=1e-6)
+    # fp32 per-row sums then an fp64 column sum: rounding of ~64k partial sums, |err| << 1e-2
+    assert th.allclose(a1.double().sum(0), m.double().sum(0), rtol=1e-6, atol=2e-2)
     # (3) equals torch's own index_add on device within fp32 reassociation
     ref = th.zeros(n, h, device=gpu).index_add_(0, td, m)
     assert th.allclose(a1, ref, rtol=1e-5, atol=1e-5)

@@ -1,0 +1,96 @@
+"""GPU parity of the sibling layers on the same kernels: CompGCNLayer (SCM) and DualGraphConv
+(UNC), against the reference's golden vectors.  fp32 tolerances as in test_gpu_dmplayer.py."""
+import numpy as np
+import pytest
+import torch as th
+
+from conftest import golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return th.from_numpy(np.asarray(a))
+
+
+def _close(got, ref, rtol=1e-5, atol=1e-5, what=""):
+    got, ref = got.detach().double().cpu(), _t(ref).double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max())) if ref.numel() else 1.0
+    err = float((got - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= (atol + rtol) * scale, "%s: max err %g (scale %g)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("path", golden_files("compgcn_"))
+def test_compgcn_layer_matches_reference_golden(path, gpu):
+    from dualmessagepassing_amd.compgcn import CompGCNLayer
+    from dualmessagepassing_amd.graph import BatchedGraph
+    d = load_golden(path)
+    h = d["x"].shape[1]
+    layer = CompGCNLayer(h, h, self_loop=bool(d["self_loop"]), comp_opt=str(d["comp_opt"]),
+                         edge_norm=str(d["edge_norm"]), bias=True, batch_norm=False, act_func="relu")
+    layer.load_state_dict({k[2:]: _t(v) for k, v in d.items() if k.startswith("p.")}, strict=True)
+    layer.to(gpu)
+    g = BatchedGraph(_t(d["src"]).to(gpu), _t(d["dst"]).to(gpu), int(d["num_nodes"]))
+    if "rev" in d:
+        g.edata["is_reversed"] = _t(d["rev"]).to(gpu)
+    x = _t(d["x"]).to(gpu).requires_grad_(True)
+    z = _t(d["z"]).to(gpu).requires_grad_(True)
+    node_out, edge_out = layer(g, x, z)
+    if "norm" in d:
+        _close(g.edata["norm"], d["norm"], 1e-6, 1e-6, "norm")
+    _close(node_out, d["node_out"], what="node_out")
+    _close(edge_out, d["edge_out"], what="edge_out")
+    ((node_out * _t(d["wn"]).to(gpu)).sum() + (edge_out * _t(d["we"]).to(gpu)).sum()).backward()
+    _close(x.grad, d["dx"], what="dx")
+    _close(z.grad, d["dz"], what="dz")
+    for k, p in layer.named_parameters():
+        if "g." + k in d:
+            _close(p.grad, d["g." + k], 2e-4, 2e-4, "grad " + k)
+
+
+@pytest.mark.parametrize("path", golden_files("unc_dualconv_"))
+def test_unc_dual_graph_conv_matches_reference_golden(path, gpu):
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd.unc import DualGraphConv, compute_edgenorm
+    d = load_golden(path)
+    h = d["x"].shape[1]
+    act = th.nn.Tanh() if str(d["activation"]) == "tanh" else None
+    layer = DualGraphConv(h, h, activation=act, dropout=0.0)
+    sd = {k[2:]: _t(v) for k, v in d.items() if k.startswith("p.")}
+    sd.update({k[2:]: _t(v) for k, v in d.items() if k.startswith("b.")})
+    layer.load_state_dict(sd, strict=True)  # incl. the unused nfc/efc and the BN buffers
+    layer.to(gpu).train(bool(d["bn_train"]))
+    g = BatchedGraph(_t(d["src"]).to(gpu), _t(d["dst"]).to(gpu), int(d["num_nodes"]))
+    norm = compute_edgenorm(g)
+    _close(norm, d["norm"], 1e-6, 1e-6, "edge norm")
+    x = _t(d["x"]).to(gpu).requires_grad_(True)
+    z = _t(d["z"]).to(gpu).requires_grad_(True)
+    node_out, edge_out = layer(g, x, z, norm)
+    assert th.equal(g.ndata["out_deg"].cpu(), _t(d["out_deg"]))
+    _close(node_out, d["node_out"], 2e-5, 2e-5, "node_out")
+    _close(edge_out, d["edge_out"], 2e-5, 2e-5, "edge_out")
+    ((node_out * _t(d["wn"]).to(gpu)).sum() + (edge_out * _t(d["we"]).to(gpu)).sum()).backward()
+    _close(x.grad, d["dx"], 2e-5, 2e-5, "dx")
+    _close(z.grad, d["dz"], 2e-5, 2e-5, "dz")
+    for k, p in layer.named_parameters():
+        if "g." + k in d:
+            _close(p.grad, d["g." + k], 2e-4, 2e-4, "grad " + k)
+        else:
+            assert p.grad is None  # nfc / efc / out_weight: unused, exactly as in the reference
+    if bool(d["bn_train"]):
+        for k, b in layer.named_buffers():
+            if "num_batches" not in k:
+                _close(b, d["b_after." + k], what=k)
+
+
+def test_build_graph_from_triplets_and_norm(gpu):
+    """utils.py:473-491 semantics: sort by (src,dst,rel), forward + reversed copies, types, 1/in-degree."""
+    from dualmessagepassing_amd.unc import build_graph_from_triplets
+    trip = np.array([[2, 0, 1], [0, 1, 2], [0, 0, 1], [2, 1, 1], [1, 0, 0]])
+    g = build_graph_from_triplets(3, 2, trip, gpu)
+    u, v = g.all_edges()
+    assert u.cpu().tolist() == [0, 0, 1, 2, 2, 1, 2, 0, 1, 1] and v.cpu().tolist() == [1, 2, 0, 1, 1, 0, 0, 1, 2, 2]
+    assert g.edata["type"].cpu().tolist() == [0, 1, 0, 0, 1, 2, 3, 2, 2, 3]
+    indeg = np.bincount(v.cpu().numpy(), minlength=3)
+    assert np.allclose(g.edata["norm"].cpu().numpy()[:, 0], 1.0 / indeg[v.cpu().numpy()])
