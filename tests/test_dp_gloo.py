@@ -1,0 +1,106 @@
+"""Multi-process data-parallel path on CPU (gloo, world_size 2): the flat-buffer gradient
+all-reduce reproduces the single-process global-batch gradient, parameters without a gradient
+are handled, and shards partition the batch.  RCCL replaces gloo on the GPU box."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dualmessagepassing_amd.dp import FlatGradSync, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.a = torch.nn.Linear(6, 5)
+        self.b = torch.nn.Linear(5, 1)
+        self.unused = torch.nn.Linear(3, 3)   # never gets a gradient (like UNC nfc/efc)
+        self.shared = self.a                  # aliased module, as with share_rep_net
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.shared(x))).squeeze(-1)
+
+
+def _data(n=24):
+    g = torch.Generator().manual_seed(11)
+    return torch.randn(n, 6, generator=g), torch.randn(n, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = Tiny()
+        if rank != 0:  # de-synchronise, then check broadcast_parameters restores rank 0's values
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        sync = FlatGradSync(model)
+        sync.broadcast_parameters(src=0)
+        x, y = _data()
+        lo, hi = shard_range(x.size(0), rank, world)
+        sync.zero()
+        loss = torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi])  # mean over the local shard
+        loss.backward()
+        work = sync.sync(async_op=(rank % 2 == 0))
+        sync.finish(work)
+        out[rank] = sync.flat.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_allreduce_matches_global_batch():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        flats = [out[r] for r in range(world)]
+    assert torch.equal(flats[0], flats[1])
+    # single-process reference on the whole batch (equal shards -> mean of means = global mean)
+    model = Tiny()
+    ref = FlatGradSync(model)
+    x, y = _data()
+    torch.nn.functional.mse_loss(model(x), y).backward()
+    assert torch.allclose(flats[0], ref.flat, rtol=1e-5, atol=1e-6)
+    # the never-used parameters stay exactly zero in the buffer
+    n_unused = sum(p.numel() for p in model.unused.parameters())
+    assert n_unused > 0 and int((ref.flat == 0).sum()) >= n_unused
+
+
+def test_flat_buffer_views_and_dedup():
+    model = Tiny()
+    sync = FlatGradSync(model)
+    n = sum(p.numel() for p in {id(p): p for p in model.parameters()}.values())
+    assert sync.flat.numel() == n          # the aliased module is counted once
+    model(torch.randn(4, 6)).sum().backward()
+    for p in sync.params:
+        assert p.grad.data_ptr() >= sync.flat.data_ptr()  # grads are views into the flat buffer
+    before = sync.flat.clone()
+    sync.sync()                            # world size 1: no-op
+    assert torch.equal(before, sync.flat)
+    sync.zero()
+    assert float(sync.flat.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in sync.params)
+
+
+@pytest.mark.parametrize("n,world", [(1024, 8), (10, 3), (2, 4), (0, 2)])
+def test_shard_range_partitions(n, world):
+    spans = [shard_range(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1
