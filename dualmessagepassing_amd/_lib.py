@@ -34,9 +34,9 @@ SIGNATURES = {
     "dmp_dedupe_first": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_scan_workspace_words": (c_size, [c_i64]),
     "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
-    "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr]),
     "dmp_seg_sum2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64,
-                             c_ptr]),
+                             c_int, c_ptr]),
     "dmp_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_gather_select": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr,
                                   c_i64, c_ptr]),
@@ -49,7 +49,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -56,13 +56,17 @@ __device__ __forceinline__ float4 had4(const float4 &a, const float4 &b) {
 // broadcast by shuffle and the source rows are fetched four at a time (four
 // independent 16-B loads in flight per lane) and added in CSR order.
 // ---------------------------------------------------------------------------
-template <int G, bool SPLIT, bool WEIGHTED>
+template <int G, bool SPLIT, bool WEIGHTED, bool REMAP>
 __global__ __launch_bounds__(kBlock) void seg_sum_vec(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
     float s0, float s1, float *__restrict__ out, int64_t ldo) {
   constexpr int RPB = kBlock / G;
-  const int row = xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G;
+  constexpr int U = 8;  // independent 16-B row loads in flight per lane
+  // REMAP (XCD-local rows): needed when rows are shared between destinations (incidence
+  // CSR) and also faster when M was just written by the previous kernel (59 vs 70 us);
+  // plain dispatch order only wins (~3 us) on a cold read-once stream (scripts/kbench.py).
+  const int row = (REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * RPB + threadIdx.x / G;
   const int lane = threadIdx.x % G;
   if (row >= N) return;
   const int beg = rowptr[row], end = rowptr[row + 1];
@@ -78,39 +82,24 @@ __global__ __launch_bounds__(kBlock) void seg_sum_vec(
         my = ent[base + lane];
         if (WEIGHTED) myw = ew[my >> 1];
       }
-      int j = 0;
-      for (; j + 4 <= cnt; j += 4) {
-        const int e0 = __shfl(my, j, G), e1 = __shfl(my, j + 1, G);
-        const int e2 = __shfl(my, j + 2, G), e3 = __shfl(my, j + 3, G);
-        float w0 = 1.f, w1 = 1.f, w2 = 1.f, w3 = 1.f;
-        if (WEIGHTED) {
-          w0 = __shfl(myw, j, G); w1 = __shfl(myw, j + 1, G);
-          w2 = __shfl(myw, j + 2, G); w3 = __shfl(myw, j + 3, G);
-        }
-        if (act) {
-          float4 v0 = ld4(M + (int64_t)(e0 >> 1) * ldm + c);
-          float4 v1 = ld4(M + (int64_t)(e1 >> 1) * ldm + c);
-          float4 v2 = ld4(M + (int64_t)(e2 >> 1) * ldm + c);
-          float4 v3 = ld4(M + (int64_t)(e3 >> 1) * ldm + c);
-          if (WEIGHTED) { v0 = mul4(v0, w0); v1 = mul4(v1, w1); v2 = mul4(v2, w2); v3 = mul4(v3, w3); }
-          if (SPLIT) {
-            if (e0 & 1) add4(a1, v0); else add4(a0, v0);
-            if (e1 & 1) add4(a1, v1); else add4(a0, v1);
-            if (e2 & 1) add4(a1, v2); else add4(a0, v2);
-            if (e3 & 1) add4(a1, v3); else add4(a0, v3);
-          } else {
-            add4(a0, v0); add4(a0, v1); add4(a0, v2); add4(a0, v3);
+      for (int j = 0; j < cnt; j += U) {
+        float4 v[U];
+        int e[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          e[k] = __shfl(my, min(j + k, G - 1), G);
+          float w = 1.f;
+          if (WEIGHTED) w = __shfl(myw, min(j + k, G - 1), G);
+          if (act && j + k < cnt) {
+            v[k] = ld4(M + (int64_t)(e[k] >> 1) * ldm + c);
+            if (WEIGHTED) v[k] = mul4(v[k], w);
           }
         }
-      }
-      for (; j < cnt; ++j) {
-        const int e0 = __shfl(my, j, G);
-        float w0 = 1.f;
-        if (WEIGHTED) w0 = __shfl(myw, j, G);
-        if (act) {
-          float4 v0 = ld4(M + (int64_t)(e0 >> 1) * ldm + c);
-          if (WEIGHTED) v0 = mul4(v0, w0);
-          if (SPLIT && (e0 & 1)) add4(a1, v0); else add4(a0, v0);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          if (act && j + k < cnt) {
+            if (SPLIT && (e[k] & 1)) add4(a1, v[k]); else add4(a0, v[k]);
+          }
         }
       }
     }
@@ -150,33 +139,44 @@ __global__ __launch_bounds__(kBlock) void seg_sum_scalar(
 }
 
 // ---------------------------------------------------------------------------
-// Per-edge streaming kernels: a G-lane group per edge row, ROWS rows per group
-// (all loads of the ROWS rows are issued before the first store).
+// Per-edge streaming kernels: a G-lane group per R consecutive edge rows.  The first R
+// lanes of the group fetch the R rows' indices / flags with one load each and broadcast
+// them by shuffle, then all loads of the R rows are issued before the first store.
+// Plain dispatch order (no XCD remap): measured faster for pure streams (kbench).
 // ---------------------------------------------------------------------------
-constexpr int kRowsPerGroup = 2;
-
-template <int G, bool WEIGHTED>
+template <int G, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void gather_rows_vec(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ idx,
     const float *__restrict__ ew, int64_t E, int H, float *__restrict__ out, int64_t ldo) {
-  constexpr int RPB = kBlock / G;
-  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  constexpr int GPB = kBlock / G;
+  const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
-  for (int c = lane * 4; c < H; c += G * 4) {
-    float4 v[kRowsPerGroup];
+  if (e0 >= E) return;
+  int mi = 0;
+  float mw = 1.f;
+  if (lane < R && e0 + lane < E) {
+    mi = idx[e0 + lane];
+    if (WEIGHTED) mw = ew[e0 + lane];
+  }
+  int r[R];
+  float w[R];
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) {
-        v[k] = ld4(X + (int64_t)idx[e] * ldx + c);
-        if (WEIGHTED) v[k] = mul4(v[k], ew[e]);
+  for (int k = 0; k < R; ++k) {  // broadcasts outside the column loop: every lane takes part
+    r[k] = __shfl(mi, k, G);
+    w[k] = WEIGHTED ? __shfl(mw, k, G) : 1.f;
+  }
+  for (int c = lane * 4; c < H; c += G * 4) {
+    float4 v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (e0 + k < E) {
+        v[k] = ld4(X + (int64_t)r[k] * ldx + c);
+        if (WEIGHTED) v[k] = mul4(v[k], w[k]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) st4(out + e * ldo + c, v[k]);
-    }
+    for (int k = 0; k < R; ++k)
+      if (e0 + k < E) st4(out + (e0 + k) * ldo + c, v[k]);
   }
 }
 
@@ -190,31 +190,39 @@ __global__ __launch_bounds__(kBlock) void gather_rows_scalar(
   for (int c = threadIdx.x % kWave; c < H; c += kWave) out[e * ldo + c] = X[r * ldx + c] * w;
 }
 
-template <int G, bool WEIGHTED>
+template <int G, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void gather_select_vec(
     const float *__restrict__ D, int64_t ldd, const int32_t *__restrict__ dst,
     const uint8_t *__restrict__ flag, const float *__restrict__ ew, int64_t E, int H,
     float s0, float s1, float *__restrict__ out, int64_t ldo) {
-  constexpr int RPB = kBlock / G;
-  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  constexpr int GPB = kBlock / G;
+  const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
+  if (e0 >= E) return;
+  int md = 0, mf = 0;
+  float ms = s0;
+  if (lane < R && e0 + lane < E) {
+    md = dst[e0 + lane];
+    mf = flag ? flag[e0 + lane] : 0;
+    ms = mf ? s1 : s0;
+    if (WEIGHTED) ms *= ew[e0 + lane];
+  }
+  int64_t off[R];
+  float sc[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int d = __shfl(md, k, G), f = __shfl(mf, k, G);
+    off[k] = (int64_t)d * ldd + (f ? H : 0);
+    sc[k] = __shfl(ms, k, G);
+  }
   for (int c = lane * 4; c < H; c += G * 4) {
-    float4 v[kRowsPerGroup];
+    float4 v[R];
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) {
-        const bool f = flag && flag[e];
-        float s = f ? s1 : s0;
-        if (WEIGHTED) s *= ew[e];
-        v[k] = mul4(ld4(D + (int64_t)dst[e] * ldd + (f ? H : 0) + c), s);
-      }
-    }
+    for (int k = 0; k < R; ++k)
+      if (e0 + k < E) v[k] = mul4(ld4(D + off[k] + c), sc[k]);
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) st4(out + e * ldo + c, v[k]);
-    }
+    for (int k = 0; k < R; ++k)
+      if (e0 + k < E) st4(out + (e0 + k) * ldo + c, v[k]);
   }
 }
 
@@ -233,41 +241,54 @@ __global__ __launch_bounds__(kBlock) void gather_select_scalar(
 
 // Y[e] = ((G0 + coef*G1) + (P[a,0:H] - P[b,H:2H])) + bias     (reference order,
 // dmpnn.py:147: matmul(Z,eloop) + add + agg, then + ebias)
-template <int G>
+template <int G, int R>
 __global__ __launch_bounds__(kBlock) void edge_combine_vec(
     const float *__restrict__ Gm, int64_t ldg, const float *__restrict__ P, int64_t ldp,
     const float *__restrict__ coef, const float *__restrict__ bias,
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
     const uint8_t *__restrict__ flag, int64_t E, int H, float *__restrict__ Y, int64_t ldy) {
-  constexpr int RPB = kBlock / G;
-  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  constexpr int GPB = kBlock / G;
+  const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
+  if (e0 >= E) return;
+  int ma = 0, mb = 0;
+  float mc = 0.f;
+  if (lane < R && e0 + lane < E) {
+    const int u = src[e0 + lane], v = dst[e0 + lane];
+    const bool f = flag && flag[e0 + lane];
+    ma = f ? u : v;  // row of P[:, 0:H]  (W_dst side)
+    mb = f ? v : u;  // row of P[:, H:2H] (W_src side)
+    mc = coef[v];
+  }
+  int ra[R], rb[R];
+  float cf[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    ra[k] = __shfl(ma, k, G);
+    rb[k] = __shfl(mb, k, G);
+    cf[k] = __shfl(mc, k, G);
+  }
   for (int c = lane * 4; c < H; c += G * 4) {
     const float4 bi = bias ? ld4(bias + c) : zero4();
-    float4 y[kRowsPerGroup];
+    float4 g0[R], g1[R], pa[R], pb[R];
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) {
-        const int u = src[e], v = dst[e];
-        const bool f = flag && flag[e];
-        const float cf = coef[v];
-        const int a = f ? u : v, b = f ? v : u;
-        const float4 g0 = ld4(Gm + e * ldg + c);
-        const float4 g1 = ld4(Gm + e * ldg + H + c);
-        const float4 pa = ld4(P + (int64_t)a * ldp + c);
-        const float4 pb = ld4(P + (int64_t)b * ldp + H + c);
-        float4 t = mul4(g1, cf);
-        add4(t, g0);
-        add4(t, sub4(pa, pb));
-        add4(t, bi);
-        y[k] = t;
+    for (int k = 0; k < R; ++k) {
+      if (e0 + k < E) {
+        g0[k] = ld4(Gm + (e0 + k) * ldg + c);
+        g1[k] = ld4(Gm + (e0 + k) * ldg + H + c);
+        pa[k] = ld4(P + (int64_t)ra[k] * ldp + c);
+        pb[k] = ld4(P + (int64_t)rb[k] * ldp + H + c);
       }
     }
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) st4(Y + e * ldy + c, y[k]);
+    for (int k = 0; k < R; ++k) {
+      if (e0 + k < E) {
+        float4 t = mul4(g1[k], cf[k]);
+        add4(t, g0[k]);
+        add4(t, sub4(pa[k], pb[k]));
+        add4(t, bi);
+        st4(Y + (e0 + k) * ldy + c, t);
+      }
     }
   }
 }
@@ -292,27 +313,29 @@ __global__ __launch_bounds__(kBlock) void edge_combine_scalar(
   }
 }
 
-template <int G>
+template <int G, int R>
 __global__ __launch_bounds__(kBlock) void edge_combine_bwd_g_vec(
     const float *__restrict__ dY, int64_t ldy, const float *__restrict__ coef,
     const int32_t *__restrict__ dst, int64_t E, int H, float *__restrict__ dG, int64_t ldg) {
-  constexpr int RPB = kBlock / G;
-  const int64_t e0 = ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * RPB + threadIdx.x / G) * kRowsPerGroup;
+  constexpr int GPB = kBlock / G;
+  const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
+  if (e0 >= E) return;
+  float mc = 0.f;
+  if (lane < R && e0 + lane < E) mc = coef[dst[e0 + lane]];
+  float cf[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) cf[k] = __shfl(mc, k, G);
   for (int c = lane * 4; c < H; c += G * 4) {
-    float4 v[kRowsPerGroup];
-    float cf[kRowsPerGroup];
+    float4 v[R];
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) { v[k] = ld4(dY + e * ldy + c); cf[k] = coef[dst[e]]; }
-    }
+    for (int k = 0; k < R; ++k)
+      if (e0 + k < E) v[k] = ld4(dY + (e0 + k) * ldy + c);
 #pragma unroll
-    for (int k = 0; k < kRowsPerGroup; ++k) {
-      const int64_t e = e0 + k;
-      if (e < E) {
-        st4(dG + e * ldg + c, v[k]);
-        st4(dG + e * ldg + H + c, mul4(v[k], cf[k]));
+    for (int k = 0; k < R; ++k) {
+      if (e0 + k < E) {
+        st4(dG + (e0 + k) * ldg + c, v[k]);
+        st4(dG + (e0 + k) * ldg + H + c, mul4(v[k], cf[k]));
       }
     }
   }
@@ -495,9 +518,12 @@ extern "C" {
 int dmp_abi_version(void) { return DMP_ABI_VERSION; }
 const char *dmp_last_hip_error(void) { return g_last_err; }
 
+#define DMP_SS(SP, WT, RM) \
+  seg_sum_vec<G, SP, WT, RM><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
+
 static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                         const float *ew, int64_t N, int H, bool split, float s0, float s1,
-                        float *out, int64_t ldo, void *stream) {
+                        float *out, int64_t ldo, int rows_shared, void *stream) {
   if (N < 0 || H <= 0 || ldm < H || ldo < (split ? 2 * H : H)) return DMP_ERR_BAD_ARG;
   if (N == 0) return DMP_OK;
   if (!M || !rowptr || !ent || !out) return DMP_ERR_BAD_ARG;
@@ -506,12 +532,12 @@ static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, cons
   if (vec_ok(H, {ldm, ldo}, {M, out})) {
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(N, kBlock / G);
-      if (split) {
-        if (ew) seg_sum_vec<G, true, true><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
-        else seg_sum_vec<G, true, false><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+      if (rows_shared) {
+        if (split) { if (ew) DMP_SS(true, true, true); else DMP_SS(true, false, true); }
+        else { if (ew) DMP_SS(false, true, true); else DMP_SS(false, false, true); }
       } else {
-        if (ew) seg_sum_vec<G, false, true><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
-        else seg_sum_vec<G, false, false><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo);
+        if (split) { if (ew) DMP_SS(true, true, false); else DMP_SS(true, false, false); }
+        else { if (ew) DMP_SS(false, true, false); else DMP_SS(false, false, false); }
       }
     });
   } else {
@@ -524,14 +550,14 @@ static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, cons
 
 int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                 const float *edge_w, int64_t num_nodes, int H, float *out, int64_t ldo,
-                void *stream) {
-  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, false, 1.f, 1.f, out, ldo, stream);
+                int rows_shared, void *stream) {
+  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, false, 1.f, 1.f, out, ldo, rows_shared, stream);
 }
 
 int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                  const float *edge_w, int64_t num_nodes, int H, float s0, float s1, float *out,
-                 int64_t ldo, void *stream) {
-  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, true, s0, s1, out, ldo, stream);
+                 int64_t ldo, int rows_shared, void *stream) {
+  return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, true, s0, s1, out, ldo, rows_shared, stream);
 }
 
 int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx, const float *edge_w,
@@ -543,9 +569,9 @@ int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx, const float
   hipStream_t st = (hipStream_t)stream;
   if (vec_ok(H, {ldx, ldo}, {X, out})) {
     DMP_DISPATCH_G(H, {
-      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
-      if (edge_w) gather_rows_vec<G, true><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
-      else gather_rows_vec<G, false><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
+      const unsigned nb = blocks_for(E, (kBlock / G) * 4);
+      if (edge_w) gather_rows_vec<G, 4, true><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
+      else gather_rows_vec<G, 4, false><<<nb, kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
     });
   } else {
     gather_rows_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(X, ldx, idx, edge_w, E, H, out, ldo);
@@ -563,9 +589,9 @@ int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst, const uin
   hipStream_t st = (hipStream_t)stream;
   if (vec_ok(H, {ldd, ldo}, {D, out})) {
     DMP_DISPATCH_G(H, {
-      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
-      if (edge_w) gather_select_vec<G, true><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
-      else gather_select_vec<G, false><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+      const unsigned nb = blocks_for(E, (kBlock / G) * 4);
+      if (edge_w) gather_select_vec<G, 4, true><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+      else gather_select_vec<G, 4, false><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
     });
   } else {
     gather_select_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
@@ -583,8 +609,8 @@ int dmp_edge_combine(const float *Gm, int64_t ldg, const float *P, int64_t ldp, 
   hipStream_t st = (hipStream_t)stream;
   if (vec_ok(H, {ldg, ldp, ldy}, {Gm, P, Y, bias})) {
     DMP_DISPATCH_G(H, {
-      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
-      edge_combine_vec<G><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
+      const unsigned nb = blocks_for(E, (kBlock / G) * 2);
+      edge_combine_vec<G, 2><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
     });
   } else {
     edge_combine_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
@@ -601,8 +627,8 @@ int dmp_edge_combine_bwd_g(const float *dY, int64_t ldy, const float *coef, cons
   hipStream_t st = (hipStream_t)stream;
   if (vec_ok(H, {ldy, ldg}, {dY, dG})) {
     DMP_DISPATCH_G(H, {
-      const unsigned nb = blocks_for(E, (kBlock / G) * kRowsPerGroup);
-      edge_combine_bwd_g_vec<G><<<nb, kBlock, 0, st>>>(dY, ldy, coef, dst, E, H, dG, ldg);
+      const unsigned nb = blocks_for(E, kBlock / G);
+      edge_combine_bwd_g_vec<G, 1><<<nb, kBlock, 0, st>>>(dY, ldy, coef, dst, E, H, dG, ldg);
     });
   } else {
     edge_combine_bwd_g_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(dY, ldy, coef, dst, E, H, dG, ldg);

@@ -40,7 +40,7 @@ def _vec(t, dtype):
 
 
 # ----------------------------------------------------------------------------- raw launches
-def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0):
+def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True):
     lib = _lib.load()
     _lib.require_gpu(M, rowptr, ent, edge_w)
     M, ldm = _mat(M)
@@ -53,11 +53,11 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,
-                                   ptr(out), out.size(1), stream_ptr()), "dmp_seg_sum2")
+                                   ptr(out), out.size(1), int(rows_shared), stream_ptr()), "dmp_seg_sum2")
     else:
         with _lib.timed("seg_sum[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H,
-                                  ptr(out), out.size(1), stream_ptr()), "dmp_seg_sum")
+                                  ptr(out), out.size(1), int(rows_shared), stream_ptr()), "dmp_seg_sum")
     return out
 
 
@@ -187,7 +187,7 @@ class _EdgeCombine(torch.autograd.Function):
                                                  2 * H, stream_ptr()), "dmp_edge_combine_bwd_g")
         if ctx.needs_input_grad[1]:
             inc_ptr, inc_ent = ix.incidence()
-            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0)
+            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0, rows_shared=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dY.sum(0)
         return dG, dP, db, None, None
