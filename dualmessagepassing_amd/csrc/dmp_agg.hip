@@ -193,8 +193,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows_scalar(
 template <int G, int R, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void gather_select_vec(
     const float *__restrict__ D, int64_t ldd, const int32_t *__restrict__ dst,
-    const uint8_t *__restrict__ flag, const float *__restrict__ ew, int64_t E, int H,
-    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+    const uint8_t *__restrict__ flag, const float *__restrict__ ew, const float *__restrict__ base,
+    int64_t ldb, int64_t E, int H, float s0, float s1, float *__restrict__ out, int64_t ldo) {
   constexpr int GPB = kBlock / G;
   const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
@@ -218,8 +218,16 @@ __global__ __launch_bounds__(kBlock) void gather_select_vec(
   for (int c = lane * 4; c < H; c += G * 4) {
     float4 v[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-      if (e0 + k < E) v[k] = mul4(ld4(D + off[k] + c), sc[k]);
+    for (int k = 0; k < R; ++k) {
+      if (e0 + k < E) {
+        v[k] = mul4(ld4(D + off[k] + c), sc[k]);
+        if (base) {  // out = base + gathered (gradient accumulation fused into the gather)
+          float4 t = ld4(base + (e0 + k) * ldb + c);
+          add4(t, v[k]);
+          v[k] = t;
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k)
       if (e0 + k < E) st4(out + (e0 + k) * ldo + c, v[k]);
@@ -228,15 +236,18 @@ __global__ __launch_bounds__(kBlock) void gather_select_vec(
 
 __global__ __launch_bounds__(kBlock) void gather_select_scalar(
     const float *__restrict__ D, int64_t ldd, const int32_t *__restrict__ dst,
-    const uint8_t *__restrict__ flag, const float *__restrict__ ew, int64_t E, int H,
-    float s0, float s1, float *__restrict__ out, int64_t ldo) {
+    const uint8_t *__restrict__ flag, const float *__restrict__ ew, const float *__restrict__ base,
+    int64_t ldb, int64_t E, int H, float s0, float s1, float *__restrict__ out, int64_t ldo) {
   const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
   if (e >= E) return;
   const bool f = flag && flag[e];
   float s = f ? s1 : s0;
   if (ew) s *= ew[e];
   const float *d = D + (int64_t)dst[e] * ldd + (f ? H : 0);
-  for (int c = threadIdx.x % kWave; c < H; c += kWave) out[e * ldo + c] = d[c] * s;
+  for (int c = threadIdx.x % kWave; c < H; c += kWave) {
+    const float v = d[c] * s;
+    out[e * ldo + c] = base ? base[e * ldb + c] + v : v;
+  }
 }
 
 // Y[e] = ((G0 + coef*G1) + (P[a,0:H] - P[b,H:2H])) + bias     (reference order,
@@ -580,21 +591,21 @@ int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx, const float
 }
 
 int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst, const uint8_t *flag,
-                      const float *edge_w, int64_t E, int H, float s0, float s1, float *out,
-                      int64_t ldo, void *stream) {
-  if (E < 0 || H <= 0 || ldd < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
+                      const float *edge_w, const float *base, int64_t ldb, int64_t E, int H,
+                      float s0, float s1, float *out, int64_t ldo, void *stream) {
+  if (E < 0 || H <= 0 || ldd < 2 * H || ldo < H || (base && ldb < H)) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
   if (!D || !dst || !out) return DMP_ERR_BAD_ARG;
   if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(H, {ldd, ldo}, {D, out})) {
+  if (vec_ok(H, {ldd, ldo, base ? ldb : 0}, {D, out, base})) {
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(E, (kBlock / G) * 4);
-      if (edge_w) gather_select_vec<G, 4, true><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
-      else gather_select_vec<G, 4, false><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+      if (edge_w) gather_select_vec<G, 4, true><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, base, ldb, E, H, s0, s1, out, ldo);
+      else gather_select_vec<G, 4, false><<<nb, kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, base, ldb, E, H, s0, s1, out, ldo);
     });
   } else {
-    gather_select_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, E, H, s0, s1, out, ldo);
+    gather_select_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(D, ldd, dst, flag, edge_w, base, ldb, E, H, s0, s1, out, ldo);
   }
   return check_launch();
 }

@@ -1,0 +1,250 @@
+// Row-wise epilogue kernels of the fused DMPLayer (gfx950): the elementwise steps between
+// the GEMMs and the aggregation kernels, each a single streaming pass that also emits the
+// column sums the bias gradients need (as per-workgroup partial rows, reduced by
+// reduce_partials in a fixed order -> bit-stable, no atomics).
+//
+//   gate_residual        out  = prev + gate (.) upd            (dmpnn.py:263-273: v*gate, residual add)
+//   scale_rows_colsum    dUpd = gate (.) dOut ; colsum(dUpd)   (its backward + d b2 of the MLP)
+//   relu_bwd_colsum      dPre = act>0 ? dH : 0 ; colsum(dPre)  (ReLU backward + d b0 of the MLP)
+//   bwd_g_colsum         dG   = [dY | coef[dst] dY] ; colsum(dY)  (edge_combine backward + d ebias)
+//   colsum               colsum(A)
+//   reduce_partials      out[l] = sum_s partial[s, l]          (also the split-K dW reduction)
+//
+// All HBM-bound; G = H/4 lanes per row, float4 per lane, U rows in flight per group,
+// persistent workgroups (<= kMaxPartials) walking row chunks in a grid-stride loop.
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+constexpr int kMaxPartials = 1024;  // partial rows written by one launch (4 workgroups per CU)
+constexpr int kU = 4;               // rows per group per iteration
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ float4 mul4(const float4 &a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4 };
+
+struct RowArgs {
+  const float *a; int64_t lda;   // first input  (prev | dOut | dH  | dY | A)
+  const float *b; int64_t ldb;   // second input (upd  |  -   | act | -  | -)
+  const float *rowscale;         // gate [R] or coef [N] (OP_BWD_G_CS, indexed through dst)
+  const int32_t *dst;            // OP_BWD_G_CS only
+  float *out; int64_t ldo;       // output (may be NULL for OP_SCALE_CS without gate / OP_COLSUM)
+  float *partial;                // [gridDim.x, H] column-sum partials (NULL for OP_GATE_RES)
+  int64_t R; int H;
+};
+
+template <int G, int OP>
+__global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
+  constexpr int GPB = kBlock / G;
+  __shared__ float4 red[kBlock];
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t chunk = (int64_t)GPB * kU;
+  for (int c0 = 0; c0 < p.H; c0 += G * 4) {
+    const int c = c0 + lane * 4;
+    const bool act = c < p.H;
+    float4 cs = zero4();
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < p.R; base += (int64_t)gridDim.x * chunk) {
+      const int64_t r0 = base + (int64_t)grp * kU;
+      // per-row scalars: lanes 0..kU-1 fetch, then broadcast (all lanes of the group take part)
+      float ms = 1.f;
+      if (lane < kU && r0 + lane < p.R) {
+        if (OP == OP_GATE_RES || OP == OP_SCALE_CS) ms = p.rowscale ? p.rowscale[r0 + lane] : 1.f;
+        if (OP == OP_BWD_G_CS) ms = p.rowscale[p.dst[r0 + lane]];
+      }
+      float sc[kU];
+#pragma unroll
+      for (int k = 0; k < kU; ++k) sc[k] = __shfl(ms, k, G);
+      if (!act) continue;
+      float4 x[kU], y[kU];
+#pragma unroll
+      for (int k = 0; k < kU; ++k) {
+        const int64_t r = r0 + k;
+        if (r < p.R) {
+          if (OP == OP_GATE_RES) {
+            x[k] = p.a ? ld4(p.a + r * p.lda + c) : zero4();
+            y[k] = ld4(p.b + r * p.ldb + c);
+          } else if (OP == OP_RELU_BWD_CS) {
+            x[k] = ld4(p.a + r * p.lda + c);
+            y[k] = ld4(p.b + r * p.ldb + c);
+          } else {
+            x[k] = ld4(p.a + r * p.lda + c);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kU; ++k) {
+        const int64_t r = r0 + k;
+        if (r >= p.R) continue;
+        if (OP == OP_GATE_RES) {
+          float4 t = p.rowscale ? mul4(y[k], sc[k]) : y[k];  // (upd * gate), then + prev: reference order
+          if (p.a) add4(t, x[k]);
+          st4(p.out + r * p.ldo + c, t);
+        } else if (OP == OP_SCALE_CS) {
+          float4 t = p.rowscale ? mul4(x[k], sc[k]) : x[k];
+          if (p.out) st4(p.out + r * p.ldo + c, t);
+          add4(cs, t);
+        } else if (OP == OP_RELU_BWD_CS) {
+          float4 t = make_float4(y[k].x > 0.f ? x[k].x : 0.f, y[k].y > 0.f ? x[k].y : 0.f,
+                                 y[k].z > 0.f ? x[k].z : 0.f, y[k].w > 0.f ? x[k].w : 0.f);
+          st4(p.out + r * p.ldo + c, t);
+          add4(cs, t);
+        } else if (OP == OP_BWD_G_CS) {
+          st4(p.out + r * p.ldo + c, x[k]);
+          st4(p.out + r * p.ldo + p.H + c, mul4(x[k], sc[k]));
+          add4(cs, x[k]);
+        } else {
+          add4(cs, x[k]);
+        }
+      }
+    }
+    if (OP != OP_GATE_RES) {
+      // fixed-order combine of the groups' column partials
+      red[threadIdx.x] = cs;
+      __syncthreads();
+      if (grp == 0 && act) {
+        float4 t = red[lane];
+#pragma unroll
+        for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
+        st4(p.partial + (int64_t)blockIdx.x * p.H + c, t);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// out[l..l+3] = sum_s partial[s, l..l+3], s ascending within a group, groups combined in order.
+template <bool ACCUM>
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float *__restrict__ partial, int64_t S,
+                                                                 int64_t L, float *__restrict__ out) {
+  constexpr int G = 32, GPB = kBlock / G;
+  __shared__ float4 red[kBlock];
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t l = ((int64_t)blockIdx.x * G + lane) * 4;
+  float4 acc = zero4();
+  if (l < L) {
+    // group g owns the contiguous slice of S/GPB rows -> one fixed summation order
+    const int64_t per = (S + GPB - 1) / GPB;
+    const int64_t s0 = grp * per, s1 = min(S, s0 + per);
+    int64_t s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const float4 a = ld4(partial + s * L + l), b = ld4(partial + (s + 1) * L + l);
+      const float4 c = ld4(partial + (s + 2) * L + l), d = ld4(partial + (s + 3) * L + l);
+      add4(acc, a); add4(acc, b); add4(acc, c); add4(acc, d);
+    }
+    for (; s < s1; ++s) add4(acc, ld4(partial + s * L + l));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (grp == 0 && l < L) {
+    float4 t = red[lane];
+#pragma unroll
+    for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
+    if (ACCUM) add4(t, ld4(out + l));
+    st4(out + l, t);
+  }
+}
+
+inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
+
+inline unsigned grid_for(int64_t R, int G) {
+  const int64_t chunk = (int64_t)(kBlock / G) * kU;
+  const int64_t nb = (R + chunk - 1) / chunk;
+  return (unsigned)(nb < kMaxPartials ? (nb > 0 ? nb : 1) : kMaxPartials);
+}
+
+template <int OP>
+int launch_rowop(const RowArgs &p, hipStream_t st) {
+  const int g = group_lanes(p.H);
+  if (g == 16) rowop_kernel<16, OP><<<grid_for(p.R, 16), kBlock, 0, st>>>(p);
+  else if (g == 32) rowop_kernel<32, OP><<<grid_for(p.R, 32), kBlock, 0, st>>>(p);
+  else rowop_kernel<64, OP><<<grid_for(p.R, 64), kBlock, 0, st>>>(p);
+  return check_launch();
+}
+
+inline bool ok16(const void *q) { return !q || aligned16(q); }
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int64_t dmp_colsum_partial_rows(int64_t rows, int H) {
+  if (rows <= 0 || H <= 0) return 1;
+  return (int64_t)grid_for(rows, group_lanes(H));
+}
+
+#define DMP_ROW_CHECK(cond) \
+  if (!(cond)) return DMP_ERR_BAD_ARG
+
+static int vec_shape_ok(int H, int64_t l0, int64_t l1, int64_t l2) {
+  return H > 0 && H % 4 == 0 && l0 % 4 == 0 && l1 % 4 == 0 && l2 % 4 == 0;
+}
+
+int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t ldu, const float *gate,
+                      int64_t R, int H, float *out, int64_t ldo, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0);
+  if (R == 0) return DMP_OK;
+  DMP_ROW_CHECK(upd && out && ldu >= H && ldo >= H && (!prev || ldp >= H));
+  if (!vec_shape_ok(H, prev ? ldp : 0, ldu, ldo) || !ok16(prev) || !ok16(upd) || !ok16(out)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{prev, ldp, upd, ldu, gate, nullptr, out, ldo, nullptr, R, H};
+  return launch_rowop<OP_GATE_RES>(p, (hipStream_t)stream);
+}
+
+int dmp_scale_rows_colsum(const float *dOut, int64_t ldd, const float *gate, int64_t R, int H, float *dUpd,
+                          int64_t ldu, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0 && partial);
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(dOut && ldd >= H && (!dUpd || ldu >= H) && (!gate || dUpd));
+  if (!vec_shape_ok(H, ldd, dUpd ? ldu : 0, 0) || !ok16(dOut) || !ok16(dUpd) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{dOut, ldd, nullptr, 0, gate, nullptr, dUpd, ldu, partial, R, H};
+  return launch_rowop<OP_SCALE_CS>(p, (hipStream_t)stream);
+}
+
+int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda, int64_t R, int H,
+                        float *dPre, int64_t ldp, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0 && partial);
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(dH && act && dPre && ldh >= H && lda >= H && ldp >= H);
+  if (!vec_shape_ok(H, ldh, lda, ldp) || !ok16(dH) || !ok16(act) || !ok16(dPre) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{dH, ldh, act, lda, nullptr, nullptr, dPre, ldp, partial, R, H};
+  return launch_rowop<OP_RELU_BWD_CS>(p, (hipStream_t)stream);
+}
+
+int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef, const int32_t *dst,
+                                  int64_t E, int H, float *dG, int64_t ldg, float *partial, void *stream) {
+  DMP_ROW_CHECK(E >= 0 && H > 0 && partial);
+  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(dY && coef && dst && dG && ldy >= H && ldg >= 2 * H);
+  if (!vec_shape_ok(H, ldy, ldg, 0) || !ok16(dY) || !ok16(dG) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{dY, ldy, nullptr, 0, coef, dst, dG, ldg, partial, E, H};
+  return launch_rowop<OP_BWD_G_CS>(p, (hipStream_t)stream);
+}
+
+int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0 && partial);
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(A && lda >= H);
+  if (!vec_shape_ok(H, lda, 0, 0) || !ok16(A) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{A, lda, nullptr, 0, nullptr, nullptr, nullptr, 0, partial, R, H};
+  return launch_rowop<OP_COLSUM>(p, (hipStream_t)stream);
+}
+
+int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out, int accumulate, void *stream) {
+  DMP_ROW_CHECK(S >= 0 && L > 0 && out);
+  if (L % 4 || !ok16(partial) || !ok16(out)) return DMP_ERR_UNSUPPORTED;
+  DMP_ROW_CHECK(S == 0 || partial);
+  const unsigned nb = (unsigned)((L / 4 + 31) / 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (accumulate) reduce_partials_kernel<true><<<nb, kBlock, 0, st>>>(partial, S, L, out);
+  else reduce_partials_kernel<false><<<nb, kBlock, 0, st>>>(partial, S, L, out);
+  return check_launch();
+}
+
+}  // extern "C"

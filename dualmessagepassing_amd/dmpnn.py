@@ -153,6 +153,43 @@ class DMPLayer(nn.Module):
 
         return node_out, edge_out
 
+    # ---- single-node fused path (fused.py): layer + gate + residual in one autograd node
+    def fused_ok(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None):
+        """True when the hand-orchestrated fused path computes exactly this layer's function."""
+        if not (isinstance(graph, BatchedGraph) and REVFLAG in graph.edata):
+            return False
+        if self.input_dim != self.hidden_dim or self.hidden_dim % 4 != 0 or self.nbias is None:
+            return False
+        if self.drop.p > 0.0 and self.training:
+            return False
+        for mlp in (self.nmlp, self.emlp):
+            if len(mlp) != 3 or not isinstance(mlp[0], nn.Linear) or type(mlp[1]) is not nn.ReLU \
+                    or not isinstance(mlp[2], nn.Linear) or mlp[0].bias is None or mlp[2].bias is None:
+                return False
+        for t in (node_feat, edge_feat):
+            if t is None or not t.is_cuda or t.dtype != th.float32 or t.dim() != 2 or t.size(1) != self.hidden_dim:
+                return False
+        for g in (v_gate, e_gate):
+            if g is not None and (g.requires_grad or g.dtype != th.float32 or g.numel() != g.size(0)):
+                return False
+        return True
+
+    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True):
+        """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
+        ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
+        loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
+        from . import fused
+        g = graph
+        g.ndata[NODEFEAT] = node_feat
+        if OUTDEGREE not in g.ndata:
+            g.ndata[OUTDEGREE] = g.out_degrees()
+        g.edata[EDGEFEAT] = edge_feat
+        ix = g.index()
+        coef = ix.degree_coef(g.ndata[OUTDEGREE])
+        vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
+        eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
+        return fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self)
+
     def extra_repr(self):
         return "in=%s, out=%s" % (self.input_dim, self.hidden_dim)
 
@@ -210,6 +247,12 @@ class DMPNNRepMixin:
             e_outputs = [p_e_emb]
 
         for layer in self.p_rep_net[self.rep_key]:
+            if p_v_zero_mask is None and p_e_zero_mask is None and getattr(self, "use_fused", True) \
+                    and hasattr(layer, "fused_ok") and layer.fused_ok(pattern, v_outputs[-1], e_outputs[-1]):
+                v, e = layer.forward_fused(pattern, v_outputs[-1], e_outputs[-1], None, None, self.rep_residual)
+                v_outputs.append(v)
+                e_outputs.append(e)
+                continue
             v, e = layer(pattern, v_outputs[-1], e_outputs[-1])
             if p_v_zero_mask is not None:
                 v = v.masked_fill(p_v_zero_mask, 0.0)
@@ -243,6 +286,12 @@ class DMPNNRepMixin:
             e_outputs = [g_e_emb]
 
         for layer in self.g_rep_net[self.rep_key]:
+            if getattr(self, "use_fused", True) and hasattr(layer, "fused_ok") \
+                    and layer.fused_ok(graph, v_outputs[-1], e_outputs[-1], v_gate, e_gate):
+                v, e = layer.forward_fused(graph, v_outputs[-1], e_outputs[-1], v_gate, e_gate, self.rep_residual)
+                v_outputs.append(v)
+                e_outputs.append(e)
+                continue
             v, e = layer(graph, v_outputs[-1], e_outputs[-1])
             if v_gate is not None:
                 v = v * v_gate

@@ -1,0 +1,207 @@
+"""One DMPLayer (+ the rep-net's gate and residual) as a single autograd node.
+
+Same math as ``dmpnn.dual_message_passing`` + the two 2-layer ReLU MLPs + ``v*gate`` +
+residual add (SubgraphCountingMatching/models/dmpnn.py:111-166,245-277), but forward and
+backward are orchestrated by hand so that every elementwise step between the GEMMs is one
+HIP streaming pass (``csrc/dmp_fused.hip``) and gradient accumulation happens inside the
+kernels / GEMM epilogues instead of as separate ``add`` launches:
+
+  forward   S=seg_sum2(Z) | XP=X[Wnl|Wdst|Wsrc] | T=XP0+S[Win;Wout]+bn | nmlp | Xn=X+gv*On
+            G=Z[Wel|Wsrc-Wdst] | Y=edge_combine(G,XP12,be) | emlp | Zn=Z+ge*Oe
+  backward  gate*dOut (+colsum) -> GEMMs -> relu_bwd (+colsum) -> GEMMs -> bwd_g (+colsum),
+            seg_sum2 over the incidence CSR, dZ = dZn + gather_select(dS), dZ += dG Wes^T
+  saved     X, Z, S, T, H1n, Y, H1e  (two new [E,H] tensors per layer)
+
+Eligibility (``DMPLayer.fused_ok``): 2-layer MLPs, ReLU, no BatchNorm, bias, no active dropout,
+square weights, H % 4 == 0, ``is_reversed`` present, gates without gradient.  Anything else
+takes the modular path (same kernels, torch autograd in between).
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+
+
+def _partials(rows, H, dev):
+    lib = _lib.load()
+    return torch.empty((int(lib.dmp_colsum_partial_rows(rows, H)), H), dtype=torch.float32, device=dev)
+
+
+def reduce_partials(partial, out=None, accumulate=False):
+    """``out[l] (+)= sum_s partial[s, l]`` in a fixed order (HIP)."""
+    lib = _lib.load()
+    S = partial.size(0)
+    L = partial.numel() // max(S, 1)
+    if out is None:
+        out = torch.empty(L, dtype=torch.float32, device=partial.device)
+    check(lib.dmp_reduce_partials(ptr(partial), S, L, ptr(out), int(accumulate), stream_ptr()), "dmp_reduce_partials")
+    return out
+
+
+def gate_residual(prev, upd, gate):
+    lib = _lib.load()
+    R, H = upd.shape
+    out = torch.empty_like(upd)
+    with _lib.timed("gate_residual[H=%d,R=%d]" % (H, R), 4 * H * R * (3 if prev is not None else 2) + (4 * R if gate is not None else 0)):
+        check(lib.dmp_gate_residual(ptr(prev), H, ptr(upd), H, ptr(gate), R, H, ptr(out), H, stream_ptr()),
+              "dmp_gate_residual")
+    return out
+
+
+def scale_rows_colsum(d_out, gate):
+    """-> (gate (.) d_out  [aliases d_out when gate is None], column sums [H])."""
+    lib = _lib.load()
+    R, H = d_out.shape
+    part = _partials(R, H, d_out.device)
+    d_upd = torch.empty_like(d_out) if gate is not None else None
+    with _lib.timed("scale_rows_colsum[H=%d,R=%d]" % (H, R), 4 * H * R * (2 if gate is not None else 1)):
+        check(lib.dmp_scale_rows_colsum(ptr(d_out), H, ptr(gate), R, H, ptr(d_upd), H, ptr(part), stream_ptr()),
+              "dmp_scale_rows_colsum")
+    return (d_upd if gate is not None else d_out), reduce_partials(part)
+
+
+def relu_bwd_colsum_(d_h, act):
+    """In place: d_h <- act > 0 ? d_h : 0; returns (d_h, column sums [H])."""
+    lib = _lib.load()
+    R, H = d_h.shape
+    part = _partials(R, H, d_h.device)
+    with _lib.timed("relu_bwd_colsum[H=%d,R=%d]" % (H, R), 12 * H * R):
+        check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, ptr(d_h), H, ptr(part), stream_ptr()),
+              "dmp_relu_bwd_colsum")
+    return d_h, reduce_partials(part)
+
+
+def bwd_g_colsum(d_y, coef, dst32):
+    lib = _lib.load()
+    E, H = d_y.shape
+    part = _partials(E, H, d_y.device)
+    d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_y.device)
+    with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]" % (H, E), 12 * H * E + 4 * E + 4 * coef.numel()):
+        check(lib.dmp_edge_combine_bwd_g_colsum(ptr(d_y), H, ptr(coef), ptr(dst32), E, H, ptr(d_g), 2 * H, ptr(part),
+                                                stream_ptr()), "dmp_edge_combine_bwd_g_colsum")
+    return d_g, reduce_partials(part)
+
+
+def colsum(a):
+    lib = _lib.load()
+    R, H = a.shape
+    part = _partials(R, H, a.device)
+    check(lib.dmp_colsum_partials(ptr(a), H, R, H, ptr(part), stream_ptr()), "dmp_colsum_partials")
+    return reduce_partials(part)
+
+
+def atb(a, b):
+    """``a.T @ b`` for tall-skinny operands: batched GEMM over 4096-row slices (MFMA through
+    hipBLASLt) + the fixed-order HIP reduction of the slice products."""
+    R = a.size(0)
+    rows = ops._SPLITK_ROWS
+    if R < 4 * rows:
+        return a.t() @ b
+    S = R // rows
+    main = S * rows
+    part = torch.bmm(a[:main].view(S, rows, a.size(1)).transpose(1, 2), b[:main].view(S, rows, b.size(1)))
+    out = reduce_partials(part.view(S, -1)).view(a.size(1), b.size(1))
+    if main < R:
+        out.addmm_(a[main:].t(), b[main:])
+    return out
+
+
+def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H):
+    lib = _lib.load()
+    E = index.num_edges
+    Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
+    with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 9 * E + 4 * index.num_nodes):
+        check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(bias), ptr(index.src32), ptr(index.dst32),
+                                   ptr(index.rev8), E, H, ptr(Y), H, stream_ptr()), "dmp_edge_combine")
+    return Y
+
+
+class _FusedDMPLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, in_w, out_w, src_w, dst_w, nloop_w, eloop_w,
+                nbias, ebias, nW0, nb0, nW2, nb2, eW0, eb0, eW2, eb2):
+        _lib.require_gpu(x, z)
+        H = nloop_w.size(1)
+        x, z = x.contiguous(), z.contiguous()
+        N = index.num_nodes
+        # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
+        S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
+        Wio = torch.cat([in_w, out_w], dim=0)
+        Wx = torch.cat([nloop_w, dst_w, src_w], dim=1)
+        XP = x @ Wx                                       # [X Wnl | X Wdst | X Wsrc]
+        T = S @ Wio
+        T += XP[:, :H]
+        T += nbias
+        H1n = torch._addmm_activation(nb0, T, nW0.t(), use_gelu=False)
+        On = torch.addmm(nb2, H1n, nW2.t())
+        xn = gate_residual(x if residual else None, On, v_gate)
+        # ---- edge side (dmpnn.py:112,120,124 + 142-156)
+        Wes = torch.cat([eloop_w, src_w - dst_w], dim=1)
+        G = z @ Wes
+        Y = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, ebias, coef, index, H)
+        del G
+        H1e = torch._addmm_activation(eb0, Y, eW0.t(), use_gelu=False)
+        Oe = torch.addmm(eb2, H1e, eW2.t())
+        zn = gate_residual(z if residual else None, Oe, e_gate)
+        ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
+        ctx.v_gate, ctx.e_gate = v_gate, e_gate
+        ctx.save_for_backward(x, z, S, T, H1n, Y, H1e, Wio, Wx, Wes, nW0, nW2, eW0, eW2)
+        return xn, zn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dxn, dzn):
+        x, z, S, T, H1n, Y, H1e, Wio, Wx, Wes, nW0, nW2, eW0, eW2 = ctx.saved_tensors
+        ix, coef, H = ctx.index, ctx.coef, ctx.H
+        N = ix.num_nodes
+        dxn, dzn = dxn.contiguous(), dzn.contiguous()
+        # ---- edge side, down to the gathered node projections
+        dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
+        dW2e = atb(dOe, H1e)
+        dH1e = dOe @ eW2
+        dPre, db0e = relu_bwd_colsum_(dH1e, H1e)
+        dW0e = atb(dPre, Y)
+        dY = dPre @ eW0
+        del dPre, dH1e
+        dG, deb = bwd_g_colsum(dY, coef, ix.dst32)
+        inc_ptr, inc_ent = ix.incidence()
+        dP = ops.seg_sum_raw(dY, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
+        del dY
+        dWes = atb(z, dG)
+        # ---- node side
+        dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
+        dW2n = atb(dOn, H1n)
+        dH1n = dOn @ nW2
+        dPn, db0n = relu_bwd_colsum_(dH1n, H1n)
+        dW0n = atb(dPn, T)
+        dT = dPn @ nW0
+        dnb = colsum(dT)
+        dS = dT @ Wio.t()
+        dWio = atb(S, dT)
+        dXP = torch.cat([dT, dP], dim=1)
+        dWx = atb(x, dXP)
+        dx = None
+        if ctx.needs_input_grad[3]:
+            dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
+        # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
+        dz = None
+        if ctx.needs_input_grad[4]:
+            dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0, base=dzn if ctx.residual else None)
+            dz.addmm_(dG, Wes.t())
+        d_in, d_out = dWio[:H], dWio[H:]
+        d_nloop = dWx[:, :H]
+        d_dst = dWx[:, H:2 * H] - dWes[:, H:]
+        d_src = dWx[:, 2 * H:] + dWes[:, H:]
+        d_eloop = dWes[:, :H]
+        return (None, None, None, dx, dz, None, None, d_in, d_out, d_src, d_dst, d_nloop, d_eloop, dnb, deb,
+                dW0n, db0n, dW2n, db2n, dW0e, db0e, dW2e, db2e)
+
+
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer):
+    n0, n2 = layer.nmlp[0], layer.nmlp[2]
+    e0, e2 = layer.emlp[0], layer.emlp[2]
+    return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, layer.in_weight, layer.out_weight,
+                                layer.src_weight, layer.dst_weight, layer.nloop_weight, layer.eloop_weight,
+                                layer.nbias, layer.ebias, n0.weight, n0.bias, n2.weight, n2.bias, e0.weight, e0.bias,
+                                e2.weight, e2.bias)

@@ -74,16 +74,21 @@ def gather_rows_raw(X, idx32, edge_w=None):
     return out
 
 
-def gather_select_raw(D, dst32, rev8, H, edge_w=None, s0=1.0, s1=1.0):
+def gather_select_raw(D, dst32, rev8, H, edge_w=None, s0=1.0, s1=1.0, base=None):
+    """``out[e] = base[e] + w_e * (rev[e] ? s1 D[dst e, H:] : s0 D[dst e, :H])`` (base optional)."""
     lib = _lib.load()
-    _lib.require_gpu(D, dst32, rev8, edge_w)
+    _lib.require_gpu(D, dst32, rev8, edge_w, base)
     D, ldd = _mat(D)
     E = dst32.numel()
     out = torch.empty((E, H), dtype=torch.float32, device=D.device)
     ew = _vec(edge_w, torch.float32)
-    with _lib.timed("gather_select[H=%d,E=%d]" % (H, E), 4 * H * (E + 2 * D.size(0)) + 5 * E):
-        check(lib.dmp_gather_select(ptr(D), ldd, ptr(dst32), ptr(rev8), ptr(ew), E, H, s0, s1, ptr(out), H,
-                                    stream_ptr()), "dmp_gather_select")
+    ldb = 0
+    if base is not None:
+        base, ldb = _mat(base)
+    nbytes = 4 * H * (E + 2 * D.size(0)) + 5 * E + (4 * H * E if base is not None else 0)
+    with _lib.timed("gather_select%s[H=%d,E=%d]" % ("+base" if base is not None else "", H, E), nbytes):
+        check(lib.dmp_gather_select(ptr(D), ldd, ptr(dst32), ptr(rev8), ptr(ew), ptr(base), ldb, E, H, s0, s1,
+                                    ptr(out), H, stream_ptr()), "dmp_gather_select")
     return out
 
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 2
+#define DMP_ABI_VERSION 3
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -223,14 +223,14 @@ int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx,
                     int64_t ldo, void *stream);
 
 /*
- * Backward of dmp_seg_sum2 over the in-CSR:
- *     out[e, :] = w_e * (flag[e] ? s1 * D[dst[e], H:2H] : s0 * D[dst[e], 0:H])
- *   D [N, ldd>=2H], out [E, ldo>=H], flag may be NULL (all 0)
+ * Backward of dmp_seg_sum2 over the in-CSR, optionally accumulating onto `base`:
+ *     out[e, :] = base[e, :] + w_e * (flag[e] ? s1 * D[dst[e], H:2H] : s0 * D[dst[e], 0:H])
+ *   D [N, ldd>=2H], out [E, ldo>=H], flag may be NULL (all 0), base [E, ldb>=H] or NULL (0)
  */
 int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst,
                       const uint8_t *flag, const float *edge_w,
-                      int64_t num_edges, int H, float s0, float s1, float *out,
-                      int64_t ldo, void *stream);
+                      const float *base, int64_t ldb, int64_t num_edges, int H,
+                      float s0, float s1, float *out, int64_t ldo, void *stream);
 
 /*
  * DMPLayer edge pre-activation (dmpnn.py:112,120,124,142-151), project-then-gather:
@@ -281,6 +281,51 @@ int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X,
                         const uint8_t *flag, const float *norm,
                         int64_t num_edges, int H, int comp, float *dZ,
                         int64_t lddz, float *dXe, int64_t lddxe, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Row-wise epilogues of the fused layer (fp32, HBM-bound, H % 4 == 0)       */
+/* ------------------------------------------------------------------------- */
+
+/* Number of partial rows the *_colsum kernels write for `rows` input rows (<= 1024). */
+int64_t dmp_colsum_partial_rows(int64_t rows, int H);
+
+/*
+ * Gate + residual of the rep-net loop (dmpnn.py:263-273: `v = v * v_gate`,
+ * `v_outputs[-1] + v`):   out[r] = prev[r] + gate[r] * upd[r]
+ * prev may be NULL (no residual), gate may be NULL (pattern side: no gate).
+ */
+int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t ldu,
+                      const float *gate, int64_t rows, int H, float *out, int64_t ldo,
+                      void *stream);
+
+/*
+ * Backward of the gate and the bias gradient of the layer before it:
+ *     dUpd[r] = gate[r] * dOut[r];  partial[b, :] = column sums of dUpd over workgroup b's rows
+ * gate NULL: dUpd is dOut itself (pass dUpd = NULL), only the column sums are produced.
+ * partial: [dmp_colsum_partial_rows(rows, H), H]; finish with dmp_reduce_partials.
+ */
+int dmp_scale_rows_colsum(const float *dOut, int64_t ldd, const float *gate, int64_t rows,
+                          int H, float *dUpd, int64_t ldu, float *partial, void *stream);
+
+/* ReLU backward (`threshold_backward`: dPre = act > 0 ? dH : 0; the MLPs of dmpnn.py:45-60)
+ * + column sums of dPre (gradient of the preceding Linear's bias).  dPre may alias dH. */
+int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda,
+                        int64_t rows, int H, float *dPre, int64_t ldp, float *partial,
+                        void *stream);
+
+/* dmp_edge_combine_bwd_g + column sums of dY (gradient of ebias, dmpnn.py:148-149). */
+int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef,
+                                  const int32_t *dst, int64_t num_edges, int H, float *dG,
+                                  int64_t ldg, float *partial, void *stream);
+
+/* Column-sum partials of A [rows, H]. */
+int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float *partial,
+                        void *stream);
+
+/* out[l] (+)= sum_s partial[s, l], s in a fixed order; L % 4 == 0.  Also reduces the
+ * split-K partial products of the weight gradients. */
+int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out,
+                        int accumulate, void *stream);
 
 #ifdef __cplusplus
 }

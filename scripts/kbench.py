@@ -61,7 +61,7 @@ report("seg_sum (in-CSR)", lambda i: lib.dmp_seg_sum(Z[i].data_ptr(), h, ix.in_p
        4 * h * e + 4 * h * n + 4 * e + 4 * (n + 1))
 report("seg_sum2 (incidence)", lambda i: lib.dmp_seg_sum2(Z[i].data_ptr(), h, inc_ptr.data_ptr(), inc_ent.data_ptr(), None, n, h, 1.0, -1.0, OUT_N2[i].data_ptr(), 2 * h, 1, st),
        4 * h * e + 8 * h * n + 8 * e + 4 * (n + 1))
-report("gather_select", lambda i: lib.dmp_gather_select(P2[i].data_ptr(), 2 * h, ix.dst32.data_ptr(), ix.rev8.data_ptr(), None, e, h, -1.0, 1.0, OUT_E[i].data_ptr(), h, st),
+report("gather_select", lambda i: lib.dmp_gather_select(P2[i].data_ptr(), 2 * h, ix.dst32.data_ptr(), ix.rev8.data_ptr(), None, None, 0, e, h, -1.0, 1.0, OUT_E[i].data_ptr(), h, st),
        4 * h * (e + 2 * n) + 5 * e)
 report("gather_rows", lambda i: lib.dmp_gather_rows(P2[i].data_ptr(), 2 * h, ix.dst32.data_ptr(), None, e, h, OUT_E[i].data_ptr(), h, st),
        4 * h * (e + n) + 4 * e)

@@ -180,3 +180,59 @@ def test_cpu_tensors_are_rejected():
     g = BatchedGraph(th.tensor([0, 1]), th.tensor([1, 0]), 2)
     with pytest.raises(_lib.DmpError):
         layer(g, th.randn(2, 8), th.randn(2, 8))
+
+
+@pytest.mark.parametrize("batch,n,m,h,gates,residual", [
+    (8, 16, 40, 32, True, True), (8, 16, 40, 32, False, True), (8, 16, 40, 32, True, False),
+    (64, 64, 256, 128, True, True),      # enough rows for the split-K weight-gradient path
+    (3, 5, 7, 20, True, True),
+])
+def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, residual, gpu):
+    """The single-node fused layer (fused.py) == the modular layer + gate + residual == oracle."""
+    from dualmessagepassing_amd.dmpnn import DMPNNRep
+    from dualmessagepassing_amd.graph import BatchedGraph
+    rng = np.random.default_rng(n * h + batch)
+    src, dst, rev, N, bnn, bne = er_batch(batch, n, m, rng)
+    E, L = len(src), 2
+    gen = th.Generator().manual_seed(h + n)
+    layers = [O.random_dmp_params(h, h, gen) for _ in range(L)]
+    v0, e0 = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
+    wv, we = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
+    vg = (th.rand(N, 1, generator=gen) < 0.7).float() if gates else None
+    eg = (th.rand(E, 1, generator=gen) < 0.7).float() if gates else None
+    ts, td, tr = _t(src), _t(dst), _t(rev)
+    # oracle
+    lo = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+    vo, eo = v0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+    rv, re = O.dmpnn_graph_rep(lo, ts, td, tr, O.out_degrees(ts, N), vo, eo, vg, eg, residual, "relu")
+    ((rv * wv).sum() + (re * we).sum()).backward()
+    results = {}
+    for fused in (True, False):
+        net = DMPNNRep(hid_dim=h, rep_num_graph_layers=L, rep_num_pattern_layers=L, share_rep_net=True,
+                       rep_residual=residual, rep_dmpnn_batch_norm=False, rep_act_func="relu")
+        sd = {}
+        for i, p in enumerate(layers):
+            for k, v in p.items():
+                sd["g_rep_net.dmpnn.graph_dmpnn_(%d).%s" % (i, k)] = v
+                sd["p_rep_net.dmpnn.graph_dmpnn_(%d).%s" % (i, k)] = v
+        net.load_state_dict(sd, strict=True)
+        net.to(gpu)
+        net.use_fused = fused
+        g = BatchedGraph(ts.to(gpu), td.to(gpu), N, _t(bnn).to(gpu), _t(bne).to(gpu))
+        g.edata["is_reversed"] = tr.to(gpu)
+        vgp, egp = v0.to(gpu).requires_grad_(True), e0.to(gpu).requires_grad_(True)
+        a, b = net.get_graph_rep(g, vgp, egp, v_gate=None if vg is None else vg.to(gpu),
+                                 e_gate=None if eg is None else eg.to(gpu))
+        ((a * wv.to(gpu)).sum() + (b * we.to(gpu)).sum()).backward()
+        results[fused] = (a, b, vgp.grad, egp.grad, {k: p.grad for k, p in net.g_rep_net.named_parameters()})
+        _close(a, rv, 1e-4, 1e-4, "v_rep fused=%s" % fused)
+        _close(b, re, 1e-4, 1e-4, "e_rep fused=%s" % fused)
+        _close(vgp.grad, vo.grad, 1e-4, 1e-4, "dv fused=%s" % fused)
+        _close(egp.grad, eo.grad, 1e-4, 1e-4, "de fused=%s" % fused)
+        for i in range(L):
+            for k, p in lo[i].items():
+                _close(results[fused][4]["dmpnn.graph_dmpnn_(%d).%s" % (i, k)], p.grad, 3e-4, 3e-4,
+                       "grad %d.%s fused=%s" % (i, k, fused))
+    # fused vs modular: same kernels and GEMMs, only the orchestration differs
+    for x, y in zip(results[True][:4], results[False][:4]):
+        assert th.allclose(x, y, rtol=1e-5, atol=1e-5)

@@ -174,3 +174,67 @@ def test_config2_size_properties(gpu):
     lhs = (a1.double() * y.double()).sum()
     rhs = (m.double() * ops.gather_rows_raw(y, ix.dst32).double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-7 * abs(float(lhs)) + 1e-3
+
+
+@pytest.mark.parametrize("rows,h", [(1, 4), (37, 8), (1000, 128), (70000, 128), (5000, 256), (300, 512)])
+def test_row_epilogue_kernels(rows, h, gpu):
+    """gate_residual / scale_rows_colsum / relu_bwd_colsum / bwd_g_colsum / colsum / reduce_partials
+    (csrc/dmp_fused.hip) against torch formulas: elementwise parts bit-exact, column sums 1e-5."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(rows + h)
+    a = th.randn(rows, h, generator=gen).to(gpu)
+    b = th.randn(rows, h, generator=gen).to(gpu)
+    gate = (th.rand(rows, generator=gen) < 0.6).float().to(gpu)
+    assert th.equal(fused.gate_residual(a, b, gate), a + b * gate[:, None])
+    assert th.equal(fused.gate_residual(None, b, gate), b * gate[:, None])
+    assert th.equal(fused.gate_residual(a, b, None), a + b)
+    d, cs = fused.scale_rows_colsum(a, gate)
+    assert th.equal(d, a * gate[:, None])
+    assert th.allclose(cs, d.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    d, cs = fused.scale_rows_colsum(a, None)
+    assert d.data_ptr() == a.data_ptr()
+    assert th.allclose(cs, a.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    dh = a.clone()
+    d, cs = fused.relu_bwd_colsum_(dh, b)
+    ref = th.where(b > 0, a, th.zeros_like(a))
+    assert th.equal(d, ref) and d.data_ptr() == dh.data_ptr()
+    assert th.allclose(cs, ref.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    n = max(1, rows // 3)
+    coef = th.rand(n, generator=gen).to(gpu) + 1.0
+    dst = th.randint(0, n, (rows,), generator=gen).int().to(gpu)
+    dg, cs = fused.bwd_g_colsum(a, coef, dst)
+    assert th.equal(dg, th.cat([a, a * coef[dst.long()][:, None]], 1))
+    assert th.allclose(cs, a.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    assert th.allclose(fused.colsum(a), a.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    # two launches give identical bits (fixed reduction tree)
+    assert th.equal(fused.colsum(a), fused.colsum(a))
+    part = th.randn(7, 4 * h, generator=gen).to(gpu)
+    out = fused.reduce_partials(part)
+    assert th.allclose(out, part.sum(0), rtol=1e-6, atol=1e-5)
+    out2 = fused.reduce_partials(part, out.clone(), accumulate=True)
+    assert th.allclose(out2, 2 * part.sum(0), rtol=1e-6, atol=1e-5)
+
+
+def test_split_k_weight_gradient_product(gpu):
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(9)
+    for rows in (100, 16384, 50000):
+        a = th.randn(rows, 128, generator=gen).to(gpu)
+        b = th.randn(rows, 256, generator=gen).to(gpu)
+        ref = (a.double().t() @ b.double()).float()
+        got = fused.atb(a, b)
+        assert th.allclose(got, ref, rtol=1e-4, atol=2e-3)
+
+
+def test_gather_select_with_base(gpu):
+    from dualmessagepassing_amd import ops
+    rng = np.random.default_rng(4)
+    src, dst, rev, n = GRAPHS["er_batch"](rng)
+    ix = _index(src, dst, n, rev, gpu)
+    h = 64
+    gen = th.Generator().manual_seed(2)
+    d2 = th.randn(n, 2 * h, generator=gen).to(gpu)
+    base = th.randn(len(src), h, generator=gen).to(gpu)
+    plain = ops.gather_select_raw(d2, ix.dst32, ix.rev8, h, None, -1.0, 1.0)
+    got = ops.gather_select_raw(d2, ix.dst32, ix.rev8, h, None, -1.0, 1.0, base=base)
+    assert th.equal(got, base + plain)
