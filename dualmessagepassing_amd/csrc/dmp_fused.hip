@@ -26,7 +26,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ float4 mul4(const float4 &a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
-enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4 };
+enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4, OP_RELU_BWD_G_CS = 5 };
 
 struct RowArgs {
   const float *a; int64_t lda;   // first input  (prev | dOut | dH  | dY | A)
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
       float ms = 1.f;
       if (lane < kU && r0 + lane < p.R) {
         if (OP == OP_GATE_RES || OP == OP_SCALE_CS) ms = p.rowscale ? p.rowscale[r0 + lane] : 1.f;
-        if (OP == OP_BWD_G_CS) ms = p.rowscale[p.dst[r0 + lane]];
+        if (OP == OP_BWD_G_CS || OP == OP_RELU_BWD_G_CS) ms = p.rowscale[p.dst[r0 + lane]];
       }
       float sc[kU];
 #pragma unroll
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           if (OP == OP_GATE_RES) {
             x[k] = p.a ? ld4(p.a + r * p.lda + c) : zero4();
             y[k] = ld4(p.b + r * p.ldb + c);
-          } else if (OP == OP_RELU_BWD_CS) {
+          } else if (OP == OP_RELU_BWD_CS || OP == OP_RELU_BWD_G_CS) {
             x[k] = ld4(p.a + r * p.lda + c);
             y[k] = ld4(p.b + r * p.ldb + c);
           } else {
@@ -97,6 +97,12 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           st4(p.out + r * p.ldo + c, x[k]);
           st4(p.out + r * p.ldo + p.H + c, mul4(x[k], sc[k]));
           add4(cs, x[k]);
+        } else if (OP == OP_RELU_BWD_G_CS) {
+          float4 t = make_float4(y[k].x > 0.f ? x[k].x : 0.f, y[k].y > 0.f ? x[k].y : 0.f,
+                                 y[k].z > 0.f ? x[k].z : 0.f, y[k].w > 0.f ? x[k].w : 0.f);
+          st4(p.out + r * p.ldo + c, t);
+          st4(p.out + r * p.ldo + p.H + c, mul4(t, sc[k]));
+          add4(cs, t);
         } else {
           add4(cs, x[k]);
         }
@@ -225,6 +231,17 @@ int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coe
   if (!vec_shape_ok(H, ldy, ldg, 0) || !ok16(dY) || !ok16(dG) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   RowArgs p{dY, ldy, nullptr, 0, coef, dst, dG, ldg, partial, E, H};
   return launch_rowop<OP_BWD_G_CS>(p, (hipStream_t)stream);
+}
+
+int dmp_relu_bwd_g_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda, const float *coef,
+                          const int32_t *dst, int64_t E, int H, float *dG, int64_t ldg, float *partial,
+                          void *stream) {
+  DMP_ROW_CHECK(E >= 0 && H > 0 && partial);
+  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(dH && act && coef && dst && dG && ldh >= H && lda >= H && ldg >= 2 * H);
+  if (!vec_shape_ok(H, ldh, lda, ldg) || !ok16(dH) || !ok16(act) || !ok16(dG) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{dH, ldh, act, lda, coef, dst, dG, ldg, partial, E, H};
+  return launch_rowop<OP_RELU_BWD_G_CS>(p, (hipStream_t)stream);
 }
 
 int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *partial, void *stream) {

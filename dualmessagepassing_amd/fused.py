@@ -6,11 +6,18 @@ backward are orchestrated by hand so that every elementwise step between the GEM
 HIP streaming pass (``csrc/dmp_fused.hip``) and gradient accumulation happens inside the
 kernels / GEMM epilogues instead of as separate ``add`` launches:
 
-  forward   S=seg_sum2(Z) | XP=X[Wnl|Wdst|Wsrc] | T=XP0+S[Win;Wout]+bn | nmlp | Xn=X+gv*On
-            G=Z[Wel|Wsrc-Wdst] | Y=edge_combine(G,XP12,be) | emlp | Zn=Z+ge*Oe
-  backward  gate*dOut (+colsum) -> GEMMs -> relu_bwd (+colsum) -> GEMMs -> bwd_g (+colsum),
-            seg_sum2 over the incidence CSR, dZ = dZn + gather_select(dS), dZ += dG Wes^T
-  saved     X, Z, S, T, H1n, Y, H1e  (two new [E,H] tensors per layer)
+The first Linear of each MLP follows the message sum with no non-linearity in between
+(dmpnn.py:131-136,147-152), so its weight is folded into the projections:
+``(Z Wel + c Z Wsd + P_d[v] - P_s[u] + be) W0^T + b0 = Z (Wel W0^T) + c Z (Wsd W0^T) + P'_d[v] - P'_s[u] + b'``
+-- one [E,H]x[H,H] product less per layer in forward, input-gradient and weight-gradient
+(9 instead of 12 E-row GEMM units), and the pre-activation tensor never exists.
+
+  forward   S=seg_sum2(Z) | XP=X[Wnl W0n^T | Wdst W0e^T | Wsrc W0e^T] | H1n=relu(XP0+S Bn+b'n) | On | Xn=X+gv*On
+            G=Z[Wel W0e^T | (Wsrc-Wdst) W0e^T] | H1e=edge_combine_relu(G,XP12,b'e) | Oe | Zn=Z+ge*Oe
+  backward  gate*dOut (+colsum) -> GEMMs -> relu_bwd fused with edge_combine's backward (+colsum),
+            seg_sum2 over the incidence CSR, dZ = dZn + gather_select(dS), dZ += dG W'^T,
+            then the small [H,H] chain back to the individual parameters
+  saved     X, Z, S, H1n, H1e  (ONE new [E,H] tensor per layer)
 
 Eligibility (``DMPLayer.fused_ok``): 2-layer MLPs, ReLU, no BatchNorm, bias, no active dropout,
 square weights, H % 4 == 0, ``is_reversed`` present, gates without gradient.  Anything else
@@ -107,14 +114,26 @@ def atb(a, b):
     return out
 
 
-def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H):
+def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False):
     lib = _lib.load()
     E = index.num_edges
     Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
     with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 9 * E + 4 * index.num_nodes):
         check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(bias), ptr(index.src32), ptr(index.dst32),
-                                   ptr(index.rev8), E, H, ptr(Y), H, stream_ptr()), "dmp_edge_combine")
+                                   ptr(index.rev8), E, H, int(relu), ptr(Y), H, stream_ptr()), "dmp_edge_combine")
     return Y
+
+
+def relu_bwd_g_colsum(d_h, act, coef, dst32):
+    """-> (dG = [dPre | coef[dst] dPre] with dPre = act>0 ? d_h : 0,  column sums of dPre)."""
+    lib = _lib.load()
+    E, H = d_h.shape
+    part = _partials(E, H, d_h.device)
+    d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_h.device)
+    with _lib.timed("relu_bwd_g_colsum[H=%d,E=%d]" % (H, E), 16 * H * E + 4 * E + 4 * coef.numel()):
+        check(lib.dmp_relu_bwd_g_colsum(ptr(d_h), H, ptr(act), H, ptr(coef), ptr(dst32), E, H, ptr(d_g), 2 * H,
+                                        ptr(part), stream_ptr()), "dmp_relu_bwd_g_colsum")
+    return d_g, reduce_partials(part)
 
 
 class _FusedDMPLayer(torch.autograd.Function):
@@ -125,34 +144,40 @@ class _FusedDMPLayer(torch.autograd.Function):
         H = nloop_w.size(1)
         x, z = x.contiguous(), z.contiguous()
         N = index.num_nodes
+        # ---- fold the first Linear of each MLP into the projections (tiny [.,H]x[H,H] products)
+        Mn = torch.cat([nloop_w, in_w, out_w, nbias.unsqueeze(0)], dim=0)           # [3H+1, H]
+        Cn = Mn @ nW0.t()
+        Me = torch.cat([eloop_w, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], dim=0)  # [4H+1, H]
+        Ce = Me @ eW0.t()
+        Bn = Cn[H:3 * H]                                                            # [Win;Wout] W0n^T
+        bn = Cn[3 * H] + nb0
+        Wx = torch.cat([Cn[:H], Ce[2 * H:3 * H], Ce[3 * H:4 * H]], dim=1)           # [H,3H]
+        Wes = torch.cat([Ce[:H], Ce[H:2 * H]], dim=1)                                # [H,2H]
+        be = Ce[4 * H] + eb0
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
-        Wio = torch.cat([in_w, out_w], dim=0)
-        Wx = torch.cat([nloop_w, dst_w, src_w], dim=1)
-        XP = x @ Wx                                       # [X Wnl | X Wdst | X Wsrc]
-        T = S @ Wio
-        T += XP[:, :H]
-        T += nbias
-        H1n = torch._addmm_activation(nb0, T, nW0.t(), use_gelu=False)
+        XP = x @ Wx
+        H1n = S @ Bn
+        H1n += XP[:, :H]
+        H1n += bn
+        H1n.relu_()
         On = torch.addmm(nb2, H1n, nW2.t())
         xn = gate_residual(x if residual else None, On, v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        Wes = torch.cat([eloop_w, src_w - dst_w], dim=1)
         G = z @ Wes
-        Y = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, ebias, coef, index, H)
+        H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True)
         del G
-        H1e = torch._addmm_activation(eb0, Y, eW0.t(), use_gelu=False)
         Oe = torch.addmm(eb2, H1e, eW2.t())
         zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate = v_gate, e_gate
-        ctx.save_for_backward(x, z, S, T, H1n, Y, H1e, Wio, Wx, Wes, nW0, nW2, eW0, eW2)
+        ctx.save_for_backward(x, z, S, H1n, H1e, Mn, Me, Bn, Wx, Wes, nW0, nW2, eW0, eW2)
         return xn, zn
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dxn, dzn):
-        x, z, S, T, H1n, Y, H1e, Wio, Wx, Wes, nW0, nW2, eW0, eW2 = ctx.saved_tensors
+        x, z, S, H1n, H1e, Mn, Me, Bn, Wx, Wes, nW0, nW2, eW0, eW2 = ctx.saved_tensors
         ix, coef, H = ctx.index, ctx.coef, ctx.H
         N = ix.num_nodes
         dxn, dzn = dxn.contiguous(), dzn.contiguous()
@@ -160,27 +185,20 @@ class _FusedDMPLayer(torch.autograd.Function):
         dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
         dW2e = atb(dOe, H1e)
         dH1e = dOe @ eW2
-        dPre, db0e = relu_bwd_colsum_(dH1e, H1e)
-        dW0e = atb(dPre, Y)
-        dY = dPre @ eW0
-        del dPre, dH1e
-        dG, deb = bwd_g_colsum(dY, coef, ix.dst32)
+        dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)       # dG[:, :H] is dPre
+        del dH1e
         inc_ptr, inc_ent = ix.incidence()
-        dP = ops.seg_sum_raw(dY, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
-        del dY
-        dWes = atb(z, dG)
+        dP = ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
+        dWes = atb(z, dG)                                            # [H,2H] = [dA_e | dB_e]
         # ---- node side
         dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
         dW2n = atb(dOn, H1n)
         dH1n = dOn @ nW2
-        dPn, db0n = relu_bwd_colsum_(dH1n, H1n)
-        dW0n = atb(dPn, T)
-        dT = dPn @ nW0
-        dnb = colsum(dT)
-        dS = dT @ Wio.t()
-        dWio = atb(S, dT)
-        dXP = torch.cat([dT, dP], dim=1)
-        dWx = atb(x, dXP)
+        dPn, dbn = relu_bwd_colsum_(dH1n, H1n)
+        dS = dPn @ Bn.t()
+        dBn = atb(S, dPn)                                            # [2H,H]
+        dXP = torch.cat([dPn, dP], dim=1)                            # [N,3H]
+        dWx = atb(x, dXP)                                            # [H,3H] = [dA_n | dPd | dPs]
         dx = None
         if ctx.needs_input_grad[3]:
             dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
@@ -189,13 +207,20 @@ class _FusedDMPLayer(torch.autograd.Function):
         if ctx.needs_input_grad[4]:
             dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0, base=dzn if ctx.residual else None)
             dz.addmm_(dG, Wes.t())
-        d_in, d_out = dWio[:H], dWio[H:]
-        d_nloop = dWx[:, :H]
-        d_dst = dWx[:, H:2 * H] - dWes[:, H:]
-        d_src = dWx[:, 2 * H:] + dWes[:, H:]
-        d_eloop = dWes[:, :H]
+        # ---- unfold: C = M @ W0^T  =>  dM = dC @ W0,  dW0 = dC^T @ M
+        dCn = torch.cat([dWx[:, :H], dBn, dbn.unsqueeze(0)], dim=0)                  # [3H+1, H]
+        dMn = dCn @ nW0
+        dW0n = dCn.t() @ Mn
+        dCe = torch.cat([dWes[:, :H], dWes[:, H:], dWx[:, H:2 * H], dWx[:, 2 * H:], dbe.unsqueeze(0)], dim=0)
+        dMe = dCe @ eW0
+        dW0e = dCe.t() @ Me
+        d_nloop, d_in, d_out, dnb = dMn[:H], dMn[H:2 * H], dMn[2 * H:3 * H], dMn[3 * H]
+        d_eloop, d_sd = dMe[:H], dMe[H:2 * H]
+        d_dst = dMe[2 * H:3 * H] - d_sd
+        d_src = dMe[3 * H:4 * H] + d_sd
+        deb = dMe[4 * H]
         return (None, None, None, dx, dz, None, None, d_in, d_out, d_src, d_dst, d_nloop, d_eloop, dnb, deb,
-                dW0n, db0n, dW2n, db2n, dW0e, db0e, dW2e, db2e)
+                dW0n, dbn, dW2n, db2n, dW0e, dbe, dW2e, db2e)
 
 
 def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer):

@@ -171,7 +171,7 @@ class _EdgeCombine(torch.autograd.Function):
         b = _vec(bias, torch.float32)
         with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * P.size(0)) + 9 * E + 4 * P.size(0)):
             check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(b), ptr(index.src32),
-                                       ptr(index.dst32), ptr(index.rev8), E, H, ptr(Y), H, stream_ptr()),
+                                       ptr(index.dst32), ptr(index.rev8), E, H, 0, ptr(Y), H, stream_ptr()),
                   "dmp_edge_combine")
         ctx.index, ctx.coef, ctx.H = index, coef, H
         ctx.has_bias = bias is not None

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 3
+#define DMP_ABI_VERSION 4
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -239,11 +239,14 @@ int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst,
  *                       : P[dst e,0:H] - P[src e,H:2H])
  * where G = Z @ [W_eloop | W_src - W_dst]  and  P = X @ [W_dst | W_src].
  *   G [E, ldg>=2H], P [N, ldp>=2H], coef [N], bias [H] or NULL, Y [E, ldy>=H]
+ * relu != 0 applies max(.,0) to Y: used when the first Linear of the edge MLP (no
+ * non-linearity sits between it and this sum, dmpnn.py:147-152) has been folded into
+ * G and P by multiplying the weights, so Y is already the MLP's hidden activation.
  */
 int dmp_edge_combine(const float *G, int64_t ldg, const float *P, int64_t ldp,
                      const float *coef, const float *bias, const int32_t *src,
                      const int32_t *dst, const uint8_t *flag,
-                     int64_t num_edges, int H, float *Y, int64_t ldy,
+                     int64_t num_edges, int H, int relu, float *Y, int64_t ldy,
                      void *stream);
 
 /*
@@ -317,6 +320,12 @@ int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t 
 int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef,
                                   const int32_t *dst, int64_t num_edges, int H, float *dG,
                                   int64_t ldg, float *partial, void *stream);
+
+/* ReLU backward fused with dmp_edge_combine_bwd_g (for the folded first Linear):
+ *     dPre = act > 0 ? dH : 0;  dG = [dPre | coef[dst] * dPre];  partial = column sums of dPre */
+int dmp_relu_bwd_g_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda,
+                          const float *coef, const int32_t *dst, int64_t num_edges, int H,
+                          float *dG, int64_t ldg, float *partial, void *stream);
 
 /* Column-sum partials of A [rows, H]. */
 int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float *partial,

@@ -233,6 +233,23 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
             for k, p in lo[i].items():
                 _close(results[fused][4]["dmpnn.graph_dmpnn_(%d).%s" % (i, k)], p.grad, 3e-4, 3e-4,
                        "grad %d.%s fused=%s" % (i, k, fused))
-    # fused vs modular: same kernels and GEMMs, only the orchestration differs
-    for x, y in zip(results[True][:4], results[False][:4]):
-        assert th.allclose(x, y, rtol=1e-5, atol=1e-5)
+    # Against an fp64 run of the same math the product must be no worse than a few times the
+    # fp32 restatement of the reference; fused and modular paths differ from
+    # each other only by fp32 re-association (the fused path also folds W0 into the projections).
+    l64 = [{k: v.double() for k, v in p.items()} for p in layers]
+    v64, e64 = v0.double().requires_grad_(True), e0.double().requires_grad_(True)
+    a64, b64 = O.dmpnn_graph_rep(l64, ts, td, tr, O.out_degrees(ts, N), v64, e64,
+                                 None if vg is None else vg.double(), None if eg is None else eg.double(),
+                                 residual, "relu")
+    ((a64 * wv.double()).sum() + (b64 * we.double()).sum()).backward()
+    refs64 = (a64, b64, v64.grad, e64.grad)
+    refs32 = (rv, re, vo.grad, eo.grad)
+    for i, name in enumerate(("v_rep", "e_rep", "dv", "de")):
+        r64 = refs64[i].detach()
+        scale = max(1.0, float(r64.abs().max()))
+        e32 = float((refs32[i].detach().double() - r64).abs().max())
+        for fused in (True, False):
+            err = float((results[fused][i].detach().cpu().double() - r64).abs().max())
+            assert err <= max(6.0 * e32, 2e-6 * scale), \
+                "%s fused=%s: err %g vs fp32-oracle err %g" % (name, fused, err, e32)
+        _close(results[True][i], results[False][i].detach().cpu(), 1e-4, 1e-4, "fused vs modular " + name)
