@@ -81,3 +81,25 @@ def batchify(samples, return_weights=None, device=None):
     if device is not None:
         counts = counts.to(device)
     return _id, pattern, graph, counts, (None, None)
+
+
+def union_graphs(a, b):
+    """Block-diagonal union of two (batched) graphs: nodes/edges of ``a`` first, then ``b`` with its
+    node ids shifted by ``a.number_of_nodes()`` -- ``dgl.batch([a, b])`` semantics on the structure.
+    Used to run a SHARED rep-net once over pattern and target batches (same weights, per-row
+    ops, no BatchNorm), instead of twice.  Carries ``is_reversed`` and cached degrees."""
+    from .constants import INDEGREE, OUTDEGREE, REVFLAG
+    na = a.number_of_nodes()
+    src = torch.cat([a._src, b._src + na])
+    dst = torch.cat([a._dst, b._dst + na])
+    bnn = torch.cat([a.batch_num_nodes(), b.batch_num_nodes()])
+    bne = torch.cat([a.batch_num_edges(), b.batch_num_edges()])
+    g = BatchedGraph(src, dst, na + b.number_of_nodes(), bnn, bne)
+    if (REVFLAG in a.edata) != (REVFLAG in b.edata):
+        raise ValueError("union_graphs: is_reversed must be present on both graphs or on neither")
+    if REVFLAG in a.edata:
+        g.edata[REVFLAG] = torch.cat([a.edata[REVFLAG], b.edata[REVFLAG]])
+    for k in (INDEGREE, OUTDEGREE):
+        if k in a.ndata and k in b.ndata:
+            g.ndata[k] = torch.cat([a.ndata[k], b.ndata[k]])
+    return g

@@ -205,6 +205,9 @@ class DMPNNRepMixin:
 
     rep_key = "dmpnn"
 
+    def get_joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
+        return joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
+
     def create_rep_net(self, type, **kw):
         if type == "graph":
             num_layers = kw.get("rep_num_graph_layers", 1)
@@ -306,6 +309,62 @@ class DMPNNRepMixin:
         return v_outputs[-1], e_outputs[-1]
 
 
+def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
+    """``get_pattern_rep`` + ``get_graph_rep`` (dmpnn.py:215-277) in ONE pass over the union of
+    the two batched graphs, when the rep-net is shared (``share_rep_net``, dmpnn.py:186-188) and
+    every layer is eligible for the fused path.  Pattern rows get gate 1 (the pattern side has no
+    gate, basemodel.py:1515).  Returns ``(p_v_rep, p_e_rep, g_v_rep, g_e_rep)`` or ``None`` if not
+    applicable (callers then run the two loops separately)."""
+    from . import fused
+    from .collate import union_graphs
+    if not getattr(model, "use_fused", True) or model.p_rep_net is not model.g_rep_net:
+        return None
+    layers = list(model.g_rep_net[model.rep_key])
+    if not layers or not all(hasattr(l, "fused_ok") for l in layers):
+        return None
+    if not (isinstance(pattern, BatchedGraph) and isinstance(graph, BatchedGraph)):
+        return None
+    if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
+        return None
+    np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
+    if v_gate is not None:
+        g_v_emb = g_v_emb * v_gate
+    if e_gate is not None:
+        g_e_emb = g_e_emb * e_gate
+    v = th.cat([p_v_emb, g_v_emb], dim=0)
+    e = th.cat([p_e_emb, g_e_emb], dim=0)
+    vg = eg = None
+    if v_gate is not None:
+        vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
+    if e_gate is not None:
+        eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
+    u = getattr(pattern, "_union_cache", None)
+    if u is None or u[0] is not graph:
+        u = (graph, union_graphs(pattern, graph))
+        pattern._union_cache = u
+    union = u[1]
+    if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):
+        return None
+    for layer in layers:
+        v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual)
+    p_v, g_v = _SplitRows.apply(v, np_)
+    p_e, g_e = _SplitRows.apply(e, ep_)
+    return p_v, p_e, g_v, g_e
+
+
+class _SplitRows(th.autograd.Function):
+    """(x[:n], x[n:]) whose backward is ONE concatenation (autograd's slice backward would
+    allocate and add two zero-padded full-size tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        return th.cat([da, db], dim=0), None
+
+
 class DMPNNRep(DMPNNRepMixin, nn.Module):
     """The representation stage of ``DMPNN`` on its own: ``g_rep_net`` / ``p_rep_net``
     with the reference's child names (``g_rep_net.dmpnn.graph_dmpnn_(i).*``), so a
@@ -320,6 +379,9 @@ class DMPNNRep(DMPNNRepMixin, nn.Module):
         self.p_rep_net = self.create_rep_net(type="pattern", **kw)
 
     def forward(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
+        joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
+        if joint is not None:
+            return joint
         p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
         g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=v_gate, e_gate=e_gate)
         return p_v_rep, p_e_rep, g_v_rep, g_e_rep

@@ -253,3 +253,38 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
             assert err <= max(6.0 * e32, 2e-6 * scale), \
                 "%s fused=%s: err %g vs fp32-oracle err %g" % (name, fused, err, e32)
         _close(results[True][i], results[False][i].detach().cpu(), 1e-4, 1e-4, "fused vs modular " + name)
+
+
+def test_joint_pattern_graph_pass_matches_reference_golden(gpu):
+    """DMPNNRep.forward runs the SHARED rep-net once over the union of the pattern and target
+    batches; results must equal the reference's two separate loops (golden dmpnn_rep.npz), and
+    the parameter gradients the sum of both losses' gradients."""
+    from dualmessagepassing_amd.dmpnn import DMPNNRep
+    d = load_golden(golden_files("dmpnn_rep")[0])
+    h, L = int(d["hid"]), int(d["layers"])
+    net = DMPNNRep(hid_dim=h, rep_num_graph_layers=L, rep_num_pattern_layers=L, share_rep_net=True,
+                   rep_residual=True, rep_dmpnn_batch_norm=False, rep_act_func="relu")
+    sd = {"g_rep_net." + k[2:]: _t(v) for k, v in d.items() if k.startswith("p.")}
+    sd.update({"p_rep_net." + k[2:]: _t(v) for k, v in d.items() if k.startswith("p.")})
+    net.load_state_dict(sd, strict=True)
+    net.to(gpu)
+    pg, gg = _graph(d, gpu, "p_"), _graph(d, gpu, "g_")
+    pv = _t(d["p_v_emb"]).to(gpu).requires_grad_(True)
+    pe = _t(d["p_e_emb"]).to(gpu).requires_grad_(True)
+    gv = _t(d["g_v_emb"]).to(gpu).requires_grad_(True)
+    ge = _t(d["g_e_emb"]).to(gpu).requires_grad_(True)
+    assert net.get_joint_rep(pg, gg, pv, pe, gv, ge, _t(d["g_v_gate"]).to(gpu), _t(d["g_e_gate"]).to(gpu)) is not None
+    p_v, p_e, g_v, g_e = net(pg, gg, pv, pe, gv, ge, v_gate=_t(d["g_v_gate"]).to(gpu), e_gate=_t(d["g_e_gate"]).to(gpu))
+    _close(p_v, d["p_v_rep"], 1e-4, 1e-4, "p_v_rep")
+    _close(p_e, d["p_e_rep"], 1e-4, 1e-4, "p_e_rep")
+    _close(g_v, d["g_v_rep"], 1e-4, 1e-4, "g_v_rep")
+    _close(g_e, d["g_e_rep"], 1e-4, 1e-4, "g_e_rep")
+    loss = (p_v * _t(d["p_wv"]).to(gpu)).sum() + (p_e * _t(d["p_we"]).to(gpu)).sum() \
+        + (g_v * _t(d["g_wv"]).to(gpu)).sum() + (g_e * _t(d["g_we"]).to(gpu)).sum()
+    loss.backward()
+    _close(pv.grad, d["p_dv_emb"], 1e-4, 1e-4, "p dv")
+    _close(pe.grad, d["p_de_emb"], 1e-4, 1e-4, "p de")
+    _close(gv.grad, d["g_dv_emb"], 1e-4, 1e-4, "g dv")
+    _close(ge.grad, d["g_de_emb"], 1e-4, 1e-4, "g de")
+    for k, p in net.g_rep_net.named_parameters():
+        _close(p.grad, _t(d["p_grad." + k]) + _t(d["g_grad." + k]), 2e-4, 2e-4, "grad " + k)
