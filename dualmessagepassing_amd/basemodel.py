@@ -1,0 +1,385 @@
+"""Model skeleton around the hot path: enc -> filter -> emb -> rep -> pred, on the device.
+
+Mirror of ``BaseModel`` / ``GraphAdjModelV2`` (SubgraphCountingMatching/models/basemodel.py:15-160,
+965-1663) for the configurations the DMPNN / CompGCN training commands use (Multihot / Position
+encodings, the four embedding kinds, ``ScalarFilter``, Mean / Sum / Max pooling heads).  Same
+constructor keywords, sub-module names (hence ``state_dict`` keys) and ``forward(pattern, graph)
+-> OutputDict`` with the reference's 15 keys.
+
+The reference's per-sample Python loops (``utils/dl.py:51-81,113-127``, ``basemodel.py:1411,1421``)
+are replaced by index arithmetic on the device; uniform-size batches take the same reshape fast
+paths as the reference.  ``model.expand()`` (vocabulary growth for fine-tuning) is not provided.
+"""
+from collections import OrderedDict
+
+import torch as th
+import torch.nn as nn
+
+from .compgcn import CompGCNRepMixin
+from .constants import REVFLAG
+from .dmpnn import DMPNNRepMixin
+from .embed import (EquivariantEmbedding, MultihotEmbedding, NormalEmbedding, OrthogonalEmbedding,
+                    PositionEmbedding, UniformEmbedding, get_enc_len)
+from .pred import PRED_NETS
+
+
+class OutputDict(OrderedDict):
+    """Ordered mapping with attribute access (container.py:14-100, the part callers use)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys())
+
+
+class ScalarFilter(nn.Module):
+    """filter.py:6-16: gate[b, j] = any_i (g_x[b, j] == p_x[b, i])."""
+
+    def forward(self, p_x, g_x):
+        matrix = g_x.unsqueeze(2) - p_x.unsqueeze(1)
+        return th.max(matrix == 0, dim=2)[0]
+
+
+# ----------------------------------------------------------------------------- padding helpers
+def _segments(graph, kind):
+    seg = graph.node_graph if kind == "node" else graph.edge_graph
+    sizes = graph.batch_num_nodes() if kind == "node" else graph.batch_num_edges()
+    if seg is None:
+        seg = th.repeat_interleave(th.arange(sizes.numel(), device=sizes.device), sizes)
+    return seg.long(), sizes
+
+
+def _max_len(sizes):
+    return int(sizes.max().item()) if sizes.numel() else 0
+
+
+def len_to_mask(lens, max_len):
+    """``batch_convert_len_to_mask(lens, pre_pad=True)`` (utils/dl.py:113-127), vectorised."""
+    return th.arange(max_len, device=lens.device).unsqueeze(0) >= (max_len - lens).unsqueeze(1)
+
+
+class _Padder:
+    """``split_and_batchify_graph_feats(x, sizes, pre_pad=True)[0]`` (utils/dl.py:51-81) for one
+    graph and one element kind: rows of graph i go to ``[i, max - size_i :]``, zeros in front."""
+
+    def __init__(self, graph, kind):
+        self.seg, self.sizes = _segments(graph, kind)
+        self.bsz = int(self.sizes.numel())
+        self.max = _max_len(self.sizes)
+        n = int(self.seg.numel())
+        self.uniform = self.bsz * self.max == n
+        if not self.uniform:
+            off = th.zeros(self.bsz + 1, dtype=th.int64, device=self.sizes.device)
+            th.cumsum(self.sizes, 0, out=off[1:])
+            pos = th.arange(n, device=self.sizes.device) - off[self.seg]
+            self.idx = self.seg * self.max + (self.max - self.sizes[self.seg]) + pos
+
+    def pad(self, x):
+        x = x.reshape(x.size(0), -1)
+        if self.uniform:
+            return x.view(self.bsz, self.max, -1)
+        out = th.zeros((self.bsz * self.max, x.size(1)), dtype=x.dtype, device=x.device)
+        return out.index_copy(0, self.idx, x).view(self.bsz, self.max, -1)
+
+    def unpad(self, y):
+        """inverse gather: [B, max, ...] -> rows in graph order (basemodel.py:1411,1421)."""
+        y = y.reshape(self.bsz * self.max, -1)
+        return y if self.uniform else y[self.idx]
+
+    def mask(self):
+        return len_to_mask(self.sizes, self.max).view(self.bsz, -1, 1)
+
+
+class BaseModel(nn.Module):
+    """basemodel.py:15-160."""
+
+    def __init__(self, **kw):
+        super(BaseModel, self).__init__()
+        self.max_ngv = kw["max_ngv"]
+        self.max_ngvl = kw["max_ngvl"]
+        self.max_nge = kw["max_nge"]
+        self.max_ngel = kw["max_ngel"]
+        self.max_npv = kw["max_npv"]
+        self.max_npvl = kw["max_npvl"]
+        self.max_npe = kw["max_npe"]
+        self.max_npel = kw["max_npel"]
+        self.base = kw.get("base", 2)
+        self.hid_dim = kw.get("hid_dim", 64)
+        self.share_emb_net = kw.get("share_emb_net", True)
+        self.share_enc_net = kw.get("share_enc_net", True)
+        self.share_rep_net = kw.get("share_rep_net", True)
+        self.rep_residual = kw.get("rep_residual", True)
+        self.pred_with_enc = kw.get("pred_with_enc", False)
+        self.pred_with_deg = kw.get("pred_with_deg", False)
+        # same construction order as the reference (parameter registration order)
+        self.g_enc_net = self.create_enc_net(type="graph", **kw)
+        self.p_enc_net = self.create_enc_net(type="pattern", **kw)
+        self.filter_net = self.create_filter_net(**kw)
+        self.g_emb_net = self.create_emb_net(type="graph", **kw)
+        self.p_emb_net = self.create_emb_net(type="pattern", **kw)
+        self.g_rep_net = self.create_rep_net(type="graph", **kw)
+        self.p_rep_net = self.create_rep_net(type="pattern", **kw)
+        self.pred_net = self.create_pred_net(**kw)
+
+    def refine_node_weights(self, weights, use_max=False):
+        return weights
+
+    def refine_edge_weights(self, weights, use_max=False):
+        return weights
+
+
+class GraphAdjModelV2(BaseModel):
+    """basemodel.py:965-1663."""
+
+    def __init__(self, **kw):
+        self.add_node_id = kw.get("add_node_id", kw.get("gnn_add_node_id", False))
+        self.add_edge_id = kw.get("add_edge_id", kw.get("gnn_add_edge_id", False))
+        self.node_pred = kw.get("node_pred", True)
+        self.edge_pred = kw.get("edge_pred", True)
+        super(GraphAdjModelV2, self).__init__(**kw)
+
+    # ---- construction (basemodel.py:973-1340)
+    def _enc_set(self, enc_net, nv, nvl, nel):
+        if enc_net == "Multihot":
+            return OrderedDict({"v": MultihotEmbedding(nv, self.base), "vl": MultihotEmbedding(nvl, self.base),
+                                "el": MultihotEmbedding(nel, self.base)})
+        if enc_net == "Position":
+            return OrderedDict({
+                "v": PositionEmbedding(int(get_enc_len(nv - 1, self.base)) * self.base, nv),
+                "vl": PositionEmbedding(int(get_enc_len(nvl - 1, self.base)) * self.base, nvl),
+                "el": PositionEmbedding(int(get_enc_len(nel - 1, self.base)) * self.base, nel)})
+        raise NotImplementedError(enc_net)
+
+    def create_enc_net(self, type, **kw):
+        enc_net = kw.get("enc_net", "Multihot")
+        if type == "graph":
+            nets = self._enc_set(enc_net, self.max_ngv, self.max_ngvl, self.max_ngel)
+        elif type == "pattern":
+            if self.share_enc_net:
+                return self.g_enc_net
+            nets = self._enc_set(enc_net, self.max_npv, self.max_npvl, self.max_npel)
+        else:
+            raise ValueError(type)
+        for net in nets.values():
+            net.weight.requires_grad = False
+        return nn.ModuleDict(nets)
+
+    def create_filter_net(self, **kw):
+        filter_net = kw.get("filter_net", "None")
+        if filter_net == "None":
+            return None
+        if filter_net == "ScalarFilter":
+            return nn.ModuleDict({"vl": ScalarFilter(), "el": ScalarFilter()})
+        raise ValueError(filter_net)
+
+    def create_emb_net(self, type, **kw):
+        emb_net = kw.get("emb_net", "Orthogonal")
+        enc_dims = self.get_graph_enc_dims() if type == "graph" else self.get_pattern_enc_dims()
+        cls = {"Orthogonal": OrthogonalEmbedding, "Normal": NormalEmbedding, "Uniform": UniformEmbedding,
+               "Equivariant": EquivariantEmbedding}.get(emb_net)
+        if cls is None:
+            raise ValueError(emb_net)
+        nets = OrderedDict({k: cls(enc_dims[k], self.hid_dim) for k in ("v", "vl", "el")})
+        with th.no_grad():  # basemodel.py:1066-1070: rescale because of multi-hot inputs
+            for k in nets:
+                nets[k].weight.div_(enc_dims[k] // self.base)
+        return nn.ModuleDict(nets)
+
+    def create_pred_net(self, **kw):
+        name = kw.get("pred_net", "SumPredictNet")
+        if name not in PRED_NETS:
+            raise NotImplementedError("pred_net=%s is outside the MI355X hot-path scope" % name)
+        return_weights = kw.get("pred_return_weights", "none")
+        rep_v_dim, rep_e_dim = self.get_rep_dim()
+        args = dict(hidden_dim=kw.get("pred_hid_dim", 64), act_func=kw.get("pred_act_func", "relu"),
+                    dropout=kw.get("pred_dropout", 0.0))
+        return nn.ModuleDict({
+            "v": PRED_NETS[name](rep_v_dim, return_weights="node" in return_weights, **args) if self.node_pred else None,
+            "e": PRED_NETS[name](rep_e_dim, return_weights="edge" in return_weights, **args) if self.edge_pred else None,
+        })
+
+    def _enc_dims(self, nv, nvl, nel):
+        return OrderedDict({"v": int(get_enc_len(nv - 1, self.base)) * self.base,
+                            "vl": int(get_enc_len(nvl - 1, self.base)) * self.base,
+                            "el": int(get_enc_len(nel - 1, self.base)) * self.base})
+
+    def get_graph_enc_dims(self):
+        return self._enc_dims(self.max_ngv, self.max_ngvl, self.max_ngel)
+
+    def get_pattern_enc_dims(self):
+        if self.share_enc_net:
+            return self.get_graph_enc_dims()
+        return self._enc_dims(self.max_npv, self.max_npvl, self.max_npel)
+
+    def get_graph_enc_dim(self):
+        d = self.get_graph_enc_dims()
+        return d["v"] + d["vl"], (d["v"] + d["vl"]) * 2 + d["el"]
+
+    def get_rep_dim(self):
+        rep_v_dim, rep_e_dim = self.hid_dim, self.hid_dim
+        if self.pred_with_enc:
+            enc_v_dim, enc_e_dim = self.get_graph_enc_dim()
+            rep_v_dim += enc_v_dim
+            rep_e_dim += enc_e_dim
+        if self.pred_with_deg:
+            rep_v_dim += 2
+            rep_e_dim += 2
+        return rep_v_dim, rep_e_dim
+
+    # ---- forward pieces (basemodel.py:1394-1498)
+    def get_filter_gate(self, pattern, graph, pads):
+        if self.filter_net is None or len(self.filter_net) == 0:
+            return None, None
+        p_vl = pads["pv"].pad(pattern.ndata["label"].view(-1, 1))
+        g_vl = pads["gv"].pad(graph.ndata["label"].view(-1, 1))
+        vl_gate = pads["gv"].unpad(self.filter_net["vl"](p_vl, g_vl)).view(-1, 1)
+        p_el = pads["pe"].pad(pattern.edata["label"].view(-1, 1))
+        g_el = pads["ge"].pad(graph.edata["label"].view(-1, 1))
+        el_gate = pads["ge"].unpad(self.filter_net["el"](p_el, g_el)).view(-1, 1)
+        return vl_gate, el_gate
+
+    def _enc(self, net, g):
+        enc = OrderedDict({"v": net["v"](g.ndata["id"].view(-1)), "vl": net["vl"](g.ndata["label"].view(-1)),
+                           "el": net["el"](g.edata["label"].view(-1))})
+        if self.add_edge_id:
+            u, v = g.all_edges(form="uv", order="eid")
+            enc["src"] = enc["v"][u]
+            enc["dst"] = enc["v"][v]
+        return enc
+
+    def get_pattern_enc(self, pattern):
+        return self._enc(self.p_enc_net, pattern)
+
+    def get_graph_enc(self, graph):
+        return self._enc(self.g_enc_net, graph)
+
+    def _emb(self, net, enc):
+        v_emb = net["vl"](enc["vl"])
+        if self.add_node_id:
+            v_emb = v_emb + net["v"](enc["v"])
+        e_emb = net["el"](enc["el"])
+        if self.add_edge_id:
+            e_emb = e_emb + net["v"](enc["src"]) + net["v"](enc["dst"])
+        return v_emb, e_emb
+
+    def get_pattern_emb(self, p_enc):
+        return self._emb(self.p_emb_net, p_enc)
+
+    def get_graph_emb(self, g_enc):
+        return self._emb(self.g_emb_net, g_enc)
+
+    def get_subiso_pred(self, p_v_rep, p_v_mask, p_e_rep, p_e_mask, g_v_rep, g_v_mask, g_e_rep, g_e_mask):
+        v_pred_c = v_pred_w = e_pred_c = e_pred_w = None
+        if self.node_pred:
+            v_pred_c, v_pred_w = self.pred_net["v"](p_v_rep, p_v_mask, g_v_rep, g_v_mask)
+        if self.edge_pred:
+            e_pred_c, e_pred_w = self.pred_net["e"](p_e_rep, p_e_mask, g_e_rep, g_e_mask)
+        if self.node_pred and self.edge_pred:
+            g_v_len = g_v_mask.float().sum(dim=1).view(-1, 1)
+            g_e_len = g_e_mask.float().sum(dim=1).view(-1, 1)
+            g_len = g_v_len + g_e_len
+            return (g_v_len / g_len) * v_pred_c + (g_e_len / g_len) * e_pred_c, (v_pred_w, e_pred_w)
+        if self.node_pred:
+            return v_pred_c, (v_pred_w, e_pred_w)
+        if self.edge_pred:
+            return e_pred_c, (v_pred_w, e_pred_w)
+        raise ValueError
+
+    # ---- forward (basemodel.py:1500-1663)
+    def forward(self, pattern, graph):
+        bsz = pattern.batch_size
+        pads = {"pv": _Padder(pattern, "node"), "pe": _Padder(pattern, "edge"),
+                "gv": _Padder(graph, "node"), "ge": _Padder(graph, "edge")}
+        p_v_mask, p_e_mask = pads["pv"].mask(), pads["pe"].mask()
+        g_v_mask, g_e_mask = pads["gv"].mask(), pads["ge"].mask()
+        vl_gate, el_gate = self.get_filter_gate(pattern, graph, pads)
+        if vl_gate is not None:  # bool gate * float features == float gate * float features
+            vl_gate, el_gate = vl_gate.float(), el_gate.float()
+
+        p_enc = self.get_pattern_enc(pattern)
+        p_v_emb, p_e_emb = self.get_pattern_emb(p_enc)
+        g_enc = self.get_graph_enc(graph)
+        g_v_emb, g_e_emb = self.get_graph_emb(g_enc)
+        joint = None
+        if hasattr(self, "get_joint_rep"):
+            joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
+        if joint is not None:
+            p_v_rep, p_e_rep, g_v_rep, g_e_rep = joint
+        else:
+            p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
+            g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=vl_gate, e_gate=el_gate)
+
+        # reversed edges do not take part in the edge head (basemodel.py:1521-1531)
+        if REVFLAG in pattern.edata:
+            p_e_mask = p_e_mask.masked_fill(pads["pe"].pad(pattern.edata[REVFLAG]).view(bsz, -1, 1).bool(), 0)
+        if REVFLAG in graph.edata:
+            g_e_mask = g_e_mask.masked_fill(pads["ge"].pad(graph.edata[REVFLAG]).view(bsz, -1, 1).bool(), 0)
+
+        if self.pred_with_deg:
+            p_out_deg = pattern.out_degrees().float().view(-1, 1)
+            p_in_deg = pattern.in_degrees().float().view(-1, 1)
+            g_out_deg = graph.out_degrees().float().view(-1, 1)
+            g_in_deg = graph.in_degrees().float().view(-1, 1)
+
+        p_v_output = g_v_output = p_e_output = g_e_output = None
+        if self.node_pred:
+            p_add, g_add = [], []
+            if self.pred_with_enc:
+                p_add += [p_enc["v"], p_enc["vl"]]
+                g_add += [g_enc["v"], g_enc["vl"]]
+            if self.pred_with_deg:
+                p_add += [p_out_deg, p_in_deg]
+                g_add += [g_out_deg, g_in_deg]
+            p_v_output = th.cat([self.refine_node_weights(th.cat(p_add, dim=-1)), p_v_rep], dim=-1) if p_add else p_v_rep
+            g_v_output = th.cat([self.refine_node_weights(th.cat(g_add, dim=-1)), g_v_rep], dim=-1) if g_add else g_v_rep
+            p_v_mask = self.refine_node_weights(p_v_mask)
+            p_v_output = pads["pv"].pad(p_v_output).masked_fill(~p_v_mask, 0)
+            g_v_mask = self.refine_node_weights(g_v_mask)
+            g_v_output = pads["gv"].pad(g_v_output).masked_fill(~g_v_mask, 0)
+        if self.edge_pred:
+            p_u, p_v = pattern.all_edges(form="uv", order="eid")
+            g_u, g_v = graph.all_edges(form="uv", order="eid")
+            p_add, g_add = [], []
+            if self.pred_with_enc:
+                p_add += [p_enc["v"][p_u], p_enc["v"][p_v], p_enc["vl"][p_u], p_enc["el"], p_enc["vl"][p_v]]
+                g_add += [g_enc["v"][g_u], g_enc["v"][g_v], g_enc["vl"][g_u], g_enc["el"], g_enc["vl"][g_v]]
+            if self.pred_with_deg:
+                p_add += [p_out_deg[p_u], p_in_deg[p_v]]
+                g_add += [g_out_deg[g_u], g_in_deg[g_v]]
+            p_e_output = th.cat([self.refine_edge_weights(th.cat(p_add, dim=-1)), p_e_rep], dim=-1) if p_add else p_e_rep
+            g_e_output = th.cat([self.refine_edge_weights(th.cat(g_add, dim=-1)), g_e_rep], dim=-1) if g_add else g_e_rep
+            p_e_mask = self.refine_edge_weights(p_e_mask)
+            p_e_output = pads["pe"].pad(p_e_output).masked_fill(~p_e_mask, 0)
+            g_e_mask = self.refine_edge_weights(g_e_mask)
+            g_e_output = pads["ge"].pad(g_e_output).masked_fill(~g_e_mask, 0)
+
+        p_v_mask, p_e_mask = p_v_mask.view(bsz, -1), p_e_mask.view(bsz, -1)
+        g_v_mask, g_e_mask = g_v_mask.view(bsz, -1), g_e_mask.view(bsz, -1)
+        pred_c, (pred_v, pred_e) = self.get_subiso_pred(p_v_output, p_v_mask, p_e_output, p_e_mask,
+                                                        g_v_output, g_v_mask, g_e_output, g_e_mask)
+        return OutputDict(p_v_emb=p_v_emb, p_e_emb=p_e_emb, g_v_emb=g_v_emb, g_e_emb=g_e_emb,
+                          p_v_rep=p_v_rep, p_e_rep=p_e_rep, g_v_rep=g_v_rep, g_e_rep=g_e_rep,
+                          p_v_mask=p_v_mask, p_e_mask=p_e_mask, g_v_mask=g_v_mask, g_e_mask=g_e_mask,
+                          pred_c=pred_c, pred_v=pred_v, pred_e=pred_e)
+
+
+class DMPNN(DMPNNRepMixin, GraphAdjModelV2):
+    """``models/dmpnn.py:179-277``: ``DMPNN(**config)`` as built by ``train.py:68-87``."""
+
+
+class CompGCN(CompGCNRepMixin, GraphAdjModelV2):
+    """``models/compgcn.py:289-385``."""
+
+
+def build_model(**config):
+    """``train.py:68-87`` for the two rep-nets on the MI355X path."""
+    rep_net = config.get("rep_net", "DMPNN")
+    if rep_net == "DMPNN":
+        return DMPNN(**config)
+    if rep_net == "CompGCN":
+        return CompGCN(**config)
+    raise NotImplementedError("rep_net=%s is outside the MI355X hot-path scope" % rep_net)

@@ -1,0 +1,120 @@
+"""Fixed encodings and learned embeddings of the model skeleton -- same classes, shapes and
+initialisers as ``SubgraphCountingMatching/models/embed.py`` (the numba helpers restated in
+numpy; they only run at construction time)."""
+import numpy as np
+import torch as th
+import torch.nn as nn
+
+
+def get_enc_len(x, base=10):
+    """embed.py:8-35: number of base-``base`` digits of x (at least 1)."""
+    def one(n):
+        n, cnt = int(n), 0
+        while n > 0:
+            n //= base
+            cnt += 1
+        return max(cnt, 1)
+    if isinstance(x, (int, float, np.integer)):
+        return one(x)
+    arr = np.asarray(x).astype(np.int64)
+    return np.array([one(v) for v in arr.reshape(-1)], dtype=np.int64).reshape(arr.shape)
+
+
+def int2multihot(x, len_x, base=10):
+    """embed.py:70-100: per digit position a one-hot of size ``base`` (most significant first;
+    leading positions encode digit 0)."""
+    arr = np.atleast_1d(np.asarray(x)).astype(np.int64)
+    rep = np.zeros((len(arr), len_x * base), dtype=np.int64)
+    for i, n in enumerate(arr):
+        n = int(n) % base ** len_x
+        idx = (len_x - 1) * base
+        while n:
+            rep[i, idx + n % base] = 1
+            n //= base
+            idx -= base
+        while idx >= 0:
+            rep[i, idx] = 1
+            idx -= base
+    return rep
+
+
+class Embedding(nn.Embedding):
+    """embed.py:103-120: index lookup for long inputs, ``x @ weight`` for float encodings."""
+
+    def forward(self, x):
+        if x.dtype == th.long:
+            return super(Embedding, self).forward(x)
+        if x.dtype == th.float and x.size(-1) == self.num_embeddings:
+            x_size = x.size()
+            emb = th.matmul(x.view(-1, x_size[-1]), self.weight)
+            return emb.view(x_size[:-1] + (self.embedding_dim,))
+        raise NotImplementedError
+
+    def get_output_dim(self):
+        return self.embedding_dim
+
+
+def _zero_pad(emb):
+    if emb.padding_idx is not None:
+        with th.no_grad():
+            emb.weight[emb.padding_idx].fill_(0)
+
+
+class NormalEmbedding(Embedding):
+    def __init__(self, num_embeddings, embedding_dim, **kw):
+        super(NormalEmbedding, self).__init__(num_embeddings, embedding_dim, **kw)
+        nn.init.normal_(self.weight, 0.0, 1.0)
+        _zero_pad(self)
+
+
+class UniformEmbedding(Embedding):
+    def __init__(self, num_embeddings, embedding_dim, **kw):
+        super(UniformEmbedding, self).__init__(num_embeddings, embedding_dim, **kw)
+        nn.init.uniform_(self.weight, -1.0, 1.0)
+        _zero_pad(self)
+
+
+class OrthogonalEmbedding(Embedding):
+    def __init__(self, num_embeddings, embedding_dim, **kw):
+        super(OrthogonalEmbedding, self).__init__(num_embeddings, embedding_dim, **kw)
+        nn.init.orthogonal_(self.weight)
+        _zero_pad(self)
+
+
+class EquivariantEmbedding(Embedding):
+    """embed.py:162-196: rows are rolls of one learned vector; ``weight`` and ``row_vec`` are both
+    Parameters, as in the reference."""
+
+    def __init__(self, num_embeddings, embedding_dim, **kw):
+        super(EquivariantEmbedding, self).__init__(num_embeddings, embedding_dim, **kw)
+        self.row_vec = nn.Parameter(th.empty(self.embedding_dim))
+        nn.init.normal_(self.row_vec, 0.0, 1.0)
+        with th.no_grad():
+            for i in range(num_embeddings):
+                self.weight[i].copy_(th.roll(self.row_vec, i, 0))
+
+
+class MultihotEmbedding(Embedding):
+    """embed.py:199-210: frozen multi-hot code table ``[max_n, 2 * enc_len]``."""
+
+    def __init__(self, max_n=1024, base=2):
+        self.max_n, self.base = max_n, base
+        enc_len = int(get_enc_len(max_n - 1, base))
+        super(MultihotEmbedding, self).__init__(max_n, 2 * enc_len)
+        with th.no_grad():
+            self.weight.copy_(th.from_numpy(int2multihot(np.arange(0, max_n), enc_len, base)).float())
+
+    def extra_repr(self):
+        return "base=%d, max_n=%d, enc_dim=%d" % (self.base, self.max_n, self.weight.shape[1])
+
+
+class PositionEmbedding(Embedding):
+    """embed.py:213-224: frozen sinusoid table."""
+
+    def __init__(self, embedding_dim, max_len=512, scale=1):
+        freq_seq = th.arange(0, embedding_dim, 2.0, dtype=th.float)
+        inv_freq = th.pow(10000, (freq_seq / embedding_dim)).reciprocal()
+        sinusoid_inp = th.outer(th.arange(0, max_len, 1.0), inv_freq)
+        super(PositionEmbedding, self).__init__(max_len, embedding_dim)
+        with th.no_grad():
+            self.weight.copy_(th.cat([th.sin(sinusoid_inp), th.cos(sinusoid_inp)], dim=-1) * scale)

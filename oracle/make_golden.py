@@ -14,6 +14,7 @@ Fixtures
   compgcn_*.npz      CompGCNLayer fwd+bwd (models/compgcn.py:265-274)
   linegraph_*.npz    convert_to_dual_graph (utils/graph.py:74-169)
   addrev_*.npz       add_reversed_edges, GraphAdj branch (train.py:299-327)
+  fullmodel_*.npz    DMPNN.forward(pattern, graph): 15 OutputDict entries + grads (basemodel.py:1500-1663)
   unc_dualconv_*.npz DualGraphConv (UNC Model/DMPNN/src/model.py:117-273) -- separate interpreter
 """
 import os
@@ -306,6 +307,82 @@ def gen_addrev():
         print("wrote addrev_%s.npz" % name)
 
 
+def gen_full_model():
+    """Full ``DMPNN.forward(pattern, graph)`` of the reference (models/basemodel.py:1500-1663 +
+    models/dmpnn.py) -> the 15 OutputDict entries and the gradients of ``pred_c.sum()``.
+    'uniform': BASELINE config-1 shape (B=32, pattern (8,12), target (64,256), add_rev, hid 64);
+    'ragged' : different sizes per pair (exercises the padding / mask / filter-gate paths)."""
+    import dgl
+    from models.dmpnn import DMPNN
+
+    def make_batch(sizes, n_vl, n_el, rng):
+        gs = []
+        for n, m in sizes:
+            u, v = er_edges(n, m, rng)
+            e = len(u)
+            uu, vv, rev = with_rev(u, v)
+            g = dgl.DGLGraph.from_edges(uu, vv, n)
+            el = rng.integers(0, n_el, size=e)
+            g.ndata["id"] = th.arange(n)
+            g.ndata["label"] = th.from_numpy(rng.integers(0, n_vl, size=n))
+            g.edata["id"] = th.cat([th.arange(e), th.arange(e) + max(m for _, m in sizes)])
+            g.edata["label"] = th.from_numpy(np.concatenate([el, el + n_el]))
+            g.edata["is_reversed"] = th.from_numpy(rev)
+            g.ndata["in_deg"] = g.in_degrees()
+            g.ndata["out_deg"] = g.out_degrees()
+            gs.append(g)
+        return dgl.batch(gs)
+
+    cases = {
+        "uniform": dict(p_sizes=[(8, 12)] * 32, g_sizes=[(64, 256)] * 32, hid=64, layers=3, extra={}),
+        "ragged": dict(p_sizes=[(3, 3), (5, 9), (4, 6), (8, 12), (2, 1), (6, 10)],
+                       g_sizes=[(10, 30), (16, 50), (7, 12), (20, 64), (5, 8), (12, 40)], hid=16, layers=2,
+                       extra={"pred_with_deg": True, "pred_with_enc": True}),
+    }
+    for tag, c in cases.items():
+        rng = np.random.default_rng(31 if tag == "uniform" else 32)
+        th.manual_seed(7 if tag == "uniform" else 8)
+        pattern = make_batch(c["p_sizes"], 8, 8, rng)
+        graph = make_batch(c["g_sizes"], 16, 16, rng)
+        config = dict(max_ngv=64, max_ngvl=16, max_nge=512, max_ngel=32, max_npv=8, max_npvl=8, max_npe=24,
+                      max_npel=16, base=2, hid_dim=c["hid"], share_emb_net=True, share_enc_net=True,
+                      share_rep_net=True, rep_residual=True, enc_net="Multihot", emb_net="Orthogonal",
+                      filter_net="ScalarFilter", rep_net="DMPNN", rep_num_graph_layers=c["layers"],
+                      rep_num_pattern_layers=c["layers"], rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False,
+                      rep_act_func="relu", rep_dropout=0.0, init_neigenv=6.0, init_eeigenv=5.0,
+                      pred_net="SumPredictNet", pred_hid_dim=c["hid"], pred_act_func="relu", pred_dropout=0.0,
+                      node_pred=True, edge_pred=True)
+        config.update(c["extra"])
+        model = DMPNN(**config)
+        with th.no_grad():  # pred_fc2 is zero-initialised: make the head's output depend on its input
+            for head in model.pred_net.values():
+                head.pred_fc2.weight.uniform_(-0.3, 0.3)
+                head.pred_fc2.bias.uniform_(-0.1, 0.1)
+        out = model(pattern, graph)
+        out["pred_c"].sum().backward()
+        d = {"config_keys": np.array(sorted(config.keys())),
+             "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())])}
+        for t, g in (("p", pattern), ("g", graph)):
+            d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(),
+                      t + "_bnn": g.batch_num_nodes(), t + "_bne": g.batch_num_edges()})
+            for k, v in g.ndata.items():
+                if k in ("id", "label", "in_deg", "out_deg"):
+                    d["%s_ndata.%s" % (t, k)] = v
+            for k, v in g.edata.items():
+                if k in ("id", "label", "is_reversed"):
+                    d["%s_edata.%s" % (t, k)] = v
+        for k, v in model.state_dict().items():
+            d["sd." + k] = v
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                d["grad." + k] = p.grad
+        for k, v in out.items():
+            if v is not None:
+                d["out." + k] = v
+        np.savez_compressed(os.path.join(OUT, "fullmodel_%s.npz" % tag), **t2n(d))
+        print("wrote fullmodel_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
+
+
 UNC_SCRIPT = r'''
 import os, sys
 import numpy as np, torch as th
@@ -369,6 +446,7 @@ def main():
     gen_compgcn()
     gen_linegraph()
     gen_addrev()
+    gen_full_model()
     gen_unc()
 
 
