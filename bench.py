@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: (pattern, graph) pairs/sec of the DMPNN rep-net fwd+bwd at hid=128
+"""Headline benchmark: (pattern, graph) pairs/sec of the full DMPNN model fwd+bwd at hid=128
 on MI355X (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -15,8 +15,10 @@ One step (timed) = what the reference does per batch after the DataLoader hands 
 (SubgraphCountingMatching/train.py:606-686), inputs already resident in HBM:
   device collate of the B pattern and B target graphs (dgl.batch, dataset.py:1320-1328)
   -> graph index build (CSR by dst / by src, degrees)
-  -> DMPNN.get_pattern_rep + get_graph_rep (3 layers, gates, residual; dmpnn.py:215-277)
-  -> sum-pool head + MSE loss on the counts -> backward
+  -> DMPNN(**config).forward(pattern, graph): multihot encodings, embeddings, ScalarFilter gates,
+     3 shared DMPLayers on pattern and target (gates, residual; dmpnn.py:215-277), SumPredictNet
+     heads on nodes and edges (basemodel.py:1500-1663)
+  -> MSE loss on the counts -> backward
   -> ONE all-reduce of the flat gradient buffer (RCCL) -> AdamW step.
 
 The JSON line also carries
@@ -57,87 +59,92 @@ def er_local_edges(batch, n, m, rng):
 
 
 def make_shard(cfg, rank, device):
-    """Per-rank synthetic shard, resident in HBM: per-graph LOCAL edge lists (as a dataset
-    would hold them after add_reversed_edges), sizes, gates, input embeddings, counts."""
+    """Per-rank synthetic shard, resident in HBM, as a dataset would hold it after the reference's
+    preprocessing (ids = arange, add_reversed_edges, degrees): per-graph LOCAL edge lists back to
+    back, node/edge ids and labels, is_reversed, sizes, counts."""
     rng = np.random.default_rng(1000 * cfg["config_id"] + rank)
-    B, H = cfg["batch"], cfg["hid"]
+    B = cfg["batch"]
     out = {}
-    for tag, n, m in (("p", cfg["p_nodes"], cfg["p_edges"]), ("g", cfg["g_nodes"], cfg["g_edges"])):
+    for tag, n, m, nvl, nel in (("p", cfg["p_nodes"], cfg["p_edges"], cfg["p_labels"], cfg["p_labels"]),
+                                ("g", cfg["g_nodes"], cfg["g_edges"], cfg["g_labels"], cfg["g_labels"])):
         u, v = er_local_edges(B, n, m, rng)
-        # add_reversed_edges (train.py:299-327): [forward | reversed] per graph
+        # add_reversed_edges (train.py:299-327): [forward | reversed] per graph, id + max_ne, label + max_nel
         src = np.concatenate([u, v], axis=1).reshape(-1)
         dst = np.concatenate([v, u], axis=1).reshape(-1)
         rev = np.concatenate([np.zeros((B, m), bool), np.ones((B, m), bool)], axis=1).reshape(-1)
+        el = rng.integers(0, nel, size=(B, m))
+        elabel = np.concatenate([el, el + nel], axis=1).reshape(-1)
+        eid = np.tile(np.concatenate([np.arange(m), m + np.arange(m)]), B)
+        nid = np.tile(np.arange(n), B)
+        nlabel = rng.integers(0, nvl, size=B * n)
         out[tag] = dict(
             local_src=torch.from_numpy(src).to(device), local_dst=torch.from_numpy(dst).to(device),
-            rev=torch.from_numpy(rev).to(device),
+            ndata={"id": torch.from_numpy(nid).to(device), "label": torch.from_numpy(nlabel).to(device)},
+            edata={"id": torch.from_numpy(eid).to(device), "label": torch.from_numpy(elabel).to(device),
+                   "is_reversed": torch.from_numpy(rev).to(device)},
             num_nodes=torch.full((B,), n, dtype=torch.int64, device=device),
             num_edges=torch.full((B,), 2 * m, dtype=torch.int64, device=device),
-            N=B * n, E=B * 2 * m, n=n, e=2 * m)
+            N=B * n, E=B * 2 * m)
     g = torch.Generator(device="cpu").manual_seed(1000 * cfg["config_id"] + rank)
-    for tag in ("p", "g"):
-        out[tag]["v_emb"] = torch.randn(out[tag]["N"], H, generator=g).to(device).requires_grad_(True)
-        out[tag]["e_emb"] = torch.randn(out[tag]["E"], H, generator=g).to(device).requires_grad_(True)
-    # filter gates of the target graph (ScalarFilter: label occurs in the pattern; filter.py:6-16)
-    out["g"]["v_gate"] = (torch.rand(out["g"]["N"], 1, generator=g) < 0.75).float().to(device)
-    out["g"]["e_gate"] = (torch.rand(out["g"]["E"], 1, generator=g) < 0.75).float().to(device)
     out["counts"] = torch.randint(0, 64, (B,), generator=g).float().to(device)
     return out
 
 
-class Head(torch.nn.Module):
-    """Sum-pool readout -> count (a reduced SumPredictNet, pred.py:87-156: pools pattern and
-    graph representations per pair and regresses the count)."""
-
-    def __init__(self, hid):
-        super().__init__()
-        self.p = torch.nn.Linear(hid, hid)
-        self.g = torch.nn.Linear(hid, hid)
-        self.out = torch.nn.Linear(4 * hid, 1)
-
-    def forward(self, p_v, g_v, B):
-        p = self.p(p_v.view(B, -1, p_v.size(-1)).sum(1))
-        g = self.g(g_v.view(B, -1, g_v.size(-1)).sum(1))
-        return self.out(torch.relu(torch.cat([p, g, g - p, g * p], dim=1))).squeeze(-1)
+def model_config(cfg):
+    """The reference's DMPNN training configuration (SubgraphCountingMatching/README.md:72-94,
+    'Complex' command) at BASELINE's hid=128; vocabulary sizes after --add_rev doubling."""
+    return dict(max_ngv=cfg["g_nodes"], max_ngvl=cfg["g_labels"], max_nge=2 * cfg["g_edges"], max_ngel=2 * cfg["g_labels"],
+                max_npv=cfg["p_nodes"], max_npvl=cfg["p_labels"], max_npe=2 * cfg["p_edges"], max_npel=2 * cfg["p_labels"],
+                base=2, hid_dim=cfg["hid"], share_emb_net=True, share_enc_net=True, share_rep_net=True,
+                rep_residual=True, enc_net="Multihot", emb_net="Orthogonal", filter_net="ScalarFilter",
+                rep_net="DMPNN", rep_num_graph_layers=cfg["layers"], rep_num_pattern_layers=cfg["layers"],
+                rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False, rep_act_func="relu", rep_dropout=0.0,
+                init_neigenv=4.0, init_eeigenv=4.0, pred_net="SumPredictNet", pred_hid_dim=cfg["hid"],
+                pred_act_func="relu", pred_dropout=0.0, node_pred=True, edge_pred=True)
 
 
 def build_step(cfg, shard, device):
+    from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device
-    from dualmessagepassing_amd.dmpnn import DMPNNRep
     from dualmessagepassing_amd.dp import FlatGradSync
 
     torch.manual_seed(0)
-    net = DMPNNRep(hid_dim=cfg["hid"], rep_num_graph_layers=cfg["layers"], rep_num_pattern_layers=cfg["layers"],
-                   share_rep_net=True, rep_residual=True, rep_dmpnn_batch_norm=False, rep_act_func="relu",
-                   init_neigenv=4.0, init_eeigenv=4.0).to(device)
-    head = Head(cfg["hid"]).to(device)
-    model = torch.nn.ModuleDict({"rep": net, "head": head})
+    model = build_model(**model_config(cfg)).to(device)
     sync = FlatGradSync(model)
     sync.broadcast_parameters()
     opt = torch.optim.AdamW(sync.params, lr=1e-4, weight_decay=1e-5, fused=True)
-    B = cfg["batch"]
 
     def step():
         sync.zero()
-        for tag in ("p", "g"):
-            shard[tag]["v_emb"].grad = None
-            shard[tag]["e_emb"].grad = None
         p, g = shard["p"], shard["g"]
         pattern = collate_device(p["local_src"], p["local_dst"], p["num_nodes"], p["num_edges"], p["N"], p["E"],
-                                 edata={"is_reversed": p["rev"]})
+                                 ndata=p["ndata"], edata=p["edata"])
         graph = collate_device(g["local_src"], g["local_dst"], g["num_nodes"], g["num_edges"], g["N"], g["E"],
-                               edata={"is_reversed": g["rev"]})
-        p_v, p_e, g_v, g_e = net(pattern, graph, p["v_emb"], p["e_emb"], g["v_emb"], g["e_emb"],
-                                 v_gate=g["v_gate"], e_gate=g["e_gate"])
-        pred = head(p_v, g_v, B)
-        # edge reps feed the loss too (edge_pred in the reference), so their backward is not pruned
-        loss = torch.nn.functional.mse_loss(pred, shard["counts"]) + 1e-3 * (g_e.square().mean() + p_e.square().mean())
+                               ndata=g["ndata"], edata=g["edata"])
+        out = model(pattern, graph)
+        loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])  # count loss (train.py:624-628)
         loss.backward()
         sync.sync()
         opt.step()
         return loss
 
     return step, model
+
+
+def pmc_traffic(n_rows, n_edges, H):
+    """HBM bytes per launch of the scatter-add kernel from the committed rocprofv3 PMC run
+    (profiles/r01_pmc_seg_sum2.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950).
+    Returned only if that run was taken at this launch shape; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_seg_sum2.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("rows") == n_rows and d.get("edges") == n_edges and d.get("H") == H:
+            return d["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, seconds_budget=20.0):
@@ -181,7 +188,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         if el > seconds_budget or n >= 50:
             break
     return {"value": B * n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of B=%d pairs (same shapes, hid=%d, %d layers, fwd+bwd, fp32), torch %s CPU, %d threads"
+            "sample": "%d steps of B=%d pairs; rep-net stage only (3-layer pattern + target DMPNN rep-nets with gates/residual, "
+                      "same shapes, hid=%d, %d layers, fwd+bwd, fp32; enc/emb/pred heads not included), torch %s CPU, %d threads"
                       % (n, B, H, L, torch.__version__, cores)}
 
 
@@ -236,14 +244,18 @@ def main():
     if rank == 0:
         pairs = cfg["batch"] * world * args.steps
         H = cfg["hid"]
-        gN, gE = cfg["batch"] * cfg["g_nodes"], cfg["batch"] * 2 * cfg["g_edges"]
-        key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, gN, gE)
+        # the scatter-add launch: the shared rep-net runs once over the union of the pattern and
+        # target batches, so one launch covers N = B*(8+64) destination rows and E = B*(24+512) edge rows
+        uN = cfg["batch"] * (cfg["p_nodes"] + cfg["g_nodes"])
+        uE = cfg["batch"] * 2 * (cfg["p_edges"] + cfg["g_edges"])
+        key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
         roof = None
         if key in kern:
             k = kern[key]
-            roof = {"bound": "hbm", "kernel": "dmp::seg_sum_vec<32,split> (node aggregation by destination, target graph)",
+            roof = {"bound": "hbm", "kernel": "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
+                                              "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
                     "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(uN, uE, H),
                     "bytes_per_launch": int(k["bytes"]), "avg_us": round(k["avg_us"], 2), "launches": k["launches"]}
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=128", "value": round(pairs / dt, 1),
@@ -251,7 +263,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ER pattern(8,12)x target(64,256), add_rev, "
-                                   "batch=%d pairs/GPU, 3-layer shared DMPNN rep-net, hid=%d, fp32" % (cfg["batch"], H),
+                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, Orthogonal emb, ScalarFilter, "
+                                   "3 shared DMPLayers, SumPredictNet node+edge heads), hid=%d, fp32" % (cfg["batch"], H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW"},
             "roofline": roof,

@@ -15,6 +15,7 @@ from collections import OrderedDict
 import torch as th
 import torch.nn as nn
 
+from . import ops
 from .compgcn import CompGCNRepMixin
 from .constants import REVFLAG
 from .dmpnn import DMPNNRepMixin
@@ -92,6 +93,16 @@ class _Padder:
 
     def mask(self):
         return len_to_mask(self.sizes, self.max).view(self.bsz, -1, 1)
+
+
+def _pool_index(graph, kind):
+    cache = graph.__dict__.setdefault("_pool_cache", {})
+    if kind not in cache:
+        if kind == "node":
+            cache[kind] = ops.PoolIndex(graph.batch_num_nodes())
+        else:
+            cache[kind] = ops.PoolIndex(graph.batch_num_edges(), graph.edata.get(REVFLAG))
+    return cache[kind]
 
 
 class BaseModel(nn.Module):
@@ -289,6 +300,26 @@ class GraphAdjModelV2(BaseModel):
             return e_pred_c, (v_pred_w, e_pred_w)
         raise ValueError
 
+    def get_subiso_pred_pooled(self, p_v_sum, p_v_mask, p_e_sum, p_e_mask, g_v_sum, g_v_mask, g_e_sum, g_e_mask):
+        """``get_subiso_pred`` (basemodel.py:1477-1498) on per-graph sums instead of padded rows."""
+        cnt = lambda m: m.float().sum(dim=1).view(-1, 1)
+        v_pred_c = e_pred_c = None
+        if self.node_pred:
+            v_pred_c, _ = self.pred_net["v"].forward_pooled(p_v_sum, p_v_mask.size(1), cnt(p_v_mask),
+                                                            g_v_sum, g_v_mask.size(1), cnt(g_v_mask))
+        if self.edge_pred:
+            e_pred_c, _ = self.pred_net["e"].forward_pooled(p_e_sum, p_e_mask.size(1), cnt(p_e_mask),
+                                                            g_e_sum, g_e_mask.size(1), cnt(g_e_mask))
+        if self.node_pred and self.edge_pred:
+            g_v_len, g_e_len = cnt(g_v_mask), cnt(g_e_mask)
+            g_len = g_v_len + g_e_len
+            return (g_v_len / g_len) * v_pred_c + (g_e_len / g_len) * e_pred_c, (None, None)
+        if self.node_pred:
+            return v_pred_c, (None, None)
+        if self.edge_pred:
+            return e_pred_c, (None, None)
+        raise ValueError
+
     # ---- forward (basemodel.py:1500-1663)
     def forward(self, pattern, graph):
         bsz = pattern.batch_size
@@ -325,6 +356,9 @@ class GraphAdjModelV2(BaseModel):
             g_out_deg = graph.out_degrees().float().view(-1, 1)
             g_in_deg = graph.in_degrees().float().view(-1, 1)
 
+        # pool-then-project (pred.py heads that sum/average rows): per-graph sums straight from the
+        # un-padded representations with the segment-sum kernel; otherwise the reference's padded path
+        pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         p_v_output = g_v_output = p_e_output = g_e_output = None
         if self.node_pred:
             p_add, g_add = [], []
@@ -337,9 +371,13 @@ class GraphAdjModelV2(BaseModel):
             p_v_output = th.cat([self.refine_node_weights(th.cat(p_add, dim=-1)), p_v_rep], dim=-1) if p_add else p_v_rep
             g_v_output = th.cat([self.refine_node_weights(th.cat(g_add, dim=-1)), g_v_rep], dim=-1) if g_add else g_v_rep
             p_v_mask = self.refine_node_weights(p_v_mask)
-            p_v_output = pads["pv"].pad(p_v_output).masked_fill(~p_v_mask, 0)
             g_v_mask = self.refine_node_weights(g_v_mask)
-            g_v_output = pads["gv"].pad(g_v_output).masked_fill(~g_v_mask, 0)
+            if pooled:
+                p_v_output = ops.seg_pool(p_v_output, _pool_index(pattern, "node"))
+                g_v_output = ops.seg_pool(g_v_output, _pool_index(graph, "node"))
+            else:
+                p_v_output = pads["pv"].pad(p_v_output).masked_fill(~p_v_mask, 0)
+                g_v_output = pads["gv"].pad(g_v_output).masked_fill(~g_v_mask, 0)
         if self.edge_pred:
             p_u, p_v = pattern.all_edges(form="uv", order="eid")
             g_u, g_v = graph.all_edges(form="uv", order="eid")
@@ -353,14 +391,23 @@ class GraphAdjModelV2(BaseModel):
             p_e_output = th.cat([self.refine_edge_weights(th.cat(p_add, dim=-1)), p_e_rep], dim=-1) if p_add else p_e_rep
             g_e_output = th.cat([self.refine_edge_weights(th.cat(g_add, dim=-1)), g_e_rep], dim=-1) if g_add else g_e_rep
             p_e_mask = self.refine_edge_weights(p_e_mask)
-            p_e_output = pads["pe"].pad(p_e_output).masked_fill(~p_e_mask, 0)
             g_e_mask = self.refine_edge_weights(g_e_mask)
-            g_e_output = pads["ge"].pad(g_e_output).masked_fill(~g_e_mask, 0)
+            if pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
+                d = p_e_output.size(1)
+                p_e_output = ops.seg_pool(p_e_output, _pool_index(pattern, "edge"))[:, :d]
+                g_e_output = ops.seg_pool(g_e_output, _pool_index(graph, "edge"))[:, :d]
+            else:
+                p_e_output = pads["pe"].pad(p_e_output).masked_fill(~p_e_mask, 0)
+                g_e_output = pads["ge"].pad(g_e_output).masked_fill(~g_e_mask, 0)
 
         p_v_mask, p_e_mask = p_v_mask.view(bsz, -1), p_e_mask.view(bsz, -1)
         g_v_mask, g_e_mask = g_v_mask.view(bsz, -1), g_e_mask.view(bsz, -1)
-        pred_c, (pred_v, pred_e) = self.get_subiso_pred(p_v_output, p_v_mask, p_e_output, p_e_mask,
-                                                        g_v_output, g_v_mask, g_e_output, g_e_mask)
+        if pooled:
+            pred_c, (pred_v, pred_e) = self.get_subiso_pred_pooled(p_v_output, p_v_mask, p_e_output, p_e_mask,
+                                                                   g_v_output, g_v_mask, g_e_output, g_e_mask)
+        else:
+            pred_c, (pred_v, pred_e) = self.get_subiso_pred(p_v_output, p_v_mask, p_e_output, p_e_mask,
+                                                            g_v_output, g_v_mask, g_e_output, g_e_mask)
         return OutputDict(p_v_emb=p_v_emb, p_e_emb=p_e_emb, g_v_emb=g_v_emb, g_e_emb=g_e_emb,
                           p_v_rep=p_v_rep, p_e_rep=p_e_rep, g_v_rep=g_v_rep, g_e_rep=g_e_rep,
                           p_v_mask=p_v_mask, p_e_mask=p_e_mask, g_v_mask=g_v_mask, g_e_mask=g_e_mask,

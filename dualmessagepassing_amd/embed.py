@@ -5,6 +5,8 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
+from . import ops
+
 
 def get_enc_len(x, base=10):
     """embed.py:8-35: number of base-``base`` digits of x (at least 1)."""
@@ -46,7 +48,8 @@ class Embedding(nn.Embedding):
             return super(Embedding, self).forward(x)
         if x.dtype == th.float and x.size(-1) == self.num_embeddings:
             x_size = x.size()
-            emb = th.matmul(x.view(-1, x_size[-1]), self.weight)
+            # x @ weight; the weight gradient x^T dOut has K = #rows (5e5 edges): split-K product
+            emb = ops.matmul_xw(x.view(-1, x_size[-1]), self.weight)
             return emb.view(x_size[:-1] + (self.embedding_dim,))
         raise NotImplementedError
 

@@ -364,3 +364,64 @@ def apply_mlp(seq, x):
             x = m(x)
             i += 1
     return x
+
+
+# ----------------------------------------------------------------------------- per-graph pooling
+class PoolIndex:
+    """Index for summing the rows (nodes or edges) of every graph of a batch with the segment-sum
+    kernel: each graph's contiguous row range is cut into chunks of ``CHUNK`` rows ("virtual rows",
+    enough of them to fill the chip), chunk sums are then summed per graph.  ``flag`` (edges:
+    is_reversed) splits the sum into [non-flagged | flagged] halves."""
+
+    CHUNK = 64
+
+    def __init__(self, sizes, flag=None):
+        dev = sizes.device
+        sizes = sizes.to(torch.int64)
+        B = int(sizes.numel())
+        off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(sizes, 0, out=off[1:])
+        R = int(off[-1].item())
+        C = self.CHUNK
+        nchunk = (sizes + C - 1) // C
+        coff = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nchunk, 0, out=coff[1:])
+        V = int(coff[-1].item())
+        cgraph = torch.repeat_interleave(torch.arange(B, device=dev), nchunk, output_size=V)
+        cstart = off[cgraph] + (torch.arange(V, device=dev) - coff[cgraph]) * C
+        vptr = torch.empty(V + 1, dtype=torch.int64, device=dev)
+        vptr[:V] = cstart
+        vptr[V] = R
+        self.num_graphs, self.num_rows, self.num_chunks = B, R, V
+        self.vptr = vptr.to(torch.int32)
+        ent = torch.arange(R, device=dev, dtype=torch.int64) << 1
+        if flag is not None:
+            ent = ent | flag.view(-1).to(torch.int64)
+        self.vent = ent.to(torch.int32)
+        self.gptr = coff.to(torch.int32)
+        self.gent = (torch.arange(V, device=dev, dtype=torch.int64) << 1).to(torch.int32)
+        self.seg32 = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), sizes, output_size=R)
+        self.flag8 = None if flag is None else flag.view(-1).to(torch.uint8).contiguous()
+
+
+class _SegPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool):
+        ctx.pool, ctx.H = pool, x.size(1)
+        split = pool.flag8 is not None
+        part = seg_sum_raw(x, pool.vptr, pool.vent, pool.num_chunks, None, split, 1.0, 1.0, rows_shared=False)
+        return seg_sum_raw(part, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        p = ctx.pool
+        if p.flag8 is not None:
+            return gather_select_raw(d, p.seg32, p.flag8, ctx.H, None, 1.0, 1.0), None
+        return gather_rows_raw(d, p.seg32), None
+
+
+def seg_pool(x, pool):
+    """Per-graph sums of the rows of ``x``: [B, H], or [B, 2H] = [sum over non-flagged | flagged]
+    when the PoolIndex carries a flag.  Fixed summation order (bit-stable)."""
+    return _SegPool.apply(x, pool)

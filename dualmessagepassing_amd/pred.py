@@ -81,12 +81,41 @@ class PredictNet(nn.Module):
         return y, w
 
 
+    # ---- pool-then-project: sum/mean pooling commutes with the affine p_fc / g_fc, so the per-row
+    # Linear over [B, L, D] (an E-row GEMM and its [B, L, hid] intermediate) collapses to a
+    # [B, D] x [D, hid] product on the per-graph sums:  sum_j (W x_j + b) = W sum_j x_j + L b.
+    pool_kind = None  # "sum" | "mean" for the poolable heads
+
+    def poolable(self):
+        return self.pool_kind is not None and self.weight_fc1 is None and not (self.drop.p > 0.0 and self.training)
+
+    def forward_pooled(self, p_sum, p_pad_len, pl, g_sum, g_pad_len, gl):
+        """p_sum / g_sum [B, D]: sums of the (masked) pattern / graph rows; *_pad_len: padded length L
+        of the reference's [B, L, D] tensors (every padded or masked position contributes the bias);
+        pl / gl [B, 1]: mask counts (pred.py:93-96)."""
+        pl_inv, gl_inv = 1.0 / pl, 1.0 / gl
+        if self.pool_kind == "sum":
+            p = th.nn.functional.linear(p_sum, self.p_fc.weight) + float(p_pad_len) * self.p_fc.bias
+            g = th.nn.functional.linear(g_sum, self.g_fc.weight) + float(g_pad_len) * self.g_fc.bias
+        else:
+            p = self.p_fc(p_sum / float(p_pad_len))
+            g = self.g_fc(g_sum / float(g_pad_len))
+        y = th.cat([p, g, g - p, g * p, pl, gl, pl_inv, gl_inv], dim=1)
+        y = self.act(self.pred_fc1(y))
+        y = self.pred_fc2(th.cat([y, pl, gl, pl_inv, gl_inv], dim=1))
+        return y, None
+
+
 class MeanPredictNet(PredictNet):
+    pool_kind = "mean"
+
     def agg_graph(self, g_rep, g_mask=None):
         return th.mean(g_rep, dim=1)
 
 
 class SumPredictNet(PredictNet):
+    pool_kind = "sum"
+
     def agg_graph(self, g_rep, g_mask=None):
         return th.sum(g_rep, dim=1)
 
