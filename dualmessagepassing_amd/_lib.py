@@ -132,6 +132,7 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None   # if set: time only launches whose name starts with this prefix
         self.records = {}  # name -> list of (start_event, end_event, algorithmic_bytes)
 
     def reset(self):
@@ -161,7 +162,8 @@ class timed:
         self.name, self.nbytes = name, nbytes
 
     def __enter__(self):
-        if timer.enabled:
+        self.on = timer.enabled and (timer.only is None or self.name.startswith(timer.only))
+        if self.on:
             import torch
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
@@ -169,7 +171,7 @@ class timed:
         return self
 
     def __exit__(self, *exc):
-        if timer.enabled:
+        if self.on:
             self.b.record()
             timer.records.setdefault(self.name, []).append((self.a, self.b, self.nbytes))
         return False

@@ -58,6 +58,30 @@ class FlatGradSync:
     def zero(self):
         self.flat.zero_()
 
+    # ---- alternative to accumulating into the views: let autograd produce fresh gradient tensors
+    # (no per-parameter ``grad += new`` launches) and pack them with one multi-tensor copy
+    def detach_grads(self):
+        """Call before backward instead of ``zero()``: parameters start without a ``.grad``."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """After backward: copy the fresh gradients into the flat buffer (zeros where a parameter
+        got none) and point every ``.grad`` at its slice again."""
+        self.flat.zero_()
+        views, grads = [], []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[off:off + n].view_as(p)
+            if p.grad is not None:
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+            off += n
+        if views:
+            torch._foreach_copy_(views, grads)
+
     def broadcast_parameters(self, src=0):
         if self.world > 1:
             for p in self.params:

@@ -104,3 +104,22 @@ def test_shard_range_partitions(n, world):
     assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
     sizes = [b - a for a, b in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_equals_accumulate_into_views():
+    """detach_grads()/pack() (fresh gradients, one multi-tensor copy) fills the flat buffer exactly
+    like accumulating into the views, and leaves zeros for parameters without a gradient."""
+    x, y = _data()
+    m1, m2 = Tiny(), Tiny()
+    s1, s2 = FlatGradSync(m1), FlatGradSync(m2)
+    s1.zero()
+    torch.nn.functional.mse_loss(m1(x), y).backward()
+    s2.detach_grads()
+    torch.nn.functional.mse_loss(m2(x), y).backward()
+    assert all(p.grad is None for p in m2.unused.parameters())
+    s2.pack()
+    assert torch.equal(s1.flat, s2.flat)
+    for p in s2.params:  # .grad is a view of the flat buffer again (what the optimizer / all-reduce use)
+        assert p.grad is not None and p.grad.data_ptr() >= s2.flat.data_ptr()
+    s2.flat.mul_(2.0)
+    assert torch.equal(s2.params[0].grad, s1.params[0].grad * 2.0)
