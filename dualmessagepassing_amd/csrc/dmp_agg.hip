@@ -539,9 +539,15 @@ static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, cons
                         float *out, int64_t ldo, int rows_shared, void *stream) {
   if (N < 0 || H <= 0 || ldm < H || ldo < (split ? 2 * H : H)) return DMP_ERR_BAD_ARG;
   if (N == 0) return DMP_OK;
-  if (!M || !rowptr || !ent || !out) return DMP_ERR_BAD_ARG;
+  if (!rowptr || !out) return DMP_ERR_BAD_ARG;
   if (N >= kMaxRows) return DMP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (!M || !ent) {  // a graph without edges: every sum is empty
+    const size_t width = sizeof(float) * (size_t)(split ? 2 * H : H);
+    hipError_t e = hipMemset2DAsync(out, sizeof(float) * (size_t)ldo, 0, width, (size_t)N, st);
+    if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
+    return DMP_OK;
+  }
   if (vec_ok(H, {ldm, ldo}, {M, out})) {
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(N, kBlock / G);

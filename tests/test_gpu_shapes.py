@@ -1,0 +1,138 @@
+"""GPU parity at the other BASELINE shapes (reduced batch so the CPU oracle finishes in seconds)
+and on degenerate graphs: config 4 (pattern (16,32) x target (512,4096), hid 128), config 5
+(Cora-shaped single graph N=2708, E=10858 with reversed copies, UNC DualGraphConv x2, hid 256),
+graphs without edges, a single node, one giant hub."""
+import numpy as np
+import pytest
+import torch as th
+
+import dmp_oracle as O
+from util_graphs import er_batch, er_edges
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return th.from_numpy(np.asarray(a))
+
+
+def _close(got, ref, tol, what):
+    got, ref = got.detach().double().cpu(), ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max())) if ref.numel() else 1.0
+    err = float((got - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= tol * scale, "%s: max err %g (scale %g)" % (what, err, scale)
+
+
+def test_config4_shape_three_layer_rep(gpu):
+    from dualmessagepassing_amd.dmpnn import DMPNNRep
+    from dualmessagepassing_amd.graph import BatchedGraph
+    rng = np.random.default_rng(4000)
+    h, L, B = 128, 3, 4
+    ps, pd, pr, pn, pbnn, pbne = er_batch(B, 16, 32, rng)
+    gs, gd, gr, gn, gbnn, gbne = er_batch(B, 512, 4096, rng)
+    gen = th.Generator().manual_seed(4)
+    layers = [O.random_dmp_params(h, h, gen) for _ in range(L)]
+    net = DMPNNRep(hid_dim=h, rep_num_graph_layers=L, rep_num_pattern_layers=L, share_rep_net=True,
+                   rep_residual=True, rep_dmpnn_batch_norm=False, rep_act_func="relu")
+    sd = {}
+    for i, p in enumerate(layers):
+        for k, v in p.items():
+            sd["g_rep_net.dmpnn.graph_dmpnn_(%d).%s" % (i, k)] = v
+            sd["p_rep_net.dmpnn.graph_dmpnn_(%d).%s" % (i, k)] = v
+    net.load_state_dict(sd, strict=True)
+    net.to(gpu)
+    pv, pe = th.randn(pn, h, generator=gen), th.randn(len(ps), h, generator=gen)
+    gv, ge = th.randn(gn, h, generator=gen), th.randn(len(gs), h, generator=gen)
+    vg = (th.rand(gn, 1, generator=gen) < 0.8).float()
+    eg = (th.rand(len(gs), 1, generator=gen) < 0.8).float()
+    tps, tpd, tpr, tgs, tgd, tgr = map(_t, (ps, pd, pr, gs, gd, gr))
+    a_o, b_o = O.dmpnn_graph_rep(layers, tps, tpd, tpr, O.out_degrees(tps, pn), pv, pe)
+    c_o, d_o = O.dmpnn_graph_rep(layers, tgs, tgd, tgr, O.out_degrees(tgs, gn), gv, ge, vg, eg)
+    pg = BatchedGraph(tps.to(gpu), tpd.to(gpu), pn, _t(pbnn).to(gpu), _t(pbne).to(gpu), None, {"is_reversed": tpr.to(gpu)})
+    gg = BatchedGraph(tgs.to(gpu), tgd.to(gpu), gn, _t(gbnn).to(gpu), _t(gbne).to(gpu), None, {"is_reversed": tgr.to(gpu)})
+    a, b, c, d = net(pg, gg, pv.to(gpu), pe.to(gpu), gv.to(gpu), ge.to(gpu), v_gate=vg.to(gpu), e_gate=eg.to(gpu))
+    for got, ref, nm in ((a, a_o, "p_v"), (b, b_o, "p_e"), (c, c_o, "g_v"), (d, d_o, "g_e")):
+        _close(got, ref, 2e-4, nm)
+
+
+def test_config5_cora_shape_unc_two_layers(gpu):
+    """UNC DMPNN stack (model.py:296-316): DualGraphConv(tanh) -> DualGraphConv(None), BN in eval."""
+    from dualmessagepassing_amd.unc import DualGraphConv, build_graph_from_triplets
+    rng = np.random.default_rng(5000)
+    n, m, h = 2708, 5429, 256
+    u, v = er_edges(n, m, rng)
+    trip = np.stack([u, np.zeros(m, np.int64), v], 1)
+    g = build_graph_from_triplets(n, 1, trip, gpu)
+    assert g.number_of_edges() == 10858
+    src, dst = (t.cpu() for t in g.all_edges())
+    norm = O.unc_edge_norm(src, dst, n, "in")
+    _close(g.edata["norm"], norm, 1e-6, "norm")
+    th.manual_seed(5)
+    l1 = DualGraphConv(h, h, activation=th.nn.Tanh()).eval()
+    l2 = DualGraphConv(h, h, activation=None).eval()
+    for layer in (l1, l2):
+        with th.no_grad():
+            for seq in (layer.nmlp, layer.emlp):
+                seq[1].running_mean.uniform_(-0.2, 0.2)
+                seq[1].running_var.uniform_(0.5, 1.5)
+    x, z = th.randn(n, h), th.randn(10858, h)
+    out_deg = O.out_degrees(src, n)
+
+    def oracle(layer, x, z, act):
+        p = {k: v.detach() for k, v in layer.named_parameters()}
+        bn = {m + ".1": {"running_mean": getattr(layer, m)[1].running_mean.clone(),
+                         "running_var": getattr(layer, m)[1].running_var.clone()} for m in ("nmlp", "emlp")}
+        return O.dual_graph_conv(p, src, dst, out_deg, x, z, norm, None, bn, False, act)
+
+    xo, zo = oracle(l1, x, z, "tanh")
+    xo, zo = oracle(l2, xo, zo, None)
+    l1.to(gpu)
+    l2.to(gpu)
+    xg, zg = l1(g, x.to(gpu), z.to(gpu), g.edata["norm"])
+    xg, zg = l2(g, xg, zg, g.edata["norm"])
+    _close(xg, xo, 5e-5, "node rep")
+    _close(zg, zo, 5e-5, "edge rep")
+
+
+@pytest.mark.parametrize("case", ["no_edges", "single_node", "hub"])
+def test_degenerate_graphs_through_the_layer(case, gpu):
+    from dualmessagepassing_amd.dmpnn import DMPLayer
+    from dualmessagepassing_amd.graph import BatchedGraph
+    rng = np.random.default_rng(9)
+    if case == "no_edges":
+        src, dst, n = np.zeros(0, np.int64), np.zeros(0, np.int64), 5
+    elif case == "single_node":
+        src, dst, n = np.array([0, 0], np.int64), np.array([0, 0], np.int64), 1   # two self loops
+    else:
+        n = 40
+        src = np.concatenate([np.arange(1, n), np.zeros(n - 1, np.int64)]).astype(np.int64)  # star in + out
+        dst = np.concatenate([np.zeros(n - 1, np.int64), np.arange(1, n)]).astype(np.int64)
+        src, dst = np.tile(src, 30), np.tile(dst, 30)                                       # in-degree 1170 at the hub
+    e, h = len(src), 16
+    rev = rng.random(e) < 0.5
+    gen = th.Generator().manual_seed(3)
+    p = O.random_dmp_params(h, h, gen)
+    x = th.randn(n, h, generator=gen)
+    z = th.randn(e, h, generator=gen)
+    ts, td, tr = _t(src), _t(dst), _t(rev)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xo, zo = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    no, eo, _, _ = O.dmp_layer(po, ts, td, tr, O.out_degrees(ts, n), xo, zo)
+    (no.sum() + (eo * eo).sum()).backward()
+    layer = DMPLayer(h, h, batch_norm=False)
+    layer.load_state_dict(p)
+    layer.to(gpu)
+    g = BatchedGraph(ts.to(gpu), td.to(gpu), n, None, None, None, {"is_reversed": tr.to(gpu)})
+    xg, zg = x.to(gpu).requires_grad_(True), z.to(gpu).requires_grad_(True)
+    for fused in (False, True):
+        xg.grad = zg.grad = None
+        if fused:
+            ng, eg = layer.forward_fused(g, xg, zg, None, None, residual=False)
+        else:
+            ng, eg = layer(g, xg, zg)
+        _close(ng, no, 1e-4, "node_out fused=%s" % fused)
+        _close(eg, eo, 1e-4, "edge_out fused=%s" % fused)
+        (ng.sum() + (eg * eg).sum()).backward()
+        _close(xg.grad, xo.grad, 1e-4, "dx fused=%s" % fused)
+        _close(zg.grad, zo.grad, 1e-4, "dz fused=%s" % fused)
