@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=CFG["batch"], help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path on a single-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
@@ -224,6 +225,8 @@ def main():
 
     cfg = dict(CFG, batch=args.batch)
     from dualmessagepassing_amd import _lib
+    from dualmessagepassing_amd.tuning import enable_tuned_gemms
+    tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
     shard = make_shard(cfg, rank, device)
     step, model = build_step(cfg, shard, device)
 
@@ -285,7 +288,8 @@ def main():
                                    "batch=%d pairs/GPU, full DMPNN model (Multihot enc, Orthogonal emb, ScalarFilter, "
                                    "3 shared DMPLayers, SumPredictNet node+edge heads), hid=%d, fp32" % (cfg["batch"], H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
-                       "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW"},
+                       "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW",
+                       "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},
             "roofline": roof,
             "kernels": {n: {"avg_us": round(v["avg_us"], 2), "gbps": round(v["gbps"], 1), "launches": v["launches"],
                             "bytes": int(v["bytes"])} for n, v in sorted(kern.items())},
