@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdmp_hip.so")
-SOURCES = ["dmp_agg.hip", "dmp_graph.hip", "dmp_fused.hip"]
+SOURCES = ["dmp_agg.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip"]
 HEADERS = ["dmp_common.h", os.path.join("..", "..", "include", "dmp_hip.h")]
 ARCH = "gfx950"
 

@@ -47,6 +47,11 @@ SIGNATURES = {
     "dmp_edge_combine_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_colsum_partials": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr]),
+    "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                   c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_out_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
+                                  c_i64, c_ptr]),
+    "dmp_gemm_k128": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_edge_combine": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                  c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_relu_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
@@ -58,7 +63,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

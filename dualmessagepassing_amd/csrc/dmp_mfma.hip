@@ -1,0 +1,231 @@
+// Fused MFMA kernels of the DMPLayer edge chain (gfx950, fp32 in / fp32 accumulate, exact fp32:
+// v_mfma_f32_32x32x2_f32).  K = H = 128 only; other widths take the GEMM + epilogue-kernel path.
+//
+// Structure (one persistent 512-thread workgroup per CU, 8 waves = 2 per SIMD):
+//   * the [128, NC*128] weight panel lives in REGISTERS for the whole kernel: wave w keeps the
+//     fragments of its 32-column slice (w&3) of every panel, b[p][s] = B[s + 64h][128p + 32(w&3) + l]
+//     (h = lane>>5, l = lane&31): no LDS or cache traffic for the weights inside the loop;
+//   * 128-row tiles of the streamed operand go global -> registers (prefetched one tile ahead,
+//     in flight under the MFMAs) -> LDS (132-float rows: conflict-free ds_read_b128);
+//   * wave w computes row sub-tiles {2(w>>2), 2(w>>2)+1}: 64 k-steps x NC panels of 32x32x2 MFMAs
+//     per sub-tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's
+//     A operands are 4 consecutive floats of its LDS row (one ds_read_b128 per 4 MFMAs);
+//   * the epilogue runs on the accumulator registers (row = (r&3)+8(r>>2)+4h, col = l), then the
+//     32x32 result goes through a per-wave LDS transpose so that stores are 16 B per lane.
+//
+//   dmp_edge_fwd_fused   H1[e] = relu(Z W'[:, :H] + coef[dst e] Z W'[:, H:] + P[a_e, 0:H] - P[b_e, H:2H] + b)
+//                        = the G GEMM + dmp_edge_combine(relu) of the fused layer in one pass
+//                        (the [E,2H] product never reaches HBM)
+//   dmp_out_fwd_fused    Zn[e] = Z[e] + gate[e] (H1[e] W2^T + b2)   = Linear + dmp_gate_residual
+//   dmp_gemm_k128        plain C = A B (development / tests)
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kTileRows = 128;
+constexpr int kLdsStride = 132;
+constexpr int kThreads = 512;
+constexpr int kScrStride = 36;
+
+enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2 };
+
+struct MfmaArgs {
+  const float *A; int64_t lda;      // streamed operand [E,128]
+  const float *B; int64_t ldb;      // weights: B[k*ldb + j] (bt == 0) or B[j*ldb + k] (bt == 1)
+  int bt;
+  float *C; int64_t ldc;            // output [E, 128] (EPI_EDGE / EPI_GATE_RES) or [E, NC*128]
+  int64_t E;
+  // EPI_EDGE
+  const float *P; int64_t ldp;      // node projections [N, >=2H]: P[:, 0:H] (W_dst side), P[:, H:2H] (W_src side)
+  const float *coef;                // [N]
+  const int32_t *src, *dst; const uint8_t *flag;
+  const float *bias;                // [128] or NULL
+  // EPI_GATE_RES
+  const float *R; int64_t ldr;      // residual rows [E,128] or NULL
+  const float *gate;                // [E] or NULL
+};
+
+template <int NC, int EPI>
+__global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
+  __shared__ float As[kTileRows * kLdsStride];
+  __shared__ float Cs[8 * 32 * kScrStride];
+  __shared__ int rowA[kTileRows], rowB[kTileRows];
+  __shared__ float rowS[kTileRows];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int cs = wave & 3, rh = wave >> 2;
+  const int col = 32 * cs + li;
+  float b[NC][64];
+#pragma unroll
+  for (int q = 0; q < NC; ++q)
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+      const int k = s + 64 * h, j = 128 * q + col;
+      b[q][s] = p.bt ? p.B[(int64_t)j * p.ldb + k] : p.B[(int64_t)k * p.ldb + j];
+    }
+  const float bias_j = (EPI != EPI_NONE && p.bias) ? p.bias[col] : 0.f;
+
+  const int64_t ntiles = (p.E + kTileRows - 1) / kTileRows;
+  float4 pre[8];
+  auto load_tile = [&](int64_t t) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int q = threadIdx.x + kThreads * m;
+      const int64_t row = t * kTileRows + (q >> 5);
+      pre[m] = row < p.E ? *reinterpret_cast<const float4 *>(p.A + row * p.lda + (q & 31) * 4) : make_float4(0, 0, 0, 0);
+    }
+  };
+  int64_t t = blockIdx.x;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile: LDS reads done
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int q = threadIdx.x + kThreads * m;
+      *reinterpret_cast<float4 *>(&As[(q >> 5) * kLdsStride + (q & 31) * 4]) = pre[m];
+    }
+    if (EPI == EPI_EDGE && threadIdx.x < kTileRows) {
+      const int64_t e = t * kTileRows + threadIdx.x;
+      int a = 0, bb = 0;
+      float cf = 0.f;
+      if (e < p.E) {
+        const int u = p.src[e], v = p.dst[e];
+        const bool f = p.flag && p.flag[e];
+        a = f ? u : v;
+        bb = f ? v : u;
+        cf = p.coef[v];
+      }
+      rowA[threadIdx.x] = a; rowB[threadIdx.x] = bb; rowS[threadIdx.x] = cf;
+    }
+    if (EPI == EPI_GATE_RES && threadIdx.x < kTileRows) {
+      const int64_t e = t * kTileRows + threadIdx.x;
+      rowS[threadIdx.x] = (p.gate && e < p.E) ? p.gate[e] : 1.f;
+    }
+    __syncthreads();
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // next tile in flight under the MFMAs
+#pragma unroll 1
+    for (int ss = 0; ss < 2; ++ss) {
+      const int sub = 2 * rh + ss;
+      const int64_t tile_row = t * kTileRows + 32 * sub;
+      f32x16 acc[NC];
+      if (EPI == EPI_EDGE) {
+        // the gathered node projections + bias initialise the first accumulator (no extra pass,
+        // no extra registers): acc0 = (P[a, j] - P[b, H + j]) + bias_j
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float pa = p.P[(int64_t)rowA[rl] * p.ldp + col];
+          const float pb = p.P[(int64_t)rowB[rl] * p.ldp + 128 + col];
+          acc[0][r] = (pa - pb) + bias_j;
+          acc[NC - 1][r] = NC > 1 ? 0.f : acc[0][r];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      }
+      const float *arow = &As[(32 * sub + li) * kLdsStride + 64 * h];
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * s4);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][4 * s4 + 0], acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][4 * s4 + 1], acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][4 * s4 + 2], acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][4 * s4 + 3], acc[q], 0, 0, 0);
+        }
+      }
+      float *scr = &Cs[wave * 32 * kScrStride];
+      constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = acc[q][r];
+          if (EPI == EPI_EDGE) {
+            v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
+            v = fmaxf(v, 0.f);
+          } else if (EPI == EPI_GATE_RES) {
+            v = (v + bias_j) * rowS[32 * sub + rr];
+          }
+          scr[rr * kScrStride + li] = v;
+        }
+        // written and read by the same wave: LDS operations of one wave complete in order
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rr = 8 * k + (lane >> 3), c4 = (lane & 7) * 4;
+          float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + c4]);
+          const int64_t row = tile_row + rr;
+          if (row < p.E) {
+            if (EPI == EPI_GATE_RES && p.R) {
+              const float4 z = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + 32 * cs + c4);
+              v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w;
+            }
+            *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 * q + 32 * cs + c4) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+inline unsigned grid_blocks(int64_t E) {
+  const int64_t ntiles = (E + kTileRows - 1) / kTileRows;
+  return (unsigned)(ntiles < 256 ? (ntiles > 0 ? ntiles : 1) : 256);
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed, float *C,
+                  int64_t ldc, int64_t E, int ncols, void *stream) {
+  if (E < 0 || lda < 128 || ldc < ncols || (ncols != 128 && ncols != 256)) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!A || !B || !C || lda % 4 || ldc % 4 || !aligned16(A) || !aligned16(C)) return DMP_ERR_BAD_ARG;
+  MfmaArgs p{};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bt = b_transposed; p.C = C; p.ldc = ldc; p.E = E;
+  hipStream_t st = (hipStream_t)stream;
+  if (ncols == 128) mfma_k128<1, EPI_NONE><<<grid_blocks(E), kThreads, 0, st>>>(p);
+  else mfma_k128<2, EPI_NONE><<<grid_blocks(E), kThreads, 0, st>>>(p);
+  return check_launch();
+}
+
+int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
+                       const float *coef, const float *bias, const int32_t *src, const int32_t *dst,
+                       const uint8_t *flag, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
+  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!Z || !W || !P || !coef || !src || !dst || !H1 || ldz < H || ldw < 2 * H || ldp < 2 * H || ldh < H)
+    return DMP_ERR_BAD_ARG;
+  if (ldz % 4 || ldh % 4 || !aligned16(Z) || !aligned16(H1)) return DMP_ERR_UNSUPPORTED;
+  MfmaArgs p{};
+  p.A = Z; p.lda = ldz; p.B = W; p.ldb = ldw; p.bt = 0; p.C = H1; p.ldc = ldh; p.E = E;
+  p.P = P; p.ldp = ldp; p.coef = coef; p.src = src; p.dst = dst; p.flag = flag; p.bias = bias;
+  mfma_k128<2, EPI_EDGE><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
+                      const float *gate, const float *R, int64_t ldr, int64_t E, int H, float *out,
+                      int64_t ldo, void *stream) {
+  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!Hin || !W2 || !out || ldh < H || ldw < H || ldo < H || (R && ldr < H)) return DMP_ERR_BAD_ARG;
+  if (ldh % 4 || ldo % 4 || (R && ldr % 4) || !aligned16(Hin) || !aligned16(out) || (R && !aligned16(R)))
+    return DMP_ERR_UNSUPPORTED;
+  MfmaArgs p{};
+  p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw; p.bt = 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]
+  p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.gate = gate; p.R = R; p.ldr = ldr;
+  mfma_k128<1, EPI_GATE_RES><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+}  // extern "C"

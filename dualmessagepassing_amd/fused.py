@@ -136,6 +136,34 @@ def relu_bwd_g_colsum(d_h, act, coef, dst32):
     return d_g, reduce_partials(part)
 
 
+USE_MFMA_KERNELS = True  # H == 128: fused MFMA kernels for the edge chain (csrc/dmp_mfma.hip)
+
+
+def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
+    """relu(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128)."""
+    lib = _lib.load()
+    E, H = z.shape
+    out = torch.empty((E, H), dtype=torch.float32, device=z.device)
+    Wes = Wes.contiguous()
+    with _lib.timed("edge_fwd_mfma[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 9 * E):
+        check(lib.dmp_edge_fwd_fused(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, ptr(coef), ptr(bias),
+                                     ptr(index.src32), ptr(index.dst32), ptr(index.rev8), E, H, ptr(out), H,
+                                     stream_ptr()), "dmp_edge_fwd_fused")
+    return out
+
+
+def out_fwd_mfma(h1, W2, b2, gate, prev):
+    """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128)."""
+    lib = _lib.load()
+    R, H = h1.shape
+    out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
+    W2 = W2.contiguous()
+    with _lib.timed("out_fwd_mfma[H=%d,R=%d]" % (H, R), 4 * H * R * (3 if prev is not None else 2)):
+        check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2), W2.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H,
+                                    ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
+    return out
+
+
 class _FusedDMPLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, in_w, out_w, src_w, dst_w, nloop_w, eloop_w,
@@ -164,11 +192,15 @@ class _FusedDMPLayer(torch.autograd.Function):
         On = torch.addmm(nb2, H1n, nW2.t())
         xn = gate_residual(x if residual else None, On, v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        G = z @ Wes
-        H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True)
-        del G
-        Oe = torch.addmm(eb2, H1e, eW2.t())
-        zn = gate_residual(z if residual else None, Oe, e_gate)
+        if USE_MFMA_KERNELS and H == 128:
+            H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index)
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
+        else:
+            G = z @ Wes
+            H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True)
+            del G
+            Oe = torch.addmm(eb2, H1e, eW2.t())
+            zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate = v_gate, e_gate
         ctx.save_for_backward(x, z, S, H1n, H1e, Mn, Me, Bn, Wx, Wes, nW0, nW2, eW0, eW2)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 4
+#define DMP_ABI_VERSION 5
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -335,6 +335,37 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * split-K partial products of the weight gradients. */
 int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out,
                         int accumulate, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * The E-row projection of the layer and dmp_edge_combine(relu) in one pass
+ * (dmpnn.py:112,120,124,142-152 with the first Linear of emlp folded in, see fused.py):
+ *     H1[e] = relu( Z[e] W[:, 0:H] + coef[dst e] * Z[e] W[:, H:2H] + b
+ *                   + (flag[e] ? P[src e,0:H] - P[dst e,H:2H] : P[dst e,0:H] - P[src e,H:2H]) )
+ *   Z [E, ldz>=H], W [H, ldw>=2H] row-major ([in, out] layout), P [N, ldp>=2H], H1 [E, ldh>=H].
+ * The [E,2H] product never reaches HBM.  Returns DMP_ERR_UNSUPPORTED unless H == 128.
+ */
+int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
+                       const float *P, int64_t ldp, const float *coef, const float *bias,
+                       const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                       int64_t num_edges, int H, float *H1, int64_t ldh, void *stream);
+
+/*
+ * Second Linear of the MLP + gate + residual in one pass (dmpnn.py:136,152 + 263-273):
+ *     out[r] = R[r] + gate[r] * (Hin[r] W2^T + b2)
+ *   W2 [H, ldw>=H] in nn.Linear layout [out, in]; gate [rows] or NULL (1); R [rows, ldr] or NULL (0).
+ */
+int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw,
+                      const float *bias, const float *gate, const float *R, int64_t ldr,
+                      int64_t rows, int H, float *out, int64_t ldo, void *stream);
+
+/* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
+ * the bare pipeline of the two kernels above, kept for tests and tuning. */
+int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed,
+                  float *C, int64_t ldc, int64_t rows, int ncols, void *stream);
 
 #ifdef __cplusplus
 }
