@@ -17,6 +17,10 @@
 //                        = the G GEMM + dmp_edge_combine(relu) of the fused layer in one pass
 //                        (the [E,2H] product never reaches HBM)
 //   dmp_out_fwd_fused    Zn[e] = Z[e] + gate[e] (H1[e] W2^T + b2)   = Linear + dmp_gate_residual
+//   dmp_bwd_h1_fused     dG[e] = [dPre | coef[dst e] dPre], dPre = H1[e] > 0 ? dO[e] W2 : 0, + column sums of dPre
+//                        = Linear backward + ReLU backward + edge_combine backward in one pass
+//   dmp_bwd_z_fused      dZ[e] = base[e] + s(flag) D[dst e, half] + dPre[e] A'^T + coef[dst e] dPre[e] B'^T
+//                        = seg_sum2 backward (gather) + K=2H input-gradient GEMM + accumulation in one pass
 //   dmp_gemm_k128        plain C = A B (development / tests)
 #include "dmp_common.h"
 
@@ -29,7 +33,7 @@ constexpr int kLdsStride = 132;
 constexpr int kThreads = 512;
 constexpr int kScrStride = 36;
 
-enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2 };
+enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2, EPI_RELU_BWD_G = 3, EPI_DZ = 4 };
 
 struct MfmaArgs {
   const float *A; int64_t lda;      // streamed operand [E,128]
@@ -43,8 +47,13 @@ struct MfmaArgs {
   const int32_t *src, *dst; const uint8_t *flag;
   const float *bias;                // [128] or NULL
   // EPI_GATE_RES
-  const float *R; int64_t ldr;      // residual rows [E,128] or NULL
+  const float *R; int64_t ldr;      // residual rows [E,128] or NULL (EPI_DZ: upstream gradient dZn;
+                                    // EPI_RELU_BWD_G: the saved activation H1 for the ReLU mask)
   const float *gate;                // [E] or NULL
+  // EPI_RELU_BWD_G
+  float *partial;                   // [2*gridDim.x, 128] column-sum partials of dPre
+  // EPI_DZ: gathered term  s(flag) * D[dst, flag ? H : 0 + j]
+  const float *D; int64_t ldd; float s0, s1;
 };
 
 template <int NC, int EPI>
@@ -62,9 +71,14 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
       const int k = s + 64 * h, j = 128 * q + col;
-      b[q][s] = p.bt ? p.B[(int64_t)j * p.ldb + k] : p.B[(int64_t)k * p.ldb + j];
+      // bt 0: B[k][j] row-major; 1: transposed storage B^T[j][k]; 2: panel q is the K-slice
+      // [128q, 128q+128) of a transposed [128, NC*128] matrix: B_q[k][col] = W[col][128q + k]
+      b[q][s] = p.bt == 0 ? p.B[(int64_t)k * p.ldb + j]
+              : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
+                          : p.B[(int64_t)col * p.ldb + 128 * q + k];
     }
-  const float bias_j = (EPI != EPI_NONE && p.bias) ? p.bias[col] : 0.f;
+  const float bias_j = ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) ? p.bias[col] : 0.f;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
 
   const int64_t ntiles = (p.E + kTileRows - 1) / kTileRows;
   float4 pre[8];
@@ -102,6 +116,17 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
       const int64_t e = t * kTileRows + threadIdx.x;
       rowS[threadIdx.x] = (p.gate && e < p.E) ? p.gate[e] : 1.f;
     }
+    if (EPI == EPI_RELU_BWD_G && threadIdx.x < kTileRows) {
+      const int64_t e = t * kTileRows + threadIdx.x;
+      rowS[threadIdx.x] = e < p.E ? p.coef[p.dst[e]] : 0.f;
+    }
+    if (EPI == EPI_DZ && threadIdx.x < kTileRows) {
+      const int64_t e = t * kTileRows + threadIdx.x;
+      int v = 0, f = 0;
+      float cf = 0.f;
+      if (e < p.E) { v = p.dst[e]; f = (p.flag && p.flag[e]) ? 1 : 0; cf = p.coef[v]; }
+      rowA[threadIdx.x] = v; rowB[threadIdx.x] = f; rowS[threadIdx.x] = cf;
+    }
     __syncthreads();
     if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // next tile in flight under the MFMAs
 #pragma unroll 1
@@ -118,6 +143,17 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
           const float pa = p.P[(int64_t)rowA[rl] * p.ldp + col];
           const float pb = p.P[(int64_t)rowB[rl] * p.ldp + 128 + col];
           acc[0][r] = (pa - pb) + bias_j;
+          acc[NC - 1][r] = NC > 1 ? 0.f : acc[0][r];
+        }
+      } else if (EPI == EPI_DZ) {
+        // backward of the flag-split segment sum, gathered into the accumulator:
+        // acc0 = s(flag) * D[dst, (flag ? H : 0) + j]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int f = rowB[rl];
+          const float d = p.D[(int64_t)rowA[rl] * p.ldd + (f ? 128 : 0) + col];
+          acc[0][r] = d * (f ? p.s1 : p.s0);
           acc[NC - 1][r] = NC > 1 ? 0.f : acc[0][r];
         }
       } else {
@@ -149,6 +185,8 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
           if (EPI == EPI_EDGE) {
             v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
             v = fmaxf(v, 0.f);
+          } else if (EPI == EPI_DZ) {
+            v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
           } else if (EPI == EPI_GATE_RES) {
             v = (v + bias_j) * rowS[32 * sub + rr];
           }
@@ -161,9 +199,19 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
           float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + c4]);
           const int64_t row = tile_row + rr;
           if (row < p.E) {
-            if (EPI == EPI_GATE_RES && p.R) {
+            if ((EPI == EPI_GATE_RES || EPI == EPI_DZ) && p.R) {
               const float4 z = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + 32 * cs + c4);
               v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w;
+            }
+            if (EPI == EPI_RELU_BWD_G) {
+              // dPre = H1 > 0 ? dH1 : 0;  dG = [dPre | coef[dst] dPre];  column sums of dPre
+              const float4 a = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + 32 * cs + c4);
+              v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f;
+              v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+              colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+              const float cf = rowS[32 * sub + rr];
+              *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 + 32 * cs + c4) =
+                  make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf);
             }
             *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 * q + 32 * cs + c4) = v;
           }
@@ -171,8 +219,20 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
       }
     }
   }
+  if (EPI == EPI_RELU_BWD_G) {
+    // PARTIALS: lanes with equal (lane & 7) hold the same 4 columns for 8 different rows: fixed-order
+    // xor-shuffle tree over lane>>3, then one partial row per (workgroup, row half)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      colsum.x += __shfl_xor(colsum.x, off, 64); colsum.y += __shfl_xor(colsum.y, off, 64);
+      colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
+    }
+    if (lane < 8)
+      *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * 2 + rh) * 128 + 32 * cs + lane * 4) = colsum;
+  }
 }
 
+// (the column-sum write-out of EPI_RELU_BWD_G lives at the end of mfma_k128, see PARTIALS below)
 inline unsigned grid_blocks(int64_t E) {
   const int64_t ntiles = (E + kTileRows - 1) / kTileRows;
   return (unsigned)(ntiles < 256 ? (ntiles > 0 ? ntiles : 1) : 256);
@@ -225,6 +285,41 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
   p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw; p.bt = 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]
   p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.gate = gate; p.R = R; p.ldr = ldr;
   mfma_k128<1, EPI_GATE_RES><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int64_t dmp_mfma_partial_rows(int64_t E) { return 2 * (int64_t)grid_blocks(E); }
+
+int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                     const float *coef, const int32_t *dst, int64_t E, int H, float *dG, int64_t ldg,
+                     float *partial, void *stream) {
+  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!partial) return DMP_ERR_BAD_ARG;
+  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * 2 * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!dO || !W2 || !H1 || !coef || !dst || !dG || ldo < H || ldw < H || ldh < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
+  if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
+    return DMP_ERR_UNSUPPORTED;
+  MfmaArgs p{};
+  p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
+  p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.coef = coef; p.dst = dst; p.partial = partial;
+  mfma_k128<1, EPI_RELU_BWD_G><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                    const float *base, int64_t ldb, const float *coef, const int32_t *dst, const uint8_t *flag,
+                    float s0, float s1, int64_t E, int H, float *dZ, int64_t ldz, void *stream) {
+  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!dPre || !W || !D || !coef || !dst || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H || ldz < H || (base && ldb < H))
+    return DMP_ERR_BAD_ARG;
+  if (ldp % 4 || ldz % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(dZ) || (base && !aligned16(base)))
+    return DMP_ERR_UNSUPPORTED;
+  MfmaArgs p{};
+  p.A = dPre; p.lda = ldp; p.B = W; p.ldb = ldw; p.bt = 2;  // panels = K-slices of W'^T
+  p.C = dZ; p.ldc = ldz; p.E = E; p.R = base; p.ldr = ldb; p.coef = coef; p.dst = dst; p.flag = flag;
+  p.D = D; p.ldd = ldd; p.s0 = s0; p.s1 = s1;
+  mfma_k128<2, EPI_DZ><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 

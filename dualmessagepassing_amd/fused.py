@@ -164,6 +164,33 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     return out
 
 
+def bwd_h1_mfma(d_o, W2, h1, coef, dst32):
+    """-> (dG = [dPre | coef[dst] dPre] with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128."""
+    lib = _lib.load()
+    E, H = d_o.shape
+    d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_o.device)
+    part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
+    W2 = W2.contiguous()
+    with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), 16 * H * E + 4 * E):
+        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(coef), ptr(dst32), E, H,
+                                   ptr(d_g), 2 * H, ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
+    return d_g, reduce_partials(part)
+
+
+def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
+    """base + gather_select(d_s) + dPre Wes[:, :H]^T + coef[dst] dPre Wes[:, H:]^T  (dPre = d_g[:, :H]); H=128."""
+    lib = _lib.load()
+    E, H = d_g.size(0), d_g.size(1) // 2
+    out = torch.empty((E, H), dtype=torch.float32, device=d_g.device)
+    Wes = Wes.contiguous()
+    d_s = d_s.contiguous()
+    with _lib.timed("bwd_z_mfma[H=%d,E=%d]" % (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
+        check(lib.dmp_bwd_z_fused(ptr(d_g), 2 * H, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), ptr(base), H,
+                                  ptr(coef), ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, E, H, ptr(out), H,
+                                  stream_ptr()), "dmp_bwd_z_fused")
+    return out
+
+
 class _FusedDMPLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, in_w, out_w, src_w, dst_w, nloop_w, eloop_w,
@@ -216,9 +243,13 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- edge side, down to the gathered node projections
         dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
         dW2e = atb(dOe, H1e)
-        dH1e = dOe @ eW2
-        dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)       # dG[:, :H] is dPre
-        del dH1e
+        mfma = USE_MFMA_KERNELS and H == 128
+        if mfma:
+            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix.dst32)         # dG[:, :H] is dPre
+        else:
+            dH1e = dOe @ eW2
+            dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
+            del dH1e
         inc_ptr, inc_ent = ix.incidence()
         dP = ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
         dWes = atb(z, dG)                                            # [H,2H] = [dA_e | dB_e]
@@ -237,8 +268,12 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
         dz = None
         if ctx.needs_input_grad[4]:
-            dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0, base=dzn if ctx.residual else None)
-            dz.addmm_(dG, Wes.t())
+            if mfma:
+                dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
+            else:
+                dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
+                                           base=dzn if ctx.residual else None)
+                dz.addmm_(dG, Wes.t())
         # ---- unfold: C = M @ W0^T  =>  dM = dC @ W0,  dW0 = dC^T @ M
         dCn = torch.cat([dWx[:, :H], dBn, dbn.unsqueeze(0)], dim=0)                  # [3H+1, H]
         dMn = dCn @ nW0

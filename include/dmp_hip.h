@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 5
+#define DMP_ABI_VERSION 6
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -361,6 +361,30 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw,
                       const float *bias, const float *gate, const float *R, int64_t ldr,
                       int64_t rows, int H, float *out, int64_t ldo, void *stream);
+
+/*
+ * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
+ *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coef[dst e] * dPre[e]]
+ *     partial = column sums of dPre per (workgroup, row half): dmp_mfma_partial_rows(E) rows of H floats
+ *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
+ */
+int64_t dmp_mfma_partial_rows(int64_t num_edges);
+int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
+                     const float *H1, int64_t ldh, const float *coef, const int32_t *dst,
+                     int64_t num_edges, int H, float *dG, int64_t ldg, float *partial,
+                     void *stream);
+
+/*
+ * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
+ *     dZ[e] = base[e] + s(flag e) * D[dst e, (flag e ? H : 0) + :] + dPre[e] W[:, 0:H]^T
+ *             + coef[dst e] * dPre[e] W[:, H:2H]^T
+ *   dPre [E, ldp>=H] (e.g. the first half of dG, ldp = 2H), W [H, ldw>=2H] the forward weight panel,
+ *   D [N, ldd>=2H] the gradient of dmp_seg_sum2's output, base [E, ldb] or NULL, s(0)=s0, s(1)=s1.
+ */
+int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
+                    const float *D, int64_t ldd, const float *base, int64_t ldb,
+                    const float *coef, const int32_t *dst, const uint8_t *flag, float s0,
+                    float s1, int64_t num_edges, int H, float *dZ, int64_t ldz, void *stream);
 
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
  * the bare pipeline of the two kernels above, kept for tests and tuning. */

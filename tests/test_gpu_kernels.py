@@ -292,3 +292,44 @@ def test_mfma_kernels_h128(rows, gpu):
         if p_ is not None:
             ref = ref + p_.double()
         assert th.allclose(got.double(), ref, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("rows", [1, 129, 4097, 70001])
+def test_mfma_backward_kernels_h128(rows, gpu):
+    """dmp_bwd_h1_fused / dmp_bwd_z_fused against fp64 formulas and against the unfused kernels."""
+    from dualmessagepassing_amd import fused, ops
+    h = 128
+    gen = th.Generator().manual_seed(rows + 1)
+    rng = np.random.default_rng(rows + 1)
+    n = max(2, rows // 5)
+    src = rng.integers(0, n, rows).astype(np.int64)
+    dst = rng.integers(0, n, rows).astype(np.int64)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = th.randn(rows, h, generator=gen).clamp_min(0).to(gpu)
+    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
+    d_g, cs = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix.dst32)
+    td = _t(dst).to(gpu)
+    dpre = th.where(h1 > 0, (d_o.double() @ w2.double()), th.zeros(1, dtype=th.float64, device=gpu))
+    ref = th.cat([dpre, dpre * coef.double()[td][:, None]], 1)
+    assert th.allclose(d_g.double(), ref, rtol=1e-5, atol=2e-4)
+    assert th.allclose(cs.double(), dpre.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    g2, cs2 = fused.relu_bwd_g_colsum(d_o @ w2, h1, coef, ix.dst32)      # the two-kernel path
+    assert th.allclose(d_g, g2, rtol=1e-5, atol=2e-4) and th.allclose(cs, cs2, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5))
+    # input gradient
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    base = th.randn(rows, h, generator=gen).to(gpu)
+    tr = _t(rev).to(gpu)
+    gs = th.where(tr[:, None], d_s.double()[td][:, h:], -d_s.double()[td][:, :h])
+    for b_ in (base, None):
+        got = fused.bwd_z_mfma(d_g, wes, d_s, b_, coef, ix)
+        ref = gs + d_g.double() @ wes.double().t()
+        if b_ is not None:
+            ref = ref + b_.double()
+        assert th.allclose(got.double(), ref, rtol=1e-5, atol=3e-4)
+        two = ops.gather_select_raw(d_s, ix.dst32, ix.rev8, h, None, -1.0, 1.0, base=b_)
+        two.addmm_(d_g, wes.t())
+        assert th.allclose(got, two, rtol=1e-5, atol=3e-4)
