@@ -1,14 +1,15 @@
 // Fused MFMA kernels of the DMPLayer edge chain (gfx950, fp32 in / fp32 accumulate, exact fp32:
 // v_mfma_f32_32x32x2_f32).  K = H = 128 only; other widths take the GEMM + epilogue-kernel path.
 //
-// Structure (one persistent 512-thread workgroup per CU, 8 waves = 2 per SIMD):
+// Structure (two persistent 256-thread workgroups per CU, out of phase with each other so that one
+// streams / stores while the other issues MFMAs; 4 waves each, 2 waves per SIMD in total):
 //   * the [128, NC*128] weight panel lives in REGISTERS for the whole kernel: wave w keeps the
 //     fragments of its 32-column slice (w&3) of every panel, b[p][s] = B[s + 64h][128p + 32(w&3) + l]
 //     (h = lane>>5, l = lane&31): no LDS or cache traffic for the weights inside the loop;
-//   * 128-row tiles of the streamed operand go global -> registers (prefetched one tile ahead,
+//   * 64-row tiles of the streamed operand go global -> registers (prefetched one tile ahead,
 //     in flight under the MFMAs) -> LDS (132-float rows: conflict-free ds_read_b128);
-//   * wave w computes row sub-tiles {2(w>>2), 2(w>>2)+1}: 64 k-steps x NC panels of 32x32x2 MFMAs
-//     per sub-tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's
+//   * every wave computes both 32-row sub-tiles of a 64-row tile: 64 k-steps x NC panels of
+//     32x32x2 MFMAs per sub-tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's
 //     A operands are 4 consecutive floats of its LDS row (one ds_read_b128 per 4 MFMAs);
 //   * the epilogue runs on the accumulator registers (row = (r&3)+8(r>>2)+4h, col = l), then the
 //     32x32 result goes through a per-wave LDS transpose so that stores are 16 B per lane.
@@ -28,10 +29,12 @@ namespace dmp {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kTileRows = 128;
+constexpr int kTileRows = 64;     // rows per tile: 2 sub-tiles of 32
 constexpr int kLdsStride = 132;
-constexpr int kThreads = 512;
+constexpr int kThreads = 256;     // 4 waves; two such workgroups share a CU and run out of phase
+constexpr int kWaves = kThreads / 64;
 constexpr int kScrStride = 36;
+constexpr int kPreLoads = kTileRows * 32 / kThreads;  // float4 loads per thread per tile
 
 enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2, EPI_RELU_BWD_G = 3, EPI_DZ = 4 };
 
@@ -59,11 +62,11 @@ struct MfmaArgs {
 template <int NC, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
   __shared__ float As[kTileRows * kLdsStride];
-  __shared__ float Cs[8 * 32 * kScrStride];
+  __shared__ float Cs[kWaves * 32 * kScrStride];
   __shared__ int rowA[kTileRows], rowB[kTileRows];
   __shared__ float rowS[kTileRows];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-  const int cs = wave & 3, rh = wave >> 2;
+  const int cs = wave;  // this wave's 32-column slice; it computes both 32-row sub-tiles of a tile
   const int col = 32 * cs + li;
   float b[NC][64];
 #pragma unroll
@@ -81,10 +84,10 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
 
   const int64_t ntiles = (p.E + kTileRows - 1) / kTileRows;
-  float4 pre[8];
+  float4 pre[kPreLoads];
   auto load_tile = [&](int64_t t) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < kPreLoads; ++m) {
       const int q = threadIdx.x + kThreads * m;
       const int64_t row = t * kTileRows + (q >> 5);
       pre[m] = row < p.E ? *reinterpret_cast<const float4 *>(p.A + row * p.lda + (q & 31) * 4) : make_float4(0, 0, 0, 0);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
   for (; t < ntiles; t += gridDim.x) {
     __syncthreads();  // previous tile: LDS reads done
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < kPreLoads; ++m) {
       const int q = threadIdx.x + kThreads * m;
       *reinterpret_cast<float4 *>(&As[(q >> 5) * kLdsStride + (q & 31) * 4]) = pre[m];
     }
@@ -130,8 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
     __syncthreads();
     if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // next tile in flight under the MFMAs
 #pragma unroll 1
-    for (int ss = 0; ss < 2; ++ss) {
-      const int sub = 2 * rh + ss;
+    for (int sub = 0; sub < kTileRows / 32; ++sub) {
       const int64_t tile_row = t * kTileRows + 32 * sub;
       f32x16 acc[NC];
       if (EPI == EPI_EDGE) {
@@ -228,14 +230,15 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
       colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
     }
     if (lane < 8)
-      *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * 2 + rh) * 128 + 32 * cs + lane * 4) = colsum;
+      *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * 128 + 32 * cs + lane * 4) = colsum;
   }
 }
 
 // (the column-sum write-out of EPI_RELU_BWD_G lives at the end of mfma_k128, see PARTIALS below)
-inline unsigned grid_blocks(int64_t E) {
+inline unsigned grid_blocks(int64_t E, int per_cu = 2) {
   const int64_t ntiles = (E + kTileRows - 1) / kTileRows;
-  return (unsigned)(ntiles < 256 ? (ntiles > 0 ? ntiles : 1) : 256);
+  const int64_t cap = 256 * per_cu;  // resident workgroups: 2 per CU (NC = 2: 256 VGPRs), 3 for NC = 1
+  return (unsigned)(ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap);
 }
 
 }  // namespace
@@ -253,7 +256,7 @@ int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int 
   MfmaArgs p{};
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bt = b_transposed; p.C = C; p.ldc = ldc; p.E = E;
   hipStream_t st = (hipStream_t)stream;
-  if (ncols == 128) mfma_k128<1, EPI_NONE><<<grid_blocks(E), kThreads, 0, st>>>(p);
+  if (ncols == 128) mfma_k128<1, EPI_NONE><<<grid_blocks(E, 3), kThreads, 0, st>>>(p);
   else mfma_k128<2, EPI_NONE><<<grid_blocks(E), kThreads, 0, st>>>(p);
   return check_launch();
 }
@@ -284,25 +287,25 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
   MfmaArgs p{};
   p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw; p.bt = 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]
   p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.gate = gate; p.R = R; p.ldr = ldr;
-  mfma_k128<1, EPI_GATE_RES><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  mfma_k128<1, EPI_GATE_RES><<<grid_blocks(E, 2), kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 
-int64_t dmp_mfma_partial_rows(int64_t E) { return 2 * (int64_t)grid_blocks(E); }
+int64_t dmp_mfma_partial_rows(int64_t E) { return (int64_t)grid_blocks(E, 3); }
 
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const float *coef, const int32_t *dst, int64_t E, int H, float *dG, int64_t ldg,
                      float *partial, void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (!partial) return DMP_ERR_BAD_ARG;
-  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * 2 * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   if (!dO || !W2 || !H1 || !coef || !dst || !dG || ldo < H || ldw < H || ldh < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
   if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
     return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.coef = coef; p.dst = dst; p.partial = partial;
-  mfma_k128<1, EPI_RELU_BWD_G><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
+  mfma_k128<1, EPI_RELU_BWD_G><<<grid_blocks(E, 3), kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 
