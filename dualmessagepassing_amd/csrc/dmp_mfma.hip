@@ -11,8 +11,9 @@
 //   * every wave computes both 32-row sub-tiles of a 64-row tile: 64 k-steps x NC panels of
 //     32x32x2 MFMAs per sub-tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's
 //     A operands are 4 consecutive floats of its LDS row (one ds_read_b128 per 4 MFMAs);
-//   * the epilogue runs on the accumulator registers (row = (r&3)+8(r>>2)+4h, col = l), then the
-//     32x32 result goes through a per-wave LDS transpose so that stores are 16 B per lane.
+//   * the 32x32 accumulators (row = (r&3)+8(r>>2)+4h, col = l) go through a per-wave LDS transpose;
+//     the epilogue (gathered node rows, gate, residual, ReLU mask, column sums) runs on the
+//     transposed float4s, whose operands were requested before the transpose, and stores 16 B per lane.
 //
 //   dmp_edge_fwd_fused   H1[e] = relu(Z W'[:, :H] + coef[dst e] Z W'[:, H:] + P[a_e, 0:H] - P[b_e, H:2H] + b)
 //                        = the G GEMM + dmp_edge_combine(relu) of the fused layer in one pass
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
               : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
                           : p.B[(int64_t)col * p.ldb + 128 * q + k];
     }
-  const float bias_j = ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) ? p.bias[col] : 0.f;
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
 
   const int64_t ntiles = (p.E + kTileRows - 1) / kTileRows;
@@ -136,34 +136,10 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
     for (int sub = 0; sub < kTileRows / 32; ++sub) {
       const int64_t tile_row = t * kTileRows + 32 * sub;
       f32x16 acc[NC];
-      if (EPI == EPI_EDGE) {
-        // the gathered node projections + bias initialise the first accumulator (no extra pass,
-        // no extra registers): acc0 = (P[a, j] - P[b, H + j]) + bias_j
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float pa = p.P[(int64_t)rowA[rl] * p.ldp + col];
-          const float pb = p.P[(int64_t)rowB[rl] * p.ldp + 128 + col];
-          acc[0][r] = (pa - pb) + bias_j;
-          acc[NC - 1][r] = NC > 1 ? 0.f : acc[0][r];
-        }
-      } else if (EPI == EPI_DZ) {
-        // backward of the flag-split segment sum, gathered into the accumulator:
-        // acc0 = s(flag) * D[dst, (flag ? H : 0) + j]
+      for (int q = 0; q < NC; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int f = rowB[rl];
-          const float d = p.D[(int64_t)rowA[rl] * p.ldd + (f ? 128 : 0) + col];
-          acc[0][r] = d * (f ? p.s1 : p.s0);
-          acc[NC - 1][r] = NC > 1 ? 0.f : acc[0][r];
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < NC; ++q)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-      }
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
       const float *arow = &As[(32 * sub + li) * kLdsStride + 64 * h];
 #pragma unroll
       for (int s4 = 0; s4 < 16; ++s4) {
@@ -178,22 +154,46 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
       }
       float *scr = &Cs[wave * 32 * kScrStride];
       constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
+      // Row-gathered / row-streamed epilogue operands, fetched as float4 in the layout of the wide
+      // store phase (lane -> row 8k + lane/8, 4 consecutive columns); all loads are issued before
+      // the accumulators take their trip through the LDS scratch, so their latency overlaps it.
+      float4 g0[4], g1[4];
+      auto fetch_epilogue_operands = [&]() {
+      if (EPI == EPI_EDGE || EPI == EPI_DZ || EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rr = 8 * k + (lane >> 3), c4 = 32 * cs + (lane & 7) * 4;
+          const int rl = 32 * sub + rr;
+          const int64_t row = tile_row + rr;
+          g0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          g1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < p.E) {
+            if (EPI == EPI_EDGE) {
+              g0[k] = *reinterpret_cast<const float4 *>(p.P + (int64_t)rowA[rl] * p.ldp + c4);
+              g1[k] = *reinterpret_cast<const float4 *>(p.P + (int64_t)rowB[rl] * p.ldp + 128 + c4);
+            } else if (EPI == EPI_DZ) {
+              g0[k] = *reinterpret_cast<const float4 *>(p.D + (int64_t)rowA[rl] * p.ldd + (rowB[rl] ? 128 : 0) + c4);
+              if (p.R) g1[k] = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + c4);
+            } else if (p.R) {  // EPI_GATE_RES: residual rows; EPI_RELU_BWD_G: saved activation
+              g0[k] = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + c4);
+            }
+          }
+        }
+      }
+      };
+      // NC = 2: the accumulators fill the register file, so the operands are requested after the
+      // accumulators have been parked in the scratch; NC = 1: before, overlapping the round trip
+      if (NC == 1) fetch_epilogue_operands();
 #pragma unroll
       for (int q = 0; q < NOUT; ++q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
           float v = acc[q][r];
-          if (EPI == EPI_EDGE) {
-            v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
-            v = fmaxf(v, 0.f);
-          } else if (EPI == EPI_DZ) {
-            v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
-          } else if (EPI == EPI_GATE_RES) {
-            v = (v + bias_j) * rowS[32 * sub + rr];
-          }
+          if (EPI == EPI_EDGE || EPI == EPI_DZ) v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
           scr[rr * kScrStride + li] = v;
         }
+        if (NC != 1) fetch_epilogue_operands();
         // written and read by the same wave: LDS operations of one wave complete in order
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -201,15 +201,26 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
           float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + c4]);
           const int64_t row = tile_row + rr;
           if (row < p.E) {
-            if ((EPI == EPI_GATE_RES || EPI == EPI_DZ) && p.R) {
-              const float4 z = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + 32 * cs + c4);
-              v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w;
-            }
-            if (EPI == EPI_RELU_BWD_G) {
+            if (EPI == EPI_EDGE) {
+              // ((G0 + coef G1) + (P[a] - P[b])) + bias, then ReLU: the reference's order (dmpnn.py:147-152)
+              const float4 bi = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 32 * cs + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bi.x, 0.f);
+              v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bi.y, 0.f);
+              v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bi.z, 0.f);
+              v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bi.w, 0.f);
+            } else if (EPI == EPI_DZ) {
+              const float sg = rowB[32 * sub + rr] ? p.s1 : p.s0;
+              v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
+              v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
+            } else if (EPI == EPI_GATE_RES) {
+              const float gt = rowS[32 * sub + rr];
+              const float4 bi = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 32 * cs + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.x = (v.x + bi.x) * gt + g0[k].x; v.y = (v.y + bi.y) * gt + g0[k].y;
+              v.z = (v.z + bi.z) * gt + g0[k].z; v.w = (v.w + bi.w) * gt + g0[k].w;
+            } else if (EPI == EPI_RELU_BWD_G) {
               // dPre = H1 > 0 ? dH1 : 0;  dG = [dPre | coef[dst] dPre];  column sums of dPre
-              const float4 a = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + 32 * cs + c4);
-              v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f;
-              v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+              v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
+              v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
               colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
               const float cf = rowS[32 * sub + rr];
               *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 + 32 * cs + c4) =
