@@ -3,17 +3,26 @@
 The shared library is the product: it is built here (cross-compiled, no GPU
 needed), travels with the tree to the GPU box, and is loaded by ``_lib.py``
 through ctypes.  There is no JIT cache and no CPU fallback.
+
+Staleness is decided by a content hash of the sources (file times do not survive
+being copied to another machine); concurrent builders (one process per GPU) are
+serialised by a lock file and each compiles into its own temporary directory.
 """
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdmp_hip.so")
+HASH_PATH = LIB_PATH + ".srchash"
 SOURCES = ["dmp_agg.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip"]
 HEADERS = ["dmp_common.h", os.path.join("..", "..", "include", "dmp_hip.h")]
 ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def find_hipcc():
@@ -23,15 +32,21 @@ def find_hipcc():
     return None
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
+def source_hash():
+    h = hashlib.sha256()
+    h.update((ARCH + " ".join(FLAGS)).encode())
     for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+        return True
+    with open(HASH_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_lib(force=False, verbose=False):
@@ -41,28 +56,40 @@ def build_lib(force=False, verbose=False):
     hipcc = find_hipcc()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libdmp_hip.so (set HIPCC or install ROCm)")
-    objs = []
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-        if verbose and out:
-            print(out.decode(errors="replace"))
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc link failed:\n%s" % r.stdout.decode(errors="replace"))
-    os.replace(tmp, LIB_PATH)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():  # another process built it while we waited
+                return LIB_PATH
+            want = source_hash()
+            with tempfile.TemporaryDirectory(prefix="dmp_build_") as tmp:
+                objs, procs = [], []
+                for src in SOURCES:
+                    obj = os.path.join(tmp, src.replace(".hip", ".o"))
+                    cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                    objs.append(obj)
+                for src, p in procs:
+                    out, _ = p.communicate()
+                    if p.returncode != 0:
+                        raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+                    if verbose and out:
+                        print(out.decode(errors="replace"))
+                so = os.path.join(tmp, "libdmp_hip.so")
+                r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs,
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc link failed:\n%s" % r.stdout.decode(errors="replace"))
+                staged = LIB_PATH + ".tmp.%d" % os.getpid()
+                shutil.copyfile(so, staged)
+                os.replace(staged, LIB_PATH)
+                with open(HASH_PATH + ".tmp", "w") as f:
+                    f.write(want + "\n")
+                os.replace(HASH_PATH + ".tmp", HASH_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

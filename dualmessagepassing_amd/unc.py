@@ -141,3 +141,65 @@ def build_graph_from_triplets(num_nodes, num_rels, triplets, device):
     g.edata["type"] = torch.from_numpy(rel).to(device)
     g.edata["norm"] = compute_edgenorm(g)
     return g
+
+
+class EmbeddingLayer(nn.Module):
+    """UNC model.py:41-52: learned table, uniform(-1/sqrt(d), 1/sqrt(d))."""
+
+    def __init__(self, num_emb, emb_dim):
+        super(EmbeddingLayer, self).__init__()
+        self.embedding = nn.Embedding(num_emb, emb_dim)
+        scale = 1 / (emb_dim) ** 0.5
+        nn.init.uniform_(self.embedding.weight, -scale, scale)
+
+    def forward(self, g, x):
+        return self.embedding(x.squeeze())
+
+    @property
+    def weight(self):
+        return self.embedding.weight
+
+
+class EmbeddingLayerAttri(nn.Module):
+    """UNC model.py:55-65: frozen pre-trained attributes."""
+
+    def __init__(self, attri):
+        super(EmbeddingLayerAttri, self).__init__()
+        self.embedding = nn.Embedding.from_pretrained(torch.as_tensor(attri))
+
+    def forward(self, g, x):
+        return self.embedding(x.squeeze())
+
+    @property
+    def weight(self):
+        return self.embedding.weight
+
+
+class DMPNN(nn.Module):
+    """UNC ``DMPNN(BaseModel)`` (model.py:68-115,281-328): node / relation embeddings ->
+    ``num_hidden_layers`` x DualGraphConv (Tanh between layers, none after the last) -> per-relation
+    mean of the edge representations.  ``forward(g, h, r, norm) -> (h, z, r_rep)``."""
+
+    def __init__(self, node_attri, rel_attri, num_nodes, h_dim, out_dim, num_rels, num_hidden_layers=1,
+                 dropout=0, use_cuda=False):
+        super(DMPNN, self).__init__()
+        self.num_nodes, self.h_dim, self.out_dim = num_nodes, h_dim, out_dim
+        self.num_rels, self.num_hidden_layers, self.dropout, self.use_cuda = num_rels, num_hidden_layers, dropout, use_cuda
+        self.node_emb = EmbeddingLayerAttri(node_attri) if node_attri is not None else EmbeddingLayer(num_nodes, h_dim)
+        self.rel_emb = EmbeddingLayerAttri(rel_attri) if rel_attri is not None else EmbeddingLayer(num_rels, h_dim)
+        self.layers = nn.ModuleList()
+        for idx in range(num_hidden_layers):
+            in_dim = h_dim if idx == 0 else out_dim
+            act = nn.Tanh() if idx < num_hidden_layers - 1 else None
+            self.layers.append(DualGraphConv(in_dim, out_dim, activation=act, dropout=dropout))
+
+    def forward(self, g, h, r, norm):
+        h = self.node_emb(g, h)
+        z = self.rel_emb(g, r)
+        for layer in self.layers:
+            h, z = layer(g, h, z, norm)
+        # model.py:319-325: masked mean of the edge representations per relation type
+        r_rep = torch.cat(
+            [z.masked_fill((r != i).view(-1, 1), 0.0).sum(dim=0, keepdim=True) / ((r == i).sum().float() + 1e-8)
+             for i in range(self.num_rels)], dim=0)
+        return h, z, r_rep

@@ -314,6 +314,7 @@ def gen_full_model():
     'ragged' : different sizes per pair (exercises the padding / mask / filter-gate paths)."""
     import dgl
     from models.dmpnn import DMPNN
+    from models.compgcn import CompGCN
 
     def make_batch(sizes, n_vl, n_el, rng):
         gs = []
@@ -333,11 +334,16 @@ def gen_full_model():
             gs.append(g)
         return dgl.batch(gs)
 
+    ragged = dict(p_sizes=[(3, 3), (5, 9), (4, 6), (8, 12), (2, 1), (6, 10)],
+                  g_sizes=[(10, 30), (16, 50), (7, 12), (20, 64), (5, 8), (12, 40)])
     cases = {
         "uniform": dict(p_sizes=[(8, 12)] * 32, g_sizes=[(64, 256)] * 32, hid=64, layers=3, extra={}),
-        "ragged": dict(p_sizes=[(3, 3), (5, 9), (4, 6), (8, 12), (2, 1), (6, 10)],
-                       g_sizes=[(10, 30), (16, 50), (7, 12), (20, 64), (5, 8), (12, 40)], hid=16, layers=2,
-                       extra={"pred_with_deg": True, "pred_with_enc": True}),
+        "ragged": dict(hid=16, layers=2, extra={"pred_with_deg": True, "pred_with_enc": True}, **ragged),
+        # CompGCN(**config) (models/compgcn.py:289-385) through the same skeleton
+        "compgcn": dict(hid=16, layers=2, extra={"rep_net": "CompGCN", "rep_compgcn_comp_opt": "mult",
+                                                 "rep_compgcn_edge_norm": "both", "pred_net": "MeanPredictNet"}, **ragged),
+        # four optimizer steps of the count loss (train.py:624-686: MSE on pred_c, AdamW(amsgrad), grad clip)
+        "train4": dict(hid=16, layers=2, extra={}, train_steps=4, **ragged),
     }
     for tag, c in cases.items():
         rng = np.random.default_rng(31 if tag == "uniform" else 32)
@@ -353,15 +359,33 @@ def gen_full_model():
                       pred_net="SumPredictNet", pred_hid_dim=c["hid"], pred_act_func="relu", pred_dropout=0.0,
                       node_pred=True, edge_pred=True)
         config.update(c["extra"])
-        model = DMPNN(**config)
+        model = (CompGCN if config["rep_net"] == "CompGCN" else DMPNN)(**config)
         with th.no_grad():  # pred_fc2 is zero-initialised: make the head's output depend on its input
             for head in model.pred_net.values():
                 head.pred_fc2.weight.uniform_(-0.3, 0.3)
                 head.pred_fc2.bias.uniform_(-0.1, 0.1)
-        out = model(pattern, graph)
-        out["pred_c"].sum().backward()
         d = {"config_keys": np.array(sorted(config.keys())),
              "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())])}
+        for k, v in model.state_dict().items():
+            d["sd." + k] = v.clone()
+        if c.get("train_steps"):
+            counts = th.from_numpy(rng.integers(0, 20, size=len(c["p_sizes"]))).float()
+            opt = th.optim.AdamW([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=1e-5, amsgrad=True)
+            losses = []
+            for _ in range(c["train_steps"]):
+                opt.zero_grad()
+                o = model(pattern, graph)
+                loss = th.nn.functional.mse_loss(o["pred_c"].view(-1), counts)
+                loss.backward()
+                th.nn.utils.clip_grad_norm_(model.parameters(), 8.0)   # train.py:679-681 (max_grad_norm)
+                opt.step()
+                losses.append(float(loss))
+            d["train_counts"], d["train_losses"] = counts, np.array(losses)
+            for k, v in model.state_dict().items():
+                d["sd_after." + k] = v.clone()
+            print("  train losses", losses)
+        out = model(pattern, graph)
+        out["pred_c"].sum().backward()
         for t, g in (("p", pattern), ("g", graph)):
             d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(),
                       t + "_bnn": g.batch_num_nodes(), t + "_bne": g.batch_num_edges()})
@@ -371,11 +395,10 @@ def gen_full_model():
             for k, v in g.edata.items():
                 if k in ("id", "label", "is_reversed"):
                     d["%s_edata.%s" % (t, k)] = v
-        for k, v in model.state_dict().items():
-            d["sd." + k] = v
-        for k, p in model.named_parameters():
-            if p.grad is not None:
-                d["grad." + k] = p.grad
+        if not c.get("train_steps"):
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    d["grad." + k] = p.grad
         for k, v in out.items():
             if v is not None:
                 d["out." + k] = v
@@ -428,6 +451,38 @@ for tag, n, m, h, act, bn_train in (("small", 12, 30, 8, None, False), ("tanh", 
         d["b_after." + k] = b
     np.savez_compressed(os.path.join(%(out)r, "unc_dualconv_%%s.npz" %% tag), **t2n(d))
     print("wrote unc_dualconv_%%s.npz" %% tag)
+
+# whole UNC DMPNN model (model.py:281-328): embeddings -> 2 x DualGraphConv -> per-relation means
+from model import DMPNN
+n, m, h, nrel = 30, 70, 16, 3
+u, v = er_edges(n, m, rng)
+rel = rng.integers(0, nrel, size=m)
+u2, v2 = np.concatenate([u, v]), np.concatenate([v, u])
+etype = np.concatenate([rel, rel + nrel])
+th.manual_seed(77)
+model = DMPNN(None, None, n, h, h, nrel * 2, 2, 0.0, False)
+model.eval()
+with th.no_grad():
+    for layer in model.layers:
+        for seq in (layer.nmlp, layer.emlp):
+            seq[1].running_mean.uniform_(-0.2, 0.2); seq[1].running_var.uniform_(0.5, 1.5)
+g = dgl.DGLGraph.from_edges(u2, v2, n)
+norm = g.in_degrees().float()[g._v].reciprocal().unsqueeze(-1)
+hid = th.arange(n)
+r = th.from_numpy(etype)
+hh, zz, rr = model(g, hid, r, norm)
+w1, w2, w3 = th.randn_like(hh), th.randn_like(zz), th.randn_like(rr)
+((hh * w1).sum() + (zz * w2).sum() + (rr * w3).sum()).backward()
+d = {"src": u2, "dst": v2, "num_nodes": n, "etype": etype, "norm": norm, "h": hh, "z": zz, "r": rr,
+     "w1": w1, "w2": w2, "w3": w3, "hid": h, "num_rels": nrel * 2}
+for k, p in model.named_parameters():
+    d["p." + k] = p
+    if p.grad is not None:
+        d["g." + k] = p.grad
+for k, b in model.named_buffers():
+    d["b." + k] = b
+np.savez_compressed(os.path.join(%(out)r, "unc_model.npz"), **t2n(d))
+print("wrote unc_model.npz")
 '''
 
 

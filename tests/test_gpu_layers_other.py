@@ -94,3 +94,27 @@ def test_build_graph_from_triplets_and_norm(gpu):
     assert g.edata["type"].cpu().tolist() == [0, 1, 0, 0, 1, 2, 3, 2, 2, 3]
     indeg = np.bincount(v.cpu().numpy(), minlength=3)
     assert np.allclose(g.edata["norm"].cpu().numpy()[:, 0], 1.0 / indeg[v.cpu().numpy()])
+
+
+def test_unc_dmpnn_model_matches_reference_golden(gpu):
+    """Whole UNC DMPNN (embeddings -> 2 x DualGraphConv with Tanh between -> per-relation means)."""
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd.unc import DMPNN
+    d = load_golden(golden_files("unc_model")[0])
+    n, h, nrel = int(d["num_nodes"]), int(d["hid"]), int(d["num_rels"])
+    model = DMPNN(None, None, n, h, h, nrel, 2, 0.0)
+    sd = {k[2:]: _t(v) for k, v in d.items() if k.startswith("p.")}
+    sd.update({k[2:]: _t(v) for k, v in d.items() if k.startswith("b.")})
+    model.load_state_dict(sd, strict=True)
+    model.to(gpu).eval()
+    g = BatchedGraph(_t(d["src"]).to(gpu), _t(d["dst"]).to(gpu), n)
+    hh, zz, rr = model(g, th.arange(n, device=gpu), _t(d["etype"]).to(gpu), _t(d["norm"]).to(gpu))
+    _close(hh, d["h"], 5e-5, 5e-5, "h")
+    _close(zz, d["z"], 5e-5, 5e-5, "z")
+    _close(rr, d["r"], 5e-5, 5e-5, "r")
+    ((hh * _t(d["w1"]).to(gpu)).sum() + (zz * _t(d["w2"]).to(gpu)).sum() + (rr * _t(d["w3"]).to(gpu)).sum()).backward()
+    for k, p in model.named_parameters():
+        if "g." + k in d:
+            _close(p.grad, d["g." + k], 3e-4, 3e-4, "grad " + k)
+        else:
+            assert p.grad is None, k
