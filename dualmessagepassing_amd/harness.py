@@ -1,0 +1,172 @@
+"""Thin training / evaluation harness around the drop-in model.
+
+Reproduces the loop semantics of ``SubgraphCountingMatching/train.py:449-844`` (train_epoch) and
+``:847-1061`` (evaluate_epoch) for the GraphAdj models on the MI355X path: count loss
+``bp_crit(leaky_relu(pred_c, neg_slp), counts)``, evaluation metric on ``relu(pred_c)``, optional
+representation regulariser, gradient clipping, AdamW; without the reference's seven ``.item()``
+host syncs per step (running sums stay on the device).  Plus a synthetic (pattern, graph) dataset
+with exact subgraph-isomorphism counts for smoke-level training runs: the reference's datasets are
+external downloads that are not available offline.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .collate import collate_device
+from .dp import FlatGradSync
+
+
+def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
+    """Number of label-preserving injective maps of the pattern's nodes into the graph's nodes such
+    that every pattern edge (u -> v, label l) has an image edge with the same label (the reference
+    data's ``counts``: non-induced subgraph isomorphisms).  Plain backtracking on the host; meant
+    for the small synthetic sets of the harness."""
+    np_, ng = len(p_vl), len(g_vl)
+    adj = {}
+    for u, v, l in zip(g_src.tolist(), g_dst.tolist(), g_el.tolist()):
+        adj.setdefault((u, v), set()).add(l)
+    pe = list(zip(p_src.tolist(), p_dst.tolist(), p_el.tolist()))
+    touching = [[(u, v, l) for (u, v, l) in pe if u == k or v == k] for k in range(np_)]
+    mapping, used = [-1] * np_, [False] * ng
+
+    def rec(k):
+        if k == np_:
+            return 1
+        total = 0
+        for cand in range(ng):
+            if used[cand] or g_vl[cand] != p_vl[k]:
+                continue
+            mapping[k] = cand
+            good = True
+            for u, v, l in touching[k]:   # every pattern edge whose endpoints are both placed
+                mu, mv = mapping[u], mapping[v]
+                if mu >= 0 and mv >= 0 and l not in adj.get((mu, mv), ()):
+                    good = False
+                    break
+            if good:
+                used[cand] = True
+                total += rec(k + 1)
+                used[cand] = False
+            mapping[k] = -1
+        return total
+
+    return rec(0)
+
+
+def _er_edges(n, m, rng):
+    total = n * (n - 1)
+    pick = rng.choice(total, size=m, replace=False)
+    u = pick // (n - 1)
+    r = pick % (n - 1)
+    return u.astype(np.int64), (r + (r >= u)).astype(np.int64)
+
+
+class SyntheticPairs:
+    """Directed ER (pattern, graph) pairs with uniform labels and exact counts, stored the way the
+    reference's preprocessing leaves a GraphAdj sample: ids = arange, reversed edges appended
+    ([forward | reversed], id + max_ne, label + max_nel, is_reversed; train.py:299-327)."""
+
+    def __init__(self, num_pairs, p_nodes, p_edges, g_nodes, g_edges, n_vlabels, n_elabels, seed=0):
+        rng = np.random.default_rng(seed)
+        self.shape = dict(p_nodes=p_nodes, p_edges=p_edges, g_nodes=g_nodes, g_edges=g_edges,
+                          n_vlabels=n_vlabels, n_elabels=n_elabels)
+        self.samples = []
+        for _ in range(num_pairs):
+            pu, pv = _er_edges(p_nodes, p_edges, rng)
+            gu, gv = _er_edges(g_nodes, g_edges, rng)
+            pvl, gvl = rng.integers(0, n_vlabels, p_nodes), rng.integers(0, n_vlabels, g_nodes)
+            pel, gel = rng.integers(0, n_elabels, p_edges), rng.integers(0, n_elabels, g_edges)
+            c = count_subisomorphisms(pu, pv, pvl, pel, gu, gv, gvl, gel)
+            self.samples.append({"pattern": self._with_rev(pu, pv, pvl, pel, p_edges, n_elabels),
+                                 "graph": self._with_rev(gu, gv, gvl, gel, g_edges, n_elabels), "counts": c})
+
+    @staticmethod
+    def _with_rev(u, v, vl, el, max_ne, max_nel):
+        e = len(u)
+        return {"src": np.concatenate([u, v]), "dst": np.concatenate([v, u]), "vlabel": vl,
+                "elabel": np.concatenate([el, el + max_nel]), "eid": np.concatenate([np.arange(e), max_ne + np.arange(e)]),
+                "rev": np.concatenate([np.zeros(e, bool), np.ones(e, bool)]), "num_nodes": len(vl)}
+
+    def __len__(self):
+        return len(self.samples)
+
+    def model_config(self, hid_dim=64, layers=3, rep_net="DMPNN", **kw):
+        s = self.shape
+        cfg = dict(max_ngv=s["g_nodes"], max_ngvl=s["n_vlabels"], max_nge=2 * s["g_edges"], max_ngel=2 * s["n_elabels"],
+                   max_npv=s["p_nodes"], max_npvl=s["n_vlabels"], max_npe=2 * s["p_edges"], max_npel=2 * s["n_elabels"],
+                   base=2, hid_dim=hid_dim, share_rep_net=True, rep_residual=True, enc_net="Multihot",
+                   emb_net="Orthogonal", filter_net="ScalarFilter", rep_net=rep_net, rep_num_graph_layers=layers,
+                   rep_num_pattern_layers=layers, rep_dmpnn_batch_norm=False, rep_act_func="relu",
+                   pred_net="SumPredictNet", pred_hid_dim=hid_dim, node_pred=True, edge_pred=True)
+        cfg.update(kw)
+        return cfg
+
+    def batchify(self, indices, device):
+        """``GraphAdjDataset.batchify`` (dataset.py:1604-1636) + ``.to(device)`` (train.py:606-607):
+        concatenated local arrays are uploaded once, batching itself happens on the device."""
+        out = []
+        for key in ("pattern", "graph"):
+            gs = [self.samples[i][key] for i in indices]
+            cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
+            nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
+            ne_ = np.array([len(g["src"]) for g in gs], np.int64)
+            nid = torch.from_numpy(np.concatenate([np.arange(n) for n in nn_])).to(device)
+            out.append(collate_device(cat("src"), cat("dst"), torch.from_numpy(nn_).to(device),
+                                      torch.from_numpy(ne_).to(device), int(nn_.sum()), int(ne_.sum()),
+                                      ndata={"id": nid, "label": cat("vlabel")},
+                                      edata={"id": cat("eid"), "label": cat("elabel"), "is_reversed": cat("rev", torch.bool)}))
+        counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
+        return out[0], out[1], counts.unsqueeze(-1)
+
+
+_CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
+
+
+def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_loss="MSE", eval_metric="MAE",
+                neg_slp=0.0, rep_reg_w=0.0, max_grad_norm=8.0, order=None):
+    """One pass over ``dataset`` (train.py:449-844 for the count loss).  Returns
+    ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end)."""
+    model.train()
+    sync = sync or FlatGradSync(model)
+    order = np.arange(len(dataset)) if order is None else np.asarray(order)
+    tot_loss = torch.zeros((), device=device)
+    tot_eval = torch.zeros((), device=device)
+    cnt = 0
+    for i in range(0, len(order), batch_size):
+        idx = order[i:i + batch_size]
+        pattern, graph, counts = dataset.batchify(idx, device)
+        sync.detach_grads()
+        out = model(pattern, graph)
+        pred = out["pred_c"]
+        loss = _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
+        if rep_reg_w > 0:  # train.py:651-659
+            reg = sum(_CRIT[bp_loss](out[k], torch.zeros_like(out[k])) * out[k].size(1)
+                      for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep"))
+            loss = loss + rep_reg_w * reg
+        loss.backward()
+        sync.pack()
+        sync.sync()
+        if max_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(sync.params, max_grad_norm)
+        optimizer.step()
+        with torch.no_grad():
+            tot_loss += loss.detach() * len(idx)
+            tot_eval += _CRIT[eval_metric](F.relu(pred), counts) * len(idx)
+        cnt += len(idx)
+    return {"bp_loss": float(tot_loss / max(cnt, 1)), "eval_metric": float(tot_eval / max(cnt, 1))}
+
+
+@torch.no_grad()
+def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
+    """train.py:847-1061 reduced to the count metrics: MAE / MSE of ``relu(pred_c)`` and the
+    predictions themselves."""
+    model.eval()
+    preds, targets = [], []
+    for i in range(0, len(dataset), batch_size):
+        idx = np.arange(i, min(i + batch_size, len(dataset)))
+        pattern, graph, counts = dataset.batchify(idx, device)
+        preds.append(F.relu(model(pattern, graph)["pred_c"]))
+        targets.append(counts)
+    pred, target = torch.cat(preds), torch.cat(targets)
+    return {"MAE": float(F.l1_loss(pred, target)), "MSE": float(F.mse_loss(pred, target)),
+            "eval_metric": float(_CRIT[eval_metric](pred, target)), "pred": pred.view(-1).cpu(), "counts": target.view(-1).cpu()}

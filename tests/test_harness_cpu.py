@@ -1,0 +1,50 @@
+"""Host-side pieces of the harness: the exact subgraph-isomorphism counter against networkx's VF2
+monomorphism enumeration, and the synthetic dataset's layout (reversed edges as train.py:299-327)."""
+import networkx as nx
+import numpy as np
+
+from dualmessagepassing_amd.harness import SyntheticPairs, count_subisomorphisms
+
+
+def _nx_count(ps, pd, pvl, pel, gs, gd, gvl, gel):
+    P, G = nx.DiGraph(), nx.DiGraph()
+    for i, l in enumerate(pvl):
+        P.add_node(i, label=int(l))
+    for i, l in enumerate(gvl):
+        G.add_node(i, label=int(l))
+    for u, v, l in zip(ps, pd, pel):
+        P.add_edge(int(u), int(v), label=int(l))
+    for u, v, l in zip(gs, gd, gel):
+        G.add_edge(int(u), int(v), label=int(l))
+    gm = nx.algorithms.isomorphism.DiGraphMatcher(
+        G, P, node_match=lambda a, b: a["label"] == b["label"], edge_match=lambda a, b: a["label"] == b["label"])
+    return sum(1 for _ in gm.subgraph_monomorphisms_iter())
+
+
+def test_counter_matches_networkx_vf2():
+    rng = np.random.default_rng(0)
+    seen_positive = 0
+    for _ in range(25):
+        pn, gn = int(rng.integers(2, 5)), int(rng.integers(5, 9))
+        pe, ge = int(rng.integers(1, pn * (pn - 1) + 1)), int(rng.integers(4, gn * (gn - 1) // 2))
+        from dualmessagepassing_amd.harness import _er_edges
+        ps, pd = _er_edges(pn, pe, rng)
+        gs, gd = _er_edges(gn, ge, rng)
+        pvl, gvl = rng.integers(0, 2, pn), rng.integers(0, 2, gn)
+        pel, gel = rng.integers(0, 2, pe), rng.integers(0, 2, ge)
+        c = count_subisomorphisms(ps, pd, pvl, pel, gs, gd, gvl, gel)
+        assert c == _nx_count(ps, pd, pvl, pel, gs, gd, gvl, gel)
+        seen_positive += c > 0
+    assert seen_positive >= 5
+
+
+def test_synthetic_pairs_layout():
+    ds = SyntheticPairs(6, 3, 3, 8, 14, 2, 2, seed=1)
+    assert len(ds) == 6
+    s = ds.samples[0]["graph"]
+    e = 14
+    assert len(s["src"]) == 2 * e and np.array_equal(s["src"][e:], s["dst"][:e]) and np.array_equal(s["dst"][e:], s["src"][:e])
+    assert np.array_equal(s["rev"], np.r_[np.zeros(e, bool), np.ones(e, bool)])
+    assert np.array_equal(s["eid"], np.r_[np.arange(e), e + np.arange(e)]) and np.array_equal(s["elabel"][e:], s["elabel"][:e] + 2)
+    cfg = ds.model_config(hid_dim=16, layers=2)
+    assert cfg["max_nge"] == 2 * e and cfg["max_ngel"] == 4 and cfg["rep_net"] == "DMPNN"
