@@ -45,13 +45,17 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 me
 
 CFG = dict(config_id=2, batch=1024, hid=128, layers=3, p_nodes=8, p_edges=12, g_nodes=64, g_edges=256,
            p_labels=8, g_labels=16)
+# BASELINE configs[3] per-GPU shard (the 8-GPU case): not the bench line, selectable for size checks
+CFG4 = dict(CFG, config_id=4, p_nodes=16, p_edges=32, g_nodes=512, g_edges=4096)
 
 
 def er_local_edges(batch, n, m, rng):
     """[batch, m] local endpoints of directed G(n, m) graphs (distinct ordered pairs, u != v)."""
     total = n * (n - 1)
-    # argsort of random keys = sampling without replacement, vectorised over the batch
-    pick = np.argsort(rng.random((batch, total)), axis=1)[:, :m]
+    if batch * total > (1 << 26):  # large graphs: one draw per graph instead of a [batch, total] key matrix
+        pick = np.stack([rng.choice(total, size=m, replace=False) for _ in range(batch)])
+    else:  # argsort of random keys = sampling without replacement, vectorised over the batch
+        pick = np.argsort(rng.random((batch, total)), axis=1)[:, :m]
     u = pick // (n - 1)
     r = pick % (n - 1)
     v = r + (r >= u)
@@ -200,6 +204,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=CFG["batch"], help="pairs per GPU")
+    ap.add_argument("--workload", type=int, default=2, choices=(2, 4), help="BASELINE config id: 2 = the metric's "
+                    "configuration (default, the bench line); 4 = the per-GPU shard of the 8-GPU configuration (size check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -223,7 +229,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    cfg = dict(CFG, batch=args.batch)
+    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -284,9 +290,11 @@ def main():
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ER pattern(8,12)x target(64,256), add_rev, "
+            "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
                                    "batch=%d pairs/GPU, full DMPNN model (Multihot enc, Orthogonal emb, ScalarFilter, "
-                                   "3 shared DMPLayers, SumPredictNet node+edge heads), hid=%d, fp32" % (cfg["batch"], H),
+                                   "3 shared DMPLayers, SumPredictNet node+edge heads), hid=%d, fp32"
+                                   % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
+                                      cfg["batch"], H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},

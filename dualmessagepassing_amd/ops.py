@@ -49,7 +49,8 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     ew = _vec(edge_w, torch.float32)
     nent = ent.numel()
     # algorithmic bytes: every source row once, every output row once, the CSR arrays once
-    nbytes = 4 * H * nent + 4 * out.size(1) * num_nodes + 4 * nent + 4 * (num_nodes + 1) + (4 * nent if ew is not None else 0)
+    src_rows = min(nent, M.size(0))  # incidence CSRs list every source row twice: distinct rows count once
+    nbytes = 4 * H * src_rows + 4 * out.size(1) * num_nodes + 4 * nent + 4 * (num_nodes + 1) + (4 * nent if ew is not None else 0)
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,
