@@ -32,6 +32,10 @@ SIGNATURES = {
     "dmp_first_edge_of_id": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "dmp_dedupe_table_words": (c_size, [c_i64]),
     "dmp_dedupe_first": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "dmp_subiso_node_weights": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_pattern_edge_active": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_subiso_edge_weights": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "dmp_scan_workspace_words": (c_size, [c_i64]),
     "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr]),
@@ -68,7 +72,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -67,20 +67,124 @@ def batch(graphs, device=None):
     return collate_device(ls, ld, nn, ne, sum(nn_host), sum(ne_host), ndata, edata)
 
 
+def _offsets(sizes):
+    off = torch.zeros(sizes.numel() + 1, dtype=torch.int64, device=sizes.device)
+    torch.cumsum(sizes, 0, out=off[1:])
+    return off
+
+
+def _pre_pad(flat, sizes, seg):
+    """``batch_convert_tensor_to_tensor(rows, pre_pad=True)`` (utils/dl.py:89-110): row i of the
+    result holds sample i's values right-aligned, zeros in front.  One host sync (the padded length,
+    as the reference's ``max(batch_lens)``)."""
+    B, m = int(sizes.numel()), int(sizes.max().item()) if sizes.numel() else 0
+    out = torch.zeros((B, m), dtype=flat.dtype, device=flat.device)
+    if flat.numel():
+        off = _offsets(sizes)
+        seg = seg.long()
+        pos = torch.arange(flat.numel(), device=flat.device) - off[seg]
+        out.view(-1).index_copy_(0, seg * m + (m - sizes[seg]) + pos, flat)
+    return out
+
+
+def subiso_weights(pattern, graph, sub_flat, sample_ptr, return_weights=("node", "edge"), validate=False,
+                   work_hint=0):
+    """Node / edge subisomorphism weights of a whole batch on the device
+    (``GraphAdjDataset.calculate_node_weights`` / ``calculate_edge_weights`` +
+    ``compute_nodeseq_subisoweights`` / ``compute_edgeseq_subisoweights``, dataset.py:54-107,1491-1520),
+    pre-padded like ``batchify`` does (dataset.py:1618-1634).
+
+    pattern / graph: BatchedGraphs from ``collate_device`` / ``batch`` with ``edata["label"]``;
+    sub_flat [T] int64: the samples' ``subisomorphisms`` tensors flattened back to back;
+    sample_ptr [B+1] int64: first element of each sample.  Returns ``(node_weights [B, max_nodes] |
+    None, edge_weights [B, max_edges] | None)``, int64."""
+    lib = _lib.load()
+    if isinstance(return_weights, str):
+        return_weights = return_weights.split(",")
+    _lib.require_gpu(sub_flat, sample_ptr)
+    if sub_flat.dtype != torch.int64 or sample_ptr.dtype != torch.int64:
+        raise _lib.DmpError("subiso_weights: int64 inputs expected")
+    sub_flat, sample_ptr = sub_flat.contiguous(), sample_ptr.contiguous()
+    B, T = graph.batch_size, int(sub_flat.numel())
+    if pattern.batch_size != B or sample_ptr.numel() != B + 1:
+        raise _lib.DmpError("subiso_weights: batch sizes disagree")
+    dev = sub_flat.device
+    g_node_off = getattr(graph, "node_offsets", None)
+    if g_node_off is None:
+        g_node_off = _offsets(graph.batch_num_nodes())
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    st = stream_ptr()
+    node_w = edge_w = None
+    if "node" in return_weights:
+        N = graph.number_of_nodes()
+        flat = torch.empty(N, dtype=torch.int64, device=dev)
+        check(lib.dmp_subiso_node_weights(ptr(sub_flat), T, ptr(sample_ptr), B, ptr(g_node_off), ptr(flat), N,
+                                          ptr(status[0:]), st), "dmp_subiso_node_weights")
+        node_w = _pre_pad(flat, graph.batch_num_nodes(), _segment_ids(graph, "node"))
+    if "edge" in return_weights:
+        from .constants import EDGELABEL
+        E, PE = graph.number_of_edges(), pattern.number_of_edges()
+        p_node_off = getattr(pattern, "node_offsets", None)
+        p_edge_off = getattr(pattern, "edge_offsets", None)
+        if p_node_off is None:
+            p_node_off, p_edge_off = _offsets(pattern.batch_num_nodes()), _offsets(pattern.batch_num_edges())
+        flat = torch.empty(E, dtype=torch.int64, device=dev)
+        active = torch.empty(max(PE, 1), dtype=torch.uint8, device=dev)
+        p_seg = _segment_ids(pattern, "edge")
+        check(lib.dmp_pattern_edge_active(ptr(pattern._src), ptr(pattern._dst), ptr(p_edge_off), ptr(p_seg), PE,
+                                          ptr(active), st), "dmp_pattern_edge_active")
+        pn, pe = pattern.batch_num_nodes(), pattern.batch_num_edges()
+        rows = (sample_ptr[1:] - sample_ptr[:-1]) // pn.clamp(min=1)
+        work_ptr = _offsets(rows * pe)
+        idx = graph.index()
+        check(lib.dmp_subiso_edge_weights(ptr(sub_flat), T, ptr(sample_ptr), ptr(work_ptr), B, ptr(p_node_off),
+                                          ptr(p_edge_off), ptr(pattern._src), ptr(pattern._dst),
+                                          ptr(pattern.edata[EDGELABEL].contiguous()), ptr(active), ptr(g_node_off),
+                                          ptr(idx.out_ptr), ptr(idx.out_ent), ptr(idx.dst32),
+                                          ptr(graph.edata[EDGELABEL].contiguous()), ptr(flat), E, int(work_hint),
+                                          ptr(status[1:]), st), "dmp_subiso_edge_weights")
+        edge_w = _pre_pad(flat, graph.batch_num_edges(), _segment_ids(graph, "edge"))
+    if validate and int(status.sum().item()) != 0:
+        raise _lib.DmpError("subiso_weights: a subisomorphism row refers to a node outside its target graph")
+    return node_w, edge_w
+
+
+def _segment_ids(g, kind):
+    seg = getattr(g, "node_graph" if kind == "node" else "edge_graph", None)
+    if seg is None:
+        sizes = g.batch_num_nodes() if kind == "node" else g.batch_num_edges()
+        total = g.number_of_nodes() if kind == "node" else g.number_of_edges()
+        seg = torch.repeat_interleave(torch.arange(sizes.numel(), device=sizes.device), sizes,
+                                      output_size=total).to(torch.int32)
+    return seg
+
+
 def batchify(samples, return_weights=None, device=None):
     """``GraphAdjDataset.batchify`` (dataset.py:1604-1636) for samples
-    ``{"id", "pattern", "graph", "counts"}`` -> ``(_id, pattern, graph, counts, (None, None))``.
-    The optional subisomorphism node/edge weights of the reference (numba host counters,
-    dataset.py:1618-1634) are outside the hot path and not produced here."""
-    if return_weights is not None:
-        raise NotImplementedError("node/edge subisomorphism weights are not part of the MI355X hot path")
+    ``{"id", "pattern", "graph", "counts"[, "subisomorphisms"]}`` ->
+    ``(_id, pattern, graph, counts, (node_weights, edge_weights))``.  With ``return_weights``
+    ("node", "edge" or "node,edge") the subisomorphism weights are computed for the whole batch on
+    the device (``subiso_weights``) instead of per sample by host counters."""
     _id = [x["id"] for x in samples]
     pattern = batch([x["pattern"] for x in samples], device)
     graph = batch([x["graph"] for x in samples], device)
     counts = torch.tensor([x["counts"] for x in samples], dtype=torch.int64)
     if device is not None:
         counts = counts.to(device)
-    return _id, pattern, graph, counts, (None, None)
+    if return_weights is None:
+        return _id, pattern, graph, counts, (None, None)
+    dev = graph.device
+    subs = [x["subisomorphisms"].reshape(-1).to(torch.int64) for x in samples]
+    sizes = [int(t.numel()) for t in subs]
+    sub_flat = torch.cat(subs).to(dev) if sum(sizes) else torch.zeros(0, dtype=torch.int64, device=dev)
+    ptr_host = [0]
+    for n in sizes:
+        ptr_host.append(ptr_host[-1] + n)
+    sample_ptr = torch.tensor(ptr_host, dtype=torch.int64).to(dev)
+    hint = sum((n // max(x["pattern"].number_of_nodes(), 1)) * x["pattern"].number_of_edges()
+               for n, x in zip(sizes, samples))
+    return _id, pattern, graph, counts, subiso_weights(pattern, graph, sub_flat, sample_ptr, return_weights,
+                                                       work_hint=hint)
 
 
 def union_graphs(a, b):

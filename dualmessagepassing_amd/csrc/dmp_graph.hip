@@ -368,6 +368,76 @@ inline uint64_t table_size(int64_t M) {
   return c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Subisomorphism weights of GraphAdjDataset.batchify (dataset.py:54-107,1491-1520,1618-1634),
+// whole batch at once.  sub: the batch's subisomorphism rows back to back (row = target node per
+// pattern node, graph-local); sample_ptr[i] = first element of sample i.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t upper_slot(const int64_t *ptr, int64_t n, int64_t x) {
+  // largest i in [0, n) with ptr[i] <= x   (ptr non-decreasing, ptr[0] <= x < ptr[n])
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (ptr[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void subiso_node_k(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
+                              const int64_t *g_node_off, unsigned long long *out, int32_t *status) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = upper_slot(sample_ptr, B, t);
+    const int64_t v = sub[t], n = g_node_off[i + 1] - g_node_off[i];
+    if (v < 0 || v >= n) { if (status) atomicOr(status, 1); continue; }
+    atomicAdd(out + g_node_off[i] + v, 1ULL);
+  }
+}
+
+// compute_edgeseq_subisoweights keeps one label list per (u, v) key, filled run by run of equal
+// consecutive keys in edge-id order: a later run of the same key replaces the earlier one
+// (dataset.py:79-88).  active[j] = 1 iff edge j belongs to the LAST run of its key.
+__global__ void pattern_edge_active_k(const int64_t *p_src, const int64_t *p_dst, const int64_t *p_edge_off,
+                                      const int32_t *p_edge_graph, int64_t PE, uint8_t *active) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= PE) return;
+  const int64_t end = p_edge_off[p_edge_graph[j] + 1];
+  const int64_t u = p_src[j], v = p_dst[j];
+  bool left_run = false, alive = true;
+  for (int64_t k = j + 1; k < end; ++k) {
+    const bool same = p_src[k] == u && p_dst[k] == v;
+    if (!same) left_run = true;
+    else if (left_run) { alive = false; break; }
+  }
+  active[j] = alive ? 1 : 0;
+}
+
+__global__ void subiso_edge_k(const int64_t *sub, const int64_t *sample_ptr, const int64_t *work_ptr, int64_t B,
+                              const int64_t *p_node_off, const int64_t *p_edge_off, const int64_t *p_src,
+                              const int64_t *p_dst, const int64_t *p_label, const uint8_t *active,
+                              const int64_t *g_node_off, const int32_t *out_ptr, const int32_t *out_ent,
+                              const int32_t *g_dst, const int64_t *g_label, unsigned long long *out,
+                              int32_t *status) {
+  const int64_t W = work_ptr[B];
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < W; w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = upper_slot(work_ptr, B, w);
+    const int64_t pe = p_edge_off[i + 1] - p_edge_off[i], pn = p_node_off[i + 1] - p_node_off[i];
+    const int64_t local = w - work_ptr[i];
+    const int64_t r = local / pe, j = p_edge_off[i] + local % pe;
+    if (!active[j]) continue;
+    const int64_t *row = sub + sample_ptr[i] + r * pn;
+    const int64_t gn = g_node_off[i + 1] - g_node_off[i];
+    const int64_t mu = row[p_src[j] - p_node_off[i]], mv = row[p_dst[j] - p_node_off[i]];
+    if (mu < 0 || mu >= gn || mv < 0 || mv >= gn) { if (status) atomicOr(status, 1); continue; }
+    const int64_t u = g_node_off[i] + mu;
+    const int32_t v = (int32_t)(g_node_off[i] + mv);
+    const int64_t l = p_label[j];
+    for (int32_t q = out_ptr[u]; q < out_ptr[u + 1]; ++q) {
+      const int32_t e = out_ent[q] >> 1;
+      if (g_dst[e] == v && g_label[e] == l) atomicAdd(out + e, 1ULL);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -521,6 +591,60 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l, const int64_t *
   unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
   dedupe_insert<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1);
   dedupe_lookup<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1, keep);
+  return check_launch();
+}
+
+int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
+                            const int64_t *g_node_off, int64_t *out, int64_t N, int32_t *status, void *stream) {
+  if (T < 0 || B < 0 || N < 0) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0) {
+    if (!out) return DMP_ERR_BAD_ARG;
+    DMP_HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)N, st));
+  }
+  if (status) DMP_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  if (T == 0) return DMP_OK;
+  if (B == 0 || N == 0 || !sub || !sample_ptr || !g_node_off) return DMP_ERR_BAD_ARG;
+  const int64_t blocks = (T + kBlock - 1) / kBlock;
+  subiso_node_k<<<(unsigned)(blocks < 65536 ? blocks : 65536), kBlock, 0, st>>>(
+      sub, T, sample_ptr, B, g_node_off, reinterpret_cast<unsigned long long *>(out), status);
+  return check_launch();
+}
+
+int dmp_pattern_edge_active(const int64_t *p_src, const int64_t *p_dst, const int64_t *p_edge_off,
+                            const int32_t *p_edge_graph, int64_t PE, uint8_t *active, void *stream) {
+  if (PE < 0) return DMP_ERR_BAD_ARG;
+  if (PE == 0) return DMP_OK;
+  if (!p_src || !p_dst || !p_edge_off || !p_edge_graph || !active) return DMP_ERR_BAD_ARG;
+  pattern_edge_active_k<<<nblk(PE), kBlock, 0, (hipStream_t)stream>>>(p_src, p_dst, p_edge_off, p_edge_graph, PE, active);
+  return check_launch();
+}
+
+int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, const int64_t *work_ptr,
+                            int64_t B, const int64_t *p_node_off, const int64_t *p_edge_off,
+                            const int64_t *p_src, const int64_t *p_dst, const int64_t *p_label,
+                            const uint8_t *active, const int64_t *g_node_off, const int32_t *g_out_ptr,
+                            const int32_t *g_out_ent, const int32_t *g_dst, const int64_t *g_label,
+                            int64_t *out, int64_t E, int64_t work_hint, int32_t *status, void *stream) {
+  if (T < 0 || B < 0 || E < 0) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (E > 0) {
+    if (!out) return DMP_ERR_BAD_ARG;
+    DMP_HIP_TRY(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)E, st));
+  }
+  if (status) DMP_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+  if (T == 0 || E == 0) return DMP_OK;
+  if (B == 0 || !sub || !sample_ptr || !work_ptr || !p_node_off || !p_edge_off || !p_src || !p_dst || !p_label ||
+      !active || !g_node_off || !g_out_ptr || !g_out_ent || !g_dst || !g_label)
+    return DMP_ERR_BAD_ARG;
+  // the exact amount of work (rows x pattern edges, summed) lives on the device in work_ptr[B];
+  // work_hint only sizes the grid (grid-stride loop), so no host sync is needed
+  int64_t blocks = ((work_hint > 0 ? work_hint : T) + kBlock - 1) / kBlock;
+  if (blocks > 65536) blocks = 65536;
+  subiso_edge_k<<<(unsigned)blocks, kBlock, 0, st>>>(sub, sample_ptr, work_ptr, B, p_node_off, p_edge_off, p_src,
+                                                    p_dst, p_label, active, g_node_off, g_out_ptr, g_out_ent,
+                                                    g_dst, g_label, reinterpret_cast<unsigned long long *>(out),
+                                                    status);
   return check_launch();
 }
 

@@ -12,15 +12,16 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .collate import collate_device
+from .collate import collate_device, subiso_weights
 from .dp import FlatGradSync
 
 
-def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
-    """Number of label-preserving injective maps of the pattern's nodes into the graph's nodes such
-    that every pattern edge (u -> v, label l) has an image edge with the same label (the reference
-    data's ``counts``: non-induced subgraph isomorphisms).  Plain backtracking on the host; meant
-    for the small synthetic sets of the harness."""
+def enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
+    """All label-preserving injective maps of the pattern's nodes into the graph's nodes such that
+    every pattern edge (u -> v, label l) has an image edge with the same label (non-induced
+    subgraph isomorphisms: a sample's ``subisomorphisms`` rows, whose number is its ``counts``).
+    Plain backtracking on the host; meant for the small synthetic sets of the harness.
+    Returns an int64 array [counts, pattern_nodes] in lexicographic order."""
     np_, ng = len(p_vl), len(g_vl)
     adj = {}
     for u, v, l in zip(g_src.tolist(), g_dst.tolist(), g_el.tolist()):
@@ -29,10 +30,12 @@ def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
     touching = [[(u, v, l) for (u, v, l) in pe if u == k or v == k] for k in range(np_)]
     mapping, used = [-1] * np_, [False] * ng
 
+    found = []
+
     def rec(k):
         if k == np_:
-            return 1
-        total = 0
+            found.append(tuple(mapping))
+            return
         for cand in range(ng):
             if used[cand] or g_vl[cand] != p_vl[k]:
                 continue
@@ -45,12 +48,17 @@ def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
                     break
             if good:
                 used[cand] = True
-                total += rec(k + 1)
+                rec(k + 1)
                 used[cand] = False
             mapping[k] = -1
-        return total
 
-    return rec(0)
+    rec(0)
+    return np.array(found, dtype=np.int64).reshape(-1, np_)
+
+
+def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
+    """``counts`` of a (pattern, graph) pair: the number of subisomorphisms."""
+    return len(enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el))
 
 
 def _er_edges(n, m, rng):
@@ -76,9 +84,10 @@ class SyntheticPairs:
             gu, gv = _er_edges(g_nodes, g_edges, rng)
             pvl, gvl = rng.integers(0, n_vlabels, p_nodes), rng.integers(0, n_vlabels, g_nodes)
             pel, gel = rng.integers(0, n_elabels, p_edges), rng.integers(0, n_elabels, g_edges)
-            c = count_subisomorphisms(pu, pv, pvl, pel, gu, gv, gvl, gel)
+            sub = enumerate_subisomorphisms(pu, pv, pvl, pel, gu, gv, gvl, gel)
             self.samples.append({"pattern": self._with_rev(pu, pv, pvl, pel, p_edges, n_elabels),
-                                 "graph": self._with_rev(gu, gv, gvl, gel, g_edges, n_elabels), "counts": c})
+                                 "graph": self._with_rev(gu, gv, gvl, gel, g_edges, n_elabels),
+                                 "counts": len(sub), "subisomorphisms": sub})
 
     @staticmethod
     def _with_rev(u, v, vl, el, max_ne, max_nel):
@@ -101,9 +110,11 @@ class SyntheticPairs:
         cfg.update(kw)
         return cfg
 
-    def batchify(self, indices, device):
+    def batchify(self, indices, device, return_weights=None):
         """``GraphAdjDataset.batchify`` (dataset.py:1604-1636) + ``.to(device)`` (train.py:606-607):
-        concatenated local arrays are uploaded once, batching itself happens on the device."""
+        concatenated local arrays are uploaded once, batching itself happens on the device.  Returns
+        ``(pattern, graph, counts [B, 1], (node_weights, edge_weights))``; the weights (pre-padded
+        int64 ``[B, max]``, or None) are computed on the device when ``return_weights`` names them."""
         out = []
         for key in ("pattern", "graph"):
             gs = [self.samples[i][key] for i in indices]
@@ -116,15 +127,34 @@ class SyntheticPairs:
                                       ndata={"id": nid, "label": cat("vlabel")},
                                       edata={"id": cat("eid"), "label": cat("elabel"), "is_reversed": cat("rev", torch.bool)}))
         counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
-        return out[0], out[1], counts.unsqueeze(-1)
+        weights = (None, None)
+        if return_weights:
+            subs = [self.samples[i]["subisomorphisms"].reshape(-1) for i in indices]
+            ptr_host = np.concatenate([[0], np.cumsum([len(x) for x in subs])]).astype(np.int64)
+            hint = sum(self.samples[i]["counts"] * len(self.samples[i]["pattern"]["src"]) for i in indices)
+            weights = subiso_weights(out[0], out[1], torch.from_numpy(np.concatenate(subs)).to(device),
+                                     torch.from_numpy(ptr_host).to(device), return_weights, work_hint=int(hint))
+        return out[0], out[1], counts.unsqueeze(-1), weights
 
 
 _CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
 
 
+def _match_terms(crit, pred, weights, mask, pred_c, neg_slp):
+    """train.py:627-649: matching loss and regulariser of one of pred_v / pred_e ([B, max_len])."""
+    with torch.no_grad():
+        weights = weights.float().masked_fill_(~mask, 0)
+        pred.masked_fill_(~mask, 0)  # in place on the model output, as the reference does
+    loss = crit(F.leaky_relu(pred, neg_slp), weights) * pred.size(1)
+    reg = crit(F.relu(pred - pred_c), torch.zeros_like(pred)) * pred.size(1)
+    return loss, reg
+
+
 def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_loss="MSE", eval_metric="MAE",
-                neg_slp=0.0, rep_reg_w=0.0, max_grad_norm=8.0, order=None):
-    """One pass over ``dataset`` (train.py:449-844 for the count loss).  Returns
+                neg_slp=0.0, rep_reg_w=0.0, match_loss_w=0.0, match_reg_w=0.0, max_grad_norm=8.0, order=None):
+    """One pass over ``dataset`` (train.py:449-844): count loss, optional representation regulariser
+    and, with ``match_loss_w`` / ``match_reg_w`` and a model built with ``pred_return_weights``, the
+    node / edge matching losses against the batch's subisomorphism weights.  Returns
     ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end)."""
     model.train()
     sync = sync or FlatGradSync(model)
@@ -134,11 +164,16 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
     cnt = 0
     for i in range(0, len(order), batch_size):
         idx = order[i:i + batch_size]
-        pattern, graph, counts = dataset.batchify(idx, device)
+        want = ("node", "edge") if (match_loss_w > 0 or match_reg_w > 0) else None
+        pattern, graph, counts, (node_w, edge_w) = dataset.batchify(idx, device, return_weights=want)
         sync.detach_grads()
         out = model(pattern, graph)
         pred = out["pred_c"]
         loss = _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
+        for w, pk, mk in ((node_w, "pred_v", "g_v_mask"), (edge_w, "pred_e", "g_e_mask")):
+            if w is not None and out[pk] is not None:
+                m_loss, m_reg = _match_terms(_CRIT[bp_loss], out[pk], w, out[mk], pred, neg_slp)
+                loss = loss + match_loss_w * m_loss + match_reg_w * m_reg
         if rep_reg_w > 0:  # train.py:651-659
             reg = sum(_CRIT[bp_loss](out[k], torch.zeros_like(out[k])) * out[k].size(1)
                       for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep"))
@@ -164,7 +199,7 @@ def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
     preds, targets = [], []
     for i in range(0, len(dataset), batch_size):
         idx = np.arange(i, min(i + batch_size, len(dataset)))
-        pattern, graph, counts = dataset.batchify(idx, device)
+        pattern, graph, counts, _ = dataset.batchify(idx, device)
         preds.append(F.relu(model(pattern, graph)["pred_c"]))
         targets.append(counts)
     pred, target = torch.cat(preds), torch.cat(targets)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 6
+#define DMP_ABI_VERSION 7
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -171,6 +171,37 @@ size_t dmp_dedupe_table_words(int64_t num_items);
 int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
                      const int64_t *key_b, int64_t num_items, int64_t *table,
                      uint8_t *keep, void *stream);
+
+/* Subisomorphism weights of a batch (the optional `node_weights` / `edge_weights` of
+ * GraphAdjDataset.batchify, SubgraphCountingMatching/dataset.py:1618-1634; counters
+ * compute_nodeseq_subisoweights :54-61, compute_edgeseq_subisoweights :64-107,
+ * calculate_{node,edge}_weights :1491-1520), whole batch per launch, int64, exact.
+ *   sub         : the subisomorphism rows of samples 0..B-1 back to back; a row holds, per pattern
+ *                 node, the graph-local target node it maps to.  T = total elements.
+ *   sample_ptr  : [B+1] first element of each sample in `sub`.
+ *   *_node_off / *_edge_off : [B+1] offsets of the batched pattern (p) / target (g) graph.
+ *   dmp_subiso_node_weights : out[g_node_off[i] + x] = #rows of sample i containing x.
+ *   dmp_pattern_edge_active : active[j] = 1 iff pattern edge j lies in the LAST run of equal
+ *                 consecutive (src, dst) pairs of its graph (the reference's per-key dict keeps
+ *                 only that run, dataset.py:79-88).
+ *   dmp_subiso_edge_weights : out[e] = #{(row, active pattern edge j) : row maps (src_j, dst_j)
+ *                 onto the endpoints of target edge e and label_j = label_e}.
+ *                 work_ptr [B+1] = exclusive prefix of rows_i * pattern_edges_i;
+ *                 g_out_ptr / g_out_ent: CSR by source of the batched target (dmp_csr_build);
+ *                 work_hint: host estimate of work_ptr[B] (grid sizing only; 0 = unknown).
+ *   status      : optional device flag, set to 1 when a row entry is outside its target graph. */
+int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
+                            const int64_t *g_node_off, int64_t *out, int64_t N,
+                            int32_t *status, void *stream);
+int dmp_pattern_edge_active(const int64_t *p_src, const int64_t *p_dst, const int64_t *p_edge_off,
+                            const int32_t *p_edge_graph, int64_t PE, uint8_t *active, void *stream);
+int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr,
+                            const int64_t *work_ptr, int64_t B, const int64_t *p_node_off,
+                            const int64_t *p_edge_off, const int64_t *p_src, const int64_t *p_dst,
+                            const int64_t *p_label, const uint8_t *active, const int64_t *g_node_off,
+                            const int32_t *g_out_ptr, const int32_t *g_out_ent, const int32_t *g_dst,
+                            const int64_t *g_label, int64_t *out, int64_t E, int64_t work_hint,
+                            int32_t *status, void *stream);
 
 /* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
  * ws: scratch of dmp_scan_workspace_words(n) int64 words. */

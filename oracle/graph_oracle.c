@@ -139,3 +139,71 @@ void orc_eigen_bounds(const int64_t *src, const int64_t *dst, int64_t E, int64_t
   *node_eigenv = mn; *edge_eigenv = me;
   free(ind); free(outd);
 }
+
+/* compute_nodeseq_subisoweights (dataset.py:54-61): how many subisomorphisms use each target node.
+ * sub = [rows, width] target node per pattern node. */
+void orc_subiso_node_weights(const int64_t *sub, int64_t rows, int64_t width, int64_t num_nodes, int64_t *w) {
+  memset(w, 0, sizeof(int64_t) * (size_t)num_nodes);
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t j = 0; j < width; ++j) w[sub[r * width + j]] += 1;
+}
+
+static int64_t bisect_left_i64(const int64_t *a, int64_t x, int64_t lo, int64_t hi) { /* dataset.py:22-30 */
+  while (lo < hi) {
+    int64_t mid = (lo + hi) / 2;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* GraphAdjDataset.calculate_edge_weights (dataset.py:1503-1520) around
+ * compute_edgeseq_subisoweights (dataset.py:64-107).  Pattern edges come in eid order, target
+ * edges are looked up in (src, dst)-sorted order and the counts are written back by edge id.
+ * The pattern's label lists are kept per (u, v) key in a dict that is filled run by run of equal
+ * consecutive keys (:79-88): a key that shows up again later REPLACES its earlier run. */
+void orc_subiso_edge_weights(const int64_t *p_u, const int64_t *p_v, const int64_t *p_el, int64_t p_len,
+                             const int64_t *g_u, const int64_t *g_v, const int64_t *g_el, int64_t g_len,
+                             const int64_t *sub, int64_t rows, int64_t width, int64_t *w) {
+  memset(w, 0, sizeof(int64_t) * (size_t)g_len);
+  if (rows == 0 || p_len == 0 || g_len == 0) return;                    /* counts == 0 -> zeros (:1504) */
+  /* all_edges(order="srcdst") (:1509): stable sort of the edge ids by (src, dst) */
+  int64_t *ord = (int64_t *)malloc(sizeof(int64_t) * (size_t)g_len);
+  for (int64_t i = 0; i < g_len; ++i) ord[i] = i;
+  for (int64_t i = 1; i < g_len; ++i) {                                   /* insertion sort: stable */
+    int64_t e = ord[i], j = i - 1;
+    while (j >= 0 && (g_u[ord[j]] > g_u[e] || (g_u[ord[j]] == g_u[e] && g_v[ord[j]] > g_v[e]))) { ord[j + 1] = ord[j]; --j; }
+    ord[j + 1] = e;
+  }
+  int64_t *su = (int64_t *)malloc(sizeof(int64_t) * (size_t)g_len), *sv = (int64_t *)malloc(sizeof(int64_t) * (size_t)g_len);
+  int64_t *sl = (int64_t *)malloc(sizeof(int64_t) * (size_t)g_len), *sw = (int64_t *)calloc((size_t)g_len, sizeof(int64_t));
+  for (int64_t i = 0; i < g_len; ++i) { su[i] = g_u[ord[i]]; sv[i] = g_v[ord[i]]; sl[i] = g_el[ord[i]]; }
+  int64_t max_v = 0;                                                       /* :77-78 */
+  for (int64_t i = 0; i < p_len; ++i) { if (p_u[i] > max_v) max_v = p_u[i]; if (p_v[i] > max_v) max_v = p_v[i]; }
+  for (int64_t i = 0; i < g_len; ++i) { if (g_u[i] > max_v) max_v = g_u[i]; if (g_v[i] > max_v) max_v = g_v[i]; }
+  int64_t mod = max_v + 1;
+  /* dict key -> (start, len) of its LAST run (:79-88) */
+  int64_t *dk = (int64_t *)malloc(sizeof(int64_t) * (size_t)p_len), *ds = (int64_t *)malloc(sizeof(int64_t) * (size_t)p_len);
+  int64_t *dl = (int64_t *)malloc(sizeof(int64_t) * (size_t)p_len), nd = 0;
+  for (int64_t i = 0; i < p_len;) {
+    int64_t key = p_u[i] * mod + p_v[i], j = i + 1;
+    while (j < p_len && p_u[j] * mod + p_v[j] == key) ++j;
+    int64_t slot = nd;
+    for (int64_t q = 0; q < nd; ++q) if (dk[q] == key) slot = q;
+    dk[slot] = key; ds[slot] = i; dl[slot] = j - i;
+    if (slot == nd) ++nd;
+    i = j;
+  }
+  for (int64_t r = 0; r < rows; ++r) {                                   /* :90-106 (key order is immaterial) */
+    const int64_t *m = sub + r * width;
+    for (int64_t q = 0; q < nd; ++q) {
+      int64_t u = m[dk[q] / mod], v = m[dk[q] % mod];
+      int64_t u_i = bisect_left_i64(su, u, 0, g_len), u_j = bisect_left_i64(su, u + 1, 0, g_len);
+      int64_t v_i = bisect_left_i64(sv, v, u_i, u_j), v_j = bisect_left_i64(sv, v + 1, v_i, u_j);
+      for (int64_t k = v_i; k < v_j; ++k)
+        for (int64_t t = 0; t < dl[q]; ++t)
+          if (p_el[ds[q] + t] == sl[k]) sw[k] += 1;
+    }
+  }
+  for (int64_t i = 0; i < g_len; ++i) w[ord[i]] = sw[i];                 /* edge_weights[g_eid] = ... (:1512) */
+  free(ord); free(su); free(sv); free(sl); free(sw); free(dk); free(ds); free(dl);
+}

@@ -104,3 +104,44 @@ def convert_to_dual_graph(src, dst, n, ndata, edata):
     if "id" not in ndata:
         dual_edata["id"] = pay.copy()                                       # graph.py:141-142
     return dsrc, ddst, dn, dual_ndata, dual_edata
+
+
+def subiso_node_weights(sub, num_nodes):
+    sub = _i64(sub)
+    rows, width = (sub.shape if sub.ndim == 2 else (0, 1))
+    w = np.zeros(max(num_nodes, 1), np.int64)
+    lib().orc_subiso_node_weights(_p(sub), ctypes.c_int64(rows), ctypes.c_int64(width), ctypes.c_int64(num_nodes), _p(w))
+    return w[:num_nodes]
+
+
+def subiso_edge_weights(p_u, p_v, p_el, g_u, g_v, g_el, sub):
+    p_u, p_v, p_el, g_u, g_v, g_el, sub = map(_i64, (p_u, p_v, p_el, g_u, g_v, g_el, sub))
+    rows, width = (sub.shape if sub.ndim == 2 else (0, 1))
+    w = np.zeros(max(len(g_u), 1), np.int64)
+    lib().orc_subiso_edge_weights(_p(p_u), _p(p_v), _p(p_el), ctypes.c_int64(len(p_u)), _p(g_u), _p(g_v), _p(g_el),
+                                  ctypes.c_int64(len(g_u)), _p(sub), ctypes.c_int64(rows), ctypes.c_int64(width), _p(w))
+    return w[:len(g_u)]
+
+
+def pre_pad(rows, pad=0):
+    """``batch_convert_tensor_to_tensor(rows, pre_pad=True)`` (utils/dl.py:89-110) for 1-D rows."""
+    m = max(len(r) for r in rows)
+    out = np.full((len(rows), m), pad, dtype=rows[0].dtype)
+    for i, r in enumerate(rows):
+        if len(r):
+            out[i, m - len(r):] = r
+    return out
+
+
+def batch_subiso_weights(d):
+    """Whole fixture (tests/golden/subiso_weights_*.npz layout) -> padded node / edge weights."""
+    nw, ew = [], []
+    po, go, pn, gn = 0, 0, d["p_num_nodes"], d["g_num_nodes"]
+    for i in range(len(pn)):
+        pe, ge = int(d["p_num_edges"][i]), int(d["g_num_edges"][i])
+        sub = d["sub_flat"][d["sample_ptr"][i]:d["sample_ptr"][i + 1]].reshape(-1, int(pn[i]))
+        nw.append(subiso_node_weights(sub, int(gn[i])))
+        ew.append(subiso_edge_weights(d["p_src"][po:po + pe], d["p_dst"][po:po + pe], d["p_elabel"][po:po + pe],
+                                      d["g_src"][go:go + ge], d["g_dst"][go:go + ge], d["g_elabel"][go:go + ge], sub))
+        po, go = po + pe, go + ge
+    return pre_pad(nw), pre_pad(ew)

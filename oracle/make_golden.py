@@ -344,6 +344,8 @@ def gen_full_model():
                                                  "rep_compgcn_edge_norm": "both", "pred_net": "MeanPredictNet"}, **ragged),
         # four optimizer steps of the count loss (train.py:624-686: MSE on pred_c, AdamW(amsgrad), grad clip)
         "train4": dict(hid=16, layers=2, extra={}, train_steps=4, **ragged),
+        # per-node / per-edge matching outputs pred_v, pred_e (pred.py:118-131; train.py:627-649 consumes them)
+        "matchw": dict(hid=16, layers=2, extra={"pred_return_weights": "node,edge"}, **ragged),
     }
     for tag, c in cases.items():
         rng = np.random.default_rng(31 if tag == "uniform" else 32)
@@ -364,6 +366,9 @@ def gen_full_model():
             for head in model.pred_net.values():
                 head.pred_fc2.weight.uniform_(-0.3, 0.3)
                 head.pred_fc2.bias.uniform_(-0.1, 0.1)
+                if head.weight_fc2 is not None:
+                    head.weight_fc2.weight.uniform_(-0.3, 0.3)
+                    head.weight_fc2.bias.uniform_(-0.1, 0.1)
         d = {"config_keys": np.array(sorted(config.keys())),
              "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())])}
         for k, v in model.state_dict().items():
@@ -385,7 +390,11 @@ def gen_full_model():
                 d["sd_after." + k] = v.clone()
             print("  train losses", losses)
         out = model(pattern, graph)
-        out["pred_c"].sum().backward()
+        total = out["pred_c"].sum()
+        for k in ("pred_v", "pred_e"):
+            if out[k] is not None:
+                total = total + out[k].sum()
+        total.backward()
         for t, g in (("p", pattern), ("g", graph)):
             d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(),
                       t + "_bnn": g.batch_num_nodes(), t + "_bne": g.batch_num_edges()})
@@ -492,6 +501,84 @@ def gen_unc():
     subprocess.run([sys.executable, "-c", code], check=True)
 
 
+def enumerate_subisomorphisms(pu, pv, pel, pvl, gu, gv, gel, gvl):
+    """All injective label-preserving node maps under which every pattern edge (u, v, l) has an
+    image edge with label l (tiny inputs only): the ``subisomorphisms`` field of a data sample."""
+    import itertools
+    have = set(zip(gu.tolist(), gv.tolist(), gel.tolist()))
+    out = []
+    for m in itertools.permutations(range(len(gvl)), len(pvl)):
+        if all(gvl[m[i]] == pvl[i] for i in range(len(pvl))) and \
+                all((m[u], m[v], l) in have for u, v, l in zip(pu.tolist(), pv.tolist(), pel.tolist())):
+            out.append(m)
+    return np.array(out, dtype=np.int64).reshape(-1, len(pvl))
+
+
+def gen_subiso_weights():
+    """``GraphAdjDataset.batchify(batch, return_weights="node,edge")`` (dataset.py:1604-1636) ->
+    pre-padded node / edge subisomorphism weights, through the reference's own counters
+    (``compute_nodeseq_subisoweights`` / ``compute_edgeseq_subisoweights``, dataset.py:54-107, and
+    ``calculate_{node,edge}_weights``, dataset.py:1491-1520)."""
+    import dgl
+    import dataset as ref_dataset  # reference module
+
+    def make_graph(u, v, el, vl, rev):
+        n, e = len(vl), len(u)
+        g = ref_dataset.Graph()
+        g.add_nodes(n)
+        dgl.DGLGraph.add_edges(g, u, v)
+        g.ndata["id"], g.ndata["label"] = th.arange(n), th.from_numpy(np.asarray(vl, np.int64))
+        g.edata["id"], g.edata["label"] = th.arange(e), th.from_numpy(np.asarray(el, np.int64))
+        if rev:  # train.py:303-316
+            g.edata["is_reversed"] = th.zeros((e,), dtype=th.bool)
+            dgl.DGLGraph.add_edges(g, v, u, data={"id": th.arange(e) + 64, "label": g.edata["label"][:e] + 8,
+                                                 "is_reversed": th.ones((e,), dtype=th.bool)})
+        return g
+
+    def sample(pu, pv, pel, pvl, gu, gv, gel, gvl, rev, name):
+        pu, pv, gu, gv = (np.asarray(a, np.int64) for a in (pu, pv, gu, gv))
+        pel, pvl, gel, gvl = (np.asarray(a, np.int64) for a in (pel, pvl, gel, gvl))
+        sub = enumerate_subisomorphisms(pu, pv, pel, pvl, gu, gv, gel, gvl)
+        return {"id": name, "pattern": make_graph(pu, pv, pel, pvl, rev), "graph": make_graph(gu, gv, gel, gvl, rev),
+                "counts": len(sub), "subisomorphisms": th.from_numpy(sub)}
+
+    def er_sample(rng, pn, pm, gn, gm, nvl, nel, rev, name):
+        pu, pv = er_edges(pn, pm, rng)
+        gu, gv = er_edges(gn, gm, rng)
+        return sample(pu, pv, rng.integers(0, nel, pm), rng.integers(0, nvl, pn),
+                      gu, gv, rng.integers(0, nel, gm), rng.integers(0, nvl, gn), rev, name)
+
+    rng = np.random.default_rng(77)
+    cases = {}
+    for rev in (False, True):
+        batch = [er_sample(rng, 3, 2, 7, 18, 2, 1, rev, "a-0"), er_sample(rng, 2, 1, 6, 12, 1, 2, rev, "b-1"),
+                 er_sample(rng, 4, 4, 8, 30, 1, 1, rev, "c-2"), er_sample(rng, 3, 3, 5, 6, 3, 3, rev, "d-3"),
+                 er_sample(rng, 3, 2, 9, 24, 2, 1, rev, "e-4")]
+        # antiparallel pattern edges: with reversed copies the key (v, u) occurs twice, apart (dict overwrite, dataset.py:84)
+        batch.append(sample([0, 1, 1], [1, 0, 2], [0, 0, 0], [0, 0, 0],
+                            [0, 1, 1, 2, 2, 3, 3], [1, 0, 2, 1, 3, 2, 0], [0] * 7, [0] * 4, rev, "anti-5"))
+        # parallel pattern edges in one run (labels 0, 1) and split in two runs (label 0 | other | label 1);
+        # parallel target edges with equal and different labels
+        batch.append(sample([0, 0, 1], [1, 1, 2], [0, 1, 0], [0, 0, 0],
+                            [0, 0, 0, 1, 1, 2, 3], [1, 1, 1, 2, 2, 3, 0], [0, 1, 1, 0, 0, 0, 0], [0] * 4, rev, "par-6"))
+        batch.append(sample([0, 1, 0], [1, 2, 1], [0, 0, 1], [0, 0, 0],
+                            [0, 0, 0, 1, 1, 2, 3], [1, 1, 1, 2, 2, 3, 0], [0, 1, 1, 0, 0, 0, 0], [0] * 4, rev, "split-7"))
+        cases["rev" if rev else "plain"] = batch
+    for tag, batch in cases.items():
+        assert any(x["counts"] == 0 for x in batch) and sum(x["counts"] > 0 for x in batch) >= 5, [x["counts"] for x in batch]
+        _, pattern, graph, counts, (nw, ew) = ref_dataset.GraphAdjDataset.batchify(batch, return_weights="node,edge")
+        d = {"counts": counts, "node_weights": nw, "edge_weights": ew,
+             "sub_flat": th.cat([x["subisomorphisms"].reshape(-1) for x in batch]),
+             "sample_ptr": th.tensor([0] + list(np.cumsum([x["subisomorphisms"].numel() for x in batch])))}
+        for t, g in (("p", pattern), ("g", graph)):
+            off_n = th.cat([th.zeros(1, dtype=th.long), th.cumsum(g.batch_num_nodes(), 0)])[:-1]
+            eg = th.repeat_interleave(th.arange(len(batch)), g.batch_num_edges())
+            d.update({t + "_src": g._u - off_n[eg], t + "_dst": g._v - off_n[eg], t + "_elabel": g.edata["label"],
+                      t + "_num_nodes": g.batch_num_nodes(), t + "_num_edges": g.batch_num_edges()})
+        np.savez_compressed(os.path.join(OUT, "subiso_weights_%s.npz" % tag), **t2n(d))
+        print("wrote subiso_weights_%s.npz" % tag, "counts", counts.tolist(), "nw", tuple(nw.shape), "ew", tuple(ew.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import ref_standin
@@ -503,6 +590,7 @@ def main():
     gen_addrev()
     gen_full_model()
     gen_unc()
+    gen_subiso_weights()
 
 
 if __name__ == "__main__":

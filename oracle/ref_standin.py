@@ -129,8 +129,14 @@ class DGLGraph:
         return th.bincount(self._v, minlength=self._n)
 
     def all_edges(self, form="uv", order="eid"):
-        assert order == "eid"
         e = th.arange(self._u.numel())
+        if order == "srcdst":  # DGL: sorted by (src, dst); equal pairs keep edge-id order
+            key = self._u * max(self._n, 1) + self._v
+            e = th.sort(key, stable=True)[1]
+            if form == "eid":
+                return e
+            return (self._u[e], self._v[e]) if form == "uv" else (self._u[e], self._v[e], e)
+        assert order == "eid"
         if form == "uv":
             return self._u, self._v
         if form == "eid":

@@ -63,3 +63,16 @@ def test_collate_and_csr_oracle_basics():
     assert list(ptr) == [0, 1, 4, 4] and list(ent) == [3, 0, 5, 6]
     a, b = GO.eigen_bounds([0, 1, 2], [1, 2, 0], 3)
     assert (a, b) == (2.0, 2.0)
+
+
+@pytest.mark.parametrize("path", golden_files("subiso_weights_"))
+def test_subiso_weight_oracle_matches_reference(path):
+    """batchify(return_weights="node,edge") of the reference (dataset.py:1604-1636) -- including the
+    samples where a repeated (u, v) key replaces its earlier run -- against the C restatement."""
+    d = load_golden(path)
+    nw, ew = GO.batch_subiso_weights(d)
+    assert nw.dtype == np.int64 and np.array_equal(nw, d["node_weights"])
+    assert np.array_equal(ew, d["edge_weights"])
+    # every subisomorphism row touches pattern_nodes target nodes
+    rows = (np.diff(d["sample_ptr"]) // d["p_num_nodes"])
+    assert np.array_equal(nw.sum(1), rows * d["p_num_nodes"]) and np.array_equal(rows, d["counts"])
