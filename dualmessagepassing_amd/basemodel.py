@@ -179,6 +179,61 @@ class BaseModel(nn.Module):
     def refine_edge_weights(self, weights, use_max=False):
         return weights
 
+    def expand(self, **kw):
+        """basemodel.py:167-219: grow the vocabulary-dependent parts (encodings, embeddings and, with
+        ``pred_with_enc``, the heads) to larger ``max_*`` sizes; trained weights land in the trailing
+        corner of the new, otherwise zero, tensors (multi-hot codes are right-aligned)."""
+        if "base" in kw and kw["base"] != self.base:
+            raise ValueError("expand: base must not change")
+        kw = dict(kw)
+        keys = ["max_npv", "max_npvl", "max_npe", "max_npel", "max_ngv", "max_ngvl", "max_nge", "max_ngel"]
+        bak = {k: getattr(self, k) for k in keys}
+        for k in keys:
+            setattr(self, k, max(kw.get(k, -1), bak[k]))
+        old = {k: getattr(self, k) for k in ("g_enc_net", "p_enc_net", "filter_net", "g_emb_net", "p_emb_net", "pred_net")}
+        try:
+            dev = next(self.parameters()).device
+            self.g_enc_net = self.create_enc_net(type="graph", **kw).to(dev)
+            self.p_enc_net = self.g_enc_net if self.share_enc_net else self.create_enc_net(type="pattern", **kw).to(dev)
+            new_filter = self.create_filter_net(**kw)
+            if new_filter is not None:
+                expand_dimensions(old["filter_net"], new_filter.to(dev), pre_pad=True)
+            self.filter_net = new_filter
+            new_g_emb = self.create_emb_net(type="graph", **kw).to(dev)
+            expand_dimensions(old["g_emb_net"], new_g_emb, pre_pad=True)
+            self.g_emb_net = new_g_emb
+            if self.share_emb_net:
+                self.p_emb_net = self.g_emb_net
+            else:
+                new_p_emb = self.create_emb_net(type="pattern", **kw).to(dev)
+                expand_dimensions(old["p_emb_net"], new_p_emb, pre_pad=True)
+                self.p_emb_net = new_p_emb
+            if self.pred_with_enc:
+                new_pred = self.create_pred_net(**kw).to(dev)
+                expand_dimensions(old["pred_net"], new_pred, pre_pad=True)
+                self.pred_net = new_pred
+        except Exception:
+            for k, v in bak.items():
+                setattr(self, k, v)
+            for k, v in old.items():
+                setattr(self, k, v)
+            raise
+
+
+def expand_dimensions(old_module, new_module, pre_pad=True):
+    """utils/dl.py:157-191: zero the new tensors and copy the old ones into their trailing
+    (``pre_pad``) or leading corner, parameter by parameter of equal name."""
+    with th.no_grad():
+        if isinstance(old_module, th.Tensor):
+            new_module.zero_()
+            idx = tuple(slice(-n, None) if pre_pad else slice(0, n) for n in old_module.size())
+            new_module[idx].copy_(old_module)
+            return
+        old_params = dict(old_module.named_parameters())
+        for name, param in new_module.named_parameters():
+            if name in old_params:
+                expand_dimensions(old_params[name], param, pre_pad)
+
 
 class GraphAdjModelV2(BaseModel):
     """basemodel.py:965-1663."""

@@ -376,7 +376,17 @@ class PoolIndex:
 
     CHUNK = 64
 
-    def __init__(self, sizes, flag=None):
+    @classmethod
+    def from_keys(cls, keys, num_keys):
+        """Index for summing rows by an arbitrary integer key in [0, num_keys) (e.g. the relation
+        type of an edge): rows are visited key by key in ascending row order (stable sort), so the
+        sums are bit-stable; same two-level chunking as for the contiguous per-graph ranges."""
+        keys = keys.view(-1).to(torch.int64)
+        order = torch.sort(keys, stable=True)[1]
+        sizes = torch.bincount(keys, minlength=num_keys)
+        return cls(sizes, order=order, seg=keys)
+
+    def __init__(self, sizes, flag=None, order=None, seg=None):
         dev = sizes.device
         sizes = sizes.to(torch.int64)
         B = int(sizes.numel())
@@ -395,13 +405,16 @@ class PoolIndex:
         vptr[V] = R
         self.num_graphs, self.num_rows, self.num_chunks = B, R, V
         self.vptr = vptr.to(torch.int32)
-        ent = torch.arange(R, device=dev, dtype=torch.int64) << 1
+        rows = torch.arange(R, device=dev, dtype=torch.int64) if order is None else order.to(torch.int64)
+        ent = rows << 1
         if flag is not None:
-            ent = ent | flag.view(-1).to(torch.int64)
+            ent = ent | flag.view(-1).to(torch.int64)[rows]
         self.vent = ent.to(torch.int32)
         self.gptr = coff.to(torch.int32)
         self.gent = (torch.arange(V, device=dev, dtype=torch.int64) << 1).to(torch.int32)
-        self.seg32 = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), sizes, output_size=R)
+        self.sizes = sizes
+        self.seg32 = (torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), sizes, output_size=R)
+                      if seg is None else seg.to(torch.int32).contiguous())
         self.flag8 = None if flag is None else flag.view(-1).to(torch.uint8).contiguous()
 
 

@@ -15,11 +15,13 @@ Differences from the SCM layer, all preserved:
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from .constants import OUTDEGREE, REVFLAG
 from .dmpnn import dual_message_passing
 from .graph import BatchedGraph
+from .ops import PoolIndex, seg_pool
 
 
 class DualGraphConv(nn.Module):
@@ -198,8 +200,83 @@ class DMPNN(nn.Module):
         z = self.rel_emb(g, r)
         for layer in self.layers:
             h, z = layer(g, h, z, norm)
-        # model.py:319-325: masked mean of the edge representations per relation type
-        r_rep = torch.cat(
-            [z.masked_fill((r != i).view(-1, 1), 0.0).sum(dim=0, keepdim=True) / ((r == i).sum().float() + 1e-8)
-             for i in range(self.num_rels)], dim=0)
+        # model.py:319-325 (one masked full-size sum per relation type there): mean of the edge
+        # representations per relation type as ONE keyed segment sum; the index is memoised per
+        # relation tensor (UNC trains on one fixed graph)
+        pool = self._rel_pool(r)
+        r_rep = seg_pool(z, pool) / (pool.sizes.float().view(-1, 1) + 1e-8)
         return h, z, r_rep
+
+    def _rel_pool(self, r):
+        key = (r.data_ptr(), r._version, int(r.numel()), r.device)
+        cached = getattr(self, "_rel_pool_cache", None)
+        if cached is None or cached[0] != key:
+            self._rel_pool_cache = cached = (key, PoolIndex.from_keys(r, self.num_rels), r)  # r kept alive: ptr stays unique
+        return cached[1]
+
+
+class TrainModel(nn.Module):
+    """UNC ``TrainModel`` (model.py:631-744): the DMPNN encoder with ``2 * num_rels`` edge types plus
+    the link-prediction (DistMult score) or node-classification head and their regularisers."""
+
+    def __init__(self, node_attri, num_nodes, o_dim, num_rels, nlabel, num_hidden_layers=1, dropout=0,
+                 use_cuda=False, reg_param=0):
+        super(TrainModel, self).__init__()
+        i_dim = o_dim if node_attri is None else node_attri.shape[1]
+        self.model = DMPNN(node_attri, None, num_nodes, i_dim, o_dim, num_rels * 2, num_hidden_layers, dropout, use_cuda)
+        self.reg_param = reg_param
+        if nlabel == 0:
+            self.supervised = False
+            self.w_relation = nn.Parameter(torch.Tensor(num_rels, o_dim))
+            nn.init.xavier_uniform_(self.w_relation, gain=nn.init.calculate_gain("relu"))
+        else:
+            self.supervised = True
+            self.node_fc = nn.Linear(o_dim, nlabel)
+            nn.init.xavier_uniform_(self.node_fc.weight, gain=nn.init.calculate_gain("sigmoid"))
+            nn.init.zeros_(self.node_fc.bias)
+        self.edge_fc = nn.Linear(o_dim, o_dim)
+        nn.init.xavier_uniform_(self.edge_fc.weight, gain=nn.init.calculate_gain("sigmoid"))
+        nn.init.zeros_(self.edge_fc.bias)
+
+    def calc_score(self, embedding, triplets):
+        node_emb = embedding[0] if isinstance(embedding, (tuple, list)) else embedding
+        s = node_emb[triplets[:, 0]]
+        r = self.w_relation[triplets[:, 1]]
+        o = node_emb[triplets[:, 2]]
+        return torch.sum(s * r * o, dim=1)
+
+    def forward(self, g, h, edge_type, edge_norm):
+        output = self.model.forward(g, h, edge_type, edge_norm)
+        pred = None
+        if self.supervised:
+            pred = self.node_fc(output[0] if isinstance(output, (tuple, list)) else output)
+        return output, pred
+
+    def unsupervised_regularization_loss(self, embedding, edge_type=None):
+        # model.py:692-714 (needs ``w_relation``: as in the reference, only defined for nlabel == 0)
+        reg = torch.mean(self.w_relation.pow(2))
+        embs = list(embedding) if isinstance(embedding, (tuple, list)) else [embedding]
+        for emb in embs:
+            reg = reg + torch.mean(emb.pow(2))
+        if edge_type is not None:
+            for emb in embs:
+                if emb.size(0) == edge_type.size(0):
+                    mask = edge_type < self.w_relation.size(0)
+                    emb_diff = self.edge_fc(emb[mask]) - torch.index_select(self.w_relation, 0, edge_type[mask])
+                    reg = reg + torch.mean(torch.pow(emb_diff, 2))
+        return reg
+
+    def get_unsupervised_loss(self, g, embedding, edge_type, triplets, labels):
+        score = self.calc_score(embedding, triplets)
+        predict_loss = F.binary_cross_entropy_with_logits(score, labels)
+        return predict_loss + self.reg_param * self.unsupervised_regularization_loss(embedding, edge_type=edge_type)
+
+    def supervised_regularization_loss(self, embedding, edge_type=None):
+        return self.unsupervised_regularization_loss(embedding, edge_type=edge_type)
+
+    def get_supervised_loss(self, g, embedding, edge_type, pred, matched_labels, matched_index, multi):
+        if multi:
+            predict_loss = F.binary_cross_entropy(torch.sigmoid(pred[matched_index]), matched_labels)
+        else:
+            predict_loss = F.nll_loss(F.log_softmax(pred[matched_index], dim=1), matched_labels)
+        return predict_loss + self.reg_param * self.supervised_regularization_loss(embedding, edge_type=edge_type)

@@ -492,6 +492,43 @@ for k, b in model.named_buffers():
     d["b." + k] = b
 np.savez_compressed(os.path.join(%(out)r, "unc_model.npz"), **t2n(d))
 print("wrote unc_model.npz")
+# TrainModel (model.py:631-744): link-prediction head + regulariser, and the supervised head
+from model import TrainModel
+for tag, nlabel in (("unsup", 0), ("sup", 4)):
+    th.manual_seed(91 + nlabel)
+    tm = TrainModel(None, n, h, nrel, nlabel, num_hidden_layers=2, dropout=0.0, use_cuda=False, reg_param=0.01)
+    tm.eval()
+    if nlabel:  # the reference's regulariser reads w_relation, which only the unsupervised ctor creates
+        tm.w_relation = th.nn.Parameter(th.randn(nrel, h) * 0.1)
+    with th.no_grad():
+        for layer in tm.model.layers:
+            for seq in (layer.nmlp, layer.emlp):
+                seq[1].running_mean.uniform_(-0.2, 0.2); seq[1].running_var.uniform_(0.5, 1.5)
+    emb, pred = tm(g, hid, r, norm)
+    d = {"src": u2, "dst": v2, "num_nodes": n, "etype": etype, "norm": norm, "hid": h, "num_rels": nrel, "nlabel": nlabel}
+    if nlabel == 0:
+        trip = np.stack([rng.integers(0, n, 50), rng.integers(0, nrel, 50), rng.integers(0, n, 50)], 1)
+        lab = (rng.random(50) < 0.5).astype(np.float32)
+        loss = tm.get_unsupervised_loss(g, emb, r, th.from_numpy(trip), th.from_numpy(lab))
+        d.update({"triplets": trip, "labels": lab})
+    else:
+        midx = rng.choice(n, 12, replace=False)
+        mlab = rng.integers(0, nlabel, 12)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = tm.get_supervised_loss(g, emb, r, pred, th.from_numpy(mlab), th.from_numpy(midx), False)
+        d.update({"matched_index": midx, "matched_labels": mlab, "pred": pred})
+    loss.backward()
+    d["loss"] = loss.detach()
+    for k, p in tm.named_parameters():
+        d["p." + k] = p
+        if p.grad is not None:
+            d["g." + k] = p.grad
+    for k, b in tm.named_buffers():
+        d["b." + k] = b
+    np.savez_compressed(os.path.join(%(out)r, "unc_train_%%s.npz" %% tag), **t2n(d))
+    print("wrote unc_train_%%s.npz" %% tag, float(loss))
 '''
 
 
@@ -579,6 +616,33 @@ def gen_subiso_weights():
         print("wrote subiso_weights_%s.npz" % tag, "counts", counts.tolist(), "nw", tuple(nw.shape), "ew", tuple(ew.shape))
 
 
+def gen_expand():
+    """``BaseModel.expand(**kw)`` of the reference (models/basemodel.py:167-219 over
+    utils/dl.py:157-191): state_dict before and after growing the vocabularies."""
+    from models.dmpnn import DMPNN
+    th.manual_seed(99)
+    config = dict(max_ngv=16, max_ngvl=4, max_nge=40, max_ngel=6, max_npv=4, max_npvl=4, max_npe=8, max_npel=6,
+                  base=2, hid_dim=8, share_emb_net=False, share_enc_net=False, share_rep_net=True, rep_residual=True,
+                  enc_net="Multihot", emb_net="Orthogonal", filter_net="ScalarFilter", rep_net="DMPNN",
+                  rep_num_graph_layers=1, rep_num_pattern_layers=1, rep_dmpnn_batch_norm=False,
+                  pred_net="SumPredictNet", pred_hid_dim=8, pred_with_enc=True, node_pred=True, edge_pred=True)
+    grow = dict(max_ngv=40, max_ngvl=9, max_nge=40, max_ngel=20, max_npv=4, max_npvl=5, max_npe=20, max_npel=3)
+    model = DMPNN(**config)
+    with th.no_grad():
+        for head in model.pred_net.values():
+            head.pred_fc2.weight.uniform_(-0.3, 0.3)
+    d = {"config_keys": np.array(sorted(config.keys())), "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())]),
+         "grow_keys": np.array(sorted(grow.keys())), "grow_vals": np.array([grow[k] for k in sorted(grow.keys())])}
+    for k, v in model.state_dict().items():
+        d["sd." + k] = v.clone()
+    model.expand(**dict(config, **grow))   # the callers pass the whole (new) config: create_*_net read their kinds from it
+    for k, v in model.state_dict().items():
+        d["sd_after." + k] = v.clone()
+    d["max_after"] = np.array([getattr(model, k) for k in sorted(grow.keys())])
+    np.savez_compressed(os.path.join(OUT, "expand_dmpnn.npz"), **t2n(d))
+    print("wrote expand_dmpnn.npz", {k: tuple(v.shape) for k, v in model.state_dict().items() if "emb_net" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import ref_standin
@@ -591,6 +655,7 @@ def main():
     gen_full_model()
     gen_unc()
     gen_subiso_weights()
+    gen_expand()
 
 
 if __name__ == "__main__":

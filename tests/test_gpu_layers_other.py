@@ -118,3 +118,57 @@ def test_unc_dmpnn_model_matches_reference_golden(gpu):
             _close(p.grad, d["g." + k], 3e-4, 3e-4, "grad " + k)
         else:
             assert p.grad is None, k
+
+
+@pytest.mark.parametrize("tag", ["unsup", "sup"])
+def test_unc_train_model_losses_match_reference(tag, gpu):
+    """UNC TrainModel (model.py:631-744): encoder + DistMult / node-classification head + regulariser;
+    loss value and every parameter gradient against the reference's own run."""
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd.unc import TrainModel
+    d = load_golden(golden_files("unc_train_" + tag)[0])
+    n, h, nrel, nlabel = int(d["num_nodes"]), int(d["hid"]), int(d["num_rels"]), int(d["nlabel"])
+    tm = TrainModel(None, n, h, nrel, nlabel, num_hidden_layers=2, dropout=0.0, reg_param=0.01)
+    if nlabel:
+        tm.w_relation = th.nn.Parameter(th.zeros(nrel, h))
+    sd = {k[2:]: _t(v) for k, v in d.items() if k.startswith("p.") or k.startswith("b.")}
+    tm.load_state_dict(sd, strict=True)
+    tm.to(gpu).eval()
+    g = BatchedGraph(_t(d["src"]).to(gpu), _t(d["dst"]).to(gpu), n)
+    r = _t(d["etype"]).to(gpu)
+    emb, pred = tm(g, th.arange(n, device=gpu), r, _t(d["norm"]).to(gpu))
+    if nlabel == 0:
+        assert pred is None
+        loss = tm.get_unsupervised_loss(g, emb, r, _t(d["triplets"]).to(gpu), _t(d["labels"]).to(gpu))
+    else:
+        _close(pred, d["pred"], 5e-5, 5e-5, "pred")
+        loss = tm.get_supervised_loss(g, emb, r, pred, _t(d["matched_labels"]).to(gpu), _t(d["matched_index"]).to(gpu), False)
+    _close(loss, d["loss"], 2e-5, 2e-5, "loss")
+    loss.backward()
+    seen = 0
+    for k, p in tm.named_parameters():
+        if "g." + k in d:
+            _close(p.grad, d["g." + k], 3e-4, 3e-6, "grad " + k)
+            seen += 1
+        else:
+            assert p.grad is None, k
+    assert seen > 20
+
+
+def test_keyed_segment_pool_equals_masked_sums(gpu):
+    """PoolIndex.from_keys: sums of rows by an arbitrary key (relation types incl. an unused one),
+    forward and backward, against per-key masked sums in fp64; run-to-run bitwise stable."""
+    from dualmessagepassing_amd.ops import PoolIndex, seg_pool
+    gen = th.Generator().manual_seed(3)
+    E, H, K = 5000, 48, 7
+    keys = th.randint(0, K - 1, (E,), generator=gen).to(gpu)          # key K-1 never occurs
+    x = th.randn(E, H, generator=gen).to(gpu).requires_grad_(True)
+    pool = PoolIndex.from_keys(keys, K)
+    out = seg_pool(x, pool)
+    want = th.stack([x.detach().double()[keys == k].sum(0) for k in range(K)])
+    assert out.shape == (K, H) and float(out[K - 1].detach().abs().max()) == 0.0
+    assert th.allclose(out.double(), want, rtol=1e-6, atol=1e-5)
+    assert th.equal(out, seg_pool(x, pool))
+    w = th.randn(K, H, generator=gen).to(gpu)
+    (out * w).sum().backward()
+    assert th.equal(x.grad, w[keys])
