@@ -1,73 +1,130 @@
 // Fused MFMA kernels of the DMPLayer edge chain (gfx950, fp32 in / fp32 accumulate, exact fp32:
 // v_mfma_f32_32x32x2_f32).  K = H = 128 only; other widths take the GEMM + epilogue-kernel path.
 //
-// Structure (two persistent 256-thread workgroups per CU, out of phase with each other so that one
-// streams / stores while the other issues MFMAs; 4 waves each, 2 waves per SIMD in total):
+// Structure: persistent 256-thread workgroups (4 waves, one 32-column slice of every output panel
+// each), 2 (NC = 2) or 3 (NC = 1) resident per CU and not synchronised with each other: while one
+// issues the MFMAs of a 32-row tile, the others stage / transpose / store theirs.
 //   * the [128, NC*128] weight panel lives in REGISTERS for the whole kernel: wave w keeps the
-//     fragments of its 32-column slice (w&3) of every panel, b[p][s] = B[s + 64h][128p + 32(w&3) + l]
+//     fragments of its 32-column slice of every panel, b[p][s] = B[s + 64h][128p + 32w + l]
 //     (h = lane>>5, l = lane&31): no LDS or cache traffic for the weights inside the loop;
-//   * 64-row tiles of the streamed operand go global -> registers (prefetched one tile ahead,
-//     in flight under the MFMAs) -> LDS (132-float rows: conflict-free ds_read_b128);
-//   * every wave computes both 32-row sub-tiles of a 64-row tile: 64 k-steps x NC panels of
-//     32x32x2 MFMAs per sub-tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's
-//     A operands are 4 consecutive floats of its LDS row (one ds_read_b128 per 4 MFMAs);
+//   * 32-row tiles of the streamed operand go global -> registers (prefetched two tiles ahead) ->
+//     LDS (132-float rows: conflict-free ds_read_b128); 64 k-steps x NC panels of 32x32x2 MFMAs per
+//     tile, k-step s pairs k = s (lanes 0-31) with k = s+64 (lanes 32-63) so that a lane's A operands
+//     are 4 consecutive floats of its LDS row (one ds_read_b128 per 4 MFMAs, requested one group
+//     of MFMAs ahead);
 //   * the 32x32 accumulators (row = (r&3)+8(r>>2)+4h, col = l) go through a per-wave LDS transpose;
 //     the epilogue (gathered node rows, gate, residual, ReLU mask, column sums) runs on the
-//     transposed float4s, whose operands were requested before the transpose, and stores 16 B per lane.
+//     transposed float4s and stores 16 B per lane.
+//   * per tile:  MFMA phase | barrier | stage next tile, prefetch the one after | barrier | epilogue.
 //
-//   dmp_edge_fwd_fused   H1[e] = relu(Z W'[:, :H] + coef[dst e] Z W'[:, H:] + P[a_e, 0:H] - P[b_e, H:2H] + b)
+// What shaped the non-MFMA part (per-phase cycle counters, scripts/mb_phase.py; knobs, scripts/mb_dbg.py):
+//   * while another wave of the SIMD streams f32 MFMAs back to back (64 cycles each, they occupy the
+//     f32 vector lanes), a wave gets roughly ONE instruction issued per MFMA -- of any kind.  What
+//     does not fit under the partner's MFMA phase (64 x NC instructions per tile) is exposed.  So
+//     the instruction count of everything else is what matters: wave-uniform values are forced
+//     into SGPRs, all global accesses are buffer instructions (SGPR descriptor rebased per tile,
+//     per-lane offsets computed once, bounds checks by the descriptor's range: no address
+//     arithmetic, no predicates, no branches), the per-edge selectors / scales are precomputed
+//     arrays (dmp_edge_select_build) prefetched like the rows instead of dependent index loads;
+//   * loads and stores retire through ONE in-order counter (vmcnt): the rows are staged before the
+//     epilogue's stores are issued, so the wait for prefetched rows never sits behind younger stores;
+//     the barrier orders LDS only (__syncthreads would drain vmcnt);
+//   * 128-bit buffer stores with an SGPR offset read their data registers late (see voffC below).
+// An experimental second driver (PP = 1, dmp_dev_set_mfma_variant) pairs two wave groups in one
+// 512-thread workgroup and forces them half an iteration apart with barriers ("ping-pong"); it wins
+// on the bare GEMM but not with the fused epilogues, and is not used by default.
+//
+//   dmp_edge_fwd_fused   H1[e] = relu(Z W'[:, :H] + coefE[e] Z W'[:, H:] + P[selA e, 0:H] - P[selB e, H:2H] + b)
 //                        = the G GEMM + dmp_edge_combine(relu) of the fused layer in one pass
 //                        (the [E,2H] product never reaches HBM)
 //   dmp_out_fwd_fused    Zn[e] = Z[e] + gate[e] (H1[e] W2^T + b2)   = Linear + dmp_gate_residual
-//   dmp_bwd_h1_fused     dG[e] = [dPre | coef[dst e] dPre], dPre = H1[e] > 0 ? dO[e] W2 : 0, + column sums of dPre
+//   dmp_bwd_h1_fused     dG[e] = [dPre | coefE[e] dPre], dPre = H1[e] > 0 ? dO[e] W2 : 0, + column sums of dPre
 //                        = Linear backward + ReLU backward + edge_combine backward in one pass
-//   dmp_bwd_z_fused      dZ[e] = base[e] + s(flag) D[dst e, half] + dPre[e] A'^T + coef[dst e] dPre[e] B'^T
+//   dmp_bwd_z_fused      dZ[e] = base[e] + s(flag) D[dst e, half] + dPre[e] A'^T + coefE[e] dPre[e] B'^T
 //                        = seg_sum2 backward (gather) + K=2H input-gradient GEMM + accumulation in one pass
 //   dmp_gemm_k128        plain C = A B (development / tests)
 #include "dmp_common.h"
 
+#ifndef DMP_DBG
+#define DMP_DBG 0
+#endif
+#ifdef DMP_DBG_STANDALONE
+namespace dmp { void set_last_hip_error(hipError_t) {} }
+#endif
+
 namespace dmp {
 namespace {
 
+#if DMP_DBG & 16
+__device__ long long g_dbg[8 * 8];  // [wave][compute, mem, barrier, steps, stage] cycles of workgroup 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kTileRows = 64;     // rows per tile: 2 sub-tiles of 32
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLdsStride = 132;
-constexpr int kThreads = 256;     // 4 waves; two such workgroups share a CU and run out of phase
-constexpr int kWaves = kThreads / 64;
 constexpr int kScrStride = 36;
-constexpr int kPreLoads = kTileRows * 32 / kThreads;  // float4 loads per thread per tile
+constexpr int kSub = 32;                                  // rows per tile / phase
+constexpr int kGroupThreads = 256;                        // 4 waves: one column slice each
+constexpr int kPPThreads = 2 * kGroupThreads;
+constexpr int kSubLoads = kSub * 32 / kGroupThreads;      // float4 loads per thread per tile (4)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence over every address
+// space: each wave would drain its outstanding global loads AND stores before the barrier.
+// Nothing is exchanged through global memory inside these kernels.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Raw buffer access: SGPR descriptor (base + byte range, out-of-range loads return 0 and stores are
+// dropped) + per-lane byte offset + SGPR byte offset.  No VALU address arithmetic.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store4(float4 v, rsrc_t r, uint32_t voff, uint32_t soff) {
+  u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
+}
+// bytes of a tile of `rows` rows with leading dimension ld (floats) of which `cols` are touched
+__device__ __forceinline__ uint32_t tile_bytes(int rows, int64_t ld, int cols) {
+  return rows > 0 ? (uint32_t)(((int64_t)(rows - 1) * ld + cols) * 4) : 0u;
+}
 
 enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2, EPI_RELU_BWD_G = 3, EPI_DZ = 4 };
 
 struct MfmaArgs {
   const float *A; int64_t lda;      // streamed operand [E,128]
-  const float *B; int64_t ldb;      // weights: B[k*ldb + j] (bt == 0) or B[j*ldb + k] (bt == 1)
+  const float *B; int64_t ldb;      // weights: B[k*ldb + j] (bt == 0) or B[j*ldb + k] (bt == 1), bt == 2 see below
   int bt;
-  float *C; int64_t ldc;            // output [E, 128] (EPI_EDGE / EPI_GATE_RES) or [E, NC*128]
+  float *C; int64_t ldc;            // output [E, 128] (EPI_EDGE / EPI_GATE_RES / EPI_DZ) or [E, NC*128]
   int64_t E;
-  // EPI_EDGE
-  const float *P; int64_t ldp;      // node projections [N, >=2H]: P[:, 0:H] (W_dst side), P[:, H:2H] (W_src side)
-  const float *coef;                // [N]
-  const int32_t *src, *dst; const uint8_t *flag;
+  // per-row (per-edge) arrays, prefetched with the rows
+  const int32_t *idxA;              // EPI_EDGE: node whose P[:, 0:H] row is added; EPI_DZ: dst node
+  const int32_t *idxB;              // EPI_EDGE: node whose P[:, H:2H] row is subtracted
+  const uint8_t *flag;              // EPI_DZ: is_reversed (selects the half of D and the sign) or NULL
+  const float *rowscale;            // EPI_EDGE / EPI_RELU_BWD_G / EPI_DZ: coef[dst e]; EPI_GATE_RES: gate or NULL (1)
+  // gathered table: EPI_EDGE P [N, ldt>=2H]; EPI_DZ D [N, ldt>=2H]
+  const float *T; int64_t ldt; int64_t num_nodes;
   const float *bias;                // [128] or NULL
-  // EPI_GATE_RES
-  const float *R; int64_t ldr;      // residual rows [E,128] or NULL (EPI_DZ: upstream gradient dZn;
-                                    // EPI_RELU_BWD_G: the saved activation H1 for the ReLU mask)
-  const float *gate;                // [E] or NULL
-  // EPI_RELU_BWD_G
-  float *partial;                   // [2*gridDim.x, 128] column-sum partials of dPre
-  // EPI_DZ: gathered term  s(flag) * D[dst, flag ? H : 0 + j]
-  const float *D; int64_t ldd; float s0, s1;
+  const float *R; int64_t ldr;      // EPI_GATE_RES: residual rows [E,128] or NULL; EPI_DZ: upstream gradient
+                                    // or NULL; EPI_RELU_BWD_G: the saved activation H1 for the ReLU mask
+  float *partial;                   // EPI_RELU_BWD_G: [2*gridDim.x, 128] column-sum partials of dPre
+  float s0, s1;                     // EPI_DZ: sign / scale of the gathered term by flag
 };
 
-template <int NC, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
-  __shared__ float As[kTileRows * kLdsStride];
-  __shared__ float Cs[kWaves * 32 * kScrStride];
-  __shared__ int rowA[kTileRows], rowB[kTileRows];
-  __shared__ float rowS[kTileRows];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-  const int cs = wave;  // this wave's 32-column slice; it computes both 32-row sub-tiles of a tile
+template <int NC, int EPI, int PP>
+__global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 ? 3 : 2)) void mfma_pp(MfmaArgs p) {
+  constexpr int NG = PP ? 2 : 1;                            // wave groups per workgroup
+  __shared__ float As[NG][kSub * kLdsStride];
+  __shared__ float Cs[4 * NG][32 * kScrStride];
+  __shared__ uint32_t rowA[NG][2][kSub], rowB[NG][2][kSub];   // [group][tile parity][row]
+  __shared__ float rowS[NG][2][kSub];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int grp = wave >> 2, cs = wave & 3, gtid = threadIdx.x & (kGroupThreads - 1);
   const int col = 32 * cs + li;
   float b[NC][64];
 #pragma unroll
@@ -81,175 +138,319 @@ __global__ __launch_bounds__(kThreads, 2) void mfma_k128(MfmaArgs p) {
               : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
                           : p.B[(int64_t)col * p.ldb + 128 * q + k];
     }
-  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
-
-  const int64_t ntiles = (p.E + kTileRows - 1) / kTileRows;
-  float4 pre[kPreLoads];
-  auto load_tile = [&](int64_t t) {
 #pragma unroll
-    for (int m = 0; m < kPreLoads; ++m) {
-      const int q = threadIdx.x + kThreads * m;
-      const int64_t row = t * kTileRows + (q >> 5);
-      pre[m] = row < p.E ? *reinterpret_cast<const float4 *>(p.A + row * p.lda + (q & 31) * 4) : make_float4(0, 0, 0, 0);
+  for (int q = 0; q < NC; ++q)
+#pragma unroll
+    for (int s = 0; s < 64; ++s) asm volatile("" ::"v"(b[q][s]));  // loads complete here, not inside the loop
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
+  float *As_g = As[grp];
+  float *scr = Cs[wave];
+
+  // per-lane constants of the wide (float4) layout: lane -> row 8k + lane/8, 4 columns from c4
+  const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
+  // Stores take a per-lane VGPR offset for every 8-row group and NO SGPR offset: a 128-bit buffer
+  // store with an SGPR offset reads its data registers late (the "store data" hazard the ISA
+  // documents for this form); next to a streaming MFMA wave that read was seen arriving after the
+  // registers had been reused, two instructions later.
+  uint32_t voffC[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) voffC[k] = ((uint32_t)(8 * k + lrow) * (uint32_t)p.ldc + (uint32_t)c4) * 4u;
+  const uint32_t voffR = ((uint32_t)lrow * (uint32_t)p.ldr + (uint32_t)c4) * 4u;
+  const uint32_t voffA = ((uint32_t)(gtid >> 5) * (uint32_t)p.lda + (uint32_t)(gtid & 31) * 4u) * 4u;
+  const uint32_t voffT = (uint32_t)c4 * 4u;
+  // SGPR byte offsets of the 8-row groups of a tile
+  const uint32_t grpA = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8 * p.lda * 4));
+  const uint32_t grpR = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8 * p.ldr * 4));
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
+  constexpr int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (EPI == EPI_RELU_BWD_G ? 256 : 128);
+
+  // whole-array descriptors: per-row arrays and the gathered table
+  const uint32_t rows4 = (uint32_t)(p.E * 4);
+  const rsrc_t rs_idxA = make_rsrc(p.idxA, p.idxA ? rows4 : 0u);
+  const rsrc_t rs_idxB = make_rsrc(p.idxB, p.idxB ? rows4 : 0u);
+  const rsrc_t rs_flag = make_rsrc(p.flag, p.flag ? (uint32_t)p.E : 0u);
+  const rsrc_t rs_scale = make_rsrc(p.rowscale, p.rowscale ? rows4 : 0u);
+  const rsrc_t rs_T = make_rsrc(p.T, p.T ? (uint32_t)(p.num_nodes * p.ldt * 4) : 0u);  // < 4 GiB (checked by the host)
+
+  // tile indices are 32-bit and wave-uniform (SGPRs)
+  const int ntiles = (int)((p.E + kSub - 1) / kSub);
+  const int stride = (int)gridDim.x * NG;
+  const int first = (int)blockIdx.x * NG;
+  const int niter = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // group 0's tile count (>= group 1's)
+  auto tile_rows = [&](int t) {                            // valid rows of tile t (0 past the end), scalar
+    const int64_t left = p.E - (int64_t)t * kSub;
+    return (int)(left < 0 ? 0 : (left > kSub ? kSub : left));
+  };
+
+  float4 pre[kSubLoads];
+  uint32_t pre_a = 0, pre_b = 0;
+  float pre_s = 0.f;
+  auto load_rows = [&](int t) {                           // global -> registers: rows + per-row scalars of tile t
+    const rsrc_t ra = make_rsrc(p.A + (int64_t)t * kSub * p.lda, tile_bytes(tile_rows(t), p.lda, 128));
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      if (!(DMP_DBG & 4) || t < 2 * (int)gridDim.x) pre[m] = buf_load4(ra, voffA, m * grpA);
+    if (EPI != EPI_NONE && gtid < kSub) {
+      const uint32_t so = (uint32_t)t * (kSub * 4u);      // E * 4 < 2^32 (checked by the host)
+      if (EPI == EPI_EDGE || EPI == EPI_DZ) pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, gtid * 4, (int)so, 0);
+      if (EPI == EPI_EDGE) pre_b = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, gtid * 4, (int)so, 0);
+      if (EPI == EPI_DZ) pre_b = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, gtid, (int)(so >> 2), 0);
+      pre_s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_scale, gtid * 4, (int)so, 0));
     }
   };
-  int64_t t = blockIdx.x;
-  if (t < ntiles) load_tile(t);
-  for (; t < ntiles; t += gridDim.x) {
-    __syncthreads();  // previous tile: LDS reads done
+  auto stage = [&](int par) {                             // registers -> LDS
 #pragma unroll
-    for (int m = 0; m < kPreLoads; ++m) {
-      const int q = threadIdx.x + kThreads * m;
-      *reinterpret_cast<float4 *>(&As[(q >> 5) * kLdsStride + (q & 31) * 4]) = pre[m];
-    }
-    if (EPI == EPI_EDGE && threadIdx.x < kTileRows) {
-      const int64_t e = t * kTileRows + threadIdx.x;
-      int a = 0, bb = 0;
-      float cf = 0.f;
-      if (e < p.E) {
-        const int u = p.src[e], v = p.dst[e];
-        const bool f = p.flag && p.flag[e];
-        a = f ? u : v;
-        bb = f ? v : u;
-        cf = p.coef[v];
+    for (int m = 0; m < kSubLoads; ++m)
+      if (!(DMP_DBG & 8) || pre[m].x == 123.456f)
+      *reinterpret_cast<float4 *>(&As_g[((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+    if (EPI != EPI_NONE && gtid < kSub) {
+      uint32_t a = 0, bb = 0;
+      if (EPI == EPI_EDGE) {                              // byte offsets of the two gathered P rows
+        a = pre_a * (uint32_t)(p.ldt * 4);
+        bb = pre_b * (uint32_t)(p.ldt * 4) + 512u;
+      } else if (EPI == EPI_DZ) {
+        bb = pre_b;
+        a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? 512u : 0u);
       }
-      rowA[threadIdx.x] = a; rowB[threadIdx.x] = bb; rowS[threadIdx.x] = cf;
+      rowA[grp][par][gtid] = a; rowB[grp][par][gtid] = bb;
+      rowS[grp][par][gtid] = (EPI == EPI_GATE_RES && !p.rowscale) ? 1.f : pre_s;
     }
-    if (EPI == EPI_GATE_RES && threadIdx.x < kTileRows) {
-      const int64_t e = t * kTileRows + threadIdx.x;
-      rowS[threadIdx.x] = (p.gate && e < p.E) ? p.gate[e] : 1.f;
-    }
-    if (EPI == EPI_RELU_BWD_G && threadIdx.x < kTileRows) {
-      const int64_t e = t * kTileRows + threadIdx.x;
-      rowS[threadIdx.x] = e < p.E ? p.coef[p.dst[e]] : 0.f;
-    }
-    if (EPI == EPI_DZ && threadIdx.x < kTileRows) {
-      const int64_t e = t * kTileRows + threadIdx.x;
-      int v = 0, f = 0;
-      float cf = 0.f;
-      if (e < p.E) { v = p.dst[e]; f = (p.flag && p.flag[e]) ? 1 : 0; cf = p.coef[v]; }
-      rowA[threadIdx.x] = v; rowB[threadIdx.x] = f; rowS[threadIdx.x] = cf;
-    }
-    __syncthreads();
-    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // next tile in flight under the MFMAs
-#pragma unroll 1
-    for (int sub = 0; sub < kTileRows / 32; ++sub) {
-      const int64_t tile_row = t * kTileRows + 32 * sub;
-      f32x16 acc[NC];
+  };
+
+  f32x16 acc[NC];
+  float4 g0[4], g1[4];
+  auto fetch_operands = [&](int t, int par) {             // epilogue operands of tile t, in store layout
+    const rsrc_t rr_ = make_rsrc(p.R ? p.R + (int64_t)t * kSub * p.ldr : nullptr,
+                                 p.R ? tile_bytes(tile_rows(t), p.ldr, 128) : 0u);
 #pragma unroll
-      for (int q = 0; q < NC; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-      const float *arow = &As[(32 * sub + li) * kLdsStride + 64 * h];
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * s4);
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][4 * s4 + 0], acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][4 * s4 + 1], acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][4 * s4 + 2], acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][4 * s4 + 3], acc[q], 0, 0, 0);
-        }
-      }
-      float *scr = &Cs[wave * 32 * kScrStride];
-      constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
-      // Row-gathered / row-streamed epilogue operands, fetched as float4 in the layout of the wide
-      // store phase (lane -> row 8k + lane/8, 4 consecutive columns); all loads are issued before
-      // the accumulators take their trip through the LDS scratch, so their latency overlaps it.
-      float4 g0[4], g1[4];
-      auto fetch_epilogue_operands = [&]() {
-      if (EPI == EPI_EDGE || EPI == EPI_DZ || EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rr = 8 * k + (lane >> 3), c4 = 32 * cs + (lane & 7) * 4;
-          const int rl = 32 * sub + rr;
-          const int64_t row = tile_row + rr;
-          g0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          g1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row < p.E) {
-            if (EPI == EPI_EDGE) {
-              g0[k] = *reinterpret_cast<const float4 *>(p.P + (int64_t)rowA[rl] * p.ldp + c4);
-              g1[k] = *reinterpret_cast<const float4 *>(p.P + (int64_t)rowB[rl] * p.ldp + 128 + c4);
-            } else if (EPI == EPI_DZ) {
-              g0[k] = *reinterpret_cast<const float4 *>(p.D + (int64_t)rowA[rl] * p.ldd + (rowB[rl] ? 128 : 0) + c4);
-              if (p.R) g1[k] = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + c4);
-            } else if (p.R) {  // EPI_GATE_RES: residual rows; EPI_RELU_BWD_G: saved activation
-              g0[k] = *reinterpret_cast<const float4 *>(p.R + row * p.ldr + c4);
-            }
-          }
-        }
-      }
-      };
-      // NC = 2: the accumulators fill the register file, so the operands are requested after the
-      // accumulators have been parked in the scratch; NC = 1: before, overlapping the round trip
-      if (NC == 1) fetch_epilogue_operands();
-#pragma unroll
-      for (int q = 0; q < NOUT; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = acc[q][r];
-          if (EPI == EPI_EDGE || EPI == EPI_DZ) v = v + rowS[32 * sub + rr] * acc[NC - 1][r];
-          scr[rr * kScrStride + li] = v;
-        }
-        if (NC != 1) fetch_epilogue_operands();
-        // written and read by the same wave: LDS operations of one wave complete in order
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rr = 8 * k + (lane >> 3), c4 = (lane & 7) * 4;
-          float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + c4]);
-          const int64_t row = tile_row + rr;
-          if (row < p.E) {
-            if (EPI == EPI_EDGE) {
-              // ((G0 + coef G1) + (P[a] - P[b])) + bias, then ReLU: the reference's order (dmpnn.py:147-152)
-              const float4 bi = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 32 * cs + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-              v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bi.x, 0.f);
-              v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bi.y, 0.f);
-              v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bi.z, 0.f);
-              v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bi.w, 0.f);
-            } else if (EPI == EPI_DZ) {
-              const float sg = rowB[32 * sub + rr] ? p.s1 : p.s0;
-              v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
-              v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
-            } else if (EPI == EPI_GATE_RES) {
-              const float gt = rowS[32 * sub + rr];
-              const float4 bi = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 32 * cs + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-              v.x = (v.x + bi.x) * gt + g0[k].x; v.y = (v.y + bi.y) * gt + g0[k].y;
-              v.z = (v.z + bi.z) * gt + g0[k].z; v.w = (v.w + bi.w) * gt + g0[k].w;
-            } else if (EPI == EPI_RELU_BWD_G) {
-              // dPre = H1 > 0 ? dH1 : 0;  dG = [dPre | coef[dst] dPre];  column sums of dPre
-              v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
-              v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
-              colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
-              const float cf = rowS[32 * sub + rr];
-              *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 + 32 * cs + c4) =
-                  make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf);
-            }
-            *reinterpret_cast<float4 *>(p.C + row * p.ldc + 128 * q + 32 * cs + c4) = v;
-          }
-        }
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 8 * k + lrow;
+      if (EPI == EPI_EDGE) {
+        g0[k] = buf_load4(rs_T, rowA[grp][par][rr] + voffT, 0);
+        g1[k] = buf_load4(rs_T, rowB[grp][par][rr] + voffT, 0);
+      } else if (EPI == EPI_DZ) {
+        g0[k] = buf_load4(rs_T, rowA[grp][par][rr] + voffT, 0);
+        g1[k] = buf_load4(rr_, voffR, k * grpR);
+      } else if (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G) {
+        g0[k] = buf_load4(rr_, voffR, k * grpR);
       }
     }
+  };
+  auto compute = [&]() {                                  // MFMA phase: 64 k-steps x NC panels on As_g
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const float *arow = &As_g[li * kLdsStride + 64 * h];
+    // the A operands of k-steps 4(s4+1).. are requested BEFORE the MFMAs of k-steps 4 s4.. issue
+    float4 a4 = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      float4 an = a4;
+      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][4 * s4 + 0], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][4 * s4 + 1], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][4 * s4 + 2], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][4 * s4 + 3], acc[q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+    }
+  };
+  // NC = 1: the epilogue operands are requested before the MFMA phase (registers to spare);
+  // NC = 2: after the accumulators have been parked in the scratch -- the other group's MFMA
+  // phase covers their latency
+  constexpr bool kEarly = (NC == 1);
+#if DMP_DBG & 64
+  long long c_e1 = 0, c_e2 = 0;
+#endif
+  auto epilogue = [&](int t, int par) {                   // transpose through LDS, combine, store
+    constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
+#if DMP_DBG & 64
+    const long long c_e0 = clock64();
+#endif
+    const rsrc_t rc = make_rsrc(p.C + (int64_t)t * kSub * p.ldc, tile_bytes(tile_rows(t), p.ldc, kOutCols));
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[q][r];
+        if (EPI == EPI_EDGE || EPI == EPI_DZ) v = v + rowS[grp][par][rr] * acc[NC - 1][r];
+        if (!(DMP_DBG & 2)) scr[rr * kScrStride + li] = v;
+      }
+#if DMP_DBG & 64
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      c_e1 += clock64() - c_e0;
+#endif
+      if (EPI != EPI_NONE && !kEarly) fetch_operands(t, par);
+      // written and read by the same wave: LDS operations of one wave complete in order
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = 8 * k + lrow;
+        float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
+        if (DMP_DBG & 2) v = make_float4(acc[q][4 * k], acc[q][4 * k + 1], acc[q][4 * k + 2], acc[q][4 * k + 3]);
+        if (EPI == EPI_EDGE) {
+          // ((G0 + coef G1) + (P[a] - P[b])) + bias, then ReLU: the reference's order (dmpnn.py:147-152)
+          v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bias4.x, 0.f);
+          v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bias4.y, 0.f);
+          v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bias4.z, 0.f);
+          v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bias4.w, 0.f);
+        } else if (EPI == EPI_DZ) {
+          const float sg = rowB[grp][par][rr] ? p.s1 : p.s0;
+          v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
+          v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
+        } else if (EPI == EPI_GATE_RES) {
+          const float gt = rowS[grp][par][rr];
+          v.x = (v.x + bias4.x) * gt + g0[k].x; v.y = (v.y + bias4.y) * gt + g0[k].y;
+          v.z = (v.z + bias4.z) * gt + g0[k].z; v.w = (v.w + bias4.w) * gt + g0[k].w;
+        } else if (EPI == EPI_RELU_BWD_G) {
+          // dPre = H1 > 0 ? dH1 : 0;  dG = [dPre | coef[dst] dPre];  column sums of dPre
+          // (rows past the end: H1 reads as 0 -> dPre = 0, nothing stored)
+          v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
+          v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
+          colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+          const float cf = rowS[grp][par][rr];
+          buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + 512u, 0);
+        }
+        buf_store4(v, rc, voffC[k] + 512u * q, 0);
+      }
+    }
+#if DMP_DBG & 64
+    c_e2 += clock64() - c_e0;
+#endif
+  };
+
+  const int t0 = first + grp;
+  const int mine = t0 < ntiles ? (ntiles - t0 + stride - 1) / stride : 0;
+  auto tile = [&](int k) { return __builtin_amdgcn_readfirstlane(t0 + k * stride); };
+  if (!PP) {
+    // Independent 256-thread workgroups (2-3 resident per CU, not synchronised with each other).
+    // Per tile k:  MFMA phase | barrier | stage k+1, prefetch k+2 | barrier | epilogue k.
+    // The wait for the prefetched rows in `stage` only has YOUNGER traffic behind it (the previous
+    // epilogue's stores, the early operand loads), which the in-order counter lets it skip.
+    load_rows(tile(0));
+    stage(0);
+    load_rows(tile(1));
+    lds_barrier();
+    for (int k = 0; k < mine; ++k) {
+      const int par = k & 1;
+      if (EPI != EPI_NONE && kEarly) fetch_operands(tile(k), par);
+      compute();
+      lds_barrier();               // every wave is done reading this tile's rows
+      stage(par ^ 1);
+      load_rows(tile(k + 2));
+      lds_barrier();               // tile k+1 is in LDS for everyone
+      epilogue(tile(k), par);
+    }
+  } else {
+    // Both groups run the SAME step sequence, one step apart: in step s a group does its memory phase
+    // when (s + grp) is even (staging of its next tile, epilogue of the tile it computed last, prefetch
+    // of the tile after) and its MFMA phase when (s + grp) is odd.  Tile k of a group: first + grp + k*stride;
+    // tiles past the end are all-zero / dropped by the buffer range checks.
+    int staged = 0, computed = 0, stored = 0;
+    load_rows(tile(0));
+  #if DMP_DBG & 16
+    long long c_comp = 0, c_mem = 0, c_bar = 0, c_stage = 0;
+  #endif
+    for (int s = 0; s < 2 * niter + 2; ++s) {
+  #if DMP_DBG & 16
+      const long long c0 = clock64();
+  #endif
+      if (((s + grp) & 1) == 0) {
+        // Staging first, the next prefetch last (one in-order vmcnt, see the header); unconditional,
+        // on one straight-line path, so that the compiler sees the prefetch registers as free and does
+        // not drain the epilogue's stores before reusing them.
+        stage(staged & 1);
+        ++staged;
+  #if DMP_DBG & 16
+        c_stage += clock64() - c0;
+  #endif
+        if (stored < computed) {
+          epilogue(tile(stored), stored & 1);
+          ++stored;
+        }
+        load_rows(tile(staged));
+  #if DMP_DBG & 16
+        c_mem += clock64() - c0;
+  #endif
+      } else if (computed < staged && computed < mine) {
+        if (EPI != EPI_NONE && kEarly) fetch_operands(tile(computed), computed & 1);
+        compute();
+        ++computed;
+  #if DMP_DBG & 16
+        asm volatile("s_nop 0" ::"v"(acc[0][0]));
+        c_comp += clock64() - c0;
+  #endif
+      }
+  #if DMP_DBG & 16
+      const long long c1 = clock64();
+  #endif
+      lds_barrier();
+  #if DMP_DBG & 16
+      c_bar += clock64() - c1;
+  #endif
+    }
+  #if DMP_DBG & 16
+    if (blockIdx.x == 0 && lane == 0) {
+      g_dbg[wave * 8 + 0] = c_comp; g_dbg[wave * 8 + 1] = c_mem; g_dbg[wave * 8 + 2] = c_bar;
+      g_dbg[wave * 8 + 3] = 2 * niter + 2; g_dbg[wave * 8 + 4] = c_stage;
+  #if DMP_DBG & 64
+      g_dbg[wave * 8 + 5] = c_e1; g_dbg[wave * 8 + 6] = c_e2;
+  #endif
+    }
+  #endif
+
   }
+
   if (EPI == EPI_RELU_BWD_G) {
-    // PARTIALS: lanes with equal (lane & 7) hold the same 4 columns for 8 different rows: fixed-order
-    // xor-shuffle tree over lane>>3, then one partial row per (workgroup, row half)
+    // lanes with equal (lane & 7) hold the same 4 columns for 8 different rows: fixed-order
+    // xor-shuffle tree over lane>>3, then one partial row per (workgroup, group)
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
       colsum.x += __shfl_xor(colsum.x, off, 64); colsum.y += __shfl_xor(colsum.y, off, 64);
       colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
     }
     if (lane < 8)
-      *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * 128 + 32 * cs + lane * 4) = colsum;
+      *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * NG + grp) * 128 + 32 * cs + lane * 4) = colsum;
   }
 }
 
-// (the column-sum write-out of EPI_RELU_BWD_G lives at the end of mfma_k128, see PARTIALS below)
-inline unsigned grid_blocks(int64_t E, int per_cu = 2) {
-  const int64_t ntiles = (E + kTileRows - 1) / kTileRows;
-  const int64_t cap = 256 * per_cu;  // resident workgroups: 2 per CU (NC = 2: 256 VGPRs), 3 for NC = 1
+inline unsigned pp_blocks(int64_t E) {
+  const int64_t pairs = ((E + kSub - 1) / kSub + 1) / 2;
+  return (unsigned)(pairs < 256 ? (pairs > 0 ? pairs : 1) : 256);
+}
+
+int g_variant = 0;  // development switch: 0 = independent workgroups, 1 = ping-pong pairs
+
+inline unsigned wg_blocks(int64_t E, int per_cu) {
+  const int64_t ntiles = (E + kSub - 1) / kSub, cap = 256 * per_cu;
   return (unsigned)(ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap);
+}
+
+template <int NC, int EPI>
+inline int launch_mfma(const MfmaArgs &p, hipStream_t st) {
+  if (g_variant == 1) mfma_pp<NC, EPI, 1><<<pp_blocks(p.E), kPPThreads, 0, st>>>(p);
+  else mfma_pp<NC, EPI, 0><<<wg_blocks(p.E, NC == 1 ? 3 : 2), kGroupThreads, 0, st>>>(p);
+  return check_launch();
+}
+
+// 32-bit byte offsets inside the kernel
+inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32); }
+
+__global__ void edge_select_k(const int32_t *src, const int32_t *dst, const uint8_t *flag, const float *coef,
+                              int64_t E, int32_t *selA, int32_t *selB, float *coefE) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int u = src[e], v = dst[e];
+  const bool f = flag && flag[e];
+  selA[e] = f ? u : v;
+  selB[e] = f ? v : u;
+  coefE[e] = coef[v];
 }
 
 }  // namespace
@@ -259,32 +460,43 @@ using namespace dmp;
 
 extern "C" {
 
+int dmp_edge_select_build(const int32_t *src, const int32_t *dst, const uint8_t *flag, const float *coef,
+                          int64_t E, int32_t *selA, int32_t *selB, float *coefE, void *stream) {
+  if (E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!src || !dst || !coef || !selA || !selB || !coefE) return DMP_ERR_BAD_ARG;
+  edge_select_k<<<(unsigned)((E + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(src, dst, flag, coef, E, selA,
+                                                                                         selB, coefE);
+  return check_launch();
+}
+
 int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed, float *C,
                   int64_t ldc, int64_t E, int ncols, void *stream) {
   if (E < 0 || lda < 128 || ldc < ncols || (ncols != 128 && ncols != 256)) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
   if (!A || !B || !C || lda % 4 || ldc % 4 || !aligned16(A) || !aligned16(C)) return DMP_ERR_BAD_ARG;
+  if (!fits32(kSub, lda) || !fits32(kSub, ldc)) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bt = b_transposed; p.C = C; p.ldc = ldc; p.E = E;
+  p.ldr = 128; p.ldt = 256;
   hipStream_t st = (hipStream_t)stream;
-  if (ncols == 128) mfma_k128<1, EPI_NONE><<<grid_blocks(E, 3), kThreads, 0, st>>>(p);
-  else mfma_k128<2, EPI_NONE><<<grid_blocks(E), kThreads, 0, st>>>(p);
-  return check_launch();
+  return ncols == 128 ? launch_mfma<1, EPI_NONE>(p, st) : launch_mfma<2, EPI_NONE>(p, st);
 }
 
 int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
-                       const float *coef, const float *bias, const int32_t *src, const int32_t *dst,
-                       const uint8_t *flag, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
-  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+                       int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
+                       const float *coefE, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
+  if (E < 0 || num_nodes < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
-  if (!Z || !W || !P || !coef || !src || !dst || !H1 || ldz < H || ldw < 2 * H || ldp < 2 * H || ldh < H)
+  if (!Z || !W || !P || !selA || !selB || !coefE || !H1 || ldz < H || ldw < 2 * H || ldp < 2 * H || ldh < H)
     return DMP_ERR_BAD_ARG;
-  if (ldz % 4 || ldh % 4 || !aligned16(Z) || !aligned16(H1)) return DMP_ERR_UNSUPPORTED;
+  if (ldz % 4 || ldh % 4 || ldp % 4 || !aligned16(Z) || !aligned16(H1) || !aligned16(P) || (bias && !aligned16(bias)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(num_nodes, ldp) || !fits32(E, 1) || !fits32(kSub, ldz) || !fits32(kSub, ldh)) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
-  p.A = Z; p.lda = ldz; p.B = W; p.ldb = ldw; p.bt = 0; p.C = H1; p.ldc = ldh; p.E = E;
-  p.P = P; p.ldp = ldp; p.coef = coef; p.src = src; p.dst = dst; p.flag = flag; p.bias = bias;
-  mfma_k128<2, EPI_EDGE><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
+  p.A = Z; p.lda = ldz; p.B = W; p.ldb = ldw; p.bt = 0; p.C = H1; p.ldc = ldh; p.E = E; p.ldr = 128;
+  p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.idxA = selA; p.idxB = selB; p.rowscale = coefE; p.bias = bias;
+  return launch_mfma<2, EPI_EDGE>(p, (hipStream_t)stream);
 }
 
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
@@ -293,48 +505,58 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Hin || !W2 || !out || ldh < H || ldw < H || ldo < H || (R && ldr < H)) return DMP_ERR_BAD_ARG;
-  if (ldh % 4 || ldo % 4 || (R && ldr % 4) || !aligned16(Hin) || !aligned16(out) || (R && !aligned16(R)))
+  if (ldh % 4 || ldo % 4 || (R && ldr % 4) || !aligned16(Hin) || !aligned16(out) || (R && !aligned16(R)) ||
+      (bias && !aligned16(bias)))
     return DMP_ERR_UNSUPPORTED;
+  if (!fits32(E, 1) || !fits32(kSub, ldh) || !fits32(kSub, ldo) || (R && !fits32(kSub, ldr))) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw; p.bt = 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]
-  p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.gate = gate; p.R = R; p.ldr = ldr;
-  mfma_k128<1, EPI_GATE_RES><<<grid_blocks(E, 2), kThreads, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
+  p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : 128; p.ldt = 256;
+  return launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
-int64_t dmp_mfma_partial_rows(int64_t E) { return (int64_t)grid_blocks(E, 3); }
+int64_t dmp_mfma_partial_rows(int64_t E) { return g_variant == 1 ? 2 * (int64_t)pp_blocks(E) : (int64_t)wg_blocks(E, 3); }
+
+void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
 
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                     const float *coef, const int32_t *dst, int64_t E, int H, float *dG, int64_t ldg,
-                     float *partial, void *stream) {
+                     const float *coefE, int64_t E, int H, float *dG, int64_t ldg, float *partial, void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (!partial) return DMP_ERR_BAD_ARG;
-  if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
-  if (!dO || !W2 || !H1 || !coef || !dst || !dG || ldo < H || ldw < H || ldh < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
+  if (E == 0)
+    return hipMemsetAsync(partial, 0, sizeof(float) * 128 * (size_t)dmp_mfma_partial_rows(0), (hipStream_t)stream) == hipSuccess
+               ? DMP_OK : DMP_ERR_HIP;
+  if (!dO || !W2 || !H1 || !coefE || !dG || ldo < H || ldw < H || ldh < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
   if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
     return DMP_ERR_UNSUPPORTED;
+  if (!fits32(E, 1) || !fits32(kSub, ldo) || !fits32(kSub, ldh) || !fits32(kSub, ldg)) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
-  p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.coef = coef; p.dst = dst; p.partial = partial;
-  mfma_k128<1, EPI_RELU_BWD_G><<<grid_blocks(E, 3), kThreads, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
+  p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = coefE; p.partial = partial; p.ldt = 256;
+  return launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 
 int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
-                    const float *base, int64_t ldb, const float *coef, const int32_t *dst, const uint8_t *flag,
-                    float s0, float s1, int64_t E, int H, float *dZ, int64_t ldz, void *stream) {
-  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+                    int64_t num_nodes, const float *base, int64_t ldb, const float *coefE, const int32_t *dst,
+                    const uint8_t *flag, float s0, float s1, int64_t E, int H, float *dZ, int64_t ldz, void *stream) {
+  if (E < 0 || num_nodes < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
-  if (!dPre || !W || !D || !coef || !dst || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H || ldz < H || (base && ldb < H))
+  if (!dPre || !W || !D || !coefE || !dst || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H || ldz < H || (base && ldb < H))
     return DMP_ERR_BAD_ARG;
-  if (ldp % 4 || ldz % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(dZ) || (base && !aligned16(base)))
+  if (ldp % 4 || ldz % 4 || ldd % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(dZ) || !aligned16(D) ||
+      (base && !aligned16(base)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(num_nodes, ldd) || !fits32(E, 1) || !fits32(kSub, ldp) || !fits32(kSub, ldz) || (base && !fits32(kSub, ldb)))
     return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = dPre; p.lda = ldp; p.B = W; p.ldb = ldw; p.bt = 2;  // panels = K-slices of W'^T
-  p.C = dZ; p.ldc = ldz; p.E = E; p.R = base; p.ldr = ldb; p.coef = coef; p.dst = dst; p.flag = flag;
-  p.D = D; p.ldd = ldd; p.s0 = s0; p.s1 = s1;
-  mfma_k128<2, EPI_DZ><<<grid_blocks(E), kThreads, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
+  p.C = dZ; p.ldc = ldz; p.E = E; p.R = base; p.ldr = base ? ldb : 128; p.rowscale = coefE; p.idxA = dst; p.flag = flag;
+  p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.s0 = s0; p.s1 = s1;
+  return launch_mfma<2, EPI_DZ>(p, (hipStream_t)stream);
 }
+
+#if DMP_DBG & 16
+void dmp_dev_read_dbg(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
+#endif
 
 }  // extern "C"

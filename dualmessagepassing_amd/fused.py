@@ -139,16 +139,23 @@ def relu_bwd_g_colsum(d_h, act, coef, dst32):
 USE_MFMA_KERNELS = True  # H == 128: fused MFMA kernels for the edge chain (csrc/dmp_mfma.hip)
 
 
+def mfma_ok(index, H):
+    """The fused MFMA kernels take H = 128 and address the gathered tables / per-edge arrays with
+    32-bit byte offsets: [N, 3H] fp32 projections and E-float arrays must stay below 4 GiB."""
+    return USE_MFMA_KERNELS and H == 128 and index.num_nodes * 3 * H * 4 < 2 ** 32 and index.num_edges * 4 < 2 ** 32
+
+
 def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
     """relu(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128)."""
     lib = _lib.load()
     E, H = z.shape
     out = torch.empty((E, H), dtype=torch.float32, device=z.device)
     Wes = Wes.contiguous()
-    with _lib.timed("edge_fwd_mfma[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 9 * E):
-        check(lib.dmp_edge_fwd_fused(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, ptr(coef), ptr(bias),
-                                     ptr(index.src32), ptr(index.dst32), ptr(index.rev8), E, H, ptr(out), H,
-                                     stream_ptr()), "dmp_edge_fwd_fused")
+    sel_a, sel_b, coef_e = index.edge_select(coef)
+    with _lib.timed("edge_fwd_mfma[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
+        check(lib.dmp_edge_fwd_fused(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
+                                     ptr(sel_a), ptr(sel_b), ptr(coef_e), E, H, ptr(out), H, stream_ptr()),
+              "dmp_edge_fwd_fused")
     return out
 
 
@@ -164,7 +171,7 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef, dst32):
+def bwd_h1_mfma(d_o, W2, h1, coef, index):
     """-> (dG = [dPre | coef[dst] dPre] with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128."""
     lib = _lib.load()
     E, H = d_o.shape
@@ -172,7 +179,7 @@ def bwd_h1_mfma(d_o, W2, h1, coef, dst32):
     part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), 16 * H * E + 4 * E):
-        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(coef), ptr(dst32), E, H,
+        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]), E, H,
                                    ptr(d_g), 2 * H, ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
 
@@ -185,9 +192,9 @@ def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
     Wes = Wes.contiguous()
     d_s = d_s.contiguous()
     with _lib.timed("bwd_z_mfma[H=%d,E=%d]" % (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
-        check(lib.dmp_bwd_z_fused(ptr(d_g), 2 * H, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), ptr(base), H,
-                                  ptr(coef), ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, E, H, ptr(out), H,
-                                  stream_ptr()), "dmp_bwd_z_fused")
+        check(lib.dmp_bwd_z_fused(ptr(d_g), 2 * H, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
+                                  ptr(base), H, ptr(index.edge_select(coef)[2]), ptr(index.dst32), ptr(index.rev8),
+                                  -1.0, 1.0, E, H, ptr(out), H, stream_ptr()), "dmp_bwd_z_fused")
     return out
 
 
@@ -219,7 +226,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         On = torch.addmm(nb2, H1n, nW2.t())
         xn = gate_residual(x if residual else None, On, v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        if USE_MFMA_KERNELS and H == 128:
+        if mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index)
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
         else:
@@ -243,9 +250,9 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- edge side, down to the gathered node projections
         dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
         dW2e = atb(dOe, H1e)
-        mfma = USE_MFMA_KERNELS and H == 128
+        mfma = mfma_ok(ix, H)
         if mfma:
-            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix.dst32)         # dG[:, :H] is dPre
+            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix)         # dG[:, :H] is dPre
         else:
             dH1e = dOe @ eW2
             dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)

@@ -108,6 +108,23 @@ class GraphIndex:
             self._coef = {key: c}
         return c
 
+    def edge_select(self, coef):
+        """Per-edge selectors of the fused edge chain (``dmp_edge_select_build``): ``(selA, selB, coefE)``
+        with selA = is_reversed ? src : dst, selB = the other endpoint, coefE = coef[dst]; cached per
+        coefficient tensor (they depend only on the structure and the degrees)."""
+        key = (coef.data_ptr(), coef._version)
+        cached = getattr(self, "_esel", None)
+        if cached is None or cached[0] != key:
+            lib = _lib.load()
+            E = self.num_edges
+            sel_a = torch.empty(E, dtype=torch.int32, device=self.device)
+            sel_b = torch.empty(E, dtype=torch.int32, device=self.device)
+            coef_e = torch.empty(E, dtype=torch.float32, device=self.device)
+            check(lib.dmp_edge_select_build(ptr(self.src32), ptr(self.dst32), ptr(self.rev8), ptr(coef), E, ptr(sel_a),
+                                            ptr(sel_b), ptr(coef_e), stream_ptr()), "dmp_edge_select_build")
+            self._esel = cached = (key, (sel_a, sel_b, coef_e), coef)
+        return cached[1]
+
 
 class _Gather:
     """``edges.src`` / ``edges.dst`` views handed to message UDFs."""

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 7
+#define DMP_ABI_VERSION 8
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -372,16 +372,27 @@ int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out,
 /* ------------------------------------------------------------------------- */
 
 /*
+ * Per-edge selectors of the edge chain, built once per batched graph (they depend only on the
+ * structure and the degrees; dmpnn.py:111-124,144-146):
+ *     selA[e] = flag[e] ? src[e] : dst[e]     (node whose W_dst-side projection is added)
+ *     selB[e] = flag[e] ? dst[e] : src[e]     (node whose W_src-side projection is subtracted)
+ *     coefE[e] = coef[dst[e]]                 (coef = dmp_degree_coef)
+ */
+int dmp_edge_select_build(const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                          const float *coef, int64_t num_edges, int32_t *selA, int32_t *selB,
+                          float *coefE, void *stream);
+
+/*
  * The E-row projection of the layer and dmp_edge_combine(relu) in one pass
  * (dmpnn.py:112,120,124,142-152 with the first Linear of emlp folded in, see fused.py):
- *     H1[e] = relu( Z[e] W[:, 0:H] + coef[dst e] * Z[e] W[:, H:2H] + b
- *                   + (flag[e] ? P[src e,0:H] - P[dst e,H:2H] : P[dst e,0:H] - P[src e,H:2H]) )
- *   Z [E, ldz>=H], W [H, ldw>=2H] row-major ([in, out] layout), P [N, ldp>=2H], H1 [E, ldh>=H].
- * The [E,2H] product never reaches HBM.  Returns DMP_ERR_UNSUPPORTED unless H == 128.
+ *     H1[e] = relu( Z[e] W[:, 0:H] + coefE[e] * Z[e] W[:, H:2H] + b + P[selA e, 0:H] - P[selB e, H:2H] )
+ *   Z [E, ldz>=H], W [H, ldw>=2H] row-major ([in, out] layout), P [num_nodes, ldp>=2H], H1 [E, ldh>=H].
+ * The [E,2H] product never reaches HBM.  Returns DMP_ERR_UNSUPPORTED unless H == 128, or when
+ * num_nodes*ldp*4 or E*4 do not fit 32 bits (the kernels address tables with 32-bit byte offsets).
  */
 int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
-                       const float *P, int64_t ldp, const float *coef, const float *bias,
-                       const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                       const float *P, int64_t ldp, int64_t num_nodes, const float *bias,
+                       const int32_t *selA, const int32_t *selB, const float *coefE,
                        int64_t num_edges, int H, float *H1, int64_t ldh, void *stream);
 
 /*
@@ -395,26 +406,25 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
 
 /*
  * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
- *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coef[dst e] * dPre[e]]
- *     partial = column sums of dPre per (workgroup, row half): dmp_mfma_partial_rows(E) rows of H floats
+ *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
+ *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
  *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
  */
 int64_t dmp_mfma_partial_rows(int64_t num_edges);
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
-                     const float *H1, int64_t ldh, const float *coef, const int32_t *dst,
-                     int64_t num_edges, int H, float *dG, int64_t ldg, float *partial,
-                     void *stream);
+                     const float *H1, int64_t ldh, const float *coefE, int64_t num_edges, int H,
+                     float *dG, int64_t ldg, float *partial, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
  *     dZ[e] = base[e] + s(flag e) * D[dst e, (flag e ? H : 0) + :] + dPre[e] W[:, 0:H]^T
- *             + coef[dst e] * dPre[e] W[:, H:2H]^T
+ *             + coefE[e] * dPre[e] W[:, H:2H]^T
  *   dPre [E, ldp>=H] (e.g. the first half of dG, ldp = 2H), W [H, ldw>=2H] the forward weight panel,
- *   D [N, ldd>=2H] the gradient of dmp_seg_sum2's output, base [E, ldb] or NULL, s(0)=s0, s(1)=s1.
+ *   D [num_nodes, ldd>=2H] the gradient of dmp_seg_sum2's output, base [E, ldb] or NULL, s(0)=s0, s(1)=s1.
  */
 int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
-                    const float *D, int64_t ldd, const float *base, int64_t ldb,
-                    const float *coef, const int32_t *dst, const uint8_t *flag, float s0,
+                    const float *D, int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
+                    const float *coefE, const int32_t *dst, const uint8_t *flag, float s0,
                     float s1, int64_t num_edges, int H, float *dZ, int64_t ldz, void *stream);
 
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):

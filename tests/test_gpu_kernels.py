@@ -310,7 +310,7 @@ def test_mfma_backward_kernels_h128(rows, gpu):
     d_o = th.randn(rows, h, generator=gen).to(gpu)
     h1 = th.randn(rows, h, generator=gen).clamp_min(0).to(gpu)
     w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
-    d_g, cs = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix.dst32)
+    d_g, cs = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix)
     td = _t(dst).to(gpu)
     dpre = th.where(h1 > 0, (d_o.double() @ w2.double()), th.zeros(1, dtype=th.float64, device=gpu))
     ref = th.cat([dpre, dpre * coef.double()[td][:, None]], 1)
@@ -333,3 +333,41 @@ def test_mfma_backward_kernels_h128(rows, gpu):
         two = ops.gather_select_raw(d_s, ix.dst32, ix.rev8, h, None, -1.0, 1.0, base=b_)
         two.addmm_(d_g, wes.t())
         assert th.allclose(got, two, rtol=1e-5, atol=3e-4)
+
+
+def test_mfma_kernels_are_repeatable_under_load(gpu):
+    """The fused MFMA kernels at a multi-tile size, 12 back-to-back launches each: every launch must
+    reproduce the first one bit for bit and match the fp64 formula (catches register / LDS hazards
+    that only show when several workgroups share a SIMD)."""
+    from dualmessagepassing_amd import fused
+    rows, h = 150001, 128
+    gen = th.Generator().manual_seed(11)
+    rng = np.random.default_rng(11)
+    n = rows // 7
+    ix = _index(rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64), n,
+                rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = th.randn(rows, h, generator=gen).clamp_min(0).to(gpu)
+    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    gate = th.rand(rows, generator=gen).to(gpu)
+    calls = {
+        "edge_fwd": lambda: fused.edge_fwd_mfma(d_o, wes, xp[:, h:], 3 * h, bias, coef, ix),
+        "out_fwd": lambda: fused.out_fwd_mfma(h1, w2, bias, gate, d_o),
+        "bwd_h1": lambda: fused.bwd_h1_mfma(d_o, w2, h1, coef, ix)[0],
+        "bwd_z": lambda: fused.bwd_z_mfma(th.cat([d_o, d_o], 1), wes, d_s, h1, coef, ix),
+    }
+    td = th.from_numpy(ix.dst32.cpu().numpy().astype(np.int64)).to(gpu)
+    dpre = th.where(h1 > 0, d_o.double() @ w2.double(), th.zeros(1, dtype=th.float64, device=gpu))
+    want_h1 = th.cat([dpre, dpre * coef.double()[td][:, None]], 1)
+    for name, f in calls.items():
+        outs = [f() for _ in range(12)]
+        th.cuda.synchronize()
+        for o in outs[1:]:
+            assert th.equal(o, outs[0]), name
+        if name == "bwd_h1":
+            assert th.allclose(outs[0].double(), want_h1, rtol=1e-5, atol=2e-4)
