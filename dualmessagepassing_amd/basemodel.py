@@ -22,6 +22,7 @@ from .dmpnn import DMPNNRepMixin
 from .embed import (EquivariantEmbedding, MultihotEmbedding, NormalEmbedding, OrthogonalEmbedding,
                     PositionEmbedding, UniformEmbedding, get_enc_len)
 from .pred import PRED_NETS
+from .rgnn import RGCNRepMixin, RGINRepMixin
 
 
 class OutputDict(OrderedDict):
@@ -233,6 +234,139 @@ def expand_dimensions(old_module, new_module, pre_pad=True):
         for name, param in new_module.named_parameters():
             if name in old_params:
                 expand_dimensions(old_params[name], param, pre_pad)
+
+
+class GraphAdjModel(BaseModel):
+    """basemodel.py:619-962: the node-only skeleton (RGCN / RGIN): vertex id + label encodings,
+    vertex-label filter gate, one pooling head; edge outputs are None."""
+
+    def __init__(self, **kw):
+        self.add_node_id = kw.get("add_node_id", kw.get("gnn_add_node_id", False))
+        super(GraphAdjModel, self).__init__(**kw)
+
+    def _enc_set(self, enc_net, nv, nvl):
+        if enc_net == "Multihot":
+            return OrderedDict({"v": MultihotEmbedding(nv, self.base), "vl": MultihotEmbedding(nvl, self.base)})
+        if enc_net == "Position":
+            return OrderedDict({"v": PositionEmbedding(int(get_enc_len(nv - 1, self.base)) * self.base, nv),
+                                "vl": PositionEmbedding(int(get_enc_len(nvl - 1, self.base)) * self.base, nvl)})
+        raise NotImplementedError(enc_net)
+
+    def create_enc_net(self, type, **kw):
+        enc_net = kw.get("enc_net", "Multihot")
+        if type == "graph":
+            nets = self._enc_set(enc_net, self.max_ngv, self.max_ngvl)
+        elif type == "pattern":
+            if self.share_enc_net:
+                return self.g_enc_net
+            nets = self._enc_set(enc_net, self.max_npv, self.max_npvl)
+        else:
+            raise ValueError(type)
+        for net in nets.values():
+            net.weight.requires_grad = False
+        return nn.ModuleDict(nets)
+
+    def create_filter_net(self, **kw):
+        filter_net = kw.get("filter_net", "None")
+        if filter_net == "None":
+            return None
+        if filter_net == "ScalarFilter":
+            return nn.ModuleDict({"vl": ScalarFilter()})
+        raise ValueError(filter_net)
+
+    def create_emb_net(self, type, **kw):  # basemodel.py:69-91 (no rescaling in this skeleton)
+        emb_net = kw.get("emb_net", "Orthogonal")
+        dims = self.get_graph_enc_dims() if type == "graph" else self.get_pattern_enc_dims()
+        cls = {"Orthogonal": OrthogonalEmbedding, "Normal": NormalEmbedding, "Uniform": UniformEmbedding,
+               "Equivariant": EquivariantEmbedding}.get(emb_net)
+        if cls is None:
+            raise ValueError(emb_net)
+        return nn.ModuleDict(OrderedDict({k: cls(v, self.hid_dim) for k, v in dims.items()}))
+
+    def create_pred_net(self, **kw):
+        name = kw.get("pred_net", "SumPredictNet")
+        if name not in PRED_NETS:
+            raise NotImplementedError("pred_net=%s is outside the MI355X hot-path scope" % name)
+        return PRED_NETS[name](self.get_rep_dim(), hidden_dim=kw.get("pred_hid_dim", 64),
+                               act_func=kw.get("pred_act_func", "relu"), dropout=kw.get("pred_dropout", 0.0),
+                               return_weights="node" in kw.get("pred_return_weights", "none"))
+
+    def _enc_dims(self, nv, nvl):
+        return OrderedDict({"v": int(get_enc_len(nv - 1, self.base)) * self.base,
+                            "vl": int(get_enc_len(nvl - 1, self.base)) * self.base})
+
+    def get_graph_enc_dims(self):
+        return self._enc_dims(self.max_ngv, self.max_ngvl)
+
+    def get_pattern_enc_dims(self):
+        return self.get_graph_enc_dims() if self.share_enc_net else self._enc_dims(self.max_npv, self.max_npvl)
+
+    def get_rep_dim(self):  # basemodel.py:117-123
+        rep_dim = self.hid_dim
+        if self.pred_with_enc:
+            rep_dim += sum(self.get_graph_enc_dims().values())
+        if self.pred_with_deg:
+            rep_dim += 2
+        return rep_dim
+
+    def get_filter_gate(self, pattern, graph, pv, gv):
+        if self.filter_net is None or len(self.filter_net) == 0:
+            return None
+        p_vl = pv.pad(pattern.ndata["label"].view(-1, 1))
+        g_vl = gv.pad(graph.ndata["label"].view(-1, 1))
+        return gv.unpad(self.filter_net["vl"](p_vl, g_vl)).view(-1, 1)
+
+    def _enc(self, net, g):
+        return OrderedDict({"v": net["v"](g.ndata["id"].view(-1)), "vl": net["vl"](g.ndata["label"].view(-1))})
+
+    def _emb(self, net, enc):
+        emb = net["vl"](enc["vl"])
+        if self.add_node_id:
+            emb = emb + net["v"](enc["v"])
+        return emb
+
+    def get_subiso_pred(self, p_v_rep, p_v_mask, g_v_rep, g_v_mask):
+        v_pred_c, v_pred_w = self.pred_net(p_v_rep, p_v_mask, g_v_rep, g_v_mask)
+        return v_pred_c, (v_pred_w, None)
+
+    def forward(self, pattern, graph):  # basemodel.py:877-962
+        bsz = pattern.batch_size
+        pv, gv = _padder(pattern, "node"), _padder(graph, "node")
+        p_v_mask, g_v_mask = pv.mask(), gv.mask()
+        vl_gate = self.get_filter_gate(pattern, graph, pv, gv)
+        if vl_gate is not None:
+            vl_gate = vl_gate.float()
+        p_enc = self._enc(self.p_enc_net, pattern)
+        p_v_emb = self._emb(self.p_emb_net, p_enc)
+        p_v_rep = self.get_pattern_rep(pattern, p_v_emb)
+        g_enc = self._enc(self.g_enc_net, graph)
+        g_v_emb = self._emb(self.g_emb_net, g_enc)
+        g_v_rep = self.get_graph_rep(graph, g_v_emb, gate=vl_gate)
+
+        p_add, g_add = [], []
+        if self.pred_with_enc:
+            p_add += [p_enc["v"], p_enc["vl"]]
+            g_add += [g_enc["v"], g_enc["vl"]]
+        if self.pred_with_deg:
+            p_add += [pattern.out_degrees().float().view(-1, 1), pattern.in_degrees().float().view(-1, 1)]
+            g_add += [graph.out_degrees().float().view(-1, 1), graph.in_degrees().float().view(-1, 1)]
+        p_v_output = th.cat([self.refine_node_weights(th.cat(p_add, dim=-1)), p_v_rep], dim=-1) if p_add else p_v_rep
+        g_v_output = th.cat([self.refine_node_weights(th.cat(g_add, dim=-1)), g_v_rep], dim=-1) if g_add else g_v_rep
+        p_v_mask, g_v_mask = self.refine_node_weights(p_v_mask), self.refine_node_weights(g_v_mask)
+        p_v_mask2, g_v_mask2 = p_v_mask.view(bsz, -1), g_v_mask.view(bsz, -1)
+        if self.pred_net.poolable():  # pool-then-project on per-graph sums (see GraphAdjModelV2.forward)
+            cnt = lambda m: m.float().sum(dim=1).view(-1, 1)
+            pred_c, pred_v = self.pred_net.forward_pooled(
+                ops.seg_pool(p_v_output, _pool_index(pattern, "node")), p_v_mask2.size(1), cnt(p_v_mask2),
+                ops.seg_pool(g_v_output, _pool_index(graph, "node")), g_v_mask2.size(1), cnt(g_v_mask2))
+        else:
+            p_pad = pv.pad(p_v_output).masked_fill(~p_v_mask, 0)
+            g_pad = gv.pad(g_v_output).masked_fill(~g_v_mask, 0)
+            pred_c, (pred_v, _) = self.get_subiso_pred(p_pad, p_v_mask2, g_pad, g_v_mask2)
+        return OutputDict(p_v_emb=p_v_emb, p_e_emb=None, g_v_emb=g_v_emb, g_e_emb=None,
+                          p_v_rep=p_v_rep, p_e_rep=None, g_v_rep=g_v_rep, g_e_rep=None,
+                          p_v_mask=p_v_mask2, p_e_mask=None, g_v_mask=g_v_mask2, g_e_mask=None,
+                          pred_c=pred_c, pred_v=pred_v, pred_e=None)
 
 
 class GraphAdjModelV2(BaseModel):
@@ -514,11 +648,23 @@ class CompGCN(CompGCNRepMixin, GraphAdjModelV2):
     """``models/compgcn.py:289-385``."""
 
 
+class RGCN(RGCNRepMixin, GraphAdjModel):
+    """``models/rgcn.py:215-300``."""
+
+
+class RGIN(RGINRepMixin, GraphAdjModel):
+    """``models/rgin.py:175-260``."""
+
+
 def build_model(**config):
-    """``train.py:68-87`` for the two rep-nets on the MI355X path."""
+    """``train.py:68-87`` for the rep-nets on the MI355X path."""
     rep_net = config.get("rep_net", "DMPNN")
     if rep_net == "DMPNN":
         return DMPNN(**config)
     if rep_net == "CompGCN":
         return CompGCN(**config)
+    if rep_net == "RGCN":
+        return RGCN(**config)
+    if rep_net == "RGIN":
+        return RGIN(**config)
     raise NotImplementedError("rep_net=%s is outside the MI355X hot-path scope" % rep_net)

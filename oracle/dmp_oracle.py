@@ -263,3 +263,50 @@ def random_dmp_params(h_in, h, gen, act_func="relu", init_neigenv=4.0, init_eeig
             p["%s.%d.weight" % (m, 2 * i)] = ((th.rand(h, h, generator=gen, dtype=th.float64) * 2 - 1) * am).to(dtype)
             p["%s.%d.bias" % (m, 2 * i)] = ((th.rand(h, generator=gen, dtype=th.float64) - 0.5) * 0.1).to(dtype)
     return p
+
+
+def rel_dense_weight(params, num_rels, in_dim, out_dim, regularizer, num_bases):
+    """Per-type [in, out] matrices of RGCNLayer / RGINLayer (rgcn.py:98-104 basis, :112-116 bdd)."""
+    w = params["weight"]
+    if regularizer in ("none", "basis"):
+        if "w_comp" in params and params["w_comp"] is not None:
+            return th.matmul(params["w_comp"], w.view(w.size(0), in_dim * out_dim)).view(num_rels, in_dim, out_dim)
+        return w
+    si, so = in_dim // num_bases, out_dim // num_bases
+    blocks = w.view(num_rels, num_bases, si, so)
+    return th.stack([th.block_diag(*[blocks[r, b] for b in range(num_bases)]) for r in range(num_rels)])
+
+
+def rel_layer(params, src, dst, etype, x, kind, num_rels, regularizer="basis", num_bases=-1, edge_norm="in",
+              self_loop=True, act_func="relu", num_mlp_layers=2):
+    """RGCNLayer.forward (rgcn.py:125-199) for kind == "rgcn", RGINLayer.forward (rgin.py:124-160)
+    for kind == "rgin", in the reference's order: per-edge matrix (bmm), norm, fn.sum, update."""
+    n, in_dim = x.shape
+    out_dim = params["bias"].numel()
+    if regularizer == "none" or num_bases is None or num_bases > num_rels or num_bases <= 0:
+        num_bases = num_rels
+    w = rel_dense_weight(params, num_rels, in_dim, out_dim, regularizer, num_bases).index_select(0, etype)
+    msg = th.bmm(x[src].unsqueeze(1), w).squeeze(1)
+    act = activation(act_func)
+    if kind == "rgcn":
+        add = 1.0 if self_loop else 0.0
+        ind, outd = in_degrees(dst, n).float(), out_degrees(src, n).float()
+        inn = ((1.0 / (ind + add)) if self_loop else (1.0 / ind).masked_fill(ind == 0, 0.0)).view(-1, 1)
+        outn = ((1.0 / (outd + add)) if self_loop else (1.0 / outd).masked_fill(outd == 0, 0.0)).view(-1, 1)
+        if edge_norm == "in":
+            msg, node_norm = msg * inn[dst], inn
+        elif edge_norm == "both":
+            msg, node_norm = msg * (outn[src] * inn[dst]) ** 0.5, (inn * outn) ** 0.5
+        else:
+            node_norm = None
+        out = seg_sum(msg, dst, n)
+        if self_loop:
+            loop = x @ params["loop_weight"]
+            out = out + (loop * node_norm if node_norm is not None else loop)
+        return act(out + params["bias"])
+    out = seg_sum(msg, dst, n)
+    if self_loop:
+        out = out + x @ params["loop_weight"]
+    out = out + params["bias"]
+    out = mlp(out, params, "mlp", act, num_mlp_layers) if num_mlp_layers > 0 else act(out)
+    return act(out)

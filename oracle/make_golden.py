@@ -643,6 +643,92 @@ def gen_expand():
     print("wrote expand_dmpnn.npz", {k: tuple(v.shape) for k, v in model.state_dict().items() if "emb_net" in k})
 
 
+def gen_rgnn():
+    """RGCNLayer / RGINLayer (models/rgcn.py:14-213, models/rgin.py:16-172) and the full
+    ``RGCN(**config)`` / ``RGIN(**config)`` models (GraphAdjModel skeleton, basemodel.py:619-962)."""
+    import dgl
+    from models.rgcn import RGCN, RGCNLayer
+    from models.rgin import RGIN, RGINLayer
+    rng = np.random.default_rng(404)
+    layer_cases = [
+        ("rgcn_full_in", RGCNLayer, dict(num_rels=5, regularizer="basis", num_bases=-1, edge_norm="in")),
+        ("rgcn_basis2_both", RGCNLayer, dict(num_rels=5, regularizer="basis", num_bases=2, edge_norm="both")),
+        ("rgcn_bdd_none", RGCNLayer, dict(num_rels=4, regularizer="bdd", num_bases=2, edge_norm="none", self_loop=False)),
+        ("rgin_full", RGINLayer, dict(num_rels=5, regularizer="basis", num_bases=-1)),
+        ("rgin_bdd", RGINLayer, dict(num_rels=6, regularizer="bdd", num_bases=4, act_func="leaky_relu")),
+    ]
+    for tag, cls, kw in layer_cases:
+        n, m, h = 24, 90, 16
+        u, v = er_edges(n, m, rng)
+        th.manual_seed(seed_of("rgnn", tag))
+        layer = cls(h, h, **kw)
+        with th.no_grad():
+            layer.bias.uniform_(-0.2, 0.2)
+        g = dgl.DGLGraph.from_edges(u, v, n)
+        etype = th.from_numpy(rng.integers(0, kw["num_rels"], size=m))
+        x = th.randn(n, h, requires_grad=True)
+        out, _ = layer(g, x, etype)
+        w = th.randn_like(out)
+        (out * w).sum().backward()
+        d = {"src": u, "dst": v, "num_nodes": n, "etype": etype, "x": x, "w": w, "out": out, "dx": x.grad,
+             "kw_keys": np.array(sorted(kw)), "kw_vals": np.array([repr(kw[k]) for k in sorted(kw)])}
+        for k, p in layer.named_parameters():
+            d["p." + k] = p
+            d["g." + k] = p.grad
+        np.savez_compressed(os.path.join(OUT, "rgnn_layer_%s.npz" % tag), **t2n(d))
+        print("wrote rgnn_layer_%s.npz" % tag)
+
+    def make_batch(sizes, n_vl, n_el, rng):
+        gs = []
+        for n, m in sizes:
+            u, v = er_edges(n, m, rng)
+            g = dgl.DGLGraph.from_edges(u, v, n)
+            g.ndata["id"] = th.arange(n)
+            g.ndata["label"] = th.from_numpy(rng.integers(0, n_vl, size=n))
+            g.edata["id"] = th.arange(m)
+            g.edata["label"] = th.from_numpy(rng.integers(0, n_el, size=m))
+            gs.append(g)
+        return dgl.batch(gs)
+
+    p_sizes = [(3, 3), (5, 9), (4, 6), (8, 12), (2, 1), (6, 10)]
+    g_sizes = [(10, 30), (16, 50), (7, 12), (20, 64), (5, 8), (12, 40)]
+    for tag, cls, extra in (("rgcn", RGCN, {"rep_net": "RGCN", "rep_rgcn_edge_norm": "in", "pred_with_deg": True}),
+                            ("rgin", RGIN, {"rep_net": "RGIN", "rep_rgin_num_bases": 2, "pred_net": "MaxPredictNet",
+                                            "pred_with_enc": True, "add_node_id": True, "share_enc_net": True})):
+        rng = np.random.default_rng(41)
+        th.manual_seed(seed_of("rgnn-model", tag))
+        pattern, graph = make_batch(p_sizes, 4, 3, rng), make_batch(g_sizes, 6, 5, rng)
+        config = dict(max_ngv=20, max_ngvl=6, max_nge=64, max_ngel=5, max_npv=8, max_npvl=4, max_npe=12, max_npel=3,
+                      base=2, hid_dim=16, share_emb_net=False, share_enc_net=False, share_rep_net=False,
+                      rep_residual=True, enc_net="Multihot", emb_net="Orthogonal", filter_net="ScalarFilter",
+                      rep_num_graph_layers=2, rep_num_pattern_layers=2, rep_act_func="relu", rep_dropout=0.0,
+                      pred_net="SumPredictNet", pred_hid_dim=16, pred_act_func="relu", pred_dropout=0.0)
+        config.update(extra)
+        model = cls(**config)
+        with th.no_grad():
+            model.pred_net.pred_fc2.weight.uniform_(-0.3, 0.3)
+            model.pred_net.pred_fc2.bias.uniform_(-0.1, 0.1)
+        d = {"config_keys": np.array(sorted(config.keys())), "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())])}
+        for k, v in model.state_dict().items():
+            d["sd." + k] = v.clone()
+        out = model(pattern, graph)
+        out["pred_c"].sum().backward()
+        for t, g in (("p", pattern), ("g", graph)):
+            d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(),
+                      t + "_bnn": g.batch_num_nodes(), t + "_bne": g.batch_num_edges()})
+            for k in ("id", "label"):
+                d["%s_ndata.%s" % (t, k)] = g.ndata[k]
+                d["%s_edata.%s" % (t, k)] = g.edata[k]
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                d["grad." + k] = p.grad
+        for k, v in out.items():
+            if v is not None:
+                d["out." + k] = v
+        np.savez_compressed(os.path.join(OUT, "rgnn_model_%s.npz" % tag), **t2n(d))
+        print("wrote rgnn_model_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import ref_standin
@@ -656,6 +742,7 @@ def main():
     gen_unc()
     gen_subiso_weights()
     gen_expand()
+    gen_rgnn()
 
 
 if __name__ == "__main__":

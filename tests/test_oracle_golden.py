@@ -123,3 +123,22 @@ def test_unc_dual_graph_conv_matches_reference(path):
         for m in ("nmlp", "emlp"):
             _close(bn[m + ".1"]["running_mean"], d["b_after.%s.1.running_mean" % m])
             _close(bn[m + ".1"]["running_var"], d["b_after.%s.1.running_var" % m])
+
+
+@pytest.mark.parametrize("path", golden_files("rgnn_layer_"))
+def test_relational_layer_oracle_matches_reference(path):
+    """RGCNLayer / RGINLayer restatement (oracle/dmp_oracle.py::rel_layer) vs the reference's own run."""
+    d = load_golden(path)
+    kw = {str(k): eval(str(v)) for k, v in zip(d["kw_keys"], d["kw_vals"])}
+    params = {k[2:]: _t(v).clone().requires_grad_(True) for k, v in d.items() if k.startswith("p.")}
+    x = _t(d["x"]).clone().requires_grad_(True)
+    kind = "rgin" if "rgin" in path else "rgcn"
+    out = O.rel_layer(params, _t(d["src"]), _t(d["dst"]), _t(d["etype"]), x, kind, kw["num_rels"],
+                      regularizer=kw.get("regularizer", "basis"), num_bases=kw.get("num_bases", -1),
+                      edge_norm=kw.get("edge_norm", "in"), self_loop=kw.get("self_loop", True),
+                      act_func=kw.get("act_func", "relu"))
+    assert th.allclose(out, _t(d["out"]), rtol=1e-5, atol=1e-5)
+    (out * _t(d["w"])).sum().backward()
+    assert th.allclose(x.grad, _t(d["dx"]), rtol=1e-5, atol=1e-5)
+    for k, p in params.items():
+        assert th.allclose(p.grad, _t(d["g." + k]), rtol=1e-4, atol=1e-5), k
