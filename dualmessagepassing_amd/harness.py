@@ -8,6 +8,8 @@ host syncs per step (running sums stay on the device).  Plus a synthetic (patter
 with exact subgraph-isomorphism counts for smoke-level training runs: the reference's datasets are
 external downloads that are not available offline.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -69,25 +71,31 @@ def _er_edges(n, m, rng):
     return u.astype(np.int64), (r + (r >= u)).astype(np.int64)
 
 
-class SyntheticPairs:
-    """Directed ER (pattern, graph) pairs with uniform labels and exact counts, stored the way the
-    reference's preprocessing leaves a GraphAdj sample: ids = arange, reversed edges appended
-    ([forward | reversed], id + max_ne, label + max_nel, is_reversed; train.py:299-327)."""
+class PairDataset:
+    """(pattern, graph) samples in memory, stored the way the reference's preprocessing leaves a
+    GraphAdj sample: ids = arange, reversed edges appended ([forward | reversed], id + max_ne,
+    label + max_nel, is_reversed; train.py:299-327).  ``shape`` holds the dataset-wide maxima the
+    model vocabulary is sized by (train.py:1164-1181)."""
 
-    def __init__(self, num_pairs, p_nodes, p_edges, g_nodes, g_edges, n_vlabels, n_elabels, seed=0):
-        rng = np.random.default_rng(seed)
-        self.shape = dict(p_nodes=p_nodes, p_edges=p_edges, g_nodes=g_nodes, g_edges=g_edges,
-                          n_vlabels=n_vlabels, n_elabels=n_elabels)
-        self.samples = []
-        for _ in range(num_pairs):
-            pu, pv = _er_edges(p_nodes, p_edges, rng)
-            gu, gv = _er_edges(g_nodes, g_edges, rng)
-            pvl, gvl = rng.integers(0, n_vlabels, p_nodes), rng.integers(0, n_vlabels, g_nodes)
-            pel, gel = rng.integers(0, n_elabels, p_edges), rng.integers(0, n_elabels, g_edges)
-            sub = enumerate_subisomorphisms(pu, pv, pvl, pel, gu, gv, gvl, gel)
-            self.samples.append({"pattern": self._with_rev(pu, pv, pvl, pel, p_edges, n_elabels),
-                                 "graph": self._with_rev(gu, gv, gvl, gel, g_edges, n_elabels),
-                                 "counts": len(sub), "subisomorphisms": sub})
+    def __init__(self, samples, shape):
+        self.samples, self.shape = samples, shape
+
+    @classmethod
+    def from_loaded(cls, loaded):
+        """Samples as ``dataio.load_data`` returns them (forward edges only) -> PairDataset."""
+        mx = lambda f: max([f(x) for x in loaded] + [1])
+        shape = dict(p_nodes=mx(lambda x: x["pattern"]["num_nodes"]), p_edges=mx(lambda x: len(x["pattern"]["src"])),
+                     g_nodes=mx(lambda x: x["graph"]["num_nodes"]), g_edges=mx(lambda x: len(x["graph"]["src"])),
+                     n_vlabels=mx(lambda x: int(max(x["pattern"]["vlabel"].max(initial=0), x["graph"]["vlabel"].max(initial=0))) + 1),
+                     n_elabels=mx(lambda x: int(max(x["pattern"]["elabel"].max(initial=0), x["graph"]["elabel"].max(initial=0))) + 1))
+        samples = []
+        for x in loaded:
+            p, g = x["pattern"], x["graph"]
+            samples.append({"id": x["id"],
+                            "pattern": cls._with_rev(p["src"], p["dst"], p["vlabel"], p["elabel"], shape["p_edges"], shape["n_elabels"]),
+                            "graph": cls._with_rev(g["src"], g["dst"], g["vlabel"], g["elabel"], shape["g_edges"], shape["n_elabels"]),
+                            "counts": int(x["counts"]), "subisomorphisms": np.asarray(x["subisomorphisms"], np.int64).reshape(-1, p["num_nodes"])})
+        return cls(samples, shape)
 
     @staticmethod
     def _with_rev(u, v, vl, el, max_ne, max_nel):
@@ -99,6 +107,9 @@ class SyntheticPairs:
     def __len__(self):
         return len(self.samples)
 
+    def subset(self, indices):
+        return PairDataset([self.samples[i] for i in indices], self.shape)
+
     def model_config(self, hid_dim=64, layers=3, rep_net="DMPNN", **kw):
         s = self.shape
         cfg = dict(max_ngv=s["g_nodes"], max_ngvl=s["n_vlabels"], max_nge=2 * s["g_edges"], max_ngel=2 * s["n_elabels"],
@@ -109,6 +120,20 @@ class SyntheticPairs:
                    pred_net="SumPredictNet", pred_hid_dim=hid_dim, node_pred=True, edge_pred=True)
         cfg.update(kw)
         return cfg
+
+    def to_files(self, root, shared_graph=False):
+        """Write the forward edges of every sample in the reference's directory layout
+        (``dataio.save_pairs``); sample ``i`` becomes pattern ``P_<i // 10>`` ... only when the
+        samples carry no ids of their own: synthetic sets get ``P_i`` / ``G_i``."""
+        from . import dataio
+        out = []
+        for i, x in enumerate(self.samples):
+            fwd = lambda g: {"num_nodes": g["num_nodes"], "src": g["src"][:len(g["src"]) // 2], "dst": g["dst"][:len(g["dst"]) // 2],
+                             "vlabel": g["vlabel"], "elabel": g["elabel"][:len(g["elabel"]) // 2]}
+            pid, gid = (x["id"].split("-", 1) if "id" in x else ("P_%d" % i, "G_%d" % i))
+            out.append({"pattern_id": pid, "graph_id": gid, "pattern": fwd(x["pattern"]), "graph": fwd(x["graph"]),
+                        "counts": x["counts"], "subisomorphisms": x["subisomorphisms"]})
+        dataio.save_pairs(root, out, shared_graph)
 
     def batchify(self, indices, device, return_weights=None):
         """``GraphAdjDataset.batchify`` (dataset.py:1604-1636) + ``.to(device)`` (train.py:606-607):
@@ -135,6 +160,25 @@ class SyntheticPairs:
             weights = subiso_weights(out[0], out[1], torch.from_numpy(np.concatenate(subs)).to(device),
                                      torch.from_numpy(ptr_host).to(device), return_weights, work_hint=int(hint))
         return out[0], out[1], counts.unsqueeze(-1), weights
+
+
+class SyntheticPairs(PairDataset):
+    """Directed ER (pattern, graph) pairs with uniform labels and exact counts."""
+
+    def __init__(self, num_pairs, p_nodes, p_edges, g_nodes, g_edges, n_vlabels, n_elabels, seed=0):
+        rng = np.random.default_rng(seed)
+        self.shape = dict(p_nodes=p_nodes, p_edges=p_edges, g_nodes=g_nodes, g_edges=g_edges,
+                          n_vlabels=n_vlabels, n_elabels=n_elabels)
+        self.samples = []
+        for _ in range(num_pairs):
+            pu, pv = _er_edges(p_nodes, p_edges, rng)
+            gu, gv = _er_edges(g_nodes, g_edges, rng)
+            pvl, gvl = rng.integers(0, n_vlabels, p_nodes), rng.integers(0, n_vlabels, g_nodes)
+            pel, gel = rng.integers(0, n_elabels, p_edges), rng.integers(0, n_elabels, g_edges)
+            sub = enumerate_subisomorphisms(pu, pv, pvl, pel, gu, gv, gvl, gel)
+            self.samples.append({"pattern": self._with_rev(pu, pv, pvl, pel, p_edges, n_elabels),
+                                 "graph": self._with_rev(gu, gv, gvl, gel, g_edges, n_elabels),
+                                 "counts": len(sub), "subisomorphisms": sub})
 
 
 _CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
@@ -205,3 +249,41 @@ def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
     pred, target = torch.cat(preds), torch.cat(targets)
     return {"MAE": float(F.l1_loss(pred, target)), "MSE": float(F.mse_loss(pred, target)),
             "eval_metric": float(_CRIT[eval_metric](pred, target)), "pred": pred.view(-1).cpu(), "counts": target.view(-1).cpu()}
+
+
+def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_dir=None, config=None, sync=None,
+        eval_metric="MAE", seed=0, **train_kw):
+    """The epoch loop of ``train.py:1296-1380`` reduced to its contract: per epoch one shuffled training
+    pass and one dev evaluation; with ``save_dir`` the run directory the reference's tooling expects --
+    ``config.json``, ``epoch%d.pt`` (state dict of every epoch), ``log.txt`` whose "best" lines
+    (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history."""
+    from . import dataio
+    sync = sync or FlatGradSync(model)
+    rng = np.random.default_rng(seed)
+    log = None
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+        if config is not None:
+            dataio.save_config(config, os.path.join(save_dir, "config.json"))
+        log = open(os.path.join(save_dir, "log.txt"), "w")
+    best, history = (float("inf"), -1), []
+    try:
+        for epoch in range(epochs):
+            tr = train_epoch(model, optimizer, train_set, batch_size, device, sync=sync, eval_metric=eval_metric,
+                             order=rng.permutation(len(train_set)), **train_kw)
+            dev = evaluate_epoch(model, dev_set, batch_size, device, eval_metric=eval_metric)
+            history.append({"epoch": epoch, "train": tr, "dev": {k: dev[k] for k in ("MAE", "MSE", "eval_metric")}})
+            if save_dir is not None:
+                torch.save(model.state_dict(), dataio.checkpoint_path(save_dir, epoch))
+            if dev["eval_metric"] < best[0]:
+                best = (dev["eval_metric"], epoch)
+            if log is not None:
+                log.write("data_type: train\tepoch: %03d/%03d\tbp_loss: %.5f\teval-%s: %.5f\n"
+                          % (epoch, epochs, tr["bp_loss"], eval_metric, tr["eval_metric"]))
+                log.write("data_type: dev\tepoch: %03d/%03d\teval-%s: %.5f\n" % (epoch, epochs, eval_metric, dev["eval_metric"]))
+                log.write(dataio.best_line("dev", best[1], epochs, **{"eval-" + eval_metric: "%.5f" % best[0]}) + "\n")
+                log.flush()
+    finally:
+        if log is not None:
+            log.close()
+    return history

@@ -57,3 +57,34 @@ def test_training_with_matching_losses(gpu):
             for _ in range(40)]
     after = match_error()
     assert np.isfinite(hist).all() and after < 0.8 * before, (before, after, hist[::8])
+
+
+def test_fit_from_dataset_directory(tmp_path, gpu):
+    """Config-3 style run: dataset written in the reference's directory layout, loaded back, split
+    by its rule, trained with checkpoints / config / log in the reference's run-directory form."""
+    import os
+    from dualmessagepassing_amd import dataio
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatGradSync
+    from dualmessagepassing_amd.harness import PairDataset, SyntheticPairs, evaluate_epoch, fit
+    root, run = os.path.join(tmp_path, "data"), os.path.join(tmp_path, "run")
+    SyntheticPairs(120, 3, 2, 8, 16, 2, 1, seed=6).to_files(root)
+    data, _ = dataio.load_data(os.path.join(root, "patterns"), os.path.join(root, "graphs"), os.path.join(root, "metadata"))
+    full = PairDataset.from_loaded(data["train"] + data["dev"] + data["test"])
+    n_tr, n_dev = len(data["train"]), len(data["dev"])
+    train, dev = full.subset(range(n_tr)), full.subset(range(n_tr, n_tr + n_dev))
+    assert (len(train), len(dev)) == (96, 12)
+    th.manual_seed(0)
+    config = full.model_config(hid_dim=32, layers=2)
+    model = build_model(**config).to(gpu)
+    sync = FlatGradSync(model)
+    opt = th.optim.AdamW(sync.params, lr=2e-3, weight_decay=1e-5, amsgrad=True)
+    hist = fit(model, opt, train, dev, 25, 32, gpu, save_dir=run, config=config, sync=sync, neg_slp=0.01)
+    assert len(hist) == 25 and hist[-1]["train"]["bp_loss"] < hist[0]["train"]["bp_loss"]
+    assert dataio.load_config(os.path.join(run, "config.json"))["hid_dim"] == 32
+    best = dataio.get_best_epochs(os.path.join(run, "log.txt"))["eval-MAE"]["dev"]
+    assert best[1] == pytest.approx(min(h["dev"]["eval_metric"] for h in hist), abs=1e-4)
+    # the best epoch's checkpoint reproduces its dev metric (evaluate.py loads it the same way, train.py:97-106)
+    again = build_model(**dataio.load_config(os.path.join(run, "config.json"))).to(gpu)
+    again.load_state_dict(th.load(dataio.checkpoint_path(run, best[0]), map_location=gpu))
+    assert evaluate_epoch(again, dev, 32, gpu)["eval_metric"] == pytest.approx(best[1], abs=1e-4)
