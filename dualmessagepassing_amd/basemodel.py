@@ -130,6 +130,20 @@ def _pool_index(graph, kind):
     return _memo(("pool", _tensor_key(sizes), _tensor_key(flag)), lambda: _Keep(ops.PoolIndex(sizes, flag), sizes, flag)).obj
 
 
+def _pool_index_union(pattern, graph, kind):
+    """PoolIndex over [pattern graphs | target graphs] (2B segments) of the union row order."""
+    if kind == "node":
+        a, b, fa, fb = pattern.batch_num_nodes(), graph.batch_num_nodes(), None, None
+    else:
+        a, b = pattern.batch_num_edges(), graph.batch_num_edges()
+        fa, fb = pattern.edata.get(REVFLAG), graph.edata.get(REVFLAG)
+
+    def build():
+        flag = None if fa is None or fb is None else th.cat([fa.view(-1), fb.view(-1)])
+        return _Keep(ops.PoolIndex(th.cat([a, b]), flag), a, b, fa, fb)
+    return _memo(("upool", _tensor_key(a), _tensor_key(b), _tensor_key(fa), _tensor_key(fb)), build).obj
+
+
 class _Keep:
     def __init__(self, obj, *tensors):
         self.obj, self.tensors = obj, tensors
@@ -564,8 +578,9 @@ class GraphAdjModelV2(BaseModel):
         joint = None
         if hasattr(self, "get_joint_rep"):
             joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
+        v_union = e_union = None
         if joint is not None:
-            p_v_rep, p_e_rep, g_v_rep, g_e_rep = joint
+            p_v_rep, p_e_rep, g_v_rep, g_e_rep, v_union, e_union = joint
         else:
             p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
             g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=vl_gate, e_gate=el_gate)
@@ -598,7 +613,12 @@ class GraphAdjModelV2(BaseModel):
             g_v_output = th.cat([self.refine_node_weights(th.cat(g_add, dim=-1)), g_v_rep], dim=-1) if g_add else g_v_rep
             p_v_mask = self.refine_node_weights(p_v_mask)
             g_v_mask = self.refine_node_weights(g_v_mask)
-            if pooled:
+            if pooled and v_union is not None and not p_add:
+                # the shared rep-net ran over the union of both batches: pool the union rows once
+                # (its backward is the union gradient itself, no concatenation of two halves)
+                sums = ops.seg_pool(v_union, _pool_index_union(pattern, graph, "node"))
+                p_v_output, g_v_output = sums[:bsz], sums[bsz:]
+            elif pooled:
                 p_v_output = ops.seg_pool(p_v_output, _pool_index(pattern, "node"))
                 g_v_output = ops.seg_pool(g_v_output, _pool_index(graph, "node"))
             else:
@@ -618,7 +638,10 @@ class GraphAdjModelV2(BaseModel):
             g_e_output = th.cat([self.refine_edge_weights(th.cat(g_add, dim=-1)), g_e_rep], dim=-1) if g_add else g_e_rep
             p_e_mask = self.refine_edge_weights(p_e_mask)
             g_e_mask = self.refine_edge_weights(g_e_mask)
-            if pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
+            if pooled and e_union is not None and not p_add:
+                sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge"))[:, :e_union.size(1)]
+                p_e_output, g_e_output = sums[:bsz], sums[bsz:]
+            elif pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
                 d = p_e_output.size(1)
                 p_e_output = ops.seg_pool(p_e_output, _pool_index(pattern, "edge"))[:, :d]
                 g_e_output = ops.seg_pool(g_e_output, _pool_index(graph, "edge"))[:, :d]

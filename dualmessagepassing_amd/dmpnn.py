@@ -327,12 +327,8 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
         return None
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
-    if v_gate is not None:
-        g_v_emb = g_v_emb * v_gate
-    if e_gate is not None:
-        g_e_emb = g_e_emb * e_gate
-    v = th.cat([p_v_emb, g_v_emb], dim=0)
-    e = th.cat([p_e_emb, g_e_emb], dim=0)
+    v = _GateConcat.apply(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
+    e = _GateConcat.apply(p_e_emb, g_e_emb, e_gate)
     vg = eg = None
     if v_gate is not None:
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
@@ -349,7 +345,38 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual)
     p_v, g_v = _SplitRows.apply(v, np_)
     p_e, g_e = _SplitRows.apply(e, ep_)
-    return p_v, p_e, g_v, g_e
+    return p_v, p_e, g_v, g_e, v, e
+
+
+class _GateConcat(th.autograd.Function):
+    """``cat([p, gate * g])`` written once: the pattern rows are copied, the gated target rows go
+    straight into their place in the union buffer (instead of a multiply pass plus a concatenation
+    pass over the E-row tensors).  ``gate`` ([rows, 1] or None) carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, p, g, gate):
+        from . import _lib
+        lib = _lib.load()
+        _lib.require_gpu(p, g)
+        p, g = p.contiguous(), g.contiguous()
+        n, H = p.size(0), p.size(1)
+        out = th.empty((n + g.size(0), H), dtype=p.dtype, device=p.device)
+        out[:n].copy_(p)
+        if g.size(0) > 0:
+            gt = None if gate is None else gate.reshape(-1).contiguous()
+            _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
+                                             _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_gate_residual")
+        ctx.n, ctx.gate = n, gate
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        from . import fused
+        d = d.contiguous()
+        dg = d[ctx.n:]
+        if ctx.gate is not None and dg.size(0) > 0:
+            dg = fused.gate_residual(None, dg, ctx.gate.reshape(-1).contiguous())
+        return d[:ctx.n], dg, None
 
 
 class _SplitRows(th.autograd.Function):
@@ -358,10 +385,18 @@ class _SplitRows(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        ctx.n, ctx.shape = n, x.shape
         return x[:n], x[n:]
 
     @staticmethod
     def backward(ctx, da, db):
+        if da is None and db is None:
+            return None, None
+        if da is None or db is None:  # only one side is used downstream
+            out = (da if da is not None else db).new_zeros(ctx.shape)
+            (out[:ctx.n] if da is not None else out[ctx.n:]).copy_(da if da is not None else db)
+            return out, None
         return th.cat([da, db], dim=0), None
 
 
@@ -381,7 +416,7 @@ class DMPNNRep(DMPNNRepMixin, nn.Module):
     def forward(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
         joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
         if joint is not None:
-            return joint
+            return joint[:4]
         p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
         g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=v_gate, e_gate=e_gate)
         return p_v_rep, p_e_rep, g_v_rep, g_e_rep
