@@ -46,6 +46,20 @@ class ScalarFilter(nn.Module):
         return th.max(matrix == 0, dim=2)[0]
 
 
+def scalar_filter_gate(p_pad, p_label, g_pad, g_label, num_labels):
+    """``ScalarFilter`` on the pre-padded label matrices (filter.py:10-16 after
+    ``split_and_batchify_graph_feats(..., pre_pad=True)``, basemodel.py:1394-1423), evaluated per row
+    instead of as a ``[B, g_len, p_len]`` comparison cube: a row of the target passes iff its label
+    occurs among the labels of the pattern of the same pair -- or is 0 and that pattern is shorter
+    than the longest one of the batch (its pre-padding zeros take part in the reference's comparison)."""
+    B, L = p_pad.bsz, int(num_labels)
+    present = th.zeros(B * L, dtype=th.bool, device=p_label.device)
+    present.index_fill_(0, p_pad.seg * L + p_label.view(-1), True)
+    if not p_pad.uniform:
+        present.view(B, L)[:, 0] |= p_pad.sizes < p_pad.max
+    return present.index_select(0, g_pad.seg * L + g_label.view(-1)).view(-1, 1)
+
+
 # ----------------------------------------------------------------------------- padding helpers
 def _segments(graph, kind):
     seg = graph.node_graph if kind == "node" else graph.edge_graph
@@ -326,6 +340,8 @@ class GraphAdjModel(BaseModel):
     def get_filter_gate(self, pattern, graph, pv, gv):
         if self.filter_net is None or len(self.filter_net) == 0:
             return None
+        if type(self.filter_net["vl"]) is ScalarFilter:
+            return scalar_filter_gate(pv, pattern.ndata["label"], gv, graph.ndata["label"], max(self.max_ngvl, self.max_npvl))
         p_vl = pv.pad(pattern.ndata["label"].view(-1, 1))
         g_vl = gv.pad(graph.ndata["label"].view(-1, 1))
         return gv.unpad(self.filter_net["vl"](p_vl, g_vl)).view(-1, 1)
@@ -485,6 +501,11 @@ class GraphAdjModelV2(BaseModel):
     def get_filter_gate(self, pattern, graph, pads):
         if self.filter_net is None or len(self.filter_net) == 0:
             return None, None
+        if type(self.filter_net["vl"]) is ScalarFilter and type(self.filter_net["el"]) is ScalarFilter:
+            return (scalar_filter_gate(pads["pv"], pattern.ndata["label"], pads["gv"], graph.ndata["label"],
+                                       max(self.max_ngvl, self.max_npvl)),
+                    scalar_filter_gate(pads["pe"], pattern.edata["label"], pads["ge"], graph.edata["label"],
+                                       max(self.max_ngel, self.max_npel)))
         p_vl = pads["pv"].pad(pattern.ndata["label"].view(-1, 1))
         g_vl = pads["gv"].pad(graph.ndata["label"].view(-1, 1))
         vl_gate = pads["gv"].unpad(self.filter_net["vl"](p_vl, g_vl)).view(-1, 1)
