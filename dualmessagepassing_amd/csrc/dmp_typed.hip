@@ -1,0 +1,276 @@
+// Class-typed variants of the fused edge-chain MFMA kernels (gfx950, exact fp32, H = K = 128).
+//
+// The DMPLayer edge pre-activation is  Z[e] A' + c_e Z[e] B' + ...  with c_e = coef[dst e], a function
+// of out_deg[dst e] only (dmpnn.py:144-151).  All edges of one degree class therefore share ONE weight
+// matrix  W_g = A' + c_g B':  sorted by class and cut into 32-row tiles that never mix classes, the two
+// [E,H]x[H,H] products of the reference collapse into one (and likewise dZ = dPre W_g^T in backward).
+// Rows stay where they are: a tile is a list of 32 edge ids (`slot_edge`, -1 = padding); the kernel
+// gathers its rows of the streamed operand by id and scatters its output rows by id.
+//
+// Structure as mfma_pp<1, EPI, 0> (dmp_mfma.hip): persistent 256-thread workgroups, 3 per CU, weight
+// panel W_g in registers (rebuilt only when the workgroup's contiguous tile range crosses into the
+// next class), buffer addressing with per-lane offsets, LDS-only barriers, three-deep prefetch
+// (ids of tile k+3, rows of tile k+2, staging of tile k+1 while tile k is computed).
+#include "dmp_mfma_common.h"
+
+namespace dmp {
+namespace {
+
+enum { TEPI_EDGE = 1, TEPI_DZ = 4 };
+
+struct TypedArgs {
+  const float *A; int64_t lda;          // streamed operand [E,128], rows gathered by edge id
+  const float *W; int64_t ldw;          // [128, ldw >= 256] = [A' | B'] row-major (the forward weight panel)
+  int transposed;                       // 0: B_g[k][j] = W[k][j] + c W[k][128+j]   (edge_fwd)
+                                        // 1: B_g[k][j] = W[j][k] + c W[j][128+k]   (dZ = dPre W_g^T)
+  float *C; int64_t ldc;                // output [E,128], rows scattered by edge id
+  int64_t E;
+  const int32_t *slot_edge;             // [num_tiles_bound * 32] edge id per slot, -1 = padding
+  const float *tile_scale;              // [num_tiles_bound] c_g of the tile's class
+  const int32_t *num_tiles;             // device scalar: tiles actually used
+  const int32_t *idxA, *idxB;           // TEPI_EDGE: [E] node ids of the added / subtracted P rows; TEPI_DZ: idxA = dst
+  const uint8_t *flag;                  // TEPI_DZ: is_reversed or NULL
+  const float *T; int64_t ldt; int64_t num_nodes;   // gathered table P / D [N, >= 256]
+  const float *bias;                    // TEPI_EDGE: [128] or NULL
+  const float *R; int64_t ldr;          // TEPI_DZ: upstream gradient rows [E,128] or NULL
+  float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
+};
+
+template <int EPI>
+__global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
+  __shared__ float As[kSub * kLdsStride];
+  __shared__ float Cs[4][32 * kScrStride];
+  __shared__ uint32_t rowA[2][kSub], rowB[2][kSub], rowC[2][kSub], rowR[2][kSub];   // [tile parity][row] byte offsets
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, cs = wave, gtid = threadIdx.x;
+  const int col = 32 * cs + li;
+  float *scr = Cs[wave];
+  const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
+  const uint32_t colA = (uint32_t)(gtid & 31) * 16u, col4 = (uint32_t)c4 * 4u;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == TEPI_EDGE && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
+
+  const uint32_t rows4 = (uint32_t)(p.E * 4);
+  const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.E * p.lda * 4));       // all < 4 GiB: checked by the host
+  const rsrc_t rs_C = make_rsrc(p.C, (uint32_t)(p.E * p.ldc * 4));
+  const rsrc_t rs_R = make_rsrc(p.R, p.R ? (uint32_t)(p.E * p.ldr * 4) : 0u);
+  const rsrc_t rs_T = make_rsrc(p.T, (uint32_t)(p.num_nodes * p.ldt * 4));
+  const rsrc_t rs_idxA = make_rsrc(p.idxA, p.idxA ? rows4 : 0u);
+  const rsrc_t rs_idxB = make_rsrc(p.idxB, p.idxB ? rows4 : 0u);
+  const rsrc_t rs_flag = make_rsrc(p.flag, p.flag ? (uint32_t)p.E : 0u);
+  constexpr uint32_t kOOB = 0xFFFFF000u;                                   // byte offset beyond any descriptor range
+
+  // this workgroup's contiguous tile range (tiles are sorted by class)
+  const int ntiles = __builtin_amdgcn_readfirstlane(*p.num_tiles);
+  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int mine = hi > lo ? hi - lo : 0;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));   // past the end: reads 0 (guarded below)
+
+  // W_g fragments: b[s] = B_g[s + 64h][col]
+  float b[64];
+  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)(128 * p.ldw * 4));
+  const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + 64 * h : (int64_t)64 * h * p.ldw + col) * 4u;
+  const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.transposed ? 4 : p.ldw * 4));  // bytes from k to k+1
+  auto load_panel = [&](float c) {
+    // The offsets hang off a value the optimiser cannot see through: otherwise it hoists the 128
+    // address computations out of the tile loop and keeps them live in registers across it.
+    uint32_t off;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
+#pragma unroll
+    for (int s0 = 0; s0 < 64; s0 += 8) {
+      float w0[8], w1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
+        w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + 512, (int)((s0 + j) * w_step), 0));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[s0 + j] = w0[j] + c * w1[j];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- three-deep prefetch state
+  int id_rows[kSubLoads];       // edge ids of the 4 rows this thread loads (rows gtid/32 + 8m)
+  int id_own = -1;              // edge id of row gtid (threads < 32): per-row scalars
+  float4 pre[kSubLoads];
+  uint32_t pre_a = 0, pre_b = 0;
+  auto load_ids = [&](int k) {                            // ids of tile lo + k (-1 past the end)
+    const bool ok = k < mine;
+    const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+    if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
+  };
+  int own_staged = -1;
+  auto load_rows = [&]() {                                // rows + per-row scalars of the tile whose ids are loaded
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) {
+      const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
+      pre[m] = buf_load4(rs_A, off, 0);
+    }
+    if (gtid < kSub) {
+      const uint32_t eo = id_own >= 0 ? (uint32_t)id_own * 4u : kOOB;
+      pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
+      if (EPI == TEPI_EDGE) pre_b = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, (int)eo, 0, 0);
+      if (EPI == TEPI_DZ) pre_b = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
+      own_staged = id_own;
+    }
+  };
+  auto stage = [&](int par) {                             // registers -> LDS
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      *reinterpret_cast<float4 *>(&As[((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+    if (gtid < kSub) {
+      const bool ok = own_staged >= 0;
+      uint32_t a = kOOB, bb = kOOB;
+      if (EPI == TEPI_EDGE) {
+        if (ok) { a = pre_a * (uint32_t)(p.ldt * 4); bb = pre_b * (uint32_t)(p.ldt * 4) + 512u; }
+      } else {
+        bb = pre_b;                                       // flag
+        if (ok) a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? 512u : 0u);
+      }
+      rowA[par][gtid] = a; rowB[par][gtid] = bb;
+      rowC[par][gtid] = ok ? (uint32_t)own_staged * (uint32_t)(p.ldc * 4) : kOOB;
+      rowR[par][gtid] = (ok && p.R) ? (uint32_t)own_staged * (uint32_t)(p.ldr * 4) : kOOB;
+    }
+  };
+
+  f32x16 acc;
+  float4 g0[4], g1[4];
+  auto fetch_operands = [&](int par) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 8 * k + lrow;
+      g0[k] = buf_load4(rs_T, rowA[par][rr] + col4, 0);
+      if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
+      else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
+    }
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *arow = &As[li * kLdsStride + 64 * h];
+    float4 a4 = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      float4 an = a4;
+      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+    }
+  };
+  auto epilogue = [&](int par) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * h) * kScrStride + li] = acc[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 8 * k + lrow;
+      float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
+      if (EPI == TEPI_EDGE) {
+        v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bias4.x, 0.f);
+        v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bias4.y, 0.f);
+        v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bias4.z, 0.f);
+        v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bias4.w, 0.f);
+      } else {
+        const float sg = rowB[par][rr] ? p.s1 : p.s0;
+        v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
+        v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
+      }
+      buf_store4(v, rs_C, rowC[par][rr] + col4, 0);       // padding rows: offset out of range, dropped
+    }
+  };
+
+  if (mine == 0) return;
+  load_ids(0);
+  load_rows();                 // tile 0
+  load_ids(1);
+  stage(0);
+  load_rows();                 // tile 1
+  load_ids(2);
+  lds_barrier();
+  int k = 0;
+  while (k < mine) {
+    // tiles of one degree class: W_g is built once per class segment of this workgroup's range
+    const float c = p.tile_scale[__builtin_amdgcn_readfirstlane(lo + k)];
+    load_panel(c);
+    do {
+      const int par = k & 1;
+      fetch_operands(par);
+      compute();
+      lds_barrier();             // every wave is done reading this tile's rows
+      stage(par ^ 1);            // tile k+1 (rows were requested one iteration ago)
+      load_rows();               // tile k+2 (ids were requested one iteration ago)
+      load_ids(k + 3);
+      lds_barrier();             // tile k+1 is in LDS for everyone
+      epilogue(par);
+      ++k;
+    } while (k < mine && p.tile_scale[__builtin_amdgcn_readfirstlane(lo + k)] == c);
+  }
+}
+
+inline unsigned typed_blocks(int64_t tiles_bound) {
+  const int64_t cap = 256 * 3;
+  return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
+}
+inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
+                       int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
+                       const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
+                       int64_t tiles_bound, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
+  if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!Z || !W || !P || !selA || !selB || !slot_edge || !tile_scale || !num_tiles || !H1 || ldz < H || ldw < 2 * H ||
+      ldp < 2 * H || ldh < H)
+    return DMP_ERR_BAD_ARG;
+  if (ldz % 4 || ldh % 4 || ldp % 4 || !aligned16(Z) || !aligned16(H1) || !aligned16(P) || (bias && !aligned16(bias)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(num_nodes, ldp) || !fits32(E, ldz) || !fits32(E, ldh) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  TypedArgs p{};
+  p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
+  p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
+  p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias;
+  mfma_typed<TEPI_EDGE><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                    int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
+                    float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
+                    int64_t tiles_bound, int64_t E, int H, float *dZ, int64_t ldz, void *stream) {
+  if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!dPre || !W || !D || !dst || !slot_edge || !tile_scale || !num_tiles || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H ||
+      ldz < H || (base && ldb < H))
+    return DMP_ERR_BAD_ARG;
+  if (ldp % 4 || ldz % 4 || ldd % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(dZ) || !aligned16(D) ||
+      (base && !aligned16(base)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(num_nodes, ldd) || !fits32(E, ldp) || !fits32(E, ldz) || (base && !fits32(E, ldb)) || !fits32(tiles_bound * kSub, 1))
+    return DMP_ERR_UNSUPPORTED;
+  TypedArgs p{};
+  p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = 1; p.C = dZ; p.ldc = ldz; p.E = E;
+  p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
+  p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : 128;
+  p.s0 = s0; p.s1 = s1;
+  mfma_typed<TEPI_DZ><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -159,6 +159,46 @@ def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
     return out
 
 
+import os as _os
+USE_TYPED_KERNELS = not _os.environ.get("DMP_NO_TYPED")  # degree-class tiles: one weight panel instead of two in edge_fwd / bwd_z (csrc/dmp_typed.hip)
+
+
+def typed_ok(index, H):
+    """Class-typed kernels: as mfma_ok, plus whole [E, H] arrays addressed with 32-bit byte offsets."""
+    return USE_TYPED_KERNELS and mfma_ok(index, H) and index.num_edges * 2 * H * 4 < 2 ** 32 - 8192
+
+
+def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index):
+    """edge_fwd_mfma with W_g = Wes[:, :H] + c_g Wes[:, H:] per degree class: one product instead of two."""
+    lib = _lib.load()
+    E, H = z.shape
+    out = torch.empty((E, H), dtype=torch.float32, device=z.device)
+    Wes = Wes.contiguous()
+    sel_a, sel_b, _ = index.edge_select(coef)
+    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    with _lib.timed("edge_fwd_typed[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
+        check(lib.dmp_edge_fwd_typed(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
+                                     ptr(sel_a), ptr(sel_b), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound,
+                                     E, H, ptr(out), H, stream_ptr()), "dmp_edge_fwd_typed")
+    return out
+
+
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
+    """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre)."""
+    lib = _lib.load()
+    E, H = d_pre.size(0), Wes.size(0)
+    out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
+    Wes = Wes.contiguous()
+    d_s = d_s.contiguous()
+    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    with _lib.timed("bwd_z_typed[H=%d,E=%d]" % (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
+        check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
+                                  ptr(base), H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, ptr(slot_edge),
+                                  ptr(tile_scale), ptr(num_tiles), bound, E, H, ptr(out), H, stream_ptr()),
+              "dmp_bwd_z_typed")
+    return out
+
+
 def out_fwd_mfma(h1, W2, b2, gate, prev):
     """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128)."""
     lib = _lib.load()
@@ -226,7 +266,10 @@ class _FusedDMPLayer(torch.autograd.Function):
         On = torch.addmm(nb2, H1n, nW2.t())
         xn = gate_residual(x if residual else None, On, v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        if mfma_ok(index, H):
+        if typed_ok(index, H):
+            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index)
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
+        elif mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index)
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
         else:
@@ -276,7 +319,10 @@ class _FusedDMPLayer(torch.autograd.Function):
         dz = None
         if ctx.needs_input_grad[4]:
             if mfma:
-                dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                if typed_ok(ix, H):
+                    dz = bwd_z_typed(dG, 2 * H, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                else:
+                    dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
             else:
                 dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                            base=dzn if ctx.residual else None)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 8
+#define DMP_ABI_VERSION 9
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -426,6 +426,28 @@ int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     const float *D, int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
                     const float *coefE, const int32_t *dst, const uint8_t *flag, float s0,
                     float s1, int64_t num_edges, int H, float *dZ, int64_t ldz, void *stream);
+
+/*
+ * Class-typed variants (csrc/dmp_typed.hip).  coefE[e] depends on out_deg[dst e] only, so all edges of
+ * one degree class share the weight matrix W_g = W[:, 0:H] + c_g W[:, H:2H]; over tiles of 32 edges
+ * of equal class the two products of dmp_edge_fwd_fused / dmp_bwd_z_fused collapse into one.
+ *   slot_edge  [tiles_bound * 32] int32: edge id per tile slot, tiles sorted by class, -1 = padding
+ *   tile_scale [tiles_bound] float     : c_g of each tile
+ *   num_tiles  device int32 scalar     : tiles in use (<= tiles_bound, the host-side bound)
+ * Rows are gathered / scattered by edge id; outputs equal the untyped kernels' up to fp32 rounding
+ * of W_g.  DMP_ERR_UNSUPPORTED additionally when E*ld*4 does not fit 32 bits.
+ */
+int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P,
+                       int64_t ldp, int64_t num_nodes, const float *bias, const int32_t *selA,
+                       const int32_t *selB, const int32_t *slot_edge, const float *tile_scale,
+                       const int32_t *num_tiles, int64_t tiles_bound, int64_t num_edges, int H,
+                       float *H1, int64_t ldh, void *stream);
+int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D,
+                    int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
+                    const int32_t *dst, const uint8_t *flag, float s0, float s1,
+                    const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
+                    int64_t tiles_bound, int64_t num_edges, int H, float *dZ, int64_t ldz,
+                    void *stream);
 
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
  * the bare pipeline of the two kernels above, kept for tests and tuning. */

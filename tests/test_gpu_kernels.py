@@ -371,3 +371,44 @@ def test_mfma_kernels_are_repeatable_under_load(gpu):
             assert th.equal(o, outs[0]), name
         if name == "bwd_h1":
             assert th.allclose(outs[0].double(), want_h1, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("rows", [31, 1000, 70001])
+def test_typed_edge_kernels_equal_untyped(rows, gpu):
+    """Class-typed edge_fwd / bwd_z (one W_g = A' + c_g B' panel per degree class, rows gathered and
+    scattered through the class-sorted tile list) against the untyped fused kernels and fp64."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + 7)
+    rng = np.random.default_rng(rows + 7)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    slot_edge, tile_scale, num_tiles, bound = ix.class_tiles(coef)
+    nt = int(num_tiles.item())
+    se = slot_edge.view(-1, 32)[:nt].cpu().numpy()
+    assert sorted(se[se >= 0].tolist()) == list(range(rows))                      # every edge in exactly one slot
+    ce = ix.edge_select(coef)[2].cpu().numpy()
+    ts = tile_scale[:nt].cpu().numpy()
+    for t in range(nt):
+        ids = se[t][se[t] >= 0]
+        assert len(ids) > 0 and np.all(ce[ids] == ts[t])                           # one class per tile, its own scale
+    assert nt <= rows // 32 + len(np.unique(ce)) and (se[nt:] == -1).all() if nt < len(se) else True
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    got = fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix)
+    ref = fused.edge_fwd_mfma(z, wes, xp[:, h:], 3 * h, bias, coef, ix)
+    assert th.allclose(got, ref, rtol=1e-5, atol=2e-5)
+    d_pre = th.randn(rows, 2 * h, generator=gen).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    base = th.randn(rows, h, generator=gen).to(gpu)
+    for b_ in (base, None):
+        got = fused.bwd_z_typed(d_pre, 2 * h, wes, d_s, b_, coef, ix)
+        ref = fused.bwd_z_mfma(d_pre, wes, d_s, b_, coef, ix)
+        assert th.allclose(got, ref, rtol=1e-5, atol=2e-5)
+    assert th.equal(fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix),
+                    fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix))
