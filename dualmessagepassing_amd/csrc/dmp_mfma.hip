@@ -129,7 +129,9 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   const uint32_t grpR = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8 * p.ldr * 4));
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
-  constexpr int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (EPI == EPI_RELU_BWD_G ? 256 : 128);
+  // EPI_RELU_BWD_G writes [dPre | coef dPre] when the output has room for both halves (ldc >= 256), dPre only otherwise
+  const bool both_halves = EPI == EPI_RELU_BWD_G && p.ldc >= 256;
+  const int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (both_halves ? 256 : 128);
 
   // whole-array descriptors: per-row arrays and the gathered table
   const uint32_t rows4 = (uint32_t)(p.E * 4);
@@ -280,8 +282,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
           v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
           v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
           colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
-          const float cf = rowS[grp][par][rr];
-          buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + 512u, 0);
+          if (both_halves) {
+            const float cf = rowS[grp][par][rr];
+            buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + 512u, 0);
+          }
         }
         buf_store4(v, rc, voffC[k] + 512u * q, 0);
       }
@@ -492,7 +496,7 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
   if (E == 0)
     return hipMemsetAsync(partial, 0, sizeof(float) * 128 * (size_t)dmp_mfma_partial_rows(0), (hipStream_t)stream) == hipSuccess
                ? DMP_OK : DMP_ERR_HIP;
-  if (!dO || !W2 || !H1 || !coefE || !dG || ldo < H || ldw < H || ldh < H || ldg < 2 * H) return DMP_ERR_BAD_ARG;
+  if (!dO || !W2 || !H1 || !coefE || !dG || ldo < H || ldw < H || ldh < H || ldg < H) return DMP_ERR_BAD_ARG;
   if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
     return DMP_ERR_UNSUPPORTED;
   if (!fits32(E, 1) || !fits32(kSub, ldo) || !fits32(kSub, ldh) || !fits32(kSub, ldg)) return DMP_ERR_UNSUPPORTED;

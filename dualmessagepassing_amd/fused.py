@@ -199,6 +199,23 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
     return out
 
 
+def atb_typed(z, d_pre, coef, index):
+    """[z^T d_pre | z^T (coef[dst] (.) d_pre)]  ([H, 2H]) over the class-sorted tiles: one product's worth of
+    MFMAs for both halves (csrc/dmp_typed.hip::atb_typed_k), fixed-order reduction of the workgroup partials."""
+    lib = _lib.load()
+    E, H = z.shape
+    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    G = int(lib.dmp_atb_typed_blocks(bound))
+    part = torch.empty((2, G, H * H), dtype=torch.float32, device=z.device)
+    with _lib.timed("atb_typed[H=%d,E=%d]" % (H, E), 8 * H * E):
+        check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
+                                ptr(num_tiles), bound, E, H, ptr(part[0]), ptr(part[1]), stream_ptr()), "dmp_atb_typed")
+    out = torch.empty((H, 2 * H), dtype=torch.float32, device=z.device)
+    out[:, :H] = reduce_partials(part[0]).view(H, H)
+    out[:, H:] = reduce_partials(part[1]).view(H, H)
+    return out
+
+
 def out_fwd_mfma(h1, W2, b2, gate, prev):
     """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128)."""
     lib = _lib.load()
@@ -211,16 +228,16 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef, index):
-    """-> (dG = [dPre | coef[dst] dPre] with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128."""
+def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True):
+    """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128."""
     lib = _lib.load()
     E, H = d_o.shape
-    d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_o.device)
+    d_g = torch.empty((E, 2 * H if both_halves else H), dtype=torch.float32, device=d_o.device)
     part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
-    with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), 16 * H * E + 4 * E):
+    with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), (16 if both_halves else 12) * H * E + 4 * E):
         check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]), E, H,
-                                   ptr(d_g), 2 * H, ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
+                                   ptr(d_g), d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
 
 
@@ -293,16 +310,16 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- edge side, down to the gathered node projections
         dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
         dW2e = atb(dOe, H1e)
-        mfma = mfma_ok(ix, H)
+        mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
         if mfma:
-            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix)         # dG[:, :H] is dPre
+            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=not typed)  # dG[:, :H] is dPre
         else:
             dH1e = dOe @ eW2
             dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
             del dH1e
         inc_ptr, inc_ent = ix.incidence()
         dP = ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
-        dWes = atb(z, dG)                                            # [H,2H] = [dA_e | dB_e]
+        dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)  # [H,2H] = [dA_e | dB_e]
         # ---- node side
         dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
         dW2n = atb(dOn, H1n)
@@ -319,8 +336,8 @@ class _FusedDMPLayer(torch.autograd.Function):
         dz = None
         if ctx.needs_input_grad[4]:
             if mfma:
-                if typed_ok(ix, H):
-                    dz = bwd_z_typed(dG, 2 * H, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                if typed:
+                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:
                     dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
             else:

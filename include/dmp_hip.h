@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 9
+#define DMP_ABI_VERSION 10
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -408,7 +408,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
  * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
  *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
  *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
- *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
+ *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H];
+ *   with H <= ldg < 2H only dPre is written (dG [E, ldg]).
  */
 int64_t dmp_mfma_partial_rows(int64_t num_edges);
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
@@ -448,6 +449,20 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                     int64_t tiles_bound, int64_t num_edges, int H, float *dZ, int64_t ldz,
                     void *stream);
+
+/*
+ * Weight gradient of the class-typed edge chain:  with G_c = sum over the edges e of class c of
+ * Z[e]^T dPre[e]  ([H,H]),  dA' = sum_c G_c  and  dB' = sum_c c_c G_c  (the two halves of dW for
+ * W = [A' | B']) from ONE pass and one product's worth of MFMAs.  Every workgroup walks a contiguous
+ * range of the class-sorted tiles and writes two [H,H] partials (running total, coefficient-weighted
+ * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats, to be summed with
+ * dmp_reduce_partials (fixed order: bit-stable for a given tile list).
+ */
+int64_t dmp_atb_typed_blocks(int64_t tiles_bound);
+int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
+                  const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
+                  int64_t tiles_bound, int64_t num_edges, int H, float *partial_T,
+                  float *partial_B, void *stream);
 
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
  * the bare pipeline of the two kernels above, kept for tests and tuning. */

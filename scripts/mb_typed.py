@@ -57,3 +57,9 @@ se2 = th.full((bound * 32,), -1, dtype=th.int32, device=dev)
 T("full + index_put", lambda: th.full((bound * 32,), -1, dtype=th.int32, device=dev).index_put_((slot,), order.to(th.int32)))
 T("searchsorted", lambda: th.searchsorted(tile_end, th.arange(bound, device=dev), right=True))
 T("gather dst class", lambda: coef[ix.dst32.long()])
+dp = dpre[:, :h].contiguous()
+print("atb untyped [z^T dG]   %7.1f us" % timeit(lambda: fused.atb(z, dpre)))
+print("atb typed              %7.1f us" % timeit(lambda: fused.atb_typed(z, dp, coef, ix)))
+w2 = (th.randn(h, h, generator=g) * .1).to(gpu); h1 = z.clamp_min(0)
+print("bwd_h1 both halves     %7.1f us" % timeit(lambda: fused.bwd_h1_mfma(dp, w2, h1, coef, ix)))
+print("bwd_h1 dPre only       %7.1f us" % timeit(lambda: fused.bwd_h1_mfma(dp, w2, h1, coef, ix, both_halves=False)))

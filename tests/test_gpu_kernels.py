@@ -412,3 +412,26 @@ def test_typed_edge_kernels_equal_untyped(rows, gpu):
         assert th.allclose(got, ref, rtol=1e-5, atol=2e-5)
     assert th.equal(fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix),
                     fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix))
+
+
+@pytest.mark.parametrize("rows", [31, 1000, 70001])
+def test_typed_weight_gradient(rows, gpu):
+    """atb_typed: [z^T dPre | z^T (coef[dst] dPre)] over the class-sorted tiles vs fp64, and bit-stable."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + 9)
+    rng = np.random.default_rng(rows + 9)
+    n = max(2, rows // 6)
+    ix = _index(rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64), n,
+                rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    got = fused.atb_typed(z, d_pre, coef, ix)
+    ce = ix.edge_select(coef)[2].double()
+    want = th.cat([z.double().t() @ d_pre.double(), z.double().t() @ (d_pre.double() * ce[:, None])], 1)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    assert th.equal(got, fused.atb_typed(z, d_pre, coef, ix))
+    d_g, _ = fused.bwd_h1_mfma(d_pre, (th.randn(h, h, generator=gen) * 0.1).to(gpu), z.clamp_min(0), coef, ix, both_halves=False)
+    assert d_g.shape == (rows, h)
