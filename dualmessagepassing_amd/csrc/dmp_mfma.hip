@@ -45,6 +45,9 @@
 //   dmp_gemm_k128        plain C = A B (development / tests)
 #include "dmp_mfma_common.h"
 
+// Development builds (scripts/mb_dbg.py, scripts/mb_phase.py): -DDMP_DBG=<bits>, compiled out by default.
+//   1 no output stores, 2 no accumulator transpose, 4 no row prefetch after the first tiles, 8 no staging
+//   writes (results are wrong: timing only); 16 per-phase cycle counters, 64 finer epilogue counters.
 #ifndef DMP_DBG
 #define DMP_DBG 0
 #endif
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
             buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + 512u, 0);
           }
         }
-        buf_store4(v, rc, voffC[k] + 512u * q, 0);
+        if (!(DMP_DBG & 1) || v.x == 123.456f) buf_store4(v, rc, voffC[k] + 512u * q, 0);
       }
     }
 #if DMP_DBG & 64
