@@ -159,8 +159,7 @@ def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
     return out
 
 
-import os as _os
-USE_TYPED_KERNELS = not _os.environ.get("DMP_NO_TYPED")  # degree-class tiles: one weight panel instead of two in edge_fwd / bwd_z (csrc/dmp_typed.hip)
+USE_TYPED_KERNELS = True  # degree-class tiles: one weight panel instead of two in edge_fwd / bwd_z (csrc/dmp_typed.hip)
 
 
 def typed_ok(index, H):

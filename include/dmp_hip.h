@@ -464,6 +464,11 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
                   int64_t tiles_bound, int64_t num_edges, int H, float *partial_T,
                   float *partial_B, void *stream);
 
+/* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
+ * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup
+ * held half an iteration apart by barriers).  Process-wide; results are identical. */
+void dmp_dev_set_mfma_variant(int variant);
+
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
  * the bare pipeline of the two kernels above, kept for tests and tuning. */
 int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed,

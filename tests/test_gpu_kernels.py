@@ -435,3 +435,36 @@ def test_typed_weight_gradient(rows, gpu):
     assert th.equal(got, fused.atb_typed(z, d_pre, coef, ix))
     d_g, _ = fused.bwd_h1_mfma(d_pre, (th.randn(h, h, generator=gen) * 0.1).to(gpu), z.clamp_min(0), coef, ix, both_halves=False)
     assert d_g.shape == (rows, h)
+
+
+def test_pingpong_driver_matches_default(gpu):
+    """The experimental ping-pong driver of the fused MFMA kernels (dmp_dev_set_mfma_variant(1)) computes
+    bit-identical results to the default independent-workgroup driver."""
+    from dualmessagepassing_amd import _lib, fused
+    lib = _lib.load()
+    rows, h = 40003, 128
+    gen = th.Generator().manual_seed(3)
+    rng = np.random.default_rng(3)
+    n = rows // 6
+    ix = _index(rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64), n,
+                rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    gate = th.rand(rows, generator=gen).to(gpu)
+
+    def run():
+        return (fused.edge_fwd_mfma(z, wes, xp[:, h:], 3 * h, bias, coef, ix), fused.out_fwd_mfma(z, w2, bias, gate, z),
+                fused.bwd_h1_mfma(z, w2, z.clamp_min(0), coef, ix)[0],
+                fused.bwd_z_mfma(th.cat([z, z], 1), wes, xp[:, :2 * h].contiguous(), z, coef, ix))
+    base = run()
+    try:
+        lib.dmp_dev_set_mfma_variant(1)
+        other = run()
+    finally:
+        lib.dmp_dev_set_mfma_variant(0)
+    for a, b in zip(base, other):
+        assert th.equal(a, b)
