@@ -152,6 +152,25 @@ def pmc_traffic(n_rows, n_edges, H):
     return None
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
+
+
+def mfma_rooflines(kern, H, E):
+    """{kernel: {avg_us, tflops, frac}} for the fused MFMA kernels seen by the HIP-event timer; flops =
+    2*E*H*H per [E,H]x[H,H] product the kernel performs (1 for the class-typed kernels, out_fwd and
+    bwd_h1; 2 for the two-panel edge_fwd / bwd_z)."""
+    products = {"edge_fwd_typed": 1, "bwd_z_typed": 1, "atb_typed": 1, "out_fwd_mfma": 1, "bwd_h1_mfma": 1,
+                "edge_fwd_mfma": 2, "bwd_z_mfma": 2}
+    out = {}
+    for name, v in kern.items():
+        base = name.split("[", 1)[0]
+        if base in products and ("E=%d" % E in name or "R=%d" % E in name):
+            tf = products[base] * 2.0 * E * H * H / (v["avg_us"] * 1e-6) / 1e12
+            out[base] = {"avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS}
+    return out
+
+
 def cpu_baseline(cfg, seconds_budget=20.0):
     """CPU oracle (oracle/dmp_oracle.py: reference op order, torch CPU, all host cores) on a
     bounded sample of the same workload: fwd+bwd of the 3-layer pattern + graph rep-nets."""
@@ -299,6 +318,9 @@ def main():
                        "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},
             "roofline": roof,
+            # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32
+            # v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak): their MFMA-roofline fractions, for context
+            "mfma_kernels": mfma_rooflines(kern, H, uE),
             "kernels": {n: {"avg_us": round(v["avg_us"], 2), "gbps": round(v["gbps"], 1), "launches": v["launches"],
                             "bytes": int(v["bytes"])} for n, v in sorted(kern.items())},
         }
