@@ -156,6 +156,61 @@ class _GatherRows(torch.autograd.Function):
         return seg_sum_raw(dO, ix.in_ptr, ix.in_ent, ix.num_nodes), None, None
 
 
+class _TakeRows(torch.autograd.Function):
+    """``X[idx]`` for an arbitrary int64 index vector: forward = row gather, backward = fixed-order
+    segment sum over a CSR of the index values (torch's advanced-indexing backward serialises on
+    repeated indices: 1.9 ms for 21,716 lookups into 2,708 rows in the UNC score head)."""
+
+    @staticmethod
+    def forward(ctx, X, idx):
+        lib = _lib.load()
+        _lib.require_gpu(X, idx)
+        idx = idx.view(-1).to(torch.int64).contiguous()
+        M, N = idx.numel(), X.size(0)
+        i32 = dict(dtype=torch.int32, device=X.device)
+        ctx.rowptr, ctx.ent = torch.empty(N + 1, **i32), torch.empty(M, **i32)
+        idx32, deg = torch.empty(M, **i32), torch.empty(N, dtype=torch.int64, device=X.device)
+        status = torch.empty(1, **i32)
+        ws = torch.empty(lib.dmp_csr_workspace_words(N, M), **i32)
+        check(lib.dmp_csr_build(ptr(idx), None, M, N, ptr(ctx.rowptr), ptr(ctx.ent), ptr(idx32), ptr(deg), ptr(status),
+                                ptr(ws), stream_ptr()), "dmp_csr_build(index)")
+        ctx.N = N
+        return gather_rows_raw(X.contiguous(), idx32)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dO):
+        return seg_sum_raw(dO.contiguous(), ctx.rowptr, ctx.ent, ctx.N, rows_shared=False), None
+
+
+def take_rows(X, idx):
+    """Differentiable ``X[idx]`` (rows) on the gather / segment-sum kernels."""
+    return _TakeRows.apply(X, idx)
+
+
+class _TakeRowsSmallTable(torch.autograd.Function):
+    """``W[idx]`` for a table with few rows and very many lookups per row (relation embeddings):
+    backward = keyed two-level segment sum (``PoolIndex.from_keys``), fixed order."""
+
+    @staticmethod
+    def forward(ctx, W, idx):
+        _lib.require_gpu(W, idx)
+        idx = idx.view(-1).to(torch.int64)
+        ctx.pool = PoolIndex.from_keys(idx, W.size(0))
+        return gather_rows_raw(W.contiguous(), idx.to(torch.int32))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dO):
+        p = ctx.pool
+        part = seg_sum_raw(dO.contiguous(), p.vptr, p.vent, p.num_chunks, None, False, rows_shared=False)
+        return seg_sum_raw(part, p.gptr, p.gent, p.num_graphs, None, False, rows_shared=False), None
+
+
+def take_rows_small_table(W, idx):
+    return _TakeRowsSmallTable.apply(W, idx)
+
+
 class _EdgeCombine(torch.autograd.Function):
     """DMPLayer edge pre-activation, one kernel (dmpnn.py:112,120,124,142-151)."""
 
@@ -382,9 +437,10 @@ class PoolIndex:
         type of an edge): rows are visited key by key in ascending row order (stable sort), so the
         sums are bit-stable; same two-level chunking as for the contiguous per-graph ranges."""
         keys = keys.view(-1).to(torch.int64)
-        order = torch.sort(keys, stable=True)[1]
-        sizes = torch.bincount(keys, minlength=num_keys)
-        return cls(sizes, order=order, seg=keys)
+        skeys, order = torch.sort(keys, stable=True)
+        # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
+        marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))
+        return cls(marks[1:] - marks[:-1], order=order, seg=keys)
 
     def __init__(self, sizes, flag=None, order=None, seg=None):
         dev = sizes.device

@@ -240,9 +240,10 @@ class TrainModel(nn.Module):
 
     def calc_score(self, embedding, triplets):
         node_emb = embedding[0] if isinstance(embedding, (tuple, list)) else embedding
-        s = node_emb[triplets[:, 0]]
-        r = self.w_relation[triplets[:, 1]]
-        o = node_emb[triplets[:, 2]]
+        # model.py:669-677; the two endpoint lookups as ONE row gather whose backward is a segment sum
+        so = ops.take_rows(node_emb, torch.cat([triplets[:, 0], triplets[:, 2]]))
+        s, o = so[:triplets.size(0)], so[triplets.size(0):]
+        r = ops.take_rows_small_table(self.w_relation, triplets[:, 1])
         return torch.sum(s * r * o, dim=1)
 
     def forward(self, g, h, edge_type, edge_norm):
@@ -261,9 +262,12 @@ class TrainModel(nn.Module):
         if edge_type is not None:
             for emb in embs:
                 if emb.size(0) == edge_type.size(0):
-                    mask = edge_type < self.w_relation.size(0)
-                    emb_diff = self.edge_fc(emb[mask]) - torch.index_select(self.w_relation, 0, edge_type[mask])
-                    reg = reg + torch.mean(torch.pow(emb_diff, 2))
+                    # model.py:703-707 selects the rows with ``emb[mask]`` (a host sync for the row count and a
+                    # serialised indexing backward); same mean as a mask-weighted sum over all rows
+                    num_rels = self.w_relation.size(0)
+                    mask = (edge_type < num_rels).to(emb.dtype).unsqueeze(1)
+                    emb_diff = self.edge_fc(emb) - ops.take_rows_small_table(self.w_relation, edge_type.clamp(max=num_rels - 1))
+                    reg = reg + (torch.pow(emb_diff, 2) * mask).sum() / (mask.sum() * emb_diff.size(1))
         return reg
 
     def get_unsupervised_loss(self, g, embedding, edge_type, triplets, labels):
