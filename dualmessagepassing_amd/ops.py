@@ -440,25 +440,33 @@ class PoolIndex:
         skeys, order = torch.sort(keys, stable=True)
         # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
         marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))
-        return cls(marks[1:] - marks[:-1], order=order, seg=keys)
+        return cls(marks[1:] - marks[:-1], order=order, seg=keys, num_rows=int(keys.numel()))
 
-    def __init__(self, sizes, flag=None, order=None, seg=None):
+    def __init__(self, sizes, flag=None, order=None, seg=None, num_rows=None):
+        """``num_rows`` (host int: the total number of rows) makes the construction free of host syncs:
+        the chunk table is then sized by the bound ``num_rows // CHUNK + len(sizes)`` and its unused tail
+        consists of empty chunks."""
         dev = sizes.device
         sizes = sizes.to(torch.int64)
         B = int(sizes.numel())
         off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
         torch.cumsum(sizes, 0, out=off[1:])
-        R = int(off[-1].item())
         C = self.CHUNK
         nchunk = (sizes + C - 1) // C
         coff = torch.zeros(B + 1, dtype=torch.int64, device=dev)
         torch.cumsum(nchunk, 0, out=coff[1:])
-        V = int(coff[-1].item())
-        cgraph = torch.repeat_interleave(torch.arange(B, device=dev), nchunk, output_size=V)
-        cstart = off[cgraph] + (torch.arange(V, device=dev) - coff[cgraph]) * C
-        vptr = torch.empty(V + 1, dtype=torch.int64, device=dev)
-        vptr[:V] = cstart
-        vptr[V] = R
+        if num_rows is None:
+            R, V = int(off[-1].item()), int(coff[-1].item())
+            cgraph = torch.repeat_interleave(torch.arange(B, device=dev), nchunk, output_size=V)
+            cstart = off[cgraph] + (torch.arange(V, device=dev) - coff[cgraph]) * C
+        else:
+            R, V = int(num_rows), int(num_rows) // C + B
+            v = torch.arange(V, device=dev)
+            cgraph = torch.searchsorted(coff[1:], v, right=True)              # == B for the unused tail
+            real = cgraph < B
+            cg = cgraph.clamp(max=max(B - 1, 0))
+            cstart = torch.where(real, off[cg] + (v - coff[cg]) * C, torch.full_like(v, R))
+        vptr = torch.cat([cstart, torch.full((1,), R, dtype=torch.int64, device=dev)])
         self.num_graphs, self.num_rows, self.num_chunks = B, R, V
         self.vptr = vptr.to(torch.int32)
         rows = torch.arange(R, device=dev, dtype=torch.int64) if order is None else order.to(torch.int64)

@@ -46,3 +46,4 @@ def step():
 
 
 print("UNC DMPNN hid=256, 2 layers, N=%d, E=%d: forward %.3f ms, train step (fwd+bwd+Adam) %.3f ms" % (n, 2 * m, timeit(fwd), timeit(step)))
+
