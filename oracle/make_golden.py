@@ -529,6 +529,20 @@ for tag, nlabel in (("unsup", 0), ("sup", 4)):
         d["b." + k] = b
     np.savez_compressed(os.path.join(%(out)r, "unc_train_%%s.npz" %% tag), **t2n(d))
     print("wrote unc_train_%%s.npz" %% tag, float(loss))
+# mini-batch helpers with exact integer semantics (utils.py:539-567)
+import utils as unc_utils
+np.random.seed(1234)
+pos = np.stack([rng.integers(0, 40, 25), rng.integers(0, 3, 25), rng.integers(0, 40, 25)], 1).astype(np.int64)
+neg = unc_utils.negative_sampling(pos, 40, 4)
+np.random.seed(1234)                                   # the same draws, in the function's order
+values = np.random.randint(40 - 1, size=100)
+choices = np.random.uniform(size=100)
+subg_nids = np.sort(rng.choice(200, 60, replace=False)).astype(np.int64)
+ori = subg_nids[rng.integers(0, 60, 80)]
+mapped = unc_utils.convert_subgraph_nids(ori, subg_nids)
+np.savez_compressed(os.path.join(%(out)r, "unc_sampling.npz"), pos=pos, neg=neg, values=values, choices=choices,
+                    subg_nids=subg_nids, ori=ori, mapped=mapped, num_entity=40, negative_rate=4)
+print("wrote unc_sampling.npz")
 '''
 
 

@@ -1,0 +1,88 @@
+"""UNC mini-batch construction on the device (unc_sampling.py): the integer parts against the
+reference's own functions (tests/golden/unc_sampling.npz, utils.py:539-567), the random parts through
+the properties that define them (DGL's samplers are not available; their random streams are not pinned)."""
+import numpy as np
+import pytest
+import torch as th
+
+from conftest import golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(n, m, gpu, seed=0):
+    from dualmessagepassing_amd.graph import BatchedGraph
+    rng = np.random.default_rng(seed)
+    src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    g.edata["type"] = th.from_numpy(rng.integers(0, 3, m)).to(gpu)
+    return g, src, dst
+
+
+def test_negative_sampling_and_nid_conversion_match_reference(gpu):
+    from dualmessagepassing_amd.unc_sampling import convert_subgraph_nids, negative_sampling
+    d = load_golden(golden_files("unc_sampling")[0])
+    neg = negative_sampling(th.from_numpy(d["pos"]).to(gpu), int(d["num_entity"]), int(d["negative_rate"]),
+                            values=th.from_numpy(d["values"]).to(gpu), choices=th.from_numpy(d["choices"]).to(gpu))
+    assert np.array_equal(neg.cpu().numpy(), d["neg"])
+    mapped = convert_subgraph_nids(th.from_numpy(d["ori"]).to(gpu), th.from_numpy(d["subg_nids"]).to(gpu), 200)
+    assert np.array_equal(mapped.cpu().numpy(), d["mapped"])
+    # drawn on the device: replaced endpoints differ from the originals, relations and the other endpoint stay
+    pos = th.from_numpy(d["pos"]).to(gpu)
+    gen = th.Generator(device=gpu).manual_seed(1)
+    neg2 = negative_sampling(pos, 40, 4, generator=gen)
+    rep = pos.repeat(4, 1)
+    changed_s, changed_o = neg2[:, 0] != rep[:, 0], neg2[:, 2] != rep[:, 2]
+    assert bool((changed_s ^ changed_o).all()) and th.equal(neg2[:, 1], rep[:, 1])
+    assert int(neg2[:, [0, 2]].min()) >= 0 and int(neg2[:, [0, 2]].max()) < 40
+
+
+def test_sample_in_edges_properties(gpu):
+    from dualmessagepassing_amd.unc_sampling import sample_in_edges
+    g, src, dst = _graph(300, 6000, gpu)
+    nodes = th.arange(0, 300, 3, device=gpu)
+    gen = th.Generator(device=gpu).manual_seed(5)
+    mask = sample_in_edges(g, nodes, 7, gen).cpu().numpy()
+    indeg = np.bincount(dst, minlength=300)
+    got = np.bincount(dst[mask], minlength=300)
+    want = np.where(np.arange(300) % 3 == 0, np.minimum(indeg, 7), 0)
+    assert np.array_equal(got, want)
+    gen2 = th.Generator(device=gpu).manual_seed(5)
+    assert np.array_equal(mask, sample_in_edges(g, nodes, 7, gen2).cpu().numpy())       # same generator state, same sample
+    other = sample_in_edges(g, nodes, 7, th.Generator(device=gpu).manual_seed(6)).cpu().numpy()
+    assert (other != mask).any()
+    # roughly uniform: over many draws every in-edge of a node with 2*width in-edges is picked about half the time
+    v = int(np.argmax(indeg == indeg[indeg >= 14].min())) if (indeg >= 14).any() else 0
+    picks = np.zeros(len(dst))
+    only_v = th.tensor([v], device=gpu)
+    for s in range(200):
+        picks += sample_in_edges(g, only_v, indeg[v] // 2, th.Generator(device=gpu).manual_seed(100 + s)).cpu().numpy()
+    freq = picks[dst == v] / 200
+    assert abs(freq.mean() - (indeg[v] // 2) / indeg[v]) < 1e-9 and freq.min() > 0.25 and freq.max() < 0.75
+
+
+def test_subgraph_sampling_and_batch_construction(gpu):
+    from dualmessagepassing_amd.unc_sampling import generate_sampled_graph_and_labels_unsupervised, sample_subgraph_by_neighbors
+    g, src, dst = _graph(500, 4000, gpu, seed=2)
+    seeds = th.tensor([3, 77, 78, 410], device=gpu)
+    gen = th.Generator(device=gpu).manual_seed(9)
+    sub, nid = sample_subgraph_by_neighbors(g, seeds, depth=2, width=5, generator=gen)
+    nid_h = nid.cpu().numpy()
+    assert np.all(np.diff(nid_h) > 0) and set([3, 77, 78, 410]) <= set(nid_h.tolist())
+    u, v = sub.all_edges(form="uv", order="eid")
+    eid = sub.edata["_ID"].cpu().numpy()
+    assert np.array_equal(nid_h[u.cpu().numpy()], src[eid]) and np.array_equal(nid_h[v.cpu().numpy()], dst[eid])
+    assert th.equal(sub.edata["type"], g.edata["type"][sub.edata["_ID"]])
+    assert int(sub.in_degrees().max()) <= 5
+    deg = (sub.in_degrees() + sub.out_degrees()).cpu().numpy()
+    assert all(deg[i] > 0 or nid_h[i] in (3, 77, 78, 410) for i in range(len(nid_h)))
+    # whole batch: positives + negatives in subgraph ids, labels, edge norms, dropped edges
+    rng = np.random.default_rng(4)
+    pick = rng.choice(4000, 32, replace=False)
+    edges = th.from_numpy(np.stack([src[pick], rng.integers(0, 3, 32), dst[pick]], 1)).to(gpu)
+    sub, samples, labels = generate_sampled_graph_and_labels_unsupervised(g, edges, 2, 6, 0.5, 3, th.Generator(device=gpu).manual_seed(3))
+    assert samples.shape == (128, 3) and float(labels.sum()) == 32 and labels[:32].min() == 1
+    nid = sub.ndata["_ID"]
+    assert th.equal(nid[samples[:32, 0]], edges[:, 0]) and th.equal(nid[samples[:32, 2]], edges[:, 2])
+    assert int(samples[:, [0, 2]].min()) >= 0 and int(samples[:, [0, 2]].max()) < sub.number_of_nodes()
+    assert sub.edata["norm"].shape == (sub.number_of_edges(), 1)
