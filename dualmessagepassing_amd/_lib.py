@@ -36,6 +36,9 @@ SIGNATURES = {
     "dmp_pattern_edge_active": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_subiso_edge_weights": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "dmp_class_tiles_segsum_words": (c_i64, [c_int]),
+    "dmp_class_tiles_workspace_words": (c_size, [c_i64, c_int]),
+    "dmp_class_tiles": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_scan_workspace_words": (c_size, [c_i64]),
     "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr]),
@@ -80,7 +83,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

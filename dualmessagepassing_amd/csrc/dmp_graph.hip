@@ -438,6 +438,195 @@ __global__ void subiso_edge_k(const int64_t *sub, const int64_t *sample_ptr, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Degree-class tile list of the typed edge kernels (csrc/dmp_typed.hip), built on the device in five
+// launches without atomics deciding any order: slot order = class ascending, nodes of a class in
+// ascending id, the in-edges of a node in ascending edge id (= its in-CSR row).
+//   deg[v]   : the integer degree the layer's coefficient is computed from (class key), clamped to C-1
+//   cnt[c]   : in-edges whose destination has degree c
+//   tile_off : exclusive prefix of ceil(cnt[c] / 32) (tiles never mix classes)
+// ---------------------------------------------------------------------------------------------
+constexpr int kCtLdsBins = 4096;
+
+__global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                    int64_t N, int C, unsigned long long *cnt, int32_t *status) {
+  __shared__ unsigned int h[kCtLdsBins];
+  for (int i = threadIdx.x; i < kCtLdsBins; i += kBlock) h[i] = 0u;
+  __syncthreads();
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v < N) {
+    const unsigned int d = (unsigned int)(in_ptr[v + 1] - in_ptr[v]);
+    int64_t k = deg[v];
+    if (k < 0) k = 0;
+    if (k >= C - 1) {
+      if (k > C - 1 && d > 0 && status) atomicOr(status, 1);   // classes beyond the table share (and poison) the last one
+      k = C - 1;
+    }
+    if (d > 0) {
+      if (k < kCtLdsBins) atomicAdd(&h[k], d);                 // integer sums: the result does not depend on the order
+      else atomicAdd(cnt + k, (unsigned long long)d);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kCtLdsBins && i < C; i += kBlock)
+    if (h[i]) atomicAdd(cnt + i, (unsigned long long)h[i]);
+}
+
+// one block: tile_off[c] = sum_{c' < c} ceil(cnt[c'] / 32); tile_off[C] = tiles in use (also to num_tiles)
+__global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__restrict__ cnt, int C, int32_t *tile_off,
+                                                  int32_t *num_tiles) {
+  __shared__ int part[1024];
+  const int per = (C + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < C ? lo + per : C;
+  int sum = 0;
+  for (int c0 = lo; c0 < hi; c0 += 16) {                       // 16 independent loads in flight
+    unsigned long long v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = c0 + j < hi ? cnt[c0 + j] : 0ull;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += (int)((v[j] + 31) >> 5);
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {                   // inclusive Hillis-Steele scan of the 1024 partial sums
+    const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - sum;
+  for (int c = lo; c < hi; ++c) {
+    tile_off[c] = run;
+    run += (int)((cnt[c] + 31) >> 5);
+  }
+  if (threadIdx.x == 1023) { tile_off[C] = part[1023]; *num_tiles = part[1023]; }
+}
+
+// node_base[v] = first slot of v's in-edges = 32 * tile_off[class] + in-edges of the class's nodes with a lower id.
+// One wave per (class, node segment) walks its nodes in ascending id, 64 at a time, with a wave scan;
+// the common classes (degree < kCtFast) split the node range into kCtSegs segments whose totals are
+// taken in a first pass (ct_seg_k), rarer classes (hubs) walk the whole range with one wave.
+// The class's wave of segment 0 also writes the class's coefficient into its tiles.
+constexpr int kCtFast = 1024;
+constexpr int kCtSegs = 32;
+
+__device__ __forceinline__ int ct_key(const int64_t *deg, int64_t v, int C) {
+  const int64_t k = deg[v];
+  return (int)(k < 0 ? 0 : (k > C - 1 ? C - 1 : k));
+}
+
+__device__ __forceinline__ void ct_class_seg(int w, int C, int64_t N, int &c, int64_t &lo, int64_t &hi) {
+  // waves [0, kCtFast * kCtSegs): (class, node segment) of the common classes
+  c = w / kCtSegs;
+  const int64_t per = ((N + kCtSegs - 1) / kCtSegs + 63) & ~(int64_t)63;
+  lo = (int64_t)(w % kCtSegs) * per;
+  hi = lo + per < N ? lo + per : N;
+  if (lo > N) lo = N;
+}
+
+__global__ __launch_bounds__(kBlock) void ct_seg_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                   int64_t N, int C, const unsigned long long *__restrict__ cnt,
+                                                   int32_t *segsum) {
+  const int w = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int fast = C < kCtFast ? C : kCtFast;
+  if (w >= fast * kCtSegs) return;
+  int c;
+  int64_t lo, hi;
+  ct_class_seg(w, C, N, c, lo, hi);
+  if (cnt[c] == 0) return;
+  int sum = 0;
+  for (int64_t v0 = lo + lane; v0 < hi; v0 += 256) {           // 4 independent chunks of 64 nodes in flight
+    int k[4], a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t v = v0 + 64 * j;
+      const bool ok = v < hi;
+      k[j] = ok ? ct_key(deg, v, C) : -1;
+      a[j] = ok ? in_ptr[v] : 0;
+      b[j] = ok ? in_ptr[v + 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += k[j] == c ? b[j] - a[j] : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);   // integer: order-free
+  if (lane == 0) segsum[w] = sum;
+}
+
+constexpr int kCtSlowWaves = 256;   // workers that share the rare classes >= kCtFast among themselves
+
+__device__ __forceinline__ void ct_walk(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr, int C, int c,
+                                        int64_t lo, int64_t hi, int running, int lane, int32_t *node_base) {
+  auto fetch = [&](int64_t v, int &k, int &d) {
+    k = -1; d = 0;
+    if (v < hi) { k = ct_key(deg, v, C); d = in_ptr[v + 1] - in_ptr[v]; }
+  };
+  int kn, dn;
+  fetch(lo + lane, kn, dn);
+  for (int64_t base = lo; base < hi; base += 64) {
+    const int64_t v = base + lane;
+    const bool m = kn == c;
+    const int d = m ? dn : 0;
+    fetch(v + 64, kn, dn);                                     // next 64 nodes: in flight under the scan
+    int incl = d;                                              // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (m) node_base[v] = running + incl - d;
+    running += __shfl(incl, 63, 64);
+  }
+}
+
+__device__ __forceinline__ void ct_write_scale(int c, int C, const int32_t *status, int t0, int t1, int lane, float *tile_scale) {
+  float scale = 2.0f * (1.0f + log2f(1.0f + (float)c));        // == degree_coef_k for this degree
+  if (c == C - 1 && status && *status) scale = __builtin_nanf("");
+  for (int t = t0 + lane; t < t1; t += 64) tile_scale[t] = scale;
+}
+
+__global__ __launch_bounds__(kBlock) void ct_base_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                    int64_t N, int C, const unsigned long long *__restrict__ cnt,
+                                                    const int32_t *__restrict__ tile_off, const int32_t *__restrict__ status,
+                                                    const int32_t *__restrict__ segsum, int32_t *node_base, float *tile_scale) {
+  const int w = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int fast = C < kCtFast ? C : kCtFast;
+  if (w < fast * kCtSegs) {
+    int c;
+    int64_t lo, hi;
+    ct_class_seg(w, C, N, c, lo, hi);
+    if (cnt[c] == 0) return;
+    const int s = w % kCtSegs;
+    int running = tile_off[c] * 32;
+    for (int j = 0; j < s; ++j) running += segsum[w - s + j];
+    if (s == 0) ct_write_scale(c, C, status, tile_off[c], tile_off[c + 1], lane, tile_scale);
+    ct_walk(deg, in_ptr, C, c, lo, hi, running, lane, node_base);
+  } else if (w < fast * kCtSegs + kCtSlowWaves) {
+    // this worker's contiguous share of the rare classes; 64 of them are tested at a time (one per lane)
+    const int per = (C - fast + kCtSlowWaves - 1) / kCtSlowWaves;
+    const int c_lo = fast + (w - fast * kCtSegs) * per, c_hi = c_lo + per < C ? c_lo + per : C;
+    for (int cb = c_lo; cb < c_hi; cb += 64) {
+      const int cl = cb + lane;
+      unsigned long long live = __ballot(cl < c_hi && cnt[cl] != 0);
+      while (live) {
+        const int c = cb + __builtin_ctzll(live);
+        live &= live - 1;
+        ct_write_scale(c, C, status, tile_off[c], tile_off[c + 1], lane, tile_scale);
+        ct_walk(deg, in_ptr, C, c, 0, N, tile_off[c] * 32, lane, node_base);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                    const int32_t *__restrict__ node_base, int64_t N, int32_t *slot_edge) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v >= N) return;
+  const int lo = in_ptr[v], hi = in_ptr[v + 1];
+  if (hi == lo) return;
+  int s = node_base[v];
+  for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -645,6 +834,46 @@ int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample
                                                     p_dst, p_label, active, g_node_off, g_out_ptr, g_out_ent,
                                                     g_dst, g_label, reinterpret_cast<unsigned long long *>(out),
                                                     status);
+  return check_launch();
+}
+
+int64_t dmp_class_tiles_segsum_words(int num_classes) {
+  return (int64_t)(num_classes < kCtFast ? num_classes : kCtFast) * kCtSegs;
+}
+
+size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
+  // int32 words: [cnt 2C | status 1 | pad 1 | tile_off C+1 | segsum | node_base N]
+  if (num_nodes < 0 || num_classes < 2) return 0;
+  return (size_t)(2 * (int64_t)num_classes + 2 + num_classes + 1 + dmp_class_tiles_segsum_words(num_classes) + num_nodes + 8);
+}
+
+int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t N, int64_t E,
+                    int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge, float *tile_scale,
+                    int32_t *num_tiles, void *stream) {
+  if (N < 0 || E < 0 || num_classes < 2 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+  if (!ws || !slot_edge || !tile_scale || !num_tiles) return DMP_ERR_BAD_ARG;
+  if (N > 0 && (!deg || !in_ptr)) return DMP_ERR_BAD_ARG;
+  if (E > 0 && !in_ent) return DMP_ERR_BAD_ARG;
+  if (tiles_bound < E / 32 + num_classes) return DMP_ERR_BAD_ARG;      // every class may add one partial tile
+  if ((reinterpret_cast<uintptr_t>(ws) & 7u) != 0) return DMP_ERR_BAD_ARG;
+  unsigned long long *cnt = reinterpret_cast<unsigned long long *>(ws);
+  int32_t *status = ws + 2 * (int64_t)num_classes;
+  int32_t *tile_off = status + 2;
+  int32_t *segsum = tile_off + num_classes + 1;
+  int32_t *node_base = segsum + dmp_class_tiles_segsum_words(num_classes);
+  hipStream_t st = (hipStream_t)stream;
+  DMP_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int32_t) * (size_t)(2 * (int64_t)num_classes + 2), st));    // counters + status
+  DMP_HIP_TRY(hipMemsetAsync(slot_edge, 0xFF, sizeof(int32_t) * (size_t)tiles_bound * 32, st));      // -1 = padding
+  if (N > 0) ct_hist_k<<<nblk(N), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, status);
+  ct_scan_k<<<1, 1024, 0, st>>>(cnt, num_classes, tile_off, num_tiles);
+  if (N > 0) {
+    const int fast = num_classes < kCtFast ? num_classes : kCtFast;
+    const int64_t waves = (int64_t)fast * kCtSegs + kCtSlowWaves;
+    ct_seg_k<<<nblk((int64_t)fast * kCtSegs * 64), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, segsum);
+    ct_base_k<<<nblk(waves * 64), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, tile_off, status, segsum, node_base,
+                                                  tile_scale);
+    ct_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, node_base, N, slot_edge);
+  }
   return check_launch();
 }
 

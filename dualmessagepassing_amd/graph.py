@@ -106,6 +106,7 @@ class GraphIndex:
             c = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
             check(lib.dmp_degree_coef(ptr(out_deg), self.num_nodes, ptr(c), stream_ptr()), "dmp_degree_coef")
             self._coef = {key: c}
+            self._coef_deg = (c, out_deg)    # the integer degrees this coefficient tensor was computed from
         return c
 
     def edge_select(self, coef):
@@ -133,39 +134,63 @@ class GraphIndex:
         values) and cut into tiles of 32 that never mix values.  Returns ``(slot_edge int32
         [tiles_bound * 32] (-1 = padding), tile_scale float [tiles_bound], num_tiles int32 [1] (device),
         tiles_bound (host int))``.  No host sync: the number of tiles in use stays on the device and the
-        arrays are sized by a host-side bound.  More than MAX_EDGE_CLASSES distinct values poison the
-        overflow class with NaN (loud, not silently wrong).  Cached per coefficient tensor."""
+        arrays are sized by a host-side bound.  More than MAX_EDGE_CLASSES classes poison the overflow
+        class with NaN (loud, not silently wrong).  Cached per coefficient tensor.  When the coefficient
+        is this index's own ``degree_coef`` the list is built by ``dmp_class_tiles`` from the integer
+        degrees; otherwise by a value sort."""
         key = (coef.data_ptr(), coef._version)
         cached = getattr(self, "_ctiles", None)
         if cached is None or cached[0] != key:
-            E, dev = self.num_edges, self.device
-            C = max(1, min(self.MAX_EDGE_CLASSES, E))
-            bound = E // 32 + C + 1
-            coef_e = self.edge_select(coef)[2]
-            slot_edge = torch.full((bound * 32,), -1, dtype=torch.int32, device=dev)
-            if E == 0:
-                res = (slot_edge, torch.zeros(bound, dtype=torch.float32, device=dev),
-                       torch.zeros(1, dtype=torch.int32, device=dev), bound)
+            src = getattr(self, "_coef_deg", None)
+            if src is not None and src[0] is coef and self.num_edges > 0:
+                res = self._class_tiles_device(src[1])
             else:
-                vals, order = torch.sort(coef_e, stable=True)
-                cidx = torch.zeros(E, dtype=torch.int64, device=dev)
-                torch.cumsum(vals[1:] != vals[:-1], 0, out=cidx[1:])      # class of each sorted position
-                over = cidx[-1] >= C - 1
-                cidx.clamp_(max=C - 1)
-                # cidx is sorted: class sizes from its boundaries (a bincount would serialise its atomics
-                # on the handful of hot bins: 5 ms at E = 549 k)
-                marks = torch.searchsorted(cidx, torch.arange(C + 1, device=dev))
-                seg_start, cnt = marks[:-1], marks[1:] - marks[:-1]
-                ntile = (cnt + 31) >> 5
-                tile_end = torch.cumsum(ntile, 0)
-                slot = (tile_end - ntile)[cidx] * 32 + (torch.arange(E, device=dev) - seg_start[cidx])
-                slot_edge[slot] = order.to(torch.int32)
-                tile_class = torch.searchsorted(tile_end, torch.arange(bound, device=dev), right=True).clamp_(max=C - 1)
-                tile_scale = vals[seg_start.clamp(max=E - 1)][tile_class]
-                tile_scale = torch.where((tile_class == C - 1) & over, torch.full_like(tile_scale, float("nan")), tile_scale)
-                res = (slot_edge, tile_scale.contiguous(), tile_end[-1:].to(torch.int32), bound)
+                res = self._class_tiles_by_value(coef)
             self._ctiles = cached = (key, res, coef)
         return cached[1]
+
+    def _class_tiles_device(self, deg):
+        """``coef`` came from ``degree_coef(deg)``: classes are the integer degrees; five HIP launches
+        (``dmp_class_tiles``), slot order = class, node id, edge id."""
+        lib = _lib.load()
+        E, N, C, dev = self.num_edges, self.num_nodes, self.MAX_EDGE_CLASSES, self.device
+        bound = E // 32 + C + 1
+        slot_edge = torch.empty(bound * 32, dtype=torch.int32, device=dev)
+        tile_scale = torch.empty(bound, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.dmp_class_tiles_workspace_words(N, C)) + 2, dtype=torch.int32, device=dev)
+        num_tiles = ws[-1:]                                    # allocations are 8-byte aligned; the tail word is ours
+        check(lib.dmp_class_tiles(ptr(deg), ptr(self.in_ptr), ptr(self.in_ent), N, E, C, bound, ptr(ws), ptr(slot_edge),
+                                  ptr(tile_scale), ptr(num_tiles), stream_ptr()), "dmp_class_tiles")
+        return slot_edge, tile_scale, num_tiles, bound
+
+    def _class_tiles_by_value(self, coef):
+        """Generic fallback (a coefficient tensor of unknown origin): classes = distinct values of
+        ``coef[dst]``, found by a value sort with a handful of tensor ops."""
+        E, dev = self.num_edges, self.device
+        C = max(1, min(self.MAX_EDGE_CLASSES, E))
+        bound = E // 32 + C + 1
+        coef_e = self.edge_select(coef)[2]
+        slot_edge = torch.full((bound * 32,), -1, dtype=torch.int32, device=dev)
+        if E == 0:
+            return (slot_edge, torch.zeros(bound, dtype=torch.float32, device=dev),
+                    torch.zeros(1, dtype=torch.int32, device=dev), bound)
+        vals, order = torch.sort(coef_e, stable=True)
+        cidx = torch.zeros(E, dtype=torch.int64, device=dev)
+        torch.cumsum(vals[1:] != vals[:-1], 0, out=cidx[1:])      # class of each sorted position
+        over = cidx[-1] >= C - 1
+        cidx.clamp_(max=C - 1)
+        # cidx is sorted: class sizes from its boundaries (a bincount would serialise its atomics
+        # on the handful of hot bins: 5 ms at E = 549 k)
+        marks = torch.searchsorted(cidx, torch.arange(C + 1, device=dev))
+        seg_start, cnt = marks[:-1], marks[1:] - marks[:-1]
+        ntile = (cnt + 31) >> 5
+        tile_end = torch.cumsum(ntile, 0)
+        slot = (tile_end - ntile)[cidx] * 32 + (torch.arange(E, device=dev) - seg_start[cidx])
+        slot_edge[slot] = order.to(torch.int32)
+        tile_class = torch.searchsorted(tile_end, torch.arange(bound, device=dev), right=True).clamp_(max=C - 1)
+        tile_scale = vals[seg_start.clamp(max=E - 1)][tile_class]
+        tile_scale = torch.where((tile_class == C - 1) & over, torch.full_like(tile_scale, float("nan")), tile_scale)
+        return slot_edge, tile_scale.contiguous(), tile_end[-1:].to(torch.int32), bound
 
 
 class _Gather:

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 10
+#define DMP_ABI_VERSION 11
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -202,6 +202,24 @@ int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample
                             const int32_t *g_out_ptr, const int32_t *g_out_ent, const int32_t *g_dst,
                             const int64_t *g_label, int64_t *out, int64_t E, int64_t work_hint,
                             int32_t *status, void *stream);
+
+/*
+ * Tile list of the class-typed edge kernels, built on the device (no host sync, no order decided by
+ * atomics): edges grouped by the degree `deg[dst]` their coefficient is computed from, classes
+ * ascending, nodes of a class in ascending id, the in-edges of a node in ascending edge id; every
+ * class starts a new 32-slot tile.
+ *   deg [N] int64 (the tensor passed to dmp_degree_coef), in_ptr / in_ent: CSR by destination;
+ *   num_classes: size of the class table (degrees >= num_classes - 1 share -- and poison with NaN --
+ *   the last class; status is set to 1 then); tiles_bound >= E / 32 + num_classes.
+ *   out: slot_edge [tiles_bound * 32] (-1 = padding), tile_scale [tiles_bound] = dmp_degree_coef of the
+ *   tile's class (entries past num_tiles are not written), num_tiles [1];
+ *   ws: 8-byte aligned scratch of dmp_class_tiles_workspace_words(N, num_classes) int32 words.
+ */
+int64_t dmp_class_tiles_segsum_words(int num_classes);
+size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes);
+int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t num_nodes,
+                    int64_t num_edges, int num_classes, int64_t tiles_bound, int32_t *ws,
+                    int32_t *slot_edge, float *tile_scale, int32_t *num_tiles, void *stream);
 
 /* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
  * ws: scratch of dmp_scan_workspace_words(n) int64 words. */

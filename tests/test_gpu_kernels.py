@@ -386,16 +386,25 @@ def test_typed_edge_kernels_equal_untyped(rows, gpu):
     rev = rng.random(rows) < 0.5
     ix = _index(src, dst, n, rev, gpu)
     coef = ix.degree_coef(ix.out_deg)
-    slot_edge, tile_scale, num_tiles, bound = ix.class_tiles(coef)
-    nt = int(num_tiles.item())
-    se = slot_edge.view(-1, 32)[:nt].cpu().numpy()
-    assert sorted(se[se >= 0].tolist()) == list(range(rows))                      # every edge in exactly one slot
     ce = ix.edge_select(coef)[2].cpu().numpy()
-    ts = tile_scale[:nt].cpu().numpy()
-    for t in range(nt):
-        ids = se[t][se[t] >= 0]
-        assert len(ids) > 0 and np.all(ce[ids] == ts[t])                           # one class per tile, its own scale
-    assert nt <= rows // 32 + len(np.unique(ce)) and (se[nt:] == -1).all() if nt < len(se) else True
+    builds = {"device": ix.class_tiles(coef), "by_value": ix._class_tiles_by_value(coef)}
+    for how, (slot_edge, tile_scale, num_tiles, bound) in builds.items():
+        nt = int(num_tiles.item())
+        full = slot_edge.view(-1, 32).cpu().numpy()
+        se = full[:nt]
+        assert sorted(se[se >= 0].tolist()) == list(range(rows)), how             # every edge in exactly one slot
+        assert (full[nt:] == -1).all(), how
+        ts = tile_scale[:nt].cpu().numpy()
+        for t in range(nt):
+            ids = se[t][se[t] >= 0]
+            assert len(ids) > 0 and np.all(ce[ids] == ts[t]), how                  # one class per tile, its own scale
+        assert nt <= rows // 32 + len(np.unique(ce)), how
+        assert np.all(np.diff(ts) >= 0), how                                       # classes ascending
+    # device builder: within a class nodes ascending, in-edges of a node in ascending edge id
+    se = builds["device"][0].view(-1)[:int(builds["device"][2].item()) * 32].cpu().numpy()
+    live = se[se >= 0]
+    keyed = np.stack([ce[live], dst[live], live], 1)
+    assert np.array_equal(keyed, keyed[np.lexsort((keyed[:, 2], keyed[:, 1], keyed[:, 0]))])
     z = th.randn(rows, h, generator=gen).to(gpu)
     wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
     xp = th.randn(n, 3 * h, generator=gen).to(gpu)
