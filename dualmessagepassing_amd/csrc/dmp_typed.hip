@@ -330,7 +330,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_typed_k(const float *Z, 
     fold(cur);
   }
   // accumulator (j, r) of wave w: row 32w + (r&3) + 8(r>>2) + 4h, column 32j + li
-  float *pt = partial_T + (int64_t)blockIdx.x * 128 * 128, *pb = partial_B + (int64_t)blockIdx.x * 128 * 128;
+  // partial_B == partial_T + 128*128 interleaves the two partials per workgroup ([G][2][H*H]: one reduction for both)
+  const int64_t pstride = partial_B == partial_T + 128 * 128 ? 2 * 128 * 128 : 128 * 128;
+  float *pt = partial_T + (int64_t)blockIdx.x * pstride, *pb = partial_B + (int64_t)blockIdx.x * pstride;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll

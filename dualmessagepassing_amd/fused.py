@@ -68,15 +68,18 @@ def scale_rows_colsum(d_out, gate):
     return (d_upd if gate is not None else d_out), reduce_partials(part)
 
 
-def relu_bwd_colsum_(d_h, act):
-    """In place: d_h <- act > 0 ? d_h : 0; returns (d_h, column sums [H])."""
+def relu_bwd_colsum_(d_h, act, out=None):
+    """d_h <- act > 0 ? d_h : 0 (in place, or into ``out``: e.g. a column slice of a wider matrix);
+    returns (result, column sums [H])."""
     lib = _lib.load()
     R, H = d_h.shape
     part = _partials(R, H, d_h.device)
+    dst = d_h if out is None else out
+    ldo = dst.stride(0) if R > 1 else H
     with _lib.timed("relu_bwd_colsum[H=%d,R=%d]" % (H, R), 12 * H * R):
-        check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, ptr(d_h), H, ptr(part), stream_ptr()),
+        check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, ptr(dst), ldo, ptr(part), stream_ptr()),
               "dmp_relu_bwd_colsum")
-    return d_h, reduce_partials(part)
+    return dst, reduce_partials(part)
 
 
 def bwd_g_colsum(d_y, coef, dst32):
@@ -199,20 +202,18 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
 
 
 def atb_typed(z, d_pre, coef, index):
-    """[z^T d_pre | z^T (coef[dst] (.) d_pre)]  ([H, 2H]) over the class-sorted tiles: one product's worth of
-    MFMAs for both halves (csrc/dmp_typed.hip::atb_typed_k), fixed-order reduction of the workgroup partials."""
+    """``(z^T d_pre, z^T (coef[dst] (.) d_pre))``  (two [H, H]) over the class-sorted tiles: one product's worth
+    of MFMAs for both (csrc/dmp_typed.hip::atb_typed_k), one fixed-order reduction of the workgroup partials."""
     lib = _lib.load()
     E, H = z.shape
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     G = int(lib.dmp_atb_typed_blocks(bound))
-    part = torch.empty((2, G, H * H), dtype=torch.float32, device=z.device)
+    part = torch.empty((G, 2, H * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]" % (H, E), 8 * H * E):
         check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
-                                ptr(num_tiles), bound, E, H, ptr(part[0]), ptr(part[1]), stream_ptr()), "dmp_atb_typed")
-    out = torch.empty((H, 2 * H), dtype=torch.float32, device=z.device)
-    out[:, :H] = reduce_partials(part[0]).view(H, H)
-    out[:, H:] = reduce_partials(part[1]).view(H, H)
-    return out
+                                ptr(num_tiles), bound, E, H, ptr(part), ptr(part[0, 1]), stream_ptr()), "dmp_atb_typed")
+    both = reduce_partials(part.view(G, -1)).view(2, H, H)
+    return both[0], both[1]
 
 
 def out_fwd_mfma(h1, W2, b2, gate, prev):
@@ -317,16 +318,20 @@ class _FusedDMPLayer(torch.autograd.Function):
             dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
             del dH1e
         inc_ptr, inc_ent = ix.incidence()
-        dP = ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
-        dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)  # [H,2H] = [dA_e | dB_e]
+        dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
+        ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:])
+        if typed:
+            dAe, dBe = atb_typed(z, dG, coef, ix)
+        else:
+            dWes = atb(z, dG)                                        # [H,2H] = [dA_e | dB_e]
+            dAe, dBe = dWes[:, :H], dWes[:, H:]
         # ---- node side
         dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
         dW2n = atb(dOn, H1n)
         dH1n = dOn @ nW2
-        dPn, dbn = relu_bwd_colsum_(dH1n, H1n)
+        dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
         dS = dPn @ Bn.t()
         dBn = atb(S, dPn)                                            # [2H,H]
-        dXP = torch.cat([dPn, dP], dim=1)                            # [N,3H]
         dWx = atb(x, dXP)                                            # [H,3H] = [dA_n | dPd | dPs]
         dx = None
         if ctx.needs_input_grad[3]:
@@ -347,7 +352,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         dCn = torch.cat([dWx[:, :H], dBn, dbn.unsqueeze(0)], dim=0)                  # [3H+1, H]
         dMn = dCn @ nW0
         dW0n = dCn.t() @ Mn
-        dCe = torch.cat([dWes[:, :H], dWes[:, H:], dWx[:, H:2 * H], dWx[:, 2 * H:], dbe.unsqueeze(0)], dim=0)
+        dCe = torch.cat([dAe, dBe, dWx[:, H:2 * H], dWx[:, 2 * H:], dbe.unsqueeze(0)], dim=0)
         dMe = dCe @ eW0
         dW0e = dCe.t() @ Me
         d_nloop, d_in, d_out, dnb = dMn[:H], dMn[H:2 * H], dMn[2 * H:3 * H], dMn[3 * H]

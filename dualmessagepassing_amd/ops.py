@@ -40,12 +40,18 @@ def _vec(t, dtype):
 
 
 # ----------------------------------------------------------------------------- raw launches
-def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True):
+def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None):
+    """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride)."""
     lib = _lib.load()
     _lib.require_gpu(M, rowptr, ent, edge_w)
     M, ldm = _mat(M)
     H = M.size(1)
-    out = torch.empty((num_nodes, 2 * H if split else H), dtype=torch.float32, device=M.device)
+    width = 2 * H if split else H
+    if out is None:
+        out = torch.empty((num_nodes, width), dtype=torch.float32, device=M.device)
+    elif out.shape != (num_nodes, width) or out.dtype != torch.float32 or (num_nodes > 1 and out.stride(1) != 1):
+        raise _lib.DmpError("seg_sum: bad out tensor")
+    ldo = out.stride(0) if num_nodes > 1 else max(out.size(1), 1)
     ew = _vec(edge_w, torch.float32)
     nent = ent.numel()
     # algorithmic bytes: every source row once, every output row once, the CSR arrays once
@@ -54,11 +60,11 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,
-                                   ptr(out), out.size(1), int(rows_shared), stream_ptr()), "dmp_seg_sum2")
+                                   ptr(out), ldo, int(rows_shared), stream_ptr()), "dmp_seg_sum2")
     else:
         with _lib.timed("seg_sum[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H,
-                                  ptr(out), out.size(1), int(rows_shared), stream_ptr()), "dmp_seg_sum")
+                                  ptr(out), ldo, int(rows_shared), stream_ptr()), "dmp_seg_sum")
     return out
 
 

@@ -473,7 +473,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  * Z[e]^T dPre[e]  ([H,H]),  dA' = sum_c G_c  and  dB' = sum_c c_c G_c  (the two halves of dW for
  * W = [A' | B']) from ONE pass and one product's worth of MFMAs.  Every workgroup walks a contiguous
  * range of the class-sorted tiles and writes two [H,H] partials (running total, coefficient-weighted
- * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats, to be summed with
+ * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats each -- or, when
+ * partial_B == partial_T + H*H, one interleaved [blocks, 2, H*H] buffer --, to be summed with
  * dmp_reduce_partials (fixed order: bit-stable for a given tile list).
  */
 int64_t dmp_atb_typed_blocks(int64_t tiles_bound);
