@@ -472,33 +472,52 @@ __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ 
     if (h[i]) atomicAdd(cnt + i, (unsigned long long)h[i]);
 }
 
-// one block: tile_off[c] = sum_{c' < c} ceil(cnt[c'] / 32); tile_off[C] = tiles in use (also to num_tiles)
+// one block: tile_off[c] = sum_{c' < c} ceil(cnt[c'] / 32); tile_off[C] = tiles in use (also to num_tiles).
+// Class c = j * 1024 + t sits in row j (<= 64 rows: C <= 65536), column t = thread: coalesced loads all in
+// flight at once, a wave scan per row, then one scan over the (row, wave) totals in row-major order.
 __global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__restrict__ cnt, int C, int32_t *tile_off,
                                                   int32_t *num_tiles) {
-  __shared__ int part[1024];
-  const int per = (C + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < C ? lo + per : C;
-  int sum = 0;
-  for (int c0 = lo; c0 < hi; c0 += 16) {                       // 16 independent loads in flight
-    unsigned long long v[16];
+  constexpr int kRows = 64;
+  __shared__ int part[kRows * 16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rows = (C + 1023) >> 10;
+  int v[kRows];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = c0 + j < hi ? cnt[c0 + j] : 0ull;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sum += (int)((v[j] + 31) >> 5);
+  for (int j = 0; j < kRows; ++j) {
+    const int c = j * 1024 + t;
+    v[j] = (j < rows && c < C) ? (int)((cnt[c] + 31) >> 5) : 0;
   }
-  part[threadIdx.x] = sum;
+#pragma unroll
+  for (int j = 0; j < kRows; ++j) {                            // inclusive scan of row j inside the wave
+    int x = v[j];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    v[j] = x;
+    if (lane == 63) part[j * 16 + wave] = x;
+  }
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {                   // inclusive Hillis-Steele scan of the 1024 partial sums
-    const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+  const int mine = part[t];
+  for (int off = 1; off < 1024; off <<= 1) {                   // inclusive Hillis-Steele scan of the 1024 (row, wave) totals
+    const int add = t >= off ? part[t - off] : 0;
     __syncthreads();
-    part[threadIdx.x] += add;
+    part[t] += add;
     __syncthreads();
   }
-  int run = part[threadIdx.x] - sum;
-  for (int c = lo; c < hi; ++c) {
-    tile_off[c] = run;
-    run += (int)((cnt[c] + 31) >> 5);
+  const int total = part[1023];
+  __syncthreads();
+  part[t] -= mine;                                             // exclusive
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kRows; ++j) {
+    const int c = j * 1024 + t;
+    if (j < rows && c < C) {
+      const int incl = v[j] + part[j * 16 + wave];
+      tile_off[c] = incl - (int)((cnt[c] + 31) >> 5);
+    }
   }
-  if (threadIdx.x == 1023) { tile_off[C] = part[1023]; *num_tiles = part[1023]; }
+  if (t == 0) { tile_off[C] = total; *num_tiles = total; }
 }
 
 // node_base[v] = first slot of v's in-edges = 32 * tile_off[class] + in-edges of the class's nodes with a lower id.
@@ -850,7 +869,7 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
 int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t N, int64_t E,
                     int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge, float *tile_scale,
                     int32_t *num_tiles, void *stream) {
-  if (N < 0 || E < 0 || num_classes < 2 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+  if (N < 0 || E < 0 || num_classes < 2 || num_classes > 65536 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (!ws || !slot_edge || !tile_scale || !num_tiles) return DMP_ERR_BAD_ARG;
   if (N > 0 && (!deg || !in_ptr)) return DMP_ERR_BAD_ARG;
   if (E > 0 && !in_ent) return DMP_ERR_BAD_ARG;

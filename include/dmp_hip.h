@@ -209,7 +209,7 @@ int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample
  * ascending, nodes of a class in ascending id, the in-edges of a node in ascending edge id; every
  * class starts a new 32-slot tile.
  *   deg [N] int64 (the tensor passed to dmp_degree_coef), in_ptr / in_ent: CSR by destination;
- *   num_classes: size of the class table (degrees >= num_classes - 1 share -- and poison with NaN --
+ *   num_classes: size of the class table, 2..65536 (degrees >= num_classes - 1 share -- and poison with NaN --
  *   the last class; status is set to 1 then); tiles_bound >= E / 32 + num_classes.
  *   out: slot_edge [tiles_bound * 32] (-1 = padding), tile_scale [tiles_bound] = dmp_degree_coef of the
  *   tile's class (entries past num_tiles are not written), num_tiles [1];
