@@ -115,8 +115,9 @@ def build_step(cfg, shard, device):
     torch.manual_seed(0)
     model = build_model(**model_config(cfg)).to(device)
     sync = FlatGradSync(model)
+    master = sync.flatten_parameters()      # one AdamW launch over the flat buffer: the same elementwise update
     sync.broadcast_parameters()
-    opt = torch.optim.AdamW(sync.params, lr=1e-4, weight_decay=1e-5, fused=True)
+    opt = torch.optim.AdamW([master], lr=1e-4, weight_decay=1e-5, fused=True)
 
     def step():
         sync.detach_grads()

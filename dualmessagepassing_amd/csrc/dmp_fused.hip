@@ -155,6 +155,48 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float *__
   }
 }
 
+// Several independent reductions in one launch: workgroup b serves segment i with blk0[i] <= b < blk0[i+1];
+// the order of the additions of every segment is that of reduce_partials_kernel.
+constexpr int kMaxSegments = DMP_REDUCE_MAX_SEGMENTS;
+struct ReduceSegs {
+  const float *partial[kMaxSegments];
+  float *out[kMaxSegments];
+  int64_t S[kMaxSegments], L[kMaxSegments];
+  int blk0[kMaxSegments + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const ReduceSegs a) {
+  constexpr int G = 32, GPB = kBlock / G;
+  __shared__ float4 red[kBlock];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.blk0[i + 1]) ++i;
+  const float *__restrict__ partial = a.partial[i];
+  const int64_t S = a.S[i], L = a.L[i];
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t l = ((int64_t)((int)blockIdx.x - a.blk0[i]) * G + lane) * 4;
+  float4 acc = zero4();
+  if (l < L) {
+    const int64_t per = (S + GPB - 1) / GPB;
+    const int64_t s0 = grp * per, s1 = min(S, s0 + per);
+    int64_t s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const float4 x = ld4(partial + s * L + l), y = ld4(partial + (s + 1) * L + l);
+      const float4 z = ld4(partial + (s + 2) * L + l), w = ld4(partial + (s + 3) * L + l);
+      add4(acc, x); add4(acc, y); add4(acc, z); add4(acc, w);
+    }
+    for (; s < s1; ++s) add4(acc, ld4(partial + s * L + l));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (grp == 0 && l < L) {
+    float4 t = red[lane];
+#pragma unroll
+    for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
+    st4(a.out[i] + l, t);
+  }
+}
+
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
 
 inline unsigned grid_for(int64_t R, int G) {
@@ -261,6 +303,27 @@ int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out, 
   hipStream_t st = (hipStream_t)stream;
   if (accumulate) reduce_partials_kernel<true><<<nb, kBlock, 0, st>>>(partial, S, L, out);
   else reduce_partials_kernel<false><<<nb, kBlock, 0, st>>>(partial, S, L, out);
+  return check_launch();
+}
+
+int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, const int64_t *L, float *const *outs,
+                              int n, void *stream) {
+  DMP_ROW_CHECK(n >= 0 && n <= kMaxSegments);
+  if (n == 0) return DMP_OK;
+  DMP_ROW_CHECK(partials && S && L && outs);
+  ReduceSegs a;
+  int64_t blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    DMP_ROW_CHECK(S[i] >= 0 && L[i] > 0 && outs[i] && (S[i] == 0 || partials[i]));
+    if (L[i] % 4 || !ok16(partials[i]) || !ok16(outs[i])) return DMP_ERR_UNSUPPORTED;
+    a.partial[i] = partials[i]; a.out[i] = outs[i]; a.S[i] = S[i]; a.L[i] = L[i];
+    a.blk0[i] = (int)blocks;
+    blocks += (L[i] / 4 + 31) / 32;
+    if (blocks > 0x7fffffff) return DMP_ERR_UNSUPPORTED;
+  }
+  a.blk0[n] = (int)blocks;
+  a.n = n;
+  reduce_partials_multi_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

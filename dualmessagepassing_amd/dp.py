@@ -51,6 +51,24 @@ class FlatGradSync:
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
+    def flatten_parameters(self):
+        """Move every parameter's storage into one contiguous buffer (each ``p.data`` becomes a view of
+        it) and return ONE ``nn.Parameter`` over that buffer whose ``.grad`` is the flat gradient:
+        an elementwise optimizer (Adam / AdamW / SGD with one parameter group) stepped on it performs
+        exactly the per-parameter updates, in one launch instead of one multi-tensor chunk list."""
+        if getattr(self, "master", None) is None:
+            store = torch.empty_like(self.flat)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                v = store[off:off + n].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                off += n
+            self.master = torch.nn.Parameter(store, requires_grad=True)
+            self.master.grad = self.flat
+        return self.master
+
     @property
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -84,6 +102,9 @@ class FlatGradSync:
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
+            if getattr(self, "master", None) is not None:
+                dist.broadcast(self.master.data, src=src, group=self.group)
+                return
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
 

@@ -35,6 +35,40 @@ def _partials(rows, H, dev):
     return torch.empty((int(lib.dmp_colsum_partial_rows(rows, H)), H), dtype=torch.float32, device=dev)
 
 
+MAX_REDUCE_SEGMENTS = 16   # DMP_REDUCE_MAX_SEGMENTS
+_deferred = []             # innermost active ``deferred_reductions`` collector last
+
+
+class deferred_reductions:
+    """Inside the block ``reduce_partials`` only records its job and returns the (not yet written) result
+    tensor; the jobs run as ONE launch (``dmp_reduce_partials_multi``) when the block is left.  For results
+    that are consumed later anyway -- a layer backward's parameter gradients: 9 reductions -> 1."""
+
+    def __enter__(self):
+        self.jobs = []
+        _deferred.append(self)
+        return self
+
+    def flush(self):
+        import ctypes
+        lib = _lib.load()
+        jobs, self.jobs = self.jobs, []
+        for i in range(0, len(jobs), MAX_REDUCE_SEGMENTS):
+            chunk = jobs[i:i + MAX_REDUCE_SEGMENTS]
+            n = len(chunk)
+            P = (ctypes.c_void_p * n)(*[ptr(j[0]) for j in chunk])
+            S = (ctypes.c_int64 * n)(*[j[1] for j in chunk])
+            L = (ctypes.c_int64 * n)(*[j[2] for j in chunk])
+            O = (ctypes.c_void_p * n)(*[ptr(j[3]) for j in chunk])
+            check(lib.dmp_reduce_partials_multi(P, S, L, O, n, stream_ptr()), "dmp_reduce_partials_multi")
+
+    def __exit__(self, exc_type, exc, tb):
+        _deferred.remove(self)
+        if exc_type is None:
+            self.flush()
+        return False
+
+
 def reduce_partials(partial, out=None, accumulate=False):
     """``out[l] (+)= sum_s partial[s, l]`` in a fixed order (HIP)."""
     lib = _lib.load()
@@ -42,6 +76,9 @@ def reduce_partials(partial, out=None, accumulate=False):
     L = partial.numel() // max(S, 1)
     if out is None:
         out = torch.empty(L, dtype=torch.float32, device=partial.device)
+    if _deferred and not accumulate and partial.is_contiguous():
+        _deferred[-1].jobs.append((partial, S, L, out))      # keeps ``partial`` alive until the launch
+        return out
     check(lib.dmp_reduce_partials(ptr(partial), S, L, ptr(out), int(accumulate), stream_ptr()), "dmp_reduce_partials")
     return out
 
@@ -110,11 +147,12 @@ def atb(a, b):
         return a.t() @ b
     S = R // rows
     main = S * rows
-    part = torch.bmm(a[:main].view(S, rows, a.size(1)).transpose(1, 2), b[:main].view(S, rows, b.size(1)))
-    out = reduce_partials(part.view(S, -1)).view(a.size(1), b.size(1))
-    if main < R:
-        out.addmm_(a[main:].t(), b[main:])
-    return out
+    tail = 1 if main < R else 0
+    part = torch.empty((S + tail, a.size(1), b.size(1)), dtype=a.dtype, device=a.device)
+    torch.bmm(a[:main].view(S, rows, a.size(1)).transpose(1, 2), b[:main].view(S, rows, b.size(1)), out=part[:S])
+    if tail:
+        torch.mm(a[main:].t(), b[main:], out=part[S])        # the ragged last slice: one more partial
+    return reduce_partials(part.view(S + tail, -1)).view(a.size(1), b.size(1))
 
 
 def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False):
@@ -307,47 +345,50 @@ class _FusedDMPLayer(torch.autograd.Function):
         ix, coef, H = ctx.index, ctx.coef, ctx.H
         N = ix.num_nodes
         dxn, dzn = dxn.contiguous(), dzn.contiguous()
-        # ---- edge side, down to the gathered node projections
-        dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
-        dW2e = atb(dOe, H1e)
-        mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
-        if mfma:
-            dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=not typed)  # dG[:, :H] is dPre
-        else:
-            dH1e = dOe @ eW2
-            dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
-            del dH1e
-        inc_ptr, inc_ent = ix.incidence()
-        dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
-        ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:])
-        if typed:
-            dAe, dBe = atb_typed(z, dG, coef, ix)
-        else:
-            dWes = atb(z, dG)                                        # [H,2H] = [dA_e | dB_e]
-            dAe, dBe = dWes[:, :H], dWes[:, H:]
-        # ---- node side
-        dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
-        dW2n = atb(dOn, H1n)
-        dH1n = dOn @ nW2
-        dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
-        dS = dPn @ Bn.t()
-        dBn = atb(S, dPn)                                            # [2H,H]
-        dWx = atb(x, dXP)                                            # [H,3H] = [dA_n | dPd | dPs]
-        dx = None
-        if ctx.needs_input_grad[3]:
-            dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
-        # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
-        dz = None
-        if ctx.needs_input_grad[4]:
+        # the parameter-gradient partials (biases, split-K weight gradients) are only consumed by the unfold step
+        # below: their nine reductions run as one launch when this block is left
+        with deferred_reductions():
+            # ---- edge side, down to the gathered node projections
+            dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
+            dW2e = atb(dOe, H1e)
+            mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
             if mfma:
-                if typed:
-                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix)
-                else:
-                    dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=not typed)  # dG[:, :H] is dPre
             else:
-                dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
-                                           base=dzn if ctx.residual else None)
-                dz.addmm_(dG, Wes.t())
+                dH1e = dOe @ eW2
+                dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
+                del dH1e
+            inc_ptr, inc_ent = ix.incidence()
+            dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
+            ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:])
+            if typed:
+                dAe, dBe = atb_typed(z, dG, coef, ix)
+            else:
+                dWes = atb(z, dG)                                        # [H,2H] = [dA_e | dB_e]
+                dAe, dBe = dWes[:, :H], dWes[:, H:]
+            # ---- node side
+            dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
+            dW2n = atb(dOn, H1n)
+            dH1n = dOn @ nW2
+            dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
+            dS = dPn @ Bn.t()
+            dBn = atb(S, dPn)                                            # [2H,H]
+            dWx = atb(x, dXP)                                            # [H,3H] = [dA_n | dPd | dPs]
+            dx = None
+            if ctx.needs_input_grad[3]:
+                dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
+            # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
+            dz = None
+            if ctx.needs_input_grad[4]:
+                if mfma:
+                    if typed:
+                        dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix)
+                    else:
+                        dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                else:
+                    dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
+                                               base=dzn if ctx.residual else None)
+                    dz.addmm_(dG, Wes.t())
         # ---- unfold: C = M @ W0^T  =>  dM = dC @ W0,  dW0 = dC^T @ M
         dCn = torch.cat([dWx[:, :H], dBn, dbn.unsqueeze(0)], dim=0)                  # [3H+1, H]
         dMn = dCn @ nW0

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 11
+#define DMP_ABI_VERSION 12
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -384,6 +384,13 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * split-K partial products of the weight gradients. */
 int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out,
                         int accumulate, void *stream);
+
+/* n <= DMP_REDUCE_MAX_SEGMENTS independent reductions in one launch (the partials of the parameter
+ * gradients of one layer's backward): outs[i][l] = sum_s partials[i][s, l], each in the order of
+ * dmp_reduce_partials.  The four arrays are HOST arrays of n entries (device pointers / sizes). */
+#define DMP_REDUCE_MAX_SEGMENTS 16
+int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, const int64_t *L,
+                              float *const *outs, int n, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */

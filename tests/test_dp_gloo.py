@@ -123,3 +123,25 @@ def test_pack_equals_accumulate_into_views():
         assert p.grad is not None and p.grad.data_ptr() >= s2.flat.data_ptr()
     s2.flat.mul_(2.0)
     assert torch.equal(s2.params[0].grad, s1.params[0].grad * 2.0)
+
+
+def test_flattened_parameters_step_like_per_parameter_adamw():
+    """flatten_parameters(): AdamW on the one flat parameter performs exactly the per-parameter updates
+    (elementwise optimizer, one parameter group), and the module keeps computing with the views."""
+    x, y = _data()
+    m1, m2 = Tiny(), Tiny()
+    s1, s2 = FlatGradSync(m1), FlatGradSync(m2)
+    master = s2.flatten_parameters()
+    assert s2.flatten_parameters() is master
+    o1 = torch.optim.AdamW(s1.params, lr=1e-2, weight_decay=1e-2)
+    o2 = torch.optim.AdamW([master], lr=1e-2, weight_decay=1e-2)
+    for _ in range(3):
+        for s, m, o in ((s1, m1, o1), (s2, m2, o2)):
+            s.detach_grads()
+            torch.nn.functional.mse_loss(m(x), y).backward()
+            s.pack()
+            o.step()
+    for p, q in zip(s1.params, s2.params):
+        assert torch.equal(p.data, q.data)
+        assert q.data.data_ptr() >= master.data.data_ptr()
+    assert master.grad is s2.flat

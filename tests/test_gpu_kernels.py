@@ -215,6 +215,29 @@ def test_row_epilogue_kernels(rows, h, gpu):
     assert th.allclose(out2, 2 * part.sum(0), rtol=1e-6, atol=1e-5)
 
 
+def test_deferred_reductions_equal_immediate(gpu):
+    """Reductions recorded inside ``deferred_reductions`` run as one multi-segment launch (two when more
+    than DMP_REDUCE_MAX_SEGMENTS jobs are queued) and give the bits of the one-at-a-time kernel."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(12)
+    shapes = [(1, 4), (7, 128), (1024, 128), (134, 16384), (3, 49152)] + [(5 + i, 4 * (i + 1)) for i in range(14)]
+    parts = [th.randn(s, l, generator=gen).to(gpu) for s, l in shapes]
+    want = [fused.reduce_partials(p) for p in parts]
+    with fused.deferred_reductions():
+        got = [fused.reduce_partials(p) for p in parts]
+    assert len(parts) > fused.MAX_REDUCE_SEGMENTS
+    for w, g, (s, l) in zip(want, got, shapes):
+        assert g.shape == (l,) and th.equal(w, g), (s, l)
+    # a job list left by an exception is dropped, not launched
+    try:
+        with fused.deferred_reductions():
+            fused.reduce_partials(parts[1])
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert not fused._deferred
+
+
 def test_split_k_weight_gradient_product(gpu):
     from dualmessagepassing_amd import fused
     gen = th.Generator().manual_seed(9)
