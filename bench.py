@@ -110,14 +110,14 @@ def model_config(cfg):
 def build_step(cfg, shard, device):
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device
-    from dualmessagepassing_amd.dp import FlatGradSync
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
 
     torch.manual_seed(0)
     model = build_model(**model_config(cfg)).to(device)
     sync = FlatGradSync(model)
     master = sync.flatten_parameters()      # one AdamW launch over the flat buffer: the same elementwise update
     sync.broadcast_parameters()
-    opt = torch.optim.AdamW([master], lr=1e-4, weight_decay=1e-5, fused=True)
+    opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True)   # the reference's optimizer (train.py:1231)
 
     def step():
         sync.detach_grads()

@@ -10,6 +10,7 @@ import threading
 from . import _build
 
 c_i64 = ctypes.c_int64
+c_double = ctypes.c_double
 c_int = ctypes.c_int
 c_f32 = ctypes.c_float
 c_ptr = ctypes.c_void_p
@@ -55,6 +56,8 @@ SIGNATURES = {
     "dmp_colsum_partials": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
+    "dmp_adamw_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
+                               c_double, c_i64, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_i64, c_int, c_ptr, c_i64, c_ptr]),
@@ -84,7 +87,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

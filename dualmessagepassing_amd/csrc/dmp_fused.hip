@@ -12,6 +12,8 @@
 //
 // All HBM-bound; G = H/4 lanes per row, float4 per lane, U rows in flight per group,
 // persistent workgroups (<= kMaxPartials) walking row chunks in a grid-stride loop.
+#include <math.h>
+
 #include "dmp_common.h"
 
 namespace dmp {
@@ -197,6 +199,48 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const Red
   }
 }
 
+// AdamW (decoupled weight decay, optional AMSGrad) over one flat fp32 buffer: torch.optim.AdamW's
+// single-tensor update, element by element, in one launch.
+struct AdamArgs {
+  float *p; const float *g; float *m, *v, *vmax;
+  int64_t n;
+  float decay, beta1_c, beta2, beta2_c, step_size, inv_bc2_sqrt, eps;
+};
+
+__global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < a.n; i += stride) {
+    float p[4], g[4], m[4], v[4], vm[4];
+    const bool full = i + 4 <= a.n;
+    const int cnt = full ? 4 : (int)(a.n - i);
+    if (full) {
+      *reinterpret_cast<float4 *>(p) = ld4(a.p + i); *reinterpret_cast<float4 *>(g) = ld4(a.g + i);
+      *reinterpret_cast<float4 *>(m) = ld4(a.m + i); *reinterpret_cast<float4 *>(v) = ld4(a.v + i);
+      if (a.vmax) *reinterpret_cast<float4 *>(vm) = ld4(a.vmax + i);
+    } else {
+      for (int k = 0; k < cnt; ++k) { p[k] = a.p[i + k]; g[k] = a.g[i + k]; m[k] = a.m[i + k]; v[k] = a.v[i + k]; if (a.vmax) vm[k] = a.vmax[i + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= cnt) break;
+      p[k] = p[k] * a.decay;
+      m[k] = m[k] + a.beta1_c * (g[k] - m[k]);
+      v[k] = v[k] * a.beta2 + a.beta2_c * g[k] * g[k];
+      float d = v[k];
+      if (a.vmax) { vm[k] = fmaxf(vm[k], v[k]); d = vm[k]; }
+      const float denom = __fsqrt_rn(d) * a.inv_bc2_sqrt + a.eps;
+      p[k] = p[k] - a.step_size * (m[k] / denom);
+    }
+    if (full) {
+      st4(a.p + i, *reinterpret_cast<float4 *>(p)); st4(a.m + i, *reinterpret_cast<float4 *>(m));
+      st4(a.v + i, *reinterpret_cast<float4 *>(v));
+      if (a.vmax) st4(a.vmax + i, *reinterpret_cast<float4 *>(vm));
+    } else {
+      for (int k = 0; k < cnt; ++k) { a.p[i + k] = p[k]; a.m[i + k] = m[k]; a.v[i + k] = v[k]; if (a.vmax) a.vmax[i + k] = vm[k]; }
+    }
+  }
+}
+
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
 
 inline unsigned grid_for(int64_t R, int G) {
@@ -324,6 +368,25 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
   a.blk0[n] = (int)blocks;
   a.n = n;
   reduce_partials_multi_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(a);
+  return check_launch();
+}
+
+int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                   int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                   void *stream) {
+  DMP_ROW_CHECK(n >= 0 && step >= 1 && lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
+  if (n == 0) return DMP_OK;
+  DMP_ROW_CHECK(param && grad && exp_avg && exp_avg_sq);
+  if (!ok16(param) || !ok16(grad) || !ok16(exp_avg) || !ok16(exp_avg_sq) || !ok16(max_exp_avg_sq)) return DMP_ERR_UNSUPPORTED;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2);
+  a.step_size = (float)(lr / bc1); a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); a.eps = (float)eps;
+  int64_t nb = (n / 4 + kBlock) / kBlock;
+  if (nb > 2048) nb = 2048;
+  adamw_kernel<<<(unsigned)nb, kBlock, 0, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

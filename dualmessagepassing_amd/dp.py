@@ -125,3 +125,40 @@ class FlatGradSync:
             work.wait()
             if self.average:
                 self.flat.div_(self.world)
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` (optionally ``amsgrad``: the reference's optimizer, train.py:1231) whose step is
+    ONE HIP launch per parameter tensor (``dmp_adamw_step``) -- meant for the single flat parameter of
+    ``FlatGradSync.flatten_parameters()``.  Learning-rate schedulers work as usual (``param_groups``).
+    fp32 contiguous CUDA parameters only; no CPU path."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_gpu(p, p.grad)
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise ValueError("FlatAdamW needs contiguous fp32 parameters and gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                    if group["amsgrad"]:
+                        st["max_exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                _lib.check(lib.dmp_adamw_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                              st["exp_avg_sq"].data_ptr(), _lib.ptr(st.get("max_exp_avg_sq")), p.numel(),
+                                              float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"],
+                                              _lib.stream_ptr()), "dmp_adamw_step")
+        return loss

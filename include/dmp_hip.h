@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 12
+#define DMP_ABI_VERSION 13
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -391,6 +391,17 @@ int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out,
 #define DMP_REDUCE_MAX_SEGMENTS 16
 int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, const int64_t *L,
                               float *const *outs, int n, void *stream);
+
+/*
+ * One AdamW step over a flat fp32 buffer (the optimizer of SubgraphCountingMatching/train.py:1231:
+ * AdamW(lr, weight_decay, amsgrad=True); torch.optim.AdamW's update, element by element):
+ *     p *= 1 - lr * weight_decay;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g^2;
+ *     [vmax = max(vmax, v)];  p -= lr / (1 - beta1^step) * m / (sqrt(vmax or v) / sqrt(1 - beta2^step) + eps)
+ * max_exp_avg_sq NULL: no AMSGrad.  step counts from 1.  All buffers [n], 16-byte aligned.
+ */
+int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int64_t step, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */

@@ -88,3 +88,32 @@ def test_fit_from_dataset_directory(tmp_path, gpu):
     again = build_model(**dataio.load_config(os.path.join(run, "config.json"))).to(gpu)
     again.load_state_dict(th.load(dataio.checkpoint_path(run, best[0]), map_location=gpu))
     assert evaluate_epoch(again, dev, 32, gpu)["eval_metric"] == pytest.approx(best[1], abs=1e-4)
+
+
+@pytest.mark.parametrize("amsgrad", [False, True])
+@pytest.mark.parametrize("n", [1, 7, 4096, 600_001])
+def test_flat_adamw_matches_torch_adamw(n, amsgrad, gpu):
+    """dp.FlatAdamW (one HIP launch, dmp_adamw_step) against torch.optim.AdamW on the same gradients:
+    the update of train.py:1231, including bias correction over several steps and a changed lr."""
+    from dualmessagepassing_amd.dp import FlatAdamW
+    gen = th.Generator().manual_seed(n)
+    p0 = th.randn(n, generator=gen)
+    a = th.nn.Parameter(p0.clone().to(gpu))
+    b = th.nn.Parameter(p0.clone().to(gpu))
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, amsgrad=amsgrad)
+    oa, ob = FlatAdamW([a], **kw), th.optim.AdamW([b], **kw)
+    for it in range(6):
+        g = (th.randn(n, generator=gen) * (10.0 if it == 2 else 1.0)).to(gpu)   # a spike: AMSGrad's max matters afterwards
+        a.grad, b.grad = g.clone(), g.clone()
+        if it == 4:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 1e-3
+        oa.step()
+        ob.step()
+        assert th.allclose(a.data, b.data, rtol=2e-6, atol=2e-7), (it, (a.data - b.data).abs().max().item())
+    st = oa.state[a]
+    assert st["step"] == 6 and ("max_exp_avg_sq" in st) == amsgrad
+    c = th.nn.Parameter(th.zeros(4))
+    c.grad = th.zeros(4)
+    with pytest.raises(Exception, match="GPU only"):
+        FlatAdamW([c]).step()                                                       # CPU tensors are refused
