@@ -1,0 +1,312 @@
+// Weight gradients of the edge chain as tall-skinny products  T = Z^T D  ([E,128]^T [E,128] -> [128,128],
+// the contraction runs over the edges), fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   dmp_atb_typed   T = sum_e Z[e]^T dPre[e]  and  B = sum_e c_e Z[e]^T dPre[e]  over the class-sorted tile
+//                   list (c_e = the coefficient of e's degree class): dA' and dB' of the class-typed edge
+//                   chain (dmpnn.py:144-156 backward), one product's worth of MFMAs for both.
+//   dmp_atb_rows    T = (g (.) Z)^T D  and the column sums of g (.) Z  over plain row tiles: the gradient of
+//                   the second edge Linear with the layer's edge gate and its bias gradient fused in
+//                   (dmpnn.py:263-273 backward: dO = gate * dOut, dW2 = dO^T H1, db2 = sum dO).
+//
+// A workgroup (4 waves) owns a contiguous range of 32-row tiles and keeps the running [128,128] total in
+// registers: wave (p, q) holds the 64 x 128 block of output rows 64p.. for the tile's rows 16q..16q+15
+// (8 accumulators; the contraction is split over the two wave pairs so that every LDS operand read feeds
+// 8/6 MFMAs instead of 4/5); the two halves are added through LDS and the total goes to the workgroup's
+// partial with 16-byte accesses.  Typed: a class that ends inside the range emits  T += acc, B += c * acc
+// and restarts the accumulators (and the load pipeline) -- ranges are contiguous in the class-sorted
+// order, so this happens at most (classes in use) times per launch, and no coefficient-weighted second
+// accumulator set is needed.  The per-workgroup partials are summed by dmp_reduce_partials: every sum
+// has a fixed order, bit-stable for a given tile list.
+#include "dmp_mfma_common.h"
+
+namespace dmp {
+namespace {
+
+struct AtbArgs {
+  const float *Z; int64_t ldz;
+  const float *D; int64_t ldd;
+  int64_t E;                       // rows of Z and D
+  const int32_t *slot_edge;        // typed: [tiles * 32] row of every slot, -1 = padding
+  const float *tile_scale;         // typed: [tiles] coefficient of the tile's class
+  const int32_t *num_tiles;        // typed: [1] tiles in use (device)
+  int plain_tiles;                 // rows variant: ceil(E / 32)
+  const float *gate;               // rows variant: row scale of Z or NULL
+  float *pT, *pB;                  // [gridDim.x] partials, `pstride` floats apart
+  int64_t pstride;
+  float *pCS;                      // rows variant: [gridDim.x, 128] column sums of g (.) Z
+};
+
+template <bool TYPED>
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
+  __shared__ float smem[128 * 128];                        // tiles: Zs | Ds (2 x 32 x 132); at the end: the [128,128] total
+  float *Zs = smem, *Ds = smem + kSub * kLdsStride;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pw = wave & 1, qw = wave >> 1;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
+  const uint32_t colA = (uint32_t)(gtid & 31) * 16u;
+  constexpr uint32_t kOOB = 0xFFFFF000u;
+  const rsrc_t rs_Z = make_rsrc(p.Z, (uint32_t)(p.E * p.ldz * 4));
+  const rsrc_t rs_D = make_rsrc(p.D, (uint32_t)(p.E * p.ldd * 4));
+  const bool gated = !TYPED && p.gate != nullptr;
+  const rsrc_t rs_G = make_rsrc(p.gate, gated ? (uint32_t)(p.E * 4) : 0u);
+  const int ntiles = TYPED ? __builtin_amdgcn_readfirstlane(*p.num_tiles) : p.plain_tiles;
+  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int mine = hi > lo ? hi - lo : 0;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, TYPED ? (uint32_t)ntiles * (kSub * 4u) : 0u);
+  float *pt = p.pT + (int64_t)blockIdx.x * p.pstride;
+  float *pb = TYPED ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;
+
+  f32x16 acc[2][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  int id_rows[kSubLoads];
+  float4 preZ[kSubLoads], preD[kSubLoads];
+  float preG[kSubLoads];
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);             // gated: this thread's 4 columns of sum g (.) Z
+  auto load_ids = [&](int k) {
+    const bool ok = k < mine;
+    if (TYPED) {
+      const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
+#pragma unroll
+      for (int m = 0; m < kSubLoads; ++m)
+        id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+    } else {
+#pragma unroll
+      for (int m = 0; m < kSubLoads; ++m) {
+        const int64_t r = (int64_t)(lo + k) * kSub + (gtid >> 5) + 8 * m;
+        id_rows[m] = ok && r < p.E ? (int)r : -1;
+      }
+    }
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) {
+      const bool ok = id_rows[m] >= 0;
+      preZ[m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldz * 4) + colA : kOOB, 0);
+      preD[m] = buf_load4(rs_D, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
+      if (!TYPED) {
+        preG[m] = 1.f;
+        if (gated) preG[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_G, ok ? (int)((uint32_t)id_rows[m] * 4u) : (int)kOOB, 0, 0));
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) {
+      const int o = ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
+      float4 z = preZ[m];
+      if (!TYPED && gated) {
+        z = make_float4(z.x * preG[m], z.y * preG[m], z.z * preG[m], z.w * preG[m]);
+        cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
+      } else if (!TYPED && p.pCS) {
+        cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
+      }
+      *reinterpret_cast<float4 *>(&Zs[o]) = z;
+      *reinterpret_cast<float4 *>(&Ds[o]) = preD[m];
+    }
+  };
+  auto compute = [&]() {
+    // k-step s of wave (p, q): row 16q + s of the tile (lanes 0-31) paired with row 16q + 8 + s (lanes 32-63);
+    // A operands: columns 64p + li and 64p + 32 + li of Z, B operands: columns 32j + li of D.
+    // The operands of step s+1 are requested before the MFMAs of step s.
+    const float *zp = &Zs[(16 * qw + 8 * h) * kLdsStride + 64 * pw + li];
+    const float *dp = &Ds[(16 * qw + 8 * h) * kLdsStride + li];
+    float a0 = zp[0], a1 = zp[32], b0 = dp[0], b1 = dp[32], b2 = dp[64], b3 = dp[96];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float x0 = a0, x1 = a1, y0 = b0, y1 = b1, y2 = b2, y3 = b3;
+      if (s + 1 < 8) {
+        x0 = zp[(s + 1) * kLdsStride]; x1 = zp[(s + 1) * kLdsStride + 32];
+        y0 = dp[(s + 1) * kLdsStride]; y1 = dp[(s + 1) * kLdsStride + 32];
+        y2 = dp[(s + 1) * kLdsStride + 64]; y3 = dp[(s + 1) * kLdsStride + 96];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = x0; a1 = x1; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
+    }
+  };
+  // accumulator (i, j, r) of wave (p, q): output row 64p + 32i + (r&3) + 8(r>>2) + 4h, column 32j + li
+  auto out_index = [&](int i, int j, int r) { return (64 * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + 32 * j + li; };
+
+  // Emit the accumulators: the two row halves are added through LDS (which must be free: the staged tile is
+  // given up), then every thread adds its 16 float4 of the [128,128] total to the workgroup's partial --
+  // T (+)= total, B (+)= c * total; the first emission stores, later ones (typed: one per class that ends
+  // inside the range) read back what the SAME thread wrote before.
+  bool emitted = false;
+  auto emit = [&](float c) {
+    __syncthreads();
+    if (qw == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) smem[out_index(i, j, r)] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (qw == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = out_index(i, j, r);
+            smem[o] = acc[i][j][r] + smem[o];
+          }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+      const int o = (m * kGroupThreads + gtid) * 4;
+      const float4 v = *reinterpret_cast<const float4 *>(&smem[o]);
+      float4 t = v, b = make_float4(c * v.x, c * v.y, c * v.z, c * v.w);
+      if (emitted) {
+        const float4 t0 = *reinterpret_cast<const float4 *>(pt + o);
+        t.x += t0.x; t.y += t0.y; t.z += t0.z; t.w += t0.w;
+        if (TYPED) {
+          const float4 b0 = *reinterpret_cast<const float4 *>(pb + o);
+          b.x += b0.x; b.y += b0.y; b.z += b0.z; b.w += b0.w;
+        }
+      }
+      *reinterpret_cast<float4 *>(pt + o) = t;
+      if (TYPED) *reinterpret_cast<float4 *>(pb + o) = b;
+    }
+    emitted = true;
+  };
+  // (re)start the pipeline at tile k: tile k staged in LDS, tile k+1's rows and tile k+2's ids requested
+  auto start_at = [&](int k) {
+    load_ids(k);
+    load_rows();
+    load_ids(k + 1);
+    stage();
+    load_rows();
+    load_ids(k + 2);
+    lds_barrier();
+  };
+
+  // typed: the class structure of the range is read 64 tiles at a time -- lane l keeps the coefficient of tile
+  // 64c + l, bit l of `starts` says "tile 64c + l begins a new class" -- so that the hot loop tests a scalar
+  // bit instead of waiting for a load behind the row prefetch
+  float cur = 0.f, sv = 0.f;
+  unsigned long long starts = 0;
+  if (mine > 0) {
+    start_at(0);
+    int k = 0;
+    while (k < mine) {
+      if (TYPED) {
+        bool boundary = true;                               // left the hot loop inside a chunk: tile k begins a new class
+        if ((k & 63) == 0) {
+          const float last = __shfl(sv, 63);
+          sv = k + lane < mine ? p.tile_scale[lo + k + lane] : 0.f;
+          float up = __shfl_up(sv, 1);
+          if (lane == 0) up = k > 0 ? last : sv;
+          starts = __ballot(k + lane < mine && __float_as_uint(sv) != __float_as_uint(up));
+          boundary = (starts & 1ull) != 0;
+        }
+        if (boundary) {                                     // classes are sorted: the finished class's total goes out
+          emit(cur);
+          zero_acc();
+          __syncthreads();                                  // LDS goes back to the tiles
+          start_at(k);
+        }
+        cur = __shfl(sv, k & 63);
+      }
+      do {                                                  // the hot loop: tiles of one class inside one chunk
+        compute();
+        lds_barrier();
+        stage();
+        load_rows();
+        load_ids(k + 3);
+        lds_barrier();
+        ++k;
+      } while (k < mine && (!TYPED || ((k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0)));
+    }
+  }
+  emit(cur);
+  if (!TYPED && p.pCS) {
+    // column sums: the 8 threads that staged the same 4 columns, added in a fixed order
+    __syncthreads();
+    *reinterpret_cast<float4 *>(&smem[(gtid >> 5) * 128 + (gtid & 31) * 4]) = cs;
+    __syncthreads();
+    if (gtid < 32) {
+      float4 t = *reinterpret_cast<const float4 *>(&smem[gtid * 4]);
+#pragma unroll
+      for (int g = 1; g < 8; ++g) {
+        const float4 u = *reinterpret_cast<const float4 *>(&smem[g * 128 + gtid * 4]);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *reinterpret_cast<float4 *>(p.pCS + (int64_t)blockIdx.x * 128 + gtid * 4) = t;
+    }
+  }
+}
+
+inline unsigned atb_blocks(int64_t tiles) {
+  const int64_t cap = 256 * 2;                             // two resident workgroups per CU
+  return (unsigned)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int64_t dmp_atb_typed_blocks(int64_t tiles_bound) { return (int64_t)atb_blocks(tiles_bound); }
+
+int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, const int32_t *slot_edge,
+                  const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H,
+                  float *partial_T, float *partial_B, void *stream) {
+  if (E < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!partial_T || !partial_B || !num_tiles || !slot_edge || !tile_scale) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!Z || !dPre || ldz < H || ldp < H)) return DMP_ERR_BAD_ARG;
+  if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre))) || !aligned16(partial_T) || !aligned16(partial_B))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(E, ldz) || !fits32(E, ldp) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  AtbArgs a{};
+  a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
+  a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
+  a.pstride = partial_B == partial_T + 128 * 128 ? 2 * 128 * 128 : 128 * 128;   // interleaved [G][2][H*H] or two [G][H*H]
+  atb_k<true><<<atb_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(a);
+  return check_launch();
+}
+
+int64_t dmp_atb_rows_blocks(int64_t rows) { return (int64_t)atb_blocks((rows + kSub - 1) / kSub); }
+
+int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int H,
+                 float *partial, float *partial_colsum, void *stream) {
+  if (rows < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!partial) return DMP_ERR_BAD_ARG;
+  if (rows > 0 && (!A || !B || lda < H || ldb < H)) return DMP_ERR_BAD_ARG;
+  if (lda % 4 || ldb % 4 || (rows > 0 && (!aligned16(A) || !aligned16(B))) || !aligned16(partial) ||
+      (partial_colsum && !aligned16(partial_colsum)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!fits32(rows, lda) || !fits32(rows, ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+  AtbArgs a{};
+  a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
+  a.gate = gate; a.pT = partial; a.pstride = 128 * 128; a.pCS = partial_colsum;
+  atb_k<false><<<atb_blocks(a.plain_tiles), kGroupThreads, 0, (hipStream_t)stream>>>(a);
+  return check_launch();
+}
+
+}  // extern "C"

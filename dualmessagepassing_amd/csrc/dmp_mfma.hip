@@ -82,6 +82,7 @@ struct MfmaArgs {
                                     // or NULL; EPI_RELU_BWD_G: the saved activation H1 for the ReLU mask
   float *partial;                   // EPI_RELU_BWD_G: [2*gridDim.x, 128] column-sum partials of dPre
   float s0, s1;                     // EPI_DZ: sign / scale of the gathered term by flag
+  int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
 };
 
 template <int NC, int EPI, int PP>
@@ -282,6 +283,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
         } else if (EPI == EPI_RELU_BWD_G) {
           // dPre = H1 > 0 ? dH1 : 0;  dG = [dPre | coef[dst] dPre];  column sums of dPre
           // (rows past the end: H1 reads as 0 -> dPre = 0, nothing stored)
+          if (p.gated) {                                     // dO = gate * dOut: a row scale commutes with the product
+            const float gt = rowS[grp][par][rr];
+            v.x *= gt; v.y *= gt; v.z *= gt; v.w *= gt;
+          }
           v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
           v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
           colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
@@ -493,9 +498,10 @@ int64_t dmp_mfma_partial_rows(int64_t E) { return g_variant == 1 ? 2 * (int64_t)
 void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
 
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                     const float *coefE, int64_t E, int H, float *dG, int64_t ldg, float *partial, void *stream) {
+                     const float *coefE, const float *gate, int64_t E, int H, float *dG, int64_t ldg, float *partial,
+                     void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
-  if (!partial) return DMP_ERR_BAD_ARG;
+  if (!partial || (gate && ldg >= 2 * H)) return DMP_ERR_BAD_ARG;
   if (E == 0)
     return hipMemsetAsync(partial, 0, sizeof(float) * 128 * (size_t)dmp_mfma_partial_rows(0), (hipStream_t)stream) == hipSuccess
                ? DMP_OK : DMP_ERR_HIP;
@@ -505,7 +511,8 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
   if (!fits32(E, 1) || !fits32(kSub, ldo) || !fits32(kSub, ldh) || !fits32(kSub, ldg)) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
-  p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = coefE; p.partial = partial; p.ldt = 256;
+  p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
+  p.partial = partial; p.ldt = 256;
   return launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 

@@ -217,137 +217,6 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight gradient over the class-sorted tiles:  T = sum_e Z[e]^T dPre[e],  B = sum_e c_e Z[e]^T dPre[e].
-// A workgroup accumulates the running total T over its contiguous tile range in registers (wave w:
-// output rows 32w..32w+31, all 128 columns = 4 accumulators); classes arrive in sorted order, so with
-// P_c the total after class c:  B = sum_c c_c (P_c - P_{c-1}) = sum_c (c_c - c_{c+1}) P_c + c_last P_last
-// -- at every class boundary B += (c_old - c_new) * T, at the end B += c_last * T: two accumulator
-// sets instead of three, and one product's worth of MFMAs for both halves of dW.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_typed_k(const float *Z, int64_t ldz, const float *D, int64_t ldd,
-                                                                int64_t E, const int32_t *slot_edge, const float *tile_scale,
-                                                                const int32_t *num_tiles, float *partial_T, float *partial_B) {
-  __shared__ float Zs[kSub * kLdsStride];
-  __shared__ float Ds[kSub * kLdsStride];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
-  const uint32_t colA = (uint32_t)(gtid & 31) * 16u;
-  constexpr uint32_t kOOB = 0xFFFFF000u;
-  const rsrc_t rs_Z = make_rsrc(Z, (uint32_t)(E * ldz * 4));
-  const rsrc_t rs_D = make_rsrc(D, (uint32_t)(E * ldd * 4));
-  const int ntiles = __builtin_amdgcn_readfirstlane(*num_tiles);
-  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int lo = (int)blockIdx.x * chunk;
-  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-  const int mine = hi > lo ? hi - lo : 0;
-  const rsrc_t rs_slot = make_rsrc(slot_edge, (uint32_t)ntiles * (kSub * 4u));
-
-  f32x16 accT[4], accB[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accT[j][r] = 0.f; accB[j][r] = 0.f; }
-
-  int id_rows[kSubLoads];
-  float4 preZ[kSubLoads], preD[kSubLoads];
-  auto load_ids = [&](int k) {
-    const bool ok = k < mine;
-    const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
-#pragma unroll
-    for (int m = 0; m < kSubLoads; ++m)
-      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
-  };
-  auto load_rows = [&]() {
-#pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) {
-      const bool ok = id_rows[m] >= 0;
-      preZ[m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(ldz * 4) + colA : kOOB, 0);
-      preD[m] = buf_load4(rs_D, ok ? (uint32_t)id_rows[m] * (uint32_t)(ldd * 4) + colA : kOOB, 0);
-    }
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) {
-      const int o = ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
-      *reinterpret_cast<float4 *>(&Zs[o]) = preZ[m];
-      *reinterpret_cast<float4 *>(&Ds[o]) = preD[m];
-    }
-  };
-  auto compute = [&]() {
-    // k-step s pairs edge s (lanes 0-31) with edge s+16 (lanes 32-63); A operand: feature 32w+li of Z,
-    // B operands: features 32j+li of dPre.  Operands of step s+1 are requested before the MFMAs of step s.
-    const float *zp = &Zs[(16 * h) * kLdsStride + 32 * wave + li];
-    const float *dp = &Ds[(16 * h) * kLdsStride + li];
-    float a = zp[0], b0 = dp[0], b1 = dp[32], b2 = dp[64], b3 = dp[96];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      float an = a, c0 = b0, c1 = b1, c2 = b2, c3 = b3;
-      if (s + 1 < 16) {
-        an = zp[(s + 1) * kLdsStride];
-        c0 = dp[(s + 1) * kLdsStride]; c1 = dp[(s + 1) * kLdsStride + 32];
-        c2 = dp[(s + 1) * kLdsStride + 64]; c3 = dp[(s + 1) * kLdsStride + 96];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      accT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accT[0], 0, 0, 0);
-      accT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accT[1], 0, 0, 0);
-      accT[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, accT[2], 0, 0, 0);
-      accT[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, accT[3], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
-    }
-  };
-  auto fold = [&](float w) {                                // B += w * T
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accB[j][r] = accB[j][r] + w * accT[j][r];
-  };
-
-  float cur = 0.f;
-  if (mine > 0) {
-    cur = tile_scale[lo];
-    load_ids(0);
-    load_rows();
-    load_ids(1);
-    stage();
-    load_rows();
-    load_ids(2);
-    lds_barrier();
-    for (int k = 0; k < mine; ++k) {
-      const float c = tile_scale[__builtin_amdgcn_readfirstlane(lo + k)];
-      if (c != cur) {                                       // class boundary (classes are sorted)
-        fold(cur - c);
-        cur = c;
-      }
-      compute();
-      lds_barrier();
-      stage();
-      load_rows();
-      load_ids(k + 3);
-      lds_barrier();
-    }
-    fold(cur);
-  }
-  // accumulator (j, r) of wave w: row 32w + (r&3) + 8(r>>2) + 4h, column 32j + li
-  // partial_B == partial_T + 128*128 interleaves the two partials per workgroup ([G][2][H*H]: one reduction for both)
-  const int64_t pstride = partial_B == partial_T + 128 * 128 ? 2 * 128 * 128 : 128 * 128;
-  float *pt = partial_T + (int64_t)blockIdx.x * pstride, *pb = partial_B + (int64_t)blockIdx.x * pstride;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h, colo = 32 * j + li;
-      pt[row * 128 + colo] = accT[j][r];
-      pb[row * 128 + colo] = accB[j][r];
-    }
-}
-
-inline unsigned atb_blocks(int64_t tiles_bound) {
-  const int64_t cap = 256 * 2;
-  return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
-}
-
 inline unsigned typed_blocks(int64_t tiles_bound) {
   const int64_t cap = 256 * 3;
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
@@ -401,21 +270,6 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : 128;
   p.s0 = s0; p.s1 = s1;
   mfma_typed<TEPI_DZ><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
-}
-
-int64_t dmp_atb_typed_blocks(int64_t tiles_bound) { return (int64_t)atb_blocks(tiles_bound); }
-
-int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, const int32_t *slot_edge,
-                  const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H,
-                  float *partial_T, float *partial_B, void *stream) {
-  if (E < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
-  if (!partial_T || !partial_B || !num_tiles || !slot_edge || !tile_scale) return DMP_ERR_BAD_ARG;
-  if (E > 0 && (!Z || !dPre || ldz < H || ldp < H)) return DMP_ERR_BAD_ARG;
-  if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre)))) return DMP_ERR_UNSUPPORTED;
-  if (!fits32(E, ldz) || !fits32(E, ldp) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
-  atb_typed_k<<<atb_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(Z, ldz, dPre, ldp, E, slot_edge, tile_scale,
-                                                                                num_tiles, partial_T, partial_B);
   return check_launch();
 }
 

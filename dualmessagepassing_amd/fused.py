@@ -266,17 +266,32 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True):
-    """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128."""
+def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True, gate=None):
+    """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128.
+    ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here."""
     lib = _lib.load()
     E, H = d_o.shape
     d_g = torch.empty((E, 2 * H if both_halves else H), dtype=torch.float32, device=d_o.device)
     part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), (16 if both_halves else 12) * H * E + 4 * E):
-        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]), E, H,
-                                   ptr(d_g), d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
+        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]),
+                                   ptr(gate), E, H, ptr(d_g), d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
+
+
+def atb_rows(a, b, gate=None):
+    """``((gate (.) a)^T b  [H,H],  column sums of gate (.) a  [H])`` in one MFMA pass over the rows
+    (csrc/dmp_atb.hip); H = 128.  The second Linear's weight and bias gradient with the gate fused in."""
+    lib = _lib.load()
+    R, H = a.shape
+    G = int(lib.dmp_atb_rows_blocks(R))
+    part = torch.empty((G, H * H), dtype=torch.float32, device=a.device)
+    part_cs = torch.empty((G, H), dtype=torch.float32, device=a.device)
+    with _lib.timed("atb_rows[H=%d,R=%d]" % (H, R), 8 * H * R + (4 * R if gate is not None else 0)):
+        check(lib.dmp_atb_rows(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, H, ptr(part), ptr(part_cs),
+                               stream_ptr()), "dmp_atb_rows")
+    return reduce_partials(part).view(H, H), reduce_partials(part_cs)
 
 
 def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
@@ -349,11 +364,18 @@ class _FusedDMPLayer(torch.autograd.Function):
         # below: their nine reductions run as one launch when this block is left
         with deferred_reductions():
             # ---- edge side, down to the gathered node projections
-            dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
-            dW2e = atb(dOe, H1e)
             mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
-            if mfma:
-                dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=not typed)  # dG[:, :H] is dPre
+            if typed:
+                # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)
+                dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
+                dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate)  # dG is dPre
+            else:
+                dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
+                dW2e = atb(dOe, H1e)
+            if typed:
+                pass
+            elif mfma:
+                dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=True)         # dG[:, :H] is dPre
             else:
                 dH1e = dOe @ eW2
                 dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 13
+#define DMP_ABI_VERSION 14
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -445,12 +445,14 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
  *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
  *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
  *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H];
- *   with H <= ldg < 2H only dPre is written (dG [E, ldg]).
+ *   with H <= ldg < 2H only dPre is written (dG [E, ldg]), and then `gate` [E] (or NULL) may carry the
+ *   layer's edge gate: dO is the UNgated output gradient and dPre[e] = H1[e] > 0 ? gate[e] (dO[e] W2) : 0
+ *   (the separate gate pass of the backward is fused away; gate must be NULL when ldg >= 2H).
  */
 int64_t dmp_mfma_partial_rows(int64_t num_edges);
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
-                     const float *H1, int64_t ldh, const float *coefE, int64_t num_edges, int H,
-                     float *dG, int64_t ldg, float *partial, void *stream);
+                     const float *H1, int64_t ldh, const float *coefE, const float *gate,
+                     int64_t num_edges, int H, float *dG, int64_t ldg, float *partial, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
@@ -500,6 +502,19 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
                   const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                   int64_t tiles_bound, int64_t num_edges, int H, float *partial_T,
                   float *partial_B, void *stream);
+
+/*
+ * Gradient of the second edge Linear with the layer's edge gate fused in (dmpnn.py:263-273 backward:
+ * dO = gate * dOut, dW2 = dO^T H1, db2 = column sums of dO), one pass over plain 32-row tiles:
+ *     partial[b]        = (gate (.) A)^T B  over workgroup b's rows   ([H,H], A = dOut, B = H1)
+ *     partial_colsum[b] = column sums of gate (.) A over the same rows ([H]; may be NULL)
+ *   A [rows, lda>=H], B [rows, ldb>=H], gate [rows] or NULL (1); H = 128 only;
+ *   partial: [dmp_atb_rows_blocks(rows), H*H], partial_colsum: [dmp_atb_rows_blocks(rows), H];
+ *   finish both with dmp_reduce_partials.
+ */
+int64_t dmp_atb_rows_blocks(int64_t rows);
+int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
+                 int64_t rows, int H, float *partial, float *partial_colsum, void *stream);
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup

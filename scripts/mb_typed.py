@@ -63,3 +63,10 @@ print("atb typed              %7.1f us" % timeit(lambda: fused.atb_typed(z, dp, 
 w2 = (th.randn(h, h, generator=g) * .1).to(gpu); h1 = z.clamp_min(0)
 print("bwd_h1 both halves     %7.1f us" % timeit(lambda: fused.bwd_h1_mfma(dp, w2, h1, coef, ix)))
 print("bwd_h1 dPre only       %7.1f us" % timeit(lambda: fused.bwd_h1_mfma(dp, w2, h1, coef, ix, both_halves=False)))
+gate = th.rand(e, generator=g).to(gpu)
+def old_path():
+    d_o, db = fused.scale_rows_colsum(dp, gate)
+    return fused.atb(d_o, h1), db
+print("gate pass + bmm dW2    %7.1f us" % timeit(old_path))
+print("atb_rows gated         %7.1f us" % timeit(lambda: fused.atb_rows(dp, h1, gate)))
+print("bwd_h1 dPre only gated %7.1f us" % timeit(lambda: fused.bwd_h1_mfma(dp, w2, h1, coef, ix, both_halves=False, gate=gate)))

@@ -339,6 +339,14 @@ def test_mfma_backward_kernels_h128(rows, gpu):
     ref = th.cat([dpre, dpre * coef.double()[td][:, None]], 1)
     assert th.allclose(d_g.double(), ref, rtol=1e-5, atol=2e-4)
     assert th.allclose(cs.double(), dpre.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    # dPre alone with the edge gate fused in: dPre = h1 > 0 ? gate (d_o w2) : 0 (gate * d_o never materialised)
+    gate = (th.rand(rows, generator=gen) * (th.rand(rows, generator=gen) > 0.3)).to(gpu)
+    d_p, csg = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix, both_halves=False, gate=gate)
+    refg = dpre * gate.double()[:, None]
+    assert d_p.shape == (rows, h) and th.allclose(d_p.double(), refg, rtol=1e-5, atol=2e-4)
+    assert th.allclose(csg.double(), refg.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    d_p1, _ = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix, both_halves=False)
+    assert th.equal(d_p1, d_g[:, :h])
     g2, cs2 = fused.relu_bwd_g_colsum(d_o @ w2, h1, coef, ix.dst32)      # the two-kernel path
     assert th.allclose(d_g, g2, rtol=1e-5, atol=2e-4) and th.allclose(cs, cs2, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5))
     # input gradient
@@ -444,6 +452,26 @@ def test_typed_edge_kernels_equal_untyped(rows, gpu):
         assert th.allclose(got, ref, rtol=1e-5, atol=2e-5)
     assert th.equal(fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix),
                     fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix))
+
+
+@pytest.mark.parametrize("rows", [1, 31, 4097, 70001])
+@pytest.mark.parametrize("gated", [False, True])
+def test_gated_weight_gradient_rows(rows, gated, gpu):
+    """fused.atb_rows: (gate (.) a)^T b and the column sums of gate (.) a in one MFMA pass, against the
+    fp64 product; the same bits on every launch; strided operands (a column slice of a wider matrix)."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + int(gated))
+    wide = th.randn(rows, 2 * h, generator=gen).to(gpu)
+    a, b = wide[:, h:], th.randn(rows, h, generator=gen).to(gpu)
+    gate = (th.rand(rows, generator=gen) * (th.rand(rows, generator=gen) > 0.3)).to(gpu) if gated else None
+    got, cs = fused.atb_rows(a, b, gate)
+    ga = a.double() * (gate.double()[:, None] if gated else 1.0)
+    tol = 1e-4 * max(1.0, rows ** 0.5)
+    assert got.shape == (h, h) and th.allclose(got, (ga.t() @ b.double()).float(), rtol=1e-5, atol=tol)
+    assert cs.shape == (h,) and th.allclose(cs, ga.sum(0).float(), rtol=1e-5, atol=tol)
+    got2, cs2 = fused.atb_rows(a, b, gate)
+    assert th.equal(got, got2) and th.equal(cs, cs2)
 
 
 @pytest.mark.parametrize("rows", [31, 1000, 70001])
