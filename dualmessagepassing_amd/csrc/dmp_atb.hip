@@ -17,6 +17,8 @@
 // order, so this happens at most (classes in use) times per launch, and no coefficient-weighted second
 // accumulator set is needed.  The per-workgroup partials are summed by dmp_reduce_partials: every sum
 // has a fixed order, bit-stable for a given tile list.
+#include <type_traits>
+
 #include "dmp_mfma_common.h"
 
 namespace dmp {
@@ -38,8 +40,9 @@ struct AtbArgs {
 
 template <bool TYPED>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  __shared__ float smem[128 * 128];                        // tiles: Zs | Ds (2 x 32 x 132); at the end: the [128,128] total
-  float *Zs = smem, *Ds = smem + kSub * kLdsStride;
+  // two tile buffers (Zs | Ds, 2 x 32 x 132 floats each) = 67584 bytes; emit() reuses the first 64 KB for the [128,128] total
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kTile = kSub * kLdsStride, kBuf = 2 * kTile;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int pw = wave & 1, qw = wave >> 1;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
@@ -69,9 +72,12 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   };
   zero_acc();
 
+#ifdef DMP_ATB_DBG
+  bool warm = false;
+#endif
   int id_rows[kSubLoads];
-  float4 preZ[kSubLoads], preD[kSubLoads];
-  float preG[kSubLoads];
+  float4 preZ[2][kSubLoads], preD[2][kSubLoads];           // two sets of prefetched rows: tiles of even / odd pipeline phase
+  float preG[2][kSubLoads];
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);             // gated: this thread's 4 columns of sum g (.) Z
   auto load_ids = [&](int k) {
     const bool ok = k < mine;
@@ -88,39 +94,52 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
       }
     }
   };
-  auto load_rows = [&]() {
-#pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) {
-      const bool ok = id_rows[m] >= 0;
-      preZ[m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldz * 4) + colA : kOOB, 0);
-      preD[m] = buf_load4(rs_D, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
-      if (!TYPED) {
-        preG[m] = 1.f;
-        if (gated) preG[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_G, ok ? (int)((uint32_t)id_rows[m] * 4u) : (int)kOOB, 0, 0));
-      }
+  auto load_row = [&](auto set, int m) {                    // rows of slice m of the tile whose ids are in id_rows
+    constexpr int S = decltype(set)::value;
+#ifdef DMP_ATB_DBG
+    if ((DMP_ATB_DBG & 2) && warm) return;
+#endif
+    const bool ok = id_rows[m] >= 0;
+    preZ[S][m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldz * 4) + colA : kOOB, 0);
+    preD[S][m] = buf_load4(rs_D, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
+    if (!TYPED) {
+      preG[S][m] = 1.f;
+      if (gated) preG[S][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_G, ok ? (int)((uint32_t)id_rows[m] * 4u) : (int)kOOB, 0, 0));
     }
   };
-  auto stage = [&]() {
+  auto load_rows = [&](auto set) {
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) {
-      const int o = ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
-      float4 z = preZ[m];
-      if (!TYPED && gated) {
-        z = make_float4(z.x * preG[m], z.y * preG[m], z.z * preG[m], z.w * preG[m]);
-        cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
-      } else if (!TYPED && p.pCS) {
-        cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
-      }
-      *reinterpret_cast<float4 *>(&Zs[o]) = z;
-      *reinterpret_cast<float4 *>(&Ds[o]) = preD[m];
-    }
+    for (int m = 0; m < kSubLoads; ++m) load_row(set, m);
   };
-  auto compute = [&]() {
-    // k-step s of wave (p, q): row 16q + s of the tile (lanes 0-31) paired with row 16q + 8 + s (lanes 32-63);
-    // A operands: columns 64p + li and 64p + 32 + li of Z, B operands: columns 32j + li of D.
-    // The operands of step s+1 are requested before the MFMAs of step s.
-    const float *zp = &Zs[(16 * qw + 8 * h) * kLdsStride + 64 * pw + li];
-    const float *dp = &Ds[(16 * qw + 8 * h) * kLdsStride + li];
+  auto stage_row = [&](auto set, int m) {                   // slice m of row set S -> tile buffer S
+    constexpr int S = decltype(set)::value;
+    const int o = S * kBuf + ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
+    float4 z = preZ[S][m];
+    if (!TYPED && gated) {
+      z = make_float4(z.x * preG[S][m], z.y * preG[S][m], z.z * preG[S][m], z.w * preG[S][m]);
+      cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
+    } else if (!TYPED && p.pCS) {
+      cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
+    }
+    *reinterpret_cast<float4 *>(&smem[o]) = z;
+    *reinterpret_cast<float4 *>(&smem[o + kTile]) = preD[S][m];
+  };
+  auto stage = [&](auto set) {
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(set, m);
+  };
+  // One tile of pipeline phase PH (tiles alternate between the two LDS buffers / row sets, counted from the last
+  // start_at): the MFMAs of tile k (buffer PH) with, in their shadow, the staging of tile k+1 into the other
+  // buffer (k-steps 0-3), the row requests of tile k+3 into the set just staged (k-steps 4-7) and the id
+  // requests of tile k+4 -- rows are requested two tiles before they are staged.
+  // k-step s of wave (p, q): row 16q + s of the tile (lanes 0-31) paired with row 16q + 8 + s (lanes 32-63);
+  // A operands: columns 64p + li and 64p + 32 + li of Z, B operands: columns 32j + li of D.
+  // The operands of step s+1 are requested before the MFMAs of step s.
+  auto tile_step = [&](int k, auto phase) {
+    constexpr int PH = decltype(phase)::value;
+    std::integral_constant<int, PH ^ 1> other;
+    const float *zp = &smem[PH * kBuf + (16 * qw + 8 * h) * kLdsStride + 64 * pw + li];
+    const float *dp = zp + kTile - 64 * pw;
     float a0 = zp[0], a1 = zp[32], b0 = dp[0], b1 = dp[32], b2 = dp[64], b3 = dp[96];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -131,6 +150,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
         y2 = dp[(s + 1) * kLdsStride + 64]; y3 = dp[(s + 1) * kLdsStride + 96];
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef DMP_ATB_DBG
+      if (!(DMP_ATB_DBG & 4)) {
+#endif
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
@@ -139,7 +161,13 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
       acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+#ifdef DMP_ATB_DBG
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      if (s < 4) stage_row(other, s);
+      else load_row(other, s - 4);
+      if (s == 7) load_ids(k + 4);
       a0 = x0; a1 = x1; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
     }
   };
@@ -193,13 +221,19 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
     emitted = true;
   };
   // (re)start the pipeline at tile k: tile k staged in LDS, tile k+1's rows and tile k+2's ids requested
+  std::integral_constant<int, 0> ph0;
+  std::integral_constant<int, 1> ph1;
+  // (re)start the pipeline at tile k (phase 0): tile k staged in buffer 0, the rows of tiles k+1 / k+2 requested
+  // into sets 1 / 0, the ids of tile k+3 requested
   auto start_at = [&](int k) {
     load_ids(k);
-    load_rows();
+    load_rows(ph0);
     load_ids(k + 1);
-    stage();
-    load_rows();
+    stage(ph0);
+    load_rows(ph1);
     load_ids(k + 2);
+    load_rows(ph0);
+    load_ids(k + 3);
     lds_barrier();
   };
 
@@ -209,8 +243,8 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   float cur = 0.f, sv = 0.f;
   unsigned long long starts = 0;
   if (mine > 0) {
-    start_at(0);
     int k = 0;
+    bool restart = true;                                    // the hot loop was left: the pipeline starts over at tile k
     while (k < mine) {
       if (TYPED) {
         bool boundary = true;                               // left the hot loop inside a chunk: tile k begins a new class
@@ -226,19 +260,25 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
           emit(cur);
           zero_acc();
           __syncthreads();                                  // LDS goes back to the tiles
-          start_at(k);
         }
         cur = __shfl(sv, k & 63);
       }
-      do {                                                  // the hot loop: tiles of one class inside one chunk
-        compute();
-        lds_barrier();
-        stage();
-        load_rows();
-        load_ids(k + 3);
+      if (restart) start_at(k);
+#ifdef DMP_ATB_DBG
+      warm = true;
+#endif
+      // the hot loop: tiles of one class inside one chunk of 64, two pipeline phases per trip
+      auto more = [&]() { return k < mine && (!TYPED || ((k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0)); };
+      for (;;) {
+        tile_step(k, ph0);
+        lds_barrier();                                      // tile k+1 is staged for everyone, tile k's buffer is free
+        ++k;
+        if (!more()) break;
+        tile_step(k, ph1);
         lds_barrier();
         ++k;
-      } while (k < mine && (!TYPED || ((k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0)));
+        if (!more()) break;
+      }
     }
   }
   emit(cur);
@@ -257,6 +297,15 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
       *reinterpret_cast<float4 *>(p.pCS + (int64_t)blockIdx.x * 128 + gtid * 4) = t;
     }
   }
+}
+
+constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
+template <bool TYPED>
+bool lds_ready() {
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<TYPED>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAtbLdsBytes);
+  if (e != hipSuccess) set_last_hip_error(e);
+  return e == hipSuccess;
 }
 
 inline unsigned atb_blocks(int64_t tiles) {
@@ -287,7 +336,8 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
   a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
   a.pstride = partial_B == partial_T + 128 * 128 ? 2 * 128 * 128 : 128 * 128;   // interleaved [G][2][H*H] or two [G][H*H]
-  atb_k<true><<<atb_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(a);
+  if (!lds_ready<true>()) return DMP_ERR_HIP;
+  atb_k<true><<<atb_blocks(tiles_bound), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 
@@ -305,7 +355,8 @@ int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
   a.gate = gate; a.pT = partial; a.pstride = 128 * 128; a.pCS = partial_colsum;
-  atb_k<false><<<atb_blocks(a.plain_tiles), kGroupThreads, 0, (hipStream_t)stream>>>(a);
+  if (!lds_ready<false>()) return DMP_ERR_HIP;
+  atb_k<false><<<atb_blocks(a.plain_tiles), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 
