@@ -451,7 +451,9 @@ constexpr int kCtLdsBins = 4096;
 __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
                                                     int64_t N, int C, unsigned long long *cnt, int32_t *status) {
   __shared__ unsigned int h[kCtLdsBins];
+  __shared__ int top;                                          // largest class in use in this block
   for (int i = threadIdx.x; i < kCtLdsBins; i += kBlock) h[i] = 0u;
+  if (threadIdx.x == 0) top = 0;
   __syncthreads();
   const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (v < N) {
@@ -463,23 +465,28 @@ __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ 
       k = C - 1;
     }
     if (d > 0) {
-      if (k < kCtLdsBins) atomicAdd(&h[k], d);                 // integer sums: the result does not depend on the order
+      if (k < kCtLdsBins) atomicAdd(&h[k], d);                 // integer sums / maxima: the result does not depend on the order
       else atomicAdd(cnt + k, (unsigned long long)d);
+      atomicMax(&top, (int)k);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kCtLdsBins && i < C; i += kBlock)
     if (h[i]) atomicAdd(cnt + i, (unsigned long long)h[i]);
+  if (threadIdx.x == 0 && top > 0 && status) atomicMax(status + 1, top);   // status[1]: largest class in use (the scan stops there)
 }
 
 // one block: tile_off[c] = sum_{c' < c} ceil(cnt[c'] / 32); tile_off[C] = tiles in use (also to num_tiles).
 // Class c = j * 1024 + t sits in row j (<= 64 rows: C <= 65536), column t = thread: coalesced loads all in
 // flight at once, a wave scan per row, then one scan over the (row, wave) totals in row-major order.
-__global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__restrict__ cnt, int C, int32_t *tile_off,
-                                                  int32_t *num_tiles) {
+__global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__restrict__ cnt, int C, const int32_t *__restrict__ status,
+                                                  int32_t *tile_off, int32_t *num_tiles) {
   constexpr int kRows = 64;
   __shared__ int part[kRows * 16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rows = (C + 1023) >> 10;
+  // classes above the largest one in use (status[1], from ct_hist_k) are empty and never looked up: only the rows
+  // up to tile_off[top + 1] are scanned -- one or two of the 64 for the degrees of real graphs
+  const int top = status[1] < C - 1 ? status[1] : C - 1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rows = ((top + 1) >> 10) + 1;
   int v[kRows];
 #pragma unroll
   for (int j = 0; j < kRows; ++j) {
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__re
   }
 #pragma unroll
   for (int j = 0; j < kRows; ++j) {                            // inclusive scan of row j inside the wave
+    if (j >= rows) { if (lane == 63) part[j * 16 + wave] = 0; continue; }
     int x = v[j];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -884,7 +892,7 @@ int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in
   DMP_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int32_t) * (size_t)(2 * (int64_t)num_classes + 2), st));    // counters + status
   DMP_HIP_TRY(hipMemsetAsync(slot_edge, 0xFF, sizeof(int32_t) * (size_t)tiles_bound * 32, st));      // -1 = padding
   if (N > 0) ct_hist_k<<<nblk(N), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, status);
-  ct_scan_k<<<1, 1024, 0, st>>>(cnt, num_classes, tile_off, num_tiles);
+  ct_scan_k<<<1, 1024, 0, st>>>(cnt, num_classes, status, tile_off, num_tiles);
   if (N > 0) {
     const int fast = num_classes < kCtFast ? num_classes : kCtFast;
     const int64_t waves = (int64_t)fast * kCtSegs + kCtSlowWaves;
