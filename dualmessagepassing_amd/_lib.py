@@ -55,6 +55,7 @@ SIGNATURES = {
     "dmp_edge_combine_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_colsum_partials": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr]),
+    "dmp_add_bias_relu": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
                                c_double, c_i64, c_ptr]),
@@ -89,7 +90,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -28,7 +28,8 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ float4 mul4(const float4 &a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
-enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4, OP_RELU_BWD_G_CS = 5 };
+enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4, OP_RELU_BWD_G_CS = 5,
+       OP_ADD_BIAS_RELU = 6 };
 
 struct RowArgs {
   const float *a; int64_t lda;   // first input  (prev | dOut | dH  | dY | A)
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
     const int c = c0 + lane * 4;
     const bool act = c < p.H;
     float4 cs = zero4();
+    const float4 colv = (OP == OP_ADD_BIAS_RELU && act && p.rowscale) ? ld4(p.rowscale + c) : zero4();   // the bias of this lane's columns
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < p.R; base += (int64_t)gridDim.x * chunk) {
       const int64_t r0 = base + (int64_t)grp * kU;
       // per-row scalars: lanes 0..kU-1 fetch, then broadcast (all lanes of the group take part)
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           if (OP == OP_GATE_RES) {
             x[k] = p.a ? ld4(p.a + r * p.lda + c) : zero4();
             y[k] = ld4(p.b + r * p.ldb + c);
-          } else if (OP == OP_RELU_BWD_CS || OP == OP_RELU_BWD_G_CS) {
+          } else if (OP == OP_RELU_BWD_CS || OP == OP_RELU_BWD_G_CS || OP == OP_ADD_BIAS_RELU) {
             x[k] = ld4(p.a + r * p.lda + c);
             y[k] = ld4(p.b + r * p.ldb + c);
           } else {
@@ -86,6 +88,11 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           float4 t = p.rowscale ? mul4(y[k], sc[k]) : y[k];  // (upd * gate), then + prev: reference order
           if (p.a) add4(t, x[k]);
           st4(p.out + r * p.ldo + c, t);
+        } else if (OP == OP_ADD_BIAS_RELU) {
+          float4 t = x[k];
+          add4(t, y[k]);
+          add4(t, colv);
+          st4(p.out + r * p.ldo + c, make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)));
         } else if (OP == OP_SCALE_CS) {
           float4 t = p.rowscale ? mul4(x[k], sc[k]) : x[k];
           if (p.out) st4(p.out + r * p.ldo + c, t);
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
         }
       }
     }
-    if (OP != OP_GATE_RES) {
+    if (OP != OP_GATE_RES && OP != OP_ADD_BIAS_RELU) {
       // fixed-order combine of the groups' column partials
       red[threadIdx.x] = cs;
       __syncthreads();
@@ -287,6 +294,16 @@ int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t 
   if (!vec_shape_ok(H, prev ? ldp : 0, ldu, ldo) || !ok16(prev) || !ok16(upd) || !ok16(out)) return DMP_ERR_UNSUPPORTED;
   RowArgs p{prev, ldp, upd, ldu, gate, nullptr, out, ldo, nullptr, R, H};
   return launch_rowop<OP_GATE_RES>(p, (hipStream_t)stream);
+}
+
+int dmp_add_bias_relu(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, int64_t R, int H,
+                      float *out, int64_t ldo, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0);
+  if (R == 0) return DMP_OK;
+  DMP_ROW_CHECK(a && b && out && lda >= H && ldb >= H && ldo >= H);
+  if (!vec_shape_ok(H, lda, ldb, ldo) || !ok16(a) || !ok16(b) || !ok16(out) || !ok16(bias)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{a, lda, b, ldb, bias, nullptr, out, ldo, nullptr, R, H};
+  return launch_rowop<OP_ADD_BIAS_RELU>(p, (hipStream_t)stream);
 }
 
 int dmp_scale_rows_colsum(const float *dOut, int64_t ldd, const float *gate, int64_t R, int H, float *dUpd,

@@ -93,6 +93,16 @@ def gate_residual(prev, upd, gate):
     return out
 
 
+def add_bias_relu_(a, b, bias):
+    """a <- relu(a + b + bias) in one pass (``b`` may be a column slice of a wider matrix)."""
+    lib = _lib.load()
+    R, H = a.shape
+    with _lib.timed("add_bias_relu[H=%d,R=%d]" % (H, R), 12 * H * R):
+        check(lib.dmp_add_bias_relu(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), R, H, ptr(a), a.stride(0),
+                                    stream_ptr()), "dmp_add_bias_relu")
+    return a
+
+
 def scale_rows_colsum(d_out, gate):
     """-> (gate (.) d_out  [aliases d_out when gate is None], column sums [H])."""
     lib = _lib.load()
@@ -329,10 +339,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
         XP = x @ Wx
-        H1n = S @ Bn
-        H1n += XP[:, :H]
-        H1n += bn
-        H1n.relu_()
+        H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn)
         On = torch.addmm(nb2, H1n, nW2.t())
         xn = gate_residual(x if residual else None, On, v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 14
+#define DMP_ABI_VERSION 15
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -349,6 +349,12 @@ int64_t dmp_colsum_partial_rows(int64_t rows, int H);
 int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t ldu,
                       const float *gate, int64_t rows, int H, float *out, int64_t ldo,
                       void *stream);
+
+/* First MLP Linear of the node update after the fold (dmpnn.py:129-140):  out = relu(a + b + bias)
+ * in one pass -- a: the projected aggregate S Bn, b: the self-loop projection (a column slice of XP),
+ * bias [H] or NULL.  out may alias a. */
+int dmp_add_bias_relu(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias,
+                      int64_t rows, int H, float *out, int64_t ldo, void *stream);
 
 /*
  * Backward of the gate and the bias gradient of the layer before it:

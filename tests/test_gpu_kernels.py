@@ -206,6 +206,12 @@ def test_row_epilogue_kernels(rows, h, gpu):
     assert th.equal(dg, th.cat([a, a * coef[dst.long()][:, None]], 1))
     assert th.allclose(cs, a.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
     assert th.allclose(fused.colsum(a), a.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    # relu(a + b + bias) in place, b a column slice of a wider matrix
+    wide = th.randn(rows, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    a2 = a.clone()
+    assert fused.add_bias_relu_(a2, wide[:, h:2 * h], bias) is a2
+    assert th.equal(a2, ((a + wide[:, h:2 * h]) + bias).clamp_min(0))
     # two launches give identical bits (fixed reduction tree)
     assert th.equal(fused.colsum(a), fused.colsum(a))
     part = th.randn(7, 4 * h, generator=gen).to(gpu)
