@@ -33,8 +33,8 @@ struct AtbArgs {
   const int32_t *num_tiles;        // typed: [1] tiles in use (device)
   int plain_tiles;                 // rows variant: ceil(E / 32)
   const float *gate;               // rows variant: row scale of Z or NULL
-  float *pT, *pB;                  // [gridDim.x] partials, `pstride` floats apart
-  int64_t pstride;
+  float *pT, *pB;                  // [gridDim.x] partials, `pstride` floats apart, rows `ldp` floats apart
+  int64_t pstride; int ldp;
   float *pCS;                      // rows variant: [gridDim.x, 128] column sums of g (.) Z
 };
 
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
     __syncthreads();
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) {
-      const int o = (m * kGroupThreads + gtid) * 4;
-      const float4 v = *reinterpret_cast<const float4 *>(&smem[o]);
+      const int l = (m * kGroupThreads + gtid) * 4;         // element (l / 128, l % 128) of the total
+      const float4 v = *reinterpret_cast<const float4 *>(&smem[l]);
+      const int o = (l >> 7) * p.ldp + (l & 127);
       float4 t = v, b = make_float4(c * v.x, c * v.y, c * v.z, c * v.w);
       if (emitted) {
         const float4 t0 = *reinterpret_cast<const float4 *>(pt + o);
@@ -335,7 +336,9 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   AtbArgs a{};
   a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
   a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
-  a.pstride = partial_B == partial_T + 128 * 128 ? 2 * 128 * 128 : 128 * 128;   // interleaved [G][2][H*H] or two [G][H*H]
+  const bool wide = partial_B == partial_T + 128;          // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
+  a.pstride = wide ? 2 * 128 * 128 : 128 * 128;
+  a.ldp = wide ? 256 : 128;
   if (!lds_ready<true>()) return DMP_ERR_HIP;
   atb_k<true><<<atb_blocks(tiles_bound), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
@@ -354,7 +357,7 @@ int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const
   if (!fits32(rows, lda) || !fits32(rows, ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
-  a.gate = gate; a.pT = partial; a.pstride = 128 * 128; a.pCS = partial_colsum;
+  a.gate = gate; a.pT = partial; a.pstride = 128 * 128; a.ldp = 128; a.pCS = partial_colsum;
   if (!lds_ready<false>()) return DMP_ERR_HIP;
   atb_k<false><<<atb_blocks(a.plain_tiles), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();

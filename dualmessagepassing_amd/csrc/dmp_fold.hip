@@ -1,0 +1,262 @@
+// Parameter algebra of the fused DMPNN layer for ALL layers of a rep-net in one launch each.
+//
+// The layer folds the first Linear of its two MLPs into the projections (dmpnn.py:111-156: the projections
+// are linear and feed a Linear):  C = M W0^T  with  M = [W_loop; W_in; W_out; bias]  (node side) or
+// [W_eloop; W_src - W_dst; W_dst; W_src; ebias]  (edge side).  Per layer that is a dozen [<=513,128]x[128,128]
+// products, concatenations and bias additions -- microseconds of arithmetic, but two dozen launches per layer
+// and step when done with library calls.  Here:
+//   dmp_fold_layers    every block row of every layer's C, written straight into the layouts the layer's
+//                      kernels read (Bn [2H,H], bn [H], Wx [H,3H], Wes [H,2H], be [H])
+//   dmp_unfold_layers  the backward: dM = dC W0 (row jobs, with the +-d(src-dst) terms folded in) and
+//                      dW0 = dC^T M (column jobs over the gathered block rows)
+// H = 128 only (one 128-wide output panel per job).  Plain fp32 FMAs through LDS tiles; nothing here is
+// bandwidth- or MFMA-relevant, the point is the launch count.
+#include <initializer_list>
+
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+constexpr int kH = 128;
+constexpr int kThreads = 256;
+constexpr int kRowsPerWG = 16;
+constexpr int kPad = 132;
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// out[i, :] = (A[i, :] + s2 * A2[i, :]) op(W) (+ addv), rows x 128, contraction over 128:
+//   wT = 1: out[i, j] = sum_k a[i, k] W[j, k]   (C = M W0^T: W0 in nn.Linear layout [out, in])
+//   wT = 0: out[i, k] = sum_j a[i, j] W[j, k]   (dM = dC W0)
+struct RowJob {
+  const float *A; const float *A2; const float *W; const float *addv; float *out;
+  int lda, lda2, ldo, rows, wT;
+  float s2;
+};
+constexpr int kMaxRowJobs = 27;
+struct RowJobs { RowJob job[kMaxRowJobs]; int blk0[kMaxRowJobs + 1]; int n; };
+
+__global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
+  __shared__ float As[kRowsPerWG * kPad];
+  __shared__ float Ws[32 * kPad];
+  int q = 0;
+  while (q + 1 < t.n && (int)blockIdx.x >= t.blk0[q + 1]) ++q;
+  const RowJob &jb = t.job[q];
+  const int i0 = ((int)blockIdx.x - t.blk0[q]) * kRowsPerWG;
+  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15;
+  // the 16 x 128 operand rows (zero past the job's rows)
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 + row < jb.rows) {
+      a = ldg4(jb.A + (int64_t)(i0 + row) * jb.lda + c4);
+      if (jb.A2) {
+        const float4 b = ldg4(jb.A2 + (int64_t)(i0 + row) * jb.lda2 + c4);
+        a.x += jb.s2 * b.x; a.y += jb.s2 * b.y; a.z += jb.s2 * b.z; a.w += jb.s2 * b.w;
+      }
+    }
+    *reinterpret_cast<float4 *>(&As[row * kPad + c4]) = a;
+  }
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int k0 = 0; k0 < kH; k0 += 32) {
+    __syncthreads();
+    if (jb.wT) {                                            // Ws[kk][j] = W[j][k0 + kk]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
+        const float4 w = ldg4(jb.W + j * kH + k0 + kk4);
+        Ws[(kk4 + 0) * kPad + j] = w.x; Ws[(kk4 + 1) * kPad + j] = w.y;
+        Ws[(kk4 + 2) * kPad + j] = w.z; Ws[(kk4 + 3) * kPad + j] = w.w;
+      }
+    } else {                                                // Ws[jj][k] = W[k0 + jj][k]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+        *reinterpret_cast<float4 *>(&Ws[row * kPad + c4]) = ldg4(jb.W + (k0 + row) * kH + c4);
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float a = As[r * kPad + k0 + kk];
+      const float4 w0 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8]);
+      const float4 w1 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8 + 4]);
+      acc[0] += a * w0.x; acc[1] += a * w0.y; acc[2] += a * w0.z; acc[3] += a * w0.w;
+      acc[4] += a * w1.x; acc[5] += a * w1.y; acc[6] += a * w1.z; acc[7] += a * w1.w;
+    }
+  }
+  if (i0 + r < jb.rows) {
+    if (jb.addv) {
+      const float4 v0 = ldg4(jb.addv + cg * 8), v1 = ldg4(jb.addv + cg * 8 + 4);
+      acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+      acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+    }
+    float *o = jb.out + (int64_t)(i0 + r) * jb.ldo + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// out[j, k] = sum over the sources s and their rows i of dC_s[i, j] * (M_s[i, k] - M2_s[i, k]):  dW0 = dC^T M
+struct ColSrc { const float *dC; const float *M; const float *M2; int ldc, rows; };
+struct ColJob { ColSrc src[5]; float *out; int nsrc; };
+constexpr int kMaxColJobs = 6;
+struct ColJobs { ColJob job[kMaxColJobs]; int n; };
+
+__global__ __launch_bounds__(kThreads) void coljob_k(const ColJobs t) {
+  __shared__ float Cs[kRowsPerWG * 17];
+  __shared__ float Ms[kRowsPerWG * kPad];
+  const ColJob &jb = t.job[blockIdx.x / (kH / kRowsPerWG)];
+  const int j0 = ((int)blockIdx.x % (kH / kRowsPerWG)) * kRowsPerWG;
+  const int tid = threadIdx.x, jr = tid >> 4, cg = tid & 15;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int s = 0; s < jb.nsrc; ++s) {
+    const ColSrc &sr = jb.src[s];
+    for (int i0 = 0; i0 < sr.rows; i0 += kRowsPerWG) {
+      __syncthreads();
+      {
+        const int i = tid >> 4, jj = tid & 15;
+        Cs[i * 17 + jj] = i0 + i < sr.rows ? sr.dC[(int64_t)(i0 + i) * sr.ldc + j0 + jj] : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + row < sr.rows) {
+          a = ldg4(sr.M + (i0 + row) * kH + c4);
+          if (sr.M2) {
+            const float4 b = ldg4(sr.M2 + (i0 + row) * kH + c4);
+            a.x -= b.x; a.y -= b.y; a.z -= b.z; a.w -= b.w;
+          }
+        }
+        *reinterpret_cast<float4 *>(&Ms[row * kPad + c4]) = a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kRowsPerWG; ++i) {
+        const float c = Cs[i * 17 + jr];
+        const float4 w0 = *reinterpret_cast<const float4 *>(&Ms[i * kPad + cg * 8]);
+        const float4 w1 = *reinterpret_cast<const float4 *>(&Ms[i * kPad + cg * 8 + 4]);
+        acc[0] += c * w0.x; acc[1] += c * w0.y; acc[2] += c * w0.z; acc[3] += c * w0.w;
+        acc[4] += c * w1.x; acc[5] += c * w1.y; acc[6] += c * w1.z; acc[7] += c * w1.w;
+      }
+    }
+  }
+  float *o = jb.out + (j0 + jr) * kH + cg * 8;
+  *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+inline void add_row_job(RowJobs &t, int &blocks, const float *A, int lda, const float *A2, int lda2, float s2, const float *W,
+                        int wT, float *out, int ldo, const float *addv, int rows) {
+  RowJob &j = t.job[t.n];
+  j.A = A; j.lda = lda; j.A2 = A2; j.lda2 = lda2; j.s2 = s2; j.W = W; j.wT = wT; j.out = out; j.ldo = ldo; j.addv = addv;
+  j.rows = rows;
+  t.blk0[t.n] = blocks;
+  blocks += (rows + kRowsPerWG - 1) / kRowsPerWG;
+  t.n += 1;
+  t.blk0[t.n] = blocks;
+}
+
+inline bool all16(std::initializer_list<const void *> ps) {
+  for (const void *q : ps)
+    if (!q || (reinterpret_cast<uintptr_t>(q) & 15u)) return false;
+  return true;
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int num_layers, int H, void *stream) {
+  if (num_layers < 0 || (num_layers > 0 && (!w || !f))) return DMP_ERR_BAD_ARG;
+  if (H != kH) return DMP_ERR_UNSUPPORTED;
+  for (int l0 = 0; l0 < num_layers; l0 += DMP_FOLD_MAX_LAYERS) {
+    RowJobs t;
+    t.n = 0;
+    int blocks = 0;
+    for (int l = l0; l < num_layers && l < l0 + DMP_FOLD_MAX_LAYERS; ++l) {
+      const dmp_layer_weights &a = w[l];
+      const dmp_layer_folded &o = f[l];
+      if (!all16({a.nloop_w, a.in_w, a.out_w, a.nbias, a.eloop_w, a.src_w, a.dst_w, a.ebias, a.nW0, a.nb0, a.eW0, a.eb0, o.Bn,
+                  o.bn, o.Wx, o.Wes, o.be}))
+        return DMP_ERR_BAD_ARG;
+      // node side: Cn = [W_loop; W_in; W_out; nbias] W0n^T -> Wx[:, 0:H], Bn[0:H], Bn[H:2H], bn (+ nb0)
+      add_row_job(t, blocks, a.nloop_w, kH, nullptr, 0, 0.f, a.nW0, 1, o.Wx, 3 * kH, nullptr, kH);
+      add_row_job(t, blocks, a.in_w, kH, nullptr, 0, 0.f, a.nW0, 1, o.Bn, kH, nullptr, kH);
+      add_row_job(t, blocks, a.out_w, kH, nullptr, 0, 0.f, a.nW0, 1, o.Bn + kH * kH, kH, nullptr, kH);
+      add_row_job(t, blocks, a.nbias, kH, nullptr, 0, 0.f, a.nW0, 1, o.bn, kH, a.nb0, 1);
+      // edge side: Ce = [W_eloop; W_src - W_dst; W_dst; W_src; ebias] W0e^T -> Wes[:, 0:H], Wes[:, H:2H], Wx[:, H:2H], Wx[:, 2H:3H], be (+ eb0)
+      add_row_job(t, blocks, a.eloop_w, kH, nullptr, 0, 0.f, a.eW0, 1, o.Wes, 2 * kH, nullptr, kH);
+      add_row_job(t, blocks, a.src_w, kH, a.dst_w, kH, -1.f, a.eW0, 1, o.Wes + kH, 2 * kH, nullptr, kH);
+      add_row_job(t, blocks, a.dst_w, kH, nullptr, 0, 0.f, a.eW0, 1, o.Wx + kH, 3 * kH, nullptr, kH);
+      add_row_job(t, blocks, a.src_w, kH, nullptr, 0, 0.f, a.eW0, 1, o.Wx + 2 * kH, 3 * kH, nullptr, kH);
+      add_row_job(t, blocks, a.ebias, kH, nullptr, 0, 0.f, a.eW0, 1, o.be, kH, a.eb0, 1);
+    }
+    rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    const int rc = check_launch();
+    if (rc != DMP_OK) return rc;
+  }
+  return DMP_OK;
+}
+
+int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *g, const dmp_layer_weight_grads *d,
+                      int num_layers, int H, void *stream) {
+  if (num_layers < 0 || (num_layers > 0 && (!w || !g || !d))) return DMP_ERR_BAD_ARG;
+  if (H != kH) return DMP_ERR_UNSUPPORTED;
+  for (int l0 = 0; l0 < num_layers; l0 += DMP_FOLD_MAX_LAYERS) {
+    RowJobs t;
+    ColJobs c;
+    t.n = 0;
+    c.n = 0;
+    int blocks = 0;
+    for (int l = l0; l < num_layers && l < l0 + DMP_FOLD_MAX_LAYERS; ++l) {
+      const dmp_layer_weights &a = w[l];
+      const dmp_layer_folded_grads &u = g[l];
+      const dmp_layer_weight_grads &o = d[l];
+      if (!all16({a.nloop_w, a.in_w, a.out_w, a.nbias, a.eloop_w, a.src_w, a.dst_w, a.ebias, a.nW0, a.eW0, u.dBn, u.dbn, u.dWx,
+                  u.dWes, u.dbe, o.nloop_w, o.in_w, o.out_w, o.nbias, o.eloop_w, o.src_w, o.dst_w, o.ebias, o.nW0, o.eW0}))
+        return DMP_ERR_BAD_ARG;
+      // dM = dC W0; the rows of d(W_src - W_dst) = dWes[:, H:2H] W0e enter d_dst with -, d_src with +
+      add_row_job(t, blocks, u.dWx, 3 * kH, nullptr, 0, 0.f, a.nW0, 0, o.nloop_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dBn, kH, nullptr, 0, 0.f, a.nW0, 0, o.in_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dBn + kH * kH, kH, nullptr, 0, 0.f, a.nW0, 0, o.out_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dbn, kH, nullptr, 0, 0.f, a.nW0, 0, o.nbias, kH, nullptr, 1);
+      add_row_job(t, blocks, u.dWes, 2 * kH, nullptr, 0, 0.f, a.eW0, 0, o.eloop_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dWx + kH, 3 * kH, u.dWes + kH, 2 * kH, -1.f, a.eW0, 0, o.dst_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dWx + 2 * kH, 3 * kH, u.dWes + kH, 2 * kH, 1.f, a.eW0, 0, o.src_w, kH, nullptr, kH);
+      add_row_job(t, blocks, u.dbe, kH, nullptr, 0, 0.f, a.eW0, 0, o.ebias, kH, nullptr, 1);
+      // dW0 = dC^T M over the block rows
+      ColJob &n = c.job[c.n++];
+      n.out = o.nW0; n.nsrc = 4;
+      n.src[0] = ColSrc{u.dWx, a.nloop_w, nullptr, 3 * kH, kH};
+      n.src[1] = ColSrc{u.dBn, a.in_w, nullptr, kH, kH};
+      n.src[2] = ColSrc{u.dBn + kH * kH, a.out_w, nullptr, kH, kH};
+      n.src[3] = ColSrc{u.dbn, a.nbias, nullptr, kH, 1};
+      ColJob &e = c.job[c.n++];
+      e.out = o.eW0; e.nsrc = 5;
+      e.src[0] = ColSrc{u.dWes, a.eloop_w, nullptr, 2 * kH, kH};
+      e.src[1] = ColSrc{u.dWes + kH, a.src_w, a.dst_w, 2 * kH, kH};
+      e.src[2] = ColSrc{u.dWx + kH, a.dst_w, nullptr, 3 * kH, kH};
+      e.src[3] = ColSrc{u.dWx + 2 * kH, a.src_w, nullptr, 3 * kH, kH};
+      e.src[4] = ColSrc{u.dbe, a.ebias, nullptr, kH, 1};
+    }
+    rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    int rc = check_launch();
+    if (rc != DMP_OK) return rc;
+    coljob_k<<<c.n * (kH / kRowsPerWG), kThreads, 0, (hipStream_t)stream>>>(c);
+    rc = check_launch();
+    if (rc != DMP_OK) return rc;
+  }
+  return DMP_OK;
+}
+
+}  // extern "C"

@@ -174,7 +174,7 @@ class DMPLayer(nn.Module):
                 return False
         return True
 
-    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True):
+    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
@@ -188,7 +188,7 @@ class DMPLayer(nn.Module):
         coef = ix.degree_coef(g.ndata[OUTDEGREE])
         vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
         eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
-        return fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self)
+        return fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded)
 
     def extra_repr(self):
         return "in=%s, out=%s" % (self.input_dim, self.hidden_dim)
@@ -341,8 +341,10 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     union = u[1]
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):
         return None
-    for layer in layers:
-        v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual)
+    from . import fused
+    folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch
+    for layer, fw in zip(layers, folded):
+        v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw)
     p_v, g_v = _SplitRows.apply(v, np_)
     p_e, g_e = _SplitRows.apply(e, ep_)
     return p_v, p_e, g_v, g_e, v, e

@@ -250,18 +250,18 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
 
 
 def atb_typed(z, d_pre, coef, index):
-    """``(z^T d_pre, z^T (coef[dst] (.) d_pre))``  (two [H, H]) over the class-sorted tiles: one product's worth
-    of MFMAs for both (csrc/dmp_typed.hip::atb_typed_k), one fixed-order reduction of the workgroup partials."""
+    """``[z^T d_pre | z^T (coef[dst] (.) d_pre)]``  ([H, 2H]: the gradient of ``Wes`` in its layout) over the
+    class-sorted tiles: one product's worth of MFMAs for both halves (csrc/dmp_atb.hip), one fixed-order
+    reduction of the workgroup partials."""
     lib = _lib.load()
     E, H = z.shape
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     G = int(lib.dmp_atb_typed_blocks(bound))
-    part = torch.empty((G, 2, H * H), dtype=torch.float32, device=z.device)
+    part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]" % (H, E), 8 * H * E):
         check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
-                                ptr(num_tiles), bound, E, H, ptr(part), ptr(part[0, 1]), stream_ptr()), "dmp_atb_typed")
-    both = reduce_partials(part.view(G, -1)).view(2, H, H)
-    return both[0], both[1]
+                                ptr(num_tiles), bound, E, H, ptr(part), ptr(part[0, 0, H:]), stream_ptr()), "dmp_atb_typed")
+    return reduce_partials(part.view(G, -1)).view(H, 2 * H)
 
 
 def out_fwd_mfma(h1, W2, b2, gate, prev):
@@ -318,24 +318,122 @@ def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
     return out
 
 
-class _FusedDMPLayer(torch.autograd.Function):
+# ----------------------------------------------------------------------------- parameter algebra (fold / unfold)
+_FOLD_IN = ("nloop_w", "in_w", "out_w", "nbias", "eloop_w", "src_w", "dst_w", "ebias", "nW0", "nb0", "eW0", "eb0")
+_FOLD_OUT = ("Bn", "bn", "Wx", "Wes", "be")
+_FOLD_GRAD = ("nloop_w", "in_w", "out_w", "nbias", "eloop_w", "src_w", "dst_w", "ebias", "nW0", "eW0")
+
+
+def _struct(name, fields):
+    import ctypes
+    return type(name, (ctypes.Structure,), {"_fields_": [(f, ctypes.c_void_p) for f in fields]})
+
+
+_LayerWeights = _struct("dmp_layer_weights", _FOLD_IN)
+_LayerFolded = _struct("dmp_layer_folded", _FOLD_OUT)
+_LayerFoldedGrads = _struct("dmp_layer_folded_grads", ["d" + f for f in _FOLD_OUT])
+_LayerWeightGrads = _struct("dmp_layer_weight_grads", _FOLD_GRAD)
+
+
+def _carve(buf, shapes):
+    out, off = [], 0
+    for shp in shapes:
+        n = 1
+        for d in shp:
+            n *= d
+        out.append(buf[off:off + n].view(shp))
+        off += n
+    return out
+
+
+class _FoldLayers(torch.autograd.Function):
+    """The first MLP Linear of every layer folded into its projections (see include/dmp_hip.h,
+    ``dmp_fold_layers``): one launch forward, two backward, for all layers -- instead of a dozen small
+    library products, concatenations and additions per layer and direction."""
+
     @staticmethod
-    def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, in_w, out_w, src_w, dst_w, nloop_w, eloop_w,
-                nbias, ebias, nW0, nb0, nW2, nb2, eW0, eb0, eW2, eb2):
+    def forward(ctx, L, *params):
+        lib = _lib.load()
+        params = [p.detach().contiguous() for p in params]
+        _lib.require_gpu(*params)
+        H = params[0].size(1)
+        shapes = [(2 * H, H), (H,), (H, 3 * H), (H, 2 * H), (H,)]
+        per = sum(a[0] * (a[1] if len(a) > 1 else 1) for a in shapes)
+        buf = torch.empty(L * per, dtype=torch.float32, device=params[0].device)
+        W, F, outs = (_LayerWeights * L)(), (_LayerFolded * L)(), []
+        for l in range(L):
+            for name, t in zip(_FOLD_IN, params[12 * l:12 * l + 12]):
+                setattr(W[l], name, ptr(t))
+            views = _carve(buf[l * per:(l + 1) * per], shapes)
+            for name, t in zip(_FOLD_OUT, views):
+                setattr(F[l], name, ptr(t))
+            outs += views
+        check(lib.dmp_fold_layers(W, F, L, H, stream_ptr()), "dmp_fold_layers")
+        ctx.save_for_backward(*params)
+        ctx.L, ctx.H, ctx.weights = L, H, W
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        params = ctx.saved_tensors
+        L, H = ctx.L, ctx.H
+        shapes = [(H, H), (H, H), (H, H), (H,), (H, H), (H, H), (H, H), (H,), (H, H), (H, H)]
+        per = 8 * H * H + 2 * H
+        buf = torch.empty(L * per, dtype=torch.float32, device=params[0].device)
+        G, D, out, keep = (_LayerFoldedGrads * L)(), (_LayerWeightGrads * L)(), [None], []
+        fshapes = [(2 * H, H), (H,), (H, 3 * H), (H, 2 * H), (H,)]
+        for l in range(L):
+            gl = []
+            for g, shp, name in zip(grads[5 * l:5 * l + 5], fshapes, _FOLD_OUT):
+                g = torch.zeros(shp, dtype=torch.float32, device=buf.device) if g is None else g.contiguous()
+                setattr(G[l], "d" + name, ptr(g))
+                gl.append(g)
+            keep.append(gl)
+            d = _carve(buf[l * per:(l + 1) * per], shapes)
+            for name, t in zip(_FOLD_GRAD, d):
+                setattr(D[l], name, ptr(t))
+            # order of the inputs: nloop, in, out, nbias, eloop, src, dst, ebias, nW0, nb0 (= dbn), eW0, eb0 (= dbe)
+            out += d[:9] + [gl[1], d[9], gl[4]]
+        check(lib.dmp_unfold_layers(ctx.weights, G, D, L, H, stream_ptr()), "dmp_unfold_layers")
+        return tuple(out)
+
+
+def _layer_params(layer):
+    n0, e0 = layer.nmlp[0], layer.emlp[0]
+    return (layer.nloop_weight, layer.in_weight, layer.out_weight, layer.nbias, layer.eloop_weight, layer.src_weight,
+            layer.dst_weight, layer.ebias, n0.weight, n0.bias, e0.weight, e0.bias)
+
+
+def fold_layers(layers):
+    """-> one ``(Bn, bn, Wx, Wes, be)`` per layer.  H = 128 on the GPU: one HIP launch for all layers (and two
+    for their backward); otherwise the same algebra in differentiable torch ops."""
+    layers = list(layers)
+    H = layers[0].nloop_weight.size(1)
+    if H == 128 and layers[0].nloop_weight.is_cuda and all(l.nloop_weight.size(1) == H for l in layers):
+        flat = _FoldLayers.apply(len(layers), *[p for l in layers for p in _layer_params(l)])
+        return [tuple(flat[5 * i:5 * i + 5]) for i in range(len(layers))]
+    out = []
+    for l in layers:
+        nloop, in_w, out_w, nbias, eloop, src_w, dst_w, ebias, nW0, nb0, eW0, eb0 = _layer_params(l)
+        Cn = torch.cat([nloop, in_w, out_w, nbias.unsqueeze(0)], dim=0) @ nW0.t()               # [3H+1, H]
+        Ce = torch.cat([eloop, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], dim=0) @ eW0.t()  # [4H+1, H]
+        out.append((Cn[H:3 * H], Cn[3 * H] + nb0, torch.cat([Cn[:H], Ce[2 * H:3 * H], Ce[3 * H:4 * H]], dim=1),
+                    torch.cat([Ce[:H], Ce[H:2 * H]], dim=1), Ce[4 * H] + eb0))
+    return out
+
+
+class _FusedDMPLayer(torch.autograd.Function):
+    """One DMPNN layer + gate + residual over the folded weights of ``fold_layers``."""
+
+    @staticmethod
+    def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2):
         _lib.require_gpu(x, z)
-        H = nloop_w.size(1)
+        H = Bn.size(1)
         x, z = x.contiguous(), z.contiguous()
+        Bn, Wx, Wes = Bn.contiguous(), Wx.contiguous(), Wes.contiguous()
         N = index.num_nodes
-        # ---- fold the first Linear of each MLP into the projections (tiny [.,H]x[H,H] products)
-        Mn = torch.cat([nloop_w, in_w, out_w, nbias.unsqueeze(0)], dim=0)           # [3H+1, H]
-        Cn = Mn @ nW0.t()
-        Me = torch.cat([eloop_w, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], dim=0)  # [4H+1, H]
-        Ce = Me @ eW0.t()
-        Bn = Cn[H:3 * H]                                                            # [Win;Wout] W0n^T
-        bn = Cn[3 * H] + nb0
-        Wx = torch.cat([Cn[:H], Ce[2 * H:3 * H], Ce[3 * H:4 * H]], dim=1)           # [H,3H]
-        Wes = torch.cat([Ce[:H], Ce[H:2 * H]], dim=1)                                # [H,2H]
-        be = Ce[4 * H] + eb0
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
         XP = x @ Wx
@@ -357,18 +455,18 @@ class _FusedDMPLayer(torch.autograd.Function):
             zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate = v_gate, e_gate
-        ctx.save_for_backward(x, z, S, H1n, H1e, Mn, Me, Bn, Wx, Wes, nW0, nW2, eW0, eW2)
+        ctx.save_for_backward(x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
         return xn, zn
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dxn, dzn):
-        x, z, S, H1n, H1e, Mn, Me, Bn, Wx, Wes, nW0, nW2, eW0, eW2 = ctx.saved_tensors
+        x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2 = ctx.saved_tensors
         ix, coef, H = ctx.index, ctx.coef, ctx.H
         N = ix.num_nodes
         dxn, dzn = dxn.contiguous(), dzn.contiguous()
-        # the parameter-gradient partials (biases, split-K weight gradients) are only consumed by the unfold step
-        # below: their nine reductions run as one launch when this block is left
+        # the parameter-gradient partials (biases, split-K weight gradients) are consumed after the layer (by the
+        # unfold of fold_layers / the optimizer): their reductions run as one launch when this block is left
         with deferred_reductions():
             # ---- edge side, down to the gathered node projections
             mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
@@ -379,22 +477,16 @@ class _FusedDMPLayer(torch.autograd.Function):
             else:
                 dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
                 dW2e = atb(dOe, H1e)
-            if typed:
-                pass
-            elif mfma:
-                dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=True)         # dG[:, :H] is dPre
-            else:
-                dH1e = dOe @ eW2
-                dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
-                del dH1e
+                if mfma:
+                    dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=True)     # dG[:, :H] is dPre
+                else:
+                    dH1e = dOe @ eW2
+                    dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
+                    del dH1e
             inc_ptr, inc_ent = ix.incidence()
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
             ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:])
-            if typed:
-                dAe, dBe = atb_typed(z, dG, coef, ix)
-            else:
-                dWes = atb(z, dG)                                        # [H,2H] = [dA_e | dB_e]
-                dAe, dBe = dWes[:, :H], dWes[:, H:]
+            dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
             dW2n = atb(dOn, H1n)
@@ -418,26 +510,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
-        # ---- unfold: C = M @ W0^T  =>  dM = dC @ W0,  dW0 = dC^T @ M
-        dCn = torch.cat([dWx[:, :H], dBn, dbn.unsqueeze(0)], dim=0)                  # [3H+1, H]
-        dMn = dCn @ nW0
-        dW0n = dCn.t() @ Mn
-        dCe = torch.cat([dAe, dBe, dWx[:, H:2 * H], dWx[:, 2 * H:], dbe.unsqueeze(0)], dim=0)
-        dMe = dCe @ eW0
-        dW0e = dCe.t() @ Me
-        d_nloop, d_in, d_out, dnb = dMn[:H], dMn[H:2 * H], dMn[2 * H:3 * H], dMn[3 * H]
-        d_eloop, d_sd = dMe[:H], dMe[H:2 * H]
-        d_dst = dMe[2 * H:3 * H] - d_sd
-        d_src = dMe[3 * H:4 * H] + d_sd
-        deb = dMe[4 * H]
-        return (None, None, None, dx, dz, None, None, d_in, d_out, d_src, d_dst, d_nloop, d_eloop, dnb, deb,
-                dW0n, dbn, dW2n, db2n, dW0e, dbe, dW2e, db2e)
+        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e)
 
 
-def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer):
-    n0, n2 = layer.nmlp[0], layer.nmlp[2]
-    e0, e2 = layer.emlp[0], layer.emlp[2]
-    return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, layer.in_weight, layer.out_weight,
-                                layer.src_weight, layer.dst_weight, layer.nloop_weight, layer.eloop_weight,
-                                layer.nbias, layer.ebias, n0.weight, n0.bias, n2.weight, n2.bias, e0.weight, e0.bias,
-                                e2.weight, e2.bias)
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None):
+    """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch)."""
+    n2, e2 = layer.nmlp[2], layer.emlp[2]
+    Bn, bn, Wx, Wes, be = folded if folded is not None else fold_layers([layer])[0]
+    return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
+                                n2.weight, n2.bias, e2.weight, e2.bias)

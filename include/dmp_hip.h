@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 15
+#define DMP_ABI_VERSION 16
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -409,6 +409,31 @@ int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, void *stream);
 
+/*
+ * Parameter algebra of the fused layer for all layers of a rep-net in one launch (H = 128 only).
+ * The first Linear of the node / edge MLP (dmpnn.py:45-60,129-156) is folded into the projections that
+ * feed it:  [W_loop; W_in; W_out; nbias] W0n^T  and  [W_eloop; W_src - W_dst; W_dst; W_src; ebias] W0e^T,
+ * written in the layouts the layer kernels read:
+ *   Bn [2H,H] = [W_in; W_out] W0n^T,   bn [H] = nbias W0n^T + nb0,
+ *   Wx [H,3H] = [W_loop W0n^T | W_dst W0e^T | W_src W0e^T],
+ *   Wes [H,2H] = [W_eloop W0e^T | (W_src - W_dst) W0e^T],   be [H] = ebias W0e^T + eb0.
+ * All weights [H,H] row-major as the reference stores them (dmpnn.py:97-109; W0: nn.Linear [out,in]),
+ * biases [H]; every pointer 16-byte aligned.  The struct arrays are HOST arrays of num_layers entries.
+ * dmp_unfold_layers is the backward: from the gradients of the folded tensors to those of the weights
+ * (the gradients of nb0 / eb0 are dbn / dbe themselves and are not written).
+ */
+#define DMP_FOLD_MAX_LAYERS 3   /* layers per launch; more are split over launches */
+typedef struct {
+  const float *nloop_w, *in_w, *out_w, *nbias, *eloop_w, *src_w, *dst_w, *ebias, *nW0, *nb0, *eW0, *eb0;
+} dmp_layer_weights;
+typedef struct { float *Bn, *bn, *Wx, *Wes, *be; } dmp_layer_folded;
+typedef struct { const float *dBn, *dbn, *dWx, *dWes, *dbe; } dmp_layer_folded_grads;
+typedef struct { float *nloop_w, *in_w, *out_w, *nbias, *eloop_w, *src_w, *dst_w, *ebias, *nW0, *eW0; } dmp_layer_weight_grads;
+int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int num_layers, int H,
+                    void *stream);
+int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *g,
+                      const dmp_layer_weight_grads *d, int num_layers, int H, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */
 /* ------------------------------------------------------------------------- */
@@ -500,8 +525,9 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  * W = [A' | B']) from ONE pass and one product's worth of MFMAs.  Every workgroup walks a contiguous
  * range of the class-sorted tiles and writes two [H,H] partials (running total, coefficient-weighted
  * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats each -- or, when
- * partial_B == partial_T + H*H, one interleaved [blocks, 2, H*H] buffer --, to be summed with
- * dmp_reduce_partials (fixed order: bit-stable for a given tile list).
+ * partial_B == partial_T + H, one [blocks, H, 2H] buffer with [T | B] side by side (its reduction is
+ * dW = [dA' | dB'] in the layout of W) --, to be summed with dmp_reduce_partials (fixed order:
+ * bit-stable for a given tile list).
  */
 int64_t dmp_atb_typed_blocks(int64_t tiles_bound);
 int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,

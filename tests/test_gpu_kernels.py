@@ -493,12 +493,12 @@ def test_typed_weight_gradient(rows, gpu):
     coef = ix.degree_coef(ix.out_deg)
     z = th.randn(rows, h, generator=gen).to(gpu)
     d_pre = th.randn(rows, h, generator=gen).to(gpu)
-    got = th.cat(fused.atb_typed(z, d_pre, coef, ix), 1)
+    got = fused.atb_typed(z, d_pre, coef, ix)
     ce = ix.edge_select(coef)[2].double()
     want = th.cat([z.double().t() @ d_pre.double(), z.double().t() @ (d_pre.double() * ce[:, None])], 1)
     scale = float(want.abs().max())
     assert float((got.double() - want).abs().max()) <= 2e-5 * scale
-    assert th.equal(got, th.cat(fused.atb_typed(z, d_pre, coef, ix), 1))
+    assert th.equal(got, fused.atb_typed(z, d_pre, coef, ix))
     d_g, _ = fused.bwd_h1_mfma(d_pre, (th.randn(h, h, generator=gen) * 0.1).to(gpu), z.clamp_min(0), coef, ix, both_halves=False)
     assert d_g.shape == (rows, h)
 
@@ -534,3 +534,40 @@ def test_pingpong_driver_matches_default(gpu):
         lib.dmp_dev_set_mfma_variant(0)
     for a, b in zip(base, other):
         assert th.equal(a, b)
+
+
+@pytest.mark.parametrize("num_layers", [1, 3, 4])
+def test_fold_layers_matches_torch_algebra(num_layers, gpu):
+    """fused.fold_layers (dmp_fold_layers / dmp_unfold_layers: one launch for all layers) against the same
+    algebra in differentiable torch ops: the folded weights and, through a random cotangent, every parameter
+    gradient (4 layers: more than DMP_FOLD_MAX_LAYERS, split over launches)."""
+    from dualmessagepassing_amd import fused
+    from dualmessagepassing_amd.dmpnn import DMPLayer
+    th.manual_seed(num_layers)
+    h = 128
+    layers = [DMPLayer(h, h, num_mlp_layers=2).to(gpu) for _ in range(num_layers)]
+    for l in layers:
+        for p in l.parameters():
+            p.data.normal_(0.0, 0.3)
+    got = fused.fold_layers(layers)
+    assert fused._FoldLayers is not None and all(t.is_cuda for f in got for t in f)
+    want = []
+    for l in layers:
+        nloop, in_w, out_w, nbias, eloop, src_w, dst_w, ebias, nW0, nb0, eW0, eb0 = fused._layer_params(l)
+        Cn = th.cat([nloop, in_w, out_w, nbias.unsqueeze(0)], 0) @ nW0.t()
+        Ce = th.cat([eloop, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], 0) @ eW0.t()
+        want.append((Cn[h:3 * h], Cn[3 * h] + nb0, th.cat([Cn[:h], Ce[2 * h:3 * h], Ce[3 * h:4 * h]], 1),
+                     th.cat([Ce[:h], Ce[h:2 * h]], 1), Ce[4 * h] + eb0))
+    gen = th.Generator().manual_seed(5)
+    loss_g = loss_w = 0.0
+    for fg, fw in zip(got, want):
+        for a, b in zip(fg, fw):
+            assert a.shape == b.shape and th.allclose(a, b, rtol=1e-5, atol=1e-5), (a - b).abs().max()
+            cot = th.randn(a.shape, generator=gen).to(gpu)
+            loss_g = loss_g + (a * cot).sum()
+            loss_w = loss_w + (b * cot).sum()
+    params = [p for l in layers for p in fused._layer_params(l)]
+    g_got = th.autograd.grad(loss_g, params)
+    g_want = th.autograd.grad(loss_w, params)
+    for i, (a, b) in enumerate(zip(g_got, g_want)):
+        assert th.allclose(a, b, rtol=1e-5, atol=1e-4), (i, (a - b).abs().max().item())
