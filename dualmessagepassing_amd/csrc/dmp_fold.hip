@@ -106,50 +106,50 @@ struct ColJob { ColSrc src[5]; float *out; int nsrc; };
 constexpr int kMaxColJobs = 6;
 struct ColJobs { ColJob job[kMaxColJobs]; int n; };
 
+constexpr int kColChunk = 64;                               // block rows contracted per LDS round
+constexpr int kColW = 32;                                   // output columns per workgroup (x 16 output rows): 32 workgroups per job
 __global__ __launch_bounds__(kThreads) void coljob_k(const ColJobs t) {
-  __shared__ float Cs[kRowsPerWG * 17];
-  __shared__ float Ms[kRowsPerWG * kPad];
-  const ColJob &jb = t.job[blockIdx.x / (kH / kRowsPerWG)];
-  const int j0 = ((int)blockIdx.x % (kH / kRowsPerWG)) * kRowsPerWG;
-  const int tid = threadIdx.x, jr = tid >> 4, cg = tid & 15;
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  __shared__ float Cs[kColChunk * 17];
+  __shared__ float Ms[kColChunk * (kColW + 4)];
+  constexpr int kPerJob = (kH / kRowsPerWG) * (kH / kColW);
+  const ColJob &jb = t.job[blockIdx.x / kPerJob];
+  const int sub = (int)blockIdx.x % kPerJob;
+  const int j0 = (sub / (kH / kColW)) * kRowsPerWG, k0 = (sub % (kH / kColW)) * kColW;
+  const int tid = threadIdx.x, jr = tid >> 4, cq = tid & 15;
+  float acc0 = 0.f, acc1 = 0.f;
   for (int s = 0; s < jb.nsrc; ++s) {
     const ColSrc &sr = jb.src[s];
-    for (int i0 = 0; i0 < sr.rows; i0 += kRowsPerWG) {
+    for (int i0 = 0; i0 < sr.rows; i0 += kColChunk) {
       __syncthreads();
-      {
-        const int i = tid >> 4, jj = tid & 15;
+#pragma unroll
+      for (int m = 0; m < kColChunk / 16; ++m) {
+        const int i = (tid >> 4) + 16 * m, jj = tid & 15;
         Cs[i * 17 + jj] = i0 + i < sr.rows ? sr.dC[(int64_t)(i0 + i) * sr.ldc + j0 + jj] : 0.f;
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+      for (int m = 0; m < kColChunk / 32; ++m) {            // 64 rows x 32 columns = 512 float4: two per thread
+        const int row = (tid >> 3) + 32 * m, c4 = (tid & 7) * 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 + row < sr.rows) {
-          a = ldg4(sr.M + (i0 + row) * kH + c4);
+          a = ldg4(sr.M + (i0 + row) * kH + k0 + c4);
           if (sr.M2) {
-            const float4 b = ldg4(sr.M2 + (i0 + row) * kH + c4);
+            const float4 b = ldg4(sr.M2 + (i0 + row) * kH + k0 + c4);
             a.x -= b.x; a.y -= b.y; a.z -= b.z; a.w -= b.w;
           }
         }
-        *reinterpret_cast<float4 *>(&Ms[row * kPad + c4]) = a;
+        *reinterpret_cast<float4 *>(&Ms[row * (kColW + 4) + c4]) = a;
       }
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < kRowsPerWG; ++i) {
+      const int lim = sr.rows - i0 < kColChunk ? sr.rows - i0 : kColChunk;
+#pragma unroll 8
+      for (int i = 0; i < lim; ++i) {
         const float c = Cs[i * 17 + jr];
-        const float4 w0 = *reinterpret_cast<const float4 *>(&Ms[i * kPad + cg * 8]);
-        const float4 w1 = *reinterpret_cast<const float4 *>(&Ms[i * kPad + cg * 8 + 4]);
-        acc[0] += c * w0.x; acc[1] += c * w0.y; acc[2] += c * w0.z; acc[3] += c * w0.w;
-        acc[4] += c * w1.x; acc[5] += c * w1.y; acc[6] += c * w1.z; acc[7] += c * w1.w;
+        const float2 w = *reinterpret_cast<const float2 *>(&Ms[i * (kColW + 4) + cq * 2]);
+        acc0 += c * w.x; acc1 += c * w.y;
       }
     }
   }
-  float *o = jb.out + (j0 + jr) * kH + cg * 8;
-  *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  *reinterpret_cast<float2 *>(jb.out + (j0 + jr) * kH + k0 + cq * 2) = make_float2(acc0, acc1);
 }
 
 inline void add_row_job(RowJobs &t, int &blocks, const float *A, int lda, const float *A2, int lda2, float s2, const float *W,
@@ -252,7 +252,7 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
     rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
     int rc = check_launch();
     if (rc != DMP_OK) return rc;
-    coljob_k<<<c.n * (kH / kRowsPerWG), kThreads, 0, (hipStream_t)stream>>>(c);
+    coljob_k<<<c.n * (kH / kRowsPerWG) * (kH / kColW), kThreads, 0, (hipStream_t)stream>>>(c);
     rc = check_launch();
     if (rc != DMP_OK) return rc;
   }

@@ -3,7 +3,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from dualmessagepassing_amd.tuning import enable_tuned_gemms
-enable_tuned_gemms()
+if not os.environ.get("NO_TUNE"): enable_tuned_gemms()
 dev = torch.device("cuda:0")
 cfg = dict(bench.CFG)
 shard = bench.make_shard(cfg, 0, dev)
