@@ -160,7 +160,7 @@ def mfma_rooflines(kern, H, E):
     """{kernel: {avg_us, tflops, frac}} for the fused MFMA kernels seen by the HIP-event timer; flops =
     2*E*H*H per [E,H]x[H,H] product the kernel performs (1 for the class-typed kernels, out_fwd and
     bwd_h1; 2 for the two-panel edge_fwd / bwd_z)."""
-    products = {"edge_fwd_typed": 1, "bwd_z_typed": 1, "atb_typed": 1, "out_fwd_mfma": 1, "bwd_h1_mfma": 1,
+    products = {"edge_fwd_typed": 1, "bwd_z_typed": 1, "atb_typed": 1, "atb_rows": 1, "out_fwd_mfma": 1, "bwd_h1_mfma": 1,
                 "edge_fwd_mfma": 2, "bwd_z_mfma": 2}
     out = {}
     for name, v in kern.items():
@@ -316,7 +316,7 @@ def main():
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
                                       cfg["batch"], H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
-                       "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW",
+                       "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},
             "roofline": roof,
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32
