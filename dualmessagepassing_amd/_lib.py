@@ -147,8 +147,9 @@ def ptr(t):
 
 
 def stream_ptr():
+    """Raw ``hipStream_t`` of torch's current stream on the current device (what every launch is ordered on)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_gpu(*tensors):
@@ -190,18 +191,23 @@ timer = KernelTimer()
 
 
 class timed:
-    """``with timed(name, nbytes): <one kernel launch>``"""
+    """``with timed(name_format, format_args, nbytes): <one kernel launch>`` -- the name is only formatted
+    when the timer is on (the product path pays one attribute test per launch)."""
+    __slots__ = ("fmt", "args", "nbytes", "name", "on", "a", "b")
 
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, fmt, args, nbytes):
+        self.fmt, self.args, self.nbytes = fmt, args, nbytes
 
     def __enter__(self):
-        self.on = timer.enabled and (timer.only is None or self.name.startswith(timer.only))
-        if self.on:
-            import torch
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+        self.on = False
+        if timer.enabled:
+            self.name = self.fmt % self.args
+            self.on = timer.only is None or self.name.startswith(timer.only)
+            if self.on:
+                import torch
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
         return self
 
     def __exit__(self, *exc):

@@ -563,16 +563,17 @@ class GraphAdjModelV2(BaseModel):
 
     def get_subiso_pred_pooled(self, p_v_sum, p_v_mask, p_e_sum, p_e_mask, g_v_sum, g_v_mask, g_e_sum, g_e_mask):
         """``get_subiso_pred`` (basemodel.py:1477-1498) on per-graph sums instead of padded rows."""
-        cnt = lambda m: m.float().sum(dim=1).view(-1, 1)
+        cnt = lambda m: m.sum(dim=1, dtype=th.float32).view(-1, 1)
         v_pred_c = e_pred_c = None
         if self.node_pred:
+            g_v_len = cnt(g_v_mask)
             v_pred_c, _ = self.pred_net["v"].forward_pooled(p_v_sum, p_v_mask.size(1), cnt(p_v_mask),
-                                                            g_v_sum, g_v_mask.size(1), cnt(g_v_mask))
+                                                            g_v_sum, g_v_mask.size(1), g_v_len)
         if self.edge_pred:
+            g_e_len = cnt(g_e_mask)
             e_pred_c, _ = self.pred_net["e"].forward_pooled(p_e_sum, p_e_mask.size(1), cnt(p_e_mask),
-                                                            g_e_sum, g_e_mask.size(1), cnt(g_e_mask))
+                                                            g_e_sum, g_e_mask.size(1), g_e_len)
         if self.node_pred and self.edge_pred:
-            g_v_len, g_e_len = cnt(g_v_mask), cnt(g_e_mask)
             g_len = g_v_len + g_e_len
             return (g_v_len / g_len) * v_pred_c + (g_e_len / g_len) * e_pred_c, (None, None)
         if self.node_pred:

@@ -87,7 +87,7 @@ def gate_residual(prev, upd, gate):
     lib = _lib.load()
     R, H = upd.shape
     out = torch.empty_like(upd)
-    with _lib.timed("gate_residual[H=%d,R=%d]" % (H, R), 4 * H * R * (3 if prev is not None else 2) + (4 * R if gate is not None else 0)):
+    with _lib.timed("gate_residual[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2) + (4 * R if gate is not None else 0)):
         check(lib.dmp_gate_residual(ptr(prev), H, ptr(upd), H, ptr(gate), R, H, ptr(out), H, stream_ptr()),
               "dmp_gate_residual")
     return out
@@ -97,7 +97,7 @@ def add_bias_relu_(a, b, bias):
     """a <- relu(a + b + bias) in one pass (``b`` may be a column slice of a wider matrix)."""
     lib = _lib.load()
     R, H = a.shape
-    with _lib.timed("add_bias_relu[H=%d,R=%d]" % (H, R), 12 * H * R):
+    with _lib.timed("add_bias_relu[H=%d,R=%d]", (H, R), 12 * H * R):
         check(lib.dmp_add_bias_relu(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), R, H, ptr(a), a.stride(0),
                                     stream_ptr()), "dmp_add_bias_relu")
     return a
@@ -109,7 +109,7 @@ def scale_rows_colsum(d_out, gate):
     R, H = d_out.shape
     part = _partials(R, H, d_out.device)
     d_upd = torch.empty_like(d_out) if gate is not None else None
-    with _lib.timed("scale_rows_colsum[H=%d,R=%d]" % (H, R), 4 * H * R * (2 if gate is not None else 1)):
+    with _lib.timed("scale_rows_colsum[H=%d,R=%d]", (H, R), 4 * H * R * (2 if gate is not None else 1)):
         check(lib.dmp_scale_rows_colsum(ptr(d_out), H, ptr(gate), R, H, ptr(d_upd), H, ptr(part), stream_ptr()),
               "dmp_scale_rows_colsum")
     return (d_upd if gate is not None else d_out), reduce_partials(part)
@@ -123,7 +123,7 @@ def relu_bwd_colsum_(d_h, act, out=None):
     part = _partials(R, H, d_h.device)
     dst = d_h if out is None else out
     ldo = dst.stride(0) if R > 1 else H
-    with _lib.timed("relu_bwd_colsum[H=%d,R=%d]" % (H, R), 12 * H * R):
+    with _lib.timed("relu_bwd_colsum[H=%d,R=%d]", (H, R), 12 * H * R):
         check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, ptr(dst), ldo, ptr(part), stream_ptr()),
               "dmp_relu_bwd_colsum")
     return dst, reduce_partials(part)
@@ -134,7 +134,7 @@ def bwd_g_colsum(d_y, coef, dst32):
     E, H = d_y.shape
     part = _partials(E, H, d_y.device)
     d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_y.device)
-    with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]" % (H, E), 12 * H * E + 4 * E + 4 * coef.numel()):
+    with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]", (H, E), 12 * H * E + 4 * E + 4 * coef.numel()):
         check(lib.dmp_edge_combine_bwd_g_colsum(ptr(d_y), H, ptr(coef), ptr(dst32), E, H, ptr(d_g), 2 * H, ptr(part),
                                                 stream_ptr()), "dmp_edge_combine_bwd_g_colsum")
     return d_g, reduce_partials(part)
@@ -169,7 +169,7 @@ def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False):
     lib = _lib.load()
     E = index.num_edges
     Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
-    with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 9 * E + 4 * index.num_nodes):
+    with _lib.timed("edge_combine[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 9 * E + 4 * index.num_nodes):
         check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(bias), ptr(index.src32), ptr(index.dst32),
                                    ptr(index.rev8), E, H, int(relu), ptr(Y), H, stream_ptr()), "dmp_edge_combine")
     return Y
@@ -181,7 +181,7 @@ def relu_bwd_g_colsum(d_h, act, coef, dst32):
     E, H = d_h.shape
     part = _partials(E, H, d_h.device)
     d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_h.device)
-    with _lib.timed("relu_bwd_g_colsum[H=%d,E=%d]" % (H, E), 16 * H * E + 4 * E + 4 * coef.numel()):
+    with _lib.timed("relu_bwd_g_colsum[H=%d,E=%d]", (H, E), 16 * H * E + 4 * E + 4 * coef.numel()):
         check(lib.dmp_relu_bwd_g_colsum(ptr(d_h), H, ptr(act), H, ptr(coef), ptr(dst32), E, H, ptr(d_g), 2 * H,
                                         ptr(part), stream_ptr()), "dmp_relu_bwd_g_colsum")
     return d_g, reduce_partials(part)
@@ -203,7 +203,7 @@ def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
     out = torch.empty((E, H), dtype=torch.float32, device=z.device)
     Wes = Wes.contiguous()
     sel_a, sel_b, coef_e = index.edge_select(coef)
-    with _lib.timed("edge_fwd_mfma[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
+    with _lib.timed("edge_fwd_mfma[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_fused(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
                                      ptr(sel_a), ptr(sel_b), ptr(coef_e), E, H, ptr(out), H, stream_ptr()),
               "dmp_edge_fwd_fused")
@@ -226,7 +226,7 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index):
     Wes = Wes.contiguous()
     sel_a, sel_b, _ = index.edge_select(coef)
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    with _lib.timed("edge_fwd_typed[H=%d,E=%d]" % (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
+    with _lib.timed("edge_fwd_typed[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_typed(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
                                      ptr(sel_a), ptr(sel_b), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound,
                                      E, H, ptr(out), H, stream_ptr()), "dmp_edge_fwd_typed")
@@ -241,7 +241,7 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
     Wes = Wes.contiguous()
     d_s = d_s.contiguous()
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    with _lib.timed("bwd_z_typed[H=%d,E=%d]" % (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
+    with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
                                   ptr(base), H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, ptr(slot_edge),
                                   ptr(tile_scale), ptr(num_tiles), bound, E, H, ptr(out), H, stream_ptr()),
@@ -258,7 +258,7 @@ def atb_typed(z, d_pre, coef, index):
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     G = int(lib.dmp_atb_typed_blocks(bound))
     part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
-    with _lib.timed("atb_typed[H=%d,E=%d]" % (H, E), 8 * H * E):
+    with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
         check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
                                 ptr(num_tiles), bound, E, H, ptr(part), ptr(part[0, 0, H:]), stream_ptr()), "dmp_atb_typed")
     return reduce_partials(part.view(G, -1)).view(H, 2 * H)
@@ -270,7 +270,7 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     R, H = h1.shape
     out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
     W2 = W2.contiguous()
-    with _lib.timed("out_fwd_mfma[H=%d,R=%d]" % (H, R), 4 * H * R * (3 if prev is not None else 2)):
+    with _lib.timed("out_fwd_mfma[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
         check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2), W2.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H,
                                     ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
     return out
@@ -284,7 +284,7 @@ def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True, gate=None):
     d_g = torch.empty((E, 2 * H if both_halves else H), dtype=torch.float32, device=d_o.device)
     part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
-    with _lib.timed("bwd_h1_mfma[H=%d,E=%d]" % (H, E), (16 if both_halves else 12) * H * E + 4 * E):
+    with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
         check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]),
                                    ptr(gate), E, H, ptr(d_g), d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
@@ -298,7 +298,7 @@ def atb_rows(a, b, gate=None):
     G = int(lib.dmp_atb_rows_blocks(R))
     part = torch.empty((G, H * H), dtype=torch.float32, device=a.device)
     part_cs = torch.empty((G, H), dtype=torch.float32, device=a.device)
-    with _lib.timed("atb_rows[H=%d,R=%d]" % (H, R), 8 * H * R + (4 * R if gate is not None else 0)):
+    with _lib.timed("atb_rows[H=%d,R=%d]", (H, R), 8 * H * R + (4 * R if gate is not None else 0)):
         check(lib.dmp_atb_rows(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, H, ptr(part), ptr(part_cs),
                                stream_ptr()), "dmp_atb_rows")
     return reduce_partials(part).view(H, H), reduce_partials(part_cs)
@@ -311,7 +311,7 @@ def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
     out = torch.empty((E, H), dtype=torch.float32, device=d_g.device)
     Wes = Wes.contiguous()
     d_s = d_s.contiguous()
-    with _lib.timed("bwd_z_mfma[H=%d,E=%d]" % (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
+    with _lib.timed("bwd_z_mfma[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_fused(ptr(d_g), 2 * H, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
                                   ptr(base), H, ptr(index.edge_select(coef)[2]), ptr(index.dst32), ptr(index.rev8),
                                   -1.0, 1.0, E, H, ptr(out), H, stream_ptr()), "dmp_bwd_z_fused")

@@ -58,11 +58,11 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     src_rows = min(nent, M.size(0))  # incidence CSRs list every source row twice: distinct rows count once
     nbytes = 4 * H * src_rows + 4 * out.size(1) * num_nodes + 4 * nent + 4 * (num_nodes + 1) + (4 * nent if ew is not None else 0)
     if split:
-        with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
+        with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,
                                    ptr(out), ldo, int(rows_shared), stream_ptr()), "dmp_seg_sum2")
     else:
-        with _lib.timed("seg_sum[H=%d,rows=%d,ent=%d]" % (H, num_nodes, nent), nbytes):
+        with _lib.timed("seg_sum[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H,
                                   ptr(out), ldo, int(rows_shared), stream_ptr()), "dmp_seg_sum")
     return out
@@ -75,7 +75,7 @@ def gather_rows_raw(X, idx32, edge_w=None):
     E, H = idx32.numel(), X.size(1)
     out = torch.empty((E, H), dtype=torch.float32, device=X.device)
     ew = _vec(edge_w, torch.float32)
-    with _lib.timed("gather_rows[H=%d,E=%d]" % (H, E), 4 * H * (E + X.size(0)) + 4 * E):
+    with _lib.timed("gather_rows[H=%d,E=%d]", (H, E), 4 * H * (E + X.size(0)) + 4 * E):
         check(lib.dmp_gather_rows(ptr(X), ldx, ptr(idx32), ptr(ew), E, H, ptr(out), H, stream_ptr()),
               "dmp_gather_rows")
     return out
@@ -93,7 +93,7 @@ def gather_select_raw(D, dst32, rev8, H, edge_w=None, s0=1.0, s1=1.0, base=None)
     if base is not None:
         base, ldb = _mat(base)
     nbytes = 4 * H * (E + 2 * D.size(0)) + 5 * E + (4 * H * E if base is not None else 0)
-    with _lib.timed("gather_select%s[H=%d,E=%d]" % ("+base" if base is not None else "", H, E), nbytes):
+    with _lib.timed("gather_select%s[H=%d,E=%d]", ("+base" if base is not None else "", H, E), nbytes):
         check(lib.dmp_gather_select(ptr(D), ldd, ptr(dst32), ptr(rev8), ptr(ew), ptr(base), ldb, E, H, s0, s1,
                                     ptr(out), H, stream_ptr()), "dmp_gather_select")
     return out
@@ -231,7 +231,7 @@ class _EdgeCombine(torch.autograd.Function):
             raise _lib.DmpError("edge_combine: G must be [E,2H], P [N,2H]")
         Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
         b = _vec(bias, torch.float32)
-        with _lib.timed("edge_combine[H=%d,E=%d]" % (H, E), 4 * H * (3 * E + 2 * P.size(0)) + 9 * E + 4 * P.size(0)):
+        with _lib.timed("edge_combine[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * P.size(0)) + 9 * E + 4 * P.size(0)):
             check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(b), ptr(index.src32),
                                        ptr(index.dst32), ptr(index.rev8), E, H, 0, ptr(Y), H, stream_ptr()),
                   "dmp_edge_combine")
@@ -249,7 +249,7 @@ class _EdgeCombine(torch.autograd.Function):
         dG = dP = db = None
         if ctx.needs_input_grad[0]:
             dG = torch.empty((E, 2 * H), dtype=torch.float32, device=dY.device)
-            with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]" % (H, E), 4 * H * 3 * E + 4 * E + 4 * ix.num_nodes):
+            with _lib.timed("edge_combine_bwd_g[H=%d,E=%d]", (H, E), 4 * H * 3 * E + 4 * E + 4 * ix.num_nodes):
                 check(lib.dmp_edge_combine_bwd_g(ptr(dY), ldy, ptr(ctx.coef), ptr(ix.dst32), E, H, ptr(dG),
                                                  2 * H, stream_ptr()), "dmp_edge_combine_bwd_g")
         if ctx.needs_input_grad[1]:

@@ -95,8 +95,9 @@ class PredictNet(nn.Module):
         pl / gl [B, 1]: mask counts (pred.py:93-96)."""
         pl_inv, gl_inv = 1.0 / pl, 1.0 / gl
         if self.pool_kind == "sum":
-            p = th.nn.functional.linear(p_sum, self.p_fc.weight) + float(p_pad_len) * self.p_fc.bias
-            g = th.nn.functional.linear(g_sum, self.g_fc.weight) + float(g_pad_len) * self.g_fc.bias
+            # W sum_j x_j + L b as one addmm each (beta = L scales the bias)
+            p = th.addmm(self.p_fc.bias, p_sum, self.p_fc.weight.t(), beta=float(p_pad_len))
+            g = th.addmm(self.g_fc.bias, g_sum, self.g_fc.weight.t(), beta=float(g_pad_len))
         else:
             p = self.p_fc(p_sum / float(p_pad_len))
             g = self.g_fc(g_sum / float(g_pad_len))

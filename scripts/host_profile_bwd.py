@@ -1,0 +1,21 @@
+"""Dev aid: cProfile of a bench step with the autograd engine on the calling thread (so the Python of the
+custom backward functions is visible)."""
+import cProfile, os, pstats, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from dualmessagepassing_amd.tuning import enable_tuned_gemms
+enable_tuned_gemms()
+dev = torch.device("cuda:0")
+cfg = dict(bench.CFG)
+shard = bench.make_shard(cfg, 0, dev)
+step, model = bench.build_step(cfg, shard, dev)
+with torch.autograd.set_multithreading_enabled(False):
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(30): step()
+    pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "45")))
