@@ -35,7 +35,8 @@ struct AtbArgs {
   const float *gate;               // rows variant: row scale of Z or NULL
   float *pT, *pB;                  // [gridDim.x] partials, `pstride` floats apart, rows `ldp` floats apart
   int64_t pstride; int ldp;
-  float *pCS;                      // rows variant: [gridDim.x, 128] column sums of g (.) Z
+  float *pCS;                      // rows variant: [gridDim.x, cs_ld] column sums of g (.) Z
+  int nb, cs_ld;                   // rows variant: blockIdx.y = a * nb + b picks the 128-column blocks a of Z and b of D
 };
 
 template <bool TYPED>
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
   const uint32_t colA = (uint32_t)(gtid & 31) * 16u;
   constexpr uint32_t kOOB = 0xFFFFF000u;
-  const rsrc_t rs_Z = make_rsrc(p.Z, (uint32_t)(p.E * p.ldz * 4));
-  const rsrc_t rs_D = make_rsrc(p.D, (uint32_t)(p.E * p.ldd * 4));
+  const int ya = TYPED ? 0 : (int)blockIdx.y / p.nb, yb = TYPED ? 0 : (int)blockIdx.y % p.nb;
+  const rsrc_t rs_Z = make_rsrc(p.Z + 128 * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + 128) * 4) : 0u);
+  const rsrc_t rs_D = make_rsrc(p.D + 128 * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + 128) * 4) : 0u);
   const bool gated = !TYPED && p.gate != nullptr;
   const rsrc_t rs_G = make_rsrc(p.gate, gated ? (uint32_t)(p.E * 4) : 0u);
   const int ntiles = TYPED ? __builtin_amdgcn_readfirstlane(*p.num_tiles) : p.plain_tiles;
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
   const int mine = hi > lo ? hi - lo : 0;
   const rsrc_t rs_slot = make_rsrc(p.slot_edge, TYPED ? (uint32_t)ntiles * (kSub * 4u) : 0u);
-  float *pt = p.pT + (int64_t)blockIdx.x * p.pstride;
+  float *pt = p.pT + (int64_t)blockIdx.x * p.pstride + (int64_t)ya * 128 * p.ldp + yb * 128;
+  float *const pcs = !TYPED && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * 128 : nullptr;
   float *pb = TYPED ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;
 
   f32x16 acc[2][4];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
     }
   }
   emit(cur);
-  if (!TYPED && p.pCS) {
+  if (!TYPED && pcs) {
     // column sums: the 8 threads that staged the same 4 columns, added in a fixed order
     __syncthreads();
     *reinterpret_cast<float4 *>(&smem[(gtid >> 5) * 128 + (gtid & 31) * 4]) = cs;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
         const float4 u = *reinterpret_cast<const float4 *>(&smem[g * 128 + gtid * 4]);
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      *reinterpret_cast<float4 *>(p.pCS + (int64_t)blockIdx.x * 128 + gtid * 4) = t;
+      *reinterpret_cast<float4 *>(pcs + gtid * 4) = t;
     }
   }
 }
@@ -344,22 +347,33 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   return check_launch();
 }
 
-int64_t dmp_atb_rows_blocks(int64_t rows) { return (int64_t)atb_blocks((rows + kSub - 1) / kSub); }
+// one wave of workgroups over all (a, b) output blocks together
+static unsigned rows_blocks(int64_t rows, int M, int N) {
+  const int64_t tiles = (rows + kSub - 1) / kSub, nblk = (int64_t)(M / 128) * (N / 128);
+  int64_t g = 512 / (nblk > 0 ? nblk : 1);
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles > 0 ? tiles : 1;
+  return (unsigned)g;
+}
 
-int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int H,
+int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N) { return (int64_t)rows_blocks(rows, M, N); }
+
+int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
                  float *partial, float *partial_colsum, void *stream) {
-  if (rows < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (rows < 0 || M <= 0 || N <= 0) return DMP_ERR_BAD_ARG;
+  if (M % 128 || N % 128 || (int64_t)(M / 128) * (N / 128) > 65535) return DMP_ERR_UNSUPPORTED;
   if (!partial) return DMP_ERR_BAD_ARG;
-  if (rows > 0 && (!A || !B || lda < H || ldb < H)) return DMP_ERR_BAD_ARG;
+  if (rows > 0 && (!A || !B || lda < M || ldb < N)) return DMP_ERR_BAD_ARG;
   if (lda % 4 || ldb % 4 || (rows > 0 && (!aligned16(A) || !aligned16(B))) || !aligned16(partial) ||
       (partial_colsum && !aligned16(partial_colsum)))
     return DMP_ERR_UNSUPPORTED;
   if (!fits32(rows, lda) || !fits32(rows, ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
-  a.gate = gate; a.pT = partial; a.pstride = 128 * 128; a.ldp = 128; a.pCS = partial_colsum;
+  a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / 128; a.cs_ld = M;
   if (!lds_ready<false>()) return DMP_ERR_HIP;
-  atb_k<false><<<atb_blocks(a.plain_tiles), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  const dim3 grid(rows_blocks(rows, M, N), (unsigned)((M / 128) * (N / 128)));
+  atb_k<false><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

@@ -290,18 +290,27 @@ def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True, gate=None):
     return d_g, reduce_partials(part)
 
 
-def atb_rows(a, b, gate=None):
-    """``((gate (.) a)^T b  [H,H],  column sums of gate (.) a  [H])`` in one MFMA pass over the rows
-    (csrc/dmp_atb.hip); H = 128.  The second Linear's weight and bias gradient with the gate fused in."""
+def atb_rows(a, b, gate=None, colsum=True):
+    """``((gate (.) a)^T b  [M,N],  column sums of gate (.) a  [M] (or None))`` in one MFMA pass over the rows
+    (csrc/dmp_atb.hip); M, N multiples of 128.  A Linear's weight and bias gradient with a row gate fused in."""
     lib = _lib.load()
-    R, H = a.shape
-    G = int(lib.dmp_atb_rows_blocks(R))
-    part = torch.empty((G, H * H), dtype=torch.float32, device=a.device)
-    part_cs = torch.empty((G, H), dtype=torch.float32, device=a.device)
-    with _lib.timed("atb_rows[H=%d,R=%d]", (H, R), 8 * H * R + (4 * R if gate is not None else 0)):
-        check(lib.dmp_atb_rows(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, H, ptr(part), ptr(part_cs),
+    R, M = a.shape
+    N = b.size(1)
+    G = int(lib.dmp_atb_rows_blocks(R, M, N))
+    part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
+    part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
+    with _lib.timed("atb_rows[M=%d,N=%d,R=%d]", (M, N, R), 4 * (M + N) * R + (4 * R if gate is not None else 0)):
+        check(lib.dmp_atb_rows(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, M, N, ptr(part), ptr(part_cs),
                                stream_ptr()), "dmp_atb_rows")
-    return reduce_partials(part).view(H, H), reduce_partials(part_cs)
+    return reduce_partials(part).view(M, N), (reduce_partials(part_cs) if colsum else None)
+
+
+def atb_ok(a, b):
+    """The MFMA weight-gradient kernel takes this product (else: ``atb``, batched library GEMMs)."""
+    return (a.is_cuda and a.dtype == torch.float32 and a.size(1) % 128 == 0 and b.size(1) % 128 == 0 and a.size(0) >= 4096
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and a.size(0) * max(a.stride(0), b.stride(0)) * 4 < (1 << 32) - 8192)
 
 
 def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
@@ -489,12 +498,13 @@ class _FusedDMPLayer(torch.autograd.Function):
             dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
-            dW2n = atb(dOn, H1n)
+            wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
+            dW2n = wg(dOn, H1n)
             dH1n = dOn @ nW2
             dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
             dS = dPn @ Bn.t()
-            dBn = atb(S, dPn)                                            # [2H,H]
-            dWx = atb(x, dXP)                                            # [H,3H] = [dA_n | dPd | dPs]
+            dBn = wg(S, dPn)                                             # [2H,H]
+            dWx = wg(x, dXP)                                             # [H,3H] = [dA_n | dPd | dPs]
             dx = None
             if ctx.needs_input_grad[3]:
                 dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 16
+#define DMP_ABI_VERSION 17
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -536,17 +536,19 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
                   float *partial_B, void *stream);
 
 /*
- * Gradient of the second edge Linear with the layer's edge gate fused in (dmpnn.py:263-273 backward:
- * dO = gate * dOut, dW2 = dO^T H1, db2 = column sums of dO), one pass over plain 32-row tiles:
- *     partial[b]        = (gate (.) A)^T B  over workgroup b's rows   ([H,H], A = dOut, B = H1)
- *     partial_colsum[b] = column sums of gate (.) A over the same rows ([H]; may be NULL)
- *   A [rows, lda>=H], B [rows, ldb>=H], gate [rows] or NULL (1); H = 128 only;
- *   partial: [dmp_atb_rows_blocks(rows), H*H], partial_colsum: [dmp_atb_rows_blocks(rows), H];
+ * Tall-skinny weight-gradient product with an optional row gate fused in -- e.g. the second edge Linear's
+ * gradient (dmpnn.py:263-273 backward: dO = gate * dOut, dW2 = dO^T H1, db2 = column sums of dO) -- in one
+ * pass over plain 32-row tiles:
+ *     partial[b]        = (gate (.) A)^T B  over workgroup b's rows   ([M,N])
+ *     partial_colsum[b] = column sums of gate (.) A over the same rows ([M]; may be NULL)
+ *   A [rows, lda>=M], B [rows, ldb>=N], gate [rows] or NULL (1); M and N multiples of 128 (every 128 x 128
+ *   output block is one workgroup column of the launch);
+ *   partial: [dmp_atb_rows_blocks(rows, M, N), M*N], partial_colsum: [dmp_atb_rows_blocks(rows, M, N), M];
  *   finish both with dmp_reduce_partials.
  */
-int64_t dmp_atb_rows_blocks(int64_t rows);
+int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N);
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
-                 int64_t rows, int H, float *partial, float *partial_colsum, void *stream);
+                 int64_t rows, int M, int N, float *partial, float *partial_colsum, void *stream);
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup

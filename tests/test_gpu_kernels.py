@@ -478,6 +478,15 @@ def test_gated_weight_gradient_rows(rows, gated, gpu):
     assert cs.shape == (h,) and th.allclose(cs, ga.sum(0).float(), rtol=1e-5, atol=tol)
     got2, cs2 = fused.atb_rows(a, b, gate)
     assert th.equal(got, got2) and th.equal(cs, cs2)
+    # several 128 x 128 output blocks in one launch: [rows,256]^T [rows,384], operands that are column slices
+    if rows > 1:
+        a3 = th.randn(rows, 2 * h + 4, generator=gen).to(gpu)[:, :2 * h]
+        b3 = th.randn(rows, 3 * h, generator=gen).to(gpu)
+        got3, cs3 = fused.atb_rows(a3, b3, gate)
+        g3 = a3.double() * (gate.double()[:, None] if gated else 1.0)
+        assert got3.shape == (2 * h, 3 * h) and th.allclose(got3, (g3.t() @ b3.double()).float(), rtol=1e-5, atol=tol)
+        assert th.allclose(cs3, g3.sum(0).float(), rtol=1e-5, atol=tol)
+        assert fused.atb_rows(a3, b3, gate, colsum=False)[1] is None
 
 
 @pytest.mark.parametrize("rows", [31, 1000, 70001])
