@@ -512,6 +512,43 @@ def test_typed_weight_gradient(rows, gpu):
     assert d_g.shape == (rows, h)
 
 
+@pytest.mark.parametrize("case", ["many_classes", "long_ranges"])
+def test_typed_weight_gradient_class_structure(case, gpu):
+    """The weight-gradient kernel's two rare paths: (many_classes) thousands of coefficient classes of one tile
+    each, so every workgroup range ends several classes (emit + accumulator / pipeline restart per tile); and
+    (long_ranges) more than 64 tiles per workgroup, so the class bit mask is re-read inside a range."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(21)
+    rng = np.random.default_rng(21)
+    if case == "many_classes":
+        n, deg = 4000, 20
+        dst = np.repeat(np.arange(n), deg).astype(np.int64)
+        src = rng.integers(0, n, n * deg).astype(np.int64)
+        perm = rng.permutation(n * deg)
+        src, dst = src[perm], dst[perm]
+        ix = _index(src, dst, n, rng.random(n * deg) < 0.5, gpu)
+        coef = (th.rand(n, generator=gen) + 0.5).to(gpu)            # a distinct value per node: 4000 classes (value-sorted tile list)
+    else:
+        n, rows = 5000, 1_100_000                                   # 34 375 tiles + classes over 512 workgroups: > 64 per range
+        ix = _index(rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64), n,
+                    rng.random(rows) < 0.5, gpu)
+        coef = ix.degree_coef(ix.out_deg)
+    rows = ix.num_edges
+    se, ts, nt, bound = ix.class_tiles(coef)
+    tiles = int(nt)
+    classes = th.unique(ts[:tiles]).numel()
+    assert ((classes >= 3900 and tiles >= 3900) if case == "many_classes" else tiles > 64 * 512), (classes, tiles)
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    got = fused.atb_typed(z, d_pre, coef, ix)
+    ce = coef[ix.dst32.long()].double()
+    want = th.cat([z.double().t() @ d_pre.double(), z.double().t() @ (d_pre.double() * ce[:, None])], 1)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    assert th.equal(got, fused.atb_typed(z, d_pre, coef, ix))
+
+
 def test_pingpong_driver_matches_default(gpu):
     """The experimental ping-pong driver of the fused MFMA kernels (dmp_dev_set_mfma_variant(1)) computes
     bit-identical results to the default independent-workgroup driver."""
