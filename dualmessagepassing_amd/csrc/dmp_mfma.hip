@@ -83,6 +83,7 @@ struct MfmaArgs {
   float *partial;                   // EPI_RELU_BWD_G: [2*gridDim.x, 128] column-sum partials of dPre
   float s0, s1;                     // EPI_DZ: sign / scale of the gathered term by flag
   int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
+  int both;                         // EPI_RELU_BWD_G: write [dPre | coef dPre] (rowscale = coef[dst e]) instead of dPre alone
 };
 
 template <int NC, int EPI, int PP>
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   const uint32_t grpR = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8 * p.ldr * 4));
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
-  // EPI_RELU_BWD_G writes [dPre | coef dPre] when the output has room for both halves (ldc >= 256), dPre only otherwise
-  const bool both_halves = EPI == EPI_RELU_BWD_G && p.ldc >= 256;
+  // EPI_RELU_BWD_G writes [dPre | coef dPre] when asked for both halves (p.both), dPre only otherwise
+  const bool both_halves = EPI == EPI_RELU_BWD_G && p.both != 0;
   const int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (both_halves ? 256 : 128);
 
   // whole-array descriptors: per-row arrays and the gathered table
@@ -501,18 +502,19 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
                      const float *coefE, const float *gate, int64_t E, int H, float *dG, int64_t ldg, float *partial,
                      void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
-  if (!partial || (gate && ldg >= 2 * H)) return DMP_ERR_BAD_ARG;
+  const bool both = coefE != nullptr;                      // with coefE: dG = [dPre | coefE dPre]; without: dPre alone
+  if (!partial || (gate && both)) return DMP_ERR_BAD_ARG;
   if (E == 0)
     return hipMemsetAsync(partial, 0, sizeof(float) * 128 * (size_t)dmp_mfma_partial_rows(0), (hipStream_t)stream) == hipSuccess
                ? DMP_OK : DMP_ERR_HIP;
-  if (!dO || !W2 || !H1 || !coefE || !dG || ldo < H || ldw < H || ldh < H || ldg < H) return DMP_ERR_BAD_ARG;
+  if (!dO || !W2 || !H1 || !dG || ldo < H || ldw < H || ldh < H || ldg < (both ? 2 * H : H)) return DMP_ERR_BAD_ARG;
   if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
     return DMP_ERR_UNSUPPORTED;
   if (!fits32(E, 1) || !fits32(kSub, ldo) || !fits32(kSub, ldh) || !fits32(kSub, ldg)) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
-  p.partial = partial; p.ldt = 256;
+  p.both = both; p.partial = partial; p.ldt = 256;
   return launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 

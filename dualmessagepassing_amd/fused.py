@@ -276,17 +276,24 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef, index, both_halves=True, gate=None):
+def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None):
     """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128.
-    ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here."""
+    ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here.
+    ``out`` (dPre alone only): destination [R, H], e.g. a column slice of a wider matrix."""
     lib = _lib.load()
     E, H = d_o.shape
-    d_g = torch.empty((E, 2 * H if both_halves else H), dtype=torch.float32, device=d_o.device)
+    if both_halves:
+        d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_o.device)
+        coef_e = index.edge_select(coef)[2]
+    else:
+        d_g = out if out is not None else torch.empty((E, H), dtype=torch.float32, device=d_o.device)
+        coef_e = None
     part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
-        check(lib.dmp_bwd_h1_fused(ptr(d_o), H, ptr(W2), W2.size(1), ptr(h1), H, ptr(index.edge_select(coef)[2]),
-                                   ptr(gate), E, H, ptr(d_g), d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
+        check(lib.dmp_bwd_h1_fused(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
+                                   ptr(gate), E, H, ptr(d_g), d_g.stride(0) if E > 1 else d_g.size(1), ptr(part),
+                                   stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
 
 
@@ -447,8 +454,10 @@ class _FusedDMPLayer(torch.autograd.Function):
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
         XP = x @ Wx
         H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn)
-        On = torch.addmm(nb2, H1n, nW2.t())
-        xn = gate_residual(x if residual else None, On, v_gate)
+        if H == 128:   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
+            xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None)
+        else:
+            xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
         if typed_ok(index, H):
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index)
@@ -497,11 +506,16 @@ class _FusedDMPLayer(torch.autograd.Function):
             ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:])
             dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
-            dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
-            dW2n = wg(dOn, H1n)
-            dH1n = dOn @ nW2
-            dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
+            if H == 128 and atb_ok(dxn, H1n):
+                # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
+                dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
+                dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H])
+            else:
+                dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
+                dW2n = wg(dOn, H1n)
+                dH1n = dOn @ nW2
+                dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
             dS = dPn @ Bn.t()
             dBn = wg(S, dPn)                                             # [2H,H]
             dWx = wg(x, dXP)                                             # [H,3H] = [dA_n | dPd | dPs]

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 17
+#define DMP_ABI_VERSION 18
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -475,10 +475,11 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
  * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
  *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
  *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
- *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H];
- *   with H <= ldg < 2H only dPre is written (dG [E, ldg]), and then `gate` [E] (or NULL) may carry the
- *   layer's edge gate: dO is the UNgated output gradient and dPre[e] = H1[e] > 0 ? gate[e] (dO[e] W2) : 0
- *   (the separate gate pass of the backward is fused away; gate must be NULL when ldg >= 2H).
+ *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
+ *   coefE NULL: only dPre is written (dG [E, ldg>=H]: may be a column slice of a wider matrix), and then
+ *   `gate` [E] (or NULL) may carry a row gate: dO is the UNgated output gradient and
+ *   dPre[e] = H1[e] > 0 ? gate[e] (dO[e] W2) : 0 -- the separate gate pass of the backward is fused away
+ *   (gate must be NULL with coefE).  Also serves the node update's MLP (rows = nodes, gate = v_gate).
  */
 int64_t dmp_mfma_partial_rows(int64_t num_edges);
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,

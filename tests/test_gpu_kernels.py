@@ -353,6 +353,11 @@ def test_mfma_backward_kernels_h128(rows, gpu):
     assert th.allclose(csg.double(), refg.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
     d_p1, _ = fused.bwd_h1_mfma(d_o, w2, h1, coef, ix, both_halves=False)
     assert th.equal(d_p1, d_g[:, :h])
+    # no graph at all (the node update's MLP), output into a column slice of a wider matrix
+    wide = th.full((rows, 3 * h), 7.0, device=gpu)
+    d_p2, cs2_ = fused.bwd_h1_mfma(d_o, w2, h1, both_halves=False, gate=gate, out=wide[:, :h])
+    assert d_p2.data_ptr() == wide.data_ptr() and th.equal(wide[:, :h], d_p) and th.equal(cs2_, csg)
+    assert bool((wide[:, h:] == 7.0).all())
     g2, cs2 = fused.relu_bwd_g_colsum(d_o @ w2, h1, coef, ix.dst32)      # the two-kernel path
     assert th.allclose(d_g, g2, rtol=1e-5, atol=2e-4) and th.allclose(cs, cs2, rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5))
     # input gradient
