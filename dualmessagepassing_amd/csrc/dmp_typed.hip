@@ -197,11 +197,29 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   load_rows();                 // tile 1
   load_ids(2);
   lds_barrier();
+  // The class structure of the range is read 64 tiles at a time: lane l keeps the coefficient of tile 64c + l,
+  // bit l of `starts` says "tile 64c + l begins a new class".  The hot loop then tests a scalar bit -- a
+  // per-tile coefficient load in its condition was a vector load the loop had to wait for with vmcnt(0),
+  // i.e. behind the row prefetch and the epilogue's stores it had just issued.
   int k = 0;
+  float sv = 0.f, c_have = 0.f;
+  bool have_panel = false;
+  unsigned long long starts = 0;
   while (k < mine) {
+    if ((k & 63) == 0) {
+      const float last = __shfl(sv, 63);
+      sv = k + lane < mine ? p.tile_scale[lo + k + lane] : 0.f;
+      float up = __shfl_up(sv, 1);
+      if (lane == 0) up = k > 0 ? last : sv;
+      starts = __ballot(k + lane < mine && __float_as_uint(sv) != __float_as_uint(up));
+    }
     // tiles of one degree class: W_g is built once per class segment of this workgroup's range
-    const float c = p.tile_scale[__builtin_amdgcn_readfirstlane(lo + k)];
-    load_panel(c);
+    const float c = __shfl(sv, k & 63);
+    if (!have_panel || __float_as_uint(c) != __float_as_uint(c_have)) {
+      load_panel(c);
+      c_have = c;
+      have_panel = true;
+    }
     do {
       const int par = k & 1;
       fetch_operands(par);
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       lds_barrier();             // tile k+1 is in LDS for everyone
       epilogue(par);
       ++k;
-    } while (k < mine && p.tile_scale[__builtin_amdgcn_readfirstlane(lo + k)] == c);
+    } while (k < mine && (k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0);
   }
 }
 
