@@ -67,7 +67,7 @@ SIGNATURES = {
     "dmp_edge_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
-                                c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+                                c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
     "dmp_atb_typed_blocks": (c_i64, [c_i64]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
@@ -92,7 +92,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

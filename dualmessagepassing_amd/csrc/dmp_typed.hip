@@ -106,9 +106,15 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
   };
   int own_staged = -1;
+#ifdef DMP_TY_DBG
+  bool warm = false;
+#endif
   auto load_rows = [&]() {                                // rows + per-row scalars of the tile whose ids are loaded
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m) {
+#ifdef DMP_TY_DBG
+      if ((DMP_TY_DBG & 8) && warm) break;
+#endif
       const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
       pre[m] = buf_load4(rs_A, off, 0);
     }
@@ -142,6 +148,13 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   f32x16 acc;
   float4 g0[4], g1[4];
   auto fetch_operands = [&](int par) {
+#ifdef DMP_TY_DBG
+    if (DMP_TY_DBG & 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; }
+      return;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = 8 * k + lrow;
@@ -153,6 +166,9 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   auto compute = [&]() {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#ifdef DMP_TY_DBG
+    if (DMP_TY_DBG & 1) return;
+#endif
     const float *arow = &As[li * kLdsStride + 64 * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
@@ -185,6 +201,9 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
         v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
         v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
       }
+#ifdef DMP_TY_DBG
+      if ((DMP_TY_DBG & 4) && v.x != 123.456f) continue;
+#endif
       buf_store4(v, rs_C, rowC[par][rr] + col4, 0);       // padding rows: offset out of range, dropped
     }
   };
@@ -220,6 +239,9 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       c_have = c;
       have_panel = true;
     }
+#ifdef DMP_TY_DBG
+    warm = true;
+#endif
     do {
       const int par = k & 1;
       fetch_operands(par);
@@ -271,7 +293,7 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
                     int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
                     float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t E, int H, float *dZ, int64_t ldz, void *stream) {
+                    int64_t tiles_bound, int64_t E, int H, int w_transposed, float *dZ, int64_t ldz, void *stream) {
   if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!dPre || !W || !D || !dst || !slot_edge || !tile_scale || !num_tiles || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H ||
@@ -283,7 +305,7 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   if (!fits32(num_nodes, ldd) || !fits32(E, ldp) || !fits32(E, ldz) || (base && !fits32(E, ldb)) || !fits32(tiles_bound * kSub, 1))
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
-  p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = 1; p.C = dZ; p.ldc = ldz; p.E = E;
+  p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
   p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : 128;
   p.s0 = s0; p.s1 = s1;

@@ -238,13 +238,15 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
     out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
-    Wes = Wes.contiguous()
+    # [A'^T | B'^T]: the kernel's per-class panel reads become coalesced (one tiny launch here instead of a
+    # strided 128-instruction panel read per class segment in each of its 768 workgroups)
+    WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
     d_s = d_s.contiguous()
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
-        check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(Wes), Wes.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
+        check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
                                   ptr(base), H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, ptr(slot_edge),
-                                  ptr(tile_scale), ptr(num_tiles), bound, E, H, ptr(out), H, stream_ptr()),
+                                  ptr(tile_scale), ptr(num_tiles), bound, E, H, 1, ptr(out), H, stream_ptr()),
               "dmp_bwd_z_typed")
     return out
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 18
+#define DMP_ABI_VERSION 19
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -507,6 +507,9 @@ int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  *   num_tiles  device int32 scalar     : tiles in use (<= tiles_bound, the host-side bound)
  * Rows are gathered / scattered by edge id; outputs equal the untyped kernels' up to fp32 rounding
  * of W_g.  DMP_ERR_UNSUPPORTED additionally when E*ld*4 does not fit 32 bits.
+ * dmp_bwd_z_typed, w_transposed != 0: W holds [A'^T | B'^T] (each half transposed) instead of [A' | B'] --
+ * the per-class panel of dZ = dPre W_g^T is then read with coalesced loads (a strided panel read costs
+ * every workgroup several microseconds per class segment).
  */
 int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P,
                        int64_t ldp, int64_t num_nodes, const float *bias, const int32_t *selA,
@@ -517,8 +520,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
                     const int32_t *dst, const uint8_t *flag, float s0, float s1,
                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t num_edges, int H, float *dZ, int64_t ldz,
-                    void *stream);
+                    int64_t tiles_bound, int64_t num_edges, int H, int w_transposed, float *dZ,
+                    int64_t ldz, void *stream);
 
 /*
  * Weight gradient of the class-typed edge chain:  with G_c = sum over the edges e of class c of
