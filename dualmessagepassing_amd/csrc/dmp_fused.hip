@@ -248,6 +248,60 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
   }
 }
 
+// Weight gradient of a narrow input layer fused with a row gate:  out[k, :] = sum_r X[r, k] * gate[r] * D[r, :]
+// (X [R, K <= 16]: the multihot label encodings, D [R, 128]: the upstream gradient of gate * (X W)).  One pass
+// over D instead of materialising gate * D and running a [K, R] x [R, 128] product over it.  A 32-lane group
+// owns a row (float4 per lane); lanes 0..K-1 fetch the row's K inputs, broadcast by shuffle; 4 rows in flight.
+constexpr int kSmallK = 16;
+struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial; };
+
+__global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
+  constexpr int G = 32, GPB = kBlock / G;
+  __shared__ float4 red[kBlock];
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  float4 acc[kSmallK];
+#pragma unroll
+  for (int k = 0; k < kSmallK; ++k) acc[k] = zero4();
+  const int64_t chunk = (int64_t)GPB * kU;
+  for (int64_t base = (int64_t)blockIdx.x * chunk; base < p.R; base += (int64_t)gridDim.x * chunk) {
+    const int64_t r0 = base + (int64_t)grp * kU;
+    float4 d[kU];
+    float xs[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t r = r0 + u;
+      const bool ok = r < p.R;
+      d[u] = ok ? ld4(p.D + r * p.ldd + lane * 4) : zero4();
+      float x = (ok && lane < p.K) ? p.X[r * p.ldx + lane] : 0.f;
+      if (ok && p.gate) x *= p.gate[r];                     // every lane reads the row's gate (one broadcast line)
+      xs[u] = x;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int k = 0; k < kSmallK; ++k) {
+        const float w = __shfl(xs[u], k, G);                // 0 for k >= K: those accumulators stay 0
+        acc[k].x += w * d[u].x; acc[k].y += w * d[u].y; acc[k].z += w * d[u].z; acc[k].w += w * d[u].w;
+      }
+  }
+  // fixed-order combine of the 8 groups, one k at a time
+  for (int k = 0; k < p.K; ++k) {
+    float4 mine = zero4();
+#pragma unroll
+    for (int kk = 0; kk < kSmallK; ++kk)
+      if (kk == k) mine = acc[kk];
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = red[lane];
+#pragma unroll
+      for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
+      st4(p.partial + ((int64_t)blockIdx.x * p.K + k) * 128 + lane * 4, t);
+    }
+    __syncthreads();
+  }
+}
+
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
 
 inline unsigned grid_for(int64_t R, int G) {
@@ -354,6 +408,20 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *pa
   if (!vec_shape_ok(H, lda, 0, 0) || !ok16(A) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   RowArgs p{A, lda, nullptr, 0, nullptr, nullptr, nullptr, 0, partial, R, H};
   return launch_rowop<OP_COLSUM>(p, (hipStream_t)stream);
+}
+
+int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)grid_for(rows, 32); }
+
+int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,
+                   float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && K > 0 && partial);
+  if (H != 128 || K > kSmallK) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)K * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(X && D && ldx >= K && ldd >= H);
+  if (ldd % 4 || !ok16(D) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial};
+  smallk_atb_k<<<grid_for(R, 32), kBlock, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
 }
 
 int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out, int accumulate, void *stream) {

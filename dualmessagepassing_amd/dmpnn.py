@@ -327,8 +327,8 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
         return None
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
-    v = _GateConcat.apply(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
-    e = _GateConcat.apply(p_e_emb, g_e_emb, e_gate)
+    v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
+    e = _gate_concat(p_e_emb, g_e_emb, e_gate)
     vg = eg = None
     if v_gate is not None:
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
@@ -353,10 +353,13 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
 class _GateConcat(th.autograd.Function):
     """``cat([p, gate * g])`` written once: the pattern rows are copied, the gated target rows go
     straight into their place in the union buffer (instead of a multiply pass plus a concatenation
-    pass over the E-row tensors).  ``gate`` ([rows, 1] or None) carries no gradient."""
+    pass over the E-row tensors).  ``gate`` ([rows, 1] or None) carries no gradient.
+    ``enc`` / ``W`` (optional): ``g`` is ``enc @ W`` (a label embedding, passed DETACHED): the backward then
+    returns ``dW = enc^T (gate * d[n:])`` from one pass over the upstream gradient instead of materialising
+    ``gate * d[n:]`` for the embedding's own backward product."""
 
     @staticmethod
-    def forward(ctx, p, g, gate):
+    def forward(ctx, p, g, gate, enc=None, W=None):
         from . import _lib
         lib = _lib.load()
         _lib.require_gpu(p, g)
@@ -368,7 +371,7 @@ class _GateConcat(th.autograd.Function):
             gt = None if gate is None else gate.reshape(-1).contiguous()
             _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
                                              _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_gate_residual")
-        ctx.n, ctx.gate = n, gate
+        ctx.n, ctx.gate, ctx.enc = n, gate, enc
         return out
 
     @staticmethod
@@ -376,9 +379,24 @@ class _GateConcat(th.autograd.Function):
         from . import fused
         d = d.contiguous()
         dg = d[ctx.n:]
-        if ctx.gate is not None and dg.size(0) > 0:
-            dg = fused.gate_residual(None, dg, ctx.gate.reshape(-1).contiguous())
-        return d[:ctx.n], dg, None
+        gate = None if ctx.gate is None else ctx.gate.reshape(-1).contiguous()
+        if ctx.enc is not None:
+            dW = fused.smallk_atb(ctx.enc, dg, gate) if dg.size(0) > 0 else th.zeros((ctx.enc.size(1), d.size(1)), device=d.device)
+            return d[:ctx.n], None, None, None, dW
+        if gate is not None and dg.size(0) > 0:
+            dg = fused.gate_residual(None, dg, gate)
+        return d[:ctx.n], dg, None, None, None
+
+
+def _gate_concat(p, g, gate):
+    """``_GateConcat`` with the embedding-aware backward when ``g`` is a plain label embedding."""
+    from . import fused
+    src = getattr(g, "_dmp_src", None)
+    if (src is not None and g.dim() == 2 and g.size(1) == 128 and g.is_cuda and g.dtype == th.float32
+            and src[0].dtype == th.float32 and src[0].size(1) <= fused.SMALLK_MAX and src[0].size(0) == g.size(0)
+            and src[0].stride(1) == 1 and src[1].requires_grad and th.is_grad_enabled()):
+        return _GateConcat.apply(p, g.detach(), gate, src[0], src[1])
+    return _GateConcat.apply(p, g, gate)
 
 
 class _SplitRows(th.autograd.Function):

@@ -49,8 +49,12 @@ class Embedding(nn.Embedding):
         if x.dtype == th.float and x.size(-1) == self.num_embeddings:
             x_size = x.size()
             # x @ weight; the weight gradient x^T dOut has K = #rows (5e5 edges): split-K product
-            emb = ops.matmul_xw(x.view(-1, x_size[-1]), self.weight)
-            return emb.view(x_size[:-1] + (self.embedding_dim,))
+            x2d = x.view(-1, x_size[-1])
+            emb = ops.matmul_xw(x2d, self.weight).view(x_size[:-1] + (self.embedding_dim,))
+            # where the embedding came from: a consumer that gates the rows (the joint rep-net pass) can then
+            # produce the weight gradient in one pass over its own upstream gradient (fused.smallk_atb)
+            emb._dmp_src = (x2d, self.weight)
+            return emb
         raise NotImplementedError
 
     def get_output_dim(self):

@@ -314,6 +314,23 @@ def atb_rows(a, b, gate=None, colsum=True):
     return reduce_partials(part).view(M, N), (reduce_partials(part_cs) if colsum else None)
 
 
+SMALLK_MAX = 16
+
+
+def smallk_atb(x, d, gate=None):
+    """``x^T (gate (.) d)``  ([K, H], K <= 16, H = 128) in one pass over ``d``: the weight gradient of a narrow
+    input layer (label encodings @ W) whose output was gated row-wise (csrc/dmp_fused.hip::smallk_atb_k)."""
+    lib = _lib.load()
+    R, K = x.shape
+    H = d.size(1)
+    G = int(lib.dmp_smallk_atb_blocks(R))
+    part = torch.empty((G, K * H), dtype=torch.float32, device=d.device)
+    with _lib.timed("smallk_atb[K=%d,R=%d]", (K, R), 4 * (H + K + 1) * R):
+        check(lib.dmp_smallk_atb(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ptr(gate), R, H, ptr(part), stream_ptr()),
+              "dmp_smallk_atb")
+    return reduce_partials(part).view(K, H)
+
+
 def atb_ok(a, b):
     """The MFMA weight-gradient kernel takes this product (else: ``atb``, batched library GEMMs)."""
     return (a.is_cuda and a.dtype == torch.float32 and a.size(1) % 128 == 0 and b.size(1) % 128 == 0 and a.size(0) >= 4096

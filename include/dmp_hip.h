@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 19
+#define DMP_ABI_VERSION 20
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -385,6 +385,16 @@ int dmp_relu_bwd_g_colsum(const float *dH, int64_t ldh, const float *act, int64_
 /* Column-sum partials of A [rows, H]. */
 int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float *partial,
                         void *stream);
+
+/* Weight gradient of a narrow input layer with a row gate fused in (the label-embedding products of
+ * embed.py:103-120 feeding `e = e * e_gate`, basemodel.py:1515):
+ *     partial[b][k, :] = sum over workgroup b's rows r of X[r, k] * gate[r] * D[r, :]
+ * X [rows, ldx >= K] (K <= 16 inputs per row: the multihot label encodings), D [rows, ldd >= H] the upstream
+ * gradient of gate * (X W), gate [rows] or NULL; H = 128 only.
+ * partial: [dmp_smallk_atb_blocks(rows), K*H]; finish with dmp_reduce_partials. */
+int64_t dmp_smallk_atb_blocks(int64_t rows);
+int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
+                   int64_t rows, int H, float *partial, void *stream);
 
 /* out[l] (+)= sum_s partial[s, l], s in a fixed order; L % 4 == 0.  Also reduces the
  * split-K partial products of the weight gradients. */

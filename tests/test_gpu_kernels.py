@@ -622,3 +622,22 @@ def test_fold_layers_matches_torch_algebra(num_layers, gpu):
     g_want = th.autograd.grad(loss_w, params)
     for i, (a, b) in enumerate(zip(g_got, g_want)):
         assert th.allclose(a, b, rtol=1e-5, atol=1e-4), (i, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("rows,k", [(1, 1), (37, 10), (70001, 10), (5000, 16)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_smallk_gated_weight_gradient(rows, k, gated, gpu):
+    """fused.smallk_atb: x^T (gate (.) d) for a narrow x (label encodings) in one pass, against fp64, bit-stable;
+    d a row slice of a larger matrix (the union gradient's target rows)."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows * 31 + k)
+    x = (th.rand(rows, k, generator=gen) < 0.5).float().to(gpu)
+    full = th.randn(rows + 5, h, generator=gen).to(gpu)
+    d = full[5:]
+    gate = (th.rand(rows, generator=gen) > 0.4).float().to(gpu) if gated else None
+    got = fused.smallk_atb(x, d, gate)
+    gd = d.double() * (gate.double()[:, None] if gated else 1.0)
+    want = (x.double().t() @ gd).float()
+    assert got.shape == (k, h) and th.allclose(got, want, rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    assert th.equal(got, fused.smallk_atb(x, d, gate))
