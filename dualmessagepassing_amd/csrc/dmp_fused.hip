@@ -250,57 +250,82 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
 
 // Weight gradient of a narrow input layer fused with a row gate:  out[k, :] = sum_r X[r, k] * gate[r] * D[r, :]
 // (X [R, K <= 16]: the multihot label encodings, D [R, 128]: the upstream gradient of gate * (X W)).  One pass
-// over D instead of materialising gate * D and running a [K, R] x [R, 128] product over it.  A 32-lane group
-// owns a row (float4 per lane); lanes 0..K-1 fetch the row's K inputs, broadcast by shuffle; 4 rows in flight.
+// over D instead of materialising gate * D and running a [K, R] x [R, 128] product over it.  A wave owns a row
+// at a time (float2 per lane), so the row's K inputs and its gate are wave-uniform: one vector load, v_readlane, SGPR operands
+// of the FMAs; 4 rows in flight per wave.
 constexpr int kSmallK = 16;
+constexpr int kSmallRows = 4;                                 // rows in flight per wave (the loop is one memory round trip per batch)
 struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial; };
 
+template <int K>
 __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
-  constexpr int G = 32, GPB = kBlock / G;
-  __shared__ float4 red[kBlock];
-  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
-  float4 acc[kSmallK];
+  constexpr int WPB = kBlock / 64, kRows = kSmallRows;
+  __shared__ float2 red[kBlock];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  float2 acc[K];
 #pragma unroll
-  for (int k = 0; k < kSmallK; ++k) acc[k] = zero4();
-  const int64_t chunk = (int64_t)GPB * kU;
-  for (int64_t base = (int64_t)blockIdx.x * chunk; base < p.R; base += (int64_t)gridDim.x * chunk) {
-    const int64_t r0 = base + (int64_t)grp * kU;
-    float4 d[kU];
-    float xs[kU];
+  for (int k = 0; k < K; ++k) acc[k] = make_float2(0.f, 0.f);
+  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  // lanes 0..K-1 fetch a row's inputs, lane K its gate (one load each); the values are read back lane by lane
+  // into wave-uniform operands (v_readlane: no memory traffic, no LDS).  The next batch's loads are issued
+  // before the current batch's FMAs.
+  float2 d[kRows], dn[kRows];
+  float mine[kRows], minen[kRows];
+  auto load_batch = [&](int64_t r0, float2 (&dd)[kRows], float (&mm)[kRows]) {
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int64_t r = r0 + u;
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      d[u] = ok ? ld4(p.D + r * p.ldd + lane * 4) : zero4();
-      float x = (ok && lane < p.K) ? p.X[r * p.ldx + lane] : 0.f;
-      if (ok && p.gate) x *= p.gate[r];                     // every lane reads the row's gate (one broadcast line)
-      xs[u] = x;
+      dd[u] = ok ? *reinterpret_cast<const float2 *>(p.D + r * p.ldd + lane * 2) : make_float2(0.f, 0.f);
+      // one load instruction for both: lanes < K point into the row of X, lane K at the row's gate
+      const float *src = lane < K ? p.X + r * p.ldx + lane : p.gate + r;
+      float m = (lane == K && !p.gate) ? 1.f : 0.f;
+      if (ok && (lane < K || (lane == K && p.gate))) m = *src;
+      mm[u] = m;
+    }
+  };
+  int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
+  if (r0 < p.R) load_batch(r0, d, mine);
+  for (; r0 < p.R; r0 += stride) {
+    load_batch(r0 + stride, dn, minen);                     // rows past the end read as zeros
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
+      const float scaled = mine[u] * g;                     // lane k: gate * X[r, k]
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scaled), k));
+        // v_fmac with the wave-uniform operand straight from its SGPR (the compiler would broadcast it into a
+        // VGPR pair for a packed FMA: two extra moves per FMA in a VALU-bound loop); a sum: no order to keep
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k].x) : "s"(x), "v"(d[u].x));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k].y) : "s"(x), "v"(d[u].y));
+      }
     }
 #pragma unroll
-    for (int u = 0; u < kU; ++u)
-#pragma unroll
-      for (int k = 0; k < kSmallK; ++k) {
-        const float w = __shfl(xs[u], k, G);                // 0 for k >= K: those accumulators stay 0
-        acc[k].x += w * d[u].x; acc[k].y += w * d[u].y; acc[k].z += w * d[u].z; acc[k].w += w * d[u].w;
-      }
+    for (int u = 0; u < kRows; ++u) { d[u] = dn[u]; mine[u] = minen[u]; }
   }
-  // fixed-order combine of the 8 groups, one k at a time
-  for (int k = 0; k < p.K; ++k) {
-    float4 mine = zero4();
+  // fixed-order combine of the 4 waves, one k at a time
 #pragma unroll
-    for (int kk = 0; kk < kSmallK; ++kk)
-      if (kk == k) mine = acc[kk];
-    red[threadIdx.x] = mine;
+  for (int k = 0; k < K; ++k) {
+    red[threadIdx.x] = acc[k];
     __syncthreads();
-    if (grp == 0) {
-      float4 t = red[lane];
+    if (wave == 0) {
+      float2 t = red[lane];
 #pragma unroll
-      for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
-      st4(p.partial + ((int64_t)blockIdx.x * p.K + k) * 128 + lane * 4, t);
+      for (int w = 1; w < WPB; ++w) { t.x += red[w * 64 + lane].x; t.y += red[w * 64 + lane].y; }
+      *reinterpret_cast<float2 *>(p.partial + ((int64_t)blockIdx.x * K + k) * 128 + lane * 2) = t;
     }
     __syncthreads();
   }
 }
+
+inline unsigned smallk_blocks(int64_t R) {
+  const int64_t chunk = (int64_t)(kBlock / 64) * kSmallRows, nb = (R + chunk - 1) / chunk;
+  return (unsigned)(nb < kMaxPartials ? (nb > 0 ? nb : 1) : kMaxPartials);
+}
+
+template <int K>
+void launch_smallk(const SmallKArgs &p, hipStream_t st) { smallk_atb_k<K><<<smallk_blocks(p.R), kBlock, 0, st>>>(p); }
 
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
 
@@ -410,7 +435,7 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *pa
   return launch_rowop<OP_COLSUM>(p, (hipStream_t)stream);
 }
 
-int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)grid_for(rows, 32); }
+int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)smallk_blocks(rows); }
 
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,
                    float *partial, void *stream) {
@@ -418,9 +443,19 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
   if (H != 128 || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)K * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   DMP_ROW_CHECK(X && D && ldx >= K && ldd >= H);
-  if (ldd % 4 || !ok16(D) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  if (ldd % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial};
-  smallk_atb_k<<<grid_for(R, 32), kBlock, 0, (hipStream_t)stream>>>(p);
+  hipStream_t st = (hipStream_t)stream;
+  switch (K) {   // K is a compile-time constant of the kernel: the accumulators live in registers
+    case 1: launch_smallk<1>(p, st); break;   case 2: launch_smallk<2>(p, st); break;
+    case 3: launch_smallk<3>(p, st); break;   case 4: launch_smallk<4>(p, st); break;
+    case 5: launch_smallk<5>(p, st); break;   case 6: launch_smallk<6>(p, st); break;
+    case 7: launch_smallk<7>(p, st); break;   case 8: launch_smallk<8>(p, st); break;
+    case 9: launch_smallk<9>(p, st); break;   case 10: launch_smallk<10>(p, st); break;
+    case 11: launch_smallk<11>(p, st); break; case 12: launch_smallk<12>(p, st); break;
+    case 13: launch_smallk<13>(p, st); break; case 14: launch_smallk<14>(p, st); break;
+    case 15: launch_smallk<15>(p, st); break; default: launch_smallk<16>(p, st); break;
+  }
   return check_launch();
 }
 
