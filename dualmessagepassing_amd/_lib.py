@@ -58,6 +58,7 @@ SIGNATURES = {
     "dmp_add_bias_relu": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_fold_layers": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_unfold_layers": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    "dmp_smallk_embed_gate": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_smallk_atb_blocks": (c_i64, [c_i64]),
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
@@ -94,7 +95,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -319,6 +319,52 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   }
 }
 
+// The forward of the same narrow layer with its gate:  out[r, :] = gate[r] * sum_k X[r, k] W[k, :]  -- the gated
+// embedding rows written straight into their place (the union buffer of the joint rep-net pass) from the K
+// inputs per row instead of from the [R, 128] embedding.  W lives in registers (float2 per lane and input).
+struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo; };
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) {
+  constexpr int WPB = kBlock / 64, kRows = kSmallRows;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  float2 w[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = *reinterpret_cast<const float2 *>(p.W + k * p.ldw + lane * 2);
+  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  for (int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows; r0 < p.R; r0 += stride) {
+    float mine[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t r = r0 + u;
+      const bool ok = r < p.R;
+      const float *src = lane < K ? p.X + r * p.ldx + lane : p.gate + r;
+      float m = (lane == K && !p.gate) ? 1.f : 0.f;
+      if (ok && (lane < K || (lane == K && p.gate))) m = *src;
+      mine[u] = m;
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t r = r0 + u;
+      if (r >= p.R) break;
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
+      float2 e = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {                         // sum over k ascending, then the gate: (X W) * gate as the reference
+        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), k));
+        e.x += x * w[k].x; e.y += x * w[k].y;
+      }
+      *reinterpret_cast<float2 *>(p.out + r * p.ldo + lane * 2) = make_float2(e.x * g, e.y * g);
+    }
+  }
+}
+
+template <int K>
+void launch_smallk_fwd(const SmallKFwdArgs &p, hipStream_t st) {
+  const int64_t chunk = (int64_t)(kBlock / 64) * kSmallRows, nb = (p.R + chunk - 1) / chunk;
+  smallk_embed_k<K><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
+}
+
 inline unsigned smallk_blocks(int64_t R) {
   const int64_t chunk = (int64_t)(kBlock / 64) * kSmallRows, nb = (R + chunk - 1) / chunk;
   return (unsigned)(nb < kMaxPartials ? (nb > 0 ? nb : 1) : kMaxPartials);
@@ -455,6 +501,28 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
     case 11: launch_smallk<11>(p, st); break; case 12: launch_smallk<12>(p, st); break;
     case 13: launch_smallk<13>(p, st); break; case 14: launch_smallk<14>(p, st); break;
     case 15: launch_smallk<15>(p, st); break; default: launch_smallk<16>(p, st); break;
+  }
+  return check_launch();
+}
+
+int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, float *out, int64_t ldo, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && K > 0);
+  if (H != 128 || K > kSmallK) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return DMP_OK;
+  DMP_ROW_CHECK(X && W && out && ldx >= K && ldw >= H && ldo >= H);
+  if (ldw % 2 || ldo % 2 || (reinterpret_cast<uintptr_t>(W) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return DMP_ERR_UNSUPPORTED;
+  SmallKFwdArgs p{X, ldx, W, ldw, gate, R, out, ldo};
+  hipStream_t st = (hipStream_t)stream;
+  switch (K) {
+    case 1: launch_smallk_fwd<1>(p, st); break;   case 2: launch_smallk_fwd<2>(p, st); break;
+    case 3: launch_smallk_fwd<3>(p, st); break;   case 4: launch_smallk_fwd<4>(p, st); break;
+    case 5: launch_smallk_fwd<5>(p, st); break;   case 6: launch_smallk_fwd<6>(p, st); break;
+    case 7: launch_smallk_fwd<7>(p, st); break;   case 8: launch_smallk_fwd<8>(p, st); break;
+    case 9: launch_smallk_fwd<9>(p, st); break;   case 10: launch_smallk_fwd<10>(p, st); break;
+    case 11: launch_smallk_fwd<11>(p, st); break; case 12: launch_smallk_fwd<12>(p, st); break;
+    case 13: launch_smallk_fwd<13>(p, st); break; case 14: launch_smallk_fwd<14>(p, st); break;
+    case 15: launch_smallk_fwd<15>(p, st); break; default: launch_smallk_fwd<16>(p, st); break;
   }
   return check_launch();
 }

@@ -369,8 +369,14 @@ class _GateConcat(th.autograd.Function):
         out[:n].copy_(p)
         if g.size(0) > 0:
             gt = None if gate is None else gate.reshape(-1).contiguous()
-            _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
-                                             _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_gate_residual")
+            if enc is not None:   # the gated rows from the K inputs per row instead of from the [rows, H] embedding
+                Wd = W.detach()
+                _lib.check(lib.dmp_smallk_embed_gate(_lib.ptr(enc), enc.stride(0), enc.size(1), _lib.ptr(Wd), Wd.stride(0),
+                                                     _lib.ptr(gt), g.size(0), H, _lib.ptr(out[n:]), H, _lib.stream_ptr()),
+                           "dmp_smallk_embed_gate")
+            else:
+                _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
+                                                 _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_gate_residual")
         ctx.n, ctx.gate, ctx.enc = n, gate, enc
         return out
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 20
+#define DMP_ABI_VERSION 21
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -392,6 +392,10 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * X [rows, ldx >= K] (K <= 16 inputs per row: the multihot label encodings), D [rows, ldd >= H] the upstream
  * gradient of gate * (X W), gate [rows] or NULL; H = 128 only.
  * partial: [dmp_smallk_atb_blocks(rows), K*H]; finish with dmp_reduce_partials. */
+/* Forward of the same layer with its gate:  out[r, :] = gate[r] * (X[r, :K] W)  with W [K, ldw >= H]
+ * (embed.py:103-120 + basemodel.py:1515), written where the caller wants the gated rows (ldo >= H). */
+int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw,
+                          const float *gate, int64_t rows, int H, float *out, int64_t ldo, void *stream);
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);

@@ -641,3 +641,31 @@ def test_smallk_gated_weight_gradient(rows, k, gated, gpu):
     want = (x.double().t() @ gd).float()
     assert got.shape == (k, h) and th.allclose(got, want, rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
     assert th.equal(got, fused.smallk_atb(x, d, gate))
+
+
+@pytest.mark.parametrize("rows,k", [(1, 3), (4099, 10), (70001, 16)])
+def test_gate_concat_from_label_encodings(rows, k, gpu):
+    """dmpnn._gate_concat with a plain label embedding as the gated half: the union rows come from the K inputs
+    per row (dmp_smallk_embed_gate) and the embedding's weight gradient from one gated pass over the upstream
+    gradient (dmp_smallk_atb) -- against the unfused autograd path cat([p, gate * (enc @ W)])."""
+    from dualmessagepassing_amd import dmpnn
+    from dualmessagepassing_amd.embed import Embedding
+    h, n_p = 128, 37
+    gen = th.Generator().manual_seed(rows + k)
+    emb = Embedding(k, h).to(gpu)
+    enc = (th.rand(rows, k, generator=gen) < 0.4).float().to(gpu)
+    p = th.randn(n_p, h, generator=gen).to(gpu).requires_grad_(True)
+    gate = (th.rand(rows, 1, generator=gen) > 0.3).float().to(gpu)
+    cot = th.randn(n_p + rows, h, generator=gen).to(gpu)
+    g = emb(enc)
+    assert getattr(g, "_dmp_src", None) is not None
+    out = dmpnn._gate_concat(p, g, gate)
+    ref = th.cat([p, gate * (enc @ emb.weight)], 0)
+    assert th.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    gp, gw = th.autograd.grad((out * cot).sum(), [p, emb.weight])
+    rp, rw = th.autograd.grad((ref * cot).sum(), [p, emb.weight])
+    assert th.equal(gp, rp) and th.allclose(gw, rw, rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    # an embedding that was modified afterwards (e.g. + id embedding) takes the generic path
+    g2 = emb(enc) + 1.0
+    assert getattr(g2, "_dmp_src", None) is None
+    assert th.allclose(dmpnn._gate_concat(p, g2, gate), th.cat([p, gate * g2], 0), rtol=1e-6, atol=1e-6)
