@@ -86,19 +86,27 @@ class FlatGradSync:
     def pack(self):
         """After backward: copy the fresh gradients into the flat buffer (zeros where a parameter
         got none) and point every ``.grad`` at its slice again."""
-        self.flat.zero_()
-        views, grads = [], []
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            v = self.flat[off:off + n].view_as(p)
-            if p.grad is not None:
-                views.append(v)
-                grads.append(p.grad)
+        views = getattr(self, "_views", None)
+        if views is None:                                    # the slices never change: built once
+            views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                views.append(self.flat[off:off + n].view_as(p))
+                off += n
+            self._views = views
+        dst, src, missing = [], [], False
+        for p, v in zip(self.params, views):
+            g = p.grad
+            if g is None:
+                missing = True
+            elif g is not v:
+                dst.append(v)
+                src.append(g)
             p.grad = v
-            off += n
-        if views:
-            torch._foreach_copy_(views, grads)
+        if missing:                                          # parameters without a gradient this step keep zeros
+            self.flat.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
