@@ -147,6 +147,15 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 
   f32x16 acc;
   float4 g0[4], g1[4];
+  auto fetch_operand = [&](int par, int k) {               // rows 8k + lrow of the tile
+#ifdef DMP_TY_DBG
+    if (DMP_TY_DBG & 2) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; return; }
+#endif
+    const int rr = 8 * k + lrow;
+    g0[k] = buf_load4(rs_T, rowA[par][rr] + col4, 0);
+    if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
+    else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
+  };
   auto fetch_operands = [&](int par) {
 #ifdef DMP_TY_DBG
     if (DMP_TY_DBG & 2) {
@@ -163,11 +172,13 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
     }
   };
-  auto compute = [&]() {
+  // The MFMA phase, with the epilogue operand requests of the same tile in its shadow: two of the eight loads
+  // (and the LDS reads of their row offsets) after each of the first four MFMA groups.
+  auto compute = [&](int par) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #ifdef DMP_TY_DBG
-    if (DMP_TY_DBG & 1) return;
+    if (DMP_TY_DBG & 1) { fetch_operands(par); return; }
 #endif
     const float *arow = &As[li * kLdsStride + 64 * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * s4 + 2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (s4 < 4) fetch_operand(par, s4);
       a4 = an;
     }
   };
@@ -244,8 +256,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 #endif
     do {
       const int par = k & 1;
-      fetch_operands(par);
-      compute();
+      compute(par);
       lds_barrier();             // every wave is done reading this tile's rows
       stage(par ^ 1);            // tile k+1 (rows were requested one iteration ago)
       load_rows();               // tile k+2 (ids were requested one iteration ago)
