@@ -38,9 +38,14 @@ struct TypedArgs {
 
 template <int EPI>
 __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
-  __shared__ float As[kSub * kLdsStride];
+  // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
+  // TEPI_DZ keeps the two-barrier order (MFMA phase | stage + requests | epilogue): its epilogue waits for streamed
+  // base rows, and the extra phase between their request and their use hides them better (measured: +3 % otherwise).
+  constexpr bool kPipelined = EPI == TEPI_EDGE;
+  __shared__ float As[kPipelined ? 2 : 1][kSub * kLdsStride];
   __shared__ float Cs[4][32 * kScrStride];
-  __shared__ uint32_t rowA[2][kSub], rowB[2][kSub], rowC[2][kSub], rowR[2][kSub];   // [tile parity][row] byte offsets
+  __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] byte offsets: tile k's are read
+                                                                                     // (epilogue) while tile k+2's are written
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, cs = wave, gtid = threadIdx.x;
   const int col = 32 * cs + li;
@@ -109,15 +114,14 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 #ifdef DMP_TY_DBG
   bool warm = false;
 #endif
-  auto load_rows = [&]() {                                // rows + per-row scalars of the tile whose ids are loaded
-#pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) {
+  auto load_row = [&](int m) {
 #ifdef DMP_TY_DBG
-      if ((DMP_TY_DBG & 8) && warm) break;
+    if ((DMP_TY_DBG & 8) && warm) return;
 #endif
-      const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
-      pre[m] = buf_load4(rs_A, off, 0);
-    }
+    const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
+    pre[m] = buf_load4(rs_A, off, 0);
+  };
+  auto load_row_scalars = [&]() {
     if (gtid < kSub) {
       const uint32_t eo = id_own >= 0 ? (uint32_t)id_own * 4u : kOOB;
       pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
@@ -126,10 +130,15 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       own_staged = id_own;
     }
   };
-  auto stage = [&](int par) {                             // registers -> LDS
+  auto load_rows = [&]() {                                // rows + per-row scalars of the tile whose ids are loaded
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m)
-      *reinterpret_cast<float4 *>(&As[((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+    for (int m = 0; m < kSubLoads; ++m) load_row(m);
+    load_row_scalars();
+  };
+  auto stage_row = [&](int buf, int m) {                   // registers -> LDS, one of the thread's four row pieces
+    *reinterpret_cast<float4 *>(&As[buf][((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+  };
+  auto stage_scalars = [&](int par) {                      // per-row byte offsets of the staged tile (threads < 32)
     if (gtid < kSub) {
       const bool ok = own_staged >= 0;
       uint32_t a = kOOB, bb = kOOB;
@@ -144,6 +153,11 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       rowR[par][gtid] = (ok && p.R) ? (uint32_t)own_staged * (uint32_t)(p.ldr * 4) : kOOB;
     }
   };
+  auto stage = [&](int buf, int par) {
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(buf, m);
+    stage_scalars(par);
+  };
 
   f32x16 acc;
   float4 g0[4], g1[4];
@@ -156,22 +170,6 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
     else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
   };
-  auto fetch_operands = [&](int par) {
-#ifdef DMP_TY_DBG
-    if (DMP_TY_DBG & 2) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; }
-      return;
-    }
-#endif
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rr = 8 * k + lrow;
-      g0[k] = buf_load4(rs_T, rowA[par][rr] + col4, 0);
-      if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
-      else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
-    }
-  };
   // The MFMA phase, with the epilogue operand requests of the same tile in its shadow: two of the eight loads
   // (and the LDS reads of their row offsets) after each of the first four MFMA groups.
   auto compute = [&](int par) {
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 #ifdef DMP_TY_DBG
     if (DMP_TY_DBG & 1) { fetch_operands(par); return; }
 #endif
-    const float *arow = &As[li * kLdsStride + 64 * h];
+    const float *arow = &As[0][li * kLdsStride + 64 * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) {
@@ -193,6 +191,40 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (s4 < 4) fetch_operand(par, s4);
+      a4 = an;
+    }
+  };
+  // One tile: the MFMAs of tile k (As[k & 1]) with, in the shadow of its 16 MFMA groups: the tile's epilogue operand
+  // requests (groups 0-3), the staging of tile k+1 into the other buffer (groups 4-8), the row requests of tile
+  // k+2 (groups 9-13) and the id requests of tile k+3 (group 14).  par3 = k % 3 indexes the per-row offset arrays.
+  auto tile_step = [&](int k, int par3) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
+    const float *arow = &As[buf][li * kLdsStride + 64 * h];
+    float4 a4 = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      float4 an = a4;
+      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef DMP_TY_DBG
+      if (!(DMP_TY_DBG & 1)) {
+#endif
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
+#ifdef DMP_TY_DBG
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (s4 < 4) fetch_operand(par3, s4);
+      else if (s4 < 8) stage_row(buf ^ 1, s4 - 4);
+      else if (s4 == 8) stage_scalars(nxt3);
+      else if (s4 < 13) load_row(s4 - 9);
+      else if (s4 == 13) load_row_scalars();
+      else if (s4 == 14) load_ids(k + 3);
       a4 = an;
     }
   };
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   load_ids(0);
   load_rows();                 // tile 0
   load_ids(1);
-  stage(0);
+  stage(0, 0);
   load_rows();                 // tile 1
   load_ids(2);
   lds_barrier();
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   // bit l of `starts` says "tile 64c + l begins a new class".  The hot loop then tests a scalar bit -- a
   // per-tile coefficient load in its condition was a vector load the loop had to wait for with vmcnt(0),
   // i.e. behind the row prefetch and the epilogue's stores it had just issued.
-  int k = 0;
+  int k = 0, par3 = 0;
   float sv = 0.f, c_have = 0.f;
   bool have_panel = false;
   unsigned long long starts = 0;
@@ -255,15 +287,20 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     warm = true;
 #endif
     do {
-      const int par = k & 1;
-      compute(par);
-      lds_barrier();             // every wave is done reading this tile's rows
-      stage(par ^ 1);            // tile k+1 (rows were requested one iteration ago)
-      load_rows();               // tile k+2 (ids were requested one iteration ago)
-      load_ids(k + 3);
-      lds_barrier();             // tile k+1 is in LDS for everyone
-      epilogue(par);
+      if (kPipelined) {
+        tile_step(k, par3);
+        lds_barrier();           // tile k+1 is staged for everyone, everyone is done with tile k's rows
+      } else {
+        compute(par3);
+        lds_barrier();           // every wave is done reading this tile's rows
+        stage(0, par3 == 2 ? 0 : par3 + 1);   // tile k+1 (rows were requested one iteration ago)
+        load_rows();             // tile k+2 (ids were requested one iteration ago)
+        load_ids(k + 3);
+        lds_barrier();           // tile k+1 is in LDS for everyone
+      }
+      epilogue(par3);
       ++k;
+      par3 = par3 == 2 ? 0 : par3 + 1;
     } while (k < mine && (k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0);
   }
 }
