@@ -89,10 +89,15 @@ struct MfmaArgs {
 template <int NC, int EPI, int PP>
 __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 ? 3 : 2)) void mfma_pp(MfmaArgs p) {
   constexpr int NG = PP ? 2 : 1;                            // wave groups per workgroup
-  __shared__ float As[NG][kSub * kLdsStride];
+  // kPipe (one panel, streamed epilogue operand: out_fwd / bwd_h1): one barrier per tile, the staging of the next
+  // tile (second As buffer), the row requests of the tile after it and the epilogue operand requests of the NEXT
+  // tile (second operand register set: streamed rows need a whole tile of latency) in the MFMA shadow.
+  constexpr bool kPipe = !PP && NC == 1 && (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G);
+  constexpr int NBUF = kPipe ? 2 : 1, NPAR = kPipe ? 3 : 2;
+  __shared__ float As[NG * NBUF][kSub * kLdsStride];
   __shared__ float Cs[4 * NG][32 * kScrStride];
-  __shared__ uint32_t rowA[NG][2][kSub], rowB[NG][2][kSub];   // [group][tile parity][row]
-  __shared__ float rowS[NG][2][kSub];
+  __shared__ uint32_t rowA[NG][NPAR][kSub], rowB[NG][NPAR][kSub];   // [group][tile parity (kPipe: tile % 3)][row]
+  __shared__ float rowS[NG][NPAR][kSub];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   const int grp = wave >> 2, cs = wave & 3, gtid = threadIdx.x & (kGroupThreads - 1);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
 #pragma unroll
     for (int s = 0; s < 64; ++s) asm volatile("" ::"v"(b[q][s]));  // loads complete here, not inside the loop
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
-  float *As_g = As[grp];
+  float *As_g = As[grp * NBUF];
   float *scr = Cs[wave];
 
   // per-lane constants of the wide (float4) layout: lane -> row 8k + lane/8, 4 columns from c4
@@ -191,8 +196,22 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
     }
   };
 
+  auto stage_row_to = [&](int buf, int m) {
+    *reinterpret_cast<float4 *>(&As[buf][((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+  };
+  auto stage_scalars_to = [&](int par) {
+    if (gtid < kSub) rowS[grp][par][gtid] = (EPI == EPI_GATE_RES && !p.rowscale) ? 1.f : pre_s;
+  };
+  auto load_scalars_of = [&](int t) {
+    if (gtid < kSub) {
+      const uint32_t so = (uint32_t)t * (kSub * 4u);
+      pre_s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_scale, gtid * 4, (int)so, 0));
+    }
+  };
+
   f32x16 acc[NC];
   float4 g0[4], g1[4];
+  float4 g0n[kPipe ? 4 : 1];                               // kPipe: the next tile's epilogue operand rows
   auto fetch_operands = [&](int t, int par) {             // epilogue operands of tile t, in store layout
     const rsrc_t rr_ = make_rsrc(p.R ? p.R + (int64_t)t * kSub * p.ldr : nullptr,
                                  p.R ? tile_bytes(tile_rows(t), p.ldr, 128) : 0u);
@@ -231,6 +250,32 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][4 * s4 + 3], acc[q], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+    }
+  };
+  auto tile_step = [&](int k, int par3, int t1, int t2) {   // kPipe only: tile k in As[k & 1]; t1 / t2: the next two tiles
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
+    const rsrc_t rr1 = make_rsrc(p.R ? p.R + (int64_t)t1 * kSub * p.ldr : nullptr, p.R ? tile_bytes(tile_rows(t1), p.ldr, 128) : 0u);
+    const rsrc_t ra2 = make_rsrc(p.A + (int64_t)t2 * kSub * p.lda, tile_bytes(tile_rows(t2), p.lda, 128));
+    const float *arow = &As[buf][li * kLdsStride + 64 * h];
+    float4 a4 = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      float4 an = a4;
+      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[0][4 * s4 + 0], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[0][4 * s4 + 1], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[0][4 * s4 + 2], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[0][4 * s4 + 3], acc[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s4 < 4) g0n[kPipe ? s4 : 0] = buf_load4(rr1, voffR, s4 * grpR);          // tile k+1's operand rows 8 s4 + lrow
+      else if (s4 < 8) stage_row_to(buf ^ 1, s4 - 4);                              // tile k+1 -> the other buffer
+      else if (s4 == 8) stage_scalars_to(nxt3);
+      else if (s4 < 13) pre[s4 - 9] = buf_load4(ra2, voffA, (s4 - 9) * grpA);      // tile k+2's rows
+      else if (s4 == 13) load_scalars_of(t2);
       a4 = an;
     }
   };
@@ -307,7 +352,25 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   const int t0 = first + grp;
   const int mine = t0 < ntiles ? (ntiles - t0 + stride - 1) / stride : 0;
   auto tile = [&](int k) { return __builtin_amdgcn_readfirstlane(t0 + k * stride); };
-  if (!PP) {
+  if (kPipe) {
+    // Per tile k:  MFMA phase with everything else in its shadow | barrier | epilogue k.
+    load_rows(tile(0));
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row_to(0, m);
+    stage_scalars_to(0);
+    load_rows(tile(1));
+    fetch_operands(tile(0), 0);
+    lds_barrier();
+    int par3 = 0;
+    for (int k = 0; k < mine; ++k) {
+      tile_step(k, par3, tile(k + 1), tile(k + 2));
+      lds_barrier();               // tile k+1 is staged for everyone, everyone is done with tile k's rows
+      epilogue(tile(k), par3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g0[q] = g0n[kPipe ? q : 0];
+      par3 = par3 == 2 ? 0 : par3 + 1;
+    }
+  } else if (!PP) {
     // Independent 256-thread workgroups (2-3 resident per CU, not synchronised with each other).
     // Per tile k:  MFMA phase | barrier | stage k+1, prefetch k+2 | barrier | epilogue k.
     // The wait for the prefetched rows in `stage` only has YOUNGER traffic behind it (the previous
