@@ -542,8 +542,8 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 }
 
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
-                      const float *gate, const float *R, int64_t ldr, int64_t E, int H, float *out,
-                      int64_t ldo, void *stream) {
+                      const float *gate, const float *R, int64_t ldr, int64_t E, int H, int w_in_out,
+                      float *out, int64_t ldo, void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Hin || !W2 || !out || ldh < H || ldw < H || ldo < H || (R && ldr < H)) return DMP_ERR_BAD_ARG;
@@ -552,7 +552,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
     return DMP_ERR_UNSUPPORTED;
   if (!fits32(E, 1) || !fits32(kSub, ldh) || !fits32(kSub, ldo) || (R && !fits32(kSub, ldr))) return DMP_ERR_UNSUPPORTED;
   MfmaArgs p{};
-  p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw; p.bt = 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]
+  p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw;
+  p.bt = w_in_out ? 0 : 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]; [in, out] (its transpose): B[k][j] = W2[k][j]
   p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : 128; p.ldt = 256;
   return launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream);
 }

@@ -271,9 +271,9 @@ def out_fwd_mfma(h1, W2, b2, gate, prev):
     lib = _lib.load()
     R, H = h1.shape
     out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
-    W2 = W2.contiguous()
+    W2t = W2.t().contiguous()     # [in, out]: coalesced weight-panel reads in each of the kernel's workgroups
     with _lib.timed("out_fwd_mfma[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
-        check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2), W2.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H,
+        check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H, 1,
                                     ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
     return out
 

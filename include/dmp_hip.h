@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 21
+#define DMP_ABI_VERSION 22
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -479,11 +479,12 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 /*
  * Second Linear of the MLP + gate + residual in one pass (dmpnn.py:136,152 + 263-273):
  *     out[r] = R[r] + gate[r] * (Hin[r] W2^T + b2)
- *   W2 [H, ldw>=H] in nn.Linear layout [out, in]; gate [rows] or NULL (1); R [rows, ldr] or NULL (0).
+ *   W2 [H, ldw>=H] in nn.Linear layout [out, in], or -- w_in_out != 0 -- its transpose [in, out] (every
+ *   workgroup then reads its weight panel with coalesced loads); gate [rows] or NULL (1); R [rows, ldr] or NULL (0).
  */
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw,
                       const float *bias, const float *gate, const float *R, int64_t ldr,
-                      int64_t rows, int H, float *out, int64_t ldo, void *stream);
+                      int64_t rows, int H, int w_in_out, float *out, int64_t ldo, void *stream);
 
 /*
  * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
