@@ -9,7 +9,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "_dbg", "libmfma_80.so"))
 P, I64, I, F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 lib.dmp_gemm_k128.argtypes = [P, I64, P, I64, I, P, I64, I64, I, P]
 lib.dmp_edge_fwd_fused.argtypes = [P, I64, P, I64, P, I64, I64, P, P, P, P, I64, I, P, I64, P]
-lib.dmp_bwd_h1_fused.argtypes = [P, I64, P, I64, P, I64, P, I64, I, P, I64, P, P]
+lib.dmp_bwd_h1_fused.argtypes = [P, I64, P, I64, P, I64, P, P, I64, I, P, I64, P, P]
 lib.dmp_out_fwd_fused.argtypes = [P, I64, P, I64, P, P, P, I64, I64, I, I, P, I64, P]
 lib.dmp_bwd_z_fused.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, P, F, F, I64, I, P, I64, P]
 lib.dmp_dev_read_dbg.argtypes = [P]
@@ -25,7 +25,7 @@ calls = {
     "gemm N=128": lambda: lib.dmp_gemm_k128(d(Z[0]), H, d(W1), H, 0, d(O), H, E, 128, st),
     "gemm N=256": lambda: lib.dmp_gemm_k128(d(Z[0]), H, d(W2), 2 * H, 0, d(O2), 2 * H, E, 256, st),
     "edge_fwd": lambda: lib.dmp_edge_fwd_fused(d(Z[0]), H, d(W2), 2 * H, d(Pn), 2 * H, N_, d(bias), d(src), d(dst), d(coefE), E, H, d(O), H, st),
-    "bwd_h1": lambda: lib.dmp_bwd_h1_fused(d(Z[0]), H, d(W1), H, d(Z[1]), H, d(coefE), E, H, d(O2), 2 * H, d(part), st),
+    "bwd_h1": lambda: lib.dmp_bwd_h1_fused(d(Z[0]), H, d(W1), H, d(Z[1]), H, d(coefE), None, E, H, d(O2), 2 * H, d(part), st),
     "out_fwd": lambda: lib.dmp_out_fwd_fused(d(Z[0]), H, d(W1), H, d(bias), d(gate), d(Z[1]), H, E, H, 0, d(O), H, st),
     "bwd_z": lambda: lib.dmp_bwd_z_fused(d(Z[0]), H, d(W2), 2 * H, d(Pn), 2 * H, N_, d(Z[1]), H, d(coefE), d(dst), d(flag), -1.0, 1.0, E, H, d(O), H, st),
 }
