@@ -110,3 +110,40 @@ def test_training_steps_match_reference(fused, gpu):
     after = {k[9:]: v for k, v in d.items() if k.startswith("sd_after.")}
     for k, v in model.state_dict().items():
         _close(v, after[k], 2e-3, "param after training " + k)
+
+
+@pytest.mark.parametrize("kind", ["SumPredictNet", "MeanPredictNet"])
+def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
+    """pred._PooledHead (the pooled head as one hand-written autograd node) against the same algebra recorded op by
+    op: prediction and every input / parameter gradient."""
+    from dualmessagepassing_amd.pred import PRED_NETS
+    th.manual_seed(5)
+    B, d, h = 257, 128, 128
+    net = PRED_NETS[kind](d, h, act_func="relu").to(gpu)
+    for p in net.parameters():
+        p.data.normal_(0.0, 0.2)
+    gen = th.Generator().manual_seed(6)
+    ps = th.randn(B, d, generator=gen).to(gpu).requires_grad_(True)
+    gs = th.randn(B, d, generator=gen).to(gpu).requires_grad_(True)
+    pl = th.randint(1, 9, (B, 1), generator=gen).float().to(gpu)
+    gl = th.randint(1, 65, (B, 1), generator=gen).float().to(gpu)
+    Lp, Lg = 8, 64
+    y, _ = net.forward_pooled(ps, Lp, pl, gs, Lg, gl)
+
+    def reference():
+        if net.pool_kind == "sum":
+            p = th.nn.functional.linear(ps, net.p_fc.weight) + float(Lp) * net.p_fc.bias
+            g = th.nn.functional.linear(gs, net.g_fc.weight) + float(Lg) * net.g_fc.bias
+        else:
+            p, g = net.p_fc(ps / float(Lp)), net.g_fc(gs / float(Lg))
+        f = th.cat([p, g, g - p, g * p, pl, gl, 1.0 / pl, 1.0 / gl], dim=1)
+        y1 = th.relu(net.pred_fc1(f))
+        return net.pred_fc2(th.cat([y1, pl, gl, 1.0 / pl, 1.0 / gl], dim=1))
+    ref = reference()
+    assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    cot = th.randn(B, 1, generator=gen).to(gpu)
+    wrt = [ps, gs] + list(net.parameters())
+    got = th.autograd.grad((y * cot).sum(), wrt)
+    want = th.autograd.grad((ref * cot).sum(), wrt)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=1e-4), (i, (a - b).abs().max().item())
