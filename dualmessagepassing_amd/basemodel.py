@@ -38,6 +38,21 @@ class OutputDict(OrderedDict):
         return tuple(self[k] for k in self.keys())
 
 
+class _Blend(th.autograd.Function):
+    """``wa * a + wb * b`` with constant weights (basemodel.py:1489-1492: the node / edge head predictions weighted by
+    the share of target nodes / edges): one autograd node, two launches each way."""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        ctx.save_for_backward(wa, wb)
+        return th.addcmul(wa * a, wb, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        wa, wb = ctx.saved_tensors
+        return wa * d, wb * d, None, None
+
+
 class ScalarFilter(nn.Module):
     """filter.py:6-16: gate[b, j] = any_i (g_x[b, j] == p_x[b, i])."""
 
@@ -575,7 +590,7 @@ class GraphAdjModelV2(BaseModel):
                                                             g_e_sum, g_e_mask.size(1), g_e_len)
         if self.node_pred and self.edge_pred:
             g_len = g_v_len + g_e_len
-            return (g_v_len / g_len) * v_pred_c + (g_e_len / g_len) * e_pred_c, (None, None)
+            return _Blend.apply(v_pred_c, e_pred_c, g_v_len / g_len, g_e_len / g_len), (None, None)
         if self.node_pred:
             return v_pred_c, (None, None)
         if self.edge_pred:
