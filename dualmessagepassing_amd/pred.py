@@ -38,14 +38,15 @@ class _PooledHead(th.autograd.Function):
         db2 = dy.sum(0)
         dy1 = th.ops.aten.threshold_backward(dy * W2[:, :h], y1s[:, :h], 0.0)    # [B, h]
         dW1 = dy1.t() @ f
-        db1 = dy1.sum(0)
         df = dy1 @ W1                                                       # [B, 4h + 4]
         p, g = f[:, :h], f[:, h:2 * h]
         dfp, dfg, dfd, dfm = df[:, :h], df[:, h:2 * h], df[:, 2 * h:3 * h], df[:, 3 * h:4 * h]
         dp = th.addcmul(dfp - dfd, dfm, g)
         dg = th.addcmul(dfg + dfd, dfm, p)
         dWp, dWg = dp.t() @ ps, dg.t() @ gs
-        dbp, dbg = dp.sum(0) * ctx.scale_p, dg.sum(0) * ctx.scale_g
+        # the three bias gradients as ONE ones-row product (a dim-0 reduction kernel per [B, h] matrix costs more)
+        sums = (dy.new_ones((1, dy.size(0))) @ th.cat([dy1, dp, dg], dim=1)).view(3, h)
+        db1, dbp, dbg = sums[0], sums[1] * ctx.scale_p, sums[2] * ctx.scale_g
         dps = dp @ Wp if ctx.needs_input_grad[0] else None
         dgs = dg @ Wg if ctx.needs_input_grad[1] else None
         return dps, dgs, None, None, None, None, dWp, dbp, dWg, dbg, dW1, db1, dW2, db2
