@@ -56,6 +56,8 @@ SIGNATURES = {
     "dmp_colsum_partials": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr]),
     "dmp_add_bias_relu": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_heads_forward": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "dmp_heads_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "dmp_fold_layers": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_unfold_layers": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_smallk_embed_gate": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
@@ -95,7 +97,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

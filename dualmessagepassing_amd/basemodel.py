@@ -576,6 +576,32 @@ class GraphAdjModelV2(BaseModel):
             return e_pred_c, (v_pred_w, e_pred_w)
         raise ValueError
 
+    def _hip_heads_ok(self, v_sums, e_sums):
+        if not (self.node_pred or self.edge_pred):
+            return False
+        if self.node_pred and not self.pred_net["v"].hip_head_ok(v_sums):
+            return False
+        if self.edge_pred and not self.pred_net["e"].hip_head_ok(e_sums):
+            return False
+        return True
+
+    def get_subiso_pred_hip(self, v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask):
+        """``get_subiso_pred`` (basemodel.py:1477-1498) on the pooled union rows: every head and their blend in one
+        autograd node / three HIP launches (``pred._PooledHeadsHIP``)."""
+        from .pred import _PooledHeadsHIP
+        cnt = lambda m: m.sum(dim=1, dtype=th.float32).view(-1, 1)
+        args, g_lens = [], []
+        for key, on, sums, pm, gm in (("v", self.node_pred, v_sums, p_v_mask, g_v_mask), ("e", self.edge_pred, e_sums, p_e_mask, g_e_mask)):
+            if on:
+                gl = cnt(gm)
+                g_lens.append(gl)
+                args.append([sums, cnt(pm), gl, float(pm.size(1)), float(gm.size(1)), None] + list(self.pred_net[key].head_params()))
+        if len(args) == 2:
+            g_len = g_lens[0] + g_lens[1]
+            args[0][5], args[1][5] = g_lens[0] / g_len, g_lens[1] / g_len
+        flat = [a for head in args for a in head]
+        return _PooledHeadsHIP.apply(len(args), *flat), (None, None)
+
     def get_subiso_pred_pooled(self, p_v_sum, p_v_mask, p_e_sum, p_e_mask, g_v_sum, g_v_mask, g_e_sum, g_e_mask):
         """``get_subiso_pred`` (basemodel.py:1477-1498) on per-graph sums instead of padded rows."""
         cnt = lambda m: m.sum(dim=1, dtype=th.float32).view(-1, 1)
@@ -638,6 +664,7 @@ class GraphAdjModelV2(BaseModel):
         # un-padded representations with the segment-sum kernel; otherwise the reference's padded path
         pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         p_v_output = g_v_output = p_e_output = g_e_output = None
+        v_sums = e_sums = None      # [2B, H] pooled rows of the union pass (pattern graphs, then target graphs)
         if self.node_pred:
             p_add, g_add = [], []
             if self.pred_with_enc:
@@ -653,7 +680,7 @@ class GraphAdjModelV2(BaseModel):
             if pooled and v_union is not None and not p_add:
                 # the shared rep-net ran over the union of both batches: pool the union rows once
                 # (its backward is the union gradient itself, no concatenation of two halves)
-                sums = ops.seg_pool(v_union, _pool_index_union(pattern, graph, "node"))
+                sums = v_sums = ops.seg_pool(v_union, _pool_index_union(pattern, graph, "node"))
                 p_v_output, g_v_output = sums[:bsz], sums[bsz:]
             elif pooled:
                 p_v_output = ops.seg_pool(p_v_output, _pool_index(pattern, "node"))
@@ -676,7 +703,7 @@ class GraphAdjModelV2(BaseModel):
             p_e_mask = self.refine_edge_weights(p_e_mask)
             g_e_mask = self.refine_edge_weights(g_e_mask)
             if pooled and e_union is not None and not p_add:
-                sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge"))[:, :e_union.size(1)]
+                sums = e_sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge"))[:, :e_union.size(1)]
                 p_e_output, g_e_output = sums[:bsz], sums[bsz:]
             elif pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
                 d = p_e_output.size(1)
@@ -688,7 +715,9 @@ class GraphAdjModelV2(BaseModel):
 
         p_v_mask, p_e_mask = p_v_mask.view(bsz, -1), p_e_mask.view(bsz, -1)
         g_v_mask, g_e_mask = g_v_mask.view(bsz, -1), g_e_mask.view(bsz, -1)
-        if pooled:
+        if pooled and self._hip_heads_ok(v_sums, e_sums):
+            pred_c, (pred_v, pred_e) = self.get_subiso_pred_hip(v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask)
+        elif pooled:
             pred_c, (pred_v, pred_e) = self.get_subiso_pred_pooled(p_v_output, p_v_mask, p_e_output, p_e_mask,
                                                                    g_v_output, g_v_mask, g_e_output, g_e_mask)
         else:

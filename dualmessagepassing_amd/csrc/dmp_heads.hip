@@ -1,0 +1,343 @@
+// The pooled prediction heads (SubgraphCountingMatching/models/pred.py:93-156 on per-graph sums, the node and the
+// edge head of basemodel.py:1477-1498) as three launches for ALL heads: forward, backward over the rows, backward
+// weight gradients.  The tensors are tiny ([B, 128..516], B = pairs per batch): the algebra is ~60 launches per
+// step when done op by op, i.e. pure launch latency at the end of forward and the start of backward.
+//
+//   p = ps Wp^T + sp bp;  g = gs Wg^T + sg bg;  s = [pl, gl, 1/pl, 1/gl]
+//   f = [p | g | g - p | g * p | s]  (4h + 4);  y1 = relu(f W1^T + b1);  y = [y1 | s] W2^T + b2
+//
+// h = input width = 128 only.  Plain fp32 FMAs through LDS tiles (as csrc/dmp_fold.hip): 16 rows per workgroup,
+// thread (r, cg) owns 8 consecutive columns of row r.
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+constexpr int kH = 128, kF = 4 * kH + 4, kYS = kH + 4;
+constexpr int kThreads = 256, kRows = 16, kPad = 132, kFPad = 520;
+constexpr int kMaxHeads = DMP_HEADS_MAX;
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+struct Heads {
+  dmp_head_weights w[kMaxHeads];
+  dmp_head_io io[kMaxHeads];
+  dmp_head_grads gr[kMaxHeads];
+  int B;
+};
+
+// acc[8] += A_lds[r][0..127] . op(W)[.., 8 cg ..]   for one 128-wide contraction; W element (j, k) at W[j * ldw + k]
+//   wT = 1: out col j, contraction k: out[j] = sum_k a[k] W[j][k]     (x W^T, W in nn.Linear layout)
+//   wT = 0: out col k, contraction j: out[k] = sum_j a[j] W[j][k]     (x W)
+// a0: first contraction index inside As rows (the operand row holds >= a0 + 128 values at stride 1).
+__device__ __forceinline__ void gemm128(float (&acc)[8], const float *As_row, const float *W, int ldw, int wT, int wcol0,
+                                        float *Ws, int tid, int cg) {
+  for (int k0 = 0; k0 < kH; k0 += 32) {
+    __syncthreads();
+    if (wT) {                                               // Ws[kk][j] = W[j][k0 + kk]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
+        const float4 w = ldg4(W + (int64_t)j * ldw + wcol0 + k0 + kk4);
+        Ws[(kk4 + 0) * kPad + j] = w.x; Ws[(kk4 + 1) * kPad + j] = w.y;
+        Ws[(kk4 + 2) * kPad + j] = w.z; Ws[(kk4 + 3) * kPad + j] = w.w;
+      }
+    } else {                                                // Ws[jj][k] = W[k0 + jj][wcol0 + k]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+        *reinterpret_cast<float4 *>(&Ws[row * kPad + c4]) = ldg4(W + (int64_t)(k0 + row) * ldw + wcol0 + c4);
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float a = As_row[k0 + kk];
+      const float4 w0 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8]);
+      const float4 w1 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8 + 4]);
+      acc[0] += a * w0.x; acc[1] += a * w0.y; acc[2] += a * w0.z; acc[3] += a * w0.w;
+      acc[4] += a * w1.x; acc[5] += a * w1.y; acc[6] += a * w1.z; acc[7] += a * w1.w;
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_rows(float *As, const float *X, int64_t ldx, int i0, int B, int tid) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 + row < B) a = ldg4(X + (int64_t)(i0 + row) * ldx + c4);
+    *reinterpret_cast<float4 *>(&As[row * kPad + c4]) = a;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
+  __shared__ float As[kRows * kPad];
+  __shared__ float Fs[kRows * kFPad];
+  __shared__ float Ws[32 * kPad];
+  const dmp_head_weights &w = t.w[blockIdx.y];
+  const dmp_head_io &io = t.io[blockIdx.y];
+  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15, i0 = (int)blockIdx.x * kRows, b = i0 + r;
+  const bool live = b < t.B;
+  float p[8], g[8];
+  // p = ps Wp^T + sp bp,  g = gs Wg^T + sg bg
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { p[e] = 0.f; g[e] = 0.f; }
+  stage_rows(As, io.ps, io.ld_ps, i0, t.B, tid);
+  gemm128(p, &As[r * kPad], w.Wp, kH, 1, 0, Ws, tid, cg);
+  __syncthreads();
+  stage_rows(As, io.gs, io.ld_gs, i0, t.B, tid);
+  gemm128(g, &As[r * kPad], w.Wg, kH, 1, 0, Ws, tid, cg);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    p[e] += io.scale_p * w.bp[cg * 8 + e];
+    g[e] += io.scale_g * w.bg[cg * 8 + e];
+  }
+  // f = [p | g | g - p | g * p | s]
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) { s4[0] = io.pl[b]; s4[1] = io.gl[b]; s4[2] = 1.0f / s4[0]; s4[3] = 1.0f / s4[1]; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg * 8 + e;
+    Fs[r * kFPad + c] = p[e];
+    Fs[r * kFPad + kH + c] = g[e];
+    Fs[r * kFPad + 2 * kH + c] = g[e] - p[e];
+    Fs[r * kFPad + 3 * kH + c] = g[e] * p[e];
+  }
+  if (cg < 4) Fs[r * kFPad + 4 * kH + cg] = s4[cg];
+  __syncthreads();
+  if (live) {
+    float *F = io.F + (int64_t)b * kF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4 *>(F + q * kH + cg * 8) = *reinterpret_cast<const float4 *>(&Fs[r * kFPad + q * kH + cg * 8]);
+      *reinterpret_cast<float4 *>(F + q * kH + cg * 8 + 4) = *reinterpret_cast<const float4 *>(&Fs[r * kFPad + q * kH + cg * 8 + 4]);
+    }
+    if (cg < 4) F[4 * kH + cg] = s4[cg];
+  }
+  // y1 = relu(f W1^T + b1): four 128-wide contractions + the four scalars
+  float y1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y1[e] = w.b1[cg * 8 + e];
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) gemm128(y1, &Fs[r * kFPad + q * kH], w.W1, kF, 1, q * kH, Ws, tid, cg);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float *wr = w.W1 + (int64_t)(cg * 8 + e) * kF + 4 * kH;
+    y1[e] += s4[0] * wr[0] + s4[1] * wr[1] + s4[2] * wr[2] + s4[3] * wr[3];
+    y1[e] = fmaxf(y1[e], 0.f);
+  }
+  // y = [y1 | s] W2^T + b2
+  float part = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part += y1[e] * w.W2[cg * 8 + e];
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
+  if (live) {
+    float *ys = io.Y1S + (int64_t)b * kYS;
+    *reinterpret_cast<float4 *>(ys + cg * 8) = make_float4(y1[0], y1[1], y1[2], y1[3]);
+    *reinterpret_cast<float4 *>(ys + cg * 8 + 4) = make_float4(y1[4], y1[5], y1[6], y1[7]);
+    if (cg < 4) ys[kH + cg] = s4[cg];
+    if (cg == 0)
+      io.y[b] = part + s4[0] * w.W2[kH] + s4[1] * w.W2[kH + 1] + s4[2] * w.W2[kH + 2] + s4[3] * w.W2[kH + 3] + w.b2[0];
+  }
+}
+
+// Backward over the rows: dy -> dy1 (ReLU mask) -> df = dy1 W1 -> dp, dg -> dps = dp Wp, dgs = dg Wg.
+// Writes what the weight gradients need (dY1, dP, dG) and the input gradients.
+__global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
+  __shared__ float As[kRows * kPad];
+  __shared__ float Ws[32 * kPad];
+  const dmp_head_weights &w = t.w[blockIdx.y];
+  const dmp_head_io &io = t.io[blockIdx.y];
+  const dmp_head_grads &gr = t.gr[blockIdx.y];
+  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15, i0 = (int)blockIdx.x * kRows, b = i0 + r;
+  const bool live = b < t.B;
+  const float dy = live ? gr.dy[b] * (gr.dy_scale ? gr.dy_scale[b] : 1.0f) : 0.f;
+  // dy1 = y1 > 0 ? dy W2 : 0
+  float d1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float y1 = live ? io.Y1S[(int64_t)b * kYS + cg * 8 + e] : 0.f;
+    d1[e] = y1 > 0.f ? dy * w.W2[cg * 8 + e] : 0.f;
+    As[r * kPad + cg * 8 + e] = d1[e];
+  }
+  if (live) {
+    float *o = gr.dY1 + (int64_t)b * kH + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(d1[0], d1[1], d1[2], d1[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(d1[4], d1[5], d1[6], d1[7]);
+  }
+  // df blocks: [dfp | dfg | dfd | dfm] = dy1 W1[:, 0:4h]
+  float df[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) df[q][e] = 0.f;
+    gemm128(df[q], &As[r * kPad], w.W1, kF, 0, q * kH, Ws, tid, cg);
+  }
+  float dp[8], dg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float p = live ? io.F[(int64_t)b * kF + cg * 8 + e] : 0.f;
+    const float g = live ? io.F[(int64_t)b * kF + kH + cg * 8 + e] : 0.f;
+    dp[e] = (df[0][e] - df[2][e]) + df[3][e] * g;
+    dg[e] = (df[1][e] + df[2][e]) + df[3][e] * p;
+  }
+  if (live) {
+    float *o = gr.dP + (int64_t)b * kH + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(dp[4], dp[5], dp[6], dp[7]);
+    o = gr.dG + (int64_t)b * kH + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+  }
+  // input gradients: dps = dp Wp, dgs = dg Wg
+  float out[8];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dp[e]; out[e] = 0.f; }
+  gemm128(out, &As[r * kPad], w.Wp, kH, 0, 0, Ws, tid, cg);
+  if (live && gr.dps) {
+    float *o = gr.dps + (int64_t)b * gr.ld_dps + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dg[e]; out[e] = 0.f; }
+  gemm128(out, &As[r * kPad], w.Wg, kH, 0, 0, Ws, tid, cg);
+  if (live && gr.dgs) {
+    float *o = gr.dgs + (int64_t)b * gr.ld_dgs + cg * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+  }
+}
+
+// Weight gradients: out[j, k] = sum_i dC[i, j] M[i, k]  (j < nj <= 128, k < ncols), bias[j] = bscale * sum_i dC[i, j].
+// One workgroup per (job, 16 output rows, 32 output columns); the batch rows are contracted 64 at a time.
+struct WJob { const float *dC; const float *M; const float *row_scale; float *out; float *bias; int64_t ldc, ldm; int nj, ncols, ldo; float bscale; };
+constexpr int kMaxWJobs = 4 * kMaxHeads;
+struct WJobs { WJob job[kMaxWJobs]; int blk0[kMaxWJobs + 1]; int n; int B; };
+constexpr int kChunk = 64, kColW = 32;
+
+__global__ __launch_bounds__(kThreads) void heads_bwd_w_k(const WJobs t) {
+  __shared__ float Cs[kChunk * 17];
+  __shared__ float Ms[kChunk * (kColW + 4)];
+  int q = 0;
+  while (q + 1 < t.n && (int)blockIdx.x >= t.blk0[q + 1]) ++q;
+  const WJob &jb = t.job[q];
+  const int kblocks = (jb.ncols + kColW - 1) / kColW;
+  const int sub = (int)blockIdx.x - t.blk0[q];
+  const int j0 = (sub / kblocks) * kRows, k0 = (sub % kblocks) * kColW;
+  const int tid = threadIdx.x, jr = tid >> 4, cq = tid & 15;
+  float acc0 = 0.f, acc1 = 0.f, bsum = 0.f;
+  for (int i0 = 0; i0 < t.B; i0 += kChunk) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kChunk / 16; ++m) {
+      const int i = (tid >> 4) + 16 * m, jj = tid & 15;
+      float c = 0.f;
+      if (i0 + i < t.B && j0 + jj < jb.nj) {
+        c = jb.dC[(int64_t)(i0 + i) * jb.ldc + j0 + jj];
+        if (jb.row_scale) c *= jb.row_scale[i0 + i];
+      }
+      Cs[i * 17 + jj] = c;
+    }
+#pragma unroll
+    for (int m = 0; m < (kChunk * kColW) / kThreads; ++m) {
+      const int e = m * kThreads + tid, row = e / kColW, c = e % kColW;
+      Ms[row * (kColW + 4) + c] = (i0 + row < t.B && k0 + c < jb.ncols) ? jb.M[(int64_t)(i0 + row) * jb.ldm + k0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int lim = t.B - i0 < kChunk ? t.B - i0 : kChunk;
+#pragma unroll 8
+    for (int i = 0; i < lim; ++i) {
+      const float c = Cs[i * 17 + jr];
+      const float2 m2 = *reinterpret_cast<const float2 *>(&Ms[i * (kColW + 4) + cq * 2]);
+      acc0 += c * m2.x; acc1 += c * m2.y;
+      bsum += c;
+    }
+  }
+  if (j0 + jr < jb.nj) {
+    const int k = k0 + cq * 2;
+    if (k < jb.ncols) jb.out[(int64_t)(j0 + jr) * jb.ldo + k] = acc0;
+    if (k + 1 < jb.ncols) jb.out[(int64_t)(j0 + jr) * jb.ldo + k + 1] = acc1;
+    if (jb.bias && k0 == 0 && cq == 0) jb.bias[j0 + jr] = jb.bscale * bsum;
+  }
+}
+
+inline void add_wjob(WJobs &t, int &blocks, const float *dC, int64_t ldc, int nj, const float *row_scale, const float *M,
+                     int64_t ldm, int ncols, float *out, int ldo, float *bias, float bscale) {
+  WJob &j = t.job[t.n];
+  j.dC = dC; j.ldc = ldc; j.nj = nj; j.row_scale = row_scale; j.M = M; j.ldm = ldm; j.ncols = ncols; j.out = out; j.ldo = ldo;
+  j.bias = bias; j.bscale = bscale;
+  t.blk0[t.n] = blocks;
+  blocks += ((nj + kRows - 1) / kRows) * ((ncols + kColW - 1) / kColW);
+  t.n += 1;
+  t.blk0[t.n] = blocks;
+}
+
+inline bool ok16p(const void *q) { return q && (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+bool heads_valid(const dmp_head_weights *w, const dmp_head_io *io, int n, int B, int H) {
+  if (n < 1 || n > kMaxHeads || B < 0 || H != kH || !w || !io) return false;
+  for (int i = 0; i < n; ++i) {
+    if (!ok16p(w[i].Wp) || !ok16p(w[i].bp) || !ok16p(w[i].Wg) || !ok16p(w[i].bg) || !ok16p(w[i].W1) || !ok16p(w[i].b1) ||
+        !ok16p(w[i].W2) || !w[i].b2)
+      return false;
+    if (!ok16p(io[i].ps) || !ok16p(io[i].gs) || !io[i].pl || !io[i].gl || !ok16p(io[i].F) || !ok16p(io[i].Y1S) || !io[i].y ||
+        io[i].ld_ps < kH || io[i].ld_gs < kH || io[i].ld_ps % 4 || io[i].ld_gs % 4)
+      return false;
+  }
+  return true;
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H, void *stream) {
+  if (H != kH && H > 0) return DMP_ERR_UNSUPPORTED;
+  if (!heads_valid(w, io, num_heads, B, H)) return DMP_ERR_BAD_ARG;
+  if (B == 0) return DMP_OK;
+  Heads t;
+  for (int i = 0; i < num_heads; ++i) { t.w[i] = w[i]; t.io[i] = io[i]; t.gr[i] = dmp_head_grads{}; }
+  t.B = B;
+  heads_fwd_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
+  return check_launch();
+}
+
+int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g, int num_heads, int B,
+                       int H, void *stream) {
+  if (H != kH && H > 0) return DMP_ERR_UNSUPPORTED;
+  if (!heads_valid(w, io, num_heads, B, H) || !g) return DMP_ERR_BAD_ARG;
+  for (int i = 0; i < num_heads; ++i) {
+    if (!g[i].dy || !ok16p(g[i].dY1) || !ok16p(g[i].dP) || !ok16p(g[i].dG) || (g[i].dps && (!ok16p(g[i].dps) || g[i].ld_dps % 4)) ||
+        (g[i].dgs && (!ok16p(g[i].dgs) || g[i].ld_dgs % 4)) || !g[i].dWp || !g[i].dbp || !g[i].dWg || !g[i].dbg || !g[i].dW1 ||
+        !g[i].db1 || !g[i].dW2 || !g[i].db2)
+      return DMP_ERR_BAD_ARG;
+  }
+  if (B == 0) return DMP_OK;   // the caller zero-fills the weight gradients of an empty batch
+  Heads t;
+  WJobs wj;
+  wj.n = 0; wj.B = B;
+  int blocks = 0;
+  for (int i = 0; i < num_heads; ++i) {
+    t.w[i] = w[i]; t.io[i] = io[i]; t.gr[i] = g[i];
+    add_wjob(wj, blocks, g[i].dY1, kH, kH, nullptr, io[i].F, kF, kF, g[i].dW1, kF, g[i].db1, 1.0f);
+    add_wjob(wj, blocks, g[i].dP, kH, kH, nullptr, io[i].ps, io[i].ld_ps, kH, g[i].dWp, kH, g[i].dbp, io[i].scale_p);
+    add_wjob(wj, blocks, g[i].dG, kH, kH, nullptr, io[i].gs, io[i].ld_gs, kH, g[i].dWg, kH, g[i].dbg, io[i].scale_g);
+    add_wjob(wj, blocks, g[i].dy, 1, 1, g[i].dy_scale, io[i].Y1S, kYS, kYS, g[i].dW2, kYS, g[i].db2, 1.0f);
+  }
+  t.B = B;
+  heads_bwd_rows_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
+  int rc = check_launch();
+  if (rc != DMP_OK) return rc;
+  heads_bwd_w_k<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(wj);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -44,12 +44,16 @@ class FlatGradSync:
             if p.device != dev or p.dtype != dt:
                 raise ValueError("all parameters must share device and dtype")
         self.params = params
-        self.flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-        off = 0
+        # every slice starts on a 16-byte boundary (the HIP kernels take 16-byte-aligned parameter pointers when the
+        # parameters themselves are moved into such a buffer, flatten_parameters): sizes rounded up to 4 elements,
+        # the padding stays zero
+        self.offsets, off = [], 0
         for p in params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(off, device=dev, dtype=dt)
+        for p, off in zip(params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def flatten_parameters(self):
         """Move every parameter's storage into one contiguous buffer (each ``p.data`` becomes a view of
@@ -57,14 +61,11 @@ class FlatGradSync:
         an elementwise optimizer (Adam / AdamW / SGD with one parameter group) stepped on it performs
         exactly the per-parameter updates, in one launch instead of one multi-tensor chunk list."""
         if getattr(self, "master", None) is None:
-            store = torch.empty_like(self.flat)
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                v = store[off:off + n].view_as(p)
+            store = torch.zeros_like(self.flat)
+            for p, off in zip(self.params, self.offsets):
+                v = store[off:off + p.numel()].view_as(p)
                 v.copy_(p.data)
                 p.data = v
-                off += n
             self.master = torch.nn.Parameter(store, requires_grad=True)
             self.master.grad = self.flat
         return self.master
@@ -88,11 +89,7 @@ class FlatGradSync:
         got none) and point every ``.grad`` at its slice again."""
         views = getattr(self, "_views", None)
         if views is None:                                    # the slices never change: built once
-            views, off = [], 0
-            for p in self.params:
-                n = p.numel()
-                views.append(self.flat[off:off + n].view_as(p))
-                off += n
+            views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
             self._views = views
         dst, src, missing = [], [], False
         for p, v in zip(self.params, views):

@@ -52,6 +52,104 @@ class _PooledHead(th.autograd.Function):
         return dps, dgs, None, None, None, None, dWp, dbp, dWg, dbg, dW1, db1, dW2, db2
 
 
+_HEAD_STRUCTS = None
+
+
+def _head_structs():
+    """ctypes mirrors of dmp_head_weights / dmp_head_io / dmp_head_grads (include/dmp_hip.h), built once."""
+    global _HEAD_STRUCTS
+    if _HEAD_STRUCTS is None:
+        _HEAD_STRUCTS = _make_head_structs()
+    return _HEAD_STRUCTS
+
+
+def _make_head_structs():
+    import ctypes
+    P, I64, F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+    W = type("dmp_head_weights", (ctypes.Structure,), {"_fields_": [(n, P) for n in ("Wp", "bp", "Wg", "bg", "W1", "b1", "W2", "b2")]})
+    IO = type("dmp_head_io", (ctypes.Structure,), {"_fields_": [("ps", P), ("ld_ps", I64), ("gs", P), ("ld_gs", I64), ("pl", P), ("gl", P),
+                                                                ("scale_p", F32), ("scale_g", F32), ("F", P), ("Y1S", P), ("y", P)]})
+    G = type("dmp_head_grads", (ctypes.Structure,), {"_fields_": [("dy", P), ("dy_scale", P), ("dY1", P), ("dP", P), ("dG", P), ("dps", P),
+                                                                  ("ld_dps", I64), ("dgs", P), ("ld_dgs", I64)]
+                                                     + [(n, P) for n in ("dWp", "dbp", "dWg", "dbg", "dW1", "db1", "dW2", "db2")]})
+    return W, IO, G
+
+
+class _PooledHeadsHIP(th.autograd.Function):
+    """All pooled heads of the model and their blend in three HIP launches (csrc/dmp_heads.hip):
+    ``pred = sum_i blend_i * head_i(sums_i[:B], sums_i[B:])``.  Inputs per head: ``sums`` [2B, H] (pattern rows, then
+    target rows: one gradient buffer comes back), ``pl`` / ``gl`` [B, 1], the bias factors, the blend weight [B, 1]
+    (no gradient) and the eight parameters.  H = hidden = 128, ReLU."""
+
+    @staticmethod
+    def forward(ctx, n_heads, *args):
+        from . import _lib
+        lib = _lib.load()
+        Wt, IOt, Gt = _head_structs()
+        per = 6 + 8
+        heads = [args[i * per:(i + 1) * per] for i in range(n_heads)]
+        B = heads[0][0].size(0) // 2
+        dev = heads[0][0].device
+        W, IO = (Wt * n_heads)(), (IOt * n_heads)()
+        keep, ys = [], []
+        for i, (sums, pl, gl, sp, sg, blend, Wp, bp, Wg, bg, W1, b1, W2, b2) in enumerate(heads):
+            sums = sums.contiguous()
+            _lib.require_gpu(sums, Wp)
+            h = Wp.size(0)
+            prm = [t.detach().contiguous() for t in (Wp, bp, Wg, bg, W1, b1, W2, b2)]
+            pl_, gl_ = pl.reshape(-1).contiguous().float(), gl.reshape(-1).contiguous().float()
+            F = th.empty((B, 4 * h + 4), dtype=th.float32, device=dev)
+            Y1S = th.empty((B, h + 4), dtype=th.float32, device=dev)
+            y = th.empty((B, 1), dtype=th.float32, device=dev)
+            for name, t in zip(("Wp", "bp", "Wg", "bg", "W1", "b1", "W2", "b2"), prm):
+                setattr(W[i], name, t.data_ptr())
+            IO[i].ps, IO[i].ld_ps, IO[i].gs, IO[i].ld_gs = sums.data_ptr(), sums.stride(0), sums[B:].data_ptr(), sums.stride(0)
+            IO[i].pl, IO[i].gl, IO[i].scale_p, IO[i].scale_g = pl_.data_ptr(), gl_.data_ptr(), float(sp), float(sg)
+            IO[i].F, IO[i].Y1S, IO[i].y = F.data_ptr(), Y1S.data_ptr(), y.data_ptr()
+            keep.append((sums, pl_, gl_, F, Y1S, blend.reshape(-1).contiguous().float() if blend is not None else None, prm))
+            ys.append(y)
+        _lib.check(lib.dmp_heads_forward(W, IO, n_heads, B, heads[0][6].size(0), _lib.stream_ptr()), "dmp_heads_forward")
+        ctx.keep, ctx.structs, ctx.n, ctx.B, ctx.per = keep, (W, IO), n_heads, B, per
+        out = None
+        for (k, y) in zip(keep, ys):
+            term = y if k[5] is None else y * k[5].view(-1, 1)
+            out = term if out is None else out + term
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        from . import _lib
+        lib = _lib.load()
+        _, _, Gt = _head_structs()
+        W, IO = ctx.structs
+        n, B = ctx.n, ctx.B
+        d = d.contiguous().float()
+        G = (Gt * n)()
+        grads, hold = [None], []
+        for i, (sums, pl_, gl_, F, Y1S, blend, prm) in enumerate(ctx.keep):
+            h = prm[0].size(0)
+            dev = sums.device
+            scr = th.empty((3, B, h), dtype=th.float32, device=dev)
+            dsums = th.empty_like(sums)
+            shapes = [(h, h), (h,), (h, h), (h,), (h, 4 * h + 4), (h,), (1, h + 4), (1,)]
+            sizes = [a[0] * (a[1] if len(a) > 1 else 1) for a in shapes]
+            offs, tot = [], 0
+            for z in sizes:
+                offs.append(tot)
+                tot += (z + 3) // 4 * 4
+            buf = th.empty(tot, dtype=th.float32, device=dev)
+            outs = [buf[o:o + z].view(shp) for o, z, shp in zip(offs, sizes, shapes)]
+            G[i].dy, G[i].dy_scale = d.data_ptr(), (blend.data_ptr() if blend is not None else None)
+            G[i].dY1, G[i].dP, G[i].dG = scr[0].data_ptr(), scr[1].data_ptr(), scr[2].data_ptr()
+            G[i].dps, G[i].ld_dps, G[i].dgs, G[i].ld_dgs = dsums.data_ptr(), dsums.stride(0), dsums[B:].data_ptr(), dsums.stride(0)
+            for name, t in zip(("dWp", "dbp", "dWg", "dbg", "dW1", "db1", "dW2", "db2"), outs):
+                setattr(G[i], name, t.data_ptr())
+            hold.append((scr, buf))
+            grads += [dsums, None, None, None, None, None] + outs
+        _lib.check(lib.dmp_heads_backward(W, IO, G, n, B, ctx.keep[0][6][0].size(0), _lib.stream_ptr()), "dmp_heads_backward")
+        return tuple(grads)
+
+
 class PredictNet(nn.Module):
     def __init__(self, input_dim, hidden_dim, act_func="relu", dropout=0.0, return_weights=False):
         super(PredictNet, self).__init__()
@@ -133,6 +231,15 @@ class PredictNet(nn.Module):
 
     def poolable(self):
         return self.pool_kind is not None and self.weight_fc1 is None and not (self.drop.p > 0.0 and self.training)
+
+    def hip_head_ok(self, sums):
+        """The three-launch HIP heads (``_PooledHeadsHIP``) compute this head: ReLU, width 128, fp32 on the GPU."""
+        return (type(self.act) is nn.ReLU and self.pool_kind == "sum" and self.input_dim == 128 and self.hidden_dim == 128
+                and sums is not None and sums.is_cuda and sums.dtype == th.float32 and sums.dim() == 2 and sums.size(1) == 128)
+
+    def head_params(self):
+        return (self.p_fc.weight, self.p_fc.bias, self.g_fc.weight, self.g_fc.bias, self.pred_fc1.weight, self.pred_fc1.bias,
+                self.pred_fc2.weight, self.pred_fc2.bias)
 
     def forward_pooled(self, p_sum, p_pad_len, pl, g_sum, g_pad_len, gl):
         """p_sum / g_sum [B, D]: sums of the (masked) pattern / graph rows; *_pad_len: padded length L

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 22
+#define DMP_ABI_VERSION 23
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -447,6 +447,33 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
                     void *stream);
 int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *g,
                       const dmp_layer_weight_grads *d, int num_layers, int H, void *stream);
+
+/*
+ * The pooled prediction heads (SubgraphCountingMatching/models/pred.py:93-156 applied to per-graph sums; the node
+ * and the edge head of basemodel.py:1477-1498) for all heads in one launch forward and two backward:
+ *     p = ps Wp^T + scale_p bp;  g = gs Wg^T + scale_g bg;  s = [pl, gl, 1/pl, 1/gl]
+ *     f = [p | g | g - p | g * p | s];  y1 = relu(f W1^T + b1);  y = [y1 | s] W2^T + b2
+ * H = width of ps / gs and of the hidden layer = 128 only.  Weights in nn.Linear layout: Wp, Wg [H,H], W1 [H,4H+4],
+ * W2 [1,H+4]; ps / gs [B, ld >= H]; pl / gl [B] (mask counts); scale_p / scale_g: the factor on the bias (the padded
+ * length for sum pooling).  Forward writes y [B] and keeps F [B,4H+4] = f and Y1S [B,H+4] = [y1 | s] for backward.
+ * Backward: dy [B] (times dy_scale [B] if given: the blend weight of this head) -> dps / dgs [B, ld] (may be NULL),
+ * all weight / bias gradients (fully written), through the scratch dY1, dP, dG [B,H].
+ * The struct arrays are HOST arrays of num_heads <= DMP_HEADS_MAX entries.
+ */
+#define DMP_HEADS_MAX 2
+typedef struct { const float *Wp, *bp, *Wg, *bg, *W1, *b1, *W2, *b2; } dmp_head_weights;
+typedef struct {
+  const float *ps; int64_t ld_ps; const float *gs; int64_t ld_gs; const float *pl, *gl; float scale_p, scale_g;
+  float *F, *Y1S, *y;
+} dmp_head_io;
+typedef struct {
+  const float *dy, *dy_scale; float *dY1, *dP, *dG; float *dps; int64_t ld_dps; float *dgs; int64_t ld_dgs;
+  float *dWp, *dbp, *dWg, *dbg, *dW1, *db1, *dW2, *db2;
+} dmp_head_grads;
+int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H,
+                      void *stream);
+int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g,
+                       int num_heads, int B, int H, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */

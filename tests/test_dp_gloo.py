@@ -85,8 +85,10 @@ def test_flat_grad_allreduce_matches_global_batch():
 def test_flat_buffer_views_and_dedup():
     model = Tiny()
     sync = FlatGradSync(model)
-    n = sum(p.numel() for p in {id(p): p for p in model.parameters()}.values())
-    assert sync.flat.numel() == n          # the aliased module is counted once
+    uniq = list({id(p): p for p in model.parameters()}.values())
+    # the aliased module is counted once; every slice starts on a 16-byte boundary (sizes rounded up to 4 elements)
+    assert sync.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in uniq)
+    assert all(off % 4 == 0 for off in sync.offsets) and len(sync.offsets) == len(uniq)
     model(torch.randn(4, 6)).sum().backward()
     for p in sync.params:
         assert p.grad.data_ptr() >= sync.flat.data_ptr()  # grads are views into the flat buffer

@@ -147,3 +147,45 @@ def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
     want = th.autograd.grad((ref * cot).sum(), wrt)
     for i, (a, b) in enumerate(zip(got, want)):
         assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=1e-4), (i, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("B", [1, 257, 1024])
+@pytest.mark.parametrize("n_heads", [1, 2])
+def test_hip_heads_match_op_by_op(B, n_heads, gpu):
+    """pred._PooledHeadsHIP (all heads + blend: one launch forward, two backward) against the op-by-op algebra:
+    the blended prediction and every input / parameter gradient."""
+    from dualmessagepassing_amd.pred import PRED_NETS, _PooledHeadsHIP
+    th.manual_seed(7 + B)
+    d = h = 128
+    nets = [PRED_NETS["SumPredictNet"](d, h, act_func="relu").to(gpu) for _ in range(n_heads)]
+    gen = th.Generator().manual_seed(8)
+    for net in nets:
+        for p in net.parameters():
+            p.data.normal_(0.0, 0.2)
+    sums = [th.randn(2 * B, d, generator=gen).to(gpu).requires_grad_(True) for _ in range(n_heads)]
+    pls = [th.randint(1, 9, (B, 1), generator=gen).float().to(gpu) for _ in range(n_heads)]
+    gls = [th.randint(1, 65, (B, 1), generator=gen).float().to(gpu) for _ in range(n_heads)]
+    Lp, Lg = 8.0, 64.0
+    blends = [None] if n_heads == 1 else [gls[0] / (gls[0] + gls[1]), gls[1] / (gls[0] + gls[1])]
+    flat = []
+    for i, net in enumerate(nets):
+        flat += [sums[i], pls[i], gls[i], Lp, Lg, blends[i]] + list(net.head_params())
+    y = _PooledHeadsHIP.apply(n_heads, *flat)
+
+    ref = 0.0
+    for i, net in enumerate(nets):
+        ps, gs, pl, gl = sums[i][:B], sums[i][B:], pls[i], gls[i]
+        p = th.nn.functional.linear(ps, net.p_fc.weight) + Lp * net.p_fc.bias
+        g = th.nn.functional.linear(gs, net.g_fc.weight) + Lg * net.g_fc.bias
+        f = th.cat([p, g, g - p, g * p, pl, gl, 1.0 / pl, 1.0 / gl], dim=1)
+        y1 = th.relu(net.pred_fc1(f))
+        yi = net.pred_fc2(th.cat([y1, pl, gl, 1.0 / pl, 1.0 / gl], dim=1))
+        ref = ref + (yi if blends[i] is None else blends[i] * yi)
+    assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-4), (y - ref).abs().max()
+    cot = th.randn(B, 1, generator=gen).to(gpu)
+    wrt = sums + [p for net in nets for p in net.head_params()]
+    got = th.autograd.grad((y * cot).sum(), wrt)
+    want = th.autograd.grad((ref * cot).sum(), wrt)
+    for i, (a, b) in enumerate(zip(got, want)):
+        tol = 1e-4 * max(1.0, float(b.abs().max()))
+        assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=tol), (i, (a - b).abs().max().item())
