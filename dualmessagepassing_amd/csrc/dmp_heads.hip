@@ -32,23 +32,32 @@ struct Heads {
 // a0: first contraction index inside As rows (the operand row holds >= a0 + 128 values at stride 1).
 __device__ __forceinline__ void gemm128(float (&acc)[8], const float *As_row, const float *W, int ldw, int wT, int wcol0,
                                         float *Ws, int tid, int cg) {
+  // the next 32-deep slice of W is requested before the current one is consumed (these kernels are a chain of
+  // L2 round trips otherwise: 16 rows per workgroup leave nothing else to overlap them with)
+  float4 nx[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (wT) nx[m] = ldg4(W + (int64_t)((tid >> 3) + 32 * m) * ldw + wcol0 + k0 + (tid & 7) * 4);
+      else nx[m] = ldg4(W + (int64_t)(k0 + (tid >> 5) + 8 * m) * ldw + wcol0 + (tid & 31) * 4);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < kH; k0 += 32) {
     __syncthreads();
     if (wT) {                                               // Ws[kk][j] = W[j][k0 + kk]
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
-        const float4 w = ldg4(W + (int64_t)j * ldw + wcol0 + k0 + kk4);
-        Ws[(kk4 + 0) * kPad + j] = w.x; Ws[(kk4 + 1) * kPad + j] = w.y;
-        Ws[(kk4 + 2) * kPad + j] = w.z; Ws[(kk4 + 3) * kPad + j] = w.w;
+        Ws[(kk4 + 0) * kPad + j] = nx[m].x; Ws[(kk4 + 1) * kPad + j] = nx[m].y;
+        Ws[(kk4 + 2) * kPad + j] = nx[m].z; Ws[(kk4 + 3) * kPad + j] = nx[m].w;
       }
     } else {                                                // Ws[jj][k] = W[k0 + jj][wcol0 + k]
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
-        *reinterpret_cast<float4 *>(&Ws[row * kPad + c4]) = ldg4(W + (int64_t)(k0 + row) * ldw + wcol0 + c4);
-      }
+      for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<float4 *>(&Ws[((tid >> 5) + 8 * m) * kPad + (tid & 31) * 4]) = nx[m];
     }
+    if (k0 + 32 < kH) fetch(k0 + 32);
     __syncthreads();
 #pragma unroll 8
     for (int kk = 0; kk < 32; ++kk) {
@@ -231,8 +240,8 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_w_k(const WJobs t) {
   const int j0 = (sub / kblocks) * kRows, k0 = (sub % kblocks) * kColW;
   const int tid = threadIdx.x, jr = tid >> 4, cq = tid & 15;
   float acc0 = 0.f, acc1 = 0.f, bsum = 0.f;
-  for (int i0 = 0; i0 < t.B; i0 += kChunk) {
-    __syncthreads();
+  float cn[kChunk / 16], mn[(kChunk * kColW) / kThreads];
+  auto fetch = [&](int i0) {                                // the next chunk's operands are requested a chunk ahead
 #pragma unroll
     for (int m = 0; m < kChunk / 16; ++m) {
       const int i = (tid >> 4) + 16 * m, jj = tid & 15;
@@ -241,13 +250,25 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_w_k(const WJobs t) {
         c = jb.dC[(int64_t)(i0 + i) * jb.ldc + j0 + jj];
         if (jb.row_scale) c *= jb.row_scale[i0 + i];
       }
-      Cs[i * 17 + jj] = c;
+      cn[m] = c;
     }
 #pragma unroll
     for (int m = 0; m < (kChunk * kColW) / kThreads; ++m) {
       const int e = m * kThreads + tid, row = e / kColW, c = e % kColW;
-      Ms[row * (kColW + 4) + c] = (i0 + row < t.B && k0 + c < jb.ncols) ? jb.M[(int64_t)(i0 + row) * jb.ldm + k0 + c] : 0.f;
+      mn[m] = (i0 + row < t.B && k0 + c < jb.ncols) ? jb.M[(int64_t)(i0 + row) * jb.ldm + k0 + c] : 0.f;
     }
+  };
+  fetch(0);
+  for (int i0 = 0; i0 < t.B; i0 += kChunk) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kChunk / 16; ++m) Cs[((tid >> 4) + 16 * m) * 17 + (tid & 15)] = cn[m];
+#pragma unroll
+    for (int m = 0; m < (kChunk * kColW) / kThreads; ++m) {
+      const int e = m * kThreads + tid;
+      Ms[(e / kColW) * (kColW + 4) + e % kColW] = mn[m];
+    }
+    if (i0 + kChunk < t.B) fetch(i0 + kChunk);
     __syncthreads();
     const int lim = t.B - i0 < kChunk ? t.B - i0 : kChunk;
 #pragma unroll 8
