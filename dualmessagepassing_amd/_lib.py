@@ -77,6 +77,8 @@ SIGNATURES = {
     "dmp_atb_typed_blocks": (c_i64, [c_i64]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_rows_blocks": (c_i64, [c_i64, c_int, c_int]),
+    "dmp_atb_jobs_blocks": (c_i64, [c_i64, c_int]),
+    "dmp_atb_rows_jobs": (c_int, [c_ptr, c_int, c_i64, c_ptr]),
     "dmp_atb_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_out_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                   c_i64, c_ptr]),
@@ -97,7 +99,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

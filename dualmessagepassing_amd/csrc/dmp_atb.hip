@@ -40,7 +40,7 @@ struct AtbArgs {
 };
 
 template <bool TYPED>
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
+__device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
   // two tile buffers (Zs | Ds, 2 x 32 x 132 floats each) = 67584 bytes; emit() reuses the first 64 KB for the [128,128] total
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTile = kSub * kLdsStride, kBuf = 2 * kTile;
@@ -49,7 +49,6 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
   const uint32_t colA = (uint32_t)(gtid & 31) * 16u;
   constexpr uint32_t kOOB = 0xFFFFF000u;
-  const int ya = TYPED ? 0 : (int)blockIdx.y / p.nb, yb = TYPED ? 0 : (int)blockIdx.y % p.nb;
   const rsrc_t rs_Z = make_rsrc(p.Z + 128 * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + 128) * 4) : 0u);
   const rsrc_t rs_D = make_rsrc(p.D + 128 * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + 128) * 4) : 0u);
   const bool gated = !TYPED && p.gate != nullptr;
@@ -303,6 +302,19 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
   }
 }
 
+template <bool TYPED>
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
+  atb_body<TYPED>(p, TYPED ? 0 : (int)blockIdx.y / p.nb, TYPED ? 0 : (int)blockIdx.y % p.nb);
+}
+
+// Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
+// job = one 128 x 128 output block with its own operands, gate and partial; the launch's one wave of workgroups
+// is shared by all blocks, so every workgroup gets a long tile range and the per-workgroup costs (pipeline
+// start, LDS reduction, 64 KB partial) are paid 512 times in total instead of 512 times per product.
+constexpr int kMaxAtbJobs = DMP_ATB_MAX_JOBS;
+struct AtbJobs { AtbArgs job[kMaxAtbJobs]; };
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<false>(t.job[blockIdx.y], 0, 0); }
+
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
 template <bool TYPED>
 bool lds_ready() {
@@ -357,6 +369,32 @@ static unsigned rows_blocks(int64_t rows, int M, int N) {
 }
 
 int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N) { return (int64_t)rows_blocks(rows, M, N); }
+
+int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs) { return (int64_t)rows_blocks(rows, 128, 128 * (num_jobs > 0 ? num_jobs : 1)); }
+
+int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream) {
+  if (rows < 0 || num_jobs < 1 || num_jobs > kMaxAtbJobs || !jobs) return DMP_ERR_BAD_ARG;
+  AtbJobs t;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_atb_job &j = jobs[i];
+    if (!j.partial || (rows > 0 && (!j.A || !j.B || j.lda < 128 || j.ldb < 128)) || j.ldp < 128) return DMP_ERR_BAD_ARG;
+    if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial) ||
+        (j.partial_colsum && !aligned16(j.partial_colsum)))
+      return DMP_ERR_UNSUPPORTED;
+    if (!fits32(rows, j.lda) || !fits32(rows, j.ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+    AtbArgs a{};
+    a.Z = j.A; a.ldz = j.lda; a.D = j.B; a.ldd = j.ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
+    a.gate = j.gate; a.pT = j.partial; a.pstride = j.partial_stride; a.ldp = j.ldp; a.pCS = j.partial_colsum;
+    a.nb = 1; a.cs_ld = j.cs_ld;
+    t.job[i] = a;
+  }
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_jobs_k),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAtbLdsBytes);
+  if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
+  const dim3 grid((unsigned)dmp_atb_jobs_blocks(rows, num_jobs), (unsigned)num_jobs);
+  atb_jobs_k<<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(t);
+  return check_launch();
+}
 
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
                  float *partial, float *partial_colsum, void *stream) {

@@ -331,6 +331,49 @@ def smallk_atb(x, d, gate=None):
     return reduce_partials(part).view(K, H)
 
 
+_ATB_JOB = None
+MAX_ATB_JOBS = 8
+
+
+def atb_rows_multi(products):
+    """Several ``atb_rows`` products over the SAME rows in ONE launch: ``products`` = list of ``(a, b, gate, colsum)``
+    (a [R, 128 ma], b [R, 128 nb]); returns a list of ``(a^T b  [128 ma, 128 nb], column sums or None)``.  The launch's
+    workgroups are shared by all 128 x 128 output blocks, so short inputs (the node side: R = nodes) get long
+    tile ranges per workgroup instead of paying every workgroup's fixed costs once per product."""
+    global _ATB_JOB
+    import ctypes
+    lib = _lib.load()
+    if _ATB_JOB is None:
+        P, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        _ATB_JOB = type("dmp_atb_job", (ctypes.Structure,), {"_fields_": [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("gate", P), ("partial", P),
+                                                                          ("partial_stride", I64), ("ldp", I), ("partial_colsum", P), ("cs_ld", I)]})
+    R = products[0][0].size(0)
+    nblk = sum((a.size(1) // 128) * (b.size(1) // 128) for a, b, _, _ in products)
+    if nblk > MAX_ATB_JOBS:
+        raise ValueError("atb_rows_multi: more than %d output blocks" % MAX_ATB_JOBS)
+    G = int(lib.dmp_atb_jobs_blocks(R, nblk))
+    jobs = (_ATB_JOB * nblk)()
+    parts, k = [], 0
+    for a, b, gate, colsum in products:
+        M, N = a.size(1), b.size(1)
+        part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
+        part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
+        parts.append((part, part_cs, M, N))
+        for ia in range(M // 128):
+            for ib in range(N // 128):
+                j = jobs[k]
+                j.A, j.lda, j.B, j.ldb = a.data_ptr() + 512 * ia, a.stride(0), b.data_ptr() + 512 * ib, b.stride(0)
+                j.gate = ptr(gate)
+                j.partial, j.partial_stride, j.ldp = part.data_ptr() + 4 * (ia * 128 * N + ib * 128), M * N, N
+                j.partial_colsum = (part_cs.data_ptr() + 512 * ia) if (colsum and ib == 0) else None
+                j.cs_ld = M
+                k += 1
+    with _lib.timed("atb_rows_multi[blocks=%d,R=%d]", (nblk, R), 0):
+        check(lib.dmp_atb_rows_jobs(jobs, nblk, R, stream_ptr()), "dmp_atb_rows_jobs")
+    return [(reduce_partials(part).view(M, N), (reduce_partials(part_cs) if part_cs is not None else None))
+            for part, part_cs, M, N in parts]
+
+
 def atb_ok(a, b):
     """The MFMA weight-gradient kernel takes this product (else: ``atb``, batched library GEMMs)."""
     return (a.is_cuda and a.dtype == torch.float32 and a.size(1) % 128 == 0 and b.size(1) % 128 == 0 and a.size(0) >= 4096
@@ -526,9 +569,11 @@ class _FusedDMPLayer(torch.autograd.Function):
             dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
+            one_launch = H == 128 and atb_ok(dxn, H1n) and atb_ok(x, dXP) and atb_ok(S, dXP)
             if H == 128 and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
-                dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
+                if not one_launch:
+                    dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
                 dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H])
             else:
                 dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
@@ -536,8 +581,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dH1n = dOn @ nW2
                 dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
             dS = dPn @ Bn.t()
-            dBn = wg(S, dPn)                                             # [2H,H]
-            dWx = wg(x, dXP)                                             # [H,3H] = [dA_n | dPd | dPs]
+            if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
+                (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (S, dPn, None, False),
+                                                                    (x, dXP, None, False)])
+            else:
+                dBn = wg(S, dPn)                                         # [2H,H]
+                dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]
             dx = None
             if ctx.needs_input_grad[3]:
                 dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()

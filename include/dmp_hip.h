@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 23
+#define DMP_ABI_VERSION 24
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -595,6 +595,19 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
 int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N);
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
                  int64_t rows, int M, int N, float *partial, float *partial_colsum, void *stream);
+
+/* Several such products over the SAME rows in one launch (the node update's three weight gradients): every job is
+ * one 128 x 128 output block  partial[b] = (gate (.) A[:, 0:128])^T B[:, 0:128]  (callers pass column-offset
+ * pointers for the blocks of a wider product), written at partial + b * partial_stride with row stride ldp;
+ * partial_colsum + b * cs_ld (or NULL) gets the column sums of gate (.) A.  b < dmp_atb_jobs_blocks(rows, num_jobs):
+ * the launch's workgroups are shared by all jobs.  `jobs` is a HOST array of num_jobs <= DMP_ATB_MAX_JOBS entries. */
+#define DMP_ATB_MAX_JOBS 8
+typedef struct {
+  const float *A; int64_t lda; const float *B; int64_t ldb; const float *gate;
+  float *partial; int64_t partial_stride; int ldp; float *partial_colsum; int cs_ld;
+} dmp_atb_job;
+int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs);
+int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream);
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup

@@ -669,3 +669,27 @@ def test_gate_concat_from_label_encodings(rows, k, gpu):
     g2 = emb(enc) + 1.0
     assert getattr(g2, "_dmp_src", None) is None
     assert th.allclose(dmpnn._gate_concat(p, g2, gate), th.cat([p, gate * g2], 0), rtol=1e-6, atol=1e-6)
+
+
+def test_weight_gradients_sharing_one_launch(gpu):
+    """fused.atb_rows_multi: three products over the same rows (gated [R,128]^T [R,128] with column sums, [R,256]^T
+    [R,128], [R,128]^T [R,384]: six output blocks) from one launch -- the bits of the one-product launches differ
+    only through the tile ranges, so compare against fp64."""
+    from dualmessagepassing_amd import fused
+    h, rows = 128, 70001
+    gen = th.Generator().manual_seed(77)
+    dx = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = th.randn(rows, h, generator=gen).to(gpu)
+    S = th.randn(rows, 2 * h, generator=gen).to(gpu)
+    dXP = th.randn(rows, 3 * h, generator=gen).to(gpu)
+    x = th.randn(rows, h, generator=gen).to(gpu)
+    gate = (th.rand(rows, generator=gen) > 0.3).float().to(gpu)
+    (a, cs), (b, n1), (c, n2) = fused.atb_rows_multi([(dx, h1, gate, True), (S, dXP[:, :h], None, False), (x, dXP, None, False)])
+    assert n1 is None and n2 is None
+    tol = 1e-4 * rows ** 0.5
+    gd = dx.double() * gate.double()[:, None]
+    assert th.allclose(a, (gd.t() @ h1.double()).float(), rtol=1e-5, atol=tol) and th.allclose(cs, gd.sum(0).float(), rtol=1e-5, atol=tol)
+    assert b.shape == (2 * h, h) and th.allclose(b, (S.double().t() @ dXP[:, :h].double()).float(), rtol=1e-5, atol=tol)
+    assert c.shape == (h, 3 * h) and th.allclose(c, (x.double().t() @ dXP.double()).float(), rtol=1e-5, atol=tol)
+    again = fused.atb_rows_multi([(dx, h1, gate, True), (S, dXP[:, :h], None, False), (x, dXP, None, False)])
+    assert th.equal(a, again[0][0]) and th.equal(b, again[1][0]) and th.equal(c, again[2][0])
