@@ -29,11 +29,11 @@ __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cas
 //   wT = 1: out[i, j] = sum_k a[i, k] W[j, k]   (C = M W0^T: W0 in nn.Linear layout [out, in])
 //   wT = 0: out[i, k] = sum_j a[i, j] W[j, k]   (dM = dC W0)
 struct RowJob {
-  const float *A; const float *A2; const float *W; const float *addv; float *out;
+  const float *A; const float *A2; const float *W; const float *Wsub; const float *addv; float *out;
   int lda, lda2, ldo, rows, wT;
   float s2;
 };
-constexpr int kMaxRowJobs = 27;
+constexpr int kMaxRowJobs = 13 * DMP_FOLD_MAX_LAYERS;   // fold: 9 + 4 optional transposes per layer; unfold: 8
 struct RowJobs { RowJob job[kMaxRowJobs]; int blk0[kMaxRowJobs + 1]; int n; };
 
 __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
@@ -67,7 +67,11 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
-        const float4 w = ldg4(jb.W + j * kH + k0 + kk4);
+        float4 w = ldg4(jb.W + j * kH + k0 + kk4);
+        if (jb.Wsub) {
+          const float4 u = ldg4(jb.Wsub + j * kH + k0 + kk4);
+          w.x -= u.x; w.y -= u.y; w.z -= u.z; w.w -= u.w;
+        }
         Ws[(kk4 + 0) * kPad + j] = w.x; Ws[(kk4 + 1) * kPad + j] = w.y;
         Ws[(kk4 + 2) * kPad + j] = w.z; Ws[(kk4 + 3) * kPad + j] = w.w;
       }
@@ -153,8 +157,9 @@ __global__ __launch_bounds__(kThreads) void coljob_k(const ColJobs t) {
 }
 
 inline void add_row_job(RowJobs &t, int &blocks, const float *A, int lda, const float *A2, int lda2, float s2, const float *W,
-                        int wT, float *out, int ldo, const float *addv, int rows) {
+                        int wT, float *out, int ldo, const float *addv, int rows, const float *Wsub = nullptr) {
   RowJob &j = t.job[t.n];
+  j.Wsub = Wsub;
   j.A = A; j.lda = lda; j.A2 = A2; j.lda2 = lda2; j.s2 = s2; j.W = W; j.wT = wT; j.out = out; j.ldo = ldo; j.addv = addv;
   j.rows = rows;
   t.blk0[t.n] = blocks;
@@ -189,6 +194,10 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
       if (!all16({a.nloop_w, a.in_w, a.out_w, a.nbias, a.eloop_w, a.src_w, a.dst_w, a.ebias, a.nW0, a.nb0, a.eW0, a.eb0, o.Bn,
                   o.bn, o.Wx, o.Wes, o.be}))
         return DMP_ERR_BAD_ARG;
+      if (t.n + 13 > kMaxRowJobs) return DMP_ERR_BAD_ARG;      // 9 + 4 jobs per layer below
+      for (const void *q : {(const void *)a.nW2, (const void *)a.eW2, (const void *)a.eye, (const void *)o.WesT, (const void *)o.nW2t,
+                            (const void *)o.eW2t})
+        if (q && (reinterpret_cast<uintptr_t>(q) & 15u)) return DMP_ERR_BAD_ARG;
       // node side: Cn = [W_loop; W_in; W_out; nbias] W0n^T -> Wx[:, 0:H], Bn[0:H], Bn[H:2H], bn (+ nb0)
       add_row_job(t, blocks, a.nloop_w, kH, nullptr, 0, 0.f, a.nW0, 1, o.Wx, 3 * kH, nullptr, kH);
       add_row_job(t, blocks, a.in_w, kH, nullptr, 0, 0.f, a.nW0, 1, o.Bn, kH, nullptr, kH);
@@ -200,6 +209,14 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
       add_row_job(t, blocks, a.dst_w, kH, nullptr, 0, 0.f, a.eW0, 1, o.Wx + kH, 3 * kH, nullptr, kH);
       add_row_job(t, blocks, a.src_w, kH, nullptr, 0, 0.f, a.eW0, 1, o.Wx + 2 * kH, 3 * kH, nullptr, kH);
       add_row_job(t, blocks, a.ebias, kH, nullptr, 0, 0.f, a.eW0, 1, o.be, kH, a.eb0, 1);
+      // the transposed copies the backward / second-Linear kernels read their (coalesced) weight panels from:
+      // WesT = [A'^T | B'^T] with A'^T = W0e W_eloop^T, B'^T = W0e (W_src - W_dst)^T;  W2^T = I W2^T
+      if (o.WesT) {
+        add_row_job(t, blocks, a.eW0, kH, nullptr, 0, 0.f, a.eloop_w, 1, o.WesT, 2 * kH, nullptr, kH);
+        add_row_job(t, blocks, a.eW0, kH, nullptr, 0, 0.f, a.src_w, 1, o.WesT + kH, 2 * kH, nullptr, kH, a.dst_w);
+      }
+      if (o.nW2t && a.nW2 && a.eye) add_row_job(t, blocks, a.eye, kH, nullptr, 0, 0.f, a.nW2, 1, o.nW2t, kH, nullptr, kH);
+      if (o.eW2t && a.eW2 && a.eye) add_row_job(t, blocks, a.eye, kH, nullptr, 0, 0.f, a.eW2, 1, o.eW2t, kH, nullptr, kH);
     }
     rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
     const int rc = check_launch();
@@ -225,6 +242,7 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
       if (!all16({a.nloop_w, a.in_w, a.out_w, a.nbias, a.eloop_w, a.src_w, a.dst_w, a.ebias, a.nW0, a.eW0, u.dBn, u.dbn, u.dWx,
                   u.dWes, u.dbe, o.nloop_w, o.in_w, o.out_w, o.nbias, o.eloop_w, o.src_w, o.dst_w, o.ebias, o.nW0, o.eW0}))
         return DMP_ERR_BAD_ARG;
+      if (t.n + 8 > kMaxRowJobs || c.n + 2 > kMaxColJobs) return DMP_ERR_BAD_ARG;
       // dM = dC W0; the rows of d(W_src - W_dst) = dWes[:, H:2H] W0e enter d_dst with -, d_src with +
       add_row_job(t, blocks, u.dWx, 3 * kH, nullptr, 0, 0.f, a.nW0, 0, o.nloop_w, kH, nullptr, kH);
       add_row_job(t, blocks, u.dBn, kH, nullptr, 0, 0.f, a.nW0, 0, o.in_w, kH, nullptr, kH);

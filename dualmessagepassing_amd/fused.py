@@ -233,14 +233,16 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index):
     return out
 
 
-def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index):
-    """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre)."""
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None):
+    """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
+    ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch)."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
     out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
-    # [A'^T | B'^T]: the kernel's per-class panel reads become coalesced (one tiny launch here instead of a
-    # strided 128-instruction panel read per class segment in each of its 768 workgroups)
-    WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
+    # [A'^T | B'^T]: the kernel's per-class panel reads become coalesced (instead of a strided 128-instruction
+    # panel read per class segment in each of its 768 workgroups)
+    if WesT is None:
+        WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
     d_s = d_s.contiguous()
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
@@ -266,12 +268,14 @@ def atb_typed(z, d_pre, coef, index):
     return reduce_partials(part.view(G, -1)).view(H, 2 * H)
 
 
-def out_fwd_mfma(h1, W2, b2, gate, prev):
-    """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128)."""
+def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
+    """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128).
+    ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch)."""
     lib = _lib.load()
     R, H = h1.shape
     out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
-    W2t = W2.t().contiguous()     # [in, out]: coalesced weight-panel reads in each of the kernel's workgroups
+    if W2t is None:
+        W2t = W2.t().contiguous() # [in, out]: coalesced weight-panel reads in each of the kernel's workgroups
     with _lib.timed("out_fwd_mfma[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
         check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H, 1,
                                     ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
@@ -398,7 +402,9 @@ def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):
 
 # ----------------------------------------------------------------------------- parameter algebra (fold / unfold)
 _FOLD_IN = ("nloop_w", "in_w", "out_w", "nbias", "eloop_w", "src_w", "dst_w", "ebias", "nW0", "nb0", "eW0", "eb0")
+_FOLD_AUX_IN = ("nW2", "eW2", "eye")          # forward only: no gradient flows through the transposed copies
 _FOLD_OUT = ("Bn", "bn", "Wx", "Wes", "be")
+_FOLD_AUX_OUT = ("WesT", "nW2t", "eW2t")
 _FOLD_GRAD = ("nloop_w", "in_w", "out_w", "nbias", "eloop_w", "src_w", "dst_w", "ebias", "nW0", "eW0")
 
 
@@ -407,8 +413,8 @@ def _struct(name, fields):
     return type(name, (ctypes.Structure,), {"_fields_": [(f, ctypes.c_void_p) for f in fields]})
 
 
-_LayerWeights = _struct("dmp_layer_weights", _FOLD_IN)
-_LayerFolded = _struct("dmp_layer_folded", _FOLD_OUT)
+_LayerWeights = _struct("dmp_layer_weights", _FOLD_IN + _FOLD_AUX_IN)
+_LayerFolded = _struct("dmp_layer_folded", _FOLD_OUT + _FOLD_AUX_OUT)
 _LayerFoldedGrads = _struct("dmp_layer_folded_grads", ["d" + f for f in _FOLD_OUT])
 _LayerWeightGrads = _struct("dmp_layer_weight_grads", _FOLD_GRAD)
 
@@ -424,6 +430,9 @@ def _carve(buf, shapes):
     return out
 
 
+_EYE = {}
+
+
 class _FoldLayers(torch.autograd.Function):
     """The first MLP Linear of every layer folded into its projections (see include/dmp_hip.h,
     ``dmp_fold_layers``): one launch forward, two backward, for all layers -- instead of a dozen small
@@ -431,24 +440,32 @@ class _FoldLayers(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, L, *params):
+        # per layer: the 12 folded inputs + the two second Linears (nW2, eW2: only their transposes are made here)
         lib = _lib.load()
         params = [p.detach().contiguous() for p in params]
         _lib.require_gpu(*params)
         H = params[0].size(1)
-        shapes = [(2 * H, H), (H,), (H, 3 * H), (H, 2 * H), (H,)]
+        dev = params[0].device
+        eye = _EYE.get((dev.index, H))
+        if eye is None:
+            eye = _EYE[(dev.index, H)] = torch.eye(H, dtype=torch.float32, device=dev)
+        shapes = [(2 * H, H), (H,), (H, 3 * H), (H, 2 * H), (H,), (H, 2 * H), (H, H), (H, H)]
         per = sum(a[0] * (a[1] if len(a) > 1 else 1) for a in shapes)
-        buf = torch.empty(L * per, dtype=torch.float32, device=params[0].device)
-        W, F, outs = (_LayerWeights * L)(), (_LayerFolded * L)(), []
+        buf = torch.empty(L * per, dtype=torch.float32, device=dev)
+        W, F, outs, aux = (_LayerWeights * L)(), (_LayerFolded * L)(), [], []
         for l in range(L):
-            for name, t in zip(_FOLD_IN, params[12 * l:12 * l + 12]):
+            pl = params[14 * l:14 * l + 14]
+            for name, t in zip(_FOLD_IN + _FOLD_AUX_IN, pl + [eye]):
                 setattr(W[l], name, ptr(t))
             views = _carve(buf[l * per:(l + 1) * per], shapes)
-            for name, t in zip(_FOLD_OUT, views):
+            for name, t in zip(_FOLD_OUT + _FOLD_AUX_OUT, views):
                 setattr(F[l], name, ptr(t))
             outs += views
+            aux += views[5:]
         check(lib.dmp_fold_layers(W, F, L, H, stream_ptr()), "dmp_fold_layers")
         ctx.save_for_backward(*params)
         ctx.L, ctx.H, ctx.weights = L, H, W
+        ctx.mark_non_differentiable(*aux)
         return tuple(outs)
 
     @staticmethod
@@ -464,7 +481,7 @@ class _FoldLayers(torch.autograd.Function):
         fshapes = [(2 * H, H), (H,), (H, 3 * H), (H, 2 * H), (H,)]
         for l in range(L):
             gl = []
-            for g, shp, name in zip(grads[5 * l:5 * l + 5], fshapes, _FOLD_OUT):
+            for g, shp, name in zip(grads[8 * l:8 * l + 5], fshapes, _FOLD_OUT):
                 g = torch.zeros(shp, dtype=torch.float32, device=buf.device) if g is None else g.contiguous()
                 setattr(G[l], "d" + name, ptr(g))
                 gl.append(g)
@@ -473,7 +490,7 @@ class _FoldLayers(torch.autograd.Function):
             for name, t in zip(_FOLD_GRAD, d):
                 setattr(D[l], name, ptr(t))
             # order of the inputs: nloop, in, out, nbias, eloop, src, dst, ebias, nW0, nb0 (= dbn), eW0, eb0 (= dbe)
-            out += d[:9] + [gl[1], d[9], gl[4]]
+            out += d[:9] + [gl[1], d[9], gl[4], None, None]          # + nW2, eW2: nothing flows back through the transposes
         check(lib.dmp_unfold_layers(ctx.weights, G, D, L, H, stream_ptr()), "dmp_unfold_layers")
         return tuple(out)
 
@@ -484,21 +501,30 @@ def _layer_params(layer):
             layer.dst_weight, layer.ebias, n0.weight, n0.bias, e0.weight, e0.bias)
 
 
+def _layer_aux_params(layer):
+    return (layer.nmlp[2].weight, layer.emlp[2].weight)
+
+
 def fold_layers(layers):
-    """-> one ``(Bn, bn, Wx, Wes, be)`` per layer.  H = 128 on the GPU: one HIP launch for all layers (and two
-    for their backward); otherwise the same algebra in differentiable torch ops."""
+    """-> one ``(Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t)`` per layer (the last three: transposed copies without
+    gradient, the layouts the kernels read coalesced).  H = 128 on the GPU: one HIP launch for all layers (and two for
+    their backward); otherwise the same algebra in differentiable torch ops."""
     layers = list(layers)
     H = layers[0].nloop_weight.size(1)
     if H == 128 and layers[0].nloop_weight.is_cuda and all(l.nloop_weight.size(1) == H for l in layers):
-        flat = _FoldLayers.apply(len(layers), *[p for l in layers for p in _layer_params(l)])
-        return [tuple(flat[5 * i:5 * i + 5]) for i in range(len(layers))]
+        flat = _FoldLayers.apply(len(layers), *[p for l in layers for p in _layer_params(l) + _layer_aux_params(l)])
+        return [tuple(flat[8 * i:8 * i + 8]) for i in range(len(layers))]
     out = []
     for l in layers:
         nloop, in_w, out_w, nbias, eloop, src_w, dst_w, ebias, nW0, nb0, eW0, eb0 = _layer_params(l)
         Cn = torch.cat([nloop, in_w, out_w, nbias.unsqueeze(0)], dim=0) @ nW0.t()               # [3H+1, H]
         Ce = torch.cat([eloop, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], dim=0) @ eW0.t()  # [4H+1, H]
+        Wes = torch.cat([Ce[:H], Ce[H:2 * H]], dim=1)
+        nW2, eW2 = _layer_aux_params(l)
+        with torch.no_grad():
+            aux = (torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1), nW2.t().contiguous(), eW2.t().contiguous())
         out.append((Cn[H:3 * H], Cn[3 * H] + nb0, torch.cat([Cn[:H], Ce[2 * H:3 * H], Ce[3 * H:4 * H]], dim=1),
-                    torch.cat([Ce[:H], Ce[H:2 * H]], dim=1), Ce[4 * H] + eb0))
+                    Wes, Ce[4 * H] + eb0) + aux)
     return out
 
 
@@ -506,7 +532,8 @@ class _FusedDMPLayer(torch.autograd.Function):
     """One DMPNN layer + gate + residual over the folded weights of ``fold_layers``."""
 
     @staticmethod
-    def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2):
+    def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
+                WesT=None, nW2t=None, eW2t=None):
         _lib.require_gpu(x, z)
         H = Bn.size(1)
         x, z = x.contiguous(), z.contiguous()
@@ -517,16 +544,16 @@ class _FusedDMPLayer(torch.autograd.Function):
         XP = x @ Wx
         H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn)
         if H == 128:   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
-            xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None)
+            xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None, nW2t)
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
         if typed_ok(index, H):
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index)
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         elif mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index)
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None)
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         else:
             G = z @ Wes
             H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True)
@@ -534,7 +561,7 @@ class _FusedDMPLayer(torch.autograd.Function):
             Oe = torch.addmm(eb2, H1e, eW2.t())
             zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
-        ctx.v_gate, ctx.e_gate = v_gate, e_gate
+        ctx.v_gate, ctx.e_gate, ctx.WesT = v_gate, e_gate, WesT
         ctx.save_for_backward(x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
         return xn, zn
 
@@ -595,19 +622,19 @@ class _FusedDMPLayer(torch.autograd.Function):
             if ctx.needs_input_grad[4]:
                 if mfma:
                     if typed:
-                        dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix)
+                        dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT)
                     else:
                         dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
-        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e)
+        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None)
 
 
 def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None):
     """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch)."""
     n2, e2 = layer.nmlp[2], layer.emlp[2]
-    Bn, bn, Wx, Wes, be = folded if folded is not None else fold_layers([layer])[0]
+    Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t = folded if folded is not None else fold_layers([layer])[0]
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
-                                n2.weight, n2.bias, e2.weight, e2.bias)
+                                n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 24
+#define DMP_ABI_VERSION 25
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -439,8 +439,13 @@ int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_a
 #define DMP_FOLD_MAX_LAYERS 3   /* layers per launch; more are split over launches */
 typedef struct {
   const float *nloop_w, *in_w, *out_w, *nbias, *eloop_w, *src_w, *dst_w, *ebias, *nW0, *nb0, *eW0, *eb0;
+  const float *nW2, *eW2, *eye;   /* optional (forward only): the second Linears [H,H] and an [H,H] identity matrix */
 } dmp_layer_weights;
-typedef struct { float *Bn, *bn, *Wx, *Wes, *be; } dmp_layer_folded;
+typedef struct {
+  float *Bn, *bn, *Wx, *Wes, *be;
+  float *WesT, *nW2t, *eW2t;      /* optional outputs (NULL to skip): [A'^T | B'^T] [H,2H] and the transposed second Linears
+                                     [in,out] -- the layouts dmp_bwd_z_typed / dmp_out_fwd_fused read coalesced */
+} dmp_layer_folded;
 typedef struct { const float *dBn, *dbn, *dWx, *dWes, *dbe; } dmp_layer_folded_grads;
 typedef struct { float *nloop_w, *in_w, *out_w, *nbias, *eloop_w, *src_w, *dst_w, *ebias, *nW0, *eW0; } dmp_layer_weight_grads;
 int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int num_layers, int H,

@@ -596,7 +596,7 @@ def test_fold_layers_matches_torch_algebra(num_layers, gpu):
     from dualmessagepassing_amd.dmpnn import DMPLayer
     th.manual_seed(num_layers)
     h = 128
-    layers = [DMPLayer(h, h, num_mlp_layers=2).to(gpu) for _ in range(num_layers)]
+    layers = [DMPLayer(h, h, num_mlp_layers=2, batch_norm=False).to(gpu) for _ in range(num_layers)]   # Linear-ReLU-Linear MLPs: the fused path
     for l in layers:
         for p in l.parameters():
             p.data.normal_(0.0, 0.3)
@@ -607,12 +607,17 @@ def test_fold_layers_matches_torch_algebra(num_layers, gpu):
         nloop, in_w, out_w, nbias, eloop, src_w, dst_w, ebias, nW0, nb0, eW0, eb0 = fused._layer_params(l)
         Cn = th.cat([nloop, in_w, out_w, nbias.unsqueeze(0)], 0) @ nW0.t()
         Ce = th.cat([eloop, src_w - dst_w, dst_w, src_w, ebias.unsqueeze(0)], 0) @ eW0.t()
+        wes = th.cat([Ce[:h], Ce[h:2 * h]], 1)
         want.append((Cn[h:3 * h], Cn[3 * h] + nb0, th.cat([Cn[:h], Ce[2 * h:3 * h], Ce[3 * h:4 * h]], 1),
-                     th.cat([Ce[:h], Ce[h:2 * h]], 1), Ce[4 * h] + eb0))
+                     wes, Ce[4 * h] + eb0))
+        # the transposed copies (no gradient): [A'^T | B'^T] and the second Linears' transposes
+        f = got[len(want) - 1]
+        assert th.allclose(f[5], th.cat([wes[:, :h].t(), wes[:, h:].t()], 1), rtol=1e-5, atol=1e-5) and not f[5].requires_grad
+        assert th.equal(f[6], l.nmlp[2].weight.t()) and th.equal(f[7], l.emlp[2].weight.t())
     gen = th.Generator().manual_seed(5)
     loss_g = loss_w = 0.0
     for fg, fw in zip(got, want):
-        for a, b in zip(fg, fw):
+        for a, b in zip(fg[:5], fw):
             assert a.shape == b.shape and th.allclose(a, b, rtol=1e-5, atol=1e-5), (a - b).abs().max()
             cot = th.randn(a.shape, generator=gen).to(gpu)
             loss_g = loss_g + (a * cot).sum()
