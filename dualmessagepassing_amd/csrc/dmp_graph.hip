@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void csr_fill(const int64_t *__restrict__ k
 // Restore ascending eid inside each row (the atomic fill arrives almost sorted,
 // so insertion sort is near linear); rows longer than kHeapFrom use heap sort.
 constexpr int kHeapFrom = 96;
+constexpr int kRegSort = 32;
 __device__ void sift_down(int32_t *a, int start, int end) {
   int root = start;
   while (2 * root + 1 <= end) {
@@ -159,7 +160,32 @@ __global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restric
   const int n = end - beg;
   if (degree) degree[r] = n;
   int32_t *a = ent + beg;
-  if (n <= kHeapFrom) {
+  if (n <= kRegSort) {
+    // Short rows (the common case): one batch of loads, a bitonic network in
+    // registers, one batch of stores -- no dependent global round trips.
+    int32_t v[kRegSort];
+#pragma unroll
+    for (int i = 0; i < kRegSort; ++i) v[i] = i < n ? a[i] : INT32_MAX;
+#pragma unroll
+    for (int k = 2; k <= kRegSort; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < kRegSort; ++i) {
+          const int l = i ^ j;
+          if (l > i) {
+            const int32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+            const bool up = (i & k) == 0;
+            v[i] = up ? lo : hi;
+            v[l] = up ? hi : lo;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kRegSort; ++i)
+      if (i < n) a[i] = v[i];
+  } else if (n <= kHeapFrom) {
     for (int i = 1; i < n; ++i) {
       const int32_t x = a[i];
       int j = i - 1;
