@@ -466,6 +466,7 @@ class _FoldLayers(torch.autograd.Function):
         ctx.save_for_backward(*params)
         ctx.L, ctx.H, ctx.weights = L, H, W
         ctx.mark_non_differentiable(*aux)
+        ctx.set_materialize_grads(False)   # no zero tensors for the (non-differentiable) transposed copies
         return tuple(outs)
 
     @staticmethod

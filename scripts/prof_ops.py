@@ -22,5 +22,9 @@ for e in prof.key_averages(group_by_input_shape=True):
     if dt > 0:
         rows.append((dt / STEPS, e.count / STEPS, e.key, str(e.input_shapes)[:150]))
 rows.sort(reverse=True)
+import re
+flt = os.environ.get("FILTER")
+if flt:
+    rows = [r for r in rows if re.search(flt, r[2])]
 for dt, c, k, s in rows[:int(os.environ.get("TOP", "90"))]:
     print("%8.1f us/step %5.1f/step  %-45s %s" % (dt, c, k[:45], s))
