@@ -214,6 +214,28 @@ struct AdamArgs {
   float decay, beta1_c, beta2, beta2_c, step_size, inv_bc2_sqrt, eps;
 };
 
+struct PackSegs {
+  const float *src[DMP_PACK_MAX_SEGMENTS];
+  int64_t off[DMP_PACK_MAX_SEGMENTS];
+  int64_t len[DMP_PACK_MAX_SEGMENTS];
+};
+
+// blockIdx.y = segment, blockIdx.x strides over it in float4 steps (scalar loads for unaligned sources and tails)
+__global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a, float *__restrict__ dst) {
+  const int s = blockIdx.y;
+  const float *__restrict__ src = a.src[s];
+  float *__restrict__ out = dst + a.off[s];
+  const int64_t n = a.len[s];
+  const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * kBlock * 4) {
+    if (vec && i + 4 <= n) {
+      *reinterpret_cast<float4 *>(out + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+      for (int64_t j = i; j < n && j < i + 4; ++j) out[j] = src[j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
   const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < a.n; i += stride) {
@@ -557,6 +579,34 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
   a.n = n;
   reduce_partials_multi_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(a);
   return check_launch();
+}
+
+int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, float *dst,
+                      void *stream) {
+  DMP_ROW_CHECK(n >= 0);
+  if (n == 0) return DMP_OK;
+  DMP_ROW_CHECK(src && dst_off && len && dst);
+  if (!ok16(dst)) return DMP_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    DMP_ROW_CHECK(len[i] >= 0 && dst_off[i] >= 0 && (len[i] == 0 || src[i]));
+    if (dst_off[i] % 4) return DMP_ERR_UNSUPPORTED;
+  }
+  for (int base = 0; base < n; base += DMP_PACK_MAX_SEGMENTS) {
+    const int cnt = n - base < DMP_PACK_MAX_SEGMENTS ? n - base : DMP_PACK_MAX_SEGMENTS;
+    PackSegs a;
+    int64_t longest = 0;
+    for (int i = 0; i < cnt; ++i) {
+      a.src[i] = src[base + i]; a.off[i] = dst_off[base + i]; a.len[i] = len[base + i];
+      if (a.len[i] > longest) longest = a.len[i];
+    }
+    if (longest == 0) continue;
+    int64_t nb = (longest + 4 * kBlock - 1) / (4 * kBlock);
+    if (nb > 64) nb = 64;
+    pack_segments_kernel<<<dim3((unsigned)nb, (unsigned)cnt), kBlock, 0, (hipStream_t)stream>>>(a, dst);
+    const int rc = check_launch();
+    if (rc != DMP_OK) return rc;
+  }
+  return DMP_OK;
 }
 
 int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,

@@ -91,19 +91,40 @@ class FlatGradSync:
         if views is None:                                    # the slices never change: built once
             views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
             self._views = views
-        dst, src, missing = [], [], False
-        for p, v in zip(self.params, views):
+        dst, src, which, missing = [], [], [], False
+        for i, (p, v) in enumerate(zip(self.params, views)):
             g = p.grad
             if g is None:
                 missing = True
             elif g is not v:
                 dst.append(v)
                 src.append(g)
+                which.append(i)
             p.grad = v
         if missing:                                          # parameters without a gradient this step keep zeros
             self.flat.zero_()
-        if dst:
+        if not dst:
+            return
+        if self.flat.is_cuda and self.flat.dtype == torch.float32 and all(g.dtype == torch.float32 for g in src):
+            self._pack_hip(src, which)                       # one launch (csrc/dmp_fused.hip::pack_segments_kernel)
+        else:
             torch._foreach_copy_(dst, src)
+
+    def _pack_hip(self, src, which):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        n = len(src)
+        key = tuple(which)
+        cached = getattr(self, "_pack_tables", None)
+        if cached is None or cached[0] != key:               # the slice table only changes with the set of gradients
+            offs = (ctypes.c_int64 * n)(*[self.offsets[i] for i in which])
+            lens = (ctypes.c_int64 * n)(*[self.params[i].numel() for i in which])
+            cached = self._pack_tables = (key, offs, lens)
+        src = [g if g.is_contiguous() else g.contiguous() for g in src]
+        ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in src])
+        _lib.check(lib.dmp_pack_segments(ptrs, cached[1], cached[2], n, self.flat.data_ptr(), _lib.stream_ptr()),
+                   "dmp_pack_segments")
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:

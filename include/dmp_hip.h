@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 25
+#define DMP_ABI_VERSION 26
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -422,6 +422,17 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
 int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, void *stream);
+
+/*
+ * Pack n separate fp32 arrays into one flat buffer in one launch (train.py:1231's optimizer and the gradient
+ * all-reduce work on ONE flat gradient; autograd hands back one tensor per parameter):
+ *   dst[dst_off[i] : dst_off[i] + len[i]] = src[i][0 : len[i]]      i < n
+ * src / dst_off / len are HOST arrays; every dst_off[i] a multiple of 4 and dst 16-byte aligned; the sources
+ * need no alignment.  Any n (split over launches of DMP_PACK_MAX_SEGMENTS).
+ */
+#define DMP_PACK_MAX_SEGMENTS 64
+int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, float *dst,
+                      void *stream);
 
 /*
  * Parameter algebra of the fused layer for all layers of a rep-net in one launch (H = 128 only).

@@ -117,3 +117,59 @@ def test_flat_adamw_matches_torch_adamw(n, amsgrad, gpu):
     c.grad = th.zeros(4)
     with pytest.raises(Exception, match="GPU only"):
         FlatAdamW([c]).step()                                                       # CPU tensors are refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [1, 7, 64, 150])
+def test_pack_segments_bit_exact(count, gpu):
+    """dmp_pack_segments (one launch per 64 arrays) against slice copies: ragged lengths incl. 0 and 1, sources that
+    are not 16-byte aligned, more arrays than one launch takes."""
+    import ctypes
+    from dualmessagepassing_amd import _lib
+    lib = _lib.load()
+    g = th.Generator().manual_seed(count)
+    lens = [int(x) for x in th.randint(0, 5000, (count,), generator=g)]
+    lens[0] = 70001
+    if count > 2:
+        lens[1], lens[2] = 0, 1
+    pool = th.randn(sum(lens) + 3 * count + 8, generator=g).cuda()
+    srcs, pos = [], 0
+    for i, n in enumerate(lens):
+        pos += i % 4                                   # misalign most of the sources
+        srcs.append(pool[pos:pos + n])
+        pos += n
+    offs, off = [], 0
+    for n in lens:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    flat = th.full((off + 4,), -7.0, device="cuda")
+    want = flat.clone()
+    for s, o, n in zip(srcs, offs, lens):
+        want[o:o + n] = s
+    P = (ctypes.c_void_p * count)(*[s.data_ptr() if s.numel() else None for s in srcs])
+    O, N = (ctypes.c_int64 * count)(*offs), (ctypes.c_int64 * count)(*lens)
+    _lib.check(lib.dmp_pack_segments(P, O, N, count, flat.data_ptr(), _lib.stream_ptr()), "dmp_pack_segments")
+    assert th.equal(flat, want)
+    O[0] = 2                                           # destination slices must start on 16-byte boundaries
+    assert lib.dmp_pack_segments(P, O, N, count, flat.data_ptr(), _lib.stream_ptr()) != 0
+
+
+@pytest.mark.gpu
+def test_flat_grad_sync_pack_on_gpu(gpu):
+    """FlatGradSync.pack() on device tensors: fresh gradients land in their slices, a missing one leaves zeros."""
+    from dualmessagepassing_amd.dp import FlatGradSync
+    ps = [th.nn.Parameter(th.randn(s, device="cuda")) for s in [(128, 128), (128,), (1,), (3, 5), (1, 132)]]
+    holder = th.nn.Module()
+    holder.ps = th.nn.ParameterList(ps)
+    sync = FlatGradSync(holder)
+    for rnd in range(2):
+        sync.detach_grads()
+        gs = [th.randn_like(p) for p in ps]
+        for i, (p, g_) in enumerate(zip(ps, gs)):
+            if not (rnd == 1 and i == 3):
+                p.grad = g_.t().contiguous().t() if g_.dim() == 2 and rnd == 0 else g_
+        sync.pack()
+        for i, (p, g_, o) in enumerate(zip(ps, gs, sync.offsets)):
+            got = sync.flat[o:o + p.numel()].view_as(p)
+            assert p.grad.data_ptr() == got.data_ptr()
+            assert th.equal(got, th.zeros_like(g_) if (rnd == 1 and i == 3) else g_)
