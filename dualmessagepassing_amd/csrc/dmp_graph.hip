@@ -680,6 +680,31 @@ __global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ 
   for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
 }
 
+// ---- ScalarFilter gates (filter.py:6-16): mark the labels of every pattern, then look the target rows up
+struct FilterJobs {
+  dmp_filter_job job[DMP_FILTER_MAX_JOBS];
+  int n;
+};
+__global__ __launch_bounds__(kBlock) void filter_mark_k(const FilterJobs t, int64_t B, uint8_t *__restrict__ present) {
+  const dmp_filter_job &j = t.job[blockIdx.y];
+  uint8_t *__restrict__ pr = present + j.present_off;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < j.num_p) {
+    const int64_t b = j.p_seg[i], l = j.p_label[i];
+    if (b >= 0 && b < B && l >= 0 && l < j.num_labels) pr[b * j.num_labels + l] = 1;
+  }
+  // a pattern shorter than the longest one is pre-padded with zeros: label 0 takes part in the comparison
+  if (j.p_sizes && i < B && j.p_sizes[i] < j.p_max) pr[i * j.num_labels] = 1;
+}
+__global__ __launch_bounds__(kBlock) void filter_gate_k(const FilterJobs t, int64_t B, const uint8_t *__restrict__ present) {
+  const dmp_filter_job &j = t.job[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= j.num_g) return;
+  const int64_t b = j.g_seg[i], l = j.g_label[i];
+  const bool in = b >= 0 && b < B && l >= 0 && l < j.num_labels;
+  j.gate[i] = (in && present[j.present_off + b * j.num_labels + l]) ? 1.f : 0.f;
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -898,6 +923,42 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
   // int32 words: [cnt 2C | status 1 | pad 1 | tile_off C+1 | segsum | node_base N]
   if (num_nodes < 0 || num_classes < 2) return 0;
   return (size_t)(2 * (int64_t)num_classes + 2 + num_classes + 1 + dmp_class_tiles_segsum_words(num_classes) + num_nodes + 8);
+}
+
+int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B, uint8_t *present,
+                            int64_t present_bytes, void *stream) {
+  if (num_jobs < 0 || num_jobs > DMP_FILTER_MAX_JOBS || B < 0 || present_bytes < 0) return DMP_ERR_BAD_ARG;
+  if (num_jobs == 0) return DMP_OK;
+  if (!jobs) return DMP_ERR_BAD_ARG;
+  FilterJobs t;
+  t.n = num_jobs;
+  int64_t most_p = 0, most_g = 0;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_filter_job &j = jobs[i];
+    if (j.num_p < 0 || j.num_g < 0 || j.num_labels < 1 || j.present_off < 0 || j.p_max < 0) return DMP_ERR_BAD_ARG;
+    if (j.present_off + B * j.num_labels > present_bytes) return DMP_ERR_BAD_ARG;
+    if ((j.num_p > 0 && (!j.p_seg || !j.p_label)) || (j.num_g > 0 && (!j.g_seg || !j.g_label || !j.gate)))
+      return DMP_ERR_BAD_ARG;
+    t.job[i] = j;
+    const int64_t mp = j.num_p > (j.p_sizes ? B : 0) ? j.num_p : (j.p_sizes ? B : 0);
+    if (mp > most_p) most_p = mp;
+    if (j.num_g > most_g) most_g = j.num_g;
+  }
+  if (present_bytes > 0) {
+    if (!present) return DMP_ERR_BAD_ARG;
+    DMP_HIP_TRY(hipMemsetAsync(present, 0, (size_t)present_bytes, (hipStream_t)stream));
+  }
+  if (most_p > 0) {
+    filter_mark_k<<<dim3((unsigned)((most_p + kBlock - 1) / kBlock), (unsigned)num_jobs), kBlock, 0,
+                    (hipStream_t)stream>>>(t, B, present);
+    DMP_HIP_TRY(hipGetLastError());
+  }
+  if (most_g > 0) {
+    filter_gate_k<<<dim3((unsigned)((most_g + kBlock - 1) / kBlock), (unsigned)num_jobs), kBlock, 0,
+                    (hipStream_t)stream>>>(t, B, present);
+    DMP_HIP_TRY(hipGetLastError());
+  }
+  return DMP_OK;
 }
 
 int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t N, int64_t E,

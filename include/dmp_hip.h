@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 26
+#define DMP_ABI_VERSION 27
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -422,6 +422,28 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
 int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, void *stream);
+
+/*
+ * ScalarFilter gates of a batch of (pattern, target) pairs (filter.py:6-16 on the pre-padded label matrices,
+ * basemodel.py:1394-1423) for several element kinds (node labels, edge labels) in three dispatches:
+ *   gate[j] = 1.0 if the label of target row j occurs among the labels of the pattern of the same pair, else 0.0;
+ *   label 0 also passes when that pattern is shorter than p_max (its pre-padding zeros take part in the
+ *   reference's comparison).
+ * p_seg / g_seg: pair id of every pattern / target row, labels in [0, num_labels) (rows with labels outside
+ * that range never match and mark nothing).  p_sizes [B] rows per pattern, or NULL when every pattern has
+ * p_max rows.  present: scratch of present_bytes >= sum over jobs of B * num_labels bytes, job i using
+ * [present_off, present_off + B * num_labels).  The jobs array is a HOST array.
+ */
+#define DMP_FILTER_MAX_JOBS 4
+typedef struct {
+  const int64_t *p_seg, *p_label; int64_t num_p;
+  const int64_t *p_sizes; int64_t p_max;
+  const int64_t *g_seg, *g_label; int64_t num_g;
+  int64_t num_labels, present_off;
+  float *gate;                      /* [num_g] */
+} dmp_filter_job;
+int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B, uint8_t *present,
+                            int64_t present_bytes, void *stream);
 
 /*
  * Pack n separate fp32 arrays into one flat buffer in one launch (train.py:1231's optimizer and the gradient

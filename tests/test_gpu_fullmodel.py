@@ -189,3 +189,49 @@ def test_hip_heads_match_op_by_op(B, n_heads, gpu):
     for i, (a, b) in enumerate(zip(got, want)):
         tol = 1e-4 * max(1.0, float(b.abs().max()))
         assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=tol), (i, (a - b).abs().max().item())
+
+
+class _FakePad:
+    def __init__(self, sizes):
+        self.sizes = th.as_tensor(sizes, dtype=th.int64, device="cuda")
+        self.bsz, self.max = len(sizes), int(max(sizes))
+        self.seg = th.repeat_interleave(th.arange(self.bsz, device="cuda"), self.sizes)
+        self.uniform = self.bsz * self.max == int(sum(sizes))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("num_labels", [1, 16, 300])
+def test_scalar_filter_gates_match_padded_filter(ragged, num_labels, gpu):
+    """dmp_scalar_filter_gates (two element kinds in one call) against (a) the row-wise torch form and (b) the
+    reference's formulation: ScalarFilter on the PRE-PADDED label matrices (filter.py:6-16, basemodel.py:1394-1423),
+    where the zeros in front of a short pattern take part in the comparison."""
+    from dualmessagepassing_amd.basemodel import ScalarFilter, scalar_filter_gate, scalar_filter_gates
+    rng = np.random.default_rng(num_labels + ragged)
+    B = 37
+    jobs, want = [], []
+    for kind in range(2):
+        ps = rng.integers(1, 9, B) if ragged else np.full(B, 5 + kind)
+        gs = rng.integers(1, 70, B) if ragged else np.full(B, 33)
+        p_pad, g_pad = _FakePad(ps.tolist()), _FakePad(gs.tolist())
+        pl = rng.integers(0, num_labels, int(ps.sum()))
+        gl = rng.integers(0, num_labels, int(gs.sum()))
+        jobs.append((p_pad, th.as_tensor(pl, device="cuda").view(-1, 1), g_pad, th.as_tensor(gl, device="cuda"), num_labels))
+        # (b) the padded cube, pair by pair
+        pm, gm = int(ps.max()), int(gs.max())
+        P, G = np.zeros((B, pm), np.int64), np.zeros((B, gm), np.int64)
+        po = go = 0
+        rows = []
+        for b in range(B):
+            P[b, pm - ps[b]:] = pl[po:po + ps[b]]
+            G[b, gm - gs[b]:] = gl[go:go + gs[b]]
+            po, go = po + ps[b], go + gs[b]
+        cube = ScalarFilter()(th.as_tensor(P).unsqueeze(-1).squeeze(-1), th.as_tensor(G))
+        for b in range(B):
+            rows.append(cube[b, gm - gs[b]:])
+        want.append(th.cat(rows).float().view(-1, 1))
+    got = scalar_filter_gates(jobs)
+    for j, g, w in zip(jobs, got, want):
+        assert g.dtype == th.float32 and g.shape == w.shape
+        assert th.equal(g.cpu(), w)
+        assert th.equal(g, scalar_filter_gate(*j).float())
