@@ -119,6 +119,51 @@ def scalar_filter_gates(jobs):
     return gates
 
 
+_MASK_JOB = None
+
+
+def len_masks(jobs):
+    """Pre-padding masks ``[B, max, 1]`` (bool) and their row counts ``[B, 1]`` (float) for several element kinds --
+    ``jobs`` = list of ``(padder, rev)`` with ``rev`` the per-row is-reversed flags or None (reversed edges leave
+    the mask, basemodel.py:1521-1531).  Device tensors: ONE launch for all kinds (csrc/dmp_graph.hip::len_masks_k)
+    instead of the arange / compare / masked_fill / sum chain per kind."""
+    global _MASK_JOB
+    if not all(p.sizes.is_cuda for p, _ in jobs):
+        out = []
+        for p, rev in jobs:
+            m = p.mask()
+            if rev is not None:
+                m = m.masked_fill(p.pad(rev).view(p.bsz, -1, 1).bool(), 0)
+            out.append((m, m.view(p.bsz, -1).sum(dim=1, dtype=th.float32).view(-1, 1)))
+        return out
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    if _MASK_JOB is None:
+        class _Job(ctypes.Structure):
+            _fields_ = [("sizes", ctypes.c_void_p), ("off", ctypes.c_void_p), ("max_len", ctypes.c_int64),
+                        ("rev", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("count", ctypes.c_void_p)]
+        _MASK_JOB = _Job
+    B, dev = jobs[0][0].bsz, jobs[0][0].sizes.device
+    J, keep, out = (_MASK_JOB * len(jobs))(), [], []
+    for i, (p, rev) in enumerate(jobs):
+        if p.bsz != B:
+            raise ValueError("mask jobs must cover the same graphs")
+        sizes = p.sizes.long().contiguous()
+        off = None if p.uniform else p.off.contiguous()
+        if rev is not None:
+            rev = rev.reshape(-1).contiguous()
+            rev = rev.view(th.uint8) if rev.element_size() == 1 else (rev != 0).view(th.uint8)
+        mask = th.empty((B, p.max, 1), dtype=th.bool, device=dev)
+        count = th.empty((B, 1), dtype=th.float32, device=dev)
+        J[i].sizes, J[i].off, J[i].max_len = sizes.data_ptr(), (None if off is None else off.data_ptr()), p.max
+        J[i].rev, J[i].mask, J[i].count = (None if rev is None else rev.data_ptr()), mask.data_ptr(), count.data_ptr()
+        keep.append((sizes, off, rev))
+        out.append((mask, count))
+    _lib.check(lib.dmp_len_masks(J, len(jobs), B, _lib.stream_ptr()), "dmp_len_masks")
+    return out
+
+
 # ----------------------------------------------------------------------------- padding helpers
 def _segments(graph, kind):
     seg = graph.node_graph if kind == "node" else graph.edge_graph
@@ -150,6 +195,7 @@ class _Padder:
         if not self.uniform:
             off = th.zeros(self.bsz + 1, dtype=th.int64, device=self.sizes.device)
             th.cumsum(self.sizes, 0, out=off[1:])
+            self.off = off[:-1]
             pos = th.arange(n, device=self.sizes.device) - off[self.seg]
             self.idx = self.seg * self.max + (self.max - self.sizes[self.seg]) + pos
 
@@ -629,7 +675,7 @@ class GraphAdjModelV2(BaseModel):
             return False
         return True
 
-    def get_subiso_pred_hip(self, v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask):
+    def get_subiso_pred_hip(self, v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask, counts=None):
         """``get_subiso_pred`` (basemodel.py:1477-1498) on the pooled union rows: every head and their blend in one
         autograd node / three HIP launches (``pred._PooledHeadsHIP``)."""
         from .pred import _PooledHeadsHIP
@@ -637,9 +683,10 @@ class GraphAdjModelV2(BaseModel):
         args, g_lens = [], []
         for key, on, sums, pm, gm in (("v", self.node_pred, v_sums, p_v_mask, g_v_mask), ("e", self.edge_pred, e_sums, p_e_mask, g_e_mask)):
             if on:
-                gl = cnt(gm)
+                gl = cnt(gm) if counts is None else counts["g" + key]       # the mask kernel counted the rows already
+                pl = cnt(pm) if counts is None else counts["p" + key]
                 g_lens.append(gl)
-                args.append([sums, cnt(pm), gl, float(pm.size(1)), float(gm.size(1)), None] + list(self.pred_net[key].head_params()))
+                args.append([sums, pl, gl, float(pm.size(1)), float(gm.size(1)), None] + list(self.pred_net[key].head_params()))
         if len(args) == 2:
             g_len = g_lens[0] + g_lens[1]
             args[0][5], args[1][5] = g_lens[0] / g_len, g_lens[1] / g_len
@@ -672,8 +719,11 @@ class GraphAdjModelV2(BaseModel):
         bsz = pattern.batch_size
         pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"),
                 "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
-        p_v_mask, p_e_mask = pads["pv"].mask(), pads["pe"].mask()
-        g_v_mask, g_e_mask = pads["gv"].mask(), pads["ge"].mask()
+        # reversed edges do not take part in the edge head (basemodel.py:1521-1531)
+        (p_v_mask, p_v_cnt), (p_e_mask, p_e_cnt), (g_v_mask, g_v_cnt), (g_e_mask, g_e_cnt) = len_masks(
+            [(pads["pv"], None), (pads["pe"], pattern.edata.get(REVFLAG)),
+             (pads["gv"], None), (pads["ge"], graph.edata.get(REVFLAG))])
+        counts = {"pv": p_v_cnt, "pe": p_e_cnt, "gv": g_v_cnt, "ge": g_e_cnt}
         vl_gate, el_gate = self.get_filter_gate(pattern, graph, pads)
         if vl_gate is not None:  # bool gate * float features == float gate * float features
             vl_gate, el_gate = vl_gate.float(), el_gate.float()
@@ -691,12 +741,6 @@ class GraphAdjModelV2(BaseModel):
         else:
             p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
             g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=vl_gate, e_gate=el_gate)
-
-        # reversed edges do not take part in the edge head (basemodel.py:1521-1531)
-        if REVFLAG in pattern.edata:
-            p_e_mask = p_e_mask.masked_fill(pads["pe"].pad(pattern.edata[REVFLAG]).view(bsz, -1, 1).bool(), 0)
-        if REVFLAG in graph.edata:
-            g_e_mask = g_e_mask.masked_fill(pads["ge"].pad(graph.edata[REVFLAG]).view(bsz, -1, 1).bool(), 0)
 
         if self.pred_with_deg:
             p_out_deg = pattern.out_degrees().float().view(-1, 1)
@@ -760,7 +804,8 @@ class GraphAdjModelV2(BaseModel):
         p_v_mask, p_e_mask = p_v_mask.view(bsz, -1), p_e_mask.view(bsz, -1)
         g_v_mask, g_e_mask = g_v_mask.view(bsz, -1), g_e_mask.view(bsz, -1)
         if pooled and self._hip_heads_ok(v_sums, e_sums):
-            pred_c, (pred_v, pred_e) = self.get_subiso_pred_hip(v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask)
+            pred_c, (pred_v, pred_e) = self.get_subiso_pred_hip(v_sums, p_v_mask, g_v_mask, e_sums, p_e_mask, g_e_mask,
+                                                                counts=counts)
         elif pooled:
             pred_c, (pred_v, pred_e) = self.get_subiso_pred_pooled(p_v_output, p_v_mask, p_e_output, p_e_mask,
                                                                    g_v_output, g_v_mask, g_e_output, g_e_mask)

@@ -680,6 +680,33 @@ __global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ 
   for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
 }
 
+// ---- pre-padding masks + counts (utils/dl.py:113-127): one workgroup per (graph, job)
+struct MaskJobs {
+  dmp_mask_job job[DMP_MASK_MAX_JOBS];
+};
+__global__ __launch_bounds__(kBlock) void len_masks_k(const MaskJobs t) {
+  const dmp_mask_job &j = t.job[blockIdx.y];
+  const int64_t b = blockIdx.x, L = j.max_len;
+  const int64_t size = j.sizes[b], pad = L - size;
+  const int64_t start = j.off ? j.off[b] : b * L;
+  int cnt = 0;
+  for (int64_t x = threadIdx.x; x < L; x += kBlock) {
+    bool m = x >= pad;
+    if (m && j.rev) m = j.rev[start + x - pad] == 0;
+    j.mask[b * L + x] = m ? 1 : 0;
+    cnt += m ? 1 : 0;
+  }
+  __shared__ int part[kBlock / 64];
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kBlock / 64; ++w) total += part[w];
+    j.count[b] = (float)total;
+  }
+}
+
 // ---- ScalarFilter gates (filter.py:6-16): mark the labels of every pattern, then look the target rows up
 struct FilterJobs {
   dmp_filter_job job[DMP_FILTER_MAX_JOBS];
@@ -923,6 +950,21 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
   // int32 words: [cnt 2C | status 1 | pad 1 | tile_off C+1 | segsum | node_base N]
   if (num_nodes < 0 || num_classes < 2) return 0;
   return (size_t)(2 * (int64_t)num_classes + 2 + num_classes + 1 + dmp_class_tiles_segsum_words(num_classes) + num_nodes + 8);
+}
+
+int dmp_len_masks(const dmp_mask_job *jobs, int num_jobs, int64_t B, void *stream) {
+  if (num_jobs < 0 || num_jobs > DMP_MASK_MAX_JOBS || B < 0 || B > 0x7fffffffLL) return DMP_ERR_BAD_ARG;
+  if (num_jobs == 0 || B == 0) return DMP_OK;
+  if (!jobs) return DMP_ERR_BAD_ARG;
+  MaskJobs t;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_mask_job &j = jobs[i];
+    if (j.max_len < 0 || !j.sizes || !j.count || (j.max_len > 0 && !j.mask)) return DMP_ERR_BAD_ARG;
+    t.job[i] = j;
+  }
+  len_masks_k<<<dim3((unsigned)B, (unsigned)num_jobs), kBlock, 0, (hipStream_t)stream>>>(t);
+  DMP_HIP_TRY(hipGetLastError());
+  return DMP_OK;
 }
 
 int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B, uint8_t *present,

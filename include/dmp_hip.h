@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 27
+#define DMP_ABI_VERSION 28
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -444,6 +444,23 @@ typedef struct {
 } dmp_filter_job;
 int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B, uint8_t *present,
                             int64_t present_bytes, void *stream);
+
+/*
+ * Pre-padding masks of a batch and their row counts (utils/dl.py:113-127 batch_convert_len_to_mask(pre_pad=True);
+ * basemodel.py:1521-1531: reversed edges leave the edge masks) for several element kinds in one launch:
+ *   mask[b, j]  = j >= max_len - sizes[b]  and not rev[off[b] + j - (max_len - sizes[b])]      (uint8 0/1 = torch.bool)
+ *   count[b]    = number of set entries of row b (fp32)
+ * sizes [B] rows of every graph; off [B] first row of every graph (NULL: b * max_len, i.e. all graphs have
+ * max_len rows); rev: one byte per row or NULL.  The jobs array is a HOST array.
+ */
+#define DMP_MASK_MAX_JOBS 4
+typedef struct {
+  const int64_t *sizes, *off; int64_t max_len;
+  const uint8_t *rev;
+  uint8_t *mask;                    /* [B, max_len] */
+  float *count;                     /* [B] */
+} dmp_mask_job;
+int dmp_len_masks(const dmp_mask_job *jobs, int num_jobs, int64_t B, void *stream);
 
 /*
  * Pack n separate fp32 arrays into one flat buffer in one launch (train.py:1231's optimizer and the gradient

@@ -235,3 +235,39 @@ def test_scalar_filter_gates_match_padded_filter(ragged, num_labels, gpu):
         assert g.dtype == th.float32 and g.shape == w.shape
         assert th.equal(g.cpu(), w)
         assert th.equal(g, scalar_filter_gate(*j).float())
+
+
+class _Sizes:
+    """Just enough of a batched graph for basemodel._Padder."""
+    node_graph = edge_graph = None
+
+    def __init__(self, sizes, dev):
+        self._s = th.as_tensor(sizes, dtype=th.int64, device=dev)
+
+    def batch_num_nodes(self):
+        return self._s
+
+    def batch_num_edges(self):
+        return self._s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("rev_dtype", [th.bool, th.uint8, th.int64])
+def test_len_masks_match_torch_chain(ragged, rev_dtype, gpu):
+    """dmp_len_masks (all element kinds in one launch) against the arange / compare / masked_fill / sum chain
+    (utils/dl.py:113-127 pre-padding masks; basemodel.py:1521-1531 reversed edges leave the edge masks)."""
+    from dualmessagepassing_amd.basemodel import _Padder, len_masks
+    rng = np.random.default_rng(int(ragged) + 3)
+    B = 53
+    jobs = {"cpu": [], "cuda": []}
+    for kind, hi in (("node", 9), ("edge", 700), ("node", 300), ("edge", 1)):
+        sizes = rng.integers(1, hi + 1, B) if ragged else np.full(B, hi)
+        rev = (rng.random(int(sizes.sum())) < 0.4) if kind == "edge" else None
+        for dev in ("cpu", "cuda"):
+            r = None if rev is None else th.as_tensor(rev).to(rev_dtype).to(dev)
+            jobs[dev].append((_Padder(_Sizes(sizes.tolist(), dev), kind), r))
+    want, got = len_masks(jobs["cpu"]), len_masks(jobs["cuda"])
+    for (wm, wc), (gm, gc) in zip(want, got):
+        assert gm.dtype == th.bool and gm.shape == wm.shape and gc.shape == wc.shape and gc.dtype == th.float32
+        assert th.equal(gm.cpu(), wm) and th.equal(gc.cpu(), wc)
