@@ -29,45 +29,54 @@ struct Heads {
 // acc[8] += A_lds[r][0..127] . op(W)[.., 8 cg ..]   for one 128-wide contraction; W element (j, k) at W[j * ldw + k]
 //   wT = 1: out col j, contraction k: out[j] = sum_k a[k] W[j][k]     (x W^T, W in nn.Linear layout)
 //   wT = 0: out col k, contraction j: out[k] = sum_j a[j] W[j][k]     (x W)
-// a0: first contraction index inside As rows (the operand row holds >= a0 + 128 values at stride 1).
-__device__ __forceinline__ void gemm128(float (&acc)[8], const float *As_row, const float *W, int ldw, int wT, int wcol0,
+// A: the 16 operand rows in LDS (row i at A + i * lda, >= 128 values at stride 1, 16-byte aligned rows).
+// The 16 x 128 product runs on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32: wave w owns output columns 32 w .. 32 w + 31):
+// every lane requests its share of the whole 128-deep weight panel in ONE batch of loads straight in the operand layout
+// (one L2 round trip per product instead of one per 32-deep LDS slice), the A operand comes from LDS as float4 (lane
+// (m, kq) takes k = 16 kb + 4 kq .. + 3, the weights follow the same order); the 16 x 128 result goes through Ws
+// (>= 16 * kPad floats) into the (row r = tid / 16, 8 columns cg) accumulators of the callers' epilogues.
+__device__ __forceinline__ void gemm128(float (&acc)[8], const float *A, int lda, const float *W, int ldw, int wT, int wcol0,
                                         float *Ws, int tid, int cg) {
-  // the next 32-deep slice of W is requested before the current one is consumed (these kernels are a chain of
-  // L2 round trips otherwise: 16 rows per workgroup leave nothing else to overlap them with)
-  float4 nx[4];
-  auto fetch = [&](int k0) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+  float4 bw[2][8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (wT) nx[m] = ldg4(W + (int64_t)((tid >> 3) + 32 * m) * ldw + wcol0 + k0 + (tid & 7) * 4);
-      else nx[m] = ldg4(W + (int64_t)(k0 + (tid >> 5) + 8 * m) * ldw + wcol0 + (tid & 31) * 4);
-    }
-  };
-  fetch(0);
-  for (int k0 = 0; k0 < kH; k0 += 32) {
-    __syncthreads();
-    if (wT) {                                               // Ws[kk][j] = W[j][k0 + kk]
+  for (int t = 0; t < 2; ++t) {
+    const int n = wave * 32 + t * 16 + m;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
-        Ws[(kk4 + 0) * kPad + j] = nx[m].x; Ws[(kk4 + 1) * kPad + j] = nx[m].y;
-        Ws[(kk4 + 2) * kPad + j] = nx[m].z; Ws[(kk4 + 3) * kPad + j] = nx[m].w;
+    for (int kb = 0; kb < 8; ++kb) {
+      const int k = kb * 16 + 4 * kq;
+      if (wT) {
+        bw[t][kb] = ldg4(W + (int64_t)n * ldw + wcol0 + k);
+      } else {
+        const float *c = W + (int64_t)k * ldw + wcol0 + n;
+        bw[t][kb] = make_float4(c[0], c[ldw], c[2 * (int64_t)ldw], c[3 * (int64_t)ldw]);
       }
-    } else {                                                // Ws[jj][k] = W[k0 + jj][wcol0 + k]
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        *reinterpret_cast<float4 *>(&Ws[((tid >> 5) + 8 * m) * kPad + (tid & 31) * 4]) = nx[m];
-    }
-    if (k0 + 32 < kH) fetch(k0 + 32);
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      const float a = As_row[k0 + kk];
-      const float4 w0 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8]);
-      const float4 w1 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8 + 4]);
-      acc[0] += a * w0.x; acc[1] += a * w0.y; acc[2] += a * w0.z; acc[3] += a * w0.w;
-      acc[4] += a * w1.x; acc[5] += a * w1.y; acc[6] += a * w1.z; acc[7] += a * w1.w;
     }
   }
+  __syncthreads();                                          // the callers' operand rows are in LDS; Ws is free again
+  f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    const float4 a = *reinterpret_cast<const float4 *>(A + m * lda + kb * 16 + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[t][kb].x, d[t], 0, 0, 0);
+      d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[t][kb].y, d[t], 0, 0, 0);
+      d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[t][kb].z, d[t], 0, 0, 0);
+      d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[t][kb].w, d[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * 32 + t * 16 + m] = d[t][i];
+  __syncthreads();
+  const int r = tid >> 4;
+  const float4 o0 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8]);
+  const float4 o1 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8 + 4]);
+  acc[0] += o0.x; acc[1] += o0.y; acc[2] += o0.z; acc[3] += o0.w;
+  acc[4] += o1.x; acc[5] += o1.y; acc[6] += o1.z; acc[7] += o1.w;
 }
 
 __device__ __forceinline__ void stage_rows(float *As, const float *X, int64_t ldx, int i0, int B, int tid) {
@@ -83,7 +92,7 @@ __device__ __forceinline__ void stage_rows(float *As, const float *X, int64_t ld
 __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
   __shared__ float As[kRows * kPad];
   __shared__ float Fs[kRows * kFPad];
-  __shared__ float Ws[32 * kPad];
+  __shared__ float Ws[16 * kPad];
   const dmp_head_weights &w = t.w[blockIdx.y];
   const dmp_head_io &io = t.io[blockIdx.y];
   const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15, i0 = (int)blockIdx.x * kRows, b = i0 + r;
@@ -93,10 +102,10 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { p[e] = 0.f; g[e] = 0.f; }
   stage_rows(As, io.ps, io.ld_ps, i0, t.B, tid);
-  gemm128(p, &As[r * kPad], w.Wp, kH, 1, 0, Ws, tid, cg);
+  gemm128(p, As, kPad, w.Wp, kH, 1, 0, Ws, tid, cg);
   __syncthreads();
   stage_rows(As, io.gs, io.ld_gs, i0, t.B, tid);
-  gemm128(g, &As[r * kPad], w.Wg, kH, 1, 0, Ws, tid, cg);
+  gemm128(g, As, kPad, w.Wg, kH, 1, 0, Ws, tid, cg);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     p[e] += io.scale_p * w.bp[cg * 8 + e];
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) y1[e] = w.b1[cg * 8 + e];
 #pragma unroll 1
-  for (int q = 0; q < 4; ++q) gemm128(y1, &Fs[r * kFPad + q * kH], w.W1, kF, 1, q * kH, Ws, tid, cg);
+  for (int q = 0; q < 4; ++q) gemm128(y1, Fs + q * kH, kFPad, w.W1, kF, 1, q * kH, Ws, tid, cg);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float *wr = w.W1 + (int64_t)(cg * 8 + e) * kF + 4 * kH;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
 // Writes what the weight gradients need (dY1, dP, dG) and the input gradients.
 __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
   __shared__ float As[kRows * kPad];
-  __shared__ float Ws[32 * kPad];
+  __shared__ float Ws[16 * kPad];
   const dmp_head_weights &w = t.w[blockIdx.y];
   const dmp_head_io &io = t.io[blockIdx.y];
   const dmp_head_grads &gr = t.gr[blockIdx.y];
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) df[q][e] = 0.f;
-    gemm128(df[q], &As[r * kPad], w.W1, kF, 0, q * kH, Ws, tid, cg);
+    gemm128(df[q], As, kPad, w.W1, kF, 0, q * kH, Ws, tid, cg);
   }
   float dp[8], dg[8];
 #pragma unroll
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dp[e]; out[e] = 0.f; }
-  gemm128(out, &As[r * kPad], w.Wp, kH, 0, 0, Ws, tid, cg);
+  gemm128(out, As, kPad, w.Wp, kH, 0, 0, Ws, tid, cg);
   if (live && gr.dps) {
     float *o = gr.dps + (int64_t)b * gr.ld_dps + cg * 8;
     *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dg[e]; out[e] = 0.f; }
-  gemm128(out, &As[r * kPad], w.Wg, kH, 0, 0, Ws, tid, cg);
+  gemm128(out, As, kPad, w.Wg, kH, 0, 0, Ws, tid, cg);
   if (live && gr.dgs) {
     float *o = gr.dgs + (int64_t)b * gr.ld_dgs + cg * 8;
     *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
