@@ -232,67 +232,70 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
 }
 
 // Weight gradients: out[j, k] = sum_i dC[i, j] M[i, k]  (j < nj <= 128, k < ncols), bias[j] = bscale * sum_i dC[i, j].
-// One workgroup per (job, 16 output rows, 32 output columns); the batch rows are contracted 64 at a time.
+// One workgroup per (job, 16 output rows, 16 output columns) on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32 contracts four
+// batch rows per instruction): the four waves take interleaved groups of four batch rows, every lane requests its A / B
+// operands of kSteps instructions in one batch straight in the operand layout, a batch ahead of the one being
+// multiplied (B = 1024: four dependent L2 round trips per workgroup instead of sixteen staged 64-row chunks), and the
+// four partial tiles meet in LDS.
 struct WJob { const float *dC; const float *M; const float *row_scale; float *out; float *bias; int64_t ldc, ldm; int nj, ncols, ldo; float bscale; };
 constexpr int kMaxWJobs = 4 * kMaxHeads;
 struct WJobs { WJob job[kMaxWJobs]; int blk0[kMaxWJobs + 1]; int n; int B; };
-constexpr int kChunk = 64, kColW = 32;
+constexpr int kColW = 16, kSteps = 16;
 
 __global__ __launch_bounds__(kThreads) void heads_bwd_w_k(const WJobs t) {
-  __shared__ float Cs[kChunk * 17];
-  __shared__ float Ms[kChunk * (kColW + 4)];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[4 * 16 * 17];
+  __shared__ float bred[4 * 64];
   int q = 0;
   while (q + 1 < t.n && (int)blockIdx.x >= t.blk0[q + 1]) ++q;
   const WJob &jb = t.job[q];
   const int kblocks = (jb.ncols + kColW - 1) / kColW;
   const int sub = (int)blockIdx.x - t.blk0[q];
   const int j0 = (sub / kblocks) * kRows, k0 = (sub % kblocks) * kColW;
-  const int tid = threadIdx.x, jr = tid >> 4, cq = tid & 15;
-  float acc0 = 0.f, acc1 = 0.f, bsum = 0.f;
-  float cn[kChunk / 16], mn[(kChunk * kColW) / kThreads];
-  auto fetch = [&](int i0) {                                // the next chunk's operands are requested a chunk ahead
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+  const bool a_on = j0 + m < jb.nj, b_on = k0 + m < jb.ncols;
+  const float *ap = jb.dC + j0 + m, *bp = jb.M + k0 + m;
+  const int groups = (t.B + 3) / 4;                         // groups of four batch rows; wave w takes w, w + 4, ...
+  float an[kSteps], sn[kSteps], bn[kSteps];
+  auto fetch = [&](int g0) {
 #pragma unroll
-    for (int m = 0; m < kChunk / 16; ++m) {
-      const int i = (tid >> 4) + 16 * m, jj = tid & 15;
-      float c = 0.f;
-      if (i0 + i < t.B && j0 + jj < jb.nj) {
-        c = jb.dC[(int64_t)(i0 + i) * jb.ldc + j0 + jj];
-        if (jb.row_scale) c *= jb.row_scale[i0 + i];
-      }
-      cn[m] = c;
-    }
-#pragma unroll
-    for (int m = 0; m < (kChunk * kColW) / kThreads; ++m) {
-      const int e = m * kThreads + tid, row = e / kColW, c = e % kColW;
-      mn[m] = (i0 + row < t.B && k0 + c < jb.ncols) ? jb.M[(int64_t)(i0 + row) * jb.ldm + k0 + c] : 0.f;
+    for (int st = 0; st < kSteps; ++st) {
+      const int64_t i = 4 * (int64_t)(g0 + wave + 4 * st) + kq;
+      const bool in = i < t.B;
+      an[st] = (in && a_on) ? ap[i * jb.ldc] : 0.f;
+      sn[st] = (in && jb.row_scale) ? jb.row_scale[i] : 1.0f;
+      bn[st] = (in && b_on) ? bp[i * jb.ldm] : 0.f;
     }
   };
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
   fetch(0);
-  for (int i0 = 0; i0 < t.B; i0 += kChunk) {
-    __syncthreads();
+  for (int g0 = 0; g0 < groups; g0 += 4 * kSteps) {
+    float a[kSteps], b[kSteps];
 #pragma unroll
-    for (int m = 0; m < kChunk / 16; ++m) Cs[((tid >> 4) + 16 * m) * 17 + (tid & 15)] = cn[m];
+    for (int st = 0; st < kSteps; ++st) { a[st] = an[st] * sn[st]; b[st] = bn[st]; }
+    if (g0 + 4 * kSteps < groups) fetch(g0 + 4 * kSteps);
 #pragma unroll
-    for (int m = 0; m < (kChunk * kColW) / kThreads; ++m) {
-      const int e = m * kThreads + tid;
-      Ms[(e / kColW) * (kColW + 4) + e % kColW] = mn[m];
-    }
-    if (i0 + kChunk < t.B) fetch(i0 + kChunk);
-    __syncthreads();
-    const int lim = t.B - i0 < kChunk ? t.B - i0 : kChunk;
-#pragma unroll 8
-    for (int i = 0; i < lim; ++i) {
-      const float c = Cs[i * 17 + jr];
-      const float2 m2 = *reinterpret_cast<const float2 *>(&Ms[i * (kColW + 4) + cq * 2]);
-      acc0 += c * m2.x; acc1 += c * m2.y;
-      bsum += c;
+    for (int st = 0; st < kSteps; ++st) {
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], b[st], d, 0, 0, 0);
+      bsum += a[st];
     }
   }
-  if (j0 + jr < jb.nj) {
-    const int k = k0 + cq * 2;
-    if (k < jb.ncols) jb.out[(int64_t)(j0 + jr) * jb.ldo + k] = acc0;
-    if (k + 1 < jb.ncols) jb.out[(int64_t)(j0 + jr) * jb.ldo + k + 1] = acc1;
-    if (jb.bias && k0 == 0 && cq == 0) jb.bias[j0 + jr] = jb.bscale * bsum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * kq + i) * 17 + m] = d[i];
+  bred[wave * 64 + lane] = bsum;
+  __syncthreads();
+  const int jr = tid >> 4, kc = tid & 15;
+  if (j0 + jr < jb.nj && k0 + kc < jb.ncols)
+    jb.out[(int64_t)(j0 + jr) * jb.ldo + k0 + kc] =
+        (red[(0 * 16 + jr) * 17 + kc] + red[(1 * 16 + jr) * 17 + kc]) + (red[(2 * 16 + jr) * 17 + kc] + red[(3 * 16 + jr) * 17 + kc]);
+  if (jb.bias && k0 == 0 && tid < 16 && j0 + tid < jb.nj) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += bred[w * 64 + c * 16 + tid];
+    jb.bias[j0 + tid] = jb.bscale * sum;
   }
 }
 
