@@ -189,6 +189,13 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const Red
     const int64_t per = (S + GPB - 1) / GPB;
     const int64_t s0 = grp * per, s1 = min(S, s0 + per);
     int64_t s = s0;
+    for (; s + 8 <= s1; s += 8) {                           // eight rows in flight per thread: the pass is latency-bound otherwise
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(partial + (s + u) * L + l);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) add4(acc, v[u]);
+    }
     for (; s + 4 <= s1; s += 4) {
       const float4 x = ld4(partial + s * L + l), y = ld4(partial + (s + 1) * L + l);
       const float4 z = ld4(partial + (s + 2) * L + l), w = ld4(partial + (s + 3) * L + l);
