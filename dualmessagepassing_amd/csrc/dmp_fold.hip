@@ -9,8 +9,9 @@
 //                      kernels read (Bn [2H,H], bn [H], Wx [H,3H], Wes [H,2H], be [H])
 //   dmp_unfold_layers  the backward: dM = dC W0 (row jobs, with the +-d(src-dst) terms folded in) and
 //                      dW0 = dC^T M (column jobs over the gathered block rows)
-// H = 128 only (one 128-wide output panel per job).  Plain fp32 FMAs through LDS tiles; nothing here is
-// bandwidth- or MFMA-relevant, the point is the launch count.
+// H = 128 only (one 128-wide output panel per job).  Nothing here is bandwidth-relevant; the point is the launch
+// count and the length of each workgroup's chain of dependent L2 round trips: the products run on the fp32 MFMA pipe
+// with every lane requesting its operands in the MFMA layout in one batch (no staged LDS slices).
 #include <initializer_list>
 
 #include "dmp_common.h"
@@ -38,7 +39,7 @@ struct RowJobs { RowJob job[kMaxRowJobs]; int blk0[kMaxRowJobs + 1]; int n; };
 
 __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
   __shared__ float As[kRowsPerWG * kPad];
-  __shared__ float Ws[32 * kPad];
+  __shared__ float Ws[kRowsPerWG * kPad];
   int q = 0;
   while (q + 1 < t.n && (int)blockIdx.x >= t.blk0[q + 1]) ++q;
   const RowJob &jb = t.job[q];
@@ -58,39 +59,55 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
     }
     *reinterpret_cast<float4 *>(&As[row * kPad + c4]) = a;
   }
-  float acc[8];
+  // 16 x 128 x 128 on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32; wave w owns output columns 32 w .. 32 w + 31): every lane
+  // requests its share of the whole weight panel in one batch of loads, straight in the operand layout (one L2 round trip
+  // instead of one per 32-deep LDS slice); lane (m, kq) contracts k = 16 kb + 4 kq .. + 3 of block kb
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wave = tid >> 6, mm = lane & 15, kq = lane >> 4;
+  float4 bw[2][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int k0 = 0; k0 < kH; k0 += 32) {
-    __syncthreads();
-    if (jb.wT) {                                            // Ws[kk][j] = W[j][k0 + kk]
+  for (int tt = 0; tt < 2; ++tt) {
+    const int n = wave * 32 + tt * 16 + mm;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int j = (tid >> 3) + 32 * m, kk4 = (tid & 7) * 4;
-        float4 w = ldg4(jb.W + j * kH + k0 + kk4);
+    for (int kb = 0; kb < 8; ++kb) {
+      const int k = kb * 16 + 4 * kq;
+      if (jb.wT) {
+        float4 w = ldg4(jb.W + n * kH + k);
         if (jb.Wsub) {
-          const float4 u = ldg4(jb.Wsub + j * kH + k0 + kk4);
+          const float4 u = ldg4(jb.Wsub + n * kH + k);
           w.x -= u.x; w.y -= u.y; w.z -= u.z; w.w -= u.w;
         }
-        Ws[(kk4 + 0) * kPad + j] = w.x; Ws[(kk4 + 1) * kPad + j] = w.y;
-        Ws[(kk4 + 2) * kPad + j] = w.z; Ws[(kk4 + 3) * kPad + j] = w.w;
+        bw[tt][kb] = w;
+      } else {
+        const float *c = jb.W + k * kH + n;
+        bw[tt][kb] = make_float4(c[0], c[kH], c[2 * kH], c[3 * kH]);
       }
-    } else {                                                // Ws[jj][k] = W[k0 + jj][k]
+    }
+  }
+  __syncthreads();
+  f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
-        *reinterpret_cast<float4 *>(&Ws[row * kPad + c4]) = ldg4(jb.W + (k0 + row) * kH + c4);
-      }
+  for (int kb = 0; kb < 8; ++kb) {
+    const float4 a = *reinterpret_cast<const float4 *>(&As[mm * kPad + kb * 16 + 4 * kq]);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[tt][kb].x, d[tt], 0, 0, 0);
+      d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[tt][kb].y, d[tt], 0, 0, 0);
+      d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[tt][kb].z, d[tt], 0, 0, 0);
+      d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw[tt][kb].w, d[tt], 0, 0, 0);
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      const float a = As[r * kPad + k0 + kk];
-      const float4 w0 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8]);
-      const float4 w1 = *reinterpret_cast<const float4 *>(&Ws[kk * kPad + cg * 8 + 4]);
-      acc[0] += a * w0.x; acc[1] += a * w0.y; acc[2] += a * w0.z; acc[3] += a * w0.w;
-      acc[4] += a * w1.x; acc[5] += a * w1.y; acc[6] += a * w1.z; acc[7] += a * w1.w;
-    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * 32 + tt * 16 + mm] = d[tt][i];
+  __syncthreads();
+  float acc[8];
+  {
+    const float4 o0 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8]);
+    const float4 o1 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8 + 4]);
+    acc[0] = o0.x; acc[1] = o0.y; acc[2] = o0.z; acc[3] = o0.w;
+    acc[4] = o1.x; acc[5] = o1.y; acc[6] = o1.z; acc[7] = o1.w;
   }
   if (i0 + r < jb.rows) {
     if (jb.addv) {
@@ -110,50 +127,54 @@ struct ColJob { ColSrc src[5]; float *out; int nsrc; };
 constexpr int kMaxColJobs = 6;
 struct ColJobs { ColJob job[kMaxColJobs]; int n; };
 
-constexpr int kColChunk = 64;                               // block rows contracted per LDS round
-constexpr int kColW = 32;                                   // output columns per workgroup (x 16 output rows): 32 workgroups per job
+constexpr int kColW = 16;                                   // one 16 x 16 output tile per workgroup: 64 workgroups per job
+constexpr int kColSteps = 8;                                // MFMA steps (x 4 block rows x 4 waves = 128 rows) per batch of loads
 __global__ __launch_bounds__(kThreads) void coljob_k(const ColJobs t) {
-  __shared__ float Cs[kColChunk * 17];
-  __shared__ float Ms[kColChunk * (kColW + 4)];
+  // fp32 MFMA (v_mfma_f32_16x16x4_f32 contracts four block rows per instruction): the four waves take interleaved groups
+  // of four rows, every lane requests the operands of a 128-row batch in one go, a batch (or source) ahead of the one
+  // being multiplied; the four partial tiles meet in LDS
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[4 * 16 * 17];
   constexpr int kPerJob = (kH / kRowsPerWG) * (kH / kColW);
   const ColJob &jb = t.job[blockIdx.x / kPerJob];
   const int sub = (int)blockIdx.x % kPerJob;
   const int j0 = (sub / (kH / kColW)) * kRowsPerWG, k0 = (sub % (kH / kColW)) * kColW;
-  const int tid = threadIdx.x, jr = tid >> 4, cq = tid & 15;
-  float acc0 = 0.f, acc1 = 0.f;
-  for (int s = 0; s < jb.nsrc; ++s) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+  float an[kColSteps], bn[kColSteps], un[kColSteps];
+  auto fetch = [&](int s, int g0) {
     const ColSrc &sr = jb.src[s];
-    for (int i0 = 0; i0 < sr.rows; i0 += kColChunk) {
-      __syncthreads();
 #pragma unroll
-      for (int m = 0; m < kColChunk / 16; ++m) {
-        const int i = (tid >> 4) + 16 * m, jj = tid & 15;
-        Cs[i * 17 + jj] = i0 + i < sr.rows ? sr.dC[(int64_t)(i0 + i) * sr.ldc + j0 + jj] : 0.f;
-      }
-#pragma unroll
-      for (int m = 0; m < kColChunk / 32; ++m) {            // 64 rows x 32 columns = 512 float4: two per thread
-        const int row = (tid >> 3) + 32 * m, c4 = (tid & 7) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i0 + row < sr.rows) {
-          a = ldg4(sr.M + (i0 + row) * kH + k0 + c4);
-          if (sr.M2) {
-            const float4 b = ldg4(sr.M2 + (i0 + row) * kH + k0 + c4);
-            a.x -= b.x; a.y -= b.y; a.z -= b.z; a.w -= b.w;
-          }
-        }
-        *reinterpret_cast<float4 *>(&Ms[row * (kColW + 4) + c4]) = a;
-      }
-      __syncthreads();
-      const int lim = sr.rows - i0 < kColChunk ? sr.rows - i0 : kColChunk;
-#pragma unroll 8
-      for (int i = 0; i < lim; ++i) {
-        const float c = Cs[i * 17 + jr];
-        const float2 w = *reinterpret_cast<const float2 *>(&Ms[i * (kColW + 4) + cq * 2]);
-        acc0 += c * w.x; acc1 += c * w.y;
-      }
+    for (int st = 0; st < kColSteps; ++st) {
+      const int i = 4 * (g0 + wave + 4 * st) + kq;
+      const bool in = i < sr.rows;
+      an[st] = in ? sr.dC[(int64_t)i * sr.ldc + j0 + m] : 0.f;
+      bn[st] = in ? sr.M[i * kH + k0 + m] : 0.f;
+      un[st] = (in && sr.M2) ? sr.M2[i * kH + k0 + m] : 0.f;
     }
+  };
+  auto advance = [&](int &s, int &g0) {
+    g0 += 4 * kColSteps;
+    while (s < jb.nsrc && 4 * g0 >= jb.src[s].rows) { ++s; g0 = 0; }
+  };
+  int s = 0, g0 = 0;
+  while (s < jb.nsrc && jb.src[s].rows <= 0) ++s;
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  if (s < jb.nsrc) fetch(s, g0);
+  while (s < jb.nsrc) {
+    float a[kColSteps], b[kColSteps];
+#pragma unroll
+    for (int st = 0; st < kColSteps; ++st) { a[st] = an[st]; b[st] = bn[st] - un[st]; }
+    advance(s, g0);
+    if (s < jb.nsrc) fetch(s, g0);
+#pragma unroll
+    for (int st = 0; st < kColSteps; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], b[st], d, 0, 0, 0);
   }
-  *reinterpret_cast<float2 *>(jb.out + (j0 + jr) * kH + k0 + cq * 2) = make_float2(acc0, acc1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * kq + i) * 17 + m] = d[i];
+  __syncthreads();
+  const int jr = tid >> 4, kc = tid & 15;
+  jb.out[(j0 + jr) * kH + k0 + kc] =
+      (red[(0 * 16 + jr) * 17 + kc] + red[(1 * 16 + jr) * 17 + kc]) + (red[(2 * 16 + jr) * 17 + kc] + red[(3 * 16 + jr) * 17 + kc]);
 }
 
 inline void add_row_job(RowJobs &t, int &blocks, const float *A, int lda, const float *A2, int lda2, float s2, const float *W,
