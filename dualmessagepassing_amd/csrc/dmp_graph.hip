@@ -560,7 +560,7 @@ __global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__re
 // taken in a first pass (ct_seg_k), rarer classes (hubs) walk the whole range with one wave.
 // The class's wave of segment 0 also writes the class's coefficient into its tiles.
 constexpr int kCtFast = 1024;
-constexpr int kCtSegs = 32;
+constexpr int kCtSegs = 128;
 
 __device__ __forceinline__ int ct_key(const int64_t *deg, int64_t v, int C) {
   const int64_t k = deg[v];
