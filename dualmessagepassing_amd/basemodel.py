@@ -20,7 +20,7 @@ from .compgcn import CompGCNRepMixin
 from .constants import REVFLAG
 from .dmpnn import DMPNNRepMixin
 from .embed import (EquivariantEmbedding, MultihotEmbedding, NormalEmbedding, OrthogonalEmbedding,
-                    PositionEmbedding, UniformEmbedding, get_enc_len)
+                    PositionEmbedding, UniformEmbedding, get_enc_len, lookup_rows)
 from .pred import PRED_NETS
 from .rgnn import RGCNRepMixin, RGINRepMixin
 
@@ -453,7 +453,8 @@ class GraphAdjModel(BaseModel):
         return gv.unpad(self.filter_net["vl"](p_vl, g_vl)).view(-1, 1)
 
     def _enc(self, net, g):
-        return OrderedDict({"v": net["v"](g.ndata["id"].view(-1)), "vl": net["vl"](g.ndata["label"].view(-1))})
+        v, vl = lookup_rows([net["v"], net["vl"]], [g.ndata["id"].view(-1), g.ndata["label"].view(-1)])
+        return OrderedDict({"v": v, "vl": vl})
 
     def _emb(self, net, enc):
         emb = net["vl"](enc["vl"])
@@ -620,8 +621,9 @@ class GraphAdjModelV2(BaseModel):
         return vl_gate, el_gate
 
     def _enc(self, net, g):
-        enc = OrderedDict({"v": net["v"](g.ndata["id"].view(-1)), "vl": net["vl"](g.ndata["label"].view(-1)),
-                           "el": net["el"](g.edata["label"].view(-1))})
+        v, vl, el = lookup_rows([net["v"], net["vl"], net["el"]],
+                                [g.ndata["id"].view(-1), g.ndata["label"].view(-1), g.edata["label"].view(-1)])
+        enc = OrderedDict({"v": v, "vl": vl, "el": el})
         if self.add_edge_id:
             u, v = g.all_edges(form="uv", order="eid")
             enc["src"] = enc["v"][u]

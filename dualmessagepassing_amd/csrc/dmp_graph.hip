@@ -533,13 +533,14 @@ __global__ __launch_bounds__(1024) void ct_scan_k(const unsigned long long *__re
   }
   __syncthreads();
   const int mine = part[t];
-  for (int off = 1; off < 1024; off <<= 1) {                   // inclusive Hillis-Steele scan of the 1024 (row, wave) totals
-    const int add = t >= off ? part[t - off] : 0;
+  const int live = rows * 16;                                  // the (row, wave) totals past the scanned rows are zero
+  for (int off = 1; off < live; off <<= 1) {                   // inclusive Hillis-Steele scan of the live totals
+    const int add = (t >= off && t < live) ? part[t - off] : 0;
     __syncthreads();
     part[t] += add;
     __syncthreads();
   }
-  const int total = part[1023];
+  const int total = part[live - 1];
   __syncthreads();
   part[t] -= mine;                                             // exclusive
   __syncthreads();
@@ -678,6 +679,21 @@ __global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ 
   if (hi == lo) return;
   int s = node_base[v];
   for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
+}
+
+// ---- enc = table[ids] for several small tables (embed.py:199-224): one thread per output element
+struct LookupJobs {
+  dmp_lookup_job job[DMP_LOOKUP_MAX_JOBS];
+};
+__global__ __launch_bounds__(kBlock) void table_rows_k(const LookupJobs t) {
+  const dmp_lookup_job &j = t.job[blockIdx.y];
+  const int64_t total = j.rows * j.width;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / j.width;
+    const int c = (int)(i - r * j.width);
+    const int64_t id = j.idx[r];
+    j.out[i] = (id >= 0 && id < j.table_rows) ? j.table[id * j.ld + c] : __builtin_nanf("");
+  }
 }
 
 // ---- pre-padding masks + counts (utils/dl.py:113-127): one workgroup per (graph, job)
@@ -950,6 +966,27 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
   // int32 words: [cnt 2C | status 1 | pad 1 | tile_off C+1 | segsum | node_base N]
   if (num_nodes < 0 || num_classes < 2) return 0;
   return (size_t)(2 * (int64_t)num_classes + 2 + num_classes + 1 + dmp_class_tiles_segsum_words(num_classes) + num_nodes + 8);
+}
+
+int dmp_table_rows(const dmp_lookup_job *jobs, int num_jobs, void *stream) {
+  if (num_jobs < 0 || num_jobs > DMP_LOOKUP_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  if (num_jobs == 0) return DMP_OK;
+  if (!jobs) return DMP_ERR_BAD_ARG;
+  LookupJobs t;
+  int64_t most = 0;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_lookup_job &j = jobs[i];
+    if (j.rows < 0 || j.width < 1 || j.table_rows < 0 || j.ld < j.width) return DMP_ERR_BAD_ARG;
+    if (j.rows > 0 && (!j.table || !j.idx || !j.out)) return DMP_ERR_BAD_ARG;
+    t.job[i] = j;
+    if (j.rows * j.width > most) most = j.rows * j.width;
+  }
+  if (most == 0) return DMP_OK;
+  int64_t nb = (most + kBlock - 1) / kBlock;
+  if (nb > 8192) nb = 8192;
+  table_rows_k<<<dim3((unsigned)nb, (unsigned)num_jobs), kBlock, 0, (hipStream_t)stream>>>(t);
+  DMP_HIP_TRY(hipGetLastError());
+  return DMP_OK;
 }
 
 int dmp_len_masks(const dmp_mask_job *jobs, int num_jobs, int64_t B, void *stream) {

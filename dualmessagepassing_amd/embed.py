@@ -40,6 +40,41 @@ def int2multihot(x, len_x, base=10):
     return rep
 
 
+_LOOKUP_JOB = None
+
+
+def lookup_rows(nets, ids):
+    """``[net(i) for net, i in zip(nets, ids)]`` for index inputs.  Frozen fp32 tables on the device (the multi-hot /
+    position encodings, embed.py:199-224): ONE launch for all of them (csrc/dmp_graph.hip::table_rows_k) instead
+    of one gather each; anything else goes through the modules."""
+    global _LOOKUP_JOB
+    from . import _lib
+    ok = len(nets) <= 8 and all(
+        isinstance(n, nn.Embedding) and n.padding_idx is None and n.max_norm is None and not n.weight.requires_grad
+        and n.weight.is_cuda and n.weight.dtype == th.float32 and n.weight.stride(1) == 1
+        and i.dtype == th.long and i.is_cuda and i.dim() == 1 for n, i in zip(nets, ids))
+    if not ok:
+        return [n(i) for n, i in zip(nets, ids)]
+    import ctypes
+    lib = _lib.load()
+    if _LOOKUP_JOB is None:
+        class _Job(ctypes.Structure):
+            _fields_ = [("table", ctypes.c_void_p), ("ld", ctypes.c_int64), ("table_rows", ctypes.c_int64),
+                        ("width", ctypes.c_int), ("idx", ctypes.c_void_p), ("rows", ctypes.c_int64),
+                        ("out", ctypes.c_void_p)]
+        _LOOKUP_JOB = _Job
+    J, keep, outs = (_LOOKUP_JOB * len(nets))(), [], []
+    for k, (n, i) in enumerate(zip(nets, ids)):
+        w, i = n.weight.detach(), i.contiguous()
+        out = th.empty((i.numel(), w.size(1)), dtype=th.float32, device=w.device)
+        J[k].table, J[k].ld, J[k].table_rows, J[k].width = w.data_ptr(), w.stride(0), w.size(0), w.size(1)
+        J[k].idx, J[k].rows, J[k].out = i.data_ptr(), i.numel(), out.data_ptr()
+        keep.append((w, i))
+        outs.append(out)
+    _lib.check(lib.dmp_table_rows(J, len(nets), _lib.stream_ptr()), "dmp_table_rows")
+    return outs
+
+
 class Embedding(nn.Embedding):
     """embed.py:103-120: index lookup for long inputs, ``x @ weight`` for float encodings."""
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 28
+#define DMP_ABI_VERSION 29
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -461,6 +461,20 @@ typedef struct {
   float *count;                     /* [B] */
 } dmp_mask_job;
 int dmp_len_masks(const dmp_mask_job *jobs, int num_jobs, int64_t B, void *stream);
+
+/*
+ * Row lookups into small frozen tables (the multi-hot / position encodings of ids and labels, embed.py:199-224:
+ * enc = table[ids]) for several (table, ids) pairs in one launch:
+ *   out[r, 0:width] = table[idx[r], 0:width]        r < rows
+ * idx values outside [0, table_rows) give NaN rows.  The jobs array is a HOST array.
+ */
+#define DMP_LOOKUP_MAX_JOBS 8
+typedef struct {
+  const float *table; int64_t ld, table_rows; int width;
+  const int64_t *idx; int64_t rows;
+  float *out;                       /* [rows, width], dense */
+} dmp_lookup_job;
+int dmp_table_rows(const dmp_lookup_job *jobs, int num_jobs, void *stream);
 
 /*
  * Pack n separate fp32 arrays into one flat buffer in one launch (train.py:1231's optimizer and the gradient

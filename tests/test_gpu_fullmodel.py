@@ -271,3 +271,24 @@ def test_len_masks_match_torch_chain(ragged, rev_dtype, gpu):
     for (wm, wc), (gm, gc) in zip(want, got):
         assert gm.dtype == th.bool and gm.shape == wm.shape and gc.shape == wc.shape and gc.dtype == th.float32
         assert th.equal(gm.cpu(), wm) and th.equal(gc.cpu(), wc)
+
+
+@pytest.mark.gpu
+def test_table_lookups_match_embedding_modules(gpu):
+    """dmp_table_rows (all encodings of a batch in one launch) against the modules' own lookups, bit for bit;
+    trainable tables and non-index inputs keep going through the modules."""
+    from dualmessagepassing_amd.embed import MultihotEmbedding, PositionEmbedding, NormalEmbedding, lookup_rows
+    g = th.Generator().manual_seed(5)
+    nets = [MultihotEmbedding(64, 2).cuda(), MultihotEmbedding(16, 2).cuda(), PositionEmbedding(10, 32).cuda(),
+            MultihotEmbedding(300, 2).cuda()]
+    for n in nets:
+        n.weight.requires_grad = False
+    ids = [th.randint(0, n.weight.size(0), (rows,), generator=g).cuda() for n, rows in zip(nets, (70001, 1, 0, 513))]
+    got = lookup_rows(nets, ids)
+    for n, i, o in zip(nets, ids, got):
+        assert o.shape == (i.numel(), n.weight.size(1)) and th.equal(o, n(i))
+    train = NormalEmbedding(12, 128).cuda()                      # trainable: stays on the module (autograd)
+    out = lookup_rows([train], [th.randint(0, 12, (9,), generator=g).cuda()])[0]
+    assert out.requires_grad
+    bad = lookup_rows(nets[:1], [th.tensor([3, 64, -1], device="cuda")])[0]
+    assert th.equal(bad[0], nets[0].weight[3]) and bool(th.isnan(bad[1:]).all())
