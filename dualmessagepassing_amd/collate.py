@@ -187,6 +187,51 @@ def batchify(samples, return_weights=None, device=None):
                                                        work_hint=hint)
 
 
+_CONCAT_JOB = None
+
+
+def concat_pairs(pairs):
+    """``[cat([a, b + add]) for (a, b, add) in pairs]`` (1-D tensors; ``a`` may be ``(n, fill)`` for a constant fp32
+    block; ``add`` only for int64).  Device tensors: ONE launch for all pairs (csrc/dmp_graph.hip::concat_pairs_k)."""
+    global _CONCAT_JOB
+    import ctypes
+    from . import _lib
+
+    def plain(a, b, add):
+        if isinstance(a, tuple):
+            a = torch.full((a[0],), a[1], dtype=b.dtype, device=b.device)
+        return torch.cat([a.reshape(-1), b.reshape(-1) + add if add else b.reshape(-1)])
+
+    ok = 0 < len(pairs) <= 12 and all(
+        b.is_cuda and b.element_size() in (1, 4, 8) and (not add or b.dtype == torch.int64)
+        and ((isinstance(a, tuple) and b.dtype == torch.float32) or (torch.is_tensor(a) and a.is_cuda and a.dtype == b.dtype))
+        for a, b, add in pairs)
+    if not ok:
+        return [plain(*p) for p in pairs]
+    lib = _lib.load()
+    if _CONCAT_JOB is None:
+        class _Job(ctypes.Structure):
+            _fields_ = [("a", ctypes.c_void_p), ("na", ctypes.c_int64), ("b", ctypes.c_void_p), ("nb", ctypes.c_int64),
+                        ("out", ctypes.c_void_p), ("elem_size", ctypes.c_int), ("add_b", ctypes.c_int64),
+                        ("fill_a", ctypes.c_float)]
+        _CONCAT_JOB = _Job
+    J, keep, outs = (_CONCAT_JOB * len(pairs))(), [], []
+    for k, (a, b, add) in enumerate(pairs):
+        b = b.reshape(-1).contiguous()
+        if isinstance(a, tuple):
+            na, fill, a = int(a[0]), float(a[1]), None
+        else:
+            a = a.reshape(-1).contiguous()
+            na, fill = a.numel(), 0.0
+        out = torch.empty(na + b.numel(), dtype=b.dtype, device=b.device)
+        J[k].a, J[k].na, J[k].b, J[k].nb = (None if a is None else a.data_ptr()), na, b.data_ptr(), b.numel()
+        J[k].out, J[k].elem_size, J[k].add_b, J[k].fill_a = out.data_ptr(), b.element_size(), int(add or 0), fill
+        keep.append((a, b))
+        outs.append(out)
+    _lib.check(lib.dmp_concat_pairs(J, len(pairs), _lib.stream_ptr()), "dmp_concat_pairs")
+    return outs
+
+
 def union_graphs(a, b):
     """Block-diagonal union of two (batched) graphs: nodes/edges of ``a`` first, then ``b`` with its
     node ids shifted by ``a.number_of_nodes()`` -- ``dgl.batch([a, b])`` semantics on the structure.
@@ -194,16 +239,20 @@ def union_graphs(a, b):
     ops, no BatchNorm), instead of twice.  Carries ``is_reversed`` and cached degrees."""
     from .constants import INDEGREE, OUTDEGREE, REVFLAG
     na = a.number_of_nodes()
-    src = torch.cat([a._src, b._src + na])
-    dst = torch.cat([a._dst, b._dst + na])
-    bnn = torch.cat([a.batch_num_nodes(), b.batch_num_nodes()])
-    bne = torch.cat([a.batch_num_edges(), b.batch_num_edges()])
-    g = BatchedGraph(src, dst, na + b.number_of_nodes(), bnn, bne)
     if (REVFLAG in a.edata) != (REVFLAG in b.edata):
         raise ValueError("union_graphs: is_reversed must be present on both graphs or on neither")
+    pairs = [(a._src, b._src, na), (a._dst, b._dst, na), (a.batch_num_nodes(), b.batch_num_nodes(), 0),
+             (a.batch_num_edges(), b.batch_num_edges(), 0)]
+    extra = []
     if REVFLAG in a.edata:
-        g.edata[REVFLAG] = torch.cat([a.edata[REVFLAG], b.edata[REVFLAG]])
+        extra.append(("e", REVFLAG))
+        pairs.append((a.edata[REVFLAG], b.edata[REVFLAG], 0))
     for k in (INDEGREE, OUTDEGREE):
         if k in a.ndata and k in b.ndata:
-            g.ndata[k] = torch.cat([a.ndata[k], b.ndata[k]])
+            extra.append(("n", k))
+            pairs.append((a.ndata[k], b.ndata[k], 0))
+    out = concat_pairs(pairs)                                # all structure arrays of the union in one launch
+    g = BatchedGraph(out[0], out[1], na + b.number_of_nodes(), out[2], out[3])
+    for (where, k), t in zip(extra, out[4:]):
+        (g.edata if where == "e" else g.ndata)[k] = t
     return g

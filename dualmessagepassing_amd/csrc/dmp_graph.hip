@@ -681,6 +681,30 @@ __global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ 
   for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
 }
 
+// ---- out = [a | b (+ add)] for several array pairs: the structure arrays of the union of two batches
+struct ConcatJobs {
+  dmp_concat_job job[DMP_CONCAT_MAX_JOBS];
+};
+__global__ __launch_bounds__(kBlock) void concat_pairs_k(const ConcatJobs t) {
+  const dmp_concat_job &j = t.job[blockIdx.y];
+  const int64_t n = j.na + j.nb;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const bool first = i < j.na;
+    const int64_t k = first ? i : i - j.na;
+    if (j.elem_size == 8) {
+      const int64_t v = first ? static_cast<const int64_t *>(j.a)[k] : static_cast<const int64_t *>(j.b)[k] + j.add_b;
+      static_cast<int64_t *>(j.out)[i] = v;
+    } else if (j.elem_size == 4) {
+      float v;
+      if (first) v = j.a ? static_cast<const float *>(j.a)[k] : j.fill_a;
+      else v = static_cast<const float *>(j.b)[k];
+      static_cast<float *>(j.out)[i] = v;                   // bit copy for any 4-byte type (no arithmetic on it)
+    } else {
+      static_cast<uint8_t *>(j.out)[i] = first ? static_cast<const uint8_t *>(j.a)[k] : static_cast<const uint8_t *>(j.b)[k];
+    }
+  }
+}
+
 // ---- enc = table[ids] for several small tables (embed.py:199-224): one thread per output element
 struct LookupJobs {
   dmp_lookup_job job[DMP_LOOKUP_MAX_JOBS];
@@ -966,6 +990,29 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes) {
   // int32 words: [cnt 2C | status 1 | pad 1 | tile_off C+1 | segsum | node_base N]
   if (num_nodes < 0 || num_classes < 2) return 0;
   return (size_t)(2 * (int64_t)num_classes + 2 + num_classes + 1 + dmp_class_tiles_segsum_words(num_classes) + num_nodes + 8);
+}
+
+int dmp_concat_pairs(const dmp_concat_job *jobs, int num_jobs, void *stream) {
+  if (num_jobs < 0 || num_jobs > DMP_CONCAT_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  if (num_jobs == 0) return DMP_OK;
+  if (!jobs) return DMP_ERR_BAD_ARG;
+  ConcatJobs t;
+  int64_t most = 0;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_concat_job &j = jobs[i];
+    if (j.na < 0 || j.nb < 0 || (j.elem_size != 1 && j.elem_size != 4 && j.elem_size != 8)) return DMP_ERR_BAD_ARG;
+    if (j.na > 0 && !j.a && j.elem_size != 4) return DMP_ERR_BAD_ARG;
+    if ((j.nb > 0 && !j.b) || (j.na + j.nb > 0 && !j.out)) return DMP_ERR_BAD_ARG;
+    if (j.add_b != 0 && j.elem_size != 8) return DMP_ERR_BAD_ARG;
+    t.job[i] = j;
+    if (j.na + j.nb > most) most = j.na + j.nb;
+  }
+  if (most == 0) return DMP_OK;
+  int64_t nb = (most + kBlock - 1) / kBlock;
+  if (nb > 4096) nb = 4096;
+  concat_pairs_k<<<dim3((unsigned)nb, (unsigned)num_jobs), kBlock, 0, (hipStream_t)stream>>>(t);
+  DMP_HIP_TRY(hipGetLastError());
+  return DMP_OK;
 }
 
 int dmp_table_rows(const dmp_lookup_job *jobs, int num_jobs, void *stream) {

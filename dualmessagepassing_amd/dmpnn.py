@@ -330,9 +330,12 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
     e = _gate_concat(p_e_emb, g_e_emb, e_gate)
     vg = eg = None
-    if v_gate is not None:
+    if v_gate is not None and e_gate is not None:            # ones for the pattern rows, the gates for the target rows
+        from .collate import concat_pairs
+        vg, eg = concat_pairs([((np_, 1.0), v_gate.reshape(-1).to(v.dtype), 0), ((ep_, 1.0), e_gate.reshape(-1).to(e.dtype), 0)])
+    elif v_gate is not None:
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
-    if e_gate is not None:
+    elif e_gate is not None:
         eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
     u = getattr(pattern, "_union_cache", None)
     if u is None or u[0] is not graph:

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 29
+#define DMP_ABI_VERSION 30
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -475,6 +475,24 @@ typedef struct {
   float *out;                       /* [rows, width], dense */
 } dmp_lookup_job;
 int dmp_table_rows(const dmp_lookup_job *jobs, int num_jobs, void *stream);
+
+/*
+ * Several two-way concatenations in one launch (the block-diagonal union of the pattern and target batches,
+ * dgl.batch([a, b]) on the structure arrays: edge endpoints of b shifted by a's node count; the gate vectors of the
+ * union pass: ones for the pattern rows):
+ *   out[0:na] = a (or fill_a when a is NULL, 4-byte elements only),   out[na:na+nb] = b (+ add_b, 8-byte = int64 only)
+ * elem_size in {1, 4, 8}.  The jobs array is a HOST array.
+ */
+#define DMP_CONCAT_MAX_JOBS 12
+typedef struct {
+  const void *a; int64_t na;
+  const void *b; int64_t nb;
+  void *out;
+  int elem_size;
+  int64_t add_b;
+  float fill_a;
+} dmp_concat_job;
+int dmp_concat_pairs(const dmp_concat_job *jobs, int num_jobs, void *stream);
 
 /*
  * Pack n separate fp32 arrays into one flat buffer in one launch (train.py:1231's optimizer and the gradient

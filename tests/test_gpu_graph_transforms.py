@@ -153,3 +153,22 @@ def test_collate_addrev_degrees_batched(gpu):
         sl = slice(2 * eo[i], 2 * eo[i + 1])
         a, b = GO.eigen_bounds(uu[sl] - no[i], vv[sl] - no[i], int(nn[i]))
         assert float(nd[i]) == a and float(ed[i]) == b
+
+
+@pytest.mark.gpu
+def test_concat_pairs_bit_exact(gpu):
+    """dmp_concat_pairs (the structure arrays of a union of two batches in one launch) against torch.cat: int64 with
+    and without the node shift, bool / uint8 flags, int32, fp32 with a constant first block, empty halves."""
+    import torch as th
+    from dualmessagepassing_amd.collate import concat_pairs
+    g = th.Generator().manual_seed(11)
+    ri = lambda n, dt=th.int64: th.randint(0, 1000, (n,), generator=g).to(dt)
+    pairs_cpu = [(ri(24576), ri(524288), 8192), (ri(5), ri(0), 0), (ri(0), ri(7), 3), (ri(1024), ri(1024), 0),
+                 (ri(300) > 500, ri(70001) > 500, 0), (ri(9, th.uint8), ri(11, th.uint8), 0),
+                 (ri(13, th.int32), ri(17, th.int32), 0), ((8192, 1.0), th.rand(65536, generator=g), 0),
+                 (th.rand(3, generator=g), th.rand(5, generator=g), 0)]
+    to = lambda t: t.cuda() if th.is_tensor(t) else t
+    got = concat_pairs([(to(a), to(b), add) for a, b, add in pairs_cpu])
+    want = concat_pairs(pairs_cpu)                               # CPU tensors: the torch.cat path
+    for w, o in zip(want, got):
+        assert o.is_cuda and o.dtype == w.dtype and th.equal(o.cpu(), w)
