@@ -689,9 +689,8 @@ class GraphAdjModelV2(BaseModel):
                 pl = cnt(pm) if counts is None else counts["p" + key]
                 g_lens.append(gl)
                 args.append([sums, pl, gl, float(pm.size(1)), float(gm.size(1)), None] + list(self.pred_net[key].head_params()))
-        if len(args) == 2:
-            g_len = g_lens[0] + g_lens[1]
-            args[0][5], args[1][5] = g_lens[0] / g_len, g_lens[1] / g_len
+        if len(args) == 2:                                   # blend weights g_i_len / (g_v_len + g_e_len): inside the op
+            args[0][5] = args[1][5] = "len"
         flat = [a for head in args for a in head]
         return _PooledHeadsHIP.apply(len(args), *flat), (None, None)
 

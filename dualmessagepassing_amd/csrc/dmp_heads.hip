@@ -299,6 +299,22 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_w_k(const WJobs t) {
   }
 }
 
+struct BlendArgs { const float *y[kMaxHeads]; const float *gl[kMaxHeads]; float *w[kMaxHeads]; float *out; int n, B; };
+__global__ __launch_bounds__(kThreads) void heads_blend_k(const BlendArgs a) {
+  const int b = (int)blockIdx.x * kThreads + threadIdx.x;
+  if (b >= a.B) return;
+  float total = a.gl[0][b];
+  for (int i = 1; i < a.n; ++i) total = total + a.gl[i][b];
+  float out = 0.f;
+  for (int i = 0; i < a.n; ++i) {
+    const float w = a.gl[i][b] / total;
+    a.w[i][b] = w;
+    const float term = __fmul_rn(a.y[i][b], w);             // separate multiply and add, as the op-by-op blend rounds
+    out = i == 0 ? term : __fadd_rn(out, term);
+  }
+  a.out[b] = out;
+}
+
 inline void add_wjob(WJobs &t, int &blocks, const float *dC, int64_t ldc, int nj, const float *row_scale, const float *M,
                      int64_t ldm, int ncols, float *out, int ldo, float *bias, float bscale) {
   WJob &j = t.job[t.n];
@@ -340,6 +356,21 @@ int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_
   for (int i = 0; i < num_heads; ++i) { t.w[i] = w[i]; t.io[i] = io[i]; t.gr[i] = dmp_head_grads{}; }
   t.B = B;
   heads_fwd_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
+  return check_launch();
+}
+
+int dmp_heads_blend(const float *const *y, const float *const *gl, float *const *w, int num_heads, int B, float *out,
+                    void *stream) {
+  if (num_heads < 1 || num_heads > kMaxHeads || B < 0 || !y || !gl || !w) return DMP_ERR_BAD_ARG;
+  if (B == 0) return DMP_OK;
+  if (!out) return DMP_ERR_BAD_ARG;
+  BlendArgs a;
+  for (int i = 0; i < num_heads; ++i) {
+    if (!y[i] || !gl[i] || !w[i]) return DMP_ERR_BAD_ARG;
+    a.y[i] = y[i]; a.gl[i] = gl[i]; a.w[i] = w[i];
+  }
+  a.out = out; a.n = num_heads; a.B = B;
+  heads_blend_k<<<(unsigned)((B + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

@@ -106,10 +106,22 @@ class _PooledHeadsHIP(th.autograd.Function):
             IO[i].ps, IO[i].ld_ps, IO[i].gs, IO[i].ld_gs = sums.data_ptr(), sums.stride(0), sums[B:].data_ptr(), sums.stride(0)
             IO[i].pl, IO[i].gl, IO[i].scale_p, IO[i].scale_g = pl_.data_ptr(), gl_.data_ptr(), float(sp), float(sg)
             IO[i].F, IO[i].Y1S, IO[i].y = F.data_ptr(), Y1S.data_ptr(), y.data_ptr()
-            keep.append((sums, pl_, gl_, F, Y1S, blend.reshape(-1).contiguous().float() if blend is not None else None, prm))
+            keep.append((sums, pl_, gl_, F, Y1S,
+                         blend.reshape(-1).contiguous().float() if th.is_tensor(blend) else None, prm))
             ys.append(y)
         _lib.check(lib.dmp_heads_forward(W, IO, n_heads, B, heads[0][6].size(0), _lib.stream_ptr()), "dmp_heads_forward")
         ctx.keep, ctx.structs, ctx.n, ctx.B, ctx.per = keep, (W, IO), n_heads, B, per
+        if n_heads > 1 and all(isinstance(h[5], str) and h[5] == "len" for h in heads):
+            # blend by the sizes of the target graphs (basemodel.py:1488-1494): weights and blended count in one launch
+            import ctypes
+            ws = [th.empty(B, dtype=th.float32, device=dev) for _ in range(n_heads)]
+            out = th.empty((B, 1), dtype=th.float32, device=dev)
+            Y = (ctypes.c_void_p * n_heads)(*[y.data_ptr() for y in ys])
+            G = (ctypes.c_void_p * n_heads)(*[k[2].data_ptr() for k in keep])
+            Wp_ = (ctypes.c_void_p * n_heads)(*[w_.data_ptr() for w_ in ws])
+            _lib.check(lib.dmp_heads_blend(Y, G, Wp_, n_heads, B, out.data_ptr(), _lib.stream_ptr()), "dmp_heads_blend")
+            ctx.keep = [k[:5] + (w_,) + k[6:] for k, w_ in zip(keep, ws)]
+            return out
         out = None
         for (k, y) in zip(keep, ys):
             term = y if k[5] is None else y * k[5].view(-1, 1)

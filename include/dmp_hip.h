@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 30
+#define DMP_ABI_VERSION 31
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -561,6 +561,16 @@ int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_
                       void *stream);
 int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g,
                        int num_heads, int B, int H, void *stream);
+
+/*
+ * Blend of the heads' counts by the sizes of their target graphs (basemodel.py:1488-1494):
+ *   w_i[b] = gl_i[b] / sum_k gl_k[b],   out[b] = sum_i y_i[b] * w_i[b]   (terms added in head order)
+ * y / gl / w are HOST arrays of num_heads device pointers ([B] each); the weights w_i are written for the backward
+ * (dmp_head_grads.dy_scale).
+ */
+int dmp_heads_blend(const float *const *y, const float *const *gl, float *const *w, int num_heads, int B, float *out,
+                    void *stream);
+
 
 /* ------------------------------------------------------------------------- */
 /* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */
