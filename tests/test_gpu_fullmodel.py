@@ -150,11 +150,12 @@ def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
 
 
 @pytest.mark.parametrize("B", [1, 257, 1024])
-@pytest.mark.parametrize("n_heads", [1, 2])
+@pytest.mark.parametrize("n_heads", [1, 2, -2])
 def test_hip_heads_match_op_by_op(B, n_heads, gpu):
     """pred._PooledHeadsHIP (all heads + blend: one launch forward, two backward) against the op-by-op algebra:
     the blended prediction and every input / parameter gradient."""
     from dualmessagepassing_amd.pred import PRED_NETS, _PooledHeadsHIP
+    by_len, n_heads = n_heads < 0, abs(n_heads)      # -2: the blend weights come out of the op itself (dmp_heads_blend)
     th.manual_seed(7 + B)
     d = h = 128
     nets = [PRED_NETS["SumPredictNet"](d, h, act_func="relu").to(gpu) for _ in range(n_heads)]
@@ -169,7 +170,7 @@ def test_hip_heads_match_op_by_op(B, n_heads, gpu):
     blends = [None] if n_heads == 1 else [gls[0] / (gls[0] + gls[1]), gls[1] / (gls[0] + gls[1])]
     flat = []
     for i, net in enumerate(nets):
-        flat += [sums[i], pls[i], gls[i], Lp, Lg, blends[i]] + list(net.head_params())
+        flat += [sums[i], pls[i], gls[i], Lp, Lg, "len" if by_len else blends[i]] + list(net.head_params())
     y = _PooledHeadsHIP.apply(n_heads, *flat)
 
     ref = 0.0
