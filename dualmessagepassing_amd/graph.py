@@ -53,7 +53,7 @@ class GraphIndex:
         self.num_nodes, self.num_edges, self.device = N, E, dev
         if rev is not None:
             if rev.dtype == torch.bool:
-                rev = rev.to(torch.uint8)
+                rev = rev.contiguous().view(torch.uint8)      # same bytes (0 / 1): no conversion pass
             elif rev.dtype != torch.uint8:
                 raise _lib.DmpError("is_reversed must be bool or uint8")
             rev = rev.contiguous().view(-1)

@@ -93,7 +93,8 @@ class _PooledHeadsHIP(th.autograd.Function):
         W, IO = (Wt * n_heads)(), (IOt * n_heads)()
         keep, ys = [], []
         for i, (sums, pl, gl, sp, sg, blend, Wp, bp, Wg, bg, W1, b1, W2, b2) in enumerate(heads):
-            sums = sums.contiguous()
+            if sums.stride(1) != 1 or sums.stride(0) % 4 or sums.data_ptr() % 16:   # the kernels take any 16-byte-aligned row stride
+                sums = sums.contiguous()
             _lib.require_gpu(sums, Wp)
             h = Wp.size(0)
             prm = [t.detach().contiguous() for t in (Wp, bp, Wg, bg, W1, b1, W2, b2)]
@@ -142,7 +143,7 @@ class _PooledHeadsHIP(th.autograd.Function):
             h = prm[0].size(0)
             dev = sums.device
             scr = th.empty((3, B, h), dtype=th.float32, device=dev)
-            dsums = th.empty_like(sums)
+            dsums = th.empty(sums.shape, dtype=sums.dtype, device=sums.device)
             shapes = [(h, h), (h,), (h, h), (h,), (h, 4 * h + 4), (h,), (1, h + 4), (1,)]
             sizes = [a[0] * (a[1] if len(a) > 1 else 1) for a in shapes]
             offs, tot = [], 0
