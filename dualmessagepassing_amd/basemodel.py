@@ -83,11 +83,10 @@ def scalar_filter_gates(jobs):
     num_labels)`` -- as float ``[rows, 1]`` gates.  Device tensors: three dispatches for all jobs together
     (csrc/dmp_graph.hip::dmp_scalar_filter_gates) instead of nine small torch launches per kind."""
     global _FILTER_JOB
-    if not all(j[1].is_cuda and j[3].is_cuda for j in jobs):
-        return [scalar_filter_gate(*j).float() for j in jobs]
     import ctypes
     from . import _lib
     lib = _lib.load()
+    _lib.require_gpu(*[t for j in jobs for t in (j[1], j[3])])   # no host implementation: device tensors only
     if _FILTER_JOB is None:
         class _Job(ctypes.Structure):
             _fields_ = [("p_seg", ctypes.c_void_p), ("p_label", ctypes.c_void_p), ("num_p", ctypes.c_int64),
@@ -128,17 +127,10 @@ def len_masks(jobs):
     the mask, basemodel.py:1521-1531).  Device tensors: ONE launch for all kinds (csrc/dmp_graph.hip::len_masks_k)
     instead of the arange / compare / masked_fill / sum chain per kind."""
     global _MASK_JOB
-    if not all(p.sizes.is_cuda for p, _ in jobs):
-        out = []
-        for p, rev in jobs:
-            m = p.mask()
-            if rev is not None:
-                m = m.masked_fill(p.pad(rev).view(p.bsz, -1, 1).bool(), 0)
-            out.append((m, m.view(p.bsz, -1).sum(dim=1, dtype=th.float32).view(-1, 1)))
-        return out
     import ctypes
     from . import _lib
     lib = _lib.load()
+    _lib.require_gpu(*[p.sizes for p, _ in jobs])            # no host implementation: device tensors only
     if _MASK_JOB is None:
         class _Job(ctypes.Structure):
             _fields_ = [("sizes", ctypes.c_void_p), ("off", ctypes.c_void_p), ("max_len", ctypes.c_int64),

@@ -259,6 +259,16 @@ def test_len_masks_match_torch_chain(ragged, rev_dtype, gpu):
     """dmp_len_masks (all element kinds in one launch) against the arange / compare / masked_fill / sum chain
     (utils/dl.py:113-127 pre-padding masks; basemodel.py:1521-1531 reversed edges leave the edge masks)."""
     from dualmessagepassing_amd.basemodel import _Padder, len_masks
+
+    def torch_chain(jobs):       # the ops the launch replaces, on the host
+        out = []
+        for p, rev in jobs:
+            m = p.mask()
+            if rev is not None:
+                m = m.masked_fill(p.pad(rev).view(p.bsz, -1, 1).bool(), 0)
+            out.append((m, m.view(p.bsz, -1).sum(dim=1, dtype=th.float32).view(-1, 1)))
+        return out
+
     rng = np.random.default_rng(int(ragged) + 3)
     B = 53
     jobs = {"cpu": [], "cuda": []}
@@ -268,7 +278,9 @@ def test_len_masks_match_torch_chain(ragged, rev_dtype, gpu):
         for dev in ("cpu", "cuda"):
             r = None if rev is None else th.as_tensor(rev).to(rev_dtype).to(dev)
             jobs[dev].append((_Padder(_Sizes(sizes.tolist(), dev), kind), r))
-    want, got = len_masks(jobs["cpu"]), len_masks(jobs["cuda"])
+    want, got = torch_chain(jobs["cpu"]), len_masks(jobs["cuda"])
+    with pytest.raises(Exception):
+        len_masks(jobs["cpu"])                                   # host tensors are refused, not silently computed
     for (wm, wc), (gm, gc) in zip(want, got):
         assert gm.dtype == th.bool and gm.shape == wm.shape and gc.shape == wc.shape and gc.dtype == th.float32
         assert th.equal(gm.cpu(), wm) and th.equal(gc.cpu(), wc)
