@@ -65,6 +65,9 @@ SIGNATURES = {
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_scalar_filter_gates": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_i64, c_ptr]),
+    "dmp_csr_pair_workspace_words": (ctypes.c_size_t, [c_i64]),
+    "dmp_csr_build_pair": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                   c_ptr, c_ptr]),
     "dmp_heads_blend": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "dmp_concat_pairs": (c_int, [c_ptr, c_int, c_ptr]),
     "dmp_table_rows": (c_int, [c_ptr, c_int, c_ptr]),
@@ -105,7 +108,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

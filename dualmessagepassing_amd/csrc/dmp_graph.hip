@@ -151,10 +151,8 @@ __device__ void sift_down(int32_t *a, int start, int end) {
     root = sw;
   }
 }
-__global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restrict__ rowptr, int64_t N,
-                                                        int32_t *__restrict__ ent,
-                                                        int64_t *__restrict__ degree) {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void csr_sort_row(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ ent,
+                                             int64_t *__restrict__ degree, int64_t r) {
   if (r >= N) return;
   const int beg = rowptr[r], end = rowptr[r + 1];
   const int n = end - beg;
@@ -199,6 +197,94 @@ __global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restric
       sift_down(a, 0, e - 1);
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restrict__ rowptr, int64_t N,
+                                                        int32_t *__restrict__ ent,
+                                                        int64_t *__restrict__ degree) {
+  csr_sort_row(rowptr, N, ent, degree, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+}
+
+// ---- both CSRs of a graph (by destination and by source) built side by side: blockIdx.y picks the key array, so the
+// nine dispatches of a build are paid once for the pair
+struct CsrPair {
+  const int64_t *key[2];
+  int32_t *rowptr[2], *ent[2], *key32[2], *cnt[2], *tiles[2];
+  int64_t *degree[2];
+  int32_t *status;                                              // [2]
+};
+__global__ __launch_bounds__(kBlock) void csr_count_pair(const CsrPair p, int64_t E, int64_t N) {
+  const int y = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t k = p.key[y][e];
+  const bool ok = k >= 0 && k < N;
+  if (p.key32[y]) p.key32[y][e] = ok ? (int32_t)k : 0;
+  if (ok) atomicAdd(&p.cnt[y][k], 1);
+  else atomicOr(p.status + y, 1);
+}
+__global__ __launch_bounds__(kBlock) void scan_tiles_pair(const CsrPair p, int64_t n) {
+  __shared__ int32_t lds[kBlock / kWave];
+  const int y = blockIdx.y;
+  const int32_t *__restrict__ in = p.cnt[y];
+  int32_t *__restrict__ out = p.rowptr[y];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int32_t v[kScanItems];
+  int32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    sum += v[k];
+  }
+  int32_t total;
+  int32_t pre = block_exclusive_scan<int32_t>(sum, lds, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = pre;
+    pre += v[k];
+  }
+  if (threadIdx.x == 0) p.tiles[y][blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void scan_tile_sums_pair(const CsrPair p, int64_t ntiles, int64_t n) {
+  __shared__ int32_t lds[kBlock / kWave];
+  const int y = blockIdx.y;
+  int32_t *__restrict__ tile_sum = p.tiles[y];
+  int32_t carry = 0;
+  for (int64_t base = 0; base < ntiles; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const int32_t v = i < ntiles ? tile_sum[i] : 0;
+    int32_t total;
+    const int32_t pre = block_exclusive_scan<int32_t>(v, lds, total);
+    if (i < ntiles) tile_sum[i] = carry + pre;
+    carry += total;
+  }
+  if (threadIdx.x == 0) p.rowptr[y][n] = carry;
+}
+// rowptr += tile offset; the counters become the fill cursors (= rowptr)
+__global__ __launch_bounds__(kBlock) void scan_finish_pair(const CsrPair p, int64_t n) {
+  const int y = blockIdx.y;
+  const int32_t off = p.tiles[y][blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) {
+      const int32_t v = p.rowptr[y][base + k] + off;
+      p.rowptr[y][base + k] = v;
+      p.cnt[y][base + k] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void csr_fill_pair(const CsrPair p, const uint8_t *__restrict__ flag, int64_t E, int64_t N) {
+  const int y = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t k = p.key[y][e];
+  if (k < 0 || k >= N) return;
+  const int pos = atomicAdd(&p.cnt[y][k], 1);
+  p.ent[y][pos] = ((int32_t)e << 1) | (flag ? (flag[e] ? 1 : 0) : 0);
+}
+__global__ __launch_bounds__(kBlock) void csr_sort_rows_pair(const CsrPair p, int64_t N) {
+  const int y = blockIdx.y;
+  csr_sort_row(p.rowptr[y], N, p.ent[y], p.degree[y], (int64_t)blockIdx.x * kBlock + threadIdx.x);
 }
 
 __global__ __launch_bounds__(kBlock) void copy_i32(const int32_t *__restrict__ a, int64_t n,
@@ -790,6 +876,47 @@ size_t dmp_csr_workspace_words(int64_t N, int64_t E) {
   if (N < 0) return 0;
   // cnt/cursor [N] + scan tile sums
   return (size_t)N + (size_t)scan_tiles_for(N) + 8;
+}
+
+size_t dmp_csr_pair_workspace_words(int64_t N) {
+  if (N < 0) return 0;
+  return 2 * ((size_t)N + (size_t)scan_tiles_for(N)) + 8;
+}
+
+int dmp_csr_build_pair(const int64_t *dst, const int64_t *src, const uint8_t *flag, int64_t E, int64_t N,
+                       int32_t *in_ptr, int32_t *in_ent, int32_t *dst32, int64_t *in_deg,
+                       int32_t *out_ptr, int32_t *out_ent, int32_t *src32, int64_t *out_deg,
+                       int32_t *status, int32_t *ws, void *stream) {
+  if (E < 0 || N < 0 || !in_ptr || !out_ptr || !status || !ws) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!dst || !src || !in_ent || !out_ent)) return DMP_ERR_BAD_ARG;
+  if (E >= ((int64_t)1 << 30) || N >= ((int64_t)1 << 31) - 1) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = scan_tiles_for(N);
+  CsrPair p;
+  p.key[0] = dst; p.key[1] = src;
+  p.rowptr[0] = in_ptr; p.rowptr[1] = out_ptr;
+  p.ent[0] = in_ent; p.ent[1] = out_ent;
+  p.key32[0] = dst32; p.key32[1] = src32;
+  p.degree[0] = in_deg; p.degree[1] = out_deg;
+  p.cnt[0] = ws; p.cnt[1] = ws + N;
+  p.tiles[0] = ws + 2 * N; p.tiles[1] = ws + 2 * N + ntiles;
+  p.status = status;
+  DMP_HIP_TRY(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st));
+  if (N == 0) {
+    DMP_HIP_TRY(hipMemsetAsync(in_ptr, 0, sizeof(int32_t), st));
+    DMP_HIP_TRY(hipMemsetAsync(out_ptr, 0, sizeof(int32_t), st));
+    if (E > 0) DMP_HIP_TRY(hipMemsetAsync(status, 0x01, 2 * sizeof(int32_t), st));   // every endpoint is out of range
+    return DMP_OK;
+  }
+  DMP_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int32_t) * (size_t)(2 * N), st));
+  const int64_t nt = (N + kScanTile - 1) / kScanTile;           // tiles in use (the layout keeps one spare per array)
+  if (E > 0) csr_count_pair<<<dim3(nblk(E), 2), kBlock, 0, st>>>(p, E, N);
+  scan_tiles_pair<<<dim3((unsigned)nt, 2), kBlock, 0, st>>>(p, N);
+  scan_tile_sums_pair<<<dim3(1, 2), kBlock, 0, st>>>(p, nt, N);
+  scan_finish_pair<<<dim3((unsigned)nt, 2), kBlock, 0, st>>>(p, N);
+  if (E > 0) csr_fill_pair<<<dim3(nblk(E), 2), kBlock, 0, st>>>(p, flag, E, N);
+  csr_sort_rows_pair<<<dim3(nblk(N), 2), kBlock, 0, st>>>(p, N);
+  return check_launch();
 }
 
 int dmp_csr_build(const int64_t *key, const uint8_t *flag, int64_t E, int64_t N, int32_t *rowptr,

@@ -61,21 +61,21 @@ class GraphIndex:
                 raise _lib.DmpError("is_reversed must have one entry per edge")
         self.rev8 = rev
         i32 = dict(dtype=torch.int32, device=dev)
-        ws = torch.empty(lib.dmp_csr_workspace_words(N, E), **i32)
+        ws = torch.empty(lib.dmp_csr_pair_workspace_words(N), **i32)
         status = torch.empty(2, **i32)
         self.in_ptr = torch.empty(N + 1, **i32)
         self.in_ent = torch.empty(E, **i32)
         self.dst32 = torch.empty(E, **i32)
         self.in_deg = torch.empty(N, dtype=torch.int64, device=dev)
-        st = stream_ptr()
-        check(lib.dmp_csr_build(ptr(dst), ptr(rev), E, N, ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32),
-                                ptr(self.in_deg), ptr(status[0:]), ptr(ws), st), "dmp_csr_build(dst)")
         self.out_ptr = torch.empty(N + 1, **i32)
         self.out_ent = torch.empty(E, **i32)
         self.src32 = torch.empty(E, **i32)
         self.out_deg = torch.empty(N, dtype=torch.int64, device=dev)
-        check(lib.dmp_csr_build(ptr(src), ptr(rev), E, N, ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32),
-                                ptr(self.out_deg), ptr(status[1:]), ptr(ws), st), "dmp_csr_build(src)")
+        # the in-CSR (by destination) and the out-CSR (by source) side by side: one set of dispatches for both
+        check(lib.dmp_csr_build_pair(ptr(dst), ptr(src), ptr(rev), E, N,
+                                     ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32), ptr(self.in_deg),
+                                     ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32), ptr(self.out_deg),
+                                     ptr(status), ptr(ws), stream_ptr()), "dmp_csr_build_pair")
         self._inc = None
         self._coef = {}
         if validate and int(status.sum().item()) != 0:

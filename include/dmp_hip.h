@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 31
+#define DMP_ABI_VERSION 32
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -76,6 +76,18 @@ int dmp_csr_build(const int64_t *key, const uint8_t *flag, int64_t num_edges,
                   int64_t num_nodes, int32_t *rowptr, int32_t *ent,
                   int32_t *key32, int64_t *degree, int32_t *status,
                   int32_t *ws, void *stream);
+
+/*
+ * Both CSRs of a graph -- by destination (in_*) and by source (out_*) -- built side by side: the same arrays two
+ * dmp_csr_build calls produce (rows in ascending edge id, entry = eid << 1 | flag), with the dispatches of a build paid
+ * once for the pair.  status: [2] (bit 0 of status[0] / status[1]: a dst / src endpoint outside [0, N)).
+ * ws: dmp_csr_pair_workspace_words(N) int32 words.
+ */
+size_t dmp_csr_pair_workspace_words(int64_t num_nodes);
+int dmp_csr_build_pair(const int64_t *dst, const int64_t *src, const uint8_t *flag, int64_t num_edges, int64_t num_nodes,
+                       int32_t *in_ptr, int32_t *in_ent, int32_t *dst32, int64_t *in_deg,
+                       int32_t *out_ptr, int32_t *out_ent, int32_t *src32, int64_t *out_deg,
+                       int32_t *status, int32_t *ws, void *stream);
 
 /*
  * Incidence CSR: for node w, its in-edges (flag = is_reversed) followed by its

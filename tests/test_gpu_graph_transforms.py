@@ -172,3 +172,37 @@ def test_concat_pairs_bit_exact(gpu):
     want = concat_pairs(pairs_cpu)                               # CPU tensors: the torch.cat path
     for w, o in zip(want, got):
         assert o.is_cuda and o.dtype == w.dtype and th.equal(o.cpu(), w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,E", [(1, 0), (5, 40), (2049, 30000), (73728, 200001)])
+def test_csr_build_pair_equals_two_builds(N, E, gpu):
+    """dmp_csr_build_pair against two dmp_csr_build calls: identical rowptr / entries / 32-bit keys / degrees / status,
+    including out-of-range endpoints (flagged, skipped)."""
+    import torch as th
+    from dualmessagepassing_amd import _lib
+    lib = _lib.load()
+    g = th.Generator().manual_seed(N + E)
+    src = th.randint(0, N, (E,), generator=g)
+    dst = th.randint(0, N, (E,), generator=g)
+    if E > 10:
+        dst[3], src[7] = N + 5, -1                               # out of range: status bit, no entry
+    flag = (th.rand(E, generator=g) < 0.5).to(th.uint8)
+    src, dst, flag = src.cuda(), dst.cuda(), flag.cuda()
+    i32 = dict(dtype=th.int32, device="cuda")
+    mk = lambda: (th.full((N + 1,), -1, **i32), th.full((E,), -1, **i32), th.full((E,), -1, **i32),
+                  th.full((N,), -1, dtype=th.int64, device="cuda"))
+    P = _lib.ptr
+    single, st1 = [mk(), mk()], th.full((2,), 7, **i32)
+    ws = th.empty(lib.dmp_csr_workspace_words(N, E), **i32)
+    for k, (key, o) in enumerate(zip((dst, src), single)):
+        _lib.check(lib.dmp_csr_build(P(key), P(flag), E, N, P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(st1[k:]), P(ws),
+                                     _lib.stream_ptr()), "dmp_csr_build")
+    pair, st2 = [mk(), mk()], th.full((2,), 7, **i32)
+    ws2 = th.empty(lib.dmp_csr_pair_workspace_words(N), **i32)
+    _lib.check(lib.dmp_csr_build_pair(P(dst), P(src), P(flag), E, N, *[P(t) for t in pair[0]], *[P(t) for t in pair[1]],
+                                      P(st2), P(ws2), _lib.stream_ptr()), "dmp_csr_build_pair")
+    assert th.equal(st1, st2)
+    for a, b in zip(single, pair):
+        valid = int(a[0][N])                                      # entries past the valid ones are never written
+        assert th.equal(a[0], b[0]) and th.equal(a[1][:valid], b[1][:valid]) and th.equal(a[2], b[2]) and th.equal(a[3], b[3])
