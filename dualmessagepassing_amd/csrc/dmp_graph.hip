@@ -301,24 +301,19 @@ __global__ __launch_bounds__(kBlock) void incidence_ptr(const int32_t *__restric
   if (i <= N) inc_ptr[i] = in_ptr[i] + out_ptr[i];
 }
 // one thread per incidence entry: binary search for the owning node
+// one thread per node: its in-entries, then its out-entries (flag bit flipped), in CSR order.  (A thread per entry with a
+// binary search over the row offsets was 17 dependent round trips per entry: 23 us for 1.1 M entries.)
 __global__ __launch_bounds__(kBlock) void incidence_fill(const int32_t *__restrict__ in_ptr,
                                                          const int32_t *__restrict__ in_ent,
                                                          const int32_t *__restrict__ out_ptr,
                                                          const int32_t *__restrict__ out_ent, int64_t N,
                                                          int64_t E2, int32_t *__restrict__ inc_ent) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= E2) return;
-  // largest w with in_ptr[w] + out_ptr[w] <= i
-  int64_t lo = 0, hi = N;  // invariant: ptr[lo] <= i < ptr[hi]
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)in_ptr[mid] + out_ptr[mid] <= i) lo = mid; else hi = mid;
-  }
-  const int64_t w = lo;
-  const int64_t k = i - ((int64_t)in_ptr[w] + out_ptr[w]);
-  const int nin = in_ptr[w + 1] - in_ptr[w];
-  if (k < nin) inc_ent[i] = in_ent[in_ptr[w] + k];
-  else inc_ent[i] = out_ent[out_ptr[w] + (k - nin)] ^ 1;
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= N) return;
+  const int a0 = in_ptr[w], a1 = in_ptr[w + 1], b0 = out_ptr[w], b1 = out_ptr[w + 1];
+  int64_t o = (int64_t)a0 + b0;
+  for (int k = a0; k < a1 && o < E2; ++k) inc_ent[o++] = in_ent[k];
+  for (int k = b0; k < b1 && o < E2; ++k) inc_ent[o++] = out_ent[k] ^ 1;
 }
 
 __global__ __launch_bounds__(kBlock) void degree_coef_k(const int64_t *__restrict__ deg, int64_t N,
@@ -949,7 +944,7 @@ int dmp_incidence_build(const int32_t *in_ptr, const int32_t *in_ent, const int3
   hipStream_t st = (hipStream_t)stream;
   incidence_ptr<<<nblk(N + 1), kBlock, 0, st>>>(in_ptr, out_ptr, N, inc_ptr);
   if (E > 0 && N > 0)
-    incidence_fill<<<nblk(2 * E), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, N, 2 * E, inc_ent);
+    incidence_fill<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, N, 2 * E, inc_ent);
   return check_launch();
 }
 
