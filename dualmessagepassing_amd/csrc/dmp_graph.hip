@@ -335,26 +335,47 @@ __device__ __forceinline__ int64_t upper_graph(const int64_t *off, int64_t B, in
   }
   return lo;
 }
-__global__ __launch_bounds__(kBlock) void collate_edges(const int64_t *__restrict__ ls,
-                                                        const int64_t *__restrict__ ld,
-                                                        const int64_t *__restrict__ node_off,
-                                                        const int64_t *__restrict__ edge_off, int64_t B,
-                                                        int64_t E, int64_t *__restrict__ src,
-                                                        int64_t *__restrict__ dst,
-                                                        int32_t *__restrict__ edge_graph) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= E) return;
-  const int64_t g = upper_graph(edge_off, B, e);
-  const int64_t o = node_off[g];
-  src[e] = ls[e] + o;
-  dst[e] = ld[e] + o;
-  if (edge_graph) edge_graph[e] = (int32_t)g;
+// node and edge offsets in one launch (blockIdx.y: 0 = nodes, 1 = edges; B <= one scan tile), then the edge and the
+// node pass in one launch: four dispatches of a collate become two
+__global__ __launch_bounds__(kBlock) void collate_offsets(const int64_t *__restrict__ num_nodes, const int64_t *__restrict__ num_edges,
+                                                          int64_t B, int64_t *__restrict__ node_off, int64_t *__restrict__ edge_off) {
+  __shared__ int64_t lds[kBlock / kWave];
+  const int64_t *__restrict__ in = blockIdx.y == 0 ? num_nodes : num_edges;
+  int64_t *__restrict__ out = blockIdx.y == 0 ? node_off : edge_off;
+  const int64_t base = (int64_t)threadIdx.x * kScanItems;
+  int64_t v[kScanItems];
+  int64_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < B) ? in[base + k] : 0;
+    sum += v[k];
+  }
+  int64_t total;
+  int64_t pre = block_exclusive_scan<int64_t>(sum, lds, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < B) out[base + k] = pre;
+    pre += v[k];
+  }
+  if (threadIdx.x == 0) out[B] = total;
 }
-__global__ __launch_bounds__(kBlock) void collate_nodes(const int64_t *__restrict__ node_off, int64_t B,
-                                                        int64_t N, int32_t *__restrict__ node_graph) {
-  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (v >= N) return;
-  node_graph[v] = (int32_t)upper_graph(node_off, B, v);
+__global__ __launch_bounds__(kBlock) void collate_both(const int64_t *__restrict__ ls, const int64_t *__restrict__ ld,
+                                                       const int64_t *__restrict__ node_off, const int64_t *__restrict__ edge_off,
+                                                       int64_t B, int64_t E, int64_t N, int64_t *__restrict__ src,
+                                                       int64_t *__restrict__ dst, int32_t *__restrict__ edge_graph,
+                                                       int32_t *__restrict__ node_graph) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.y == 0) {
+    if (i >= E) return;
+    const int64_t g = upper_graph(edge_off, B, i);
+    const int64_t o = node_off[g];
+    src[i] = ls[i] + o;
+    dst[i] = ld[i] + o;
+    if (edge_graph) edge_graph[i] = (int32_t)g;
+  } else {
+    if (i >= N || !node_graph) return;
+    node_graph[i] = (int32_t)upper_graph(node_off, B, i);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void add_rev_k(
@@ -981,11 +1002,13 @@ int dmp_collate(const int64_t *local_src, const int64_t *local_dst, const int64_
     return DMP_OK;
   }
   // B <= 2048: one tile each; the tile total lands in off[B] twice (harmless)
-  scan_tiles<int64_t, int64_t><<<1, kBlock, 0, st>>>(num_nodes, B, node_off, node_off + B);
-  scan_tiles<int64_t, int64_t><<<1, kBlock, 0, st>>>(num_edges, B, edge_off, edge_off + B);
-  if (E > 0)
-    collate_edges<<<nblk(E), kBlock, 0, st>>>(local_src, local_dst, node_off, edge_off, B, E, src, dst, edge_graph);
-  if (node_graph && N > 0) collate_nodes<<<nblk(N), kBlock, 0, st>>>(node_off, B, N, node_graph);
+  collate_offsets<<<dim3(1, 2), kBlock, 0, st>>>(num_nodes, num_edges, B, node_off, edge_off);
+  const bool nodes = node_graph && N > 0;
+  if (E > 0 || nodes) {
+    const int64_t most = (nodes && N > E) ? N : (E > 0 ? E : N);
+    collate_both<<<dim3(nblk(most), nodes ? 2 : 1), kBlock, 0, st>>>(local_src, local_dst, node_off, edge_off, B, E, N, src, dst,
+                                                                   edge_graph, node_graph);
+  }
   return check_launch();
 }
 
