@@ -88,7 +88,7 @@ def make_shard(cfg, rank, device):
                    "is_reversed": torch.from_numpy(rev).to(device)},
             num_nodes=torch.full((B,), n, dtype=torch.int64, device=device),
             num_edges=torch.full((B,), 2 * m, dtype=torch.int64, device=device),
-            N=B * n, E=B * 2 * m)
+            N=B * n, E=B * 2 * m, max_n=n, max_e=2 * m)   # host-side sizes a dataset knows
     g = torch.Generator(device="cpu").manual_seed(1000 * cfg["config_id"] + rank)
     out["counts"] = torch.randint(0, 64, (B,), generator=g).float().to(device)
     return out
@@ -122,10 +122,15 @@ def build_step(cfg, shard, device):
     def step():
         sync.detach_grads()
         p, g = shard["p"], shard["g"]
-        pattern = collate_device(p["local_src"], p["local_dst"], p["num_nodes"], p["num_edges"], p["N"], p["E"],
-                                 ndata=p["ndata"], edata=p["edata"])
-        graph = collate_device(g["local_src"], g["local_dst"], g["num_nodes"], g["num_edges"], g["N"], g["E"],
-                               ndata=g["ndata"], edata=g["edata"])
+        # a loader hands over NEW size / flag tensors with every batch: nothing derived from them (padding maps,
+        # pooling indexes, CSR, degree classes) may be carried over from the previous step
+        fresh = lambda d: (d["num_nodes"].clone(), d["num_edges"].clone(), dict(d["edata"], is_reversed=d["edata"]["is_reversed"].clone()))
+        pn, pe, ped = fresh(p)
+        gn, ge, ged = fresh(g)
+        pattern = collate_device(p["local_src"], p["local_dst"], pn, pe, p["N"], p["E"], ndata=p["ndata"], edata=ped,
+                                 max_nodes=p["max_n"], max_edges=p["max_e"])
+        graph = collate_device(g["local_src"], g["local_dst"], gn, ge, g["N"], g["E"], ndata=g["ndata"], edata=ged,
+                               max_nodes=g["max_n"], max_edges=g["max_e"])
         out = model(pattern, graph)
         loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])  # count loss (train.py:624-628)
         loss.backward()

@@ -169,11 +169,48 @@ def stream_ptr():
 
 
 def require_gpu(*tensors):
+    """Every tensor of a launch must live on the GPU that is CURRENT: the library launches on the current device's
+    stream (``stream_ptr``) and never switches devices itself, so a tensor of another GPU would be handed to the wrong
+    device's stream.  Module ``forward``s enter the device of their inputs (``on_input_device``); anything that reaches
+    an op with a foreign tensor raises here instead of faulting on the GPU."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise DmpError(
                 "dualmessagepassing_amd ops run on an AMD GPU only (tensor on %s); "
                 "there is no CPU fallback in the product path" % (t.device,))
+        if cur is None:
+            import torch
+            cur = torch._C._cuda_getDevice()
+        if t.device.index != cur:
+            raise DmpError("tensor on %s but the current device is cuda:%d: launches go to the current device's stream "
+                           "(use torch.cuda.set_device / `with torch.cuda.device(...)`)" % (t.device, cur))
+
+
+def _first_cuda_index(objs):
+    for o in objs:
+        dev = getattr(o, "device", None)          # tensors and graph objects both carry one
+        if dev is not None and getattr(dev, "type", None) == "cuda":
+            return dev.index
+    return None
+
+
+def on_input_device(fn):
+    """Decorator for module ``forward``s: run with the GPU of the first CUDA tensor / graph argument as the current
+    device (the autograd engine does the same for the backward of what was recorded)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kw):
+        import torch
+        idx = _first_cuda_index(args) if args else None
+        if idx is None or idx == torch._C._cuda_getDevice():
+            return fn(self, *args, **kw)
+        with torch.cuda.device(idx):
+            return fn(self, *args, **kw)
+    return wrapped
 
 
 # ----------------------------------------------------------------------------- per-launch timing

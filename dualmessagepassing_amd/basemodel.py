@@ -8,7 +8,7 @@ constructor keywords, sub-module names (hence ``state_dict`` keys) and ``forward
 
 The reference's per-sample Python loops (``utils/dl.py:51-81,113-127``, ``basemodel.py:1411,1421``)
 are replaced by index arithmetic on the device; uniform-size batches take the same reshape fast
-paths as the reference.  ``model.expand()`` (vocabulary growth for fine-tuning) is not provided.
+paths as the reference.  ``model.expand(**config)`` grows the vocabulary-dependent parts for fine-tuning.
 """
 from collections import OrderedDict
 
@@ -16,8 +16,10 @@ import torch as th
 import torch.nn as nn
 
 from . import ops
+from ._lib import on_input_device
 from .compgcn import CompGCNRepMixin
 from .constants import REVFLAG
+from .graph import as_batched
 from .dmpnn import DMPNNRepMixin
 from .embed import (EquivariantEmbedding, MultihotEmbedding, NormalEmbedding, OrthogonalEmbedding,
                     PositionEmbedding, UniformEmbedding, get_enc_len, lookup_rows)
@@ -181,7 +183,9 @@ class _Padder:
     def __init__(self, graph, kind):
         self.seg, self.sizes = _segments(graph, kind)
         self.bsz = int(self.sizes.numel())
-        self.max = _max_len(self.sizes)
+        # the padded length: from the collate when the dataset supplied it (host int), else one device round trip
+        hint = getattr(graph, "max_num_nodes" if kind == "node" else "max_num_edges", None)
+        self.max = int(hint) if hint is not None else _max_len(self.sizes)
         n = int(self.seg.numel())
         self.uniform = self.bsz * self.max == n
         if not self.uniform:
@@ -238,7 +242,9 @@ def _pool_index(graph, kind):
     else:
         sizes, flag = graph.batch_num_edges(), graph.edata.get(REVFLAG)
     # the cached object keeps its source tensors alive, so a data_ptr cannot be recycled under it
-    return _memo(("pool", _tensor_key(sizes), _tensor_key(flag)), lambda: _Keep(ops.PoolIndex(sizes, flag), sizes, flag)).obj
+    rows = graph.number_of_nodes() if kind == "node" else graph.number_of_edges()      # host ints: no sync in the build
+    return _memo(("pool", _tensor_key(sizes), _tensor_key(flag)),
+                 lambda: _Keep(ops.PoolIndex(sizes, flag, num_rows=rows), sizes, flag)).obj
 
 
 def _pool_index_union(pattern, graph, kind):
@@ -249,9 +255,12 @@ def _pool_index_union(pattern, graph, kind):
         a, b = pattern.batch_num_edges(), graph.batch_num_edges()
         fa, fb = pattern.edata.get(REVFLAG), graph.edata.get(REVFLAG)
 
+    rows = (pattern.number_of_nodes() + graph.number_of_nodes() if kind == "node"
+            else pattern.number_of_edges() + graph.number_of_edges())                     # host ints: no sync in the build
+
     def build():
         flag = None if fa is None or fb is None else th.cat([fa.view(-1), fb.view(-1)])
-        return _Keep(ops.PoolIndex(th.cat([a, b]), flag), a, b, fa, fb)
+        return _Keep(ops.PoolIndex(th.cat([a, b]), flag, num_rows=rows), a, b, fa, fb)
     return _memo(("upool", _tensor_key(a), _tensor_key(b), _tensor_key(fa), _tensor_key(fb)), build).obj
 
 
@@ -458,7 +467,9 @@ class GraphAdjModel(BaseModel):
         v_pred_c, v_pred_w = self.pred_net(p_v_rep, p_v_mask, g_v_rep, g_v_mask)
         return v_pred_c, (v_pred_w, None)
 
+    @on_input_device
     def forward(self, pattern, graph):  # basemodel.py:877-962
+        pattern, graph = as_batched(pattern), as_batched(graph)   # DGLGraph-in (train.py:606-611)
         bsz = pattern.batch_size
         pv, gv = _padder(pattern, "node"), _padder(graph, "node")
         p_v_mask, g_v_mask = pv.mask(), gv.mask()
@@ -708,7 +719,9 @@ class GraphAdjModelV2(BaseModel):
         raise ValueError
 
     # ---- forward (basemodel.py:1500-1663)
+    @on_input_device
     def forward(self, pattern, graph):
+        pattern, graph = as_batched(pattern), as_batched(graph)   # DGLGraph-in (train.py:606-611)
         bsz = pattern.batch_size
         pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"),
                 "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}

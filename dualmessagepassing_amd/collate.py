@@ -14,11 +14,13 @@ from .graph import BatchedGraph
 
 
 def collate_device(local_src, local_dst, num_nodes, num_edges, total_nodes, total_edges, ndata=None,
-                   edata=None, with_segments=True):
+                   edata=None, with_segments=True, max_nodes=None, max_edges=None):
     """Device collate of per-graph LOCAL edge lists laid out back to back.
 
     local_src/local_dst [E] int64 (device), num_nodes/num_edges [B] int64 (device);
     total_nodes/total_edges are host ints (the dataset knows them; no device sync here).
+    max_nodes/max_edges (optional host ints): the largest graph of the batch, which the dataset also
+    knows -- the model's padding helpers then need no ``sizes.max().item()`` round trip per batch.
     Returns a BatchedGraph with global endpoints, ``batch_num_nodes/edges`` and, if
     ``with_segments``, ``node_graph`` / ``edge_graph`` (owning graph per node / edge).
     """
@@ -45,6 +47,8 @@ def collate_device(local_src, local_dst, num_nodes, num_edges, total_nodes, tota
     g = BatchedGraph(src, dst, N, num_nodes, num_edges, ndata, edata)
     g.node_graph, g.edge_graph = ng, eg
     g.node_offsets, g.edge_offsets = node_off, edge_off
+    g.max_num_nodes = None if max_nodes is None else int(max_nodes)
+    g.max_num_edges = None if max_edges is None else int(max_edges)
     return g
 
 
@@ -64,7 +68,8 @@ def batch(graphs, device=None):
     edata = {k: torch.cat([g.edata[k] for g in graphs], 0).to(dev) for k in graphs[0].edata}
     nn = torch.tensor(nn_host, dtype=torch.int64).to(dev)
     ne = torch.tensor(ne_host, dtype=torch.int64).to(dev)
-    return collate_device(ls, ld, nn, ne, sum(nn_host), sum(ne_host), ndata, edata)
+    return collate_device(ls, ld, nn, ne, sum(nn_host), sum(ne_host), ndata, edata,
+                          max_nodes=max(nn_host), max_edges=max(ne_host))
 
 
 def _offsets(sizes):

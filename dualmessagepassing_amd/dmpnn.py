@@ -25,13 +25,14 @@ import torch as th
 import torch.nn as nn
 
 from . import ops
+from ._lib import on_input_device
 from .act import init_module, init_weight, map_activation_str_to_layer
-from .constants import (EDGEFEAT, NODEAGG, NODEFEAT, OUTDEGREE, REVFLAG)
-from .graph import BatchedGraph
+from .constants import (EDGEAGG, EDGEFEAT, NODEAGG, NODEFEAT, OUTDEGREE, REVFLAG)
+from .graph import BatchedGraph, as_batched
 
 
 def dual_message_passing(graph, x, z, in_weight, out_weight, src_weight, dst_weight, nloop_weight, eloop_weight,
-                         nbias, ebias, has_rev, edge_norm=None):
+                         nbias, ebias, has_rev, edge_norm=None, edge_msg_out=None):
     """The linear part of one dual-message-passing layer (dmpnn.py:111-151; UNC model.py:222-257):
     returns ``(node_pre [N,H], edge_pre [E,H], node_agg [N,H])`` with
 
@@ -40,6 +41,8 @@ def dual_message_passing(graph, x, z, in_weight, out_weight, src_weight, dst_wei
         edge_msg = r_e ? X[src] W_dst - X[dst] W_src : X[dst] W_dst - X[src] W_src
 
     ``edge_norm`` [E] or [E,1]: per-edge scale n_e of the node messages (UNC only).
+    ``edge_msg_out``: a dict that receives ``edge_msg`` [E,H] under EDGEAGG -- the reference leaves it in
+    ``edata["edge_agg"]`` as a side effect nobody reads (dmpnn.py:126); materialised only on request.
     Two HIP kernels (seg_sum2 / edge_combine) + four GEMMs."""
     ix = graph.index()
     coef = ix.degree_coef(graph.ndata[OUTDEGREE])
@@ -57,6 +60,14 @@ def dual_message_passing(graph, x, z, in_weight, out_weight, src_weight, dst_wei
         node_pre = node_pre + nbias
     gm = ops.matmul_xw(z, th.cat([eloop_weight, src_weight - dst_weight], dim=1))
     edge_pre = ops.edge_combine(gm, xp[:, h:], ebias, coef, ix)
+    if edge_msg_out is not None:
+        with th.no_grad():
+            u, v = graph.all_edges(form="uv", order="eid")
+            pd, ps = xp[:, h:2 * h], xp[:, 2 * h:]
+            fwd = pd[v] - ps[u]
+            if has_rev:
+                fwd = th.where(graph.edata[REVFLAG].view(-1, 1).bool(), pd[u] - ps[v], fwd)
+            edge_msg_out[EDGEAGG] = fwd
     return node_pre, edge_pre, agg
 
 
@@ -94,6 +105,9 @@ class DMPLayer(nn.Module):
         self.emlp = self._make_mlp(hidden_dim, num_mlp_layers, batch_norm, act_func)
         self.act = map_activation_str_to_layer(act_func)
         self.drop = nn.Dropout(dropout)
+        # edata["edge_agg"] (the [E,H] edge message the reference's UDF leaves behind, dmpnn.py:126) is written
+        # only when asked for: no caller reads it, and it is one more [E,H] tensor per layer
+        self.write_edge_agg = False
 
         # dmpnn.py:64-75
         for w in (self.in_weight, self.out_weight, self.src_weight, self.dst_weight,
@@ -128,11 +142,9 @@ class DMPLayer(nn.Module):
                 mods.append(map_activation_str_to_layer(act_func))
         return nn.Sequential(*mods)
 
+    @on_input_device
     def forward(self, graph, node_feat, edge_feat):
-        if not isinstance(graph, BatchedGraph):
-            raise TypeError("DMPLayer expects a dualmessagepassing_amd BatchedGraph "
-                            "(see collate.from_dgl for DGLGraph inputs)")
-        g = graph
+        g = as_batched(graph)   # DGLGraph-in (dmpnn.py:158): any graph object with the DGL surface, frames shared
         # _node_init_func / _edge_init_func (dmpnn.py:96-109)
         if node_feat is not None:
             g.ndata[NODEFEAT] = node_feat
@@ -143,7 +155,8 @@ class DMPLayer(nn.Module):
         x, z = g.ndata[NODEFEAT], g.edata[EDGEFEAT]
         node_pre, edge_pre, agg = dual_message_passing(
             g, x, z, self.in_weight, self.out_weight, self.src_weight, self.dst_weight, self.nloop_weight,
-            self.eloop_weight, self.nbias, self.ebias, has_rev=REVFLAG in g.edata)
+            self.eloop_weight, self.nbias, self.ebias, has_rev=REVFLAG in g.edata,
+            edge_msg_out=g.edata if self.write_edge_agg else None)
         g.ndata[NODEAGG] = agg
         # _node_update_func / _edge_update_func tails (dmpnn.py:135-140,151-156)
         out = ops.apply_mlp(self.nmlp, node_pre) if len(self.nmlp) > 0 else self.act(node_pre)
@@ -156,7 +169,7 @@ class DMPLayer(nn.Module):
     # ---- single-node fused path (fused.py): layer + gate + residual in one autograd node
     def fused_ok(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None):
         """True when the hand-orchestrated fused path computes exactly this layer's function."""
-        if not (isinstance(graph, BatchedGraph) and REVFLAG in graph.edata):
+        if not (hasattr(graph, "edata") and REVFLAG in graph.edata):
             return False
         if self.input_dim != self.hidden_dim or self.hidden_dim % 4 != 0 or self.nbias is None:
             return False
@@ -174,12 +187,13 @@ class DMPLayer(nn.Module):
                 return False
         return True
 
+    @on_input_device
     def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
         from . import fused
-        g = graph
+        g = as_batched(graph)
         g.ndata[NODEFEAT] = node_feat
         if OUTDEGREE not in g.ndata:
             g.ndata[OUTDEGREE] = g.out_degrees()
@@ -322,8 +336,7 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     layers = list(model.g_rep_net[model.rep_key])
     if not layers or not all(hasattr(l, "fused_ok") for l in layers):
         return None
-    if not (isinstance(pattern, BatchedGraph) and isinstance(graph, BatchedGraph)):
-        return None
+    pattern, graph = as_batched(pattern), as_batched(graph)
     if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
         return None
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
@@ -442,6 +455,7 @@ class DMPNNRep(DMPNNRepMixin, nn.Module):
         self.g_rep_net = self.create_rep_net(type="graph", **kw)
         self.p_rep_net = self.create_rep_net(type="pattern", **kw)
 
+    @on_input_device
     def forward(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
         joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
         if joint is not None:

@@ -91,24 +91,50 @@ class FlatGradSync:
         if views is None:                                    # the slices never change: built once
             views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
             self._views = views
-        dst, src, which, missing = [], [], [], False
+        dst, src, which, missing, live = [], [], [], False, []
         for i, (p, v) in enumerate(zip(self.params, views)):
             g = p.grad
             if g is None:
                 missing = True
-            elif g is not v:
-                dst.append(v)
-                src.append(g)
-                which.append(i)
+            else:
+                live.append(i)
+                if g is not v:
+                    dst.append(v)
+                    src.append(g)
+                    which.append(i)
             p.grad = v
         if missing:                                          # parameters without a gradient this step keep zeros
             self.flat.zero_()
+        self._note_live(live if missing else None)
         if not dst:
             return
         if self.flat.is_cuda and self.flat.dtype == torch.float32 and all(g.dtype == torch.float32 for g in src):
             self._pack_hip(src, which)                       # one launch (csrc/dmp_fused.hip::pack_segments_kernel)
         else:
             torch._foreach_copy_(dst, src)
+
+    def _note_live(self, live):
+        """torch.optim.AdamW (the reference's optimizer, train.py:1231) skips parameters whose ``.grad`` is None: no weight
+        decay, no moment update.  The flat optimizer sees one parameter; it is told which contiguous runs of the buffer
+        belong to parameters that received a gradient this step (None = all of it)."""
+        master = getattr(self, "master", None)
+        if master is None:
+            return
+        if live is None:
+            master._dmp_live_runs = None
+            return
+        key = tuple(live)
+        cached = getattr(self, "_live_cache", None)
+        if cached is None or cached[0] != key:
+            runs = []
+            for i in live:
+                off, n = self.offsets[i], (self.params[i].numel() + 3) // 4 * 4
+                if runs and runs[-1][0] + runs[-1][1] == off:
+                    runs[-1][1] += n
+                else:
+                    runs.append([off, n])
+            cached = self._live_cache = (key, [(a, b) for a, b in runs])
+        master._dmp_live_runs = cached[1]
 
     def _pack_hip(self, src, which):
         import ctypes
@@ -183,8 +209,14 @@ class FlatAdamW(torch.optim.Optimizer):
                     if group["amsgrad"]:
                         st["max_exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                _lib.check(lib.dmp_adamw_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                              st["exp_avg_sq"].data_ptr(), _lib.ptr(st.get("max_exp_avg_sq")), p.numel(),
-                                              float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"],
-                                              _lib.stream_ptr()), "dmp_adamw_step")
+                # runs of the buffer whose parameters received a gradient (FlatGradSync.pack); parameters without one
+                # are left untouched like torch.optim.AdamW does (they share the buffer's step count, though)
+                runs = getattr(p, "_dmp_live_runs", None) or [(0, p.numel())]
+                mx = st.get("max_exp_avg_sq")
+                for off, n in runs:
+                    b = 4 * off
+                    _lib.check(lib.dmp_adamw_step(p.data_ptr() + b, p.grad.data_ptr() + b, st["exp_avg"].data_ptr() + b,
+                                                  st["exp_avg_sq"].data_ptr() + b, None if mx is None else mx.data_ptr() + b, n,
+                                                  float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"],
+                                                  _lib.stream_ptr()), "dmp_adamw_step")
         return loss

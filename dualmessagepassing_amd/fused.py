@@ -23,6 +23,8 @@ Eligibility (``DMPLayer.fused_ok``): 2-layer MLPs, ReLU, no BatchNorm, bias, no 
 square weights, H % 4 == 0, ``is_reversed`` present, gates without gradient.  Anything else
 takes the modular path (same kernels, torch autograd in between).
 """
+import threading
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -36,7 +38,17 @@ def _partials(rows, H, dev):
 
 
 MAX_REDUCE_SEGMENTS = 16   # DMP_REDUCE_MAX_SEGMENTS
-_deferred = []             # innermost active ``deferred_reductions`` collector last
+
+
+class _Deferred(threading.local):
+    """Per-thread stack of active ``deferred_reductions`` collectors (autograd runs backward on one worker thread
+    per device: a job must never land in another thread's collector, whose flush is on another stream)."""
+
+    def __init__(self):
+        self.stack = []
+
+
+_deferred = _Deferred()
 
 
 class deferred_reductions:
@@ -46,7 +58,7 @@ class deferred_reductions:
 
     def __enter__(self):
         self.jobs = []
-        _deferred.append(self)
+        _deferred.stack.append(self)
         return self
 
     def flush(self):
@@ -63,7 +75,7 @@ class deferred_reductions:
             check(lib.dmp_reduce_partials_multi(P, S, L, O, n, stream_ptr()), "dmp_reduce_partials_multi")
 
     def __exit__(self, exc_type, exc, tb):
-        _deferred.remove(self)
+        _deferred.stack.remove(self)
         if exc_type is None:
             self.flush()
         return False
@@ -76,8 +88,8 @@ def reduce_partials(partial, out=None, accumulate=False):
     L = partial.numel() // max(S, 1)
     if out is None:
         out = torch.empty(L, dtype=torch.float32, device=partial.device)
-    if _deferred and not accumulate and partial.is_contiguous():
-        _deferred[-1].jobs.append((partial, S, L, out))      # keeps ``partial`` alive until the launch
+    if _deferred.stack and not accumulate and partial.is_contiguous():
+        _deferred.stack[-1].jobs.append((partial, S, L, out))      # keeps ``partial`` alive until the launch
         return out
     check(lib.dmp_reduce_partials(ptr(partial), S, L, ptr(out), int(accumulate), stream_ptr()), "dmp_reduce_partials")
     return out

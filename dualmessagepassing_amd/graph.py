@@ -236,7 +236,7 @@ class BatchedGraph:
     """A block-diagonal batch of directed multigraphs in eid order."""
 
     def __init__(self, src, dst, num_nodes, batch_num_nodes=None, batch_num_edges=None, ndata=None,
-                 edata=None):
+                 edata=None, share_frames=False):
         if src.dtype != torch.int64 or dst.dtype != torch.int64:
             raise ValueError("src/dst must be int64")
         if src.shape != dst.shape or src.dim() != 1:
@@ -245,12 +245,58 @@ class BatchedGraph:
         self._n = int(num_nodes)
         self._bnn = batch_num_nodes
         self._bne = batch_num_edges
-        self.ndata = dict(ndata) if ndata else {}
-        self.edata = dict(edata) if edata else {}
+        if share_frames:   # the caller's own frame objects (``from_graph``): layer side effects land on the caller's graph
+            self.ndata, self.edata = ndata, edata
+        else:
+            self.ndata = dict(ndata) if ndata else {}
+            self.edata = dict(edata) if edata else {}
         self._index = None
         self._index_key = None
         self.node_graph = None  # int32 [N] owning graph of each node (set by collate)
         self.edge_graph = None
+
+    # ---- DGLGraph-in: any graph object with the surface the reference's models touch
+    @classmethod
+    def from_graph(cls, obj):
+        """Adapter for the reference's call convention ``layer(graph: dgl.DGLGraph, ...)`` (dmpnn.py:158-166;
+        train.py:606-611 passes ``dataset.Graph``, dataset.py:1053-1134).  ``obj`` is duck-typed: it needs
+        ``all_edges(form="uv", order="eid")``, ``number_of_nodes()``, ``ndata`` / ``edata`` (mutable mappings
+        of device tensors) and, for batches, ``batch_num_nodes()`` / ``batch_num_edges()``.  The result
+        SHARES the caller's frames, so what the reference's layer leaves on the graph (``ndata["out_deg"]``,
+        ``"node_feat"``, ``"node_agg"``, ``edata["edge_feat"]``, dmpnn.py:96-109) lands on ``obj`` itself.
+        Built once per graph object and edge tensor (the CSR index is cached with it)."""
+        if isinstance(obj, cls):
+            return obj
+        for need in ("all_edges", "number_of_nodes", "ndata", "edata"):
+            if not hasattr(obj, need):
+                raise TypeError("expected a graph with all_edges / number_of_nodes / ndata / edata (DGLGraph surface); "
+                                "got %s" % type(obj).__name__)
+        u, v = obj.all_edges(form="uv", order="eid")
+        cached = getattr(obj, "_dmp_batched", None)
+        if cached is not None and cached[0] is u and cached[1] is v and cached[2]._n == int(obj.number_of_nodes()):
+            return cached[2]
+        if not (torch.is_tensor(u) and torch.is_tensor(v)):
+            raise TypeError("all_edges must return tensors")
+        _lib.require_gpu(u, v)                                    # no CPU path: move the graph first (graph.to(device))
+        src, dst = u.to(torch.int64), v.to(torch.int64)           # DGL idtype int32 graphs: widened once
+        n = int(obj.number_of_nodes())
+        bnn = bne = None
+        if hasattr(obj, "batch_num_nodes") and hasattr(obj, "batch_num_edges"):
+            bnn, bne = obj.batch_num_nodes(), obj.batch_num_edges()
+            bnn = torch.as_tensor(bnn, dtype=torch.int64).to(src.device)
+            bne = torch.as_tensor(bne, dtype=torch.int64).to(src.device)
+            if bnn.numel() <= 1:
+                bnn = bne = None
+        g = cls(src, dst, n, bnn, bne, obj.ndata, obj.edata, share_frames=True)
+        if bnn is not None:   # owning graph per node / edge, as the device collate leaves them (no host sync: sizes are known)
+            ids = torch.arange(bnn.numel(), dtype=torch.int32, device=src.device)
+            g.node_graph = torch.repeat_interleave(ids, bnn, output_size=n)
+            g.edge_graph = torch.repeat_interleave(ids, bne, output_size=int(src.numel()))
+        try:
+            obj._dmp_batched = (u, v, g)
+        except Exception:   # objects with __slots__: converted again on every call
+            pass
+        return g
 
     # ---- sizes
     @property
@@ -355,3 +401,8 @@ class BatchedGraph:
         if self.edge_graph is not None:
             g.edge_graph = self.edge_graph.to(device)
         return g
+
+
+def as_batched(graph):
+    """``BatchedGraph.from_graph`` under the name the layers call at the top of their ``forward``."""
+    return graph if isinstance(graph, BatchedGraph) else BatchedGraph.from_graph(graph)

@@ -150,7 +150,8 @@ class PairDataset:
             out.append(collate_device(cat("src"), cat("dst"), torch.from_numpy(nn_).to(device),
                                       torch.from_numpy(ne_).to(device), int(nn_.sum()), int(ne_.sum()),
                                       ndata={"id": nid, "label": cat("vlabel")},
-                                      edata={"id": cat("eid"), "label": cat("elabel"), "is_reversed": cat("rev", torch.bool)}))
+                                      edata={"id": cat("eid"), "label": cat("elabel"), "is_reversed": cat("rev", torch.bool)},
+                                      max_nodes=int(nn_.max(initial=0)), max_edges=int(ne_.max(initial=0))))
         counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
         weights = (None, None)
         if return_weights:

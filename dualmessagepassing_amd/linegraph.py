@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .constants import EDGEID, NODEID, NODELABEL
-from .graph import BatchedGraph
+from .graph import BatchedGraph, as_batched
 
 
 def _offsets(counts):
@@ -57,8 +57,7 @@ def _candidates(graph):
 
 def convert_to_dual_graph(graph):
     """BatchedGraph (one graph or a batch) -> its directed line graph, same class."""
-    if not isinstance(graph, BatchedGraph):
-        raise TypeError("convert_to_dual_graph expects a BatchedGraph")
+    graph = as_batched(graph)
     lib = _lib.load()
     _lib.require_gpu(graph._src)
     dev = graph.device

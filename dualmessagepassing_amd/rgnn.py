@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib, ops
 from .act import init_weight, map_activation_str_to_layer
 from .constants import EDGETYPE, INDEGREE, INNORM, NODEFEAT, NORM, OUTDEGREE, OUTNORM
-from .graph import GraphIndex
+from .graph import GraphIndex, as_batched
 
 _TYPED_CACHE = OrderedDict()
 _TYPED_CACHE_MAX = 16
@@ -205,7 +205,9 @@ class RGCNLayer(_RelLayer):
                 d = g.ndata[OUTDEGREE].float()
                 g.ndata[OUTNORM] = ((1.0 / (d + add)) if self.self_loop else (1.0 / d).masked_fill_(d == 0, 0.0)).view(-1, 1)
 
+    @_lib.on_input_device
     def forward(self, g, node_feat, edge_type):
+        g = as_batched(g)   # DGLGraph-in (rgcn.py:182)
         if node_feat is not None:
             g.ndata[NODEFEAT] = node_feat
         self._norms(g)
@@ -265,7 +267,9 @@ class RGINLayer(_RelLayer):
         self.drop = nn.Dropout(dropout)
         self._init_rel_weights(act_func)
 
+    @_lib.on_input_device
     def forward(self, g, node_feat, edge_type):
+        g = as_batched(g)   # DGLGraph-in (rgin.py:124)
         if node_feat is not None:
             g.ndata[NODEFEAT] = node_feat
         if edge_type is not None:

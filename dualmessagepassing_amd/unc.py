@@ -18,9 +18,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from ._lib import on_input_device
 from .constants import OUTDEGREE, REVFLAG
 from .dmpnn import dual_message_passing
-from .graph import BatchedGraph
+from .graph import BatchedGraph, as_batched
 from .ops import PoolIndex, seg_pool
 
 
@@ -83,10 +84,9 @@ class DualGraphConv(nn.Module):
             self.dst_weight.data.div_(init_eeigenv)
             self.eloop_weight.data.div_(init_eeigenv)
 
+    @on_input_device
     def forward(self, graph, node_feat, edge_feat, edge_norm=None):
-        if not isinstance(graph, BatchedGraph):
-            raise TypeError("DualGraphConv expects a dualmessagepassing_amd BatchedGraph")
-        g = graph
+        g = as_batched(graph)   # DGLGraph-in (model.py:267): frames shared with the caller's graph
         # _node_init_func / _edge_init_func (model.py:207-221)
         g.ndata["h"] = node_feat
         if OUTDEGREE not in g.ndata:
@@ -195,6 +195,7 @@ class DMPNN(nn.Module):
             act = nn.Tanh() if idx < num_hidden_layers - 1 else None
             self.layers.append(DualGraphConv(in_dim, out_dim, activation=act, dropout=dropout))
 
+    @on_input_device
     def forward(self, g, h, r, norm):
         h = self.node_emb(g, h)
         z = self.rel_emb(g, r)
@@ -246,6 +247,7 @@ class TrainModel(nn.Module):
         r = ops.take_rows_small_table(self.w_relation, triplets[:, 1])
         return torch.sum(s * r * o, dim=1)
 
+    @on_input_device
     def forward(self, g, h, edge_type, edge_norm):
         output = self.model.forward(g, h, edge_type, edge_norm)
         pred = None

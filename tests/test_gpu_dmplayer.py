@@ -52,10 +52,12 @@ def test_dmplayer_matches_reference_golden(path, gpu):
     g.index(validate=True)
     x = _t(d["x"]).to(gpu).requires_grad_(True)
     z = _t(d["z"]).to(gpu).requires_grad_(True)
+    layer.write_edge_agg = True      # the reference's UDF side effect (dmpnn.py:126), opt-in here
     node_out, edge_out = layer(g, x, z)
     _close(node_out, d["node_out"], what="node_out")
     _close(edge_out, d["edge_out"], what="edge_out")
     _close(g.ndata["node_agg"], d["node_agg"], what="node_agg")
+    _close(g.edata["edge_agg"], d["edge_agg"], what="edge_agg")
     ((node_out * _t(d["wn"]).to(gpu)).sum() + (edge_out * _t(d["we"]).to(gpu)).sum()).backward()
     _close(x.grad, d["dx"], what="dx")
     _close(z.grad, d["dz"], what="dz")
