@@ -96,15 +96,18 @@ def make_shard(cfg, rank, device):
 
 def model_config(cfg):
     """The reference's DMPNN training configuration (SubgraphCountingMatching/README.md:72-94,
-    'Complex' command) at BASELINE's hid=128; vocabulary sizes after --add_rev doubling."""
+    'Complex' command) at BASELINE's hid=128; vocabulary sizes after --add_rev doubling.  Activations and
+    embedding kind are the reference's shipped defaults (config.py:242-245,298-301,370-373: leaky_relu with
+    slope 1/5.5 in the rep-net MLPs and the heads, Equivariant embeddings; no README command overrides them);
+    ``--act relu --emb Orthogonal`` reproduces the round-1 line."""
     return dict(max_ngv=cfg["g_nodes"], max_ngvl=cfg["g_labels"], max_nge=2 * cfg["g_edges"], max_ngel=2 * cfg["g_labels"],
                 max_npv=cfg["p_nodes"], max_npvl=cfg["p_labels"], max_npe=2 * cfg["p_edges"], max_npel=2 * cfg["p_labels"],
                 base=2, hid_dim=cfg["hid"], share_emb_net=True, share_enc_net=True, share_rep_net=True,
-                rep_residual=True, enc_net="Multihot", emb_net="Orthogonal", filter_net="ScalarFilter",
+                rep_residual=True, enc_net="Multihot", emb_net=cfg.get("emb", "Equivariant"), filter_net="ScalarFilter",
                 rep_net="DMPNN", rep_num_graph_layers=cfg["layers"], rep_num_pattern_layers=cfg["layers"],
-                rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False, rep_act_func="relu", rep_dropout=0.0,
+                rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False, rep_act_func=cfg.get("act", "leaky_relu"), rep_dropout=0.0,
                 init_neigenv=4.0, init_eeigenv=4.0, pred_net="SumPredictNet", pred_hid_dim=cfg["hid"],
-                pred_act_func="relu", pred_dropout=0.0, node_pred=True, edge_pred=True)
+                pred_act_func=cfg.get("act", "leaky_relu"), pred_dropout=0.0, node_pred=True, edge_pred=True)
 
 
 def build_step(cfg, shard, device):
@@ -188,7 +191,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     B, H, L = 32, cfg["hid"], cfg["layers"]
     rng = np.random.default_rng(7)
     gen = torch.Generator().manual_seed(7)
-    layers = [{k: v.requires_grad_(True) for k, v in O.random_dmp_params(H, H, gen).items()} for _ in range(L)]
+    act = cfg.get("act", "leaky_relu")
+    layers = [{k: v.requires_grad_(True) for k, v in O.random_dmp_params(H, H, gen, act).items()} for _ in range(L)]
     data = {}
     for tag, n, m in (("p", cfg["p_nodes"], cfg["p_edges"]), ("g", cfg["g_nodes"], cfg["g_edges"])):
         u, v = er_local_edges(B, n, m, rng)
@@ -205,8 +209,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     def one():
         ps, pd, pr, pdeg, pv, pe = data["p"]
         gs, gd, gr, gdeg, gv, ge = data["g"]
-        a, b = O.dmpnn_graph_rep(layers, ps, pd, pr, pdeg, pv, pe)
-        c, d = O.dmpnn_graph_rep(layers, gs, gd, gr, gdeg, gv, ge, vg, eg)
+        a, b = O.dmpnn_graph_rep(layers, ps, pd, pr, pdeg, pv, pe, act_func=act)
+        c, d = O.dmpnn_graph_rep(layers, gs, gd, gr, gdeg, gv, ge, vg, eg, act_func=act)
         (a.square().mean() + b.square().mean() + c.square().mean() + d.square().mean()).backward()
 
     one()  # warm-up
@@ -217,7 +221,7 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 50:
             break
-    return {"value": B * n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": B * n / el, "unit": "pairs/s (rep-net stage only)", "cores": cores, "kind": "port",
             "sample": "%d steps of B=%d pairs; rep-net stage only (3-layer pattern + target DMPNN rep-nets with gates/residual, "
                       "same shapes, hid=%d, %d layers, fwd+bwd, fp32; enc/emb/pred heads not included), torch %s CPU, %d threads"
                       % (n, B, H, L, torch.__version__, cores)}
@@ -231,6 +235,10 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG["batch"], help="pairs per GPU")
     ap.add_argument("--workload", type=int, default=2, choices=(2, 4), help="BASELINE config id: 2 = the metric's "
                     "configuration (default, the bench line); 4 = the per-GPU shard of the 8-GPU configuration (size check)")
+    ap.add_argument("--act", default="leaky_relu", choices=("leaky_relu", "relu"), help="rep-net / head activation "
+                    "(leaky_relu = the reference's default, config.py:298-301,370-373)")
+    ap.add_argument("--emb", default="Equivariant", choices=("Equivariant", "Orthogonal", "Normal", "Uniform"),
+                    help="embedding kind (Equivariant = the reference's default, config.py:242-245)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -254,7 +262,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch)
+    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -316,10 +324,11 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
-                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, Orthogonal emb, ScalarFilter, "
-                                   "3 shared DMPLayers, SumPredictNet node+edge heads), hid=%d, fp32"
+                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, ScalarFilter, "
+                                   "3 shared DMPLayers, SumPredictNet node+edge heads), activation %s, hid=%d, fp32; a new batch "
+                                   "(fresh size / flag tensors) every step"
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
-                                      cfg["batch"], H),
+                                      cfg["batch"], cfg["emb"], cfg["act"] + (" (slope 1/5.5)" if cfg["act"] == "leaky_relu" else ""), H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},

@@ -51,13 +51,13 @@ SIGNATURES = {
     "dmp_colsum_partial_rows": (c_i64, [c_i64, c_int]),
     "dmp_gate_residual": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_scale_rows_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
-    "dmp_relu_bwd_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_relu_bwd_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_edge_combine_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_colsum_partials": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr]),
-    "dmp_add_bias_relu": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
-    "dmp_heads_forward": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
-    "dmp_heads_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "dmp_add_bias_relu": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
+    "dmp_heads_forward": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_ptr]),
+    "dmp_heads_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_ptr]),
     "dmp_fold_layers": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_unfold_layers": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_smallk_embed_gate": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
@@ -77,9 +77,9 @@ SIGNATURES = {
                                c_double, c_i64, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
-                                   c_i64, c_int, c_ptr, c_i64, c_ptr]),
+                                   c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_edge_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                                   c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+                                   c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                 c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
@@ -92,14 +92,14 @@ SIGNATURES = {
     "dmp_out_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                   c_i64, c_ptr]),
     "dmp_mfma_partial_rows": (c_i64, [c_i64]),
-    "dmp_bwd_h1_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
+    "dmp_bwd_h1_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr]),
     "dmp_bwd_z_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                                 c_f32, c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_gemm_k128": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_edge_combine": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
-                                 c_int, c_int, c_ptr, c_i64, c_ptr]),
-    "dmp_relu_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
+                                 c_int, c_int, c_f32, c_ptr, c_i64, c_ptr]),
+    "dmp_relu_bwd_g_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64,
                                       c_ptr, c_ptr]),
     "dmp_edge_combine_bwd_g": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_compgcn_agg": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
@@ -108,7 +108,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -695,7 +695,8 @@ class GraphAdjModelV2(BaseModel):
         if len(args) == 2:                                   # blend weights g_i_len / (g_v_len + g_e_len): inside the op
             args[0][5] = args[1][5] = "len"
         flat = [a for head in args for a in head]
-        return _PooledHeadsHIP.apply(len(args), *flat), (None, None)
+        slopes = {self.pred_net[k].act_slope() for k, on in (("v", self.node_pred), ("e", self.edge_pred)) if on}
+        return _PooledHeadsHIP.apply(len(args), slopes.pop(), *flat), (None, None)
 
     def get_subiso_pred_pooled(self, p_v_sum, p_v_mask, p_e_sum, p_e_mask, g_v_sum, g_v_mask, g_e_sum, g_e_mask):
         """``get_subiso_pred`` (basemodel.py:1477-1498) on per-graph sums instead of padded rows."""

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void edge_combine_vec(
     const float *__restrict__ Gm, int64_t ldg, const float *__restrict__ P, int64_t ldp,
     const float *__restrict__ coef, const float *__restrict__ bias,
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
-    const uint8_t *__restrict__ flag, int64_t E, int H, float *__restrict__ Y, int64_t ldy) {
+    const uint8_t *__restrict__ flag, int64_t E, int H, float slope, float *__restrict__ Y, int64_t ldy) {
   constexpr int GPB = kBlock / G;
   const int64_t e0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / G) * R;
   const int lane = threadIdx.x % G;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void edge_combine_vec(
         add4(t, g0[k]);
         add4(t, sub4(pa[k], pb[k]));
         add4(t, bi);
-        if (RELU) t = make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f));
+        if (RELU) t = make_float4(act_fwd(t.x, slope), act_fwd(t.y, slope), act_fwd(t.z, slope), act_fwd(t.w, slope));
         st4(Y + (e0 + k) * ldy + c, t);
       }
     }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void edge_combine_scalar(
     const float *__restrict__ Gm, int64_t ldg, const float *__restrict__ P, int64_t ldp,
     const float *__restrict__ coef, const float *__restrict__ bias,
     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
-    const uint8_t *__restrict__ flag, int64_t E, int H, int relu, float *__restrict__ Y, int64_t ldy) {
+    const uint8_t *__restrict__ flag, int64_t E, int H, int relu, float slope, float *__restrict__ Y, int64_t ldy) {
   const int64_t e = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
   if (e >= E) return;
   const int u = src[e], v = dst[e];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void edge_combine_scalar(
     t += Gm[e * ldg + c];
     t += P[a * ldp + c] - P[b * ldp + H + c];
     if (bias) t += bias[c];
-    if (relu) t = fmaxf(t, 0.f);
+    if (relu) t = act_fwd(t, slope);
     Y[e * ldy + c] = t;
   }
 }
@@ -620,9 +620,10 @@ int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst, const uin
 
 int dmp_edge_combine(const float *Gm, int64_t ldg, const float *P, int64_t ldp, const float *coef,
                      const float *bias, const int32_t *src, const int32_t *dst,
-                     const uint8_t *flag, int64_t E, int H, int relu, float *Y, int64_t ldy,
+                     const uint8_t *flag, int64_t E, int H, int relu, float slope, float *Y, int64_t ldy,
                      void *stream) {
   if (E < 0 || H <= 0 || ldg < 2 * H || ldp < 2 * H || ldy < H) return DMP_ERR_BAD_ARG;
+  if (relu && !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Gm || !P || !coef || !src || !dst || !Y) return DMP_ERR_BAD_ARG;
   if (E >= kMaxRows) return DMP_ERR_UNSUPPORTED;
@@ -630,11 +631,11 @@ int dmp_edge_combine(const float *Gm, int64_t ldg, const float *P, int64_t ldp, 
   if (vec_ok(H, {ldg, ldp, ldy}, {Gm, P, Y, bias})) {
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(E, (kBlock / G) * 2);
-      if (relu) edge_combine_vec<G, 2, true><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
-      else edge_combine_vec<G, 2, false><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, Y, ldy);
+      if (relu) edge_combine_vec<G, 2, true><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, slope, Y, ldy);
+      else edge_combine_vec<G, 2, false><<<nb, kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, slope, Y, ldy);
     });
   } else {
-    edge_combine_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, relu, Y, ldy);
+    edge_combine_scalar<<<blocks_for(E, kBlock / kWave), kBlock, 0, st>>>(Gm, ldg, P, ldp, coef, bias, src, dst, flag, E, H, relu, slope, Y, ldy);
   }
   return check_launch();
 }

@@ -34,4 +34,14 @@ inline int check_launch() {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// The MLP activations of the layers: ReLU (slope 0) or LeakyReLU with negative slope a (the reference's default
+// `leaky_relu`, a = 1/5.5: utils/act.py:27,466; UNC model.py:145-157).  For 0 <= a <= 1:
+//   forward   max(x, a x)            == x > 0 ? x : a x   (torch's formula, one rounding of a x)
+//   backward  y > 0 ? d : a d        on the SAVED OUTPUT y: sign(y) == sign(x) for a > 0, and a == 0 is torch's
+//                                    threshold_backward on the output
+// (a = 0 gives -0.0 where ReLU gives +0.0: equal under ==, invisible to the > 0 masks and to sums.)
+inline bool slope_ok(float a) { return a >= 0.f && a <= 1.f; }
+__device__ __forceinline__ float act_fwd(float x, float a) { return fmaxf(x, a * x); }
+__device__ __forceinline__ float act_bwd(float y, float d, float a) { return y > 0.f ? d : a * d; }
+
 }  // namespace dmp

@@ -39,6 +39,7 @@ struct RowArgs {
   float *out; int64_t ldo;       // output (may be NULL for OP_SCALE_CS without gate / OP_COLSUM)
   float *partial;                // [gridDim.x, H] column-sum partials (NULL for OP_GATE_RES)
   int64_t R; int H;
+  float slope;                   // negative slope of the activation (0 = ReLU): OP_ADD_BIAS_RELU, OP_RELU_BWD_*
 };
 
 template <int G, int OP>
@@ -92,14 +93,14 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           float4 t = x[k];
           add4(t, y[k]);
           add4(t, colv);
-          st4(p.out + r * p.ldo + c, make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)));
+          st4(p.out + r * p.ldo + c, make_float4(act_fwd(t.x, p.slope), act_fwd(t.y, p.slope), act_fwd(t.z, p.slope), act_fwd(t.w, p.slope)));
         } else if (OP == OP_SCALE_CS) {
           float4 t = p.rowscale ? mul4(x[k], sc[k]) : x[k];
           if (p.out) st4(p.out + r * p.ldo + c, t);
           add4(cs, t);
         } else if (OP == OP_RELU_BWD_CS) {
-          float4 t = make_float4(y[k].x > 0.f ? x[k].x : 0.f, y[k].y > 0.f ? x[k].y : 0.f,
-                                 y[k].z > 0.f ? x[k].z : 0.f, y[k].w > 0.f ? x[k].w : 0.f);
+          float4 t = make_float4(act_bwd(y[k].x, x[k].x, p.slope), act_bwd(y[k].y, x[k].y, p.slope),
+                                 act_bwd(y[k].z, x[k].z, p.slope), act_bwd(y[k].w, x[k].w, p.slope));
           st4(p.out + r * p.ldo + c, t);
           add4(cs, t);
         } else if (OP == OP_BWD_G_CS) {
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           st4(p.out + r * p.ldo + p.H + c, mul4(x[k], sc[k]));
           add4(cs, x[k]);
         } else if (OP == OP_RELU_BWD_G_CS) {
-          float4 t = make_float4(y[k].x > 0.f ? x[k].x : 0.f, y[k].y > 0.f ? x[k].y : 0.f,
-                                 y[k].z > 0.f ? x[k].z : 0.f, y[k].w > 0.f ? x[k].w : 0.f);
+          float4 t = make_float4(act_bwd(y[k].x, x[k].x, p.slope), act_bwd(y[k].y, x[k].y, p.slope),
+                                 act_bwd(y[k].z, x[k].z, p.slope), act_bwd(y[k].w, x[k].w, p.slope));
           st4(p.out + r * p.ldo + c, t);
           st4(p.out + r * p.ldo + p.H + c, mul4(t, sc[k]));
           add4(cs, t);
@@ -451,12 +452,13 @@ int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t 
 }
 
 int dmp_add_bias_relu(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias, int64_t R, int H,
-                      float *out, int64_t ldo, void *stream) {
+                      float slope, float *out, int64_t ldo, void *stream) {
   DMP_ROW_CHECK(R >= 0 && H > 0);
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return DMP_OK;
   DMP_ROW_CHECK(a && b && out && lda >= H && ldb >= H && ldo >= H);
   if (!vec_shape_ok(H, lda, ldb, ldo) || !ok16(a) || !ok16(b) || !ok16(out) || !ok16(bias)) return DMP_ERR_UNSUPPORTED;
-  RowArgs p{a, lda, b, ldb, bias, nullptr, out, ldo, nullptr, R, H};
+  RowArgs p{a, lda, b, ldb, bias, nullptr, out, ldo, nullptr, R, H, slope};
   return launch_rowop<OP_ADD_BIAS_RELU>(p, (hipStream_t)stream);
 }
 
@@ -470,13 +472,14 @@ int dmp_scale_rows_colsum(const float *dOut, int64_t ldd, const float *gate, int
   return launch_rowop<OP_SCALE_CS>(p, (hipStream_t)stream);
 }
 
-int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda, int64_t R, int H,
+int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda, int64_t R, int H, float slope,
                         float *dPre, int64_t ldp, float *partial, void *stream) {
   DMP_ROW_CHECK(R >= 0 && H > 0 && partial);
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   DMP_ROW_CHECK(dH && act && dPre && ldh >= H && lda >= H && ldp >= H);
   if (!vec_shape_ok(H, ldh, lda, ldp) || !ok16(dH) || !ok16(act) || !ok16(dPre) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
-  RowArgs p{dH, ldh, act, lda, nullptr, nullptr, dPre, ldp, partial, R, H};
+  RowArgs p{dH, ldh, act, lda, nullptr, nullptr, dPre, ldp, partial, R, H, slope};
   return launch_rowop<OP_RELU_BWD_CS>(p, (hipStream_t)stream);
 }
 
@@ -491,13 +494,14 @@ int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coe
 }
 
 int dmp_relu_bwd_g_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda, const float *coef,
-                          const int32_t *dst, int64_t E, int H, float *dG, int64_t ldg, float *partial,
+                          const int32_t *dst, int64_t E, int H, float slope, float *dG, int64_t ldg, float *partial,
                           void *stream) {
   DMP_ROW_CHECK(E >= 0 && H > 0 && partial);
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   DMP_ROW_CHECK(dH && act && coef && dst && dG && ldh >= H && lda >= H && ldg >= 2 * H);
   if (!vec_shape_ok(H, ldh, lda, ldg) || !ok16(dH) || !ok16(act) || !ok16(dG) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
-  RowArgs p{dH, ldh, act, lda, coef, dst, dG, ldg, partial, E, H};
+  RowArgs p{dH, ldh, act, lda, coef, dst, dG, ldg, partial, E, H, slope};
   return launch_rowop<OP_RELU_BWD_G_CS>(p, (hipStream_t)stream);
 }
 

@@ -24,6 +24,7 @@ struct Heads {
   dmp_head_io io[kMaxHeads];
   dmp_head_grads gr[kMaxHeads];
   int B;
+  float slope;   // negative slope of the heads' activation (0 = ReLU; pred_act_func, pred.py:36)
 };
 
 // acc[8] += A_lds[r][0..127] . op(W)[.., 8 cg ..]   for one 128-wide contraction; W element (j, k) at W[j * ldw + k]
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
   for (int e = 0; e < 8; ++e) {
     const float *wr = w.W1 + (int64_t)(cg * 8 + e) * kF + 4 * kH;
     y1[e] += s4[0] * wr[0] + s4[1] * wr[1] + s4[2] * wr[2] + s4[3] * wr[3];
-    y1[e] = fmaxf(y1[e], 0.f);
+    y1[e] = act_fwd(y1[e], t.slope);
   }
   // y = [y1 | s] W2^T + b2
   float part = 0.f;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float y1 = live ? io.Y1S[(int64_t)b * kYS + cg * 8 + e] : 0.f;
-    d1[e] = y1 > 0.f ? dy * w.W2[cg * 8 + e] : 0.f;
+    d1[e] = act_bwd(y1, dy * w.W2[cg * 8 + e], t.slope);
     As[r * kPad + cg * 8 + e] = d1[e];
   }
   if (live) {
@@ -348,13 +349,14 @@ using namespace dmp;
 
 extern "C" {
 
-int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H, void *stream) {
-  if (H != kH && H > 0) return DMP_ERR_UNSUPPORTED;
+int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H, float slope,
+                      void *stream) {
+  if ((H != kH && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (!heads_valid(w, io, num_heads, B, H)) return DMP_ERR_BAD_ARG;
   if (B == 0) return DMP_OK;
   Heads t;
   for (int i = 0; i < num_heads; ++i) { t.w[i] = w[i]; t.io[i] = io[i]; t.gr[i] = dmp_head_grads{}; }
-  t.B = B;
+  t.B = B; t.slope = slope;
   heads_fwd_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
   return check_launch();
 }
@@ -375,8 +377,8 @@ int dmp_heads_blend(const float *const *y, const float *const *gl, float *const 
 }
 
 int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g, int num_heads, int B,
-                       int H, void *stream) {
-  if (H != kH && H > 0) return DMP_ERR_UNSUPPORTED;
+                       int H, float slope, void *stream) {
+  if ((H != kH && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (!heads_valid(w, io, num_heads, B, H) || !g) return DMP_ERR_BAD_ARG;
   for (int i = 0; i < num_heads; ++i) {
     if (!g[i].dy || !ok16p(g[i].dY1) || !ok16p(g[i].dP) || !ok16p(g[i].dG) || (g[i].dps && (!ok16p(g[i].dps) || g[i].ld_dps % 4)) ||
@@ -396,7 +398,7 @@ int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const d
     add_wjob(wj, blocks, g[i].dG, kH, kH, nullptr, io[i].gs, io[i].ld_gs, kH, g[i].dWg, kH, g[i].dbg, io[i].scale_g);
     add_wjob(wj, blocks, g[i].dy, 1, 1, g[i].dy_scale, io[i].Y1S, kYS, kYS, g[i].dW2, kYS, g[i].db2, 1.0f);
   }
-  t.B = B;
+  t.B = B; t.slope = slope;
   heads_bwd_rows_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
   int rc = check_launch();
   if (rc != DMP_OK) return rc;

@@ -84,6 +84,7 @@ struct MfmaArgs {
   float s0, s1;                     // EPI_DZ: sign / scale of the gathered term by flag
   int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
   int both;                         // EPI_RELU_BWD_G: write [dPre | coef dPre] (rowscale = coef[dst e]) instead of dPre alone
+  float slope;                      // EPI_EDGE / EPI_RELU_BWD_G: negative slope of the activation (0 = ReLU)
 };
 
 template <int NC, int EPI, int PP>
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   if ((EPI == EPI_EDGE || EPI == EPI_GATE_RES) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   // EPI_RELU_BWD_G writes [dPre | coef dPre] when asked for both halves (p.both), dPre only otherwise
   const bool both_halves = EPI == EPI_RELU_BWD_G && p.both != 0;
+  const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
   const int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (both_halves ? 256 : 128);
 
   // whole-array descriptors: per-row arrays and the gathered table
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
         if (DMP_DBG & 2) v = make_float4(acc[q][4 * k], acc[q][4 * k + 1], acc[q][4 * k + 2], acc[q][4 * k + 3]);
         if (EPI == EPI_EDGE) {
           // ((G0 + coef G1) + (P[a] - P[b])) + bias, then ReLU: the reference's order (dmpnn.py:147-152)
-          v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bias4.x, 0.f);
-          v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bias4.y, 0.f);
-          v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bias4.z, 0.f);
-          v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bias4.w, 0.f);
+          v.x = act_fwd((v.x + (g0[k].x - g1[k].x)) + bias4.x, slope);
+          v.y = act_fwd((v.y + (g0[k].y - g1[k].y)) + bias4.y, slope);
+          v.z = act_fwd((v.z + (g0[k].z - g1[k].z)) + bias4.z, slope);
+          v.w = act_fwd((v.w + (g0[k].w - g1[k].w)) + bias4.w, slope);
         } else if (EPI == EPI_DZ) {
           const float sg = rowB[grp][par][rr] ? p.s1 : p.s0;
           v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
@@ -333,8 +335,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
             const float gt = rowS[grp][par][rr];
             v.x *= gt; v.y *= gt; v.z *= gt; v.w *= gt;
           }
-          v.x = g0[k].x > 0.f ? v.x : 0.f; v.y = g0[k].y > 0.f ? v.y : 0.f;
-          v.z = g0[k].z > 0.f ? v.z : 0.f; v.w = g0[k].w > 0.f ? v.w : 0.f;
+          v.x = act_bwd(g0[k].x, v.x, slope); v.y = act_bwd(g0[k].y, v.y, slope);
+          v.z = act_bwd(g0[k].z, v.z, slope); v.w = act_bwd(g0[k].w, v.w, slope);
           colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
           if (both_halves) {
             const float cf = rowS[grp][par][rr];
@@ -527,8 +529,9 @@ int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int 
 
 int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
                        int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
-                       const float *coefE, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
+                       const float *coefE, int64_t E, int H, float slope, float *H1, int64_t ldh, void *stream) {
   if (E < 0 || num_nodes < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Z || !W || !P || !selA || !selB || !coefE || !H1 || ldz < H || ldw < 2 * H || ldp < 2 * H || ldh < H)
     return DMP_ERR_BAD_ARG;
@@ -538,6 +541,7 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   MfmaArgs p{};
   p.A = Z; p.lda = ldz; p.B = W; p.ldb = ldw; p.bt = 0; p.C = H1; p.ldc = ldh; p.E = E; p.ldr = 128;
   p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.idxA = selA; p.idxB = selB; p.rowscale = coefE; p.bias = bias;
+  p.slope = slope;
   return launch_mfma<2, EPI_EDGE>(p, (hipStream_t)stream);
 }
 
@@ -563,9 +567,10 @@ int64_t dmp_mfma_partial_rows(int64_t E) { return g_variant == 1 ? 2 * (int64_t)
 void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
 
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                     const float *coefE, const float *gate, int64_t E, int H, float *dG, int64_t ldg, float *partial,
-                     void *stream) {
+                     const float *coefE, const float *gate, int64_t E, int H, float slope, float *dG, int64_t ldg,
+                     float *partial, void *stream) {
   if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   const bool both = coefE != nullptr;                      // with coefE: dG = [dPre | coefE dPre]; without: dPre alone
   if (!partial || (gate && both)) return DMP_ERR_BAD_ARG;
   if (E == 0)
@@ -578,7 +583,7 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
-  p.both = both; p.partial = partial; p.ldt = 256;
+  p.both = both; p.partial = partial; p.ldt = 256; p.slope = slope;
   return launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 

@@ -34,6 +34,7 @@ struct TypedArgs {
   const float *bias;                    // TEPI_EDGE: [128] or NULL
   const float *R; int64_t ldr;          // TEPI_DZ: upstream gradient rows [E,128] or NULL
   float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
+  float slope;                          // TEPI_EDGE: negative slope of the activation (0 = ReLU)
 };
 
 template <int EPI>
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   const uint32_t colA = (uint32_t)(gtid & 31) * 16u, col4 = (uint32_t)c4 * 4u;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI == TEPI_EDGE && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
+  const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
   const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.E * p.lda * 4));       // all < 4 GiB: checked by the host
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       const int rr = 8 * k + lrow;
       float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
       if (EPI == TEPI_EDGE) {
-        v.x = fmaxf((v.x + (g0[k].x - g1[k].x)) + bias4.x, 0.f);
-        v.y = fmaxf((v.y + (g0[k].y - g1[k].y)) + bias4.y, 0.f);
-        v.z = fmaxf((v.z + (g0[k].z - g1[k].z)) + bias4.z, 0.f);
-        v.w = fmaxf((v.w + (g0[k].w - g1[k].w)) + bias4.w, 0.f);
+        v.x = act_fwd((v.x + (g0[k].x - g1[k].x)) + bias4.x, slope);
+        v.y = act_fwd((v.y + (g0[k].y - g1[k].y)) + bias4.y, slope);
+        v.z = act_fwd((v.z + (g0[k].z - g1[k].z)) + bias4.z, slope);
+        v.w = act_fwd((v.w + (g0[k].w - g1[k].w)) + bias4.w, slope);
       } else {
         const float sg = rowB[par][rr] ? p.s1 : p.s0;
         v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
@@ -321,8 +323,9 @@ extern "C" {
 int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
                        int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
                        const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                       int64_t tiles_bound, int64_t E, int H, float *H1, int64_t ldh, void *stream) {
+                       int64_t tiles_bound, int64_t E, int H, float slope, float *H1, int64_t ldh, void *stream) {
   if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Z || !W || !P || !selA || !selB || !slot_edge || !tile_scale || !num_tiles || !H1 || ldz < H || ldw < 2 * H ||
       ldp < 2 * H || ldh < H)
@@ -333,7 +336,7 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   TypedArgs p{};
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
   p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
-  p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias;
+  p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias; p.slope = slope;
   mfma_typed<TEPI_EDGE><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }

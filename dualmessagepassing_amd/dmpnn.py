@@ -175,10 +175,13 @@ class DMPLayer(nn.Module):
             return False
         if self.drop.p > 0.0 and self.training:
             return False
-        for mlp in (self.nmlp, self.emlp):
-            if len(mlp) != 3 or not isinstance(mlp[0], nn.Linear) or type(mlp[1]) is not nn.ReLU \
+        from .fused import activation_slope
+        for mlp in (self.nmlp, self.emlp):   # Linear -> ReLU | LeakyReLU (the reference's default, config.py:298-301) -> Linear
+            if len(mlp) != 3 or not isinstance(mlp[0], nn.Linear) or activation_slope(mlp[1]) is None \
                     or not isinstance(mlp[2], nn.Linear) or mlp[0].bias is None or mlp[2].bias is None:
                 return False
+        if activation_slope(self.nmlp[1]) != activation_slope(self.emlp[1]):
+            return False
         for t in (node_feat, edge_feat):
             if t is None or not t.is_cuda or t.dtype != th.float32 or t.dim() != 2 or t.size(1) != self.hidden_dim:
                 return False

@@ -105,12 +105,13 @@ def gate_residual(prev, upd, gate):
     return out
 
 
-def add_bias_relu_(a, b, bias):
-    """a <- relu(a + b + bias) in one pass (``b`` may be a column slice of a wider matrix)."""
+def add_bias_relu_(a, b, bias, slope=0.0):
+    """a <- act(a + b + bias) in one pass (``b`` may be a column slice of a wider matrix); act = ReLU, or LeakyReLU
+    with negative slope ``slope``."""
     lib = _lib.load()
     R, H = a.shape
     with _lib.timed("add_bias_relu[H=%d,R=%d]", (H, R), 12 * H * R):
-        check(lib.dmp_add_bias_relu(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), R, H, ptr(a), a.stride(0),
+        check(lib.dmp_add_bias_relu(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), R, H, slope, ptr(a), a.stride(0),
                                     stream_ptr()), "dmp_add_bias_relu")
     return a
 
@@ -127,8 +128,8 @@ def scale_rows_colsum(d_out, gate):
     return (d_upd if gate is not None else d_out), reduce_partials(part)
 
 
-def relu_bwd_colsum_(d_h, act, out=None):
-    """d_h <- act > 0 ? d_h : 0 (in place, or into ``out``: e.g. a column slice of a wider matrix);
+def relu_bwd_colsum_(d_h, act, out=None, slope=0.0):
+    """d_h <- act > 0 ? d_h : slope * d_h (in place, or into ``out``: e.g. a column slice of a wider matrix);
     returns (result, column sums [H])."""
     lib = _lib.load()
     R, H = d_h.shape
@@ -136,7 +137,7 @@ def relu_bwd_colsum_(d_h, act, out=None):
     dst = d_h if out is None else out
     ldo = dst.stride(0) if R > 1 else H
     with _lib.timed("relu_bwd_colsum[H=%d,R=%d]", (H, R), 12 * H * R):
-        check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, ptr(dst), ldo, ptr(part), stream_ptr()),
+        check(lib.dmp_relu_bwd_colsum(ptr(d_h), H, ptr(act), H, R, H, slope, ptr(dst), ldo, ptr(part), stream_ptr()),
               "dmp_relu_bwd_colsum")
     return dst, reduce_partials(part)
 
@@ -177,24 +178,24 @@ def atb(a, b):
     return reduce_partials(part.view(S + tail, -1)).view(a.size(1), b.size(1))
 
 
-def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False):
+def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False, slope=0.0):
     lib = _lib.load()
     E = index.num_edges
     Y = torch.empty((E, H), dtype=torch.float32, device=G.device)
     with _lib.timed("edge_combine[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 9 * E + 4 * index.num_nodes):
         check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(bias), ptr(index.src32), ptr(index.dst32),
-                                   ptr(index.rev8), E, H, int(relu), ptr(Y), H, stream_ptr()), "dmp_edge_combine")
+                                   ptr(index.rev8), E, H, int(relu), slope, ptr(Y), H, stream_ptr()), "dmp_edge_combine")
     return Y
 
 
-def relu_bwd_g_colsum(d_h, act, coef, dst32):
-    """-> (dG = [dPre | coef[dst] dPre] with dPre = act>0 ? d_h : 0,  column sums of dPre)."""
+def relu_bwd_g_colsum(d_h, act, coef, dst32, slope=0.0):
+    """-> (dG = [dPre | coef[dst] dPre] with dPre = act>0 ? d_h : slope d_h,  column sums of dPre)."""
     lib = _lib.load()
     E, H = d_h.shape
     part = _partials(E, H, d_h.device)
     d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_h.device)
     with _lib.timed("relu_bwd_g_colsum[H=%d,E=%d]", (H, E), 16 * H * E + 4 * E + 4 * coef.numel()):
-        check(lib.dmp_relu_bwd_g_colsum(ptr(d_h), H, ptr(act), H, ptr(coef), ptr(dst32), E, H, ptr(d_g), 2 * H,
+        check(lib.dmp_relu_bwd_g_colsum(ptr(d_h), H, ptr(act), H, ptr(coef), ptr(dst32), E, H, slope, ptr(d_g), 2 * H,
                                         ptr(part), stream_ptr()), "dmp_relu_bwd_g_colsum")
     return d_g, reduce_partials(part)
 
@@ -208,8 +209,8 @@ def mfma_ok(index, H):
     return USE_MFMA_KERNELS and H == 128 and index.num_nodes * 3 * H * 4 < 2 ** 32 and index.num_edges * 4 < 2 ** 32
 
 
-def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
-    """relu(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128)."""
+def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index, slope=0.0):
+    """act(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128)."""
     lib = _lib.load()
     E, H = z.shape
     out = torch.empty((E, H), dtype=torch.float32, device=z.device)
@@ -217,7 +218,7 @@ def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index):
     sel_a, sel_b, coef_e = index.edge_select(coef)
     with _lib.timed("edge_fwd_mfma[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_fused(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
-                                     ptr(sel_a), ptr(sel_b), ptr(coef_e), E, H, ptr(out), H, stream_ptr()),
+                                     ptr(sel_a), ptr(sel_b), ptr(coef_e), E, H, slope, ptr(out), H, stream_ptr()),
               "dmp_edge_fwd_fused")
     return out
 
@@ -230,7 +231,7 @@ def typed_ok(index, H):
     return USE_TYPED_KERNELS and mfma_ok(index, H) and index.num_edges * 2 * H * 4 < 2 ** 32 - 8192
 
 
-def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index):
+def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
     """edge_fwd_mfma with W_g = Wes[:, :H] + c_g Wes[:, H:] per degree class: one product instead of two."""
     lib = _lib.load()
     E, H = z.shape
@@ -241,7 +242,7 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index):
     with _lib.timed("edge_fwd_typed[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_typed(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
                                      ptr(sel_a), ptr(sel_b), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound,
-                                     E, H, ptr(out), H, stream_ptr()), "dmp_edge_fwd_typed")
+                                     E, H, slope, ptr(out), H, stream_ptr()), "dmp_edge_fwd_typed")
     return out
 
 
@@ -294,8 +295,8 @@ def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None):
-    """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : 0, column sums of dPre); H=128.
+def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None, slope=0.0):
+    """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : slope (d_o W2), column sums of dPre); H=128.
     ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here.
     ``out`` (dPre alone only): destination [R, H], e.g. a column slice of a wider matrix."""
     lib = _lib.load()
@@ -310,7 +311,7 @@ def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None,
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
         check(lib.dmp_bwd_h1_fused(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
-                                   ptr(gate), E, H, ptr(d_g), d_g.stride(0) if E > 1 else d_g.size(1), ptr(part),
+                                   ptr(gate), E, H, slope, ptr(d_g), d_g.stride(0) if E > 1 else d_g.size(1), ptr(part),
                                    stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
 
@@ -546,7 +547,7 @@ class _FusedDMPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
-                WesT=None, nW2t=None, eW2t=None):
+                WesT=None, nW2t=None, eW2t=None, slope=0.0):
         _lib.require_gpu(x, z)
         H = Bn.size(1)
         x, z = x.contiguous(), z.contiguous()
@@ -555,26 +556,26 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
         XP = x @ Wx
-        H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn)
+        H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn, slope)
         if H == 128:   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
             xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None, nW2t)
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
         if typed_ok(index, H):
-            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index)
+            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         elif mfma_ok(index, H):
-            H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index)
+            H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         else:
             G = z @ Wes
-            H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True)
+            H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True, slope=slope)
             del G
             Oe = torch.addmm(eb2, H1e, eW2.t())
             zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
-        ctx.v_gate, ctx.e_gate, ctx.WesT = v_gate, e_gate, WesT
+        ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.save_for_backward(x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
         return xn, zn
 
@@ -582,7 +583,7 @@ class _FusedDMPLayer(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dxn, dzn):
         x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2 = ctx.saved_tensors
-        ix, coef, H = ctx.index, ctx.coef, ctx.H
+        ix, coef, H, slope = ctx.index, ctx.coef, ctx.H, ctx.slope
         N = ix.num_nodes
         dxn, dzn = dxn.contiguous(), dzn.contiguous()
         # the parameter-gradient partials (biases, split-K weight gradients) are consumed after the layer (by the
@@ -593,15 +594,15 @@ class _FusedDMPLayer(torch.autograd.Function):
             if typed:
                 # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)
                 dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
-                dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate)  # dG is dPre
+                dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
             else:
                 dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
                 dW2e = atb(dOe, H1e)
                 if mfma:
-                    dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=True)     # dG[:, :H] is dPre
+                    dG, dbe = bwd_h1_mfma(dOe, eW2, H1e, coef, ix, both_halves=True, slope=slope)     # dG[:, :H] is dPre
                 else:
                     dH1e = dOe @ eW2
-                    dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32)
+                    dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32, slope)
                     del dH1e
             inc_ptr, inc_ent = ix.incidence()
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
@@ -614,12 +615,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
                 if not one_launch:
                     dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
-                dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H])
+                dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope)
             else:
                 dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
                 dW2n = wg(dOn, H1n)
                 dH1n = dOn @ nW2
-                dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H])
+                dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H], slope=slope)
             dS = dPn @ Bn.t()
             if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
                 (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (S, dPn, None, False),
@@ -642,7 +643,17 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
-        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None)
+        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None)
+
+
+def activation_slope(act):
+    """Negative slope of an MLP activation module the fused path can run: 0.0 for ``nn.ReLU``, ``negative_slope``
+    for ``nn.LeakyReLU`` (the reference's default ``leaky_relu``: 1/5.5, utils/act.py:27,466); None otherwise."""
+    if type(act) is torch.nn.ReLU:
+        return 0.0
+    if type(act) is torch.nn.LeakyReLU and 0.0 <= float(act.negative_slope) <= 1.0:
+        return float(act.negative_slope)
+    return None
 
 
 def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None):
@@ -650,4 +661,4 @@ def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=N
     n2, e2 = layer.nmlp[2], layer.emlp[2]
     Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t = folded if folded is not None else fold_layers([layer])[0]
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
-                                n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t)
+                                n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]))

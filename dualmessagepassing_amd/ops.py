@@ -233,7 +233,7 @@ class _EdgeCombine(torch.autograd.Function):
         b = _vec(bias, torch.float32)
         with _lib.timed("edge_combine[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * P.size(0)) + 9 * E + 4 * P.size(0)):
             check(lib.dmp_edge_combine(ptr(G), ldg, ptr(P), ldp, ptr(coef), ptr(b), ptr(index.src32),
-                                       ptr(index.dst32), ptr(index.rev8), E, H, 0, ptr(Y), H, stream_ptr()),
+                                       ptr(index.dst32), ptr(index.rev8), E, H, 0, 0.0, ptr(Y), H, stream_ptr()),
                   "dmp_edge_combine")
         ctx.index, ctx.coef, ctx.H = index, coef, H
         ctx.has_bias = bias is not None
@@ -383,17 +383,17 @@ class _MatmulXW(torch.autograd.Function):
 
 class _LinearNN(torch.autograd.Function):
     """``F.linear(x, weight, bias)`` (nn.Linear layout [out, in]) with an optional fused ReLU
-    epilogue (hipBLASLt) and the split-K weight gradient."""
+    epilogue (hipBLASLt) or an in-place LeakyReLU (``slope`` > 0) and the split-K weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
-        if relu and bias is not None:
+    def forward(ctx, x, weight, bias, relu, slope=0.0):
+        if relu and bias is not None and slope == 0.0:
             y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
         else:
             y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
             if relu:
-                y = torch.relu_(y)
-        ctx.relu = relu
+                y = torch.relu_(y) if slope == 0.0 else torch.nn.functional.leaky_relu_(y, slope)
+        ctx.relu, ctx.slope = relu, slope
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
@@ -402,20 +402,22 @@ class _LinearNN(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        if ctx.relu:
+        if ctx.relu and ctx.slope == 0.0:
             dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
+        elif ctx.relu:   # on the saved output: sign(y) == sign(pre-activation) for a positive slope
+            dy = torch.ops.aten.leaky_relu_backward(dy, y, ctx.slope, True)
         dx = dy @ weight if ctx.needs_input_grad[0] else None
         dw = atb_splitk(dy, x) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def matmul_xw(x, W):
     return _MatmulXW.apply(x, W)
 
 
-def linear_nn(x, weight, bias=None, relu=False):
-    return _LinearNN.apply(x, weight, bias, bool(relu))
+def linear_nn(x, weight, bias=None, relu=False, slope=0.0):
+    return _LinearNN.apply(x, weight, bias, bool(relu), float(slope))
 
 
 def apply_mlp(seq, x):
@@ -426,8 +428,11 @@ def apply_mlp(seq, x):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, torch.nn.Linear):
-            fuse = i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.ReLU and m.bias is not None
-            x = linear_nn(x, m.weight, m.bias, relu=fuse)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            slope = 0.0 if type(nxt) is torch.nn.ReLU else (
+                float(nxt.negative_slope) if type(nxt) is torch.nn.LeakyReLU and 0.0 < nxt.negative_slope <= 1.0 else None)
+            fuse = slope is not None and m.bias is not None
+            x = linear_nn(x, m.weight, m.bias, relu=fuse, slope=slope if fuse else 0.0)
             i += 2 if fuse else 1
         else:
             x = m(x)

@@ -11,11 +11,11 @@ class _PooledHead(th.autograd.Function):
     """The pooled ``PredictNet`` tail (pred.py:93-156 on per-graph sums) as ONE autograd node: forward and backward
     written out in plain tensor ops -- about 10 launches forward and 20 backward per head instead of the ~55 that
     recording the same algebra op by op produces (concatenation backward as zero-padded adds, bias scalings as
-    separate nodes, ...).  ReLU heads only; ``scale_p`` / ``scale_g``: the factor on the Linear's bias (padded length
-    for sum pooling, 1 for mean pooling with pre-divided inputs)."""
+    separate nodes, ...).  ReLU / LeakyReLU heads (``slope``); ``scale_p`` / ``scale_g``: the factor on the Linear's
+    bias (padded length for sum pooling, 1 for mean pooling with pre-divided inputs)."""
 
     @staticmethod
-    def forward(ctx, ps, gs, pl, gl, scale_p, scale_g, Wp, bp, Wg, bg, W1, b1, W2, b2):
+    def forward(ctx, ps, gs, pl, gl, scale_p, scale_g, Wp, bp, Wg, bg, W1, b1, W2, b2, slope=0.0):
         h = Wp.size(0)
         p = th.addmm(bp, ps, Wp.t(), beta=scale_p)
         g = th.addmm(bg, gs, Wg.t(), beta=scale_g)
@@ -23,10 +23,13 @@ class _PooledHead(th.autograd.Function):
         f = th.cat([p, g, g - p, g * p, s], dim=1)                          # [B, 4h + 4]
         y1s = th.empty((ps.size(0), h + 4), dtype=ps.dtype, device=ps.device)
         y1s[:, h:] = s
-        th.clamp_min(th.addmm(b1, f, W1.t()), 0.0, out=y1s[:, :h])
+        if slope == 0.0:
+            th.clamp_min(th.addmm(b1, f, W1.t()), 0.0, out=y1s[:, :h])
+        else:
+            y1s[:, :h] = th.nn.functional.leaky_relu_(th.addmm(b1, f, W1.t()), slope)
         y = th.addmm(b2, y1s, W2.t())
         ctx.save_for_backward(ps, gs, f, y1s, Wp, Wg, W1, W2)
-        ctx.scale_p, ctx.scale_g = scale_p, scale_g
+        ctx.scale_p, ctx.scale_g, ctx.slope = scale_p, scale_g, slope
         return y
 
     @staticmethod
@@ -36,7 +39,10 @@ class _PooledHead(th.autograd.Function):
         dy = dy.contiguous()
         dW2 = dy.t() @ y1s                                                  # [1, h + 4]
         db2 = dy.sum(0)
-        dy1 = th.ops.aten.threshold_backward(dy * W2[:, :h], y1s[:, :h], 0.0)    # [B, h]
+        if ctx.slope == 0.0:
+            dy1 = th.ops.aten.threshold_backward(dy * W2[:, :h], y1s[:, :h], 0.0)    # [B, h]
+        else:   # on the saved output: its sign is the pre-activation's for a positive slope
+            dy1 = th.ops.aten.leaky_relu_backward(dy * W2[:, :h], y1s[:, :h], ctx.slope, True)
         dW1 = dy1.t() @ f
         df = dy1 @ W1                                                       # [B, 4h + 4]
         p, g = f[:, :h], f[:, h:2 * h]
@@ -49,7 +55,7 @@ class _PooledHead(th.autograd.Function):
         db1, dbp, dbg = sums[0], sums[1] * ctx.scale_p, sums[2] * ctx.scale_g
         dps = dp @ Wp if ctx.needs_input_grad[0] else None
         dgs = dg @ Wg if ctx.needs_input_grad[1] else None
-        return dps, dgs, None, None, None, None, dWp, dbp, dWg, dbg, dW1, db1, dW2, db2
+        return dps, dgs, None, None, None, None, dWp, dbp, dWg, dbg, dW1, db1, dW2, db2, None
 
 
 _HEAD_STRUCTS = None
@@ -79,10 +85,10 @@ class _PooledHeadsHIP(th.autograd.Function):
     """All pooled heads of the model and their blend in three HIP launches (csrc/dmp_heads.hip):
     ``pred = sum_i blend_i * head_i(sums_i[:B], sums_i[B:])``.  Inputs per head: ``sums`` [2B, H] (pattern rows, then
     target rows: one gradient buffer comes back), ``pl`` / ``gl`` [B, 1], the bias factors, the blend weight [B, 1]
-    (no gradient) and the eight parameters.  H = hidden = 128, ReLU."""
+    (no gradient) and the eight parameters.  H = hidden = 128; activation ReLU (``slope`` 0) or LeakyReLU."""
 
     @staticmethod
-    def forward(ctx, n_heads, *args):
+    def forward(ctx, n_heads, slope, *args):
         from . import _lib
         lib = _lib.load()
         Wt, IOt, Gt = _head_structs()
@@ -110,8 +116,8 @@ class _PooledHeadsHIP(th.autograd.Function):
             keep.append((sums, pl_, gl_, F, Y1S,
                          blend.reshape(-1).contiguous().float() if th.is_tensor(blend) else None, prm))
             ys.append(y)
-        _lib.check(lib.dmp_heads_forward(W, IO, n_heads, B, heads[0][6].size(0), _lib.stream_ptr()), "dmp_heads_forward")
-        ctx.keep, ctx.structs, ctx.n, ctx.B, ctx.per = keep, (W, IO), n_heads, B, per
+        _lib.check(lib.dmp_heads_forward(W, IO, n_heads, B, heads[0][6].size(0), float(slope), _lib.stream_ptr()), "dmp_heads_forward")
+        ctx.keep, ctx.structs, ctx.n, ctx.B, ctx.per, ctx.slope = keep, (W, IO), n_heads, B, per, float(slope)
         if n_heads > 1 and all(isinstance(h[5], str) and h[5] == "len" for h in heads):
             # blend by the sizes of the target graphs (basemodel.py:1488-1494): weights and blended count in one launch
             import ctypes
@@ -138,7 +144,7 @@ class _PooledHeadsHIP(th.autograd.Function):
         n, B = ctx.n, ctx.B
         d = d.contiguous().float()
         G = (Gt * n)()
-        grads, hold = [None], []
+        grads, hold = [None, None], []
         for i, (sums, pl_, gl_, F, Y1S, blend, prm) in enumerate(ctx.keep):
             h = prm[0].size(0)
             dev = sums.device
@@ -159,41 +165,41 @@ class _PooledHeadsHIP(th.autograd.Function):
                 setattr(G[i], name, t.data_ptr())
             hold.append((scr, buf))
             grads += [dsums, None, None, None, None, None] + outs
-        _lib.check(lib.dmp_heads_backward(W, IO, G, n, B, ctx.keep[0][6][0].size(0), _lib.stream_ptr()), "dmp_heads_backward")
+        _lib.check(lib.dmp_heads_backward(W, IO, G, n, B, ctx.keep[0][6][0].size(0), ctx.slope, _lib.stream_ptr()), "dmp_heads_backward")
         return tuple(grads)
 
 
 class PredictNet(nn.Module):
+    """Count head (and optional per-row matching head) over a pattern and a target representation.
+
+    Sub-modules, their order and their initialisers are the reference's (pred.py:20-54: ``state_dict`` keys and the
+    seeded initial values depend on them); the computation is organised differently: the per-row matching head never
+    builds the ``[B, L, 4h+2]`` concatenation -- the first Linear is applied block by block, and everything that
+    depends on the pair only (the pattern vector, the size features, the bias) is computed once per pair and
+    broadcast over the rows."""
+
+    # name, (in, out) as functions of (input_dim, hidden_dim), initialiser (pred.py:46-54); weight_* only with return_weights
+    _SPEC = (("p_fc", lambda d, h: (d, h), "normal", False), ("g_fc", lambda d, h: (d, h), "normal", False),
+             ("pred_fc1", lambda d, h: (4 * h + 4, h), "normal", False), ("pred_fc2", lambda d, h: (h + 4, 1), "zero", False),
+             ("weight_fc1", lambda d, h: (4 * h + 2, h), "normal", True), ("weight_fc2", lambda d, h: (h + 2, 1), "zero", True))
+
     def __init__(self, input_dim, hidden_dim, act_func="relu", dropout=0.0, return_weights=False):
         super(PredictNet, self).__init__()
-        self.input_dim = input_dim
-        self.hidden_dim = hidden_dim
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
         self.act = map_activation_str_to_layer(act_func)
         self.drop = nn.Dropout(dropout)
-        self.p_fc = nn.Linear(input_dim, hidden_dim)
-        self.g_fc = nn.Linear(input_dim, hidden_dim)
-        self.pred_fc1 = nn.Linear(hidden_dim * 4 + 4, hidden_dim)
-        self.pred_fc2 = nn.Linear(hidden_dim + 4, 1)
-        if return_weights:
-            self.weight_fc1 = nn.Linear(hidden_dim * 4 + 2, hidden_dim)
-            self.weight_fc2 = nn.Linear(hidden_dim + 2, 1)
-        else:
-            self.weight_fc1 = None
-            self.weight_fc2 = None
-        # pred.py:46-54
-        init_module(self.p_fc, activation=act_func, init="normal")
-        init_module(self.g_fc, activation=act_func, init="normal")
-        init_module(self.pred_fc1, activation=act_func, init="normal")
-        init_module(self.pred_fc2, activation=act_func, init="zero")
-        if return_weights:
-            init_module(self.weight_fc1, activation=act_func, init="normal")
-            init_module(self.weight_fc2, activation=act_func, init="zero")
+        made = []
+        for name, dims, init, optional in self._SPEC:          # construction first, initialisation after (RNG order)
+            lin = nn.Linear(*dims(input_dim, hidden_dim)) if (return_weights or not optional) else None
+            setattr(self, name, lin)
+            made.append((lin, init))
+        for lin, init in made:
+            if lin is not None:
+                init_module(lin, activation=act_func, init=init)
 
+    # ---- hooks of the reference's class (subclasses override agg_graph)
     def init_pattern(self, p_rep, p_mask=None):
         return self.p_fc(p_rep)
-
-    def agg_pattern(self, p_rep, p_mask=None):
-        return self.agg_graph(p_rep, p_mask)
 
     def init_graph(self, g_rep, g_mask=None):
         return self.g_fc(g_rep)
@@ -201,41 +207,51 @@ class PredictNet(nn.Module):
     def agg_graph(self, g_rep, g_mask=None):
         raise NotImplementedError
 
-    def forward(self, p_rep, p_mask, g_rep, g_mask):
-        # pred.py:87-156
-        bsz = p_mask.size(0)
-        g_len = g_mask.size(1)
-        pl = p_mask.float().sum(dim=1).view(bsz, 1)
-        pl_inv = 1.0 / pl
-        gl = g_mask.float().sum(dim=1).view(bsz, 1)
-        gl_inv = 1.0 / gl
-        if p_rep.dim() == 2:
-            p = p_rep.unsqueeze(1).expand(bsz, g_len, -1)
-        elif p_rep.dim() == 3:
-            p = self.init_pattern(p_rep, p_mask)
-            p = self.drop(p)
-            p = self.agg_pattern(p, p_mask)
-            p = p.unsqueeze(1).expand(bsz, g_len, -1)
-        else:
-            raise ValueError
-        g = self.init_graph(g_rep, g_mask)
-        g = self.drop(g)
-        if self.weight_fc1 is not None:
-            w = th.cat([p, g, g - p, g * p, pl.expand(bsz, g_len).unsqueeze(-1),
-                        pl_inv.expand(bsz, g_len).unsqueeze(-1)], dim=2)
-            w = self.act(self.weight_fc1(w))
-            w = self.weight_fc2(th.cat([w, pl.expand(bsz, g_len).unsqueeze(-1),
-                                        pl_inv.expand(bsz, g_len).unsqueeze(-1)], dim=2))
-            w = w.squeeze_(-1)
-        else:
-            w = None
-        p = p[:, 0, :]
-        g = self.agg_graph(g)
-        y = th.cat([p, g, g - p, g * p, pl, gl, pl_inv, gl_inv], dim=1)
-        y = self.act(self.pred_fc1(y))
-        y = self.pred_fc2(th.cat([y, pl, gl, pl_inv, gl_inv], dim=1))
-        return y, w
+    def agg_pattern(self, p_rep, p_mask=None):
+        return self.agg_graph(p_rep, p_mask)
 
+    # ---- pieces of forward
+    @staticmethod
+    def _size_features(p_mask, g_mask):
+        """[B, 4] = (pl, gl, 1/pl, 1/gl): number of unmasked pattern / target positions of every pair (pred.py:93-96)."""
+        pl = p_mask.sum(dim=1, dtype=th.float32).unsqueeze(1)
+        gl = g_mask.sum(dim=1, dtype=th.float32).unsqueeze(1)
+        return th.cat([pl, gl, pl.reciprocal(), gl.reciprocal()], dim=1)
+
+    def _pattern_vector(self, p_rep, p_mask):
+        if p_rep.dim() == 2:                                   # already one vector per pattern (pred.py:99-100)
+            return p_rep
+        if p_rep.dim() != 3:
+            raise ValueError("p_rep must be [B, dim] or [B, p_len, dim]")
+        return self.agg_pattern(self.drop(self.init_pattern(p_rep, p_mask)), p_mask)
+
+    def _row_weights(self, p, g_rows, sizes):
+        """The matching head (pred.py:113-131) on rows ``g_rows`` [B, L, h] against the pair vectors ``p`` [B, h]:
+        ``weight_fc2([act(weight_fc1([p, g, g - p, g * p, pl, 1/pl])), pl, 1/pl])`` with weight_fc1 split into its
+        column blocks: ``g (Wg + Wd)^T + (g * p) Wm^T`` per row, ``p (Wp - Wd)^T + [pl, 1/pl] Ws^T + b`` per pair."""
+        h = self.hidden_dim
+        W, b = self.weight_fc1.weight, self.weight_fc1.bias
+        Wp, Wg, Wd, Wm, Ws = W[:, :h], W[:, h:2 * h], W[:, 2 * h:3 * h], W[:, 3 * h:4 * h], W[:, 4 * h:]
+        ps = sizes[:, (0, 2)]                                  # (pl, 1/pl)
+        per_pair = th.addmm(b, p, (Wp - Wd).t()) + ps @ Ws.t()                       # [B, h]
+        hidden = self.act(g_rows @ (Wg + Wd).t() + (g_rows * p.unsqueeze(1)) @ Wm.t() + per_pair.unsqueeze(1))
+        W2, b2 = self.weight_fc2.weight, self.weight_fc2.bias
+        out = hidden @ W2[0, :h] + (ps @ W2[0, h:] + b2).unsqueeze(1)                 # [B, L]
+        return out
+
+    def _count(self, p, g, sizes):
+        """pred.py:137-154: the count from the pair vectors."""
+        feats = th.cat([p, g, g - p, g * p, sizes], dim=1)
+        return self.pred_fc2(th.cat([self.act(self.pred_fc1(feats)), sizes], dim=1))
+
+    def forward(self, p_rep, p_mask, g_rep, g_mask):
+        """p_rep [B, p_len, D] (or [B, h]), g_rep [B, g_len, D], masks [B, len] -> (count [B, 1], row weights [B, g_len]
+        or None)."""
+        sizes = self._size_features(p_mask, g_mask)
+        p = self._pattern_vector(p_rep, p_mask)
+        g_rows = self.drop(self.init_graph(g_rep, g_mask))
+        w = self._row_weights(p, g_rows, sizes) if self.weight_fc1 is not None else None
+        return self._count(p, self.agg_graph(g_rows), sizes), w
 
     # ---- pool-then-project: sum/mean pooling commutes with the affine p_fc / g_fc, so the per-row
     # Linear over [B, L, D] (an E-row GEMM and its [B, L, hid] intermediate) collapses to a
@@ -245,9 +261,14 @@ class PredictNet(nn.Module):
     def poolable(self):
         return self.pool_kind is not None and self.weight_fc1 is None and not (self.drop.p > 0.0 and self.training)
 
+    def act_slope(self):
+        """0.0 (ReLU) / the negative slope (LeakyReLU: the reference's default pred_act_func) / None (anything else)."""
+        from .fused import activation_slope
+        return activation_slope(self.act)
+
     def hip_head_ok(self, sums):
-        """The three-launch HIP heads (``_PooledHeadsHIP``) compute this head: ReLU, width 128, fp32 on the GPU."""
-        return (type(self.act) is nn.ReLU and self.pool_kind == "sum" and self.input_dim == 128 and self.hidden_dim == 128
+        """The three-launch HIP heads (``_PooledHeadsHIP``) compute this head: ReLU / LeakyReLU, width 128, fp32 on the GPU."""
+        return (self.act_slope() is not None and self.pool_kind == "sum" and self.input_dim == 128 and self.hidden_dim == 128
                 and sums is not None and sums.is_cuda and sums.dtype == th.float32 and sums.dim() == 2 and sums.size(1) == 128)
 
     def head_params(self):
@@ -258,13 +279,13 @@ class PredictNet(nn.Module):
         """p_sum / g_sum [B, D]: sums of the (masked) pattern / graph rows; *_pad_len: padded length L
         of the reference's [B, L, D] tensors (every padded or masked position contributes the bias);
         pl / gl [B, 1]: mask counts (pred.py:93-96)."""
-        if type(self.act) is nn.ReLU and p_sum.is_cuda and p_sum.dim() == 2:
+        if self.act_slope() is not None and p_sum.is_cuda and p_sum.dim() == 2:
             sp, sg = (float(p_pad_len), float(g_pad_len)) if self.pool_kind == "sum" else (1.0, 1.0)
             if self.pool_kind != "sum":
                 p_sum, g_sum = p_sum / float(p_pad_len), g_sum / float(g_pad_len)
             y = _PooledHead.apply(p_sum, g_sum, pl, gl, sp, sg, self.p_fc.weight, self.p_fc.bias, self.g_fc.weight,
                                   self.g_fc.bias, self.pred_fc1.weight, self.pred_fc1.bias, self.pred_fc2.weight,
-                                  self.pred_fc2.bias)
+                                  self.pred_fc2.bias, self.act_slope())
             return y, None
         pl_inv, gl_inv = 1.0 / pl, 1.0 / gl
         if self.pool_kind == "sum":

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 32
+#define DMP_ABI_VERSION 33
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -300,14 +300,16 @@ int dmp_gather_select(const float *D, int64_t ldd, const int32_t *dst,
  *                       : P[dst e,0:H] - P[src e,H:2H])
  * where G = Z @ [W_eloop | W_src - W_dst]  and  P = X @ [W_dst | W_src].
  *   G [E, ldg>=2H], P [N, ldp>=2H], coef [N], bias [H] or NULL, Y [E, ldy>=H]
- * relu != 0 applies max(.,0) to Y: used when the first Linear of the edge MLP (no
- * non-linearity sits between it and this sum, dmpnn.py:147-152) has been folded into
- * G and P by multiplying the weights, so Y is already the MLP's hidden activation.
+ * relu != 0 applies the MLP's activation max(y, slope * y) to Y (slope 0: ReLU; slope 1/5.5: the
+ * reference's default `leaky_relu`, utils/act.py:27,466; 0 <= slope <= 1, else DMP_ERR_UNSUPPORTED):
+ * used when the first Linear of the edge MLP (no non-linearity sits between it and this sum,
+ * dmpnn.py:147-152) has been folded into G and P by multiplying the weights, so Y is already
+ * the MLP's hidden activation.
  */
 int dmp_edge_combine(const float *G, int64_t ldg, const float *P, int64_t ldp,
                      const float *coef, const float *bias, const int32_t *src,
                      const int32_t *dst, const uint8_t *flag,
-                     int64_t num_edges, int H, int relu, float *Y, int64_t ldy,
+                     int64_t num_edges, int H, int relu, float slope, float *Y, int64_t ldy,
                      void *stream);
 
 /*
@@ -362,11 +364,11 @@ int dmp_gate_residual(const float *prev, int64_t ldp, const float *upd, int64_t 
                       const float *gate, int64_t rows, int H, float *out, int64_t ldo,
                       void *stream);
 
-/* First MLP Linear of the node update after the fold (dmpnn.py:129-140):  out = relu(a + b + bias)
- * in one pass -- a: the projected aggregate S Bn, b: the self-loop projection (a column slice of XP),
- * bias [H] or NULL.  out may alias a. */
+/* First MLP Linear of the node update after the fold (dmpnn.py:129-140):  out = act(a + b + bias),
+ * act(y) = max(y, slope * y) (slope 0: ReLU), in one pass -- a: the projected aggregate S Bn, b: the
+ * self-loop projection (a column slice of XP), bias [H] or NULL.  out may alias a. */
 int dmp_add_bias_relu(const float *a, int64_t lda, const float *b, int64_t ldb, const float *bias,
-                      int64_t rows, int H, float *out, int64_t ldo, void *stream);
+                      int64_t rows, int H, float slope, float *out, int64_t ldo, void *stream);
 
 /*
  * Backward of the gate and the bias gradient of the layer before it:
@@ -377,10 +379,11 @@ int dmp_add_bias_relu(const float *a, int64_t lda, const float *b, int64_t ldb, 
 int dmp_scale_rows_colsum(const float *dOut, int64_t ldd, const float *gate, int64_t rows,
                           int H, float *dUpd, int64_t ldu, float *partial, void *stream);
 
-/* ReLU backward (`threshold_backward`: dPre = act > 0 ? dH : 0; the MLPs of dmpnn.py:45-60)
- * + column sums of dPre (gradient of the preceding Linear's bias).  dPre may alias dH. */
+/* (Leaky)ReLU backward on the saved OUTPUT (`threshold_backward` / `leaky_relu_backward(self_is_result)`:
+ * dPre = act > 0 ? dH : slope * dH; the MLPs of dmpnn.py:45-60) + column sums of dPre (gradient of the
+ * preceding Linear's bias).  dPre may alias dH. */
 int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda,
-                        int64_t rows, int H, float *dPre, int64_t ldp, float *partial,
+                        int64_t rows, int H, float slope, float *dPre, int64_t ldp, float *partial,
                         void *stream);
 
 /* dmp_edge_combine_bwd_g + column sums of dY (gradient of ebias, dmpnn.py:148-149). */
@@ -388,10 +391,10 @@ int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coe
                                   const int32_t *dst, int64_t num_edges, int H, float *dG,
                                   int64_t ldg, float *partial, void *stream);
 
-/* ReLU backward fused with dmp_edge_combine_bwd_g (for the folded first Linear):
- *     dPre = act > 0 ? dH : 0;  dG = [dPre | coef[dst] * dPre];  partial = column sums of dPre */
+/* (Leaky)ReLU backward fused with dmp_edge_combine_bwd_g (for the folded first Linear):
+ *     dPre = act > 0 ? dH : slope * dH;  dG = [dPre | coef[dst] * dPre];  partial = column sums of dPre */
 int dmp_relu_bwd_g_colsum(const float *dH, int64_t ldh, const float *act, int64_t lda,
-                          const float *coef, const int32_t *dst, int64_t num_edges, int H,
+                          const float *coef, const int32_t *dst, int64_t num_edges, int H, float slope,
                           float *dG, int64_t ldg, float *partial, void *stream);
 
 /* Column-sum partials of A [rows, H]. */
@@ -551,7 +554,8 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
  * The pooled prediction heads (SubgraphCountingMatching/models/pred.py:93-156 applied to per-graph sums; the node
  * and the edge head of basemodel.py:1477-1498) for all heads in one launch forward and two backward:
  *     p = ps Wp^T + scale_p bp;  g = gs Wg^T + scale_g bg;  s = [pl, gl, 1/pl, 1/gl]
- *     f = [p | g | g - p | g * p | s];  y1 = relu(f W1^T + b1);  y = [y1 | s] W2^T + b2
+ *     f = [p | g | g - p | g * p | s];  y1 = act(f W1^T + b1);  y = [y1 | s] W2^T + b2
+ * act(x) = max(x, slope x): ReLU for slope 0, the reference's default pred_act_func leaky_relu for 1/5.5.
  * H = width of ps / gs and of the hidden layer = 128 only.  Weights in nn.Linear layout: Wp, Wg [H,H], W1 [H,4H+4],
  * W2 [1,H+4]; ps / gs [B, ld >= H]; pl / gl [B] (mask counts); scale_p / scale_g: the factor on the bias (the padded
  * length for sum pooling).  Forward writes y [B] and keeps F [B,4H+4] = f and Y1S [B,H+4] = [y1 | s] for backward.
@@ -570,9 +574,9 @@ typedef struct {
   float *dWp, *dbp, *dWg, *dbg, *dW1, *db1, *dW2, *db2;
 } dmp_head_grads;
 int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H,
-                      void *stream);
+                      float slope, void *stream);
 int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g,
-                       int num_heads, int B, int H, void *stream);
+                       int num_heads, int B, int H, float slope, void *stream);
 
 /*
  * Blend of the heads' counts by the sizes of their target graphs (basemodel.py:1488-1494):
@@ -602,15 +606,15 @@ int dmp_edge_select_build(const int32_t *src, const int32_t *dst, const uint8_t 
 /*
  * The E-row projection of the layer and dmp_edge_combine(relu) in one pass
  * (dmpnn.py:112,120,124,142-152 with the first Linear of emlp folded in, see fused.py):
- *     H1[e] = relu( Z[e] W[:, 0:H] + coefE[e] * Z[e] W[:, H:2H] + b + P[selA e, 0:H] - P[selB e, H:2H] )
- *   Z [E, ldz>=H], W [H, ldw>=2H] row-major ([in, out] layout), P [num_nodes, ldp>=2H], H1 [E, ldh>=H].
+ *     H1[e] = act( Z[e] W[:, 0:H] + coefE[e] * Z[e] W[:, H:2H] + b + P[selA e, 0:H] - P[selB e, H:2H] )
+ *   act(y) = max(y, slope * y), 0 <= slope <= 1 (0: ReLU).  Z [E, ldz>=H], W [H, ldw>=2H] row-major ([in, out] layout), P [num_nodes, ldp>=2H], H1 [E, ldh>=H].
  * The [E,2H] product never reaches HBM.  Returns DMP_ERR_UNSUPPORTED unless H == 128, or when
  * num_nodes*ldp*4 or E*4 do not fit 32 bits (the kernels address tables with 32-bit byte offsets).
  */
 int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
                        const float *P, int64_t ldp, int64_t num_nodes, const float *bias,
                        const int32_t *selA, const int32_t *selB, const float *coefE,
-                       int64_t num_edges, int H, float *H1, int64_t ldh, void *stream);
+                       int64_t num_edges, int H, float slope, float *H1, int64_t ldh, void *stream);
 
 /*
  * Second Linear of the MLP + gate + residual in one pass (dmpnn.py:136,152 + 263-273):
@@ -623,8 +627,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
                       int64_t rows, int H, int w_in_out, float *out, int64_t ldo, void *stream);
 
 /*
- * Backward of the second Linear, the ReLU and dmp_edge_combine in one pass:
- *     dPre[e] = H1[e] > 0 ? dO[e] W2 : 0 ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
+ * Backward of the second Linear, the (Leaky)ReLU and dmp_edge_combine in one pass:
+ *     dPre[e] = H1[e] > 0 ? dO[e] W2 : slope * (dO[e] W2) ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
  *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
  *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
  *   coefE NULL: only dPre is written (dG [E, ldg>=H]: may be a column slice of a wider matrix), and then
@@ -635,7 +639,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
 int64_t dmp_mfma_partial_rows(int64_t num_edges);
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
                      const float *H1, int64_t ldh, const float *coefE, const float *gate,
-                     int64_t num_edges, int H, float *dG, int64_t ldg, float *partial, void *stream);
+                     int64_t num_edges, int H, float slope, float *dG, int64_t ldg, float *partial,
+                     void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
@@ -666,7 +671,7 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
                        int64_t ldp, int64_t num_nodes, const float *bias, const int32_t *selA,
                        const int32_t *selB, const int32_t *slot_edge, const float *tile_scale,
                        const int32_t *num_tiles, int64_t tiles_bound, int64_t num_edges, int H,
-                       float *H1, int64_t ldh, void *stream);
+                       float slope, float *H1, int64_t ldh, void *stream);
 int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D,
                     int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
                     const int32_t *dst, const uint8_t *flag, float s0, float s1,

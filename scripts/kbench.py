@@ -65,7 +65,7 @@ report("gather_select", lambda i: lib.dmp_gather_select(P2[i].data_ptr(), 2 * h,
        4 * h * (e + 2 * n) + 5 * e)
 report("gather_rows", lambda i: lib.dmp_gather_rows(P2[i].data_ptr(), 2 * h, ix.dst32.data_ptr(), None, e, h, OUT_E[i].data_ptr(), h, st),
        4 * h * (e + n) + 4 * e)
-report("edge_combine", lambda i: lib.dmp_edge_combine(G2[i].data_ptr(), 2 * h, P2[i].data_ptr(), 2 * h, coef.data_ptr(), bias.data_ptr(), ix.src32.data_ptr(), ix.dst32.data_ptr(), ix.rev8.data_ptr(), e, h, 0, OUT_E[i].data_ptr(), h, st),
+report("edge_combine", lambda i: lib.dmp_edge_combine(G2[i].data_ptr(), 2 * h, P2[i].data_ptr(), 2 * h, coef.data_ptr(), bias.data_ptr(), ix.src32.data_ptr(), ix.dst32.data_ptr(), ix.rev8.data_ptr(), e, h, 0, 0.0, OUT_E[i].data_ptr(), h, st),
        4 * h * (3 * e + 2 * n) + 9 * e + 4 * n)
 report("edge_combine_bwd_g", lambda i: lib.dmp_edge_combine_bwd_g(Z[i].data_ptr(), h, coef.data_ptr(), ix.dst32.data_ptr(), e, h, OUT_E2[i].data_ptr(), 2 * h, st),
        12 * h * e + 4 * e + 4 * n)

@@ -39,12 +39,12 @@ def timeit(f, n=20):
     return a.elapsed_time(b) / n * 1e3
 for path in sorted(glob.glob(os.path.join(ROOT, "scripts", "_dbg", "libty_*.so")), key=lambda s: int(s.split("_")[-1][:-3])):
     lib = ctypes.CDLL(path)
-    lib.dmp_edge_fwd_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, I, P, I64, P]
+    lib.dmp_edge_fwd_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, I, F, P, I64, P]
     lib.dmp_bwd_z_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, F, F, P, P, P, I64, I64, I, P, I64, P]
     def fwd(i):
         rc = lib.dmp_edge_fwd_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, xp[:, h:].data_ptr(), 3 * h, n, bias.data_ptr(),
                                     selA.data_ptr(), selB.data_ptr(), se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h,
-                                    out.data_ptr(), h, st)
+                                    0.0, out.data_ptr(), h, st)
         assert rc == 0, rc
     def bwd(i):
         rc = lib.dmp_bwd_z_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, dsn.data_ptr(), 2 * h, n, base[i % 3].data_ptr(), h,

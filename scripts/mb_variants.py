@@ -23,8 +23,8 @@ d = lambda t: t.data_ptr()
 calls = {
     "gemm N=128": lambda: lib.dmp_gemm_k128(d(Z[0]), H, d(W1), H, 0, d(O), H, E, 128, st),
     "gemm N=256": lambda: lib.dmp_gemm_k128(d(Z[0]), H, d(W2), 2 * H, 0, d(O2), 2 * H, E, 256, st),
-    "edge_fwd": lambda: lib.dmp_edge_fwd_fused(d(Z[0]), H, d(W2), 2 * H, d(Pn), 2 * H, N_, d(bias), d(src), d(dst), d(coefE), E, H, d(O), H, st),
-    "bwd_h1": lambda: lib.dmp_bwd_h1_fused(d(Z[0]), H, d(W1), H, d(Z[1]), H, d(coefE), None, E, H, d(O2), 2 * H, d(part), st),
+    "edge_fwd": lambda: lib.dmp_edge_fwd_fused(d(Z[0]), H, d(W2), 2 * H, d(Pn), 2 * H, N_, d(bias), d(src), d(dst), d(coefE), E, H, 0.0, d(O), H, st),
+    "bwd_h1": lambda: lib.dmp_bwd_h1_fused(d(Z[0]), H, d(W1), H, d(Z[1]), H, d(coefE), None, E, H, 0.0, d(O2), 2 * H, d(part), st),
     "out_fwd": lambda: lib.dmp_out_fwd_fused(d(Z[0]), H, d(W1), H, d(bias), d(gate), d(Z[1]), H, E, H, 0, d(O), H, st),
     "bwd_z": lambda: lib.dmp_bwd_z_fused(d(Z[0]), H, d(W2), 2 * H, d(Pn), 2 * H, N_, d(Z[1]), H, d(coefE), d(dst), d(flag), -1.0, 1.0, E, H, d(O), H, st),
 }

@@ -184,12 +184,14 @@ def test_cpu_tensors_are_rejected():
         layer(g, th.randn(2, 8), th.randn(2, 8))
 
 
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])   # leaky_relu (slope 1/5.5): the reference's default rep_act_func
 @pytest.mark.parametrize("batch,n,m,h,gates,residual", [
     (8, 16, 40, 32, True, True), (8, 16, 40, 32, False, True), (8, 16, 40, 32, True, False),
     (64, 64, 256, 128, True, True),      # enough rows for the split-K weight-gradient path
+    (32, 64, 256, 64, True, True),       # the reference's hid_dim (README.md:21-119)
     (3, 5, 7, 20, True, True),
 ])
-def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, residual, gpu):
+def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, residual, act, gpu):
     """The single-node fused layer (fused.py) == the modular layer + gate + residual == oracle."""
     from dualmessagepassing_amd.dmpnn import DMPNNRep
     from dualmessagepassing_amd.graph import BatchedGraph
@@ -197,7 +199,7 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
     src, dst, rev, N, bnn, bne = er_batch(batch, n, m, rng)
     E, L = len(src), 2
     gen = th.Generator().manual_seed(h + n)
-    layers = [O.random_dmp_params(h, h, gen) for _ in range(L)]
+    layers = [O.random_dmp_params(h, h, gen, act) for _ in range(L)]
     v0, e0 = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
     wv, we = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
     vg = (th.rand(N, 1, generator=gen) < 0.7).float() if gates else None
@@ -206,12 +208,12 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
     # oracle
     lo = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
     vo, eo = v0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
-    rv, re = O.dmpnn_graph_rep(lo, ts, td, tr, O.out_degrees(ts, N), vo, eo, vg, eg, residual, "relu")
+    rv, re = O.dmpnn_graph_rep(lo, ts, td, tr, O.out_degrees(ts, N), vo, eo, vg, eg, residual, act)
     ((rv * wv).sum() + (re * we).sum()).backward()
     results = {}
     for fused in (True, False):
         net = DMPNNRep(hid_dim=h, rep_num_graph_layers=L, rep_num_pattern_layers=L, share_rep_net=True,
-                       rep_residual=residual, rep_dmpnn_batch_norm=False, rep_act_func="relu")
+                       rep_residual=residual, rep_dmpnn_batch_norm=False, rep_act_func=act)
         sd = {}
         for i, p in enumerate(layers):
             for k, v in p.items():
@@ -220,9 +222,12 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
         net.load_state_dict(sd, strict=True)
         net.to(gpu)
         net.use_fused = fused
+        assert all(l.fused_ok(None, None, None) is False for l in net.g_rep_net["dmpnn"])   # needs a graph with REVFLAG
         g = BatchedGraph(ts.to(gpu), td.to(gpu), N, _t(bnn).to(gpu), _t(bne).to(gpu))
         g.edata["is_reversed"] = tr.to(gpu)
         vgp, egp = v0.to(gpu).requires_grad_(True), e0.to(gpu).requires_grad_(True)
+        if fused:   # the fast path must be the one that runs for this activation
+            assert all(l.fused_ok(g, vgp, egp) for l in net.g_rep_net["dmpnn"])
         a, b = net.get_graph_rep(g, vgp, egp, v_gate=None if vg is None else vg.to(gpu),
                                  e_gate=None if eg is None else eg.to(gpu))
         ((a * wv.to(gpu)).sum() + (b * we.to(gpu)).sum()).backward()
@@ -242,7 +247,7 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
     v64, e64 = v0.double().requires_grad_(True), e0.double().requires_grad_(True)
     a64, b64 = O.dmpnn_graph_rep(l64, ts, td, tr, O.out_degrees(ts, N), v64, e64,
                                  None if vg is None else vg.double(), None if eg is None else eg.double(),
-                                 residual, "relu")
+                                 residual, act)
     ((a64 * wv.double()).sum() + (b64 * we.double()).sum()).backward()
     refs64 = (a64, b64, v64.grad, e64.grad)
     refs32 = (rv, re, vo.grad, eo.grad)

@@ -112,14 +112,15 @@ def test_training_steps_match_reference(fused, gpu):
         _close(v, after[k], 2e-3, "param after training " + k)
 
 
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
 @pytest.mark.parametrize("kind", ["SumPredictNet", "MeanPredictNet"])
-def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
+def test_pooled_head_single_node_matches_op_by_op(kind, act, gpu):
     """pred._PooledHead (the pooled head as one hand-written autograd node) against the same algebra recorded op by
     op: prediction and every input / parameter gradient."""
     from dualmessagepassing_amd.pred import PRED_NETS
     th.manual_seed(5)
     B, d, h = 257, 128, 128
-    net = PRED_NETS[kind](d, h, act_func="relu").to(gpu)
+    net = PRED_NETS[kind](d, h, act_func=act).to(gpu)
     for p in net.parameters():
         p.data.normal_(0.0, 0.2)
     gen = th.Generator().manual_seed(6)
@@ -137,7 +138,7 @@ def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
         else:
             p, g = net.p_fc(ps / float(Lp)), net.g_fc(gs / float(Lg))
         f = th.cat([p, g, g - p, g * p, pl, gl, 1.0 / pl, 1.0 / gl], dim=1)
-        y1 = th.relu(net.pred_fc1(f))
+        y1 = net.act(net.pred_fc1(f))
         return net.pred_fc2(th.cat([y1, pl, gl, 1.0 / pl, 1.0 / gl], dim=1))
     ref = reference()
     assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-5)
@@ -149,16 +150,17 @@ def test_pooled_head_single_node_matches_op_by_op(kind, gpu):
         assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=1e-4), (i, (a - b).abs().max().item())
 
 
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
 @pytest.mark.parametrize("B", [1, 257, 1024])
 @pytest.mark.parametrize("n_heads", [1, 2, -2])
-def test_hip_heads_match_op_by_op(B, n_heads, gpu):
+def test_hip_heads_match_op_by_op(B, n_heads, act, gpu):
     """pred._PooledHeadsHIP (all heads + blend: one launch forward, two backward) against the op-by-op algebra:
     the blended prediction and every input / parameter gradient."""
     from dualmessagepassing_amd.pred import PRED_NETS, _PooledHeadsHIP
     by_len, n_heads = n_heads < 0, abs(n_heads)      # -2: the blend weights come out of the op itself (dmp_heads_blend)
     th.manual_seed(7 + B)
     d = h = 128
-    nets = [PRED_NETS["SumPredictNet"](d, h, act_func="relu").to(gpu) for _ in range(n_heads)]
+    nets = [PRED_NETS["SumPredictNet"](d, h, act_func=act).to(gpu) for _ in range(n_heads)]
     gen = th.Generator().manual_seed(8)
     for net in nets:
         for p in net.parameters():
@@ -171,7 +173,7 @@ def test_hip_heads_match_op_by_op(B, n_heads, gpu):
     flat = []
     for i, net in enumerate(nets):
         flat += [sums[i], pls[i], gls[i], Lp, Lg, "len" if by_len else blends[i]] + list(net.head_params())
-    y = _PooledHeadsHIP.apply(n_heads, *flat)
+    y = _PooledHeadsHIP.apply(n_heads, nets[0].act_slope(), *flat)
 
     ref = 0.0
     for i, net in enumerate(nets):
@@ -179,7 +181,7 @@ def test_hip_heads_match_op_by_op(B, n_heads, gpu):
         p = th.nn.functional.linear(ps, net.p_fc.weight) + Lp * net.p_fc.bias
         g = th.nn.functional.linear(gs, net.g_fc.weight) + Lg * net.g_fc.bias
         f = th.cat([p, g, g - p, g * p, pl, gl, 1.0 / pl, 1.0 / gl], dim=1)
-        y1 = th.relu(net.pred_fc1(f))
+        y1 = net.act(net.pred_fc1(f))
         yi = net.pred_fc2(th.cat([y1, pl, gl, 1.0 / pl, 1.0 / gl], dim=1))
         ref = ref + (yi if blends[i] is None else blends[i] * yi)
     assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-4), (y - ref).abs().max()

@@ -698,3 +698,68 @@ def test_weight_gradients_sharing_one_launch(gpu):
     assert c.shape == (h, 3 * h) and th.allclose(c, (x.double().t() @ dXP.double()).float(), rtol=1e-5, atol=tol)
     again = fused.atb_rows_multi([(dx, h1, gate, True), (S, dXP[:, :h], None, False), (x, dXP, None, False)])
     assert th.equal(a, again[0][0]) and th.equal(b, again[1][0]) and th.equal(c, again[2][0])
+
+
+@pytest.mark.parametrize("slope", [1 / 5.5, 0.01, 1.0])
+@pytest.mark.parametrize("rows,h", [(70001, 128), (513, 64), (37, 20)])
+def test_activation_slope_in_every_kernel(rows, h, slope, gpu):
+    """LeakyReLU(slope) -- the reference's default rep / pred activation (utils/act.py:27,466) -- through every kernel
+    that applies or differentiates the MLP activation: equal to torch's leaky_relu / leaky_relu_backward formulas
+    (bit for bit in the streaming kernels, fp32 re-association in the MFMA ones)."""
+    from dualmessagepassing_amd import fused
+    F = th.nn.functional
+    gen = th.Generator().manual_seed(rows + h)
+    rng = np.random.default_rng(rows + h)
+    n = max(2, rows // 5)
+    src = rng.integers(0, n, rows).astype(np.int64)
+    dst = rng.integers(0, n, rows).astype(np.int64)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    a = th.randn(rows, h, generator=gen).to(gpu)
+    b = th.randn(rows, h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    # forward row pass: act(a + b + bias)
+    a2 = a.clone()
+    fused.add_bias_relu_(a2, b, bias, slope)
+    assert th.equal(a2, F.leaky_relu((a + b) + bias, slope))
+    # backward row passes on the saved OUTPUT y = act(pre)
+    y = F.leaky_relu(b, slope)
+    want = th.ops.aten.leaky_relu_backward(a, b, slope, False)
+    got, cs = fused.relu_bwd_colsum_(a.clone(), y, slope=slope)
+    assert th.equal(got, want)
+    assert th.allclose(cs, want.double().sum(0).float(), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    dg, cs = fused.relu_bwd_g_colsum(a, y, coef, ix.dst32, slope)
+    td = _t(dst).to(gpu)
+    assert th.equal(dg, th.cat([want, want * coef[td][:, None]], 1))
+    # edge_combine with the activation
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    g = a @ wes
+    pre = fused.edge_combine_raw(g, 2 * h, xp[:, h:], 3 * h, bias, coef, ix, h, relu=False)
+    out = fused.edge_combine_raw(g, 2 * h, xp[:, h:], 3 * h, bias, coef, ix, h, relu=True, slope=slope)
+    assert th.equal(out, F.leaky_relu(pre, slope))
+    if h != 128:
+        return
+    # the MFMA kernels (H = 128)
+    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
+    ref = F.leaky_relu(pre.double(), slope)
+    for fn in (fused.edge_fwd_mfma, fused.edge_fwd_typed):
+        got = fn(a, wes, xp[:, h:], 3 * h, bias, coef, ix, slope)
+        assert th.allclose(got.double(), ref, rtol=1e-5, atol=2e-4), fn.__name__
+    d_h = a.double() @ w2.double()
+    dpre = th.where(y > 0, d_h, slope * d_h)
+    d_g, cs = fused.bwd_h1_mfma(a, w2, y, coef, ix, slope=slope)
+    assert th.allclose(d_g.double(), th.cat([dpre, dpre * coef.double()[td][:, None]], 1), rtol=1e-5, atol=2e-4)
+    assert th.allclose(cs.double(), dpre.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    gate = (th.rand(rows, generator=gen) * (th.rand(rows, generator=gen) > 0.3)).to(gpu)
+    d_p, _ = fused.bwd_h1_mfma(a, w2, y, both_halves=False, gate=gate, slope=slope)
+    assert th.allclose(d_p.double(), dpre * gate.double()[:, None], rtol=1e-5, atol=2e-4)
+
+
+def test_activation_slope_outside_the_supported_range_is_refused(gpu):
+    from dualmessagepassing_amd import _lib, fused
+    a = th.randn(8, 16, device=gpu)
+    for bad in (-0.1, 1.5):
+        with pytest.raises(_lib.DmpError):
+            fused.add_bias_relu_(a.clone(), a, None, bad)
