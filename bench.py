@@ -276,6 +276,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Setup objects (modules, tuned-GEMM tables, the shard) leave the cyclic collector's working set: a full
+    # collection walking them costs tens of milliseconds and would otherwise land inside a step now and then.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     # timed region: HIP events only around the roofline kernel (the scatter-add), so that the
     # event records do not perturb the step; every other kernel is timed in extra steps below

@@ -217,7 +217,8 @@ class _Padder:
 # tensors: a loader that hands over the same size tensors again (fixed-shape batches, repeated
 # epochs) pays the sync once and the step stays asynchronous.
 _SIZE_CACHE = OrderedDict()
-_SIZE_CACHE_MAX = 64
+_SIZE_CACHE_MAX = 12   # a loader that makes new size tensors for every batch never hits: keep the retained set (and the
+                       # allocator growth it causes, a dozen device allocations over the first steps) small
 
 
 def _tensor_key(t):

@@ -268,6 +268,9 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
             dataio.save_config(config, os.path.join(save_dir, "config.json"))
         log = open(os.path.join(save_dir, "log.txt"), "w")
     best, history = (float("inf"), -1), []
+    import gc
+    gc.collect()
+    gc.freeze()      # model / dataset / optimizer objects: out of the cyclic collector's way for the whole run
     try:
         for epoch in range(epochs):
             tr = train_epoch(model, optimizer, train_set, batch_size, device, sync=sync, eval_metric=eval_metric,
@@ -285,6 +288,7 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
                 log.write(dataio.best_line("dev", best[1], epochs, **{"eval-" + eval_metric: "%.5f" % best[0]}) + "\n")
                 log.flush()
     finally:
+        gc.unfreeze()
         if log is not None:
             log.close()
     return history

@@ -8,11 +8,23 @@ dev = torch.device("cuda:0")
 cfg = dict(bench.CFG)
 shard = bench.make_shard(cfg, 0, dev)
 step, model = bench.build_step(cfg, shard, dev)
-for _ in range(5): step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20): step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("enqueue %.2f ms/step, complete %.2f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
+from dualmessagepassing_amd import basemodel
+if os.environ.get("SIZE_CACHE_MAX"): basemodel._SIZE_CACHE_MAX = int(os.environ["SIZE_CACHE_MAX"])
+for rnd in range(int(os.environ.get("ROUNDS", "3"))):
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    t0 = time.perf_counter()
+    per = []
+    for _ in range(20):
+        ts = time.perf_counter()
+        step()
+        per.append((time.perf_counter() - ts) * 1e3)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    a1 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    print("enqueue %.2f ms/step, complete %.2f ms/step; device allocations in the timed loop: %d; reserved %.0f MB"
+          % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3, a1 - a0, torch.cuda.memory_reserved() / 1e6))
+    if max(per) > 2.5 * sorted(per)[10]:
+        print("   per-step enqueue ms:", " ".join("%.1f" % x for x in per))

@@ -184,7 +184,7 @@ def test_hip_heads_match_op_by_op(B, n_heads, act, gpu):
         y1 = net.act(net.pred_fc1(f))
         yi = net.pred_fc2(th.cat([y1, pl, gl, 1.0 / pl, 1.0 / gl], dim=1))
         ref = ref + (yi if blends[i] is None else blends[i] * yi)
-    assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-4), (y - ref).abs().max()
+    assert y.shape == ref.shape and th.allclose(y, ref, rtol=1e-5, atol=1e-5 * max(10.0, float(ref.abs().max()))), (y - ref).abs().max()
     cot = th.randn(B, 1, generator=gen).to(gpu)
     wrt = sums + [p for net in nets for p in net.head_params()]
     got = th.autograd.grad((y * cot).sum(), wrt)

@@ -241,7 +241,7 @@ def test_deferred_reductions_equal_immediate(gpu):
             raise RuntimeError("x")
     except RuntimeError:
         pass
-    assert not fused._deferred
+    assert not fused._deferred.stack
 
 
 def test_split_k_weight_gradient_product(gpu):
