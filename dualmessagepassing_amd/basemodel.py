@@ -842,8 +842,13 @@ class RGIN(RGINRepMixin, GraphAdjModel):
     """``models/rgin.py:175-260``."""
 
 
-def build_model(**config):
-    """``train.py:68-87`` for the rep-nets on the MI355X path."""
+def build_model(config=None, **kw):
+    """``train.py:68-87`` for the rep-nets on the MI355X path.  Takes the reference's call form
+    ``build_model(process_model_config(config), init_neigenv=..., init_eeigenv=...)`` (the ``match_weights`` entry of the
+    run configuration becomes ``pred_return_weights``, train.py:70-86) as well as plain keywords."""
+    config = dict(config or {}, **kw)
+    if "match_weights" in config and "pred_return_weights" not in config:
+        config["pred_return_weights"] = config["match_weights"]
     rep_net = config.get("rep_net", "DMPNN")
     if rep_net == "DMPNN":
         return DMPNN(**config)

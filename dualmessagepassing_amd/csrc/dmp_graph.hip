@@ -566,6 +566,90 @@ __global__ void subiso_edge_k(const int64_t *sub, const int64_t *sample_ptr, con
   }
 }
 
+// get_dual_subisomorphisms (utils/graph.py:277-316 as convert_to_dual_data drives it, train.py:417-446): a node map
+// of a sample (one row of its `subisomorphisms`) -> for every KEY of the pattern the id of the graph edge it lands on.
+// Keys: maximal runs of consecutive pattern edges (edge-id order) with equal (src, dst); a later run of a key that
+// exists already REPLACES that key's label list but keeps its position (a Python dict, graph.py:293-300).  Entry k of a
+// row: among the graph edges mapped-src -> mapped-dst whose label occurs in key k's list, the LAST one in the
+// (src, dst)-sorted order with ties in edge-id order -- i.e. the one with the largest edge id.  Rows are p_len wide;
+// the entries past the number of keys, and keys without a matching edge, keep the reference's initial 0, which its
+// caller then sends through g_eid[0]: the id of the FIRST edge of the sorted order.
+// One thread per sample builds the key table; one thread per output entry does the lookup in the CSR by source.
+__global__ void dual_keys_k(const int64_t *p_src, const int64_t *p_dst, const int64_t *p_edge_off, int64_t B,
+                            const int64_t *g_node_off, const int64_t *g_edge_off, const int32_t *out_ptr,
+                            const int32_t *out_ent, const int32_t *g_dst, int32_t *key_lo, int32_t *key_hi,
+                            int32_t *num_keys, int64_t *first_sorted) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int64_t lo = p_edge_off[i], hi = p_edge_off[i + 1];
+  int nk = 0;
+  for (int64_t a = lo; a < hi;) {
+    int64_t b = a + 1;
+    while (b < hi && p_src[b] == p_src[a] && p_dst[b] == p_dst[a]) ++b;
+    int slot = -1;                                            // an earlier key with the same endpoints?
+    for (int k = 0; k < nk; ++k) {
+      const int64_t f = lo + key_lo[lo + k];
+      if (p_src[f] == p_src[a] && p_dst[f] == p_dst[a]) { slot = k; break; }
+    }
+    if (slot < 0) slot = nk++;
+    key_lo[lo + slot] = (int32_t)(a - lo);                   // the label list of the key: pattern edges [a, b)
+    key_hi[lo + slot] = (int32_t)(b - lo);
+    a = b;
+  }
+  num_keys[i] = nk;
+  // first edge of the graph in (src, dst, edge id) order, as a LOCAL edge id
+  int64_t first = 0;
+  for (int64_t n = g_node_off[i]; n < g_node_off[i + 1]; ++n) {
+    if (out_ptr[n + 1] > out_ptr[n]) {
+      int32_t best = out_ent[out_ptr[n]] >> 1;               // rows list ascending edge ids: the first minimum wins
+      for (int32_t q = out_ptr[n] + 1; q < out_ptr[n + 1]; ++q) {
+        const int32_t e = out_ent[q] >> 1;
+        if (g_dst[e] < g_dst[best]) best = e;
+      }
+      first = best - g_edge_off[i];
+      break;
+    }
+  }
+  first_sorted[i] = first;
+}
+
+__global__ void dual_match_k(const int64_t *sub, const int64_t *sample_ptr, const int64_t *work_ptr, int64_t B,
+                             const int64_t *p_node_off, const int64_t *p_edge_off, const int64_t *p_src,
+                             const int64_t *p_dst, const int64_t *p_label, const int32_t *key_lo, const int32_t *key_hi,
+                             const int32_t *num_keys, const int64_t *first_sorted, const int64_t *g_node_off,
+                             const int64_t *g_edge_off, const int32_t *out_ptr, const int32_t *out_ent,
+                             const int32_t *g_dst, const int64_t *g_label, int64_t *out, int32_t *status) {
+  const int64_t W = work_ptr[B];
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < W; w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = upper_slot(work_ptr, B, w);
+    const int64_t pe = p_edge_off[i + 1] - p_edge_off[i], pn = p_node_off[i + 1] - p_node_off[i];
+    const int64_t local = w - work_ptr[i];
+    const int64_t r = local / pe, k = local % pe;
+    int64_t res = first_sorted[i];
+    if (k < num_keys[i]) {
+      const int64_t e0 = p_edge_off[i];
+      const int64_t a = e0 + key_lo[e0 + k], b = e0 + key_hi[e0 + k];
+      const int64_t *row = sub + sample_ptr[i] + r * pn;
+      const int64_t gn = g_node_off[i + 1] - g_node_off[i];
+      const int64_t mu = row[p_src[a] - p_node_off[i]], mv = row[p_dst[a] - p_node_off[i]];
+      if (mu < 0 || mu >= gn || mv < 0 || mv >= gn) {
+        if (status) atomicOr(status, 1);
+      } else {
+        const int64_t u = g_node_off[i] + mu;
+        const int32_t v = (int32_t)(g_node_off[i] + mv);
+        for (int32_t q = out_ptr[u]; q < out_ptr[u + 1]; ++q) {   // ascending edge ids: the last hit is the largest
+          const int32_t e = out_ent[q] >> 1;
+          if (g_dst[e] != v) continue;
+          const int64_t l = g_label[e];
+          for (int64_t j = a; j < b; ++j)
+            if (p_label[j] == l) { res = e - g_edge_off[i]; break; }
+        }
+      }
+    }
+    out[w] = res;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Degree-class tile list of the typed edge kernels (csrc/dmp_typed.hip), built on the device in five
 // launches without atomics deciding any order: slot order = class ascending, nodes of a class in
@@ -1070,6 +1154,30 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l, const int64_t *
   unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
   dedupe_insert<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1);
   dedupe_lookup<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1, keep);
+  return check_launch();
+}
+
+int dmp_dual_subisomorphisms(const int64_t *sub, int64_t T, const int64_t *sample_ptr, const int64_t *work_ptr,
+                             int64_t work_total, int64_t B, const int64_t *p_node_off, const int64_t *p_edge_off,
+                             const int64_t *p_src, const int64_t *p_dst, const int64_t *p_label, int64_t PE,
+                             const int64_t *g_node_off, const int64_t *g_edge_off, const int32_t *g_out_ptr,
+                             const int32_t *g_out_ent, const int32_t *g_dst, const int64_t *g_label, int32_t *workspace,
+                             int64_t *first_sorted, int64_t *out, int32_t *status, void *stream) {
+  if (T < 0 || B < 0 || PE < 0 || work_total < 0) return DMP_ERR_BAD_ARG;
+  if (B == 0) return DMP_OK;
+  if (!sample_ptr || !work_ptr || !p_node_off || !p_edge_off || !g_node_off || !g_edge_off || !g_out_ptr || !workspace ||
+      !first_sorted || (PE > 0 && (!p_src || !p_dst || !p_label)) || (work_total > 0 && (!sub || !out)))
+    return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *key_lo = workspace, *key_hi = workspace + PE, *num_keys = workspace + 2 * PE;   // 2 PE + B words
+  dual_keys_k<<<nblk(B), kBlock, 0, st>>>(p_src, p_dst, p_edge_off, B, g_node_off, g_edge_off, g_out_ptr, g_out_ent, g_dst,
+                                         key_lo, key_hi, num_keys, first_sorted);
+  if (work_total > 0) {
+    const int64_t blocks = (work_total + kBlock - 1) / kBlock;
+    dual_match_k<<<(unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks), kBlock, 0, st>>>(
+        sub, sample_ptr, work_ptr, B, p_node_off, p_edge_off, p_src, p_dst, p_label, key_lo, key_hi, num_keys, first_sorted,
+        g_node_off, g_edge_off, g_out_ptr, g_out_ent, g_dst, g_label, out, status);
+  }
   return check_launch();
 }
 

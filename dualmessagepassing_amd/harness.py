@@ -8,6 +8,7 @@ host syncs per step (running sums stay on the device).  Plus a synthetic (patter
 with exact subgraph-isomorphism counts for smoke-level training runs: the reference's datasets are
 external downloads that are not available offline.
 """
+import math
 import os
 
 import numpy as np
@@ -183,6 +184,87 @@ class SyntheticPairs(PairDataset):
 
 
 _CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
+SCHEDULE_CYCLES = 2     # utils/anneal.py:7, utils/cyclical.py:7 (NUM_CYCLES, what train.py:510-562 passes)
+
+
+def scheduled_value(spec, step, total_steps, cycles=SCHEDULE_CYCLES):
+    """A loss weight / slope at optimisation step ``step`` from the reference's specification (config.py:480-515,
+    train.py:499-600): a number, ``"anneal_<shape>$a$b"`` (utils/anneal.py: ramp from a to b over the first half of each of
+    ``cycles`` periods, then hold b) or ``"cyclical_<shape>$a$b"`` (utils/cyclical.py: a -> b -> a every period); shape is
+    ``linear``, ``cosine`` or ``none`` / ``constant`` (always b).  Past ``total_steps``: b."""
+    if isinstance(spec, (int, float)):
+        return float(spec)
+    kind, a, b = spec.rsplit("$", 2)
+    a, b = float(a), float(b)
+    mode, _, shape = kind.partition("_")
+    if mode not in ("anneal", "cyclical"):
+        raise ValueError(spec)
+    if step > total_steps or shape in ("", "none", "constant"):
+        return b
+    phase = (cycles * step / max(1, total_steps)) % 1.0          # position inside the current period
+    if shape == "linear":
+        ramp = lambda t: t
+    elif shape == "cosine":
+        ramp = lambda t: (1.0 - math.cos(math.pi * t)) / 2.0
+    else:
+        raise NotImplementedError(shape)
+    if mode == "anneal":
+        return a + (b - a) * ramp(2.0 * phase) if phase < 0.5 else b
+    if shape == "linear":                                         # there and back
+        return a + (b - a) * 2.0 * phase if phase < 0.5 else b + (a - b) * (2.0 * phase - 1.0)
+    return a + (b - a) * ramp(2.0 * phase)
+
+
+def lr_factor(name, step, warmup, total, cycles=SCHEDULE_CYCLES, floor=1e-3):
+    """Learning-rate multiplier of the reference's schedulers (utils/scheduler.py:12-178) at scheduler step ``step``:
+    linear warm-up over ``warmup`` steps where the name says so, then constant / linear / cosine decay towards ``floor``
+    over ``total`` steps, ``cycles`` periods, optionally restarting every period."""
+    has_warmup = "warmup" in name
+    if has_warmup and step < warmup:
+        return step / max(1.0, float(warmup))
+    if name.startswith("constant"):
+        return 1.0
+    begin = warmup if has_warmup else 0
+    progress = (step - begin) / float(max(1, total - begin))
+    if name.startswith("linear"):
+        if name.endswith("restart"):
+            return floor if progress >= 1.0 else max(floor, 1.0 - (cycles * progress) % 1.0)
+        span = total - begin if has_warmup else total            # scheduler.py:49-52 divides by the full length without warm-up
+        return max(floor, (total - step) / float(max(1, span)))
+    if name.startswith("cosine"):
+        if name.endswith("restart"):
+            return floor if progress >= 1.0 else max(floor, 0.5 * (1.0 + math.cos(math.pi * ((cycles * progress) % 1.0))))
+        return max(floor, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * progress)))
+    raise NotImplementedError(name)
+
+
+class RunSchedule:
+    """Everything of a reference run configuration that varies with the optimisation step (train.py:1233-1253 for the
+    learning rate, :499-600 for the loss terms), from the ``config`` dictionary of ``config.py`` / ``config.json``."""
+
+    def __init__(self, config, num_train, lr=None):
+        self.config = config
+        bsz, epochs = config["train_batch_size"], config["train_epochs"]
+        self.base_lr = config["lr"] if lr is None else lr
+        self.warmup = int(num_train / bsz * 0.5 * min(epochs * 0.06, config.get("early_stop_rounds", 10)))
+        self.total = int(num_train / bsz * epochs)
+        self.floor = max(1e-3, config.get("weight_decay", 0.0))
+        if self.floor > 1e-8:
+            self.total -= self.warmup
+        self.cycles = max(1, self.total / 20000)
+        self.name = config.get("scheduler", "constant")
+        self.epoch_steps = int(math.ceil(num_train / bsz))
+        self.sched_step = 0
+
+    def lr(self):
+        return self.base_lr * lr_factor(self.name, self.sched_step, self.warmup, self.total, self.cycles, self.floor)
+
+    def loss_terms(self, epoch, batch_id):
+        step = epoch * self.epoch_steps + batch_id
+        total = self.config["train_epochs"] * self.epoch_steps
+        c = self.config
+        return {k: scheduled_value(c.get(k, d), step, total) for k, d in
+                (("neg_pred_slp", 0.0), ("match_loss_w", 0.0), ("match_reg_w", 0.0), ("rep_reg_w", 0.0))}
 
 
 def _match_terms(crit, pred, weights, mask, pred_c, neg_slp):
@@ -196,10 +278,12 @@ def _match_terms(crit, pred, weights, mask, pred_c, neg_slp):
 
 
 def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_loss="MSE", eval_metric="MAE",
-                neg_slp=0.0, rep_reg_w=0.0, match_loss_w=0.0, match_reg_w=0.0, max_grad_norm=8.0, order=None):
+                neg_slp=0.0, rep_reg_w=0.0, match_loss_w=0.0, match_reg_w=0.0, max_grad_norm=8.0, order=None,
+                schedule=None, epoch=0, match_weights=("node", "edge")):
     """One pass over ``dataset`` (train.py:449-844): count loss, optional representation regulariser
     and, with ``match_loss_w`` / ``match_reg_w`` and a model built with ``pred_return_weights``, the
-    node / edge matching losses against the batch's subisomorphism weights.  Returns
+    node / edge matching losses against the batch's subisomorphism weights.  With a ``RunSchedule`` the four loss
+    coefficients and the learning rate follow the run configuration step by step, as train.py:499-600,686 do.  Returns
     ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end)."""
     model.train()
     sync = sync or FlatGradSync(model)
@@ -207,9 +291,17 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
     tot_loss = torch.zeros((), device=device)
     tot_eval = torch.zeros((), device=device)
     cnt = 0
-    for i in range(0, len(order), batch_size):
+    if isinstance(match_weights, str):
+        match_weights = tuple(w for w in match_weights.split(",") if w in ("node", "edge"))
+    for b_id, i in enumerate(range(0, len(order), batch_size)):
         idx = order[i:i + batch_size]
-        want = ("node", "edge") if (match_loss_w > 0 or match_reg_w > 0) else None
+        if schedule is not None:
+            terms = schedule.loss_terms(epoch, b_id)
+            neg_slp, match_loss_w, match_reg_w, rep_reg_w = (terms["neg_pred_slp"], terms["match_loss_w"], terms["match_reg_w"],
+                                                             terms["rep_reg_w"])
+            for group in optimizer.param_groups:
+                group["lr"] = schedule.lr()
+        want = (tuple(match_weights) or None) if (match_loss_w > 0 or match_reg_w > 0) else None
         pattern, graph, counts, (node_w, edge_w) = dataset.batchify(idx, device, return_weights=want)
         sync.detach_grads()
         out = model(pattern, graph)
@@ -219,9 +311,9 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
             if w is not None and out[pk] is not None:
                 m_loss, m_reg = _match_terms(_CRIT[bp_loss], out[pk], w, out[mk], pred, neg_slp)
                 loss = loss + match_loss_w * m_loss + match_reg_w * m_reg
-        if rep_reg_w > 0:  # train.py:651-659
+        if rep_reg_w > 0:  # train.py:651-659 (bp_crit with slope 1: the plain criterion against zeros)
             reg = sum(_CRIT[bp_loss](out[k], torch.zeros_like(out[k])) * out[k].size(1)
-                      for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep"))
+                      for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep") if out[k] is not None)
             loss = loss + rep_reg_w * reg
         loss.backward()
         sync.pack()
@@ -229,6 +321,8 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
         if max_grad_norm > 0:
             torch.nn.utils.clip_grad_norm_(sync.params, max_grad_norm)
         optimizer.step()
+        if schedule is not None:
+            schedule.sched_step += 1
         with torch.no_grad():
             tot_loss += loss.detach() * len(idx)
             tot_eval += _CRIT[eval_metric](F.relu(pred), counts) * len(idx)

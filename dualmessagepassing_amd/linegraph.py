@@ -126,3 +126,47 @@ def convert_to_dual_graph(graph):
     out = BatchedGraph(dsrc, ddst, int(dual_bnn.sum().item()), dual_bnn if graph._bnn is not None else None,
                        dual_bne if graph._bne is not None else None, dual_ndata, dual_edata)
     return out
+
+
+def dual_subisomorphisms(pattern, graph, sub_flat, sample_ptr, rows_host=None, validate=False):
+    """``get_dual_subisomorphisms`` + the ``g_eid[...]`` mapping of ``convert_to_dual_data`` (utils/graph.py:277-316,
+    train.py:417-446) for a whole batch on the device: the samples' node maps (``subisomorphisms`` rows, flattened back to
+    back in ``sub_flat`` with ``sample_ptr`` [B+1]) become maps onto the EDGES of the target graphs -- i.e. onto the
+    nodes of their line graphs (``convert_to_dual_graph``), which is what the matching losses need after
+    ``--convert_dual``.  Returns ``(dual_flat, dual_ptr)``: per sample ``rows_i`` rows of ``pattern_edges_i`` sample-local
+    edge ids, ``dual_ptr`` [B+1] the first element of each sample.  ``rows_host`` (optional list of the samples' row
+    counts, which a dataset knows) avoids the one device round trip that sizes the output."""
+    lib = _lib.load()
+    pattern, graph = as_batched(pattern), as_batched(graph)
+    _lib.require_gpu(sub_flat, sample_ptr)
+    if sub_flat.dtype != torch.int64 or sample_ptr.dtype != torch.int64:
+        raise _lib.DmpError("dual_subisomorphisms: int64 inputs expected")
+    sub_flat, sample_ptr = sub_flat.contiguous(), sample_ptr.contiguous()
+    B = graph.batch_size
+    if pattern.batch_size != B or sample_ptr.numel() != B + 1:
+        raise _lib.DmpError("dual_subisomorphisms: batch sizes disagree")
+    dev = sub_flat.device
+    pn, pe = pattern.batch_num_nodes().to(torch.int64), pattern.batch_num_edges().to(torch.int64)
+    p_node_off, p_edge_off = _offsets(pn), _offsets(pe)
+    g_node_off, g_edge_off = _offsets(graph.batch_num_nodes().to(torch.int64)), _offsets(graph.batch_num_edges().to(torch.int64))
+    rows = (sample_ptr[1:] - sample_ptr[:-1]) // pn.clamp(min=1)
+    work_ptr = _offsets(rows * pe)
+    if rows_host is not None and getattr(pattern, "edge_sizes_host", None) is not None:
+        total = int(sum(int(r) * int(e) for r, e in zip(rows_host, pattern.edge_sizes_host)))      # no device round trip
+    else:
+        total = int(work_ptr[-1].item())
+    PE = pattern.number_of_edges()
+    ix = graph.index()
+    out = torch.empty(total, dtype=torch.int64, device=dev)
+    first = torch.empty(B, dtype=torch.int64, device=dev)
+    ws = torch.empty(2 * PE + B, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    from .constants import EDGELABEL
+    check(lib.dmp_dual_subisomorphisms(ptr(sub_flat), int(sub_flat.numel()), ptr(sample_ptr), ptr(work_ptr), total, B,
+                                       ptr(p_node_off), ptr(p_edge_off), ptr(pattern._src.contiguous()), ptr(pattern._dst.contiguous()),
+                                       ptr(pattern.edata[EDGELABEL].contiguous()), PE, ptr(g_node_off), ptr(g_edge_off),
+                                       ptr(ix.out_ptr), ptr(ix.out_ent), ptr(ix.dst32), ptr(graph.edata[EDGELABEL].contiguous()),
+                                       ptr(ws), ptr(first), ptr(out), ptr(status), stream_ptr()), "dmp_dual_subisomorphisms")
+    if validate and int(status.item()) != 0:
+        raise _lib.DmpError("dual_subisomorphisms: a subisomorphism row refers to a node outside its target graph")
+    return out, work_ptr

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 33
+#define DMP_ABI_VERSION 34
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -205,6 +205,24 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
 int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
                             const int64_t *g_node_off, int64_t *out, int64_t N,
                             int32_t *status, void *stream);
+/*
+ * get_dual_subisomorphisms (utils/graph.py:277-316 as convert_to_dual_data calls it, train.py:417-446) for a whole
+ * batch: the node maps of the samples -> per map and per pattern KEY the (sample-local) id of the graph edge it is sent
+ * to.  Keys = maximal runs of consecutive pattern edges with equal (src, dst) in edge-id order; a later run of an
+ * existing key replaces its label list and keeps its position (dict semantics, graph.py:293-300).  out: rows back to
+ * back, sample i contributing rows_i rows of p_edges_i entries (work_ptr [B+1] = exclusive prefix of rows_i * p_edges_i,
+ * work_total = work_ptr[B] as a host int); entry k < #keys: the LARGEST edge id among the graph edges
+ * map(src_k) -> map(dst_k) whose label is in key k's list (= the last one of the reference's (src, dst)-sorted scan);
+ * no such edge, or k >= #keys: the id of the first edge of that sorted order (the reference leaves index 0 there and
+ * maps it through g_eid).  first_sorted [B] receives that id per sample.  workspace: 2 * PE + B int32 words.
+ * p_src / p_dst / g_dst are batch-global node ids, the sub rows sample-local ones (as stored in the dataset).
+ */
+int dmp_dual_subisomorphisms(const int64_t *sub, int64_t T, const int64_t *sample_ptr, const int64_t *work_ptr,
+                             int64_t work_total, int64_t B, const int64_t *p_node_off, const int64_t *p_edge_off,
+                             const int64_t *p_src, const int64_t *p_dst, const int64_t *p_label, int64_t PE,
+                             const int64_t *g_node_off, const int64_t *g_edge_off, const int32_t *g_out_ptr,
+                             const int32_t *g_out_ent, const int32_t *g_dst, const int64_t *g_label,
+                             int32_t *workspace, int64_t *first_sorted, int64_t *out, int32_t *status, void *stream);
 int dmp_pattern_edge_active(const int64_t *p_src, const int64_t *p_dst, const int64_t *p_edge_off,
                             const int32_t *p_edge_graph, int64_t PE, uint8_t *active, void *stream);
 int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr,

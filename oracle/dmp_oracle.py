@@ -222,6 +222,27 @@ def unc_edge_norm(src, dst, n, norm="in"):
     return w
 
 
+def unc_build_graph(num_nodes, num_rels, triplets):
+    """``build_graph_from_triplets`` (UNC Model/DMPNN/src/utils.py:473-491): triplets (src, rel, dst) sorted by
+    (src, dst, rel) -- numpy's structured sort with ``order=["src", "dst", "rel"]`` --, the E forward edges then their
+    E reversed copies, ``type = rel | rel + num_rels``, ``norm = 1 / in_degree[dst]``.
+    Returns (src, dst, type, norm [2E, 1])."""
+    import numpy as np
+    t = np.asarray(triplets, dtype=np.int64)
+    rows = sorted(range(len(t)), key=lambda i: (t[i, 0], t[i, 2], t[i, 1]))
+    t = t[rows]
+    src = th.from_numpy(np.concatenate([t[:, 0], t[:, 2]]))
+    dst = th.from_numpy(np.concatenate([t[:, 2], t[:, 0]]))
+    typ = th.from_numpy(np.concatenate([t[:, 1], t[:, 1] + num_rels]))
+    return src, dst, typ, unc_edge_norm(src, dst, num_nodes, "in")
+
+
+def unc_eigen_bounds(src, dst, n):
+    """UNC ``compute_largest_eigenvalues`` (utils.py:456-470): the SCM rule on structure degrees."""
+    ind, outd = in_degrees(dst, n).float(), out_degrees(src, n).float()
+    return (outd[src] + ind[dst]).max(), (ind[src] + outd[dst]).max()
+
+
 def dual_graph_conv(params, src, dst, out_deg, x, z, edge_norm=None, rev=None, bn=None, training=False,
                     activation_name=None):
     """UNC ``DualGraphConv.forward`` (UNC Model/DMPNN/src/model.py:222-273): DMPLayer math with

@@ -145,3 +145,30 @@ def batch_subiso_weights(d):
                                       d["g_src"][go:go + ge], d["g_dst"][go:go + ge], d["g_elabel"][go:go + ge], sub))
         po, go = po + pe, go + ge
     return pre_pad(nw), pre_pad(ew)
+
+
+def dual_subisomorphisms(p_u, p_v, p_el, g_u, g_v, g_el, sub):
+    """``get_dual_subisomorphisms`` (utils/graph.py:277-316), plain Python (small cases).  ``g_u, g_v, g_el``: the graph's
+    edges sorted by (src, dst), as ``all_edges(order="srcdst")`` hands them over (train.py:426-428).  Runs of consecutive
+    pattern edges with an equal (u, v) key form one entry -- a later run of the same key REPLACES the earlier one but keeps
+    its position (dict semantics, graph.py:293-300) --; entry k of a row receives the index (in the sorted order) of the
+    LAST graph edge between the mapped endpoints whose label occurs in the run; entries beyond the number of keys stay 0."""
+    p_u, p_v, p_el = _i64(p_u), _i64(p_v), _i64(p_el)
+    g_u, g_v, g_el = _i64(g_u), _i64(g_v), _i64(g_el)
+    sub = np.asarray(sub, dtype=np.int64).reshape(-1, int(max(p_u.max(), p_v.max())) + 1 if len(sub) == 0 else np.asarray(sub).shape[1])
+    out = np.zeros((len(sub), len(p_el)), dtype=np.int64)
+    runs = {}
+    i = 0
+    while i < len(p_el):
+        j = i + 1
+        while j < len(p_el) and (p_u[i], p_v[i]) == (p_u[j], p_v[j]):
+            j += 1
+        runs[(int(p_u[i]), int(p_v[i]))] = [int(x) for x in p_el[i:j]]
+        i = j
+    for r, row in enumerate(sub):
+        for k, ((u, v), labels) in enumerate(runs.items()):
+            mu, mv = int(row[u]), int(row[v])
+            for idx in range(len(g_el)):
+                if g_u[idx] == mu and g_v[idx] == mv and int(g_el[idx]) in labels:
+                    out[r, k] = idx
+    return out

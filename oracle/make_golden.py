@@ -543,6 +543,24 @@ mapped = unc_utils.convert_subgraph_nids(ori, subg_nids)
 np.savez_compressed(os.path.join(%(out)r, "unc_sampling.npz"), pos=pos, neg=neg, values=values, choices=choices,
                     subg_nids=subg_nids, ori=ori, mapped=mapped, num_entity=40, negative_rate=4)
 print("wrote unc_sampling.npz")
+
+# A17: graph construction and edge normalisation by the reference's own functions (utils.py:437-491)
+trip = np.stack([rng.integers(0, 25, 60), rng.integers(0, 3, 60), rng.integers(0, 25, 60)], 1).astype(np.int64)
+trip[5] = trip[4]                                        # a duplicate triplet; node 24 may stay isolated
+gb = unc_utils.build_graph_from_triplets(25, 3, trip)
+d = {"triplets": trip, "num_nodes": 25, "num_rels": 3, "src": gb._u, "dst": gb._v, "type": gb.edata["type"], "norm": gb.edata["norm"],
+     "in_deg": gb.ndata["in_deg"], "out_deg": gb.ndata["out_deg"]}
+for mode in ("in", "out", "both"):
+    d["norm_" + mode] = unc_utils.compute_edgenorm(gb, mode)
+ne, ee = unc_utils.compute_largest_eigenvalues(gb)
+d["node_eigenv"], d["edge_eigenv"] = ne, ee
+# a directed graph with zero in- / out-degree endpoints: the NaN / Inf branches of compute_edgenorm (utils.py:450-451)
+gd = dgl.DGLGraph.from_edges(np.array([0, 0, 1, 3]), np.array([1, 2, 2, 0]), 5)
+for mode in ("in", "out", "both"):
+    d["dir_norm_" + mode] = unc_utils.compute_edgenorm(gd, mode)
+d["dir_src"], d["dir_dst"] = gd._u, gd._v
+np.savez_compressed(os.path.join(%(out)r, "unc_graph_build.npz"), **t2n(d))
+print("wrote unc_graph_build.npz", tuple(gb.edata["norm"].shape))
 '''
 
 
@@ -743,20 +761,391 @@ def gen_rgnn():
         print("wrote rgnn_model_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
 
 
+# ----------------------------------------------------------------------------- round 2: pins for A7 / A14 / A17, the
+# reference's shipped configuration, its training loop, and the dual-subisomorphism re-indexing
+README_COMPLEX_ARGS = (
+    "--add_rev True --hid_dim 64 --node_pred True --edge_pred False --match_weights node --enc_net Multihot --enc_base 2 "
+    "--emb_net Equivariant --share_emb_net True --rep_net DMPNN --rep_num_pattern_layers 3 --rep_num_graph_layers 3 "
+    "--rep_residual True --rep_dropout 0.0 --share_rep_net True --pred_net SumPredictNet --pred_hid_dim 64 --pred_dropout 0.0 "
+    "--train_grad_steps 1 --lr 1e-3 --seed 0 --gpu_id -1")          # README.md:72-94 ("Complex"), sizes / dirs given per case
+
+
+def reference_config(extra_args):
+    """The reference's OWN argument parser (config.py: every default it ships) on the README "Complex" command line."""
+    import config as refconfig
+    argv, sys.argv = sys.argv, ["train.py"] + README_COMPLEX_ARGS.split() + list(extra_args)
+    try:
+        return refconfig.get_train_config()
+    finally:
+        sys.argv = argv
+
+
+def _ref_graph(u, v, vl, el):
+    import dgl
+    import dataset as ref_dataset
+    g = ref_dataset.Graph()
+    g.add_nodes(len(vl))
+    dgl.DGLGraph.add_edges(g, np.asarray(u, np.int64), np.asarray(v, np.int64))
+    g.ndata["id"], g.ndata["label"] = th.arange(len(vl)), th.from_numpy(np.asarray(vl, np.int64))
+    g.edata["id"], g.edata["label"] = th.arange(len(u)), th.from_numpy(np.asarray(el, np.int64))
+    return g
+
+
+def gen_preprocess():
+    """A14: ``compute_largest_eigenvalues`` (utils/graph.py:40-71), ``calculate_degrees`` / ``calculate_eigenvalues``
+    (train.py:330-380) and the dataset-level ``init_neigenv / init_eeigenv`` rule (train.py:1174-1186), run by the
+    reference's own functions on a ``GraphAdjDataset`` after its ``add_reversed_edges`` (train.py:299-327)."""
+    import dataset as ref_dataset
+    import train as ref_train
+    from utils.graph import compute_largest_eigenvalues
+    rng = np.random.default_rng(2026)
+    shapes = [(3, 3, 7, 12), (4, 6, 9, 30), (2, 1, 5, 4), (8, 12, 64, 256), (5, 20, 16, 90), (1, 0, 3, 2)]
+    data = ref_dataset.GraphAdjDataset()
+    raw = []
+    for i, (pn, pm, gn, gm) in enumerate(shapes):
+        pu, pv = er_edges(pn, pm, rng) if pm else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        gu, gv = er_edges(gn, gm, rng)
+        pvl, gvl = rng.integers(0, 3, pn), rng.integers(0, 3, gn)
+        pel, gel = rng.integers(0, 2, pm), rng.integers(0, 2, gm)
+        raw.append((pu, pv, pvl, pel, gu, gv, gvl, gel))
+        data.data.append({"id": "s-%d" % i, "pattern": _ref_graph(pu, pv, pvl, pel), "graph": _ref_graph(gu, gv, gvl, gel),
+                          "counts": 0, "subisomorphisms": th.zeros((0, pn), dtype=th.long)})
+    d = {}
+    # before add_rev, on the plain graphs (no cached degrees: the function computes them)
+    for i, x in enumerate(data):
+        for t in ("pattern", "graph"):
+            if x[t].number_of_edges() == 0:
+                continue
+            ne, ee = compute_largest_eigenvalues(x[t])
+            d["plain.%d.%s.node_eigenv" % (i, t[0])], d["plain.%d.%s.edge_eigenv" % (i, t[0])] = ne, ee
+    max_npe, max_npel, max_nge, max_ngel = 20, 2, 256, 2
+    ref_train.add_reversed_edges(data, max_npe, max_npel, max_nge, max_ngel)
+    ref_train.calculate_degrees(data)
+    drop = [i for i, x in enumerate(data) if x["pattern"].number_of_edges() == 0]   # .max() of an empty tensor raises there
+    keep = ref_dataset.GraphAdjDataset()
+    keep.data = [x for i, x in enumerate(data) if i not in drop]
+    ref_train.calculate_eigenvalues(keep)
+    max_neigenv = max_eeigenv = 4.0
+    for x in keep:                                             # train.py:1183-1186
+        max_neigenv = max(max_neigenv, x["pattern"].ndata["node_eigenv"][0].item())
+        max_eeigenv = max(max_eeigenv, x["pattern"].edata["edge_eigenv"][0].item())
+    d["init_neigenv"], d["init_eeigenv"] = max_neigenv, max_eeigenv
+    d["num_samples"], d["dropped"] = len(shapes), np.array(drop, np.int64)
+    d["max_npe"], d["max_npel"], d["max_nge"], d["max_ngel"] = max_npe, max_npel, max_nge, max_ngel
+    for i, (x, r) in enumerate(zip(data, raw)):
+        for t, (u, v, vl, el) in (("p", r[:4]), ("g", r[4:])):
+            g = x["pattern" if t == "p" else "graph"]
+            d.update({"%d.%s.src" % (i, t): u, "%d.%s.dst" % (i, t): v, "%d.%s.vlabel" % (i, t): vl, "%d.%s.elabel" % (i, t): el,
+                      "%d.%s.in_deg" % (i, t): g.ndata["in_deg"], "%d.%s.out_deg" % (i, t): g.ndata["out_deg"],
+                      "%d.%s.o_src" % (i, t): g._u, "%d.%s.o_dst" % (i, t): g._v})
+            if i not in drop:
+                d["%d.%s.node_eigenv" % (i, t)] = g.ndata["node_eigenv"]
+                d["%d.%s.edge_eigenv" % (i, t)] = g.edata["edge_eigenv"]
+    np.savez_compressed(os.path.join(OUT, "preprocess_eigen.npz"), **t2n(d))
+    print("wrote preprocess_eigen.npz  init_neigenv %.1f init_eeigenv %.1f" % (max_neigenv, max_eeigenv))
+
+
+def gen_init():
+    """A7: seeded construction.  ``th.manual_seed(s); Layer(...)`` of the reference -> its ``state_dict`` (xavier with
+    the activation's gain, utils/init.py:70-143, the eigenvalue re-parameterisation dmpnn.py:78-85, Linear defaults)."""
+    from models.compgcn import CompGCNLayer
+    from models.dmpnn import DMPLayer, DMPNN
+    d = {}
+    cases = [("dmp_relu", DMPLayer, dict(input_dim=12, hidden_dim=12, init_neigenv=4.0, init_eeigenv=4.0, num_mlp_layers=2, batch_norm=False, act_func="relu")),
+             ("dmp_leaky", DMPLayer, dict(input_dim=16, hidden_dim=16, init_neigenv=7.0, init_eeigenv=5.0, num_mlp_layers=2, batch_norm=True, act_func="leaky_relu")),
+             ("dmp_tanh_m0", DMPLayer, dict(input_dim=8, hidden_dim=8, init_neigenv=4.0, init_eeigenv=6.0, num_mlp_layers=0, batch_norm=False, act_func="tanh", bias=False)),
+             ("compgcn_corr", CompGCNLayer, dict(input_dim=8, hidden_dim=8, comp_opt="corr", edge_norm="both", act_func="leaky_relu", batch_norm=True)),
+             ("compgcn_sub", CompGCNLayer, dict(input_dim=6, hidden_dim=6, comp_opt="sub", edge_norm="none", act_func="relu", self_loop=False))]
+    for tag, cls, kw in cases:
+        th.manual_seed(seed_of("init", tag))
+        layer = cls(**kw)
+        d["%s.seed" % tag] = seed_of("init", tag)
+        d["%s.kw_keys" % tag] = np.array(sorted(kw))
+        d["%s.kw_vals" % tag] = np.array([repr(kw[k]) for k in sorted(kw)])
+        for k, v in layer.state_dict().items():
+            d["%s.sd.%s" % (tag, k)] = v.clone()
+    # the whole model at the reference's shipped defaults (Equivariant embeddings, leaky_relu, node head with weights)
+    cfg = reference_config("--max_npv 8 --max_npe 8 --max_npvl 8 --max_npel 8 --max_ngv 64 --max_nge 256 --max_ngvl 16 --max_ngel 16".split())
+    import train as ref_train
+    mc = ref_train.process_model_config(cfg)
+    th.manual_seed(cfg["seed"])
+    model = ref_train.build_model(mc, init_neigenv=6.0, init_eeigenv=5.0)
+    d["model.seed"] = cfg["seed"]
+    d["model.config_json"] = np.array(json_dumps(mc))
+    for k, v in model.state_dict().items():
+        d["model.sd.%s" % k] = v.clone()
+    np.savez_compressed(os.path.join(OUT, "init_state_dicts.npz"), **t2n(d))
+    print("wrote init_state_dicts.npz", sum(1 for k in d if ".sd." in k), "tensors")
+
+
+def json_dumps(cfg):
+    import json
+    return json.dumps({k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, type(None)))}, sort_keys=True)
+
+
+def _ref_sample(rng, name, pn, pm, gn, gm, nvl, nel):
+    """One (pattern, graph) sample with its exact subisomorphisms, as the reference's loader would hold it."""
+    pu, pv = er_edges(pn, pm, rng)
+    gu, gv = er_edges(gn, gm, rng)
+    pvl, gvl = rng.integers(0, nvl, pn), rng.integers(0, nvl, gn)
+    pel, gel = rng.integers(0, nel, pm), rng.integers(0, nel, gm)
+    sub = enumerate_subisomorphisms(pu, pv, pel, pvl, gu, gv, gel, gvl)
+    raw = dict(pu=pu, pv=pv, pvl=pvl, pel=pel, gu=gu, gv=gv, gvl=gvl, gel=gel, sub=sub)
+    return {"id": name, "pattern": _ref_graph(pu, pv, pvl, pel), "graph": _ref_graph(gu, gv, gvl, gel), "counts": len(sub),
+            "subisomorphisms": th.from_numpy(sub)}, raw
+
+
+class _FixedLoader:
+    """What train_epoch / evaluate_epoch need from a DataLoader: ``dataset``, ``len`` and batches in a fixed order."""
+
+    def __init__(self, dataset, batches, return_weights):
+        self.dataset, self.batches, self.return_weights = dataset, batches, return_weights
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for idx in self.batches:
+            yield self.dataset.batchify([self.dataset[i] for i in idx], return_weights=self.return_weights)
+
+
+def gen_train_run():
+    """BASELINE config 3 in miniature: the reference's OWN pipeline on a small synthetic dataset at its shipped settings
+    (README "Complex" command: leaky_relu, Equivariant, hid 64, node head with matching weights, AdamW(amsgrad), cosine
+    warm-up / restart schedule, annealed neg_pred_slp / match_loss_w / rep_reg_w) -- ``add_reversed_edges`` ->
+    ``calculate_degrees`` -> ``calculate_eigenvalues`` -> ``build_model`` -> epochs of ``train_epoch`` +
+    ``evaluate_epoch`` (train.py:449-1061) over fixed batch orders.  Stored: the samples, the initial and final
+    ``state_dict``, per-epoch train metrics and dev MAE / predictions."""
+    import dataset as ref_dataset
+    import train as ref_train
+    from utils.scheduler import map_scheduler_str_to_scheduler
+    rng = np.random.default_rng(303)
+    n_train, n_dev, bsz, epochs = 96, 32, 32, 5
+    sets = {"train": ref_dataset.GraphAdjDataset(), "dev": ref_dataset.GraphAdjDataset()}
+    raws = {"train": [], "dev": []}
+    for split, n in (("train", n_train), ("dev", n_dev)):
+        for i in range(n):
+            pn = int(rng.integers(3, 6)); pm = int(rng.integers(pn - 1, min(8, pn * (pn - 1)) + 1))
+            gn = int(rng.integers(8, 21)); gm = int(rng.integers(2 * gn, min(64, gn * (gn - 1)) + 1))
+            x, raw = _ref_sample(rng, "%s-%d" % (split, i), pn, pm, gn, gm, 2, 2)
+            sets[split].data.append(x)
+            raws[split].append(raw)
+    args = ("--max_npv 8 --max_npe 8 --max_npvl 2 --max_npel 2 --max_ngv 20 --max_nge 64 --max_ngvl 2 --max_ngel 2 "
+            "--train_batch_size %d --eval_batch_size %d --train_epochs %d --train_log_steps 1000" % (bsz, bsz, epochs)).split()
+    config = reference_config(args)
+    random_seed = config["seed"]
+    import random
+    random.seed(random_seed); th.manual_seed(random_seed); np.random.seed(random_seed)
+    # train.py:1111-1186, in its order
+    max_ngv, max_nge, max_ngvl, max_ngel = config["max_ngv"], config["max_nge"], config["max_ngvl"], config["max_ngel"]
+    max_npv, max_npe, max_npvl, max_npel = (max_ngv, max_nge, max_ngvl, max_ngel) if config["share_emb_net"] else \
+        (config["max_npv"], config["max_npe"], config["max_npvl"], config["max_npel"])
+    for ds in sets.values():
+        for x in ds:
+            x["g_len"], x["p_len"] = len(x["graph"]), len(x["pattern"])
+        ref_train.add_reversed_edges(ds, max_npe, max_npel, max_nge, max_ngel)
+    max_neigenv = max_eeigenv = 4.0
+    for ds in sets.values():
+        ref_train.calculate_degrees(ds)
+        ref_train.calculate_eigenvalues(ds)
+        for x in ds:
+            max_neigenv = max(max_neigenv, x["pattern"].ndata["node_eigenv"][0].item())
+            max_eeigenv = max(max_eeigenv, x["pattern"].edata["edge_eigenv"][0].item())
+    model = ref_train.build_model(ref_train.process_model_config(config), init_neigenv=max_neigenv, init_eeigenv=max_eeigenv)
+    d = {"config_json": np.array(json_dumps(config)), "model_config_json": np.array(json_dumps(ref_train.process_model_config(config))),
+         "init_neigenv": max_neigenv, "init_eeigenv": max_eeigenv, "rev_max_npe": max_npe, "rev_max_npel": max_npel,
+         "rev_max_nge": max_nge, "rev_max_ngel": max_ngel}
+    for k, v in model.state_dict().items():
+        d["sd0." + k] = v.clone()
+    optimizer = th.optim.AdamW(model.parameters(), lr=config["lr"], weight_decay=config["weight_decay"], amsgrad=True)
+    optimizer.zero_grad()
+    # train.py:1233-1253
+    num_warmup_steps = int(n_train / config["train_batch_size"] * 0.5 * min(config["train_epochs"] * 0.06, config["early_stop_rounds"]))
+    num_schedule_steps = int(n_train / config["train_batch_size"] * config["train_epochs"])
+    min_percent = max(1e-3, config["weight_decay"])
+    if min_percent > 1e-8:
+        num_schedule_steps -= num_warmup_steps
+    num_cycles = max(1, num_schedule_steps / 20000)
+    scheduler = map_scheduler_str_to_scheduler(config["scheduler"], num_warmup_steps=num_warmup_steps,
+                                               num_schedule_steps=num_schedule_steps, num_cycles=num_cycles, min_percent=min_percent)
+    scheduler.set_optimizer(optimizer)
+    d.update({"num_warmup_steps": num_warmup_steps, "num_schedule_steps": num_schedule_steps, "num_cycles": num_cycles,
+              "min_percent": min_percent})
+    orders = np.stack([np.random.default_rng(1000 + e).permutation(n_train) for e in range(epochs)])
+    d["train_orders"] = orders
+    dev_batches = [list(range(i, min(i + bsz, n_dev))) for i in range(0, n_dev, bsz)]
+    hist = {"train_eval": [], "train_bp": [], "dev_eval": [], "lr": []}
+    device = th.device("cpu")
+    for epoch in range(epochs):
+        batches = [orders[epoch][i:i + bsz].tolist() for i in range(0, n_train, bsz)]
+        hist["lr"].append(scheduler.get_last_lr()[0])
+        ev, bp = ref_train.train_epoch(model, optimizer, scheduler, "train", _FixedLoader(sets["train"], batches, config["match_weights"]),
+                                       device, config, epoch, None, None)
+        dev_ev, dev_res = ref_train.evaluate_epoch(model, "dev", _FixedLoader(sets["dev"], dev_batches, config["match_weights"]),
+                                                   device, config, epoch, None, None)
+        hist["train_eval"].append(ev); hist["train_bp"].append(bp); hist["dev_eval"].append(dev_ev)
+        print("  epoch %d  train %s %.4f  bp %.4f  dev %s %.4f" % (epoch, config["eval_metric"], ev, bp, config["eval_metric"], dev_ev))
+    for k, v in hist.items():
+        d["hist." + k] = np.array(v, np.float64)
+    d["dev_pred_c"] = np.array(dev_res["prediction"]["pred_c"], np.float64).reshape(-1)
+    d["dev_counts"] = np.array(dev_res["data"]["counts"], np.float64).reshape(-1)
+    d["dev_MAE"], d["dev_MSE"] = dev_res["error"]["MAE"], dev_res["error"]["MSE"]
+    for k, v in model.state_dict().items():
+        d["sd1." + k] = v.clone()
+    for split in ("train", "dev"):
+        for i, r in enumerate(raws[split]):
+            for k, v in r.items():
+                d["%s.%d.%s" % (split, i, k)] = v
+        d[split + ".n"] = len(raws[split])
+    np.savez_compressed(os.path.join(OUT, "train_run_default.npz"), **t2n(d))
+    print("wrote train_run_default.npz  dev MAE %.4f" % d["dev_MAE"])
+
+
+def gen_default_model():
+    """``fullmodel_default``: one forward / backward of the model the README "Complex" command builds (train.py:68-87 over
+    config.py's defaults: leaky_relu 1/5.5 in rep-net and head, Equivariant embeddings, hid 64, node head only, per-node
+    matching weights) on a ragged batch -> all OutputDict entries and the gradients of pred_c.sum() + pred_v.sum()."""
+    import dgl
+    import train as ref_train
+    rng = np.random.default_rng(64)
+    cfg = reference_config("--max_npv 8 --max_npe 8 --max_npvl 8 --max_npel 8 --max_ngv 64 --max_nge 256 --max_ngvl 16 --max_ngel 16".split())
+    mc = ref_train.process_model_config(cfg)
+
+    def make_batch(sizes, n_vl, n_el, max_ne):
+        gs = []
+        for n, m in sizes:
+            u, v = er_edges(n, m, rng)
+            uu, vv, rev = with_rev(u, v)
+            g = dgl.DGLGraph.from_edges(uu, vv, n)
+            el = rng.integers(0, n_el, size=m)
+            g.ndata["id"] = th.arange(n)
+            g.ndata["label"] = th.from_numpy(rng.integers(0, n_vl, size=n))
+            g.edata["id"] = th.cat([th.arange(m), th.arange(m) + max_ne])
+            g.edata["label"] = th.from_numpy(np.concatenate([el, el + n_el]))
+            g.edata["is_reversed"] = th.from_numpy(rev)
+            g.ndata["in_deg"], g.ndata["out_deg"] = g.in_degrees(), g.out_degrees()
+            gs.append(g)
+        return dgl.batch(gs)
+
+    for tag, p_sizes, g_sizes in (("default", [(3, 3), (5, 8), (4, 6), (8, 8), (2, 1), (6, 8), (8, 7), (3, 2)],
+                                   [(10, 30), (16, 50), (7, 12), (64, 256), (5, 8), (12, 40), (40, 128), (33, 77)]),
+                                  ("default_uniform", [(8, 8)] * 16, [(64, 256)] * 16)):
+        th.manual_seed(11)
+        pattern, graph = make_batch(p_sizes, 8, 8, 256), make_batch(g_sizes, 16, 16, 256)   # share_emb_net: pattern ids in the graph vocabulary
+        model = ref_train.build_model(mc, init_neigenv=6.0, init_eeigenv=5.0)
+        with th.no_grad():
+            for head in model.pred_net.values():
+                if head is not None:
+                    head.pred_fc2.weight.uniform_(-0.3, 0.3); head.pred_fc2.bias.uniform_(-0.1, 0.1)
+                    head.weight_fc2.weight.uniform_(-0.3, 0.3); head.weight_fc2.bias.uniform_(-0.1, 0.1)
+        d = {"config_json": np.array(json_dumps(mc))}
+        for k, v in model.state_dict().items():
+            d["sd." + k] = v.clone()
+        out = model(pattern, graph)
+        (out["pred_c"].sum() + out["pred_v"].sum()).backward()
+        for t, g in (("p", pattern), ("g", graph)):
+            d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(),
+                      t + "_bnn": g.batch_num_nodes(), t + "_bne": g.batch_num_edges()})
+            for k in ("id", "label", "in_deg", "out_deg"):
+                d["%s_ndata.%s" % (t, k)] = g.ndata[k]
+            for k in ("id", "label", "is_reversed"):
+                d["%s_edata.%s" % (t, k)] = g.edata[k]
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                d["grad." + k] = p.grad
+        for k, v in out.items():
+            if v is not None:
+                d["out." + k] = v
+        np.savez_compressed(os.path.join(OUT, "fullmodel_%s.npz" % tag), **t2n(d))
+        print("wrote fullmodel_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
+
+
+def gen_schedules():
+    """Tables of the reference's step-dependent quantities: ``anneal_fn`` / ``cyclical_fn`` (utils/anneal.py, utils/cyclical.py,
+    as train.py:499-600 calls them: num_init_steps = 0) and every ``lr_lambda`` of utils/scheduler.py."""
+    from utils.anneal import anneal_fn
+    from utils.cyclical import cyclical_fn
+    from utils.scheduler import map_scheduler_str_to_scheduler, supported_schedulers
+    d, specs = {}, []
+    for shape in ("linear", "cosine", "none", "constant"):
+        for total, cyc, a, b in ((15, 2, 1.0, 0.01), (100, 2, 0.01, 0.0), (7, 3, 0.0, 1.0), (40, 1, 2.0, -1.0)):
+            steps = np.arange(0, total + 6)
+            specs.append("%s|%d|%d|%r|%r" % (shape, total, cyc, a, b))
+            d["anneal.%d" % (len(specs) - 1)] = np.array([anneal_fn(shape, int(s), num_init_steps=0, num_anneal_steps=total, num_cycles=cyc,
+                                                                    value1=a, value2=b) for s in steps], np.float64)
+            d["cyclical.%d" % (len(specs) - 1)] = np.array([cyclical_fn(shape, int(s), num_init_steps=0, num_cyclical_steps=total,
+                                                                        num_cycles=cyc, value1=a, value2=b) for s in steps], np.float64)
+    d["specs"] = np.array(specs)
+    lrs = []
+    for name in sorted(supported_schedulers):
+        for warm, total, cyc, floor in ((0, 15, 1, 1e-3), (3, 40, 2, 1e-3), (5, 30, 1.5, 0.01)):
+            sd = map_scheduler_str_to_scheduler(name, num_warmup_steps=warm, num_schedule_steps=total, num_cycles=cyc, min_percent=floor)
+            lrs.append("%s|%d|%d|%r|%r" % (name, warm, total, cyc, floor))
+            d["lr.%d" % (len(lrs) - 1)] = np.array([sd.lr_lambda(int(s)) for s in range(total + 8)], np.float64)
+    d["lr_specs"] = np.array(lrs)
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **d)
+    print("wrote schedules.npz", len(specs), "anneal/cyclical tables,", len(lrs), "lr tables")
+
+
+def gen_dual_subiso():
+    """``get_dual_subisomorphisms`` (utils/graph.py:277-316) as ``convert_to_dual_data`` drives it (train.py:417-446):
+    pattern edges in eid order, graph edges in (src, dst)-sorted order, node maps -> per pattern edge the index of the
+    matched graph edge in that sorted order, then mapped back through ``g_eid``."""
+    from utils.graph import get_dual_subisomorphisms
+    rng = np.random.default_rng(515)
+    d, n_cases = {}, 0
+    shapes = [(3, 3, 7, 20, 2, 2), (4, 5, 8, 40, 1, 2), (2, 1, 6, 12, 2, 1), (4, 4, 9, 30, 1, 1), (3, 2, 5, 10, 2, 3), (5, 6, 10, 60, 1, 2)]
+    for pn, pm, gn, gm, nvl, nel in shapes:
+        x, raw = _ref_sample(rng, "c", pn, pm, gn, gm, nvl, nel)
+        if x["counts"] == 0:
+            continue
+        p, g = x["pattern"], x["graph"]
+        p_uid, p_vid, p_eid = p.all_edges(form="all", order="eid")
+        p_elabel = p.edata["label"][p_eid]
+        g_uid, g_vid, g_eid = g.all_edges(form="all", order="srcdst")
+        g_elabel = g.edata["label"][g_eid]
+        dual = get_dual_subisomorphisms(p_uid.numpy(), p_vid.numpy(), p_elabel.numpy(), g_uid.numpy(), g_vid.numpy(),
+                                        g_elabel.numpy(), x["subisomorphisms"].numpy())
+        k = "%d." % n_cases
+        d.update({k + "p_u": p_uid, k + "p_v": p_vid, k + "p_el": p_elabel, k + "g_u_sorted": g_uid, k + "g_v_sorted": g_vid,
+                  k + "g_el_sorted": g_elabel, k + "g_eid_sorted": g_eid, k + "sub": x["subisomorphisms"], k + "dual_sorted_index": dual,
+                  k + "dual_eids": g_eid.numpy()[dual], k + "g_u": raw["gu"], k + "g_v": raw["gv"], k + "g_el": raw["gel"]})
+        n_cases += 1
+    # repeated keys: parallel pattern edges in one run, a key split into two runs (the later replaces the earlier), on
+    # multigraphs with parallel edges and loops; arbitrary injective node maps (the function does not need real matches)
+    for p_u, p_v, p_el in (([0, 0, 1], [1, 1, 2], [0, 1, 0]), ([0, 1, 0, 1], [1, 2, 1, 0], [0, 0, 1, 1]), ([0, 0, 0], [1, 1, 1], [2, 0, 1])):
+        gn, gm = 7, 60
+        g_u, g_v, g_el = rng.integers(0, gn, gm), rng.integers(0, gn, gm), rng.integers(0, 3, gm)
+        sub = np.stack([rng.permutation(gn)[:3] for _ in range(25)]).astype(np.int64)
+        order = np.lexsort((np.arange(gm), g_v, g_u))
+        dual = get_dual_subisomorphisms(np.array(p_u), np.array(p_v), np.array(p_el), g_u[order], g_v[order], g_el[order], sub)
+        k = "%d." % n_cases
+        d.update({k + "p_u": np.array(p_u), k + "p_v": np.array(p_v), k + "p_el": np.array(p_el), k + "g_u_sorted": g_u[order],
+                  k + "g_v_sorted": g_v[order], k + "g_el_sorted": g_el[order], k + "g_eid_sorted": order, k + "sub": sub,
+                  k + "dual_sorted_index": dual, k + "dual_eids": order[dual], k + "g_u": g_u, k + "g_v": g_v, k + "g_el": g_el})
+        n_cases += 1
+    d["num_cases"] = n_cases
+    np.savez_compressed(os.path.join(OUT, "dual_subiso.npz"), **t2n(d))
+    print("wrote dual_subiso.npz", n_cases, "cases")
+
+
+
+GENERATORS = ["dmplayer", "dmpnn_rep", "compgcn", "linegraph", "addrev", "full_model", "unc", "subiso_weights", "expand", "rgnn",
+              "preprocess", "init", "default_model", "train_run", "dual_subiso", "schedules"]
+
+
 def main():
+    """``python oracle/make_golden.py [generator ...]`` -- all of them without arguments."""
     os.makedirs(OUT, exist_ok=True)
     import ref_standin
     ref_standin.import_scm()
-    gen_dmplayer()
-    gen_dmpnn_rep()
-    gen_compgcn()
-    gen_linegraph()
-    gen_addrev()
-    gen_full_model()
-    gen_unc()
-    gen_subiso_weights()
-    gen_expand()
-    gen_rgnn()
+    want = sys.argv[1:] or GENERATORS
+    for name in want:
+        if name not in GENERATORS:
+            raise SystemExit("unknown generator %r (have: %s)" % (name, ", ".join(GENERATORS)))
+    sys.argv = sys.argv[:1]
+    for name in want:
+        globals()["gen_" + name]()
 
 
 if __name__ == "__main__":

@@ -43,15 +43,30 @@ FORWARD_FIXTURES = [p for p in golden_files("fullmodel_") if "train" not in p]
 def test_full_dmpnn_forward_matches_reference(path, fused, gpu):
     from dualmessagepassing_amd.basemodel import build_model
     d = load_golden(path)
-    config = {str(k): eval(str(v)) for k, v in zip(d["config_keys"], d["config_vals"])}
-    model = build_model(**config)
+    if "config_json" in d:    # the reference's own run configuration (config.py defaults + README "Complex" command line)
+        import json
+        model = build_model(json.loads(str(d["config_json"])), init_neigenv=6.0, init_eeigenv=5.0)
+    else:
+        config = {str(k): eval(str(v)) for k, v in zip(d["config_keys"], d["config_vals"])}
+        model = build_model(**config)
     sd = {k[3:]: _t(v) for k, v in d.items() if k.startswith("sd.")}
     missing, unexpected = model.load_state_dict(sd, strict=True)  # the reference's own checkpoint keys
     assert not missing and not unexpected
     model.to(gpu)
     model.use_fused = fused
     pattern, graph = _graph(d, "p", gpu), _graph(d, "g", gpu)
-    out = model(pattern, graph)
+    if fused and "default" in path:   # the shipped activation (leaky_relu) must be on the fused fast path
+        from dualmessagepassing_amd import dmpnn
+        hits = []
+        orig = dmpnn.DMPLayer.forward_fused
+        dmpnn.DMPLayer.forward_fused = lambda self, *a, **k: (hits.append(1), orig(self, *a, **k))[1]
+        try:
+            out = model(pattern, graph)
+        finally:
+            dmpnn.DMPLayer.forward_fused = orig
+        assert len(hits) == 3, "the rep-net did not take the fused path"
+    else:
+        out = model(pattern, graph)
     assert list(out.keys()) == ["p_v_emb", "p_e_emb", "g_v_emb", "g_e_emb", "p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep",
                                 "p_v_mask", "p_e_mask", "g_v_mask", "g_e_mask", "pred_c", "pred_v", "pred_e"]
     for k in ("p_v_mask", "p_e_mask", "g_v_mask", "g_e_mask"):

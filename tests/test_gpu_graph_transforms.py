@@ -206,3 +206,45 @@ def test_csr_build_pair_equals_two_builds(N, E, gpu):
     for a, b in zip(single, pair):
         valid = int(a[0][N])                                      # entries past the valid ones are never written
         assert th.equal(a[0], b[0]) and th.equal(a[1][:valid], b[1][:valid]) and th.equal(a[2], b[2]) and th.equal(a[3], b[3])
+
+
+def test_dual_subisomorphisms_match_reference_and_oracle(gpu):
+    """``linegraph.dual_subisomorphisms`` (dmp_dual_subisomorphisms) against the reference's own
+    ``get_dual_subisomorphisms`` + ``g_eid`` mapping (tests/golden/dual_subiso.npz; utils/graph.py:277-316,
+    train.py:417-446) -- every case alone and all of them as one batch -- and against the oracle restatement on patterns
+    with repeated keys (parallel edges in one run, a key split into two runs: the later run replaces the earlier)."""
+    import graph_oracle as GO
+    from dualmessagepassing_amd.collate import collate_device
+    from dualmessagepassing_amd.linegraph import dual_subisomorphisms
+    d = load_golden(golden_files("dual_subiso")[0])
+    cases = []
+    for c in range(int(d["num_cases"])):
+        k = "%d." % c
+        cases.append(dict(p_u=d[k + "p_u"], p_v=d[k + "p_v"], p_el=d[k + "p_el"], g_u=d[k + "g_u"], g_v=d[k + "g_v"], g_el=d[k + "g_el"],
+                          sub=d[k + "sub"], want=d[k + "dual_eids"], pn=d[k + "sub"].shape[1], gn=int(max(d[k + "g_u"].max(), d[k + "g_v"].max())) + 1))
+    # the oracle restatement agrees on every case (the last three have repeated pattern keys on multigraphs)
+    for c in cases:
+        order = np.lexsort((np.arange(len(c["g_u"])), c["g_v"], c["g_u"]))
+        idx = GO.dual_subisomorphisms(c["p_u"], c["p_v"], c["p_el"], c["g_u"][order], c["g_v"][order], c["g_el"][order], c["sub"])
+        assert np.array_equal(order[idx], c["want"])
+    assert len(cases) >= 7
+
+    def run(batch):
+        cat = lambda k: _t(np.concatenate([np.asarray(c[k], np.int64) for c in batch])).to(gpu)
+        sizes = lambda k: _t(np.array([len(c[k]) for c in batch], np.int64)).to(gpu)
+        pn_, gn_ = _t(np.array([c["pn"] for c in batch], np.int64)).to(gpu), _t(np.array([c["gn"] for c in batch], np.int64)).to(gpu)
+        pattern = collate_device(cat("p_u"), cat("p_v"), pn_, sizes("p_u"), sum(c["pn"] for c in batch), sum(len(c["p_u"]) for c in batch),
+                                 edata={"label": cat("p_el")})
+        graph = collate_device(cat("g_u"), cat("g_v"), gn_, sizes("g_u"), sum(c["gn"] for c in batch), sum(len(c["g_u"]) for c in batch),
+                               edata={"label": cat("g_el")})
+        flat = _t(np.concatenate([c["sub"].reshape(-1) for c in batch])).to(gpu)
+        sp = _t(np.concatenate([[0], np.cumsum([c["sub"].size for c in batch])]).astype(np.int64)).to(gpu)
+        out, optr = dual_subisomorphisms(pattern, graph, flat, sp, validate=True)
+        want = np.concatenate([np.asarray(c["want"], np.int64).reshape(-1) for c in batch])
+        assert out.dtype == th.int64 and np.array_equal(out.cpu().numpy(), want)
+        assert np.array_equal(optr.cpu().numpy(), np.concatenate([[0], np.cumsum([np.asarray(c["want"]).size for c in batch])]))
+
+    for c in cases:
+        run([c])
+    run(cases)
+    run(cases[::-1])

@@ -48,3 +48,25 @@ def test_synthetic_pairs_layout():
     assert np.array_equal(s["eid"], np.r_[np.arange(e), e + np.arange(e)]) and np.array_equal(s["elabel"][e:], s["elabel"][:e] + 2)
     cfg = ds.model_config(hid_dim=16, layers=2)
     assert cfg["max_nge"] == 2 * e and cfg["max_ngel"] == 4 and cfg["rep_net"] == "DMPNN"
+
+
+def test_step_schedules_match_reference_tables():
+    """``harness.scheduled_value`` / ``harness.lr_factor`` against tables emitted by the reference's own ``anneal_fn`` /
+    ``cyclical_fn`` / scheduler ``lr_lambda``s (tests/golden/schedules.npz, oracle/make_golden.py::gen_schedules)."""
+    import numpy as np
+    from conftest import golden_files, load_golden
+    from dualmessagepassing_amd.harness import lr_factor, scheduled_value
+    d = load_golden(golden_files("schedules")[0])
+    for i, spec in enumerate(d["specs"].tolist()):
+        shape, total, cyc, a, b = spec.split("|")
+        total, cyc = int(total), int(cyc)
+        for mode in ("anneal", "cyclical"):
+            want = d["%s.%d" % (mode, i)]
+            got = [scheduled_value("%s_%s$%s$%s" % (mode, shape, a, b), s, total, cyc) for s in range(len(want))]
+            assert np.allclose(got, want, rtol=0, atol=1e-12), (mode, spec)
+    for i, spec in enumerate(d["lr_specs"].tolist()):
+        name, warm, total, cyc, floor = spec.split("|")
+        want = d["lr.%d" % i]
+        got = [lr_factor(name, s, int(warm), int(total), float(cyc), float(floor)) for s in range(len(want))]
+        assert np.allclose(got, want, rtol=0, atol=1e-12), spec
+    assert scheduled_value(0.25, 3, 10) == 0.25
