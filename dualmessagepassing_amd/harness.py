@@ -279,12 +279,13 @@ def _match_terms(crit, pred, weights, mask, pred_c, neg_slp):
 
 def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_loss="MSE", eval_metric="MAE",
                 neg_slp=0.0, rep_reg_w=0.0, match_loss_w=0.0, match_reg_w=0.0, max_grad_norm=8.0, order=None,
-                schedule=None, epoch=0, match_weights=("node", "edge")):
+                schedule=None, epoch=0, match_weights=("node", "edge"), trace=None):
     """One pass over ``dataset`` (train.py:449-844): count loss, optional representation regulariser
     and, with ``match_loss_w`` / ``match_reg_w`` and a model built with ``pred_return_weights``, the
     node / edge matching losses against the batch's subisomorphism weights.  With a ``RunSchedule`` the four loss
     coefficients and the learning rate follow the run configuration step by step, as train.py:499-600,686 do.  Returns
-    ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end)."""
+    ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end).  ``trace``: a list that receives
+    one ``(loss, eval_metric)`` pair of device scalars per step (what the reference writes to its SummaryWriter)."""
     model.train()
     sync = sync or FlatGradSync(model)
     order = np.arange(len(dataset)) if order is None else np.asarray(order)
@@ -324,6 +325,8 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
         if schedule is not None:
             schedule.sched_step += 1
         with torch.no_grad():
+            if trace is not None:
+                trace.append((loss.detach(), _CRIT[eval_metric](F.relu(pred), counts)))
             tot_loss += loss.detach() * len(idx)
             tot_eval += _CRIT[eval_metric](F.relu(pred), counts) * len(idx)
         cnt += len(idx)

@@ -895,6 +895,17 @@ def _ref_sample(rng, name, pn, pm, gn, gm, nvl, nel):
             "subisomorphisms": th.from_numpy(sub)}, raw
 
 
+class _ScalarLog:
+    """Stands in for the SummaryWriter of train.py: keeps every ``add_scalar(tag, value, step)`` (the per-step losses,
+    learning rate and annealed coefficients train_epoch reports, train.py:688-760)."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def add_scalar(self, tag, value, step):
+        self.rows.setdefault(tag, []).append((int(step), float(value)))
+
+
 class _FixedLoader:
     """What train_epoch / evaluate_epoch need from a DataLoader: ``dataset``, ``len`` and batches in a fixed order."""
 
@@ -976,17 +987,21 @@ def gen_train_run():
     dev_batches = [list(range(i, min(i + bsz, n_dev))) for i in range(0, n_dev, bsz)]
     hist = {"train_eval": [], "train_bp": [], "dev_eval": [], "lr": []}
     device = th.device("cpu")
+    log = _ScalarLog()
     for epoch in range(epochs):
         batches = [orders[epoch][i:i + bsz].tolist() for i in range(0, n_train, bsz)]
         hist["lr"].append(scheduler.get_last_lr()[0])
         ev, bp = ref_train.train_epoch(model, optimizer, scheduler, "train", _FixedLoader(sets["train"], batches, config["match_weights"]),
-                                       device, config, epoch, None, None)
+                                       device, config, epoch, None, log)
         dev_ev, dev_res = ref_train.evaluate_epoch(model, "dev", _FixedLoader(sets["dev"], dev_batches, config["match_weights"]),
                                                    device, config, epoch, None, None)
         hist["train_eval"].append(ev); hist["train_bp"].append(bp); hist["dev_eval"].append(dev_ev)
         print("  epoch %d  train %s %.4f  bp %.4f  dev %s %.4f" % (epoch, config["eval_metric"], ev, bp, config["eval_metric"], dev_ev))
     for k, v in hist.items():
         d["hist." + k] = np.array(v, np.float64)
+    for tag, rows in log.rows.items():                          # per optimisation step
+        if tag.startswith("train/"):
+            d["step." + tag[6:]] = np.array([v for _, v in sorted(rows)], np.float64)
     d["dev_pred_c"] = np.array(dev_res["prediction"]["pred_c"], np.float64).reshape(-1)
     d["dev_counts"] = np.array(dev_res["data"]["counts"], np.float64).reshape(-1)
     d["dev_MAE"], d["dev_MSE"] = dev_res["error"]["MAE"], dev_res["error"]["MSE"]
