@@ -110,10 +110,11 @@ def model_config(cfg):
                 pred_act_func=cfg.get("act", "leaky_relu"), pred_dropout=0.0, node_pred=True, edge_pred=True)
 
 
-def build_step(cfg, shard, device):
+def build_step(cfg, shard, device, world=1):
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device
     from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    from dualmessagepassing_amd.dmpnn import prepare_joint
 
     torch.manual_seed(0)
     model = build_model(**model_config(cfg)).to(device)
@@ -122,8 +123,15 @@ def build_step(cfg, shard, device):
     sync.broadcast_parameters()
     opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True)   # the reference's optimizer (train.py:1231)
 
+    pending = []      # the gradient all-reduce of the previous step, still in flight
+
+    def finish():
+        """Second half of a step: wait (on the stream, not the host) for the gradient sum, then AdamW."""
+        if pending:
+            sync.finish(pending.pop())
+            opt.step()
+
     def step():
-        sync.detach_grads()
         p, g = shard["p"], shard["g"]
         # a loader hands over NEW size / flag tensors with every batch: nothing derived from them (padding maps,
         # pooling indexes, CSR, degree classes) may be carried over from the previous step
@@ -134,14 +142,23 @@ def build_step(cfg, shard, device):
                                  max_nodes=p["max_n"], max_edges=p["max_e"])
         graph = collate_device(g["local_src"], g["local_dst"], gn, ge, g["N"], g["E"], ndata=g["ndata"], edata=ged,
                                max_nodes=g["max_n"], max_edges=g["max_e"])
+        # The batch's structure work (collate above; CSR, incidence, degree classes, selectors here) does not depend on
+        # the parameters: it is enqueued BEFORE the previous step's gradient sum is waited for, so with more than one
+        # rank the all-reduce (on RCCL's stream) overlaps it instead of idling the compute stream.
+        if world > 1:
+            prepare_joint(pattern, graph, cfg["hid"])
+        finish()
+        sync.detach_grads()
         out = model(pattern, graph)
         loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])  # count loss (train.py:624-628)
         loss.backward()
         sync.pack()
-        sync.sync()
-        opt.step()
+        pending.append(sync.sync(async_op=True))              # None at world size 1
+        if world == 1:
+            finish()
         return loss
 
+    step.finish = finish
     return step, model
 
 
@@ -267,7 +284,7 @@ def main():
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
     shard = make_shard(cfg, rank, device)
-    step, model = build_step(cfg, shard, device)
+    step, model = build_step(cfg, shard, device, world)
 
     def barrier():
         if world > 1:
@@ -276,6 +293,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    step.finish()
     # Setup objects (modules, tuned-GEMM tables, the shard) leave the cyclic collector's working set: a full
     # collection walking them costs tens of milliseconds and would otherwise land inside a step now and then.
     import gc
@@ -290,6 +308,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    step.finish()                                            # the last step's all-reduce + optimizer update: inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     kern = _lib.timer.summary()
@@ -297,6 +316,7 @@ def main():
     _lib.timer.only = None
     for _ in range(3):  # un-timed: per-kernel numbers of the other HIP kernels on the path
         step()
+    step.finish()
     others = _lib.timer.summary()
     _lib.timer.enabled = False
     for name, v in others.items():
@@ -335,7 +355,8 @@ def main():
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
                                       cfg["batch"], cfg["emb"], cfg["act"] + (" (slope 1/5.5)" if cfg["act"] == "leaky_relu" else ""), H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
-                       "step": "device collate + index build + fwd + bwd + grad all-reduce + AdamW(amsgrad, train.py:1231) as one HIP launch",
+                       "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
+                               "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},
             "roofline": roof,
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32

@@ -326,6 +326,38 @@ class DMPNNRepMixin:
         return v_outputs[-1], e_outputs[-1]
 
 
+def _union_of(pattern, graph):
+    from .collate import union_graphs
+    u = getattr(pattern, "_union_cache", None)
+    if u is None or u[0] is not graph:
+        u = (graph, union_graphs(pattern, graph))
+        pattern._union_cache = u
+    return u[1]
+
+
+def prepare_joint(pattern, graph, hidden_dim=128, backward=True):
+    """Everything of the joint pattern + target pass that depends on the batch's STRUCTURE only -- the union graph, its
+    CSR index, degrees, coefficient vector, per-edge selectors, degree-class tiles and (``backward``) the incidence CSR --
+    built ahead of the forward pass.  A data-parallel step calls this between launching the gradient all-reduce of the
+    previous batch and waiting for it: none of it reads a parameter, so it overlaps the collective."""
+    from . import fused
+    pattern, graph = as_batched(pattern), as_batched(graph)
+    if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
+        return None
+    union = _union_of(pattern, graph)
+    ix = union.index()
+    if OUTDEGREE not in union.ndata:
+        union.ndata[OUTDEGREE] = union.out_degrees()
+    coef = ix.degree_coef(union.ndata[OUTDEGREE])
+    if fused.mfma_ok(ix, hidden_dim):
+        ix.edge_select(coef)
+    if fused.typed_ok(ix, hidden_dim):
+        ix.class_tiles(coef)
+    if backward:
+        ix.incidence()
+    return union
+
+
 def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
     """``get_pattern_rep`` + ``get_graph_rep`` (dmpnn.py:215-277) in ONE pass over the union of
     the two batched graphs, when the rep-net is shared (``share_rep_net``, dmpnn.py:186-188) and
@@ -353,11 +385,7 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
     elif e_gate is not None:
         eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
-    u = getattr(pattern, "_union_cache", None)
-    if u is None or u[0] is not graph:
-        u = (graph, union_graphs(pattern, graph))
-        pattern._union_cache = u
-    union = u[1]
+    union = _union_of(pattern, graph)
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):
         return None
     from . import fused

@@ -161,7 +161,10 @@ class FlatGradSync:
                 dist.broadcast(p.data, src=src, group=self.group)
 
     def sync(self, async_op=False):
-        """Sum the flat gradient over ranks (and divide by the world size if ``average``)."""
+        """Sum the flat gradient over ranks (and divide by the world size if ``average``).  ``async_op``: returns the
+        work handle at once; ``finish(handle)`` makes the current stream wait for the sum (no host block with RCCL) and
+        applies the average -- whatever is enqueued in between (the next batch's collate and index build, which do not
+        depend on the parameters) overlaps the collective."""
         w = self.world
         if w == 1:
             return None
