@@ -94,6 +94,31 @@ def make_shard(cfg, rank, device):
     return out
 
 
+def slice_shard(cfg, shard, lo, hi):
+    """Pairs [lo, hi) of a shard (views, no copies): a data-parallel rank's part of a global batch, or one micro-batch."""
+    out = {"counts": shard["counts"][lo:hi]}
+    for t, n, m in (("p", cfg["p_nodes"], cfg["p_edges"]), ("g", cfg["g_nodes"], cfg["g_edges"])):
+        d = shard[t]
+        ns, es = slice(lo * n, hi * n), slice(lo * 2 * m, hi * 2 * m)
+        out[t] = dict(local_src=d["local_src"][es], local_dst=d["local_dst"][es],
+                      ndata={k: v[ns] for k, v in d["ndata"].items()}, edata={k: v[es] for k, v in d["edata"].items()},
+                      num_nodes=d["num_nodes"][lo:hi], num_edges=d["num_edges"][lo:hi], N=(hi - lo) * n, E=(hi - lo) * 2 * m,
+                      max_n=n, max_e=2 * m)
+    return out
+
+
+def micro_batches_for(cfg):
+    """Micro-batches per step so that every [E, 2H] fp32 array of one pass stays below 4 GiB: the class-typed MFMA kernels
+    address whole arrays with 32-bit byte offsets (fused.typed_ok).  Pairs are independent, so a step over M equal slices
+    of the shard with the gradients summed (each slice's mean loss weighted 1/M) is the same step.  Config 2: 1;
+    config 4 (E = 8.4 M edge rows per 1024-pair shard): 4."""
+    rows = cfg["batch"] * 2 * (cfg["p_edges"] + cfg["g_edges"])
+    m = 1
+    while rows // m * 2 * cfg["hid"] * 4 >= 2 ** 32 - 8192 and m < cfg["batch"]:
+        m *= 2
+    return m
+
+
 def model_config(cfg):
     """The reference's DMPNN training configuration (SubgraphCountingMatching/README.md:72-94,
     'Complex' command) at BASELINE's hid=128; vocabulary sizes after --add_rev doubling.  Activations and
@@ -124,6 +149,11 @@ def build_step(cfg, shard, device, world=1):
     opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True)   # the reference's optimizer (train.py:1231)
 
     pending = []      # the gradient all-reduce of the previous step, still in flight
+    M = int(cfg.get("micro_batches") or micro_batches_for(cfg))
+    if cfg["batch"] % M:
+        raise SystemExit("--micro-batches must divide the batch")
+    parts = [shard] if M == 1 else [slice_shard(cfg, shard, i * (cfg["batch"] // M), (i + 1) * (cfg["batch"] // M)) for i in range(M)]
+    total = torch.zeros_like(sync.flat) if M > 1 else None    # gradient sum over the micro-batches
 
     def finish():
         """Second half of a step: wait (on the stream, not the host) for the gradient sum, then AdamW."""
@@ -131,8 +161,8 @@ def build_step(cfg, shard, device, world=1):
             sync.finish(pending.pop())
             opt.step()
 
-    def step():
-        p, g = shard["p"], shard["g"]
+    def batch_of(part):
+        p, g = part["p"], part["g"]
         # a loader hands over NEW size / flag tensors with every batch: nothing derived from them (padding maps,
         # pooling indexes, CSR, degree classes) may be carried over from the previous step
         fresh = lambda d: (d["num_nodes"].clone(), d["num_edges"].clone(), dict(d["edata"], is_reversed=d["edata"]["is_reversed"].clone()))
@@ -142,6 +172,34 @@ def build_step(cfg, shard, device, world=1):
                                  max_nodes=p["max_n"], max_edges=p["max_e"])
         graph = collate_device(g["local_src"], g["local_dst"], gn, ge, g["N"], g["E"], ndata=g["ndata"], edata=ged,
                                max_nodes=g["max_n"], max_edges=g["max_e"])
+        return pattern, graph
+
+    def step_micro():
+        """One step as M micro-batches (config 4): gradients summed in ``total``, each slice's mean loss weighted 1 / M."""
+        finish()
+        loss = None
+        for i, part in enumerate(parts):
+            pattern, graph = batch_of(part)
+            sync.detach_grads()
+            out = model(pattern, graph)
+            loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), part["counts"]) / M
+            loss.backward()
+            del out, pattern, graph
+            sync.pack()
+            if i == 0:
+                total.copy_(sync.flat)
+            else:
+                total.add_(sync.flat)
+        sync.flat.copy_(total)
+        pending.append(sync.sync(async_op=True))
+        if world == 1:
+            finish()
+        return loss
+
+    def step():
+        if M > 1:
+            return step_micro()
+        pattern, graph = batch_of(shard)
         # The batch's structure work (collate above; CSR, incidence, degree classes, selectors here) does not depend on
         # the parameters: it is enqueued BEFORE the previous step's gradient sum is waited for, so with more than one
         # rank the all-reduce (on RCCL's stream) overlaps it instead of idling the compute stream.
@@ -159,6 +217,8 @@ def build_step(cfg, shard, device, world=1):
         return loss
 
     step.finish = finish
+    step.sync = sync
+    step.micro_batches = M
     return step, model
 
 
@@ -256,6 +316,8 @@ def main():
                     "(leaky_relu = the reference's default, config.py:298-301,370-373)")
     ap.add_argument("--emb", default="Equivariant", choices=("Equivariant", "Orthogonal", "Normal", "Uniform"),
                     help="embedding kind (Equivariant = the reference's default, config.py:242-245)")
+    ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep every [E, 2H] "
+                    "array below 4 GiB: 1 for config 2, 4 for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
@@ -279,7 +341,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb)
+    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -332,8 +394,9 @@ def main():
         H = cfg["hid"]
         # the scatter-add launch: the shared rep-net runs once over the union of the pattern and
         # target batches, so one launch covers N = B*(8+64) destination rows and E = B*(24+512) edge rows
-        uN = cfg["batch"] * (cfg["p_nodes"] + cfg["g_nodes"])
-        uE = cfg["batch"] * 2 * (cfg["p_edges"] + cfg["g_edges"])
+        mb = cfg["batch"] // step.micro_batches               # pairs per pass
+        uN = mb * (cfg["p_nodes"] + cfg["g_nodes"])
+        uE = mb * 2 * (cfg["p_edges"] + cfg["g_edges"])
         key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
         roof = None
         if key in kern:
@@ -354,7 +417,7 @@ def main():
                                    "(fresh size / flag tensors) every step"
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
                                       cfg["batch"], cfg["emb"], cfg["act"] + (" (slope 1/5.5)" if cfg["act"] == "leaky_relu" else ""), H),
-                       "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world,
+                       "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world, "micro_batches": step.micro_batches,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},

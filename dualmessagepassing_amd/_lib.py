@@ -36,6 +36,8 @@ SIGNATURES = {
     "dmp_subiso_node_weights": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_dual_subisomorphisms": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_pool_index": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                               c_ptr, c_ptr]),
     "dmp_pattern_edge_active": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_subiso_edge_weights": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "dmp_pack_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
     "dmp_adamw_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
                                c_double, c_i64, c_ptr]),
+    "dmp_adamw_step_skip": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
+                                    c_double, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
@@ -110,7 +114,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 34
+ABI_VERSION = 36
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -259,9 +259,8 @@ def _pool_index_union(pattern, graph, kind):
     rows = (pattern.number_of_nodes() + graph.number_of_nodes() if kind == "node"
             else pattern.number_of_edges() + graph.number_of_edges())                     # host ints: no sync in the build
 
-    def build():
-        flag = None if fa is None or fb is None else th.cat([fa.view(-1), fb.view(-1)])
-        return _Keep(ops.PoolIndex(th.cat([a, b]), flag, num_rows=rows), a, b, fa, fb)
+    def build():   # sizes / flags as (pattern, target) pairs: built on the device without concatenating them first
+        return _Keep(ops.PoolIndex((a, b), None if fa is None or fb is None else (fa, fb), num_rows=rows), a, b, fa, fb)
     return _memo(("upool", _tensor_key(a), _tensor_key(b), _tensor_key(fa), _tensor_key(fb)), build).obj
 
 
@@ -281,33 +280,31 @@ def _padder(graph, kind):
 class BaseModel(nn.Module):
     """basemodel.py:15-160."""
 
+    # vocabulary sizes every configuration must name, and the optional switches with the reference's defaults
+    # (basemodel.py:25-41): the attribute names are part of the interface (expand(), the drivers and the mixins read them)
+    REQUIRED = ("max_ngv", "max_ngvl", "max_nge", "max_ngel", "max_npv", "max_npvl", "max_npe", "max_npel")
+    OPTIONAL = (("base", 2), ("hid_dim", 64), ("share_emb_net", True), ("share_enc_net", True), ("share_rep_net", True),
+                ("rep_residual", True), ("pred_with_enc", False), ("pred_with_deg", False))
+    # sub-networks in the order the reference registers them (``state_dict`` order, seeded-init RNG order); the pattern
+    # side follows the graph side because it may alias it (share_*_net)
+    STAGES = (("enc", True), ("filter", False), ("emb", True), ("rep", True), ("pred", False))
+
     def __init__(self, **kw):
         super(BaseModel, self).__init__()
-        self.max_ngv = kw["max_ngv"]
-        self.max_ngvl = kw["max_ngvl"]
-        self.max_nge = kw["max_nge"]
-        self.max_ngel = kw["max_ngel"]
-        self.max_npv = kw["max_npv"]
-        self.max_npvl = kw["max_npvl"]
-        self.max_npe = kw["max_npe"]
-        self.max_npel = kw["max_npel"]
-        self.base = kw.get("base", 2)
-        self.hid_dim = kw.get("hid_dim", 64)
-        self.share_emb_net = kw.get("share_emb_net", True)
-        self.share_enc_net = kw.get("share_enc_net", True)
-        self.share_rep_net = kw.get("share_rep_net", True)
-        self.rep_residual = kw.get("rep_residual", True)
-        self.pred_with_enc = kw.get("pred_with_enc", False)
-        self.pred_with_deg = kw.get("pred_with_deg", False)
-        # same construction order as the reference (parameter registration order)
-        self.g_enc_net = self.create_enc_net(type="graph", **kw)
-        self.p_enc_net = self.create_enc_net(type="pattern", **kw)
-        self.filter_net = self.create_filter_net(**kw)
-        self.g_emb_net = self.create_emb_net(type="graph", **kw)
-        self.p_emb_net = self.create_emb_net(type="pattern", **kw)
-        self.g_rep_net = self.create_rep_net(type="graph", **kw)
-        self.p_rep_net = self.create_rep_net(type="pattern", **kw)
-        self.pred_net = self.create_pred_net(**kw)
+        missing = [k for k in self.REQUIRED if k not in kw]
+        if missing:
+            raise KeyError("model configuration lacks %s" % ", ".join(missing))
+        for name in self.REQUIRED:
+            setattr(self, name, kw[name])
+        for name, default in self.OPTIONAL:
+            setattr(self, name, kw.get(name, default))
+        for stage, two_sided in self.STAGES:
+            make = getattr(self, "create_%s_net" % stage)
+            if two_sided:
+                setattr(self, "g_%s_net" % stage, make(type="graph", **kw))
+                setattr(self, "p_%s_net" % stage, make(type="pattern", **kw))
+            else:
+                setattr(self, "%s_net" % stage, make(**kw))
 
     def refine_node_weights(self, weights, use_max=False):
         return weights

@@ -220,6 +220,8 @@ struct AdamArgs {
   float *p; const float *g; float *m, *v, *vmax;
   int64_t n;
   float decay, beta1_c, beta2, beta2_c, step_size, inv_bc2_sqrt, eps;
+  int nskip;                                                  // ranges [skip_lo, skip_hi) left untouched (4-float aligned)
+  int64_t skip_lo[DMP_ADAMW_MAX_SKIP], skip_hi[DMP_ADAMW_MAX_SKIP];
 };
 
 struct PackSegs {
@@ -247,6 +249,9 @@ __global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a,
 __global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
   const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < a.n; i += stride) {
+    bool skip = false;                                         // parameters without a gradient this step (torch.optim.AdamW skips them)
+    for (int s = 0; s < a.nskip; ++s) skip |= (i >= a.skip_lo[s] && i < a.skip_hi[s]);
+    if (skip) continue;
     float p[4], g[4], m[4], v[4], vm[4];
     const bool full = i + 4 <= a.n;
     const int cnt = full ? 4 : (int)(a.n - i);
@@ -623,7 +628,15 @@ int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int
 int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
                    int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                    void *stream) {
+  return dmp_adamw_step_skip(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                             nullptr, nullptr, 0, stream);
+}
+
+int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                        int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                        const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
   DMP_ROW_CHECK(n >= 0 && step >= 1 && lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
+  DMP_ROW_CHECK(nskip >= 0 && nskip <= DMP_ADAMW_MAX_SKIP && (nskip == 0 || (skip_lo && skip_hi)));
   if (n == 0) return DMP_OK;
   DMP_ROW_CHECK(param && grad && exp_avg && exp_avg_sq);
   if (!ok16(param) || !ok16(grad) || !ok16(exp_avg) || !ok16(exp_avg_sq) || !ok16(max_exp_avg_sq)) return DMP_ERR_UNSUPPORTED;
@@ -633,6 +646,11 @@ int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_a
   a.decay = (float)(1.0 - lr * weight_decay);
   a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2);
   a.step_size = (float)(lr / bc1); a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); a.eps = (float)eps;
+  a.nskip = nskip;
+  for (int s = 0; s < nskip; ++s) {
+    if (skip_lo[s] % 4 || skip_hi[s] % 4 || skip_lo[s] > skip_hi[s]) return DMP_ERR_BAD_ARG;
+    a.skip_lo[s] = skip_lo[s]; a.skip_hi[s] = skip_hi[s];
+  }
   int64_t nb = (n / 4 + kBlock) / kBlock;
   if (nb > 2048) nb = 2048;
   adamw_kernel<<<(unsigned)nb, kBlock, 0, (hipStream_t)stream>>>(a);

@@ -566,6 +566,75 @@ __global__ void subiso_edge_k(const int64_t *sub, const int64_t *sample_ptr, con
   }
 }
 
+// Pooling index (ops.PoolIndex): the rows of every graph of a batch (contiguous ranges of `sizes[i]` rows) cut into chunks
+// of `chunk` rows, so that the per-graph sums of the prediction heads run as two launches of the segment-sum kernel
+// (rows -> chunk sums -> graph sums) with enough independent rows to fill the chip.  One single-workgroup scan for the
+// two offset vectors, one fill launch for everything else -- instead of ~20 small tensor launches per index and batch.
+//   off  [B+1] int64  first row of graph i              coff = gptr [B+1] int32  first chunk of graph i
+//   vptr [V+1] int32  first row of chunk v (V = R / chunk + B bounds the chunk count; unused tail chunks are empty)
+//   vent [R]   int32  (row << 1) | flag[row]            gent [V] int32  chunk << 1            seg [R] int32  graph of row
+// `sizes` / `flag` come as two pieces each (pattern graphs then target graphs of a union pass) to spare the concatenations.
+struct PoolArgs {
+  const int64_t *sizes_a, *sizes_b; int64_t Ba, Bb;
+  const uint8_t *flag_a, *flag_b; int64_t Ra;                // rows [0, Ra) take flag_a, the rest flag_b (NULL: 0)
+  int64_t R, V; int chunk;
+  int64_t *off; int32_t *gptr, *vptr, *vent, *gent, *seg;
+};
+
+__global__ __launch_bounds__(kBlock) void pool_offsets_k(PoolArgs a) {
+  __shared__ int64_t s_rows[kBlock], s_chunks[kBlock];
+  __shared__ int64_t base_rows, base_chunks;
+  const int64_t B = a.Ba + a.Bb;
+  if (threadIdx.x == 0) { base_rows = 0; base_chunks = 0; a.off[0] = 0; a.gptr[0] = 0; }
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < B; i0 += kBlock) {
+    const int64_t i = i0 + threadIdx.x;
+    int64_t n = 0;
+    if (i < B) n = i < a.Ba ? a.sizes_a[i] : a.sizes_b[i - a.Ba];
+    s_rows[threadIdx.x] = n;
+    s_chunks[threadIdx.x] = (n + a.chunk - 1) / a.chunk;
+    __syncthreads();
+    for (int d = 1; d < kBlock; d <<= 1) {                    // inclusive Hillis-Steele scan of the block's slice
+      int64_t r = 0, c = 0;
+      if ((int)threadIdx.x >= d) { r = s_rows[threadIdx.x - d]; c = s_chunks[threadIdx.x - d]; }
+      __syncthreads();
+      s_rows[threadIdx.x] += r; s_chunks[threadIdx.x] += c;
+      __syncthreads();
+    }
+    if (i < B) {
+      a.off[i + 1] = base_rows + s_rows[threadIdx.x];
+      a.gptr[i + 1] = (int32_t)(base_chunks + s_chunks[threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) { base_rows += s_rows[kBlock - 1]; base_chunks += s_chunks[kBlock - 1]; }
+    __syncthreads();
+  }
+}
+
+__global__ void pool_fill_k(PoolArgs a) {
+  const int64_t B = a.Ba + a.Bb;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < a.R) {
+    const uint8_t *f = t < a.Ra ? a.flag_a : a.flag_b;
+    const int64_t fi = t < a.Ra ? t : t - a.Ra;
+    a.vent[t] = (int32_t)((t << 1) | (f ? (f[fi] != 0) : 0));
+    if (a.seg) a.seg[t] = (int32_t)upper_slot(a.off, B, t);  // off[i] <= t < off[i+1] (empty graphs are skipped)
+  }
+  if (t <= a.V) {
+    int64_t first = a.R;                                      // unused tail chunks (and the closing entry): empty at the end
+    if (t < a.V && t < a.gptr[B]) {
+      int64_t lo = 0, hi = B;                                 // graph of chunk t: largest i with gptr[i] <= t
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.gptr[mid] <= t) lo = mid; else hi = mid;
+      }
+      first = a.off[lo] + (t - a.gptr[lo]) * a.chunk;
+    }
+    a.vptr[t] = (int32_t)first;
+    if (t < a.V) a.gent[t] = (int32_t)(t << 1);
+  }
+}
+
 // get_dual_subisomorphisms (utils/graph.py:277-316 as convert_to_dual_data drives it, train.py:417-446): a node map
 // of a sample (one row of its `subisomorphisms`) -> for every KEY of the pattern the id of the graph edge it lands on.
 // Keys: maximal runs of consecutive pattern edges (edge-id order) with equal (src, dst); a later run of a key that
@@ -1154,6 +1223,21 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l, const int64_t *
   unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
   dedupe_insert<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1);
   dedupe_lookup<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1, keep);
+  return check_launch();
+}
+
+int dmp_pool_index(const int64_t *sizes_a, int64_t Ba, const int64_t *sizes_b, int64_t Bb, const uint8_t *flag_a,
+                   const uint8_t *flag_b, int64_t rows_a, int64_t R, int chunk, int64_t *off, int32_t *gptr, int32_t *vptr,
+                   int32_t *vent, int32_t *gent, int32_t *seg, void *stream) {
+  if (Ba < 0 || Bb < 0 || R < 0 || rows_a < 0 || rows_a > R || chunk <= 0) return DMP_ERR_BAD_ARG;
+  if (!off || !gptr || !vptr || (Ba > 0 && !sizes_a) || (Bb > 0 && !sizes_b)) return DMP_ERR_BAD_ARG;
+  if (R >= ((int64_t)1 << 30)) return DMP_ERR_UNSUPPORTED;     // (row << 1) | flag in 32 bits
+  PoolArgs a{sizes_a, sizes_b, Ba, Bb, flag_a, flag_b, rows_a, R, R / chunk + Ba + Bb, chunk, off, gptr, vptr, vent, gent, seg};
+  if ((R > 0 && !vent) || (a.V > 0 && !gent)) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  pool_offsets_k<<<1, kBlock, 0, st>>>(a);
+  const int64_t n = (R > a.V + 1 ? R : a.V + 1);
+  pool_fill_k<<<nblk(n), kBlock, 0, st>>>(a);
   return check_launch();
 }
 

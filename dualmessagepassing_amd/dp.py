@@ -216,6 +216,22 @@ class FlatAdamW(torch.optim.Optimizer):
                 # are left untouched like torch.optim.AdamW does (they share the buffer's step count, though)
                 runs = getattr(p, "_dmp_live_runs", None) or [(0, p.numel())]
                 mx = st.get("max_exp_avg_sq")
+                gaps, pos = [], 0                            # the complement of the live runs: what the launch leaves alone
+                for off, n in runs:
+                    if off > pos:
+                        gaps.append((pos, off))
+                    pos = off + n
+                if pos < p.numel():
+                    gaps.append((pos, p.numel() // 4 * 4))
+                if len(gaps) <= 16:                          # DMP_ADAMW_MAX_SKIP: one launch
+                    import ctypes
+                    lo = (ctypes.c_int64 * max(len(gaps), 1))(*[g[0] for g in gaps])
+                    hi = (ctypes.c_int64 * max(len(gaps), 1))(*[g[1] for g in gaps])
+                    _lib.check(lib.dmp_adamw_step_skip(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                                       st["exp_avg_sq"].data_ptr(), _lib.ptr(mx), p.numel(), float(group["lr"]), b1, b2,
+                                                       group["eps"], group["weight_decay"], st["step"], lo, hi, len(gaps),
+                                                       _lib.stream_ptr()), "dmp_adamw_step_skip")
+                    continue
                 for off, n in runs:
                     b = 4 * off
                     _lib.check(lib.dmp_adamw_step(p.data_ptr() + b, p.grad.data_ptr() + b, st["exp_avg"].data_ptr() + b,

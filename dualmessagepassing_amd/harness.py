@@ -356,6 +356,8 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     ``config.json``, ``epoch%d.pt`` (state dict of every epoch), ``log.txt`` whose "best" lines
     (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history."""
     from . import dataio
+    from .tuning import enable_tuned_gemms
+    enable_tuned_gemms()      # the layer's [rows, 128] x [128, 128..384] products with the solutions picked for MI355X
     sync = sync or FlatGradSync(model)
     rng = np.random.default_rng(seed)
     log = None

@@ -463,7 +463,16 @@ class PoolIndex:
     def __init__(self, sizes, flag=None, order=None, seg=None, num_rows=None):
         """``num_rows`` (host int: the total number of rows) makes the construction free of host syncs:
         the chunk table is then sized by the bound ``num_rows // CHUNK + len(sizes)`` and its unused tail
-        consists of empty chunks."""
+        consists of empty chunks.  ``sizes`` / ``flag`` may be PAIRS of tensors (the pattern graphs, then the target
+        graphs of a union pass): on the GPU the whole index is then built by two launches (``dmp_pool_index``)."""
+        pieces = sizes if isinstance(sizes, (tuple, list)) else (sizes,)
+        if num_rows is not None and order is None and pieces[0].is_cuda:
+            self._build_device(pieces, flag, seg, int(num_rows))
+            return
+        if len(pieces) > 1:
+            sizes = torch.cat([p.view(-1) for p in pieces])
+            if isinstance(flag, (tuple, list)):
+                flag = None if any(f is None for f in flag) else torch.cat([f.view(-1) for f in flag])
         dev = sizes.device
         sizes = sizes.to(torch.int64)
         B = int(sizes.numel())
@@ -498,6 +507,44 @@ class PoolIndex:
         self.seg32 = (torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), sizes, output_size=R)
                       if seg is None else seg.to(torch.int32).contiguous())
         self.flag8 = None if flag is None else flag.view(-1).to(torch.uint8).contiguous()
+
+
+def _pool_build_device(self, pieces, flag, seg, R):
+    lib = _lib.load()
+    sizes = [p.view(-1).to(torch.int64).contiguous() for p in pieces]
+    sa, sb = sizes[0], (sizes[1] if len(sizes) > 1 else None)
+    flags = flag if isinstance(flag, (tuple, list)) else (flag,)
+    if any(f is None for f in flags):
+        flags = (None, None)
+    f8 = [None if f is None else (f.contiguous().view(-1).view(torch.uint8) if f.element_size() == 1
+                                  else (f.view(-1) != 0).view(torch.uint8)) for f in flags]
+    fa, fb = f8[0], (f8[1] if len(f8) > 1 else None)
+    _lib.require_gpu(sa, sb, fa, fb)
+    dev = sa.device
+    Ba, Bb = int(sa.numel()), (int(sb.numel()) if sb is not None else 0)
+    B, C = Ba + Bb, self.CHUNK
+    V = R // C + B
+    rows_a = R if fb is None and sb is None else (int(fa.numel()) if fa is not None else None)
+    if rows_a is None:      # two size pieces without flags: the split point is irrelevant
+        rows_a = 0
+    i32 = dict(dtype=torch.int32, device=dev)
+    off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    self.gptr, self.vptr = torch.empty(B + 1, **i32), torch.empty(V + 1, **i32)
+    self.vent, self.gent = torch.empty(R, **i32), torch.empty(V, **i32)
+    self.seg32 = torch.empty(R, **i32) if seg is None else seg.to(torch.int32).contiguous()
+    check(lib.dmp_pool_index(ptr(sa), Ba, ptr(sb), Bb, ptr(fa), ptr(fb), rows_a, R, C, ptr(off), ptr(self.gptr), ptr(self.vptr),
+                             ptr(self.vent), ptr(self.gent), ptr(self.seg32) if seg is None else None, stream_ptr()), "dmp_pool_index")
+    self.num_graphs, self.num_rows, self.num_chunks = B, R, V
+    self.sizes = sa if sb is None else torch.cat([sa, sb])
+    self.offsets = off
+    if fa is None:
+        self.flag8 = None
+    else:
+        self.flag8 = fa if fb is None else torch.cat([fa, fb])
+    self._keep = (sizes, f8)
+
+
+PoolIndex._build_device = _pool_build_device
 
 
 class _SegPool(torch.autograd.Function):

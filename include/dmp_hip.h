@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 34
+#define DMP_ABI_VERSION 36
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -205,6 +205,20 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
 int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
                             const int64_t *g_node_off, int64_t *out, int64_t N,
                             int32_t *status, void *stream);
+/*
+ * Pooling index of a batch (ops.PoolIndex): the rows of graph i are the next sizes[i] rows; every graph's range is cut
+ * into chunks of `chunk` rows so that per-graph sums (the prediction heads' Sum / Mean pooling, pred.py:93-156) run as
+ * two launches of dmp_seg_sum(2): rows -> chunk sums (CSR vptr / vent over V = R / chunk + B chunk rows, unused tail
+ * chunks empty) -> graph sums (CSR gptr / gent).  vent[r] = (r << 1) | flag[r] (flag: is_reversed for edge rows, splits
+ * the sum; NULL = 0), seg[r] = the graph of row r (optional).  sizes and flags come as TWO pieces each (the pattern graphs
+ * then the target graphs of a union pass: B = Ba + Bb, rows [0, rows_a) read flag_a).  off [B+1] int64, gptr [B+1],
+ * vptr [V+1], vent [R], gent [V], seg [R] int32.  Two launches, no host synchronisation.
+ */
+int dmp_pool_index(const int64_t *sizes_a, int64_t Ba, const int64_t *sizes_b, int64_t Bb,
+                   const uint8_t *flag_a, const uint8_t *flag_b, int64_t rows_a, int64_t R, int chunk,
+                   int64_t *off, int32_t *gptr, int32_t *vptr, int32_t *vent, int32_t *gent, int32_t *seg,
+                   void *stream);
+
 /*
  * get_dual_subisomorphisms (utils/graph.py:277-316 as convert_to_dual_data calls it, train.py:417-446) for a whole
  * batch: the node maps of the samples -> per map and per pattern KEY the (sample-local) id of the graph edge it is sent
@@ -455,6 +469,14 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
 int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, void *stream);
+/* The same step, leaving the ranges [skip_lo[k], skip_hi[k]) of the buffer untouched (nskip <= DMP_ADAMW_MAX_SKIP host
+ * entries, multiples of 4 floats): the slices of parameters that received no gradient this step, which
+ * torch.optim.AdamW skips (no decay, no moment update). */
+#define DMP_ADAMW_MAX_SKIP 16
+int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                        float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step, const int64_t *skip_lo, const int64_t *skip_hi,
+                        int nskip, void *stream);
 
 /*
  * ScalarFilter gates of a batch of (pattern, target) pairs (filter.py:6-16 on the pre-padded label matrices,

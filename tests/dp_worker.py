@@ -16,16 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def build_batch(cfg, device, lo, hi):
     import bench
-    shard = bench.make_shard(cfg, 0, device)                     # the GLOBAL batch (seeded); this rank keeps pairs [lo, hi)
-    out = {"counts": shard["counts"][lo:hi]}
-    for t, n, m in (("p", cfg["p_nodes"], cfg["p_edges"]), ("g", cfg["g_nodes"], cfg["g_edges"])):
-        d = shard[t]
-        ns, es = slice(lo * n, hi * n), slice(lo * 2 * m, hi * 2 * m)
-        out[t] = dict(local_src=d["local_src"][es], local_dst=d["local_dst"][es],
-                      ndata={k: v[ns] for k, v in d["ndata"].items()}, edata={k: v[es] for k, v in d["edata"].items()},
-                      num_nodes=d["num_nodes"][lo:hi], num_edges=d["num_edges"][lo:hi], N=(hi - lo) * n, E=(hi - lo) * 2 * m,
-                      max_n=n, max_e=2 * m)
-    return out
+    return bench.slice_shard(cfg, bench.make_shard(cfg, 0, device), lo, hi)   # the GLOBAL batch (seeded); pairs [lo, hi)
 
 
 def one_step(cfg, device, rank, world, overlap):

@@ -61,3 +61,19 @@ def test_two_rank_gradient_equals_global_batch(overlap, gpu, tmp_path):
     assert float(np.abs(got["params"] - ref_p).max()) <= 2.1e-3
     assert abs(float(got["losses"].mean()) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))   # mean of shard means = global mean
     assert float(got["losses"][0]) != float(got["losses"][1])    # the ranks did see different shards
+
+
+def test_micro_batched_step_equals_whole_batch_step(gpu):
+    """bench.py's config-4 form of a step (M micro-batches, gradients summed, each slice's mean loss weighted 1 / M)
+    against the same step over the whole shard at once: identical gradient up to fp32 summation order."""
+    import bench
+    flats = []
+    for m in (1, 4):
+        cfg = dict(bench.CFG, batch=64, act="leaky_relu", emb="Equivariant", micro_batches=m)
+        step, _ = bench.build_step(cfg, bench.make_shard(cfg, 0, gpu), gpu)
+        assert step.micro_batches == m
+        step()
+        flats.append(step.sync.flat.clone())
+    scale = max(1.0, float(flats[0].abs().max()))
+    assert float((flats[0] - flats[1]).abs().max()) <= 2e-5 * scale
+    assert bench.micro_batches_for(dict(bench.CFG)) == 1 and bench.micro_batches_for(dict(bench.CFG4)) == 4

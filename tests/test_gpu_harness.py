@@ -119,6 +119,47 @@ def test_flat_adamw_matches_torch_adamw(n, amsgrad, gpu):
         FlatAdamW([c]).step()                                                       # CPU tensors are refused
 
 
+@pytest.mark.parametrize("holes", [3, 40])
+def test_flat_adamw_skips_parameters_without_gradient_like_torch(holes, gpu):
+    """torch.optim.AdamW (the reference's optimizer, train.py:1231) leaves a parameter whose ``.grad`` is None untouched:
+    no weight decay, no moment update.  The flat optimizer does the same through FlatGradSync.pack()'s bookkeeping -- one
+    launch with the dead slices as skip ranges (<= 16), separate launches per live run beyond that."""
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+
+    class Net(th.nn.Module):
+        def __init__(self):
+            super().__init__()
+            th.manual_seed(holes)
+            self.used = th.nn.ParameterList([th.nn.Parameter(th.randn(5 + 3 * i)) for i in range(holes + 2)])
+            self.unused = th.nn.ParameterList([th.nn.Parameter(th.randn(2 + i)) for i in range(holes)])
+            self._order = [p for pair in zip(self.used, list(self.unused) + [None, None]) for p in pair if p is not None]
+
+        def parameters(self, recurse=True):          # used / unused interleaved in the flat buffer
+            return iter(self._order)
+
+        def forward(self):
+            return sum((p * p).sum() * (i + 1) for i, p in enumerate(self.used))
+
+    a, b = Net().to(gpu), Net().to(gpu)
+    a._order = [p for pair in zip(a.used, list(a.unused) + [None, None]) for p in pair if p is not None]
+    b._order = [p for pair in zip(b.used, list(b.unused) + [None, None]) for p in pair if p is not None]
+    sync = FlatGradSync(a)
+    oa = FlatAdamW([sync.flatten_parameters()], lr=1e-2, weight_decay=0.1, amsgrad=True)
+    ob = th.optim.AdamW(list(b.parameters()), lr=1e-2, weight_decay=0.1, amsgrad=True)
+    for _ in range(4):
+        sync.detach_grads()
+        a().backward()
+        sync.pack()
+        oa.step()
+        ob.zero_grad(set_to_none=True)
+        b().backward()
+        ob.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert th.allclose(p.data, q.data, rtol=2e-6, atol=2e-7)
+    for p, q in zip(a.unused, Net().unused):       # untouched: exactly the initial values (no decay)
+        assert th.equal(p.data.cpu(), q.data)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("count", [1, 7, 64, 150])
 def test_pack_segments_bit_exact(count, gpu):

@@ -763,3 +763,29 @@ def test_activation_slope_outside_the_supported_range_is_refused(gpu):
     for bad in (-0.1, 1.5):
         with pytest.raises(_lib.DmpError):
             fused.add_bias_relu_(a.clone(), a, None, bad)
+
+
+@pytest.mark.parametrize("sizes_a,sizes_b", [([5, 0, 130, 64], [1, 300]), ([7] * 50, None), ([0, 0, 3], [0]), ([64] * 1024, [512] * 1024)])
+def test_pool_index_device_build_equals_tensor_build(sizes_a, sizes_b, gpu):
+    """ops.PoolIndex built by dmp_pool_index (two launches, sizes / flags as two pieces) == the tensor-op construction:
+    every array bit for bit, and the pooled sums it produces."""
+    from dualmessagepassing_amd import ops
+    gen = th.Generator().manual_seed(3)
+    a = th.tensor(sizes_a, dtype=th.int64, device=gpu)
+    b = None if sizes_b is None else th.tensor(sizes_b, dtype=th.int64, device=gpu)
+    ra, rb = int(sum(sizes_a)), int(sum(sizes_b or []))
+    for with_flag in (False, True):
+        fa = (th.rand(ra, generator=gen) < 0.5).to(gpu) if with_flag else None
+        fb = (th.rand(rb, generator=gen) < 0.5).to(gpu) if (with_flag and b is not None) else None
+        sizes = a if b is None else th.cat([a, b])
+        flag = None if not with_flag else (fa if b is None else th.cat([fa, fb]))
+        ref = ops.PoolIndex(sizes, flag)                                       # tensor ops (host-sized)
+        got = ops.PoolIndex(a if b is None else (a, b), (fa if b is None else (fa, fb)) if with_flag else None, num_rows=ra + rb)
+        assert (got.num_graphs, got.num_rows) == (ref.num_graphs, ref.num_rows) and got.num_chunks >= ref.num_chunks
+        V = ref.num_chunks
+        assert th.equal(got.vent, ref.vent) and th.equal(got.gptr, ref.gptr) and th.equal(got.seg32, ref.seg32)
+        assert th.equal(got.vptr[:V + 1], ref.vptr) and bool((got.vptr[V:] == ra + rb).all())
+        assert th.equal(got.gent[:V], ref.gent) and th.equal(got.sizes, ref.sizes)
+        assert (got.flag8 is None) == (ref.flag8 is None) and (got.flag8 is None or th.equal(got.flag8, ref.flag8))
+        x = th.randn(ra + rb, 16, generator=gen).to(gpu)
+        assert th.equal(ops.seg_pool(x, got), ops.seg_pool(x, ref))

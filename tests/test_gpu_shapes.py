@@ -136,3 +136,55 @@ def test_degenerate_graphs_through_the_layer(case, gpu):
         (ng.sum() + (eg * eg).sum()).backward()
         _close(xg.grad, xo.grad, 1e-4, "dx fused=%s" % fused)
         _close(zg.grad, zo.grad, 1e-4, "dz fused=%s" % fused)
+
+
+@pytest.mark.parametrize("act", ["leaky_relu", "relu"])
+def test_fused_typed_layer_at_full_config2_size_against_fp64(act, gpu):
+    """BASELINE config 2 at FULL size -- the union graph of bench.py's step: 1024 x (pattern (8, 12) + target (64, 256)),
+    add_rev: N = 73,728 node rows, E = 548,864 edge rows, hid 128 -- through the fused layer on its fastest path (class-typed
+    MFMA kernels, folded first Linear, gates, residual), forward and backward, against the oracle's operation order run in
+    fp64 on the same device (every row, not a subsample).  fp32 tolerances: outputs 2e-5, input gradients 1e-4 (flip-aware:
+    see test_gpu_dmplayer._close_or_flipped), parameter gradients 5e-4 (sums over 5e5 rows) of the largest reference value."""
+    from test_gpu_dmplayer import _close_or_flipped
+    from dualmessagepassing_amd import fused
+    from dualmessagepassing_amd.dmpnn import DMPNNRep
+    from dualmessagepassing_amd.graph import BatchedGraph
+    rng = np.random.default_rng(2)
+    ps, pd, pr, pN, pbnn, pbne = er_batch(1024, 8, 12, rng)
+    gs, gd, gr, gN, gbnn, gbne = er_batch(1024, 64, 256, rng)
+    src, dst, rev = np.concatenate([ps, gs + pN]), np.concatenate([pd, gd + pN]), np.concatenate([pr, gr])
+    N, E, h = pN + gN, len(src), 128
+    assert (N, E) == (73728, 548864)
+    gen = th.Generator().manual_seed(41)
+    params = O.random_dmp_params(h, h, gen, act)
+    x, z = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
+    wv, we = th.randn(N, h, generator=gen), th.randn(E, h, generator=gen)
+    vg, eg = (th.rand(N, 1, generator=gen) < 0.7).float(), (th.rand(E, 1, generator=gen) < 0.7).float()
+    ts, td, tr = _t(src).to(gpu), _t(dst).to(gpu), _t(rev).to(gpu)
+    # fp64 oracle on the device
+    p64 = {k: v.double().to(gpu).requires_grad_(True) for k, v in params.items()}
+    x64, z64 = x.double().to(gpu).requires_grad_(True), z.double().to(gpu).requires_grad_(True)
+    rv, re = O.dmpnn_graph_rep([p64], ts, td, tr, O.out_degrees(ts, N), x64, z64, vg.double().to(gpu), eg.double().to(gpu), True, act)
+    ((rv * wv.double().to(gpu)).sum() + (re * we.double().to(gpu)).sum()).backward()
+    # product
+    net = DMPNNRep(hid_dim=h, rep_num_graph_layers=1, rep_num_pattern_layers=1, share_rep_net=True, rep_residual=True,
+                   rep_dmpnn_batch_norm=False, rep_act_func=act)
+    sd = {}
+    for k, v in params.items():
+        sd["g_rep_net.dmpnn.graph_dmpnn_(0)." + k] = v
+        sd["p_rep_net.dmpnn.graph_dmpnn_(0)." + k] = v
+    net.load_state_dict(sd, strict=True)
+    net.to(gpu)
+    g = BatchedGraph(ts, td, N, _t(np.concatenate([pbnn, gbnn])).to(gpu), _t(np.concatenate([pbne, gbne])).to(gpu))
+    g.edata["is_reversed"] = tr
+    xg, zg = x.to(gpu).requires_grad_(True), z.to(gpu).requires_grad_(True)
+    assert fused.typed_ok(g.index(), h)                        # the class-typed kernels are the ones measured by bench.py
+    a, b = net.get_graph_rep(g, xg, zg, v_gate=vg.to(gpu), e_gate=eg.to(gpu))
+    ((a * wv.to(gpu)).sum() + (b * we.to(gpu)).sum()).backward()
+    _close(a, rv.detach().cpu(), 2e-5, "v_rep")
+    _close(b, re.detach().cpu(), 2e-5, "e_rep")
+    flipped = _close_or_flipped(xg.grad, x64.grad.cpu(), 5e-5, 5e-5, "dx")
+    flipped |= _close_or_flipped(zg.grad, z64.grad.cpu(), 5e-5, 5e-5, "dz")
+    for k, p in net.g_rep_net.named_parameters():
+        ref = p64[k.split(").", 1)[1]].grad.cpu()
+        _close(p.grad, ref, 5e-3 if flipped else 5e-4, "grad " + k)
