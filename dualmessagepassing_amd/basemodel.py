@@ -71,10 +71,10 @@ def scalar_filter_gate(p_pad, p_label, g_pad, g_label, num_labels):
     than the longest one of the batch (its pre-padding zeros take part in the reference's comparison)."""
     B, L = p_pad.bsz, int(num_labels)
     present = th.zeros(B * L, dtype=th.bool, device=p_label.device)
-    present.index_fill_(0, p_pad.seg * L + p_label.view(-1), True)
+    present.index_fill_(0, p_pad.seg.long() * L + p_label.view(-1), True)
     if not p_pad.uniform:
         present.view(B, L)[:, 0] |= p_pad.sizes < p_pad.max
-    return present.index_select(0, g_pad.seg * L + g_label.view(-1)).view(-1, 1)
+    return present.index_select(0, g_pad.seg.long() * L + g_label.view(-1)).view(-1, 1)
 
 
 _FILTER_JOB = None
@@ -94,7 +94,8 @@ def scalar_filter_gates(jobs):
             _fields_ = [("p_seg", ctypes.c_void_p), ("p_label", ctypes.c_void_p), ("num_p", ctypes.c_int64),
                         ("p_sizes", ctypes.c_void_p), ("p_max", ctypes.c_int64),
                         ("g_seg", ctypes.c_void_p), ("g_label", ctypes.c_void_p), ("num_g", ctypes.c_int64),
-                        ("num_labels", ctypes.c_int64), ("present_off", ctypes.c_int64), ("gate", ctypes.c_void_p)]
+                        ("num_labels", ctypes.c_int64), ("present_off", ctypes.c_int64), ("gate", ctypes.c_void_p),
+                        ("seg_is_i32", ctypes.c_int64)]
         _FILTER_JOB = _Job
     dev = jobs[0][1].device
     B = jobs[0][0].bsz
@@ -105,12 +106,15 @@ def scalar_filter_gates(jobs):
         L = int(L)
         ps, pl = p_pad.seg.contiguous(), p_label.reshape(-1).long().contiguous()
         gs, gl = g_pad.seg.contiguous(), g_label.reshape(-1).long().contiguous()
+        if ps.dtype != gs.dtype or ps.dtype not in (th.int32, th.int64):
+            ps, gs = ps.long(), gs.long()
         sizes = None if p_pad.uniform else p_pad.sizes.long().contiguous()
         gate = th.empty((gl.numel(), 1), dtype=th.float32, device=dev)
         J[i].p_seg, J[i].p_label, J[i].num_p = ps.data_ptr(), pl.data_ptr(), pl.numel()
         J[i].p_sizes, J[i].p_max = (None if sizes is None else sizes.data_ptr()), int(p_pad.max)
         J[i].g_seg, J[i].g_label, J[i].num_g = gs.data_ptr(), gl.data_ptr(), gl.numel()
         J[i].num_labels, J[i].present_off, J[i].gate = L, off, gate.data_ptr()
+        J[i].seg_is_i32 = 1 if ps.dtype == th.int32 else 0
         off += (B * L + 15) // 16 * 16
         keep.append((ps, pl, gs, gl, sizes))
         gates.append(gate)
@@ -164,7 +168,7 @@ def _segments(graph, kind):
     sizes = graph.batch_num_nodes() if kind == "node" else graph.batch_num_edges()
     if seg is None:
         seg = th.repeat_interleave(th.arange(sizes.numel(), device=sizes.device), sizes)
-    return seg.long(), sizes
+    return seg, sizes      # int32 from the device collate, int64 otherwise: the consumers take both
 
 
 def _max_len(sizes):
@@ -192,8 +196,9 @@ class _Padder:
             off = th.zeros(self.bsz + 1, dtype=th.int64, device=self.sizes.device)
             th.cumsum(self.sizes, 0, out=off[1:])
             self.off = off[:-1]
-            pos = th.arange(n, device=self.sizes.device) - off[self.seg]
-            self.idx = self.seg * self.max + (self.max - self.sizes[self.seg]) + pos
+            seg = self.seg.long()
+            pos = th.arange(n, device=self.sizes.device) - off[seg]
+            self.idx = seg * self.max + (self.max - self.sizes[seg]) + pos
 
     def pad(self, x):
         x = x.reshape(x.size(0), -1)

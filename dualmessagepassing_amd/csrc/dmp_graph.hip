@@ -1012,7 +1012,8 @@ __global__ __launch_bounds__(kBlock) void filter_mark_k(const FilterJobs t, int6
   uint8_t *__restrict__ pr = present + j.present_off;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < j.num_p) {
-    const int64_t b = j.p_seg[i], l = j.p_label[i];
+    const int64_t b = j.seg_is_i32 ? (int64_t)static_cast<const int32_t *>(j.p_seg)[i] : static_cast<const int64_t *>(j.p_seg)[i];
+    const int64_t l = j.p_label[i];
     if (b >= 0 && b < B && l >= 0 && l < j.num_labels) pr[b * j.num_labels + l] = 1;
   }
   // a pattern shorter than the longest one is pre-padded with zeros: label 0 takes part in the comparison
@@ -1022,7 +1023,8 @@ __global__ __launch_bounds__(kBlock) void filter_gate_k(const FilterJobs t, int6
   const dmp_filter_job &j = t.job[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= j.num_g) return;
-  const int64_t b = j.g_seg[i], l = j.g_label[i];
+  const int64_t b = j.seg_is_i32 ? (int64_t)static_cast<const int32_t *>(j.g_seg)[i] : static_cast<const int64_t *>(j.g_seg)[i];
+  const int64_t l = j.g_label[i];
   const bool in = b >= 0 && b < B && l >= 0 && l < j.num_labels;
   j.gate[i] = (in && present[j.present_off + b * j.num_labels + l]) ? 1.f : 0.f;
 }

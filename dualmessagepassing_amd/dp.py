@@ -76,6 +76,7 @@ class FlatGradSync:
 
     def zero(self):
         self.flat.zero_()
+        self._zeroed_for = None
 
     # ---- alternative to accumulating into the views: let autograd produce fresh gradient tensors
     # (no per-parameter ``grad += new`` launches) and pack them with one multi-tensor copy
@@ -103,8 +104,13 @@ class FlatGradSync:
                     src.append(g)
                     which.append(i)
             p.grad = v
-        if missing:                                          # parameters without a gradient this step keep zeros
-            self.flat.zero_()
+        if missing:                                          # parameters without a gradient this step keep zeros:
+            key = tuple(live)                                # their slices were zero before and nothing writes them, so the
+            if getattr(self, "_zeroed_for", None) != key:    # buffer is cleared only when the set of live parameters changes
+                self.flat.zero_()
+                self._zeroed_for = key
+        else:
+            self._zeroed_for = None
         self._note_live(live if missing else None)
         if not dst:
             return

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 36
+#define DMP_ABI_VERSION 37
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -484,18 +484,20 @@ int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *
  *   gate[j] = 1.0 if the label of target row j occurs among the labels of the pattern of the same pair, else 0.0;
  *   label 0 also passes when that pattern is shorter than p_max (its pre-padding zeros take part in the
  *   reference's comparison).
- * p_seg / g_seg: pair id of every pattern / target row, labels in [0, num_labels) (rows with labels outside
+ * p_seg / g_seg: pair id of every pattern / target row (int64, or -- seg_is_i32 != 0 -- the int32 arrays the
+ * device collate leaves in node_graph / edge_graph), labels in [0, num_labels) (rows with labels outside
  * that range never match and mark nothing).  p_sizes [B] rows per pattern, or NULL when every pattern has
  * p_max rows.  present: scratch of present_bytes >= sum over jobs of B * num_labels bytes, job i using
  * [present_off, present_off + B * num_labels).  The jobs array is a HOST array.
  */
 #define DMP_FILTER_MAX_JOBS 4
 typedef struct {
-  const int64_t *p_seg, *p_label; int64_t num_p;
+  const void *p_seg; const int64_t *p_label; int64_t num_p;
   const int64_t *p_sizes; int64_t p_max;
-  const int64_t *g_seg, *g_label; int64_t num_g;
+  const void *g_seg; const int64_t *g_label; int64_t num_g;
   int64_t num_labels, present_off;
   float *gate;                      /* [num_g] */
+  int64_t seg_is_i32;
 } dmp_filter_job;
 int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B, uint8_t *present,
                             int64_t present_bytes, void *stream);

@@ -41,7 +41,7 @@ def activation(name):
 def seg_sum(msg, dst, num_nodes):
     """``fn.sum`` by destination (models/dmpnn.py:92,163): zeros for nodes with no
     in-edge, fp32 adds in eid order."""
-    out = th.zeros((num_nodes,) + tuple(msg.shape[1:]), dtype=msg.dtype)
+    out = th.zeros((num_nodes,) + tuple(msg.shape[1:]), dtype=msg.dtype, device=msg.device)
     return out.index_add(0, dst, msg)
 
 
