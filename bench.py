@@ -361,6 +361,7 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    gc.set_threshold(200000, 20, 20)     # young-generation passes every 200 k allocations (~30 steps) instead of every 700
     barrier()
     # timed region: HIP events only around the roofline kernel (the scatter-add), so that the
     # event records do not perturb the step; every other kernel is timed in extra steps below

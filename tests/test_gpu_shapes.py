@@ -187,4 +187,6 @@ def test_fused_typed_layer_at_full_config2_size_against_fp64(act, gpu):
     flipped |= _close_or_flipped(zg.grad, z64.grad.cpu(), 5e-5, 5e-5, "dz")
     for k, p in net.g_rep_net.named_parameters():
         ref = p64[k.split(").", 1)[1]].grad.cpu()
-        _close(p.grad, ref, 5e-3 if flipped else 5e-4, "grad " + k)
+        # with ~10^7 activations per layer a few pre-activations lie within fp32 rounding of zero: their derivative branch may
+        # differ from the fp64 run's, which moves the parameter gradients by up to a percent (ReLU: a full unit step)
+        _close(p.grad, ref, 2e-2 if flipped else 5e-4, "grad " + k)
