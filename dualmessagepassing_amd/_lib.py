@@ -36,6 +36,8 @@ SIGNATURES = {
     "dmp_subiso_node_weights": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_dual_subisomorphisms": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_random_walks": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, ctypes.c_uint64, c_ptr, c_ptr, c_ptr]),
+    "dmp_sample_in_edges": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, ctypes.c_uint64, c_ptr, c_ptr]),
     "dmp_pool_index": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                c_ptr, c_ptr]),
     "dmp_pattern_edge_active": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -114,7 +116,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -860,4 +860,7 @@ def build_model(config=None, **kw):
         return RGCN(**config)
     if rep_net == "RGIN":
         return RGIN(**config)
+    if rep_net in ("LRP", "DMPLRP"):
+        from . import lrp
+        return getattr(lrp, rep_net)(**config)
     raise NotImplementedError("rep_net=%s is outside the MI355X hot-path scope" % rep_net)

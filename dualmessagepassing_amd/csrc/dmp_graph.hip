@@ -566,6 +566,66 @@ __global__ void subiso_edge_k(const int64_t *sub, const int64_t *sample_ptr, con
   }
 }
 
+// UNC mini-batch samplers (UnsupervisedNodeClassification/Model/DMPNN/src/utils.py:279-349; DGL's random_walk /
+// sample_neighbors there).  Random choices come from a counter-based generator -- a 32-bit mix of (seed, a, b) -- so a
+// launch is reproducible from its seed and has a plain restatement (oracle/graph_oracle.py::rng_hash).
+__host__ __device__ __forceinline__ uint32_t rng_hash(uint32_t seed, uint32_t a, uint32_t b) {
+  uint32_t x = seed ^ (a * 0x9E3779B1u) ^ (((b * 0x85EBCA77u) << 15) | ((b * 0x85EBCA77u) >> 17));
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+// walk w of seed s: trace[0] = the seed; step t follows one of the current node's out-edges, the k-th of its CSR row
+// with k = (hash * out_degree) >> 32; a node without out-edges ends the walk (-1 from there on, as dgl.sampling.random_walk).
+__global__ void random_walks_k(const int32_t *out_ptr, const int32_t *out_ent, const int32_t *dst, const int64_t *seeds,
+                               int64_t S, int walks, int depth, uint32_t seed, int64_t *traces, uint8_t *visited) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= S * walks) return;
+  int64_t cur = seeds[t / walks];
+  int64_t *tr = traces ? traces + t * (depth + 1) : nullptr;
+  if (tr) tr[0] = cur;
+  if (visited) visited[cur] = 1;
+  for (int step = 1; step <= depth; ++step) {
+    if (cur >= 0) {
+      const int32_t lo = out_ptr[cur], deg = out_ptr[cur + 1] - lo;
+      if (deg == 0) {
+        cur = -1;
+      } else {
+        const uint32_t h = rng_hash(seed, (uint32_t)t, (uint32_t)step);
+        cur = dst[out_ent[lo + (int32_t)(((uint64_t)h * (uint64_t)deg) >> 32)] >> 1];
+        if (visited) visited[cur] = 1;
+      }
+    }
+    if (tr) tr[step] = cur;
+  }
+}
+
+// sample_neighbors(graph, nodes, width, edge_dir="in"): every wanted node keeps all of its in-edges if it has at most
+// `width`, else the `width` in-edges with the smallest keys hash(seed, edge id, 0) (ties: the smaller edge id) -- a uniform
+// choice without replacement.  One thread per node, an insertion list of the `width` best keys.
+constexpr int kMaxSampleWidth = 64;
+__global__ void sample_in_edges_k(const int32_t *in_ptr, const int32_t *in_ent, const uint8_t *wanted, int64_t N, int width,
+                                  uint32_t seed, uint8_t *mask) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= N || (wanted && !wanted[v])) return;
+  const int32_t lo = in_ptr[v], hi = in_ptr[v + 1];
+  if (hi - lo <= width) {
+    for (int32_t q = lo; q < hi; ++q) mask[in_ent[q] >> 1] = 1;
+    return;
+  }
+  uint64_t best[kMaxSampleWidth];                              // (key << 32) | edge id, ascending
+  int n = 0;
+  for (int32_t q = lo; q < hi; ++q) {
+    const uint32_t e = (uint32_t)(in_ent[q] >> 1);
+    const uint64_t k = ((uint64_t)rng_hash(seed, e, 0u) << 32) | e;
+    if (n == width && k >= best[n - 1]) continue;
+    int i = n < width ? n++ : n - 1;
+    while (i > 0 && best[i - 1] > k) { best[i] = best[i - 1]; --i; }
+    best[i] = k;
+  }
+  for (int i = 0; i < n; ++i) mask[(uint32_t)best[i]] = 1;
+}
+
 // Pooling index (ops.PoolIndex): the rows of every graph of a batch (contiguous ranges of `sizes[i]` rows) cut into chunks
 // of `chunk` rows, so that the per-graph sums of the prediction heads run as two launches of the segment-sum kernel
 // (rows -> chunk sums -> graph sums) with enough independent rows to fill the chip.  One single-workgroup scan for the
@@ -1225,6 +1285,30 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l, const int64_t *
   unsigned long long *t = reinterpret_cast<unsigned long long *>(table);
   dedupe_insert<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1);
   dedupe_lookup<<<nblk(M), kBlock, 0, st>>>(key_a, key_l, key_b, M, t, cap - 1, keep);
+  return check_launch();
+}
+
+int dmp_random_walks(const int32_t *out_ptr, const int32_t *out_ent, const int32_t *dst, const int64_t *seeds,
+                     int64_t num_seeds, int walks, int depth, uint64_t seed, int64_t *traces, uint8_t *visited, void *stream) {
+  if (num_seeds < 0 || walks < 0 || depth < 0) return DMP_ERR_BAD_ARG;
+  if (num_seeds == 0 || walks == 0) return DMP_OK;
+  if (!out_ptr || !seeds || (!traces && !visited) || (depth > 0 && (!out_ent || !dst))) return DMP_ERR_BAD_ARG;
+  if (num_seeds * walks >= ((int64_t)1 << 32)) return DMP_ERR_UNSUPPORTED;
+  random_walks_k<<<nblk(num_seeds * walks), kBlock, 0, (hipStream_t)stream>>>(out_ptr, out_ent, dst, seeds, num_seeds, walks, depth,
+                                                                          (uint32_t)(seed ^ (seed >> 32)), traces, visited);
+  return check_launch();
+}
+
+int dmp_sample_in_edges(const int32_t *in_ptr, const int32_t *in_ent, const uint8_t *wanted, int64_t N, int64_t E, int width,
+                        uint64_t seed, uint8_t *mask, void *stream) {
+  if (N < 0 || E < 0 || width < 0) return DMP_ERR_BAD_ARG;
+  if (width > kMaxSampleWidth) return DMP_ERR_UNSUPPORTED;
+  if (E == 0) return DMP_OK;
+  if (!in_ptr || !in_ent || !mask) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DMP_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)E, st));
+  if (N > 0 && width > 0)
+    sample_in_edges_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, wanted, N, width, (uint32_t)(seed ^ (seed >> 32)), mask);
   return check_launch();
 }
 

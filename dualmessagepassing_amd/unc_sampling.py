@@ -14,8 +14,32 @@ the reference's contract.
 """
 import torch
 
+from . import _lib
+from ._lib import check, ptr, stream_ptr
 from .graph import BatchedGraph
 from .unc import compute_edgenorm
+
+
+def _seed_of(generator, seed):
+    """The 64-bit seed of a kernel launch: given, or the next draw of ``generator`` / torch's global generator."""
+    if seed is not None:
+        return int(seed) & (2 ** 64 - 1)
+    return int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+
+
+def random_walks(graph, seed_nodes, walks, depth, seed=None, generator=None, return_traces=True):
+    """``dgl.sampling.random_walk(graph, seeds, length=depth)`` repeated ``walks`` times per seed, as ONE launch
+    (``dmp_random_walks``, a thread per walk over the CSR by source): ``(traces [S * walks, depth + 1] int64 with -1
+    after a dead end, visited bool [N])``."""
+    lib = _lib.load()
+    ix = graph.index()
+    seeds = torch.as_tensor(seed_nodes, device=ix.device).to(torch.int64).view(-1).contiguous()
+    S, N = int(seeds.numel()), graph.number_of_nodes()
+    traces = torch.empty((S * walks, depth + 1), dtype=torch.int64, device=ix.device) if return_traces else None
+    visited = torch.zeros(N, dtype=torch.uint8, device=ix.device)
+    check(lib.dmp_random_walks(ptr(ix.out_ptr), ptr(ix.out_ent), ptr(ix.dst32), ptr(seeds), S, int(walks), int(depth),
+                               _seed_of(generator, seed), ptr(traces), ptr(visited), stream_ptr()), "dmp_random_walks")
+    return traces, visited.bool()
 
 
 def negative_sampling(pos_samples, num_entity, negative_rate, values=None, choices=None, generator=None):
@@ -53,19 +77,25 @@ def sample_in_edges(graph, nodes, width, generator=None):
     node in ``nodes`` up to ``width`` of its in-edges, chosen uniformly without replacement (all of them
     if it has at most ``width``).  One random key per edge, a sort by (destination, key), the first
     ``width`` of every destination segment survive.  Returns a bool mask over the graph's edges."""
-    src, dst = graph.all_edges(form="uv", order="eid")
-    E, N, dev = dst.numel(), graph.number_of_nodes(), dst.device
-    wanted = torch.zeros(N, dtype=torch.bool, device=dev)
-    wanted[nodes] = True
-    key = torch.rand(E, device=dev, generator=generator, dtype=torch.float64)
-    order = torch.argsort(dst.to(torch.float64) + key)          # grouped by destination, random inside a group
-    sdst = dst[order]
-    start = torch.searchsorted(sdst, sdst)                       # first position of each destination's group
-    rank = torch.arange(E, device=dev) - start
-    keep_sorted = (rank < width) & wanted[sdst]
-    mask = torch.zeros(E, dtype=torch.bool, device=dev)
-    mask[order] = keep_sorted
-    return mask
+    return sample_in_edges_device(graph, nodes, width, generator=generator)
+
+
+def sample_in_edges_device(graph, nodes, width, seed=None, generator=None):
+    """``sample_in_edges`` as one launch over the CSR by destination (``dmp_sample_in_edges``: a thread per node keeps the
+    ``width`` in-edges with the smallest hashed keys).  ``nodes``: index tensor, or a bool / uint8 mask over the nodes."""
+    lib = _lib.load()
+    ix = graph.index()
+    E, N, dev = graph.number_of_edges(), graph.number_of_nodes(), ix.device
+    nodes = torch.as_tensor(nodes, device=dev)
+    if nodes.dtype in (torch.bool, torch.uint8) and nodes.numel() == N:
+        wanted = nodes.to(torch.uint8).contiguous()
+    else:
+        wanted = torch.zeros(N, dtype=torch.uint8, device=dev)
+        wanted[nodes.to(torch.int64)] = 1
+    mask = torch.empty(E, dtype=torch.uint8, device=dev)
+    check(lib.dmp_sample_in_edges(ptr(ix.in_ptr), ptr(ix.in_ent), ptr(wanted), N, E, int(width), _seed_of(generator, seed),
+                                  ptr(mask), stream_ptr()), "dmp_sample_in_edges")
+    return mask.bool()
 
 
 def sample_subgraph_by_neighbors(graph, seed_nodes, depth=2, width=10, generator=None):
@@ -104,6 +134,40 @@ def sample_subgraph_by_neighbors(graph, seed_nodes, depth=2, width=10, generator
     return sub, nid
 
 
+def _induced(graph, mask, seed_nodes):
+    """The subgraph of the sampled edges: nodes without a sampled edge are dropped unless they are seeds
+    (utils.py:297-302,333-338), ids compacted in ascending parent order, edge frames copied."""
+    src, dst = graph.all_edges(form="uv", order="eid")
+    N, dev = graph.number_of_nodes(), dst.device
+    eid = mask.nonzero().view(-1)                                # host sync: subgraph size
+    s, d = src[eid], dst[eid]
+    keep = torch.zeros(N, dtype=torch.bool, device=dev)
+    keep[s] = True
+    keep[d] = True
+    keep[seed_nodes] = True
+    nid = keep.nonzero().view(-1)
+    sub = BatchedGraph(convert_subgraph_nids(s, nid, N), convert_subgraph_nids(d, nid, N), int(nid.numel()))
+    for k, v in graph.edata.items():
+        if k not in ("in_deg", "out_deg", "norm"):
+            sub.edata[k] = v[eid]
+    sub.edata["_ID"] = eid
+    sub.ndata["_ID"] = nid
+    return sub, nid
+
+
+def sample_subgraph_by_randomwalks(graph, seed_nodes, depth=2, width=10, seed=None, generator=None):
+    """utils.py:279-313: ``width - 1`` random walks of ``depth`` steps from every seed (one launch), the union of the
+    visited nodes with the seeds, ``width`` sampled in-edges for each of them (one launch), removal of the nodes left
+    without an edge unless they are seeds.  Returns ``(subgraph, nid)`` like ``sample_subgraph_by_neighbors``."""
+    dev = graph.device
+    seed_nodes = torch.as_tensor(seed_nodes, device=dev).to(torch.int64).view(-1)
+    s0 = _seed_of(generator, seed)
+    _, visited = random_walks(graph, seed_nodes, max(width - 1, 0), depth, seed=s0, return_traces=False)
+    visited[seed_nodes] = True
+    mask = sample_in_edges_device(graph, visited, width, seed=s0 + 1)
+    return _induced(graph, mask, seed_nodes)
+
+
 def drop_edges(sub, keep_fraction, generator=None):
     """utils.py:427-429: delete ``int(E * (1 - keep_fraction))`` edge draws (with replacement, duplicates
     collapse: ``np.unique(uniform_choice_int(...))``) from the subgraph."""
@@ -124,14 +188,19 @@ def drop_edges(sub, keep_fraction, generator=None):
 
 
 def generate_sampled_graph_and_labels_unsupervised(graph, edges, sample_depth, sample_width, split_size,
-                                                   negative_rate, generator=None):
+                                                   negative_rate, generator=None, sampler="neighbor"):
     """utils.py:399-434 with the neighbour sampler: ``edges`` [B, 3] positive triplets on the device ->
     ``(subgraph, samples [B * (1 + negative_rate), 3] in subgraph node ids, labels float32)``; the
     subgraph carries ``edata["norm"]`` (``compute_edgenorm``) like the training loop computes next."""
     edges = edges.to(torch.int64)
     neg = negative_sampling(edges, graph.number_of_nodes(), negative_rate, generator=generator)
     seed = torch.unique(torch.cat([edges[:, 0], edges[:, 2], neg[:, 0], neg[:, 2]]))
-    sub, nid = sample_subgraph_by_neighbors(graph, seed, sample_depth, sample_width, generator)
+    if sampler == "neighbor":        # utils.py:416-419
+        sub, nid = sample_subgraph_by_neighbors(graph, seed, sample_depth, sample_width, generator)
+    elif sampler == "randomwalk":
+        sub, nid = sample_subgraph_by_randomwalks(graph, seed, sample_depth, sample_width, generator=generator)
+    else:
+        raise ValueError(sampler)
     samples = torch.cat([edges, neg])
     samples[:, 0] = convert_subgraph_nids(samples[:, 0], nid, graph.number_of_nodes())
     samples[:, 2] = convert_subgraph_nids(samples[:, 2], nid, graph.number_of_nodes())

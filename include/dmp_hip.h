@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 37
+#define DMP_ABI_VERSION 38
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -205,6 +205,24 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
 int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
                             const int64_t *g_node_off, int64_t *out, int64_t N,
                             int32_t *status, void *stream);
+/*
+ * UNC mini-batch samplers on the device (UnsupervisedNodeClassification/Model/DMPNN/src/utils.py:279-349, where DGL's
+ * dgl.sampling.random_walk / sample_neighbors do this on the host).  Randomness: a counter-based 32-bit mix of
+ * (seed, a, b) (oracle/graph_oracle.py::rng_hash restates it), so results are reproducible from `seed`.
+ *   dmp_random_walks   : `walks` walks of `depth` steps from every seed over the CSR by source (dmp_csr_build): step t
+ *                        of walk w takes the k-th out-edge of the current node, k = (mix(seed, w, t) * out_degree) >> 32;
+ *                        a node without out-edges ends the walk.  traces [num_seeds * walks, depth + 1] int64 (-1 after
+ *                        the end) and / or visited [N] uint8 (set to 1 for every node on a walk; the caller zeroes it).
+ *   dmp_sample_in_edges: mask[e] = 1 for the in-edges kept for every node v with wanted[v] != 0 (NULL: all nodes): all
+ *                        of them if v has at most `width` (<= 64), else the `width` with the smallest
+ *                        (mix(seed, e, 0), e) -- a uniform sample without replacement.  mask [E] uint8 is fully written.
+ */
+int dmp_random_walks(const int32_t *out_ptr, const int32_t *out_ent, const int32_t *dst, const int64_t *seeds,
+                     int64_t num_seeds, int walks, int depth, uint64_t seed, int64_t *traces, uint8_t *visited,
+                     void *stream);
+int dmp_sample_in_edges(const int32_t *in_ptr, const int32_t *in_ent, const uint8_t *wanted, int64_t N,
+                        int64_t E, int width, uint64_t seed, uint8_t *mask, void *stream);
+
 /*
  * Pooling index of a batch (ops.PoolIndex): the rows of graph i are the next sizes[i] rows; every graph's range is cut
  * into chunks of `chunk` rows so that per-graph sums (the prediction heads' Sum / Mean pooling, pred.py:93-156) run as

@@ -331,3 +331,45 @@ def rel_layer(params, src, dst, etype, x, kind, num_rels, regularizer="basis", n
     out = out + params["bias"]
     out = mlp(out, params, "mlp", act, num_mlp_layers) if num_mlp_layers > 0 else act(out)
     return act(out)
+
+
+# ----------------------------------------------------------------------------- LRP / DMPLRP (models/lrp.py, models/dmplrp.py)
+def coo_mm(indices, values, shape, x):
+    """``torch.sparse.mm(A, x)`` for a COO matrix given by its arrays: out[r] += v * x[c], nonzeros in storage order."""
+    out = th.zeros((int(shape[0]), x.size(1)), dtype=x.dtype, device=x.device)
+    return out.index_add(0, indices[0], values.to(x.dtype).unsqueeze(-1) * x[indices[1]])
+
+
+def lrp_contract(perm_rows, weight, seq_len):
+    """``einsum('dab,bca->dc', rows.view(-1, L*L, in), weight)`` (models/lrp.py:68-69): the L x L slots of every
+    permutation against ``weight`` [in, out, L*L]."""
+    return th.einsum("dab,bca->dc", perm_rows.view(-1, seq_len * seq_len, weight.size(0)), weight)
+
+
+def lrp_layer(params, pool, n2p, e2p, in_deg, x, z, act_func="relu", seq_len=4):
+    """``LRPLayer.forward`` (models/lrp.py:66-88).  pool / n2p / e2p: (indices, values, shape) of the pooling and the
+    node / edge -> permutation-slot matrices (dataset.py:1795-1862).  Returns (node_out, edge_out = z)."""
+    act = activation(act_func)
+    out = coo_mm(*n2p, x) + coo_mm(*e2p, z)
+    out = lrp_contract(out, params["weight"], seq_len)
+    if params.get("bias") is not None:
+        out = out + params["bias"]
+    out = coo_mm(*pool, act(out))
+    deg = in_deg.to(x.dtype).unsqueeze(1)
+    factor = F.linear(act(F.linear(deg, params["degnet_0.weight"], params["degnet_0.bias"])), params["degnet_1.weight"],
+                      params["degnet_1.bias"])
+    out = act(out * factor)
+    if "mlp.weight" in params:
+        out = act(F.linear(out, params["mlp.weight"], params["mlp.bias"]))
+    return out, z
+
+
+def dmplrp_layer(params, src, dst, rev, out_deg, pool, n2p, e2p, x, z, act_func="relu", seq_len=4, num_mlp_layers=2):
+    """``DMPLRPPoolLayer.forward`` (models/dmplrp.py:180-196): one DMPLayer, then its node and edge outputs through the
+    permutation slots, the slot contraction (+ lrp_bias) and the pooling -- without the activation / degree net of LRPLayer."""
+    node_out, edge_out, _, _ = dmp_layer(params, src, dst, rev, out_deg, x, z, act_func, num_mlp_layers)
+    out = coo_mm(*n2p, node_out) + coo_mm(*e2p, edge_out)
+    out = lrp_contract(out, params["lrp_weight"], seq_len)
+    if params.get("lrp_bias") is not None:
+        out = out + params["lrp_bias"]
+    return coo_mm(*pool, out), edge_out

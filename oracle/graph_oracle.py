@@ -172,3 +172,62 @@ def dual_subisomorphisms(p_u, p_v, p_el, g_u, g_v, g_el, sub):
                 if g_u[idx] == mu and g_v[idx] == mv and int(g_el[idx]) in labels:
                     out[r, k] = idx
     return out
+
+
+# ----------------------------------------------------------------------------- UNC samplers (utils.py:279-349)
+def rng_hash(seed, a, b):
+    """The counter-based generator of csrc/dmp_graph.hip (``rng_hash``): a 32-bit mix of (seed, a, b), vectorised."""
+    m = np.uint64(0xFFFFFFFF)
+    seed, a, b = (np.asarray(v, dtype=np.uint64) & m for v in (seed, a, b))
+    t = (b * np.uint64(0x85EBCA77)) & m
+    x = seed ^ ((a * np.uint64(0x9E3779B1)) & m) ^ (((t << np.uint64(15)) | (t >> np.uint64(17))) & m)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & m
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def fold_seed(seed):
+    seed = int(seed) & (2 ** 64 - 1)
+    return (seed ^ (seed >> 32)) & 0xFFFFFFFF
+
+
+def random_walks(src, dst, n, seeds, walks, depth, seed):
+    """``dgl.sampling.random_walk`` semantics (uniform out-edge per step, -1 after a node without out-edges) with the
+    product's generator: walk t takes, at step k, the out-edge number (hash(seed, t, k) * out_degree) >> 32 of the
+    current node's out-edges in ascending edge id.  Returns traces [len(seeds) * walks, depth + 1]."""
+    src, dst = _i64(src), _i64(dst)
+    out = [[] for _ in range(n)]
+    for e in range(len(src)):
+        out[src[e]].append(e)
+    s32 = fold_seed(seed)
+    traces = np.full((len(seeds) * walks, depth + 1), -1, np.int64)
+    for t in range(len(seeds) * walks):
+        cur = int(seeds[t // walks])
+        traces[t, 0] = cur
+        for k in range(1, depth + 1):
+            if cur < 0 or not out[cur]:
+                cur = -1
+            else:
+                h = int(rng_hash(s32, t, k))
+                cur = int(dst[out[cur][(h * len(out[cur])) >> 32]])
+            traces[t, k] = cur
+    return traces
+
+
+def sample_in_edges(dst, n, wanted, width, seed):
+    """``dgl.sampling.sample_neighbors(edge_dir="in")`` semantics (all in-edges of a wanted node if it has at most
+    ``width``, else ``width`` of them uniformly without replacement) with the product's keys: the ``width`` smallest
+    (hash(seed, edge id, 0), edge id).  Returns a bool mask over the edges."""
+    dst = _i64(dst)
+    s32 = fold_seed(seed)
+    mask = np.zeros(len(dst), bool)
+    keys = rng_hash(s32, np.arange(len(dst)), 0)
+    for v in range(n):
+        if not wanted[v]:
+            continue
+        es = np.nonzero(dst == v)[0]
+        if len(es) > width:
+            es = sorted(es, key=lambda e: (int(keys[e]), int(e)))[:width]
+        mask[es] = True
+    return mask

@@ -1075,6 +1075,120 @@ def gen_default_model():
         print("wrote fullmodel_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
 
 
+def gen_lrp():
+    """(f)3: ``LRPLayer`` (models/lrp.py:18-104) and ``DMPLRPPoolLayer`` (models/dmplrp.py:20-213) forward / backward with the
+    permutation matrices the reference's own ``LRPDataset`` builds (dataset.py:1751-1862: ego-net neighbour permutations of
+    length <= lrp_seq_len, node / edge -> permutation-slot selection matrices, mean pooling over a node's permutations),
+    and the full ``LRP(**config)`` / ``DMPLRP(**config)`` models (8-argument forward, lrp.py:222-390)."""
+    import dgl
+    import dataset as ref_dataset
+    from models.dmplrp import DMPLRP, DMPLRPPoolLayer
+    from models.lrp import LRP, LRPLayer
+    rng = np.random.default_rng(808)
+
+    def make(sizes, n_vl, n_el, max_ne):
+        gs = []
+        for n, m in sizes:
+            u, v = er_edges(n, m, rng)
+            uu, vv, rev = with_rev(u, v)
+            g = dgl.DGLGraph.from_edges(uu, vv, n)
+            el = rng.integers(0, n_el, size=m)
+            g.ndata["id"], g.ndata["label"] = th.arange(n), th.from_numpy(rng.integers(0, n_vl, size=n))
+            g.edata["id"] = th.cat([th.arange(m), th.arange(m) + max_ne])
+            g.edata["label"] = th.from_numpy(np.concatenate([el, el + n_el]))
+            g.edata["is_reversed"] = th.from_numpy(rev)
+            g.ndata["in_deg"], g.ndata["out_deg"] = g.in_degrees(), g.out_degrees()
+            gs.append(g)
+        return gs
+
+    def perm_inputs(gs):
+        ego = [ref_dataset.LRPDataset.graph_to_egonet_seq(g) for g in gs]
+        split = np.asarray([len(node) for seq in ego for node in seq], dtype=np.int64)
+        pool = ref_dataset.LRPDataset.build_perm_pooling_matrix(split, "mean")
+        n2p, e2p = ref_dataset.LRPDataset.build_batch_graph_to_perm_matrices(gs, ego)
+        return pool, n2p, e2p
+
+    def coo(d, key, m):
+        m = m.coalesce()
+        d[key + ".indices"], d[key + ".values"], d[key + ".shape"] = m.indices(), m.values(), np.array(m.shape)
+
+    def graph_fields(d, t, g):
+        d.update({t + "_src": g._u, t + "_dst": g._v, t + "_num_nodes": g.number_of_nodes(), t + "_bnn": g.batch_num_nodes(),
+                  t + "_bne": g.batch_num_edges()})
+        for k in ("id", "label", "in_deg", "out_deg"):
+            d["%s_ndata.%s" % (t, k)] = g.ndata[k]
+        for k in ("id", "label", "is_reversed"):
+            d["%s_edata.%s" % (t, k)] = g.edata[k]
+
+    sizes = [(5, 8), (7, 14), (4, 4), (6, 9)]
+    for tag, cls, kw in (("lrp_relu", LRPLayer, dict(input_dim=8, hidden_dim=8, lrp_seq_len=4, act_func="relu", batch_norm=False, mlp=False)),
+                         ("lrp_leaky_mlp", LRPLayer, dict(input_dim=12, hidden_dim=12, lrp_seq_len=4, act_func="leaky_relu", batch_norm=False, mlp=True)),
+                         ("dmplrp_relu", DMPLRPPoolLayer, dict(input_dim=8, hidden_dim=8, lrp_seq_len=4, num_mlp_layers=2, batch_norm=False, act_func="relu")),
+                         ("dmplrp_leaky", DMPLRPPoolLayer, dict(input_dim=16, hidden_dim=16, lrp_seq_len=4, num_mlp_layers=2, batch_norm=False,
+                                                                act_func="leaky_relu", init_neigenv=6.0, init_eeigenv=5.0))):
+        gs = make(sizes, 3, 2, 20)
+        pool, n2p, e2p = perm_inputs(gs)
+        g = dgl.batch(gs)
+        th.manual_seed(seed_of("lrp", tag))
+        layer = cls(**kw)
+        with th.no_grad():
+            for k, p in layer.named_parameters():
+                if k.endswith("bias"):
+                    p.uniform_(-0.1, 0.1)
+        h = kw["input_dim"]
+        x = th.randn(g.number_of_nodes(), h, requires_grad=True)
+        z = th.randn(g.number_of_edges(), h, requires_grad=True)
+        out = layer(g, x, z, pool, n2p, e2p)
+        node_out, edge_out = out[0], out[1]
+        wn, we = th.randn_like(node_out), th.randn_like(edge_out)
+        ((node_out * wn).sum() + (edge_out * we).sum()).backward()
+        d = {"x": x, "z": z, "node_out": node_out, "edge_out": edge_out, "wn": wn, "we": we, "dx": x.grad, "dz": z.grad,
+             "kw_keys": np.array(sorted(kw)), "kw_vals": np.array([repr(kw[k]) for k in sorted(kw)])}
+        graph_fields(d, "g", g)
+        coo(d, "pool", pool); coo(d, "n2p", n2p); coo(d, "e2p", e2p)
+        for k, p in layer.named_parameters():
+            d["p." + k] = p
+            if p.grad is not None:
+                d["g." + k] = p.grad
+        np.savez_compressed(os.path.join(OUT, "lrp_layer_%s.npz" % tag), **t2n(d))
+        print("wrote lrp_layer_%s.npz" % tag, "perm rows", n2p.shape[0])
+
+    p_sizes, g_sizes = [(3, 3), (4, 5), (2, 1), (4, 6)], [(6, 12), (8, 20), (5, 8), (7, 16)]
+    for tag, cls in (("lrp", LRP), ("dmplrp", DMPLRP)):
+        rng2 = np.random.default_rng(99)
+        th.manual_seed(seed_of("lrp-model", tag))
+        ps, gs = make(p_sizes, 3, 2, 20), make(g_sizes, 4, 3, 20)
+        config = dict(max_ngv=8, max_ngvl=4, max_nge=40, max_ngel=6, max_npv=4, max_npvl=4, max_npe=40, max_npel=6, base=2, hid_dim=8,
+                      share_emb_net=True, share_enc_net=True, share_rep_net=True, rep_residual=True, enc_net="Multihot",
+                      emb_net="Orthogonal", filter_net="ScalarFilter", rep_num_graph_layers=2, rep_num_pattern_layers=2,
+                      rep_act_func="relu", rep_dropout=0.0, lrp_seq_len=4, rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False,
+                      init_neigenv=5.0, init_eeigenv=4.0, pred_net="SumPredictNet", pred_hid_dim=8, pred_act_func="relu",
+                      pred_dropout=0.0, node_pred=True, edge_pred=True, rep_net=tag.upper())
+        model = cls(**config)
+        with th.no_grad():
+            for head in model.pred_net.values():
+                head.pred_fc2.weight.uniform_(-0.3, 0.3); head.pred_fc2.bias.uniform_(-0.1, 0.1)
+        pp, pn, pe = perm_inputs(ps)
+        gp, gn, ge = perm_inputs(gs)
+        pattern, graph = dgl.batch(ps), dgl.batch(gs)
+        d = {"config_keys": np.array(sorted(config.keys())), "config_vals": np.array([repr(config[k]) for k in sorted(config.keys())])}
+        for k, v in model.state_dict().items():
+            d["sd." + k] = v.clone()
+        out = model(pattern, pp, pn, pe, graph, gp, gn, ge)
+        out["pred_c"].sum().backward()
+        graph_fields(d, "p", pattern); graph_fields(d, "g", graph)
+        for key, m in (("p_pool", pp), ("p_n2p", pn), ("p_e2p", pe), ("g_pool", gp), ("g_n2p", gn), ("g_e2p", ge)):
+            coo(d, key, m)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                d["grad." + k] = p.grad
+        for k, v in out.items():
+            if v is not None:
+                d["out." + k] = v
+        np.savez_compressed(os.path.join(OUT, "lrp_model_%s.npz" % tag), **t2n(d))
+        print("wrote lrp_model_%s.npz" % tag, "pred_c[:3] =", out["pred_c"].view(-1)[:3].tolist())
+
+
 def gen_schedules():
     """Tables of the reference's step-dependent quantities: ``anneal_fn`` / ``cyclical_fn`` (utils/anneal.py, utils/cyclical.py,
     as train.py:499-600 calls them: num_init_steps = 0) and every ``lr_lambda`` of utils/scheduler.py."""
@@ -1146,7 +1260,7 @@ def gen_dual_subiso():
 
 
 GENERATORS = ["dmplayer", "dmpnn_rep", "compgcn", "linegraph", "addrev", "full_model", "unc", "subiso_weights", "expand", "rgnn",
-              "preprocess", "init", "default_model", "train_run", "dual_subiso", "schedules"]
+              "preprocess", "init", "default_model", "train_run", "dual_subiso", "schedules", "lrp"]
 
 
 def main():

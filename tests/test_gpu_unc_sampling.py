@@ -86,3 +86,65 @@ def test_subgraph_sampling_and_batch_construction(gpu):
     assert th.equal(nid[samples[:32, 0]], edges[:, 0]) and th.equal(nid[samples[:32, 2]], edges[:, 2])
     assert int(samples[:, [0, 2]].min()) >= 0 and int(samples[:, [0, 2]].max()) < sub.number_of_nodes()
     assert sub.edata["norm"].shape == (sub.number_of_edges(), 1)
+
+
+def test_random_walk_and_in_edge_sampling_kernels_match_oracle(gpu):
+    """dmp_random_walks / dmp_sample_in_edges (utils.py:279-313: DGL's random_walk + sample_neighbors there) against
+    the oracle restatement with the same counter-based generator: every trace entry and every mask bit exact; plus the
+    walk / sampling properties themselves."""
+    import graph_oracle as GO
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd import unc_sampling as S
+    rng = np.random.default_rng(8)
+    n, e = 60, 400
+    src = rng.integers(0, n - 5, e).astype(np.int64)          # the last 5 nodes have no out-edges: walks end there
+    dst = rng.integers(0, n, e).astype(np.int64)
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    seeds = np.array([0, 3, 3, 59, 17, 58], np.int64)
+    for seed in (1, 2 ** 40 + 12345):
+        traces, visited = S.random_walks(g, th.from_numpy(seeds).to(gpu), walks=7, depth=4, seed=seed)
+        ref = GO.random_walks(src, dst, n, seeds, 7, 4, seed)
+        assert np.array_equal(traces.cpu().numpy(), ref)
+        assert np.array_equal(visited.cpu().numpy(), np.isin(np.arange(n), ref[ref >= 0]))
+        # every step follows an existing edge; a dead end stays -1
+        edges = set(zip(src.tolist(), dst.tolist()))
+        for row in ref:
+            for a, b in zip(row[:-1], row[1:]):
+                assert (a, b) in edges or b == -1
+                assert a != -1 or b == -1
+        wanted = rng.random(n) < 0.6
+        for width in (1, 5, 64):
+            mask = S.sample_in_edges_device(g, th.from_numpy(wanted).to(gpu), width, seed=seed)
+            want = GO.sample_in_edges(dst, n, wanted, width, seed)
+            assert np.array_equal(mask.cpu().numpy(), want)
+            kept = np.bincount(dst[want], minlength=n)
+            indeg = np.bincount(dst, minlength=n)
+            assert np.array_equal(kept, np.where(wanted, np.minimum(indeg, width), 0))
+    assert not np.array_equal(GO.random_walks(src, dst, n, seeds, 7, 4, 1), GO.random_walks(src, dst, n, seeds, 7, 4, 2))
+
+
+def test_randomwalk_subgraph_sampler(gpu):
+    """sample_subgraph_by_randomwalks (utils.py:279-313): the subgraph's nodes are the seeds plus endpoints of sampled
+    edges, ids compacted in ascending parent order, every kept edge is an in-edge of a walked node, frames copied."""
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd import unc_sampling as S
+    rng = np.random.default_rng(5)
+    n, e = 300, 2500
+    src, dst = rng.integers(0, n, e).astype(np.int64), rng.integers(0, n, e).astype(np.int64)
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    g.edata["type"] = th.arange(e, device=gpu) % 3
+    seeds = th.tensor([1, 50, 299], device=gpu)
+    sub, nid = S.sample_subgraph_by_randomwalks(g, seeds, depth=2, width=4, seed=77)
+    again, nid2 = S.sample_subgraph_by_randomwalks(g, seeds, depth=2, width=4, seed=77)
+    assert th.equal(nid, nid2) and th.equal(sub.edata["_ID"], again.edata["_ID"])        # reproducible from the seed
+    nid_h, eid_h = nid.cpu().numpy(), sub.edata["_ID"].cpu().numpy()
+    assert np.all(np.diff(nid_h) > 0) and set([1, 50, 299]) <= set(nid_h.tolist())
+    u, v = sub.all_edges()
+    assert np.array_equal(nid_h[u.cpu().numpy()], src[eid_h]) and np.array_equal(nid_h[v.cpu().numpy()], dst[eid_h])
+    assert th.equal(sub.edata["type"], g.edata["type"][sub.edata["_ID"]])
+    assert np.bincount(dst[eid_h], minlength=n).max() <= 4
+    used = np.zeros(n, bool); used[src[eid_h]] = True; used[dst[eid_h]] = True; used[[1, 50, 299]] = True
+    assert np.array_equal(np.nonzero(used)[0], nid_h)
+    out = S.generate_sampled_graph_and_labels_unsupervised(g, th.tensor([[1, 0, 50], [299, 2, 7]], device=gpu), 2, 4, 0.8, 2,
+                                                           generator=th.Generator().manual_seed(3), sampler="randomwalk")
+    assert out[1].shape == (6, 3) and out[2].tolist() == [1, 1, 0, 0, 0, 0] and "norm" in out[0].edata
