@@ -242,24 +242,24 @@ def _memo(key, build):
     return val
 
 
-def _pool_index(graph, kind):
+def _pool_index(graph, kind, skip_reversed=True):
     if kind == "node":
         sizes, flag = graph.batch_num_nodes(), None
     else:
-        sizes, flag = graph.batch_num_edges(), graph.edata.get(REVFLAG)
+        sizes, flag = graph.batch_num_edges(), (graph.edata.get(REVFLAG) if skip_reversed else None)
     # the cached object keeps its source tensors alive, so a data_ptr cannot be recycled under it
     rows = graph.number_of_nodes() if kind == "node" else graph.number_of_edges()      # host ints: no sync in the build
     return _memo(("pool", _tensor_key(sizes), _tensor_key(flag)),
                  lambda: _Keep(ops.PoolIndex(sizes, flag, num_rows=rows), sizes, flag)).obj
 
 
-def _pool_index_union(pattern, graph, kind):
+def _pool_index_union(pattern, graph, kind, skip_reversed=True):
     """PoolIndex over [pattern graphs | target graphs] (2B segments) of the union row order."""
     if kind == "node":
         a, b, fa, fb = pattern.batch_num_nodes(), graph.batch_num_nodes(), None, None
     else:
         a, b = pattern.batch_num_edges(), graph.batch_num_edges()
-        fa, fb = pattern.edata.get(REVFLAG), graph.edata.get(REVFLAG)
+        fa, fb = (pattern.edata.get(REVFLAG), graph.edata.get(REVFLAG)) if skip_reversed else (None, None)
 
     rows = (pattern.number_of_nodes() + graph.number_of_nodes() if kind == "node"
             else pattern.number_of_edges() + graph.number_of_edges())                     # host ints: no sync in the build
@@ -515,6 +515,10 @@ class GraphAdjModel(BaseModel):
 class GraphAdjModelV2(BaseModel):
     """basemodel.py:965-1663."""
 
+    # GraphAdjModelV2.forward takes the reversed edges out of the edge head's masks (basemodel.py:1521-1531); the LRP /
+    # DMPLRP forwards (lrp.py:222-390, dmplrp.py:332-470) are copies of it WITHOUT that step
+    edge_head_skips_reversed = True
+
     def __init__(self, **kw):
         self.add_node_id = kw.get("add_node_id", kw.get("gnn_add_node_id", False))
         self.add_edge_id = kw.get("add_edge_id", kw.get("gnn_add_edge_id", False))
@@ -730,9 +734,10 @@ class GraphAdjModelV2(BaseModel):
         pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"),
                 "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
         # reversed edges do not take part in the edge head (basemodel.py:1521-1531)
+        skip_rev = self.edge_head_skips_reversed
         (p_v_mask, p_v_cnt), (p_e_mask, p_e_cnt), (g_v_mask, g_v_cnt), (g_e_mask, g_e_cnt) = len_masks(
-            [(pads["pv"], None), (pads["pe"], pattern.edata.get(REVFLAG)),
-             (pads["gv"], None), (pads["ge"], graph.edata.get(REVFLAG))])
+            [(pads["pv"], None), (pads["pe"], pattern.edata.get(REVFLAG) if skip_rev else None),
+             (pads["gv"], None), (pads["ge"], graph.edata.get(REVFLAG) if skip_rev else None)])
         counts = {"pv": p_v_cnt, "pe": p_e_cnt, "gv": g_v_cnt, "ge": g_e_cnt}
         vl_gate, el_gate = self.get_filter_gate(pattern, graph, pads)
         if vl_gate is not None:  # bool gate * float features == float gate * float features
@@ -801,12 +806,12 @@ class GraphAdjModelV2(BaseModel):
             p_e_mask = self.refine_edge_weights(p_e_mask)
             g_e_mask = self.refine_edge_weights(g_e_mask)
             if pooled and e_union is not None and not p_add:
-                sums = e_sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge"))[:, :e_union.size(1)]
+                sums = e_sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge", skip_rev))[:, :e_union.size(1)]
                 p_e_output, g_e_output = sums[:bsz], sums[bsz:]
             elif pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
                 d = p_e_output.size(1)
-                p_e_output = ops.seg_pool(p_e_output, _pool_index(pattern, "edge"))[:, :d]
-                g_e_output = ops.seg_pool(g_e_output, _pool_index(graph, "edge"))[:, :d]
+                p_e_output = ops.seg_pool(p_e_output, _pool_index(pattern, "edge", skip_rev))[:, :d]
+                g_e_output = ops.seg_pool(g_e_output, _pool_index(graph, "edge", skip_rev))[:, :d]
             else:
                 p_e_output = pads["pe"].pad(p_e_output).masked_fill(~p_e_mask, 0)
                 g_e_output = pads["ge"].pad(g_e_output).masked_fill(~g_e_mask, 0)

@@ -290,6 +290,8 @@ class _PermModel(_PermRepMixin, GraphAdjModelV2):
     """The 8-argument forward of lrp.py:222-390 / dmplrp.py:332-470 on the common skeleton: the permutation inputs ride
     along on the graph objects while ``GraphAdjModelV2.forward`` runs."""
 
+    edge_head_skips_reversed = False      # lrp.py:240-243 / dmplrp.py:350-353: plain length masks
+
     def forward(self, pattern, p_perm_pool, p_n_perm_matrix, p_e_perm_matrix, graph, g_perm_pool=None, g_n_perm_matrix=None,
                 g_e_perm_matrix=None):
         pattern, graph = as_batched(pattern), as_batched(graph)

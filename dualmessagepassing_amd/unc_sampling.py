@@ -24,7 +24,8 @@ def _seed_of(generator, seed):
     """The 64-bit seed of a kernel launch: given, or the next draw of ``generator`` / torch's global generator."""
     if seed is not None:
         return int(seed) & (2 ** 64 - 1)
-    return int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+    dev = generator.device if generator is not None else "cpu"
+    return int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=dev).item())
 
 
 def random_walks(graph, seed_nodes, walks, depth, seed=None, generator=None, return_traces=True):

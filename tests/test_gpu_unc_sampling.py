@@ -146,5 +146,5 @@ def test_randomwalk_subgraph_sampler(gpu):
     used = np.zeros(n, bool); used[src[eid_h]] = True; used[dst[eid_h]] = True; used[[1, 50, 299]] = True
     assert np.array_equal(np.nonzero(used)[0], nid_h)
     out = S.generate_sampled_graph_and_labels_unsupervised(g, th.tensor([[1, 0, 50], [299, 2, 7]], device=gpu), 2, 4, 0.8, 2,
-                                                           generator=th.Generator().manual_seed(3), sampler="randomwalk")
+                                                           generator=th.Generator(device=gpu).manual_seed(3), sampler="randomwalk")
     assert out[1].shape == (6, 3) and out[2].tolist() == [1, 1, 0, 0, 0, 0] and "norm" in out[0].edata
