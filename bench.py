@@ -224,13 +224,13 @@ def build_step(cfg, shard, device, world=1):
 
 def pmc_traffic(n_rows, n_edges, H):
     """HBM bytes per launch of the scatter-add kernel from the committed rocprofv3 PMC run
-    (profiles/r01_pmc_seg_sum2.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    (profiles/r02_pmc_seg_sum2.json, entry in_csr: FETCH_SIZE and WRITE_SIZE collected in separate passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950).
     Returned only if that run was taken at this launch shape; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_seg_sum2.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_seg_sum2.json")
     try:
         with open(path) as f:
-            d = json.load(f)
+            d = json.load(f)["in_csr"]
         if d.get("rows") == n_rows and d.get("edges") == n_edges and d.get("H") == H:
             return d["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
@@ -421,7 +421,8 @@ def main():
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world, "micro_batches": step.micro_batches,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
-                       "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default"},
+                       "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default",
+                       "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32
             # v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak): their MFMA-roofline fractions, for context

@@ -1,5 +1,7 @@
-"""Launch ONLY the scatter-add kernel (dmp_seg_sum2 over the in-CSR) at bench.py's launch shape
-(union of the config-2 pattern and target batches) for rocprofv3 PMC / kernel-trace passes."""
+"""Launch ONLY the scatter-add kernel (dmp_seg_sum2) at bench.py's launch shape (union of the config-2 pattern and
+target batches) for rocprofv3 PMC / kernel-trace passes: ``python prof_seg_sum2.py [reps] [in|inc]`` -- ``in``: over
+the CSR by destination (the layer's node aggregation, forward), ``inc``: over the incidence CSR (backward of the
+gathered node projections: every edge row belongs to two nodes)."""
 import os
 import sys
 
@@ -24,7 +26,13 @@ n, e, h = pn + gn, len(src), 128
 ix = GraphIndex(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n, torch.from_numpy(rev).to(dev))
 zs = [torch.randn(e, h, device=dev) for _ in range(4)]
 torch.cuda.synchronize()
-for i in range(reps):
-    s = ops.seg_sum_raw(zs[i % 4], ix.in_ptr, ix.in_ent, n, None, True, -1.0, 1.0)
+kind = sys.argv[2] if len(sys.argv) > 2 else "in"
+inc_ptr, inc_ent = ix.incidence()
 torch.cuda.synchronize()
-print("rows", n, "edges", e, "H", h)
+for i in range(reps):
+    if kind == "in":
+        s = ops.seg_sum_raw(zs[i % 4], ix.in_ptr, ix.in_ent, n, None, True, -1.0, 1.0)
+    else:
+        s = ops.seg_sum_raw(zs[i % 4], inc_ptr, inc_ent, n, None, True, 1.0, -1.0, rows_shared=True)
+torch.cuda.synchronize()
+print("rows", n, "edges", e, "H", h, "kind", kind)
