@@ -49,6 +49,8 @@ def collate_device(local_src, local_dst, num_nodes, num_edges, total_nodes, tota
     g.node_offsets, g.edge_offsets = node_off, edge_off
     g.max_num_nodes = None if max_nodes is None else int(max_nodes)
     g.max_num_edges = None if max_edges is None else int(max_edges)
+    from . import ops
+    g.tiling = ops.graph_tiling(node_off, edge_off, B, g.max_num_edges)
     return g
 
 
@@ -256,8 +258,20 @@ def union_graphs(a, b):
         if k in a.ndata and k in b.ndata:
             extra.append(("n", k))
             pairs.append((a.ndata[k], b.ndata[k], 0))
+    # per-graph offsets of the union (pattern graphs, then target graphs) when both sides carry theirs: the tiled
+    # scatter-add of the layer's backward walks whole graphs (ops.graph_tiling)
+    offs = all(getattr(x, "node_offsets", None) is not None and getattr(x, "max_num_edges", None) is not None for x in (a, b))
+    if offs:
+        pairs.append((a.node_offsets[:-1], b.node_offsets, na))
+        pairs.append((a.edge_offsets[:-1], b.edge_offsets, a.number_of_edges()))
     out = concat_pairs(pairs)                                # all structure arrays of the union in one launch
     g = BatchedGraph(out[0], out[1], na + b.number_of_nodes(), out[2], out[3])
-    for (where, k), t in zip(extra, out[4:]):
+    for (where, k), t in zip(extra, out[4:4 + len(extra)]):
         (g.edata if where == "e" else g.ndata)[k] = t
+    if offs:
+        from . import ops
+        g.node_offsets, g.edge_offsets = out[-2], out[-1]
+        g.max_num_nodes = max(a.max_num_nodes or 0, b.max_num_nodes or 0) or None
+        g.max_num_edges = max(a.max_num_edges, b.max_num_edges)
+        g.tiling = ops.graph_tiling(g.node_offsets, g.edge_offsets, a.batch_size, a.max_num_edges, b.batch_size, b.max_num_edges)
     return g

@@ -115,6 +115,59 @@ __global__ __launch_bounds__(kBlock) void seg_sum_vec(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split segment sum for block-diagonal batches whose CSR rows SHARE source rows -- the incidence CSR of the layer's
+// backward: every edge row is summed into both of its endpoints' rows.  The plain kernel reads the row twice and the
+// second read misses L2 for a third of the rows (PMC: 1.29 x the algorithmic bytes, profiles/r02_pmc_seg_sum2.json).
+// Here a workgroup owns a TILE -- a few whole graphs: their node rows and ALL the edge rows those nodes refer to, at
+// most kTileRows of them -- and one slice of kTileCols columns: it stages the slice of the tile's edge rows in LDS once
+// (one 128-byte line per row) and feeds every node sum from there, in CSR order (same summation order, same bits as
+// seg_sum_vec).  Rows in LDS are padded to 36 floats so that the 8 row groups of a wave read disjoint banks.
+// Tiles: graphs [0, Ba) in groups of ka, then graphs [Ba, Ba + Bb) in groups of kb (the pattern and the target graphs
+// of a union pass); node_off / edge_off: first node / edge row of every graph (+ the totals).
+// ---------------------------------------------------------------------------
+constexpr int kTileRows = 512, kTileCols = 32, kTilePad = 36;
+struct TileSpec { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, kb; };
+
+__global__ __launch_bounds__(kBlock, 2) void seg_sum_tiled(
+    const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ent,
+    const TileSpec ts, int H, float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  __shared__ float rows[kTileRows * kTilePad];
+  const int c0 = (int)blockIdx.x * kTileCols;                 // the slice is the fastest grid index: the four slices of a
+  const int64_t tile = blockIdx.y;                             // tile run side by side and share the rows' DRAM pages
+  const int64_t tiles_a = (ts.Ba + ts.ka - 1) / ts.ka;
+  int64_t g0, g1;
+  if (tile < tiles_a) { g0 = tile * ts.ka; g1 = g0 + ts.ka < ts.Ba ? g0 + ts.ka : ts.Ba; }
+  else { g0 = ts.Ba + (tile - tiles_a) * ts.kb; g1 = g0 + ts.kb < ts.Ba + ts.Bb ? g0 + ts.kb : ts.Ba + ts.Bb; }
+  const int64_t n0 = ts.node_off[g0], n1 = ts.node_off[g1], e0 = ts.edge_off[g0];
+  const int R = (int)(ts.edge_off[g1] - e0);
+  for (int i = threadIdx.x; i < R * 8; i += kBlock) {
+    const int r = i >> 3, q = i & 7;
+    *reinterpret_cast<float4 *>(&rows[r * kTilePad + q * 4]) = ld4(M + (e0 + r) * ldm + c0 + q * 4);
+  }
+  __syncthreads();
+  const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
+  for (int64_t row = n0 + grp; row < n1; row += kBlock / 8) {
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    float4 a0 = zero4(), a1 = zero4();
+    for (int base = beg; base < end; base += 8) {
+      const int cnt = min(8, end - base);
+      const int my = lane < cnt ? ent[base + lane] : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < cnt) {
+          const int e = __shfl(my, j, 8);
+          const float4 v = *reinterpret_cast<const float4 *>(&rows[((e >> 1) - (int)e0) * kTilePad + lane * 4]);
+          if (e & 1) add4(a1, v); else add4(a0, v);
+        }
+      }
+    }
+    float *o = out + row * ldo + c0 + lane * 4;
+    st4(o, mul4(a0, s0));
+    st4(o + H, mul4(a1, s1));
+  }
+}
+
 // Any H / any alignment: one wave per row, scalar column-strided accesses.
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock) void seg_sum_scalar(
@@ -577,6 +630,22 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr, const int32
                  const float *edge_w, int64_t num_nodes, int H, float s0, float s1, float *out,
                  int64_t ldo, int rows_shared, void *stream) {
   return seg_sum_impl(M, ldm, rowptr, ent, edge_w, num_nodes, H, true, s0, s1, out, ldo, rows_shared, stream);
+}
+
+int dmp_seg_sum2_tiled(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int64_t *node_off,
+                       const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
+                       float *out, int64_t ldo, void *stream) {
+  if (Ba < 0 || Bb < 0 || H <= 0 || ldm < H || ldo < 2 * H || (Ba > 0 && ka < 1) || (Bb > 0 && kb < 1)) return DMP_ERR_BAD_ARG;
+  if (Ba + Bb == 0) return DMP_OK;
+  if (!M || !rowptr || !ent || !node_off || !edge_off || !out) return DMP_ERR_BAD_ARG;
+  if (H % kTileCols || ldm % 4 || ldo % 4 || !aligned16(M) || !aligned16(out)) return DMP_ERR_UNSUPPORTED;
+  const int64_t tiles = (Ba > 0 ? (Ba + ka - 1) / ka : 0) + (Bb > 0 ? (Bb + kb - 1) / kb : 0);
+  if (tiles > 65535 * (int64_t)32768) return DMP_ERR_UNSUPPORTED;
+  TileSpec ts{node_off, edge_off, Ba, Bb, ka > 0 ? ka : 1, kb > 0 ? kb : 1};
+  dim3 grid((unsigned)(H / kTileCols), (unsigned)tiles);
+  if (tiles > 65535) return DMP_ERR_UNSUPPORTED;               // grid.y limit: larger batches take the plain kernel
+  seg_sum_tiled<<<grid, kBlock, 0, (hipStream_t)stream>>>(M, ldm, rowptr, ent, ts, H, s0, s1, out, ldo);
+  return check_launch();
 }
 
 int dmp_gather_rows(const float *X, int64_t ldx, const int32_t *idx, const float *edge_w,

@@ -78,6 +78,7 @@ class GraphIndex:
                                      ptr(status), ptr(ws), stream_ptr()), "dmp_csr_build_pair")
         self._inc = None
         self._coef = {}
+        self.tiling = None
         if validate and int(status.sum().item()) != 0:
             raise _lib.DmpError("edge endpoint outside [0, num_nodes)")
 
@@ -254,6 +255,7 @@ class BatchedGraph:
         self._index_key = None
         self.node_graph = None  # int32 [N] owning graph of each node (set by collate)
         self.edge_graph = None
+        self.tiling = None      # ops.graph_tiling(...) of a block-diagonal batch (set by collate / union_graphs)
 
     # ---- DGLGraph-in: any graph object with the surface the reference's models touch
     @classmethod
@@ -351,6 +353,7 @@ class BatchedGraph:
         if self._index is None or self._index_key != key:
             self._index = GraphIndex(self._src, self._dst, self._n, rev, validate=validate)
             self._index_key = key
+        self._index.tiling = getattr(self, "tiling", None)
         return self._index
 
     def in_degrees(self):

@@ -40,8 +40,26 @@ def _vec(t, dtype):
 
 
 # ----------------------------------------------------------------------------- raw launches
-def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None):
-    """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride)."""
+TILE_MAX_ROWS = 512     # kTileRows of csrc/dmp_agg.hip::seg_sum_tiled
+USE_TILED_SEG_SUM = True
+
+
+def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
+    """Tiling of a block-diagonal batch for ``dmp_seg_sum2_tiled``: ``(node_off, edge_off, Ba, Bb, ka, kb)`` with ka / kb
+    whole graphs per tile such that no tile exceeds TILE_MAX_ROWS edge rows, or None when a graph alone is larger (or the
+    per-graph maxima are unknown): the plain kernel then."""
+    if max_edges_a is None or (Bb and max_edges_b is None):
+        return None
+    if max(int(max_edges_a), int(max_edges_b or 0)) > TILE_MAX_ROWS:
+        return None
+    ka = max(1, TILE_MAX_ROWS // max(int(max_edges_a), 1))
+    kb = max(1, TILE_MAX_ROWS // max(int(max_edges_b or 1), 1))
+    return (node_off, edge_off, int(Ba), int(Bb), ka, kb)
+
+
+def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None, tiling=None):
+    """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride).
+    ``tiling`` (``graph_tiling``): the split sum over a CSR whose rows share source rows runs per graph tile from LDS."""
     lib = _lib.load()
     _lib.require_gpu(M, rowptr, ent, edge_w)
     M, ldm = _mat(M)
@@ -57,6 +75,15 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     # algorithmic bytes: every source row once, every output row once, the CSR arrays once
     src_rows = min(nent, M.size(0))  # incidence CSRs list every source row twice: distinct rows count once
     nbytes = 4 * H * src_rows + 4 * out.size(1) * num_nodes + 4 * nent + 4 * (num_nodes + 1) + (4 * nent if ew is not None else 0)
+    if split and tiling is not None and USE_TILED_SEG_SUM and ew is None and H % 32 == 0 and ldm % 4 == 0 and ldo % 4 == 0 \
+            and M.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and num_nodes > 0:
+        node_off, edge_off, Ba, Bb, ka, kb = tiling
+        tiles = (Ba + ka - 1) // ka + ((Bb + kb - 1) // kb if Bb else 0)
+        if tiles <= 65535:
+            with _lib.timed("seg_sum2_tiled[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
+                check(lib.dmp_seg_sum2_tiled(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb, H,
+                                             s0, s1, ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_tiled")
+            return out
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 38
+#define DMP_ABI_VERSION 39
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -319,6 +319,15 @@ int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr,
  * backward of dmp_edge_combine w.r.t. the projected node features.
  *   M [E, ldm>=H], out [N, ldo>=2H]
  */
+/* dmp_seg_sum2 for a block-diagonal batch whose CSR rows share source rows (the incidence CSR of the layer's backward,
+ * where every edge row is summed into both endpoints): the graphs are grouped into tiles -- graphs [0, Ba) in groups of
+ * ka, then [Ba, Ba + Bb) in groups of kb; node_off / edge_off [Ba + Bb + 1]: first node / edge row of every graph --
+ * and a workgroup stages a 32-column slice of its tile's edge rows in LDS once and sums every node row of the tile from
+ * there, in CSR order (the bits of dmp_seg_sum2).  Requirements (else DMP_ERR_UNSUPPORTED / wrong results): every CSR
+ * entry of a tile's node rows refers to an edge row of the same tile, no tile has more than 512 edge rows, H % 32 == 0. */
+int dmp_seg_sum2_tiled(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
+                       const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
+                       int H, float s0, float s1, float *out, int64_t ldo, void *stream);
 int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
                  const int32_t *ent, const float *edge_w, int64_t num_nodes,
                  int H, float s0, float s1, float *out, int64_t ldo,

@@ -789,3 +789,44 @@ def test_pool_index_device_build_equals_tensor_build(sizes_a, sizes_b, gpu):
         assert (got.flag8 is None) == (ref.flag8 is None) and (got.flag8 is None or th.equal(got.flag8, ref.flag8))
         x = th.randn(ra + rb, 16, generator=gen).to(gpu)
         assert th.equal(ops.seg_pool(x, got), ops.seg_pool(x, ref))
+
+
+@pytest.mark.parametrize("h", [32, 64, 128, 256])
+def test_tiled_incidence_segment_sum_equals_plain_kernel(h, gpu):
+    """dmp_seg_sum2_tiled (a workgroup stages a graph tile's edge rows in LDS once and feeds both endpoint sums from
+    there) gives the BITS of dmp_seg_sum2 over the incidence CSR (same CSR order of the adds): a union of small graphs
+    (several per tile) and 512-edge graphs (one per tile), ragged sizes, graphs without edges, into a column slice."""
+    from dualmessagepassing_amd import ops
+    from dualmessagepassing_amd.collate import collate_device, union_graphs
+    rng = np.random.default_rng(h)
+
+    def batch(sizes):
+        ls, ld, rv = [], [], []
+        for n, m in sizes:
+            u, v = (er_batch(1, n, m, rng)[:2] if m else (np.zeros(0, np.int64), np.zeros(0, np.int64)))
+            ls.append(u); ld.append(v); rv.append(np.concatenate([np.zeros(m, bool), np.ones(m, bool)]) if m else np.zeros(0, bool))
+        nn_ = np.array([s[0] for s in sizes], np.int64)
+        ne_ = np.array([2 * s[1] for s in sizes], np.int64)
+        g = collate_device(_t(np.concatenate(ls)).to(gpu), _t(np.concatenate(ld)).to(gpu), _t(nn_).to(gpu), _t(ne_).to(gpu),
+                           int(nn_.sum()), int(ne_.sum()), edata={"is_reversed": _t(np.concatenate(rv)).to(gpu)},
+                           max_nodes=int(nn_.max()), max_edges=int(ne_.max()))
+        return g
+    p = batch([(8, 12)] * 37 + [(3, 0), (5, 7)])
+    g = batch([(64, 256)] * 9 + [(40, 100), (64, 256), (2, 1)])
+    u = union_graphs(p, g)
+    assert u.tiling is not None and u.tiling[4] > 1 and u.tiling[5] == 1        # 21 pattern graphs per tile, 1 target graph
+    ix = u.index()
+    inc_ptr, inc_ent = ix.incidence()
+    N, E = u.number_of_nodes(), u.number_of_edges()
+    m = th.randn(E, h, device=gpu)
+    want = ops.seg_sum_raw(m, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True)
+    got = ops.seg_sum_raw(m, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, tiling=ix.tiling)
+    assert th.equal(got, want)
+    wide = th.full((N, 3 * h), 5.0, device=gpu)
+    ops.seg_sum_raw(m, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=wide[:, h:], tiling=ix.tiling)
+    assert th.equal(wide[:, h:], want) and bool((wide[:, :h] == 5.0).all())
+    # a single batch (no union) and the in-CSR work too; a graph above 512 edge rows switches the tiling off
+    assert th.equal(ops.seg_sum_raw(m[:g.number_of_edges()], *g.index().incidence(), g.number_of_nodes(), None, True, 1.0, -1.0,
+                                    tiling=g.index().tiling),
+                    ops.seg_sum_raw(m[:g.number_of_edges()], *g.index().incidence(), g.number_of_nodes(), None, True, 1.0, -1.0))
+    assert batch([(64, 300)]).tiling is None
