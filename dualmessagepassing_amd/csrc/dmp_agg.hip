@@ -63,6 +63,10 @@ __global__ __launch_bounds__(kBlock) void seg_sum_vec(
     float s0, float s1, float *__restrict__ out, int64_t ldo) {
   constexpr int RPB = kBlock / G;
   constexpr int U = 8;  // independent 16-B row loads in flight per lane
+#ifdef DMP_SEG_OCC_LDS
+  __shared__ float occ_pad[DMP_SEG_OCC_LDS / 4];               // development: caps the resident workgroups per CU
+  if (REMAP && SPLIT && N < 0) out[0] = occ_pad[threadIdx.x];
+#endif
   // REMAP (XCD-local rows): needed when rows are shared between destinations (incidence
   // CSR) and also faster when M was just written by the previous kernel (59 vs 70 us);
   // plain dispatch order only wins (~3 us) on a cold read-once stream (scripts/kbench.py).
@@ -126,43 +130,74 @@ __global__ __launch_bounds__(kBlock) void seg_sum_vec(
 // Tiles: graphs [0, Ba) in groups of ka, then graphs [Ba, Ba + Bb) in groups of kb (the pattern and the target graphs
 // of a union pass); node_off / edge_off: first node / edge row of every graph (+ the totals).
 // ---------------------------------------------------------------------------
-constexpr int kTileRows = 512, kTileCols = 32, kTilePad = 36;
+constexpr int kTileRows = 512, kTileCols = 32, kTilePad = 36, kTileThreads = 512;
 struct TileSpec { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, kb; };
 
-__global__ __launch_bounds__(kBlock, 2) void seg_sum_tiled(
+// One 512-thread workgroup per (tile, column slice), two resident per CU (72 KB of LDS each); the slice is the fastest
+// grid index, so the four workgroups that read the four 128-byte lines of a tile's rows run side by side (one DRAM page
+// activation per row).  A group of 8 lanes owns a node row.  Order inside a workgroup: request the slice's row pieces
+// (8 x 16 B per lane), then the CSR bounds and the first 16 entries of the group's row (in flight together), write
+// the pieces to LDS, barrier, node sums from LDS.
+__global__ __launch_bounds__(kTileThreads, 2) void seg_sum_tiled(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ent,
-    const TileSpec ts, int H, float s0, float s1, float *__restrict__ out, int64_t ldo) {
+    const TileSpec ts, int H, float s0, float s1, float *__restrict__ out, int64_t ldo, int nslice) {
   __shared__ float rows[kTileRows * kTilePad];
-  const int c0 = (int)blockIdx.x * kTileCols;                 // the slice is the fastest grid index: the four slices of a
-  const int64_t tile = blockIdx.y;                             // tile run side by side and share the rows' DRAM pages
-  const int64_t tiles_a = (ts.Ba + ts.ka - 1) / ts.ka;
+  constexpr int kPieces = kTileRows * 8 / kTileThreads, kRowStep = kTileThreads / 8;
+  const int64_t tile = blockIdx.x / nslice;
+  const int c0 = (int)(blockIdx.x % nslice) * kTileCols;
+  const int64_t tiles_a = ts.Ba > 0 ? (ts.Ba + ts.ka - 1) / ts.ka : 0;
   int64_t g0, g1;
   if (tile < tiles_a) { g0 = tile * ts.ka; g1 = g0 + ts.ka < ts.Ba ? g0 + ts.ka : ts.Ba; }
   else { g0 = ts.Ba + (tile - tiles_a) * ts.kb; g1 = g0 + ts.kb < ts.Ba + ts.Bb ? g0 + ts.kb : ts.Ba + ts.Bb; }
   const int64_t n0 = ts.node_off[g0], n1 = ts.node_off[g1], e0 = ts.edge_off[g0];
   const int R = (int)(ts.edge_off[g1] - e0);
-  for (int i = threadIdx.x; i < R * 8; i += kBlock) {
-    const int r = i >> 3, q = i & 7;
-    *reinterpret_cast<float4 *>(&rows[r * kTilePad + q * 4]) = ld4(M + (e0 + r) * ldm + c0 + q * 4);
+  const int q = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  float4 v[kPieces];
+  {
+    const float *src = M + (e0 + r0) * ldm + c0 + q * 4;
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k)
+      if (r0 + k * kRowStep < R) v[k] = ld4(src + (int64_t)k * kRowStep * ldm);
   }
+  const int64_t row0 = n0 + r0;
+  int beg0 = 0, end0 = 0, my0 = 0, my1 = 0;
+  if (row0 < n1) {
+    beg0 = rowptr[row0]; end0 = rowptr[row0 + 1];
+    if (beg0 + q < end0) my0 = ent[beg0 + q];
+    if (beg0 + 8 + q < end0) my1 = ent[beg0 + 8 + q];
+  }
+#pragma unroll
+  for (int k = 0; k < kPieces; ++k)
+    if (r0 + k * kRowStep < R) *reinterpret_cast<float4 *>(&rows[(r0 + k * kRowStep) * kTilePad + q * 4]) = v[k];
   __syncthreads();
-  const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
-  for (int64_t row = n0 + grp; row < n1; row += kBlock / 8) {
-    const int beg = rowptr[row], end = rowptr[row + 1];
+  auto add_entry = [&](int e, float4 &a0, float4 &a1) {
+    const float4 x = *reinterpret_cast<const float4 *>(&rows[((e >> 1) - (int)e0) * kTilePad + q * 4]);
+    if (e & 1) add4(a1, x); else add4(a0, x);
+  };
+  for (int64_t row = row0; row < n1; row += kRowStep) {
     float4 a0 = zero4(), a1 = zero4();
+    int beg, end;
+    if (row == row0) {
+      beg = beg0; end = end0;
+      const int c1 = min(8, end - beg), c2 = min(8, end - beg - 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < c1) add_entry(__shfl(my0, j, 8), a0, a1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < c2) add_entry(__shfl(my1, j, 8), a0, a1);
+      beg += 16;
+    } else {
+      beg = rowptr[row]; end = rowptr[row + 1];
+    }
     for (int base = beg; base < end; base += 8) {
       const int cnt = min(8, end - base);
-      const int my = lane < cnt ? ent[base + lane] : 0;
+      const int my = q < cnt ? ent[base + q] : 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < cnt) {
-          const int e = __shfl(my, j, 8);
-          const float4 v = *reinterpret_cast<const float4 *>(&rows[((e >> 1) - (int)e0) * kTilePad + lane * 4]);
-          if (e & 1) add4(a1, v); else add4(a0, v);
-        }
-      }
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) add_entry(__shfl(my, j, 8), a0, a1);
     }
-    float *o = out + row * ldo + c0 + lane * 4;
+    float *o = out + row * ldo + c0 + q * 4;
     st4(o, mul4(a0, s0));
     st4(o + H, mul4(a1, s1));
   }
@@ -640,11 +675,10 @@ int dmp_seg_sum2_tiled(const float *M, int64_t ldm, const int32_t *rowptr, const
   if (!M || !rowptr || !ent || !node_off || !edge_off || !out) return DMP_ERR_BAD_ARG;
   if (H % kTileCols || ldm % 4 || ldo % 4 || !aligned16(M) || !aligned16(out)) return DMP_ERR_UNSUPPORTED;
   const int64_t tiles = (Ba > 0 ? (Ba + ka - 1) / ka : 0) + (Bb > 0 ? (Bb + kb - 1) / kb : 0);
-  if (tiles > 65535 * (int64_t)32768) return DMP_ERR_UNSUPPORTED;
   TileSpec ts{node_off, edge_off, Ba, Bb, ka > 0 ? ka : 1, kb > 0 ? kb : 1};
-  dim3 grid((unsigned)(H / kTileCols), (unsigned)tiles);
-  if (tiles > 65535) return DMP_ERR_UNSUPPORTED;               // grid.y limit: larger batches take the plain kernel
-  seg_sum_tiled<<<grid, kBlock, 0, (hipStream_t)stream>>>(M, ldm, rowptr, ent, ts, H, s0, s1, out, ldo);
+  const int nslice = H / kTileCols;
+  if (tiles * nslice >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+  seg_sum_tiled<<<(unsigned)(tiles * nslice), kTileThreads, 0, (hipStream_t)stream>>>(M, ldm, rowptr, ent, ts, H, s0, s1, out, ldo, nslice);
   return check_launch();
 }
 

@@ -41,7 +41,10 @@ def _vec(t, dtype):
 
 # ----------------------------------------------------------------------------- raw launches
 TILE_MAX_ROWS = 512     # kTileRows of csrc/dmp_agg.hip::seg_sum_tiled
-USE_TILED_SEG_SUM = True
+# Experiment switch, off: the LDS-staged incidence scatter-add reads every edge row once (no re-reads) and gives the plain
+# kernel's bits, but measured 91.5 us against the plain kernel's 79-80 us at bench.py's shape (two 72 KB workgroups per
+# CU: the load -> barrier -> sums structure is exposed where the plain kernel keeps 32 waves per CU in flight); DESIGN.md §8.
+USE_TILED_SEG_SUM = False
 
 
 def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
@@ -78,8 +81,7 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
     if split and tiling is not None and USE_TILED_SEG_SUM and ew is None and H % 32 == 0 and ldm % 4 == 0 and ldo % 4 == 0 \
             and M.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and num_nodes > 0:
         node_off, edge_off, Ba, Bb, ka, kb = tiling
-        tiles = (Ba + ka - 1) // ka + ((Bb + kb - 1) // kb if Bb else 0)
-        if tiles <= 65535:
+        if True:
             with _lib.timed("seg_sum2_tiled[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
                 check(lib.dmp_seg_sum2_tiled(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb, H,
                                              s0, s1, ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_tiled")

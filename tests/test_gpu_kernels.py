@@ -799,7 +799,14 @@ def test_tiled_incidence_segment_sum_equals_plain_kernel(h, gpu):
     from dualmessagepassing_amd import ops
     from dualmessagepassing_amd.collate import collate_device, union_graphs
     rng = np.random.default_rng(h)
+    switch, ops.USE_TILED_SEG_SUM = ops.USE_TILED_SEG_SUM, True     # the experiment kernel (off by default: slower)
+    try:
+        _tiled_case(h, gpu, rng, ops, collate_device, union_graphs)
+    finally:
+        ops.USE_TILED_SEG_SUM = switch
 
+
+def _tiled_case(h, gpu, rng, ops, collate_device, union_graphs):
     def batch(sizes):
         ls, ld, rv = [], [], []
         for n, m in sizes:
