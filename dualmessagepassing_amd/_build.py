@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdmp_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["dmp_agg.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip", "dmp_typed.hip", "dmp_atb.hip", "dmp_fold.hip", "dmp_heads.hip"]
+SOURCES = ["dmp_agg.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip", "dmp_typed.hip", "dmp_atb.hip", "dmp_fold.hip", "dmp_heads.hip",
+           "dmp_subiso.cpp"]   # the last one: host-only C++ (exact subgraph-isomorphism counter), same C ABI
 HEADERS = ["dmp_common.h", "dmp_mfma_common.h", os.path.join("..", "..", "include", "dmp_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -65,7 +66,7 @@ def build_lib(force=False, verbose=False):
             with tempfile.TemporaryDirectory(prefix="dmp_build_") as tmp:
                 objs, procs = [], []
                 for src in SOURCES:
-                    obj = os.path.join(tmp, src.replace(".hip", ".o"))
+                    obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
                     cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
                     if verbose:
                         print(" ".join(cmd))
@@ -78,7 +79,7 @@ def build_lib(force=False, verbose=False):
                     if verbose and out:
                         print(out.decode(errors="replace"))
                 so = os.path.join(tmp, "libdmp_hip.so")
-                r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs,
+                r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", so] + objs,
                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
                 if r.returncode != 0:
                     raise RuntimeError("hipcc link failed:\n%s" % r.stdout.decode(errors="replace"))

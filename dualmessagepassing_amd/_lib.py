@@ -36,6 +36,10 @@ SIGNATURES = {
     "dmp_subiso_node_weights": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_dual_subisomorphisms": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_subiso_enumerate": (c_i64, [c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                     c_i64]),
+    "dmp_subiso_count_batch": (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                       c_ptr, c_int]),
     "dmp_random_walks": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, ctypes.c_uint64, c_ptr, c_ptr, c_ptr]),
     "dmp_sample_in_edges": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, ctypes.c_uint64, c_ptr, c_ptr]),
     "dmp_pool_index": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -118,7 +122,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 39
+ABI_VERSION = 40
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

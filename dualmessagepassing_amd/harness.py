@@ -19,12 +19,54 @@ from .collate import collate_device, subiso_weights
 from .dp import FlatGradSync
 
 
-def enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+
+
+def enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el, limit=-1):
     """All label-preserving injective maps of the pattern's nodes into the graph's nodes such that
     every pattern edge (u -> v, label l) has an image edge with the same label (non-induced
-    subgraph isomorphisms: a sample's ``subisomorphisms`` rows, whose number is its ``counts``).
-    Plain backtracking on the host; meant for the small synthetic sets of the harness.
-    Returns an int64 array [counts, pattern_nodes] in lexicographic order."""
+    subgraph isomorphisms: a sample's ``subisomorphisms`` rows, whose number is its ``counts``),
+    as an int64 array [counts, pattern_nodes] in lexicographic order.  Native depth-first search on the host
+    (``dmp_subiso_enumerate``, csrc/dmp_subiso.cpp); ``enumerate_subisomorphisms_py`` is its plain-Python twin."""
+    from . import _lib
+    lib = _lib.load()
+    arrs = [_i64(a) for a in (p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el)]
+    ps, pd, pvl, pel, gs, gd, gvl, gel = arrs
+    P = lambda a: a.ctypes.data if a.size else None
+    pn, cap = len(pvl), 1024
+    while True:
+        rows = np.empty((cap, max(pn, 1)), dtype=np.int64)
+        c = int(lib.dmp_subiso_enumerate(pn, len(ps), P(ps), P(pd), P(pvl), P(pel), len(gvl), len(gs), P(gs), P(gd), P(gvl), P(gel),
+                                         rows.ctypes.data, cap, int(limit)))
+        if c < 0:
+            raise ValueError("enumerate_subisomorphisms: edge endpoints outside the graphs")
+        if c <= cap:
+            return rows[:c, :pn].copy().reshape(-1, pn)
+        cap = c
+
+
+def count_subisomorphisms_batch(pairs, threads=0):
+    """``counts`` of many pairs at once over a pool of host threads (``dmp_subiso_count_batch``); ``pairs``: a list of
+    ``(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el)``."""
+    from . import _lib
+    lib = _lib.load()
+    n = len(pairs)
+    cat = lambda k: _i64(np.concatenate([_i64(p[k]) for p in pairs])) if n else np.zeros(0, np.int64)
+    off = lambda k: _i64(np.concatenate([[0], np.cumsum([len(p[k]) for p in pairs])]))
+    ps, pd, pvl, pel, gs, gd, gvl, gel = (cat(k) for k in range(8))
+    pno, peo, gno, geo = off(2), off(0), off(6), off(4)
+    counts = np.zeros(n, np.int64)
+    P = lambda a: a.ctypes.data if a.size else None
+    rc = lib.dmp_subiso_count_batch(n, P(pno), P(peo), P(ps), P(pd), P(pvl), P(pel), P(gno), P(geo), P(gs), P(gd), P(gvl), P(gel),
+                                    P(counts), int(threads))
+    if rc != 0:
+        raise ValueError("count_subisomorphisms_batch: bad input")
+    return counts
+
+
+def enumerate_subisomorphisms_py(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
+    """The same enumeration as plain backtracking in Python (cross-check of the native search)."""
     np_, ng = len(p_vl), len(g_vl)
     adj = {}
     for u, v, l in zip(g_src.tolist(), g_dst.tolist(), g_el.tolist()):
@@ -61,7 +103,7 @@ def enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el
 
 def count_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el):
     """``counts`` of a (pattern, graph) pair: the number of subisomorphisms."""
-    return len(enumerate_subisomorphisms(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el))
+    return int(count_subisomorphisms_batch([(p_src, p_dst, p_vl, p_el, g_src, g_dst, g_vl, g_el)], threads=1)[0])
 
 
 def _er_edges(n, m, rng):

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 39
+#define DMP_ABI_VERSION 40
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -205,6 +205,27 @@ int dmp_dedupe_first(const int64_t *key_a, const int64_t *key_l,
 int dmp_subiso_node_weights(const int64_t *sub, int64_t T, const int64_t *sample_ptr, int64_t B,
                             const int64_t *g_node_off, int64_t *out, int64_t N,
                             int32_t *status, void *stream);
+/*
+ * Exact subgraph isomorphisms on the HOST (csrc/dmp_subiso.cpp; host pointers, no GPU, no stream): the `counts` /
+ * `subisomorphisms` columns of a dataset in the reference's format (utils/io.py:99-115).  A match: an injective,
+ * node-label-preserving map of the pattern's nodes into the graph's such that every pattern edge (u -> v, label l) has a
+ * graph edge between the images with label l (non-induced; multigraphs: any parallel edge).
+ *   dmp_subiso_enumerate  : one pair -> the number of matches (or DMP_ERR_BAD_ARG); the first rows_capacity of them are
+ *                           written to rows [capacity, pn] in lexicographic order of the node map; limit >= 0 stops the
+ *                           search after that many matches.
+ *   dmp_subiso_count_batch: counts of num_pairs pairs given back to back (node / edge offsets [num_pairs + 1], node ids
+ *                           local to each graph), over num_threads host threads (0: all cores).
+ */
+int64_t dmp_subiso_enumerate(int64_t pn, int64_t pm, const int64_t *p_src, const int64_t *p_dst,
+                             const int64_t *p_vlabel, const int64_t *p_elabel, int64_t gn, int64_t gm,
+                             const int64_t *g_src, const int64_t *g_dst, const int64_t *g_vlabel,
+                             const int64_t *g_elabel, int64_t *rows, int64_t rows_capacity, int64_t limit);
+int dmp_subiso_count_batch(int64_t num_pairs, const int64_t *p_node_off, const int64_t *p_edge_off,
+                           const int64_t *p_src, const int64_t *p_dst, const int64_t *p_vlabel,
+                           const int64_t *p_elabel, const int64_t *g_node_off, const int64_t *g_edge_off,
+                           const int64_t *g_src, const int64_t *g_dst, const int64_t *g_vlabel,
+                           const int64_t *g_elabel, int64_t *counts, int num_threads);
+
 /*
  * UNC mini-batch samplers on the device (UnsupervisedNodeClassification/Model/DMPNN/src/utils.py:279-349, where DGL's
  * dgl.sampling.random_walk / sample_neighbors do this on the host).  Randomness: a counter-based 32-bit mix of

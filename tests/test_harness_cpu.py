@@ -70,3 +70,30 @@ def test_step_schedules_match_reference_tables():
         got = [lr_factor(name, s, int(warm), int(total), float(cyc), float(floor)) for s in range(len(want))]
         assert np.allclose(got, want, rtol=0, atol=1e-12), spec
     assert scheduled_value(0.25, 3, 10) == 0.25
+
+
+def test_native_enumeration_equals_python_twin_and_batch_counts():
+    """csrc/dmp_subiso.cpp against the plain-Python search: the same matches in the same (lexicographic) order, on
+    multigraphs with parallel edges of different labels and self loops; the threaded batch counter; the match limit."""
+    import numpy as np
+    from dualmessagepassing_amd.harness import (count_subisomorphisms_batch, enumerate_subisomorphisms, enumerate_subisomorphisms_py)
+    rng = np.random.default_rng(4)
+    pairs, total = [], 0
+    for i in range(40):
+        pn, gn = int(rng.integers(1, 5)), int(rng.integers(3, 10))
+        pe, ge = int(rng.integers(0, 7)), int(rng.integers(2, 40))
+        ps, pd = rng.integers(0, pn, pe), rng.integers(0, pn, pe)          # loops and parallel edges allowed
+        gs, gd = rng.integers(0, gn, ge), rng.integers(0, gn, ge)
+        pair = (ps, pd, rng.integers(0, 2, pn), rng.integers(0, 2, pe), gs, gd, rng.integers(0, 2, gn), rng.integers(0, 2, ge))
+        a, b = enumerate_subisomorphisms(*pair), enumerate_subisomorphisms_py(*pair)
+        assert a.shape == b.shape and np.array_equal(a, b), i
+        if len(a) > 3:
+            assert np.array_equal(enumerate_subisomorphisms(*pair, limit=3), b[:3])
+        pairs.append(pair)
+        total += len(a)
+    assert total > 100
+    counts = count_subisomorphisms_batch(pairs, threads=4)
+    assert counts.tolist() == [len(enumerate_subisomorphisms_py(*p)) for p in pairs]
+    big = (np.array([0, 1, 2]), np.array([1, 2, 0]), np.zeros(3, int), np.zeros(3, int),
+           np.repeat(np.arange(12), 11), np.concatenate([np.delete(np.arange(12), i) for i in range(12)]), np.zeros(12, int), np.zeros(132, int))
+    assert len(enumerate_subisomorphisms(*big)) == 12 * 11 * 10       # beyond the first buffer: directed triangles in K12
