@@ -316,6 +316,8 @@ def main():
                     "(leaky_relu = the reference's default, config.py:298-301,370-373)")
     ap.add_argument("--emb", default="Equivariant", choices=("Equivariant", "Orthogonal", "Normal", "Uniform"),
                     help="embedding kind (Equivariant = the reference's default, config.py:242-245)")
+    ap.add_argument("--hid", type=int, default=CFG["hid"], help="hidden width (the metric is quoted at 128; 64 = the reference's "
+                    "README width: measured for DESIGN.md, not the bench line)")
     ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep every [E, 2H] "
                     "array below 4 GiB: 1 for config 2, 4 for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -341,7 +343,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches)
+    cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
+               hid=args.hid)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -408,7 +411,7 @@ def main():
                     "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(uN, uE, H),
                     "bytes_per_launch": int(k["bytes"]), "avg_us": round(k["avg_us"], 2), "launches": k["launches"]}
         line = {
-            "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=128", "value": round(pairs / dt, 1),
+            "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -77,40 +77,38 @@ class CompGCNLayer(nn.Module):
     def self_loop(self):
         return hasattr(self, "loop_weight") and self.loop_weight is not None
 
+    # composition operators of compgcn.py:213-224 (corr: circular correlation along the feature axis via the real FFT)
+    _COMP = {
+        "sub": lambda h, r: h - r,
+        "mult": lambda h, r: h * r,
+        "corr": lambda h, r: th.fft.irfft(th.conj(th.fft.rfft(h, dim=-1)) * th.fft.rfft(r, dim=-1), n=h.size(-1), dim=-1),
+    }
+
     def _comp_func(self, head, relation):
-        # compgcn.py:213-224
-        if self.comp_opt == "sub":
-            return head - relation
-        elif self.comp_opt == "mult":
-            return head * relation
-        elif self.comp_opt == "corr":
-            return th.fft.irfft(th.conj(th.fft.rfft(head, dim=-1)) * th.fft.rfft(relation, dim=-1),
-                                n=head.size(-1), dim=-1)
-        raise NotImplementedError
+        try:
+            return self._COMP[self.comp_opt](head, relation)
+        except KeyError:
+            raise NotImplementedError(self.comp_opt)
+
+    def _node_norm(self, deg):
+        """1 / (degree + 1) with a self loop; else 1 / degree with isolated nodes at 1 (compgcn.py:177-196)."""
+        if self.self_loop:
+            return (deg + 1).reciprocal().unsqueeze(-1)
+        return deg.reciprocal().masked_fill_(deg == 0, 1.0).unsqueeze(-1)
 
     def _norms(self, g):
-        """compgcn.py:177-209: node norms from (cached) degrees, then the per-edge norm."""
-        if self.edge_norm in ("in", "both") and INNORM not in g.ndata:
-            in_deg = g.in_degrees()
-            if self.self_loop:
-                g.ndata[INNORM] = (in_deg + 1).reciprocal().unsqueeze(-1)
-            else:
-                g.ndata[INNORM] = in_deg.reciprocal().masked_fill_(in_deg == 0, 1.0).unsqueeze(-1)
-        if self.edge_norm in ("out", "both") and OUTNORM not in g.ndata:
-            out_deg = g.out_degrees()
-            if self.self_loop:
-                g.ndata[OUTNORM] = (out_deg + 1).reciprocal().unsqueeze(-1)
-            else:
-                g.ndata[OUTNORM] = out_deg.reciprocal().masked_fill_(out_deg == 0, 1.0).unsqueeze(-1)
-        if self.edge_norm == "none":
+        """Per-edge normaliser [E] (None for edge_norm "none"): the destination's in-norm, the source's out-norm, or the
+        square root of their product (compgcn.py:204-209); the node norms are cached in ``ndata`` like the reference's."""
+        want_in, want_out = self.edge_norm in ("in", "both"), self.edge_norm in ("out", "both")
+        if want_in and INNORM not in g.ndata:
+            g.ndata[INNORM] = self._node_norm(g.in_degrees())
+        if want_out and OUTNORM not in g.ndata:
+            g.ndata[OUTNORM] = self._node_norm(g.out_degrees())
+        if not (want_in or want_out):
             return None
         u, v = g.all_edges(form="uv", order="eid")
-        if self.edge_norm == "in":
-            g.edata[NORM] = g.ndata[INNORM][v]
-        elif self.edge_norm == "out":
-            g.edata[NORM] = g.ndata[OUTNORM][u]
-        else:
-            g.edata[NORM] = (g.ndata[OUTNORM][u] * g.ndata[INNORM][v]) ** 0.5
+        parts = ([g.ndata[OUTNORM][u]] if want_out else []) + ([g.ndata[INNORM][v]] if want_in else [])
+        g.edata[NORM] = parts[0] if len(parts) == 1 else (parts[0] * parts[1]) ** 0.5
         return g.edata[NORM].reshape(-1)
 
     @on_input_device
@@ -172,24 +170,7 @@ class CompGCNRepMixin(DMPNNRepMixin):
 
     rep_key = "compgcn"
 
-    def create_rep_net(self, type, **kw):
-        if type == "graph":
-            num_layers = kw.get("rep_num_graph_layers", 1)
-        elif type == "pattern":
-            if self.share_rep_net:
-                return self.g_rep_net
-            num_layers = kw.get("rep_num_pattern_layers", 1)
-        else:
-            raise ValueError(type)
-        compgcn = nn.ModuleList()
-        for i in range(num_layers):
-            compgcn.add_module(
-                "%s_compgcn_(%d)" % (type, i),
-                CompGCNLayer(
-                    self.hid_dim, self.hid_dim,
-                    comp_opt=kw.get("rep_compgcn_comp_opt", "mult"),
-                    edge_norm=kw.get("rep_compgcn_edge_norm", "none"),
-                    batch_norm=kw.get("rep_compgcn_batch_norm", False),
-                    act_func=kw.get("rep_act_func", "relu"),
-                    dropout=kw.get("rep_dropout", 0.0)))
-        return nn.ModuleDict({"compgcn": compgcn})
+    def _make_layer(self, **kw):
+        return CompGCNLayer(self.hid_dim, self.hid_dim, comp_opt=kw.get("rep_compgcn_comp_opt", "mult"),
+                            edge_norm=kw.get("rep_compgcn_edge_norm", "none"), batch_norm=kw.get("rep_compgcn_batch_norm", False),
+                            act_func=kw.get("rep_act_func", "relu"), dropout=kw.get("rep_dropout", 0.0))

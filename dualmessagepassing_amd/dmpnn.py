@@ -225,105 +225,64 @@ class DMPNNRepMixin:
     def get_joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
         return joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
 
+    def _make_layer(self, **kw):
+        return DMPLayer(self.hid_dim, self.hid_dim, init_neigenv=kw.get("init_neigenv", 4.0), init_eeigenv=kw.get("init_eeigenv", 4.0),
+                        num_mlp_layers=kw.get("rep_dmpnn_num_mlp_layers", 2), batch_norm=kw.get("rep_dmpnn_batch_norm", False),
+                        act_func=kw.get("rep_act_func", "relu"), dropout=kw.get("rep_dropout", 0.0))
+
     def create_rep_net(self, type, **kw):
-        if type == "graph":
-            num_layers = kw.get("rep_num_graph_layers", 1)
-        elif type == "pattern":
-            if self.share_rep_net:
-                return self.g_rep_net
-            num_layers = kw.get("rep_num_pattern_layers", 1)
-        else:
+        """``ModuleDict({rep_key: ModuleList})`` with children ``"<type>_<rep_key>_(<i>)"`` (the reference's ``state_dict``
+        names, dmpnn.py:183-213); the pattern side IS the graph side under ``share_rep_net``."""
+        if type not in ("graph", "pattern"):
             raise ValueError(type)
-        dmpnn = nn.ModuleList()
-        for i in range(num_layers):
-            dmpnn.add_module(
-                "%s_dmpnn_(%d)" % (type, i),
-                DMPLayer(
-                    self.hid_dim,
-                    self.hid_dim,
-                    init_neigenv=kw.get("init_neigenv", 4.0),
-                    init_eeigenv=kw.get("init_eeigenv", 4.0),
-                    num_mlp_layers=kw.get("rep_dmpnn_num_mlp_layers", 2),
-                    batch_norm=kw.get("rep_dmpnn_batch_norm", False),
-                    act_func=kw.get("rep_act_func", "relu"),
-                    dropout=kw.get("rep_dropout", 0.0)
-                )
-            )
-        return nn.ModuleDict({"dmpnn": dmpnn})
+        if type == "pattern" and self.share_rep_net:
+            return self.g_rep_net
+        layers = nn.ModuleList()
+        for i in range(kw.get("rep_num_%s_layers" % type, 1)):
+            layers.add_module("%s_%s_(%d)" % (type, self.rep_key, i), self._make_layer(**kw))
+        return nn.ModuleDict({self.rep_key: layers})
+
+    def _rep_loop(self, net, graph, v, e, v_gate=None, e_gate=None, v_zero=None, e_zero=None):
+        """The layer loop shared by the pattern and the graph side (dmpnn.py:229-241,262-275): after every layer the
+        outputs are zero-masked (pattern side) or gated (graph side) and, with ``rep_residual`` and matching shapes, added
+        to the layer's inputs.  Eligible layers take the fused single-node path (layer + gate + residual in one)."""
+        for layer in net[self.rep_key]:
+            if v_zero is None and e_zero is None and getattr(self, "use_fused", True) and hasattr(layer, "fused_ok") \
+                    and layer.fused_ok(graph, v, e, v_gate, e_gate):
+                v, e = layer.forward_fused(graph, v, e, v_gate, e_gate, self.rep_residual)
+                continue
+            nv, ne = layer(graph, v, e)
+            if v_zero is not None:
+                nv = nv.masked_fill(v_zero, 0.0)
+            if e_zero is not None:
+                ne = ne.masked_fill(e_zero, 0.0)
+            if v_gate is not None:
+                nv = nv * v_gate
+            if e_gate is not None:
+                ne = ne * e_gate
+            if self.rep_residual and v.size() == nv.size() and e.size() == ne.size():
+                v, e = v + nv, e + ne
+            else:
+                v, e = nv, ne
+        return v, e
 
     def get_pattern_rep(self, pattern, p_v_emb, p_e_emb, v_mask=None, e_mask=None):
-        # dmpnn.py:215-243
-        if v_mask is not None:
-            p_v_zero_mask = ~(v_mask)
-            v_outputs = [p_v_emb.masked_fill(p_v_zero_mask, 0.0)]
-        else:
-            p_v_zero_mask = None
-            v_outputs = [p_v_emb]
-        if e_mask is not None:
-            p_e_zero_mask = ~(e_mask)
-            e_outputs = [p_e_emb.masked_fill(p_e_zero_mask, 0.0)]
-        else:
-            p_e_zero_mask = None
-            e_outputs = [p_e_emb]
-
-        for layer in self.p_rep_net[self.rep_key]:
-            if p_v_zero_mask is None and p_e_zero_mask is None and getattr(self, "use_fused", True) \
-                    and hasattr(layer, "fused_ok") and layer.fused_ok(pattern, v_outputs[-1], e_outputs[-1]):
-                v, e = layer.forward_fused(pattern, v_outputs[-1], e_outputs[-1], None, None, self.rep_residual)
-                v_outputs.append(v)
-                e_outputs.append(e)
-                continue
-            v, e = layer(pattern, v_outputs[-1], e_outputs[-1])
-            if p_v_zero_mask is not None:
-                v = v.masked_fill(p_v_zero_mask, 0.0)
-            if p_e_zero_mask is not None:
-                e = e.masked_fill(p_e_zero_mask, 0.0)
-            if self.rep_residual and v_outputs[-1].size() == v.size() and e_outputs[-1].size() == e.size():
-                v_outputs.append(v_outputs[-1] + v)
-                e_outputs.append(e_outputs[-1] + e)
-            else:
-                v_outputs.append(v)
-                e_outputs.append(e)
-        return v_outputs[-1], e_outputs[-1]
+        # dmpnn.py:215-243: masks zero the rows before the first and after every layer
+        v_zero = None if v_mask is None else ~v_mask
+        e_zero = None if e_mask is None else ~e_mask
+        v = p_v_emb if v_zero is None else p_v_emb.masked_fill(v_zero, 0.0)
+        e = p_e_emb if e_zero is None else p_e_emb.masked_fill(e_zero, 0.0)
+        return self._rep_loop(self.p_rep_net, pattern, v, e, v_zero=v_zero, e_zero=e_zero)
 
     def get_graph_rep(self, graph, g_v_emb, g_e_emb, v_mask=None, e_mask=None, v_gate=None, e_gate=None):
-        # dmpnn.py:245-277
-        if v_mask is not None or v_gate is not None:
-            if v_gate is None:
-                v_gate = v_mask.float()
-            elif v_mask is not None:
-                v_gate = v_mask.float() * v_gate
-            v_outputs = [g_v_emb * v_gate]
-        else:
-            v_outputs = [g_v_emb]
-        if e_mask is not None or e_gate is not None:
-            if e_gate is None:
-                e_gate = e_mask.float()
-            elif e_mask is not None:
-                e_gate = e_mask.float() * e_gate
-            e_outputs = [g_e_emb * e_gate]
-        else:
-            e_outputs = [g_e_emb]
-
-        for layer in self.g_rep_net[self.rep_key]:
-            if getattr(self, "use_fused", True) and hasattr(layer, "fused_ok") \
-                    and layer.fused_ok(graph, v_outputs[-1], e_outputs[-1], v_gate, e_gate):
-                v, e = layer.forward_fused(graph, v_outputs[-1], e_outputs[-1], v_gate, e_gate, self.rep_residual)
-                v_outputs.append(v)
-                e_outputs.append(e)
-                continue
-            v, e = layer(graph, v_outputs[-1], e_outputs[-1])
-            if v_gate is not None:
-                v = v * v_gate
-            if e_gate is not None:
-                e = e * e_gate
-            if self.rep_residual and v_outputs[-1].size() == v.size() and e_outputs[-1].size() == e.size():
-                v_outputs.append(v_outputs[-1] + v)
-                e_outputs.append(e_outputs[-1] + e)
-            else:
-                v_outputs.append(v)
-                e_outputs.append(e)
-        return v_outputs[-1], e_outputs[-1]
+        # dmpnn.py:245-277: a mask acts as (or multiplies into) the gate
+        if v_mask is not None:
+            v_gate = v_mask.float() if v_gate is None else v_mask.float() * v_gate
+        if e_mask is not None:
+            e_gate = e_mask.float() if e_gate is None else e_mask.float() * e_gate
+        v = g_v_emb if v_gate is None else g_v_emb * v_gate
+        e = g_e_emb if e_gate is None else g_e_emb * e_gate
+        return self._rep_loop(self.g_rep_net, graph, v, e, v_gate=v_gate, e_gate=e_gate)
 
 
 def _union_of(pattern, graph):

@@ -93,6 +93,31 @@ def test_config5_cora_shape_unc_two_layers(gpu):
     xg, zg = l2(g, xg, zg, g.edata["norm"])
     _close(xg, xo, 5e-5, "node rep")
     _close(zg, zo, 5e-5, "edge rep")
+    # backward at the same shape (the UNC training step differentiates this stack: main.py:150-175): input and parameter
+    # gradients of both layers against the oracle's autograd
+    wn, we = th.randn(n, h), th.randn(10858, h)
+    ps = [{k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()} for layer in (l1, l2)]
+    bns = [{m + ".1": {"running_mean": getattr(layer, m)[1].running_mean.cpu().clone(), "running_var": getattr(layer, m)[1].running_var.cpu().clone()}
+            for m in ("nmlp", "emlp")} for layer in (l1, l2)]
+    x0, z0 = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    a1, b1 = O.dual_graph_conv(ps[0], src, dst, out_deg, x0, z0, norm, None, bns[0], False, "tanh")
+    a2, b2 = O.dual_graph_conv(ps[1], src, dst, out_deg, a1, b1, norm, None, bns[1], False, None)
+    ((a2 * wn).sum() + (b2 * we).sum()).backward()
+    xg0, zg0 = x.to(gpu).requires_grad_(True), z.to(gpu).requires_grad_(True)
+    for layer in (l1, l2):
+        layer.zero_grad()
+    c1, d1 = l1(g, xg0, zg0, g.edata["norm"])
+    c2, d2 = l2(g, c1, d1, g.edata["norm"])
+    ((c2 * wn.to(gpu)).sum() + (d2 * we.to(gpu)).sum()).backward()
+    from test_gpu_dmplayer import _close_or_flipped
+    flipped = _close_or_flipped(xg0.grad, x0.grad, 1e-4, 1e-4, "dx")
+    flipped |= _close_or_flipped(zg0.grad, z0.grad, 1e-4, 1e-4, "dz")
+    for layer, po in zip((l1, l2), ps):
+        for k, q in layer.named_parameters():
+            if po[k].grad is None:
+                assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
+            else:
+                _close(q.grad, po[k].grad, 5e-3 if flipped else 5e-4, "grad " + k)
 
 
 @pytest.mark.parametrize("case", ["no_edges", "single_node", "hub"])
