@@ -117,7 +117,7 @@ def test_config5_cora_shape_unc_two_layers(gpu):
             if po[k].grad is None:
                 assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
             else:
-                _close(q.grad, po[k].grad, 5e-3 if flipped else 5e-4, "grad " + k)
+                _close(q.grad, po[k].grad, 2e-2 if flipped else 5e-4, "grad " + k)
 
 
 @pytest.mark.parametrize("case", ["no_edges", "single_node", "hub"])
