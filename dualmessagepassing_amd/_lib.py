@@ -97,6 +97,10 @@ SIGNATURES = {
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                 c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
+    "dmp_rel_gemm": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
+                             c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_rel_atb_blocks": (c_i64, [c_int]),
+    "dmp_rel_atb": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_atb_typed_blocks": (c_i64, [c_i64]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_rows_blocks": (c_i64, [c_i64, c_int, c_int]),
@@ -122,7 +126,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 40
+ABI_VERSION = 41
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

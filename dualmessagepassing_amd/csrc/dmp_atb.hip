@@ -4,6 +4,9 @@
 //   dmp_atb_typed   T = sum_e Z[e]^T dPre[e]  and  B = sum_e c_e Z[e]^T dPre[e]  over the class-sorted tile
 //                   list (c_e = the coefficient of e's degree class): dA' and dB' of the class-typed edge
 //                   chain (dmpnn.py:144-156 backward), one product's worth of MFMAs for both.
+//   dmp_rel_atb     T_t = sum over the edges e of relation type t of w_e X[src e]^T D[dst e]  for every type t: the
+//                   per-type weight gradients of the relational layers (rgcn.py:98-123 backward); rows gathered through
+//                   two slot arrays, blockIdx.y = type, the type's tile range split over blockIdx.x.
 //   dmp_atb_rows    T = (g (.) Z)^T D  and the column sums of g (.) Z  over plain row tiles: the gradient of
 //                   the second edge Linear with the layer's edge gate and its bias gradient fused in
 //                   (dmpnn.py:263-273 backward: dO = gate * dOut, dW2 = dO^T H1, db2 = sum dO).
@@ -37,10 +40,16 @@ struct AtbArgs {
   int64_t pstride; int ldp;
   float *pCS;                      // rows variant: [gridDim.x, cs_ld] column sums of g (.) Z
   int nb, cs_ld;                   // rows variant: blockIdx.y = a * nb + b picks the 128-column blocks a of Z and b of D
+  const int32_t *slot_d;           // relational variant: row of D per slot (slot_edge: row of Z), -1 = padding
+  const float *slot_scale;         // relational variant: [tiles * 32] scale of Z's row per slot, or NULL
+  const int32_t *type_tile_ptr;    // relational variant: [types + 1] first tile of every type
 };
 
-template <bool TYPED>
+enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
+
+template <int MODE>
 __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
+  constexpr bool TYPED = MODE == ATB_TYPED, REL = MODE == ATB_REL;   // REL: the control flow of the rows variant over gathered rows
   // two tile buffers (Zs | Ds, 2 x 32 x 132 floats each) = 67584 bytes; emit() reuses the first 64 KB for the [128,128] total
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTile = kSub * kLdsStride, kBuf = 2 * kTile;
@@ -51,16 +60,21 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   constexpr uint32_t kOOB = 0xFFFFF000u;
   const rsrc_t rs_Z = make_rsrc(p.Z + 128 * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + 128) * 4) : 0u);
   const rsrc_t rs_D = make_rsrc(p.D + 128 * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + 128) * 4) : 0u);
-  const bool gated = !TYPED && p.gate != nullptr;
-  const rsrc_t rs_G = make_rsrc(p.gate, gated ? (uint32_t)(p.E * 4) : 0u);
-  const int ntiles = TYPED ? __builtin_amdgcn_readfirstlane(*p.num_tiles) : p.plain_tiles;
+  const bool gated = REL ? p.slot_scale != nullptr : (!TYPED && p.gate != nullptr);
+  const rsrc_t rs_G = make_rsrc(p.gate, !REL && gated ? (uint32_t)(p.E * 4) : 0u);
+  const int first = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y]) : 0;
+  const int ntiles = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y + 1]) - first
+                         : TYPED ? __builtin_amdgcn_readfirstlane(*p.num_tiles) : p.plain_tiles;
   const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int lo = (int)blockIdx.x * chunk;
-  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int lo = first + (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < first + ntiles ? lo + chunk : first + ntiles;
   const int mine = hi > lo ? hi - lo : 0;
-  const rsrc_t rs_slot = make_rsrc(p.slot_edge, TYPED ? (uint32_t)ntiles * (kSub * 4u) : 0u);
-  float *pt = p.pT + (int64_t)blockIdx.x * p.pstride + (int64_t)ya * 128 * p.ldp + yb * 128;
-  float *const pcs = !TYPED && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * 128 : nullptr;
+  const uint32_t slot_bytes = REL ? (uint32_t)p.plain_tiles * (kSub * 4u) : TYPED ? (uint32_t)ntiles * (kSub * 4u) : 0u;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, slot_bytes);
+  const rsrc_t rs_slotD = make_rsrc(p.slot_d, REL ? slot_bytes : 0u);
+  const rsrc_t rs_slotS = make_rsrc(p.slot_scale, REL && gated ? slot_bytes : 0u);
+  float *pt = p.pT + (int64_t)(REL ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x) * p.pstride + (int64_t)ya * 128 * p.ldp + yb * 128;
+  float *const pcs = MODE == ATB_ROWS && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * 128 : nullptr;
   float *pb = TYPED ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;
 
   f32x16 acc[2][4];
@@ -77,17 +91,24 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 #ifdef DMP_ATB_DBG
   bool warm = false;
 #endif
-  int id_rows[kSubLoads];
+  int id_rows[kSubLoads], id_rowsD[kSubLoads];
+  float sc_rows[kSubLoads];
   float4 preZ[2][kSubLoads], preD[2][kSubLoads];           // two sets of prefetched rows: tiles of even / odd pipeline phase
   float preG[2][kSubLoads];
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);             // gated: this thread's 4 columns of sum g (.) Z
   auto load_ids = [&](int k) {
     const bool ok = k < mine;
-    if (TYPED) {
+    if (TYPED || REL) {
       const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
 #pragma unroll
-      for (int m = 0; m < kSubLoads; ++m)
+      for (int m = 0; m < kSubLoads; ++m) {
         id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+        if (REL) {
+          id_rowsD[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotD, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+          sc_rows[m] = 1.f;
+          if (gated) sc_rows[m] = ok ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_slotS, ((gtid >> 5) + 8 * m) * 4, (int)so, 0)) : 0.f;
+        }
+      }
     } else {
 #pragma unroll
       for (int m = 0; m < kSubLoads; ++m) {
@@ -103,8 +124,10 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 #endif
     const bool ok = id_rows[m] >= 0;
     preZ[S][m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldz * 4) + colA : kOOB, 0);
-    preD[S][m] = buf_load4(rs_D, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
-    if (!TYPED) {
+    const int idD = REL ? id_rowsD[m] : id_rows[m];
+    preD[S][m] = buf_load4(rs_D, ok ? (uint32_t)idD * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
+    if (REL) preG[S][m] = sc_rows[m];
+    if (MODE == ATB_ROWS) {
       preG[S][m] = 1.f;
       if (gated) preG[S][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_G, ok ? (int)((uint32_t)id_rows[m] * 4u) : (int)kOOB, 0, 0));
     }
@@ -117,7 +140,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     constexpr int S = decltype(set)::value;
     const int o = S * kBuf + ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
     float4 z = preZ[S][m];
-    if (!TYPED && gated) {
+    if (REL) {
+      if (gated) z = make_float4(z.x * preG[S][m], z.y * preG[S][m], z.z * preG[S][m], z.w * preG[S][m]);
+    } else if (!TYPED && gated) {
       z = make_float4(z.x * preG[S][m], z.y * preG[S][m], z.z * preG[S][m], z.w * preG[S][m]);
       cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
     } else if (!TYPED && p.pCS) {
@@ -302,9 +327,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   }
 }
 
-template <bool TYPED>
+template <int MODE>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  atb_body<TYPED>(p, TYPED ? 0 : (int)blockIdx.y / p.nb, TYPED ? 0 : (int)blockIdx.y % p.nb);
+  atb_body<MODE>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
 }
 
 // Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
@@ -313,12 +338,12 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
 // start, LDS reduction, 64 KB partial) are paid 512 times in total instead of 512 times per product.
 constexpr int kMaxAtbJobs = DMP_ATB_MAX_JOBS;
 struct AtbJobs { AtbArgs job[kMaxAtbJobs]; };
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<false>(t.job[blockIdx.y], 0, 0); }
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS>(t.job[blockIdx.y], 0, 0); }
 
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
-template <bool TYPED>
+template <int MODE>
 bool lds_ready() {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<TYPED>),
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<MODE>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kAtbLdsBytes);
   if (e != hipSuccess) set_last_hip_error(e);
   return e == hipSuccess;
@@ -354,8 +379,8 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   const bool wide = partial_B == partial_T + 128;          // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
   a.pstride = wide ? 2 * 128 * 128 : 128 * 128;
   a.ldp = wide ? 256 : 128;
-  if (!lds_ready<true>()) return DMP_ERR_HIP;
-  atb_k<true><<<atb_blocks(tiles_bound), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  if (!lds_ready<ATB_TYPED>()) return DMP_ERR_HIP;
+  atb_k<ATB_TYPED><<<atb_blocks(tiles_bound), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 
@@ -396,6 +421,26 @@ int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void 
   return check_launch();
 }
 
+int64_t dmp_rel_atb_blocks(int num_rels) { return num_rels >= 512 ? 1 : 512 / (num_rels > 0 ? num_rels : 1); }
+
+int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int64_t ldd, int64_t rows_d,
+                const int32_t *slot_x, const int32_t *slot_d, const float *slot_scale, const int32_t *type_tile_ptr,
+                int num_rels, int64_t tiles, int H, float *partial, void *stream) {
+  if (rows_x < 0 || rows_d < 0 || tiles < 0 || num_rels < 1 || num_rels > 65535 || H != 128)
+    return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (!partial || !type_tile_ptr || (tiles > 0 && (!X || !D || !slot_x || !slot_d || ldx < H || ldd < H))) return DMP_ERR_BAD_ARG;
+  if (ldx % 4 || ldd % 4 || (tiles > 0 && (!aligned16(X) || !aligned16(D))) || !aligned16(partial)) return DMP_ERR_UNSUPPORTED;
+  if (!fits32(rows_x, ldx) || !fits32(rows_d, ldd) || !fits32(tiles * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  AtbArgs a{};
+  a.Z = X; a.ldz = ldx; a.D = D; a.ldd = ldd; a.E = rows_x > rows_d ? rows_x : rows_d;
+  a.slot_edge = slot_x; a.slot_d = slot_d; a.slot_scale = slot_scale; a.type_tile_ptr = type_tile_ptr;
+  a.plain_tiles = (int)tiles; a.pT = partial; a.pstride = 128 * 128; a.ldp = 128;
+  if (!lds_ready<ATB_REL>()) return DMP_ERR_HIP;
+  const dim3 grid((unsigned)dmp_rel_atb_blocks(num_rels), (unsigned)num_rels);
+  atb_k<ATB_REL><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  return check_launch();
+}
+
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
                  float *partial, float *partial_colsum, void *stream) {
   if (rows < 0 || M <= 0 || N <= 0) return DMP_ERR_BAD_ARG;
@@ -409,9 +454,9 @@ int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
   a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / 128; a.cs_ld = M;
-  if (!lds_ready<false>()) return DMP_ERR_HIP;
+  if (!lds_ready<ATB_ROWS>()) return DMP_ERR_HIP;
   const dim3 grid(rows_blocks(rows, M, N), (unsigned)((M / 128) * (N / 128)));
-  atb_k<false><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  atb_k<ATB_ROWS><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

@@ -16,7 +16,7 @@
 namespace dmp {
 namespace {
 
-enum { TEPI_EDGE = 1, TEPI_DZ = 4 };
+enum { TEPI_EDGE = 1, TEPI_DZ = 4, TEPI_REL = 8 };
 
 struct TypedArgs {
   const float *A; int64_t lda;          // streamed operand [E,128], rows gathered by edge id
@@ -26,6 +26,9 @@ struct TypedArgs {
   float *C; int64_t ldc;                // output [E,128], rows scattered by edge id
   int64_t E;
   const int32_t *slot_edge;             // [num_tiles_bound * 32] edge id per slot, -1 = padding
+  const int32_t *slot_arow;             // row of A per slot (TEPI_EDGE / TEPI_DZ: the same array as slot_edge)
+  int64_t rowsA;                        // rows of A (TEPI_EDGE / TEPI_DZ: E)
+  int num_panels;                       // TEPI_REL: W is [num_panels][128][ldw], tile_scale holds the panel index (int bits)
   const float *tile_scale;              // [num_tiles_bound] c_g of the tile's class
   const int32_t *num_tiles;             // device scalar: tiles actually used
   const int32_t *idxA, *idxB;           // TEPI_EDGE: [E] node ids of the added / subtracted P rows; TEPI_DZ: idxA = dst
@@ -42,7 +45,9 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
   // TEPI_DZ keeps the two-barrier order (MFMA phase | stage + requests | epilogue): its epilogue waits for streamed
   // base rows, and the extra phase between their request and their use hides them better (measured: +3 % otherwise).
-  constexpr bool kPipelined = EPI == TEPI_EDGE;
+  // TEPI_REL (relation-typed product, rgcn.py:98-123): plain panel W[type of the tile], rows of A gathered through
+  // slot_arow, the output row scaled by idxA-as-float[row] (the edge normaliser) -- no epilogue operands.
+  constexpr bool kPipelined = EPI != TEPI_DZ;
   __shared__ float As[kPipelined ? 2 : 1][kSub * kLdsStride];
   __shared__ float Cs[4][32 * kScrStride];
   __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] byte offsets: tile k's are read
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
-  const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.E * p.lda * 4));       // all < 4 GiB: checked by the host
+  const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.rowsA * p.lda * 4));   // all < 4 GiB: checked by the host
   const rsrc_t rs_C = make_rsrc(p.C, (uint32_t)(p.E * p.ldc * 4));
   const rsrc_t rs_R = make_rsrc(p.R, p.R ? (uint32_t)(p.E * p.ldr * 4) : 0u);
   const rsrc_t rs_T = make_rsrc(p.T, (uint32_t)(p.num_nodes * p.ldt * 4));
@@ -74,10 +79,11 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
   const int mine = hi > lo ? hi - lo : 0;
   const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));   // past the end: reads 0 (guarded below)
+  const rsrc_t rs_slotA = make_rsrc(p.slot_arow, (uint32_t)ntiles * (kSub * 4u));
 
   // W_g fragments: b[s] = B_g[s + 64h][col]
   float b[64];
-  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)(128 * p.ldw * 4));
+  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)((EPI == TEPI_REL ? p.num_panels : 1) * 128 * p.ldw * 4));
   const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + 64 * h : (int64_t)64 * h * p.ldw + col) * 4u;
   const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.transposed ? 4 : p.ldw * 4));  // bytes from k to k+1
   auto load_panel = [&](float c) {
@@ -85,16 +91,17 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     // address computations out of the tile loop and keeps them live in registers across it.
     uint32_t off;
     asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
+    if (EPI == TEPI_REL) off += (uint32_t)__float_as_int(c) * (uint32_t)(128 * p.ldw * 4);   // panel of the tile's type
 #pragma unroll
     for (int s0 = 0; s0 < 64; s0 += 8) {
       float w0[8], w1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
-        w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + 512, (int)((s0 + j) * w_step), 0));
+        if (EPI != TEPI_REL) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + 512, (int)((s0 + j) * w_step), 0));
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[s0 + j] = w0[j] + c * w1[j];
+      for (int j = 0; j < 8; ++j) b[s0 + j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
-      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
     if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
   };
   int own_staged = -1;
@@ -146,6 +153,8 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       uint32_t a = kOOB, bb = kOOB;
       if (EPI == TEPI_EDGE) {
         if (ok) { a = pre_a * (uint32_t)(p.ldt * 4); bb = pre_b * (uint32_t)(p.ldt * 4) + 512u; }
+      } else if (EPI == TEPI_REL) {
+        a = p.idxA ? pre_a : __float_as_uint(1.f);        // the row's scale (float bits)
       } else {
         bb = pre_b;                                       // flag
         if (ok) a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? 512u : 0u);
@@ -167,6 +176,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 #ifdef DMP_TY_DBG
     if (DMP_TY_DBG & 2) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; return; }
 #endif
+    if (EPI == TEPI_REL) return;
     const int rr = 8 * k + lrow;
     g0[k] = buf_load4(rs_T, rowA[par][rr] + col4, 0);
     if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
@@ -242,6 +252,9 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
         v.y = act_fwd((v.y + (g0[k].y - g1[k].y)) + bias4.y, slope);
         v.z = act_fwd((v.z + (g0[k].z - g1[k].z)) + bias4.z, slope);
         v.w = act_fwd((v.w + (g0[k].w - g1[k].w)) + bias4.w, slope);
+      } else if (EPI == TEPI_REL) {
+        const float sg = __uint_as_float(rowA[par][rr]);
+        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
       } else {
         const float sg = rowB[par][rr] ? p.s1 : p.s0;
         v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
@@ -335,7 +348,7 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   if (!fits32(num_nodes, ldp) || !fits32(E, ldz) || !fits32(E, ldh) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
-  p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
+  p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias; p.slope = slope;
   mfma_typed<TEPI_EDGE><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
@@ -357,10 +370,28 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
-  p.slot_edge = slot_edge; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
+  p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : 128;
   p.s0 = s0; p.s1 = s1;
   mfma_typed<TEPI_DZ><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, int64_t ldw, int num_rels, int w_transposed,
+                 const int32_t *slot_arow, const int32_t *slot_row, const int32_t *tile_type, const int32_t *num_tiles,
+                 int64_t tiles_bound, const float *row_scale, int64_t rows_c, int H, float *C, int64_t ldc, void *stream) {
+  if (rows_a < 0 || rows_c < 0 || tiles_bound < 0 || num_rels < 1 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (rows_c == 0 || tiles_bound == 0) return DMP_OK;
+  if (!A || !W || !slot_arow || !slot_row || !tile_type || !num_tiles || !C || lda < H || ldw < H || ldc < H) return DMP_ERR_BAD_ARG;
+  if (lda % 4 || ldc % 4 || !aligned16(A) || !aligned16(C)) return DMP_ERR_UNSUPPORTED;
+  if (!fits32(rows_a, lda) || !fits32(rows_c, ldc) || !fits32(tiles_bound * kSub, 1) || !fits32((int64_t)num_rels * 128, ldw))
+    return DMP_ERR_UNSUPPORTED;
+  TypedArgs p{};
+  p.A = A; p.lda = lda; p.rowsA = rows_a; p.W = W; p.ldw = ldw; p.num_panels = num_rels; p.transposed = w_transposed ? 1 : 0;
+  p.C = C; p.ldc = ldc; p.E = rows_c; p.slot_edge = slot_row; p.slot_arow = slot_arow;
+  p.tile_scale = reinterpret_cast<const float *>(tile_type); p.num_tiles = num_tiles;
+  p.idxA = reinterpret_cast<const int32_t *>(row_scale);
+  mfma_typed<TEPI_REL><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 

@@ -13,6 +13,7 @@ differentiable tensor ops (rgcn.py:98-104,112-116).
 """
 from collections import OrderedDict
 
+import numpy as np
 import torch as th
 import torch.nn as nn
 from torch.autograd.function import once_differentiable
@@ -24,6 +25,7 @@ from .graph import GraphIndex, as_batched
 
 _TYPED_CACHE = OrderedDict()
 _TYPED_CACHE_MAX = 16
+USE_REL_KERNELS = True      # 128 -> 128 typed products on dmp_rel_gemm / dmp_rel_atb (False: one library GEMM per type)
 
 
 class TypedIndex:
@@ -47,10 +49,39 @@ class TypedIndex:
         self.src32p = index.src32[self.perm].contiguous()
         self.dst32p = index.dst32[self.perm].contiguous()
         self.graph = GraphIndex(self.src32p.long(), self.dst32p.long(), index.num_nodes)
+        self._tiles = None
 
     def permuted(self, edge_w):
         """Per-edge weights (edge-id order) in type order, or None."""
         return None if edge_w is None else edge_w.view(-1)[self.perm].contiguous()
+
+    def tiles(self):
+        """The 32-slot tiles of the relation-typed MFMA kernels (``dmp_rel_gemm`` / ``dmp_rel_atb``): every
+        type's row block of the permuted edge list padded to whole tiles.  ``slot_row`` (row of the permuted
+        list per slot, -1 = padding), ``slot_src`` / ``slot_dst`` (its end nodes), ``tile_type``,
+        ``type_tile_ptr`` and the tile count, built once from the host-side bounds."""
+        if self._tiles is None:
+            dev = self.src32p.device
+            counts = np.diff(np.asarray(self.bounds, dtype=np.int64))
+            per_type = (counts + 31) // 32
+            tile_ptr = np.concatenate([[0], np.cumsum(per_type)])
+            total = int(tile_ptr[-1])
+            shift = np.repeat(tile_ptr[:-1] * 32 - np.asarray(self.bounds[:-1], dtype=np.int64), counts)
+            slot_row = np.full(max(total, 1) * 32, -1, dtype=np.int32)
+            rows = np.arange(self.num_edges, dtype=np.int64)
+            slot_row[rows + shift] = rows
+            slot_row = th.from_numpy(slot_row).to(dev)
+            valid = slot_row >= 0
+            at = slot_row.clamp(min=0).long()
+            neg = th.full_like(slot_row, -1)
+            self._tiles = dict(
+                slot_row=slot_row, valid=valid, at=at,
+                slot_src=th.where(valid, self.src32p[at], neg), slot_dst=th.where(valid, self.dst32p[at], neg),
+                tile_type=th.from_numpy(np.repeat(np.arange(self.num_rels, dtype=np.int32), per_type)).to(dev)
+                if total else th.zeros(1, dtype=th.int32, device=dev),
+                type_tile_ptr=th.from_numpy(tile_ptr.astype(np.int32)).to(dev),
+                num_tiles=th.tensor([total], dtype=th.int32, device=dev), total=total)
+        return self._tiles
 
 
 def typed_index(graph, etype, num_rels):
@@ -68,35 +99,88 @@ def typed_index(graph, etype, num_rels):
     return hit[0]
 
 
+def rel_ok(x, weight):
+    """The relation-typed MFMA kernels take 128 -> 128 layers (contiguous fp32 rows)."""
+    return (x.dim() == 2 and x.size(1) == 128 and weight.dim() == 3 and weight.size(1) == 128 and weight.size(2) == 128
+            and x.dtype == th.float32 and weight.dtype == th.float32)
+
+
+def rel_gemm(a, weight, slot_arow, tix, row_scale=None, transposed=False):
+    """``out[r] = row_scale[r] * a[slot_arow -> r] @ weight[type r]`` (or its transpose) for the rows ``r`` of
+    the permuted edge list (``dmp_rel_gemm``)."""
+    t = tix.tiles()
+    lib = _lib.load()
+    a, weight = a.contiguous(), weight.contiguous()
+    out = th.empty((tix.num_edges, 128), dtype=th.float32, device=a.device)
+    with _lib.timed("rel_gemm[E=%d]", (tix.num_edges,), 8 * 128 * tix.num_edges):
+        _lib.check(lib.dmp_rel_gemm(_lib.ptr(a), a.stride(0), a.size(0), _lib.ptr(weight), weight.stride(1), weight.size(0),
+                                    1 if transposed else 0, _lib.ptr(slot_arow), _lib.ptr(t["slot_row"]), _lib.ptr(t["tile_type"]),
+                                    _lib.ptr(t["num_tiles"]), t["total"], _lib.ptr(row_scale) if row_scale is not None else None,
+                                    tix.num_edges, 128, _lib.ptr(out), out.stride(0), _lib.stream_ptr()), "dmp_rel_gemm")
+    return out
+
+
+def rel_atb(x, d, tix, row_scale=None):
+    """``dW[t] = sum over the edges e of type t of row_scale_e * x[src e]^T d[dst e]`` (``dmp_rel_atb`` and a
+    fixed-order sum of its per-workgroup partials)."""
+    t = tix.tiles()
+    lib = _lib.load()
+    x, d = x.contiguous(), d.contiguous()
+    blocks = int(lib.dmp_rel_atb_blocks(tix.num_rels))
+    part = th.empty((tix.num_rels, blocks, 128, 128), dtype=th.float32, device=x.device)
+    slot_scale = None
+    if row_scale is not None:
+        slot_scale = th.where(t["valid"], row_scale[t["at"]], row_scale.new_zeros(()))
+    with _lib.timed("rel_atb[E=%d]", (tix.num_edges,), 8 * 128 * tix.num_edges):
+        _lib.check(lib.dmp_rel_atb(_lib.ptr(x), x.stride(0), x.size(0), _lib.ptr(d), d.stride(0), d.size(0), _lib.ptr(t["slot_src"]),
+                                   _lib.ptr(t["slot_dst"]), _lib.ptr(slot_scale) if slot_scale is not None else None,
+                                   _lib.ptr(t["type_tile_ptr"]), tix.num_rels, t["total"], 128, _lib.ptr(part),
+                                   _lib.stream_ptr()), "dmp_rel_atb")
+    return part.sum(1) if blocks > 1 else part[:, 0]
+
+
 class _TypedLinearAgg(th.autograd.Function):
     """``agg[v] = sum_{e: dst(e)=v} w_e * X[src e] @ W[type e]``  (rgcn.py:98-123 + fn.sum).
 
-    One GEMM per type over that type's contiguous row block (forward; two more backward).  A
-    single batched GEMM over equal, padded slices was measured 2.5x slower at BASELINE config 2
-    (hipBLASLt's batched [1024,128]x[128,128] solutions; profiles/r01_rgnn.txt): the typed MFMA
-    kernel (per-tile weight panel in registers) is the planned replacement for this loop."""
+    128 -> 128 layers run on the relation-typed MFMA kernels: the type-sorted edge list in 32-slot tiles that
+    never mix types, the source (backward: destination) rows gathered inside the kernel, the weight panel of the
+    tile's type in registers -- one launch each for the messages, the input gradient and all the weight gradients
+    (``USE_REL_KERNELS``; profiles/r02_rgnn.txt).  Other widths: one library GEMM per type over that type's
+    contiguous row block (a single batched GEMM over equal, padded slices was measured 2.5x slower at BASELINE
+    config 2: profiles/r01_rgnn.txt)."""
 
     @staticmethod
     def forward(ctx, x, weight, tix, w_p):
         _lib.require_gpu(x, weight)
         x = x.contiguous()
+        g = tix.graph
+        ctx.tix, ctx.w_p = tix, w_p
+        ctx.rel = USE_REL_KERNELS and rel_ok(x, weight) and tix.num_edges > 0
+        if ctx.rel:
+            msg = rel_gemm(x, weight, tix.tiles()["slot_src"], tix, w_p)
+            ctx.save_for_backward(x, weight)
+            return ops.seg_sum_raw(msg, g.in_ptr, g.in_ent, tix.num_nodes)
         xg = ops.gather_rows_raw(x, tix.src32p, w_p)                  # [E, in] in type order, w_e applied
         msg = th.empty((tix.num_edges, weight.size(2)), dtype=th.float32, device=x.device)
         for t in range(tix.num_rels):
             lo, hi = tix.bounds[t], tix.bounds[t + 1]
             if hi > lo:
                 th.mm(xg[lo:hi], weight[t], out=msg[lo:hi])
-        g = tix.graph
-        ctx.tix, ctx.w_p = tix, w_p
         ctx.save_for_backward(xg, weight)
         return ops.seg_sum_raw(msg, g.in_ptr, g.in_ent, tix.num_nodes)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_agg):
-        xg, weight = ctx.saved_tensors
         tix, g = ctx.tix, ctx.tix.graph
-        d_msg = ops.gather_rows_raw(d_agg.contiguous(), tix.dst32p)  # [E, out] in type order
+        d_agg = d_agg.contiguous()
+        if ctx.rel:
+            x, weight = ctx.saved_tensors
+            d_xg = rel_gemm(d_agg, weight, tix.tiles()["slot_dst"], tix, ctx.w_p, transposed=True)
+            d_x = ops.seg_sum_raw(d_xg, g.out_ptr, g.out_ent, tix.num_nodes)
+            return d_x, rel_atb(x, d_agg, tix, ctx.w_p), None, None
+        xg, weight = ctx.saved_tensors
+        d_msg = ops.gather_rows_raw(d_agg, tix.dst32p)               # [E, out] in type order
         d_xg = th.empty_like(xg)
         d_w = th.zeros_like(weight)
         for t in range(tix.num_rels):

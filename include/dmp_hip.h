@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 40
+#define DMP_ABI_VERSION 41
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -799,6 +799,32 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
 int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N);
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
                  int64_t rows, int M, int N, float *partial, float *partial_colsum, void *stream);
+
+/*
+ * Relation-typed products of the relational layers (SubgraphCountingMatching/models/rgcn.py:98-123,
+ * rgin.py:100-125: msg_e = X[src e] W[type e] (* norm e), summed by destination; the reference copies the
+ * weights to [E, in, out] with index_select + bmm).  Edges are sorted by type and cut into 32-slot tiles
+ * that never mix types (slot arrays [tiles * 32], -1 = padding; tile_type [tiles]; both in type order):
+ *
+ *   dmp_rel_gemm   C[slot_row[s]] = row_scale[slot_row[s]] * A[slot_arow[s]] W[tile type]     (w_transposed: W^T)
+ *                  forward (A = X by source node, W) and input gradient (A = d_agg by destination, W^T);
+ *                  W [num_rels, 128, ldw >= 128], num_tiles a device scalar <= tiles_bound, row_scale [rows_c] or NULL.
+ *   dmp_rel_atb    partial[t][b] = sum over type t's slots s of workgroup b of
+ *                                  slot_scale[s] * X[slot_x[s]]^T D[slot_d[s]]               ([128,128] each)
+ *                  the per-type weight gradient; type_tile_ptr [num_rels + 1] (device) = first tile of every
+ *                  type, tiles = their total; partial [num_rels, dmp_rel_atb_blocks(num_rels), 128*128], every
+ *                  entry written (zeros for a type without edges); the sum over b in a fixed order is dW[t].
+ * H = in = out = 128 only (DMP_ERR_UNSUPPORTED otherwise; the caller then runs one library GEMM per type).
+ */
+int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, int64_t ldw, int num_rels,
+                 int w_transposed, const int32_t *slot_arow, const int32_t *slot_row,
+                 const int32_t *tile_type, const int32_t *num_tiles, int64_t tiles_bound,
+                 const float *row_scale, int64_t rows_c, int H, float *C, int64_t ldc, void *stream);
+int64_t dmp_rel_atb_blocks(int num_rels);
+int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int64_t ldd, int64_t rows_d,
+                const int32_t *slot_x, const int32_t *slot_d, const float *slot_scale,
+                const int32_t *type_tile_ptr, int num_rels, int64_t tiles, int H, float *partial,
+                void *stream);
 
 /* Several such products over the SAME rows in one launch (the node update's three weight gradients): every job is
  * one 128 x 128 output block  partial[b] = (gate (.) A[:, 0:128])^T B[:, 0:128]  (callers pass column-offset

@@ -26,15 +26,18 @@ def timeit(f, iters=20):
 x = th.randn(n, h, generator=gen).to(gpu).requires_grad_(True)
 w = (th.randn(r, h, h, generator=gen) * 0.1).to(gpu).requires_grad_(True)
 tix = typed_index(g, et, r)
-print("typed_linear_agg fwd      %.3f ms" % timeit(lambda: typed_linear_agg(x.detach(), w.detach(), tix)))
-def fb():
-    x.grad = w.grad = None
-    typed_linear_agg(x, w, tix).square().sum().backward()
-print("typed_linear_agg fwd+bwd  %.3f ms   (algorithmic: 3 x 2EH^2 = %.1f GFLOP, ~%.0f MB of [E,H] rows moved)" % (
-    timeit(fb), 6 * e * h * h / 1e9, 8 * e * h * 4 / 1e6))
-for name, layer in (("RGCNLayer(in)", RGCNLayer(h, h, num_rels=r).to(gpu)), ("RGINLayer", RGINLayer(h, h, num_rels=r).to(gpu))):
-    def step():
-        for p in layer.parameters(): p.grad = None
-        x.grad = None
-        layer(g, x, et)[0].square().sum().backward()
-    print("%-14s fwd+bwd  %.3f ms" % (name, timeit(step)))
+from dualmessagepassing_amd import rgnn
+for flag, label in ((True, "relation-typed MFMA kernels (dmp_rel_gemm / dmp_rel_atb)"), (False, "one library GEMM per type")):
+    rgnn.USE_REL_KERNELS = flag
+    print("--", label)
+    print("typed_linear_agg fwd      %.3f ms" % timeit(lambda: typed_linear_agg(x.detach(), w.detach(), tix)))
+    def fb():
+        x.grad = w.grad = None
+        typed_linear_agg(x, w, tix).square().sum().backward()
+    print("typed_linear_agg fwd+bwd  %.3f ms   (algorithmic: 3 x 2EH^2 = %.1f GFLOP)" % (timeit(fb), 6 * e * h * h / 1e9))
+    for name, layer in (("RGCNLayer(in)", RGCNLayer(h, h, num_rels=r).to(gpu)), ("RGINLayer", RGINLayer(h, h, num_rels=r).to(gpu))):
+        def step():
+            for p in layer.parameters(): p.grad = None
+            x.grad = None
+            layer(g, x, et)[0].square().sum().backward()
+        print("%-14s fwd+bwd  %.3f ms" % (name, timeit(step)))
