@@ -102,6 +102,13 @@ SIGNATURES = {
     "dmp_rel_atb_blocks": (c_i64, [c_int]),
     "dmp_rel_atb": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_atb_typed_blocks": (c_i64, [c_i64]),
+    "dmp_atb_typed_blocks_h": (c_i64, [c_i64, c_int]),
+    "dmp_atb_rows_blocks_h": (c_i64, [c_i64, c_int, c_int, c_int]),
+    "dmp_atb_rows_h": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "dmp_atb_jobs_blocks_h": (c_i64, [c_i64, c_int, c_int]),
+    "dmp_atb_rows_jobs_h": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr]),
+    "dmp_mfma_partial_rows_h": (c_i64, [c_i64, c_int]),
+    "dmp_gemm_k64": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_ptr]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_rows_blocks": (c_i64, [c_i64, c_int, c_int]),
     "dmp_atb_jobs_blocks": (c_i64, [c_i64, c_int]),
@@ -126,7 +133,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 41
+ABI_VERSION = 42
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -1,5 +1,5 @@
-// Weight gradients of the edge chain as tall-skinny products  T = Z^T D  ([E,128]^T [E,128] -> [128,128],
-// the contraction runs over the edges), fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+// Weight gradients of the edge chain as tall-skinny products  T = Z^T D  ([E,H]^T [E,H] -> [H,H] per output block,
+// H = 128 or 64; the contraction runs over the edges), fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
 //
 //   dmp_atb_typed   T = sum_e Z[e]^T dPre[e]  and  B = sum_e c_e Z[e]^T dPre[e]  over the class-sorted tile
 //                   list (c_e = the coefficient of e's degree class): dA' and dB' of the class-typed edge
@@ -11,10 +11,10 @@
 //                   the second edge Linear with the layer's edge gate and its bias gradient fused in
 //                   (dmpnn.py:263-273 backward: dO = gate * dOut, dW2 = dO^T H1, db2 = sum dO).
 //
-// A workgroup (4 waves) owns a contiguous range of 32-row tiles and keeps the running [128,128] total in
-// registers: wave (p, q) holds the 64 x 128 block of output rows 64p.. for the tile's rows 16q..16q+15
-// (8 accumulators; the contraction is split over the two wave pairs so that every LDS operand read feeds
-// 8/6 MFMAs instead of 4/5); the two halves are added through LDS and the total goes to the workgroup's
+// A workgroup (4 waves) owns a contiguous range of 32-row tiles and keeps the running [H,H] total in
+// registers: wave (p, q) holds the H/2 x H block of output rows (H/2)p.. for the tile's rows 16q..16q+15
+// (H = 128: 8 accumulators, H = 64: 2; the contraction is split over the two wave pairs so that every LDS operand
+// read feeds 8/6 MFMAs instead of 4/5); the two halves are added through LDS and the total goes to the workgroup's
 // partial with 16-byte accesses.  Typed: a class that ends inside the range emits  T += acc, B += c * acc
 // and restarts the accumulators (and the load pipeline) -- ranges are contiguous in the class-sorted
 // order, so this happens at most (classes in use) times per launch, and no coefficient-weighted second
@@ -47,19 +47,21 @@ struct AtbArgs {
 
 enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
 
-template <int MODE>
+template <int MODE, int H>
 __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
   constexpr bool TYPED = MODE == ATB_TYPED, REL = MODE == ATB_REL;   // REL: the control flow of the rows variant over gathered rows
-  // two tile buffers (Zs | Ds, 2 x 32 x 132 floats each) = 67584 bytes; emit() reuses the first 64 KB for the [128,128] total
+  // two tile buffers (Zs | Ds, 2 x 32 x (H+4) floats each) = 67584 bytes at H = 128; emit() reuses the first H*H floats for the total
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kTile = kSub * kLdsStride, kBuf = 2 * kTile;
+  constexpr int kStride = H + 4, kQ = H / 4, kPass = kGroupThreads / kQ, NL = kSub / kPass;   // float4 per row, rows per load pass, passes
+  constexpr int NI = H / 64, NJ = H / 32;                                                       // accumulator blocks per wave: NI x NJ
+  constexpr int kTile = kSub * kStride, kBuf = 2 * kTile;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int pw = wave & 1, qw = wave >> 1;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
-  const uint32_t colA = (uint32_t)(gtid & 31) * 16u;
+  const uint32_t colA = (uint32_t)(gtid % kQ) * 16u;
   constexpr uint32_t kOOB = 0xFFFFF000u;
-  const rsrc_t rs_Z = make_rsrc(p.Z + 128 * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + 128) * 4) : 0u);
-  const rsrc_t rs_D = make_rsrc(p.D + 128 * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + 128) * 4) : 0u);
+  const rsrc_t rs_Z = make_rsrc(p.Z + H * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + H) * 4) : 0u);
+  const rsrc_t rs_D = make_rsrc(p.D + H * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + H) * 4) : 0u);
   const bool gated = REL ? p.slot_scale != nullptr : (!TYPED && p.gate != nullptr);
   const rsrc_t rs_G = make_rsrc(p.gate, !REL && gated ? (uint32_t)(p.E * 4) : 0u);
   const int first = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y]) : 0;
@@ -73,16 +75,16 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   const rsrc_t rs_slot = make_rsrc(p.slot_edge, slot_bytes);
   const rsrc_t rs_slotD = make_rsrc(p.slot_d, REL ? slot_bytes : 0u);
   const rsrc_t rs_slotS = make_rsrc(p.slot_scale, REL && gated ? slot_bytes : 0u);
-  float *pt = p.pT + (int64_t)(REL ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x) * p.pstride + (int64_t)ya * 128 * p.ldp + yb * 128;
-  float *const pcs = MODE == ATB_ROWS && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * 128 : nullptr;
+  float *pt = p.pT + (int64_t)(REL ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x) * p.pstride + (int64_t)ya * H * p.ldp + yb * H;
+  float *const pcs = MODE == ATB_ROWS && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * H : nullptr;
   float *pb = TYPED ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;
 
-  f32x16 acc[2][4];
+  f32x16 acc[NI][NJ];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
@@ -91,28 +93,28 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 #ifdef DMP_ATB_DBG
   bool warm = false;
 #endif
-  int id_rows[kSubLoads], id_rowsD[kSubLoads];
-  float sc_rows[kSubLoads];
-  float4 preZ[2][kSubLoads], preD[2][kSubLoads];           // two sets of prefetched rows: tiles of even / odd pipeline phase
-  float preG[2][kSubLoads];
+  int id_rows[NL], id_rowsD[NL];
+  float sc_rows[NL];
+  float4 preZ[2][NL], preD[2][NL];                         // two sets of prefetched rows: tiles of even / odd pipeline phase
+  float preG[2][NL];
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);             // gated: this thread's 4 columns of sum g (.) Z
   auto load_ids = [&](int k) {
     const bool ok = k < mine;
     if (TYPED || REL) {
       const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
 #pragma unroll
-      for (int m = 0; m < kSubLoads; ++m) {
-        id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+      for (int m = 0; m < NL; ++m) {
+        id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, ((gtid / kQ) + kPass * m) * 4, (int)so, 0) : -1;
         if (REL) {
-          id_rowsD[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotD, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+          id_rowsD[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotD, ((gtid / kQ) + kPass * m) * 4, (int)so, 0) : -1;
           sc_rows[m] = 1.f;
-          if (gated) sc_rows[m] = ok ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_slotS, ((gtid >> 5) + 8 * m) * 4, (int)so, 0)) : 0.f;
+          if (gated) sc_rows[m] = ok ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_slotS, ((gtid / kQ) + kPass * m) * 4, (int)so, 0)) : 0.f;
         }
       }
     } else {
 #pragma unroll
-      for (int m = 0; m < kSubLoads; ++m) {
-        const int64_t r = (int64_t)(lo + k) * kSub + (gtid >> 5) + 8 * m;
+      for (int m = 0; m < NL; ++m) {
+        const int64_t r = (int64_t)(lo + k) * kSub + (gtid / kQ) + kPass * m;
         id_rows[m] = ok && r < p.E ? (int)r : -1;
       }
     }
@@ -134,11 +136,11 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   };
   auto load_rows = [&](auto set) {
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) load_row(set, m);
+    for (int m = 0; m < NL; ++m) load_row(set, m);
   };
   auto stage_row = [&](auto set, int m) {                   // slice m of row set S -> tile buffer S
     constexpr int S = decltype(set)::value;
-    const int o = S * kBuf + ((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4;
+    const int o = S * kBuf + ((gtid / kQ) + kPass * m) * kStride + (gtid % kQ) * 4;
     float4 z = preZ[S][m];
     if (REL) {
       if (gated) z = make_float4(z.x * preG[S][m], z.y * preG[S][m], z.z * preG[S][m], z.w * preG[S][m]);
@@ -153,7 +155,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   };
   auto stage = [&](auto set) {
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) stage_row(set, m);
+    for (int m = 0; m < NL; ++m) stage_row(set, m);
   };
   // One tile of pipeline phase PH (tiles alternate between the two LDS buffers / row sets, counted from the last
   // start_at): the MFMAs of tile k (buffer PH) with, in their shadow, the staging of tile k+1 into the other
@@ -165,41 +167,43 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   auto tile_step = [&](int k, auto phase) {
     constexpr int PH = decltype(phase)::value;
     std::integral_constant<int, PH ^ 1> other;
-    const float *zp = &smem[PH * kBuf + (16 * qw + 8 * h) * kLdsStride + 64 * pw + li];
-    const float *dp = zp + kTile - 64 * pw;
-    float a0 = zp[0], a1 = zp[32], b0 = dp[0], b1 = dp[32], b2 = dp[64], b3 = dp[96];
+    const float *zp = &smem[PH * kBuf + (16 * qw + 8 * h) * kStride + (H / 2) * pw + li];
+    const float *dp = zp + kTile - (H / 2) * pw;
+    float a[NI], b[NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a[i] = zp[32 * i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = dp[32 * j];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      float x0 = a0, x1 = a1, y0 = b0, y1 = b1, y2 = b2, y3 = b3;
-      if (s + 1 < 8) {
-        x0 = zp[(s + 1) * kLdsStride]; x1 = zp[(s + 1) * kLdsStride + 32];
-        y0 = dp[(s + 1) * kLdsStride]; y1 = dp[(s + 1) * kLdsStride + 32];
-        y2 = dp[(s + 1) * kLdsStride + 64]; y3 = dp[(s + 1) * kLdsStride + 96];
-      }
+      float x[NI], y[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) x[i] = s + 1 < 8 ? zp[(s + 1) * kStride + 32 * i] : a[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) y[j] = s + 1 < 8 ? dp[(s + 1) * kStride + 32 * j] : b[j];
       __builtin_amdgcn_sched_barrier(0);
 #ifdef DMP_ATB_DBG
       if (!(DMP_ATB_DBG & 4)) {
 #endif
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
-      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
-      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
 #ifdef DMP_ATB_DBG
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      if (s < 4) stage_row(other, s);
-      else load_row(other, s - 4);
+      if (s < NL) stage_row(other, s < NL ? s : 0);
+      else if (s < 2 * NL) load_row(other, s < 2 * NL ? s - NL : 0);
       if (s == 7) load_ids(k + 4);
-      a0 = x0; a1 = x1; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = x[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = y[j];
     }
   };
-  // accumulator (i, j, r) of wave (p, q): output row 64p + 32i + (r&3) + 8(r>>2) + 4h, column 32j + li
-  auto out_index = [&](int i, int j, int r) { return (64 * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + 32 * j + li; };
+  // accumulator (i, j, r) of wave (p, q): output row (H/2)p + 32i + (r&3) + 8(r>>2) + 4h, column 32j + li
+  auto out_index = [&](int i, int j, int r) { return ((H / 2) * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * H + 32 * j + li; };
 
   // Emit the accumulators: the two row halves are added through LDS (which must be free: the staged tile is
   // given up), then every thread adds its 16 float4 of the [128,128] total to the workgroup's partial --
@@ -210,18 +214,18 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     __syncthreads();
     if (qw == 1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) smem[out_index(i, j, r)] = acc[i][j][r];
     }
     __syncthreads();
     if (qw == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = out_index(i, j, r);
@@ -230,10 +234,10 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     }
     __syncthreads();
 #pragma unroll 4
-    for (int m = 0; m < 16; ++m) {
-      const int l = (m * kGroupThreads + gtid) * 4;         // element (l / 128, l % 128) of the total
+    for (int m = 0; m < H * H / (4 * kGroupThreads); ++m) {
+      const int l = (m * kGroupThreads + gtid) * 4;         // element (l / H, l % H) of the total
       const float4 v = *reinterpret_cast<const float4 *>(&smem[l]);
-      const int o = (l >> 7) * p.ldp + (l & 127);
+      const int o = (l / H) * p.ldp + (l % H);
       float4 t = v, b = make_float4(c * v.x, c * v.y, c * v.z, c * v.w);
       if (emitted) {
         const float4 t0 = *reinterpret_cast<const float4 *>(pt + o);
@@ -313,13 +317,13 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   if (!TYPED && pcs) {
     // column sums: the 8 threads that staged the same 4 columns, added in a fixed order
     __syncthreads();
-    *reinterpret_cast<float4 *>(&smem[(gtid >> 5) * 128 + (gtid & 31) * 4]) = cs;
+    *reinterpret_cast<float4 *>(&smem[(gtid / kQ) * H + (gtid % kQ) * 4]) = cs;
     __syncthreads();
-    if (gtid < 32) {
+    if (gtid < kQ) {
       float4 t = *reinterpret_cast<const float4 *>(&smem[gtid * 4]);
 #pragma unroll
-      for (int g = 1; g < 8; ++g) {
-        const float4 u = *reinterpret_cast<const float4 *>(&smem[g * 128 + gtid * 4]);
+      for (int g = 1; g < kPass; ++g) {
+        const float4 u = *reinterpret_cast<const float4 *>(&smem[g * H + gtid * 4]);
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
       *reinterpret_cast<float4 *>(pcs + gtid * 4) = t;
@@ -327,9 +331,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   }
 }
 
-template <int MODE>
+template <int MODE, int H = 128>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  atb_body<MODE>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
+  atb_body<MODE, H>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
 }
 
 // Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
@@ -338,22 +342,46 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
 // start, LDS reduction, 64 KB partial) are paid 512 times in total instead of 512 times per product.
 constexpr int kMaxAtbJobs = DMP_ATB_MAX_JOBS;
 struct AtbJobs { AtbArgs job[kMaxAtbJobs]; };
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS>(t.job[blockIdx.y], 0, 0); }
+template <int H>
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS, H>(t.job[blockIdx.y], 0, 0); }
 
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
-template <int MODE>
+constexpr int kAtbLdsBytes64 = 2 * 2 * kSub * 68 * 4;         // H = 64: 34816
+constexpr int atb_lds_bytes(int H) { return H == 128 ? kAtbLdsBytes : kAtbLdsBytes64; }
+template <int MODE, int H = 128>
 bool lds_ready() {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<MODE>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAtbLdsBytes);
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<MODE, H>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, atb_lds_bytes(H));
   if (e != hipSuccess) set_last_hip_error(e);
   return e == hipSuccess;
 }
 
-inline unsigned atb_blocks(int64_t tiles) {
-  const int64_t cap = 256 * 2;                             // two resident workgroups per CU
+inline unsigned atb_blocks(int64_t tiles, int H = 128) {
+  const int64_t cap = 256 * (H == 64 ? 4 : 2);             // resident workgroups per CU: two (H = 128), four (H = 64)
   return (unsigned)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
+
+// one wave of workgroups over all (a, b) output blocks together
+static unsigned rows_blocks(int64_t rows, int M, int N, int H) {
+  const int64_t tiles = (rows + kSub - 1) / kSub, nblk = (int64_t)(M / H) * (N / H);
+  int64_t g = (H == 64 ? 1024 : 512) / (nblk > 0 ? nblk : 1);
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles > 0 ? tiles : 1;
+  return (unsigned)g;
+}
+
+
+template <int H>
+static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStream_t st) {
+  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_jobs_k<H>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, atb_lds_bytes(H));
+  if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
+  const dim3 grid(rows_blocks(rows, H, H * (num_jobs > 0 ? num_jobs : 1), H), (unsigned)num_jobs);
+  atb_jobs_k<H><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
+  return check_launch();
+}
+
 
 }  // namespace
 }  // namespace dmp
@@ -363,11 +391,13 @@ using namespace dmp;
 extern "C" {
 
 int64_t dmp_atb_typed_blocks(int64_t tiles_bound) { return (int64_t)atb_blocks(tiles_bound); }
+int64_t dmp_atb_typed_blocks_h(int64_t tiles_bound, int H) { return (int64_t)atb_blocks(tiles_bound, H == 64 ? 64 : 128); }
 
 int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, const int32_t *slot_edge,
                   const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H,
                   float *partial_T, float *partial_B, void *stream) {
-  if (E < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (!partial_T || !partial_B || !num_tiles || !slot_edge || !tile_scale) return DMP_ERR_BAD_ARG;
   if (E > 0 && (!Z || !dPre || ldz < H || ldp < H)) return DMP_ERR_BAD_ARG;
   if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre))) || !aligned16(partial_T) || !aligned16(partial_B))
@@ -376,33 +406,35 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   AtbArgs a{};
   a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
   a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
-  const bool wide = partial_B == partial_T + 128;          // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
-  a.pstride = wide ? 2 * 128 * 128 : 128 * 128;
-  a.ldp = wide ? 256 : 128;
-  if (!lds_ready<ATB_TYPED>()) return DMP_ERR_HIP;
-  atb_k<ATB_TYPED><<<atb_blocks(tiles_bound), kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  const bool wide = partial_B == partial_T + H;            // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
+  a.pstride = wide ? 2 * H * H : H * H;
+  a.ldp = wide ? 2 * H : H;
+  if (H == 128) {
+    if (!lds_ready<ATB_TYPED, 128>()) return DMP_ERR_HIP;
+    atb_k<ATB_TYPED, 128><<<atb_blocks(tiles_bound), kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
+  } else {
+    if (!lds_ready<ATB_TYPED, 64>()) return DMP_ERR_HIP;
+    atb_k<ATB_TYPED, 64><<<atb_blocks(tiles_bound, 64), kGroupThreads, atb_lds_bytes(64), (hipStream_t)stream>>>(a);
+  }
   return check_launch();
 }
 
-// one wave of workgroups over all (a, b) output blocks together
-static unsigned rows_blocks(int64_t rows, int M, int N) {
-  const int64_t tiles = (rows + kSub - 1) / kSub, nblk = (int64_t)(M / 128) * (N / 128);
-  int64_t g = 512 / (nblk > 0 ? nblk : 1);
-  if (g < 1) g = 1;
-  if (g > tiles) g = tiles > 0 ? tiles : 1;
-  return (unsigned)g;
+int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H) { return (int64_t)rows_blocks(rows, M, N, H == 64 ? 64 : 128); }
+int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N) { return dmp_atb_rows_blocks_h(rows, M, N, 128); }
+
+int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H) {
+  const int h = H == 64 ? 64 : 128;
+  return (int64_t)rows_blocks(rows, h, h * (num_jobs > 0 ? num_jobs : 1), h);
 }
+int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs) { return dmp_atb_jobs_blocks_h(rows, num_jobs, 128); }
 
-int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N) { return (int64_t)rows_blocks(rows, M, N); }
-
-int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs) { return (int64_t)rows_blocks(rows, 128, 128 * (num_jobs > 0 ? num_jobs : 1)); }
-
-int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream) {
+int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream) {
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || num_jobs < 1 || num_jobs > kMaxAtbJobs || !jobs) return DMP_ERR_BAD_ARG;
   AtbJobs t;
   for (int i = 0; i < num_jobs; ++i) {
     const dmp_atb_job &j = jobs[i];
-    if (!j.partial || (rows > 0 && (!j.A || !j.B || j.lda < 128 || j.ldb < 128)) || j.ldp < 128) return DMP_ERR_BAD_ARG;
+    if (!j.partial || (rows > 0 && (!j.A || !j.B || j.lda < H || j.ldb < H)) || j.ldp < H) return DMP_ERR_BAD_ARG;
     if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial) ||
         (j.partial_colsum && !aligned16(j.partial_colsum)))
       return DMP_ERR_UNSUPPORTED;
@@ -413,12 +445,11 @@ int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void 
     a.nb = 1; a.cs_ld = j.cs_ld;
     t.job[i] = a;
   }
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_jobs_k),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAtbLdsBytes);
-  if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
-  const dim3 grid((unsigned)dmp_atb_jobs_blocks(rows, num_jobs), (unsigned)num_jobs);
-  atb_jobs_k<<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(t);
-  return check_launch();
+  return H == 128 ? atb_jobs_launch<128>(t, num_jobs, rows, (hipStream_t)stream) : atb_jobs_launch<64>(t, num_jobs, rows, (hipStream_t)stream);
+}
+
+int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream) {
+  return dmp_atb_rows_jobs_h(jobs, num_jobs, rows, 128, stream);
 }
 
 int64_t dmp_rel_atb_blocks(int num_rels) { return num_rels >= 512 ? 1 : 512 / (num_rels > 0 ? num_rels : 1); }
@@ -435,16 +466,17 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
   a.Z = X; a.ldz = ldx; a.D = D; a.ldd = ldd; a.E = rows_x > rows_d ? rows_x : rows_d;
   a.slot_edge = slot_x; a.slot_d = slot_d; a.slot_scale = slot_scale; a.type_tile_ptr = type_tile_ptr;
   a.plain_tiles = (int)tiles; a.pT = partial; a.pstride = 128 * 128; a.ldp = 128;
-  if (!lds_ready<ATB_REL>()) return DMP_ERR_HIP;
+  if (!lds_ready<ATB_REL, 128>()) return DMP_ERR_HIP;
   const dim3 grid((unsigned)dmp_rel_atb_blocks(num_rels), (unsigned)num_rels);
-  atb_k<ATB_REL><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  atb_k<ATB_REL, 128><<<grid, kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
   return check_launch();
 }
 
-int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
-                 float *partial, float *partial_colsum, void *stream) {
+int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N, int H,
+                   float *partial, float *partial_colsum, void *stream) {
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || M <= 0 || N <= 0) return DMP_ERR_BAD_ARG;
-  if (M % 128 || N % 128 || (int64_t)(M / 128) * (N / 128) > 65535) return DMP_ERR_UNSUPPORTED;
+  if (M % H || N % H || (int64_t)(M / H) * (N / H) > 65535) return DMP_ERR_UNSUPPORTED;
   if (!partial) return DMP_ERR_BAD_ARG;
   if (rows > 0 && (!A || !B || lda < M || ldb < N)) return DMP_ERR_BAD_ARG;
   if (lda % 4 || ldb % 4 || (rows > 0 && (!aligned16(A) || !aligned16(B))) || !aligned16(partial) ||
@@ -453,11 +485,21 @@ int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const
   if (!fits32(rows, lda) || !fits32(rows, ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
-  a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / 128; a.cs_ld = M;
-  if (!lds_ready<ATB_ROWS>()) return DMP_ERR_HIP;
-  const dim3 grid(rows_blocks(rows, M, N), (unsigned)((M / 128) * (N / 128)));
-  atb_k<ATB_ROWS><<<grid, kGroupThreads, kAtbLdsBytes, (hipStream_t)stream>>>(a);
+  a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / H; a.cs_ld = M;
+  const dim3 grid(rows_blocks(rows, M, N, H), (unsigned)((M / H) * (N / H)));
+  if (H == 128) {
+    if (!lds_ready<ATB_ROWS, 128>()) return DMP_ERR_HIP;
+    atb_k<ATB_ROWS, 128><<<grid, kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
+  } else {
+    if (!lds_ready<ATB_ROWS, 64>()) return DMP_ERR_HIP;
+    atb_k<ATB_ROWS, 64><<<grid, kGroupThreads, atb_lds_bytes(64), (hipStream_t)stream>>>(a);
+  }
   return check_launch();
+}
+
+int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
+                 float *partial, float *partial_colsum, void *stream) {
+  return dmp_atb_rows_h(A, lda, B, ldb, gate, rows, M, N, 128, partial, partial_colsum, stream);
 }
 
 }  // extern "C"

@@ -9,7 +9,7 @@
 //                      kernels read (Bn [2H,H], bn [H], Wx [H,3H], Wes [H,2H], be [H])
 //   dmp_unfold_layers  the backward: dM = dC W0 (row jobs, with the +-d(src-dst) terms folded in) and
 //                      dW0 = dC^T M (column jobs over the gathered block rows)
-// H = 128 only (one 128-wide output panel per job).  Nothing here is bandwidth-relevant; the point is the launch
+// H = 128 or 64 (one H-wide output panel per job).  Nothing here is bandwidth-relevant; the point is the launch
 // count and the length of each workgroup's chain of dependent L2 round trips: the products run on the fp32 MFMA pipe
 // with every lane requesting its operands in the MFMA layout in one batch (no staged LDS slices).
 #include <initializer_list>
@@ -19,10 +19,8 @@
 namespace dmp {
 namespace {
 
-constexpr int kH = 128;
 constexpr int kThreads = 256;
 constexpr int kRowsPerWG = 16;
-constexpr int kPad = 132;
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
@@ -37,7 +35,10 @@ struct RowJob {
 constexpr int kMaxRowJobs = 13 * DMP_FOLD_MAX_LAYERS;   // fold: 9 + 4 optional transposes per layer; unfold: 8
 struct RowJobs { RowJob job[kMaxRowJobs]; int blk0[kMaxRowJobs + 1]; int n; };
 
+template <int kH>
 __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
+  constexpr int kPad = kH + 4, kQ = kH / 4, kPass = kThreads / kQ;   // LDS row stride, float4 per row, rows per staging pass
+  constexpr int NT = kH / 64, NKB = kH / 16, CW = kH / 16;           // 16-column tiles per wave, k blocks, output columns per thread
   __shared__ float As[kRowsPerWG * kPad];
   __shared__ float Ws[kRowsPerWG * kPad];
   int q = 0;
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
   const RowJob &jb = t.job[q];
   const int i0 = ((int)blockIdx.x - t.blk0[q]) * kRowsPerWG;
   const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15;
-  // the 16 x 128 operand rows (zero past the job's rows)
+  // the 16 x H operand rows (zero past the job's rows)
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
+  for (int m = 0; m < kRowsPerWG / kPass; ++m) {
+    const int row = tid / kQ + kPass * m, c4 = (tid % kQ) * 4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i0 + row < jb.rows) {
       a = ldg4(jb.A + (int64_t)(i0 + row) * jb.lda + c4);
@@ -59,17 +60,17 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
     }
     *reinterpret_cast<float4 *>(&As[row * kPad + c4]) = a;
   }
-  // 16 x 128 x 128 on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32; wave w owns output columns 32 w .. 32 w + 31): every lane
+  // 16 x H x H on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32; wave w owns output columns (H/4) w .. (H/4) w + H/4 - 1): every lane
   // requests its share of the whole weight panel in one batch of loads, straight in the operand layout (one L2 round trip
   // instead of one per 32-deep LDS slice); lane (m, kq) contracts k = 16 kb + 4 kq .. + 3 of block kb
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = tid & 63, wave = tid >> 6, mm = lane & 15, kq = lane >> 4;
-  float4 bw[2][8];
+  float4 bw[NT][NKB];
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int n = wave * 32 + tt * 16 + mm;
+  for (int tt = 0; tt < NT; ++tt) {
+    const int n = wave * (16 * NT) + tt * 16 + mm;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       const int k = kb * 16 + 4 * kq;
       if (jb.wT) {
         float4 w = ldg4(jb.W + n * kH + k);
@@ -85,12 +86,14 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
     }
   }
   __syncthreads();
-  f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 d[NT];
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
+  for (int tt = 0; tt < NT; ++tt) d[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
     const float4 a = *reinterpret_cast<const float4 *>(&As[mm * kPad + kb * 16 + 4 * kq]);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < NT; ++tt) {
       d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[tt][kb].x, d[tt], 0, 0, 0);
       d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[tt][kb].y, d[tt], 0, 0, 0);
       d[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[tt][kb].z, d[tt], 0, 0, 0);
@@ -98,26 +101,20 @@ __global__ __launch_bounds__(kThreads) void rowjob_k(const RowJobs t) {
     }
   }
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * 32 + tt * 16 + mm] = d[tt][i];
+    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * (16 * NT) + tt * 16 + mm] = d[tt][i];
   __syncthreads();
-  float acc[8];
-  {
-    const float4 o0 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8]);
-    const float4 o1 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8 + 4]);
-    acc[0] = o0.x; acc[1] = o0.y; acc[2] = o0.z; acc[3] = o0.w;
-    acc[4] = o1.x; acc[5] = o1.y; acc[6] = o1.z; acc[7] = o1.w;
-  }
   if (i0 + r < jb.rows) {
-    if (jb.addv) {
-      const float4 v0 = ldg4(jb.addv + cg * 8), v1 = ldg4(jb.addv + cg * 8 + 4);
-      acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
-      acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+#pragma unroll
+    for (int v = 0; v < CW / 4; ++v) {                      // thread (r, cg): CW consecutive columns of row r
+      float4 o4 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * CW + 4 * v]);
+      if (jb.addv) {
+        const float4 a4 = ldg4(jb.addv + cg * CW + 4 * v);
+        o4.x += a4.x; o4.y += a4.y; o4.z += a4.z; o4.w += a4.w;
+      }
+      *reinterpret_cast<float4 *>(jb.out + (int64_t)(i0 + r) * jb.ldo + cg * CW + 4 * v) = o4;
     }
-    float *o = jb.out + (int64_t)(i0 + r) * jb.ldo + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
 }
 
@@ -129,6 +126,7 @@ struct ColJobs { ColJob job[kMaxColJobs]; int n; };
 
 constexpr int kColW = 16;                                   // one 16 x 16 output tile per workgroup: 64 workgroups per job
 constexpr int kColSteps = 8;                                // MFMA steps (x 4 block rows x 4 waves = 128 rows) per batch of loads
+template <int kH>
 __global__ __launch_bounds__(kThreads) void coljob_k(const ColJobs t) {
   // fp32 MFMA (v_mfma_f32_16x16x4_f32 contracts four block rows per instruction): the four waves take interleaved groups
   // of four rows, every lane requests the operands of a 128-row batch in one go, a batch (or source) ahead of the one
@@ -204,7 +202,8 @@ extern "C" {
 
 int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int num_layers, int H, void *stream) {
   if (num_layers < 0 || (num_layers > 0 && (!w || !f))) return DMP_ERR_BAD_ARG;
-  if (H != kH) return DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  const int kH = H;
   for (int l0 = 0; l0 < num_layers; l0 += DMP_FOLD_MAX_LAYERS) {
     RowJobs t;
     t.n = 0;
@@ -239,7 +238,8 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
       if (o.nW2t && a.nW2 && a.eye) add_row_job(t, blocks, a.eye, kH, nullptr, 0, 0.f, a.nW2, 1, o.nW2t, kH, nullptr, kH);
       if (o.eW2t && a.eW2 && a.eye) add_row_job(t, blocks, a.eye, kH, nullptr, 0, 0.f, a.eW2, 1, o.eW2t, kH, nullptr, kH);
     }
-    rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    if (H == 128) rowjob_k<128><<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    else rowjob_k<64><<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
     const int rc = check_launch();
     if (rc != DMP_OK) return rc;
   }
@@ -249,7 +249,8 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
 int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *g, const dmp_layer_weight_grads *d,
                       int num_layers, int H, void *stream) {
   if (num_layers < 0 || (num_layers > 0 && (!w || !g || !d))) return DMP_ERR_BAD_ARG;
-  if (H != kH) return DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  const int kH = H;
   for (int l0 = 0; l0 < num_layers; l0 += DMP_FOLD_MAX_LAYERS) {
     RowJobs t;
     ColJobs c;
@@ -288,10 +289,12 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
       e.src[3] = ColSrc{u.dWx + 2 * kH, a.src_w, nullptr, 3 * kH, kH};
       e.src[4] = ColSrc{u.dbe, a.ebias, nullptr, kH, 1};
     }
-    rowjob_k<<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    if (H == 128) rowjob_k<128><<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
+    else rowjob_k<64><<<blocks, kThreads, 0, (hipStream_t)stream>>>(t);
     int rc = check_launch();
     if (rc != DMP_OK) return rc;
-    coljob_k<<<c.n * (kH / kRowsPerWG) * (kH / kColW), kThreads, 0, (hipStream_t)stream>>>(c);
+    if (H == 128) coljob_k<128><<<c.n * (kH / kRowsPerWG) * (kH / kColW), kThreads, 0, (hipStream_t)stream>>>(c);
+    else coljob_k<64><<<c.n * (kH / kRowsPerWG) * (kH / kColW), kThreads, 0, (hipStream_t)stream>>>(c);
     rc = check_launch();
     if (rc != DMP_OK) return rc;
   }

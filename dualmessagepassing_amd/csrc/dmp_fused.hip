@@ -292,26 +292,45 @@ constexpr int kSmallK = 16;
 constexpr int kSmallRows = 4;                                 // rows in flight per wave (the loop is one memory round trip per batch)
 struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial; };
 
-template <int K>
+// VW = H / 64 values per lane: 2 (H = 128, one float2 per lane) or 1 (H = 64)
+template <int VW> struct LaneVec { float v[VW]; };
+template <int VW> __device__ __forceinline__ LaneVec<VW> lane_load(const float *row, int lane) {
+  LaneVec<VW> o;
+  if (VW == 2) { const float2 t = *reinterpret_cast<const float2 *>(row + lane * 2); o.v[0] = t.x; o.v[VW - 1] = t.y; }
+  else o.v[0] = row[lane];
+  return o;
+}
+template <int VW> __device__ __forceinline__ void lane_store(float *row, int lane, const LaneVec<VW> &o) {
+  if (VW == 2) *reinterpret_cast<float2 *>(row + lane * 2) = make_float2(o.v[0], o.v[VW - 1]);
+  else row[lane] = o.v[0];
+}
+
+template <int K, int VW>
 __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
-  constexpr int WPB = kBlock / 64, kRows = kSmallRows;
-  __shared__ float2 red[kBlock];
+  constexpr int WPB = kBlock / 64, kRows = kSmallRows, H = 64 * VW;
+  __shared__ float red[kBlock * VW];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  float2 acc[K];
+  LaneVec<VW> acc[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) acc[k] = make_float2(0.f, 0.f);
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < VW; ++c) acc[k].v[c] = 0.f;
   const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
   // lanes 0..K-1 fetch a row's inputs, lane K its gate (one load each); the values are read back lane by lane
   // into wave-uniform operands (v_readlane: no memory traffic, no LDS).  The next batch's loads are issued
   // before the current batch's FMAs.
-  float2 d[kRows], dn[kRows];
+  LaneVec<VW> d[kRows], dn[kRows];
   float mine[kRows], minen[kRows];
-  auto load_batch = [&](int64_t r0, float2 (&dd)[kRows], float (&mm)[kRows]) {
+  auto load_batch = [&](int64_t r0, LaneVec<VW> (&dd)[kRows], float (&mm)[kRows]) {
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      dd[u] = ok ? *reinterpret_cast<const float2 *>(p.D + r * p.ldd + lane * 2) : make_float2(0.f, 0.f);
+      if (ok) dd[u] = lane_load<VW>(p.D + r * p.ldd, lane);
+      else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) dd[u].v[c] = 0.f;
+      }
       // one load instruction for both: lanes < K point into the row of X, lane K at the row's gate
       const float *src = lane < K ? p.X + r * p.ldx + lane : p.gate + r;
       float m = (lane == K && !p.gate) ? 1.f : 0.f;
@@ -332,8 +351,8 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
         const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scaled), k));
         // v_fmac with the wave-uniform operand straight from its SGPR (the compiler would broadcast it into a
         // VGPR pair for a packed FMA: two extra moves per FMA in a VALU-bound loop); a sum: no order to keep
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k].x) : "s"(x), "v"(d[u].x));
-        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k].y) : "s"(x), "v"(d[u].y));
+#pragma unroll
+        for (int c = 0; c < VW; ++c) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k].v[c]) : "s"(x), "v"(d[u].v[c]));
       }
     }
 #pragma unroll
@@ -342,13 +361,18 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   // fixed-order combine of the 4 waves, one k at a time
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    red[threadIdx.x] = acc[k];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) red[threadIdx.x * VW + c] = acc[k].v[c];
     __syncthreads();
     if (wave == 0) {
-      float2 t = red[lane];
+      LaneVec<VW> t;
 #pragma unroll
-      for (int w = 1; w < WPB; ++w) { t.x += red[w * 64 + lane].x; t.y += red[w * 64 + lane].y; }
-      *reinterpret_cast<float2 *>(p.partial + ((int64_t)blockIdx.x * K + k) * 128 + lane * 2) = t;
+      for (int c = 0; c < VW; ++c) {
+        t.v[c] = red[lane * VW + c];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) t.v[c] += red[(w * 64 + lane) * VW + c];
+      }
+      lane_store<VW>(p.partial + ((int64_t)blockIdx.x * K + k) * H, lane, t);
     }
     __syncthreads();
   }
@@ -356,16 +380,16 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
 
 // The forward of the same narrow layer with its gate:  out[r, :] = gate[r] * sum_k X[r, k] W[k, :]  -- the gated
 // embedding rows written straight into their place (the union buffer of the joint rep-net pass) from the K
-// inputs per row instead of from the [R, 128] embedding.  W lives in registers (float2 per lane and input).
+// inputs per row instead of from the [R, H] embedding.  W lives in registers (H / 64 values per lane and input).
 struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo; };
 
-template <int K>
+template <int K, int VW>
 __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) {
   constexpr int WPB = kBlock / 64, kRows = kSmallRows;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  float2 w[K];
+  LaneVec<VW> w[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) w[k] = *reinterpret_cast<const float2 *>(p.W + k * p.ldw + lane * 2);
+  for (int k = 0; k < K; ++k) w[k] = lane_load<VW>(p.W + k * p.ldw, lane);
   const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
   for (int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows; r0 < p.R; r0 += stride) {
     float mine[kRows];
@@ -383,21 +407,27 @@ __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) 
       const int64_t r = r0 + u;
       if (r >= p.R) break;
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
-      float2 e = make_float2(0.f, 0.f);
+      LaneVec<VW> e;
+#pragma unroll
+      for (int c = 0; c < VW; ++c) e.v[c] = 0.f;
 #pragma unroll
       for (int k = 0; k < K; ++k) {                         // sum over k ascending, then the gate: (X W) * gate as the reference
         const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), k));
-        e.x += x * w[k].x; e.y += x * w[k].y;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) e.v[c] += x * w[k].v[c];
       }
-      *reinterpret_cast<float2 *>(p.out + r * p.ldo + lane * 2) = make_float2(e.x * g, e.y * g);
+#pragma unroll
+      for (int c = 0; c < VW; ++c) e.v[c] *= g;
+      lane_store<VW>(p.out + r * p.ldo, lane, e);
     }
   }
 }
 
 template <int K>
-void launch_smallk_fwd(const SmallKFwdArgs &p, hipStream_t st) {
+void launch_smallk_fwd(const SmallKFwdArgs &p, int H, hipStream_t st) {
   const int64_t chunk = (int64_t)(kBlock / 64) * kSmallRows, nb = (p.R + chunk - 1) / chunk;
-  smallk_embed_k<K><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
+  if (H == 128) smallk_embed_k<K, 2><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
+  else smallk_embed_k<K, 1><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
 }
 
 inline unsigned smallk_blocks(int64_t R) {
@@ -406,7 +436,10 @@ inline unsigned smallk_blocks(int64_t R) {
 }
 
 template <int K>
-void launch_smallk(const SmallKArgs &p, hipStream_t st) { smallk_atb_k<K><<<smallk_blocks(p.R), kBlock, 0, st>>>(p); }
+void launch_smallk(const SmallKArgs &p, int H, hipStream_t st) {
+  if (H == 128) smallk_atb_k<K, 2><<<smallk_blocks(p.R), kBlock, 0, st>>>(p);
+  else smallk_atb_k<K, 1><<<smallk_blocks(p.R), kBlock, 0, st>>>(p);
+}
 
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
 
@@ -524,21 +557,21 @@ int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)smallk_blocks(rows
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,
                    float *partial, void *stream) {
   DMP_ROW_CHECK(R >= 0 && K > 0 && partial);
-  if (H != 128 || K > kSmallK) return DMP_ERR_UNSUPPORTED;
-  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)K * 128, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)K * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   DMP_ROW_CHECK(X && D && ldx >= K && ldd >= H);
   if (ldd % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {   // K is a compile-time constant of the kernel: the accumulators live in registers
-    case 1: launch_smallk<1>(p, st); break;   case 2: launch_smallk<2>(p, st); break;
-    case 3: launch_smallk<3>(p, st); break;   case 4: launch_smallk<4>(p, st); break;
-    case 5: launch_smallk<5>(p, st); break;   case 6: launch_smallk<6>(p, st); break;
-    case 7: launch_smallk<7>(p, st); break;   case 8: launch_smallk<8>(p, st); break;
-    case 9: launch_smallk<9>(p, st); break;   case 10: launch_smallk<10>(p, st); break;
-    case 11: launch_smallk<11>(p, st); break; case 12: launch_smallk<12>(p, st); break;
-    case 13: launch_smallk<13>(p, st); break; case 14: launch_smallk<14>(p, st); break;
-    case 15: launch_smallk<15>(p, st); break; default: launch_smallk<16>(p, st); break;
+    case 1: launch_smallk<1>(p, H, st); break;   case 2: launch_smallk<2>(p, H, st); break;
+    case 3: launch_smallk<3>(p, H, st); break;   case 4: launch_smallk<4>(p, H, st); break;
+    case 5: launch_smallk<5>(p, H, st); break;   case 6: launch_smallk<6>(p, H, st); break;
+    case 7: launch_smallk<7>(p, H, st); break;   case 8: launch_smallk<8>(p, H, st); break;
+    case 9: launch_smallk<9>(p, H, st); break;   case 10: launch_smallk<10>(p, H, st); break;
+    case 11: launch_smallk<11>(p, H, st); break; case 12: launch_smallk<12>(p, H, st); break;
+    case 13: launch_smallk<13>(p, H, st); break; case 14: launch_smallk<14>(p, H, st); break;
+    case 15: launch_smallk<15>(p, H, st); break; default: launch_smallk<16>(p, H, st); break;
   }
   return check_launch();
 }
@@ -546,21 +579,21 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
 int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
                           int H, float *out, int64_t ldo, void *stream) {
   DMP_ROW_CHECK(R >= 0 && K > 0);
-  if (H != 128 || K > kSmallK) return DMP_ERR_UNSUPPORTED;
+  if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return DMP_OK;
   DMP_ROW_CHECK(X && W && out && ldx >= K && ldw >= H && ldo >= H);
   if (ldw % 2 || ldo % 2 || (reinterpret_cast<uintptr_t>(W) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return DMP_ERR_UNSUPPORTED;
   SmallKFwdArgs p{X, ldx, W, ldw, gate, R, out, ldo};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 1: launch_smallk_fwd<1>(p, st); break;   case 2: launch_smallk_fwd<2>(p, st); break;
-    case 3: launch_smallk_fwd<3>(p, st); break;   case 4: launch_smallk_fwd<4>(p, st); break;
-    case 5: launch_smallk_fwd<5>(p, st); break;   case 6: launch_smallk_fwd<6>(p, st); break;
-    case 7: launch_smallk_fwd<7>(p, st); break;   case 8: launch_smallk_fwd<8>(p, st); break;
-    case 9: launch_smallk_fwd<9>(p, st); break;   case 10: launch_smallk_fwd<10>(p, st); break;
-    case 11: launch_smallk_fwd<11>(p, st); break; case 12: launch_smallk_fwd<12>(p, st); break;
-    case 13: launch_smallk_fwd<13>(p, st); break; case 14: launch_smallk_fwd<14>(p, st); break;
-    case 15: launch_smallk_fwd<15>(p, st); break; default: launch_smallk_fwd<16>(p, st); break;
+    case 1: launch_smallk_fwd<1>(p, H, st); break;   case 2: launch_smallk_fwd<2>(p, H, st); break;
+    case 3: launch_smallk_fwd<3>(p, H, st); break;   case 4: launch_smallk_fwd<4>(p, H, st); break;
+    case 5: launch_smallk_fwd<5>(p, H, st); break;   case 6: launch_smallk_fwd<6>(p, H, st); break;
+    case 7: launch_smallk_fwd<7>(p, H, st); break;   case 8: launch_smallk_fwd<8>(p, H, st); break;
+    case 9: launch_smallk_fwd<9>(p, H, st); break;   case 10: launch_smallk_fwd<10>(p, H, st); break;
+    case 11: launch_smallk_fwd<11>(p, H, st); break; case 12: launch_smallk_fwd<12>(p, H, st); break;
+    case 13: launch_smallk_fwd<13>(p, H, st); break; case 14: launch_smallk_fwd<14>(p, H, st); break;
+    case 15: launch_smallk_fwd<15>(p, H, st); break; default: launch_smallk_fwd<16>(p, H, st); break;
   }
   return check_launch();
 }

@@ -6,16 +6,23 @@
 //   p = ps Wp^T + sp bp;  g = gs Wg^T + sg bg;  s = [pl, gl, 1/pl, 1/gl]
 //   f = [p | g | g - p | g * p | s]  (4h + 4);  y1 = relu(f W1^T + b1);  y = [y1 | s] W2^T + b2
 //
-// h = input width = 128 only.  Plain fp32 FMAs through LDS tiles (as csrc/dmp_fold.hip): 16 rows per workgroup,
-// thread (r, cg) owns 8 consecutive columns of row r.
+// h = input width = hidden width = 128 or 64.  fp32 MFMA products through LDS tiles (as csrc/dmp_fold.hip): 16 rows per
+// workgroup, thread (r, cg) owns h / 16 consecutive columns of row r.
 #include "dmp_common.h"
 
 namespace dmp {
 namespace {
 
-constexpr int kH = 128, kF = 4 * kH + 4, kYS = kH + 4;
-constexpr int kThreads = 256, kRows = 16, kPad = 132, kFPad = 520;
+constexpr int kThreads = 256, kRows = 16;
 constexpr int kMaxHeads = DMP_HEADS_MAX;
+
+// widths derived from the head's input = hidden width h (128, or the reference's shipped 64)
+template <int kH> struct HeadGeom {
+  static constexpr int kF = 4 * kH + 4, kYS = kH + 4;      // feature row [p | g | g - p | g * p | s], saved [y1 | s]
+  static constexpr int kPad = kH + 4, kFPad = 4 * kH + 8;  // LDS row strides
+  static constexpr int CW = kH / 16;                       // thread (r, cg) owns CW consecutive columns of row r
+  static constexpr int NT = kH / 64, NKB = kH / 16;        // 16-column MFMA tiles per wave, k blocks of 16
+};
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
@@ -27,25 +34,27 @@ struct Heads {
   float slope;   // negative slope of the heads' activation (0 = ReLU; pred_act_func, pred.py:36)
 };
 
-// acc[8] += A_lds[r][0..127] . op(W)[.., 8 cg ..]   for one 128-wide contraction; W element (j, k) at W[j * ldw + k]
+// acc[CW] += A_lds[r][0..h-1] . op(W)[.., CW cg ..]   for one h-wide contraction; W element (j, k) at W[j * ldw + k]
 //   wT = 1: out col j, contraction k: out[j] = sum_k a[k] W[j][k]     (x W^T, W in nn.Linear layout)
 //   wT = 0: out col k, contraction j: out[k] = sum_j a[j] W[j][k]     (x W)
-// A: the 16 operand rows in LDS (row i at A + i * lda, >= 128 values at stride 1, 16-byte aligned rows).
-// The 16 x 128 product runs on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32: wave w owns output columns 32 w .. 32 w + 31):
-// every lane requests its share of the whole 128-deep weight panel in ONE batch of loads straight in the operand layout
+// A: the 16 operand rows in LDS (row i at A + i * lda, >= h values at stride 1, 16-byte aligned rows).
+// The 16 x h product runs on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32: wave w owns output columns (h/4) w .. (h/4)(w+1) - 1):
+// every lane requests its share of the whole h-deep weight panel in ONE batch of loads straight in the operand layout
 // (one L2 round trip per product instead of one per 32-deep LDS slice), the A operand comes from LDS as float4 (lane
-// (m, kq) takes k = 16 kb + 4 kq .. + 3, the weights follow the same order); the 16 x 128 result goes through Ws
-// (>= 16 * kPad floats) into the (row r = tid / 16, 8 columns cg) accumulators of the callers' epilogues.
-__device__ __forceinline__ void gemm128(float (&acc)[8], const float *A, int lda, const float *W, int ldw, int wT, int wcol0,
-                                        float *Ws, int tid, int cg) {
+// (m, kq) takes k = 16 kb + 4 kq .. + 3, the weights follow the same order); the 16 x h result goes through Ws
+// (>= 16 * kPad floats) into the (row r = tid / 16, CW columns cg) accumulators of the callers' epilogues.
+template <int kH>
+__device__ __forceinline__ void gemm_h(float (&acc)[kH / 16], const float *A, int lda, const float *W, int ldw, int wT, int wcol0,
+                                       float *Ws, int tid, int cg) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int kPad = HeadGeom<kH>::kPad, CW = HeadGeom<kH>::CW, NT = HeadGeom<kH>::NT, NKB = HeadGeom<kH>::NKB;
   const int lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
-  float4 bw[2][8];
+  float4 bw[NT][NKB];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int n = wave * 32 + t * 16 + m;
+  for (int t = 0; t < NT; ++t) {
+    const int n = wave * (16 * NT) + t * 16 + m;
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       const int k = kb * 16 + 4 * kq;
       if (wT) {
         bw[t][kb] = ldg4(W + (int64_t)n * ldw + wcol0 + k);
@@ -56,12 +65,14 @@ __device__ __forceinline__ void gemm128(float (&acc)[8], const float *A, int lda
     }
   }
   __syncthreads();                                          // the callers' operand rows are in LDS; Ws is free again
-  f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 d[NT];
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
+  for (int t = 0; t < NT; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
     const float4 a = *reinterpret_cast<const float4 *>(A + m * lda + kb * 16 + 4 * kq);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw[t][kb].x, d[t], 0, 0, 0);
       d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw[t][kb].y, d[t], 0, 0, 0);
       d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw[t][kb].z, d[t], 0, 0, 0);
@@ -69,28 +80,40 @@ __device__ __forceinline__ void gemm128(float (&acc)[8], const float *A, int lda
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * 32 + t * 16 + m] = d[t][i];
+    for (int i = 0; i < 4; ++i) Ws[(4 * kq + i) * kPad + wave * (16 * NT) + t * 16 + m] = d[t][i];
   __syncthreads();
   const int r = tid >> 4;
-  const float4 o0 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8]);
-  const float4 o1 = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * 8 + 4]);
-  acc[0] += o0.x; acc[1] += o0.y; acc[2] += o0.z; acc[3] += o0.w;
-  acc[4] += o1.x; acc[5] += o1.y; acc[6] += o1.z; acc[7] += o1.w;
-}
-
-__device__ __forceinline__ void stage_rows(float *As, const float *X, int64_t ldx, int i0, int B, int tid) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int row = (tid >> 5) + 8 * m, c4 = (tid & 31) * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i0 + row < B) a = ldg4(X + (int64_t)(i0 + row) * ldx + c4);
-    *reinterpret_cast<float4 *>(&As[row * kPad + c4]) = a;
+  for (int v = 0; v < CW / 4; ++v) {
+    const float4 o = *reinterpret_cast<const float4 *>(&Ws[r * kPad + cg * CW + 4 * v]);
+    acc[4 * v] += o.x; acc[4 * v + 1] += o.y; acc[4 * v + 2] += o.z; acc[4 * v + 3] += o.w;
   }
 }
 
+template <int kH>
+__device__ __forceinline__ void stage_rows(float *As, const float *X, int64_t ldx, int i0, int B, int tid) {
+  constexpr int kQ = kH / 4, kPass = kThreads / kQ;
+#pragma unroll
+  for (int m = 0; m < kRows / kPass; ++m) {
+    const int row = tid / kQ + kPass * m, c4 = (tid % kQ) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 + row < B) a = ldg4(X + (int64_t)(i0 + row) * ldx + c4);
+    *reinterpret_cast<float4 *>(&As[row * HeadGeom<kH>::kPad + c4]) = a;
+  }
+}
+
+// CW consecutive floats of a thread's row: registers -> memory
+template <int CW>
+__device__ __forceinline__ void store_cw(float *o, const float (&v)[CW]) {
+#pragma unroll
+  for (int q = 0; q < CW / 4; ++q) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int kH>
 __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
+  constexpr int kF = HeadGeom<kH>::kF, kYS = HeadGeom<kH>::kYS, kPad = HeadGeom<kH>::kPad, kFPad = HeadGeom<kH>::kFPad, CW = HeadGeom<kH>::CW;
   __shared__ float As[kRows * kPad];
   __shared__ float Fs[kRows * kFPad];
   __shared__ float Ws[16 * kPad];
@@ -98,26 +121,26 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
   const dmp_head_io &io = t.io[blockIdx.y];
   const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15, i0 = (int)blockIdx.x * kRows, b = i0 + r;
   const bool live = b < t.B;
-  float p[8], g[8];
+  float p[CW], g[CW];
   // p = ps Wp^T + sp bp,  g = gs Wg^T + sg bg
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { p[e] = 0.f; g[e] = 0.f; }
-  stage_rows(As, io.ps, io.ld_ps, i0, t.B, tid);
-  gemm128(p, As, kPad, w.Wp, kH, 1, 0, Ws, tid, cg);
+  for (int e = 0; e < CW; ++e) { p[e] = 0.f; g[e] = 0.f; }
+  stage_rows<kH>(As, io.ps, io.ld_ps, i0, t.B, tid);
+  gemm_h<kH>(p, As, kPad, w.Wp, kH, 1, 0, Ws, tid, cg);
   __syncthreads();
-  stage_rows(As, io.gs, io.ld_gs, i0, t.B, tid);
-  gemm128(g, As, kPad, w.Wg, kH, 1, 0, Ws, tid, cg);
+  stage_rows<kH>(As, io.gs, io.ld_gs, i0, t.B, tid);
+  gemm_h<kH>(g, As, kPad, w.Wg, kH, 1, 0, Ws, tid, cg);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    p[e] += io.scale_p * w.bp[cg * 8 + e];
-    g[e] += io.scale_g * w.bg[cg * 8 + e];
+  for (int e = 0; e < CW; ++e) {
+    p[e] += io.scale_p * w.bp[cg * CW + e];
+    g[e] += io.scale_g * w.bg[cg * CW + e];
   }
   // f = [p | g | g - p | g * p | s]
   float s4[4] = {0.f, 0.f, 0.f, 0.f};
   if (live) { s4[0] = io.pl[b]; s4[1] = io.gl[b]; s4[2] = 1.0f / s4[0]; s4[3] = 1.0f / s4[1]; }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cg * 8 + e;
+  for (int e = 0; e < CW; ++e) {
+    const int c = cg * CW + e;
     Fs[r * kFPad + c] = p[e];
     Fs[r * kFPad + kH + c] = g[e];
     Fs[r * kFPad + 2 * kH + c] = g[e] - p[e];
@@ -128,43 +151,44 @@ __global__ __launch_bounds__(kThreads) void heads_fwd_k(const Heads t) {
   if (live) {
     float *F = io.F + (int64_t)b * kF;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<float4 *>(F + q * kH + cg * 8) = *reinterpret_cast<const float4 *>(&Fs[r * kFPad + q * kH + cg * 8]);
-      *reinterpret_cast<float4 *>(F + q * kH + cg * 8 + 4) = *reinterpret_cast<const float4 *>(&Fs[r * kFPad + q * kH + cg * 8 + 4]);
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < CW / 4; ++v)
+        *reinterpret_cast<float4 *>(F + q * kH + cg * CW + 4 * v) = *reinterpret_cast<const float4 *>(&Fs[r * kFPad + q * kH + cg * CW + 4 * v]);
     if (cg < 4) F[4 * kH + cg] = s4[cg];
   }
-  // y1 = relu(f W1^T + b1): four 128-wide contractions + the four scalars
-  float y1[8];
+  // y1 = act(f W1^T + b1): four h-wide contractions + the four scalars
+  float y1[CW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) y1[e] = w.b1[cg * 8 + e];
+  for (int e = 0; e < CW; ++e) y1[e] = w.b1[cg * CW + e];
 #pragma unroll 1
-  for (int q = 0; q < 4; ++q) gemm128(y1, Fs + q * kH, kFPad, w.W1, kF, 1, q * kH, Ws, tid, cg);
+  for (int q = 0; q < 4; ++q) gemm_h<kH>(y1, Fs + q * kH, kFPad, w.W1, kF, 1, q * kH, Ws, tid, cg);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float *wr = w.W1 + (int64_t)(cg * 8 + e) * kF + 4 * kH;
+  for (int e = 0; e < CW; ++e) {
+    const float *wr = w.W1 + (int64_t)(cg * CW + e) * kF + 4 * kH;
     y1[e] += s4[0] * wr[0] + s4[1] * wr[1] + s4[2] * wr[2] + s4[3] * wr[3];
     y1[e] = act_fwd(y1[e], t.slope);
   }
   // y = [y1 | s] W2^T + b2
   float part = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) part += y1[e] * w.W2[cg * 8 + e];
+  for (int e = 0; e < CW; ++e) part += y1[e] * w.W2[cg * CW + e];
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
   if (live) {
     float *ys = io.Y1S + (int64_t)b * kYS;
-    *reinterpret_cast<float4 *>(ys + cg * 8) = make_float4(y1[0], y1[1], y1[2], y1[3]);
-    *reinterpret_cast<float4 *>(ys + cg * 8 + 4) = make_float4(y1[4], y1[5], y1[6], y1[7]);
+    store_cw<CW>(ys + cg * CW, y1);
     if (cg < 4) ys[kH + cg] = s4[cg];
     if (cg == 0)
       io.y[b] = part + s4[0] * w.W2[kH] + s4[1] * w.W2[kH + 1] + s4[2] * w.W2[kH + 2] + s4[3] * w.W2[kH + 3] + w.b2[0];
   }
 }
 
-// Backward over the rows: dy -> dy1 (ReLU mask) -> df = dy1 W1 -> dp, dg -> dps = dp Wp, dgs = dg Wg.
+// Backward over the rows: dy -> dy1 (activation mask) -> df = dy1 W1 -> dp, dg -> dps = dp Wp, dgs = dg Wg.
 // Writes what the weight gradients need (dY1, dP, dG) and the input gradients.
+template <int kH>
 __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
+  constexpr int kF = HeadGeom<kH>::kF, kYS = HeadGeom<kH>::kYS, kPad = HeadGeom<kH>::kPad, CW = HeadGeom<kH>::CW;
   __shared__ float As[kRows * kPad];
   __shared__ float Ws[16 * kPad];
   const dmp_head_weights &w = t.w[blockIdx.y];
@@ -173,63 +197,47 @@ __global__ __launch_bounds__(kThreads) void heads_bwd_rows_k(const Heads t) {
   const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15, i0 = (int)blockIdx.x * kRows, b = i0 + r;
   const bool live = b < t.B;
   const float dy = live ? gr.dy[b] * (gr.dy_scale ? gr.dy_scale[b] : 1.0f) : 0.f;
-  // dy1 = y1 > 0 ? dy W2 : 0
-  float d1[8];
+  // dy1 = y1 > 0 ? dy W2 : slope * dy W2
+  float d1[CW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float y1 = live ? io.Y1S[(int64_t)b * kYS + cg * 8 + e] : 0.f;
-    d1[e] = act_bwd(y1, dy * w.W2[cg * 8 + e], t.slope);
-    As[r * kPad + cg * 8 + e] = d1[e];
+  for (int e = 0; e < CW; ++e) {
+    const float y1 = live ? io.Y1S[(int64_t)b * kYS + cg * CW + e] : 0.f;
+    d1[e] = act_bwd(y1, dy * w.W2[cg * CW + e], t.slope);
+    As[r * kPad + cg * CW + e] = d1[e];
   }
-  if (live) {
-    float *o = gr.dY1 + (int64_t)b * kH + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(d1[0], d1[1], d1[2], d1[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(d1[4], d1[5], d1[6], d1[7]);
-  }
+  if (live) store_cw<CW>(gr.dY1 + (int64_t)b * kH + cg * CW, d1);
   // df blocks: [dfp | dfg | dfd | dfm] = dy1 W1[:, 0:4h]
-  float df[4][8];
+  float df[4][CW];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) df[q][e] = 0.f;
-    gemm128(df[q], As, kPad, w.W1, kF, 0, q * kH, Ws, tid, cg);
+    for (int e = 0; e < CW; ++e) df[q][e] = 0.f;
+    gemm_h<kH>(df[q], As, kPad, w.W1, kF, 0, q * kH, Ws, tid, cg);
   }
-  float dp[8], dg[8];
+  float dp[CW], dg[CW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float p = live ? io.F[(int64_t)b * kF + cg * 8 + e] : 0.f;
-    const float g = live ? io.F[(int64_t)b * kF + kH + cg * 8 + e] : 0.f;
+  for (int e = 0; e < CW; ++e) {
+    const float p = live ? io.F[(int64_t)b * kF + cg * CW + e] : 0.f;
+    const float g = live ? io.F[(int64_t)b * kF + kH + cg * CW + e] : 0.f;
     dp[e] = (df[0][e] - df[2][e]) + df[3][e] * g;
     dg[e] = (df[1][e] + df[2][e]) + df[3][e] * p;
   }
   if (live) {
-    float *o = gr.dP + (int64_t)b * kH + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(dp[0], dp[1], dp[2], dp[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(dp[4], dp[5], dp[6], dp[7]);
-    o = gr.dG + (int64_t)b * kH + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(dg[0], dg[1], dg[2], dg[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+    store_cw<CW>(gr.dP + (int64_t)b * kH + cg * CW, dp);
+    store_cw<CW>(gr.dG + (int64_t)b * kH + cg * CW, dg);
   }
   // input gradients: dps = dp Wp, dgs = dg Wg
-  float out[8];
+  float out[CW];
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dp[e]; out[e] = 0.f; }
-  gemm128(out, As, kPad, w.Wp, kH, 0, 0, Ws, tid, cg);
-  if (live && gr.dps) {
-    float *o = gr.dps + (int64_t)b * gr.ld_dps + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
-  }
+  for (int e = 0; e < CW; ++e) { As[r * kPad + cg * CW + e] = dp[e]; out[e] = 0.f; }
+  gemm_h<kH>(out, As, kPad, w.Wp, kH, 0, 0, Ws, tid, cg);
+  if (live && gr.dps) store_cw<CW>(gr.dps + (int64_t)b * gr.ld_dps + cg * CW, out);
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { As[r * kPad + cg * 8 + e] = dg[e]; out[e] = 0.f; }
-  gemm128(out, As, kPad, w.Wg, kH, 0, 0, Ws, tid, cg);
-  if (live && gr.dgs) {
-    float *o = gr.dgs + (int64_t)b * gr.ld_dgs + cg * 8;
-    *reinterpret_cast<float4 *>(o) = make_float4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<float4 *>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
-  }
+  for (int e = 0; e < CW; ++e) { As[r * kPad + cg * CW + e] = dg[e]; out[e] = 0.f; }
+  gemm_h<kH>(out, As, kPad, w.Wg, kH, 0, 0, Ws, tid, cg);
+  if (live && gr.dgs) store_cw<CW>(gr.dgs + (int64_t)b * gr.ld_dgs + cg * CW, out);
 }
 
 // Weight gradients: out[j, k] = sum_i dC[i, j] M[i, k]  (j < nj <= 128, k < ncols), bias[j] = bscale * sum_i dC[i, j].
@@ -330,7 +338,8 @@ inline void add_wjob(WJobs &t, int &blocks, const float *dC, int64_t ldc, int nj
 inline bool ok16p(const void *q) { return q && (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
 bool heads_valid(const dmp_head_weights *w, const dmp_head_io *io, int n, int B, int H) {
-  if (n < 1 || n > kMaxHeads || B < 0 || H != kH || !w || !io) return false;
+  const int kH = H;
+  if (n < 1 || n > kMaxHeads || B < 0 || (H != 128 && H != 64) || !w || !io) return false;
   for (int i = 0; i < n; ++i) {
     if (!ok16p(w[i].Wp) || !ok16p(w[i].bp) || !ok16p(w[i].Wg) || !ok16p(w[i].bg) || !ok16p(w[i].W1) || !ok16p(w[i].b1) ||
         !ok16p(w[i].W2) || !w[i].b2)
@@ -351,13 +360,15 @@ extern "C" {
 
 int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H, float slope,
                       void *stream) {
-  if ((H != kH && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if ((H != 128 && H != 64 && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (!heads_valid(w, io, num_heads, B, H)) return DMP_ERR_BAD_ARG;
   if (B == 0) return DMP_OK;
   Heads t;
   for (int i = 0; i < num_heads; ++i) { t.w[i] = w[i]; t.io[i] = io[i]; t.gr[i] = dmp_head_grads{}; }
   t.B = B; t.slope = slope;
-  heads_fwd_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
+  const dim3 grid((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads);
+  if (H == 128) heads_fwd_k<128><<<grid, kThreads, 0, (hipStream_t)stream>>>(t);
+  else heads_fwd_k<64><<<grid, kThreads, 0, (hipStream_t)stream>>>(t);
   return check_launch();
 }
 
@@ -378,8 +389,9 @@ int dmp_heads_blend(const float *const *y, const float *const *gl, float *const 
 
 int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g, int num_heads, int B,
                        int H, float slope, void *stream) {
-  if ((H != kH && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if ((H != 128 && H != 64 && H > 0) || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (!heads_valid(w, io, num_heads, B, H) || !g) return DMP_ERR_BAD_ARG;
+  const int kH = H, kF = 4 * H + 4, kYS = H + 4;
   for (int i = 0; i < num_heads; ++i) {
     if (!g[i].dy || !ok16p(g[i].dY1) || !ok16p(g[i].dP) || !ok16p(g[i].dG) || (g[i].dps && (!ok16p(g[i].dps) || g[i].ld_dps % 4)) ||
         (g[i].dgs && (!ok16p(g[i].dgs) || g[i].ld_dgs % 4)) || !g[i].dWp || !g[i].dbp || !g[i].dWg || !g[i].dbg || !g[i].dW1 ||
@@ -399,7 +411,9 @@ int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const d
     add_wjob(wj, blocks, g[i].dy, 1, 1, g[i].dy_scale, io[i].Y1S, kYS, kYS, g[i].dW2, kYS, g[i].db2, 1.0f);
   }
   t.B = B; t.slope = slope;
-  heads_bwd_rows_k<<<dim3((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads), kThreads, 0, (hipStream_t)stream>>>(t);
+  const dim3 grid((unsigned)((B + kRows - 1) / kRows), (unsigned)num_heads);
+  if (H == 128) heads_bwd_rows_k<128><<<grid, kThreads, 0, (hipStream_t)stream>>>(t);
+  else heads_bwd_rows_k<64><<<grid, kThreads, 0, (hipStream_t)stream>>>(t);
   int rc = check_launch();
   if (rc != DMP_OK) return rc;
   heads_bwd_w_k<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(wj);

@@ -1,5 +1,7 @@
 // Fused MFMA kernels of the DMPLayer edge chain (gfx950, fp32 in / fp32 accumulate, exact fp32:
-// v_mfma_f32_32x32x2_f32).  K = H = 128 only; other widths take the GEMM + epilogue-kernel path.
+// v_mfma_f32_32x32x2_f32).  K = H = 128; the one-panel kernels (out_fwd, bwd_h1, the plain product) also
+// K = H = 64 (the reference's shipped hidden_dim) with H / 32 = 2 waves per workgroup; other widths take the
+// GEMM + epilogue-kernel path.
 //
 // Structure: persistent 256-thread workgroups (4 waves, one 32-column slice of every output panel
 // each), 2 (NC = 2) or 3 (NC = 1) resident per CU and not synchronised with each other: while one
@@ -87,38 +89,42 @@ struct MfmaArgs {
   float slope;                      // EPI_EDGE / EPI_RELU_BWD_G: negative slope of the activation (0 = ReLU)
 };
 
-template <int NC, int EPI, int PP>
-__global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 ? 3 : 2)) void mfma_pp(MfmaArgs p) {
+template <int NC, int EPI, int PP, int H = 128>
+__global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)) void mfma_pp(MfmaArgs p) {
+  static_assert(H == 128 || (H == 64 && !PP), "H = 64: independent workgroups only");
   constexpr int NG = PP ? 2 : 1;                            // wave groups per workgroup
+  constexpr int kGThreads = 2 * H;                          // threads of a wave group: H / 32 waves, one 32-column slice each
+  constexpr int kStride = H + 4, kQ = H / 4, kHalf = H / 2, kSteps4 = H / 8;   // LDS row stride, float4 per row, k per lane half
+  constexpr uint32_t kRowBytes = H * 4u;
   // kPipe (one panel, streamed epilogue operand: out_fwd / bwd_h1): one barrier per tile, the staging of the next
   // tile (second As buffer), the row requests of the tile after it and the epilogue operand requests of the NEXT
   // tile (second operand register set: streamed rows need a whole tile of latency) in the MFMA shadow.
   constexpr bool kPipe = !PP && NC == 1 && (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G);
   constexpr int NBUF = kPipe ? 2 : 1, NPAR = kPipe ? 3 : 2;
-  __shared__ float As[NG * NBUF][kSub * kLdsStride];
-  __shared__ float Cs[4 * NG][32 * kScrStride];
+  __shared__ float As[NG * NBUF][kSub * kStride];
+  __shared__ float Cs[(H / 32) * NG][32 * kScrStride];
   __shared__ uint32_t rowA[NG][NPAR][kSub], rowB[NG][NPAR][kSub];   // [group][tile parity (kPipe: tile % 3)][row]
   __shared__ float rowS[NG][NPAR][kSub];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-  const int grp = wave >> 2, cs = wave & 3, gtid = threadIdx.x & (kGroupThreads - 1);
+  const int grp = PP ? wave >> 2 : 0, cs = PP ? wave & 3 : wave, gtid = threadIdx.x & (kGThreads - 1);
   const int col = 32 * cs + li;
-  float b[NC][64];
+  float b[NC][kHalf];
 #pragma unroll
   for (int q = 0; q < NC; ++q)
 #pragma unroll
-    for (int s = 0; s < 64; ++s) {
-      const int k = s + 64 * h, j = 128 * q + col;
+    for (int s = 0; s < kHalf; ++s) {
+      const int k = s + kHalf * h, j = H * q + col;
       // bt 0: B[k][j] row-major; 1: transposed storage B^T[j][k]; 2: panel q is the K-slice
-      // [128q, 128q+128) of a transposed [128, NC*128] matrix: B_q[k][col] = W[col][128q + k]
+      // [Hq, Hq+H) of a transposed [H, NC*H] matrix: B_q[k][col] = W[col][Hq + k]
       b[q][s] = p.bt == 0 ? p.B[(int64_t)k * p.ldb + j]
               : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
-                          : p.B[(int64_t)col * p.ldb + 128 * q + k];
+                          : p.B[(int64_t)col * p.ldb + H * q + k];
     }
 #pragma unroll
   for (int q = 0; q < NC; ++q)
 #pragma unroll
-    for (int s = 0; s < 64; ++s) asm volatile("" ::"v"(b[q][s]));  // loads complete here, not inside the loop
+    for (int s = 0; s < kHalf; ++s) asm volatile("" ::"v"(b[q][s]));  // loads complete here, not inside the loop
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
   float *As_g = As[grp * NBUF];
   float *scr = Cs[wave];
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
 #pragma unroll
   for (int k = 0; k < 4; ++k) voffC[k] = ((uint32_t)(8 * k + lrow) * (uint32_t)p.ldc + (uint32_t)c4) * 4u;
   const uint32_t voffR = ((uint32_t)lrow * (uint32_t)p.ldr + (uint32_t)c4) * 4u;
-  const uint32_t voffA = ((uint32_t)(gtid >> 5) * (uint32_t)p.lda + (uint32_t)(gtid & 31) * 4u) * 4u;
+  const uint32_t voffA = ((uint32_t)(gtid / kQ) * (uint32_t)p.lda + (uint32_t)(gtid % kQ) * 4u) * 4u;
   const uint32_t voffT = (uint32_t)c4 * 4u;
   // SGPR byte offsets of the 8-row groups of a tile
   const uint32_t grpA = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8 * p.lda * 4));
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   // EPI_RELU_BWD_G writes [dPre | coef dPre] when asked for both halves (p.both), dPre only otherwise
   const bool both_halves = EPI == EPI_RELU_BWD_G && p.both != 0;
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
-  const int kOutCols = (EPI == EPI_NONE) ? NC * 128 : (both_halves ? 256 : 128);
+  const int kOutCols = (EPI == EPI_NONE) ? NC * H : (both_halves ? 2 * H : H);
 
   // whole-array descriptors: per-row arrays and the gathered table
   const uint32_t rows4 = (uint32_t)(p.E * 4);
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   uint32_t pre_a = 0, pre_b = 0;
   float pre_s = 0.f;
   auto load_rows = [&](int t) {                           // global -> registers: rows + per-row scalars of tile t
-    const rsrc_t ra = make_rsrc(p.A + (int64_t)t * kSub * p.lda, tile_bytes(tile_rows(t), p.lda, 128));
+    const rsrc_t ra = make_rsrc(p.A + (int64_t)t * kSub * p.lda, tile_bytes(tile_rows(t), p.lda, H));
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
       if (!(DMP_DBG & 4) || t < 2 * (int)gridDim.x) pre[m] = buf_load4(ra, voffA, m * grpA);
@@ -183,15 +189,15 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
       if (!(DMP_DBG & 8) || pre[m].x == 123.456f)
-      *reinterpret_cast<float4 *>(&As_g[((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+      *reinterpret_cast<float4 *>(&As_g[((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
     if (EPI != EPI_NONE && gtid < kSub) {
       uint32_t a = 0, bb = 0;
       if (EPI == EPI_EDGE) {                              // byte offsets of the two gathered P rows
         a = pre_a * (uint32_t)(p.ldt * 4);
-        bb = pre_b * (uint32_t)(p.ldt * 4) + 512u;
+        bb = pre_b * (uint32_t)(p.ldt * 4) + kRowBytes;
       } else if (EPI == EPI_DZ) {
         bb = pre_b;
-        a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? 512u : 0u);
+        a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? kRowBytes : 0u);
       }
       rowA[grp][par][gtid] = a; rowB[grp][par][gtid] = bb;
       rowS[grp][par][gtid] = (EPI == EPI_GATE_RES && !p.rowscale) ? 1.f : pre_s;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   };
 
   auto stage_row_to = [&](int buf, int m) {
-    *reinterpret_cast<float4 *>(&As[buf][((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+    *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
   };
   auto stage_scalars_to = [&](int par) {
     if (gtid < kSub) rowS[grp][par][gtid] = (EPI == EPI_GATE_RES && !p.rowscale) ? 1.f : pre_s;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
   float4 g0n[kPipe ? 4 : 1];                               // kPipe: the next tile's epilogue operand rows
   auto fetch_operands = [&](int t, int par) {             // epilogue operands of tile t, in store layout
     const rsrc_t rr_ = make_rsrc(p.R ? p.R + (int64_t)t * kSub * p.ldr : nullptr,
-                                 p.R ? tile_bytes(tile_rows(t), p.ldr, 128) : 0u);
+                                 p.R ? tile_bytes(tile_rows(t), p.ldr, H) : 0u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = 8 * k + lrow;
@@ -236,13 +242,13 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
     for (int q = 0; q < NC; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    const float *arow = &As_g[li * kLdsStride + 64 * h];
+    const float *arow = &As_g[li * kStride + kHalf * h];
     // the A operands of k-steps 4(s4+1).. are requested BEFORE the MFMAs of k-steps 4 s4.. issue
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
+    for (int s4 = 0; s4 < kSteps4; ++s4) {
       float4 an = a4;
-      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
@@ -259,25 +265,30 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
     const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
-    const rsrc_t rr1 = make_rsrc(p.R ? p.R + (int64_t)t1 * kSub * p.ldr : nullptr, p.R ? tile_bytes(tile_rows(t1), p.ldr, 128) : 0u);
-    const rsrc_t ra2 = make_rsrc(p.A + (int64_t)t2 * kSub * p.lda, tile_bytes(tile_rows(t2), p.lda, 128));
-    const float *arow = &As[buf][li * kLdsStride + 64 * h];
+    const rsrc_t rr1 = make_rsrc(p.R ? p.R + (int64_t)t1 * kSub * p.ldr : nullptr, p.R ? tile_bytes(tile_rows(t1), p.ldr, H) : 0u);
+    const rsrc_t ra2 = make_rsrc(p.A + (int64_t)t2 * kSub * p.lda, tile_bytes(tile_rows(t2), p.lda, H));
+    // in the shadow of the MFMA groups (H = 64: 8 groups, two of these 14 actions after each)
+    auto shadow = [&](int i) {
+      if (i < 4) g0n[kPipe ? i : 0] = buf_load4(rr1, voffR, i * grpR);            // tile k+1's operand rows 8 i + lrow
+      else if (i < 8) stage_row_to(buf ^ 1, i - 4);                               // tile k+1 -> the other buffer
+      else if (i == 8) stage_scalars_to(nxt3);
+      else if (i < 13) pre[i - 9] = buf_load4(ra2, voffA, (i - 9) * grpA);        // tile k+2's rows
+      else if (i == 13) load_scalars_of(t2);
+    };
+    const float *arow = &As[buf][li * kStride + kHalf * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
+    for (int s4 = 0; s4 < kSteps4; ++s4) {
       float4 an = a4;
-      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[0][4 * s4 + 0], acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[0][4 * s4 + 1], acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[0][4 * s4 + 2], acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[0][4 * s4 + 3], acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (s4 < 4) g0n[kPipe ? s4 : 0] = buf_load4(rr1, voffR, s4 * grpR);          // tile k+1's operand rows 8 s4 + lrow
-      else if (s4 < 8) stage_row_to(buf ^ 1, s4 - 4);                              // tile k+1 -> the other buffer
-      else if (s4 == 8) stage_scalars_to(nxt3);
-      else if (s4 < 13) pre[s4 - 9] = buf_load4(ra2, voffA, (s4 - 9) * grpA);      // tile k+2's rows
-      else if (s4 == 13) load_scalars_of(t2);
+      if (kSteps4 == 16) shadow(s4);
+      else { shadow(2 * s4); shadow(2 * s4 + 1); }
       a4 = an;
     }
   };
@@ -340,10 +351,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
           colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
           if (both_halves) {
             const float cf = rowS[grp][par][rr];
-            buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + 512u, 0);
+            buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + kRowBytes, 0);
           }
         }
-        if (!(DMP_DBG & 1) || v.x == 123.456f) buf_store4(v, rc, voffC[k] + 512u * q, 0);
+        if (!(DMP_DBG & 1) || v.x == 123.456f) buf_store4(v, rc, voffC[k] + kRowBytes * q, 0);
       }
     }
 #if DMP_DBG & 64
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : kGroupThreads, PP ? 1 : (NC == 1 
       colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
     }
     if (lane < 8)
-      *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * NG + grp) * 128 + 32 * cs + lane * 4) = colsum;
+      *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * NG + grp) * H + 32 * cs + lane * 4) = colsum;
   }
 }
 
@@ -480,6 +491,13 @@ template <int NC, int EPI>
 inline int launch_mfma(const MfmaArgs &p, hipStream_t st) {
   if (g_variant == 1) mfma_pp<NC, EPI, 1><<<pp_blocks(p.E), kPPThreads, 0, st>>>(p);
   else mfma_pp<NC, EPI, 0><<<wg_blocks(p.E, NC == 1 ? 3 : 2), kGroupThreads, 0, st>>>(p);
+  return check_launch();
+}
+// H = 64, one panel: 128-thread workgroups, 5 per CU (27 KB of LDS each)
+constexpr int kPerCU64 = 5;
+template <int EPI>
+inline int launch_mfma64(const MfmaArgs &p, hipStream_t st) {
+  mfma_pp<1, EPI, 0, 64><<<wg_blocks(p.E, kPerCU64), 128, 0, st>>>(p);
   return check_launch();
 }
 
@@ -527,6 +545,17 @@ int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int 
   return ncols == 128 ? launch_mfma<1, EPI_NONE>(p, st) : launch_mfma<2, EPI_NONE>(p, st);
 }
 
+int dmp_gemm_k64(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed, float *C, int64_t ldc, int64_t E,
+                 void *stream) {
+  if (E < 0 || lda < 64 || ldc < 64) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!A || !B || !C || lda % 4 || ldc % 4 || !aligned16(A) || !aligned16(C)) return DMP_ERR_BAD_ARG;
+  if (!fits32(kSub, lda) || !fits32(kSub, ldc)) return DMP_ERR_UNSUPPORTED;
+  MfmaArgs p{};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bt = b_transposed; p.C = C; p.ldc = ldc; p.E = E; p.ldr = 64; p.ldt = 128;
+  return launch_mfma64<EPI_NONE>(p, (hipStream_t)stream);
+}
+
 int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
                        int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
                        const float *coefE, int64_t E, int H, float slope, float *H1, int64_t ldh, void *stream) {
@@ -548,7 +577,8 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
                       const float *gate, const float *R, int64_t ldr, int64_t E, int H, int w_in_out,
                       float *out, int64_t ldo, void *stream) {
-  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
   if (!Hin || !W2 || !out || ldh < H || ldw < H || ldo < H || (R && ldr < H)) return DMP_ERR_BAD_ARG;
   if (ldh % 4 || ldo % 4 || (R && ldr % 4) || !aligned16(Hin) || !aligned16(out) || (R && !aligned16(R)) ||
@@ -558,23 +588,25 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
   MfmaArgs p{};
   p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw;
   p.bt = w_in_out ? 0 : 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]; [in, out] (its transpose): B[k][j] = W2[k][j]
-  p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : 128; p.ldt = 256;
-  return launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream);
+  p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : H; p.ldt = 2 * H;
+  return H == 128 ? launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream) : launch_mfma64<EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
 int64_t dmp_mfma_partial_rows(int64_t E) { return g_variant == 1 ? 2 * (int64_t)pp_blocks(E) : (int64_t)wg_blocks(E, 3); }
+int64_t dmp_mfma_partial_rows_h(int64_t E, int H) { return H == 64 ? (int64_t)wg_blocks(E, kPerCU64) : dmp_mfma_partial_rows(E); }
 
 void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
 
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const float *coefE, const float *gate, int64_t E, int H, float slope, float *dG, int64_t ldg,
                      float *partial, void *stream) {
-  if (E < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0) return DMP_ERR_BAD_ARG;
   if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   const bool both = coefE != nullptr;                      // with coefE: dG = [dPre | coefE dPre]; without: dPre alone
   if (!partial || (gate && both)) return DMP_ERR_BAD_ARG;
   if (E == 0)
-    return hipMemsetAsync(partial, 0, sizeof(float) * 128 * (size_t)dmp_mfma_partial_rows(0), (hipStream_t)stream) == hipSuccess
+    return hipMemsetAsync(partial, 0, sizeof(float) * H * (size_t)dmp_mfma_partial_rows_h(0, H), (hipStream_t)stream) == hipSuccess
                ? DMP_OK : DMP_ERR_HIP;
   if (!dO || !W2 || !H1 || !dG || ldo < H || ldw < H || ldh < H || ldg < (both ? 2 * H : H)) return DMP_ERR_BAD_ARG;
   if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dG) || !aligned16(partial))
@@ -583,8 +615,8 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
-  p.both = both; p.partial = partial; p.ldt = 256; p.slope = slope;
-  return launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream);
+  p.both = both; p.partial = partial; p.ldt = 2 * H; p.slope = slope;
+  return H == 128 ? launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream) : launch_mfma64<EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 
 int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,

@@ -1,4 +1,4 @@
-// Class-typed variants of the fused edge-chain MFMA kernels (gfx950, exact fp32, H = K = 128).
+// Class-typed variants of the fused edge-chain MFMA kernels (gfx950, exact fp32, H = K = 128 or 64).
 //
 // The DMPLayer edge pre-activation is  Z[e] A' + c_e Z[e] B' + ...  with c_e = coef[dst e], a function
 // of out_deg[dst e] only (dmpnn.py:144-151).  All edges of one degree class therefore share ONE weight
@@ -6,6 +6,9 @@
 // [E,H]x[H,H] products of the reference collapse into one (and likewise dZ = dPre W_g^T in backward).
 // Rows stay where they are: a tile is a list of 32 edge ids (`slot_edge`, -1 = padding); the kernel
 // gathers its rows of the streamed operand by id and scatters its output rows by id.
+//
+// H = 64 (the reference's shipped hidden_dim, config.py:298-301): the same kernel with H / 32 = 2 waves per
+// workgroup (one 32-column slice each), 32 k-steps per tile, twice the workgroups per CU.
 //
 // Structure as mfma_pp<1, EPI, 0> (dmp_mfma.hip): persistent 256-thread workgroups, 3 per CU, weight
 // panel W_g in registers (rebuilt only when the workgroup's contiguous tile range crosses into the
@@ -40,16 +43,25 @@ struct TypedArgs {
   float slope;                          // TEPI_EDGE: negative slope of the activation (0 = ReLU)
 };
 
-template <int EPI>
-__global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
+template <int H> struct TypedGeom {
+  static constexpr int kThreads = 2 * H;                  // H / 32 waves: one 32-column slice each
+  static constexpr int kStride = H + 4;                   // LDS row stride (floats): conflict-free ds_read_b128
+  static constexpr int kQ = H / 4;                        // float4 per row; kThreads / kQ = 8 rows per load pass
+  static constexpr int kPerCU = H == 128 ? 3 : 5;         // workgroups per CU the grid is sized for (H = 64: LDS-bound)
+};
+
+template <int EPI, int H>
+__global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArgs p) {
+  constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
+  constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
   // TEPI_DZ keeps the two-barrier order (MFMA phase | stage + requests | epilogue): its epilogue waits for streamed
   // base rows, and the extra phase between their request and their use hides them better (measured: +3 % otherwise).
   // TEPI_REL (relation-typed product, rgcn.py:98-123): plain panel W[type of the tile], rows of A gathered through
   // slot_arow, the output row scaled by idxA-as-float[row] (the edge normaliser) -- no epilogue operands.
   constexpr bool kPipelined = EPI != TEPI_DZ;
-  __shared__ float As[kPipelined ? 2 : 1][kSub * kLdsStride];
-  __shared__ float Cs[4][32 * kScrStride];
+  __shared__ float As[kPipelined ? 2 : 1][kSub * kStride];
+  __shared__ float Cs[H / 32][32 * kScrStride];
   __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] byte offsets: tile k's are read
                                                                                      // (epilogue) while tile k+2's are written
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -57,7 +69,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   const int col = 32 * cs + li;
   float *scr = Cs[wave];
   const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
-  const uint32_t colA = (uint32_t)(gtid & 31) * 16u, col4 = (uint32_t)c4 * 4u;
+  const uint32_t colA = (uint32_t)(gtid % kQ) * 16u, col4 = (uint32_t)c4 * 4u;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI == TEPI_EDGE && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
@@ -81,24 +93,24 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));   // past the end: reads 0 (guarded below)
   const rsrc_t rs_slotA = make_rsrc(p.slot_arow, (uint32_t)ntiles * (kSub * 4u));
 
-  // W_g fragments: b[s] = B_g[s + 64h][col]
-  float b[64];
-  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)((EPI == TEPI_REL ? p.num_panels : 1) * 128 * p.ldw * 4));
-  const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + 64 * h : (int64_t)64 * h * p.ldw + col) * 4u;
+  // W_g fragments: b[s] = B_g[s + (H/2) h][col]
+  float b[kHalf];
+  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)((EPI == TEPI_REL ? p.num_panels : 1) * H * p.ldw * 4));
+  const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + kHalf * h : (int64_t)kHalf * h * p.ldw + col) * 4u;
   const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.transposed ? 4 : p.ldw * 4));  // bytes from k to k+1
   auto load_panel = [&](float c) {
-    // The offsets hang off a value the optimiser cannot see through: otherwise it hoists the 128
+    // The offsets hang off a value the optimiser cannot see through: otherwise it hoists the H
     // address computations out of the tile loop and keeps them live in registers across it.
     uint32_t off;
     asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
-    if (EPI == TEPI_REL) off += (uint32_t)__float_as_int(c) * (uint32_t)(128 * p.ldw * 4);   // panel of the tile's type
+    if (EPI == TEPI_REL) off += (uint32_t)__float_as_int(c) * (uint32_t)(H * p.ldw * 4);   // panel of the tile's type
 #pragma unroll
-    for (int s0 = 0; s0 < 64; s0 += 8) {
+    for (int s0 = 0; s0 < kHalf; s0 += 8) {
       float w0[8], w1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
-        if (EPI != TEPI_REL) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + 512, (int)((s0 + j) * w_step), 0));
+        if (EPI != TEPI_REL) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) b[s0 + j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
-      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, ((gtid >> 5) + 8 * m) * 4, (int)so, 0) : -1;
+      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, ((gtid / kQ) + 8 * m) * 4, (int)so, 0) : -1;
     if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
   };
   int own_staged = -1;
@@ -145,19 +157,19 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
     load_row_scalars();
   };
   auto stage_row = [&](int buf, int m) {                   // registers -> LDS, one of the thread's four row pieces
-    *reinterpret_cast<float4 *>(&As[buf][((gtid >> 5) + 8 * m) * kLdsStride + (gtid & 31) * 4]) = pre[m];
+    *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
   };
   auto stage_scalars = [&](int par) {                      // per-row byte offsets of the staged tile (threads < 32)
     if (gtid < kSub) {
       const bool ok = own_staged >= 0;
       uint32_t a = kOOB, bb = kOOB;
       if (EPI == TEPI_EDGE) {
-        if (ok) { a = pre_a * (uint32_t)(p.ldt * 4); bb = pre_b * (uint32_t)(p.ldt * 4) + 512u; }
+        if (ok) { a = pre_a * (uint32_t)(p.ldt * 4); bb = pre_b * (uint32_t)(p.ldt * 4) + kRowBytes; }
       } else if (EPI == TEPI_REL) {
         a = p.idxA ? pre_a : __float_as_uint(1.f);        // the row's scale (float bits)
       } else {
         bb = pre_b;                                       // flag
-        if (ok) a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? 512u : 0u);
+        if (ok) a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? kRowBytes : 0u);
       }
       rowA[par][gtid] = a; rowB[par][gtid] = bb;
       rowC[par][gtid] = ok ? (uint32_t)own_staged * (uint32_t)(p.ldc * 4) : kOOB;
@@ -190,12 +202,12 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
 #ifdef DMP_TY_DBG
     if (DMP_TY_DBG & 1) { fetch_operands(par); return; }
 #endif
-    const float *arow = &As[0][li * kLdsStride + 64 * h];
+    const float *arow = &As[0][li * kStride + kHalf * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
+    for (int s4 = 0; s4 < kSteps4; ++s4) {
       float4 an = a4;
-      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * s4 + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * s4 + 1], acc, 0, 0, 0);
@@ -209,16 +221,25 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   // One tile: the MFMAs of tile k (As[k & 1]) with, in the shadow of its 16 MFMA groups: the tile's epilogue operand
   // requests (groups 0-3), the staging of tile k+1 into the other buffer (groups 4-8), the row requests of tile
   // k+2 (groups 9-13) and the id requests of tile k+3 (group 14).  par3 = k % 3 indexes the per-row offset arrays.
+  // H = 64 has 8 MFMA groups: two of these 15 actions after each.
+  auto shadow = [&](int i, int k, int par3, int buf, int nxt3) {
+    if (i < 4) fetch_operand(par3, i);
+    else if (i < 8) stage_row(buf ^ 1, i - 4);
+    else if (i == 8) stage_scalars(nxt3);
+    else if (i < 13) load_row(i - 9);
+    else if (i == 13) load_row_scalars();
+    else if (i == 14) load_ids(k + 3);
+  };
   auto tile_step = [&](int k, int par3) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
-    const float *arow = &As[buf][li * kLdsStride + 64 * h];
+    const float *arow = &As[buf][li * kStride + kHalf * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
+    for (int s4 = 0; s4 < kSteps4; ++s4) {
       float4 an = a4;
-      if (s4 + 1 < 16) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
+      if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
 #ifdef DMP_TY_DBG
       if (!(DMP_TY_DBG & 1)) {
@@ -231,12 +252,8 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      if (s4 < 4) fetch_operand(par3, s4);
-      else if (s4 < 8) stage_row(buf ^ 1, s4 - 4);
-      else if (s4 == 8) stage_scalars(nxt3);
-      else if (s4 < 13) load_row(s4 - 9);
-      else if (s4 == 13) load_row_scalars();
-      else if (s4 == 14) load_ids(k + 3);
+      if (kSteps4 == 16) shadow(s4, k, par3, buf, nxt3);
+      else { shadow(2 * s4, k, par3, buf, nxt3); shadow(2 * s4 + 1, k, par3, buf, nxt3); }
       a4 = an;
     }
   };
@@ -320,8 +337,8 @@ __global__ __launch_bounds__(kGroupThreads, 3) void mfma_typed(TypedArgs p) {
   }
 }
 
-inline unsigned typed_blocks(int64_t tiles_bound) {
-  const int64_t cap = 256 * 3;
+inline unsigned typed_blocks(int64_t tiles_bound, int per_cu = 3) {
+  const int64_t cap = 256 * per_cu;
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
 }
 inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
@@ -337,7 +354,8 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
                        int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
                        const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                        int64_t tiles_bound, int64_t E, int H, float slope, float *H1, int64_t ldh, void *stream) {
-  if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || num_nodes < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!Z || !W || !P || !selA || !selB || !slot_edge || !tile_scale || !num_tiles || !H1 || ldz < H || ldw < 2 * H ||
@@ -350,7 +368,8 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias; p.slope = slope;
-  mfma_typed<TEPI_EDGE><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  if (H == 128) mfma_typed<TEPI_EDGE, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
+  else mfma_typed<TEPI_EDGE, 64><<<typed_blocks(tiles_bound, TypedGeom<64>::kPerCU), TypedGeom<64>::kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 
@@ -358,7 +377,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
                     float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                     int64_t tiles_bound, int64_t E, int H, int w_transposed, float *dZ, int64_t ldz, void *stream) {
-  if (E < 0 || num_nodes < 0 || tiles_bound < 0 || H != 128) return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || num_nodes < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
   if (!dPre || !W || !D || !dst || !slot_edge || !tile_scale || !num_tiles || !dZ || ldp < H || ldw < 2 * H || ldd < 2 * H ||
       ldz < H || (base && ldb < H))
@@ -371,9 +391,10 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   TypedArgs p{};
   p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
-  p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : 128;
+  p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : H;
   p.s0 = s0; p.s1 = s1;
-  mfma_typed<TEPI_DZ><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  if (H == 128) mfma_typed<TEPI_DZ, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
+  else mfma_typed<TEPI_DZ, 64><<<typed_blocks(tiles_bound, TypedGeom<64>::kPerCU), TypedGeom<64>::kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 
@@ -391,7 +412,7 @@ int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, in
   p.C = C; p.ldc = ldc; p.E = rows_c; p.slot_edge = slot_row; p.slot_arow = slot_arow;
   p.tile_scale = reinterpret_cast<const float *>(tile_type); p.num_tiles = num_tiles;
   p.idxA = reinterpret_cast<const int32_t *>(row_scale);
-  mfma_typed<TEPI_REL><<<typed_blocks(tiles_bound), kGroupThreads, 0, (hipStream_t)stream>>>(p);
+  mfma_typed<TEPI_REL, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 

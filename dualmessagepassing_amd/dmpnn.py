@@ -404,7 +404,7 @@ def _gate_concat(p, g, gate):
     """``_GateConcat`` with the embedding-aware backward when ``g`` is a plain label embedding."""
     from . import fused
     src = getattr(g, "_dmp_src", None)
-    if (src is not None and g.dim() == 2 and g.size(1) == 128 and g.is_cuda and g.dtype == th.float32
+    if (src is not None and g.dim() == 2 and g.size(1) in fused.MFMA_WIDTHS and g.is_cuda and g.dtype == th.float32
             and src[0].dtype == th.float32 and src[0].size(1) <= fused.SMALLK_MAX and src[0].size(0) == g.size(0)
             and src[0].stride(1) == 1 and src[1].requires_grad and th.is_grad_enabled()):
         return _GateConcat.apply(p, g.detach(), gate, src[0], src[1])

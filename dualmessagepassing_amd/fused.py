@@ -200,7 +200,8 @@ def relu_bwd_g_colsum(d_h, act, coef, dst32, slope=0.0):
     return d_g, reduce_partials(part)
 
 
-USE_MFMA_KERNELS = True  # H == 128: fused MFMA kernels for the edge chain (csrc/dmp_mfma.hip)
+USE_MFMA_KERNELS = True  # H == 128 / 64: fused MFMA kernels for the edge chain (csrc/dmp_mfma.hip)
+MFMA_WIDTHS = (128, 64)  # one-panel kernels (out_fwd, bwd_h1), class-typed kernels and the weight-gradient kernels
 
 
 def mfma_ok(index, H):
@@ -209,8 +210,13 @@ def mfma_ok(index, H):
     return USE_MFMA_KERNELS and H == 128 and index.num_nodes * 3 * H * 4 < 2 ** 32 and index.num_edges * 4 < 2 ** 32
 
 
+def onepanel_ok(H):
+    """out_fwd_mfma / bwd_h1_mfma (dPre alone) take this width (128, or the reference's shipped 64)."""
+    return USE_MFMA_KERNELS and H in MFMA_WIDTHS
+
+
 def edge_fwd_mfma(z, Wes, P, ldp, bias, coef, index, slope=0.0):
-    """act(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128)."""
+    """act(z Wes[:, :H] + coef[dst] z Wes[:, H:] + gathers(P) + bias): one fused MFMA kernel (H=128; the class-typed variant also H=64)."""
     lib = _lib.load()
     E, H = z.shape
     out = torch.empty((E, H), dtype=torch.float32, device=z.device)
@@ -228,7 +234,8 @@ USE_TYPED_KERNELS = True  # degree-class tiles: one weight panel instead of two 
 
 def typed_ok(index, H):
     """Class-typed kernels: as mfma_ok, plus whole [E, H] arrays addressed with 32-bit byte offsets."""
-    return USE_TYPED_KERNELS and mfma_ok(index, H) and index.num_edges * 2 * H * 4 < 2 ** 32 - 8192
+    return (USE_TYPED_KERNELS and onepanel_ok(H) and index.num_nodes * 3 * H * 4 < 2 ** 32
+            and index.num_edges * 2 * 128 * 4 < 2 ** 32 - 8192)
 
 
 def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
@@ -273,7 +280,7 @@ def atb_typed(z, d_pre, coef, index):
     lib = _lib.load()
     E, H = z.shape
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    G = int(lib.dmp_atb_typed_blocks(bound))
+    G = int(lib.dmp_atb_typed_blocks_h(bound, H))
     part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
         check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
@@ -282,7 +289,7 @@ def atb_typed(z, d_pre, coef, index):
 
 
 def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
-    """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H=128).
+    """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H = 128 or 64).
     ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch)."""
     lib = _lib.load()
     R, H = h1.shape
@@ -307,7 +314,7 @@ def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None,
     else:
         d_g = out if out is not None else torch.empty((E, H), dtype=torch.float32, device=d_o.device)
         coef_e = None
-    part = torch.empty((int(lib.dmp_mfma_partial_rows(E)), H), dtype=torch.float32, device=d_o.device)
+    part = torch.empty((int(lib.dmp_mfma_partial_rows_h(E, H)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
         check(lib.dmp_bwd_h1_fused(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
@@ -318,16 +325,17 @@ def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None,
 
 def atb_rows(a, b, gate=None, colsum=True):
     """``((gate (.) a)^T b  [M,N],  column sums of gate (.) a  [M] (or None))`` in one MFMA pass over the rows
-    (csrc/dmp_atb.hip); M, N multiples of 128.  A Linear's weight and bias gradient with a row gate fused in."""
+    (csrc/dmp_atb.hip); M, N multiples of 128 (or of 64).  A Linear's weight and bias gradient with a row gate fused in."""
     lib = _lib.load()
     R, M = a.shape
     N = b.size(1)
-    G = int(lib.dmp_atb_rows_blocks(R, M, N))
+    blk = atb_block(M, N)
+    G = int(lib.dmp_atb_rows_blocks_h(R, M, N, blk))
     part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
     part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
     with _lib.timed("atb_rows[M=%d,N=%d,R=%d]", (M, N, R), 4 * (M + N) * R + (4 * R if gate is not None else 0)):
-        check(lib.dmp_atb_rows(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, M, N, ptr(part), ptr(part_cs),
-                               stream_ptr()), "dmp_atb_rows")
+        check(lib.dmp_atb_rows_h(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, M, N, blk, ptr(part), ptr(part_cs),
+                                 stream_ptr()), "dmp_atb_rows_h")
     return reduce_partials(part).view(M, N), (reduce_partials(part_cs) if colsum else None)
 
 
@@ -335,7 +343,7 @@ SMALLK_MAX = 16
 
 
 def smallk_atb(x, d, gate=None):
-    """``x^T (gate (.) d)``  ([K, H], K <= 16, H = 128) in one pass over ``d``: the weight gradient of a narrow
+    """``x^T (gate (.) d)``  ([K, H], K <= 16, H = 128 or 64) in one pass over ``d``: the weight gradient of a narrow
     input layer (label encodings @ W) whose output was gated row-wise (csrc/dmp_fused.hip::smallk_atb_k)."""
     lib = _lib.load()
     R, K = x.shape
@@ -365,10 +373,11 @@ def atb_rows_multi(products):
         _ATB_JOB = type("dmp_atb_job", (ctypes.Structure,), {"_fields_": [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("gate", P), ("partial", P),
                                                                           ("partial_stride", I64), ("ldp", I), ("partial_colsum", P), ("cs_ld", I)]})
     R = products[0][0].size(0)
-    nblk = sum((a.size(1) // 128) * (b.size(1) // 128) for a, b, _, _ in products)
+    blk = min(atb_block(a.size(1), b.size(1)) for a, b, _, _ in products)     # one block size per launch
+    nblk = sum((a.size(1) // blk) * (b.size(1) // blk) for a, b, _, _ in products)
     if nblk > MAX_ATB_JOBS:
         raise ValueError("atb_rows_multi: more than %d output blocks" % MAX_ATB_JOBS)
-    G = int(lib.dmp_atb_jobs_blocks(R, nblk))
+    G = int(lib.dmp_atb_jobs_blocks_h(R, nblk, blk))
     jobs = (_ATB_JOB * nblk)()
     parts, k = [], 0
     for a, b, gate, colsum in products:
@@ -376,24 +385,31 @@ def atb_rows_multi(products):
         part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
         part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
         parts.append((part, part_cs, M, N))
-        for ia in range(M // 128):
-            for ib in range(N // 128):
+        for ia in range(M // blk):
+            for ib in range(N // blk):
                 j = jobs[k]
-                j.A, j.lda, j.B, j.ldb = a.data_ptr() + 512 * ia, a.stride(0), b.data_ptr() + 512 * ib, b.stride(0)
+                j.A, j.lda, j.B, j.ldb = a.data_ptr() + 4 * blk * ia, a.stride(0), b.data_ptr() + 4 * blk * ib, b.stride(0)
                 j.gate = ptr(gate)
-                j.partial, j.partial_stride, j.ldp = part.data_ptr() + 4 * (ia * 128 * N + ib * 128), M * N, N
-                j.partial_colsum = (part_cs.data_ptr() + 512 * ia) if (colsum and ib == 0) else None
+                j.partial, j.partial_stride, j.ldp = part.data_ptr() + 4 * (ia * blk * N + ib * blk), M * N, N
+                j.partial_colsum = (part_cs.data_ptr() + 4 * blk * ia) if (colsum and ib == 0) else None
                 j.cs_ld = M
                 k += 1
     with _lib.timed("atb_rows_multi[blocks=%d,R=%d]", (nblk, R), 0):
-        check(lib.dmp_atb_rows_jobs(jobs, nblk, R, stream_ptr()), "dmp_atb_rows_jobs")
+        check(lib.dmp_atb_rows_jobs_h(jobs, nblk, R, blk, stream_ptr()), "dmp_atb_rows_jobs_h")
     return [(reduce_partials(part).view(M, N), (reduce_partials(part_cs) if part_cs is not None else None))
             for part, part_cs, M, N in parts]
 
 
+def atb_block(M, N):
+    """Output block size of the MFMA weight-gradient kernel for an [M, N] product: 128, 64 or 0 (not taken)."""
+    if M % 128 == 0 and N % 128 == 0:
+        return 128
+    return 64 if (M % 64 == 0 and N % 64 == 0 and 64 in MFMA_WIDTHS) else 0
+
+
 def atb_ok(a, b):
     """The MFMA weight-gradient kernel takes this product (else: ``atb``, batched library GEMMs)."""
-    return (a.is_cuda and a.dtype == torch.float32 and a.size(1) % 128 == 0 and b.size(1) % 128 == 0 and a.size(0) >= 4096
+    return (a.is_cuda and a.dtype == torch.float32 and atb_block(a.size(1), b.size(1)) > 0 and a.size(0) >= 4096
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
             and a.size(0) * max(a.stride(0), b.stride(0)) * 4 < (1 << 32) - 8192)
@@ -521,11 +537,11 @@ def _layer_aux_params(layer):
 
 def fold_layers(layers):
     """-> one ``(Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t)`` per layer (the last three: transposed copies without
-    gradient, the layouts the kernels read coalesced).  H = 128 on the GPU: one HIP launch for all layers (and two for
+    gradient, the layouts the kernels read coalesced).  H = 128 / 64 on the GPU: one HIP launch for all layers (and two for
     their backward); otherwise the same algebra in differentiable torch ops."""
     layers = list(layers)
     H = layers[0].nloop_weight.size(1)
-    if H == 128 and layers[0].nloop_weight.is_cuda and all(l.nloop_weight.size(1) == H for l in layers):
+    if H in MFMA_WIDTHS and layers[0].nloop_weight.is_cuda and all(l.nloop_weight.size(1) == H for l in layers):
         flat = _FoldLayers.apply(len(layers), *[p for l in layers for p in _layer_params(l) + _layer_aux_params(l)])
         return [tuple(flat[8 * i:8 * i + 8]) for i in range(len(layers))]
     out = []
@@ -557,7 +573,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
         XP = x @ Wx
         H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn, slope)
-        if H == 128:   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
+        if onepanel_ok(H):   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
             xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None, nW2t)
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
@@ -611,8 +627,8 @@ class _FusedDMPLayer(torch.autograd.Function):
             dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
-            one_launch = H == 128 and atb_ok(dxn, H1n) and atb_ok(x, dXP) and atb_ok(S, dXP)
-            if H == 128 and atb_ok(dxn, H1n):
+            one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and atb_ok(S, dXP)
+            if onepanel_ok(H) and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
                 if not one_launch:
                     dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
@@ -635,11 +651,10 @@ class _FusedDMPLayer(torch.autograd.Function):
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
             dz = None
             if ctx.needs_input_grad[4]:
-                if mfma:
-                    if typed:
-                        dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT)
-                    else:
-                        dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
+                if typed:
+                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT)
+                elif mfma:
+                    dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)

@@ -403,7 +403,7 @@ class _MatmulXW(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             from . import fused
             if (x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.dim() == 2 and dy.dim() == 2
-                    and 1 <= x.size(1) <= fused.SMALLK_MAX and dy.size(1) == 128 and x.stride(1) == 1 and x.size(0) > 0):
+                    and 1 <= x.size(1) <= fused.SMALLK_MAX and dy.size(1) in fused.MFMA_WIDTHS and x.stride(1) == 1 and x.size(0) > 0):
                 dW = fused.smallk_atb(x, dy.contiguous(), None)   # narrow inputs (label encodings): one pass over dy
             else:
                 dW = atb_splitk(x, dy)

@@ -85,7 +85,7 @@ class _PooledHeadsHIP(th.autograd.Function):
     """All pooled heads of the model and their blend in three HIP launches (csrc/dmp_heads.hip):
     ``pred = sum_i blend_i * head_i(sums_i[:B], sums_i[B:])``.  Inputs per head: ``sums`` [2B, H] (pattern rows, then
     target rows: one gradient buffer comes back), ``pl`` / ``gl`` [B, 1], the bias factors, the blend weight [B, 1]
-    (no gradient) and the eight parameters.  H = hidden = 128; activation ReLU (``slope`` 0) or LeakyReLU."""
+    (no gradient) and the eight parameters.  H = hidden = 128 or 64; activation ReLU (``slope`` 0) or LeakyReLU."""
 
     @staticmethod
     def forward(ctx, n_heads, slope, *args):
@@ -267,9 +267,11 @@ class PredictNet(nn.Module):
         return activation_slope(self.act)
 
     def hip_head_ok(self, sums):
-        """The three-launch HIP heads (``_PooledHeadsHIP``) compute this head: ReLU / LeakyReLU, width 128, fp32 on the GPU."""
-        return (self.act_slope() is not None and self.pool_kind == "sum" and self.input_dim == 128 and self.hidden_dim == 128
-                and sums is not None and sums.is_cuda and sums.dtype == th.float32 and sums.dim() == 2 and sums.size(1) == 128)
+        """The three-launch HIP heads (``_PooledHeadsHIP``) compute this head: ReLU / LeakyReLU, input = hidden width 128 or
+        64 (the reference's shipped pred_hid_dim), fp32 on the GPU."""
+        return (self.act_slope() is not None and self.pool_kind == "sum" and self.input_dim in (128, 64)
+                and self.hidden_dim == self.input_dim and sums is not None and sums.is_cuda and sums.dtype == th.float32
+                and sums.dim() == 2 and sums.size(1) == self.input_dim)
 
     def head_params(self):
         return (self.p_fc.weight, self.p_fc.bias, self.g_fc.weight, self.g_fc.bias, self.pred_fc1.weight, self.pred_fc1.bias,

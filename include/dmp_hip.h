@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 41
+#define DMP_ABI_VERSION 42
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -726,7 +726,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
  *   dPre[e] = H1[e] > 0 ? gate[e] (dO[e] W2) : 0 -- the separate gate pass of the backward is fused away
  *   (gate must be NULL with coefE).  Also serves the node update's MLP (rows = nodes, gate = v_gate).
  */
-int64_t dmp_mfma_partial_rows(int64_t num_edges);
+int64_t dmp_mfma_partial_rows(int64_t num_edges);            /* H = 128 */
+int64_t dmp_mfma_partial_rows_h(int64_t num_edges, int H);   /* H = 128 or 64 */
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
                      const float *H1, int64_t ldh, const float *coefE, const float *gate,
                      int64_t num_edges, int H, float slope, float *dG, int64_t ldg, float *partial,
@@ -779,7 +780,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  * dW = [dA' | dB'] in the layout of W) --, to be summed with dmp_reduce_partials (fixed order:
  * bit-stable for a given tile list).
  */
-int64_t dmp_atb_typed_blocks(int64_t tiles_bound);
+int64_t dmp_atb_typed_blocks(int64_t tiles_bound);          /* H = 128 */
+int64_t dmp_atb_typed_blocks_h(int64_t tiles_bound, int H); /* H = 128 or 64 (the reference's shipped hidden_dim) */
 int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
                   const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                   int64_t tiles_bound, int64_t num_edges, int H, float *partial_T,
@@ -799,6 +801,11 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
 int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N);
 int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
                  int64_t rows, int M, int N, float *partial, float *partial_colsum, void *stream);
+/* The same with H x H output blocks, H = 128 (the two functions above) or 64: M and N multiples of H. */
+int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H);
+int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
+                   int64_t rows, int M, int N, int H, float *partial, float *partial_colsum,
+                   void *stream);
 
 /*
  * Relation-typed products of the relational layers (SubgraphCountingMatching/models/rgcn.py:98-123,
@@ -838,6 +845,9 @@ typedef struct {
 } dmp_atb_job;
 int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs);
 int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream);
+/* H x H output blocks per job, H = 128 (the two functions above) or 64. */
+int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H);
+int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream);
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup
@@ -848,6 +858,9 @@ void dmp_dev_set_mfma_variant(int variant);
  * the bare pipeline of the two kernels above, kept for tests and tuning. */
 int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed,
                   float *C, int64_t ldc, int64_t rows, int ncols, void *stream);
+/* C[E, 64] = A[E, 64] B: the same pipeline at the reference's shipped hidden_dim (two waves per workgroup). */
+int dmp_gemm_k64(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed,
+                 float *C, int64_t ldc, int64_t rows, void *stream);
 
 #ifdef __cplusplus
 }

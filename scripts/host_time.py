@@ -6,6 +6,7 @@ from dualmessagepassing_amd.tuning import enable_tuned_gemms
 if not os.environ.get("NO_TUNE"): enable_tuned_gemms()
 dev = torch.device("cuda:0")
 cfg = dict(bench.CFG)
+if os.environ.get("HID"): cfg["hid"] = int(os.environ["HID"])
 shard = bench.make_shard(cfg, 0, dev)
 step, model = bench.build_step(cfg, shard, dev)
 from dualmessagepassing_amd import basemodel

@@ -165,17 +165,19 @@ def test_pooled_head_single_node_matches_op_by_op(kind, act, gpu):
         assert a.shape == b.shape and th.allclose(a, b, rtol=1e-4, atol=1e-4), (i, (a - b).abs().max().item())
 
 
+@pytest.mark.parametrize("width", [128, 64])
 @pytest.mark.parametrize("act", ["relu", "leaky_relu"])
 @pytest.mark.parametrize("B", [1, 257, 1024])
 @pytest.mark.parametrize("n_heads", [1, 2, -2])
-def test_hip_heads_match_op_by_op(B, n_heads, act, gpu):
+def test_hip_heads_match_op_by_op(B, n_heads, act, width, gpu):
     """pred._PooledHeadsHIP (all heads + blend: one launch forward, two backward) against the op-by-op algebra:
     the blended prediction and every input / parameter gradient."""
     from dualmessagepassing_amd.pred import PRED_NETS, _PooledHeadsHIP
     by_len, n_heads = n_heads < 0, abs(n_heads)      # -2: the blend weights come out of the op itself (dmp_heads_blend)
     th.manual_seed(7 + B)
-    d = h = 128
+    d = h = width
     nets = [PRED_NETS["SumPredictNet"](d, h, act_func=act).to(gpu) for _ in range(n_heads)]
+    assert all(net.hip_head_ok(th.empty(2, d, device=gpu)) for net in nets)
     gen = th.Generator().manual_seed(8)
     for net in nets:
         for p in net.parameters():

@@ -587,15 +587,15 @@ def test_pingpong_driver_matches_default(gpu):
         assert th.equal(a, b)
 
 
+@pytest.mark.parametrize("h", [128, 64])
 @pytest.mark.parametrize("num_layers", [1, 3, 4])
-def test_fold_layers_matches_torch_algebra(num_layers, gpu):
+def test_fold_layers_matches_torch_algebra(num_layers, h, gpu):
     """fused.fold_layers (dmp_fold_layers / dmp_unfold_layers: one launch for all layers) against the same
     algebra in differentiable torch ops: the folded weights and, through a random cotangent, every parameter
     gradient (4 layers: more than DMP_FOLD_MAX_LAYERS, split over launches)."""
     from dualmessagepassing_amd import fused
     from dualmessagepassing_amd.dmpnn import DMPLayer
     th.manual_seed(num_layers)
-    h = 128
     layers = [DMPLayer(h, h, num_mlp_layers=2, batch_norm=False).to(gpu) for _ in range(num_layers)]   # Linear-ReLU-Linear MLPs: the fused path
     for l in layers:
         for p in l.parameters():
@@ -631,11 +631,10 @@ def test_fold_layers_matches_torch_algebra(num_layers, gpu):
 
 @pytest.mark.parametrize("rows,k", [(1, 1), (37, 10), (70001, 10), (5000, 16)])
 @pytest.mark.parametrize("gated", [False, True])
-def test_smallk_gated_weight_gradient(rows, k, gated, gpu):
+def test_smallk_gated_weight_gradient(rows, k, gated, gpu, h=128):
     """fused.smallk_atb: x^T (gate (.) d) for a narrow x (label encodings) in one pass, against fp64, bit-stable;
     d a row slice of a larger matrix (the union gradient's target rows)."""
     from dualmessagepassing_amd import fused
-    h = 128
     gen = th.Generator().manual_seed(rows * 31 + k)
     x = (th.rand(rows, k, generator=gen) < 0.5).float().to(gpu)
     full = th.randn(rows + 5, h, generator=gen).to(gpu)
@@ -648,14 +647,21 @@ def test_smallk_gated_weight_gradient(rows, k, gated, gpu):
     assert th.equal(got, fused.smallk_atb(x, d, gate))
 
 
+@pytest.mark.parametrize("rows,k,gated", [(1, 1, True), (37, 10, False), (70001, 10, True), (5000, 16, True)])
+def test_smallk_gated_weight_gradient_h64(rows, k, gated, gpu):
+    """The same at the reference's shipped hidden_dim 64 (one value per lane)."""
+    test_smallk_gated_weight_gradient(rows, k, gated, gpu, h=64)
+
+
+@pytest.mark.parametrize("h", [128, 64])
 @pytest.mark.parametrize("rows,k", [(1, 3), (4099, 10), (70001, 16)])
-def test_gate_concat_from_label_encodings(rows, k, gpu):
+def test_gate_concat_from_label_encodings(rows, k, h, gpu):
     """dmpnn._gate_concat with a plain label embedding as the gated half: the union rows come from the K inputs
     per row (dmp_smallk_embed_gate) and the embedding's weight gradient from one gated pass over the upstream
     gradient (dmp_smallk_atb) -- against the unfused autograd path cat([p, gate * (enc @ W)])."""
     from dualmessagepassing_amd import dmpnn
     from dualmessagepassing_amd.embed import Embedding
-    h, n_p = 128, 37
+    n_p = 37
     gen = th.Generator().manual_seed(rows + k)
     emb = Embedding(k, h).to(gpu)
     enc = (th.rand(rows, k, generator=gen) < 0.4).float().to(gpu)
@@ -837,3 +843,106 @@ def _tiled_case(h, gpu, rng, ops, collate_device, union_graphs):
                                     tiling=g.index().tiling),
                     ops.seg_sum_raw(m[:g.number_of_edges()], *g.index().incidence(), g.number_of_nodes(), None, True, 1.0, -1.0))
     assert batch([(64, 300)]).tiling is None
+
+
+@pytest.mark.parametrize("rows", [1, 31, 129, 5000, 70001])
+@pytest.mark.parametrize("slope", [0.0, 1.0 / 5.5])
+def test_mfma_kernels_h64(rows, slope, gpu):
+    """The MFMA kernels at the reference's shipped hidden_dim 64 (config.py:298-301; two waves per workgroup): the plain
+    product, out_fwd (Linear + gate + residual), bwd_h1 (dPre alone: gate, output slice), the class-typed edge_fwd /
+    bwd_z / weight gradient and the row weight-gradient kernels (64 x 64 output blocks), each against its fp64
+    formula, bit-stable from launch to launch."""
+    from dualmessagepassing_amd import _lib, fused
+    from dualmessagepassing_amd._lib import ptr, stream_ptr
+    lib = _lib.load()
+    h = 64
+    gen = th.Generator().manual_seed(rows + 3)
+    rng = np.random.default_rng(rows + 3)
+    a = th.randn(rows, h, generator=gen).to(gpu)
+    w = th.randn(h, h, generator=gen).to(gpu)
+    c = th.empty(rows, h, device=gpu)
+    _lib.check(lib.dmp_gemm_k64(ptr(a), h, ptr(w), h, 0, ptr(c), h, rows, stream_ptr()), "gemm64")
+    assert th.allclose(c.double(), a.double() @ w.double(), rtol=1e-5, atol=2e-4)
+    _lib.check(lib.dmp_gemm_k64(ptr(a), h, ptr(w.t().contiguous()), h, 1, ptr(c), h, rows, stream_ptr()), "gemm64_t")
+    assert th.allclose(c.double(), a.double() @ w.double(), rtol=1e-5, atol=2e-4)
+    n = max(2, rows // 5)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, gpu)
+    assert fused.typed_ok(ix, h) and fused.onepanel_ok(h)
+    coef = ix.degree_coef(ix.out_deg)
+    ts, td, tr = _t(src).to(gpu), _t(dst).to(gpu), _t(rev).to(gpu)
+    ce = coef.double()[td][:, None]
+    act = lambda x: th.where(x > 0, x, slope * x)
+    # ---- out_fwd
+    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    gate = (th.rand(rows, generator=gen) * (th.rand(rows, generator=gen) > 0.3)).to(gpu)
+    prev = th.randn(rows, h, generator=gen).to(gpu)
+    for g_, p_ in ((gate, prev), (None, prev), (gate, None), (None, None)):
+        got = fused.out_fwd_mfma(a, w2, bias, g_, p_)
+        ref = a.double() @ w2.double().t() + bias.double()
+        if g_ is not None:
+            ref = ref * g_.double()[:, None]
+        if p_ is not None:
+            ref = ref + p_.double()
+        assert th.allclose(got.double(), ref, rtol=1e-5, atol=2e-4)
+        assert th.equal(got, fused.out_fwd_mfma(a, w2, bias, g_, p_))
+    # ---- bwd_h1, dPre alone
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = act(th.randn(rows, h, generator=gen)).to(gpu)
+    lin = d_o.double() @ w2.double()
+    for g_ in (gate, None):
+        d_p, cs = fused.bwd_h1_mfma(d_o, w2, h1, both_halves=False, gate=g_, slope=slope)
+        x = lin * (g_.double()[:, None] if g_ is not None else 1.0)
+        ref = th.where(h1 > 0, x, slope * x)
+        assert d_p.shape == (rows, h) and th.allclose(d_p.double(), ref, rtol=1e-5, atol=2e-4)
+        assert th.allclose(cs.double(), ref.sum(0), rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    wide = th.full((rows, 3 * h), 7.0, device=gpu)
+    d_p2, cs2 = fused.bwd_h1_mfma(d_o, w2, h1, both_halves=False, gate=gate, out=wide[:, :h], slope=slope)
+    d_p1, cs1 = fused.bwd_h1_mfma(d_o, w2, h1, both_halves=False, gate=gate, slope=slope)
+    assert th.equal(wide[:, :h], d_p1) and th.equal(cs2, cs1) and bool((wide[:, h:] == 7.0).all())
+    # ---- class-typed edge forward / input gradient / weight gradient
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    got = fused.edge_fwd_typed(a, wes, xp[:, h:], 3 * h, bias, coef, ix, slope)
+    g = a.double() @ wes.double()
+    ai, bi = th.where(tr, ts, td), th.where(tr, td, ts)
+    ref = act(g[:, :h] + ce * g[:, h:] + xp.double()[ai][:, h:2 * h] - xp.double()[bi][:, 2 * h:] + bias.double())
+    assert th.allclose(got.double(), ref, rtol=1e-5, atol=2e-4)
+    assert th.equal(got, fused.edge_fwd_typed(a, wes, xp[:, h:], 3 * h, bias, coef, ix, slope))
+    two = fused.edge_combine_raw(a @ wes, 2 * h, xp[:, h:], 3 * h, bias, coef, ix, h, relu=True, slope=slope)
+    assert th.allclose(got, two, rtol=1e-5, atol=2e-4)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    gs = th.where(tr[:, None], d_s.double()[td][:, h:], -d_s.double()[td][:, :h])
+    for b_ in (prev, None):
+        got = fused.bwd_z_typed(d_pre, h, wes, d_s, b_, coef, ix)
+        ref = gs + d_pre.double() @ wes.double()[:, :h].t() + (ce * d_pre.double()) @ wes.double()[:, h:].t()
+        if b_ is not None:
+            ref = ref + b_.double()
+        assert th.allclose(got.double(), ref, rtol=1e-5, atol=3e-4)
+        assert th.equal(got, fused.bwd_z_typed(d_pre, h, wes, d_s, b_, coef, ix))
+    got = fused.atb_typed(a, d_pre, coef, ix)
+    want = th.cat([a.double().t() @ d_pre.double(), a.double().t() @ (d_pre.double() * ce)], 1)
+    assert got.shape == (h, 2 * h) and float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert th.equal(got, fused.atb_typed(a, d_pre, coef, ix))
+    # ---- row weight gradients, 64 x 64 output blocks
+    tol = 1e-4 * max(1.0, rows ** 0.5)
+    for g_ in (gate, None):
+        got, cs = fused.atb_rows(a, d_pre, g_)
+        ga = a.double() * (g_.double()[:, None] if g_ is not None else 1.0)
+        assert got.shape == (h, h) and th.allclose(got, (ga.t() @ d_pre.double()).float(), rtol=1e-5, atol=tol)
+        assert th.allclose(cs, ga.sum(0).float(), rtol=1e-5, atol=tol)
+        assert th.equal(got, fused.atb_rows(a, d_pre, g_)[0])
+    a3 = th.randn(rows, 2 * h + 4, generator=gen).to(gpu)[:, :2 * h]
+    b3 = th.randn(rows, 3 * h, generator=gen).to(gpu)
+    got3, cs3 = fused.atb_rows(a3, b3, gate)
+    g3 = a3.double() * gate.double()[:, None]
+    assert got3.shape == (2 * h, 3 * h) and th.allclose(got3, (g3.t() @ b3.double()).float(), rtol=1e-5, atol=tol)
+    assert th.allclose(cs3, g3.sum(0).float(), rtol=1e-5, atol=tol)
+    multi = fused.atb_rows_multi([(a, d_pre, gate, True), (a3, d_pre, None, False), (a, b3, None, False)])
+    one = fused.atb_rows(a, d_pre, gate)               # other workgroup ranges than the shared launch: equal up to summation order
+    assert th.allclose(multi[0][0], one[0], rtol=1e-5, atol=tol) and th.allclose(multi[0][1], one[1], rtol=1e-5, atol=tol)
+    assert th.allclose(multi[1][0], (a3.double().t() @ d_pre.double()).float(), rtol=1e-5, atol=tol) and multi[1][1] is None
+    assert th.allclose(multi[2][0], (a.double().t() @ b3.double()).float(), rtol=1e-5, atol=tol)
