@@ -485,7 +485,7 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * embed.py:103-120 feeding `e = e * e_gate`, basemodel.py:1515):
  *     partial[b][k, :] = sum over workgroup b's rows r of X[r, k] * gate[r] * D[r, :]
  * X [rows, ldx >= K] (K <= 16 inputs per row: the multihot label encodings), D [rows, ldd >= H] the upstream
- * gradient of gate * (X W), gate [rows] or NULL; H = 128 only.
+ * gradient of gate * (X W), gate [rows] or NULL; H = 128 or 64.
  * partial: [dmp_smallk_atb_blocks(rows), K*H]; finish with dmp_reduce_partials. */
 /* Forward of the same layer with its gate:  out[r, :] = gate[r] * (X[r, :K] W)  with W [K, ldw >= H]
  * (embed.py:103-120 + basemodel.py:1515), written where the caller wants the gated rows (ldo >= H). */
@@ -611,7 +611,7 @@ int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int
                       void *stream);
 
 /*
- * Parameter algebra of the fused layer for all layers of a rep-net in one launch (H = 128 only).
+ * Parameter algebra of the fused layer for all layers of a rep-net in one launch (H = 128 or 64).
  * The first Linear of the node / edge MLP (dmpnn.py:45-60,129-156) is folded into the projections that
  * feed it:  [W_loop; W_in; W_out; nbias] W0n^T  and  [W_eloop; W_src - W_dst; W_dst; W_src; ebias] W0e^T,
  * written in the layouts the layer kernels read:
@@ -646,7 +646,7 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
  *     p = ps Wp^T + scale_p bp;  g = gs Wg^T + scale_g bg;  s = [pl, gl, 1/pl, 1/gl]
  *     f = [p | g | g - p | g * p | s];  y1 = act(f W1^T + b1);  y = [y1 | s] W2^T + b2
  * act(x) = max(x, slope x): ReLU for slope 0, the reference's default pred_act_func leaky_relu for 1/5.5.
- * H = width of ps / gs and of the hidden layer = 128 only.  Weights in nn.Linear layout: Wp, Wg [H,H], W1 [H,4H+4],
+ * H = width of ps / gs and of the hidden layer = 128 or 64.  Weights in nn.Linear layout: Wp, Wg [H,H], W1 [H,4H+4],
  * W2 [1,H+4]; ps / gs [B, ld >= H]; pl / gl [B] (mask counts); scale_p / scale_g: the factor on the bias (the padded
  * length for sum pooling).  Forward writes y [B] and keeps F [B,4H+4] = f and Y1S [B,H+4] = [y1 | s] for backward.
  * Backward: dy [B] (times dy_scale [B] if given: the blend weight of this head) -> dps / dgs [B, ld] (may be NULL),
@@ -679,7 +679,10 @@ int dmp_heads_blend(const float *const *y, const float *const *gl, float *const 
 
 
 /* ------------------------------------------------------------------------- */
-/* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32; H = 128 only) */
+/* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32).  H = 128; the one-panel kernels (dmp_out_fwd_fused,
+ * dmp_bwd_h1_fused without coefE), the class-typed kernels (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_atb_typed) and the
+ * row weight-gradient kernels (dmp_atb_rows_h, dmp_atb_rows_jobs_h) also H = 64, the reference's shipped hidden_dim
+ * (config.py:298-301): DMP_ERR_UNSUPPORTED for any other width. */
 /* ------------------------------------------------------------------------- */
 
 /*
