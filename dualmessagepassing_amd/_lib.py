@@ -134,6 +134,10 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 42
+# DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
+# lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
+# datasets once with harness.validate_samples, or run a debugging pass with this switch)
+VALIDATE = os.environ.get("DMP_VALIDATE", "") not in ("", "0")
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

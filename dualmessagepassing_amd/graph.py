@@ -79,7 +79,7 @@ class GraphIndex:
         self._inc = None
         self._coef = {}
         self.tiling = None
-        if validate and int(status.sum().item()) != 0:
+        if (validate or _lib.VALIDATE) and int(status.sum().item()) != 0:
             raise _lib.DmpError("edge endpoint outside [0, num_nodes)")
 
     def incidence(self):

@@ -391,6 +391,32 @@ def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
             "eval_metric": float(_CRIT[eval_metric](pred, target)), "pred": pred.view(-1).cpu(), "counts": target.view(-1).cpu()}
 
 
+def validate_samples(samples):
+    """Host-side check of a dataset, once: every edge endpoint of every pattern / graph inside ``[0, number_of_nodes)``
+    (the device index builds only flag such edges in a status word that the training loop does not read back) and the
+    reversed-edge flags, when present, one per edge.  Raises ``ValueError`` naming the first offending sample."""
+    samples = getattr(samples, "samples", samples)
+    for i, x in enumerate(samples):
+        for key in ("pattern", "graph"):
+            g = x[key]
+            n = g.number_of_nodes()
+            src, dst = g.all_edges(form="uv", order="eid")
+            if src.numel() and (int(th_min(src, dst)) < 0 or int(th_max(src, dst)) >= n):
+                raise ValueError("sample %d (%s): %s has an edge endpoint outside [0, %d)" % (i, x.get("id", "?"), key, n))
+            rev = g.edata.get("is_reversed") if hasattr(g, "edata") else None
+            if rev is not None and rev.numel() != src.numel():
+                raise ValueError("sample %d (%s): %s has %d is_reversed flags for %d edges" % (i, x.get("id", "?"), key, rev.numel(), src.numel()))
+    return len(samples)
+
+
+def th_min(a, b):
+    return min(a.min().item(), b.min().item())
+
+
+def th_max(a, b):
+    return max(a.max().item(), b.max().item())
+
+
 def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_dir=None, config=None, sync=None,
         eval_metric="MAE", seed=0, **train_kw):
     """The epoch loop of ``train.py:1296-1380`` reduced to its contract: per epoch one shuffled training
@@ -399,6 +425,8 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history."""
     from . import dataio
     from .tuning import enable_tuned_gemms
+    validate_samples(train_set)
+    validate_samples(dev_set)
     enable_tuned_gemms()      # the layer's [rows, 128] x [128, 128..384] products with the solutions picked for MI355X
     sync = sync or FlatGradSync(model)
     rng = np.random.default_rng(seed)

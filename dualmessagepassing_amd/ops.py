@@ -209,6 +209,8 @@ class _TakeRows(torch.autograd.Function):
         ws = torch.empty(lib.dmp_csr_workspace_words(N, M), **i32)
         check(lib.dmp_csr_build(ptr(idx), None, M, N, ptr(ctx.rowptr), ptr(ctx.ent), ptr(idx32), ptr(deg), ptr(status),
                                 ptr(ws), stream_ptr()), "dmp_csr_build(index)")
+        if _lib.VALIDATE and int(status.item()) != 0:
+            raise _lib.DmpError("take_rows: index outside [0, %d)" % N)
         ctx.N = N
         return gather_rows_raw(X.contiguous(), idx32)
 

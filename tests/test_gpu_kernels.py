@@ -946,3 +946,23 @@ def test_mfma_kernels_h64(rows, slope, gpu):
     assert th.allclose(multi[0][0], one[0], rtol=1e-5, atol=tol) and th.allclose(multi[0][1], one[1], rtol=1e-5, atol=tol)
     assert th.allclose(multi[1][0], (a3.double().t() @ d_pre.double()).float(), rtol=1e-5, atol=tol) and multi[1][1] is None
     assert th.allclose(multi[2][0], (a.double().t() @ b3.double()).float(), rtol=1e-5, atol=tol)
+
+
+def test_validate_switch_raises_on_out_of_range_entries(gpu, monkeypatch):
+    """DMP_VALIDATE (``_lib.VALIDATE``): the index builds read their status word back and raise on an edge endpoint /
+    lookup index outside its range; without it the entry is flagged only (one host sync saved per build)."""
+    from dualmessagepassing_amd import _lib, ops
+    from dualmessagepassing_amd.graph import GraphIndex
+    src = th.tensor([0, 1, 2], device=gpu)
+    dst = th.tensor([1, 5, 0], device=gpu)          # 5 >= num_nodes
+    x = th.randn(3, 8, device=gpu)
+    monkeypatch.setattr(_lib, "VALIDATE", False)
+    GraphIndex(src, dst, 3)                          # flagged, not raised
+    with pytest.raises(_lib.DmpError):
+        GraphIndex(src, dst, 3, validate=True)
+    monkeypatch.setattr(_lib, "VALIDATE", True)
+    with pytest.raises(_lib.DmpError):
+        GraphIndex(src, dst, 3)
+    with pytest.raises(_lib.DmpError):
+        ops.take_rows(x, th.tensor([0, 3], device=gpu))
+    assert th.equal(ops.take_rows(x, th.tensor([2, 0], device=gpu)), x[[2, 0]])

@@ -97,3 +97,26 @@ def test_native_enumeration_equals_python_twin_and_batch_counts():
     big = (np.array([0, 1, 2]), np.array([1, 2, 0]), np.zeros(3, int), np.zeros(3, int),
            np.repeat(np.arange(12), 11), np.concatenate([np.delete(np.arange(12), i) for i in range(12)]), np.zeros(12, int), np.zeros(132, int))
     assert len(enumerate_subisomorphisms(*big)) == 12 * 11 * 10       # beyond the first buffer: directed triangles in K12
+
+
+def test_validate_samples_names_the_bad_sample():
+    import pytest
+    """harness.validate_samples: the host-side dataset check harness.fit runs once (the device index builds only
+    flag an out-of-range endpoint in a status word)."""
+    import torch as th
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd.harness import validate_samples
+
+    def g(src, dst, n):
+        return BatchedGraph(th.tensor(src), th.tensor(dst), n)
+
+    good = {"id": "a", "pattern": g([0, 1], [1, 2], 3), "graph": g([0, 3], [3, 1], 4), "counts": 0}
+    assert validate_samples([good, good]) == 2
+    bad = dict(good, id="b", graph=g([0, 4], [3, 1], 4))
+    with pytest.raises(ValueError, match=r"sample 1 \(b\): graph"):
+        validate_samples([good, bad])
+    flagged = dict(good, id="c")
+    flagged["pattern"] = g([0, 1], [1, 2], 3)
+    flagged["pattern"].edata["is_reversed"] = th.zeros(3, dtype=th.bool)
+    with pytest.raises(ValueError, match="is_reversed"):
+        validate_samples([flagged])
