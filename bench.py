@@ -146,7 +146,8 @@ def build_step(cfg, shard, device, world=1):
     sync = FlatGradSync(model)
     master = sync.flatten_parameters()      # one AdamW launch over the flat buffer: the same elementwise update
     sync.broadcast_parameters()
-    opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True)   # the reference's optimizer (train.py:1231)
+    opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True,   # the reference's optimizer (train.py:1231)
+                    capturable=bool(cfg.get("graph")))
 
     pending = []      # the gradient all-reduce of the previous step, still in flight
     M = int(cfg.get("micro_batches") or micro_batches_for(cfg))
@@ -218,6 +219,7 @@ def build_step(cfg, shard, device, world=1):
 
     step.finish = finish
     step.sync = sync
+    step.opt = opt
     step.micro_batches = M
     return step, model
 
@@ -327,6 +329,10 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep every [E, 2H] "
                     "array below 4 GiB: 1 for config 2, 4 for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the whole step (collate, index builds, fwd, bwd, gradient pack, AdamW) as ONE HIP graph during "
+                         "the warm-up and replay it in the timed region (N = 1, one micro-batch; the per-kernel HIP-event "
+                         "numbers then come from eager steps after the timed region)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path on a single-GPU box together with --single-device)")
@@ -350,7 +356,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
-               hid=args.hid)
+               hid=args.hid, graph=args.graph)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -362,8 +368,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run, graphed = step, False
+    if args.graph and world == 1 and step.micro_batches == 1:
+        # the step reads the shard's tensors and clones the size / flag tensors itself: a replay rebuilds every index
+        # of the batch on the device exactly as an eager step does
+        from dualmessagepassing_amd.dp import StepGraph
+        run = StepGraph(lambda: step(), optimizer=step.opt, max_shapes=1)
+        graphed = True
+    for _ in range(max(args.warmup, 3) if graphed else args.warmup):   # graphed: eager, record + replay, replay
+        run()
     step.finish()
     # Setup objects (modules, tuned-GEMM tables, the shard) leave the cyclic collector's working set: a full
     # collection walking them costs tens of milliseconds and would otherwise land inside a step now and then.
@@ -376,16 +389,17 @@ def main():
     # event records do not perturb the step; every other kernel is timed in extra steps below
     _lib.timer.reset()
     _lib.timer.only = "seg_sum2["
-    _lib.timer.enabled = True
+    _lib.timer.enabled = not graphed                         # no event records inside a replayed graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     step.finish()                                            # the last step's all-reduce + optimizer update: inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     kern = _lib.timer.summary()
     _lib.timer.reset()
     _lib.timer.only = None
+    _lib.timer.enabled = True
     for _ in range(3):  # un-timed: per-kernel numbers of the other HIP kernels on the path
         step()
     step.finish()
@@ -431,6 +445,8 @@ def main():
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default",
+                       "launch": ("one HIP graph replay per step (recorded during the warm-up; roofline / kernel numbers from "
+                                  "eager steps after the timed region)") if graphed else "eager launches",
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32

@@ -222,7 +222,12 @@ struct AdamArgs {
   float decay, beta1_c, beta2, beta2_c, step_size, inv_bc2_sqrt, eps;
   int nskip;                                                  // ranges [skip_lo, skip_hi) left untouched (4-float aligned)
   int64_t skip_lo[DMP_ADAMW_MAX_SKIP], skip_hi[DMP_ADAMW_MAX_SKIP];
+  // device-resident step count and learning rate (a step captured in a HIP graph: nothing per-step in the launch arguments)
+  const double *state;                                        // [step, lr] or NULL (the fields above hold the host's values)
+  double lr_wd, beta1, beta2d;                                // state != NULL: weight decay, betas for the bias corrections
 };
+
+__global__ void adamw_tick(double *state) { state[0] += 1.0; }
 
 struct PackSegs {
   const float *src[DMP_PACK_MAX_SEGMENTS];
@@ -246,7 +251,14 @@ __global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void adamw_kernel(const AdamArgs a) {
+__global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
+  if (a.state) {                                               // the host formulas of dmp_adamw_step_skip, evaluated on the device
+    const double step = a.state[0], lr = a.state[1];
+    const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2d, step);
+    a.decay = (float)(1.0 - lr * a.lr_wd);
+    a.step_size = (float)(lr / bc1);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  }
   const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < a.n; i += stride) {
     bool skip = false;                                         // parameters without a gradient this step (torch.optim.AdamW skips them)
@@ -665,20 +677,24 @@ int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_a
                              nullptr, nullptr, 0, stream);
 }
 
-int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+static int adamw_launch(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
                         int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
-                        const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
-  DMP_ROW_CHECK(n >= 0 && step >= 1 && lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
+                        double *state, const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
+  DMP_ROW_CHECK(n >= 0 && (state || (step >= 1 && lr >= 0)) && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
   DMP_ROW_CHECK(nskip >= 0 && nskip <= DMP_ADAMW_MAX_SKIP && (nskip == 0 || (skip_lo && skip_hi)));
   if (n == 0) return DMP_OK;
   DMP_ROW_CHECK(param && grad && exp_avg && exp_avg_sq);
   if (!ok16(param) || !ok16(grad) || !ok16(exp_avg) || !ok16(exp_avg_sq) || !ok16(max_exp_avg_sq)) return DMP_ERR_UNSUPPORTED;
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   AdamArgs a;
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;
-  a.decay = (float)(1.0 - lr * weight_decay);
-  a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2);
-  a.step_size = (float)(lr / bc1); a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); a.eps = (float)eps;
+  a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.state = state; a.lr_wd = weight_decay; a.beta1 = beta1; a.beta2d = beta2;
+  a.decay = 1.f; a.step_size = 0.f; a.inv_bc2_sqrt = 1.f;
+  if (!state) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.step_size = (float)(lr / bc1); a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  }
   a.nskip = nskip;
   for (int s = 0; s < nskip; ++s) {
     if (skip_lo[s] % 4 || skip_hi[s] % 4 || skip_lo[s] > skip_hi[s]) return DMP_ERR_BAD_ARG;
@@ -686,8 +702,24 @@ int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *
   }
   int64_t nb = (n / 4 + kBlock) / kBlock;
   if (nb > 2048) nb = 2048;
+  if (state) adamw_tick<<<1, 1, 0, (hipStream_t)stream>>>(state);      // step += 1, ordered before the update on the stream
   adamw_kernel<<<(unsigned)nb, kBlock, 0, (hipStream_t)stream>>>(a);
   return check_launch();
+}
+
+int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                        int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                        const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
+  return adamw_launch(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr,
+                      skip_lo, skip_hi, nskip, stream);
+}
+
+int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                       int64_t n, double *state, double beta1, double beta2, double eps, double weight_decay,
+                       const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
+  if (!state || (reinterpret_cast<uintptr_t>(state) & 7u)) return DMP_ERR_BAD_ARG;
+  return adamw_launch(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, 0.0, beta1, beta2, eps, weight_decay, 0, state,
+                      skip_lo, skip_hi, nskip, stream);
 }
 
 }  // extern "C"

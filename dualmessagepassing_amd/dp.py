@@ -192,10 +192,34 @@ class FlatAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` (optionally ``amsgrad``: the reference's optimizer, train.py:1231) whose step is
     ONE HIP launch per parameter tensor (``dmp_adamw_step``) -- meant for the single flat parameter of
     ``FlatGradSync.flatten_parameters()``.  Learning-rate schedulers work as usual (``param_groups``).
-    fp32 contiguous CUDA parameters only; no CPU path."""
+    fp32 contiguous CUDA parameters only; no CPU path.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+    ``capturable=True``: the step count and the learning rate live in device memory (``dmp_adamw_step_dev``), so a step
+    recorded in a HIP graph (``StepGraph``) replays correctly; outside a capture ``step()`` writes the group's current
+    learning rate to the device itself, around a replay ``StepGraph`` calls ``sync_hyper()``."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        self.capturable = bool(capturable)
+
+    def _device_state(self, p, group):
+        st = self.state[p]
+        if "dev" not in st:
+            # called after this step's host-side increment: the device count starts one below (the launch adds 1 first)
+            st["dev"] = torch.tensor([float(st.get("step", 1) - 1), float(group["lr"])], dtype=torch.float64, device=p.device)
+            st["dev_lr"] = float(group["lr"])
+        return st["dev"]
+
+    @torch.no_grad()
+    def sync_hyper(self):
+        """Write every group's current learning rate to its parameters' device state (one tiny launch per parameter whose
+        rate changed; nothing when it did not).  Not capturable: call it before a graph replay."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "dev" in st and st["dev_lr"] != float(group["lr"]):
+                    st["dev"][1:].fill_(float(group["lr"]))
+                    st["dev_lr"] = float(group["lr"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -218,6 +242,11 @@ class FlatAdamW(torch.optim.Optimizer):
                     if group["amsgrad"]:
                         st["max_exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
+                state = None
+                if self.capturable:
+                    state = self._device_state(p, group)
+                    if not torch.cuda.is_current_stream_capturing():
+                        self.sync_hyper()
                 # runs of the buffer whose parameters received a gradient (FlatGradSync.pack); parameters without one
                 # are left untouched like torch.optim.AdamW does (they share the buffer's step count, though)
                 runs = getattr(p, "_dmp_live_runs", None) or [(0, p.numel())]
@@ -233,11 +262,19 @@ class FlatAdamW(torch.optim.Optimizer):
                     import ctypes
                     lo = (ctypes.c_int64 * max(len(gaps), 1))(*[g[0] for g in gaps])
                     hi = (ctypes.c_int64 * max(len(gaps), 1))(*[g[1] for g in gaps])
+                    if state is not None:
+                        _lib.check(lib.dmp_adamw_step_dev(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                                          st["exp_avg_sq"].data_ptr(), _lib.ptr(mx), p.numel(), state.data_ptr(),
+                                                          b1, b2, group["eps"], group["weight_decay"], lo, hi, len(gaps),
+                                                          _lib.stream_ptr()), "dmp_adamw_step_dev")
+                        continue
                     _lib.check(lib.dmp_adamw_step_skip(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                                        st["exp_avg_sq"].data_ptr(), _lib.ptr(mx), p.numel(), float(group["lr"]), b1, b2,
                                                        group["eps"], group["weight_decay"], st["step"], lo, hi, len(gaps),
                                                        _lib.stream_ptr()), "dmp_adamw_step_skip")
                     continue
+                if state is not None:
+                    raise ValueError("FlatAdamW(capturable=True): more than 16 gaps between the parameters with gradients")
                 for off, n in runs:
                     b = 4 * off
                     _lib.check(lib.dmp_adamw_step(p.data_ptr() + b, p.grad.data_ptr() + b, st["exp_avg"].data_ptr() + b,
@@ -245,3 +282,60 @@ class FlatAdamW(torch.optim.Optimizer):
                                                   float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"],
                                                   _lib.stream_ptr()), "dmp_adamw_step")
         return loss
+
+
+class StepGraph:
+    """A training (or evaluation) step recorded once per input shape as a HIP graph and replayed: the hot path's step is
+    ~140 launches behind ~3 ms of Python; a replay is one ``hipGraphLaunch``.  ``fn(*tensors)`` must be a pure function of
+    its tensor arguments and of state it updates in place on the device (parameters, optimizer moments: use
+    ``FlatAdamW(capturable=True)``), free of host syncs, and must return a tensor or a tuple of tensors.
+
+    Per distinct ``(shape, dtype)`` signature of the arguments: the first call runs ``fn`` eagerly (lazy initialisation,
+    library workspaces), the second copies the arguments into static buffers, records ``fn`` on them and replays, later
+    calls copy and replay.  The returned tensors are the recording's own outputs: consume them (stream-ordered) before
+    the next call with the same signature.  At most ``max_shapes`` recordings are kept (each owns the memory pool of
+    its intermediates); further signatures run eagerly.  ``optimizer.sync_hyper()`` is called before every replay."""
+
+    def __init__(self, fn, optimizer=None, max_shapes=4):
+        self.fn, self.optimizer, self.max_shapes = fn, optimizer, int(max_shapes)
+        self._seen, self._graphs = set(), {}
+        self.replays = self.eager_calls = 0
+
+    @staticmethod
+    def _key(meta, tensors):
+        return (meta,) + tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
+
+    def __call__(self, *args):
+        """``args``: the tensors; a leading non-tensor (hashable: host-side sizes the step depends on) is part of the
+        signature and passed through to ``fn`` as its first argument."""
+        meta = ()
+        if args and not torch.is_tensor(args[0]):
+            meta, args = (args[0],), args[1:]
+        tensors = args
+        key = self._key(meta, tensors)
+        rec = self._graphs.get(key)
+        if rec is None:
+            if key not in self._seen or len(self._graphs) >= self.max_shapes:
+                self._seen.add(key)
+                self.eager_calls += 1
+                return self.fn(*meta, *tensors)
+            static = [torch.empty_like(t).copy_(t) for t in tensors]
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            import warnings
+            with warnings.catch_warnings():
+                # leaf gradients are produced on the recording's side stream while the parameters were made on the default
+                # one: torch warns about the mismatch; inside the recording everything runs on the one side stream
+                warnings.filterwarnings("ignore", message=".*AccumulateGrad node's stream does not match.*")
+                with torch.cuda.graph(graph):
+                    out = self.fn(*meta, *static)
+            rec = self._graphs[key] = (graph, static, out)
+        else:
+            for s, t in zip(rec[1], tensors):
+                if s.data_ptr() != t.data_ptr():
+                    s.copy_(t)
+        if self.optimizer is not None and hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()
+        rec[0].replay()
+        self.replays += 1
+        return rec[2]

@@ -183,19 +183,9 @@ class PairDataset:
         concatenated local arrays are uploaded once, batching itself happens on the device.  Returns
         ``(pattern, graph, counts [B, 1], (node_weights, edge_weights))``; the weights (pre-padded
         int64 ``[B, max]``, or None) are computed on the device when ``return_weights`` names them."""
-        out = []
-        for key in ("pattern", "graph"):
-            gs = [self.samples[i][key] for i in indices]
-            cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
-            nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
-            ne_ = np.array([len(g["src"]) for g in gs], np.int64)
-            nid = torch.from_numpy(np.concatenate([np.arange(n) for n in nn_])).to(device)
-            out.append(collate_device(cat("src"), cat("dst"), torch.from_numpy(nn_).to(device),
-                                      torch.from_numpy(ne_).to(device), int(nn_.sum()), int(ne_.sum()),
-                                      ndata={"id": nid, "label": cat("vlabel")},
-                                      edata={"id": cat("eid"), "label": cat("elabel"), "is_reversed": cat("rev", torch.bool)},
-                                      max_nodes=int(nn_.max(initial=0)), max_edges=int(ne_.max(initial=0))))
-        counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
+        meta, tensors = self.batch_arrays(indices, device)
+        out = self.graphs_from_arrays(meta, tensors)
+        counts = tensors[-1]
         weights = (None, None)
         if return_weights:
             subs = [self.samples[i]["subisomorphisms"].reshape(-1) for i in indices]
@@ -203,7 +193,37 @@ class PairDataset:
             hint = sum(self.samples[i]["counts"] * len(self.samples[i]["pattern"]["src"]) for i in indices)
             weights = subiso_weights(out[0], out[1], torch.from_numpy(np.concatenate(subs)).to(device),
                                      torch.from_numpy(ptr_host).to(device), return_weights, work_hint=int(hint))
-        return out[0], out[1], counts.unsqueeze(-1), weights
+        return out[0], out[1], counts, weights
+
+    ARRAYS_PER_GRAPH = 9    # src, dst, num_nodes, num_edges, node id, node label, edge id, edge label, is_reversed
+
+    def batch_arrays(self, indices, device):
+        """The uploaded half of ``batchify``: ``(meta, tensors)`` with ``tensors`` = the pattern batch's nine arrays
+        (local endpoints, sizes, ids, labels, reversed flags), the graph batch's nine and ``counts [B, 1]``, and ``meta``
+        = per side ``(total nodes, total edges, largest graph's nodes, largest graph's edges)`` as host ints.  Everything
+        ``graphs_from_arrays`` then does happens on the device without a host sync (``dp.StepGraph`` records it)."""
+        meta, tensors = [], []
+        for key in ("pattern", "graph"):
+            gs = [self.samples[i][key] for i in indices]
+            cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
+            nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
+            ne_ = np.array([len(g["src"]) for g in gs], np.int64)
+            nid = torch.from_numpy(np.concatenate([np.arange(n) for n in nn_])).to(device)
+            tensors += [cat("src"), cat("dst"), torch.from_numpy(nn_).to(device), torch.from_numpy(ne_).to(device), nid,
+                        cat("vlabel"), cat("eid"), cat("elabel"), cat("rev", torch.bool)]
+            meta.append((int(nn_.sum()), int(ne_.sum()), int(nn_.max(initial=0)), int(ne_.max(initial=0))))
+        counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
+        return tuple(meta), tensors + [counts.unsqueeze(-1)]
+
+    @classmethod
+    def graphs_from_arrays(cls, meta, tensors):
+        """``(pattern, graph)`` BatchedGraphs from ``batch_arrays``' output (device collate)."""
+        out = []
+        for side, (n, e, max_n, max_e) in enumerate(meta):
+            src, dst, nn_, ne_, nid, vlabel, eid, elabel, rev = tensors[side * cls.ARRAYS_PER_GRAPH:(side + 1) * cls.ARRAYS_PER_GRAPH]
+            out.append(collate_device(src, dst, nn_, ne_, n, e, ndata={"id": nid, "label": vlabel},
+                                      edata={"id": eid, "label": elabel, "is_reversed": rev}, max_nodes=max_n, max_edges=max_e))
+        return out
 
 
 class SyntheticPairs(PairDataset):
@@ -321,13 +341,14 @@ def _match_terms(crit, pred, weights, mask, pred_c, neg_slp):
 
 def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_loss="MSE", eval_metric="MAE",
                 neg_slp=0.0, rep_reg_w=0.0, match_loss_w=0.0, match_reg_w=0.0, max_grad_norm=8.0, order=None,
-                schedule=None, epoch=0, match_weights=("node", "edge"), trace=None):
+                schedule=None, epoch=0, match_weights=("node", "edge"), trace=None, graph=None):
     """One pass over ``dataset`` (train.py:449-844): count loss, optional representation regulariser
     and, with ``match_loss_w`` / ``match_reg_w`` and a model built with ``pred_return_weights``, the
     node / edge matching losses against the batch's subisomorphism weights.  With a ``RunSchedule`` the four loss
     coefficients and the learning rate follow the run configuration step by step, as train.py:499-600,686 do.  Returns
     ``{"bp_loss", "eval_metric"}`` (sample-weighted means, one host sync at the end).  ``trace``: a list that receives
-    one ``(loss, eval_metric)`` pair of device scalars per step (what the reference writes to its SummaryWriter)."""
+    one ``(loss, eval_metric)`` pair of device scalars per step (what the reference writes to its SummaryWriter).
+    ``graph``: a ``GraphedTrainStep`` (see there) -- batches whose shape it has recorded are one HIP graph replay each."""
     model.train()
     sync = sync or FlatGradSync(model)
     order = np.arange(len(dataset)) if order is None else np.asarray(order)
@@ -345,9 +366,20 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
             for group in optimizer.param_groups:
                 group["lr"] = schedule.lr()
         want = (tuple(match_weights) or None) if (match_loss_w > 0 or match_reg_w > 0) else None
-        pattern, graph, counts, (node_w, edge_w) = dataset.batchify(idx, device, return_weights=want)
+        if graph is not None and want is None:
+            loss, ev = graph(dataset, idx, device, neg_slp, rep_reg_w)
+            if schedule is not None:
+                schedule.sched_step += 1
+            with torch.no_grad():
+                if trace is not None:
+                    trace.append((loss.clone(), ev.clone()))
+                tot_loss += loss * len(idx)
+                tot_eval += ev * len(idx)
+            cnt += len(idx)
+            continue
+        pattern, graph_b, counts, (node_w, edge_w) = dataset.batchify(idx, device, return_weights=want)
         sync.detach_grads()
-        out = model(pattern, graph)
+        out = model(pattern, graph_b)
         pred = out["pred_c"]
         loss = _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
         for w, pk, mk in ((node_w, "pred_v", "g_v_mask"), (edge_w, "pred_e", "g_e_mask")):
@@ -375,6 +407,64 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
     return {"bp_loss": float(tot_loss / max(cnt, 1)), "eval_metric": float(tot_eval / max(cnt, 1))}
 
 
+class GraphedTrainStep:
+    """The count-loss training step of ``train_epoch`` (collate, forward, loss, backward, gradient pack, clipping,
+    AdamW) as ONE HIP graph per batch shape (``dp.StepGraph``): at the reference's own batch size (64 pairs of small
+    graphs, config.py) a step is ~150 launches of microseconds each behind ~3 ms of Python, and a replay is a single
+    ``hipGraphLaunch``.  Needs one rank (no collective is recorded), ``FlatAdamW(capturable=True)`` and a dataset with
+    ``batch_arrays`` / ``graphs_from_arrays``.  The negative slope of the count loss and the representation
+    regulariser's weight are device scalars written before every replay, the learning rate goes through
+    ``optimizer.sync_hyper()``.  Batches of a shape seen for the first time, and shapes beyond ``max_shapes``
+    recordings, run eagerly -- through the same function, so both ways compute the same step."""
+
+    def __init__(self, model, optimizer, sync, bp_loss="MSE", eval_metric="MAE", max_grad_norm=8.0, with_rep_reg=False,
+                 max_shapes=4):
+        from .dp import StepGraph
+        if getattr(sync, "world", 1) != 1:
+            raise ValueError("GraphedTrainStep records single-rank steps only")
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs FlatAdamW(capturable=True)")
+        self.model, self.optimizer, self.sync = model, optimizer, sync
+        self.bp, self.ev, self.max_grad_norm, self.with_rep_reg = _CRIT[bp_loss], _CRIT[eval_metric], max_grad_norm, with_rep_reg
+        self.hyper = None
+        self._hyper_host = None
+        self.dataset_cls = None
+        self.steps = StepGraph(self._step, optimizer=optimizer, max_shapes=max_shapes)
+
+    def _step(self, meta, *tensors):
+        pattern, graph = self.dataset_cls.graphs_from_arrays(meta, tensors)
+        counts, hyper = tensors[-2], tensors[-1]
+        self.sync.detach_grads()
+        out = self.model(pattern, graph)
+        pred = out["pred_c"]
+        loss = self.bp(torch.where(pred > 0, pred, pred * hyper[0]), counts)      # leaky_relu with the slope on the device
+        if self.with_rep_reg:
+            reg = sum(self.bp(out[k], torch.zeros_like(out[k])) * out[k].size(1)
+                      for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep") if out[k] is not None)
+            loss = loss + hyper[1] * reg
+        loss.backward()
+        self.sync.pack()
+        self.sync.sync()
+        if self.max_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.sync.params, self.max_grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            return loss.detach(), self.ev(F.relu(pred), counts)
+
+    def __call__(self, dataset, indices, device, neg_slp=0.0, rep_reg_w=0.0):
+        if rep_reg_w > 0 and not self.with_rep_reg:
+            raise ValueError("GraphedTrainStep(with_rep_reg=True) to train with the representation regulariser")
+        self.dataset_cls = type(dataset)
+        meta, tensors = dataset.batch_arrays(indices, device)
+        if self.hyper is None:
+            self.hyper = torch.zeros(2, dtype=torch.float32, device=device)
+        if self._hyper_host != (float(neg_slp), float(rep_reg_w)):
+            self._hyper_host = (float(neg_slp), float(rep_reg_w))
+            self.hyper[0:1].fill_(float(neg_slp))
+            self.hyper[1:2].fill_(float(rep_reg_w))
+        return self.steps(meta, *tensors, self.hyper)
+
+
 @torch.no_grad()
 def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
     """train.py:847-1061 reduced to the count metrics: MAE / MSE of ``relu(pred_c)`` and the
@@ -399,22 +489,19 @@ def validate_samples(samples):
     for i, x in enumerate(samples):
         for key in ("pattern", "graph"):
             g = x[key]
-            n = g.number_of_nodes()
-            src, dst = g.all_edges(form="uv", order="eid")
-            if src.numel() and (int(th_min(src, dst)) < 0 or int(th_max(src, dst)) >= n):
+            if isinstance(g, dict):                          # PairDataset's stored form: numpy arrays
+                n, src, dst, rev = int(g["num_nodes"]), np.asarray(g["src"]), np.asarray(g["dst"]), g.get("rev")
+            else:                                            # a graph object (BatchedGraph / DGL surface)
+                n = int(g.number_of_nodes())
+                src, dst = (t.detach().cpu().numpy() for t in g.all_edges(form="uv", order="eid"))
+                rev = g.edata.get("is_reversed") if hasattr(g, "edata") else None
+            if len(src) != len(dst):
+                raise ValueError("sample %d (%s): %s has %d sources for %d destinations" % (i, x.get("id", "?"), key, len(src), len(dst)))
+            if len(src) and (min(src.min(), dst.min()) < 0 or max(src.max(), dst.max()) >= n):
                 raise ValueError("sample %d (%s): %s has an edge endpoint outside [0, %d)" % (i, x.get("id", "?"), key, n))
-            rev = g.edata.get("is_reversed") if hasattr(g, "edata") else None
-            if rev is not None and rev.numel() != src.numel():
-                raise ValueError("sample %d (%s): %s has %d is_reversed flags for %d edges" % (i, x.get("id", "?"), key, rev.numel(), src.numel()))
+            if rev is not None and len(rev) != len(src):
+                raise ValueError("sample %d (%s): %s has %d is_reversed flags for %d edges" % (i, x.get("id", "?"), key, len(rev), len(src)))
     return len(samples)
-
-
-def th_min(a, b):
-    return min(a.min().item(), b.min().item())
-
-
-def th_max(a, b):
-    return max(a.max().item(), b.max().item())
 
 
 def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_dir=None, config=None, sync=None,

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 42
+#define DMP_ABI_VERSION 43
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -525,6 +525,16 @@ int dmp_adamw_step_skip(float *param, const float *grad, float *exp_avg, float *
                         float *max_exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int64_t step, const int64_t *skip_lo, const int64_t *skip_hi,
                         int nskip, void *stream);
+
+/* The same update with the step count and the learning rate in DEVICE memory: state = [step, lr] (two doubles).  The
+ * call first adds 1 to state[0] (a one-thread launch ordered before the update), then evaluates the bias corrections
+ * and lr * weight_decay from the device values -- nothing that changes from step to step is left in the launch
+ * arguments, so a training step captured in a HIP graph (hipGraphLaunch / torch.cuda.CUDAGraph.replay) stays
+ * correct when replayed; the host writes state[1] before a replay when a scheduler changed the learning rate. */
+int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                       float *max_exp_avg_sq, int64_t n, double *state, double beta1, double beta2,
+                       double eps, double weight_decay, const int64_t *skip_lo, const int64_t *skip_hi,
+                       int nskip, void *stream);
 
 /*
  * ScalarFilter gates of a batch of (pattern, target) pairs (filter.py:6-16 on the pre-padded label matrices,

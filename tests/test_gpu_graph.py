@@ -1,0 +1,88 @@
+"""HIP-graph replay of a training step (dp.StepGraph, harness.GraphedTrainStep, FlatAdamW(capturable=True)): a replayed
+step must compute what the eager step computes -- same losses step by step, same parameters at the end."""
+import copy
+
+import numpy as np
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+def test_capturable_adamw_matches_the_host_step(gpu):
+    """dmp_adamw_step_dev (step count and learning rate in device memory) against dmp_adamw_step_skip (host values)
+    over a few steps with a learning-rate change and a parameter range without gradient."""
+    from dualmessagepassing_amd.dp import FlatAdamW
+    gen = th.Generator().manual_seed(3)
+    p0 = th.randn(10007, generator=gen).to(gpu)
+    ps = [p0.clone().requires_grad_(True) for _ in range(2)]
+    opts = [FlatAdamW([ps[0]], lr=3e-3, weight_decay=1e-2, amsgrad=True),
+            FlatAdamW([ps[1]], lr=3e-3, weight_decay=1e-2, amsgrad=True, capturable=True)]
+    for t in range(7):
+        g = th.randn(10007, generator=gen).to(gpu)
+        for p, opt in zip(ps, opts):
+            p.grad = g.clone()
+            p._dmp_live_runs = [(0, 4000), (6000, 4007)]            # [4000, 6000): no gradient this step
+            if t == 4:
+                opt.param_groups[0]["lr"] = 1e-3
+            opt.step()
+        assert float((ps[0] - ps[1]).abs().max()) <= 1e-7 * float(ps[0].abs().max()), t
+    assert th.equal(ps[0][4000:6000], p0[4000:6000]) and th.equal(ps[1][4000:6000], p0[4000:6000])
+    assert float(opts[1].state[ps[1]]["dev"][0]) == 7.0 and float(opts[1].state[ps[1]]["dev"][1]) == 1e-3
+
+
+def test_step_graph_records_once_per_signature(gpu):
+    from dualmessagepassing_amd.dp import StepGraph
+    acc = th.zeros(4, device=gpu)
+    calls = []
+
+    def fn(meta, x):
+        calls.append(meta)
+        acc.add_(x.sum())
+        return x * meta + 1.0, acc
+
+    sg = StepGraph(fn, max_shapes=1)
+    xs = [th.full((4,), float(i), device=gpu) for i in range(5)]
+    want_acc = 0.0
+    for i, x in enumerate(xs):
+        y, a = sg(3, x)
+        want_acc += 4.0 * i
+        assert th.equal(y, x * 3 + 1.0) and float(a[0]) == want_acc, i
+    assert sg.eager_calls == 1 and sg.replays == 4 and len(calls) == 2          # eager, recording; then replays only
+    y, _ = sg(3, th.ones(6, device=gpu))                                        # a second signature: beyond max_shapes -> eager
+    y, _ = sg(3, th.ones(6, device=gpu))
+    assert y.shape == (6,) and sg.eager_calls == 3 and sg.replays == 4
+
+
+@pytest.mark.parametrize("with_reg", [False, True])
+def test_graphed_training_equals_eager_training(with_reg, gpu):
+    """Three epochs of count-loss training (batches of two shapes: the last batch of an epoch is smaller), eager vs
+    HIP-graph replay from the same initial state: the per-step losses and the final parameters agree to fp32 rounding
+    of the optimizer's bias corrections; the learning rate changes between epochs and reaches the replayed steps."""
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    from dualmessagepassing_amd.harness import GraphedTrainStep, SyntheticPairs, train_epoch
+    ds = SyntheticPairs(56, 3, 2, 8, 16, 2, 1, seed=11)
+    th.manual_seed(5)
+    base = build_model(**ds.model_config(hid_dim=64, layers=2, rep_act_func="leaky_relu", pred_act_func="leaky_relu")).to(gpu)
+    runs = []
+    for graphed in (False, True):
+        model = copy.deepcopy(base)
+        sync = FlatGradSync(model)
+        master = sync.flatten_parameters()
+        start = master.detach().clone()
+        opt = FlatAdamW([master], lr=2e-3, weight_decay=1e-5, amsgrad=True, capturable=graphed)
+        step = GraphedTrainStep(model, opt, sync, with_rep_reg=with_reg) if graphed else None
+        trace = []
+        for epoch in range(3):
+            opt.param_groups[0]["lr"] = 2e-3 / (1 + epoch)
+            train_epoch(model, opt, ds, 16, gpu, sync=sync, neg_slp=0.01, rep_reg_w=0.05 if with_reg else 0.0,
+                        order=np.random.default_rng(epoch).permutation(len(ds)), trace=trace, graph=step)
+        th.cuda.synchronize()
+        runs.append((th.stack([t[0] for t in trace]).cpu(), master.detach().clone(), step))
+    (l0, p0, _), (l1, p1, step) = runs
+    assert step.steps.replays >= 3 * 4 - 4 and step.steps.eager_calls == 2, (step.steps.replays, step.steps.eager_calls)
+    assert l0.shape == l1.shape == (12,)
+    assert th.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0 - l1).abs().max()
+    assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max()), float((p0 - p1).abs().max())
+    assert float((p0 - start).abs().max()) > 1e-3                           # it did train

@@ -115,6 +115,10 @@ def test_validate_samples_names_the_bad_sample():
     bad = dict(good, id="b", graph=g([0, 4], [3, 1], 4))
     with pytest.raises(ValueError, match=r"sample 1 \(b\): graph"):
         validate_samples([good, bad])
+    stored = {"id": "d", "pattern": {"num_nodes": 2, "src": np.array([0, 1]), "dst": np.array([1, 0]), "rev": np.array([False, True])},
+              "graph": {"num_nodes": 3, "src": np.array([0, 3]), "dst": np.array([1, 2])}, "counts": 1}     # PairDataset's stored form
+    with pytest.raises(ValueError, match=r"sample 0 \(d\): graph"):
+        validate_samples([stored])
     flagged = dict(good, id="c")
     flagged["pattern"] = g([0, 1], [1, 2], 3)
     flagged["pattern"].edata["is_reversed"] = th.zeros(3, dtype=th.bool)
