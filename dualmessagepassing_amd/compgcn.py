@@ -19,7 +19,7 @@ from ._lib import on_input_device
 from .act import init_weight, map_activation_str_to_layer
 from .constants import (EDGEFEAT, INDEGREE, INNORM, NODEAGG, NODEFEAT, NORM, OUTDEGREE, OUTNORM, REVFLAG)
 from .dmpnn import DMPNNRepMixin
-from .graph import BatchedGraph, as_batched
+from .graph import leave_detached, BatchedGraph, as_batched
 
 
 class CompGCNLayer(nn.Module):
@@ -150,6 +150,8 @@ class CompGCNLayer(nn.Module):
 
         # _edge_update_func (compgcn.py:260-263)
         edge_out = ops.matmul_xw(z, self.rel_weight)
+        leave_detached(g.ndata, NODEFEAT, NODEAGG)
+        leave_detached(g.edata, EDGEFEAT)
         return node_out, edge_out
 
     def extra_repr(self):

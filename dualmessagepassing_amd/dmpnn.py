@@ -28,7 +28,7 @@ from . import ops
 from ._lib import on_input_device
 from .act import init_module, init_weight, map_activation_str_to_layer
 from .constants import (EDGEAGG, EDGEFEAT, NODEAGG, NODEFEAT, OUTDEGREE, REVFLAG)
-from .graph import BatchedGraph, as_batched
+from .graph import leave_detached, BatchedGraph, as_batched
 
 
 def dual_message_passing(graph, x, z, in_weight, out_weight, src_weight, dst_weight, nloop_weight, eloop_weight,
@@ -163,7 +163,8 @@ class DMPLayer(nn.Module):
         node_out = self.drop(out)
         out = ops.apply_mlp(self.emlp, edge_pre) if len(self.emlp) > 0 else self.act(edge_pre)
         edge_out = self.drop(out)
-
+        leave_detached(g.ndata, NODEFEAT, NODEAGG)
+        leave_detached(g.edata, EDGEFEAT)
         return node_out, edge_out
 
     # ---- single-node fused path (fused.py): layer + gate + residual in one autograd node
@@ -205,7 +206,10 @@ class DMPLayer(nn.Module):
         coef = ix.degree_coef(g.ndata[OUTDEGREE])
         vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
         eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
-        return fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded)
+        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded)
+        leave_detached(g.ndata, NODEFEAT)
+        leave_detached(g.edata, EDGEFEAT)
+        return out
 
     def extra_repr(self):
         return "in=%s, out=%s" % (self.input_dim, self.hidden_dim)

@@ -294,16 +294,38 @@ class StepGraph:
     library workspaces), the second copies the arguments into static buffers, records ``fn`` on them and replays, later
     calls copy and replay.  The returned tensors are the recording's own outputs: consume them (stream-ordered) before
     the next call with the same signature.  At most ``max_shapes`` recordings are kept (each owns the memory pool of
-    its intermediates); further signatures run eagerly.  ``optimizer.sync_hyper()`` is called before every replay."""
+    its intermediates); further signatures run eagerly.  ``optimizer.sync_hyper()`` is called before every replay.
+
+    Eager calls and recordings run on ONE side stream owned by this object (ordered after / before the caller's stream):
+    autograd's gradient accumulators remember the stream they were created on, and an accumulator made on the default
+    stream pulls that stream into a later recording, which the runtime cannot finish (segfault in hipStreamEndCapture on
+    this stack) -- with everything on the side stream the recording sees one stream only.  Accumulators made elsewhere
+    stay alive as long as something holds the autograd graph of an earlier step: do not keep a step's loss (undetached)
+    or other tensors with history across calls, and run every step of the run through this object (the layers of this
+    package leave only detached values on the graph objects they are given, ``graph.leave_detached``)."""
 
     def __init__(self, fn, optimizer=None, max_shapes=4):
         self.fn, self.optimizer, self.max_shapes = fn, optimizer, int(max_shapes)
         self._seen, self._graphs = set(), {}
+        self._stream = None
         self.replays = self.eager_calls = 0
 
     @staticmethod
     def _key(meta, tensors):
         return (meta,) + tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
+
+    def _side_stream(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        return self._stream
+
+    def _eager(self, meta, tensors):
+        side, cur = self._side_stream(), torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = self.fn(*meta, *tensors)
+        cur.wait_stream(side)
+        return out
 
     def __call__(self, *args):
         """``args``: the tensors; a leading non-tensor (hashable: host-side sizes the step depends on) is part of the
@@ -318,17 +340,12 @@ class StepGraph:
             if key not in self._seen or len(self._graphs) >= self.max_shapes:
                 self._seen.add(key)
                 self.eager_calls += 1
-                return self.fn(*meta, *tensors)
+                return self._eager(meta, tensors)
             static = [torch.empty_like(t).copy_(t) for t in tensors]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            import warnings
-            with warnings.catch_warnings():
-                # leaf gradients are produced on the recording's side stream while the parameters were made on the default
-                # one: torch warns about the mismatch; inside the recording everything runs on the one side stream
-                warnings.filterwarnings("ignore", message=".*AccumulateGrad node's stream does not match.*")
-                with torch.cuda.graph(graph):
-                    out = self.fn(*meta, *static)
+            with torch.cuda.graph(graph, stream=self._side_stream()):
+                out = self.fn(*meta, *static)
             rec = self._graphs[key] = (graph, static, out)
         else:
             for s, t in zip(rec[1], tensors):

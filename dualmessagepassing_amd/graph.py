@@ -233,6 +233,20 @@ class NodeBatch:
         return self._n
 
 
+def leave_detached(frame, *keys):
+    """What a layer leaves on the graph -- the reference's ``ndata["node_feat"]``, ``edata["edge_feat"]``,
+    ``ndata["node_agg"]`` side effects (dmpnn.py:96-109,163) -- as VALUES, without their autograd history: a graph object
+    that outlives the step (UNC trains on one graph; a DGL graph a caller reuses) would otherwise keep the whole step
+    alive, its activations and its gradient accumulators -- and accumulators made on one stream break the recording of a
+    later step in a HIP graph on another (``dp.StepGraph``).  The reference never differentiates through these entries
+    (every call passes its features); a call with ``node_feat=None`` now reads values only."""
+    for k in keys:
+        if k in frame:
+            t = frame[k]
+            if torch.is_tensor(t) and t.requires_grad:
+                frame[k] = t.detach()
+
+
 class BatchedGraph:
     """A block-diagonal batch of directed multigraphs in eid order."""
 

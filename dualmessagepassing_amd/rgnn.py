@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib, ops
 from .act import init_weight, map_activation_str_to_layer
 from .constants import EDGETYPE, INDEGREE, INNORM, NODEFEAT, NORM, OUTDEGREE, OUTNORM
-from .graph import GraphIndex, as_batched
+from .graph import GraphIndex, as_batched, leave_detached
 
 _TYPED_CACHE = OrderedDict()
 _TYPED_CACHE_MAX = 16
@@ -324,6 +324,7 @@ class RGCNLayer(_RelLayer):
         if self.bn is not None:
             out = self.bn(out)
         out = self.drop(self.act(out))
+        leave_detached(g.ndata, NODEFEAT)
         return out, edge_type
 
     def extra_repr(self):
@@ -365,6 +366,7 @@ class RGINLayer(_RelLayer):
             out = out + self.bias
         out = ops.apply_mlp(self.mlp, out) if len(self.mlp) > 0 else self.act(out)
         out = self.drop(self.act(out))   # rgin.py:147-152: activation after the MLP as well
+        leave_detached(g.ndata, NODEFEAT)
         return out, edge_type
 
     def extra_repr(self):

@@ -21,7 +21,7 @@ from . import ops
 from ._lib import on_input_device
 from .constants import OUTDEGREE, REVFLAG
 from .dmpnn import dual_message_passing
-from .graph import BatchedGraph, as_batched
+from .graph import BatchedGraph, as_batched, leave_detached
 from .ops import PoolIndex, seg_pool
 
 
@@ -105,6 +105,8 @@ class DualGraphConv(nn.Module):
         if self.act:
             node_out = self.act(node_out)
             edge_out = self.act(edge_out)
+        leave_detached(g.ndata, "h")          # UNC trains on ONE graph object: nothing of a step may stay alive on it
+        leave_detached(g.edata, "h")
         return node_out, edge_out
 
     def extra_repr(self):
@@ -155,7 +157,12 @@ class EmbeddingLayer(nn.Module):
         nn.init.uniform_(self.embedding.weight, -scale, scale)
 
     def forward(self, g, x):
-        return self.embedding(x.squeeze())
+        w, ids = self.embedding.weight, x.squeeze()
+        if w.is_cuda and w.requires_grad and torch.is_grad_enabled() and ids.dim() == 1:
+            # the row gather with the kernels' backward (fixed-order segment sums: torch's embedding backward sorts the
+            # indices with a library call that cannot be recorded in a HIP graph, and serialises on repeated indices)
+            return ops.take_rows_small_table(w, ids) if w.size(0) <= 64 else ops.take_rows(w, ids)
+        return self.embedding(ids)
 
     @property
     def weight(self):

@@ -47,3 +47,13 @@ def step():
 
 print("UNC DMPNN hid=256, 2 layers, N=%d, E=%d: forward %.3f ms, train step (fwd+bwd+Adam) %.3f ms" % (n, 2 * m, timeit(fwd), timeit(step)))
 
+# the same step replayed from ONE HIP graph (dp.StepGraph): torch's capturable Adam keeps its step count on the device
+from dualmessagepassing_amd.dp import StepGraph
+opt = th.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+sg = StepGraph(lambda: step())
+try:
+    ms = timeit(sg)
+    print("UNC train step as one HIP-graph replay: %.3f ms   (replays %d, eager %d)" % (ms, sg.replays, sg.eager_calls))
+except Exception as exc:                                   # a host sync inside the step cannot be recorded
+    print("UNC train step could not be recorded: %s: %s" % (type(exc).__name__, str(exc)[:300]))
+
