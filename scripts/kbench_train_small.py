@@ -33,3 +33,13 @@ for graphed in (False, True):
     print("%-28s %.3f ms/step  %8.0f pairs/s   (batch %d, loss %.4f)%s" % (
         "HIP-graph replay per step" if graphed else "eager launches", dt / steps * 1e3, steps * B / dt, B, out["bp_loss"],
         "  replays %d eager %d" % (step.steps.replays, step.steps.eager_calls) if graphed else ""))
+    if graphed:                                           # where the replayed step's time goes: replay alone vs the batch's host side
+        rec = next(iter(step.steps._graphs.values()))
+        th.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): rec[0].replay()
+        th.cuda.synchronize(); t_replay = (time.perf_counter() - t0) / 50 * 1e3
+        idx = np.arange(B)
+        t0 = time.perf_counter()
+        for _ in range(50): ds.batch_arrays(idx, gpu)
+        th.cuda.synchronize(); t_batch = (time.perf_counter() - t0) / 50 * 1e3
+        print("    of which: graph replay alone %.3f ms, batch_arrays (host concatenation + uploads) %.3f ms" % (t_replay, t_batch))
