@@ -348,12 +348,22 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) 
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
 constexpr int kAtbLdsBytes64 = 2 * 2 * kSub * 68 * 4;         // H = 64: 34816
 constexpr int atb_lds_bytes(int H) { return H == 128 ? kAtbLdsBytes : kAtbLdsBytes64; }
+// The dynamic-LDS opt-in is a per-device function attribute: set once per (kernel, device) -- a process that drives
+// several devices passes through here once for each (the writes of the flag race benignly: the call is idempotent).
+constexpr int kMaxDevices = 64;
+inline bool opt_in_lds(const void *kernel, int bytes, bool (&done)[kMaxDevices]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  if (done[dev]) return true;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { set_last_hip_error(e); return false; }
+  done[dev] = true;
+  return true;
+}
 template <int MODE, int H = 128>
 bool lds_ready() {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_k<MODE, H>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, atb_lds_bytes(H));
-  if (e != hipSuccess) set_last_hip_error(e);
-  return e == hipSuccess;
+  static bool done[kMaxDevices] = {};
+  return opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H>), atb_lds_bytes(H), done);
 }
 
 inline unsigned atb_blocks(int64_t tiles, int H = 128) {
@@ -374,9 +384,8 @@ static unsigned rows_blocks(int64_t rows, int M, int N, int H) {
 
 template <int H>
 static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStream_t st) {
-  static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb_jobs_k<H>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, atb_lds_bytes(H));
-  if (e != hipSuccess) { set_last_hip_error(e); return DMP_ERR_HIP; }
+  static bool done[kMaxDevices] = {};
+  if (!opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H>), atb_lds_bytes(H), done)) return DMP_ERR_HIP;
   const dim3 grid(rows_blocks(rows, H, H * (num_jobs > 0 ? num_jobs : 1), H), (unsigned)num_jobs);
   atb_jobs_k<H><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
   return check_launch();
