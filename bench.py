@@ -265,6 +265,17 @@ def mfma_rooflines(kern, H, E):
     return out
 
 
+def sparse_end_to_end(cfg, pairs_per_s):
+    """Algorithmic bytes of the sparse kernels per pair (per layer and graph, forward + backward,
+    ``4H(4E + 6N) + 26E + 12(N + 1)``; E counts the reversed copies) times the measured pairs/s, against the HBM peak."""
+    H, L = cfg["hid"], cfg["layers"]
+    per_pair = 0
+    for n, e in ((cfg["p_nodes"], 2 * cfg["p_edges"]), (cfg["g_nodes"], 2 * cfg["g_edges"])):
+        per_pair += L * (4 * H * (4 * e + 6 * n) + 26 * e + 12 * (n + 1))
+    gbps = per_pair * pairs_per_s / 1e9
+    return {"bytes_per_pair": per_pair, "gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+
+
 def cpu_baseline(cfg, seconds_budget=20.0):
     """CPU oracle (oracle/dmp_oracle.py: reference op order, torch CPU, all host cores) on a
     bounded sample of the same workload: fwd+bwd of the 3-layer pattern + graph rep-nets."""
@@ -449,6 +460,10 @@ def main():
                                   "eager steps after the timed region)") if graphed else "eager launches",
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
+            # the compulsory traffic of the sparse kernels alone (seg-sum / gather-combine, forward + backward,
+            # pattern + target, all layers) over the END-TO-END step time -- how far the whole step is from a sparse-only
+            # HBM roofline (the step also runs 460 GFLOP of dense fp32 products, which bound it)
+            "sparse_path_end_to_end": sparse_end_to_end(cfg, pairs / dt),
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32
             # v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak): their MFMA-roofline fractions, for context
             "mfma_kernels": mfma_rooflines(kern, H, uE),
