@@ -8,7 +8,12 @@ dev = torch.device("cuda:0")
 cfg = dict(bench.CFG)
 if os.environ.get("HID"): cfg["hid"] = int(os.environ["HID"])
 shard = bench.make_shard(cfg, 0, dev)
+if os.environ.get("GRAPH"): cfg["graph"] = True
 step, model = bench.build_step(cfg, shard, dev)
+if os.environ.get("GRAPH"):      # the step replayed from one HIP graph (dp.StepGraph), as bench.py --graph runs it
+    from dualmessagepassing_amd.dp import StepGraph
+    eager_step = step
+    step = StepGraph(lambda: eager_step(), optimizer=eager_step.opt, max_shapes=1)
 from dualmessagepassing_amd import basemodel
 if os.environ.get("SIZE_CACHE_MAX"): basemodel._SIZE_CACHE_MAX = int(os.environ["SIZE_CACHE_MAX"])
 for rnd in range(int(os.environ.get("ROUNDS", "3"))):
