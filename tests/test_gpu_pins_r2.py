@@ -102,7 +102,8 @@ def _dataset_from_fixture(d, split, tmp_path):
     return PairDataset(samples, {})
 
 
-def test_training_run_at_shipped_settings_matches_reference(gpu, tmp_path):
+@pytest.mark.parametrize("fixture", ["train_run_default", "train_run_compgcn"])
+def test_training_run_at_shipped_settings_matches_reference(fixture, gpu, tmp_path):
     """BASELINE config 3 in miniature.  The reference's own train.py pipeline (README "Complex" settings: leaky_relu,
     Equivariant embeddings, hid 64, node head + node matching weights, AdamW(amsgrad), cosine-restart learning rate,
     annealed neg_pred_slp / match_reg_w, rep_reg_w) trained 5 epochs on 96 synthetic pairs on the CPU; the product trains
@@ -111,11 +112,13 @@ def test_training_run_at_shipped_settings_matches_reference(gpu, tmp_path):
     loss trajectory is spiky (per-step losses between 10 and 270), so fp32 re-association differences grow step by step;
     the reference itself is only reproducible to ~1e-5 between two CPU runs.  Asserted: the first three steps within
     2e-3, every step within 6 %, per-epoch training means within 5 %, dev error within 10 % after every epoch and 2 % after
-    the last, final dev MAE within 5 %, final parameters within 3e-2."""
+    the last, final dev MAE within 5 %, final parameters within 3e-2.
+    ``train_run_compgcn``: the same run with ``--rep_net CompGCN`` (composition ``corr``; ``--rep_compgcn_edge_norm both``,
+    because with the shipped ``none`` the reference itself diverges on a dataset of this size)."""
     from dualmessagepassing_amd import dmpnn, harness
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.dp import FlatGradSync
-    d = load_golden(golden_files("train_run_default")[0])
+    d = load_golden(golden_files(fixture)[0])
     config = json.loads(str(d["config_json"]))
     train_set, dev_set = _dataset_from_fixture(d, "train", tmp_path), _dataset_from_fixture(d, "dev", tmp_path)
     for x in dev_set.samples + train_set.samples:
@@ -152,7 +155,8 @@ def test_training_run_at_shipped_settings_matches_reference(gpu, tmp_path):
             hist["train_bp"].append(tr["bp_loss"]); hist["train_eval"].append(tr["eval_metric"]); hist["dev_eval"].append(dev["eval_metric"])
     finally:
         dmpnn.DMPLayer.forward_fused = orig
-    assert len(hits) >= 3 * 3 * config["train_epochs"], "the shipped configuration did not run on the fused path"
+    if config["rep_net"] == "DMPNN":
+        assert len(hits) >= 3 * 3 * config["train_epochs"], "the shipped configuration did not run on the fused path"
     assert np.allclose(hist["lr"], d["hist.lr"], rtol=1e-9)
     step_loss = np.array([float(a) for a, _ in trace])
     step_eval = np.array([float(b) for _, b in trace])
