@@ -1,0 +1,124 @@
+"""The UNC training loop around ``unc.TrainModel`` and the device samplers (BASELINE config 5: one large graph, no
+batch sharding).  What ``UnsupervisedNodeClassification/Model/DMPNN/src/main.py:99-211`` does per run, with the
+reference's semantics and without its per-step host round trips:
+
+* ``load_links`` / ``save_embeddings``: the ``link.dat`` / output file formats (``utils.py:219-258``);
+* ``train_unsupervised``: edge mini-batches -> negative samples + sampled sub-graph (``unc_sampling``) -> encoder ->
+  link-prediction loss (``TrainModel.get_unsupervised_loss``) -> clip -> Adam -> cosine learning rate; the epoch count
+  rescaled by ``edges / nodes`` and the stop at the first epoch whose mean loss rises, as ``main.py:104,178-182``;
+* ``collect_node_embeddings``: the output pass of ``main.py:185-211`` -- every sampled sub-graph's encoder output
+  blended into the embedding table by how much of a node's neighbourhood the sample covered.
+
+Everything stays on the device; the mean loss of an epoch is read back once per epoch."""
+import math
+
+import numpy as np
+import torch
+
+from .unc import build_graph_from_triplets, compute_edgenorm
+from .unc_sampling import generate_sampled_graph_and_labels_unsupervised
+
+SUBGRAPH_NID = "_ID"     # parent node id of every sub-graph node (dgl.NID in the reference)
+
+
+def load_links(path):
+    """``link.dat`` (utils.py:219-229): first line ``num_nodes num_rels``, then one ``src rel dst [weight ...]`` row of
+    integers per line.  Returns ``(triplets int64 [M, >=3], num_nodes, num_rels)``."""
+    with open(path) as f:
+        head = f.readline().split()
+        num_nodes, num_rels = int(head[0]), int(head[1])
+        rows = [[int(t) for t in line.split()] for line in f if line.strip()]
+    return np.asarray(rows, dtype=np.int64).reshape(len(rows), -1), num_nodes, num_rels
+
+
+def save_embeddings(path, embeddings, index=None, header=""):
+    """The reference's output file (utils.py:243-258): a header line, then ``node_id<TAB>v0 v1 ...`` per node."""
+    emb = np.asarray(embeddings)
+    ids = np.arange(len(emb)) if index is None else np.asarray(index)
+    with open(path, "w") as f:
+        f.write(str(header) + "\n")
+        for n, row in zip(ids, emb):
+            f.write("%d\t%s\n" % (int(n), " ".join(row.astype(str))))
+
+
+def _edge_batches(triplets, batch_size, generator):
+    """Shuffled mini-batches of positive triplets (the reference's ``DataLoader(..., shuffle=True)``)."""
+    order = torch.randperm(triplets.size(0), generator=generator, device=generator.device if generator is not None else None)
+    order = order.to(triplets.device)
+    for i in range(0, triplets.size(0), batch_size):
+        yield triplets[order[i:i + batch_size]]
+
+
+def _encode(model, graph, batch, sampler, sample_depth, sample_width, graph_split_size, negative_sample, generator):
+    sub, samples, labels = generate_sampled_graph_and_labels_unsupervised(
+        graph, batch, sample_depth, sample_width, graph_split_size, negative_sample, generator=generator, sampler=sampler)
+    edge_type = sub.edata["type"]
+    embed, _ = model(sub, sub.ndata[SUBGRAPH_NID], edge_type, sub.edata["norm"])
+    return sub, samples, labels, edge_type, embed
+
+
+def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=2000, lr=1e-3, grad_norm=1.0,
+                       sampler="neighbor", sample_depth=6, sample_width=128, graph_split_size=0.5, negative_sample=5,
+                       rescale_epochs=True, seed=0, log=None):
+    """main.py:99-183 for the unsupervised objective.  ``triplets`` [M, 3] (device, int64): the positive edges;
+    ``graph``: ``build_graph_from_triplets`` of them (both directions, ``edata["type"]`` / ``["norm"]``).
+    Returns the per-epoch mean losses (training stops after the first epoch whose mean loss rises)."""
+    dev = triplets.device
+    triplets = triplets[:, :3].to(torch.int64)
+    steps_per_epoch = math.ceil(triplets.size(0) / graph_batch_size)
+    if rescale_epochs:                                        # main.py:104: epochs counted in passes over the NODES
+        n_epochs = math.ceil(n_epochs * steps_per_epoch * graph_batch_size / graph.number_of_nodes())
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, n_epochs * steps_per_epoch, eta_min=3e-6)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    model.train()
+    history, prev = [], float("inf")
+    for epoch in range(n_epochs):
+        total = torch.zeros((), device=dev)
+        for batch in _edge_batches(triplets, graph_batch_size, gen):
+            sub, samples, labels, edge_type, embed = _encode(model, graph, batch, sampler, sample_depth, sample_width,
+                                                             graph_split_size, negative_sample, gen)
+            loss = model.get_unsupervised_loss(sub, embed, edge_type, samples, labels)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
+            optimizer.step()
+            scheduler.step()
+            total += loss.detach()
+        mean = float(total) / steps_per_epoch                 # the epoch's one host sync
+        history.append(mean)
+        if log is not None:
+            log("Epoch %05d | Loss %.4f" % (epoch, mean))
+        if mean > prev:                                       # main.py:180-182
+            break
+        prev = mean
+    return history
+
+
+@torch.no_grad()
+def collect_node_embeddings(model, graph, triplets, graph_batch_size=2000, sampler="neighbor", sample_depth=6,
+                            sample_width=128, graph_split_size=0.5, negative_sample=5, seed=0):
+    """main.py:185-211: starting from the embedding table, every sampled sub-graph's encoder output is blended in with
+    weight ``(in_deg_sub + 1) / (in_deg_full + 1)`` per node.  Returns ``(node_emb [N, d] on the device, covered bool [N])``."""
+    dev = triplets.device
+    triplets = triplets[:, :3].to(torch.int64)
+    model.eval()
+    node_emb = model.model.node_emb.weight.detach().clone()
+    covered = torch.zeros(graph.number_of_nodes(), dtype=torch.bool, device=dev)
+    full_in = graph.in_degrees().float()
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    for i in range(0, triplets.size(0), 4 * graph_batch_size):            # unshuffled, four times the training batch
+        batch = triplets[i:i + 4 * graph_batch_size]
+        sub, _, _, _, embed = _encode(model, graph, batch, sampler, sample_depth, sample_width, graph_split_size,
+                                      negative_sample, gen)
+        nid = sub.ndata[SUBGRAPH_NID]
+        coef = ((sub.in_degrees().float() + 1) / (full_in[nid] + 1)).view(-1, 1)
+        node_emb[nid] = node_emb[nid] * (1 - coef) + embed[0] * coef
+        covered[nid] = True
+    return node_emb, covered
+
+
+def graph_of(triplets_np, num_nodes, num_rels, device):
+    """``(graph, triplets on the device)`` for ``train_unsupervised`` from ``load_links``' output."""
+    trip = np.asarray(triplets_np)[:, :3]
+    return build_graph_from_triplets(num_nodes, num_rels, trip, device), torch.from_numpy(trip).to(device)

@@ -124,3 +124,17 @@ def test_validate_samples_names_the_bad_sample():
     flagged["pattern"].edata["is_reversed"] = th.zeros(3, dtype=th.bool)
     with pytest.raises(ValueError, match="is_reversed"):
         validate_samples([flagged])
+
+
+def test_link_file_round_trip(tmp_path):
+    from dualmessagepassing_amd.unc_harness import load_links, save_embeddings
+    trip = np.array([[0, 0, 1], [2, 1, 0], [1, 0, 2]], np.int64)
+    p = tmp_path / "link.dat"
+    p.write_text("3 2\n" + "".join("%d %d %d\n" % tuple(r) for r in trip))
+    got, n, r = load_links(str(p))
+    assert (n, r) == (3, 2) and np.array_equal(got, trip)
+    out = tmp_path / "emb.dat"
+    save_embeddings(str(out), np.array([[0.5, 1.0], [2.0, -1.0]], np.float32), index=[2, 0], header="args")
+    lines = out.read_text().splitlines()
+    assert lines[0] == "args" and lines[1].split("\t")[0] == "2" and lines[1].split("\t")[1].split() == ["0.5", "1.0"]
+    assert lines[2].startswith("0\t2.0 -1.0")
