@@ -276,38 +276,64 @@ def sparse_end_to_end(cfg, pairs_per_s):
     return {"bytes_per_pair": per_pair, "gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
-    """CPU oracle (oracle/dmp_oracle.py: reference op order, torch CPU, all host cores) on a
-    bounded sample of the same workload: fwd+bwd of the 3-layer pattern + graph rep-nets."""
+def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
+    """The same step on the host cores with the CPU oracle (oracle/model_oracle.py + dmp_oracle.py: the reference's
+    operation order -- gather-then-project layers, padded [B, L, D] heads, per-sample Python loops -- in torch CPU ops,
+    pinned by the reference's own full-model runs): collate of B per-graph arrays, forward of the WHOLE model, count
+    loss, backward, AdamW(amsgrad) -- on a bounded sample (B = 32 pairs per step, the reference's own CPU-runnable batch
+    size, BASELINE configs[0]) of the same synthetic workload, from the product model's initial ``state_dict``."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import dmp_oracle as O
+    import model_oracle as MO
     # the oracle's ops are small; past ~32 threads torch's intra-op pool only adds contention
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     B, H, L = 32, cfg["hid"], cfg["layers"]
     rng = np.random.default_rng(7)
-    gen = torch.Generator().manual_seed(7)
-    act = cfg.get("act", "leaky_relu")
-    layers = [{k: v.requires_grad_(True) for k, v in O.random_dmp_params(H, H, gen, act).items()} for _ in range(L)]
-    data = {}
-    for tag, n, m in (("p", cfg["p_nodes"], cfg["p_edges"]), ("g", cfg["g_nodes"], cfg["g_edges"])):
-        u, v = er_local_edges(B, n, m, rng)
-        off = (np.arange(B) * n)[:, None]
-        src = torch.from_numpy(np.concatenate([u + off, v + off], axis=1).reshape(-1))
-        dst = torch.from_numpy(np.concatenate([v + off, u + off], axis=1).reshape(-1))
-        rev = torch.from_numpy(np.concatenate([np.zeros((B, m), bool), np.ones((B, m), bool)], 1).reshape(-1))
-        N, E = B * n, B * 2 * m
-        data[tag] = (src, dst, rev, O.out_degrees(src, N), torch.randn(N, H, generator=gen).requires_grad_(True),
-                     torch.randn(E, H, generator=gen).requires_grad_(True))
-    vg = (torch.rand(data["g"][4].size(0), 1, generator=gen) < 0.75).float()
-    eg = (torch.rand(data["g"][5].size(0), 1, generator=gen) < 0.75).float()
+    mc = model_config(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in state_dict.items()}
+    for k in list(sd):                                       # shared sub-networks: one parameter under two names
+        twin = "g_" + k[2:]
+        if k.startswith("p_") and twin in sd and sd[k].shape == sd[twin].shape and torch.equal(sd[k], sd[twin]):
+            sd[k] = sd[twin]
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and "enc_net" not in k and not any(v is q for q in params):
+            params.append(v.requires_grad_(True))
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, amsgrad=True)
+    samples = []                                             # per-pair arrays, as a dataset holds them
+    for _ in range(B):
+        pair = {}
+        for tag, n, m, nl in (("p", cfg["p_nodes"], cfg["p_edges"], cfg["p_labels"]), ("g", cfg["g_nodes"], cfg["g_edges"], cfg["g_labels"])):
+            u, v = er_local_edges(1, n, m, rng)
+            el = rng.integers(0, nl, m)
+            pair[tag] = dict(src=np.concatenate([u[0], v[0]]), dst=np.concatenate([v[0], u[0]]), n=n,
+                             rev=np.concatenate([np.zeros(m, bool), np.ones(m, bool)]), elabel=np.concatenate([el, el + nl]),
+                             eid=np.concatenate([np.arange(m), m + np.arange(m)]), label=rng.integers(0, nl, n))
+        pair["count"] = float(rng.integers(0, 64))
+        samples.append(pair)
+
+    def collate(tag):
+        off, parts = 0, {k: [] for k in ("src", "dst", "rev", "elabel", "eid", "label", "id")}
+        for s in samples:
+            g = s[tag]
+            parts["src"].append(g["src"] + off); parts["dst"].append(g["dst"] + off)
+            for k in ("rev", "elabel", "eid", "label"):
+                parts[k].append(g[k])
+            parts["id"].append(np.arange(g["n"]))
+            off += g["n"]
+        t = {k: torch.from_numpy(np.concatenate(v)) for k, v in parts.items()}
+        t["bnn"] = [s[tag]["n"] for s in samples]
+        t["bne"] = [len(s[tag]["src"]) for s in samples]
+        return t
 
     def one():
-        ps, pd, pr, pdeg, pv, pe = data["p"]
-        gs, gd, gr, gdeg, gv, ge = data["g"]
-        a, b = O.dmpnn_graph_rep(layers, ps, pd, pr, pdeg, pv, pe, act_func=act)
-        c, d = O.dmpnn_graph_rep(layers, gs, gd, gr, gdeg, gv, ge, vg, eg, act_func=act)
-        (a.square().mean() + b.square().mean() + c.square().mean() + d.square().mean()).backward()
+        pattern, graph = collate("p"), collate("g")
+        counts = torch.tensor([s["count"] for s in samples]).view(-1, 1)
+        out = MO.model_forward(sd, mc, pattern, graph)
+        loss = torch.nn.functional.mse_loss(out["pred_c"], counts)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
 
     one()  # warm-up
     t0, n = time.perf_counter(), 0
@@ -317,10 +343,11 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 50:
             break
-    return {"value": B * n / el, "unit": "pairs/s (rep-net stage only)", "cores": cores, "kind": "port",
-            "sample": "%d steps of B=%d pairs; rep-net stage only (3-layer pattern + target DMPNN rep-nets with gates/residual, "
-                      "same shapes, hid=%d, %d layers, fwd+bwd, fp32; enc/emb/pred heads not included), torch %s CPU, %d threads"
-                      % (n, B, H, L, torch.__version__, cores)}
+    return {"value": B * n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of B=%d pairs of the same shapes; the same step composition as the GPU line (collate, whole "
+                      "model forward: encodings, embeddings, ScalarFilter, %d-layer pattern + target DMPNN rep-nets, node + edge "
+                      "SumPredictNet heads; count loss, backward, AdamW(amsgrad)), hid=%d, fp32, reference operation order, "
+                      "torch %s CPU, %d threads" % (n, B, L, H, torch.__version__, cores)}
 
 
 def main():
@@ -373,6 +400,8 @@ def main():
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
     shard = make_shard(cfg, rank, device)
     step, model = build_step(cfg, shard, device, world)
+    initial_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1
+                                                                                              and not args.no_cpu_baseline) else None
 
     def barrier():
         if world > 1:
@@ -471,7 +500,7 @@ def main():
                             "bytes": int(v["bytes"])} for n, v in sorted(kern.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, initial_state)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
