@@ -324,3 +324,60 @@ def test_table_lookups_match_embedding_modules(gpu):
     assert out.requires_grad
     bad = lookup_rows(nets[:1], [th.tensor([3, 64, -1], device="cuda")])[0]
     assert th.equal(bad[0], nets[0].weight[3]) and bool(th.isnan(bad[1:]).all())
+
+
+@pytest.mark.parametrize("hid,act", [(64, "leaky_relu"), (128, "relu")])
+def test_full_model_matches_the_model_oracle_at_config_1(hid, act, gpu):
+    """BASELINE configs[0] shape (32 pairs of pattern (8,12) x target (64,256), add_rev, 3 layers) with bench.py's
+    synthetic batch and model configuration: the product (fused path, HIP heads) against oracle/model_oracle.py (the
+    reference's operation order on the CPU, pinned by the reference's own runs) from the same ``state_dict`` -- all
+    outputs, and every parameter gradient of the count loss."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import model_oracle as MO
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.collate import collate_device
+    cfg = dict(bench.CFG, batch=32, hid=hid, act=act)
+    shard = bench.make_shard(cfg, 0, gpu)
+    th.manual_seed(3)
+    model = build_model(**bench.model_config(cfg)).to(gpu)
+    sides, batched = {}, {}
+    for tag in ("p", "g"):
+        s = shard[tag]
+        batched[tag] = collate_device(s["local_src"], s["local_dst"], s["num_nodes"], s["num_edges"], s["N"], s["E"], ndata=s["ndata"],
+                                      edata=s["edata"], max_nodes=s["max_n"], max_edges=s["max_e"])
+        src, dst = batched[tag].all_edges(form="uv", order="eid")
+        sides[tag] = {"src": src.cpu(), "dst": dst.cpu(), "bnn": s["num_nodes"].tolist(), "bne": s["num_edges"].tolist(),
+                      "id": s["ndata"]["id"].cpu(), "label": s["ndata"]["label"].cpu(), "eid": s["edata"]["id"].cpu(),
+                      "elabel": s["edata"]["label"].cpu(), "rev": s["edata"]["is_reversed"].cpu()}
+    out = model(batched["p"], batched["g"])
+    out["pred_c"].sum().backward()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k in list(sd):
+        twin = "g_" + k[2:]
+        if k.startswith("p_") and twin in sd and sd[k].shape == sd[twin].shape and th.equal(sd[k], sd[twin]):
+            sd[k] = sd[twin]
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    ref = MO.model_forward(sd, bench.model_config(cfg), sides["p"], sides["g"])
+    ref["pred_c"].sum().backward()
+    for k in ("p_v_mask", "p_e_mask", "g_v_mask", "g_e_mask"):
+        assert th.equal(out[k].cpu(), ref[k]), k
+    for k, tol in (("p_v_emb", 2e-5), ("g_e_emb", 2e-5), ("p_v_rep", 2e-4), ("p_e_rep", 2e-4), ("g_v_rep", 2e-4), ("g_e_rep", 2e-4),
+                   ("pred_c", 2e-4)):
+        _close(out[k], ref[k].detach().numpy(), tol, k)
+    checked = 0
+    for k, p in model.named_parameters():
+        g = sd[k].grad
+        if g is None or p.grad is None:
+            continue
+        scale = max(1.0, float(g.abs().max()))
+        err = (p.grad.detach().cpu() - g).abs()
+        # an activation within fp32 rounding of zero may take the other derivative branch (see test_gpu_dmplayer._close_or_flipped)
+        assert float(err.max()) <= 5e-3 * scale and float((err > 5e-4 * scale).float().mean()) <= 0.02, (k, float(err.max()), scale)
+        checked += 1
+    assert checked > 30
