@@ -215,3 +215,26 @@ def test_fused_typed_layer_at_full_config2_size_against_fp64(act, gpu):
         # with ~10^7 activations per layer a few pre-activations lie within fp32 rounding of zero: their derivative branch may
         # differ from the fp64 run's, which moves the parameter gradients by up to a percent (ReLU: a full unit step)
         _close(p.grad, ref, 2e-2 if flipped else 5e-4, "grad " + k)
+
+
+def test_micro_batched_step_equals_the_one_pass_step(gpu):
+    """bench.py's config-4 step splits the shard into micro-batches so that every [E, 2H] array stays below the 32-bit
+    offset range of the class-typed kernels; pairs are independent, so the summed gradient of M slices (each slice's mean
+    loss weighted 1 / M) is the gradient of the whole shard.  Checked at the config-4 graph shapes on 64 pairs: one pass
+    against four micro-batches, the whole flat gradient."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    flats = []
+    for m in (1, 4):
+        cfg = dict(bench.CFG4, batch=64, micro_batches=m, act="leaky_relu", emb="Equivariant")
+        shard = bench.make_shard(cfg, 0, gpu)
+        step, model = bench.build_step(cfg, shard, gpu)
+        assert step.micro_batches == m
+        step()
+        th.cuda.synchronize()
+        flats.append(step.sync.flat.detach().clone())
+    g1, g4 = flats
+    scale = float(g1.abs().max())
+    assert scale > 0 and float((g1 - g4).abs().max()) <= 2e-4 * scale, (float((g1 - g4).abs().max()), scale)
