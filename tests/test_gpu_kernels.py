@@ -140,12 +140,14 @@ def test_edge_combine_fwd_bwd(h, gpu):
     assert th.allclose(bg.grad.cpu().double(), bo.grad, rtol=2e-5, atol=2e-4)
 
 
-# ----------------------------------------------------------------------------- full size (config 2)
-def test_config2_size_properties(gpu):
-    """B=1024 x target(64, 256->512 edges), H=128: size-independent checks."""
+# ----------------------------------------------------------------------------- full size (configs 2 and 4)
+@pytest.mark.parametrize("batch,g_nodes,g_edges", [(1024, 64, 256), (1024, 512, 4096)])
+def test_config2_size_properties(batch, g_nodes, g_edges, gpu):
+    """BASELINE configs[1] (B=1024 x target(64, 256->512 edges)) and configs[3]'s per-GPU shard (B=1024 x target(512,
+    4096->8192 edges): N = 524,288, E = 8,388,608, one [E,H] array = 4.3 GB), H=128: size-independent checks."""
     from dualmessagepassing_amd import ops
     rng = np.random.default_rng(2000)
-    src, dst, rev, n, _, _ = er_batch(1024, 64, 256, rng)
+    src, dst, rev, n, _, _ = er_batch(batch, g_nodes, g_edges, rng)
     e, h = len(src), 128
     ix = _index(src, dst, n, rev, gpu)
     # (1) sum of all-ones rows = in-degree, split by flag; exact in fp32 (small integers)
@@ -161,8 +163,8 @@ def test_config2_size_properties(gpu):
     a1 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
     a2 = ops.seg_sum_raw(m, ix.in_ptr, ix.in_ent, n)
     assert th.equal(a1, a2)
-    # fp32 per-row sums then an fp64 column sum: rounding of ~64k partial sums, |err| << 1e-2
-    assert th.allclose(a1.double().sum(0), m.double().sum(0), rtol=1e-6, atol=2e-2)
+    # fp32 per-row sums then an fp64 column sum: rounding of ~64k (config 4: ~512k) partial sums, |err| << 1e-2 (1e-1)
+    assert th.allclose(a1.double().sum(0), m.double().sum(0), rtol=1e-6, atol=2e-2 * (e / 524288) ** 0.5)
     # (3) equals torch's own index_add on device within fp32 reassociation
     ref = th.zeros(n, h, device=gpu).index_add_(0, td, m)
     assert th.allclose(a1, ref, rtol=1e-5, atol=1e-5)
@@ -173,7 +175,7 @@ def test_config2_size_properties(gpu):
     y = th.randn(n, h, generator=gen).to(gpu)
     lhs = (a1.double() * y.double()).sum()
     rhs = (m.double() * ops.gather_rows_raw(y, ix.dst32).double()).sum()
-    assert abs(float(lhs - rhs)) <= 1e-7 * abs(float(lhs)) + 1e-3
+    assert abs(float(lhs - rhs)) <= 1e-7 * abs(float(lhs)) + 1e-3 * (e / 524288) ** 0.5
 
 
 @pytest.mark.parametrize("rows,h", [(1, 4), (37, 8), (1000, 128), (70000, 128), (5000, 256), (300, 512)])
