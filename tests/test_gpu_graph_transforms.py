@@ -248,3 +248,52 @@ def test_dual_subisomorphisms_match_reference_and_oracle(gpu):
         run([c])
     run(cases)
     run(cases[::-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,n,m", [(1024, 64, 256), (64, 512, 4096)])
+def test_integer_transforms_bit_exact_at_baseline_sizes(batch, n, m, gpu):
+    """BASELINE configs[1] target batch (1024 x (64, 256)) and 64 graphs of configs[3]'s target shape (512, 4096): device
+    collate, add_reversed_edges and the line-graph transform of the whole batch, bit for bit against the sequential C
+    oracle applied graph by graph (dgl.batch order)."""
+    from dualmessagepassing_amd.collate import collate_device
+    from dualmessagepassing_amd.linegraph import convert_to_dual_graph
+    from dualmessagepassing_amd.preprocess import add_reversed_edges
+    rng = np.random.default_rng(batch + n)
+    per = [er_edges(n, m, rng) for _ in range(batch)]
+    ls, ld = np.concatenate([p[0] for p in per]), np.concatenate([p[1] for p in per])
+    nn, ne = np.full(batch, n, np.int64), np.full(batch, m, np.int64)
+    eid = np.tile(np.arange(m), batch)
+    el = rng.integers(0, 16, size=batch * m)
+    nl = rng.integers(0, 16, size=batch * n)
+    g = collate_device(_t(ls).to(gpu), _t(ld).to(gpu), _t(nn).to(gpu), _t(ne).to(gpu), batch * n, batch * m,
+                       {"id": _t(np.tile(np.arange(n), batch)).to(gpu), "label": _t(nl).to(gpu)},
+                       {"id": _t(eid).to(gpu), "label": _t(el).to(gpu)})
+    src, dst, no, eo, eg, ng = GO.collate(ls, ld, nn, ne)
+    u, v = g.all_edges()
+    assert np.array_equal(u.cpu().numpy(), src) and np.array_equal(v.cpu().numpy(), dst)
+    assert np.array_equal(g.edge_graph.cpu().numpy(), eg) and np.array_equal(g.node_graph.cpu().numpy(), ng)
+    r = add_reversed_edges(g, m, 16)
+    ru, rv = (t.cpu().numpy() for t in r.all_edges())
+    rid, rl, rr = r.edata["id"].cpu().numpy(), r.edata["label"].cpu().numpy(), r.edata["is_reversed"].cpu().numpy()
+    dg = convert_to_dual_graph(r)
+    du, dv = (t.cpu().numpy() for t in dg.all_edges())
+    dnn, dne = dg.batch_num_nodes().cpu().numpy(), dg.batch_num_edges().cpu().numpy()
+    d_nd = {k: t.cpu().numpy() for k, t in dg.ndata.items()}
+    d_ed = {k: t.cpu().numpy() for k, t in dg.edata.items()}
+    n_off = e_off = dn_off = de_off = 0
+    for i in range(batch):
+        a = GO.add_reversed_edges(per[i][0], per[i][1], np.arange(m), el[i * m:(i + 1) * m], m, 16)
+        sl = slice(e_off, e_off + 2 * m)
+        assert np.array_equal(ru[sl] - n_off, a[0]) and np.array_equal(rv[sl] - n_off, a[1]), i
+        assert np.array_equal(rid[sl], a[2]) and np.array_equal(rl[sl], a[3]) and np.array_equal(rr[sl], a[4]), i
+        s, t, dn, dnd, ded = GO.convert_to_dual_graph(a[0], a[1], n, {"id": np.arange(n), "label": nl[i * n:(i + 1) * n]},
+                                                      {"id": a[2], "label": a[3], "is_reversed": a[4]})
+        assert int(dnn[i]) == dn and int(dne[i]) == len(s), i
+        assert np.array_equal(du[de_off:de_off + len(s)] - dn_off, s) and np.array_equal(dv[de_off:de_off + len(s)] - dn_off, t), i
+        for k, x in dnd.items():
+            assert np.array_equal(d_nd[k][dn_off:dn_off + dn], x), (i, k)
+        for k, x in ded.items():
+            assert np.array_equal(d_ed[k][de_off:de_off + len(s)], x), (i, k)
+        n_off += n; e_off += 2 * m; dn_off += dn; de_off += len(s)
+    assert dn_off == dg.number_of_nodes() and de_off == dg.number_of_edges()
