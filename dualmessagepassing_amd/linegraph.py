@@ -72,7 +72,10 @@ def convert_to_dual_graph(graph):
     # ---- dual nodes (graph.py:80-103)
     if has_eid:
         eids = graph.edata[EDGEID].to(torch.int64).contiguous()
-        kmax = torch.zeros(B, **i64).scatter_reduce(0, edge_graph, eids + 1, reduce="amax", include_self=True)
+        # largest id + 1 per graph.  The edges of a graph are contiguous: a segmented maximum (a thread per graph) -- the
+        # scatter_reduce form ran 5.2 ms of atomic maxima onto B addresses, 78 % of the whole transform.  Ids are far
+        # below 2^53, so the float64 detour of segment_reduce is exact.
+        kmax = torch.segment_reduce((eids + 1).to(torch.float64), "max", lengths=bne, unsafe=True, initial=0.0).to(torch.int64)
         id_off = _offsets(kmax)               # graph g owns dual-node slots [id_off[g], id_off[g+1])
         gid = eids + id_off[edge_graph]       # edge id made unique across the batch
         K = int(id_off[-1].item())
