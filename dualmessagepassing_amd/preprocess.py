@@ -74,9 +74,10 @@ def calculate_degrees(graph):
     return graph
 
 
-def _segment_max(values, seg, num_segments):
-    out = torch.full((num_segments,), float("-inf"), dtype=values.dtype, device=values.device)
-    return out.scatter_reduce(0, seg.long(), values, reduce="amax", include_self=True)
+def _segment_max(values, lengths):
+    """Maximum over consecutive runs of ``lengths`` entries (``-inf`` for an empty run): the edges of a graph are
+    contiguous in a batch, so this is a segmented reduction -- not a scatter of atomic maxima onto B addresses."""
+    return torch.segment_reduce(values, "max", lengths=lengths.to(torch.int64), unsafe=True, initial=float("-inf"))
 
 
 def compute_largest_eigenvalues(graph):
@@ -91,10 +92,8 @@ def compute_largest_eigenvalues(graph):
     B = graph.batch_size
     if B == 1:
         return nd.max().view(1), ed.max().view(1)
-    seg = graph.edge_graph
-    if seg is None:
-        seg = torch.repeat_interleave(torch.arange(B, device=u.device), graph.batch_num_edges())
-    return _segment_max(nd, seg, B), _segment_max(ed, seg, B)
+    bne = graph.batch_num_edges()
+    return _segment_max(nd, bne), _segment_max(ed, bne)
 
 
 def calculate_eigenvalues(graph):
