@@ -10,6 +10,8 @@ averaging the per-rank gradients reproduces the global-batch gradient for equal 
 The payload is small (~0.6 M parameters = 2.4 MB at H=128): latency-bound, so it is sent
 as one message instead of per-parameter buckets.
 """
+from collections import OrderedDict
+
 import torch
 import torch.distributed as dist
 
@@ -304,9 +306,11 @@ class StepGraph:
     or other tensors with history across calls, and run every step of the run through this object (the layers of this
     package leave only detached values on the graph objects they are given, ``graph.leave_detached``)."""
 
+    MAX_SEEN = 1024      # signatures remembered as "seen once" (oldest forgotten first)
+
     def __init__(self, fn, optimizer=None, max_shapes=4):
         self.fn, self.optimizer, self.max_shapes = fn, optimizer, int(max_shapes)
-        self._seen, self._graphs = set(), {}
+        self._seen, self._graphs = OrderedDict(), {}
         self._stream = None
         self.replays = self.eager_calls = 0
 
@@ -338,7 +342,9 @@ class StepGraph:
         rec = self._graphs.get(key)
         if rec is None:
             if key not in self._seen or len(self._graphs) >= self.max_shapes:
-                self._seen.add(key)
+                self._seen[key] = True
+                while len(self._seen) > self.MAX_SEEN:          # ragged data: every batch a new signature -- bounded memory
+                    self._seen.popitem(last=False)
                 self.eager_calls += 1
                 return self._eager(meta, tensors)
             static = [torch.empty_like(t).copy_(t) for t in tensors]
