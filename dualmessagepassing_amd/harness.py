@@ -481,6 +481,35 @@ def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
             "eval_metric": float(_CRIT[eval_metric](pred, target)), "pred": pred.view(-1).cpu(), "counts": target.view(-1).cpu()}
 
 
+def evaluate_run(save_dir, datasets, device, batch_size=None, eval_metric=None, epoch=None, stamp=""):
+    """``evaluate.py`` (lines 60-245) for a run directory written by ``fit`` (or by the reference's ``train.py``):
+    ``config.json`` -> ``build_model``; the dev-best epoch of ``log.txt`` (``utils/log.py:60-76``) -> its ``epoch%d.pt``
+    (strict load); every split of ``datasets`` (name -> PairDataset) evaluated and written to
+    ``eval_<split>_results_<stamp>.json`` with the reference's result layout (``data`` / ``prediction`` / ``error``);
+    one "best" line per split appended to ``log.txt``.  Returns ``{split: {"MAE", "MSE", "eval_metric"}}``."""
+    import json
+    from . import dataio
+    from .basemodel import build_model
+    config = dataio.load_config(os.path.join(save_dir, "config.json"))
+    metric = eval_metric or config.get("eval_metric", "MAE")
+    if epoch is None:
+        best = dataio.get_best_epochs(os.path.join(save_dir, "log.txt"))
+        epoch = best["eval-" + metric]["dev"][0]
+    model = build_model(config).to(device)
+    model.load_state_dict(torch.load(dataio.checkpoint_path(save_dir, epoch), map_location=device), strict=True)
+    out = {}
+    with open(os.path.join(save_dir, "log.txt"), "a") as log:
+        for split, ds in datasets.items():
+            res = evaluate_epoch(model, ds, batch_size or config.get("eval_batch_size", 64), device, eval_metric=metric)
+            out[split] = {k: res[k] for k in ("MAE", "MSE", "eval_metric")}
+            ids = [x.get("id", str(i)) for i, x in enumerate(ds.samples)]
+            with open(os.path.join(save_dir, "eval_%s_results_%s.json" % (split, stamp)), "w") as f:
+                json.dump({"data": {"id": ids, "counts": res["counts"].tolist()}, "prediction": {"pred_c": res["pred"].tolist()},
+                           "error": {"MAE": res["MAE"], "MSE": res["MSE"]}}, f)
+            log.write(dataio.best_line(split, epoch, epoch, **{"eval-" + metric: "%.3f" % res["eval_metric"]}) + "\n")
+    return out
+
+
 def validate_samples(samples):
     """Host-side check of a dataset, once: every edge endpoint of every pattern / graph inside ``[0, number_of_nodes)``
     (the device index builds only flag such edges in a status word that the training loop does not read back) and the

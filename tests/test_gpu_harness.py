@@ -88,6 +88,17 @@ def test_fit_from_dataset_directory(tmp_path, gpu):
     again = build_model(**dataio.load_config(os.path.join(run, "config.json"))).to(gpu)
     again.load_state_dict(th.load(dataio.checkpoint_path(run, best[0]), map_location=gpu))
     assert evaluate_epoch(again, dev, 32, gpu)["eval_metric"] == pytest.approx(best[1], abs=1e-4)
+    # evaluate.py for the run directory: best checkpoint -> per-split result files and "best" lines
+    import json
+    from dualmessagepassing_amd.harness import evaluate_run
+    test = full.subset(range(n_tr + n_dev, len(full)))
+    res = evaluate_run(run, {"dev": dev, "test": test}, gpu, batch_size=32, stamp="t")
+    assert res["dev"]["eval_metric"] == pytest.approx(best[1], abs=1e-4) and np.isfinite(res["test"]["MAE"])
+    saved = json.load(open(os.path.join(run, "eval_test_results_t.json")))
+    assert len(saved["prediction"]["pred_c"]) == len(test) == len(saved["data"]["counts"])
+    assert saved["error"]["MAE"] == pytest.approx(res["test"]["MAE"])
+    assert saved["data"]["counts"] == [float(x["counts"]) for x in test.samples]
+    assert dataio.get_best_epochs(os.path.join(run, "log.txt"))["eval-MAE"]["test"][1] == pytest.approx(res["test"]["eval_metric"], abs=1e-3)
 
 
 @pytest.mark.parametrize("amsgrad", [False, True])
