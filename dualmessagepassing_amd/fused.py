@@ -356,6 +356,19 @@ def smallk_atb(x, d, gate=None):
     return reduce_partials(part).view(K, H)
 
 
+def smallk_embed(x, W, gate=None):
+    """``gate (.) (x @ W)``  for a narrow ``x`` ([R, K <= 16]: label encodings) and ``W`` [K, H], H = 128 or 64: one pass,
+    the K rows of W in registers (csrc/dmp_fused.hip::smallk_embed_k)."""
+    lib = _lib.load()
+    R, K = x.shape
+    H = W.size(1)
+    out = torch.empty((R, H), dtype=torch.float32, device=x.device)
+    with _lib.timed("smallk_embed[K=%d,R=%d]", (K, R), 4 * (H + K + 1) * R):
+        check(lib.dmp_smallk_embed_gate(ptr(x), x.stride(0), K, ptr(W), W.stride(0), ptr(gate), R, H, ptr(out), H, stream_ptr()),
+              "dmp_smallk_embed_gate")
+    return out
+
+
 _ATB_JOB = None
 MAX_ATB_JOBS = 8
 

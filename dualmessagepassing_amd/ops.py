@@ -394,6 +394,13 @@ class _MatmulXW(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W):
         ctx.save_for_backward(x, W)
+        from . import fused
+        if (x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2 and W.dim() == 2
+                and 1 <= x.size(1) <= fused.SMALLK_MAX and W.size(1) in fused.MFMA_WIDTHS and x.stride(1) == 1 and x.size(0) > 0
+                and W.is_contiguous()):
+            # narrow inputs (label encodings @ embedding table): the small-K kernel, W in registers -- a library GEMM
+            # pays its solution lookup again for every new row count (ragged batches: ~80 us of host time per call)
+            return fused.smallk_embed(x, W)
         return x @ W
 
     @staticmethod
