@@ -163,10 +163,10 @@ def test_degenerate_graphs_through_the_layer(case, gpu):
         _close(zg.grad, zo.grad, 1e-4, "dz fused=%s" % fused)
 
 
-@pytest.mark.parametrize("act", ["leaky_relu", "relu"])
-def test_fused_typed_layer_at_full_config2_size_against_fp64(act, gpu):
+@pytest.mark.parametrize("act,h", [("leaky_relu", 128), ("relu", 128), ("leaky_relu", 64)])
+def test_fused_typed_layer_at_full_config2_size_against_fp64(act, h, gpu):
     """BASELINE config 2 at FULL size -- the union graph of bench.py's step: 1024 x (pattern (8, 12) + target (64, 256)),
-    add_rev: N = 73,728 node rows, E = 548,864 edge rows, hid 128 -- through the fused layer on its fastest path (class-typed
+    add_rev: N = 73,728 node rows, E = 548,864 edge rows, hid 128 (and the shipped hid 64) -- through the fused layer on its fastest path (class-typed
     MFMA kernels, folded first Linear, gates, residual), forward and backward, against the oracle's operation order run in
     fp64 on the same device (every row, not a subsample).  fp32 tolerances: outputs 2e-5, input gradients 1e-4 (flip-aware:
     see test_gpu_dmplayer._close_or_flipped), parameter gradients 5e-4 (sums over 5e5 rows) of the largest reference value."""
@@ -178,7 +178,7 @@ def test_fused_typed_layer_at_full_config2_size_against_fp64(act, gpu):
     ps, pd, pr, pN, pbnn, pbne = er_batch(1024, 8, 12, rng)
     gs, gd, gr, gN, gbnn, gbne = er_batch(1024, 64, 256, rng)
     src, dst, rev = np.concatenate([ps, gs + pN]), np.concatenate([pd, gd + pN]), np.concatenate([pr, gr])
-    N, E, h = pN + gN, len(src), 128
+    N, E = pN + gN, len(src)                                   # h: hid 128 (BASELINE) and the reference's shipped 64
     assert (N, E) == (73728, 548864)
     gen = th.Generator().manual_seed(41)
     params = O.random_dmp_params(h, h, gen, act)
