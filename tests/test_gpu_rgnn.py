@@ -160,3 +160,42 @@ def test_relation_typed_kernels_match_fp64_and_the_per_type_loop(n, e, r, skew, 
         assert float((a.double() - ref).abs().max()) <= 2e-5 * scale, name
         assert float((a - c).abs().max()) <= 4e-5 * scale, name + " vs per-type loop"
         assert th.equal(a, b), name + " not bit-stable"
+
+
+@pytest.mark.parametrize("rep_net", ["RGCN", "RGIN"])
+def test_relational_model_at_hid_128_on_the_typed_kernels(rep_net, gpu):
+    """The whole RGCN / RGIN counting model at hid 128 (the reference fixtures use small widths, i.e. the per-type GEMM
+    loop): the relation-typed MFMA kernels against that loop -- prediction, representations and every parameter
+    gradient -- on a batch of the reference fixture's structure with the vocabulary sizes of its configuration."""
+    from dualmessagepassing_amd import rgnn
+    from dualmessagepassing_amd.basemodel import build_model
+    d = load_golden([p for p in golden_files("rgnn_model_") if rep_net.lower() in p.lower()][0])
+    config = {str(k): eval(str(v)) for k, v in zip(d["config_keys"], d["config_vals"])}
+    config.update(hid_dim=128, pred_hid_dim=128)
+    th.manual_seed(13)
+    model = build_model(**config).to(gpu)
+    runs = []
+    for flag in (True, False):
+        rgnn.USE_REL_KERNELS = flag
+        try:
+            for p in model.parameters():
+                p.grad = None
+            hits = []
+            orig = rgnn.rel_gemm
+            rgnn.rel_gemm = lambda *a, **k: (hits.append(1), orig(*a, **k))[1]
+            try:
+                out = model(_graph(d, "p", gpu), _graph(d, "g", gpu))
+                out["pred_c"].sum().backward()
+            finally:
+                rgnn.rel_gemm = orig
+            assert (len(hits) > 0) == flag
+            runs.append((out["pred_c"].detach().clone(), out["g_v_rep"].detach().clone(),
+                         {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            rgnn.USE_REL_KERNELS = True
+    (c0, r0, g0), (c1, r1, g1) = runs
+    _close(c0, c1.cpu().numpy(), 2e-4, "pred_c")
+    _close(r0, r1.cpu().numpy(), 2e-4, "g_v_rep")
+    assert set(g0) == set(g1) and len(g0) >= 10
+    for k in g0:
+        _close(g0[k], g1[k].cpu().numpy(), 1e-3, "grad " + k)
