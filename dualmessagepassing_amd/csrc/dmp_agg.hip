@@ -56,7 +56,9 @@ __device__ __forceinline__ float4 had4(const float4 &a, const float4 &b) {
 // broadcast by shuffle and the source rows are fetched four at a time (four
 // independent 16-B loads in flight per lane) and added in CSR order.
 // ---------------------------------------------------------------------------
-template <int G, bool SPLIT, bool WEIGHTED, bool REMAP>
+// KIND is not used by the code: 1 tags the launches over an incidence CSR (every source row listed under two destinations),
+// so that a profiler's per-kernel statistics keep them apart from the launches over a CSR by destination.
+template <int G, bool SPLIT, bool WEIGHTED, bool REMAP, int KIND = 0>
 __global__ __launch_bounds__(kBlock) void seg_sum_vec(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
@@ -621,6 +623,8 @@ const char *dmp_last_hip_error(void) { return g_last_err; }
 
 #define DMP_SS(SP, WT, RM) \
   seg_sum_vec<G, SP, WT, RM><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
+#define DMP_SS_INC() \
+  seg_sum_vec<G, true, false, true, 1><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
 
 static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                         const float *ew, int64_t N, int H, bool split, float s0, float s1,
@@ -640,7 +644,7 @@ static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, cons
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(N, kBlock / G);
       if (rows_shared) {
-        if (split) { if (ew) DMP_SS(true, true, true); else DMP_SS(true, false, true); }
+        if (split) { if (ew) DMP_SS(true, true, true); else if (rows_shared == 2) DMP_SS_INC(); else DMP_SS(true, false, true); }
         else { if (ew) DMP_SS(false, true, true); else DMP_SS(false, false, true); }
       } else {
         if (split) { if (ew) DMP_SS(true, true, false); else DMP_SS(true, false, false); }

@@ -635,7 +635,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                     del dH1e
             inc_ptr, inc_ent = ix.incidence()
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
-            ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=True, out=dXP[:, H:],
+            ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=dXP[:, H:],
                             tiling=ix.tiling)
             dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side

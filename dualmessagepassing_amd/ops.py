@@ -285,7 +285,7 @@ class _EdgeCombine(torch.autograd.Function):
                                                  2 * H, stream_ptr()), "dmp_edge_combine_bwd_g")
         if ctx.needs_input_grad[1]:
             inc_ptr, inc_ent = ix.incidence()
-            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0, rows_shared=True)
+            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0, rows_shared=2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dY.sum(0)
         return dG, dP, db, None, None

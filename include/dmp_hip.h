@@ -324,7 +324,9 @@ int dmp_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out,
  *   one XCD (private L2): right when M rows are listed by several destinations (the
  *   incidence CSR) and, measured, also when M was produced by the kernel just before
  *   (59 vs 70 us at E=524288, H=128).  0 = plain dispatch order: ~3 us faster for a cold,
- *   read-once stream.  The shipped host side passes 1.
+ *   read-once stream.  The shipped host side passes 1.  2 = as 1, said of an incidence CSR (every
+ *   row of M listed under two destinations): the same code as a separate kernel instantiation,
+ *   so that per-kernel profiler statistics keep the two launch kinds apart.
  */
 int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr,
                 const int32_t *ent, const float *edge_w, int64_t num_nodes,

@@ -33,6 +33,6 @@ for i in range(reps):
     if kind == "in":
         s = ops.seg_sum_raw(zs[i % 4], ix.in_ptr, ix.in_ent, n, None, True, -1.0, 1.0)
     else:
-        s = ops.seg_sum_raw(zs[i % 4], inc_ptr, inc_ent, n, None, True, 1.0, -1.0, rows_shared=True)
+        s = ops.seg_sum_raw(zs[i % 4], inc_ptr, inc_ent, n, None, True, 1.0, -1.0, rows_shared=2)
 torch.cuda.synchronize()
 print("rows", n, "edges", e, "H", h, "kind", kind)
