@@ -415,6 +415,10 @@ def main():
         from dualmessagepassing_amd.dp import StepGraph
         run = StepGraph(lambda: step(), optimizer=step.opt, max_shapes=1)
         graphed = True
+    if graphed:          # the recordings' side stream is the current stream of everything below (see dp.StepGraph)
+        import contextlib
+        stack = contextlib.ExitStack()
+        stack.enter_context(run.on_stream())
     for _ in range(max(args.warmup, 3) if graphed else args.warmup):   # graphed: eager, record + replay, replay
         run()
     step.finish()

@@ -304,7 +304,14 @@ class StepGraph:
     this stack) -- with everything on the side stream the recording sees one stream only.  Accumulators made elsewhere
     stay alive as long as something holds the autograd graph of an earlier step: do not keep a step's loss (undetached)
     or other tensors with history across calls, and run every step of the run through this object (the layers of this
-    package leave only detached values on the graph objects they are given, ``graph.leave_detached``)."""
+    package leave only detached values on the graph objects they are given, ``graph.leave_detached``).
+
+    Second hazard of this stack (ROCm 7.2, measured): a blocking copy of 64 KB or more between host and device on the LEGACY
+    DEFAULT stream (``tensor.cpu()``, ``torch.save`` of device tensors, ``tensor.to(device)``) between two recordings makes
+    the later recording fault at replay (GPU memory access fault); the same copies on any other stream, pinned
+    non-blocking copies, and copies after the last recording are harmless.  Run the loop that owns this object under
+    ``with step_graph.on_stream():`` -- everything the loop does then happens on this object's side stream
+    (``harness.fit`` does)."""
 
     MAX_SEEN = 1024      # signatures remembered as "seen once" (oldest forgotten first)
 
@@ -322,6 +329,25 @@ class StepGraph:
         if self._stream is None:
             self._stream = torch.cuda.Stream()
         return self._stream
+
+    @property
+    def stream(self):
+        """The side stream eager calls and recordings run on."""
+        return self._side_stream()
+
+    def on_stream(self):
+        """Context manager: the enclosed code runs with this object's side stream as the current stream (ordered after the
+        work already queued on the caller's stream, and the caller's stream waits for it on exit)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            side, cur = self._side_stream(), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                yield side
+            cur.wait_stream(side)
+        return ctx()
 
     def _eager(self, meta, tensors):
         side, cur = self._side_stream(), torch.cuda.current_stream()

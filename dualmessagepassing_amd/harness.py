@@ -366,7 +366,7 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
             for group in optimizer.param_groups:
                 group["lr"] = schedule.lr()
         want = (tuple(match_weights) or None) if (match_loss_w > 0 or match_reg_w > 0) else None
-        if graph is not None and want is None:
+        if graph and want is None:
             loss, ev = graph(dataset, idx, device, neg_slp, rep_reg_w)
             if schedule is not None:
                 schedule.sched_step += 1
@@ -538,13 +538,22 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     """The epoch loop of ``train.py:1296-1380`` reduced to its contract: per epoch one shuffled training
     pass and one dev evaluation; with ``save_dir`` the run directory the reference's tooling expects --
     ``config.json``, ``epoch%d.pt`` (state dict of every epoch), ``log.txt`` whose "best" lines
-    (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history."""
+    (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history.
+    ``graph=True`` (with ``FlatAdamW(capturable=True)``, one rank): training steps whose batch shape repeats are
+    recorded once and replayed as one HIP graph (``GraphedTrainStep``)."""
     from . import dataio
     from .tuning import enable_tuned_gemms
     validate_samples(train_set)
     validate_samples(dev_set)
     enable_tuned_gemms()      # the layer's [rows, 128] x [128, 128..384] products with the solutions picked for MI355X
     sync = sync or FlatGradSync(model)
+    if train_kw.get("graph") is True:       # graph=True: replay recorded steps where the setup allows it, else eager
+        ok = getattr(optimizer, "capturable", False) and getattr(sync, "world", 1) == 1
+        train_kw["graph"] = GraphedTrainStep(model, optimizer, sync, bp_loss=train_kw.get("bp_loss", "MSE"), eval_metric=eval_metric,
+                                             max_grad_norm=train_kw.get("max_grad_norm", 8.0),
+                                             with_rep_reg=train_kw.get("rep_reg_w", 0.0) > 0) if ok else None
+    elif not train_kw.get("graph"):
+        train_kw.pop("graph", None)
     rng = np.random.default_rng(seed)
     log = None
     if save_dir is not None:
@@ -556,7 +565,12 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     import gc
     gc.collect()
     gc.freeze()      # model / dataset / optimizer objects: out of the cyclic collector's way for the whole run
+    import contextlib
+    graphed = train_kw.get("graph")
+    # recorded steps: the whole loop (evaluation, checkpoint copies) on the recordings' side stream -- see dp.StepGraph
+    stream_ctx = graphed.steps.on_stream() if graphed else contextlib.nullcontext()
     try:
+      with stream_ctx:
         for epoch in range(epochs):
             tr = train_epoch(model, optimizer, train_set, batch_size, device, sync=sync, eval_metric=eval_metric,
                              order=rng.permutation(len(train_set)), **train_kw)

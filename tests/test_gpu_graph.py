@@ -86,3 +86,30 @@ def test_graphed_training_equals_eager_training(with_reg, gpu):
     assert th.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0 - l1).abs().max()
     assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max()), float((p0 - p1).abs().max())
     assert float((p0 - start).abs().max()) > 1e-3                           # it did train
+
+
+def test_fit_with_graph_replay(tmp_path, gpu):
+    """harness.fit(graph=True): the run trains through recorded steps (uniform synthetic set: two batch shapes) and leaves
+    the same run directory as an eager fit; its dev metric after every epoch equals the eager run's."""
+    import os
+    from dualmessagepassing_amd import dataio
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    from dualmessagepassing_amd.harness import SyntheticPairs, fit
+    ds = SyntheticPairs(72, 3, 2, 8, 16, 2, 1, seed=9)
+    train, dev = ds.subset(range(56)), ds.subset(range(56, 72))
+    config = ds.model_config(hid_dim=64, layers=2)
+    th.manual_seed(2)
+    base = build_model(**config).to(gpu)
+    hists = []
+    for graphed in (False, True):
+        model = copy.deepcopy(base)
+        sync = FlatGradSync(model)
+        opt = FlatAdamW([sync.flatten_parameters()], lr=2e-3, weight_decay=1e-5, amsgrad=True, capturable=graphed)
+        run = os.path.join(tmp_path, "run%d" % graphed)
+        hists.append(fit(model, opt, train, dev, 4, 16, gpu, save_dir=run, config=config, sync=sync, neg_slp=0.01, seed=3,
+                         graph=graphed))
+        assert os.path.exists(dataio.checkpoint_path(run, 3)) and "eval-MAE" in dataio.get_best_epochs(os.path.join(run, "log.txt"))
+    for a, b in zip(*hists):
+        assert a["dev"]["eval_metric"] == pytest.approx(b["dev"]["eval_metric"], rel=1e-4, abs=1e-5)
+        assert a["train"]["bp_loss"] == pytest.approx(b["train"]["bp_loss"], rel=1e-4, abs=1e-5)
