@@ -415,7 +415,9 @@ class GraphedTrainStep:
     ``batch_arrays`` / ``graphs_from_arrays``.  The negative slope of the count loss and the representation
     regulariser's weight are device scalars written before every replay, the learning rate goes through
     ``optimizer.sync_hyper()``.  Batches of a shape seen for the first time, and shapes beyond ``max_shapes``
-    recordings, run eagerly -- through the same function, so both ways compute the same step."""
+    recordings, run eagerly -- through the same function, so both ways compute the same step.  Run the training loop
+    under ``with step.steps.on_stream():`` when it also copies sizeable tensors between host and device (checkpoints,
+    predictions): see ``dp.StepGraph`` (``fit(graph=True)`` does)."""
 
     def __init__(self, model, optimizer, sync, bp_loss="MSE", eval_metric="MAE", max_grad_norm=8.0, with_rep_reg=False,
                  max_shapes=4):
