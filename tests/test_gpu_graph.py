@@ -1,15 +1,57 @@
 """HIP-graph replay of a training step (dp.StepGraph, harness.GraphedTrainStep, FlatAdamW(capturable=True)): a replayed
-step must compute what the eager step computes -- same losses step by step, same parameters at the end."""
+step must compute what the eager step computes -- same losses step by step, same parameters at the end.
+
+Every case runs in a fresh child process (``test_*`` below start ``test_inner_*`` through pytest with
+DMP_GRAPH_TESTS_INLINE=1): what goes wrong with a recording on this stack goes wrong as a segfault or a GPU memory fault
+of the whole process (see dp.StepGraph), and one such failure must not take the rest of the GPU suite with it."""
 import copy
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch as th
 
 pytestmark = pytest.mark.gpu
+INLINE = os.environ.get("DMP_GRAPH_TESTS_INLINE") == "1"
+inner = pytest.mark.skipif(not INLINE, reason="runs in a child process started by its test_* wrapper")
+outer = pytest.mark.skipif(INLINE, reason="wrapper: the child process runs the inner case")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _isolated(node):
+    """Run ``tests/test_gpu_graph.py::<node>`` in a child process; fail with its output if it fails or dies."""
+    env = dict(os.environ, DMP_GRAPH_TESTS_INLINE="1")
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-m", "pytest", "%s::%s" % (os.path.abspath(__file__), node), "-q", "-x",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    assert r.returncode == 0 and " passed" in r.stdout, "child exited with %s:\n%s" % (r.returncode, tail)
+
+
+@outer
 def test_capturable_adamw_matches_the_host_step(gpu):
+    _isolated("test_inner_capturable_adamw_matches_the_host_step")
+
+
+@outer
+def test_step_graph_records_once_per_signature(gpu):
+    _isolated("test_inner_step_graph_records_once_per_signature")
+
+
+@outer
+@pytest.mark.parametrize("with_reg", [False, True])
+def test_graphed_training_equals_eager_training(with_reg, gpu):
+    _isolated("test_inner_graphed_training_equals_eager_training[%s]" % with_reg)
+
+
+@outer
+def test_fit_with_graph_replay(gpu):
+    _isolated("test_inner_fit_with_graph_replay")
+
+
+@inner
+def test_inner_capturable_adamw_matches_the_host_step(gpu):
     """dmp_adamw_step_dev (step count and learning rate in device memory) against dmp_adamw_step_skip (host values)
     over a few steps with a learning-rate change and a parameter range without gradient."""
     from dualmessagepassing_amd.dp import FlatAdamW
@@ -31,7 +73,8 @@ def test_capturable_adamw_matches_the_host_step(gpu):
     assert float(opts[1].state[ps[1]]["dev"][0]) == 7.0 and float(opts[1].state[ps[1]]["dev"][1]) == 1e-3
 
 
-def test_step_graph_records_once_per_signature(gpu):
+@inner
+def test_inner_step_graph_records_once_per_signature(gpu):
     from dualmessagepassing_amd.dp import StepGraph
     acc = th.zeros(4, device=gpu)
     calls = []
@@ -54,8 +97,9 @@ def test_step_graph_records_once_per_signature(gpu):
     assert y.shape == (6,) and sg.eager_calls == 3 and sg.replays == 4
 
 
+@inner
 @pytest.mark.parametrize("with_reg", [False, True])
-def test_graphed_training_equals_eager_training(with_reg, gpu):
+def test_inner_graphed_training_equals_eager_training(with_reg, gpu):
     """Three epochs of count-loss training (batches of two shapes: the last batch of an epoch is smaller), eager vs
     HIP-graph replay from the same initial state: the per-step losses and the final parameters agree to fp32 rounding
     of the optimizer's bias corrections; the learning rate changes between epochs and reaches the replayed steps."""
@@ -88,7 +132,8 @@ def test_graphed_training_equals_eager_training(with_reg, gpu):
     assert float((p0 - start).abs().max()) > 1e-3                           # it did train
 
 
-def test_fit_with_graph_replay(tmp_path, gpu):
+@inner
+def test_inner_fit_with_graph_replay(tmp_path, gpu):
     """harness.fit(graph=True): the run trains through recorded steps (uniform synthetic set: two batch shapes) and leaves
     the same run directory as an eager fit; its dev metric after every epoch equals the eager run's."""
     import os
