@@ -3,8 +3,11 @@
 on MI355X (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts its N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --workload 4                  (the scaling configuration, BASELINE configs[3]: 1024 pairs of
+                                                            pattern (16,32) x target (512,4096) per GPU)
 
 Workload = BASELINE.json configs[1] per GPU: synthetic directed Erdos-Renyi pairs,
 pattern (|V|=8, |E|=12) x target (|V|=64, |E|=256), reversed edges added (E -> 2E, the
@@ -276,7 +279,7 @@ def sparse_end_to_end(cfg, pairs_per_s):
     return {"bytes_per_pair": per_pair, "gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
 
 
-def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
+def cpu_baseline(cfg, state_dict, seconds_budget=20.0, B=32, max_steps=50, warm=True):
     """The same step on the host cores with the CPU oracle (oracle/model_oracle.py + dmp_oracle.py: the reference's
     operation order -- gather-then-project layers, padded [B, L, D] heads, per-sample Python loops -- in torch CPU ops,
     pinned by the reference's own full-model runs): collate of B per-graph arrays, forward of the WHOLE model, count
@@ -287,7 +290,7 @@ def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
     # the oracle's ops are small; past ~32 threads torch's intra-op pool only adds contention
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    B, H, L = 32, cfg["hid"], cfg["layers"]
+    H, L = cfg["hid"], cfg["layers"]
     rng = np.random.default_rng(7)
     mc = model_config(cfg)
     sd = {k: v.detach().cpu().clone() for k, v in state_dict.items()}
@@ -335,19 +338,85 @@ def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
         loss.backward()
         opt.step()
 
-    one()  # warm-up
+    if warm:
+        one()  # warm-up
     t0, n = time.perf_counter(), 0
     while True:
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 50:
+        if el > seconds_budget or n >= max_steps:
             break
     return {"value": B * n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": "%d steps of B=%d pairs of the same shapes; the same step composition as the GPU line (collate, whole "
                       "model forward: encodings, embeddings, ScalarFilter, %d-layer pattern + target DMPNN rep-nets, node + edge "
                       "SumPredictNet heads; count loss, backward, AdamW(amsgrad)), hid=%d, fp32, reference operation order, "
                       "torch %s CPU, %d threads" % (n, B, L, H, torch.__version__, cores)}
+
+
+def spawn_check(args, rank, world):
+    """--spawn-check: the multi-rank plumbing of this script without the GPU step (tests/test_bench_spawn.py)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = "gloo" if args.backend == "nccl" and not torch.cuda.is_available() else args.backend
+    seen = 1
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % args.hid, "value": None, "unit": "pairs/s",
+                          "n_gpus": world, "ranks_seen": seen, "backend": backend if world > 1 else None, "steps": args.steps,
+                          "warmup": args.warmup, "spawn_check": True,
+                          "launcher": "bench.py (self-spawned ranks)" if os.environ.get("DMP_BENCH_SPAWNED") else "external"}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this script (one per GPU) and relay
+    rank 0's JSON line.  Called BEFORE anything touches the GPU in this process (a process that has initialised HIP must
+    neither fork ranks nor exec), the children are started with ``subprocess`` (fresh interpreters, no inherited GPU
+    state), rendezvous on 127.0.0.1.  Returns the exit code: non-zero if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DMP_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+        # rank 0 writes the line to our stdout; the other ranks print nothing on stdout anyway
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    deadline = None
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                if deadline is None:                           # a dead rank leaves the others in a collective: bound the wait
+                    deadline = time.monotonic() + 30.0
+        if deadline is not None and alive and time.monotonic() > deadline:
+            for p in alive:
+                p.kill()                                       # exactly the processes started above
+            for p in alive:
+                p.wait()
+            alive = []
+    if rc:
+        print("bench.py: a rank process failed (exit code %d)" % rc, file=sys.stderr, flush=True)
+    return rc
 
 
 def main():
@@ -375,11 +444,28 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path on a single-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="testing aid (runs without a GPU): start the ranks, form the process group, count them with an "
+                         "all-reduce and print a line with n_gpus / ranks_seen and value null -- no step is run")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the parent of N fresh rank processes and never touches the GPU itself
+        if not (args.single_device or args.spawn_check):
+            have = torch.cuda.device_count()                   # counting devices does not initialise HIP on this image
+            if have < args.gpus:
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --single-device to time-share one GPU "
+                                 "with --backend gloo as a plumbing test)" % (args.gpus, have))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's --nproc-per-node must equal --gpus)"
+                         % (args.gpus, world))
+    if args.spawn_check:
+        return spawn_check(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback in the product path)")
     if args.single_device:
@@ -434,12 +520,19 @@ def main():
     _lib.timer.reset()
     _lib.timer.only = "seg_sum2["
     _lib.timer.enabled = not graphed                         # no event records inside a replayed graph
+    # one event record per step on the step's stream (the stream run() launches on): the spread of the device time per
+    # step; 20 steps of 6 ms are too short to trust a mean alone.  Event k marks the enqueue point of step k, so a
+    # difference is the device time of one step once the queue is full (the GPU-bound case).
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         run()
     step.finish()                                            # the last step's all-reduce + optimizer update: inside the timed region
+    marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.steps else []
     kern = _lib.timer.summary()
     _lib.timer.reset()
     _lib.timer.only = None
@@ -452,10 +545,17 @@ def main():
     for name, v in others.items():
         kern.setdefault(name, v)
 
+    ranks_seen, devices = 1, [torch.cuda.get_device_name(device)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        c = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(c)                                   # every rank that timed the region adds one
+        ranks_seen = int(c.item())
+        names = [None] * world
+        dist.all_gather_object(names, "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(device)))
+        devices = names
 
     if rank == 0:
         pairs = cfg["batch"] * world * args.steps
@@ -476,8 +576,15 @@ def main():
                     "bytes_per_launch": int(k["bytes"]), "avg_us": round(k["avg_us"], 2), "launches": k["launches"]}
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
-            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+            "devices": devices, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # device time per step between consecutive per-step event records on rank 0 (min / median / max)
+            "step_ms_min": round(per_step_ms[0], 3) if per_step_ms else None,
+            "step_ms_median": round(per_step_ms[len(per_step_ms) // 2], 3) if per_step_ms else None,
+            "step_ms_max": round(per_step_ms[-1], 3) if per_step_ms else None,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
                                    "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, ScalarFilter, "
@@ -503,8 +610,19 @@ def main():
             "kernels": {n: {"avg_us": round(v["avg_us"], 2), "gbps": round(v["gbps"], 1), "launches": v["launches"],
                             "bytes": int(v["bytes"])} for n, v in sorted(kern.items())},
         }
+        line["launcher"] = ("bench.py (self-spawned ranks)" if os.environ.get("DMP_BENCH_SPAWNED") else
+                            "external (torch.distributed.run)") if world > 1 else "single process"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, initial_state)
+            # the same CPU step at the GPU line's batch size (B = 1024 pairs; at most 2 steps, no warm-up step): the
+            # B = 32 sample above is the reference's own CPU-runnable batch size, this one is the like-for-like size
+            try:
+                import psutil
+                room = psutil.virtual_memory().available >= 48 * 2 ** 30
+            except ImportError:
+                room = False
+            if room and args.workload == 2:
+                line["cpu_baseline_b1024"] = cpu_baseline(cfg, initial_state, seconds_budget=12.0, B=cfg["batch"], max_steps=2, warm=False)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
