@@ -626,6 +626,47 @@ __global__ void sample_in_edges_k(const int32_t *in_ptr, const int32_t *in_ent, 
   for (int i = 0; i < n; ++i) mask[(uint32_t)best[i]] = 1;
 }
 
+// The same choice for ANY width (the reference's default sample width is 128, main.py:294): a wave per node, no list.
+// The width-th smallest key t of the row is found by bisection on the 32-bit key (33 counting passes over the row,
+// lanes strided); every edge with key < t is kept, and of the edges with key == t the first `need` in row order (rows
+// list edges in ascending edge id, so that is the tie rule "smaller edge id").
+__global__ __launch_bounds__(kBlock) void sample_in_edges_wave_k(const int32_t *in_ptr, const int32_t *in_ent, const uint8_t *wanted,
+                                                               int64_t N, int width, uint32_t seed, uint8_t *mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (v >= N || (wanted && !wanted[v])) return;                // wave-uniform
+  const int32_t lo = in_ptr[v], hi = in_ptr[v + 1];
+  if (hi - lo <= width) {
+    for (int32_t q = lo + lane; q < hi; q += 64) mask[in_ent[q] >> 1] = 1;
+    return;
+  }
+  auto count_le = [&](uint32_t t) {
+    int c = 0;
+    for (int32_t q = lo + lane; q < hi; q += 64) c += rng_hash(seed, (uint32_t)(in_ent[q] >> 1), 0u) <= t;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    return c;
+  };
+  uint32_t a = 0u, b = 0xFFFFFFFFu;                             // smallest t with count(key <= t) >= width
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (count_le(mid) >= width) b = mid; else a = mid + 1;
+  }
+  const uint32_t t = a;
+  int need = width - (t ? count_le(t - 1) : 0);                // ties to take, >= 1
+  for (int32_t q0 = lo; q0 < hi; q0 += 64) {
+    const int32_t q = q0 + lane;
+    uint32_t e = 0, k = 0xFFFFFFFFu;
+    const bool in = q < hi;
+    if (in) { e = (uint32_t)(in_ent[q] >> 1); k = rng_hash(seed, e, 0u); }
+    const bool tie = in && k == t;
+    const unsigned long long ties = __ballot(tie);
+    const int before = __popcll(ties & ((1ull << lane) - 1ull));
+    if (in && (k < t || (tie && before < need))) mask[e] = 1;
+    need -= __popcll(ties);
+    if (need < 0) need = 0;
+  }
+}
+
 // Pooling index (ops.PoolIndex): the rows of every graph of a batch (contiguous ranges of `sizes[i]` rows) cut into chunks
 // of `chunk` rows, so that the per-graph sums of the prediction heads run as two launches of the segment-sum kernel
 // (rows -> chunk sums -> graph sums) with enough independent rows to fill the chip.  One single-workgroup scan for the
@@ -1302,13 +1343,15 @@ int dmp_random_walks(const int32_t *out_ptr, const int32_t *out_ent, const int32
 int dmp_sample_in_edges(const int32_t *in_ptr, const int32_t *in_ent, const uint8_t *wanted, int64_t N, int64_t E, int width,
                         uint64_t seed, uint8_t *mask, void *stream) {
   if (N < 0 || E < 0 || width < 0) return DMP_ERR_BAD_ARG;
-  if (width > kMaxSampleWidth) return DMP_ERR_UNSUPPORTED;
   if (E == 0) return DMP_OK;
   if (!in_ptr || !in_ent || !mask) return DMP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   DMP_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)E, st));
-  if (N > 0 && width > 0)
-    sample_in_edges_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, wanted, N, width, (uint32_t)(seed ^ (seed >> 32)), mask);
+  const uint32_t s32 = (uint32_t)(seed ^ (seed >> 32));
+  if (N > 0 && width > 0) {
+    if (width <= kMaxSampleWidth) sample_in_edges_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, wanted, N, width, s32, mask);
+    else sample_in_edges_wave_k<<<nblk(N * 64), kBlock, 0, st>>>(in_ptr, in_ent, wanted, N, width, s32, mask);   // any width
+  }
   return check_launch();
 }
 

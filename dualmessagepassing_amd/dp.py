@@ -108,9 +108,14 @@ class FlatGradSync:
             p.grad = v
         if missing:                                          # parameters without a gradient this step keep zeros:
             key = tuple(live)                                # their slices were zero before and nothing writes them, so the
-            if getattr(self, "_zeroed_for", None) != key:    # buffer is cleared only when the set of live parameters changes
+            # buffer is cleared only when the set of live parameters changes.  Inside a stream capture the clearing is
+            # ALWAYS recorded (whether it is needed at a replay depends on what ran in between, which the recording cannot
+            # know: an eager step with a larger live set would leave its values in the slices this recording treats as
+            # missing), and the host-side note is dropped so that the next eager step clears too.
+            capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+            if capturing or getattr(self, "_zeroed_for", None) != key:
                 self.flat.zero_()
-                self._zeroed_for = key
+            self._zeroed_for = None if capturing else key
         else:
             self._zeroed_for = None
         self._note_live(live if missing else None)
@@ -211,6 +216,33 @@ class FlatAdamW(torch.optim.Optimizer):
             st["dev"] = torch.tensor([float(st.get("step", 1) - 1), float(group["lr"])], dtype=torch.float64, device=p.device)
             st["dev_lr"] = float(group["lr"])
         return st["dev"]
+
+    @torch.no_grad()
+    def sync_state(self):
+        """Read the device-side step counts back into ``state[p]["step"]`` (one host sync): graph replays advance only the
+        device count.  ``state_dict()`` calls it."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "dev" in st:
+                    st["step"] = int(round(float(st["dev"][0].item())))
+
+    def state_dict(self):
+        """``torch.optim.Optimizer.state_dict`` with the step counts current (``sync_state``) and without the device-side
+        scalars (``dev`` / ``dev_lr``: rebuilt from ``step`` and the group's rate on the next step), so the saved state
+        loads into a capturable or a plain ``FlatAdamW`` alike."""
+        self.sync_state()
+        sd = super().state_dict()
+        sd["state"] = {k: {n: v for n, v in st.items() if n not in ("dev", "dev_lr")} for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():                       # the device scalars follow the loaded step count
+            st.pop("dev", None)
+            st.pop("dev_lr", None)
+            if torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"].item())
 
     @torch.no_grad()
     def sync_hyper(self):

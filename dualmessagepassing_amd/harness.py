@@ -551,9 +551,15 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     sync = sync or FlatGradSync(model)
     if train_kw.get("graph") is True:       # graph=True: replay recorded steps where the setup allows it, else eager
         ok = getattr(optimizer, "capturable", False) and getattr(sync, "world", 1) == 1
+        # the regulariser is part of the recording when it can be on at ANY step of the run: a positive constant, or a
+        # schedule's value (a number or an annealing spec string in its config: on unless it is the constant 0)
+        reg = train_kw.get("rep_reg_w", 0.0)
+        sched = train_kw.get("schedule")
+        if sched is not None:
+            reg = sched.config.get("rep_reg_w", 0.0)
+        with_reg = (isinstance(reg, str) and reg.strip() not in ("", "0", "0.0")) or (not isinstance(reg, str) and float(reg) > 0)
         train_kw["graph"] = GraphedTrainStep(model, optimizer, sync, bp_loss=train_kw.get("bp_loss", "MSE"), eval_metric=eval_metric,
-                                             max_grad_norm=train_kw.get("max_grad_norm", 8.0),
-                                             with_rep_reg=train_kw.get("rep_reg_w", 0.0) > 0) if ok else None
+                                             max_grad_norm=train_kw.get("max_grad_norm", 8.0), with_rep_reg=with_reg) if ok else None
     elif not train_kw.get("graph"):
         train_kw.pop("graph", None)
     rng = np.random.default_rng(seed)
@@ -575,7 +581,7 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
       with stream_ctx:
         for epoch in range(epochs):
             tr = train_epoch(model, optimizer, train_set, batch_size, device, sync=sync, eval_metric=eval_metric,
-                             order=rng.permutation(len(train_set)), **train_kw)
+                             order=rng.permutation(len(train_set)), **dict(train_kw, epoch=epoch))
             dev = evaluate_epoch(model, dev_set, batch_size, device, eval_metric=eval_metric)
             history.append({"epoch": epoch, "train": tr, "dev": {k: dev[k] for k in ("MAE", "MSE", "eval_metric")}})
             if save_dir is not None:

@@ -235,8 +235,10 @@ int dmp_subiso_count_batch(int64_t num_pairs, const int64_t *p_node_off, const i
  *                        a node without out-edges ends the walk.  traces [num_seeds * walks, depth + 1] int64 (-1 after
  *                        the end) and / or visited [N] uint8 (set to 1 for every node on a walk; the caller zeroes it).
  *   dmp_sample_in_edges: mask[e] = 1 for the in-edges kept for every node v with wanted[v] != 0 (NULL: all nodes): all
- *                        of them if v has at most `width` (<= 64), else the `width` with the smallest
- *                        (mix(seed, e, 0), e) -- a uniform sample without replacement.  mask [E] uint8 is fully written.
+ *                        of them if v has at most `width`, else the `width` with the smallest
+ *                        (mix(seed, e, 0), e) -- a uniform sample without replacement (any width: a thread per node
+ *                        with a sorted list up to 64, a wave per node bisecting the key threshold above; the
+ *                        reference's default sample width is 128, main.py:294).  mask [E] uint8 is fully written.
  */
 int dmp_random_walks(const int32_t *out_ptr, const int32_t *out_ent, const int32_t *dst, const int64_t *seeds,
                      int64_t num_seeds, int walks, int depth, uint64_t seed, int64_t *traces, uint8_t *visited,

@@ -25,8 +25,20 @@ import torch.nn.functional as F
 LEAKY_RELU_A = 1 / 5.5  # constants.py:10
 
 
+KINKED = ("relu", "leaky_relu")  # activations whose derivative jumps at 0
+
+
 def activation(name):
     # utils/act.py:457-474
+    fn = _activation(name)
+    if name in KINKED:
+        return fn
+    smooth = lambda x: fn(x)
+    smooth.smooth = True          # the probe below records "no kink here" for these
+    return smooth
+
+
+def _activation(name):
     return {
         "none": lambda x: x,
         "relu": F.relu,
@@ -36,6 +48,19 @@ def activation(name):
         "elu": F.elu,
         "gelu": F.gelu,
     }[name]
+
+
+# Test hook: when a list, every pre-activation of a piecewise-linear activation the oracle evaluates is appended to it
+# as (site, tensor): the parity tests use the values to find the few activations that lie within rounding of the kink
+# (tests/util_flips.py).  Not part of the arithmetic.
+PROBE = None
+
+
+def probe(site, pre, act=None):
+    if PROBE is not None:
+        # a smooth activation has no ambiguous elements: its layer is still recorded (the tracing needs every layer)
+        PROBE.append((site, th.full_like(pre[:, :1], float("inf")) if getattr(act, "smooth", False) else pre.detach()))
+    return pre
 
 
 def seg_sum(msg, dst, num_nodes):
@@ -66,7 +91,7 @@ def mlp(x, params, prefix, act, num_layers=2, bn=None, training=False):
                 x = F.batch_norm(x, b["running_mean"], b["running_var"], params["%s.%d.weight" % (prefix, idx)],
                                  params["%s.%d.bias" % (prefix, idx)], training, 0.1, 1e-5)
                 idx += 1
-            x = act(x)
+            x = act(probe(prefix, x, act))
             idx += 1
     return x
 

@@ -26,8 +26,14 @@ import numpy as np
 import torch as th
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+# DMP_GOLDEN_OUT: write somewhere else (tests/test_fixtures_regenerate.py regenerates into a temporary directory)
+OUT = os.environ.get("DMP_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
+
+# Reproducible to the bit: one CPU thread (multi-threaded reductions sum in a thread-count-dependent order; a chaotic
+# five-epoch training run amplifies that to percents) and deterministic algorithms only.
+th.set_num_threads(1)
+th.use_deterministic_algorithms(True)
 
 
 def er_edges(n, m, rng):
@@ -566,7 +572,7 @@ print("wrote unc_graph_build.npz", tuple(gb.edata["norm"].shape))
 
 def gen_unc():
     # the UNC package's top-level module is also called ``utils`` -> separate interpreter
-    code = UNC_SCRIPT % {"here": HERE, "out": OUT}
+    code = "import torch as _th\n_th.set_num_threads(1)\n_th.use_deterministic_algorithms(True)\n" + UNC_SCRIPT % {"here": HERE, "out": OUT}
     subprocess.run([sys.executable, "-c", code], check=True)
 
 

@@ -82,11 +82,11 @@ def _head(sd, prefix, act, p_out, p_mask, g_out, g_mask, pool, return_weights):
     if return_weights:
         pe = p.unsqueeze(1).expand(bsz, g_len, -1)
         ple, plie = pl.expand(bsz, g_len).unsqueeze(-1), (1.0 / pl).expand(bsz, g_len).unsqueeze(-1)
-        w = act(lin("weight_fc1", th.cat([pe, g_rows, g_rows - pe, g_rows * pe, ple, plie], 2)))
+        w = act(O.probe(prefix + ".weight_fc1", lin("weight_fc1", th.cat([pe, g_rows, g_rows - pe, g_rows * pe, ple, plie], 2))))
         w = lin("weight_fc2", th.cat([w, ple, plie], 2)).squeeze(-1)
     g = agg(g_rows)
     y = th.cat([p, g, g - p, g * p, pl, gl, 1.0 / pl, 1.0 / gl], 1)
-    y = act(lin("pred_fc1", y))
+    y = act(O.probe(prefix + ".pred_fc1", lin("pred_fc1", y)))
     return lin("pred_fc2", th.cat([y, pl, gl, 1.0 / pl, 1.0 / gl], 1)), w
 
 

@@ -50,6 +50,21 @@ def test_fit_with_graph_replay(gpu):
     _isolated("test_inner_fit_with_graph_replay")
 
 
+@outer
+def test_optimizer_state_dict_after_replays(gpu):
+    _isolated("test_inner_optimizer_state_dict_after_replays")
+
+
+@outer
+def test_recorded_pack_clears_missing_slices(gpu):
+    _isolated("test_inner_recorded_pack_clears_missing_slices")
+
+
+@outer
+def test_fit_with_graph_replay_and_scheduled_regulariser(gpu):
+    _isolated("test_inner_fit_with_graph_replay_and_scheduled_regulariser")
+
+
 @inner
 def test_inner_capturable_adamw_matches_the_host_step(gpu):
     """dmp_adamw_step_dev (step count and learning rate in device memory) against dmp_adamw_step_skip (host values)
@@ -157,4 +172,113 @@ def test_inner_fit_with_graph_replay(tmp_path, gpu):
         assert os.path.exists(dataio.checkpoint_path(run, 3)) and "eval-MAE" in dataio.get_best_epochs(os.path.join(run, "log.txt"))
     for a, b in zip(*hists):
         assert a["dev"]["eval_metric"] == pytest.approx(b["dev"]["eval_metric"], rel=1e-4, abs=1e-5)
+        assert a["train"]["bp_loss"] == pytest.approx(b["train"]["bp_loss"], rel=1e-4, abs=1e-5)
+
+
+@inner
+def test_inner_optimizer_state_dict_after_replays(gpu):
+    """replays advance the step count on the device only.  ``state_dict()`` must carry the true count, and the
+    state must load into a plain (non-capturable) FlatAdamW that then continues exactly like the capturable one."""
+    from dualmessagepassing_amd.dp import FlatAdamW, StepGraph
+    gen = th.Generator().manual_seed(4)
+    p = th.randn(4099, generator=gen).to(gpu).requires_grad_(True)
+    g = th.randn(4099, generator=gen).to(gpu)
+    p.grad = g.clone()
+    opt = FlatAdamW([p], lr=1e-2, weight_decay=1e-2, amsgrad=True, capturable=True)
+
+    def fn(gr):
+        p.grad.copy_(gr)
+        opt.step()
+        return p.detach().sum().view(1)
+    run = StepGraph(fn, optimizer=opt)
+    with run.on_stream():
+        for _ in range(6):                                            # eager, record + replay, 4 replays
+            run(g)
+    th.cuda.synchronize()
+    assert run.replays == 5
+    sd = opt.state_dict()
+    st = sd["state"][0]
+    assert st["step"] == 6 and "dev" not in st and "dev_lr" not in st
+    q = p.detach().clone().requires_grad_(True)
+    plain = FlatAdamW([q], lr=1e-2, weight_decay=1e-2, amsgrad=True)
+    plain.load_state_dict(sd)
+    q.grad = g.clone()
+    plain.step()                                                      # step 7 on the host-side count
+    with run.on_stream():
+        run(g)                                                        # step 7 replayed
+    th.cuda.synchronize()
+    assert float((p - q).abs().max()) <= 1e-7 * float(p.abs().max())
+    # and back: a capturable optimizer that loads the state rebuilds its device count from it
+    r = q.detach().clone().requires_grad_(True)
+    cap = FlatAdamW([r], lr=1e-2, weight_decay=1e-2, amsgrad=True, capturable=True)
+    cap.load_state_dict(plain.state_dict())
+    r.grad, q.grad = g.clone(), g.clone()
+    cap.step()
+    plain.step()
+    assert float(cap.state[r]["dev"][0]) == 8.0
+    assert float((r - q).abs().max()) <= 1e-7 * float(q.abs().max())
+
+
+@inner
+def test_inner_recorded_pack_clears_missing_slices(gpu):
+    """``FlatGradSync.pack`` recorded in a graph must clear the slices of parameters without a gradient at every
+    replay -- an eager step with a LARGER live set in between leaves its gradients there otherwise."""
+    from dualmessagepassing_amd.dp import FlatGradSync, StepGraph
+
+    class Two(th.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = th.nn.Parameter(th.ones(64))
+            self.b = th.nn.Parameter(th.ones(32))
+    m = Two().to(gpu)
+    sync = FlatGradSync(m)
+    x = th.arange(64, dtype=th.float32, device=gpu)
+
+    def only_a(t):
+        sync.detach_grads()
+        (m.a * t).sum().backward()
+        sync.pack()
+        return sync.flat.clone()
+    run = StepGraph(only_a)
+    with run.on_stream():
+        run(x)
+        out = run(x)                                                  # recorded: b has no gradient
+        assert float(out[64:].abs().max()) == 0.0
+        sync.detach_grads()                                           # an eager step where BOTH get gradients
+        ((m.a * x).sum() + (m.b * 3.0).sum()).backward()
+        sync.pack()
+        assert float(sync.flat[64:96].min()) == 3.0
+        out = run(x)                                                  # replay: b's slice must be cleared again
+        th.cuda.synchronize()
+        assert run.replays == 2
+        assert float(out[64:].abs().max()) == 0.0 and th.equal(out[:64], x)
+        sync.detach_grads()                                           # an eager step with the recording's live set clears too
+        ((m.a * x).sum() + (m.b * 3.0).sum()).backward()
+        sync.pack()
+        sync.detach_grads()
+        (m.a * x).sum().backward()
+        sync.pack()
+        assert float(sync.flat[64:].abs().max()) == 0.0
+
+
+@inner
+def test_inner_fit_with_graph_replay_and_scheduled_regulariser(gpu):
+    """``fit(graph=True, schedule=RunSchedule(config))`` with a non-zero / annealed ``rep_reg_w`` in the config
+    used to raise mid-epoch (the recorded step was built without the regulariser)."""
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    from dualmessagepassing_amd.harness import RunSchedule, SyntheticPairs, fit
+    ds = SyntheticPairs(48, 3, 2, 8, 16, 2, 1, seed=9)
+    train, dev = ds.subset(range(32)), ds.subset(range(32, 48))
+    config = ds.model_config(hid_dim=64, layers=2)
+    th.manual_seed(2)
+    base = build_model(**config).to(gpu)
+    hists = []
+    for graphed in (False, True):
+        model = copy.deepcopy(base)
+        sync = FlatGradSync(model)
+        opt = FlatAdamW([sync.flatten_parameters()], lr=2e-3, weight_decay=1e-5, amsgrad=True, capturable=graphed)
+        run_cfg = dict(config, train_batch_size=16, train_epochs=3, lr=2e-3, scheduler="constant", rep_reg_w=0.05, neg_pred_slp=0.01)
+        hists.append(fit(model, opt, train, dev, 3, 16, gpu, sync=sync, seed=3, graph=graphed, schedule=RunSchedule(run_cfg, len(train))))
+    for a, b in zip(*hists):
         assert a["train"]["bp_loss"] == pytest.approx(b["train"]["bp_loss"], rel=1e-4, abs=1e-5)

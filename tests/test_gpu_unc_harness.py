@@ -53,3 +53,24 @@ def test_unsupervised_training_learns_the_link_structure(sampler, gpu):
                          th.randint(0, n, (trip.size(0),), device=gpu)], 1)
         pos, neg = model.calc_score(emb, trip), model.calc_score(emb, fake)
     assert float(pos.mean()) > float(neg.mean()) + 0.1, (float(pos.mean()), float(neg.mean()))
+
+
+def test_training_loop_at_the_reference_default_sample_width(gpu):
+    """``train_unsupervised`` / ``collect_node_embeddings`` default to sample_width = 128 (main.py:294); the
+    default call must run (a hub with more than 128 in-edges makes the sampler actually select)."""
+    from dualmessagepassing_amd.unc import TrainModel
+    from dualmessagepassing_amd.unc_harness import collect_node_embeddings, graph_of, train_unsupervised
+    rng = np.random.default_rng(3)
+    n = 400
+    trip_np = _two_communities(rng, n)
+    hub = np.stack([np.arange(1, 301), np.zeros(300, np.int64), np.zeros(300, np.int64)], 1)   # 300 edges into node 0
+    trip_np = np.unique(np.concatenate([trip_np, hub]), axis=0)
+    graph, trip = graph_of(trip_np, n, 1, gpu)
+    assert int(graph.in_degrees().max()) > 128
+    th.manual_seed(0)
+    model = TrainModel(None, n, 32, 1, 0, num_hidden_layers=2, dropout=0.0, reg_param=0.01).to(gpu)
+    hist = train_unsupervised(model, graph, trip, n_epochs=2, graph_batch_size=500, lr=5e-3, sampler="neighbor", negative_sample=2,
+                              rescale_epochs=False, seed=1)
+    assert len(hist) >= 1 and np.isfinite(hist).all()
+    emb, covered = collect_node_embeddings(model, graph, trip, graph_batch_size=500, sampler="neighbor", negative_sample=2, seed=2)
+    assert emb.shape == (n, 32) and bool(th.isfinite(emb).all())

@@ -113,7 +113,7 @@ def test_random_walk_and_in_edge_sampling_kernels_match_oracle(gpu):
                 assert (a, b) in edges or b == -1
                 assert a != -1 or b == -1
         wanted = rng.random(n) < 0.6
-        for width in (1, 5, 64):
+        for width in (1, 5, 64, 65, 128, 300):   # > 64: the wave-per-node kernel (the reference's default width is 128)
             mask = S.sample_in_edges_device(g, th.from_numpy(wanted).to(gpu), width, seed=seed)
             want = GO.sample_in_edges(dst, n, wanted, width, seed)
             assert np.array_equal(mask.cpu().numpy(), want)
@@ -148,3 +148,26 @@ def test_randomwalk_subgraph_sampler(gpu):
     out = S.generate_sampled_graph_and_labels_unsupervised(g, th.tensor([[1, 0, 50], [299, 2, 7]], device=gpu), 2, 4, 0.8, 2,
                                                            generator=th.Generator(device=gpu).manual_seed(3), sampler="randomwalk")
     assert out[1].shape == (6, 3) and out[2].tolist() == [1, 1, 0, 0, 0, 0] and "norm" in out[0].edata
+
+
+def test_in_edge_sampler_beyond_64_on_hub_nodes(gpu):
+    """widths above 64 (the reference's default sample width is 128, main.py:294) used to be refused.  Hubs with
+    in-degrees above the width exercise the wave-per-node selection: exact against the oracle, tie rule included."""
+    import graph_oracle as GO
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd import unc_sampling as S
+    rng = np.random.default_rng(21)
+    n = 300
+    hubs = np.array([0, 7, 299])
+    dst = np.concatenate([rng.integers(0, n, 2000), np.repeat(hubs, [700, 129, 1025])]).astype(np.int64)
+    rng.shuffle(dst)
+    src = rng.integers(0, n, len(dst)).astype(np.int64)
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    indeg = np.bincount(dst, minlength=n)
+    for seed in (5, 2 ** 33 + 9):
+        for width in (65, 128, 129, 700, 1024):
+            for wanted in (np.ones(n, bool), rng.random(n) < 0.5):
+                mask = S.sample_in_edges_device(g, th.from_numpy(wanted).to(gpu), width, seed=seed).cpu().numpy()
+                want = GO.sample_in_edges(dst, n, wanted, width, seed)
+                assert np.array_equal(mask, want), (seed, width)
+                assert np.array_equal(np.bincount(dst[mask], minlength=n), np.where(wanted, np.minimum(indeg, width), 0))
