@@ -196,7 +196,7 @@ def test_inner_optimizer_state_dict_after_replays(gpu):
             run(g)
     th.cuda.synchronize()
     assert run.replays == 5
-    sd = opt.state_dict()
+    sd = copy.deepcopy(opt.state_dict())                              # load_state_dict keeps same-device tensors by reference
     st = sd["state"][0]
     assert st["step"] == 6 and "dev" not in st and "dev_lr" not in st
     q = p.detach().clone().requires_grad_(True)
@@ -211,7 +211,7 @@ def test_inner_optimizer_state_dict_after_replays(gpu):
     # and back: a capturable optimizer that loads the state rebuilds its device count from it
     r = q.detach().clone().requires_grad_(True)
     cap = FlatAdamW([r], lr=1e-2, weight_decay=1e-2, amsgrad=True, capturable=True)
-    cap.load_state_dict(plain.state_dict())
+    cap.load_state_dict(copy.deepcopy(plain.state_dict()))
     r.grad, q.grad = g.clone(), g.clone()
     cap.step()
     plain.step()

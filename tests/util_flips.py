@@ -28,14 +28,16 @@ def ambiguous_rows(pre, tau=TAU):
     if pre.numel() == 0:
         return th.zeros(pre.shape[0], dtype=th.bool, device=pre.device)
     scale = max(1.0, float(pre.abs().max()))
-    return (pre.abs() <= tau * scale).any(dim=1)
+    # exact zeros are not ambiguous: they are structural (a gated-out row: zero inputs, zero bias), exact in the product
+    # too, and both sides take the same branch at 0 (the negative-side slope)
+    return ((pre.abs() <= tau * scale) & (pre != 0)).any(dim=1)
 
 
 def count_ambiguous(probes, tau=TAU):
     n = 0
     for _, pre in probes:
         if pre.numel():
-            n += int((pre.detach().double().abs() <= tau * max(1.0, float(pre.abs().max()))).sum())
+            n += int(((pre.detach().double().abs() <= tau * max(1.0, float(pre.abs().max()))) & (pre != 0)).sum())
     return n
 
 
