@@ -99,6 +99,8 @@ SIGNATURES = {
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                 c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
+    "dmp_dev_set_exact_fp32": (None, [c_int]),
+    "dmp_dev_get_exact_fp32": (c_int, []),
     "dmp_rel_gemm": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
                              c_int, c_ptr, c_i64, c_ptr]),
     "dmp_rel_atb_blocks": (c_i64, [c_int]),
@@ -175,6 +177,8 @@ def load(build_if_missing=True):
             fn.argtypes = args
         if lib.dmp_abi_version() != ABI_VERSION:
             raise DmpError("libdmp_hip.so ABI %d != binding ABI %d" % (lib.dmp_abi_version(), ABI_VERSION))
+        if os.environ.get("DMP_EXACT_FP32") == "1":   # development switch: f32-input MFMA instead of the bf16x6 products
+            lib.dmp_dev_set_exact_fp32(1)
         _lib = lib
     return _lib
 

@@ -34,6 +34,45 @@ __device__ __forceinline__ void buf_store4(float4 v, rsrc_t r, uint32_t voff, ui
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
 }
+// ---- fp32 products on the bf16 matrix pipe ("bf16x6").  gfx950's f32-input MFMA runs at the f32 vector rate, 1/16 of
+// the bf16 MFMA rate.  An fp32 value is the EXACT sum of three bf16 pieces (8 + 8 + 8 significant bits, round-to-nearest
+// splits: x = hi + mid + lo up to the last piece's rounding, 2^-25 relative); a product a b is the sum of nine piece
+// products, of which the six with piece indices i + j <= 2 carry everything down to 2^-24 of |a b| (the three dropped
+// ones are below 2^-23 together).  Piece products are exact in the MFMA's fp32 accumulation (8 x 8 bits), so six
+// v_mfma_f32_32x32x16_bf16 give an fp32-accurate 32x32x16 block in 6 x 32 cycles instead of 8 x 64 for the f32 form
+// (2.67 x), at ~5.5 VALU instructions per operand element for the split.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));    // 8 bf16 = 4 VGPRs: one MFMA operand fragment
+union Frag8 { bf16x8 v; uint32_t u[4]; };
+struct Split8 { Frag8 hi, mid, lo; };
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {   // (bf16(a), bf16(b)), round to nearest even; a in the low half
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split_pair(float f0, float f1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = cvt_pk_bf16(f0, f1);
+  const float r0 = f0 - __uint_as_float(h << 16), r1 = f1 - __uint_as_float(h & 0xFFFF0000u);   // exact
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);   // exact
+  l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ void split8(const float4 &x, const float4 &y, Split8 &s) {   // 8 consecutive k of one row / column
+  split_pair(x.x, x.y, s.hi.u[0], s.mid.u[0], s.lo.u[0]);
+  split_pair(x.z, x.w, s.hi.u[1], s.mid.u[1], s.lo.u[1]);
+  split_pair(y.x, y.y, s.hi.u[2], s.mid.u[2], s.lo.u[2]);
+  split_pair(y.z, y.w, s.hi.u[3], s.mid.u[3], s.lo.u[3]);
+}
+// acc += A B for a 32x32x16 block given as pieces; the small terms first
+__device__ __forceinline__ f32x16 mfma_x6(const Split8 &a, const Split8 &b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo.v, b.hi.v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi.v, b.lo.v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid.v, b.mid.v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid.v, b.hi.v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi.v, b.mid.v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi.v, b.hi.v, acc, 0, 0, 0);
+  return acc;
+}
+
 // bytes of a tile of `rows` rows with leading dimension ld (floats) of which `cols` are touched
 __device__ __forceinline__ uint32_t tile_bytes(int rows, int64_t ld, int cols) {
   return rows > 0 ? (uint32_t)(((int64_t)(rows - 1) * ld + cols) * 4) : 0u;

@@ -14,6 +14,8 @@
 // panel W_g in registers (rebuilt only when the workgroup's contiguous tile range crosses into the
 // next class), buffer addressing with per-lane offsets, LDS-only barriers, three-deep prefetch
 // (ids of tile k+3, rows of tile k+2, staging of tile k+1 while tile k is computed).
+#include <type_traits>
+
 #include "dmp_mfma_common.h"
 
 namespace dmp {
@@ -50,8 +52,15 @@ template <int H> struct TypedGeom {
   static constexpr int kPerCU = H == 128 ? 3 : 5;         // workgroups per CU the grid is sized for (H = 64: LDS-bound)
 };
 
-template <int EPI, int H>
-__global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArgs p) {
+// X6: the products on the bf16 matrix pipe as six piece products per 16-deep k-group (dmp_mfma_common.h, "bf16x6":
+// fp32-accurate, 2.67 x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32); the weight panel is kept in registers as
+// pieces (96 instead of 64 VGPRs at H = 128: two workgroups per CU instead of three), the streamed operand is split as
+// it is read from LDS.  !X6: exact fp32 MFMA (development / comparison switch, dmp_dev_set_exact_fp32).
+#ifndef DMP_TY_VAR
+#define DMP_TY_VAR 0      // development knobs (scripts/build_dbg.sh): 16 TEPI_DZ pipelined under X6, 32 three waves per SIMD under X6
+#endif
+template <int EPI, int H, bool X6>
+__global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) ? 2 : 3) void mfma_typed(TypedArgs p) {
   constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
   constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
@@ -59,8 +68,13 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
   // base rows, and the extra phase between their request and their use hides them better (measured: +3 % otherwise).
   // TEPI_REL (relation-typed product, rgcn.py:98-123): plain panel W[type of the tile], rows of A gathered through
   // slot_arow, the output row scaled by idxA-as-float[row] (the edge normaliser) -- no epilogue operands.
-  constexpr bool kPipelined = EPI != TEPI_DZ;
-  __shared__ float As[kPipelined ? 2 : 1][kSub * kStride];
+  constexpr bool kPipelined = EPI != TEPI_DZ || X6;   // X6: one code path (the deeper prefetch lives in the pipelined form)
+  // the staged tile: fp32 rows of kStride floats; X6: three bf16 planes (hi | mid | lo pieces, split once by the staging
+  // thread), rows of kStrideD dwords (H bf16 + 8 of padding: 68 dwords at H = 128, = 4 mod 64 as the fp32 stride:
+  // conflict-free ds_read_b128 of 8 consecutive k per lane)
+  constexpr int kStrideD = (H + 8) / 2, kPlane = kSub * kStrideD;
+  constexpr int kTileWords = X6 ? 3 * kPlane : kSub * kStride;
+  __shared__ __attribute__((aligned(16))) float As[kPipelined ? 2 : 1][kTileWords];
   __shared__ float Cs[H / 32][32 * kScrStride];
   __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] byte offsets: tile k's are read
                                                                                      // (epilogue) while tile k+2's are written
@@ -93,8 +107,10 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
   const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));   // past the end: reads 0 (guarded below)
   const rsrc_t rs_slotA = make_rsrc(p.slot_arow, (uint32_t)ntiles * (kSub * 4u));
 
-  // W_g fragments: b[s] = B_g[s + (H/2) h][col]
-  float b[kHalf];
+  // W_g fragments: b[s] = B_g[s + (H/2) h][col]; X6: the same values as bf16 pieces, fragment g = k-steps 8g .. 8g+7
+  constexpr int kGroups = kHalf / 8;
+  float b[X6 ? 1 : kHalf];
+  Split8 B6[X6 ? kGroups : 1];
   const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)((EPI == TEPI_REL ? p.num_panels : 1) * H * p.ldw * 4));
   const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + kHalf * h : (int64_t)kHalf * h * p.ldw + col) * 4u;
   const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.transposed ? 4 : p.ldw * 4));  // bytes from k to k+1
@@ -112,17 +128,31 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
         w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
         if (EPI != TEPI_REL) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
       }
+      if (X6) {
+        float w[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[s0 + j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
+        for (int j = 0; j < 8; ++j) w[j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
+        split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[X6 ? s0 / 8 : 0]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[X6 ? 0 : s0 + j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // ---- three-deep prefetch state
+  // ---- prefetch state.  !X6: three deep (ids of tile k+3, rows of tile k+2 in registers, tile k+1 staged while tile k
+  // is computed).  X6: one tile deeper -- the kernel then runs at two workgroups per CU, and what it sustains is set by
+  // the bytes it keeps in flight, not by its matrix work: rows of tiles k+2 AND k+3 in two register sets (tile t in set
+  // t & 1), ids of tile k+4.
+  constexpr bool kDeep = X6 && (DMP_TY_VAR & 64);          // the deeper row prefetch: measured, no gain (kept as a knob)
+  constexpr int NSET = kDeep ? 2 : 1, kAhead = kDeep ? 3 : 2;
   int id_rows[kSubLoads];       // edge ids of the 4 rows this thread loads (rows gtid/32 + 8m)
   int id_own = -1;              // edge id of row gtid (threads < 32): per-row scalars
-  float4 pre[kSubLoads];
-  uint32_t pre_a = 0, pre_b = 0;
+  float4 pre[NSET][kSubLoads];
+  uint32_t pre_a[NSET] = {}, pre_b[NSET] = {};
+  std::integral_constant<int, 0> set0;
+  std::integral_constant<int, NSET - 1> set1;
   auto load_ids = [&](int k) {                            // ids of tile lo + k (-1 past the end)
     const bool ok = k < mine;
     const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
@@ -131,55 +161,71 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
       id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, ((gtid / kQ) + 8 * m) * 4, (int)so, 0) : -1;
     if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
   };
-  int own_staged = -1;
+  int own_staged[NSET];
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) own_staged[q] = -1;
 #ifdef DMP_TY_DBG
   bool warm = false;
 #endif
-  auto load_row = [&](int m) {
+  auto load_row = [&](auto set, int m) {                    // into register set S
+    constexpr int S = decltype(set)::value;
 #ifdef DMP_TY_DBG
     if ((DMP_TY_DBG & 8) && warm) return;
 #endif
     const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
-    pre[m] = buf_load4(rs_A, off, 0);
+    pre[S][m] = buf_load4(rs_A, off, 0);
   };
-  auto load_row_scalars = [&]() {
+  auto load_row_scalars = [&](auto set) {
+    constexpr int S = decltype(set)::value;
     if (gtid < kSub) {
       const uint32_t eo = id_own >= 0 ? (uint32_t)id_own * 4u : kOOB;
-      pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
-      if (EPI == TEPI_EDGE) pre_b = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, (int)eo, 0, 0);
-      if (EPI == TEPI_DZ) pre_b = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
-      own_staged = id_own;
+      pre_a[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
+      if (EPI == TEPI_EDGE) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, (int)eo, 0, 0);
+      if (EPI == TEPI_DZ) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
+      own_staged[S] = id_own;
     }
   };
-  auto load_rows = [&]() {                                // rows + per-row scalars of the tile whose ids are loaded
+  auto load_rows = [&](auto set) {                          // rows + per-row scalars of the tile whose ids are loaded
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) load_row(m);
-    load_row_scalars();
+    for (int m = 0; m < kSubLoads; ++m) load_row(set, m);
+    load_row_scalars(set);
   };
-  auto stage_row = [&](int buf, int m) {                   // registers -> LDS, one of the thread's four row pieces
-    *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
+  auto stage_row = [&](int buf, auto set, int m) {           // register set S -> LDS, one of the thread's four row pieces
+    constexpr int S = decltype(set)::value;
+    if (X6) {
+      uint2 ph, pm, pl;
+      split_pair(pre[S][m].x, pre[S][m].y, ph.x, pm.x, pl.x);
+      split_pair(pre[S][m].z, pre[S][m].w, ph.y, pm.y, pl.y);
+      uint32_t *q = reinterpret_cast<uint32_t *>(&As[buf][0]) + ((gtid / kQ) + 8 * m) * kStrideD + (gtid % kQ) * 2;
+      *reinterpret_cast<uint2 *>(q) = ph;
+      *reinterpret_cast<uint2 *>(q + kPlane) = pm;
+      *reinterpret_cast<uint2 *>(q + 2 * kPlane) = pl;
+    } else {
+      *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[S][m];
+    }
   };
-  auto stage_scalars = [&](int par) {                      // per-row byte offsets of the staged tile (threads < 32)
+  auto stage_scalars = [&](int par, auto set) {            // per-row byte offsets of the staged tile (threads < 32)
+    constexpr int S = decltype(set)::value;
     if (gtid < kSub) {
-      const bool ok = own_staged >= 0;
+      const bool ok = own_staged[S] >= 0;
       uint32_t a = kOOB, bb = kOOB;
       if (EPI == TEPI_EDGE) {
-        if (ok) { a = pre_a * (uint32_t)(p.ldt * 4); bb = pre_b * (uint32_t)(p.ldt * 4) + kRowBytes; }
+        if (ok) { a = pre_a[S] * (uint32_t)(p.ldt * 4); bb = pre_b[S] * (uint32_t)(p.ldt * 4) + kRowBytes; }
       } else if (EPI == TEPI_REL) {
-        a = p.idxA ? pre_a : __float_as_uint(1.f);        // the row's scale (float bits)
+        a = p.idxA ? pre_a[S] : __float_as_uint(1.f);     // the row's scale (float bits)
       } else {
-        bb = pre_b;                                       // flag
-        if (ok) a = pre_a * (uint32_t)(p.ldt * 4) + (bb ? kRowBytes : 0u);
+        bb = pre_b[S];                                    // flag
+        if (ok) a = pre_a[S] * (uint32_t)(p.ldt * 4) + (bb ? kRowBytes : 0u);
       }
       rowA[par][gtid] = a; rowB[par][gtid] = bb;
-      rowC[par][gtid] = ok ? (uint32_t)own_staged * (uint32_t)(p.ldc * 4) : kOOB;
-      rowR[par][gtid] = (ok && p.R) ? (uint32_t)own_staged * (uint32_t)(p.ldr * 4) : kOOB;
+      rowC[par][gtid] = ok ? (uint32_t)own_staged[S] * (uint32_t)(p.ldc * 4) : kOOB;
+      rowR[par][gtid] = (ok && p.R) ? (uint32_t)own_staged[S] * (uint32_t)(p.ldr * 4) : kOOB;
     }
   };
-  auto stage = [&](int buf, int par) {
+  auto stage = [&](int buf, int par, auto set) {
 #pragma unroll
-    for (int m = 0; m < kSubLoads; ++m) stage_row(buf, m);
-    stage_scalars(par);
+    for (int m = 0; m < kSubLoads; ++m) stage_row(buf, set, m);
+    stage_scalars(par, set);
   };
 
   f32x16 acc;
@@ -194,25 +240,66 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
     if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
     else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
   };
+  // X6: the tile's product on the bf16 pipe.  Per 16-deep k-group g: six MFMAs on the three piece fragments of A (this
+  // lane's 8 consecutive k = kHalf h + 8g .. of row li: one ds_read_b128 per plane, requested one group ahead) and the
+  // panel fragment B6[g]; the caller's 16 actions (requests / staging of the neighbouring tiles) are spread between them.
+  auto x6_tile = [&](const float *tile, auto &&action) {
+    constexpr int kPer = 16 / kGroups;                      // actions per group: 2 (H = 128) or 4 (H = 64)
+    const uint32_t *ar = reinterpret_cast<const uint32_t *>(tile) + li * kStrideD + (kHalf / 2) * h;
+    Frag8 ah, am, al;
+    ah.v = *reinterpret_cast<const bf16x8 *>(ar);
+    am.v = *reinterpret_cast<const bf16x8 *>(ar + kPlane);
+    al.v = *reinterpret_cast<const bf16x8 *>(ar + 2 * kPlane);
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      Frag8 nh = ah, nm = am, nl = al;
+      if (g + 1 < kGroups) {
+        nh.v = *reinterpret_cast<const bf16x8 *>(ar + 4 * (g + 1));
+        nm.v = *reinterpret_cast<const bf16x8 *>(ar + kPlane + 4 * (g + 1));
+        nl.v = *reinterpret_cast<const bf16x8 *>(ar + 2 * kPlane + 4 * (g + 1));
+      }
+      const Split8 &bb = B6[X6 ? g : 0];
+      int done = 0;
+      auto after = [&](int n) {                             // the actions due after the n-th MFMA of the group
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+          if (6 * (q + 1) / kPer == n) { action(kPer * g + q); ++done; }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bb.hi.v, acc, 0, 0, 0); after(1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.lo.v, acc, 0, 0, 0); after(2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.mid.v, acc, 0, 0, 0); after(3);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.hi.v, acc, 0, 0, 0); after(4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.mid.v, acc, 0, 0, 0); after(5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.hi.v, acc, 0, 0, 0); after(6);
+      (void)done;
+      ah = nh; am = nm; al = nl;
+    }
+  };
   // The MFMA phase, with the epilogue operand requests of the same tile in its shadow: two of the eight loads
   // (and the LDS reads of their row offsets) after each of the first four MFMA groups.
   auto compute = [&](int par) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #ifdef DMP_TY_DBG
-    if (DMP_TY_DBG & 1) { fetch_operands(par); return; }
+    if (DMP_TY_DBG & 1) { for (int k = 0; k < 4; ++k) fetch_operand(par, k); return; }
 #endif
     const float *arow = &As[0][li * kStride + kHalf * h];
+    if (X6) {
+      x6_tile(&As[0][0], [&](int i) { if (i < 4) fetch_operand(par, i); });
+      return;
+    }
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
     for (int s4 = 0; s4 < kSteps4; ++s4) {
       float4 an = a4;
       if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * s4 + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * s4 + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * s4 + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[X6 ? 0 : 4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[X6 ? 0 : 4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[X6 ? 0 : 4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[X6 ? 0 : 4 * s4 + 3], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (s4 < 4) fetch_operand(par, s4);
       a4 = an;
@@ -222,19 +309,25 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
   // requests (groups 0-3), the staging of tile k+1 into the other buffer (groups 4-8), the row requests of tile
   // k+2 (groups 9-13) and the id requests of tile k+3 (group 14).  par3 = k % 3 indexes the per-row offset arrays.
   // H = 64 has 8 MFMA groups: two of these 15 actions after each.
-  auto shadow = [&](int i, int k, int par3, int buf, int nxt3) {
-    if (i < 4) fetch_operand(par3, i);
-    else if (i < 8) stage_row(buf ^ 1, i - 4);
-    else if (i == 8) stage_scalars(nxt3);
-    else if (i < 13) load_row(i - 9);
-    else if (i == 13) load_row_scalars();
-    else if (i == 14) load_ids(k + 3);
+  // `nset`: the register set of tile k+1 (X6: (k + 1) & 1, a compile-time phase; else 0) -- staged now, then refilled
+  // with the rows of tile k + kAhead
+  auto shadow = [&](int i, int k, int par3, int buf, int nxt3, auto nset) {
+    if (i < 4) { if (!X6) fetch_operand(par3, i); }       // X6: requested by the previous tile's epilogue (below)
+    else if (i < 8) stage_row(buf ^ 1, nset, i - 4);
+    else if (i == 8) stage_scalars(nxt3, nset);
+    else if (i < 13) load_row(nset, i - 9);
+    else if (i == 13) load_row_scalars(nset);
+    else if (i == 14) load_ids(k + kAhead + 1);
   };
-  auto tile_step = [&](int k, int par3) {
+  auto tile_step = [&](int k, int par3, auto nset) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
     const float *arow = &As[buf][li * kStride + kHalf * h];
+    if (X6) {
+      x6_tile(&As[buf][0], [&](int i) { shadow(i, k, par3, buf, nxt3, nset); });
+      return;
+    }
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
     for (int s4 = 0; s4 < kSteps4; ++s4) {
@@ -244,16 +337,16 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
 #ifdef DMP_TY_DBG
       if (!(DMP_TY_DBG & 1)) {
 #endif
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * s4 + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * s4 + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * s4 + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * s4 + 3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[X6 ? 0 : 4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[X6 ? 0 : 4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[X6 ? 0 : 4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[X6 ? 0 : 4 * s4 + 3], acc, 0, 0, 0);
 #ifdef DMP_TY_DBG
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      if (kSteps4 == 16) shadow(s4, k, par3, buf, nxt3);
-      else { shadow(2 * s4, k, par3, buf, nxt3); shadow(2 * s4 + 1, k, par3, buf, nxt3); }
+      if (kSteps4 == 16) shadow(s4, k, par3, buf, nxt3, nset);
+      else { shadow(2 * s4, k, par3, buf, nxt3, nset); shadow(2 * s4 + 1, k, par3, buf, nxt3, nset); }
       a4 = an;
     }
   };
@@ -281,17 +374,37 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
       if ((DMP_TY_DBG & 4) && v.x != 123.456f) continue;
 #endif
       buf_store4(v, rs_C, rowC[par][rr] + col4, 0);       // padding rows: offset out of range, dropped
+      // X6: this chunk's operand registers are free -- request the NEXT tile's rows into them now (its row offsets were
+      // staged during this tile's MFMA phase, before the barrier).  With the short bf16 MFMA phase, operands requested at
+      // the start of their own tile's phase (the f32 form) arrive after the epilogue wants them: this way they have a
+      // whole iteration.  Past the last tile the offsets are out of range: the loads return zeros.
+      if (X6) fetch_operand(par == 2 ? 0 : par + 1, k);
     }
   };
 
   if (mine == 0) return;
-  load_ids(0);
-  load_rows();                 // tile 0
-  load_ids(1);
-  stage(0, 0);
-  load_rows();                 // tile 1
-  load_ids(2);
+  if (kDeep) {
+    load_ids(0);
+    load_rows(set0);           // tile 0 -> set 0
+    load_ids(1);
+    load_rows(set1);           // tile 1 -> set 1
+    load_ids(2);
+    stage(0, 0, set0);         // waits for tile 0's rows only (the counter is in order)
+    load_rows(set0);           // tile 2 -> set 0
+    load_ids(3);
+  } else {
+    load_ids(0);
+    load_rows(set0);           // tile 0
+    load_ids(1);
+    stage(0, 0, set0);
+    load_rows(set0);           // tile 1
+    load_ids(2);
+  }
   lds_barrier();
+  if (X6) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fetch_operand(0, c);        // tile 0's epilogue operands (later tiles: by the epilogue before)
+  }
   // The class structure of the range is read 64 tiles at a time: lane l keeps the coefficient of tile 64c + l,
   // bit l of `starts` says "tile 64c + l begins a new class".  The hot loop then tests a scalar bit -- a
   // per-tile coefficient load in its condition was a vector load the loop had to wait for with vmcnt(0),
@@ -320,13 +433,14 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 3) void mfma_typed(TypedArg
 #endif
     do {
       if (kPipelined) {
-        tile_step(k, par3);
+        if (kDeep && (k & 1) == 0) tile_step(k, par3, set1);   // tile k+1 sits in set (k + 1) & 1
+        else tile_step(k, par3, set0);
         lds_barrier();           // tile k+1 is staged for everyone, everyone is done with tile k's rows
       } else {
         compute(par3);
         lds_barrier();           // every wave is done reading this tile's rows
-        stage(0, par3 == 2 ? 0 : par3 + 1);   // tile k+1 (rows were requested one iteration ago)
-        load_rows();             // tile k+2 (ids were requested one iteration ago)
+        stage(0, par3 == 2 ? 0 : par3 + 1, set0);   // tile k+1 (rows were requested one iteration ago)
+        load_rows(set0);         // tile k+2 (ids were requested one iteration ago)
         load_ids(k + 3);
         lds_barrier();           // tile k+1 is in LDS for everyone
       }
@@ -343,12 +457,25 @@ inline unsigned typed_blocks(int64_t tiles_bound, int per_cu = 3) {
 }
 inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
 
+int g_exact_fp32 = 0;   // development switch: 1 = the f32-input MFMA (exact fp32) instead of the bf16x6 products
+
+template <int EPI, int H>
+inline void launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st) {
+  if (g_exact_fp32)
+    mfma_typed<EPI, H, false><<<typed_blocks(tiles_bound, H == 128 ? 3 : TypedGeom<64>::kPerCU), TypedGeom<H>::kThreads, 0, st>>>(p);
+  else
+    mfma_typed<EPI, H, true><<<typed_blocks(tiles_bound, H == 128 ? ((DMP_TY_VAR & 32) ? 3 : 2) : 4), TypedGeom<H>::kThreads, 0, st>>>(p);
+}
+
 }  // namespace
 }  // namespace dmp
 
 using namespace dmp;
 
 extern "C" {
+
+void dmp_dev_set_exact_fp32(int on) { g_exact_fp32 = on ? 1 : 0; }
+int dmp_dev_get_exact_fp32(void) { return g_exact_fp32; }
 
 int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp,
                        int64_t num_nodes, const float *bias, const int32_t *selA, const int32_t *selB,
@@ -368,8 +495,8 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias; p.slope = slope;
-  if (H == 128) mfma_typed<TEPI_EDGE, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
-  else mfma_typed<TEPI_EDGE, 64><<<typed_blocks(tiles_bound, TypedGeom<64>::kPerCU), TypedGeom<64>::kThreads, 0, (hipStream_t)stream>>>(p);
+  if (H == 128) launch_typed<TEPI_EDGE, 128>(p, tiles_bound, (hipStream_t)stream);
+  else launch_typed<TEPI_EDGE, 64>(p, tiles_bound, (hipStream_t)stream);
   return check_launch();
 }
 
@@ -393,8 +520,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : H;
   p.s0 = s0; p.s1 = s1;
-  if (H == 128) mfma_typed<TEPI_DZ, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
-  else mfma_typed<TEPI_DZ, 64><<<typed_blocks(tiles_bound, TypedGeom<64>::kPerCU), TypedGeom<64>::kThreads, 0, (hipStream_t)stream>>>(p);
+  if (H == 128) launch_typed<TEPI_DZ, 128>(p, tiles_bound, (hipStream_t)stream);
+  else launch_typed<TEPI_DZ, 64>(p, tiles_bound, (hipStream_t)stream);
   return check_launch();
 }
 
@@ -412,7 +539,7 @@ int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, in
   p.C = C; p.ldc = ldc; p.E = rows_c; p.slot_edge = slot_row; p.slot_arow = slot_arow;
   p.tile_scale = reinterpret_cast<const float *>(tile_type); p.num_tiles = num_tiles;
   p.idxA = reinterpret_cast<const int32_t *>(row_scale);
-  mfma_typed<TEPI_REL, 128><<<typed_blocks(tiles_bound), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
+  launch_typed<TEPI_REL, 128>(p, tiles_bound, (hipStream_t)stream);
   return check_launch();
 }
 

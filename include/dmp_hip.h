@@ -871,6 +871,14 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
  * held half an iteration apart by barriers).  Process-wide; results are identical. */
 void dmp_dev_set_mfma_variant(int variant);
 
+/* Arithmetic of the class-typed kernels' products (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_rel_gemm).  Default (0):
+ * fp32 operands split into three bf16 pieces each, six piece products per 16-deep k-group on the bf16 matrix pipe,
+ * fp32 accumulation ("bf16x6": every partial product carried to 2^-24 of its magnitude, i.e. fp32-accurate; gfx950's
+ * f32-input MFMA has 1/16 of the bf16 MFMA rate).  1: the f32-input MFMA (bitwise an fmaf chain), kept for comparison
+ * and as the reference point of the parity tests.  Process-wide development switch. */
+void dmp_dev_set_exact_fp32(int on);
+int dmp_dev_get_exact_fp32(void);
+
 /* Plain C[E, ncols] = A[E,128] B (ncols = 128 or 256; B[k*ldb+j], or B[j*ldb+k] if b_transposed):
  * the bare pipeline of the two kernels above, kept for tests and tuning. */
 int dmp_gemm_k128(const float *A, int64_t lda, const float *B, int64_t ldb, int b_transposed,

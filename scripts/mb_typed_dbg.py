@@ -37,10 +37,15 @@ def timeit(f, n=20):
     for i in range(n): f(i)
     b.record(); th.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-for path in sorted(glob.glob(os.path.join(ROOT, "scripts", "_dbg", "libty_*.so")), key=lambda s: int(s.split("_")[-1][:-3])):
+paths = sorted(glob.glob(os.path.join(ROOT, "scripts", "_dbg", "libty_*.so")), key=lambda s: int(s.split("_")[-1][:-3]))
+paths = [os.path.join(ROOT, "dualmessagepassing_amd", "csrc", "libdmp_hip.so")] * 2 + paths      # the product library: bf16x6, then exact fp32
+for n_path, path in enumerate(paths):
     lib = ctypes.CDLL(path)
+    if hasattr(lib, "dmp_dev_set_exact_fp32"):
+        lib.dmp_dev_set_exact_fp32(1 if n_path == 1 else 0)
+        print("exact_fp32 =", lib.dmp_dev_get_exact_fp32())
     lib.dmp_edge_fwd_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, I, F, P, I64, P]
-    lib.dmp_bwd_z_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, F, F, P, P, P, I64, I64, I, P, I64, P]
+    lib.dmp_bwd_z_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, F, F, P, P, P, I64, I64, I, I, P, I64, P]
     def fwd(i):
         rc = lib.dmp_edge_fwd_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, xp[:, h:].data_ptr(), 3 * h, n, bias.data_ptr(),
                                     selA.data_ptr(), selB.data_ptr(), se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h,
@@ -48,7 +53,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "scripts", "_dbg", "libty_*.so")
         assert rc == 0, rc
     def bwd(i):
         rc = lib.dmp_bwd_z_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, dsn.data_ptr(), 2 * h, n, base[i % 3].data_ptr(), h,
-                                 ix.dst32.data_ptr(), ix.rev8.data_ptr(), -1.0, 1.0, se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h,
+                                 ix.dst32.data_ptr(), ix.rev8.data_ptr(), -1.0, 1.0, se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h, 0,
                                  out.data_ptr(), h, st)
         assert rc == 0, rc
     print("%-14s edge_fwd %7.1f us   bwd_z %7.1f us" % (os.path.basename(path), timeit(fwd), timeit(bwd)), flush=True)
