@@ -99,6 +99,8 @@ SIGNATURES = {
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                 c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
+    "dmp_gemm_x6": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_f32,
+                            c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_dev_set_exact_fp32": (None, [c_int]),
     "dmp_dev_get_exact_fp32": (c_int, []),
     "dmp_rel_gemm": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,

@@ -178,6 +178,33 @@ def atb(a, b):
     return reduce_partials(part.view(S + tail, -1)).view(a.size(1), b.size(1))
 
 
+USE_GEMM_X6 = True   # node-side row-block products on the bf16 matrix pipe (csrc/dmp_gemm6.hip) instead of library fp32 GEMMs
+
+
+def gemm_x6_ok(*mats):
+    """``gemm_x6`` takes these fp32 operands (row-major, 16-byte aligned rows)."""
+    return USE_GEMM_X6 and all(m is None or (m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.stride(1) == 1
+                                            and m.stride(0) % 4 == 0 and m.data_ptr() % 16 == 0) for m in mats)
+
+
+def gemm_x6(a1, B, a2=None, transB=False, bias=None, add=None, rowscale=None, slope=None, out=None):
+    """``epi([a1 | a2] @ B)`` (``B`` [K, N]; ``transB``: ``B`` is given as [N, K]) on the bf16 matrix pipe, fp32-accurate
+    (``dmp_gemm_x6``).  ``epi(P) = act(P + bias + add)``, or with ``rowscale``: ``add + rowscale * act(P + bias)``;
+    ``slope`` None: no activation, else LeakyReLU(slope) (0.0 = ReLU).  K's parts multiples of 16, N a multiple of 64."""
+    lib = _lib.load()
+    R, K1 = a1.shape
+    K2 = a2.size(1) if a2 is not None else 0
+    N = B.size(0) if transB else B.size(1)
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=a1.device)
+    with _lib.timed("gemm_x6[K=%d,N=%d,R=%d]", (K1 + K2, N, R), 4 * R * (K1 + K2 + N * (2 if add is not None else 1))):
+        check(lib.dmp_gemm_x6(ptr(a1), a1.stride(0), K1, ptr(a2), a2.stride(0) if a2 is not None else 0, K2, ptr(B), B.stride(0),
+                              int(transB), ptr(bias), ptr(add), add.stride(0) if add is not None else 0, ptr(rowscale),
+                              int(slope is not None), float(slope or 0.0), ptr(out), out.stride(0), R, N, stream_ptr()),
+              "dmp_gemm_x6")
+    return out
+
+
 def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False, slope=0.0):
     lib = _lib.load()
     E = index.num_edges

@@ -871,6 +871,21 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
  * held half an iteration apart by barriers).  Process-wide; results are identical. */
 void dmp_dev_set_mfma_variant(int variant);
 
+/*
+ * Node-side row-block products on the bf16 matrix pipe ("bf16x6": fp32 operands as three bf16 pieces, six piece products
+ * per 16-deep k-group, fp32 accumulation -- fp32-accurate; csrc/dmp_gemm6.hip).  Replaces the library fp32 GEMMs
+ * (f32-input MFMA: 1/16 of the bf16 rate) of the DMPLayer's node side: x @ [W_nl' | W_dst' | W_src'], [S | x] @ [B_n; W_nl']
+ * with the bias / activation epilogue (dmpnn.py:113,121,129-140), dP_n @ B_n^T, dx = dx_n + dXP @ W_x^T.
+ *   C[R, N] = epi([A1 | A2] B),  A1 [R, K1], A2 [R, K2] or NULL (K1, K2 multiples of 16), N a multiple of 64,
+ *   B[k][n] = B[k * ldb + n] (transB = 0) or B[n * ldb + k] (transB = 1).
+ *   epi(P) = act(P + bias + Cadd)                       rowscale == NULL   (act = 0: identity; else LeakyReLU(slope), 0 = ReLU)
+ *          = Cadd + rowscale[r] * act(P + bias)         rowscale != NULL   (Linear + gate + residual)
+ * bias [N], Cadd [R, N] (ld ldadd), rowscale [R]: each may be NULL.  C may alias Cadd.
+ */
+int dmp_gemm_x6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2, const float *B, int64_t ldb,
+                int transB, const float *bias, const float *Cadd, int64_t ldadd, const float *rowscale, int act, float slope,
+                float *C, int64_t ldc, int64_t R, int N, void *stream);
+
 /* Arithmetic of the class-typed kernels' products (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_rel_gemm).  Default (0):
  * fp32 operands split into three bf16 pieces each, six piece products per 16-deep k-group on the bf16 matrix pipe,
  * fp32 accumulation ("bf16x6": every partial product carried to 2^-24 of its magnitude, i.e. fp32-accurate; gfx950's
