@@ -748,11 +748,24 @@ class GraphAdjModelV2(BaseModel):
         g_enc = self.get_graph_enc(graph)
         g_v_emb, g_e_emb = self.get_graph_emb(g_enc)
         joint = None
+        pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         if hasattr(self, "get_joint_rep"):
-            joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
+            # heads that pool over the un-augmented representations: the last layer pools its own outputs (and its backward
+            # then never builds the [E, H] gradient of the edge representation, fused._FusedDMPLayer)
+            pools = None
+            if pooled and not self.pred_with_enc and not self.pred_with_deg and (self.node_pred or self.edge_pred):
+                pools = (_pool_index_union(pattern, graph, "node") if self.node_pred else None,
+                         _pool_index_union(pattern, graph, "edge", skip_rev) if self.edge_pred else None)
+            try:
+                joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate, pools=pools)
+            except TypeError:       # a rep-net without the pooled form
+                joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
         v_union = e_union = None
+        union_sums = (None, None)
         if joint is not None:
-            p_v_rep, p_e_rep, g_v_rep, g_e_rep, v_union, e_union = joint
+            p_v_rep, p_e_rep, g_v_rep, g_e_rep, v_union, e_union = joint[:6]
+            if len(joint) > 6:
+                union_sums = joint[6]
         else:
             p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
             g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=vl_gate, e_gate=el_gate)
@@ -765,7 +778,6 @@ class GraphAdjModelV2(BaseModel):
 
         # pool-then-project (pred.py heads that sum/average rows): per-graph sums straight from the
         # un-padded representations with the segment-sum kernel; otherwise the reference's padded path
-        pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         p_v_output = g_v_output = p_e_output = g_e_output = None
         v_sums = e_sums = None      # [2B, H] pooled rows of the union pass (pattern graphs, then target graphs)
         if self.node_pred:
@@ -783,7 +795,8 @@ class GraphAdjModelV2(BaseModel):
             if pooled and v_union is not None and not p_add:
                 # the shared rep-net ran over the union of both batches: pool the union rows once
                 # (its backward is the union gradient itself, no concatenation of two halves)
-                sums = v_sums = ops.seg_pool(v_union, _pool_index_union(pattern, graph, "node"))
+                sums = v_sums = (union_sums[0] if union_sums[0] is not None
+                                 else ops.seg_pool(v_union, _pool_index_union(pattern, graph, "node")))
                 p_v_output, g_v_output = sums[:bsz], sums[bsz:]
             elif pooled:
                 p_v_output = ops.seg_pool(p_v_output, _pool_index(pattern, "node"))
@@ -806,7 +819,8 @@ class GraphAdjModelV2(BaseModel):
             p_e_mask = self.refine_edge_weights(p_e_mask)
             g_e_mask = self.refine_edge_weights(g_e_mask)
             if pooled and e_union is not None and not p_add:
-                sums = e_sums = ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge", skip_rev))[:, :e_union.size(1)]
+                sums = e_sums = (union_sums[1] if union_sums[1] is not None
+                                 else ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge", skip_rev)))[:, :e_union.size(1)]
                 p_e_output, g_e_output = sums[:bsz], sums[bsz:]
             elif pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
                 d = p_e_output.size(1)

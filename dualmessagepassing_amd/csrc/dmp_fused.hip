@@ -29,7 +29,7 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 __device__ __forceinline__ float4 mul4(const float4 &a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
 enum { OP_GATE_RES = 0, OP_SCALE_CS = 1, OP_RELU_BWD_CS = 2, OP_BWD_G_CS = 3, OP_COLSUM = 4, OP_RELU_BWD_G_CS = 5,
-       OP_ADD_BIAS_RELU = 6 };
+       OP_ADD_BIAS_RELU = 6, OP_RELU_BWD_GATHER_CS = 7 };
 
 struct RowArgs {
   const float *a; int64_t lda;   // first input  (prev | dOut | dH  | dY | A)
@@ -61,9 +61,18 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
         if (OP == OP_GATE_RES || OP == OP_SCALE_CS) ms = p.rowscale ? p.rowscale[r0 + lane] : 1.f;
         if (OP == OP_BWD_G_CS || OP == OP_RELU_BWD_G_CS) ms = p.rowscale[p.dst[r0 + lane]];
       }
+      int mi = -1;                                   // OP_RELU_BWD_GATHER_CS: the table row of this row's upstream gradient
+      if (OP == OP_RELU_BWD_GATHER_CS && lane < kU && r0 + lane < p.R) {
+        ms = p.rowscale ? p.rowscale[r0 + lane] : 1.f;
+        mi = p.dst[r0 + lane];
+      }
       float sc[kU];
+      int tr[kU];
 #pragma unroll
-      for (int k = 0; k < kU; ++k) sc[k] = __shfl(ms, k, G);
+      for (int k = 0; k < kU; ++k) {
+        sc[k] = __shfl(ms, k, G);
+        tr[k] = OP == OP_RELU_BWD_GATHER_CS ? __shfl(mi, k, G) : 0;
+      }
       if (!act) continue;
       float4 x[kU], y[kU];
 #pragma unroll
@@ -72,6 +81,9 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
         if (r < p.R) {
           if (OP == OP_GATE_RES) {
             x[k] = p.a ? ld4(p.a + r * p.lda + c) : zero4();
+            y[k] = ld4(p.b + r * p.ldb + c);
+          } else if (OP == OP_RELU_BWD_GATHER_CS) {     // upstream row = rowscale[r] * table[map[r]] (map < 0: zero)
+            x[k] = tr[k] >= 0 ? mul4(ld4(p.a + (int64_t)tr[k] * p.lda + c), sc[k]) : zero4();
             y[k] = ld4(p.b + r * p.ldb + c);
           } else if (OP == OP_RELU_BWD_CS || OP == OP_RELU_BWD_G_CS || OP == OP_ADD_BIAS_RELU) {
             x[k] = ld4(p.a + r * p.lda + c);
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void rowop_kernel(RowArgs p) {
           float4 t = p.rowscale ? mul4(x[k], sc[k]) : x[k];
           if (p.out) st4(p.out + r * p.ldo + c, t);
           add4(cs, t);
-        } else if (OP == OP_RELU_BWD_CS) {
+        } else if (OP == OP_RELU_BWD_CS || OP == OP_RELU_BWD_GATHER_CS) {
           float4 t = make_float4(act_bwd(y[k].x, x[k].x, p.slope), act_bwd(y[k].y, x[k].y, p.slope),
                                  act_bwd(y[k].z, x[k].z, p.slope), act_bwd(y[k].w, x[k].w, p.slope));
           st4(p.out + r * p.ldo + c, t);
@@ -531,6 +543,17 @@ int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t 
   if (!vec_shape_ok(H, ldh, lda, ldp) || !ok16(dH) || !ok16(act) || !ok16(dPre) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   RowArgs p{dH, ldh, act, lda, nullptr, nullptr, dPre, ldp, partial, R, H, slope};
   return launch_rowop<OP_RELU_BWD_CS>(p, (hipStream_t)stream);
+}
+
+int dmp_relu_bwd_gathered_colsum(const float *table, int64_t ldt, const int32_t *rowmap, const float *gate, const float *act,
+                                 int64_t lda, int64_t R, int H, float slope, float *dPre, int64_t ldp, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && H > 0 && partial);
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(table && rowmap && act && dPre && ldt >= H && lda >= H && ldp >= H);
+  if (!vec_shape_ok(H, ldt, lda, ldp) || !ok16(table) || !ok16(act) || !ok16(dPre) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
+  RowArgs p{table, ldt, act, lda, gate, rowmap, dPre, ldp, partial, R, H, slope};
+  return launch_rowop<OP_RELU_BWD_GATHER_CS>(p, (hipStream_t)stream);
 }
 
 int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef, const int32_t *dst,

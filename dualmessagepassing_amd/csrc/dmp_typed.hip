@@ -41,6 +41,7 @@ struct TypedArgs {
   const float *T; int64_t ldt; int64_t num_nodes;   // gathered table P / D [N, >= 256]
   const float *bias;                    // TEPI_EDGE: [128] or NULL
   const float *R; int64_t ldr;          // TEPI_DZ: upstream gradient rows [E,128] or NULL
+  const int32_t *rmap; int64_t rowsR;   // TEPI_DZ: R is a [rowsR, ldr] table, row rmap[e] (< 0: zero) for edge e; NULL: row e
   float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
   float slope;                          // TEPI_EDGE: negative slope of the activation (0 = ReLU)
 };
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
   const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.rowsA * p.lda * 4));   // all < 4 GiB: checked by the host
   const rsrc_t rs_C = make_rsrc(p.C, (uint32_t)(p.E * p.ldc * 4));
-  const rsrc_t rs_R = make_rsrc(p.R, p.R ? (uint32_t)(p.E * p.ldr * 4) : 0u);
+  const rsrc_t rs_R = make_rsrc(p.R, p.R ? (uint32_t)((p.rmap ? p.rowsR : p.E) * p.ldr * 4) : 0u);
+  const rsrc_t rs_rmap = make_rsrc(p.rmap, p.rmap ? rows4 : 0u);
   const rsrc_t rs_T = make_rsrc(p.T, (uint32_t)(p.num_nodes * p.ldt * 4));
   const rsrc_t rs_idxA = make_rsrc(p.idxA, p.idxA ? rows4 : 0u);
   const rsrc_t rs_idxB = make_rsrc(p.idxB, p.idxB ? rows4 : 0u);
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   int id_own = -1;              // edge id of row gtid (threads < 32): per-row scalars
   float4 pre[NSET][kSubLoads];
   uint32_t pre_a[NSET] = {}, pre_b[NSET] = {};
+  int pre_r[NSET] = {};              // TEPI_DZ: row of R for this thread's row (threads < 32)
   std::integral_constant<int, 0> set0;
   std::integral_constant<int, NSET - 1> set1;
   auto load_ids = [&](int k) {                            // ids of tile lo + k (-1 past the end)
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
       pre_a[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
       if (EPI == TEPI_EDGE) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, (int)eo, 0, 0);
       if (EPI == TEPI_DZ) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
+      if (EPI == TEPI_DZ) pre_r[S] = p.rmap ? (id_own >= 0 ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rmap, (int)eo, 0, 0) : -1) : id_own;
       own_staged[S] = id_own;
     }
   };
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
       }
       rowA[par][gtid] = a; rowB[par][gtid] = bb;
       rowC[par][gtid] = ok ? (uint32_t)own_staged[S] * (uint32_t)(p.ldc * 4) : kOOB;
-      rowR[par][gtid] = (ok && p.R) ? (uint32_t)own_staged[S] * (uint32_t)(p.ldr * 4) : kOOB;
+      rowR[par][gtid] = (ok && p.R && (EPI != TEPI_DZ || pre_r[S] >= 0)) ? (uint32_t)(EPI == TEPI_DZ ? pre_r[S] : own_staged[S]) * (uint32_t)(p.ldr * 4) : kOOB;
     }
   };
   auto stage = [&](int buf, int par, auto set) {
@@ -503,7 +507,8 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
                     int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
                     float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t E, int H, int w_transposed, float *dZ, int64_t ldz, void *stream) {
+                    int64_t tiles_bound, int64_t E, int H, int w_transposed, const int32_t *base_map, int64_t base_rows,
+                    float *dZ, int64_t ldz, void *stream) {
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0 || num_nodes < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
@@ -513,13 +518,14 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   if (ldp % 4 || ldz % 4 || ldd % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(dZ) || !aligned16(D) ||
       (base && !aligned16(base)))
     return DMP_ERR_UNSUPPORTED;
-  if (!fits32(num_nodes, ldd) || !fits32(E, ldp) || !fits32(E, ldz) || (base && !fits32(E, ldb)) || !fits32(tiles_bound * kSub, 1))
+  if (base_map && (!base || base_rows < 0)) return DMP_ERR_BAD_ARG;
+  if (!fits32(num_nodes, ldd) || !fits32(E, ldp) || !fits32(E, ldz) || (base && !fits32(base_map ? base_rows : E, ldb)) || !fits32(tiles_bound * kSub, 1))
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : H;
-  p.s0 = s0; p.s1 = s1;
+  p.s0 = s0; p.s1 = s1; p.rmap = base_map; p.rowsR = base_rows;
   if (H == 128) launch_typed<TEPI_DZ, 128>(p, tiles_bound, (hipStream_t)stream);
   else launch_typed<TEPI_DZ, 64>(p, tiles_bound, (hipStream_t)stream);
   return check_launch();

@@ -192,7 +192,7 @@ class DMPLayer(nn.Module):
         return True
 
     @on_input_device
-    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None):
+    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
@@ -206,7 +206,7 @@ class DMPLayer(nn.Module):
         coef = ix.degree_coef(g.ndata[OUTDEGREE])
         vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
         eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
-        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded)
+        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded, pools)
         leave_detached(g.ndata, NODEFEAT)
         leave_detached(g.edata, EDGEFEAT)
         return out
@@ -226,8 +226,8 @@ class DMPNNRepMixin:
 
     rep_key = "dmpnn"
 
-    def get_joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
-        return joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate)
+    def get_joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None, pools=None):
+        return joint_rep(self, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate, pools)
 
     def _make_layer(self, **kw):
         return DMPLayer(self.hid_dim, self.hid_dim, init_neigenv=kw.get("init_neigenv", 4.0), init_eeigenv=kw.get("init_eeigenv", 4.0),
@@ -321,7 +321,7 @@ def prepare_joint(pattern, graph, hidden_dim=128, backward=True):
     return union
 
 
-def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None):
+def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None, pools=None):
     """``get_pattern_rep`` + ``get_graph_rep`` (dmpnn.py:215-277) in ONE pass over the union of
     the two batched graphs, when the rep-net is shared (``share_rep_net``, dmpnn.py:186-188) and
     every layer is eligible for the fused path.  Pattern rows get gate 1 (the pattern side has no
@@ -353,11 +353,18 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         return None
     from . import fused
     folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch
-    for layer, fw in zip(layers, folded):
-        v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw)
+    sums = (None, None)
+    for i, (layer, fw) in enumerate(zip(layers, folded)):
+        if pools is not None and i == len(layers) - 1:
+            # the last layer also pools its outputs per graph (``pools``: PoolIndex over the union's node / edge rows): a
+            # gradient that comes back only through the edge sums never becomes an [E, H] tensor (fused._FusedDMPLayer)
+            v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
+            sums = (vs, es)
+        else:
+            v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw)
     p_v, g_v = _SplitRows.apply(v, np_)
     p_e, g_e = _SplitRows.apply(e, ep_)
-    return p_v, p_e, g_v, g_e, v, e
+    return p_v, p_e, g_v, g_e, v, e, sums
 
 
 class _GateConcat(th.autograd.Function):

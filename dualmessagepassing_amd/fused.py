@@ -142,6 +142,36 @@ def relu_bwd_colsum_(d_h, act, out=None, slope=0.0):
     return dst, reduce_partials(part)
 
 
+def relu_bwd_gathered_colsum(table, rowmap, gate, act, slope=0.0):
+    """``dPre[r] = act[r] > 0 ? u : slope * u`` with ``u = gate[r] * table[rowmap[r]]`` (a zero row where ``rowmap[r] < 0``), and
+    the column sums of dPre: the activation backward of a layer whose upstream gradient is one [H] vector per graph."""
+    lib = _lib.load()
+    R, H = act.shape
+    part = _partials(R, H, act.device)
+    out = torch.empty((R, H), dtype=torch.float32, device=act.device)
+    with _lib.timed("relu_bwd_gathered[H=%d,R=%d]", (H, R), 8 * H * R + 8 * R + 4 * H * table.size(0)):
+        check(lib.dmp_relu_bwd_gathered_colsum(ptr(table), table.stride(0), ptr(rowmap), ptr(gate), ptr(act), act.stride(0), R, H,
+                                               slope, ptr(out), H, ptr(part), stream_ptr()), "dmp_relu_bwd_gathered_colsum")
+    return out, reduce_partials(part)
+
+
+def pool_rows(x, pool, weight=None):
+    """Per-graph sums of the rows of ``x`` over ``pool`` (``ops.PoolIndex``): [G, H], or [G, 2H] = [non-flagged | flagged] when
+    the index carries a flag; ``weight`` [rows]: a row scale.  Raw (no autograd): two launches of the segment-sum kernel."""
+    split = pool.flag8 is not None
+    part = ops.seg_sum_raw(x, pool.vptr, pool.vent, pool.num_chunks, weight, split, 1.0, 1.0, rows_shared=False)
+    return ops.seg_sum_raw(part, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
+
+
+def pool_rowmap(pool):
+    """int32 [rows]: the graph of every row, -1 for flagged rows (they are masked out of the pooled sum)."""
+    m = getattr(pool, "_rowmap", None)
+    if m is None:
+        m = pool.seg32 if pool.flag8 is None else torch.where(pool.flag8 != 0, torch.full_like(pool.seg32, -1), pool.seg32)
+        pool._rowmap = m
+    return m
+
+
 def bwd_g_colsum(d_y, coef, dst32):
     lib = _lib.load()
     E, H = d_y.shape
@@ -280,9 +310,10 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
     return out
 
 
-def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None):
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
-    ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch)."""
+    ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
+    ``base_map`` (int32 [E]): ``base`` is a small table and edge e adds its row ``base_map[e]`` (< 0: nothing)."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
     out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
@@ -294,8 +325,9 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None):
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
-                                  ptr(base), H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0, ptr(slot_edge),
-                                  ptr(tile_scale), ptr(num_tiles), bound, E, H, 1, ptr(out), H, stream_ptr()),
+                                  ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
+                                  ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1, ptr(base_map),
+                                  base.size(0) if base_map is not None else 0, ptr(out), H, stream_ptr()),
               "dmp_bwd_z_typed")
     return out
 
@@ -603,7 +635,11 @@ class _FusedDMPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
-                WesT=None, nW2t=None, eW2t=None, slope=0.0):
+                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None):
+        """``vpool`` / ``epool`` (``ops.PoolIndex`` over the node / edge rows; the LAST layer of a rep-net whose outputs
+        feed sum / mean pooling heads): two more outputs, the per-graph sums of ``xn`` / ``zn`` ([G, H]; edges with a flag
+        [G, 2H] = [non-reversed | reversed]).  A gradient that arrives ONLY through the edge sums is never expanded to
+        [E, H]: every row of a graph has the same gradient vector, see ``backward``."""
         _lib.require_gpu(x, z)
         H = Bn.size(1)
         x, z = x.contiguous(), z.contiguous()
@@ -632,22 +668,60 @@ class _FusedDMPLayer(torch.autograd.Function):
             zn = gate_residual(z if residual else None, Oe, e_gate)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
+        ctx.vpool, ctx.epool = vpool, epool
         ctx.save_for_backward(x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
-        return xn, zn
+        if vpool is None and epool is None:
+            return xn, zn
+        ctx.set_materialize_grads(False)    # a missing gradient stays None (the common case: only the sums are used)
+        vs = pool_rows(xn, vpool) if vpool is not None else None
+        es = pool_rows(zn, epool) if epool is not None else None
+        return xn, zn, vs, es
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dxn, dzn):
+    def backward(ctx, dxn, dzn, dvs=None, des=None):
         x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2 = ctx.saved_tensors
         ix, coef, H, slope = ctx.index, ctx.coef, ctx.H, ctx.slope
         N = ix.num_nodes
-        dxn, dzn = dxn.contiguous(), dzn.contiguous()
+        # ---- gradients through the pooled sums (last layer).  Node side: expanded (N rows are cheap).  Edge side: if the
+        # sums are the ONLY consumer of zn, dzn[e] = T[graph of e] (zero for reversed edges) with T = des[:, :H] and
+        #   dH1 = (g (.) dzn) W2 = g[e] (T W2)[graph of e]             -> no E-row product, no [E, H] gradient tensor
+        #   dW2 = (g (.) dzn)^T H1 = T^T Q,  Q[b] = sum_{e in b} g[e] H1[e]   -> one pooled pass over H1
+        #   db2 = T^T (sum_{e in b} g[e])
+        # and the residual term of dz reads T through the row map.
+        lazy = None
+        if dvs is not None:
+            vp = ctx.vpool
+            exp = ops.gather_rows_raw(dvs.contiguous(), vp.seg32)
+            dxn = exp if dxn is None else dxn + exp
+        if des is not None:
+            ep = ctx.epool
+            if dzn is None and typed_ok(ix, H) and H1e.size(0) > 0:
+                lazy = (des[:, :H].contiguous(), pool_rowmap(ep), ep)
+            else:
+                exp = (ops.gather_select_raw(des.contiguous(), ep.seg32, ep.flag8, H, None, 1.0, 1.0) if ep.flag8 is not None
+                       else ops.gather_rows_raw(des.contiguous(), ep.seg32))
+                dzn = exp if dzn is None else dzn + exp
+        if dxn is None:
+            dxn = torch.zeros_like(x)
+        if dzn is None and lazy is None:
+            dzn = torch.zeros_like(z)
+        dxn = dxn.contiguous()
+        dzn = dzn.contiguous() if dzn is not None else None
         # the parameter-gradient partials (biases, split-K weight gradients) are consumed after the layer (by the
         # unfold of fold_layers / the optimizer): their reductions run as one launch when this block is left
         with deferred_reductions():
             # ---- edge side, down to the gathered node projections
             mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
-            if typed:
+            if lazy is not None:
+                T, emap, ep = lazy
+                dG, dbe = relu_bwd_gathered_colsum(T @ eW2, emap, ctx.e_gate, H1e, slope)     # dG is dPre
+                Q = pool_rows(H1e, ep, ctx.e_gate)[:, :H]
+                dW2e = T.t() @ Q
+                # gated row counts per graph through the vector kernel (4 equal columns: the scalar path is slow)
+                g4 = (ctx.e_gate if ctx.e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
+                db2e = pool_rows(g4.view(-1, 1).repeat(1, 4), ep)[:, 0] @ T
+            elif typed:
                 # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)
                 dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
                 dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
@@ -691,7 +765,10 @@ class _FusedDMPLayer(torch.autograd.Function):
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
             dz = None
             if ctx.needs_input_grad[4]:
-                if typed:
+                if lazy is not None:
+                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
+                                     base_map=lazy[1] if ctx.residual else None)
+                elif typed:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT)
                 elif mfma:
                     dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
@@ -699,7 +776,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
-        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None)
+        return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None,
+                None, None)
 
 
 def activation_slope(act):
@@ -712,9 +790,12 @@ def activation_slope(act):
     return None
 
 
-def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None):
-    """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch)."""
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None):
+    """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch).
+    ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None)``: also returns the per-graph sums of both outputs."""
     n2, e2 = layer.nmlp[2], layer.emlp[2]
     Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t = folded if folded is not None else fold_layers([layer])[0]
+    vpool, epool = pools if pools is not None else (None, None)
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
-                                n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]))
+                                n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]),
+                                vpool, epool)

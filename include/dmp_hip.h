@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 43
+#define DMP_ABI_VERSION 44
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -470,6 +470,15 @@ int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t 
                         int64_t rows, int H, float slope, float *dPre, int64_t ldp, float *partial,
                         void *stream);
 
+/*
+ * The same with the upstream gradient given through a row map: dH[r] = gate[r] * table[rowmap[r]] (rowmap[r] < 0: a zero
+ * row; gate NULL: 1).  The backward of a layer whose output feeds ONLY per-graph sum / mean pooling heads
+ * (basemodel.py:1545-1631 -> pred.py:176-214): the gradient of every row of a graph is the same [H] vector, so
+ * d(out) W2 is a [graphs, H] product and the [rows, H] gradient tensor never exists (dmpnn.py:142-156 backward).
+ */
+int dmp_relu_bwd_gathered_colsum(const float *table, int64_t ldt, const int32_t *rowmap, const float *gate, const float *act,
+                                 int64_t lda, int64_t R, int H, float slope, float *dPre, int64_t ldp, float *partial, void *stream);
+
 /* dmp_edge_combine_bwd_g + column sums of dY (gradient of ebias, dmpnn.py:148-149). */
 int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef,
                                   const int32_t *dst, int64_t num_edges, int H, float *dG,
@@ -774,6 +783,9 @@ int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  * dmp_bwd_z_typed, w_transposed != 0: W holds [A'^T | B'^T] (each half transposed) instead of [A' | B'] --
  * the per-class panel of dZ = dPre W_g^T is then read with coalesced loads (a strided panel read costs
  * every workgroup several microseconds per class segment).
+ * dmp_bwd_z_typed, base_map != NULL: `base` is a [base_rows, ldb] table and edge e adds row base_map[e] of it (< 0: nothing)
+ * instead of row e of an [E, ldb] array -- the residual path of a layer whose output gradient is a per-graph vector
+ * (see dmp_relu_bwd_gathered_colsum).
  */
 int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P,
                        int64_t ldp, int64_t num_nodes, const float *bias, const int32_t *selA,
@@ -784,8 +796,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
                     const int32_t *dst, const uint8_t *flag, float s0, float s1,
                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t num_edges, int H, int w_transposed, float *dZ,
-                    int64_t ldz, void *stream);
+                    int64_t tiles_bound, int64_t num_edges, int H, int w_transposed,
+                    const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldz, void *stream);
 
 /*
  * Weight gradient of the class-typed edge chain:  with G_c = sum over the edges e of class c of

@@ -45,7 +45,7 @@ for n_path, path in enumerate(paths):
         lib.dmp_dev_set_exact_fp32(1 if n_path == 1 else 0)
         print("exact_fp32 =", lib.dmp_dev_get_exact_fp32())
     lib.dmp_edge_fwd_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, I, F, P, I64, P]
-    lib.dmp_bwd_z_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, F, F, P, P, P, I64, I64, I, I, P, I64, P]
+    lib.dmp_bwd_z_typed.argtypes = [P, I64, P, I64, P, I64, I64, P, I64, P, P, F, F, P, P, P, I64, I64, I, I, P, I64, P, I64, P]
     def fwd(i):
         rc = lib.dmp_edge_fwd_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, xp[:, h:].data_ptr(), 3 * h, n, bias.data_ptr(),
                                     selA.data_ptr(), selB.data_ptr(), se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h,
@@ -53,7 +53,7 @@ for n_path, path in enumerate(paths):
         assert rc == 0, rc
     def bwd(i):
         rc = lib.dmp_bwd_z_typed(Z[i % 3].data_ptr(), h, wes.data_ptr(), 2 * h, dsn.data_ptr(), 2 * h, n, base[i % 3].data_ptr(), h,
-                                 ix.dst32.data_ptr(), ix.rev8.data_ptr(), -1.0, 1.0, se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h, 0,
+                                 ix.dst32.data_ptr(), ix.rev8.data_ptr(), -1.0, 1.0, se.data_ptr(), ts.data_ptr(), nt.data_ptr(), bound, e, h, 0, None, 0,
                                  out.data_ptr(), h, st)
         assert rc == 0, rc
     print("%-14s edge_fwd %7.1f us   bwd_z %7.1f us" % (os.path.basename(path), timeit(fwd), timeit(bwd)), flush=True)

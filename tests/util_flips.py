@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 
 TAU = 1e-5          # |pre-activation| <= TAU * max(1, |pre|max): "within rounding of the kink"
-LOOSE = 5e-2        # bound on a traced element's error, relative to the reference's largest value
+LOOSE = 0.25       # bound on a traced element's error, relative to the reference's largest value (a flipped ReLU derivative moves one term of the sum by its full size)
 
 
 def ambiguous_rows(pre, tau=TAU):
