@@ -8,8 +8,21 @@ parameter names/shapes, ``forward(graph, node_feat, edge_feat) -> (node_out, edg
 
 The composition and the per-edge norm are fused into the segment sum (one HIP kernel,
 ``dmp_compgcn_agg``), and the W_in / W_out products are applied to the N summed rows instead
-of the E message rows.  ``comp_opt="corr"`` (circular correlation by FFT, compgcn.py:218-222)
-runs the FFTs in torch and the flag-split segment sum on the result.
+of the E message rows.
+
+``comp_opt="corr"`` -- the reference's DEFAULT composition (config.py:170-172) -- is the circular correlation
+``irfft(conj(rfft(h)) * rfft(r))`` (compgcn.py:218-222).  The reference gathers ``X[src]`` to [E, H], runs two forward and
+one inverse FFT over E rows and then the products.  The DFT is a fixed linear map, so it commutes with the sum over the
+in-edges:
+
+    sum_e norm_e irfft(conj(F x_src(e)) . F z_e) W = irfft(sum_e norm_e conj(F x_src(e)) . F z_e) W
+
+    Fx = X D        [N, 2 bins]     D: the real DFT as an [H, 2 bins] matrix, (re, im) interleaved
+    Fz = Z D        [E, 2 bins]     one E-row product (the only [E, .] tensor of the composition)
+    S  = dmp_compgcn_agg(Fx, Fz, comp = conj-multiply)        [N, 2 x 2 bins]   the same fused gather + multiply + segment sum
+    agg = S [D^-1 W_in ; D^-1 W_out]                          N rows; D^-1 W is an [2 bins, H] matrix built per call (tiny)
+
+-- no per-edge FFT, no gathered [E, H] tensor, no library FFT call.
 """
 import torch as th
 import torch.nn as nn
@@ -20,6 +33,41 @@ from .act import init_weight, map_activation_str_to_layer
 from .constants import (EDGEFEAT, INDEGREE, INNORM, NODEAGG, NODEFEAT, NORM, OUTDEGREE, OUTNORM, REVFLAG)
 from .dmpnn import DMPNNRepMixin
 from .graph import leave_detached, BatchedGraph, as_batched
+
+
+_DFT = {}
+USE_FREQ_DOMAIN_CORR = True    # False: the reference's own formulation (gather, library FFTs over E rows), kept for comparison
+
+
+def dft_matrices(h, device):
+    """``(D [h, w], Dinv [w, h])`` with ``x @ D`` = rfft(x) as interleaved (re, im) pairs (w = 2 (h // 2 + 1) rounded up to a
+    multiple of 4, the padding columns zero) and ``F @ Dinv`` = irfft(F, n=h) (which ignores the imaginary parts of the
+    DC and Nyquist bins, as the library's real inverse does).  Built in float64, cached per (h, device)."""
+    key = (int(h), str(device))
+    if key not in _DFT:
+        bins = h // 2 + 1
+        w = (2 * bins + 3) // 4 * 4
+        j = th.arange(h, dtype=th.float64).view(-1, 1)
+        k = th.arange(bins, dtype=th.float64).view(1, -1)
+        ang = 2.0 * th.pi * j * k / h
+        D = th.zeros(h, w, dtype=th.float64)
+        D[:, 0:2 * bins:2] = th.cos(ang)
+        D[:, 1:2 * bins:2] = -th.sin(ang)
+        c = th.full((bins,), 2.0, dtype=th.float64)
+        c[0] = 1.0
+        if h % 2 == 0:
+            c[-1] = 1.0
+        Dinv = th.zeros(w, h, dtype=th.float64)
+        Dinv[0:2 * bins:2] = (th.cos(ang) * c).t() / h
+        Dinv[1:2 * bins:2] = (-th.sin(ang) * c).t() / h
+        _DFT[key] = (D.float().to(device), Dinv.float().to(device))
+    return _DFT[key]
+
+
+def _cmul_conj(fx, fr):
+    """``conj(fx) * fr`` over interleaved (re, im) rows (``fr`` broadcasts over the rows)."""
+    xr, xi, rr, ri = fx[:, 0::2], fx[:, 1::2], fr[:, 0::2], fr[:, 1::2]
+    return th.stack([xr * rr + xi * ri, xr * ri - xi * rr], dim=-1).reshape(fx.size(0), -1)
 
 
 class CompGCNLayer(nn.Module):
@@ -125,20 +173,35 @@ class CompGCNLayer(nn.Module):
         h = self.input_dim
 
         # _node_message_func + fn.sum (compgcn.py:226-238,271)
+        fx = None
         if self.comp_opt in ("sub", "mult"):
             s = ops.compgcn_agg(x, z, norm, ix, ops.COMP_SUB if self.comp_opt == "sub" else ops.COMP_MULT)
+            w_in, w_out = self.in_weight, self.out_weight
+        elif self.comp_opt == "corr" and x.is_cuda and USE_FREQ_DOMAIN_CORR:
+            # the correlation in the frequency domain (module docstring): two products with the DFT matrix, the fused
+            # conj-multiply segment sum, the inverse transform folded into the weights of the N-row product
+            D, Dinv = dft_matrices(h, x.device)
+            fx = ops.matmul_xw(x, D)
+            s = ops.compgcn_agg(fx, ops.matmul_xw(z, D), norm, ix, ops.COMP_CMUL)
+            w_in, w_out = Dinv @ self.in_weight, Dinv @ self.out_weight
+            h = D.size(1)
         else:
             comp = self._comp_func(ops.gather_src(x, ix), z)
             s = ops.seg_sum2(comp, ix, norm, 1.0, 1.0)
+            w_in, w_out = self.in_weight, self.out_weight
         if has_rev:
-            agg = ops.matmul_xw(s, th.cat([self.in_weight, self.out_weight], dim=0))
+            agg = ops.matmul_xw(s, th.cat([w_in, w_out], dim=0))
         else:
-            agg = ops.matmul_xw(s[:, :h], self.in_weight)
+            agg = ops.matmul_xw(s[:, :h], w_in)
         g.ndata[NODEAGG] = agg
 
         # _node_update_func (compgcn.py:240-258)
         if self.self_loop:
-            loop_msg = th.matmul(self._comp_func(x, self.loop_rel), self.loop_weight)
+            if fx is not None:      # corr(x, loop_rel) from the transform of x that is already there
+                D, Dinv = dft_matrices(self.input_dim, x.device)
+                loop_msg = th.matmul(_cmul_conj(fx, th.matmul(self.loop_rel, D)), Dinv @ self.loop_weight)
+            else:
+                loop_msg = th.matmul(self._comp_func(x, self.loop_rel), self.loop_weight)
             out = (agg + loop_msg) * 0.3333333
         else:
             out = agg * 0.5

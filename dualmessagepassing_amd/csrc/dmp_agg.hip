@@ -49,6 +49,13 @@ __device__ __forceinline__ float4 sub4(const float4 &a, const float4 &b) {
 __device__ __forceinline__ float4 had4(const float4 &a, const float4 &b) {
   return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
+// a float4 as two complex numbers (re, im | re, im):  conj(a) b,  a b,  conj(a) b with the roles used by the backward
+__device__ __forceinline__ float4 cmulc4(const float4 &a, const float4 &b) {     // conj(a) * b
+  return make_float4(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x, a.z * b.z + a.w * b.w, a.z * b.w - a.w * b.z);
+}
+__device__ __forceinline__ float4 cmul4(const float4 &a, const float4 &b) {      // a * b
+  return make_float4(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w, a.z * b.w + a.w * b.z);
+}
 
 // ---------------------------------------------------------------------------
 // Segment sum.  One G-lane group per destination row.  The group's lanes first
@@ -492,8 +499,8 @@ __global__ __launch_bounds__(kBlock) void compgcn_agg_vec(
         if (act) {
           const float4 x0 = ld4(X + (int64_t)u0 * ldx + c), z0 = ld4(Z + (int64_t)(e0 >> 1) * ldz + c);
           const float4 x1 = ld4(X + (int64_t)u1 * ldx + c), z1 = ld4(Z + (int64_t)(e1 >> 1) * ldz + c);
-          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : had4(x0, z0), w0);
-          const float4 m1 = mul4(COMP == 0 ? sub4(x1, z1) : had4(x1, z1), w1);
+          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : COMP == 1 ? had4(x0, z0) : cmulc4(x0, z0), w0);
+          const float4 m1 = mul4(COMP == 0 ? sub4(x1, z1) : COMP == 1 ? had4(x1, z1) : cmulc4(x1, z1), w1);
           if (e0 & 1) add4(a1, m0); else add4(a0, m0);
           if (e1 & 1) add4(a1, m1); else add4(a0, m1);
         }
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void compgcn_agg_vec(
         const float w0 = __shfl(myw, j, G);
         if (act) {
           const float4 x0 = ld4(X + (int64_t)u0 * ldx + c), z0 = ld4(Z + (int64_t)(e0 >> 1) * ldz + c);
-          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : had4(x0, z0), w0);
+          const float4 m0 = mul4(COMP == 0 ? sub4(x0, z0) : COMP == 1 ? had4(x0, z0) : cmulc4(x0, z0), w0);
           if (e0 & 1) add4(a1, m0); else add4(a0, m0);
         }
       }
@@ -558,10 +565,16 @@ __global__ __launch_bounds__(kBlock) void compgcn_agg_bwd_vec(
     if (COMP == 0) {
       st4(dZ + e * lddz + c, mul4(g, -1.f));
       st4(dXe + e * lddxe + c, g);
-    } else {
+    } else if (COMP == 1) {
       const float4 x = ld4(X + (int64_t)u * ldx + c), z = ld4(Z + e * ldz + c);
       st4(dZ + e * lddz + c, had4(g, x));
       st4(dXe + e * lddxe + c, had4(g, z));
+    } else {
+      // m = conj(x) z as pairs of reals: dz = x g (complex product), dx = conj(g) z ... written out:
+      //   dz_re = g_re x_re - g_im x_im, dz_im = g_re x_im + g_im x_re;  dx_re = g_re z_re + g_im z_im, dx_im = g_re z_im - g_im z_re
+      const float4 x = ld4(X + (int64_t)u * ldx + c), z = ld4(Z + e * ldz + c);
+      st4(dZ + e * lddz + c, cmul4(g, x));
+      st4(dXe + e * lddxe + c, cmulc4(g, z));
     }
   }
 }
@@ -768,7 +781,7 @@ int dmp_edge_combine_bwd_g(const float *dY, int64_t ldy, const float *coef, cons
 int dmp_compgcn_agg(const float *X, int64_t ldx, const float *Z, int64_t ldz, const int32_t *rowptr,
                     const int32_t *ent, const int32_t *src, const float *norm, int64_t N, int H,
                     int comp, float *out, int64_t ldo, void *stream) {
-  if (N < 0 || H <= 0 || ldx < H || ldz < H || ldo < 2 * H || (comp != 0 && comp != 1)) return DMP_ERR_BAD_ARG;
+  if (N < 0 || H <= 0 || ldx < H || ldz < H || ldo < 2 * H || comp < 0 || comp > 2) return DMP_ERR_BAD_ARG;
   if (N == 0) return DMP_OK;
   if (!X || !Z || !rowptr || !ent || !src || !out) return DMP_ERR_BAD_ARG;
   if (N >= kMaxRows) return DMP_ERR_UNSUPPORTED;
@@ -777,9 +790,11 @@ int dmp_compgcn_agg(const float *X, int64_t ldx, const float *Z, int64_t ldz, co
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(N, kBlock / G);
       if (comp == 0) compgcn_agg_vec<G, 0><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
-      else compgcn_agg_vec<G, 1><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+      else if (comp == 1) compgcn_agg_vec<G, 1><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
+      else compgcn_agg_vec<G, 2><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
     });
   } else {
+    if (comp == 2) return DMP_ERR_UNSUPPORTED;               // complex pairs: the float4 path only (H % 4 == 0, aligned rows)
     const unsigned nb = blocks_for(N, kBlock / kWave);
     if (comp == 0) compgcn_agg_scalar<0><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
     else compgcn_agg_scalar<1><<<nb, kBlock, 0, st>>>(X, ldx, Z, ldz, rowptr, ent, src, norm, (int)N, H, out, ldo);
@@ -791,8 +806,7 @@ int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X, int64_t ldx
                         int64_t ldz, const int32_t *src, const int32_t *dst, const uint8_t *flag,
                         const float *norm, int64_t E, int H, int comp, float *dZ, int64_t lddz,
                         float *dXe, int64_t lddxe, void *stream) {
-  if (E < 0 || H <= 0 || ldd < 2 * H || ldx < H || ldz < H || lddz < H || lddxe < H ||
-      (comp != 0 && comp != 1))
+  if (E < 0 || H <= 0 || ldd < 2 * H || ldx < H || ldz < H || lddz < H || lddxe < H || comp < 0 || comp > 2)
     return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
   if (!D || !X || !Z || !src || !dst || !dZ || !dXe) return DMP_ERR_BAD_ARG;
@@ -802,9 +816,11 @@ int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X, int64_t ldx
     DMP_DISPATCH_G(H, {
       const unsigned nb = blocks_for(E, kBlock / G);
       if (comp == 0) compgcn_agg_bwd_vec<G, 0><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
-      else compgcn_agg_bwd_vec<G, 1><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+      else if (comp == 1) compgcn_agg_bwd_vec<G, 1><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
+      else compgcn_agg_bwd_vec<G, 2><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
     });
   } else {
+    if (comp == 2) return DMP_ERR_UNSUPPORTED;
     const unsigned nb = blocks_for(E, kBlock / kWave);
     if (comp == 0) compgcn_agg_bwd_scalar<0><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);
     else compgcn_agg_bwd_scalar<1><<<nb, kBlock, 0, st>>>(D, ldd, X, ldx, Z, ldz, src, dst, flag, norm, E, H, dZ, lddz, dXe, lddxe);

@@ -357,7 +357,7 @@ def edge_combine(G, P, bias, coef, index):
     return _EdgeCombine.apply(G, P, bias, coef, index)
 
 
-COMP_SUB, COMP_MULT = 0, 1
+COMP_SUB, COMP_MULT, COMP_CMUL = 0, 1, 2      # CMUL: conj(x) * z over interleaved (re, im) pairs (the corr composition in the frequency domain)
 
 
 def compgcn_agg(X, Z, norm, index, comp):

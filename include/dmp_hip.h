@@ -409,7 +409,11 @@ int dmp_edge_combine_bwd_g(const float *dY, int64_t ldy, const float *coef,
 /*
  * CompGCN message aggregation (compgcn.py:213-238 + fn.sum), sum moved in front
  * of the W_in / W_out products:
- *     m_e = norm_e * comp(X[src e], Z[e]),  comp = sub (0): x - z, mult (1): x * z
+ *     m_e = norm_e * comp(X[src e], Z[e]),  comp = sub (0): x - z, mult (1): x * z,
+ *           cmul (2): conj(x) * z over rows of interleaved (re, im) pairs (H = 2 x bins, H % 4 == 0) -- the reference's
+ *           default composition "corr" (config.py:170-172; compgcn.py:218-222: irfft(conj(rfft h) rfft r)) in the frequency
+ *           domain: the DFT is linear, so the transform of the rows is a product with a fixed matrix on either side of the
+ *           sum (X D, Z D before; D^-1 [W_in; W_out] folded into the N-row product after) and no per-edge FFT exists
  *     out[v, 0:H ] = sum_{e->v, flag=0} m_e ;  out[v, H:2H] = sum_{e->v, flag=1} m_e
  * so that node_agg = out @ [W_in ; W_out].  norm may be NULL.
  */
@@ -421,8 +425,8 @@ int dmp_compgcn_agg(const float *X, int64_t ldx, const float *Z, int64_t ldz,
 /*
  * Backward of dmp_compgcn_agg w.r.t. Z (per edge, streaming):
  *     g_e = norm_e * D[dst e, flag ? H:2H : 0:H]
- *     dZ[e] = sub: -g_e          mult: g_e * X[src e]
- * and the per-edge term of dX:  dXe[e] = sub: g_e   mult: g_e * Z[e]
+ *     dZ[e] = sub: -g_e          mult: g_e * X[src e]          cmul: g_e * X[src e]  (complex product)
+ * and the per-edge term of dX:  dXe[e] = sub: g_e   mult: g_e * Z[e]   cmul: conj(g_e) * Z[e]
  * (dX = dmp_seg_sum of dXe over the CSR by src).
  */
 int dmp_compgcn_agg_bwd(const float *D, int64_t ldd, const float *X,
