@@ -111,13 +111,14 @@ def slice_shard(cfg, shard, lo, hi):
 
 
 def micro_batches_for(cfg):
-    """Micro-batches per step so that every [E, 2H] fp32 array of one pass stays below 4 GiB: the class-typed MFMA kernels
-    address whole arrays with 32-bit byte offsets (fused.typed_ok).  Pairs are independent, so a step over M equal slices
-    of the shard with the gradients summed (each slice's mean loss weighted 1/M) is the same step.  Config 2: 1;
-    config 4 (E = 8.4 M edge rows per 1024-pair shard): 4."""
+    """Micro-batches per step so that one pass stays inside the kernels' index range: 2^30 edge rows (packed
+    (row << 1) | flag entries) -- rows are addressed by index, so the SIZE of an [E, H] array is no limit any more (round 2
+    split config 4's 8.4 M-row shard four ways to keep every array below 4 GiB of 32-bit byte offsets).  Pairs are
+    independent, so a step over M equal slices of the shard with the gradients summed (each slice's mean loss weighted
+    1/M) is the same step (``--micro-batches`` forces it).  Config 2: 1; config 4: 1."""
     rows = cfg["batch"] * 2 * (cfg["p_edges"] + cfg["g_edges"])
     m = 1
-    while rows // m * 2 * cfg["hid"] * 4 >= 2 ** 32 - 8192 and m < cfg["batch"]:
+    while rows // m >= 2 ** 30 and m < cfg["batch"]:
         m *= 2
     return m
 

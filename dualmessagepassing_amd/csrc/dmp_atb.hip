@@ -60,8 +60,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
   const uint32_t colA = (uint32_t)(gtid % kQ) * 16u;
   constexpr uint32_t kOOB = 0xFFFFF000u;
-  const rsrc_t rs_Z = make_rsrc(p.Z + H * ya, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldz + H) * 4) : 0u);
-  const rsrc_t rs_D = make_rsrc(p.D + H * yb, p.E > 0 ? (uint32_t)(((p.E - 1) * p.ldd + H) * 4) : 0u);
+  // rows by INDEX (structured descriptors, dmp_mfma_common.h): any array size; the column block is in the base
+  const srsrc_t rs_Z = make_srsrc(p.Z + H * ya, p.ldz, p.E);
+  const srsrc_t rs_D = make_srsrc(p.D + H * yb, p.ldd, p.E);
   const bool gated = REL ? p.slot_scale != nullptr : (!TYPED && p.gate != nullptr);
   const rsrc_t rs_G = make_rsrc(p.gate, !REL && gated ? (uint32_t)(p.E * 4) : 0u);
   const int first = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y]) : 0;
@@ -125,9 +126,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     if ((DMP_ATB_DBG & 2) && warm) return;
 #endif
     const bool ok = id_rows[m] >= 0;
-    preZ[S][m] = buf_load4(rs_Z, ok ? (uint32_t)id_rows[m] * (uint32_t)(p.ldz * 4) + colA : kOOB, 0);
+    preZ[S][m] = sbuf_load4(rs_Z, id_rows[m], colA);          // -1: out of range, zeros
     const int idD = REL ? id_rowsD[m] : id_rows[m];
-    preD[S][m] = buf_load4(rs_D, ok ? (uint32_t)idD * (uint32_t)(p.ldd * 4) + colA : kOOB, 0);
+    preD[S][m] = sbuf_load4(rs_D, ok ? idD : -1, colA);
     if (REL) preG[S][m] = sc_rows[m];
     if (MODE == ATB_ROWS) {
       preG[S][m] = 1.f;
@@ -411,7 +412,7 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   if (E > 0 && (!Z || !dPre || ldz < H || ldp < H)) return DMP_ERR_BAD_ARG;
   if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre))) || !aligned16(partial_T) || !aligned16(partial_B))
     return DMP_ERR_UNSUPPORTED;
-  if (!fits32(E, ldz) || !fits32(E, ldp) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(ldz) || !stride_ok(ldp) || E >= ((int64_t)1 << 31) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
   a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
@@ -447,7 +448,7 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
     if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial) ||
         (j.partial_colsum && !aligned16(j.partial_colsum)))
       return DMP_ERR_UNSUPPORTED;
-    if (!fits32(rows, j.lda) || !fits32(rows, j.ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+    if (!stride_ok(j.lda) || !stride_ok(j.ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
     AtbArgs a{};
     a.Z = j.A; a.ldz = j.lda; a.D = j.B; a.ldd = j.ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
     a.gate = j.gate; a.pT = j.partial; a.pstride = j.partial_stride; a.ldp = j.ldp; a.pCS = j.partial_colsum;
@@ -470,7 +471,8 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
     return H == 128 ? DMP_ERR_BAD_ARG : DMP_ERR_UNSUPPORTED;
   if (!partial || !type_tile_ptr || (tiles > 0 && (!X || !D || !slot_x || !slot_d || ldx < H || ldd < H))) return DMP_ERR_BAD_ARG;
   if (ldx % 4 || ldd % 4 || (tiles > 0 && (!aligned16(X) || !aligned16(D))) || !aligned16(partial)) return DMP_ERR_UNSUPPORTED;
-  if (!fits32(rows_x, ldx) || !fits32(rows_d, ldd) || !fits32(tiles * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(ldx) || !stride_ok(ldd) || rows_x >= ((int64_t)1 << 31) || rows_d >= ((int64_t)1 << 31) || !fits32(tiles * kSub, 1))
+    return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = X; a.ldz = ldx; a.D = D; a.ldd = ldd; a.E = rows_x > rows_d ? rows_x : rows_d;
   a.slot_edge = slot_x; a.slot_d = slot_d; a.slot_scale = slot_scale; a.type_tile_ptr = type_tile_ptr;
@@ -491,7 +493,7 @@ int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, con
   if (lda % 4 || ldb % 4 || (rows > 0 && (!aligned16(A) || !aligned16(B))) || !aligned16(partial) ||
       (partial_colsum && !aligned16(partial_colsum)))
     return DMP_ERR_UNSUPPORTED;
-  if (!fits32(rows, lda) || !fits32(rows, ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(lda) || !stride_ok(ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
   a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / H; a.cs_ld = M;

@@ -73,6 +73,35 @@ __device__ __forceinline__ f32x16 mfma_x6(const Split8 &a, const Split8 &b, f32x
   return acc;
 }
 
+// ---- structured buffer access: address = base + index * stride + offset, the descriptor holds the row stride in bytes
+// (<= 16383) and the number of rows; a row index beyond it (e.g. -1) reads zeros / drops the store.  Rows addressed by
+// INDEX reach any array size (a 32-bit byte offset ends at 4 GiB: one [E, 128] fp32 array of BASELINE config 4's shard
+// is 4.3 GB) and need no multiply.  clang has no builtin for the indexed form: the LLVM intrinsics are declared by name
+// (waitcnt tracking stays with the compiler, unlike inline asm).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ i32x4 llvm_struct_buffer_load_v4i32(i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4i32");
+__device__ void llvm_struct_buffer_store_v4i32(i32x4 data, i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.store.v4i32");
+typedef i32x4 srsrc_t;
+__device__ __forceinline__ srsrc_t make_srsrc(const void *base, int64_t ld_floats, int64_t rows) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  srsrc_t r;
+  r.x = (int)(uint32_t)a;
+  r.y = (int)(((uint32_t)(a >> 32) & 0xFFFFu) | ((uint32_t)(ld_floats * 4) << 16));
+  r.z = base ? (int)(uint32_t)rows : 0;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ float4 sbuf_load4(srsrc_t r, int row, uint32_t col_bytes) {
+  const i32x4 v = llvm_struct_buffer_load_v4i32(r, row, (int)col_bytes, 0, 0);
+  return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ void sbuf_store4(float4 v, srsrc_t r, int row, uint32_t col_bytes) {
+  i32x4 u;
+  u.x = __float_as_int(v.x); u.y = __float_as_int(v.y); u.z = __float_as_int(v.z); u.w = __float_as_int(v.w);
+  llvm_struct_buffer_store_v4i32(u, r, row, (int)col_bytes, 0, 0);
+}
+inline bool stride_ok(int64_t ld_floats) { return ld_floats > 0 && ld_floats * 4 <= 16383; }
+
 // bytes of a tile of `rows` rows with leading dimension ld (floats) of which `cols` are touched
 __device__ __forceinline__ uint32_t tile_bytes(int rows, int64_t ld, int cols) {
   return rows > 0 ? (uint32_t)(((int64_t)(rows - 1) * ld + cols) * 4) : 0u;

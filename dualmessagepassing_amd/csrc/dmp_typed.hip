@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   constexpr int kTileWords = X6 ? 3 * kPlane : kSub * kStride;
   __shared__ __attribute__((aligned(16))) float As[kPipelined ? 2 : 1][kTileWords];
   __shared__ float Cs[H / 32][32 * kScrStride];
-  __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] byte offsets: tile k's are read
+  __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] row INDICES (-1: none): tile k's are read
                                                                                      // (epilogue) while tile k+2's are written
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, cs = wave, gtid = threadIdx.x;
@@ -90,11 +90,12 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
-  const rsrc_t rs_A = make_rsrc(p.A, (uint32_t)(p.rowsA * p.lda * 4));   // all < 4 GiB: checked by the host
-  const rsrc_t rs_C = make_rsrc(p.C, (uint32_t)(p.E * p.ldc * 4));
-  const rsrc_t rs_R = make_rsrc(p.R, p.R ? (uint32_t)((p.rmap ? p.rowsR : p.E) * p.ldr * 4) : 0u);
+  // rows of the big arrays are addressed by INDEX (structured descriptors: any array size, dmp_mfma_common.h)
+  const srsrc_t rs_A = make_srsrc(p.A, p.lda, p.rowsA);
+  const srsrc_t rs_C = make_srsrc(p.C, p.ldc, p.E);
+  const srsrc_t rs_R = make_srsrc(p.R, p.ldr, p.rmap ? p.rowsR : p.E);
   const rsrc_t rs_rmap = make_rsrc(p.rmap, p.rmap ? rows4 : 0u);
-  const rsrc_t rs_T = make_rsrc(p.T, (uint32_t)(p.num_nodes * p.ldt * 4));
+  const srsrc_t rs_T = make_srsrc(p.T, p.ldt, p.num_nodes);
   const rsrc_t rs_idxA = make_rsrc(p.idxA, p.idxA ? rows4 : 0u);
   const rsrc_t rs_idxB = make_rsrc(p.idxB, p.idxB ? rows4 : 0u);
   const rsrc_t rs_flag = make_rsrc(p.flag, p.flag ? (uint32_t)p.E : 0u);
@@ -175,8 +176,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
 #ifdef DMP_TY_DBG
     if ((DMP_TY_DBG & 8) && warm) return;
 #endif
-    const uint32_t off = id_rows[m] >= 0 ? (uint32_t)id_rows[m] * (uint32_t)(p.lda * 4) + colA : kOOB;
-    pre[S][m] = buf_load4(rs_A, off, 0);
+    pre[S][m] = sbuf_load4(rs_A, id_rows[m], colA);           // id -1 (padding, past the end): out of range, zeros
   };
   auto load_row_scalars = [&](auto set) {
     constexpr int S = decltype(set)::value;
@@ -212,18 +212,19 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
     constexpr int S = decltype(set)::value;
     if (gtid < kSub) {
       const bool ok = own_staged[S] >= 0;
-      uint32_t a = kOOB, bb = kOOB;
+      constexpr uint32_t kNone = 0xFFFFFFFFu;            // row index beyond any descriptor
+      uint32_t a = kNone, bb = kNone;
       if (EPI == TEPI_EDGE) {
-        if (ok) { a = pre_a[S] * (uint32_t)(p.ldt * 4); bb = pre_b[S] * (uint32_t)(p.ldt * 4) + kRowBytes; }
+        if (ok) { a = pre_a[S]; bb = pre_b[S]; }          // the two gathered nodes
       } else if (EPI == TEPI_REL) {
         a = p.idxA ? pre_a[S] : __float_as_uint(1.f);     // the row's scale (float bits)
       } else {
-        bb = pre_b[S];                                    // flag
-        if (ok) a = pre_a[S] * (uint32_t)(p.ldt * 4) + (bb ? kRowBytes : 0u);
+        bb = pre_b[S];                                    // flag: selects the half of the gathered row and the sign
+        if (ok) a = pre_a[S];
       }
       rowA[par][gtid] = a; rowB[par][gtid] = bb;
-      rowC[par][gtid] = ok ? (uint32_t)own_staged[S] * (uint32_t)(p.ldc * 4) : kOOB;
-      rowR[par][gtid] = (ok && p.R && (EPI != TEPI_DZ || pre_r[S] >= 0)) ? (uint32_t)(EPI == TEPI_DZ ? pre_r[S] : own_staged[S]) * (uint32_t)(p.ldr * 4) : kOOB;
+      rowC[par][gtid] = ok ? (uint32_t)own_staged[S] : kNone;
+      rowR[par][gtid] = (ok && p.R && (EPI != TEPI_DZ || pre_r[S] >= 0)) ? (uint32_t)(EPI == TEPI_DZ ? pre_r[S] : own_staged[S]) : kNone;
     }
   };
   auto stage = [&](int buf, int par, auto set) {
@@ -240,9 +241,13 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
 #endif
     if (EPI == TEPI_REL) return;
     const int rr = 8 * k + lrow;
-    g0[k] = buf_load4(rs_T, rowA[par][rr] + col4, 0);
-    if (EPI == TEPI_EDGE) g1[k] = buf_load4(rs_T, rowB[par][rr] + col4, 0);
-    else g1[k] = buf_load4(rs_R, rowR[par][rr] + col4, 0);
+    if (EPI == TEPI_EDGE) {
+      g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4);
+      g1[k] = sbuf_load4(rs_T, (int)rowB[par][rr], col4 + kRowBytes);
+    } else {
+      g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4 + (rowB[par][rr] ? kRowBytes : 0u));
+      g1[k] = sbuf_load4(rs_R, (int)rowR[par][rr], col4);
+    }
   };
   // X6: the tile's product on the bf16 pipe.  Per 16-deep k-group g: six MFMAs on the three piece fragments of A (this
   // lane's 8 consecutive k = kHalf h + 8g .. of row li: one ds_read_b128 per plane, requested one group ahead) and the
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
 #ifdef DMP_TY_DBG
       if ((DMP_TY_DBG & 4) && v.x != 123.456f) continue;
 #endif
-      buf_store4(v, rs_C, rowC[par][rr] + col4, 0);       // padding rows: offset out of range, dropped
+      sbuf_store4(v, rs_C, (int)rowC[par][rr], col4);       // padding rows: index out of range, dropped
       // X6: this chunk's operand registers are free -- request the NEXT tile's rows into them now (its row offsets were
       // staged during this tile's MFMA phase, before the barrier).  With the short bf16 MFMA phase, operands requested at
       // the start of their own tile's phase (the f32 form) arrive after the epilogue wants them: this way they have a
@@ -494,7 +499,9 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
     return DMP_ERR_BAD_ARG;
   if (ldz % 4 || ldh % 4 || ldp % 4 || !aligned16(Z) || !aligned16(H1) || !aligned16(P) || (bias && !aligned16(bias)))
     return DMP_ERR_UNSUPPORTED;
-  if (!fits32(num_nodes, ldp) || !fits32(E, ldz) || !fits32(E, ldh) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(ldp) || !stride_ok(ldz) || !stride_ok(ldh) || E >= ((int64_t)1 << 30) || num_nodes >= ((int64_t)1 << 31) ||
+      !fits32(tiles_bound * kSub, 1))
+    return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
@@ -519,7 +526,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
       (base && !aligned16(base)))
     return DMP_ERR_UNSUPPORTED;
   if (base_map && (!base || base_rows < 0)) return DMP_ERR_BAD_ARG;
-  if (!fits32(num_nodes, ldd) || !fits32(E, ldp) || !fits32(E, ldz) || (base && !fits32(base_map ? base_rows : E, ldb)) || !fits32(tiles_bound * kSub, 1))
+  if (!stride_ok(ldd) || !stride_ok(ldp) || !stride_ok(ldz) || (base && !stride_ok(ldb)) || E >= ((int64_t)1 << 30) ||
+      num_nodes >= ((int64_t)1 << 31) || !fits32(tiles_bound * kSub, 1))
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
@@ -538,7 +546,8 @@ int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, in
   if (rows_c == 0 || tiles_bound == 0) return DMP_OK;
   if (!A || !W || !slot_arow || !slot_row || !tile_type || !num_tiles || !C || lda < H || ldw < H || ldc < H) return DMP_ERR_BAD_ARG;
   if (lda % 4 || ldc % 4 || !aligned16(A) || !aligned16(C)) return DMP_ERR_UNSUPPORTED;
-  if (!fits32(rows_a, lda) || !fits32(rows_c, ldc) || !fits32(tiles_bound * kSub, 1) || !fits32((int64_t)num_rels * 128, ldw))
+  if (!stride_ok(lda) || !stride_ok(ldc) || rows_a >= ((int64_t)1 << 31) || rows_c >= ((int64_t)1 << 30) || !fits32(tiles_bound * kSub, 1) ||
+      !fits32((int64_t)num_rels * 128, ldw))
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = A; p.lda = lda; p.rowsA = rows_a; p.W = W; p.ldw = ldw; p.num_panels = num_rels; p.transposed = w_transposed ? 1 : 0;

@@ -290,9 +290,10 @@ USE_TYPED_KERNELS = True  # degree-class tiles: one weight panel instead of two 
 
 
 def typed_ok(index, H):
-    """Class-typed kernels: as mfma_ok, plus whole [E, H] arrays addressed with 32-bit byte offsets."""
-    return (USE_TYPED_KERNELS and onepanel_ok(H) and index.num_nodes * 3 * H * 4 < 2 ** 32
-            and index.num_edges * 2 * 128 * 4 < 2 ** 32 - 8192)
+    """Class-typed kernels: rows are addressed by index (structured buffer descriptors), so the [E, H] arrays may be of
+    any size (BASELINE config 4's 1024-pair shard: 8.4 M edge rows, 4.3 GB per array, one pass); what is 32-bit are the
+    packed (row << 1 | flag) index entries and the per-edge int32 arrays."""
+    return USE_TYPED_KERNELS and onepanel_ok(H) and index.num_nodes < 2 ** 31 and index.num_edges < 2 ** 30
 
 
 def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
@@ -484,7 +485,7 @@ def atb_ok(a, b):
     return (a.is_cuda and a.dtype == torch.float32 and atb_block(a.size(1), b.size(1)) > 0 and a.size(0) >= 4096
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
-            and a.size(0) * max(a.stride(0), b.stride(0)) * 4 < (1 << 32) - 8192)
+            and a.size(0) < 2 ** 31 - 64 and max(a.stride(0), b.stride(0)) * 4 <= 16383)   # rows by index: any array size
 
 
 def bwd_z_mfma(d_g, Wes, d_s, base, coef, index):

@@ -253,3 +253,31 @@ def test_micro_batched_step_equals_the_one_pass_step(gpu):
     g1, g4 = flats
     scale = float(g1.abs().max())
     assert scale > 0 and float((g1 - g4).abs().max()) <= 2e-4 * scale, (float((g1 - g4).abs().max()), scale)
+
+
+def test_config4_shard_in_one_pass_at_full_size(gpu):
+    """BASELINE configs[3]'s per-GPU shard at FULL size: 1024 pairs of pattern (16, 32) x target (512, 4096), add_rev -- the
+    union graph has 8,454,144 edge rows, ONE [E, 128] fp32 array is 4.33 GB, beyond what a 32-bit byte offset reaches.
+    The typed / weight-gradient kernels address rows by index (structured buffer descriptors), so the shard runs as one
+    pass (round 2 needed four micro-batches); its flat gradient must equal the four-pass gradient -- whose arrays all stay
+    below 4 GiB -- to fp32 rounding of the different summation split."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    flats = []
+    for m in (4, 1):
+        cfg = dict(bench.CFG4, micro_batches=m, act="leaky_relu", emb="Equivariant")
+        shard = bench.make_shard(cfg, 0, gpu)
+        assert 1024 * 2 * (32 + 4096) * 128 * 4 > 2 ** 32
+        step, model = bench.build_step(cfg, shard, gpu)
+        assert step.micro_batches == m
+        step()
+        th.cuda.synchronize()
+        flats.append(step.sync.flat.detach().clone())
+        del step, model, shard
+        th.cuda.empty_cache()
+    g4, g1 = flats
+    scale = float(g4.abs().max())
+    assert scale > 0 and bool(th.isfinite(g1).all())
+    assert float((g1 - g4).abs().max()) <= 5e-4 * scale, (float((g1 - g4).abs().max()), scale)
