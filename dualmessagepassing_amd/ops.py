@@ -492,11 +492,20 @@ class PoolIndex:
         """Index for summing rows by an arbitrary integer key in [0, num_keys) (e.g. the relation
         type of an edge): rows are visited key by key in ascending row order (stable sort), so the
         sums are bit-stable; same two-level chunking as for the contiguous per-graph ranges."""
+        # one-entry memo: a fixed graph's relation types (UNC trains on ONE graph) meet this with the same tensor every step,
+        # and the construction is ~25 small launches (sort, scans, searches)
+        memo = cls.__dict__.get("_keys_memo")
+        ident = (keys.data_ptr(), keys._version, int(keys.numel()), str(keys.device), str(keys.dtype), int(num_keys))
+        if memo is not None and memo[0] == ident:
+            return memo[1]
+        keys_in = keys
         keys = keys.view(-1).to(torch.int64)
         skeys, order = torch.sort(keys, stable=True)
         # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
         marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))
-        return cls(marks[1:] - marks[:-1], order=order, seg=keys, num_rows=int(keys.numel()))
+        out = cls(marks[1:] - marks[:-1], order=order, seg=keys, num_rows=int(keys.numel()))
+        cls._keys_memo = (ident, out, keys_in)            # the tensor is kept alive: its address stays unique
+        return out
 
     def __init__(self, sizes, flag=None, order=None, seg=None, num_rows=None):
         """``num_rows`` (host int: the total number of rows) makes the construction free of host syncs:

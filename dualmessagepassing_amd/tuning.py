@@ -21,6 +21,10 @@ def enable_tuned_gemms(path=None, allow_tuning=False):
         return False
     import torch.cuda.tunable as tn
     path = path or DEFAULT_FILE
+    tune_out = os.environ.get("DMP_TUNE_OUT")       # development: tune the shapes this run meets and write them to this file
+    if tune_out:
+        allow_tuning = True
+        tn.set_filename(tune_out)
     tn.enable(True)
     tn.tuning_enable(bool(allow_tuning))
     try:
