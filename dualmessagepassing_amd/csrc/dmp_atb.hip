@@ -47,7 +47,11 @@ struct AtbArgs {
 
 enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
 
-template <int MODE, int H>
+// X6: the products on the bf16 matrix pipe (dmp_mfma_common.h, "bf16x6": fp32-accurate, 6 x 32 instead of 8 x 64 matrix-pipe
+// cycles per 16 contracted rows).  Wave (p, q) contracts exactly one 16-row k-group per tile (rows 16q ..): a lane's
+// fragment is 8 consecutive ROWS (8h ..) of one column, read as 8 ds_read_b32 down the fp32 tile and split in registers
+// (the same 48 LDS reads per wave and tile as the f32 form's 8 k-steps x 6 operands).
+template <int MODE, int H, bool X6>
 __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
   constexpr bool TYPED = MODE == ATB_TYPED, REL = MODE == ATB_REL;   // REL: the control flow of the rows variant over gathered rows
   // two tile buffers (Zs | Ds, 2 x 32 x (H+4) floats each) = 67584 bytes at H = 128; emit() reuses the first H*H floats for the total
@@ -170,6 +174,42 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     std::integral_constant<int, PH ^ 1> other;
     const float *zp = &smem[PH * kBuf + (16 * qw + 8 * h) * kStride + (H / 2) * pw + li];
     const float *dp = zp + kTile - (H / 2) * pw;
+    if (X6) {
+      // fragments: element j of lane (li, h) = row 16q + 8h + j of the operand's column; the staging of tile k+1, the
+      // row requests of tile k+3 and the id requests of tile k+4 are spread between the NI x NJ blocks' MFMAs
+      Split8 fa[NI];
+      auto frag = [&](const float *col, Split8 &f) {            // two rows at a time: no eight-float temporary
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          split_pair(col[(2 * t) * kStride], col[(2 * t + 1) * kStride], f.hi.u[t], f.mid.u[t], f.lo.u[t]);
+      };
+#pragma unroll
+      for (int i = 0; i < NI; ++i) frag(zp + 32 * i, fa[i]);
+      int act = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        Split8 fb;                                           // one B fragment at a time: NI + 1 fragments live, not NI + NJ
+        frag(dp + 32 * j, fb);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef DMP_ATB_DBG
+          if (!(DMP_ATB_DBG & 4))
+#endif
+          acc[i][j] = mfma_x6(fa[i], fb, acc[i][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          // 2 NL actions over NI * NJ blocks (H = 128: 8 actions, 8 blocks; H = 64: 4 actions, 2 blocks)
+          constexpr int kPerBlock = (2 * NL + NI * NJ - 1) / (NI * NJ);
+#pragma unroll
+          for (int u = 0; u < kPerBlock; ++u, ++act) {
+            if (act < NL) stage_row(other, act < NL ? act : 0);
+            else if (act < 2 * NL) load_row(other, act < 2 * NL ? act - NL : 0);
+          }
+        }
+      }
+      load_ids(k + 4);
+      return;
+    }
     float a[NI], b[NJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i) a[i] = zp[32 * i];
@@ -332,9 +372,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   }
 }
 
-template <int MODE, int H = 128>
+template <int MODE, int H = 128, bool X6 = true>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  atb_body<MODE, H>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
+  atb_body<MODE, H, X6>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
 }
 
 // Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
@@ -343,8 +383,8 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
 // start, LDS reduction, 64 KB partial) are paid 512 times in total instead of 512 times per product.
 constexpr int kMaxAtbJobs = DMP_ATB_MAX_JOBS;
 struct AtbJobs { AtbArgs job[kMaxAtbJobs]; };
-template <int H>
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS, H>(t.job[blockIdx.y], 0, 0); }
+template <int H, bool X6 = true>
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS, H, X6>(t.job[blockIdx.y], 0, 0); }
 
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
 constexpr int kAtbLdsBytes64 = 2 * 2 * kSub * 68 * 4;         // H = 64: 34816
@@ -363,8 +403,18 @@ inline bool opt_in_lds(const void *kernel, int bytes, bool (&done)[kMaxDevices])
 }
 template <int MODE, int H = 128>
 bool lds_ready() {
-  static bool done[kMaxDevices] = {};
-  return opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H>), atb_lds_bytes(H), done);
+  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {};
+  return opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, true>), atb_lds_bytes(H), done) &&
+         opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, false>), atb_lds_bytes(H), done_exact);
+}
+// The bf16x6 form is used where it was measured faster: the class-typed product (its rows are gathered, the f32 form's
+// matrix work is what bounds it: 172 -> 148 us at bench.py's shape).  The plain-row forms stay on the f32-input MFMA: the
+// gated rows variant needs 42 more registers than the file has at H = 128 (spills: 168 -> 179 us), the multi-job launch of
+// the node side came out equal (138 vs 140 us).
+template <int MODE, int H>
+void launch_atb(const AtbArgs &a, dim3 grid, hipStream_t st) {
+  if (g_exact_fp32 || MODE != ATB_TYPED) atb_k<MODE, H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
+  else atb_k<MODE, H, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
 }
 
 inline unsigned atb_blocks(int64_t tiles, int H = 128) {
@@ -385,10 +435,12 @@ static unsigned rows_blocks(int64_t rows, int M, int N, int H) {
 
 template <int H>
 static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStream_t st) {
-  static bool done[kMaxDevices] = {};
-  if (!opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H>), atb_lds_bytes(H), done)) return DMP_ERR_HIP;
+  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {};
+  if (!opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, true>), atb_lds_bytes(H), done) ||
+      !opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, false>), atb_lds_bytes(H), done_exact))
+    return DMP_ERR_HIP;
   const dim3 grid(rows_blocks(rows, H, H * (num_jobs > 0 ? num_jobs : 1), H), (unsigned)num_jobs);
-  atb_jobs_k<H><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
+  atb_jobs_k<H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);   // f32-input MFMA (see launch_atb)
   return check_launch();
 }
 
@@ -421,10 +473,10 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
   a.ldp = wide ? 2 * H : H;
   if (H == 128) {
     if (!lds_ready<ATB_TYPED, 128>()) return DMP_ERR_HIP;
-    atb_k<ATB_TYPED, 128><<<atb_blocks(tiles_bound), kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
+    launch_atb<ATB_TYPED, 128>(a, dim3(atb_blocks(tiles_bound)), (hipStream_t)stream);
   } else {
     if (!lds_ready<ATB_TYPED, 64>()) return DMP_ERR_HIP;
-    atb_k<ATB_TYPED, 64><<<atb_blocks(tiles_bound, 64), kGroupThreads, atb_lds_bytes(64), (hipStream_t)stream>>>(a);
+    launch_atb<ATB_TYPED, 64>(a, dim3(atb_blocks(tiles_bound, 64)), (hipStream_t)stream);
   }
   return check_launch();
 }
@@ -479,7 +531,7 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
   a.plain_tiles = (int)tiles; a.pT = partial; a.pstride = 128 * 128; a.ldp = 128;
   if (!lds_ready<ATB_REL, 128>()) return DMP_ERR_HIP;
   const dim3 grid((unsigned)dmp_rel_atb_blocks(num_rels), (unsigned)num_rels);
-  atb_k<ATB_REL, 128><<<grid, kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
+  launch_atb<ATB_REL, 128>(a, grid, (hipStream_t)stream);
   return check_launch();
 }
 
@@ -500,10 +552,10 @@ int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, con
   const dim3 grid(rows_blocks(rows, M, N, H), (unsigned)((M / H) * (N / H)));
   if (H == 128) {
     if (!lds_ready<ATB_ROWS, 128>()) return DMP_ERR_HIP;
-    atb_k<ATB_ROWS, 128><<<grid, kGroupThreads, atb_lds_bytes(128), (hipStream_t)stream>>>(a);
+    launch_atb<ATB_ROWS, 128>(a, grid, (hipStream_t)stream);
   } else {
     if (!lds_ready<ATB_ROWS, 64>()) return DMP_ERR_HIP;
-    atb_k<ATB_ROWS, 64><<<grid, kGroupThreads, atb_lds_bytes(64), (hipStream_t)stream>>>(a);
+    launch_atb<ATB_ROWS, 64>(a, grid, (hipStream_t)stream);
   }
   return check_launch();
 }

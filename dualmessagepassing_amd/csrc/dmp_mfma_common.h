@@ -100,6 +100,8 @@ __device__ __forceinline__ void sbuf_store4(float4 v, srsrc_t r, int row, uint32
   u.x = __float_as_int(v.x); u.y = __float_as_int(v.y); u.z = __float_as_int(v.z); u.w = __float_as_int(v.w);
   llvm_struct_buffer_store_v4i32(u, r, row, (int)col_bytes, 0, 0);
 }
+extern int g_exact_fp32;      // development switch (dmp_dev_set_exact_fp32): 1 = f32-input MFMA instead of the bf16x6 products
+
 inline bool stride_ok(int64_t ld_floats) { return ld_floats > 0 && ld_floats * 4 <= 16383; }
 
 // bytes of a tile of `rows` rows with leading dimension ld (floats) of which `cols` are touched

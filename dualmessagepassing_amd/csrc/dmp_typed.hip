@@ -466,7 +466,6 @@ inline unsigned typed_blocks(int64_t tiles_bound, int per_cu = 3) {
 }
 inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32) - 8192; }
 
-int g_exact_fp32 = 0;   // development switch: 1 = the f32-input MFMA (exact fp32) instead of the bf16x6 products
 
 template <int EPI, int H>
 inline void launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st) {
@@ -478,6 +477,8 @@ inline void launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st
 
 }  // namespace
 }  // namespace dmp
+
+namespace dmp { int g_exact_fp32 = 0; }   // development switch: 1 = the f32-input MFMA (exact fp32) instead of the bf16x6 products
 
 using namespace dmp;
 
