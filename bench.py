@@ -228,20 +228,62 @@ def build_step(cfg, shard, device, world=1):
     return step, model
 
 
-def pmc_traffic(n_rows, n_edges, H):
-    """HBM bytes per launch of the scatter-add kernel from the committed rocprofv3 PMC run
-    (profiles/r02_pmc_seg_sum2.json, entry in_csr: FETCH_SIZE and WRITE_SIZE collected in separate passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950).
-    Returned only if that run was taken at this launch shape; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_seg_sum2.json")
+PROFILE_ROUND = "r03"
+SEG_IN = "seg_sum_vec<32, true, false, true, 0>"       # flag-split segment sum over the CSR by destination (forward)
+SEG_INC = "seg_sum_vec<32, true, false, true, 1>"      # the same kernel over the incidence CSR (backward of the edge gathers)
+
+
+def committed_profile(n_rows, n_edges, H):
+    """What the committed profiles of this round say about the two scatter-add launches, if they were taken at this launch
+    shape (``profiles/<round>_profile_meta.json``): the rocprofv3 ``--kernel-trace --stats`` average duration
+    (``<round>_bench_kernel_stats.csv``) and the PMC traffic per launch (``<round>_pmc_h128.json``: FETCH_SIZE and WRITE_SIZE
+    from separate ``--pmc`` passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950).
+    -> {"in": {"avg_us_rocprof", "traffic"}, "inc": {...}}; entries are None where nothing matches."""
+    out = {"in": {"avg_us_rocprof": None, "traffic": None}, "inc": {"avg_us_rocprof": None, "traffic": None}}
+    base = os.path.join(ROOT, "profiles", PROFILE_ROUND)
     try:
-        with open(path) as f:
-            d = json.load(f)["in_csr"]
-        if d.get("rows") == n_rows and d.get("edges") == n_edges and d.get("H") == H:
-            return d["hbm_bytes_per_launch"]
+        with open(base + "_profile_meta.json") as f:
+            meta = json.load(f)
+        if (meta.get("rows"), meta.get("edges"), meta.get("H")) != (n_rows, n_edges, H):
+            return out
+    except (OSError, ValueError):
+        return out
+    try:
+        import csv
+        with open(base + "_bench_kernel_stats.csv") as f:
+            for r in csv.DictReader(f):
+                for tag, name in (("in", SEG_IN), ("inc", SEG_INC)):
+                    if name in r["Name"]:
+                        out[tag]["avg_us_rocprof"] = round(float(r["AverageNs"]) / 1e3, 2)
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    try:
+        with open(base + "_pmc_h128.json") as f:
+            k = json.load(f)["kernels"]
+        for tag, name in (("in", SEG_IN), ("inc", SEG_INC)):
+            if name in k:
+                out[tag]["traffic"] = int(k[name]["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
+def seg_roofline(k, what, own_bytes, survey_bytes, prof):
+    """``roofline`` object of one scatter-add launch kind: achieved = the kernel's own algorithmic bytes / its HIP-event
+    time inside the timed steps; beside it the same with SURVEY §8(d)'s byte count, and both over the committed rocprof
+    duration."""
+    us = k["avg_us"]
+    r = {"bound": "hbm", "kernel": what, "achieved": round(own_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": prof["traffic"],
+         "bytes_per_launch": int(own_bytes), "avg_us": round(us, 2), "launches": k["launches"],
+         "bytes_survey": int(survey_bytes), "frac_survey_bytes": round(survey_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+         "avg_us_rocprof": prof["avg_us_rocprof"]}
+    if prof["avg_us_rocprof"]:
+        r["frac_rocprof"] = round(own_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
+        r["frac_survey_bytes_rocprof"] = round(survey_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
+    if prof["traffic"]:
+        r["traffic_over_algorithmic"] = round(prof["traffic"] / own_bytes, 4)
+    return r
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
@@ -258,13 +300,17 @@ def mfma_rooflines(kern, H, E):
         base = name.split("[", 1)[0]
         if base in products and ("E=%d" % E in name or "R=%d" % E in name):
             tf = products[base] * 2.0 * E * H * H / (v["avg_us"] * 1e-6) / 1e12
+            # round 3: the class-typed kernels multiply on the bf16 pipe (three bf16 pieces per fp32 operand, six piece
+            # products: fp32-accurate, 6/16 of the f32 form's matrix cycles); "tflops" stays the fp32-equivalent rate and
+            # "frac" its ratio to the F32-input MFMA peak, for comparison with earlier rounds -- their bound is HBM
+            x6 = base in ("edge_fwd_typed", "bwd_z_typed", "atb_typed")
             out[base] = {"avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                         "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS}
+                         "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "arithmetic": "bf16x6 (fp32-accurate)" if x6 else "f32 MFMA"}
             # flops per byte fall with H (2 H^2 flops against ~8-12 H bytes per row): at H = 64 the same kernels sit nearer
             # the HBM roof than the MFMA roof -- both fractions are reported, "bound" names the nearer roof
             hbm_frac = v["gbps"] / 8000.0
             out[base]["hbm_gbps"], out[base]["hbm_frac"] = round(v["gbps"], 1), round(hbm_frac, 4)
-            if hbm_frac > out[base]["frac"]:
+            if hbm_frac > out[base]["frac"] or x6:
                 out[base]["bound"] = "hbm"
     return out
 
@@ -567,14 +613,17 @@ def main():
         uN = mb * (cfg["p_nodes"] + cfg["g_nodes"])
         uE = mb * 2 * (cfg["p_edges"] + cfg["g_edges"])
         key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
-        roof = None
-        if key in kern:
-            k = kern[key]
-            roof = {"bound": "hbm", "kernel": "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
-                                              "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
-                    "achieved": round(k["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(k["gbps"] / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(uN, uE, H),
-                    "bytes_per_launch": int(k["bytes"]), "avg_us": round(k["avg_us"], 2), "launches": k["launches"]}
+        key_inc = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)
+        prof = committed_profile(uN, uE, H)
+        roof = roof_bwd = None
+        if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
+            roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
+                                "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key]["bytes"],
+                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"])
+        if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
+            roof_bwd = seg_roofline(kern[key_inc], "dmp::seg_sum_vec<32,split,remap,incidence> (gradient of the gathered node projections: "
+                                    "N=%d rows, 2 x E=%d incidence entries, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
+                                    4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"])
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -587,6 +636,7 @@ def main():
             "step_ms_max": round(per_step_ms[-1], 3) if per_step_ms else None,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 storage and accumulation; dense products on the f32-input MFMA except the class-typed edge kernels (fp32 operands as 3 bf16 pieces, 6 piece products per partial product: fp32-accurate, parity tests at the fp32 tolerances; DMP_EXACT_FP32=1 switches them back)",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
                                    "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, ScalarFilter, "
                                    "3 shared DMPLayers, SumPredictNet node+edge heads), activation %s, hid=%d, fp32; a new batch "
@@ -601,6 +651,7 @@ def main():
                                   "eager steps after the timed region)") if graphed else "eager launches",
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
+            "roofline_bwd": roof_bwd,
             # the compulsory traffic of the sparse kernels alone (seg-sum / gather-combine, forward + backward,
             # pattern + target, all layers) over the END-TO-END step time -- how far the whole step is from a sparse-only
             # HBM roofline (the step also runs 460 GFLOP of dense fp32 products, which bound it)

@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import on_input_device
 from .compgcn import CompGCNRepMixin
+from .embed import materialize
 from .constants import REVFLAG
 from .graph import as_batched
 from .dmpnn import DMPNNRepMixin
@@ -28,7 +29,28 @@ from .rgnn import RGCNRepMixin, RGINRepMixin
 
 
 class OutputDict(OrderedDict):
-    """Ordered mapping with attribute access (container.py:14-100, the part callers use)."""
+    """Ordered mapping with attribute access (container.py:14-100, the part callers use).  An entry may be deferred
+    (``embed.DeferredEmbedding``: the target embeddings, which the joint rep-net pass does not need as tensors): it becomes
+    its tensor the first time it is read, by whatever accessor."""
+
+    def _resolve(self, k, v):
+        from .embed import DeferredEmbedding
+        if isinstance(v, DeferredEmbedding):
+            v = v.materialize()
+            OrderedDict.__setitem__(self, k, v)
+        return v
+
+    def __getitem__(self, k):
+        return self._resolve(k, OrderedDict.__getitem__(self, k))
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
 
     def __getattr__(self, k):
         try:
@@ -661,6 +683,21 @@ class GraphAdjModelV2(BaseModel):
     def get_graph_emb(self, g_enc):
         return self._emb(self.g_emb_net, g_enc)
 
+    def get_graph_emb_deferred(self, g_enc):
+        """``get_graph_emb`` whose label embeddings (float encodings @ table, no id terms) are left uncomputed
+        (``embed.DeferredEmbedding``): the joint rep-net pass makes its gated input rows from the encodings themselves."""
+        from .embed import DeferredEmbedding, Embedding
+        net = self.g_emb_net
+        if self.add_node_id or self.add_edge_id or not th.is_grad_enabled():
+            return self.get_graph_emb(g_enc)
+        out = []
+        for key in ("vl", "el"):
+            enc, m = g_enc[key], net[key]
+            ok = (isinstance(m, Embedding) and th.is_tensor(enc) and enc.dtype == th.float32 and enc.dim() == 2 and enc.is_cuda
+                  and enc.size(-1) == m.num_embeddings)
+            out.append(DeferredEmbedding(m, enc) if ok else m(enc))
+        return tuple(out)
+
     def get_subiso_pred(self, p_v_rep, p_v_mask, p_e_rep, p_e_mask, g_v_rep, g_v_mask, g_e_rep, g_e_mask):
         v_pred_c = v_pred_w = e_pred_c = e_pred_w = None
         if self.node_pred:
@@ -746,7 +783,7 @@ class GraphAdjModelV2(BaseModel):
         p_enc = self.get_pattern_enc(pattern)
         p_v_emb, p_e_emb = self.get_pattern_emb(p_enc)
         g_enc = self.get_graph_enc(graph)
-        g_v_emb, g_e_emb = self.get_graph_emb(g_enc)
+        g_v_emb, g_e_emb = self.get_graph_emb_deferred(g_enc) if hasattr(self, "get_joint_rep") else self.get_graph_emb(g_enc)
         joint = None
         pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         if hasattr(self, "get_joint_rep"):
@@ -768,6 +805,7 @@ class GraphAdjModelV2(BaseModel):
                 union_sums = joint[6]
         else:
             p_v_rep, p_e_rep = self.get_pattern_rep(pattern, p_v_emb, p_e_emb)
+            g_v_emb, g_e_emb = materialize(g_v_emb), materialize(g_e_emb)
             g_v_rep, g_e_rep = self.get_graph_rep(graph, g_v_emb, g_e_emb, v_gate=vl_gate, e_gate=el_gate)
 
         if self.pred_with_deg:

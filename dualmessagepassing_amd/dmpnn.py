@@ -337,6 +337,8 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     pattern, graph = as_batched(pattern), as_batched(graph)
     if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
         return None
+    from .embed import materialize
+    p_v_emb, p_e_emb = materialize(p_v_emb), materialize(p_e_emb)       # the pattern side is small: plain tensors
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
     v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
     e = _gate_concat(p_e_emb, g_e_emb, e_gate)
@@ -379,17 +381,23 @@ class _GateConcat(th.autograd.Function):
     def forward(ctx, p, g, gate, enc=None, W=None):
         from . import _lib
         lib = _lib.load()
-        _lib.require_gpu(p, g)
-        p, g = p.contiguous(), g.contiguous()
+        if g is None:                      # the embedding itself was never materialised (embed.DeferredEmbedding): rows from enc
+            _lib.require_gpu(p, enc)
+            p = p.contiguous()
+            rows_g = enc.size(0)
+        else:
+            _lib.require_gpu(p, g)
+            p, g = p.contiguous(), g.contiguous()
+            rows_g = g.size(0)
         n, H = p.size(0), p.size(1)
-        out = th.empty((n + g.size(0), H), dtype=p.dtype, device=p.device)
+        out = th.empty((n + rows_g, H), dtype=p.dtype, device=p.device)
         out[:n].copy_(p)
-        if g.size(0) > 0:
+        if rows_g > 0:
             gt = None if gate is None else gate.reshape(-1).contiguous()
             if enc is not None:   # the gated rows from the K inputs per row instead of from the [rows, H] embedding
                 Wd = W.detach()
                 _lib.check(lib.dmp_smallk_embed_gate(_lib.ptr(enc), enc.stride(0), enc.size(1), _lib.ptr(Wd), Wd.stride(0),
-                                                     _lib.ptr(gt), g.size(0), H, _lib.ptr(out[n:]), H, _lib.stream_ptr()),
+                                                     _lib.ptr(gt), rows_g, H, _lib.ptr(out[n:]), H, _lib.stream_ptr()),
                            "dmp_smallk_embed_gate")
             else:
                 _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
@@ -414,7 +422,14 @@ class _GateConcat(th.autograd.Function):
 def _gate_concat(p, g, gate):
     """``_GateConcat`` with the embedding-aware backward when ``g`` is a plain label embedding."""
     from . import fused
+    from .embed import DeferredEmbedding
     src = getattr(g, "_dmp_src", None)
+    if isinstance(g, DeferredEmbedding):
+        if (g.dim() == 2 and g.size(1) in fused.MFMA_WIDTHS and g.is_cuda and g.dtype == th.float32 and src[0].dtype == th.float32
+                and src[0].size(1) <= fused.SMALLK_MAX and src[0].stride(1) == 1 and src[1].requires_grad and th.is_grad_enabled()):
+            return _GateConcat.apply(p, None, gate, src[0], src[1])
+        g = g.materialize()
+        src = getattr(g, "_dmp_src", None)
     if (src is not None and g.dim() == 2 and g.size(1) in fused.MFMA_WIDTHS and g.is_cuda and g.dtype == th.float32
             and src[0].dtype == th.float32 and src[0].size(1) <= fused.SMALLK_MAX and src[0].size(0) == g.size(0)
             and src[0].stride(1) == 1 and src[1].requires_grad and th.is_grad_enabled()):

@@ -76,4 +76,5 @@ def test_micro_batched_step_equals_whole_batch_step(gpu):
         flats.append(step.sync.flat.clone())
     scale = max(1.0, float(flats[0].abs().max()))
     assert float((flats[0] - flats[1]).abs().max()) <= 2e-5 * scale
-    assert bench.micro_batches_for(dict(bench.CFG)) == 1 and bench.micro_batches_for(dict(bench.CFG4)) == 4
+    # round 3: rows are addressed by index, so config 4's 8.4 M-row shard is one pass too (4 in round 2: 32-bit byte offsets)
+    assert bench.micro_batches_for(dict(bench.CFG)) == 1 and bench.micro_batches_for(dict(bench.CFG4)) == 1
