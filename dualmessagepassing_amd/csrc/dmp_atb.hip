@@ -51,7 +51,8 @@ enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
 // cycles per 16 contracted rows).  Wave (p, q) contracts exactly one 16-row k-group per tile (rows 16q ..): a lane's
 // fragment is 8 consecutive ROWS (8h ..) of one column, read as 8 ds_read_b32 down the fp32 tile and split in registers
 // (the same 48 LDS reads per wave and tile as the f32 form's 8 k-steps x 6 operands).
-template <int MODE, int H, bool X6>
+// BIG: an operand array of 4 GiB or more: rows through 64-bit pointers (dmp_mfma_common.h).
+template <int MODE, int H, bool X6, bool BIG = false>
 __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
   constexpr bool TYPED = MODE == ATB_TYPED, REL = MODE == ATB_REL;   // REL: the control flow of the rows variant over gathered rows
   // two tile buffers (Zs | Ds, 2 x 32 x (H+4) floats each) = 67584 bytes at H = 128; emit() reuses the first H*H floats for the total
@@ -130,9 +131,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     if ((DMP_ATB_DBG & 2) && warm) return;
 #endif
     const bool ok = id_rows[m] >= 0;
-    preZ[S][m] = sbuf_load4(rs_Z, id_rows[m], colA);          // -1: out of range, zeros
+    preZ[S][m] = row_load4<BIG>(rs_Z, p.Z + H * ya, p.ldz, id_rows[m], colA);          // -1: zeros
     const int idD = REL ? id_rowsD[m] : id_rows[m];
-    preD[S][m] = sbuf_load4(rs_D, ok ? idD : -1, colA);
+    preD[S][m] = row_load4<BIG>(rs_D, p.D + H * yb, p.ldd, ok ? idD : -1, colA);
     if (REL) preG[S][m] = sc_rows[m];
     if (MODE == ATB_ROWS) {
       preG[S][m] = 1.f;
@@ -372,9 +373,9 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   }
 }
 
-template <int MODE, int H = 128, bool X6 = true>
+template <int MODE, int H = 128, bool X6 = true, bool BIG = false>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  atb_body<MODE, H, X6>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
+  atb_body<MODE, H, X6, BIG>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
 }
 
 // Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
@@ -403,9 +404,10 @@ inline bool opt_in_lds(const void *kernel, int bytes, bool (&done)[kMaxDevices])
 }
 template <int MODE, int H = 128>
 bool lds_ready() {
-  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {};
+  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {}, done_big[kMaxDevices] = {};
   return opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, true>), atb_lds_bytes(H), done) &&
-         opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, false>), atb_lds_bytes(H), done_exact);
+         opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, false>), atb_lds_bytes(H), done_exact) &&
+         opt_in_lds(reinterpret_cast<const void *>(&atb_k<MODE, H, MODE == ATB_TYPED, true>), atb_lds_bytes(H), done_big);
 }
 // The bf16x6 form is used where it was measured faster: the class-typed product (its rows are gathered, the f32 form's
 // matrix work is what bounds it: 172 -> 148 us at bench.py's shape).  The plain-row forms stay on the f32-input MFMA: the
@@ -413,6 +415,10 @@ bool lds_ready() {
 // the node side came out equal (138 vs 140 us).
 template <int MODE, int H>
 void launch_atb(const AtbArgs &a, dim3 grid, hipStream_t st) {
+  if (!fits4g(a.E, a.ldz) || !fits4g(a.E, a.ldd)) {           // an operand of 4 GiB or more: 64-bit row addressing
+    atb_k<MODE, H, MODE == ATB_TYPED, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
+    return;
+  }
   if (g_exact_fp32 || MODE != ATB_TYPED) atb_k<MODE, H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
   else atb_k<MODE, H, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
 }
@@ -500,7 +506,8 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
     if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial) ||
         (j.partial_colsum && !aligned16(j.partial_colsum)))
       return DMP_ERR_UNSUPPORTED;
-    if (!stride_ok(j.lda) || !stride_ok(j.ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+    if (!stride_ok(j.lda) || !stride_ok(j.ldb) || rows > 0x7fffffff - kSub || !fits4g(rows, j.lda) || !fits4g(rows, j.ldb))
+      return DMP_ERR_UNSUPPORTED;      // the multi-job launch has no 64-bit form (node-side operands)
     AtbArgs a{};
     a.Z = j.A; a.ldz = j.lda; a.D = j.B; a.ldd = j.ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
     a.gate = j.gate; a.pT = j.partial; a.pstride = j.partial_stride; a.ldp = j.ldp; a.pCS = j.partial_colsum;

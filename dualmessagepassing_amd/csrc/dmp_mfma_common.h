@@ -74,10 +74,12 @@ __device__ __forceinline__ f32x16 mfma_x6(const Split8 &a, const Split8 &b, f32x
 }
 
 // ---- structured buffer access: address = base + index * stride + offset, the descriptor holds the row stride in bytes
-// (<= 16383) and the number of rows; a row index beyond it (e.g. -1) reads zeros / drops the store.  Rows addressed by
-// INDEX reach any array size (a 32-bit byte offset ends at 4 GiB: one [E, 128] fp32 array of BASELINE config 4's shard
-// is 4.3 GB) and need no multiply.  clang has no builtin for the indexed form: the LLVM intrinsics are declared by name
-// (waitcnt tracking stays with the compiler, unlike inline asm).
+// (<= 16383) and the number of rows; a row index beyond it (e.g. -1) reads zeros / drops the store, and no multiply is
+// needed.  It does NOT reach beyond 4 GiB: index * stride is formed modulo 2^32 on gfx950 (scripts/sbuf_probe.hip: row
+// 8,388,608 of a 512-byte-stride array reads row 0), although the range check is on the index.  Arrays of 4 GiB and
+// more (one [E, 128] fp32 array of BASELINE config 4's shard is 4.3 GB) take the kernels' BIG instantiations, which
+// address rows through 64-bit pointers (row_load4 / row_store4 below).  clang has no builtin for the indexed form: the
+// LLVM intrinsics are declared by name (waitcnt tracking stays with the compiler, unlike inline asm).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ i32x4 llvm_struct_buffer_load_v4i32(i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4i32");
 __device__ void llvm_struct_buffer_store_v4i32(i32x4 data, i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.store.v4i32");
@@ -101,6 +103,21 @@ __device__ __forceinline__ void sbuf_store4(float4 v, srsrc_t r, int row, uint32
   llvm_struct_buffer_store_v4i32(u, r, row, (int)col_bytes, 0, 0);
 }
 extern int g_exact_fp32;      // development switch (dmp_dev_set_exact_fp32): 1 = f32-input MFMA instead of the bf16x6 products
+
+// Row access of the kernels that gather / scatter rows by id.  !BIG: structured descriptor (above).  BIG: 64-bit pointer
+// arithmetic; a negative row (padding slot, past the end) reads row 0 and returns zeros / skips the store.
+template <bool BIG>
+__device__ __forceinline__ float4 row_load4(srsrc_t rs, const float *base, int64_t ld, int row, uint32_t col_bytes) {
+  if (!BIG) return sbuf_load4(rs, row, col_bytes);
+  const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)(row < 0 ? 0 : row) * ld + (col_bytes >> 2));
+  return row < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
+}
+template <bool BIG>
+__device__ __forceinline__ void row_store4(float4 v, srsrc_t rs, float *base, int64_t ld, int row, uint32_t col_bytes) {
+  if (!BIG) { sbuf_store4(v, rs, row, col_bytes); return; }
+  if (row >= 0) *reinterpret_cast<float4 *>(base + (int64_t)row * ld + (col_bytes >> 2)) = v;
+}
+inline bool fits4g(int64_t rows, int64_t ld_floats) { return rows * ld_floats * 4 < ((int64_t)1 << 32) - 65536; }
 
 inline bool stride_ok(int64_t ld_floats) { return ld_floats > 0 && ld_floats * 4 <= 16383; }
 

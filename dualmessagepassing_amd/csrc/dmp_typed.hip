@@ -60,7 +60,8 @@ template <int H> struct TypedGeom {
 #ifndef DMP_TY_VAR
 #define DMP_TY_VAR 0      // development knobs (scripts/build_dbg.sh): 16 TEPI_DZ pipelined under X6, 32 three waves per SIMD under X6
 #endif
-template <int EPI, int H, bool X6>
+// BIG: the streamed / scattered row arrays (A, C, R) are 4 GiB or larger: rows through 64-bit pointers (dmp_mfma_common.h).
+template <int EPI, int H, bool X6, bool BIG = false>
 __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) ? 2 : 3) void mfma_typed(TypedArgs p) {
   constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
   constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
 #ifdef DMP_TY_DBG
     if ((DMP_TY_DBG & 8) && warm) return;
 #endif
-    pre[S][m] = sbuf_load4(rs_A, id_rows[m], colA);           // id -1 (padding, past the end): out of range, zeros
+    pre[S][m] = row_load4<BIG>(rs_A, p.A, p.lda, id_rows[m], colA);   // id -1 (padding, past the end): zeros
   };
   auto load_row_scalars = [&](auto set) {
     constexpr int S = decltype(set)::value;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
       g1[k] = sbuf_load4(rs_T, (int)rowB[par][rr], col4 + kRowBytes);
     } else {
       g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4 + (rowB[par][rr] ? kRowBytes : 0u));
-      g1[k] = sbuf_load4(rs_R, (int)rowR[par][rr], col4);
+      g1[k] = row_load4<BIG>(rs_R, p.R, p.ldr, (int)rowR[par][rr], col4);
     }
   };
   // X6: the tile's product on the bf16 pipe.  Per 16-deep k-group g: six MFMAs on the three piece fragments of A (this
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
 #ifdef DMP_TY_DBG
       if ((DMP_TY_DBG & 4) && v.x != 123.456f) continue;
 #endif
-      sbuf_store4(v, rs_C, (int)rowC[par][rr], col4);       // padding rows: index out of range, dropped
+      row_store4<BIG>(v, rs_C, p.C, p.ldc, (int)rowC[par][rr], col4);   // padding rows: dropped
       // X6: this chunk's operand registers are free -- request the NEXT tile's rows into them now (its row offsets were
       // staged during this tile's MFMA phase, before the barrier).  With the short bf16 MFMA phase, operands requested at
       // the start of their own tile's phase (the f32 form) arrive after the epilogue wants them: this way they have a
@@ -468,11 +469,18 @@ inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)
 
 
 template <int EPI, int H>
-inline void launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st) {
+inline int launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st) {
+  const bool big = !fits4g(p.rowsA, p.lda) || !fits4g(p.E, p.ldc) || (p.R && !fits4g(p.rmap ? p.rowsR : p.E, p.ldr));
+  if (big) {                      // 64-bit row addressing: the bf16x6 form only
+    if (g_exact_fp32) return DMP_ERR_UNSUPPORTED;
+    mfma_typed<EPI, H, true, true><<<typed_blocks(tiles_bound, H == 128 ? 2 : 4), TypedGeom<H>::kThreads, 0, st>>>(p);
+    return check_launch();
+  }
   if (g_exact_fp32)
     mfma_typed<EPI, H, false><<<typed_blocks(tiles_bound, H == 128 ? 3 : TypedGeom<64>::kPerCU), TypedGeom<H>::kThreads, 0, st>>>(p);
   else
     mfma_typed<EPI, H, true><<<typed_blocks(tiles_bound, H == 128 ? ((DMP_TY_VAR & 32) ? 3 : 2) : 4), TypedGeom<H>::kThreads, 0, st>>>(p);
+  return check_launch();
 }
 
 }  // namespace
@@ -507,9 +515,8 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   p.A = Z; p.lda = ldz; p.W = W; p.ldw = ldw; p.transposed = 0; p.C = H1; p.ldc = ldh; p.E = E;
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = selA; p.idxB = selB; p.T = P; p.ldt = ldp; p.num_nodes = num_nodes; p.bias = bias; p.slope = slope;
-  if (H == 128) launch_typed<TEPI_EDGE, 128>(p, tiles_bound, (hipStream_t)stream);
-  else launch_typed<TEPI_EDGE, 64>(p, tiles_bound, (hipStream_t)stream);
-  return check_launch();
+  return H == 128 ? launch_typed<TEPI_EDGE, 128>(p, tiles_bound, (hipStream_t)stream)
+                  : launch_typed<TEPI_EDGE, 64>(p, tiles_bound, (hipStream_t)stream);
 }
 
 int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
@@ -535,9 +542,8 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : H;
   p.s0 = s0; p.s1 = s1; p.rmap = base_map; p.rowsR = base_rows;
-  if (H == 128) launch_typed<TEPI_DZ, 128>(p, tiles_bound, (hipStream_t)stream);
-  else launch_typed<TEPI_DZ, 64>(p, tiles_bound, (hipStream_t)stream);
-  return check_launch();
+  return H == 128 ? launch_typed<TEPI_DZ, 128>(p, tiles_bound, (hipStream_t)stream)
+                  : launch_typed<TEPI_DZ, 64>(p, tiles_bound, (hipStream_t)stream);
 }
 
 int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, int64_t ldw, int num_rels, int w_transposed,
@@ -555,8 +561,7 @@ int dmp_rel_gemm(const float *A, int64_t lda, int64_t rows_a, const float *W, in
   p.C = C; p.ldc = ldc; p.E = rows_c; p.slot_edge = slot_row; p.slot_arow = slot_arow;
   p.tile_scale = reinterpret_cast<const float *>(tile_type); p.num_tiles = num_tiles;
   p.idxA = reinterpret_cast<const int32_t *>(row_scale);
-  launch_typed<TEPI_REL, 128>(p, tiles_bound, (hipStream_t)stream);
-  return check_launch();
+  return launch_typed<TEPI_REL, 128>(p, tiles_bound, (hipStream_t)stream);
 }
 
 }  // extern "C"

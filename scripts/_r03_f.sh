@@ -1,8 +1,2 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O; cd $R
-timeout 1500 python -m pytest tests -q -m gpu -x > $O/pytest.log 2>&1; tail -12 $O/pytest.log
-timeout 300 python3 bench.py --no-cpu-baseline > $O/bench.json 2> $O/err1.txt
-python3 - <<PY
-import json
-d=json.load(open("$O/bench.json"))
-print(d["value"], d["ms_per_step"], d["step_ms_median"], {k.split("[")[0]:v["avg_us"] for k,v in d["kernels"].items() if v["avg_us"]>50})
-PY
+timeout 1800 python -m pytest tests -q -m gpu > $O/pytest.log 2>&1; tail -8 $O/pytest.log
