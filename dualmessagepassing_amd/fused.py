@@ -311,6 +311,32 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
     return out
 
 
+USE_EDGE_CHAIN = True   # H = 128: edge_fwd_typed + out_fwd as one launch (csrc/dmp_chain.hip)
+
+
+def edge_chain_ok(index, H):
+    lib = _lib.load()
+    return USE_EDGE_CHAIN and H == 128 and typed_ok(index, H) and not lib.dmp_dev_get_exact_fp32()
+
+
+def edge_chain_fwd(z, Wes, P, ldp, bias, coef, index, eW2t, eb2, gate, residual, slope=0.0):
+    """``(H1e, zn)``: ``edge_fwd_typed`` and ``out_fwd_mfma`` of the edge side in ONE launch -- the H1 tile goes from the first
+    product's epilogue to the second product through LDS (three passes over [E, H] arrays instead of six)."""
+    lib = _lib.load()
+    E, H = z.shape
+    h1 = torch.empty((E, H), dtype=torch.float32, device=z.device)
+    zn = torch.empty((E, H), dtype=torch.float32, device=z.device)
+    Wes = Wes.contiguous()
+    sel_a, sel_b, _ = index.edge_select(coef)
+    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    with _lib.timed("edge_chain_fwd[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 16 * E):
+        check(lib.dmp_edge_chain_fwd(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias), ptr(sel_a), ptr(sel_b),
+                                     ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, E, H, slope, ptr(h1), H,
+                                     ptr(eW2t), eW2t.size(1), ptr(eb2), ptr(gate), int(bool(residual)), ptr(zn), H, stream_ptr()),
+              "dmp_edge_chain_fwd")
+    return h1, zn
+
+
 def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
@@ -655,7 +681,9 @@ class _FusedDMPLayer(torch.autograd.Function):
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        if typed_ok(index, H):
+        if edge_chain_ok(index, H) and eW2t is not None:
+            H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
+        elif typed_ok(index, H):
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         elif mfma_ok(index, H):

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 44
+#define DMP_ABI_VERSION 45
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -886,6 +886,21 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup
  * held half an iteration apart by barriers).  Process-wide; results are identical. */
 void dmp_dev_set_mfma_variant(int variant);
+
+/*
+ * The edge chain forward as ONE launch (csrc/dmp_chain.hip; H = 128, bf16x6 products):
+ *     H1[e] = act(Z[e] W_g + P[selA e, 0:H] - P[selB e, H:2H] + bias)           = dmp_edge_fwd_typed
+ *     Zn[e] = (residual ? Z[e] : 0) + gate[e] (H1[e] W2^T + b2)                 = dmp_out_fwd_fused
+ * (dmpnn.py:142-156 + 262-275).  Two wave groups of a 512-thread workgroup hold the two weight panels; the H1 tile goes
+ * from the first product's epilogue to the second product through LDS: Z is read once, H1 and Zn are written once (three
+ * passes over [E, H] arrays instead of six).  W2t: the second Linear's weight transposed ([in, out], leading dim ldw2).
+ * Arguments otherwise as the two functions it replaces.  DMP_ERR_UNSUPPORTED with the exact-fp32 switch on.
+ */
+int dmp_edge_chain_fwd(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp, int64_t num_nodes,
+                       const float *bias, const int32_t *selA, const int32_t *selB, const int32_t *slot_edge,
+                       const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t num_edges, int H,
+                       float slope, float *H1, int64_t ldh, const float *W2t, int64_t ldw2, const float *b2, const float *gate,
+                       int residual, float *Zn, int64_t ldo, void *stream);
 
 /*
  * Node-side row-block products on the bf16 matrix pipe ("bf16x6": fp32 operands as three bf16 pieces, six piece products
