@@ -473,6 +473,78 @@ inline unsigned grid_for(int64_t R, int G) {
   return (unsigned)(nb < kMaxPartials ? (nb > 0 ? nb : 1) : kMaxPartials);
 }
 
+
+// The last layer's activation backward with its pooled companion (see dmp_relu_bwd_gathered_colsum): one pass over the saved
+// activation H1 [R, H] walks the pooling index's chunks (vptr / vent: <= 64 rows of one graph each, (row << 1) | flag) and
+// produces  dPre[r] = act'(H1[r]) (.) (gate[r] table[rowmap[r]])  (rowmap < 0: zero),  the column sums of dPre, AND the
+// gated per-chunk sums  Qc[c] = [sum_{flag=0} gate[r] H1[r] | sum_{flag=1} ...]  that the weight gradient of the layer's
+// second Linear needs (dW2 = T^T Q): H1 is read once for both.  A G-lane group per chunk, four rows in flight.
+struct PoolBwdArgs {
+  const float *h1; int64_t ldh; const float *table; int64_t ldt; const int32_t *rowmap; const float *gate;
+  const int32_t *vptr, *vent; int64_t V; int H; float slope;
+  float *dpre; int64_t ldp; float *qc; float *partial;
+};
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void pool_relu_bwd_k(PoolBwdArgs p) {
+  constexpr int GPB = kBlock / G;
+  __shared__ float4 red[kBlock];
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int c = lane * 4;
+  const bool act = c < p.H;
+  float4 cs = zero4();
+  for (int64_t ch = (int64_t)blockIdx.x * GPB + grp; ch < p.V; ch += (int64_t)gridDim.x * GPB) {
+    const int beg = p.vptr[ch], end = p.vptr[ch + 1];
+    float4 q0 = zero4(), q1 = zero4();
+    for (int base = beg; base < end; base += kU) {
+      // per-row scalars of up to kU rows: lanes 0..kU-1 fetch, then broadcast
+      int ent = 0, mi = -1;
+      float gt = 0.f;
+      if (lane < kU && base + lane < end) {
+        ent = p.vent[base + lane];
+        const int r = ent >> 1;
+        mi = p.rowmap[r];
+        gt = p.gate ? p.gate[r] : 1.f;
+      }
+      float4 hv[kU], uv[kU];
+      int en[kU], tr[kU];
+      float sc[kU];
+#pragma unroll
+      for (int k = 0; k < kU; ++k) { en[k] = __shfl(ent, k, G); tr[k] = __shfl(mi, k, G); sc[k] = __shfl(gt, k, G); }
+      if (!act) continue;
+#pragma unroll
+      for (int k = 0; k < kU; ++k)
+        if (base + k < end) {
+          hv[k] = ld4(p.h1 + (int64_t)(en[k] >> 1) * p.ldh + c);
+          uv[k] = tr[k] >= 0 ? ld4(p.table + (int64_t)tr[k] * p.ldt + c) : zero4();
+        }
+#pragma unroll
+      for (int k = 0; k < kU; ++k)
+        if (base + k < end) {
+          const float4 u = mul4(uv[k], sc[k]);
+          const float4 t = make_float4(act_bwd(hv[k].x, u.x, p.slope), act_bwd(hv[k].y, u.y, p.slope),
+                                       act_bwd(hv[k].z, u.z, p.slope), act_bwd(hv[k].w, u.w, p.slope));
+          st4(p.dpre + (int64_t)(en[k] >> 1) * p.ldp + c, t);
+          add4(cs, t);
+          const float4 gh = mul4(hv[k], sc[k]);
+          if (en[k] & 1) add4(q1, gh); else add4(q0, gh);
+        }
+    }
+    if (act) {
+      st4(p.qc + ch * 2 * p.H + c, q0);
+      st4(p.qc + ch * 2 * p.H + p.H + c, q1);
+    }
+  }
+  red[threadIdx.x] = cs;
+  __syncthreads();
+  if (grp == 0 && act) {
+    float4 t = red[lane];
+#pragma unroll
+    for (int g = 1; g < GPB; ++g) add4(t, red[g * G + lane]);
+    st4(p.partial + (int64_t)blockIdx.x * p.H + c, t);
+  }
+}
+
 template <int OP>
 int launch_rowop(const RowArgs &p, hipStream_t st) {
   const int g = group_lanes(p.H);
@@ -554,6 +626,32 @@ int dmp_relu_bwd_gathered_colsum(const float *table, int64_t ldt, const int32_t 
   if (!vec_shape_ok(H, ldt, lda, ldp) || !ok16(table) || !ok16(act) || !ok16(dPre) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
   RowArgs p{table, ldt, act, lda, gate, rowmap, dPre, ldp, partial, R, H, slope};
   return launch_rowop<OP_RELU_BWD_GATHER_CS>(p, (hipStream_t)stream);
+}
+
+int64_t dmp_pool_relu_bwd_blocks(int64_t num_chunks, int H) {
+  const int g = group_lanes(H);
+  const int64_t nb = (num_chunks + kBlock / g - 1) / (kBlock / g);
+  return nb < 1 ? 1 : (nb < kMaxPartials ? nb : kMaxPartials);
+}
+
+int dmp_pool_relu_bwd(const float *h1, int64_t ldh, const float *table, int64_t ldt, const int32_t *rowmap, const float *gate,
+                      const int32_t *vptr, const int32_t *vent, int64_t num_chunks, int64_t R, int H, float slope, float *dPre,
+                      int64_t ldp, float *chunk_sums, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && num_chunks >= 0 && H > 0 && partial);
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  const int64_t nb = dmp_pool_relu_bwd_blocks(num_chunks, H);
+  if (R == 0 || num_chunks == 0)
+    return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)H * (size_t)nb, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(h1 && table && rowmap && vptr && vent && dPre && chunk_sums && ldh >= H && ldt >= H && ldp >= H);
+  if (!vec_shape_ok(H, ldh, ldt, ldp) || H > 256 || !ok16(h1) || !ok16(table) || !ok16(dPre) || !ok16(chunk_sums) || !ok16(partial))
+    return DMP_ERR_UNSUPPORTED;
+  PoolBwdArgs p{h1, ldh, table, ldt, rowmap, gate, vptr, vent, num_chunks, H, slope, dPre, ldp, chunk_sums, partial};
+  hipStream_t st = (hipStream_t)stream;
+  const int g = group_lanes(H);
+  if (g == 16) pool_relu_bwd_k<16><<<(unsigned)nb, kBlock, 0, st>>>(p);
+  else if (g == 32) pool_relu_bwd_k<32><<<(unsigned)nb, kBlock, 0, st>>>(p);
+  else pool_relu_bwd_k<64><<<(unsigned)nb, kBlock, 0, st>>>(p);
+  return check_launch();
 }
 
 int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef, const int32_t *dst,

@@ -155,6 +155,23 @@ def relu_bwd_gathered_colsum(table, rowmap, gate, act, slope=0.0):
     return out, reduce_partials(part)
 
 
+def pool_relu_bwd(table, rowmap, gate, act, pool, slope=0.0):
+    """``relu_bwd_gathered_colsum`` and ``pool_rows(act, pool, gate)`` in ONE pass over ``act`` (``dmp_pool_relu_bwd``):
+    -> (dPre [R, H], column sums of dPre [H], Q [graphs, 2H] = gated per-graph sums of ``act`` by flag)."""
+    lib = _lib.load()
+    R, H = act.shape
+    V = pool.num_chunks
+    nb = int(lib.dmp_pool_relu_bwd_blocks(V, H))
+    part = torch.empty((nb, H), dtype=torch.float32, device=act.device)
+    out = torch.empty((R, H), dtype=torch.float32, device=act.device)
+    qc = torch.empty((V, 2 * H), dtype=torch.float32, device=act.device)
+    with _lib.timed("pool_relu_bwd[H=%d,R=%d]", (H, R), 8 * H * R + 12 * R + 8 * H * V):
+        check(lib.dmp_pool_relu_bwd(ptr(act), act.stride(0), ptr(table), table.stride(0), ptr(rowmap), ptr(gate), ptr(pool.vptr),
+                                    ptr(pool.vent), V, R, H, slope, ptr(out), H, ptr(qc), ptr(part), stream_ptr()), "dmp_pool_relu_bwd")
+    Q = ops.seg_sum_raw(qc, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
+    return out, reduce_partials(part), Q
+
+
 def pool_rows(x, pool, weight=None):
     """Per-graph sums of the rows of ``x`` over ``pool`` (``ops.PoolIndex``): [G, H], or [G, 2H] = [non-flagged | flagged] when
     the index carries a flag; ``weight`` [rows]: a row scale.  Raw (no autograd): two launches of the segment-sum kernel."""
@@ -744,8 +761,12 @@ class _FusedDMPLayer(torch.autograd.Function):
             mfma, typed = mfma_ok(ix, H), typed_ok(ix, H)
             if lazy is not None:
                 T, emap, ep = lazy
-                dG, dbe = relu_bwd_gathered_colsum(T @ eW2, emap, ctx.e_gate, H1e, slope)     # dG is dPre
-                Q = pool_rows(H1e, ep, ctx.e_gate)[:, :H]
+                if H % 4 == 0 and H <= 256:
+                    dG, dbe, Q = pool_relu_bwd(T @ eW2, emap, ctx.e_gate, H1e, ep, slope)       # dG is dPre; one pass over H1e
+                    Q = Q[:, :H]
+                else:
+                    dG, dbe = relu_bwd_gathered_colsum(T @ eW2, emap, ctx.e_gate, H1e, slope)
+                    Q = pool_rows(H1e, ep, ctx.e_gate)[:, :H]
                 dW2e = T.t() @ Q
                 # gated row counts per graph through the vector kernel (4 equal columns: the scalar path is slow)
                 g4 = (ctx.e_gate if ctx.e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))

@@ -495,16 +495,22 @@ class PoolIndex:
         # one-entry memo: a fixed graph's relation types (UNC trains on ONE graph) meet this with the same tensor every step,
         # and the construction is ~25 small launches (sort, scans, searches)
         memo = cls.__dict__.get("_keys_memo")
-        ident = (keys.data_ptr(), keys._version, int(keys.numel()), str(keys.device), str(keys.dtype), int(num_keys))
-        if memo is not None and memo[0] == ident:
-            return memo[1]
+        if memo is None:
+            memo = cls._keys_memo = []
+        ident = (keys.data_ptr(), keys._version, int(keys.numel()), tuple(keys.stride()), str(keys.device), str(keys.dtype), int(num_keys))
+        for i, m in enumerate(memo):
+            if m[0] == ident:
+                if i:
+                    memo.insert(0, memo.pop(i))             # most recently used first
+                return m[1]
         keys_in = keys
         keys = keys.view(-1).to(torch.int64)
         skeys, order = torch.sort(keys, stable=True)
         # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
         marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))
         out = cls(marks[1:] - marks[:-1], order=order, seg=keys, num_rows=int(keys.numel()))
-        cls._keys_memo = (ident, out, keys_in)            # the tensor is kept alive: its address stays unique
+        memo.insert(0, (ident, out, keys_in))             # the tensor is kept alive: its address stays unique
+        del memo[4:]                                        # a few entries: a step meets two or three different key tensors
         return out
 
     def __init__(self, sizes, flag=None, order=None, seg=None, num_rows=None):

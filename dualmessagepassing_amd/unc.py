@@ -274,8 +274,15 @@ class TrainModel(nn.Module):
                     # model.py:703-707 selects the rows with ``emb[mask]`` (a host sync for the row count and a
                     # serialised indexing backward); same mean as a mask-weighted sum over all rows
                     num_rels = self.w_relation.size(0)
-                    mask = (edge_type < num_rels).to(emb.dtype).unsqueeze(1)
-                    emb_diff = self.edge_fc(emb) - ops.take_rows_small_table(self.w_relation, edge_type.clamp(max=num_rels - 1))
+                    # per edge-type tensor: the mask and the clamped types (a fresh clamp result every step would also
+                    # defeat the keyed pool index's memo: ~25 launches of sorting per step on the one fixed graph)
+                    ck = (edge_type.data_ptr(), edge_type._version, int(edge_type.numel()), emb.dtype)
+                    cached = getattr(self, "_etype_cache", None)
+                    if cached is None or cached[0] != ck:
+                        cached = self._etype_cache = (ck, (edge_type < num_rels).to(emb.dtype).unsqueeze(1),
+                                                      edge_type.clamp(max=num_rels - 1), edge_type)
+                    mask, clamped = cached[1], cached[2]
+                    emb_diff = self.edge_fc(emb) - ops.take_rows_small_table(self.w_relation, clamped)
                     reg = reg + (torch.pow(emb_diff, 2) * mask).sum() / (mask.sum() * emb_diff.size(1))
         return reg
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 45
+#define DMP_ABI_VERSION 46
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -482,6 +482,17 @@ int dmp_relu_bwd_colsum(const float *dH, int64_t ldh, const float *act, int64_t 
  */
 int dmp_relu_bwd_gathered_colsum(const float *table, int64_t ldt, const int32_t *rowmap, const float *gate, const float *act,
                                  int64_t lda, int64_t R, int H, float slope, float *dPre, int64_t ldp, float *partial, void *stream);
+
+/*
+ * The same pass ALSO producing the gated per-chunk sums of the saved activation over a pooling index (ops.PoolIndex: vptr
+ * [num_chunks + 1], vent [R] = (row << 1) | flag, chunks of <= 64 rows of one graph): chunk_sums [num_chunks, 2H] =
+ * [sum_{flag = 0} gate[r] act[r] | sum_{flag = 1} ...] -- the operand of dW2 = T^T Q for a layer whose output gradient is a
+ * per-graph vector -- so that the activation is read once for both.  partial: [dmp_pool_relu_bwd_blocks(...), H].
+ */
+int64_t dmp_pool_relu_bwd_blocks(int64_t num_chunks, int H);
+int dmp_pool_relu_bwd(const float *act, int64_t lda, const float *table, int64_t ldt, const int32_t *rowmap, const float *gate,
+                      const int32_t *vptr, const int32_t *vent, int64_t num_chunks, int64_t R, int H, float slope, float *dPre,
+                      int64_t ldp, float *chunk_sums, float *partial, void *stream);
 
 /* dmp_edge_combine_bwd_g + column sums of dY (gradient of ebias, dmpnn.py:148-149). */
 int dmp_edge_combine_bwd_g_colsum(const float *dY, int64_t ldy, const float *coef,

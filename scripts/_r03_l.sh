@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03l; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x -k "edge_chain" > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullmodel.py tests/test_gpu_pins_r2.py -q -m gpu -x > $O/pytest.log 2>&1; tail -6 $O/pytest.log
 timeout 300 python3 bench.py --no-cpu-baseline > $O/bench.json 2> $O/err1.txt; tail -2 $O/err1.txt
 python3 - <<PY
 import json

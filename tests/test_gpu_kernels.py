@@ -1012,3 +1012,39 @@ def test_edge_chain_forward_equals_the_two_kernels(rows, gated, residual, slope,
     assert float((zn.double() - z64).abs().max()) <= 2e-5 * max(1.0, float(z64.abs().max()))
     h1b, znb = fused.edge_chain_fwd(z, wes, xp[:, h:], 3 * h, bias, coef, ix, w2.t().contiguous(), b2, gate, residual, slope)
     assert th.equal(h1, h1b) and th.equal(zn, znb)                        # repeatable
+
+
+@pytest.mark.parametrize("h", [128, 64, 20])
+@pytest.mark.parametrize("flagged,gated", [(True, True), (False, False), (True, False)])
+def test_pooled_activation_backward_equals_its_two_passes(h, flagged, gated, gpu):
+    """dmp_pool_relu_bwd (the last layer's activation backward from a per-graph gradient table AND the gated per-graph sums
+    of the saved activation, one pass) against dmp_relu_bwd_gathered_colsum + the pooled segment sums, and fp64."""
+    from dualmessagepassing_amd import fused, ops
+    gen = th.Generator().manual_seed(h + 3)
+    sizes = th.tensor([5, 0, 64, 65, 130, 1, 700, 33], dtype=th.int64)
+    R, G = int(sizes.sum()), sizes.numel()
+    flag = (th.rand(R, generator=gen) < 0.5) if flagged else None
+    pool = ops.PoolIndex(sizes.to(gpu), None if flag is None else flag.to(gpu), num_rows=R)
+    act = th.randn(R, h, generator=gen).to(gpu)
+    table = th.randn(G, h, generator=gen).to(gpu)
+    gate = (th.rand(R, generator=gen) < 0.7).float().to(gpu) if gated else None
+    rowmap = fused.pool_rowmap(pool)
+    slope = 1 / 5.5
+    d_ref, cs_ref = fused.relu_bwd_gathered_colsum(table, rowmap, gate, act, slope)
+    q_ref = fused.pool_rows(act, pool, gate)
+    d, cs, q = fused.pool_relu_bwd(table, rowmap, gate, act, pool, slope)
+    assert th.equal(d, d_ref)
+    assert th.allclose(cs, cs_ref, rtol=1e-5, atol=1e-4)
+    w = q_ref.size(1)                                                     # [G, 2H] with a flag, [G, H] without
+    assert q.size(1) == 2 * h and th.allclose(q[:, :w], q_ref, rtol=1e-5, atol=1e-4)
+    if not flagged:
+        assert float(q[:, h:].abs().max()) == 0.0
+    # fp64
+    seg = th.repeat_interleave(th.arange(G), sizes).to(gpu)
+    g64 = th.ones(R, device=gpu, dtype=th.float64) if gate is None else gate.double()
+    live = th.ones(R, device=gpu, dtype=th.bool) if flag is None else ~flag.to(gpu)
+    u = th.where(live.view(-1, 1), g64.view(-1, 1) * table.double()[seg], th.zeros(1, device=gpu, dtype=th.float64))
+    want = th.where(act.double() > 0, u, slope * u)
+    assert float((d.double() - want).abs().max()) <= 1e-6
+    q64 = th.zeros(G, h, device=gpu, dtype=th.float64).index_add_(0, seg[live], (g64.view(-1, 1) * act.double())[live])
+    assert float((q[:, :h].double() - q64).abs().max()) <= 1e-4
