@@ -76,6 +76,11 @@ SIGNATURES = {
     "dmp_smallk_atb_blocks": (c_i64, [c_i64]),
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
+    "dmp_l0_pack": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "dmp_l0_edge_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,
+                                c_ptr, c_i64, c_ptr]),
+    "dmp_l0_bwd_w_blocks": (c_i64, [c_i64]),
+    "dmp_l0_bwd_w": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_scalar_filter_gates": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_csr_pair_workspace_words": (ctypes.c_size_t, [c_i64]),
     "dmp_csr_build_pair": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -145,7 +150,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 46
+ABI_VERSION = 47
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

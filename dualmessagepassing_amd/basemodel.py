@@ -793,9 +793,10 @@ class GraphAdjModelV2(BaseModel):
             if pooled and not self.pred_with_enc and not self.pred_with_deg and (self.node_pred or self.edge_pred):
                 pools = (_pool_index_union(pattern, graph, "node") if self.node_pred else None,
                          _pool_index_union(pattern, graph, "edge", skip_rev) if self.edge_pred else None)
-            try:
+            import inspect
+            if "pools" in inspect.signature(self.get_joint_rep).parameters:
                 joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate, pools=pools)
-            except TypeError:       # a rep-net without the pooled form
+            else:                   # a rep-net without the pooled form
                 joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
         v_union = e_union = None
         union_sums = (None, None)

@@ -1,0 +1,367 @@
+// The FIRST layer of a rep-net whose edge input rows are a label embedding (gfx950).
+//
+// The reference embeds the multi-hot edge label code ([E, K], K ~ 10) into hid_dim and hands the [E, H] rows to the first
+// DMPLayer (basemodel.py:1393-1420, dmpnn.py:111-156).  Every product of that layer with its edge input is therefore a
+// product with  z0 = enc W  of rank K:
+//     z0 (A + c B)                    = enc (W A) + c enc (W B)                  (the edge pre-activation)
+//     sum over a node's edges of z0   = (sum of enc) W                           (the node aggregate)
+//     z0^T [dPre | c dPre]            = W^T (enc^T [dPre | c dPre])              (the class-typed weight gradient)
+//     enc^T dz0                       = enc^T dzn + (enc^T [dPre | c dPre]) [A|B]^T + (sum of enc)^T dS   (the embedding's gradient)
+// so the E-row MFMA kernels of the general layer (one product forward, two backward, a scatter-add and the [E, H] input
+// gradient) become two streaming passes with K fused multiply-adds per element: no matrix pipe, no class tiles, the
+// edge rows in their natural (graph-major) order.
+//
+//   l0_pack_k        encU[r] = r < n ? enc_p[r] : gate[r-n] enc_g[r-n]   zero-padded to Kpad (16-byte rows for the segment sum)
+//   l0_edge_fwd_k    H1[r]   = act(encU[r] MA + c_r encU[r] MB + P[a_r, 0:H] - P[b_r, H:2H] + bias)
+//   l0_bwd_w_k       partial sums of  encU^T dPre,  (c encU)^T dPre,  encU^T dZn
+//
+// A wave owns a row at a time (H / 64 values per lane); the row's K inputs, its coefficient and its two node rows are
+// wave-uniform: one vector load, v_readlane, SGPR operands (as smallk_* in dmp_fused.hip).
+#include "dmp_common.h"
+
+namespace dmp {
+namespace {
+
+#ifndef DMP_L0_VAR
+#define DMP_L0_VAR 0                  // development knobs (scripts/build_dbg.sh, scripts/mb_l0.py)
+#endif
+constexpr int kL0K = 16;              // widest label code
+constexpr int kL0Rows = 4;            // rows in flight per wave
+constexpr int kFwdRows = 4;
+constexpr bool kBwdWide = !(DMP_L0_VAR & 256);          // four accumulators per combine round (-6 us at E = 549 k)
+constexpr bool kBwdNoPrefetch = !(DMP_L0_VAR & 512);    // 8 rows per batch, no second register set (-5 us)
+constexpr int kL0MaxPartials = 1024;
+constexpr int kLaneCoef = 16, kLaneA = 17, kLaneB = 18;   // lanes that fetch the row's coefficient and node rows
+
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <int VW> struct Vec;
+template <> struct Vec<1> { float v; };
+template <> struct Vec<2> { f2_t v; };
+__device__ __forceinline__ Vec<1> vload1(const float *row, int lane) { Vec<1> o; o.v = row[lane]; return o; }
+template <int VW> __device__ __forceinline__ Vec<VW> vload(const float *row, int lane) {
+  Vec<VW> o;
+  if constexpr (VW == 2) o.v = *reinterpret_cast<const f2_t *>(row + lane * 2);
+  else o.v = row[lane];
+  return o;
+}
+template <int VW> __device__ __forceinline__ void vstore(float *row, int lane, const Vec<VW> &o) {
+  if constexpr (VW == 2) *reinterpret_cast<f2_t *>(row + lane * 2) = o.v;
+  else row[lane] = o.v;
+}
+template <int VW> __device__ __forceinline__ Vec<VW> vzero() {
+  Vec<VW> o;
+  if constexpr (VW == 2) o.v = f2_t{0.f, 0.f};
+  else o.v = 0.f;
+  return o;
+}
+// acc += s * v with the wave-uniform s straight from an SGPR.  H = 128: both of the lane's columns in ONE packed FMA (the
+// scalar is the low half of an SGPR pair, read for both halves: op_sel_hi 0) -- these kernels are VALU-bound otherwise.
+__device__ __forceinline__ void fmac_s(Vec<2> &acc, float s, const Vec<2> &v) {
+  const unsigned long long sp = (unsigned long long)__builtin_bit_cast(unsigned, s);
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc.v) : "s"(sp), "v"(v.v));
+}
+__device__ __forceinline__ void fmac_s(Vec<1> &acc, float s, const Vec<1> &v) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc.v) : "s"(s), "v"(v.v));
+}
+template <int VW> __device__ __forceinline__ float &at(Vec<VW> &a, int c) {
+  if constexpr (VW == 2) return reinterpret_cast<float *>(&a.v)[c];
+  else return a.v;
+}
+template <int VW> __device__ __forceinline__ float at(const Vec<VW> &a, int c) {
+  if constexpr (VW == 2) return a.v[c];
+  else return a.v;
+}
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int lane_i(float v, int l) { return __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l); }
+
+struct PackArgs {
+  const float *encp; int64_t ldp; int64_t n; const float *encg; int64_t ldg; const float *gate; int64_t rows_g;
+  int K, Kpad; float *out;
+};
+
+__global__ __launch_bounds__(kBlock) void l0_pack_k(const PackArgs p) {
+  const int64_t total = (p.n + p.rows_g) * p.Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / p.Kpad;
+    const int c = (int)(i - r * p.Kpad);
+    float v = 0.f;
+    if (c < p.K) {
+      if (r < p.n) v = p.encp[r * p.ldp + c];
+      else { v = p.encg[(r - p.n) * p.ldg + c]; if (p.gate) v *= p.gate[r - p.n]; }
+    }
+    p.out[i] = v;
+  }
+}
+
+struct FwdArgs {
+  const float *enc; int64_t lde;           // [R, >= K] gated label codes of the union's edge rows
+  const float *M; int64_t ldm;             // [K, 2H] = W [A | B]
+  const float *P; int64_t ldp;             // node projections [N, >= 2H]: P[a, 0:H] - P[b, H:2H]
+  const float *bias; const float *coef_e; const int32_t *sel_a, *sel_b;
+  int64_t R; float slope; float *out; int64_t ldo;
+};
+
+template <int K, int VW>
+__global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
+  constexpr int WPB = kBlock / 64, kRows = kFwdRows, H = 64 * VW;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  Vec<VW> ma[K], mb[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { ma[k] = vload<VW>(p.M + k * p.ldm, lane); mb[k] = vload<VW>(p.M + k * p.ldm + H, lane); }
+  Vec<VW> bias = vzero<VW>();
+  if (p.bias) bias = vload<VW>(p.bias, lane);
+  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  // the row's scalars: lanes 0..K-1 its label code, three more lanes its coefficient and its two node rows -- one load
+  // instruction per row, each lane with its own base and step
+  const char *base = reinterpret_cast<const char *>(p.enc + lane);
+  int64_t step = p.lde * 4;
+  if (lane == kLaneCoef) { base = reinterpret_cast<const char *>(p.coef_e); step = 4; }
+  if (lane == kLaneA) { base = reinterpret_cast<const char *>(p.sel_a); step = 4; }
+  if (lane == kLaneB) { base = reinterpret_cast<const char *>(p.sel_b); step = 4; }
+  const bool on = lane < K || (lane >= kLaneCoef && lane <= kLaneB);
+  auto fetch = [&](int64_t r0, float (&mm)[kRows]) {
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t r = r0 + u;                             // wave-uniform
+      float m = 0.f;                                        // rows past the end: code 0, node rows 0 (loaded, never stored)
+      if (on && r < p.R) m = *reinterpret_cast<const float *>(base + r * step);
+      mm[u] = m;
+    }
+  };
+  // Measured (scripts/mb_l0.py, knob builds): 135 us at E = 549 k, of which the scalars + epilogue 25, the FMAs 30, the
+  // stores 32-49 and the two gathers 30-41 -- they add up whatever the occupancy (3..6 waves per SIMD), the rows per batch,
+  // a two-batch software pipeline with the gathers issued ahead of the stores, contiguous row runs per workgroup or an
+  // XCD-aware order (all within 135-145 us); PMC: 281 MB written, 260 MB fetched (the node rows 3 x).
+  float mine[kRows], next[kRows];
+  int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
+  if (r0 < p.R) fetch(r0, mine);
+  for (; r0 < p.R; r0 += stride) {
+    fetch(r0 + stride, next);                               // the next batch's scalars: a dependent round trip less per batch
+    Vec<VW> pa[kRows], pb[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      pa[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneA) * p.ldp, lane);
+      pb[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneB) * p.ldp + H, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      if (r0 + u >= p.R) break;
+      const float cf = lane_f(mine[u], kLaneCoef);
+      Vec<VW> g0 = vzero<VW>(), g1 = vzero<VW>();
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float x = lane_f(mine[u], k);
+        fmac_s(g0, x, ma[k]);
+        fmac_s(g1, x, mb[k]);
+      }
+      Vec<VW> t;
+#pragma unroll
+      for (int c = 0; c < VW; ++c) {
+        // ((G0 + coef G1) + (P[a] - P[b])) + bias: the order of the general layer (dmp_agg.hip::edge_combine)
+        float y = at<VW>(g1, c) * cf;
+        y += at<VW>(g0, c);
+        y += at<VW>(pa[u], c) - at<VW>(pb[u], c);
+        y += at<VW>(bias, c);
+        at<VW>(t, c) = act_fwd(y, p.slope);
+      }
+      vstore<VW>(p.out + (r0 + u) * p.ldo, lane, t);
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) mine[u] = next[u];
+  }
+}
+
+struct BwdArgs {
+  const float *enc; int64_t lde; const float *coef_e;
+  const float *dPre; int64_t ldd;          // [R, >= H]
+  const float *dZn; int64_t ldz;           // [R, >= H] or NULL (no residual connection)
+  int64_t R; float *partial;               // [blocks, K, (dZn ? 3 : 2) * H]
+};
+
+template <int K, int VW, bool RES>
+__global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
+  constexpr int WPB = kBlock / 64, kRows = kBwdNoPrefetch ? 8 : kL0Rows, H = 64 * VW, NACC = (RES ? 3 : 2) * K;
+  __shared__ float red4[(kBwdWide ? kBlock / 64 : 1) * kBlock * VW];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  Vec<VW> acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = vzero<VW>();
+  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  Vec<VW> d[kRows], dn[kRows], z[RES ? kRows : 1], zn[RES ? kRows : 1];
+  float mine[kRows], minen[kRows];
+  auto load_batch = [&](int64_t r0, Vec<VW> (&dd)[kRows], Vec<VW> (&zz)[RES ? kRows : 1], float (&mm)[kRows]) {
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t r = r0 + u;                             // wave-uniform
+      const bool ok = r < p.R;
+      if (ok) {
+        dd[u] = vload<VW>(p.dPre + r * p.ldd, lane);
+        if (RES) zz[u] = vload<VW>(p.dZn + r * p.ldz, lane);
+      } else {
+        dd[u] = vzero<VW>();
+        if (RES) zz[u] = vzero<VW>();
+      }
+      const float *src = lane == kLaneCoef ? p.coef_e + r : p.enc + r * p.lde + lane;
+      float m = 0.f;
+      if (ok && (lane < K || lane == kLaneCoef)) m = *src;
+      mm[u] = m;
+    }
+  };
+  int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
+  if (!kBwdNoPrefetch && r0 < p.R) load_batch(r0, d, z, mine);
+  for (; r0 < p.R; r0 += stride) {
+    if (kBwdNoPrefetch) load_batch(r0, d, z, mine);
+    else load_batch(r0 + stride, dn, zn, minen);            // rows past the end read as zeros
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const float cf = lane_f(mine[u], kLaneCoef);
+      Vec<VW> cd;                                           // c_r dPre[r]: (c enc)^T dPre = enc^T (c dPre), one scalar per input
+#pragma unroll
+      for (int c = 0; c < VW; ++c) at<VW>(cd, c) = at<VW>(d[u], c) * cf;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float x = lane_f(mine[u], k);
+        fmac_s(acc[k], x, d[u]);
+        fmac_s(acc[K + k], x, cd);
+        if (RES) fmac_s(acc[2 * K + k], x, z[u]);
+      }
+    }
+    if (!kBwdNoPrefetch) {
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) { d[u] = dn[u]; mine[u] = minen[u]; if (RES) z[u] = zn[u]; }
+    }
+  }
+  // fixed-order combine of the 4 waves.  kBwdWide: four accumulators per round, wave w sums (and stores) the w-th of them.
+  if constexpr (kBwdWide) {
+#pragma unroll
+    for (int k0 = 0; k0 < NACC; k0 += WPB) {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j)
+        if (k0 + j < NACC) {
+#pragma unroll
+          for (int c = 0; c < VW; ++c) red4[((j * WPB + wave) * 64 + lane) * VW + c] = at<VW>(acc[k0 + j], c);
+        }
+      __syncthreads();
+      const int k = k0 + wave;
+      if (k < NACC) {
+        Vec<VW> t;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) {
+          float a = red4[((wave * WPB) * 64 + lane) * VW + c];
+#pragma unroll
+          for (int w = 1; w < WPB; ++w) a += red4[((wave * WPB + w) * 64 + lane) * VW + c];
+          at<VW>(t, c) = a;
+        }
+        vstore<VW>(p.partial + ((int64_t)blockIdx.x * NACC + (k % K) * (NACC / K) + k / K) * H, lane, t);
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+#pragma unroll
+      for (int c = 0; c < VW; ++c) red4[threadIdx.x * VW + c] = at<VW>(acc[k], c);
+      __syncthreads();
+      if (wave == 0) {
+        Vec<VW> t;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) {
+          float a = red4[lane * VW + c];
+#pragma unroll
+          for (int w = 1; w < WPB; ++w) a += red4[(w * 64 + lane) * VW + c];
+          at<VW>(t, c) = a;
+        }
+        // row k of the [K, (2 or 3) H] result: [enc^T dPre | (c enc)^T dPre | enc^T dZn]
+        vstore<VW>(p.partial + ((int64_t)blockIdx.x * NACC + (k % K) * (NACC / K) + k / K) * H, lane, t);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+inline unsigned l0_blocks(int64_t R, int64_t cap) {
+  const int64_t chunk = (int64_t)(kBlock / 64) * (kBwdNoPrefetch ? 8 : kL0Rows), nb = (R + chunk - 1) / chunk;
+  return (unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap);
+}
+
+template <int K>
+void launch_fwd(const FwdArgs &p, int H, hipStream_t st) {
+  const int64_t chunk = (int64_t)(kBlock / 64) * kFwdRows, want = (p.R + chunk - 1) / chunk;
+  const unsigned nb = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
+  if (H == 128) l0_edge_fwd_k<K, 2><<<nb, kBlock, 0, st>>>(p);
+  else l0_edge_fwd_k<K, 1><<<nb, kBlock, 0, st>>>(p);
+}
+
+template <int K>
+void launch_bwd(const BwdArgs &p, int H, hipStream_t st) {
+  const unsigned nb = l0_blocks(p.R, kL0MaxPartials);
+  if (H == 128) { if (p.dZn) l0_bwd_w_k<K, 2, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 2, false><<<nb, kBlock, 0, st>>>(p); }
+  else { if (p.dZn) l0_bwd_w_k<K, 1, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 1, false><<<nb, kBlock, 0, st>>>(p); }
+}
+
+#define L0_SWITCH(K, CALL)                                                                          \
+  switch (K) {                                                                                      \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; \
+    case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; default: CALL(16); break; \
+  }
+
+inline bool al8(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; }
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
+                int64_t rows_g, int K, int Kpad, float *out, void *stream) {
+  if (rows_p < 0 || rows_g < 0 || K <= 0 || Kpad < K || !out) return DMP_ERR_BAD_ARG;
+  if ((rows_p > 0 && (!enc_p || ldp < K)) || (rows_g > 0 && (!enc_g || ldg < K))) return DMP_ERR_BAD_ARG;
+  const int64_t total = (rows_p + rows_g) * Kpad;
+  if (total == 0) return DMP_OK;
+  const int64_t nb = (total + kBlock - 1) / kBlock;
+  PackArgs p{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, out};
+  l0_pack_k<<<(unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
+int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                    const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t R, int H,
+                    float slope, float *out, int64_t ldo, void *stream) {
+  if (R < 0 || K <= 0) return DMP_ERR_BAD_ARG;
+  if ((H != 128 && H != 64) || K > kL0K || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return DMP_OK;
+  if (!enc || !M || !P || !coef_e || !sel_a || !sel_b || !out || lde < K || ldm < 2 * H || ldp < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
+  if (ldm % 2 || ldp % 2 || ldo % 2 || !al8(M) || !al8(P) || !al8(out) || !al8(bias)) return DMP_ERR_UNSUPPORTED;
+  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo};
+  hipStream_t st = (hipStream_t)stream;
+#define L0_CALL(KK) launch_fwd<KK>(p, H, st)
+  L0_SWITCH(K, L0_CALL)
+#undef L0_CALL
+  return check_launch();
+}
+
+int64_t dmp_l0_bwd_w_blocks(int64_t rows) { return (int64_t)l0_blocks(rows, kL0MaxPartials); }
+
+int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
+                 int64_t ldz, int64_t R, int H, float *partial, void *stream) {
+  if (R < 0 || K <= 0 || !partial) return DMP_ERR_BAD_ARG;
+  if ((H != 128 && H != 64) || K > kL0K) return DMP_ERR_UNSUPPORTED;
+  const int nacc = (dZn ? 3 : 2) * K;
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)nacc * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!enc || !coef_e || !dPre || lde < K || ldd < H || (dZn && ldz < H)) return DMP_ERR_BAD_ARG;
+  if (ldd % 2 || ldz % 2 || !al8(dPre) || !al8(dZn) || !al8(partial)) return DMP_ERR_UNSUPPORTED;
+  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial};
+  hipStream_t st = (hipStream_t)stream;
+#define L0_CALL(KK) launch_bwd<KK>(p, H, st)
+  L0_SWITCH(K, L0_CALL)
+#undef L0_CALL
+  return check_launch();
+}
+
+}  // extern "C"

@@ -192,7 +192,7 @@ class DMPLayer(nn.Module):
         return True
 
     @on_input_device
-    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None):
+    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None, l0=None):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
@@ -206,7 +206,7 @@ class DMPLayer(nn.Module):
         coef = ix.degree_coef(g.ndata[OUTDEGREE])
         vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
         eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
-        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded, pools)
+        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded, pools, l0)
         leave_detached(g.ndata, NODEFEAT)
         leave_detached(g.edata, EDGEFEAT)
         return out
@@ -340,8 +340,18 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     from .embed import materialize
     p_v_emb, p_e_emb = materialize(p_v_emb), materialize(p_e_emb)       # the pattern side is small: plain tensors
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
-    v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
-    e = _gate_concat(p_e_emb, g_e_emb, e_gate)
+    union = _union_of(pattern, graph)
+    l0 = _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate, np_)
+    v = None
+    if l0 is not None:        # the first layer works on the label codes: its [E, H] input rows are only its residual term
+        with th.no_grad():
+            e = _GateConcat.apply(p_e_emb, None, e_gate, g_e_emb._dmp_src[0], g_e_emb._dmp_src[1])
+            if l0.venc is not None:
+                v = _GateConcat.apply(p_v_emb, None, v_gate, g_v_emb._dmp_src[0], g_v_emb._dmp_src[1])
+    else:
+        e = _gate_concat(p_e_emb, g_e_emb, e_gate)
+    if v is None:
+        v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
     vg = eg = None
     if v_gate is not None and e_gate is not None:            # ones for the pattern rows, the gates for the target rows
         from .collate import concat_pairs
@@ -350,8 +360,9 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
     elif e_gate is not None:
         eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
-    union = _union_of(pattern, graph)
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):
+        if l0 is not None:
+            raise RuntimeError("joint_rep: layer-0 label-code path chosen for layers the fused path cannot run")
         return None
     from . import fused
     folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch
@@ -363,10 +374,37 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
             v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
             sums = (vs, es)
         else:
-            v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw)
+            v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None)
     p_v, g_v = _SplitRows.apply(v, np_)
     p_e, g_e = _SplitRows.apply(e, ep_)
     return p_v, p_e, g_v, g_e, v, e, sums
+
+
+def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate, p_nodes):
+    """``fused.Layer0Codes`` when the first layer can run on the label codes of its edge rows (``fused.l0_ok``: both edge
+    embeddings are ``codes @ table`` with tables of the same shape -- one shared table, or the pattern's stacked over the
+    target's) and is not also the pooled last layer; with the node rows' codes as well when they qualify.  Else None."""
+    from . import fused
+    if len(layers) < 2 or not th.is_grad_enabled():
+        return None
+    ps, gs = getattr(p_e_emb, "_dmp_src", None), getattr(g_e_emb, "_dmp_src", None)
+    if ps is None or gs is None or not gs[1].requires_grad or not ps[1].requires_grad:
+        return None
+    H = layers[0].hidden_dim
+    if layers[0].input_dim != H or not fused.l0_ok(union.index(), H, ps[0], gs[0], ps[1], gs[1]):
+        return None
+    if e_gate is not None and (e_gate.requires_grad or e_gate.numel() != gs[0].size(0)):
+        return None
+    shared = ps[1] is gs[1]
+    l0 = fused.Layer0Codes(fused.l0_pack(ps[0], gs[0], e_gate), gs[0].size(1), gs[1] if shared else th.cat([ps[1], gs[1]], dim=0),
+                           0 if shared else ps[0].size(0), 0 if shared else p_nodes)
+    pv, gv = getattr(p_v_emb, "_dmp_src", None), getattr(g_v_emb, "_dmp_src", None)
+    if (fused.USE_LAYER0_NODES and pv is not None and gv is not None and gv[1].requires_grad and pv[1].requires_grad
+            and (pv[1] is gv[1]) == shared and pv[0].size(0) == p_nodes and fused.l0_nodes_ok(H, pv[0], gv[0], pv[1], gv[1])
+            and (v_gate is None or (not v_gate.requires_grad and v_gate.numel() == gv[0].size(0)))):
+        l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate), gv[0].size(1)
+        l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
+    return l0
 
 
 class _GateConcat(th.autograd.Function):

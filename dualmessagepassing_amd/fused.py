@@ -451,7 +451,7 @@ def atb_rows(a, b, gate=None, colsum=True):
 SMALLK_MAX = 16
 
 
-def smallk_atb(x, d, gate=None):
+def smallk_atb(x, d, gate=None, out=None):
     """``x^T (gate (.) d)``  ([K, H], K <= 16, H = 128 or 64) in one pass over ``d``: the weight gradient of a narrow
     input layer (label encodings @ W) whose output was gated row-wise (csrc/dmp_fused.hip::smallk_atb_k)."""
     lib = _lib.load()
@@ -462,20 +462,95 @@ def smallk_atb(x, d, gate=None):
     with _lib.timed("smallk_atb[K=%d,R=%d]", (K, R), 4 * (H + K + 1) * R):
         check(lib.dmp_smallk_atb(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ptr(gate), R, H, ptr(part), stream_ptr()),
               "dmp_smallk_atb")
-    return reduce_partials(part).view(K, H)
+    return reduce_partials(part, None if out is None else out.view(-1)).view(K, H)
 
 
-def smallk_embed(x, W, gate=None):
+def smallk_embed(x, W, gate=None, out=None):
     """``gate (.) (x @ W)``  for a narrow ``x`` ([R, K <= 16]: label encodings) and ``W`` [K, H], H = 128 or 64: one pass,
-    the K rows of W in registers (csrc/dmp_fused.hip::smallk_embed_k)."""
+    the K rows of W in registers (csrc/dmp_fused.hip::smallk_embed_k).  ``W`` / ``out`` may be column blocks of wider
+    matrices (unit inner stride)."""
     lib = _lib.load()
     R, K = x.shape
     H = W.size(1)
-    out = torch.empty((R, H), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((R, H), dtype=torch.float32, device=x.device)
     with _lib.timed("smallk_embed[K=%d,R=%d]", (K, R), 4 * (H + K + 1) * R):
-        check(lib.dmp_smallk_embed_gate(ptr(x), x.stride(0), K, ptr(W), W.stride(0), ptr(gate), R, H, ptr(out), H, stream_ptr()),
-              "dmp_smallk_embed_gate")
+        check(lib.dmp_smallk_embed_gate(ptr(x), x.stride(0), K, ptr(W), W.stride(0), ptr(gate), R, H, ptr(out), out.stride(0),
+                                        stream_ptr()), "dmp_smallk_embed_gate")
     return out
+
+
+# ---- the first layer of a rep-net straight from the label codes (csrc/dmp_layer0.hip)
+L0_KMAX = 16
+# the joint rep-net pass hands the first layer the packed label codes instead of differentiable [E, H] rows
+# (dmpnn.joint_rep); DMP_LAYER0=0 keeps the general path
+USE_LAYER0 = _os.environ.get("DMP_LAYER0", "1") == "1"
+USE_LAYER0_NODES = _os.environ.get("DMP_LAYER0_NODES", "1") == "1"    # ... and the node rows' codes as well
+
+
+def l0_pack(enc_p, enc_g, gate=None):
+    """``[enc_p ; gate * enc_g]`` zero-padded to a multiple of 4 columns: the gated label codes of the union's edge rows."""
+    lib = _lib.load()
+    _lib.require_gpu(enc_p, enc_g)
+    K = enc_g.size(1)
+    Kpad = (K + 3) // 4 * 4
+    n, rows_g = enc_p.size(0), enc_g.size(0)
+    out = torch.empty((n + rows_g, Kpad), dtype=torch.float32, device=enc_g.device)
+    gt = None if gate is None else gate.reshape(-1).contiguous()
+    check(lib.dmp_l0_pack(ptr(enc_p), enc_p.stride(0) if n else K, n, ptr(enc_g), enc_g.stride(0) if rows_g else K, ptr(gt), rows_g,
+                          K, Kpad, ptr(out), stream_ptr()), "dmp_l0_pack")
+    return out
+
+
+def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None):
+    """``act(enc M[:, :H] + coef[dst] enc M[:, H:] + P[a, 0:H] - P[b, H:2H] + bias)`` -- ``edge_fwd_typed`` for input rows
+    ``enc W`` of rank K with ``M = W Wes``: no class tiles, rows in their own order.  ``rows = (r0, r1)``: only that range
+    of the edge rows (written into ``out[r0:r1]``): rows of another embedding table take another ``M``."""
+    lib = _lib.load()
+    E, H = enc.size(0), M.size(1) // 2
+    if out is None:
+        out = torch.empty((E, H), dtype=torch.float32, device=enc.device)
+    r0, r1 = (0, E) if rows is None else rows
+    sel_a, sel_b, coef_e = index.edge_select(coef)
+    with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
+        check(lib.dmp_l0_edge_fwd(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
+                                  ptr(sel_a[r0:]), ptr(sel_b[r0:]), r1 - r0, H, slope, ptr(out[r0:]), out.stride(0), stream_ptr()),
+              "dmp_l0_edge_fwd")
+    return out
+
+
+def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None):
+    """-> ``[enc^T dPre | (coef_e enc)^T dPre (| enc^T dZn)]`` as one [K, 2H or 3H] matrix: one pass over the gradients
+    (over the rows ``rows = (r0, r1)`` only; ``out``: where the reduced sums go)."""
+    lib = _lib.load()
+    E, H = d_pre.shape
+    r0, r1 = (0, E) if rows is None else rows
+    nacc = (3 if d_zn is not None else 2) * K
+    G = int(lib.dmp_l0_bwd_w_blocks(r1 - r0))
+    part = torch.empty((G, nacc * H), dtype=torch.float32, device=d_pre.device)
+    with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
+        check(lib.dmp_l0_bwd_w(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
+                               ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0, r1 - r0, H,
+                               ptr(part), stream_ptr()), "dmp_l0_bwd_w")
+    return reduce_partials(part, None if out is None else out.view(-1)).view(K, (nacc // K) * H)
+
+
+class Layer0Codes:
+    """What the first layer of a rep-net needs INSTEAD of differentiable input rows, when those rows are label embeddings.
+    ``enc`` [E, Kpad]: the packed gated label codes of the union's edge rows (``l0_pack``), ``K`` of them per row;
+    ``W`` [K, H]: the embedding table (edge rows = ``enc W``), or [2K, H] = the pattern's table over the target's, the
+    pattern's rows being the first ``esplit`` edges / ``nsplit`` nodes.  Optionally the same for the node rows:
+    ``venc`` [N, Kvpad], ``VK``, ``WV`` [VK or 2 VK, H]."""
+
+    def __init__(self, enc, K, W, esplit=0, nsplit=0, venc=None, VK=0, WV=None):
+        self.enc, self.K, self.W, self.esplit, self.nsplit = enc, K, W, esplit, nsplit
+        self.venc, self.VK, self.WV = venc, VK, WV
+
+    def tables(self, E, N):
+        """-> one ``(table, edge rows, node rows)`` per embedding table."""
+        if self.W.size(0) == self.K:
+            return [(0, (0, E), (0, N))]
+        return [t for t in ((0, (0, self.esplit), (0, self.nsplit)), (1, (self.esplit, E), (self.nsplit, N))) if t[1][1] > t[1][0]]
 
 
 _ATB_JOB = None
@@ -685,8 +760,12 @@ class _FusedDMPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
-                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None):
-        """``vpool`` / ``epool`` (``ops.PoolIndex`` over the node / edge rows; the LAST layer of a rep-net whose outputs
+                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None):
+        """``l0`` (``Layer0Codes``) with ``W0 = l0.W`` / ``WV0 = l0.WV`` as differentiable inputs: the FIRST layer of a rep-net
+        whose edge rows are a label embedding, ``z = enc W0``.  Every product with ``z`` runs on its K-column factor
+        (csrc/dmp_layer0.hip); ``z`` itself is only read as the residual and takes no gradient: the embedding's gradient comes
+        back as ``dW0``.  With ``l0.venc`` the same for the node rows ``x = venc WV0`` (products with ``x`` -> ``dWV0``).
+        ``vpool`` / ``epool`` (``ops.PoolIndex`` over the node / edge rows; the LAST layer of a rep-net whose outputs
         feed sum / mean pooling heads): two more outputs, the per-graph sums of ``xn`` / ``zn`` ([G, H]; edges with a flag
         [G, 2H] = [non-reversed | reversed]).  A gradient that arrives ONLY through the edge sums is never expanded to
         [E, H]: every row of a graph has the same gradient vector, see ``backward``."""
@@ -696,15 +775,46 @@ class _FusedDMPLayer(torch.autograd.Function):
         Bn, Wx, Wes = Bn.contiguous(), Wx.contiguous(), Wes.contiguous()
         N = index.num_nodes
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
-        S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
-        XP = x @ Wx
-        H1n = add_bias_relu_(S @ Bn, XP[:, :H], bn, slope)
+        S0 = M0 = tables = None
+        if l0 is not None:     # sum of z over a node's edges = (sum of the label codes) W0
+            enc0, K0 = l0.enc, l0.K
+            tables = l0.tables(z.size(0), N)
+            S0 = ops.seg_sum_raw(enc0, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)        # [N, 2 Kpad] = [in | out]
+            # S = [S0_in W0 | S0_out W0] is never built:  S Bn = S0_in (W0 Bn_in) + S0_out (W0 Bn_out), two K-column products
+            Kp = enc0.size(1)
+            WB = torch.matmul(W0, Bn.view(2, H, H))                                                  # [2, T K, H]
+            SB = torch.empty((N, H), dtype=torch.float32, device=z.device)
+            for t, _, (n0, n1) in tables:
+                if n1 > n0:
+                    torch.mm(S0[n0:n1, :K0], WB[0, t * K0:(t + 1) * K0], out=SB[n0:n1])
+                    SB[n0:n1].addmm_(S0[n0:n1, Kp:Kp + K0], WB[1, t * K0:(t + 1) * K0])
+            M0 = W0 @ Wes                                                                            # [T K, 2H] = W0 [A | B]
+            S = None
+        else:
+            S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
+            SB = S @ Bn
+        if l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
+            VK = l0.VK
+            MV = WV0 @ Wx                                                                            # [T VK, 3H]
+            XP = torch.empty((N, 3 * H), dtype=torch.float32, device=z.device)
+            for t, _, (n0, n1) in tables:
+                for j in range(3):
+                    if n1 > n0:
+                        smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK, j * H:(j + 1) * H], None, XP[n0:n1, j * H:(j + 1) * H])
+        else:
+            XP = x @ Wx
+        H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
         if onepanel_ok(H):   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
             xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None, nW2t)
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
-        if edge_chain_ok(index, H) and eW2t is not None:
+        if l0 is not None:
+            H1e = torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
+            for t, rows, _ in tables:
+                l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e)
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
+        elif edge_chain_ok(index, H) and eW2t is not None:
             H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
@@ -721,7 +831,9 @@ class _FusedDMPLayer(torch.autograd.Function):
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
-        ctx.save_for_backward(x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
+        ctx.l0, ctx.l0_S0, ctx.l0_tables = l0, S0, tables
+        ctx.l0_W = None if l0 is None else (W0.detach(), None if WV0 is None else WV0.detach())
+        ctx.save_for_backward(x, z if l0 is None else None, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
         if vpool is None and epool is None:
             return xn, zn
         ctx.set_materialize_grads(False)    # a missing gradient stays None (the common case: only the sums are used)
@@ -794,13 +906,23 @@ class _FusedDMPLayer(torch.autograd.Function):
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
             ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=dXP[:, H:],
                             tiling=ix.tiling)
-            dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
+            l0, tables = ctx.l0, ctx.l0_tables
+            vcodes = l0 is not None and l0.venc is not None
+            if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor
+                W0, WV0 = ctx.l0_W
+                K0, TK = l0.K, W0.size(0)
+                XX = torch.empty((TK, (3 if ctx.residual else 2) * H), dtype=torch.float32, device=dG.device)
+                for t, rows, _ in tables:
+                    l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0])
+                dWes = None
+            else:
+                dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
-            one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and atb_ok(S, dXP)
+            one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
             if onepanel_ok(H) and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
-                if not one_launch:
+                if not one_launch or vcodes:
                     dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
                 dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope)
             else:
@@ -808,19 +930,45 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dW2n = wg(dOn, H1n)
                 dH1n = dOn @ nW2
                 dPn, dbn = relu_bwd_colsum_(dH1n, H1n, out=dXP[:, :H], slope=slope)
-            dS = dPn @ Bn.t()
-            if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
-                (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (S, dPn, None, False),
-                                                                    (x, dXP, None, False)])
+            if l0 is not None:
+                # S = [S0_in W0 | S0_out W0] was never built: X[h] = S0_h^T dPn per table (N rows, K columns) carries both
+                # dBn_h = W0^T X[h] and the segment sums' part of the embedding gradient, sum_h X[h] Bn_h^T (no dS either)
+                Kp, S0 = l0.enc.size(1), ctx.l0_S0
+                Xn = torch.zeros((2, TK, H), dtype=torch.float32, device=dPn.device)
+                for t, _, (n0, n1) in tables:
+                    if n1 > n0:
+                        for h in (0, 1):
+                            smallk_atb(S0[n0:n1, h * Kp:h * Kp + K0], dPn[n0:n1], out=Xn[h, t * K0:(t + 1) * K0])
+                dS = dBn = dWx = None
+                if vcodes:
+                    # x = venc WV0:  x^T dXP = WV0^T (venc^T dXP)  and  venc^T dx = venc^T dxn + (venc^T dXP) Wx^T -- N-row
+                    # passes on K columns instead of two [N,H] x [H,3H] products and the three-block weight gradient
+                    VK, TVK = l0.VK, WV0.size(0)
+                    Yn = torch.zeros((4 if ctx.residual else 3, TVK, H), dtype=torch.float32, device=dPn.device)
+                    for t, _, (n0, n1) in tables:
+                        if n1 > n0:
+                            for j in range(3):
+                                smallk_atb(l0.venc[n0:n1, :VK], dXP[n0:n1, j * H:(j + 1) * H], out=Yn[j, t * VK:(t + 1) * VK])
+                            if ctx.residual:
+                                smallk_atb(l0.venc[n0:n1, :VK], dxn[n0:n1], out=Yn[3, t * VK:(t + 1) * VK])
+                elif one_launch:
+                    (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (x, dXP, None, False)])
+                else:
+                    dWx = wg(x, dXP)
             else:
-                dBn = wg(S, dPn)                                         # [2H,H]
-                dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]
+                dS = dPn @ Bn.t()
+                if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
+                    (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (S, dPn, None, False),
+                                                                        (x, dXP, None, False)])
+                else:
+                    dBn = wg(S, dPn)                                         # [2H,H]
+                    dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]
             dx = None
             if ctx.needs_input_grad[3]:
                 dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
             dz = None
-            if ctx.needs_input_grad[4]:
+            if l0 is None and ctx.needs_input_grad[4]:
                 if lazy is not None:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
                                      base_map=lazy[1] if ctx.residual else None)
@@ -832,8 +980,19 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dz = ops.gather_select_raw(dS, ix.dst32, ix.rev8, H, None, -1.0, 1.0,
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
+        dW0 = dWV0 = None
+        if l0 is not None:       # after the reductions of the block above have run
+            dWes = W0.t() @ XX[:, :2 * H]                                  # z^T [dPre | c dPre] = W0^T (enc^T [dPre | c dPre])
+            dBn = torch.matmul(W0.t(), Xn).view(2 * H, H)
+            T3 = torch.bmm(Xn, Bn.view(2, H, H).transpose(1, 2)).sum(0)
+            # enc^T dz = enc^T dzn + (enc^T [dPre | c dPre]) [A | B]^T + (sum of enc)^T dS
+            dW0 = torch.addmm(T3 + XX[:, 2 * H:] if ctx.residual else T3, XX[:, :2 * H], Wes.t())
+            if vcodes:
+                Y = Yn[:3].transpose(0, 1).reshape(WV0.size(0), 3 * H)     # venc^T dXP  [T VK, 3H]
+                dWx = WV0.t() @ Y
+                dWV0 = torch.addmm(Yn[3], Y, Wx.t()) if ctx.residual else Y @ Wx.t()
         return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None,
-                None, None)
+                None, None, None, dW0, dWV0)
 
 
 def activation_slope(act):
@@ -846,12 +1005,29 @@ def activation_slope(act):
     return None
 
 
-def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None):
+def l0_ok(index, H, enc_p, enc_g, W_p, W_g):
+    """The first layer can run on the label codes: embedding tables of the same (at most L0_KMAX) number of rows on both
+    sides, the class-typed kernels' shape limits (the backward's dPre comes from them)."""
+    return (USE_LAYER0 and H in MFMA_WIDTHS and enc_p.size(1) == enc_g.size(1) == W_g.size(0) == W_p.size(0) <= L0_KMAX
+            and W_g.size(1) == W_p.size(1) == H and W_g.dtype == W_p.dtype == enc_p.dtype == enc_g.dtype == torch.float32
+            and enc_p.stride(1) == 1 and enc_g.stride(1) == 1 and enc_g.is_cuda and index.num_edges > 0 and typed_ok(index, H)
+            and onepanel_ok(H))
+
+
+def l0_nodes_ok(H, enc_p, enc_g, W_p, W_g):
+    """The node rows of the first layer can run on their label codes as well (same conditions as the edge rows)."""
+    return (enc_p.size(1) == enc_g.size(1) == W_g.size(0) == W_p.size(0) <= SMALLK_MAX and W_g.size(1) == W_p.size(1) == H
+            and W_g.dtype == W_p.dtype == enc_p.dtype == enc_g.dtype == torch.float32 and enc_p.stride(1) == 1
+            and enc_g.stride(1) == 1 and enc_g.is_cuda and H in MFMA_WIDTHS)
+
+
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None):
     """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch).
-    ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None)``: also returns the per-graph sums of both outputs."""
+    ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None)``: also returns the per-graph sums of both outputs.
+    ``l0`` (``Layer0Codes``): ``z`` is ``l0.enc @ l0.W`` (and ``x`` is ``l0.venc @ l0.WV``), see ``_FusedDMPLayer.forward``."""
     n2, e2 = layer.nmlp[2], layer.emlp[2]
     Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t = folded if folded is not None else fold_layers([layer])[0]
     vpool, epool = pools if pools is not None else (None, None)
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
                                 n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]),
-                                vpool, epool)
+                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 46
+#define DMP_ABI_VERSION 47
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -522,6 +522,25 @@ int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, in
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);
+
+/* The FIRST layer of a rep-net whose edge input is a label embedding z0 = enc W (basemodel.py:1393-1420 feeding
+ * dmpnn.py:111-156): every product of the layer with z0 has rank K <= 16, so it is computed from the label codes
+ * (csrc/dmp_layer0.hip).  H = 128 or 64.
+ *   dmp_l0_pack      out[r, 0:Kpad] = r < rows_p ? enc_p[r, 0:K] : gate[r - rows_p] * enc_g[r - rows_p, 0:K], zero-padded
+ *                    (the union's edge rows: pattern rows first, then the gated target rows; gate may be NULL).
+ *   dmp_l0_edge_fwd  out[r] = act(enc[r] MA + coef_e[r] (enc[r] MB) + P[sel_a[r], 0:H] - P[sel_b[r], H:2H] + bias)
+ *                    with M = [MA | MB] = W [A | B]  ([K, ldm >= 2H]); replaces dmp_edge_fwd_typed for this layer.
+ *   dmp_l0_bwd_w     partial[b] = [enc^T dPre | (coef_e enc)^T dPre | enc^T dZn] over workgroup b's rows
+ *                    ([dmp_l0_bwd_w_blocks(rows), K, (dZn ? 3 : 2) * H]; finish with dmp_reduce_partials): the
+ *                    class-typed weight gradient is W^T of the first two blocks, the embedding's gradient needs all three. */
+int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
+                int64_t rows_g, int K, int Kpad, float *out, void *stream);
+int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                    const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t rows,
+                    int H, float slope, float *out, int64_t ldo, void *stream);
+int64_t dmp_l0_bwd_w_blocks(int64_t rows);
+int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd,
+                 const float *dZn, int64_t ldz, int64_t rows, int H, float *partial, void *stream);
 
 /* out[l] (+)= sum_s partial[s, l], s in a fixed order; L % 4 == 0.  Also reduces the
  * split-K partial products of the weight gradients. */

@@ -1,0 +1,177 @@
+"""The first layer of a rep-net on the label codes of its edge rows (csrc/dmp_layer0.hip, fused.l0_*): the kernels
+against fp64, the layer against the general fused layer fed ``codes @ table`` (values and every gradient), and the
+whole model with the path on and off.  Reference: basemodel.py:1393-1420 (embeddings) feeding dmpnn.py:111-156."""
+import numpy as np
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(src, dst, n, rev, dev):
+    from dualmessagepassing_amd.graph import GraphIndex
+    return GraphIndex(th.from_numpy(src).to(dev), th.from_numpy(dst).to(dev), n, th.from_numpy(rev).to(dev), validate=True)
+
+
+def _case(rows, n_pat, k, h, gated, seed, dev):
+    rng = np.random.default_rng(seed)
+    gen = th.Generator().manual_seed(seed)
+    n = max(4, rows // 7)
+    n_split = max(1, n // 40) if n_pat else 0             # the pattern's edges stay among the pattern's nodes (a union of two batches)
+    src, dst = rng.integers(n_split, n, rows).astype(np.int64), rng.integers(n_split, n, rows).astype(np.int64)
+    if n_pat:
+        src[:n_pat], dst[:n_pat] = rng.integers(0, n_split, n_pat), rng.integers(0, n_split, n_pat)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, dev)
+    coef = ix.degree_coef(ix.out_deg)
+    enc = (th.rand(rows, k, generator=gen) < 0.5).float().to(dev)          # multi-hot codes
+    enc_p, enc_g = enc[:n_pat], enc[n_pat:]
+    gate = (th.rand(rows - n_pat, generator=gen) < 0.7).float().to(dev) if gated else None
+    W = th.randn(k, h, generator=gen).to(dev)
+    return ix, coef, enc_p, enc_g, gate, W, gen, n, n_split
+
+
+@pytest.mark.parametrize("rows,n_pat", [(1, 0), (5, 5), (1000, 37), (70001, 900), (548864, 1200)])
+@pytest.mark.parametrize("k,h,gated,slope", [(10, 128, True, 1 / 5.5), (10, 64, False, 0.0), (16, 128, True, 0.0), (3, 128, False, 1 / 5.5)])
+def test_layer0_kernels_against_fp64(rows, n_pat, k, h, gated, slope, gpu):
+    from dualmessagepassing_amd import fused
+    ix, coef, enc_p, enc_g, gate, W, gen, n, _ = _case(rows, n_pat, k, h, gated, rows + k, gpu)
+    encU = fused.l0_pack(enc_p, enc_g, gate)
+    kpad = (k + 3) // 4 * 4
+    ref = th.zeros(rows, kpad, device=gpu)
+    ref[:n_pat, :k] = enc_p
+    ref[n_pat:, :k] = enc_g if gate is None else enc_g * gate.view(-1, 1)
+    assert th.equal(encU, ref)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    M = W @ wes
+    h1 = fused.l0_edge_fwd(encU, k, M, xp[:, h:], 3 * h, bias, coef, ix, slope)
+    a, b, cf = (t.long() if i < 2 else t.double() for i, t in enumerate(ix.edge_select(coef)))
+    ed, P = encU[:, :k].double(), xp.double()
+    z = ed @ W.double()
+    pre = z @ wes[:, :h].double() + cf.view(-1, 1) * (z @ wes[:, h:].double()) + P[a, h:2 * h] - P[b, 2 * h:] + bias.double()
+    h64 = th.where(pre > 0, pre, slope * pre)
+    assert float((h1.double() - h64).abs().max()) <= 2e-5 * max(1.0, float(h64.abs().max()))
+    assert th.equal(h1, fused.l0_edge_fwd(encU, k, M, xp[:, h:], 3 * h, bias, coef, ix, slope))      # repeatable
+    # the backward pass: one read of dPre (and the residual gradient)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    d_zn = th.randn(rows, h, generator=gen).to(gpu)
+    for dz in (d_zn, None):
+        xx = fused.l0_bwd_w(encU, k, ix.edge_select(coef)[2], d_pre, dz)
+        want = [ed.t() @ d_pre.double(), (ed * cf.view(-1, 1)).t() @ d_pre.double()] + ([ed.t() @ dz.double()] if dz is not None else [])
+        want = th.cat(want, dim=1)
+        assert xx.shape == want.shape
+        assert float((xx.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def _layer_case(h, slope_act, gated, residual, seed, dev):
+    from dualmessagepassing_amd.dmpnn import DMPLayer
+    rows, n_pat, k = 6000, 150, 10
+    ix, coef, enc_p, enc_g, gate, W, gen, n, n_split = _case(rows, n_pat, k, h, gated, seed, dev)
+    th.manual_seed(seed)
+    layer = DMPLayer(h, h, batch_norm=False, act_func="leaky_relu" if slope_act == "linear" else slope_act).to(dev)
+    if slope_act == "linear":      # negative slope 1: no kink, so the two paths' gradients cannot differ by an activation's side
+        layer.nmlp[1], layer.emlp[1] = th.nn.LeakyReLU(1.0), th.nn.LeakyReLU(1.0)
+    x = th.randn(n, h, generator=gen).to(dev).requires_grad_(True)
+    vg = (th.rand(n, generator=gen) < 0.8).float().to(dev) if gated else None
+    eg = th.cat([th.ones(n_pat, device=dev), gate]) if gated else None
+    return ix, coef, enc_p, enc_g, gate, W, layer, x, vg, eg, k, rows, n_pat, n_split
+
+
+@pytest.mark.parametrize("h,act", [(128, "linear"), (128, "leaky_relu"), (64, "relu"), (64, "linear")])
+@pytest.mark.parametrize("gated,residual", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("tables,nodes", [(1, False), (2, False), (1, True), (2, True)])
+def test_layer0_equals_the_general_layer(h, act, gated, residual, tables, nodes, gpu):
+    """Same layer, same inputs: the label-code path against the general fused layer reading ``z = codes @ table`` (and
+    ``x = node codes @ node table`` with ``nodes``) -- outputs, input gradient, every parameter gradient and the tables'
+    gradients.  The products are re-associated, so the two differ by fp32 rounding -- and, with a kinked activation, by the
+    side a pre-activation within rounding of zero falls on: outputs are held to rounding always, gradients to rounding with
+    the kink-free activation (negative slope 1) and to a few such rows otherwise."""
+    from dualmessagepassing_amd import fused
+    ix, coef, enc_p, enc_g, gate, W, layer, x, vg, eg, k, rows, n_pat, n_split = _layer_case(h, act, gated, residual, 7, gpu)
+    assert fused.l0_ok(ix, h, enc_p, enc_g, W, W)
+    gen = th.Generator().manual_seed(5)
+    if tables == 2:                                       # the pattern's own table stacked over the target's (no share_emb_net)
+        W = th.cat([th.randn(k, h, generator=gen).to(gpu), W])
+    encU = fused.l0_pack(enc_p, enc_g, gate)
+    n, vk = x.size(0), 8
+    venc = (th.rand(n, vk, generator=gen) < 0.5).float().to(gpu)
+    vencU = fused.l0_pack(venc[:n_split], venc[n_split:], vg[n_split:] if vg is not None else None)
+    WV = th.randn(tables * vk, h, generator=gen).to(gpu)
+    gen = th.Generator().manual_seed(99)
+    gx, gz = th.randn(x.shape, generator=gen).to(gpu), th.randn(rows, h, generator=gen).to(gpu)
+    params = list(layer.parameters())
+
+    def run(l0):
+        W0, WV0 = W.clone().requires_grad_(True), WV.clone().requires_grad_(True)
+        z = encU[:, :k] @ W0 if tables == 1 else th.cat([encU[:n_pat, :k] @ W0[:k], encU[n_pat:, :k] @ W0[k:]])
+        if nodes:
+            xin = vencU[:, :vk] @ WV0 if tables == 1 else th.cat([vencU[:n_split, :vk] @ WV0[:vk], vencU[n_split:, :vk] @ WV0[vk:]])
+        else:
+            xin = x
+        if l0:
+            split = (0, 0) if tables == 1 else (n_pat, n_split)
+            codes = fused.Layer0Codes(encU, k, W0, *split)
+            if nodes:
+                codes.venc, codes.VK, codes.WV = vencU, vk, WV0
+            xn, zn = fused.fused_dmp_layer(ix, coef, residual, xin.detach() if nodes else xin, z.detach(), vg, eg, layer, l0=codes)
+        else:
+            xn, zn = fused.fused_dmp_layer(ix, coef, residual, xin, z, vg, eg, layer)
+        grads = th.autograd.grad([xn, zn], [WV0 if nodes else x, W0] + params, [gx, gz], allow_unused=True)
+        return [xn.detach(), zn.detach()] + list(grads)
+
+    got, want = run(True), run(False)
+    names = ["xn", "zn", "dWV0" if nodes else "dx", "dW0"] + [n for n, _ in layer.named_parameters()]
+    for name, g, w in zip(names, got, want):
+        assert (g is None) == (w is None), name
+        if g is None:
+            continue
+        scale = max(1.0, float(w.abs().max()))
+        tol = 3e-5 if act == "linear" or name in ("xn", "zn") else 3e-3
+        assert float((g - w).abs().max()) <= tol * scale, (name, float((g - w).abs().max()), scale)
+
+
+def test_model_with_and_without_the_label_code_path(gpu):
+    """The BASELINE configs[0] batch through the whole model with the first layer on the label codes (default) and on the
+    general path: prediction and every parameter gradient."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from dualmessagepassing_amd import fused
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.collate import collate_device
+    cfg = dict(bench.CFG, batch=32)
+    shard = bench.make_shard(cfg, 0, gpu)
+    th.manual_seed(3)
+    model = build_model(**bench.model_config(cfg)).to(gpu)
+    gs = {}
+    for tag in ("p", "g"):
+        s = shard[tag]
+        gs[tag] = lambda s=s: collate_device(s["local_src"], s["local_dst"], s["num_nodes"], s["num_edges"], s["N"], s["E"],
+                                              ndata=s["ndata"], edata=s["edata"], max_nodes=s["max_n"], max_edges=s["max_e"])
+    out = {}
+    saved = fused.USE_LAYER0
+    try:
+        for on in (True, False):
+            fused.USE_LAYER0 = on
+            model.zero_grad(set_to_none=True)
+            calls = []
+            orig = fused.l0_edge_fwd
+            fused.l0_edge_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                pred = model(gs["p"](), gs["g"]())["pred_c"]
+            finally:
+                fused.l0_edge_fwd = orig
+            assert bool(calls) == on                      # the path under test is the one that ran
+            (pred ** 2).sum().backward()
+            out[on] = (pred.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        fused.USE_LAYER0 = saved
+    (p1, g1), (p0, g0) = out[True], out[False]
+    assert float((p1 - p0).abs().max()) <= 2e-5 * max(1.0, float(p0.abs().max()))
+    assert set(g1) == set(g0)
+    for n in g0:
+        scale = max(1.0, float(g0[n].abs().max()))
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
