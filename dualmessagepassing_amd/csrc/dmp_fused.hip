@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
 // of the FMAs; 4 rows in flight per wave.
 constexpr int kSmallK = 16;
 constexpr int kSmallRows = 4;                                 // rows in flight per wave (the loop is one memory round trip per batch)
-struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial; };
+struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial;
+                    int ncols; const float *D2; int64_t ldd2; };   // blockIdx.y = column block j: D[:, jH:(j+1)H], or D2 for j == ncols
 
 // VW = H / 64 values per lane: 2 (H = 128, one float2 per lane) or 1 (H = 64)
 template <int VW> struct LaneVec { float v[VW]; };
@@ -334,6 +335,10 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   constexpr int WPB = kBlock / 64, kRows = kSmallRows, H = 64 * VW;
   __shared__ float red[kBlock * VW];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int colblk = blockIdx.y;                            // one launch for several column blocks of the upstream gradient
+  const float *Dj = colblk < p.ncols ? p.D + (int64_t)colblk * H : p.D2;
+  const int64_t ldj = colblk < p.ncols ? p.ldd : p.ldd2;
+  float *partial = p.partial + (int64_t)colblk * gridDim.x * K * H;
   LaneVec<VW> acc[K];
 #pragma unroll
   for (int k = 0; k < K; ++k)
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      if (ok) dd[u] = lane_load<VW>(p.D + r * p.ldd, lane);
+      if (ok) dd[u] = lane_load<VW>(Dj + r * ldj, lane);
       else {
 #pragma unroll
         for (int c = 0; c < VW; ++c) dd[u].v[c] = 0.f;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
 #pragma unroll
         for (int w = 1; w < WPB; ++w) t.v[c] += red[(w * 64 + lane) * VW + c];
       }
-      lane_store<VW>(p.partial + ((int64_t)blockIdx.x * K + k) * H, lane, t);
+      lane_store<VW>(partial + ((int64_t)blockIdx.x * K + k) * H, lane, t);
     }
     __syncthreads();
   }
@@ -405,15 +410,16 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
 // The forward of the same narrow layer with its gate:  out[r, :] = gate[r] * sum_k X[r, k] W[k, :]  -- the gated
 // embedding rows written straight into their place (the union buffer of the joint rep-net pass) from the K
 // inputs per row instead of from the [R, H] embedding.  W lives in registers (H / 64 values per lane and input).
-struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo; };
+struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo; };   // blockIdx.y: column block of W / out
 
 template <int K, int VW>
 __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) {
   constexpr int WPB = kBlock / 64, kRows = kSmallRows;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int64_t coloff = (int64_t)blockIdx.y * (64 * VW);
   LaneVec<VW> w[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) w[k] = lane_load<VW>(p.W + k * p.ldw, lane);
+  for (int k = 0; k < K; ++k) w[k] = lane_load<VW>(p.W + k * p.ldw + coloff, lane);
   const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
   for (int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows; r0 < p.R; r0 += stride) {
     float mine[kRows];
@@ -442,16 +448,17 @@ __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) 
       }
 #pragma unroll
       for (int c = 0; c < VW; ++c) e.v[c] *= g;
-      lane_store<VW>(p.out + r * p.ldo, lane, e);
+      lane_store<VW>(p.out + r * p.ldo + coloff, lane, e);
     }
   }
 }
 
 template <int K>
-void launch_smallk_fwd(const SmallKFwdArgs &p, int H, hipStream_t st) {
+void launch_smallk_fwd(const SmallKFwdArgs &p, int H, int ncols, hipStream_t st) {
   const int64_t chunk = (int64_t)(kBlock / 64) * kSmallRows, nb = (p.R + chunk - 1) / chunk;
-  if (H == 128) smallk_embed_k<K, 2><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
-  else smallk_embed_k<K, 1><<<(unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st>>>(p);
+  const dim3 grid((unsigned)(nb < 4096 ? nb : 4096), (unsigned)ncols);
+  if (H == 128) smallk_embed_k<K, 2><<<grid, kBlock, 0, st>>>(p);
+  else smallk_embed_k<K, 1><<<grid, kBlock, 0, st>>>(p);
 }
 
 inline unsigned smallk_blocks(int64_t R) {
@@ -461,8 +468,9 @@ inline unsigned smallk_blocks(int64_t R) {
 
 template <int K>
 void launch_smallk(const SmallKArgs &p, int H, hipStream_t st) {
-  if (H == 128) smallk_atb_k<K, 2><<<smallk_blocks(p.R), kBlock, 0, st>>>(p);
-  else smallk_atb_k<K, 1><<<smallk_blocks(p.R), kBlock, 0, st>>>(p);
+  const dim3 grid(smallk_blocks(p.R), (unsigned)(p.ncols + (p.D2 ? 1 : 0)));
+  if (H == 128) smallk_atb_k<K, 2><<<grid, kBlock, 0, st>>>(p);
+  else smallk_atb_k<K, 1><<<grid, kBlock, 0, st>>>(p);
 }
 
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
@@ -687,14 +695,16 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *pa
 
 int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)smallk_blocks(rows); }
 
-int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,
-                   float *partial, void *stream) {
-  DMP_ROW_CHECK(R >= 0 && K > 0 && partial);
+int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2, int64_t ldd2,
+                        const float *gate, int64_t R, int H, float *partial, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && K > 0 && partial && ncols >= 0 && ncols + (D2 ? 1 : 0) >= 1 && ncols <= 8);
   if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
-  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)K * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
-  DMP_ROW_CHECK(X && D && ldx >= K && ldd >= H);
-  if (ldd % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || !ok16(partial)) return DMP_ERR_UNSUPPORTED;
-  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial};
+  const int nblk = ncols + (D2 ? 1 : 0);
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)nblk * K * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  DMP_ROW_CHECK(X && (D || ncols == 0) && ldx >= K && (ncols == 0 || ldd >= (int64_t)ncols * H) && (!D2 || ldd2 >= H));
+  if (ldd % 2 || ldd2 % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || (reinterpret_cast<uintptr_t>(D2) & 7u) || !ok16(partial))
+    return DMP_ERR_UNSUPPORTED;
+  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial, ncols, D2, ldd2};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {   // K is a compile-time constant of the kernel: the accumulators live in registers
     case 1: launch_smallk<1>(p, H, st); break;   case 2: launch_smallk<2>(p, H, st); break;
@@ -709,26 +719,37 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
   return check_launch();
 }
 
-int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
-                          int H, float *out, int64_t ldo, void *stream) {
-  DMP_ROW_CHECK(R >= 0 && K > 0);
+int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,
+                   float *partial, void *stream) {
+  DMP_ROW_CHECK(R == 0 || (D && ldd >= H));
+  return dmp_smallk_atb_cols(X, ldx, K, D, ldd, 1, nullptr, 0, gate, R, H, partial, stream);
+}
+
+int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, int ncols, float *out, int64_t ldo, void *stream) {
+  DMP_ROW_CHECK(R >= 0 && K > 0 && ncols >= 1 && ncols <= 8);
   if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return DMP_OK;
-  DMP_ROW_CHECK(X && W && out && ldx >= K && ldw >= H && ldo >= H);
+  DMP_ROW_CHECK(X && W && out && ldx >= K && ldw >= (int64_t)ncols * H && ldo >= (int64_t)ncols * H);
   if (ldw % 2 || ldo % 2 || (reinterpret_cast<uintptr_t>(W) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return DMP_ERR_UNSUPPORTED;
   SmallKFwdArgs p{X, ldx, W, ldw, gate, R, out, ldo};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 1: launch_smallk_fwd<1>(p, H, st); break;   case 2: launch_smallk_fwd<2>(p, H, st); break;
-    case 3: launch_smallk_fwd<3>(p, H, st); break;   case 4: launch_smallk_fwd<4>(p, H, st); break;
-    case 5: launch_smallk_fwd<5>(p, H, st); break;   case 6: launch_smallk_fwd<6>(p, H, st); break;
-    case 7: launch_smallk_fwd<7>(p, H, st); break;   case 8: launch_smallk_fwd<8>(p, H, st); break;
-    case 9: launch_smallk_fwd<9>(p, H, st); break;   case 10: launch_smallk_fwd<10>(p, H, st); break;
-    case 11: launch_smallk_fwd<11>(p, H, st); break; case 12: launch_smallk_fwd<12>(p, H, st); break;
-    case 13: launch_smallk_fwd<13>(p, H, st); break; case 14: launch_smallk_fwd<14>(p, H, st); break;
-    case 15: launch_smallk_fwd<15>(p, H, st); break; default: launch_smallk_fwd<16>(p, H, st); break;
+    case 1: launch_smallk_fwd<1>(p, H, ncols, st); break;   case 2: launch_smallk_fwd<2>(p, H, ncols, st); break;
+    case 3: launch_smallk_fwd<3>(p, H, ncols, st); break;   case 4: launch_smallk_fwd<4>(p, H, ncols, st); break;
+    case 5: launch_smallk_fwd<5>(p, H, ncols, st); break;   case 6: launch_smallk_fwd<6>(p, H, ncols, st); break;
+    case 7: launch_smallk_fwd<7>(p, H, ncols, st); break;   case 8: launch_smallk_fwd<8>(p, H, ncols, st); break;
+    case 9: launch_smallk_fwd<9>(p, H, ncols, st); break;   case 10: launch_smallk_fwd<10>(p, H, ncols, st); break;
+    case 11: launch_smallk_fwd<11>(p, H, ncols, st); break; case 12: launch_smallk_fwd<12>(p, H, ncols, st); break;
+    case 13: launch_smallk_fwd<13>(p, H, ncols, st); break; case 14: launch_smallk_fwd<14>(p, H, ncols, st); break;
+    case 15: launch_smallk_fwd<15>(p, H, ncols, st); break; default: launch_smallk_fwd<16>(p, H, ncols, st); break;
   }
   return check_launch();
+}
+
+int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, float *out, int64_t ldo, void *stream) {
+  return dmp_smallk_embed_cols(X, ldx, K, W, ldw, gate, R, H, 1, out, ldo, stream);
 }
 
 int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out, int accumulate, void *stream) {

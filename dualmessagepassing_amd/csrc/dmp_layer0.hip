@@ -11,7 +11,8 @@
 // gradient) become two streaming passes with K fused multiply-adds per element: no matrix pipe, no class tiles, the
 // edge rows in their natural (graph-major) order.
 //
-//   l0_pack_k        encU[r] = r < n ? enc_p[r] : gate[r-n] enc_g[r-n]   zero-padded to Kpad (16-byte rows for the segment sum)
+//   l0_pack_k        encU[r] = r < n ? enc_p[r] : gate[r-n] enc_g[r-n]   zero-padded to Kpad (16-byte rows for the segment sum);
+//                    with a column offset for the second kind of rows, two tables read as ONE of 2K rows (node rows)
 //   l0_edge_fwd_k    H1[r]   = act(encU[r] MA + c_r encU[r] MB + P[a_r, 0:H] - P[b_r, H:2H] + bias)
 //   l0_bwd_w_k       partial sums of  encU^T dPre,  (c encU)^T dPre,  encU^T dZn
 //
@@ -78,7 +79,7 @@ __device__ __forceinline__ int lane_i(float v, int l) { return __builtin_amdgcn_
 
 struct PackArgs {
   const float *encp; int64_t ldp; int64_t n; const float *encg; int64_t ldg; const float *gate; int64_t rows_g;
-  int K, Kpad; float *out;
+  int K, Kpad, goff; float *out;
 };
 
 __global__ __launch_bounds__(kBlock) void l0_pack_k(const PackArgs p) {
@@ -87,10 +88,8 @@ __global__ __launch_bounds__(kBlock) void l0_pack_k(const PackArgs p) {
     const int64_t r = i / p.Kpad;
     const int c = (int)(i - r * p.Kpad);
     float v = 0.f;
-    if (c < p.K) {
-      if (r < p.n) v = p.encp[r * p.ldp + c];
-      else { v = p.encg[(r - p.n) * p.ldg + c]; if (p.gate) v *= p.gate[r - p.n]; }
-    }
+    if (r < p.n) { if (c < p.K) v = p.encp[r * p.ldp + c]; }
+    else if (c >= p.goff && c < p.goff + p.K) { v = p.encg[(r - p.n) * p.ldg + c - p.goff]; if (p.gate) v *= p.gate[r - p.n]; }
     p.out[i] = v;
   }
 }
@@ -319,13 +318,13 @@ using namespace dmp;
 extern "C" {
 
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
-                int64_t rows_g, int K, int Kpad, float *out, void *stream) {
-  if (rows_p < 0 || rows_g < 0 || K <= 0 || Kpad < K || !out) return DMP_ERR_BAD_ARG;
+                int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream) {
+  if (rows_p < 0 || rows_g < 0 || K <= 0 || goff < 0 || Kpad < goff + K || !out) return DMP_ERR_BAD_ARG;
   if ((rows_p > 0 && (!enc_p || ldp < K)) || (rows_g > 0 && (!enc_g || ldg < K))) return DMP_ERR_BAD_ARG;
   const int64_t total = (rows_p + rows_g) * Kpad;
   if (total == 0) return DMP_OK;
   const int64_t nb = (total + kBlock - 1) / kBlock;
-  PackArgs p{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, out};
+  PackArgs p{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, goff, out};
   l0_pack_k<<<(unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }

@@ -402,7 +402,8 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
     if (fused.USE_LAYER0_NODES and pv is not None and gv is not None and gv[1].requires_grad and pv[1].requires_grad
             and (pv[1] is gv[1]) == shared and pv[0].size(0) == p_nodes and fused.l0_nodes_ok(H, pv[0], gv[0], pv[1], gv[1])
             and (v_gate is None or (not v_gate.requires_grad and v_gate.numel() == gv[0].size(0)))):
-        l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate), gv[0].size(1)
+        stacked = not shared and 2 * gv[0].size(1) <= fused.SMALLK_MAX    # two tables as ONE of 2 VK rows: no second launches
+        l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate, stacked), gv[0].size(1) * (2 if stacked else 1)
         l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
     return l0
 

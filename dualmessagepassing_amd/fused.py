@@ -465,18 +465,41 @@ def smallk_atb(x, d, gate=None, out=None):
     return reduce_partials(part, None if out is None else out.view(-1)).view(K, H)
 
 
-def smallk_embed(x, W, gate=None, out=None):
-    """``gate (.) (x @ W)``  for a narrow ``x`` ([R, K <= 16]: label encodings) and ``W`` [K, H], H = 128 or 64: one pass,
-    the K rows of W in registers (csrc/dmp_fused.hip::smallk_embed_k).  ``W`` / ``out`` may be column blocks of wider
-    matrices (unit inner stride)."""
+def smallk_embed(x, W, gate=None, out=None, H=None):
+    """``gate (.) (x @ W)``  for a narrow ``x`` ([R, K <= 16]: label encodings) and ``W`` [K, C]: one pass, the K rows of W
+    in registers (csrc/dmp_fused.hip::smallk_embed_k).  C = 128 or 64, or a multiple of 128 (one launch, a grid row per
+    block of 128 columns); ``W`` / ``out`` may be column blocks of wider matrices (unit inner stride)."""
     lib = _lib.load()
     R, K = x.shape
-    H = W.size(1)
+    C = W.size(1)
+    H = H if H is not None else (C if C in (64, 128) else 128)
+    ncols = C // H
     if out is None:
-        out = torch.empty((R, H), dtype=torch.float32, device=x.device)
-    with _lib.timed("smallk_embed[K=%d,R=%d]", (K, R), 4 * (H + K + 1) * R):
-        check(lib.dmp_smallk_embed_gate(ptr(x), x.stride(0), K, ptr(W), W.stride(0), ptr(gate), R, H, ptr(out), out.stride(0),
-                                        stream_ptr()), "dmp_smallk_embed_gate")
+        out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    with _lib.timed("smallk_embed[K=%d,R=%d]", (K, R), 4 * (C + K + 1) * R):
+        check(lib.dmp_smallk_embed_cols(ptr(x), x.stride(0), K, ptr(W), W.stride(0), ptr(gate), R, H, ncols, ptr(out), out.stride(0),
+                                        stream_ptr()), "dmp_smallk_embed_cols")
+    return out
+
+
+def smallk_atb_cols(x, d, d2=None, out=None, H=None):
+    """``x^T [d | d2]`` per block of 128 (or 64: one block) columns -> [blocks, K, H]: ``smallk_atb`` over the column blocks
+    of ``d`` [R, ncols H] and one more matrix ``d2`` [R, H] in ONE launch."""
+    lib = _lib.load()
+    R, K = x.shape
+    C = d.size(1)
+    H = H if H is not None else (C if C in (64, 128) else 128)
+    ncols = C // H
+    nblk = ncols + (1 if d2 is not None else 0)
+    G = int(lib.dmp_smallk_atb_blocks(R))
+    part = torch.empty((nblk, G, K * H), dtype=torch.float32, device=d.device)
+    if out is None:
+        out = torch.empty((nblk, K, H), dtype=torch.float32, device=d.device)
+    with _lib.timed("smallk_atb[K=%d,R=%d]", (K, R), 4 * (nblk * H + K + 1) * R):
+        check(lib.dmp_smallk_atb_cols(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2), d2.stride(0) if d2 is not None else 0,
+                                      None, R, H, ptr(part), stream_ptr()), "dmp_smallk_atb_cols")
+    for j in range(nblk):
+        reduce_partials(part[j], out[j].view(-1))
     return out
 
 
@@ -488,17 +511,20 @@ USE_LAYER0 = _os.environ.get("DMP_LAYER0", "1") == "1"
 USE_LAYER0_NODES = _os.environ.get("DMP_LAYER0_NODES", "1") == "1"    # ... and the node rows' codes as well
 
 
-def l0_pack(enc_p, enc_g, gate=None):
-    """``[enc_p ; gate * enc_g]`` zero-padded to a multiple of 4 columns: the gated label codes of the union's edge rows."""
+def l0_pack(enc_p, enc_g, gate=None, stacked=False):
+    """``[enc_p ; gate * enc_g]`` zero-padded to a multiple of 4 columns: the gated label codes of the union's rows.
+    ``stacked``: the second kind of rows keep their codes in columns K..2K-1, so that two embedding tables stacked to
+    [2K, H] act as ONE table on the packed codes (the node rows: 2K <= 16)."""
     lib = _lib.load()
     _lib.require_gpu(enc_p, enc_g)
     K = enc_g.size(1)
-    Kpad = (K + 3) // 4 * 4
+    goff = K if stacked else 0
+    Kpad = (goff + K + 3) // 4 * 4
     n, rows_g = enc_p.size(0), enc_g.size(0)
     out = torch.empty((n + rows_g, Kpad), dtype=torch.float32, device=enc_g.device)
     gt = None if gate is None else gate.reshape(-1).contiguous()
     check(lib.dmp_l0_pack(ptr(enc_p), enc_p.stride(0) if n else K, n, ptr(enc_g), enc_g.stride(0) if rows_g else K, ptr(gt), rows_g,
-                          K, Kpad, ptr(out), stream_ptr()), "dmp_l0_pack")
+                          K, Kpad, goff, ptr(out), stream_ptr()), "dmp_l0_pack")
     return out
 
 
@@ -545,6 +571,12 @@ class Layer0Codes:
     def __init__(self, enc, K, W, esplit=0, nsplit=0, venc=None, VK=0, WV=None):
         self.enc, self.K, self.W, self.esplit, self.nsplit = enc, K, W, esplit, nsplit
         self.venc, self.VK, self.WV = venc, VK, WV
+
+    def vtables(self, N):
+        """-> one ``(table, node rows)`` per table of the node rows' embedding."""
+        if self.WV.size(0) == self.VK:
+            return [(0, (0, N))]
+        return [t for t in ((0, (0, self.nsplit)), (1, (self.nsplit, N))) if t[1][1] > t[1][0]]
 
     def tables(self, E, N):
         """-> one ``(table, edge rows, node rows)`` per embedding table."""
@@ -797,10 +829,8 @@ class _FusedDMPLayer(torch.autograd.Function):
             VK = l0.VK
             MV = WV0 @ Wx                                                                            # [T VK, 3H]
             XP = torch.empty((N, 3 * H), dtype=torch.float32, device=z.device)
-            for t, _, (n0, n1) in tables:
-                for j in range(3):
-                    if n1 > n0:
-                        smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK, j * H:(j + 1) * H], None, XP[n0:n1, j * H:(j + 1) * H])
+            for t, (n0, n1) in l0.vtables(N):
+                smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK], None, XP[n0:n1], H)
         else:
             XP = x @ Wx
         H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
@@ -945,12 +975,9 @@ class _FusedDMPLayer(torch.autograd.Function):
                     # passes on K columns instead of two [N,H] x [H,3H] products and the three-block weight gradient
                     VK, TVK = l0.VK, WV0.size(0)
                     Yn = torch.zeros((4 if ctx.residual else 3, TVK, H), dtype=torch.float32, device=dPn.device)
-                    for t, _, (n0, n1) in tables:
-                        if n1 > n0:
-                            for j in range(3):
-                                smallk_atb(l0.venc[n0:n1, :VK], dXP[n0:n1, j * H:(j + 1) * H], out=Yn[j, t * VK:(t + 1) * VK])
-                            if ctx.residual:
-                                smallk_atb(l0.venc[n0:n1, :VK], dxn[n0:n1], out=Yn[3, t * VK:(t + 1) * VK])
+                    for t, (n0, n1) in l0.vtables(N):
+                        smallk_atb_cols(l0.venc[n0:n1, :VK], dXP[n0:n1], dxn[n0:n1] if ctx.residual else None,
+                                        Yn[:, t * VK:(t + 1) * VK], H)
                 elif one_launch:
                     (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (x, dXP, None, False)])
                 else:

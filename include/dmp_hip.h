@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 47
+#define DMP_ABI_VERSION 48
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -519,6 +519,13 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * (embed.py:103-120 + basemodel.py:1515), written where the caller wants the gated rows (ldo >= H). */
 int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw,
                           const float *gate, int64_t rows, int H, float *out, int64_t ldo, void *stream);
+/* The same two over several column blocks in ONE launch: W / out [.., ncols * H] (ncols <= 8 blocks of H columns), and
+ * D [rows, ncols * H] plus an optional further block D2 [rows, H] of another matrix (NULL: none).
+ * partial: [ncols (+1), dmp_smallk_atb_blocks(rows), K*H] -- one dmp_reduce_partials per column block. */
+int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate,
+                          int64_t rows, int H, int ncols, float *out, int64_t ldo, void *stream);
+int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                        int64_t ldd2, const float *gate, int64_t rows, int H, float *partial, void *stream);
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);
@@ -527,14 +534,16 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
  * dmpnn.py:111-156): every product of the layer with z0 has rank K <= 16, so it is computed from the label codes
  * (csrc/dmp_layer0.hip).  H = 128 or 64.
  *   dmp_l0_pack      out[r, 0:Kpad] = r < rows_p ? enc_p[r, 0:K] : gate[r - rows_p] * enc_g[r - rows_p, 0:K], zero-padded
- *                    (the union's edge rows: pattern rows first, then the gated target rows; gate may be NULL).
+ *                    (the union's edge rows: pattern rows first, then the gated target rows; gate may be NULL).  The target
+ *                    rows' codes start at column goff: with goff = K the two kinds of rows occupy disjoint columns, so two
+ *                    embedding tables stacked to [2K, H] act as one (Kpad >= goff + K).
  *   dmp_l0_edge_fwd  out[r] = act(enc[r] MA + coef_e[r] (enc[r] MB) + P[sel_a[r], 0:H] - P[sel_b[r], H:2H] + bias)
  *                    with M = [MA | MB] = W [A | B]  ([K, ldm >= 2H]); replaces dmp_edge_fwd_typed for this layer.
  *   dmp_l0_bwd_w     partial[b] = [enc^T dPre | (coef_e enc)^T dPre | enc^T dZn] over workgroup b's rows
  *                    ([dmp_l0_bwd_w_blocks(rows), K, (dZn ? 3 : 2) * H]; finish with dmp_reduce_partials): the
  *                    class-typed weight gradient is W^T of the first two blocks, the embedding's gradient needs all three. */
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
-                int64_t rows_g, int K, int Kpad, float *out, void *stream);
+                int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream);
 int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                     const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t rows,
                     int H, float slope, float *out, int64_t ldo, void *stream);

@@ -62,3 +62,26 @@ def test_parent_fails_when_a_rank_fails():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert r.returncode != 0
     assert "needs an AMD GPU" in r.stderr and "rank process failed" in r.stderr
+
+
+def test_default_mode_tries_the_graph_child_then_the_eager_child():
+    """``python bench.py`` at N = 1 replays the step from a HIP graph in a child process and falls back to an eager child
+    when that one fails (no GPU needed: the children are stubbed by DMP_BENCH_CHILD_SELFTEST)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, want, fallback in (("graph_ok", "graph", False), ("graph_fails", "eager", True)):
+        env = dict(os.environ, DMP_BENCH_CHILD_SELFTEST=mode)
+        env.pop("DMP_BENCH_CHILD", None)
+        env.pop("WORLD_SIZE", None)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["config"]["launch"] == want
+        assert ("launch_fallback" in d["config"]) == fallback
+        assert (b"failed" in p.stderr) == fallback
