@@ -466,14 +466,24 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def profiler_attached():
+    """rocprofv3 (or another tool that preloads into this process) is driving the run."""
+    return any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def graph_then_eager(argv):
     """``python bench.py`` at N = 1: run ``bench.py --graph`` in a child process and relay its JSON line; if that child
-    fails (exit code, or no line), say so on stderr and run ``bench.py --eager`` in a second child.  Returns the exit code."""
+    fails (exit code, or no line), say so on stderr and run ``bench.py --eager`` in a second child.  Returns the exit code
+    (None: children cannot be started here)."""
     import subprocess
     env = dict(os.environ, DMP_BENCH_CHILD="1")
     note = None
     for mode in ("--graph", "--eager"):
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv) + [mode], env=env, stdout=subprocess.PIPE)
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv) + [mode], env=env, stdout=subprocess.PIPE)
+        except OSError as e:                                   # no child processes here: the caller runs the step itself
+            print("bench.py: cannot start a child process (%s): eager launches in this process" % e, file=sys.stderr, flush=True)
+            return None
         out = p.stdout.decode(errors="replace").splitlines()
         lines = [l for l in out if l.startswith("{")]
         for l in out:                                          # anything else the child printed
@@ -543,8 +553,15 @@ def main():
             and not os.environ.get("DMP_BENCH_CHILD")):
         # N = 1, no mode asked for: the step replayed from one HIP graph (how harness.fit(graph=True) trains), in a child
         # process -- a recording that fails takes its process with it -- and eager launches in a second child if it does.
-        # This process never touches the GPU.
-        sys.exit(graph_then_eager(sys.argv[1:]))
+        # This process never touches the GPU.  Under a profiler (its preloaded library has initialised the GPU in THIS
+        # process, which must then not start programs) and wherever children cannot be started: in this process.
+        if profiler_attached():
+            args.graph = True
+        else:
+            rc = graph_then_eager(sys.argv[1:])
+            if rc is not None:
+                sys.exit(rc)
+            args.eager = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -629,7 +646,7 @@ def main():
         _lib.timer.reset()
         _lib.timer.only = "seg_sum2["
         _lib.timer.enabled = True
-        for _ in range(2):
+        for _ in range(max(args.warmup, 5)):                   # the eager path's own warm-up (its allocations are not the graph's)
             step()
         step.finish()
         barrier()
