@@ -45,6 +45,8 @@ TILE_MAX_ROWS = 512     # kTileRows of csrc/dmp_agg.hip::seg_sum_tiled
 # kernel's bits, but measured 91.5 us against the plain kernel's 79-80 us at bench.py's shape (two 72 KB workgroups per
 # CU: the load -> barrier -> sums structure is exposed where the plain kernel keeps 32 waves per CU in flight); DESIGN.md §8.
 USE_TILED_SEG_SUM = False
+import os as _os
+USE_HIP_BATCHNORM = _os.environ.get("DMP_HIP_BATCHNORM", "1") == "1"   # training-mode BatchNorm1d of the MLPs on csrc/dmp_bn.hip
 
 
 def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
@@ -458,20 +460,88 @@ def linear_nn(x, weight, bias=None, relu=False, slope=0.0):
     return _LinearNN.apply(x, weight, bias, bool(relu), float(slope))
 
 
+class _BatchNormActTrain(torch.autograd.Function):
+    """``act(BatchNorm1d(x))`` in training mode (csrc/dmp_bn.hip): statistics, running-average update, normalisation and
+    the activation that follows in three small launches; the backward likewise."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
+        lib = _lib.load()
+        _lib.require_gpu(x)
+        x = x.contiguous()
+        R, C = x.shape
+        nb = int(lib.dmp_bn_partial_rows(R, C))
+        partial = torch.empty((nb, 2 * C), dtype=torch.float32, device=x.device)
+        stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        act = slope is not None
+        check(lib.dmp_bn_train_fwd(ptr(x), x.stride(0), R, C, ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
+                                   ptr(running_var), int(act), float(slope or 0.0), ptr(partial), ptr(stats), ptr(out), out.stride(0),
+                                   stream_ptr()), "dmp_bn_train_fwd")
+        ctx.save_for_backward(x, out if act else None, gamma)
+        ctx.stats, ctx.partial, ctx.slope = stats, partial, slope
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, gamma = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        act = ctx.slope is not None
+        check(lib.dmp_bn_train_bwd(ptr(x), x.stride(0), ptr(y), y.stride(0) if act else 0, ptr(dy), dy.stride(0), R, C, ptr(gamma),
+                                   int(act), float(ctx.slope or 0.0), ptr(ctx.partial), ptr(ctx.stats), ptr(dx), dx.stride(0),
+                                   stream_ptr()), "dmp_bn_train_bwd")
+        dgamma = ctx.stats[3 * C:] if gamma is not None else None
+        dbeta = ctx.stats[2 * C:3 * C] if gamma is not None else None
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_act_ok(bn, x):
+    """``batch_norm_act`` runs this module on this input: a training-mode ``BatchNorm1d`` with running statistics and a fixed
+    momentum over fp32 rows on the GPU, a width the kernel covers (csrc/dmp_bn.hip)."""
+    C = bn.num_features
+    return (type(bn) is torch.nn.BatchNorm1d and bn.training and bn.track_running_stats and bn.momentum is not None
+            and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(0) > 1 and x.size(1) == C
+            and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0 and (bn.weight is None) == (bn.bias is None))
+
+
+def batch_norm_act(bn, x, slope=None):
+    """``LeakyReLU(slope)(bn(x))`` (``slope`` None: no activation) for a module / input that ``batch_norm_act_ok`` accepts:
+    same values and the same side effects on the module's buffers as the module call."""
+    with torch.no_grad():
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
+
+
+def _act_slope(m):
+    if type(m) is torch.nn.ReLU:
+        return 0.0
+    if type(m) is torch.nn.LeakyReLU and 0.0 < m.negative_slope <= 1.0:
+        return float(m.negative_slope)
+    return None
+
+
 def apply_mlp(seq, x):
     """Run an ``nn.Sequential`` of Linear / BatchNorm / activation modules (nmlp / emlp,
-    dmpnn.py:45-60) with the Linear layers on ``linear_nn`` and Linear+ReLU pairs fused."""
+    dmpnn.py:45-60) with the Linear layers on ``linear_nn``, Linear+ReLU pairs fused and training-mode
+    BatchNorm1d (+ the activation after it) on ``batch_norm_act``."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
         if isinstance(m, torch.nn.Linear):
-            nxt = mods[i + 1] if i + 1 < len(mods) else None
-            slope = 0.0 if type(nxt) is torch.nn.ReLU else (
-                float(nxt.negative_slope) if type(nxt) is torch.nn.LeakyReLU and 0.0 < nxt.negative_slope <= 1.0 else None)
+            slope = _act_slope(nxt)
             fuse = slope is not None and m.bias is not None
             x = linear_nn(x, m.weight, m.bias, relu=fuse, slope=slope if fuse else 0.0)
             i += 2 if fuse else 1
+        elif USE_HIP_BATCHNORM and isinstance(m, torch.nn.BatchNorm1d) and batch_norm_act_ok(m, x):
+            slope = _act_slope(nxt)
+            x = batch_norm_act(m, x, slope)
+            i += 2 if slope is not None else 1
         else:
             x = m(x)
             i += 1

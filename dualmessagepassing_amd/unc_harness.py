@@ -68,7 +68,12 @@ def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=200
     steps_per_epoch = math.ceil(triplets.size(0) / graph_batch_size)
     if rescale_epochs:                                        # main.py:104: epochs counted in passes over the NODES
         n_epochs = math.ceil(n_epochs * steps_per_epoch * graph_batch_size / graph.number_of_nodes())
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    # Adam (main.py:112) as ONE launch over the flat parameter buffer: with weight_decay 0 the AdamW kernel IS Adam, and a
+    # parameter that never receives a gradient (nfc / efc, model.py:137-138) keeps zero moments and does not move
+    from .dp import FlatAdamW, FlatGradSync
+    sync = FlatGradSync(model)
+    master = sync.flatten_parameters()
+    optimizer = FlatAdamW([master], lr=lr, weight_decay=0.0)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, n_epochs * steps_per_epoch, eta_min=3e-6)
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
@@ -79,9 +84,10 @@ def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=200
             sub, samples, labels, edge_type, embed = _encode(model, graph, batch, sampler, sample_depth, sample_width,
                                                              graph_split_size, negative_sample, gen)
             loss = model.get_unsupervised_loss(sub, embed, edge_type, samples, labels)
-            optimizer.zero_grad(set_to_none=True)
+            sync.detach_grads()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
+            sync.pack()
+            torch.nn.utils.clip_grad_norm_([master], grad_norm)   # the flat gradient's norm is the norm over all parameters
             optimizer.step()
             scheduler.step()
             total += loss.detach()

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 48
+#define DMP_ABI_VERSION 49
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -550,6 +550,23 @@ int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
 int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd,
                  const float *dZn, int64_t ldz, int64_t rows, int H, float *partial, void *stream);
+
+/* BatchNorm1d in TRAINING mode over the rows of x [rows, C] with the activation that follows it fused in (the UNC layers'
+ * MLPs: Linear -> BatchNorm1d -> LeakyReLU -> Linear, UNC model.py:145-157; torch.nn.BatchNorm1d semantics: biased variance
+ * for the normalisation, running_var from the unbiased one, `momentum` update; running_* may be NULL).  csrc/dmp_bn.hip.
+ *   fwd: out = act(gamma (x - mean) / sqrt(var + eps) + beta)  (act != 0: LeakyReLU(slope), slope 0 = ReLU);
+ *        stats[0:C] = mean, stats[C:2C] = 1 / sqrt(var + eps) (kept for the backward).
+ *   bwd: dx = gamma invstd (dyb - sum(dyb) / rows - xhat sum(dyb xhat) / rows), dyb = act'(y) dy (y: the saved output);
+ *        stats[2C:3C] = dbeta, stats[3C:4C] = dgamma.
+ * partial: [dmp_bn_partial_rows(rows, C), 2C] scratch; stats: [4C].  C % 4 == 0, 256 % (C / 4) == 0, C <= 1024 (else
+ * DMP_ERR_UNSUPPORTED: 0 from dmp_bn_partial_rows); all matrices 16-byte aligned with row strides % 4 == 0. */
+int64_t dmp_bn_partial_rows(int64_t rows, int C);
+int dmp_bn_train_fwd(const float *x, int64_t ldx, int64_t rows, int C, const float *gamma, const float *beta, float eps,
+                     float momentum, float *running_mean, float *running_var, int act, float slope, float *partial,
+                     float *stats, float *out, int64_t ldo, void *stream);
+int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows,
+                     int C, const float *gamma, int act, float slope, float *partial, float *stats, float *dx, int64_t ldo,
+                     void *stream);
 
 /* out[l] (+)= sum_s partial[s, l], s in a fixed order; L % 4 == 0.  Also reduces the
  * split-K partial products of the weight gradients. */

@@ -18,7 +18,10 @@ g = build_graph_from_triplets(n, 1, trip, gpu)
 etype, norm = g.edata["type"], g.edata["norm"]
 th.manual_seed(0)
 model = TrainModel(None, n, h, 1, 0, num_hidden_layers=2, dropout=0.0, reg_param=0.01).to(gpu)
-opt = th.optim.Adam(model.parameters(), lr=1e-3)
+from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+sync = FlatGradSync(model)
+master = sync.flatten_parameters()
+opt = FlatAdamW([master], lr=1e-3, weight_decay=0.0)      # Adam (UNC main.py:112) as one launch over the flat parameters
 nid = th.arange(n, device=gpu)
 samples = th.from_numpy(np.concatenate([trip, np.stack([rng.integers(0, n, m), np.zeros(m, np.int64), rng.integers(0, n, m)], 1)])).to(gpu)
 labels = th.cat([th.ones(m), th.zeros(m)]).to(gpu)
@@ -37,20 +40,21 @@ def fwd():
 
 
 def step():
-    opt.zero_grad(set_to_none=True)
+    sync.detach_grads()
     emb, _ = model(g, nid, etype, norm)
     loss = model.get_unsupervised_loss(g, emb, etype, samples, labels)
     loss.backward()
+    sync.pack()
     opt.step()
     return loss
 
 
 print("UNC DMPNN hid=256, 2 layers, N=%d, E=%d: forward %.3f ms, train step (fwd+bwd+Adam) %.3f ms" % (n, 2 * m, timeit(fwd), timeit(step)))
 
-# the same step replayed from ONE HIP graph (dp.StepGraph): torch's capturable Adam keeps its step count on the device
+# the same step replayed from ONE HIP graph (dp.StepGraph): the optimizer keeps its step count and rate on the device
 from dualmessagepassing_amd.dp import StepGraph
-opt = th.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
-sg = StepGraph(lambda: step())
+opt = FlatAdamW([master], lr=1e-3, weight_decay=0.0, capturable=True)
+sg = StepGraph(lambda: step(), optimizer=opt)
 try:
     ms = timeit(sg)
     print("UNC train step as one HIP-graph replay: %.3f ms   (replays %d, eager %d)" % (ms, sg.replays, sg.eager_calls))

@@ -1,0 +1,64 @@
+"""Training-mode BatchNorm1d (+ the activation after it) on csrc/dmp_bn.hip against torch.nn.BatchNorm1d: values, running
+statistics, gradients (UNC model.py:145-157: Linear -> BatchNorm1d -> LeakyReLU -> Linear)."""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,c", [(2, 256), (37, 256), (2708, 256), (10858, 256), (70001, 128), (513, 64), (1000, 32)])
+@pytest.mark.parametrize("slope", [None, 1 / 5.5, 0.0])
+def test_batch_norm_act_equals_the_module(rows, c, slope, gpu):
+    from dualmessagepassing_amd import ops
+    gen = th.Generator().manual_seed(rows + c)
+    x0 = (th.randn(rows, c, generator=gen) * 3.0 + th.randn(c, generator=gen) * 5.0).to(gpu)      # means far from 0
+    dy = th.randn(rows, c, generator=gen).to(gpu)
+    bn_a, bn_b = th.nn.BatchNorm1d(c).to(gpu), th.nn.BatchNorm1d(c).to(gpu)
+    init = (th.rand(c, generator=gen) + 0.5, th.randn(c, generator=gen), th.randn(c, generator=gen), th.rand(c, generator=gen) + 0.5)
+    with th.no_grad():
+        for bn in (bn_a, bn_b):
+            for t, v in zip((bn.weight, bn.bias, bn.running_mean, bn.running_var), init):
+                t.copy_(v)
+    act = (lambda t: t) if slope is None else (th.nn.ReLU() if slope == 0.0 else th.nn.LeakyReLU(slope))
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    assert ops.batch_norm_act_ok(bn_a, xa)
+    for _ in range(2):                                         # two steps: the running averages accumulate
+        ya = ops.batch_norm_act(bn_a, xa, slope)
+        yb = act(bn_b(xb))
+    ga = th.autograd.grad(ya, [xa, bn_a.weight, bn_a.bias], dy)
+    gb = th.autograd.grad(yb, [xb, bn_b.weight, bn_b.bias], dy)
+    # fp64 reference of the forward
+    xd = x0.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    ref = (xd - mean) / (var + bn_b.eps).sqrt() * bn_b.weight.double() + bn_b.bias.double()
+    if slope is not None:
+        ref = th.where(ref > 0, ref, slope * ref)
+    assert float((ya.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((ya - yb).abs().max()) <= 2e-5 * max(1.0, float(yb.abs().max()))
+    assert th.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    assert th.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 2
+    for name, a, b in zip(("dx", "dgamma", "dbeta"), ga, gb):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 5e-5 * scale, (name, float((a - b).abs().max()), scale)
+
+
+def test_apply_mlp_takes_the_hip_batch_norm_in_training_only(gpu):
+    from dualmessagepassing_amd import ops
+    th.manual_seed(0)
+    mlp = th.nn.Sequential(th.nn.Linear(256, 256), th.nn.BatchNorm1d(256), th.nn.LeakyReLU(1 / 5.5), th.nn.Linear(256, 256)).to(gpu)
+    x = th.randn(300, 256, device=gpu)
+    calls = []
+    orig = ops.batch_norm_act
+    ops.batch_norm_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        mlp.train()
+        y = ops.apply_mlp(mlp, x)
+        assert calls == [1]
+        ref_mlp = th.nn.Sequential(*[m for m in mlp])
+        mlp.eval()
+        ye = ops.apply_mlp(mlp, x)
+        assert calls == [1]                                    # eval mode: the module itself
+    finally:
+        ops.batch_norm_act = orig
+    assert y.shape == ye.shape == (300, 256)
