@@ -47,19 +47,32 @@ __global__ __launch_bounds__(kBlock) void bn_partial_k(const BnArgs p) {
     else shift = ld4(p.x + c);
   }
   if (on) {
-    for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + grp; r < p.R; r += (int64_t)gridDim.x * rows_per_pass) {
-      const float4 x = ld4(p.x + r * p.ldx + c);
-      if (BWD) {
-        const float4 y = ld4(p.y + r * p.ldy + c);
-        float4 d = ld4(p.dy + r * p.lddy + c);
-        d.x = act_bwd(y.x, d.x, p.slope); d.y = act_bwd(y.y, d.y, p.slope); d.z = act_bwd(y.z, d.z, p.slope); d.w = act_bwd(y.w, d.w, p.slope);
-        a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-        b.x += d.x * ((x.x - mean.x) * invstd.x); b.y += d.y * ((x.y - mean.y) * invstd.y);
-        b.z += d.z * ((x.z - mean.z) * invstd.z); b.w += d.w * ((x.w - mean.w) * invstd.w);
-      } else {
-        const float4 d = make_float4(x.x - shift.x, x.y - shift.y, x.z - shift.z, x.w - shift.w);
-        a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-        b.x += d.x * d.x; b.y += d.y * d.y; b.z += d.z * d.z; b.w += d.w * d.w;
+    const int64_t step = (int64_t)gridDim.x * rows_per_pass;
+    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_pass + grp; r0 < p.R; r0 += 4 * step) {
+      float4 x[4], y[4], d[4];                               // four rows in flight: the loop is a memory round trip per pass
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * step;
+        const bool ok = r < p.R;
+        x[u] = ok ? ld4(p.x + r * p.ldx + c) : (BWD ? mean : shift);
+        if (BWD) {
+          y[u] = ok ? ld4(p.y + r * p.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          d[u] = ok ? ld4(p.dy + r * p.lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (BWD) {
+          float4 g = d[u];
+          g.x = act_bwd(y[u].x, g.x, p.slope); g.y = act_bwd(y[u].y, g.y, p.slope); g.z = act_bwd(y[u].z, g.z, p.slope); g.w = act_bwd(y[u].w, g.w, p.slope);
+          a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+          b.x += g.x * ((x[u].x - mean.x) * invstd.x); b.y += g.y * ((x[u].y - mean.y) * invstd.y);
+          b.z += g.z * ((x[u].z - mean.z) * invstd.z); b.w += g.w * ((x[u].w - mean.w) * invstd.w);
+        } else {
+          const float4 e = make_float4(x[u].x - shift.x, x[u].y - shift.y, x[u].z - shift.z, x[u].w - shift.w);
+          a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+          b.x += e.x * e.x; b.y += e.y * e.y; b.z += e.z * e.z; b.w += e.w * e.w;
+        }
       }
     }
   }
@@ -84,17 +97,19 @@ struct BnFinArgs {
   float *stats;                        // forward: writes mean | invstd; backward: writes dbeta | dgamma at [2C, 4C)
 };
 
-// one workgroup: lanes own 4 columns each (C / 4 lanes), the row groups of the block split the partial rows among them (a
+// a workgroup per 32 columns: 8 lanes own 4 columns each, the 32 row groups of the block split the partial rows among them (a
 // fixed split, combined in a fixed order through LDS: bit-stable), sums in double
+constexpr int kFinCols = 32;
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void bn_finalize_k(const BnFinArgs p) {
   __shared__ double red[2][kBlock][4];
-  const int G = p.C / 4, groups = kBlock / G;
+  constexpr int G = kFinCols / 4, groups = kBlock / G;
   const int lane = threadIdx.x % G, grp = threadIdx.x / G;
-  const int c = lane * 4;
+  const int c = blockIdx.x * kFinCols + lane * 4;
+  const bool on = c < p.C;                                   // C % 4 == 0: a lane's 4 columns are in or out together
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
   const int per = (p.blocks + groups - 1) / groups;
-  const int s0 = grp * per, s1 = (s0 + per < p.blocks) ? s0 + per : p.blocks;
+  const int s0 = grp * per, s1 = !on ? s0 : ((s0 + per < p.blocks) ? s0 + per : p.blocks);
 #pragma unroll 4
   for (int s = s0; s < s1; ++s) {
     const float4 u = ld4(p.partial + (int64_t)s * 2 * p.C + c), v = ld4(p.partial + (int64_t)s * 2 * p.C + p.C + c);
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_k(const BnFinArgs p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = a[j]; red[1][threadIdx.x][j] = b[j]; }
   __syncthreads();
-  if (grp != 0) return;
+  if (grp != 0 || !on) return;
   for (int g = 1; g < groups; ++g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] += red[0][g * G + lane][j]; b[j] += red[1][g * G + lane][j]; }
@@ -200,7 +215,7 @@ int dmp_bn_train_fwd(const float *x, int64_t ldx, int64_t rows, int C, const flo
   BnArgs a{x, ldx, nullptr, 0, nullptr, 0, rows, C, partial, stats, slope};
   bn_partial_k<false><<<nb, kBlock, 0, st>>>(a);
   BnFinArgs f{partial, (int)nb, rows, C, x, eps, momentum, running_mean, running_var, stats};
-  bn_finalize_k<false><<<1, kBlock, 0, st>>>(f);
+  bn_finalize_k<false><<<(unsigned)((C + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(f);
   BnApplyArgs ap{x, ldx, nullptr, 0, nullptr, 0, gamma, beta, stats, rows, C, slope, act, out, ldo};
   const int rows_per_pass = kBlock / (C / 4);
   const int64_t want = (rows + rows_per_pass - 1) / rows_per_pass;
@@ -224,7 +239,7 @@ int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, c
   BnArgs a{x, ldx, ym, ldm, dy, lddy, rows, C, partial, stats, sl};
   bn_partial_k<true><<<nb, kBlock, 0, st>>>(a);
   BnFinArgs f{partial, (int)nb, rows, C, nullptr, 0.f, 0.f, nullptr, nullptr, stats};
-  bn_finalize_k<true><<<1, kBlock, 0, st>>>(f);
+  bn_finalize_k<true><<<(unsigned)((C + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(f);
   BnApplyArgs ap{x, ldx, ym, ldm, dy, lddy, gamma, nullptr, stats, rows, C, sl, 1, dx, ldo};
   const int rows_per_pass = kBlock / (C / 4);
   const int64_t want = (rows + rows_per_pass - 1) / rows_per_pass;
