@@ -132,7 +132,8 @@ def test_layer0_equals_the_general_layer(h, act, gated, residual, tables, nodes,
         assert float((g - w).abs().max()) <= tol * scale, (name, float((g - w).abs().max()), scale)
 
 
-def test_model_with_and_without_the_label_code_path(gpu):
+@pytest.mark.parametrize("hid,act,emb", [(128, "leaky_relu", "Equivariant"), (64, "relu", "Orthogonal"), (128, "relu", "Normal")])
+def test_model_with_and_without_the_label_code_path(hid, act, emb, gpu):
     """The BASELINE configs[0] batch through the whole model with the first layer on the label codes (default) and on the
     general path: prediction and every parameter gradient."""
     import os
@@ -142,7 +143,7 @@ def test_model_with_and_without_the_label_code_path(gpu):
     from dualmessagepassing_amd import fused
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device
-    cfg = dict(bench.CFG, batch=32)
+    cfg = dict(bench.CFG, batch=32, hid=hid, act=act, emb=emb)
     shard = bench.make_shard(cfg, 0, gpu)
     th.manual_seed(3)
     model = build_model(**bench.model_config(cfg)).to(gpu)
