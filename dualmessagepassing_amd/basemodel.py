@@ -31,11 +31,12 @@ from .rgnn import RGCNRepMixin, RGINRepMixin
 class OutputDict(OrderedDict):
     """Ordered mapping with attribute access (container.py:14-100, the part callers use).  An entry may be deferred
     (``embed.DeferredEmbedding``: the target embeddings, which the joint rep-net pass does not need as tensors): it becomes
-    its tensor the first time it is read, by whatever accessor."""
+    its tensor the first time it is read, by whatever accessor.  Likewise ``embed.DeferredRows`` (the last layer's edge rows
+    under pooling heads)."""
 
     def _resolve(self, k, v):
-        from .embed import DeferredEmbedding
-        if isinstance(v, DeferredEmbedding):
+        from .embed import DeferredEmbedding, DeferredRows
+        if isinstance(v, (DeferredEmbedding, DeferredRows)):
             v = v.materialize()
             OrderedDict.__setitem__(self, k, v)
         return v

@@ -367,17 +367,52 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     from . import fused
     folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch
     sums = (None, None)
+    lazy_e = None
     for i, (layer, fw) in enumerate(zip(layers, folded)):
         if pools is not None and i == len(layers) - 1:
             # the last layer also pools its outputs per graph (``pools``: PoolIndex over the union's node / edge rows): a
-            # gradient that comes back only through the edge sums never becomes an [E, H] tensor (fused._FusedDMPLayer)
-            v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
+            # gradient that comes back only through the edge sums never becomes an [E, H] tensor (fused._FusedDMPLayer) --
+            # and the edge rows themselves are only formed if somebody reads them (``embed.DeferredRows``): their sums come
+            # from two pooled passes.  A reader gets the rows, differentiable, from the layer's ordinary form.
+            if pools[1] is not None and getattr(model, "lazy_edge_rep", True) and th.is_grad_enabled():
+                v_in, e_in = v, e
+                v, _, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, tuple(pools[:2]) + (False,))
+                lazy_e = _LazyEdgeRows(lambda: layer.forward_fused(union, v_in, e_in, vg, eg, model.rep_residual, fw)[1],
+                                       ep_, (e_in.size(0), layer.hidden_dim), e_in.dtype, e_in.device)
+            else:
+                v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
             sums = (vs, es)
         else:
             v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None)
     p_v, g_v = _SplitRows.apply(v, np_)
+    if lazy_e is not None:
+        return p_v, lazy_e.part(0), g_v, lazy_e.part(1), v, lazy_e.whole(), sums
     p_e, g_e = _SplitRows.apply(e, ep_)
     return p_v, p_e, g_v, g_e, v, e, sums
+
+
+class _LazyEdgeRows:
+    """The union's edge rows of the last layer, computed on first access (``fn``), and their pattern / target parts."""
+
+    def __init__(self, fn, split, shape, dtype, device):
+        self._fn, self._split, self._shape, self._dtype, self._device = fn, split, shape, dtype, device
+        self._rows = self._parts = None
+
+    def _get(self):
+        if self._rows is None:
+            self._rows = self._fn()
+            self._parts = _SplitRows.apply(self._rows, self._split)
+            self._fn = None
+        return self._rows, self._parts
+
+    def whole(self):
+        from .embed import DeferredRows
+        return DeferredRows(lambda: self._get()[0], self._shape, self._dtype, self._device)
+
+    def part(self, i):
+        from .embed import DeferredRows
+        rows = self._split if i == 0 else self._shape[0] - self._split
+        return DeferredRows(lambda: self._get()[1][i], (rows, self._shape[1]), self._dtype, self._device)
 
 
 def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate, p_nodes):

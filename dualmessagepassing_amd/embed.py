@@ -121,9 +121,32 @@ class DeferredEmbedding:
         return self._value
 
 
+class DeferredRows:
+    """A [rows, width] tensor that is computed (by ``fn``, once) only if somebody reads it -- the edge representation of the
+    LAST rep-net layer under sum / mean pooling heads: the heads read per-graph sums, which the layer produces without ever
+    forming the rows (``fused._FusedDMPLayer``, ``edge_rows=False``); ``OutputDict["g_e_rep"]`` and friends still deliver the
+    rows, differentiable, by running the layer's ordinary form on first access."""
+
+    def __init__(self, fn, shape, dtype, device):
+        self._fn, self._value = fn, None
+        self.shape, self.dtype, self.device, self.is_cuda = th.Size(shape), dtype, device, device.type == "cuda"
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def dim(self):
+        return len(self.shape)
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._fn()
+            self._fn = None
+        return self._value
+
+
 def materialize(t):
-    """The tensor behind ``t`` (a tensor, None or a ``DeferredEmbedding``)."""
-    return t.materialize() if isinstance(t, DeferredEmbedding) else t
+    """The tensor behind ``t`` (a tensor, None, a ``DeferredEmbedding`` or ``DeferredRows``)."""
+    return t.materialize() if isinstance(t, (DeferredEmbedding, DeferredRows)) else t
 
 
 def _zero_pad(emb):

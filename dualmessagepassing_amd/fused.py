@@ -792,11 +792,14 @@ class _FusedDMPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
-                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None):
+                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None, edge_rows=True):
         """``l0`` (``Layer0Codes``) with ``W0 = l0.W`` / ``WV0 = l0.WV`` as differentiable inputs: the FIRST layer of a rep-net
         whose edge rows are a label embedding, ``z = enc W0``.  Every product with ``z`` runs on its K-column factor
         (csrc/dmp_layer0.hip); ``z`` itself is only read as the residual and takes no gradient: the embedding's gradient comes
         back as ``dW0``.  With ``l0.venc`` the same for the node rows ``x = venc WV0`` (products with ``x`` -> ``dWV0``).
+        ``edge_rows=False`` (with ``epool``): ``zn`` is not formed (None is returned in its place); its per-graph sums are
+        ``pool(zn) = pool(z) + pool(g (.) H1) W2^T + (sum g) b2`` -- two pooled passes over E rows instead of the Linear +
+        gate + residual kernel (two reads, one write) and a pooled pass over its output.
         ``vpool`` / ``epool`` (``ops.PoolIndex`` over the node / edge rows; the LAST layer of a rep-net whose outputs
         feed sum / mean pooling heads): two more outputs, the per-graph sums of ``xn`` / ``zn`` ([G, H]; edges with a flag
         [G, 2H] = [non-reversed | reversed]).  A gradient that arrives ONLY through the edge sums is never expanded to
@@ -839,25 +842,27 @@ class _FusedDMPLayer(torch.autograd.Function):
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
+        sums_only = epool is not None and not edge_rows
+        zn = None
         if l0 is not None:
             H1e = torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
             for t, rows, _ in tables:
                 l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e)
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
-        elif edge_chain_ok(index, H) and eW2t is not None:
+        elif edge_chain_ok(index, H) and eW2t is not None and not sums_only:
             H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         elif mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         else:
             G = z @ Wes
             H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True, slope=slope)
             del G
-            Oe = torch.addmm(eb2, H1e, eW2.t())
-            zn = gate_residual(z if residual else None, Oe, e_gate)
+            if not sums_only:
+                Oe = torch.addmm(eb2, H1e, eW2.t())
+                zn = gate_residual(z if residual else None, Oe, e_gate)
+        if zn is None and not sums_only:
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
@@ -868,7 +873,18 @@ class _FusedDMPLayer(torch.autograd.Function):
             return xn, zn
         ctx.set_materialize_grads(False)    # a missing gradient stays None (the common case: only the sums are used)
         vs = pool_rows(xn, vpool) if vpool is not None else None
-        es = pool_rows(zn, epool) if epool is not None else None
+        if sums_only:
+            halves = 2 if epool.flag8 is not None else 1
+            G_ = epool.num_graphs
+            Q = pool_rows(H1e, epool, e_gate).view(G_ * halves, H)                      # sum of g H1 per graph (and flag)
+            ones = (e_gate if e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
+            cnt = pool_rows(ones.view(-1, 1).repeat(1, 4), epool).view(G_ * halves, 4)[:, :1]   # sum of g (vector kernel: 4 equal columns)
+            es = torch.addmm(cnt * eb2, Q, eW2.t())
+            if residual:
+                es = es + pool_rows(z, epool).view(G_ * halves, H)
+            es = es.view(G_, halves * H)
+        else:
+            es = pool_rows(zn, epool) if epool is not None else None
         return xn, zn, vs, es
 
     @staticmethod
@@ -1019,7 +1035,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dWx = WV0.t() @ Y
                 dWV0 = torch.addmm(Yn[3], Y, Wx.t()) if ctx.residual else Y @ Wx.t()
         return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None,
-                None, None, None, dW0, dWV0)
+                None, None, None, dW0, dWV0, None)
 
 
 def activation_slope(act):
@@ -1050,11 +1066,13 @@ def l0_nodes_ok(H, enc_p, enc_g, W_p, W_g):
 
 def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None):
     """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch).
-    ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None)``: also returns the per-graph sums of both outputs.
+    ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None[, edge rows wanted])``: also returns the per-graph sums of
+    both outputs; with the third entry False the edge rows themselves are not formed (None in their place).
     ``l0`` (``Layer0Codes``): ``z`` is ``l0.enc @ l0.W`` (and ``x`` is ``l0.venc @ l0.WV``), see ``_FusedDMPLayer.forward``."""
     n2, e2 = layer.nmlp[2], layer.emlp[2]
     Bn, bn, Wx, Wes, be, WesT, nW2t, eW2t = folded if folded is not None else fold_layers([layer])[0]
-    vpool, epool = pools if pools is not None else (None, None)
+    vpool, epool = pools[:2] if pools is not None else (None, None)
+    edge_rows = pools[2] if pools is not None and len(pools) > 2 else True
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
                                 n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]),
-                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV)
+                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV, edge_rows)
