@@ -229,8 +229,8 @@ def build_step(cfg, shard, device, world=1):
 
 
 PROFILE_ROUND = "r03"
-SEG_IN = "seg_sum_vec<32, true, false, true, 0>"       # flag-split segment sum over the CSR by destination (forward)
-SEG_INC = "seg_sum_vec<32, true, false, true, 1>"      # the same kernel over the incidence CSR (backward of the edge gathers)
+SEG_IN = "seg_sum_vec<32, true, false, true, 0, 256>"       # flag-split segment sum over the CSR by destination (forward)
+SEG_INC = "seg_sum_vec<32, true, false, true, 1, 256>"      # the same kernel over the incidence CSR (backward of the edge gathers)
 
 
 def committed_profile(n_rows, n_edges, H):
