@@ -360,9 +360,7 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
     elif e_gate is not None:
         eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
-    if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):
-        if l0 is not None:
-            raise RuntimeError("joint_rep: layer-0 label-code path chosen for layers the fused path cannot run")
+    if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):     # e.g. dropout in training: the callers run the two loops
         return None
     from . import fused
     folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch

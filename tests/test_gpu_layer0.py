@@ -176,3 +176,36 @@ def test_model_with_and_without_the_label_code_path(hid, act, emb, gpu):
     for n in g0:
         scale = max(1.0, float(g0[n].abs().max()))
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * scale, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
+def test_a_model_the_fused_path_cannot_run_falls_back(gpu):
+    """Dropout in the rep-net (training mode) takes the layers off the fused path: the joint pass declines -- also after it
+    has looked at the label codes -- and the model runs the reference's two loops."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from dualmessagepassing_amd import fused
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.collate import collate_device
+    cfg = dict(bench.CFG, batch=8)
+    shard = bench.make_shard(cfg, 0, gpu)
+    th.manual_seed(3)
+    model = build_model(**dict(bench.model_config(cfg), rep_dropout=0.2)).to(gpu)
+    model.train()
+    gs = []
+    for tag in ("p", "g"):
+        s = shard[tag]
+        gs.append(collate_device(s["local_src"], s["local_dst"], s["num_nodes"], s["num_edges"], s["N"], s["E"], ndata=s["ndata"],
+                                 edata=s["edata"], max_nodes=s["max_n"], max_edges=s["max_e"]))
+    calls = []
+    orig = fused.l0_edge_fwd
+    fused.l0_edge_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = model(*gs)
+    finally:
+        fused.l0_edge_fwd = orig
+    assert not calls
+    (out["pred_c"] ** 2).sum().backward()
+    assert all(th.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert th.is_tensor(out["g_e_rep"]) and out["g_e_rep"].shape[1] == cfg["hid"]
