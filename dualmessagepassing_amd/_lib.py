@@ -223,6 +223,18 @@ def stream_ptr():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+_CAPTURE_PINS = []
+
+
+def pin_for_capture(*tensors):
+    """A tensor that was allocated OUTSIDE a stream capture (a memoised index array) and is about to be read by kernels
+    being recorded must outlive the recording: the memo that owns it may evict it later.  Inside a capture this keeps a
+    reference for the life of the process (small integer arrays, a few per recording); outside it does nothing."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        _CAPTURE_PINS.extend(t for t in tensors if t is not None)
+
+
 def require_gpu(*tensors):
     """Every tensor of a launch must live on the GPU that is CURRENT: the library launches on the current device's
     stream (``stream_ptr``) and never switches devices itself, so a tensor of another GPU would be handed to the wrong

@@ -198,33 +198,55 @@ class _TakeRows(torch.autograd.Function):
     segment sum over a CSR of the index values (torch's advanced-indexing backward serialises on
     repeated indices: 1.9 ms for 21,716 lookups into 2,708 rows in the UNC score head)."""
 
+    _memo = []     # (ident of the key tensor, (rowptr, ent, idx32), key tensor): see PoolIndex.from_keys
+
     @staticmethod
-    def forward(ctx, X, idx):
+    def forward(ctx, X, idx, key=None):
         lib = _lib.load()
         _lib.require_gpu(X, idx)
-        idx = idx.view(-1).to(torch.int64).contiguous()
         M, N = idx.numel(), X.size(0)
-        i32 = dict(dtype=torch.int32, device=X.device)
-        ctx.rowptr, ctx.ent = torch.empty(N + 1, **i32), torch.empty(M, **i32)
-        idx32, deg = torch.empty(M, **i32), torch.empty(N, dtype=torch.int64, device=X.device)
-        status = torch.empty(1, **i32)
-        ws = torch.empty(lib.dmp_csr_workspace_words(N, M), **i32)
-        check(lib.dmp_csr_build(ptr(idx), None, M, N, ptr(ctx.rowptr), ptr(ctx.ent), ptr(idx32), ptr(deg), ptr(status),
-                                ptr(ws), stream_ptr()), "dmp_csr_build(index)")
-        if _lib.VALIDATE and int(status.item()) != 0:
-            raise _lib.DmpError("take_rows: index outside [0, %d)" % N)
+        # The CSR of the index values only depends on ``idx``: a caller that looks up the SAME index tensor step after step
+        # (UNC: the node ids of its one graph, the triplets of a full-graph step) gets it from a small memo keyed on the
+        # tensor's identity and version (``key``: the tensor ``idx`` was derived from, when ``idx`` itself is a temporary).
+        k = key if key is not None else idx
+        ident = (k.data_ptr(), k._version, int(k.numel()), tuple(k.stride()), str(k.device), str(k.dtype), int(M), int(N))
+        memo, hit = _TakeRows._memo, None
+        for i, m in enumerate(memo):
+            if m[0] == ident:
+                if i:
+                    memo.insert(0, memo.pop(i))
+                hit = m[1]
+                _lib.pin_for_capture(*hit)
+                break
+        if hit is None:
+            idx = idx.view(-1).to(torch.int64).contiguous()
+            i32 = dict(dtype=torch.int32, device=X.device)
+            rowptr, ent = torch.empty(N + 1, **i32), torch.empty(M, **i32)
+            idx32, deg = torch.empty(M, **i32), torch.empty(N, dtype=torch.int64, device=X.device)
+            status = torch.empty(1, **i32)
+            ws = torch.empty(lib.dmp_csr_workspace_words(N, M), **i32)
+            check(lib.dmp_csr_build(ptr(idx), None, M, N, ptr(rowptr), ptr(ent), ptr(idx32), ptr(deg), ptr(status),
+                                    ptr(ws), stream_ptr()), "dmp_csr_build(index)")
+            if _lib.VALIDATE and int(status.item()) != 0:
+                raise _lib.DmpError("take_rows: index outside [0, %d)" % N)
+            hit = (rowptr, ent, idx32)
+            if not torch.cuda.is_current_stream_capturing():    # arrays made inside a recording belong to its memory pool
+                memo.insert(0, (ident, hit, k))                 # the key tensor is kept alive: its address stays unique
+                del memo[4:]
+        ctx.rowptr, ctx.ent = hit[0], hit[1]
         ctx.N = N
-        return gather_rows_raw(X.contiguous(), idx32)
+        return gather_rows_raw(X.contiguous(), hit[2])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dO):
-        return seg_sum_raw(dO.contiguous(), ctx.rowptr, ctx.ent, ctx.N, rows_shared=False), None
+        return seg_sum_raw(dO.contiguous(), ctx.rowptr, ctx.ent, ctx.N, rows_shared=False), None, None
 
 
-def take_rows(X, idx):
-    """Differentiable ``X[idx]`` (rows) on the gather / segment-sum kernels."""
-    return _TakeRows.apply(X, idx)
+def take_rows(X, idx, key=None):
+    """Differentiable ``X[idx]`` (rows) on the gather / segment-sum kernels.  ``key``: the tensor ``idx`` was computed
+    from, if ``idx`` is a temporary (the index's CSR is memoised on the key's identity and version)."""
+    return _TakeRows.apply(X, idx, key)
 
 
 class _TakeRowsSmallTable(torch.autograd.Function):
@@ -578,6 +600,7 @@ class PoolIndex:
             if m[0] == ident:
                 if i:
                     memo.insert(0, memo.pop(i))             # most recently used first
+                _lib.pin_for_capture(m[1])                  # a recording that reads the index keeps it alive
                 return m[1]
         keys_in = keys
         keys = keys.view(-1).to(torch.int64)

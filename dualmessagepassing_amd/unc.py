@@ -249,7 +249,7 @@ class TrainModel(nn.Module):
     def calc_score(self, embedding, triplets):
         node_emb = embedding[0] if isinstance(embedding, (tuple, list)) else embedding
         # model.py:669-677; the two endpoint lookups as ONE row gather whose backward is a segment sum
-        so = ops.take_rows(node_emb, torch.cat([triplets[:, 0], triplets[:, 2]]))
+        so = ops.take_rows(node_emb, torch.cat([triplets[:, 0], triplets[:, 2]]), key=triplets)
         s, o = so[:triplets.size(0)], so[triplets.size(0):]
         r = ops.take_rows_small_table(self.w_relation, triplets[:, 1])
         return torch.sum(s * r * o, dim=1)
