@@ -221,7 +221,23 @@ def build_step(cfg, shard, device, world=1):
             finish()
         return loss
 
+    def front():
+        """The recordable part of a data-parallel step: batch, forward, loss, backward, gradient pack (no collective)."""
+        pattern, graph = batch_of(shard)
+        sync.detach_grads()
+        out = model(pattern, graph)
+        loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])
+        loss.backward()
+        sync.pack()
+        return loss
+
+    def tail():
+        """... and what follows it with eager launches: the gradient all-reduce (RCCL) and the optimizer update."""
+        sync.sync()
+        opt.step()
+
     step.finish = finish
+    step.front, step.tail = front, tail
     step.sync = sync
     step.opt = opt
     step.micro_batches = M
@@ -606,6 +622,19 @@ def main():
         from dualmessagepassing_amd.dp import StepGraph
         run = StepGraph(lambda: step(), optimizer=step.opt, max_shapes=1)
         graphed = True
+    elif args.graph and world > 1 and step.micro_batches == 1:
+        # more than one rank: forward + backward + gradient pack replayed from one HIP graph per rank, the gradient
+        # all-reduce and the optimizer update launched eagerly after every replay (no collective inside a recording)
+        from dualmessagepassing_amd.dp import StepGraph
+        front_graph = StepGraph(lambda: step.front(), optimizer=step.opt, max_shapes=1)
+
+        def run():
+            loss = front_graph()
+            step.tail()
+            return loss
+
+        run.on_stream = front_graph.on_stream
+        graphed = True
     if graphed:          # the recordings' side stream is the current stream of everything below (see dp.StepGraph)
         import contextlib
         stack = contextlib.ExitStack()
@@ -724,7 +753,10 @@ def main():
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default",
-                       "launch": ("one HIP graph replay per step (recorded during the warm-up; the roofline kernel's HIP-event time "
+                       "launch": (("one HIP graph replay per step" if world == 1 else
+                                   "forward + backward + gradient pack as one HIP graph replay per rank and step, all-reduce and "
+                                   "optimizer update launched eagerly")
+                                  + " (recorded during the warm-up; the roofline kernel's HIP-event time "
                                   "from the same number of eager steps run after the timed region: eager_ms_per_step)")
                        if graphed else "eager launches",
                        "eager_ms_per_step": round(eager_ms, 3) if eager_ms is not None else None,

@@ -52,3 +52,12 @@ def test_cpu_baseline_object(gpu):
     d = _run("--eager", timeout=900)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+
+
+def test_two_ranks_replay_their_forward_backward(gpu):
+    """--gpus 2 --graph: each rank replays forward + backward + gradient pack from one HIP graph, the all-reduce and the
+    optimizer update follow eagerly (here: two ranks time-sharing the one GPU over gloo -- the plumbing, not a scaling run)."""
+    d = _run("--gpus", "2", "--backend", "gloo", "--single-device", "--graph", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["launch"].startswith("forward + backward + gradient pack as one HIP graph replay per rank")
+    assert d["value"] > 0 and abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
