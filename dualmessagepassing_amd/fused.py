@@ -582,7 +582,10 @@ class Layer0Codes:
         """-> one ``(table, edge rows, node rows)`` per embedding table."""
         if self.W.size(0) == self.K:
             return [(0, (0, E), (0, N))]
-        return [t for t in ((0, (0, self.esplit), (0, self.nsplit)), (1, (self.esplit, E), (self.nsplit, N))) if t[1][1] > t[1][0]]
+        # a table stays in the list while it has edge rows OR node rows (a pattern batch without edges still has nodes, whose
+        # aggregates are zero rows): the loops over the list skip the empty range themselves
+        return [t for t in ((0, (0, self.esplit), (0, self.nsplit)), (1, (self.esplit, E), (self.nsplit, N)))
+                if t[1][1] > t[1][0] or t[2][1] > t[2][0]]
 
 
 _ATB_JOB = None
@@ -847,7 +850,8 @@ class _FusedDMPLayer(torch.autograd.Function):
         if l0 is not None:
             H1e = torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
             for t, rows, _ in tables:
-                l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e)
+                if rows[1] > rows[0]:
+                    l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e)
         elif edge_chain_ok(index, H) and eW2t is not None and not sums_only:
             H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
@@ -957,9 +961,11 @@ class _FusedDMPLayer(torch.autograd.Function):
             if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor
                 W0, WV0 = ctx.l0_W
                 K0, TK = l0.K, W0.size(0)
-                XX = torch.empty((TK, (3 if ctx.residual else 2) * H), dtype=torch.float32, device=dG.device)
+                full = all(r[1] > r[0] and n[1] > n[0] for _, r, n in tables) and len(tables) * K0 == TK   # every table has edge rows and node rows
+                XX = (torch.empty if full else torch.zeros)((TK, (3 if ctx.residual else 2) * H), dtype=torch.float32, device=dG.device)
                 for t, rows, _ in tables:
-                    l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0])
+                    if rows[1] > rows[0]:
+                        l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0])
                 dWes = None
             else:
                 dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
@@ -980,7 +986,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # S = [S0_in W0 | S0_out W0] was never built: X[h] = S0_h^T dPn per table (N rows, K columns) carries both
                 # dBn_h = W0^T X[h] and the segment sums' part of the embedding gradient, sum_h X[h] Bn_h^T (no dS either)
                 Kp, S0 = l0.enc.size(1), ctx.l0_S0
-                Xn = torch.zeros((2, TK, H), dtype=torch.float32, device=dPn.device)
+                Xn = (torch.empty if full else torch.zeros)((2, TK, H), dtype=torch.float32, device=dPn.device)
                 for t, _, (n0, n1) in tables:
                     if n1 > n0:
                         for h in (0, 1):
@@ -990,7 +996,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                     # x = venc WV0:  x^T dXP = WV0^T (venc^T dXP)  and  venc^T dx = venc^T dxn + (venc^T dXP) Wx^T -- N-row
                     # passes on K columns instead of two [N,H] x [H,3H] products and the three-block weight gradient
                     VK, TVK = l0.VK, WV0.size(0)
-                    Yn = torch.zeros((4 if ctx.residual else 3, TVK, H), dtype=torch.float32, device=dPn.device)
+                    vfull = all(n1 > n0 for _, (n0, n1) in l0.vtables(N)) and len(l0.vtables(N)) * VK == TVK
+                    Yn = (torch.empty if vfull else torch.zeros)((4 if ctx.residual else 3, TVK, H), dtype=torch.float32, device=dPn.device)
                     for t, (n0, n1) in l0.vtables(N):
                         smallk_atb_cols(l0.venc[n0:n1, :VK], dXP[n0:n1], dxn[n0:n1] if ctx.residual else None,
                                         Yn[:, t * VK:(t + 1) * VK], H)

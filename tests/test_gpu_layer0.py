@@ -13,11 +13,12 @@ def _index(src, dst, n, rev, dev):
     return GraphIndex(th.from_numpy(src).to(dev), th.from_numpy(dst).to(dev), n, th.from_numpy(rev).to(dev), validate=True)
 
 
-def _case(rows, n_pat, k, h, gated, seed, dev):
+def _case(rows, n_pat, k, h, gated, seed, dev, n_split=None):
     rng = np.random.default_rng(seed)
     gen = th.Generator().manual_seed(seed)
     n = max(4, rows // 7)
-    n_split = max(1, n // 40) if n_pat else 0             # the pattern's edges stay among the pattern's nodes (a union of two batches)
+    if n_split is None:
+        n_split = max(1, n // 40) if n_pat else 0         # the pattern's edges stay among the pattern's nodes (a union of two batches)
     src, dst = rng.integers(n_split, n, rows).astype(np.int64), rng.integers(n_split, n, rows).astype(np.int64)
     if n_pat:
         src[:n_pat], dst[:n_pat] = rng.integers(0, n_split, n_pat), rng.integers(0, n_split, n_pat)
@@ -65,10 +66,10 @@ def test_layer0_kernels_against_fp64(rows, n_pat, k, h, gated, slope, gpu):
         assert float((xx.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
-def _layer_case(h, slope_act, gated, residual, seed, dev):
+def _layer_case(h, slope_act, gated, residual, seed, dev, n_pat=150, n_split=None):
     from dualmessagepassing_amd.dmpnn import DMPLayer
-    rows, n_pat, k = 6000, 150, 10
-    ix, coef, enc_p, enc_g, gate, W, gen, n, n_split = _case(rows, n_pat, k, h, gated, seed, dev)
+    rows, k = 6000, 10
+    ix, coef, enc_p, enc_g, gate, W, gen, n, n_split = _case(rows, n_pat, k, h, gated, seed, dev, n_split)
     th.manual_seed(seed)
     layer = DMPLayer(h, h, batch_norm=False, act_func="leaky_relu" if slope_act == "linear" else slope_act).to(dev)
     if slope_act == "linear":      # negative slope 1: no kink, so the two paths' gradients cannot differ by an activation's side
@@ -81,15 +82,16 @@ def _layer_case(h, slope_act, gated, residual, seed, dev):
 
 @pytest.mark.parametrize("h,act", [(128, "linear"), (128, "leaky_relu"), (64, "relu"), (64, "linear")])
 @pytest.mark.parametrize("gated,residual", [(True, True), (False, True), (True, False)])
-@pytest.mark.parametrize("tables,nodes", [(1, False), (2, False), (1, True), (2, True)])
-def test_layer0_equals_the_general_layer(h, act, gated, residual, tables, nodes, gpu):
+@pytest.mark.parametrize("tables,nodes,n_pat,n_split", [(1, False, 150, None), (2, False, 150, None), (1, True, 150, None), (2, True, 150, None),
+                                                          (2, True, 0, 5), (2, False, 0, 5)])      # the last two: pattern nodes, no pattern edges
+def test_layer0_equals_the_general_layer(h, act, gated, residual, tables, nodes, n_pat, n_split, gpu):
     """Same layer, same inputs: the label-code path against the general fused layer reading ``z = codes @ table`` (and
     ``x = node codes @ node table`` with ``nodes``) -- outputs, input gradient, every parameter gradient and the tables'
     gradients.  The products are re-associated, so the two differ by fp32 rounding -- and, with a kinked activation, by the
     side a pre-activation within rounding of zero falls on: outputs are held to rounding always, gradients to rounding with
     the kink-free activation (negative slope 1) and to a few such rows otherwise."""
     from dualmessagepassing_amd import fused
-    ix, coef, enc_p, enc_g, gate, W, layer, x, vg, eg, k, rows, n_pat, n_split = _layer_case(h, act, gated, residual, 7, gpu)
+    ix, coef, enc_p, enc_g, gate, W, layer, x, vg, eg, k, rows, n_pat, n_split = _layer_case(h, act, gated, residual, 7, gpu, n_pat, n_split)
     assert fused.l0_ok(ix, h, enc_p, enc_g, W, W)
     gen = th.Generator().manual_seed(5)
     if tables == 2:                                       # the pattern's own table stacked over the target's (no share_emb_net)

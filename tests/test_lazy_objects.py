@@ -53,6 +53,7 @@ def test_layer0_codes_table_ranges():
     two = Layer0Codes(enc, 10, th.zeros(20, 128), esplit=3, nsplit=2)
     assert two.tables(10, 7) == [(0, (0, 3), (0, 2)), (1, (3, 10), (2, 7))]
     assert Layer0Codes(enc, 10, th.zeros(20, 128), esplit=0, nsplit=0).tables(10, 7) == [(1, (0, 10), (0, 7))]   # no pattern rows
+    assert Layer0Codes(enc, 10, th.zeros(20, 128), esplit=0, nsplit=2).tables(10, 7) == [(0, (0, 0), (0, 2)), (1, (0, 10), (2, 7))]   # pattern nodes without edges
     two.venc, two.VK, two.WV = th.zeros(7, 16), 16, th.zeros(16, 128)      # the node rows' two tables stacked as one
     assert two.vtables(7) == [(0, (0, 7))]
     two.VK, two.WV = 8, th.zeros(16, 128)
