@@ -883,6 +883,7 @@ class _FusedDMPLayer(torch.autograd.Function):
             Q = pool_rows(H1e, epool, e_gate).view(G_ * halves, H)                      # sum of g H1 per graph (and flag)
             ones = (e_gate if e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
             cnt = pool_rows(ones.view(-1, 1).repeat(1, 4), epool).view(G_ * halves, 4)[:, :1]   # sum of g (vector kernel: 4 equal columns)
+            ctx.gcnt = cnt.view(G_, halves)                                                  # the backward's db2 needs them again
             es = torch.addmm(cnt * eb2, Q, eW2.t())
             if residual:
                 es = es + pool_rows(z, epool).view(G_ * halves, H)
@@ -937,8 +938,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                     Q = pool_rows(H1e, ep, ctx.e_gate)[:, :H]
                 dW2e = T.t() @ Q
                 # gated row counts per graph through the vector kernel (4 equal columns: the scalar path is slow)
-                g4 = (ctx.e_gate if ctx.e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
-                db2e = pool_rows(g4.view(-1, 1).repeat(1, 4), ep)[:, 0] @ T
+                gcnt = getattr(ctx, "gcnt", None)
+                if gcnt is None:
+                    g4 = (ctx.e_gate if ctx.e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
+                    gcnt = pool_rows(g4.view(-1, 1).repeat(1, 4), ep)
+                db2e = gcnt[:, 0] @ T
             elif typed:
                 # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)
                 dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
