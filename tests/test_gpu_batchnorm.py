@@ -6,7 +6,7 @@ import torch as th
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("rows,c", [(2, 256), (37, 256), (2708, 256), (10858, 256), (70001, 128), (513, 64), (1000, 32)])
+@pytest.mark.parametrize("rows,c", [(2, 256), (37, 256), (2708, 256), (10858, 256), (70001, 128), (513, 64), (1000, 32), (300, 512), (129, 1024), (50, 8)])
 @pytest.mark.parametrize("slope", [None, 1 / 5.5, 0.0])
 def test_batch_norm_act_equals_the_module(rows, c, slope, gpu):
     from dualmessagepassing_amd import ops
