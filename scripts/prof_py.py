@@ -5,7 +5,7 @@ import bench
 from dualmessagepassing_amd.tuning import enable_tuned_gemms
 enable_tuned_gemms()
 dev = torch.device("cuda:0")
-cfg = dict(bench.CFG)
+cfg = dict(bench.CFG, batch=int(os.environ.get('BATCH', bench.CFG['batch'])))   # BATCH=16: host-bound, no queue back-pressure in the numbers
 shard = bench.make_shard(cfg, 0, dev)
 step, model = bench.build_step(cfg, shard, dev)
 for _ in range(5): step()
@@ -18,5 +18,4 @@ with torch.autograd.set_multithreading_enabled(False):     # backward on this th
     pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(12)
-st.print_callers("view")
+st.sort_stats("tottime").print_stats(55)
