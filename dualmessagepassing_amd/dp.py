@@ -408,7 +408,10 @@ class StepGraph:
             static = [torch.empty_like(t).copy_(t) for t in tensors]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self._side_stream()):
+            # with a process group alive its watchdog thread polls events while we record: only THIS thread's calls are
+            # policed then (torch's "thread_local" capture mode); a single process keeps the strict default
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(graph, stream=self._side_stream(), capture_error_mode=mode):
                 out = self.fn(*meta, *static)
             rec = self._graphs[key] = (graph, static, out)
         else:
