@@ -110,6 +110,21 @@ def slice_shard(cfg, shard, lo, hi):
     return out
 
 
+def concat_shards(shards):
+    """The shards of several ranks as ONE batch (rank 0's pairs first): the global batch a data-parallel step works on,
+    for comparing the ranks' averaged gradient with a single process's (``--emulate-world``)."""
+    out = {"counts": torch.cat([s["counts"] for s in shards])}
+    for t in ("p", "g"):
+        ds = [s[t] for s in shards]
+        out[t] = dict(local_src=torch.cat([d["local_src"] for d in ds]), local_dst=torch.cat([d["local_dst"] for d in ds]),
+                      ndata={k: torch.cat([d["ndata"][k] for d in ds]) for k in ds[0]["ndata"]},
+                      edata={k: torch.cat([d["edata"][k] for d in ds]) for k in ds[0]["edata"]},
+                      num_nodes=torch.cat([d["num_nodes"] for d in ds]), num_edges=torch.cat([d["num_edges"] for d in ds]),
+                      N=sum(d["N"] for d in ds), E=sum(d["E"] for d in ds), max_n=max(d["max_n"] for d in ds),
+                      max_e=max(d["max_e"] for d in ds))
+    return out
+
+
 def micro_batches_for(cfg):
     """Micro-batches per step so that one pass stays inside the kernels' index range: 2^30 edge rows (packed
     (row << 1) | flag entries) -- rows are addressed by index, so the SIZE of an [E, H] array is no limit any more (round 2
@@ -160,10 +175,23 @@ def build_step(cfg, shard, device, world=1):
     parts = [shard] if M == 1 else [slice_shard(cfg, shard, i * (cfg["batch"] // M), (i + 1) * (cfg["batch"] // M)) for i in range(M)]
     total = torch.zeros_like(sync.flat) if M > 1 else None    # gradient sum over the micro-batches
 
+    ar_events = []    # (before, after) event pairs around the wait for the gradient sum: how long the compute stream stood still
+
+    def timed_wait(fn):
+        if world > 1 and step.time_allreduce:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ar_events.append((a, b))
+        else:
+            fn()
+
     def finish():
         """Second half of a step: wait (on the stream, not the host) for the gradient sum, then AdamW."""
         if pending:
-            sync.finish(pending.pop())
+            work = pending.pop()
+            timed_wait(lambda: sync.finish(work))
             opt.step()
 
     def batch_of(part):
@@ -201,7 +229,13 @@ def build_step(cfg, shard, device, world=1):
             finish()
         return loss
 
-    def step():
+    def read_all(out):
+        """Every entry of the output dictionary formed in HBM (``--all-outputs`` / ``all_outputs_ms_per_step``): the
+        reference returns all 15 as tensors (basemodel.py:1645-1661); here four of them (``g_v_emb`` / ``g_e_emb``, and with
+        ``model.lazy_edge_rep`` the last layer's ``p_e_rep`` / ``g_e_rep``) are formed on first read."""
+        return [v for _, v in out.items()]
+
+    def step(all_outputs=False):
         if M > 1:
             return step_micro()
         pattern, graph = batch_of(shard)
@@ -212,9 +246,19 @@ def build_step(cfg, shard, device, world=1):
             prepare_joint(pattern, graph, cfg["hid"])
         finish()
         sync.detach_grads()
-        out = model(pattern, graph)
+        if all_outputs:
+            lazy, model.lazy_edge_rep = getattr(model, "lazy_edge_rep", True), False
+            try:
+                out = model(pattern, graph)
+            finally:
+                model.lazy_edge_rep = lazy
+            keep = read_all(out)                               # alive until the backward has run
+        else:
+            out = model(pattern, graph)
         loss = torch.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])  # count loss (train.py:624-628)
         loss.backward()
+        if all_outputs:
+            del keep
         sync.pack()
         pending.append(sync.sync(async_op=True))              # None at world size 1
         if world == 1:
@@ -234,9 +278,11 @@ def build_step(cfg, shard, device, world=1):
 
     def tail():
         """... and what follows it with eager launches: the gradient all-reduce (RCCL) and the optimizer update."""
-        sync.sync()
+        timed_wait(sync.sync)
         opt.step()
 
+    step.time_allreduce = False
+    step.ar_events = ar_events
     step.finish = finish
     step.front, step.tail = front, tail
     step.sync = sync
@@ -245,14 +291,14 @@ def build_step(cfg, shard, device, world=1):
     return step, model
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 SEG_IN = "seg_sum_vec<32, true, false, true, 0, 256>"       # flag-split segment sum over the CSR by destination (forward)
-SEG_INC = "seg_sum_vec<32, true, false, true, 1, 256>"      # the same kernel over the incidence CSR (backward of the edge gathers)
+SEG_INC = "seg_acc_graphs_k<128, "                           # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
 
 
 def committed_profile(n_rows, n_edges, H):
     """What the committed profiles of this round say about the two scatter-add launches, if they were taken at this launch
-    shape (``profiles/<round>_profile_meta.json``): the rocprofv3 ``--kernel-trace --stats`` average duration
+    shape and with this build of the kernels (``profiles/<round>_profile_meta.json``: rows, edges, H, lib_srchash): the rocprofv3 ``--kernel-trace --stats`` average duration
     (``<round>_bench_kernel_stats.csv``) and the PMC traffic per launch (``<round>_pmc_h128.json``: FETCH_SIZE and WRITE_SIZE
     from separate ``--pmc`` passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950).
     -> {"in": {"avg_us_rocprof", "traffic"}, "inc": {...}}; entries are None where nothing matches."""
@@ -262,6 +308,11 @@ def committed_profile(n_rows, n_edges, H):
         with open(base + "_profile_meta.json") as f:
             meta = json.load(f)
         if (meta.get("rows"), meta.get("edges"), meta.get("H")) != (n_rows, n_edges, H):
+            return out
+        # ... and with THIS build of the library: the profiles record the content hash of the kernel sources they were
+        # taken with (csrc/libdmp_hip.so.srchash); numbers of another build are dropped, not quoted
+        from dualmessagepassing_amd import _build
+        if meta.get("lib_srchash") != _build.source_hash():
             return out
     except (OSError, ValueError):
         return out
@@ -278,8 +329,9 @@ def committed_profile(n_rows, n_edges, H):
         with open(base + "_pmc_h128.json") as f:
             k = json.load(f)["kernels"]
         for tag, name in (("in", SEG_IN), ("inc", SEG_INC)):
-            if name in k:
-                out[tag]["traffic"] = int(k[name]["hbm_bytes_per_launch"])
+            for key, v in k.items():
+                if name in key:
+                    out[tag]["traffic"] = int(v["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -510,7 +562,7 @@ def graph_then_eager(argv):
             line = lines[-1]
             if note:
                 d = json.loads(line)
-                d["config"]["launch_fallback"] = note
+                d["config"]["launch_fallback"] = d["launch_fallback"] = note
                 line = json.dumps(d)
             print(line, flush=True)
             return 0
@@ -533,19 +585,27 @@ def main():
                     help="embedding kind (Equivariant = the reference's default, config.py:242-245)")
     ap.add_argument("--hid", type=int, default=CFG["hid"], help="hidden width (the metric is quoted at 128; 64 = the reference's "
                     "README width: measured for DESIGN.md, not the bench line)")
-    ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep every [E, 2H] "
-                    "array below 4 GiB: 1 for config 2, 4 for config 4)")
+    ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep the edge rows of "
+                    "one pass below 2^30: 1 for config 2 and for config 4's 1024-pair shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
     ap.add_argument("--graph", action="store_true",
                     help="record the whole step (collate, index builds, fwd, bwd, gradient pack, AdamW) as ONE HIP graph during "
                          "the warm-up and replay it in the timed region (N = 1, one micro-batch; the per-kernel HIP-event "
                          "numbers then come from eager steps after the timed region).  The DEFAULT at N = 1: tried in a child "
-                         "process first, eager launches in a second child if that one fails")
-    ap.add_argument("--eager", action="store_true", help="eager launches in the timed region (the default at N > 1)")
+                         "process first, eager launches in a second child if that one fails.  At N > 1 (also the default there): "
+                         "forward + backward + gradient pack replayed per rank, all-reduce and optimizer update launched eagerly")
+    ap.add_argument("--eager", action="store_true", help="eager launches in the timed region")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep hipBLASLt's default solution heuristic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "smoke-test the multi-rank path on a single-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--dump-grad", default=None, metavar="PATH",
+                    help="testing aid: before the warm-up, one forward + backward + gradient pack + all-reduce (averaged) from "
+                         "the initial parameters; rank 0 saves the flat gradient and its own shard's predictions to PATH")
+    ap.add_argument("--emulate-world", type=int, default=1, metavar="W",
+                    help="testing aid (one process): the batch is the shards of ranks 0..W-1 back to back -- the global batch "
+                         "of a W-rank run")
     ap.add_argument("--spawn-check", action="store_true",
                     help="testing aid (runs without a GPU): start the ranks, form the process group, count them with an "
                          "all-reduce and print a line with n_gpus / ranks_seen and value null -- no step is run")
@@ -558,7 +618,15 @@ def main():
             if have < args.gpus:
                 raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --single-device to time-share one GPU "
                                  "with --backend gloo as a plumbing test)" % (args.gpus, have))
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        rc = spawn_ranks(args.gpus, sys.argv[1:])
+        if rc != 0 and not (args.graph or args.eager or args.spawn_check):
+            # default mode at N > 1: every rank replays forward + backward + gradient pack from one HIP graph; if that rank
+            # set failed (a recording that faults takes its process with it), the same ranks once more with eager launches
+            note = "bench.py --gpus %d (replayed front) failed with exit code %d: eager launches instead" % (args.gpus, rc)
+            print(note, file=sys.stderr, flush=True)
+            os.environ["DMP_BENCH_FALLBACK_NOTE"] = note
+            rc = spawn_ranks(args.gpus, sys.argv[1:] + ["--eager"])
+        sys.exit(rc)
 
     selftest = os.environ.get("DMP_BENCH_CHILD_SELFTEST")     # testing aid (no GPU): what the two children of the default mode do
     if selftest and os.environ.get("DMP_BENCH_CHILD"):
@@ -601,13 +669,33 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    # N > 1 without a mode flag: forward + backward + gradient pack replayed from one HIP graph per rank (eager launches need
+    # ~5 ms of host time per step and rank, as much as the device time: N Python launchers on one host would set the curve),
+    # all-reduce and optimizer update launched eagerly behind every replay; a recording that RAISES on any rank sends all
+    # ranks back to eager launches (agreed by an all-reduce after the warm-up)
+    auto_graph = world > 1 and not (args.graph or args.eager)
+    if auto_graph:
+        args.graph = True
     cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
                hid=args.hid, graph=args.graph)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
-    shard = make_shard(cfg, rank, device)
+    if args.emulate_world > 1:
+        if world != 1:
+            raise SystemExit("bench.py: --emulate-world is a single-process aid")
+        shard = concat_shards([make_shard(cfg, r, device) for r in range(args.emulate_world)])
+        cfg = dict(cfg, batch=cfg["batch"] * args.emulate_world)
+    else:
+        shard = make_shard(cfg, rank, device)
     step, model = build_step(cfg, shard, device, world)
+    if args.dump_grad:
+        step.front()
+        step.sync.sync()                                       # the ranks' average (nothing at world size 1)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"flat": step.sync.flat.detach().cpu(), "pred_c": step.last_pred_c.cpu(), "world": world,
+                        "batch": cfg["batch"]}, args.dump_grad)
     initial_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1
                                                                                               and not args.no_cpu_baseline) else None
 
@@ -621,16 +709,28 @@ def main():
         # the step reads the shard's tensors and clones the size / flag tensors itself: a replay rebuilds every index
         # of the batch on the device exactly as an eager step does
         from dualmessagepassing_amd.dp import StepGraph
-        run = StepGraph(lambda: step(), optimizer=step.opt, max_shapes=1)
+        # (a leading non-tensor argument is part of a recording's signature: ``run("all")`` is the all-outputs step)
+        run = StepGraph(lambda *m: step(all_outputs=bool(m)), optimizer=step.opt, max_shapes=2)
         graphed = True
     elif args.graph and world > 1 and step.micro_batches == 1:
         # more than one rank: forward + backward + gradient pack replayed from one HIP graph per rank, the gradient
         # all-reduce and the optimizer update launched eagerly after every replay (no collective inside a recording)
         from dualmessagepassing_amd.dp import StepGraph
         front_graph = StepGraph(lambda: step.front(), optimizer=step.opt, max_shapes=1)
+        graph_state = {"ok": True, "note": None}
 
         def run():
-            loss = front_graph()
+            if graph_state["ok"]:
+                try:
+                    loss = front_graph()
+                except Exception as e:                        # noqa: BLE001 -- whatever the recording raised
+                    if not auto_graph:
+                        raise
+                    graph_state["ok"], graph_state["note"] = False, "rank %d: recording failed (%s: %s)" % (rank, type(e).__name__, e)
+                    print("bench.py " + graph_state["note"], file=sys.stderr, flush=True)
+                    loss = step.front()                        # the same collectives as the other ranks: front, then tail
+            else:
+                loss = step.front()
             step.tail()
             return loss
 
@@ -643,6 +743,17 @@ def main():
     for _ in range(max(args.warmup, 3) if graphed else args.warmup):   # graphed: eager, record + replay, replay
         run()
     step.finish()
+    launch_fallback = os.environ.get("DMP_BENCH_FALLBACK_NOTE")
+    if graphed and world > 1:
+        ok = torch.tensor([1 if graph_state["ok"] else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:                                # some rank could not record: every rank launches eagerly
+            launch_fallback = graph_state["note"] or "another rank's recording failed: eager launches on every rank"
+            run, graphed = step, False
+            for _ in range(2):
+                run()
+            step.finish()
+    step.time_allreduce = True
     # Setup objects (modules, tuned-GEMM tables, the shard) leave the cyclic collector's working set: a full
     # collection walking them costs tens of milliseconds and would otherwise land inside a step now and then.
     import gc
@@ -653,28 +764,39 @@ def main():
     # timed region: HIP events only around the roofline kernel (the scatter-add), so that the
     # event records do not perturb the step; every other kernel is timed in extra steps below
     _lib.timer.reset()
-    _lib.timer.only = "seg_sum2["
+    _lib.timer.only = "seg_sum2"
     _lib.timer.enabled = not graphed                         # no event records inside a replayed graph
     # one event record per step on the step's stream (the stream run() launches on): the spread of the device time per
     # step; 20 steps of 6 ms are too short to trust a mean alone.  Event k marks the enqueue point of step k, so a
     # difference is the device time of one step once the queue is full (the GPU-bound case).
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    del step.ar_events[:]
+    host_s = 0.0                                             # host time inside run(): enqueue (and, with gloo, the blocking collective)
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
+        h0 = time.perf_counter()
         run()
+        host_s += time.perf_counter() - h0
     step.finish()                                            # the last step's all-reduce + optimizer update: inside the timed region
     marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
     per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.steps else []
+    step.time_allreduce = False
+    ar_ms = [a.elapsed_time(b) for a, b in step.ar_events]
+    mine = {"rank": rank, "host_ms_per_step": round(host_s / max(args.steps, 1) * 1e3, 3),
+            "allreduce_wait_ms": round(sum(ar_ms) / len(ar_ms), 3) if ar_ms else None,
+            "allreduce_wait_ms_max": round(max(ar_ms), 3) if ar_ms else None,
+            "step_ms_median": round(per_step_ms[len(per_step_ms) // 2], 3) if per_step_ms else None,
+            "wall_ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3)}
     kern = _lib.timer.summary()
     eager_ms = None
     if graphed:
         # the same K steps once more as eager launches: the scatter-add's HIP-event time (no event records inside a replayed
         # graph) and the eager step time, reported beside the replayed one
         _lib.timer.reset()
-        _lib.timer.only = "seg_sum2["
+        _lib.timer.only = "seg_sum2"
         _lib.timer.enabled = True
         for _ in range(max(args.warmup, 5)):                   # the eager path's own warm-up (its allocations are not the graph's)
             step()
@@ -688,6 +810,23 @@ def main():
         barrier()
         eager_ms = (time.perf_counter() - te) / max(args.steps, 1) * 1e3
         kern = _lib.timer.summary()
+    all_ms = None
+    if world == 1 and step.micro_batches == 1 and not args.no_all_outputs:
+        # the same step with every entry of the output dictionary formed (the reference returns all 15 as tensors,
+        # basemodel.py:1645-1661): the last layer's edge rows built by the layer itself (lazy_edge_rep off), the target
+        # embeddings read -- same launch mode as the timed region, reported beside the headline, never as `value`
+        fn = (lambda: run("all")) if graphed else (lambda: step(all_outputs=True))
+        _lib.timer.enabled = False
+        for _ in range(3):                                     # graphed: eager, record + replay, replay
+            fn()
+        step.finish()
+        barrier()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        step.finish()
+        barrier()
+        all_ms = (time.perf_counter() - ta) / max(args.steps, 1) * 1e3
     _lib.timer.reset()
     _lib.timer.only = None
     _lib.timer.enabled = True
@@ -700,6 +839,7 @@ def main():
         kern.setdefault(name, v)
 
     ranks_seen, devices = 1, [torch.cuda.get_device_name(device)]
+    per_rank = [mine]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -710,6 +850,8 @@ def main():
         names = [None] * world
         dist.all_gather_object(names, "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(device)))
         devices = names
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         pairs = cfg["batch"] * world * args.steps
@@ -720,7 +862,9 @@ def main():
         uN = mb * (cfg["p_nodes"] + cfg["g_nodes"])
         uE = mb * 2 * (cfg["p_edges"] + cfg["g_edges"])
         key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
-        key_inc = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)
+        key_inc = "seg_sum2_graphs[H=%d,rows=%d,E=%d]" % (H, uN, uE)      # one pass over the edge rows (csrc/dmp_segacc.hip) ...
+        if key_inc not in kern:
+            key_inc = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)   # ... or the segment sum over the incidence CSR
         prof = committed_profile(uN, uE, H)
         roof = roof_bwd = None
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
@@ -728,8 +872,9 @@ def main():
                                 "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key]["bytes"],
                                 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"])
         if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
-            roof_bwd = seg_roofline(kern[key_inc], "dmp::seg_sum_vec<32,split,remap,incidence> (gradient of the gathered node projections: "
-                                    "N=%d rows, 2 x E=%d incidence entries, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
+            roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if "graphs" in key_inc
+                                                    else "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints") +
+                                    "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
                                     4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"])
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
@@ -743,6 +888,14 @@ def main():
             "step_ms_max": round(per_step_ms[-1], 3) if per_step_ms else None,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # how the timed steps were launched, and the other mode's / the all-outputs step's time beside it
+            "launch_mode": ("hip_graph_replay" if world == 1 else "hip_graph_replay_front+eager_allreduce_adamw") if graphed else "eager",
+            "launch_fallback": launch_fallback,
+            "eager_ms_per_step": round(eager_ms, 3) if eager_ms is not None else None,
+            "all_outputs_ms_per_step": round(all_ms, 3) if all_ms is not None else None,
+            # per rank: host time inside the step call, the compute stream's wait for the gradient sum (HIP events around
+            # the all-reduce / its wait), device time per step -- what a bad scaling curve is diagnosed from
+            "per_rank": per_rank,
             "arithmetic": "fp32 storage and accumulation; dense products on the f32-input MFMA except the class-typed edge kernels (fp32 operands as 3 bf16 pieces, 6 piece products per partial product: fp32-accurate, parity tests at the fp32 tolerances; DMP_EXACT_FP32=1 switches them back)",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
                                    "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, ScalarFilter, "
@@ -761,6 +914,9 @@ def main():
                                   "from the same number of eager steps run after the timed region: eager_ms_per_step)")
                        if graphed else "eager launches",
                        "eager_ms_per_step": round(eager_ms, 3) if eager_ms is not None else None,
+                       "all_outputs_ms_per_step": round(all_ms, 3) if all_ms is not None else None,
+                       "all_outputs": "same launch mode, model.lazy_edge_rep = False and all 15 OutputDict entries read (g_v_emb, "
+                                      "g_e_emb, p_e_rep, g_e_rep formed in HBM as the reference forms them)",
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
             "roofline_bwd": roof_bwd,

@@ -51,6 +51,7 @@ def collate_device(local_src, local_dst, num_nodes, num_edges, total_nodes, tota
     g.max_num_edges = None if max_edges is None else int(max_edges)
     from . import ops
     g.tiling = ops.graph_tiling(node_off, edge_off, B, g.max_num_edges)
+    g.node_tiling = ops.graph_node_tiling(node_off, edge_off, B, g.max_num_nodes)
     return g
 
 
@@ -274,4 +275,5 @@ def union_graphs(a, b):
         g.max_num_nodes = max(a.max_num_nodes or 0, b.max_num_nodes or 0) or None
         g.max_num_edges = max(a.max_num_edges, b.max_num_edges)
         g.tiling = ops.graph_tiling(g.node_offsets, g.edge_offsets, a.batch_size, a.max_num_edges, b.batch_size, b.max_num_edges)
+        g.node_tiling = ops.graph_node_tiling(g.node_offsets, g.edge_offsets, a.batch_size, a.max_num_nodes, b.batch_size, b.max_num_nodes)
     return g

@@ -2,7 +2,7 @@
 //
 //   csr_build          counting sort of the edge list by dst (or src); rows in
 //                      ascending eid -> every later segment sum has one fixed order
-//   incidence_build    in-edges ++ out-edges (flag flipped) per node
+//   incidence_build    in-edges and out-edges (flag flipped) per node, merged by edge id
 //   degree_coef        2(1+log2(1+out_deg))
 //   collate            dgl.batch: node-offset concatenation
 //   add_reversed_edges train.py:299-327
@@ -300,9 +300,11 @@ __global__ __launch_bounds__(kBlock) void incidence_ptr(const int32_t *__restric
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i <= N) inc_ptr[i] = in_ptr[i] + out_ptr[i];
 }
-// one thread per incidence entry: binary search for the owning node
-// one thread per node: its in-entries, then its out-entries (flag bit flipped), in CSR order.  (A thread per entry with a
-// binary search over the row offsets was 17 dependent round trips per entry: 23 us for 1.1 M entries.)
+// one thread per node: its in-entries and its out-entries (flag bit flipped) MERGED by ascending edge id (both lists are
+// sorted; an edge that is both -- a self loop -- lists its in-entry first), so that every per-node, per-half sum over the
+// incidence CSR runs in ascending eid: the order in which the one-pass kernel (csrc/dmp_segacc.hip) streams the edge rows.
+// (A thread per entry with a binary search over the row offsets was 17 dependent round trips per entry: 23 us for 1.1 M
+// entries.)
 __global__ __launch_bounds__(kBlock) void incidence_fill(const int32_t *__restrict__ in_ptr,
                                                          const int32_t *__restrict__ in_ent,
                                                          const int32_t *__restrict__ out_ptr,
@@ -310,10 +312,19 @@ __global__ __launch_bounds__(kBlock) void incidence_fill(const int32_t *__restri
                                                          int64_t E2, int32_t *__restrict__ inc_ent) {
   const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (w >= N) return;
-  const int a0 = in_ptr[w], a1 = in_ptr[w + 1], b0 = out_ptr[w], b1 = out_ptr[w + 1];
-  int64_t o = (int64_t)a0 + b0;
-  for (int k = a0; k < a1 && o < E2; ++k) inc_ent[o++] = in_ent[k];
-  for (int k = b0; k < b1 && o < E2; ++k) inc_ent[o++] = out_ent[k] ^ 1;
+  int a = in_ptr[w], b = out_ptr[w];
+  const int a1 = in_ptr[w + 1], b1 = out_ptr[w + 1];
+  int64_t o = (int64_t)a + b;
+  int x = a < a1 ? in_ent[a] : 0, y = b < b1 ? out_ent[b] : 0;
+  while ((a < a1 || b < b1) && o < E2) {
+    if (b >= b1 || (a < a1 && (x >> 1) <= (y >> 1))) {
+      inc_ent[o++] = x;
+      if (++a < a1) x = in_ent[a];
+    } else {
+      inc_ent[o++] = y ^ 1;
+      if (++b < b1) y = out_ent[b];
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void degree_coef_k(const int64_t *__restrict__ deg, int64_t N,

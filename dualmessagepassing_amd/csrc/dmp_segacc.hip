@@ -1,0 +1,173 @@
+// Scatter-add of edge rows into BOTH endpoint rows in ONE pass over the edge rows (gfx950 / MI355X).
+//
+// The backward of the DMPLayer's gathered node projections (SubgraphCountingMatching/models/dmpnn.py:111-127: the
+// message UDF reads P_d[dst] - P_s[src], swapped for reversed edges) sums every row of dPre [E, H] into two node rows:
+//     out[a_e, 0:H ] += s0 * M[e]        a_e = is_reversed ? src : dst      (dP_d)
+//     out[b_e, H:2H] += s1 * M[e]        b_e = the other endpoint           (dP_s, s1 = -1)
+// dmp_seg_sum2 over the incidence CSR does this node by node and reads every edge row twice; the second read -- by the
+// other endpoint's workgroup -- misses the XCD's L2 for a third of the rows (PMC: 1.29 x the algorithmic bytes).
+//
+// Here the EDGE rows are streamed once, in eid order, and the sums live in REGISTERS: in a block-diagonal batch the edges
+// of a graph are contiguous and touch only that graph's nodes, so a workgroup owns a TILE of whole graphs with at most
+// kAccNodes = 64 nodes, and wave c of it owns the 64-column slice [64c, 64c + 64) of every row: lane l keeps
+// acc[node][half][64c + l] for all 64 nodes and both halves in 128 VGPRs (v64..v191, pinned).  A row arrives as one dword
+// per lane (a 256-byte piece of the row per wave-instruction; the waves of the workgroup together read whole rows; 32
+// rows in flight per wave), its two endpoints reach the scalar unit by v_readlane, and the two adds are
+//     s_set_gpr_idx_idx a_e ; v_add_f32 v[64 + a_e], v[64 + a_e], x        (VGPR index mode: SRC0 and DST relative)
+//     s_set_gpr_idx_idx b_e ; v_add_f32 v[128 + b_e], v[128 + b_e], x
+// -- no LDS, no atomics, no barrier, two vector instructions per row.  Every accumulator receives its addends in
+// ascending eid: one fixed summation order, run-to-run bit-stable, and the bits of dmp_seg_sum2 over
+// dmp_incidence_build's CSR (rows merged by eid).  Rows whose endpoint lies outside the tile (never in a block-diagonal
+// batch) add into a trash register.
+//
+// Forms that were built and measured at bench.py's shape (E = 548,864 rows of 512 bytes; dmp_seg_sum2 over the incidence
+// CSR: 74-77 us stand-alone, 80.8 us in the step), all bit-identical to it:
+//   * sums in LDS, ds_add_f32 one row per instruction: 749 us -- the LDS float atomic serialises the 64 lanes of a
+//     wave-instruction (~200 cycles each);
+//   * this form: 73-82 us stand-alone, 71 us in the step, 1.0 x its algorithmic bytes; 32, 48 or 60 rows in flight per
+//     wave make no difference (82.4 / 81.0 / 81.4 us on one box);
+//   * wave h sums half h of ALL columns from whole-row loads (512 contiguous bytes per instruction, every row requested by
+//     both waves of the workgroup): 91 us -- the partner's duplicate requests are not free; with workgroups walking two
+//     tiles each (an even mix of pattern and target tiles, no workgroup left alone at the end): 95 us.
+#include "dmp_mfma_common.h"
+
+namespace dmp {
+namespace {
+
+constexpr int kAccNodes = 64;      // node rows of a tile = accumulator registers per half
+constexpr int kRing = 32;          // rows in flight per wave (one dword per lane each) = rows per super-group
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, kb; };
+
+// four rows: x_t into v[64 + i_t] and into v[128 + j_t]
+#define DMP_ACC4(X0, X1, X2, X3, I0, I1, I2, I3, J0, J1, J2, J3)                                                       \
+  asm volatile(                                                                                                        \
+      "s_set_gpr_idx_on %[i0], 0x9\n\t"                                                                                \
+      "v_add_f32 v64, v64, %[x0]\n\t"                                                                                  \
+      "s_set_gpr_idx_idx %[j0]\n\t"                                                                                    \
+      "v_add_f32 v128, v128, %[x0]\n\t"                                                                                \
+      "s_set_gpr_idx_idx %[i1]\n\t"                                                                                    \
+      "v_add_f32 v64, v64, %[x1]\n\t"                                                                                  \
+      "s_set_gpr_idx_idx %[j1]\n\t"                                                                                    \
+      "v_add_f32 v128, v128, %[x1]\n\t"                                                                                \
+      "s_set_gpr_idx_idx %[i2]\n\t"                                                                                    \
+      "v_add_f32 v64, v64, %[x2]\n\t"                                                                                  \
+      "s_set_gpr_idx_idx %[j2]\n\t"                                                                                    \
+      "v_add_f32 v128, v128, %[x2]\n\t"                                                                                \
+      "s_set_gpr_idx_idx %[i3]\n\t"                                                                                    \
+      "v_add_f32 v64, v64, %[x3]\n\t"                                                                                  \
+      "s_set_gpr_idx_idx %[j3]\n\t"                                                                                    \
+      "v_add_f32 v128, v128, %[x3]\n\t"                                                                                \
+      "s_set_gpr_idx_off"                                                                                              \
+      : "+{v[64:95]}"(A0), "+{v[96:127]}"(A1), "+{v[128:159]}"(B0), "+{v[160:191]}"(B1), "+{v192}"(trash)             \
+      : [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [i0] "s"(I0), [i1] "s"(I1), [i2] "s"(I2),              \
+        [i3] "s"(I3), [j0] "s"(J0), [j1] "s"(J1), [j2] "s"(J2), [j3] "s"(J3))
+
+// H: row width (64 or 128) = 64 columns per wave, H / 64 waves per workgroup, one workgroup per tile.
+template <int H>
+__global__ __launch_bounds__(H) void seg_acc_graphs_k(
+    const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ selA, const int32_t *__restrict__ selB,
+    const GraphTiles ts, float s0, float s1, float *__restrict__ out, int64_t ldo) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  // the tile: graphs [g0, g1)
+  const int64_t tile = blockIdx.x;
+  const int64_t tiles_a = ts.Ba > 0 ? (ts.Ba + ts.ka - 1) / ts.ka : 0;
+  int64_t g0, g1;
+  if (tile < tiles_a) { g0 = tile * ts.ka; g1 = g0 + ts.ka < ts.Ba ? g0 + ts.ka : ts.Ba; }
+  else { g0 = ts.Ba + (tile - tiles_a) * ts.kb; g1 = g0 + ts.kb < ts.Ba + ts.Bb ? g0 + ts.kb : ts.Ba + ts.Bb; }
+  const int64_t n0 = ts.node_off[g0], e0 = ts.edge_off[g0];
+  const int nodes = min((int)(ts.node_off[g1] - n0), kAccNodes);
+  const int R = (int)(ts.edge_off[g1] - e0);
+
+  // raw buffer descriptors over the tile's rows / selectors / output rows: per-lane offsets are computed once, the row
+  // offset is a scalar, rows past the tile's end read zeros and stores past its last node are dropped (no address
+  // arithmetic, predicates or branches in the loops)
+  const rsrc_t rsM = make_rsrc(M + e0 * ldm, tile_bytes(R, ldm, H));
+  const rsrc_t rsA = make_rsrc(selA + e0, (uint32_t)R * 4u), rsB = make_rsrc(selB + e0, (uint32_t)R * 4u);
+  const uint32_t voff = (uint32_t)(64 * c + lane) * 4u;
+  const uint32_t rowb = (uint32_t)(ldm * 4);
+  auto load_row = [&](int r) -> float {                         // row r of the tile, this wave's columns
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, (int)voff, (int)((uint32_t)r * rowb), 0));
+  };
+  auto load_sel = [&](int sg, int &a, int &b) {                 // endpoints of row kRing sg + lane
+    a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, sg * (kRing * 4), 0);
+    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsB, lane * 4, sg * (kRing * 4), 0);
+  };
+
+  f32x32 A0, A1, B0, B1;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { A0[i] = 0.f; A1[i] = 0.f; B0[i] = 0.f; B1[i] = 0.f; }
+  float trash = 0.f;
+
+  const int nsg = (R + kRing - 1) / kRing;                      // super-groups of kRing rows (one endpoint dword per lane < kRing)
+  float v[kRing];
+  int na, nb;
+  load_sel(0, na, nb);
+  asm volatile("" ::: "memory");     // keep the endpoint loads OLDER than the ring (the waits count younger operations)
+#pragma unroll
+  for (int k = 0; k < kRing; ++k) v[k] = load_row(k);
+  for (int sg = 0; sg < nsg; ++sg) {
+    // register indices of this super-group's rows: node - n0 relative to v64 (half 0) / v128 (half 1); the trash
+    // register v192 = index 128 / 64 for rows past the end and endpoints outside the tile
+    const bool in = lane < kRing && sg * kRing + lane < R;
+    const uint32_t ua = (uint32_t)(na - (int32_t)n0), ub = (uint32_t)(nb - (int32_t)n0);
+    const int pa = (in && ua < (uint32_t)nodes) ? (int)ua : 128;
+    const int pb = (in && ub < (uint32_t)nodes) ? (int)ub : 64;
+#pragma unroll
+    for (int g = 0; g < kRing; g += 4) {
+      // the next super-group's endpoints: requested with half a ring of row loads behind them, so that the wait for
+      // them at the top of the next iteration leaves the ring in flight
+      if (g == (kRing / 8) * 4) load_sel(sg + 1, na, nb);       // past the last super-group: zeros, never used
+      const float x0 = v[g], x1 = v[g + 1], x2 = v[g + 2], x3 = v[g + 3];
+      const int r = (sg + 1) * kRing + g;                       // kRing rows ahead
+      v[g] = load_row(r); v[g + 1] = load_row(r + 1); v[g + 2] = load_row(r + 2); v[g + 3] = load_row(r + 3);
+      const int i0 = __builtin_amdgcn_readlane(pa, g), i1 = __builtin_amdgcn_readlane(pa, g + 1);
+      const int i2 = __builtin_amdgcn_readlane(pa, g + 2), i3 = __builtin_amdgcn_readlane(pa, g + 3);
+      const int j0 = __builtin_amdgcn_readlane(pb, g), j1 = __builtin_amdgcn_readlane(pb, g + 1);
+      const int j2 = __builtin_amdgcn_readlane(pb, g + 2), j3 = __builtin_amdgcn_readlane(pb, g + 3);
+      DMP_ACC4(x0, x1, x2, x3, i0, i1, i2, i3, j0, j1, j2, j3);
+    }
+  }
+  // the sums: 256 contiguous bytes per store instruction (this wave's columns of one node row and half)
+  const rsrc_t rsO = make_rsrc(out + n0 * ldo, tile_bytes(nodes, ldo, 2 * H));
+  const uint32_t orow = (uint32_t)(ldo * 4);
+  auto put = [&](int node, float a, float b) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a * s0), rsO, (int)voff, (int)((uint32_t)node * orow), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b * s1), rsO, (int)(voff + H * 4), (int)((uint32_t)node * orow), 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 32; ++i) put(i, A0[i], B0[i]);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) put(32 + i, A1[i], B1[i]);
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_seg_sum2_graphs_max_nodes(void) { return kAccNodes; }
+
+int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
+                        const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
+                        float *out, int64_t ldo, void *stream) {
+  if (Ba < 0 || Bb < 0 || H <= 0 || ldm < H || ldo < 2 * H || (Ba > 0 && ka < 1) || (Bb > 0 && kb < 1)) return DMP_ERR_BAD_ARG;
+  if (Ba + Bb == 0) return DMP_OK;
+  if (!M || !sel_a || !sel_b || !node_off || !edge_off || !out) return DMP_ERR_BAD_ARG;
+  if ((H != 64 && H != 128) || ldm % 4 || ldo % 4 || !aligned16(M) || !aligned16(out)) return DMP_ERR_UNSUPPORTED;
+  const int64_t tiles = (Ba > 0 ? (Ba + ka - 1) / ka : 0) + (Bb > 0 ? (Bb + kb - 1) / kb : 0);
+  if (tiles >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+  GraphTiles ts{node_off, edge_off, Ba, Bb, ka > 0 ? ka : 1, kb > 0 ? kb : 1};
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)tiles;
+  if (H == 128) seg_acc_graphs_k<128><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
+  else seg_acc_graphs_k<64><<<nb, 64, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
+  return check_launch();
+}
+
+}  // extern "C"

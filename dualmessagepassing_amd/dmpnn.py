@@ -316,8 +316,8 @@ def prepare_joint(pattern, graph, hidden_dim=128, backward=True):
         ix.edge_select(coef)
     if fused.typed_ok(ix, hidden_dim):
         ix.class_tiles(coef)
-    if backward:
-        ix.incidence()
+    if backward and not (ops.USE_GRAPH_SEG_SUM and ix.node_tiling is not None and hidden_dim in (64, 128)):
+        ix.incidence()                     # the one-pass endpoint sums (ops.endpoint_sums) need no incidence CSR
     return union
 
 

@@ -956,10 +956,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dH1e = dOe @ eW2
                     dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32, slope)
                     del dH1e
-            inc_ptr, inc_ent = ix.incidence()
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
-            ops.seg_sum_raw(dG[:, :H], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=dXP[:, H:],
-                            tiling=ix.tiling)
+            ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:])                       # dPre into both endpoints' rows: the backward scatter-add
             l0, tables = ctx.l0, ctx.l0_tables
             vcodes = l0 is not None and l0.venc is not None
             if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor

@@ -79,6 +79,7 @@ class GraphIndex:
         self._inc = None
         self._coef = {}
         self.tiling = None
+        self.node_tiling = None      # ops.graph_node_tiling(...): whole graphs per tile of the one-pass endpoint sums
         if (validate or _lib.VALIDATE) and int(status.sum().item()) != 0:
             raise _lib.DmpError("edge endpoint outside [0, num_nodes)")
 
@@ -126,6 +127,22 @@ class GraphIndex:
                                             ptr(sel_b), ptr(coef_e), stream_ptr()), "dmp_edge_select_build")
             self._esel = cached = (key, (sel_a, sel_b, coef_e), coef)
         return cached[1]
+
+    def endpoint_select(self):
+        """``(selA, selB)`` of ``edge_select`` without the coefficient: selA = is_reversed ? src : dst, selB = the other
+        endpoint (int32 [E]).  Taken from the selectors the forward pass built when there are any."""
+        cached = getattr(self, "_esel", None)
+        if cached is not None:
+            return cached[1][0], cached[1][1]
+        ep = getattr(self, "_epsel", None)
+        if ep is None:
+            if self.rev8 is None:
+                ep = (self.dst32, self.src32)
+            else:
+                r = self.rev8.bool()
+                ep = (torch.where(r, self.src32, self.dst32), torch.where(r, self.dst32, self.src32))
+            self._epsel = ep
+        return ep
 
     MAX_EDGE_CLASSES = 65536
 
@@ -270,6 +287,7 @@ class BatchedGraph:
         self.node_graph = None  # int32 [N] owning graph of each node (set by collate)
         self.edge_graph = None
         self.tiling = None      # ops.graph_tiling(...) of a block-diagonal batch (set by collate / union_graphs)
+        self.node_tiling = None  # ops.graph_node_tiling(...)
 
     # ---- DGLGraph-in: any graph object with the surface the reference's models touch
     @classmethod
@@ -368,6 +386,7 @@ class BatchedGraph:
             self._index = GraphIndex(self._src, self._dst, self._n, rev, validate=validate)
             self._index_key = key
         self._index.tiling = getattr(self, "tiling", None)
+        self._index.node_tiling = getattr(self, "node_tiling", None)
         return self._index
 
     def in_degrees(self):

@@ -62,6 +62,60 @@ def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
     return (node_off, edge_off, int(Ba), int(Bb), ka, kb)
 
 
+# The layer backward's scatter-add of dPre into both endpoint rows as ONE pass over the edge rows with the sums of a graph
+# tile in registers (csrc/dmp_segacc.hip): on by default where a block-diagonal batch says how its graphs tile.  DMP_GRAPH_SEG_SUM=0
+# takes dmp_seg_sum2 over the incidence CSR instead (same bits: both sum in ascending eid).
+USE_GRAPH_SEG_SUM = _os.environ.get("DMP_GRAPH_SEG_SUM", "1") == "1"
+GRAPH_ACC_NODES = 64       # dmp_seg_sum2_graphs_max_nodes(): node rows of a tile
+
+
+def graph_node_tiling(node_off, edge_off, Ba, max_nodes_a, Bb=0, max_nodes_b=None):
+    """Tiling of a block-diagonal batch for ``dmp_seg_sum2_graphs``: ``(node_off, edge_off, Ba, Bb, ka, kb)`` with ka / kb
+    whole graphs per tile such that no tile has more than GRAPH_ACC_NODES nodes, or None when a graph
+    alone is larger (or the per-graph maxima are unknown): ``dmp_seg_sum2`` over the incidence CSR then."""
+    if max_nodes_a is None or (Bb and max_nodes_b is None):
+        return None
+    if max(int(max_nodes_a), int(max_nodes_b or 0)) > GRAPH_ACC_NODES:
+        return None
+    ka = max(1, GRAPH_ACC_NODES // max(int(max_nodes_a), 1))
+    kb = max(1, GRAPH_ACC_NODES // max(int(max_nodes_b or 1), 1))
+    return (node_off, edge_off, int(Ba), int(Bb), ka, kb)
+
+
+def graph_seg_ok(index, M, H, out=None):
+    """``endpoint_sums`` can take the one-pass kernel for this index / operand."""
+    return (USE_GRAPH_SEG_SUM and getattr(index, "node_tiling", None) is not None and H in (64, 128) and M.is_cuda
+            and M.dtype == torch.float32 and M.dim() == 2 and M.stride(1) == 1 and M.stride(0) % 4 == 0 and M.data_ptr() % 16 == 0
+            and M.size(0) == index.num_edges and index.num_edges > 0
+            and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
+
+
+def endpoint_sums(M, index, out=None):
+    """``[sum_{e: a_e = v} M[e] | -sum_{e: b_e = v} M[e]]`` ([N, 2H]; a_e = is_reversed ? src : dst, b_e the other endpoint):
+    the gradient of the gathered node projections of the layer's edge pre-activation (dmpnn.py:111-127), every sum in
+    ascending eid.  One pass over the edge rows where the batch tiles by graphs (``dmp_seg_sum2_graphs``), else
+    ``dmp_seg_sum2`` over the incidence CSR (every row read twice)."""
+    H, N = M.size(1), index.num_nodes
+    if graph_seg_ok(index, M, H, out):
+        lib = _lib.load()
+        node_off, edge_off, Ba, Bb, ka, kb = index.node_tiling
+        sel_a, sel_b = index.endpoint_select()
+        _lib.require_gpu(M, sel_a, sel_b, node_off, edge_off)
+        if out is None:
+            out = torch.empty((N, 2 * H), dtype=torch.float32, device=M.device)
+        elif out.shape != (N, 2 * H) or out.dtype != torch.float32:
+            raise _lib.DmpError("endpoint_sums: bad out tensor")
+        E = M.size(0)
+        nbytes = 4 * H * E + 8 * H * N + 8 * E + 16 * (Ba + Bb + 1)
+        with _lib.timed("seg_sum2_graphs[H=%d,rows=%d,E=%d]", (H, N, E), nbytes):
+            check(lib.dmp_seg_sum2_graphs(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb, H,
+                                          1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, stream_ptr()),
+                  "dmp_seg_sum2_graphs")
+        return out
+    inc_ptr, inc_ent = index.incidence()
+    return seg_sum_raw(M, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=out, tiling=index.tiling)
+
+
 def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None, tiling=None):
     """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride).
     ``tiling`` (``graph_tiling``): the split sum over a CSR whose rows share source rows runs per graph tile from LDS."""
@@ -308,8 +362,7 @@ class _EdgeCombine(torch.autograd.Function):
                 check(lib.dmp_edge_combine_bwd_g(ptr(dY), ldy, ptr(ctx.coef), ptr(ix.dst32), E, H, ptr(dG),
                                                  2 * H, stream_ptr()), "dmp_edge_combine_bwd_g")
         if ctx.needs_input_grad[1]:
-            inc_ptr, inc_ent = ix.incidence()
-            dP = seg_sum_raw(dY, inc_ptr, inc_ent, ix.num_nodes, None, True, 1.0, -1.0, rows_shared=2)
+            dP = endpoint_sums(dY, ix)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dY.sum(0)
         return dG, dP, db, None, None

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 49
+#define DMP_ABI_VERSION 50
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -90,8 +90,9 @@ int dmp_csr_build_pair(const int64_t *dst, const int64_t *src, const uint8_t *fl
                        int32_t *status, int32_t *ws, void *stream);
 
 /*
- * Incidence CSR: for node w, its in-edges (flag = is_reversed) followed by its
- * out-edges (flag = !is_reversed).  This is the index of the backward of the
+ * Incidence CSR: for node w, its in-edges (flag = is_reversed) and its
+ * out-edges (flag = !is_reversed), merged by ascending edge id (a self loop lists
+ * its in-entry first).  This is the index of the backward of the
  * implicit line-graph edge message (dmpnn.py:112,120: d/dX of
  * X[dst]W_dst - X[src]W_src with the src/dst swap on reversed edges).
  *
@@ -357,6 +358,24 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
                  const int32_t *ent, const float *edge_w, int64_t num_nodes,
                  int H, float s0, float s1, float *out, int64_t ldo,
                  int rows_shared, void *stream);
+
+/*
+ * The same sums as dmp_seg_sum2 over the incidence CSR -- the backward of the gathered node projections of
+ * DMPLayer._node_message_func (dmpnn.py:111-127: dP_d[a_e] += dPre[e], dP_s[b_e] -= dPre[e]) -- from ONE pass over the
+ * edge rows (csrc/dmp_segacc.hip):
+ *     out[v, 0:H ] = s0 * sum_{e: sel_a[e] = v} M[e, :]        out[v, H:2H] = s1 * sum_{e: sel_b[e] = v} M[e, :]
+ * every sum in ascending e (the bits of dmp_seg_sum2 over dmp_incidence_build's CSR when sel_a / sel_b are
+ * dmp_edge_select_build's selectors).  For a block-diagonal batch: graphs [0, Ba) are grouped ka to a tile, graphs
+ * [Ba, Ba + Bb) kb to a tile; node_off / edge_off [Ba + Bb + 1]: first node / edge row of every graph.  A workgroup
+ * streams its tile's edge rows once and keeps the tile's node sums in registers (a wave: 64 columns x 64 nodes x 2 halves).  Requirements: no tile has more than dmp_seg_sum2_graphs_max_nodes() nodes (further nodes of a tile are left
+ * unwritten), every edge of a tile has both endpoints among the tile's nodes (others are dropped), H is 64 or 128
+ * (DMP_ERR_UNSUPPORTED otherwise: the caller falls back to dmp_seg_sum2).
+ *   M [E, ldm>=H], sel_a / sel_b [E] int32 (node ids), out [N, ldo>=2H]
+ */
+int dmp_seg_sum2_graphs_max_nodes(void);
+int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b,
+                        const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
+                        int H, float s0, float s1, float *out, int64_t ldo, void *stream);
 
 /*
  * Row gather by an int32 index -- `edges.src[k]` / `edges.dst[k]` inside the

@@ -78,6 +78,7 @@ def _compare(tag, pred, flat, ref_pred, ref_grads, pred_tol=1e-4, grad_tol=5e-4)
     assert err <= pred_tol * scale, "%s: pred_c err %g (scale %g)" % (tag, err, scale)
     checked = 0
     seen = set()
+    why = {"no oracle gradient": 0, "shared tensor seen": 0, "zero oracle gradient": 0}
     for name, g in flat.items():
         ref = ref_grads.get(name)
         if ref is None:
@@ -85,20 +86,23 @@ def _compare(tag, pred, flat, ref_pred, ref_grads, pred_tol=1e-4, grad_tol=5e-4)
             ref = ref_grads.get(twin)
         if ref is None:                                          # a parameter the oracle gives no gradient: zeros here too
             assert float(g.abs().max()) == 0.0, (tag, name)
+            why["no oracle gradient"] += 1
             continue
         if id(ref) in seen:
+            why["shared tensor seen"] += 1
             continue
         seen.add(id(ref))
         s = float(ref.abs().max())
         if s == 0.0:
             assert float(g.abs().max()) == 0.0, (tag, name)
+            why["zero oracle gradient"] += 1
             continue
         e = float((g - ref).abs().max())
         # a (Leaky)ReLU whose pre-activation lies within rounding of its kink may take the other branch (util_flips):
         # at this size it moves ONE term of a sum over ~10^5..10^8 terms, far inside the bound
         assert e <= grad_tol * s, "%s: %s gradient err %g > %g of its largest entry %g" % (tag, name, e, grad_tol, s)
         checked += 1
-    assert checked >= 20, checked
+    assert checked >= 60, (tag, checked, len(flat), why)
     return checked
 
 
@@ -113,6 +117,12 @@ def _run_case(cfg, gpu, oracle_chunk):
     shard = bench.make_shard(cfg, 0, gpu)
     step, model = bench.build_step(dict(cfg, graph=True), shard, gpu, 1)
     assert getattr(model, "lazy_edge_rep", True)
+    # away from the initial parameters: the reference zero-initialises the heads' last Linear (pred.py), so at step 0 every
+    # gradient upstream of it is exactly zero on both sides and the comparison would hold vacuously for 64 of 76 tensors
+    gen = th.Generator().manual_seed(1234)
+    with th.no_grad():
+        for p in step.sync.params:
+            p.add_((0.05 * th.randn(p.shape, generator=gen)).to(gpu))
     ref_pred, ref_grads = _oracle(cfg, shard, model, oracle_chunk)
 
     # one eager run (HIP-event timer on: its record names say which kernels the step ran)

@@ -61,3 +61,27 @@ def test_two_ranks_replay_their_forward_backward(gpu):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
     assert d["config"]["launch"].startswith("forward + backward + gradient pack as one HIP graph replay per rank")
     assert d["value"] > 0 and abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+
+
+def test_two_ranks_on_the_scaling_workload_default_mode_and_their_gradient(gpu, tmp_path):
+    """`bench.py --gpus 2 --workload 4 --batch 64` (BASELINE configs[3]'s shapes, two ranks time-sharing the one GPU over
+    gloo): without a mode flag every rank replays forward + backward + gradient pack; both ranks are counted; the line
+    carries per-rank host / all-reduce-wait / device times; and the ranks' averaged gradient equals the gradient of ONE
+    process on the global batch (rank 0's pairs, then rank 1's)."""
+    import torch as th
+    two, one = str(tmp_path / "two.pt"), str(tmp_path / "one.pt")
+    flags = ["--workload", "4", "--batch", "64", "--no-cpu-baseline", "--steps", "2", "--warmup", "2"]
+    d = _run("--gpus", "2", "--backend", "gloo", "--single-device", "--dump-grad", two, *flags, timeout=1200)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["launch_fallback"] is None
+    assert d["launch_mode"] == "hip_graph_replay_front+eager_allreduce_adamw"
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert r["host_ms_per_step"] > 0 and r["allreduce_wait_ms"] is not None and r["allreduce_wait_ms"] >= 0 and r["step_ms_median"] > 0
+    assert d["config"]["global_batch"] == 128 and "configs[3]" in d["config"]["workload"]
+    e = _run("--emulate-world", "2", "--eager", "--no-all-outputs", "--dump-grad", one, *flags, timeout=1200)
+    assert e["n_gpus"] == 1 and e["config"]["global_batch"] == 128
+    a, b = th.load(two), th.load(one)
+    assert a["world"] == 2 and b["world"] == 1 and b["batch"] == 128
+    assert th.equal(a["pred_c"].view(-1), b["pred_c"].view(-1)[:64]) or float((a["pred_c"].view(-1) - b["pred_c"].view(-1)[:64]).abs().max()) <= 1e-4 * max(1.0, float(b["pred_c"].abs().max()))
+    scale = float(b["flat"].abs().max())
+    assert scale > 0 and float((a["flat"] - b["flat"]).abs().max()) <= 2e-5 * scale

@@ -55,8 +55,10 @@ def test_csr_and_incidence_build_bit_exact(name, gpu):
     assert np.array_equal(ix.dst32.cpu().numpy(), dst.astype(np.int32))
     inc_ptr, inc_ent = ix.incidence()
     ref_ptr = ip.astype(np.int64) + op
-    ref_ent = np.concatenate([np.concatenate([ie[ip[w]:ip[w + 1]], oe[op[w]:op[w + 1]] ^ 1]) for w in range(n)]) \
-        if n else np.zeros(0)
+    def merged(w):       # in-entries and out-entries (flag flipped) by ascending edge id, an in-entry first on a tie (self loop)
+        both = [(int(x) >> 1, 0, int(x)) for x in ie[ip[w]:ip[w + 1]]] + [(int(x) >> 1, 1, int(x) ^ 1) for x in oe[op[w]:op[w + 1]]]
+        return np.array([x for _, _, x in sorted(both)], dtype=np.int64)
+    ref_ent = np.concatenate([merged(w) for w in range(n)]) if n else np.zeros(0)
     assert np.array_equal(inc_ptr.cpu().numpy(), ref_ptr.astype(np.int32))
     assert np.array_equal(inc_ent.cpu().numpy(), ref_ent.astype(np.int32))
 
@@ -1048,3 +1050,87 @@ def test_pooled_activation_backward_equals_its_two_passes(h, flagged, gated, gpu
     assert float((d.double() - want).abs().max()) <= 1e-6
     q64 = th.zeros(G, h, device=gpu, dtype=th.float64).index_add_(0, seg[live], (g64.view(-1, 1) * act.double())[live])
     assert float((q[:, :h].double() - q64).abs().max()) <= 1e-4
+
+
+def _graph_batch(sizes, rng, gpu, random_flags=False):
+    from dualmessagepassing_amd.collate import collate_device
+    ls, ld, rv = [], [], []
+    for n, m in sizes:
+        u, v = (er_batch(1, n, m, rng)[:2] if m else (np.zeros(0, np.int64), np.zeros(0, np.int64)))
+        ls.append(u); ld.append(v)
+        rv.append(rng.random(2 * m) < 0.5 if random_flags else np.concatenate([np.zeros(m, bool), np.ones(m, bool)]))
+    nn_ = np.array([s[0] for s in sizes], np.int64)
+    ne_ = np.array([2 * s[1] for s in sizes], np.int64)
+    return collate_device(_t(np.concatenate(ls)).to(gpu), _t(np.concatenate(ld)).to(gpu), _t(nn_).to(gpu), _t(ne_).to(gpu),
+                          int(nn_.sum()), int(ne_.sum()), edata={"is_reversed": _t(np.concatenate(rv).astype(bool)).to(gpu)},
+                          max_nodes=int(nn_.max()), max_edges=int(ne_.max()))
+
+
+@pytest.mark.parametrize("h", [64, 128])
+@pytest.mark.parametrize("random_flags", [False, True])
+def test_one_pass_endpoint_sums_equal_the_incidence_segment_sum(h, random_flags, gpu):
+    """dmp_seg_sum2_graphs (csrc/dmp_segacc.hip: the edge rows of a graph tile streamed ONCE, both endpoints' sums kept in
+    registers, added in ascending eid) gives the BITS of dmp_seg_sum2 over the incidence CSR (rows merged by eid): a union
+    of small graphs (8 per tile) and 64-node graphs (one per tile), ragged sizes, graphs without edges or nodes' worth of
+    edges that are not a multiple of the 4-row blocks / super-groups, reversed flags as add_reversed_edges sets
+    them and at random, into a fresh tensor and into a column slice; and agrees with an fp64 scatter."""
+    from dualmessagepassing_amd import ops
+    from dualmessagepassing_amd.collate import union_graphs
+    rng = np.random.default_rng(1000 * h + int(random_flags))
+    p = _graph_batch([(8, 12)] * 37 + [(3, 0), (5, 7), (8, 28)], rng, gpu, random_flags)
+    g = _graph_batch([(64, 256)] * 9 + [(40, 100), (64, 256), (2, 1), (64, 611), (33, 33)], rng, gpu, random_flags)
+    u = union_graphs(p, g)
+    assert u.node_tiling is not None and u.node_tiling[4] == 8 and u.node_tiling[5] == 1
+    ix = u.index()
+    N, E = u.number_of_nodes(), u.number_of_edges()
+    m = th.randn(E, h, device=gpu)
+    inc_ptr, inc_ent = ix.incidence()
+    want = ops.seg_sum_raw(m, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2)
+    saved, ops.USE_GRAPH_SEG_SUM = ops.USE_GRAPH_SEG_SUM, True
+    try:
+        assert ops.graph_seg_ok(ix, m, h)
+        got = ops.endpoint_sums(m, ix)
+        assert th.equal(got, want)
+        wide = th.full((N, 3 * h), 5.0, device=gpu)
+        ops.endpoint_sums(m, ix, out=wide[:, h:])
+        assert th.equal(wide[:, h:], want) and bool((wide[:, :h] == 5.0).all())
+        # a strided operand (a column slice of a wider matrix)
+        m2 = th.randn(E, 2 * h, device=gpu)
+        assert th.equal(ops.endpoint_sums(m2[:, h:], ix), ops.seg_sum_raw(m2[:, h:], inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2))
+        # a single batch without a union
+        gi = g.index()
+        mg = m[:g.number_of_edges()].contiguous()
+        assert th.equal(ops.endpoint_sums(mg, gi), ops.seg_sum_raw(mg, *gi.incidence(), g.number_of_nodes(), None, True, 1.0, -1.0, rows_shared=2))
+    finally:
+        ops.USE_GRAPH_SEG_SUM = saved
+    # the definition, in fp64
+    sel_a, sel_b = ix.endpoint_select()
+    ref = th.zeros(N, 2 * h, dtype=th.float64, device=gpu)
+    ref[:, :h].index_add_(0, sel_a.long(), m.double())
+    ref[:, h:].index_add_(0, sel_b.long(), -m.double())
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    # a graph with more nodes than a tile holds switches the one-pass kernel off (the caller takes the incidence CSR)
+    assert _graph_batch([(65, 10)], rng, gpu).node_tiling is None
+
+
+def test_one_pass_endpoint_sums_at_config_2_size(gpu):
+    """bench.py's launch shape (union of 1024 pattern + 1024 target graphs, hid 128): bits of the incidence segment sum,
+    twice the same bits (no arrival-order dependence), and the sum of ones = the degree counts."""
+    from dualmessagepassing_amd import ops
+    from dualmessagepassing_amd.collate import union_graphs
+    rng = np.random.default_rng(11)
+    p = _graph_batch([(8, 12)] * 1024, rng, gpu)
+    g = _graph_batch([(64, 256)] * 1024, rng, gpu)
+    u = union_graphs(p, g)
+    ix = u.index()
+    N, E, h = u.number_of_nodes(), u.number_of_edges(), 128
+    m = th.randn(E, h, device=gpu)
+    assert ops.graph_seg_ok(ix, m, h)
+    got = ops.endpoint_sums(m, ix)
+    want = ops.seg_sum_raw(m, *ix.incidence(), N, None, True, 1.0, -1.0, rows_shared=2)
+    assert th.equal(got, want)
+    assert th.equal(ops.endpoint_sums(m, ix), got)
+    ones = ops.endpoint_sums(th.ones(E, h, device=gpu), ix)
+    sel_a, sel_b = ix.endpoint_select()
+    assert th.equal(ones[:, 0], th.bincount(sel_a.long(), minlength=N).float())
+    assert th.equal(ones[:, h], -th.bincount(sel_b.long(), minlength=N).float())
