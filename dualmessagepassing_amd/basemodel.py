@@ -47,6 +47,24 @@ class OutputDict(OrderedDict):
     def get(self, k, default=None):
         return self[k] if k in self else default
 
+    def pop(self, k, *default):
+        if k in self:
+            v = self[k]                                    # a deferred entry leaves the dictionary as its tensor
+            OrderedDict.__delitem__(self, k)
+            return v
+        if default:
+            return default[0]
+        raise KeyError(k)
+
+    def popitem(self, last=True):
+        k = next(reversed(self.keys())) if last else next(iter(self.keys()))
+        return k, self.pop(k)
+
+    def setdefault(self, k, default=None):
+        if k not in self:
+            OrderedDict.__setitem__(self, k, default)
+        return self[k]
+
     def values(self):
         return [self[k] for k in self.keys()]
 

@@ -887,7 +887,10 @@ class _FusedDMPLayer(torch.autograd.Function):
             es = torch.addmm(cnt * eb2, Q, eW2.t())
             if residual:
                 es = es + pool_rows(z, epool).view(G_ * halves, H)
-            es = es.view(G_, halves * H)
+            # ... of which only the NON-FLAGGED half is returned ([G, H]): without the rows the backward propagates a gradient
+            # through that half only (the row map is -1 for flagged rows), so the flagged sums are not handed out as if they
+            # were differentiable (the heads mask reversed edges out and read [:, :H] anyway, basemodel.py:1545-1631)
+            es = es.view(G_, halves * H)[:, :H]
         else:
             es = pool_rows(zn, epool) if epool is not None else None
         return xn, zn, vs, es
@@ -911,8 +914,10 @@ class _FusedDMPLayer(torch.autograd.Function):
             dxn = exp if dxn is None else dxn + exp
         if des is not None:
             ep = ctx.epool
-            if dzn is None and typed_ok(ix, H) and H1e.size(0) > 0:
-                lazy = (des[:, :H].contiguous(), pool_rowmap(ep), ep)
+            if dzn is None and typed_ok(ix, H) and H1e.size(0) > 0 and des.size(1) == H:
+                # des is [G, H]: the row-less forward hands out the non-flagged sums only, or no flag splits the sums.  A
+                # [G, 2H] gradient (forward with rows, flag-split sums) may carry a flagged half: the expanded path below
+                lazy = (des.contiguous(), pool_rowmap(ep), ep)
             else:
                 exp = (ops.gather_select_raw(des.contiguous(), ep.seg32, ep.flag8, H, None, 1.0, 1.0) if ep.flag8 is not None
                        else ops.gather_rows_raw(des.contiguous(), ep.seg32))

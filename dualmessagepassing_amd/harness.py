@@ -379,7 +379,13 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
             continue
         pattern, graph_b, counts, (node_w, edge_w) = dataset.batchify(idx, device, return_weights=want)
         sync.detach_grads()
-        out = model(pattern, graph_b)
+        # the representation regulariser reads the last layer's edge rows: with it the layer forms them itself (the deferred
+        # form would run the layer's forward a second time on first access)
+        lazy, model.lazy_edge_rep = getattr(model, "lazy_edge_rep", True), not (rep_reg_w > 0)
+        try:
+            out = model(pattern, graph_b)
+        finally:
+            model.lazy_edge_rep = lazy
         pred = out["pred_c"]
         loss = _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
         for w, pk, mk in ((node_w, "pred_v", "g_v_mask"), (edge_w, "pred_e", "g_e_mask")):
@@ -437,7 +443,11 @@ class GraphedTrainStep:
         pattern, graph = self.dataset_cls.graphs_from_arrays(meta, tensors)
         counts, hyper = tensors[-2], tensors[-1]
         self.sync.detach_grads()
-        out = self.model(pattern, graph)
+        lazy, self.model.lazy_edge_rep = getattr(self.model, "lazy_edge_rep", True), not self.with_rep_reg   # see train_epoch
+        try:
+            out = self.model(pattern, graph)
+        finally:
+            self.model.lazy_edge_rep = lazy
         pred = out["pred_c"]
         loss = self.bp(torch.where(pred > 0, pred, pred * hyper[0]), counts)      # leaky_relu with the slope on the device
         if self.with_rep_reg:

@@ -247,6 +247,25 @@ class _GatherRows(torch.autograd.Function):
         return seg_sum_raw(dO, ix.in_ptr, ix.in_ent, ix.num_nodes), None, None
 
 
+def mark_immutable(*tensors):
+    """Declare index tensors (node ids, relation types, triplets of a FIXED graph) as never refilled in place.  The index
+    structures derived from such a tensor (``take_rows``'s CSR, ``PoolIndex.from_keys``) are memoised on the tensor's identity
+    and version; while a step is being RECORDED (``dp.StepGraph``) a memo hit leaves the index build out of the recording,
+    which is only right if the tensor's contents cannot change between replays -- a replay runs no Python, so an in-place
+    refill of a closed-over buffer would go unnoticed.  Inside a recording the memos are therefore consulted for marked
+    tensors only; everything else is rebuilt (and recorded).  Returns its argument(s)."""
+    for t in tensors:
+        if t is not None:
+            t._dmp_immutable = True
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def _memo_usable(key_tensor):
+    """A memo entry keyed on ``key_tensor`` may be used: always outside a stream capture, inside one only for tensors the
+    caller has marked immutable."""
+    return not (key_tensor.is_cuda and torch.cuda.is_current_stream_capturing()) or getattr(key_tensor, "_dmp_immutable", False)
+
+
 class _TakeRows(torch.autograd.Function):
     """``X[idx]`` for an arbitrary int64 index vector: forward = row gather, backward = fixed-order
     segment sum over a CSR of the index values (torch's advanced-indexing backward serialises on
@@ -255,7 +274,7 @@ class _TakeRows(torch.autograd.Function):
     _memo = []     # (ident of the key tensor, (rowptr, ent, idx32), key tensor): see PoolIndex.from_keys
 
     @staticmethod
-    def forward(ctx, X, idx, key=None):
+    def forward(ctx, X, idx, key=None, tag=None):
         lib = _lib.load()
         _lib.require_gpu(X, idx)
         M, N = idx.numel(), X.size(0)
@@ -263,9 +282,10 @@ class _TakeRows(torch.autograd.Function):
         # (UNC: the node ids of its one graph, the triplets of a full-graph step) gets it from a small memo keyed on the
         # tensor's identity and version (``key``: the tensor ``idx`` was derived from, when ``idx`` itself is a temporary).
         k = key if key is not None else idx
-        ident = (k.data_ptr(), k._version, int(k.numel()), tuple(k.stride()), str(k.device), str(k.dtype), int(M), int(N))
+        # (``tag``: how ``idx`` was derived from ``key`` -- two derivations of equal length from one key must not share an entry)
+        ident = (k.data_ptr(), k._version, int(k.numel()), tuple(k.stride()), str(k.device), str(k.dtype), int(M), int(N), tag)
         memo, hit = _TakeRows._memo, None
-        for i, m in enumerate(memo):
+        for i, m in enumerate(memo if _memo_usable(k) else ()):
             if m[0] == ident:
                 if i:
                     memo.insert(0, memo.pop(i))
@@ -294,13 +314,14 @@ class _TakeRows(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dO):
-        return seg_sum_raw(dO.contiguous(), ctx.rowptr, ctx.ent, ctx.N, rows_shared=False), None, None
+        return seg_sum_raw(dO.contiguous(), ctx.rowptr, ctx.ent, ctx.N, rows_shared=False), None, None, None
 
 
-def take_rows(X, idx, key=None):
+def take_rows(X, idx, key=None, tag=None):
     """Differentiable ``X[idx]`` (rows) on the gather / segment-sum kernels.  ``key``: the tensor ``idx`` was computed
-    from, if ``idx`` is a temporary (the index's CSR is memoised on the key's identity and version)."""
-    return _TakeRows.apply(X, idx, key)
+    from, if ``idx`` is a temporary (the index's CSR is memoised on the key's identity and version); ``tag`` (hashable): which
+    derivation of ``key`` this is, when a caller derives more than one index of the same length from it."""
+    return _TakeRows.apply(X, idx, key, tag)
 
 
 class _TakeRowsSmallTable(torch.autograd.Function):
@@ -565,6 +586,7 @@ class _BatchNormActTrain(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         lib = _lib.load()
         x, y, gamma = ctx.saved_tensors
@@ -575,8 +597,8 @@ class _BatchNormActTrain(torch.autograd.Function):
         check(lib.dmp_bn_train_bwd(ptr(x), x.stride(0), ptr(y), y.stride(0) if act else 0, ptr(dy), dy.stride(0), R, C, ptr(gamma),
                                    int(act), float(ctx.slope or 0.0), ptr(ctx.partial), ptr(ctx.stats), ptr(dx), dx.stride(0),
                                    stream_ptr()), "dmp_bn_train_bwd")
-        dgamma = ctx.stats[3 * C:] if gamma is not None else None
-        dbeta = ctx.stats[2 * C:3 * C] if gamma is not None else None
+        dgamma = ctx.stats[3 * C:].clone() if gamma is not None else None      # copies: the statistics buffer stays the node's own
+        dbeta = ctx.stats[2 * C:3 * C].clone() if gamma is not None else None
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -649,7 +671,7 @@ class PoolIndex:
         if memo is None:
             memo = cls._keys_memo = []
         ident = (keys.data_ptr(), keys._version, int(keys.numel()), tuple(keys.stride()), str(keys.device), str(keys.dtype), int(num_keys))
-        for i, m in enumerate(memo):
+        for i, m in enumerate(memo if _memo_usable(keys) else ()):
             if m[0] == ident:
                 if i:
                     memo.insert(0, memo.pop(i))             # most recently used first
@@ -661,8 +683,9 @@ class PoolIndex:
         # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
         marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))
         out = cls(marks[1:] - marks[:-1], order=order, seg=keys, num_rows=int(keys.numel()))
-        memo.insert(0, (ident, out, keys_in))             # the tensor is kept alive: its address stays unique
-        del memo[4:]                                        # a few entries: a step meets two or three different key tensors
+        if not (keys_in.is_cuda and torch.cuda.is_current_stream_capturing()):   # an index made inside a recording lives in its pool
+            memo.insert(0, (ident, out, keys_in))         # the tensor is kept alive: its address stays unique
+            del memo[4:]                                    # a few entries: a step meets two or three different key tensors
         return out
 
     def __init__(self, sizes, flag=None, order=None, seg=None, num_rows=None):

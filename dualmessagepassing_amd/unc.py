@@ -218,6 +218,8 @@ class DMPNN(nn.Module):
     def _rel_pool(self, r):
         key = (r.data_ptr(), r._version, int(r.numel()), r.device)
         cached = getattr(self, "_rel_pool_cache", None)
+        if cached is not None and not ops._memo_usable(r):
+            cached = None                                      # being recorded and not marked immutable (ops.mark_immutable)
         if cached is None or cached[0] != key:
             self._rel_pool_cache = cached = (key, PoolIndex.from_keys(r, self.num_rels), r)  # r kept alive: ptr stays unique
         return cached[1]
@@ -249,7 +251,7 @@ class TrainModel(nn.Module):
     def calc_score(self, embedding, triplets):
         node_emb = embedding[0] if isinstance(embedding, (tuple, list)) else embedding
         # model.py:669-677; the two endpoint lookups as ONE row gather whose backward is a segment sum
-        so = ops.take_rows(node_emb, torch.cat([triplets[:, 0], triplets[:, 2]]), key=triplets)
+        so = ops.take_rows(node_emb, torch.cat([triplets[:, 0], triplets[:, 2]]), key=triplets, tag="subject|object")
         s, o = so[:triplets.size(0)], so[triplets.size(0):]
         r = ops.take_rows_small_table(self.w_relation, triplets[:, 1])
         return torch.sum(s * r * o, dim=1)
@@ -278,6 +280,8 @@ class TrainModel(nn.Module):
                     # defeat the keyed pool index's memo: ~25 launches of sorting per step on the one fixed graph)
                     ck = (edge_type.data_ptr(), edge_type._version, int(edge_type.numel()), emb.dtype)
                     cached = getattr(self, "_etype_cache", None)
+                    if cached is not None and not ops._memo_usable(edge_type):
+                        cached = None                          # being recorded and not marked immutable: rebuilt in the recording
                     if cached is None or cached[0] != ck:
                         cached = self._etype_cache = (ck, (edge_type < num_rels).to(emb.dtype).unsqueeze(1),
                                                       edge_type.clamp(max=num_rels - 1), edge_type)

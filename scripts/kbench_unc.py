@@ -25,6 +25,9 @@ opt = FlatAdamW([master], lr=1e-3, weight_decay=0.0)      # Adam (UNC main.py:11
 nid = th.arange(n, device=gpu)
 samples = th.from_numpy(np.concatenate([trip, np.stack([rng.integers(0, n, m), np.zeros(m, np.int64), rng.integers(0, n, m)], 1)])).to(gpu)
 labels = th.cat([th.ones(m), th.zeros(m)]).to(gpu)
+from dualmessagepassing_amd import ops
+ops.mark_immutable(nid, etype, samples)    # the ONE graph's ids / relation types / triplets: never refilled in place, so a
+                                           # recorded step may take their memoised indexes (ops.mark_immutable)
 
 
 def timeit(f, it=30):
