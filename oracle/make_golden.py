@@ -124,6 +124,57 @@ def gen_dmplayer():
         print("wrote", fn)
 
 
+def gen_dmplayer_bn():
+    """DMPLayer with its constructor default ``batch_norm=True`` (models/dmpnn.py:17-28,45-60: Linear -> BatchNorm1d ->
+    activation -> Linear in both MLPs): training mode (batch statistics, running-average update) and evaluation mode (the
+    running statistics a training pass has left), forward + backward."""
+    import dgl
+    from models.dmpnn import DMPLayer
+    rng = np.random.default_rng(4321)
+    graphs = named_graphs(rng)
+    cases = [("er8_12", 64, "relu"), ("er64_256", 64, "leaky_relu"), ("er64_256", 128, "relu"), ("star8", 8, "leaky_relu")]
+    for name, h, act in cases:
+        u, v, n = graphs[name]
+        u, v, rev = with_rev(u, v)
+        th.manual_seed(seed_of("bn", name, h, act))
+        layer = DMPLayer(h, h, init_neigenv=4.0, init_eeigenv=4.0, num_mlp_layers=2, batch_norm=True, act_func=act, dropout=0.0)
+        with th.no_grad():
+            layer.nbias.uniform_(-0.1, 0.1)
+            layer.ebias.uniform_(-0.1, 0.1)
+            for m in list(layer.nmlp.modules()) + list(layer.emlp.modules()):
+                if isinstance(m, th.nn.Linear):
+                    m.bias.uniform_(-0.1, 0.1)
+                if isinstance(m, th.nn.BatchNorm1d):              # affine parameters and running statistics that matter
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.2, 0.2)
+                    m.running_mean.uniform_(-0.3, 0.3)
+                    m.running_var.uniform_(0.5, 2.0)
+        x0, z0 = th.randn(n, h), th.randn(len(u), h)
+        for mode in ("train", "eval"):
+            layer.train(mode == "train")
+            g = dgl.DGLGraph.from_edges(u, v, n)
+            g.edata["is_reversed"] = th.from_numpy(rev)
+            d = {"src": u, "dst": v, "rev": rev, "num_nodes": n, "act_func": act, "mode": mode}
+            for k, b in layer.named_buffers():                    # the statistics BEFORE the pass
+                d["b0." + k] = b.clone()
+            x, z = x0.clone().requires_grad_(True), z0.clone().requires_grad_(True)
+            for p in layer.parameters():
+                p.grad = None
+            node_out, edge_out = layer(g, x, z)
+            wn, we = th.randn_like(node_out), th.randn_like(edge_out)
+            ((node_out * wn).sum() + (edge_out * we).sum()).backward()
+            d.update({"out_deg": g.ndata["out_deg"], "x": x, "z": z, "node_out": node_out, "edge_out": edge_out, "wn": wn,
+                      "we": we, "dx": x.grad, "dz": z.grad})
+            for k, p in layer.named_parameters():
+                d["p." + k] = p
+                d["g." + k] = p.grad
+            for k, b in layer.named_buffers():                    # ... and after it (training mode moves them)
+                d["b1." + k] = b.clone()
+            fn = "bnlayer_dmp_%s_h%d_%s_%s.npz" % (name, h, act, mode)
+            np.savez_compressed(os.path.join(OUT, fn), **t2n(d))
+            print("wrote", fn)
+
+
 def gen_dmpnn_rep():
     """get_pattern_rep / get_graph_rep of the reference DMPNN class, called unbound on a
     light holder object (they only touch p_rep_net / g_rep_net / rep_residual)."""
@@ -1277,7 +1328,7 @@ def gen_dual_subiso():
 
 
 
-GENERATORS = ["dmplayer", "dmpnn_rep", "compgcn", "linegraph", "addrev", "full_model", "unc", "subiso_weights", "expand", "rgnn",
+GENERATORS = ["dmplayer", "dmplayer_bn", "dmpnn_rep", "compgcn", "linegraph", "addrev", "full_model", "unc", "subiso_weights", "expand", "rgnn",
               "preprocess", "init", "default_model", "train_run", "train_run_compgcn", "dual_subiso", "schedules", "lrp"]
 
 
