@@ -65,24 +65,13 @@ __device__ __forceinline__ float4 cmul4(const float4 &a, const float4 &b) {     
 // ---------------------------------------------------------------------------
 // KIND is not used by the code: 1 tags the launches over an incidence CSR (every source row listed under two destinations),
 // so that a profiler's per-kernel statistics keep them apart from the launches over a CSR by destination.
-#ifndef DMP_SEG_VAR
-#define DMP_SEG_VAR 0     // knobs (scripts/mb_seg_var.py).  1: non-temporal stores of the sums in the incidence launches: 80.4 ->
-                          // 75.9 us stand-alone (the output rows do not push the edge rows, read a second time by the other
-                          // endpoint, out of L2), but NO gain inside the step (80.7 us, dPre fresh from the kernel before:
-                          // gpurun_out r03w) -- off; 2 / 4 / 8: wider workgroups (a graph's nodes on one CU): slower; 16 / 32:
-                          // 4 / 16 row loads in flight per lane: slower; 64: non-temporal stores in the launches by destination
-#endif
 template <int G, bool SPLIT, bool WEIGHTED, bool REMAP, int KIND = 0, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
     float s0, float s1, float *__restrict__ out, int64_t ldo) {
   constexpr int RPB = BLOCK / G;
-  constexpr int U = (KIND == 1 && (DMP_SEG_VAR & 16)) ? 4 : ((KIND == 1 && (DMP_SEG_VAR & 32)) ? 16 : 8);  // independent 16-B row loads in flight per lane
-#ifdef DMP_SEG_OCC_LDS
-  __shared__ float occ_pad[DMP_SEG_OCC_LDS / 4];               // development: caps the resident workgroups per CU
-  if (REMAP && SPLIT && N < 0) out[0] = occ_pad[threadIdx.x];
-#endif
+  constexpr int U = 8;  // independent 16-B row loads in flight per lane (4 and 16 measured slower over the incidence CSR)
   // REMAP (XCD-local rows): needed when rows are shared between destinations (incidence
   // CSR) and also faster when M was just written by the previous kernel (59 vs 70 us);
   // plain dispatch order only wins (~3 us) on a cold read-once stream (scripts/kbench.py).
@@ -125,11 +114,7 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
     }
     if (act) {
       float *o = out + (int64_t)row * ldo + c;
-      if (SPLIT && ((KIND == 1 && (DMP_SEG_VAR & 1)) || (KIND == 0 && (DMP_SEG_VAR & 64)))) {
-        const float4 u = mul4(a0, s0), w = mul4(a1, s1);
-        __builtin_nontemporal_store(u.x, o); __builtin_nontemporal_store(u.y, o + 1); __builtin_nontemporal_store(u.z, o + 2); __builtin_nontemporal_store(u.w, o + 3);
-        __builtin_nontemporal_store(w.x, o + H); __builtin_nontemporal_store(w.y, o + H + 1); __builtin_nontemporal_store(w.z, o + H + 2); __builtin_nontemporal_store(w.w, o + H + 3);
-      } else if (SPLIT) {
+      if (SPLIT) {   // (non-temporal stores of the sums: -5.6 % stand-alone over the incidence CSR, nothing inside the step)
         st4(o, mul4(a0, s0));
         st4(o + H, mul4(a1, s1));
       } else {
@@ -647,19 +632,8 @@ const char *dmp_last_hip_error(void) { return g_last_err; }
 
 #define DMP_SS(SP, WT, RM) \
   seg_sum_vec<G, SP, WT, RM><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
-#if DMP_SEG_VAR & 2   // a 1024-thread workgroup of 16-lane groups: 64 rows -- the nodes of a whole target graph -- side by side on one CU
-#define DMP_SS_INC() \
-  seg_sum_vec<16, true, false, true, 1, 1024><<<blocks_for(N, 1024 / 16), 1024, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
-#elif DMP_SEG_VAR & 4   // 512 threads, 16-lane groups: 32 rows
-#define DMP_SS_INC() \
-  seg_sum_vec<16, true, false, true, 1, 512><<<blocks_for(N, 512 / 16), 512, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
-#elif DMP_SEG_VAR & 8   // 1024 threads, 32-lane groups: 32 rows
-#define DMP_SS_INC() \
-  seg_sum_vec<32, true, false, true, 1, 1024><<<blocks_for(N, 1024 / 32), 1024, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
-#else
 #define DMP_SS_INC() \
   seg_sum_vec<G, true, false, true, 1><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
-#endif
 
 static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                         const float *ew, int64_t N, int H, bool split, float s0, float s1,

@@ -96,9 +96,6 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   };
   zero_acc();
 
-#ifdef DMP_ATB_DBG
-  bool warm = false;
-#endif
   int id_rows[NL], id_rowsD[NL];
   float sc_rows[NL];
   float4 preZ[2][NL], preD[2][NL];                         // two sets of prefetched rows: tiles of even / odd pipeline phase
@@ -127,9 +124,6 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   };
   auto load_row = [&](auto set, int m) {                    // rows of slice m of the tile whose ids are in id_rows
     constexpr int S = decltype(set)::value;
-#ifdef DMP_ATB_DBG
-    if ((DMP_ATB_DBG & 2) && warm) return;
-#endif
     const bool ok = id_rows[m] >= 0;
     preZ[S][m] = row_load4<BIG>(rs_Z, p.Z + H * ya, p.ldz, id_rows[m], colA);          // -1: zeros
     const int idD = REL ? id_rowsD[m] : id_rows[m];
@@ -194,9 +188,6 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           __builtin_amdgcn_sched_barrier(0);
-#ifdef DMP_ATB_DBG
-          if (!(DMP_ATB_DBG & 4))
-#endif
           acc[i][j] = mfma_x6(fa[i], fb, acc[i][j]);
           __builtin_amdgcn_sched_barrier(0);
           // 2 NL actions over NI * NJ blocks (H = 128: 8 actions, 8 blocks; H = 64: 4 actions, 2 blocks)
@@ -224,16 +215,10 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 #pragma unroll
       for (int j = 0; j < NJ; ++j) y[j] = s + 1 < 8 ? dp[(s + 1) * kStride + 32 * j] : b[j];
       __builtin_amdgcn_sched_barrier(0);
-#ifdef DMP_ATB_DBG
-      if (!(DMP_ATB_DBG & 4)) {
-#endif
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-#ifdef DMP_ATB_DBG
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if (s < NL) stage_row(other, s < NL ? s : 0);
       else if (s < 2 * NL) load_row(other, s < 2 * NL ? s - NL : 0);
@@ -338,9 +323,6 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
         cur = __shfl(sv, k & 63);
       }
       if (restart) start_at(k);
-#ifdef DMP_ATB_DBG
-      warm = true;
-#endif
       // the hot loop: tiles of one class inside one chunk of 64, two pipeline phases per trip
       auto more = [&]() { return k < mine && (!TYPED || ((k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0)); };
       for (;;) {

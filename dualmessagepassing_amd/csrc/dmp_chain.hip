@@ -40,9 +40,6 @@ struct ChainArgs {
   float *Zn; int64_t ldo;                               // output rows [E, H]
 };
 
-#ifndef DMP_CH_DBG
-#define DMP_CH_DBG 0   // development knobs (timing only): 1 no P-row gathers, 2 no stores, 4 no residual row loads in group B, 8 no MFMAs
-#endif
 constexpr int kCH = 128;                                  // hidden width
 constexpr int kCStrideD = (kCH + 8) / 2, kCPlane = kSub * kCStrideD;   // bf16 plane rows: 68 dwords (see dmp_typed.hip)
 constexpr int kCHalf = kCH / 2, kCGroups = kCHalf / 8, kCQ = kCH / 4;
@@ -97,19 +94,15 @@ __global__ __launch_bounds__(512, 2) void edge_chain_k(ChainArgs p) {
       }
       const Split8 &bb = B6[g];
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DMP_CH_DBG & 8)) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bb.hi.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.lo.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.mid.v, acc, 0, 0, 0);
-      } else acc[g] += __uint_as_float(al.u[0] ^ bb.hi.u[1]);
       __builtin_amdgcn_sched_barrier(0);
       action(2 * g);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DMP_CH_DBG & 8)) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.hi.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.mid.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.hi.v, acc, 0, 0, 0);
-      }
       __builtin_amdgcn_sched_barrier(0);
       action(2 * g + 1);
       ah = nh; am = nm; al = nl;
@@ -195,7 +188,6 @@ __global__ __launch_bounds__(512, 2) void edge_chain_k(ChainArgs p) {
     float4 g0[4], g1[4];
     auto fetch_operand = [&](int par, int k) {
       const int rr = 8 * k + lrow;
-      if (DMP_CH_DBG & 1) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; return; }
       g0[k] = sbuf_load4(rs_P, (int)rowA[par][rr], col4);
       g1[k] = sbuf_load4(rs_P, (int)rowB[par][rr], col4 + kRowBytes);
     };
@@ -220,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void edge_chain_k(ChainArgs p) {
         v.w = act_fwd((v.w + (g0[q].w - g1[q].w)) + bias4.w, slope);
         const int id = (int)rowC[par][rr];
         if (id < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);              // padding rows: zeros in the image
-        if (!(DMP_CH_DBG & 2) || v.x == 123.456f) row_store4<BIG>(v, rs_H1, p.H1, p.ldh, id, col4);
+        row_store4<BIG>(v, rs_H1, p.H1, p.ldh, id, col4);
         uint2 ph, pm, pl;
         split_pair(v.x, v.y, ph.x, pm.x, pl.x);
         split_pair(v.z, v.w, ph.y, pm.y, pl.y);
@@ -294,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void edge_chain_k(ChainArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int id = (int)rowC[par3][8 * q + lrow];
-          zr[q] = (p.residual && !(DMP_CH_DBG & 4)) ? row_load4<BIG>(rs_Z, p.Z, p.ldz, id, col4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          zr[q] = (p.residual) ? row_load4<BIG>(rs_Z, p.Z, p.ldz, id, col4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         x6_tile(&Hs[t & 1][0], B2, [&](int) {});
         park();
@@ -305,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void edge_chain_k(ChainArgs p) {
           const float gt = rowG[par3][rr];
           v.x = (v.x + b24.x) * gt + zr[q].x; v.y = (v.y + b24.y) * gt + zr[q].y;
           v.z = (v.z + b24.z) * gt + zr[q].z; v.w = (v.w + b24.w) * gt + zr[q].w;
-          if (!(DMP_CH_DBG & 2) || v.x == 123.456f) row_store4<BIG>(v, rs_Zn, p.Zn, p.ldo, (int)rowC[par3][rr], col4);
+          row_store4<BIG>(v, rs_Zn, p.Zn, p.ldo, (int)rowC[par3][rr], col4);
         }
         par3 = par3 == 2 ? 0 : par3 + 1;
       }

@@ -31,9 +31,6 @@ struct Gemm6Args {
   float *C; int64_t ldc; int64_t R; int N;
 };
 
-#ifndef DMP_G6_DBG
-#define DMP_G6_DBG 0          // development knobs (scripts/build_dbg.sh): 1 no MFMAs, 2 no global loads after the first steps, 4 no stores,
-#endif                        // 8 no LDS piece writes after the first step, 16 no fragment reads (timing only: results are wrong)
 constexpr int kBM = 128, kKS = 16;            // rows per tile, k per step
 constexpr int kRowD = 12;                     // dwords per plane row: 16 bf16 (8 dwords) + 4 of padding (16-byte aligned rows;
                                               // 12 r mod 64 is a different multiple of 4 for 16 different r mod 16: conflict-free)
@@ -142,14 +139,13 @@ __global__ __launch_bounds__(256, 2) void gemm6_k(Gemm6Args p) {
       fb[j].mid.v = *reinterpret_cast<const bf16x8 *>(q + kPlane);
       fb[j].lo.v = *reinterpret_cast<const bf16x8 *>(q + 2 * kPlane);
     }
-    if (s + 1 < nsteps && !(DMP_G6_DBG & 8)) store_step(next, buf ^ 1);
-    if (s + kDepth < nsteps && !(DMP_G6_DBG & 2)) load_step(self, s + kDepth);
+    if (s + 1 < nsteps) store_step(next, buf ^ 1);
+    if (s + kDepth < nsteps) load_step(self, s + kDepth);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        if (!(DMP_G6_DBG & 1)) acc[i][j] = mfma_x6(fa[i], fb[j], acc[i][j]);
-        else acc[i][j][0] += __uint_as_float(fa[i].hi.u[0] ^ fb[j].lo.u[3]);
+        acc[i][j] = mfma_x6(fa[i], fb[j], acc[i][j]);
     lds_barrier();               // LDS only: __syncthreads() would wait for the prefetched global loads too
   };
   for (int s = 0; s < nsteps; s += kDepth) {
@@ -179,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm6_k(Gemm6Args p) {
           if (p.Cadd) v += p.Cadd[row * p.ldadd + col];
           if (p.act) v = act_fwd(v, p.slope);
         }
-        if (!(DMP_G6_DBG & 4) || v == 123.456f) p.C[row * p.ldc + col] = v;
+        p.C[row * p.ldc + col] = v;
       }
   }
 }

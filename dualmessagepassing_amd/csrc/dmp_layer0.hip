@@ -23,14 +23,11 @@
 namespace dmp {
 namespace {
 
-#ifndef DMP_L0_VAR
-#define DMP_L0_VAR 0                  // development knobs (scripts/build_dbg.sh, scripts/mb_l0.py)
-#endif
 constexpr int kL0K = 16;              // widest label code
 constexpr int kL0Rows = 4;            // rows in flight per wave
 constexpr int kFwdRows = 4;
-constexpr bool kBwdWide = !(DMP_L0_VAR & 256);          // four accumulators per combine round (-6 us at E = 549 k)
-constexpr bool kBwdNoPrefetch = !(DMP_L0_VAR & 512);    // 8 rows per batch, no second register set (-5 us)
+constexpr bool kBwdWide = true;          // four accumulators per combine round (-6 us at E = 549 k)
+constexpr bool kBwdNoPrefetch = true;    // 8 rows per batch, no second register set (-5 us)
 constexpr int kL0MaxPartials = 1024;
 constexpr int kLaneCoef = 16, kLaneA = 17, kLaneB = 18;   // lanes that fetch the row's coefficient and node rows
 
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
       mm[u] = m;
     }
   };
-  // Measured (scripts/mb_l0.py, knob builds): 135 us at E = 549 k, of which the scalars + epilogue 25, the FMAs 30, the
+  // Measured (knob builds of round 3): 135 us at E = 549 k, of which the scalars + epilogue 25, the FMAs 30, the
   // stores 32-49 and the two gathers 30-41 -- they add up whatever the occupancy (3..6 waves per SIMD), the rows per batch,
   // a two-batch software pipeline with the gathers issued ahead of the stores, contiguous row runs per workgroup or an
   // XCD-aware order (all within 135-145 us); PMC: 281 MB written, 260 MB fetched (the node rows 3 x).

@@ -19,7 +19,8 @@
 //     transposed float4s and stores 16 B per lane.
 //   * per tile:  MFMA phase | barrier | stage next tile, prefetch the one after | barrier | epilogue.
 //
-// What shaped the non-MFMA part (per-phase cycle counters, scripts/mb_phase.py; knobs, scripts/mb_dbg.py):
+// What shaped the non-MFMA part (per-phase cycle counters and knob builds of rounds 1-3; the timing-only knob code is no
+// longer part of this translation unit -- the findings are in DESIGN.md, appendix):
 //   * while another wave of the SIMD streams f32 MFMAs back to back (64 cycles each, they occupy the
 //     f32 vector lanes), a wave gets roughly ONE instruction issued per MFMA -- of any kind.  What
 //     does not fit under the partner's MFMA phase (64 x NC instructions per tile) is exposed.  So
@@ -47,22 +48,10 @@
 //   dmp_gemm_k128        plain C = A B (development / tests)
 #include "dmp_mfma_common.h"
 
-// Development builds (scripts/mb_dbg.py, scripts/mb_phase.py): -DDMP_DBG=<bits>, compiled out by default.
-//   1 no output stores, 2 no accumulator transpose, 4 no row prefetch after the first tiles, 8 no staging
-//   writes (results are wrong: timing only); 16 per-phase cycle counters, 64 finer epilogue counters.
-#ifndef DMP_DBG
-#define DMP_DBG 0
-#endif
-#ifdef DMP_DBG_STANDALONE
-namespace dmp { void set_last_hip_error(hipError_t) {} }
-#endif
 
 namespace dmp {
 namespace {
 
-#if DMP_DBG & 16
-__device__ long long g_dbg[8 * 8];  // [wave][compute, mem, barrier, steps, stage] cycles of workgroup 0
-#endif
 
 enum { EPI_NONE = 0, EPI_EDGE = 1, EPI_GATE_RES = 2, EPI_RELU_BWD_G = 3, EPI_DZ = 4 };
 
@@ -176,7 +165,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
     const rsrc_t ra = make_rsrc(p.A + (int64_t)t * kSub * p.lda, tile_bytes(tile_rows(t), p.lda, H));
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
-      if (!(DMP_DBG & 4) || t < 2 * (int)gridDim.x) pre[m] = buf_load4(ra, voffA, m * grpA);
+      pre[m] = buf_load4(ra, voffA, m * grpA);
     if (EPI != EPI_NONE && gtid < kSub) {
       const uint32_t so = (uint32_t)t * (kSub * 4u);      // E * 4 < 2^32 (checked by the host)
       if (EPI == EPI_EDGE || EPI == EPI_DZ) pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, gtid * 4, (int)so, 0);
@@ -188,7 +177,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
   auto stage = [&](int par) {                             // registers -> LDS
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
-      if (!(DMP_DBG & 8) || pre[m].x == 123.456f)
+      if (true || pre[m].x == 123.456f)
       *reinterpret_cast<float4 *>(&As_g[((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
     if (EPI != EPI_NONE && gtid < kSub) {
       uint32_t a = 0, bb = 0;
@@ -296,14 +285,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
   // NC = 2: after the accumulators have been parked in the scratch -- the other group's MFMA
   // phase covers their latency
   constexpr bool kEarly = (NC == 1);
-#if DMP_DBG & 64
-  long long c_e1 = 0, c_e2 = 0;
-#endif
   auto epilogue = [&](int t, int par) {                   // transpose through LDS, combine, store
     constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
-#if DMP_DBG & 64
-    const long long c_e0 = clock64();
-#endif
     const rsrc_t rc = make_rsrc(p.C + (int64_t)t * kSub * p.ldc, tile_bytes(tile_rows(t), p.ldc, kOutCols));
 #pragma unroll
     for (int q = 0; q < NOUT; ++q) {
@@ -312,19 +295,14 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[q][r];
         if (EPI == EPI_EDGE || EPI == EPI_DZ) v = v + rowS[grp][par][rr] * acc[NC - 1][r];
-        if (!(DMP_DBG & 2)) scr[rr * kScrStride + li] = v;
+        scr[rr * kScrStride + li] = v;
       }
-#if DMP_DBG & 64
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      c_e1 += clock64() - c_e0;
-#endif
       if (EPI != EPI_NONE && !kEarly) fetch_operands(t, par);
       // written and read by the same wave: LDS operations of one wave complete in order
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int rr = 8 * k + lrow;
         float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
-        if (DMP_DBG & 2) v = make_float4(acc[q][4 * k], acc[q][4 * k + 1], acc[q][4 * k + 2], acc[q][4 * k + 3]);
         if (EPI == EPI_EDGE) {
           // ((G0 + coef G1) + (P[a] - P[b])) + bias, then ReLU: the reference's order (dmpnn.py:147-152)
           v.x = act_fwd((v.x + (g0[k].x - g1[k].x)) + bias4.x, slope);
@@ -354,12 +332,9 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
             buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + kRowBytes, 0);
           }
         }
-        if (!(DMP_DBG & 1) || v.x == 123.456f) buf_store4(v, rc, voffC[k] + kRowBytes * q, 0);
+        buf_store4(v, rc, voffC[k] + kRowBytes * q, 0);
       }
     }
-#if DMP_DBG & 64
-    c_e2 += clock64() - c_e0;
-#endif
   };
 
   const int t0 = first + grp;
@@ -409,56 +384,25 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
     // tiles past the end are all-zero / dropped by the buffer range checks.
     int staged = 0, computed = 0, stored = 0;
     load_rows(tile(0));
-  #if DMP_DBG & 16
-    long long c_comp = 0, c_mem = 0, c_bar = 0, c_stage = 0;
-  #endif
     for (int s = 0; s < 2 * niter + 2; ++s) {
-  #if DMP_DBG & 16
-      const long long c0 = clock64();
-  #endif
       if (((s + grp) & 1) == 0) {
         // Staging first, the next prefetch last (one in-order vmcnt, see the header); unconditional,
         // on one straight-line path, so that the compiler sees the prefetch registers as free and does
         // not drain the epilogue's stores before reusing them.
         stage(staged & 1);
         ++staged;
-  #if DMP_DBG & 16
-        c_stage += clock64() - c0;
-  #endif
         if (stored < computed) {
           epilogue(tile(stored), stored & 1);
           ++stored;
         }
         load_rows(tile(staged));
-  #if DMP_DBG & 16
-        c_mem += clock64() - c0;
-  #endif
       } else if (computed < staged && computed < mine) {
         if (EPI != EPI_NONE && kEarly) fetch_operands(tile(computed), computed & 1);
         compute();
         ++computed;
-  #if DMP_DBG & 16
-        asm volatile("s_nop 0" ::"v"(acc[0][0]));
-        c_comp += clock64() - c0;
-  #endif
       }
-  #if DMP_DBG & 16
-      const long long c1 = clock64();
-  #endif
       lds_barrier();
-  #if DMP_DBG & 16
-      c_bar += clock64() - c1;
-  #endif
     }
-  #if DMP_DBG & 16
-    if (blockIdx.x == 0 && lane == 0) {
-      g_dbg[wave * 8 + 0] = c_comp; g_dbg[wave * 8 + 1] = c_mem; g_dbg[wave * 8 + 2] = c_bar;
-      g_dbg[wave * 8 + 3] = 2 * niter + 2; g_dbg[wave * 8 + 4] = c_stage;
-  #if DMP_DBG & 64
-      g_dbg[wave * 8 + 5] = c_e1; g_dbg[wave * 8 + 6] = c_e2;
-  #endif
-    }
-  #endif
 
   }
 
@@ -638,8 +582,5 @@ int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
   return launch_mfma<2, EPI_DZ>(p, (hipStream_t)stream);
 }
 
-#if DMP_DBG & 16
-void dmp_dev_read_dbg(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * 64); }
-#endif
 
 }  // extern "C"

@@ -57,12 +57,9 @@ template <int H> struct TypedGeom {
 // fp32-accurate, 2.67 x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32); the weight panel is kept in registers as
 // pieces (96 instead of 64 VGPRs at H = 128: two workgroups per CU instead of three), the streamed operand is split as
 // it is read from LDS.  !X6: exact fp32 MFMA (development / comparison switch, dmp_dev_set_exact_fp32).
-#ifndef DMP_TY_VAR
-#define DMP_TY_VAR 0      // development knobs (scripts/build_dbg.sh): 16 TEPI_DZ pipelined under X6, 32 three waves per SIMD under X6
-#endif
 // BIG: the streamed / scattered row arrays (A, C, R) are 4 GiB or larger: rows through 64-bit pointers (dmp_mfma_common.h).
 template <int EPI, int H, bool X6, bool BIG = false>
-__global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) ? 2 : 3) void mfma_typed(TypedArgs p) {
+__global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typed(TypedArgs p) {
   constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
   constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   // is computed).  X6: one tile deeper -- the kernel then runs at two workgroups per CU, and what it sustains is set by
   // the bytes it keeps in flight, not by its matrix work: rows of tiles k+2 AND k+3 in two register sets (tile t in set
   // t & 1), ids of tile k+4.
-  constexpr bool kDeep = X6 && (DMP_TY_VAR & 64);          // the deeper row prefetch: measured, no gain (kept as a knob)
+  constexpr bool kDeep = false;                   // the deeper row prefetch (two register sets): measured, no gain
   constexpr int NSET = kDeep ? 2 : 1, kAhead = kDeep ? 3 : 2;
   int id_rows[kSubLoads];       // edge ids of the 4 rows this thread loads (rows gtid/32 + 8m)
   int id_own = -1;              // edge id of row gtid (threads < 32): per-row scalars
@@ -169,14 +166,8 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   int own_staged[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q) own_staged[q] = -1;
-#ifdef DMP_TY_DBG
-  bool warm = false;
-#endif
   auto load_row = [&](auto set, int m) {                    // into register set S
     constexpr int S = decltype(set)::value;
-#ifdef DMP_TY_DBG
-    if ((DMP_TY_DBG & 8) && warm) return;
-#endif
     pre[S][m] = row_load4<BIG>(rs_A, p.A, p.lda, id_rows[m], colA);   // id -1 (padding, past the end): zeros
   };
   auto load_row_scalars = [&](auto set) {
@@ -237,9 +228,6 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   f32x16 acc;
   float4 g0[4], g1[4];
   auto fetch_operand = [&](int par, int k) {               // rows 8k + lrow of the tile
-#ifdef DMP_TY_DBG
-    if (DMP_TY_DBG & 2) { g0[k] = make_float4(0.f, 0.f, 0.f, 0.f); g1[k] = g0[k]; return; }
-#endif
     if (EPI == TEPI_REL) return;
     const int rr = 8 * k + lrow;
     if (EPI == TEPI_EDGE) {
@@ -292,9 +280,6 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
   auto compute = [&](int par) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#ifdef DMP_TY_DBG
-    if (DMP_TY_DBG & 1) { for (int k = 0; k < 4; ++k) fetch_operand(par, k); return; }
-#endif
     const float *arow = &As[0][li * kStride + kHalf * h];
     if (X6) {
       x6_tile(&As[0][0], [&](int i) { if (i < 4) fetch_operand(par, i); });
@@ -344,16 +329,10 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
       float4 an = a4;
       if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
-#ifdef DMP_TY_DBG
-      if (!(DMP_TY_DBG & 1)) {
-#endif
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[X6 ? 0 : 4 * s4 + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[X6 ? 0 : 4 * s4 + 1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[X6 ? 0 : 4 * s4 + 2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[X6 ? 0 : 4 * s4 + 3], acc, 0, 0, 0);
-#ifdef DMP_TY_DBG
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if (kSteps4 == 16) shadow(s4, k, par3, buf, nxt3, nset);
       else { shadow(2 * s4, k, par3, buf, nxt3, nset); shadow(2 * s4 + 1, k, par3, buf, nxt3, nset); }
@@ -380,9 +359,6 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
         v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
         v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
       }
-#ifdef DMP_TY_DBG
-      if ((DMP_TY_DBG & 4) && v.x != 123.456f) continue;
-#endif
       row_store4<BIG>(v, rs_C, p.C, p.ldc, (int)rowC[par][rr], col4);   // padding rows: dropped
       // X6: this chunk's operand registers are free -- request the NEXT tile's rows into them now (its row offsets were
       // staged during this tile's MFMA phase, before the barrier).  With the short bf16 MFMA phase, operands requested at
@@ -438,9 +414,6 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6 && !(DMP_TY_VAR & 32)) 
       c_have = c;
       have_panel = true;
     }
-#ifdef DMP_TY_DBG
-    warm = true;
-#endif
     do {
       if (kPipelined) {
         if (kDeep && (k & 1) == 0) tile_step(k, par3, set1);   // tile k+1 sits in set (k + 1) & 1
@@ -479,7 +452,7 @@ inline int launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st)
   if (g_exact_fp32)
     mfma_typed<EPI, H, false><<<typed_blocks(tiles_bound, H == 128 ? 3 : TypedGeom<64>::kPerCU), TypedGeom<H>::kThreads, 0, st>>>(p);
   else
-    mfma_typed<EPI, H, true><<<typed_blocks(tiles_bound, H == 128 ? ((DMP_TY_VAR & 32) ? 3 : 2) : 4), TypedGeom<H>::kThreads, 0, st>>>(p);
+    mfma_typed<EPI, H, true><<<typed_blocks(tiles_bound, H == 128 ? 2 : 4), TypedGeom<H>::kThreads, 0, st>>>(p);
   return check_launch();
 }
 
