@@ -49,88 +49,101 @@ def map_activation_str_to_layer(act_func, **kw):
     return act
 
 
+# activation name -> the nonlinearity whose gain torch's table holds (utils/init.py:17-50 maps names the same way:
+# the rectifier family shares "relu", the parametrised rectifiers "leaky_relu", the normalising ones "sigmoid")
+_GAIN_OF = dict.fromkeys(("none", "maximum", "minimum"), "linear")
+_GAIN_OF.update(dict.fromkeys(("relu", "relu6", "elu", "selu", "celu", "gelu"), "relu"))
+_GAIN_OF.update(dict.fromkeys(("leaky_relu", "prelu"), "leaky_relu"))
+_GAIN_OF.update(dict.fromkeys(("softmax", "sparsemax", "gumbel_softmax", "sigmoid"), "sigmoid"))
+_GAIN_OF["tanh"] = "tanh"
+
+
 def calculate_gain(activation):
-    # utils/init.py:17-50
-    if isinstance(activation, str):
-        if activation in ["none", "maximum", "minimum"]:
-            nonlinearity = "linear"
-        elif activation in ["relu", "relu6", "elu", "selu", "celu", "gelu"]:
-            nonlinearity = "relu"
-        elif activation in ["leaky_relu", "prelu"]:
-            nonlinearity = "leaky_relu"
-        elif activation in ["softmax", "sparsemax", "gumbel_softmax"]:
-            nonlinearity = "sigmoid"
-        elif activation in ["sigmoid", "tanh"]:
-            nonlinearity = activation
-        else:
-            raise NotImplementedError(activation)
-    else:
+    if not isinstance(activation, str):
         raise ValueError(activation)
-    return nn.init.calculate_gain(nonlinearity, LEAKY_RELU_A)
+    kind = _GAIN_OF.get(activation)
+    if kind is None:
+        raise NotImplementedError(activation)
+    return nn.init.calculate_gain(kind, LEAKY_RELU_A)
 
 
 def _fans(x):
-    # utils/init.py:53-64 (note: "fan_in" is size(1) -- symmetric in the formula below)
+    """(fan_in, fan_out) as utils/init.py:53-64 counts them: size(1) and size(0) times the receptive field."""
     if x.dim() < 2:
         x = x.unsqueeze(-1)
-    rf = 1
-    if x.dim() > 2:
-        rf = x[0][0].numel()
-    return x.size(1) * rf, x.size(0) * rf
+    field = x[0][0].numel() if x.dim() > 2 else 1
+    return x.size(1) * field, x.size(0) * field
+
+
+def _glorot_bound(x, gain):
+    """Xavier / Glorot uniform bound sqrt(3) * std with std = gain * sqrt(2 / (fan_in + fan_out)), evaluated in the reference's
+    order of operations (utils/init.py:71-76) so that seeded draws agree to the bit."""
+    std = gain * math.sqrt(2.0 / float(sum(_fans(x))))
+    return 1.7320508075688772 * std
+
+
+# weight initialisers by name (utils/init.py:67-99,125-143): each takes the tensor and the activation's gain
+_INITS = {
+    "zero": lambda x, gain: nn.init.zeros_(x),
+    "uniform": lambda x, gain: nn.init.uniform_(x, -_glorot_bound(x, gain), _glorot_bound(x, gain)),
+    "normal": lambda x, gain: nn.init.normal_(x, 0, gain / math.sqrt(_fans(x)[0])),
+    "orthogonal": lambda x, gain: nn.init.orthogonal_(x, gain=1.0),      # the reference ignores the gain here
+}
 
 
 def xavier_uniform_init(x, gain=1.0):
-    # utils/init.py:71-76
-    fan_in, fan_out = _fans(x)
-    std = gain * math.sqrt(2.0 / float(fan_in + fan_out))
-    a = 1.7320508075688772 * std
-    return nn.init.uniform_(x, -a, a)
+    return _INITS["uniform"](x, gain)
 
 
 def kaiming_normal_init(x, gain=1.0):
-    fan_in, _ = _fans(x)
-    return nn.init.normal_(x, 0, gain / math.sqrt(fan_in))
+    return _INITS["normal"](x, gain)
 
 
 def zero_init(x, gain=1.0):
-    return nn.init.zeros_(x)
+    return _INITS["zero"](x, gain)
 
 
 def orthogonal_init(x, gain=1.0):
-    return nn.init.orthogonal_(x, gain=1.0)
+    return _INITS["orthogonal"](x, gain)
 
 
-_INITS = {"zero": zero_init, "uniform": xavier_uniform_init, "normal": kaiming_normal_init,
-          "orthogonal": orthogonal_init}
+def _check_init(init):
+    if init not in _INITS:
+        raise ValueError("init=%s is not supported now." % (init))
 
 
 def init_weight(x, activation="none", init="uniform"):
-    # utils/init.py:125-143
-    if init not in _INITS:
-        raise ValueError("init=%s is not supported now." % (init))
+    """utils/init.py:125-143."""
+    _check_init(init)
     if isinstance(x, th.Tensor):
-        _INITS[init](x, gain=calculate_gain(activation))
+        _INITS[init](x, calculate_gain(activation))
+
+
+# embedding tables by init name (utils/init.py:160-178): unit-scale draws, not gain-scaled
+_EMBEDDING_INITS = {
+    "uniform": lambda w: nn.init.uniform_(w, -1.0, 1.0),
+    "normal": lambda w: nn.init.normal_(w, 0.0, 1.0),
+    "orthogonal": lambda w: nn.init.orthogonal_(w, gain=math.sqrt(_fans(w)[0])),
+}
+_WEIGHTED = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)
+_NORMS = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm)
 
 
 def init_module(x, activation="none", init="uniform"):
-    # utils/init.py:146-192 (Linear / norm branches; the only module kinds on this path)
-    if init not in _INITS:
-        raise ValueError("init=%s is not supported now." % (init))
+    """utils/init.py:146-192 for the module kinds on this path: weighted layers (weight by ``init``, zero bias), embeddings
+    (``_EMBEDDING_INITS``, padding row zeroed), normalisation layers (identity affine map)."""
+    _check_init(init)
     gain = calculate_gain(activation)
-    if isinstance(x, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)):
-        _INITS[init](x.weight, gain=gain)
+    if isinstance(x, _WEIGHTED):
+        _INITS[init](x.weight, gain)
         if getattr(x, "bias", None) is not None:
             nn.init.zeros_(x.bias)
     elif isinstance(x, nn.Embedding):
         with th.no_grad():
-            if init == "uniform":
-                nn.init.uniform_(x.weight, -1.0, 1.0)
-            elif init == "normal":
-                nn.init.normal_(x.weight, 0.0, 1.0)
-            elif init == "orthogonal":
-                nn.init.orthogonal_(x.weight, gain=math.sqrt(_fans(x.weight)[0]) * 1.0)
+            if init in _EMBEDDING_INITS:
+                _EMBEDDING_INITS[init](x.weight)
             if x.padding_idx is not None:
                 x.weight[x.padding_idx].fill_(0)
-    elif isinstance(x, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm)):
+    elif isinstance(x, _NORMS):
         nn.init.ones_(x.weight)
         nn.init.zeros_(x.bias)
