@@ -919,6 +919,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # [G, 2H] gradient (forward with rows, flag-split sums) may carry a flagged half: the expanded path below
                 lazy = (des.contiguous(), pool_rowmap(ep), ep)
             else:
+                if ep.flag8 is not None and des.size(1) == H:     # the row-less forward's [G, H]: nothing flows to the flagged rows
+                    des = torch.cat([des, torch.zeros_like(des)], dim=1)
                 exp = (ops.gather_select_raw(des.contiguous(), ep.seg32, ep.flag8, H, None, 1.0, 1.0) if ep.flag8 is not None
                        else ops.gather_rows_raw(des.contiguous(), ep.seg32))
                 dzn = exp if dzn is None else dzn + exp

@@ -1076,6 +1076,40 @@ def _gen_train_run(out_name, extra=""):
     d["dev_MAE"], d["dev_MSE"] = dev_res["error"]["MAE"], dev_res["error"]["MSE"]
     for k, v in model.state_dict().items():
         d["sd1." + k] = v.clone()
+    # ---- the SAME run from initial parameters moved by one / eight units in the last place (every float parameter times
+    # 1 +- 2^-23 / 2^-20, alternating signs): how far the reference's own trajectory moves under a perturbation of the size of an fp32
+    # rounding -- the yardstick for a re-associated implementation's per-step deviations
+    sd0 = {k[4:]: v for k, v in d.items() if k.startswith("sd0.")}
+    for tag2, eps in (("twin", 2.0 ** -23), ("twin8", 2.0 ** -20)):       # one unit in the last place; eight of them (~1e-6)
+        random.seed(random_seed); th.manual_seed(random_seed); np.random.seed(random_seed)
+        twin = ref_train.build_model(ref_train.process_model_config(config), init_neigenv=max_neigenv, init_eeigenv=max_eeigenv)
+        with th.no_grad():
+            moved = {}
+            for k, v in sd0.items():
+                if v.is_floating_point():
+                    sign = th.where(th.arange(v.numel()).view(v.shape) % 2 == 0, 1.0, -1.0)
+                    moved[k] = v * (1.0 + sign * eps)
+                else:
+                    moved[k] = v.clone()
+        twin.load_state_dict(moved)
+        opt2 = th.optim.AdamW(twin.parameters(), lr=config["lr"], weight_decay=config["weight_decay"], amsgrad=True)
+        opt2.zero_grad()
+        sched2 = map_scheduler_str_to_scheduler(config["scheduler"], num_warmup_steps=num_warmup_steps,
+                                                num_schedule_steps=num_schedule_steps, num_cycles=num_cycles, min_percent=min_percent)
+        sched2.set_optimizer(opt2)
+        log2 = _ScalarLog()
+        twin_dev = []
+        for epoch in range(epochs):
+            batches = [orders[epoch][i:i + bsz].tolist() for i in range(0, n_train, bsz)]
+            ref_train.train_epoch(twin, opt2, sched2, "train", _FixedLoader(sets["train"], batches, config["match_weights"]),
+                                  device, config, epoch, None, log2)
+            dev_ev2, _ = ref_train.evaluate_epoch(twin, "dev", _FixedLoader(sets["dev"], dev_batches, config["match_weights"]),
+                                                  device, config, epoch, None, None)
+            twin_dev.append(dev_ev2)
+        d[tag2 + ".hist.dev_eval"] = np.array(twin_dev, np.float64)
+        for tag, rows in log2.rows.items():
+            if tag.startswith("train/"):
+                d[tag2 + ".step." + tag[6:]] = np.array([v for _, v in sorted(rows)], np.float64)
     for split in ("train", "dev"):
         for i, r in enumerate(raws[split]):
             for k, v in r.items():

@@ -63,4 +63,4 @@ def test_layer_with_batch_norm_matches_the_reference(path, gpu):
             _close(p.grad, d["g." + k], 2e-4, "grad " + k)
     for k, b in layer.named_buffers():
         _close(b.float() if b.dtype != th.float32 else b, d["b1." + k].astype(np.float64) if d["b1." + k].dtype.kind == "i" else d["b1." + k],
-               1e-6, "buffer " + k)
+               1e-5, "buffer " + k)         # batch variance over 10^2..10^4 rows in another summation order

@@ -165,6 +165,17 @@ def test_training_run_at_shipped_settings_matches_reference(fixture, gpu, tmp_pa
     print("per-step relative deviation of the training loss:", np.round(rel, 5).tolist())
     assert rel[:3].max() <= 2e-3, rel.tolist()                       # before anything can have been amplified
     assert rel.max() <= 6e-2, rel.tolist()
+    # How sensitive is the run itself?  The fixture holds the reference's OWN trajectory from initial parameters moved by
+    # one and by eight units in the last place (oracle/make_golden.py: "twin", "twin8"): its per-step losses move by up to
+    # 0.5 % (DMPNN; the CompGCN run does not amplify: < 1e-5) -- a perturbation of 1e-7 .. 1e-6 grows 5 x 10^4-fold within
+    # 15 steps.  A re-associated implementation perturbs every activation by ~1e-6, not just the initial parameters, so
+    # its deviations are held to within an order of magnitude of the twins' (and to the 6 % above).
+    twin = max(float(np.max(np.abs(d[t + ".step.train-%s" % config["bp_loss"]] - ref_loss) / ref_loss)) for t in ("twin", "twin8"))
+    if config["rep_net"] == "DMPNN":
+        assert 1e-3 <= twin <= 2e-2, twin                            # the reference amplifies rounding-size perturbations
+        assert rel.max() <= 15.0 * twin, (rel.max(), twin)
+    else:
+        assert twin <= 1e-4 and rel.max() <= 1e-3, (twin, rel.tolist())   # no amplification: the run is held to 1e-3 per step
     assert np.allclose(step_eval, ref_eval, rtol=8e-2, atol=0.3), (step_eval.tolist(), ref_eval.tolist())
     assert np.allclose(hist["train_bp"], d["hist.train_bp"], rtol=5e-2), (hist["train_bp"], d["hist.train_bp"].tolist())
     # the dev error right after the loss spike of epoch 1 is the most sensitive number of the run; the end point is not
