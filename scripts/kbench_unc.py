@@ -10,7 +10,7 @@ from dualmessagepassing_amd.tuning import enable_tuned_gemms
 enable_tuned_gemms()
 gpu = th.device("cuda:0")
 rng = np.random.default_rng(5)
-n, m, h = 2708, 5429, 256
+n, m, h = 2708, 5429, int(os.environ.get("UNC_HID", "256"))    # 256: BASELINE configs[4]; 50: the width the reference ships (main.py:244, run.sh:8)
 pick = rng.choice(n * (n - 1), size=m, replace=False)
 u = pick // (n - 1); r = pick % (n - 1); v = r + (r >= u)
 trip = np.stack([u, np.zeros(m, np.int64), v], 1)
@@ -52,7 +52,7 @@ def step():
     return loss
 
 
-print("UNC DMPNN hid=256, 2 layers, N=%d, E=%d: forward %.3f ms, train step (fwd+bwd+Adam) %.3f ms" % (n, 2 * m, timeit(fwd), timeit(step)))
+print("UNC DMPNN hid=%d, 2 layers, N=%d, E=%d: forward %.3f ms, train step (fwd+bwd+Adam) %.3f ms" % (h, n, 2 * m, timeit(fwd), timeit(step)))
 
 # the same step replayed from ONE HIP graph (dp.StepGraph): the optimizer keeps its step count and rate on the device
 from dualmessagepassing_amd.dp import StepGraph
