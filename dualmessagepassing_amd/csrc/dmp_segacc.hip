@@ -13,9 +13,9 @@
 // acc[node][half][64c + l] for all 64 nodes and both halves in 128 VGPRs (v64..v191, pinned).  A row arrives as one dword
 // per lane (a 256-byte piece of the row per wave-instruction; the waves of the workgroup together read whole rows; 32
 // rows in flight per wave), its two endpoints reach the scalar unit by v_readlane, and the two adds are
-//     s_set_gpr_idx_idx a_e ; v_add_f32 v[64 + a_e], v[64 + a_e], x        (VGPR index mode: SRC0 and DST relative)
-//     s_set_gpr_idx_idx b_e ; v_add_f32 v[128 + b_e], v[128 + b_e], x
-// -- no LDS, no atomics, no barrier, two vector instructions per row.  Every accumulator receives its addends in
+//     t = v[64 + a_e] ; t += x ; v[64 + a_e] = t          (VGPR index mode: v_mov with a relative source / destination)
+//     u = v[128 + b_e]; u += x ; v[128 + b_e] = u
+// -- no LDS, no atomics, no barrier, six vector instructions per row.  Every accumulator receives its addends in
 // ascending eid: one fixed summation order, run-to-run bit-stable, and the bits of dmp_seg_sum2 over
 // dmp_incidence_build's CSR (rows merged by eid).  Rows whose endpoint lies outside the tile (never in a block-diagonal
 // batch) add into a trash register.
@@ -41,29 +41,31 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, kb; };
 
-// four rows: x_t into v[64 + i_t] and into v[128 + j_t]
+// One row: x into v[64 + i] and into v[128 + j], each as  read (v_mov, SRC0 relative) -> v_add -> write (v_mov, DST
+// relative) -- the form the compiler itself gives an indexed register update.  Two findings are built into this block
+// (scripts/stress_segacc.py reproduces both):
+//  * `v_add_f32 v[64 + i], v[64 + i], x` with SRC0 and DST relative in ONE instruction (index mode 0x9) computes the right
+//    sums but corrupts OTHER waves on the CU: a GEMM running beside it on a second stream returned wrong values in 12 % of
+//    the launches, two processes sharing the GPU died with memory faults -- while every single-stream test passed (inside
+//    one stream a kernel never shares a CU with another kernel).  With one relative operand per v_mov: 0 of 2000.
+//  * s_set_gpr_idx_* write M0, which the compiler does not know about: saved and put back around the block.
+#define DMP_ROW(X, I, J)                                                                                               \
+      "s_set_gpr_idx_on " I ", 0x1\n\tv_mov_b32 %[t], v64\n\ts_set_gpr_idx_idx " J "\n\tv_mov_b32 %[u], v128\n\t"       \
+      "s_set_gpr_idx_off\n\tv_add_f32 %[t], %[t], " X "\n\tv_add_f32 %[u], %[u], " X "\n\t"                             \
+      "s_set_gpr_idx_on " I ", 0x8\n\tv_mov_b32 v64, %[t]\n\ts_set_gpr_idx_idx " J "\n\tv_mov_b32 v128, %[u]\n\t"       \
+      "s_set_gpr_idx_off\n\t"
+// four rows, in order (consecutive rows may meet in a register)
 #define DMP_ACC4(X0, X1, X2, X3, I0, I1, I2, I3, J0, J1, J2, J3)                                                       \
   asm volatile(                                                                                                        \
-      "s_set_gpr_idx_on %[i0], 0x9\n\t"                                                                                \
-      "v_add_f32 v64, v64, %[x0]\n\t"                                                                                  \
-      "s_set_gpr_idx_idx %[j0]\n\t"                                                                                    \
-      "v_add_f32 v128, v128, %[x0]\n\t"                                                                                \
-      "s_set_gpr_idx_idx %[i1]\n\t"                                                                                    \
-      "v_add_f32 v64, v64, %[x1]\n\t"                                                                                  \
-      "s_set_gpr_idx_idx %[j1]\n\t"                                                                                    \
-      "v_add_f32 v128, v128, %[x1]\n\t"                                                                                \
-      "s_set_gpr_idx_idx %[i2]\n\t"                                                                                    \
-      "v_add_f32 v64, v64, %[x2]\n\t"                                                                                  \
-      "s_set_gpr_idx_idx %[j2]\n\t"                                                                                    \
-      "v_add_f32 v128, v128, %[x2]\n\t"                                                                                \
-      "s_set_gpr_idx_idx %[i3]\n\t"                                                                                    \
-      "v_add_f32 v64, v64, %[x3]\n\t"                                                                                  \
-      "s_set_gpr_idx_idx %[j3]\n\t"                                                                                    \
-      "v_add_f32 v128, v128, %[x3]\n\t"                                                                                \
-      "s_set_gpr_idx_off"                                                                                              \
-      : "+{v[64:95]}"(A0), "+{v[96:127]}"(A1), "+{v[128:159]}"(B0), "+{v[160:191]}"(B1), "+{v192}"(trash)             \
+      "s_mov_b32 %[m0s], m0\n\t"                                                                                       \
+      DMP_ROW("%[x0]", "%[i0]", "%[j0]") DMP_ROW("%[x1]", "%[i1]", "%[j1]")                                            \
+      DMP_ROW("%[x2]", "%[i2]", "%[j2]") DMP_ROW("%[x3]", "%[i3]", "%[j3]")                                            \
+      "s_mov_b32 m0, %[m0s]"                                                                                           \
+      : "+{v[64:95]}"(A0), "+{v[96:127]}"(A1), "+{v[128:159]}"(B0), "+{v[160:191]}"(B1), "+{v192}"(trash),            \
+        [m0s] "=&s"(m0_saved), [t] "=&v"(tmp_t), [u] "=&v"(tmp_u)                                                      \
       : [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [i0] "s"(I0), [i1] "s"(I1), [i2] "s"(I2),              \
-        [i3] "s"(I3), [j0] "s"(J0), [j1] "s"(J1), [j2] "s"(J2), [j3] "s"(J3))
+        [i3] "s"(I3), [j0] "s"(J0), [j1] "s"(J1), [j2] "s"(J2), [j3] "s"(J3)                                          \
+      : "memory")
 
 // H: row width (64 or 128) = 64 columns per wave, H / 64 waves per workgroup, one workgroup per tile.
 template <int H>
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
   const rsrc_t rsA = make_rsrc(selA + e0, (uint32_t)R * 4u), rsB = make_rsrc(selB + e0, (uint32_t)R * 4u);
   const uint32_t voff = (uint32_t)(64 * c + lane) * 4u;
   const uint32_t rowb = (uint32_t)(ldm * 4);
-  auto load_row = [&](int r) -> float {                         // row r of the tile, this wave's columns
+  auto load_row = [&](int r) -> float {                         // row r of the tile, this wave's columns (scalar row offset)
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, (int)voff, (int)((uint32_t)r * rowb), 0));
   };
   auto load_sel = [&](int sg, int &a, int &b) {                 // endpoints of row kRing sg + lane
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
 
   const int nsg = (R + kRing - 1) / kRing;                      // super-groups of kRing rows (one endpoint dword per lane < kRing)
   float v[kRing];
-  int na, nb;
+  int na, nb, m0_saved;
+  float tmp_t, tmp_u;
   load_sel(0, na, nb);
   asm volatile("" ::: "memory");     // keep the endpoint loads OLDER than the ring (the waits count younger operations)
 #pragma unroll
@@ -114,21 +117,24 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
     // register v192 = index 128 / 64 for rows past the end and endpoints outside the tile
     const bool in = lane < kRing && sg * kRing + lane < R;
     const uint32_t ua = (uint32_t)(na - (int32_t)n0), ub = (uint32_t)(nb - (int32_t)n0);
-    const int pa = (in && ua < (uint32_t)nodes) ? (int)ua : 128;
-    const int pb = (in && ub < (uint32_t)nodes) ? (int)ub : 64;
+    int pa = (in && ua < (uint32_t)nodes) ? (int)ua : 128;
+    int pb = (in && ub < (uint32_t)nodes) ? (int)ub : 64;
 #pragma unroll
     for (int g = 0; g < kRing; g += 4) {
-      // the next super-group's endpoints: requested with half a ring of row loads behind them, so that the wait for
-      // them at the top of the next iteration leaves the ring in flight
-      if (g == (kRing / 8) * 4) load_sel(sg + 1, na, nb);       // past the last super-group: zeros, never used
-      const float x0 = v[g], x1 = v[g + 1], x2 = v[g + 2], x3 = v[g + 3];
-      const int r = (sg + 1) * kRing + g;                       // kRing rows ahead
-      v[g] = load_row(r); v[g + 1] = load_row(r + 1); v[g + 2] = load_row(r + 2); v[g + 3] = load_row(r + 3);
+      // the next super-group's endpoints: requested ahead of this iteration's row loads, so that the wait for them at
+      // the top of the next iteration (all but the 32 youngest operations) leaves the ring in flight
+      if (g == 0) load_sel(sg + 1, na, nb);                     // past the last super-group: zeros, never used
+      asm volatile("" : "+v"(pa), "+v"(pb));                    // the block's eight v_readlane stay HERE (hoisted to the loop
+                                                                // top, the 64 results of a ring held 64 SGPRs live)
       const int i0 = __builtin_amdgcn_readlane(pa, g), i1 = __builtin_amdgcn_readlane(pa, g + 1);
       const int i2 = __builtin_amdgcn_readlane(pa, g + 2), i3 = __builtin_amdgcn_readlane(pa, g + 3);
       const int j0 = __builtin_amdgcn_readlane(pb, g), j1 = __builtin_amdgcn_readlane(pb, g + 1);
       const int j2 = __builtin_amdgcn_readlane(pb, g + 2), j3 = __builtin_amdgcn_readlane(pb, g + 3);
-      DMP_ACC4(x0, x1, x2, x3, i0, i1, i2, i3, j0, j1, j2, j3);
+      DMP_ACC4(v[g], v[g + 1], v[g + 2], v[g + 3], i0, i1, i2, i3, j0, j1, j2, j3);
+      // ... and the same four ring slots take the rows kRing ahead: AFTER the adds (the block is a memory barrier to the
+      // compiler), so the loads land in the registers the adds have just read -- no second register set, no copies
+      const int r = (sg + 1) * kRing + g;
+      v[g] = load_row(r); v[g + 1] = load_row(r + 1); v[g + 2] = load_row(r + 2); v[g + 3] = load_row(r + 3);
     }
   }
   // the sums: 256 contiguous bytes per store instruction (this wave's columns of one node row and half)

@@ -1134,3 +1134,42 @@ def test_one_pass_endpoint_sums_at_config_2_size(gpu):
     sel_a, sel_b = ix.endpoint_select()
     assert th.equal(ones[:, 0], th.bincount(sel_a.long(), minlength=N).float())
     assert th.equal(ones[:, h], -th.bincount(sel_b.long(), minlength=N).float())
+
+
+def test_one_pass_endpoint_sums_beside_other_kernels(gpu):
+    """dmp_seg_sum2_graphs keeps its sums in registers addressed through the VGPR index mode.  Inside one stream a kernel never
+    shares a CU with another kernel -- two streams (and two processes on one GPU) do: a first form of the kernel (one v_add_f32
+    with a relative source AND destination) gave the right sums and corrupted the waves of a GEMM running beside it in 12 % of
+    the launches (scripts/stress_segacc.py).  Here: the kernel on one stream, a GEMM / a row copy / the incidence segment sum on
+    another, every result against its stand-alone value."""
+    from dualmessagepassing_amd import ops
+    from dualmessagepassing_amd.collate import union_graphs
+    rng = np.random.default_rng(12)
+    u = union_graphs(_graph_batch([(8, 12)] * 512, rng, gpu), _graph_batch([(64, 256)] * 512, rng, gpu))
+    ix = u.index()
+    N, E, h = u.number_of_nodes(), u.number_of_edges(), 128
+    m = th.randn(E, h, device=gpu)
+    assert ops.graph_seg_ok(ix, m, h)
+    inc = ix.incidence()
+    want = ops.seg_sum_raw(m, inc[0], inc[1], N, None, True, 1.0, -1.0, rows_shared=2)
+    a, b = th.randn(4096, 512, device=gpu), th.randn(512, 512, device=gpu)
+    x = th.randn(E, h, device=gpu)
+    want_mm, want_copy = a @ b, x.clone()
+    sa, sb = th.cuda.Stream(), th.cuda.Stream()
+    th.cuda.synchronize()
+    bad = {"sums": 0, "gemm": 0, "copy": 0, "incidence": 0}
+    for _ in range(200):
+        with th.cuda.stream(sa):
+            g1 = ops.endpoint_sums(m, ix)
+            g2 = ops.endpoint_sums(m, ix)
+        with th.cuda.stream(sb):
+            mm = a @ b
+            cp = x.clone()
+            si = ops.seg_sum_raw(m, inc[0], inc[1], N, None, True, 1.0, -1.0, rows_shared=2)
+            mm2 = a @ b
+        th.cuda.synchronize()
+        bad["sums"] += int(not th.equal(g1, want)) + int(not th.equal(g2, want))
+        bad["gemm"] += int(not th.equal(mm, want_mm)) + int(not th.equal(mm2, want_mm))
+        bad["copy"] += int(not th.equal(cp, want_copy))
+        bad["incidence"] += int(not th.equal(si, want))
+    assert not any(bad.values()), bad
