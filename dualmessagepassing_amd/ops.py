@@ -247,23 +247,31 @@ class _GatherRows(torch.autograd.Function):
         return seg_sum_raw(dO, ix.in_ptr, ix.in_ent, ix.num_nodes), None, None
 
 
+_IMMUTABLE = {}     # storage address -> a tensor of that storage (kept alive: the address stays unique)
+
+
 def mark_immutable(*tensors):
     """Declare index tensors (node ids, relation types, triplets of a FIXED graph) as never refilled in place.  The index
     structures derived from such a tensor (``take_rows``'s CSR, ``PoolIndex.from_keys``) are memoised on the tensor's identity
     and version; while a step is being RECORDED (``dp.StepGraph``) a memo hit leaves the index build out of the recording,
     which is only right if the tensor's contents cannot change between replays -- a replay runs no Python, so an in-place
     refill of a closed-over buffer would go unnoticed.  Inside a recording the memos are therefore consulted for marked
-    tensors only; everything else is rebuilt (and recorded).  Returns its argument(s)."""
+    tensors only; everything else is rebuilt (and recorded).  The mark is on the STORAGE: views of a marked tensor
+    (``ids.squeeze()``) are marked too.  Returns its argument(s)."""
     for t in tensors:
         if t is not None:
-            t._dmp_immutable = True
+            _IMMUTABLE[t.untyped_storage().data_ptr()] = t
     return tensors[0] if len(tensors) == 1 else tensors
+
+
+def is_immutable(t):
+    return t.untyped_storage().data_ptr() in _IMMUTABLE
 
 
 def _memo_usable(key_tensor):
     """A memo entry keyed on ``key_tensor`` may be used: always outside a stream capture, inside one only for tensors the
     caller has marked immutable."""
-    return not (key_tensor.is_cuda and torch.cuda.is_current_stream_capturing()) or getattr(key_tensor, "_dmp_immutable", False)
+    return not (key_tensor.is_cuda and torch.cuda.is_current_stream_capturing()) or is_immutable(key_tensor)
 
 
 class _TakeRows(torch.autograd.Function):

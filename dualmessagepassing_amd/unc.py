@@ -285,6 +285,8 @@ class TrainModel(nn.Module):
                     if cached is None or cached[0] != ck:
                         cached = self._etype_cache = (ck, (edge_type < num_rels).to(emb.dtype).unsqueeze(1),
                                                       edge_type.clamp(max=num_rels - 1), edge_type)
+                        if ops.is_immutable(edge_type):       # what is derived from a fixed tensor is fixed
+                            ops.mark_immutable(cached[1], cached[2])
                     mask, clamped = cached[1], cached[2]
                     emb_diff = self.edge_fc(emb) - ops.take_rows_small_table(self.w_relation, clamped)
                     reg = reg + (torch.pow(emb_diff, 2) * mask).sum() / (mask.sum() * emb_diff.size(1))
