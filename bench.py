@@ -316,7 +316,7 @@ def build_step(cfg, shard, device, world=1):
 
 PROFILE_ROUND = "r04"
 SEG_IN = "seg_sum_vec<32, true, false, true, 0, 256>"       # flag-split segment sum over the CSR by destination (forward)
-SEG_INC = "seg_acc_graphs_k<128, "                           # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
+SEG_INC = "seg_acc_graphs_k<128>"                            # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
 
 
 def committed_profile(n_rows, n_edges, H):
