@@ -265,7 +265,7 @@ def build_step(cfg, shard, device, world=1):
         # The batch's structure work (collate above; CSR, incidence, degree classes, selectors here) does not depend on
         # the parameters: it is enqueued BEFORE the previous step's gradient sum is waited for, so with more than one
         # rank the all-reduce (on RCCL's stream) overlaps it instead of idling the compute stream.
-        if world > 1:
+        if world > 1 and not model.gate_capacity:
             prepare_joint(pattern, graph, cfg["hid"])
         finish()
         sync.detach_grads()
@@ -304,6 +304,24 @@ def build_step(cfg, shard, device, world=1):
         timed_wait(sync.sync)
         opt.step()
 
+    def gate_compact(on):
+        """The rep-net on the target edges the filter gate keeps (basemodel.set_gate_capacity), or back on every edge row:
+        capacity from this rank's own shard with a margin -- the batch shapes stay fixed, so the step still replays.
+        -> {"capacity", "kept", "edges"} or None."""
+        step.gate_capacity = None
+        if not on or M != 1:
+            model.set_gate_capacity(None)
+            return None
+        pattern, graph = batch_of(shard)
+        cap = model.calibrate_gate_capacity(pattern, graph)
+        del pattern, graph
+        if not cap:
+            return None
+        step.gate_capacity = cap
+        return {"capacity": cap, "edges": shard["g"]["E"]}
+
+    step.set_gate_compact = gate_compact
+    gate_compact(cfg.get("gate_compact"))
     step.time_allreduce = False
     step.ar_events = ar_events
     step.finish = finish
@@ -357,6 +375,30 @@ def committed_profile(n_rows, n_edges, H):
                     out[tag]["traffic"] = int(v["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
+    return out
+
+
+def gate_summary(g, cfg, step, H):
+    """The secondary `gate_compact` object of the line: the step with the rep-net on the kept target edges (+ padding)."""
+    mb = cfg["batch"] // step.micro_batches
+    uN = mb * (cfg["p_nodes"] + cfg["g_nodes"])
+    uE = mb * 2 * cfg["p_edges"] + g["capacity"]
+    out = {"what": "same step, same launch mode, model.set_gate_capacity(capacity): the rep-net runs on the target edges the "
+                   "ScalarFilter gate keeps plus inert padding up to `capacity` (a gate-0 edge is a zero row through every "
+                   "layer of the reference, basemodel.py:1515-1531); outputs and gradients equal, g_e_rep gets its zero rows "
+                   "back on first read; the kept share depends on the labels (here %d pattern / %d target labels, uniform)"
+                   % (cfg["p_labels"], cfg["g_labels"]),
+           "ms_per_step": g["ms_per_step"], "value": g["value"], "unit": "pairs/s", "capacity": g["capacity"],
+           "target_edge_rows": g["edges"], "capacity_fraction": round(g["capacity"] / g["edges"], 4)}
+    none = {"avg_us_rocprof": None, "traffic": None}
+    k = g["kern"].get("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE))
+    if k:
+        out["roofline"] = seg_roofline(k, "dmp::seg_sum_vec<32,split,remap> at N=%d rows, E=%d edge rows" % (uN, uE), k["bytes"],
+                                       4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), none)
+    k = g["kern"].get("seg_sum2_graphs[H=%d,rows=%d,E=%d]" % (H, uN, uE))
+    if k:
+        out["roofline_bwd"] = seg_roofline(k, "dmp::seg_acc_graphs_k at N=%d rows, E=%d edge rows" % (uN, uE), k["bytes"],
+                                           4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), none)
     return out
 
 
@@ -612,6 +654,10 @@ def main():
                     "one pass below 2^30: 1 for config 2 and for config 4's 1024-pair shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
+    ap.add_argument("--no-gate-compact", action="store_true", help="skip the extra un-timed steps behind the gate_compact object")
+    ap.add_argument("--gate-compact", action="store_true",
+                    help="run the rep-net on the target edges the filter gate keeps (model.set_gate_capacity; capacity "
+                         "calibrated on the shard): same outputs, a data-dependent share of the edge rows")
     ap.add_argument("--graph", action="store_true",
                     help="record the whole step (collate, index builds, fwd, bwd, gradient pack, AdamW) as ONE HIP graph during "
                          "the warm-up and replay it in the timed region (N = 1, one micro-batch; the per-kernel HIP-event "
@@ -700,7 +746,7 @@ def main():
     if auto_graph:
         args.graph = True
     cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
-               hid=args.hid, graph=args.graph)
+               hid=args.hid, graph=args.graph, gate_compact=args.gate_compact)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -733,7 +779,8 @@ def main():
         # of the batch on the device exactly as an eager step does
         from dualmessagepassing_amd.dp import StepGraph
         # (a leading non-tensor argument is part of a recording's signature: ``run("all")`` is the all-outputs step)
-        run = StepGraph(lambda *m: step(all_outputs=bool(m)), optimizer=step.opt, max_shapes=2)
+        # (``run("gate")``: the step with the gate capacity set -- the model's state at recording time is part of it)
+        run = StepGraph(lambda *m: step(all_outputs="all" in m), optimizer=step.opt, max_shapes=3)
         graphed = True
     elif args.graph and world > 1 and step.micro_batches == 1:
         # more than one rank: forward + backward + gradient pack replayed from one HIP graph per rank, the gradient
@@ -850,6 +897,45 @@ def main():
         step.finish()
         barrier()
         all_ms = (time.perf_counter() - ta) / max(args.steps, 1) * 1e3
+    gate_line = None
+    if world == 1 and step.micro_batches == 1 and not args.gate_compact and not args.no_gate_compact:
+        # the same step with the rep-net on the target edges the filter gate keeps (model.set_gate_capacity): same outputs
+        # (tests/test_gpu_compact.py, test_gpu_bench_composite.py), a share of the edge rows that depends on the labels --
+        # same launch mode as the timed region, reported beside the headline, never as `value`
+        info = step.set_gate_compact(True)
+        if info is not None:
+            _lib.timer.enabled = False
+            run_c = (lambda: run("gate")) if graphed else step
+            for _ in range(3):                                 # graphed: eager, record + replay, replay
+                run_c()
+            step.finish()
+            barrier()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                run_c()
+            step.finish()
+            barrier()
+            g_ms = (time.perf_counter() - tg) / max(args.steps, 1) * 1e3
+            # the two scatter-add launches at this row count: HIP events, eager launches
+            _lib.timer.reset()
+            _lib.timer.only = "seg_sum2"
+            _lib.timer.enabled = True
+            for _ in range(3):
+                step()
+            step.finish()
+            barrier()
+            _lib.timer.reset()
+            for _ in range(args.steps):
+                step()
+            step.finish()
+            barrier()
+            kern_c = _lib.timer.summary()
+            _lib.timer.enabled = False
+            bits = model.compaction_status()
+            if bits:
+                raise SystemExit("bench.py: gate compaction status %d (a batch did not fit its capacity)" % bits)
+            gate_line = dict(info, ms_per_step=round(g_ms, 3), value=round(cfg["batch"] / g_ms * 1e3, 1), kern=kern_c)
+        step.set_gate_compact(False)
     _lib.timer.reset()
     _lib.timer.only = None
     _lib.timer.enabled = True
@@ -884,6 +970,8 @@ def main():
         mb = cfg["batch"] // step.micro_batches               # pairs per pass
         uN = mb * (cfg["p_nodes"] + cfg["g_nodes"])
         uE = mb * 2 * (cfg["p_edges"] + cfg["g_edges"])
+        if step.gate_capacity:                                # the rep-net ran on the kept target edges + padding
+            uE = mb * 2 * cfg["p_edges"] + step.gate_capacity
         key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
         key_inc = "seg_sum2_graphs[H=%d,rows=%d,E=%d]" % (H, uN, uE)      # one pass over the edge rows (csrc/dmp_segacc.hip) ...
         if key_inc not in kern:
@@ -943,6 +1031,7 @@ def main():
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2)},
             "roofline": roof,
             "roofline_bwd": roof_bwd,
+            "gate_compact": gate_summary(gate_line, cfg, step, H) if gate_line else None,
             # the compulsory traffic of the sparse kernels alone (seg-sum / gather-combine, forward + backward,
             # pattern + target, all layers) over the END-TO-END step time -- how far the whole step is from a sparse-only
             # HBM roofline (the step also runs 460 GFLOP of dense fp32 products, which bound it)

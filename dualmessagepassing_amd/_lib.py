@@ -55,6 +55,11 @@ SIGNATURES = {
     "dmp_seg_sum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr]),
     "dmp_seg_sum2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64,
                              c_int, c_ptr]),
+    "dmp_small_gemm_jobs": (c_int, [c_ptr, c_int, c_ptr]),
+    "dmp_gate_compact_hist_nodes": (c_int, []),
+    "dmp_gate_compact": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_out_degrees": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "dmp_seg_sum2_graphs_max_nodes": (c_int, []),
     "dmp_seg_sum2_graphs": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                     c_ptr, c_i64, c_ptr]),
@@ -106,6 +111,8 @@ SIGNATURES = {
                                     c_double, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step_dev": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                    c_ptr, c_ptr, c_int, c_ptr]),
+    "dmp_adamw_step_guarded": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
+                                       c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
@@ -160,7 +167,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 50
+ABI_VERSION = 52
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

@@ -323,6 +323,15 @@ def _padder(graph, kind):
     return _memo(("pad", _tensor_key(sizes)), lambda: _Keep(_Padder(graph, kind), sizes)).obj
 
 
+def _expanded(comp, rows_c):
+    """The target's [E, H] edge rows from the compacted batch's (``collate.CompactedEdges.expand``); rows that have not
+    been formed (``embed.DeferredRows``) stay unformed until somebody reads them."""
+    from .embed import DeferredRows
+    if isinstance(rows_c, DeferredRows):
+        return DeferredRows(lambda: comp.expand(rows_c.materialize()), (comp.num_edges, rows_c.size(1)), rows_c.dtype, rows_c.device)
+    return comp.expand(rows_c)
+
+
 class BaseModel(nn.Module):
     """basemodel.py:15-160."""
 
@@ -655,6 +664,67 @@ class GraphAdjModelV2(BaseModel):
             rep_e_dim += 2
         return rep_v_dim, rep_e_dim
 
+    # ---- gate compaction (collate.compact_gated_edges): the rep-net on the edges the filter gate keeps
+    gate_capacity = None        # edge rows of the compacted target batch; None: the rep-net runs on every edge
+
+    def set_gate_capacity(self, capacity):
+        """Run the rep-net on the target edges the filter gate keeps, as a batch of ``capacity`` edge rows (kept edges +
+        inert padding; ``None`` / 0 turns it off).  A gate-0 edge is a zero row through the reference's whole rep-net
+        (basemodel.py:1515-1531, dmpnn.py:262-275), so every output is what it was -- ``g_e_rep`` gets its zero rows back on
+        first read.  A batch that keeps MORE than ``capacity`` edges cannot be represented: bit 0 of the status word goes up
+        (``compaction_status()``; ``compaction_word`` for ``dp.FlatAdamW.set_veto``, which then drops that step) and the
+        caller runs such a batch with the capacity off; ``calibrate_gate_capacity`` picks a capacity from a batch."""
+        self.gate_capacity = int(capacity) if capacity else None
+        if self.gate_capacity and getattr(self, "_compact_status", None) is None:
+            # [0] flags since the last guarded optimizer step, [1] flags it has collected, [2] last step dropped, [3] steps dropped
+            self._compact_status = th.zeros(4, dtype=th.int32, device=next(self.parameters()).device)
+        return self
+
+    @property
+    def compaction_word(self):
+        return getattr(self, "_compact_status", None)
+
+    def compaction_status(self, clear=True):
+        """Flags raised by the forward passes since the last clear (one host sync): 1 = a batch kept more edges than
+        ``gate_capacity`` (its outputs and gradients were wrong; a ``FlatAdamW`` with ``set_veto(model.compaction_word)``
+        dropped that step), 2 = padding fell on a graph without nodes.  ``compaction_dropped_steps()`` counts the drops."""
+        st = getattr(self, "_compact_status", None)
+        if st is None:
+            return 0
+        host = st.tolist()
+        bits = host[0] | host[1]
+        if clear and bits:
+            st[:2].zero_()
+        return bits
+
+    def compaction_dropped_steps(self):
+        st = getattr(self, "_compact_status", None)
+        return 0 if st is None else int(st[3].item())
+
+    def calibrate_gate_capacity(self, pattern, graph, margin=1.15, multiple=1024):
+        """``set_gate_capacity`` from one batch: the edges its gate keeps (one host sync), times ``margin``, rounded up to a
+        multiple of ``multiple``; left off where that would not shrink the batch by a tenth.  Returns the capacity or None."""
+        pattern, graph = as_batched(pattern), as_batched(graph)
+        pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"), "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
+        el_gate = self.get_filter_gate(pattern, graph, pads)[1]
+        if el_gate is None:
+            return self.set_gate_capacity(None).gate_capacity
+        kept, E = int((el_gate != 0).sum().item()), graph.number_of_edges()
+        cap = -(-int(kept * margin + graph.batch_size) // multiple) * multiple
+        return self.set_gate_capacity(cap if cap <= 0.9 * E else None).gate_capacity
+
+    def _compact_gated(self, pattern, graph, el_gate):
+        """``collate.CompactedEdges`` for this batch, or None (capacity off, no gate, options that read per-edge extras)."""
+        if not self.gate_capacity or el_gate is None or not hasattr(self, "get_joint_rep") or self.pred_with_enc or self.pred_with_deg:
+            return None
+        if el_gate.requires_grad or self.add_edge_id or not graph.is_batched_on_device():
+            return None
+        from .collate import compact_gated_edges, out_degrees
+        comp = compact_gated_edges(graph, el_gate, self.gate_capacity, self._compact_status[:1])
+        if comp is not None:
+            out_degrees(pattern)                   # the union graph then carries both sides' degrees: none is derived from the kept edges
+        return comp
+
     # ---- forward pieces (basemodel.py:1394-1498)
     def get_filter_gate(self, pattern, graph, pads):
         if self.filter_net is None or len(self.filter_net) == 0:
@@ -805,18 +875,35 @@ class GraphAdjModelV2(BaseModel):
         g_v_emb, g_e_emb = self.get_graph_emb_deferred(g_enc) if hasattr(self, "get_joint_rep") else self.get_graph_emb(g_enc)
         joint = None
         pooled = all(h is None or h.poolable() for h in self.pred_net.values())
+        comp = self._compact_gated(pattern, graph, el_gate)
+        rep_graph = graph                                           # the graph the rep-net runs on
         if hasattr(self, "get_joint_rep"):
-            # heads that pool over the un-augmented representations: the last layer pools its own outputs (and its backward
-            # then never builds the [E, H] gradient of the edge representation, fused._FusedDMPLayer)
-            pools = None
-            if pooled and not self.pred_with_enc and not self.pred_with_deg and (self.node_pred or self.edge_pred):
-                pools = (_pool_index_union(pattern, graph, "node") if self.node_pred else None,
-                         _pool_index_union(pattern, graph, "edge", skip_rev) if self.edge_pred else None)
             import inspect
-            if "pools" in inspect.signature(self.get_joint_rep).parameters:
-                joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate, pools=pools)
-            else:                   # a rep-net without the pooled form
-                joint = self.get_joint_rep(pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, vl_gate, el_gate)
+            with_pools = "pools" in inspect.signature(self.get_joint_rep).parameters
+
+            def run_joint(rg, e_emb, e_gate):
+                # heads that pool over the un-augmented representations: the last layer pools its own outputs (and its backward
+                # then never builds the [E, H] gradient of the edge representation, fused._FusedDMPLayer)
+                pools = None
+                if pooled and not self.pred_with_enc and not self.pred_with_deg and (self.node_pred or self.edge_pred):
+                    pools = (_pool_index_union(pattern, rg, "node") if self.node_pred else None,
+                             _pool_index_union(pattern, rg, "edge", skip_rev) if self.edge_pred else None)
+                if with_pools:
+                    return self.get_joint_rep(pattern, rg, p_v_emb, p_e_emb, g_v_emb, e_emb, vl_gate, e_gate, pools=pools)
+                return self.get_joint_rep(pattern, rg, p_v_emb, p_e_emb, g_v_emb, e_emb, vl_gate, e_gate)   # no pooled form
+
+            if comp is not None:
+                # the rep-net on the kept edges (+ inert padding): their encodings' rows, their gates, their graph
+                g_enc_c = OrderedDict(g_enc)
+                g_enc_c["el"] = comp.take(g_enc["el"])
+                joint = run_joint(comp.graph, self.get_graph_emb_deferred(g_enc_c)[1], comp.gate)
+                if joint is not None:
+                    rep_graph = comp.graph
+                    joint = list(joint)
+                    joint[3] = _expanded(comp, joint[3])            # g_e_rep: the gated-out edges' zero rows back in place
+            if joint is None:
+                comp = None
+                joint = run_joint(graph, g_e_emb, el_gate)
         v_union = e_union = None
         union_sums = (None, None)
         if joint is not None:
@@ -878,7 +965,7 @@ class GraphAdjModelV2(BaseModel):
             g_e_mask = self.refine_edge_weights(g_e_mask)
             if pooled and e_union is not None and not p_add:
                 sums = e_sums = (union_sums[1] if union_sums[1] is not None
-                                 else ops.seg_pool(e_union, _pool_index_union(pattern, graph, "edge", skip_rev)))[:, :e_union.size(1)]
+                                 else ops.seg_pool(e_union, _pool_index_union(pattern, rep_graph, "edge", skip_rev)))[:, :e_union.size(1)]
                 p_e_output, g_e_output = sums[:bsz], sums[bsz:]
             elif pooled:  # reversed edges are masked out of the edge head: keep the non-flagged half
                 d = p_e_output.size(1)

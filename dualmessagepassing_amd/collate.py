@@ -277,3 +277,106 @@ def union_graphs(a, b):
         g.tiling = ops.graph_tiling(g.node_offsets, g.edge_offsets, a.batch_size, a.max_num_edges, b.batch_size, b.max_num_edges)
         g.node_tiling = ops.graph_node_tiling(g.node_offsets, g.edge_offsets, a.batch_size, a.max_num_nodes, b.batch_size, b.max_num_nodes)
     return g
+
+
+class CompactedEdges:
+    """What ``compact_gated_edges`` hands back: ``graph`` (the kept edges + padding, ``capacity`` edge rows), ``eid_map``
+    int64 [capacity] (the edge's row in the graph it came from; 0 for padding rows), ``gate`` float [capacity, 1] (0 for
+    padding rows), ``num_edges`` (rows of the graph it came from)."""
+
+    def __init__(self, graph, eid_map, gate, num_edges, kept):
+        self.graph, self.eid_map, self.gate, self.num_edges, self.kept = graph, eid_map, gate, int(num_edges), kept
+
+    def take(self, rows):
+        """The compacted batch's rows of a per-edge tensor of the original graph (padding rows: row 0, gate 0)."""
+        return rows.index_select(0, self.eid_map)
+
+    def expand(self, rows_c):
+        """[num_edges, width] rows of the original graph from the compacted batch's rows: zero rows for the edges the gate
+        removed (what the reference computes for them: basemodel.py:1515-1531), differentiable."""
+        return _ExpandRows.apply(rows_c, self.eid_map, self.gate, self.num_edges)
+
+
+class _ExpandRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows_c, eid_map, gate, num_edges):
+        out = torch.zeros((num_edges, rows_c.size(1)), dtype=rows_c.dtype, device=rows_c.device)
+        # padding rows are zero rows added into row 0: kept rows have distinct targets, so the order of the adds is immaterial
+        out.index_add_(0, eid_map, rows_c * gate.view(-1, 1).ne(0).to(rows_c.dtype))
+        ctx.save_for_backward(eid_map, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        eid_map, gate = ctx.saved_tensors
+        return d.index_select(0, eid_map) * gate.view(-1, 1).ne(0).to(d.dtype), None, None, None
+
+
+def out_degrees(graph):
+    """``graph.out_degrees()`` (dataset.py:1230-1236) from the edge list alone (``dmp_out_degrees``), cached in
+    ``ndata["out_deg"]`` like the reference's: no CSR of the graph is built for it."""
+    from .constants import OUTDEGREE
+    if OUTDEGREE not in graph.ndata:
+        lib = _lib.load()
+        src = graph._src
+        _lib.require_gpu(src)
+        deg = torch.empty(graph.number_of_nodes(), dtype=torch.int64, device=src.device)
+        check(lib.dmp_out_degrees(ptr(src), src.numel(), deg.numel(), ptr(deg), stream_ptr()), "dmp_out_degrees")
+        graph.ndata[OUTDEGREE] = deg
+    return graph.ndata[OUTDEGREE]
+
+
+def compact_gated_edges(graph, e_gate, capacity, status):
+    """The edges of a block-diagonal batch that a filter gate keeps, as a batch of exactly ``capacity`` edges
+    (``dmp_gate_compact``, csrc/dmp_compact.hip) -- or None where that does not apply (no per-graph offsets, ``capacity``
+    not below the edge count).
+
+    Why this is the same function: the reference multiplies the target's edge embeddings and every layer's edge update by
+    the gate (basemodel.py:1515-1531, dmpnn.py:262-275), so a gate-0 edge is a zero row throughout, adds nothing to a node
+    sum, a pooled sum or a gradient, and only the DEGREES of its endpoints see it (dmpnn.py:101,144-146): the compacted graph
+    carries the whole graph's out-degrees in ``ndata["out_deg"]`` (shared frames, as the reference's layer leaves them).
+    Kept edges stay in ascending eid inside their graph (fixed-order sums keep their order); ``capacity - kept`` padding
+    edges (gate 0, self-loops dealt over the graphs and their nodes) make the shapes independent of the labels, so a
+    recorded step replays.  ``status`` (int32 [1], device, owned by the caller) is OR-ed with 1 if more than ``capacity``
+    edges were kept (the result is truncated and must not be used), with 2 if padding fell on a graph without nodes.
+    No host sync."""
+    from . import ops
+    from .constants import OUTDEGREE, REVFLAG
+    lib = _lib.load()
+    E, N, B, cap = graph.number_of_edges(), graph.number_of_nodes(), graph.batch_size, int(capacity)
+    node_off, edge_off = getattr(graph, "node_offsets", None), getattr(graph, "edge_offsets", None)
+    if node_off is None or edge_off is None or E == 0 or cap <= 0 or cap >= E or getattr(graph, "max_num_edges", None) is None:
+        return None
+    gate = e_gate.reshape(-1)
+    _lib.require_gpu(gate, graph._src, status)
+    if gate.dtype != torch.float32 or gate.numel() != E or status.dtype != torch.int32:
+        raise _lib.DmpError("compact_gated_edges: float gate with one entry per edge, int32 status word")
+    gate = gate.contiguous()
+    dev = gate.device
+    ids = torch.empty((3, cap), dtype=torch.int64, device=dev)               # src | dst | eid map
+    gate_c = torch.empty((cap, 1), dtype=torch.float32, device=dev)
+    sizes = torch.empty(2 * B + 1, dtype=torch.int64, device=dev)            # edges per graph | edge offsets
+    kept = torch.empty(B, dtype=torch.int32, device=dev)
+    rev = graph.edata.get(REVFLAG)
+    rev_c = None
+    if rev is not None:
+        if rev.element_size() != 1:
+            raise _lib.DmpError("is_reversed must be bool or uint8")
+        rev = rev.contiguous().view(-1)
+        rev_c = torch.empty(cap, dtype=rev.dtype, device=dev)
+    deg = None if OUTDEGREE in graph.ndata else torch.empty(N, dtype=torch.int64, device=dev)
+    big = graph.max_num_nodes is None or graph.max_num_nodes > int(lib.dmp_gate_compact_hist_nodes())
+    check(lib.dmp_gate_compact(ptr(gate), ptr(graph._src), ptr(graph._dst), ptr(rev), ptr(node_off), ptr(edge_off), B, N, E, cap,
+                               1 if big else 0, ptr(kept), ptr(deg), ptr(ids[0]), ptr(ids[1]), ptr(rev_c), ptr(ids[2]), ptr(gate_c),
+                               ptr(sizes[:B]), ptr(sizes[B:]), ptr(status), stream_ptr()), "dmp_gate_compact")
+    if deg is not None:
+        graph.ndata[OUTDEGREE] = deg
+    g = BatchedGraph(ids[0], ids[1], N, graph.batch_num_nodes(), sizes[:B], graph.ndata, {} if rev_c is None else {REVFLAG: rev_c},
+                     share_frames=True)
+    g.node_graph = graph.node_graph
+    g.node_offsets, g.edge_offsets = node_off, sizes[B:]
+    g.max_num_nodes = graph.max_num_nodes
+    g.max_num_edges = int(graph.max_num_edges) + cap // B + 1                # kept edges of a graph + its share of the padding
+    g.tiling = ops.graph_tiling(node_off, g.edge_offsets, B, g.max_num_edges)
+    g.node_tiling = ops.graph_node_tiling(node_off, g.edge_offsets, B, g.max_num_nodes)
+    return CompactedEdges(g, ids[2], gate_c, E, kept)

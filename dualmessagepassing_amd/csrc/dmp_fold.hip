@@ -193,6 +193,75 @@ inline bool all16(std::initializer_list<const void *> ps) {
   return true;
 }
 
+// ---- several small products in one launch (dmp_small_gemm_jobs): a workgroup = a 16 x 64 tile of one job's output.  These
+// products are latency-bound (a handful of workgroups, contractions of 16 .. 512): the contraction runs in chunks of 128
+// split over the workgroup's four waves (wave w takes k = k0 + 32 w .. + 31 of each chunk), so a K = 512 product is four
+// round trips to memory with 32 independent B loads per lane in flight in each.  The A chunk (16 x 128) goes through LDS
+// and is read back as wave-uniform broadcasts.  The four partial tiles are summed in wave order: deterministic.
+struct GemmJobs { dmp_gemm_job job[DMP_GEMM_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void small_gemm_jobs_k(const GemmJobs t) {
+  constexpr int KC = 128, KW = 32;
+  __shared__ float4 As[KC][4];                                      // [k][row / 4]
+  __shared__ float Red[3][16][64];
+  const dmp_gemm_job &j = t.job[blockIdx.y];
+  const int tiles_n = (j.N + 63) / 64, tiles_m = (j.M + 15) / 16;
+  if ((int)blockIdx.x >= tiles_n * tiles_m) return;                 // whole workgroups only: no barrier is skipped by a part
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (int)(blockIdx.x % tiles_n) * 64 + lane, row0 = (int)(blockIdx.x / tiles_n) * 16;
+  const int cc = c < j.N ? c : 0;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float *As_f = reinterpret_cast<float *>(&As[0][0]);
+  for (int q = 0; q < j.num_terms; ++q) {
+    const dmp_gemm_term &m = j.term[q];
+    const float *__restrict__ A = m.A;
+    const float *__restrict__ B = m.B;
+    const int64_t sa_r = m.transA ? 1 : m.lda, sa_k = m.transA ? m.lda : 1;
+    const int64_t sb_k = m.transB ? 1 : m.ldb, sb_c = m.transB ? m.ldb : 1;
+    for (int k0 = 0; k0 < m.K; k0 += KC) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                                 // 2,048 elements of A, read along its unit stride
+        const int e = (int)threadIdx.x + 256 * u;
+        const int lr = m.transA ? (e & 15) : (e >> 7), lk = m.transA ? (e >> 4) : (e & 127);
+        const int r = row0 + lr, k = k0 + lk;
+        As_f[lk * 16 + lr] = (r < j.M && k < m.K) ? A[r * sa_r + k * sa_k] : 0.f;
+      }
+      float bv[KW];
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        const int k = k0 + KW * w + kk;
+        bv[kk] = k < m.K ? B[k * sb_k + cc * sb_c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const float4 a = As[KW * w + kk][i4];
+          acc[4 * i4 + 0] = fmaf(a.x, bv[kk], acc[4 * i4 + 0]);
+          acc[4 * i4 + 1] = fmaf(a.y, bv[kk], acc[4 * i4 + 1]);
+          acc[4 * i4 + 2] = fmaf(a.z, bv[kk], acc[4 * i4 + 2]);
+          acc[4 * i4 + 3] = fmaf(a.w, bv[kk], acc[4 * i4 + 3]);
+        }
+      }
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Red[w - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (w > 0 || c >= j.N) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = row0 + i;
+    const float v = ((acc[i] + Red[0][i][lane]) + Red[1][i][lane]) + Red[2][i][lane];
+    if (r < j.M) j.C[(int64_t)r * j.ldc + c] = j.C0 ? v + j.C0[(int64_t)r * j.ldc0 + c] : v;
+  }
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -299,6 +368,30 @@ int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *
     if (rc != DMP_OK) return rc;
   }
   return DMP_OK;
+}
+
+int dmp_small_gemm_jobs(const dmp_gemm_job *jobs, int num_jobs, void *stream) {
+  if (num_jobs < 0 || num_jobs > DMP_GEMM_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  if (num_jobs == 0) return DMP_OK;
+  if (!jobs) return DMP_ERR_BAD_ARG;
+  GemmJobs t;
+  int most = 0;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_gemm_job &j = jobs[i];
+    if (j.num_terms < 0 || j.num_terms > DMP_GEMM_MAX_TERMS || j.M < 0 || j.N < 0 || j.ldc < j.N || (j.C0 && j.ldc0 < j.N)) return DMP_ERR_BAD_ARG;
+    if (j.M > 0 && j.N > 0 && !j.C) return DMP_ERR_BAD_ARG;
+    for (int q = 0; q < j.num_terms; ++q) {
+      const dmp_gemm_term &m = j.term[q];
+      if (m.K < 0 || (m.K > 0 && j.M > 0 && j.N > 0 && (!m.A || !m.B))) return DMP_ERR_BAD_ARG;
+      if (m.lda < (m.transA ? j.M : m.K) || m.ldb < (m.transB ? m.K : j.N)) return DMP_ERR_BAD_ARG;
+    }
+    t.job[i] = j;
+    const int tiles = ((j.M + 15) / 16) * ((j.N + 63) / 64);
+    if (tiles > most) most = tiles;
+  }
+  if (most == 0) return DMP_OK;
+  small_gemm_jobs_k<<<dim3((unsigned)most, (unsigned)num_jobs), 256, 0, (hipStream_t)stream>>>(t);
+  return check_launch();
 }
 
 }  // extern "C"

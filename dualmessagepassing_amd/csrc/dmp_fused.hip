@@ -237,9 +237,24 @@ struct AdamArgs {
   // device-resident step count and learning rate (a step captured in a HIP graph: nothing per-step in the launch arguments)
   const double *state;                                        // [step, lr] or NULL (the fields above hold the host's values)
   double lr_wd, beta1, beta2d;                                // state != NULL: weight decay, betas for the bias corrections
+  const int32_t *veto;                                        // dmp_adamw_step_guarded: veto[2] != 0 -> this step is dropped
 };
 
-__global__ void adamw_tick(double *state) { state[0] += 1.0; }
+// step += 1 -- unless the step is vetoed (dmp_adamw_step_guarded): veto[0] = flags raised since the last optimizer step
+// (e.g. by dmp_gate_compact: a batch that did not fit its capacity), veto[1] = every flag ever raised (for the host),
+// veto[2] = was this step dropped, veto[3] = steps dropped so far
+__global__ void adamw_tick(double *state, int32_t *veto, int32_t mask) {
+  bool drop = false;
+  if (veto) {
+    const int32_t f = veto[0];
+    drop = (f & mask) != 0;
+    veto[1] |= f;
+    veto[0] = 0;
+    veto[2] = drop ? 1 : 0;
+    if (drop) veto[3] += 1;
+  }
+  if (!drop) state[0] += 1.0;
+}
 
 struct PackSegs {
   const float *src[DMP_PACK_MAX_SEGMENTS];
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a,
 }
 
 __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
+  if (a.veto && a.veto[2]) return;                             // a dropped step: parameters and moments stay as they are
   if (a.state) {                                               // the host formulas of dmp_adamw_step_skip, evaluated on the device
     const double step = a.state[0], lr = a.state[1];
     const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2d, step);
@@ -821,7 +837,8 @@ int dmp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_a
 
 static int adamw_launch(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
                         int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
-                        double *state, const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream) {
+                        double *state, const int64_t *skip_lo, const int64_t *skip_hi, int nskip, void *stream,
+                        int32_t *veto = nullptr, int32_t veto_mask = 0) {
   DMP_ROW_CHECK(n >= 0 && (state || (step >= 1 && lr >= 0)) && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
   DMP_ROW_CHECK(nskip >= 0 && nskip <= DMP_ADAMW_MAX_SKIP && (nskip == 0 || (skip_lo && skip_hi)));
   if (n == 0) return DMP_OK;
@@ -830,7 +847,7 @@ static int adamw_launch(float *param, const float *grad, float *exp_avg, float *
   AdamArgs a;
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;
   a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2); a.eps = (float)eps;
-  a.state = state; a.lr_wd = weight_decay; a.beta1 = beta1; a.beta2d = beta2;
+  a.state = state; a.lr_wd = weight_decay; a.beta1 = beta1; a.beta2d = beta2; a.veto = veto;
   a.decay = 1.f; a.step_size = 0.f; a.inv_bc2_sqrt = 1.f;
   if (!state) {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -844,7 +861,7 @@ static int adamw_launch(float *param, const float *grad, float *exp_avg, float *
   }
   int64_t nb = (n / 4 + kBlock) / kBlock;
   if (nb > 2048) nb = 2048;
-  if (state) adamw_tick<<<1, 1, 0, (hipStream_t)stream>>>(state);      // step += 1, ordered before the update on the stream
+  if (state) adamw_tick<<<1, 1, 0, (hipStream_t)stream>>>(state, veto, veto_mask);   // step += 1, ordered before the update on the stream
   adamw_kernel<<<(unsigned)nb, kBlock, 0, (hipStream_t)stream>>>(a);
   return check_launch();
 }
@@ -862,6 +879,15 @@ int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *e
   if (!state || (reinterpret_cast<uintptr_t>(state) & 7u)) return DMP_ERR_BAD_ARG;
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, 0.0, beta1, beta2, eps, weight_decay, 0, state,
                       skip_lo, skip_hi, nskip, stream);
+}
+
+int dmp_adamw_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                           int64_t n, double *state, double beta1, double beta2, double eps, double weight_decay,
+                           const int64_t *skip_lo, const int64_t *skip_hi, int nskip, int32_t *veto, int32_t veto_mask,
+                           void *stream) {
+  if (!state || (reinterpret_cast<uintptr_t>(state) & 7u) || !veto) return DMP_ERR_BAD_ARG;
+  return adamw_launch(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, 0.0, beta1, beta2, eps, weight_decay, 0, state,
+                      skip_lo, skip_hi, nskip, stream, veto, veto_mask);
 }
 
 }  // extern "C"

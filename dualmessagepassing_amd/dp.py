@@ -208,6 +208,16 @@ class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         self.capturable = bool(capturable)
+        self.veto = None      # (int32 [4] device tensor, mask): ``set_veto``
+
+    def set_veto(self, word, mask=1):
+        """Drop a step when a device-side flag is up (``dmp_adamw_step_guarded``), as a loss-scaling optimizer drops a step
+        whose gradients overflowed: ``word`` = int32 [4] on the device, ``word[0]`` = flags raised since the last step
+        (``GraphAdjModelV2.set_gate_capacity``: a batch that kept more edges than the capacity ORs bit 0 -- its gradients
+        are wrong).  A dropped step leaves parameters, moments and the step count alone; ``word[3]`` counts them.  No
+        host sync, so it replays; the step count then lives on the device whether or not ``capturable`` was asked for."""
+        self.veto = None if word is None else (word, int(mask))
+        return self
 
     def _device_state(self, p, group):
         st = self.state[p]
@@ -277,7 +287,7 @@ class FlatAdamW(torch.optim.Optimizer):
                         st["max_exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 state = None
-                if self.capturable:
+                if self.capturable or self.veto is not None:
                     state = self._device_state(p, group)
                     if not torch.cuda.is_current_stream_capturing():
                         self.sync_hyper()
@@ -296,6 +306,14 @@ class FlatAdamW(torch.optim.Optimizer):
                     import ctypes
                     lo = (ctypes.c_int64 * max(len(gaps), 1))(*[g[0] for g in gaps])
                     hi = (ctypes.c_int64 * max(len(gaps), 1))(*[g[1] for g in gaps])
+                    if state is not None and self.veto is not None:
+                        _lib.require_gpu(self.veto[0])
+                        _lib.check(lib.dmp_adamw_step_guarded(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                                              st["exp_avg_sq"].data_ptr(), _lib.ptr(mx), p.numel(), state.data_ptr(),
+                                                              b1, b2, group["eps"], group["weight_decay"], lo, hi, len(gaps),
+                                                              self.veto[0].data_ptr(), self.veto[1], _lib.stream_ptr()),
+                                   "dmp_adamw_step_guarded")
+                        continue
                     if state is not None:
                         _lib.check(lib.dmp_adamw_step_dev(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                                           st["exp_avg_sq"].data_ptr(), _lib.ptr(mx), p.numel(), state.data_ptr(),
@@ -308,7 +326,7 @@ class FlatAdamW(torch.optim.Optimizer):
                                                        _lib.stream_ptr()), "dmp_adamw_step_skip")
                     continue
                 if state is not None:
-                    raise ValueError("FlatAdamW(capturable=True): more than 16 gaps between the parameters with gradients")
+                    raise ValueError("FlatAdamW(capturable=True / set_veto): more than 16 gaps between the parameters with gradients")
                 for off, n in runs:
                     b = 4 * off
                     _lib.check(lib.dmp_adamw_step(p.data_ptr() + b, p.grad.data_ptr() + b, st["exp_avg"].data_ptr() + b,

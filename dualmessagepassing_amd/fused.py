@@ -790,6 +790,59 @@ def fold_layers(layers):
     return out
 
 
+_GEMM_TYPES = None
+USE_SMALL_GEMM_JOBS = _os.environ.get("DMP_SMALL_GEMM_JOBS", "1") == "1"
+
+
+def small_gemm_jobs(jobs):
+    """Several small fp32 products in ONE launch (``dmp_small_gemm_jobs``, csrc/dmp_fold.hip).  ``jobs``: list of
+    ``(out, terms, addend)`` with ``terms`` a list of ``(A, transA, B, transB)`` -- ``out = sum_t op(A_t) op(B_t) (+ addend)``,
+    ``op(X) = X^T`` when the flag is set; operands are 2-D fp32 tensors with unit inner stride (any row stride: column slices
+    and ``out`` views of wider tensors are fine), ``out`` must not alias an operand.  At most 12 jobs of at most 3 terms."""
+    global _GEMM_TYPES
+    import ctypes
+    lib = _lib.load()
+    if _GEMM_TYPES is None:
+        class _Term(ctypes.Structure):
+            _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64),
+                        ("transA", ctypes.c_int32), ("transB", ctypes.c_int32), ("K", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+        class _Job(ctypes.Structure):
+            _fields_ = [("term", _Term * 3), ("C0", ctypes.c_void_p), ("ldc0", ctypes.c_int64), ("C", ctypes.c_void_p),
+                        ("ldc", ctypes.c_int64), ("num_terms", ctypes.c_int32), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+                        ("pad", ctypes.c_int32)]
+        _GEMM_TYPES = (_Term, _Job)
+    _, Job = _GEMM_TYPES
+    if not 0 < len(jobs) <= 12:
+        raise _lib.DmpError("small_gemm_jobs: 1..12 jobs")
+    J = (Job * len(jobs))()
+
+    def ld(t):
+        if t.dim() != 2 or t.dtype != torch.float32 or (t.size(1) > 1 and t.stride(1) != 1):
+            raise _lib.DmpError("small_gemm_jobs: 2-D fp32 operands with unit inner stride")
+        return t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+
+    keep = []
+    for n, (out, terms, addend) in enumerate(jobs):
+        M, N = out.shape
+        if not 0 < len(terms) <= 3:
+            raise _lib.DmpError("small_gemm_jobs: 1..3 terms per job")
+        _lib.require_gpu(out, addend, *[x for tm in terms for x in (tm[0], tm[2])])
+        for q, (A, ta, B, tb) in enumerate(terms):
+            K = A.size(0) if ta else A.size(1)
+            if (A.size(1) if ta else A.size(0)) != M or (B.size(1) if tb else B.size(0)) != K or (B.size(0) if tb else B.size(1)) != N:
+                raise _lib.DmpError("small_gemm_jobs: shapes of job %d, term %d" % (n, q))
+            T = J[n].term[q]
+            T.A, T.lda, T.B, T.ldb, T.transA, T.transB, T.K = A.data_ptr(), ld(A), B.data_ptr(), ld(B), int(bool(ta)), int(bool(tb)), K
+            keep.append((A, B))
+        J[n].num_terms, J[n].M, J[n].N, J[n].C, J[n].ldc = len(terms), M, N, out.data_ptr(), ld(out)
+        if addend is not None:
+            if addend.shape != out.shape:
+                raise _lib.DmpError("small_gemm_jobs: addend shape")
+            J[n].C0, J[n].ldc0 = addend.data_ptr(), ld(addend)
+    check(lib.dmp_small_gemm_jobs(J, len(jobs), stream_ptr()), "dmp_small_gemm_jobs")
+
+
 class _FusedDMPLayer(torch.autograd.Function):
     """One DMPNN layer + gate + residual over the folded weights of ``fold_layers``."""
 
@@ -820,20 +873,34 @@ class _FusedDMPLayer(torch.autograd.Function):
             S0 = ops.seg_sum_raw(enc0, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)        # [N, 2 Kpad] = [in | out]
             # S = [S0_in W0 | S0_out W0] is never built:  S Bn = S0_in (W0 Bn_in) + S0_out (W0 Bn_out), two K-column products
             Kp = enc0.size(1)
-            WB = torch.matmul(W0, Bn.view(2, H, H))                                                  # [2, T K, H]
+            vcodes_f = l0.venc is not None
+            if USE_SMALL_GEMM_JOBS:   # the parameter-only products of this layer in ONE launch: W0 Bn_in, W0 Bn_out, W0 [A | B], WV0 Wx
+                TK = W0.size(0)
+                WB = torch.empty((2, TK, H), dtype=torch.float32, device=z.device)
+                M0 = torch.empty((TK, 2 * H), dtype=torch.float32, device=z.device)
+                jobs = [(WB[0], [(W0, False, Bn[:H], False)], None), (WB[1], [(W0, False, Bn[H:], False)], None),
+                        (M0, [(W0, False, Wes, False)], None)]
+                if vcodes_f:
+                    MV = torch.empty((WV0.size(0), 3 * H), dtype=torch.float32, device=z.device)
+                    jobs.append((MV, [(WV0, False, Wx, False)], None))
+                small_gemm_jobs(jobs)
+            else:
+                WB = torch.matmul(W0, Bn.view(2, H, H))                                              # [2, T K, H]
             SB = torch.empty((N, H), dtype=torch.float32, device=z.device)
             for t, _, (n0, n1) in tables:
                 if n1 > n0:
                     torch.mm(S0[n0:n1, :K0], WB[0, t * K0:(t + 1) * K0], out=SB[n0:n1])
                     SB[n0:n1].addmm_(S0[n0:n1, Kp:Kp + K0], WB[1, t * K0:(t + 1) * K0])
-            M0 = W0 @ Wes                                                                            # [T K, 2H] = W0 [A | B]
+            if not USE_SMALL_GEMM_JOBS:
+                M0 = W0 @ Wes                                                                        # [T K, 2H] = W0 [A | B]
             S = None
         else:
             S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
             SB = S @ Bn
         if l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK
-            MV = WV0 @ Wx                                                                            # [T VK, 3H]
+            if not USE_SMALL_GEMM_JOBS:
+                MV = WV0 @ Wx                                                                        # [T VK, 3H]
             XP = torch.empty((N, 3 * H), dtype=torch.float32, device=z.device)
             for t, (n0, n1) in l0.vtables(N):
                 smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK], None, XP[n0:n1], H)
@@ -1040,7 +1107,25 @@ class _FusedDMPLayer(torch.autograd.Function):
                                                base=dzn if ctx.residual else None)
                     dz.addmm_(dG, Wes.t())
         dW0 = dWV0 = None
-        if l0 is not None:       # after the reductions of the block above have run
+        if l0 is not None and USE_SMALL_GEMM_JOBS:       # after the reductions of the block above have run: ONE launch
+            # dWes = W0^T (enc^T [dPre | c dPre]);  dBn_h = W0^T X_h;  enc^T dz = (enc^T [dPre | c dPre]) [A | B]^T + sum_h X_h Bn_h^T
+            # (+ enc^T dzn);  dWx = WV0^T (venc^T dXP) block by block;  venc^T dx = sum_b Y_b Wx_b^T (+ venc^T dxn)
+            dev = XX.device
+            dWes = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+            dBn = torch.empty((2 * H, H), dtype=torch.float32, device=dev)
+            dW0 = torch.empty((W0.size(0), H), dtype=torch.float32, device=dev)
+            jobs = [(dWes, [(W0, True, XX[:, :2 * H], False)], None),
+                    (dBn[:H], [(W0, True, Xn[0], False)], None), (dBn[H:], [(W0, True, Xn[1], False)], None),
+                    (dW0, [(XX[:, :2 * H], False, Wes, True), (Xn[0], False, Bn[:H], True), (Xn[1], False, Bn[H:], True)],
+                     XX[:, 2 * H:] if ctx.residual else None)]
+            if vcodes:
+                dWx = torch.empty((H, 3 * H), dtype=torch.float32, device=dev)
+                dWV0 = torch.empty((WV0.size(0), H), dtype=torch.float32, device=dev)
+                for b3 in range(3):
+                    jobs.append((dWx[:, b3 * H:(b3 + 1) * H], [(WV0, True, Yn[b3], False)], None))
+                jobs.append((dWV0, [(Yn[b3], False, Wx[:, b3 * H:(b3 + 1) * H], True) for b3 in range(3)], Yn[3] if ctx.residual else None))
+            small_gemm_jobs(jobs)
+        elif l0 is not None:
             dWes = W0.t() @ XX[:, :2 * H]                                  # z^T [dPre | c dPre] = W0^T (enc^T [dPre | c dPre])
             dBn = torch.matmul(W0.t(), Xn).view(2 * H, H)
             T3 = torch.bmm(Xn, Bn.view(2, H, H).transpose(1, 2)).sum(0)

@@ -363,6 +363,11 @@ class BatchedGraph:
     def device(self):
         return self._src.device
 
+    def is_batched_on_device(self):
+        """A block-diagonal batch whose per-graph offsets and size bounds came with it (``collate.collate_device``)."""
+        return (getattr(self, "node_offsets", None) is not None and getattr(self, "edge_offsets", None) is not None
+                and getattr(self, "max_num_edges", None) is not None and self._src.is_cuda)
+
     # ---- structure
     def all_edges(self, form="uv", order="eid"):
         if order != "eid":

@@ -483,11 +483,16 @@ def evaluate_epoch(model, dataset, batch_size, device, eval_metric="MAE"):
     predictions themselves."""
     model.eval()
     preds, targets = [], []
-    for i in range(0, len(dataset), batch_size):
-        idx = np.arange(i, min(i + batch_size, len(dataset)))
-        pattern, graph, counts, _ = dataset.batchify(idx, device)
-        preds.append(F.relu(model(pattern, graph)["pred_c"]))
-        targets.append(counts)
+    # no optimizer step here that could drop a batch which does not fit a gate capacity: every edge row as it stands
+    cap, model.gate_capacity = getattr(model, "gate_capacity", None), None
+    try:
+        for i in range(0, len(dataset), batch_size):
+            idx = np.arange(i, min(i + batch_size, len(dataset)))
+            pattern, graph, counts, _ = dataset.batchify(idx, device)
+            preds.append(F.relu(model(pattern, graph)["pred_c"]))
+            targets.append(counts)
+    finally:
+        model.gate_capacity = cap
     pred, target = torch.cat(preds), torch.cat(targets)
     return {"MAE": float(F.l1_loss(pred, target)), "MSE": float(F.mse_loss(pred, target)),
             "eval_metric": float(_CRIT[eval_metric](pred, target)), "pred": pred.view(-1).cpu(), "counts": target.view(-1).cpu()}
@@ -552,7 +557,12 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     ``config.json``, ``epoch%d.pt`` (state dict of every epoch), ``log.txt`` whose "best" lines
     (``utils/log.py:50-57``) ``dataio.get_best_epochs`` reads back.  Returns the per-epoch history.
     ``graph=True`` (with ``FlatAdamW(capturable=True)``, one rank): training steps whose batch shape repeats are
-    recorded once and replayed as one HIP graph (``GraphedTrainStep``)."""
+    recorded once and replayed as one HIP graph (``GraphedTrainStep``).
+    ``gate_compact=True`` (or a margin, e.g. 1.25): training forward passes run the rep-net on the target edges the filter
+    gate keeps (``model.set_gate_capacity``; capacity = the largest kept count of up to eight training batches x the margin).
+    A batch that keeps more than that raises a device flag and the optimizer drops its step (``FlatAdamW.set_veto``, as a
+    loss-scaling optimizer drops an overflowed step); the history counts them (``dropped_steps``).  Evaluation passes run
+    on every edge row."""
     from . import dataio
     from .tuning import enable_tuned_gemms
     validate_samples(train_set)
@@ -573,6 +583,15 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     elif not train_kw.get("graph"):
         train_kw.pop("graph", None)
     rng = np.random.default_rng(seed)
+    compact = train_kw.pop("gate_compact", False)
+    if compact and hasattr(model, "calibrate_gate_capacity") and hasattr(optimizer, "set_veto"):
+        margin, cap = (1.15 if compact is True else float(compact)), 0
+        with torch.enable_grad():
+            for i in range(0, min(len(train_set), 8 * batch_size), batch_size):
+                pattern, graph_b = train_set.batchify(np.arange(i, min(i + batch_size, len(train_set))), device)[:2]
+                cap = max(cap, model.calibrate_gate_capacity(pattern, graph_b, margin=margin, multiple=256) or 0)
+        model.set_gate_capacity(cap or None)
+        optimizer.set_veto(model.compaction_word if cap else None)
     log = None
     if save_dir is not None:
         os.makedirs(save_dir, exist_ok=True)
@@ -594,6 +613,8 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
                              order=rng.permutation(len(train_set)), **dict(train_kw, epoch=epoch))
             dev = evaluate_epoch(model, dev_set, batch_size, device, eval_metric=eval_metric)
             history.append({"epoch": epoch, "train": tr, "dev": {k: dev[k] for k in ("MAE", "MSE", "eval_metric")}})
+            if getattr(model, "gate_capacity", None):
+                history[-1]["dropped_steps"] = model.compaction_dropped_steps()       # cumulative (one host sync per epoch)
             if save_dir is not None:
                 torch.save(model.state_dict(), dataio.checkpoint_path(save_dir, epoch))
             if dev["eval_metric"] < best[0]:

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 50
+#define DMP_ABI_VERSION 52
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -359,6 +359,24 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
                  int H, float s0, float s1, float *out, int64_t ldo,
                  int rows_shared, void *stream);
 
+/* Gate compaction of a block-diagonal batch (csrc/dmp_compact.hip): the edges a filter gate keeps (gate[e] != 0), graph by
+ * graph in ascending eid, as a batch of exactly `cap` edges -- `cap - kept` padding edges (gate 0, self-loops dealt over
+ * the graphs and their nodes) follow each graph's kept edges.  An edge with gate 0 is a zero row through the whole rep-net
+ * of the reference (basemodel.py:1515-1531, dmpnn.py:215-277: embeddings and every layer update are multiplied by the
+ * gate); only the degrees see it, so `out_deg` [N] (optional) receives the out-degrees of the WHOLE graph (dmpnn.py:101).
+ * Outputs: src_c / dst_c / eid_map (the edge's eid; 0 for padding) [cap] int64, rev_c [cap] (optional), gate_c [cap],
+ * num_edges_c [B], edge_off_c [B + 1]; kept [B] int32 workspace = kept edges per graph; status[0] is OR-ed with: bit 0 = more
+ * kept edges than cap (outputs truncated: run the batch as it stands), bit 1 = padding fell on a graph without nodes (the
+ * caller clears the word; it is never reset here, so one word can watch over many recorded steps).
+ * zero_deg: clear out_deg first (needed when a graph has more than dmp_gate_compact_hist_nodes() nodes).  Two launches. */
+int dmp_gate_compact_hist_nodes(void);
+int dmp_gate_compact(const float *gate, const int64_t *src, const int64_t *dst, const uint8_t *rev, const int64_t *node_off,
+                     const int64_t *edge_off, int64_t B, int64_t N, int64_t E, int64_t cap, int zero_deg, int32_t *kept,
+                     int64_t *out_deg, int64_t *src_c, int64_t *dst_c, uint8_t *rev_c, int64_t *eid_map, float *gate_c,
+                     int64_t *num_edges_c, int64_t *edge_off_c, int32_t *status, void *stream);
+/* Out-degrees of an edge list (graph.out_degrees(), dataset.py:1230-1236) without building its CSR: deg[u] = #{e: src[e] == u}. */
+int dmp_out_degrees(const int64_t *src, int64_t E, int64_t N, int64_t *deg, void *stream);
+
 /*
  * The same sums as dmp_seg_sum2 over the incidence CSR -- the backward of the gathered node projections of
  * DMPLayer._node_message_func (dmpnn.py:111-127: dP_d[a_e] += dPre[e], dP_s[b_e] -= dPre[e]) -- from ONE pass over the
@@ -628,6 +646,16 @@ int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *e
                        double eps, double weight_decay, const int64_t *skip_lo, const int64_t *skip_hi,
                        int nskip, void *stream);
 
+/* dmp_adamw_step_dev that DROPS the step when a device-side flag says so (as a loss-scaling optimizer drops a step whose
+ * gradients overflowed): veto = int32 [4] in device memory.  veto[0] collects flags raised since the last optimizer step
+ * (dmp_gate_compact ORs bit 0 into it for a batch that kept more edges than its capacity -- its gradients are wrong);
+ * if veto[0] & veto_mask the step count is not advanced and parameters and moments are left as they are.  Either way
+ * veto[1] |= veto[0], veto[0] = 0, veto[2] = this step was dropped, veto[3] += dropped.  No host sync: replays. */
+int dmp_adamw_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                           int64_t n, double *state, double beta1, double beta2, double eps, double weight_decay,
+                           const int64_t *skip_lo, const int64_t *skip_hi, int nskip, int32_t *veto, int32_t veto_mask,
+                           void *stream);
+
 /*
  * ScalarFilter gates of a batch of (pattern, target) pairs (filter.py:6-16 on the pre-padded label matrices,
  * basemodel.py:1394-1423) for several element kinds (node labels, edge labels) in three dispatches:
@@ -741,6 +769,27 @@ int dmp_fold_layers(const dmp_layer_weights *w, const dmp_layer_folded *f, int n
                     void *stream);
 int dmp_unfold_layers(const dmp_layer_weights *w, const dmp_layer_folded_grads *g,
                       const dmp_layer_weight_grads *d, int num_layers, int H, void *stream);
+
+/*
+ * Several SMALL dense products in one launch (csrc/dmp_fold.hip): the parameter-only algebra of the first layer on
+ * the label codes (fused.Layer0Codes: W0 [A | B], W0 Bn, WV0 Wx forward; their gradients backward -- a dozen products
+ * with 10..20 rows or columns, each a library call of 5..13 us before).  Job j:
+ *     C_j [M, N] = sum_{t < num_terms} op(A_t) [M, K_t]  op(B_t) [K_t, N]  (+ C0_j)
+ * op(X) = X or X^T (trans flag: the operand is stored transposed, i.e. A as [K, M] / B as [N, K]); leading dimensions
+ * in floats; fp32 FMA chains in k order, terms in order, C0 added last.  At most DMP_GEMM_MAX_JOBS jobs of at most
+ * DMP_GEMM_MAX_TERMS terms; C must not alias an operand of the same launch.
+ */
+#define DMP_GEMM_MAX_JOBS 12
+#define DMP_GEMM_MAX_TERMS 3
+typedef struct {
+  const float *A; int64_t lda; const float *B; int64_t ldb; int32_t transA, transB, K, pad;
+} dmp_gemm_term;
+typedef struct {
+  dmp_gemm_term term[DMP_GEMM_MAX_TERMS];
+  const float *C0; int64_t ldc0; float *C; int64_t ldc; int32_t num_terms, M, N, pad;
+} dmp_gemm_job;
+int dmp_small_gemm_jobs(const dmp_gemm_job *jobs, int num_jobs, void *stream);
+
 
 /*
  * The pooled prediction heads (SubgraphCountingMatching/models/pred.py:93-156 applied to per-graph sums; the node

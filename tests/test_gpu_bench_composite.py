@@ -150,6 +150,24 @@ def _run_case(cfg, gpu, oracle_chunk):
         assert g.replays == 2
         th.cuda.synchronize()
         _compare("replayed", step.last_pred_c, _named_flat(step, model), ref_pred, ref_grads)
+    # the same step with the rep-net on the target edges the filter gate keeps (bench.py's `gate_compact` object;
+    # model.set_gate_capacity): the oracle computes every edge row, gated ones included -- same pred_c, same gradient
+    info = step.set_gate_compact(True)
+    assert info is not None and info["capacity"] < 0.7 * info["edges"], info
+    step.sync.flat.fill_(float("nan"))
+    step.front()
+    _compare("gate-compact eager", step.last_pred_c, _named_flat(step, model), ref_pred, ref_grads)
+    g2 = StepGraph(lambda: step.front(), optimizer=None, max_shapes=1)
+    with g2.on_stream():
+        g2()
+        g2()
+        step.sync.flat.fill_(float("nan"))
+        g2()
+        assert g2.replays == 2
+        th.cuda.synchronize()
+        _compare("gate-compact replayed", step.last_pred_c, _named_flat(step, model), ref_pred, ref_grads)
+    assert model.compaction_status() == 0
+    step.set_gate_compact(False)
     return checked
 
 

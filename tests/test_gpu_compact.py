@@ -1,0 +1,236 @@
+"""Gate compaction (``collate.compact_gated_edges`` -> ``dmp_gate_compact``, ``GraphAdjModelV2.set_gate_capacity``).
+
+An edge the filter gate removes is a zero row through the reference's whole rep-net (basemodel.py:1515-1531,
+dmpnn.py:262-275): the model may run its rep-net on the kept edges only.  Checked here: the integer transform against a
+numpy restatement (bit-exact: order, per-graph counts, padding, degrees, overflow flag), and the model with the capacity
+set against the same model without it -- every one of the 15 outputs and every parameter gradient.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _random_batch(rng, B, max_n, max_e, gpu, empty_graphs=False):
+    from dualmessagepassing_amd.collate import collate_device
+    nn = rng.integers(1, max_n + 1, size=B)
+    ne = rng.integers(0, max_e + 1, size=B)
+    if empty_graphs:
+        ne[rng.integers(0, B, size=max(1, B // 5))] = 0
+    ls = np.concatenate([rng.integers(0, n, size=e) for n, e in zip(nn, ne)]).astype(np.int64)
+    ld = np.concatenate([rng.integers(0, n, size=e) for n, e in zip(nn, ne)]).astype(np.int64)
+    rev = rng.integers(0, 2, size=int(ne.sum())).astype(np.uint8)
+    t = lambda a: th.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    g = collate_device(t(ls), t(ld), t(nn.astype(np.int64)), t(ne.astype(np.int64)), int(nn.sum()), int(ne.sum()),
+                       edata={"is_reversed": t(rev)}, max_nodes=int(nn.max()), max_edges=int(max(ne.max(), 1)))
+    return g, nn, ne, rev
+
+
+def _reference(g, nn, ne, rev, gate, cap):
+    """numpy restatement of dmp_gate_compact."""
+    src, dst = g._src.cpu().numpy(), g._dst.cpu().numpy()
+    B = len(nn)
+    eoff = np.concatenate([[0], np.cumsum(ne)])
+    noff = np.concatenate([[0], np.cumsum(nn)])
+    kept = np.array([int((gate[eoff[i]:eoff[i + 1]] != 0).sum()) for i in range(B)])
+    P = cap - int(kept.sum())
+    over = P < 0
+    P = max(P, 0)
+    q, r = divmod(P, B)
+    out = {k: [] for k in ("src", "dst", "rev", "eid", "gate")}
+    sizes = []
+    for i in range(B):
+        pad = q + (1 if i < r else 0)
+        for e in range(eoff[i], eoff[i + 1]):
+            if gate[e] != 0:
+                out["src"].append(src[e]); out["dst"].append(dst[e]); out["rev"].append(rev[e]); out["eid"].append(e)
+                out["gate"].append(gate[e])
+        for j in range(pad):
+            node = noff[i] + (j % nn[i])
+            out["src"].append(node); out["dst"].append(node); out["rev"].append(0); out["eid"].append(0); out["gate"].append(0.0)
+        sizes.append(kept[i] + pad)
+    deg = np.bincount(src, minlength=int(nn.sum()))
+    return {k: np.array(v) for k, v in out.items()}, np.array(sizes), deg, over
+
+
+@pytest.mark.parametrize("B,max_n,max_e,frac,empty", [(37, 9, 40, 0.4, False), (64, 64, 512, 0.35, False), (5, 3000, 700, 0.5, False),
+                                                      (16, 12, 30, 0.3, True), (1, 8, 24, 0.5, False)])
+def test_gate_compact_matches_its_restatement(B, max_n, max_e, frac, empty):
+    from dualmessagepassing_amd.collate import compact_gated_edges
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(B * 1000 + max_e)
+    g, nn, ne, rev = _random_batch(rng, B, max_n, max_e, gpu, empty)
+    E = int(ne.sum())
+    gate = (rng.random(E) < frac).astype(np.float32)
+    kept = int(gate.sum())
+    for cap in (kept + B + 3, kept, kept + 1, max(1, kept - 2)):
+        if cap >= E or cap <= 0:
+            continue
+        status = th.zeros(1, dtype=th.int32, device=gpu)
+        g.ndata.pop("out_deg", None)
+        comp = compact_gated_edges(g, th.from_numpy(gate).to(gpu).view(-1, 1), cap, status)
+        assert comp is not None
+        ref, sizes, deg, over = _reference(g, nn, ne, rev, gate, cap)
+        assert bool(int(status.item()) & 1) == over
+        assert np.array_equal(g.ndata["out_deg"].cpu().numpy(), deg)            # the WHOLE graph's degrees
+        if over:
+            continue
+        c = comp.graph
+        assert c.number_of_edges() == cap and c.number_of_nodes() == g.number_of_nodes()
+        assert np.array_equal(c._src.cpu().numpy(), ref["src"]) and np.array_equal(c._dst.cpu().numpy(), ref["dst"])
+        assert np.array_equal(c.edata["is_reversed"].cpu().numpy(), ref["rev"])
+        assert np.array_equal(comp.eid_map.cpu().numpy(), ref["eid"])
+        assert np.array_equal(comp.gate.view(-1).cpu().numpy(), ref["gate"].astype(np.float32))
+        assert np.array_equal(c.batch_num_edges().cpu().numpy(), sizes)
+        assert np.array_equal(c.edge_offsets.cpu().numpy(), np.concatenate([[0], np.cumsum(sizes)]))
+        # expand: kept rows back in place, zero rows elsewhere; its backward gathers and gates
+        rows = th.randn(cap, 8, device=gpu) * comp.gate
+        rows.requires_grad_(True)
+        full = comp.expand(rows)
+        want = np.zeros((E, 8), np.float32)
+        k = ref["gate"] != 0
+        want[ref["eid"][k]] = rows.detach().cpu().numpy()[k]
+        assert np.array_equal(full.detach().cpu().numpy(), want)
+        d = th.randn(E, 8, device=gpu)
+        full.backward(d)
+        wd = d.cpu().numpy()[ref["eid"]] * k[:, None]
+        assert np.array_equal(rows.grad.cpu().numpy(), wd.astype(np.float32))
+
+
+def _model_and_batch(cfg, gpu):
+    sys.path.insert(0, ROOT)
+    import bench
+    shard = bench.make_shard(cfg, 0, gpu)
+    step, model = bench.build_step(dict(cfg, graph=False), shard, gpu, 1)
+    gen = th.Generator().manual_seed(99)
+    with th.no_grad():                      # away from the zero-initialised head (tests/test_gpu_bench_composite.py)
+        for p in step.sync.params:
+            p.add_((0.05 * th.randn(p.shape, generator=gen)).to(gpu))
+    return bench, shard, step, model
+
+
+def _outputs_and_grads(bench, cfg, shard, step, model, lazy):
+    from dualmessagepassing_amd.collate import collate_device
+    p, g = shard["p"], shard["g"]
+    pattern = collate_device(p["local_src"], p["local_dst"], p["num_nodes"].clone(), p["num_edges"].clone(), p["N"], p["E"],
+                             ndata=p["ndata"], edata=dict(p["edata"]), max_nodes=p["max_n"], max_edges=p["max_e"])
+    graph = collate_device(g["local_src"], g["local_dst"], g["num_nodes"].clone(), g["num_edges"].clone(), g["N"], g["E"],
+                           ndata=g["ndata"], edata=dict(g["edata"]), max_nodes=g["max_n"], max_edges=g["max_e"])
+    model.lazy_edge_rep = lazy
+    step.sync.detach_grads()
+    out = model(pattern, graph)
+    from dualmessagepassing_amd.embed import materialize
+    vals = {k: materialize(v) for k, v in out.items()}
+    loss = th.nn.functional.mse_loss(out["pred_c"].view(-1), shard["counts"])
+    # a second term through the edge representation's rows, so that the expanded rows' backward is exercised as well
+    if not lazy:
+        w = th.linspace(-1.0, 1.0, vals["g_e_rep"].numel(), device=vals["g_e_rep"].device).view_as(vals["g_e_rep"])
+        loss = loss + 1e-3 * (vals["g_e_rep"] * w).sum()
+    loss.backward()
+    step.sync.pack()
+    return {k: (None if v is None else v.detach().float().cpu()) for k, v in vals.items() if not isinstance(v, tuple)}, step.sync.flat.detach().cpu().clone()
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_model_with_gate_capacity_equals_the_model_without(lazy):
+    gpu = th.device("cuda:0")
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = dict(bench.CFG, batch=96)
+    bench_, shard, step, model = _model_and_batch(cfg, gpu)
+    ref_out, ref_flat = _outputs_and_grads(bench_, cfg, shard, step, model, lazy)
+    p, g = shard["p"], shard["g"]
+    from dualmessagepassing_amd.collate import collate_device
+    pattern = collate_device(p["local_src"], p["local_dst"], p["num_nodes"], p["num_edges"], p["N"], p["E"], ndata=p["ndata"],
+                             edata=p["edata"], max_nodes=p["max_n"], max_edges=p["max_e"])
+    graph = collate_device(g["local_src"], g["local_dst"], g["num_nodes"], g["num_edges"], g["N"], g["E"], ndata=g["ndata"],
+                           edata=g["edata"], max_nodes=g["max_n"], max_edges=g["max_e"])
+    cap = model.calibrate_gate_capacity(pattern, graph, margin=1.1, multiple=256)
+    assert cap is not None and cap < 0.7 * g["E"], (cap, g["E"])
+    out, flat = _outputs_and_grads(bench_, cfg, shard, step, model, lazy)
+    assert model.compaction_status() == 0
+    assert set(out) == set(ref_out)
+    for k, v in ref_out.items():
+        if v is None:
+            assert out[k] is None
+            continue
+        assert out[k].shape == v.shape, k
+        s = max(1e-6, float(v.abs().max()))
+        assert float((out[k] - v).abs().max()) <= 2e-5 * s, (k, float((out[k] - v).abs().max()), s)
+    by = {}
+    for prm, off in zip(step.sync.params, step.sync.offsets):
+        by[off] = prm.numel()
+    for off, n in by.items():
+        a, b = flat[off:off + n], ref_flat[off:off + n]
+        s = float(b.abs().max())
+        if s == 0.0:
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert float((a - b).abs().max()) <= 5e-5 * s, (off, n, float((a - b).abs().max()), s)
+    # a capacity the batch does not fit in: flagged, not silently wrong
+    model.set_gate_capacity(1024)
+    _outputs_and_grads(bench_, cfg, shard, step, model, lazy)
+    assert model.compaction_status() & 1
+    assert model.compaction_status() == 0                      # cleared by the read
+    model.set_gate_capacity(None)
+
+
+def test_guarded_adamw_drops_a_flagged_step():
+    """``FlatAdamW.set_veto``: a step whose flag word is up leaves parameters, moments and the step count alone."""
+    from dualmessagepassing_amd.dp import FlatAdamW
+    gpu = th.device("cuda:0")
+    th.manual_seed(3)
+    p = th.nn.Parameter(th.randn(4099, device=gpu))
+    q = th.nn.Parameter(p.detach().clone())
+    word = th.zeros(4, dtype=th.int32, device=gpu)
+    opt = FlatAdamW([p], lr=1e-2, weight_decay=1e-2, amsgrad=True).set_veto(word, 1)
+    ref = FlatAdamW([q], lr=1e-2, weight_decay=1e-2, amsgrad=True, capturable=True)
+    grads = [th.randn(4099, device=gpu) for _ in range(3)]
+    p.grad, q.grad = grads[0].clone(), grads[0].clone()
+    opt.step(); ref.step()
+    assert th.equal(p, q) and word.tolist() == [0, 0, 0, 0]
+    before = p.detach().clone()
+    word[0] = 3                                                # bit 0 (vetoes) and bit 1 (does not)
+    p.grad = grads[1].clone()
+    opt.step()
+    assert th.equal(p, before) and word.tolist() == [0, 3, 1, 1]
+    p.grad, q.grad = grads[2].clone(), grads[2].clone()
+    opt.step(); ref.step()                                     # the guarded optimizer's SECOND counted step
+    assert th.equal(p, q) and word.tolist() == [0, 3, 0, 1]
+    word[0] = 2                                                # a flag outside the mask: the step goes ahead
+    p.grad, q.grad = grads[1].clone(), grads[1].clone()
+    opt.step(); ref.step()
+    assert th.equal(p, q) and word.tolist() == [0, 3, 0, 1]
+    opt.sync_state()
+    assert opt.state[p]["step"] == 3
+
+
+def test_fit_with_gate_compact_trains_like_fit_without():
+    """``harness.fit(gate_compact=True)``: same losses epoch by epoch as the run on every edge row, nothing dropped."""
+    from dualmessagepassing_amd import harness
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    gpu = th.device("cuda:0")
+    data = harness.SyntheticPairs(96, 4, 5, 24, 60, 6, 6, seed=5)
+    hist = {}
+    for mode in (False, True):
+        th.manual_seed(0)
+        model = build_model(**data.model_config(hid_dim=128, layers=3)).to(gpu)
+        sync = FlatGradSync(model)
+        master = sync.flatten_parameters()
+        opt = FlatAdamW([master], lr=1e-3, weight_decay=1e-5, amsgrad=True)
+        hist[mode] = harness.fit(model, opt, data.subset(range(64)), data.subset(range(64, 96)), 3, 32, gpu, sync=sync, seed=1,
+                                 gate_compact=1.35 if mode else False)
+        if mode:
+            assert model.gate_capacity, "the gate removed too little for a capacity to be set"
+            assert hist[mode][-1]["dropped_steps"] == 0
+    for a, b in zip(hist[False], hist[True]):
+        for part in ("train", "dev"):
+            for k, v in a[part].items():
+                assert abs(v - b[part][k]) <= 2e-4 * max(1.0, abs(v)), (part, k, v, b[part][k])

@@ -1173,3 +1173,40 @@ def test_one_pass_endpoint_sums_beside_other_kernels(gpu):
         bad["copy"] += int(not th.equal(cp, want_copy))
         bad["incidence"] += int(not th.equal(si, want))
     assert not any(bad.values()), bad
+
+
+def test_small_gemm_jobs_match_fp64(gpu):
+    """dmp_small_gemm_jobs: several small products in one launch -- plain and transposed operands, up to three terms,
+    an addend, operands and outputs that are column slices of wider tensors, ragged sizes (not multiples of the 16 x 64
+    tile), a job with K = 0 terms' worth of nothing but the addend."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(77)
+    r = lambda *s: th.randn(*s, generator=gen).to(gpu)
+    H = 128
+    W0, Wes, Bn, Wx = r(20, H), r(H, 2 * H), r(2 * H, H), r(H, 3 * H)
+    XX, Xn, Yn, WV0 = r(20, 3 * H), r(2, 20, H), r(4, 16, H), r(16, H)
+    outs = {"M0": th.empty(20, 2 * H, device=gpu), "dWes": th.empty(H, 2 * H, device=gpu), "dBn": th.empty(2 * H, H, device=gpu),
+            "dW0": th.empty(20, H, device=gpu), "dWx": th.full((H, 3 * H), 7.0, device=gpu), "dWV0": th.empty(16, H, device=gpu),
+            "odd": th.empty(5, 70, device=gpu)}
+    a5, b5 = r(5, 33), r(33, 70)
+    jobs = [(outs["M0"], [(W0, False, Wes, False)], None),
+            (outs["dWes"], [(W0, True, XX[:, :2 * H], False)], None),
+            (outs["dBn"][:H], [(W0, True, Xn[0], False)], None), (outs["dBn"][H:], [(W0, True, Xn[1], False)], None),
+            (outs["dW0"], [(XX[:, :2 * H], False, Wes, True), (Xn[0], False, Bn[:H], True), (Xn[1], False, Bn[H:], True)], XX[:, 2 * H:]),
+            (outs["dWx"][:, H:2 * H], [(WV0, True, Yn[1], False)], None),
+            (outs["dWV0"], [(Yn[b], False, Wx[:, b * H:(b + 1) * H], True) for b in range(3)], Yn[3]),
+            (outs["odd"], [(a5, False, b5, False)], None)]
+    fused.small_gemm_jobs(jobs)
+    d = lambda t: t.double()
+    want = {"M0": d(W0) @ d(Wes), "dWes": d(W0).t() @ d(XX[:, :2 * H]),
+            "dBn": th.cat([d(W0).t() @ d(Xn[0]), d(W0).t() @ d(Xn[1])]),
+            "dW0": d(XX[:, :2 * H]) @ d(Wes).t() + d(Xn[0]) @ d(Bn[:H]).t() + d(Xn[1]) @ d(Bn[H:]).t() + d(XX[:, 2 * H:]),
+            "dWV0": sum(d(Yn[b]) @ d(Wx[:, b * H:(b + 1) * H]).t() for b in range(3)) + d(Yn[3]), "odd": d(a5) @ d(b5)}
+    for k, w in want.items():
+        err = float((outs[k].double() - w).abs().max())
+        assert err <= 2e-5 * max(1.0, float(w.abs().max())), (k, err)
+    w = d(WV0).t() @ d(Yn[1])
+    assert float((outs["dWx"][:, H:2 * H].double() - w).abs().max()) <= 2e-5 * float(w.abs().max())
+    assert bool((outs["dWx"][:, :H] == 7.0).all()) and bool((outs["dWx"][:, 2 * H:] == 7.0).all())   # the slice only
+    with pytest.raises(Exception):
+        fused.small_gemm_jobs([(outs["odd"], [(a5, False, b5, True)], None)])                       # shapes that do not chain
