@@ -156,7 +156,7 @@ def model_config(cfg):
 
 def build_step(cfg, shard, device, world=1):
     from dualmessagepassing_amd.basemodel import build_model
-    from dualmessagepassing_amd.collate import collate_device
+    from dualmessagepassing_amd.collate import collate_device_many
     from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
     from dualmessagepassing_amd.dmpnn import prepare_joint
 
@@ -224,10 +224,11 @@ def build_step(cfg, shard, device, world=1):
         # timed is the step, not this emulation of a loader)
         (pn, pe, prev), (gn, ge, grev) = fresh_of(part)
         ped, ged = dict(p["edata"], is_reversed=prev), dict(g["edata"], is_reversed=grev)
-        pattern = collate_device(p["local_src"], p["local_dst"], pn, pe, p["N"], p["E"], ndata=p["ndata"], edata=ped,
-                                 max_nodes=p["max_n"], max_edges=p["max_e"])
-        graph = collate_device(g["local_src"], g["local_dst"], gn, ge, g["N"], g["E"], ndata=g["ndata"], edata=ged,
-                               max_nodes=g["max_n"], max_edges=g["max_e"])
+        pattern, graph = collate_device_many([                  # both batches in one pair of launches
+            dict(local_src=p["local_src"], local_dst=p["local_dst"], num_nodes=pn, num_edges=pe, total_nodes=p["N"], total_edges=p["E"],
+                 ndata=p["ndata"], edata=ped, max_nodes=p["max_n"], max_edges=p["max_e"]),
+            dict(local_src=g["local_src"], local_dst=g["local_dst"], num_nodes=gn, num_edges=ge, total_nodes=g["N"], total_edges=g["E"],
+                 ndata=g["ndata"], edata=ged, max_nodes=g["max_n"], max_edges=g["max_e"])])
         return pattern, graph
 
     def step_micro():

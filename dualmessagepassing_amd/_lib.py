@@ -56,6 +56,12 @@ SIGNATURES = {
     "dmp_seg_sum2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64,
                              c_int, c_ptr]),
     "dmp_small_gemm_jobs": (c_int, [c_ptr, c_int, c_ptr]),
+    "dmp_pool_index_jobs": (c_int, [c_ptr, c_int, c_ptr]),
+    "dmp_collate_jobs": (c_int, [c_ptr, c_int, c_ptr]),
+    "dmp_csr_build_graphs_max_nodes": (c_int, []),
+    "dmp_csr_build_graphs": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                     c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_pool_weight_sums": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_gate_compact_hist_nodes": (c_int, []),
     "dmp_gate_compact": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -167,7 +173,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 52
+ABI_VERSION = 53
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

@@ -294,20 +294,36 @@ def _pool_index(graph, kind, skip_reversed=True):
                  lambda: _Keep(ops.PoolIndex(sizes, flag, num_rows=rows), sizes, flag)).obj
 
 
-def _pool_index_union(pattern, graph, kind, skip_reversed=True):
-    """PoolIndex over [pattern graphs | target graphs] (2B segments) of the union row order."""
+def _pool_union_spec(pattern, graph, kind, skip_reversed):
     if kind == "node":
         a, b, fa, fb = pattern.batch_num_nodes(), graph.batch_num_nodes(), None, None
     else:
         a, b = pattern.batch_num_edges(), graph.batch_num_edges()
         fa, fb = (pattern.edata.get(REVFLAG), graph.edata.get(REVFLAG)) if skip_reversed else (None, None)
-
     rows = (pattern.number_of_nodes() + graph.number_of_nodes() if kind == "node"
             else pattern.number_of_edges() + graph.number_of_edges())                     # host ints: no sync in the build
+    key = ("upool", _tensor_key(a), _tensor_key(b), _tensor_key(fa), _tensor_key(fb))
+    return key, ((a, b), None if fa is None or fb is None else (fa, fb), rows), (a, b, fa, fb)
 
-    def build():   # sizes / flags as (pattern, target) pairs: built on the device without concatenating them first
-        return _Keep(ops.PoolIndex((a, b), None if fa is None or fb is None else (fa, fb), num_rows=rows), a, b, fa, fb)
-    return _memo(("upool", _tensor_key(a), _tensor_key(b), _tensor_key(fa), _tensor_key(fb)), build).obj
+
+def _pool_index_union(pattern, graph, kind, skip_reversed=True):
+    """PoolIndex over [pattern graphs | target graphs] (2B segments) of the union row order."""
+    return _pool_indexes_union(pattern, graph, (kind,), skip_reversed)[0]
+
+
+def _pool_indexes_union(pattern, graph, kinds, skip_reversed=True):
+    """``_pool_index_union`` for several element kinds: the indexes that are not memoised yet are built together (sizes /
+    flags as (pattern, target) pairs, on the device without concatenating them first: one pair of launches for all)."""
+    specs = [_pool_union_spec(pattern, graph, k, skip_reversed) for k in kinds]
+    missing = [i for i, (key, _, _) in enumerate(specs) if key not in _SIZE_CACHE]
+    if missing:
+        if all(th.is_tensor(specs[i][2][0]) and specs[i][2][0].is_cuda for i in missing):
+            built = ops.pool_indexes([specs[i][1] for i in missing])
+        else:
+            built = [ops.PoolIndex(specs[i][1][0], specs[i][1][1], num_rows=specs[i][1][2]) for i in missing]
+        for i, obj in zip(missing, built):
+            _memo(specs[i][0], lambda obj=obj, i=i: _Keep(obj, *specs[i][2]))
+    return [_memo(key, None).obj for key, _, _ in specs]
 
 
 class _Keep:
@@ -886,8 +902,9 @@ class GraphAdjModelV2(BaseModel):
                 # then never builds the [E, H] gradient of the edge representation, fused._FusedDMPLayer)
                 pools = None
                 if pooled and not self.pred_with_enc and not self.pred_with_deg and (self.node_pred or self.edge_pred):
-                    pools = (_pool_index_union(pattern, rg, "node") if self.node_pred else None,
-                             _pool_index_union(pattern, rg, "edge", skip_rev) if self.edge_pred else None)
+                    kinds = [k for k, on in (("node", self.node_pred), ("edge", self.edge_pred)) if on]
+                    built = dict(zip(kinds, _pool_indexes_union(pattern, rg, kinds, skip_rev)))      # one pair of launches
+                    pools = (built.get("node"), built.get("edge"))
                 if with_pools:
                     return self.get_joint_rep(pattern, rg, p_v_emb, p_e_emb, g_v_emb, e_emb, vl_gate, e_gate, pools=pools)
                 return self.get_joint_rep(pattern, rg, p_v_emb, p_e_emb, g_v_emb, e_emb, vl_gate, e_gate)   # no pooled form

@@ -55,6 +55,65 @@ def collate_device(local_src, local_dst, num_nodes, num_edges, total_nodes, tota
     return g
 
 
+_COLLATE_JOB = None
+
+
+def collate_device_many(batches):
+    """``collate_device`` for several batches -- the pattern batch and the target batch of a step -- in ONE pair of launches
+    (``dmp_collate_jobs``).  ``batches``: list of dicts with ``collate_device``'s arguments (``local_src``, ``local_dst``,
+    ``num_nodes``, ``num_edges``, ``total_nodes``, ``total_edges`` and optionally ``ndata``, ``edata``, ``max_nodes``,
+    ``max_edges``).  Returns the BatchedGraphs in order."""
+    global _COLLATE_JOB
+    import ctypes
+    lib = _lib.load()
+    if _COLLATE_JOB is None:
+        P, I = ctypes.c_void_p, ctypes.c_int64
+
+        class _Job(ctypes.Structure):
+            _fields_ = [("local_src", P), ("local_dst", P), ("num_nodes", P), ("num_edges", P), ("B", I), ("N", I), ("E", I),
+                        ("node_off", P), ("edge_off", P), ("src", P), ("dst", P), ("edge_graph", P), ("node_graph", P)]
+        _COLLATE_JOB = _Job
+    if not 0 < len(batches) <= 4 or any(int(b["num_nodes"].numel()) == 0 or int(b["num_nodes"].numel()) > 2048 for b in batches):
+        return [collate_device(b["local_src"], b["local_dst"], b["num_nodes"], b["num_edges"], b["total_nodes"], b["total_edges"],
+                               b.get("ndata"), b.get("edata"), True, b.get("max_nodes"), b.get("max_edges")) for b in batches]
+    J = (_COLLATE_JOB * len(batches))()
+    made, keep = [], []
+    for k, b in enumerate(batches):
+        ls, ld, nn, ne = b["local_src"], b["local_dst"], b["num_nodes"], b["num_edges"]
+        _lib.require_gpu(ls, ld, nn, ne)
+        for t in (ls, ld, nn, ne):
+            if t.dtype != torch.int64:
+                raise _lib.DmpError("collate inputs must be int64")
+        ls, ld, nn, ne = ls.contiguous(), ld.contiguous(), nn.contiguous(), ne.contiguous()
+        B, N, E = int(nn.numel()), int(b["total_nodes"]), int(b["total_edges"])
+        if ls.numel() != E or ld.numel() != E or ne.numel() != B:
+            raise _lib.DmpError("collate: inconsistent sizes")
+        dev = ls.device
+        offs = torch.empty(2 * (B + 1), dtype=torch.int64, device=dev)
+        ends = torch.empty((2, E), dtype=torch.int64, device=dev)
+        eg = torch.empty(E, dtype=torch.int32, device=dev)
+        ng = torch.empty(N, dtype=torch.int32, device=dev)
+        j = J[k]
+        j.local_src, j.local_dst, j.num_nodes, j.num_edges, j.B, j.N, j.E = ptr(ls), ptr(ld), ptr(nn), ptr(ne), B, N, E
+        j.node_off, j.edge_off, j.src, j.dst = ptr(offs[:B + 1]), ptr(offs[B + 1:]), ptr(ends[0]), ptr(ends[1])
+        j.edge_graph, j.node_graph = ptr(eg), ptr(ng)
+        keep.append((ls, ld, nn, ne))
+        made.append((b, nn, ne, N, B, offs, ends, eg, ng))
+    check(lib.dmp_collate_jobs(J, len(batches), stream_ptr()), "dmp_collate_jobs")
+    from . import ops
+    out = []
+    for b, nn, ne, N, B, offs, ends, eg, ng in made:
+        g = BatchedGraph(ends[0], ends[1], N, nn, ne, b.get("ndata"), b.get("edata"))
+        g.node_graph, g.edge_graph = ng, eg
+        g.node_offsets, g.edge_offsets = offs[:B + 1], offs[B + 1:]
+        g.max_num_nodes = None if b.get("max_nodes") is None else int(b["max_nodes"])
+        g.max_num_edges = None if b.get("max_edges") is None else int(b["max_edges"])
+        g.tiling = ops.graph_tiling(g.node_offsets, g.edge_offsets, B, g.max_num_edges)
+        g.node_tiling = ops.graph_node_tiling(g.node_offsets, g.edge_offsets, B, g.max_num_nodes)
+        out.append(g)
+    return out
+
+
 def batch(graphs, device=None):
     """``Graph.batch(list_of_graphs)`` (dataset.py:1320-1328): list of single graphs -> one
     block-diagonal BatchedGraph on ``device`` (default: the graphs' device, which must be a GPU)."""

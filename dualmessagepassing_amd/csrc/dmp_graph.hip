@@ -151,13 +151,7 @@ __device__ void sift_down(int32_t *a, int start, int end) {
     root = sw;
   }
 }
-__device__ __forceinline__ void csr_sort_row(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ ent,
-                                             int64_t *__restrict__ degree, int64_t r) {
-  if (r >= N) return;
-  const int beg = rowptr[r], end = rowptr[r + 1];
-  const int n = end - beg;
-  if (degree) degree[r] = n;
-  int32_t *a = ent + beg;
+__device__ __forceinline__ void csr_sort_span(int32_t *__restrict__ a, const int n) {
   if (n <= kRegSort) {
     // Short rows (the common case): one batch of loads, a bitonic network in
     // registers, one batch of stores -- no dependent global round trips.
@@ -197,6 +191,13 @@ __device__ __forceinline__ void csr_sort_row(const int32_t *__restrict__ rowptr,
       sift_down(a, 0, e - 1);
     }
   }
+}
+__device__ __forceinline__ void csr_sort_row(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ ent,
+                                             int64_t *__restrict__ degree, int64_t r) {
+  if (r >= N) return;
+  const int beg = rowptr[r], end = rowptr[r + 1];
+  if (degree) degree[r] = end - beg;
+  csr_sort_span(ent + beg, end - beg);
 }
 
 __global__ __launch_bounds__(kBlock) void csr_sort_rows(const int32_t *__restrict__ rowptr, int64_t N,
@@ -285,6 +286,69 @@ __global__ __launch_bounds__(kBlock) void csr_fill_pair(const CsrPair p, const u
 __global__ __launch_bounds__(kBlock) void csr_sort_rows_pair(const CsrPair p, int64_t N) {
   const int y = blockIdx.y;
   csr_sort_row(p.rowptr[y], N, p.ent[y], p.degree[y], (int64_t)blockIdx.x * kBlock + threadIdx.x);
+}
+
+// ---- both CSRs of a BLOCK-DIAGONAL batch in ONE launch (dmp_csr_build_graphs): a workgroup per graph.  The edges of
+// graph g are rows [edge_off[g], edge_off[g + 1]) of both entry arrays and touch only its nodes, so the degree counters, their
+// prefix sums and the fill cursors of a graph live in LDS (a graph of at most kCsrGraphNodes nodes): count -> scan -> fill ->
+// sort every row by edge id, with workgroup barriers between the phases instead of eight dispatches and a zeroed scratch.
+constexpr int kCsrGraphNodes = 2048;
+struct CsrGraphs {
+  const int64_t *key[2]; const uint8_t *flag; const int64_t *node_off, *edge_off; int64_t B, N, E;
+  int32_t *rowptr[2], *ent[2], *key32[2]; int64_t *degree[2]; int32_t *status;
+};
+__global__ __launch_bounds__(kBlock) void csr_graphs_k(const CsrGraphs p) {
+  __shared__ int32_t cnt[2][kCsrGraphNodes];
+  __shared__ int32_t lds[kBlock / kWave];
+  const int64_t g = blockIdx.x;
+  const int64_t n0 = p.node_off[g], e0 = p.edge_off[g], e1 = p.edge_off[g + 1];
+  const int n = (int)(p.node_off[g + 1] - n0);
+  for (int i = threadIdx.x; i < n; i += kBlock) { cnt[0][i] = 0; cnt[1][i] = 0; }
+  __syncthreads();
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int64_t k = p.key[y][e];
+      const bool ok = k >= n0 && k < n0 + n;
+      if (p.key32[y]) p.key32[y][e] = ok ? (int32_t)k : 0;
+      if (ok) atomicAdd(&cnt[y][k - n0], 1);
+      else atomicOr(p.status + y, 1);
+    }
+  }
+  __syncthreads();
+  const int ipt = (n + kBlock - 1) / kBlock, base = threadIdx.x * ipt;        // consecutive nodes per thread
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    int32_t sum = 0;
+    for (int i = base; i < base + ipt && i < n; ++i) sum += cnt[y][i];
+    int32_t total;
+    int32_t pre = (int32_t)e0 + block_exclusive_scan<int32_t>(sum, lds, total);
+    for (int i = base; i < base + ipt && i < n; ++i) {
+      const int32_t v = cnt[y][i];
+      p.rowptr[y][n0 + i] = pre;
+      cnt[y][i] = pre;                                                        // the row's fill cursor
+      pre += v;
+    }
+    if (g == p.B - 1 && threadIdx.x == 0) p.rowptr[y][p.N] = (int32_t)p.E;
+  }
+  __syncthreads();
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
+    const int32_t v = ((int32_t)e << 1) | (p.flag ? (p.flag[e] ? 1 : 0) : 0);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int64_t k = p.key[y][e];
+      if (k >= n0 && k < n0 + n) p.ent[y][atomicAdd(&cnt[y][k - n0], 1)] = v;
+    }
+  }
+  __syncthreads();                                                            // the entries of this graph are in place (same workgroup)
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int beg = i == 0 ? (int)e0 : cnt[y][i - 1], end = cnt[y][i];      // a cursor ends where the next row begins
+      if (p.degree[y]) p.degree[y][n0 + i] = end - beg;
+      csr_sort_span(p.ent[y] + beg, end - beg);
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void copy_i32(const int32_t *__restrict__ a, int64_t n,
@@ -386,6 +450,46 @@ __global__ __launch_bounds__(kBlock) void collate_both(const int64_t *__restrict
   } else {
     if (i >= N || !node_graph) return;
     node_graph[i] = (int32_t)upper_graph(node_off, B, i);
+  }
+}
+
+// several batches (the pattern batch and the target batch of a step) in the same two launches: blockIdx.y = 2 job + part
+struct CollateJobs { dmp_collate_job job[DMP_COLLATE_MAX_JOBS]; };
+__global__ __launch_bounds__(kBlock) void collate_offsets_jobs(const CollateJobs t) {
+  __shared__ int64_t lds[kBlock / kWave];
+  const dmp_collate_job &j = t.job[blockIdx.y >> 1];
+  const int64_t *__restrict__ in = (blockIdx.y & 1) == 0 ? j.num_nodes : j.num_edges;
+  int64_t *__restrict__ out = (blockIdx.y & 1) == 0 ? j.node_off : j.edge_off;
+  const int64_t base = (int64_t)threadIdx.x * kScanItems;
+  int64_t v[kScanItems];
+  int64_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < j.B) ? in[base + k] : 0;
+    sum += v[k];
+  }
+  int64_t total;
+  int64_t pre = block_exclusive_scan<int64_t>(sum, lds, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < j.B) out[base + k] = pre;
+    pre += v[k];
+  }
+  if (threadIdx.x == 0) out[j.B] = total;
+}
+__global__ __launch_bounds__(kBlock) void collate_both_jobs(const CollateJobs t) {
+  const dmp_collate_job &j = t.job[blockIdx.y >> 1];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((blockIdx.y & 1) == 0) {
+    if (i >= j.E) return;
+    const int64_t g = upper_graph(j.edge_off, j.B, i);
+    const int64_t o = j.node_off[g];
+    j.src[i] = j.local_src[i] + o;
+    j.dst[i] = j.local_dst[i] + o;
+    if (j.edge_graph) j.edge_graph[i] = (int32_t)g;
+  } else {
+    if (i >= j.N || !j.node_graph) return;
+    j.node_graph[i] = (int32_t)upper_graph(j.node_off, j.B, i);
   }
 }
 
@@ -691,9 +795,13 @@ struct PoolArgs {
   const uint8_t *flag_a, *flag_b; int64_t Ra;                // rows [0, Ra) take flag_a, the rest flag_b (NULL: 0)
   int64_t R, V; int chunk;
   int64_t *off; int32_t *gptr, *vptr, *vent, *gent, *seg;
+  uint8_t *flag8; int32_t *rowmap; int64_t *sizes;           // optional: both pieces' flags / sizes back to back; seg or -1 if flagged
 };
+struct PoolJobs { PoolArgs job[DMP_POOL_MAX_JOBS]; };
 
-__global__ __launch_bounds__(kBlock) void pool_offsets_k(PoolArgs a) {
+// blockIdx.x = job
+__global__ __launch_bounds__(kBlock) void pool_offsets_k(const PoolJobs jobs) {
+  const PoolArgs &a = jobs.job[blockIdx.x];
   __shared__ int64_t s_rows[kBlock], s_chunks[kBlock];
   __shared__ int64_t base_rows, base_chunks;
   const int64_t B = a.Ba + a.Bb;
@@ -703,6 +811,7 @@ __global__ __launch_bounds__(kBlock) void pool_offsets_k(PoolArgs a) {
     const int64_t i = i0 + threadIdx.x;
     int64_t n = 0;
     if (i < B) n = i < a.Ba ? a.sizes_a[i] : a.sizes_b[i - a.Ba];
+    if (i < B && a.sizes) a.sizes[i] = n;
     s_rows[threadIdx.x] = n;
     s_chunks[threadIdx.x] = (n + a.chunk - 1) / a.chunk;
     __syncthreads();
@@ -723,14 +832,22 @@ __global__ __launch_bounds__(kBlock) void pool_offsets_k(PoolArgs a) {
   }
 }
 
-__global__ void pool_fill_k(PoolArgs a) {
+// blockIdx.y = job
+__global__ void pool_fill_k(const PoolJobs jobs) {
+  const PoolArgs &a = jobs.job[blockIdx.y];
   const int64_t B = a.Ba + a.Bb;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t < a.R) {
     const uint8_t *f = t < a.Ra ? a.flag_a : a.flag_b;
     const int64_t fi = t < a.Ra ? t : t - a.Ra;
-    a.vent[t] = (int32_t)((t << 1) | (f ? (f[fi] != 0) : 0));
-    if (a.seg) a.seg[t] = (int32_t)upper_slot(a.off, B, t);  // off[i] <= t < off[i+1] (empty graphs are skipped)
+    const int fl = f ? (f[fi] != 0) : 0;
+    a.vent[t] = (int32_t)((t << 1) | fl);
+    if (a.flag8) a.flag8[t] = (uint8_t)fl;
+    if (a.seg || a.rowmap) {
+      const int32_t g = (int32_t)upper_slot(a.off, B, t);     // off[i] <= t < off[i+1] (empty graphs are skipped)
+      if (a.seg) a.seg[t] = g;
+      if (a.rowmap) a.rowmap[t] = fl ? -1 : g;
+    }
   }
   if (t <= a.V) {
     int64_t first = a.R;                                      // unused tail chunks (and the closing entry): empty at the end
@@ -744,6 +861,26 @@ __global__ void pool_fill_k(PoolArgs a) {
     }
     a.vptr[t] = (int32_t)first;
     if (t < a.V) a.gent[t] = (int32_t)(t << 1);
+  }
+}
+
+// sum of a row weight per graph (and flag half): a wave per graph
+__global__ __launch_bounds__(kBlock) void pool_weight_sums_k(const float *__restrict__ w, const uint8_t *__restrict__ flag8,
+                                                             const int64_t *__restrict__ off, int64_t B, int halves,
+                                                             float *__restrict__ out) {
+  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (g >= B) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int64_t r = off[g] + lane; r < off[g + 1]; r += kWave) {
+    const float v = w ? w[r] : 1.f;
+    if (halves == 2 && flag8[r]) s1 += v; else s0 += v;
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, kWave); s1 += __shfl_xor(s1, o, kWave); }
+  if (lane == 0) {
+    out[g * halves] = s0;
+    if (halves == 2) out[g * halves + 1] = s1;
   }
 }
 
@@ -1202,6 +1339,23 @@ int dmp_csr_build_pair(const int64_t *dst, const int64_t *src, const uint8_t *fl
   return check_launch();
 }
 
+int dmp_csr_build_graphs_max_nodes(void) { return kCsrGraphNodes; }
+
+int dmp_csr_build_graphs(const int64_t *dst, const int64_t *src, const uint8_t *flag, const int64_t *node_off,
+                         const int64_t *edge_off, int64_t B, int64_t E, int64_t N, int32_t *in_ptr, int32_t *in_ent,
+                         int32_t *dst32, int64_t *in_deg, int32_t *out_ptr, int32_t *out_ent, int32_t *src32,
+                         int64_t *out_deg, int32_t *status, void *stream) {
+  if (E < 0 || N < 0 || B <= 0 || !in_ptr || !out_ptr || !status || !node_off || !edge_off) return DMP_ERR_BAD_ARG;
+  if (E > 0 && (!dst || !src || !in_ent || !out_ent)) return DMP_ERR_BAD_ARG;
+  if (E >= ((int64_t)1 << 30) || N >= ((int64_t)1 << 31) - 1 || B > 0x7fffffff) return DMP_ERR_UNSUPPORTED;
+  CsrGraphs p;
+  p.key[0] = dst; p.key[1] = src; p.flag = flag; p.node_off = node_off; p.edge_off = edge_off; p.B = B; p.N = N; p.E = E;
+  p.rowptr[0] = in_ptr; p.rowptr[1] = out_ptr; p.ent[0] = in_ent; p.ent[1] = out_ent;
+  p.key32[0] = dst32; p.key32[1] = src32; p.degree[0] = in_deg; p.degree[1] = out_deg; p.status = status;
+  csr_graphs_k<<<(unsigned)B, kBlock, 0, (hipStream_t)stream>>>(p);
+  return check_launch();
+}
+
 int dmp_csr_build(const int64_t *key, const uint8_t *flag, int64_t E, int64_t N, int32_t *rowptr,
                   int32_t *ent, int32_t *key32, int64_t *degree, int32_t *status, int32_t *ws,
                   void *stream) {
@@ -1276,6 +1430,25 @@ int dmp_collate(const int64_t *local_src, const int64_t *local_dst, const int64_
     collate_both<<<dim3(nblk(most), nodes ? 2 : 1), kBlock, 0, st>>>(local_src, local_dst, node_off, edge_off, B, E, N, src, dst,
                                                                    edge_graph, node_graph);
   }
+  return check_launch();
+}
+
+int dmp_collate_jobs(const dmp_collate_job *jobs, int n, void *stream) {
+  if (!jobs || n < 1 || n > DMP_COLLATE_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  CollateJobs t;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const dmp_collate_job &j = jobs[i];
+    if (j.B <= 0 || j.N < 0 || j.E < 0 || !j.node_off || !j.edge_off || !j.num_nodes || !j.num_edges) return DMP_ERR_BAD_ARG;
+    if (j.E > 0 && (!j.local_src || !j.local_dst || !j.src || !j.dst)) return DMP_ERR_BAD_ARG;
+    if (j.B > kScanTile) return DMP_ERR_UNSUPPORTED;         // sizes are scanned by single-tile launches, as in dmp_collate
+    t.job[i] = j;
+    const int64_t m = j.E > j.N ? j.E : j.N;
+    if (m > most) most = m;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  collate_offsets_jobs<<<dim3(1, 2 * n), kBlock, 0, st>>>(t);
+  if (most > 0) collate_both_jobs<<<dim3(nblk(most), 2 * n), kBlock, 0, st>>>(t);
   return check_launch();
 }
 
@@ -1366,18 +1539,41 @@ int dmp_sample_in_edges(const int32_t *in_ptr, const int32_t *in_ent, const uint
   return check_launch();
 }
 
+int dmp_pool_index_jobs(const dmp_pool_job *jobs, int n, void *stream) {
+  if (!jobs || n < 1 || n > DMP_POOL_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  PoolJobs t;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const dmp_pool_job &j = jobs[i];
+    if (j.Ba < 0 || j.Bb < 0 || j.R < 0 || j.rows_a < 0 || j.rows_a > j.R || j.chunk <= 0) return DMP_ERR_BAD_ARG;
+    if (!j.off || !j.gptr || !j.vptr || (j.Ba > 0 && !j.sizes_a) || (j.Bb > 0 && !j.sizes_b)) return DMP_ERR_BAD_ARG;
+    if (j.R >= ((int64_t)1 << 30)) return DMP_ERR_UNSUPPORTED;     // (row << 1) | flag in 32 bits
+    PoolArgs a{j.sizes_a, j.sizes_b, j.Ba, j.Bb, j.flag_a, j.flag_b, j.rows_a, j.R, j.R / j.chunk + j.Ba + j.Bb, j.chunk, j.off,
+               j.gptr, j.vptr, j.vent, j.gent, j.seg, j.flag8, j.rowmap, j.sizes};
+    if ((a.R > 0 && !a.vent) || (a.V > 0 && !a.gent)) return DMP_ERR_BAD_ARG;
+    t.job[i] = a;
+    const int64_t m = a.R > a.V + 1 ? a.R : a.V + 1;
+    if (m > most) most = m;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  pool_offsets_k<<<(unsigned)n, kBlock, 0, st>>>(t);
+  pool_fill_k<<<dim3((unsigned)nblk(most), (unsigned)n), kBlock, 0, st>>>(t);
+  return check_launch();
+}
+
 int dmp_pool_index(const int64_t *sizes_a, int64_t Ba, const int64_t *sizes_b, int64_t Bb, const uint8_t *flag_a,
                    const uint8_t *flag_b, int64_t rows_a, int64_t R, int chunk, int64_t *off, int32_t *gptr, int32_t *vptr,
                    int32_t *vent, int32_t *gent, int32_t *seg, void *stream) {
-  if (Ba < 0 || Bb < 0 || R < 0 || rows_a < 0 || rows_a > R || chunk <= 0) return DMP_ERR_BAD_ARG;
-  if (!off || !gptr || !vptr || (Ba > 0 && !sizes_a) || (Bb > 0 && !sizes_b)) return DMP_ERR_BAD_ARG;
-  if (R >= ((int64_t)1 << 30)) return DMP_ERR_UNSUPPORTED;     // (row << 1) | flag in 32 bits
-  PoolArgs a{sizes_a, sizes_b, Ba, Bb, flag_a, flag_b, rows_a, R, R / chunk + Ba + Bb, chunk, off, gptr, vptr, vent, gent, seg};
-  if ((R > 0 && !vent) || (a.V > 0 && !gent)) return DMP_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  pool_offsets_k<<<1, kBlock, 0, st>>>(a);
-  const int64_t n = (R > a.V + 1 ? R : a.V + 1);
-  pool_fill_k<<<nblk(n), kBlock, 0, st>>>(a);
+  dmp_pool_job j{sizes_a, sizes_b, Ba, Bb, flag_a, flag_b, rows_a, R, chunk, off, gptr, vptr, vent, gent, seg, nullptr, nullptr,
+                 nullptr};
+  return dmp_pool_index_jobs(&j, 1, stream);
+}
+
+int dmp_pool_weight_sums(const float *w, const uint8_t *flag8, const int64_t *off, int64_t B, float *out, void *stream) {
+  if (B < 0) return DMP_ERR_BAD_ARG;
+  if (B == 0) return DMP_OK;
+  if (!off || !out) return DMP_ERR_BAD_ARG;
+  pool_weight_sums_k<<<nblk(B * kWave), kBlock, 0, (hipStream_t)stream>>>(w, flag8, off, B, flag8 ? 2 : 1, out);
   return check_launch();
 }
 

@@ -180,9 +180,23 @@ def pool_rows(x, pool, weight=None):
     return ops.seg_sum_raw(part, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
 
 
+def pool_weight_sums(pool, weight=None):
+    """[G, 1] per-graph sums of a row weight over ``pool`` (``ops.PoolIndex``), [G, 2] = [non-flagged | flagged] when the
+    index carries a flag; ``weight`` None: row counts (``dmp_pool_weight_sums``)."""
+    lib = _lib.load()
+    if not getattr(pool, "rows_in_order", False):
+        raise _lib.DmpError("pool_weight_sums: an index over rows in their own order")
+    halves = 2 if pool.flag8 is not None else 1
+    out = torch.empty((pool.num_graphs, halves), dtype=torch.float32, device=pool.offsets.device)
+    w = None if weight is None else weight.reshape(-1).contiguous()
+    check(lib.dmp_pool_weight_sums(ptr(w), ptr(pool.flag8), ptr(pool.offsets), pool.num_graphs, ptr(out), stream_ptr()),
+          "dmp_pool_weight_sums")
+    return out
+
+
 def pool_rowmap(pool):
     """int32 [rows]: the graph of every row, -1 for flagged rows (they are masked out of the pooled sum)."""
-    m = getattr(pool, "_rowmap", None)
+    m = getattr(pool, "_rowmap", None)                  # written by the index build itself (dmp_pool_index_jobs) where it ran
     if m is None:
         m = pool.seg32 if pool.flag8 is None else torch.where(pool.flag8 != 0, torch.full_like(pool.seg32, -1), pool.seg32)
         pool._rowmap = m
@@ -887,7 +901,7 @@ class _FusedDMPLayer(torch.autograd.Function):
             else:
                 WB = torch.matmul(W0, Bn.view(2, H, H))                                              # [2, T K, H]
             SB = torch.empty((N, H), dtype=torch.float32, device=z.device)
-            for t, _, (n0, n1) in tables:
+            for t, _, (n0, n1) in tables:      # (N-row products: the small-product kernel is built for a few hundred rows)
                 if n1 > n0:
                     torch.mm(S0[n0:n1, :K0], WB[0, t * K0:(t + 1) * K0], out=SB[n0:n1])
                     SB[n0:n1].addmm_(S0[n0:n1, Kp:Kp + K0], WB[1, t * K0:(t + 1) * K0])
@@ -948,12 +962,17 @@ class _FusedDMPLayer(torch.autograd.Function):
             halves = 2 if epool.flag8 is not None else 1
             G_ = epool.num_graphs
             Q = pool_rows(H1e, epool, e_gate).view(G_ * halves, H)                      # sum of g H1 per graph (and flag)
-            ones = (e_gate if e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
-            cnt = pool_rows(ones.view(-1, 1).repeat(1, 4), epool).view(G_ * halves, 4)[:, :1]   # sum of g (vector kernel: 4 equal columns)
-            ctx.gcnt = cnt.view(G_, halves)                                                  # the backward's db2 needs them again
-            es = torch.addmm(cnt * eb2, Q, eW2.t())
-            if residual:
-                es = es + pool_rows(z, epool).view(G_ * halves, H)
+            cnt = pool_weight_sums(epool, e_gate)                                        # sum of g per graph (and flag)
+            ctx.gcnt = cnt                                                               # the backward's db2 needs them again
+            cnt = cnt.view(G_ * halves, 1)
+            zs = pool_rows(z, epool).view(G_ * halves, H) if residual else None
+            if USE_SMALL_GEMM_JOBS and Q.is_contiguous() and eW2.is_contiguous():
+                es = torch.empty((G_ * halves, H), dtype=torch.float32, device=Q.device)  # Q W2^T + cnt b2 (+ sum of z): one launch
+                small_gemm_jobs([(es, [(Q, False, eW2, True), (cnt, False, eb2.view(1, H), False)], zs)])
+            else:
+                es = torch.addmm(cnt * eb2, Q, eW2.t())
+                if residual:
+                    es = es + zs
             # ... of which only the NON-FLAGGED half is returned ([G, H]): without the rows the backward propagates a gradient
             # through that half only (the row map is -1 for flagged rows), so the flagged sums are not handed out as if they
             # were differentiable (the heads mask reversed edges out and read [:, :H] anyway, basemodel.py:1545-1631)
@@ -1011,11 +1030,10 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dG, dbe = relu_bwd_gathered_colsum(T @ eW2, emap, ctx.e_gate, H1e, slope)
                     Q = pool_rows(H1e, ep, ctx.e_gate)[:, :H]
                 dW2e = T.t() @ Q
-                # gated row counts per graph through the vector kernel (4 equal columns: the scalar path is slow)
+                # gated row counts per graph
                 gcnt = getattr(ctx, "gcnt", None)
                 if gcnt is None:
-                    g4 = (ctx.e_gate if ctx.e_gate is not None else torch.ones(H1e.size(0), dtype=torch.float32, device=H1e.device))
-                    gcnt = pool_rows(g4.view(-1, 1).repeat(1, 4), ep)
+                    gcnt = pool_weight_sums(ep, ctx.e_gate)
                 db2e = gcnt[:, 0] @ T
             elif typed:
                 # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)

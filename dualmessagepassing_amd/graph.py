@@ -12,6 +12,8 @@ Degree caching follows ``dataset.Graph.in_degrees/out_degrees``
 Edges are kept in eid order; CSR arrays are an *index* into that order and never
 reorder features (outputs of every layer stay in eid order).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -31,6 +33,9 @@ class function:  # namespace mirroring ``import dgl.function as fn``
     sum = SumReducer
 
 
+USE_GRAPH_CSR = os.environ.get("DMP_GRAPH_CSR", "1") == "1"   # block-diagonal batches: both CSRs from ONE launch (dmp_csr_build_graphs)
+
+
 class GraphIndex:
     """Device-resident integer index of one (batched) graph.
 
@@ -41,7 +46,9 @@ class GraphIndex:
     in_deg/out_deg  int64 degree vectors (structure-derived)
     """
 
-    def __init__(self, src, dst, num_nodes, rev=None, validate=False):
+    _status = {}     # device -> int32 [2] that the one-launch build ORs into (cleared when a validation reads it)
+
+    def __init__(self, src, dst, num_nodes, rev=None, validate=False, offsets=None):
         lib = _lib.load()
         _lib.require_gpu(src, dst, rev)
         if src.dtype != torch.int64 or dst.dtype != torch.int64:
@@ -61,8 +68,6 @@ class GraphIndex:
                 raise _lib.DmpError("is_reversed must have one entry per edge")
         self.rev8 = rev
         i32 = dict(dtype=torch.int32, device=dev)
-        ws = torch.empty(lib.dmp_csr_pair_workspace_words(N), **i32)
-        status = torch.empty(2, **i32)
         self.in_ptr = torch.empty(N + 1, **i32)
         self.in_ent = torch.empty(E, **i32)
         self.dst32 = torch.empty(E, **i32)
@@ -71,17 +76,33 @@ class GraphIndex:
         self.out_ent = torch.empty(E, **i32)
         self.src32 = torch.empty(E, **i32)
         self.out_deg = torch.empty(N, dtype=torch.int64, device=dev)
-        # the in-CSR (by destination) and the out-CSR (by source) side by side: one set of dispatches for both
-        check(lib.dmp_csr_build_pair(ptr(dst), ptr(src), ptr(rev), E, N,
-                                     ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32), ptr(self.in_deg),
-                                     ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32), ptr(self.out_deg),
-                                     ptr(status), ptr(ws), stream_ptr()), "dmp_csr_build_pair")
+        if offsets is not None and E > 0 and N > 0:
+            # a block-diagonal batch whose graphs fit a workgroup's LDS counters (``offsets`` = node offsets, edge offsets,
+            # number of graphs; the caller checked the largest graph): both CSRs in ONE launch
+            node_off, edge_off, B = offsets
+            status = GraphIndex._status.get(dev)
+            if status is None:
+                status = GraphIndex._status[dev] = torch.zeros(2, **i32)
+            check(lib.dmp_csr_build_graphs(ptr(dst), ptr(src), ptr(rev), ptr(node_off), ptr(edge_off), int(B), E, N,
+                                           ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32), ptr(self.in_deg),
+                                           ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32), ptr(self.out_deg),
+                                           ptr(status), stream_ptr()), "dmp_csr_build_graphs")
+        else:
+            ws = torch.empty(lib.dmp_csr_pair_workspace_words(N), **i32)
+            status = torch.empty(2, **i32)
+            # the in-CSR (by destination) and the out-CSR (by source) side by side: one set of dispatches for both
+            check(lib.dmp_csr_build_pair(ptr(dst), ptr(src), ptr(rev), E, N,
+                                         ptr(self.in_ptr), ptr(self.in_ent), ptr(self.dst32), ptr(self.in_deg),
+                                         ptr(self.out_ptr), ptr(self.out_ent), ptr(self.src32), ptr(self.out_deg),
+                                         ptr(status), ptr(ws), stream_ptr()), "dmp_csr_build_pair")
         self._inc = None
         self._coef = {}
         self.tiling = None
         self.node_tiling = None      # ops.graph_node_tiling(...): whole graphs per tile of the one-pass endpoint sums
         if (validate or _lib.VALIDATE) and int(status.sum().item()) != 0:
-            raise _lib.DmpError("edge endpoint outside [0, num_nodes)")
+            status.zero_()
+            raise _lib.DmpError("edge endpoint outside [0, num_nodes)" if offsets is None else
+                                "edge endpoint outside its graph's node range (not a block-diagonal batch)")
 
     def incidence(self):
         if self._inc is None:
@@ -388,7 +409,12 @@ class BatchedGraph:
         rev = self.edata.get(REVFLAG)
         key = None if rev is None else (rev.data_ptr(), rev._version)
         if self._index is None or self._index_key != key:
-            self._index = GraphIndex(self._src, self._dst, self._n, rev, validate=validate)
+            offsets = None
+            if (USE_GRAPH_CSR and self.is_batched_on_device() and getattr(self, "max_num_nodes", None) is not None
+                    and self.max_num_nodes <= _lib.load().dmp_csr_build_graphs_max_nodes()
+                    and int(self.node_offsets.numel()) - 1 == int(self.edge_offsets.numel()) - 1 > 0):
+                offsets = (self.node_offsets, self.edge_offsets, int(self.node_offsets.numel()) - 1)
+            self._index = GraphIndex(self._src, self._dst, self._n, rev, validate=validate, offsets=offsets)
             self._index_key = key
         self._index.tiling = getattr(self, "tiling", None)
         self._index.node_tiling = getattr(self, "node_tiling", None)

@@ -218,12 +218,14 @@ class PairDataset:
     @classmethod
     def graphs_from_arrays(cls, meta, tensors):
         """``(pattern, graph)`` BatchedGraphs from ``batch_arrays``' output (device collate)."""
-        out = []
+        from .collate import collate_device_many
+        jobs = []
         for side, (n, e, max_n, max_e) in enumerate(meta):
             src, dst, nn_, ne_, nid, vlabel, eid, elabel, rev = tensors[side * cls.ARRAYS_PER_GRAPH:(side + 1) * cls.ARRAYS_PER_GRAPH]
-            out.append(collate_device(src, dst, nn_, ne_, n, e, ndata={"id": nid, "label": vlabel},
-                                      edata={"id": eid, "label": elabel, "is_reversed": rev}, max_nodes=max_n, max_edges=max_e))
-        return out
+            jobs.append(dict(local_src=src, local_dst=dst, num_nodes=nn_, num_edges=ne_, total_nodes=n, total_edges=e,
+                             ndata={"id": nid, "label": vlabel}, edata={"id": eid, "label": elabel, "is_reversed": rev},
+                             max_nodes=max_n, max_edges=max_e))
+        return collate_device_many(jobs)                         # both sides in one pair of launches
 
 
 class SyntheticPairs(PairDataset):

@@ -740,13 +740,32 @@ class PoolIndex:
         self.gptr = coff.to(torch.int32)
         self.gent = (torch.arange(V, device=dev, dtype=torch.int64) << 1).to(torch.int32)
         self.sizes = sizes
+        self.offsets = off
+        self.rows_in_order = order is None                # graph i's rows are rows offsets[i] .. offsets[i + 1]
         self.seg32 = (torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), sizes, output_size=R)
                       if seg is None else seg.to(torch.int32).contiguous())
         self.flag8 = None if flag is None else flag.view(-1).to(torch.uint8).contiguous()
 
 
-def _pool_build_device(self, pieces, flag, seg, R):
-    lib = _lib.load()
+_POOL_JOB = None
+
+
+def _pool_job_type():
+    global _POOL_JOB
+    if _POOL_JOB is None:
+        import ctypes
+        P, I = ctypes.c_void_p, ctypes.c_int64
+
+        class _Job(ctypes.Structure):
+            _fields_ = [("sizes_a", P), ("sizes_b", P), ("Ba", I), ("Bb", I), ("flag_a", P), ("flag_b", P), ("rows_a", I), ("R", I),
+                        ("chunk", ctypes.c_int), ("off", P), ("gptr", P), ("vptr", P), ("vent", P), ("gent", P), ("seg", P),
+                        ("flag8", P), ("rowmap", P), ("sizes", P)]
+        _POOL_JOB = _Job
+    return _POOL_JOB
+
+
+def _pool_prepare(self, pieces, flag, seg, R, job):
+    """Allocate this index's arrays and describe its build as one ``dmp_pool_job``."""
     sizes = [p.view(-1).to(torch.int64).contiguous() for p in pieces]
     sa, sb = sizes[0], (sizes[1] if len(sizes) > 1 else None)
     flags = flag if isinstance(flag, (tuple, list)) else (flag,)
@@ -768,16 +787,43 @@ def _pool_build_device(self, pieces, flag, seg, R):
     self.gptr, self.vptr = torch.empty(B + 1, **i32), torch.empty(V + 1, **i32)
     self.vent, self.gent = torch.empty(R, **i32), torch.empty(V, **i32)
     self.seg32 = torch.empty(R, **i32) if seg is None else seg.to(torch.int32).contiguous()
-    check(lib.dmp_pool_index(ptr(sa), Ba, ptr(sb), Bb, ptr(fa), ptr(fb), rows_a, R, C, ptr(off), ptr(self.gptr), ptr(self.vptr),
-                             ptr(self.vent), ptr(self.gent), ptr(self.seg32) if seg is None else None, stream_ptr()), "dmp_pool_index")
     self.num_graphs, self.num_rows, self.num_chunks = B, R, V
-    self.sizes = sa if sb is None else torch.cat([sa, sb])
+    self.sizes = sa if sb is None else torch.empty(B, dtype=torch.int64, device=dev)       # both pieces back to back
     self.offsets = off
-    if fa is None:
-        self.flag8 = None
-    else:
-        self.flag8 = fa if fb is None else torch.cat([fa, fb])
+    self.rows_in_order = True
+    self.flag8, self._rowmap = None, None
+    if fa is not None:
+        self.flag8 = fa if fb is None else torch.empty(R, dtype=torch.uint8, device=dev)
+        self._rowmap = torch.empty(R, **i32)              # the graph of every row, -1 for flagged rows (fused.pool_rowmap)
+    job.sizes_a, job.sizes_b, job.Ba, job.Bb = sa.data_ptr(), ptr(sb), Ba, Bb
+    job.flag_a, job.flag_b, job.rows_a, job.R, job.chunk = ptr(fa), ptr(fb), rows_a, R, C
+    job.off, job.gptr, job.vptr, job.vent, job.gent = off.data_ptr(), self.gptr.data_ptr(), self.vptr.data_ptr(), ptr(self.vent), ptr(self.gent)
+    job.seg = self.seg32.data_ptr() if (seg is None and R > 0) else None
+    job.flag8 = self.flag8.data_ptr() if (fb is not None and R > 0) else None
+    job.rowmap = self._rowmap.data_ptr() if (self._rowmap is not None and R > 0) else None
+    job.sizes = self.sizes.data_ptr() if (sb is not None and B > 0) else None
     self._keep = (sizes, f8)
+
+
+def _pool_build_device(self, pieces, flag, seg, R):
+    J = (_pool_job_type() * 1)()
+    _pool_prepare(self, pieces, flag, seg, R, J[0])
+    check(_lib.load().dmp_pool_index_jobs(J, 1, stream_ptr()), "dmp_pool_index_jobs")
+
+
+def pool_indexes(specs):
+    """Several ``PoolIndex`` objects from ONE pair of launches (``dmp_pool_index_jobs``): ``specs`` = list of
+    ``(sizes, flag, num_rows)`` as ``PoolIndex(sizes, flag, num_rows=...)`` takes them (device tensors)."""
+    out = [PoolIndex.__new__(PoolIndex) for _ in specs]
+    lib = _lib.load()
+    for i in range(0, len(specs), 4):                    # DMP_POOL_MAX_JOBS
+        part = specs[i:i + 4]
+        J = (_pool_job_type() * len(part))()
+        for k, (sizes, flag, rows) in enumerate(part):
+            pieces = sizes if isinstance(sizes, (tuple, list)) else (sizes,)
+            _pool_prepare(out[i + k], pieces, flag, None, int(rows), J[k])
+        check(lib.dmp_pool_index_jobs(J, len(part), stream_ptr()), "dmp_pool_index_jobs")
+    return out
 
 
 PoolIndex._build_device = _pool_build_device

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 52
+#define DMP_ABI_VERSION 53
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -89,6 +89,18 @@ int dmp_csr_build_pair(const int64_t *dst, const int64_t *src, const uint8_t *fl
                        int32_t *out_ptr, int32_t *out_ent, int32_t *src32, int64_t *out_deg,
                        int32_t *status, int32_t *ws, void *stream);
 
+/* dmp_csr_build_pair for a BLOCK-DIAGONAL batch (what dgl.batch makes, dataset.py:1320-1328: the edges of graph g are the
+ * rows [edge_off[g], edge_off[g + 1]) and join nodes [node_off[g], node_off[g + 1]) only) in ONE launch: a workgroup per
+ * graph counts, scans, fills and sorts with the graph's counters in LDS.  Every graph has at most
+ * dmp_csr_build_graphs_max_nodes() nodes (the caller checks: larger graphs take dmp_csr_build_pair) and node_off[B] == N.
+ * Same outputs, bit for bit (rows in ascending edge id).  status [2] is only OR-ed into (bit 0: an endpoint outside its
+ * graph's node range -- such an edge is left out); the caller clears it. */
+int dmp_csr_build_graphs_max_nodes(void);
+int dmp_csr_build_graphs(const int64_t *dst, const int64_t *src, const uint8_t *flag, const int64_t *node_off,
+                         const int64_t *edge_off, int64_t B, int64_t E, int64_t N, int32_t *in_ptr, int32_t *in_ent,
+                         int32_t *dst32, int64_t *in_deg, int32_t *out_ptr, int32_t *out_ent, int32_t *src32,
+                         int64_t *out_deg, int32_t *status, void *stream);
+
 /*
  * Incidence CSR: for node w, its in-edges (flag = is_reversed) and its
  * out-edges (flag = !is_reversed), merged by ascending edge id (a self loop lists
@@ -133,6 +145,15 @@ int dmp_collate(const int64_t *local_src, const int64_t *local_dst,
                 int64_t *node_off, int64_t *edge_off, int64_t *src,
                 int64_t *dst, int32_t *edge_graph, int32_t *node_graph,
                 void *stream);
+
+/* dmp_collate for several batches in the same two launches (a step collates its pattern batch and its target batch).
+ * `jobs` is a HOST array; every job has 1 <= B <= 2048 graphs; edge_graph / node_graph may be NULL. */
+typedef struct {
+  const int64_t *local_src, *local_dst, *num_nodes, *num_edges; int64_t B, N, E;
+  int64_t *node_off, *edge_off, *src, *dst; int32_t *edge_graph, *node_graph;
+} dmp_collate_job;
+#define DMP_COLLATE_MAX_JOBS 4
+int dmp_collate_jobs(const dmp_collate_job *jobs, int n, void *stream);
 
 /*
  * `add_reversed_edges` (GraphAdj branch), SubgraphCountingMatching/train.py:299-327:
@@ -260,6 +281,24 @@ int dmp_pool_index(const int64_t *sizes_a, int64_t Ba, const int64_t *sizes_b, i
                    const uint8_t *flag_a, const uint8_t *flag_b, int64_t rows_a, int64_t R, int chunk,
                    int64_t *off, int32_t *gptr, int32_t *vptr, int32_t *vent, int32_t *gent, int32_t *seg,
                    void *stream);
+
+/* Several pooling indexes in the same two launches (a step needs the node index and the edge index of its batch), with
+ * three optional outputs per index: flag8 [R] = the flags of both pieces back to back (0 / 1), rowmap [R] = seg[r], or -1
+ * for a flagged row (the rows the pooled heads mask out, basemodel.py:1521-1531), sizes [Ba + Bb] = both size pieces back
+ * to back.  `jobs` is a HOST array. */
+typedef struct {
+  const int64_t *sizes_a, *sizes_b; int64_t Ba, Bb;
+  const uint8_t *flag_a, *flag_b; int64_t rows_a, R; int chunk;
+  int64_t *off; int32_t *gptr, *vptr, *vent, *gent, *seg;
+  uint8_t *flag8; int32_t *rowmap; int64_t *sizes;
+} dmp_pool_job;
+#define DMP_POOL_MAX_JOBS 4
+int dmp_pool_index_jobs(const dmp_pool_job *jobs, int n, void *stream);
+/* Per-graph sums of a row weight over a pooling index: out [B, 1] = sum_{r in graph} w[r], or with flag8 (dmp_pool_index_jobs)
+ * out [B, 2] = [sum over the non-flagged rows | sum over the flagged rows]; w NULL = 1 (row counts).  off [B + 1] = the index's
+ * row offsets.  Fixed summation order (a wave per graph, lane-strided, butterfly): run-to-run bit-stable. */
+int dmp_pool_weight_sums(const float *w, const uint8_t *flag8, const int64_t *off, int64_t B, float *out, void *stream);
+
 
 /*
  * get_dual_subisomorphisms (utils/graph.py:277-316 as convert_to_dual_data calls it, train.py:417-446) for a whole

@@ -234,3 +234,81 @@ def test_fit_with_gate_compact_trains_like_fit_without():
         for part in ("train", "dev"):
             for k, v in a[part].items():
                 assert abs(v - b[part][k]) <= 2e-4 * max(1.0, abs(v)), (part, k, v, b[part][k])
+
+
+@pytest.mark.parametrize("B,max_n,max_e,empty", [(37, 9, 40, False), (64, 64, 512, False), (5, 2048, 9000, False), (16, 12, 30, True),
+                                                 (1, 8, 24, False), (300, 3, 700, False)])
+def test_one_launch_csr_build_equals_the_pair_build(B, max_n, max_e, empty):
+    """``dmp_csr_build_graphs`` (a workgroup per graph, counters in LDS) against ``dmp_csr_build_pair``: every array equal."""
+    from dualmessagepassing_amd.graph import GraphIndex
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(7 * B + max_e)
+    g, nn, ne, rev = _random_batch(rng, B, max_n, max_e, gpu, empty)
+    a = GraphIndex(g._src, g._dst, g.number_of_nodes(), g.edata["is_reversed"], validate=True)
+    b = GraphIndex(g._src, g._dst, g.number_of_nodes(), g.edata["is_reversed"], validate=True,
+                   offsets=(g.node_offsets, g.edge_offsets, B))
+    for k in ("in_ptr", "in_ent", "dst32", "in_deg", "out_ptr", "out_ent", "src32", "out_deg"):
+        assert th.equal(getattr(a, k), getattr(b, k)), k
+    assert g.index().in_ptr.data_ptr() != a.in_ptr.data_ptr() and th.equal(g.index().in_ent, a.in_ent)    # the batch's own build
+    # an edge that leaves its graph is reported, not silently mis-filed
+    if B > 1 and int(ne[0]) > 0:
+        bad = g._dst.clone()
+        bad[0] = g.number_of_nodes() - 1
+        with pytest.raises(Exception):
+            GraphIndex(g._src, bad, g.number_of_nodes(), g.edata["is_reversed"], validate=True, offsets=(g.node_offsets, g.edge_offsets, B))
+
+
+def test_pool_indexes_built_together_equal_the_single_builds():
+    from dualmessagepassing_amd import fused, ops
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(11)
+    sa, sb = rng.integers(0, 9, 40), rng.integers(0, 70, 40)
+    ea, eb = rng.integers(0, 30, 40), rng.integers(0, 600, 40)
+    t = lambda a, dt=th.int64: th.from_numpy(np.ascontiguousarray(a)).to(dt).to(gpu)
+    fa, fb = rng.integers(0, 2, int(ea.sum())), rng.integers(0, 2, int(eb.sum()))
+    specs = [((t(sa), t(sb)), None, int(sa.sum() + sb.sum())),
+             ((t(ea), t(eb)), (t(fa, th.uint8), t(fb, th.uint8)), int(ea.sum() + eb.sum()))]
+    many = ops.pool_indexes(specs)
+    for spec, got in zip(specs, many):
+        one = ops.PoolIndex(spec[0], spec[1], num_rows=spec[2])
+        for k in ("gptr", "vptr", "vent", "gent", "seg32", "offsets", "sizes"):
+            assert th.equal(getattr(one, k), getattr(got, k)), k
+        assert (one.flag8 is None) == (got.flag8 is None)
+        if one.flag8 is not None:
+            assert th.equal(one.flag8, got.flag8)
+            want = th.where(one.flag8 != 0, th.full_like(one.seg32, -1), one.seg32)
+            assert th.equal(fused.pool_rowmap(got), want)
+            w = th.rand(spec[2], device=gpu)
+            cnt = fused.pool_weight_sums(got, w).double().cpu().numpy()
+            off = got.offsets.cpu().numpy()
+            f = got.flag8.cpu().numpy()
+            wn = w.double().cpu().numpy()
+            for i in range(got.num_graphs):
+                rows = slice(off[i], off[i + 1])
+                assert abs(cnt[i, 0] - wn[rows][f[rows] == 0].sum()) < 1e-4 and abs(cnt[i, 1] - wn[rows][f[rows] != 0].sum()) < 1e-4
+            assert th.equal(fused.pool_weight_sums(got), fused.pool_weight_sums(got, th.ones(spec[2], device=gpu)))
+
+
+def test_collate_many_equals_collate_device():
+    from dualmessagepassing_amd.collate import collate_device, collate_device_many
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(3)
+    jobs = []
+    for B, max_n, max_e in ((33, 9, 20), (33, 70, 500), (1, 5, 0)):
+        nn = rng.integers(1, max_n + 1, size=B)
+        ne = rng.integers(0, max_e + 1, size=B)
+        t = lambda a: th.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(gpu)
+        ls = np.concatenate([rng.integers(0, n, size=e) for n, e in zip(nn, ne)] + [np.zeros(0, np.int64)])
+        ld = np.concatenate([rng.integers(0, n, size=e) for n, e in zip(nn, ne)] + [np.zeros(0, np.int64)])
+        jobs.append(dict(local_src=t(ls), local_dst=t(ld), num_nodes=t(nn), num_edges=t(ne), total_nodes=int(nn.sum()),
+                         total_edges=int(ne.sum()), ndata={"x": t(np.arange(nn.sum()))}, edata={}, max_nodes=int(nn.max()),
+                         max_edges=int(max(ne.max(), 1))))
+    many = collate_device_many(jobs)
+    for j, g in zip(jobs, many):
+        one = collate_device(j["local_src"], j["local_dst"], j["num_nodes"], j["num_edges"], j["total_nodes"], j["total_edges"],
+                             ndata=j["ndata"], edata=j["edata"], max_nodes=j["max_nodes"], max_edges=j["max_edges"])
+        for k in ("_src", "_dst", "node_graph", "edge_graph", "node_offsets", "edge_offsets"):
+            assert th.equal(getattr(one, k), getattr(g, k)), k
+        assert (one.max_num_nodes, one.max_num_edges, one.tiling is None, one.node_tiling is None) == \
+               (g.max_num_nodes, g.max_num_edges, g.tiling is None, g.node_tiling is None)
+        assert g.ndata["x"] is not None and g.batch_size == one.batch_size
