@@ -655,6 +655,8 @@ def main():
                     "one pass below 2^30: 1 for config 2 and for config 4's 1024-pair shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
+    ap.add_argument("--extended-steps", type=int, default=200,
+                    help="further steps after the timed region (same launch mode, one event record each) behind `steps_extended`; 0 = none")
     ap.add_argument("--no-gate-compact", action="store_true", help="skip the extra un-timed steps behind the gate_compact object")
     ap.add_argument("--gate-compact", action="store_true",
                     help="run the rep-net on the target edges the filter gate keeps (model.set_gate_capacity; capacity "
@@ -862,6 +864,26 @@ def main():
             "step_ms_median": round(per_step_ms[len(per_step_ms) // 2], 3) if per_step_ms else None,
             "wall_ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3)}
     kern = _lib.timer.summary()
+    extended = None
+    if args.extended_steps > 0:
+        # the driver fixes --steps 20 (0.1 s of device time): the same step, same launch mode, for `--extended-steps` more
+        # steps with one event record per step -- a median over a second of work, reported beside the line, never as `value`
+        _lib.timer.enabled = False
+        n_ext = args.extended_steps
+        ext_marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_ext + 1)]
+        barrier()
+        tx = time.perf_counter()
+        for i in range(n_ext):
+            ext_marks[i].record()
+            run()
+        step.finish()
+        ext_marks[n_ext].record()
+        barrier()
+        ext_dt = time.perf_counter() - tx
+        ext_ms = sorted(ext_marks[i].elapsed_time(ext_marks[i + 1]) for i in range(n_ext))
+        extended = {"steps": n_ext, "ms_per_step": round(ext_dt / n_ext * 1e3, 3), "step_ms_min": round(ext_ms[0], 3),
+                    "step_ms_median": round(ext_ms[n_ext // 2], 3), "step_ms_p90": round(ext_ms[(9 * n_ext) // 10], 3),
+                    "step_ms_max": round(ext_ms[-1], 3), "value": round(cfg["batch"] * world * n_ext / ext_dt, 1)}
     eager_ms = None
     if graphed:
         # the same K steps once more as eager launches: the scatter-add's HIP-event time (no event records inside a replayed
@@ -1005,6 +1027,7 @@ def main():
             "launch_fallback": launch_fallback,
             "eager_ms_per_step": round(eager_ms, 3) if eager_ms is not None else None,
             "all_outputs_ms_per_step": round(all_ms, 3) if all_ms is not None else None,
+            "steps_extended": extended,
             # per rank: host time inside the step call, the compute stream's wait for the gradient sum (HIP events around
             # the all-reduce / its wait), device time per step -- what a bad scaling curve is diagnosed from
             "per_rank": per_rank,

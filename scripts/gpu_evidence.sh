@@ -10,12 +10,15 @@
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/${TAG}z && mkdir -p $O
 timeout 500 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_err.txt
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python3 $R/bench.py --graph --no-cpu-baseline --no-all-outputs > $O/prof_bench.json 2> $O/err.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python3 $R/bench.py --graph --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 > $O/prof_bench.json 2> $O/err.txt
 rm -f $O/prof/*trace*
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs > /dev/null 2> $O/err_f.txt
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs > /dev/null 2> $O/err_w.txt
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k -o k -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs > /dev/null 2> $O/err_k.txt
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 > /dev/null 2> $O/err_f.txt
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 > /dev/null 2> $O/err_w.txt
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k -o k -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 > /dev/null 2> $O/err_k.txt
 rm -f $O/k/*trace*
+# the gate-compact mode of the same step (bench.py's `gate_compact` object): its own kernel statistics
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profgc -o g -- python3 $R/bench.py --graph --gate-compact --no-cpu-baseline --no-all-outputs --extended-steps 0 > $O/prof_bench_gate_compact.json 2> $O/err_gc.txt
+rm -f $O/profgc/*trace*
 cd $R
 python3 - <<PY
 import csv, collections, json, sys
@@ -39,10 +42,10 @@ for k in f:
                       "hbm_bytes_per_launch": hbm, "rocprof_avg_us_all_launches": t.get(k)}
         print("%-44s HBM %7.1f MB per large launch  (avg over all launches %6.1f us)" % (short, hbm / 1e6, t.get(k, 0)))
 json.dump({"kernels": out, "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE counts half of a 16-B/lane stream on gfx950, MI355X_MICROARCH.md; the one-pass endpoint sums load 4 B per lane: the same doubling reproduces their byte count); large = dispatches above half of the kernel's largest (the E-row launches)",
-           "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --kernel-trace --stats (separate passes) -- python3 bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs",
+           "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --kernel-trace --stats (separate passes) -- python3 bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0",
            "shape": {"rows": 73728, "edges": 548864, "H": 128}}, open("$O/pmc_h128.json", "w"), indent=1)
 json.dump({"rows": 73728, "edges": 548864, "H": 128, "lib_srchash": _build.source_hash(),
-           "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --graph --no-cpu-baseline --no-all-outputs (kernel stats: the default mode of bench.py at N = 1, run in the profiled process itself); rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --kernel-trace --stats -- python3 bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs (PMC, separate passes)",
+           "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --graph --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 (kernel stats: the default mode of bench.py at N = 1, run in the profiled process itself); rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --kernel-trace --stats -- python3 bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 (PMC, separate passes)",
            "note": "launch shape of the two scatter-add launches of bench.py (union of 1024 pattern + target graphs, hid 128); lib_srchash = content hash of the kernel sources (dualmessagepassing_amd/_build.py::source_hash): bench.py quotes these profiles only for the same build"},
           open("$O/profile_meta.json", "w"), indent=1)
 PY
