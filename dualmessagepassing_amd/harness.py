@@ -247,6 +247,61 @@ class SyntheticPairs(PairDataset):
                                  "counts": len(sub), "subisomorphisms": sub})
 
 
+class SmallLikePairs(PairDataset):
+    """Ragged (pattern, graph) pairs in the size ranges of the reference's "small" setting (SubgraphCountingMatching/
+    README.md:72-94: patterns of at most 8 nodes / 8 edges, graphs of at most 64 nodes / 256 edges, at most 16 labels) with
+    exact counts; the published dataset itself is a download that is not available offline.  A pattern is a random
+    spanning tree plus random extra edges (connected: an isolated pattern node would multiply the count by the number of
+    free graph nodes); a graph is directed ER noise with uniform labels into which 0 .. 12 copies of its pattern are
+    planted (node labels overwritten, the pattern's edges added), so that counts are mostly small positive numbers instead
+    of zeros and rare explosions.  Counts are EXACT whatever the planting did: they come from the native search over a
+    pool of host threads (``count_subisomorphisms_batch``); the enumerations themselves are not kept (count loss only)."""
+
+    def __init__(self, num_pairs, seed=0, threads=0):
+        rng = np.random.default_rng(seed)
+        self.shape = dict(p_nodes=8, p_edges=8, g_nodes=64, g_edges=256, n_vlabels=16, n_elabels=16)
+        raw = []
+        for _ in range(num_pairs):
+            pn = int(rng.choice([3, 4, 8]))
+            pe = int({3: rng.choice([2, 4]), 4: rng.choice([4, 8]), 8: 8}[pn])
+            gn = int(rng.choice([8, 16, 32, 64]))
+            ge = int(min(gn * rng.choice([1, 2, 4]), 256))
+            nl = int(rng.choice([4, 8, 16]))
+            # pattern: a spanning tree in random orientation, then distinct extra ordered pairs
+            perm = rng.permutation(pn)
+            pairs = set()
+            for k in range(1, pn):
+                a, b = int(perm[k]), int(perm[rng.integers(0, k)])
+                pairs.add((a, b) if rng.random() < 0.5 else (b, a))
+            while len(pairs) < pe:
+                a, b = int(rng.integers(0, pn)), int(rng.integers(0, pn))
+                if a != b:
+                    pairs.add((a, b))
+            pu, pv = (np.array(x, np.int64) for x in zip(*sorted(pairs)))
+            pvl, pel = rng.integers(0, nl, pn), rng.integers(0, nl, pe)
+            gvl = rng.integers(0, nl, gn)
+            copies = int(rng.integers(0, min(12, gn // pn) + 1))
+            edges = {}
+            for _c in range(copies):
+                where = rng.choice(gn, size=pn, replace=False)
+                gvl[where] = pvl
+                for u, v, l in zip(pu, pv, pel):
+                    edges[(int(where[u]), int(where[v]))] = int(l)
+            while len(edges) < ge:                            # ER noise up to the edge budget
+                a, b = int(rng.integers(0, gn)), int(rng.integers(0, gn))
+                if a != b and (a, b) not in edges:
+                    edges[(a, b)] = int(rng.integers(0, nl))
+            keys = sorted(edges)[:256]
+            gu, gv = (np.array(x, np.int64) for x in zip(*keys))
+            gel = np.array([edges[k] for k in keys], np.int64)
+            raw.append((pu, pv, pvl, pel, gu, gv, gvl, gel))
+        counts = count_subisomorphisms_batch(raw, threads)
+        self.samples = []
+        for (pu, pv, pvl, pel, gu, gv, gvl, gel), c in zip(raw, counts):
+            self.samples.append({"pattern": self._with_rev(pu, pv, pvl, pel, 8, 16), "graph": self._with_rev(gu, gv, gvl, gel, 256, 16),
+                                 "counts": int(c), "subisomorphisms": np.zeros((0, len(pvl)), np.int64)})
+
+
 _CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
 SCHEDULE_CYCLES = 2     # utils/anneal.py:7, utils/cyclical.py:7 (NUM_CYCLES, what train.py:510-562 passes)
 
