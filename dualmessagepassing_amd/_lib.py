@@ -239,16 +239,32 @@ def stream_ptr():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
-_CAPTURE_PINS = []
+_CAPTURE_PINS = []         # pins of recordings nobody owns (a bare torch.cuda.graph around library calls)
+_PIN_OWNER = []            # the innermost recording's own list (dp.StepGraph): its pins die with the recording
+
+
+class capture_pins:
+    """``with capture_pins() as pins:`` around a stream capture -- tensors pinned inside (``pin_for_capture``) go to ``pins``,
+    which the owner of the recording keeps for as long as it keeps the recording."""
+
+    def __enter__(self):
+        self.pins = []
+        _PIN_OWNER.append(self.pins)
+        return self.pins
+
+    def __exit__(self, *exc):
+        _PIN_OWNER.pop()
+        return False
 
 
 def pin_for_capture(*tensors):
     """A tensor that was allocated OUTSIDE a stream capture (a memoised index array) and is about to be read by kernels
     being recorded must outlive the recording: the memo that owns it may evict it later.  Inside a capture this keeps a
-    reference for the life of the process (small integer arrays, a few per recording); outside it does nothing."""
+    reference in the recording's own pin list (``capture_pins``; ``dp.StepGraph`` drops it with the recording) or, for a
+    capture nobody registered, for the life of the process; outside a capture it does nothing."""
     import torch
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        _CAPTURE_PINS.extend(t for t in tensors if t is not None)
+        (_PIN_OWNER[-1] if _PIN_OWNER else _CAPTURE_PINS).extend(t for t in tensors if t is not None)
 
 
 def require_gpu(*tensors):

@@ -429,9 +429,10 @@ class StepGraph:
             # with a process group alive its watchdog thread polls events while we record: only THIS thread's calls are
             # policed then (torch's "thread_local" capture mode); a single process keeps the strict default
             mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-            with torch.cuda.graph(graph, stream=self._side_stream(), capture_error_mode=mode):
+            from . import _lib
+            with _lib.capture_pins() as pins, torch.cuda.graph(graph, stream=self._side_stream(), capture_error_mode=mode):
                 out = self.fn(*meta, *static)
-            rec = self._graphs[key] = (graph, static, out)
+            rec = self._graphs[key] = (graph, static, out, pins)     # memoised index arrays the recording reads: kept with it
         else:
             for s, t in zip(rec[1], tensors):
                 if s.data_ptr() != t.data_ptr():

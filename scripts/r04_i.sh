@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out/r04i
+timeout 1500 python -m pytest tests/test_gpu_compact.py tests/test_gpu_bench_line.py tests/test_gpu_graph.py -x -q -m gpu > gpurun_out/r04i/tests.log 2>&1
+echo "rc=$?" >> gpurun_out/r04i/tests.log
+tail -25 gpurun_out/r04i/tests.log

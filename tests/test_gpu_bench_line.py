@@ -40,6 +40,12 @@ def test_default_mode_replays_and_eager_agrees(gpu):
     _check_contract(d)
     assert d["config"]["launch"].startswith("one HIP graph replay per step") and "launch_fallback" not in d["config"]
     assert d["config"]["eager_ms_per_step"] > 0
+    # the two secondary measurements of the default line: 200 further steps, and the step with the gate capacity set
+    x = d["steps_extended"]
+    assert x["steps"] == 200 and x["step_ms_min"] <= x["step_ms_median"] <= x["step_ms_p90"] <= x["step_ms_max"] and x["value"] > 0
+    gc = d["gate_compact"]
+    assert gc["ms_per_step"] > 0 and 0 < gc["capacity"] < gc["target_edge_rows"] and gc["unit"] == "pairs/s"
+    assert abs(gc["value"] - 16 / (gc["ms_per_step"] * 1e-3)) <= 0.01 * gc["value"]
     e = _run("--eager", "--no-cpu-baseline")
     _check_contract(e)
     assert e["config"]["launch"] == "eager launches" and e["config"]["eager_ms_per_step"] is None

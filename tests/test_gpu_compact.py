@@ -211,8 +211,10 @@ def test_guarded_adamw_drops_a_flagged_step():
     assert opt.state[p]["step"] == 3
 
 
-def test_fit_with_gate_compact_trains_like_fit_without():
-    """``harness.fit(gate_compact=True)``: same losses epoch by epoch as the run on every edge row, nothing dropped."""
+@pytest.mark.parametrize("graphed", [False, True])
+def test_fit_with_gate_compact_trains_like_fit_without(graphed):
+    """``harness.fit(gate_compact=True)``: same losses epoch by epoch as the run on every edge row, nothing dropped -- with
+    eager launches and with the steps recorded as HIP graphs (the compaction and the guarded optimizer replay)."""
     from dualmessagepassing_amd import harness
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
@@ -224,9 +226,9 @@ def test_fit_with_gate_compact_trains_like_fit_without():
         model = build_model(**data.model_config(hid_dim=128, layers=3)).to(gpu)
         sync = FlatGradSync(model)
         master = sync.flatten_parameters()
-        opt = FlatAdamW([master], lr=1e-3, weight_decay=1e-5, amsgrad=True)
+        opt = FlatAdamW([master], lr=1e-3, weight_decay=1e-5, amsgrad=True, capturable=graphed)
         hist[mode] = harness.fit(model, opt, data.subset(range(64)), data.subset(range(64, 96)), 3, 32, gpu, sync=sync, seed=1,
-                                 gate_compact=1.35 if mode else False)
+                                 gate_compact=1.35 if mode else False, graph=graphed)
         if mode:
             assert model.gate_capacity, "the gate removed too little for a capacity to be set"
             assert hist[mode][-1]["dropped_steps"] == 0
