@@ -76,6 +76,10 @@ struct MfmaArgs {
   int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
   int both;                         // EPI_RELU_BWD_G: write [dPre | coef dPre] (rowscale = coef[dst e]) instead of dPre alone
   float slope;                      // EPI_EDGE / EPI_RELU_BWD_G: negative slope of the activation (0 = ReLU)
+  // EPI_GATE_RES / EPI_RELU_BWD_G (pipelined form): bit r of rowmask[t] == 0 -> row 32 t + r has gate 0, and the rows of A (and,
+  // for EPI_RELU_BWD_G, of R) it would have contributed are not fetched: their products are multiplied by the zero gate anyway
+  // (out = R + 0 (...), dPre = act'(.) 0).  NULL: every row is fetched.
+  const uint32_t *rowmask;
 };
 
 template <int NC, int EPI, int PP, int H = 128>
@@ -158,14 +162,28 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
     return (int)(left < 0 ? 0 : (left > kSub ? kSub : left));
   };
 
+  // row mask of tile t as a wave-uniform word (scalar load); tiles past the end: no rows
+  constexpr bool kMasked = kPipe;
+  auto mask_of = [&](int t) -> uint32_t {
+    if (!kMasked || !p.rowmask) return 0xffffffffu;
+    return t < ntiles ? p.rowmask[t] : 0u;
+  };
+  // a lane's byte offset for row r of a tile with mask mk: out of the descriptor's range for a masked row (the load returns
+  // zeros and moves nothing)
+  // (mk8 = the mask shifted down by the row group's 8 m: a scalar; bit = this lane's row bit inside a group of 8 rows)
+  auto voff_if = [&](uint32_t mk8, uint32_t bit, uint32_t voff) -> uint32_t { return voff | ((mk8 & bit) ? 0u : 0x80000000u); };
+  const uint32_t abit = 1u << (gtid / kQ);                 // A rows of a thread: gtid / kQ + 8 m
+  const uint32_t rbit = 1u << (lane >> 3);                 // operand rows of a lane: 8 k + lane / 8
+
   float4 pre[kSubLoads];
   uint32_t pre_a = 0, pre_b = 0;
   float pre_s = 0.f;
   auto load_rows = [&](int t) {                           // global -> registers: rows + per-row scalars of tile t
     const rsrc_t ra = make_rsrc(p.A + (int64_t)t * kSub * p.lda, tile_bytes(tile_rows(t), p.lda, H));
+    const uint32_t mk = mask_of(t);
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m)
-      pre[m] = buf_load4(ra, voffA, m * grpA);
+      pre[m] = buf_load4(ra, kMasked ? voff_if(mk >> (8 * m), abit, voffA) : voffA, m * grpA);
     if (EPI != EPI_NONE && gtid < kSub) {
       const uint32_t so = (uint32_t)t * (kSub * 4u);      // E * 4 < 2^32 (checked by the host)
       if (EPI == EPI_EDGE || EPI == EPI_DZ) pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, gtid * 4, (int)so, 0);
@@ -221,6 +239,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
       } else if (EPI == EPI_DZ) {
         g0[k] = buf_load4(rs_T, rowA[grp][par][rr] + voffT, 0);
         g1[k] = buf_load4(rr_, voffR, k * grpR);
+      } else if (EPI == EPI_RELU_BWD_G && kMasked) {
+        g0[k] = buf_load4(rr_, voff_if(mask_of(t) >> (8 * k), rbit, voffR), k * grpR);
       } else if (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G) {
         g0[k] = buf_load4(rr_, voffR, k * grpR);
       }
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
       a4 = an;
     }
   };
-  auto tile_step = [&](int k, int par3, int t1, int t2) {   // kPipe only: tile k in As[k & 1]; t1 / t2: the next two tiles
+  auto tile_step = [&](int k, int par3, int t1, int t2, uint32_t mk1, uint32_t mk2) {   // kPipe only: tile k in As[k & 1]; t1 / t2: the next two tiles (mk1 / mk2: their row masks)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
     const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
@@ -258,10 +278,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
     const rsrc_t ra2 = make_rsrc(p.A + (int64_t)t2 * kSub * p.lda, tile_bytes(tile_rows(t2), p.lda, H));
     // in the shadow of the MFMA groups (H = 64: 8 groups, two of these 14 actions after each)
     auto shadow = [&](int i) {
-      if (i < 4) g0n[kPipe ? i : 0] = buf_load4(rr1, voffR, i * grpR);            // tile k+1's operand rows 8 i + lrow
+      if (i < 4) g0n[kPipe ? i : 0] = buf_load4(rr1, EPI == EPI_RELU_BWD_G ? voff_if(mk1 >> (8 * i), rbit, voffR) : voffR, i * grpR);   // tile k+1's operand rows 8 i + lrow
       else if (i < 8) stage_row_to(buf ^ 1, i - 4);                               // tile k+1 -> the other buffer
       else if (i == 8) stage_scalars_to(nxt3);
-      else if (i < 13) pre[i - 9] = buf_load4(ra2, voffA, (i - 9) * grpA);        // tile k+2's rows
+      else if (i < 13) pre[i - 9] = buf_load4(ra2, voff_if(mk2 >> (8 * (i - 9)), abit, voffA), (i - 9) * grpA);   // tile k+2's rows
       else if (i == 13) load_scalars_of(t2);
     };
     const float *arow = &As[buf][li * kStride + kHalf * h];
@@ -350,8 +370,11 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
     fetch_operands(tile(0), 0);
     lds_barrier();
     int par3 = 0;
+    uint32_t mk1 = mask_of(tile(1)), mk2 = mask_of(tile(2));
     for (int k = 0; k < mine; ++k) {
-      tile_step(k, par3, tile(k + 1), tile(k + 2));
+      const uint32_t mk3 = mask_of(tile(k + 3));             // requested a whole tile before its first use
+      tile_step(k, par3, tile(k + 1), tile(k + 2), mk1, mk2);
+      mk1 = mk2; mk2 = mk3;
       lds_barrier();               // tile k+1 is staged for everyone, everyone is done with tile k's rows
       epilogue(tile(k), par3);
 #pragma unroll
@@ -448,6 +471,15 @@ inline int launch_mfma64(const MfmaArgs &p, hipStream_t st) {
 // 32-bit byte offsets inside the kernel
 inline bool fits32(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32); }
 
+// bit r of mask[t] = (gate[32 t + r] != 0); rows past the end: 0
+__global__ __launch_bounds__(256) void row_mask_bits_k(const float *__restrict__ gate, int64_t E, uint32_t *__restrict__ mask) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool on = r < E && gate[r] != 0.f;
+  const unsigned long long b = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0 && r < ((E + 31) / 32) * 32) mask[r >> 5] = (uint32_t)(b >> (lane & 32));
+}
+
 __global__ void edge_select_k(const int32_t *src, const int32_t *dst, const uint8_t *flag, const float *coef,
                               int64_t E, int32_t *selA, int32_t *selB, float *coefE) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -518,9 +550,24 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
   return launch_mfma<2, EPI_EDGE>(p, (hipStream_t)stream);
 }
 
+int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream) {
+  if (E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!gate || !mask) return DMP_ERR_BAD_ARG;
+  row_mask_bits_k<<<(unsigned)((E + 255) / 256), 256, 0, (hipStream_t)stream>>>(gate, E, mask);
+  return check_launch();
+}
+
 int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
                       const float *gate, const float *R, int64_t ldr, int64_t E, int H, int w_in_out,
                       float *out, int64_t ldo, void *stream) {
+  return dmp_out_fwd_fused_masked(Hin, ldh, W2, ldw, bias, gate, nullptr, R, ldr, E, H, w_in_out, out, ldo, stream);
+}
+
+int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
+                             const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
+                             int w_in_out, float *out, int64_t ldo, void *stream) {
+  if (rowmask && !gate) return DMP_ERR_BAD_ARG;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
@@ -533,6 +580,7 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
   p.A = Hin; p.lda = ldh; p.B = W2; p.ldb = ldw;
   p.bt = w_in_out ? 0 : 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]; [in, out] (its transpose): B[k][j] = W2[k][j]
   p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : H; p.ldt = 2 * H;
+  p.rowmask = g_variant == 1 ? nullptr : rowmask;
   return H == 128 ? launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream) : launch_mfma64<EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
@@ -544,6 +592,13 @@ void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
 int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const float *coefE, const float *gate, int64_t E, int H, float slope, float *dG, int64_t ldg,
                      float *partial, void *stream) {
+  return dmp_bwd_h1_fused_masked(dO, ldo, W2, ldw, H1, ldh, coefE, gate, nullptr, E, H, slope, dG, ldg, partial, stream);
+}
+
+int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
+                            float *dG, int64_t ldg, float *partial, void *stream) {
+  if (rowmask && !gate) return DMP_ERR_BAD_ARG;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0) return DMP_ERR_BAD_ARG;
   if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
@@ -560,6 +615,7 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
   p.both = both; p.partial = partial; p.ldt = 2 * H; p.slope = slope;
+  p.rowmask = g_variant == 1 ? nullptr : rowmask;
   return H == 128 ? launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream) : launch_mfma64<EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 

@@ -411,17 +411,41 @@ def atb_typed(z, d_pre, coef, index):
     return reduce_partials(part.view(G, -1)).view(H, 2 * H)
 
 
+USE_ROW_MASKS = _os.environ.get("DMP_ROW_MASKS", "1") == "1"   # gated E-row kernels do not fetch the rows a zero gate annihilates
+
+
+def gate_row_mask(gate):
+    """uint32 [(R + 31) // 32]: bit r of word t = (gate[32 t + r] != 0) (``dmp_row_mask_bits``), for the ``_masked`` kernels;
+    memoised on the gate tensor (a layer's forward and backward, and every layer of a rep-net, share the gate)."""
+    if gate is None or not USE_ROW_MASKS:
+        return None
+    hit = getattr(gate, "_dmp_row_mask", None)
+    if hit is not None and hit[0] == gate._version:
+        return hit[1]
+    lib = _lib.load()
+    R = gate.numel()
+    mask = torch.empty(((R + 31) // 32,), dtype=torch.int32, device=gate.device)
+    check(lib.dmp_row_mask_bits(ptr(gate), R, ptr(mask), stream_ptr()), "dmp_row_mask_bits")
+    try:
+        gate._dmp_row_mask = (gate._version, mask)
+    except Exception:
+        pass
+    return mask
+
+
 def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
     """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H = 128 or 64).
-    ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch)."""
+    ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch).
+    With a gate the rows of ``h1`` under a zero gate are not fetched (``gate_row_mask``): their term is multiplied by 0."""
     lib = _lib.load()
     R, H = h1.shape
     out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
     if W2t is None:
         W2t = W2.t().contiguous() # [in, out]: coalesced weight-panel reads in each of the kernel's workgroups
+    mask = gate_row_mask(gate)
     with _lib.timed("out_fwd_mfma[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
-        check(lib.dmp_out_fwd_fused(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(prev), H, R, H, 1,
-                                    ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
+        check(lib.dmp_out_fwd_fused_masked(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(mask), ptr(prev), H, R, H, 1,
+                                           ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
     return out
 
 
@@ -440,9 +464,9 @@ def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None,
     part = torch.empty((int(lib.dmp_mfma_partial_rows_h(E, H)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
-        check(lib.dmp_bwd_h1_fused(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
-                                   ptr(gate), E, H, slope, ptr(d_g), d_g.stride(0) if E > 1 else d_g.size(1), ptr(part),
-                                   stream_ptr()), "dmp_bwd_h1_fused")
+        check(lib.dmp_bwd_h1_fused_masked(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
+                                          ptr(gate), ptr(gate_row_mask(gate)), E, H, slope, ptr(d_g),
+                                          d_g.stride(0) if E > 1 else d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
     return d_g, reduce_partials(part)
 
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 53
+#define DMP_ABI_VERSION 54
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -925,6 +925,19 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
                      const float *H1, int64_t ldh, const float *coefE, const float *gate,
                      int64_t num_edges, int H, float slope, float *dG, int64_t ldg, float *partial,
                      void *stream);
+
+/* Row masks for gated E-row kernels: bit r of mask[t] = (gate[32 t + r] != 0), mask [(E + 31) / 32] words.  The `_masked` forms of
+ * dmp_out_fwd_fused / dmp_bwd_h1_fused take it beside the gate and do not FETCH the operand rows of a masked row (H1 in the
+ * forward kernel; dO and H1 in the backward kernel): those rows' products are multiplied by their zero gate
+ * (out = R + 0 (h1 W2^T + b2) = R, dPre = act'(.) (0 dO W2) = 0), so the results are the unmasked kernels' -- with 60 % of the rows gated
+ * out (a ScalarFilter target batch, basemodel.py:1515-1531) a fifth / two fifths of the kernels' bytes are not moved. */
+int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream);
+int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
+                             const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
+                             int w_in_out, float *out, int64_t ldo, void *stream);
+int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
+                            float *dG, int64_t ldg, float *partial, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):

@@ -314,3 +314,38 @@ def test_collate_many_equals_collate_device():
         assert (one.max_num_nodes, one.max_num_edges, one.tiling is None, one.node_tiling is None) == \
                (g.max_num_nodes, g.max_num_edges, g.tiling is None, g.node_tiling is None)
         assert g.ndata["x"] is not None and g.batch_size == one.batch_size
+
+
+@pytest.mark.parametrize("H,R", [(128, 4099), (64, 2051), (128, 31)])
+def test_masked_row_kernels_do_not_read_gated_rows_and_equal_the_unmasked(H, R):
+    """``dmp_out_fwd_fused_masked`` / ``dmp_bwd_h1_fused_masked``: same results as the kernels that fetch every row, and
+    the rows under a zero gate are really not fetched (poisoned with NaN, the results stay what they were)."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    g = th.Generator(device=gpu).manual_seed(H + R)
+    gate = (th.rand(R, device=gpu, generator=g) < 0.4).float()
+    h1 = th.randn(R, H, device=gpu, generator=g)
+    prev = th.randn(R, H, device=gpu, generator=g)
+    d_o = th.randn(R, H, device=gpu, generator=g)
+    W2 = th.randn(H, H, device=gpu, generator=g) / H ** 0.5
+    b2 = th.randn(H, device=gpu, generator=g)
+    mask = fused.gate_row_mask(gate)
+    bits = mask.cpu().numpy().view(np.uint32)
+    want = (gate.cpu().numpy() != 0)
+    got = np.array([(bits[r >> 5] >> (r & 31)) & 1 for r in range(R)], bool)
+    assert np.array_equal(got, want)
+    fused.USE_ROW_MASKS = False
+    try:
+        ref_out = fused.out_fwd_mfma(h1, W2, b2, gate, prev)
+        ref_dg, ref_db = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18)
+    finally:
+        fused.USE_ROW_MASKS = True
+    dead = gate == 0
+    h1p, d_op = h1.clone(), d_o.clone()
+    h1p[dead] = float("nan")
+    d_op[dead] = float("nan")
+    out = fused.out_fwd_mfma(h1p, W2, b2, gate, prev)
+    dg, db = fused.bwd_h1_mfma(d_op, W2, h1p, both_halves=False, gate=gate, slope=0.18)
+    assert th.equal(out, ref_out)
+    assert th.equal(dg, ref_dg) and th.equal(db, ref_db)
+    assert bool(th.isfinite(out).all()) and bool(th.isfinite(dg).all())
