@@ -117,6 +117,8 @@ SIGNATURES = {
                                     c_double, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step_dev": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                    c_ptr, c_ptr, c_int, c_ptr]),
+    "dmp_adamw_step_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_double, c_double,
+                                        c_double, c_double, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step_guarded": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                        c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -178,7 +180,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 54
+ABI_VERSION = 55
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

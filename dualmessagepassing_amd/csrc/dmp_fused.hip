@@ -238,6 +238,10 @@ struct AdamArgs {
   const double *state;                                        // [step, lr] or NULL (the fields above hold the host's values)
   double lr_wd, beta1, beta2d;                                // state != NULL: weight decay, betas for the bias corrections
   const int32_t *veto;                                        // dmp_adamw_step_guarded: veto[2] != 0 -> this step is dropped
+  // dmp_adamw_step_segments: the buffer is P parameter tensors back to back (segment s = elements [seg_off[s], seg_off[s + 1])),
+  // each with its OWN step count as torch.optim.AdamW keeps it; seg_tab[2 s] = lr / (1 - beta1^step_s) or < 0 for a segment
+  // without a gradient this step, seg_tab[2 s + 1] = 1 / sqrt(1 - beta2^step_s) (written by adamw_tick_segments)
+  const int64_t *seg_off; const float *seg_tab; int P;
 };
 
 // step += 1 -- unless the step is vetoed (dmp_adamw_step_guarded): veto[0] = flags raised since the last optimizer step
@@ -254,6 +258,38 @@ __global__ void adamw_tick(double *state, int32_t *veto, int32_t mask) {
     if (drop) veto[3] += 1;
   }
   if (!drop) state[0] += 1.0;
+}
+
+// per-segment step counts (state[2 + s]) and step sizes: one block; the veto logic of adamw_tick first
+struct SegTick { double *state; float *tab; int P; double beta1, beta2; int32_t *veto; int32_t mask; uint64_t live[DMP_ADAMW_MAX_SEGMENTS / 64]; int all; };
+__global__ __launch_bounds__(kBlock) void adamw_tick_segments(const SegTick t) {
+  __shared__ int drop_s;
+  if (threadIdx.x == 0) {
+    bool drop = false;
+    if (t.veto) {
+      const int32_t f = t.veto[0];
+      drop = (f & t.mask) != 0;
+      t.veto[1] |= f;
+      t.veto[0] = 0;
+      t.veto[2] = drop ? 1 : 0;
+      if (drop) t.veto[3] += 1;
+    }
+    if (!drop) t.state[0] += 1.0;                              // optimizer steps taken (what a single-count state reports)
+    drop_s = drop ? 1 : 0;
+  }
+  __syncthreads();
+  const double lr = t.state[1];
+  for (int s = threadIdx.x; s < t.P; s += kBlock) {
+    const bool live = t.all || ((t.live[s >> 6] >> (s & 63)) & 1ull);
+    if (live && !drop_s) {
+      const double step = t.state[2 + s] + 1.0;
+      t.state[2 + s] = step;
+      t.tab[2 * s] = (float)(lr / (1.0 - pow(t.beta1, step)));
+      t.tab[2 * s + 1] = (float)(1.0 / sqrt(1.0 - pow(t.beta2, step)));
+    } else {
+      t.tab[2 * s] = -1.f;
+    }
+  }
 }
 
 struct PackSegs {
@@ -280,7 +316,9 @@ __global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a,
 
 __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
   if (a.veto && a.veto[2]) return;                             // a dropped step: parameters and moments stay as they are
-  if (a.state) {                                               // the host formulas of dmp_adamw_step_skip, evaluated on the device
+  if (a.seg_tab) {
+    a.decay = (float)(1.0 - a.state[1] * a.lr_wd);
+  } else if (a.state) {                                        // the host formulas of dmp_adamw_step_skip, evaluated on the device
     const double step = a.state[0], lr = a.state[1];
     const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2d, step);
     a.decay = (float)(1.0 - lr * a.lr_wd);
@@ -292,6 +330,16 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
     bool skip = false;                                         // parameters without a gradient this step (torch.optim.AdamW skips them)
     for (int s = 0; s < a.nskip; ++s) skip |= (i >= a.skip_lo[s] && i < a.skip_hi[s]);
     if (skip) continue;
+    if (a.seg_tab) {                                           // this element's parameter tensor: its own bias corrections
+      int lo = 0, hi = a.P;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.seg_off[mid] <= i) lo = mid; else hi = mid;
+      }
+      a.step_size = a.seg_tab[2 * lo];
+      if (a.step_size < 0.f) continue;                         // no gradient this step: untouched, its step count stands
+      a.inv_bc2_sqrt = a.seg_tab[2 * lo + 1];
+    }
     float p[4], g[4], m[4], v[4], vm[4];
     const bool full = i + 4 <= a.n;
     const int cnt = full ? 4 : (int)(a.n - i);
@@ -848,6 +896,7 @@ static int adamw_launch(float *param, const float *grad, float *exp_avg, float *
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;
   a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2); a.eps = (float)eps;
   a.state = state; a.lr_wd = weight_decay; a.beta1 = beta1; a.beta2d = beta2; a.veto = veto;
+  a.seg_off = nullptr; a.seg_tab = nullptr; a.P = 0;
   a.decay = 1.f; a.step_size = 0.f; a.inv_bc2_sqrt = 1.f;
   if (!state) {
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -879,6 +928,32 @@ int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *e
   if (!state || (reinterpret_cast<uintptr_t>(state) & 7u)) return DMP_ERR_BAD_ARG;
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n, 0.0, beta1, beta2, eps, weight_decay, 0, state,
                       skip_lo, skip_hi, nskip, stream);
+}
+
+int dmp_adamw_step_segments(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                            int64_t n, double *state, const int64_t *seg_off, int P, const uint64_t *live, float *seg_tab,
+                            double beta1, double beta2, double eps, double weight_decay, int32_t *veto, int32_t veto_mask,
+                            void *stream) {
+  DMP_ROW_CHECK(n >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
+  if (!state || (reinterpret_cast<uintptr_t>(state) & 7u) || !seg_off || !seg_tab || P < 1 || P > DMP_ADAMW_MAX_SEGMENTS)
+    return DMP_ERR_BAD_ARG;
+  if (n == 0) return DMP_OK;
+  DMP_ROW_CHECK(param && grad && exp_avg && exp_avg_sq);
+  if (!ok16(param) || !ok16(grad) || !ok16(exp_avg) || !ok16(exp_avg_sq) || !ok16(max_exp_avg_sq)) return DMP_ERR_UNSUPPORTED;
+  SegTick t;
+  t.state = state; t.tab = seg_tab; t.P = P; t.beta1 = beta1; t.beta2 = beta2; t.veto = veto; t.mask = veto_mask; t.all = live ? 0 : 1;
+  for (int w = 0; w < DMP_ADAMW_MAX_SEGMENTS / 64; ++w) t.live[w] = (live && w < (P + 63) / 64) ? live[w] : 0ull;
+  AdamArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;
+  a.beta1_c = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.state = state; a.lr_wd = weight_decay; a.beta1 = beta1; a.beta2d = beta2; a.veto = veto;
+  a.decay = 1.f; a.step_size = 0.f; a.inv_bc2_sqrt = 1.f; a.nskip = 0;
+  a.seg_off = seg_off; a.seg_tab = seg_tab; a.P = P;
+  int64_t nb = (n / 4 + kBlock) / kBlock;
+  if (nb > 2048) nb = 2048;
+  adamw_tick_segments<<<1, kBlock, 0, (hipStream_t)stream>>>(t);
+  adamw_kernel<<<(unsigned)nb, kBlock, 0, (hipStream_t)stream>>>(a);
+  return check_launch();
 }
 
 int dmp_adamw_step_guarded(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,

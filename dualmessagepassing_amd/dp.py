@@ -12,6 +12,8 @@ as one message instead of per-parameter buckets.
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -70,6 +72,10 @@ class FlatGradSync:
                 p.data = v
             self.master = torch.nn.Parameter(store, requires_grad=True)
             self.master.grad = self.flat
+            # where the parameter tensors sit in the buffer: FlatAdamW keeps one step count per tensor, as torch.optim.AdamW does
+            self.master._dmp_seg = (torch.tensor(self.offsets + [int(self.flat.numel())], dtype=torch.int64, device=self.flat.device),
+                                    len(self.params))
+            self.master._dmp_live_params = None
         return self.master
 
     @property
@@ -133,6 +139,7 @@ class FlatGradSync:
         master = getattr(self, "master", None)
         if master is None:
             return
+        master._dmp_live_params = None if live is None else tuple(live)
         if live is None:
             master._dmp_live_runs = None
             return
@@ -195,11 +202,19 @@ class FlatGradSync:
                 self.flat.div_(self.world)
 
 
+USE_SEGMENT_STEPS = os.environ.get("DMP_ADAMW_SEGMENTS", "1") == "1"   # one AdamW step count per parameter tensor of a flat buffer
+
+
 class FlatAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` (optionally ``amsgrad``: the reference's optimizer, train.py:1231) whose step is
     ONE HIP launch per parameter tensor (``dmp_adamw_step``) -- meant for the single flat parameter of
     ``FlatGradSync.flatten_parameters()``.  Learning-rate schedulers work as usual (``param_groups``).
     fp32 contiguous CUDA parameters only; no CPU path.
+
+    On the flat parameter of ``FlatGradSync.flatten_parameters()`` every parameter TENSOR of the buffer keeps its own step
+    count (``dmp_adamw_step_segments``: a tensor that first receives a gradient at step k starts its bias corrections at
+    1, one without a gradient is left alone -- ``torch.optim.AdamW``'s per-tensor state); the counts and the learning rate
+    live in device memory, so such a step also replays from a HIP graph.
 
     ``capturable=True``: the step count and the learning rate live in device memory (``dmp_adamw_step_dev``), so a step
     recorded in a HIP graph (``StepGraph``) replays correctly; outside a capture ``step()`` writes the group's current
@@ -229,13 +244,30 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def sync_state(self):
-        """Read the device-side step counts back into ``state[p]["step"]`` (one host sync): graph replays advance only the
-        device count.  ``state_dict()`` calls it."""
+        """Read the device-side step counts back into ``state[p]["step"]`` (and ``["seg_steps"]``: one count per parameter
+        tensor of a flat buffer) -- one host sync: graph replays advance only the device counts.  ``state_dict()`` calls it."""
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state.get(p)
-                if st and "dev" in st:
+                if st and "dev_seg" in st:
+                    host = st["dev_seg"].tolist()
+                    st["step"] = int(round(host[0]))
+                    st["seg_steps"] = [int(round(x)) for x in host[2:]]
+                elif st and "dev" in st:
                     st["step"] = int(round(float(st["dev"][0].item())))
+
+    def _segment_state(self, p, group, P):
+        """Device state of the per-tensor form: doubles [steps taken, lr, step of tensor 0, ..., step of tensor P - 1]."""
+        st = self.state[p]
+        if "dev_seg" not in st:
+            seg = st.get("seg_steps")
+            if seg is None or len(seg) != P:
+                seg = [st.get("step", 1) - 1] * P               # an older state: every tensor at the buffer's count
+            st["dev_seg"] = torch.tensor([float(st.get("step", 1) - 1), float(group["lr"])] + [float(x) for x in seg],
+                                         dtype=torch.float64, device=p.device)
+            st["seg_tab"] = torch.empty(2 * P, dtype=torch.float32, device=p.device)
+            st["dev_lr"] = float(group["lr"])
+        return st["dev_seg"], st["seg_tab"]
 
     def state_dict(self):
         """``torch.optim.Optimizer.state_dict`` with the step counts current (``sync_state``) and without the device-side
@@ -243,7 +275,7 @@ class FlatAdamW(torch.optim.Optimizer):
         loads into a capturable or a plain ``FlatAdamW`` alike."""
         self.sync_state()
         sd = super().state_dict()
-        sd["state"] = {k: {n: v for n, v in st.items() if n not in ("dev", "dev_lr")} for k, st in sd["state"].items()}
+        sd["state"] = {k: {n: v for n, v in st.items() if n not in ("dev", "dev_lr", "dev_seg", "seg_tab")} for k, st in sd["state"].items()}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -251,6 +283,8 @@ class FlatAdamW(torch.optim.Optimizer):
         for st in self.state.values():                       # the device scalars follow the loaded step count
             st.pop("dev", None)
             st.pop("dev_lr", None)
+            st.pop("dev_seg", None)
+            st.pop("seg_tab", None)
             if torch.is_tensor(st.get("step")):
                 st["step"] = int(st["step"].item())
 
@@ -261,8 +295,10 @@ class FlatAdamW(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state.get(p)
-                if st and "dev" in st and st["dev_lr"] != float(group["lr"]):
-                    st["dev"][1:].fill_(float(group["lr"]))
+                if st and ("dev" in st or "dev_seg" in st) and st["dev_lr"] != float(group["lr"]):
+                    for key in ("dev", "dev_seg"):
+                        if key in st:
+                            st[key][1:2].fill_(float(group["lr"]))
                     st["dev_lr"] = float(group["lr"])
 
     @torch.no_grad()
@@ -286,6 +322,30 @@ class FlatAdamW(torch.optim.Optimizer):
                     if group["amsgrad"]:
                         st["max_exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
+                seg = getattr(p, "_dmp_seg", None)
+                if seg is not None and USE_SEGMENT_STEPS and seg[1] <= 1024 and seg[0].device == p.device:
+                    # a flat buffer of parameter tensors: one step count per tensor (torch.optim.AdamW's state), on the device
+                    import ctypes
+                    dev, tab = self._segment_state(p, group, seg[1])
+                    if not torch.cuda.is_current_stream_capturing():
+                        self.sync_hyper()
+                    live = getattr(p, "_dmp_live_params", None)
+                    bits = None
+                    if live is not None:
+                        words = [0] * ((seg[1] + 63) // 64)
+                        for i in live:
+                            words[i >> 6] |= 1 << (i & 63)
+                        bits = (ctypes.c_uint64 * len(words))(*words)
+                    veto = self.veto
+                    if veto is not None:
+                        _lib.require_gpu(veto[0])
+                    _lib.check(lib.dmp_adamw_step_segments(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                                           st["exp_avg_sq"].data_ptr(), _lib.ptr(st.get("max_exp_avg_sq")), p.numel(),
+                                                           dev.data_ptr(), seg[0].data_ptr(), seg[1], bits, tab.data_ptr(), b1, b2,
+                                                           group["eps"], group["weight_decay"],
+                                                           None if veto is None else veto[0].data_ptr(), 0 if veto is None else veto[1],
+                                                           _lib.stream_ptr()), "dmp_adamw_step_segments")
+                    continue
                 state = None
                 if self.capturable or self.veto is not None:
                     state = self._device_state(p, group)

@@ -1,15 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04i
-timeout 1500 python -m pytest tests/test_gpu_compact.py tests/test_gpu_kernels.py tests/test_gpu_dmplayer.py tests/test_gpu_bench_composite.py -x -q -m gpu > gpurun_out/r04i/tests.log 2>&1
+timeout 1800 python -m pytest tests/test_gpu_compact.py tests/test_gpu_graph.py tests/test_gpu_dp.py tests/test_gpu_harness.py tests/test_gpu_unc_harness.py tests/test_gpu_pins_r2.py tests/test_gpu_bench_line.py -x -q -m gpu > gpurun_out/r04i/tests.log 2>&1
 echo "rc=$?" >> gpurun_out/r04i/tests.log
-tail -12 gpurun_out/r04i/tests.log
-timeout 500 python3 bench.py --no-cpu-baseline --no-all-outputs --extended-steps 0 > gpurun_out/r04i/bench.json 2> gpurun_out/r04i/bench.err
-DMP_ROW_MASKS=0 timeout 500 python3 bench.py --no-cpu-baseline --no-all-outputs --extended-steps 0 > gpurun_out/r04i/bench_off.json 2>> gpurun_out/r04i/bench.err
-python3 - <<'PY'
-import json
-for n in ("bench","bench_off"):
-    p=json.loads([l for l in open("gpurun_out/r04i/%s.json"%n) if l.startswith("{")][-1])
-    print(n, p["value"], p["ms_per_step"], p["step_ms_median"], "gate:", p["gate_compact"]["ms_per_step"])
-    for k,v in sorted(p["kernels"].items()):
-        if any(x in k for x in ("out_fwd_mfma[H=128,R=548864","bwd_h1_mfma[H=128,E=548864","atb_rows[M=128,N=128,R=548864")): print("   ", k, v["avg_us"])
-PY
+tail -25 gpurun_out/r04i/tests.log

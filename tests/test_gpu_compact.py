@@ -349,3 +349,55 @@ def test_masked_row_kernels_do_not_read_gated_rows_and_equal_the_unmasked(H, R):
     assert th.equal(out, ref_out)
     assert th.equal(dg, ref_dg) and th.equal(db, ref_db)
     assert bool(th.isfinite(out).all()) and bool(th.isfinite(dg).all())
+
+
+@pytest.mark.parametrize("amsgrad", [True, False])
+def test_flat_adamw_keeps_one_step_count_per_parameter_tensor(amsgrad):
+    """A parameter that first receives a gradient at optimizer step k gets torch.optim.AdamW's bias corrections (its own
+    count starts at 1), one that skips steps keeps its count -- on the flat buffer of ``FlatGradSync.flatten_parameters``."""
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    gpu = th.device("cuda:0")
+    th.manual_seed(5)
+
+    class M(th.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = th.nn.Parameter(th.randn(37, 5))
+            self.b = th.nn.Parameter(th.randn(130))
+            self.c = th.nn.Parameter(th.randn(8, 8))
+
+    m = M().to(gpu)
+    ref = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    sync = FlatGradSync(m)
+    opt = FlatAdamW([sync.flatten_parameters()], lr=3e-3, weight_decay=1e-2, amsgrad=amsgrad)
+    ropt = th.optim.AdamW(ref, lr=3e-3, weight_decay=1e-2, amsgrad=amsgrad)
+    live_at = [(0,), (0, 2), (0, 1, 2), (0, 1), (1, 2), (0, 1, 2), (2,)]        # b joins at step 3, c skips steps 4 and 1
+    params = list(m.parameters())
+    for step, live in enumerate(live_at):
+        sync.detach_grads()
+        for r in ref:
+            r.grad = None
+        for i in live:
+            g = th.randn(params[i].shape, device=gpu)
+            params[i].grad = g.clone()
+            ref[i].grad = g.clone()
+        sync.pack()
+        opt.step()
+        ropt.step()
+        for i, (p, r) in enumerate(zip(params, ref)):
+            err = float((p.detach() - r.detach()).abs().max())
+            assert err <= 2e-6 * max(1.0, float(r.detach().abs().max())), (step, i, err)
+    opt.sync_state()
+    st = opt.state[sync.master]
+    assert st["seg_steps"] == [5, 4, 5] and st["step"] == 7
+    sd = opt.state_dict()
+    opt2 = FlatAdamW([sync.master], lr=3e-3, weight_decay=1e-2, amsgrad=amsgrad)
+    opt2.load_state_dict(sd)
+    sync.detach_grads()
+    for i in range(3):
+        g = th.randn(params[i].shape, device=gpu)
+        params[i].grad = g.clone(); ref[i].grad = g.clone()
+    sync.pack()
+    opt2.step(); ropt.step()                                       # the reloaded optimizer carries the per-tensor counts on
+    for p, r in zip(params, ref):
+        assert float((p.detach() - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
