@@ -438,4 +438,5 @@ def compact_gated_edges(graph, e_gate, capacity, status):
     g.max_num_edges = int(graph.max_num_edges) + cap // B + 1                # kept edges of a graph + its share of the padding
     g.tiling = ops.graph_tiling(node_off, g.edge_offsets, B, g.max_num_edges)
     g.node_tiling = ops.graph_node_tiling(node_off, g.edge_offsets, B, g.max_num_nodes)
+    gate_c._dmp_dense_gate = True                         # ones but for the padding rows: the masked-row kernels have nothing to skip
     return CompactedEdges(g, ids[2], gate_c, E, kept)

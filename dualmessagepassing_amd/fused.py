@@ -419,15 +419,22 @@ def gate_row_mask(gate):
     memoised on the gate tensor (a layer's forward and backward, and every layer of a rep-net, share the gate)."""
     if gate is None or not USE_ROW_MASKS:
         return None
-    hit = getattr(gate, "_dmp_row_mask", None)
-    if hit is not None and hit[0] == gate._version:
+    # the layers hand their kernels reshaped VIEWS of the gate they were given (a new tensor object per layer): the mask
+    # hangs on the tensor the views share (same memory, same version counter), so a rep-net builds it once per step
+    owner = gate._base if gate._base is not None else gate
+    if owner.data_ptr() != gate.data_ptr() or owner.numel() != gate.numel():
+        owner = gate
+    if getattr(owner, "_dmp_dense_gate", False):            # a gate its maker knows to be (almost) all ones: nothing to skip
+        return None
+    hit = getattr(owner, "_dmp_row_mask", None)
+    if hit is not None and hit[0] == owner._version:
         return hit[1]
     lib = _lib.load()
     R = gate.numel()
     mask = torch.empty(((R + 31) // 32,), dtype=torch.int32, device=gate.device)
     check(lib.dmp_row_mask_bits(ptr(gate), R, ptr(mask), stream_ptr()), "dmp_row_mask_bits")
     try:
-        gate._dmp_row_mask = (gate._version, mask)
+        owner._dmp_row_mask = (owner._version, mask)
     except Exception:
         pass
     return mask
