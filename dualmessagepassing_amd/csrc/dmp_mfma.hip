@@ -82,9 +82,15 @@ struct MfmaArgs {
   const uint32_t *rowmask;
 };
 
-template <int NC, int EPI, int PP, int H = 128>
-__global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)) void mfma_pp(MfmaArgs p) {
+// X6 (the pipelined one-panel form only): the product on the bf16 matrix pipe as six piece products per 16-deep k-group
+// (dmp_mfma_common.h, "bf16x6": fp32-accurate) -- the weight panel lives in registers as pieces (96 instead of 64 VGPRs:
+// two workgroups per CU instead of three), a staged tile is three bf16 planes (split once, by the staging thread).  At
+// 18 GFLOP per E-row launch the f32-input MFMA is as tight a bound as the kernel's bytes (114 us of matrix pipe at its
+// peak); on bf16x6 (43 us) the row masks' saved bytes become time.
+template <int NC, int EPI, int PP, int H = 128, bool X6 = false>
+__global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 1 ? 3 : 2))) void mfma_pp(MfmaArgs p) {
   static_assert(H == 128 || (H == 64 && !PP), "H = 64: independent workgroups only");
+  static_assert(!X6 || (!PP && NC == 1 && (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G)), "bf16x6: the pipelined one-panel form");
   constexpr int NG = PP ? 2 : 1;                            // wave groups per workgroup
   constexpr int kGThreads = 2 * H;                          // threads of a wave group: H / 32 waves, one 32-column slice each
   constexpr int kStride = H + 4, kQ = H / 4, kHalf = H / 2, kSteps4 = H / 8;   // LDS row stride, float4 per row, k per lane half
@@ -94,7 +100,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
   // tile (second operand register set: streamed rows need a whole tile of latency) in the MFMA shadow.
   constexpr bool kPipe = !PP && NC == 1 && (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G);
   constexpr int NBUF = kPipe ? 2 : 1, NPAR = kPipe ? 3 : 2;
-  __shared__ float As[NG * NBUF][kSub * kStride];
+  // X6: a staged tile = three bf16 planes (hi | mid | lo), rows of kStrideD dwords (H bf16 + 8 of padding: conflict-free
+  // ds_read_b128 of 8 consecutive k per lane, as in dmp_typed.hip)
+  constexpr int kStrideD = (H + 8) / 2, kPlane = kSub * kStrideD, kGroups = kHalf / 8;
+  __shared__ __attribute__((aligned(16))) float As[NG * NBUF][X6 ? 3 * kPlane : kSub * kStride];
   __shared__ float Cs[(H / 32) * NG][32 * kScrStride];
   __shared__ uint32_t rowA[NG][NPAR][kSub], rowB[NG][NPAR][kSub];   // [group][tile parity (kPipe: tile % 3)][row]
   __shared__ float rowS[NG][NPAR][kSub];
@@ -102,22 +111,38 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   const int grp = PP ? wave >> 2 : 0, cs = PP ? wave & 3 : wave, gtid = threadIdx.x & (kGThreads - 1);
   const int col = 32 * cs + li;
-  float b[NC][kHalf];
+  float b[NC][X6 ? 1 : kHalf];
+  Split8 B6[X6 ? kGroups : 1];                              // X6: fragment g = the pieces of k-steps kHalf h + 8 g .. + 7
+  auto wload = [&](int q, int s) {
+    const int k = s + kHalf * h, j = H * q + col;
+    // bt 0: B[k][j] row-major; 1: transposed storage B^T[j][k]; 2: panel q is the K-slice
+    // [Hq, Hq+H) of a transposed [H, NC*H] matrix: B_q[k][col] = W[col][Hq + k]
+    return p.bt == 0 ? p.B[(int64_t)k * p.ldb + j]
+         : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
+                     : p.B[(int64_t)col * p.ldb + H * q + k];
+  };
+  if (X6) {
 #pragma unroll
-  for (int q = 0; q < NC; ++q)
+    for (int g = 0; g < kGroups; ++g) {
+      float w[8];
 #pragma unroll
-    for (int s = 0; s < kHalf; ++s) {
-      const int k = s + kHalf * h, j = H * q + col;
-      // bt 0: B[k][j] row-major; 1: transposed storage B^T[j][k]; 2: panel q is the K-slice
-      // [Hq, Hq+H) of a transposed [H, NC*H] matrix: B_q[k][col] = W[col][Hq + k]
-      b[q][s] = p.bt == 0 ? p.B[(int64_t)k * p.ldb + j]
-              : p.bt == 1 ? p.B[(int64_t)j * p.ldb + k]
-                          : p.B[(int64_t)col * p.ldb + H * q + k];
+      for (int j = 0; j < 8; ++j) w[j] = wload(0, 8 * g + j);
+      split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[X6 ? g : 0]);
     }
 #pragma unroll
-  for (int q = 0; q < NC; ++q)
+    for (int g = 0; g < kGroups; ++g)
 #pragma unroll
-    for (int s = 0; s < kHalf; ++s) asm volatile("" ::"v"(b[q][s]));  // loads complete here, not inside the loop
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(B6[X6 ? g : 0].hi.u[j]), "v"(B6[X6 ? g : 0].mid.u[j]), "v"(B6[X6 ? g : 0].lo.u[j]));
+  } else {
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int s = 0; s < kHalf; ++s) b[q][X6 ? 0 : s] = wload(q, s);
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int s = 0; s < kHalf; ++s) asm volatile("" ::"v"(b[q][X6 ? 0 : s]));  // loads complete here, not inside the loop
+  }
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);  // EPI_RELU_BWD_G: this lane's 4 columns
   float *As_g = As[grp * NBUF];
   float *scr = Cs[wave];
@@ -212,7 +237,17 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
   };
 
   auto stage_row_to = [&](int buf, int m) {
-    *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
+    if (X6) {                                              // split once, here: three bf16 planes
+      uint2 ph, pm, pl;
+      split_pair(pre[m].x, pre[m].y, ph.x, pm.x, pl.x);
+      split_pair(pre[m].z, pre[m].w, ph.y, pm.y, pl.y);
+      uint32_t *q = reinterpret_cast<uint32_t *>(&As[buf][0]) + ((gtid / kQ) + 8 * m) * kStrideD + (gtid % kQ) * 2;
+      *reinterpret_cast<uint2 *>(q) = ph;
+      *reinterpret_cast<uint2 *>(q + kPlane) = pm;
+      *reinterpret_cast<uint2 *>(q + 2 * kPlane) = pl;
+    } else {
+      *reinterpret_cast<float4 *>(&As[buf][((gtid / kQ) + 8 * m) * kStride + (gtid % kQ) * 4]) = pre[m];
+    }
   };
   auto stage_scalars_to = [&](int par) {
     if (gtid < kSub) rowS[grp][par][gtid] = (EPI == EPI_GATE_RES && !p.rowscale) ? 1.f : pre_s;
@@ -261,10 +296,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][4 * s4 + 0], acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][4 * s4 + 1], acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][4 * s4 + 2], acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][4 * s4 + 3], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][X6 ? 0 : 4 * s4 + 0], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][X6 ? 0 : 4 * s4 + 1], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][X6 ? 0 : 4 * s4 + 2], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][X6 ? 0 : 4 * s4 + 3], acc[q], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       a4 = an;
@@ -284,6 +319,42 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
       else if (i < 13) pre[i - 9] = buf_load4(ra2, voff_if(mk2 >> (8 * (i - 9)), abit, voffA), (i - 9) * grpA);   // tile k+2's rows
       else if (i == 13) load_scalars_of(t2);
     };
+    if (X6) {
+      // per 16-deep k-group g: six MFMAs on the three piece fragments of A (this lane's 8 consecutive k = kHalf h + 8 g ..
+      // of row li: one ds_read_b128 per plane, requested one group ahead) and the panel fragment B6[g]; the 14 shadow
+      // actions are spread between them (two per group at H = 128, four at H = 64)
+      constexpr int kPer = 16 / kGroups;
+      const uint32_t *ar = reinterpret_cast<const uint32_t *>(&As[buf][0]) + li * kStrideD + (kHalf / 2) * h;
+      Frag8 ah, am, al;
+      ah.v = *reinterpret_cast<const bf16x8 *>(ar);
+      am.v = *reinterpret_cast<const bf16x8 *>(ar + kPlane);
+      al.v = *reinterpret_cast<const bf16x8 *>(ar + 2 * kPlane);
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        Frag8 nh = ah, nm = am, nl = al;
+        if (g + 1 < kGroups) {
+          nh.v = *reinterpret_cast<const bf16x8 *>(ar + 4 * (g + 1));
+          nm.v = *reinterpret_cast<const bf16x8 *>(ar + kPlane + 4 * (g + 1));
+          nl.v = *reinterpret_cast<const bf16x8 *>(ar + 2 * kPlane + 4 * (g + 1));
+        }
+        const Split8 &bb = B6[X6 ? g : 0];
+        auto after = [&](int n) {                           // the actions due after the n-th MFMA of the group
+#pragma unroll
+          for (int q = 0; q < kPer; ++q)
+            if (6 * (q + 1) / kPer == n) shadow(kPer * g + q);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bb.hi.v, acc[0], 0, 0, 0); after(1);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.lo.v, acc[0], 0, 0, 0); after(2);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.mid.v, acc[0], 0, 0, 0); after(3);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.hi.v, acc[0], 0, 0, 0); after(4);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.mid.v, acc[0], 0, 0, 0); after(5);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.hi.v, acc[0], 0, 0, 0); after(6);
+        ah = nh; am = nm; al = nl;
+      }
+      return;
+    }
     const float *arow = &As[buf][li * kStride + kHalf * h];
     float4 a4 = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
@@ -291,10 +362,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (NC == 1 ? 3 : 2)
       float4 an = a4;
       if (s4 + 1 < kSteps4) an = *reinterpret_cast<const float4 *>(arow + 4 * (s4 + 1));
       __builtin_amdgcn_sched_barrier(0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[0][4 * s4 + 0], acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[0][4 * s4 + 1], acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[0][4 * s4 + 2], acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[0][4 * s4 + 3], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[0][X6 ? 0 : 4 * s4 + 0], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[0][X6 ? 0 : 4 * s4 + 1], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[0][X6 ? 0 : 4 * s4 + 2], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[0][X6 ? 0 : 4 * s4 + 3], acc[0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kSteps4 == 16) shadow(s4);
       else { shadow(2 * s4); shadow(2 * s4 + 1); }
@@ -454,10 +525,17 @@ inline unsigned wg_blocks(int64_t E, int per_cu) {
   return (unsigned)(ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap);
 }
 
+// the pipelined one-panel kernels (out_fwd, bwd_h1) at H = 128: on the bf16 pipe (two workgroups per CU) unless the
+// development switch asks for the exact f32 MFMA (dmp_dev_set_exact_fp32) or for the ping-pong variant
+template <int EPI> constexpr bool x6_kind() { return EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G; }
+template <int NC, int EPI> inline bool x6_on() { return NC == 1 && x6_kind<EPI>() && g_variant == 0 && !g_exact_fp32; }
 template <int NC, int EPI>
 inline int launch_mfma(const MfmaArgs &p, hipStream_t st) {
   if (g_variant == 1) mfma_pp<NC, EPI, 1><<<pp_blocks(p.E), kPPThreads, 0, st>>>(p);
-  else mfma_pp<NC, EPI, 0><<<wg_blocks(p.E, NC == 1 ? 3 : 2), kGroupThreads, 0, st>>>(p);
+  else if constexpr (NC == 1 && x6_kind<EPI>()) {
+    if (x6_on<NC, EPI>()) mfma_pp<NC, EPI, 0, 128, true><<<wg_blocks(p.E, 2), kGroupThreads, 0, st>>>(p);
+    else mfma_pp<NC, EPI, 0><<<wg_blocks(p.E, 3), kGroupThreads, 0, st>>>(p);
+  } else mfma_pp<NC, EPI, 0><<<wg_blocks(p.E, NC == 1 ? 3 : 2), kGroupThreads, 0, st>>>(p);
   return check_launch();
 }
 // H = 64, one panel: 128-thread workgroups, 5 per CU (27 KB of LDS each)
@@ -584,7 +662,9 @@ int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int
   return H == 128 ? launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream) : launch_mfma64<EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
-int64_t dmp_mfma_partial_rows(int64_t E) { return g_variant == 1 ? 2 * (int64_t)pp_blocks(E) : (int64_t)wg_blocks(E, 3); }
+int64_t dmp_mfma_partial_rows(int64_t E) {      // = the grid of the EPI_RELU_BWD_G launch (bwd_h1): one partial row per workgroup
+  return g_variant == 1 ? 2 * (int64_t)pp_blocks(E) : (int64_t)wg_blocks(E, x6_on<1, EPI_RELU_BWD_G>() ? 2 : 3);
+}
 int64_t dmp_mfma_partial_rows_h(int64_t E, int H) { return H == 64 ? (int64_t)wg_blocks(E, kPerCU64) : dmp_mfma_partial_rows(E); }
 
 void dmp_dev_set_mfma_variant(int v) { g_variant = v; }

@@ -83,6 +83,18 @@ def run_all(gpu, rows=4099, h=128):
         scale = th.cat([zd.abs().t() @ dd.abs(), zd.abs().t() @ (dd.abs() * ce[:, None])], 1)
         x6, ex = _both(lib, lambda: fused.atb_typed(z, d, coef, ix))
         r["atb_typed"] = (_rel(x6, ref, scale), _rel(ex, ref, scale), bool(th.isfinite(x6).all()))
+        # --- out_fwd (round 4 on bf16x6): prev + gate (z W2^T + b2) with prev = 0, b2 = 0, gate = 1: z W2^T
+        w2 = wes[:, :h].t().contiguous()                              # nn.Linear weight [out, in]: W2[j][k] = A[k][j]
+        ones = th.ones(rows, device=gpu)
+        ref = zd @ wd[:, :h]
+        scale = zd.abs() @ wd[:, :h].abs()
+        x6, ex = _both(lib, lambda: fused.out_fwd_mfma(z, w2, None, ones, None))
+        r["out_fwd"] = (_rel(x6, ref, scale), _rel(ex, ref, scale), bool(th.isfinite(x6).all()))
+        # --- bwd_h1 (round 4 on bf16x6): act'(H1) (gate z) W2 with H1 > 0 everywhere, gate = 1: z W2, W2 = A^T's storage
+        w2b = wes[:, :h].contiguous()                                 # dH1 = dO @ W2 with W2 [out = k, in = j] = A[k][j]
+        pos = th.ones(rows, h, device=gpu)
+        x6, ex = _both(lib, lambda: fused.bwd_h1_mfma(z, w2b, pos, both_halves=False, gate=ones, slope=0.0)[0])
+        r["bwd_h1"] = (_rel(x6, ref, scale), _rel(ex, ref, scale), bool(th.isfinite(x6).all()))
         # --- gemm_x6 (always bf16x6) against torch's fp32 product
         B = wes[:, :h].contiguous()
         ref = zd @ B.double()

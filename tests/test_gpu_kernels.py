@@ -581,12 +581,17 @@ def test_pingpong_driver_matches_default(gpu):
         return (fused.edge_fwd_mfma(z, wes, xp[:, h:], 3 * h, bias, coef, ix), fused.out_fwd_mfma(z, w2, bias, gate, z),
                 fused.bwd_h1_mfma(z, w2, z.clamp_min(0), coef, ix)[0],
                 fused.bwd_z_mfma(th.cat([z, z], 1), wes, xp[:, :2 * h].contiguous(), z, coef, ix))
-    base = run()
+    # (both on the f32-input MFMA: the default driver's one-panel kernels run on the bf16 pipe otherwise, round 4)
+    lib.dmp_dev_set_exact_fp32(1)
     try:
-        lib.dmp_dev_set_mfma_variant(1)
-        other = run()
+        base = run()
+        try:
+            lib.dmp_dev_set_mfma_variant(1)
+            other = run()
+        finally:
+            lib.dmp_dev_set_mfma_variant(0)
     finally:
-        lib.dmp_dev_set_mfma_variant(0)
+        lib.dmp_dev_set_exact_fp32(0)
     for a, b in zip(base, other):
         assert th.equal(a, b)
 
