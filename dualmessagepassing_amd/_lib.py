@@ -147,6 +147,7 @@ SIGNATURES = {
     "dmp_atb_typed_blocks_h": (c_i64, [c_i64, c_int]),
     "dmp_atb_rows_blocks_h": (c_i64, [c_i64, c_int, c_int, c_int]),
     "dmp_atb_rows_h": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "dmp_atb_rows_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_jobs_blocks_h": (c_i64, [c_i64, c_int, c_int]),
     "dmp_atb_rows_jobs_h": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr]),
     "dmp_mfma_partial_rows_h": (c_i64, [c_i64, c_int]),
@@ -180,7 +181,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 55
+ABI_VERSION = 56
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

@@ -43,6 +43,8 @@ struct AtbArgs {
   const int32_t *slot_d;           // relational variant: row of D per slot (slot_edge: row of Z), -1 = padding
   const float *slot_scale;         // relational variant: [tiles * 32] scale of Z's row per slot, or NULL
   const int32_t *type_tile_ptr;    // relational variant: [types + 1] first tile of every type
+  const uint32_t *rowmask;         // rows variant with a gate: bit r of rowmask[t] == 0 -> row 32 t + r has gate 0 and is not fetched
+  int rows_x6;                     // rows variant: 1 = on the bf16 pipe (dmp_atb_rows_masked picks it)
 };
 
 enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
@@ -115,10 +117,13 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
         }
       }
     } else {
+      // rows under a zero gate (dmp_row_mask_bits) are not fetched: they contribute gate * z = 0 to every sum
+      const uint32_t mk = (MODE == ATB_ROWS && p.rowmask && ok) ? p.rowmask[lo + k] : 0xffffffffu;
 #pragma unroll
       for (int m = 0; m < NL; ++m) {
-        const int64_t r = (int64_t)(lo + k) * kSub + (gtid / kQ) + kPass * m;
-        id_rows[m] = ok && r < p.E ? (int)r : -1;
+        const int rt = (gtid / kQ) + kPass * m;
+        const int64_t r = (int64_t)(lo + k) * kSub + rt;
+        id_rows[m] = ok && r < p.E && ((mk >> rt) & 1u) ? (int)r : -1;
       }
     }
   };
@@ -401,7 +406,8 @@ void launch_atb(const AtbArgs &a, dim3 grid, hipStream_t st) {
     atb_k<MODE, H, MODE == ATB_TYPED, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
     return;
   }
-  if (g_exact_fp32 || MODE != ATB_TYPED) atb_k<MODE, H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
+  const bool x6 = MODE == ATB_TYPED || (MODE == ATB_ROWS && a.rows_x6);
+  if (g_exact_fp32 || !x6) atb_k<MODE, H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
   else atb_k<MODE, H, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
 }
 
@@ -526,6 +532,12 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
 
 int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N, int H,
                    float *partial, float *partial_colsum, void *stream) {
+  return dmp_atb_rows_masked(A, lda, B, ldb, gate, nullptr, 0, rows, M, N, H, partial, partial_colsum, stream);
+}
+
+int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, const uint32_t *rowmask,
+                        int x6, int64_t rows, int M, int N, int H, float *partial, float *partial_colsum, void *stream) {
+  if (rowmask && !gate) return DMP_ERR_BAD_ARG;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || M <= 0 || N <= 0) return DMP_ERR_BAD_ARG;
   if (M % H || N % H || (int64_t)(M / H) * (N / H) > 65535) return DMP_ERR_UNSUPPORTED;
@@ -538,6 +550,7 @@ int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, con
   AtbArgs a{};
   a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
   a.gate = gate; a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.pCS = partial_colsum; a.nb = N / H; a.cs_ld = M;
+  a.rowmask = rowmask; a.rows_x6 = x6 ? 1 : 0;
   const dim3 grid(rows_blocks(rows, M, N, H), (unsigned)((M / H) * (N / H)));
   if (H == 128) {
     if (!lds_ready<ATB_ROWS, 128>()) return DMP_ERR_HIP;

@@ -488,11 +488,12 @@ def atb_rows(a, b, gate=None, colsum=True):
     part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
     part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
     with _lib.timed("atb_rows[M=%d,N=%d,R=%d]", (M, N, R), 4 * (M + N) * R + (4 * R if gate is not None else 0)):
-        check(lib.dmp_atb_rows_h(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), R, M, N, blk, ptr(part), ptr(part_cs),
-                                 stream_ptr()), "dmp_atb_rows_h")
+        check(lib.dmp_atb_rows_masked(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), ptr(gate_row_mask(gate)), ATB_ROWS_X6,
+                                      R, M, N, blk, ptr(part), ptr(part_cs), stream_ptr()), "dmp_atb_rows_masked")
     return reduce_partials(part).view(M, N), (reduce_partials(part_cs) if colsum else None)
 
 
+ATB_ROWS_X6 = int(_os.environ.get("DMP_ATB_ROWS_X6", "0"))   # the gated rows weight gradient on the bf16 pipe (csrc/dmp_atb.hip)
 SMALLK_MAX = 16
 
 

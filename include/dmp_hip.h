@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 55
+#define DMP_ABI_VERSION 56
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1028,6 +1028,11 @@ int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H);
 int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
                    int64_t rows, int M, int N, int H, float *partial, float *partial_colsum,
                    void *stream);
+/* dmp_atb_rows_h with a row mask (dmp_row_mask_bits of the gate: the rows under a zero gate, which contribute gate * a = 0 to
+ * every sum, are not fetched) and the choice of the matrix pipe: x6 != 0 = bf16x6 (fp32-accurate, dmp_dev_set_exact_fp32
+ * overrides), 0 = the f32-input MFMA. */
+int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, const uint32_t *rowmask,
+                        int x6, int64_t rows, int M, int N, int H, float *partial, float *partial_colsum, void *stream);
 
 /*
  * Relation-typed products of the relational layers (SubgraphCountingMatching/models/rgcn.py:98-123,
