@@ -100,8 +100,12 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
           float w = 1.f;
           if (WEIGHTED) w = __shfl(myw, min(j + k, G - 1), G);
           if (act && j + k < cnt) {
-            v[k] = ld4(M + (int64_t)(e[k] >> 1) * ldm + c);
-            if (WEIGHTED) v[k] = mul4(v[k], w);
+            if (WEIGHTED && w == 0.f) {
+              v[k] = zero4();                                  // a row with weight 0 (a gated-out edge) is not fetched: 0 * row = 0
+            } else {
+              v[k] = ld4(M + (int64_t)(e[k] >> 1) * ldm + c);
+              if (WEIGHTED) v[k] = mul4(v[k], w);
+            }
           }
         }
 #pragma unroll

@@ -587,8 +587,10 @@ __global__ __launch_bounds__(kBlock) void pool_relu_bwd_k(PoolBwdArgs p) {
 #pragma unroll
       for (int k = 0; k < kU; ++k)
         if (base + k < end) {
-          hv[k] = ld4(p.h1 + (int64_t)(en[k] >> 1) * p.ldh + c);
-          uv[k] = tr[k] >= 0 ? ld4(p.table + (int64_t)tr[k] * p.ldt + c) : zero4();
+          // a row under a zero gate: dPre = act'(.) (0 u) = 0 and 0 h1 = 0 whatever h1 holds -- neither row is fetched
+          const bool live = sc[k] != 0.f;
+          hv[k] = live ? ld4(p.h1 + (int64_t)(en[k] >> 1) * p.ldh + c) : zero4();
+          uv[k] = (live && tr[k] >= 0) ? ld4(p.table + (int64_t)tr[k] * p.ldt + c) : zero4();
         }
 #pragma unroll
       for (int k = 0; k < kU; ++k)

@@ -174,6 +174,8 @@ struct BwdArgs {
   const float *dPre; int64_t ldd;          // [R, >= H]
   const float *dZn; int64_t ldz;           // [R, >= H] or NULL (no residual connection)
   int64_t R; float *partial;               // [blocks, K, (dZn ? 3 : 2) * H]
+  const uint32_t *rowmask;                 // bit r of rowmask[t] == 0: row 32 t + r has an all-zero code row (a zero gate went into
+                                           // l0_pack): its dPre / dZn rows are not fetched (they would be multiplied by zeros).  NULL: all
 };
 
 template <int K, int VW, bool RES>
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      if (ok) {
+      const bool live = ok && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));   // scalar load, scalar branch
+      if (live) {
         dd[u] = vload<VW>(p.dPre + r * p.ldd, lane);
         if (RES) zz[u] = vload<VW>(p.dZn + r * p.ldz, lane);
       } else {
@@ -346,13 +349,18 @@ int64_t dmp_l0_bwd_w_blocks(int64_t rows) { return (int64_t)l0_blocks(rows, kL0M
 
 int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
                  int64_t ldz, int64_t R, int H, float *partial, void *stream) {
+  return dmp_l0_bwd_w_masked(enc, lde, K, coef_e, dPre, ldd, dZn, ldz, nullptr, R, H, partial, stream);
+}
+
+int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
+                        int64_t ldz, const uint32_t *rowmask, int64_t R, int H, float *partial, void *stream) {
   if (R < 0 || K <= 0 || !partial) return DMP_ERR_BAD_ARG;
   if ((H != 128 && H != 64) || K > kL0K) return DMP_ERR_UNSUPPORTED;
   const int nacc = (dZn ? 3 : 2) * K;
   if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)nacc * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   if (!enc || !coef_e || !dPre || lde < K || ldd < H || (dZn && ldz < H)) return DMP_ERR_BAD_ARG;
   if (ldd % 2 || ldz % 2 || !al8(dPre) || !al8(dZn) || !al8(partial)) return DMP_ERR_UNSUPPORTED;
-  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial};
+  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial, rowmask};
   hipStream_t st = (hipStream_t)stream;
 #define L0_CALL(KK) launch_bwd<KK>(p, H, st)
   L0_SWITCH(K, L0_CALL)

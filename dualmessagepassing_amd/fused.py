@@ -591,19 +591,22 @@ def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=
     return out
 
 
-def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None):
+def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None, gate=None):
     """-> ``[enc^T dPre | (coef_e enc)^T dPre (| enc^T dZn)]`` as one [K, 2H or 3H] matrix: one pass over the gradients
-    (over the rows ``rows = (r0, r1)`` only; ``out``: where the reduced sums go)."""
+    (over the rows ``rows = (r0, r1)`` only; ``out``: where the reduced sums go).  ``gate``: the gate ``l0_pack`` multiplied
+    the codes by -- the gradient rows of all-zero code rows are then not fetched (``gate_row_mask``)."""
     lib = _lib.load()
     E, H = d_pre.shape
     r0, r1 = (0, E) if rows is None else rows
+    mask = gate_row_mask(gate) if (gate is not None and gate.numel() == E and r0 % 32 == 0) else None
     nacc = (3 if d_zn is not None else 2) * K
     G = int(lib.dmp_l0_bwd_w_blocks(r1 - r0))
     part = torch.empty((G, nacc * H), dtype=torch.float32, device=d_pre.device)
     with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
-        check(lib.dmp_l0_bwd_w(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
-                               ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0, r1 - r0, H,
-                               ptr(part), stream_ptr()), "dmp_l0_bwd_w")
+        check(lib.dmp_l0_bwd_w_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
+                                      ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0,
+                                      None if mask is None else ptr(mask[r0 // 32:]), r1 - r0, H, ptr(part), stream_ptr()),
+              "dmp_l0_bwd_w")
     return reduce_partials(part, None if out is None else out.view(-1)).view(K, (nacc // K) * H)
 
 
@@ -1091,7 +1094,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                 XX = (torch.empty if full else torch.zeros)((TK, (3 if ctx.residual else 2) * H), dtype=torch.float32, device=dG.device)
                 for t, rows, _ in tables:
                     if rows[1] > rows[0]:
-                        l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0])
+                        l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0],
+                                 gate=ctx.e_gate)
                 dWes = None
             else:
                 dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 56
+#define DMP_ABI_VERSION 57
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -626,6 +626,10 @@ int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
 int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd,
                  const float *dZn, int64_t ldz, int64_t rows, int H, float *partial, void *stream);
+/* dmp_l0_bwd_w with a row mask: bit r of rowmask[t] == 0 says the code row 32 t + r is all zeros (the row's gate was 0 when
+ * dmp_l0_pack made it), so its dPre / dZn rows -- which would be multiplied by those zeros -- are not fetched. */
+int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
+                        int64_t ldz, const uint32_t *rowmask, int64_t R, int H, float *partial, void *stream);
 
 /* BatchNorm1d in TRAINING mode over the rows of x [rows, C] with the activation that follows it fused in (the UNC layers'
  * MLPs: Linear -> BatchNorm1d -> LeakyReLU -> Linear, UNC model.py:145-157; torch.nn.BatchNorm1d semantics: biased variance
