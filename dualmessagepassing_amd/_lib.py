@@ -90,6 +90,7 @@ SIGNATURES = {
     "dmp_smallk_atb_blocks": (c_i64, [c_i64]),
     "dmp_smallk_embed_cols": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_smallk_atb_cols": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "dmp_smallk_atb_cols_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_l0_pack": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
@@ -163,6 +164,7 @@ SIGNATURES = {
     "dmp_out_fwd_fused_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                          c_i64, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "dmp_row_mask_rows": (c_int, [c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr]),
     "dmp_mfma_partial_rows": (c_i64, [c_i64]),
     "dmp_bwd_h1_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr]),
@@ -182,7 +184,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 57
+ABI_VERSION = 59
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

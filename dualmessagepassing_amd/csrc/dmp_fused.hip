@@ -379,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamArgs a) {
 constexpr int kSmallK = 16;
 constexpr int kSmallRows = 4;                                 // rows in flight per wave (the loop is one memory round trip per batch)
 struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial;
-                    int ncols; const float *D2; int64_t ldd2; };   // blockIdx.y = column block j: D[:, jH:(j+1)H], or D2 for j == ncols
+                    int ncols; const float *D2; int64_t ldd2;      // blockIdx.y = column block j: D[:, jH:(j+1)H], or D2 for j == ncols
+                    const uint32_t *rowmask; };                    // bit r of rowmask[t] == 0: row 32 t + r of X is all zeros (or its gate is 0): its D rows are not fetched
 
 // VW = H / 64 values per lane: 2 (H = 128, one float2 per lane) or 1 (H = 64)
 template <int VW> struct LaneVec { float v[VW]; };
@@ -419,7 +420,8 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      if (ok) dd[u] = lane_load<VW>(Dj + r * ldj, lane);
+      const bool live = ok && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));   // scalar load, scalar branch
+      if (live) dd[u] = lane_load<VW>(Dj + r * ldj, lane);
       else {
 #pragma unroll
         for (int c = 0; c < VW; ++c) dd[u].v[c] = 0.f;
@@ -437,6 +439,10 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
     load_batch(r0 + stride, dn, minen);                     // rows past the end read as zeros
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
+      if (p.rowmask) {                                       // a masked row: all of its products are zero (wave-uniform test)
+        const int64_t r = r0 + u;
+        if (r < p.R && !((p.rowmask[r >> 5] >> (r & 31)) & 1u)) continue;
+      }
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
       const float scaled = mine[u] * g;                     // lane k: gate * X[r, k]
 #pragma unroll
@@ -763,6 +769,12 @@ int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)smallk_blocks(rows
 
 int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2, int64_t ldd2,
                         const float *gate, int64_t R, int H, float *partial, void *stream) {
+  return dmp_smallk_atb_cols_masked(X, ldx, K, D, ldd, ncols, D2, ldd2, gate, nullptr, R, H, partial, stream);
+}
+
+int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                               int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
+                               void *stream) {
   DMP_ROW_CHECK(R >= 0 && K > 0 && partial && ncols >= 0 && ncols + (D2 ? 1 : 0) >= 1 && ncols <= 8);
   if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   const int nblk = ncols + (D2 ? 1 : 0);
@@ -770,7 +782,7 @@ int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int6
   DMP_ROW_CHECK(X && (D || ncols == 0) && ldx >= K && (ncols == 0 || ldd >= (int64_t)ncols * H) && (!D2 || ldd2 >= H));
   if (ldd % 2 || ldd2 % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || (reinterpret_cast<uintptr_t>(D2) & 7u) || !ok16(partial))
     return DMP_ERR_UNSUPPORTED;
-  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial, ncols, D2, ldd2};
+  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial, ncols, D2, ldd2, rowmask};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {   // K is a compile-time constant of the kernel: the accumulators live in registers
     case 1: launch_smallk<1>(p, H, st); break;   case 2: launch_smallk<2>(p, H, st); break;

@@ -215,6 +215,10 @@ __global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
     else load_batch(r0 + stride, dn, zn, minen);            // rows past the end read as zeros
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
+      if (p.rowmask) {                                       // an all-zero code row: nothing to add (wave-uniform test)
+        const int64_t r = r0 + u;
+        if (r < p.R && !((p.rowmask[r >> 5] >> (r & 31)) & 1u)) continue;
+      }
       const float cf = lane_f(mine[u], kLaneCoef);
       Vec<VW> cd;                                           // c_r dPre[r]: (c enc)^T dPre = enc^T (c dPre), one scalar per input
 #pragma unroll

@@ -558,6 +558,17 @@ __global__ __launch_bounds__(256) void row_mask_bits_k(const float *__restrict__
   if ((lane & 31) == 0 && r < ((E + 31) / 32) * 32) mask[r >> 5] = (uint32_t)(b >> (lane & 32));
 }
 
+// bit r of mask[t] = (row 32 t + r of X [R, ldx] has a non-zero among its first K entries)
+__global__ __launch_bounds__(256) void row_mask_rows_k(const float *__restrict__ X, int64_t ldx, int K, int64_t R, uint32_t *__restrict__ mask) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool on = false;
+  if (r < R)
+    for (int k = 0; k < K; ++k) on |= X[r * ldx + k] != 0.f;
+  const unsigned long long b = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0 && r < ((R + 31) / 32) * 32) mask[r >> 5] = (uint32_t)(b >> (lane & 32));
+}
+
 __global__ void edge_select_k(const int32_t *src, const int32_t *dst, const uint8_t *flag, const float *coef,
                               int64_t E, int32_t *selA, int32_t *selB, float *coefE) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -633,6 +644,14 @@ int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream
   if (E == 0) return DMP_OK;
   if (!gate || !mask) return DMP_ERR_BAD_ARG;
   row_mask_bits_k<<<(unsigned)((E + 255) / 256), 256, 0, (hipStream_t)stream>>>(gate, E, mask);
+  return check_launch();
+}
+
+int dmp_row_mask_rows(const float *X, int64_t ldx, int K, int64_t R, uint32_t *mask, void *stream) {
+  if (R < 0 || K < 0) return DMP_ERR_BAD_ARG;
+  if (R == 0) return DMP_OK;
+  if (!X || !mask || ldx < K) return DMP_ERR_BAD_ARG;
+  row_mask_rows_k<<<(unsigned)((R + 255) / 256), 256, 0, (hipStream_t)stream>>>(X, ldx, K, R, mask);
   return check_launch();
 }
 

@@ -440,6 +440,10 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
         stacked = not shared and 2 * gv[0].size(1) <= fused.SMALLK_MAX    # two tables as ONE of 2 VK rows: no second launches
         l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate, stacked), gv[0].size(1) * (2 if stacked else 1)
         l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
+        if v_gate is not None:
+            l0.venc_mask = fused.code_row_mask(l0.venc, l0.VK)        # the node code rows a zero gate wiped: the backward skips their gradient rows
+    if e_gate is not None and not getattr(e_gate, "_dmp_dense_gate", False):
+        l0.enc_mask = fused.code_row_mask(l0.enc, l0.K)
     return l0
 
 

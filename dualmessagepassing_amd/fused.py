@@ -440,6 +440,18 @@ def gate_row_mask(gate):
     return mask
 
 
+def code_row_mask(enc, K):
+    """uint32 [(R + 31) // 32]: bit r of word t = (row 32 t + r of ``enc`` has a non-zero among its first K entries)
+    (``dmp_row_mask_rows``): the packed label codes' live rows -- a gated-out row is all zeros, and so is every product with it."""
+    if not USE_ROW_MASKS or enc is None:
+        return None
+    lib = _lib.load()
+    R = enc.size(0)
+    mask = torch.empty(((R + 31) // 32,), dtype=torch.int32, device=enc.device)
+    check(lib.dmp_row_mask_rows(ptr(enc), enc.stride(0), int(K), R, ptr(mask), stream_ptr()), "dmp_row_mask_rows")
+    return mask
+
+
 def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
     """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H = 128 or 64).
     ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch).
@@ -528,9 +540,10 @@ def smallk_embed(x, W, gate=None, out=None, H=None):
     return out
 
 
-def smallk_atb_cols(x, d, d2=None, out=None, H=None):
+def smallk_atb_cols(x, d, d2=None, out=None, H=None, mask=None):
     """``x^T [d | d2]`` per block of 128 (or 64: one block) columns -> [blocks, K, H]: ``smallk_atb`` over the column blocks
-    of ``d`` [R, ncols H] and one more matrix ``d2`` [R, H] in ONE launch."""
+    of ``d`` [R, ncols H] and one more matrix ``d2`` [R, H] in ONE launch.  ``mask`` (uint32 words, ``gate_row_mask``, aligned
+    to x's first row): the rows of ``d`` / ``d2`` whose row of ``x`` is known to be all zeros are not fetched."""
     lib = _lib.load()
     R, K = x.shape
     C = d.size(1)
@@ -542,8 +555,9 @@ def smallk_atb_cols(x, d, d2=None, out=None, H=None):
     if out is None:
         out = torch.empty((nblk, K, H), dtype=torch.float32, device=d.device)
     with _lib.timed("smallk_atb[K=%d,R=%d]", (K, R), 4 * (nblk * H + K + 1) * R):
-        check(lib.dmp_smallk_atb_cols(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2), d2.stride(0) if d2 is not None else 0,
-                                      None, R, H, ptr(part), stream_ptr()), "dmp_smallk_atb_cols")
+        check(lib.dmp_smallk_atb_cols_masked(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2),
+                                             d2.stride(0) if d2 is not None else 0, None, ptr(mask), R, H, ptr(part), stream_ptr()),
+              "dmp_smallk_atb_cols")
     for j in range(nblk):
         reduce_partials(part[j], out[j].view(-1))
     return out
@@ -591,14 +605,15 @@ def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=
     return out
 
 
-def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None, gate=None):
+def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None, mask=None):
     """-> ``[enc^T dPre | (coef_e enc)^T dPre (| enc^T dZn)]`` as one [K, 2H or 3H] matrix: one pass over the gradients
-    (over the rows ``rows = (r0, r1)`` only; ``out``: where the reduced sums go).  ``gate``: the gate ``l0_pack`` multiplied
-    the codes by -- the gradient rows of all-zero code rows are then not fetched (``gate_row_mask``)."""
+    (over the rows ``rows = (r0, r1)`` only; ``out``: where the reduced sums go).  ``mask`` (``code_row_mask(enc, K)``): the
+    gradient rows of all-zero code rows are not fetched."""
     lib = _lib.load()
     E, H = d_pre.shape
     r0, r1 = (0, E) if rows is None else rows
-    mask = gate_row_mask(gate) if (gate is not None and gate.numel() == E and r0 % 32 == 0) else None
+    if mask is not None and r0 % 32 != 0:
+        mask = None
     nacc = (3 if d_zn is not None else 2) * K
     G = int(lib.dmp_l0_bwd_w_blocks(r1 - r0))
     part = torch.empty((G, nacc * H), dtype=torch.float32, device=d_pre.device)
@@ -1095,7 +1110,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                 for t, rows, _ in tables:
                     if rows[1] > rows[0]:
                         l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0],
-                                 gate=ctx.e_gate)
+                                 mask=getattr(l0, "enc_mask", None))
                 dWes = None
             else:
                 dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
@@ -1128,9 +1143,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                     VK, TVK = l0.VK, WV0.size(0)
                     vfull = all(n1 > n0 for _, (n0, n1) in l0.vtables(N)) and len(l0.vtables(N)) * VK == TVK
                     Yn = (torch.empty if vfull else torch.zeros)((4 if ctx.residual else 3, TVK, H), dtype=torch.float32, device=dPn.device)
+                    vmask = getattr(l0, "venc_mask", None)
                     for t, (n0, n1) in l0.vtables(N):
+                        # (the packed node codes carry the node gate: a gated-out node's code row is all zeros)
                         smallk_atb_cols(l0.venc[n0:n1, :VK], dXP[n0:n1], dxn[n0:n1] if ctx.residual else None,
-                                        Yn[:, t * VK:(t + 1) * VK], H)
+                                        Yn[:, t * VK:(t + 1) * VK], H,
+                                        mask=vmask[n0 // 32:] if (vmask is not None and n0 % 32 == 0) else None)
                 elif one_launch:
                     (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (x, dXP, None, False)])
                 else:

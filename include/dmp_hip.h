@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 57
+#define DMP_ABI_VERSION 59
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -602,6 +602,11 @@ int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, in
                           int64_t rows, int H, int ncols, float *out, int64_t ldo, void *stream);
 int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
                         int64_t ldd2, const float *gate, int64_t rows, int H, float *partial, void *stream);
+/* ... with a row mask (dmp_row_mask_bits): rows of D / D2 whose bit is 0 -- rows whose X row is all zeros, or whose gate is 0 -- are
+ * not fetched. */
+int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                               int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
+                               void *stream);
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);
@@ -949,6 +954,9 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
  * (out = R + 0 (h1 W2^T + b2) = R, dPre = act'(.) (0 dO W2) = 0), so the results are the unmasked kernels' -- with 60 % of the rows gated
  * out (a ScalarFilter target batch, basemodel.py:1515-1531) a fifth / two fifths of the kernels' bytes are not moved. */
 int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream);
+/* ... of the rows of a matrix: bit r of mask[t] = (row 32 t + r of X [R, ldx] has a non-zero among its first K entries) -- the label
+ * code rows that dmp_l0_pack multiplied by a zero gate; for dmp_l0_bwd_w_masked / dmp_smallk_atb_cols_masked. */
+int dmp_row_mask_rows(const float *X, int64_t ldx, int K, int64_t R, uint32_t *mask, void *stream);
 int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
                              const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
                              int w_in_out, float *out, int64_t ldo, void *stream);
