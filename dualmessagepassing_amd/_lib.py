@@ -130,6 +130,9 @@ SIGNATURES = {
                                    c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                 c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "dmp_bwd_z_typed_arow": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
+                                     c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "dmp_mask_slots": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_pool_relu_bwd_blocks": (c_i64, [c_i64, c_int]),
     "dmp_pool_relu_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                                   c_ptr, c_ptr, c_ptr]),
@@ -184,7 +187,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 59
+ABI_VERSION = 60
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

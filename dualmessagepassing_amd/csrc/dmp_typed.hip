@@ -456,6 +456,15 @@ inline int launch_typed(const TypedArgs &p, int64_t tiles_bound, hipStream_t st)
   return check_launch();
 }
 
+// a tile slot list whose gated-out edges read as padding (dmp_mask_slots)
+__global__ __launch_bounds__(256) void mask_slots_k(const int32_t *__restrict__ slot, int64_t n, const float *__restrict__ gate,
+                                                    int64_t E, int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t e = slot[i];
+  out[i] = (e >= 0 && e < E && gate[e] != 0.f) ? e : -1;
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -497,6 +506,23 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                     int64_t tiles_bound, int64_t E, int H, int w_transposed, const int32_t *base_map, int64_t base_rows,
                     float *dZ, int64_t ldz, void *stream) {
+  return dmp_bwd_z_typed_arow(dPre, ldp, W, ldw, D, ldd, num_nodes, base, ldb, dst, flag, s0, s1, slot_edge, nullptr, tile_scale,
+                              num_tiles, tiles_bound, E, H, w_transposed, base_map, base_rows, dZ, ldz, stream);
+}
+
+int dmp_mask_slots(const int32_t *slot, int64_t n, const float *gate, int64_t E, int32_t *out, void *stream) {
+  if (n < 0 || E < 0) return DMP_ERR_BAD_ARG;
+  if (n == 0) return DMP_OK;
+  if (!slot || !gate || !out) return DMP_ERR_BAD_ARG;
+  mask_slots_k<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(slot, n, gate, E, out);
+  return check_launch();
+}
+
+int dmp_bwd_z_typed_arow(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                         int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
+                         float s0, float s1, const int32_t *slot_edge, const int32_t *slot_arow, const float *tile_scale,
+                         const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, int w_transposed,
+                         const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldz, void *stream) {
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0 || num_nodes < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
@@ -512,7 +538,7 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
     return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = dPre; p.lda = ldp; p.W = W; p.ldw = ldw; p.transposed = w_transposed ? 0 : 1; p.C = dZ; p.ldc = ldz; p.E = E;
-  p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
+  p.slot_edge = slot_edge; p.slot_arow = slot_arow ? slot_arow : slot_edge; p.rowsA = E; p.tile_scale = tile_scale; p.num_tiles = num_tiles;
   p.idxA = dst; p.flag = flag; p.T = D; p.ldt = ldd; p.num_nodes = num_nodes; p.R = base; p.ldr = base ? ldb : H;
   p.s0 = s0; p.s1 = s1; p.rmap = base_map; p.rowsR = base_rows;
   return H == 128 ? launch_typed<TEPI_DZ, 128>(p, tiles_bound, (hipStream_t)stream)

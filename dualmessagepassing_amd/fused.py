@@ -374,10 +374,38 @@ def edge_chain_fwd(z, Wes, P, ldp, bias, coef, index, eW2t, eb2, gate, residual,
     return h1, zn
 
 
-def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None):
+def masked_slots(index, coef, gate):
+    """The class-tile slot list of ``index`` with the edges under a zero ``gate`` turned into padding (``dmp_mask_slots``), or
+    None (no gate, masks off, a gate known to be dense).  For kernels whose streamed rows are ZERO for such edges -- ``dPre``
+    of a gated layer: ``atb_typed`` skips the edge, ``bwd_z_typed`` skips the fetch of its ``dPre`` row.  Memoised on the gate
+    (shared by the layers of a rep-net) per slot list."""
+    if gate is None or not USE_ROW_MASKS:
+        return None
+    owner = gate._base if gate._base is not None else gate
+    if owner.data_ptr() != gate.data_ptr() or owner.numel() != gate.numel():
+        owner = gate
+    if getattr(owner, "_dmp_dense_gate", False):
+        return None
+    slot_edge = index.class_tiles(coef)[0]
+    hit = getattr(owner, "_dmp_masked_slots", None)
+    if hit is not None and hit[0] == owner._version and hit[1] is slot_edge:
+        return hit[2]
+    lib = _lib.load()
+    out = torch.empty_like(slot_edge)
+    check(lib.dmp_mask_slots(ptr(slot_edge), slot_edge.numel(), ptr(gate), gate.numel(), ptr(out), stream_ptr()), "dmp_mask_slots")
+    try:
+        owner._dmp_masked_slots = (owner._version, slot_edge, out)
+    except Exception:
+        pass
+    return out
+
+
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
-    ``base_map`` (int32 [E]): ``base`` is a small table and edge e adds its row ``base_map[e]`` (< 0: nothing)."""
+    ``base_map`` (int32 [E]): ``base`` is a small table and edge e adds its row ``base_map[e]`` (< 0: nothing).
+    ``gate``: the layer's edge gate when ``d_pre`` is the gated layer's (its rows under a zero gate ARE zero): those rows are
+    not fetched (``masked_slots``)."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
     out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
@@ -388,21 +416,25 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     d_s = d_s.contiguous()
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
-        check(lib.dmp_bwd_z_typed(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
-                                  ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
-                                  ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1, ptr(base_map),
-                                  base.size(0) if base_map is not None else 0, ptr(out), H, stream_ptr()),
+        check(lib.dmp_bwd_z_typed_arow(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
+                                       ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
+                                       ptr(slot_edge), ptr(masked_slots(index, coef, gate)), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1,
+                                       ptr(base_map), base.size(0) if base_map is not None else 0, ptr(out), H, stream_ptr()),
               "dmp_bwd_z_typed")
     return out
 
 
-def atb_typed(z, d_pre, coef, index):
+def atb_typed(z, d_pre, coef, index, gate=None):
     """``[z^T d_pre | z^T (coef[dst] (.) d_pre)]``  ([H, 2H]: the gradient of ``Wes`` in its layout) over the
     class-sorted tiles: one product's worth of MFMAs for both halves (csrc/dmp_atb.hip), one fixed-order
-    reduction of the workgroup partials."""
+    reduction of the workgroup partials.  ``gate``: the layer's edge gate when ``d_pre`` is the gated layer's (zero rows under
+    a zero gate): those edges are skipped, neither of their rows is fetched (``masked_slots``)."""
     lib = _lib.load()
     E, H = z.shape
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    ms = masked_slots(index, coef, gate)
+    if ms is not None:
+        slot_edge = ms
     G = int(lib.dmp_atb_typed_blocks_h(bound, H))
     part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
@@ -1113,7 +1145,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                                  mask=getattr(l0, "enc_mask", None))
                 dWes = None
             else:
-                dWes = atb_typed(z, dG, coef, ix) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
+                # (dG = dPre has zero rows under a zero edge gate, whichever kernel made it: the typed kernels skip those edges)
+                dWes = atb_typed(z, dG, coef, ix, gate=ctx.e_gate) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
             one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
@@ -1169,9 +1202,9 @@ class _FusedDMPLayer(torch.autograd.Function):
             if l0 is None and ctx.needs_input_grad[4]:
                 if lazy is not None:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
-                                     base_map=lazy[1] if ctx.residual else None)
+                                     base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate)
                 elif typed:
-                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT)
+                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT, gate=ctx.e_gate)
                 elif mfma:
                     dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:

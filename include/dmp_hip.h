@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 59
+#define DMP_ABI_VERSION 60
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1003,6 +1003,16 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
                     int64_t tiles_bound, int64_t num_edges, int H, int w_transposed,
                     const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldz, void *stream);
+/* Gated class tiles: out[s] = slot[s] if gate[slot[s]] != 0 else -1 (a tile slot list whose gated-out edges read as padding).
+ * dmp_atb_typed takes it in place of slot_edge (a gated-out edge has dPre = 0: its z^T dPre term is zero, neither row is
+ * fetched); dmp_bwd_z_typed_arow takes it as the row list of its streamed operand dPre (slot_arow; NULL = slot_edge), while the
+ * output rows, the gathered term and the base rows still follow slot_edge: dz[e] = base[e] + select(D)[e] + 0 for such an edge. */
+int dmp_mask_slots(const int32_t *slot, int64_t n, const float *gate, int64_t E, int32_t *out, void *stream);
+int dmp_bwd_z_typed_arow(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                         int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
+                         float s0, float s1, const int32_t *slot_edge, const int32_t *slot_arow, const float *tile_scale,
+                         const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, int w_transposed,
+                         const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldz, void *stream);
 
 /*
  * Weight gradient of the class-typed edge chain:  with G_c = sum over the edges e of class c of
