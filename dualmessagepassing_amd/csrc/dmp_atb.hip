@@ -499,7 +499,7 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
     AtbArgs a{};
     a.Z = j.A; a.ldz = j.lda; a.D = j.B; a.ldd = j.ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
     a.gate = j.gate; a.pT = j.partial; a.pstride = j.partial_stride; a.ldp = j.ldp; a.pCS = j.partial_colsum;
-    a.nb = 1; a.cs_ld = j.cs_ld;
+    a.nb = 1; a.cs_ld = j.cs_ld; a.rowmask = j.rowmask;
     t.job[i] = a;
   }
   return H == 128 ? atb_jobs_launch<128>(t, num_jobs, rows, (hipStream_t)stream) : atb_jobs_launch<64>(t, num_jobs, rows, (hipStream_t)stream);

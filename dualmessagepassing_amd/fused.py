@@ -689,8 +689,9 @@ MAX_ATB_JOBS = 8
 
 
 def atb_rows_multi(products):
-    """Several ``atb_rows`` products over the SAME rows in ONE launch: ``products`` = list of ``(a, b, gate, colsum)``
-    (a [R, 128 ma], b [R, 128 nb]); returns a list of ``(a^T b  [128 ma, 128 nb], column sums or None)``.  The launch's
+    """Several ``atb_rows`` products over the SAME rows in ONE launch: ``products`` = list of ``(a, b, gate, colsum[, mask])``
+    (a [R, 128 ma], b [R, 128 nb]; ``mask``: a ``gate_row_mask`` whose zero bits mark rows where ``gate (.) a`` or ``b`` is
+    known to be all zeros: not fetched); returns a list of ``(a^T b  [128 ma, 128 nb], column sums or None)``.  The launch's
     workgroups are shared by all 128 x 128 output blocks, so short inputs (the node side: R = nodes) get long
     tile ranges per workgroup instead of paying every workgroup's fixed costs once per product."""
     global _ATB_JOB
@@ -699,16 +700,18 @@ def atb_rows_multi(products):
     if _ATB_JOB is None:
         P, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         _ATB_JOB = type("dmp_atb_job", (ctypes.Structure,), {"_fields_": [("A", P), ("lda", I64), ("B", P), ("ldb", I64), ("gate", P), ("partial", P),
-                                                                          ("partial_stride", I64), ("ldp", I), ("partial_colsum", P), ("cs_ld", I)]})
+                                                                          ("partial_stride", I64), ("ldp", I), ("partial_colsum", P), ("cs_ld", I),
+                                                                          ("rowmask", P)]})
     R = products[0][0].size(0)
-    blk = min(atb_block(a.size(1), b.size(1)) for a, b, _, _ in products)     # one block size per launch
-    nblk = sum((a.size(1) // blk) * (b.size(1) // blk) for a, b, _, _ in products)
+    products = [tuple(pr) + (None,) * (5 - len(pr)) for pr in products]
+    blk = min(atb_block(a.size(1), b.size(1)) for a, b, _, _, _ in products)     # one block size per launch
+    nblk = sum((a.size(1) // blk) * (b.size(1) // blk) for a, b, _, _, _ in products)
     if nblk > MAX_ATB_JOBS:
         raise ValueError("atb_rows_multi: more than %d output blocks" % MAX_ATB_JOBS)
     G = int(lib.dmp_atb_jobs_blocks_h(R, nblk, blk))
     jobs = (_ATB_JOB * nblk)()
     parts, k = [], 0
-    for a, b, gate, colsum in products:
+    for a, b, gate, colsum, mask in products:
         M, N = a.size(1), b.size(1)
         part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
         part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
@@ -718,6 +721,7 @@ def atb_rows_multi(products):
                 j = jobs[k]
                 j.A, j.lda, j.B, j.ldb = a.data_ptr() + 4 * blk * ia, a.stride(0), b.data_ptr() + 4 * blk * ib, b.stride(0)
                 j.gate = ptr(gate)
+                j.rowmask = ptr(mask)
                 j.partial, j.partial_stride, j.ldp = part.data_ptr() + 4 * (ia * blk * N + ib * blk), M * N, N
                 j.partial_colsum = (part_cs.data_ptr() + 4 * blk * ia) if (colsum and ib == 0) else None
                 j.cs_ld = M
@@ -1183,13 +1187,15 @@ class _FusedDMPLayer(torch.autograd.Function):
                                         Yn[:, t * VK:(t + 1) * VK], H,
                                         mask=vmask[n0 // 32:] if (vmask is not None and n0 % 32 == 0) else None)
                 elif one_launch:
-                    (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (x, dXP, None, False)])
+                    (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, gate_row_mask(ctx.v_gate)), (x, dXP, None, False)])
                 else:
                     dWx = wg(x, dXP)
             else:
                 dS = dPn @ Bn.t()
                 if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
-                    (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True), (S, dPn, None, False),
+                    # (dPn = act'(H1n) ((v_gate dxn) W2): zero rows under a zero node gate -- the first two products skip them)
+                    vm = gate_row_mask(ctx.v_gate)
+                    (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, vm), (S, dPn, None, False, vm),
                                                                         (x, dXP, None, False)])
                 else:
                     dBn = wg(S, dPn)                                         # [2H,H]

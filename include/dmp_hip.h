@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 60
+#define DMP_ABI_VERSION 61
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1091,6 +1091,8 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
 typedef struct {
   const float *A; int64_t lda; const float *B; int64_t ldb; const float *gate;
   float *partial; int64_t partial_stride; int ldp; float *partial_colsum; int cs_ld;
+  const uint32_t *rowmask;   /* optional (dmp_row_mask_bits): rows whose bit is 0 -- rows where A (after its gate) or B is known to be
+                              * all zeros -- are not fetched */
 } dmp_atb_job;
 int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs);
 int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream);

@@ -11,5 +11,5 @@ for n in ("bench","bench_nomask"):
     p=json.loads([l for l in open("gpurun_out/r04i/%s.json"%n) if l.startswith("{")][-1])
     print(n, p["value"], p["ms_per_step"], p["step_ms_median"], p.get("gate_compact") and p["gate_compact"]["ms_per_step"])
     for k,v in sorted(p["kernels"].items()):
-        if any(x in k for x in ("atb_typed[","bwd_z_typed[")): print("   ", k, v["avg_us"])
+        if any(x in k for x in ("atb_rows_multi","atb_typed[")): print("   ", k, v["avg_us"])
 PY
