@@ -96,6 +96,8 @@ SIGNATURES = {
     "dmp_l0_pack": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "dmp_l0_edge_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,
                                 c_ptr, c_i64, c_ptr]),
+    "dmp_l0_edge_fwd_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
+                                       c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_l0_bwd_w_blocks": (c_i64, [c_i64]),
     "dmp_bn_partial_rows": (c_i64, [c_i64, c_int]),
     "dmp_bn_train_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_int, c_f32, c_ptr, c_ptr, c_ptr,
@@ -187,7 +189,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 61
+ABI_VERSION = 62
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

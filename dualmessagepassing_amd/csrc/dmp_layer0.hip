@@ -97,6 +97,8 @@ struct FwdArgs {
   const float *P; int64_t ldp;             // node projections [N, >= 2H]: P[a, 0:H] - P[b, H:2H]
   const float *bias; const float *coef_e; const int32_t *sel_a, *sel_b;
   int64_t R; float slope; float *out; int64_t ldo;
+  const uint32_t *rowmask;                 // bit r of rowmask[t] == 0: row 32 t + r is a DEAD row (its consumers all multiply it by a zero
+                                           // gate and skip it): nothing is gathered, computed or stored for it.  NULL: every row
 };
 
 template <int K, int VW>
@@ -136,14 +138,23 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   for (; r0 < p.R; r0 += stride) {
     fetch(r0 + stride, next);                               // the next batch's scalars: a dependent round trip less per batch
     Vec<VW> pa[kRows], pb[kRows];
+    bool live[kRows];
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      pa[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneA) * p.ldp, lane);
-      pb[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneB) * p.ldp + H, lane);
+      const int64_t r = r0 + u;                             // wave-uniform: scalar load, scalar branch
+      live[u] = r < p.R && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));
+      if (live[u]) {
+        pa[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneA) * p.ldp, lane);
+        pb[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneB) * p.ldp + H, lane);
+      } else {
+        pa[u] = vzero<VW>();
+        pb[u] = vzero<VW>();
+      }
     }
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       if (r0 + u >= p.R) break;
+      if (!live[u]) continue;
       const float cf = lane_f(mine[u], kLaneCoef);
       Vec<VW> g0 = vzero<VW>(), g1 = vzero<VW>();
 #pragma unroll
@@ -336,12 +347,18 @@ int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *en
 int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                     const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t R, int H,
                     float slope, float *out, int64_t ldo, void *stream) {
+  return dmp_l0_edge_fwd_masked(enc, lde, K, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, nullptr, R, H, slope, out, ldo, stream);
+}
+
+int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                           const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
+                           const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream) {
   if (R < 0 || K <= 0) return DMP_ERR_BAD_ARG;
   if ((H != 128 && H != 64) || K > kL0K || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return DMP_OK;
   if (!enc || !M || !P || !coef_e || !sel_a || !sel_b || !out || lde < K || ldm < 2 * H || ldp < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
   if (ldm % 2 || ldp % 2 || ldo % 2 || !al8(M) || !al8(P) || !al8(out) || !al8(bias)) return DMP_ERR_UNSUPPORTED;
-  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo};
+  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo, rowmask};
   hipStream_t st = (hipStream_t)stream;
 #define L0_CALL(KK) launch_fwd<KK>(p, H, st)
   L0_SWITCH(K, L0_CALL)

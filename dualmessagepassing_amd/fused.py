@@ -327,14 +327,19 @@ def typed_ok(index, H):
     return USE_TYPED_KERNELS and onepanel_ok(H) and index.num_nodes < 2 ** 31 and index.num_edges < 2 ** 30
 
 
-def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0):
-    """edge_fwd_mfma with W_g = Wes[:, :H] + c_g Wes[:, H:] per degree class: one product instead of two."""
+def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None):
+    """edge_fwd_mfma with W_g = Wes[:, :H] + c_g Wes[:, H:] per degree class: one product instead of two.
+    ``dead_gate``: an edge gate all of whose zeros mark DEAD output rows (every consumer multiplies them by that zero and
+    skips them): those edges are padding slots of the tile list -- nothing is read, computed or stored for them."""
     lib = _lib.load()
     E, H = z.shape
-    out = torch.empty((E, H), dtype=torch.float32, device=z.device)
+    out = dead_rows_buffer((E, H), z.device)
     Wes = Wes.contiguous()
     sel_a, sel_b, _ = index.edge_select(coef)
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    ms = masked_slots(index, coef, dead_gate) if dead_gate is not None else None
+    if ms is not None:
+        slot_edge = ms
     with _lib.timed("edge_fwd_typed[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_typed(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
                                      ptr(sel_a), ptr(sel_b), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound,
@@ -444,6 +449,18 @@ def atb_typed(z, d_pre, coef, index, gate=None):
 
 
 USE_ROW_MASKS = _os.environ.get("DMP_ROW_MASKS", "1") == "1"   # gated E-row kernels do not fetch the rows a zero gate annihilates
+# ... and the two kernels that PRODUCE the first MLP's activation H1 leave out the rows all of whose consumers skip them
+# (dead values: out_fwd, bwd_h1, atb_rows, the pooled passes multiply them by the zero gate).  Only with USE_ROW_MASKS.
+SKIP_DEAD_ROWS = _os.environ.get("DMP_SKIP_DEAD_ROWS", "1") == "1"
+POISON_DEAD_ROWS = _os.environ.get("DMP_POISON_DEAD_ROWS", "0") == "1"   # testing aid: buffers with dead rows start as NaN
+
+
+def dead_rows_buffer(shape, device):
+    """An [E, H] buffer whose dead rows nobody writes: uninitialised -- or NaN throughout under ``POISON_DEAD_ROWS``, so that a
+    consumer that does fetch a dead row shows up as NaN in its results."""
+    if POISON_DEAD_ROWS:
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def gate_row_mask(gate):
@@ -620,19 +637,23 @@ def l0_pack(enc_p, enc_g, gate=None, stacked=False):
     return out
 
 
-def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None):
+def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None, mask=None):
     """``act(enc M[:, :H] + coef[dst] enc M[:, H:] + P[a, 0:H] - P[b, H:2H] + bias)`` -- ``edge_fwd_typed`` for input rows
     ``enc W`` of rank K with ``M = W Wes``: no class tiles, rows in their own order.  ``rows = (r0, r1)``: only that range
-    of the edge rows (written into ``out[r0:r1]``): rows of another embedding table take another ``M``."""
+    of the edge rows (written into ``out[r0:r1]``): rows of another embedding table take another ``M``.  ``mask`` (a
+    ``gate_row_mask`` over all E rows): its zero bits mark DEAD output rows, left out entirely."""
     lib = _lib.load()
     E, H = enc.size(0), M.size(1) // 2
     if out is None:
         out = torch.empty((E, H), dtype=torch.float32, device=enc.device)
     r0, r1 = (0, E) if rows is None else rows
     sel_a, sel_b, coef_e = index.edge_select(coef)
+    if mask is not None and r0 % 32 != 0:
+        mask = None
     with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
-        check(lib.dmp_l0_edge_fwd(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
-                                  ptr(sel_a[r0:]), ptr(sel_b[r0:]), r1 - r0, H, slope, ptr(out[r0:]), out.stride(0), stream_ptr()),
+        check(lib.dmp_l0_edge_fwd_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
+                                         ptr(sel_a[r0:]), ptr(sel_b[r0:]), None if mask is None else ptr(mask[r0 // 32:]), r1 - r0, H,
+                                         slope, ptr(out[r0:]), out.stride(0), stream_ptr()),
               "dmp_l0_edge_fwd")
     return out
 
@@ -1014,15 +1035,21 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- edge side (dmpnn.py:112,120,124 + 142-156)
         sums_only = epool is not None and not edge_rows
         zn = None
+        # H1e rows under a zero edge gate are DEAD values when the layer runs on the masked kernels: out_fwd / the pooled
+        # passes forward and bwd_h1 / atb_rows / pool_relu_bwd backward all multiply them by that zero and do not fetch them
+        # (typed_ok: the backward takes the same branch).  The two producers then leave those rows out.
+        dead_gate = e_gate if (SKIP_DEAD_ROWS and USE_ROW_MASKS and e_gate is not None and typed_ok(index, H)
+                               and gate_row_mask(e_gate) is not None) else None
         if l0 is not None:
-            H1e = torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
+            H1e = dead_rows_buffer((z.size(0), H), z.device) if dead_gate is not None else torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
             for t, rows, _ in tables:
                 if rows[1] > rows[0]:
-                    l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e)
+                    l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e,
+                                mask=gate_row_mask(dead_gate) if dead_gate is not None else None)
         elif edge_chain_ok(index, H) and eW2t is not None and not sums_only:
             H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
-            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
+            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope, dead_gate=dead_gate)
         elif mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
         else:

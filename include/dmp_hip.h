@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 61
+#define DMP_ABI_VERSION 62
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -628,6 +628,12 @@ int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *en
 int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                     const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t rows,
                     int H, float slope, float *out, int64_t ldo, void *stream);
+/* ... leaving out DEAD rows: bit r of rowmask[t] == 0 says that every consumer of row 32 t + r of `out` multiplies it by a zero gate
+ * and does not fetch it (the `_masked` kernels, dmp_pool_relu_bwd, the weighted dmp_seg_sum): nothing is gathered, computed or
+ * STORED for such a row -- `out` keeps whatever the buffer held there. */
+int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                           const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
+                           const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream);
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
 int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd,
                  const float *dZn, int64_t ldz, int64_t rows, int H, float *partial, void *stream);

@@ -401,3 +401,42 @@ def test_flat_adamw_keeps_one_step_count_per_parameter_tensor(amsgrad):
     opt2.step(); ropt.step()                                       # the reloaded optimizer carries the per-tensor counts on
     for p, r in zip(params, ref):
         assert float((p.detach() - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_zero_gate_skipping_leaves_every_output_and_gradient_as_it_was(lazy):
+    """The masked kernels (rows under a zero gate are not fetched) and the dead H1 rows (not even produced) against the same
+    model with all of that switched off -- with the dead rows' buffers poisoned (NaN), so that a consumer which does fetch one
+    cannot go unnoticed."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = dict(bench.CFG, batch=96)
+    bench_, shard, step, model = _model_and_batch(cfg, gpu)
+    fused.USE_ROW_MASKS = False
+    try:
+        ref_out, ref_flat = _outputs_and_grads(bench_, cfg, shard, step, model, lazy)
+    finally:
+        fused.USE_ROW_MASKS = True
+    assert fused.SKIP_DEAD_ROWS
+    fused.POISON_DEAD_ROWS = True
+    try:
+        out, flat = _outputs_and_grads(bench_, cfg, shard, step, model, lazy)
+    finally:
+        fused.POISON_DEAD_ROWS = False
+    for k, v in ref_out.items():
+        if v is None:
+            assert out[k] is None
+            continue
+        assert bool(th.isfinite(out[k]).all()), k
+        s = max(1e-6, float(v.abs().max()))
+        assert float((out[k] - v).abs().max()) <= 2e-5 * s, (k, float((out[k] - v).abs().max()), s)
+    assert bool(th.isfinite(flat).all())
+    for prm, off in zip(step.sync.params, step.sync.offsets):
+        a, b = flat[off:off + prm.numel()], ref_flat[off:off + prm.numel()]
+        s = float(b.abs().max())
+        if s == 0.0:
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
