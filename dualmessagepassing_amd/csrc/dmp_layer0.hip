@@ -119,7 +119,10 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   if (lane == kLaneA) { base = reinterpret_cast<const char *>(p.sel_a); step = 4; }
   if (lane == kLaneB) { base = reinterpret_cast<const char *>(p.sel_b); step = 4; }
   const bool on = lane < K || (lane >= kLaneCoef && lane <= kLaneB);
-  auto fetch = [&](int64_t r0, float (&mm)[kRows]) {
+  static_assert(32 % kRows == 0, "a batch of rows lies inside one mask word");
+  auto fetch = [&](int64_t r0, float (&mm)[kRows], uint32_t &lv) {
+    // the batch's row-mask bits with its scalars, a whole batch ahead of their use (r0 is a multiple of kRows: one word)
+    lv = (p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
@@ -133,28 +136,24 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   // a two-batch software pipeline with the gathers issued ahead of the stores, contiguous row runs per workgroup or an
   // XCD-aware order (all within 135-145 us); PMC: 281 MB written, 260 MB fetched (the node rows 3 x).
   float mine[kRows], next[kRows];
+  uint32_t lv = 0xffffffffu, lvn = 0xffffffffu;
   int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
-  if (r0 < p.R) fetch(r0, mine);
+  if (r0 < p.R) fetch(r0, mine, lv);
   for (; r0 < p.R; r0 += stride) {
-    fetch(r0 + stride, next);                               // the next batch's scalars: a dependent round trip less per batch
+    fetch(r0 + stride, next, lvn);                          // the next batch's scalars: a dependent round trip less per batch
     Vec<VW> pa[kRows], pb[kRows];
-    bool live[kRows];
+    // a dead row (mask bit 0) gathers node row 0 instead of its own two (one cached line: no traffic, and no branch in the
+    // load / compute sequence -- control flow here costs the loop its overlapped loads: measured 120 -> 170 us) and is not stored
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      const int64_t r = r0 + u;                             // wave-uniform: scalar load, scalar branch
-      live[u] = r < p.R && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));
-      if (live[u]) {
-        pa[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneA) * p.ldp, lane);
-        pb[u] = vload<VW>(p.P + (int64_t)lane_i(mine[u], kLaneB) * p.ldp + H, lane);
-      } else {
-        pa[u] = vzero<VW>();
-        pb[u] = vzero<VW>();
-      }
+      const bool live = (lv >> u) & 1u;                      // wave-uniform: scalar selects
+      const int ia = live ? lane_i(mine[u], kLaneA) : 0, ib = live ? lane_i(mine[u], kLaneB) : 0;
+      pa[u] = vload<VW>(p.P + (int64_t)ia * p.ldp, lane);
+      pb[u] = vload<VW>(p.P + (int64_t)ib * p.ldp + H, lane);
     }
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       if (r0 + u >= p.R) break;
-      if (!live[u]) continue;
       const float cf = lane_f(mine[u], kLaneCoef);
       Vec<VW> g0 = vzero<VW>(), g1 = vzero<VW>();
 #pragma unroll
@@ -173,10 +172,11 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
         y += at<VW>(bias, c);
         at<VW>(t, c) = act_fwd(y, p.slope);
       }
-      vstore<VW>(p.out + (r0 + u) * p.ldo, lane, t);
+      if ((lv >> u) & 1u) vstore<VW>(p.out + (r0 + u) * p.ldo, lane, t);
     }
 #pragma unroll
     for (int u = 0; u < kRows; ++u) mine[u] = next[u];
+    lv = lvn;
   }
 }
 
