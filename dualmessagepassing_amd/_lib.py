@@ -154,6 +154,7 @@ SIGNATURES = {
     "dmp_atb_typed_blocks_h": (c_i64, [c_i64, c_int]),
     "dmp_atb_rows_blocks_h": (c_i64, [c_i64, c_int, c_int, c_int]),
     "dmp_atb_rows_h": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "dmp_atb_rows_plain": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "dmp_atb_rows_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_jobs_blocks_h": (c_i64, [c_i64, c_int, c_int]),
     "dmp_atb_rows_jobs_h": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr]),
@@ -173,6 +174,8 @@ SIGNATURES = {
     "dmp_mfma_partial_rows": (c_i64, [c_i64]),
     "dmp_bwd_h1_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr]),
+    "dmp_bwd_h1_fused_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr,
+                                        c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_bwd_h1_fused_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr,
                                         c_i64, c_ptr, c_ptr]),
     "dmp_bwd_z_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
@@ -189,7 +192,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 62
+ABI_VERSION = 64
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

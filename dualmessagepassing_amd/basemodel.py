@@ -162,6 +162,8 @@ def scalar_filter_gates(jobs):
     present = th.empty(max(off, 1), dtype=th.uint8, device=dev)
     _lib.check(lib.dmp_scalar_filter_gates(J, len(jobs), B, present.data_ptr(), off, _lib.stream_ptr()),
                "dmp_scalar_filter_gates")
+    for g in gates:
+        g._dmp_binary = True          # exactly 0.0 / 1.0: kernels may treat such a gate as a row mask
     return gates
 
 

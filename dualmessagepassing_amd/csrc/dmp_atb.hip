@@ -47,7 +47,8 @@ struct AtbArgs {
   int rows_x6;                     // rows variant: 1 = on the bf16 pipe (dmp_atb_rows_masked picks it)
 };
 
-enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
+enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2, ATB_PLAIN = 3 };   // PLAIN: the rows variant without a gate and without column sums (compile time: the gated form
+                                                                    // spills on the bf16 pipe; a 0 / 1 gate is fully expressed by the row mask)
 
 // X6: the products on the bf16 matrix pipe (dmp_mfma_common.h, "bf16x6": fp32-accurate, 6 x 32 instead of 8 x 64 matrix-pipe
 // cycles per 16 contracted rows).  Wave (p, q) contracts exactly one 16-row k-group per tile (rows 16q ..): a lane's
@@ -57,6 +58,7 @@ enum { ATB_ROWS = 0, ATB_TYPED = 1, ATB_REL = 2 };
 template <int MODE, int H, bool X6, bool BIG = false>
 __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const int yb) {
   constexpr bool TYPED = MODE == ATB_TYPED, REL = MODE == ATB_REL;   // REL: the control flow of the rows variant over gathered rows
+  constexpr bool PLAIN = MODE == ATB_PLAIN, ROWSLIKE = MODE == ATB_ROWS || PLAIN;
   // two tile buffers (Zs | Ds, 2 x 32 x (H+4) floats each) = 67584 bytes at H = 128; emit() reuses the first H*H floats for the total
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kStride = H + 4, kQ = H / 4, kPass = kGroupThreads / kQ, NL = kSub / kPass;   // float4 per row, rows per load pass, passes
@@ -70,7 +72,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   // rows by INDEX (structured descriptors, dmp_mfma_common.h): any array size; the column block is in the base
   const srsrc_t rs_Z = make_srsrc(p.Z + H * ya, p.ldz, p.E);
   const srsrc_t rs_D = make_srsrc(p.D + H * yb, p.ldd, p.E);
-  const bool gated = REL ? p.slot_scale != nullptr : (!TYPED && p.gate != nullptr);
+  const bool gated = REL ? p.slot_scale != nullptr : (!TYPED && !PLAIN && p.gate != nullptr);
   const rsrc_t rs_G = make_rsrc(p.gate, !REL && gated ? (uint32_t)(p.E * 4) : 0u);
   const int first = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y]) : 0;
   const int ntiles = REL ? __builtin_amdgcn_readfirstlane(p.type_tile_ptr[blockIdx.y + 1]) - first
@@ -118,7 +120,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
       }
     } else {
       // rows under a zero gate (dmp_row_mask_bits) are not fetched: they contribute gate * z = 0 to every sum
-      const uint32_t mk = (MODE == ATB_ROWS && p.rowmask && ok) ? p.rowmask[lo + k] : 0xffffffffu;
+      const uint32_t mk = (ROWSLIKE && p.rowmask && ok) ? p.rowmask[lo + k] : 0xffffffffu;
 #pragma unroll
       for (int m = 0; m < NL; ++m) {
         const int rt = (gtid / kQ) + kPass * m;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     } else if (!TYPED && gated) {
       z = make_float4(z.x * preG[S][m], z.y * preG[S][m], z.z * preG[S][m], z.w * preG[S][m]);
       cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
-    } else if (!TYPED && p.pCS) {
+    } else if (!TYPED && !PLAIN && p.pCS) {
       cs.x += z.x; cs.y += z.y; cs.z += z.z; cs.w += z.w;
     }
     *reinterpret_cast<float4 *>(&smem[o]) = z;
@@ -343,7 +345,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
     }
   }
   emit(cur);
-  if (!TYPED && pcs) {
+  if (!TYPED && !PLAIN && pcs) {
     // column sums: the 8 threads that staged the same 4 columns, added in a fixed order
     __syncthreads();
     *reinterpret_cast<float4 *>(&smem[(gtid / kQ) * H + (gtid % kQ) * 4]) = cs;
@@ -362,7 +364,8 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
 
 template <int MODE, int H = 128, bool X6 = true, bool BIG = false>
 __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
-  atb_body<MODE, H, X6, BIG>(p, MODE == ATB_ROWS ? (int)blockIdx.y / p.nb : 0, MODE == ATB_ROWS ? (int)blockIdx.y % p.nb : 0);
+  atb_body<MODE, H, X6, BIG>(p, (MODE == ATB_ROWS || MODE == ATB_PLAIN) ? (int)blockIdx.y / p.nb : 0,
+                             (MODE == ATB_ROWS || MODE == ATB_PLAIN) ? (int)blockIdx.y % p.nb : 0);
 }
 
 // Several products over the SAME rows in one launch (the node side's three weight gradients): blockIdx.y picks a
@@ -406,7 +409,7 @@ void launch_atb(const AtbArgs &a, dim3 grid, hipStream_t st) {
     atb_k<MODE, H, MODE == ATB_TYPED, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
     return;
   }
-  const bool x6 = MODE == ATB_TYPED || (MODE == ATB_ROWS && a.rows_x6);
+  const bool x6 = MODE == ATB_TYPED || MODE == ATB_PLAIN || (MODE == ATB_ROWS && a.rows_x6);   // PLAIN: no gate / column sums in the kernel -- it fits the file
   if (g_exact_fp32 || !x6) atb_k<MODE, H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
   else atb_k<MODE, H, true><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(a);
 }
@@ -558,6 +561,29 @@ int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb
   } else {
     if (!lds_ready<ATB_ROWS, 64>()) return DMP_ERR_HIP;
     launch_atb<ATB_ROWS, 64>(a, grid, (hipStream_t)stream);
+  }
+  return check_launch();
+}
+
+int dmp_atb_rows_plain(const float *A, int64_t lda, const float *B, int64_t ldb, const uint32_t *rowmask, int64_t rows, int M, int N,
+                       int H, float *partial, void *stream) {
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (rows < 0 || M <= 0 || N <= 0) return DMP_ERR_BAD_ARG;
+  if (M % H || N % H || (int64_t)(M / H) * (N / H) > 65535) return DMP_ERR_UNSUPPORTED;
+  if (!partial) return DMP_ERR_BAD_ARG;
+  if (rows > 0 && (!A || !B || lda < M || ldb < N)) return DMP_ERR_BAD_ARG;
+  if (lda % 4 || ldb % 4 || (rows > 0 && (!aligned16(A) || !aligned16(B))) || !aligned16(partial)) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(lda) || !stride_ok(ldb) || rows > 0x7fffffff - kSub) return DMP_ERR_UNSUPPORTED;
+  AtbArgs a{};
+  a.Z = A; a.ldz = lda; a.D = B; a.ldd = ldb; a.E = rows; a.plain_tiles = (int)((rows + kSub - 1) / kSub);
+  a.pT = partial; a.pstride = (int64_t)M * N; a.ldp = N; a.nb = N / H; a.cs_ld = M; a.rowmask = rowmask;
+  const dim3 grid(rows_blocks(rows, M, N, H), (unsigned)((M / H) * (N / H)));
+  if (H == 128) {
+    if (!lds_ready<ATB_PLAIN, 128>()) return DMP_ERR_HIP;
+    launch_atb<ATB_PLAIN, 128>(a, grid, (hipStream_t)stream);
+  } else {
+    if (!lds_ready<ATB_PLAIN, 64>()) return DMP_ERR_HIP;
+    launch_atb<ATB_PLAIN, 64>(a, grid, (hipStream_t)stream);
   }
   return check_launch();
 }

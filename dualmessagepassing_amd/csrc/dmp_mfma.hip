@@ -72,6 +72,8 @@ struct MfmaArgs {
   const float *R; int64_t ldr;      // EPI_GATE_RES: residual rows [E,128] or NULL; EPI_DZ: upstream gradient
                                     // or NULL; EPI_RELU_BWD_G: the saved activation H1 for the ReLU mask
   float *partial;                   // EPI_RELU_BWD_G: [2*gridDim.x, 128] column-sum partials of dPre
+  float *partialA;                  // EPI_RELU_BWD_G, pipelined form, optional: [gridDim.x, H] column sums of the FETCHED rows of A -- with
+                                    // a row mask of a 0 / 1 gate that is sum_e gate_e A[e] (the bias gradient of the Linear behind the gate)
   float s0, s1;                     // EPI_DZ: sign / scale of the gathered term by flag
   int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
   int both;                         // EPI_RELU_BWD_G: write [dPre | coef dPre] (rowscale = coef[dst e]) instead of dPre alone
@@ -236,7 +238,9 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
     }
   };
 
+  float4 csA = make_float4(0.f, 0.f, 0.f, 0.f);            // partialA: this thread's 4 columns of the rows it stages
   auto stage_row_to = [&](int buf, int m) {
+    if (EPI == EPI_RELU_BWD_G && kPipe && p.partialA) { csA.x += pre[m].x; csA.y += pre[m].y; csA.z += pre[m].z; csA.w += pre[m].w; }
     if (X6) {                                              // split once, here: three bf16 planes
       uint2 ph, pm, pl;
       split_pair(pre[m].x, pre[m].y, ph.x, pm.x, pl.x);
@@ -510,6 +514,22 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
     }
     if (lane < 8)
       *reinterpret_cast<float4 *>(p.partial + ((int64_t)blockIdx.x * NG + grp) * H + 32 * cs + lane * 4) = colsum;
+    if (kPipe && p.partialA) {
+      // the 8 threads that staged the same 4 columns (gtid % kQ), added in a fixed order through the tile buffer
+      lds_barrier();
+      float *red = reinterpret_cast<float *>(&As[0][0]);
+      *reinterpret_cast<float4 *>(&red[(gtid / kQ) * H + (gtid % kQ) * 4]) = csA;
+      lds_barrier();
+      if (gtid < kQ) {
+        float4 t = *reinterpret_cast<const float4 *>(&red[gtid * 4]);
+#pragma unroll
+        for (int g = 1; g < kGThreads / kQ; ++g) {
+          const float4 u = *reinterpret_cast<const float4 *>(&red[g * H + gtid * 4]);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4 *>(p.partialA + (int64_t)blockIdx.x * H + gtid * 4) = t;
+      }
+    }
   }
 }
 
@@ -697,7 +717,14 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
 int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                             const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
                             float *dG, int64_t ldg, float *partial, void *stream) {
+  return dmp_bwd_h1_fused_colsum(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, E, H, slope, dG, ldg, partial, nullptr, stream);
+}
+
+int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
+                            float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream) {
   if (rowmask && !gate) return DMP_ERR_BAD_ARG;
+  if (partial_rows && (g_variant == 1 || !aligned16(partial_rows))) return DMP_ERR_UNSUPPORTED;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0) return DMP_ERR_BAD_ARG;
   if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
@@ -713,7 +740,7 @@ int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64
   MfmaArgs p{};
   p.A = dO; p.lda = ldo; p.B = W2; p.ldb = ldw; p.bt = 0;  // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
-  p.both = both; p.partial = partial; p.ldt = 2 * H; p.slope = slope;
+  p.both = both; p.partial = partial; p.ldt = 2 * H; p.slope = slope; p.partialA = partial_rows;
   p.rowmask = g_variant == 1 ? nullptr : rowmask;
   return H == 128 ? launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream) : launch_mfma64<EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }

@@ -360,6 +360,9 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
     elif e_gate is not None:
         eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
+    for made, src in ((vg, v_gate), (eg, e_gate)):           # ones for the pattern rows + a 0 / 1 gate: still 0 / 1
+        if made is not None and getattr(src, "_dmp_binary", False):
+            made._dmp_binary = True
     if eg is not None and getattr(e_gate, "_dmp_dense_gate", False):
         eg._dmp_dense_gate = True        # the kept edges of a compacted batch (collate.compact_gated_edges): ones but for the padding
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):     # e.g. dropout in training: the callers run the two loops

@@ -517,10 +517,20 @@ def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
     return out
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None, slope=0.0):
+def binary_gate_mask(gate):
+    """The row mask of a gate flagged 0 / 1 (``_dmp_binary``, e.g. a ScalarFilter gate), else None: for such a gate the mask says
+    everything the gate says."""
+    if gate is None or not USE_PLAIN_ATB or not getattr(_gate_owner(gate), "_dmp_binary", False):
+        return None
+    return gate_row_mask(gate)
+
+
+def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None, slope=0.0, rows_colsum=False):
     """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : slope (d_o W2), column sums of dPre); H=128.
     ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here.
-    ``out`` (dPre alone only): destination [R, H], e.g. a column slice of a wider matrix."""
+    ``out`` (dPre alone only): destination [R, H], e.g. a column slice of a wider matrix.
+    ``rows_colsum``: a third result, the column sums of the rows of ``d_o`` the kernel fetched -- with the row mask of a 0 / 1
+    gate (``binary_gate_mask``) that is ``sum_e gate_e d_o[e]``, the bias gradient of the Linear behind the gate."""
     lib = _lib.load()
     E, H = d_o.shape
     if both_halves:
@@ -532,21 +542,47 @@ def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None,
     part = torch.empty((int(lib.dmp_mfma_partial_rows_h(E, H)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
-        check(lib.dmp_bwd_h1_fused_masked(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
+        part_rows = torch.empty_like(part) if rows_colsum else None
+        check(lib.dmp_bwd_h1_fused_colsum(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
                                           ptr(gate), ptr(gate_row_mask(gate)), E, H, slope, ptr(d_g),
-                                          d_g.stride(0) if E > 1 else d_g.size(1), ptr(part), stream_ptr()), "dmp_bwd_h1_fused")
+                                          d_g.stride(0) if E > 1 else d_g.size(1), ptr(part), ptr(part_rows), stream_ptr()),
+              "dmp_bwd_h1_fused")
+    if rows_colsum:
+        return d_g, reduce_partials(part), reduce_partials(part_rows)
     return d_g, reduce_partials(part)
+
+
+def _gate_owner(gate):
+    """The tensor a gate's views share (``gate_row_mask``): where its memoised masks and flags hang."""
+    owner = gate._base if gate._base is not None else gate
+    if owner.data_ptr() != gate.data_ptr() or owner.numel() != gate.numel():
+        owner = gate
+    return owner
+
+
+USE_PLAIN_ATB = _os.environ.get("DMP_PLAIN_ATB", "1") == "1"
 
 
 def atb_rows(a, b, gate=None, colsum=True):
     """``((gate (.) a)^T b  [M,N],  column sums of gate (.) a  [M] (or None))`` in one MFMA pass over the rows
-    (csrc/dmp_atb.hip); M, N multiples of 128 (or of 64).  A Linear's weight and bias gradient with a row gate fused in."""
+    (csrc/dmp_atb.hip); M, N multiples of 128 (or of 64).  A Linear's weight and bias gradient with a row gate fused in.
+    A gate flagged as 0 / 1 (``_dmp_binary``: a ScalarFilter gate) is fully expressed by its row mask: the product then runs
+    ungated over the masked-in rows on the bf16 pipe (``dmp_atb_rows_plain``), the column sums as a one-column ``smallk_atb``."""
     lib = _lib.load()
     R, M = a.shape
     N = b.size(1)
     blk = atb_block(M, N)
     G = int(lib.dmp_atb_rows_blocks_h(R, M, N, blk))
     part = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
+    mask = binary_gate_mask(gate)
+    if mask is not None and M % blk == 0 and blk in (64, 128):
+        with _lib.timed("atb_rows_plain[M=%d,N=%d,R=%d]", (M, N, R), 4 * (M + N) * R):
+            check(lib.dmp_atb_rows_plain(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(mask), R, M, N, blk, ptr(part), stream_ptr()),
+                  "dmp_atb_rows_plain")
+        cs = None
+        if colsum:   # sum over the kept rows of a = gate^T a: the K = 1 case of the narrow weight-gradient kernel, same mask
+            cs = smallk_atb_cols(gate.reshape(-1, 1), a, H=blk, mask=mask).reshape(M)
+        return reduce_partials(part).view(M, N), cs
     part_cs = torch.empty((G, M), dtype=torch.float32, device=a.device) if colsum else None
     with _lib.timed("atb_rows[M=%d,N=%d,R=%d]", (M, N, R), 4 * (M + N) * R + (4 * R if gate is not None else 0)):
         check(lib.dmp_atb_rows_masked(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(gate), ptr(gate_row_mask(gate)), ATB_ROWS_X6,
@@ -1150,8 +1186,14 @@ class _FusedDMPLayer(torch.autograd.Function):
                 db2e = gcnt[:, 0] @ T
             elif typed:
                 # the gate is applied inside the two consumers of dO = gate * dzn (no [E,H] pass of its own)
-                dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
-                dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
+                if binary_gate_mask(ctx.e_gate) is not None:
+                    # a 0 / 1 gate: bwd_h1 hands out sum_e g_e dzn[e] (db2) from the rows it fetches anyway, and the weight
+                    # gradient runs ungated over the masked-in rows on the bf16 pipe
+                    dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True)
+                    dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
+                else:
+                    dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
+                    dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
             else:
                 dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
                 dW2e = atb(dOe, H1e)
@@ -1183,9 +1225,14 @@ class _FusedDMPLayer(torch.autograd.Function):
             one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
             if onepanel_ok(H) and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
-                if not one_launch or vcodes:
-                    dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
-                dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope)
+                if (not one_launch or vcodes) and binary_gate_mask(ctx.v_gate) is not None:
+                    dPn, dbn, db2n = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope,
+                                                 rows_colsum=True)
+                    dW2n = atb_rows(dxn, H1n, ctx.v_gate, colsum=False)[0]
+                else:
+                    if not one_launch or vcodes:
+                        dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
+                    dPn, dbn = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope)
             else:
                 dOn, db2n = scale_rows_colsum(dxn, ctx.v_gate)
                 dW2n = wg(dOn, H1n)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 62
+#define DMP_ABI_VERSION 64
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -969,6 +969,13 @@ int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int
 int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                             const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
                             float *dG, int64_t ldg, float *partial, void *stream);
+/* ... that also hands out the column sums of the rows of dO it FETCHED: partial_rows [dmp_mfma_partial_rows_h(E, H), H] (or NULL), summed by
+ * dmp_reduce_partials.  With the row mask of a 0 / 1 gate that is sum_e gate_e dO[e] -- the bias gradient of the Linear behind the gate
+ * (dmpnn.py:45-60: db2), for which dmp_atb_rows otherwise carries column sums: the weight gradient can then run ungated
+ * (dmp_atb_rows_plain).  Without a mask: the column sums of all of dO. */
+int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
+                            float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
@@ -1061,6 +1068,12 @@ int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, con
  * overrides), 0 = the f32-input MFMA. */
 int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, const uint32_t *rowmask,
                         int x6, int64_t rows, int M, int N, int H, float *partial, float *partial_colsum, void *stream);
+/* The rows product without a gate and without column sums, over the rows of a row mask (NULL: all): A^T B restricted to the masked-in
+ * rows -- which IS (gate (.) A)^T B for a 0 / 1 gate whose mask it is.  On the bf16 pipe (bf16x6; the gated form above does not fit the
+ * register file there); the bias gradient (column sums of the gated A) comes from dmp_smallk_atb_cols_masked with the gate as its
+ * one-column X.  partial as dmp_atb_rows_h (same number of blocks). */
+int dmp_atb_rows_plain(const float *A, int64_t lda, const float *B, int64_t ldb, const uint32_t *rowmask, int64_t rows, int M, int N,
+                       int H, float *partial, void *stream);
 
 /*
  * Relation-typed products of the relational layers (SubgraphCountingMatching/models/rgcn.py:98-123,

@@ -440,3 +440,45 @@ def test_zero_gate_skipping_leaves_every_output_and_gradient_as_it_was(lazy):
             assert float(a.abs().max()) == 0.0
         else:
             assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
+
+
+@pytest.mark.parametrize("R,M,N", [(40003, 128, 128), (5000, 64, 64), (8200, 128, 256)])
+def test_binary_gate_weight_gradient_on_the_plain_rows_product(R, M, N):
+    """``fused.atb_rows`` with a gate flagged 0 / 1: the ungated product over the masked-in rows (bf16x6) + the one-column
+    column sums against fp64 and against the gated f32 form; rows under a zero gate are never fetched (NaN there)."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    g = th.Generator(device=gpu).manual_seed(R + M)
+    gate = (th.rand(R, device=gpu, generator=g) < 0.4).float()
+    a = th.randn(R, M, device=gpu, generator=g)
+    b = th.randn(R, N, device=gpu, generator=g)
+    ref_w = (a.double() * gate.double()[:, None]).t() @ b.double()
+    ref_c = (a.double() * gate.double()[:, None]).sum(0)
+    w0, c0 = fused.atb_rows(a, b, gate)                           # not flagged: the gated form
+    gate._dmp_binary = True
+    ap, bp = a.clone(), b.clone()
+    ap[gate == 0] = float("nan")
+    bp[gate == 0] = float("nan")
+    w1, c1 = fused.atb_rows(ap, bp, gate)
+    scale = float((a.double().abs() * gate.double()[:, None]).t().matmul(b.double().abs()).max())
+    for w, c in ((w0, c0), (w1, c1)):
+        assert bool(th.isfinite(w).all()) and bool(th.isfinite(c).all())
+        assert float((w.double() - ref_w).abs().max()) <= 2e-6 * scale
+        assert float((c.double() - ref_c).abs().max()) <= 2e-6 * float(gate.sum())
+
+
+@pytest.mark.parametrize("H,R", [(128, 40003), (64, 5000)])
+def test_bwd_h1_hands_out_the_gated_column_sums(H, R):
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    g = th.Generator(device=gpu).manual_seed(H + R)
+    gate = (th.rand(R, device=gpu, generator=g) < 0.4).float()
+    gate._dmp_binary = True
+    d_o = th.randn(R, H, device=gpu, generator=g)
+    h1 = th.randn(R, H, device=gpu, generator=g)
+    W2 = th.randn(H, H, device=gpu, generator=g) / H ** 0.5
+    dg0, db0 = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18)
+    dg1, db1, cs = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18, rows_colsum=True)
+    assert th.equal(dg0, dg1) and th.equal(db0, db1)
+    ref = (d_o.double() * gate.double()[:, None]).sum(0)
+    assert float((cs.double() - ref).abs().max()) <= 2e-6 * float(gate.sum())
