@@ -374,8 +374,8 @@ __global__ __launch_bounds__(kGroupThreads, 2) void atb_k(const AtbArgs p) {
 // start, LDS reduction, 64 KB partial) are paid 512 times in total instead of 512 times per product.
 constexpr int kMaxAtbJobs = DMP_ATB_MAX_JOBS;
 struct AtbJobs { AtbArgs job[kMaxAtbJobs]; };
-template <int H, bool X6 = true>
-__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<ATB_ROWS, H, X6>(t.job[blockIdx.y], 0, 0); }
+template <int H, bool X6 = true, int MODE = ATB_ROWS>
+__global__ __launch_bounds__(kGroupThreads, 2) void atb_jobs_k(const AtbJobs t) { atb_body<MODE, H, X6>(t.job[blockIdx.y], 0, 0); }
 
 constexpr int kAtbLdsBytes = 2 * 2 * kSub * kLdsStride * 4;   // 67584: above the 64 KB static limit -> dynamic LDS, opted in once
 constexpr int kAtbLdsBytes64 = 2 * 2 * kSub * 68 * 4;         // H = 64: 34816
@@ -430,14 +430,18 @@ static unsigned rows_blocks(int64_t rows, int M, int N, int H) {
 }
 
 
+// plain: no job has a gate or column sums -- the launch runs the ungated form on the bf16 pipe (it fits the register file there,
+// the gated form does not: see launch_atb)
 template <int H>
-static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStream_t st) {
-  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {};
+static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStream_t st, bool plain) {
+  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {}, done_plain[kMaxDevices] = {};
   if (!opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, true>), atb_lds_bytes(H), done) ||
-      !opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, false>), atb_lds_bytes(H), done_exact))
+      !opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, false>), atb_lds_bytes(H), done_exact) ||
+      !opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, true, ATB_PLAIN>), atb_lds_bytes(H), done_plain))
     return DMP_ERR_HIP;
   const dim3 grid(rows_blocks(rows, H, H * (num_jobs > 0 ? num_jobs : 1), H), (unsigned)num_jobs);
-  atb_jobs_k<H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);   // f32-input MFMA (see launch_atb)
+  if (plain && !g_exact_fp32) atb_jobs_k<H, true, ATB_PLAIN><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
+  else atb_jobs_k<H, false><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);   // f32-input MFMA (see launch_atb)
   return check_launch();
 }
 
@@ -491,8 +495,10 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || num_jobs < 1 || num_jobs > kMaxAtbJobs || !jobs) return DMP_ERR_BAD_ARG;
   AtbJobs t;
+  bool plain = true;
   for (int i = 0; i < num_jobs; ++i) {
     const dmp_atb_job &j = jobs[i];
+    plain = plain && !j.gate && !j.partial_colsum;
     if (!j.partial || (rows > 0 && (!j.A || !j.B || j.lda < H || j.ldb < H)) || j.ldp < H) return DMP_ERR_BAD_ARG;
     if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial) ||
         (j.partial_colsum && !aligned16(j.partial_colsum)))
@@ -505,7 +511,8 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
     a.nb = 1; a.cs_ld = j.cs_ld; a.rowmask = j.rowmask;
     t.job[i] = a;
   }
-  return H == 128 ? atb_jobs_launch<128>(t, num_jobs, rows, (hipStream_t)stream) : atb_jobs_launch<64>(t, num_jobs, rows, (hipStream_t)stream);
+  return H == 128 ? atb_jobs_launch<128>(t, num_jobs, rows, (hipStream_t)stream, plain)
+                  : atb_jobs_launch<64>(t, num_jobs, rows, (hipStream_t)stream, plain);
 }
 
 int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream) {

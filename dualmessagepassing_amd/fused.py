@@ -1225,10 +1225,12 @@ class _FusedDMPLayer(torch.autograd.Function):
             one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
             if onepanel_ok(H) and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
-                if (not one_launch or vcodes) and binary_gate_mask(ctx.v_gate) is not None:
+                if binary_gate_mask(ctx.v_gate) is not None:
+                    # a 0 / 1 node gate: db2n from the rows bwd_h1 fetches, the weight gradient(s) ungated over the masked-in rows
                     dPn, dbn, db2n = bwd_h1_mfma(dxn, nW2, H1n, both_halves=False, gate=ctx.v_gate, out=dXP[:, :H], slope=slope,
                                                  rows_colsum=True)
-                    dW2n = atb_rows(dxn, H1n, ctx.v_gate, colsum=False)[0]
+                    if not one_launch or vcodes:
+                        dW2n = atb_rows(dxn, H1n, ctx.v_gate, colsum=False)[0]
                 else:
                     if not one_launch or vcodes:
                         dW2n, db2n = atb_rows(dxn, H1n, ctx.v_gate)
@@ -1261,7 +1263,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                                         Yn[:, t * VK:(t + 1) * VK], H,
                                         mask=vmask[n0 // 32:] if (vmask is not None and n0 % 32 == 0) else None)
                 elif one_launch:
-                    (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, gate_row_mask(ctx.v_gate)), (x, dXP, None, False)])
+                    vm = binary_gate_mask(ctx.v_gate)
+                    if vm is not None:    # (db2n came from bwd_h1; no job carries a gate: the launch runs on the bf16 pipe)
+                        (dW2n, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (x, dXP, None, False)])
+                    else:
+                        (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, gate_row_mask(ctx.v_gate)), (x, dXP, None, False)])
                 else:
                     dWx = wg(x, dXP)
             else:
@@ -1269,8 +1275,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
                     # (dPn = act'(H1n) ((v_gate dxn) W2): zero rows under a zero node gate -- the first two products skip them)
                     vm = gate_row_mask(ctx.v_gate)
-                    (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, vm), (S, dPn, None, False, vm),
-                                                                        (x, dXP, None, False)])
+                    if binary_gate_mask(ctx.v_gate) is not None:   # (db2n came from bwd_h1; no job carries a gate: bf16 pipe)
+                        (dW2n, _), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (S, dPn, None, False, vm),
+                                                                         (x, dXP, None, False)])
+                    else:
+                        (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, vm), (S, dPn, None, False, vm),
+                                                                            (x, dXP, None, False)])
                 else:
                     dBn = wg(S, dPn)                                         # [2H,H]
                     dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]

@@ -1118,6 +1118,8 @@ int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void 
 /* H x H output blocks per job, H = 128 (the two functions above) or 64. */
 int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H);
 int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream);
+/* (a launch none of whose jobs has a gate or column sums runs on the bf16 pipe, bf16x6: the 0 / 1-gated products of a step come as
+ * row masks, their column sums from dmp_bwd_h1_fused_colsum) */
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup

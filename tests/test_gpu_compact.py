@@ -482,3 +482,29 @@ def test_bwd_h1_hands_out_the_gated_column_sums(H, R):
     assert th.equal(dg0, dg1) and th.equal(db0, db1)
     ref = (d_o.double() * gate.double()[:, None]).sum(0)
     assert float((cs.double() - ref).abs().max()) <= 2e-6 * float(gate.sum())
+
+
+@pytest.mark.parametrize("R,H", [(9001, 128), (2500, 64)])
+def test_rows_jobs_without_gates_run_ungated_over_the_masked_in_rows(R, H):
+    """``fused.atb_rows_multi`` whose jobs carry neither a gate nor column sums (the node side of a step under a 0 / 1 gate):
+    one bf16x6 launch; rows a job's mask leaves out are never fetched (NaN there), jobs without a mask read every row."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    g = th.Generator(device=gpu).manual_seed(R + H)
+    gate = (th.rand(R, device=gpu, generator=g) < 0.4).float()
+    gate._dmp_binary = True
+    mask = fused.binary_gate_mask(gate)
+    assert mask is not None
+    a = th.randn(R, H, device=gpu, generator=g)
+    b = th.randn(R, H, device=gpu, generator=g)
+    x = th.randn(R, H, device=gpu, generator=g)
+    y = th.randn(R, 2 * H, device=gpu, generator=g)
+    ap, bp = a.clone(), b.clone()
+    ap[gate == 0] = float("nan")
+    bp[gate == 0] = float("nan")
+    (w, c), (wx, cx) = fused.atb_rows_multi([(ap, bp, None, False, mask), (x, y, None, False)])
+    assert c is None and cx is None
+    ref_w = (a.double() * gate.double()[:, None]).t() @ b.double()
+    ref_x = x.double().t() @ y.double()
+    assert float((w.double() - ref_w).abs().max()) <= 2e-6 * float(((a.double().abs() * gate.double()[:, None]).t() @ b.double().abs()).max())
+    assert float((wx.double() - ref_x).abs().max()) <= 2e-6 * float((x.double().abs().t() @ y.double().abs()).max())
