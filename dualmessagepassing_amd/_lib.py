@@ -69,6 +69,8 @@ SIGNATURES = {
     "dmp_seg_sum2_graphs_max_nodes": (c_int, []),
     "dmp_seg_sum2_graphs": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                     c_ptr, c_i64, c_ptr]),
+    "dmp_seg_sum2_graphs_masked": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
+                                           c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_seg_sum2_tiled": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                    c_ptr, c_i64, c_ptr]),
     "dmp_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
@@ -169,6 +171,10 @@ SIGNATURES = {
                                   c_i64, c_ptr]),
     "dmp_out_fwd_fused_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                          c_i64, c_ptr]),
+    "dmp_out_fwd_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
+                                       c_i64, c_ptr]),
+    "dmp_bwd_h1_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_f32, c_ptr,
+                                      c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_row_mask_rows": (c_int, [c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr]),
     "dmp_mfma_partial_rows": (c_i64, [c_i64]),
@@ -192,7 +198,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 64
+ABI_VERSION = 65
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

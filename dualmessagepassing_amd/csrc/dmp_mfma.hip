@@ -78,6 +78,8 @@ struct MfmaArgs {
   int gated;                        // EPI_RELU_BWD_G, dPre only: rowscale is the edge gate applied to the product's rows
   int both;                         // EPI_RELU_BWD_G: write [dPre | coef dPre] (rowscale = coef[dst e]) instead of dPre alone
   float slope;                      // EPI_EDGE / EPI_RELU_BWD_G: negative slope of the activation (0 = ReLU)
+  int dead_rows;                    // pipelined form with a row mask: bit 0 = R's masked-out rows are zeros (not fetched: EPI_GATE_RES),
+                                    // bit 1 = the masked-out rows of C are not stored (every reader of C leaves them out)
   // EPI_GATE_RES / EPI_RELU_BWD_G (pipelined form): bit r of rowmask[t] == 0 -> row 32 t + r has gate 0, and the rows of A (and,
   // for EPI_RELU_BWD_G, of R) it would have contributed are not fetched: their products are multiplied by the zero gate anyway
   // (out = R + 0 (...), dPre = act'(.) 0).  NULL: every row is fetched.
@@ -201,6 +203,9 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
   auto voff_if = [&](uint32_t mk8, uint32_t bit, uint32_t voff) -> uint32_t { return voff | ((mk8 & bit) ? 0u : 0x80000000u); };
   const uint32_t abit = 1u << (gtid / kQ);                 // A rows of a thread: gtid / kQ + 8 m
   const uint32_t rbit = 1u << (lane >> 3);                 // operand rows of a lane: 8 k + lane / 8
+  // what a mask says about the residual rows (EPI_GATE_RES) / about the stores: everything unless the caller said otherwise
+  const uint32_t res_all = (kMasked && (p.dead_rows & 1)) ? 0u : 0xffffffffu;
+  const uint32_t store_all = (kMasked && (p.dead_rows & 2)) ? 0u : 0xffffffffu;
 
   float4 pre[kSubLoads];
   uint32_t pre_a = 0, pre_b = 0;
@@ -280,6 +285,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
         g1[k] = buf_load4(rr_, voffR, k * grpR);
       } else if (EPI == EPI_RELU_BWD_G && kMasked) {
         g0[k] = buf_load4(rr_, voff_if(mask_of(t) >> (8 * k), rbit, voffR), k * grpR);
+      } else if (EPI == EPI_GATE_RES && kMasked) {
+        g0[k] = buf_load4(rr_, voff_if((mask_of(t) | res_all) >> (8 * k), rbit, voffR), k * grpR);
       } else if (EPI == EPI_GATE_RES || EPI == EPI_RELU_BWD_G) {
         g0[k] = buf_load4(rr_, voffR, k * grpR);
       }
@@ -315,9 +322,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
     const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
     const rsrc_t rr1 = make_rsrc(p.R ? p.R + (int64_t)t1 * kSub * p.ldr : nullptr, p.R ? tile_bytes(tile_rows(t1), p.ldr, H) : 0u);
     const rsrc_t ra2 = make_rsrc(p.A + (int64_t)t2 * kSub * p.lda, tile_bytes(tile_rows(t2), p.lda, H));
+    const uint32_t mk1r = EPI == EPI_RELU_BWD_G ? mk1 : (mk1 | res_all);         // the operand rows of tile k+1 to fetch
     // in the shadow of the MFMA groups (H = 64: 8 groups, two of these 14 actions after each)
     auto shadow = [&](int i) {
-      if (i < 4) g0n[kPipe ? i : 0] = buf_load4(rr1, EPI == EPI_RELU_BWD_G ? voff_if(mk1 >> (8 * i), rbit, voffR) : voffR, i * grpR);   // tile k+1's operand rows 8 i + lrow
+      if (i < 4) g0n[kPipe ? i : 0] = buf_load4(rr1, voff_if(mk1r >> (8 * i), rbit, voffR), i * grpR);   // tile k+1's operand rows 8 i + lrow
       else if (i < 8) stage_row_to(buf ^ 1, i - 4);                               // tile k+1 -> the other buffer
       else if (i == 8) stage_scalars_to(nxt3);
       else if (i < 13) pre[i - 9] = buf_load4(ra2, voff_if(mk2 >> (8 * (i - 9)), abit, voffA), (i - 9) * grpA);   // tile k+2's rows
@@ -380,7 +388,8 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
   // NC = 2: after the accumulators have been parked in the scratch -- the other group's MFMA
   // phase covers their latency
   constexpr bool kEarly = (NC == 1);
-  auto epilogue = [&](int t, int par) {                   // transpose through LDS, combine, store
+  auto epilogue = [&](int t, int par, uint32_t mk0 = 0xffffffffu) {   // transpose through LDS, combine, store (mk0: the tile's row mask)
+    const uint32_t mks = mk0 | store_all;
     constexpr int NOUT = (EPI == EPI_NONE) ? NC : 1;
     const rsrc_t rc = make_rsrc(p.C + (int64_t)t * kSub * p.ldc, tile_bytes(tile_rows(t), p.ldc, kOutCols));
 #pragma unroll
@@ -424,10 +433,10 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
           colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
           if (both_halves) {
             const float cf = rowS[grp][par][rr];
-            buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, voffC[k] + kRowBytes, 0);
+            buf_store4(make_float4(v.x * cf, v.y * cf, v.z * cf, v.w * cf), rc, (kMasked ? voff_if(mks >> (8 * k), rbit, voffC[k]) : voffC[k]) + kRowBytes, 0);
           }
         }
-        buf_store4(v, rc, voffC[k] + kRowBytes * q, 0);
+        buf_store4(v, rc, (kMasked ? voff_if(mks >> (8 * k), rbit, voffC[k]) : voffC[k]) + kRowBytes * q, 0);
       }
     }
   };
@@ -445,13 +454,14 @@ __global__ __launch_bounds__(PP ? kPPThreads : 2 * H, PP ? 1 : (X6 ? 2 : (NC == 
     fetch_operands(tile(0), 0);
     lds_barrier();
     int par3 = 0;
-    uint32_t mk1 = mask_of(tile(1)), mk2 = mask_of(tile(2));
+    uint32_t mk0 = mask_of(tile(0)), mk1 = mask_of(tile(1)), mk2 = mask_of(tile(2));
     for (int k = 0; k < mine; ++k) {
       const uint32_t mk3 = mask_of(tile(k + 3));             // requested a whole tile before its first use
       tile_step(k, par3, tile(k + 1), tile(k + 2), mk1, mk2);
-      mk1 = mk2; mk2 = mk3;
+      const uint32_t mke = mk0;
+      mk0 = mk1; mk1 = mk2; mk2 = mk3;
       lds_barrier();               // tile k+1 is staged for everyone, everyone is done with tile k's rows
-      epilogue(tile(k), par3);
+      epilogue(tile(k), par3, mke);
 #pragma unroll
       for (int q = 0; q < 4; ++q) g0[q] = g0n[kPipe ? q : 0];
       par3 = par3 == 2 ? 0 : par3 + 1;
@@ -684,7 +694,14 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
 int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
                              const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
                              int w_in_out, float *out, int64_t ldo, void *stream) {
+  return dmp_out_fwd_fused_rows(Hin, ldh, W2, ldw, bias, gate, rowmask, 0, R, ldr, E, H, w_in_out, out, ldo, stream);
+}
+
+int dmp_out_fwd_fused_rows(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
+                           const float *gate, const uint32_t *rowmask, int dead_rows, const float *R, int64_t ldr, int64_t E, int H,
+                           int w_in_out, float *out, int64_t ldo, void *stream) {
   if (rowmask && !gate) return DMP_ERR_BAD_ARG;
+  if (dead_rows < 0 || dead_rows > 3 || (dead_rows && !rowmask)) return DMP_ERR_BAD_ARG;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0) return DMP_ERR_BAD_ARG;
   if (E == 0) return DMP_OK;
@@ -698,6 +715,7 @@ int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int
   p.bt = w_in_out ? 0 : 1;  // nn.Linear weight [out, in]: B[k][j] = W2[j][k]; [in, out] (its transpose): B[k][j] = W2[k][j]
   p.C = out; p.ldc = ldo; p.E = E; p.bias = bias; p.rowscale = gate; p.R = R; p.ldr = R ? ldr : H; p.ldt = 2 * H;
   p.rowmask = g_variant == 1 ? nullptr : rowmask;
+  p.dead_rows = dead_rows;
   return H == 128 ? launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream) : launch_mfma64<EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
@@ -717,13 +735,20 @@ int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
 int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                             const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
                             float *dG, int64_t ldg, float *partial, void *stream) {
-  return dmp_bwd_h1_fused_colsum(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, E, H, slope, dG, ldg, partial, nullptr, stream);
+  return dmp_bwd_h1_fused_rows(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, 0, E, H, slope, dG, ldg, partial, nullptr, stream);
 }
 
 int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                             const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
                             float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream) {
+  return dmp_bwd_h1_fused_rows(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, 0, E, H, slope, dG, ldg, partial, partial_rows, stream);
+}
+
+int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                          const float *coefE, const float *gate, const uint32_t *rowmask, int skip_dead_stores, int64_t E, int H,
+                          float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream) {
   if (rowmask && !gate) return DMP_ERR_BAD_ARG;
+  if (skip_dead_stores && !rowmask) return DMP_ERR_BAD_ARG;
   if (partial_rows && (g_variant == 1 || !aligned16(partial_rows))) return DMP_ERR_UNSUPPORTED;
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0) return DMP_ERR_BAD_ARG;
@@ -742,6 +767,7 @@ int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64
   p.C = dG; p.ldc = ldg; p.E = E; p.R = H1; p.ldr = ldh; p.rowscale = gate ? gate : coefE; p.gated = gate != nullptr;
   p.both = both; p.partial = partial; p.ldt = 2 * H; p.slope = slope; p.partialA = partial_rows;
   p.rowmask = g_variant == 1 ? nullptr : rowmask;
+  p.dead_rows = skip_dead_stores ? 2 : 0;
   return H == 128 ? launch_mfma<1, EPI_RELU_BWD_G>(p, (hipStream_t)stream) : launch_mfma64<EPI_RELU_BWD_G>(p, (hipStream_t)stream);
 }
 

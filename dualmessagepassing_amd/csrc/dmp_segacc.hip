@@ -68,10 +68,14 @@ struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, 
       : "memory")
 
 // H: row width (64 or 128) = 64 columns per wave, H / 64 waves per workgroup, one workgroup per tile.
-template <int H>
+// MASKED: bit (e & 31) of rowmask[e >> 5] clear = row e of M is known to be all zeros (the gradient rows a 0 / 1 edge gate
+// wiped, dmp_row_mask_bits): such a row is requested past the end of its descriptor -- the load returns zeros without
+// memory traffic, the instruction stream is the same.
+template <int H, bool MASKED = false>
 __global__ __launch_bounds__(H) void seg_acc_graphs_k(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ selA, const int32_t *__restrict__ selB,
-    const GraphTiles ts, float s0, float s1, float *__restrict__ out, int64_t ldo) {
+    const GraphTiles ts, float s0, float s1, float *__restrict__ out, int64_t ldo,
+    const uint32_t *__restrict__ rowmask = nullptr, int64_t mask_words = 0) {
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
   // the tile: graphs [g0, g1)
@@ -91,8 +95,22 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
   const rsrc_t rsA = make_rsrc(selA + e0, (uint32_t)R * 4u), rsB = make_rsrc(selB + e0, (uint32_t)R * 4u);
   const uint32_t voff = (uint32_t)(64 * c + lane) * 4u;
   const uint32_t rowb = (uint32_t)(ldm * 4);
-  auto load_row = [&](int r) -> float {                         // row r of the tile, this wave's columns (scalar row offset)
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, (int)voff, (int)((uint32_t)r * rowb), 0));
+  // (a masked-out row: the same load through a descriptor of zero records -- one scalar select, no vector instruction)
+  const float *const baseM = M + e0 * ldm;
+  const uint32_t bytesM = tile_bytes(R, ldm, H);
+  auto load_row = [&](int r, uint32_t live = 1u) -> float {     // row r of the tile, this wave's columns (scalar row offset)
+    const rsrc_t rs = MASKED ? make_rsrc(baseM, live ? bytesM : 0u) : rsM;
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((uint32_t)r * rowb), 0));
+  };
+  // mask bits of the tile's rows 32 sg .. 32 sg + 31 (rows e0 + 32 sg ...: two words of the mask, wave-uniform)
+  // (word indices clamped to the mask's last word: what they say about rows past the tile's end is not used -- those rows
+  // lie past the end of the descriptor anyway)
+  const int msh = (int)(e0 & 31), mw0 = (int)(e0 >> 5), mlast = (int)mask_words - 1;
+  auto mask_sg = [&](int sg) -> uint32_t {
+    if (!MASKED) return 0xffffffffu;
+    const int w = mw0 + sg;
+    const uint32_t lo = rowmask[min(w, mlast)], hi = rowmask[min(w + 1, mlast)];
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> msh);
   };
   auto load_sel = [&](int sg, int &a, int &b) {                 // endpoints of row kRing sg + lane
     a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, sg * (kRing * 4), 0);
@@ -110,9 +128,13 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
   float tmp_t, tmp_u;
   load_sel(0, na, nb);
   asm volatile("" ::: "memory");     // keep the endpoint loads OLDER than the ring (the waits count younger operations)
+  uint32_t m_next = mask_sg(0);      // the mask words run two super-groups ahead of the adds (scalar loads)
 #pragma unroll
-  for (int k = 0; k < kRing; ++k) v[k] = load_row(k);
+  for (int k = 0; k < kRing; ++k) v[k] = load_row(k, (m_next >> k) & 1u);
+  m_next = mask_sg(1);
   for (int sg = 0; sg < nsg; ++sg) {
+    const uint32_t m_load = m_next;  // rows of super-group sg + 1, requested below
+    m_next = mask_sg(sg + 2);
     // register indices of this super-group's rows: node - n0 relative to v64 (half 0) / v128 (half 1); the trash
     // register v192 = index 128 / 64 for rows past the end and endpoints outside the tile
     const bool in = lane < kRing && sg * kRing + lane < R;
@@ -134,7 +156,8 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
       // ... and the same four ring slots take the rows kRing ahead: AFTER the adds (the block is a memory barrier to the
       // compiler), so the loads land in the registers the adds have just read -- no second register set, no copies
       const int r = (sg + 1) * kRing + g;
-      v[g] = load_row(r); v[g + 1] = load_row(r + 1); v[g + 2] = load_row(r + 2); v[g + 3] = load_row(r + 3);
+      v[g] = load_row(r, (m_load >> g) & 1u); v[g + 1] = load_row(r + 1, (m_load >> (g + 1)) & 1u);
+      v[g + 2] = load_row(r + 2, (m_load >> (g + 2)) & 1u); v[g + 3] = load_row(r + 3, (m_load >> (g + 3)) & 1u);
     }
   }
   // the sums: 256 contiguous bytes per store instruction (this wave's columns of one node row and half)
@@ -159,9 +182,9 @@ extern "C" {
 
 int dmp_seg_sum2_graphs_max_nodes(void) { return kAccNodes; }
 
-int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
-                        const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
-                        float *out, int64_t ldo, void *stream) {
+static int seg_sum2_graphs_impl(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
+                                const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
+                                float *out, int64_t ldo, const uint32_t *rowmask, int64_t mask_words, void *stream) {
   if (Ba < 0 || Bb < 0 || H <= 0 || ldm < H || ldo < 2 * H || (Ba > 0 && ka < 1) || (Bb > 0 && kb < 1)) return DMP_ERR_BAD_ARG;
   if (Ba + Bb == 0) return DMP_OK;
   if (!M || !sel_a || !sel_b || !node_off || !edge_off || !out) return DMP_ERR_BAD_ARG;
@@ -171,9 +194,26 @@ int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const
   GraphTiles ts{node_off, edge_off, Ba, Bb, ka > 0 ? ka : 1, kb > 0 ? kb : 1};
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = (unsigned)tiles;
-  if (H == 128) seg_acc_graphs_k<128><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
+  if (rowmask) {
+    if (H == 128) seg_acc_graphs_k<128, true><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words);
+    else seg_acc_graphs_k<64, true><<<nb, 64, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words);
+  } else if (H == 128) seg_acc_graphs_k<128><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
   else seg_acc_graphs_k<64><<<nb, 64, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
   return check_launch();
+}
+
+int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
+                        const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
+                        float *out, int64_t ldo, void *stream) {
+  return seg_sum2_graphs_impl(M, ldm, sel_a, sel_b, node_off, edge_off, Ba, Bb, ka, kb, H, s0, s1, out, ldo, nullptr, 0, stream);
+}
+
+int dmp_seg_sum2_graphs_masked(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
+                               const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
+                               float *out, int64_t ldo, const uint32_t *rowmask, int64_t num_rows, void *stream) {
+  if (!rowmask || num_rows < 0) return DMP_ERR_BAD_ARG;
+  return seg_sum2_graphs_impl(M, ldm, sel_a, sel_b, node_off, edge_off, Ba, Bb, ka, kb, H, s0, s1, out, ldo, rowmask,
+                              (num_rows + 31) / 32, stream);
 }
 
 }  // extern "C"

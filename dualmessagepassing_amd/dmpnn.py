@@ -192,7 +192,8 @@ class DMPLayer(nn.Module):
         return True
 
     @on_input_device
-    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None, l0=None):
+    def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None, l0=None,
+                      inner=False):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
@@ -206,7 +207,7 @@ class DMPLayer(nn.Module):
         coef = ix.degree_coef(g.ndata[OUTDEGREE])
         vg = None if v_gate is None else v_gate.reshape(-1).contiguous()
         eg = None if e_gate is None else e_gate.reshape(-1).contiguous()
-        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded, pools, l0)
+        out = fused.fused_dmp_layer(ix, coef, residual, node_feat, edge_feat, vg, eg, self, folded, pools, l0, inner)
         leave_detached(g.ndata, NODEFEAT)
         leave_detached(g.edata, EDGEFEAT)
         return out
@@ -363,6 +364,8 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     for made, src in ((vg, v_gate), (eg, e_gate)):           # ones for the pattern rows + a 0 / 1 gate: still 0 / 1
         if made is not None and getattr(src, "_dmp_binary", False):
             made._dmp_binary = True
+    if eg is not None:
+        eg._dmp_zero_rows = True         # e's target rows were multiplied by this gate above (_gate_concat / the packed codes)
     if eg is not None and getattr(e_gate, "_dmp_dense_gate", False):
         eg._dmp_dense_gate = True        # the kept edges of a compacted batch (collate.compact_gated_edges): ones but for the padding
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):     # e.g. dropout in training: the callers run the two loops
@@ -386,7 +389,9 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
                 v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
             sums = (vs, es)
         else:
-            v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None)
+            # (inner: the next layer of this loop, under the same gates, is the only reader of this layer's edge rows)
+            v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None,
+                                       inner=i < len(layers) - 1)
     p_v, g_v = _SplitRows.apply(v, np_)
     if lazy_e is not None:
         return p_v, lazy_e.part(0), g_v, lazy_e.part(1), v, lazy_e.whole(), sums

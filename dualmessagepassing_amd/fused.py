@@ -501,20 +501,39 @@ def code_row_mask(enc, K):
     return mask
 
 
-def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None):
+def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None, dead_rows=0):
     """prev + gate * (h1 W2^T + b2): Linear + gate + residual in one fused MFMA kernel (H = 128 or 64).
     ``W2t``: ``W2.t()`` contiguous if the caller has it already (``fold_layers`` makes it in its launch).
-    With a gate the rows of ``h1`` under a zero gate are not fetched (``gate_row_mask``): their term is multiplied by 0."""
+    With a gate the rows of ``h1`` under a zero gate are not fetched (``gate_row_mask``): their term is multiplied by 0.
+    ``dead_rows`` (``zero_rows_gate`` holds for the gate): 1 = the rows of ``prev`` under a zero gate are zeros and not fetched;
+    3 = the output rows under a zero gate (zeros) are not stored either -- every reader leaves them out."""
     lib = _lib.load()
     R, H = h1.shape
-    out = torch.empty((R, H), dtype=torch.float32, device=h1.device)
+    mask = gate_row_mask(gate)
+    if mask is None:
+        dead_rows = 0
+    out = dead_rows_buffer((R, H), h1.device) if dead_rows & 2 else torch.empty((R, H), dtype=torch.float32, device=h1.device)
     if W2t is None:
         W2t = W2.t().contiguous() # [in, out]: coalesced weight-panel reads in each of the kernel's workgroups
-    mask = gate_row_mask(gate)
     with _lib.timed("out_fwd_mfma[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
-        check(lib.dmp_out_fwd_fused_masked(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(mask), ptr(prev), H, R, H, 1,
-                                           ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
+        check(lib.dmp_out_fwd_fused_rows(ptr(h1), H, ptr(W2t), W2t.size(1), ptr(b2), ptr(gate), ptr(mask), int(dead_rows), ptr(prev), H,
+                                         R, H, 1, ptr(out), H, stream_ptr()), "dmp_out_fwd_fused")
     return out
+
+
+USE_MASKED_SUMS = _os.environ.get("DMP_MASKED_SUMS", "1") != "0"   # the scatter-adds skip the rows a 0 / 1 edge gate wiped
+
+
+def zero_rows_gate(gate):
+    """``gate`` is 0 / 1 (``_dmp_binary``) AND its maker multiplied the rep-net's input rows by it (``_dmp_zero_rows``, set by
+    ``dmpnn.joint_rep``: the union's edge rows are ``[pattern rows | gate * target rows]``): every layer's input rows under a
+    zero of the gate are zeros -- ``zn = z + gate (...)`` (dmpnn.py:215-277) keeps them so -- and sums over rows may leave
+    them out."""
+    if gate is None or not USE_MASKED_SUMS or not USE_ROW_MASKS:
+        return False
+    owner = _gate_owner(gate)
+    return bool(getattr(owner, "_dmp_binary", False) and getattr(owner, "_dmp_zero_rows", False)
+                and not getattr(owner, "_dmp_dense_gate", False))
 
 
 def binary_gate_mask(gate):
@@ -525,27 +544,32 @@ def binary_gate_mask(gate):
     return gate_row_mask(gate)
 
 
-def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None, slope=0.0, rows_colsum=False):
+def bwd_h1_mfma(d_o, W2, h1, coef=None, index=None, both_halves=True, gate=None, out=None, slope=0.0, rows_colsum=False,
+                skip_dead_stores=False):
     """-> (dG = [dPre | coef[dst] dPre] (or dPre alone) with dPre = h1>0 ? d_o W2 : slope (d_o W2), column sums of dPre); H=128.
     ``gate`` (dPre alone only): ``d_o`` is the ungated output gradient, its rows are scaled by the gate here.
     ``out`` (dPre alone only): destination [R, H], e.g. a column slice of a wider matrix.
     ``rows_colsum``: a third result, the column sums of the rows of ``d_o`` the kernel fetched -- with the row mask of a 0 / 1
-    gate (``binary_gate_mask``) that is ``sum_e gate_e d_o[e]``, the bias gradient of the Linear behind the gate."""
+    gate (``binary_gate_mask``) that is ``sum_e gate_e d_o[e]``, the bias gradient of the Linear behind the gate.
+    ``skip_dead_stores`` (dPre alone, gated): dPre's rows under a zero gate (zeros) are not stored: every reader leaves them out."""
     lib = _lib.load()
     E, H = d_o.shape
+    mask = gate_row_mask(gate)
+    skip_dead_stores = bool(skip_dead_stores and mask is not None and not both_halves and out is None)
     if both_halves:
         d_g = torch.empty((E, 2 * H), dtype=torch.float32, device=d_o.device)
         coef_e = index.edge_select(coef)[2]
     else:
-        d_g = out if out is not None else torch.empty((E, H), dtype=torch.float32, device=d_o.device)
+        d_g = out if out is not None else (dead_rows_buffer((E, H), d_o.device) if skip_dead_stores
+                                           else torch.empty((E, H), dtype=torch.float32, device=d_o.device))
         coef_e = None
     part = torch.empty((int(lib.dmp_mfma_partial_rows_h(E, H)), H), dtype=torch.float32, device=d_o.device)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_mfma[H=%d,E=%d]", (H, E), (16 if both_halves else 12) * H * E + 4 * E):
         part_rows = torch.empty_like(part) if rows_colsum else None
-        check(lib.dmp_bwd_h1_fused_colsum(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
-                                          ptr(gate), ptr(gate_row_mask(gate)), E, H, slope, ptr(d_g),
-                                          d_g.stride(0) if E > 1 else d_g.size(1), ptr(part), ptr(part_rows), stream_ptr()),
+        check(lib.dmp_bwd_h1_fused_rows(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(coef_e),
+                                        ptr(gate), ptr(mask), int(skip_dead_stores), E, H, slope, ptr(d_g),
+                                        d_g.stride(0) if E > 1 else d_g.size(1), ptr(part), ptr(part_rows), stream_ptr()),
               "dmp_bwd_h1_fused")
     if rows_colsum:
         return d_g, reduce_partials(part), reduce_partials(part_rows)
@@ -1005,7 +1029,8 @@ class _FusedDMPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
-                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None, edge_rows=True):
+                WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None, edge_rows=True,
+                inner=False):
         """``l0`` (``Layer0Codes``) with ``W0 = l0.W`` / ``WV0 = l0.WV`` as differentiable inputs: the FIRST layer of a rep-net
         whose edge rows are a label embedding, ``z = enc W0``.  Every product with ``z`` runs on its K-column factor
         (csrc/dmp_layer0.hip); ``z`` itself is only read as the residual and takes no gradient: the embedding's gradient comes
@@ -1052,7 +1077,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                 M0 = W0 @ Wes                                                                        # [T K, 2H] = W0 [A | B]
             S = None
         else:
-            S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)
+            # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
+            S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, e_gate.reshape(-1) if zero_rows_gate(e_gate) else None, True, -1.0, 1.0)
             SB = S @ Bn
         if l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK
@@ -1096,7 +1122,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 Oe = torch.addmm(eb2, H1e, eW2.t())
                 zn = gate_residual(z if residual else None, Oe, e_gate)
         if zn is None and not sums_only:
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t)
+            # a gate whose maker wiped the rep-net's input rows (zero_rows_gate): z's rows under its zeros are zeros -- not
+            # fetched; as an INNER layer of a rep-net (``inner``: the next layer of the same rep-net, under the same gate,
+            # is the only reader of zn) the output's zero rows are not stored either
+            dead = (3 if inner else 1) if (dead_gate is not None and zero_rows_gate(e_gate)) else 0
+            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
@@ -1114,7 +1144,9 @@ class _FusedDMPLayer(torch.autograd.Function):
             cnt = pool_weight_sums(epool, e_gate)                                        # sum of g per graph (and flag)
             ctx.gcnt = cnt                                                               # the backward's db2 needs them again
             cnt = cnt.view(G_ * halves, 1)
-            zs = pool_rows(z, epool).view(G_ * halves, H) if residual else None
+            # (z's rows under a zero of a gate whose maker wiped the input are zeros, and as an inner layer's output not even
+            # written: weight 0, not fetched)
+            zs = pool_rows(z, epool, e_gate if zero_rows_gate(e_gate) else None).view(G_ * halves, H) if residual else None
             if USE_SMALL_GEMM_JOBS and Q.is_contiguous() and eW2.is_contiguous():
                 es = torch.empty((G_ * halves, H), dtype=torch.float32, device=Q.device)  # Q W2^T + cnt b2 (+ sum of z): one launch
                 small_gemm_jobs([(es, [(Q, False, eW2, True), (cnt, False, eb2.view(1, H), False)], zs)])
@@ -1189,7 +1221,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 if binary_gate_mask(ctx.e_gate) is not None:
                     # a 0 / 1 gate: bwd_h1 hands out sum_e g_e dzn[e] (db2) from the rows it fetches anyway, and the weight
                     # gradient runs ungated over the masked-in rows on the bf16 pipe
-                    dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True)
+                    # (dPre's zero rows are not stored: the class-tile kernels, the scatter-add and the layer-0 products below
+                    # leave them out)
+                    dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
+                                                skip_dead_stores=USE_MASKED_SUMS and SKIP_DEAD_ROWS and masked_slots(ix, coef, ctx.e_gate) is not None
+                                                and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
                     dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:
                     dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
@@ -1204,7 +1240,10 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32, slope)
                     del dH1e
             dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
-            ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:])                       # dPre into both endpoints' rows: the backward scatter-add
+            # dPre into both endpoints' rows: the backward scatter-add (dPre's rows under a zero edge gate are zeros: not fetched)
+            sums_masked = typed and USE_MASKED_SUMS and ctx.e_gate is not None and gate_row_mask(ctx.e_gate) is not None
+            ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:], mask=gate_row_mask(ctx.e_gate) if sums_masked else None,
+                              gate=ctx.e_gate if sums_masked else None)
             l0, tables = ctx.l0, ctx.l0_tables
             vcodes = l0 is not None and l0.venc is not None
             if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor
@@ -1331,7 +1370,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dWx = WV0.t() @ Y
                 dWV0 = torch.addmm(Yn[3], Y, Wx.t()) if ctx.residual else Y @ Wx.t()
         return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None,
-                None, None, None, dW0, dWV0, None)
+                None, None, None, dW0, dWV0, None, None)
 
 
 def activation_slope(act):
@@ -1360,7 +1399,7 @@ def l0_nodes_ok(H, enc_p, enc_g, W_p, W_g):
             and enc_g.stride(1) == 1 and enc_g.is_cuda and H in MFMA_WIDTHS)
 
 
-def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None):
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None, inner=False):
     """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch).
     ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None[, edge rows wanted])``: also returns the per-graph sums of
     both outputs; with the third entry False the edge rows themselves are not formed (None in their place).
@@ -1371,4 +1410,4 @@ def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=N
     edge_rows = pools[2] if pools is not None and len(pools) > 2 else True
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
                                 n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]),
-                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV, edge_rows)
+                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV, edge_rows, bool(inner))

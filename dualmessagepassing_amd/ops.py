@@ -90,11 +90,13 @@ def graph_seg_ok(index, M, H, out=None):
             and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
 
 
-def endpoint_sums(M, index, out=None):
+def endpoint_sums(M, index, out=None, mask=None, gate=None):
     """``[sum_{e: a_e = v} M[e] | -sum_{e: b_e = v} M[e]]`` ([N, 2H]; a_e = is_reversed ? src : dst, b_e the other endpoint):
     the gradient of the gathered node projections of the layer's edge pre-activation (dmpnn.py:111-127), every sum in
     ascending eid.  One pass over the edge rows where the batch tiles by graphs (``dmp_seg_sum2_graphs``), else
-    ``dmp_seg_sum2`` over the incidence CSR (every row read twice)."""
+    ``dmp_seg_sum2`` over the incidence CSR (every row read twice).  ``mask`` (``fused.gate_row_mask``): zero bits mark rows
+    of ``M`` that are all zeros (the rows a 0 / 1 edge gate wiped): the one-pass kernel does not fetch them; ``gate``: the same
+    as [E] floats, for the segment sum over the incidence CSR (a row of weight 0 is not fetched there)."""
     H, N = M.size(1), index.num_nodes
     if graph_seg_ok(index, M, H, out):
         lib = _lib.load()
@@ -108,11 +110,18 @@ def endpoint_sums(M, index, out=None):
         E = M.size(0)
         nbytes = 4 * H * E + 8 * H * N + 8 * E + 16 * (Ba + Bb + 1)
         with _lib.timed("seg_sum2_graphs[H=%d,rows=%d,E=%d]", (H, N, E), nbytes):
-            check(lib.dmp_seg_sum2_graphs(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb, H,
-                                          1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, stream_ptr()),
-                  "dmp_seg_sum2_graphs")
+            if mask is not None:
+                check(lib.dmp_seg_sum2_graphs_masked(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb,
+                                                     ka, kb, H, 1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, ptr(mask), E,
+                                                     stream_ptr()), "dmp_seg_sum2_graphs_masked")
+            else:
+                check(lib.dmp_seg_sum2_graphs(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb,
+                                              H, 1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, stream_ptr()),
+                      "dmp_seg_sum2_graphs")
         return out
     inc_ptr, inc_ent = index.incidence()
+    if gate is not None:
+        return seg_sum_raw(M, inc_ptr, inc_ent, N, gate.reshape(-1), True, 1.0, -1.0, rows_shared=2, out=out)
     return seg_sum_raw(M, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=out, tiling=index.tiling)
 
 

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 64
+#define DMP_ABI_VERSION 65
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -433,6 +433,12 @@ int dmp_seg_sum2_graphs_max_nodes(void);
 int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b,
                         const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
                         int H, float s0, float s1, float *out, int64_t ldo, void *stream);
+/* ... where rows of M are known to be all zeros: rowmask [ceil(num_rows / 32)] (dmp_row_mask_bits: bit e & 31 of word e >> 5
+ * clear = row e is zero, e.g. the dPre rows a 0 / 1 edge gate wiped in dmp_bwd_h1_fused_masked) -- those rows are not fetched. */
+int dmp_seg_sum2_graphs_masked(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b,
+                               const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
+                               int H, float s0, float s1, float *out, int64_t ldo, const uint32_t *rowmask, int64_t num_rows,
+                               void *stream);
 
 /*
  * Row gather by an int32 index -- `edges.src[k]` / `edges.dst[k]` inside the
@@ -976,6 +982,21 @@ int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64
 int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                             const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
                             float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
+
+/* ... where the caller knows more about the masked-out rows (the rep-net of a ScalarFilter batch: the union's edge rows are
+ * [pattern rows | gate * target rows], and zn = z + gate (...) keeps a masked-out row of every layer's input at zero):
+ *   dmp_out_fwd_fused_rows, dead_rows bit 0: R's masked-out rows are zeros -- not fetched (the output rows are zeros);
+ *                           dead_rows bit 1: the masked-out rows of `out` are not STORED (every reader of `out` leaves them out:
+ *                           the next layer's masked kernels) -- `out` keeps whatever it held there;
+ *   dmp_bwd_h1_fused_rows, skip_dead_stores: the masked-out rows of dG (zeros) are not stored (its readers -- the class-tile
+ *                           kernels with masked slots, dmp_seg_sum2_graphs_masked, dmp_l0_bwd_w_masked -- leave them out).
+ * Both need the row mask. */
+int dmp_out_fwd_fused_rows(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
+                           const float *gate, const uint32_t *rowmask, int dead_rows, const float *R, int64_t ldr, int64_t E, int H,
+                           int w_in_out, float *out, int64_t ldo, void *stream);
+int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                          const float *coefE, const float *gate, const uint32_t *rowmask, int skip_dead_stores, int64_t E, int H,
+                          float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):

@@ -508,3 +508,64 @@ def test_rows_jobs_without_gates_run_ungated_over_the_masked_in_rows(R, H):
     ref_x = x.double().t() @ y.double()
     assert float((w.double() - ref_w).abs().max()) <= 2e-6 * float(((a.double().abs() * gate.double()[:, None]).t() @ b.double().abs()).max())
     assert float((wx.double() - ref_x).abs().max()) <= 2e-6 * float((x.double().abs().t() @ y.double().abs()).max())
+
+
+@pytest.mark.parametrize("H,R", [(128, 4099), (64, 2051), (128, 31)])
+def test_dead_rows_are_neither_fetched_nor_stored_where_the_caller_says_so(H, R):
+    """``dmp_out_fwd_fused_rows`` / ``dmp_bwd_h1_fused_rows``: with residual rows that ARE zero under the zero gates, bit 0
+    leaves them unfetched (NaN there changes nothing), bit 1 / ``skip_dead_stores`` leaves the output's rows under a zero
+    gate as they were (a sentinel survives) and every other row is the plain kernel's."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    g = th.Generator(device=gpu).manual_seed(3 * H + R)
+    gate = (th.rand(R, device=gpu, generator=g) < 0.4).float()
+    dead = gate == 0
+    h1 = th.randn(R, H, device=gpu, generator=g)
+    prev = th.randn(R, H, device=gpu, generator=g) * gate[:, None]
+    d_o = th.randn(R, H, device=gpu, generator=g)
+    W2 = th.randn(H, H, device=gpu, generator=g) / H ** 0.5
+    b2 = th.randn(H, device=gpu, generator=g)
+    ref_out = fused.out_fwd_mfma(h1, W2, b2, gate, prev)
+    ref_dg, ref_db = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18)
+    assert float(ref_out[dead].abs().max()) == 0.0 and float(ref_dg[dead].abs().max()) == 0.0
+    prev_p = prev.clone()
+    prev_p[dead] = float("nan")
+    out1 = fused.out_fwd_mfma(h1, W2, b2, gate, prev_p, dead_rows=1)
+    assert th.equal(out1, ref_out)
+    saved = fused.dead_rows_buffer
+    fused.dead_rows_buffer = lambda shape, device: th.full(shape, 7.5, dtype=th.float32, device=device)
+    try:
+        out3 = fused.out_fwd_mfma(h1, W2, b2, gate, prev_p, dead_rows=3)
+        dg, db = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18, skip_dead_stores=True)
+    finally:
+        fused.dead_rows_buffer = saved
+    assert th.equal(out3[~dead], ref_out[~dead]) and bool((out3[dead] == 7.5).all())
+    assert th.equal(dg[~dead], ref_dg[~dead]) and bool((dg[dead] == 7.5).all()) and th.equal(db, ref_db)
+
+
+@pytest.mark.parametrize("H", [128, 64])
+def test_masked_endpoint_sums_equal_the_plain_ones_without_reading_zero_rows(H):
+    """``dmp_seg_sum2_graphs_masked``: rows under a clear mask bit are not fetched (NaN there), the sums are the bits of the
+    kernel that reads the zero rows; also over the incidence CSR (weights) when the batch does not tile by graphs."""
+    from dualmessagepassing_amd import ops, fused
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(H)
+    graph = _random_batch(rng, 37, 20, 90, gpu)[0]
+    ix = graph.index()
+    E = ix.num_edges
+    assert ops.graph_seg_ok(ix, th.empty(E, H, device=gpu), H)          # the one-pass kernel is what runs first
+    g = th.Generator(device=gpu).manual_seed(H)
+    gate = (th.rand(E, device=gpu, generator=g) < 0.45).float()
+    M = th.randn(E, H, device=gpu, generator=g) * gate[:, None]
+    ref = ops.endpoint_sums(M, ix)
+    Mp = M.clone()
+    Mp[gate == 0] = float("nan")
+    got = ops.endpoint_sums(Mp, ix, mask=fused.gate_row_mask(gate), gate=gate)
+    assert th.equal(got, ref)
+    saved = ops.USE_GRAPH_SEG_SUM
+    ops.USE_GRAPH_SEG_SUM = False
+    try:
+        got2 = ops.endpoint_sums(Mp, ix, mask=fused.gate_row_mask(gate), gate=gate)
+    finally:
+        ops.USE_GRAPH_SEG_SUM = saved
+    assert th.equal(got2, ref)
