@@ -321,6 +321,12 @@ def build_step(cfg, shard, device, world=1):
         step.gate_capacity = cap
         return {"capacity": cap, "edges": shard["g"]["E"]}
 
+    def gate_kept_edges():
+        """(target edge rows this rank's filter gate keeps, target edge rows) -- one host sync, outside every timed region."""
+        pattern, graph = batch_of(shard)
+        return model.gate_kept_edges(pattern, graph)
+
+    step.gate_kept_edges = gate_kept_edges
     step.set_gate_compact = gate_compact
     gate_compact(cfg.get("gate_compact"))
     step.time_allreduce = False
@@ -334,8 +340,12 @@ def build_step(cfg, shard, device, world=1):
 
 
 PROFILE_ROUND = "r04"
-SEG_IN = "seg_sum_vec<32, true, false, true, 0, 256>"       # flag-split segment sum over the CSR by destination (forward)
-SEG_INC = "seg_acc_graphs_k<128>"                            # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
+# the two scatter-add launches as rocprofv3 names them; first the forms that leave out the rows a 0 / 1 edge gate wiped (what
+# the step runs under a ScalarFilter gate), then the forms that read every row
+SEG_IN = ("seg_sum_vec<32, true, true, true, 0, 256>",      # flag-split segment sum over the CSR by destination (forward), gate-weighted
+          "seg_sum_vec<32, true, false, true, 0, 256>")
+SEG_INC = ("seg_acc_graphs_k<128, true>",                    # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
+           "seg_acc_graphs_k<128, false>", "seg_acc_graphs_k<128>")
 
 
 def committed_profile(n_rows, n_edges, H):
@@ -361,19 +371,25 @@ def committed_profile(n_rows, n_edges, H):
     try:
         import csv
         with open(base + "_bench_kernel_stats.csv") as f:
-            for r in csv.DictReader(f):
-                for tag, name in (("in", SEG_IN), ("inc", SEG_INC)):
-                    if name in r["Name"]:
-                        out[tag]["avg_us_rocprof"] = round(float(r["AverageNs"]) / 1e3, 2)
+            rows = list(csv.DictReader(f))
+        for tag, names in (("in", SEG_IN), ("inc", SEG_INC)):
+            for name in names:                                  # the first form the profile holds
+                hit = [r for r in rows if name in r["Name"]]
+                if hit:
+                    out[tag]["avg_us_rocprof"] = round(float(hit[0]["AverageNs"]) / 1e3, 2)
+                    out[tag]["kernel_rocprof"] = name
+                    break
     except (OSError, ValueError, KeyError):
         pass
     try:
         with open(base + "_pmc_h128.json") as f:
             k = json.load(f)["kernels"]
-        for tag, name in (("in", SEG_IN), ("inc", SEG_INC)):
-            for key, v in k.items():
-                if name in key:
-                    out[tag]["traffic"] = int(v["hbm_bytes_per_launch"])
+        for tag, names in (("in", SEG_IN), ("inc", SEG_INC)):
+            for name in names:
+                hit = [v for key, v in k.items() if name in key]
+                if hit:
+                    out[tag]["traffic"] = int(hit[0]["hbm_bytes_per_launch"])
+                    break
     except (OSError, ValueError, KeyError):
         pass
     return out
@@ -403,10 +419,12 @@ def gate_summary(g, cfg, step, H):
     return out
 
 
-def seg_roofline(k, what, own_bytes, survey_bytes, prof):
+def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, row_bytes=0):
     """``roofline`` object of one scatter-add launch kind: achieved = the kernel's own algorithmic bytes / its HIP-event
     time inside the timed steps; beside it the same with SURVEY §8(d)'s byte count, and both over the committed rocprof
-    duration."""
+    duration.  ``skipped_rows``: rows of the summed array that are zeros under the batch's 0 / 1 edge gate and that the
+    launch does not fetch (the algorithmic byte counts above still count them: they are what the sum is defined over) --
+    reported with the bytes the launch does fetch and their rate."""
     us = k["avg_us"]
     r = {"bound": "hbm", "kernel": what, "achieved": round(own_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": prof["traffic"],
@@ -418,6 +436,16 @@ def seg_roofline(k, what, own_bytes, survey_bytes, prof):
         r["frac_survey_bytes_rocprof"] = round(survey_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
     if prof["traffic"]:
         r["traffic_over_algorithmic"] = round(prof["traffic"] / own_bytes, 4)
+    if skipped_rows:
+        fetched = own_bytes - skipped_rows * row_bytes
+        r["rows_not_fetched"] = int(skipped_rows)
+        r["bytes_fetched"] = int(fetched)
+        r["frac_fetched_bytes"] = round(fetched / us / 1e3 / HBM_PEAK_GBPS, 4)
+        r["note"] = ("%d of the summed rows are zeros under this batch's 0/1 edge gate (the ScalarFilter gate multiplies the rep-net's "
+                     "input rows, basemodel.py:1515-1531) and are not fetched: `achieved`/`frac` price the sum over ALL rows, as "
+                     "SURVEY 8(d) counts it; `bytes_fetched`/`frac_fetched_bytes` are what the launch moves" % skipped_rows)
+        if prof["traffic"]:
+            r["traffic_over_fetched"] = round(prof["traffic"] / fetched, 4)
     return r
 
 
@@ -1001,15 +1029,23 @@ def main():
             key_inc = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)   # ... or the segment sum over the incidence CSR
         prof = committed_profile(uN, uE, H)
         roof = roof_bwd = None
+        # rows the two scatter-adds leave out: the target edge rows under a zero of the filter's 0 / 1 edge gate (not in the
+        # gate-compact mode: its batch holds the kept rows only)
+        skipped = 0
+        from dualmessagepassing_amd import fused as _fused
+        if _fused.USE_MASKED_SUMS and _fused.USE_ROW_MASKS and not step.gate_capacity and step.micro_batches == 1:
+            kept_e, all_e = step.gate_kept_edges()
+            skipped = (all_e - kept_e) if kept_e is not None else 0
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
             roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
                                 "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key]["bytes"],
-                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"])
+                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"], skipped, 4 * H)
         if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
             roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if "graphs" in key_inc
                                                     else "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints") +
                                     "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
-                                    4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"])
+                                    4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"],
+                                    skipped if "graphs" in key_inc else 0, 4 * H)
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,

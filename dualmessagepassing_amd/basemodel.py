@@ -722,14 +722,19 @@ class GraphAdjModelV2(BaseModel):
     def calibrate_gate_capacity(self, pattern, graph, margin=1.15, multiple=1024):
         """``set_gate_capacity`` from one batch: the edges its gate keeps (one host sync), times ``margin``, rounded up to a
         multiple of ``multiple``; left off where that would not shrink the batch by a tenth.  Returns the capacity or None."""
+        kept, E = self.gate_kept_edges(pattern, graph)
+        if kept is None:
+            return self.set_gate_capacity(None).gate_capacity
+        cap = -(-int(kept * margin + as_batched(graph).batch_size) // multiple) * multiple
+        return self.set_gate_capacity(cap if cap <= 0.9 * E else None).gate_capacity
+
+    def gate_kept_edges(self, pattern, graph):
+        """``(target edges the filter's edge gate keeps, target edges)`` of one batch (one host sync); ``(None, E)`` without an edge gate."""
         pattern, graph = as_batched(pattern), as_batched(graph)
         pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"), "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
         el_gate = self.get_filter_gate(pattern, graph, pads)[1]
-        if el_gate is None:
-            return self.set_gate_capacity(None).gate_capacity
-        kept, E = int((el_gate != 0).sum().item()), graph.number_of_edges()
-        cap = -(-int(kept * margin + graph.batch_size) // multiple) * multiple
-        return self.set_gate_capacity(cap if cap <= 0.9 * E else None).gate_capacity
+        E = graph.number_of_edges()
+        return (None if el_gate is None else int((el_gate != 0).sum().item())), E
 
     def _compact_gated(self, pattern, graph, el_gate):
         """``collate.CompactedEdges`` for this batch, or None (capacity off, no gate, options that read per-edge extras)."""

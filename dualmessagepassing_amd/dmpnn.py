@@ -193,7 +193,7 @@ class DMPLayer(nn.Module):
 
     @on_input_device
     def forward_fused(self, graph, node_feat, edge_feat, v_gate=None, e_gate=None, residual=True, folded=None, pools=None, l0=None,
-                      inner=False):
+                      inner=0):
         """``(node_feat + v_gate * node_out, edge_feat + e_gate * edge_out)`` (without the
         ``node_feat +`` / ``edge_feat +`` terms if ``residual`` is False) -- one layer of the
         loops in ``get_pattern_rep`` / ``get_graph_rep`` (dmpnn.py:229-241,262-275)."""
@@ -382,16 +382,17 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
             # from two pooled passes.  A reader gets the rows, differentiable, from the layer's ordinary form.
             if pools[1] is not None and getattr(model, "lazy_edge_rep", True) and th.is_grad_enabled():
                 v_in, e_in = v, e
-                v, _, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, tuple(pools[:2]) + (False,))
+                v, _, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, tuple(pools[:2]) + (False,),
+                                                   inner=2 if i > 0 else 0)
                 lazy_e = _LazyEdgeRows(lambda: layer.forward_fused(union, v_in, e_in, vg, eg, model.rep_residual, fw)[1],
                                        ep_, (e_in.size(0), layer.hidden_dim), e_in.dtype, e_in.device)
             else:
-                v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools)
+                v, e, vs, es = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, pools, inner=2 if i > 0 else 0)
             sums = (vs, es)
         else:
             # (inner: the next layer of this loop, under the same gates, is the only reader of this layer's edge rows)
             v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None,
-                                       inner=i < len(layers) - 1)
+                                       inner=(1 if i < len(layers) - 1 else 0) | (2 if i > 0 else 0))
     p_v, g_v = _SplitRows.apply(v, np_)
     if lazy_e is not None:
         return p_v, lazy_e.part(0), g_v, lazy_e.part(1), v, lazy_e.whole(), sums

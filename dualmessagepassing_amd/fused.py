@@ -405,25 +405,34 @@ def masked_slots(index, coef, gate):
     return out
 
 
-def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None):
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
     ``base_map`` (int32 [E]): ``base`` is a small table and edge e adds its row ``base_map[e]`` (< 0: nothing).
     ``gate``: the layer's edge gate when ``d_pre`` is the gated layer's (its rows under a zero gate ARE zero): those rows are
-    not fetched (``masked_slots``)."""
+    not fetched (``masked_slots``).  ``dead_rows`` (with ``gate``; ``zero_rows_gate`` holds): the input gradient of an edge
+    under a zero gate is never used as a number (whoever made the rows multiplied them by the gate) -- ``"leave"``: those edges
+    are padding slots, nothing is fetched, computed or stored for them (every reader of the result leaves them out);
+    ``"zero"``: likewise, their output rows are zeros."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
-    out = torch.empty((E, H), dtype=torch.float32, device=d_pre.device)
+    ms = masked_slots(index, coef, gate)
+    if ms is None:
+        dead_rows = None
+    out = (torch.zeros((E, H), dtype=torch.float32, device=d_pre.device) if dead_rows == "zero" else
+           dead_rows_buffer((E, H), d_pre.device) if dead_rows == "leave" else torch.empty((E, H), dtype=torch.float32, device=d_pre.device))
     # [A'^T | B'^T]: the kernel's per-class panel reads become coalesced (instead of a strided 128-instruction
     # panel read per class segment in each of its 768 workgroups)
     if WesT is None:
         WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
     d_s = d_s.contiguous()
     slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+    if dead_rows is not None:
+        slot_edge = ms
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_typed_arow(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
                                        ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
-                                       ptr(slot_edge), ptr(masked_slots(index, coef, gate)), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1,
+                                       ptr(slot_edge), ptr(ms), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1,
                                        ptr(base_map), base.size(0) if base_map is not None else 0, ptr(out), H, stream_ptr()),
               "dmp_bwd_z_typed")
     return out
@@ -1030,8 +1039,10 @@ class _FusedDMPLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, index, coef, residual, x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be, nW2, nb2, eW2, eb2,
                 WesT=None, nW2t=None, eW2t=None, slope=0.0, vpool=None, epool=None, l0=None, W0=None, WV0=None, edge_rows=True,
-                inner=False):
-        """``l0`` (``Layer0Codes``) with ``W0 = l0.W`` / ``WV0 = l0.WV`` as differentiable inputs: the FIRST layer of a rep-net
+                inner=0):
+        """``inner``: this layer's place among the layers of a rep-net that share its gates -- bit 0: another layer follows (the
+        only reader of the edge rows returned here), bit 1: another layer precedes (the only reader of the edge rows' gradient).
+        ``l0`` (``Layer0Codes``) with ``W0 = l0.W`` / ``WV0 = l0.WV`` as differentiable inputs: the FIRST layer of a rep-net
         whose edge rows are a label embedding, ``z = enc W0``.  Every product with ``z`` runs on its K-column factor
         (csrc/dmp_layer0.hip); ``z`` itself is only read as the residual and takes no gradient: the embedding's gradient comes
         back as ``dW0``.  With ``l0.venc`` the same for the node rows ``x = venc WV0`` (products with ``x`` -> ``dWV0``).
@@ -1125,11 +1136,12 @@ class _FusedDMPLayer(torch.autograd.Function):
             # a gate whose maker wiped the rep-net's input rows (zero_rows_gate): z's rows under its zeros are zeros -- not
             # fetched; as an INNER layer of a rep-net (``inner``: the next layer of the same rep-net, under the same gate,
             # is the only reader of zn) the output's zero rows are not stored either
-            dead = (3 if inner else 1) if (dead_gate is not None and zero_rows_gate(e_gate)) else 0
+            dead = (3 if (inner & 1) else 1) if (dead_gate is not None and zero_rows_gate(e_gate)) else 0
             zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
+        ctx.inner = int(inner)
         ctx.l0, ctx.l0_S0, ctx.l0_tables = l0, S0, tables
         ctx.l0_W = None if l0 is None else (W0.detach(), None if WV0 is None else WV0.detach())
         ctx.save_for_backward(x, z if l0 is None else None, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
@@ -1329,11 +1341,16 @@ class _FusedDMPLayer(torch.autograd.Function):
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
             dz = None
             if l0 is None and ctx.needs_input_grad[4]:
+                # the input gradient of an edge under a zero of a gate that wiped the rep-net's input rows is multiplied by that
+                # zero further down: not computed.  After the first layer (``inner`` bit 1) its reader is the layer before,
+                # which leaves those rows out; the first layer hands zeros to whoever made the rows.
+                dead_dz = (("leave" if (ctx.inner & 2) else "zero") if (typed and SKIP_DEAD_ROWS and zero_rows_gate(ctx.e_gate)) else None)
                 if lazy is not None:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
-                                     base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate)
+                                     base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate, dead_rows=dead_dz)
                 elif typed:
-                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT, gate=ctx.e_gate)
+                    dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT, gate=ctx.e_gate,
+                                     dead_rows=dead_dz)
                 elif mfma:
                     dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:
@@ -1399,7 +1416,7 @@ def l0_nodes_ok(H, enc_p, enc_g, W_p, W_g):
             and enc_g.stride(1) == 1 and enc_g.is_cuda and H in MFMA_WIDTHS)
 
 
-def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None, inner=False):
+def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=None, pools=None, l0=None, inner=0):
     """``folded``: this layer's entry of ``fold_layers`` (rep-nets fold all their layers in one launch).
     ``pools`` = ``(node PoolIndex or None, edge PoolIndex or None[, edge rows wanted])``: also returns the per-graph sums of
     both outputs; with the third entry False the edge rows themselves are not formed (None in their place).
@@ -1410,4 +1427,4 @@ def fused_dmp_layer(index, coef, residual, x, z, v_gate, e_gate, layer, folded=N
     edge_rows = pools[2] if pools is not None and len(pools) > 2 else True
     return _FusedDMPLayer.apply(index, coef, bool(residual), x, z, v_gate, e_gate, Bn, bn, Wx, Wes, be,
                                 n2.weight, n2.bias, e2.weight, e2.bias, WesT, nW2t, eW2t, activation_slope(layer.nmlp[1]),
-                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV, edge_rows, bool(inner))
+                                vpool, epool, l0, None if l0 is None else l0.W, None if l0 is None else l0.WV, edge_rows, int(inner))

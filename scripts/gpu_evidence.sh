@@ -34,7 +34,7 @@ f = load("$O/f/f_counter_collection.csv", "FETCH_SIZE"); w = load("$O/w/w_counte
 t = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open("$O/k/k_kernel_stats.csv"))}
 out = {}
 for k in f:
-    if any(x in k for x in ("mfma_typed", "mfma_pp", "atb_k", "atb_jobs", "pool_relu_bwd_k", "seg_sum_vec<32, true, false, true", "seg_acc_graphs_k", "l0_edge_fwd_k", "l0_bwd_w_k")):
+    if any(x in k for x in ("mfma_typed", "mfma_pp", "atb_k", "atb_jobs", "pool_relu_bwd_k", "seg_sum_vec<32, true, true, true", "seg_sum_vec<32, true, false, true", "seg_acc_graphs_k", "l0_edge_fwd_k", "l0_bwd_w_k")):
         fv = [v for v in f[k] if v > 0.5 * max(f[k])]; wv = [v for v in w.get(k, [0]) if v > 0.5 * max(w.get(k, [1]))]
         hbm = (2 * sum(fv) / len(fv) + (sum(wv) / len(wv) if wv else 0)) * 1024
         short = k.replace("void dmp::(anonymous namespace)::", "").split("(")[0]
