@@ -267,7 +267,7 @@ def build_step(cfg, shard, device, world=1):
         # the parameters: it is enqueued BEFORE the previous step's gradient sum is waited for, so with more than one
         # rank the all-reduce (on RCCL's stream) overlaps it instead of idling the compute stream.
         if world > 1 and not model.gate_capacity:
-            prepare_joint(pattern, graph, cfg["hid"])
+            prepare_joint(pattern, graph, cfg["hid"], class_tiles=not live_tiles_apply)
         finish()
         sync.detach_grads()
         if all_outputs:
@@ -327,6 +327,11 @@ def build_step(cfg, shard, device, world=1):
         return model.gate_kept_edges(pattern, graph)
 
     step.gate_kept_edges = gate_kept_edges
+    # (a 0 / 1 edge gate: the class-typed kernels walk tiles over the kept edges, built in the forward pass)
+    from dualmessagepassing_amd import fused as _fused
+    filt = getattr(model, "filter_net", None)
+    live_tiles_apply = bool(_fused.USE_LIVE_TILES and _fused.USE_ROW_MASKS and filt is not None and len(filt) > 0
+                            and type(filt["el"]).__name__ == "ScalarFilter")
     step.set_gate_compact = gate_compact
     gate_compact(cfg.get("gate_compact"))
     step.time_allreduce = False

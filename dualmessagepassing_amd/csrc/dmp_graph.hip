@@ -978,7 +978,22 @@ __global__ void dual_match_k(const int64_t *sub, const int64_t *sample_ptr, cons
 // ---------------------------------------------------------------------------------------------
 constexpr int kCtLdsBins = 4096;
 
+// in-edges of node v that count: all of its in-CSR row, or (row_cnt: the gated build) those a 0 / 1 edge gate keeps
+__device__ __forceinline__ int ct_rows(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ row_cnt, int64_t v) {
+  return row_cnt ? row_cnt[v] : in_ptr[v + 1] - in_ptr[v];
+}
+
+__global__ __launch_bounds__(kBlock) void ct_live_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                    const float *__restrict__ gate, int64_t N, int32_t *__restrict__ row_cnt) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v >= N) return;
+  int c = 0;
+  for (int q = in_ptr[v], hi = in_ptr[v + 1]; q < hi; ++q) c += gate[in_ent[q] >> 1] != 0.f;
+  row_cnt[v] = c;
+}
+
 __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                    const int32_t *__restrict__ row_cnt,
                                                     int64_t N, int C, unsigned long long *cnt, int32_t *status) {
   __shared__ unsigned int h[kCtLdsBins];
   __shared__ int top;                                          // largest class in use in this block
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ 
   __syncthreads();
   const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (v < N) {
-    const unsigned int d = (unsigned int)(in_ptr[v + 1] - in_ptr[v]);
+    const unsigned int d = (unsigned int)ct_rows(in_ptr, row_cnt, v);
     int64_t k = deg[v];
     if (k < 0) k = 0;
     if (k >= C - 1) {
@@ -1082,6 +1097,7 @@ __device__ __forceinline__ void ct_class_seg(int w, int C, int64_t N, int &c, in
 }
 
 __global__ __launch_bounds__(kBlock) void ct_seg_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                   const int32_t *__restrict__ row_cnt,
                                                    int64_t N, int C, const unsigned long long *__restrict__ cnt,
                                                    int32_t *segsum) {
   const int w = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6), lane = threadIdx.x & 63;
@@ -1093,17 +1109,16 @@ __global__ __launch_bounds__(kBlock) void ct_seg_k(const int64_t *__restrict__ d
   if (cnt[c] == 0) return;
   int sum = 0;
   for (int64_t v0 = lo + lane; v0 < hi; v0 += 256) {           // 4 independent chunks of 64 nodes in flight
-    int k[4], a[4], b[4];
+    int k[4], d[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t v = v0 + 64 * j;
       const bool ok = v < hi;
       k[j] = ok ? ct_key(deg, v, C) : -1;
-      a[j] = ok ? in_ptr[v] : 0;
-      b[j] = ok ? in_ptr[v + 1] : 0;
+      d[j] = ok ? ct_rows(in_ptr, row_cnt, v) : 0;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sum += k[j] == c ? b[j] - a[j] : 0;
+    for (int j = 0; j < 4; ++j) sum += k[j] == c ? d[j] : 0;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);   // integer: order-free
@@ -1112,11 +1127,12 @@ __global__ __launch_bounds__(kBlock) void ct_seg_k(const int64_t *__restrict__ d
 
 constexpr int kCtSlowWaves = 256;   // workers that share the rare classes >= kCtFast among themselves
 
-__device__ __forceinline__ void ct_walk(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr, int C, int c,
+__device__ __forceinline__ void ct_walk(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                        const int32_t *__restrict__ row_cnt, int C, int c,
                                         int64_t lo, int64_t hi, int running, int lane, int32_t *node_base) {
   auto fetch = [&](int64_t v, int &k, int &d) {
     k = -1; d = 0;
-    if (v < hi) { k = ct_key(deg, v, C); d = in_ptr[v + 1] - in_ptr[v]; }
+    if (v < hi) { k = ct_key(deg, v, C); d = ct_rows(in_ptr, row_cnt, v); }
   };
   int kn, dn;
   fetch(lo + lane, kn, dn);
@@ -1143,6 +1159,7 @@ __device__ __forceinline__ void ct_write_scale(int c, int C, const int32_t *stat
 }
 
 __global__ __launch_bounds__(kBlock) void ct_base_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
+                                                    const int32_t *__restrict__ row_cnt,
                                                     int64_t N, int C, const unsigned long long *__restrict__ cnt,
                                                     const int32_t *__restrict__ tile_off, const int32_t *__restrict__ status,
                                                     const int32_t *__restrict__ segsum, int32_t *node_base, float *tile_scale) {
@@ -1157,7 +1174,7 @@ __global__ __launch_bounds__(kBlock) void ct_base_k(const int64_t *__restrict__ 
     int running = tile_off[c] * 32;
     for (int j = 0; j < s; ++j) running += segsum[w - s + j];
     if (s == 0) ct_write_scale(c, C, status, tile_off[c], tile_off[c + 1], lane, tile_scale);
-    ct_walk(deg, in_ptr, C, c, lo, hi, running, lane, node_base);
+    ct_walk(deg, in_ptr, row_cnt, C, c, lo, hi, running, lane, node_base);
   } else if (w < fast * kCtSegs + kCtSlowWaves) {
     // this worker's contiguous share of the rare classes; 64 of them are tested at a time (one per lane)
     const int per = (C - fast + kCtSlowWaves - 1) / kCtSlowWaves;
@@ -1169,20 +1186,24 @@ __global__ __launch_bounds__(kBlock) void ct_base_k(const int64_t *__restrict__ 
         const int c = cb + __builtin_ctzll(live);
         live &= live - 1;
         ct_write_scale(c, C, status, tile_off[c], tile_off[c + 1], lane, tile_scale);
-        ct_walk(deg, in_ptr, C, c, 0, N, tile_off[c] * 32, lane, node_base);
+        ct_walk(deg, in_ptr, row_cnt, C, c, 0, N, tile_off[c] * 32, lane, node_base);
       }
     }
   }
 }
 
 __global__ __launch_bounds__(kBlock) void ct_fill_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
-                                                    const int32_t *__restrict__ node_base, int64_t N, int32_t *slot_edge) {
+                                                    const int32_t *__restrict__ node_base, int64_t N, int32_t *slot_edge,
+                                                    const float *__restrict__ gate, const int32_t *__restrict__ row_cnt) {
   const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (v >= N) return;
   const int lo = in_ptr[v], hi = in_ptr[v + 1];
-  if (hi == lo) return;
+  if (hi == lo || (row_cnt && row_cnt[v] == 0)) return;        // (node_base is only written for nodes with rows that count)
   int s = node_base[v];
-  for (int q = lo; q < hi; ++q) slot_edge[s++] = in_ent[q] >> 1;
+  for (int q = lo; q < hi; ++q) {
+    const int e = in_ent[q] >> 1;
+    if (!gate || gate[e] != 0.f) slot_edge[s++] = e;
+  }
 }
 
 // ---- out = [a | b (+ add)] for several array pairs: the structure arrays of the union of two batches
@@ -1760,9 +1781,28 @@ int dmp_scalar_filter_gates(const dmp_filter_job *jobs, int num_jobs, int64_t B,
   return DMP_OK;
 }
 
+static int class_tiles_impl(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int32_t *row_cnt,
+                            int64_t N, int64_t E, int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge,
+                            float *tile_scale, int32_t *num_tiles, void *stream);
+
 int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t N, int64_t E,
                     int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge, float *tile_scale,
                     int32_t *num_tiles, void *stream) {
+  return class_tiles_impl(deg, in_ptr, in_ent, nullptr, nullptr, N, E, num_classes, tiles_bound, ws, slot_edge, tile_scale, num_tiles,
+                          stream);
+}
+
+int dmp_class_tiles_gated(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int32_t *row_cnt,
+                          int64_t N, int64_t E, int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge,
+                          float *tile_scale, int32_t *num_tiles, void *stream) {
+  if (!gate || (N > 0 && !row_cnt)) return DMP_ERR_BAD_ARG;
+  return class_tiles_impl(deg, in_ptr, in_ent, gate, row_cnt, N, E, num_classes, tiles_bound, ws, slot_edge, tile_scale, num_tiles,
+                          stream);
+}
+
+static int class_tiles_impl(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int32_t *row_cnt,
+                            int64_t N, int64_t E, int num_classes, int64_t tiles_bound, int32_t *ws, int32_t *slot_edge,
+                            float *tile_scale, int32_t *num_tiles, void *stream) {
   if (N < 0 || E < 0 || num_classes < 2 || num_classes > 65536 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
   if (!ws || !slot_edge || !tile_scale || !num_tiles) return DMP_ERR_BAD_ARG;
   if (N > 0 && (!deg || !in_ptr)) return DMP_ERR_BAD_ARG;
@@ -1777,15 +1817,16 @@ int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in
   hipStream_t st = (hipStream_t)stream;
   DMP_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int32_t) * (size_t)(2 * (int64_t)num_classes + 2), st));    // counters + status
   DMP_HIP_TRY(hipMemsetAsync(slot_edge, 0xFF, sizeof(int32_t) * (size_t)tiles_bound * 32, st));      // -1 = padding
-  if (N > 0) ct_hist_k<<<nblk(N), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, status);
+  if (N > 0 && gate) ct_live_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, N, row_cnt);
+  if (N > 0) ct_hist_k<<<nblk(N), kBlock, 0, st>>>(deg, in_ptr, row_cnt, N, num_classes, cnt, status);
   ct_scan_k<<<1, 1024, 0, st>>>(cnt, num_classes, status, tile_off, num_tiles);
   if (N > 0) {
     const int fast = num_classes < kCtFast ? num_classes : kCtFast;
     const int64_t waves = (int64_t)fast * kCtSegs + kCtSlowWaves;
-    ct_seg_k<<<nblk((int64_t)fast * kCtSegs * 64), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, segsum);
-    ct_base_k<<<nblk(waves * 64), kBlock, 0, st>>>(deg, in_ptr, N, num_classes, cnt, tile_off, status, segsum, node_base,
+    ct_seg_k<<<nblk((int64_t)fast * kCtSegs * 64), kBlock, 0, st>>>(deg, in_ptr, row_cnt, N, num_classes, cnt, segsum);
+    ct_base_k<<<nblk(waves * 64), kBlock, 0, st>>>(deg, in_ptr, row_cnt, N, num_classes, cnt, tile_off, status, segsum, node_base,
                                                   tile_scale);
-    ct_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, node_base, N, slot_edge);
+    ct_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, node_base, N, slot_edge, gate, row_cnt);
   }
   return check_launch();
 }

@@ -299,11 +299,13 @@ def _union_of(pattern, graph):
     return u[1]
 
 
-def prepare_joint(pattern, graph, hidden_dim=128, backward=True):
+def prepare_joint(pattern, graph, hidden_dim=128, backward=True, class_tiles=True):
     """Everything of the joint pattern + target pass that depends on the batch's STRUCTURE only -- the union graph, its
     CSR index, degrees, coefficient vector, per-edge selectors, degree-class tiles and (``backward``) the incidence CSR --
     built ahead of the forward pass.  A data-parallel step calls this between launching the gradient all-reduce of the
-    previous batch and waiting for it: none of it reads a parameter, so it overlaps the collective."""
+    previous batch and waiting for it: none of it reads a parameter, so it overlaps the collective.
+    ``class_tiles=False``: the degree-class tiles are left to the forward pass (under a 0 / 1 edge gate it builds them over
+    the kept edges, ``fused.live_tiles``: the list over all edges would not be used)."""
     from . import fused
     pattern, graph = as_batched(pattern), as_batched(graph)
     if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
@@ -315,7 +317,7 @@ def prepare_joint(pattern, graph, hidden_dim=128, backward=True):
     coef = ix.degree_coef(union.ndata[OUTDEGREE])
     if fused.mfma_ok(ix, hidden_dim):
         ix.edge_select(coef)
-    if fused.typed_ok(ix, hidden_dim):
+    if class_tiles and fused.typed_ok(ix, hidden_dim):
         ix.class_tiles(coef)
     if backward and not (ops.USE_GRAPH_SEG_SUM and ix.node_tiling is not None and hidden_dim in (64, 128)):
         ix.incidence()                     # the one-pass endpoint sums (ops.endpoint_sums) need no incidence CSR

@@ -336,10 +336,14 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None)
     out = dead_rows_buffer((E, H), z.device)
     Wes = Wes.contiguous()
     sel_a, sel_b, _ = index.edge_select(coef)
-    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    ms = masked_slots(index, coef, dead_gate) if dead_gate is not None else None
-    if ms is not None:
-        slot_edge = ms
+    lt = live_tiles(index, coef, dead_gate) if dead_gate is not None else None
+    if lt is not None:
+        slot_edge, tile_scale, num_tiles, bound = lt
+    else:
+        slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+        ms = masked_slots(index, coef, dead_gate) if dead_gate is not None else None
+        if ms is not None:
+            slot_edge = ms
     with _lib.timed("edge_fwd_typed[H=%d,E=%d]", (H, E), 4 * H * (2 * E + 2 * index.num_nodes) + 12 * E):
         check(lib.dmp_edge_fwd_typed(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias),
                                      ptr(sel_a), ptr(sel_b), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound,
@@ -405,6 +409,30 @@ def masked_slots(index, coef, gate):
     return out
 
 
+USE_LIVE_TILES = _os.environ.get("DMP_LIVE_TILES", "1") == "1"
+
+
+def live_tiles(index, coef, gate):
+    """The class-tile list of ``index`` over the edges a 0 / 1 ``gate`` keeps (``GraphIndex.class_tiles_gated``: an edge under
+    a zero gate has no slot at all, so the kernels walk 46 % of the tiles of a ScalarFilter batch instead of all of them with
+    padding slots inside), or None -- a gate not flagged 0 / 1, masks off, a coefficient of unknown origin.  For the launches
+    that LEAVE OUT such edges (``masked_slots`` turns them into padding where every edge needs its slot).  Memoised on the gate."""
+    if gate is None or not USE_ROW_MASKS or not USE_LIVE_TILES:
+        return None
+    owner = _gate_owner(gate)
+    if getattr(owner, "_dmp_dense_gate", False) or not getattr(owner, "_dmp_binary", False):
+        return None
+    hit = getattr(owner, "_dmp_live_tiles", None)
+    if hit is not None and hit[0] == owner._version and hit[1] is index and hit[2] is coef:
+        return hit[3]
+    res = index.class_tiles_gated(coef, gate.reshape(-1))
+    try:
+        owner._dmp_live_tiles = (owner._version, index, coef, res)
+    except Exception:
+        pass
+    return res
+
+
 def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
@@ -416,7 +444,8 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     ``"zero"``: likewise, their output rows are zeros."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
-    ms = masked_slots(index, coef, gate)
+    lt = live_tiles(index, coef, gate) if dead_rows is not None else None
+    ms = lt[0] if lt is not None else masked_slots(index, coef, gate)
     if ms is None:
         dead_rows = None
     out = (torch.zeros((E, H), dtype=torch.float32, device=d_pre.device) if dead_rows == "zero" else
@@ -426,9 +455,12 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     if WesT is None:
         WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
     d_s = d_s.contiguous()
-    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    if dead_rows is not None:
-        slot_edge = ms
+    if lt is not None:
+        slot_edge, tile_scale, num_tiles, bound = lt
+    else:
+        slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+        if dead_rows is not None:
+            slot_edge = ms
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_typed_arow(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
                                        ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
@@ -445,10 +477,14 @@ def atb_typed(z, d_pre, coef, index, gate=None):
     a zero gate): those edges are skipped, neither of their rows is fetched (``masked_slots``)."""
     lib = _lib.load()
     E, H = z.shape
-    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    ms = masked_slots(index, coef, gate)
-    if ms is not None:
-        slot_edge = ms
+    lt = live_tiles(index, coef, gate)
+    if lt is not None:
+        slot_edge, tile_scale, num_tiles, bound = lt
+    else:
+        slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
+        ms = masked_slots(index, coef, gate)
+        if ms is not None:
+            slot_edge = ms
     G = int(lib.dmp_atb_typed_blocks_h(bound, H))
     part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
@@ -1236,7 +1272,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                     # (dPre's zero rows are not stored: the class-tile kernels, the scatter-add and the layer-0 products below
                     # leave them out)
                     dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
-                                                skip_dead_stores=USE_MASKED_SUMS and SKIP_DEAD_ROWS and masked_slots(ix, coef, ctx.e_gate) is not None
+                                                skip_dead_stores=USE_MASKED_SUMS and SKIP_DEAD_ROWS and gate_row_mask(ctx.e_gate) is not None
                                                 and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
                     dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:

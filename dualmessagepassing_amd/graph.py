@@ -202,6 +202,25 @@ class GraphIndex:
                                   ptr(tile_scale), ptr(num_tiles), stream_ptr()), "dmp_class_tiles")
         return slot_edge, tile_scale, num_tiles, bound
 
+    def class_tiles_gated(self, coef, gate):
+        """``class_tiles`` over the edges a 0 / 1 edge ``gate`` ([E] floats) keeps -- edges under a zero gate get no slot
+        (``dmp_class_tiles_gated``) -- or None where the list cannot be built on the device from the integer degrees.
+        Not cached here (the gate changes with every batch: ``fused.live_tiles`` memoises per gate)."""
+        src = getattr(self, "_coef_deg", None)
+        if src is None or src[0] is not coef or self.num_edges == 0:
+            return None
+        lib = _lib.load()
+        E, N, C, dev = self.num_edges, self.num_nodes, self.MAX_EDGE_CLASSES, self.device
+        bound = E // 32 + C + 1
+        slot_edge = torch.empty(bound * 32, dtype=torch.int32, device=dev)
+        tile_scale = torch.empty(bound, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.dmp_class_tiles_workspace_words(N, C)) + 2, dtype=torch.int32, device=dev)
+        row_cnt = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        num_tiles = ws[-1:]
+        check(lib.dmp_class_tiles_gated(ptr(src[1]), ptr(self.in_ptr), ptr(self.in_ent), ptr(gate), ptr(row_cnt), N, E, C, bound, ptr(ws),
+                                        ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), stream_ptr()), "dmp_class_tiles_gated")
+        return slot_edge, tile_scale, num_tiles, bound
+
     def _class_tiles_by_value(self, coef):
         """Generic fallback (a coefficient tensor of unknown origin): classes = distinct values of
         ``coef[dst]``, found by a value sort with a handful of tensor ops."""

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 65
+#define DMP_ABI_VERSION 66
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -345,6 +345,13 @@ size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes);
 int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t num_nodes,
                     int64_t num_edges, int num_classes, int64_t tiles_bound, int32_t *ws,
                     int32_t *slot_edge, float *tile_scale, int32_t *num_tiles, void *stream);
+/* ... over the edges a 0 / 1 edge gate keeps (gate [E] floats: an edge with gate 0 gets no slot; row_cnt [N]: scratch, the kept
+ * in-edges of every node): the class-typed kernels of a gated layer then walk the kept edges' tiles only -- for the launches whose
+ * rows under a zero gate are dead (dmp_edge_fwd_typed's output rows, dmp_atb_typed's products, dmp_bwd_z_typed_arow's gradient
+ * rows: dmpnn.py:215-277 multiplies all of them by the gate).  Same order, same tile_scale, tiles_bound as dmp_class_tiles. */
+int dmp_class_tiles_gated(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int32_t *row_cnt,
+                          int64_t num_nodes, int64_t num_edges, int num_classes, int64_t tiles_bound, int32_t *ws,
+                          int32_t *slot_edge, float *tile_scale, int32_t *num_tiles, void *stream);
 
 /* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
  * ws: scratch of dmp_scan_workspace_words(n) int64 words. */
