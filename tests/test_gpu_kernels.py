@@ -469,6 +469,69 @@ def test_typed_edge_kernels_equal_untyped(rows, gpu):
                     fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix))
 
 
+@pytest.mark.parametrize("rows,keep", [(31, 0.5), (1000, 0.4), (70001, 0.46), (500, 0.0), (500, 1.0)])
+def test_class_tiles_over_the_kept_edges(rows, keep, gpu):
+    """``dmp_class_tiles_gated``: the tile list of the edges a 0 / 1 gate keeps -- every kept edge in exactly one slot, no
+    other edge anywhere, one class per tile with its scale, classes / nodes / edge ids ascending -- and the three class-typed
+    launches over it equal the launches over all edges on the kept rows (rows under a zero gate: never read, NaN there)."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + 11)
+    rng = np.random.default_rng(rows + 11)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    rev = rng.random(rows) < 0.5
+    ix = _index(src, dst, n, rev, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    ce = ix.edge_select(coef)[2].cpu().numpy()
+    g_np = (rng.random(rows) < keep).astype(np.float32)
+    gate = th.from_numpy(g_np).to(gpu)
+    gate._dmp_binary = True
+    slot_edge, tile_scale, num_tiles, bound = ix.class_tiles_gated(coef, gate)
+    assert bound == ix.class_tiles(coef)[3]
+    nt = int(num_tiles.item())
+    full = slot_edge.view(-1, 32).cpu().numpy()
+    se = full[:nt]
+    kept = np.nonzero(g_np)[0]
+    assert sorted(se[se >= 0].tolist()) == kept.tolist()
+    assert (full[nt:] == -1).all()
+    ts = tile_scale[:nt].cpu().numpy()
+    for t in range(nt):
+        ids = se[t][se[t] >= 0]
+        assert len(ids) > 0 and np.all(ce[ids] == ts[t])
+    assert nt <= len(kept) // 32 + len(np.unique(ce[kept])) if len(kept) else nt == 0
+    live = se.reshape(-1)[se.reshape(-1) >= 0]
+    keyed = np.stack([ce[live], dst[live], live], 1)
+    assert np.array_equal(keyed, keyed[np.lexsort((keyed[:, 2], keyed[:, 1], keyed[:, 0]))])
+    if rows < 1000:
+        return
+    # the launches: kept rows as over all edges, dead rows untouched
+    dead = gate == 0
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    zp = z.clone()
+    zp[dead] = float("nan")
+    ref = fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix)
+    got = fused.edge_fwd_typed(zp, wes, xp[:, h:], 3 * h, bias, coef, ix, dead_gate=gate)
+    assert th.equal(got[~dead], ref[~dead])
+    d_pre = th.randn(rows, h, generator=gen).to(gpu) * gate[:, None]
+    dpp = d_pre.clone()
+    dpp[dead] = float("nan")
+    ref_w = fused.atb_typed(z, d_pre, coef, ix)
+    got_w = fused.atb_typed(zp, dpp, coef, ix, gate=gate)
+    assert bool(th.isfinite(got_w).all())
+    assert float((got_w - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    base = th.randn(rows, h, generator=gen).to(gpu)
+    bp = base.clone()
+    bp[dead] = float("nan")
+    ref_z = fused.bwd_z_typed(d_pre, h, wes, d_s, base, coef, ix)
+    got_z = fused.bwd_z_typed(dpp, h, wes, d_s, bp, coef, ix, gate=gate, dead_rows="zero")
+    assert th.equal(got_z[~dead], ref_z[~dead]) and float(got_z[dead].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("rows", [1, 31, 4097, 70001])
 @pytest.mark.parametrize("gated", [False, True])
 def test_gated_weight_gradient_rows(rows, gated, gpu):
