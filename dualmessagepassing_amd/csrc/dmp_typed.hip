@@ -21,7 +21,10 @@
 namespace dmp {
 namespace {
 
-enum { TEPI_EDGE = 1, TEPI_DZ = 4, TEPI_REL = 8 };
+// TEPI_OUT / TEPI_H1: the second Linear of the edge MLP over the tiles of the KEPT edges of a 0 / 1 edge gate (dmp_class_tiles_gated;
+// the classes play no part: one plain panel) -- out[e] = R[e] + A[e] W + bias and dPre[e] = act'(R[e]) (.) (A[e] W) with its column
+// sums; what dmp_mfma.hip's one-panel kernels do over ALL rows in eid order (their products for the rows under a zero gate are zeros).
+enum { TEPI_EDGE = 1, TEPI_DZ = 4, TEPI_REL = 8, TEPI_OUT = 16, TEPI_H1 = 32 };
 
 struct TypedArgs {
   const float *A; int64_t lda;          // streamed operand [E,128], rows gathered by edge id
@@ -43,7 +46,9 @@ struct TypedArgs {
   const float *R; int64_t ldr;          // TEPI_DZ: upstream gradient rows [E,128] or NULL
   const int32_t *rmap; int64_t rowsR;   // TEPI_DZ: R is a [rowsR, ldr] table, row rmap[e] (< 0: zero) for edge e; NULL: row e
   float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
-  float slope;                          // TEPI_EDGE: negative slope of the activation (0 = ReLU)
+  float slope;                          // TEPI_EDGE / TEPI_H1: negative slope of the activation (0 = ReLU)
+  float *partial;                       // TEPI_H1: [gridDim.x, H] column sums of dPre per workgroup
+  float *partialA;                      // TEPI_H1, optional: [gridDim.x, H] column sums of the fetched rows of A
 };
 
 template <int H> struct TypedGeom {
@@ -83,8 +88,10 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
   float *scr = Cs[wave];
   const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
   const uint32_t colA = (uint32_t)(gtid % kQ) * 16u, col4 = (uint32_t)c4 * 4u;
+  constexpr bool kPlainPanel = EPI == TEPI_REL || EPI == TEPI_OUT || EPI == TEPI_H1;   // no class term in the panel
+  constexpr bool kRowsOnly = EPI == TEPI_OUT || EPI == TEPI_H1;                         // epilogue operand: row e of R, nothing gathered
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == TEPI_EDGE && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
+  if ((EPI == TEPI_EDGE || EPI == TEPI_OUT) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
@@ -127,16 +134,16 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
-        if (EPI != TEPI_REL) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
+        if (!kPlainPanel) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
       }
       if (X6) {
         float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
+        for (int j = 0; j < 8; ++j) w[j] = kPlainPanel ? w0[j] : w0[j] + c * w1[j];
         split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[X6 ? s0 / 8 : 0]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[X6 ? 0 : s0 + j] = EPI == TEPI_REL ? w0[j] : w0[j] + c * w1[j];
+        for (int j = 0; j < 8; ++j) b[X6 ? 0 : s0 + j] = kPlainPanel ? w0[j] : w0[j] + c * w1[j];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
     constexpr int S = decltype(set)::value;
     if (gtid < kSub) {
       const uint32_t eo = id_own >= 0 ? (uint32_t)id_own * 4u : kOOB;
-      pre_a[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
+      if (!kRowsOnly) pre_a[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxA, (int)eo, 0, 0);
       if (EPI == TEPI_EDGE) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b32(rs_idxB, (int)eo, 0, 0);
       if (EPI == TEPI_DZ) pre_b[S] = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
       if (EPI == TEPI_DZ) pre_r[S] = p.rmap ? (id_own >= 0 ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rmap, (int)eo, 0, 0) : -1) : id_own;
@@ -186,8 +193,10 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
     for (int m = 0; m < kSubLoads; ++m) load_row(set, m);
     load_row_scalars(set);
   };
+  float4 csA = make_float4(0.f, 0.f, 0.f, 0.f);            // TEPI_H1, partialA: this thread's 4 columns of the rows it stages
   auto stage_row = [&](int buf, auto set, int m) {           // register set S -> LDS, one of the thread's four row pieces
     constexpr int S = decltype(set)::value;
+    if (EPI == TEPI_H1 && p.partialA) { csA.x += pre[S][m].x; csA.y += pre[S][m].y; csA.z += pre[S][m].z; csA.w += pre[S][m].w; }
     if (X6) {
       uint2 ph, pm, pl;
       split_pair(pre[S][m].x, pre[S][m].y, ph.x, pm.x, pl.x);
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
         if (ok) { a = pre_a[S]; bb = pre_b[S]; }          // the two gathered nodes
       } else if (EPI == TEPI_REL) {
         a = p.idxA ? pre_a[S] : __float_as_uint(1.f);     // the row's scale (float bits)
+      } else if (kRowsOnly) {
       } else {
         bb = pre_b[S];                                    // flag: selects the half of the gathered row and the sign
         if (ok) a = pre_a[S];
@@ -233,6 +243,8 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
     if (EPI == TEPI_EDGE) {
       g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4);
       g1[k] = sbuf_load4(rs_T, (int)rowB[par][rr], col4 + kRowBytes);
+    } else if (kRowsOnly) {
+      g1[k] = row_load4<BIG>(rs_R, p.R, p.ldr, (int)rowR[par][rr], col4);
     } else {
       g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4 + (rowB[par][rr] ? kRowBytes : 0u));
       g1[k] = row_load4<BIG>(rs_R, p.R, p.ldr, (int)rowR[par][rr], col4);
@@ -339,6 +351,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       a4 = an;
     }
   };
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);         // TEPI_H1: this lane's 4 columns of dPre
   auto epilogue = [&](int par) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * h) * kScrStride + li] = acc[r];
@@ -354,6 +367,13 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       } else if (EPI == TEPI_REL) {
         const float sg = __uint_as_float(rowA[par][rr]);
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+      } else if (EPI == TEPI_OUT) {                          // as dmp_mfma.hip's EPI_GATE_RES with gate 1: (product + bias) + residual
+        v.x = (v.x + bias4.x) + g1[k].x; v.y = (v.y + bias4.y) + g1[k].y;
+        v.z = (v.z + bias4.z) + g1[k].z; v.w = (v.w + bias4.w) + g1[k].w;
+      } else if (EPI == TEPI_H1) {                           // padding rows: the activation reads as 0, the product is 0 -> 0
+        v.x = act_bwd(g1[k].x, v.x, slope); v.y = act_bwd(g1[k].y, v.y, slope);
+        v.z = act_bwd(g1[k].z, v.z, slope); v.w = act_bwd(g1[k].w, v.w, slope);
+        colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
       } else {
         const float sg = rowB[par][rr] ? p.s1 : p.s0;
         v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
@@ -368,7 +388,15 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
     }
   };
 
-  if (mine == 0) return;
+  if (mine == 0) {
+    if (EPI == TEPI_H1) {                                    // this workgroup's partial rows: zeros
+      if (gtid < kQ) {
+        *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * H + gtid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.partialA) *reinterpret_cast<float4 *>(p.partialA + (int64_t)blockIdx.x * H + gtid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
   if (kDeep) {
     load_ids(0);
     load_rows(set0);           // tile 0 -> set 0
@@ -431,6 +459,32 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       ++k;
       par3 = par3 == 2 ? 0 : par3 + 1;
     } while (k < mine && (k & 63) != 0 && ((starts >> (k & 63)) & 1ull) == 0);
+  }
+  if (EPI == TEPI_H1) {
+    // lanes with equal (lane & 7) hold the same 4 columns for 8 different rows: fixed-order xor-shuffle tree over lane >> 3,
+    // then one partial row per workgroup (dmp_mfma.hip's EPI_RELU_BWD_G does the same)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      colsum.x += __shfl_xor(colsum.x, off, 64); colsum.y += __shfl_xor(colsum.y, off, 64);
+      colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
+    }
+    if (lane < 8) *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * H + 32 * cs + lane * 4) = colsum;
+    if (p.partialA) {
+      // the 8 threads that staged the same 4 columns (gtid % kQ), added in a fixed order through the tile buffer
+      lds_barrier();
+      float *red = reinterpret_cast<float *>(&As[0][0]);
+      *reinterpret_cast<float4 *>(&red[(gtid / kQ) * H + (gtid % kQ) * 4]) = csA;
+      lds_barrier();
+      if (gtid < kQ) {
+        float4 t = *reinterpret_cast<const float4 *>(&red[gtid * 4]);
+#pragma unroll
+        for (int g = 1; g < TypedGeom<H>::kThreads / kQ; ++g) {
+          const float4 u = *reinterpret_cast<const float4 *>(&red[g * H + gtid * 4]);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4 *>(p.partialA + (int64_t)blockIdx.x * H + gtid * 4) = t;
+      }
+    }
   }
 }
 
@@ -508,6 +562,61 @@ int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
                     float *dZ, int64_t ldz, void *stream) {
   return dmp_bwd_z_typed_arow(dPre, ldp, W, ldw, D, ldd, num_nodes, base, ldb, dst, flag, s0, s1, slot_edge, nullptr, tile_scale,
                               num_tiles, tiles_bound, E, H, w_transposed, base_map, base_rows, dZ, ldz, stream);
+}
+
+// rows of the partial arrays of dmp_bwd_h1_typed = the grid of its launch (launch_typed)
+int64_t dmp_typed_partial_rows(int64_t tiles_bound, int H) {
+  return (int64_t)typed_blocks(tiles_bound, g_exact_fp32 ? (H == 128 ? 3 : TypedGeom<64>::kPerCU) : (H == 128 ? 2 : 4));
+}
+
+static int rows_typed_check(const float *A, int64_t lda, const float *W, int64_t ldw, const float *R, int64_t ldr, const float *C,
+                            int64_t ldc, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
+                            int64_t tiles_bound, int64_t E, int H) {
+  if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+  if (!A || !W || !C || !slot_edge || !tile_scale || !num_tiles || lda < H || ldw < H || ldc < H || (R && ldr < H)) return DMP_ERR_BAD_ARG;
+  if (lda % 4 || ldc % 4 || (R && ldr % 4) || !aligned16(A) || !aligned16(C) || (R && !aligned16(R))) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(lda) || !stride_ok(ldc) || (R && !stride_ok(ldr)) || E >= ((int64_t)1 << 30) || !fits32(tiles_bound * kSub, 1) ||
+      !fits32(H, ldw))
+    return DMP_ERR_UNSUPPORTED;
+  return DMP_OK;
+}
+
+int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
+                      int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
+                      int64_t E, int H, float *out, int64_t ldo, void *stream) {
+  if (E == 0) return (E < 0) ? DMP_ERR_BAD_ARG : DMP_OK;
+  const int rc = rows_typed_check(Hin, ldh, W2, ldw, R, ldr, out, ldo, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
+  if (rc != DMP_OK) return rc;
+  if (bias && !aligned16(bias)) return DMP_ERR_UNSUPPORTED;
+  TypedArgs p{};
+  p.A = Hin; p.lda = ldh; p.W = W2; p.ldw = ldw; p.transposed = w_in_out ? 0 : 1;   // [in, out]: B[k][j] = W2[k][j]; nn.Linear's [out, in]: W2[j][k]
+  p.C = out; p.ldc = ldo; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
+  p.num_tiles = num_tiles; p.bias = bias; p.R = R; p.ldr = R ? ldr : H; p.num_panels = 1;
+  return H == 128 ? launch_typed<TEPI_OUT, 128>(p, tiles_bound, (hipStream_t)stream)
+                  : launch_typed<TEPI_OUT, 64>(p, tiles_bound, (hipStream_t)stream);
+}
+
+int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
+                     int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream) {
+  if (!partial || !aligned16(partial) || (partial_rows && !aligned16(partial_rows))) return DMP_ERR_BAD_ARG;
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if (E == 0) {
+    const size_t bytes = sizeof(float) * H * (size_t)dmp_typed_partial_rows(tiles_bound, H);
+    if (hipMemsetAsync(partial, 0, bytes, (hipStream_t)stream) != hipSuccess) return DMP_ERR_HIP;
+    if (partial_rows && hipMemsetAsync(partial_rows, 0, bytes, (hipStream_t)stream) != hipSuccess) return DMP_ERR_HIP;
+    return DMP_OK;
+  }
+  if (!H1) return DMP_ERR_BAD_ARG;
+  const int rc = rows_typed_check(dO, ldo, W2, ldw, H1, ldh, dG, ldg, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
+  if (rc != DMP_OK) return rc;
+  TypedArgs p{};
+  p.A = dO; p.lda = ldo; p.W = W2; p.ldw = ldw; p.transposed = 0;                    // dH1 = dO @ W2, W2 [out, in] = B[k = out][j = in]
+  p.C = dG; p.ldc = ldg; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
+  p.num_tiles = num_tiles; p.R = H1; p.ldr = ldh; p.slope = slope; p.partial = partial; p.partialA = partial_rows; p.num_panels = 1;
+  return H == 128 ? launch_typed<TEPI_H1, 128>(p, tiles_bound, (hipStream_t)stream)
+                  : launch_typed<TEPI_H1, 64>(p, tiles_bound, (hipStream_t)stream);
 }
 
 int dmp_mask_slots(const int32_t *slot, int64_t n, const float *gate, int64_t E, int32_t *out, void *stream) {

@@ -566,6 +566,41 @@ def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None, dead_rows=0):
     return out
 
 
+USE_TYPED_ROWS = _os.environ.get("DMP_TYPED_ROWS", "1") == "1"   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
+
+
+def out_fwd_typed(h1, W2t, b2, prev, tiles):
+    """``prev + (h1 W2^T + b2)`` for the edges of ``tiles`` (``live_tiles``: the edges a 0 / 1 gate keeps, gate 1 there); the
+    other rows of the result are not written (``dead_rows_buffer``).  ``W2t`` [in, out]."""
+    lib = _lib.load()
+    R, H = h1.shape
+    slot_edge, tile_scale, num_tiles, bound = tiles
+    out = dead_rows_buffer((R, H), h1.device)
+    with _lib.timed("out_fwd_typed[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
+        check(lib.dmp_out_fwd_typed(ptr(h1), h1.stride(0), ptr(W2t), W2t.size(1), 1, ptr(b2), ptr(prev), prev.stride(0) if prev is not None else H,
+                                    ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, R, H, ptr(out), H, stream_ptr()),
+              "dmp_out_fwd_typed")
+    return out
+
+
+def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0):
+    """``(dPre, column sums of dPre, column sums of the kept rows of d_o)`` with ``dPre[e] = act'(h1[e]) (.) (d_o[e] W2)`` for the
+    edges of ``tiles`` (``live_tiles``); the other rows of ``dPre`` are not written (``dead_rows_buffer``)."""
+    lib = _lib.load()
+    E, H = d_o.shape
+    slot_edge, tile_scale, num_tiles, bound = tiles
+    d_g = dead_rows_buffer((E, H), d_o.device)
+    G = int(lib.dmp_typed_partial_rows(bound, H))
+    part = torch.empty((G, H), dtype=torch.float32, device=d_o.device)
+    part_rows = torch.empty_like(part)
+    W2 = W2.contiguous()
+    with _lib.timed("bwd_h1_typed[H=%d,E=%d]", (H, E), 12 * H * E + 4 * E):
+        check(lib.dmp_bwd_h1_typed(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(slot_edge), ptr(tile_scale),
+                                   ptr(num_tiles), bound, E, H, slope, ptr(d_g), H, ptr(part), ptr(part_rows), stream_ptr()),
+              "dmp_bwd_h1_typed")
+    return d_g, reduce_partials(part), reduce_partials(part_rows)
+
+
 USE_MASKED_SUMS = _os.environ.get("DMP_MASKED_SUMS", "1") != "0"   # the scatter-adds skip the rows a 0 / 1 edge gate wiped
 
 
@@ -1173,7 +1208,11 @@ class _FusedDMPLayer(torch.autograd.Function):
             # fetched; as an INNER layer of a rep-net (``inner``: the next layer of the same rep-net, under the same gate,
             # is the only reader of zn) the output's zero rows are not stored either
             dead = (3 if (inner & 1) else 1) if (dead_gate is not None and zero_rows_gate(e_gate)) else 0
-            zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
+            lt = live_tiles(index, coef, e_gate) if (dead == 3 and USE_TYPED_ROWS and eW2t is not None) else None
+            if lt is not None:      # nothing to write for the rows under a zero gate: the kept edges' tiles only
+                zn = out_fwd_typed(H1e, eW2t, eb2, z if residual else None, lt)
+            else:
+                zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
@@ -1271,9 +1310,14 @@ class _FusedDMPLayer(torch.autograd.Function):
                     # gradient runs ungated over the masked-in rows on the bf16 pipe
                     # (dPre's zero rows are not stored: the class-tile kernels, the scatter-add and the layer-0 products below
                     # leave them out)
-                    dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
-                                                skip_dead_stores=USE_MASKED_SUMS and SKIP_DEAD_ROWS and gate_row_mask(ctx.e_gate) is not None
-                                                and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
+                    skip = (USE_MASKED_SUMS and SKIP_DEAD_ROWS and gate_row_mask(ctx.e_gate) is not None
+                            and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
+                    lt = live_tiles(ix, coef, ctx.e_gate) if (skip and USE_TYPED_ROWS) else None
+                    if lt is not None:      # over the kept edges' tiles only
+                        dG, dbe, db2e = bwd_h1_typed(dzn, eW2, H1e, lt, slope)
+                    else:
+                        dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
+                                                    skip_dead_stores=skip)
                     dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:
                     dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)

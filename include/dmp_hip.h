@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 66
+#define DMP_ABI_VERSION 67
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1004,6 +1004,26 @@ int dmp_out_fwd_fused_rows(const float *Hin, int64_t ldh, const float *W2, int64
 int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                           const float *coefE, const float *gate, const uint32_t *rowmask, int skip_dead_stores, int64_t E, int H,
                           float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
+
+/*
+ * ... and over the tiles of the KEPT edges only (dmp_class_tiles_gated's slot_edge / tile_scale / num_tiles / tiles_bound; the rows
+ * are gathered and scattered by edge id as in the class-typed kernels, csrc/dmp_typed.hip), for a 0 / 1 gate whose kept rows
+ * have gate 1:
+ *   dmp_out_fwd_typed   out[e] = R[e] + (Hin[e] W2^T + bias)   for the kept e; the other rows of `out` are not written
+ *                       (W2: nn.Linear's [out, in], or w_in_out: its transpose [in, out]; R may be NULL)
+ *   dmp_bwd_h1_typed    dG[e] = act'(H1[e]) (.) (dO[e] W2)      for the kept e; the other rows of dG are not written;
+ *                       partial / partial_rows [dmp_typed_partial_rows(tiles_bound, H), H]: column sums of dG / of the fetched
+ *                       rows of dO per workgroup (partial_rows may be NULL), summed by dmp_reduce_partials
+ * -- the work of dmp_out_fwd_fused_rows(dead_rows = 3) / dmp_bwd_h1_fused_rows(skip_dead_stores) without the tiles' worth of
+ * zero rows in between the kept ones.
+ */
+int64_t dmp_typed_partial_rows(int64_t tiles_bound, int H);
+int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
+                      int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
+                      int64_t E, int H, float *out, int64_t ldo, void *stream);
+int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                     const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
+                     int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
 
 /*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):

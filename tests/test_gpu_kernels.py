@@ -532,6 +532,49 @@ def test_class_tiles_over_the_kept_edges(rows, keep, gpu):
     assert th.equal(got_z[~dead], ref_z[~dead]) and float(got_z[dead].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,h", [(1000, 128), (70001, 128), (5000, 64)])
+def test_second_linear_over_the_kept_edges_tiles(rows, h, gpu):
+    """``dmp_out_fwd_typed`` / ``dmp_bwd_h1_typed`` (the kept edges' tiles of a 0 / 1 gate) against the one-panel kernels over
+    all rows: equal on the kept rows up to the summation order of the bf16x6 products (same products, same order inside a
+    row: equal bits), the other rows untouched, the column sums to fp32 accuracy; rows under a zero gate are never read."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(rows + h)
+    rng = np.random.default_rng(rows + h)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    gate = th.from_numpy((rng.random(rows) < 0.46).astype(np.float32)).to(gpu)
+    gate._dmp_binary = True
+    dead = gate == 0
+    tiles = fused.live_tiles(ix, coef, gate)
+    assert tiles is not None
+    h1 = th.randn(rows, h, generator=gen).to(gpu)
+    prev = th.randn(rows, h, generator=gen).to(gpu) * gate[:, None]
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    W2 = (th.randn(h, h, generator=gen) / h ** 0.5).to(gpu)
+    b2 = th.randn(h, generator=gen).to(gpu)
+    ref_out = fused.out_fwd_mfma(h1, W2, b2, gate, prev)
+    ref_dg, ref_db, ref_rows = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=gate, slope=0.18, rows_colsum=True)
+    h1p, prevp, dop = h1.clone(), prev.clone(), d_o.clone()
+    for t in (h1p, prevp, dop):
+        t[dead] = float("nan")
+    saved = fused.dead_rows_buffer
+    fused.dead_rows_buffer = lambda shape, device: th.full(shape, 7.5, dtype=th.float32, device=device)
+    try:
+        out = fused.out_fwd_typed(h1p, W2.t().contiguous(), b2, prevp, tiles)
+        dg, db, db_rows = fused.bwd_h1_typed(dop, W2, h1p, tiles, slope=0.18)
+    finally:
+        fused.dead_rows_buffer = saved
+    assert bool((out[dead] == 7.5).all()) and bool((dg[dead] == 7.5).all())
+    s_out, s_dg = float(ref_out.abs().max()), float(ref_dg.abs().max())
+    assert float((out[~dead] - ref_out[~dead]).abs().max()) <= 2e-6 * s_out
+    assert float((dg[~dead] - ref_dg[~dead]).abs().max()) <= 2e-6 * s_dg
+    kept = float(gate.sum())
+    assert float((db - ref_db).abs().max()) <= 2e-6 * max(1.0, kept) * s_dg
+    assert float((db_rows - ref_rows).abs().max()) <= 2e-6 * max(1.0, kept) * float(d_o.abs().max())
+
+
 @pytest.mark.parametrize("rows", [1, 31, 4097, 70001])
 @pytest.mark.parametrize("gated", [False, True])
 def test_gated_weight_gradient_rows(rows, gated, gpu):
