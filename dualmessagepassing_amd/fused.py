@@ -566,6 +566,7 @@ def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None, dead_rows=0):
     return out
 
 
+USE_TYPED_ATB_ROWS = _os.environ.get("DMP_TYPED_ATB_ROWS", "1") == "1"
 USE_TYPED_ROWS = _os.environ.get("DMP_TYPED_ROWS", "1") == "1"   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
 
 
@@ -1318,7 +1319,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                     else:
                         dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
                                                     skip_dead_stores=skip)
-                    dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
+                    if lt is not None and USE_TYPED_ATB_ROWS:
+                        # dO^T H1 over the kept edges' tiles: the class-tile weight-gradient kernel's first half (its class-scaled
+                        # second half costs no further products) -- no tiles' worth of zero rows in between
+                        dW2e = atb_typed(dzn, H1e, coef, ix, gate=ctx.e_gate)[:, :H]
+                    else:
+                        dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:
                     dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
                     dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
