@@ -326,6 +326,35 @@ def build_step(cfg, shard, device, world=1):
         pattern, graph = batch_of(shard)
         return model.gate_kept_edges(pattern, graph)
 
+    def plain_scatter_adds(H, launches=20):
+        """The two scatter-add launches over ALL rows of an [E, H] array on this step's own union index (the kernels the masked
+        forms derive from, and what runs without a 0 / 1 gate): HIP-event time per launch, outside every timed region, inputs
+        written by a launch just before as in the step.  -> {"fwd_us", "bwd_us"} or None."""
+        from dualmessagepassing_amd import ops as _ops
+        pattern, graph = batch_of(shard)
+        union = prepare_joint(pattern, graph, H, backward=False, class_tiles=False)
+        if union is None:
+            return None
+        ix = union.index()
+        E, N = ix.num_edges, ix.num_nodes
+        Mrows = torch.randn(E, H, device=device)
+        res = {}
+        for name, fn in (("fwd_us", lambda: _ops.seg_sum_raw(Mrows, ix.in_ptr, ix.in_ent, N, None, True, -1.0, 1.0)),
+                         ("bwd_us", lambda: _ops.endpoint_sums(Mrows, ix))):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+            for i in range(launches + 2):
+                Mrows.mul_(1.0)                                 # the rows come from the launch before, as in the step
+                if i >= 2:
+                    ev[i - 2][0].record()
+                fn()
+                if i >= 2:
+                    ev[i - 2][1].record()
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+            res[name] = t[len(t) // 2]
+        return res
+
+    step.plain_scatter_adds = plain_scatter_adds
     step.gate_kept_edges = gate_kept_edges
     # (a 0 / 1 edge gate: the class-typed kernels walk tiles over the kept edges, built in the forward pass)
     from dualmessagepassing_amd import fused as _fused
@@ -425,12 +454,16 @@ def gate_summary(g, cfg, step, H):
 
 
 def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, row_bytes=0):
-    """``roofline`` object of one scatter-add launch kind: achieved = the kernel's own algorithmic bytes / its HIP-event
-    time inside the timed steps; beside it the same with SURVEY §8(d)'s byte count, and both over the committed rocprof
-    duration.  ``skipped_rows``: rows of the summed array that are zeros under the batch's 0 / 1 edge gate and that the
-    launch does not fetch (the algorithmic byte counts above still count them: they are what the sum is defined over) --
-    reported with the bytes the launch does fetch and their rate."""
+    """``roofline`` object of one scatter-add launch kind: achieved = the launch's algorithmic bytes / its HIP-event time
+    inside the timed steps; beside it the same with SURVEY §8(d)'s byte count, and both over the committed rocprof duration.
+    ``skipped_rows``: rows of the summed array that are zeros under the batch's 0 / 1 edge gate and that the launch does not
+    fetch.  The algorithmic bytes are then those of the rows the sum still has to read (``achieved`` / ``frac`` stay what the
+    memory system does, never above its peak); the figures over ALL rows of the array -- what the launch replaces -- are
+    reported beside them as ``*_all_rows`` (an effective rate: it can exceed the peak)."""
     us = k["avg_us"]
+    all_own, all_survey = own_bytes, survey_bytes
+    own_bytes -= skipped_rows * row_bytes
+    survey_bytes -= skipped_rows * row_bytes
     r = {"bound": "hbm", "kernel": what, "achieved": round(own_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": prof["traffic"],
          "bytes_per_launch": int(own_bytes), "avg_us": round(us, 2), "launches": k["launches"],
@@ -442,15 +475,15 @@ def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, row_byt
     if prof["traffic"]:
         r["traffic_over_algorithmic"] = round(prof["traffic"] / own_bytes, 4)
     if skipped_rows:
-        fetched = own_bytes - skipped_rows * row_bytes
         r["rows_not_fetched"] = int(skipped_rows)
-        r["bytes_fetched"] = int(fetched)
-        r["frac_fetched_bytes"] = round(fetched / us / 1e3 / HBM_PEAK_GBPS, 4)
+        r["bytes_all_rows"] = int(all_own)
+        r["bytes_survey_all_rows"] = int(all_survey)
+        r["effective_frac_all_rows"] = round(all_own / us / 1e3 / HBM_PEAK_GBPS, 4)
+        r["effective_frac_survey_bytes_all_rows"] = round(all_survey / us / 1e3 / HBM_PEAK_GBPS, 4)
         r["note"] = ("%d of the summed rows are zeros under this batch's 0/1 edge gate (the ScalarFilter gate multiplies the rep-net's "
-                     "input rows, basemodel.py:1515-1531) and are not fetched: `achieved`/`frac` price the sum over ALL rows, as "
-                     "SURVEY 8(d) counts it; `bytes_fetched`/`frac_fetched_bytes` are what the launch moves" % skipped_rows)
-        if prof["traffic"]:
-            r["traffic_over_fetched"] = round(prof["traffic"] / fetched, 4)
+                     "input rows, basemodel.py:1515-1531) and are not fetched: the byte counts and `frac` are those of the rows the "
+                     "launch reads; `*_all_rows` price the same launch time against the whole array (the launch it replaces), an "
+                     "effective figure that may exceed the peak" % skipped_rows)
     return r
 
 
@@ -1051,6 +1084,17 @@ def main():
                                     "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
                                     4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"],
                                     skipped if "graphs" in key_inc else 0, 4 * H)
+        if skipped and world == 1:
+            # ... and the same two launches over ALL rows (no mask, no weights): the kernels as they run without a 0 / 1 gate,
+            # timed stand-alone on this step's index -- so that the fraction of the unmasked kernels stays on record
+            plain = step.plain_scatter_adds(H)
+            for r_, key_, own_, sv_ in ((roof, "fwd_us", 4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1), 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1)),
+                                        (roof_bwd, "bwd_us", 4 * H * (uE + 2 * uN) + 8 * uE + 16 * (cfg["batch"] * 2 + 1), 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1))):
+                if r_ is not None and plain:
+                    r_["all_rows_launch"] = {"what": "the same kernel without the mask / the gate weights, every row read; stand-alone, median of 20 launches",
+                                             "avg_us": round(plain[key_], 2), "bytes": int(own_),
+                                             "frac": round(own_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4),
+                                             "frac_survey_bytes": round(sv_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4)}
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,

@@ -87,7 +87,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   const rsrc_t rs_slotS = make_rsrc(p.slot_scale, REL && gated ? slot_bytes : 0u);
   float *pt = p.pT + (int64_t)(REL ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x) * p.pstride + (int64_t)ya * H * p.ldp + yb * H;
   float *const pcs = MODE == ATB_ROWS && p.pCS && yb == 0 ? p.pCS + (int64_t)blockIdx.x * p.cs_ld + ya * H : nullptr;
-  float *pb = TYPED ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;
+  float *pb = (TYPED && p.pB) ? p.pB + (int64_t)blockIdx.x * p.pstride : nullptr;   // NULL: the plain total alone
 
   f32x16 acc[NI][NJ];
   auto zero_acc = [&]() {
@@ -276,13 +276,13 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
       if (emitted) {
         const float4 t0 = *reinterpret_cast<const float4 *>(pt + o);
         t.x += t0.x; t.y += t0.y; t.z += t0.z; t.w += t0.w;
-        if (TYPED) {
+        if (TYPED && pb) {
           const float4 b0 = *reinterpret_cast<const float4 *>(pb + o);
           b.x += b0.x; b.y += b0.y; b.z += b0.z; b.w += b0.w;
         }
       }
       *reinterpret_cast<float4 *>(pt + o) = t;
-      if (TYPED) *reinterpret_cast<float4 *>(pb + o) = b;
+      if (TYPED && pb) *reinterpret_cast<float4 *>(pb + o) = b;
     }
     emitted = true;
   };
@@ -461,15 +461,15 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
                   float *partial_T, float *partial_B, void *stream) {
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (E < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
-  if (!partial_T || !partial_B || !num_tiles || !slot_edge || !tile_scale) return DMP_ERR_BAD_ARG;
+  if (!partial_T || !num_tiles || !slot_edge || !tile_scale) return DMP_ERR_BAD_ARG;   // partial_B NULL: Z^T dPre alone
   if (E > 0 && (!Z || !dPre || ldz < H || ldp < H)) return DMP_ERR_BAD_ARG;
-  if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre))) || !aligned16(partial_T) || !aligned16(partial_B))
+  if (ldz % 4 || ldp % 4 || (E > 0 && (!aligned16(Z) || !aligned16(dPre))) || !aligned16(partial_T) || (partial_B && !aligned16(partial_B)))
     return DMP_ERR_UNSUPPORTED;
   if (!stride_ok(ldz) || !stride_ok(ldp) || E >= ((int64_t)1 << 31) || !fits32(tiles_bound * kSub, 1)) return DMP_ERR_UNSUPPORTED;
   AtbArgs a{};
   a.Z = Z; a.ldz = ldz; a.D = dPre; a.ldd = ldp; a.E = E; a.slot_edge = slot_edge; a.tile_scale = tile_scale;
   a.num_tiles = num_tiles; a.pT = partial_T; a.pB = partial_B;
-  const bool wide = partial_B == partial_T + H;            // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
+  const bool wide = partial_B && partial_B == partial_T + H;            // one [G][H][2H] buffer ([T | B] side by side) or two [G][H*H]
   a.pstride = wide ? 2 * H * H : H * H;
   a.ldp = wide ? 2 * H : H;
   if (H == 128) {

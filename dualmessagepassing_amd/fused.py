@@ -470,7 +470,7 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     return out
 
 
-def atb_typed(z, d_pre, coef, index, gate=None):
+def atb_typed(z, d_pre, coef, index, gate=None, plain=False):
     """``[z^T d_pre | z^T (coef[dst] (.) d_pre)]``  ([H, 2H]: the gradient of ``Wes`` in its layout) over the
     class-sorted tiles: one product's worth of MFMAs for both halves (csrc/dmp_atb.hip), one fixed-order
     reduction of the workgroup partials.  ``gate``: the layer's edge gate when ``d_pre`` is the gated layer's (zero rows under
@@ -486,6 +486,12 @@ def atb_typed(z, d_pre, coef, index, gate=None):
         if ms is not None:
             slot_edge = ms
     G = int(lib.dmp_atb_typed_blocks_h(bound, H))
+    if plain:       # ``z^T d_pre`` alone ([H, H]): half the partials
+        part = torch.empty((G, H, H), dtype=torch.float32, device=z.device)
+        with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
+            check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
+                                    ptr(num_tiles), bound, E, H, ptr(part), None, stream_ptr()), "dmp_atb_typed")
+        return reduce_partials(part.view(G, -1)).view(H, H)
     part = torch.empty((G, H, 2 * H), dtype=torch.float32, device=z.device)
     with _lib.timed("atb_typed[H=%d,E=%d]", (H, E), 8 * H * E):
         check(lib.dmp_atb_typed(ptr(z), z.stride(0), ptr(d_pre), d_pre.stride(0), ptr(slot_edge), ptr(tile_scale),
@@ -1322,7 +1328,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                     if lt is not None and USE_TYPED_ATB_ROWS:
                         # dO^T H1 over the kept edges' tiles: the class-tile weight-gradient kernel's first half (its class-scaled
                         # second half costs no further products) -- no tiles' worth of zero rows in between
-                        dW2e = atb_typed(dzn, H1e, coef, ix, gate=ctx.e_gate)[:, :H]
+                        dW2e = atb_typed(dzn, H1e, coef, ix, gate=ctx.e_gate, plain=True)
                     else:
                         dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:

@@ -1083,7 +1083,8 @@ int dmp_bwd_z_typed_arow(const float *dPre, int64_t ldp, const float *W, int64_t
  * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats each -- or, when
  * partial_B == partial_T + H, one [blocks, H, 2H] buffer with [T | B] side by side (its reduction is
  * dW = [dA' | dB'] in the layout of W) --, to be summed with dmp_reduce_partials (fixed order:
- * bit-stable for a given tile list).
+ * bit-stable for a given tile list).  partial_B NULL: the plain total sum_e Z[e]^T dPre[e] alone (a Linear's weight
+ * gradient over the edges of a tile list, e.g. dO^T H1 over dmp_class_tiles_gated's kept edges).
  */
 int64_t dmp_atb_typed_blocks(int64_t tiles_bound);          /* H = 128 */
 int64_t dmp_atb_typed_blocks_h(int64_t tiles_bound, int H); /* H = 128 or 64 (the reference's shipped hidden_dim) */

@@ -34,8 +34,8 @@ def _check_contract(d, steps=3, warmup=2):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] > 0 and r["avg_us"] > 0
     if "rows_not_fetched" in r:      # the batch's 0 / 1 edge gate: rows the launch leaves out, and the bytes it does move
-        assert 0 < r["rows_not_fetched"] and 0 < r["bytes_fetched"] < r["bytes_per_launch"]
-        assert r["frac_fetched_bytes"] < r["frac"] and "note" in r
+        assert 0 < r["rows_not_fetched"] and 0 < r["bytes_per_launch"] < r["bytes_all_rows"]
+        assert r["frac"] < r["effective_frac_all_rows"] and r["frac"] < 1.0 and "note" in r
 
 
 def test_default_mode_replays_and_eager_agrees(gpu):
