@@ -176,6 +176,11 @@ SIGNATURES = {
                                        c_i64, c_ptr]),
     "dmp_bwd_h1_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_f32, c_ptr,
                                       c_i64, c_ptr, c_ptr, c_ptr]),
+    "dmp_kept_rows_scratch_words": (c_i64, [c_i64]),
+    "dmp_kept_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_l0_edge_fwd_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
+                                     c_f32, c_ptr, c_i64, c_ptr]),
+    "dmp_l0_bwd_w_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_typed_partial_rows": (c_i64, [c_i64, c_int]),
     "dmp_out_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
                                   c_i64, c_ptr]),
@@ -204,7 +209,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 67
+ABI_VERSION = 68
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

@@ -99,9 +99,12 @@ struct FwdArgs {
   int64_t R; float slope; float *out; int64_t ldo;
   const uint32_t *rowmask;                 // bit r of rowmask[t] == 0: row 32 t + r is a DEAD row (its consumers all multiply it by a zero
                                            // gate and skip it): nothing is gathered, computed or stored for it.  NULL: every row
+  const int32_t *list, *count;             // LIST form: the rows to do, ascending (dmp_kept_rows: the rows whose mask bit is set), *count of them
 };
 
-template <int K, int VW>
+// LIST: the kernel walks a list of row ids instead of the rows 0 .. R-1 -- the rows a 0 / 1 gate keeps; a batch of rows is then
+// kRows KEPT rows (the masked form spends a batch's issue slots on its dead rows too).
+template <int K, int VW, bool LIST = false>
 __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   constexpr int WPB = kBlock / 64, kRows = kFwdRows, H = 64 * VW;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -120,15 +123,18 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   if (lane == kLaneB) { base = reinterpret_cast<const char *>(p.sel_b); step = 4; }
   const bool on = lane < K || (lane >= kLaneCoef && lane <= kLaneB);
   static_assert(32 % kRows == 0, "a batch of rows lies inside one mask word");
-  auto fetch = [&](int64_t r0, float (&mm)[kRows], uint32_t &lv) {
+  const int64_t limit = LIST ? (int64_t)*p.count : p.R;    // batches of rows: positions in the list / rows
+  auto fetch = [&](int64_t r0, float (&mm)[kRows], uint32_t &lv, int (&id)[kRows]) {
     // the batch's row-mask bits with its scalars, a whole batch ahead of their use (r0 is a multiple of kRows: one word)
-    lv = (p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
+    lv = (!LIST && p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      const int64_t r = r0 + u;                             // wave-uniform
+      const int64_t q = r0 + u;                             // wave-uniform
+      const int64_t r = LIST ? (q < limit ? (int64_t)p.list[q] : -1) : q;
       float m = 0.f;                                        // rows past the end: code 0, node rows 0 (loaded, never stored)
-      if (on && r < p.R) m = *reinterpret_cast<const float *>(base + r * step);
+      if (on && (LIST ? r >= 0 : r < p.R)) m = *reinterpret_cast<const float *>(base + r * step);
       mm[u] = m;
+      id[u] = (int)r;
     }
   };
   // Measured (knob builds of round 3): 135 us at E = 549 k, of which the scalars + epilogue 25, the FMAs 30, the
@@ -136,11 +142,12 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
   // a two-batch software pipeline with the gathers issued ahead of the stores, contiguous row runs per workgroup or an
   // XCD-aware order (all within 135-145 us); PMC: 281 MB written, 260 MB fetched (the node rows 3 x).
   float mine[kRows], next[kRows];
+  int rid[kRows], ridn[kRows];
   uint32_t lv = 0xffffffffu, lvn = 0xffffffffu;
   int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
-  if (r0 < p.R) fetch(r0, mine, lv);
-  for (; r0 < p.R; r0 += stride) {
-    fetch(r0 + stride, next, lvn);                          // the next batch's scalars: a dependent round trip less per batch
+  if (r0 < limit) fetch(r0, mine, lv, rid);
+  for (; r0 < limit; r0 += stride) {
+    fetch(r0 + stride, next, lvn, ridn);                    // the next batch's scalars: a dependent round trip less per batch
     Vec<VW> pa[kRows], pb[kRows];
     // a dead row (mask bit 0) gathers node row 0 instead of its own two (one cached line: no traffic, and no branch in the
     // load / compute sequence -- control flow here costs the loop its overlapped loads: measured 120 -> 170 us) and is not stored
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
     }
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      if (r0 + u >= p.R) break;
+      if (r0 + u >= limit) break;
       const float cf = lane_f(mine[u], kLaneCoef);
       Vec<VW> g0 = vzero<VW>(), g1 = vzero<VW>();
 #pragma unroll
@@ -172,10 +179,10 @@ __global__ __launch_bounds__(kBlock) void l0_edge_fwd_k(const FwdArgs p) {
         y += at<VW>(bias, c);
         at<VW>(t, c) = act_fwd(y, p.slope);
       }
-      if ((lv >> u) & 1u) vstore<VW>(p.out + (r0 + u) * p.ldo, lane, t);
+      if ((lv >> u) & 1u) vstore<VW>(p.out + (LIST ? (int64_t)rid[u] : r0 + u) * p.ldo, lane, t);
     }
 #pragma unroll
-    for (int u = 0; u < kRows; ++u) mine[u] = next[u];
+    for (int u = 0; u < kRows; ++u) { mine[u] = next[u]; rid[u] = ridn[u]; }
     lv = lvn;
   }
 }
@@ -187,9 +194,10 @@ struct BwdArgs {
   int64_t R; float *partial;               // [blocks, K, (dZn ? 3 : 2) * H]
   const uint32_t *rowmask;                 // bit r of rowmask[t] == 0: row 32 t + r has an all-zero code row (a zero gate went into
                                            // l0_pack): its dPre / dZn rows are not fetched (they would be multiplied by zeros).  NULL: all
+  const int32_t *list, *count;             // LIST form (see l0_edge_fwd_k): the rows to add, *count of them
 };
 
-template <int K, int VW, bool RES>
+template <int K, int VW, bool RES, bool LIST = false>
 __global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
   constexpr int WPB = kBlock / 64, kRows = kBwdNoPrefetch ? 8 : kL0Rows, H = 64 * VW, NACC = (RES ? 3 : 2) * K;
   __shared__ float red4[(kBwdWide ? kBlock / 64 : 1) * kBlock * VW];
@@ -200,12 +208,14 @@ __global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
   const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
   Vec<VW> d[kRows], dn[kRows], z[RES ? kRows : 1], zn[RES ? kRows : 1];
   float mine[kRows], minen[kRows];
+  const int64_t limit = LIST ? (int64_t)*p.count : p.R;
   auto load_batch = [&](int64_t r0, Vec<VW> (&dd)[kRows], Vec<VW> (&zz)[RES ? kRows : 1], float (&mm)[kRows]) {
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      const int64_t r = r0 + u;                             // wave-uniform
-      const bool ok = r < p.R;
-      const bool live = ok && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));   // scalar load, scalar branch
+      const int64_t q = r0 + u;                             // wave-uniform
+      const int64_t r = LIST ? (q < limit ? (int64_t)p.list[q] : 0) : q;
+      const bool ok = q < limit;
+      const bool live = ok && (LIST || !p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));   // scalar load, scalar branch
       if (live) {
         dd[u] = vload<VW>(p.dPre + r * p.ldd, lane);
         if (RES) zz[u] = vload<VW>(p.dZn + r * p.ldz, lane);
@@ -220,13 +230,13 @@ __global__ __launch_bounds__(kBlock) void l0_bwd_w_k(const BwdArgs p) {
     }
   };
   int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
-  if (!kBwdNoPrefetch && r0 < p.R) load_batch(r0, d, z, mine);
-  for (; r0 < p.R; r0 += stride) {
+  if (!kBwdNoPrefetch && r0 < limit) load_batch(r0, d, z, mine);
+  for (; r0 < limit; r0 += stride) {
     if (kBwdNoPrefetch) load_batch(r0, d, z, mine);
     else load_batch(r0 + stride, dn, zn, minen);            // rows past the end read as zeros
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      if (p.rowmask) {                                       // an all-zero code row: nothing to add (wave-uniform test)
+      if (!LIST && p.rowmask) {                              // an all-zero code row: nothing to add (wave-uniform test)
         const int64_t r = r0 + u;
         if (r < p.R && !((p.rowmask[r >> 5] >> (r & 31)) & 1u)) continue;
       }
@@ -304,15 +314,66 @@ template <int K>
 void launch_fwd(const FwdArgs &p, int H, hipStream_t st) {
   const int64_t chunk = (int64_t)(kBlock / 64) * kFwdRows, want = (p.R + chunk - 1) / chunk;
   const unsigned nb = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
-  if (H == 128) l0_edge_fwd_k<K, 2><<<nb, kBlock, 0, st>>>(p);
+  if (p.list) {
+    if (H == 128) l0_edge_fwd_k<K, 2, true><<<nb, kBlock, 0, st>>>(p);
+    else l0_edge_fwd_k<K, 1, true><<<nb, kBlock, 0, st>>>(p);
+  } else if (H == 128) l0_edge_fwd_k<K, 2><<<nb, kBlock, 0, st>>>(p);
   else l0_edge_fwd_k<K, 1><<<nb, kBlock, 0, st>>>(p);
 }
 
 template <int K>
 void launch_bwd(const BwdArgs &p, int H, hipStream_t st) {
   const unsigned nb = l0_blocks(p.R, kL0MaxPartials);
+  if (p.list) {
+    if (H == 128) { if (p.dZn) l0_bwd_w_k<K, 2, true, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 2, false, true><<<nb, kBlock, 0, st>>>(p); }
+    else { if (p.dZn) l0_bwd_w_k<K, 1, true, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 1, false, true><<<nb, kBlock, 0, st>>>(p); }
+    return;
+  }
   if (H == 128) { if (p.dZn) l0_bwd_w_k<K, 2, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 2, false><<<nb, kBlock, 0, st>>>(p); }
   else { if (p.dZn) l0_bwd_w_k<K, 1, true><<<nb, kBlock, 0, st>>>(p); else l0_bwd_w_k<K, 1, false><<<nb, kBlock, 0, st>>>(p); }
+}
+
+// ---- the rows whose mask bit is set, ascending (dmp_kept_rows): per-block counts, then every block ranks and writes its rows
+constexpr int kKeptWords = 256;          // mask words per block
+__global__ __launch_bounds__(kKeptWords) void kept_count_k(const uint32_t *__restrict__ mask, int64_t R, int32_t *__restrict__ blk) {
+  __shared__ int red[kKeptWords / 64];
+  const int64_t W = (R + 31) / 32, w = (int64_t)blockIdx.x * kKeptWords + threadIdx.x;
+  uint32_t m = w < W ? mask[w] : 0u;
+  if (w == W - 1 && (R & 31)) m &= (1u << (R & 31)) - 1u;      // bits past the last row do not count
+  int c = __popc(m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < kKeptWords / 64; ++i) t += red[i]; blk[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kKeptWords) void kept_fill_k(const uint32_t *__restrict__ mask, int64_t R, const int32_t *__restrict__ blk,
+                                                           int32_t *__restrict__ list, int32_t *__restrict__ count) {
+  __shared__ int red[kKeptWords / 64], wtot[kKeptWords / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // rows kept by the blocks before this one (a few dozen to a few hundred words out of L2); the last block also has the total
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kKeptWords) before += blk[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int i = 0; i < kKeptWords / 64; ++i) before += red[i];
+  const int64_t W = (R + 31) / 32, w = (int64_t)blockIdx.x * kKeptWords + threadIdx.x;
+  uint32_t m = w < W ? mask[w] : 0u;
+  if (w == W - 1 && (R & 31)) m &= (1u << (R & 31)) - 1u;
+  const int c = __popc(m);
+  int incl = c;                                                // inclusive scan inside the wave, then over the waves
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int pos = before + incl - c;
+  for (int i = 0; i < wave; ++i) pos += wtot[i];
+  const int base = (int)(w * 32);
+  while (m) { const int b = __builtin_ctz(m); m &= m - 1; list[pos++] = base + b; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kKeptWords - 1) *count = pos;   // (the last thread's pos: everything before it + its own)
 }
 
 #define L0_SWITCH(K, CALL)                                                                          \
@@ -358,9 +419,55 @@ int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M,
   if (R == 0) return DMP_OK;
   if (!enc || !M || !P || !coef_e || !sel_a || !sel_b || !out || lde < K || ldm < 2 * H || ldp < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
   if (ldm % 2 || ldp % 2 || ldo % 2 || !al8(M) || !al8(P) || !al8(out) || !al8(bias)) return DMP_ERR_UNSUPPORTED;
-  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo, rowmask};
+  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo, rowmask, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
 #define L0_CALL(KK) launch_fwd<KK>(p, H, st)
+  L0_SWITCH(K, L0_CALL)
+#undef L0_CALL
+  return check_launch();
+}
+
+int64_t dmp_kept_rows_scratch_words(int64_t R) { return ((R + 31) / 32 + kKeptWords - 1) / kKeptWords + 1; }
+
+int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int32_t *scratch, int32_t *list, int32_t *count, void *stream) {
+  if (R < 0 || !count) return DMP_ERR_BAD_ARG;
+  if (R >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (R == 0) return hipMemsetAsync(count, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!rowmask || !scratch || !list) return DMP_ERR_BAD_ARG;
+  const unsigned nb = (unsigned)(((R + 31) / 32 + kKeptWords - 1) / kKeptWords);
+  kept_count_k<<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch);
+  kept_fill_k<<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch, list, count);
+  return check_launch();
+}
+
+int dmp_l0_edge_fwd_rows(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                         const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
+                         const int32_t *list, const int32_t *count, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream) {
+  if (R < 0 || K <= 0 || !list || !count) return DMP_ERR_BAD_ARG;
+  if ((H != 128 && H != 64) || K > kL0K || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if (R == 0) return DMP_OK;
+  if (!enc || !M || !P || !coef_e || !sel_a || !sel_b || !out || lde < K || ldm < 2 * H || ldp < 2 * H || ldo < H) return DMP_ERR_BAD_ARG;
+  if (ldm % 2 || ldp % 2 || ldo % 2 || !al8(M) || !al8(P) || !al8(out) || !al8(bias)) return DMP_ERR_UNSUPPORTED;
+  FwdArgs p{enc, lde, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, R, slope, out, ldo, nullptr, list, count};
+  hipStream_t st = (hipStream_t)stream;
+#define L0_CALL(KK) launch_fwd<KK>(p, H, st)
+  L0_SWITCH(K, L0_CALL)
+#undef L0_CALL
+  return check_launch();
+}
+
+int dmp_l0_bwd_w_rows(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
+                      int64_t ldz, const int32_t *list, const int32_t *count, int64_t R, int H, float *partial, void *stream) {
+  if (R < 0 || K <= 0 || !partial || !list || !count) return DMP_ERR_BAD_ARG;
+  if ((H != 128 && H != 64) || K > kL0K) return DMP_ERR_UNSUPPORTED;
+  const int nacc = (dZn ? 3 : 2) * K;
+  if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)nacc * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!enc || !coef_e || !dPre || lde < K || ldd < H || (dZn && ldz < H)) return DMP_ERR_BAD_ARG;
+  if (ldd % 2 || ldz % 2 || !al8(dPre) || !al8(dZn) || !al8(partial)) return DMP_ERR_UNSUPPORTED;
+  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial, nullptr, list, count};
+  hipStream_t st = (hipStream_t)stream;
+#define L0_CALL(KK) launch_bwd<KK>(p, H, st)
   L0_SWITCH(K, L0_CALL)
 #undef L0_CALL
   return check_launch();
@@ -381,7 +488,7 @@ int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_
   if (R == 0) return hipMemsetAsync(partial, 0, sizeof(float) * (size_t)nacc * H, (hipStream_t)stream) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   if (!enc || !coef_e || !dPre || lde < K || ldd < H || (dZn && ldz < H)) return DMP_ERR_BAD_ARG;
   if (ldd % 2 || ldz % 2 || !al8(dPre) || !al8(dZn) || !al8(partial)) return DMP_ERR_UNSUPPORTED;
-  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial, rowmask};
+  BwdArgs p{enc, lde, coef_e, dPre, ldd, dZn, ldz, R, partial, rowmask, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
 #define L0_CALL(KK) launch_bwd<KK>(p, H, st)
   L0_SWITCH(K, L0_CALL)

@@ -784,6 +784,33 @@ def l0_pack(enc_p, enc_g, gate=None, stacked=False):
     return out
 
 
+USE_L0_ROW_LISTS = _os.environ.get("DMP_L0_ROW_LISTS", "1") == "1"
+L0_LIST_MIN_ROWS = 32768       # shorter row ranges (the pattern side) keep the masked form: the list costs two launches
+
+
+def kept_rows(mask, r0, r1):
+    """``(list int32 [r1 - r0], count int32 [1])``: the rows of ``[r0, r1)`` (r0 a multiple of 32) whose bit of ``mask`` is set, as
+    ids relative to r0, ascending (``dmp_kept_rows``); memoised on the mask tensor (the forward and the backward of a layer
+    share it)."""
+    memo = getattr(mask, "_dmp_kept_rows", None)
+    if memo is None:
+        memo = {}
+        try:
+            mask._dmp_kept_rows = memo
+        except Exception:
+            pass
+    hit = memo.get((r0, r1))
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    R = r1 - r0
+    out = torch.empty(R + 1 + int(lib.dmp_kept_rows_scratch_words(R)), dtype=torch.int32, device=mask.device)
+    lst, cnt, scratch = out[:R], out[R:R + 1], out[R + 1:]
+    check(lib.dmp_kept_rows(ptr(mask[r0 // 32:]), R, ptr(scratch), ptr(lst), ptr(cnt), stream_ptr()), "dmp_kept_rows")
+    memo[(r0, r1)] = (lst, cnt)
+    return lst, cnt
+
+
 def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None, mask=None):
     """``act(enc M[:, :H] + coef[dst] enc M[:, H:] + P[a, 0:H] - P[b, H:2H] + bias)`` -- ``edge_fwd_typed`` for input rows
     ``enc W`` of rank K with ``M = W Wes``: no class tiles, rows in their own order.  ``rows = (r0, r1)``: only that range
@@ -797,6 +824,13 @@ def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=
     sel_a, sel_b, coef_e = index.edge_select(coef)
     if mask is not None and r0 % 32 != 0:
         mask = None
+    if mask is not None and USE_L0_ROW_LISTS and r1 - r0 >= L0_LIST_MIN_ROWS:
+        lst, cnt = kept_rows(mask, r0, r1)
+        with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
+            check(lib.dmp_l0_edge_fwd_rows(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
+                                           ptr(sel_a[r0:]), ptr(sel_b[r0:]), ptr(lst), ptr(cnt), r1 - r0, H, slope, ptr(out[r0:]),
+                                           out.stride(0), stream_ptr()), "dmp_l0_edge_fwd_rows")
+        return out
     with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
         check(lib.dmp_l0_edge_fwd_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
                                          ptr(sel_a[r0:]), ptr(sel_b[r0:]), None if mask is None else ptr(mask[r0 // 32:]), r1 - r0, H,
@@ -817,6 +851,13 @@ def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None, mask=None):
     nacc = (3 if d_zn is not None else 2) * K
     G = int(lib.dmp_l0_bwd_w_blocks(r1 - r0))
     part = torch.empty((G, nacc * H), dtype=torch.float32, device=d_pre.device)
+    if mask is not None and USE_L0_ROW_LISTS and r1 - r0 >= L0_LIST_MIN_ROWS:
+        lst, cnt = kept_rows(mask, r0, r1)
+        with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
+            check(lib.dmp_l0_bwd_w_rows(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
+                                        ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0,
+                                        ptr(lst), ptr(cnt), r1 - r0, H, ptr(part), stream_ptr()), "dmp_l0_bwd_w_rows")
+        return reduce_partials(part, None if out is None else out.view(-1)).view(K, (nacc // K) * H)
     with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
         check(lib.dmp_l0_bwd_w_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
                                       ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0,
@@ -1357,8 +1398,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 XX = (torch.empty if full else torch.zeros)((TK, (3 if ctx.residual else 2) * H), dtype=torch.float32, device=dG.device)
                 for t, rows, _ in tables:
                     if rows[1] > rows[0]:
+                        # (the rows to add: those with a non-zero code row -- or, where dPre's rows under a zero gate were not
+                        # stored, the rows the gate keeps: the same list the forward walked; a kept row with a zero code adds zeros)
                         l0_bwd_w(l0.enc, K0, ix.edge_select(coef)[2], dG, dzn if ctx.residual else None, rows, XX[t * K0:(t + 1) * K0],
-                                 mask=getattr(l0, "enc_mask", None))
+                                 mask=(gate_row_mask(ctx.e_gate) if (getattr(l0, "enc_mask", None) is not None and binary_gate_mask(ctx.e_gate) is not None)
+                                       else getattr(l0, "enc_mask", None)))
                 dWes = None
             else:
                 # (dG = dPre has zero rows under a zero edge gate, whichever kernel made it: the typed kernels skip those edges)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 67
+#define DMP_ABI_VERSION 68
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -654,6 +654,18 @@ int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, cons
  * dmp_l0_pack made it), so its dPre / dZn rows -- which would be multiplied by those zeros -- are not fetched. */
 int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
                         int64_t ldz, const uint32_t *rowmask, int64_t R, int H, float *partial, void *stream);
+/* ... over a LIST of rows instead of the rows 0 .. R-1 (the kept rows of a 0 / 1 gate, dmp_kept_rows: ascending row ids, their number
+ * in device memory): a batch of rows is then kRows kept rows -- the masked forms spend a batch's slots on its dead rows too.
+ *   dmp_kept_rows: list [<= R] = the rows r < R whose bit (r & 31) of rowmask[r >> 5] is set, *count = how many;
+ *   scratch: dmp_kept_rows_scratch_words(R) int32 words. */
+int64_t dmp_kept_rows_scratch_words(int64_t R);
+int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int32_t *scratch, int32_t *list, int32_t *count, void *stream);
+int dmp_l0_edge_fwd_rows(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
+                         const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
+                         const int32_t *list, const int32_t *count, int64_t R, int H, float slope, float *out, int64_t ldo,
+                         void *stream);
+int dmp_l0_bwd_w_rows(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
+                      int64_t ldz, const int32_t *list, const int32_t *count, int64_t R, int H, float *partial, void *stream);
 
 /* BatchNorm1d in TRAINING mode over the rows of x [rows, C] with the activation that follows it fused in (the UNC layers'
  * MLPs: Linear -> BatchNorm1d -> LeakyReLU -> Linear, UNC model.py:145-157; torch.nn.BatchNorm1d semantics: biased variance

@@ -211,3 +211,46 @@ def test_a_model_the_fused_path_cannot_run_falls_back(gpu):
     (out["pred_c"] ** 2).sum().backward()
     assert all(th.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert th.is_tensor(out["g_e_rep"]) and out["g_e_rep"].shape[1] == cfg["hid"]
+
+
+@pytest.mark.parametrize("rows,r0,keep", [(70001, 0, 0.46), (548864, 24576, 0.46), (40000, 32, 0.0), (40000, 0, 1.0), (33000, 64, 0.5)])
+@pytest.mark.parametrize("k,h", [(10, 128), (16, 64)])
+def test_layer0_kernels_over_the_kept_rows_list(rows, r0, keep, k, h, gpu):
+    """``dmp_kept_rows`` (the rows of a range whose mask bit is set, ascending, counted on the device) against numpy, and the
+    list forms of the two layer-0 kernels against their masked forms: the same kept output rows (the others untouched), the
+    same sums up to their order; rows outside the list are never read (NaN there)."""
+    from dualmessagepassing_amd import fused
+    ix, coef, enc_p, enc_g, _, W, gen, n, _ = _case(rows, 0, k, h, False, rows + k + r0, gpu)
+    rng = np.random.default_rng(rows + r0)
+    g_np = (rng.random(rows) < keep).astype(np.float32)
+    gate = th.from_numpy(g_np).to(gpu)
+    mask = fused.gate_row_mask(gate)
+    lst, cnt = fused.kept_rows(mask, r0, rows)
+    want = np.nonzero(g_np[r0:])[0]
+    assert int(cnt.item()) == len(want) and np.array_equal(lst[:len(want)].cpu().numpy(), want)
+    encU = fused.l0_pack(enc_p, enc_g, gate)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    M = W @ wes
+    dead = gate == 0
+    saved = fused.USE_L0_ROW_LISTS
+    res = {}
+    for lists in (False, True):
+        fused.USE_L0_ROW_LISTS = lists
+        try:
+            out = th.full((rows, h), 7.5, device=gpu)
+            fused.l0_edge_fwd(encU, k, M, xp[:, h:], 3 * h, bias, coef, ix, 0.18, rows=(r0, rows), out=out, mask=mask)
+            d_pre = th.randn(rows, h, generator=th.Generator().manual_seed(5)).to(gpu)
+            d_zn = th.randn(rows, h, generator=th.Generator().manual_seed(6)).to(gpu)
+            d_pre[dead] = float("nan")
+            d_zn[dead] = float("nan")
+            xx = fused.l0_bwd_w(encU, k, ix.edge_select(coef)[2], d_pre, d_zn, rows=(r0, rows), mask=mask)
+        finally:
+            fused.USE_L0_ROW_LISTS = saved
+        res[lists] = (out, xx)
+    (o0, x0), (o1, x1) = res[False], res[True]
+    assert th.equal(o0, o1)                                           # kept rows: the same arithmetic; the others: the sentinel
+    assert bool((o1[r0:][dead[r0:]] == 7.5).all()) and bool((o1[:r0] == 7.5).all())
+    assert bool(th.isfinite(x1).all())
+    assert float((x1 - x0).abs().max()) <= 2e-5 * max(1.0, float(x0.abs().max()))
