@@ -339,7 +339,8 @@ def build_step(cfg, shard, device, world=1):
         E, N = ix.num_edges, ix.num_nodes
         Mrows = torch.randn(E, H, device=device)
         res = {}
-        for name, fn in (("fwd_us", lambda: _ops.seg_sum_raw(Mrows, ix.in_ptr, ix.in_ent, N, None, True, -1.0, 1.0)),
+        # (rows_shared=3: the same kernel code under its own name, so that a profile keeps these launches apart from the step's)
+        for name, fn in (("fwd_us", lambda: _ops.seg_sum_raw(Mrows, ix.in_ptr, ix.in_ent, N, None, True, -1.0, 1.0, rows_shared=3)),
                          ("bwd_us", lambda: _ops.endpoint_sums(Mrows, ix))):
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
             for i in range(launches + 2):
@@ -376,8 +377,8 @@ def build_step(cfg, shard, device, world=1):
 PROFILE_ROUND = "r04"
 # the two scatter-add launches as rocprofv3 names them; first the forms that leave out the rows a 0 / 1 edge gate wiped (what
 # the step runs under a ScalarFilter gate), then the forms that read every row
-SEG_IN = ("seg_sum_vec<32, true, true, true, 0, 256>",      # flag-split segment sum over the CSR by destination (forward), gate-weighted
-          "seg_sum_vec<32, true, false, true, 0, 256>")
+SEG_IN = ("seg_sum_vec<32, true, false, true, 0, 256>",     # flag-split segment sum over the CSR by destination (forward; under a 0 / 1 gate: over the kept edges' CSR)
+          "seg_sum_vec<32, true, true, true, 0, 256>")      # ... gate-weighted (DMP_KEEP_CSR=0)
 SEG_INC = ("seg_acc_graphs_k<128, true>",                    # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
            "seg_acc_graphs_k<128, false>", "seg_acc_graphs_k<128>")
 
@@ -1077,7 +1078,8 @@ def main():
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
             roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
                                 "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key]["bytes"],
-                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"], skipped, 4 * H)
+                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"], skipped,
+                                4 * H + (4 if _fused.USE_KEEP_CSR else 0))     # (over the kept edges' CSR: no index entry either)
         if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
             roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if "graphs" in key_inc
                                                     else "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints") +

@@ -50,6 +50,8 @@ SIGNATURES = {
     "dmp_class_tiles_segsum_words": (c_i64, [c_int]),
     "dmp_class_tiles_workspace_words": (c_size, [c_i64, c_int]),
     "dmp_class_tiles": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_csr_keep_scratch_words": (c_i64, [c_i64]),
+    "dmp_csr_keep": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_class_tiles_gated": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_scan_workspace_words": (c_size, [c_i64]),
     "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
@@ -209,7 +211,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 68
+ABI_VERSION = 69
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

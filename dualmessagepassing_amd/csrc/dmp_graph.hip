@@ -992,6 +992,58 @@ __global__ __launch_bounds__(kBlock) void ct_live_k(const int32_t *__restrict__ 
   row_cnt[v] = c;
 }
 
+// ---- the in-CSR of the edges a 0 / 1 gate keeps (dmp_csr_keep): (1) every node counts the kept entries of its row, every
+// block adds its nodes' counts up; (2) every block sums the block totals before it, ranks its nodes with a block scan, and
+// every node copies the kept entries of its row in order.  No atomics: the layout is a function of the inputs alone.
+__global__ __launch_bounds__(kBlock) void keep_count_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                       const float *__restrict__ gate, int64_t N, int32_t *__restrict__ row_cnt,
+                                                       int32_t *__restrict__ blk) {
+  __shared__ int red[kBlock / 64];
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int c = 0;
+  if (v < N) {
+    for (int q = in_ptr[v], hi = in_ptr[v + 1]; q < hi; ++q) c += gate[in_ent[q] >> 1] != 0.f;
+    row_cnt[v] = c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; blk[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kBlock) void keep_fill_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                      const float *__restrict__ gate, const int32_t *__restrict__ row_cnt,
+                                                      const int32_t *__restrict__ blk, int64_t N, int32_t *__restrict__ keep_ptr,
+                                                      int32_t *__restrict__ keep_ent) {
+  __shared__ int red[kBlock / 64], wtot[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) before += blk[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int i = 0; i < kBlock / 64; ++i) before += red[i];
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int c = v < N ? row_cnt[v] : 0;
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int s = before + incl - c;
+  for (int w = 0; w < wave; ++w) s += wtot[w];
+  if (v < N) {
+    keep_ptr[v] = s;
+    for (int q = in_ptr[v], hi = in_ptr[v + 1]; q < hi; ++q) {
+      const int e = in_ent[q];
+      if (gate[e >> 1] != 0.f) keep_ent[s++] = e;
+    }
+    if (v == N - 1) keep_ptr[N] = s;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
                                                     const int32_t *__restrict__ row_cnt,
                                                     int64_t N, int C, unsigned long long *cnt, int32_t *status) {
@@ -1790,6 +1842,21 @@ int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in
                     int32_t *num_tiles, void *stream) {
   return class_tiles_impl(deg, in_ptr, in_ent, nullptr, nullptr, N, E, num_classes, tiles_bound, ws, slot_edge, tile_scale, num_tiles,
                           stream);
+}
+
+int64_t dmp_csr_keep_scratch_words(int64_t N) { return N + (N + kBlock - 1) / kBlock + 1; }
+
+int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t N, int32_t *row_cnt, int32_t *keep_ptr,
+                 int32_t *keep_ent, void *stream) {
+  if (N < 0) return DMP_ERR_BAD_ARG;
+  if (!keep_ptr) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) return hipMemsetAsync(keep_ptr, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!in_ptr || !in_ent || !gate || !row_cnt || !keep_ent) return DMP_ERR_BAD_ARG;
+  int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block of kBlock nodes
+  keep_count_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, N, row_cnt, blk);
+  keep_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, row_cnt, blk, N, keep_ptr, keep_ent);
+  return check_launch();
 }
 
 int dmp_class_tiles_gated(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int32_t *row_cnt,

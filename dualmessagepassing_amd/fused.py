@@ -433,6 +433,35 @@ def live_tiles(index, coef, gate):
     return res
 
 
+USE_KEEP_CSR = _os.environ.get("DMP_KEEP_CSR", "1") == "1"
+
+
+def keep_in_csr(index, gate):
+    """``(keep_ptr, keep_ent)``: ``index``'s CSR by destination over the edges a 0 / 1 ``gate`` keeps (``dmp_csr_keep``), memoised
+    on the gate (the layers of a rep-net share it), or None."""
+    if gate is None or not USE_KEEP_CSR or not USE_ROW_MASKS or index.num_edges == 0:
+        return None
+    owner = _gate_owner(gate)
+    if getattr(owner, "_dmp_dense_gate", False) or not getattr(owner, "_dmp_binary", False):
+        return None
+    hit = getattr(owner, "_dmp_keep_csr", None)
+    if hit is not None and hit[0] == owner._version and hit[1] is index:
+        return hit[2]
+    lib = _lib.load()
+    N, dev = index.num_nodes, index.in_ptr.device
+    nscr = int(lib.dmp_csr_keep_scratch_words(N))
+    ws = torch.empty(nscr + N + 1 + index.in_ent.numel(), dtype=torch.int32, device=dev)
+    row_cnt, keep_ptr, keep_ent = ws[:nscr], ws[nscr:nscr + N + 1], ws[nscr + N + 1:]
+    check(lib.dmp_csr_keep(ptr(index.in_ptr), ptr(index.in_ent), ptr(gate.reshape(-1)), N, ptr(row_cnt), ptr(keep_ptr), ptr(keep_ent),
+                           stream_ptr()), "dmp_csr_keep")
+    res = (keep_ptr, keep_ent)
+    try:
+        owner._dmp_keep_csr = (owner._version, index, res)
+    except Exception:
+        pass
+    return res
+
+
 def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
@@ -1208,7 +1237,11 @@ class _FusedDMPLayer(torch.autograd.Function):
             S = None
         else:
             # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
-            S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, e_gate.reshape(-1) if zero_rows_gate(e_gate) else None, True, -1.0, 1.0)
+            kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
+            if kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
+                S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0)
+            else:
+                S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, e_gate.reshape(-1) if zero_rows_gate(e_gate) else None, True, -1.0, 1.0)
             SB = S @ Bn
         if l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 68
+#define DMP_ABI_VERSION 69
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -353,6 +353,14 @@ int dmp_class_tiles_gated(const int64_t *deg, const int32_t *in_ptr, const int32
                           int64_t num_nodes, int64_t num_edges, int num_classes, int64_t tiles_bound, int32_t *ws,
                           int32_t *slot_edge, float *tile_scale, int32_t *num_tiles, void *stream);
 
+/* The CSR by destination restricted to the edges a 0 / 1 edge gate keeps: keep_ptr [N + 1], keep_ent [<= entries of in_ent] (the
+ * kept entries of every row in their order, packed (eid << 1 | flag) as in in_ent), row_cnt [dmp_csr_keep_scratch_words(N)] scratch.  A segment sum over it
+ * (dmp_seg_sum2: the node aggregation of dmpnn.py:92,163) reads the kept rows only -- for summands that are zeros under a zero
+ * gate the same sums (x + 0 = x), without the skipped rows' entries in its instruction stream. */
+int64_t dmp_csr_keep_scratch_words(int64_t num_nodes);
+int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t num_nodes, int32_t *row_cnt,
+                 int32_t *keep_ptr, int32_t *keep_ent, void *stream);
+
 /* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
  * ws: scratch of dmp_scan_workspace_words(n) int64 words. */
 size_t dmp_scan_workspace_words(int64_t n);
@@ -375,7 +383,8 @@ int dmp_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out,
  *   (59 vs 70 us at E=524288, H=128).  0 = plain dispatch order: ~3 us faster for a cold,
  *   read-once stream.  The shipped host side passes 1.  2 = as 1, said of an incidence CSR (every
  *   row of M listed under two destinations): the same code as a separate kernel instantiation,
- *   so that per-kernel profiler statistics keep the two launch kinds apart.
+ *   so that per-kernel profiler statistics keep the two launch kinds apart.  3 (dmp_seg_sum2 without weights): as 1 under a
+ *   third kernel name -- for a measurement launch that a profile must keep apart from a step's own launches (bench.py).
  */
 int dmp_seg_sum(const float *M, int64_t ldm, const int32_t *rowptr,
                 const int32_t *ent, const float *edge_w, int64_t num_nodes,

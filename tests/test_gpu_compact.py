@@ -569,3 +569,34 @@ def test_masked_endpoint_sums_equal_the_plain_ones_without_reading_zero_rows(H):
     finally:
         ops.USE_GRAPH_SEG_SUM = saved
     assert th.equal(got2, ref)
+
+
+@pytest.mark.parametrize("B,max_n,max_e,keep", [(37, 20, 90, 0.46), (64, 64, 512, 0.4), (5, 2048, 9000, 0.5), (16, 12, 30, 0.0), (16, 12, 30, 1.0)])
+def test_in_csr_over_the_kept_edges(B, max_n, max_e, keep):
+    """``dmp_csr_keep``: the CSR by destination restricted to the edges a 0 / 1 gate keeps -- every row's kept entries in their
+    order, packed as in the whole CSR -- and the node aggregation over it equals the gate-weighted one bit for bit."""
+    from dualmessagepassing_amd import fused, ops
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(B + max_e)
+    graph = _random_batch(rng, B, max_n, max_e, gpu)[0]
+    ix = graph.index()
+    E, N = ix.num_edges, ix.num_nodes
+    g_np = (rng.random(E) < keep).astype(np.float32)
+    gate = th.from_numpy(g_np).to(gpu)
+    gate._dmp_binary = True
+    kp, ke = fused.keep_in_csr(ix, gate)
+    ptr_, ent_ = ix.in_ptr.cpu().numpy(), ix.in_ent.cpu().numpy()
+    want_ptr, want_ent = [0], []
+    for v in range(N):
+        row = [e for e in ent_[ptr_[v]:ptr_[v + 1]] if g_np[e >> 1] != 0]
+        want_ent += row
+        want_ptr.append(len(want_ent))
+    assert np.array_equal(kp.cpu().numpy(), np.array(want_ptr, np.int32))
+    assert np.array_equal(ke.cpu().numpy()[:len(want_ent)], np.array(want_ent, np.int32))
+    H = 128
+    M = th.randn(E, H, device=gpu) * gate[:, None]
+    Mp = M.clone()
+    Mp[gate == 0] = float("nan")
+    ref = ops.seg_sum_raw(M, ix.in_ptr, ix.in_ent, N, gate, True, -1.0, 1.0)
+    got = ops.seg_sum_raw(Mp, kp, ke, N, None, True, -1.0, 1.0)
+    assert th.equal(got, ref)
