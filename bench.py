@@ -154,7 +154,10 @@ def model_config(cfg):
                 pred_act_func=cfg.get("act", "leaky_relu"), pred_dropout=0.0, node_pred=True, edge_pred=True)
 
 
-def build_step(cfg, shard, device, world=1):
+def build_step(cfg, shard, device, world=1, collective=False):
+    """``collective``: run the N > 1 code path (async all-reduce, stream-ordered wait, software-pipelined index build)
+    whatever the world size -- ``--force-collective``: a one-rank RCCL group on a single GPU."""
+    multi = world > 1 or collective
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device_many
     from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
@@ -162,7 +165,7 @@ def build_step(cfg, shard, device, world=1):
 
     torch.manual_seed(0)
     model = build_model(**model_config(cfg)).to(device)
-    sync = FlatGradSync(model)
+    sync = FlatGradSync(model, force_collective=collective)
     master = sync.flatten_parameters()      # one AdamW launch over the flat buffer: the same elementwise update
     sync.broadcast_parameters()
     opt = FlatAdamW([master], lr=1e-4, weight_decay=1e-5, amsgrad=True,   # the reference's optimizer (train.py:1231)
@@ -178,7 +181,7 @@ def build_step(cfg, shard, device, world=1):
     ar_events = []    # (before, after) event pairs around the wait for the gradient sum: how long the compute stream stood still
 
     def timed_wait(fn):
-        if world > 1 and step.time_allreduce:
+        if multi and step.time_allreduce:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             fn()
@@ -249,7 +252,7 @@ def build_step(cfg, shard, device, world=1):
                 total.add_(sync.flat)
         sync.flat.copy_(total)
         pending.append(sync.sync(async_op=True))
-        if world == 1:
+        if not multi:
             finish()
         return loss
 
@@ -266,7 +269,7 @@ def build_step(cfg, shard, device, world=1):
         # The batch's structure work (collate above; CSR, incidence, degree classes, selectors here) does not depend on
         # the parameters: it is enqueued BEFORE the previous step's gradient sum is waited for, so with more than one
         # rank the all-reduce (on RCCL's stream) overlaps it instead of idling the compute stream.
-        if world > 1 and not model.gate_capacity:
+        if multi and not model.gate_capacity:
             prepare_joint(pattern, graph, cfg["hid"], class_tiles=not live_tiles_apply)
         finish()
         sync.detach_grads()
@@ -284,8 +287,8 @@ def build_step(cfg, shard, device, world=1):
         if all_outputs:
             del keep
         sync.pack()
-        pending.append(sync.sync(async_op=True))              # None at world size 1
-        if world == 1:
+        pending.append(sync.sync(async_op=True))              # None at world size 1 (unless the collective is forced)
+        if not multi:
             finish()
         return loss
 
@@ -745,6 +748,10 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=1, metavar="W",
                     help="testing aid (one process): the batch is the shards of ranks 0..W-1 back to back -- the global batch "
                          "of a W-rank run")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: form a ONE-rank nccl (RCCL) process group on this GPU and run the N > 1 code path -- "
+                         "replayed front, sync.sync(async_op=True), the next batch's prepare_joint, sync.finish (stream-ordered "
+                         "Work.wait), AdamW -- so that the path the 8-GPU run takes has executed on RCCL.  No scaling claim.")
     ap.add_argument("--spawn-check", action="store_true",
                     help="testing aid (runs without a GPU): start the ranks, form the process group, count them with an "
                          "all-reduce and print a line with n_gpus / ranks_seen and value null -- no step is run")
@@ -773,7 +780,9 @@ def main():
             sys.exit(3)
         print(json.dumps({"value": 1.0, "config": {"launch": "graph" if args.graph else "eager"}}), flush=True)
         return
-    if ("WORLD_SIZE" not in os.environ and args.gpus == 1 and not (args.graph or args.eager or args.spawn_check)
+    if args.force_collective and args.gpus != 1:
+        raise SystemExit("bench.py: --force-collective is the one-rank form of the N > 1 path (--gpus 1)")
+    if ("WORLD_SIZE" not in os.environ and args.gpus == 1 and not (args.graph or args.eager or args.spawn_check or args.force_collective)
             and not os.environ.get("DMP_BENCH_CHILD")):
         # N = 1, no mode asked for: the step replayed from one HIP graph (how harness.fit(graph=True) trains), in a child
         # process -- a recording that fails takes its process with it -- and eager launches in a second child if it does.
@@ -801,8 +810,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_collective
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -812,7 +827,7 @@ def main():
     # ~5 ms of host time per step and rank, as much as the device time: N Python launchers on one host would set the curve),
     # all-reduce and optimizer update launched eagerly behind every replay; a recording that RAISES on any rank sends all
     # ranks back to eager launches (agreed by an all-reduce after the warm-up)
-    auto_graph = world > 1 and not (args.graph or args.eager)
+    auto_graph = multi and not (args.graph or args.eager)
     if auto_graph:
         args.graph = True
     cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
@@ -827,7 +842,7 @@ def main():
         cfg = dict(cfg, batch=cfg["batch"] * args.emulate_world)
     else:
         shard = make_shard(cfg, rank, device)
-    step, model = build_step(cfg, shard, device, world)
+    step, model = build_step(cfg, shard, device, world, collective=args.force_collective)
     if args.dump_grad:
         step.front()
         step.sync.sync()                                       # the ranks' average (nothing at world size 1)
@@ -836,15 +851,15 @@ def main():
             torch.save({"flat": step.sync.flat.detach().cpu(), "pred_c": step.last_pred_c.cpu(), "world": world,
                         "batch": cfg["batch"]}, args.dump_grad)
     initial_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1
-                                                                                              and not args.no_cpu_baseline) else None
+                                                                                              and not multi and not args.no_cpu_baseline) else None
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     run, graphed = step, False
-    if args.graph and world == 1 and step.micro_batches == 1:
+    if args.graph and not multi and step.micro_batches == 1:
         # the step reads the shard's tensors and clones the size / flag tensors itself: a replay rebuilds every index
         # of the batch on the device exactly as an eager step does
         from dualmessagepassing_amd.dp import StepGraph
@@ -852,7 +867,7 @@ def main():
         # (``run("gate")``: the step with the gate capacity set -- the model's state at recording time is part of it)
         run = StepGraph(lambda *m: step(all_outputs="all" in m), optimizer=step.opt, max_shapes=3)
         graphed = True
-    elif args.graph and world > 1 and step.micro_batches == 1:
+    elif args.graph and multi and step.micro_batches == 1:
         # more than one rank: forward + backward + gradient pack replayed from one HIP graph per rank, the gradient
         # all-reduce and the optimizer update launched eagerly after every replay (no collective inside a recording)
         from dualmessagepassing_amd.dp import StepGraph
@@ -884,7 +899,7 @@ def main():
         run()
     step.finish()
     launch_fallback = os.environ.get("DMP_BENCH_FALLBACK_NOTE")
-    if graphed and world > 1:
+    if graphed and multi:
         ok = torch.tensor([1 if graph_state["ok"] else 0], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:                                # some rank could not record: every rank launches eagerly
@@ -971,7 +986,7 @@ def main():
         eager_ms = (time.perf_counter() - te) / max(args.steps, 1) * 1e3
         kern = _lib.timer.summary()
     all_ms = None
-    if world == 1 and step.micro_batches == 1 and not args.no_all_outputs:
+    if not multi and step.micro_batches == 1 and not args.no_all_outputs:
         # the same step with every entry of the output dictionary formed (the reference returns all 15 as tensors,
         # basemodel.py:1645-1661): the last layer's edge rows built by the layer itself (lazy_edge_rep off), the target
         # embeddings read -- same launch mode as the timed region, reported beside the headline, never as `value`
@@ -988,7 +1003,7 @@ def main():
         barrier()
         all_ms = (time.perf_counter() - ta) / max(args.steps, 1) * 1e3
     gate_line = None
-    if world == 1 and step.micro_batches == 1 and not args.gate_compact and not args.no_gate_compact:
+    if not multi and step.micro_batches == 1 and not args.gate_compact and not args.no_gate_compact:
         # the same step with the rep-net on the target edges the filter gate keeps (model.set_gate_capacity): same outputs
         # (tests/test_gpu_compact.py, test_gpu_bench_composite.py), a share of the edge rows that depends on the labels --
         # same launch mode as the timed region, reported beside the headline, never as `value`
@@ -1039,7 +1054,7 @@ def main():
 
     ranks_seen, devices = 1, [torch.cuda.get_device_name(device)]
     per_rank = [mine]
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -1086,7 +1101,7 @@ def main():
                                     "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
                                     4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"],
                                     skipped if "graphs" in key_inc else 0, 4 * H)
-        if skipped and world == 1:
+        if skipped and not multi:
             # ... and the same two launches over ALL rows (no mask, no weights): the kernels as they run without a 0 / 1 gate,
             # timed stand-alone on this step's index -- so that the fraction of the unmasked kernels stays on record
             plain = step.plain_scatter_adds(H)
@@ -1100,7 +1115,9 @@ def main():
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
-            "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+            "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if multi else None,
+            # --force-collective: the N > 1 code path on a one-rank process group (what ran, not a scaling figure)
+            "collective_forced": bool(args.force_collective),
             "devices": devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             # device time per step between consecutive per-step event records on rank 0 (min / median / max)
@@ -1110,7 +1127,7 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # how the timed steps were launched, and the other mode's / the all-outputs step's time beside it
-            "launch_mode": ("hip_graph_replay" if world == 1 else "hip_graph_replay_front+eager_allreduce_adamw") if graphed else "eager",
+            "launch_mode": ("hip_graph_replay" if not multi else "hip_graph_replay_front+eager_allreduce_adamw") if graphed else "eager",
             "launch_fallback": launch_fallback,
             "eager_ms_per_step": round(eager_ms, 3) if eager_ms is not None else None,
             "all_outputs_ms_per_step": round(all_ms, 3) if all_ms is not None else None,
@@ -1129,7 +1146,7 @@ def main():
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",
                        "gemm_solutions": "tuned (TunableOp file)" if tuned else "library default",
-                       "launch": (("one HIP graph replay per step" if world == 1 else
+                       "launch": (("one HIP graph replay per step" if not multi else
                                    "forward + backward + gradient pack as one HIP graph replay per rank and step, all-reduce and "
                                    "optimizer update launched eagerly")
                                   + " (recorded during the warm-up; the roofline kernel's HIP-event time "
@@ -1155,7 +1172,7 @@ def main():
         }
         line["launcher"] = ("bench.py (self-spawned ranks)" if os.environ.get("DMP_BENCH_SPAWNED") else
                             "external (torch.distributed.run)") if world > 1 else "single process"
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, initial_state)
             # the same CPU step at the GPU line's batch size (B = 1024 pairs; at most 2 steps, no warm-up step): the
             # B = 32 sample above is the reference's own CPU-runnable batch size, this one is the like-for-like size
@@ -1167,7 +1184,7 @@ def main():
             if room and args.workload == 2:
                 line["cpu_baseline_b1024"] = cpu_baseline(cfg, initial_state, seconds_budget=12.0, B=cfg["batch"], max_steps=2, warm=False)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,9 +33,12 @@ class FlatGradSync:
     Use ``zero()`` instead of ``optimizer.zero_grad()`` (which would drop the views).
     """
 
-    def __init__(self, module, group=None, average=True):
+    def __init__(self, module, group=None, average=True, force_collective=False):
+        """``force_collective``: issue the all-reduce / broadcast on a ONE-rank process group too (a one-rank RCCL group on
+        a single GPU runs the code path of the N > 1 step: ``bench.py --force-collective``)."""
         self.group = group
         self.average = average
+        self.force_collective = bool(force_collective)
         seen, params = set(), []
         for p in module.parameters():  # shared modules (share_rep_net) appear once
             if p.requires_grad and id(p) not in seen:
@@ -173,7 +176,7 @@ class FlatGradSync:
                    "dmp_pack_segments")
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.world > 1 or (self.force_collective and dist.is_available() and dist.is_initialized()):
             if getattr(self, "master", None) is not None:
                 dist.broadcast(self.master.data, src=src, group=self.group)
                 return
@@ -186,7 +189,7 @@ class FlatGradSync:
         applies the average -- whatever is enqueued in between (the next batch's collate and index build, which do not
         depend on the parameters) overlaps the collective."""
         w = self.world
-        if w == 1:
+        if w == 1 and not (self.force_collective and dist.is_available() and dist.is_initialized()):
             return None
         if async_op:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -231,6 +234,11 @@ class FlatAdamW(torch.optim.Optimizer):
         (``GraphAdjModelV2.set_gate_capacity``: a batch that kept more edges than the capacity ORs bit 0 -- its gradients
         are wrong).  A dropped step leaves parameters, moments and the step count alone; ``word[3]`` counts them.  No
         host sync, so it replays; the step count then lives on the device whether or not ``capturable`` was asked for."""
+        if word is not None and sum(len(g["params"]) for g in self.param_groups) != 1:
+            # the veto word is consumed (flags cleared, drop latched) by the ONE launch of the one parameter tensor: with
+            # several tensors the first launch would clear it and the others would apply the flagged gradients
+            raise ValueError("FlatAdamW.set_veto: the optimizer must hold exactly one (flat) parameter tensor, "
+                             "FlatGradSync.flatten_parameters()")
         self.veto = None if word is None else (word, int(mask))
         return self
 
@@ -306,6 +314,8 @@ class FlatAdamW(torch.optim.Optimizer):
         from . import _lib
         loss = closure() if closure is not None else None
         lib = _lib.load()
+        if self.veto is not None and sum(len(g["params"]) for g in self.param_groups) != 1:      # (add_param_group after set_veto)
+            raise ValueError("FlatAdamW: a veto word needs exactly one (flat) parameter tensor")
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

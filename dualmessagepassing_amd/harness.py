@@ -619,9 +619,13 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     gate keeps (``model.set_gate_capacity``; capacity = the largest kept count of up to eight training batches x the margin).
     A batch that keeps more than that raises a device flag and the optimizer drops its step (``FlatAdamW.set_veto``, as a
     loss-scaling optimizer drops an overflowed step); the history counts them (``dropped_steps``).  Evaluation passes run
-    on every edge row."""
+    on every edge row.  Single rank only (the veto is rank-local: refused with a multi-rank ``sync``)."""
     from . import dataio
     from .tuning import enable_tuned_gemms
+    if train_kw.get("gate_compact") and getattr(sync, "world", 1) > 1:
+        # the overflow flag and the capacity are rank-local: a rank whose batch overflowed would still feed its (wrong)
+        # gradients to the all-reduce and only IT would drop the step -- the replicas would drift apart for good
+        raise ValueError("fit(gate_compact=...) is a single-rank option: the overflow veto is rank-local (world size %d)" % sync.world)
     validate_samples(train_set)
     validate_samples(dev_set)
     enable_tuned_gemms()      # the layer's [rows, 128] x [128, 128..384] products with the solutions picked for MI355X

@@ -147,3 +147,37 @@ def test_flattened_parameters_step_like_per_parameter_adamw():
         assert torch.equal(p.data, q.data)
         assert q.data.data_ptr() >= master.data.data_ptr()
     assert master.grad is s2.flat
+
+
+def _one_rank_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x, y = _data()
+        res = []
+        for force in (False, True):
+            model = Tiny()
+            sync = FlatGradSync(model, force_collective=force)
+            sync.broadcast_parameters(src=0)
+            sync.zero()
+            torch.nn.functional.mse_loss(model(x), y).backward()
+            work = sync.sync(async_op=True)
+            res.append((work is not None, sync.flat.clone()))
+            sync.finish(work)
+            res[-1] = res[-1] + (sync.flat.clone(),)
+        out[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collective_on_a_one_rank_group_is_the_identity():
+    """``FlatGradSync(force_collective=True)`` on a ONE-rank group (what ``bench.py --force-collective`` does over RCCL on a
+    single GPU): the all-reduce is issued (a work handle comes back), ``finish`` waits and averages over one rank, and the
+    flat gradient is what the collective-free object holds."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    (issued0, before0, after0), (issued1, before1, after1) = out[0]
+    assert issued0 is False and issued1 is True
+    assert torch.equal(before0, after0) and torch.equal(before1, after1) and torch.equal(after0, after1)

@@ -94,3 +94,28 @@ def test_two_ranks_on_the_scaling_workload_default_mode_and_their_gradient(gpu, 
     assert th.equal(a["pred_c"].view(-1), b["pred_c"].view(-1)[:64]) or float((a["pred_c"].view(-1) - b["pred_c"].view(-1)[:64]).abs().max()) <= 1e-4 * max(1.0, float(b["pred_c"].abs().max()))
     scale = float(b["flat"].abs().max())
     assert scale > 0 and float((a["flat"] - b["flat"]).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("mode", ["default", "--eager"])
+def test_one_rank_rccl_group_runs_the_multi_rank_path(gpu, mode, tmp_path):
+    """`bench.py --gpus 1 --force-collective` forms a ONE-rank nccl (= RCCL) process group on the single
+    GPU and runs the code path of the N > 1 step -- default mode: StepGraph(front) replayed next to RCCL's stream, then the
+    all-reduce and AdamW launched eagerly; --eager: sync.sync(async_op=True) -> the next batch's prepare_joint ->
+    sync.finish (stream-ordered Work.wait) -> AdamW.  One rank: the all-reduce is the identity, so the step must equal the
+    collective-free step -- the gradient dump of the forced run equals the plain run's bit for bit.  No scaling claim."""
+    import torch as th
+    flags = ["--force-collective", "--no-cpu-baseline", "--extended-steps", "0"] + ([] if mode == "default" else [mode])
+    forced = str(tmp_path / "forced.pt")
+    d = _run(*flags, "--dump-grad", forced)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["backend"] == "nccl (RCCL)" and d["collective_forced"] is True
+    assert d["value"] > 0 and abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    if mode == "default":
+        assert d["launch_mode"] == "hip_graph_replay_front+eager_allreduce_adamw" and d["launch_fallback"] is None
+    else:
+        assert d["launch_mode"] == "eager"
+    pr = d["per_rank"][0]
+    assert pr["rank"] == 0 and pr["allreduce_wait_ms"] is not None and pr["allreduce_wait_ms"] >= 0.0    # the wait was timed: the collective ran
+    plain = str(tmp_path / "plain.pt")
+    _run("--eager", "--no-cpu-baseline", "--extended-steps", "0", "--no-all-outputs", "--no-gate-compact", "--dump-grad", plain)
+    a, b = th.load(forced), th.load(plain)
+    assert th.equal(a["flat"], b["flat"]) and th.equal(a["pred_c"], b["pred_c"])

@@ -138,3 +138,30 @@ def test_link_file_round_trip(tmp_path):
     lines = out.read_text().splitlines()
     assert lines[0] == "args" and lines[1].split("\t")[0] == "2" and lines[1].split("\t")[1].split() == ["0.5", "1.0"]
     assert lines[2].startswith("0\t2.0 -1.0")
+
+
+def test_gate_compact_is_refused_under_data_parallelism():
+    """the gate-compaction overflow veto is rank-local -- with a multi-rank gradient sync the overflowing rank's
+    wrong gradients would still be all-reduced into every replica.  ``fit`` refuses the combination before touching data."""
+    import pytest
+    from dualmessagepassing_amd import harness
+
+    class TwoRanks:
+        world = 2
+
+    with pytest.raises(ValueError, match="single-rank"):
+        harness.fit(None, None, [], [], 1, 4, "cpu", sync=TwoRanks(), gate_compact=True)
+
+
+def test_veto_word_needs_one_flat_parameter():
+    """the veto word is consumed by the launch of ONE parameter tensor; with several, the first launch would
+    clear it and the others would apply the flagged gradients.  ``set_veto`` refuses such an optimizer."""
+    import pytest
+    import torch
+    from dualmessagepassing_amd.dp import FlatAdamW
+    a, b = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
+    word = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(ValueError, match="exactly one"):
+        FlatAdamW([a, b]).set_veto(word)
+    opt = FlatAdamW([a]).set_veto(word)
+    assert opt.veto is not None and FlatAdamW([a, b]).set_veto(None).veto is None
