@@ -73,7 +73,8 @@ SIGNATURES = {
     "dmp_seg_sum2_graphs": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                     c_ptr, c_i64, c_ptr]),
     "dmp_seg_sum2_graphs_masked": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
-                                           c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+                                           c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "dmp_seg_sum2_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_seg_sum2_tiled": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                    c_ptr, c_i64, c_ptr]),
     "dmp_gather_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
@@ -131,6 +132,7 @@ SIGNATURES = {
     "dmp_adamw_step_guarded": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                        c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr]),
     "dmp_edge_select_build": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_edge_select_nodes": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_edge_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_edge_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -179,13 +181,13 @@ SIGNATURES = {
     "dmp_bwd_h1_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_f32, c_ptr,
                                       c_i64, c_ptr, c_ptr, c_ptr]),
     "dmp_kept_rows_scratch_words": (c_i64, [c_i64]),
-    "dmp_kept_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_kept_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_l0_edge_fwd_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
                                      c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_l0_bwd_w_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_typed_partial_rows": (c_i64, [c_i64, c_int]),
-    "dmp_out_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
-                                  c_i64, c_ptr]),
+    "dmp_out_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32,
+                                  c_ptr, c_i64, c_ptr]),
     "dmp_bwd_h1_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
@@ -211,7 +213,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 69
+ABI_VERSION = 70
 # DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
 # lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this switch)

@@ -347,6 +347,9 @@ __global__ __launch_bounds__(kKeptWords) void kept_count_k(const uint32_t *__res
   __syncthreads();
   if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < kKeptWords / 64; ++i) t += red[i]; blk[blockIdx.x] = t; }
 }
+// TILES: the list doubles as a slot list of 32-row tiles for the tile kernels (csrc/dmp_typed.hip): the entries from *count up
+// to the next multiple of 32 are set to -1 (padding slots) and count[1] = the number of tiles, (*count + 31) / 32.
+template <bool TILES>
 __global__ __launch_bounds__(kKeptWords) void kept_fill_k(const uint32_t *__restrict__ mask, int64_t R, const int32_t *__restrict__ blk,
                                                            int32_t *__restrict__ list, int32_t *__restrict__ count) {
   __shared__ int red[kKeptWords / 64], wtot[kKeptWords / 64];
@@ -373,7 +376,13 @@ __global__ __launch_bounds__(kKeptWords) void kept_fill_k(const uint32_t *__rest
   for (int i = 0; i < wave; ++i) pos += wtot[i];
   const int base = (int)(w * 32);
   while (m) { const int b = __builtin_ctz(m); m &= m - 1; list[pos++] = base + b; }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kKeptWords - 1) *count = pos;   // (the last thread's pos: everything before it + its own)
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kKeptWords - 1) {   // (the last thread's pos: everything before it + its own)
+    *count = pos;
+    if (TILES) {
+      for (int i = pos; i < ((pos + 31) & ~31); ++i) list[i] = -1;
+      count[1] = (pos + 31) >> 5;
+    }
+  }
 }
 
 #define L0_SWITCH(K, CALL)                                                                          \
@@ -429,15 +438,16 @@ int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M,
 
 int64_t dmp_kept_rows_scratch_words(int64_t R) { return ((R + 31) / 32 + kKeptWords - 1) / kKeptWords + 1; }
 
-int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int32_t *scratch, int32_t *list, int32_t *count, void *stream) {
+int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int tiles, int32_t *scratch, int32_t *list, int32_t *count, void *stream) {
   if (R < 0 || !count) return DMP_ERR_BAD_ARG;
-  if (R >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+  if (R >= ((int64_t)1 << 31) - 32) return DMP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (R == 0) return hipMemsetAsync(count, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (R == 0) return hipMemsetAsync(count, 0, (tiles ? 2 : 1) * sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   if (!rowmask || !scratch || !list) return DMP_ERR_BAD_ARG;
   const unsigned nb = (unsigned)(((R + 31) / 32 + kKeptWords - 1) / kKeptWords);
   kept_count_k<<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch);
-  kept_fill_k<<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch, list, count);
+  if (tiles) kept_fill_k<true><<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch, list, count);
+  else kept_fill_k<false><<<nb, kKeptWords, 0, st>>>(rowmask, R, scratch, list, count);
   return check_launch();
 }
 

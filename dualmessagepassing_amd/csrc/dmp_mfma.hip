@@ -610,6 +610,21 @@ __global__ void edge_select_k(const int32_t *src, const int32_t *dst, const uint
   coefE[e] = coef[v];
 }
 
+// the selectors with the nodes under a zero of a 0 / 1 node gate replaced by -1 (an index no descriptor holds: the tile
+// kernels' gathers of such a node's row return zeros without touching memory), and the destination likewise
+__global__ void edge_select_nodes_k(const int32_t *src, const int32_t *dst, const uint8_t *flag, const uint32_t *nodemask,
+                                    int64_t E, int32_t *selA, int32_t *selB, int32_t *dstM) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int u = src[e], v = dst[e];
+  if (!((nodemask[u >> 5] >> (u & 31)) & 1u)) u = -1;
+  if (!((nodemask[v >> 5] >> (v & 31)) & 1u)) v = -1;
+  const bool f = flag && flag[e];
+  selA[e] = f ? u : v;
+  selB[e] = f ? v : u;
+  dstM[e] = v;
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -624,6 +639,16 @@ int dmp_edge_select_build(const int32_t *src, const int32_t *dst, const uint8_t 
   if (!src || !dst || !coef || !selA || !selB || !coefE) return DMP_ERR_BAD_ARG;
   edge_select_k<<<(unsigned)((E + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(src, dst, flag, coef, E, selA,
                                                                                          selB, coefE);
+  return check_launch();
+}
+
+int dmp_edge_select_nodes(const int32_t *src, const int32_t *dst, const uint8_t *flag, const uint32_t *nodemask, int64_t E,
+                          int32_t *selA, int32_t *selB, int32_t *dstM, void *stream) {
+  if (E < 0) return DMP_ERR_BAD_ARG;
+  if (E == 0) return DMP_OK;
+  if (!src || !dst || !nodemask || !selA || !selB || !dstM) return DMP_ERR_BAD_ARG;
+  edge_select_nodes_k<<<(unsigned)((E + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(src, dst, flag, nodemask, E, selA,
+                                                                                               selB, dstM);
   return check_launch();
 }
 

@@ -71,11 +71,15 @@ struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, 
 // MASKED: bit (e & 31) of rowmask[e >> 5] clear = row e of M is known to be all zeros (the gradient rows a 0 / 1 edge gate
 // wiped, dmp_row_mask_bits): such a row is requested past the end of its descriptor -- the load returns zeros without
 // memory traffic, the instruction stream is the same.
-template <int H, bool MASKED = false>
+// NODES: bit (v & 31) of nodemask[v >> 5] clear = node row v of `out` is DEAD (a node under a zero of a 0 / 1 node gate: its
+// gradient row is multiplied by that zero further down): not stored -- the store goes through a descriptor of zero records;
+// the caller's selectors route such a node's addends to the trash register (dmp_edge_select_nodes: -1).
+template <int H, bool MASKED = false, bool NODES = false>
 __global__ __launch_bounds__(H) void seg_acc_graphs_k(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ selA, const int32_t *__restrict__ selB,
     const GraphTiles ts, float s0, float s1, float *__restrict__ out, int64_t ldo,
-    const uint32_t *__restrict__ rowmask = nullptr, int64_t mask_words = 0) {
+    const uint32_t *__restrict__ rowmask = nullptr, int64_t mask_words = 0,
+    const uint32_t *__restrict__ nodemask = nullptr, int64_t node_words = 0) {
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
   // the tile: graphs [g0, g1)
@@ -161,11 +165,23 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
     }
   }
   // the sums: 256 contiguous bytes per store instruction (this wave's columns of one node row and half)
-  const rsrc_t rsO = make_rsrc(out + n0 * ldo, tile_bytes(nodes, ldo, 2 * H));
+  const uint32_t bytesO = tile_bytes(nodes, ldo, 2 * H);
+  const rsrc_t rsO = make_rsrc(out + n0 * ldo, bytesO);
   const uint32_t orow = (uint32_t)(ldo * 4);
+  // the kept bits of the tile's 64 node rows (wave-uniform: scalar loads; word indices clamped to the mask's last word --
+  // what they say about rows past the tile's last node is not used, those stores fall outside the descriptor anyway)
+  uint32_t nm0 = 0xffffffffu, nm1 = 0xffffffffu;
+  if (NODES) {
+    const int w = (int)(n0 >> 5), sh = (int)(n0 & 31), wl = (int)node_words - 1;
+    const uint32_t q0 = nodemask[min(w, wl)], q1 = nodemask[min(w + 1, wl)], q2 = nodemask[min(w + 2, wl)];
+    nm0 = (uint32_t)(((((uint64_t)q1) << 32) | q0) >> sh);
+    nm1 = (uint32_t)(((((uint64_t)q2) << 32) | q1) >> sh);
+  }
   auto put = [&](int node, float a, float b) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a * s0), rsO, (int)voff, (int)((uint32_t)node * orow), 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b * s1), rsO, (int)(voff + H * 4), (int)((uint32_t)node * orow), 0);
+    const uint32_t live = NODES ? (((node < 32 ? nm0 : nm1) >> (node & 31)) & 1u) : 1u;
+    const rsrc_t rs = NODES ? make_rsrc(out + n0 * ldo, live ? bytesO : 0u) : rsO;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a * s0), rs, (int)voff, (int)((uint32_t)node * orow), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b * s1), rs, (int)(voff + H * 4), (int)((uint32_t)node * orow), 0);
   };
 #pragma unroll
   for (int i = 0; i < 32; ++i) put(i, A0[i], B0[i]);
@@ -184,7 +200,8 @@ int dmp_seg_sum2_graphs_max_nodes(void) { return kAccNodes; }
 
 static int seg_sum2_graphs_impl(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
                                 const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
-                                float *out, int64_t ldo, const uint32_t *rowmask, int64_t mask_words, void *stream) {
+                                float *out, int64_t ldo, const uint32_t *rowmask, int64_t mask_words, void *stream,
+                                const uint32_t *nodemask = nullptr, int64_t node_words = 0) {
   if (Ba < 0 || Bb < 0 || H <= 0 || ldm < H || ldo < 2 * H || (Ba > 0 && ka < 1) || (Bb > 0 && kb < 1)) return DMP_ERR_BAD_ARG;
   if (Ba + Bb == 0) return DMP_OK;
   if (!M || !sel_a || !sel_b || !node_off || !edge_off || !out) return DMP_ERR_BAD_ARG;
@@ -194,7 +211,10 @@ static int seg_sum2_graphs_impl(const float *M, int64_t ldm, const int32_t *sel_
   GraphTiles ts{node_off, edge_off, Ba, Bb, ka > 0 ? ka : 1, kb > 0 ? kb : 1};
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = (unsigned)tiles;
-  if (rowmask) {
+  if (rowmask && nodemask) {
+    if (H == 128) seg_acc_graphs_k<128, true, true><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words, nodemask, node_words);
+    else seg_acc_graphs_k<64, true, true><<<nb, 64, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words, nodemask, node_words);
+  } else if (rowmask) {
     if (H == 128) seg_acc_graphs_k<128, true><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words);
     else seg_acc_graphs_k<64, true><<<nb, 64, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo, rowmask, mask_words);
   } else if (H == 128) seg_acc_graphs_k<128><<<nb, 128, 0, st>>>(M, ldm, sel_a, sel_b, ts, s0, s1, out, ldo);
@@ -210,10 +230,11 @@ int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const
 
 int dmp_seg_sum2_graphs_masked(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b, const int64_t *node_off,
                                const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb, int H, float s0, float s1,
-                               float *out, int64_t ldo, const uint32_t *rowmask, int64_t num_rows, void *stream) {
-  if (!rowmask || num_rows < 0) return DMP_ERR_BAD_ARG;
+                               float *out, int64_t ldo, const uint32_t *rowmask, int64_t num_rows, const uint32_t *nodemask,
+                               int64_t num_nodes, void *stream) {
+  if (!rowmask || num_rows < 0 || (nodemask && num_nodes <= 0)) return DMP_ERR_BAD_ARG;
   return seg_sum2_graphs_impl(M, ldm, sel_a, sel_b, node_off, edge_off, Ba, Bb, ka, kb, H, s0, s1, out, ldo, rowmask,
-                              (num_rows + 31) / 32, stream);
+                              (num_rows + 31) / 32, stream, nodemask, nodemask ? (num_nodes + 31) / 32 : 0);
 }
 
 }  // extern "C"

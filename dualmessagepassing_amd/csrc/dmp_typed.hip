@@ -47,6 +47,7 @@ struct TypedArgs {
   const int32_t *rmap; int64_t rowsR;   // TEPI_DZ: R is a [rowsR, ldr] table, row rmap[e] (< 0: zero) for edge e; NULL: row e
   float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
   float slope;                          // TEPI_EDGE / TEPI_H1: negative slope of the activation (0 = ReLU)
+  int act;                              // TEPI_OUT: != 0: the activation (slope) is applied to the output row
   float *partial;                       // TEPI_H1: [gridDim.x, H] column sums of dPre per workgroup
   float *partialA;                      // TEPI_H1, optional: [gridDim.x, H] column sums of the fetched rows of A
 };
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((EPI == TEPI_EDGE || EPI == TEPI_OUT) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
+  const bool act_out = EPI == TEPI_OUT && __builtin_amdgcn_readfirstlane(p.act) != 0;
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
   // rows of the big arrays are addressed by INDEX (structured descriptors: any array size, dmp_mfma_common.h)
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       } else if (EPI == TEPI_OUT) {                          // as dmp_mfma.hip's EPI_GATE_RES with gate 1: (product + bias) + residual
         v.x = (v.x + bias4.x) + g1[k].x; v.y = (v.y + bias4.y) + g1[k].y;
         v.z = (v.z + bias4.z) + g1[k].z; v.w = (v.w + bias4.w) + g1[k].w;
+        if (act_out) { v.x = act_fwd(v.x, slope); v.y = act_fwd(v.y, slope); v.z = act_fwd(v.z, slope); v.w = act_fwd(v.w, slope); }
       } else if (EPI == TEPI_H1) {                           // padding rows: the activation reads as 0, the product is 0 -> 0
         v.x = act_bwd(g1[k].x, v.x, slope); v.y = act_bwd(g1[k].y, v.y, slope);
         v.z = act_bwd(g1[k].z, v.z, slope); v.w = act_bwd(g1[k].w, v.w, slope);
@@ -584,15 +587,16 @@ static int rows_typed_check(const float *A, int64_t lda, const float *W, int64_t
 
 int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
                       int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
-                      int64_t E, int H, float *out, int64_t ldo, void *stream) {
+                      int64_t E, int H, int act, float slope, float *out, int64_t ldo, void *stream) {
   if (E == 0) return (E < 0) ? DMP_ERR_BAD_ARG : DMP_OK;
+  if (act && !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
   const int rc = rows_typed_check(Hin, ldh, W2, ldw, R, ldr, out, ldo, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
   if (rc != DMP_OK) return rc;
   if (bias && !aligned16(bias)) return DMP_ERR_UNSUPPORTED;
   TypedArgs p{};
   p.A = Hin; p.lda = ldh; p.W = W2; p.ldw = ldw; p.transposed = w_in_out ? 0 : 1;   // [in, out]: B[k][j] = W2[k][j]; nn.Linear's [out, in]: W2[j][k]
   p.C = out; p.ldc = ldo; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
-  p.num_tiles = num_tiles; p.bias = bias; p.R = R; p.ldr = R ? ldr : H; p.num_panels = 1;
+  p.num_tiles = num_tiles; p.bias = bias; p.R = R; p.ldr = R ? ldr : H; p.num_panels = 1; p.act = act ? 1 : 0; p.slope = slope;
   return H == 128 ? launch_typed<TEPI_OUT, 128>(p, tiles_bound, (hipStream_t)stream)
                   : launch_typed<TEPI_OUT, 64>(p, tiles_bound, (hipStream_t)stream);
 }

@@ -368,6 +368,8 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
             made._dmp_binary = True
     if eg is not None:
         eg._dmp_zero_rows = True         # e's target rows were multiplied by this gate above (_gate_concat / the packed codes)
+    if vg is not None:
+        vg._dmp_zero_rows = True         # ... and v's target rows by this one: a gated-out node is a zero row in every layer
     if eg is not None and getattr(e_gate, "_dmp_dense_gate", False):
         eg._dmp_dense_gate = True        # the kept edges of a compacted batch (collate.compact_gated_edges): ones but for the padding
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):     # e.g. dropout in training: the callers run the two loops

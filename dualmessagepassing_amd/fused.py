@@ -327,15 +327,16 @@ def typed_ok(index, H):
     return USE_TYPED_KERNELS and onepanel_ok(H) and index.num_nodes < 2 ** 31 and index.num_edges < 2 ** 30
 
 
-def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None):
+def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None, sel=None):
     """edge_fwd_mfma with W_g = Wes[:, :H] + c_g Wes[:, H:] per degree class: one product instead of two.
     ``dead_gate``: an edge gate all of whose zeros mark DEAD output rows (every consumer multiplies them by that zero and
-    skips them): those edges are padding slots of the tile list -- nothing is read, computed or stored for them."""
+    skips them): those edges are padding slots of the tile list -- nothing is read, computed or stored for them.
+    ``sel`` = ``NodeRows.sel``: the selectors with the nodes whose rows of ``P`` were never written replaced by -1 (read as zeros)."""
     lib = _lib.load()
     E, H = z.shape
     out = dead_rows_buffer((E, H), z.device)
     Wes = Wes.contiguous()
-    sel_a, sel_b, _ = index.edge_select(coef)
+    sel_a, sel_b = (sel[0], sel[1]) if sel is not None else index.edge_select(coef)[:2]
     lt = live_tiles(index, coef, dead_gate) if dead_gate is not None else None
     if lt is not None:
         slot_edge, tile_scale, num_tiles, bound = lt
@@ -462,7 +463,7 @@ def keep_in_csr(index, gate):
     return res
 
 
-def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None):
+def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None, dst=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
     ``base_map`` (int32 [E]): ``base`` is a small table and edge e adds its row ``base_map[e]`` (< 0: nothing).
@@ -470,7 +471,8 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     not fetched (``masked_slots``).  ``dead_rows`` (with ``gate``; ``zero_rows_gate`` holds): the input gradient of an edge
     under a zero gate is never used as a number (whoever made the rows multiplied them by the gate) -- ``"leave"``: those edges
     are padding slots, nothing is fetched, computed or stored for them (every reader of the result leaves them out);
-    ``"zero"``: likewise, their output rows are zeros."""
+    ``"zero"``: likewise, their output rows are zeros.
+    ``dst`` (``NodeRows.sel[2]``): the destinations with the nodes whose rows of ``d_s`` were never written replaced by -1."""
     lib = _lib.load()
     E, H = d_pre.size(0), Wes.size(0)
     lt = live_tiles(index, coef, gate) if dead_rows is not None else None
@@ -492,7 +494,7 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
             slot_edge = ms
     with _lib.timed("bwd_z_typed[H=%d,E=%d]", (H, E), 4 * H * E * (3 if base is not None else 2) + 5 * E):
         check(lib.dmp_bwd_z_typed_arow(ptr(d_pre), ld_pre, ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
-                                       ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32), ptr(index.rev8), -1.0, 1.0,
+                                       ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32 if dst is None else dst), ptr(index.rev8), -1.0, 1.0,
                                        ptr(slot_edge), ptr(ms), ptr(tile_scale), ptr(num_tiles), bound, E, H, 1,
                                        ptr(base_map), base.size(0) if base_map is not None else 0, ptr(out), H, stream_ptr()),
               "dmp_bwd_z_typed")
@@ -605,34 +607,40 @@ USE_TYPED_ATB_ROWS = _os.environ.get("DMP_TYPED_ATB_ROWS", "1") == "1"
 USE_TYPED_ROWS = _os.environ.get("DMP_TYPED_ROWS", "1") == "1"   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
 
 
-def out_fwd_typed(h1, W2t, b2, prev, tiles):
-    """``prev + (h1 W2^T + b2)`` for the edges of ``tiles`` (``live_tiles``: the edges a 0 / 1 gate keeps, gate 1 there); the
-    other rows of the result are not written (``dead_rows_buffer``).  ``W2t`` [in, out]."""
+def out_fwd_typed(h1, W2t, b2, prev, tiles, out=None, w_in_out=True, slope=None):
+    """``prev + (h1 W2^T + b2)`` for the rows of ``tiles`` (``live_tiles``: the edges a 0 / 1 gate keeps, gate 1 there; or
+    ``NodeRows.tiles``: the kept nodes); the other rows of the result are not written (``dead_rows_buffer``).  ``W2t`` [in, out]
+    (any row stride: a column block of a wider matrix), or with ``w_in_out=False`` the Linear's own [out, in].  ``out``: the
+    destination (may be ``prev``: a product accumulates onto its own output); ``slope``: LeakyReLU(slope) on the result."""
     lib = _lib.load()
     R, H = h1.shape
     slot_edge, tile_scale, num_tiles, bound = tiles
-    out = dead_rows_buffer((R, H), h1.device)
+    if out is None:
+        out = dead_rows_buffer((R, H), h1.device)
     with _lib.timed("out_fwd_typed[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
-        check(lib.dmp_out_fwd_typed(ptr(h1), h1.stride(0), ptr(W2t), W2t.size(1), 1, ptr(b2), ptr(prev), prev.stride(0) if prev is not None else H,
-                                    ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, R, H, ptr(out), H, stream_ptr()),
+        check(lib.dmp_out_fwd_typed(ptr(h1), h1.stride(0), ptr(W2t), W2t.stride(0), int(bool(w_in_out)), ptr(b2), ptr(prev),
+                                    prev.stride(0) if prev is not None else H,
+                                    ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, R, H, int(slope is not None), float(slope or 0.0),
+                                    ptr(out), out.stride(0), stream_ptr()),
               "dmp_out_fwd_typed")
     return out
 
 
-def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0):
+def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0, out=None):
     """``(dPre, column sums of dPre, column sums of the kept rows of d_o)`` with ``dPre[e] = act'(h1[e]) (.) (d_o[e] W2)`` for the
-    edges of ``tiles`` (``live_tiles``); the other rows of ``dPre`` are not written (``dead_rows_buffer``)."""
+    rows of ``tiles`` (``live_tiles`` / ``NodeRows.tiles``); the other rows of ``dPre`` are not written (``dead_rows_buffer``, or
+    ``out``: e.g. a column block of a wider matrix)."""
     lib = _lib.load()
     E, H = d_o.shape
     slot_edge, tile_scale, num_tiles, bound = tiles
-    d_g = dead_rows_buffer((E, H), d_o.device)
+    d_g = out if out is not None else dead_rows_buffer((E, H), d_o.device)
     G = int(lib.dmp_typed_partial_rows(bound, H))
     part = torch.empty((G, H), dtype=torch.float32, device=d_o.device)
     part_rows = torch.empty_like(part)
     W2 = W2.contiguous()
     with _lib.timed("bwd_h1_typed[H=%d,E=%d]", (H, E), 12 * H * E + 4 * E):
         check(lib.dmp_bwd_h1_typed(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(slot_edge), ptr(tile_scale),
-                                   ptr(num_tiles), bound, E, H, slope, ptr(d_g), H, ptr(part), ptr(part_rows), stream_ptr()),
+                                   ptr(num_tiles), bound, E, H, slope, ptr(d_g), d_g.stride(0), ptr(part), ptr(part_rows), stream_ptr()),
               "dmp_bwd_h1_typed")
     return d_g, reduce_partials(part), reduce_partials(part_rows)
 
@@ -817,10 +825,13 @@ USE_L0_ROW_LISTS = _os.environ.get("DMP_L0_ROW_LISTS", "1") == "1"
 L0_LIST_MIN_ROWS = 32768       # shorter row ranges (the pattern side) keep the masked form: the list costs two launches
 
 
-def kept_rows(mask, r0, r1):
+def kept_rows(mask, r0, r1, tiles=False):
     """``(list int32 [r1 - r0], count int32 [1])``: the rows of ``[r0, r1)`` (r0 a multiple of 32) whose bit of ``mask`` is set, as
     ids relative to r0, ascending (``dmp_kept_rows``); memoised on the mask tensor (the forward and the backward of a layer
-    share it)."""
+    share it).  ``tiles``: the list padded with -1 to whole 32-row tiles and ``count`` int32 [2] = (rows, tiles): a slot list
+    for the tile kernels (``node_tiles``)."""
+    if tiles:
+        return _kept_row_tiles(mask, r0, r1)
     memo = getattr(mask, "_dmp_kept_rows", None)
     if memo is None:
         memo = {}
@@ -835,9 +846,70 @@ def kept_rows(mask, r0, r1):
     R = r1 - r0
     out = torch.empty(R + 1 + int(lib.dmp_kept_rows_scratch_words(R)), dtype=torch.int32, device=mask.device)
     lst, cnt, scratch = out[:R], out[R:R + 1], out[R + 1:]
-    check(lib.dmp_kept_rows(ptr(mask[r0 // 32:]), R, ptr(scratch), ptr(lst), ptr(cnt), stream_ptr()), "dmp_kept_rows")
+    check(lib.dmp_kept_rows(ptr(mask[r0 // 32:]), R, 0, ptr(scratch), ptr(lst), ptr(cnt), stream_ptr()), "dmp_kept_rows")
     memo[(r0, r1)] = (lst, cnt)
     return lst, cnt
+
+
+def _kept_row_tiles(mask, r0, r1):
+    memo = getattr(mask, "_dmp_kept_tiles", None)
+    if memo is None:
+        memo = {}
+        try:
+            mask._dmp_kept_tiles = memo
+        except Exception:
+            pass
+    hit = memo.get((r0, r1))
+    if hit is not None:
+        return hit
+    lib = _lib.load()
+    R = r1 - r0
+    cap = (R + 31) // 32 * 32
+    out = torch.empty(cap + 2 + int(lib.dmp_kept_rows_scratch_words(R)), dtype=torch.int32, device=mask.device)
+    lst, cnt, scratch = out[:cap], out[cap:cap + 2], out[cap + 2:]
+    check(lib.dmp_kept_rows(ptr(mask[r0 // 32:]), R, 1, ptr(scratch), ptr(lst), ptr(cnt), stream_ptr()), "dmp_kept_rows")
+    memo[(r0, r1)] = (lst, cnt)
+    return lst, cnt
+
+
+USE_NODE_ROWS = _os.environ.get("DMP_NODE_ROWS", "1") == "1"   # the node side of a layer over the nodes a 0 / 1 node gate keeps
+
+
+class NodeRows:
+    """The nodes a 0 / 1 node gate keeps, as the kernels of a layer's node side want them (``node_rows``): ``mask`` (uint32
+    words, bit = kept), ``rows`` = ``(list, count)`` ascending ids (``dmp_kept_rows``), ``tiles`` = the same list as a tile slot
+    list ``(slot, tile_scale, num_tiles, bound)`` for ``dmp_out_fwd_typed`` / ``dmp_bwd_h1_typed``, ``sel`` = the per-edge
+    selectors / destinations with the other nodes replaced by -1 (``GraphIndex.edge_select_nodes``)."""
+
+    def __init__(self, mask, rows, tiles, sel):
+        self.mask, self.rows, self.tiles, self.sel = mask, rows, tiles, sel
+
+
+def node_rows(index, v_gate, H):
+    """``NodeRows`` when a layer's node side can run on the kept nodes only: ``v_gate`` is 0 / 1 and its maker multiplied the
+    rep-net's input node rows by it (``zero_rows_gate``: the rows under its zeros are zeros in EVERY layer, dmpnn.py:245-277,
+    so for such a node v the aggregate A[v], the projections P[v], node_out[v] and every gradient row of v are dead), the
+    tile kernels take the shape.  Memoised on the gate (the layers of a rep-net share it).  Else None."""
+    if (not USE_NODE_ROWS or not USE_PLAIN_ATB or v_gate is None or not zero_rows_gate(v_gate) or not typed_ok(index, H)
+            or index.num_edges == 0):
+        return None
+    mask = gate_row_mask(v_gate)
+    if mask is None:
+        return None
+    owner = _gate_owner(v_gate)
+    hit = getattr(owner, "_dmp_node_rows", None)
+    if hit is not None and hit[0] == owner._version and hit[1] is index:
+        return hit[2]
+    N = index.num_nodes
+    lst, cnt = kept_rows(mask, 0, N, tiles=True)
+    bound = (N + 31) // 32
+    scale = torch.zeros(bound, dtype=torch.float32, device=mask.device)
+    res = NodeRows(mask, (lst, cnt[0:1]), (lst, scale, cnt[1:2], bound), index.edge_select_nodes(mask))
+    try:
+        owner._dmp_node_rows = (owner._version, index, res)
+    except Exception:
+        pass
+    return res
 
 
 def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None, mask=None):
@@ -1206,6 +1278,12 @@ class _FusedDMPLayer(torch.autograd.Function):
         x, z = x.contiguous(), z.contiguous()
         Bn, Wx, Wes = Bn.contiguous(), Wx.contiguous(), Wes.contiguous()
         N = index.num_nodes
+        # ---- the nodes a 0 / 1 node gate keeps (``node_rows``): a node under a zero of a gate whose maker wiped the input rows
+        # is a zero row in every layer, so its aggregate, its projections, its update and all of its gradient rows are dead --
+        # the node side runs on the kept nodes' tiles, the edge kernels read a dead node's (unwritten) rows as zeros
+        nd = node_rows(index, v_gate, H) if (N >= 4096 and onepanel_ok(H)) else None
+        if nd is not None and l0 is not None and any(n0 % 32 for _, _, (n0, _) in l0.tables(z.size(0), N)):
+            nd = None          # (the backward's row masks start at a table's first node)
         # ---- node side (dmpnn.py:113,121,125 + fn.sum + 129-140)
         S0 = M0 = tables = None
         if l0 is not None:     # sum of z over a node's edges = (sum of the label codes) W0
@@ -1238,12 +1316,27 @@ class _FusedDMPLayer(torch.autograd.Function):
         else:
             # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
             kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
-            if kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
+            if kc is not None and nd is not None:   # ... and over the kept NODES' rows only: the others' aggregates are dead
+                S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows)
+            elif kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0)
             else:
                 S = ops.seg_sum_raw(z, index.in_ptr, index.in_ent, N, e_gate.reshape(-1) if zero_rows_gate(e_gate) else None, True, -1.0, 1.0)
-            SB = S @ Bn
-        if l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
+            if nd is None:
+                SB = S @ Bn
+        if l0 is None and nd is not None:
+            # the node side on the kept nodes' tiles (the tile kernel with a plain panel, one 128-wide block product per launch;
+            # a product accumulates onto its own output): H1n = act(x Wx0 + S_in Bn_in + S_out Bn_out + bn), the two gathered
+            # projection blocks, xn = x + (H1n W2^T + b2) -- nothing is read or written for the other nodes
+            T = nd.tiles
+            XP = dead_rows_buffer((N, 3 * H), z.device)
+            H1n = dead_rows_buffer((N, H), z.device)
+            out_fwd_typed(x, Wx[:, :H], bn, None, T, out=H1n)
+            out_fwd_typed(S[:, :H], Bn[:H], None, H1n, T, out=H1n)
+            out_fwd_typed(S[:, H:], Bn[H:], None, H1n, T, out=H1n, slope=slope)
+            out_fwd_typed(x, Wx[:, H:2 * H], None, None, T, out=XP[:, H:2 * H])
+            out_fwd_typed(x, Wx[:, 2 * H:], None, None, T, out=XP[:, 2 * H:])
+        elif l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK
             if not USE_SMALL_GEMM_JOBS:
                 MV = WV0 @ Wx                                                                        # [T VK, 3H]
@@ -1252,8 +1345,17 @@ class _FusedDMPLayer(torch.autograd.Function):
                 smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK], None, XP[n0:n1], H)
         else:
             XP = x @ Wx
-        H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
-        if onepanel_ok(H):   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
+        if l0 is not None or nd is None:
+            H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
+        if nd is not None:
+            # (an INNER layer's xn is read by the next layer of this rep-net only, under the same gate: the dead rows stay
+            # unwritten; the last layer's rows go to the caller: zeros there)
+            xn = dead_rows_buffer((N, H), z.device) if (inner & 1) else torch.zeros((N, H), dtype=torch.float32, device=z.device)
+            if nW2t is not None:
+                out_fwd_typed(H1n, nW2t, nb2, x if residual else None, nd.tiles, out=xn)
+            else:
+                out_fwd_typed(H1n, nW2, nb2, x if residual else None, nd.tiles, out=xn, w_in_out=False)
+        elif onepanel_ok(H):   # Linear + gate + residual in one fused MFMA kernel, as on the edge side
             xn = out_fwd_mfma(H1n, nW2, nb2, v_gate, x if residual else None, nW2t)
         else:
             xn = gate_residual(x if residual else None, torch.addmm(nb2, H1n, nW2.t()), v_gate)
@@ -1271,10 +1373,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 if rows[1] > rows[0]:
                     l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e,
                                 mask=gate_row_mask(dead_gate) if dead_gate is not None else None)
-        elif edge_chain_ok(index, H) and eW2t is not None and not sums_only:
+        elif nd is None and edge_chain_ok(index, H) and eW2t is not None and not sums_only:
             H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
-            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope, dead_gate=dead_gate)
+            # (under ``nd`` the projection rows of the dead nodes were never written: their selectors read as zeros)
+            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope, dead_gate=dead_gate, sel=None if nd is None else nd.sel)
         elif mfma_ok(index, H):
             H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
         else:
@@ -1298,6 +1401,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
         ctx.inner = int(inner)
+        ctx.nd = nd
         ctx.l0, ctx.l0_S0, ctx.l0_tables = l0, S0, tables
         ctx.l0_W = None if l0 is None else (W0.detach(), None if WV0 is None else WV0.detach())
         ctx.save_for_backward(x, z if l0 is None else None, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2)
@@ -1336,6 +1440,7 @@ class _FusedDMPLayer(torch.autograd.Function):
         x, z, S, H1n, H1e, Bn, Wx, Wes, nW2, eW2 = ctx.saved_tensors
         ix, coef, H, slope = ctx.index, ctx.coef, ctx.H, ctx.slope
         N = ix.num_nodes
+        nd = ctx.nd       # the kept nodes of a 0 / 1 node gate (``node_rows``): every gradient row of another node is dead
         # ---- gradients through the pooled sums (last layer).  Node side: expanded (N rows are cheap).  Edge side: if the
         # sums are the ONLY consumer of zn, dzn[e] = T[graph of e] (zero for reversed edges) with T = des[:, :H] and
         #   dH1 = (g (.) dzn) W2 = g[e] (T W2)[graph of e]             -> no E-row product, no [E, H] gradient tensor
@@ -1417,11 +1522,14 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dH1e = dOe @ eW2
                     dG, dbe = relu_bwd_g_colsum(dH1e, H1e, coef, ix.dst32, slope)
                     del dH1e
-            dXP = torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)   # [dPn | dP]: written in place, no concatenation
+            # [dPn | dP]: written in place, no concatenation (under ``nd``: the kept nodes' rows only)
+            dXP = dead_rows_buffer((N, 3 * H), x.device) if nd is not None else torch.empty((N, 3 * H), dtype=torch.float32, device=x.device)
             # dPre into both endpoints' rows: the backward scatter-add (dPre's rows under a zero edge gate are zeros: not fetched)
             sums_masked = typed and USE_MASKED_SUMS and ctx.e_gate is not None and gate_row_mask(ctx.e_gate) is not None
+            # (... and the rows of the dead nodes are neither summed nor stored)
+            nodes = (nd.mask, nd.sel[:2]) if (nd is not None and sums_masked and ops.graph_seg_ok(ix, dG[:, :H], H, dXP[:, H:])) else None
             ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:], mask=gate_row_mask(ctx.e_gate) if sums_masked else None,
-                              gate=ctx.e_gate if sums_masked else None)
+                              gate=ctx.e_gate if sums_masked else None, nodes=nodes)
             l0, tables = ctx.l0, ctx.l0_tables
             vcodes = l0 is not None and l0.venc is not None
             if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor
@@ -1443,7 +1551,14 @@ class _FusedDMPLayer(torch.autograd.Function):
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
             one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
-            if onepanel_ok(H) and atb_ok(dxn, H1n):
+            if nd is not None and not (one_launch and binary_gate_mask(ctx.v_gate) is not None):
+                raise _lib.DmpError("fused layer backward: the kept-node path needs the masked weight-gradient launch")
+            if nd is not None:
+                # dPn = act'(H1n) (.) (dxn W2) on the kept nodes' tiles; db2n = the column sums of the dxn rows it fetches
+                dPn, dbn, db2n = bwd_h1_typed(dxn, nW2, H1n, nd.tiles, slope, out=dXP[:, :H])
+                if vcodes:
+                    dW2n = atb_rows(dxn, H1n, ctx.v_gate, colsum=False)[0]
+            elif onepanel_ok(H) and atb_ok(dxn, H1n):
                 # as on the edge side: the node gate lives inside the two consumers of dO = v_gate * dxn
                 if binary_gate_mask(ctx.v_gate) is not None:
                     # a 0 / 1 node gate: db2n from the rows bwd_h1 fetches, the weight gradient(s) ungated over the masked-in rows
@@ -1468,7 +1583,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 for t, _, (n0, n1) in tables:
                     if n1 > n0:
                         for h in (0, 1):
-                            smallk_atb(S0[n0:n1, h * Kp:h * Kp + K0], dPn[n0:n1], out=Xn[h, t * K0:(t + 1) * K0])
+                            if nd is not None:     # (dPn's rows of the dead nodes were not written: masked out)
+                                smallk_atb_cols(S0[n0:n1, h * Kp:h * Kp + K0], dPn[n0:n1], None, Xn[h, t * K0:(t + 1) * K0].unsqueeze(0), H,
+                                                mask=nd.mask[n0 // 32:])
+                            else:
+                                smallk_atb(S0[n0:n1, h * Kp:h * Kp + K0], dPn[n0:n1], out=Xn[h, t * K0:(t + 1) * K0])
                 dS = dBn = dWx = None
                 if vcodes:
                     # x = venc WV0:  x^T dXP = WV0^T (venc^T dXP)  and  venc^T dx = venc^T dxn + (venc^T dXP) Wx^T -- N-row
@@ -1485,19 +1604,25 @@ class _FusedDMPLayer(torch.autograd.Function):
                 elif one_launch:
                     vm = binary_gate_mask(ctx.v_gate)
                     if vm is not None:    # (db2n came from bwd_h1; no job carries a gate: the launch runs on the bf16 pipe)
-                        (dW2n, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (x, dXP, None, False)])
+                        (dW2n, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (x, dXP, None, False, vm if nd is not None else None)])
                     else:
                         (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, gate_row_mask(ctx.v_gate)), (x, dXP, None, False)])
                 else:
                     dWx = wg(x, dXP)
             else:
-                dS = dPn @ Bn.t()
+                if nd is not None:     # dS = dPn Bn^T on the kept nodes' tiles; the edge kernel reads a dead node's rows as zeros
+                    dS = dead_rows_buffer((N, 2 * H), x.device)
+                    out_fwd_typed(dPn, Bn[:H], None, None, nd.tiles, out=dS[:, :H], w_in_out=False)
+                    out_fwd_typed(dPn, Bn[H:], None, None, nd.tiles, out=dS[:, H:], w_in_out=False)
+                else:
+                    dS = dPn @ Bn.t()
                 if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
                     # (dPn = act'(H1n) ((v_gate dxn) W2): zero rows under a zero node gate -- the first two products skip them)
                     vm = gate_row_mask(ctx.v_gate)
                     if binary_gate_mask(ctx.v_gate) is not None:   # (db2n came from bwd_h1; no job carries a gate: bf16 pipe)
+                        # (under ``nd`` x's and dXP's rows of the dead nodes were never written: the third product skips them too)
                         (dW2n, _), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (S, dPn, None, False, vm),
-                                                                         (x, dXP, None, False)])
+                                                                         (x, dXP, None, False, vm if nd is not None else None)])
                     else:
                         (dW2n, db2n), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, vm), (S, dPn, None, False, vm),
                                                                             (x, dXP, None, False)])
@@ -1505,7 +1630,15 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dBn = wg(S, dPn)                                         # [2H,H]
                     dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]
             dx = None
-            if ctx.needs_input_grad[3]:
+            if ctx.needs_input_grad[3] and nd is not None:
+                # dx = dxn + dXP Wx^T on the kept nodes' tiles, one 128-deep block of the contraction per launch.  A dead node's
+                # row is multiplied by the gate's zero further down: left unwritten where the layer before is the only reader
+                # (``inner`` bit 1), zeros for whoever made the rows of the first layer
+                dx = dead_rows_buffer((N, H), x.device) if (ctx.inner & 2) else torch.zeros((N, H), dtype=torch.float32, device=x.device)
+                for b3 in range(3):
+                    out_fwd_typed(dXP[:, b3 * H:(b3 + 1) * H], Wx[:, b3 * H:(b3 + 1) * H], None,
+                                  (dxn if ctx.residual else None) if b3 == 0 else dx, nd.tiles, out=dx, w_in_out=False)
+            elif ctx.needs_input_grad[3]:
                 dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place
             dz = None
@@ -1514,12 +1647,13 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # zero further down: not computed.  After the first layer (``inner`` bit 1) its reader is the layer before,
                 # which leaves those rows out; the first layer hands zeros to whoever made the rows.
                 dead_dz = (("leave" if (ctx.inner & 2) else "zero") if (typed and SKIP_DEAD_ROWS and zero_rows_gate(ctx.e_gate)) else None)
+                dst_m = None if nd is None else nd.sel[2]      # (dS's rows of the dead nodes were not written: read as zeros)
                 if lazy is not None:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
-                                     base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate, dead_rows=dead_dz)
+                                     base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate, dead_rows=dead_dz, dst=dst_m)
                 elif typed:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, dzn if ctx.residual else None, coef, ix, ctx.WesT, gate=ctx.e_gate,
-                                     dead_rows=dead_dz)
+                                     dead_rows=dead_dz, dst=dst_m)
                 elif mfma:
                     dz = bwd_z_mfma(dG, Wes, dS, dzn if ctx.residual else None, coef, ix)
                 else:

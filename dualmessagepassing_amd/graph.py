@@ -149,6 +149,20 @@ class GraphIndex:
             self._esel = cached = (key, (sel_a, sel_b, coef_e), coef)
         return cached[1]
 
+    def edge_select_nodes(self, nodemask):
+        """``(selA, selB, dstM)`` of ``edge_select`` / the destinations with every node whose bit of ``nodemask`` (uint32
+        words, ``fused.gate_row_mask`` of a 0 / 1 node gate) is clear replaced by -1 (``dmp_edge_select_nodes``): the tile
+        kernels read such a node's rows as zeros without fetching them.  Memoised per mask tensor."""
+        cached = getattr(self, "_esel_nodes", None)
+        if cached is None or cached[0] is not nodemask:
+            lib = _lib.load()
+            E = self.num_edges
+            out = torch.empty((3, E), dtype=torch.int32, device=self.device)
+            check(lib.dmp_edge_select_nodes(ptr(self.src32), ptr(self.dst32), ptr(self.rev8), ptr(nodemask), E, ptr(out[0]), ptr(out[1]),
+                                            ptr(out[2]), stream_ptr()), "dmp_edge_select_nodes")
+            self._esel_nodes = cached = (nodemask, (out[0], out[1], out[2]))
+        return cached[1]
+
     def endpoint_select(self):
         """``(selA, selB)`` of ``edge_select`` without the coefficient: selA = is_reversed ? src : dst, selB = the other
         endpoint (int32 [E]).  Taken from the selectors the forward pass built when there are any."""

@@ -90,18 +90,22 @@ def graph_seg_ok(index, M, H, out=None):
             and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
 
 
-def endpoint_sums(M, index, out=None, mask=None, gate=None):
+def endpoint_sums(M, index, out=None, mask=None, gate=None, nodes=None):
     """``[sum_{e: a_e = v} M[e] | -sum_{e: b_e = v} M[e]]`` ([N, 2H]; a_e = is_reversed ? src : dst, b_e the other endpoint):
     the gradient of the gathered node projections of the layer's edge pre-activation (dmpnn.py:111-127), every sum in
     ascending eid.  One pass over the edge rows where the batch tiles by graphs (``dmp_seg_sum2_graphs``), else
     ``dmp_seg_sum2`` over the incidence CSR (every row read twice).  ``mask`` (``fused.gate_row_mask``): zero bits mark rows
     of ``M`` that are all zeros (the rows a 0 / 1 edge gate wiped): the one-pass kernel does not fetch them; ``gate``: the same
-    as [E] floats, for the segment sum over the incidence CSR (a row of weight 0 is not fetched there)."""
+    as [E] floats, for the segment sum over the incidence CSR (a row of weight 0 is not fetched there).
+    ``nodes`` = ``(node mask words, (sel_a, sel_b) of GraphIndex.edge_select_nodes)`` (with ``mask``, one-pass kernel only):
+    the rows of the result for nodes whose mask bit is clear are DEAD -- not summed, not stored."""
     H, N = M.size(1), index.num_nodes
+    if nodes is not None and not (mask is not None and graph_seg_ok(index, M, H, out)):
+        raise _lib.DmpError("endpoint_sums: a node mask needs the one-pass kernel and a row mask")
     if graph_seg_ok(index, M, H, out):
         lib = _lib.load()
         node_off, edge_off, Ba, Bb, ka, kb = index.node_tiling
-        sel_a, sel_b = index.endpoint_select()
+        sel_a, sel_b = index.endpoint_select() if nodes is None else nodes[1]
         _lib.require_gpu(M, sel_a, sel_b, node_off, edge_off)
         if out is None:
             out = torch.empty((N, 2 * H), dtype=torch.float32, device=M.device)
@@ -113,7 +117,8 @@ def endpoint_sums(M, index, out=None, mask=None, gate=None):
             if mask is not None:
                 check(lib.dmp_seg_sum2_graphs_masked(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb,
                                                      ka, kb, H, 1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, ptr(mask), E,
-                                                     stream_ptr()), "dmp_seg_sum2_graphs_masked")
+                                                     None if nodes is None else ptr(nodes[0]), N, stream_ptr()),
+                      "dmp_seg_sum2_graphs_masked")
             else:
                 check(lib.dmp_seg_sum2_graphs(ptr(M), M.stride(0), ptr(sel_a), ptr(sel_b), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb,
                                               H, 1.0, -1.0, ptr(out), out.stride(0) if N > 1 else 2 * H, stream_ptr()),
@@ -125,9 +130,12 @@ def endpoint_sums(M, index, out=None, mask=None, gate=None):
     return seg_sum_raw(M, inc_ptr, inc_ent, N, None, True, 1.0, -1.0, rows_shared=2, out=out, tiling=index.tiling)
 
 
-def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None, tiling=None):
+def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None, tiling=None,
+                rows=None):
     """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride).
-    ``tiling`` (``graph_tiling``): the split sum over a CSR whose rows share source rows runs per graph tile from LDS."""
+    ``tiling`` (``graph_tiling``): the split sum over a CSR whose rows share source rows runs per graph tile from LDS.
+    ``rows`` = ``(list, count)`` (``fused.kept_rows``; split sums without weights, with ``out``): only the destination rows of
+    the list are summed and written (``dmp_seg_sum2_rows``)."""
     lib = _lib.load()
     _lib.require_gpu(M, rowptr, ent, edge_w)
     M, ldm = _mat(M)
@@ -151,6 +159,13 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
                 check(lib.dmp_seg_sum2_tiled(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(node_off), ptr(edge_off), Ba, Bb, ka, kb, H,
                                              s0, s1, ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_tiled")
             return out
+    if rows is not None:
+        if not split or ew is not None:
+            raise _lib.DmpError("seg_sum: a row list goes with the split sum without weights")
+        with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
+            check(lib.dmp_seg_sum2_rows(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(rows[0]), ptr(rows[1]), num_nodes, H, s0, s1,
+                                        ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_rows")
+        return out
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
             check(lib.dmp_seg_sum2(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(ew), num_nodes, H, s0, s1,

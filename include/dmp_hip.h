@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 69
+#define DMP_ABI_VERSION 70
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -413,6 +413,12 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
                  const int32_t *ent, const float *edge_w, int64_t num_nodes,
                  int H, float s0, float s1, float *out, int64_t ldo,
                  int rows_shared, void *stream);
+/* ... for the destination rows of a LIST only (rowlist [<= num_nodes] ascending row ids, *rowcount of them in device memory:
+ * dmp_kept_rows of a 0 / 1 NODE gate): the other rows of `out` are not written.  A node under a zero of the ScalarFilter's
+ * node gate is a zero row in every layer (dmpnn.py:245-277), its aggregate feeds only its own (gated) update: dead. */
+int dmp_seg_sum2_rows(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int32_t *rowlist,
+                      const int32_t *rowcount, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
+                      void *stream);
 
 /* Gate compaction of a block-diagonal batch (csrc/dmp_compact.hip): the edges a filter gate keeps (gate[e] != 0), graph by
  * graph in ascending eid, as a batch of exactly `cap` edges -- `cap - kept` padding edges (gate 0, self-loops dealt over
@@ -450,11 +456,14 @@ int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const
                         const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
                         int H, float s0, float s1, float *out, int64_t ldo, void *stream);
 /* ... where rows of M are known to be all zeros: rowmask [ceil(num_rows / 32)] (dmp_row_mask_bits: bit e & 31 of word e >> 5
- * clear = row e is zero, e.g. the dPre rows a 0 / 1 edge gate wiped in dmp_bwd_h1_fused_masked) -- those rows are not fetched. */
+ * clear = row e is zero, e.g. the dPre rows a 0 / 1 edge gate wiped in dmp_bwd_h1_fused_masked) -- those rows are not fetched.
+ * nodemask (optional) [ceil(num_nodes / 32)]: bit v & 31 of word v >> 5 clear = row v of `out` is dead (a node under a zero of
+ * a 0 / 1 node gate: its gradient is multiplied by that zero further down, dmpnn.py:245-277) and is NOT STORED -- `out` keeps
+ * whatever it held there; with dmp_edge_select_nodes' selectors (-1 for such a node) its addends are dropped too. */
 int dmp_seg_sum2_graphs_masked(const float *M, int64_t ldm, const int32_t *sel_a, const int32_t *sel_b,
                                const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
                                int H, float s0, float s1, float *out, int64_t ldo, const uint32_t *rowmask, int64_t num_rows,
-                               void *stream);
+                               const uint32_t *nodemask, int64_t num_nodes, void *stream);
 
 /*
  * Row gather by an int32 index -- `edges.src[k]` / `edges.dst[k]` inside the
@@ -666,9 +675,12 @@ int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_
 /* ... over a LIST of rows instead of the rows 0 .. R-1 (the kept rows of a 0 / 1 gate, dmp_kept_rows: ascending row ids, their number
  * in device memory): a batch of rows is then kRows kept rows -- the masked forms spend a batch's slots on its dead rows too.
  *   dmp_kept_rows: list [<= R] = the rows r < R whose bit (r & 31) of rowmask[r >> 5] is set, *count = how many;
- *   scratch: dmp_kept_rows_scratch_words(R) int32 words. */
+ *   scratch: dmp_kept_rows_scratch_words(R) int32 words.
+ *   tiles != 0: the list is also a slot list of 32-row tiles for the tile kernels (dmp_out_fwd_typed, dmp_bwd_h1_typed: the
+ *   node side of a layer over the nodes a 0 / 1 node gate keeps): list [(R + 31) / 32 * 32], the entries from *count to the next
+ *   multiple of 32 are -1 (padding slots), count [2] with count[1] = the number of tiles. */
 int64_t dmp_kept_rows_scratch_words(int64_t R);
-int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int32_t *scratch, int32_t *list, int32_t *count, void *stream);
+int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int tiles, int32_t *scratch, int32_t *list, int32_t *count, void *stream);
 int dmp_l0_edge_fwd_rows(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                          const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                          const int32_t *list, const int32_t *count, int64_t R, int H, float slope, float *out, int64_t ldo,
@@ -947,6 +959,13 @@ int dmp_heads_blend(const float *const *y, const float *const *gl, float *const 
 int dmp_edge_select_build(const int32_t *src, const int32_t *dst, const uint8_t *flag,
                           const float *coef, int64_t num_edges, int32_t *selA, int32_t *selB,
                           float *coefE, void *stream);
+/* ... for a rep-net whose NODE rows under a zero of a 0 / 1 node gate are zeros in every layer (the ScalarFilter gate
+ * multiplies the input rows and every layer's update, dmpnn.py:245-277): selA / selB / dstM [E] as above (dstM = dst) with
+ * every such node replaced by -1, an index outside any descriptor -- the tile kernels' gathers of its (never written)
+ * projection / gradient rows return zeros without touching memory, the one-pass endpoint sums drop its addends.
+ *   nodemask [ceil(N / 32)]: bit v & 31 of word v >> 5 set = node v is kept (dmp_row_mask_bits of the node gate). */
+int dmp_edge_select_nodes(const int32_t *src, const int32_t *dst, const uint8_t *flag, const uint32_t *nodemask,
+                          int64_t num_edges, int32_t *selA, int32_t *selB, int32_t *dstM, void *stream);
 
 /*
  * The E-row projection of the layer and dmp_edge_combine(relu) in one pass
@@ -1031,7 +1050,11 @@ int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t
  * are gathered and scattered by edge id as in the class-typed kernels, csrc/dmp_typed.hip), for a 0 / 1 gate whose kept rows
  * have gate 1:
  *   dmp_out_fwd_typed   out[e] = R[e] + (Hin[e] W2^T + bias)   for the kept e; the other rows of `out` are not written
- *                       (W2: nn.Linear's [out, in], or w_in_out: its transpose [in, out]; R may be NULL)
+ *                       (W2: nn.Linear's [out, in], or w_in_out: its transpose [in, out]; R may be NULL; R may be `out`: a row is
+ *                       read before it is written, so a product accumulates onto its own output -- a K = 2H / 3H product as two /
+ *                       three launches; act != 0: out[e] = LeakyReLU_slope(...) -- the node side of a layer over the tiles of the
+ *                       nodes a 0 / 1 node gate keeps, dmp_kept_rows(tiles = 1): x W_x, act(x W_0 + S B_n + b), x + H1 W2^T + b2,
+ *                       dP_n B_n^T, dxn + dXP W_x^T of dmpnn.py:113,121,129-140)
  *   dmp_bwd_h1_typed    dG[e] = act'(H1[e]) (.) (dO[e] W2)      for the kept e; the other rows of dG are not written;
  *                       partial / partial_rows [dmp_typed_partial_rows(tiles_bound, H), H]: column sums of dG / of the fetched
  *                       rows of dO per workgroup (partial_rows may be NULL), summed by dmp_reduce_partials
@@ -1041,7 +1064,7 @@ int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t
 int64_t dmp_typed_partial_rows(int64_t tiles_bound, int H);
 int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
                       int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
-                      int64_t E, int H, float *out, int64_t ldo, void *stream);
+                      int64_t E, int H, int act, float slope, float *out, int64_t ldo, void *stream);
 int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
                      int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
