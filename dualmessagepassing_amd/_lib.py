@@ -186,8 +186,7 @@ SIGNATURES = {
                                      c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_l0_bwd_w_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_typed_partial_rows": (c_i64, [c_i64, c_int]),
-    "dmp_out_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_f32,
-                                  c_ptr, c_i64, c_ptr]),
+    "dmp_out_fwd_typed": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_bwd_h1_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),

@@ -44,6 +44,7 @@ struct TypedArgs {
   const float *T; int64_t ldt; int64_t num_nodes;   // gathered table P / D [N, >= 256]
   const float *bias;                    // TEPI_EDGE: [128] or NULL
   const float *R; int64_t ldr;          // TEPI_DZ: upstream gradient rows [E,128] or NULL
+  const float *R2; int64_t ldr2;        // TEPI_OUT: a second addend row e (out = R + R2 + A W + bias) or NULL
   const int32_t *rmap; int64_t rowsR;   // TEPI_DZ: R is a [rowsR, ldr] table, row rmap[e] (< 0: zero) for edge e; NULL: row e
   float s0, s1;                         // TEPI_DZ: scale of the gathered term by flag
   float slope;                          // TEPI_EDGE / TEPI_H1: negative slope of the activation (0 = ReLU)
@@ -65,7 +66,7 @@ template <int H> struct TypedGeom {
 // it is read from LDS.  !X6: exact fp32 MFMA (development / comparison switch, dmp_dev_set_exact_fp32).
 // BIG: the streamed / scattered row arrays (A, C, R) are 4 GiB or larger: rows through 64-bit pointers (dmp_mfma_common.h).
 template <int EPI, int H, bool X6, bool BIG = false>
-__global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typed(TypedArgs p) {
+__device__ __forceinline__ void typed_body(const TypedArgs &p) {
   constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
   constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
@@ -95,12 +96,14 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
   if ((EPI == TEPI_EDGE || EPI == TEPI_OUT) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
   const bool act_out = EPI == TEPI_OUT && __builtin_amdgcn_readfirstlane(p.act) != 0;
+  const bool has_r2 = EPI == TEPI_OUT && p.R2 != nullptr;                                   // wave-uniform (a kernel argument)
 
   const uint32_t rows4 = (uint32_t)(p.E * 4);
   // rows of the big arrays are addressed by INDEX (structured descriptors: any array size, dmp_mfma_common.h)
   const srsrc_t rs_A = make_srsrc(p.A, p.lda, p.rowsA);
   const srsrc_t rs_C = make_srsrc(p.C, p.ldc, p.E);
   const srsrc_t rs_R = make_srsrc(p.R, p.ldr, p.rmap ? p.rowsR : p.E);
+  const srsrc_t rs_R2 = make_srsrc(p.R2, p.R2 ? p.ldr2 : (int64_t)H, p.R2 ? p.E : 0);        // (no second addend: zero records)
   const rsrc_t rs_rmap = make_rsrc(p.rmap, p.rmap ? rows4 : 0u);
   const srsrc_t rs_T = make_srsrc(p.T, p.ldt, p.num_nodes);
   const rsrc_t rs_idxA = make_rsrc(p.idxA, p.idxA ? rows4 : 0u);
@@ -130,22 +133,28 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
     uint32_t off;
     asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
     if (EPI == TEPI_REL) off += (uint32_t)__float_as_int(c) * (uint32_t)(H * p.ldw * 4);   // panel of the tile's type
+    // kPB values per round trip: a plain panel (one load per value) comes in rounds of 32 -- with a few tiles per workgroup
+    // (the node side: ~1 k tiles over the grid) the panel's dependent round trips ARE the launch
+    constexpr int kPB = (kPlainPanel && X6 && kHalf % 32 == 0) ? 32 : 8;
 #pragma unroll
-    for (int s0 = 0; s0 < kHalf; s0 += 8) {
-      float w0[8], w1[8];
+    for (int s0 = 0; s0 < kHalf; s0 += kPB) {
+      float w0[kPB], w1[kPlainPanel ? 1 : kPB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kPB; ++j) {
         w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
-        if (!kPlainPanel) w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
+        if (!kPlainPanel) w1[kPlainPanel ? 0 : j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
       }
-      if (X6) {
-        float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = kPlainPanel ? w0[j] : w0[j] + c * w1[j];
-        split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[X6 ? s0 / 8 : 0]);
-      } else {
+      for (int q = 0; q < kPB; q += 8) {
+        if (X6) {
+          float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[X6 ? 0 : s0 + j] = kPlainPanel ? w0[j] : w0[j] + c * w1[j];
+          for (int j = 0; j < 8; ++j) w[j] = kPlainPanel ? w0[q + j] : w0[q + j] + c * w1[kPlainPanel ? 0 : q + j];
+          split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[X6 ? (s0 + q) / 8 : 0]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b[X6 ? 0 : s0 + q + j] = kPlainPanel ? w0[q + j] : w0[q + j] + c * w1[kPlainPanel ? 0 : q + j];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -247,6 +256,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       g1[k] = sbuf_load4(rs_T, (int)rowB[par][rr], col4 + kRowBytes);
     } else if (kRowsOnly) {
       g1[k] = row_load4<BIG>(rs_R, p.R, p.ldr, (int)rowR[par][rr], col4);
+      if (EPI == TEPI_OUT && !BIG && has_r2) g0[k] = sbuf_load4(rs_R2, (int)rowC[par][rr], col4);   // (padding rows: zeros)
     } else {
       g0[k] = sbuf_load4(rs_T, (int)rowA[par][rr], col4 + (rowB[par][rr] ? kRowBytes : 0u));
       g1[k] = row_load4<BIG>(rs_R, p.R, p.ldr, (int)rowR[par][rr], col4);
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
       } else if (EPI == TEPI_OUT) {                          // as dmp_mfma.hip's EPI_GATE_RES with gate 1: (product + bias) + residual
         v.x = (v.x + bias4.x) + g1[k].x; v.y = (v.y + bias4.y) + g1[k].y;
         v.z = (v.z + bias4.z) + g1[k].z; v.w = (v.w + bias4.w) + g1[k].w;
+        if (!BIG && has_r2) { v.x += g0[k].x; v.y += g0[k].y; v.z += g0[k].z; v.w += g0[k].w; }       // the second addend
         if (act_out) { v.x = act_fwd(v.x, slope); v.y = act_fwd(v.y, slope); v.z = act_fwd(v.z, slope); v.w = act_fwd(v.w, slope); }
       } else if (EPI == TEPI_H1) {                           // padding rows: the activation reads as 0, the product is 0 -> 0
         v.x = act_bwd(g1[k].x, v.x, slope); v.y = act_bwd(g1[k].y, v.y, slope);
@@ -491,6 +502,21 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typ
   }
 }
 
+template <int EPI, int H, bool X6, bool BIG = false>
+__global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typed(TypedArgs p) {
+  typed_body<EPI, H, X6, BIG>(p);
+}
+
+// Several TEPI_OUT products over the SAME tile list in one launch (the node side of a layer: up to kTypedJobs independent
+// 128-wide block products over the kept nodes' tiles): grid.y = the job, grid.x = the workgroups of one job -- every workgroup
+// loads ONE panel and walks a contiguous range of the shared tile list.
+constexpr int kTypedJobs = 6;
+struct TypedJobs { TypedArgs job[kTypedJobs]; };
+template <int H>
+__global__ __launch_bounds__(TypedGeom<H>::kThreads, 2) void mfma_typed_jobs(TypedJobs js) {
+  typed_body<TEPI_OUT, H, true, false>(js.job[blockIdx.y]);
+}
+
 inline unsigned typed_blocks(int64_t tiles_bound, int per_cu = 3) {
   const int64_t cap = 256 * per_cu;
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
@@ -585,20 +611,46 @@ static int rows_typed_check(const float *A, int64_t lda, const float *W, int64_t
   return DMP_OK;
 }
 
-int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
-                      int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
-                      int64_t E, int H, int act, float slope, float *out, int64_t ldo, void *stream) {
+int dmp_out_fwd_typed(const dmp_typed_job *jobs, int num_jobs, const int32_t *slot_edge, const float *tile_scale,
+                      const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, void *stream) {
+  if (!jobs || num_jobs < 1 || num_jobs > kTypedJobs) return DMP_ERR_BAD_ARG;
   if (E == 0) return (E < 0) ? DMP_ERR_BAD_ARG : DMP_OK;
-  if (act && !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
-  const int rc = rows_typed_check(Hin, ldh, W2, ldw, R, ldr, out, ldo, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
-  if (rc != DMP_OK) return rc;
-  if (bias && !aligned16(bias)) return DMP_ERR_UNSUPPORTED;
-  TypedArgs p{};
-  p.A = Hin; p.lda = ldh; p.W = W2; p.ldw = ldw; p.transposed = w_in_out ? 0 : 1;   // [in, out]: B[k][j] = W2[k][j]; nn.Linear's [out, in]: W2[j][k]
-  p.C = out; p.ldc = ldo; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
-  p.num_tiles = num_tiles; p.bias = bias; p.R = R; p.ldr = R ? ldr : H; p.num_panels = 1; p.act = act ? 1 : 0; p.slope = slope;
-  return H == 128 ? launch_typed<TEPI_OUT, 128>(p, tiles_bound, (hipStream_t)stream)
-                  : launch_typed<TEPI_OUT, 64>(p, tiles_bound, (hipStream_t)stream);
+  TypedJobs js{};
+  for (int j = 0; j < num_jobs; ++j) {
+    const dmp_typed_job &q = jobs[j];
+    const int rc = rows_typed_check(q.Hin, q.ldh, q.W2, q.ldw, q.R, q.ldr, q.out, q.ldo, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
+    if (rc != DMP_OK) return rc;
+    if (q.bias && !aligned16(q.bias)) return DMP_ERR_UNSUPPORTED;
+    if (q.act && !slope_ok(q.slope)) return DMP_ERR_UNSUPPORTED;
+    if (q.R2 && (q.ldr2 < H || q.ldr2 % 4 || !aligned16(q.R2) || !stride_ok(q.ldr2) || !fits4g(E, q.ldr2))) return DMP_ERR_UNSUPPORTED;
+    TypedArgs &p = js.job[j];
+    p.A = q.Hin; p.lda = q.ldh; p.W = q.W2; p.ldw = q.ldw; p.transposed = q.w_in_out ? 0 : 1;   // [in, out]: B[k][j] = W2[k][j]; nn.Linear's [out, in]: W2[j][k]
+    p.C = q.out; p.ldc = q.ldo; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
+    p.num_tiles = num_tiles; p.bias = q.bias; p.R = q.R; p.ldr = q.R ? q.ldr : H; p.R2 = q.R2; p.ldr2 = q.R2 ? q.ldr2 : H;
+    p.num_panels = 1; p.act = q.act ? 1 : 0; p.slope = q.slope;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (num_jobs == 1) {
+    if (js.job[0].R2 && (!fits4g(js.job[0].rowsA, js.job[0].lda) || !fits4g(E, js.job[0].ldc))) return DMP_ERR_UNSUPPORTED;   // (the 64-bit row form has no second addend)
+    return H == 128 ? launch_typed<TEPI_OUT, 128>(js.job[0], tiles_bound, st) : launch_typed<TEPI_OUT, 64>(js.job[0], tiles_bound, st);
+  }
+  if (g_exact_fp32) {          // development switch: one launch per job on the f32-input MFMA
+    for (int j = 0; j < num_jobs; ++j) {
+      const int rc = H == 128 ? launch_typed<TEPI_OUT, 128>(js.job[j], tiles_bound, st) : launch_typed<TEPI_OUT, 64>(js.job[j], tiles_bound, st);
+      if (rc != DMP_OK) return rc;
+    }
+    return DMP_OK;
+  }
+  for (int j = 0; j < num_jobs; ++j)
+    if (!fits4g(js.job[j].rowsA, js.job[j].lda) || !fits4g(E, js.job[j].ldc) || (js.job[j].R && !fits4g(E, js.job[j].ldr))) return DMP_ERR_UNSUPPORTED;
+  // the grid the single launch would get, shared out over the jobs (every workgroup loads one panel)
+  const unsigned cap = typed_blocks(tiles_bound, H == 128 ? 2 : 4);
+  unsigned gx = (cap + num_jobs - 1) / num_jobs;
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, (unsigned)num_jobs);
+  if (H == 128) mfma_typed_jobs<128><<<grid, TypedGeom<128>::kThreads, 0, st>>>(js);
+  else mfma_typed_jobs<64><<<grid, TypedGeom<64>::kThreads, 0, st>>>(js);
+  return check_launch();
 }
 
 int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,

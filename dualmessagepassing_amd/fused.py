@@ -607,22 +607,50 @@ USE_TYPED_ATB_ROWS = _os.environ.get("DMP_TYPED_ATB_ROWS", "1") == "1"
 USE_TYPED_ROWS = _os.environ.get("DMP_TYPED_ROWS", "1") == "1"   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
 
 
-def out_fwd_typed(h1, W2t, b2, prev, tiles, out=None, w_in_out=True, slope=None):
+_TYPED_JOB = None
+
+
+def typed_jobs(jobs, tiles):
+    """Up to six products ``out = prev + prev2 + (a W + bias)`` (optionally through LeakyReLU) for the rows of ONE tile list in
+    ONE launch (``dmp_out_fwd_typed``: grid.y = the job).  ``jobs``: dicts with ``a`` [R, H] (any row stride), ``W`` (``[in, out]``,
+    or with ``w_in_out=False`` a Linear's ``[out, in]``; any row stride: a block of a wider matrix), ``out`` [R, H] view, and
+    optionally ``bias``, ``prev``, ``prev2``, ``slope``.  Rows outside the tiles are not written."""
+    global _TYPED_JOB
+    import ctypes
+    lib = _lib.load()
+    if _TYPED_JOB is None:
+        P, I64, I, F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        _TYPED_JOB = type("dmp_typed_job", (ctypes.Structure,), {"_fields_": [
+            ("Hin", P), ("ldh", I64), ("W2", P), ("ldw", I64), ("w_in_out", I), ("bias", P), ("R", P), ("ldr", I64), ("R2", P), ("ldr2", I64),
+            ("act", I), ("slope", F), ("out", P), ("ldo", I64)]})
+    slot_edge, tile_scale, num_tiles, bound = tiles
+    R, H = jobs[0]["a"].shape
+    J = (_TYPED_JOB * len(jobs))()
+    for j, q in zip(J, jobs):
+        a, W, out = q["a"], q["W"], q["out"]
+        prev, prev2, slope = q.get("prev"), q.get("prev2"), q.get("slope")
+        _lib.require_gpu(a, W, out, prev, prev2, q.get("bias"))
+        j.Hin, j.ldh, j.W2, j.ldw, j.w_in_out = a.data_ptr(), a.stride(0), W.data_ptr(), W.stride(0), int(bool(q.get("w_in_out", True)))
+        j.bias = ptr(q.get("bias"))
+        j.R, j.ldr = ptr(prev), (prev.stride(0) if prev is not None else H)
+        j.R2, j.ldr2 = ptr(prev2), (prev2.stride(0) if prev2 is not None else H)
+        j.act, j.slope = int(slope is not None), float(slope or 0.0)
+        j.out, j.ldo = out.data_ptr(), out.stride(0)
+    with _lib.timed("out_fwd_typed[H=%d,R=%d,jobs=%d]", (H, R, len(jobs)), 4 * H * R * 3 * len(jobs)):
+        check(lib.dmp_out_fwd_typed(J, len(jobs), ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, R, H, stream_ptr()),
+              "dmp_out_fwd_typed")
+
+
+def out_fwd_typed(h1, W2t, b2, prev, tiles, out=None, w_in_out=True, slope=None, prev2=None):
     """``prev + (h1 W2^T + b2)`` for the rows of ``tiles`` (``live_tiles``: the edges a 0 / 1 gate keeps, gate 1 there; or
     ``NodeRows.tiles``: the kept nodes); the other rows of the result are not written (``dead_rows_buffer``).  ``W2t`` [in, out]
     (any row stride: a column block of a wider matrix), or with ``w_in_out=False`` the Linear's own [out, in].  ``out``: the
-    destination (may be ``prev``: a product accumulates onto its own output); ``slope``: LeakyReLU(slope) on the result."""
-    lib = _lib.load()
+    destination (may be ``prev``: a product accumulates onto its own output); ``prev2``: a second addend; ``slope``:
+    LeakyReLU(slope) on the result."""
     R, H = h1.shape
-    slot_edge, tile_scale, num_tiles, bound = tiles
     if out is None:
         out = dead_rows_buffer((R, H), h1.device)
-    with _lib.timed("out_fwd_typed[H=%d,R=%d]", (H, R), 4 * H * R * (3 if prev is not None else 2)):
-        check(lib.dmp_out_fwd_typed(ptr(h1), h1.stride(0), ptr(W2t), W2t.stride(0), int(bool(w_in_out)), ptr(b2), ptr(prev),
-                                    prev.stride(0) if prev is not None else H,
-                                    ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, R, H, int(slope is not None), float(slope or 0.0),
-                                    ptr(out), out.stride(0), stream_ptr()),
-              "dmp_out_fwd_typed")
+    typed_jobs([dict(a=h1, W=W2t, bias=b2, prev=prev, prev2=prev2, out=out, w_in_out=w_in_out, slope=slope)], tiles)
     return out
 
 
@@ -1325,17 +1353,17 @@ class _FusedDMPLayer(torch.autograd.Function):
             if nd is None:
                 SB = S @ Bn
         if l0 is None and nd is not None:
-            # the node side on the kept nodes' tiles (the tile kernel with a plain panel, one 128-wide block product per launch;
-            # a product accumulates onto its own output): H1n = act(x Wx0 + S_in Bn_in + S_out Bn_out + bn), the two gathered
-            # projection blocks, xn = x + (H1n W2^T + b2) -- nothing is read or written for the other nodes
+            # the node side on the kept nodes' tiles (the tile kernel with a plain panel, 128-wide block products; independent
+            # products share a launch): H1n = act(x Wx0 + S_in Bn_in + S_out Bn_out + bn) as two partial products + a third
+            # that adds them up, the two gathered projection blocks, xn = x + (H1n W2^T + b2) -- nothing is read or written
+            # for the other nodes
             T = nd.tiles
-            XP = dead_rows_buffer((N, 3 * H), z.device)
+            XP = dead_rows_buffer((N, 3 * H), z.device)          # [x Wx0 + bn (a partial) | P_dst | P_src]
+            T1 = dead_rows_buffer((N, H), z.device)
             H1n = dead_rows_buffer((N, H), z.device)
-            out_fwd_typed(x, Wx[:, :H], bn, None, T, out=H1n)
-            out_fwd_typed(S[:, :H], Bn[:H], None, H1n, T, out=H1n)
-            out_fwd_typed(S[:, H:], Bn[H:], None, H1n, T, out=H1n, slope=slope)
-            out_fwd_typed(x, Wx[:, H:2 * H], None, None, T, out=XP[:, H:2 * H])
-            out_fwd_typed(x, Wx[:, 2 * H:], None, None, T, out=XP[:, 2 * H:])
+            typed_jobs([dict(a=x, W=Wx[:, :H], bias=bn, out=XP[:, :H]), dict(a=S[:, :H], W=Bn[:H], out=T1),
+                        dict(a=x, W=Wx[:, H:2 * H], out=XP[:, H:2 * H]), dict(a=x, W=Wx[:, 2 * H:], out=XP[:, 2 * H:])], T)
+            out_fwd_typed(S[:, H:], Bn[H:], None, XP[:, :H], T, out=H1n, slope=slope, prev2=T1)
         elif l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK
             if not USE_SMALL_GEMM_JOBS:
@@ -1612,8 +1640,12 @@ class _FusedDMPLayer(torch.autograd.Function):
             else:
                 if nd is not None:     # dS = dPn Bn^T on the kept nodes' tiles; the edge kernel reads a dead node's rows as zeros
                     dS = dead_rows_buffer((N, 2 * H), x.device)
-                    out_fwd_typed(dPn, Bn[:H], None, None, nd.tiles, out=dS[:, :H], w_in_out=False)
-                    out_fwd_typed(dPn, Bn[H:], None, None, nd.tiles, out=dS[:, H:], w_in_out=False)
+                    jobs = [dict(a=dPn, W=Bn[:H], w_in_out=False, out=dS[:, :H]), dict(a=dPn, W=Bn[H:], w_in_out=False, out=dS[:, H:])]
+                    if ctx.needs_input_grad[3]:    # ... and in the same launch two of the three partial products of dx = dxn + dXP Wx^T
+                        dxU = dead_rows_buffer((N, 2 * H), x.device)
+                        jobs += [dict(a=dXP[:, :H], W=Wx[:, :H], w_in_out=False, prev=dxn if ctx.residual else None, out=dxU[:, :H]),
+                                 dict(a=dXP[:, H:2 * H], W=Wx[:, H:2 * H], w_in_out=False, out=dxU[:, H:])]
+                    typed_jobs(jobs, nd.tiles)
                 else:
                     dS = dPn @ Bn.t()
                 if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
@@ -1631,13 +1663,16 @@ class _FusedDMPLayer(torch.autograd.Function):
                     dWx = wg(x, dXP)                                         # [H,3H] = [dA_n | dPd | dPs]
             dx = None
             if ctx.needs_input_grad[3] and nd is not None:
-                # dx = dxn + dXP Wx^T on the kept nodes' tiles, one 128-deep block of the contraction per launch.  A dead node's
-                # row is multiplied by the gate's zero further down: left unwritten where the layer before is the only reader
-                # (``inner`` bit 1), zeros for whoever made the rows of the first layer
+                # dx = dxn + dXP Wx^T on the kept nodes' tiles: the third 128-deep block of the contraction + the two partial
+                # products made beside dS.  A dead node's row is multiplied by the gate's zero further down: left unwritten
+                # where the layer before is the only reader (``inner`` bit 1), zeros for whoever made the first layer's rows
                 dx = dead_rows_buffer((N, H), x.device) if (ctx.inner & 2) else torch.zeros((N, H), dtype=torch.float32, device=x.device)
-                for b3 in range(3):
-                    out_fwd_typed(dXP[:, b3 * H:(b3 + 1) * H], Wx[:, b3 * H:(b3 + 1) * H], None,
-                                  (dxn if ctx.residual else None) if b3 == 0 else dx, nd.tiles, out=dx, w_in_out=False)
+                if l0 is None:
+                    out_fwd_typed(dXP[:, 2 * H:], Wx[:, 2 * H:], None, dxU[:, :H], nd.tiles, out=dx, w_in_out=False, prev2=dxU[:, H:])
+                else:      # (a first layer on the label codes of its edge rows only: no dS launch to share)
+                    for b3 in range(3):
+                        out_fwd_typed(dXP[:, b3 * H:(b3 + 1) * H], Wx[:, b3 * H:(b3 + 1) * H], None,
+                                      (dxn if ctx.residual else None) if b3 == 0 else dx, nd.tiles, out=dx, w_in_out=False)
             elif ctx.needs_input_grad[3]:
                 dx = torch.addmm(dxn, dXP, Wx.t()) if ctx.residual else dXP @ Wx.t()
             # ---- edge side, input gradient: residual + seg_sum2 backward + GEMM, accumulated in place

@@ -1049,12 +1049,13 @@ int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t
  * ... and over the tiles of the KEPT edges only (dmp_class_tiles_gated's slot_edge / tile_scale / num_tiles / tiles_bound; the rows
  * are gathered and scattered by edge id as in the class-typed kernels, csrc/dmp_typed.hip), for a 0 / 1 gate whose kept rows
  * have gate 1:
- *   dmp_out_fwd_typed   out[e] = R[e] + (Hin[e] W2^T + bias)   for the kept e; the other rows of `out` are not written
- *                       (W2: nn.Linear's [out, in], or w_in_out: its transpose [in, out]; R may be NULL; R may be `out`: a row is
- *                       read before it is written, so a product accumulates onto its own output -- a K = 2H / 3H product as two /
- *                       three launches; act != 0: out[e] = LeakyReLU_slope(...) -- the node side of a layer over the tiles of the
- *                       nodes a 0 / 1 node gate keeps, dmp_kept_rows(tiles = 1): x W_x, act(x W_0 + S B_n + b), x + H1 W2^T + b2,
- *                       dP_n B_n^T, dxn + dXP W_x^T of dmpnn.py:113,121,129-140)
+ *   dmp_out_fwd_typed   out[e] = R[e] + R2[e] + (Hin[e] W2^T + bias)   for the kept e; the other rows of `out` are not written
+ *                       (W2: nn.Linear's [out, in], or w_in_out: its transpose [in, out]; R, R2 may be NULL; R may be `out`: a row
+ *                       is read before it is written; act != 0: out[e] = LeakyReLU_slope(...)).  num_jobs (<= 6) such products over
+ *                       the SAME tile list run as ONE launch (grid.y = the job; every workgroup loads one weight panel) -- the
+ *                       node side of a layer over the tiles of the nodes a 0 / 1 node gate keeps, dmp_kept_rows(tiles = 1):
+ *                       x W_x, act(x W_0 + S B_n + b), x + H1 W2^T + b2, dP_n B_n^T, dxn + dXP W_x^T of dmpnn.py:113,121,129-140
+ *                       as 128-wide block products
  *   dmp_bwd_h1_typed    dG[e] = act'(H1[e]) (.) (dO[e] W2)      for the kept e; the other rows of dG are not written;
  *                       partial / partial_rows [dmp_typed_partial_rows(tiles_bound, H), H]: column sums of dG / of the fetched
  *                       rows of dO per workgroup (partial_rows may be NULL), summed by dmp_reduce_partials
@@ -1062,9 +1063,17 @@ int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t
  * zero rows in between the kept ones.
  */
 int64_t dmp_typed_partial_rows(int64_t tiles_bound, int H);
-int dmp_out_fwd_typed(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, int w_in_out, const float *bias, const float *R,
-                      int64_t ldr, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound,
-                      int64_t E, int H, int act, float slope, float *out, int64_t ldo, void *stream);
+typedef struct {
+  const float *Hin; int64_t ldh;       /* streamed rows [E, ldh >= H] */
+  const float *W2; int64_t ldw; int w_in_out;
+  const float *bias;                   /* [H] or NULL */
+  const float *R; int64_t ldr;         /* addend rows or NULL */
+  const float *R2; int64_t ldr2;       /* second addend rows or NULL */
+  int act; float slope;
+  float *out; int64_t ldo;
+} dmp_typed_job;
+int dmp_out_fwd_typed(const dmp_typed_job *jobs, int num_jobs, const int32_t *slot_edge, const float *tile_scale,
+                      const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, void *stream);
 int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
                      int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);

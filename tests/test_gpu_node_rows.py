@@ -140,6 +140,19 @@ def test_tile_kernel_accumulates_and_activates_on_the_kept_nodes(H, gpu):
     scale = float((A[keep].double().abs() @ Wt.double().abs().t()).max())
     assert float((dst[keep].double() - ref).abs().max()) <= 2e-6 * scale
     assert bool((wide[:, :H] == 7.5).all()) and bool((dst[~keep] == 7.5).all())
+    # several products over the same tiles in ONE launch, then a product with two addends (the forms the fused layer uses)
+    o = [th.full((N, H), 7.5, device=gpu) for _ in range(4)]
+    fused.typed_jobs([dict(a=A[:, :H], W=W[:H], bias=bias, out=o[0]), dict(a=A[:, H:2 * H], W=W[H:2 * H], out=o[1]),
+                      dict(a=A[:, :H], W=Wt[:, :H], w_in_out=False, prev=base, out=o[2]),
+                      dict(a=A[:, 2 * H:], W=Wt[:, 2 * H:], w_in_out=False, slope=0.0, out=o[3])], T)
+    fused.out_fwd_typed(A[:, 2 * H:], W[2 * H:], None, o[0], T, out=o[0], slope=0.18, prev2=o[1])
+    refs = [th.nn.functional.leaky_relu(A[keep].double() @ W.double() + bias.double(), 0.18),
+            A[keep, H:2 * H].double() @ W[H:2 * H].double(),
+            base[keep].double() + A[keep, :H].double() @ Wt[:, :H].double().t(),
+            th.relu(A[keep, 2 * H:].double() @ Wt[:, 2 * H:].double().t())]
+    for got, ref in zip(o, refs):
+        assert float((got[keep].double() - ref).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max())) * 3
+        assert bool((got[~keep] == 7.5).all())
 
 
 @pytest.mark.parametrize("lazy", [True, False])
