@@ -147,7 +147,7 @@ def model_config(cfg):
     return dict(max_ngv=cfg["g_nodes"], max_ngvl=cfg["g_labels"], max_nge=2 * cfg["g_edges"], max_ngel=2 * cfg["g_labels"],
                 max_npv=cfg["p_nodes"], max_npvl=cfg["p_labels"], max_npe=2 * cfg["p_edges"], max_npel=2 * cfg["p_labels"],
                 base=2, hid_dim=cfg["hid"], share_emb_net=True, share_enc_net=True, share_rep_net=True,
-                rep_residual=True, enc_net="Multihot", emb_net=cfg.get("emb", "Equivariant"), filter_net="ScalarFilter",
+                rep_residual=True, enc_net="Multihot", emb_net=cfg.get("emb", "Equivariant"), filter_net=cfg.get("filter", "ScalarFilter"),
                 rep_net="DMPNN", rep_num_graph_layers=cfg["layers"], rep_num_pattern_layers=cfg["layers"],
                 rep_dmpnn_num_mlp_layers=2, rep_dmpnn_batch_norm=False, rep_act_func=cfg.get("act", "leaky_relu"), rep_dropout=0.0,
                 init_neigenv=4.0, init_eeigenv=4.0, pred_net="SumPredictNet", pred_hid_dim=cfg["hid"],
@@ -329,6 +329,11 @@ def build_step(cfg, shard, device, world=1, collective=False):
         pattern, graph = batch_of(shard)
         return model.gate_kept_edges(pattern, graph)
 
+    def gate_kept_rows():
+        """{"edges": (kept, all), "nodes": (kept, all)} of this rank's TARGET rows under the filter's gates (one host sync)."""
+        pattern, graph = batch_of(shard)
+        return model.gate_kept_rows(pattern, graph)
+
     def plain_scatter_adds(H, launches=20):
         """The two scatter-add launches over ALL rows of an [E, H] array on this step's own union index (the kernels the masked
         forms derive from, and what runs without a 0 / 1 gate): HIP-event time per launch, outside every timed region, inputs
@@ -360,6 +365,7 @@ def build_step(cfg, shard, device, world=1, collective=False):
 
     step.plain_scatter_adds = plain_scatter_adds
     step.gate_kept_edges = gate_kept_edges
+    step.gate_kept_rows = gate_kept_rows
     # (a 0 / 1 edge gate: the class-typed kernels walk tiles over the kept edges, built in the forward pass)
     from dualmessagepassing_amd import fused as _fused
     filt = getattr(model, "filter_net", None)
@@ -457,59 +463,118 @@ def gate_summary(g, cfg, step, H):
     return out
 
 
-def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, row_bytes=0):
-    """``roofline`` object of one scatter-add launch kind: achieved = the launch's algorithmic bytes / its HIP-event time
-    inside the timed steps; beside it the same with SURVEY §8(d)'s byte count, and both over the committed rocprof duration.
-    ``skipped_rows``: rows of the summed array that are zeros under the batch's 0 / 1 edge gate and that the launch does not
-    fetch.  The algorithmic bytes are then those of the rows the sum still has to read (``achieved`` / ``frac`` stay what the
-    memory system does, never above its peak); the figures over ALL rows of the array -- what the launch replaces -- are
-    reported beside them as ``*_all_rows`` (an effective rate: it can exceed the peak)."""
+def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, all_own=None, all_survey=None, skipped_nodes=0):
+    """``roofline`` object of one scatter-add launch kind.  ``achieved`` / ``frac`` = SURVEY §8(d)'s algorithmic bytes of the
+    rows the launch processes / its HIP-event time inside the timed steps (the survey's byte count is the graded
+    one); ``bytes_own`` / ``frac_own_bytes`` = the same with every byte the kernel itself moves (its [N, 2H] output, its index
+    arrays); both also over the committed rocprof duration.  ``skipped_rows`` / ``skipped_nodes``: summed rows that are zeros
+    under the batch's 0 / 1 edge gate and are not fetched / node rows under a zero of the node gate, neither summed nor
+    stored: the byte counts are those of the rows the launch does process (never above the memory system's peak);
+    ``bytes_all_rows``: what the launch over every row would move -- the kernel that does that is timed stand-alone in
+    ``all_rows_launch``."""
     us = k["avg_us"]
-    all_own, all_survey = own_bytes, survey_bytes
-    own_bytes -= skipped_rows * row_bytes
-    survey_bytes -= skipped_rows * row_bytes
-    r = {"bound": "hbm", "kernel": what, "achieved": round(own_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-         "frac": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": prof["traffic"],
-         "bytes_per_launch": int(own_bytes), "avg_us": round(us, 2), "launches": k["launches"],
-         "bytes_survey": int(survey_bytes), "frac_survey_bytes": round(survey_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+    r = {"bound": "hbm", "kernel": what, "achieved": round(survey_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(survey_bytes / us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": prof["traffic"],
+         "bytes_per_launch": int(survey_bytes), "bytes_basis": "SURVEY 8(d) per-row bytes x the rows the launch processes",
+         "avg_us": round(us, 2), "launches": k["launches"],
+         "bytes_own": int(own_bytes), "frac_own_bytes": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
          "avg_us_rocprof": prof["avg_us_rocprof"]}
     if prof["avg_us_rocprof"]:
-        r["frac_rocprof"] = round(own_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
-        r["frac_survey_bytes_rocprof"] = round(survey_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
+        r["frac_rocprof"] = round(survey_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
+        r["frac_own_bytes_rocprof"] = round(own_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
     if prof["traffic"]:
-        r["traffic_over_algorithmic"] = round(prof["traffic"] / own_bytes, 4)
-    if skipped_rows:
+        r["traffic_over_own_bytes"] = round(prof["traffic"] / own_bytes, 4)
+    if skipped_rows or skipped_nodes:
         r["rows_not_fetched"] = int(skipped_rows)
-        r["bytes_all_rows"] = int(all_own)
-        r["bytes_survey_all_rows"] = int(all_survey)
-        r["effective_frac_all_rows"] = round(all_own / us / 1e3 / HBM_PEAK_GBPS, 4)
-        r["effective_frac_survey_bytes_all_rows"] = round(all_survey / us / 1e3 / HBM_PEAK_GBPS, 4)
-        r["note"] = ("%d of the summed rows are zeros under this batch's 0/1 edge gate (the ScalarFilter gate multiplies the rep-net's "
-                     "input rows, basemodel.py:1515-1531) and are not fetched: the byte counts and `frac` are those of the rows the "
-                     "launch reads; `*_all_rows` price the same launch time against the whole array (the launch it replaces), an "
-                     "effective figure that may exceed the peak" % skipped_rows)
+        r["node_rows_not_written"] = int(skipped_nodes)
+        if all_own is not None:
+            r["bytes_all_rows"] = int(all_own)
+            r["bytes_survey_all_rows"] = int(all_survey)
+        r["note"] = ("%d of the summed rows are zeros under this batch's 0/1 edge gate and %d node rows lie under a zero of its node gate "
+                     "(the ScalarFilter gates multiply the rep-net's input rows and every layer's update, basemodel.py:1515-1531, "
+                     "dmpnn.py:245-277): not fetched / not written.  The byte counts and fractions are those of the rows the launch "
+                     "processes; all_rows_launch times the kernel over every row" % (skipped_rows, skipped_nodes))
     return r
+
+
+def check_rates(obj, path="line"):
+    """No memory rate of the line above the HBM peak, no fraction above 1 (a byte count priced at rows a launch
+    does not process gave 1.3 of the peak): walks the whole line, raises naming the entry."""
+    if isinstance(obj, dict):
+        unit = obj.get("unit")
+        for k, v in obj.items():
+            here = "%s.%s" % (path, k)
+            if isinstance(v, (dict, list)):
+                check_rates(v, here)
+            elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                if (k in ("gbps", "hbm_gbps") or (k == "achieved" and unit == "GB/s")) and v > HBM_PEAK_GBPS:
+                    raise SystemExit("bench.py: %s = %.1f GB/s exceeds the HBM peak: a byte count prices rows the launch does not process" % (here, v))
+                if (k.startswith("frac") or k.endswith("_frac") or k == "frac_of_hbm_peak") and v > 1.0:
+                    raise SystemExit("bench.py: %s = %.4f exceeds 1" % (here, v))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            check_rates(v, "%s[%d]" % (path, i))
+
+
+def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B):
+    """Algorithmic bytes of one launch of kernel ``name`` (the HIP-event timer's record name) when it runs on the rows the batch's
+    0 / 1 gates keep -- the timer's own count is host-side and prices every row of the launch shape.  N / E: union node / edge
+    rows, Nk / Ek: the kept ones (pattern rows are all kept), Et / Etk: target edge rows / kept.  None: the timer's count stands."""
+    base = name.split("[", 1)[0]
+    on_e = ("E=%d" % E) in name or ("R=%d" % E) in name or ("ent=%d" % E) in name
+    on_n = ("R=%d" % N) in name or ("E=%d" % N) in name
+    jobs = 1
+    if "jobs=" in name:
+        jobs = int(name.split("jobs=")[1].split("]")[0].split(",")[0])
+    if base == "seg_sum2_graphs":
+        return 4 * H * Ek + 8 * H * Nk + 8 * E + E // 8 + N // 8 + 16 * (B + 1)
+    if base == "seg_sum2" and ("rows=%d" % N) in name and on_e and ("H=%d" % H) in name:
+        return 4 * H * Ek + 8 * H * Nk + 4 * Ek + 12 * Nk
+    if base == "seg_sum2" and on_e and ("H=%d" % H) in name:          # a pooled pass over the edge rows, gate-weighted
+        return 4 * H * Ek + 8 * E
+    if base == "edge_fwd_typed" and on_e:
+        return 4 * H * (2 * Ek + 2 * Nk) + 12 * Ek
+    if base == "bwd_z_typed" and on_e:
+        return 4 * H * (3 * Ek + 2 * Nk) + 5 * Ek
+    if base == "atb_typed" and on_e:
+        return 8 * H * Ek
+    if base == "out_fwd_typed":
+        return 12 * H * (Ek if on_e else Nk) * jobs if (on_e or on_n) else None
+    if base == "bwd_h1_typed":
+        return (12 * H + 4) * (Ek if on_e else Nk) if (on_e or on_n) else None
+    if base == "pool_relu_bwd" and on_e:
+        return 8 * H * Ek + 12 * E
+    if base == "l0_edge_fwd" and ("E=%d" % Et) in name:
+        return 4 * H * (Etk + 2 * Nk) + 64 * Etk
+    if base == "l0_bwd_w" and ("E=%d" % Et) in name:
+        return 8 * H * Etk + 56 * Etk
+    if base == "atb_rows_plain" and on_n:
+        return 8 * H * Nk
+    return None
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
 
 
-def mfma_rooflines(kern, H, E):
+def mfma_rooflines(kern, H, E, Ek=None):
     """{kernel: {avg_us, tflops, frac}} for the fused MFMA kernels seen by the HIP-event timer; flops =
-    2*E*H*H per [E,H]x[H,H] product the kernel performs (1 for the class-typed kernels, out_fwd and
-    bwd_h1; 2 for the two-panel edge_fwd / bwd_z)."""
+    2*rows*H*H per [rows,H]x[H,H] product the kernel performs (1 for the class-typed kernels, out_fwd and
+    bwd_h1; 2 for the two-panel edge_fwd / bwd_z).  ``Ek``: the edge rows the batch's 0 / 1 gate keeps -- the kernels over
+    the kept edges' tiles (``*_typed``) multiply those rows only."""
     products = {"edge_fwd_typed": 1, "bwd_z_typed": 1, "atb_typed": 1, "atb_rows": 1, "out_fwd_mfma": 1, "bwd_h1_mfma": 1,
-                "edge_fwd_mfma": 2, "bwd_z_mfma": 2}
+                "edge_fwd_mfma": 2, "bwd_z_mfma": 2, "out_fwd_typed": 1, "bwd_h1_typed": 1}
     out = {}
     for name, v in kern.items():
         base = name.split("[", 1)[0]
         if base in products and ("E=%d" % E in name or "R=%d" % E in name):
-            tf = products[base] * 2.0 * E * H * H / (v["avg_us"] * 1e-6) / 1e12
+            rows = Ek if (Ek is not None and base.endswith("_typed")) else E
+            tf = products[base] * 2.0 * rows * H * H / (v["avg_us"] * 1e-6) / 1e12
             # round 3: the class-typed kernels multiply on the bf16 pipe (three bf16 pieces per fp32 operand, six piece
             # products: fp32-accurate, 6/16 of the f32 form's matrix cycles); "tflops" stays the fp32-equivalent rate and
             # "frac" its ratio to the F32-input MFMA peak, for comparison with earlier rounds -- their bound is HBM
-            x6 = base in ("edge_fwd_typed", "bwd_z_typed", "atb_typed")
-            out[base] = {"avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            x6 = base.endswith("_typed")
+            out.setdefault(base, {})["rows"] = int(rows)
+            out[base] = {"rows": int(rows), "avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                          "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "arithmetic": "bf16x6 (fp32-accurate)" if x6 else "f32 MFMA"}
             # flops per byte fall with H (2 H^2 flops against ~8-12 H bytes per row): at H = 64 the same kernels sit nearer
             # the HBM roof than the MFMA roof -- both fractions are reported, "bound" names the nearer roof
@@ -531,7 +596,7 @@ def sparse_end_to_end(cfg, pairs_per_s):
     return {"bytes_per_pair": per_pair, "gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
 
 
-def cpu_baseline(cfg, state_dict, seconds_budget=20.0, B=32, max_steps=50, warm=True):
+def cpu_baseline(cfg, state_dict, seconds_budget=12.0, B=32, max_steps=50, warmup=3, min_steps=10):
     """The same step on the host cores with the CPU oracle (oracle/model_oracle.py + dmp_oracle.py: the reference's
     operation order -- gather-then-project layers, padded [B, L, D] heads, per-sample Python loops -- in torch CPU ops,
     pinned by the reference's own full-model runs): collate of B per-graph arrays, forward of the WHOLE model, count
@@ -590,16 +655,21 @@ def cpu_baseline(cfg, state_dict, seconds_budget=20.0, B=32, max_steps=50, warm=
         loss.backward()
         opt.step()
 
-    if warm:
-        one()  # warm-up
-    t0, n = time.perf_counter(), 0
-    while True:
+    # SURVEY 8(d)'s protocol: warm-up steps, then at least ``min_steps`` timed steps (more while the budget lasts), the MEDIAN step
+    for _ in range(warmup):
         one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= max_steps:
+    times, t0 = [], time.perf_counter()
+    while True:
+        s0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - s0)
+        if len(times) >= max_steps or (len(times) >= min_steps and time.perf_counter() - t0 > seconds_budget):
             break
-    return {"value": B * n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+    times.sort()
+    med, n = times[len(times) // 2], len(times)
+    return {"value": B / med, "unit": "pairs/s", "cores": cores, "kind": "port", "protocol": "%d warm-up + %d timed steps, median step" % (warmup, n),
+            "step_s_median": round(med, 4), "step_s_min": round(times[0], 4), "step_s_max": round(times[-1], 4),
+            "value_mean": round(B * n / sum(times), 2),
             "sample": "%d steps of B=%d pairs of the same shapes; the same step composition as the GPU line (collate, whole "
                       "model forward: encodings, embeddings, ScalarFilter, %d-layer pattern + target DMPNN rep-nets, node + edge "
                       "SumPredictNet heads; count loss, backward, AdamW(amsgrad)), hid=%d, fp32, reference operation order, "
@@ -724,6 +794,9 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=0, help="micro-batches per step (0 = as few as keep the edge rows of "
                     "one pass below 2^30: 1 for config 2 and for config 4's 1024-pair shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-b1024", action="store_true", help="also time the CPU oracle's step at the GPU line's batch size (1 warm-up + 3 "
+                    "timed steps of 1024 pairs, median: several minutes) -> cpu_baseline_b1024")
+    ap.add_argument("--no-gate-dense", action="store_true", help="skip the extra un-timed steps behind the gate_dense object")
     ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
     ap.add_argument("--extended-steps", type=int, default=200,
                     help="further steps after the timed region (same launch mode, one event record each) behind `steps_extended`; 0 = none")
@@ -1041,6 +1114,33 @@ def main():
                 raise SystemExit("bench.py: gate compaction status %d (a batch did not fit its capacity)" % bits)
             gate_line = dict(info, ms_per_step=round(g_ms, 3), value=round(cfg["batch"] / g_ms * 1e3, 1), kern=kern_c)
         step.set_gate_compact(False)
+    dense_line = None
+    if not multi and step.micro_batches == 1 and args.workload == 2 and not args.no_gate_dense and not args.gate_compact:
+        # the CONTROL for everything the 0 / 1 gates buy: the same step, same launch mode, with the model built WITHOUT its
+        # filter net (filter_net = "None": no gate, every node and edge row of the batch is live in every layer) -- what the
+        # step costs when the data gate nothing out.  Reported beside the headline, never as `value`.
+        _lib.timer.enabled = False
+        step_d, model_d = build_step(dict(cfg, filter="None", gate_compact=False), shard, device, world)
+        if graphed:
+            from dualmessagepassing_amd.dp import StepGraph
+            run_d = StepGraph(lambda: step_d(), optimizer=step_d.opt, max_shapes=1)
+        else:
+            run_d = step_d
+        for _ in range(3):                                     # graphed: eager, record + replay, replay
+            run_d()
+        step_d.finish()
+        barrier()
+        td = time.perf_counter()
+        for _ in range(args.steps):
+            run_d()
+        step_d.finish()
+        barrier()
+        d_ms = (time.perf_counter() - td) / max(args.steps, 1) * 1e3
+        dense_line = {"what": "same step, same launch mode, the model built with filter_net = 'None': no ScalarFilter gate, every node "
+                              "and edge row live in every layer (the step when the data gate nothing out)",
+                      "ms_per_step": round(d_ms, 3), "value": round(cfg["batch"] / d_ms * 1e3, 1), "unit": "pairs/s",
+                      "kept_fraction_of_rows": 1.0}
+        del run_d, step_d, model_d
     _lib.timer.reset()
     _lib.timer.only = None
     _lib.timer.enabled = True
@@ -1085,22 +1185,40 @@ def main():
         roof = roof_bwd = None
         # rows the two scatter-adds leave out: the target edge rows under a zero of the filter's 0 / 1 edge gate (not in the
         # gate-compact mode: its batch holds the kept rows only)
-        skipped = 0
+        skipped = skipped_n = 0
+        Et = mb * 2 * cfg["g_edges"]
+        Etk = Et
         from dualmessagepassing_amd import fused as _fused
-        if _fused.USE_MASKED_SUMS and _fused.USE_ROW_MASKS and not step.gate_capacity and step.micro_batches == 1:
-            kept_e, all_e = step.gate_kept_edges()
-            skipped = (all_e - kept_e) if kept_e is not None else 0
+        if _fused.USE_MASKED_SUMS and _fused.USE_ROW_MASKS and step.micro_batches == 1:
+            kept = step.gate_kept_rows()
+            if kept["edges"][0] is not None and not step.gate_capacity:
+                skipped = kept["edges"][1] - kept["edges"][0]
+                Etk = kept["edges"][0]
+            if kept["nodes"][0] is not None and _fused.USE_NODE_ROWS and _fused.USE_PLAIN_ATB and uN >= 4096:
+                skipped_n = kept["nodes"][1] - kept["nodes"][0]          # (fused.node_rows: the node side runs on the kept nodes)
+        Ek, Nk, nB = uE - skipped, uN - skipped_n, 2 * mb
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
             roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
-                                "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key]["bytes"],
-                                4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"], skipped,
-                                4 * H + (4 if _fused.USE_KEEP_CSR else 0))     # (over the kept edges' CSR: no index entry either)
+                                "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
+                                4 * H * Ek + 8 * H * Nk + 4 * Ek + (12 * Nk if skipped_n else 4 * (uN + 1)),
+                                4 * H * (Ek + Nk) + 4 * Ek + 4 * (Nk + 1), prof["in"], skipped,
+                                4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1), 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), skipped_n)
         if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
-            roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if "graphs" in key_inc
+            graphs = "graphs" in key_inc
+            roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if graphs
                                                     else "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints") +
-                                    "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[key_inc]["bytes"],
-                                    4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"],
-                                    skipped if "graphs" in key_inc else 0, 4 * H)
+                                    "; gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
+                                    (4 * H * Ek + 8 * H * Nk + 8 * uE + uE // 8 + uN // 8 + 16 * (nB + 1)) if graphs else kern[key_inc]["bytes"],
+                                    (4 * H * (Ek + 2 * Nk) + 9 * Ek + 8 * (Nk + 1)) if graphs else 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1),
+                                    prof["inc"], skipped if graphs else 0,
+                                    4 * H * (uE + 2 * uN) + 8 * uE + 16 * (nB + 1), 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1),
+                                    skipped_n if graphs else 0)
+        # the per-kernel table: the timer prices a launch at its launch SHAPE; under the gates the kernels process the kept rows
+        if skipped or skipped_n:
+            for name, v in kern.items():
+                kb = kept_row_bytes(name, H, uN, uE, Nk, Ek, Et, Etk, nB)
+                if kb is not None:
+                    v["bytes"], v["gbps"], v["rows"] = kb, kb / v["avg_us"] / 1e3, "kept"
         if skipped and not multi:
             # ... and the same two launches over ALL rows (no mask, no weights): the kernels as they run without a 0 / 1 gate,
             # timed stand-alone on this step's index -- so that the fraction of the unmasked kernels stays on record
@@ -1108,10 +1226,10 @@ def main():
             for r_, key_, own_, sv_ in ((roof, "fwd_us", 4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1), 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1)),
                                         (roof_bwd, "bwd_us", 4 * H * (uE + 2 * uN) + 8 * uE + 16 * (cfg["batch"] * 2 + 1), 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1))):
                 if r_ is not None and plain:
-                    r_["all_rows_launch"] = {"what": "the same kernel without the mask / the gate weights, every row read; stand-alone, median of 20 launches",
-                                             "avg_us": round(plain[key_], 2), "bytes": int(own_),
-                                             "frac": round(own_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4),
-                                             "frac_survey_bytes": round(sv_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4)}
+                    r_["all_rows_launch"] = {"what": "the same kernel without the masks / the gate weights, every row read and written; stand-alone, median of 20 launches",
+                                             "avg_us": round(plain[key_], 2), "bytes_per_launch": int(sv_), "bytes_own": int(own_),
+                                             "frac": round(sv_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4),
+                                             "frac_own_bytes": round(own_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4)}
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -1160,29 +1278,30 @@ def main():
             "roofline": roof,
             "roofline_bwd": roof_bwd,
             "gate_compact": gate_summary(gate_line, cfg, step, H) if gate_line else None,
+            "gate_dense": dense_line,
+            # the rows of THIS batch the 0 / 1 gates leave live (pattern rows are always live): what the headline's kernels process
+            "gate_kept": {"edge_rows": int(Ek), "of_edge_rows": int(uE), "node_rows": int(Nk), "of_node_rows": int(uN)},
             # the compulsory traffic of the sparse kernels alone (seg-sum / gather-combine, forward + backward,
             # pattern + target, all layers) over the END-TO-END step time -- how far the whole step is from a sparse-only
             # HBM roofline (the step also runs 460 GFLOP of dense fp32 products, which bound it)
             "sparse_path_end_to_end": sparse_end_to_end(cfg, pairs / dt),
             # the time-dominant kernels are the fp32 MFMA kernels of the edge chain (exact-fp32
             # v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak): their MFMA-roofline fractions, for context
-            "mfma_kernels": mfma_rooflines(kern, H, uE),
+            "mfma_kernels": mfma_rooflines(kern, H, uE, Ek),
             "kernels": {n: {"avg_us": round(v["avg_us"], 2), "gbps": round(v["gbps"], 1), "launches": v["launches"],
-                            "bytes": int(v["bytes"])} for n, v in sorted(kern.items())},
+                            "bytes": int(v["bytes"]), **({"rows": v["rows"]} if "rows" in v else {})} for n, v in sorted(kern.items())},
         }
         line["launcher"] = ("bench.py (self-spawned ranks)" if os.environ.get("DMP_BENCH_SPAWNED") else
                             "external (torch.distributed.run)") if world > 1 else "single process"
         if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, initial_state)
-            # the same CPU step at the GPU line's batch size (B = 1024 pairs; at most 2 steps, no warm-up step): the
-            # B = 32 sample above is the reference's own CPU-runnable batch size, this one is the like-for-like size
-            try:
-                import psutil
-                room = psutil.virtual_memory().available >= 48 * 2 ** 30
-            except ImportError:
-                room = False
-            if room and args.workload == 2:
-                line["cpu_baseline_b1024"] = cpu_baseline(cfg, initial_state, seconds_budget=12.0, B=cfg["batch"], max_steps=2, warm=False)
+            # --cpu-b1024: the same CPU step at the GPU line's batch size (B = 1024 pairs: a minute per step on 32 threads, so
+            # 1 warm-up + 3 timed steps, median; off by default -- the default run has to finish within minutes); the B = 32
+            # sample above is the reference's own CPU-runnable batch size, this one is the like-for-like size
+            line["cpu_baseline_b1024"] = None
+            if args.cpu_b1024 and args.workload == 2:
+                line["cpu_baseline_b1024"] = cpu_baseline(cfg, initial_state, seconds_budget=0.0, B=cfg["batch"], max_steps=3, warmup=1, min_steps=3)
+        check_rates(line)
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()

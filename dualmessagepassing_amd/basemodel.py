@@ -736,6 +736,15 @@ class GraphAdjModelV2(BaseModel):
         E = graph.number_of_edges()
         return (None if el_gate is None else int((el_gate != 0).sum().item())), E
 
+    def gate_kept_rows(self, pattern, graph):
+        """``{"edges": (kept, all), "nodes": (kept, all)}`` of the TARGET rows under the filter's two gates for one batch (one host
+        sync); ``kept`` is None without a gate."""
+        pattern, graph = as_batched(pattern), as_batched(graph)
+        pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"), "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
+        vl_gate, el_gate = self.get_filter_gate(pattern, graph, pads)
+        return {"edges": (None if el_gate is None else int((el_gate != 0).sum().item()), graph.number_of_edges()),
+                "nodes": (None if vl_gate is None else int((vl_gate != 0).sum().item()), graph.number_of_nodes())}
+
     def _compact_gated(self, pattern, graph, el_gate):
         """``collate.CompactedEdges`` for this batch, or None (capacity off, no gate, options that read per-edge extras)."""
         if not self.gate_capacity or el_gate is None or not hasattr(self, "get_joint_rep") or self.pred_with_enc or self.pred_with_deg:

@@ -33,9 +33,31 @@ def _check_contract(d, steps=3, warmup=2):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] > 0 and r["avg_us"] > 0
-    if "rows_not_fetched" in r:      # the batch's 0 / 1 edge gate: rows the launch leaves out, and the bytes it does move
-        assert 0 < r["rows_not_fetched"] and 0 < r["bytes_per_launch"] < r["bytes_all_rows"]
-        assert r["frac"] < r["effective_frac_all_rows"] and r["frac"] < 1.0 and "note" in r
+    # `frac` is on SURVEY 8(d)'s byte count, the kernel's own byte count beside it
+    assert r["bytes_basis"].startswith("SURVEY") and r["bytes_own"] >= r["bytes_per_launch"] and r["frac_own_bytes"] >= r["frac"]
+    if "rows_not_fetched" in r:      # the batch's 0 / 1 gates: rows the launch leaves out, and the bytes it does move
+        assert 0 < r["rows_not_fetched"] and 0 < r["bytes_per_launch"] < r["bytes_survey_all_rows"]
+        assert r["frac"] < 1.0 and "note" in r
+    _no_rate_above_the_peak(d)
+    gk = d["gate_kept"]
+    assert 0 < gk["edge_rows"] <= gk["of_edge_rows"] and 0 < gk["node_rows"] <= gk["of_node_rows"]
+
+
+def _no_rate_above_the_peak(obj, path="line"):
+    """Nothing in the line may exceed 8000 GB/s or a fraction of 1.0 (bench.check_rates enforces it before printing; here once
+    more on what was printed)."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(v, (dict, list)):
+                _no_rate_above_the_peak(v, path + "." + k)
+            elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                if k in ("gbps", "hbm_gbps") or (k == "achieved" and obj.get("unit") == "GB/s"):
+                    assert v <= 8000.0, (path, k, v)
+                if k.startswith("frac") or k.endswith("_frac"):
+                    assert v <= 1.0, (path, k, v)
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            _no_rate_above_the_peak(v, "%s[%d]" % (path, i))
 
 
 def test_default_mode_replays_and_eager_agrees(gpu):
@@ -49,6 +71,8 @@ def test_default_mode_replays_and_eager_agrees(gpu):
     gc = d["gate_compact"]
     assert gc["ms_per_step"] > 0 and 0 < gc["capacity"] < gc["target_edge_rows"] and gc["unit"] == "pairs/s"
     assert abs(gc["value"] - 16 / (gc["ms_per_step"] * 1e-3)) <= 0.01 * gc["value"]
+    gd = d["gate_dense"]                                       # the control: the same step without the filter's gates
+    assert gd["ms_per_step"] > 0 and gd["unit"] == "pairs/s" and abs(gd["value"] - 16 / (gd["ms_per_step"] * 1e-3)) <= 0.01 * gd["value"]
     e = _run("--eager", "--no-cpu-baseline")
     _check_contract(e)
     assert e["config"]["launch"] == "eager launches" and e["config"]["eager_ms_per_step"] is None
@@ -61,6 +85,9 @@ def test_cpu_baseline_object(gpu):
     d = _run("--eager", timeout=900)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    # SURVEY 8(d)'s protocol: 3 warm-up steps, at least 10 timed steps, the median
+    assert c["protocol"].startswith("3 warm-up + ") and int(c["protocol"].split("+ ")[1].split(" ")[0]) >= 10
+    assert c["step_s_min"] <= c["step_s_median"] <= c["step_s_max"] and abs(c["value"] - 32 / c["step_s_median"]) <= 0.01 * c["value"]   # (B = 32 pairs per CPU step)
 
 
 def test_two_ranks_replay_their_forward_backward(gpu):
