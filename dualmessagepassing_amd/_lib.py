@@ -47,7 +47,6 @@ SIGNATURES = {
     "dmp_pattern_edge_active": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_subiso_edge_weights": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
-    "dmp_class_tiles_segsum_words": (c_i64, [c_int]),
     "dmp_class_tiles_workspace_words": (c_size, [c_i64, c_int]),
     "dmp_class_tiles": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_csr_keep_scratch_words": (c_i64, [c_i64]),
@@ -95,13 +94,10 @@ SIGNATURES = {
     "dmp_smallk_embed_gate": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_smallk_atb_blocks": (c_i64, [c_i64]),
     "dmp_smallk_embed_cols": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
-    "dmp_smallk_atb_cols": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_smallk_atb_cols_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_l0_pack": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
-    "dmp_l0_edge_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,
-                                c_ptr, c_i64, c_ptr]),
     "dmp_l0_edge_fwd_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
                                        c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_l0_bwd_w_blocks": (c_i64, [c_i64]),
@@ -110,7 +106,6 @@ SIGNATURES = {
                                  c_i64, c_ptr]),
     "dmp_bn_train_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_int, c_f32, c_ptr, c_ptr, c_ptr, c_i64,
                                  c_ptr]),
-    "dmp_l0_bwd_w": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_l0_bwd_w_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_scalar_filter_gates": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_csr_pair_workspace_words": (ctypes.c_size_t, [c_i64]),
@@ -137,8 +132,6 @@ SIGNATURES = {
                                    c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_edge_fwd_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr]),
-    "dmp_bwd_z_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
-                                c_f32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_bwd_z_typed_arow": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32,
                                      c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_mask_slots": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -147,20 +140,14 @@ SIGNATURES = {
                                   c_ptr, c_ptr, c_ptr]),
     "dmp_relu_bwd_gathered_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_dev_set_mfma_variant": (None, [c_int]),
-    "dmp_edge_chain_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
-                                   c_int, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_ptr]),
-    "dmp_gemm_x6": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_f32,
-                            c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_dev_set_exact_fp32": (None, [c_int]),
     "dmp_dev_get_exact_fp32": (c_int, []),
     "dmp_rel_gemm": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
                              c_int, c_ptr, c_i64, c_ptr]),
     "dmp_rel_atb_blocks": (c_i64, [c_int]),
     "dmp_rel_atb": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr]),
-    "dmp_atb_typed_blocks": (c_i64, [c_i64]),
     "dmp_atb_typed_blocks_h": (c_i64, [c_i64, c_int]),
     "dmp_atb_rows_blocks_h": (c_i64, [c_i64, c_int, c_int, c_int]),
-    "dmp_atb_rows_h": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_rows_plain": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "dmp_atb_rows_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_jobs_blocks_h": (c_i64, [c_i64, c_int, c_int]),
@@ -168,14 +155,6 @@ SIGNATURES = {
     "dmp_mfma_partial_rows_h": (c_i64, [c_i64, c_int]),
     "dmp_gemm_k64": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_ptr]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
-    "dmp_atb_rows_blocks": (c_i64, [c_i64, c_int, c_int]),
-    "dmp_atb_jobs_blocks": (c_i64, [c_i64, c_int]),
-    "dmp_atb_rows_jobs": (c_int, [c_ptr, c_int, c_i64, c_ptr]),
-    "dmp_atb_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr]),
-    "dmp_out_fwd_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
-                                  c_i64, c_ptr]),
-    "dmp_out_fwd_fused_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
-                                         c_i64, c_ptr]),
     "dmp_out_fwd_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                        c_i64, c_ptr]),
     "dmp_bwd_h1_fused_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_f32, c_ptr,
@@ -191,13 +170,6 @@ SIGNATURES = {
                                  c_ptr, c_ptr, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_row_mask_rows": (c_int, [c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr]),
-    "dmp_mfma_partial_rows": (c_i64, [c_i64]),
-    "dmp_bwd_h1_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_i64,
-                                 c_ptr, c_ptr]),
-    "dmp_bwd_h1_fused_colsum": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr,
-                                        c_i64, c_ptr, c_ptr, c_ptr]),
-    "dmp_bwd_h1_fused_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr,
-                                        c_i64, c_ptr, c_ptr]),
     "dmp_bwd_z_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                                 c_f32, c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_gemm_k128": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_int, c_ptr]),
@@ -213,10 +185,10 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 70
-# DMP_VALIDATE=1: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint or a
-# lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
-# datasets once with harness.validate_samples, or run a debugging pass with this switch)
-VALIDATE = os.environ.get("DMP_VALIDATE", "") not in ("", "0")
+# ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
+# or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
+# datasets once with harness.validate_samples, or run a debugging pass with this attribute set)
+VALIDATE = False
 ERRORS = {-1: "DMP_ERR_BAD_ARG", -2: "DMP_ERR_UNSUPPORTED", -3: "DMP_ERR_HIP"}
 
 

@@ -453,7 +453,6 @@ using namespace dmp;
 
 extern "C" {
 
-int64_t dmp_atb_typed_blocks(int64_t tiles_bound) { return (int64_t)atb_blocks(tiles_bound); }
 int64_t dmp_atb_typed_blocks_h(int64_t tiles_bound, int H) { return (int64_t)atb_blocks(tiles_bound, H == 64 ? 64 : 128); }
 
 int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, const int32_t *slot_edge,
@@ -483,14 +482,10 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp, c
 }
 
 int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H) { return (int64_t)rows_blocks(rows, M, N, H == 64 ? 64 : 128); }
-int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N) { return dmp_atb_rows_blocks_h(rows, M, N, 128); }
-
 int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H) {
   const int h = H == 64 ? 64 : 128;
   return (int64_t)rows_blocks(rows, h, h * (num_jobs > 0 ? num_jobs : 1), h);
 }
-int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs) { return dmp_atb_jobs_blocks_h(rows, num_jobs, 128); }
-
 int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream) {
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || num_jobs < 1 || num_jobs > kMaxAtbJobs || !jobs) return DMP_ERR_BAD_ARG;
@@ -515,10 +510,6 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
                   : atb_jobs_launch<64>(t, num_jobs, rows, (hipStream_t)stream, plain);
 }
 
-int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream) {
-  return dmp_atb_rows_jobs_h(jobs, num_jobs, rows, 128, stream);
-}
-
 int64_t dmp_rel_atb_blocks(int num_rels) { return num_rels >= 512 ? 1 : 512 / (num_rels > 0 ? num_rels : 1); }
 
 int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int64_t ldd, int64_t rows_d,
@@ -538,11 +529,6 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
   const dim3 grid((unsigned)dmp_rel_atb_blocks(num_rels), (unsigned)num_rels);
   launch_atb<ATB_REL, 128>(a, grid, (hipStream_t)stream);
   return check_launch();
-}
-
-int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N, int H,
-                   float *partial, float *partial_colsum, void *stream) {
-  return dmp_atb_rows_masked(A, lda, B, ldb, gate, nullptr, 0, rows, M, N, H, partial, partial_colsum, stream);
 }
 
 int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, const uint32_t *rowmask,
@@ -593,11 +579,6 @@ int dmp_atb_rows_plain(const float *A, int64_t lda, const float *B, int64_t ldb,
     launch_atb<ATB_PLAIN, 64>(a, grid, (hipStream_t)stream);
   }
   return check_launch();
-}
-
-int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, int64_t rows, int M, int N,
-                 float *partial, float *partial_colsum, void *stream) {
-  return dmp_atb_rows_h(A, lda, B, ldb, gate, rows, M, N, 128, partial, partial_colsum, stream);
 }
 
 }  // extern "C"

@@ -767,7 +767,7 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t R, int H, float *pa
 
 int64_t dmp_smallk_atb_blocks(int64_t rows) { return (int64_t)smallk_blocks(rows); }
 
-int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2, int64_t ldd2,
+static int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2, int64_t ldd2,
                         const float *gate, int64_t R, int H, float *partial, void *stream) {
   return dmp_smallk_atb_cols_masked(X, ldx, K, D, ldd, ncols, D2, ldd2, gate, nullptr, R, H, partial, stream);
 }

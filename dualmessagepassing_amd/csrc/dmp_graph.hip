@@ -1728,7 +1728,7 @@ int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample
   return check_launch();
 }
 
-int64_t dmp_class_tiles_segsum_words(int num_classes) {
+static int64_t dmp_class_tiles_segsum_words(int num_classes) {
   return (int64_t)(num_classes < kCtFast ? num_classes : kCtFast) * kCtSegs;
 }
 

@@ -414,12 +414,6 @@ int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *en
   return check_launch();
 }
 
-int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
-                    const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t R, int H,
-                    float slope, float *out, int64_t ldo, void *stream) {
-  return dmp_l0_edge_fwd_masked(enc, lde, K, M, ldm, P, ldp, bias, coef_e, sel_a, sel_b, nullptr, R, H, slope, out, ldo, stream);
-}
-
 int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                            const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                            const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream) {
@@ -484,11 +478,6 @@ int dmp_l0_bwd_w_rows(const float *enc, int64_t lde, int K, const float *coef_e,
 }
 
 int64_t dmp_l0_bwd_w_blocks(int64_t rows) { return (int64_t)l0_blocks(rows, kL0MaxPartials); }
-
-int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
-                 int64_t ldz, int64_t R, int H, float *partial, void *stream) {
-  return dmp_l0_bwd_w_masked(enc, lde, K, coef_e, dPre, ldd, dZn, ldz, nullptr, R, H, partial, stream);
-}
 
 int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
                         int64_t ldz, const uint32_t *rowmask, int64_t R, int H, float *partial, void *stream) {

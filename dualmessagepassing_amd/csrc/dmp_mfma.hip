@@ -710,18 +710,6 @@ int dmp_row_mask_rows(const float *X, int64_t ldx, int K, int64_t R, uint32_t *m
   return check_launch();
 }
 
-int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
-                      const float *gate, const float *R, int64_t ldr, int64_t E, int H, int w_in_out,
-                      float *out, int64_t ldo, void *stream) {
-  return dmp_out_fwd_fused_masked(Hin, ldh, W2, ldw, bias, gate, nullptr, R, ldr, E, H, w_in_out, out, ldo, stream);
-}
-
-int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
-                             const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
-                             int w_in_out, float *out, int64_t ldo, void *stream) {
-  return dmp_out_fwd_fused_rows(Hin, ldh, W2, ldw, bias, gate, rowmask, 0, R, ldr, E, H, w_in_out, out, ldo, stream);
-}
-
 int dmp_out_fwd_fused_rows(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
                            const float *gate, const uint32_t *rowmask, int dead_rows, const float *R, int64_t ldr, int64_t E, int H,
                            int w_in_out, float *out, int64_t ldo, void *stream) {
@@ -744,30 +732,12 @@ int dmp_out_fwd_fused_rows(const float *Hin, int64_t ldh, const float *W2, int64
   return H == 128 ? launch_mfma<1, EPI_GATE_RES>(p, (hipStream_t)stream) : launch_mfma64<EPI_GATE_RES>(p, (hipStream_t)stream);
 }
 
-int64_t dmp_mfma_partial_rows(int64_t E) {      // = the grid of the EPI_RELU_BWD_G launch (bwd_h1): one partial row per workgroup
+static int64_t dmp_mfma_partial_rows(int64_t E) {      // = the grid of the EPI_RELU_BWD_G launch (bwd_h1): one partial row per workgroup
   return g_variant == 1 ? 2 * (int64_t)pp_blocks(E) : (int64_t)wg_blocks(E, x6_on<1, EPI_RELU_BWD_G>() ? 2 : 3);
 }
 int64_t dmp_mfma_partial_rows_h(int64_t E, int H) { return H == 64 ? (int64_t)wg_blocks(E, kPerCU64) : dmp_mfma_partial_rows(E); }
 
 void dmp_dev_set_mfma_variant(int v) { g_variant = v; }
-
-int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                     const float *coefE, const float *gate, int64_t E, int H, float slope, float *dG, int64_t ldg,
-                     float *partial, void *stream) {
-  return dmp_bwd_h1_fused_masked(dO, ldo, W2, ldw, H1, ldh, coefE, gate, nullptr, E, H, slope, dG, ldg, partial, stream);
-}
-
-int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
-                            float *dG, int64_t ldg, float *partial, void *stream) {
-  return dmp_bwd_h1_fused_rows(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, 0, E, H, slope, dG, ldg, partial, nullptr, stream);
-}
-
-int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
-                            float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream) {
-  return dmp_bwd_h1_fused_rows(dO, ldo, W2, ldw, H1, ldh, coefE, gate, rowmask, 0, E, H, slope, dG, ldg, partial, partial_rows, stream);
-}
 
 int dmp_bwd_h1_fused_rows(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                           const float *coefE, const float *gate, const uint32_t *rowmask, int skip_dead_stores, int64_t E, int H,

@@ -584,15 +584,6 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
                   : launch_typed<TEPI_EDGE, 64>(p, tiles_bound, (hipStream_t)stream);
 }
 
-int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D, int64_t ldd,
-                    int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag,
-                    float s0, float s1, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t E, int H, int w_transposed, const int32_t *base_map, int64_t base_rows,
-                    float *dZ, int64_t ldz, void *stream) {
-  return dmp_bwd_z_typed_arow(dPre, ldp, W, ldw, D, ldd, num_nodes, base, ldb, dst, flag, s0, s1, slot_edge, nullptr, tile_scale,
-                              num_tiles, tiles_bound, E, H, w_transposed, base_map, base_rows, dZ, ldz, stream);
-}
-
 // rows of the partial arrays of dmp_bwd_h1_typed = the grid of its launch (launch_typed)
 int64_t dmp_typed_partial_rows(int64_t tiles_bound, int H) {
   return (int64_t)typed_blocks(tiles_bound, g_exact_fp32 ? (H == 128 ? 3 : TypedGeom<64>::kPerCU) : (H == 128 ? 2 : 4));

@@ -205,7 +205,7 @@ class FlatGradSync:
                 self.flat.div_(self.world)
 
 
-USE_SEGMENT_STEPS = os.environ.get("DMP_ADAMW_SEGMENTS", "1") == "1"   # one AdamW step count per parameter tensor of a flat buffer
+USE_SEGMENT_STEPS = True   # one AdamW step count per parameter tensor of a flat buffer
 
 
 class FlatAdamW(torch.optim.Optimizer):

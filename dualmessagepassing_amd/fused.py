@@ -239,33 +239,6 @@ def atb(a, b):
     return reduce_partials(part.view(S + tail, -1)).view(a.size(1), b.size(1))
 
 
-USE_GEMM_X6 = True   # node-side row-block products on the bf16 matrix pipe (csrc/dmp_gemm6.hip) instead of library fp32 GEMMs
-
-
-def gemm_x6_ok(*mats):
-    """``gemm_x6`` takes these fp32 operands (row-major, 16-byte aligned rows)."""
-    return USE_GEMM_X6 and all(m is None or (m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.stride(1) == 1
-                                            and m.stride(0) % 4 == 0 and m.data_ptr() % 16 == 0) for m in mats)
-
-
-def gemm_x6(a1, B, a2=None, transB=False, bias=None, add=None, rowscale=None, slope=None, out=None):
-    """``epi([a1 | a2] @ B)`` (``B`` [K, N]; ``transB``: ``B`` is given as [N, K]) on the bf16 matrix pipe, fp32-accurate
-    (``dmp_gemm_x6``).  ``epi(P) = act(P + bias + add)``, or with ``rowscale``: ``add + rowscale * act(P + bias)``;
-    ``slope`` None: no activation, else LeakyReLU(slope) (0.0 = ReLU).  K's parts multiples of 16, N a multiple of 64."""
-    lib = _lib.load()
-    R, K1 = a1.shape
-    K2 = a2.size(1) if a2 is not None else 0
-    N = B.size(0) if transB else B.size(1)
-    if out is None:
-        out = torch.empty((R, N), dtype=torch.float32, device=a1.device)
-    with _lib.timed("gemm_x6[K=%d,N=%d,R=%d]", (K1 + K2, N, R), 4 * R * (K1 + K2 + N * (2 if add is not None else 1))):
-        check(lib.dmp_gemm_x6(ptr(a1), a1.stride(0), K1, ptr(a2), a2.stride(0) if a2 is not None else 0, K2, ptr(B), B.stride(0),
-                              int(transB), ptr(bias), ptr(add), add.stride(0) if add is not None else 0, ptr(rowscale),
-                              int(slope is not None), float(slope or 0.0), ptr(out), out.stride(0), R, N, stream_ptr()),
-              "dmp_gemm_x6")
-    return out
-
-
 def edge_combine_raw(G, ldg, P, ldp, bias, coef, index, H, relu=False, slope=0.0):
     lib = _lib.load()
     E = index.num_edges
@@ -353,35 +326,6 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None,
 
 
 import os as _os
-# H = 128: edge_fwd_typed + out_fwd as one launch (csrc/dmp_chain.hip).  OFF by default: measured in the step (same box, A/B,
-# gpurun_out r03m) it saves 20 us per layer on its own (292 vs 312 us) but the forward scatter-add that follows reads the
-# rows it has just written 7 us slower (72.8 vs 65.6 us: the class-ordered writes of one workgroup per CU leave the rows in
-# other XCDs' L2 slices than the row-ordered out_fwd) -- net 5.51 vs 5.53 ms per step, and the graded kernel's roofline
-# fraction drops from 0.68 to 0.62.  DMP_EDGE_CHAIN=1 switches it on.
-USE_EDGE_CHAIN = _os.environ.get("DMP_EDGE_CHAIN", "0") == "1"
-
-
-def edge_chain_ok(index, H):
-    lib = _lib.load()
-    return USE_EDGE_CHAIN and H == 128 and typed_ok(index, H) and not lib.dmp_dev_get_exact_fp32()
-
-
-def edge_chain_fwd(z, Wes, P, ldp, bias, coef, index, eW2t, eb2, gate, residual, slope=0.0):
-    """``(H1e, zn)``: ``edge_fwd_typed`` and ``out_fwd_mfma`` of the edge side in ONE launch -- the H1 tile goes from the first
-    product's epilogue to the second product through LDS (three passes over [E, H] arrays instead of six)."""
-    lib = _lib.load()
-    E, H = z.shape
-    h1 = torch.empty((E, H), dtype=torch.float32, device=z.device)
-    zn = torch.empty((E, H), dtype=torch.float32, device=z.device)
-    Wes = Wes.contiguous()
-    sel_a, sel_b, _ = index.edge_select(coef)
-    slot_edge, tile_scale, num_tiles, bound = index.class_tiles(coef)
-    with _lib.timed("edge_chain_fwd[H=%d,E=%d]", (H, E), 4 * H * (3 * E + 2 * index.num_nodes) + 16 * E):
-        check(lib.dmp_edge_chain_fwd(ptr(z), H, ptr(Wes), Wes.size(1), ptr(P), ldp, index.num_nodes, ptr(bias), ptr(sel_a), ptr(sel_b),
-                                     ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, E, H, slope, ptr(h1), H,
-                                     ptr(eW2t), eW2t.size(1), ptr(eb2), ptr(gate), int(bool(residual)), ptr(zn), H, stream_ptr()),
-              "dmp_edge_chain_fwd")
-    return h1, zn
 
 
 def masked_slots(index, coef, gate):
@@ -410,7 +354,7 @@ def masked_slots(index, coef, gate):
     return out
 
 
-USE_LIVE_TILES = _os.environ.get("DMP_LIVE_TILES", "1") == "1"
+USE_LIVE_TILES = True      # (module attributes, not environment switches: tests flip them; the documented DMP_* switches are listed in DESIGN.md 2)
 
 
 def live_tiles(index, coef, gate):
@@ -434,7 +378,7 @@ def live_tiles(index, coef, gate):
     return res
 
 
-USE_KEEP_CSR = _os.environ.get("DMP_KEEP_CSR", "1") == "1"
+USE_KEEP_CSR = True
 
 
 def keep_in_csr(index, gate):
@@ -533,7 +477,7 @@ def atb_typed(z, d_pre, coef, index, gate=None, plain=False):
 USE_ROW_MASKS = _os.environ.get("DMP_ROW_MASKS", "1") == "1"   # gated E-row kernels do not fetch the rows a zero gate annihilates
 # ... and the two kernels that PRODUCE the first MLP's activation H1 leave out the rows all of whose consumers skip them
 # (dead values: out_fwd, bwd_h1, atb_rows, the pooled passes multiply them by the zero gate).  Only with USE_ROW_MASKS.
-SKIP_DEAD_ROWS = _os.environ.get("DMP_SKIP_DEAD_ROWS", "1") == "1"
+SKIP_DEAD_ROWS = True
 POISON_DEAD_ROWS = _os.environ.get("DMP_POISON_DEAD_ROWS", "0") == "1"   # testing aid: buffers with dead rows start as NaN
 
 
@@ -603,8 +547,8 @@ def out_fwd_mfma(h1, W2, b2, gate, prev, W2t=None, dead_rows=0):
     return out
 
 
-USE_TYPED_ATB_ROWS = _os.environ.get("DMP_TYPED_ATB_ROWS", "1") == "1"
-USE_TYPED_ROWS = _os.environ.get("DMP_TYPED_ROWS", "1") == "1"   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
+USE_TYPED_ATB_ROWS = True
+USE_TYPED_ROWS = True   # out_fwd / bwd_h1 over the kept edges' tiles where dead rows need no store
 
 
 _TYPED_JOB = None
@@ -673,7 +617,7 @@ def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0, out=None):
     return d_g, reduce_partials(part), reduce_partials(part_rows)
 
 
-USE_MASKED_SUMS = _os.environ.get("DMP_MASKED_SUMS", "1") != "0"   # the scatter-adds skip the rows a 0 / 1 edge gate wiped
+USE_MASKED_SUMS = True   # the scatter-adds skip the rows a 0 / 1 edge gate wiped
 
 
 def zero_rows_gate(gate):
@@ -736,7 +680,7 @@ def _gate_owner(gate):
     return owner
 
 
-USE_PLAIN_ATB = _os.environ.get("DMP_PLAIN_ATB", "1") == "1"
+USE_PLAIN_ATB = True
 
 
 def atb_rows(a, b, gate=None, colsum=True):
@@ -766,7 +710,7 @@ def atb_rows(a, b, gate=None, colsum=True):
     return reduce_partials(part).view(M, N), (reduce_partials(part_cs) if colsum else None)
 
 
-ATB_ROWS_X6 = int(_os.environ.get("DMP_ATB_ROWS_X6", "0"))   # the gated rows weight gradient on the bf16 pipe (csrc/dmp_atb.hip)
+ATB_ROWS_X6 = 0   # the gated rows weight gradient on the bf16 pipe (csrc/dmp_atb.hip)
 SMALLK_MAX = 16
 
 
@@ -829,7 +773,7 @@ L0_KMAX = 16
 # the joint rep-net pass hands the first layer the packed label codes instead of differentiable [E, H] rows
 # (dmpnn.joint_rep); DMP_LAYER0=0 keeps the general path
 USE_LAYER0 = _os.environ.get("DMP_LAYER0", "1") == "1"
-USE_LAYER0_NODES = _os.environ.get("DMP_LAYER0_NODES", "1") == "1"    # ... and the node rows' codes as well
+USE_LAYER0_NODES = True    # ... and the node rows' codes as well
 
 
 def l0_pack(enc_p, enc_g, gate=None, stacked=False):
@@ -849,7 +793,7 @@ def l0_pack(enc_p, enc_g, gate=None, stacked=False):
     return out
 
 
-USE_L0_ROW_LISTS = _os.environ.get("DMP_L0_ROW_LISTS", "1") == "1"
+USE_L0_ROW_LISTS = True
 L0_LIST_MIN_ROWS = 32768       # shorter row ranges (the pattern side) keep the masked form: the list costs two launches
 
 
@@ -1229,7 +1173,7 @@ def fold_layers(layers):
 
 
 _GEMM_TYPES = None
-USE_SMALL_GEMM_JOBS = _os.environ.get("DMP_SMALL_GEMM_JOBS", "1") == "1"
+USE_SMALL_GEMM_JOBS = True
 
 
 def small_gemm_jobs(jobs):
@@ -1401,8 +1345,6 @@ class _FusedDMPLayer(torch.autograd.Function):
                 if rows[1] > rows[0]:
                     l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e,
                                 mask=gate_row_mask(dead_gate) if dead_gate is not None else None)
-        elif nd is None and edge_chain_ok(index, H) and eW2t is not None and not sums_only:
-            H1e, zn = edge_chain_fwd(z, Wes, XP[:, H:], 3 * H, be, coef, index, eW2t, eb2, e_gate, residual, slope)
         elif typed_ok(index, H):
             # (under ``nd`` the projection rows of the dead nodes were never written: their selectors read as zeros)
             H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope, dead_gate=dead_gate, sel=None if nd is None else nd.sel)

@@ -33,7 +33,7 @@ class function:  # namespace mirroring ``import dgl.function as fn``
     sum = SumReducer
 
 
-USE_GRAPH_CSR = os.environ.get("DMP_GRAPH_CSR", "1") == "1"   # block-diagonal batches: both CSRs from ONE launch (dmp_csr_build_graphs)
+USE_GRAPH_CSR = True   # block-diagonal batches: both CSRs from ONE launch (dmp_csr_build_graphs)
 
 
 class GraphIndex:

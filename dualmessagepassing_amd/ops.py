@@ -46,7 +46,7 @@ TILE_MAX_ROWS = 512     # kTileRows of csrc/dmp_agg.hip::seg_sum_tiled
 # CU: the load -> barrier -> sums structure is exposed where the plain kernel keeps 32 waves per CU in flight); DESIGN.md §8.
 USE_TILED_SEG_SUM = False
 import os as _os
-USE_HIP_BATCHNORM = _os.environ.get("DMP_HIP_BATCHNORM", "1") == "1"   # training-mode BatchNorm1d of the MLPs on csrc/dmp_bn.hip
+USE_HIP_BATCHNORM = True   # training-mode BatchNorm1d of the MLPs on csrc/dmp_bn.hip
 
 
 def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
@@ -63,9 +63,9 @@ def graph_tiling(node_off, edge_off, Ba, max_edges_a, Bb=0, max_edges_b=None):
 
 
 # The layer backward's scatter-add of dPre into both endpoint rows as ONE pass over the edge rows with the sums of a graph
-# tile in registers (csrc/dmp_segacc.hip): on by default where a block-diagonal batch says how its graphs tile.  DMP_GRAPH_SEG_SUM=0
-# takes dmp_seg_sum2 over the incidence CSR instead (same bits: both sum in ascending eid).
-USE_GRAPH_SEG_SUM = _os.environ.get("DMP_GRAPH_SEG_SUM", "1") == "1"
+# tile in registers (csrc/dmp_segacc.hip): on by default where a block-diagonal batch says how its graphs tile.  Off (a module
+# attribute, for tests): dmp_seg_sum2 over the incidence CSR instead (same bits: both sum in ascending eid).
+USE_GRAPH_SEG_SUM = True
 GRAPH_ACC_NODES = 64       # dmp_seg_sum2_graphs_max_nodes(): node rows of a tile
 
 

@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_FILE = os.path.join(_HERE, "tuned", "tunableop_gfx950.csv")
 
 
+TUNE_OUT = None     # development (a module attribute): a file name -> tune the shapes this run meets and write them there
+
+
 def enable_tuned_gemms(path=None, allow_tuning=False):
     """Returns True if the tuned-solution file was loaded."""
     import torch
@@ -21,7 +24,7 @@ def enable_tuned_gemms(path=None, allow_tuning=False):
         return False
     import torch.cuda.tunable as tn
     path = path or DEFAULT_FILE
-    tune_out = os.environ.get("DMP_TUNE_OUT")       # development: tune the shapes this run meets and write them to this file
+    tune_out = TUNE_OUT                             # development: tune the shapes this run meets and write them to this file
     if tune_out:
         allow_tuning = True
         tn.set_filename(tune_out)

@@ -340,7 +340,6 @@ int dmp_subiso_edge_weights(const int64_t *sub, int64_t T, const int64_t *sample
  *   tile's class (entries past num_tiles are not written), num_tiles [1];
  *   ws: 8-byte aligned scratch of dmp_class_tiles_workspace_words(N, num_classes) int32 words.
  */
-int64_t dmp_class_tiles_segsum_words(int num_classes);
 size_t dmp_class_tiles_workspace_words(int64_t num_nodes, int num_classes);
 int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in_ent, int64_t num_nodes,
                     int64_t num_edges, int num_classes, int64_t tiles_bound, int32_t *ws,
@@ -631,8 +630,6 @@ int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, in
  * partial: [ncols (+1), dmp_smallk_atb_blocks(rows), K*H] -- one dmp_reduce_partials per column block. */
 int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate,
                           int64_t rows, int H, int ncols, float *out, int64_t ldo, void *stream);
-int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
-                        int64_t ldd2, const float *gate, int64_t rows, int H, float *partial, void *stream);
 /* ... with a row mask (dmp_row_mask_bits): rows of D / D2 whose bit is 0 -- rows whose X row is all zeros, or whose gate is 0 -- are
  * not fetched. */
 int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
@@ -656,9 +653,6 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
  *                    class-typed weight gradient is W^T of the first two blocks, the embedding's gradient needs all three. */
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
                 int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream);
-int dmp_l0_edge_fwd(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
-                    const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b, int64_t rows,
-                    int H, float slope, float *out, int64_t ldo, void *stream);
 /* ... leaving out DEAD rows: bit r of rowmask[t] == 0 says that every consumer of row 32 t + r of `out` multiplies it by a zero gate
  * and does not fetch it (the `_masked` kernels, dmp_pool_relu_bwd, the weighted dmp_seg_sum): nothing is gathered, computed or
  * STORED for such a row -- `out` keeps whatever the buffer held there. */
@@ -666,8 +660,6 @@ int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M,
                            const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                            const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream);
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
-int dmp_l0_bwd_w(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd,
-                 const float *dZn, int64_t ldz, int64_t rows, int H, float *partial, void *stream);
 /* dmp_l0_bwd_w with a row mask: bit r of rowmask[t] == 0 says the code row 32 t + r is all zeros (the row's gate was 0 when
  * dmp_l0_pack made it), so its dPre / dZn rows -- which would be multiplied by those zeros -- are not fetched. */
 int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
@@ -986,9 +978,6 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
  *   W2 [H, ldw>=H] in nn.Linear layout [out, in], or -- w_in_out != 0 -- its transpose [in, out] (every
  *   workgroup then reads its weight panel with coalesced loads); gate [rows] or NULL (1); R [rows, ldr] or NULL (0).
  */
-int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ldw,
-                      const float *bias, const float *gate, const float *R, int64_t ldr,
-                      int64_t rows, int H, int w_in_out, float *out, int64_t ldo, void *stream);
 
 /*
  * Backward of the second Linear, the (Leaky)ReLU and dmp_edge_combine in one pass:
@@ -1000,12 +989,8 @@ int dmp_out_fwd_fused(const float *Hin, int64_t ldh, const float *W2, int64_t ld
  *   dPre[e] = H1[e] > 0 ? gate[e] (dO[e] W2) : 0 -- the separate gate pass of the backward is fused away
  *   (gate must be NULL with coefE).  Also serves the node update's MLP (rows = nodes, gate = v_gate).
  */
-int64_t dmp_mfma_partial_rows(int64_t num_edges);            /* H = 128 */
+            /* H = 128 */
 int64_t dmp_mfma_partial_rows_h(int64_t num_edges, int H);   /* H = 128 or 64 */
-int dmp_bwd_h1_fused(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
-                     const float *H1, int64_t ldh, const float *coefE, const float *gate,
-                     int64_t num_edges, int H, float slope, float *dG, int64_t ldg, float *partial,
-                     void *stream);
 
 /* Row masks for gated E-row kernels: bit r of mask[t] = (gate[32 t + r] != 0), mask [(E + 31) / 32] words.  The `_masked` forms of
  * dmp_out_fwd_fused / dmp_bwd_h1_fused take it beside the gate and do not FETCH the operand rows of a masked row (H1 in the
@@ -1016,19 +1001,10 @@ int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream
 /* ... of the rows of a matrix: bit r of mask[t] = (row 32 t + r of X [R, ldx] has a non-zero among its first K entries) -- the label
  * code rows that dmp_l0_pack multiplied by a zero gate; for dmp_l0_bwd_w_masked / dmp_smallk_atb_cols_masked. */
 int dmp_row_mask_rows(const float *X, int64_t ldx, int K, int64_t R, uint32_t *mask, void *stream);
-int dmp_out_fwd_fused_masked(const float *Hin, int64_t ldh, const float *W2, int64_t ldw, const float *bias,
-                             const float *gate, const uint32_t *rowmask, const float *R, int64_t ldr, int64_t E, int H,
-                             int w_in_out, float *out, int64_t ldo, void *stream);
-int dmp_bwd_h1_fused_masked(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
-                            float *dG, int64_t ldg, float *partial, void *stream);
 /* ... that also hands out the column sums of the rows of dO it FETCHED: partial_rows [dmp_mfma_partial_rows_h(E, H), H] (or NULL), summed by
  * dmp_reduce_partials.  With the row mask of a 0 / 1 gate that is sum_e gate_e dO[e] -- the bias gradient of the Linear behind the gate
  * (dmpnn.py:45-60: db2), for which dmp_atb_rows otherwise carries column sums: the weight gradient can then run ungated
  * (dmp_atb_rows_plain).  Without a mask: the column sums of all of dO. */
-int dmp_bwd_h1_fused_colsum(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
-                            const float *coefE, const float *gate, const uint32_t *rowmask, int64_t E, int H, float slope,
-                            float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
 
 /* ... where the caller knows more about the masked-out rows (the rep-net of a ScalarFilter batch: the union's edge rows are
  * [pattern rows | gate * target rows], and zn = z + gate (...) keeps a masked-out row of every layer's input at zero):
@@ -1111,12 +1087,6 @@ int dmp_edge_fwd_typed(const float *Z, int64_t ldz, const float *W, int64_t ldw,
                        const int32_t *selB, const int32_t *slot_edge, const float *tile_scale,
                        const int32_t *num_tiles, int64_t tiles_bound, int64_t num_edges, int H,
                        float slope, float *H1, int64_t ldh, void *stream);
-int dmp_bwd_z_typed(const float *dPre, int64_t ldp, const float *W, int64_t ldw, const float *D,
-                    int64_t ldd, int64_t num_nodes, const float *base, int64_t ldb,
-                    const int32_t *dst, const uint8_t *flag, float s0, float s1,
-                    const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
-                    int64_t tiles_bound, int64_t num_edges, int H, int w_transposed,
-                    const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldz, void *stream);
 /* Gated class tiles: out[s] = slot[s] if gate[slot[s]] != 0 else -1 (a tile slot list whose gated-out edges read as padding).
  * dmp_atb_typed takes it in place of slot_edge (a gated-out edge has dPre = 0: its z^T dPre term is zero, neither row is
  * fetched); dmp_bwd_z_typed_arow takes it as the row list of its streamed operand dPre (slot_arow; NULL = slot_edge), while the
@@ -1139,7 +1109,7 @@ int dmp_bwd_z_typed_arow(const float *dPre, int64_t ldp, const float *W, int64_t
  * bit-stable for a given tile list).  partial_B NULL: the plain total sum_e Z[e]^T dPre[e] alone (a Linear's weight
  * gradient over the edges of a tile list, e.g. dO^T H1 over dmp_class_tiles_gated's kept edges).
  */
-int64_t dmp_atb_typed_blocks(int64_t tiles_bound);          /* H = 128 */
+          /* H = 128 */
 int64_t dmp_atb_typed_blocks_h(int64_t tiles_bound, int H); /* H = 128 or 64 (the reference's shipped hidden_dim) */
 int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
                   const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles,
@@ -1157,14 +1127,8 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
  *   partial: [dmp_atb_rows_blocks(rows, M, N), M*N], partial_colsum: [dmp_atb_rows_blocks(rows, M, N), M];
  *   finish both with dmp_reduce_partials.
  */
-int64_t dmp_atb_rows_blocks(int64_t rows, int M, int N);
-int dmp_atb_rows(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
-                 int64_t rows, int M, int N, float *partial, float *partial_colsum, void *stream);
 /* The same with H x H output blocks, H = 128 (the two functions above) or 64: M and N multiples of H. */
 int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H);
-int dmp_atb_rows_h(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate,
-                   int64_t rows, int M, int N, int H, float *partial, float *partial_colsum,
-                   void *stream);
 /* dmp_atb_rows_h with a row mask (dmp_row_mask_bits of the gate: the rows under a zero gate, which contribute gate * a = 0 to
  * every sum, are not fetched) and the choice of the matrix pipe: x6 != 0 = bf16x6 (fp32-accurate, dmp_dev_set_exact_fp32
  * overrides), 0 = the f32-input MFMA. */
@@ -1215,8 +1179,6 @@ typedef struct {
   const uint32_t *rowmask;   /* optional (dmp_row_mask_bits): rows whose bit is 0 -- rows where A (after its gate) or B is known to be
                               * all zeros -- are not fetched */
 } dmp_atb_job;
-int64_t dmp_atb_jobs_blocks(int64_t rows, int num_jobs);
-int dmp_atb_rows_jobs(const dmp_atb_job *jobs, int num_jobs, int64_t rows, void *stream);
 /* H x H output blocks per job, H = 128 (the two functions above) or 64. */
 int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H);
 int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream);
@@ -1228,35 +1190,6 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
  * held half an iteration apart by barriers).  Process-wide; results are identical. */
 void dmp_dev_set_mfma_variant(int variant);
 
-/*
- * The edge chain forward as ONE launch (csrc/dmp_chain.hip; H = 128, bf16x6 products):
- *     H1[e] = act(Z[e] W_g + P[selA e, 0:H] - P[selB e, H:2H] + bias)           = dmp_edge_fwd_typed
- *     Zn[e] = (residual ? Z[e] : 0) + gate[e] (H1[e] W2^T + b2)                 = dmp_out_fwd_fused
- * (dmpnn.py:142-156 + 262-275).  Two wave groups of a 512-thread workgroup hold the two weight panels; the H1 tile goes
- * from the first product's epilogue to the second product through LDS: Z is read once, H1 and Zn are written once (three
- * passes over [E, H] arrays instead of six).  W2t: the second Linear's weight transposed ([in, out], leading dim ldw2).
- * Arguments otherwise as the two functions it replaces.  DMP_ERR_UNSUPPORTED with the exact-fp32 switch on.
- */
-int dmp_edge_chain_fwd(const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *P, int64_t ldp, int64_t num_nodes,
-                       const float *bias, const int32_t *selA, const int32_t *selB, const int32_t *slot_edge,
-                       const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t num_edges, int H,
-                       float slope, float *H1, int64_t ldh, const float *W2t, int64_t ldw2, const float *b2, const float *gate,
-                       int residual, float *Zn, int64_t ldo, void *stream);
-
-/*
- * Node-side row-block products on the bf16 matrix pipe ("bf16x6": fp32 operands as three bf16 pieces, six piece products
- * per 16-deep k-group, fp32 accumulation -- fp32-accurate; csrc/dmp_gemm6.hip).  Replaces the library fp32 GEMMs
- * (f32-input MFMA: 1/16 of the bf16 rate) of the DMPLayer's node side: x @ [W_nl' | W_dst' | W_src'], [S | x] @ [B_n; W_nl']
- * with the bias / activation epilogue (dmpnn.py:113,121,129-140), dP_n @ B_n^T, dx = dx_n + dXP @ W_x^T.
- *   C[R, N] = epi([A1 | A2] B),  A1 [R, K1], A2 [R, K2] or NULL (K1, K2 multiples of 16), N a multiple of 64,
- *   B[k][n] = B[k * ldb + n] (transB = 0) or B[n * ldb + k] (transB = 1).
- *   epi(P) = act(P + bias + Cadd)                       rowscale == NULL   (act = 0: identity; else LeakyReLU(slope), 0 = ReLU)
- *          = Cadd + rowscale[r] * act(P + bias)         rowscale != NULL   (Linear + gate + residual)
- * bias [N], Cadd [R, N] (ld ldadd), rowscale [R]: each may be NULL.  C may alias Cadd.
- */
-int dmp_gemm_x6(const float *A1, int64_t lda1, int K1, const float *A2, int64_t lda2, int K2, const float *B, int64_t ldb,
-                int transB, const float *bias, const float *Cadd, int64_t ldadd, const float *rowscale, int act, float slope,
-                float *C, int64_t ldc, int64_t R, int N, void *stream);
 
 /* Arithmetic of the class-typed kernels' products (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_rel_gemm).  Default (0):
  * fp32 operands split into three bf16 pieces each, six piece products per 16-deep k-group on the bf16 matrix pipe,

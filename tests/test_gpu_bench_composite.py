@@ -73,7 +73,7 @@ def _named_flat(step, model):
     return out
 
 
-def _compare(tag, pred, flat, ref_pred, ref_grads, pred_tol=1e-4, grad_tol=5e-4):
+def _compare(tag, pred, flat, ref_pred, ref_grads, pred_tol=1e-4, grad_tol=2e-4):      # pred_c 1e-4, parameter gradients 2e-4
     scale = max(1.0, float(ref_pred.abs().max()))
     err = float((pred.cpu().view(-1) - ref_pred).abs().max())
     assert err <= pred_tol * scale, "%s: pred_c err %g (scale %g)" % (tag, err, scale)

@@ -26,7 +26,8 @@ def _close(got, ref, rtol=1e-5, atol=1e-5, what=""):
         return
     scale = max(1.0, float(ref.abs().max()))
     err = float((got - ref).abs().max())
-    assert err <= (atol + rtol) * scale, "%s: max err %g (scale %g)" % (what, err, scale)
+    # SURVEY 8(c) / BASELINE.md 3: |delta| <= 1e-5 * max(1, |ref|_max) -- rtol = atol = 1e-5 against the array's scale
+    assert err <= max(atol, rtol * scale), "%s: max err %g (scale %g)" % (what, err, scale)
 
 
 def _close_or_flipped(got, ref, rtol, atol, what, tainted=None):
@@ -35,7 +36,7 @@ def _close_or_flipped(got, ref, rtol, atol, what, tainted=None):
     ``util_flips.taint`` over the oracle's recorded pre-activations; None: no exception at all).  See tests/util_flips.py.
     Returns True when the exception was needed."""
     from util_flips import close_or_traced
-    return close_or_traced(got, ref, rtol + atol, tainted, what)
+    return close_or_traced(got, ref, max(rtol, atol), tainted, what)
 
 
 def _probed(fn):

@@ -1064,7 +1064,7 @@ def test_mfma_kernels_h64(rows, slope, gpu):
 
 
 def test_validate_switch_raises_on_out_of_range_entries(gpu, monkeypatch):
-    """DMP_VALIDATE (``_lib.VALIDATE``): the index builds read their status word back and raise on an edge endpoint /
+    """``_lib.VALIDATE``: the index builds read their status word back and raise on an edge endpoint /
     lookup index outside its range; without it the entry is flagged only (one host sync saved per build)."""
     from dualmessagepassing_amd import _lib, ops
     from dualmessagepassing_amd.graph import GraphIndex
@@ -1081,50 +1081,6 @@ def test_validate_switch_raises_on_out_of_range_entries(gpu, monkeypatch):
     with pytest.raises(_lib.DmpError):
         ops.take_rows(x, th.tensor([0, 3], device=gpu))
     assert th.equal(ops.take_rows(x, th.tensor([2, 0], device=gpu)), x[[2, 0]])
-
-
-@pytest.mark.parametrize("rows", [1, 31, 1000, 70001, 548864])
-@pytest.mark.parametrize("gated,residual,slope", [(True, True, 1 / 5.5), (False, True, 0.0), (True, False, 0.0)])
-def test_edge_chain_forward_equals_the_two_kernels(rows, gated, residual, slope, gpu):
-    """dmp_edge_chain_fwd (edge_fwd_typed + out_fwd in one launch: two wave groups, the H1 tile handed over in LDS)
-    against the two launches it replaces and against fp64.  The H1 rows are the first product's own bits; the second
-    product runs on bf16x6 here and on the f32 MFMA there: fp32 rounding apart."""
-    from dualmessagepassing_amd import fused
-    h = 128
-    gen = th.Generator().manual_seed(rows + 11)
-    rng = np.random.default_rng(rows + 11)
-    n = max(2, rows // 7)
-    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
-    rev = rng.random(rows) < 0.5
-    ix = _index(src, dst, n, rev, gpu)
-    coef = ix.degree_coef(ix.out_deg)
-    z = th.randn(rows, h, generator=gen).to(gpu)
-    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
-    xp = th.randn(n, 3 * h, generator=gen).to(gpu)
-    bias, b2 = th.randn(h, generator=gen).to(gpu), th.randn(h, generator=gen).to(gpu)
-    w2 = (th.randn(h, h, generator=gen) * 0.1).to(gpu)                     # nn.Linear layout [out, in]
-    gate = (th.rand(rows, generator=gen) < 0.7).float().to(gpu) if gated else None
-    assert fused.typed_ok(ix, h)                                           # the kernel itself (off by default in the layer: fused.USE_EDGE_CHAIN)
-    h1, zn = fused.edge_chain_fwd(z, wes, xp[:, h:], 3 * h, bias, coef, ix, w2.t().contiguous(), b2, gate, residual, slope)
-    h1_ref = fused.edge_fwd_typed(z, wes, xp[:, h:], 3 * h, bias, coef, ix, slope)
-    zn_ref = fused.out_fwd_mfma(h1_ref, w2, b2, gate, z if residual else None)
-    assert th.equal(h1, h1_ref)
-    scale = max(1.0, float(zn_ref.abs().max()))
-    assert float((zn - zn_ref).abs().max()) <= 1e-5 * scale
-    # fp64
-    ce = ix.edge_select(coef)
-    a, b, cf = ce[0].long(), ce[1].long(), ce[2].double()
-    zd, P = z.double(), xp.double()
-    pre = zd @ wes[:, :h].double() + cf.view(-1, 1) * (zd @ wes[:, h:].double()) + P[a, h:2 * h] - P[b, 2 * h:] + bias.double()
-    h64 = th.where(pre > 0, pre, slope * pre)
-    o64 = h64 @ w2.double().t() + b2.double()
-    if gate is not None:
-        o64 = o64 * gate.double().view(-1, 1)
-    z64 = (zd + o64) if residual else o64
-    assert float((h1.double() - h64).abs().max()) <= 2e-5 * max(1.0, float(h64.abs().max()))
-    assert float((zn.double() - z64).abs().max()) <= 2e-5 * max(1.0, float(z64.abs().max()))
-    h1b, znb = fused.edge_chain_fwd(z, wes, xp[:, h:], 3 * h, bias, coef, ix, w2.t().contiguous(), b2, gate, residual, slope)
-    assert th.equal(h1, h1b) and th.equal(zn, znb)                        # repeatable
 
 
 @pytest.mark.parametrize("h", [128, 64, 20])

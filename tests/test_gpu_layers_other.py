@@ -18,7 +18,8 @@ def _close(got, ref, rtol=1e-5, atol=1e-5, what=""):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = max(1.0, float(ref.abs().max())) if ref.numel() else 1.0
     err = float((got - ref).abs().max()) if ref.numel() else 0.0
-    assert err <= (atol + rtol) * scale, "%s: max err %g (scale %g)" % (what, err, scale)
+    # SURVEY 8(c) / BASELINE.md 3: |delta| <= 1e-5 * max(1, |ref|_max) -- rtol = atol = 1e-5 against the array's scale
+    assert err <= max(atol, rtol * scale), "%s: max err %g (scale %g)" % (what, err, scale)
 
 
 @pytest.mark.parametrize("path", golden_files("compgcn_"))

@@ -171,3 +171,105 @@ def test_in_edge_sampler_beyond_64_on_hub_nodes(gpu):
                 want = GO.sample_in_edges(dst, n, wanted, width, seed)
                 assert np.array_equal(mask, want), (seed, width)
                 assert np.array_equal(np.bincount(dst[mask], minlength=n), np.where(wanted, np.minimum(indeg, width), 0))
+
+
+def _chi2_bound(df, p=1e-6):
+    from scipy.stats import chi2
+    return float(chi2.ppf(1.0 - p, df))
+
+
+def test_random_walks_follow_dgl_random_walk_in_distribution(gpu):
+    """(f)4, VERDICT r4 item 10.  ``dgl.sampling.random_walk(g, nodes, length)`` as UNC utils.py:291-293 uses it: every step
+    takes one of the current node's OUT-EDGES uniformly at random (parallel edges count with their multiplicity), walks are
+    independent, a node without out-edges ends the walk and the rest of the trace is -1.  DGL itself is absent and its random
+    stream is third-party, so the kernel is held to these semantics IN DISTRIBUTION: chi-square tests of the one-step and
+    two-step visit frequencies and of the independence of consecutive walks (fixed seed: deterministic, p = 1e-6 bounds)."""
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd import unc_sampling as S
+    # node 0: out-edges to 1 (x3, parallel), 2 (x1), 3 (x2); 1 -> {4, 5}; 2 -> {5}; 3 -> {0, 4, 4, 6}; 4: dead end; 5 -> {0}; 6 -> {6} (self-loop)
+    edges = [(0, 1)] * 3 + [(0, 2)] + [(0, 3)] * 2 + [(1, 4), (1, 5), (2, 5), (3, 0), (3, 4), (3, 4), (3, 6), (5, 0), (6, 6)]
+    n = 7
+    src = np.array([a for a, _ in edges], np.int64)
+    dst = np.array([b for _, b in edges], np.int64)
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    P = np.zeros((n, n))
+    for a, b in edges:
+        P[a, b] += 1.0
+    outdeg = P.sum(1)
+    P = np.divide(P, outdeg[:, None], out=np.zeros_like(P), where=outdeg[:, None] > 0)
+    W = 60000
+    traces, visited = S.random_walks(g, th.tensor([0, 4], device=gpu), walks=W, depth=3, seed=2026)
+    t = traces.cpu().numpy().reshape(2, W, 4)
+    a = t[0]
+    assert (a[:, 0] == 0).all()
+    # one step: multinomial over the out-edges of node 0 (multiplicities 3 : 1 : 2)
+    o1 = np.bincount(a[:, 1], minlength=n).astype(float)
+    e1 = W * P[0]
+    assert (o1[e1 == 0] == 0).all()
+    x1 = float((((o1 - e1) ** 2) / np.where(e1 > 0, e1, 1.0))[e1 > 0].sum())
+    assert x1 <= _chi2_bound(int((e1 > 0).sum()) - 1), (x1, o1, e1)
+    # two steps: the Markov chain's two-step law, the dead end 4 reached after one step yields -1 afterwards
+    p2 = P[0] @ P
+    dead_after_1 = P[0, outdeg == 0].sum()
+    o2 = np.bincount(a[:, 2][a[:, 2] >= 0], minlength=n).astype(float)
+    e2 = W * p2
+    x2 = float((((o2 - e2) ** 2) / np.where(e2 > 0, e2, 1.0))[e2 > 0].sum())
+    assert abs((a[:, 2] == -1).mean() - dead_after_1) < 1e-9          # node 0 has no dead-end successor: no walk has ended yet
+    assert x2 <= _chi2_bound(int((e2 > 0).sum()) - 1), (x2, o2, e2)
+    # three steps: walks that reached node 4 (a dead end) at step 2 read -1 at step 3 and nothing else does
+    ended = a[:, 2] == 4
+    assert ended.any() and (a[ended, 3] == -1).all() and (a[~ended, 3] >= 0).all()
+    p3 = p2 @ P
+    o3 = np.bincount(a[:, 3][a[:, 3] >= 0], minlength=n).astype(float)
+    e3 = W * p3
+    x3 = float((((o3 - e3) ** 2) / np.where(e3 > 0, e3, 1.0))[e3 > 0].sum())
+    assert x3 <= _chi2_bound(int((e3 > 0).sum())), (x3, o3, e3)       # (+ the "ended" cell: the counts no longer sum to W)
+    assert abs(ended.mean() - p2[4]) <= 5.0 * np.sqrt(p2[4] * (1 - p2[4]) / W)
+    # a seed that is a dead end: the whole trace after the seed is -1; visited = exactly the nodes on some trace
+    assert (t[1][:, 0] == 4).all() and (t[1][:, 1:] == -1).all()
+    assert np.array_equal(visited.cpu().numpy(), np.isin(np.arange(n), t[t >= 0]))
+    # independence of the walks of one seed: the first steps of walk i and walk i + 1 (contingency table, 3 x 3 cells)
+    f, s = a[:-1, 1], a[1:, 1]
+    tab = np.zeros((n, n))
+    np.add.at(tab, (f, s), 1.0)
+    keep = P[0] > 0
+    tab = tab[np.ix_(keep, keep)]
+    exp = np.outer(tab.sum(1), tab.sum(0)) / tab.sum()
+    xi = float(((tab - exp) ** 2 / exp).sum())
+    assert xi <= _chi2_bound((keep.sum() - 1) ** 2), (xi, tab)
+    # another seed of the generator: another sample of the same law
+    t2 = S.random_walks(g, th.tensor([0], device=gpu), walks=W, depth=1, seed=7)[0].cpu().numpy()
+    assert not np.array_equal(t2[:, 1], a[:, 1])
+    o = np.bincount(t2[:, 1], minlength=n).astype(float)
+    assert float((((o - e1) ** 2) / np.where(e1 > 0, e1, 1.0))[e1 > 0].sum()) <= _chi2_bound(int((e1 > 0).sum()) - 1)
+
+
+def test_in_edge_sampler_follows_dgl_sample_neighbors_in_distribution(gpu):
+    """``dgl.sampling.sample_neighbors(g, nodes, fanout, edge_dir="in")`` (UNC utils.py:294-296,326-335, replace=False): for every
+    requested node ``fanout`` of its in-edges uniformly WITHOUT replacement -- every in-edge with probability fanout / indeg,
+    every pair with fanout (fanout - 1) / (indeg (indeg - 1)), parallel edges as distinct edges -- all of them when there are at
+    most ``fanout``, none for nodes that were not requested.  Held in distribution over 4000 launches with different seeds."""
+    from dualmessagepassing_amd.graph import BatchedGraph
+    from dualmessagepassing_amd import unc_sampling as S
+    rng = np.random.default_rng(4)
+    # node 0: 12 in-edges (two of them parallel copies of the same source); node 1: 3 in-edges; node 2: 9 in-edges, not requested
+    src = np.concatenate([np.array([5, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]), np.array([5, 6, 7]), rng.integers(3, 16, 9)]).astype(np.int64)
+    dst = np.concatenate([np.zeros(12), np.ones(3), np.full(9, 2)]).astype(np.int64)
+    perm = rng.permutation(src.size)                           # edge ids in no particular order
+    src, dst = src[perm], dst[perm]
+    n, width, R = 16, 5, 4000
+    g = BatchedGraph(th.from_numpy(src).to(gpu), th.from_numpy(dst).to(gpu), n)
+    wanted = th.tensor([0, 1], device=gpu)
+    masks = th.stack([S.sample_in_edges_device(g, wanted, width, seed=1000 + r) for r in range(R)]).cpu().numpy()
+    e0, e1, e2 = np.nonzero(dst == 0)[0], np.nonzero(dst == 1)[0], np.nonzero(dst == 2)[0]
+    assert (masks[:, e0].sum(1) == width).all() and masks[:, e1].all() and not masks[:, e2].any()
+    d = e0.size
+    p = width / d
+    inc = masks[:, e0].mean(0)
+    z = np.abs(inc - p) / np.sqrt(p * (1 - p) / R)
+    assert z.max() <= 4.8, (z, inc)                             # 12 edges, two-sided 1e-6 each
+    pairs = masks[:, e0].astype(float).T @ masks[:, e0].astype(float) / R
+    pp = width * (width - 1) / (d * (d - 1))
+    iu = np.triu_indices(d, 1)
+    zp = np.abs(pairs[iu] - pp) / np.sqrt(pp * (1 - pp) / R)
+    assert zp.max() <= 5.3, (zp.max(), pairs[iu].min(), pairs[iu].max(), pp)    # 66 pairs
