@@ -383,13 +383,14 @@ def build_step(cfg, shard, device, world=1, collective=False):
     return step, model
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 # the two scatter-add launches as rocprofv3 names them; first the forms that leave out the rows a 0 / 1 edge gate wiped (what
 # the step runs under a ScalarFilter gate), then the forms that read every row
 SEG_IN = ("seg_sum_vec<32, true, false, true, 0, 256>",     # flag-split segment sum over the CSR by destination (forward; under a 0 / 1 gate: over the kept edges' CSR)
           "seg_sum_vec<32, true, true, true, 0, 256>")      # ... gate-weighted (DMP_KEEP_CSR=0)
-SEG_INC = ("seg_acc_graphs_k<128, true>",                    # backward of the edge gathers: the one-pass endpoint sums (csrc/dmp_segacc.hip)
-           "seg_acc_graphs_k<128, false>", "seg_acc_graphs_k<128>")
+SEG_INC = ("seg_sum_vec<32, true, false, true, 1, 256>",     # backward of the edge gathers: the segment sum over the kept edges' incidence CSR (both gates)
+           "seg_acc_graphs_k<128, true",                     # ... the one-pass endpoint sums (csrc/dmp_segacc.hip), masked
+           "seg_acc_graphs_k<128, false", "seg_acc_graphs_k<128>")
 
 
 def committed_profile(n_rows, n_edges, H):
@@ -1178,6 +1179,7 @@ def main():
         if step.gate_capacity:                                # the rep-net ran on the kept target edges + padding
             uE = mb * 2 * cfg["p_edges"] + step.gate_capacity
         key = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE)
+        key_kinc = "seg_sum2_kept_inc[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)   # the segment sum over the kept edges' incidence CSR, a row per kept node (both gates)
         key_inc = "seg_sum2_graphs[H=%d,rows=%d,E=%d]" % (H, uN, uE)      # one pass over the edge rows (csrc/dmp_segacc.hip) ...
         if key_inc not in kern:
             key_inc = "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)   # ... or the segment sum over the incidence CSR
@@ -1188,6 +1190,7 @@ def main():
         skipped = skipped_n = 0
         Et = mb * 2 * cfg["g_edges"]
         Etk = Et
+        kept = {}
         from dualmessagepassing_amd import fused as _fused
         if _fused.USE_MASKED_SUMS and _fused.USE_ROW_MASKS and step.micro_batches == 1:
             kept = step.gate_kept_rows()
@@ -1197,13 +1200,27 @@ def main():
             if kept["nodes"][0] is not None and _fused.USE_NODE_ROWS and _fused.USE_PLAIN_ATB and uN >= 4096:
                 skipped_n = kept["nodes"][1] - kept["nodes"][0]          # (fused.node_rows: the node side runs on the kept nodes)
         Ek, Nk, nB = uE - skipped, uN - skipped_n, 2 * mb
+        # the backward's sums over the kept edges' incidence CSR fetch the kept edges WITH a kept endpoint (pattern edges: all)
+        Ek1 = (uE - Et) + kept.get("edges_with_kept_endpoint", Etk) if (skipped or skipped_n) else uE
+        inc_k = 2 * (uE - Et) + kept.get("kept_incidences", 2 * Etk) if (skipped or skipped_n) else 2 * uE
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
             roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
                                 "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
                                 4 * H * Ek + 8 * H * Nk + 4 * Ek + (12 * Nk if skipped_n else 4 * (uN + 1)),
                                 4 * H * (Ek + Nk) + 4 * Ek + 4 * (Nk + 1), prof["in"], skipped,
                                 4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1), 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), skipped_n)
-        if key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
+        if key_kinc in kern and (skipped or skipped_n):
+            # backward of the edge gathers under both gates: every kept node's two sums over its kept edges (ascending edge id)
+            roof_bwd = seg_roofline(kern[key_kinc], "dmp::seg_sum_vec<32,split,remap,incidence> over the kept edges' incidence CSR, a row per "
+                                    "kept node (dmp_incidence_keep + dmp_seg_sum2_rows); gradient of the gathered node projections: N=%d rows, "
+                                    "E=%d edge rows, H=%d" % (uN, uE, H),
+                                    4 * H * Ek1 + 8 * H * Nk + 4 * inc_k + 12 * Nk,
+                                    4 * H * (Ek1 + 2 * Nk) + 9 * Ek1 + 8 * (Nk + 1), prof["inc"], uE - Ek1,
+                                    4 * H * (uE + 2 * uN) + 8 * uE + 8 * (uN + 1), 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), skipped_n)
+            roof_bwd["row_reads"] = int(inc_k)      # (an edge row with both endpoints kept is read twice, by workgroups of one XCD)
+            kern[key_kinc]["bytes"], kern[key_kinc]["rows"] = 4 * H * Ek1 + 8 * H * Nk + 4 * inc_k + 12 * Nk, "kept"
+            kern[key_kinc]["gbps"] = kern[key_kinc]["bytes"] / kern[key_kinc]["avg_us"] / 1e3
+        elif key_inc in kern:  # backward of the edge gathers: the same kernel over the incidence CSR (every edge row under both endpoints)
             graphs = "graphs" in key_inc
             roof_bwd = seg_roofline(kern[key_inc], ("dmp::seg_acc_graphs_k (one pass over the edge rows, both endpoints' sums in registers" if graphs
                                                     else "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints") +

@@ -742,8 +742,17 @@ class GraphAdjModelV2(BaseModel):
         pattern, graph = as_batched(pattern), as_batched(graph)
         pads = {"pv": _padder(pattern, "node"), "pe": _padder(pattern, "edge"), "gv": _padder(graph, "node"), "ge": _padder(graph, "edge")}
         vl_gate, el_gate = self.get_filter_gate(pattern, graph, pads)
-        return {"edges": (None if el_gate is None else int((el_gate != 0).sum().item()), graph.number_of_edges()),
-                "nodes": (None if vl_gate is None else int((vl_gate != 0).sum().item()), graph.number_of_nodes())}
+        out = {"edges": (None if el_gate is None else int((el_gate != 0).sum().item()), graph.number_of_edges()),
+               "nodes": (None if vl_gate is None else int((vl_gate != 0).sum().item()), graph.number_of_nodes())}
+        if el_gate is not None and vl_gate is not None:
+            # kept edges with a kept endpoint, and (kept edge, kept endpoint) pairs: what the backward's endpoint sums over the
+            # kept edges' incidence CSR fetch / add (fused.NodeRows.kept_incidence)
+            u, v = graph.all_edges(form="uv", order="eid")
+            ke, kv = el_gate.reshape(-1) != 0, vl_gate.reshape(-1) != 0
+            ku, kw = kv[u.long()] & ke, kv[v.long()] & ke
+            out["edges_with_kept_endpoint"] = int((ku | kw).sum().item())
+            out["kept_incidences"] = int(ku.sum().item() + kw.sum().item())
+        return out
 
     def _compact_gated(self, pattern, graph, el_gate):
         """``collate.CompactedEdges`` for this batch, or None (capacity off, no gate, options that read per-edge extras)."""

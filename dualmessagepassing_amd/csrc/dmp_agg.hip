@@ -70,7 +70,7 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ ent, const float *__restrict__ ew, int N, int H,
     float s0, float s1, float *__restrict__ out, int64_t ldo,
-    const int32_t *__restrict__ rowlist = nullptr, const int32_t *__restrict__ rowcount = nullptr) {
+    const int32_t *__restrict__ rowlist = nullptr, const int32_t *__restrict__ rowcount = nullptr, int ptr_by_pos = 0) {
   constexpr int RPB = BLOCK / G;
   constexpr int U = 8;  // independent 16-B row loads in flight per lane (4 and 16 measured slower over the incidence CSR)
   // REMAP (XCD-local rows): needed when rows are shared between destinations (incidence
@@ -79,11 +79,13 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
   int row = (REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * RPB + threadIdx.x / G;
   const int lane = threadIdx.x % G;
   if (row >= N) return;
+  int prow = row;       // the row of the CSR
   if (rowlist) {        // the destination rows to do, ascending (the nodes a 0 / 1 node gate keeps): the others are left unwritten
     if (row >= *rowcount) return;
     row = rowlist[row];
+    if (!ptr_by_pos) prow = row;     // (ptr_by_pos: the CSR has one row per list position, dmp_incidence_keep)
   }
-  const int beg = rowptr[row], end = rowptr[row + 1];
+  const int beg = rowptr[prow], end = rowptr[prow + 1];
   for (int c0 = 0; c0 < H; c0 += G * 4) {
     const int c = c0 + lane * 4;
     const bool act = c < H;
@@ -640,20 +642,20 @@ int dmp_abi_version(void) { return DMP_ABI_VERSION; }
 const char *dmp_last_hip_error(void) { return g_last_err; }
 
 #define DMP_SS(SP, WT, RM) \
-  seg_sum_vec<G, SP, WT, RM><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo, rowlist, rowcount)
+  seg_sum_vec<G, SP, WT, RM><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo, rowlist, rowcount, ptr_by_pos)
 #define DMP_SS_INC() \
-  seg_sum_vec<G, true, false, true, 1><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
+  seg_sum_vec<G, true, false, true, 1><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo, rowlist, rowcount, ptr_by_pos)
 #define DMP_SS_TAG2() \
   seg_sum_vec<G, true, false, true, 2><<<nb, kBlock, 0, st>>>(M, ldm, rowptr, ent, ew, (int)N, H, s0, s1, out, ldo)
 
 static int seg_sum_impl(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent,
                         const float *ew, int64_t N, int H, bool split, float s0, float s1,
                         float *out, int64_t ldo, int rows_shared, void *stream,
-                        const int32_t *rowlist = nullptr, const int32_t *rowcount = nullptr) {
+                        const int32_t *rowlist = nullptr, const int32_t *rowcount = nullptr, int ptr_by_pos = 0) {
   if (N < 0 || H <= 0 || ldm < H || ldo < (split ? 2 * H : H)) return DMP_ERR_BAD_ARG;
   if (N == 0) return DMP_OK;
   if (!rowptr || !out) return DMP_ERR_BAD_ARG;
-  if (rowlist && (!rowcount || !M || !ent || !vec_ok(H, {ldm, ldo}, {M, out}) || rows_shared == 2 || rows_shared == 3)) return DMP_ERR_UNSUPPORTED;
+  if (rowlist && (!rowcount || !M || !ent || !vec_ok(H, {ldm, ldo}, {M, out}) || rows_shared == 3 || (rows_shared == 2 && !split) || ew)) return DMP_ERR_UNSUPPORTED;
   if (N >= kMaxRows) return DMP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (!M || !ent) {  // a graph without edges: every sum is empty
@@ -695,9 +697,12 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr, const int32
 }
 
 int dmp_seg_sum2_rows(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int32_t *rowlist,
-                      const int32_t *rowcount, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo, void *stream) {
+                      const int32_t *rowcount, int ptr_by_pos, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
+                      void *stream) {
   if (!rowlist || !rowcount) return DMP_ERR_BAD_ARG;
-  return seg_sum_impl(M, ldm, rowptr, ent, nullptr, num_nodes, H, true, s0, s1, out, ldo, 1, stream, rowlist, rowcount);
+  // (ptr_by_pos: an incidence CSR -- the kernel instantiation tagged so, so that a profile keeps the backward's sums apart)
+  return seg_sum_impl(M, ldm, rowptr, ent, nullptr, num_nodes, H, true, s0, s1, out, ldo, ptr_by_pos ? 2 : 1, stream, rowlist, rowcount,
+                      ptr_by_pos ? 1 : 0);
 }
 
 int dmp_seg_sum2_tiled(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int64_t *node_off,

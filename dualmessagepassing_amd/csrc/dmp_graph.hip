@@ -1044,6 +1044,78 @@ __global__ __launch_bounds__(kBlock) void keep_fill_k(const int32_t *__restrict_
   }
 }
 
+// ---- the INCIDENCE CSR over the kept edges, for the kept nodes only (dmp_incidence_keep): row i belongs to node list[i]
+// (i < *count: the nodes a 0 / 1 node gate keeps, ascending) and lists the node's in-entries and out-entries (flag flipped)
+// whose edge a 0 / 1 edge gate keeps, MERGED by ascending edge id as incidence_fill merges them.  Same two passes as the
+// kept in-CSR above: (1) kept entries per row, block totals; (2) block offsets, ranks, the merge.  keep_ptr is indexed by the
+// POSITION i, not by the node.
+__global__ __launch_bounds__(kBlock) void inc_keep_count_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                           const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_ent,
+                                                           const float *__restrict__ gate, const int32_t *__restrict__ list,
+                                                           const int32_t *__restrict__ count, int32_t *__restrict__ row_cnt,
+                                                           int32_t *__restrict__ blk) {
+  __shared__ int red[kBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t n = *count;
+  int c = 0;
+  if (i < n) {
+    const int v = list[i];
+    for (int q = in_ptr[v], hi = in_ptr[v + 1]; q < hi; ++q) c += gate[in_ent[q] >> 1] != 0.f;
+    for (int q = out_ptr[v], hi = out_ptr[v + 1]; q < hi; ++q) c += gate[out_ent[q] >> 1] != 0.f;
+    row_cnt[i] = c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; ++k) t += red[k]; blk[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kBlock) void inc_keep_fill_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                          const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_ent,
+                                                          const float *__restrict__ gate, const int32_t *__restrict__ list,
+                                                          const int32_t *__restrict__ count, const int32_t *__restrict__ row_cnt,
+                                                          const int32_t *__restrict__ blk, int32_t *__restrict__ keep_ptr,
+                                                          int32_t *__restrict__ keep_ent) {
+  __shared__ int red[kBlock / 64], wtot[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) before += blk[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int k = 0; k < kBlock / 64; ++k) before += red[k];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t n = *count;
+  const int c = i < n ? row_cnt[i] : 0;
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int s = before + incl - c;
+  for (int w = 0; w < wave; ++w) s += wtot[w];
+  if (i < n) {
+    keep_ptr[i] = s;
+    const int v = list[i];
+    int a = in_ptr[v], b = out_ptr[v];
+    const int a1 = in_ptr[v + 1], b1 = out_ptr[v + 1];
+    int x = a < a1 ? in_ent[a] : 0, y = b < b1 ? out_ent[b] : 0;
+    while (a < a1 || b < b1) {                                  // incidence_fill's merge (an edge that is both lists its in-entry first)
+      if (b >= b1 || (a < a1 && (x >> 1) <= (y >> 1))) {
+        if (gate[x >> 1] != 0.f) keep_ent[s++] = x;
+        if (++a < a1) x = in_ent[a];
+      } else {
+        if (gate[y >> 1] != 0.f) keep_ent[s++] = y ^ 1;
+        if (++b < b1) y = out_ent[b];
+      }
+    }
+    if (i == n - 1) keep_ptr[n] = s;
+  }
+  if (i == 0 && n == 0) keep_ptr[0] = 0;
+}
+
 __global__ __launch_bounds__(kBlock) void ct_hist_k(const int64_t *__restrict__ deg, const int32_t *__restrict__ in_ptr,
                                                     const int32_t *__restrict__ row_cnt,
                                                     int64_t N, int C, unsigned long long *cnt, int32_t *status) {
@@ -1856,6 +1928,19 @@ int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate
   int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block of kBlock nodes
   keep_count_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, N, row_cnt, blk);
   keep_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, row_cnt, blk, N, keep_ptr, keep_ent);
+  return check_launch();
+}
+
+int dmp_incidence_keep(const int32_t *in_ptr, const int32_t *in_ent, const int32_t *out_ptr, const int32_t *out_ent, const float *gate,
+                       const int32_t *list, const int32_t *count, int64_t N, int32_t *row_cnt, int32_t *keep_ptr, int32_t *keep_ent,
+                       void *stream) {
+  if (N < 0 || !keep_ptr) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) return hipMemsetAsync(keep_ptr, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!in_ptr || !in_ent || !out_ptr || !out_ent || !gate || !list || !count || !row_cnt || !keep_ent) return DMP_ERR_BAD_ARG;
+  int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block (dmp_csr_keep_scratch_words)
+  inc_keep_count_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, gate, list, count, row_cnt, blk);
+  inc_keep_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, gate, list, count, row_cnt, blk, keep_ptr, keep_ent);
   return check_launch();
 }
 

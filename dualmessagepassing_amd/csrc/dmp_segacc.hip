@@ -67,6 +67,17 @@ struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, 
         [i3] "s"(I3), [j0] "s"(J0), [j1] "s"(J1), [j2] "s"(J2), [j3] "s"(J3)                                          \
       : "memory")
 
+// one row (the masked form: a row whose mask bit is clear skips the block -- a scalar branch around twelve instructions)
+#define DMP_ACC1(X0, I0, J0)                                                                                           \
+  asm volatile(                                                                                                        \
+      "s_mov_b32 %[m0s], m0\n\t"                                                                                       \
+      DMP_ROW("%[x0]", "%[i0]", "%[j0]")                                                                               \
+      "s_mov_b32 m0, %[m0s]"                                                                                           \
+      : "+{v[64:95]}"(A0), "+{v[96:127]}"(A1), "+{v[128:159]}"(B0), "+{v[160:191]}"(B1), "+{v192}"(trash),            \
+        [m0s] "=&s"(m0_saved), [t] "=&v"(tmp_t), [u] "=&v"(tmp_u)                                                      \
+      : [x0] "v"(X0), [i0] "s"(I0), [j0] "s"(J0)                                                                       \
+      : "memory")
+
 // H: row width (64 or 128) = 64 columns per wave, H / 64 waves per workgroup, one workgroup per tile.
 // MASKED: bit (e & 31) of rowmask[e >> 5] clear = row e of M is known to be all zeros (the gradient rows a 0 / 1 edge gate
 // wiped, dmp_row_mask_bits): such a row is requested past the end of its descriptor -- the load returns zeros without
@@ -74,7 +85,9 @@ struct GraphTiles { const int64_t *node_off, *edge_off; int64_t Ba, Bb; int ka, 
 // NODES: bit (v & 31) of nodemask[v >> 5] clear = node row v of `out` is DEAD (a node under a zero of a 0 / 1 node gate: its
 // gradient row is multiplied by that zero further down): not stored -- the store goes through a descriptor of zero records;
 // the caller's selectors route such a node's addends to the trash register (dmp_edge_select_nodes: -1).
-template <int H, bool MASKED = false, bool NODES = false>
+// RING: rows in flight per wave = rows per super-group (32 or 64).  Measured (round 5, masked form at bench.py's shape, 42 % of
+// the rows kept): a ring of 64 is SLOWER (57.3 against 50.5 us) -- the launch is not short of requests in flight
+template <int H, bool MASKED = false, bool NODES = false, int RING = kRing>
 __global__ __launch_bounds__(H) void seg_acc_graphs_k(
     const float *__restrict__ M, int64_t ldm, const int32_t *__restrict__ selA, const int32_t *__restrict__ selB,
     const GraphTiles ts, float s0, float s1, float *__restrict__ out, int64_t ldo,
@@ -110,15 +123,18 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
   // (word indices clamped to the mask's last word: what they say about rows past the tile's end is not used -- those rows
   // lie past the end of the descriptor anyway)
   const int msh = (int)(e0 & 31), mw0 = (int)(e0 >> 5), mlast = (int)mask_words - 1;
-  auto mask_sg = [&](int sg) -> uint32_t {
-    if (!MASKED) return 0xffffffffu;
-    const int w = mw0 + sg;
-    const uint32_t lo = rowmask[min(w, mlast)], hi = rowmask[min(w + 1, mlast)];
-    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> msh);
+  auto mask_sg = [&](int sg) -> uint64_t {                      // bit k: row RING sg + k of the tile
+    if (!MASKED) return ~0ull;
+    const int w = mw0 + sg * (RING / 32);
+    const uint32_t q0 = rowmask[min(w, mlast)], q1 = rowmask[min(w + 1, mlast)];
+    const uint64_t lo = (((((uint64_t)q1) << 32) | q0) >> msh) & 0xffffffffull;
+    if (RING == 32) return lo;
+    const uint32_t q2 = rowmask[min(w + 2, mlast)];
+    return lo | ((((((uint64_t)q2) << 32) | q1) >> msh) << 32);
   };
-  auto load_sel = [&](int sg, int &a, int &b) {                 // endpoints of row kRing sg + lane
-    a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, sg * (kRing * 4), 0);
-    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsB, lane * 4, sg * (kRing * 4), 0);
+  auto load_sel = [&](int sg, int &a, int &b) {                 // endpoints of row RING sg + lane
+    a = (int)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, sg * (RING * 4), 0);
+    b = (int)__builtin_amdgcn_raw_buffer_load_b32(rsB, lane * 4, sg * (RING * 4), 0);
   };
 
   f32x32 A0, A1, B0, B1;
@@ -126,43 +142,58 @@ __global__ __launch_bounds__(H) void seg_acc_graphs_k(
   for (int i = 0; i < 32; ++i) { A0[i] = 0.f; A1[i] = 0.f; B0[i] = 0.f; B1[i] = 0.f; }
   float trash = 0.f;
 
-  const int nsg = (R + kRing - 1) / kRing;                      // super-groups of kRing rows (one endpoint dword per lane < kRing)
-  float v[kRing];
+  const int nsg = (R + RING - 1) / RING;                      // super-groups of RING rows (one endpoint dword per lane < RING)
+  float v[RING];
   int na, nb, m0_saved;
   float tmp_t, tmp_u;
   load_sel(0, na, nb);
   asm volatile("" ::: "memory");     // keep the endpoint loads OLDER than the ring (the waits count younger operations)
-  uint32_t m_next = mask_sg(0);      // the mask words run two super-groups ahead of the adds (scalar loads)
+  uint64_t m_next = mask_sg(0);      // the mask words run two super-groups ahead of the adds (scalar loads)
 #pragma unroll
-  for (int k = 0; k < kRing; ++k) v[k] = load_row(k, (m_next >> k) & 1u);
+  for (int k = 0; k < RING; ++k) v[k] = load_row(k, (uint32_t)((m_next >> k) & 1ull));
   m_next = mask_sg(1);
+  uint64_t m_cur = mask_sg(0);          // the rows of the super-group being added
   for (int sg = 0; sg < nsg; ++sg) {
-    const uint32_t m_load = m_next;  // rows of super-group sg + 1, requested below
+    const uint64_t m_load = m_next;  // rows of super-group sg + 1, requested below
     m_next = mask_sg(sg + 2);
     // register indices of this super-group's rows: node - n0 relative to v64 (half 0) / v128 (half 1); the trash
     // register v192 = index 128 / 64 for rows past the end and endpoints outside the tile
-    const bool in = lane < kRing && sg * kRing + lane < R;
+    const bool in = lane < RING && sg * RING + lane < R;
     const uint32_t ua = (uint32_t)(na - (int32_t)n0), ub = (uint32_t)(nb - (int32_t)n0);
     int pa = (in && ua < (uint32_t)nodes) ? (int)ua : 128;
     int pb = (in && ub < (uint32_t)nodes) ? (int)ub : 64;
 #pragma unroll
-    for (int g = 0; g < kRing; g += 4) {
+    for (int g = 0; g < RING; g += 4) {
       // the next super-group's endpoints: requested ahead of this iteration's row loads, so that the wait for them at
       // the top of the next iteration (all but the 32 youngest operations) leaves the ring in flight
       if (g == 0) load_sel(sg + 1, na, nb);                     // past the last super-group: zeros, never used
       asm volatile("" : "+v"(pa), "+v"(pb));                    // the block's eight v_readlane stay HERE (hoisted to the loop
                                                                 // top, the 64 results of a ring held 64 SGPRs live)
-      const int i0 = __builtin_amdgcn_readlane(pa, g), i1 = __builtin_amdgcn_readlane(pa, g + 1);
-      const int i2 = __builtin_amdgcn_readlane(pa, g + 2), i3 = __builtin_amdgcn_readlane(pa, g + 3);
-      const int j0 = __builtin_amdgcn_readlane(pb, g), j1 = __builtin_amdgcn_readlane(pb, g + 1);
-      const int j2 = __builtin_amdgcn_readlane(pb, g + 2), j3 = __builtin_amdgcn_readlane(pb, g + 3);
-      DMP_ACC4(v[g], v[g + 1], v[g + 2], v[g + 3], i0, i1, i2, i3, j0, j1, j2, j3);
-      // ... and the same four ring slots take the rows kRing ahead: AFTER the adds (the block is a memory barrier to the
+      if (MASKED) {
+        // a masked-out row (its load came back as zeros through the zero-record descriptor) adds nothing: its twelve
+        // instructions are skipped by a scalar branch -- the kernel is bound by this per-row instruction stream, and under a
+        // ScalarFilter gate 58 % of the rows are such rows.  The loads stay unconditional: the wait counts stay static.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if ((m_cur >> (g + q)) & 1ull) {
+            const int iq = __builtin_amdgcn_readlane(pa, g + q), jq = __builtin_amdgcn_readlane(pb, g + q);
+            DMP_ACC1(v[g + q], iq, jq);
+          }
+        }
+      } else {
+        const int i0 = __builtin_amdgcn_readlane(pa, g), i1 = __builtin_amdgcn_readlane(pa, g + 1);
+        const int i2 = __builtin_amdgcn_readlane(pa, g + 2), i3 = __builtin_amdgcn_readlane(pa, g + 3);
+        const int j0 = __builtin_amdgcn_readlane(pb, g), j1 = __builtin_amdgcn_readlane(pb, g + 1);
+        const int j2 = __builtin_amdgcn_readlane(pb, g + 2), j3 = __builtin_amdgcn_readlane(pb, g + 3);
+        DMP_ACC4(v[g], v[g + 1], v[g + 2], v[g + 3], i0, i1, i2, i3, j0, j1, j2, j3);
+      }
+      // ... and the same four ring slots take the rows RING ahead: AFTER the adds (the block is a memory barrier to the
       // compiler), so the loads land in the registers the adds have just read -- no second register set, no copies
-      const int r = (sg + 1) * kRing + g;
-      v[g] = load_row(r, (m_load >> g) & 1u); v[g + 1] = load_row(r + 1, (m_load >> (g + 1)) & 1u);
-      v[g + 2] = load_row(r + 2, (m_load >> (g + 2)) & 1u); v[g + 3] = load_row(r + 3, (m_load >> (g + 3)) & 1u);
+      const int r = (sg + 1) * RING + g;
+      v[g] = load_row(r, (uint32_t)((m_load >> g) & 1ull)); v[g + 1] = load_row(r + 1, (uint32_t)((m_load >> (g + 1)) & 1ull));
+      v[g + 2] = load_row(r + 2, (uint32_t)((m_load >> (g + 2)) & 1ull)); v[g + 3] = load_row(r + 3, (uint32_t)((m_load >> (g + 3)) & 1ull));
     }
+    m_cur = m_load;
   }
   // the sums: 256 contiguous bytes per store instruction (this wave's columns of one node row and half)
   const uint32_t bytesO = tile_bytes(nodes, ldo, 2 * H);

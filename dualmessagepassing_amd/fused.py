@@ -845,6 +845,7 @@ def _kept_row_tiles(mask, r0, r1):
 
 
 USE_NODE_ROWS = _os.environ.get("DMP_NODE_ROWS", "1") == "1"   # the node side of a layer over the nodes a 0 / 1 node gate keeps
+USE_KEPT_INCIDENCE = True     # ... and its backward's endpoint sums as a segment sum over the kept edges' incidence CSR
 
 
 class NodeRows:
@@ -855,6 +856,26 @@ class NodeRows:
 
     def __init__(self, mask, rows, tiles, sel):
         self.mask, self.rows, self.tiles, self.sel = mask, rows, tiles, sel
+        self._kinc = None
+
+    def kept_incidence(self, index, e_gate):
+        """``(ptr, ent)``: the incidence CSR over the edges the 0 / 1 ``e_gate`` keeps, one row per POSITION of ``rows``
+        (``dmp_incidence_keep``): what the backward's endpoint sums walk -- an edge row without a kept endpoint is never
+        fetched.  Memoised per gate (the layers of a rep-net share it)."""
+        owner = _gate_owner(e_gate)
+        hit = self._kinc
+        if hit is not None and hit[0] is owner and hit[1] == owner._version:
+            return hit[2]
+        lib = _lib.load()
+        N, dev = index.num_nodes, index.in_ptr.device
+        nscr = int(lib.dmp_csr_keep_scratch_words(N))
+        ws = torch.empty(nscr + N + 1 + 2 * index.num_edges, dtype=torch.int32, device=dev)
+        row_cnt, kptr, kent = ws[:nscr], ws[nscr:nscr + N + 1], ws[nscr + N + 1:]
+        check(lib.dmp_incidence_keep(ptr(index.in_ptr), ptr(index.in_ent), ptr(index.out_ptr), ptr(index.out_ent), ptr(e_gate.reshape(-1)),
+                                     ptr(self.rows[0]), ptr(self.rows[1]), N, ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()),
+              "dmp_incidence_keep")
+        self._kinc = (owner, owner._version, (kptr, kent))
+        return kptr, kent
 
 
 def node_rows(index, v_gate, H):
@@ -899,12 +920,12 @@ def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=
         mask = None
     if mask is not None and USE_L0_ROW_LISTS and r1 - r0 >= L0_LIST_MIN_ROWS:
         lst, cnt = kept_rows(mask, r0, r1)
-        with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
+        with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + min(2 * index.num_nodes, 2 * (r1 - r0))) + (4 * enc.size(1) + 12) * (r1 - r0)):
             check(lib.dmp_l0_edge_fwd_rows(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
                                            ptr(sel_a[r0:]), ptr(sel_b[r0:]), ptr(lst), ptr(cnt), r1 - r0, H, slope, ptr(out[r0:]),
                                            out.stride(0), stream_ptr()), "dmp_l0_edge_fwd_rows")
         return out
-    with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + 2 * index.num_nodes) + (4 * enc.size(1) + 12) * (r1 - r0)):
+    with _lib.timed("l0_edge_fwd[K=%d,E=%d]", (K, r1 - r0), 4 * H * (r1 - r0 + min(2 * index.num_nodes, 2 * (r1 - r0))) + (4 * enc.size(1) + 12) * (r1 - r0)):
         check(lib.dmp_l0_edge_fwd_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(M), M.stride(0), ptr(P), ldp, ptr(bias), ptr(coef_e[r0:]),
                                          ptr(sel_a[r0:]), ptr(sel_b[r0:]), None if mask is None else ptr(mask[r0 // 32:]), r1 - r0, H,
                                          slope, ptr(out[r0:]), out.stride(0), stream_ptr()),
@@ -1497,9 +1518,15 @@ class _FusedDMPLayer(torch.autograd.Function):
             # dPre into both endpoints' rows: the backward scatter-add (dPre's rows under a zero edge gate are zeros: not fetched)
             sums_masked = typed and USE_MASKED_SUMS and ctx.e_gate is not None and gate_row_mask(ctx.e_gate) is not None
             # (... and the rows of the dead nodes are neither summed nor stored)
-            nodes = (nd.mask, nd.sel[:2]) if (nd is not None and sums_masked and ops.graph_seg_ok(ix, dG[:, :H], H, dXP[:, H:])) else None
-            ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:], mask=gate_row_mask(ctx.e_gate) if sums_masked else None,
-                              gate=ctx.e_gate if sums_masked else None, nodes=nodes)
+            if nd is not None and sums_masked and USE_KEPT_INCIDENCE and zero_rows_gate(ctx.e_gate) and H % 4 == 0:
+                # every kept node's two sums over its KEPT edges (the incidence CSR over the kept edges, a row per kept node):
+                # the plain segment-sum kernel, ascending edge id -- an edge row without a kept endpoint is never fetched
+                kp, ke = nd.kept_incidence(ix, ctx.e_gate)
+                ops.seg_sum_raw(dG[:, :H], kp, ke, N, None, True, 1.0, -1.0, out=dXP[:, H:], rows=nd.rows, ptr_by_pos=True, tag="seg_sum2_kept_inc")
+            else:
+                nodes = (nd.mask, nd.sel[:2]) if (nd is not None and sums_masked and ops.graph_seg_ok(ix, dG[:, :H], H, dXP[:, H:])) else None
+                ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:], mask=gate_row_mask(ctx.e_gate) if sums_masked else None,
+                                  gate=ctx.e_gate if sums_masked else None, nodes=nodes)
             l0, tables = ctx.l0, ctx.l0_tables
             vcodes = l0 is not None and l0.venc is not None
             if l0 is not None:   # z = enc W0: one pass over dPre (and the residual gradient) on the K-column factor

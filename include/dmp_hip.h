@@ -416,8 +416,18 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
  * dmp_kept_rows of a 0 / 1 NODE gate): the other rows of `out` are not written.  A node under a zero of the ScalarFilter's
  * node gate is a zero row in every layer (dmpnn.py:245-277), its aggregate feeds only its own (gated) update: dead. */
 int dmp_seg_sum2_rows(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int32_t *rowlist,
-                      const int32_t *rowcount, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
+                      const int32_t *rowcount, int ptr_by_pos, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
                       void *stream);
+/* The incidence CSR (dmp_incidence_build: a node's in-entries and out-entries, flag flipped, merged by ascending edge id) over the
+ * edges a 0 / 1 edge gate keeps (gate [E] floats), for the nodes of a list only (list / count: dmp_kept_rows of a 0 / 1 node gate):
+ * keep_ptr [*count + 1] is indexed by the POSITION in the list, keep_ent [<= 2 kept edges]; row_cnt: dmp_csr_keep_scratch_words(N)
+ * scratch.  dmp_seg_sum2_rows(ptr_by_pos = 1) over it is the backward of the gathered node projections (dmpnn.py:111-127) under
+ * the ScalarFilter's gates: every kept node's two sums over its kept edges in ascending edge id -- the bits of dmp_seg_sum2 over
+ * the full incidence CSR (the left-out addends are zero rows, the left-out nodes' rows dead) from the fewest row reads: an edge
+ * row with no kept endpoint is never fetched. */
+int dmp_incidence_keep(const int32_t *in_ptr, const int32_t *in_ent, const int32_t *out_ptr, const int32_t *out_ent,
+                       const float *gate, const int32_t *list, const int32_t *count, int64_t num_nodes, int32_t *row_cnt,
+                       int32_t *keep_ptr, int32_t *keep_ent, void *stream);
 
 /* Gate compaction of a block-diagonal batch (csrc/dmp_compact.hip): the edges a filter gate keeps (gate[e] != 0), graph by
  * graph in ascending eid, as a batch of exactly `cap` edges -- `cap - kept` padding edges (gate 0, self-loops dealt over

@@ -103,6 +103,21 @@ def test_scatter_adds_leave_out_the_dead_nodes_rows(H, gpu):
     outb = th.full((N, 2 * H), 7.5, device=gpu)
     ops.endpoint_sums(Mp, ix, out=outb, mask=emask, gate=e_gate, nodes=(vmask, sel[:2]))
     assert th.equal(outb[keep], refb[keep]) and bool((outb[~keep] == 7.5).all())
+    # ... and as a segment sum over the kept edges' incidence CSR with a row per kept node (what the fused layer's backward
+    # runs under both gates): the same bits, and an edge row WITHOUT a kept endpoint is never fetched (NaN there too)
+    nd = fused.NodeRows(vmask, rows, None, sel)
+    kp, ke = nd.kept_incidence(ix, e_gate)
+    src, dst = ix.src32.long(), ix.dst32.long()
+    untouched = (e_gate == 0) | ~(keep[src] | keep[dst])
+    Mq = M.clone()
+    Mq[untouched] = float("nan")
+    outc = th.full((N, 2 * H), 7.5, device=gpu)
+    ops.seg_sum_raw(Mq, kp, ke, N, None, True, 1.0, -1.0, out=outc, rows=rows, ptr_by_pos=True)
+    assert th.equal(outc[keep], refb[keep]) and bool((outc[~keep] == 7.5).all())
+    n = int(rows[1].item())
+    full_inc = ix.incidence()
+    want = sum(int(((e_gate[(full_inc[1][full_inc[0][v]:full_inc[0][v + 1]] >> 1).long()]) != 0).sum()) for v in rows[0][:200].tolist())
+    assert int(kp[200].item()) == want and int(kp[n].item()) <= 2 * int((e_gate != 0).sum())
 
 
 @pytest.mark.parametrize("H", [128, 64])
