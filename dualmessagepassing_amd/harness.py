@@ -197,23 +197,77 @@ class PairDataset:
 
     ARRAYS_PER_GRAPH = 9    # src, dst, num_nodes, num_edges, node id, node label, edge id, edge label, is_reversed
 
-    def batch_arrays(self, indices, device):
+    def pad_buckets(self, batch_size, levels=4):
+        """``pad`` for ``batch_arrays``: the per-graph maxima of the dataset per side and the number of capacity levels.  A
+        padded batch holds ``batch_size`` real + ``batch_size`` inert pairs and its four totals (nodes / edges of both sides)
+        are those of level k of ``levels`` -- k / levels of what ``batch_size`` largest graphs would take, the smallest level
+        this batch fits -- so a ragged dataset meets at most ``levels`` batch shapes and a recorded step (``GraphedTrainStep``)
+        replays for every batch."""
+        out = {"batch": int(batch_size), "levels": int(levels)}
+        for key in ("pattern", "graph"):
+            out[key] = (max(2, max(int(x[key]["num_nodes"]) for x in self.samples)), max(1, max(len(x[key]["src"]) for x in self.samples)))
+        return out
+
+    def batch_arrays(self, indices, device, pad=None):
         """The uploaded half of ``batchify``: ``(meta, tensors)`` with ``tensors`` = the pattern batch's nine arrays
         (local endpoints, sizes, ids, labels, reversed flags), the graph batch's nine and ``counts [B, 1]``, and ``meta``
         = per side ``(total nodes, total edges, largest graph's nodes, largest graph's edges)`` as host ints.  Everything
-        ``graphs_from_arrays`` then does happens on the device without a host sync (``dp.StepGraph`` records it)."""
+        ``graphs_from_arrays`` then does happens on the device without a host sync (``dp.StepGraph`` records it).
+        ``pad`` (``pad_buckets``): the batch is extended to ``2 pad["batch"]`` pairs by INERT pairs -- pairs of label-0 graphs
+        whose sizes take the four totals up to a capacity level, and whose weight in the loss is zero (a last tensor,
+        ``weights [2 B, 1]``, is appended).  Pairs are
+        independent in the model (block-diagonal batches, no BatchNorm), so the real pairs' predictions are unchanged and
+        an inert pair, whose prediction carries no loss, adds exact zeros to every gradient: a ragged dataset then meets a
+        handful of batch shapes instead of one per batch."""
         meta, tensors = [], []
+        extra, level = 0, 0
+        if pad is not None:
+            B, K = pad["batch"], pad["levels"]
+            if len(indices) > B:
+                raise ValueError("batch_arrays(pad=...): more pairs than the padding was laid out for")
+            extra = 2 * B - len(indices)                          # inert pairs: the batch always holds 2 B pairs
+            tot = {key: (sum(int(self.samples[i][key]["num_nodes"]) for i in indices), sum(len(self.samples[i][key]["src"]) for i in indices))
+                   for key in ("pattern", "graph")}
+            caps = lambda key, k: (-(-(B * pad[key][0] + B) * k // K), -(-B * pad[key][1] * k // K))
+            level = next(k for k in range(1, K + 1)
+                         if all(tot[key][0] + extra <= caps(key, k)[0] + (extra - B) and tot[key][1] <= caps(key, k)[1] for key in tot))
         for key in ("pattern", "graph"):
             gs = [self.samples[i][key] for i in indices]
+            if pad is not None:
+                cn, ce = caps(key, level)
+                gs = gs + self._inert_graphs(tot[key], cn + (extra - B), ce, extra)
             cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
             nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
             ne_ = np.array([len(g["src"]) for g in gs], np.int64)
             nid = torch.from_numpy(np.concatenate([np.arange(n) for n in nn_])).to(device)
             tensors += [cat("src"), cat("dst"), torch.from_numpy(nn_).to(device), torch.from_numpy(ne_).to(device), nid,
                         cat("vlabel"), cat("eid"), cat("elabel"), cat("rev", torch.bool)]
-            meta.append((int(nn_.sum()), int(ne_.sum()), int(nn_.max(initial=0)), int(ne_.max(initial=0))))
-        counts = torch.tensor([self.samples[i]["counts"] for i in indices], dtype=torch.float32, device=device)
-        return tuple(meta), tensors + [counts.unsqueeze(-1)]
+            if pad is not None:     # the dataset's per-graph maxima: one signature per capacity level, whatever this batch holds
+                meta.append((int(nn_.sum()), int(ne_.sum()), int(pad[key][0]), int(pad[key][1])))
+            else:
+                meta.append((int(nn_.sum()), int(ne_.sum()), int(nn_.max(initial=0)), int(ne_.max(initial=0))))
+        counts = torch.tensor([self.samples[i]["counts"] for i in indices] + [0] * extra, dtype=torch.float32, device=device)
+        if pad is None:
+            return tuple(meta), tensors + [counts.unsqueeze(-1)]
+        weights = torch.tensor([1.0] * len(indices) + [0.0] * extra, dtype=torch.float32, device=device)
+        return tuple(meta), tensors + [counts.unsqueeze(-1), weights.unsqueeze(-1)]
+
+    @staticmethod
+    def _inert_graphs(tot, cap_n, cap_e, extra):
+        """``extra`` label-0 graphs that take a side's node / edge totals ``tot`` up to ``(cap_n, cap_e)``: nodes dealt evenly
+        (every inert graph has at least one), edges too (a ring over the graph's nodes: valid endpoints, parallel edges when
+        the ring wraps)."""
+        n_pad, e_pad = cap_n - tot[0], cap_e - tot[1]
+        if n_pad < extra or e_pad < 0:
+            raise ValueError("batch_arrays(pad=...): the batch does not fit its capacity level")
+        out = []
+        for j in range(extra):
+            n = n_pad // extra + (1 if j < n_pad % extra else 0)
+            e = e_pad // extra + (1 if j < e_pad % extra else 0)
+            a = np.arange(e, dtype=np.int64) % n
+            out.append({"src": a, "dst": (a + 1) % n, "vlabel": np.zeros(n, np.int64), "elabel": np.zeros(e, np.int64),
+                        "eid": np.arange(e, dtype=np.int64), "rev": np.zeros(e, bool), "num_nodes": n})
+        return out
 
     @classmethod
     def graphs_from_arrays(cls, meta, tensors):
@@ -483,7 +537,13 @@ class GraphedTrainStep:
     predictions): see ``dp.StepGraph`` (``fit(graph=True)`` does)."""
 
     def __init__(self, model, optimizer, sync, bp_loss="MSE", eval_metric="MAE", max_grad_norm=8.0, with_rep_reg=False,
-                 max_shapes=4):
+                 max_shapes=4, pad="auto"):
+        """``pad``: ragged datasets (every batch another pair of (N, E) totals: the reference's bucket-sorted batches,
+        utils/sampler.py:10-84, train.py:1283-1290) never repeat a shape, so nothing would replay.  ``"auto"`` / True:
+        batches are padded with inert pairs to one of ``max_shapes`` capacity levels (``PairDataset.batch_arrays(pad=...)``;
+        "auto": only when the dataset's graphs differ in size); the inert pairs carry weight 0 in the loss and the metric.
+        Not with the representation regulariser (it reads every row) or BatchNorm layers (their statistics would see the
+        inert rows): such runs keep the exact shapes."""
         from .dp import StepGraph
         if getattr(sync, "world", 1) != 1:
             raise ValueError("GraphedTrainStep records single-rank steps only")
@@ -494,11 +554,17 @@ class GraphedTrainStep:
         self.hyper = None
         self._hyper_host = None
         self.dataset_cls = None
+        self.pad, self._pad_spec = pad, None
+        if pad and (with_rep_reg or any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules())):
+            self.pad = None
+        self.max_shapes = int(max_shapes)
         self.steps = StepGraph(self._step, optimizer=optimizer, max_shapes=max_shapes)
 
     def _step(self, meta, *tensors):
         pattern, graph = self.dataset_cls.graphs_from_arrays(meta, tensors)
-        counts, hyper = tensors[-2], tensors[-1]
+        n = 2 * self.dataset_cls.ARRAYS_PER_GRAPH
+        counts, hyper = tensors[n], tensors[-1]
+        weights = tensors[n + 1] if len(tensors) == n + 3 else None        # a padded batch: 1 for the real pairs, 0 for the inert ones
         self.sync.detach_grads()
         lazy, self.model.lazy_edge_rep = getattr(self.model, "lazy_edge_rep", True), not self.with_rep_reg   # see train_epoch
         try:
@@ -506,7 +572,11 @@ class GraphedTrainStep:
         finally:
             self.model.lazy_edge_rep = lazy
         pred = out["pred_c"]
-        loss = self.bp(torch.where(pred > 0, pred, pred * hyper[0]), counts)      # leaky_relu with the slope on the device
+        act = torch.where(pred > 0, pred, pred * hyper[0])                        # leaky_relu with the slope on the device
+        if weights is not None:      # the mean over the REAL pairs (train.py:463-480's batch mean)
+            loss = (self.bp(act, counts, reduction="none") * weights).sum() / weights.sum()
+        else:
+            loss = self.bp(act, counts)
         if self.with_rep_reg:
             reg = sum(self.bp(out[k], torch.zeros_like(out[k])) * out[k].size(1)
                       for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep") if out[k] is not None)
@@ -518,13 +588,25 @@ class GraphedTrainStep:
             torch.nn.utils.clip_grad_norm_(self.sync.params, self.max_grad_norm)
         self.optimizer.step()
         with torch.no_grad():
+            if weights is not None:
+                return loss.detach(), (self.ev(F.relu(pred), counts, reduction="none") * weights).sum() / weights.sum()
             return loss.detach(), self.ev(F.relu(pred), counts)
+
+    def _padding(self, dataset, indices):
+        """The dataset's padding layout (``pad_buckets``), decided at the first batch: the batch size is that batch's."""
+        if self.pad and self._pad_spec is None:
+            ragged = len({(int(x[k]["num_nodes"]), len(x[k]["src"])) for x in dataset.samples for k in ("pattern", "graph")}) > 2
+            self._pad_spec = dataset.pad_buckets(len(indices), levels=self.max_shapes) if (self.pad is True or ragged) else False
+        return self._pad_spec or None
 
     def __call__(self, dataset, indices, device, neg_slp=0.0, rep_reg_w=0.0):
         if rep_reg_w > 0 and not self.with_rep_reg:
             raise ValueError("GraphedTrainStep(with_rep_reg=True) to train with the representation regulariser")
         self.dataset_cls = type(dataset)
-        meta, tensors = dataset.batch_arrays(indices, device)
+        pad = self._padding(dataset, indices)
+        if pad is not None and len(indices) > pad["batch"]:
+            pad = None
+        meta, tensors = dataset.batch_arrays(indices, device, pad=pad) if pad is not None else dataset.batch_arrays(indices, device)
         if self.hyper is None:
             self.hyper = torch.zeros(2, dtype=torch.float32, device=device)
         if self._hyper_host != (float(neg_slp), float(rep_reg_w)):

@@ -31,11 +31,21 @@ for i in range(S):
 ds = PairDataset(samples, shape)
 th.manual_seed(0)
 model = build_model(**ds.model_config(hid_dim=64, layers=3, rep_act_func="leaky_relu", pred_act_func="leaky_relu", emb_net="Equivariant")).to(gpu)
-sync = FlatGradSync(model)
-opt = FlatAdamW([sync.flatten_parameters()], lr=1e-3, weight_decay=1e-5, amsgrad=True)
+from dualmessagepassing_amd.harness import GraphedTrainStep
 B = 64
-for epoch in range(4):
-    th.cuda.synchronize(); t0 = time.perf_counter()
-    out = train_epoch(model, opt, ds, B, gpu, sync=sync, neg_slp=0.01, order=np.random.default_rng(epoch).permutation(S))
-    th.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("epoch %d: %.3f ms/step  (%d ragged batches of %d pairs, %.0f pairs/s)" % (epoch, dt / (S // B) * 1e3, S // B, B, S / dt), flush=True)
+for graphed in (False, True):
+    th.manual_seed(0)
+    model = build_model(**ds.model_config(hid_dim=64, layers=3, rep_act_func="leaky_relu", pred_act_func="leaky_relu", emb_net="Equivariant")).to(gpu)
+    sync = FlatGradSync(model)
+    opt = FlatAdamW([sync.flatten_parameters()], lr=1e-3, weight_decay=1e-5, amsgrad=True, capturable=graphed)
+    # graphed: batches padded with inert pairs to one of four capacity levels (PairDataset.batch_arrays(pad=...)), so every step replays
+    step = GraphedTrainStep(model, opt, sync, max_shapes=4) if graphed else None
+    import contextlib
+    with (step.steps.on_stream() if graphed else contextlib.nullcontext()):
+        for epoch in range(4):
+            th.cuda.synchronize(); t0 = time.perf_counter()
+            out = train_epoch(model, opt, ds, B, gpu, sync=sync, neg_slp=0.01, order=np.random.default_rng(epoch).permutation(S), graph=step)
+            th.cuda.synchronize(); dt = time.perf_counter() - t0
+            print("%s epoch %d: %.3f ms/step  (%d ragged batches of %d pairs, %.0f pairs/s)%s"
+                  % ("padded + replayed" if graphed else "exact shapes, eager", epoch, dt / (S // B) * 1e3, S // B, B, S / dt,
+                     "  replays %d eager %d" % (step.steps.replays, step.steps.eager_calls) if graphed else ""), flush=True)
