@@ -132,7 +132,9 @@ __global__ __launch_bounds__(kBlock) void gate_fill_k(const GateFill a) {
   for (int64_t j = threadIdx.x; j < pad; j += kBlock) {
     const int64_t pos = off + kept_g + j;
     if (pos >= a.cap) break;
-    const int64_t node = n0 + (n > 0 ? j % n : 0);
+    // (a graph without nodes cannot hold its share of the padding: status bit 1 is up -- the guarded optimizer drops the step,
+    // harness.fit arms the veto on both bits -- and the endpoint is clamped to a node of the batch so that nothing indexes past it)
+    const int64_t node = n > 0 ? n0 + j % n : (n0 > 0 ? n0 - 1 : 0);
     a.src_c[pos] = node;
     a.dst_c[pos] = node;
     if (a.rev_c) a.rev_c[pos] = 0;

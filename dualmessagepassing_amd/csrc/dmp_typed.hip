@@ -92,6 +92,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   const uint32_t colA = (uint32_t)(gtid % kQ) * 16u, col4 = (uint32_t)c4 * 4u;
   constexpr bool kPlainPanel = EPI == TEPI_REL || EPI == TEPI_OUT || EPI == TEPI_H1;   // no class term in the panel
   constexpr bool kRowsOnly = EPI == TEPI_OUT || EPI == TEPI_H1;                         // epilogue operand: row e of R, nothing gathered
+  constexpr bool kFixedPanel = kRowsOnly;                                               // one panel for the whole launch (no class term, no type)
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((EPI == TEPI_EDGE || EPI == TEPI_OUT) && p.bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + c4);
   const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));   // SGPR
@@ -424,6 +425,10 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
     load_ids(0);
     load_rows(set0);           // tile 0
     load_ids(1);
+    // a panel that does not depend on the tile's class (TEPI_OUT / TEPI_H1) is requested HERE, behind tile 0's rows and ahead
+    // of the wait for them: its round trip runs beside theirs instead of after it -- with a few tiles per workgroup (the node
+    // side of a layer: ~1 k tiles over the grid) the launch is little more than these two latencies
+    if (kFixedPanel) load_panel(0.f);
     stage(0, 0, set0);
     load_rows(set0);           // tile 1
     load_ids(2);
@@ -451,7 +456,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
     }
     // tiles of one degree class: W_g is built once per class segment of this workgroup's range
     const float c = __shfl(sv, k & 63);
-    if (!have_panel || __float_as_uint(c) != __float_as_uint(c_have)) {
+    if (!kFixedPanel && (!have_panel || __float_as_uint(c) != __float_as_uint(c_have))) {
       load_panel(c);
       c_have = c;
       have_panel = true;

@@ -495,6 +495,13 @@ class StepGraph:
                 return self._eager(meta, tensors)
             static = [torch.empty_like(t).copy_(t) for t in tensors]
             torch.cuda.synchronize()
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                # RCCL's watchdog thread polls the completion events of the collectives still on its list (every 100 ms); a
+                # poll that lands inside the stream capture below fails in the runtime and aborts the process (found by the
+                # one-rank RCCL run of round 5: one run in three).  Everything is complete after the synchronize above: give the
+                # watchdog two of its periods to retire its list, then record.  (At most ``max_shapes`` times per run.)
+                import time
+                time.sleep(0.25)
             graph = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread polls events while we record: only THIS thread's calls are
             # policed then (torch's "thread_local" capture mode); a single process keeps the strict default

@@ -940,22 +940,27 @@ def l0_bwd_w(enc, K, coef_e, d_pre, d_zn=None, rows=None, out=None, mask=None):
     lib = _lib.load()
     E, H = d_pre.shape
     r0, r1 = (0, E) if rows is None else rows
+    own = False                          # ``mask`` covers the range alone (bit 0 = row r0), not all E rows
     if mask is not None and r0 % 32 != 0:
-        mask = None
+        # a row range that starts inside a mask word (a ragged pattern batch: the target's rows begin anywhere): the range's own
+        # mask from its code rows.  NOT optional: where the layers leave dead rows unwritten (``dead_rows_buffer``) the rows
+        # of ``d_pre`` / ``d_zn`` under a zero gate hold garbage -- their code rows are zeros, so this mask leaves them out
+        mask, own = code_row_mask(enc[r0:r1], K), True
     nacc = (3 if d_zn is not None else 2) * K
     G = int(lib.dmp_l0_bwd_w_blocks(r1 - r0))
     part = torch.empty((G, nacc * H), dtype=torch.float32, device=d_pre.device)
     if mask is not None and USE_L0_ROW_LISTS and r1 - r0 >= L0_LIST_MIN_ROWS:
-        lst, cnt = kept_rows(mask, r0, r1)
+        lst, cnt = kept_rows(mask, 0, r1 - r0) if own else kept_rows(mask, r0, r1)
         with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
             check(lib.dmp_l0_bwd_w_rows(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
                                         ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0,
                                         ptr(lst), ptr(cnt), r1 - r0, H, ptr(part), stream_ptr()), "dmp_l0_bwd_w_rows")
         return reduce_partials(part, None if out is None else out.view(-1)).view(K, (nacc // K) * H)
+    words = None if mask is None else (mask if own else mask[r0 // 32:])
     with _lib.timed("l0_bwd_w[K=%d,E=%d]", (K, r1 - r0), 4 * (H * (2 if d_zn is not None else 1) + enc.size(1) + 1) * (r1 - r0)):
         check(lib.dmp_l0_bwd_w_masked(ptr(enc[r0:]), enc.stride(0), K, ptr(coef_e[r0:]), ptr(d_pre[r0:]), d_pre.stride(0),
                                       ptr(d_zn[r0:]) if d_zn is not None else None, d_zn.stride(0) if d_zn is not None else 0,
-                                      None if mask is None else ptr(mask[r0 // 32:]), r1 - r0, H, ptr(part), stream_ptr()),
+                                      ptr(words), r1 - r0, H, ptr(part), stream_ptr()),
               "dmp_l0_bwd_w")
     return reduce_partials(part, None if out is None else out.view(-1)).view(K, (nacc // K) * H)
 

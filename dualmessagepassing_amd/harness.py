@@ -698,7 +698,7 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     ``graph=True`` (with ``FlatAdamW(capturable=True)``, one rank): training steps whose batch shape repeats are
     recorded once and replayed as one HIP graph (``GraphedTrainStep``).
     ``gate_compact=True`` (or a margin, e.g. 1.25): training forward passes run the rep-net on the target edges the filter
-    gate keeps (``model.set_gate_capacity``; capacity = the largest kept count of up to eight training batches x the margin).
+    gate keeps (``model.set_gate_capacity``; capacity = the largest kept count over the training batches in their stored order x the margin; batches are shuffled in training, so a batch can still exceed it: such steps are dropped, counted, and a warning is raised above 1 % of the steps).
     A batch that keeps more than that raises a device flag and the optimizer drops its step (``FlatAdamW.set_veto``, as a
     loss-scaling optimizer drops an overflowed step); the history counts them (``dropped_steps``).  Evaluation passes run
     on every edge row.  Single rank only (the veto is rank-local: refused with a multi-rank ``sync``)."""
@@ -730,11 +730,13 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
     if compact and hasattr(model, "calibrate_gate_capacity") and hasattr(optimizer, "set_veto"):
         margin, cap = (1.15 if compact is True else float(compact)), 0
         with torch.enable_grad():
-            for i in range(0, min(len(train_set), 8 * batch_size), batch_size):
+            for i in range(0, len(train_set), batch_size):     # every training batch once: the gates only (no rep-net pass)
                 pattern, graph_b = train_set.batchify(np.arange(i, min(i + batch_size, len(train_set))), device)[:2]
                 cap = max(cap, model.calibrate_gate_capacity(pattern, graph_b, margin=margin, multiple=256) or 0)
         model.set_gate_capacity(cap or None)
-        optimizer.set_veto(model.compaction_word if cap else None)
+        # (bit 0: a batch kept more edges than the capacity; bit 1: a graph without nodes was dealt padding edges -- both make
+        # the step's gradients unusable, both drop it)
+        optimizer.set_veto(model.compaction_word if cap else None, mask=3)
     log = None
     if save_dir is not None:
         os.makedirs(save_dir, exist_ok=True)
@@ -758,6 +760,11 @@ def fit(model, optimizer, train_set, dev_set, epochs, batch_size, device, save_d
             history.append({"epoch": epoch, "train": tr, "dev": {k: dev[k] for k in ("MAE", "MSE", "eval_metric")}})
             if getattr(model, "gate_capacity", None):
                 history[-1]["dropped_steps"] = model.compaction_dropped_steps()       # cumulative (one host sync per epoch)
+                steps_so_far = (epoch + 1) * max(1, -(-len(train_set) // batch_size))
+                if history[-1]["dropped_steps"] > 0.01 * steps_so_far:
+                    import warnings
+                    warnings.warn("fit(gate_compact): %d of %d optimizer steps were dropped (batches that kept more edges than the "
+                                  "capacity): raise the margin" % (history[-1]["dropped_steps"], steps_so_far))
             if save_dir is not None:
                 torch.save(model.state_dict(), dataio.checkpoint_path(save_dir, epoch))
             if dev["eval_metric"] < best[0]:
