@@ -62,10 +62,19 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   // two tile buffers (Zs | Ds, 2 x 32 x (H+4) floats each) = 67584 bytes at H = 128; emit() reuses the first H*H floats for the total
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kStride = H + 4, kQ = H / 4, kPass = kGroupThreads / kQ, NL = kSub / kPass;   // float4 per row, rows per load pass, passes
-  constexpr int NI = H / 64, NJ = H / 32;                                                       // accumulator blocks per wave: NI x NJ
+  // QUAD: wave (p, c) owns a QUADRANT of the [H, H] total and contracts both 16-row k-groups of a tile (4 accumulators at
+  // H = 128); else wave (p, q) owns the half (H/2) p .. of the rows, ALL columns, and contracts k-group q (8 accumulators; the
+  // two q's totals meet in LDS at the end).  The class-typed product takes the quadrants: with 8 accumulators its bf16x6
+  // form needed 347 registers and spilled 91 of them to scratch (round 5: 100 -> 80 us at bench.py's shape); the row forms
+  // (node side: every tile of the rows is walked, masked or not) are bound by the fragment splits, which the quadrants do a
+  // third more of (8 instead of 6 fragments per wave and tile: 89 -> 101 us) -- they keep the halves.
+  constexpr bool QUAD = MODE == ATB_TYPED;
+  constexpr int NI = H / 64, NJ = QUAD ? H / 64 : H / 32;                                       // accumulator blocks per wave: NI x NJ
+  constexpr int KG = QUAD ? 2 : 1;                                                              // k-groups a wave contracts per tile
   constexpr int kTile = kSub * kStride, kBuf = 2 * kTile;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pw = wave & 1, qw = wave >> 1;
+  const int pw = wave & 1, qw = wave >> 1;                 // QUAD: rows (H/2) pw .., columns (H/2) qw ..; else rows (H/2) pw .., k-group qw
+  const int kq = QUAD ? 0 : qw, cq = QUAD ? qw : 0;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, gtid = threadIdx.x;
   const uint32_t colA = (uint32_t)(gtid % kQ) * 16u;
   constexpr uint32_t kOOB = 0xFFFFF000u;
@@ -174,53 +183,58 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   auto tile_step = [&](int k, auto phase) {
     constexpr int PH = decltype(phase)::value;
     std::integral_constant<int, PH ^ 1> other;
-    const float *zp = &smem[PH * kBuf + (16 * qw + 8 * h) * kStride + (H / 2) * pw + li];
-    const float *dp = zp + kTile - (H / 2) * pw;
+    const float *zp = &smem[PH * kBuf + (16 * kq + 8 * h) * kStride + (H / 2) * pw + li];
+    const float *dp = &smem[PH * kBuf + kTile + (16 * kq + 8 * h) * kStride + (H / 2) * cq + li];
     if (X6) {
       // fragments: element j of lane (li, h) = row 16q + 8h + j of the operand's column; the staging of tile k+1, the
       // row requests of tile k+3 and the id requests of tile k+4 are spread between the NI x NJ blocks' MFMAs
-      Split8 fa[NI];
       auto frag = [&](const float *col, Split8 &f) {            // two rows at a time: no eight-float temporary
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           split_pair(col[(2 * t) * kStride], col[(2 * t + 1) * kStride], f.hi.u[t], f.mid.u[t], f.lo.u[t]);
       };
-#pragma unroll
-      for (int i = 0; i < NI; ++i) frag(zp + 32 * i, fa[i]);
       int act = 0;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        Split8 fb;                                           // one B fragment at a time: NI + 1 fragments live, not NI + NJ
-        frag(dp + 32 * j, fb);
+      for (int kg = 0; kg < KG; ++kg) {                        // QUAD: the tile's two 16-row k-groups, one after the other
+        Split8 fa[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          __builtin_amdgcn_sched_barrier(0);
-          acc[i][j] = mfma_x6(fa[i], fb, acc[i][j]);
-          __builtin_amdgcn_sched_barrier(0);
-          // 2 NL actions over NI * NJ blocks (H = 128: 8 actions, 8 blocks; H = 64: 4 actions, 2 blocks)
-          constexpr int kPerBlock = (2 * NL + NI * NJ - 1) / (NI * NJ);
+        for (int i = 0; i < NI; ++i) frag(zp + 16 * kg * kStride + 32 * i, fa[i]);
 #pragma unroll
-          for (int u = 0; u < kPerBlock; ++u, ++act) {
-            if (act < NL) stage_row(other, act < NL ? act : 0);
-            else if (act < 2 * NL) load_row(other, act < 2 * NL ? act - NL : 0);
+        for (int j = 0; j < NJ; ++j) {
+          Split8 fb;                                           // one B fragment at a time: NI + 1 fragments live
+          frag(dp + 16 * kg * kStride + 32 * j, fb);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[i][j] = mfma_x6(fa[i], fb, acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            // 2 NL actions over KG NI NJ blocks (H = 128: 8 actions, 8 blocks; H = 64: 4 actions, 2 blocks)
+            constexpr int kPerBlock = (2 * NL + KG * NI * NJ - 1) / (KG * NI * NJ);
+#pragma unroll
+            for (int u = 0; u < kPerBlock; ++u, ++act) {
+              if (act < NL) stage_row(other, act < NL ? act : 0);
+              else if (act < 2 * NL) load_row(other, act < 2 * NL ? act - NL : 0);
+            }
           }
         }
       }
       load_ids(k + 4);
       return;
     }
+    // k-step s of the wave: row 16 (s / 8) + (s % 8) of the tile (lanes 0-31) paired with that row + 8 (lanes 32-63)
+    auto srow = [](int s) { return (16 * (s >> 3) + (s & 7)); };
     float a[NI], b[NJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i) a[i] = zp[32 * i];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) b[j] = dp[32 * j];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 8 * KG; ++s) {
       float x[NI], y[NJ];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) x[i] = s + 1 < 8 ? zp[(s + 1) * kStride + 32 * i] : a[i];
+      for (int i = 0; i < NI; ++i) x[i] = s + 1 < 8 * KG ? zp[srow(s + 1) * kStride + 32 * i] : a[i];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) y[j] = s + 1 < 8 ? dp[(s + 1) * kStride + 32 * j] : b[j];
+      for (int j = 0; j < NJ; ++j) y[j] = s + 1 < 8 * KG ? dp[srow(s + 1) * kStride + 32 * j] : b[j];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -229,15 +243,15 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
       __builtin_amdgcn_sched_barrier(0);
       if (s < NL) stage_row(other, s < NL ? s : 0);
       else if (s < 2 * NL) load_row(other, s < 2 * NL ? s - NL : 0);
-      if (s == 7) load_ids(k + 4);
+      if (s == 8 * KG - 1) load_ids(k + 4);
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = x[i];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) b[j] = y[j];
     }
   };
-  // accumulator (i, j, r) of wave (p, q): output row (H/2)p + 32i + (r&3) + 8(r>>2) + 4h, column 32j + li
-  auto out_index = [&](int i, int j, int r) { return ((H / 2) * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * H + 32 * j + li; };
+  // accumulator (i, j, r) of wave (p, c): output row (H/2)p + 32i + (r&3) + 8(r>>2) + 4h, column (H/2)c + 32j + li
+  auto out_index = [&](int i, int j, int r) { return ((H / 2) * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * H + (H / 2) * cq + 32 * j + li; };
 
   // Emit the accumulators: the two row halves are added through LDS (which must be free: the staged tile is
   // given up), then every thread adds its 16 float4 of the [128,128] total to the workgroup's partial --
@@ -246,7 +260,7 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
   bool emitted = false;
   auto emit = [&](float c) {
     __syncthreads();
-    if (qw == 1) {
+    if (QUAD || qw == 1) {      // QUAD: every wave holds its own quadrant of the total: straight to LDS (the 16-byte stores below read whole rows)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -255,18 +269,20 @@ __device__ __forceinline__ void atb_body(const AtbArgs &p, const int ya, const i
           for (int r = 0; r < 16; ++r) smem[out_index(i, j, r)] = acc[i][j][r];
     }
     __syncthreads();
-    if (qw == 0) {
+    if (!QUAD) {
+      if (qw == 0) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = out_index(i, j, r);
-            smem[o] = acc[i][j][r] + smem[o];
-          }
+            for (int r = 0; r < 16; ++r) {
+              const int o = out_index(i, j, r);
+              smem[o] = acc[i][j][r] + smem[o];
+            }
+      }
+      __syncthreads();
     }
-    __syncthreads();
 #pragma unroll 4
     for (int m = 0; m < H * H / (4 * kGroupThreads); ++m) {
       const int l = (m * kGroupThreads + gtid) * 4;         // element (l / H, l % H) of the total

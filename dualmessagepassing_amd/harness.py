@@ -228,14 +228,18 @@ class PairDataset:
             extra = 2 * B - len(indices)                          # inert pairs: the batch always holds 2 B pairs
             tot = {key: (sum(int(self.samples[i][key]["num_nodes"]) for i in indices), sum(len(self.samples[i][key]["src"]) for i in indices))
                    for key in ("pattern", "graph")}
-            caps = lambda key, k: (-(-(B * pad[key][0] + B) * k // K), -(-B * pad[key][1] * k // K))
-            level = next(k for k in range(1, K + 1)
-                         if all(tot[key][0] + extra <= caps(key, k)[0] + (extra - B) and tot[key][1] <= caps(key, k)[1] for key in tot))
+            # level k: k / K of what B largest graphs would take, + one node and one edge for each of B inert graphs (an inert
+            # graph without an edge would put 1 / 0 into the heads' length features, pred.py:93-96)
+            caps = lambda key, k: (-(-B * pad[key][0] * k // K) + B, -(-B * pad[key][1] * k // K) + B)
+            fits = lambda k: all(tot[key][0] + extra <= caps(key, k)[0] and tot[key][1] + extra <= caps(key, k)[1] for key in tot)
+            level = next((k for k in range(1, K + 1) if fits(k)), None)
+            if level is None:
+                raise ValueError("batch_arrays(pad=...): the batch does not fit %d graphs of the dataset's largest size" % B)
         for key in ("pattern", "graph"):
             gs = [self.samples[i][key] for i in indices]
             if pad is not None:
                 cn, ce = caps(key, level)
-                gs = gs + self._inert_graphs(tot[key], cn + (extra - B), ce, extra)
+                gs = gs + self._inert_graphs(tot[key], cn, ce, extra, pad[key])
             cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
             nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
             ne_ = np.array([len(g["src"]) for g in gs], np.int64)
@@ -253,17 +257,19 @@ class PairDataset:
         return tuple(meta), tensors + [counts.unsqueeze(-1), weights.unsqueeze(-1)]
 
     @staticmethod
-    def _inert_graphs(tot, cap_n, cap_e, extra):
+    def _inert_graphs(tot, cap_n, cap_e, extra, largest=None):
         """``extra`` label-0 graphs that take a side's node / edge totals ``tot`` up to ``(cap_n, cap_e)``: nodes dealt evenly
-        (every inert graph has at least one), edges too (a ring over the graph's nodes: valid endpoints, parallel edges when
-        the ring wraps)."""
+        (every inert graph has at least one), edges too (at least one each; a ring over the graph's nodes: valid endpoints,
+        parallel edges when the ring wraps).  ``largest``: the dataset's largest graph (nodes, edges) no inert graph may exceed."""
         n_pad, e_pad = cap_n - tot[0], cap_e - tot[1]
-        if n_pad < extra or e_pad < 0:
+        if n_pad < extra or e_pad < extra:
             raise ValueError("batch_arrays(pad=...): the batch does not fit its capacity level")
         out = []
         for j in range(extra):
             n = n_pad // extra + (1 if j < n_pad % extra else 0)
             e = e_pad // extra + (1 if j < e_pad % extra else 0)
+            if largest is not None and (n > largest[0] or e > largest[1]):
+                raise ValueError("batch_arrays(pad=...): an inert graph would exceed the dataset's largest graph (a batch of empty graphs?)")
             a = np.arange(e, dtype=np.int64) % n
             out.append({"src": a, "dst": (a + 1) % n, "vlabel": np.zeros(n, np.int64), "elabel": np.zeros(e, np.int64),
                         "eid": np.arange(e, dtype=np.int64), "rev": np.zeros(e, bool), "num_nodes": n})
