@@ -152,7 +152,8 @@ SIGNATURES = {
     "dmp_atb_rows_plain": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "dmp_atb_rows_masked": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "dmp_atb_jobs_blocks_h": (c_i64, [c_i64, c_int, c_int]),
-    "dmp_atb_rows_jobs_h": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr]),
+    "dmp_atb_rows_jobs_h": (c_int, [c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "dmp_atb_tile_jobs_blocks": (c_i64, [c_i64, c_int, c_int]),
     "dmp_mfma_partial_rows_h": (c_i64, [c_i64, c_int]),
     "dmp_gemm_k64": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_i64, c_ptr]),
     "dmp_atb_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),

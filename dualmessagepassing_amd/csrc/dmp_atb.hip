@@ -462,6 +462,25 @@ static int atb_jobs_launch(const AtbJobs &t, int num_jobs, int64_t rows, hipStre
 }
 
 
+// the tile-list form of the multi-job launch: blockIdx.y = the job, blockIdx.x splits the SHARED tile list
+static unsigned tile_jobs_blocks(int64_t tiles_bound, int num_jobs, int H) {
+  int64_t g = (int64_t)atb_blocks(tiles_bound, H) / (num_jobs > 0 ? num_jobs : 1);
+  if (g < 1) g = 1;
+  if (g > tiles_bound) g = tiles_bound > 0 ? tiles_bound : 1;
+  return (unsigned)g;
+}
+template <int H>
+static int atb_tile_jobs_launch(const AtbJobs &t, int num_jobs, int64_t tiles_bound, hipStream_t st) {
+  static bool done[kMaxDevices] = {}, done_exact[kMaxDevices] = {};
+  if (!opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, true, ATB_TYPED>), atb_lds_bytes(H), done) ||
+      !opt_in_lds(reinterpret_cast<const void *>(&atb_jobs_k<H, false, ATB_TYPED>), atb_lds_bytes(H), done_exact))
+    return DMP_ERR_HIP;
+  const dim3 grid(tile_jobs_blocks(tiles_bound, num_jobs, H), (unsigned)num_jobs);
+  if (g_exact_fp32) atb_jobs_k<H, false, ATB_TYPED><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
+  else atb_jobs_k<H, true, ATB_TYPED><<<grid, kGroupThreads, atb_lds_bytes(H), st>>>(t);
+  return check_launch();
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -502,10 +521,33 @@ int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H) {
   const int h = H == 64 ? 64 : 128;
   return (int64_t)rows_blocks(rows, h, h * (num_jobs > 0 ? num_jobs : 1), h);
 }
-int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream) {
+/* ... of the tile-list form (rows of every job's partial = the grid's x extent) */
+int64_t dmp_atb_tile_jobs_blocks(int64_t tiles_bound, int num_jobs, int H) { return (int64_t)tile_jobs_blocks(tiles_bound, num_jobs, H == 64 ? 64 : 128); }
+int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, const int32_t *slot_row,
+                        const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, void *stream) {
   if (H != 128 && H != 64) return DMP_ERR_UNSUPPORTED;
   if (rows < 0 || num_jobs < 1 || num_jobs > kMaxAtbJobs || !jobs) return DMP_ERR_BAD_ARG;
   AtbJobs t;
+  if (slot_row) {
+    // over a TILE LIST (rows gathered by slot, the tile count in device memory) instead of the rows 0 .. rows-1: the node side of
+    // a layer under a 0 / 1 node gate walks the kept nodes' tiles (dmp_kept_rows(tiles = 1)) -- 41 % of the tiles at bench.py's labels
+    if (!tile_scale || !num_tiles || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+    if (!fits32(tiles_bound * kSub, 1) || rows >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+    for (int i = 0; i < num_jobs; ++i) {
+      const dmp_atb_job &j = jobs[i];
+      if (j.gate || j.partial_colsum || j.rowmask) return DMP_ERR_BAD_ARG;      // the list says which rows take part
+      if (!j.partial || (rows > 0 && (!j.A || !j.B || j.lda < H || j.ldb < H)) || j.ldp < H) return DMP_ERR_BAD_ARG;
+      if (j.lda % 4 || j.ldb % 4 || j.ldp % 4 || (rows > 0 && (!aligned16(j.A) || !aligned16(j.B))) || !aligned16(j.partial))
+        return DMP_ERR_UNSUPPORTED;
+      if (!stride_ok(j.lda) || !stride_ok(j.ldb) || !fits4g(rows, j.lda) || !fits4g(rows, j.ldb)) return DMP_ERR_UNSUPPORTED;
+      AtbArgs a{};
+      a.Z = j.A; a.ldz = j.lda; a.D = j.B; a.ldd = j.ldb; a.E = rows; a.slot_edge = slot_row; a.tile_scale = tile_scale;
+      a.num_tiles = num_tiles; a.pT = j.partial; a.pB = nullptr; a.pstride = j.partial_stride; a.ldp = j.ldp;
+      t.job[i] = a;
+    }
+    return H == 128 ? atb_tile_jobs_launch<128>(t, num_jobs, tiles_bound, (hipStream_t)stream)
+                    : atb_tile_jobs_launch<64>(t, num_jobs, tiles_bound, (hipStream_t)stream);
+  }
   bool plain = true;
   for (int i = 0; i < num_jobs; ++i) {
     const dmp_atb_job &j = jobs[i];

@@ -846,6 +846,7 @@ def _kept_row_tiles(mask, r0, r1):
 
 USE_NODE_ROWS = _os.environ.get("DMP_NODE_ROWS", "1") == "1"   # the node side of a layer over the nodes a 0 / 1 node gate keeps
 USE_KEPT_INCIDENCE = True     # ... and its backward's endpoint sums as a segment sum over the kept edges' incidence CSR
+USE_NODE_TILE_ATB = True      # ... and the node side's weight gradients over the kept nodes' tiles
 
 
 class NodeRows:
@@ -996,12 +997,14 @@ _ATB_JOB = None
 MAX_ATB_JOBS = 8
 
 
-def atb_rows_multi(products):
+def atb_rows_multi(products, tiles=None):
     """Several ``atb_rows`` products over the SAME rows in ONE launch: ``products`` = list of ``(a, b, gate, colsum[, mask])``
     (a [R, 128 ma], b [R, 128 nb]; ``mask``: a ``gate_row_mask`` whose zero bits mark rows where ``gate (.) a`` or ``b`` is
     known to be all zeros: not fetched); returns a list of ``(a^T b  [128 ma, 128 nb], column sums or None)``.  The launch's
     workgroups are shared by all 128 x 128 output blocks, so short inputs (the node side: R = nodes) get long
-    tile ranges per workgroup instead of paying every workgroup's fixed costs once per product."""
+    tile ranges per workgroup instead of paying every workgroup's fixed costs once per product.
+    ``tiles`` (``NodeRows.tiles``): the products run over that tile list (rows gathered by slot: the kept nodes of a 0 / 1 node
+    gate) instead of all rows -- jobs then carry neither gates, column sums nor masks: the list says which rows take part."""
     global _ATB_JOB
     import ctypes
     lib = _lib.load()
@@ -1016,7 +1019,9 @@ def atb_rows_multi(products):
     nblk = sum((a.size(1) // blk) * (b.size(1) // blk) for a, b, _, _, _ in products)
     if nblk > MAX_ATB_JOBS:
         raise ValueError("atb_rows_multi: more than %d output blocks" % MAX_ATB_JOBS)
-    G = int(lib.dmp_atb_jobs_blocks_h(R, nblk, blk))
+    if tiles is not None and any(gate is not None or colsum or mask is not None for _, _, gate, colsum, mask in products):
+        raise _lib.DmpError("atb_rows_multi(tiles=...): jobs without gate, column sums or mask")
+    G = int(lib.dmp_atb_tile_jobs_blocks(tiles[3], nblk, blk)) if tiles is not None else int(lib.dmp_atb_jobs_blocks_h(R, nblk, blk))
     jobs = (_ATB_JOB * nblk)()
     parts, k = [], 0
     for a, b, gate, colsum, mask in products:
@@ -1035,7 +1040,11 @@ def atb_rows_multi(products):
                 j.cs_ld = M
                 k += 1
     with _lib.timed("atb_rows_multi[blocks=%d,R=%d]", (nblk, R), 0):
-        check(lib.dmp_atb_rows_jobs_h(jobs, nblk, R, blk, stream_ptr()), "dmp_atb_rows_jobs_h")
+        if tiles is not None:
+            check(lib.dmp_atb_rows_jobs_h(jobs, nblk, R, blk, ptr(tiles[0]), ptr(tiles[1]), ptr(tiles[2]), tiles[3], stream_ptr()),
+                  "dmp_atb_rows_jobs_h")
+        else:
+            check(lib.dmp_atb_rows_jobs_h(jobs, nblk, R, blk, None, None, None, 0, stream_ptr()), "dmp_atb_rows_jobs_h")
     return [(reduce_partials(part).view(M, N), (reduce_partials(part_cs) if part_cs is not None else None))
             for part, part_cs, M, N in parts]
 
@@ -1605,7 +1614,9 @@ class _FusedDMPLayer(torch.autograd.Function):
                                         mask=vmask[n0 // 32:] if (vmask is not None and n0 % 32 == 0) else None)
                 elif one_launch:
                     vm = binary_gate_mask(ctx.v_gate)
-                    if vm is not None:    # (db2n came from bwd_h1; no job carries a gate: the launch runs on the bf16 pipe)
+                    if nd is not None and USE_NODE_TILE_ATB:     # over the kept nodes' tiles
+                        (dW2n, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False), (x, dXP, None, False)], tiles=nd.tiles)
+                    elif vm is not None:    # (db2n came from bwd_h1; no job carries a gate: the launch runs on the bf16 pipe)
                         (dW2n, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (x, dXP, None, False, vm if nd is not None else None)])
                     else:
                         (dW2n, db2n), (dWx, _) = atb_rows_multi([(dxn, H1n, ctx.v_gate, True, gate_row_mask(ctx.v_gate)), (x, dXP, None, False)])
@@ -1625,7 +1636,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 if one_launch:   # the three node-side weight gradients (1 + 2 + 3 output blocks) share one launch
                     # (dPn = act'(H1n) ((v_gate dxn) W2): zero rows under a zero node gate -- the first two products skip them)
                     vm = gate_row_mask(ctx.v_gate)
-                    if binary_gate_mask(ctx.v_gate) is not None:   # (db2n came from bwd_h1; no job carries a gate: bf16 pipe)
+                    if nd is not None and USE_NODE_TILE_ATB:
+                        # the three products over the kept nodes' tiles (rows gathered by slot): 41 % of the row tiles at
+                        # bench.py's labels, and nothing of a dead node's (unwritten) rows is touched
+                        (dW2n, _), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False), (S, dPn, None, False), (x, dXP, None, False)],
+                                                                        tiles=nd.tiles)
+                    elif binary_gate_mask(ctx.v_gate) is not None:   # (db2n came from bwd_h1; no job carries a gate: bf16 pipe)
                         # (under ``nd`` x's and dXP's rows of the dead nodes were never written: the third product skips them too)
                         (dW2n, _), (dBn, _), (dWx, _) = atb_rows_multi([(dxn, H1n, None, False, vm), (S, dPn, None, False, vm),
                                                                          (x, dXP, None, False, vm if nd is not None else None)])

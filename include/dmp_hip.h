@@ -1191,7 +1191,13 @@ typedef struct {
 } dmp_atb_job;
 /* H x H output blocks per job, H = 128 (the two functions above) or 64. */
 int64_t dmp_atb_jobs_blocks_h(int64_t rows, int num_jobs, int H);
-int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, void *stream);
+/* slot_row != NULL: the jobs run over a TILE LIST instead of the rows 0 .. rows-1 -- slot_row [tiles_bound * 32] row ids (-1 =
+ * padding), tile_scale [tiles_bound] (constant: one "class"), *num_tiles tiles in use (device): dmp_kept_rows(tiles = 1) of a
+ * 0 / 1 node gate, i.e. the node side's weight gradients over the kept nodes only (rows of A and B gathered by slot; jobs
+ * without gate / column sums / row mask; partials [dmp_atb_tile_jobs_blocks(tiles_bound, num_jobs, H)] per job).  Else NULLs. */
+int64_t dmp_atb_tile_jobs_blocks(int64_t tiles_bound, int num_jobs, int H);
+int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, const int32_t *slot_row,
+                        const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, void *stream);
 /* (a launch none of whose jobs has a gate or column sums runs on the bf16 pipe, bf16x6: the 0 / 1-gated products of a step come as
  * row masks, their column sums from dmp_bwd_h1_fused_colsum) */
 

@@ -217,3 +217,30 @@ def test_model_with_the_kept_node_path_equals_the_model_without_it(lazy, gpu):
             assert float(a.abs().max()) == 0.0
         else:
             assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
+
+
+@pytest.mark.parametrize("H", [128, 64])
+def test_weight_gradients_over_the_kept_nodes_tiles(H, gpu):
+    """``atb_rows_multi(tiles=...)``: several ``a^T b`` products over the rows of ONE tile list (rows gathered by slot) in one
+    launch -- against fp64 over the kept rows; a dead row is never fetched (NaN there)."""
+    from dualmessagepassing_amd import fused
+    g = th.Generator(device=gpu).manual_seed(H + 7)
+    N = 9000
+    v_gate = (th.rand(N, device=gpu, generator=g) < 0.41).float()
+    vmask = fused.gate_row_mask(v_gate)
+    lst, cnt = fused.kept_rows(vmask, 0, N, tiles=True)
+    T = (lst, th.zeros((N + 31) // 32, device=gpu), cnt[1:2], (N + 31) // 32)
+    keep = v_gate != 0
+    a1, b1 = th.randn(N, H, device=gpu, generator=g), th.randn(N, H, device=gpu, generator=g)
+    a2, b2 = th.randn(N, 2 * H, device=gpu, generator=g), th.randn(N, H, device=gpu, generator=g)
+    a3, b3 = th.randn(N, H, device=gpu, generator=g), th.randn(N, 3 * H, device=gpu, generator=g)
+    for t in (a1, b1, a2, b2, a3, b3):
+        t[~keep] = float("nan")
+    (w1, _), (w2, _), (w3, _) = fused.atb_rows_multi([(a1, b1, None, False), (a2, b2, None, False), (a3, b3, None, False)], tiles=T)
+    for w, a, b in ((w1, a1, b1), (w2, a2, b2), (w3, a3, b3)):
+        ref = a[keep].double().t() @ b[keep].double()
+        scale = float((a[keep].double().abs().t() @ b[keep].double().abs()).max())
+        assert w.shape == ref.shape and bool(th.isfinite(w).all())
+        assert float((w.double() - ref).abs().max()) <= 2e-6 * scale
+    with pytest.raises(Exception):
+        fused.atb_rows_multi([(a1, b1, v_gate, False)], tiles=T)          # the list says which rows take part: no gates here
