@@ -73,7 +73,7 @@ SIGNATURES = {
                                     c_ptr, c_i64, c_ptr]),
     "dmp_seg_sum2_graphs_masked": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                            c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
-    "dmp_seg_sum2_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64, c_ptr]),
+    "dmp_seg_sum2_rows": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_f32, c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_incidence_keep": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_seg_sum2_tiled": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                    c_ptr, c_i64, c_ptr]),

@@ -697,11 +697,11 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr, const int32
 }
 
 int dmp_seg_sum2_rows(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int32_t *rowlist,
-                      const int32_t *rowcount, int ptr_by_pos, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
-                      void *stream) {
+                      const int32_t *rowcount, int ptr_by_pos, int incidence, int64_t num_nodes, int H, float s0, float s1, float *out,
+                      int64_t ldo, void *stream) {
   if (!rowlist || !rowcount) return DMP_ERR_BAD_ARG;
-  // (ptr_by_pos: an incidence CSR -- the kernel instantiation tagged so, so that a profile keeps the backward's sums apart)
-  return seg_sum_impl(M, ldm, rowptr, ent, nullptr, num_nodes, H, true, s0, s1, out, ldo, ptr_by_pos ? 2 : 1, stream, rowlist, rowcount,
+  // (incidence: said of an incidence CSR -- the kernel instantiation tagged so, so that a profile keeps the backward's sums apart)
+  return seg_sum_impl(M, ldm, rowptr, ent, nullptr, num_nodes, H, true, s0, s1, out, ldo, incidence ? 2 : 1, stream, rowlist, rowcount,
                       ptr_by_pos ? 1 : 0);
 }
 

@@ -1061,7 +1061,8 @@ __global__ __launch_bounds__(kBlock) void inc_keep_count_k(const int32_t *__rest
   if (i < n) {
     const int v = list[i];
     for (int q = in_ptr[v], hi = in_ptr[v + 1]; q < hi; ++q) c += gate[in_ent[q] >> 1] != 0.f;
-    for (int q = out_ptr[v], hi = out_ptr[v + 1]; q < hi; ++q) c += gate[out_ent[q] >> 1] != 0.f;
+    if (out_ptr)          // (NULL: the in-entries alone -- the kept edges' CSR by destination with a row per list position)
+      for (int q = out_ptr[v], hi = out_ptr[v + 1]; q < hi; ++q) c += gate[out_ent[q] >> 1] != 0.f;
     row_cnt[i] = c;
   }
 #pragma unroll
@@ -1099,8 +1100,8 @@ __global__ __launch_bounds__(kBlock) void inc_keep_fill_k(const int32_t *__restr
   if (i < n) {
     keep_ptr[i] = s;
     const int v = list[i];
-    int a = in_ptr[v], b = out_ptr[v];
-    const int a1 = in_ptr[v + 1], b1 = out_ptr[v + 1];
+    int a = in_ptr[v], b = out_ptr ? out_ptr[v] : 0;
+    const int a1 = in_ptr[v + 1], b1 = out_ptr ? out_ptr[v + 1] : 0;
     int x = a < a1 ? in_ent[a] : 0, y = b < b1 ? out_ent[b] : 0;
     while (a < a1 || b < b1) {                                  // incidence_fill's merge (an edge that is both lists its in-entry first)
       if (b >= b1 || (a < a1 && (x >> 1) <= (y >> 1))) {
@@ -1937,7 +1938,7 @@ int dmp_incidence_keep(const int32_t *in_ptr, const int32_t *in_ent, const int32
   if (N < 0 || !keep_ptr) return DMP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return hipMemsetAsync(keep_ptr, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
-  if (!in_ptr || !in_ent || !out_ptr || !out_ent || !gate || !list || !count || !row_cnt || !keep_ent) return DMP_ERR_BAD_ARG;
+  if (!in_ptr || !in_ent || (out_ptr && !out_ent) || !gate || !list || !count || !row_cnt || !keep_ent) return DMP_ERR_BAD_ARG;
   int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block (dmp_csr_keep_scratch_words)
   inc_keep_count_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, gate, list, count, row_cnt, blk);
   inc_keep_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, out_ptr, out_ent, gate, list, count, row_cnt, blk, keep_ptr, keep_ent);

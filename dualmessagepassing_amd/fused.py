@@ -859,23 +859,27 @@ class NodeRows:
         self.mask, self.rows, self.tiles, self.sel = mask, rows, tiles, sel
         self._kinc = None
 
-    def kept_incidence(self, index, e_gate):
+    def kept_incidence(self, index, e_gate, in_only=False):
         """``(ptr, ent)``: the incidence CSR over the edges the 0 / 1 ``e_gate`` keeps, one row per POSITION of ``rows``
         (``dmp_incidence_keep``): what the backward's endpoint sums walk -- an edge row without a kept endpoint is never
-        fetched.  Memoised per gate (the layers of a rep-net share it)."""
+        fetched.  ``in_only``: the in-entries alone = the kept edges' CSR by destination, a row per position (the forward
+        aggregation).  Memoised per gate (the layers of a rep-net share it)."""
         owner = _gate_owner(e_gate)
-        hit = self._kinc
-        if hit is not None and hit[0] is owner and hit[1] == owner._version:
-            return hit[2]
+        memo = self._kinc if self._kinc is not None and self._kinc[0] is owner and self._kinc[1] == owner._version else (owner, owner._version, {})
+        self._kinc = memo
+        hit = memo[2].get(bool(in_only))
+        if hit is not None:
+            return hit
         lib = _lib.load()
         N, dev = index.num_nodes, index.in_ptr.device
         nscr = int(lib.dmp_csr_keep_scratch_words(N))
-        ws = torch.empty(nscr + N + 1 + 2 * index.num_edges, dtype=torch.int32, device=dev)
+        ws = torch.empty(nscr + N + 1 + (1 if in_only else 2) * index.num_edges, dtype=torch.int32, device=dev)
         row_cnt, kptr, kent = ws[:nscr], ws[nscr:nscr + N + 1], ws[nscr + N + 1:]
-        check(lib.dmp_incidence_keep(ptr(index.in_ptr), ptr(index.in_ent), ptr(index.out_ptr), ptr(index.out_ent), ptr(e_gate.reshape(-1)),
+        check(lib.dmp_incidence_keep(ptr(index.in_ptr), ptr(index.in_ent), None if in_only else ptr(index.out_ptr),
+                                     None if in_only else ptr(index.out_ent), ptr(e_gate.reshape(-1)),
                                      ptr(self.rows[0]), ptr(self.rows[1]), N, ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()),
               "dmp_incidence_keep")
-        self._kinc = (owner, owner._version, (kptr, kent))
+        memo[2][bool(in_only)] = (kptr, kent)
         return kptr, kent
 
 
@@ -1322,8 +1326,13 @@ class _FusedDMPLayer(torch.autograd.Function):
             S = None
         else:
             # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
-            kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
-            if kc is not None and nd is not None:   # ... and over the kept NODES' rows only: the others' aggregates are dead
+            kc = keep_in_csr(index, e_gate) if (zero_rows_gate(e_gate) and not (nd is not None and USE_KEPT_INCIDENCE)) else None
+            if nd is not None and USE_KEPT_INCIDENCE and zero_rows_gate(e_gate) and USE_KEEP_CSR:
+                # ... over the kept NODES' rows only (the others' aggregates are dead), through the kept edges' CSR with a row
+                # per kept node: the row group finds its entries by its position -- one dependent load less than via the node id
+                kp, ke = nd.kept_incidence(index, e_gate, in_only=True)
+                S = ops.seg_sum_raw(z, kp, ke, N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows, ptr_by_pos=True)
+            elif kc is not None and nd is not None:
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows)
             elif kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0)
@@ -1536,7 +1545,8 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # every kept node's two sums over its KEPT edges (the incidence CSR over the kept edges, a row per kept node):
                 # the plain segment-sum kernel, ascending edge id -- an edge row without a kept endpoint is never fetched
                 kp, ke = nd.kept_incidence(ix, ctx.e_gate)
-                ops.seg_sum_raw(dG[:, :H], kp, ke, N, None, True, 1.0, -1.0, out=dXP[:, H:], rows=nd.rows, ptr_by_pos=True, tag="seg_sum2_kept_inc")
+                ops.seg_sum_raw(dG[:, :H], kp, ke, N, None, True, 1.0, -1.0, out=dXP[:, H:], rows=nd.rows, ptr_by_pos=True, tag="seg_sum2_kept_inc",
+                                incidence=True)
             else:
                 nodes = (nd.mask, nd.sel[:2]) if (nd is not None and sums_masked and ops.graph_seg_ok(ix, dG[:, :H], H, dXP[:, H:])) else None
                 ops.endpoint_sums(dG[:, :H], ix, out=dXP[:, H:], mask=gate_row_mask(ctx.e_gate) if sums_masked else None,

@@ -131,7 +131,7 @@ def endpoint_sums(M, index, out=None, mask=None, gate=None, nodes=None):
 
 
 def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=1.0, rows_shared=True, out=None, tiling=None,
-                rows=None, ptr_by_pos=False, tag=None):
+                rows=None, ptr_by_pos=False, tag=None, incidence=False):
     """``out``: optional destination (e.g. a column slice of a wider matrix: unit inner stride, any row stride).
     ``tiling`` (``graph_tiling``): the split sum over a CSR whose rows share source rows runs per graph tile from LDS.
     ``rows`` = ``(list, count)`` (``fused.kept_rows``; split sums without weights, with ``out``): only the destination rows of
@@ -164,8 +164,8 @@ def seg_sum_raw(M, rowptr, ent, num_nodes, edge_w=None, split=False, s0=1.0, s1=
         if not split or ew is not None:
             raise _lib.DmpError("seg_sum: a row list goes with the split sum without weights")
         with _lib.timed((tag or "seg_sum2") + "[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):
-            check(lib.dmp_seg_sum2_rows(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(rows[0]), ptr(rows[1]), int(bool(ptr_by_pos)), num_nodes, H,
-                                        s0, s1, ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_rows")
+            check(lib.dmp_seg_sum2_rows(ptr(M), ldm, ptr(rowptr), ptr(ent), ptr(rows[0]), ptr(rows[1]), int(bool(ptr_by_pos)), int(bool(incidence)),
+                                        num_nodes, H, s0, s1, ptr(out), ldo, stream_ptr()), "dmp_seg_sum2_rows")
         return out
     if split:
         with _lib.timed("seg_sum2[H=%d,rows=%d,ent=%d]", (H, num_nodes, nent), nbytes):

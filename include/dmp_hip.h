@@ -416,12 +416,13 @@ int dmp_seg_sum2(const float *M, int64_t ldm, const int32_t *rowptr,
  * dmp_kept_rows of a 0 / 1 NODE gate): the other rows of `out` are not written.  A node under a zero of the ScalarFilter's
  * node gate is a zero row in every layer (dmpnn.py:245-277), its aggregate feeds only its own (gated) update: dead. */
 int dmp_seg_sum2_rows(const float *M, int64_t ldm, const int32_t *rowptr, const int32_t *ent, const int32_t *rowlist,
-                      const int32_t *rowcount, int ptr_by_pos, int64_t num_nodes, int H, float s0, float s1, float *out, int64_t ldo,
-                      void *stream);
+                      const int32_t *rowcount, int ptr_by_pos, int incidence, int64_t num_nodes, int H, float s0, float s1, float *out,
+                      int64_t ldo, void *stream);
 /* The incidence CSR (dmp_incidence_build: a node's in-entries and out-entries, flag flipped, merged by ascending edge id) over the
  * edges a 0 / 1 edge gate keeps (gate [E] floats), for the nodes of a list only (list / count: dmp_kept_rows of a 0 / 1 node gate):
  * keep_ptr [*count + 1] is indexed by the POSITION in the list, keep_ent [<= 2 kept edges]; row_cnt: dmp_csr_keep_scratch_words(N)
- * scratch.  dmp_seg_sum2_rows(ptr_by_pos = 1) over it is the backward of the gathered node projections (dmpnn.py:111-127) under
+ * scratch.  out_ptr / out_ent NULL: the in-entries alone -- the kept edges' CSR by destination with a row per list position (the
+ * forward node aggregation: the row group of a kept node finds its entries without the node's row pointers).  dmp_seg_sum2_rows(ptr_by_pos = 1) over it is the backward of the gathered node projections (dmpnn.py:111-127) under
  * the ScalarFilter's gates: every kept node's two sums over its kept edges in ascending edge id -- the bits of dmp_seg_sum2 over
  * the full incidence CSR (the left-out addends are zero rows, the left-out nodes' rows dead) from the fewest row reads: an edge
  * row with no kept endpoint is never fetched. */
@@ -465,7 +466,7 @@ int dmp_seg_sum2_graphs(const float *M, int64_t ldm, const int32_t *sel_a, const
                         const int64_t *node_off, const int64_t *edge_off, int64_t Ba, int64_t Bb, int ka, int kb,
                         int H, float s0, float s1, float *out, int64_t ldo, void *stream);
 /* ... where rows of M are known to be all zeros: rowmask [ceil(num_rows / 32)] (dmp_row_mask_bits: bit e & 31 of word e >> 5
- * clear = row e is zero, e.g. the dPre rows a 0 / 1 edge gate wiped in dmp_bwd_h1_fused_masked) -- those rows are not fetched.
+ * clear = row e is zero, e.g. the dPre rows a 0 / 1 edge gate wiped in dmp_bwd_h1_fused_rows) -- those rows are not fetched.
  * nodemask (optional) [ceil(num_nodes / 32)]: bit v & 31 of word v >> 5 clear = row v of `out` is dead (a node under a zero of
  * a 0 / 1 node gate: its gradient is multiplied by that zero further down, dmpnn.py:245-277) and is NOT STORED -- `out` keeps
  * whatever it held there; with dmp_edge_select_nodes' selectors (-1 for such a node) its addends are dropped too. */
@@ -656,9 +657,9 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
  *                    (the union's edge rows: pattern rows first, then the gated target rows; gate may be NULL).  The target
  *                    rows' codes start at column goff: with goff = K the two kinds of rows occupy disjoint columns, so two
  *                    embedding tables stacked to [2K, H] act as one (Kpad >= goff + K).
- *   dmp_l0_edge_fwd  out[r] = act(enc[r] MA + coef_e[r] (enc[r] MB) + P[sel_a[r], 0:H] - P[sel_b[r], H:2H] + bias)
+ *   dmp_l0_edge_fwd_masked  out[r] = act(enc[r] MA + coef_e[r] (enc[r] MB) + P[sel_a[r], 0:H] - P[sel_b[r], H:2H] + bias)
  *                    with M = [MA | MB] = W [A | B]  ([K, ldm >= 2H]); replaces dmp_edge_fwd_typed for this layer.
- *   dmp_l0_bwd_w     partial[b] = [enc^T dPre | (coef_e enc)^T dPre | enc^T dZn] over workgroup b's rows
+ *   dmp_l0_bwd_w_masked     partial[b] = [enc^T dPre | (coef_e enc)^T dPre | enc^T dZn] over workgroup b's rows
  *                    ([dmp_l0_bwd_w_blocks(rows), K, (dZn ? 3 : 2) * H]; finish with dmp_reduce_partials): the
  *                    class-typed weight gradient is W^T of the first two blocks, the embedding's gradient needs all three. */
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
@@ -670,7 +671,7 @@ int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M,
                            const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                            const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream);
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
-/* dmp_l0_bwd_w with a row mask: bit r of rowmask[t] == 0 says the code row 32 t + r is all zeros (the row's gate was 0 when
+/* dmp_l0_bwd_w_masked with a row mask: bit r of rowmask[t] == 0 says the code row 32 t + r is all zeros (the row's gate was 0 when
  * dmp_l0_pack made it), so its dPre / dZn rows -- which would be multiplied by those zeros -- are not fetched. */
 int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_e, const float *dPre, int64_t ldd, const float *dZn,
                         int64_t ldz, const uint32_t *rowmask, int64_t R, int H, float *partial, void *stream);
@@ -876,7 +877,7 @@ typedef struct {
 typedef struct {
   float *Bn, *bn, *Wx, *Wes, *be;
   float *WesT, *nW2t, *eW2t;      /* optional outputs (NULL to skip): [A'^T | B'^T] [H,2H] and the transposed second Linears
-                                     [in,out] -- the layouts dmp_bwd_z_typed / dmp_out_fwd_fused read coalesced */
+                                     [in,out] -- the layouts dmp_bwd_z_typed_arow / dmp_out_fwd_fused_rows read coalesced */
 } dmp_layer_folded;
 typedef struct { const float *dBn, *dbn, *dWx, *dWes, *dbe; } dmp_layer_folded_grads;
 typedef struct { float *nloop_w, *in_w, *out_w, *nbias, *eloop_w, *src_w, *dst_w, *ebias, *nW0, *eW0; } dmp_layer_weight_grads;
@@ -945,9 +946,9 @@ int dmp_heads_blend(const float *const *y, const float *const *gl, float *const 
 
 
 /* ------------------------------------------------------------------------- */
-/* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32).  H = 128; the one-panel kernels (dmp_out_fwd_fused,
- * dmp_bwd_h1_fused without coefE), the class-typed kernels (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_atb_typed) and the
- * row weight-gradient kernels (dmp_atb_rows_h, dmp_atb_rows_jobs_h) also H = 64, the reference's shipped hidden_dim
+/* Fused MFMA kernels of the edge chain (fp32 MFMA, exact fp32).  H = 128; the one-panel kernels (dmp_out_fwd_fused_rows,
+ * dmp_bwd_h1_fused_rows without coefE), the class-typed kernels (dmp_edge_fwd_typed, dmp_bwd_z_typed_arow, dmp_atb_typed) and the
+ * row weight-gradient kernels (dmp_atb_rows_masked, dmp_atb_rows_jobs_h) also H = 64, the reference's shipped hidden_dim
  * (config.py:298-301): DMP_ERR_UNSUPPORTED for any other width. */
 /* ------------------------------------------------------------------------- */
 
@@ -992,7 +993,7 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 /*
  * Backward of the second Linear, the (Leaky)ReLU and dmp_edge_combine in one pass:
  *     dPre[e] = H1[e] > 0 ? dO[e] W2 : slope * (dO[e] W2) ;   dG[e] = [dPre[e] | coefE[e] * dPre[e]]
- *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows(E) rows of H floats
+ *     partial = column sums of dPre per (workgroup, wave group): dmp_mfma_partial_rows_h(E) rows of H floats
  *   dO [E, ldo>=H] (already gated), W2 [H, ldw>=H] in nn.Linear layout, H1 [E, ldh>=H], dG [E, ldg>=2H].
  *   coefE NULL: only dPre is written (dG [E, ldg>=H]: may be a column slice of a wider matrix), and then
  *   `gate` [E] (or NULL) may carry a row gate: dO is the UNgated output gradient and
@@ -1003,7 +1004,7 @@ int dmp_edge_fwd_fused(const float *Z, int64_t ldz, const float *W, int64_t ldw,
 int64_t dmp_mfma_partial_rows_h(int64_t num_edges, int H);   /* H = 128 or 64 */
 
 /* Row masks for gated E-row kernels: bit r of mask[t] = (gate[32 t + r] != 0), mask [(E + 31) / 32] words.  The `_masked` forms of
- * dmp_out_fwd_fused / dmp_bwd_h1_fused take it beside the gate and do not FETCH the operand rows of a masked row (H1 in the
+ * dmp_out_fwd_fused_rows / dmp_bwd_h1_fused_rows take it beside the gate and do not FETCH the operand rows of a masked row (H1 in the
  * forward kernel; dO and H1 in the backward kernel): those rows' products are multiplied by their zero gate
  * (out = R + 0 (h1 W2^T + b2) = R, dPre = act'(.) (0 dO W2) = 0), so the results are the unmasked kernels' -- with 60 % of the rows gated
  * out (a ScalarFilter target batch, basemodel.py:1515-1531) a fifth / two fifths of the kernels' bytes are not moved. */
@@ -1013,7 +1014,7 @@ int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream
 int dmp_row_mask_rows(const float *X, int64_t ldx, int K, int64_t R, uint32_t *mask, void *stream);
 /* ... that also hands out the column sums of the rows of dO it FETCHED: partial_rows [dmp_mfma_partial_rows_h(E, H), H] (or NULL), summed by
  * dmp_reduce_partials.  With the row mask of a 0 / 1 gate that is sum_e gate_e dO[e] -- the bias gradient of the Linear behind the gate
- * (dmpnn.py:45-60: db2), for which dmp_atb_rows otherwise carries column sums: the weight gradient can then run ungated
+ * (dmpnn.py:45-60: db2), for which dmp_atb_rows_masked otherwise carries column sums: the weight gradient can then run ungated
  * (dmp_atb_rows_plain).  Without a mask: the column sums of all of dO. */
 
 /* ... where the caller knows more about the masked-out rows (the rep-net of a ScalarFilter batch: the union's edge rows are
@@ -1085,10 +1086,10 @@ int dmp_bwd_z_fused(const float *dPre, int64_t ldp, const float *W, int64_t ldw,
  *   num_tiles  device int32 scalar     : tiles in use (<= tiles_bound, the host-side bound)
  * Rows are gathered / scattered by edge id; outputs equal the untyped kernels' up to fp32 rounding
  * of W_g.  DMP_ERR_UNSUPPORTED additionally when E*ld*4 does not fit 32 bits.
- * dmp_bwd_z_typed, w_transposed != 0: W holds [A'^T | B'^T] (each half transposed) instead of [A' | B'] --
+ * dmp_bwd_z_typed_arow, w_transposed != 0: W holds [A'^T | B'^T] (each half transposed) instead of [A' | B'] --
  * the per-class panel of dZ = dPre W_g^T is then read with coalesced loads (a strided panel read costs
  * every workgroup several microseconds per class segment).
- * dmp_bwd_z_typed, base_map != NULL: `base` is a [base_rows, ldb] table and edge e adds row base_map[e] of it (< 0: nothing)
+ * dmp_bwd_z_typed_arow, base_map != NULL: `base` is a [base_rows, ldb] table and edge e adds row base_map[e] of it (< 0: nothing)
  * instead of row e of an [E, ldb] array -- the residual path of a layer whose output gradient is a per-graph vector
  * (see dmp_relu_bwd_gathered_colsum).
  */
@@ -1113,7 +1114,7 @@ int dmp_bwd_z_typed_arow(const float *dPre, int64_t ldp, const float *W, int64_t
  * Z[e]^T dPre[e]  ([H,H]),  dA' = sum_c G_c  and  dB' = sum_c c_c G_c  (the two halves of dW for
  * W = [A' | B']) from ONE pass and one product's worth of MFMAs.  Every workgroup walks a contiguous
  * range of the class-sorted tiles and writes two [H,H] partials (running total, coefficient-weighted
- * total); partial_T / partial_B: [dmp_atb_typed_blocks(tiles_bound), H*H] floats each -- or, when
+ * total); partial_T / partial_B: [dmp_atb_typed_blocks_h(tiles_bound), H*H] floats each -- or, when
  * partial_B == partial_T + H, one [blocks, H, 2H] buffer with [T | B] side by side (its reduction is
  * dW = [dA' | dB'] in the layout of W) --, to be summed with dmp_reduce_partials (fixed order:
  * bit-stable for a given tile list).  partial_B NULL: the plain total sum_e Z[e]^T dPre[e] alone (a Linear's weight
@@ -1134,12 +1135,12 @@ int dmp_atb_typed(const float *Z, int64_t ldz, const float *dPre, int64_t ldp,
  *     partial_colsum[b] = column sums of gate (.) A over the same rows ([M]; may be NULL)
  *   A [rows, lda>=M], B [rows, ldb>=N], gate [rows] or NULL (1); M and N multiples of 128 (every 128 x 128
  *   output block is one workgroup column of the launch);
- *   partial: [dmp_atb_rows_blocks(rows, M, N), M*N], partial_colsum: [dmp_atb_rows_blocks(rows, M, N), M];
+ *   partial: [dmp_atb_rows_blocks_h(rows, M, N), M*N], partial_colsum: [dmp_atb_rows_blocks_h(rows, M, N), M];
  *   finish both with dmp_reduce_partials.
  */
 /* The same with H x H output blocks, H = 128 (the two functions above) or 64: M and N multiples of H. */
 int64_t dmp_atb_rows_blocks_h(int64_t rows, int M, int N, int H);
-/* dmp_atb_rows_h with a row mask (dmp_row_mask_bits of the gate: the rows under a zero gate, which contribute gate * a = 0 to
+/* dmp_atb_rows_masked with a row mask (dmp_row_mask_bits of the gate: the rows under a zero gate, which contribute gate * a = 0 to
  * every sum, are not fetched) and the choice of the matrix pipe: x6 != 0 = bf16x6 (fp32-accurate, dmp_dev_set_exact_fp32
  * overrides), 0 = the f32-input MFMA. */
 int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb, const float *gate, const uint32_t *rowmask,
@@ -1147,7 +1148,7 @@ int dmp_atb_rows_masked(const float *A, int64_t lda, const float *B, int64_t ldb
 /* The rows product without a gate and without column sums, over the rows of a row mask (NULL: all): A^T B restricted to the masked-in
  * rows -- which IS (gate (.) A)^T B for a 0 / 1 gate whose mask it is.  On the bf16 pipe (bf16x6; the gated form above does not fit the
  * register file there); the bias gradient (column sums of the gated A) comes from dmp_smallk_atb_cols_masked with the gate as its
- * one-column X.  partial as dmp_atb_rows_h (same number of blocks). */
+ * one-column X.  partial as dmp_atb_rows_masked (same number of blocks). */
 int dmp_atb_rows_plain(const float *A, int64_t lda, const float *B, int64_t ldb, const uint32_t *rowmask, int64_t rows, int M, int N,
                        int H, float *partial, void *stream);
 
@@ -1180,7 +1181,7 @@ int dmp_rel_atb(const float *X, int64_t ldx, int64_t rows_x, const float *D, int
 /* Several such products over the SAME rows in one launch (the node update's three weight gradients): every job is
  * one 128 x 128 output block  partial[b] = (gate (.) A[:, 0:128])^T B[:, 0:128]  (callers pass column-offset
  * pointers for the blocks of a wider product), written at partial + b * partial_stride with row stride ldp;
- * partial_colsum + b * cs_ld (or NULL) gets the column sums of gate (.) A.  b < dmp_atb_jobs_blocks(rows, num_jobs):
+ * partial_colsum + b * cs_ld (or NULL) gets the column sums of gate (.) A.  b < dmp_atb_jobs_blocks_h(rows, num_jobs):
  * the launch's workgroups are shared by all jobs.  `jobs` is a HOST array of num_jobs <= DMP_ATB_MAX_JOBS entries. */
 #define DMP_ATB_MAX_JOBS 8
 typedef struct {
@@ -1199,7 +1200,7 @@ int64_t dmp_atb_tile_jobs_blocks(int64_t tiles_bound, int num_jobs, int H);
 int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int H, const int32_t *slot_row,
                         const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, void *stream);
 /* (a launch none of whose jobs has a gate or column sums runs on the bf16 pipe, bf16x6: the 0 / 1-gated products of a step come as
- * row masks, their column sums from dmp_bwd_h1_fused_colsum) */
+ * row masks, their column sums from dmp_bwd_h1_fused_rows (partial_rows)) */
 
 /* Development switch (not part of the product path): 0 = independent 256-thread workgroups (default),
  * 1 = the experimental "ping-pong" driver of csrc/dmp_mfma.hip (two wave groups per 512-thread workgroup
@@ -1207,7 +1208,7 @@ int dmp_atb_rows_jobs_h(const dmp_atb_job *jobs, int num_jobs, int64_t rows, int
 void dmp_dev_set_mfma_variant(int variant);
 
 
-/* Arithmetic of the class-typed kernels' products (dmp_edge_fwd_typed, dmp_bwd_z_typed, dmp_rel_gemm).  Default (0):
+/* Arithmetic of the class-typed kernels' products (dmp_edge_fwd_typed, dmp_bwd_z_typed_arow, dmp_rel_gemm).  Default (0):
  * fp32 operands split into three bf16 pieces each, six piece products per 16-deep k-group on the bf16 matrix pipe,
  * fp32 accumulation ("bf16x6": every partial product carried to 2^-24 of its magnitude, i.e. fp32-accurate; gfx950's
  * f32-input MFMA has 1/16 of the bf16 MFMA rate).  1: the f32-input MFMA (bitwise an fmaf chain), kept for comparison

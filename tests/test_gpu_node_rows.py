@@ -96,6 +96,11 @@ def test_scatter_adds_leave_out_the_dead_nodes_rows(H, gpu):
     ops.seg_sum_raw(Mp, kc[0], kc[1], N, None, True, -1.0, 1.0, out=out, rows=rows)
     keep = v_gate != 0
     assert th.equal(out[keep], ref[keep]) and bool((out[~keep] == 7.5).all())
+    # ... and through the kept edges' CSR with a row per kept node (row pointers by list position: what the layer runs)
+    kpi, kei = fused.NodeRows(vmask, rows, None, None).kept_incidence(ix, e_gate, in_only=True)
+    out2 = th.full((N, 2 * H), 7.5, device=gpu)
+    ops.seg_sum_raw(Mp, kpi, kei, N, None, True, -1.0, 1.0, out=out2, rows=rows, ptr_by_pos=True)
+    assert th.equal(out2[keep], ref[keep]) and bool((out2[~keep] == 7.5).all())
     # backward: both endpoints' sums, dead nodes neither summed nor stored
     emask = fused.gate_row_mask(e_gate)
     refb = ops.endpoint_sums(M, ix, mask=emask, gate=e_gate)
