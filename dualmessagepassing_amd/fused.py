@@ -1326,13 +1326,10 @@ class _FusedDMPLayer(torch.autograd.Function):
             S = None
         else:
             # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
-            kc = keep_in_csr(index, e_gate) if (zero_rows_gate(e_gate) and not (nd is not None and USE_KEPT_INCIDENCE)) else None
-            if nd is not None and USE_KEPT_INCIDENCE and zero_rows_gate(e_gate) and USE_KEEP_CSR:
-                # ... over the kept NODES' rows only (the others' aggregates are dead), through the kept edges' CSR with a row
-                # per kept node: the row group finds its entries by its position -- one dependent load less than via the node id
-                kp, ke = nd.kept_incidence(index, e_gate, in_only=True)
-                S = ops.seg_sum_raw(z, kp, ke, N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows, ptr_by_pos=True)
-            elif kc is not None and nd is not None:
+            kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
+            if kc is not None and nd is not None:   # ... and over the kept NODES' rows only: the others' aggregates are dead
+                # (measured: row pointers by list position -- ``NodeRows.kept_incidence(in_only=True)``, one dependent load less
+                # per row group -- leave the launch at 28.6 us, and that index takes 26 us to build against 14 for this one)
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows)
             elif kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0)
