@@ -76,7 +76,14 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
   // REMAP (XCD-local rows): needed when rows are shared between destinations (incidence
   // CSR) and also faster when M was just written by the previous kernel (59 vs 70 us);
   // plain dispatch order only wins (~3 us) on a cold read-once stream (scripts/kbench.py).
-  int row = (REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * RPB + threadIdx.x / G;
+  // (under a row list the launch is sized for all N rows but only the first *rowcount list positions have work: the remap runs
+  // over THOSE workgroups -- over the whole grid the list's positions would all land on the first XCDs, 3.2 of 8 at 40 % kept rows)
+  int nwg = gridDim.x;
+  if (rowlist) {
+    nwg = (*rowcount + RPB - 1) / RPB;
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  int row = (REMAP ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x) * RPB + threadIdx.x / G;
   const int lane = threadIdx.x % G;
   if (row >= N) return;
   int prow = row;       // the row of the CSR

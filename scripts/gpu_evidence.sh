@@ -66,7 +66,7 @@ python3 - <<PY
 import json
 for n in ("bench_line", "config4_bench_line", "gloo_2rank_single_device_line", "gloo_2rank_config4_line", "bench_eager_line", "h64_bench_line"):
     try:
-        d = json.loads([l for l in open("$O/%s.json" % n) if l.startswith("{")][-1]); print(n, d["value"], d["ms_per_step"], d.get("n_gpus"), d.get("launch_mode"), d.get("roofline") and d["roofline"]["frac_survey_bytes"], d.get("roofline_bwd") and d["roofline_bwd"]["frac_survey_bytes"], d.get("all_outputs_ms_per_step"))
+        d = json.loads([l for l in open("$O/%s.json" % n) if l.startswith("{")][-1]); print(n, d["value"], d["ms_per_step"], d.get("n_gpus"), d.get("launch_mode"), d.get("roofline") and d["roofline"]["frac"], d.get("roofline_bwd") and d["roofline_bwd"]["frac"], d.get("all_outputs_ms_per_step"))
     except Exception as e: print(n, "failed", e)
 PY
 cat $O/unc.txt
