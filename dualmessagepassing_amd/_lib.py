@@ -102,6 +102,9 @@ SIGNATURES = {
     "dmp_l0_edge_fwd_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
                                        c_f32, c_ptr, c_i64, c_ptr]),
     "dmp_l0_bwd_w_blocks": (c_i64, [c_i64]),
+    "dmp_l0_node_pack_rows": (c_i64, []),
+    "dmp_l0_node_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_f32, c_ptr,
+                                c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_bn_partial_rows": (c_i64, [c_i64, c_int]),
     "dmp_bn_train_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_int, c_f32, c_ptr, c_ptr, c_ptr,
                                  c_i64, c_ptr]),
@@ -186,7 +189,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 70
+ABI_VERSION = 71
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

@@ -910,12 +910,20 @@ class GraphAdjModelV2(BaseModel):
         if vl_gate is not None:  # bool gate * float features == float gate * float features
             vl_gate, el_gate = vl_gate.float(), el_gate.float()
 
+        pooled = all(h is None or h.poolable() for h in self.pred_net.values())
+        if hasattr(self, "get_joint_rep") and not self.gate_capacity and vl_gate is not None and el_gate is not None:
+            # the index arrays the joint pass derives from the structure and the gates alone: on the side stream from here on,
+            # beside the encoding / embedding kernels below and the first layer's node side (side.py)
+            from .dmpnn import prefetch_joint_indexes
+            kinds = ()
+            if pooled and not self.pred_with_enc and not self.pred_with_deg:
+                kinds = tuple(k for k, on in (("node", self.node_pred), ("edge", self.edge_pred)) if on)
+            prefetch_joint_indexes(self, pattern, graph, vl_gate, el_gate, kinds, skip_rev)
         p_enc = self.get_pattern_enc(pattern)
         p_v_emb, p_e_emb = self.get_pattern_emb(p_enc)
         g_enc = self.get_graph_enc(graph)
         g_v_emb, g_e_emb = self.get_graph_emb_deferred(g_enc) if hasattr(self, "get_joint_rep") else self.get_graph_emb(g_enc)
         joint = None
-        pooled = all(h is None or h.poolable() for h in self.pred_net.values())
         comp = self._compact_gated(pattern, graph, el_gate)
         rep_graph = graph                                           # the graph the rep-net runs on
         if hasattr(self, "get_joint_rep"):
@@ -946,6 +954,8 @@ class GraphAdjModelV2(BaseModel):
             if joint is None:
                 comp = None
                 joint = run_joint(graph, g_e_emb, el_gate)
+            from . import side
+            side.join()          # (whatever path the pass took: nothing of the side stream outlives it)
         v_union = e_union = None
         union_sums = (None, None)
         if joint is not None:

@@ -385,6 +385,135 @@ __global__ __launch_bounds__(kKeptWords) void kept_fill_k(const uint32_t *__rest
   }
 }
 
+// The first layer's NODE side from the label codes, one pass:  with node rows x = venc WV0 and edge rows z0 = enc W0 (so a
+// node's aggregates are S_h = S0_h W0, S0_h = the sums of its in / out edges' codes) everything the layer computes per node
+// before its second Linear is linear in ~36 code columns per row:
+//     H1n[r] = act( venc[r] (WV0 Wx_0) + S0_in[r] (W0 Bn_in) + S0_out[r] (W0 Bn_out) + bn )        blockIdx.y == 0
+//     P[r]   = venc[r] (WV0 [Wx_1 | Wx_2])                                                         blockIdx.y == 1, 2
+// (dmpnn.py:113,121,125,129-140) -- instead of four N-row library products, an N x 3H product from the codes and a row pass
+// (111 us of launches at N = 73 k).  A wave owns a row at a time; the row's codes are wave-uniform (one load per lane, read
+// back by v_readlane as SGPR operands), the matrices' rows live in registers.  ``rowmask`` (the kept nodes of a 0 / 1 node
+// gate): a dead row's H1n is left unwritten (every consumer walks the kept nodes' tiles); its P rows are written as ZEROS
+// (its code row is zero) -- the first layer's edge kernel gathers P through the plain selectors.
+constexpr int kNodeKT = 40;             // code columns per row the registers hold: VK + 2 K0 (the packed matrix has kNodeKT rows)
+constexpr int kNodeRows = 16;           // rows in flight per wave
+struct NodeFwdArgs {
+  const float *venc; int64_t ldv; int VK;
+  const float *S0; int64_t lds; int K0, Kp;
+  const float *W; int64_t ldw;            // [kNodeKT, 3H] packed: rows 0 .. VK-1 = WV0 Wx (all three blocks), then K0 rows W0 Bn_in and K0 rows
+                                          // W0 Bn_out in the FIRST block only; every other entry zero
+  const float *bias; float slope;
+  const uint32_t *rowmask;                // bit r of word t: node 32 t + r is kept (absolute node ids); NULL: all
+  const int32_t *list, *count;            // the kept nodes' ids, ascending (dmp_kept_rows over ALL nodes), *count of them; NULL: rows n0 .. n1-1
+  int64_t n0, n1;                         // the node rows of this table
+  float *h1; int64_t ldh; float *P; int64_t ldp;
+  int64_t q_begin;                        // list form: the first list position that can hold a row of this table (host lower bound)
+};
+
+// blockIdx.y: 0 = H1n, 1 / 2 = the projection blocks, 3 = zero rows of P for the dead nodes (with a mask).  Under a list the
+// launch walks the list's positions from q_begin on, sixteen per wave, and acts on the rows of its table (n0 <= r < n1): every
+// batch is sixteen LIVE rows.  A wave's life is five dependent round trips (count, list, codes + matrix, stores) whatever it
+// does, so the launch lasts (waves / resident waves) lifetimes: measured stage by stage at bench.py's shape, a launch that
+// walked every list position with eight rows per wave spent 12 of its 43 us in waves that found no row of their table and ran
+// 2-5 rounds of waves; the fixed kNodeKT-row matrix (zero rows past the columns in use) keeps the instruction stream free of
+// branches (a run-time column count: ~2,000 scalar instructions of address selection per wave).
+template <int VW>
+__global__ __launch_bounds__(kBlock) void l0_node_fwd_k(const NodeFwdArgs p) {
+  constexpr int WPB = kBlock / 64, kRows = kNodeRows, H = 64 * VW;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int blk = blockIdx.y;
+  if (blk == 3) {                                                 // a dead node's projections: zeros (its code row is zero)
+    if (!p.rowmask) return;
+    const Vec<VW> zero = vzero<VW>();
+    // a wave per mask word: one load, then stores only (no wait between them)
+    const int64_t w0 = p.n0 >> 5, w1 = (p.n1 + 31) >> 5;
+    for (int64_t wi = w0 + (int64_t)blockIdx.x * WPB + wave; wi < w1; wi += (int64_t)gridDim.x * WPB) {
+      uint32_t deadbits = ~p.rowmask[wi];
+      deadbits = __builtin_amdgcn_readfirstlane(deadbits);
+      while (deadbits) {
+        const int b = __builtin_ctz(deadbits);
+        deadbits &= deadbits - 1;
+        const int64_t r = wi * 32 + b;
+        if (r < p.n0 || r >= p.n1) continue;
+        vstore<VW>(p.P + r * p.ldp, lane, zero);
+        vstore<VW>(p.P + r * p.ldp + H, lane, zero);
+      }
+    }
+    return;
+  }
+  // positions of the list (a row below n1 cannot sit at position n1 or later) / rows of the range
+  const int64_t limit = p.list ? ((int64_t)*p.count < p.n1 ? (int64_t)*p.count : p.n1) : p.n1 - p.n0;
+  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  int64_t q0 = p.q_begin + ((int64_t)blockIdx.x * WPB + wave) * kRows;
+  if (q0 >= limit) return;
+  Vec<VW> w[kNodeKT];
+#pragma unroll
+  for (int k = 0; k < kNodeKT; ++k) w[k] = vload<VW>(p.W + k * p.ldw + (int64_t)blk * H, lane);
+  Vec<VW> bias = vzero<VW>();
+  if (blk == 0 && p.bias) bias = vload<VW>(p.bias, lane);
+  // this lane's code column: lanes 0 .. VK-1 the node's own code, the next K0 its in-sums, the next K0 its out-sums
+  const float *base = p.venc + lane;
+  int64_t step = p.ldv;
+  if (lane >= p.VK) { base = p.S0 + (lane - p.VK < p.K0 ? lane - p.VK : p.Kp + lane - p.VK - p.K0); step = p.lds; }
+  const bool on = lane < p.VK + 2 * p.K0;
+  float *const outb = blk == 0 ? p.h1 : p.P + (int64_t)(blk - 1) * H;
+  const int64_t ldo = blk == 0 ? p.ldh : p.ldp;
+  for (; q0 < limit; q0 += stride) {
+    // (every load below is issued unconditionally at a clamped index and its result selected afterwards: a wave-uniform
+    // condition around a load is a scalar branch -- a basic block and a wait per row)
+    int rid[kRows], raw[kRows];
+    uint32_t word[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int64_t qc = q0 + u < limit ? q0 + u : limit - 1;     // (limit >= 1 here)
+      raw[u] = p.list ? p.list[qc] : (int)(p.n0 + qc);
+    }
+    if (!p.list && p.rowmask) {
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) word[u] = p.rowmask[raw[u] >> 5];
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      int r = raw[u];
+      const bool dead = !p.list && p.rowmask && !((word[u] >> (r & 31)) & 1u);
+      if (q0 + u >= limit || r < p.n0 || r >= p.n1 || dead) r = -1;      // (a list over all nodes: the other table's rows)
+      rid[u] = __builtin_amdgcn_readfirstlane(r);
+    }
+    float mine[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const float m = on ? base[(int64_t)(rid[u] >= 0 ? rid[u] : (int)p.n0) * step] : 0.f;
+      mine[u] = rid[u] >= 0 ? m : 0.f;
+    }
+    // all eight code loads land HERE, before the first store: gfx9 counts loads and stores in one in-order counter, so a wait
+    // for a later row's codes placed after an earlier row's store also waits for that store's acknowledgement
+    static_assert(kRows == 16, "the pins below list sixteen values");
+    asm volatile("" : "+v"(mine[0]), "+v"(mine[1]), "+v"(mine[2]), "+v"(mine[3]), "+v"(mine[4]), "+v"(mine[5]), "+v"(mine[6]), "+v"(mine[7]));
+    asm volatile("" : "+v"(mine[8]), "+v"(mine[9]), "+v"(mine[10]), "+v"(mine[11]), "+v"(mine[12]), "+v"(mine[13]), "+v"(mine[14]), "+v"(mine[15]));
+    // four rows' sums side by side: a row's kNodeKT multiply-adds are one dependent chain (and every scalar operand a
+    // v_readlane the next instruction waits for) -- 6.4 us for 8 rows one after the other
+#pragma unroll
+    for (int u0 = 0; u0 < kRows; u0 += 4) {
+      if (rid[u0] < 0 && rid[u0 + 1] < 0 && rid[u0 + 2] < 0 && rid[u0 + 3] < 0) continue;
+      Vec<VW> e[4] = {bias, bias, bias, bias};
+#pragma unroll
+      for (int k = 0; k < kNodeKT; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fmac_s(e[j], lane_f(mine[u0 + j], k), w[k]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (rid[u0 + j] < 0) continue;
+        if (blk == 0) {
+#pragma unroll
+          for (int c = 0; c < VW; ++c) at<VW>(e[j], c) = act_fwd(at<VW>(e[j], c), p.slope);
+        }
+        vstore<VW>(outb + (int64_t)rid[u0 + j] * ldo, lane, e[j]);
+      }
+    }
+  }
+}
+
 #define L0_SWITCH(K, CALL)                                                                          \
   switch (K) {                                                                                      \
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
@@ -474,6 +603,29 @@ int dmp_l0_bwd_w_rows(const float *enc, int64_t lde, int K, const float *coef_e,
 #define L0_CALL(KK) launch_bwd<KK>(p, H, st)
   L0_SWITCH(K, L0_CALL)
 #undef L0_CALL
+  return check_launch();
+}
+
+int64_t dmp_l0_node_pack_rows(void) { return kNodeKT; }
+
+int dmp_l0_node_fwd(const float *venc, int64_t ldv, int VK, const float *S0, int64_t lds, int K0, int Kp, const float *W, int64_t ldw,
+                    const float *bias, float slope, const uint32_t *rowmask, const int32_t *list, const int32_t *count, int64_t list_bound,
+                    int64_t q_begin, int64_t n0, int64_t n1, int H, float *h1, int64_t ldh, float *P, int64_t ldp, void *stream) {
+  if (n0 < 0 || n1 < n0 || VK <= 0 || K0 <= 0 || Kp < K0 || (list && (!count || !rowmask || list_bound < 0 || q_begin < 0 || q_begin > n0)))
+    return DMP_ERR_BAD_ARG;
+  if (n1 >= ((int64_t)1 << 31)) return DMP_ERR_UNSUPPORTED;
+  if ((H != 128 && H != 64) || VK + 2 * K0 > kNodeKT || !slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  if (n1 == n0) return DMP_OK;
+  if (!venc || !S0 || !W || !h1 || !P || ldv < VK || lds < 2 * Kp || ldw < 3 * H || ldh < H || ldp < 2 * H) return DMP_ERR_BAD_ARG;
+  if (ldw % 2 || ldh % 2 || ldp % 2 || !al8(W) || !al8(h1) || !al8(P) || !al8(bias)) return DMP_ERR_UNSUPPORTED;
+  NodeFwdArgs p{venc, ldv, VK, S0, lds, K0, Kp, W, ldw, bias, slope, rowmask, list, count, n0, n1, h1, ldh, P, ldp, list ? q_begin : 0};
+  // (list form: the positions q_begin .. that can hold rows below n1: at most n1 - q_begin of them, and no more than the list has)
+  const int64_t chunk = (int64_t)(kBlock / 64) * kNodeRows;
+  const int64_t walk = list ? ((list_bound < n1 ? list_bound : n1) - q_begin > 0 ? (list_bound < n1 ? list_bound : n1) - q_begin : 0) : n1 - n0;
+  const int64_t nb = (walk + chunk - 1) / chunk;
+  const dim3 grid((unsigned)(nb < 4096 ? (nb > 0 ? nb : 1) : 4096), rowmask ? 4u : 3u);
+  if (H == 128) l0_node_fwd_k<2><<<grid, kBlock, 0, (hipStream_t)stream>>>(p);
+  else l0_node_fwd_k<1><<<grid, kBlock, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 

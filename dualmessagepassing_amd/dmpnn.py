@@ -324,6 +324,107 @@ def prepare_joint(pattern, graph, hidden_dim=128, backward=True, class_tiles=Tru
     return union
 
 
+def _joint_gates(v_gate, e_gate, np_, ep_, dtype, device):
+    """``(vg, eg)``: the union's gates -- ones for the pattern rows, the target's gates for its rows -- with the marks the
+    kernels read (0 / 1, wiped input rows).  Memoised on the target's gate tensors (``prefetch_joint_indexes`` makes them
+    ahead of the pass, on the side stream)."""
+    owner = e_gate if e_gate is not None else v_gate
+    if owner is None:
+        return None, None
+    key = (None if v_gate is None else (v_gate.data_ptr(), v_gate._version), None if e_gate is None else (e_gate.data_ptr(), e_gate._version),
+           np_, ep_, dtype)
+    hit = getattr(owner, "_dmp_joint_gates", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    vg = eg = None
+    if v_gate is not None and e_gate is not None:            # ones for the pattern rows, the gates for the target rows
+        from .collate import concat_pairs
+        vg, eg = concat_pairs([((np_, 1.0), v_gate.reshape(-1).to(dtype), 0), ((ep_, 1.0), e_gate.reshape(-1).to(dtype), 0)])
+    elif v_gate is not None:
+        vg = th.cat([th.ones(np_, dtype=dtype, device=device), v_gate.reshape(-1)])
+    elif e_gate is not None:
+        eg = th.cat([th.ones(ep_, dtype=dtype, device=device), e_gate.reshape(-1)])
+    for made, src in ((vg, v_gate), (eg, e_gate)):           # ones for the pattern rows + a 0 / 1 gate: still 0 / 1
+        if made is not None and getattr(src, "_dmp_binary", False):
+            made._dmp_binary = True
+    if eg is not None:
+        eg._dmp_zero_rows = True         # e's target rows are multiplied by this gate (_gate_concat / the packed codes)
+    if vg is not None:
+        vg._dmp_zero_rows = True         # ... and v's target rows by this one: a gated-out node is a zero row in every layer
+        vg._dmp_ones_prefix = np_        # (its first np_ entries are ones by construction: the pattern's nodes are all kept)
+    if eg is not None and getattr(e_gate, "_dmp_dense_gate", False):
+        eg._dmp_dense_gate = True        # the kept edges of a compacted batch (collate.compact_gated_edges): ones but for the padding
+    try:
+        owner._dmp_joint_gates = (key, vg, eg)
+    except Exception:
+        pass
+    return vg, eg
+
+
+def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(), skip_rev=True):
+    """Everything ``joint_rep`` and its layers derive from the batch's STRUCTURE and its two filter gates alone, issued on the
+    side stream (``side.fork``) as soon as the gates exist: the union graph and its CSR index, the degree coefficients, the
+    edge selectors; the union's gates, their row masks, the kept nodes' list / tiles / selectors, the kept edge rows of
+    the first layer; the kept edges' class tiles, their CSR by destination, the pooling indexes, the kept incidence CSR of
+    the backward.  None of it reads a parameter or a feature row, so it runs beside the embedding kernels and the first
+    layer's node side; every product lands in the memo its consumer looks it up in, and the consumer ``side.wait``s for its
+    stage first.  Nothing here decides anything: a product that turns out unused costs a few microseconds of the side
+    stream; one that is missing is built by its consumer on the main stream as before."""
+    from . import fused, side
+    if not side.USE_SIDE_STREAM or not getattr(model, "use_fused", True) or not hasattr(model, "g_rep_net"):
+        return
+    if model.p_rep_net is not model.g_rep_net or v_gate is None or e_gate is None or not e_gate.is_cuda:
+        return
+    layers = list(model.g_rep_net[model.rep_key])
+    if not layers or not all(hasattr(l, "fused_ok") for l in layers):
+        return
+    pattern, graph = as_batched(pattern), as_batched(graph)
+    if (REVFLAG in pattern.edata) != (REVFLAG in graph.edata):
+        return
+    H = layers[0].hidden_dim
+    np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
+    side.join()              # (a step that never joined -- an exception on the way: nothing of it may stay dangling)
+    with side.fork() as forked:
+        if not forked:
+            return
+        union = _union_of(pattern, graph)
+        ix = union.index()
+        if OUTDEGREE not in union.ndata:
+            union.ndata[OUTDEGREE] = union.out_degrees()
+        coef = ix.degree_coef(union.ndata[OUTDEGREE])
+        if fused.mfma_ok(ix, H):
+            ix.edge_select(coef)
+        side.mark("index")
+        vg, eg = _joint_gates(v_gate, e_gate, np_, ep_, th.float32, e_gate.device)
+        N, E = ix.num_nodes, ix.num_edges
+        nd = None
+        if N >= 4096 and fused.onepanel_ok(H):
+            nd = fused.node_rows(ix, vg, H)
+        side.mark("nodes")
+        typed = fused.typed_ok(ix, H)
+        if typed and fused.SKIP_DEAD_ROWS and fused.USE_ROW_MASKS:
+            mask = fused.gate_row_mask(eg)
+            if (mask is not None and fused.USE_L0_ROW_LISTS and len(layers) > 1 and ep_ % 32 == 0 and E - ep_ >= fused.L0_LIST_MIN_ROWS
+                    and th.is_grad_enabled()):
+                fused.kept_rows(mask, ep_, E)          # the first layer's target rows (fused.l0_edge_fwd / l0_bwd_w)
+        side.mark("erows")
+        if typed and fused.zero_rows_gate(eg):
+            fused.live_tiles(ix, coef, eg)
+            side.mark("tiles")
+            fused.keep_in_csr(ix, eg)
+            side.mark("keepcsr")
+        if pool_kinds:
+            from .basemodel import _pool_indexes_union
+            built = dict(zip(pool_kinds, _pool_indexes_union(pattern, graph, pool_kinds, skip_rev)))
+            if built.get("edge") is not None and typed and fused.zero_rows_gate(eg) and th.is_grad_enabled():
+                fused.keep_pool_csr(built["edge"], eg)     # the pooled passes of the last layer over the kept edges
+        side.mark("pools")
+        if (nd is not None and typed and fused.USE_MASKED_SUMS and fused.USE_KEPT_INCIDENCE and fused.zero_rows_gate(eg) and H % 4 == 0
+                and fused.gate_row_mask(eg) is not None and th.is_grad_enabled()):
+            nd.kept_incidence(ix, eg)
+        side.mark("incidence")
+
+
 def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=None, e_gate=None, pools=None):
     """``get_pattern_rep`` + ``get_graph_rep`` (dmpnn.py:215-277) in ONE pass over the union of
     the two batched graphs, when the rep-net is shared (``share_rep_net``, dmpnn.py:186-188) and
@@ -355,30 +456,19 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         e = _gate_concat(p_e_emb, g_e_emb, e_gate)
     if v is None:
         v = _gate_concat(p_v_emb, g_v_emb, v_gate)   # [pattern rows | gate * target rows] in one pass
-    vg = eg = None
-    if v_gate is not None and e_gate is not None:            # ones for the pattern rows, the gates for the target rows
-        from .collate import concat_pairs
-        vg, eg = concat_pairs([((np_, 1.0), v_gate.reshape(-1).to(v.dtype), 0), ((ep_, 1.0), e_gate.reshape(-1).to(e.dtype), 0)])
-    elif v_gate is not None:
-        vg = th.cat([th.ones(np_, dtype=v.dtype, device=v.device), v_gate.reshape(-1)])
-    elif e_gate is not None:
-        eg = th.cat([th.ones(ep_, dtype=e.dtype, device=e.device), e_gate.reshape(-1)])
-    for made, src in ((vg, v_gate), (eg, e_gate)):           # ones for the pattern rows + a 0 / 1 gate: still 0 / 1
-        if made is not None and getattr(src, "_dmp_binary", False):
-            made._dmp_binary = True
-    if eg is not None:
-        eg._dmp_zero_rows = True         # e's target rows were multiplied by this gate above (_gate_concat / the packed codes)
-    if vg is not None:
-        vg._dmp_zero_rows = True         # ... and v's target rows by this one: a gated-out node is a zero row in every layer
-    if eg is not None and getattr(e_gate, "_dmp_dense_gate", False):
-        eg._dmp_dense_gate = True        # the kept edges of a compacted batch (collate.compact_gated_edges): ones but for the padding
+    vg, eg = _joint_gates(v_gate, e_gate, np_, ep_, v.dtype, v.device)
+    from . import side
     if not all(l.fused_ok(union, v, e, vg, eg) for l in layers):     # e.g. dropout in training: the callers run the two loops
+        side.join()
         return None
     from . import fused
     folded = fused.fold_layers(layers)                       # the parameter algebra of all layers: one launch
+    side.wait("index")                                       # (prefetch_joint_indexes: the union's CSR, coefficients, selectors)
     sums = (None, None)
     lazy_e = None
     for i, (layer, fw) in enumerate(zip(layers, folded)):
+        if i == len(layers) - 1:
+            side.wait("pools")
         if pools is not None and i == len(layers) - 1:
             # the last layer also pools its outputs per graph (``pools``: PoolIndex over the union's node / edge rows): a
             # gradient that comes back only through the edge sums never becomes an [E, H] tensor (fused._FusedDMPLayer) --
@@ -397,6 +487,7 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
             # (inner: the next layer of this loop, under the same gates, is the only reader of this layer's edge rows)
             v, e = layer.forward_fused(union, v, e, vg, eg, model.rep_residual, fw, None, l0 if i == 0 else None,
                                        inner=(1 if i < len(layers) - 1 else 0) | (2 if i > 0 else 0))
+    side.join()              # (the kept incidence CSR of the backward: long done; nothing of the side stream outlives the pass)
     p_v, g_v = _SplitRows.apply(v, np_)
     if lazy_e is not None:
         return p_v, lazy_e.part(0), g_v, lazy_e.part(1), v, lazy_e.whole(), sums

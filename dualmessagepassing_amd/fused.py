@@ -155,28 +155,71 @@ def relu_bwd_gathered_colsum(table, rowmap, gate, act, slope=0.0):
     return out, reduce_partials(part)
 
 
-def pool_relu_bwd(table, rowmap, gate, act, pool, slope=0.0):
+def pool_relu_bwd(table, rowmap, gate, act, pool, slope=0.0, skip_dead=False):
     """``relu_bwd_gathered_colsum`` and ``pool_rows(act, pool, gate)`` in ONE pass over ``act`` (``dmp_pool_relu_bwd``):
-    -> (dPre [R, H], column sums of dPre [H], Q [graphs, 2H] = gated per-graph sums of ``act`` by flag)."""
+    -> (dPre [R, H], column sums of dPre [H], Q [graphs, 2H] = gated per-graph sums of ``act`` by flag).
+    ``skip_dead`` (every consumer of dPre leaves out the rows under a zero of the 0 / 1 ``gate``): the pass walks the kept
+    rows' chunk table (``keep_pool_csr``) -- dPre's rows under a zero gate are not stored, nor are their entries walked."""
     lib = _lib.load()
     R, H = act.shape
     V = pool.num_chunks
     nb = int(lib.dmp_pool_relu_bwd_blocks(V, H))
     part = torch.empty((nb, H), dtype=torch.float32, device=act.device)
-    out = torch.empty((R, H), dtype=torch.float32, device=act.device)
+    kc = keep_pool_csr(pool, gate) if skip_dead else None
+    vptr, vent = (pool.vptr, pool.vent) if kc is None else kc
+    out = dead_rows_buffer((R, H), act.device) if kc is not None else torch.empty((R, H), dtype=torch.float32, device=act.device)
     qc = torch.empty((V, 2 * H), dtype=torch.float32, device=act.device)
     with _lib.timed("pool_relu_bwd[H=%d,R=%d]", (H, R), 8 * H * R + 12 * R + 8 * H * V):
-        check(lib.dmp_pool_relu_bwd(ptr(act), act.stride(0), ptr(table), table.stride(0), ptr(rowmap), ptr(gate), ptr(pool.vptr),
-                                    ptr(pool.vent), V, R, H, slope, ptr(out), H, ptr(qc), ptr(part), stream_ptr()), "dmp_pool_relu_bwd")
+        check(lib.dmp_pool_relu_bwd(ptr(act), act.stride(0), ptr(table), table.stride(0), ptr(rowmap), ptr(gate), ptr(vptr),
+                                    ptr(vent), V, R, H, slope, ptr(out), H, ptr(qc), ptr(part), stream_ptr()), "dmp_pool_relu_bwd")
     Q = ops.seg_sum_raw(qc, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
     return out, reduce_partials(part), Q
 
 
+USE_KEEP_POOL = True
+
+
+def keep_pool_csr(pool, gate):
+    """``(ptr, ent)``: the chunk table of ``pool`` over the rows a 0 / 1 ``gate`` keeps (``dmp_csr_keep`` on the pooling index's
+    chunk CSR), memoised on the gate per index, or None.  A pooled pass with a 0 / 1 row weight is then the PLAIN segment sum
+    over 42 % of the entries (full load slots) instead of the weighted one that walks every entry: 46 -> 28 us at bench.py's
+    shape; same sums, same order (the skipped rows added zeros)."""
+    if gate is None or not USE_KEEP_POOL or not USE_ROW_MASKS or pool.num_chunks == 0 or gate.numel() == 0:
+        return None
+    owner = _gate_owner(gate)
+    if getattr(owner, "_dmp_dense_gate", False) or not getattr(owner, "_dmp_binary", False):
+        return None
+    memo = getattr(owner, "_dmp_keep_pool", None)
+    if memo is None or memo[0] != owner._version:
+        memo = (owner._version, {})
+        try:
+            owner._dmp_keep_pool = memo
+        except Exception:
+            return None
+    hit = memo[1].get(id(pool))
+    if hit is not None and hit[0] is pool:
+        return hit[1]
+    lib = _lib.load()
+    V, dev = pool.num_chunks, pool.vptr.device
+    nscr = int(lib.dmp_csr_keep_scratch_words(V))
+    ws = torch.empty(nscr + V + 1 + pool.vent.numel(), dtype=torch.int32, device=dev)
+    row_cnt, kptr, kent = ws[:nscr], ws[nscr:nscr + V + 1], ws[nscr + V + 1:]
+    check(lib.dmp_csr_keep(ptr(pool.vptr), ptr(pool.vent), ptr(gate.reshape(-1)), V, ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()),
+          "dmp_csr_keep")
+    memo[1][id(pool)] = (pool, (kptr, kent))
+    return kptr, kent
+
+
 def pool_rows(x, pool, weight=None):
     """Per-graph sums of the rows of ``x`` over ``pool`` (``ops.PoolIndex``): [G, H], or [G, 2H] = [non-flagged | flagged] when
-    the index carries a flag; ``weight`` [rows]: a row scale.  Raw (no autograd): two launches of the segment-sum kernel."""
+    the index carries a flag; ``weight`` [rows]: a row scale (a 0 / 1 gate: the pass runs over the kept rows' chunk table,
+    ``keep_pool_csr``).  Raw (no autograd): two launches of the segment-sum kernel."""
     split = pool.flag8 is not None
-    part = ops.seg_sum_raw(x, pool.vptr, pool.vent, pool.num_chunks, weight, split, 1.0, 1.0, rows_shared=False)
+    kc = keep_pool_csr(pool, weight) if (weight is not None and x.size(1) % 4 == 0 and x.is_contiguous()) else None
+    if kc is not None:
+        part = ops.seg_sum_raw(x, kc[0], kc[1], pool.num_chunks, None, split, 1.0, 1.0, rows_shared=False)
+    else:
+        part = ops.seg_sum_raw(x, pool.vptr, pool.vent, pool.num_chunks, weight, split, 1.0, 1.0, rows_shared=False)
     return ops.seg_sum_raw(part, pool.gptr, pool.gent, pool.num_graphs, None, False, rows_shared=False)
 
 
@@ -855,8 +898,9 @@ class NodeRows:
     list ``(slot, tile_scale, num_tiles, bound)`` for ``dmp_out_fwd_typed`` / ``dmp_bwd_h1_typed``, ``sel`` = the per-edge
     selectors / destinations with the other nodes replaced by -1 (``GraphIndex.edge_select_nodes``)."""
 
-    def __init__(self, mask, rows, tiles, sel):
+    def __init__(self, mask, rows, tiles, sel, prefix=0):
         self.mask, self.rows, self.tiles, self.sel = mask, rows, tiles, sel
+        self.prefix = int(prefix)     # the first ``prefix`` nodes are all kept (the pattern's nodes of a joint pass): list[q] == q there
         self._kinc = None
 
     def kept_incidence(self, index, e_gate, in_only=False):
@@ -902,12 +946,44 @@ def node_rows(index, v_gate, H):
     lst, cnt = kept_rows(mask, 0, N, tiles=True)
     bound = (N + 31) // 32
     scale = torch.zeros(bound, dtype=torch.float32, device=mask.device)
-    res = NodeRows(mask, (lst, cnt[0:1]), (lst, scale, cnt[1:2], bound), index.edge_select_nodes(mask))
+    res = NodeRows(mask, (lst, cnt[0:1]), (lst, scale, cnt[1:2], bound), index.edge_select_nodes(mask),
+                   prefix=min(int(getattr(owner, "_dmp_ones_prefix", 0)), N))
     try:
         owner._dmp_node_rows = (owner._version, index, res)
     except Exception:
         pass
     return res
+
+
+# (measured, round 5: LARGE kernels do not gain from the side stream -- the weight-gradient launches of a layer's backward beside its
+# data-gradient chain +2.6 %, the second half of a layer's node side beside its edge side +1.8 % per step: two bandwidth-bound
+# launches in flight slow each other down by more than the tails they fill.  The side stream carries the small index builds only.)
+USE_L0_NODE_FWD = True     # the first layer's node side from the label codes as one pass (csrc/dmp_layer0.hip::l0_node_fwd_k)
+L0_NODE_MAX_COLS = 40      # code columns per node row that kernel holds in registers: VK + 2 K0
+
+
+def l0_node_pack(VK, K0, H, Mv, Ma, Mb):
+    """The packed matrix ``dmp_l0_node_fwd`` reads, [L0_NODE_MAX_COLS, 3H], from its three parts (``Mv`` [VK, 3H] = WV0 Wx, ``Ma`` /
+    ``Mb`` [K0, H] = W0 Bn_in / W0 Bn_out); the layer writes the parts in place instead (one small-product launch)."""
+    W = torch.zeros((L0_NODE_MAX_COLS, 3 * H), dtype=torch.float32, device=Mv.device)
+    W[:VK] = Mv
+    W[VK:VK + K0, :H] = Ma
+    W[VK + K0:VK + 2 * K0, :H] = Mb
+    return W
+
+
+def l0_node_fwd(venc, VK, S0, K0, Kp, W, bias, slope, mask, n0, n1, H, h1, P, rows=None, q_begin=0):
+    """``h1[n0:n1] = act([venc | S0_in | S0_out] W[:, :H] + bias)`` and ``P[n0:n1] = [venc | ..] W[:, H:3H]`` from the node rows'
+    label codes and their edges' code sums (``dmp_l0_node_fwd``; ``W``: the packed matrix, ``l0_node_pack``); ``mask``: the
+    kept nodes (``NodeRows.mask``) -- a dead node's ``h1`` row is left unwritten, its ``P`` row is zeros; ``rows`` =
+    ``NodeRows.rows`` (the kept nodes' list over ALL nodes, with ``mask``): the launch walks the list instead of the masked rows,
+    from position ``q_begin`` on (<= n0: e.g. ``NodeRows.prefix``, the leading nodes known to be all kept)."""
+    lib = _lib.load()
+    lst, cnt = rows if (rows is not None and mask is not None) else (None, None)
+    with _lib.timed("l0_node_fwd[K=%d,R=%d]", (VK + 2 * K0, n1 - n0), 4 * (3 * H + VK + 2 * K0) * (n1 - n0)):
+        check(lib.dmp_l0_node_fwd(ptr(venc), venc.stride(0), VK, ptr(S0), S0.stride(0), K0, Kp, ptr(W), W.stride(0), ptr(bias), float(slope),
+                                  ptr(mask), ptr(lst), ptr(cnt), 0 if lst is None else lst.numel(), min(int(q_begin), n0), n0, n1, H,
+                                  ptr(h1), h1.stride(0), ptr(P), P.stride(0), stream_ptr()), "dmp_l0_node_fwd")
 
 
 def l0_edge_fwd(enc, K, M, P, ldp, bias, coef, index, slope=0.0, rows=None, out=None, mask=None):
@@ -1213,6 +1289,7 @@ def fold_layers(layers):
 
 _GEMM_TYPES = None
 USE_SMALL_GEMM_JOBS = True
+SMALL_GEMM_MAX_ROWS = 1024     # output rows up to which a product goes into the small-product launch (latency-oriented: a column per thread)
 
 
 def small_gemm_jobs(jobs):
@@ -1292,6 +1369,8 @@ class _FusedDMPLayer(torch.autograd.Function):
         # ---- the nodes a 0 / 1 node gate keeps (``node_rows``): a node under a zero of a gate whose maker wiped the input rows
         # is a zero row in every layer, so its aggregate, its projections, its update and all of its gradient rows are dead --
         # the node side runs on the kept nodes' tiles, the edge kernels read a dead node's (unwritten) rows as zeros
+        from . import side      # (index builds issued ahead on the side stream, dmpnn.prefetch_joint_indexes: wait for a stage at its first use)
+        side.wait("nodes")
         nd = node_rows(index, v_gate, H) if (N >= 4096 and onepanel_ok(H)) else None
         if nd is not None and l0 is not None and any(n0 % 32 for _, _, (n0, _) in l0.tables(z.size(0), N)):
             nd = None          # (the backward's row masks start at a table's first node)
@@ -1304,28 +1383,54 @@ class _FusedDMPLayer(torch.autograd.Function):
             # S = [S0_in W0 | S0_out W0] is never built:  S Bn = S0_in (W0 Bn_in) + S0_out (W0 Bn_out), two K-column products
             Kp = enc0.size(1)
             vcodes_f = l0.venc is not None
+            node_pass = (USE_L0_NODE_FWD and vcodes_f and USE_SMALL_GEMM_JOBS and H in MFMA_WIDTHS and l0.VK + 2 * K0 <= L0_NODE_MAX_COLS
+                         and W0.size(0) // K0 <= 2)
             if USE_SMALL_GEMM_JOBS:   # the parameter-only products of this layer in ONE launch: W0 Bn_in, W0 Bn_out, W0 [A | B], WV0 Wx
                 TK = W0.size(0)
-                WB = torch.empty((2, TK, H), dtype=torch.float32, device=z.device)
                 M0 = torch.empty((TK, 2 * H), dtype=torch.float32, device=z.device)
-                jobs = [(WB[0], [(W0, False, Bn[:H], False)], None), (WB[1], [(W0, False, Bn[H:], False)], None),
-                        (M0, [(W0, False, Wes, False)], None)]
-                if vcodes_f:
-                    MV = torch.empty((WV0.size(0), 3 * H), dtype=torch.float32, device=z.device)
-                    jobs.append((MV, [(WV0, False, Wx, False)], None))
+                jobs = [(M0, [(W0, False, Wes, False)], None)]
+                if node_pass:
+                    # ... written straight into the node pass's packed matrix, one per embedding table: rows 0 .. VK-1 = WV0 Wx (three
+                    # column blocks), then K0 rows W0 Bn_in and K0 rows W0 Bn_out in the first block; zeros elsewhere
+                    VK = l0.VK
+                    WP = torch.zeros((TK // K0, L0_NODE_MAX_COLS, 3 * H), dtype=torch.float32, device=z.device)
+                    for t in range(TK // K0):
+                        WVt = WV0 if WV0.size(0) == VK else WV0[t * VK:(t + 1) * VK]
+                        jobs += [(WP[t, :VK], [(WVt, False, Wx, False)], None),
+                                 (WP[t, VK:VK + K0, :H], [(W0[t * K0:(t + 1) * K0], False, Bn[:H], False)], None),
+                                 (WP[t, VK + K0:VK + 2 * K0, :H], [(W0[t * K0:(t + 1) * K0], False, Bn[H:], False)], None)]
+                else:
+                    WB = torch.empty((2, TK, H), dtype=torch.float32, device=z.device)
+                    jobs += [(WB[0], [(W0, False, Bn[:H], False)], None), (WB[1], [(W0, False, Bn[H:], False)], None)]
+                    if vcodes_f:
+                        MV = torch.empty((WV0.size(0), 3 * H), dtype=torch.float32, device=z.device)
+                        jobs.append((MV, [(WV0, False, Wx, False)], None))
                 small_gemm_jobs(jobs)
             else:
                 WB = torch.matmul(W0, Bn.view(2, H, H))                                              # [2, T K, H]
-            SB = torch.empty((N, H), dtype=torch.float32, device=z.device)
-            for t, _, (n0, n1) in tables:      # (N-row products: the small-product kernel is built for a few hundred rows)
-                if n1 > n0:
-                    torch.mm(S0[n0:n1, :K0], WB[0, t * K0:(t + 1) * K0], out=SB[n0:n1])
-                    SB[n0:n1].addmm_(S0[n0:n1, Kp:Kp + K0], WB[1, t * K0:(t + 1) * K0])
+            if node_pass:
+                # the whole node side before the second Linear in ONE pass over the codes: H1n and the two projection blocks
+                # (the kept nodes' H1n rows only; a dead node's projection rows are zeros)
+                H1n = dead_rows_buffer((N, H), z.device) if nd is not None else torch.empty((N, H), dtype=torch.float32, device=z.device)
+                PX = torch.empty((N, 2 * H), dtype=torch.float32, device=z.device)
+                for t, _, (n0, n1) in tables:
+                    if n1 > n0 and (nd is None or n1 <= nd.prefix):      # (no gate, or the pattern's nodes -- all kept: every row)
+                        l0_node_fwd(l0.venc, VK, S0, K0, Kp, WP[t], bn, slope, None, n0, n1, H, H1n, PX)
+                    elif n1 > n0:
+                        l0_node_fwd(l0.venc, VK, S0, K0, Kp, WP[t], bn, slope, nd.mask, n0, n1, H, H1n, PX, rows=nd.rows,
+                                    q_begin=min(nd.prefix, n0))
+            else:
+                SB = torch.empty((N, H), dtype=torch.float32, device=z.device)
+                for t, _, (n0, n1) in tables:      # (N-row products: the small-product kernel is built for a few hundred rows)
+                    if n1 > n0:
+                        torch.mm(S0[n0:n1, :K0], WB[0, t * K0:(t + 1) * K0], out=SB[n0:n1])
+                        SB[n0:n1].addmm_(S0[n0:n1, Kp:Kp + K0], WB[1, t * K0:(t + 1) * K0])
             if not USE_SMALL_GEMM_JOBS:
                 M0 = W0 @ Wes                                                                        # [T K, 2H] = W0 [A | B]
             S = None
         else:
             # (input rows under a zero of a gate whose maker wiped them -- ``_dmp_zero_rows`` -- are zeros: not fetched)
+            side.wait("keepcsr")
             kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
             if kc is not None and nd is not None:   # ... and over the kept NODES' rows only: the others' aggregates are dead
                 # (measured: row pointers by list position -- ``NodeRows.kept_incidence(in_only=True)``, one dependent load less
@@ -1349,6 +1454,8 @@ class _FusedDMPLayer(torch.autograd.Function):
             typed_jobs([dict(a=x, W=Wx[:, :H], bias=bn, out=XP[:, :H]), dict(a=S[:, :H], W=Bn[:H], out=T1),
                         dict(a=x, W=Wx[:, H:2 * H], out=XP[:, H:2 * H]), dict(a=x, W=Wx[:, 2 * H:], out=XP[:, 2 * H:])], T)
             out_fwd_typed(S[:, H:], Bn[H:], None, XP[:, :H], T, out=H1n, slope=slope, prev2=T1)
+        elif l0 is not None and node_pass:
+            pass
         elif l0 is not None and l0.venc is not None:     # x Wx = venc (WV0 Wx): three column blocks of K-column products
             VK = l0.VK
             if not USE_SMALL_GEMM_JOBS:
@@ -1358,8 +1465,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 smallk_embed(l0.venc[n0:n1, :VK], MV[t * VK:(t + 1) * VK], None, XP[n0:n1], H)
         else:
             XP = x @ Wx
-        if l0 is not None or nd is None:
-            H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
+        if l0 is not None and node_pass:
+            PXr, ldpx = PX, 2 * H                # the gathered projections [P_dst | P_src]
+        else:
+            PXr, ldpx = XP[:, H:], 3 * H
+            if l0 is not None or nd is None:
+                H1n = add_bias_relu_(SB, XP[:, :H], bn, slope)
         if nd is not None:
             # (an INNER layer's xn is read by the next layer of this rep-net only, under the same gate: the dead rows stay
             # unwritten; the last layer's rows go to the caller: zeros there)
@@ -1378,22 +1489,23 @@ class _FusedDMPLayer(torch.autograd.Function):
         # H1e rows under a zero edge gate are DEAD values when the layer runs on the masked kernels: out_fwd / the pooled
         # passes forward and bwd_h1 / atb_rows / pool_relu_bwd backward all multiply them by that zero and do not fetch them
         # (typed_ok: the backward takes the same branch).  The two producers then leave those rows out.
+        side.wait("erows" if l0 is not None else "tiles")      # (a layer on the label codes needs the tiles only for its second Linear)
         dead_gate = e_gate if (SKIP_DEAD_ROWS and USE_ROW_MASKS and e_gate is not None and typed_ok(index, H)
                                and gate_row_mask(e_gate) is not None) else None
         if l0 is not None:
             H1e = dead_rows_buffer((z.size(0), H), z.device) if dead_gate is not None else torch.empty((z.size(0), H), dtype=torch.float32, device=z.device)
             for t, rows, _ in tables:
                 if rows[1] > rows[0]:
-                    l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], XP[:, H:], 3 * H, be, coef, index, slope, rows, H1e,
+                    l0_edge_fwd(enc0, K0, M0[t * K0:(t + 1) * K0], PXr, ldpx, be, coef, index, slope, rows, H1e,
                                 mask=gate_row_mask(dead_gate) if dead_gate is not None else None)
         elif typed_ok(index, H):
             # (under ``nd`` the projection rows of the dead nodes were never written: their selectors read as zeros)
-            H1e = edge_fwd_typed(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope, dead_gate=dead_gate, sel=None if nd is None else nd.sel)
+            H1e = edge_fwd_typed(z, Wes, PXr, ldpx, be, coef, index, slope, dead_gate=dead_gate, sel=None if nd is None else nd.sel)
         elif mfma_ok(index, H):
-            H1e = edge_fwd_mfma(z, Wes, XP[:, H:], 3 * H, be, coef, index, slope)
+            H1e = edge_fwd_mfma(z, Wes, PXr, ldpx, be, coef, index, slope)
         else:
             G = z @ Wes
-            H1e = edge_combine_raw(G, 2 * H, XP[:, H:], 3 * H, be, coef, index, H, relu=True, slope=slope)
+            H1e = edge_combine_raw(G, 2 * H, PXr, ldpx, be, coef, index, H, relu=True, slope=slope)
             del G
             if not sums_only:
                 Oe = torch.addmm(eb2, H1e, eW2.t())
@@ -1403,6 +1515,7 @@ class _FusedDMPLayer(torch.autograd.Function):
             # fetched; as an INNER layer of a rep-net (``inner``: the next layer of the same rep-net, under the same gate,
             # is the only reader of zn) the output's zero rows are not stored either
             dead = (3 if (inner & 1) else 1) if (dead_gate is not None and zero_rows_gate(e_gate)) else 0
+            side.wait("tiles")
             lt = live_tiles(index, coef, e_gate) if (dead == 3 and USE_TYPED_ROWS and eW2t is not None) else None
             if lt is not None:      # nothing to write for the rows under a zero gate: the kept edges' tiles only
                 zn = out_fwd_typed(H1e, eW2t, eb2, z if residual else None, lt)
@@ -1430,13 +1543,14 @@ class _FusedDMPLayer(torch.autograd.Function):
             # (z's rows under a zero of a gate whose maker wiped the input are zeros, and as an inner layer's output not even
             # written: weight 0, not fetched)
             zs = pool_rows(z, epool, e_gate if zero_rows_gate(e_gate) else None).view(G_ * halves, H) if residual else None
-            if USE_SMALL_GEMM_JOBS and Q.is_contiguous() and eW2.is_contiguous():
+            if USE_SMALL_GEMM_JOBS and Q.is_contiguous() and eW2.is_contiguous() and Q.size(0) <= SMALL_GEMM_MAX_ROWS:
                 es = torch.empty((G_ * halves, H), dtype=torch.float32, device=Q.device)  # Q W2^T + cnt b2 (+ sum of z): one launch
                 small_gemm_jobs([(es, [(Q, False, eW2, True), (cnt, False, eb2.view(1, H), False)], zs)])
             else:
-                es = torch.addmm(cnt * eb2, Q, eW2.t())
-                if residual:
-                    es = es + zs
+                # (thousands of graphs: the small-product kernel is built for a few hundred rows -- 43 us at 4096 rows against
+                # 13 for a library product + one row pass)
+                es = torch.addmm(zs, Q, eW2.t()) if residual else Q @ eW2.t()
+                es.addcmul_(cnt, eb2.view(1, H))
             # ... of which only the NON-FLAGGED half is returned ([G, H]): without the rows the backward propagates a gradient
             # through that half only (the row map is -1 for flagged rows), so the flagged sums are not handed out as if they
             # were differentiable (the heads mask reversed edges out and read [:, :H] anyway, basemodel.py:1545-1631)
@@ -1489,7 +1603,12 @@ class _FusedDMPLayer(torch.autograd.Function):
             if lazy is not None:
                 T, emap, ep = lazy
                 if H % 4 == 0 and H <= 256:
-                    dG, dbe, Q = pool_relu_bwd(T @ eW2, emap, ctx.e_gate, H1e, ep, slope)       # dG is dPre; one pass over H1e
+                    # (dPre's rows under a zero of a 0 / 1 gate: every reader below leaves them out -- the kept incidence sums,
+                    # the class-tile kernels over the kept edges' tiles)
+                    skip = (typed and USE_MASKED_SUMS and SKIP_DEAD_ROWS and ctx.l0 is None and binary_gate_mask(ctx.e_gate) is not None
+                            and zero_rows_gate(ctx.e_gate) and live_tiles(ix, coef, ctx.e_gate) is not None and nd is not None
+                            and USE_KEPT_INCIDENCE)
+                    dG, dbe, Q = pool_relu_bwd(T @ eW2, emap, ctx.e_gate, H1e, ep, slope, skip_dead=skip)       # dG is dPre; one pass over H1e
                     Q = Q[:, :H]
                 else:
                     dG, dbe = relu_bwd_gathered_colsum(T @ eW2, emap, ctx.e_gate, H1e, slope)

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 70
+#define DMP_ABI_VERSION 71
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -670,6 +670,22 @@ int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *en
 int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                            const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                            const uint32_t *rowmask, int64_t R, int H, float slope, float *out, int64_t ldo, void *stream);
+/* The first layer's NODE side from the label codes, one pass (dmpnn.py:113,121,125,129-140 with node rows x = venc WV0 and edge
+ * rows z0 = enc W0, so that a node's aggregates are S0_h W0 with S0_h the sums of its in / out edges' codes):
+ *   h1[r]          = act([venc[r] | S0[r, 0:K0] | S0[r, Kp:Kp+K0]] W[:, 0:H] + bias)
+ *   P[r, 0:2H]     = [venc[r] | ...] W[:, H:3H]                                                (the gathered projections, ldp >= 2H)
+ * for the node rows n0 <= r < n1 of one embedding table.  W [dmp_l0_node_pack_rows(), ldw >= 3H], packed by the caller: rows
+ * 0 .. VK-1 = WV0 Wx, rows VK .. VK+K0-1 = W0 Bn_in and the next K0 rows W0 Bn_out in the first H columns, every other entry ZERO
+ * (VK + 2 K0 <= dmp_l0_node_pack_rows()).  rowmask (bit r & 31 of word r >> 5, absolute node ids; NULL: every row): a DEAD node's h1
+ * row is left unwritten (its consumers walk the kept nodes' tiles), its P row is written as zeros (its code row is zero; the first
+ * layer's edge kernel gathers P through the plain selectors).  list / count (optional, with rowmask; dmp_kept_rows over ALL nodes,
+ * list_bound >= *count known to the host): the launch walks the list's positions from q_begin on -- sixteen live rows per wave and
+ * batch -- and acts on the entries inside [n0, n1); q_begin <= n0: a position the caller knows to precede the table's first row
+ * (0 is always valid; n0 when every node below n0 is kept). */
+int64_t dmp_l0_node_pack_rows(void);
+int dmp_l0_node_fwd(const float *venc, int64_t ldv, int VK, const float *S0, int64_t lds, int K0, int Kp, const float *W, int64_t ldw,
+                    const float *bias, float slope, const uint32_t *rowmask, const int32_t *list, const int32_t *count, int64_t list_bound,
+                    int64_t q_begin, int64_t n0, int64_t n1, int H, float *h1, int64_t ldh, float *P, int64_t ldp, void *stream);
 int64_t dmp_l0_bwd_w_blocks(int64_t rows);
 /* dmp_l0_bwd_w_masked with a row mask: bit r of rowmask[t] == 0 says the code row 32 t + r is all zeros (the row's gate was 0 when
  * dmp_l0_pack made it), so its dPre / dZn rows -- which would be multiplied by those zeros -- are not fetched. */

@@ -254,3 +254,45 @@ def test_layer0_kernels_over_the_kept_rows_list(rows, r0, keep, k, h, gpu):
     assert bool((o1[r0:][dead[r0:]] == 7.5).all()) and bool((o1[:r0] == 7.5).all())
     assert bool(th.isfinite(x1).all())
     assert float((x1 - x0).abs().max()) <= 2e-5 * max(1.0, float(x0.abs().max()))
+
+
+@pytest.mark.parametrize("n,n0,vk,k0,h,masked,slope", [(1, 0, 8, 10, 128, False, 0.0), (777, 0, 16, 10, 128, True, 1 / 5.5), (73728, 8192, 16, 10, 128, True, 1 / 5.5),
+                                                         (5000, 37, 16, 12, 64, True, 0.0), (4096, 0, 4, 3, 64, False, 1 / 5.5), (70001, 0, 16, 10, 128, False, 0.0)])
+@pytest.mark.parametrize("listed", [False, True])
+def test_layer0_node_pass_against_fp64(n, n0, vk, k0, h, masked, slope, listed, gpu):
+    """``dmp_l0_node_fwd``: the first layer's node side from the node codes and the edges' code sums in one pass -- against fp64,
+    over a row range, with the kept nodes' mask (dead rows: H1n untouched, projections zero)."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(n + vk + k0)
+    kp = (k0 + 3) // 4 * 4
+    venc = (th.rand(n, (vk + 3) // 4 * 4, generator=gen) < 0.4).float().to(gpu)
+    S0 = th.randint(-3, 6, (n, 2 * kp), generator=gen).float().to(gpu)
+    keep = (th.rand(n, generator=gen) < 0.4).to(gpu) if masked else th.ones(n, dtype=th.bool, device=gpu)
+    venc = venc * keep.view(-1, 1).float()                 # a dead node's code row is zero (l0_pack multiplies by the gate)
+    mask = fused.gate_row_mask(keep.float()) if masked else None
+    Mv = th.randn(vk, 3 * h, generator=gen).to(gpu)
+    Ma, Mb = th.randn(k0, h, generator=gen).to(gpu), th.randn(k0, h, generator=gen).to(gpu)
+    bias = th.randn(h, generator=gen).to(gpu)
+    h1 = th.full((n, h), -7.0, device=gpu)
+    P = th.full((n, 2 * h), -7.0, device=gpu)
+    klist = None
+    if listed and masked:                                  # the kept nodes' list over ALL nodes (NodeRows.rows)
+        lst, cnt = fused.kept_rows(mask, 0, n, tiles=True)
+        klist = (lst, cnt[0:1])
+    elif listed:
+        pytest.skip("a list comes with a mask")
+    W = fused.l0_node_pack(vk, k0, h, Mv, Ma, Mb)
+    fused.l0_node_fwd(venc, vk, S0, k0, kp, W, bias, slope, mask, n0, n, h, h1, P, rows=klist)
+    pre = venc[:, :vk].double() @ Mv[:, :h].double() + S0[:, :k0].double() @ Ma.double() + S0[:, kp:kp + k0].double() @ Mb.double() + bias.double()
+    ref = th.where(pre > 0, pre, slope * pre)
+    rows = th.arange(n, device=gpu) >= n0
+    live = rows & keep
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((h1.double() - ref)[live].abs().max()) <= tol if bool(live.any()) else True
+    assert bool((h1[~live] == -7.0).all())                # rows outside the range / dead rows: not written
+    pref = venc[:, :vk].double() @ Mv[:, h:].double()
+    assert float((P.double() - pref)[rows].abs().max()) <= tol if bool(rows.any()) else True
+    assert bool((P[rows & ~keep] == 0).all()) and bool((P[~rows] == -7.0).all())
+    h1b, Pb = th.full_like(h1, -7.0), th.full_like(P, -7.0)
+    fused.l0_node_fwd(venc, vk, S0, k0, kp, W, bias, slope, mask, n0, n, h, h1b, Pb, rows=klist)
+    assert th.equal(h1, h1b) and th.equal(P, Pb)          # repeatable
