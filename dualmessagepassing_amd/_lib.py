@@ -93,6 +93,7 @@ SIGNATURES = {
     "dmp_fold_layers": (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_unfold_layers": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "dmp_smallk_embed_gate": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "dmp_smallk_embed_live": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_smallk_atb_blocks": (c_i64, [c_i64]),
     "dmp_smallk_embed_cols": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     "dmp_smallk_atb_cols_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
@@ -189,7 +190,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 71
+ABI_VERSION = 72
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

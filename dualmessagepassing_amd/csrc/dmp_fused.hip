@@ -486,7 +486,8 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
 // The forward of the same narrow layer with its gate:  out[r, :] = gate[r] * sum_k X[r, k] W[k, :]  -- the gated
 // embedding rows written straight into their place (the union buffer of the joint rep-net pass) from the K
 // inputs per row instead of from the [R, H] embedding.  W lives in registers (H / 64 values per lane and input).
-struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo; };   // blockIdx.y: column block of W / out
+struct SmallKFwdArgs { const float *X; int64_t ldx; const float *W; int64_t ldw; const float *gate; int64_t R; float *out; int64_t ldo;   // blockIdx.y: column block of W / out
+                       int skip_zero; };   // rows whose gate is 0 are not stored (DEAD rows: every reader leaves them out)
 
 template <int K, int VW>
 __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) {
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(kBlock) void smallk_embed_k(const SmallKFwdArgs p) 
       const int64_t r = r0 + u;
       if (r >= p.R) break;
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
+      if (p.skip_zero && g == 0.f) continue;                  // wave-uniform
       LaneVec<VW> e;
 #pragma unroll
       for (int c = 0; c < VW; ++c) e.v[c] = 0.f;
@@ -809,14 +811,14 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
   return dmp_smallk_atb_cols(X, ldx, K, D, ldd, 1, nullptr, 0, gate, R, H, partial, stream);
 }
 
-int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
-                          int H, int ncols, float *out, int64_t ldo, void *stream) {
+static int smallk_embed_launch(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                               int H, int ncols, float *out, int64_t ldo, int live_only, void *stream) {
   DMP_ROW_CHECK(R >= 0 && K > 0 && ncols >= 1 && ncols <= 8);
   if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   if (R == 0) return DMP_OK;
   DMP_ROW_CHECK(X && W && out && ldx >= K && ldw >= (int64_t)ncols * H && ldo >= (int64_t)ncols * H);
   if (ldw % 2 || ldo % 2 || (reinterpret_cast<uintptr_t>(W) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return DMP_ERR_UNSUPPORTED;
-  SmallKFwdArgs p{X, ldx, W, ldw, gate, R, out, ldo};
+  SmallKFwdArgs p{X, ldx, W, ldw, gate, R, out, ldo, (live_only && gate) ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
     case 1: launch_smallk_fwd<1>(p, H, ncols, st); break;   case 2: launch_smallk_fwd<2>(p, H, ncols, st); break;
@@ -831,9 +833,20 @@ int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, in
   return check_launch();
 }
 
+int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, int ncols, float *out, int64_t ldo, void *stream) {
+  return smallk_embed_launch(X, ldx, K, W, ldw, gate, R, H, ncols, out, ldo, 0, stream);
+}
+
 int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
                           int H, float *out, int64_t ldo, void *stream) {
-  return dmp_smallk_embed_cols(X, ldx, K, W, ldw, gate, R, H, 1, out, ldo, stream);
+  return smallk_embed_launch(X, ldx, K, W, ldw, gate, R, H, 1, out, ldo, 0, stream);
+}
+
+int dmp_smallk_embed_live(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, float *out, int64_t ldo, void *stream) {
+  if (!gate) return DMP_ERR_BAD_ARG;
+  return smallk_embed_launch(X, ldx, K, W, ldw, gate, R, H, 1, out, ldo, 1, stream);
 }
 
 int dmp_reduce_partials(const float *partial, int64_t S, int64_t L, float *out, int accumulate, void *stream) {

@@ -448,10 +448,14 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     l0 = _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_gate, np_)
     v = None
     if l0 is not None:        # the first layer works on the label codes: its [E, H] input rows are only its residual term
+        from . import fused
+        # ... which the layer reads over the kept edges' / nodes' tiles only: the rows under a zero of a 0 / 1 gate are not even stored
+        live_e, live_v = fused.l0_dead_inputs(union.index(), layers[0].hidden_dim, *_joint_gates(v_gate, e_gate, np_, ep_, p_e_emb.dtype, p_e_emb.device),
+                                              l0)
         with th.no_grad():
-            e = _GateConcat.apply(p_e_emb, None, e_gate, g_e_emb._dmp_src[0], g_e_emb._dmp_src[1])
+            e = _GateConcat.apply(p_e_emb, None, e_gate, g_e_emb._dmp_src[0], g_e_emb._dmp_src[1], live_e)
             if l0.venc is not None:
-                v = _GateConcat.apply(p_v_emb, None, v_gate, g_v_emb._dmp_src[0], g_v_emb._dmp_src[1])
+                v = _GateConcat.apply(p_v_emb, None, v_gate, g_v_emb._dmp_src[0], g_v_emb._dmp_src[1], live_v)
     else:
         e = _gate_concat(p_e_emb, g_e_emb, e_gate)
     if v is None:
@@ -560,7 +564,9 @@ class _GateConcat(th.autograd.Function):
     ``gate * d[n:]`` for the embedding's own backward product."""
 
     @staticmethod
-    def forward(ctx, p, g, gate, enc=None, W=None):
+    def forward(ctx, p, g, gate, enc=None, W=None, live_only=False):
+        """``live_only`` (with ``enc`` and a 0 / 1 ``gate``): the rows under a zero of the gate are not stored -- every reader of
+        the result leaves them out (the first layer of a joint pass over the kept edges' / nodes' tiles)."""
         from . import _lib
         lib = _lib.load()
         if g is None:                      # the embedding itself was never materialised (embed.DeferredEmbedding): rows from enc
@@ -572,15 +578,20 @@ class _GateConcat(th.autograd.Function):
             p, g = p.contiguous(), g.contiguous()
             rows_g = g.size(0)
         n, H = p.size(0), p.size(1)
-        out = th.empty((n + rows_g, H), dtype=p.dtype, device=p.device)
+        live_only = bool(live_only and enc is not None and gate is not None and p.dtype == th.float32)
+        if live_only:
+            from . import fused
+            out = fused.dead_rows_buffer((n + rows_g, H), p.device)
+        else:
+            out = th.empty((n + rows_g, H), dtype=p.dtype, device=p.device)
         out[:n].copy_(p)
         if rows_g > 0:
             gt = None if gate is None else gate.reshape(-1).contiguous()
             if enc is not None:   # the gated rows from the K inputs per row instead of from the [rows, H] embedding
                 Wd = W.detach()
-                _lib.check(lib.dmp_smallk_embed_gate(_lib.ptr(enc), enc.stride(0), enc.size(1), _lib.ptr(Wd), Wd.stride(0),
-                                                     _lib.ptr(gt), rows_g, H, _lib.ptr(out[n:]), H, _lib.stream_ptr()),
-                           "dmp_smallk_embed_gate")
+                fn = lib.dmp_smallk_embed_live if live_only else lib.dmp_smallk_embed_gate
+                _lib.check(fn(_lib.ptr(enc), enc.stride(0), enc.size(1), _lib.ptr(Wd), Wd.stride(0),
+                              _lib.ptr(gt), rows_g, H, _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_smallk_embed_gate")
             else:
                 _lib.check(lib.dmp_gate_residual(None, H, _lib.ptr(g), H, _lib.ptr(gt), g.size(0), H,
                                                  _lib.ptr(out[n:]), H, _lib.stream_ptr()), "dmp_gate_residual")
@@ -595,10 +606,10 @@ class _GateConcat(th.autograd.Function):
         gate = None if ctx.gate is None else ctx.gate.reshape(-1).contiguous()
         if ctx.enc is not None:
             dW = fused.smallk_atb(ctx.enc, dg, gate) if dg.size(0) > 0 else th.zeros((ctx.enc.size(1), d.size(1)), device=d.device)
-            return d[:ctx.n], None, None, None, dW
+            return d[:ctx.n], None, None, None, dW, None
         if gate is not None and dg.size(0) > 0:
             dg = fused.gate_residual(None, dg, gate)
-        return d[:ctx.n], dg, None, None, None
+        return d[:ctx.n], dg, None, None, None, None
 
 
 def _gate_concat(p, g, gate):

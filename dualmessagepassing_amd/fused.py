@@ -1844,6 +1844,22 @@ class _FusedDMPLayer(torch.autograd.Function):
                 None, None, None, dW0, dWV0, None, None)
 
 
+def l0_dead_inputs(index, H, vg, eg, l0):
+    """``(edges, nodes)``: may the input rows of a first layer on the label codes (``l0``) stay UNWRITTEN under the zeros of the
+    union's 0 / 1 gates?  The layer reads its edge rows ``z`` only as the residual term of its second Linear -- over the kept
+    edges' tiles when the conditions below hold (the ones ``_FusedDMPLayer.forward`` tests) -- and its node rows ``x`` (with
+    node codes) only as the residual term over the kept nodes' tiles."""
+    if l0 is None or not SKIP_DEAD_ROWS or not USE_ROW_MASKS or not USE_TYPED_ROWS or not typed_ok(index, H):
+        return False, False
+    edges = bool(eg is not None and zero_rows_gate(eg) and gate_row_mask(eg) is not None and USE_LIVE_TILES
+                 and getattr(index, "_coef_deg", None) is not None)
+    N = index.num_nodes
+    nodes = bool(l0.venc is not None and vg is not None and USE_NODE_ROWS and USE_PLAIN_ATB and N >= 4096 and onepanel_ok(H) and zero_rows_gate(vg)
+                 and gate_row_mask(vg) is not None and index.num_edges > 0
+                 and not any(n0 % 32 for _, _, (n0, _) in l0.tables(index.num_edges, N)))
+    return edges, nodes
+
+
 def activation_slope(act):
     """Negative slope of an MLP activation module the fused path can run: 0.0 for ``nn.ReLU``, ``negative_slope``
     for ``nn.LeakyReLU`` (the reference's default ``leaky_relu``: 1/5.5, utils/act.py:27,466); None otherwise."""

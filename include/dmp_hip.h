@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 71
+#define DMP_ABI_VERSION 72
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -636,6 +636,10 @@ int dmp_colsum_partials(const float *A, int64_t lda, int64_t rows, int H, float 
  * (embed.py:103-120 + basemodel.py:1515), written where the caller wants the gated rows (ldo >= H). */
 int dmp_smallk_embed_gate(const float *X, int64_t ldx, int K, const float *W, int64_t ldw,
                           const float *gate, int64_t rows, int H, float *out, int64_t ldo, void *stream);
+/* ... leaving out DEAD rows: a row whose gate is 0 is NOT stored (`out` keeps whatever the buffer held there) -- for a 0 / 1 gate
+ * all of whose readers skip the rows under its zeros (the first layer's residual term under the kept edges' tiles). */
+int dmp_smallk_embed_live(const float *X, int64_t ldx, int K, const float *W, int64_t ldw, const float *gate, int64_t R,
+                          int H, float *out, int64_t ldo, void *stream);
 /* The same two over several column blocks in ONE launch: W / out [.., ncols * H] (ncols <= 8 blocks of H columns), and
  * D [rows, ncols * H] plus an optional further block D2 [rows, H] of another matrix (NULL: none).
  * partial: [ncols (+1), dmp_smallk_atb_blocks(rows), K*H] -- one dmp_reduce_partials per column block. */

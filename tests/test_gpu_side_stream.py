@@ -1,0 +1,121 @@
+"""The index builds of a step on the side stream (dualmessagepassing_amd/side.py, dmpnn.prefetch_joint_indexes; round 5).
+
+Everything the joint pass derives from the batch's structure and its two 0 / 1 gates (the union's CSR, coefficients, selectors,
+row masks, kept-row lists, the kept edges' tiles / CSR / incidence CSR, the pooling indexes) is issued on a second stream beside
+the embedding and first-layer kernels.  Same kernels, same inputs, same order of additions -- only the stream differs: the step
+must equal the one-stream step BIT FOR BIT, eagerly and as a replayed HIP graph (where the fork becomes a branch of the graph),
+and every stage must be joined when the forward pass returns."""
+import os
+import sys
+
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(gpu, batch=96):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_compact import _model_and_batch, _outputs_and_grads
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = dict(bench.CFG, batch=batch)
+    bench_, shard, step, model = _model_and_batch(cfg, gpu)
+    return bench_, cfg, shard, step, model, _outputs_and_grads
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_step_with_the_side_stream_equals_the_one_stream_step_bit_for_bit(lazy, gpu):
+    from dualmessagepassing_amd import dmpnn, side
+    bench_, cfg, shard, step, model, run = _setup(gpu)
+    side.USE_SIDE_STREAM = False
+    try:
+        ref_out, ref_flat = run(bench_, cfg, shard, step, model, lazy)
+    finally:
+        side.USE_SIDE_STREAM = True
+    forked = []
+    real = dmpnn.prefetch_joint_indexes
+
+    def spy(*a, **k):
+        real(*a, **k)
+        forked.append(len(side._pending))
+
+    dmpnn.prefetch_joint_indexes = spy
+    try:
+        import dualmessagepassing_amd.basemodel  # noqa: F401  (the model looks the function up in dmpnn at call time)
+        out, flat = run(bench_, cfg, shard, step, model, lazy)
+    finally:
+        dmpnn.prefetch_joint_indexes = real
+    assert forked and max(forked) >= 5, "the prefetch did not fork its stages: %r" % (forked,)
+    assert not side._pending, "stages left unjoined after the pass: %r" % ([n for n, _, _ in side._pending],)
+    for k, v in ref_out.items():
+        if v is None:
+            assert out[k] is None
+        else:
+            assert th.equal(out[k], v), k
+    assert th.equal(flat, ref_flat)
+
+
+def test_side_stream_stages_are_waited_in_order_and_joined(gpu):
+    """``side.fork`` / ``mark`` / ``wait`` / ``join`` on their own: a stage's wait drops the earlier stages, work issued in a fork
+    is visible after its wait, a nested fork is a no-op, nothing stays pending after ``join``."""
+    from dualmessagepassing_amd import side
+    x = th.zeros(1 << 20, device=gpu)
+    with side.fork() as f:
+        assert f and side.active()
+        with side.fork() as inner:
+            assert inner is False
+        a = x + 1.0
+        side.mark("a")
+        b = a * 3.0
+        side.mark("b")
+        c = b - 1.0
+        side.mark("c")
+    assert [n for n, _, _ in side._pending] == ["a", "b", "c", "_end"]
+    side.wait("b")
+    assert [n for n, _, _ in side._pending] == ["c", "_end"]
+    assert float(b.sum()) == 3.0 * (1 << 20)
+    side.wait("nope")                                   # an unknown stage: nothing happens
+    side.join()
+    assert not side._pending and float(c.sum()) == 2.0 * (1 << 20)
+    side.USE_SIDE_STREAM = False
+    try:
+        with side.fork() as f:
+            assert f is False and not side.active()
+    finally:
+        side.USE_SIDE_STREAM = True
+
+
+def test_replayed_step_with_the_forked_branch_equals_the_one_stream_recording(gpu):
+    """``dp.StepGraph`` records bench.py's step (forward + backward + gradient pack) with its forked index branch and replays it:
+    predictions and the flat gradient equal those of a recording made with the side stream off, bit for bit."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dualmessagepassing_amd import side
+    from dualmessagepassing_amd.dp import StepGraph
+    cfg = dict(bench.CFG, batch=64)
+    shard = bench.make_shard(cfg, 0, gpu)
+    step, model = bench.build_step(dict(cfg, graph=True), shard, gpu, 1)
+    gen = th.Generator().manual_seed(7)
+    with th.no_grad():
+        for prm in step.sync.params:
+            prm.add_((0.05 * th.randn(prm.shape, generator=gen)).to(gpu))
+    res = {}
+    for on in (False, True):
+        side.USE_SIDE_STREAM = on
+        try:
+            g = StepGraph(lambda: step.front(), optimizer=None, max_shapes=1)
+            with g.on_stream():
+                g()                                   # eager
+                g()                                   # recorded + replayed
+                step.sync.flat.fill_(float("nan"))
+                g()                                   # replayed
+                assert g.replays == 2
+                th.cuda.synchronize()
+                res[on] = (step.last_pred_c.detach().clone(), step.sync.flat.detach().clone())
+        finally:
+            side.USE_SIDE_STREAM = True
+        assert not side._pending
+    assert bool(th.isfinite(res[True][1]).all())
+    assert th.equal(res[True][0], res[False][0]) and th.equal(res[True][1], res[False][1])
