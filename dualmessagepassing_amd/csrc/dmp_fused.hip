@@ -188,6 +188,8 @@ struct ReduceSegs {
   int n;
 };
 
+// (measured, round 5: an XCD-contiguous order of the column chunks -- xcd_remap of the block index -- is SLOWER, 32.8 -> 39.7 us at
+// the layer backward's 133 MB: the plain order spreads every partial row over all XCDs' memory channels at once)
 __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const ReduceSegs a) {
   constexpr int G = 32, GPB = kBlock / G;
   __shared__ float4 red[kBlock];
