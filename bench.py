@@ -491,9 +491,10 @@ def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, all_own
         if all_own is not None:
             r["bytes_all_rows"] = int(all_own)
             r["bytes_survey_all_rows"] = int(all_survey)
-        r["note"] = ("%d of the summed rows are zeros under this batch's 0/1 edge gate and %d node rows lie under a zero of its node gate "
+        r["note"] = ("%d of the summed rows are not fetched -- zeros under this batch's 0/1 edge gate, or rows that only a node under a zero "
+                     "of its node gate would sum -- and %d node rows lie under a zero of the node gate: not written "
                      "(the ScalarFilter gates multiply the rep-net's input rows and every layer's update, basemodel.py:1515-1531, "
-                     "dmpnn.py:245-277): not fetched / not written.  The byte counts and fractions are those of the rows the launch "
+                     "dmpnn.py:245-277).  The byte counts and fractions are those of the rows the launch "
                      "processes; all_rows_launch times the kernel over every row" % (skipped_rows, skipped_nodes))
     return r
 
@@ -537,7 +538,7 @@ def check_rates(obj, path="line"):
             check_rates(v, "%s[%d]" % (path, i))
 
 
-def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B):
+def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B, Ein=None):
     """Algorithmic bytes of one launch of kernel ``name`` (the HIP-event timer's record name) when it runs on the rows the batch's
     0 / 1 gates keep -- the timer's own count is host-side and prices every row of the launch shape.  N / E: union node / edge
     rows, Nk / Ek: the kept ones (pattern rows are all kept), Et / Etk: target edge rows / kept.  None: the timer's count stands."""
@@ -550,7 +551,8 @@ def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B):
     if base == "seg_sum2_graphs":
         return 4 * H * Ek + 8 * H * Nk + 8 * E + E // 8 + N // 8 + 16 * (B + 1)
     if base == "seg_sum2" and ("rows=%d" % N) in name and on_e and ("H=%d" % H) in name:
-        return 4 * H * Ek + 8 * H * Nk + 4 * Ek + 12 * Nk
+        Er = Ek if Ein is None else Ein      # under the node gate: the kept edges INTO a kept node
+        return 4 * H * Er + 8 * H * Nk + 4 * Er + 12 * Nk
     if base == "seg_sum2" and on_e and ("H=%d" % H) in name:          # a pooled pass over the edge rows, gate-weighted
         return 4 * H * Ek + 8 * E
     if base == "edge_fwd_typed" and on_e:
@@ -1223,12 +1225,16 @@ def main():
         # the backward's sums over the kept edges' incidence CSR fetch the kept edges WITH a kept endpoint (pattern edges: all)
         Ek1 = (uE - Et) + kept.get("edges_with_kept_endpoint", Etk) if (skipped or skipped_n) else uE
         inc_k = 2 * (uE - Et) + kept.get("kept_incidences", 2 * Etk) if (skipped or skipped_n) else 2 * uE
+        # the forward aggregation over the kept NODES' rows fetches the kept edges INTO a kept node only (pattern edges: all)
+        Ein = (uE - Et) + kept.get("kept_in_edges", Etk) if skipped_n else Ek
         if key in kern:     # forward: S[v] = [- sum Z[e] | + sum Z[e]] over the in-edges (dmpnn.py:92,163 with the products moved behind the sum)
             roof = seg_roofline(kern[key], "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, "
                                 "N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
-                                4 * H * Ek + 8 * H * Nk + 4 * Ek + (12 * Nk if skipped_n else 4 * (uN + 1)),
-                                4 * H * (Ek + Nk) + 4 * Ek + 4 * (Nk + 1), prof["in"], skipped,
+                                4 * H * Ein + 8 * H * Nk + 4 * Ein + (12 * Nk if skipped_n else 4 * (uN + 1)),
+                                4 * H * (Ein + Nk) + 4 * Ein + 4 * (Nk + 1), prof["in"], uE - Ein,
                                 4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1), 4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), skipped_n)
+            if skipped_n:
+                roof["row_reads"] = int(Ein)     # (of the %d edge rows the 0 / 1 edge gate keeps: those whose destination node the node gate keeps too)
         if key_kinc in kern and (skipped or skipped_n):
             # backward of the edge gathers under both gates: every kept node's two sums over its kept edges (ascending edge id)
             roof_bwd = seg_roofline(kern[key_kinc], "dmp::seg_sum_vec<32,split,remap,incidence> over the kept edges' incidence CSR, a row per "
@@ -1253,7 +1259,7 @@ def main():
         # the per-kernel table: the timer prices a launch at its launch SHAPE; under the gates the kernels process the kept rows
         if skipped or skipped_n:
             for name, v in kern.items():
-                kb = kept_row_bytes(name, H, uN, uE, Nk, Ek, Et, Etk, nB)
+                kb = kept_row_bytes(name, H, uN, uE, Nk, Ek, Et, Etk, nB, Ein)
                 if kb is not None:
                     v["bytes"], v["gbps"], v["rows"] = kb, kb / v["avg_us"] / 1e3, "kept"
         if skipped and not multi:

@@ -752,6 +752,7 @@ class GraphAdjModelV2(BaseModel):
             ku, kw = kv[u.long()] & ke, kv[v.long()] & ke
             out["edges_with_kept_endpoint"] = int((ku | kw).sum().item())
             out["kept_incidences"] = int(ku.sum().item() + kw.sum().item())
+            out["kept_in_edges"] = int(kw.sum().item())      # kept edges INTO a kept node: what the forward aggregation over the kept nodes' rows fetches
         return out
 
     def _compact_gated(self, pattern, graph, el_gate):

@@ -958,7 +958,8 @@ def node_rows(index, v_gate, H):
 # (measured, round 5: LARGE kernels do not gain from the side stream -- the weight-gradient launches of a layer's backward beside its
 # data-gradient chain +2.6 %, the second half of a layer's node side beside its edge side +1.8 % per step: two bandwidth-bound
 # launches in flight slow each other down by more than the tails they fill; the partial reductions of a layer's weight gradients
-# beside the rest of its backward +1 %.  The side stream carries the small index builds only.)
+# beside the rest of its backward +1 %, the first layer's pass over dPre / dZn beside the node side's short launches +0.7 %.  The side
+# stream carries the small index builds only.)
 USE_L0_NODE_FWD = True     # the first layer's node side from the label codes as one pass (csrc/dmp_layer0.hip::l0_node_fwd_k)
 L0_NODE_MAX_COLS = 40      # code columns per node row that kernel holds in registers: VK + 2 K0
 
@@ -1434,8 +1435,8 @@ class _FusedDMPLayer(torch.autograd.Function):
             side.wait("keepcsr")
             kc = keep_in_csr(index, e_gate) if zero_rows_gate(e_gate) else None
             if kc is not None and nd is not None:   # ... and over the kept NODES' rows only: the others' aggregates are dead
-                # (measured: row pointers by list position -- ``NodeRows.kept_incidence(in_only=True)``, one dependent load less
-                # per row group -- leave the launch at 28.6 us, and that index takes 26 us to build against 14 for this one)
+                # (measured twice -- before and after the remap fix of finding (u): row pointers by list position,
+                # ``NodeRows.kept_incidence(in_only=True)``, one dependent load less per row group, leave the launch where it is)
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0, out=dead_rows_buffer((N, 2 * H), z.device), rows=nd.rows)
             elif kc is not None:      # the CSR over the kept edges: the plain kernel, no entries of skipped rows in its stream
                 S = ops.seg_sum_raw(z, kc[0], kc[1], N, None, True, -1.0, 1.0)
