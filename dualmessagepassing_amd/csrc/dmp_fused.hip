@@ -423,17 +423,18 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   // before the current batch's FMAs.
   LaneVec<VW> d[kRows], dn[kRows];
   float mine[kRows], minen[kRows];
+  static_assert(32 % kSmallRows == 0, "a batch of rows lies inside one mask word");
   auto load_batch = [&](int64_t r0, LaneVec<VW> (&dd)[kRows], float (&mm)[kRows]) {
+    // the batch's mask bits from ONE word; a dead row (or one past the end) loads row 0 of D instead of its own -- one cached
+    // line, no traffic, and no branch around the load: a wave-uniform condition around a load is a scalar branch, a basic block
+    // and a wait per row (finding (t) of DESIGN 8); its products are skipped below
+    const uint32_t word = (p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       const int64_t r = r0 + u;                             // wave-uniform
       const bool ok = r < p.R;
-      const bool live = ok && (!p.rowmask || ((p.rowmask[r >> 5] >> (r & 31)) & 1u));   // scalar load, scalar branch
-      if (live) dd[u] = lane_load<VW>(Dj + r * ldj, lane);
-      else {
-#pragma unroll
-        for (int c = 0; c < VW; ++c) dd[u].v[c] = 0.f;
-      }
+      const bool live = ok && ((word >> u) & 1u);
+      dd[u] = lane_load<VW>(Dj + (live ? r : (int64_t)0) * ldj, lane);
       // one load instruction for both: lanes < K point into the row of X, lane K at the row's gate
       const float *src = lane < K ? p.X + r * p.ldx + lane : p.gate + r;
       float m = (lane == K && !p.gate) ? 1.f : 0.f;
@@ -446,11 +447,10 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   for (; r0 < p.R; r0 += stride) {
     load_batch(r0 + stride, dn, minen);                     // rows past the end read as zeros
 #pragma unroll
+    const uint32_t wcur = p.rowmask ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
+#pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      if (p.rowmask) {                                       // a masked row: all of its products are zero (wave-uniform test)
-        const int64_t r = r0 + u;
-        if (r < p.R && !((p.rowmask[r >> 5] >> (r & 31)) & 1u)) continue;
-      }
+      if (r0 + u >= p.R || !((wcur >> u) & 1u)) continue;    // a masked row / a row past the end: all of its products are zero (wave-uniform)
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
       const float scaled = mine[u] * g;                     // lane k: gate * X[r, k]
 #pragma unroll
