@@ -410,6 +410,8 @@ def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(),
         side.mark("erows")
         if typed and fused.zero_rows_gate(eg):
             fused.live_tiles(ix, coef, eg)
+            if fused.PLAIN_ROWS_ASCENDING or (fused.PLAIN_ATB_ASCENDING and th.is_grad_enabled()):
+                fused.ascending_tiles(eg)                  # the plain-panel launches' row order
             side.mark("tiles")
             fused.keep_in_csr(ix, eg)
             side.mark("keepcsr")

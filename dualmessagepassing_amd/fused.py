@@ -450,6 +450,35 @@ def keep_in_csr(index, gate):
     return res
 
 
+# the launches over the kept edges' tiles whose panel does not depend on the degree class (second Linear forward / backward, its
+# weight gradient) walk the kept rows in ASCENDING order instead of class by class: the 512-byte row gathers then move through
+# memory front to back (measured on one box: atb_typed plain 81 -> 71 us, bwd_h1_typed 77 -> 72 us; -0.03 ms per step)
+PLAIN_ATB_ASCENDING = True
+PLAIN_ROWS_ASCENDING = True
+
+
+def ascending_tiles(gate):
+    """The rows a 0 / 1 ``gate`` keeps as a tile slot list in ASCENDING row order (``dmp_kept_rows(tiles = 1)``; the class tiles list
+    them class by class): for products that need no class -- the plain weight gradient ``dO^T H1`` -- the row gathers then walk
+    memory front to back.  ``(slot, tile_scale (zeros), num_tiles, bound)`` or None; memoised on the gate."""
+    mask = binary_gate_mask(gate)
+    if mask is None:
+        return None
+    owner = _gate_owner(gate)
+    hit = getattr(owner, "_dmp_asc_tiles", None)
+    if hit is not None and hit[0] == owner._version:
+        return hit[1]
+    R = gate.numel()
+    lst, cnt = kept_rows(mask, 0, R, tiles=True)
+    bound = (R + 31) // 32
+    res = (lst, torch.zeros(bound, dtype=torch.float32, device=mask.device), cnt[1:2], bound)
+    try:
+        owner._dmp_asc_tiles = (owner._version, res)
+    except Exception:
+        pass
+    return res
+
+
 def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None, dst=None):
     """bwd_z_mfma with the per-class matrix: base + gather_select(d_s) + dPre W_g^T  (dPre [E, H], leading dim ld_pre).
     ``WesT``: ``[A'^T | B'^T]`` if the caller has it already (``fold_layers`` makes it in its launch).
@@ -496,6 +525,10 @@ def atb_typed(z, d_pre, coef, index, gate=None, plain=False):
     lib = _lib.load()
     E, H = z.shape
     lt = live_tiles(index, coef, gate)
+    if plain and lt is not None and PLAIN_ATB_ASCENDING:
+        at = ascending_tiles(gate)
+        if at is not None:
+            lt = at
     if lt is not None:
         slot_edge, tile_scale, num_tiles, bound = lt
     else:
@@ -1520,7 +1553,8 @@ class _FusedDMPLayer(torch.autograd.Function):
             side.wait("tiles")
             lt = live_tiles(index, coef, e_gate) if (dead == 3 and USE_TYPED_ROWS and eW2t is not None) else None
             if lt is not None:      # nothing to write for the rows under a zero gate: the kept edges' tiles only
-                zn = out_fwd_typed(H1e, eW2t, eb2, z if residual else None, lt)
+                # (a plain panel needs no class: the kept edges' tiles in ascending row order -- ``ascending_tiles``)
+                zn = out_fwd_typed(H1e, eW2t, eb2, z if residual else None, (ascending_tiles(e_gate) if PLAIN_ROWS_ASCENDING else None) or lt)
             else:
                 zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
@@ -1632,7 +1666,7 @@ class _FusedDMPLayer(torch.autograd.Function):
                             and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
                     lt = live_tiles(ix, coef, ctx.e_gate) if (skip and USE_TYPED_ROWS) else None
                     if lt is not None:      # over the kept edges' tiles only
-                        dG, dbe, db2e = bwd_h1_typed(dzn, eW2, H1e, lt, slope)
+                        dG, dbe, db2e = bwd_h1_typed(dzn, eW2, H1e, (ascending_tiles(ctx.e_gate) if PLAIN_ROWS_ASCENDING else None) or lt, slope)
                     else:
                         dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
                                                     skip_dead_stores=skip)
