@@ -218,9 +218,15 @@ def load(build_if_missing=True):
         if build_if_missing:
             try:
                 path = _build.build_lib()
-            except Exception:
+            except Exception as e:
                 if not os.path.exists(path):
                     raise
+                # (a box without hipcc runs the library it was given -- but a STALE library after a failed build must not pass
+                # silently: it once hid a compile error behind green tests)
+                import sys
+                print("dualmessagepassing_amd: building libdmp_hip.so failed (%s); loading the existing %s, which %s" %
+                      (str(e).splitlines()[0][:200], path, "is STALE against the sources" if _build._stale() else "matches the sources"),
+                      file=sys.stderr)
         if not os.path.exists(path):
             raise DmpError("libdmp_hip.so is missing (%s); run __graft_entry__.build()" % path)
         lib = ctypes.CDLL(path)

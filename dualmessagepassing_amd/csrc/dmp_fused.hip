@@ -446,7 +446,6 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   if (r0 < p.R) load_batch(r0, d, mine);
   for (; r0 < p.R; r0 += stride) {
     load_batch(r0 + stride, dn, minen);                     // rows past the end read as zeros
-#pragma unroll
     const uint32_t wcur = p.rowmask ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
