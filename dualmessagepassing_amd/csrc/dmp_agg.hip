@@ -77,7 +77,10 @@ __global__ __launch_bounds__(BLOCK) void seg_sum_vec(
   // CSR) and also faster when M was just written by the previous kernel (59 vs 70 us);
   // plain dispatch order only wins (~3 us) on a cold read-once stream (scripts/kbench.py).
   // (under a row list the launch is sized for all N rows but only the first *rowcount list positions have work: the remap runs
-  // over THOSE workgroups -- over the whole grid the list's positions would all land on the first XCDs, 3.2 of 8 at 40 % kept rows)
+  // over THOSE workgroups -- over the whole grid the list's positions would all land on the first XCDs, 3.2 of 8 at 40 % kept rows.
+  // Measured and left out, round 5: a kernel of its own for the list with 2 or 3 rows per lane group and the index loads of all of
+  // them requested together -- ONE round of resident waves instead of 1.8 -- is slower, 17.6 -> 20.4 / 27 us: with ~3 entries per
+  // row the launch lives on the number of waves that have a request in flight, not on the length of a wave's dependent chain)
   int nwg = gridDim.x;
   if (rowlist) {
     nwg = (*rowcount + RPB - 1) / RPB;
