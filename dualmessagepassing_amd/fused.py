@@ -991,8 +991,9 @@ def node_rows(index, v_gate, H):
 # (measured, round 5: LARGE kernels do not gain from the side stream -- the weight-gradient launches of a layer's backward beside its
 # data-gradient chain +2.6 %, the second half of a layer's node side beside its edge side +1.8 % per step: two bandwidth-bound
 # launches in flight slow each other down by more than the tails they fill; the partial reductions of a layer's weight gradients
-# beside the rest of its backward +1 %, the first layer's pass over dPre / dZn beside the node side's short launches +0.7 %.  The side
-# stream carries the small index builds only.)
+# beside the rest of its backward +1 %, the first layer's pass over dPre / dZn beside the node side's short launches +0.7 %, the first
+# layer's input rows (a 119 MB store) on a second side lane beside the layer's first launches +0.6 %.  The side stream carries the small
+# index builds only.)
 USE_L0_NODE_FWD = True     # the first layer's node side from the label codes as one pass (csrc/dmp_layer0.hip::l0_node_fwd_k)
 L0_NODE_MAX_COLS = 40      # code columns per node row that kernel holds in registers: VK + 2 K0
 
