@@ -420,6 +420,8 @@ def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(),
             built = dict(zip(pool_kinds, _pool_indexes_union(pattern, graph, pool_kinds, skip_rev)))
             if built.get("edge") is not None and typed and fused.zero_rows_gate(eg) and th.is_grad_enabled():
                 fused.keep_pool_csr(built["edge"], eg)     # the pooled passes of the last layer over the kept edges
+                if getattr(built["edge"], "rows_in_order", False):
+                    fused.pool_weight_sums(built["edge"], eg)     # ... and the gate's per-graph sums (the pooled second Linear's bias term)
         side.mark("pools")
         if (nd is not None and typed and fused.USE_MASKED_SUMS and fused.USE_KEPT_INCIDENCE and fused.zero_rows_gate(eg) and H % 4 == 0
                 and fused.gate_row_mask(eg) is not None and th.is_grad_enabled()):
@@ -550,10 +552,14 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
         stacked = not shared and 2 * gv[0].size(1) <= fused.SMALLK_MAX    # two tables as ONE of 2 VK rows: no second launches
         l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate, stacked), gv[0].size(1) * (2 if stacked else 1)
         l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
-        if v_gate is not None:
-            l0.venc_mask = fused.code_row_mask(l0.venc, l0.VK)        # the node code rows a zero gate wiped: the backward skips their gradient rows
-    if e_gate is not None and not getattr(e_gate, "_dmp_dense_gate", False):
-        l0.enc_mask = fused.code_row_mask(l0.enc, l0.K)
+    # the code rows a zero gate wiped, as row masks: the BACKWARD skips their gradient rows -- built on the side stream (behind the
+    # index builds; joined with them when the pass ends)
+    from . import side
+    with side.fork():
+        if l0.venc is not None and v_gate is not None:
+            l0.venc_mask = fused.code_row_mask(l0.venc, l0.VK)
+        if e_gate is not None and not getattr(e_gate, "_dmp_dense_gate", False):
+            l0.enc_mask = fused.code_row_mask(l0.enc, l0.K)
     return l0
 
 

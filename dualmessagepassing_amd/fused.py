@@ -229,11 +229,22 @@ def pool_weight_sums(pool, weight=None):
     lib = _lib.load()
     if not getattr(pool, "rows_in_order", False):
         raise _lib.DmpError("pool_weight_sums: an index over rows in their own order")
+    # (a gate's sums are memoised on the gate per index: dmpnn.prefetch_joint_indexes makes them ahead, on the side stream)
+    owner = None if weight is None else _gate_owner(weight)
+    if owner is not None:
+        memo = getattr(owner, "_dmp_pool_wsums", None)
+        if memo is not None and memo[0] == owner._version and memo[1] is pool:
+            return memo[2]
     halves = 2 if pool.flag8 is not None else 1
     out = torch.empty((pool.num_graphs, halves), dtype=torch.float32, device=pool.offsets.device)
     w = None if weight is None else weight.reshape(-1).contiguous()
     check(lib.dmp_pool_weight_sums(ptr(w), ptr(pool.flag8), ptr(pool.offsets), pool.num_graphs, ptr(out), stream_ptr()),
           "dmp_pool_weight_sums")
+    if owner is not None and not weight.requires_grad:
+        try:
+            owner._dmp_pool_wsums = (owner._version, pool, out)
+        except Exception:
+            pass
     return out
 
 
