@@ -819,6 +819,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-b1024", action="store_true", help="also time the CPU oracle's step at the GPU line's batch size (1 warm-up + 3 "
                     "timed steps of 1024 pairs, median: several minutes) -> cpu_baseline_b1024")
+    ap.add_argument("--strict-rates", action="store_true", help="a rate of the line above the HBM peak (bench.check_rates) ends the run instead of being reported in the line")
     ap.add_argument("--no-gate-dense", action="store_true", help="skip the extra un-timed steps behind the gate_dense object")
     ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
     ap.add_argument("--extended-steps", type=int, default=200,
@@ -1349,7 +1350,15 @@ def main():
             line["cpu_baseline_b1024"] = None
             if args.cpu_b1024 and args.workload == 2:
                 line["cpu_baseline_b1024"] = cpu_baseline(cfg, initial_state, seconds_budget=0.0, B=cfg["batch"], max_steps=3, warmup=1, min_steps=3)
-        check_rates(line)
+        # the rate self-check: a refused rate is an accounting error -- reported IN the line (``rate_check``) and on stderr, and
+        # fatal under --strict-rates (the tests read the printed line and fail on the field); the measurement itself stands
+        try:
+            check_rates(line)
+        except SystemExit as e:
+            if args.strict_rates:
+                raise
+            line["rate_check"] = "FAILED: " + str(e).splitlines()[0][:300]
+            print(str(e), file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()

@@ -38,6 +38,7 @@ def _check_contract(d, steps=3, warmup=2):
     if "rows_not_fetched" in r:      # the batch's 0 / 1 gates: rows the launch leaves out, and the bytes it does move
         assert 0 < r["rows_not_fetched"] and 0 < r["bytes_per_launch"] < r["bytes_survey_all_rows"]
         assert (r["frac"] < 1.0 or r.get("served_from") == "infinity cache") and "note" in r
+    assert "rate_check" not in d, d.get("rate_check")      # (bench.check_rates found nothing to refuse)
     _no_rate_above_the_peak(d)
     gk = d["gate_kept"]
     assert 0 < gk["edge_rows"] <= gk["of_edge_rows"] and 0 < gk["node_rows"] <= gk["of_node_rows"]
