@@ -229,10 +229,22 @@ __global__ __launch_bounds__(256) void small_gemm_jobs_k(const GemmJobs t) {
         As_f[lk * 16 + lr] = (r < j.M && k < m.K) ? A[r * sa_r + k * sa_k] : 0.f;
       }
       float bv[KW];
+      // op(B) = B^T: a lane's 32 contraction indices are 32 CONSECUTIVE floats of its row of B -- eight 16-byte loads of one whole
+      // 128-byte line instead of 32 loads that each touch 64 different lines (the last launch of the first layer's backward: 38 us)
+      const bool bvec = m.transB && (m.ldb % 4 == 0) && (m.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+      if (bvec) {
+        const float4 *src = reinterpret_cast<const float4 *>(B + (int64_t)cc * m.ldb + k0 + KW * w);
 #pragma unroll
-      for (int kk = 0; kk < KW; ++kk) {
-        const int k = k0 + KW * w + kk;
-        bv[kk] = k < m.K ? B[k * sb_k + cc * sb_c] : 0.f;
+        for (int q4 = 0; q4 < KW / 4; ++q4) {
+          const float4 t4 = (k0 + KW * w + 4 * q4 < m.K) ? src[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          bv[4 * q4 + 0] = t4.x; bv[4 * q4 + 1] = t4.y; bv[4 * q4 + 2] = t4.z; bv[4 * q4 + 3] = t4.w;
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+          const int k = k0 + KW * w + kk;
+          bv[kk] = k < m.K ? B[k * sb_k + cc * sb_c] : 0.f;
+        }
       }
       __syncthreads();
 #pragma unroll
