@@ -1005,6 +1005,7 @@ def node_rows(index, v_gate, H):
 # beside the rest of its backward +1 %, the first layer's pass over dPre / dZn beside the node side's short launches +0.7 %, the first
 # layer's input rows (a 119 MB store) on a second side lane beside the layer's first launches +0.6 %.  The side stream carries the small
 # index builds only.)
+S0_KEPT_ROWS = True         # the first layer's code sums over the kept nodes' rows only (15 -> 10 us)
 USE_L0_NODE_FWD = True     # the first layer's node side from the label codes as one pass (csrc/dmp_layer0.hip::l0_node_fwd_k)
 L0_NODE_MAX_COLS = 40      # code columns per node row that kernel holds in registers: VK + 2 K0
 
@@ -1426,7 +1427,13 @@ class _FusedDMPLayer(torch.autograd.Function):
         if l0 is not None:     # sum of z over a node's edges = (sum of the label codes) W0
             enc0, K0 = l0.enc, l0.K
             tables = l0.tables(z.size(0), N)
-            S0 = ops.seg_sum_raw(enc0, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)        # [N, 2 Kpad] = [in | out]
+            if nd is not None and S0_KEPT_ROWS and enc0.size(1) % 4 == 0:
+                # (the code sums of the kept nodes only: every reader -- the node pass over the kept list, the backward's masked
+                # K-column products -- leaves the dead nodes' rows out)
+                S0 = ops.seg_sum_raw(enc0, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0,
+                                     out=dead_rows_buffer((N, 2 * enc0.size(1)), z.device), rows=nd.rows, tag="seg_sum2_codes")
+            else:
+                S0 = ops.seg_sum_raw(enc0, index.in_ptr, index.in_ent, N, None, True, -1.0, 1.0)    # [N, 2 Kpad] = [in | out]
             # S = [S0_in W0 | S0_out W0] is never built:  S Bn = S0_in (W0 Bn_in) + S0_out (W0 Bn_out), two K-column products
             Kp = enc0.size(1)
             vcodes_f = l0.venc is not None
