@@ -388,7 +388,8 @@ constexpr int kSmallK = 16;
 constexpr int kSmallRows = 4;                                 // rows in flight per wave (the loop is one memory round trip per batch)
 struct SmallKArgs { const float *X; int64_t ldx; int K; const float *D; int64_t ldd; const float *gate; int64_t R; float *partial;
                     int ncols; const float *D2; int64_t ldd2;      // blockIdx.y = column block j: D[:, jH:(j+1)H], or D2 for j == ncols
-                    const uint32_t *rowmask; };                    // bit r of rowmask[t] == 0: row 32 t + r of X is all zeros (or its gate is 0): its D rows are not fetched
+                    const uint32_t *rowmask;                       // bit r of rowmask[t] == 0: row 32 t + r of X is all zeros (or its gate is 0): its D rows are not fetched
+                    const int32_t *list, *count; };                // the rows to add, ascending (dmp_kept_rows), *count of them: a batch is then kSmallRows LIVE rows
 
 // VW = H / 64 values per lane: 2 (H = 128, one float2 per lane) or 1 (H = 64)
 template <int VW> struct LaneVec { float v[VW]; };
@@ -424,15 +425,17 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   LaneVec<VW> d[kRows], dn[kRows];
   float mine[kRows], minen[kRows];
   static_assert(32 % kSmallRows == 0, "a batch of rows lies inside one mask word");
+  const int64_t limit = p.list ? (int64_t)*p.count : p.R;  // positions of the list / rows
   auto load_batch = [&](int64_t r0, LaneVec<VW> (&dd)[kRows], float (&mm)[kRows]) {
     // the batch's mask bits from ONE word; a dead row (or one past the end) loads row 0 of D instead of its own -- one cached
     // line, no traffic, and no branch around the load: a wave-uniform condition around a load is a scalar branch, a basic block
     // and a wait per row (finding (t) of DESIGN 8); its products are skipped below
-    const uint32_t word = (p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
+    const uint32_t word = (!p.list && p.rowmask && r0 < p.R) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      const int64_t r = r0 + u;                             // wave-uniform
-      const bool ok = r < p.R;
+      const int64_t q = r0 + u;                             // wave-uniform: a row, or a position of the list
+      const bool ok = q < limit;
+      const int64_t r = p.list ? (int64_t)p.list[ok ? q : (limit > 0 ? limit - 1 : 0)] : q;      // (clamped: the load is issued either way)
       const bool live = ok && ((word >> u) & 1u);
       dd[u] = lane_load<VW>(Dj + (live ? r : (int64_t)0) * ldj, lane);
       // one load instruction for both: lanes < K point into the row of X, lane K at the row's gate
@@ -443,13 +446,13 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
     }
   };
   int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * kRows;
-  if (r0 < p.R) load_batch(r0, d, mine);
-  for (; r0 < p.R; r0 += stride) {
+  if (r0 < limit) load_batch(r0, d, mine);
+  for (; r0 < limit; r0 += stride) {
     load_batch(r0 + stride, dn, minen);                     // rows past the end read as zeros
-    const uint32_t wcur = p.rowmask ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
+    const uint32_t wcur = (!p.list && p.rowmask) ? (p.rowmask[r0 >> 5] >> (r0 & 31)) : 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      if (r0 + u >= p.R || !((wcur >> u) & 1u)) continue;    // a masked row / a row past the end: all of its products are zero (wave-uniform)
+      if (r0 + u >= limit || !((wcur >> u) & 1u)) continue;  // a masked row / a row past the end: all of its products are zero (wave-uniform)
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[u]), K));
       const float scaled = mine[u] * g;                     // lane k: gate * X[r, k]
 #pragma unroll
@@ -781,9 +784,9 @@ static int dmp_smallk_atb_cols(const float *X, int64_t ldx, int K, const float *
   return dmp_smallk_atb_cols_masked(X, ldx, K, D, ldd, ncols, D2, ldd2, gate, nullptr, R, H, partial, stream);
 }
 
-int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
-                               int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
-                               void *stream) {
+static int smallk_atb_cols_impl(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                                int64_t ldd2, const float *gate, const uint32_t *rowmask, const int32_t *list, const int32_t *count,
+                                int64_t R, int H, float *partial, void *stream) {
   DMP_ROW_CHECK(R >= 0 && K > 0 && partial && ncols >= 0 && ncols + (D2 ? 1 : 0) >= 1 && ncols <= 8);
   if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
   const int nblk = ncols + (D2 ? 1 : 0);
@@ -791,7 +794,7 @@ int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *
   DMP_ROW_CHECK(X && (D || ncols == 0) && ldx >= K && (ncols == 0 || ldd >= (int64_t)ncols * H) && (!D2 || ldd2 >= H));
   if (ldd % 2 || ldd2 % 2 || (reinterpret_cast<uintptr_t>(D) & 7u) || (reinterpret_cast<uintptr_t>(D2) & 7u) || !ok16(partial))
     return DMP_ERR_UNSUPPORTED;
-  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial, ncols, D2, ldd2, rowmask};
+  SmallKArgs p{X, ldx, K, D, ldd, gate, R, partial, ncols, D2, ldd2, rowmask, list, count};
   hipStream_t st = (hipStream_t)stream;
   switch (K) {   // K is a compile-time constant of the kernel: the accumulators live in registers
     case 1: launch_smallk<1>(p, H, st); break;   case 2: launch_smallk<2>(p, H, st); break;
@@ -804,6 +807,18 @@ int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *
     case 15: launch_smallk<15>(p, H, st); break; default: launch_smallk<16>(p, H, st); break;
   }
   return check_launch();
+}
+
+int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                               int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
+                               void *stream) {
+  return smallk_atb_cols_impl(X, ldx, K, D, ldd, ncols, D2, ldd2, gate, rowmask, nullptr, nullptr, R, H, partial, stream);
+}
+
+int dmp_smallk_atb_cols_rows(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                             int64_t ldd2, const int32_t *list, const int32_t *count, int64_t R, int H, float *partial, void *stream) {
+  if (!list || !count) return DMP_ERR_BAD_ARG;
+  return smallk_atb_cols_impl(X, ldx, K, D, ldd, ncols, D2, ldd2, nullptr, nullptr, list, count, R, H, partial, stream);
 }
 
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate, int64_t R, int H,

@@ -832,10 +832,12 @@ def smallk_embed(x, W, gate=None, out=None, H=None):
     return out
 
 
-def smallk_atb_cols(x, d, d2=None, out=None, H=None, mask=None):
+def smallk_atb_cols(x, d, d2=None, out=None, H=None, mask=None, rows=None):
     """``x^T [d | d2]`` per block of 128 (or 64: one block) columns -> [blocks, K, H]: ``smallk_atb`` over the column blocks
     of ``d`` [R, ncols H] and one more matrix ``d2`` [R, H] in ONE launch.  ``mask`` (uint32 words, ``gate_row_mask``, aligned
-    to x's first row): the rows of ``d`` / ``d2`` whose row of ``x`` is known to be all zeros are not fetched."""
+    to x's first row): the rows of ``d`` / ``d2`` whose row of ``x`` is known to be all zeros are not fetched.  ``rows`` =
+    ``(list, count)`` (``kept_rows`` relative to x's first row) instead of ``mask``: the launch walks the list -- every batch of
+    rows is live rows; a row outside the list must be a zero row of ``x``."""
     lib = _lib.load()
     R, K = x.shape
     C = d.size(1)
@@ -847,9 +849,14 @@ def smallk_atb_cols(x, d, d2=None, out=None, H=None, mask=None):
     if out is None:
         out = torch.empty((nblk, K, H), dtype=torch.float32, device=d.device)
     with _lib.timed("smallk_atb[K=%d,R=%d]", (K, R), 4 * (nblk * H + K + 1) * R):
-        check(lib.dmp_smallk_atb_cols_masked(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2),
-                                             d2.stride(0) if d2 is not None else 0, None, ptr(mask), R, H, ptr(part), stream_ptr()),
-              "dmp_smallk_atb_cols")
+        if rows is not None:
+            check(lib.dmp_smallk_atb_cols_rows(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2),
+                                               d2.stride(0) if d2 is not None else 0, ptr(rows[0]), ptr(rows[1]), R, H, ptr(part), stream_ptr()),
+                  "dmp_smallk_atb_cols_rows")
+        else:
+            check(lib.dmp_smallk_atb_cols_masked(ptr(x), x.stride(0), K, ptr(d), d.stride(0), ncols, ptr(d2),
+                                                 d2.stride(0) if d2 is not None else 0, None, ptr(mask), R, H, ptr(part), stream_ptr()),
+                  "dmp_smallk_atb_cols")
     for j in range(nblk):
         reduce_partials(part[j], out[j].view(-1))
     return out
@@ -1005,6 +1012,7 @@ def node_rows(index, v_gate, H):
 # beside the rest of its backward +1 %, the first layer's pass over dPre / dZn beside the node side's short launches +0.7 %, the first
 # layer's input rows (a 119 MB store) on a second side lane beside the layer's first launches +0.6 %.  The side stream carries the small
 # index builds only.)
+USE_SMALLK_LIST = True      # the first layer's node-code weight gradient over the kept nodes' list (40 -> 30 us)
 S0_KEPT_ROWS = True         # the first layer's code sums over the kept nodes' rows only (15 -> 10 us)
 USE_L0_NODE_FWD = True     # the first layer's node side from the label codes as one pass (csrc/dmp_layer0.hip::l0_node_fwd_k)
 L0_NODE_MAX_COLS = 40      # code columns per node row that kernel holds in registers: VK + 2 K0
@@ -1790,9 +1798,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                     vmask = getattr(l0, "venc_mask", None)
                     for t, (n0, n1) in l0.vtables(N):
                         # (the packed node codes carry the node gate: a gated-out node's code row is all zeros)
+                        # (one table over all nodes under the node gate: the kept nodes' list -- a node outside it has a zero code row)
+                        klist = nd.rows if (nd is not None and n0 == 0 and n1 == N and USE_SMALLK_LIST) else None
                         smallk_atb_cols(l0.venc[n0:n1, :VK], dXP[n0:n1], dxn[n0:n1] if ctx.residual else None,
                                         Yn[:, t * VK:(t + 1) * VK], H,
-                                        mask=vmask[n0 // 32:] if (vmask is not None and n0 % 32 == 0) else None)
+                                        mask=vmask[n0 // 32:] if (klist is None and vmask is not None and n0 % 32 == 0) else None, rows=klist)
                 elif one_launch:
                     vm = binary_gate_mask(ctx.v_gate)
                     if nd is not None and USE_NODE_TILE_ATB:     # over the kept nodes' tiles

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 72
+#define DMP_ABI_VERSION 73
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -650,6 +650,10 @@ int dmp_smallk_embed_cols(const float *X, int64_t ldx, int K, const float *W, in
 int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
                                int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
                                void *stream);
+/* ... over a LIST of rows (dmp_kept_rows: ascending row ids, their number in device memory; R = the list's capacity): a batch is
+ * then four LIVE rows -- the masked form spends a batch's slots on its dead rows too (three of five at the benchmark's node gate). */
+int dmp_smallk_atb_cols_rows(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
+                             int64_t ldd2, const int32_t *list, const int32_t *count, int64_t R, int H, float *partial, void *stream);
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);

@@ -296,3 +296,25 @@ def test_layer0_node_pass_against_fp64(n, n0, vk, k0, h, masked, slope, listed, 
     h1b, Pb = th.full_like(h1, -7.0), th.full_like(P, -7.0)
     fused.l0_node_fwd(venc, vk, S0, k0, kp, W, bias, slope, mask, n0, n, h, h1b, Pb, rows=klist)
     assert th.equal(h1, h1b) and th.equal(P, Pb)          # repeatable
+
+
+@pytest.mark.parametrize("R,K,h,blocks", [(1, 3, 128, 1), (777, 16, 128, 3), (73728, 16, 128, 3), (5001, 10, 64, 1)])
+def test_smallk_atb_over_a_row_list_equals_the_masked_form(R, K, h, blocks, gpu):
+    """``dmp_smallk_atb_cols_rows``: ``x^T [d | d2]`` over the kept rows' list against the masked walk over all rows and fp64."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(R + K)
+    keep = (th.rand(R, generator=gen) < 0.4).to(gpu)
+    x = ((th.rand(R, (K + 3) // 4 * 4, generator=gen) < 0.5).float().to(gpu) * keep.view(-1, 1).float())[:, :K]
+    d = th.randn(R, blocks * h, generator=gen).to(gpu)
+    d2 = th.randn(R, h, generator=gen).to(gpu)
+    d[~keep] = float("nan")                                   # a row outside the list / under the mask is never fetched
+    d2[~keep] = float("nan")
+    mask = fused.gate_row_mask(keep.float())
+    lst, cnt = fused.kept_rows(mask, 0, R, tiles=True)
+    a = fused.smallk_atb_cols(x, d, d2, None, h, mask=mask)
+    b = fused.smallk_atb_cols(x, d, d2, None, h, rows=(lst, cnt[0:1]))
+    dz, d2z = th.where(keep.view(-1, 1), d, th.zeros_like(d)).double(), th.where(keep.view(-1, 1), d2, th.zeros_like(d2)).double()
+    ref = th.stack([x.double().t() @ dz[:, j * h:(j + 1) * h] for j in range(blocks)] + [x.double().t() @ d2z])
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool(th.isfinite(a).all()) and bool(th.isfinite(b).all())
+    assert float((a.double() - ref).abs().max()) <= tol and float((b.double() - ref).abs().max()) <= tol
