@@ -383,7 +383,7 @@ def build_step(cfg, shard, device, world=1, collective=False):
     return step, model
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 # the two scatter-add launches as rocprofv3 names them; first the forms that leave out the rows a 0 / 1 edge gate wiped (what
 # the step runs under a ScalarFilter gate), then the forms that read every row
 SEG_IN = ("seg_sum_vec<32, true, false, true, 0, 256>",     # flag-split segment sum over the CSR by destination (forward; under a 0 / 1 gate: over the kept edges' CSR)
@@ -393,7 +393,12 @@ SEG_INC = ("seg_sum_vec<32, true, false, true, 1, 256>",     # backward of the e
            "seg_acc_graphs_k<128, false", "seg_acc_graphs_k<128>")
 
 
-def committed_profile(n_rows, n_edges, H):
+# ... and in the all-rows step (`bench.py --filter-net None`, the `gate_dense` object): no row list, no mask
+SEG_IN_DENSE = ("seg_sum_vec<32, true, false, true, 0, 256>",)
+SEG_INC_DENSE = ("seg_acc_graphs_k<128, false", "seg_acc_graphs_k<128>", "seg_sum_vec<32, true, false, true, 1, 256>")
+
+
+def committed_profile(n_rows, n_edges, H, variant=""):
     """What the committed profiles of this round say about the two scatter-add launches, if they were taken at this launch
     shape and with this build of the kernels (``profiles/<round>_profile_meta.json``: rows, edges, H, lib_srchash): the rocprofv3 ``--kernel-trace --stats`` average duration
     (``<round>_bench_kernel_stats.csv``) and the PMC traffic per launch (``<round>_pmc_h128.json``: FETCH_SIZE and WRITE_SIZE
@@ -415,9 +420,9 @@ def committed_profile(n_rows, n_edges, H):
         return out
     try:
         import csv
-        with open(base + "_bench_kernel_stats.csv") as f:
+        with open(base + "_bench%s_kernel_stats.csv" % variant) as f:
             rows = list(csv.DictReader(f))
-        for tag, names in (("in", SEG_IN), ("inc", SEG_INC)):
+        for tag, names in (("in", SEG_IN_DENSE if variant else SEG_IN), ("inc", SEG_INC_DENSE if variant else SEG_INC)):
             for name in names:                                  # the first form the profile holds
                 hit = [r for r in rows if name in r["Name"]]
                 if hit:
@@ -427,9 +432,9 @@ def committed_profile(n_rows, n_edges, H):
     except (OSError, ValueError, KeyError):
         pass
     try:
-        with open(base + "_pmc_h128.json") as f:
+        with open(base + "_pmc%s_h128.json" % variant) as f:
             k = json.load(f)["kernels"]
-        for tag, names in (("in", SEG_IN), ("inc", SEG_INC)):
+        for tag, names in (("in", SEG_IN_DENSE if variant else SEG_IN), ("inc", SEG_INC_DENSE if variant else SEG_INC)):
             for name in names:
                 hit = [v for key, v in k.items() if name in key]
                 if hit:
@@ -462,6 +467,32 @@ def gate_summary(g, cfg, step, H):
         out["roofline_bwd"] = seg_roofline(k, "dmp::seg_acc_graphs_k at N=%d rows, E=%d edge rows" % (uN, uE), k["bytes"],
                                            4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), none)
     return out
+
+
+def dense_summary(d, H, uN, uE, nB):
+    """The `gate_dense` object of the line: the all-rows step with its OWN ``roofline`` / ``roofline_bwd`` objects (the two
+    scatter-add launches over every row: HIP-event times from eager steps of that model, the committed rocprof duration of
+    ``bench.py --filter-net None`` beside them when the profile is of this build), its own kernel table and MFMA table."""
+    kern = d.pop("kern")
+    prof = committed_profile(uN, uE, H, variant="_gate_dense")
+    k = kern.get("seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, uE))
+    if k:
+        d["roofline"] = seg_roofline(k, "dmp::seg_sum_vec<32,split,remap> (DMPLayer node aggregation by destination, every row: N=%d rows, "
+                                     "E=%d edge rows, H=%d)" % (uN, uE, H), 4 * H * (uE + 2 * uN) + 4 * uE + 4 * (uN + 1),
+                                     4 * H * (uE + uN) + 4 * uE + 4 * (uN + 1), prof["in"])
+    kg, ki = "seg_sum2_graphs[H=%d,rows=%d,E=%d]" % (H, uN, uE), "seg_sum2[H=%d,rows=%d,ent=%d]" % (H, uN, 2 * uE)
+    if kg in kern:
+        d["roofline_bwd"] = seg_roofline(kern[kg], "dmp::seg_acc_graphs_k (one pass over every edge row, both endpoints' sums in registers; "
+                                         "gradient of the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H),
+                                         4 * H * (uE + 2 * uN) + 8 * uE + 16 * (nB + 1), 4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"])
+    elif ki in kern:
+        d["roofline_bwd"] = seg_roofline(kern[ki], "dmp::seg_sum_vec<32,split,remap,incidence> (every edge row under both endpoints; gradient of "
+                                         "the gathered node projections: N=%d rows, E=%d edge rows, H=%d)" % (uN, uE, H), kern[ki]["bytes"],
+                                         4 * H * (uE + 2 * uN) + 9 * uE + 8 * (uN + 1), prof["inc"])
+    d["mfma_kernels"] = mfma_rooflines(kern, H, uE, None)
+    d["kernels"] = {n: {"avg_us": round(v["avg_us"], 2), "gbps": round(v["gbps"], 1), "launches": v["launches"], "bytes": int(v["bytes"])}
+                    for n, v in sorted(kern.items())}
+    return d
 
 
 def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, all_own=None, all_survey=None, skipped_nodes=0):
@@ -577,6 +608,7 @@ def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B, Ein=None):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # ... dense bf16 MFMA (16 x the f32-input rate); never the 2:1-sparsity figure
 
 
 def mfma_rooflines(kern, H, E, Ek=None):
@@ -593,12 +625,16 @@ def mfma_rooflines(kern, H, E, Ek=None):
             rows = Ek if (Ek is not None and base.endswith("_typed")) else E
             tf = products[base] * 2.0 * rows * H * H / (v["avg_us"] * 1e-6) / 1e12
             # round 3: the class-typed kernels multiply on the bf16 pipe (three bf16 pieces per fp32 operand, six piece
-            # products: fp32-accurate, 6/16 of the f32 form's matrix cycles); "tflops" stays the fp32-equivalent rate and
-            # "frac" its ratio to the F32-input MFMA peak, for comparison with earlier rounds -- their bound is HBM
+            # products: fp32-accurate, 6/16 of the f32 form's matrix cycles) -- their bound is HBM
+            # (the bf16x6 kernels run on the bf16 pipe -- their matrix work is SIX bf16 piece products per
+            # fp32 product, priced against the dense bf16 peak; "tflops" stays the fp32-equivalent rate of the product)
             x6 = base.endswith("_typed")
-            out.setdefault(base, {})["rows"] = int(rows)
-            out[base] = {"rows": int(rows), "avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                         "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "arithmetic": "bf16x6 (fp32-accurate)" if x6 else "f32 MFMA"}
+            peak = MFMA_BF16_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
+            pipe_tf = 6.0 * tf if x6 else tf
+            out[base] = {"rows": int(rows), "avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "pipe_tflops": round(pipe_tf, 1),
+                         "frac": round(pipe_tf / peak, 4), "bound": "mfma", "peak": peak,
+                         "arithmetic": "bf16x6 (fp32-accurate): 6 bf16 piece products per fp32 product, frac = 6 x tflops / the dense bf16 MFMA peak"
+                                       if x6 else "f32 MFMA"}
             # flops per byte fall with H (2 H^2 flops against ~8-12 H bytes per row): at H = 64 the same kernels sit nearer
             # the HBM roof than the MFMA roof -- both fractions are reported, "bound" names the nearer roof
             hbm_frac = v["gbps"] / 8000.0
@@ -821,6 +857,10 @@ def main():
                     "timed steps of 1024 pairs, median: several minutes) -> cpu_baseline_b1024")
     ap.add_argument("--strict-rates", action="store_true", help="a rate of the line above the HBM peak (bench.check_rates) ends the run instead of being reported in the line")
     ap.add_argument("--no-gate-dense", action="store_true", help="skip the extra un-timed steps behind the gate_dense object")
+    ap.add_argument("--filter-net", default="ScalarFilter", choices=("ScalarFilter", "None"),
+                    help="None: the ALL-ROWS step as the timed step (the model built without its filter net: no 0 / 1 gate, every node "
+                         "and edge row live in every layer -- what the reference's one-label ER / Regular datasets give, README.md:22-69); "
+                         "for profiling the `gate_dense` control as the headline of its own line")
     ap.add_argument("--no-all-outputs", action="store_true", help="skip the extra un-timed steps behind all_outputs_ms_per_step")
     ap.add_argument("--extended-steps", type=int, default=200,
                     help="further steps after the timed region (same launch mode, one event record each) behind `steps_extended`; 0 = none")
@@ -928,7 +968,7 @@ def main():
     if auto_graph:
         args.graph = True
     cfg = dict(CFG if args.workload == 2 else CFG4, batch=args.batch, act=args.act, emb=args.emb, micro_batches=args.micro_batches,
-               hid=args.hid, graph=args.graph, gate_compact=args.gate_compact)
+               hid=args.hid, graph=args.graph, gate_compact=args.gate_compact, filter=args.filter_net)
     from dualmessagepassing_amd import _lib
     from dualmessagepassing_amd.tuning import enable_tuned_gemms
     tuned = False if (args.no_tuned_gemms or os.environ.get("PYTORCH_TUNABLEOP_ENABLED")) else enable_tuned_gemms()
@@ -1139,7 +1179,7 @@ def main():
             gate_line = dict(info, ms_per_step=round(g_ms, 3), value=round(cfg["batch"] / g_ms * 1e3, 1), kern=kern_c)
         step.set_gate_compact(False)
     dense_line = None
-    if not multi and step.micro_batches == 1 and args.workload == 2 and not args.no_gate_dense and not args.gate_compact:
+    if not multi and step.micro_batches == 1 and args.workload == 2 and not args.no_gate_dense and not args.gate_compact and args.filter_net == "ScalarFilter":
         # the CONTROL for everything the 0 / 1 gates buy: the same step, same launch mode, with the model built WITHOUT its
         # filter net (filter_net = "None": no gate, every node and edge row of the batch is live in every layer) -- what the
         # step costs when the data gate nothing out.  Reported beside the headline, never as `value`.
@@ -1160,10 +1200,41 @@ def main():
         step_d.finish()
         barrier()
         d_ms = (time.perf_counter() - td) / max(args.steps, 1) * 1e3
+        # ... and its own scatter-add launches (HIP events inside eager steps, as for the headline) and kernel table: the
+        # all-rows step is a first-class number (the reference's ER / Regular datasets have ONE label: nothing is gated there)
+        _lib.timer.reset()
+        _lib.timer.only = "seg_sum2"
+        _lib.timer.enabled = True
+        for _ in range(3):
+            step_d()
+        step_d.finish()
+        barrier()
+        _lib.timer.reset()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step_d()
+        step_d.finish()
+        barrier()
+        d_eager_ms = (time.perf_counter() - te) / max(args.steps, 1) * 1e3
+        kern_d = _lib.timer.summary()
+        _lib.timer.reset()
+        _lib.timer.only = None
+        side_was, _side_d = None, __import__("dualmessagepassing_amd.side", fromlist=["side"])
+        side_was, _side_d.USE_SIDE_STREAM = _side_d.USE_SIDE_STREAM, False
+        try:
+            for _ in range(3):
+                step_d()
+            step_d.finish()
+        finally:
+            _side_d.USE_SIDE_STREAM = side_was
+        for name, v in _lib.timer.summary().items():
+            kern_d.setdefault(name, v)
+        _lib.timer.enabled = False
         dense_line = {"what": "same step, same launch mode, the model built with filter_net = 'None': no ScalarFilter gate, every node "
-                              "and edge row live in every layer (the step when the data gate nothing out)",
+                              "and edge row live in every layer (the step when the data gate nothing out: the reference's one-label "
+                              "ER / Regular datasets, SubgraphCountingMatching/README.md:22-69)",
                       "ms_per_step": round(d_ms, 3), "value": round(cfg["batch"] / d_ms * 1e3, 1), "unit": "pairs/s",
-                      "kept_fraction_of_rows": 1.0}
+                      "eager_ms_per_step": round(d_eager_ms, 3), "kept_fraction_of_rows": 1.0, "kern": kern_d}
         del run_d, step_d, model_d
     _lib.timer.reset()
     _lib.timer.only = None
@@ -1279,6 +1350,8 @@ def main():
                                              "avg_us": round(plain[key_], 2), "bytes_per_launch": int(sv_), "bytes_own": int(own_),
                                              "frac": round(sv_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4),
                                              "frac_own_bytes": round(own_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4)}
+        if dense_line is not None:
+            dense_line = dense_summary(dense_line, H, uN, uE, 2 * mb)
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -1304,7 +1377,7 @@ def main():
             "per_rank": per_rank,
             "arithmetic": "fp32 storage and accumulation; dense products on the f32-input MFMA except the class-typed edge kernels (fp32 operands as 3 bf16 pieces, 6 piece products per partial product: fp32-accurate, parity tests at the fp32 tolerances; DMP_EXACT_FP32=1 switches them back)",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
-                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, ScalarFilter, "
+                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, " + ("ScalarFilter" if cfg.get("filter", "ScalarFilter") == "ScalarFilter" else "NO filter net: every row live") + ", "
                                    "3 shared DMPLayers, SumPredictNet node+edge heads), activation %s, hid=%d, fp32; a new batch "
                                    "(fresh size / flag tensors) every step"
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],

@@ -128,7 +128,7 @@ SIGNATURES = {
                                     c_double, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step_dev": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                    c_ptr, c_ptr, c_int, c_ptr]),
-    "dmp_adamw_step_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_double, c_double,
+    "dmp_adamw_step_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_double, c_double,
                                         c_double, c_double, c_ptr, c_int, c_ptr]),
     "dmp_adamw_step_guarded": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_double, c_double, c_double, c_double,
                                        c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr]),
@@ -191,7 +191,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 73
+ABI_VERSION = 74
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)
@@ -222,11 +222,16 @@ def load(build_if_missing=True):
             except Exception as e:
                 if not os.path.exists(path):
                     raise
-                # (a box without hipcc runs the library it was given -- but a STALE library after a failed build must not pass
-                # silently: it once hid a compile error behind green tests)
+                # A failed build leaves the library of an EARLIER source state in place.  It is loaded only when its content
+                # hash still matches the sources (a box without a compiler that was handed a current library); a STALE one is
+                # refused -- it once hid a compile error behind green tests -- unless DMP_ALLOW_STALE_LIB=1 asks for it.
+                stale = _build._stale()
+                if stale and os.environ.get("DMP_ALLOW_STALE_LIB") != "1":
+                    raise DmpError("building libdmp_hip.so failed (%s) and the existing %s is STALE against the sources: refusing "
+                                   "to run old kernels (DMP_ALLOW_STALE_LIB=1 overrides)" % (str(e).splitlines()[0][:300], path)) from e
                 import sys
                 print("dualmessagepassing_amd: building libdmp_hip.so failed (%s); loading the existing %s, which %s" %
-                      (str(e).splitlines()[0][:200], path, "is STALE against the sources" if _build._stale() else "matches the sources"),
+                      (str(e).splitlines()[0][:200], path, "is STALE against the sources (DMP_ALLOW_STALE_LIB=1)" if stale else "matches the sources"),
                       file=sys.stderr)
         if not os.path.exists(path):
             raise DmpError("libdmp_hip.so is missing (%s); run __graft_entry__.build()" % path)

@@ -263,7 +263,8 @@ __global__ void adamw_tick(double *state, int32_t *veto, int32_t mask) {
 }
 
 // per-segment step counts (state[2 + s]) and step sizes: one block; the veto logic of adamw_tick first
-struct SegTick { double *state; float *tab; int P; double beta1, beta2; int32_t *veto; int32_t mask; uint64_t live[DMP_ADAMW_MAX_SEGMENTS / 64]; int all; };
+struct SegTick { double *state; float *tab; int P; double beta1, beta2; int32_t *veto; int32_t mask; uint64_t live[DMP_ADAMW_MAX_SEGMENTS / 64]; int all;
+                 const float *live_dev; };   // live_dev [P] (device, or NULL): != 0 = the tensor has a gradient on SOME rank (dp.FlatGradSync)
 __global__ __launch_bounds__(kBlock) void adamw_tick_segments(const SegTick t) {
   __shared__ int drop_s;
   if (threadIdx.x == 0) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void adamw_tick_segments(const SegTick t) {
   __syncthreads();
   const double lr = t.state[1];
   for (int s = threadIdx.x; s < t.P; s += kBlock) {
-    const bool live = t.all || ((t.live[s >> 6] >> (s & 63)) & 1ull);
+    const bool live = t.live_dev ? t.live_dev[s] != 0.f : (t.all || ((t.live[s >> 6] >> (s & 63)) & 1ull));
     if (live && !drop_s) {
       const double step = t.state[2 + s] + 1.0;
       t.state[2 + s] = step;
@@ -980,9 +981,9 @@ int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *e
 }
 
 int dmp_adamw_step_segments(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
-                            int64_t n, double *state, const int64_t *seg_off, int P, const uint64_t *live, float *seg_tab,
-                            double beta1, double beta2, double eps, double weight_decay, int32_t *veto, int32_t veto_mask,
-                            void *stream) {
+                            int64_t n, double *state, const int64_t *seg_off, int P, const uint64_t *live, const float *live_dev,
+                            float *seg_tab, double beta1, double beta2, double eps, double weight_decay, int32_t *veto,
+                            int32_t veto_mask, void *stream) {
   DMP_ROW_CHECK(n >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0);
   if (!state || (reinterpret_cast<uintptr_t>(state) & 7u) || !seg_off || !seg_tab || P < 1 || P > DMP_ADAMW_MAX_SEGMENTS)
     return DMP_ERR_BAD_ARG;
@@ -990,7 +991,7 @@ int dmp_adamw_step_segments(float *param, const float *grad, float *exp_avg, flo
   DMP_ROW_CHECK(param && grad && exp_avg && exp_avg_sq);
   if (!ok16(param) || !ok16(grad) || !ok16(exp_avg) || !ok16(exp_avg_sq) || !ok16(max_exp_avg_sq)) return DMP_ERR_UNSUPPORTED;
   SegTick t;
-  t.state = state; t.tab = seg_tab; t.P = P; t.beta1 = beta1; t.beta2 = beta2; t.veto = veto; t.mask = veto_mask; t.all = live ? 0 : 1;
+  t.state = state; t.tab = seg_tab; t.P = P; t.beta1 = beta1; t.beta2 = beta2; t.veto = veto; t.mask = veto_mask; t.all = live ? 0 : 1; t.live_dev = live_dev;
   for (int w = 0; w < DMP_ADAMW_MAX_SEGMENTS / 64; ++w) t.live[w] = (live && w < (P + 63) / 64) ? live[w] : 0ull;
   AdamArgs a;
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq; a.n = n;

@@ -14,6 +14,7 @@
 // panel W_g in registers (rebuilt only when the workgroup's contiguous tile range crosses into the
 // next class), buffer addressing with per-lane offsets, LDS-only barriers, three-deep prefetch
 // (ids of tile k+3, rows of tile k+2, staging of tile k+1 while tile k is computed).
+#include <cstdlib>
 #include <type_traits>
 
 #include "dmp_mfma_common.h"
@@ -523,6 +524,8 @@ __global__ __launch_bounds__(TypedGeom<H>::kThreads, 2) void mfma_typed_jobs(Typ
 }
 
 inline unsigned typed_blocks(int64_t tiles_bound, int per_cu = 3) {
+  static const int dev_per_cu = [] { const char *e = getenv("DMP_DEV_TYPED_PER_CU"); return e ? atoi(e) : 0; }();   // development probe
+  if (dev_per_cu > 0) per_cu = dev_per_cu;
   const int64_t cap = 256 * per_cu;
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
 }

@@ -58,9 +58,18 @@ class FlatGradSync:
         for p in params:
             self.offsets.append(off)
             off += (p.numel() + 3) // 4 * 4
-        self.flat = torch.zeros(off, device=dev, dtype=dt)
+        # the payload of the all-reduce: the flat gradient, then one 0 / 1 indicator per parameter tensor ("this rank produced
+        # a gradient for it this step").  Summed with the gradient, the indicators tell every rank the UNION of the live
+        # parameters, so that all replicas step the same set (a tensor that is dead on this rank's batch but live on another's
+        # holds a non-zero average after the sum: an optimizer that skipped it here would let the replicas drift apart)
+        P = len(params)
+        self._buf = torch.zeros(off + (P + 3) // 4 * 4, device=dev, dtype=dt)
+        self.flat = self._buf[:off]
+        self.live = self._buf[off:off + P]
+        self.live.fill_(1.0)
         for p, off in zip(params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+        _warn_batch_norm(module, self)
 
     def flatten_parameters(self):
         """Move every parameter's storage into one contiguous buffer (each ``p.data`` becomes a view of
@@ -79,11 +88,17 @@ class FlatGradSync:
             self.master._dmp_seg = (torch.tensor(self.offsets + [int(self.flat.numel())], dtype=torch.int64, device=self.flat.device),
                                     len(self.params))
             self.master._dmp_live_params = None
+            self.master._dmp_live_dev = self.live if self.collective else None
         return self.master
 
     @property
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def collective(self):
+        """Does ``sync()`` issue a collective (several ranks, or a forced one-rank group)?"""
+        return self.world > 1 or (self.force_collective and dist.is_available() and dist.is_initialized())
 
     def zero(self):
         self.flat.zero_()
@@ -138,10 +153,27 @@ class FlatGradSync:
     def _note_live(self, live):
         """torch.optim.AdamW (the reference's optimizer, train.py:1231) skips parameters whose ``.grad`` is None: no weight
         decay, no moment update.  The flat optimizer sees one parameter; it is told which contiguous runs of the buffer
-        belong to parameters that received a gradient this step (None = all of it)."""
+        belong to parameters that received a gradient this step (None = all of it).
+
+        With a collective (``world > 1``) the set must be the same on every rank: this rank's 0 / 1 indicators go into the
+        tail of the all-reduce's payload (``self.live``, a device-to-device copy of a cached table: no host sync, replays),
+        the optimizer reads the summed indicators from the device (``dmp_adamw_step_segments(live_dev=...)``) and the
+        host-side set is not used.  An optimizer without per-tensor segments (more than 1024 tensors) treats every tensor as
+        live then -- the same on every rank, which is what keeps the replicas together."""
+        if self.collective:
+            P = len(self.params)
+            key = None if live is None else tuple(live)
+            tabs = self.__dict__.setdefault("_live_tabs", {})
+            tab = tabs.get(key)
+            if tab is None:
+                host = torch.ones(P) if key is None else torch.zeros(P).index_fill_(0, torch.tensor(list(key), dtype=torch.int64), 1.0)
+                tab = tabs[key] = host.to(self.live.device, self.live.dtype)
+            self.live.copy_(tab)
+            live = None
         master = getattr(self, "master", None)
         if master is None:
             return
+        master._dmp_live_dev = self.live if self.collective else None
         master._dmp_live_params = None if live is None else tuple(live)
         if live is None:
             master._dmp_live_runs = None
@@ -176,7 +208,7 @@ class FlatGradSync:
                    "dmp_pack_segments")
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1 or (self.force_collective and dist.is_available() and dist.is_initialized()):
+        if self.collective:
             if getattr(self, "master", None) is not None:
                 dist.broadcast(self.master.data, src=src, group=self.group)
                 return
@@ -189,11 +221,12 @@ class FlatGradSync:
         applies the average -- whatever is enqueued in between (the next batch's collate and index build, which do not
         depend on the parameters) overlaps the collective."""
         w = self.world
-        if w == 1 and not (self.force_collective and dist.is_available() and dist.is_initialized()):
+        if not self.collective:
             return None
+        # (gradient + live indicators: one message; the indicators stay sums -- any value above 0 means "live somewhere")
         if async_op:
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             self.flat.div_(w)
         return None
@@ -203,6 +236,20 @@ class FlatGradSync:
             work.wait()
             if self.average:
                 self.flat.div_(self.world)
+
+
+def _warn_batch_norm(module, sync):
+    """BatchNorm couples the pairs of a batch (``rep_dmpnn_batch_norm True``, config.py:201-207): under data
+    parallelism every rank normalises with the statistics of ITS shard (the running statistics are not exchanged either), so
+    a multi-rank run is not the single-device run of the global batch.  Said once per process, where the collective is set up."""
+    if not sync.collective or sync.world < 2:
+        return
+    bn = [n for n, m in module.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    if bn:
+        import warnings
+        warnings.warn("FlatGradSync over %d ranks with BatchNorm modules (%s%s): statistics are PER SHARD -- each rank normalises "
+                      "with its own pairs and keeps its own running statistics; the result differs from the single-device run of "
+                      "the global batch" % (sync.world, ", ".join(bn[:3]), ", ..." if len(bn) > 3 else ""), RuntimeWarning, stacklevel=3)
 
 
 USE_SEGMENT_STEPS = True   # one AdamW step count per parameter tensor of a flat buffer
@@ -340,6 +387,10 @@ class FlatAdamW(torch.optim.Optimizer):
                     if not torch.cuda.is_current_stream_capturing():
                         self.sync_hyper()
                     live = getattr(p, "_dmp_live_params", None)
+                    live_dev = getattr(p, "_dmp_live_dev", None)      # a data-parallel run: the union over the ranks, on the device
+                    if live_dev is not None:
+                        _lib.require_gpu(live_dev)
+                        live = None
                     bits = None
                     if live is not None:
                         words = [0] * ((seg[1] + 63) // 64)
@@ -351,7 +402,8 @@ class FlatAdamW(torch.optim.Optimizer):
                         _lib.require_gpu(veto[0])
                     _lib.check(lib.dmp_adamw_step_segments(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                                            st["exp_avg_sq"].data_ptr(), _lib.ptr(st.get("max_exp_avg_sq")), p.numel(),
-                                                           dev.data_ptr(), seg[0].data_ptr(), seg[1], bits, tab.data_ptr(), b1, b2,
+                                                           dev.data_ptr(), seg[0].data_ptr(), seg[1], bits, _lib.ptr(live_dev),
+                                                           tab.data_ptr(), b1, b2,
                                                            group["eps"], group["weight_decay"],
                                                            None if veto is None else veto[0].data_ptr(), 0 if veto is None else veto[1],
                                                            _lib.stream_ptr()), "dmp_adamw_step_segments")
@@ -404,6 +456,28 @@ class FlatAdamW(torch.optim.Optimizer):
                                                   float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"],
                                                   _lib.stream_ptr()), "dmp_adamw_step")
         return loss
+
+
+def _drain_collectives():
+    """Before a stream capture: make sure no process group's watchdog still holds a work object.  RCCL's watchdog thread
+    polls the completion events of the collectives on its list; a poll that lands inside a stream capture fails in the
+    runtime and aborts the process (found by the one-rank RCCL run of round 5).  After ``torch.cuda.synchronize()`` every
+    collective is complete but stays listed until the watchdog's next pass: ``ProcessGroup._wait_for_pending_works`` blocks
+    until that list is EMPTY -- a condition, not a delay -- and with nothing listed the watchdog has nothing to poll while
+    the recording runs (the recording itself enqueues no collective: ``StepGraph`` functions are collective-free by contract,
+    the all-reduce sits between the replayed front and the optimizer)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    from torch.distributed import distributed_c10d as c10d
+    for pg in list(getattr(c10d._world, "pg_map", {}).keys()):
+        if "nccl" not in str(dist.get_backend(pg)):          # (gloo has no watchdog list: nothing polls events)
+            continue
+        wait = getattr(pg, "_wait_for_pending_works", None)
+        if wait is None:
+            raise RuntimeError("StepGraph: this torch build cannot drain a process group's pending work before a stream capture "
+                               "(ProcessGroup._wait_for_pending_works is missing); record the step before the first collective "
+                               "of the run, or run it eagerly")
+        wait()
 
 
 class StepGraph:
@@ -495,13 +569,7 @@ class StepGraph:
                 return self._eager(meta, tensors)
             static = [torch.empty_like(t).copy_(t) for t in tensors]
             torch.cuda.synchronize()
-            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-                # RCCL's watchdog thread polls the completion events of the collectives still on its list (every 100 ms); a
-                # poll that lands inside the stream capture below fails in the runtime and aborts the process (found by the
-                # one-rank RCCL run of round 5: one run in three).  Everything is complete after the synchronize above: give the
-                # watchdog two of its periods to retire its list, then record.  (At most ``max_shapes`` times per run.)
-                import time
-                time.sleep(0.25)
+            _drain_collectives()
             graph = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread polls events while we record: only THIS thread's calls are
             # policed then (torch's "thread_local" capture mode); a single process keeps the strict default

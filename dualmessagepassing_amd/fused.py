@@ -593,6 +593,11 @@ def gate_row_mask(gate):
         return hit[1]
     lib = _lib.load()
     R = gate.numel()
+    # (a miss on the caller's stream while index builds are in flight on the side stream: the gate itself may have been
+    # written THERE (dmpnn.prefetch_joint_indexes makes the union's gates inside its fork) -- order this stream behind that
+    # stage before reading it.  The prefetch normally builds this mask too and the call above returns its memo: no wait.)
+    from . import side
+    side.wait("erows")
     mask = torch.empty(((R + 31) // 32,), dtype=torch.int32, device=gate.device)
     check(lib.dmp_row_mask_bits(ptr(gate), R, ptr(mask), stream_ptr()), "dmp_row_mask_bits")
     try:

@@ -213,8 +213,8 @@ class PairDataset:
         (local endpoints, sizes, ids, labels, reversed flags), the graph batch's nine and ``counts [B, 1]``, and ``meta``
         = per side ``(total nodes, total edges, largest graph's nodes, largest graph's edges)`` as host ints.  Everything
         ``graphs_from_arrays`` then does happens on the device without a host sync (``dp.StepGraph`` records it).
-        ``pad`` (``pad_buckets``): the batch is extended to ``2 pad["batch"]`` pairs by INERT pairs -- pairs of label-0 graphs
-        whose sizes take the four totals up to a capacity level, and whose weight in the loss is zero (a last tensor,
+        ``pad`` (``pad_buckets``): the batch is extended to ``2 pad["batch"]`` pairs by INERT pairs -- pairs of one-label graphs
+        (pattern label 0, target label 1: the filter gates wipe the inert target rows) whose sizes take the four totals up to a capacity level, and whose weight in the loss is zero (a last tensor,
         ``weights [2 B, 1]``, is appended).  Pairs are
         independent in the model (block-diagonal batches, no BatchNorm), so the real pairs' predictions are unchanged and
         an inert pair, whose prediction carries no loss, adds exact zeros to every gradient: a ragged dataset then meets a
@@ -239,7 +239,13 @@ class PairDataset:
             gs = [self.samples[i][key] for i in indices]
             if pad is not None:
                 cn, ce = caps(key, level)
-                gs = gs + self._inert_graphs(tot[key], cn, ce, extra, pad[key])
+                # an inert TARGET graph carries a node / edge label its (label-0) inert pattern does not use: the filter gates
+                # (ScalarFilter: a target row is kept when its label occurs in the pattern) zero every one of its rows, so the
+                # gated kernels leave them out and a gate capacity calibrated on the real pairs holds for the padded batch too
+                # (label 0 on both sides kept every inert edge: ~3 x the real rows as live work, and with ``gate_compact`` every
+                # padded batch overflowed its capacity -- ADVICE r5).  One-label vocabularies have no such label: 0 there.
+                lab = (0, 0) if key == "pattern" else (1 if self.shape.get("n_vlabels", 1) > 1 else 0, 1 if self.shape.get("n_elabels", 1) > 1 else 0)
+                gs = gs + self._inert_graphs(tot[key], cn, ce, extra, pad[key], vlabel=lab[0], elabel=lab[1])
             cat = lambda k, dt=torch.int64: torch.from_numpy(np.concatenate([g[k] for g in gs])).to(dt).to(device)
             nn_ = np.array([g["num_nodes"] for g in gs], np.int64)
             ne_ = np.array([len(g["src"]) for g in gs], np.int64)
@@ -257,8 +263,8 @@ class PairDataset:
         return tuple(meta), tensors + [counts.unsqueeze(-1), weights.unsqueeze(-1)]
 
     @staticmethod
-    def _inert_graphs(tot, cap_n, cap_e, extra, largest=None):
-        """``extra`` label-0 graphs that take a side's node / edge totals ``tot`` up to ``(cap_n, cap_e)``: nodes dealt evenly
+    def _inert_graphs(tot, cap_n, cap_e, extra, largest=None, vlabel=0, elabel=0):
+        """``extra`` one-label graphs (node label ``vlabel``, edge label ``elabel``) that take a side's node / edge totals ``tot`` up to ``(cap_n, cap_e)``: nodes dealt evenly
         (every inert graph has at least one), edges too (at least one each; a ring over the graph's nodes: valid endpoints,
         parallel edges when the ring wraps).  ``largest``: the dataset's largest graph (nodes, edges) no inert graph may exceed."""
         n_pad, e_pad = cap_n - tot[0], cap_e - tot[1]
@@ -271,7 +277,7 @@ class PairDataset:
             if largest is not None and (n > largest[0] or e > largest[1]):
                 raise ValueError("batch_arrays(pad=...): an inert graph would exceed the dataset's largest graph (a batch of empty graphs?)")
             a = np.arange(e, dtype=np.int64) % n
-            out.append({"src": a, "dst": (a + 1) % n, "vlabel": np.zeros(n, np.int64), "elabel": np.zeros(e, np.int64),
+            out.append({"src": a, "dst": (a + 1) % n, "vlabel": np.full(n, vlabel, np.int64), "elabel": np.full(e, elabel, np.int64),
                         "eid": np.arange(e, dtype=np.int64), "rev": np.zeros(e, bool), "num_nodes": n})
         return out
 

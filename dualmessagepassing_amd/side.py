@@ -14,26 +14,41 @@ the forking stream first, every product is consumed only after its ``wait``, and
 returns -- so memory freed on either stream is only ever reused behind work that was ordered after its last reader.
 """
 import contextlib
+import threading
 
 import torch
 
 USE_SIDE_STREAM = True      # module attribute (tests flip it): off = everything on the caller's stream, as before
 
-_streams = {}
-_pending = []               # [(name, event, device index)] in issue order
-_depth = 0
+
+class _State(threading.local):
+    """Per host thread (a thread drives one stream of launches; two threads stepping two models must not see each other's
+    stages): the side streams by device, the pending stages in issue order, the fork depth."""
+
+    def __init__(self):
+        self.streams = {}
+        self.pending = []       # [(name, event, device index)]
+        self.depth = 0
+
+
+_st = _State()
 
 
 def _stream(device):
-    s = _streams.get(device.index)
+    s = _st.streams.get(device.index)
     if s is None:
-        s = _streams[device.index] = torch.cuda.Stream(device=device)
+        s = _st.streams[device.index] = torch.cuda.Stream(device=device)
     return s
 
 
 def active():
     """True while the enclosing code runs inside ``fork()``."""
-    return _depth > 0
+    return _st.depth > 0
+
+
+def pending():
+    """Names of the stages recorded and not yet waited for (this thread)."""
+    return [n for n, _, _ in _st.pending]
 
 
 @contextlib.contextmanager
@@ -41,35 +56,42 @@ def fork(enabled=True, device=None):
     """Run the enclosed launches on the side stream (after what the current stream holds so far).  A no-op context when the
     side stream is switched off (or ``enabled`` is false), on a CPU build, or when already inside a fork.  Several forks in a
     row queue up on the one side stream; the caller keeps every tensor the forked launches read alive until its ``join()``."""
-    global _depth
-    if not enabled or not USE_SIDE_STREAM or _depth > 0 or not torch.cuda.is_available():
+    if not enabled or not USE_SIDE_STREAM or _st.depth > 0 or not torch.cuda.is_available():
         yield False
         return
     cur = torch.cuda.current_stream(device)
     s = _stream(cur.device)
     s.wait_stream(cur)
-    _depth += 1
+    _st.depth += 1
+    first = len(_st.pending)
     try:
         with torch.cuda.stream(s):
             yield True
             mark("_end")     # (so that ``join()`` after a fork without stages of its own has an event to wait for)
+    except BaseException:
+        # a fork that failed half way: its stages name products that were never (all) made -- nobody may wait for them by name;
+        # the caller's stream is ordered after whatever the side stream did get to, so nothing of it is left dangling either
+        del _st.pending[first:]
+        cur.wait_stream(s)
+        raise
     finally:
-        _depth -= 1
+        _st.depth -= 1
 
 
 def mark(name):
     """Record stage ``name`` at this point of the side stream (inside ``fork()``)."""
-    if _depth == 0:
+    if _st.depth == 0:
         return
     ev = torch.cuda.Event()
     s = torch.cuda.current_stream()
     ev.record(s)
-    _pending.append((name, ev, s.device.index))
+    _st.pending.append((name, ev, s.device.index))
 
 
 def wait(name):
     """The current stream waits for stage ``name`` (no-op if it is not pending); earlier stages are complete by then too."""
-    if not _pending or _depth > 0:
+    _pending = _st.pending
+    if not _pending or _st.depth > 0:
         return
     for i, (n, ev, _) in enumerate(_pending):
         if n == name:
@@ -80,7 +102,8 @@ def wait(name):
 
 def join():
     """The current stream waits for everything the side stream still holds."""
-    if not _pending or _depth > 0:
+    _pending = _st.pending
+    if not _pending or _st.depth > 0:
         return
     torch.cuda.current_stream().wait_event(_pending[-1][1])
     del _pending[:]

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 73
+#define DMP_ABI_VERSION 74
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -777,14 +777,17 @@ int dmp_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *e
  * torch.optim.AdamW keeps one per tensor (train.py:1231): a tensor that receives its first gradient at optimizer step k starts its
  * bias corrections at 1, a tensor without a gradient this step is left alone and its count stands.  seg_off [P + 1] (device):
  * element offsets of the tensors (multiples of 4); live (HOST, ceil(P / 64) words, or NULL = all): bit s = tensor s has a gradient
- * this step; state (device doubles) [2 + P]: [0] optimizer steps taken, [1] learning rate (written by the host), [2 + s] the
- * step count of tensor s; seg_tab (device floats) [2 P]: scratch.  veto / veto_mask as dmp_adamw_step_guarded (NULL: none).
+ * this step; live_dev (DEVICE floats [P], or NULL): when given it replaces `live` -- tensor s is live where live_dev[s] != 0
+ * (data-parallel runs: every rank adds its own 0 / 1 indicators to the gradient all-reduce, so the set is the union over the
+ * ranks and the replicas take the same step, dp.FlatGradSync); state (device doubles) [2 + P]: [0] optimizer steps taken,
+ * [1] learning rate (written by the host), [2 + s] the step count of tensor s; seg_tab (device floats) [2 P]: scratch.
+ * veto / veto_mask as dmp_adamw_step_guarded (NULL: none).
  * Two launches, nothing per step in the arguments except the live set: replays from a HIP graph. */
 #define DMP_ADAMW_MAX_SEGMENTS 1024
 int dmp_adamw_step_segments(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
-                            int64_t n, double *state, const int64_t *seg_off, int P, const uint64_t *live, float *seg_tab,
-                            double beta1, double beta2, double eps, double weight_decay, int32_t *veto, int32_t veto_mask,
-                            void *stream);
+                            int64_t n, double *state, const int64_t *seg_off, int P, const uint64_t *live, const float *live_dev,
+                            float *seg_tab, double beta1, double beta2, double eps, double weight_decay, int32_t *veto,
+                            int32_t veto_mask, void *stream);
 
 /* dmp_adamw_step_dev that DROPS the step when a device-side flag says so (as a loss-scaling optimizer drops a step whose
  * gradients overflowed): veto = int32 [4] in device memory.  veto[0] collects flags raised since the last optimizer step

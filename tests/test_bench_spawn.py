@@ -25,7 +25,7 @@ def _line(stdout):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])      # 8: the target node's rank count
 def test_gpus_flag_starts_that_many_ranks(n):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--backend", "gloo", "--single-device", "--steps", "1", "--spawn-check"],
                        env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)

@@ -79,9 +79,26 @@ def test_default_mode_replays_and_eager_agrees(gpu):
     assert abs(gc["value"] - 16 / (gc["ms_per_step"] * 1e-3)) <= 0.01 * gc["value"]
     gd = d["gate_dense"]                                       # the control: the same step without the filter's gates
     assert gd["ms_per_step"] > 0 and gd["unit"] == "pairs/s" and abs(gd["value"] - 16 / (gd["ms_per_step"] * 1e-3)) <= 0.01 * gd["value"]
+    # ... a first-class number: its own scatter-add objects over EVERY row, its own kernel and MFMA tables
+    for key in ("roofline", "roofline_bwd"):
+        r = gd[key]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["avg_us"] > 0 and "rows_not_fetched" not in r
+        assert r["bytes_basis"].startswith("SURVEY") and r["bytes_own"] >= r["bytes_per_launch"] > 0
+    assert gd["kernels"] and gd["eager_ms_per_step"] > 0 and "kern" not in gd
+    # the MFMA table: bf16x6 kernels against the dense bf16 peak (6 piece products per fp32 product), f32-input kernels against theirs
+    for tab in (d["mfma_kernels"], gd["mfma_kernels"]):
+        assert tab
+        for name, m in tab.items():
+            x6 = m["arithmetic"].startswith("bf16x6")
+            assert m["peak"] == (2500.0 if x6 else 157.3) and abs(m["frac"] - m["pipe_tflops"] / m["peak"]) < 2e-3 and m["frac"] < 1.0
+            assert abs(m["pipe_tflops"] - (6.0 if x6 else 1.0) * m["tflops"]) <= 0.6 and 0 < m["hbm_frac"] <= 1.0
     e = _run("--eager", "--no-cpu-baseline")
     _check_contract(e)
     assert e["config"]["launch"] == "eager launches" and e["config"]["eager_ms_per_step"] is None
+    # the all-rows step as the headline of its own line (what the gate_dense profiles are taken with)
+    n = _run("--graph", "--filter-net", "None", "--no-cpu-baseline", "--no-all-outputs", "--extended-steps", "0")
+    assert "NO filter net" in n["config"]["workload"] and n["gate_dense"] is None and n["value"] > 0
+    assert "rows_not_fetched" not in n["roofline"] and n["roofline"]["bytes_own"] >= n["roofline"]["bytes_per_launch"]
     g = _run("--graph", "--no-cpu-baseline")                # in this process tree: no child
     _check_contract(g)
     assert g["config"]["launch"].startswith("one HIP graph replay per step")

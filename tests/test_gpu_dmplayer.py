@@ -260,7 +260,7 @@ def test_fused_rep_path_equals_modular_path_and_oracle(batch, n, m, h, gates, re
         for i in range(L):
             for k, p in lo[i].items():
                 # a flipped activation derivative (see _close_or_flipped) perturbs every parameter gradient upstream of it
-                tol = 5e-3 if flipped[fused] else 3e-4
+                tol = 5e-3 if flipped[fused] else 2e-4      # parameter gradients 2e-4
                 _close(results[fused][4]["dmpnn.graph_dmpnn_(%d).%s" % (i, k)], p.grad, tol, tol,
                        "grad %d.%s fused=%s" % (i, k, fused))
     # Against an fp64 run of the same math the product must be no worse than a few times the

@@ -1,7 +1,7 @@
 """GPU parity of the whole ``DMPNN(**config).forward(pattern, graph)`` (model skeleton + HIP hot
 path) against the reference's own model run (tests/golden/fullmodel_*.npz): all 15 OutputDict
 entries and the gradients of ``pred_c.sum()``.  Tolerances: embeddings 1e-5, 3-layer reps and
-``pred_c`` 1e-4, parameter gradients 3e-4 (all relative to max(1, |ref|max))."""
+``pred_c`` 1e-4, parameter gradients 2e-4 (all relative to max(1, |ref|max))."""
 import numpy as np
 import pytest
 import torch as th
@@ -72,13 +72,13 @@ def test_full_dmpnn_forward_matches_reference(path, fused, gpu):
     for k in ("p_v_mask", "p_e_mask", "g_v_mask", "g_e_mask"):
         assert th.equal(out[k].cpu(), _t(d["out." + k])), k          # boolean, exact
     for k in ("p_v_emb", "p_e_emb", "g_v_emb", "g_e_emb"):
-        _close(out[k], d["out." + k], 2e-5, k)
+        _close(out[k], d["out." + k], 1e-5, k)                       # single-op outputs 1e-5
     for k in ("p_v_rep", "p_e_rep", "g_v_rep", "g_e_rep", "pred_c"):
-        _close(out[k], d["out." + k], 2e-4, k)
+        _close(out[k], d["out." + k], 1e-4, k)                       # ... 3-layer reps and pred_c 1e-4
     total = out["pred_c"].sum()
     for k in ("pred_v", "pred_e"):
         if "out." + k in d:   # pred_return_weights: per-node / per-edge matching outputs [B, max_len]
-            _close(out[k], d["out." + k], 2e-4, k)
+            _close(out[k], d["out." + k], 1e-4, k)
             total = total + out[k].sum()
         else:
             assert out[k] is None
@@ -86,7 +86,7 @@ def test_full_dmpnn_forward_matches_reference(path, fused, gpu):
     n = 0
     for k, p in model.named_parameters():
         if "grad." + k in d:
-            _close(p.grad, d["grad." + k], 3e-4, "grad " + k)
+            _close(p.grad, d["grad." + k], 2e-4, "grad " + k)           # ... parameter gradients 2e-4
             n += 1
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
@@ -459,8 +459,8 @@ def test_full_model_matches_the_model_oracle_at_config_1(hid, act, gpu):
     out, ref, got, want, touched, _ = _config1_case(hid, act, gpu)
     for k in ("p_v_mask", "p_e_mask", "g_v_mask", "g_e_mask"):
         assert th.equal(out[k].cpu(), ref[k]), k
-    for k, tol in (("p_v_emb", 2e-5), ("g_e_emb", 2e-5), ("p_v_rep", 2e-4), ("p_e_rep", 2e-4), ("g_v_rep", 2e-4), ("g_e_rep", 2e-4),
-                   ("pred_c", 2e-4)):
+    for k, tol in (("p_v_emb", 1e-5), ("g_e_emb", 1e-5), ("p_v_rep", 1e-4), ("p_e_rep", 1e-4), ("g_v_rep", 1e-4), ("g_e_rep", 1e-4),
+                   ("pred_c", 1e-4)):
         _close(out[k], ref[k].detach().numpy(), tol, k)
     assert int((~touched).sum()) >= 8, int(touched.sum())         # the strict rule must cover a good part of the batch
     assert _pair_gradients_close(got, want, touched) > 30 * 32

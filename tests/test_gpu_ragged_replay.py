@@ -117,3 +117,39 @@ def test_padded_batches_replay_and_train_like_the_exact_shapes(gpu):
     assert float((p0 - p1).abs().max()) <= 2e-4 * scale, float((p0 - p1).abs().max()) / scale
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l0, l1)
+
+
+def test_padded_replay_with_gate_compact_drops_no_step(gpu):
+    """``fit(graph=True, gate_compact=...)`` on a RAGGED dataset.  The inert target graphs of a padded batch carry a
+    label their inert patterns do not use, so the filter gates wipe every inert row: a capacity calibrated on the real pairs
+    holds for the padded batches (nothing dropped) and the run ends where the exact-shape eager run on every edge row ends."""
+    from dualmessagepassing_amd import harness
+    from dualmessagepassing_amd.basemodel import build_model
+    from dualmessagepassing_amd.dp import FlatAdamW, FlatGradSync
+    ds = harness.SmallLikePairs(160, seed=4, threads=4)
+    train, dev = ds.subset(range(128)), ds.subset(range(128, 160))
+    # the inert rows are dead under the gates: a padded batch keeps exactly the real pairs' rows
+    pad = train.pad_buckets(32, levels=4)
+    meta, tensors = train.batch_arrays(np.arange(32), gpu, pad=pad)
+    pattern, graph = train.graphs_from_arrays(meta, tensors)
+    th.manual_seed(0)
+    probe = build_model(**ds.model_config(hid_dim=128, layers=3)).to(gpu)
+    real_p, real_g = train.batchify(np.arange(32), gpu)[:2]
+    kept_padded, e_padded = probe.gate_kept_edges(pattern, graph)
+    kept_real, e_real = probe.gate_kept_edges(real_p, real_g)
+    assert kept_padded == kept_real and e_padded > e_real, (kept_padded, kept_real, e_padded, e_real)
+    hist = {}
+    for mode in ("plain", "padded+compact"):
+        th.manual_seed(0)
+        model = build_model(**ds.model_config(hid_dim=128, layers=3)).to(gpu)
+        sync = FlatGradSync(model)
+        opt = FlatAdamW([sync.flatten_parameters()], lr=5e-4, weight_decay=1e-5, amsgrad=True, capturable=mode != "plain")
+        hist[mode] = harness.fit(model, opt, train, dev, 2, 32, gpu, sync=sync, seed=1,
+                                 gate_compact=1.25 if mode != "plain" else False, graph=mode != "plain")
+        if mode != "plain":
+            assert model.gate_capacity, "the gates removed too little for a capacity to be set"
+            assert hist[mode][-1]["dropped_steps"] == 0, hist[mode][-1]
+    for a, b in zip(hist["plain"], hist["padded+compact"]):
+        for part in ("train", "dev"):
+            for k, v in a[part].items():
+                assert abs(v - b[part][k]) <= 2e-3 * max(1.0, abs(v)), (part, k, v, b[part][k])

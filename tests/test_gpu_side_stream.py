@@ -39,7 +39,7 @@ def test_step_with_the_side_stream_equals_the_one_stream_step_bit_for_bit(lazy, 
 
     def spy(*a, **k):
         real(*a, **k)
-        forked.append(len(side._pending))
+        forked.append(len(side.pending()))
 
     dmpnn.prefetch_joint_indexes = spy
     try:
@@ -48,7 +48,7 @@ def test_step_with_the_side_stream_equals_the_one_stream_step_bit_for_bit(lazy, 
     finally:
         dmpnn.prefetch_joint_indexes = real
     assert forked and max(forked) >= 5, "the prefetch did not fork its stages: %r" % (forked,)
-    assert not side._pending, "stages left unjoined after the pass: %r" % ([n for n, _, _ in side._pending],)
+    assert not side.pending(), "stages left unjoined after the pass: %r" % (side.pending(),)
     for k, v in ref_out.items():
         if v is None:
             assert out[k] is None
@@ -72,13 +72,13 @@ def test_side_stream_stages_are_waited_in_order_and_joined(gpu):
         side.mark("b")
         c = b - 1.0
         side.mark("c")
-    assert [n for n, _, _ in side._pending] == ["a", "b", "c", "_end"]
+    assert side.pending() == ["a", "b", "c", "_end"]
     side.wait("b")
-    assert [n for n, _, _ in side._pending] == ["c", "_end"]
+    assert side.pending() == ["c", "_end"]
     assert float(b.sum()) == 3.0 * (1 << 20)
     side.wait("nope")                                   # an unknown stage: nothing happens
     side.join()
-    assert not side._pending and float(c.sum()) == 2.0 * (1 << 20)
+    assert not side.pending() and float(c.sum()) == 2.0 * (1 << 20)
     side.USE_SIDE_STREAM = False
     try:
         with side.fork() as f:
@@ -116,6 +116,51 @@ def test_replayed_step_with_the_forked_branch_equals_the_one_stream_recording(gp
                 res[on] = (step.last_pred_c.detach().clone(), step.sync.flat.detach().clone())
         finally:
             side.USE_SIDE_STREAM = True
-        assert not side._pending
+        assert not side.pending()
     assert bool(th.isfinite(res[True][1]).all())
     assert th.equal(res[True][0], res[False][0]) and th.equal(res[True][1], res[False][1])
+
+
+def test_failed_fork_leaves_no_stage_behind(gpu):
+    """an exception inside ``fork()`` must not leave its stages pending (a later ``wait`` by name would order the
+    caller behind products that were never made); the state is per host thread."""
+    import threading
+    from dualmessagepassing_amd import side
+    x = th.ones(1 << 16, device=gpu)
+    with side.fork():
+        y = x + 1.0
+        side.mark("kept")
+    with pytest.raises(RuntimeError, match="boom"):
+        with side.fork():
+            z = x * 2.0
+            side.mark("lost")
+            raise RuntimeError("boom")
+    assert side.pending() == ["kept", "_end"] and not side.active()
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(side.pending()))     # another thread: its own (empty) list
+    t.start(); t.join()
+    assert seen == [[]]
+    side.join()
+    assert not side.pending() and float(y.sum()) == 2.0 * (1 << 16) and float(z.sum()) == 2.0 * (1 << 16)
+
+
+def test_row_mask_miss_on_the_main_stream_waits_for_the_side_stream(gpu):
+    """``fused.gate_row_mask`` called on the caller's stream BEFORE any wait, for a gate that the side stream is
+    still writing (a memo miss: the prefetch's and the consumer's conditions drifted apart).  The launch is ordered behind the
+    side stream's ``erows`` stage, so the mask is the finished gate's."""
+    from dualmessagepassing_amd import fused, side
+    R = 1 << 22
+    src = (th.arange(R, device=gpu) % 3 == 0).float()
+    th.cuda.synchronize()
+    with side.fork():
+        big = th.zeros(64 << 20, device=gpu)
+        for _ in range(6):                   # a few hundred microseconds of side-stream work ahead of the gate's writer
+            big.add_(1.0)
+        gate = th.empty(R, device=gpu)
+        gate.copy_(src)
+        side.mark("erows")
+    mask = fused.gate_row_mask(gate)         # a miss: nothing memoised this mask
+    side.join()
+    th.cuda.synchronize()
+    bits = ((mask.view(-1, 1).to(th.int64) >> th.arange(32, device=gpu)) & 1).reshape(-1)[:R].float()
+    assert th.equal(bits, src)

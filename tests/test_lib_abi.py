@@ -33,3 +33,36 @@ def test_abi_version_and_workspace_queries():
     assert lib.dmp_scan_workspace_words(5000) >= 3
     w = lib.dmp_dedupe_table_words(1000)
     assert w >= 2000 and (w & (w - 1)) == 0
+
+
+def test_loaded_library_matches_the_shipped_sources():
+    """The library the suite runs is the one the sources in this tree build: content hash equal, ABI number equal to the
+    header's (nothing asserted it; a stale library after a failed build passed silently)."""
+    from dualmessagepassing_amd import _build, _lib
+    lib = _lib.load()
+    assert not _build._stale(), "csrc/libdmp_hip.so was not built from the sources in this tree"
+    hdr = open(os.path.join(ROOT, "include", "dmp_hip.h")).read()
+    assert lib.dmp_abi_version() == int(re.search(r"#define\s+DMP_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION
+
+
+def test_stale_library_after_a_failed_build_is_refused(monkeypatch):
+    """``_lib.load``: a failed build + a library whose hash does not match the sources -> DmpError (not a line on stderr);
+    DMP_ALLOW_STALE_LIB=1 is the explicit way around; a failed build beside a CURRENT library still loads it."""
+    import pytest
+    from dualmessagepassing_amd import _build, _lib
+
+    def boom(*a, **k):
+        raise RuntimeError("hipcc failed on dmp_typed.hip:\nerror: pretend")
+
+    monkeypatch.setattr(_build, "build_lib", boom)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_build, "_stale", lambda: True)
+    monkeypatch.delenv("DMP_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(_lib.DmpError, match="STALE"):
+        _lib.load()
+    monkeypatch.setenv("DMP_ALLOW_STALE_LIB", "1")
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("DMP_ALLOW_STALE_LIB", raising=False)
+    monkeypatch.setattr(_build, "_stale", lambda: False)
+    assert _lib.load() is not None

@@ -15,7 +15,7 @@ def test_fork_is_a_no_op_without_a_gpu():
         side.mark("a")
     side.wait("a")
     side.join()
-    assert ran == [1] and not side._pending
+    assert ran == [1] and not side.pending()
 
 
 def test_prefetch_declines_without_gates_or_gpu():
@@ -25,4 +25,4 @@ def test_prefetch_declines_without_gates_or_gpu():
         use_fused = True
     # no rep-net attributes, no gates: nothing to do, nothing raised, nothing pending
     assert dmpnn.prefetch_joint_indexes(_M(), None, None, None, None) is None
-    assert not side._pending
+    assert not side.pending()
