@@ -363,6 +363,30 @@ def build_step(cfg, shard, device, world=1, collective=False):
             res[name] = t[len(t) // 2]
         return res
 
+    def copy_ceiling(nbytes, launches=20):
+        """What a launch of THIS size can reach at all: a plain device-to-device row copy that moves ``nbytes`` in total (half read,
+        half written; 16 bytes per lane, the library's copy kernel), timed exactly as the scatter-add launches are (HIP events around
+        single eager launches, the source written by the launch before, median of ``launches``).  A launch of tens of megabytes
+        lasts a dozen microseconds, of which the dispatch, the first requests' round trip and the last stores' drain are a fixed
+        share: the copy's fraction of the 8 TB/s peak is the ceiling any kernel of that size has on this box.  -> {"avg_us", "frac"}"""
+        n = max(int(nbytes) // 8, 1024)
+        src = torch.randn(n, device=device)
+        dst = torch.empty_like(src)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for i in range(launches + 2):
+            src.mul_(1.0)
+            if i >= 2:
+                ev[i - 2][0].record()
+            dst.copy_(src)
+            if i >= 2:
+                ev[i - 2][1].record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        us = t[len(t) // 2]
+        return {"what": "a device-to-device copy of the same total bytes (half read, half written), same timing method: the ceiling of a launch of this size",
+                "bytes": int(n * 8), "avg_us": round(us, 2), "gbps": round(n * 8 / us / 1e3, 1), "frac": round(n * 8 / us / 1e3 / HBM_PEAK_GBPS, 4)}
+
+    step.copy_ceiling = copy_ceiling
     step.plain_scatter_adds = plain_scatter_adds
     step.gate_kept_edges = gate_kept_edges
     step.gate_kept_rows = gate_kept_rows
@@ -594,7 +618,7 @@ def kept_row_bytes(name, H, N, E, Nk, Ek, Et, Etk, B, Ein=None):
         return 8 * H * Ek
     if base == "out_fwd_typed":
         return 12 * H * (Ek if on_e else Nk) * jobs if (on_e or on_n) else None
-    if base == "bwd_h1_typed":
+    if base in ("bwd_h1_typed", "bwd_h1_w"):
         return (12 * H + 4) * (Ek if on_e else Nk) if (on_e or on_n) else None
     if base == "pool_relu_bwd" and on_e:
         return 8 * H * Ek + 12 * E
@@ -617,18 +641,19 @@ def mfma_rooflines(kern, H, E, Ek=None):
     bwd_h1; 2 for the two-panel edge_fwd / bwd_z).  ``Ek``: the edge rows the batch's 0 / 1 gate keeps -- the kernels over
     the kept edges' tiles (``*_typed``) multiply those rows only."""
     products = {"edge_fwd_typed": 1, "bwd_z_typed": 1, "atb_typed": 1, "atb_rows": 1, "out_fwd_mfma": 1, "bwd_h1_mfma": 1,
-                "edge_fwd_mfma": 2, "bwd_z_mfma": 2, "out_fwd_typed": 1, "bwd_h1_typed": 1}
+                "edge_fwd_mfma": 2, "bwd_z_mfma": 2, "out_fwd_typed": 1, "bwd_h1_typed": 1,
+                "bwd_h1_w": 2}       # (both products of the second Linear's backward in one launch, csrc/dmp_h1w.hip)
     out = {}
     for name, v in kern.items():
         base = name.split("[", 1)[0]
         if base in products and ("E=%d" % E in name or "R=%d" % E in name):
-            rows = Ek if (Ek is not None and base.endswith("_typed")) else E
+            rows = Ek if (Ek is not None and (base.endswith("_typed") or base == "bwd_h1_w")) else E
             tf = products[base] * 2.0 * rows * H * H / (v["avg_us"] * 1e-6) / 1e12
             # round 3: the class-typed kernels multiply on the bf16 pipe (three bf16 pieces per fp32 operand, six piece
             # products: fp32-accurate, 6/16 of the f32 form's matrix cycles) -- their bound is HBM
             # (VERDICT r5 weak 8: the bf16x6 kernels run on the bf16 pipe -- their matrix work is SIX bf16 piece products per
             # fp32 product, priced against the dense bf16 peak; "tflops" stays the fp32-equivalent rate of the product)
-            x6 = base.endswith("_typed")
+            x6 = base.endswith("_typed") or base == "bwd_h1_w"
             peak = MFMA_BF16_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
             pipe_tf = 6.0 * tf if x6 else tf
             out[base] = {"rows": int(rows), "avg_us": round(v["avg_us"], 2), "tflops": round(tf, 1), "pipe_tflops": round(pipe_tf, 1),
@@ -1350,8 +1375,17 @@ def main():
                                              "avg_us": round(plain[key_], 2), "bytes_per_launch": int(sv_), "bytes_own": int(own_),
                                              "frac": round(sv_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4),
                                              "frac_own_bytes": round(own_ / plain[key_] / 1e3 / HBM_PEAK_GBPS, 4)}
+        if not multi:
+            # the ceiling of a launch of each scatter-add's size (its own byte count), measured live beside it
+            for r_ in (roof, roof_bwd):
+                if r_ is not None:
+                    r_["same_size_copy"] = step.copy_ceiling(r_["bytes_own"])
+                    r_["own_rate_over_copy_rate"] = round(r_["frac_own_bytes"] / r_["same_size_copy"]["frac"], 4) if r_["same_size_copy"]["frac"] else None
         if dense_line is not None:
             dense_line = dense_summary(dense_line, H, uN, uE, 2 * mb)
+            for key_ in ("roofline", "roofline_bwd"):
+                if dense_line.get(key_):
+                    dense_line[key_]["same_size_copy"] = step.copy_ceiling(dense_line[key_]["bytes_own"])
         line = {
             "metric": "(pattern,graph) pairs/sec DMPNN fwd+bwd hid=%d" % H, "value": round(pairs / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -1377,11 +1411,13 @@ def main():
             "per_rank": per_rank,
             "arithmetic": "fp32 storage and accumulation; dense products on the f32-input MFMA except the class-typed edge kernels (fp32 operands as 3 bf16 pieces, 6 piece products per partial product: fp32-accurate, parity tests at the fp32 tolerances; DMP_EXACT_FP32=1 switches them back)",
             "config": {"workload": "BASELINE configs[%d]: ER pattern(%d,%d)x target(%d,%d), add_rev, "
-                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, " + ("ScalarFilter" if cfg.get("filter", "ScalarFilter") == "ScalarFilter" else "NO filter net: every row live") + ", "
+                                   "batch=%d pairs/GPU, full DMPNN model (Multihot enc, %s emb, %s, "
                                    "3 shared DMPLayers, SumPredictNet node+edge heads), activation %s, hid=%d, fp32; a new batch "
                                    "(fresh size / flag tensors) every step"
                                    % (cfg["config_id"] - 1, cfg["p_nodes"], cfg["p_edges"], cfg["g_nodes"], cfg["g_edges"],
-                                      cfg["batch"], cfg["emb"], cfg["act"] + (" (slope 1/5.5)" if cfg["act"] == "leaky_relu" else ""), H),
+                                      cfg["batch"], cfg["emb"],
+                                      "ScalarFilter" if cfg.get("filter", "ScalarFilter") == "ScalarFilter" else "NO filter net: every row live",
+                                      cfg["act"] + (" (slope 1/5.5)" if cfg["act"] == "leaky_relu" else ""), H),
                        "global_batch": cfg["batch"] * world, "parallelism": "dp%d" % world, "micro_batches": step.micro_batches,
                        "step": "device collate + index build + fwd + bwd + grad all-reduce (async, overlapped with the next batch's "
                                "collate / index build) + AdamW(amsgrad, train.py:1231) as one HIP launch",

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdmp_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
-SOURCES = ["dmp_agg.hip", "dmp_segacc.hip", "dmp_compact.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip", "dmp_typed.hip", "dmp_atb.hip", "dmp_fold.hip", "dmp_heads.hip", "dmp_layer0.hip", "dmp_bn.hip",
+SOURCES = ["dmp_agg.hip", "dmp_segacc.hip", "dmp_compact.hip", "dmp_graph.hip", "dmp_fused.hip", "dmp_mfma.hip", "dmp_typed.hip", "dmp_h1w.hip", "dmp_atb.hip", "dmp_fold.hip", "dmp_heads.hip", "dmp_layer0.hip", "dmp_bn.hip",
            "dmp_subiso.cpp"]   # the last one: host-only C++ (exact subgraph-isomorphism counter), same C ABI
 HEADERS = ["dmp_common.h", "dmp_mfma_common.h", os.path.join("..", "..", "include", "dmp_hip.h")]
 ARCH = "gfx950"

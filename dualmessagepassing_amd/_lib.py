@@ -175,6 +175,9 @@ SIGNATURES = {
     "dmp_out_fwd_typed": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_bwd_h1_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr, c_ptr]),
+    "dmp_bwd_h1_w_blocks": (c_i64, [c_i64]),
+    "dmp_bwd_h1_w": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
+                             c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_row_mask_bits": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_row_mask_rows": (c_int, [c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr]),
     "dmp_bwd_z_fused": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,

@@ -28,6 +28,11 @@ from .pred import PRED_NETS
 from .rgnn import RGCNRepMixin, RGINRepMixin
 
 
+import os as _os
+# the order in which the forward pass ISSUES the forked index builds and the encoding / embedding kernels (both depend on the
+# gates only): a development switch for measuring how a replayed HIP graph schedules its two branches
+PREFETCH_AFTER_EMBEDDINGS = _os.environ.get("DMP_DEV_PREFETCH_LATE") == "1"
+
 class OutputDict(OrderedDict):
     """Ordered mapping with attribute access (container.py:14-100, the part callers use).  An entry may be deferred
     (``embed.DeferredEmbedding``: the target embeddings, which the joint rep-net pass does not need as tensors): it becomes
@@ -912,18 +917,25 @@ class GraphAdjModelV2(BaseModel):
             vl_gate, el_gate = vl_gate.float(), el_gate.float()
 
         pooled = all(h is None or h.poolable() for h in self.pred_net.values())
-        if hasattr(self, "get_joint_rep") and not self.gate_capacity and vl_gate is not None and el_gate is not None:
-            # the index arrays the joint pass derives from the structure and the gates alone: on the side stream from here on,
-            # beside the encoding / embedding kernels below and the first layer's node side (side.py)
-            from .dmpnn import prefetch_joint_indexes
-            kinds = ()
-            if pooled and not self.pred_with_enc and not self.pred_with_deg:
-                kinds = tuple(k for k, on in (("node", self.node_pred), ("edge", self.edge_pred)) if on)
-            prefetch_joint_indexes(self, pattern, graph, vl_gate, el_gate, kinds, skip_rev)
+
+        def prefetch():
+            if hasattr(self, "get_joint_rep") and not self.gate_capacity and vl_gate is not None and el_gate is not None:
+                # the index arrays the joint pass derives from the structure and the gates alone: on the side stream from here on,
+                # beside the encoding / embedding kernels and the first layer's node side (side.py)
+                from .dmpnn import prefetch_joint_indexes
+                kinds = ()
+                if pooled and not self.pred_with_enc and not self.pred_with_deg:
+                    kinds = tuple(k for k, on in (("node", self.node_pred), ("edge", self.edge_pred)) if on)
+                prefetch_joint_indexes(self, pattern, graph, vl_gate, el_gate, kinds, skip_rev)
+
+        if not PREFETCH_AFTER_EMBEDDINGS:
+            prefetch()
         p_enc = self.get_pattern_enc(pattern)
         p_v_emb, p_e_emb = self.get_pattern_emb(p_enc)
         g_enc = self.get_graph_enc(graph)
         g_v_emb, g_e_emb = self.get_graph_emb_deferred(g_enc) if hasattr(self, "get_joint_rep") else self.get_graph_emb(g_enc)
+        if PREFETCH_AFTER_EMBEDDINGS:
+            prefetch()
         joint = None
         comp = self._compact_gated(pattern, graph, el_gate)
         rep_graph = graph                                           # the graph the rep-net runs on

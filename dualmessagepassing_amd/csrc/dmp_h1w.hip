@@ -1,0 +1,415 @@
+// Backward of the edge MLP's second Linear over the tiles of the kept edges, BOTH of its products in one launch (gfx950, H = 128):
+//
+//   dPre[e] = act'(H1[e]) (.) (dO[e] W2)        (the input gradient, dmpnn.py:147-152 reversed; what dmp_bwd_h1_typed makes)
+//   dW2     = sum_e dO[e]^T H1[e]               (the weight gradient;                            what dmp_atb_typed(plain) makes)
+//   db2     = sum_e dO[e],  dbe = sum_e dPre[e] (the two bias gradients)
+//
+// Both products read the SAME two [E, H] operands (dO, H1).  As two launches every kept row of both arrays crosses the fabric
+// twice, and the weight-gradient kernel spends its time splitting fp32 fragments into bf16 pieces in every wave that needs
+// them.  Here a 512-thread workgroup (one per CU) owns a contiguous range of 32-row tiles and its eight waves take two ROLES:
+//
+//   waves 0-3 ("rows")    the product dO W2 as in csrc/dmp_typed.hip (TEPI_H1): the W2 panel in registers as bf16 pieces, one
+//                         32-column slice per wave, activation derivative + column sums + 16-byte row stores in the epilogue;
+//                         their 256 threads fetch, split and stage the tile's dO rows;
+//   waves 4-7 ("columns") the product dO^T H1: every wave a 64 x 64 QUADRANT of the [128, 128] total in 4 accumulators, the
+//                         contraction over the tile's 32 rows as two 16-deep k-groups; their 256 threads fetch, split and stage
+//                         the tile's H1 rows.
+//
+// ONE LDS image per operand serves both: bf16 pieces (hi | mid | lo planes) of the fp32 rows, split once by the staging thread,
+// rows of 256 bytes with the 16-byte chunks XOR-swizzled (cdna_hip_programming.md T10, image (b)).  The row product reads it by
+// rows (ds_read_b128: a lane's 8 consecutive k of its row), the column product through the hardware transpose read
+// ds_read_b64_tr_b16 (a lane's 8 consecutive ROWS of its column: two reads per fragment) -- no second copy, no fragment is split
+// twice, and the column waves run no VALU work in their loop beyond addresses.  The row waves need only the SIGN of H1 (the
+// activation's derivative on the saved output): they read it from the hi plane (bf16 rounding keeps the sign of every fp32 value
+// of magnitude >= 2^-133; below that the saved output is treated as not positive).
+//
+// Products on the bf16 pipe as six piece products (dmp_mfma_common.h, "bf16x6": fp32-accurate).  dPre is bit-identical to
+// dmp_bwd_h1_typed's (same MFMA order); dW2 differs from dmp_atb_typed's by the summation order of the workgroup partials.
+// Measured for the design: the row kernel alone keeps 92 % of its rate at ONE workgroup per CU instead of two -- a single
+// workgroup's prefetch depth already covers the fabric latency, so the second role rides in the other half of the SIMDs' slots.
+#include <type_traits>
+
+#include "dmp_mfma_common.h"
+
+namespace dmp {
+namespace {
+
+struct H1WArgs {
+  const float *dO; int64_t ldo;          // upstream gradient rows [E, 128]
+  const float *H1; int64_t ldh;          // saved activation outputs [E, 128]
+  const float *W2; int64_t ldw;          // nn.Linear weight [128 out, ldw >= 128 in]: dH1 = dO @ W2, B[k = out][j = in] = W2[k][j]
+  float *dPre; int64_t ldg;              // output rows [E, 128], scattered by edge id (rows outside the tiles are not written)
+  int64_t E;
+  const int32_t *slot_edge;              // [num_tiles_bound * 32] edge id per slot, -1 = padding
+  const int32_t *num_tiles;              // device scalar: tiles in use
+  float slope;
+  float *partial;                        // [gridDim.x, 128] column sums of dPre per workgroup
+  float *partialA;                       // [gridDim.x, 128] column sums of the fetched dO rows (db2), or NULL
+  float *partialW;                       // [gridDim.x, 128 * 128] dO^T H1 per workgroup
+};
+
+constexpr int kHW = 128, kThreadsW = 512;
+constexpr int kPlaneB = 32 * 256;                    // bytes of one bf16 plane of a 32-row tile
+constexpr int kBufB = 3 * kPlaneB;                   // one tile of one operand (hi | mid | lo): 24576
+constexpr int kOpB = 2 * kBufB;                      // both buffers of one operand: 49152
+constexpr int kImgB = 2 * kOpB;                      // dO then H1: 98304
+constexpr int kScrB = 4 * 32 * kScrStride * 4;       // the row waves' accumulator transposes: 18432
+constexpr int kRowCB = 3 * kSub * 4;                 // store rows of three tiles in flight
+constexpr int kH1WLdsBytes = kImgB + kScrB + kRowCB; // 117120: dynamic LDS, opted in once per device
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s *lds_v4s_ptr;
+
+// chunk swizzle of the image: 16-byte chunk ch (0..15) of row `row` lives at 256 row + 16 (ch ^ swz(row))
+__device__ __forceinline__ uint32_t swz(uint32_t row) { return ((row & 3u) << 2) | ((row >> 2) & 3u); }
+
+__global__ __launch_bounds__(kThreadsW, 1) void h1w_k(const H1WArgs p) {
+  extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+  float *const scr_all = reinterpret_cast<float *>(lds + kImgB);
+  uint32_t *const rowC = reinterpret_cast<uint32_t *>(lds + kImgB + kScrB);     // [3][32]: store row of every slot (-1: none)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool cols = wave >= 4;                           // role: false = the row product, true = the column product
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int u = threadIdx.x & 255;                       // staging thread of its operand: rows u / 32 + 8 m, float4 piece u % 32
+  const int srow = u >> 5, scol = u & 31;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+  const int ntiles = __builtin_amdgcn_readfirstlane(*p.num_tiles);
+  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int mine = hi > lo ? hi - lo : 0;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));
+  // the operand this thread stages: dO (row waves) or H1 (column waves)
+  const srsrc_t rs_X = cols ? make_srsrc(p.H1, p.ldh, p.E) : make_srsrc(p.dO, p.ldo, p.E);
+  const uint32_t op_off = cols ? (uint32_t)kOpB : 0u;
+
+  // ---- staging: global -> registers (requested two tiles ahead) -> three bf16 planes in LDS (one tile ahead)
+  int id_rows[kSubLoads];
+  int id_own = -1, own_staged = -1;
+  float4 pre[kSubLoads];
+  float4 csA = make_float4(0.f, 0.f, 0.f, 0.f);          // row waves, partialA: this thread's 4 columns of the dO rows it stages
+  auto load_ids = [&](int k) {
+    const bool ok = k < mine;
+    const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, (srow + 8 * m) * 4, (int)so, 0) : -1;
+    if (!cols && u < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, u * 4, (int)so, 0) : -1;
+  };
+  auto load_row = [&](int m) { pre[m] = sbuf_load4(rs_X, id_rows[m], (uint32_t)scol * 16u); };   // id -1: zeros
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) load_row(m);
+    if (!cols && u < kSub) own_staged = id_own;
+  };
+  auto stage_row = [&](int buf, int m) {
+    if (!cols && p.partialA) { csA.x += pre[m].x; csA.y += pre[m].y; csA.z += pre[m].z; csA.w += pre[m].w; }
+    uint2 ph, pm, pl;
+    split_pair(pre[m].x, pre[m].y, ph.x, pm.x, pl.x);
+    split_pair(pre[m].z, pre[m].w, ph.y, pm.y, pl.y);
+    const uint32_t r = (uint32_t)(srow + 8 * m);
+    const uint32_t off = op_off + (uint32_t)buf * kBufB + 256u * r + 16u * ((uint32_t)(scol >> 1) ^ swz(r)) + 8u * (uint32_t)(scol & 1);
+    *reinterpret_cast<uint2 *>(lds + off) = ph;
+    *reinterpret_cast<uint2 *>(lds + off + kPlaneB) = pm;
+    *reinterpret_cast<uint2 *>(lds + off + 2 * kPlaneB) = pl;
+  };
+  auto stage_scalars = [&](int par) {                   // store row of every slot of the staged tile (row waves' threads < 32)
+    if (!cols && u < kSub) rowC[par * kSub + u] = own_staged >= 0 ? (uint32_t)own_staged : kNone;
+  };
+
+  // ======================================================================== the row product (waves 0-3)
+  const int cs = wave & 3;
+  const int col = 32 * cs + li;
+  float *const scr = scr_all + cs * (32 * kScrStride);
+  const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
+  const uint32_t col4 = (uint32_t)c4 * 4u;
+  const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.slope)));
+  const srsrc_t rs_C = make_srsrc(p.dPre, p.ldg, p.E);
+  constexpr int kGroups = 8;                             // 16-deep k-groups of the 128-deep contraction: lane half h owns k = 64 h ..
+  Split8 B6[kGroups];                                    // the W2 panel's fragments of this wave's column slice, as bf16 pieces
+  auto load_panel = [&]() {
+    const rsrc_t rs_W = make_rsrc(p.W2, (uint32_t)(kHW * p.ldw * 4));
+    uint32_t off;
+    const uint32_t w_first = (uint32_t)((int64_t)64 * h * p.ldw + col) * 4u;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
+    const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.ldw * 4));
+#pragma unroll
+    for (int s0 = 0; s0 < 64; s0 += 32) {
+      float w0[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
+#pragma unroll
+      for (int q = 0; q < 32; q += 8)
+        split8(make_float4(w0[q], w0[q + 1], w0[q + 2], w0[q + 3]), make_float4(w0[q + 4], w0[q + 5], w0[q + 6], w0[q + 7]), B6[(s0 + q) / 8]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // row read of the A operand: row li, chunk 8 h + g  ->  256 li + 16 ((8 h + g) ^ swz(li)) = a0 ^ (16 g)
+  const uint32_t a0 = 256u * (uint32_t)li + 16u * ((uint32_t)(8 * h) ^ swz((uint32_t)li));
+  // the sign operand of the epilogue: H1's hi plane, rows 8 k + lrow, this lane's 4 columns
+  uint2 hs[4];
+  auto fetch_sign = [&](int buf, int k) {
+    const uint32_t rr = (uint32_t)(8 * k + lrow);
+    const uint32_t ch = (uint32_t)(4 * cs + ((lane & 7) >> 1));
+    hs[k] = *reinterpret_cast<const uint2 *>(lds + kOpB + (uint32_t)buf * kBufB + 256u * rr + 16u * (ch ^ swz(rr)) + 8u * (uint32_t)(lane & 1));
+  };
+  f32x16 acc;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one tile of the row product: 8 k-groups x 6 piece MFMAs with, in their shadow, the sign reads of this tile (groups 0-1),
+  // the staging of tile k+1 (2-4), the row requests of tile k+2 (4-6) and the id requests of tile k+3 (7)
+  auto rows_step = [&](int k, int par3) {
+    const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned char *img = lds + (uint32_t)buf * kBufB;
+    Frag8 ah, am, al;
+    ah.v = *reinterpret_cast<const bf16x8 *>(img + a0);
+    am.v = *reinterpret_cast<const bf16x8 *>(img + kPlaneB + a0);
+    al.v = *reinterpret_cast<const bf16x8 *>(img + 2 * kPlaneB + a0);
+    auto action = [&](int i) {
+      if (i < 4) fetch_sign(buf, i);
+      else if (i < 8) stage_row(buf ^ 1, i - 4);
+      else if (i == 8) stage_scalars(nxt3);
+      else if (i < 13) load_row(i - 9);
+      else if (i == 13) { if (u < kSub) own_staged = id_own; }
+      else if (i == 14) load_ids(k + 3);
+    };
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      Frag8 nh = ah, nm = am, nl = al;
+      if (g + 1 < kGroups) {
+        const uint32_t an = a0 ^ (uint32_t)(16 * (g + 1));
+        nh.v = *reinterpret_cast<const bf16x8 *>(img + an);
+        nm.v = *reinterpret_cast<const bf16x8 *>(img + kPlaneB + an);
+        nl.v = *reinterpret_cast<const bf16x8 *>(img + 2 * kPlaneB + an);
+      }
+      const Split8 &bb = B6[g];
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bb.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.lo.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.mid.v, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      action(2 * g);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.mid.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.hi.v, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      action(2 * g + 1);
+      ah = nh; am = nm; al = nl;
+    }
+  };
+  auto rows_epilogue = [&](int par) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * h) * kScrStride + li] = acc[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 8 * k + lrow;
+      float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
+      // the saved output's sign from its hi piece (padding rows: zeros -> slope * 0 = 0, and the store is dropped)
+      v.x = act_bwd(__uint_as_float(hs[k].x << 16), v.x, slope); v.y = act_bwd(__uint_as_float(hs[k].x & 0xFFFF0000u), v.y, slope);
+      v.z = act_bwd(__uint_as_float(hs[k].y << 16), v.z, slope); v.w = act_bwd(__uint_as_float(hs[k].y & 0xFFFF0000u), v.w, slope);
+      colsum.x += v.x; colsum.y += v.y; colsum.z += v.z; colsum.w += v.w;
+      sbuf_store4(v, rs_C, (int)rowC[par * kSub + rr], col4);
+    }
+  };
+
+  // ======================================================================== the column product (waves 4-7)
+  const int pw = wave & 1, qw = (wave >> 1) & 1;         // quadrant: output rows 64 pw .., columns 64 qw ..
+  // transposed read (T10): group G = lane / 16 reads the block rows 16 kg + 8 (G >> 1) + 4 t .. + 3, columns 16 (G & 1) .. + 15 of
+  // the wave's 32-column block; lane 4 q + pp of the group supplies row + q, columns 4 pp .. 4 pp + 3 and receives column (lane & 15),
+  // rows + 0 .. 3 in its four elements: fragment element 4 t + e of lane (li, h) = row 16 kg + 8 h + 4 t + e, column li.
+  //   address = 256 row + 16 (chunk ^ swz(row)) + 8 (pp & 1),  chunk = 8 half + 4 blk + 2 (G & 1) + (pp >> 1),
+  //   swz(row) = (q << 2) | (2 (G >> 1) + t)   -- blk toggles bit 2 of the chunk, t bit 0:  address = t0 ^ (64 blk) ^ (16 t) + 1024 t + 4096 kg
+  const int G16 = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  auto tr_base = [&](int half) {
+    const uint32_t row0 = (uint32_t)(8 * (G16 >> 1) + q4);
+    const uint32_t ch0 = (uint32_t)(8 * half + 2 * (G16 & 1) + (pp >> 1));
+    const uint32_t sw0 = ((uint32_t)q4 << 2) | (uint32_t)(2 * (G16 >> 1));
+    return 256u * row0 + 16u * (ch0 ^ sw0) + 8u * (uint32_t)(pp & 1);
+  };
+  const uint32_t tA = tr_base(pw), tB = (uint32_t)kOpB + tr_base(qw);
+  auto tr_frag = [&](uint32_t base, int buf, int plane, int blk, int kg, Frag8 &f) {
+    const uint32_t o0 = (base ^ (uint32_t)(64 * blk)) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg);
+    const uint32_t o1 = (base ^ (uint32_t)(64 * blk) ^ 16u) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg + 1024);
+    const v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o0));
+    const v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o1));
+    f.v = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto tr_split = [&](uint32_t base, int buf, int blk, int kg, Split8 &s) {
+    tr_frag(base, buf, 0, blk, kg, s.hi);
+    tr_frag(base, buf, 1, blk, kg, s.mid);
+    tr_frag(base, buf, 2, blk, kg, s.lo);
+  };
+  // one tile of the column product: 2 k-groups x (2 x 2) blocks x 6 piece MFMAs; in their shadow the staging of tile k+1's H1 rows,
+  // the row requests of tile k+2 and the id requests of tile k+3
+  auto cols_step = [&](int k, f32x16 (&wacc)[2][2]) {
+    const int buf = k & 1;
+    int act = 0;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      Split8 fa[2];
+      tr_split(tA, buf, 0, kg, fa[0]);
+      tr_split(tA, buf, 1, kg, fa[1]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        Split8 fb;
+        tr_split(tB, buf, jb, kg, fb);
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          __builtin_amdgcn_sched_barrier(0);
+          wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (act < 4) stage_row(buf ^ 1, act);
+          else load_row(act - 4);
+          ++act;
+        }
+      }
+    }
+    load_ids(k + 3);
+  };
+
+  // ======================================================================== the loop (both roles: one barrier per tile)
+  if (mine == 0) {                                       // nothing to do: this workgroup's partial rows are zeros
+    if (threadIdx.x < 32) {
+      *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * kHW + threadIdx.x * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.partialA) *reinterpret_cast<float4 *>(p.partialA + (int64_t)blockIdx.x * kHW + threadIdx.x * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 *pw4 = reinterpret_cast<float4 *>(p.partialW + (int64_t)blockIdx.x * (kHW * kHW));
+    for (int m = threadIdx.x; m < kHW * kHW / 4; m += kThreadsW) pw4[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  load_ids(0);
+  load_rows();                 // tile 0
+  load_ids(1);
+  // The two roles run their own loops (same number of barriers): nothing of one role's register state -- the panel's 96
+  // registers, the quadrant's 64 accumulators -- is live in the other's code.
+  float *tot = reinterpret_cast<float *>(lds);   // after the loop the image is free: the [128, 128] total goes through it for 16-byte stores
+  if (cols) {
+    f32x16 wacc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[i][j][r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(0, m);
+    load_rows();               // tile 1
+    load_ids(2);
+    lds_barrier();
+    for (int k = 0; k < mine; ++k) {
+      cols_step(k, wacc);
+      lds_barrier();           // tile k+1 is staged for everyone, everyone is done with tile k's image
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tot[(64 * pw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * kHW + 64 * qw + 32 * j + li] = wacc[i][j][r];
+  } else {
+    load_panel();              // (requested behind tile 0's rows: the two round trips run side by side)
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(0, m);
+    stage_scalars(0);
+    load_rows();               // tile 1
+    load_ids(2);
+    lds_barrier();
+    int par3 = 0;
+    for (int k = 0; k < mine; ++k) {
+      rows_step(k, par3);
+      lds_barrier();
+      rows_epilogue(par3);
+      par3 = par3 == 2 ? 0 : par3 + 1;
+    }
+    __syncthreads();
+    // column sums of dPre: lanes with equal (lane & 7) hold the same 4 columns for 8 different rows (fixed-order xor tree)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      colsum.x += __shfl_xor(colsum.x, off, 64); colsum.y += __shfl_xor(colsum.y, off, 64);
+      colsum.z += __shfl_xor(colsum.z, off, 64); colsum.w += __shfl_xor(colsum.w, off, 64);
+    }
+    if (lane < 8) *reinterpret_cast<float4 *>(p.partial + (int64_t)blockIdx.x * kHW + 32 * cs + lane * 4) = colsum;
+  }
+  __syncthreads();
+  {
+    float4 *pw4 = reinterpret_cast<float4 *>(p.partialW + (int64_t)blockIdx.x * (kHW * kHW));
+#pragma unroll 4
+    for (int m = threadIdx.x; m < kHW * kHW / 4; m += kThreadsW) pw4[m] = *reinterpret_cast<const float4 *>(&tot[m * 4]);
+  }
+  if (p.partialA) {
+    // column sums of the staged dO rows: the 8 row-wave threads that staged the same 4 columns, added in a fixed order
+    __syncthreads();
+    if (!cols) *reinterpret_cast<float4 *>(&tot[srow * kHW + scol * 4]) = csA;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float4 t = *reinterpret_cast<const float4 *>(&tot[threadIdx.x * 4]);
+#pragma unroll
+      for (int g = 1; g < 8; ++g) {
+        const float4 w = *reinterpret_cast<const float4 *>(&tot[g * kHW + threadIdx.x * 4]);
+        t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+      }
+      *reinterpret_cast<float4 *>(p.partialA + (int64_t)blockIdx.x * kHW + threadIdx.x * 4) = t;
+    }
+  }
+}
+
+inline unsigned h1w_blocks(int64_t tiles_bound) {
+  const int64_t cap = 256;                               // one workgroup per CU
+  return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
+}
+
+constexpr int kMaxDevicesW = 64;
+inline bool h1w_lds_ready() {
+  static bool done[kMaxDevicesW] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesW) dev = 0;
+  if (done[dev]) return true;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&h1w_k), hipFuncAttributeMaxDynamicSharedMemorySize, kH1WLdsBytes);
+  if (e != hipSuccess) { set_last_hip_error(e); return false; }
+  done[dev] = true;
+  return true;
+}
+
+}  // namespace
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int64_t dmp_bwd_h1_w_blocks(int64_t tiles_bound) { return (int64_t)h1w_blocks(tiles_bound); }
+
+int dmp_bwd_h1_w(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                 const int32_t *slot_edge, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, float slope,
+                 float *dPre, int64_t ldg, float *partial, float *partial_rows, float *partial_w, void *stream) {
+  if (H != 128 || g_exact_fp32) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+  if (!partial || !partial_w || !aligned16(partial) || !aligned16(partial_w) || (partial_rows && !aligned16(partial_rows))) return DMP_ERR_BAD_ARG;
+  if (!slope_ok(slope)) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 0) {
+    const size_t rows = (size_t)h1w_blocks(tiles_bound);
+    if (hipMemsetAsync(partial, 0, sizeof(float) * H * rows, st) != hipSuccess) return DMP_ERR_HIP;
+    if (partial_rows && hipMemsetAsync(partial_rows, 0, sizeof(float) * H * rows, st) != hipSuccess) return DMP_ERR_HIP;
+    if (hipMemsetAsync(partial_w, 0, sizeof(float) * H * H * rows, st) != hipSuccess) return DMP_ERR_HIP;
+    return DMP_OK;
+  }
+  if (!dO || !W2 || !H1 || !dPre || !slot_edge || !num_tiles || ldo < H || ldw < H || ldh < H || ldg < H) return DMP_ERR_BAD_ARG;
+  if (ldo % 4 || ldh % 4 || ldg % 4 || !aligned16(dO) || !aligned16(H1) || !aligned16(dPre)) return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(ldo) || !stride_ok(ldh) || !stride_ok(ldg) || E >= ((int64_t)1 << 30) || tiles_bound * kSub * 4 >= ((int64_t)1 << 32) - 8192 ||
+      (int64_t)H * ldw * 4 >= ((int64_t)1 << 32) - 8192 || !fits4g(E, ldo) || !fits4g(E, ldh) || !fits4g(E, ldg))
+    return DMP_ERR_UNSUPPORTED;                           // (arrays of 4 GiB and more: the two-launch form has the 64-bit row kernels)
+  if (!h1w_lds_ready()) return DMP_ERR_HIP;
+  H1WArgs a{};
+  a.dO = dO; a.ldo = ldo; a.H1 = H1; a.ldh = ldh; a.W2 = W2; a.ldw = ldw; a.dPre = dPre; a.ldg = ldg; a.E = E;
+  a.slot_edge = slot_edge; a.num_tiles = num_tiles; a.slope = slope; a.partial = partial; a.partialA = partial_rows; a.partialW = partial_w;
+  h1w_k<<<h1w_blocks(tiles_bound), kThreadsW, kH1WLdsBytes, st>>>(a);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -709,6 +709,34 @@ def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0, out=None):
     return d_g, reduce_partials(part), reduce_partials(part_rows)
 
 
+USE_H1W = True    # the second edge Linear's backward as ONE launch (dPre and dO^T H1 from the same fetched rows, csrc/dmp_h1w.hip)
+
+
+def h1w_ok(d_o, h1, H):
+    """The one-launch form of ``bwd_h1_typed`` + ``atb_typed(plain=True)`` applies: H = 128, the bf16x6 arithmetic, arrays below 4 GiB."""
+    lib = _lib.load()
+    return (USE_H1W and H == 128 and not lib.dmp_dev_get_exact_fp32() and d_o.size(0) * d_o.stride(0) * 4 < (1 << 32) - 65536
+            and h1.size(0) * h1.stride(0) * 4 < (1 << 32) - 65536 and d_o.size(0) * H * 4 < (1 << 32) - 65536)
+
+
+def bwd_h1_w(d_o, W2, h1, tiles, slope=0.0, out=None):
+    """``(dPre, column sums of dPre, column sums of the kept rows of d_o, d_o^T h1)`` over the rows of ``tiles``: what
+    ``bwd_h1_typed`` and ``atb_typed(d_o, h1, plain=True)`` return, from one pass over the two operands (``dmp_bwd_h1_w``)."""
+    lib = _lib.load()
+    E, H = d_o.shape
+    slot_edge, _, num_tiles, bound = tiles
+    d_g = out if out is not None else dead_rows_buffer((E, H), d_o.device)
+    G = int(lib.dmp_bwd_h1_w_blocks(bound))
+    part = torch.empty((G, H), dtype=torch.float32, device=d_o.device)
+    part_rows = torch.empty_like(part)
+    part_w = torch.empty((G, H * H), dtype=torch.float32, device=d_o.device)
+    W2 = W2.contiguous()
+    with _lib.timed("bwd_h1_w[H=%d,E=%d]", (H, E), 12 * H * E + 4 * E):
+        check(lib.dmp_bwd_h1_w(ptr(d_o), d_o.stride(0), ptr(W2), W2.size(1), ptr(h1), h1.stride(0), ptr(slot_edge), ptr(num_tiles), bound,
+                               E, H, slope, ptr(d_g), d_g.stride(0), ptr(part), ptr(part_rows), ptr(part_w), stream_ptr()), "dmp_bwd_h1_w")
+    return d_g, reduce_partials(part), reduce_partials(part_rows), reduce_partials(part_w).view(H, H)
+
+
 USE_MASKED_SUMS = True   # the scatter-adds skip the rows a 0 / 1 edge gate wiped
 
 
@@ -1697,12 +1725,18 @@ class _FusedDMPLayer(torch.autograd.Function):
                     skip = (USE_MASKED_SUMS and SKIP_DEAD_ROWS and gate_row_mask(ctx.e_gate) is not None
                             and (ctx.l0 is None or getattr(ctx.l0, "enc_mask", None) is not None))
                     lt = live_tiles(ix, coef, ctx.e_gate) if (skip and USE_TYPED_ROWS) else None
-                    if lt is not None:      # over the kept edges' tiles only
+                    dW2e = None
+                    if lt is not None and USE_TYPED_ATB_ROWS and h1w_ok(dzn, H1e, H):
+                        # both products of the second Linear's backward from ONE pass over dO and H1 (csrc/dmp_h1w.hip)
+                        dG, dbe, db2e, dW2e = bwd_h1_w(dzn, eW2, H1e, (ascending_tiles(ctx.e_gate) if PLAIN_ROWS_ASCENDING else None) or lt, slope)
+                    elif lt is not None:      # over the kept edges' tiles only
                         dG, dbe, db2e = bwd_h1_typed(dzn, eW2, H1e, (ascending_tiles(ctx.e_gate) if PLAIN_ROWS_ASCENDING else None) or lt, slope)
                     else:
                         dG, dbe, db2e = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope, rows_colsum=True,
                                                     skip_dead_stores=skip)
-                    if lt is not None and USE_TYPED_ATB_ROWS:
+                    if dW2e is not None:
+                        pass
+                    elif lt is not None and USE_TYPED_ATB_ROWS:
                         # dO^T H1 over the kept edges' tiles: the class-tile weight-gradient kernel's first half (its class-scaled
                         # second half costs no further products) -- no tiles' worth of zero rows in between
                         dW2e = atb_typed(dzn, H1e, coef, ix, gate=ctx.e_gate, plain=True)

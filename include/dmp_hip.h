@@ -1093,6 +1093,22 @@ int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw,
                      int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
 
 /*
+ * dmp_bwd_h1_typed AND the second Linear's weight gradient dO^T H1 (dmp_atb_typed's plain form) in ONE launch over the same tile
+ * list (csrc/dmp_h1w.hip; the backward of `emlp[2]`, SubgraphCountingMatching/models/dmpnn.py:147-152: both products read the same
+ * two [E, H] operands).  H = 128, bf16x6 arithmetic, arrays below 4 GiB; DMP_ERR_UNSUPPORTED otherwise (callers then run the two
+ * launches).  A 512-thread workgroup per CU: four waves form dG as dmp_bwd_h1_typed does (bit-identical rows), four waves keep the
+ * [128, 128] total of dO^T H1 in registers, both from ONE bf16-piece LDS image per operand (row reads / ds_read_b64_tr_b16).
+ *   partial, partial_rows [dmp_bwd_h1_w_blocks(tiles_bound), H]: column sums of dG / of the fetched dO rows per workgroup;
+ *   partial_w [dmp_bwd_h1_w_blocks(tiles_bound), H * H]: dO^T H1 per workgroup ([out feature of W2][in feature]: nn.Linear's
+ *   layout); all three summed by dmp_reduce_partials.  The sign of H1 (the activation's derivative on the saved output) is read
+ *   from its bf16 hi piece: an output of magnitude below 2^-133 counts as not positive.
+ */
+int64_t dmp_bwd_h1_w_blocks(int64_t tiles_bound);
+int dmp_bwd_h1_w(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
+                 const int32_t *slot_edge, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, float slope,
+                 float *dG, int64_t ldg, float *partial, float *partial_rows, float *partial_w, void *stream);
+
+/*
  * Input gradient of the edge chain in one pass (replaces dmp_gather_select + the K=2H GEMM):
  *     dZ[e] = base[e] + s(flag e) * D[dst e, (flag e ? H : 0) + :] + dPre[e] W[:, 0:H]^T
  *             + coefE[e] * dPre[e] W[:, H:2H]^T

@@ -23,7 +23,8 @@ for r in rows[span[0]:span[1]]:
     n = r["Kernel_Name"].replace("void dmp::(anonymous namespace)::", "").replace("dmp::(anonymous namespace)::", "").replace("void at::native::", "at::")
     n = n.split("(")[0][:70]
     gap = s - prev_end
-    print("%8.1f  %7.1f us  gap %6.1f  grid %-8s %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, r.get("Grid_Size", r.get("Grid_Size_X", "")), n))
+    q = "q%s/s%s" % (r.get("Queue_Id", "?"), r.get("Stream_Id", "?"))
+    print("%8.1f  %7.1f us  gap %6.1f  %-8s grid %-8s %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, q, r.get("Grid_Size", r.get("Grid_Size_X", "")), n))
     busy += e - s
     gaps += max(gap, 0)
     prev_end = max(prev_end, e)

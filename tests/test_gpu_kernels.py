@@ -575,6 +575,58 @@ def test_second_linear_over_the_kept_edges_tiles(rows, h, gpu):
     assert float((db_rows - ref_rows).abs().max()) <= 2e-6 * max(1.0, kept) * float(d_o.abs().max())
 
 
+@pytest.mark.parametrize("rows,ascending", [(40, False), (1000, True), (70001, True), (70001, False), (300000, True)])
+def test_second_linear_backward_in_one_launch(rows, ascending, gpu):
+    """``dmp_bwd_h1_w`` (csrc/dmp_h1w.hip: dPre AND dO^T H1 from one pass over the kept edges' tiles; four waves on rows, four on
+    columns, one bf16-piece LDS image per operand read by rows and through ds_read_b64_tr_b16) against the two launches it
+    replaces: dPre BIT-identical to ``dmp_bwd_h1_typed`` on the kept rows, the other rows untouched, rows under a zero gate never
+    read (NaN there); the two column sums and dO^T H1 to fp32 accuracy against fp64; the same bits on every launch."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows)
+    rng = np.random.default_rng(rows)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    gate = th.from_numpy((rng.random(rows) < 0.46).astype(np.float32)).to(gpu)
+    gate._dmp_binary = True
+    dead = gate == 0
+    tiles = fused.ascending_tiles(gate) if ascending else fused.live_tiles(ix, coef, gate)
+    assert tiles is not None
+    h1 = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = th.where(h1 > 0, h1, 0.18 * h1)                       # a saved LeakyReLU output: both signs, the sign is what counts
+    h1[rng.integers(0, rows, 5)] = 0.0                         # exact zeros: not positive
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    W2 = (th.randn(h, h, generator=gen) / h ** 0.5).to(gpu)
+    h1p, dop = h1.clone(), d_o.clone()
+    h1p[dead] = float("nan")
+    dop[dead] = float("nan")
+    saved = fused.dead_rows_buffer
+    fused.dead_rows_buffer = lambda shape, device: th.full(shape, 7.5, dtype=th.float32, device=device)
+    try:
+        ref_dg, ref_db, ref_rows = fused.bwd_h1_typed(dop, W2, h1p, tiles, slope=0.18)
+        ref_w = fused.atb_typed(dop, h1p, coef, ix, gate=gate, plain=True)
+        assert fused.h1w_ok(dop, h1p, h)
+        dg, db, db_rows, dw = fused.bwd_h1_w(dop, W2, h1p, tiles, slope=0.18)
+        dg2, db2, db_rows2, dw2 = fused.bwd_h1_w(dop, W2, h1p, tiles, slope=0.18)
+    finally:
+        fused.dead_rows_buffer = saved
+    assert bool((dg[dead] == 7.5).all())
+    assert th.equal(dg[~dead], ref_dg[~dead])                  # the same MFMA sequence per element
+    assert th.equal(dg, dg2) and th.equal(db, db2) and th.equal(db_rows, db_rows2) and th.equal(dw, dw2)
+    keep = ~dead
+    dO64, h64 = d_o[keep].double(), h1[keep].double()
+    w64 = dO64.t() @ h64
+    scale_w = float((dO64.abs().t() @ h64.abs()).max())        # the natural scale of an entry: sum |a||b|
+    assert float((dw.double() - w64).abs().max()) <= 2e-6 * scale_w, float((dw.double() - w64).abs().max()) / scale_w
+    assert float((ref_w.double() - w64).abs().max()) <= 2e-6 * scale_w
+    kept = float(gate.sum())
+    assert float((db_rows.double() - dO64.sum(0)).abs().max()) <= 2e-6 * max(1.0, kept) * float(d_o.abs().max())
+    assert float((db - ref_db).abs().max()) <= 2e-6 * max(1.0, kept) * float(ref_dg[keep].abs().max())
+    assert float((db_rows - ref_rows).abs().max()) <= 2e-6 * max(1.0, kept) * float(d_o.abs().max())
+
+
 @pytest.mark.parametrize("rows", [1, 31, 4097, 70001])
 @pytest.mark.parametrize("gated", [False, True])
 def test_gated_weight_gradient_rows(rows, gated, gpu):
