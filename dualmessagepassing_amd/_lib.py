@@ -50,7 +50,7 @@ SIGNATURES = {
     "dmp_class_tiles_workspace_words": (c_size, [c_i64, c_int]),
     "dmp_class_tiles": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_csr_keep_scratch_words": (c_i64, [c_i64]),
-    "dmp_csr_keep": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_csr_keep": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_class_tiles_gated": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dmp_scan_workspace_words": (c_size, [c_i64]),
     "dmp_exclusive_scan_i64": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
@@ -175,6 +175,10 @@ SIGNATURES = {
     "dmp_out_fwd_typed": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_bwd_h1_typed": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                                  c_ptr, c_ptr, c_ptr]),
+    "dmp_kept_rows_jobs": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dmp_row_mask_bits_jobs": (c_int, [c_ptr, c_int, c_ptr]),
+    "dmp_atb2_blocks": (c_i64, [c_i64, c_int]),
+    "dmp_atb2_jobs": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "dmp_bwd_h1_w_blocks": (c_i64, [c_i64]),
     "dmp_bwd_h1_w": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                              c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -194,7 +198,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 74
+ABI_VERSION = 77
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

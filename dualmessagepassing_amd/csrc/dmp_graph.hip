@@ -1044,6 +1044,75 @@ __global__ __launch_bounds__(kBlock) void keep_fill_k(const int32_t *__restrict_
   }
 }
 
+// ... the same two passes with a GROUP of G lanes per row, for CSRs whose rows are long (a pooling index's chunk table: ~50
+// entries per row -- a thread per row walks them one dependent, uncoalesced load at a time: 15 + 30-45 us at bench.py's shape):
+// the group strides through its row G entries at a time, counts with a group reduction, and places the kept entries with a
+// ballot + prefix popcount.  Same arrays, same bits as the thread-per-row kernels.
+template <int G>
+__global__ __launch_bounds__(kBlock) void keep_count_g_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                         const float *__restrict__ gate, int64_t N, int32_t *__restrict__ row_cnt,
+                                                         int32_t *__restrict__ blk) {
+  constexpr int RPB = kBlock / G;
+  __shared__ int red[kBlock / 64];
+  const int64_t v = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  const int gl = threadIdx.x % G;
+  int c = 0;
+  if (v < N)
+    for (int q = in_ptr[v] + gl, hi = in_ptr[v + 1]; q < hi; q += G) c += gate[in_ent[q] >> 1] != 0.f;
+  int rc = c;
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) rc += __shfl_xor(rc, off, G);
+  if (v < N && gl == 0) row_cnt[v] = rc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; blk[blockIdx.x] = t; }
+}
+template <int G>
+__global__ __launch_bounds__(kBlock) void keep_fill_g_k(const int32_t *__restrict__ in_ptr, const int32_t *__restrict__ in_ent,
+                                                        const float *__restrict__ gate, const int32_t *__restrict__ row_cnt,
+                                                        const int32_t *__restrict__ blk, int64_t N, int32_t *__restrict__ keep_ptr,
+                                                        int32_t *__restrict__ keep_ent) {
+  constexpr int RPB = kBlock / G;
+  static_assert(RPB <= 64 && G <= 32, "one wave scans the block's rows; a group's ballot bits fit a word");
+  __shared__ int red[kBlock / 64], rstart[RPB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) before += blk[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) red[wave] = before;
+  if (wave == 0) {                                               // exclusive scan of the block's row counts (RPB <= 64 rows: one wave)
+    const int64_t vr = (int64_t)blockIdx.x * RPB + lane;
+    const int c = (lane < RPB && vr < N) ? row_cnt[vr] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+    if (lane < RPB) rstart[lane] = incl - c;
+  }
+  __syncthreads();
+  before = 0;
+  for (int i = 0; i < kBlock / 64; ++i) before += red[i];
+  const int g = threadIdx.x / G, gl = threadIdx.x % G;
+  const int64_t v = (int64_t)blockIdx.x * RPB + g;
+  if (v >= N) return;                                            // (whole groups: the ballots below see whole groups of their wave)
+  int s = before + rstart[g];
+  if (gl == 0) keep_ptr[v] = s;
+  const int lo = in_ptr[v], hi = in_ptr[v + 1];
+  const int shift = (lane / G) * G;                              // this group's bits of the wave's ballot
+  for (int q0 = lo; q0 < hi; q0 += G) {
+    const int q = q0 + gl;
+    int e = 0;
+    bool keep = false;
+    if (q < hi) { e = in_ent[q]; keep = gate[e >> 1] != 0.f; }
+    const unsigned bits = (unsigned)((__ballot(keep) >> shift) & ((1ull << G) - 1ull));
+    if (keep) keep_ent[s + __popc(bits & ((1u << gl) - 1u))] = e;
+    s += __popc(bits);
+  }
+  if (v == N - 1 && gl == 0) keep_ptr[N] = s;
+}
+
 // ---- the INCIDENCE CSR over the kept edges, for the kept nodes only (dmp_incidence_keep): row i belongs to node list[i]
 // (i < *count: the nodes a 0 / 1 node gate keeps, ascending) and lists the node's in-entries and out-entries (flag flipped)
 // whose edge a 0 / 1 edge gate keeps, MERGED by ascending edge id as incidence_fill merges them.  Same two passes as the
@@ -1917,16 +1986,24 @@ int dmp_class_tiles(const int64_t *deg, const int32_t *in_ptr, const int32_t *in
                           stream);
 }
 
-int64_t dmp_csr_keep_scratch_words(int64_t N) { return N + (N + kBlock - 1) / kBlock + 1; }
+constexpr int kKeepGroup = 16;          // lanes per row of the long-row form
+int64_t dmp_csr_keep_scratch_words(int64_t N) { return N + (N + kBlock / kKeepGroup - 1) / (kBlock / kKeepGroup) + 1; }
 
-int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t N, int32_t *row_cnt, int32_t *keep_ptr,
-                 int32_t *keep_ent, void *stream) {
+int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t N, int64_t num_entries, int32_t *row_cnt,
+                 int32_t *keep_ptr, int32_t *keep_ent, void *stream) {
   if (N < 0) return DMP_ERR_BAD_ARG;
   if (!keep_ptr) return DMP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return hipMemsetAsync(keep_ptr, 0, sizeof(int32_t), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
   if (!in_ptr || !in_ent || !gate || !row_cnt || !keep_ent) return DMP_ERR_BAD_ARG;
-  int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block of kBlock nodes
+  int32_t *blk = row_cnt + N;                                  // row_cnt: N counts + one total per block of rows
+  if (num_entries >= 12 * N) {                                 // long rows (num_entries: a host-side hint, 0 = unknown): a lane group per row
+    constexpr int RPB = kBlock / kKeepGroup;
+    const unsigned nb = (unsigned)((N + RPB - 1) / RPB);
+    keep_count_g_k<kKeepGroup><<<nb, kBlock, 0, st>>>(in_ptr, in_ent, gate, N, row_cnt, blk);
+    keep_fill_g_k<kKeepGroup><<<nb, kBlock, 0, st>>>(in_ptr, in_ent, gate, row_cnt, blk, N, keep_ptr, keep_ent);
+    return check_launch();
+  }
   keep_count_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, N, row_cnt, blk);
   keep_fill_k<<<nblk(N), kBlock, 0, st>>>(in_ptr, in_ent, gate, row_cnt, blk, N, keep_ptr, keep_ent);
   return check_launch();

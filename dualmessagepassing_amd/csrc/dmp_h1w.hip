@@ -56,6 +56,7 @@ constexpr int kImgB = 2 * kOpB;                      // dO then H1: 98304
 constexpr int kScrB = 4 * 32 * kScrStride * 4;       // the row waves' accumulator transposes: 18432
 constexpr int kRowCB = 3 * kSub * 4;                 // store rows of three tiles in flight
 constexpr int kH1WLdsBytes = kImgB + kScrB + kRowCB; // 117120: dynamic LDS, opted in once per device
+constexpr int kMaxDevicesW2 = 64;
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s *lds_v4s_ptr;
@@ -358,6 +359,233 @@ __global__ __launch_bounds__(kThreadsW, 1) void h1w_k(const H1WArgs p) {
   }
 }
 
+
+// ============================================================================================================================
+// The tall-skinny weight gradients  T = sum_e Z[e]^T D[e]  (and, class-typed, B = sum_e c_e Z[e]^T D[e]) over a tile list on the
+// same image (dmp_atb2_typed / dmp_atb2_jobs; what csrc/dmp_atb.hip's bf16x6 kernels compute).  There every wave reads fp32
+// fragments down the columns of an fp32 LDS tile and splits them into bf16 pieces ITSELF -- the splits (5.5 VALU instructions
+// per element, every fragment split by every wave that needs it) are what bound those kernels (2.9 TB/s of rows at bench.py's
+// shape).  Here the staging thread splits each fetched element ONCE into the three bf16 planes and all eight waves of the
+// 512-thread workgroup read their fragments through ds_read_b64_tr_b16: no VALU work in the MFMA loop beyond addresses.
+// Waves 0-3's threads stage Z rows, waves 4-7's stage D rows (two tiles of rows in flight per thread); wave w owns the
+// 64 x 32 block of the [128, 128] total at rows 64 (w & 1), columns 32 (w >> 1): two accumulators.  A class that ends inside
+// the workgroup's tile range emits  T += acc, B += c acc  straight from the accumulators into its own partial (read-modify-
+// write by the same lane: a fixed order) and restarts them.  blockIdx.y = the job: several products over the SAME tile list
+// (the node side's three weight gradients over the kept nodes' tiles) share one launch of one workgroup per CU.
+struct Atb2Job { const float *Z; int64_t ldz; const float *D; int64_t ldd; float *pT, *pB; int64_t pstride; int ldp; };
+constexpr int kAtb2MaxJobs = 6;
+struct Atb2Args {
+  Atb2Job job[kAtb2MaxJobs];
+  int64_t E;                        // rows of every operand
+  const int32_t *slot_edge;         // [tiles * 32] row of every slot, -1 = padding
+  const float *tile_scale;          // [tiles] coefficient of the tile's class
+  const int32_t *num_tiles;         // [1] tiles in use (device)
+};
+constexpr int kAtb2LdsBytes = kImgB;
+
+__global__ __launch_bounds__(kThreadsW, 1) void atb2_k(const Atb2Args p) {
+  extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+  const Atb2Job &jb_ = p.job[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool dside = wave >= 4;                          // staging role: false = rows of Z, true = rows of D
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int u = threadIdx.x & 255;
+  const int srow = u >> 5, scol = u & 31;
+
+  const int ntiles = __builtin_amdgcn_readfirstlane(*p.num_tiles);
+  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int mine = hi > lo ? hi - lo : 0;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));
+  const srsrc_t rs_X = dside ? make_srsrc(jb_.D, jb_.ldd, p.E) : make_srsrc(jb_.Z, jb_.ldz, p.E);
+  const uint32_t op_off = dside ? (uint32_t)kOpB : 0u;
+  float *const pt = jb_.pT + (int64_t)blockIdx.x * jb_.pstride;
+  float *const pb = jb_.pB ? jb_.pB + (int64_t)blockIdx.x * jb_.pstride : nullptr;
+  const int ldp = jb_.ldp;
+
+  const int pw = wave & 1, cw = wave >> 1;               // this wave's block of the total: rows 64 pw .., columns 32 cw ..
+  f32x16 acc[2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  };
+  // accumulator (i, r): output row 64 pw + 32 i + (r & 3) + 8 (r >> 2) + 4 h, column 32 cw + li -- through buffer descriptors:
+  // one per-lane offset, the (i, r) part of the address as a scalar offset (no per-element address registers)
+  const rsrc_t rs_pt = make_rsrc(pt, (uint32_t)(kHW * ldp * 4));
+  const rsrc_t rs_pb = make_rsrc(pb, pb ? (uint32_t)(kHW * ldp * 4) : 0u);
+  const uint32_t e_voff = (uint32_t)((64 * pw + 4 * h) * ldp + 32 * cw + li) * 4u;
+  const uint32_t ldp4 = (uint32_t)__builtin_amdgcn_readfirstlane(ldp * 4);
+  bool emitted = false;
+  auto emit = [&](float c) {
+    // (all reads of what this lane stored before are requested together, then one wait: an element at a time the emission
+    // was 32 dependent round trips -- ~50 us per class boundary, more than the whole rest of the launch)
+    float t0[2][16], b0[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t so = (uint32_t)(32 * i + (r & 3) + 8 * (r >> 2)) * ldp4;
+        t0[i][r] = emitted ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pt, (int)e_voff, (int)so, 0)) : 0.f;
+        b0[i][r] = (emitted && pb) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pb, (int)e_voff, (int)so, 0)) : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t so = (uint32_t)(32 * i + (r & 3) + 8 * (r >> 2)) * ldp4;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(emitted ? acc[i][r] + t0[i][r] : acc[i][r]), rs_pt, (int)e_voff, (int)so, 0);
+        if (pb) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(emitted ? c * acc[i][r] + b0[i][r] : c * acc[i][r]), rs_pb, (int)e_voff, (int)so, 0);
+      }
+    emitted = true;
+  };
+  if (mine == 0) {                                       // (uniform per workgroup) this workgroup's partial: zeros
+    zero_acc();
+    emit(0.f);
+    return;
+  }
+
+  // ---- staging: two tiles of rows in flight per thread (sets alternate by tile parity), one tile staged ahead.  The slot ids of
+  // a tile are requested one step BEFORE the rows of the tile ahead of it: loads retire through one in-order counter, so ids
+  // requested behind a tile's row requests could only be waited for together with those rows -- one tile in flight, not two.
+  int id_rows[2][kSubLoads];
+  float4 pre[2][kSubLoads];
+  auto load_ids = [&](auto set, int k) {
+    constexpr int S = decltype(set)::value;
+    const bool ok = k < mine;
+    const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      id_rows[S][m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, (srow + 8 * m) * 4, (int)so, 0) : -1;
+  };
+  auto load_row = [&](auto set, int m) {
+    constexpr int S = decltype(set)::value;
+    pre[S][m] = sbuf_load4(rs_X, id_rows[S][m], (uint32_t)scol * 16u);
+  };
+  auto stage_row = [&](auto set, int buf, int m) {
+    constexpr int S = decltype(set)::value;
+    uint2 ph, pm, pl;
+    split_pair(pre[S][m].x, pre[S][m].y, ph.x, pm.x, pl.x);
+    split_pair(pre[S][m].z, pre[S][m].w, ph.y, pm.y, pl.y);
+    const uint32_t r = (uint32_t)(srow + 8 * m);
+    const uint32_t off = op_off + (uint32_t)buf * kBufB + 256u * r + 16u * ((uint32_t)(scol >> 1) ^ swz(r)) + 8u * (uint32_t)(scol & 1);
+    *reinterpret_cast<uint2 *>(lds + off) = ph;
+    *reinterpret_cast<uint2 *>(lds + off + kPlaneB) = pm;
+    *reinterpret_cast<uint2 *>(lds + off + 2 * kPlaneB) = pl;
+  };
+  std::integral_constant<int, 0> s0;
+  std::integral_constant<int, 1> s1;
+
+  // transposed reads (see h1w_k): fragment element 4 t + e of lane (li, h) = row 16 kg + 8 h + 4 t + e of the tile, column li of the block
+  const int G16 = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  auto tr_base = [&](int chunk8) {                       // chunk8: the block's first 16-byte chunk (a multiple of 4 blocks of 32 columns)
+    const uint32_t row0 = (uint32_t)(8 * (G16 >> 1) + q4);
+    const uint32_t ch0 = (uint32_t)(chunk8 + 2 * (G16 & 1) + (pp >> 1));
+    const uint32_t sw0 = ((uint32_t)q4 << 2) | (uint32_t)(2 * (G16 >> 1));
+    return 256u * row0 + 16u * (ch0 ^ sw0) + 8u * (uint32_t)(pp & 1);
+  };
+  const uint32_t tA = tr_base(8 * pw), tB = (uint32_t)kOpB + tr_base(4 * cw);    // A: chunks 8 pw + 4 i ..; B: chunks 4 cw ..
+  auto tr_frag = [&](uint32_t base, int buf, int plane, int blk, int kg, Frag8 &f) {
+    const uint32_t o0 = (base ^ (uint32_t)(64 * blk)) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg);
+    const uint32_t o1 = (base ^ (uint32_t)(64 * blk) ^ 16u) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg + 1024);
+    const v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o0));
+    const v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o1));
+    f.v = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto tr_split = [&](uint32_t base, int buf, int blk, int kg, Split8 &s) {
+    tr_frag(base, buf, 0, blk, kg, s.hi);
+    tr_frag(base, buf, 1, blk, kg, s.mid);
+    tr_frag(base, buf, 2, blk, kg, s.lo);
+  };
+  // one tile (buffer k & 1): 2 k-groups x 2 row blocks x 6 piece MFMAs; in their shadow: the staging of tile k+1 (its rows sit in
+  // set (k + 1) & 1 = nset), the id requests of tile k+4 (into the OTHER id set), then the row requests of tile k+3 into nset
+  // (its ids came one step ago, ahead of tile k+2's row requests)
+  auto tile_step = [&](int k, auto nset, auto oset) {
+    const int buf = k & 1;
+    int act = 0;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      Split8 fb;
+      tr_split(tB, buf, 0, kg, fb);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        Split8 fa;
+        tr_split(tA, buf, ib, kg, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[ib] = mfma_x6(fa, fb, acc[ib]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q, ++act) {
+          if (act < 4) stage_row(nset, buf ^ 1, act);
+          else {
+            if (act == 4) load_ids(oset, k + 4);
+            load_row(nset, act - 4);
+          }
+        }
+      }
+    }
+  };
+  // start the pipeline: tile 0 staged in buffer 0, the rows of tiles 1 / 2 requested into sets 1 / 0, the ids of tile 3 into set 1
+  auto start = [&]() {
+    load_ids(s0, 0);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) load_row(s0, m);
+    load_ids(s1, 1);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(s0, 0, m);
+    load_ids(s0, 2);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) load_row(s1, m);
+    load_ids(s1, 3);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) load_row(s0, m);
+    lds_barrier();
+  };
+
+  zero_acc();
+  float cur = 0.f, sv = 0.f;
+  unsigned long long starts = 0;
+  start();
+  for (int k = 0; k < mine; ++k) {
+    // the class structure of the range, 64 tiles at a time (lane l: tile 64 c + l; bit l of `starts`: that tile begins a new class)
+    if ((k & 63) == 0) {
+      const float last = __shfl(sv, 63);
+      sv = k + lane < mine ? p.tile_scale[lo + k + lane] : 0.f;
+      float up = __shfl_up(sv, 1);
+      if (lane == 0) up = k > 0 ? last : sv;
+      starts = __ballot(k + lane < mine && __float_as_uint(sv) != __float_as_uint(up));
+    }
+    if ((starts >> (k & 63)) & 1ull) {                    // (wave-uniform) tile k begins a new class: the finished class's total goes out
+      if (pb) { emit(cur); zero_acc(); }                  // (the plain total needs no class: nothing to scale)
+    }
+    cur = __shfl(sv, k & 63);
+    if (k & 1) tile_step(k, s0, s1);                      // tile k+1 is even: its rows sit in set 0
+    else tile_step(k, s1, s0);
+    lds_barrier();                                        // tile k+1 is staged for everyone, everyone is done with tile k's image
+  }
+  emit(cur);
+}
+
+inline unsigned atb2_blocks(int64_t tiles_bound, int num_jobs) {
+  int64_t g = 256 / (num_jobs > 0 ? num_jobs : 1);       // one workgroup per CU over all jobs
+  if (g < 1) g = 1;
+  if (g > tiles_bound) g = tiles_bound > 0 ? tiles_bound : 1;
+  return (unsigned)g;
+}
+
+inline bool atb2_lds_ready() {
+  static bool done[kMaxDevicesW2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesW2) dev = 0;
+  if (done[dev]) return true;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&atb2_k), hipFuncAttributeMaxDynamicSharedMemorySize, kAtb2LdsBytes);
+  if (e != hipSuccess) { set_last_hip_error(e); return false; }
+  done[dev] = true;
+  return true;
+}
+
 inline unsigned h1w_blocks(int64_t tiles_bound) {
   const int64_t cap = 256;                               // one workgroup per CU
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
@@ -409,6 +637,30 @@ int dmp_bwd_h1_w(const float *dO, int64_t ldo, const float *W2, int64_t ldw, con
   a.dO = dO; a.ldo = ldo; a.H1 = H1; a.ldh = ldh; a.W2 = W2; a.ldw = ldw; a.dPre = dPre; a.ldg = ldg; a.E = E;
   a.slot_edge = slot_edge; a.num_tiles = num_tiles; a.slope = slope; a.partial = partial; a.partialA = partial_rows; a.partialW = partial_w;
   h1w_k<<<h1w_blocks(tiles_bound), kThreadsW, kH1WLdsBytes, st>>>(a);
+  return check_launch();
+}
+
+
+int64_t dmp_atb2_blocks(int64_t tiles_bound, int num_jobs) { return (int64_t)atb2_blocks(tiles_bound, num_jobs); }
+
+int dmp_atb2_jobs(const dmp_atb2_job *jobs, int num_jobs, const int32_t *slot_row, const float *tile_scale, const int32_t *num_tiles,
+                  int64_t tiles_bound, int64_t rows, int H, void *stream) {
+  if (H != 128 || g_exact_fp32) return DMP_ERR_UNSUPPORTED;
+  if (!jobs || num_jobs < 1 || num_jobs > kAtb2MaxJobs || rows < 0 || tiles_bound < 0) return DMP_ERR_BAD_ARG;
+  if (!slot_row || !tile_scale || !num_tiles) return DMP_ERR_BAD_ARG;
+  if (rows >= ((int64_t)1 << 30) || tiles_bound * kSub * 4 >= ((int64_t)1 << 32) - 8192) return DMP_ERR_UNSUPPORTED;
+  Atb2Args a{};
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_atb2_job &j = jobs[i];
+    if (!j.partial_T || j.ldp < H || (rows > 0 && (!j.Z || !j.D || j.ldz < H || j.ldd < H))) return DMP_ERR_BAD_ARG;
+    if (j.ldz % 4 || j.ldd % 4 || (rows > 0 && (!aligned16(j.Z) || !aligned16(j.D)))) return DMP_ERR_UNSUPPORTED;
+    if (!stride_ok(j.ldz) || !stride_ok(j.ldd) || !fits4g(rows, j.ldz) || !fits4g(rows, j.ldd)) return DMP_ERR_UNSUPPORTED;
+    a.job[i].Z = j.Z; a.job[i].ldz = j.ldz; a.job[i].D = j.D; a.job[i].ldd = j.ldd; a.job[i].pT = j.partial_T; a.job[i].pB = j.partial_B;
+    a.job[i].pstride = j.partial_stride; a.job[i].ldp = j.ldp;
+  }
+  a.E = rows; a.slot_edge = slot_row; a.tile_scale = tile_scale; a.num_tiles = num_tiles;
+  if (!atb2_lds_ready()) return DMP_ERR_HIP;
+  atb2_k<<<dim3(atb2_blocks(tiles_bound, num_jobs), (unsigned)num_jobs), kThreadsW, kAtb2LdsBytes, (hipStream_t)stream>>>(a);
   return check_launch();
 }
 

@@ -559,6 +559,107 @@ int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M,
   return check_launch();
 }
 
+// ---- several kept-row lists in ONE pair of launches (dmp_kept_rows_jobs): blockIdx.y = the job; and, riding in the count
+// launch, the per-edge selectors with dead nodes as -1 (dmp_edge_select_nodes: needs the node mask only, as the lists do)
+struct KeptJobs {
+  const uint32_t *mask[DMP_KEPT_MAX_JOBS]; int64_t R[DMP_KEPT_MAX_JOBS]; int tiles[DMP_KEPT_MAX_JOBS]; int nb[DMP_KEPT_MAX_JOBS];
+  int32_t *scratch[DMP_KEPT_MAX_JOBS], *list[DMP_KEPT_MAX_JOBS], *count[DMP_KEPT_MAX_JOBS];
+  int n;
+  const int32_t *src, *dst; const uint8_t *flag; const uint32_t *nodemask; int64_t E; int32_t *selA, *selB, *dstM;
+};
+__global__ __launch_bounds__(kKeptWords) void kept_count_jobs_k(const KeptJobs t) {
+  const int j = blockIdx.y;
+  if (j == t.n) {                                   // the selectors: a grid-stride pass over the edges
+    for (int64_t e = (int64_t)blockIdx.x * kKeptWords + threadIdx.x; e < t.E; e += (int64_t)gridDim.x * kKeptWords) {
+      int u = t.src[e], v = t.dst[e];
+      if (!((t.nodemask[u >> 5] >> (u & 31)) & 1u)) u = -1;
+      if (!((t.nodemask[v >> 5] >> (v & 31)) & 1u)) v = -1;
+      const bool f = t.flag && t.flag[e];
+      t.selA[e] = f ? u : v;
+      t.selB[e] = f ? v : u;
+      t.dstM[e] = v;
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= t.nb[j]) return;
+  __shared__ int red[kKeptWords / 64];
+  const int64_t R = t.R[j], W = (R + 31) / 32, w = (int64_t)blockIdx.x * kKeptWords + threadIdx.x;
+  uint32_t m = w < W ? t.mask[j][w] : 0u;
+  if (w == W - 1 && (R & 31)) m &= (1u << (R & 31)) - 1u;
+  int c = __popc(m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < kKeptWords / 64; ++i) s += red[i]; t.scratch[j][blockIdx.x] = s; }
+}
+__global__ __launch_bounds__(kKeptWords) void kept_fill_jobs_k(const KeptJobs t) {
+  const int j = blockIdx.y;
+  if ((int)blockIdx.x >= t.nb[j]) return;
+  __shared__ int red[kKeptWords / 64], wtot[kKeptWords / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t *blk = t.scratch[j];
+  int32_t *list = t.list[j], *count = t.count[j];
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kKeptWords) before += blk[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int i = 0; i < kKeptWords / 64; ++i) before += red[i];
+  const int64_t R = t.R[j], W = (R + 31) / 32, w = (int64_t)blockIdx.x * kKeptWords + threadIdx.x;
+  uint32_t m = w < W ? t.mask[j][w] : 0u;
+  if (w == W - 1 && (R & 31)) m &= (1u << (R & 31)) - 1u;
+  const int c = __popc(m);
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int pos = before + incl - c;
+  for (int i = 0; i < wave; ++i) pos += wtot[i];
+  const int base = (int)(w * 32);
+  while (m) { const int b = __builtin_ctz(m); m &= m - 1; list[pos++] = base + b; }
+  if ((int)blockIdx.x == t.nb[j] - 1 && threadIdx.x == kKeptWords - 1) {
+    *count = pos;
+    if (t.tiles[j]) {
+      for (int i = pos; i < ((pos + 31) & ~31); ++i) list[i] = -1;
+      count[1] = (pos + 31) >> 5;
+    }
+  }
+}
+
+int dmp_kept_rows_jobs(const dmp_kept_job *jobs, int n, const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                       const uint32_t *nodemask, int64_t E, int32_t *selA, int32_t *selB, int32_t *dstM, void *stream) {
+  if (n < 0 || n > DMP_KEPT_MAX_JOBS || (n > 0 && !jobs) || E < 0) return DMP_ERR_BAD_ARG;
+  const bool sel = selA != nullptr;
+  if (sel && (E > 0) && (!src || !dst || !nodemask || !selB || !dstM)) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  KeptJobs t{};
+  int most = 0;
+  t.n = n;
+  for (int j = 0; j < n; ++j) {
+    const dmp_kept_job &q = jobs[j];
+    if (q.R <= 0 || q.R >= ((int64_t)1 << 31) - 32 || !q.mask || !q.scratch || !q.list || !q.count) return DMP_ERR_BAD_ARG;   // (empty lists: dmp_kept_rows)
+    t.mask[j] = q.mask; t.R[j] = q.R; t.tiles[j] = q.tiles ? 1 : 0; t.scratch[j] = q.scratch; t.list[j] = q.list; t.count[j] = q.count;
+    t.nb[j] = (int)(((q.R + 31) / 32 + kKeptWords - 1) / kKeptWords);
+    if (t.nb[j] > most) most = t.nb[j];
+  }
+  t.src = src; t.dst = dst; t.flag = flag; t.nodemask = nodemask; t.E = sel ? E : 0; t.selA = selA; t.selB = selB; t.dstM = dstM;
+  const bool with_sel = sel && E > 0;
+  if (n == 0 && !with_sel) return DMP_OK;
+  int gx = most;
+  if (with_sel) {
+    const int64_t eb = (E + kKeptWords - 1) / kKeptWords;
+    const int want = (int)(eb < 1024 ? eb : 1024);
+    if (want > gx) gx = want;
+  }
+  kept_count_jobs_k<<<dim3((unsigned)gx, (unsigned)(n + (with_sel ? 1 : 0))), kKeptWords, 0, st>>>(t);
+  if (n > 0) kept_fill_jobs_k<<<dim3((unsigned)most, (unsigned)n), kKeptWords, 0, st>>>(t);
+  return check_launch();
+}
+
 int64_t dmp_kept_rows_scratch_words(int64_t R) { return ((R + 31) / 32 + kKeptWords - 1) / kKeptWords + 1; }
 
 int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int tiles, int32_t *scratch, int32_t *list, int32_t *count, void *stream) {

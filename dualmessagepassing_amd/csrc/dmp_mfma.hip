@@ -588,6 +588,19 @@ __global__ __launch_bounds__(256) void row_mask_bits_k(const float *__restrict__
   if ((lane & 31) == 0 && r < ((E + 31) / 32) * 32) mask[r >> 5] = (uint32_t)(b >> (lane & 32));
 }
 
+// several gates in one launch (dmp_row_mask_bits_jobs: the union's node gate and edge gate of a step): blockIdx.y = the job
+struct RowMaskJobs { const float *gate[DMP_ROWMASK_MAX_JOBS]; int64_t R[DMP_ROWMASK_MAX_JOBS]; uint32_t *mask[DMP_ROWMASK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void row_mask_bits_jobs_k(const RowMaskJobs t) {
+  const int j = blockIdx.y;
+  const int64_t E = t.R[j];
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int64_t)blockIdx.x * 256 >= ((E + 31) / 32) * 32) return;          // (whole blocks past the job's rows)
+  const bool on = r < E && t.gate[j][r] != 0.f;
+  const unsigned long long b = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0 && r < ((E + 31) / 32) * 32) t.mask[j][r >> 5] = (uint32_t)(b >> (lane & 32));
+}
+
 // bit r of mask[t] = (row 32 t + r of X [R, ldx] has a non-zero among its first K entries)
 __global__ __launch_bounds__(256) void row_mask_rows_k(const float *__restrict__ X, int64_t ldx, int K, int64_t R, uint32_t *__restrict__ mask) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -699,6 +712,20 @@ int dmp_row_mask_bits(const float *gate, int64_t E, uint32_t *mask, void *stream
   if (E == 0) return DMP_OK;
   if (!gate || !mask) return DMP_ERR_BAD_ARG;
   row_mask_bits_k<<<(unsigned)((E + 255) / 256), 256, 0, (hipStream_t)stream>>>(gate, E, mask);
+  return check_launch();
+}
+
+int dmp_row_mask_bits_jobs(const dmp_rowmask_job *jobs, int n, void *stream) {
+  if (!jobs || n < 1 || n > DMP_ROWMASK_MAX_JOBS) return DMP_ERR_BAD_ARG;
+  RowMaskJobs t{};
+  int64_t most = 0;
+  for (int j = 0; j < n; ++j) {
+    if (jobs[j].R < 0 || (jobs[j].R > 0 && (!jobs[j].gate || !jobs[j].mask))) return DMP_ERR_BAD_ARG;
+    t.gate[j] = jobs[j].gate; t.R[j] = jobs[j].R; t.mask[j] = jobs[j].mask;
+    if (jobs[j].R > most) most = jobs[j].R;
+  }
+  if (most == 0) return DMP_OK;
+  row_mask_bits_jobs_k<<<dim3((unsigned)((most + 255) / 256), (unsigned)n), 256, 0, (hipStream_t)stream>>>(t);
   return check_launch();
 }
 

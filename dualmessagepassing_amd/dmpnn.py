@@ -397,11 +397,19 @@ def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(),
         side.mark("index")
         vg, eg = _joint_gates(v_gate, e_gate, np_, ep_, th.float32, e_gate.device)
         N, E = ix.num_nodes, ix.num_edges
+        typed = fused.typed_ok(ix, H)
+        # both gates' row masks, the three kept-row lists below and the kept nodes' selectors: three launches instead of ten
+        # (fused.gate_bundle plants each product in the memo its own function reads; the conditions are those tested below)
+        want_nodes = bool(N >= 4096 and fused.onepanel_ok(H) and fused.USE_NODE_ROWS and fused.USE_PLAIN_ATB and fused.zero_rows_gate(vg) and typed and E > 0)
+        want_l0 = bool(typed and fused.SKIP_DEAD_ROWS and fused.USE_ROW_MASKS and fused.USE_L0_ROW_LISTS and len(layers) > 1 and ep_ % 32 == 0
+                       and E - ep_ >= fused.L0_LIST_MIN_ROWS and th.is_grad_enabled())
+        want_asc = bool(typed and fused.zero_rows_gate(eg) and fused.USE_PLAIN_ATB and getattr(eg, "_dmp_binary", False)
+                        and (fused.PLAIN_ROWS_ASCENDING or (fused.PLAIN_ATB_ASCENDING and th.is_grad_enabled())))
+        fused.gate_bundle(ix, vg, eg, want_nodes, (ep_, E) if want_l0 else None, want_asc)
         nd = None
         if N >= 4096 and fused.onepanel_ok(H):
             nd = fused.node_rows(ix, vg, H)
         side.mark("nodes")
-        typed = fused.typed_ok(ix, H)
         if typed and fused.SKIP_DEAD_ROWS and fused.USE_ROW_MASKS:
             mask = fused.gate_row_mask(eg)
             if (mask is not None and fused.USE_L0_ROW_LISTS and len(layers) > 1 and ep_ % 32 == 0 and E - ep_ >= fused.L0_LIST_MIN_ROWS

@@ -204,7 +204,7 @@ def keep_pool_csr(pool, gate):
     nscr = int(lib.dmp_csr_keep_scratch_words(V))
     ws = torch.empty(nscr + V + 1 + pool.vent.numel(), dtype=torch.int32, device=dev)
     row_cnt, kptr, kent = ws[:nscr], ws[nscr:nscr + V + 1], ws[nscr + V + 1:]
-    check(lib.dmp_csr_keep(ptr(pool.vptr), ptr(pool.vent), ptr(gate.reshape(-1)), V, ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()),
+    check(lib.dmp_csr_keep(ptr(pool.vptr), ptr(pool.vent), ptr(gate.reshape(-1)), V, pool.vent.numel(), ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()),
           "dmp_csr_keep")
     memo[1][id(pool)] = (pool, (kptr, kent))
     return kptr, kent
@@ -379,6 +379,7 @@ def edge_fwd_typed(z, Wes, P, ldp, bias, coef, index, slope=0.0, dead_gate=None,
     return out
 
 
+import ctypes as _ctypes
 import os as _os
 
 
@@ -451,8 +452,8 @@ def keep_in_csr(index, gate):
     nscr = int(lib.dmp_csr_keep_scratch_words(N))
     ws = torch.empty(nscr + N + 1 + index.in_ent.numel(), dtype=torch.int32, device=dev)
     row_cnt, keep_ptr, keep_ent = ws[:nscr], ws[nscr:nscr + N + 1], ws[nscr + N + 1:]
-    check(lib.dmp_csr_keep(ptr(index.in_ptr), ptr(index.in_ent), ptr(gate.reshape(-1)), N, ptr(row_cnt), ptr(keep_ptr), ptr(keep_ent),
-                           stream_ptr()), "dmp_csr_keep")
+    check(lib.dmp_csr_keep(ptr(index.in_ptr), ptr(index.in_ent), ptr(gate.reshape(-1)), N, index.in_ent.numel(), ptr(row_cnt), ptr(keep_ptr),
+                           ptr(keep_ent), stream_ptr()), "dmp_csr_keep")
     res = (keep_ptr, keep_ent)
     try:
         owner._dmp_keep_csr = (owner._version, index, res)
@@ -466,6 +467,43 @@ def keep_in_csr(index, gate):
 # memory front to back (measured on one box: atb_typed plain 81 -> 71 us, bwd_h1_typed 77 -> 72 us; -0.03 ms per step)
 PLAIN_ATB_ASCENDING = True
 PLAIN_ROWS_ASCENDING = True
+
+
+_ZEROS = {}
+
+
+def const_zeros(n, device):
+    """A read-only float32 zero vector of ``n`` entries (a view of one cached buffer per device): the ``tile_scale`` of tile lists
+    whose kernels use a plain panel -- nobody writes it, so no launch fills it step after step.  Inside a stream capture a
+    buffer made NOW would belong to the recording's pool: a fresh tensor there, as before."""
+    key = (device.type, device.index)
+    buf = _ZEROS.get(key)
+    if buf is None or buf.numel() < n:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        buf = _ZEROS[key] = torch.zeros(max(n, 1 << 16), dtype=torch.float32, device=device)
+    return buf[:n]
+
+
+_IDENTITY_TILES = {}
+
+
+def identity_tiles(R, device):
+    """The tile slot list of ALL rows 0 .. R-1 in order (padding -1 up to a whole tile), for the tile kernels on launches without
+    a gate: ``(slot, tile_scale (zeros), num_tiles, bound)``.  A constant of (R, device): built once outside any recording."""
+    key = (int(R), device.type, device.index)
+    hit = _IDENTITY_TILES.get(key)
+    if hit is not None:
+        return hit
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return None                      # (never made inside a recording: the first, eager step of a shape makes it)
+    bound = (R + 31) // 32
+    slot = torch.arange(bound * 32, dtype=torch.int32, device=device)
+    slot[R:] = -1
+    res = (slot, const_zeros(bound, device), torch.tensor([bound], dtype=torch.int32, device=device), bound)
+    if len(_IDENTITY_TILES) < 64:
+        _IDENTITY_TILES[key] = res
+    return res
 
 
 def ascending_tiles(gate):
@@ -482,7 +520,7 @@ def ascending_tiles(gate):
     R = gate.numel()
     lst, cnt = kept_rows(mask, 0, R, tiles=True)
     bound = (R + 31) // 32
-    res = (lst, torch.zeros(bound, dtype=torch.float32, device=mask.device), cnt[1:2], bound)
+    res = (lst, const_zeros(bound, mask.device), cnt[1:2], bound)
     try:
         owner._dmp_asc_tiles = (owner._version, res)
     except Exception:
@@ -528,6 +566,45 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     return out
 
 
+USE_ATB2 = _os.environ.get("DMP_DEV_ATB2", "1") == "1"     # the tile-list weight gradients on the bf16-piece LDS image (``dmp_atb2_jobs``)
+
+
+class _Atb2Job(_ctypes.Structure):
+    _fields_ = [("Z", _ctypes.c_void_p), ("ldz", _ctypes.c_int64), ("D", _ctypes.c_void_p), ("ldd", _ctypes.c_int64),
+                ("partial_T", _ctypes.c_void_p), ("partial_B", _ctypes.c_void_p), ("partial_stride", _ctypes.c_int64), ("ldp", _ctypes.c_int)]
+
+
+def atb2_ok(a, b, H):
+    lib = _lib.load()
+    lim = (1 << 32) - 65536
+    return bool(USE_ATB2 and H == 128 and not lib.dmp_dev_get_exact_fp32() and a.size(0) == b.size(0) and a.size(0) * a.stride(0) * 4 < lim
+                and b.size(0) * b.stride(0) * 4 < lim and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
+                and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def atb2(pairs, tiles, wide=False):
+    """``[a^T b for (a, b) in pairs]`` over the rows of ``tiles`` (a, b: [R, 128] operands, column slices allowed): the products of
+    ONE launch (``dmp_atb2_jobs``: at most 6).  ``wide``: each result is ``[a^T b | a^T (c (.) b)]`` ([128, 256]; c = the class
+    coefficient of a row's tile: ``atb_typed``'s layout of dWes)."""
+    lib = _lib.load()
+    slot, tile_scale, num_tiles, bound = tiles
+    n, H = len(pairs), 128
+    R = pairs[0][0].size(0)
+    G = int(lib.dmp_atb2_blocks(bound, n))
+    W = 2 * H if wide else H
+    jobs = (_Atb2Job * n)()
+    parts = []
+    for j, (a, b) in enumerate(pairs):
+        part = torch.empty((G, H * W), dtype=torch.float32, device=a.device)
+        parts.append(part)
+        jobs[j].Z, jobs[j].ldz, jobs[j].D, jobs[j].ldd = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+        jobs[j].partial_T, jobs[j].partial_B = part.data_ptr(), (part.data_ptr() + 4 * H if wide else None)
+        jobs[j].partial_stride, jobs[j].ldp = H * W, W
+    with _lib.timed("atb2[jobs=%d,R=%d]", (n, R), 8 * H * R * n):
+        check(lib.dmp_atb2_jobs(jobs, n, ptr(slot), ptr(tile_scale), ptr(num_tiles), bound, R, H, stream_ptr()), "dmp_atb2_jobs")
+    return [reduce_partials(part).view(H, W) for part in parts]
+
+
 def atb_typed(z, d_pre, coef, index, gate=None, plain=False):
     """``[z^T d_pre | z^T (coef[dst] (.) d_pre)]``  ([H, 2H]: the gradient of ``Wes`` in its layout) over the
     class-sorted tiles: one product's worth of MFMAs for both halves (csrc/dmp_atb.hip), one fixed-order
@@ -547,6 +624,9 @@ def atb_typed(z, d_pre, coef, index, gate=None, plain=False):
         ms = masked_slots(index, coef, gate)
         if ms is not None:
             slot_edge = ms
+    if atb2_ok(z, d_pre, H):
+        # every fetched element split into bf16 pieces once, fragments through transposed LDS reads (csrc/dmp_h1w.hip::atb2_k)
+        return atb2([(z, d_pre)], (slot_edge, tile_scale, num_tiles, bound), wide=not plain)[0]
     G = int(lib.dmp_atb_typed_blocks_h(bound, H))
     if plain:       # ``z^T d_pre`` alone ([H, H]): half the partials
         part = torch.empty((G, H, H), dtype=torch.float32, device=z.device)
@@ -709,6 +789,7 @@ def bwd_h1_typed(d_o, W2, h1, tiles, slope=0.0, out=None):
     return d_g, reduce_partials(part), reduce_partials(part_rows)
 
 
+USE_H1W_DENSE = True    # ... also where no gate applies (every row live): over the identity tile list
 USE_H1W = True    # the second edge Linear's backward as ONE launch (dPre and dO^T H1 from the same fetched rows, csrc/dmp_h1w.hip)
 
 
@@ -971,6 +1052,99 @@ def _kept_row_tiles(mask, r0, r1):
     return lst, cnt
 
 
+USE_GATE_BUNDLE = True      # the index arrays a step derives from its two 0 / 1 gates in three launches instead of ten (``gate_bundle``)
+
+
+class _RowMaskJob(_ctypes.Structure):
+    _fields_ = [("gate", _ctypes.c_void_p), ("R", _ctypes.c_int64), ("mask", _ctypes.c_void_p)]
+
+
+class _KeptJob(_ctypes.Structure):
+    _fields_ = [("mask", _ctypes.c_void_p), ("R", _ctypes.c_int64), ("tiles", _ctypes.c_int), ("scratch", _ctypes.c_void_p),
+                ("list", _ctypes.c_void_p), ("count", _ctypes.c_void_p)]
+
+
+def _mask_owner(gate):
+    owner = gate._base if gate._base is not None else gate
+    if owner.data_ptr() != gate.data_ptr() or owner.numel() != gate.numel():
+        owner = gate
+    return owner
+
+
+def gate_bundle(index, v_gate, e_gate, want_nodes=False, l0_range=None, want_ascending=False):
+    """What ``gate_row_mask`` (both gates), ``kept_rows`` (the kept nodes' tiles, the first layer's kept target rows, the kept
+    edges' ascending tiles) and ``GraphIndex.edge_select_nodes`` build in ten launches of ~5 us -- links of the step's index
+    chain, which the first layer waits for -- in THREE: both masks (``dmp_row_mask_bits_jobs``), then every list's block counts
+    and the selectors, then every list's fill (``dmp_kept_rows_jobs``).  Each product lands in the memo its own function looks
+    it up in (same bits: the multi-job kernels are the single ones over ``blockIdx.y``); anything not asked for, or already
+    there, is left to those functions."""
+    if not USE_GATE_BUNDLE or not USE_ROW_MASKS:
+        return
+    lib = _lib.load()
+    todo = []
+    for g in (v_gate, e_gate):
+        if g is None or not g.is_cuda or g.dtype != torch.float32:
+            return
+        owner = _mask_owner(g)
+        if getattr(owner, "_dmp_dense_gate", False):
+            return
+        hit = getattr(owner, "_dmp_row_mask", None)
+        if hit is None or hit[0] != owner._version:
+            todo.append((g, owner))
+    if todo:
+        jobs = (_RowMaskJob * len(todo))()
+        masks = []
+        for j, (g, owner) in enumerate(todo):
+            R = g.numel()
+            m = torch.empty(((R + 31) // 32,), dtype=torch.int32, device=g.device)
+            masks.append(m)
+            jobs[j].gate, jobs[j].R, jobs[j].mask = ptr(g), R, ptr(m)
+        check(lib.dmp_row_mask_bits_jobs(jobs, len(todo), stream_ptr()), "dmp_row_mask_bits_jobs")
+        for (g, owner), m in zip(todo, masks):
+            try:
+                owner._dmp_row_mask = (owner._version, m)
+            except Exception:
+                return
+    vmask, emask = gate_row_mask(v_gate), gate_row_mask(e_gate)
+    if vmask is None or emask is None:
+        return
+    N, E = index.num_nodes, index.num_edges
+    lists = []          # (mask view, R, tiles, memo dict, key)
+    if want_nodes and N > 0:
+        memo = vmask.__dict__.setdefault("_dmp_kept_tiles", {})
+        if (0, N) not in memo:
+            lists.append((vmask, N, 1, memo, (0, N)))
+    if l0_range is not None and l0_range[1] > l0_range[0] and l0_range[0] % 32 == 0:
+        memo = emask.__dict__.setdefault("_dmp_kept_rows", {})
+        if tuple(l0_range) not in memo:
+            lists.append((emask[l0_range[0] // 32:], l0_range[1] - l0_range[0], 0, memo, tuple(l0_range)))
+    if want_ascending and E > 0:
+        memo = emask.__dict__.setdefault("_dmp_kept_tiles", {})
+        if (0, E) not in memo:
+            lists.append((emask, E, 1, memo, (0, E)))
+    sel = want_nodes and E > 0 and (getattr(index, "_esel_nodes", None) is None or index._esel_nodes[0] is not vmask)
+    if not lists and not sel:
+        return
+    jobs = (_KeptJob * max(len(lists), 1))()
+    keep = []
+    for j, (m, R, tiles, memo, key) in enumerate(lists):
+        cap = (R + 31) // 32 * 32 if tiles else R
+        ncnt = 2 if tiles else 1
+        out = torch.empty(cap + ncnt + int(lib.dmp_kept_rows_scratch_words(R)), dtype=torch.int32, device=m.device)
+        lst, cnt, scratch = out[:cap], out[cap:cap + ncnt], out[cap + ncnt:]
+        jobs[j].mask, jobs[j].R, jobs[j].tiles, jobs[j].scratch, jobs[j].list, jobs[j].count = ptr(m), R, tiles, ptr(scratch), ptr(lst), ptr(cnt)
+        keep.append((memo, key, (lst, cnt)))
+    so = torch.empty((3, E), dtype=torch.int32, device=index.device) if sel else None
+    check(lib.dmp_kept_rows_jobs(jobs, len(lists), ptr(index.src32) if sel else None, ptr(index.dst32) if sel else None,
+                                 ptr(index.rev8) if sel else None, ptr(vmask) if sel else None, E if sel else 0,
+                                 ptr(so[0]) if sel else None, ptr(so[1]) if sel else None, ptr(so[2]) if sel else None, stream_ptr()),
+          "dmp_kept_rows_jobs")
+    for memo, key, val in keep:
+        memo[key] = val
+    if sel:
+        index._esel_nodes = (vmask, (so[0], so[1], so[2]))
+
+
 USE_NODE_ROWS = _os.environ.get("DMP_NODE_ROWS", "1") == "1"   # the node side of a layer over the nodes a 0 / 1 node gate keeps
 USE_KEPT_INCIDENCE = True     # ... and its backward's endpoint sums as a segment sum over the kept edges' incidence CSR
 USE_NODE_TILE_ATB = True      # ... and the node side's weight gradients over the kept nodes' tiles
@@ -1029,7 +1203,7 @@ def node_rows(index, v_gate, H):
     N = index.num_nodes
     lst, cnt = kept_rows(mask, 0, N, tiles=True)
     bound = (N + 31) // 32
-    scale = torch.zeros(bound, dtype=torch.float32, device=mask.device)
+    scale = const_zeros(bound, mask.device)
     res = NodeRows(mask, (lst, cnt[0:1]), (lst, scale, cnt[1:2], bound), index.edge_select_nodes(mask),
                    prefix=min(int(getattr(owner, "_dmp_ones_prefix", 0)), N))
     try:
@@ -1184,6 +1358,37 @@ def atb_rows_multi(products, tiles=None):
                                                                           ("rowmask", P)]})
     R = products[0][0].size(0)
     products = [tuple(pr) + (None,) * (5 - len(pr)) for pr in products]
+    if (tiles is not None and all(gate is None and not colsum and mask is None for _, _, gate, colsum, mask in products)
+            and all(a.size(1) % 128 == 0 and b.size(1) % 128 == 0 and atb2_ok(a, b, 128) for a, b, _, _, _ in products)):
+        # over a tile list: 128 x 128 output blocks as jobs of ``dmp_atb2_jobs`` (at most 6 per launch), every product's blocks
+        # written into ONE partial of its own shape, so that one fixed-order reduction per product gives the [M, N] result
+        blocks = [(pi, ia, ib) for pi, (a, b, _, _, _) in enumerate(products) for ia in range(a.size(1) // 128) for ib in range(b.size(1) // 128)]
+        slot, tile_scale, num_tiles, bound = tiles
+        res = []
+        for i0 in range(0, len(blocks), 6):
+            chunk = blocks[i0:i0 + 6]
+            G = int(lib.dmp_atb2_blocks(bound, len(chunk)))
+            jobs2 = (_Atb2Job * len(chunk))()
+            parts2 = {}
+            for j, (pi, ia, ib) in enumerate(chunk):
+                a, b = products[pi][0], products[pi][1]
+                M, N = a.size(1), b.size(1)
+                if pi not in parts2:
+                    parts2[pi] = torch.empty((G, M * N), dtype=torch.float32, device=a.device)
+                jobs2[j].Z, jobs2[j].ldz = a.data_ptr() + 4 * 128 * ia, a.stride(0)
+                jobs2[j].D, jobs2[j].ldd = b.data_ptr() + 4 * 128 * ib, b.stride(0)
+                jobs2[j].partial_T, jobs2[j].partial_B = parts2[pi].data_ptr() + 4 * (ia * 128 * N + ib * 128), None
+                jobs2[j].partial_stride, jobs2[j].ldp = M * N, N
+            with _lib.timed("atb2[jobs=%d,R=%d]", (len(chunk), R), 8 * 128 * R * len(chunk)):
+                check(lib.dmp_atb2_jobs(jobs2, len(chunk), ptr(slot), ptr(tile_scale), ptr(num_tiles), bound, R, 128, stream_ptr()), "dmp_atb2_jobs")
+            res.append(parts2)
+        out = []
+        for pi, (a, b, _, _, _) in enumerate(products):
+            hold = [r_[pi] for r_ in res if pi in r_]
+            if len(hold) != 1:      # (a product whose blocks fell into two launches: not with <= 6 blocks; kept simple)
+                raise _lib.DmpError("atb_rows_multi(tiles=...): a product's blocks must share one launch")
+            out.append((reduce_partials(hold[0]).view(a.size(1), b.size(1)), None))
+        return out
     blk = min(atb_block(a.size(1), b.size(1)) for a, b, _, _, _ in products)     # one block size per launch
     nblk = sum((a.size(1) // blk) * (b.size(1) // blk) for a, b, _, _, _ in products)
     if nblk > MAX_ATB_JOBS:
@@ -1743,8 +1948,14 @@ class _FusedDMPLayer(torch.autograd.Function):
                     else:
                         dW2e = atb_rows(dzn, H1e, ctx.e_gate, colsum=False)[0]
                 else:
-                    dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
-                    dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
+                    it = identity_tiles(dzn.size(0), dzn.device) if (ctx.e_gate is None and USE_H1W_DENSE and h1w_ok(dzn, H1e, H)) else None
+                    if it is not None:
+                        # no gate at all (a model without a filter net: the reference's one-label datasets): every row is live --
+                        # both products of the second Linear's backward in one launch over the identity tile list
+                        dG, dbe, db2e, dW2e = bwd_h1_w(dzn, eW2, H1e, it, slope)
+                    else:
+                        dW2e, db2e = atb_rows(dzn, H1e, ctx.e_gate)
+                        dG, dbe = bwd_h1_mfma(dzn, eW2, H1e, coef, ix, both_halves=False, gate=ctx.e_gate, slope=slope)  # dG is dPre
             else:
                 dOe, db2e = scale_rows_colsum(dzn, ctx.e_gate)
                 dW2e = atb(dOe, H1e)

@@ -180,6 +180,16 @@ class GraphIndex:
         return ep
 
     MAX_EDGE_CLASSES = 65536
+    USE_DEGREE_HINT = True       # class tables sized by the batch's largest graph (``max_degree_hint``) where it is known
+    max_degree_hint = None
+
+    def _num_classes(self):
+        """Classes the device build lays its tables out for: the integer degrees 0 .. hint (+ the overflow class, which a degree
+        above the hint would land in and poison with NaN: loud, not silently wrong), or MAX_EDGE_CLASSES without a hint."""
+        h = self.max_degree_hint
+        if not self.USE_DEGREE_HINT or h is None:
+            return self.MAX_EDGE_CLASSES
+        return max(2, min(self.MAX_EDGE_CLASSES, int(h) + 2))
 
     def class_tiles(self, coef):
         """Tile list of the class-typed edge kernels (csrc/dmp_typed.hip): edges sorted by their
@@ -206,7 +216,7 @@ class GraphIndex:
         """``coef`` came from ``degree_coef(deg)``: classes are the integer degrees; five HIP launches
         (``dmp_class_tiles``), slot order = class, node id, edge id."""
         lib = _lib.load()
-        E, N, C, dev = self.num_edges, self.num_nodes, self.MAX_EDGE_CLASSES, self.device
+        E, N, C, dev = self.num_edges, self.num_nodes, self._num_classes(), self.device
         bound = E // 32 + C + 1
         slot_edge = torch.empty(bound * 32, dtype=torch.int32, device=dev)
         tile_scale = torch.empty(bound, dtype=torch.float32, device=dev)
@@ -224,7 +234,7 @@ class GraphIndex:
         if src is None or src[0] is not coef or self.num_edges == 0:
             return None
         lib = _lib.load()
-        E, N, C, dev = self.num_edges, self.num_nodes, self.MAX_EDGE_CLASSES, self.device
+        E, N, C, dev = self.num_edges, self.num_nodes, self._num_classes(), self.device
         bound = E // 32 + C + 1
         slot_edge = torch.empty(bound * 32, dtype=torch.int32, device=dev)
         tile_scale = torch.empty(bound, dtype=torch.float32, device=dev)
@@ -451,6 +461,10 @@ class BatchedGraph:
             self._index_key = key
         self._index.tiling = getattr(self, "tiling", None)
         self._index.node_tiling = getattr(self, "node_tiling", None)
+        # a node's degree is at most the number of edges of ITS graph: where the batch knows its largest graph (a host int the
+        # dataset keeps), the degree-class tile build sizes its class table by that instead of by MAX_EDGE_CLASSES
+        me = getattr(self, "max_num_edges", None)
+        self._index.max_degree_hint = int(me) if (me is not None and self.is_batched_on_device()) else None
         return self._index
 
     def in_degrees(self):

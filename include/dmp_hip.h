@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 74
+#define DMP_ABI_VERSION 77
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -357,8 +357,10 @@ int dmp_class_tiles_gated(const int64_t *deg, const int32_t *in_ptr, const int32
  * (dmp_seg_sum2: the node aggregation of dmpnn.py:92,163) reads the kept rows only -- for summands that are zeros under a zero
  * gate the same sums (x + 0 = x), without the skipped rows' entries in its instruction stream. */
 int64_t dmp_csr_keep_scratch_words(int64_t num_nodes);
-int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t num_nodes, int32_t *row_cnt,
-                 int32_t *keep_ptr, int32_t *keep_ent, void *stream);
+int dmp_csr_keep(const int32_t *in_ptr, const int32_t *in_ent, const float *gate, int64_t num_nodes, int64_t num_entries,
+                 int32_t *row_cnt, int32_t *keep_ptr, int32_t *keep_ent, void *stream);
+/* (num_entries: a host-side hint, entries of in_ent or 0 = unknown: from 12 entries per row on average -- a pooling index's chunk
+ * table -- a group of 16 lanes walks a row instead of one thread; same arrays, same bits) */
 
 /* Exclusive prefix sum of int64 counts; out has n+1 entries (out[n] = total).
  * ws: scratch of dmp_scan_workspace_words(n) int64 words. */
@@ -708,6 +710,22 @@ int dmp_l0_bwd_w_masked(const float *enc, int64_t lde, int K, const float *coef_
  *   multiple of 32 are -1 (padding slots), count [2] with count[1] = the number of tiles. */
 int64_t dmp_kept_rows_scratch_words(int64_t R);
 int dmp_kept_rows(const uint32_t *rowmask, int64_t R, int tiles, int32_t *scratch, int32_t *list, int32_t *count, void *stream);
+/* Several lists in ONE pair of launches (a step derives three from its two 0 / 1 gates: the kept nodes' tiles, the first layer's
+ * kept target edges, the kept edges' tiles in ascending order), and -- selA != NULL -- dmp_edge_select_nodes' three arrays from the
+ * count launch (they need the node mask only, as the lists do): what were seven launches of ~5 us in the step's index chain.
+ * Every job as dmp_kept_rows (R > 0); same bits. */
+#define DMP_KEPT_MAX_JOBS 4
+typedef struct {
+  const uint32_t *mask; int64_t R; int tiles;
+  int32_t *scratch;                    /* dmp_kept_rows_scratch_words(R) words */
+  int32_t *list, *count;
+} dmp_kept_job;
+int dmp_kept_rows_jobs(const dmp_kept_job *jobs, int n, const int32_t *src, const int32_t *dst, const uint8_t *flag,
+                       const uint32_t *nodemask, int64_t E, int32_t *selA, int32_t *selB, int32_t *dstM, void *stream);
+/* dmp_row_mask_bits for several gates in one launch. */
+#define DMP_ROWMASK_MAX_JOBS 4
+typedef struct { const float *gate; int64_t R; uint32_t *mask; } dmp_rowmask_job;
+int dmp_row_mask_bits_jobs(const dmp_rowmask_job *jobs, int n, void *stream);
 int dmp_l0_edge_fwd_rows(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,
                          const float *bias, const float *coef_e, const int32_t *sel_a, const int32_t *sel_b,
                          const int32_t *list, const int32_t *count, int64_t R, int H, float slope, float *out, int64_t ldo,
@@ -1091,6 +1109,25 @@ int dmp_out_fwd_typed(const dmp_typed_job *jobs, int num_jobs, const int32_t *sl
 int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
                      int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
+
+/*
+ * The tall-skinny weight gradients over a tile list on the same kind of LDS image (csrc/dmp_h1w.hip::atb2_k): per job
+ *     T = sum_e Z[e]^T D[e]      and, partial_B != NULL,      B = sum_e c(e) Z[e]^T D[e]     (c: tile_scale of e's tile)
+ * -- dmp_atb_typed's two products (the class-typed edge chain's dA', dB', dmpnn.py:144-156 backward) and dmp_atb_rows_jobs_h's tile
+ * form (the node side's weight gradients over the kept nodes' tiles) with every fetched element split into its bf16 pieces ONCE
+ * (by the staging thread) and every fragment read through ds_read_b64_tr_b16.  H = 128, bf16x6, arrays below 4 GiB; otherwise
+ * DMP_ERR_UNSUPPORTED (callers run dmp_atb_typed / dmp_atb_rows_jobs_h).  num_jobs <= 6 products over the SAME tile list share the
+ * launch (grid.y = job); partials [dmp_atb2_blocks(tiles_bound, num_jobs)] per job, `partial_stride` floats apart, rows `ldp`
+ * floats apart (partial_B = partial_T + H with ldp = 2 H: the [T | B] layout of dWes), summed by dmp_reduce_partials.
+ */
+typedef struct {
+  const float *Z; int64_t ldz;
+  const float *D; int64_t ldd;
+  float *partial_T, *partial_B; int64_t partial_stride; int ldp;
+} dmp_atb2_job;
+int64_t dmp_atb2_blocks(int64_t tiles_bound, int num_jobs);
+int dmp_atb2_jobs(const dmp_atb2_job *jobs, int num_jobs, const int32_t *slot_row, const float *tile_scale, const int32_t *num_tiles,
+                  int64_t tiles_bound, int64_t rows, int H, void *stream);
 
 /*
  * dmp_bwd_h1_typed AND the second Linear's weight gradient dO^T H1 (dmp_atb_typed's plain form) in ONE launch over the same tile

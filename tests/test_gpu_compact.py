@@ -605,3 +605,39 @@ def test_in_csr_over_the_kept_edges(B, max_n, max_e, keep):
     ref = ops.seg_sum_raw(M, ix.in_ptr, ix.in_ent, N, gate, True, -1.0, 1.0)
     got = ops.seg_sum_raw(Mp, kp, ke, N, None, True, -1.0, 1.0)
     assert th.equal(got, ref)
+
+
+@pytest.mark.parametrize("rows,avg", [(300, 50), (4099, 17), (1, 700), (10752, 51)])
+def test_kept_csr_with_a_lane_group_per_row(rows, avg):
+    """``dmp_csr_keep`` on a CSR with LONG rows (the pooling index's chunk table: ~50 entries per row): the lane-group form
+    (16 lanes per row, ballot + prefix popcount) against a numpy restatement and against the thread-per-row form (hint 0)."""
+    from dualmessagepassing_amd import _lib
+    from dualmessagepassing_amd._lib import check, ptr, stream_ptr
+    gpu = th.device("cuda:0")
+    rng = np.random.default_rng(rows + avg)
+    lens = rng.integers(0, 2 * avg + 1, rows)
+    if rows > 1:
+        lens[rng.integers(0, rows, max(1, rows // 10))] = 0      # empty rows too
+    lens[0] = max(int(lens[0]), 1)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    E = int(rp[-1])
+    ent = ((rng.permutation(E).astype(np.int64) << 1) | rng.integers(0, 2, E)).astype(np.int32)
+    g_np = (rng.random(max(E, 1)) < 0.45).astype(np.float32)
+    lib = _lib.load()
+    res = {}
+    for hint in (E, 0):
+        in_ptr, in_ent, gate = (th.from_numpy(a).to(gpu) for a in (rp, ent, g_np))
+        nscr = int(lib.dmp_csr_keep_scratch_words(rows))
+        ws = th.full((nscr + rows + 1 + max(E, 1),), -7, dtype=th.int32, device=gpu)
+        row_cnt, kptr, kent = ws[:nscr], ws[nscr:nscr + rows + 1], ws[nscr + rows + 1:]
+        check(lib.dmp_csr_keep(ptr(in_ptr), ptr(in_ent), ptr(gate), rows, hint, ptr(row_cnt), ptr(kptr), ptr(kent), stream_ptr()), "dmp_csr_keep")
+        th.cuda.synchronize()
+        res[hint] = (kptr.cpu().numpy().copy(), kent.cpu().numpy().copy())
+    want_ptr, want_ent = [0], []
+    for v in range(rows):
+        want_ent += [e for e in ent[rp[v]:rp[v + 1]] if g_np[e >> 1] != 0]
+        want_ptr.append(len(want_ent))
+    for hint, (kp, ke) in res.items():
+        assert np.array_equal(kp, np.array(want_ptr, np.int32)), hint
+        assert np.array_equal(ke[:len(want_ent)], np.array(want_ent, np.int32)), hint
+        assert bool((ke[len(want_ent):] == -7).all()), hint           # nothing written past the kept entries

@@ -329,7 +329,7 @@ def test_table_lookups_match_embedding_modules(gpu):
 PAIR_TAU = 4e-6
 
 
-def _config1_case(hid, act, gpu, corrupt_pair=None):
+def _config1_case(hid, act, gpu, corrupt_pair=None, filt="ScalarFilter"):
     """BASELINE configs[0] batch through the product and through oracle/model_oracle.py from the same ``state_dict``.
     Returns what the two tests below compare.  Parameter gradients are taken PER PAIR (the loss is a sum over pairs, so
     are its gradients): an activation within rounding of its kink (tests/util_flips.py) can move the gradients of the
@@ -344,7 +344,7 @@ def _config1_case(hid, act, gpu, corrupt_pair=None):
     import model_oracle as MO
     from dualmessagepassing_amd.basemodel import build_model
     from dualmessagepassing_amd.collate import collate_device
-    cfg = dict(bench.CFG, batch=32, hid=hid, act=act)
+    cfg = dict(bench.CFG, batch=32, hid=hid, act=act, filter=filt)
     B = cfg["batch"]
     shard = bench.make_shard(cfg, 0, gpu)
     th.manual_seed(3)
@@ -463,6 +463,17 @@ def test_full_model_matches_the_model_oracle_at_config_1(hid, act, gpu):
                    ("pred_c", 1e-4)):
         _close(out[k], ref[k].detach().numpy(), tol, k)
     assert int((~touched).sum()) >= 8, int(touched.sum())         # the strict rule must cover a good part of the batch
+    assert _pair_gradients_close(got, want, touched) > 30 * 32
+
+
+def test_full_model_without_a_filter_net_matches_the_model_oracle(gpu):
+    """The ALL-ROWS step (``filter_net = "None"``: no 0 / 1 gate, what the reference's one-label ER / Regular datasets give,
+    SubgraphCountingMatching/README.md:22-69; bench.py's ``gate_dense`` object) at config 1's shape, hid 128: outputs and every
+    pair's parameter gradients against oracle/model_oracle.py -- the ungated branches of the fused layer (the second Linear's
+    backward over the identity tile list, the class tiles over every edge)."""
+    out, ref, got, want, touched, _ = _config1_case(128, "leaky_relu", gpu, filt="None")
+    for k, tol in (("p_v_emb", 1e-5), ("g_e_emb", 1e-5), ("p_v_rep", 1e-4), ("p_e_rep", 1e-4), ("g_v_rep", 1e-4), ("g_e_rep", 1e-4), ("pred_c", 1e-4)):
+        _close(out[k], ref[k].detach().numpy(), tol, k)
     assert _pair_gradients_close(got, want, touched) > 30 * 32
 
 

@@ -1329,3 +1329,91 @@ def test_small_gemm_jobs_match_fp64(gpu):
     assert bool((outs["dWx"][:, :H] == 7.0).all()) and bool((outs["dWx"][:, 2 * H:] == 7.0).all())   # the slice only
     with pytest.raises(Exception):
         fused.small_gemm_jobs([(outs["odd"], [(a5, False, b5, True)], None)])                       # shapes that do not chain
+
+
+@pytest.mark.parametrize("rows", [40, 1000, 70001, 300000])
+def test_tile_list_weight_gradients_on_the_piece_image(rows, gpu):
+    """``dmp_atb2_jobs`` (csrc/dmp_h1w.hip::atb2_k: every element split into bf16 pieces once, fragments through
+    ds_read_b64_tr_b16) against fp64 and against the kernels it replaces: ``atb_typed`` ([z^T d | z^T (c (.) d)] over the class
+    tiles of the kept edges, and its plain form) and the node side's multi-product launch over a kept-row tile list (operands
+    that are column slices); the same bits on every launch."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows)
+    rng = np.random.default_rng(rows)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    gate = th.from_numpy((rng.random(rows) < 0.46).astype(np.float32)).to(gpu)
+    gate._dmp_binary = True
+    keep = gate != 0
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    d = th.randn(rows, h, generator=gen).to(gpu)
+    zp, dp = z.clone(), d.clone()
+    zp[~keep] = float("nan")
+    dp[~keep] = float("nan")
+    ce = ix.edge_select(coef)[2].double()
+    z64, d64 = z[keep].double(), d[keep].double()
+    want = th.cat([z64.t() @ d64, z64.t() @ (ce[keep][:, None] * d64)], dim=1)
+    scale = float((z64.abs().t() @ (ce[keep][:, None].abs().clamp(min=1.0) * d64.abs())).max())
+    res = {}
+    for on in (True, False):
+        saved = fused.USE_ATB2
+        fused.USE_ATB2 = on
+        try:
+            res[on] = (fused.atb_typed(zp, dp, coef, ix, gate=gate), fused.atb_typed(zp, dp, coef, ix, gate=gate, plain=True))
+            if on:
+                again = fused.atb_typed(zp, dp, coef, ix, gate=gate)
+        finally:
+            fused.USE_ATB2 = saved
+    assert th.equal(res[True][0], again)
+    for on in (True, False):
+        wide, plain = res[on]
+        assert wide.shape == (h, 2 * h) and plain.shape == (h, h)
+        assert float((wide.double() - want).abs().max()) <= 2e-6 * scale, (on, float((wide.double() - want).abs().max()) / scale)
+        assert float((plain.double() - want[:, :h]).abs().max()) <= 2e-6 * scale
+    # the node side's launch: three products, six 128 x 128 blocks, operands that are column slices, over a kept-row tile list
+    tiles = fused.ascending_tiles(gate)
+    S = th.randn(rows, 2 * h, generator=gen).to(gpu)
+    dXP = th.randn(rows, 3 * h, generator=gen).to(gpu)
+    for t in (S, dXP):
+        t[~keep] = float("nan")
+    got = {}
+    for on in (True, False):
+        saved = fused.USE_ATB2
+        fused.USE_ATB2 = on
+        try:
+            got[on] = [r for r, _ in fused.atb_rows_multi([(dp, zp, None, False), (S, dp[:, :h], None, False), (zp, dXP, None, False)], tiles=tiles)]
+        finally:
+            fused.USE_ATB2 = saved
+    refs = [d64.t() @ z64, S[keep].double().t() @ d64, z64.t() @ dXP[keep].double()]
+    for on in (True, False):
+        for r, w in zip(got[on], refs):
+            assert r.shape == w.shape
+            assert float((r.double() - w).abs().max()) <= 4e-6 * scale, (on, r.shape, float((r.double() - w).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("rows", [33, 5000, 70001])
+def test_second_linear_backward_without_a_gate_over_identity_tiles(rows, gpu):
+    """No gate (a model without a filter net: every row live): ``dmp_bwd_h1_w`` over the identity tile list against the two
+    all-rows launches it replaces there (``bwd_h1_mfma`` + ``atb_rows``)."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows)
+    h1 = th.randn(rows, h, generator=gen).to(gpu)
+    h1 = th.where(h1 > 0, h1, 0.18 * h1)
+    d_o = th.randn(rows, h, generator=gen).to(gpu)
+    W2 = (th.randn(h, h, generator=gen) / h ** 0.5).to(gpu)
+    tiles = fused.identity_tiles(rows, gpu)
+    assert tiles is not None and int(tiles[2][0]) == (rows + 31) // 32 and fused.identity_tiles(rows, gpu) is tiles
+    dg, db, db_rows, dw = fused.bwd_h1_w(d_o, W2, h1, tiles, slope=0.18)
+    ref_dg, ref_db = fused.bwd_h1_mfma(d_o, W2, h1, both_halves=False, gate=None, slope=0.18)
+    ref_w, ref_rows = fused.atb_rows(d_o, h1, None)
+    s_dg = float(ref_dg.abs().max())
+    assert float((dg - ref_dg).abs().max()) <= 2e-6 * s_dg
+    w64 = d_o.double().t() @ h1.double()
+    scale_w = float((d_o.double().abs().t() @ h1.double().abs()).max())
+    assert float((dw.double() - w64).abs().max()) <= 2e-6 * scale_w and float((ref_w.double() - w64).abs().max()) <= 2e-6 * scale_w
+    assert float((db - ref_db).abs().max()) <= 2e-6 * rows * s_dg
+    assert float((db_rows.double() - d_o.double().sum(0)).abs().max()) <= 2e-6 * rows * float(d_o.abs().max())
