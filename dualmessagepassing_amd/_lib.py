@@ -179,6 +179,8 @@ SIGNATURES = {
     "dmp_row_mask_bits_jobs": (c_int, [c_ptr, c_int, c_ptr]),
     "dmp_atb2_blocks": (c_i64, [c_i64, c_int]),
     "dmp_atb2_jobs": (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
+    "dmp_bwd_z_w": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_f32,
+                            c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "dmp_bwd_h1_w_blocks": (c_i64, [c_i64]),
     "dmp_bwd_h1_w": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_ptr, c_i64,
                              c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -198,7 +200,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 77
+ABI_VERSION = 78
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

@@ -586,6 +586,370 @@ inline bool atb2_lds_ready() {
   return true;
 }
 
+
+// ============================================================================================================================
+// The edge chain's input gradient AND its class-typed weight gradient in one launch (dmp_bwd_z_w; what dmp_bwd_z_typed_arow and
+// dmp_atb_typed make in two):
+//     dZ[e]  = base[e] + s(flag e) D[dst e, half(flag e)] + dPre[e] W_g(e)^T           (dmpnn.py:142-156 backward, W_g = A' + c_g B')
+//     dWes   = [ sum_e Z[e]^T dPre[e] | sum_e c(e) Z[e]^T dPre[e] ]
+// over the SAME class-sorted tile list: both read dPre.  The two roles of h1w_k on the same image: waves 0-3 ("rows") are
+// mfma_typed<TEPI_DZ> -- the per-class panel in registers, rebuilt where the workgroup's contiguous tile range crosses into the next
+// class, the gathered D rows and the base rows in the epilogue; their threads stage dPre.  Waves 4-7 ("columns") keep a 64 x 64
+// quadrant of Z^T dPre each and emit  T += acc, B += c acc  into the workgroup's partial where a class ends (atb2_k's emission);
+// their threads stage Z.  dZ is bit-identical to dmp_bwd_z_typed_arow's.
+struct DzwArgs {
+  const float *dPre; int64_t ldp;        // [E, 128] rows gathered by slot id (a padding slot / a masked-out row: -1 -> zeros)
+  const float *Z; int64_t ldz;           // [E, 128]
+  const float *W; int64_t ldw;           // [128, ldw >= 256] = [A'^T | B'^T]: B_g[k][j] = W[k][j] + c W[k][128 + j]
+  float *dZ; int64_t ldo;                // output rows, scattered by slot id
+  int64_t E;
+  const int32_t *slot_edge;              // [tiles * 32] edge id per slot, -1 = padding
+  const float *tile_scale;               // [tiles] c_g of the tile's class
+  const int32_t *num_tiles;
+  const int32_t *dst; const uint8_t *flag;          // [E]: the gathered row of D (-1: none) and its half / sign
+  const float *D; int64_t ldd; int64_t num_nodes;   // [N, >= 256]
+  const float *base; int64_t ldb;                   // upstream rows [rowsR, >= 128] or NULL
+  const int32_t *rmap; int64_t rowsR;               // base row of edge e = rmap[e] (< 0: none), or NULL: row e
+  float s0, s1;
+  float *partialW; int64_t pstride;                 // [gridDim.x] partials of [128, 256] = [T | B]
+};
+
+__global__ __launch_bounds__(kThreadsW, 1) void dzw_k(const DzwArgs p) {
+  extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+  float *const scr_all = reinterpret_cast<float *>(lds + kImgB);
+  uint32_t *const rowA = reinterpret_cast<uint32_t *>(lds + kImgB + kScrB);     // [3][32] each: gathered D row, flag, store row, base row
+  uint32_t *const rowB = rowA + 3 * kSub, *const rowC = rowB + 3 * kSub, *const rowR = rowC + 3 * kSub;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool cols = wave >= 4;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int u = threadIdx.x & 255;
+  const int srow = u >> 5, scol = u & 31;
+  constexpr uint32_t kNone = 0xFFFFFFFFu, kOOB = 0xFFFFF000u;
+
+  const int ntiles = __builtin_amdgcn_readfirstlane(*p.num_tiles);
+  const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int mine = hi > lo ? hi - lo : 0;
+  const rsrc_t rs_slot = make_rsrc(p.slot_edge, (uint32_t)ntiles * (kSub * 4u));
+  const srsrc_t rs_X = cols ? make_srsrc(p.Z, p.ldz, p.E) : make_srsrc(p.dPre, p.ldp, p.E);
+  const uint32_t op_off = cols ? (uint32_t)kOpB : 0u;
+  const uint32_t rows4 = (uint32_t)(p.E * 4);
+  const rsrc_t rs_dst = make_rsrc(p.dst, rows4);
+  const rsrc_t rs_flag = make_rsrc(p.flag, p.flag ? (uint32_t)p.E : 0u);
+  const rsrc_t rs_rmap = make_rsrc(p.rmap, p.rmap ? rows4 : 0u);
+  float *const pw_ = p.partialW + (int64_t)blockIdx.x * p.pstride;
+
+  if (mine == 0) {                                       // this workgroup's partial: zeros
+    float4 *pw4 = reinterpret_cast<float4 *>(pw_);
+    for (int m = threadIdx.x; m < kHW * 2 * kHW / 4; m += kThreadsW) pw4[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+
+  // ---- staging (as h1w_k): rows requested two tiles ahead, staged one tile ahead; the row waves' threads < 32 also carry the
+  // per-row scalars of the slot they own
+  int id_rows[kSubLoads];
+  int id_own = -1, own_staged = -1;
+  float4 pre[kSubLoads];
+  uint32_t pre_a = 0, pre_b = 0;
+  int pre_r = -1;
+  auto load_ids = [&](int k) {
+    const bool ok = k < mine;
+    const uint32_t so = (uint32_t)(lo + k) * (kSub * 4u);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m)
+      id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, (srow + 8 * m) * 4, (int)so, 0) : -1;
+    if (!cols && u < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, u * 4, (int)so, 0) : -1;
+  };
+  auto load_row = [&](int m) { pre[m] = sbuf_load4(rs_X, id_rows[m], (uint32_t)scol * 16u); };
+  auto load_row_scalars = [&]() {
+    if (!cols && u < kSub) {
+      const uint32_t eo = id_own >= 0 ? (uint32_t)id_own * 4u : kOOB;
+      pre_a = __builtin_amdgcn_raw_buffer_load_b32(rs_dst, (int)eo, 0, 0);
+      pre_b = __builtin_amdgcn_raw_buffer_load_b8(rs_flag, id_own >= 0 ? id_own : (int)kOOB, 0, 0);
+      pre_r = p.rmap ? (id_own >= 0 ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rmap, (int)eo, 0, 0) : -1) : id_own;
+      own_staged = id_own;
+    }
+  };
+  auto stage_row = [&](int buf, int m) {
+    uint2 ph, pm, pl;
+    split_pair(pre[m].x, pre[m].y, ph.x, pm.x, pl.x);
+    split_pair(pre[m].z, pre[m].w, ph.y, pm.y, pl.y);
+    const uint32_t r = (uint32_t)(srow + 8 * m);
+    const uint32_t off = op_off + (uint32_t)buf * kBufB + 256u * r + 16u * ((uint32_t)(scol >> 1) ^ swz(r)) + 8u * (uint32_t)(scol & 1);
+    *reinterpret_cast<uint2 *>(lds + off) = ph;
+    *reinterpret_cast<uint2 *>(lds + off + kPlaneB) = pm;
+    *reinterpret_cast<uint2 *>(lds + off + 2 * kPlaneB) = pl;
+  };
+  auto stage_scalars = [&](int par) {
+    if (!cols && u < kSub) {
+      const bool ok = own_staged >= 0;
+      rowA[par * kSub + u] = ok ? pre_a : kNone;
+      rowB[par * kSub + u] = pre_b;
+      rowC[par * kSub + u] = ok ? (uint32_t)own_staged : kNone;
+      rowR[par * kSub + u] = (ok && p.base && pre_r >= 0) ? (uint32_t)pre_r : kNone;
+    }
+  };
+  // the class structure of the range, 64 tiles at a time (both roles): lane l keeps the coefficient of tile 64 c + l, bit l of
+  // `starts` says "tile 64 c + l begins a new class"
+  float sv = 0.f;
+  unsigned long long starts = 0;
+  auto class_chunk = [&](int k) {
+    const float last = __shfl(sv, 63);
+    sv = k + lane < mine ? p.tile_scale[lo + k + lane] : 0.f;
+    float up = __shfl_up(sv, 1);
+    if (lane == 0) up = k > 0 ? last : sv;
+    starts = __ballot(k + lane < mine && __float_as_uint(sv) != __float_as_uint(up));
+  };
+
+  load_ids(0);
+#pragma unroll
+  for (int m = 0; m < kSubLoads; ++m) load_row(m);
+  load_row_scalars();
+  load_ids(1);
+
+  if (cols) {
+    // ================================================================== the column product Z^T dPre (waves 4-7)
+    const int pw = wave & 1, qw = (wave >> 1) & 1;
+    const int G16 = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+    auto tr_base = [&](int half) {
+      const uint32_t row0 = (uint32_t)(8 * (G16 >> 1) + q4);
+      const uint32_t ch0 = (uint32_t)(8 * half + 2 * (G16 & 1) + (pp >> 1));
+      const uint32_t sw0 = ((uint32_t)q4 << 2) | (uint32_t)(2 * (G16 >> 1));
+      return 256u * row0 + 16u * (ch0 ^ sw0) + 8u * (uint32_t)(pp & 1);
+    };
+    const uint32_t tA = (uint32_t)kOpB + tr_base(pw), tB = tr_base(qw);      // A: Z (operand 1); B: dPre (operand 0)
+    auto tr_frag = [&](uint32_t base, int buf, int plane, int blk, int kg, Frag8 &f) {
+      const uint32_t o0 = (base ^ (uint32_t)(64 * blk)) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg);
+      const uint32_t o1 = (base ^ (uint32_t)(64 * blk) ^ 16u) + (uint32_t)(buf * kBufB + plane * kPlaneB + 4096 * kg + 1024);
+      const v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o0));
+      const v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(lds + o1));
+      f.v = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto tr_split = [&](uint32_t base, int buf, int blk, int kg, Split8 &sp) {
+      tr_frag(base, buf, 0, blk, kg, sp.hi);
+      tr_frag(base, buf, 1, blk, kg, sp.mid);
+      tr_frag(base, buf, 2, blk, kg, sp.lo);
+    };
+    f32x16 wacc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wacc[i][j][r] = 0.f;
+    };
+    // accumulator (i, j, r): output row 64 pw + 32 i + (r & 3) + 8 (r >> 2) + 4 h, column 64 qw + 32 j + li of T (B: + 128)
+    const rsrc_t rs_pw = make_rsrc(pw_, (uint32_t)(kHW * 2 * kHW * 4));
+    const uint32_t e_voff = (uint32_t)((64 * pw + 4 * h) * (2 * kHW) + 64 * qw + li) * 4u;
+    bool emitted = false;
+    auto emit = [&](float c) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                         // a row block at a time: 32 + 32 reads in flight, then the adds
+        float t0[2][16], b0[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int so = ((32 * i + (r & 3) + 8 * (r >> 2)) * (2 * kHW) + 32 * j) * 4;
+            t0[j][r] = emitted ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pw, (int)e_voff, so, 0)) : 0.f;
+            b0[j][r] = emitted ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_pw, (int)e_voff, so + kHW * 4, 0)) : 0.f;
+          }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int so = ((32 * i + (r & 3) + 8 * (r >> 2)) * (2 * kHW) + 32 * j) * 4;
+            const float a = wacc[i][j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(emitted ? a + t0[j][r] : a), rs_pw, (int)e_voff, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(emitted ? c * a + b0[j][r] : c * a), rs_pw, (int)e_voff, so + kHW * 4, 0);
+          }
+      }
+      emitted = true;
+    };
+    auto cols_step = [&](int k) {
+      const int buf = k & 1;
+      int act = 0;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        Split8 fa[2];
+        tr_split(tA, buf, 0, kg, fa[0]);
+        tr_split(tA, buf, 1, kg, fa[1]);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          Split8 fb;
+          tr_split(tB, buf, jb, kg, fb);
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) {
+            __builtin_amdgcn_sched_barrier(0);
+            wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (act < 4) stage_row(buf ^ 1, act);
+            else load_row(act - 4);
+            ++act;
+          }
+        }
+      }
+      load_ids(k + 3);
+    };
+    zero_acc();
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) stage_row(0, m);
+#pragma unroll
+    for (int m = 0; m < kSubLoads; ++m) load_row(m);       // tile 1
+    load_ids(2);
+    lds_barrier();
+    float cur = 0.f;
+    for (int k = 0; k < mine; ++k) {
+      if ((k & 63) == 0) class_chunk(k);
+      if ((starts >> (k & 63)) & 1ull) { emit(cur); zero_acc(); }     // tile k begins a new class: the finished class's total goes out
+      cur = __shfl(sv, k & 63);
+      cols_step(k);
+      lds_barrier();
+    }
+    emit(cur);
+    return;
+  }
+
+  // ==================================================================== the row product dPre W_g^T (waves 0-3): mfma_typed<TEPI_DZ>
+  const int cs = wave & 3;
+  const int col = 32 * cs + li;
+  float *const scr = scr_all + cs * (32 * kScrStride);
+  const int lrow = lane >> 3, c4 = 32 * cs + (lane & 7) * 4;
+  const uint32_t col4 = (uint32_t)c4 * 4u;
+  constexpr uint32_t kRowBytes = kHW * 4u;
+  const srsrc_t rs_C = make_srsrc(p.dZ, p.ldo, p.E);
+  const srsrc_t rs_T = make_srsrc(p.D, p.ldd, p.num_nodes);
+  const srsrc_t rs_R = make_srsrc(p.base, p.base ? p.ldb : (int64_t)kHW, p.base ? (p.rmap ? p.rowsR : p.E) : 0);
+  constexpr int kGroups = 8;
+  Split8 B6[kGroups];
+  const rsrc_t rs_W = make_rsrc(p.W, (uint32_t)(kHW * p.ldw * 4));
+  const uint32_t w_first = (uint32_t)((int64_t)64 * h * p.ldw + col) * 4u;
+  const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.ldw * 4));
+  auto load_panel = [&](float c) {
+    uint32_t off;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(off) : "v"(w_first));
+#pragma unroll
+    for (int s0 = 0; s0 < 64; s0 += 8) {
+      float w0[8], w1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w0[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off, (int)((s0 + j) * w_step), 0));
+        w1[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_W, (int)off + (int)kRowBytes, (int)((s0 + j) * w_step), 0));
+      }
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = w0[j] + c * w1[j];
+      split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), B6[s0 / 8]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const uint32_t a0 = 256u * (uint32_t)li + 16u * ((uint32_t)(8 * h) ^ swz((uint32_t)li));
+  f32x16 acc;
+  float4 g0[4], g1[4];
+  auto fetch_operand = [&](int par, int k) {               // rows 8 k + lrow of the tile: the gathered D row's half, the base row
+    const int rr = 8 * k + lrow;
+    g0[k] = sbuf_load4(rs_T, (int)rowA[par * kSub + rr], col4 + (rowB[par * kSub + rr] ? kRowBytes : 0u));
+    g1[k] = sbuf_load4(rs_R, (int)rowR[par * kSub + rr], col4);
+  };
+  auto rows_step = [&](int k, int par3) {
+    const int buf = k & 1, nxt3 = par3 == 2 ? 0 : par3 + 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned char *img = lds + (uint32_t)buf * kBufB;
+    Frag8 ah, am, al;
+    ah.v = *reinterpret_cast<const bf16x8 *>(img + a0);
+    am.v = *reinterpret_cast<const bf16x8 *>(img + kPlaneB + a0);
+    al.v = *reinterpret_cast<const bf16x8 *>(img + 2 * kPlaneB + a0);
+    auto action = [&](int i) {
+      if (i < 4) {}
+      else if (i < 8) stage_row(buf ^ 1, i - 4);
+      else if (i == 8) stage_scalars(nxt3);
+      else if (i < 13) load_row(i - 9);
+      else if (i == 13) load_row_scalars();
+      else if (i == 14) load_ids(k + 3);
+    };
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      Frag8 nh = ah, nm = am, nl = al;
+      if (g + 1 < kGroups) {
+        const uint32_t an = a0 ^ (uint32_t)(16 * (g + 1));
+        nh.v = *reinterpret_cast<const bf16x8 *>(img + an);
+        nm.v = *reinterpret_cast<const bf16x8 *>(img + kPlaneB + an);
+        nl.v = *reinterpret_cast<const bf16x8 *>(img + 2 * kPlaneB + an);
+      }
+      const Split8 &bb = B6[g];
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bb.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.lo.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.mid.v, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      action(2 * g);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bb.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.mid.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bb.hi.v, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      action(2 * g + 1);
+      ah = nh; am = nm; al = nl;
+    }
+  };
+  auto rows_epilogue = [&](int par) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * h) * kScrStride + li] = acc[r];
+    const int nxt = par == 2 ? 0 : par + 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = 8 * k + lrow;
+      float4 v = *reinterpret_cast<const float4 *>(&scr[rr * kScrStride + (lane & 7) * 4]);
+      const float sg = rowB[par * kSub + rr] ? p.s1 : p.s0;
+      v.x += g1[k].x + sg * g0[k].x; v.y += g1[k].y + sg * g0[k].y;
+      v.z += g1[k].z + sg * g0[k].z; v.w += g1[k].w + sg * g0[k].w;
+      sbuf_store4(v, rs_C, (int)rowC[par * kSub + rr], col4);
+      fetch_operand(nxt, k);     // this chunk's operand registers are free: the NEXT tile's rows into them (its scalars were staged before the barrier)
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < kSubLoads; ++m) stage_row(0, m);
+  stage_scalars(0);
+#pragma unroll
+  for (int m = 0; m < kSubLoads; ++m) load_row(m);         // tile 1
+  load_row_scalars();
+  load_ids(2);
+  lds_barrier();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) fetch_operand(0, c);         // tile 0's epilogue operands (later tiles: by the epilogue before)
+  int par3 = 0;
+  float c_have = 0.f;
+  bool have_panel = false;
+  for (int k = 0; k < mine; ++k) {
+    if ((k & 63) == 0) class_chunk(k);
+    const float c = __shfl(sv, k & 63);
+    if (!have_panel || __float_as_uint(c) != __float_as_uint(c_have)) {      // W_g is built once per class segment of this range
+      load_panel(c);
+      c_have = c;
+      have_panel = true;
+    }
+    rows_step(k, par3);
+    lds_barrier();
+    rows_epilogue(par3);
+    par3 = par3 == 2 ? 0 : par3 + 1;
+  }
+}
+
+constexpr int kDzwLdsBytes = kImgB + kScrB + 4 * 3 * kSub * 4;
+inline bool dzw_lds_ready() {
+  static bool done[kMaxDevicesW2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesW2) dev = 0;
+  if (done[dev]) return true;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dzw_k), hipFuncAttributeMaxDynamicSharedMemorySize, kDzwLdsBytes);
+  if (e != hipSuccess) { set_last_hip_error(e); return false; }
+  done[dev] = true;
+  return true;
+}
+
 inline unsigned h1w_blocks(int64_t tiles_bound) {
   const int64_t cap = 256;                               // one workgroup per CU
   return (unsigned)(tiles_bound < cap ? (tiles_bound > 0 ? tiles_bound : 1) : cap);
@@ -640,6 +1004,35 @@ int dmp_bwd_h1_w(const float *dO, int64_t ldo, const float *W2, int64_t ldw, con
   return check_launch();
 }
 
+
+int dmp_bwd_z_w(const float *dPre, int64_t ldp, const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag, float s0, float s1,
+                const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H,
+                const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldo, float *partial_w, void *stream) {
+  if (H != 128 || g_exact_fp32) return DMP_ERR_UNSUPPORTED;
+  if (E < 0 || num_nodes < 0 || tiles_bound < 0 || !partial_w || !aligned16(partial_w)) return DMP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 0) return hipMemsetAsync(partial_w, 0, sizeof(float) * H * 2 * H * (size_t)h1w_blocks(tiles_bound), st) == hipSuccess ? DMP_OK : DMP_ERR_HIP;
+  if (!dPre || !Z || !W || !D || !dst || !slot_edge || !tile_scale || !num_tiles || !dZ || ldp < H || ldz < H || ldw < 2 * H || ldd < 2 * H ||
+      ldo < H || (base && ldb < H))
+    return DMP_ERR_BAD_ARG;
+  if (base_map && (!base || base_rows < 0)) return DMP_ERR_BAD_ARG;
+  if (ldp % 4 || ldz % 4 || ldo % 4 || ldd % 4 || (base && ldb % 4) || !aligned16(dPre) || !aligned16(Z) || !aligned16(dZ) || !aligned16(D) ||
+      (base && !aligned16(base)))
+    return DMP_ERR_UNSUPPORTED;
+  if (!stride_ok(ldp) || !stride_ok(ldz) || !stride_ok(ldo) || !stride_ok(ldd) || (base && !stride_ok(ldb)) || E >= ((int64_t)1 << 30) ||
+      num_nodes >= ((int64_t)1 << 31) || tiles_bound * kSub * 4 >= ((int64_t)1 << 32) - 8192 || (int64_t)H * ldw * 4 >= ((int64_t)1 << 32) - 8192 ||
+      !fits4g(E, ldp) || !fits4g(E, ldz) || !fits4g(E, ldo) || (base && !fits4g(base_map ? base_rows : E, ldb)) || !fits4g(num_nodes, ldd))
+    return DMP_ERR_UNSUPPORTED;
+  if (!dzw_lds_ready()) return DMP_ERR_HIP;
+  DzwArgs a{};
+  a.dPre = dPre; a.ldp = ldp; a.Z = Z; a.ldz = ldz; a.W = W; a.ldw = ldw; a.dZ = dZ; a.ldo = ldo; a.E = E; a.slot_edge = slot_edge;
+  a.tile_scale = tile_scale; a.num_tiles = num_tiles; a.dst = dst; a.flag = flag; a.D = D; a.ldd = ldd; a.num_nodes = num_nodes;
+  a.base = base; a.ldb = base ? ldb : H; a.rmap = base_map; a.rowsR = base_rows; a.s0 = s0; a.s1 = s1;
+  a.partialW = partial_w; a.pstride = (int64_t)H * 2 * H;
+  dzw_k<<<h1w_blocks(tiles_bound), kThreadsW, kDzwLdsBytes, st>>>(a);
+  return check_launch();
+}
 
 int64_t dmp_atb2_blocks(int64_t tiles_bound, int num_jobs) { return (int64_t)atb2_blocks(tiles_bound, num_jobs); }
 

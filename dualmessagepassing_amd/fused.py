@@ -566,6 +566,46 @@ def bwd_z_typed(d_pre, ld_pre, Wes, d_s, base, coef, index, WesT=None, base_map=
     return out
 
 
+USE_DZW = _os.environ.get("DMP_DEV_DZW", "1") == "1"     # the edge chain's input gradient and its class-typed weight gradient in ONE launch (``dmp_bwd_z_w``)
+
+
+def bwd_z_w(d_pre, z, Wes, d_s, base, coef, index, WesT=None, base_map=None, gate=None, dead_rows=None, dst=None):
+    """``(dz, dWes)`` = ``(bwd_z_typed(...), atb_typed(z, d_pre, ...))`` from one pass over ``d_pre`` (``dmp_bwd_z_w``: the two-role kernel
+    of csrc/dmp_h1w.hip with the class-typed panel and the class emission), or None where it does not apply: it needs the kept edges'
+    class tiles of a 0 / 1 gate with ``dead_rows`` set (both launches then walk the SAME list), H = 128, bf16x6, arrays below 4 GiB."""
+    lib = _lib.load()
+    E, H = d_pre.size(0), Wes.size(0)
+    lim = (1 << 32) - 65536
+    if (not USE_DZW or (dead_rows is None) != (gate is None) or H != 128 or lib.dmp_dev_get_exact_fp32() or z is None or z.size(0) != E or E * H * 4 >= lim
+            or E * d_pre.stride(0) * 4 >= lim or E * z.stride(0) * 4 >= lim or d_pre.data_ptr() % 16 or z.data_ptr() % 16
+            or d_pre.stride(0) % 4 or z.stride(0) % 4 or index.num_nodes * d_s.size(1) * 4 >= lim):
+        return None
+    if gate is None:          # no gate at all (the all-rows step): the class tiles over every edge, every output row written
+        if getattr(index, "_coef_deg", None) is None or index._coef_deg[0] is not coef or index.num_edges == 0:
+            return None
+        lt = index.class_tiles(coef)
+    else:
+        lt = live_tiles(index, coef, gate)
+    if lt is None:
+        return None
+    if base is not None and (base.stride(0) % 4 or base.data_ptr() % 16 or base.size(0) * base.stride(0) * 4 >= lim):
+        return None
+    slot_edge, tile_scale, num_tiles, bound = lt
+    out = (torch.zeros((E, H), dtype=torch.float32, device=d_pre.device) if dead_rows == "zero" else
+           dead_rows_buffer((E, H), d_pre.device) if dead_rows == "leave" else torch.empty((E, H), dtype=torch.float32, device=d_pre.device))
+    if WesT is None:
+        WesT = torch.cat([Wes[:, :H].t(), Wes[:, H:].t()], dim=1)
+    d_s = d_s.contiguous()
+    G = int(lib.dmp_bwd_h1_w_blocks(bound))
+    part = torch.empty((G, H * 2 * H), dtype=torch.float32, device=d_pre.device)
+    with _lib.timed("bwd_z_w[H=%d,E=%d]", (H, E), 4 * H * E * (4 if base is not None else 3) + 5 * E):
+        check(lib.dmp_bwd_z_w(ptr(d_pre), d_pre.stride(0), ptr(z), z.stride(0), ptr(WesT), WesT.size(1), ptr(d_s), d_s.size(1), index.num_nodes,
+                              ptr(base), base.stride(0) if base is not None else H, ptr(index.dst32 if dst is None else dst), ptr(index.rev8), -1.0, 1.0,
+                              ptr(slot_edge), ptr(tile_scale), ptr(num_tiles), bound, E, H, ptr(base_map),
+                              base.size(0) if base_map is not None else 0, ptr(out), H, ptr(part), stream_ptr()), "dmp_bwd_z_w")
+    return out, reduce_partials(part).view(H, 2 * H)
+
+
 USE_ATB2 = _os.environ.get("DMP_DEV_ATB2", "1") == "1"     # the tile-list weight gradients on the bf16-piece LDS image (``dmp_atb2_jobs``)
 
 
@@ -1997,7 +2037,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dWes = None
             else:
                 # (dG = dPre has zero rows under a zero edge gate, whichever kernel made it: the typed kernels skip those edges)
-                dWes = atb_typed(z, dG, coef, ix, gate=ctx.e_gate) if typed else atb(z, dG)   # [H,2H] = [dA_e | dB_e]
+                # (with the input gradient still to come -- ``dz`` below, over the same tile list -- both products of dPre run in ONE
+                # launch there, ``bwd_z_w``: decided here, made there)
+                fuse_dzw = bool(typed and USE_DZW and ctx.needs_input_grad[4] and H == 128 and
+                                (ctx.e_gate is None or (SKIP_DEAD_ROWS and zero_rows_gate(ctx.e_gate) and live_tiles(ix, coef, ctx.e_gate) is not None)))
+                dWes = None if fuse_dzw else (atb_typed(z, dG, coef, ix, gate=ctx.e_gate) if typed else atb(z, dG))   # [H,2H] = [dA_e | dB_e]
             # ---- node side
             wg = (lambda a, b: atb_rows(a, b, colsum=False)[0]) if atb_ok(x, dXP) else atb   # MFMA kernel or library GEMMs
             one_launch = onepanel_ok(H) and atb_ok(dxn, H1n) and atb_ok(x, dXP) and (l0 is not None or atb_ok(S, dXP))
@@ -2114,7 +2158,16 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # which leaves those rows out; the first layer hands zeros to whoever made the rows.
                 dead_dz = (("leave" if (ctx.inner & 2) else "zero") if (typed and SKIP_DEAD_ROWS and zero_rows_gate(ctx.e_gate)) else None)
                 dst_m = None if nd is None else nd.sel[2]      # (dS's rows of the dead nodes were not written: read as zeros)
-                if lazy is not None:
+                both = None
+                if typed and dWes is None:
+                    base_ = (lazy[0] if lazy is not None else dzn) if ctx.residual else None
+                    both = bwd_z_w(dG, z, Wes, dS, base_, coef, ix, ctx.WesT, base_map=lazy[1] if (lazy is not None and ctx.residual) else None,
+                                   gate=ctx.e_gate, dead_rows=dead_dz, dst=dst_m)
+                    if both is None:
+                        dWes = atb_typed(z, dG, coef, ix, gate=ctx.e_gate)
+                if both is not None:
+                    dz, dWes = both
+                elif lazy is not None:
                     dz = bwd_z_typed(dG, dG.stride(0), Wes, dS, lazy[0] if ctx.residual else None, coef, ix, ctx.WesT,
                                      base_map=lazy[1] if ctx.residual else None, gate=ctx.e_gate, dead_rows=dead_dz, dst=dst_m)
                 elif typed:

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 77
+#define DMP_ABI_VERSION 78
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1140,6 +1140,15 @@ int dmp_atb2_jobs(const dmp_atb2_job *jobs, int num_jobs, const int32_t *slot_ro
  *   layout); all three summed by dmp_reduce_partials.  The sign of H1 (the activation's derivative on the saved output) is read
  *   from its bf16 hi piece: an output of magnitude below 2^-133 counts as not positive.
  */
+/* dmp_bwd_z_typed_arow AND dmp_atb_typed in ONE launch over the same class-sorted tile list (csrc/dmp_h1w.hip::dzw_k; both read dPre):
+ *     dZ[e] = base[e] + s(flag e) D[dst e, half(flag e)] + dPre[e] W_g(e)^T,      partial_w [dmp_bwd_h1_w_blocks(tiles_bound), H * 2H] =
+ *     [sum Z^T dPre | sum c Z^T dPre] per workgroup (the [T | B] layout of dWes; summed by dmp_reduce_partials).  W = [A'^T | B'^T]
+ * (the w_transposed form of dmp_bwd_z_typed_arow); arguments as there, slot_arow = slot_edge.  dZ is bit-identical to that kernel's.
+ * H = 128, bf16x6, arrays below 4 GiB; DMP_ERR_UNSUPPORTED otherwise (callers run the two launches). */
+int dmp_bwd_z_w(const float *dPre, int64_t ldp, const float *Z, int64_t ldz, const float *W, int64_t ldw, const float *D, int64_t ldd,
+                int64_t num_nodes, const float *base, int64_t ldb, const int32_t *dst, const uint8_t *flag, float s0, float s1,
+                const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H,
+                const int32_t *base_map, int64_t base_rows, float *dZ, int64_t ldo, float *partial_w, void *stream);
 int64_t dmp_bwd_h1_w_blocks(int64_t tiles_bound);
 int dmp_bwd_h1_w(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                  const int32_t *slot_edge, const int32_t *num_tiles, int64_t tiles_bound, int64_t E, int H, float slope,

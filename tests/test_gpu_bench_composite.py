@@ -169,8 +169,10 @@ def _run_case(cfg, gpu, oracle_chunk, fp64=False):
     finally:
         _lib.timer.enabled = False
         _lib.timer.reset()
-    for k in ("l0_edge_fwd", "l0_bwd_w", "pool_relu_bwd", "edge_fwd_typed", "bwd_z_typed", "atb_typed", "seg_sum2"):
+    for k in ("l0_edge_fwd", "l0_bwd_w", "pool_relu_bwd", "edge_fwd_typed", "seg_sum2", "bwd_h1_w"):
         assert k in names, (k, sorted(names))
+    # the edge chain's input gradient + class-typed weight gradient: one launch (round 6), or the two it replaces
+    assert "bwd_z_w" in names or ("bwd_z_typed" in names and ("atb2" in names or "atb_typed" in names)), sorted(names)
     checked = _compare("eager", step.last_pred_c, _named_flat(step, model), ref_pred, ref_grads)
     if fp64:      # the stated bounds (1e-4 / 5e-4 of the largest entry) against what fp32 itself can hold at this size
         ref_pred64, ref_grads64 = _oracle(cfg, shard, model, oracle_chunk, dtype=th.float64)

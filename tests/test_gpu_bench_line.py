@@ -83,7 +83,10 @@ def test_default_mode_replays_and_eager_agrees(gpu):
     for key in ("roofline", "roofline_bwd"):
         r = gd[key]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["avg_us"] > 0 and "rows_not_fetched" not in r
-        assert r["bytes_basis"].startswith("SURVEY") and r["bytes_own"] >= r["bytes_per_launch"] > 0
+        assert r["bytes_basis"].startswith("SURVEY") and r["bytes_own"] > 0 and r["bytes_per_launch"] > 0
+        assert r["same_size_copy"]["avg_us"] > 0 and 0 < r["same_size_copy"]["frac"] <= 1.0
+    assert gd["roofline"]["bytes_own"] >= gd["roofline"]["bytes_per_launch"]      # (the forward kernel writes [N, 2H]: more than SURVEY's count)
+    assert d["roofline"]["same_size_copy"]["frac"] > 0 and d["roofline"]["own_rate_over_copy_rate"] > 0
     assert gd["kernels"] and gd["eager_ms_per_step"] > 0 and "kern" not in gd
     # the MFMA table: bf16x6 kernels against the dense bf16 peak (6 piece products per fp32 product), f32-input kernels against theirs
     for tab in (d["mfma_kernels"], gd["mfma_kernels"]):

@@ -1417,3 +1417,92 @@ def test_second_linear_backward_without_a_gate_over_identity_tiles(rows, gpu):
     assert float((dw.double() - w64).abs().max()) <= 2e-6 * scale_w and float((ref_w.double() - w64).abs().max()) <= 2e-6 * scale_w
     assert float((db - ref_db).abs().max()) <= 2e-6 * rows * s_dg
     assert float((db_rows.double() - d_o.double().sum(0)).abs().max()) <= 2e-6 * rows * float(d_o.abs().max())
+
+
+@pytest.mark.parametrize("rows,mapped,with_dst", [(1000, False, False), (70001, False, True), (70001, True, True), (300000, False, False)])
+def test_input_gradient_and_class_typed_weight_gradient_in_one_launch(rows, mapped, with_dst, gpu):
+    """``dmp_bwd_z_w`` (csrc/dmp_h1w.hip::dzw_k) against the two launches it replaces over the kept edges' class tiles: ``dz`` BIT-identical to
+    ``dmp_bwd_z_typed_arow`` on the kept rows (zeros / untouched elsewhere), ``dWes = [z^T dPre | z^T (c dPre)]`` against fp64 and ``atb_typed``;
+    NaN in every dead row of every operand; with a base TABLE + row map (the pooled last layer), with dead destinations (-1), and twice the same bits."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + mapped)
+    rng = np.random.default_rng(rows)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    gate = th.from_numpy((rng.random(rows) < 0.46).astype(np.float32)).to(gpu)
+    gate._dmp_binary = True
+    gate._dmp_zero_rows = True
+    dead = gate == 0
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    if mapped:
+        G = 37
+        base = th.randn(G, h, generator=gen).to(gpu)
+        bmap = th.from_numpy(np.where(rng.random(rows) < 0.7, rng.integers(0, G, rows), -1).astype(np.int32)).to(gpu)
+    else:
+        base, bmap = th.randn(rows, h, generator=gen).to(gpu), None
+        base[dead] = float("nan")
+    dstm = None
+    if with_dst:
+        dm = ix.dst32.clone()
+        dm[th.from_numpy(rng.random(rows) < 0.3).to(gpu)] = -1            # destinations whose rows of d_s were never written
+        dstm = dm
+    zp, dpp = z.clone(), d_pre.clone()
+    zp[dead] = float("nan")
+    dpp[dead] = float("nan")
+    for mode in ("zero", "leave"):
+        saved = fused.dead_rows_buffer
+        fused.dead_rows_buffer = lambda shape, device: th.full(shape, 7.5, dtype=th.float32, device=device)
+        try:
+            ref_z = fused.bwd_z_typed(dpp, h, wes, d_s, base, coef, ix, base_map=bmap, gate=gate, dead_rows=mode, dst=dstm)
+            both = fused.bwd_z_w(dpp, zp, wes, d_s, base, coef, ix, base_map=bmap, gate=gate, dead_rows=mode, dst=dstm)
+            again = fused.bwd_z_w(dpp, zp, wes, d_s, base, coef, ix, base_map=bmap, gate=gate, dead_rows=mode, dst=dstm)
+        finally:
+            fused.dead_rows_buffer = saved
+        assert both is not None
+        dz, dw = both
+        assert th.equal(dz[~dead], ref_z[~dead])
+        assert bool((dz[dead] == (0.0 if mode == "zero" else 7.5)).all())
+        assert th.equal(dz, again[0]) and th.equal(dw, again[1])
+    saved = fused.USE_ATB2
+    ref_w = fused.atb_typed(zp, dpp, coef, ix, gate=gate)
+    keep = ~dead
+    ce = ix.edge_select(coef)[2].double()
+    z64, d64 = z[keep].double(), d_pre[keep].double()
+    want = th.cat([z64.t() @ d64, z64.t() @ (ce[keep][:, None] * d64)], dim=1)
+    scale = float((z64.abs().t() @ (ce[keep][:, None].abs().clamp(min=1.0) * d64.abs())).max())
+    assert dw.shape == (h, 2 * h)
+    assert float((dw.double() - want).abs().max()) <= 2e-6 * scale, float((dw.double() - want).abs().max()) / scale
+    assert float((ref_w.double() - want).abs().max()) <= 2e-6 * scale
+
+
+def test_input_gradient_and_weight_gradient_in_one_launch_without_a_gate(gpu):
+    """No gate (the all-rows step): ``dmp_bwd_z_w`` over the class tiles of EVERY edge -- ``dz`` bit-identical to ``bwd_z_typed``, every row
+    written; ``dWes`` against fp64."""
+    from dualmessagepassing_amd import fused
+    rows, h = 50000, 128
+    gen = th.Generator().manual_seed(5)
+    rng = np.random.default_rng(5)
+    n = rows // 6
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    z = th.randn(rows, h, generator=gen).to(gpu)
+    wes = (th.randn(h, 2 * h, generator=gen) * 0.1).to(gpu)
+    d_pre = th.randn(rows, h, generator=gen).to(gpu)
+    d_s = th.randn(n, 2 * h, generator=gen).to(gpu)
+    base = th.randn(rows, h, generator=gen).to(gpu)
+    ref_z = fused.bwd_z_typed(d_pre, h, wes, d_s, base, coef, ix)
+    both = fused.bwd_z_w(d_pre, z, wes, d_s, base, coef, ix)
+    assert both is not None
+    dz, dw = both
+    assert th.equal(dz, ref_z)
+    ce = ix.edge_select(coef)[2].double()
+    want = th.cat([z.double().t() @ d_pre.double(), z.double().t() @ (ce[:, None] * d_pre.double())], dim=1)
+    scale = float((z.double().abs().t() @ (ce[:, None].abs().clamp(min=1.0) * d_pre.double().abs())).max())
+    assert float((dw.double() - want).abs().max()) <= 2e-6 * scale
