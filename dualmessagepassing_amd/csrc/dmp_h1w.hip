@@ -248,24 +248,27 @@ __global__ __launch_bounds__(kThreadsW, 1) void h1w_k(const H1WArgs p) {
   auto cols_step = [&](int k, f32x16 (&wacc)[2][2]) {
     const int buf = k & 1;
     int act = 0;
+    // eight blocks (kg, jb, ib); the fragments the next block needs are requested BEFORE this block's MFMAs
+    Split8 fa[2], fb, nfa[2], nfb;
+    tr_split(tA, buf, 0, 0, fa[0]);
+    tr_split(tA, buf, 1, 0, fa[1]);
+    tr_split(tB, buf, 0, 0, fb);
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      Split8 fa[2];
-      tr_split(tA, buf, 0, kg, fa[0]);
-      tr_split(tA, buf, 1, kg, fa[1]);
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        Split8 fb;
-        tr_split(tB, buf, jb, kg, fb);
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-          __builtin_amdgcn_sched_barrier(0);
-          wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (act < 4) stage_row(buf ^ 1, act);
-          else load_row(act - 4);
-          ++act;
-        }
+    for (int b = 0; b < 8; ++b) {
+      const int kg = b >> 2, jb = (b >> 1) & 1, ib = b & 1;
+      if (ib == 1 && b + 1 < 8) {                             // the next block starts a new B fragment (and, at b == 3, new A fragments)
+        tr_split(tB, buf, jb ^ 1, jb == 1 ? kg + 1 : kg, nfb);
+        if (b == 3) { tr_split(tA, buf, 0, 1, nfa[0]); tr_split(tA, buf, 1, 1, nfa[1]); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (act < 4) stage_row(buf ^ 1, act);
+      else load_row(act - 4);
+      ++act;
+      if (ib == 1 && b + 1 < 8) {
+        fb = nfb;
+        if (b == 3) { fa[0] = nfa[0]; fa[1] = nfa[1]; }
       }
     }
     load_ids(k + 3);
@@ -505,25 +508,32 @@ __global__ __launch_bounds__(kThreadsW, 1) void atb2_k(const Atb2Args p) {
   auto tile_step = [&](int k, auto nset, auto oset) {
     const int buf = k & 1;
     int act = 0;
+    // four blocks (kg, ib); the fragments of block b+1 are requested BEFORE the MFMAs of block b (a read that an MFMA waits for
+    // exposes its whole LDS latency: 8 times per tile and wave otherwise)
+    Split8 fb, fa, nfa, nfb;
+    tr_split(tB, buf, 0, 0, fb);
+    tr_split(tA, buf, 0, 0, fa);
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      Split8 fb;
-      tr_split(tB, buf, 0, kg, fb);
+    for (int b = 0; b < 4; ++b) {
+      const int kg = b >> 1, ib = b & 1;
+      if (b + 1 < 4) {
+        tr_split(tA, buf, (b + 1) & 1, (b + 1) >> 1, nfa);
+        if (ib == 1) tr_split(tB, buf, 0, kg + 1, nfb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[ib] = mfma_x6(fa, fb, acc[ib]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        Split8 fa;
-        tr_split(tA, buf, ib, kg, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        acc[ib] = mfma_x6(fa, fb, acc[ib]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q, ++act) {
-          if (act < 4) stage_row(nset, buf ^ 1, act);
-          else {
-            if (act == 4) load_ids(oset, k + 4);
-            load_row(nset, act - 4);
-          }
+      for (int q = 0; q < 2; ++q, ++act) {
+        if (act < 4) stage_row(nset, buf ^ 1, act);
+        else {
+          if (act == 4) load_ids(oset, k + 4);
+          load_row(nset, act - 4);
         }
+      }
+      if (b + 1 < 4) {
+        fa = nfa;
+        if (ib == 1) fb = nfb;
       }
     }
   };
@@ -771,24 +781,27 @@ __global__ __launch_bounds__(kThreadsW, 1) void dzw_k(const DzwArgs p) {
     auto cols_step = [&](int k) {
       const int buf = k & 1;
       int act = 0;
+      // eight blocks (kg, jb, ib); the fragments the next block needs are requested BEFORE this block's MFMAs
+      Split8 fa[2], fb, nfa[2], nfb;
+      tr_split(tA, buf, 0, 0, fa[0]);
+      tr_split(tA, buf, 1, 0, fa[1]);
+      tr_split(tB, buf, 0, 0, fb);
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        Split8 fa[2];
-        tr_split(tA, buf, 0, kg, fa[0]);
-        tr_split(tA, buf, 1, kg, fa[1]);
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-          Split8 fb;
-          tr_split(tB, buf, jb, kg, fb);
-#pragma unroll
-          for (int ib = 0; ib < 2; ++ib) {
-            __builtin_amdgcn_sched_barrier(0);
-            wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (act < 4) stage_row(buf ^ 1, act);
-            else load_row(act - 4);
-            ++act;
-          }
+      for (int b = 0; b < 8; ++b) {
+        const int kg = b >> 2, jb = (b >> 1) & 1, ib = b & 1;
+        if (ib == 1 && b + 1 < 8) {                             // the next block starts a new B fragment (and, at b == 3, new A fragments)
+          tr_split(tB, buf, jb ^ 1, jb == 1 ? kg + 1 : kg, nfb);
+          if (b == 3) { tr_split(tA, buf, 0, 1, nfa[0]); tr_split(tA, buf, 1, 1, nfa[1]); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wacc[ib][jb] = mfma_x6(fa[ib], fb, wacc[ib][jb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (act < 4) stage_row(buf ^ 1, act);
+        else load_row(act - 4);
+        ++act;
+        if (ib == 1 && b + 1 < 8) {
+          fb = nfb;
+          if (b == 3) { fa[0] = nfa[0]; fa[1] = nfa[1]; }
         }
       }
       load_ids(k + 3);
