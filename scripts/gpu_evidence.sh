@@ -7,7 +7,7 @@
 #   <tag>z/profile_meta.json          launch shape + content hash of the kernel sources these profiles were taken with
 #   config 4 shard, eager / hid 64 lines, 2-rank plumbing line, UNC, micro-benchmarks
 # Copy what is to be judged into profiles/ (tracked) afterwards.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/${TAG}z && mkdir -p $O
 timeout 900 python3 $R/bench.py --cpu-b1024 > $O/bench_line.json 2> $O/bench_err.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python3 $R/bench.py --graph --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 0 > $O/prof_bench.json 2> $O/err.txt
@@ -16,6 +16,10 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- pytho
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 0 > /dev/null 2> $O/err_w.txt
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k -o k -- python3 $R/bench.py --eager --steps 3 --warmup 2 --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 0 > /dev/null 2> $O/err_k.txt
 rm -f $O/k/*trace*
+# the ALL-ROWS step (no filter net: `gate_dense`) as the headline of its own line, and its kernel statistics
+timeout 300 python3 $R/bench.py --graph --filter-net None --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 50 > $O/bench_gate_dense_line.json 2> $O/err_gd_line.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profgd -o d -- python3 $R/bench.py --graph --filter-net None --no-cpu-baseline --no-all-outputs --no-gate-compact --extended-steps 0 > $O/prof_bench_gate_dense.json 2> $O/err_gd.txt
+rm -f $O/profgd/*trace*
 # the gate-compact mode of the same step (bench.py's `gate_compact` object): its own kernel statistics
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profgc -o g -- python3 $R/bench.py --graph --gate-compact --no-cpu-baseline --no-all-outputs --extended-steps 0 > $O/prof_bench_gate_compact.json 2> $O/err_gc.txt
 rm -f $O/profgc/*trace*
@@ -34,7 +38,7 @@ f = load("$O/f/f_counter_collection.csv", "FETCH_SIZE"); w = load("$O/w/w_counte
 t = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open("$O/k/k_kernel_stats.csv"))}
 out = {}
 for k in f:
-    if any(x in k for x in ("mfma_typed", "mfma_pp", "atb_k", "atb_jobs", "pool_relu_bwd_k", "seg_sum_vec<32, true, true, true", "seg_sum_vec<32, true, false, true", "seg_acc_graphs_k", "l0_edge_fwd_k", "l0_bwd_w_k")):
+    if any(x in k for x in ("mfma_typed", "mfma_pp", "atb_k", "atb_jobs", "pool_relu_bwd_k", "seg_sum_vec<32, true, true, true", "seg_sum_vec<32, true, false, true", "seg_acc_graphs_k", "l0_edge_fwd_k", "l0_bwd_w_k", "h1w_k", "dzw_k", "atb2_k")):
         fv = [v for v in f[k] if v > 0.5 * max(f[k])]; wv = [v for v in w.get(k, [0]) if v > 0.5 * max(w.get(k, [1]))]
         hbm = (2 * sum(fv) / len(fv) + (sum(wv) / len(wv) if wv else 0)) * 1024
         short = k.replace("void dmp::(anonymous namespace)::", "").split("(")[0]
