@@ -535,6 +535,9 @@ def seg_roofline(k, what, own_bytes, survey_bytes, prof, skipped_rows=0, all_own
          "avg_us": round(us, 2), "launches": k["launches"],
          "bytes_own": int(own_bytes), "frac_own_bytes": round(own_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
          "avg_us_rocprof": prof["avg_us_rocprof"]}
+    if k.get("interrupted"):       # launches stalled by the box (> 10x the median), left out of avg_us: _lib.KernelTimer.summary
+        r["launches_interrupted"] = int(k["interrupted"])
+        r["avg_us_all_launches"] = round(k["avg_us_all"], 2)
     if prof["avg_us_rocprof"]:
         r["frac_rocprof"] = round(survey_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)
         r["frac_own_bytes_rocprof"] = round(own_bytes / prof["avg_us_rocprof"] / 1e3 / HBM_PEAK_GBPS, 4)

@@ -52,6 +52,11 @@ struct TypedArgs {
   int act;                              // TEPI_OUT: != 0: the activation (slope) is applied to the output row
   float *partial;                       // TEPI_H1: [gridDim.x, H] column sums of dPre per workgroup
   float *partialA;                      // TEPI_H1, optional: [gridDim.x, H] column sums of the fetched rows of A
+  // TEPI_OUT with CODES: a K-extension of the product -- out[e] += codes[e] Wc (codes [E, ldcodes], Wc [kcodes <= 16, ldwc >= H]):
+  // the residual rows of a FIRST layer are a label embedding z0 = codes W_e (basemodel.py:1393-1420), so they need not exist in HBM
+  // (codes -> the code row of edge code_row0: edges below it take no codes term -- rows of ANOTHER table, which come in through R,
+  // a [rowsR, ldr] array whose missing rows read as zeros)
+  const float *codes; int64_t ldcodes; int kcodes; const float *Wc; int64_t ldwc; int64_t code_row0;
 };
 
 template <int H> struct TypedGeom {
@@ -66,8 +71,9 @@ template <int H> struct TypedGeom {
 // pieces (96 instead of 64 VGPRs at H = 128: two workgroups per CU instead of three), the streamed operand is split as
 // it is read from LDS.  !X6: exact fp32 MFMA (development / comparison switch, dmp_dev_set_exact_fp32).
 // BIG: the streamed / scattered row arrays (A, C, R) are 4 GiB or larger: rows through 64-bit pointers (dmp_mfma_common.h).
-template <int EPI, int H, bool X6, bool BIG = false>
+template <int EPI, int H, bool X6, bool BIG = false, bool CODES = false>
 __device__ __forceinline__ void typed_body(const TypedArgs &p) {
+  static_assert(!CODES || (EPI == TEPI_OUT && X6 && !BIG && H == 128), "the K-extension: TEPI_OUT, bf16x6, H = 128, arrays below 4 GiB");
   constexpr int kStride = TypedGeom<H>::kStride, kQ = TypedGeom<H>::kQ, kHalf = H / 2, kSteps4 = H / 8;
   constexpr uint32_t kRowBytes = H * 4u;                  // second half of a gathered [.., 2H] row, second weight panel
   // TEPI_EDGE: one barrier per tile, the staging / requests of the next tiles in the MFMA shadow (tile k in As[k & 1]).
@@ -83,6 +89,9 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   constexpr int kTileWords = X6 ? 3 * kPlane : kSub * kStride;
   __shared__ __attribute__((aligned(16))) float As[kPipelined ? 2 : 1][kTileWords];
   __shared__ float Cs[H / 32][32 * kScrStride];
+  // CODES: the tile's code rows as bf16 pieces, [buffer][plane][row * 8 dwords] (16 codes per row; no padding: three 16-byte reads per
+  // tile and wave, a 4-way bank conflict on them costs nothing)
+  __shared__ __attribute__((aligned(16))) uint32_t Cx[CODES ? 2 : 1][3][CODES ? kSub * 8 : 4];
   __shared__ uint32_t rowA[3][kSub], rowB[3][kSub], rowC[3][kSub], rowR[3][kSub];   // [tile % 3][row] row INDICES (-1: none): tile k's are read
                                                                                      // (epilogue) while tile k+2's are written
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -104,7 +113,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   // rows of the big arrays are addressed by INDEX (structured descriptors: any array size, dmp_mfma_common.h)
   const srsrc_t rs_A = make_srsrc(p.A, p.lda, p.rowsA);
   const srsrc_t rs_C = make_srsrc(p.C, p.ldc, p.E);
-  const srsrc_t rs_R = make_srsrc(p.R, p.ldr, p.rmap ? p.rowsR : p.E);
+  const srsrc_t rs_R = make_srsrc(p.R, p.ldr, (p.rmap || CODES) ? p.rowsR : p.E);     // (CODES: rows >= rowsR read as zeros)
   const srsrc_t rs_R2 = make_srsrc(p.R2, p.R2 ? p.ldr2 : (int64_t)H, p.R2 ? p.E : 0);        // (no second addend: zero records)
   const rsrc_t rs_rmap = make_rsrc(p.rmap, p.rmap ? rows4 : 0u);
   const srsrc_t rs_T = make_srsrc(p.T, p.ldt, p.num_nodes);
@@ -112,6 +121,10 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   const rsrc_t rs_idxB = make_rsrc(p.idxB, p.idxB ? rows4 : 0u);
   const rsrc_t rs_flag = make_rsrc(p.flag, p.flag ? (uint32_t)p.E : 0u);
   constexpr uint32_t kOOB = 0xFFFFF000u;                                   // byte offset beyond any descriptor range
+  const srsrc_t rs_codes = make_srsrc(CODES ? p.codes : nullptr, CODES ? p.ldcodes : (int64_t)4, CODES ? p.E - p.code_row0 : 0);  // (codes: row code_row0)
+  const int cq = gtid & 3, crow = gtid >> 2;                               // CODES: threads < 128 stage codes 4 cq .. 4 cq + 3 of row crow
+  const bool cstage = CODES && gtid < 4 * kSub && 4 * cq < (int)p.ldcodes && 4 * cq < 16;
+  Split8 BX;                                                               // CODES: the extension's panel fragment: BX[j] = Wc[8 h + j][col]
 
   // this workgroup's contiguous tile range (tiles are sorted by class)
   const int ntiles = __builtin_amdgcn_readfirstlane(*p.num_tiles);
@@ -130,6 +143,14 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   const uint32_t w_first = (uint32_t)(p.transposed ? (int64_t)col * p.ldw + kHalf * h : (int64_t)kHalf * h * p.ldw + col) * 4u;
   const uint32_t w_step = __builtin_amdgcn_readfirstlane((int)(p.transposed ? 4 : p.ldw * 4));  // bytes from k to k+1
   auto load_panel = [&](float c) {
+    if (CODES) {                          // rows 8 h .. 8 h + 7 of Wc (rows >= kcodes: beyond the descriptor's range -> zeros)
+      const rsrc_t rs_Wc = make_rsrc(p.Wc, (uint32_t)(p.kcodes * p.ldwc * 4));
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        w[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_Wc, (int)(((int64_t)(8 * h + j) * p.ldwc + col) * 4), 0, 0));
+      split8(make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), BX);
+    }
     // The offsets hang off a value the optimiser cannot see through: otherwise it hoists the H
     // address computations out of the tile loop and keeps them live in registers across it.
     uint32_t off;
@@ -173,6 +194,8 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   float4 pre[NSET][kSubLoads];
   uint32_t pre_a[NSET] = {}, pre_b[NSET] = {};
   int pre_r[NSET] = {};              // TEPI_DZ: row of R for this thread's row (threads < 32)
+  int id_c = -1;                     // CODES: slot id of row gtid / 4 (threads < 128)
+  float4 pre_c = make_float4(0.f, 0.f, 0.f, 0.f);
   std::integral_constant<int, 0> set0;
   std::integral_constant<int, NSET - 1> set1;
   auto load_ids = [&](int k) {                            // ids of tile lo + k (-1 past the end)
@@ -182,6 +205,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
     for (int m = 0; m < kSubLoads; ++m)
       id_rows[m] = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, ((gtid / kQ) + 8 * m) * 4, (int)so, 0) : -1;
     if (gtid < kSub) id_own = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slot, gtid * 4, (int)so, 0) : -1;
+    if (CODES && gtid < 4 * kSub) id_c = ok ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_slotA, crow * 4, (int)so, 0) : -1;
   };
   int own_staged[NSET];
 #pragma unroll
@@ -200,6 +224,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
       if (EPI == TEPI_DZ) pre_r[S] = p.rmap ? (id_own >= 0 ? (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rmap, (int)eo, 0, 0) : -1) : id_own;
       own_staged[S] = id_own;
     }
+    if (CODES) pre_c = cstage ? sbuf_load4(rs_codes, id_c - (int)p.code_row0, (uint32_t)cq * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);   // (id -1, rows below code_row0: zeros)
   };
   auto load_rows = [&](auto set) {                          // rows + per-row scalars of the tile whose ids are loaded
 #pragma unroll
@@ -242,10 +267,22 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
       rowR[par][gtid] = (ok && p.R && (EPI != TEPI_DZ || pre_r[S] >= 0)) ? (uint32_t)(EPI == TEPI_DZ ? pre_r[S] : own_staged[S]) : kNone;
     }
   };
+  auto stage_codes = [&](int buf) {                        // CODES: the tile's code rows as three bf16 planes (threads < 128)
+    if (CODES && gtid < 4 * kSub) {
+      uint2 ph, pm, pl;
+      const int kc = (int)p.kcodes - 4 * cq;                 // (a row's padding columns may hold anything: zeros from here on)
+      split_pair(kc > 0 ? pre_c.x : 0.f, kc > 1 ? pre_c.y : 0.f, ph.x, pm.x, pl.x);
+      split_pair(kc > 2 ? pre_c.z : 0.f, kc > 3 ? pre_c.w : 0.f, ph.y, pm.y, pl.y);
+      *reinterpret_cast<uint2 *>(&Cx[CODES ? buf : 0][0][crow * 8 + cq * 2]) = ph;
+      *reinterpret_cast<uint2 *>(&Cx[CODES ? buf : 0][1][crow * 8 + cq * 2]) = pm;
+      *reinterpret_cast<uint2 *>(&Cx[CODES ? buf : 0][2][crow * 8 + cq * 2]) = pl;
+    }
+  };
   auto stage = [&](int buf, int par, auto set) {
 #pragma unroll
     for (int m = 0; m < kSubLoads; ++m) stage_row(buf, set, m);
     stage_scalars(par, set);
+    stage_codes(buf);
   };
 
   f32x16 acc;
@@ -300,6 +337,19 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
       (void)done;
       ah = nh; am = nm; al = nl;
     }
+    if (CODES) {                                             // + codes Wc: one more 16-deep k-group (this lane: codes 8 h .. 8 h + 7 of row li)
+      const int cb = (tile == &As[0][0]) ? 0 : 1;
+      Frag8 ch, cm, cl;
+      ch.v = *reinterpret_cast<const bf16x8 *>(&Cx[CODES ? cb : 0][0][li * 8 + 4 * h]);
+      cm.v = *reinterpret_cast<const bf16x8 *>(&Cx[CODES ? cb : 0][1][li * 8 + 4 * h]);
+      cl.v = *reinterpret_cast<const bf16x8 *>(&Cx[CODES ? cb : 0][2][li * 8 + 4 * h]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl.v, BX.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch.v, BX.lo.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cm.v, BX.mid.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cm.v, BX.hi.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch.v, BX.mid.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch.v, BX.hi.v, acc, 0, 0, 0);
+    }
   };
   // The MFMA phase, with the epilogue operand requests of the same tile in its shadow: two of the eight loads
   // (and the LDS reads of their row offsets) after each of the first four MFMA groups.
@@ -335,7 +385,7 @@ __device__ __forceinline__ void typed_body(const TypedArgs &p) {
   auto shadow = [&](int i, int k, int par3, int buf, int nxt3, auto nset) {
     if (i < 4) { if (!X6) fetch_operand(par3, i); }       // X6: requested by the previous tile's epilogue (below)
     else if (i < 8) stage_row(buf ^ 1, nset, i - 4);
-    else if (i == 8) stage_scalars(nxt3, nset);
+    else if (i == 8) { stage_scalars(nxt3, nset); stage_codes(buf ^ 1); }
     else if (i < 13) load_row(nset, i - 9);
     else if (i == 13) load_row_scalars(nset);
     else if (i == 14) load_ids(k + kAhead + 1);
@@ -512,6 +562,10 @@ template <int EPI, int H, bool X6, bool BIG = false>
 __global__ __launch_bounds__(TypedGeom<H>::kThreads, (X6) ? 2 : 3) void mfma_typed(TypedArgs p) {
   typed_body<EPI, H, X6, BIG>(p);
 }
+// TEPI_OUT with the K-extension (the first layer's residual rows from their label codes)
+__global__ __launch_bounds__(TypedGeom<128>::kThreads, 2) void mfma_typed_codes(TypedArgs p) {
+  typed_body<TEPI_OUT, 128, true, false, true>(p);
+}
 
 // Several TEPI_OUT products over the SAME tile list in one launch (the node side of a layer: up to kTypedJobs independent
 // 128-wide block products over the kept nodes' tiles): grid.y = the job, grid.x = the workgroups of one job -- every workgroup
@@ -649,6 +703,30 @@ int dmp_out_fwd_typed(const dmp_typed_job *jobs, int num_jobs, const int32_t *sl
   const dim3 grid(gx, (unsigned)num_jobs);
   if (H == 128) mfma_typed_jobs<128><<<grid, TypedGeom<128>::kThreads, 0, st>>>(js);
   else mfma_typed_jobs<64><<<grid, TypedGeom<64>::kThreads, 0, st>>>(js);
+  return check_launch();
+}
+
+int dmp_out_fwd_typed_codes(const dmp_typed_job *job, const float *codes, int64_t ldc, int kcodes, const float *Wc, int64_t ldwc,
+                            int64_t code_row0, int64_t r_rows, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
+                            int H, void *stream) {
+  if (H != 128 || g_exact_fp32) return DMP_ERR_UNSUPPORTED;
+  if (!job || !codes || !Wc || kcodes < 1 || kcodes > 16 || ldc < kcodes || ldwc < H || code_row0 < 0 || code_row0 > E || r_rows < 0 || r_rows > E)
+    return DMP_ERR_BAD_ARG;
+  if (E == 0) return (E < 0) ? DMP_ERR_BAD_ARG : DMP_OK;
+  const dmp_typed_job &q = *job;
+  const int rc = rows_typed_check(q.Hin, q.ldh, q.W2, q.ldw, q.R, q.ldr, q.out, q.ldo, slot_edge, tile_scale, num_tiles, tiles_bound, E, H);
+  if (rc != DMP_OK) return rc;
+  if (q.R2 || (q.bias && !aligned16(q.bias)) || (q.act && !slope_ok(q.slope))) return DMP_ERR_UNSUPPORTED;
+  if (ldc % 4 || !aligned16(codes) || !stride_ok(ldc) || !fits4g(E, ldc) || !fits4g(E, q.ldh) || !fits4g(E, q.ldo) || (q.R && !fits4g(E, q.ldr)) ||
+      !fits32(kcodes, ldwc))
+    return DMP_ERR_UNSUPPORTED;
+  TypedArgs p{};
+  p.A = q.Hin; p.lda = q.ldh; p.W = q.W2; p.ldw = q.ldw; p.transposed = q.w_in_out ? 0 : 1;
+  p.C = q.out; p.ldc = q.ldo; p.E = E; p.slot_edge = slot_edge; p.slot_arow = slot_edge; p.rowsA = E; p.tile_scale = tile_scale;
+  p.num_tiles = num_tiles; p.bias = q.bias; p.R = q.R; p.ldr = q.R ? q.ldr : H; p.R2 = nullptr; p.ldr2 = H;
+  p.num_panels = 1; p.act = q.act ? 1 : 0; p.slope = q.slope;
+  p.codes = codes + code_row0 * ldc; p.ldcodes = ldc; p.kcodes = kcodes; p.Wc = Wc; p.ldwc = ldwc; p.code_row0 = code_row0; p.rowsR = q.R ? r_rows : 0;
+  mfma_typed_codes<<<typed_blocks(tiles_bound, 2), TypedGeom<128>::kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch();
 }
 

@@ -464,8 +464,14 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
         # ... which the layer reads over the kept edges' / nodes' tiles only: the rows under a zero of a 0 / 1 gate are not even stored
         live_e, live_v = fused.l0_dead_inputs(union.index(), layers[0].hidden_dim, *_joint_gates(v_gate, e_gate, np_, ep_, p_e_emb.dtype, p_e_emb.device),
                                               l0)
+        l0.z_from_codes = fused.l0_z_from_codes(union.index(), layers[0].hidden_dim, _joint_gates(v_gate, e_gate, np_, ep_, p_e_emb.dtype, p_e_emb.device)[1],
+                                                l0, live_e, model.rep_residual)
         with th.no_grad():
-            e = _GateConcat.apply(p_e_emb, None, e_gate, g_e_emb._dmp_src[0], g_e_emb._dmp_src[1], live_e)
+            if l0.z_from_codes:     # ... or not stored at all: the layer's second Linear forms the kept rows from the codes in registers
+                l0.z_head = p_e_emb.detach()          # (the pattern's rows: few, embedded by their own table)
+                e = fused.dead_rows_buffer((ep_ + g_e_emb._dmp_src[0].size(0), layers[0].hidden_dim), p_e_emb.device)
+            else:
+                e = _GateConcat.apply(p_e_emb, None, e_gate, g_e_emb._dmp_src[0], g_e_emb._dmp_src[1], live_e)
             if l0.venc is not None:
                 v = _GateConcat.apply(p_v_emb, None, v_gate, g_v_emb._dmp_src[0], g_v_emb._dmp_src[1], live_v)
     else:

@@ -797,6 +797,64 @@ def typed_jobs(jobs, tiles):
               "dmp_out_fwd_typed")
 
 
+def l0_rows(l0, W0, z):
+    """The first layer's edge rows ``z``: as given, or -- when ``dmpnn.joint_rep`` left them out (``l0.z_from_codes``) and the layer
+    did not take the launch that forms them in registers -- made here: the pattern's embedded rows (``l0.z_head``) over the target's
+    from their label codes."""
+    if l0 is None or not getattr(l0, "z_from_codes", False):
+        return z
+    n, K, H = l0.z_head.size(0), l0.K, W0.size(1)
+    out = torch.empty((l0.enc.size(0), H), dtype=torch.float32, device=l0.enc.device)
+    out[:n].copy_(l0.z_head)
+    if out.size(0) > n:
+        smallk_embed(l0.enc[n:, :K], W0.detach()[-K:], None, out[n:], H)
+    return out
+
+
+USE_OUT_CODES = _os.environ.get("DMP_DEV_OUT_CODES", "1") == "1"   # the first layer's residual rows z0 = codes W_e as a K-extension of its second Linear
+
+
+def out_codes_ok(h1, enc, K, Wc):
+    """``out_fwd_typed_codes`` applies: H = 128, bf16x6, at most 16 code columns in rows of whole 16-byte pieces, arrays below 4 GiB."""
+    lib = _lib.load()
+    lim = (1 << 32) - 65536
+    return bool(USE_OUT_CODES and h1.size(1) == 128 and not lib.dmp_dev_get_exact_fp32() and 1 <= K <= 16 and Wc.size(0) == K and Wc.size(1) == 128
+                and enc.dtype == torch.float32 and enc.stride(1) == 1 and enc.stride(0) % 4 == 0 and enc.data_ptr() % 16 == 0
+                and enc.size(0) == h1.size(0) and h1.size(0) * 128 * 4 < lim and Wc.stride(1) == 1)
+
+
+def out_fwd_typed_codes(h1, W2t, b2, enc, K, Wc, tiles, prev=None, out=None, w_in_out=True, row0=0):
+    """``prev + (h1 W2^T + enc[:, :K] Wc + b2)`` for the rows of ``tiles`` (``dmp_out_fwd_typed_codes``): the second Linear of a FIRST
+    layer whose residual rows are the label embedding ``enc Wc`` -- added as one more 16-deep k-group of the product, so the [E, H] rows
+    ``z0`` are neither written (``dmp_smallk_embed_live``) nor read.  ``row0``: the rows below it take no codes term (the pattern's
+    edges, embedded by another table); ``prev`` may then hold just those rows ([row0 or more, H]: missing rows count as zeros)."""
+    global _TYPED_JOB
+    lib = _lib.load()
+    if _TYPED_JOB is None:
+        P, I64, I, F = _ctypes.c_void_p, _ctypes.c_int64, _ctypes.c_int, _ctypes.c_float
+        _TYPED_JOB = type("dmp_typed_job", (_ctypes.Structure,), {"_fields_": [
+            ("Hin", P), ("ldh", I64), ("W2", P), ("ldw", I64), ("w_in_out", I), ("bias", P), ("R", P), ("ldr", I64), ("R2", P), ("ldr2", I64),
+            ("act", I), ("slope", F), ("out", P), ("ldo", I64)]})
+    slot_edge, tile_scale, num_tiles, bound = tiles
+    R, H = h1.shape
+    if out is None:
+        out = dead_rows_buffer((R, H), h1.device)
+    Wc = Wc.detach()
+    _lib.require_gpu(h1, W2t, out, prev, b2, enc, Wc)
+    j = _TYPED_JOB()
+    j.Hin, j.ldh, j.W2, j.ldw, j.w_in_out = h1.data_ptr(), h1.stride(0), W2t.data_ptr(), W2t.stride(0), int(bool(w_in_out))
+    j.bias = ptr(b2)
+    j.R, j.ldr = ptr(prev), (prev.stride(0) if prev is not None else H)
+    j.R2, j.ldr2 = None, H
+    j.act, j.slope = 0, 0.0
+    j.out, j.ldo = out.data_ptr(), out.stride(0)
+    with _lib.timed("out_fwd_typed_codes[H=%d,R=%d]", (H, R), 4 * H * R * 2 + 4 * enc.size(1) * R):
+        check(lib.dmp_out_fwd_typed_codes(_ctypes.byref(j), ptr(enc), enc.stride(0), int(K), ptr(Wc), Wc.stride(0), int(row0),
+                                          0 if prev is None else min(R, prev.size(0)), ptr(slot_edge), ptr(tile_scale),
+                                          ptr(num_tiles), bound, R, H, stream_ptr()), "dmp_out_fwd_typed_codes")
+    return out
+
+
 def out_fwd_typed(h1, W2t, b2, prev, tiles, out=None, w_in_out=True, slope=None, prev2=None):
     """``prev + (h1 W2^T + b2)`` for the rows of ``tiles`` (``live_tiles``: the edges a 0 / 1 gate keeps, gate 1 there; or
     ``NodeRows.tiles``: the kept nodes); the other rows of the result are not written (``dead_rows_buffer``).  ``W2t`` [in, out]
@@ -1859,9 +1917,15 @@ class _FusedDMPLayer(torch.autograd.Function):
             lt = live_tiles(index, coef, e_gate) if (dead == 3 and USE_TYPED_ROWS and eW2t is not None) else None
             if lt is not None:      # nothing to write for the rows under a zero gate: the kept edges' tiles only
                 # (a plain panel needs no class: the kept edges' tiles in ascending row order -- ``ascending_tiles``)
-                zn = out_fwd_typed(H1e, eW2t, eb2, z if residual else None, (ascending_tiles(e_gate) if PLAIN_ROWS_ASCENDING else None) or lt)
+                tl_ = (ascending_tiles(e_gate) if PLAIN_ROWS_ASCENDING else None) or lt
+                if l0 is not None and residual and getattr(l0, "z_from_codes", False) and out_codes_ok(H1e, l0.enc, l0.K, W0[-l0.K:]):
+                    # the target's residual rows z = enc W0 are not in memory at all (``dmpnn.joint_rep`` did not make them): one more
+                    # k-group over their codes; the pattern's few rows (their own table) come in as the residual operand
+                    zn = out_fwd_typed_codes(H1e, eW2t, eb2, l0.enc, l0.K, W0[-l0.K:], tl_, prev=l0.z_head, row0=l0.z_head.size(0))
+                else:
+                    zn = out_fwd_typed(H1e, eW2t, eb2, l0_rows(l0, W0, z) if residual else None, tl_)
             else:
-                zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, z if residual else None, eW2t, dead_rows=dead)
+                zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, l0_rows(l0, W0, z) if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
         ctx.v_gate, ctx.e_gate, ctx.WesT, ctx.slope = v_gate, e_gate, WesT, slope
         ctx.vpool, ctx.epool = vpool, epool
@@ -2210,6 +2274,16 @@ class _FusedDMPLayer(torch.autograd.Function):
                 dWV0 = torch.addmm(Yn[3], Y, Wx.t()) if ctx.residual else Y @ Wx.t()
         return (None, None, None, dx, dz, None, None, dBn, dbn, dWx, dWes, dbe, dW2n, db2n, dW2e, db2e, None, None, None, None,
                 None, None, None, dW0, dWV0, None, None)
+
+
+def l0_z_from_codes(index, H, eg, l0, live_edges, residual):
+    """May ``dmpnn.joint_rep`` leave the target's part of the first layer's edge rows ``z = enc W`` out of memory altogether?  With
+    a residual layer and the conditions under which its second Linear runs over the kept edges' tiles (``l0_dead_inputs``' edge
+    half), that launch adds ``enc W`` as one more k-group (``out_fwd_typed_codes``).  (A layer that ends up elsewhere makes the
+    rows itself: ``l0_rows``.)"""
+    return bool(USE_OUT_CODES and live_edges and residual and l0 is not None and H == 128
+                and not _lib.load().dmp_dev_get_exact_fp32() and l0.enc.stride(0) % 4 == 0 and l0.enc.data_ptr() % 16 == 0
+                and index.num_edges * 128 * 4 < (1 << 32) - 65536)
 
 
 def l0_dead_inputs(index, H, vg, eg, l0):

@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 78
+#define DMP_ABI_VERSION 79
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -1109,6 +1109,17 @@ int dmp_out_fwd_typed(const dmp_typed_job *jobs, int num_jobs, const int32_t *sl
 int dmp_bwd_h1_typed(const float *dO, int64_t ldo, const float *W2, int64_t ldw, const float *H1, int64_t ldh,
                      const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
                      int H, float slope, float *dG, int64_t ldg, float *partial, float *partial_rows, void *stream);
+/* dmp_out_fwd_typed (one job, no second addend) with a K-EXTENSION of the product:
+ *     out[e] = (e < r_rows ? R[e] : 0) + (Hin[e] W2^T + (e >= code_row0 ? codes[e] Wc : 0) + bias).
+ * The residual rows of a rep-net's FIRST layer are a label embedding, z0[e] = codes[e] W_e with <= 16 code columns
+ * (basemodel.py:1393-1420 feeding dmpnn.py:262-275's `zn = z + ...`): given the codes and the table the kernel adds them as one more
+ * 16-deep k-group (codes [E, ldc % 4 == 0] fp32, split into bf16 pieces like every operand; Wc [kcodes <= 16, ldwc >= H]), and the [E, H]
+ * rows z0 are never written nor read.  The reference builds one table per side (basemodel.py:51-52: share_emb_net only matters in
+ * expand()), the union's first edges being the pattern's: code_row0 = their number, R [r_rows, ldr] = their (few) embedded rows, Wc = the
+ * target's table; one shared table: code_row0 = 0, R = NULL.  H = 128, bf16x6, arrays below 4 GiB; DMP_ERR_UNSUPPORTED otherwise. */
+int dmp_out_fwd_typed_codes(const dmp_typed_job *job, const float *codes, int64_t ldc, int kcodes, const float *Wc, int64_t ldwc,
+                            int64_t code_row0, int64_t r_rows, const int32_t *slot_edge, const float *tile_scale, const int32_t *num_tiles, int64_t tiles_bound, int64_t E,
+                            int H, void *stream);
 
 /*
  * The tall-skinny weight gradients over a tile list on the same kind of LDS image (csrc/dmp_h1w.hip::atb2_k): per job

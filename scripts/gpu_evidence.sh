@@ -41,7 +41,7 @@ for k in f:
     if any(x in k for x in ("mfma_typed", "mfma_pp", "atb_k", "atb_jobs", "pool_relu_bwd_k", "seg_sum_vec<32, true, true, true", "seg_sum_vec<32, true, false, true", "seg_acc_graphs_k", "l0_edge_fwd_k", "l0_bwd_w_k", "h1w_k", "dzw_k", "atb2_k")):
         fv = [v for v in f[k] if v > 0.5 * max(f[k])]; wv = [v for v in w.get(k, [0]) if v > 0.5 * max(w.get(k, [1]))]
         hbm = (2 * sum(fv) / len(fv) + (sum(wv) / len(wv) if wv else 0)) * 1024
-        short = k.replace("void dmp::(anonymous namespace)::", "").split("(")[0]
+        short = k.replace("void ", "").replace("dmp::(anonymous namespace)::", "").split("(")[0]
         out[short] = {"FETCH_SIZE_KB_avg_large": sum(fv) / len(fv), "WRITE_SIZE_KB_avg_large": (sum(wv) / len(wv) if wv else 0),
                       "hbm_bytes_per_launch": hbm, "rocprof_avg_us_all_launches": t.get(k)}
         print("%-44s HBM %7.1f MB per large launch  (avg over all launches %6.1f us)" % (short, hbm / 1e6, t.get(k, 0)))

@@ -575,6 +575,57 @@ def test_second_linear_over_the_kept_edges_tiles(rows, h, gpu):
     assert float((db_rows - ref_rows).abs().max()) <= 2e-6 * max(1.0, kept) * float(d_o.abs().max())
 
 
+@pytest.mark.parametrize("rows,k,kpad,ascending", [(40, 3, 4, True), (1000, 7, 8, False), (70001, 9, 12, True), (70001, 16, 16, False),
+                                                  (300000, 7, 8, True)])
+def test_second_linear_with_the_residual_rows_from_their_codes(rows, k, kpad, ascending, gpu):
+    """``dmp_out_fwd_typed_codes`` (the first layer's residual rows ``z0 = codes W_e`` as one more k-group of its second Linear, so
+    that the [E, H] rows are never in memory) against ``dmp_out_fwd_typed`` reading ``z0`` made in fp64: equal on the kept rows to
+    fp32 accuracy (the codes product runs as bf16x6 like the rest), the other rows untouched, rows of h1 under a zero gate and the
+    padding columns of the code rows never read (NaN there); the same bits on every launch."""
+    from dualmessagepassing_amd import fused
+    h = 128
+    gen = th.Generator().manual_seed(rows + k)
+    rng = np.random.default_rng(rows + k)
+    n = max(2, rows // 6)
+    src, dst = rng.integers(0, n, rows).astype(np.int64), rng.integers(0, n, rows).astype(np.int64)
+    ix = _index(src, dst, n, rng.random(rows) < 0.5, gpu)
+    coef = ix.degree_coef(ix.out_deg)
+    gate = th.from_numpy((rng.random(rows) < 0.46).astype(np.float32)).to(gpu)
+    gate._dmp_binary = True
+    dead = gate == 0
+    tiles = fused.ascending_tiles(gate) if ascending else fused.live_tiles(ix, coef, gate)
+    assert tiles is not None
+    h1 = th.randn(rows, h, generator=gen).to(gpu)
+    enc = th.full((rows, kpad), float("nan"), device=gpu)
+    enc[:, :k] = th.randn(rows, k, generator=gen).to(gpu)          # (any fp32 codes, not only 0 / 1 bits)
+    enc[:, :k] *= gate[:, None]
+    Wc = th.randn(k, h, generator=gen).to(gpu)
+    W2 = (th.randn(h, h, generator=gen) / h ** 0.5).to(gpu)
+    b2 = th.randn(h, generator=gen).to(gpu)
+    assert fused.out_codes_ok(h1, enc, k, Wc)
+    row0 = 0 if rows == 1000 else min(rows // 3, 4097)           # the first rows: residual rows given, no codes term
+    head = th.randn(row0, h, generator=gen).to(gpu) if row0 else None
+    z0 = (enc[:, :k].double() @ Wc.double()).float()
+    if row0:
+        z0[:row0] = head
+        enc[:row0] = float("nan")                                # (never read)
+    h1p = h1.clone()
+    h1p[dead] = float("nan")
+    saved = fused.dead_rows_buffer
+    fused.dead_rows_buffer = lambda shape, device: th.full(shape, 7.5, dtype=th.float32, device=device)
+    try:
+        ref = fused.out_fwd_typed(h1p, W2.t().contiguous(), b2, z0, tiles)
+        out = fused.out_fwd_typed_codes(h1p, W2.t().contiguous(), b2, enc, k, Wc, tiles, prev=head, row0=row0)
+        again = fused.out_fwd_typed_codes(h1p, W2.t().contiguous(), b2, enc, k, Wc, tiles, prev=head, row0=row0)
+    finally:
+        fused.dead_rows_buffer = saved
+    assert bool((out[dead] == 7.5).all())
+    assert th.equal(out, again)
+    assert float((out[~dead] - ref[~dead]).abs().max()) <= 3e-6 * float(ref[~dead].abs().max())
+    exact = z0[~dead].double() + h1[~dead].double() @ W2.double().t() + b2.double()
+    assert float((out[~dead].double() - exact).abs().max()) <= 3e-6 * float(exact.abs().max())
+
+
 @pytest.mark.parametrize("rows,ascending", [(40, False), (1000, True), (70001, True), (70001, False), (300000, True)])
 def test_second_linear_backward_in_one_launch(rows, ascending, gpu):
     """``dmp_bwd_h1_w`` (csrc/dmp_h1w.hip: dPre AND dO^T H1 from one pass over the kept edges' tiles; four waves on rows, four on
