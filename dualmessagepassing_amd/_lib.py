@@ -375,13 +375,19 @@ class KernelTimer:
         for name, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             nbytes = sum(r[2] for r in recs) / len(recs)
-            med = sorted(ms)[len(ms) // 2]
-            kept = [t for t in ms if not (t > 10.0 * med and t > med + 1.0)] or ms
+            kept = uninterrupted(ms)
             avg = sum(kept) / len(kept)
             out[name] = {"launches": len(recs), "avg_us": avg * 1e3, "bytes": nbytes,
                          "gbps": nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
                          "interrupted": len(ms) - len(kept), "avg_us_all": sum(ms) / len(ms) * 1e3}
         return out
+
+
+def uninterrupted(ms):
+    """The launch times (ms) without the launches something else on the box stalled: more than 10x the median AND at least 1 ms
+    above it (a kernel's own spread never looks like that)."""
+    med = sorted(ms)[len(ms) // 2]
+    return [t for t in ms if not (t > 10.0 * med and t > med + 1.0)] or list(ms)
 
 
 timer = KernelTimer()

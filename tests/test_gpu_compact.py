@@ -444,6 +444,52 @@ def test_zero_gate_skipping_leaves_every_output_and_gradient_as_it_was(lazy):
             assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
 
 
+def test_first_layer_residual_rows_from_their_codes_leave_the_model_as_it_was():
+    """``fused.out_fwd_typed_codes`` in the model: the joint pass does not store the target's embedded edge rows (its placeholder is
+    poisoned with NaN here), the first layer's second Linear forms the kept ones from the label codes -- against the same model with
+    the rows stored (``USE_OUT_CODES`` off): every output and gradient equal to fp32 accuracy; and a first layer that cannot take
+    that launch (``out_codes_ok`` forced false) makes the rows itself (``l0_rows``) with the same result."""
+    from dualmessagepassing_amd import fused
+    gpu = th.device("cuda:0")
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = dict(bench.CFG, batch=96)
+    bench_, shard, step, model = _model_and_batch(cfg, gpu)
+    fused.USE_OUT_CODES = False
+    try:
+        ref_out, ref_flat = _outputs_and_grads(bench_, cfg, shard, step, model, True)
+    finally:
+        fused.USE_OUT_CODES = True
+    calls = []
+    orig, orig_ok = fused.out_fwd_typed_codes, fused.out_codes_ok
+    for fallback in (False, True):
+        fused.out_fwd_typed_codes = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        if fallback:
+            fused.out_codes_ok = lambda *a, **k: False
+        fused.POISON_DEAD_ROWS = True
+        try:
+            out, flat = _outputs_and_grads(bench_, cfg, shard, step, model, True)
+        finally:
+            fused.POISON_DEAD_ROWS = False
+            fused.out_fwd_typed_codes, fused.out_codes_ok = orig, orig_ok
+        assert len(calls) == 1                        # the launch ran once (first pass), not at all in the fallback pass
+        for k, v in ref_out.items():
+            if v is None:
+                assert out[k] is None
+                continue
+            assert bool(th.isfinite(out[k]).all()), k
+            s = max(1e-6, float(v.abs().max()))
+            assert float((out[k] - v).abs().max()) <= 2e-5 * s, (k, float((out[k] - v).abs().max()), s)
+        assert bool(th.isfinite(flat).all())
+        for prm, off in zip(step.sync.params, step.sync.offsets):
+            a, b = flat[off:off + prm.numel()], ref_flat[off:off + prm.numel()]
+            s = float(b.abs().max())
+            if s == 0.0:
+                assert float(a.abs().max()) == 0.0
+            else:
+                assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
+
+
 @pytest.mark.parametrize("R,M,N", [(40003, 128, 128), (5000, 64, 64), (8200, 128, 256)])
 def test_binary_gate_weight_gradient_on_the_plain_rows_product(R, M, N):
     """``fused.atb_rows`` with a gate flagged 0 / 1: the ungated product over the masked-in rows (bf16x6) + the one-column

@@ -66,3 +66,16 @@ def test_stale_library_after_a_failed_build_is_refused(monkeypatch):
     monkeypatch.delenv("DMP_ALLOW_STALE_LIB", raising=False)
     monkeypatch.setattr(_build, "_stale", lambda: False)
     assert _lib.load() is not None
+
+
+def test_launch_timer_leaves_out_stalled_launches_only():
+    """``_lib.uninterrupted`` (the per-launch timer behind bench.py's roofline objects): a launch stalled by the box (20 ms among
+    27 us ones) is left out; a kernel's own spread -- twice, five times the median, or 10x a sub-100-us median without the extra
+    millisecond -- is not."""
+    from dualmessagepassing_amd import _lib
+    base = [0.027] * 30 + [0.031] * 29
+    assert _lib.uninterrupted(base + [20.4]) == base
+    assert _lib.uninterrupted(base + [0.135]) == base + [0.135]
+    assert _lib.uninterrupted(base + [0.9]) == base + [0.9]          # > 10x the median but < 1 ms above it: kept
+    assert _lib.uninterrupted([5.0, 5.0, 49.0]) == [5.0, 5.0, 49.0]  # < 10x
+    assert _lib.uninterrupted([3.0]) == [3.0]
