@@ -462,6 +462,11 @@ def joint_rep(model, pattern, graph, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate=
     if l0 is not None:        # the first layer works on the label codes: its [E, H] input rows are only its residual term
         from . import fused
         # ... which the layer reads over the kept edges' / nodes' tiles only: the rows under a zero of a 0 / 1 gate are not even stored
+        # (the degree coefficients the test below asks about: memoised, the layers ask for the same -- made here when the
+        # prefetch did not, so that a step without the side stream takes the same launches as one with it)
+        if OUTDEGREE not in union.ndata:
+            union.ndata[OUTDEGREE] = union.out_degrees()
+        union.index().degree_coef(union.ndata[OUTDEGREE])
         live_e, live_v = fused.l0_dead_inputs(union.index(), layers[0].hidden_dim, *_joint_gates(v_gate, e_gate, np_, ep_, p_e_emb.dtype, p_e_emb.device),
                                               l0)
         l0.z_from_codes = fused.l0_z_from_codes(union.index(), layers[0].hidden_dim, _joint_gates(v_gate, e_gate, np_, ep_, p_e_emb.dtype, p_e_emb.device)[1],

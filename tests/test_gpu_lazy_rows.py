@@ -43,13 +43,15 @@ def test_pooled_heads_without_edge_rows_equal_the_eager_form(hid, gpu):
         calls = []
         # the E-row Linear + gate + residual launches: the one-panel kernel, or (inner layers under a 0 / 1 gate) its form
         # over the kept edges' tiles
-        orig, orig_t = fused.out_fwd_mfma, fused.out_fwd_typed
+        # (... which for a first layer on the label codes also forms the residual rows: out_fwd_typed_codes)
+        orig, orig_t, orig_c = fused.out_fwd_mfma, fused.out_fwd_typed, fused.out_fwd_typed_codes
         fused.out_fwd_mfma = lambda *a, **k: (calls.append(a[0].size(0)), orig(*a, **k))[1]
         fused.out_fwd_typed = lambda *a, **k: (calls.append(a[0].size(0)), orig_t(*a, **k))[1]
+        fused.out_fwd_typed_codes = lambda *a, **k: (calls.append(a[0].size(0)), orig_c(*a, **k))[1]
         try:
             out = model(*graphs())
         finally:
-            fused.out_fwd_mfma, fused.out_fwd_typed = orig, orig_t
+            fused.out_fwd_mfma, fused.out_fwd_typed, fused.out_fwd_typed_codes = orig, orig_t, orig_c
         raw = dict.__getitem__(out, "g_e_rep")
         assert isinstance(raw, DeferredRows) == lazy
         edge_rows = raw.size(0) + dict.__getitem__(out, "p_e_rep").size(0)
