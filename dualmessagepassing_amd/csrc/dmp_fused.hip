@@ -405,21 +405,21 @@ template <int VW> __device__ __forceinline__ void lane_store(float *row, int lan
   else row[lane] = o.v[0];
 }
 
+// (nbx: the workgroups of this product -- gridDim.x, or fewer when several products of different lengths share a launch)
 template <int K, int VW>
-__global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
+__device__ __forceinline__ void smallk_atb_body(const SmallKArgs &p, const unsigned nbx, float *red) {
   constexpr int WPB = kBlock / 64, kRows = kSmallRows, H = 64 * VW;
-  __shared__ float red[kBlock * VW];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int colblk = blockIdx.y;                            // one launch for several column blocks of the upstream gradient
   const float *Dj = colblk < p.ncols ? p.D + (int64_t)colblk * H : p.D2;
   const int64_t ldj = colblk < p.ncols ? p.ldd : p.ldd2;
-  float *partial = p.partial + (int64_t)colblk * gridDim.x * K * H;
+  float *partial = p.partial + (int64_t)colblk * nbx * K * H;
   LaneVec<VW> acc[K];
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int c = 0; c < VW; ++c) acc[k].v[c] = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * WPB * kRows;
+  const int64_t stride = (int64_t)nbx * WPB * kRows;
   // lanes 0..K-1 fetch a row's inputs, lane K its gate (one load each); the values are read back lane by lane
   // into wave-uniform operands (v_readlane: no memory traffic, no LDS).  The next batch's loads are issued
   // before the current batch's FMAs.
@@ -488,6 +488,24 @@ __global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
   }
 }
 
+template <int K, int VW>
+__global__ __launch_bounds__(kBlock) void smallk_atb_k(const SmallKArgs p) {
+  __shared__ float red[kBlock * VW];
+  smallk_atb_body<K, VW>(p, gridDim.x, red);
+}
+
+// Several such products of the same K and H in ONE launch (blockIdx.z = the product; one column block each): the first layer's
+// node-code weight gradients -- two tables x two halves of the code sums, 5-12 us apiece as launches of their own.
+constexpr int kSmallKJobs = 4;
+struct SmallKJobs { SmallKArgs job[kSmallKJobs]; unsigned nb[kSmallKJobs]; };
+template <int K, int VW>
+__global__ __launch_bounds__(kBlock) void smallk_atb_jobs_k(const SmallKJobs js) {
+  __shared__ float red[kBlock * VW];
+  const unsigned nbx = js.nb[blockIdx.z];
+  if (blockIdx.x >= nbx) return;
+  smallk_atb_body<K, VW>(js.job[blockIdx.z], nbx, red);
+}
+
 // The forward of the same narrow layer with its gate:  out[r, :] = gate[r] * sum_k X[r, k] W[k, :]  -- the gated
 // embedding rows written straight into their place (the union buffer of the joint rep-net pass) from the K
 // inputs per row instead of from the [R, H] embedding.  W lives in registers (H / 64 values per lane and input).
@@ -554,6 +572,13 @@ void launch_smallk(const SmallKArgs &p, int H, hipStream_t st) {
   const dim3 grid(smallk_blocks(p.R), (unsigned)(p.ncols + (p.D2 ? 1 : 0)));
   if (H == 128) smallk_atb_k<K, 2><<<grid, kBlock, 0, st>>>(p);
   else smallk_atb_k<K, 1><<<grid, kBlock, 0, st>>>(p);
+}
+
+template <int K>
+static void launch_smallk_jobs(const SmallKJobs &js, unsigned nbmax, int n, int H, hipStream_t st) {
+  const dim3 grid(nbmax, 1u, (unsigned)n);
+  if (H == 128) smallk_atb_jobs_k<K, 2><<<grid, kBlock, 0, st>>>(js);
+  else smallk_atb_jobs_k<K, 1><<<grid, kBlock, 0, st>>>(js);
 }
 
 inline int group_lanes(int H) { return H <= 64 ? 16 : (H <= 128 ? 32 : 64); }
@@ -814,6 +839,42 @@ int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *
                                int64_t ldd2, const float *gate, const uint32_t *rowmask, int64_t R, int H, float *partial,
                                void *stream) {
   return smallk_atb_cols_impl(X, ldx, K, D, ldd, ncols, D2, ldd2, gate, rowmask, nullptr, nullptr, R, H, partial, stream);
+}
+
+int dmp_smallk_atb_jobs(const dmp_smallk_job *jobs, int num_jobs, int K, int H, void *stream) {
+  DMP_ROW_CHECK(jobs && num_jobs >= 1 && num_jobs <= kSmallKJobs && K > 0);
+  if ((H != 128 && H != 64) || K > kSmallK) return DMP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  SmallKJobs js{};
+  unsigned nbmax = 0;
+  int n = 0;
+  for (int j = 0; j < num_jobs; ++j) {
+    const dmp_smallk_job &q = jobs[j];
+    DMP_ROW_CHECK(q.R >= 0 && q.partial);
+    if (!ok16(q.partial)) return DMP_ERR_UNSUPPORTED;
+    if (q.R == 0) {    // an empty product: its one partial row block is zeros
+      if (hipMemsetAsync(q.partial, 0, sizeof(float) * (size_t)K * H, st) != hipSuccess) return DMP_ERR_HIP;
+      continue;
+    }
+    DMP_ROW_CHECK(q.X && q.D && q.ldx >= K && q.ldd >= H);
+    if (q.ldd % 2 || (reinterpret_cast<uintptr_t>(q.D) & 7u)) return DMP_ERR_UNSUPPORTED;
+    js.job[n] = SmallKArgs{q.X, q.ldx, K, q.D, q.ldd, q.gate, q.R, q.partial, 1, nullptr, 0, q.rowmask, nullptr, nullptr};
+    js.nb[n] = smallk_blocks(q.R);
+    nbmax = js.nb[n] > nbmax ? js.nb[n] : nbmax;
+    ++n;
+  }
+  if (n == 0) return DMP_OK;
+  switch (K) {
+    case 1: launch_smallk_jobs<1>(js, nbmax, n, H, st); break;   case 2: launch_smallk_jobs<2>(js, nbmax, n, H, st); break;
+    case 3: launch_smallk_jobs<3>(js, nbmax, n, H, st); break;   case 4: launch_smallk_jobs<4>(js, nbmax, n, H, st); break;
+    case 5: launch_smallk_jobs<5>(js, nbmax, n, H, st); break;   case 6: launch_smallk_jobs<6>(js, nbmax, n, H, st); break;
+    case 7: launch_smallk_jobs<7>(js, nbmax, n, H, st); break;   case 8: launch_smallk_jobs<8>(js, nbmax, n, H, st); break;
+    case 9: launch_smallk_jobs<9>(js, nbmax, n, H, st); break;   case 10: launch_smallk_jobs<10>(js, nbmax, n, H, st); break;
+    case 11: launch_smallk_jobs<11>(js, nbmax, n, H, st); break; case 12: launch_smallk_jobs<12>(js, nbmax, n, H, st); break;
+    case 13: launch_smallk_jobs<13>(js, nbmax, n, H, st); break; case 14: launch_smallk_jobs<14>(js, nbmax, n, H, st); break;
+    case 15: launch_smallk_jobs<15>(js, nbmax, n, H, st); break; default: launch_smallk_jobs<16>(js, nbmax, n, H, st); break;
+  }
+  return check_launch();
 }
 
 int dmp_smallk_atb_cols_rows(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,

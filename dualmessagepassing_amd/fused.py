@@ -1074,6 +1074,38 @@ def smallk_atb_cols(x, d, d2=None, out=None, H=None, mask=None, rows=None):
     return out
 
 
+_SMALLK_JOB = None
+USE_SMALLK_JOBS = _os.environ.get("DMP_DEV_SMALLK_JOBS", "1") == "1"
+
+
+def smallk_atb_jobs(jobs, H):
+    """Several ``smallk_atb`` products of the same K and H in ONE launch (``dmp_smallk_atb_jobs``): ``jobs`` = up to four
+    ``(x [R, K], d [R, H], out [K, H], mask or None)`` (``mask``: ``gate_row_mask`` words aligned to the job's first row).  The
+    sums land in each job's ``out``."""
+    global _SMALLK_JOB
+    lib = _lib.load()
+    if _SMALLK_JOB is None:
+        P, I64 = _ctypes.c_void_p, _ctypes.c_int64
+        _SMALLK_JOB = type("dmp_smallk_job", (_ctypes.Structure,), {"_fields_": [
+            ("X", P), ("ldx", I64), ("D", P), ("ldd", I64), ("gate", P), ("rowmask", P), ("R", I64), ("partial", P)]})
+    K = jobs[0][0].size(1)
+    J = (_SMALLK_JOB * len(jobs))()
+    parts = []
+    for n, (x, d, out, mask) in enumerate(jobs):
+        R = x.size(0)
+        _lib.require_gpu(x, d, out, mask)
+        if x.size(1) != K or d.size(0) != R or d.size(1) != H or tuple(out.shape) != (K, H) or not out.is_contiguous():
+            raise _lib.DmpError("smallk_atb_jobs: shapes of job %d" % n)
+        part = torch.empty((int(lib.dmp_smallk_atb_blocks(R)), K * H), dtype=torch.float32, device=d.device)
+        J[n].X, J[n].ldx, J[n].D, J[n].ldd = (x.data_ptr() if R else None), x.stride(0) if R > 1 else max(K, x.stride(0)), (d.data_ptr() if R else None), d.stride(0) if R > 1 else max(H, d.stride(0))
+        J[n].gate, J[n].rowmask, J[n].R, J[n].partial = None, ptr(mask), R, part.data_ptr()
+        parts.append(part)
+    with _lib.timed("smallk_atb_jobs[K=%d,R=%d]", (K, sum(j[0].size(0) for j in jobs)), sum(4 * (H + K + 1) * j[0].size(0) for j in jobs)):
+        check(lib.dmp_smallk_atb_jobs(J, len(jobs), K, H, stream_ptr()), "dmp_smallk_atb_jobs")
+    for part, (_, _, out, _) in zip(parts, jobs):
+        reduce_partials(part, out.view(-1))
+
+
 # ---- the first layer of a rep-net straight from the label codes (csrc/dmp_layer0.hip)
 L0_KMAX = 16
 # the joint rep-net pass hands the first layer the packed label codes instead of differentiable [E, H] rows
@@ -2138,7 +2170,12 @@ class _FusedDMPLayer(torch.autograd.Function):
                 # dBn_h = W0^T X[h] and the segment sums' part of the embedding gradient, sum_h X[h] Bn_h^T (no dS either)
                 Kp, S0 = l0.enc.size(1), ctx.l0_S0
                 Xn = (torch.empty if full else torch.zeros)((2, TK, H), dtype=torch.float32, device=dPn.device)
-                for t, _, (n0, n1) in tables:
+                xjobs = [(S0[n0:n1, h * Kp:h * Kp + K0], dPn[n0:n1], Xn[h, t * K0:(t + 1) * K0],
+                          nd.mask[n0 // 32:] if nd is not None else None) for t, _, (n0, n1) in tables if n1 > n0 for h in (0, 1)]
+                if USE_SMALLK_JOBS and 0 < len(xjobs) <= 4 and dPn.stride(1) == 1 and dPn.stride(0) % 2 == 0 and dPn.data_ptr() % 8 == 0:
+                    smallk_atb_jobs(xjobs, H)          # both tables x both halves: one launch
+                    xjobs = []
+                for t, _, (n0, n1) in (tables if xjobs else []):
                     if n1 > n0:
                         for h in (0, 1):
                             if nd is not None:     # (dPn's rows of the dead nodes were not written: masked out)

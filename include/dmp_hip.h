@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 79
+#define DMP_ABI_VERSION 80
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -656,6 +656,19 @@ int dmp_smallk_atb_cols_masked(const float *X, int64_t ldx, int K, const float *
  * then four LIVE rows -- the masked form spends a batch's slots on its dead rows too (three of five at the benchmark's node gate). */
 int dmp_smallk_atb_cols_rows(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, int ncols, const float *D2,
                              int64_t ldd2, const int32_t *list, const int32_t *count, int64_t R, int H, float *partial, void *stream);
+/* Several of these products -- same K and H, one column block each, with a gate and / or a row mask or neither -- in ONE launch
+ * (num_jobs <= 4).  The first layer's node side on the label codes needs S0_h^T dPn for both halves h of the code sums and both
+ * embedding tables (dmpnn.py:92,163 re-associated: DESIGN 3): four launches of 5-12 us as one.
+ * job.partial: [dmp_smallk_atb_blocks(job.R), K*H] (an empty job: one zero block); finish each with dmp_reduce_partials. */
+typedef struct {
+  const float *X; int64_t ldx;           /* [R, ldx >= K] */
+  const float *D; int64_t ldd;           /* [R, ldd >= H] */
+  const float *gate;                     /* [R] or NULL */
+  const uint32_t *rowmask;               /* dmp_row_mask_bits words (bit 0 = the job's first row) or NULL */
+  int64_t R;
+  float *partial;
+} dmp_smallk_job;
+int dmp_smallk_atb_jobs(const dmp_smallk_job *jobs, int num_jobs, int K, int H, void *stream);
 int64_t dmp_smallk_atb_blocks(int64_t rows);
 int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t ldd, const float *gate,
                    int64_t rows, int H, float *partial, void *stream);

@@ -318,3 +318,33 @@ def test_smallk_atb_over_a_row_list_equals_the_masked_form(R, K, h, blocks, gpu)
     tol = 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool(th.isfinite(a).all()) and bool(th.isfinite(b).all())
     assert float((a.double() - ref).abs().max()) <= tol and float((b.double() - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("sizes,K,h", [((1200, 73728 - 1216), 10, 128), ((0, 5000), 7, 128), ((96, 64, 4097, 32), 16, 64), ((33,), 3, 128)])
+def test_smallk_atb_products_sharing_a_launch_equal_their_own_launches(sizes, K, h, gpu):
+    """``dmp_smallk_atb_jobs`` (the first layer's node-code weight gradients: two tables x two halves of the code sums as ONE
+    launch) against the single launches it replaces -- the same kernel body over the same workgroup count per product: equal
+    bits; masked rows are not fetched (NaN there); an empty product gives zeros."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(sum(sizes) + K)
+    jobs, refs = [], []
+    for n, R in enumerate(sizes):
+        R32 = (R + 31) // 32 * 32
+        keep = (th.rand(R, generator=gen) < 0.4).to(gpu)
+        x = (th.rand(R, 2 * 16, generator=gen) < 0.5).float().to(gpu)[:, 16 * (n & 1):16 * (n & 1) + K] * keep.view(-1, 1).float()
+        d = th.randn(R, h, generator=gen).to(gpu)
+        masked = bool(n & 1) or len(sizes) == 1
+        mask = None
+        if masked:
+            d[~keep] = float("nan")
+            mask = fused.gate_row_mask(th.cat([keep.float(), th.zeros(R32 - R, device=gpu)]))
+        out = th.full((K, h), -3.0, device=gpu)
+        jobs.append((x, d, out, mask))
+        if R:
+            refs.append(fused.smallk_atb_cols(x, d, None, None, h, mask=mask)[0])
+        else:
+            refs.append(th.zeros(K, h, device=gpu))
+    fused.smallk_atb_jobs(jobs, h)
+    for (x, d, out, mask), ref in zip(jobs, refs):
+        assert bool(th.isfinite(out).all())
+        assert th.equal(out, ref)
