@@ -811,6 +811,7 @@ def l0_rows(l0, W0, z):
     return out
 
 
+USE_OUT_CODES_DENSE = _os.environ.get("DMP_DEV_OUT_CODES_DENSE", "1") == "1"   # ... also without a gate (over the identity tile list)
 USE_OUT_CODES = _os.environ.get("DMP_DEV_OUT_CODES", "1") == "1"   # the first layer's residual rows z0 = codes W_e as a K-extension of its second Linear
 
 
@@ -1956,6 +1957,11 @@ class _FusedDMPLayer(torch.autograd.Function):
                     zn = out_fwd_typed_codes(H1e, eW2t, eb2, l0.enc, l0.K, W0[-l0.K:], tl_, prev=l0.z_head, row0=l0.z_head.size(0))
                 else:
                     zn = out_fwd_typed(H1e, eW2t, eb2, l0_rows(l0, W0, z) if residual else None, tl_)
+            elif (l0 is not None and residual and e_gate is None and getattr(l0, "z_from_codes", False) and eW2t is not None and USE_TYPED_ROWS
+                  and out_codes_ok(H1e, l0.enc, l0.K, W0[-l0.K:]) and identity_tiles(H1e.size(0), H1e.device) is not None):
+                # no gate at all (the all-rows step): the same launch over the identity tile list
+                zn = out_fwd_typed_codes(H1e, eW2t, eb2, l0.enc, l0.K, W0[-l0.K:], identity_tiles(H1e.size(0), H1e.device), prev=l0.z_head,
+                                         row0=l0.z_head.size(0))
             else:
                 zn = out_fwd_mfma(H1e, eW2, eb2, e_gate, l0_rows(l0, W0, z) if residual else None, eW2t, dead_rows=dead)
         ctx.index, ctx.coef, ctx.residual, ctx.H = index, coef, residual, H
@@ -2316,9 +2322,9 @@ class _FusedDMPLayer(torch.autograd.Function):
 def l0_z_from_codes(index, H, eg, l0, live_edges, residual):
     """May ``dmpnn.joint_rep`` leave the target's part of the first layer's edge rows ``z = enc W`` out of memory altogether?  With
     a residual layer and the conditions under which its second Linear runs over the kept edges' tiles (``l0_dead_inputs``' edge
-    half), that launch adds ``enc W`` as one more k-group (``out_fwd_typed_codes``).  (A layer that ends up elsewhere makes the
-    rows itself: ``l0_rows``.)"""
-    return bool(USE_OUT_CODES and live_edges and residual and l0 is not None and H == 128
+    half) -- or without any edge gate, over all rows -- that launch adds ``enc W`` as one more k-group (``out_fwd_typed_codes``).
+    (A layer that ends up elsewhere makes the rows itself: ``l0_rows``.)"""
+    return bool(USE_OUT_CODES and (live_edges or (eg is None and USE_OUT_CODES_DENSE and USE_TYPED_ROWS)) and residual and l0 is not None and H == 128
                 and not _lib.load().dmp_dev_get_exact_fp32() and l0.enc.stride(0) % 4 == 0 and l0.enc.data_ptr() % 16 == 0
                 and index.num_edges * 128 * 4 < (1 << 32) - 65536)
 

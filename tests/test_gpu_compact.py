@@ -444,8 +444,10 @@ def test_zero_gate_skipping_leaves_every_output_and_gradient_as_it_was(lazy):
             assert float((a - b).abs().max()) <= 5e-5 * s, (off, float((a - b).abs().max()), s)
 
 
-def test_first_layer_residual_rows_from_their_codes_leave_the_model_as_it_was():
-    """``fused.out_fwd_typed_codes`` in the model: the joint pass does not store the target's embedded edge rows (its placeholder is
+@pytest.mark.parametrize("filt", ["ScalarFilter", "None"])
+def test_first_layer_residual_rows_from_their_codes_leave_the_model_as_it_was(filt):
+    """``fused.out_fwd_typed_codes`` in the model (under the ScalarFilter gates: over the kept edges' tiles; without a filter net:
+    over all rows): the joint pass does not store the target's embedded edge rows (its placeholder is
     poisoned with NaN here), the first layer's second Linear forms the kept ones from the label codes -- against the same model with
     the rows stored (``USE_OUT_CODES`` off): every output and gradient equal to fp32 accuracy; and a first layer that cannot take
     that launch (``out_codes_ok`` forced false) makes the rows itself (``l0_rows``) with the same result."""
@@ -453,7 +455,7 @@ def test_first_layer_residual_rows_from_their_codes_leave_the_model_as_it_was():
     gpu = th.device("cuda:0")
     sys.path.insert(0, ROOT)
     import bench
-    cfg = dict(bench.CFG, batch=96)
+    cfg = dict(bench.CFG, batch=96, filter=filt)
     bench_, shard, step, model = _model_and_batch(cfg, gpu)
     fused.USE_OUT_CODES = False
     try:
