@@ -919,7 +919,7 @@ class GraphAdjModelV2(BaseModel):
         pooled = all(h is None or h.poolable() for h in self.pred_net.values())
 
         def prefetch():
-            if hasattr(self, "get_joint_rep") and not self.gate_capacity and vl_gate is not None and el_gate is not None:
+            if hasattr(self, "get_joint_rep") and not self.gate_capacity and (vl_gate is None) == (el_gate is None):
                 # the index arrays the joint pass derives from the structure and the gates alone: on the side stream from here on,
                 # beside the encoding / embedding kernels and the first layer's node side (side.py)
                 from .dmpnn import prefetch_joint_indexes

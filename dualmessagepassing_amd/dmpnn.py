@@ -361,6 +361,10 @@ def _joint_gates(v_gate, e_gate, np_, ep_, dtype, device):
     return vg, eg
 
 
+import os as _os
+PREFETCH_UNGATED = _os.environ.get("DMP_DEV_PREFETCH_UNGATED", "1") == "1"   # the side-stream index branch also without gates
+
+
 def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(), skip_rev=True):
     """Everything ``joint_rep`` and its layers derive from the batch's STRUCTURE and its two filter gates alone, issued on the
     side stream (``side.fork``) as soon as the gates exist: the union graph and its CSR index, the degree coefficients, the
@@ -373,7 +377,7 @@ def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(),
     from . import fused, side
     if not side.USE_SIDE_STREAM or not getattr(model, "use_fused", True) or not hasattr(model, "g_rep_net"):
         return
-    if model.p_rep_net is not model.g_rep_net or v_gate is None or e_gate is None or not e_gate.is_cuda:
+    if model.p_rep_net is not model.g_rep_net or (v_gate is None) != (e_gate is None) or (e_gate is not None and not e_gate.is_cuda):
         return
     layers = list(model.g_rep_net[model.rep_key])
     if not layers or not all(hasattr(l, "fused_ok") for l in layers):
@@ -384,6 +388,32 @@ def prefetch_joint_indexes(model, pattern, graph, v_gate, e_gate, pool_kinds=(),
     H = layers[0].hidden_dim
     np_, ep_ = pattern.number_of_nodes(), pattern.number_of_edges()
     side.join()              # (a step that never joined -- an exception on the way: nothing of it may stay dangling)
+    if e_gate is None:
+        # no filter net (the all-rows step): what is left is the structure itself -- the union's CSR, the coefficients and
+        # selectors, the degree-class tiles of the typed kernels, the pooling indexes
+        if not PREFETCH_UNGATED:
+            return
+        with side.fork() as forked:
+            if not forked:
+                return
+            union = _union_of(pattern, graph)
+            ix = union.index()
+            if OUTDEGREE not in union.ndata:
+                union.ndata[OUTDEGREE] = union.out_degrees()
+            coef = ix.degree_coef(union.ndata[OUTDEGREE])
+            if fused.mfma_ok(ix, H):
+                ix.edge_select(coef)
+            side.mark("index")
+            side.mark("nodes")
+            side.mark("erows")
+            if fused.typed_ok(ix, H):
+                ix.class_tiles(coef)
+            side.mark("tiles")
+            if pool_kinds:
+                from .basemodel import _pool_indexes_union
+                _pool_indexes_union(pattern, graph, pool_kinds, skip_rev)
+            side.mark("pools")
+        return
     with side.fork() as forked:
         if not forked:
             return

@@ -3,7 +3,7 @@
 #   usage: quick_bench.sh <tag> ["ENV=.. ENV2=.." ...]
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/$TAG && mkdir -p $O
-Q="--graph --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 100"
+Q="--graph --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 100 $QB_EXTRA"   # QB_EXTRA: e.g. "--filter-net None"
 i=0
 for e in "" "$@"; do
   env $e timeout 300 python3 $R/bench.py $Q > $O/line_$i.json 2> $O/err_$i.txt
@@ -18,7 +18,7 @@ except Exception as ex:
 PY
   i=$((i+1))
 done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o t -- python3 $R/bench.py --graph --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 0 > $O/prof_line.json 2> $O/prof_err.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o t -- python3 $R/bench.py --graph --no-cpu-baseline --no-all-outputs --no-gate-compact --no-gate-dense --extended-steps 0 $QB_EXTRA > $O/prof_line.json 2> $O/prof_err.txt
 python3 $R/scripts/step_timeline.py $O/p/t_kernel_trace.csv > $O/timeline.txt 2>&1
 python3 $R/scripts/show_stats.py $O/p/t_kernel_stats.csv > $O/stats.txt 2>&1
 rm -f $O/p/*trace*

@@ -15,20 +15,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(gpu, batch=96):
+def _setup(gpu, batch=96, filt="ScalarFilter"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_compact import _model_and_batch, _outputs_and_grads
     sys.path.insert(0, ROOT)
     import bench
-    cfg = dict(bench.CFG, batch=batch)
+    cfg = dict(bench.CFG, batch=batch, filter=filt)
     bench_, shard, step, model = _model_and_batch(cfg, gpu)
     return bench_, cfg, shard, step, model, _outputs_and_grads
 
 
-@pytest.mark.parametrize("lazy", [True, False])
-def test_step_with_the_side_stream_equals_the_one_stream_step_bit_for_bit(lazy, gpu):
+@pytest.mark.parametrize("lazy,filt", [(True, "ScalarFilter"), (False, "ScalarFilter"), (True, "None")])
+def test_step_with_the_side_stream_equals_the_one_stream_step_bit_for_bit(lazy, filt, gpu):
+    """(``filt`` "None": the model without a filter net -- the branch then carries the structure's own indexes only.)"""
     from dualmessagepassing_amd import dmpnn, side
-    bench_, cfg, shard, step, model, run = _setup(gpu)
+    bench_, cfg, shard, step, model, run = _setup(gpu, filt=filt)
     side.USE_SIDE_STREAM = False
     try:
         ref_out, ref_flat = run(bench_, cfg, shard, step, model, lazy)
