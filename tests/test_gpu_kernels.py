@@ -989,7 +989,8 @@ def test_activation_slope_outside_the_supported_range_is_refused(gpu):
             fused.add_bias_relu_(a.clone(), a, None, bad)
 
 
-@pytest.mark.parametrize("sizes_a,sizes_b", [([5, 0, 130, 64], [1, 300]), ([7] * 50, None), ([0, 0, 3], [0]), ([64] * 1024, [512] * 1024)])
+@pytest.mark.parametrize("sizes_a,sizes_b", [([5, 0, 130, 64], [1, 300]), ([7] * 50, None), ([0, 0, 3], [0]), ([64] * 1024, [512] * 1024),
+                                             ([3, 0, 70] * 1000, [2] * 1500)])      # (4500 graphs: three slices of the offsets scan)
 def test_pool_index_device_build_equals_tensor_build(sizes_a, sizes_b, gpu):
     """ops.PoolIndex built by dmp_pool_index (two launches, sizes / flags as two pieces) == the tensor-op construction:
     every array bit for bit, and the pooled sums it produces."""
