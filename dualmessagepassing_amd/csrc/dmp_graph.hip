@@ -1450,6 +1450,27 @@ struct LookupJobs {
 };
 __global__ __launch_bounds__(kBlock) void table_rows_k(const LookupJobs t) {
   const dmp_lookup_job &j = t.job[blockIdx.y];
+  if (j.width <= 32) {
+    // narrow rows (the multi-hot codes: 8-14 floats): a thread per ROW -- one index load, no 64-bit division per element, a wave
+    // writes 64 consecutive rows; pairs of floats where the row starts allow it
+    const bool pairs = !(j.width & 1) && !(j.ld & 1) && !(reinterpret_cast<uintptr_t>(j.table) & 7u) && !(reinterpret_cast<uintptr_t>(j.out) & 7u);
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < j.rows; r += (int64_t)gridDim.x * kBlock) {
+      const int64_t id = j.idx[r];
+      const bool ok = id >= 0 && id < j.table_rows;
+      const float *src = j.table + (ok ? id : 0) * j.ld;
+      float *dst = j.out + r * j.width;
+      if (pairs) {
+        for (int c = 0; c < j.width; c += 2) {
+          float2 v = *reinterpret_cast<const float2 *>(src + c);
+          if (!ok) v = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+          *reinterpret_cast<float2 *>(dst + c) = v;
+        }
+      } else {
+        for (int c = 0; c < j.width; ++c) dst[c] = ok ? src[c] : __builtin_nanf("");
+      }
+    }
+    return;
+  }
   const int64_t total = j.rows * j.width;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int64_t r = i / j.width;
@@ -1934,7 +1955,8 @@ int dmp_table_rows(const dmp_lookup_job *jobs, int num_jobs, void *stream) {
     if (j.rows < 0 || j.width < 1 || j.table_rows < 0 || j.ld < j.width) return DMP_ERR_BAD_ARG;
     if (j.rows > 0 && (!j.table || !j.idx || !j.out)) return DMP_ERR_BAD_ARG;
     t.job[i] = j;
-    if (j.rows * j.width > most) most = j.rows * j.width;
+    const int64_t units = j.width <= 32 ? j.rows : j.rows * j.width;      // threads of work: a row each where rows are narrow
+    if (units > most) most = units;
   }
   if (most == 0) return DMP_OK;
   int64_t nb = (most + kBlock - 1) / kBlock;

@@ -312,10 +312,10 @@ def test_table_lookups_match_embedding_modules(gpu):
     from dualmessagepassing_amd.embed import MultihotEmbedding, PositionEmbedding, NormalEmbedding, lookup_rows
     g = th.Generator().manual_seed(5)
     nets = [MultihotEmbedding(64, 2).cuda(), MultihotEmbedding(16, 2).cuda(), PositionEmbedding(10, 32).cuda(),
-            MultihotEmbedding(300, 2).cuda()]
-    for n in nets:
+            MultihotEmbedding(300, 2).cuda(), PositionEmbedding(40, 20).cuda(), th.nn.Embedding(11, 7).cuda()]
+    for n in nets:             # (narrow rows: a thread per row, in pairs or -- odd widths -- float by float; 40 columns: a thread per element)
         n.weight.requires_grad = False
-    ids = [th.randint(0, n.weight.size(0), (rows,), generator=g).cuda() for n, rows in zip(nets, (70001, 1, 0, 513))]
+    ids = [th.randint(0, n.weight.size(0), (rows,), generator=g).cuda() for n, rows in zip(nets, (70001, 1, 0, 513, 3000, 2049))]
     got = lookup_rows(nets, ids)
     for n, i, o in zip(nets, ids, got):
         assert o.shape == (i.numel(), n.weight.size(1)) and th.equal(o, n(i))
