@@ -79,15 +79,25 @@ struct PackArgs {
   int K, Kpad, goff; float *out;
 };
 
+// A thread per ROW (its gate once, its <= 16 codes, 16-byte stores: Kpad % 4 == 0 and `out` comes 16-byte aligned from the host side).
 __global__ __launch_bounds__(kBlock) void l0_pack_k(const PackArgs p) {
-  const int64_t total = (p.n + p.rows_g) * p.Kpad;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    const int64_t r = i / p.Kpad;
-    const int c = (int)(i - r * p.Kpad);
-    float v = 0.f;
-    if (r < p.n) { if (c < p.K) v = p.encp[r * p.ldp + c]; }
-    else if (c >= p.goff && c < p.goff + p.K) { v = p.encg[(r - p.n) * p.ldg + c - p.goff]; if (p.gate) v *= p.gate[r - p.n]; }
-    p.out[i] = v;
+  const int64_t rows = p.n + p.rows_g;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock) {
+    const bool pat = r < p.n;
+    const float *src = pat ? p.encp + r * p.ldp : p.encg + (r - p.n) * p.ldg;
+    const int c0 = pat ? 0 : p.goff;                       // the row's codes sit in columns c0 .. c0 + K - 1
+    const float g = (!pat && p.gate) ? p.gate[r - p.n] : 1.f;
+    float *dst = p.out + r * p.Kpad;
+    for (int c = 0; c < p.Kpad; c += 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = c + u - c0;
+        v[u] = (k >= 0 && k < p.K) ? src[k] : 0.f;
+        if (!pat && p.gate) v[u] *= g;
+      }
+      *reinterpret_cast<float4 *>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 
@@ -535,8 +545,9 @@ int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *en
                 int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream) {
   if (rows_p < 0 || rows_g < 0 || K <= 0 || goff < 0 || Kpad < goff + K || !out) return DMP_ERR_BAD_ARG;
   if ((rows_p > 0 && (!enc_p || ldp < K)) || (rows_g > 0 && (!enc_g || ldg < K))) return DMP_ERR_BAD_ARG;
-  const int64_t total = (rows_p + rows_g) * Kpad;
+  const int64_t total = rows_p + rows_g;                 // a thread per row
   if (total == 0) return DMP_OK;
+  if (Kpad % 4 || (reinterpret_cast<uintptr_t>(out) & 15u)) return DMP_ERR_UNSUPPORTED;
   const int64_t nb = (total + kBlock - 1) / kBlock;
   PackArgs p{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, goff, out};
   l0_pack_k<<<(unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, (hipStream_t)stream>>>(p);

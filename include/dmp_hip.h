@@ -679,7 +679,8 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
  *   dmp_l0_pack      out[r, 0:Kpad] = r < rows_p ? enc_p[r, 0:K] : gate[r - rows_p] * enc_g[r - rows_p, 0:K], zero-padded
  *                    (the union's edge rows: pattern rows first, then the gated target rows; gate may be NULL).  The target
  *                    rows' codes start at column goff: with goff = K the two kinds of rows occupy disjoint columns, so two
- *                    embedding tables stacked to [2K, H] act as one (Kpad >= goff + K).
+ *                    embedding tables stacked to [2K, H] act as one (Kpad >= goff + K; Kpad % 4 == 0 and `out` 16-byte aligned:
+ *                    the rows are stored in 16-byte pieces -- DMP_ERR_UNSUPPORTED otherwise).
  *   dmp_l0_edge_fwd_masked  out[r] = act(enc[r] MA + coef_e[r] (enc[r] MB) + P[sel_a[r], 0:H] - P[sel_b[r], H:2H] + bias)
  *                    with M = [MA | MB] = W [A | B]  ([K, ldm >= 2H]); replaces dmp_edge_fwd_typed for this layer.
  *   dmp_l0_bwd_w_masked     partial[b] = [enc^T dPre | (coef_e enc)^T dPre | enc^T dZn] over workgroup b's rows

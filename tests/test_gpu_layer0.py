@@ -348,3 +348,22 @@ def test_smallk_atb_products_sharing_a_launch_equal_their_own_launches(sizes, K,
     for (x, d, out, mask), ref in zip(jobs, refs):
         assert bool(th.isfinite(out).all())
         assert th.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,rows,K,stacked,gated", [(0, 1, 3, False, False), (1200, 70001, 10, False, True), (33, 4097, 8, True, True),
+                                                    (7, 0, 16, False, True), (500, 900, 5, True, False)])
+def test_packed_codes_are_the_gated_codes_in_their_columns(n, rows, K, stacked, gated, gpu):
+    """``dmp_l0_pack`` (a thread per row): ``[enc_p ; gate * enc_g]`` zero-padded to whole 16-byte pieces, the second kind of rows
+    in columns K .. 2K-1 when stacked -- against the tensor construction, bit for bit (also from wider, strided code arrays)."""
+    from dualmessagepassing_amd import fused
+    gen = th.Generator().manual_seed(n + rows + K)
+    wide_p, wide_g = th.randn(n, K + 3, generator=gen).to(gpu), th.randn(rows, K + 1, generator=gen).to(gpu)
+    enc_p, enc_g = wide_p[:, 1:K + 1], wide_g[:, :K]
+    gate = (th.rand(rows, generator=gen) < 0.5).float().to(gpu) * 1.5 if gated else None
+    got = fused.l0_pack(enc_p, enc_g, gate, stacked)
+    goff = K if stacked else 0
+    kpad = (goff + K + 3) // 4 * 4
+    ref = th.zeros(n + rows, kpad, device=gpu)
+    ref[:n, :K] = enc_p
+    ref[n:, goff:goff + K] = enc_g if gate is None else enc_g * gate.view(-1, 1)
+    assert got.shape == ref.shape and th.equal(got, ref)
