@@ -122,7 +122,7 @@ SIGNATURES = {
     "dmp_concat_pairs": (c_int, [c_ptr, c_int, c_ptr]),
     "dmp_table_rows": (c_int, [c_ptr, c_int, c_ptr]),
     "dmp_len_masks": (c_int, [c_ptr, c_int, c_i64, c_ptr]),
-    "dmp_pack_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
+    "dmp_pack_segments": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "dmp_adamw_step": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
                                c_double, c_i64, c_ptr]),
     "dmp_adamw_step_skip": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_double, c_double, c_double, c_double,
@@ -202,7 +202,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 80
+ABI_VERSION = 81
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

@@ -299,6 +299,7 @@ struct PackSegs {
   const float *src[DMP_PACK_MAX_SEGMENTS];
   int64_t off[DMP_PACK_MAX_SEGMENTS];
   int64_t len[DMP_PACK_MAX_SEGMENTS];
+  int pad;         // != 0: the floats between a segment's end and the next multiple of 4 are cleared too (a buffer laid out in 16-byte pieces)
 };
 
 // blockIdx.y = segment, blockIdx.x strides over it in float4 steps (scalar loads for unaligned sources and tails)
@@ -309,10 +310,13 @@ __global__ __launch_bounds__(kBlock) void pack_segments_kernel(const PackSegs a,
   const int64_t n = a.len[s];
   const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * kBlock * 4) {
-    if (vec && i + 4 <= n) {
+    if (!src) {                                               // a segment without a source: zeros (a parameter without a gradient)
+      if (i + 4 <= n || a.pad) *reinterpret_cast<float4 *>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      else for (int64_t j = i; j < n; ++j) out[j] = 0.f;
+    } else if (vec && i + 4 <= n) {
       *reinterpret_cast<float4 *>(out + i) = *reinterpret_cast<const float4 *>(src + i);
     } else {
-      for (int64_t j = i; j < n && j < i + 4; ++j) out[j] = src[j];
+      for (int64_t j = i; j < i + 4 && (j < n || a.pad); ++j) out[j] = j < n ? src[j] : 0.f;
     }
   }
 }
@@ -959,19 +963,20 @@ int dmp_reduce_partials_multi(const float *const *partials, const int64_t *S, co
   return check_launch();
 }
 
-int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, float *dst,
+int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, int pad_to_4, float *dst,
                       void *stream) {
   DMP_ROW_CHECK(n >= 0);
   if (n == 0) return DMP_OK;
   DMP_ROW_CHECK(src && dst_off && len && dst);
   if (!ok16(dst)) return DMP_ERR_UNSUPPORTED;
   for (int i = 0; i < n; ++i) {
-    DMP_ROW_CHECK(len[i] >= 0 && dst_off[i] >= 0 && (len[i] == 0 || src[i]));
+    DMP_ROW_CHECK(len[i] >= 0 && dst_off[i] >= 0);          // (src[i] == NULL: the segment is cleared)
     if (dst_off[i] % 4) return DMP_ERR_UNSUPPORTED;
   }
   for (int base = 0; base < n; base += DMP_PACK_MAX_SEGMENTS) {
     const int cnt = n - base < DMP_PACK_MAX_SEGMENTS ? n - base : DMP_PACK_MAX_SEGMENTS;
     PackSegs a;
+    a.pad = pad_to_4 ? 1 : 0;
     int64_t longest = 0;
     for (int i = 0; i < cnt; ++i) {
       a.src[i] = src[base + i]; a.off[i] = dst_off[base + i]; a.len[i] = len[base + i];

@@ -118,11 +118,12 @@ class FlatGradSync:
         if views is None:                                    # the slices never change: built once
             views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
             self._views = views
-        dst, src, which, missing, live = [], [], [], False, []
+        dst, src, which, missing, live, absent = [], [], [], False, [], []
         for i, (p, v) in enumerate(zip(self.params, views)):
             g = p.grad
             if g is None:
                 missing = True
+                absent.append(i)
             else:
                 live.append(i)
                 if g is not v:
@@ -130,6 +131,13 @@ class FlatGradSync:
                     src.append(g)
                     which.append(i)
             p.grad = v
+        hip = self.flat.is_cuda and self.flat.dtype == torch.float32 and all(g.dtype == torch.float32 for g in src)
+        if missing and hip and dst:
+            # ... cleared by the packing launch itself (segments without a source): no launch of its own, nothing to remember
+            self._zeroed_for = None
+            self._note_live(live)
+            self._pack_hip(src, which, absent)
+            return
         if missing:                                          # parameters without a gradient this step keep zeros:
             key = tuple(live)                                # their slices were zero before and nothing writes them, so the
             # buffer is cleared only when the set of live parameters changes.  Inside a stream capture the clearing is
@@ -145,7 +153,7 @@ class FlatGradSync:
         self._note_live(live if missing else None)
         if not dst:
             return
-        if self.flat.is_cuda and self.flat.dtype == torch.float32 and all(g.dtype == torch.float32 for g in src):
+        if hip:
             self._pack_hip(src, which)                       # one launch (csrc/dmp_fused.hip::pack_segments_kernel)
         else:
             torch._foreach_copy_(dst, src)
@@ -191,20 +199,21 @@ class FlatGradSync:
             cached = self._live_cache = (key, [(a, b) for a, b in runs])
         master._dmp_live_runs = cached[1]
 
-    def _pack_hip(self, src, which):
+    def _pack_hip(self, src, which, absent=()):
+        """``absent``: parameters without a gradient -- their slices are cleared by the same launch (sources NULL)."""
         import ctypes
         from . import _lib
         lib = _lib.load()
-        n = len(src)
-        key = tuple(which)
+        n = len(src) + len(absent)
+        key = (tuple(which), tuple(absent))
         cached = getattr(self, "_pack_tables", None)
         if cached is None or cached[0] != key:               # the slice table only changes with the set of gradients
-            offs = (ctypes.c_int64 * n)(*[self.offsets[i] for i in which])
-            lens = (ctypes.c_int64 * n)(*[self.params[i].numel() for i in which])
+            offs = (ctypes.c_int64 * n)(*[self.offsets[i] for i in list(which) + list(absent)])
+            lens = (ctypes.c_int64 * n)(*[self.params[i].numel() for i in list(which) + list(absent)])
             cached = self._pack_tables = (key, offs, lens)
         src = [g if g.is_contiguous() else g.contiguous() for g in src]
-        ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in src])
-        _lib.check(lib.dmp_pack_segments(ptrs, cached[1], cached[2], n, self.flat.data_ptr(), _lib.stream_ptr()),
+        ptrs = (ctypes.c_void_p * n)(*([g.data_ptr() for g in src] + [None] * len(absent)))
+        _lib.check(lib.dmp_pack_segments(ptrs, cached[1], cached[2], n, 1, self.flat.data_ptr(), _lib.stream_ptr()),
                    "dmp_pack_segments")
 
     def broadcast_parameters(self, src=0):

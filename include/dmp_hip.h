@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 80
+#define DMP_ABI_VERSION 81
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -909,10 +909,13 @@ int dmp_concat_pairs(const dmp_concat_job *jobs, int num_jobs, void *stream);
  * all-reduce work on ONE flat gradient; autograd hands back one tensor per parameter):
  *   dst[dst_off[i] : dst_off[i] + len[i]] = src[i][0 : len[i]]      i < n
  * src / dst_off / len are HOST arrays; every dst_off[i] a multiple of 4 and dst 16-byte aligned; the sources
- * need no alignment.  Any n (split over launches of DMP_PACK_MAX_SEGMENTS).
+ * need no alignment.  src[i] == NULL: the segment is CLEARED (a parameter that received no gradient this step: torch leaves
+ * its .grad None; the flat buffer holds zeros there) -- in the same launch, instead of clearing the whole buffer first.
+ * pad_to_4 != 0: the up-to-3 floats between a segment's end and the next multiple of 4 are cleared as well (for a buffer whose
+ * segments are laid out in 16-byte pieces, padding included: dp.FlatGradSync).  Any n (split over launches of DMP_PACK_MAX_SEGMENTS).
  */
-#define DMP_PACK_MAX_SEGMENTS 64
-int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, float *dst,
+#define DMP_PACK_MAX_SEGMENTS 128
+int dmp_pack_segments(const float *const *src, const int64_t *dst_off, const int64_t *len, int n, int pad_to_4, float *dst,
                       void *stream);
 
 /*

@@ -172,9 +172,9 @@ def test_flat_adamw_skips_parameters_without_gradient_like_torch(holes, gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("count", [1, 7, 64, 150])
+@pytest.mark.parametrize("count", [1, 7, 128, 300])
 def test_pack_segments_bit_exact(count, gpu):
-    """dmp_pack_segments (one launch per 64 arrays) against slice copies: ragged lengths incl. 0 and 1, sources that
+    """dmp_pack_segments (one launch per 128 arrays) against slice copies: ragged lengths incl. 0 and 1, sources that
     are not 16-byte aligned, more arrays than one launch takes."""
     import ctypes
     from dualmessagepassing_amd import _lib
@@ -200,10 +200,24 @@ def test_pack_segments_bit_exact(count, gpu):
         want[o:o + n] = s
     P = (ctypes.c_void_p * count)(*[s.data_ptr() if s.numel() else None for s in srcs])
     O, N = (ctypes.c_int64 * count)(*offs), (ctypes.c_int64 * count)(*lens)
-    _lib.check(lib.dmp_pack_segments(P, O, N, count, flat.data_ptr(), _lib.stream_ptr()), "dmp_pack_segments")
+    _lib.check(lib.dmp_pack_segments(P, O, N, count, 0, flat.data_ptr(), _lib.stream_ptr()), "dmp_pack_segments")
     assert th.equal(flat, want)
+    # segments WITHOUT a source are cleared (a parameter without a gradient), and with pad_to_4 so is every segment's padding up
+    # to the next 16-byte piece -- nothing else: the four floats behind the last segment keep their value
+    absent = [i for i in range(count) if i % 3 == 1]
+    for i in absent:
+        P[i] = None
+        want[offs[i]:offs[i] + lens[i]] = 0.0
+    flat.fill_(-7.0)
+    _lib.check(lib.dmp_pack_segments(P, O, N, count, 0, flat.data_ptr(), _lib.stream_ptr()), "dmp_pack_segments")
+    assert th.equal(flat, want)
+    for o, n in zip(offs, lens):
+        want[o + n:o + (n + 3) // 4 * 4] = 0.0
+    flat.fill_(-7.0)
+    _lib.check(lib.dmp_pack_segments(P, O, N, count, 1, flat.data_ptr(), _lib.stream_ptr()), "dmp_pack_segments")
+    assert th.equal(flat, want) and bool((flat[off:] == -7.0).all())
     O[0] = 2                                           # destination slices must start on 16-byte boundaries
-    assert lib.dmp_pack_segments(P, O, N, count, flat.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.dmp_pack_segments(P, O, N, count, 0, flat.data_ptr(), _lib.stream_ptr()) != 0
 
 
 @pytest.mark.gpu
