@@ -351,6 +351,37 @@ bool heads_valid(const dmp_head_weights *w, const dmp_head_io *io, int n, int B,
   return true;
 }
 
+// The count loss of a training step and its seed in ONE launch (train.py:624-628: bp_crit(leaky_relu(pred_c, slope), counts) with
+// reduction 'mean', then loss.backward()): around a thousand numbers, five torch launches (criterion, mean, two fills, the
+// criterion's backward).  One workgroup: loss[0] = mean_i crit(act(pred_i) - target_i), dpred[i] = d loss / d pred_i; fixed
+// summation order (thread-strided partial sums, a tree over the threads): the same bits on every launch.
+//   kind 0: MSE d^2      1: MAE |d|      2: smooth L1 (beta 1): d^2 / 2 inside |d| < 1, |d| - 1/2 outside
+constexpr int kLossThreads = 1024;
+__global__ __launch_bounds__(kLossThreads) void count_loss_k(const float *__restrict__ pred, const float *__restrict__ target, int64_t n,
+                                                             int kind, float slope, float *__restrict__ loss, float *__restrict__ dpred) {
+  __shared__ float red[kLossThreads];
+  const float inv_n = 1.f / (float)n;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kLossThreads) {
+    const float p = pred[i];
+    const float da = p > 0.f ? 1.f : slope;                  // leaky_relu'(p) (torch: the negative slope at p <= 0)
+    const float d = p * da - target[i];
+    float v, g;
+    if (kind == 0) { v = d * d; g = 2.f * d; }
+    else if (kind == 1) { v = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    else { const float a = fabsf(d); v = a < 1.f ? 0.5f * d * d : a - 0.5f; g = a < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+    acc += v;
+    dpred[i] = g * da * inv_n;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = kLossThreads / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
+}
+
 }  // namespace
 }  // namespace dmp
 
@@ -417,6 +448,13 @@ int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const d
   int rc = check_launch();
   if (rc != DMP_OK) return rc;
   heads_bwd_w_k<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(wj);
+  return check_launch();
+}
+
+int dmp_count_loss(const float *pred, const float *target, int64_t n, int kind, float neg_slope, float *loss, float *dpred, void *stream) {
+  if (n < 1 || kind < 0 || kind > 2 || !pred || !target || !loss || !dpred) return DMP_ERR_BAD_ARG;
+  if (n > ((int64_t)1 << 22) || !(neg_slope >= 0.f && neg_slope <= 1.f)) return DMP_ERR_UNSUPPORTED;     // (one workgroup: a batch's counts)
+  count_loss_k<<<1, kLossThreads, 0, (hipStream_t)stream>>>(pred, target, n, kind, neg_slope, loss, dpred);
   return check_launch();
 }
 

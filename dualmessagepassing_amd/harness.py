@@ -369,6 +369,43 @@ class SmallLikePairs(PairDataset):
 
 
 _CRIT = {"MAE": F.l1_loss, "MSE": F.mse_loss, "SMSE": F.smooth_l1_loss}
+_CRIT_KIND = {"MSE": 0, "MAE": 1, "SMSE": 2}
+USE_FUSED_COUNT_LOSS = True
+
+
+class _CountLossHIP(torch.autograd.Function):
+    """``bp_crit(leaky_relu(pred, neg_slope), target)`` (mean) and its gradient seed in ONE launch (``dmp_count_loss``)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, neg_slope):
+        from . import _lib
+        lib = _lib.load()
+        p, t = pred.detach().reshape(-1).contiguous(), target.reshape(-1).contiguous()
+        _lib.require_gpu(p, t)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        dpred = torch.empty_like(p)
+        with _lib.timed("count_loss[n=%d]", (p.numel(),), 12 * p.numel()):
+            _lib.check(lib.dmp_count_loss(_lib.ptr(p), _lib.ptr(t), p.numel(), int(kind), float(neg_slope), _lib.ptr(loss), _lib.ptr(dpred),
+                                          _lib.stream_ptr()), "dmp_count_loss")
+        ctx.dpred, ctx.shape = dpred, pred.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dpred * g).view(ctx.shape), None, None, None
+
+
+def count_loss(pred, target, bp_loss="MSE", neg_slope=1.0):
+    """The count loss of train.py:624-628, ``bp_crit(F.leaky_relu(pred, neg_slope), target)`` with reduction 'mean'
+    (``neg_slope`` 1: the plain criterion).  On the GPU, for fp32 tensors of equal size, the criterion, its mean and the
+    gradient seed are ONE launch (five as tensor ops); anything else goes through the tensor ops."""
+    if (USE_FUSED_COUNT_LOSS and bp_loss in _CRIT_KIND and pred.is_cuda and pred.dtype == torch.float32 and torch.is_tensor(target)
+            and target.is_cuda and target.dtype == torch.float32 and not target.requires_grad and target.numel() == pred.numel()
+            and 0 < pred.numel() <= (1 << 22) and 0.0 <= float(neg_slope) <= 1.0
+            and pred.reshape(-1).shape == target.reshape(-1).shape and (pred.dim() == target.dim() or pred.dim() == 1 or target.dim() == 1)):
+        return _CountLossHIP.apply(pred, target, _CRIT_KIND[bp_loss], float(neg_slope))
+    act = pred if float(neg_slope) == 1.0 else F.leaky_relu(pred, neg_slope)
+    return _CRIT[bp_loss](act, target)
 SCHEDULE_CYCLES = 2     # utils/anneal.py:7, utils/cyclical.py:7 (NUM_CYCLES, what train.py:510-562 passes)
 
 
@@ -510,7 +547,7 @@ def train_epoch(model, optimizer, dataset, batch_size, device, sync=None, bp_los
         finally:
             model.lazy_edge_rep = lazy
         pred = out["pred_c"]
-        loss = _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
+        loss = count_loss(pred, counts, bp_loss, neg_slp) if pred.shape == counts.shape else _CRIT[bp_loss](F.leaky_relu(pred, neg_slp), counts)
         for w, pk, mk in ((node_w, "pred_v", "g_v_mask"), (edge_w, "pred_e", "g_e_mask")):
             if w is not None and out[pk] is not None:
                 m_loss, m_reg = _match_terms(_CRIT[bp_loss], out[pk], w, out[mk], pred, neg_slp)

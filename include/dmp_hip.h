@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 81
+#define DMP_ABI_VERSION 82
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -994,6 +994,13 @@ typedef struct {
 } dmp_head_grads;
 int dmp_heads_forward(const dmp_head_weights *w, const dmp_head_io *io, int num_heads, int B, int H,
                       float slope, void *stream);
+
+/* The count loss of a training step AND its seed in one launch (train.py:624-628: `bp_crit(F.leaky_relu(pred_c, neg_slp), counts)`,
+ * reduction 'mean', followed by `loss.backward()` -- five torch launches around ~1000 numbers):
+ *     loss[0] = mean_i crit(leaky_relu(pred[i], neg_slope) - target[i]),     dpred[i] = d loss[0] / d pred[i]
+ * kind 0 = MSE, 1 = MAE (L1), 2 = smooth L1 with beta 1 (the reference's "SMSE"); neg_slope in [0, 1] (1: no activation).
+ * One workgroup, fixed summation order (bit-stable); n <= 2^22, else DMP_ERR_UNSUPPORTED (the caller uses its tensor ops). */
+int dmp_count_loss(const float *pred, const float *target, int64_t n, int kind, float neg_slope, float *loss, float *dpred, void *stream);
 int dmp_heads_backward(const dmp_head_weights *w, const dmp_head_io *io, const dmp_head_grads *g,
                        int num_heads, int B, int H, float slope, void *stream);
 
