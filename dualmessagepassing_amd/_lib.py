@@ -100,6 +100,7 @@ SIGNATURES = {
     "dmp_smallk_atb_cols_rows": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_smallk_atb": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_smallk_atb_jobs": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr]),
+    "dmp_l0_pack_jobs": (c_int, [c_ptr, c_int, c_ptr]),
     "dmp_count_loss": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr, c_ptr, c_ptr]),
     "dmp_reduce_partials_multi": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "dmp_l0_pack": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
@@ -203,7 +204,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 82
+ABI_VERSION = 83
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

@@ -798,6 +798,23 @@ class GraphAdjModelV2(BaseModel):
             enc["dst"] = enc["v"][v]
         return enc
 
+    def get_encs(self, pattern, graph):
+        """``(get_pattern_enc(pattern), get_graph_enc(graph))`` with all six table lookups in ONE launch (``embed.lookup_rows``
+        takes up to eight; a table it cannot take sends all of them through the modules, as two calls would)."""
+        pn, gn = self.p_enc_net, self.g_enc_net
+        rows = lookup_rows([pn["v"], pn["vl"], pn["el"], gn["v"], gn["vl"], gn["el"]],
+                           [pattern.ndata["id"].view(-1), pattern.ndata["label"].view(-1), pattern.edata["label"].view(-1),
+                            graph.ndata["id"].view(-1), graph.ndata["label"].view(-1), graph.edata["label"].view(-1)])
+        encs = []
+        for g, (v, vl, el) in ((pattern, rows[:3]), (graph, rows[3:])):
+            enc = OrderedDict({"v": v, "vl": vl, "el": el})
+            if self.add_edge_id:
+                u, w = g.all_edges(form="uv", order="eid")
+                enc["src"] = enc["v"][u]
+                enc["dst"] = enc["v"][w]
+            encs.append(enc)
+        return encs[0], encs[1]
+
     def get_pattern_enc(self, pattern):
         return self._enc(self.p_enc_net, pattern)
 
@@ -930,9 +947,8 @@ class GraphAdjModelV2(BaseModel):
 
         if not PREFETCH_AFTER_EMBEDDINGS:
             prefetch()
-        p_enc = self.get_pattern_enc(pattern)
+        p_enc, g_enc = self.get_encs(pattern, graph)          # (both sides' encodings: one launch)
         p_v_emb, p_e_emb = self.get_pattern_emb(p_enc)
-        g_enc = self.get_graph_enc(graph)
         g_v_emb, g_e_emb = self.get_graph_emb_deferred(g_enc) if hasattr(self, "get_joint_rep") else self.get_graph_emb(g_enc)
         if PREFETCH_AFTER_EMBEDDINGS:
             prefetch()

@@ -80,7 +80,9 @@ struct PackArgs {
 };
 
 // A thread per ROW (its gate once, its <= 16 codes, 16-byte stores: Kpad % 4 == 0 and `out` comes 16-byte aligned from the host side).
-__global__ __launch_bounds__(kBlock) void l0_pack_k(const PackArgs p) {
+struct PackJobs { PackArgs job[2]; };     // blockIdx.y = job (the edge rows' codes and the node rows' codes of a step: one launch)
+__global__ __launch_bounds__(kBlock) void l0_pack_k(const PackJobs js) {
+  const PackArgs &p = js.job[blockIdx.y];
   const int64_t rows = p.n + p.rows_g;
   for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock) {
     const bool pat = r < p.n;
@@ -541,17 +543,31 @@ using namespace dmp;
 
 extern "C" {
 
+int dmp_l0_pack_jobs(const dmp_l0_pack_job *jobs, int num_jobs, void *stream) {
+  if (!jobs || num_jobs < 1 || num_jobs > 2) return DMP_ERR_BAD_ARG;
+  PackJobs js{};
+  int64_t most = 0;
+  int n = 0;
+  for (int i = 0; i < num_jobs; ++i) {
+    const dmp_l0_pack_job &q = jobs[i];
+    if (q.rows_p < 0 || q.rows_g < 0 || q.K <= 0 || q.goff < 0 || q.Kpad < q.goff + q.K || !q.out) return DMP_ERR_BAD_ARG;
+    if ((q.rows_p > 0 && (!q.enc_p || q.ldp < q.K)) || (q.rows_g > 0 && (!q.enc_g || q.ldg < q.K))) return DMP_ERR_BAD_ARG;
+    const int64_t total = q.rows_p + q.rows_g;             // a thread per row
+    if (total == 0) continue;
+    if (q.Kpad % 4 || (reinterpret_cast<uintptr_t>(q.out) & 15u)) return DMP_ERR_UNSUPPORTED;
+    js.job[n++] = PackArgs{q.enc_p, q.ldp, q.rows_p, q.enc_g, q.ldg, q.gate, q.rows_g, q.K, q.Kpad, q.goff, q.out};
+    if (total > most) most = total;
+  }
+  if (n == 0) return DMP_OK;
+  const int64_t nb = (most + kBlock - 1) / kBlock;
+  l0_pack_k<<<dim3((unsigned)(nb < 8192 ? nb : 8192), (unsigned)n), kBlock, 0, (hipStream_t)stream>>>(js);
+  return check_launch();
+}
+
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
                 int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream) {
-  if (rows_p < 0 || rows_g < 0 || K <= 0 || goff < 0 || Kpad < goff + K || !out) return DMP_ERR_BAD_ARG;
-  if ((rows_p > 0 && (!enc_p || ldp < K)) || (rows_g > 0 && (!enc_g || ldg < K))) return DMP_ERR_BAD_ARG;
-  const int64_t total = rows_p + rows_g;                 // a thread per row
-  if (total == 0) return DMP_OK;
-  if (Kpad % 4 || (reinterpret_cast<uintptr_t>(out) & 15u)) return DMP_ERR_UNSUPPORTED;
-  const int64_t nb = (total + kBlock - 1) / kBlock;
-  PackArgs p{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, goff, out};
-  l0_pack_k<<<(unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, (hipStream_t)stream>>>(p);
-  return check_launch();
+  const dmp_l0_pack_job j{enc_p, ldp, rows_p, enc_g, ldg, gate, rows_g, K, Kpad, goff, out};
+  return dmp_l0_pack_jobs(&j, 1, stream);
 }
 
 int dmp_l0_edge_fwd_masked(const float *enc, int64_t lde, int K, const float *M, int64_t ldm, const float *P, int64_t ldp,

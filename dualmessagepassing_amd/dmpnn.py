@@ -592,14 +592,19 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
     if e_gate is not None and (e_gate.requires_grad or e_gate.numel() != gs[0].size(0)):
         return None
     shared = ps[1] is gs[1]
-    l0 = fused.Layer0Codes(fused.l0_pack(ps[0], gs[0], e_gate), gs[0].size(1), gs[1] if shared else th.cat([ps[1], gs[1]], dim=0),
-                           0 if shared else ps[0].size(0), 0 if shared else p_nodes)
     pv, gv = getattr(p_v_emb, "_dmp_src", None), getattr(g_v_emb, "_dmp_src", None)
-    if (fused.USE_LAYER0_NODES and pv is not None and gv is not None and gv[1].requires_grad and pv[1].requires_grad
-            and (pv[1] is gv[1]) == shared and pv[0].size(0) == p_nodes and fused.l0_nodes_ok(H, pv[0], gv[0], pv[1], gv[1])
-            and (v_gate is None or (not v_gate.requires_grad and v_gate.numel() == gv[0].size(0)))):
+    nodes = bool(fused.USE_LAYER0_NODES and pv is not None and gv is not None and gv[1].requires_grad and pv[1].requires_grad
+                 and (pv[1] is gv[1]) == shared and pv[0].size(0) == p_nodes and fused.l0_nodes_ok(H, pv[0], gv[0], pv[1], gv[1])
+                 and (v_gate is None or (not v_gate.requires_grad and v_gate.numel() == gv[0].size(0))))
+    specs = [(ps[0], gs[0], e_gate, False)]
+    if nodes:
         stacked = not shared and 2 * gv[0].size(1) <= fused.SMALLK_MAX    # two tables as ONE of 2 VK rows: no second launches
-        l0.venc, l0.VK = fused.l0_pack(pv[0], gv[0], v_gate, stacked), gv[0].size(1) * (2 if stacked else 1)
+        specs.append((pv[0], gv[0], v_gate, stacked))
+    packed = fused.l0_pack_many(specs)             # the edge rows' codes and the node rows' codes: one launch
+    l0 = fused.Layer0Codes(packed[0], gs[0].size(1), gs[1] if shared else th.cat([ps[1], gs[1]], dim=0),
+                           0 if shared else ps[0].size(0), 0 if shared else p_nodes)
+    if nodes:
+        l0.venc, l0.VK = packed[1], gv[0].size(1) * (2 if stacked else 1)
         l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
     # the code rows a zero gate wiped, as row masks: the BACKWARD skips their gradient rows -- built on the side stream (behind the
     # index builds; joined with them when the pass ends)

@@ -1132,6 +1132,38 @@ def l0_pack(enc_p, enc_g, gate=None, stacked=False):
     return out
 
 
+_L0_PACK_JOB = None
+
+
+def l0_pack_many(specs):
+    """``[l0_pack(*spec) for spec in specs]`` (``spec`` = ``(enc_p, enc_g, gate, stacked)``; at most two) in ONE launch
+    (``dmp_l0_pack_jobs``): a step's edge codes and node codes."""
+    global _L0_PACK_JOB
+    lib = _lib.load()
+    if _L0_PACK_JOB is None:
+        P, I64, I = _ctypes.c_void_p, _ctypes.c_int64, _ctypes.c_int
+        _L0_PACK_JOB = type("dmp_l0_pack_job", (_ctypes.Structure,), {"_fields_": [
+            ("enc_p", P), ("ldp", I64), ("rows_p", I64), ("enc_g", P), ("ldg", I64), ("gate", P), ("rows_g", I64),
+            ("K", I), ("Kpad", I), ("goff", I), ("out", P)]})
+    J = (_L0_PACK_JOB * len(specs))()
+    outs, keep = [], []
+    for i, (enc_p, enc_g, gate, stacked) in enumerate(specs):
+        _lib.require_gpu(enc_p, enc_g)
+        K = enc_g.size(1)
+        goff = K if stacked else 0
+        Kpad = (goff + K + 3) // 4 * 4
+        n, rows_g = enc_p.size(0), enc_g.size(0)
+        out = torch.empty((n + rows_g, Kpad), dtype=torch.float32, device=enc_g.device)
+        gt = None if gate is None else gate.reshape(-1).contiguous()
+        J[i].enc_p, J[i].ldp, J[i].rows_p = ptr(enc_p), (enc_p.stride(0) if n else K), n
+        J[i].enc_g, J[i].ldg, J[i].gate, J[i].rows_g = ptr(enc_g), (enc_g.stride(0) if rows_g else K), ptr(gt), rows_g
+        J[i].K, J[i].Kpad, J[i].goff, J[i].out = K, Kpad, goff, out.data_ptr()
+        outs.append(out)
+        keep.append(gt)
+    check(lib.dmp_l0_pack_jobs(J, len(specs), stream_ptr()), "dmp_l0_pack_jobs")
+    return outs
+
+
 USE_L0_ROW_LISTS = True
 L0_LIST_MIN_ROWS = 32768       # shorter row ranges (the pattern side) keep the masked form: the list costs two launches
 

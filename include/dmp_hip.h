@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 82
+#define DMP_ABI_VERSION 83
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -688,6 +688,14 @@ int dmp_smallk_atb(const float *X, int64_t ldx, int K, const float *D, int64_t l
  *                    class-typed weight gradient is W^T of the first two blocks, the embedding's gradient needs all three. */
 int dmp_l0_pack(const float *enc_p, int64_t ldp, int64_t rows_p, const float *enc_g, int64_t ldg, const float *gate,
                 int64_t rows_g, int K, int Kpad, int goff, float *out, void *stream);
+/* ... one or two of them in ONE launch (a step packs its edge rows' codes and its node rows' codes). */
+typedef struct {
+  const float *enc_p; int64_t ldp; int64_t rows_p;
+  const float *enc_g; int64_t ldg; const float *gate; int64_t rows_g;
+  int K, Kpad, goff;
+  float *out;
+} dmp_l0_pack_job;
+int dmp_l0_pack_jobs(const dmp_l0_pack_job *jobs, int num_jobs, void *stream);
 /* ... leaving out DEAD rows: bit r of rowmask[t] == 0 says that every consumer of row 32 t + r of `out` multiplies it by a zero gate
  * and does not fetch it (the `_masked` kernels, dmp_pool_relu_bwd, the weighted dmp_seg_sum): nothing is gathered, computed or
  * STORED for such a row -- `out` keeps whatever the buffer held there. */

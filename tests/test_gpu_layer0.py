@@ -367,3 +367,7 @@ def test_packed_codes_are_the_gated_codes_in_their_columns(n, rows, K, stacked, 
     ref[:n, :K] = enc_p
     ref[n:, goff:goff + K] = enc_g if gate is None else enc_g * gate.view(-1, 1)
     assert got.shape == ref.shape and th.equal(got, ref)
+    # two packings in one launch (``l0_pack_many``: a step's edge codes and node codes) are the single launches
+    other = (th.randn(5, 4, generator=gen).to(gpu), th.randn(300, 4, generator=gen).to(gpu), None, True)
+    both = fused.l0_pack_many([(enc_p, enc_g, gate, stacked), other])
+    assert th.equal(both[0], ref) and th.equal(both[1], fused.l0_pack(*other))
