@@ -601,11 +601,13 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
         stacked = not shared and 2 * gv[0].size(1) <= fused.SMALLK_MAX    # two tables as ONE of 2 VK rows: no second launches
         specs.append((pv[0], gv[0], v_gate, stacked))
     packed = fused.l0_pack_many(specs)             # the edge rows' codes and the node rows' codes: one launch
-    l0 = fused.Layer0Codes(packed[0], gs[0].size(1), gs[1] if shared else th.cat([ps[1], gs[1]], dim=0),
+    # the pattern's table over the target's, for the edge rows and for the node rows: one launch for both stacks
+    stacks = None if shared else _StackTables.apply(*([ps[1], gs[1]] + ([pv[1], gv[1]] if nodes else [])))
+    l0 = fused.Layer0Codes(packed[0], gs[0].size(1), gs[1] if shared else stacks[0],
                            0 if shared else ps[0].size(0), 0 if shared else p_nodes)
     if nodes:
         l0.venc, l0.VK = packed[1], gv[0].size(1) * (2 if stacked else 1)
-        l0.WV = gv[1] if shared else th.cat([pv[1], gv[1]], dim=0)
+        l0.WV = gv[1] if shared else stacks[1]
     # the code rows a zero gate wiped, as row masks: the BACKWARD skips their gradient rows -- built on the side stream (behind the
     # index builds; joined with them when the pass ends)
     from . import side
@@ -615,6 +617,26 @@ def _layer0_codes(union, layers, p_v_emb, p_e_emb, g_v_emb, g_e_emb, v_gate, e_g
         if e_gate is not None and not getattr(e_gate, "_dmp_dense_gate", False):
             l0.enc_mask = fused.code_row_mask(l0.enc, l0.K)
     return l0
+
+
+class _StackTables(th.autograd.Function):
+    """``(cat([a, b]), cat([c, d]))`` (one or two pairs of [K, H] tables, row-wise) in ONE launch (``collate.concat_pairs``); the
+    gradients go back as the row blocks they belong to (views: no launch)."""
+
+    @staticmethod
+    def forward(ctx, *tables):
+        from .collate import concat_pairs
+        pairs = [(tables[i], tables[i + 1]) for i in range(0, len(tables), 2)]
+        ctx.rows = [a.size(0) for a, _ in pairs]
+        outs = concat_pairs([(a.detach().contiguous(), b.detach().contiguous(), 0) for a, b in pairs])
+        return tuple(o.view(a.size(0) + b.size(0), a.size(1)) for o, (a, b) in zip(outs, pairs))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for g, n in zip(grads, ctx.rows):
+            out += [None, None] if g is None else [g[:n], g[n:]]
+        return tuple(out)
 
 
 class _GateConcat(th.autograd.Function):
