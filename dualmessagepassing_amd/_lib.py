@@ -115,6 +115,10 @@ SIGNATURES = {
                                  c_i64, c_ptr]),
     "dmp_bn_train_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_int, c_f32, c_ptr, c_ptr, c_ptr, c_i64,
                                  c_ptr]),
+    "dmp_bn_train_fwd_rows": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_int, c_f32, c_ptr, c_ptr,
+                                      c_ptr, c_i64, c_ptr]),
+    "dmp_bn_train_bwd_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_int, c_ptr, c_int, c_f32, c_ptr, c_ptr, c_ptr,
+                                      c_i64, c_ptr]),
     "dmp_l0_bwd_w_masked": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "dmp_scalar_filter_gates": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_i64, c_ptr]),
     "dmp_csr_pair_workspace_words": (ctypes.c_size_t, [c_i64]),
@@ -204,7 +208,7 @@ SIGNATURES = {
                                     c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 83
+ABI_VERSION = 84
 # ``_lib.VALIDATE = True``: index builds read back the kernels' status word (one host sync each) and raise on an edge endpoint
 # or a lookup index outside its range -- otherwise such an entry is dropped from the CSR and gathers read row 0 (validate
 # datasets once with harness.validate_samples, or run a debugging pass with this attribute set)

@@ -30,7 +30,14 @@ struct BnArgs {
   float *partial;                      // [blocks, 2C]
   float *stats;                        // [4C]: forward mean | invstd ; backward (after finalize) dbeta | dgamma in [2C, 4C)
   float slope;
+  const int64_t *rdev;                 // device-side row count or NULL: only the first min(R, *rdev) rows exist (a batch padded to a capacity)
 };
+
+__device__ __forceinline__ int64_t live_rows(int64_t R, const int64_t *rdev) {
+  if (!rdev) return R;
+  const int64_t n = *rdev;
+  return n < 1 ? 1 : (n < R ? n : R);
+}
 
 // lanes: C / 4 per row (float4 each), kBlock / (C / 4) rows per pass
 template <bool BWD>
@@ -46,14 +53,15 @@ __global__ __launch_bounds__(kBlock) void bn_partial_k(const BnArgs p) {
     if (BWD) { mean = ld4(p.stats + c); invstd = ld4(p.stats + p.C + c); }
     else shift = ld4(p.x + c);
   }
+  const int64_t R = live_rows(p.R, p.rdev);
   if (on) {
     const int64_t step = (int64_t)gridDim.x * rows_per_pass;
-    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_pass + grp; r0 < p.R; r0 += 4 * step) {
+    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_pass + grp; r0 < R; r0 += 4 * step) {
       float4 x[4], y[4], d[4];                               // four rows in flight: the loop is a memory round trip per pass
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int64_t r = r0 + u * step;
-        const bool ok = r < p.R;
+        const bool ok = r < R;
         x[u] = ok ? ld4(p.x + r * p.ldx + c) : (BWD ? mean : shift);
         if (BWD) {
           y[u] = ok ? ld4(p.y + r * p.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -95,6 +103,7 @@ struct BnFinArgs {
   float eps, momentum;
   float *running_mean, *running_var;   // may be NULL
   float *stats;                        // forward: writes mean | invstd; backward: writes dbeta | dgamma at [2C, 4C)
+  const int64_t *rdev;
 };
 
 // a workgroup per 32 columns: 8 lanes own 4 columns each, the 32 row groups of the block split the partial rows among them (a
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_k(const BnFinArgs p) {
       p.stats[2 * p.C + cc] = (float)a[j];                   // dbeta
       p.stats[3 * p.C + cc] = (float)b[j];                   // dgamma
     } else {
-      const double n = (double)p.R, md = a[j] / n;
+      const double n = (double)live_rows(p.R, p.rdev), md = a[j] / n;
       double var = b[j] / n - md * md;                       // biased, of the shifted values
       if (var < 0.0) var = 0.0;
       const float mean = (float)(md + (double)p.x0[cc]);
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_k(const BnFinArgs p) {
       p.stats[p.C + cc] = (float)(1.0 / sqrt(var + (double)p.eps));
       if (p.running_mean) p.running_mean[cc] = (1.f - p.momentum) * p.running_mean[cc] + p.momentum * mean;
       if (p.running_var) {
-        const float unbiased = (float)(p.R > 1 ? var * n / (n - 1.0) : var);
+        const float unbiased = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
         p.running_var[cc] = (1.f - p.momentum) * p.running_var[cc] + p.momentum * unbiased;
       }
     }
@@ -149,6 +158,7 @@ struct BnApplyArgs {
   const float *x; int64_t ldx; const float *y; int64_t ldy; const float *dy; int64_t lddy;
   const float *gamma, *beta, *stats; int64_t R; int C; float slope; int act;
   float *out; int64_t ldo;
+  const int64_t *rdev;                 // rows past the device-side count are written as zeros
 };
 
 template <bool BWD>
@@ -161,9 +171,11 @@ __global__ __launch_bounds__(kBlock) void bn_apply_k(const BnApplyArgs p) {
   const float4 gm = p.gamma ? ld4(p.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 bt = (!BWD && p.beta) ? ld4(p.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 db = make_float4(0.f, 0.f, 0.f, 0.f), dg = db;
-  const float inv_n = 1.f / (float)p.R;
+  const int64_t R = live_rows(p.R, p.rdev);
+  const float inv_n = 1.f / (float)R;
   if (BWD) { db = ld4(p.stats + 2 * p.C + c); dg = ld4(p.stats + 3 * p.C + c); }
   for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + grp; r < p.R; r += (int64_t)gridDim.x * rows_per_pass) {
+    if (r >= R) { st4(p.out + r * p.ldo + c, make_float4(0.f, 0.f, 0.f, 0.f)); continue; }      // a padding row
     const float4 x = ld4(p.x + r * p.ldx + c);
     const float4 xh = make_float4((x.x - mean.x) * invstd.x, (x.y - mean.y) * invstd.y, (x.z - mean.z) * invstd.z, (x.w - mean.w) * invstd.w);
     float4 o;
@@ -203,29 +215,36 @@ extern "C" {
 
 int64_t dmp_bn_partial_rows(int64_t rows, int C) { return bn_shape_ok(C) ? (int64_t)bn_blocks(rows, C) : 0; }
 
-int dmp_bn_train_fwd(const float *x, int64_t ldx, int64_t rows, int C, const float *gamma, const float *beta, float eps,
-                     float momentum, float *running_mean, float *running_var, int act, float slope, float *partial,
-                     float *stats, float *out, int64_t ldo, void *stream) {
+int dmp_bn_train_fwd_rows(const float *x, int64_t ldx, int64_t rows, const int64_t *rows_dev, int C, const float *gamma, const float *beta,
+                          float eps, float momentum, float *running_mean, float *running_var, int act, float slope, float *partial,
+                          float *stats, float *out, int64_t ldo, void *stream) {
   if (rows <= 0 || !x || !partial || !stats || !out || ldx < C || ldo < C) return DMP_ERR_BAD_ARG;
   if (!bn_shape_ok(C) || !slope_ok(slope) || ldx % 4 || ldo % 4 || !al16(x) || !al16(out) || !al16(gamma) || !al16(beta) || !al16(partial)
       || !al16(stats))
     return DMP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const unsigned nb = bn_blocks(rows, C);
-  BnArgs a{x, ldx, nullptr, 0, nullptr, 0, rows, C, partial, stats, slope};
+  BnArgs a{x, ldx, nullptr, 0, nullptr, 0, rows, C, partial, stats, slope, rows_dev};
   bn_partial_k<false><<<nb, kBlock, 0, st>>>(a);
-  BnFinArgs f{partial, (int)nb, rows, C, x, eps, momentum, running_mean, running_var, stats};
+  BnFinArgs f{partial, (int)nb, rows, C, x, eps, momentum, running_mean, running_var, stats, rows_dev};
   bn_finalize_k<false><<<(unsigned)((C + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(f);
-  BnApplyArgs ap{x, ldx, nullptr, 0, nullptr, 0, gamma, beta, stats, rows, C, slope, act, out, ldo};
+  BnApplyArgs ap{x, ldx, nullptr, 0, nullptr, 0, gamma, beta, stats, rows, C, slope, act, out, ldo, rows_dev};
   const int rows_per_pass = kBlock / (C / 4);
   const int64_t want = (rows + rows_per_pass - 1) / rows_per_pass;
   bn_apply_k<false><<<(unsigned)(want < 2048 ? want : 2048), kBlock, 0, st>>>(ap);
   return check_launch();
 }
 
-int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows, int C,
-                     const float *gamma, int act, float slope, float *partial, float *stats, float *dx, int64_t ldo,
-                     void *stream) {
+int dmp_bn_train_fwd(const float *x, int64_t ldx, int64_t rows, int C, const float *gamma, const float *beta, float eps,
+                     float momentum, float *running_mean, float *running_var, int act, float slope, float *partial,
+                     float *stats, float *out, int64_t ldo, void *stream) {
+  return dmp_bn_train_fwd_rows(x, ldx, rows, nullptr, C, gamma, beta, eps, momentum, running_mean, running_var, act, slope, partial, stats, out,
+                               ldo, stream);
+}
+
+int dmp_bn_train_bwd_rows(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows,
+                          const int64_t *rows_dev, int C, const float *gamma, int act, float slope, float *partial, float *stats, float *dx,
+                          int64_t ldo, void *stream) {
   if (rows <= 0 || !x || !dy || !partial || !stats || !dx || ldx < C || lddy < C || ldo < C || (act && (!y || ldy < C))) return DMP_ERR_BAD_ARG;
   if (!bn_shape_ok(C) || !slope_ok(slope) || ldx % 4 || ldy % 4 || lddy % 4 || ldo % 4 || !al16(x) || !al16(y) || !al16(dy) || !al16(dx)
       || !al16(gamma) || !al16(partial) || !al16(stats))
@@ -236,15 +255,21 @@ int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, c
   const float sl = act ? slope : 1.f;
   const float *ym = act ? y : dy;
   const int64_t ldm = act ? ldy : lddy;
-  BnArgs a{x, ldx, ym, ldm, dy, lddy, rows, C, partial, stats, sl};
+  BnArgs a{x, ldx, ym, ldm, dy, lddy, rows, C, partial, stats, sl, rows_dev};
   bn_partial_k<true><<<nb, kBlock, 0, st>>>(a);
-  BnFinArgs f{partial, (int)nb, rows, C, nullptr, 0.f, 0.f, nullptr, nullptr, stats};
+  BnFinArgs f{partial, (int)nb, rows, C, nullptr, 0.f, 0.f, nullptr, nullptr, stats, rows_dev};
   bn_finalize_k<true><<<(unsigned)((C + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(f);
-  BnApplyArgs ap{x, ldx, ym, ldm, dy, lddy, gamma, nullptr, stats, rows, C, sl, 1, dx, ldo};
+  BnApplyArgs ap{x, ldx, ym, ldm, dy, lddy, gamma, nullptr, stats, rows, C, sl, 1, dx, ldo, rows_dev};
   const int rows_per_pass = kBlock / (C / 4);
   const int64_t want = (rows + rows_per_pass - 1) / rows_per_pass;
   bn_apply_k<true><<<(unsigned)(want < 2048 ? want : 2048), kBlock, 0, st>>>(ap);
   return check_launch();
+}
+
+int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows, int C,
+                     const float *gamma, int act, float slope, float *partial, float *stats, float *dx, int64_t ldo,
+                     void *stream) {
+  return dmp_bn_train_bwd_rows(x, ldx, y, ldy, dy, lddy, rows, nullptr, C, gamma, act, slope, partial, stats, dx, ldo, stream);
 }
 
 }  // extern "C"

@@ -600,9 +600,11 @@ class _BatchNormActTrain(torch.autograd.Function):
     the activation that follows in three small launches; the backward likewise."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, rows_dev=None):
+        """``rows_dev`` (int64 [1] on the device, or None): only the first ``rows_dev[0]`` rows exist -- a batch padded to a capacity
+        (``unc_harness.SampledStep``): the others stay out of the statistics and come out as zeros, forward and backward."""
         lib = _lib.load()
-        _lib.require_gpu(x)
+        _lib.require_gpu(x, rows_dev)
         x = x.contiguous()
         R, C = x.shape
         nb = int(lib.dmp_bn_partial_rows(R, C))
@@ -610,11 +612,11 @@ class _BatchNormActTrain(torch.autograd.Function):
         stats = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
         act = slope is not None
-        check(lib.dmp_bn_train_fwd(ptr(x), x.stride(0), R, C, ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
-                                   ptr(running_var), int(act), float(slope or 0.0), ptr(partial), ptr(stats), ptr(out), out.stride(0),
-                                   stream_ptr()), "dmp_bn_train_fwd")
+        check(lib.dmp_bn_train_fwd_rows(ptr(x), x.stride(0), R, ptr(rows_dev), C, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                                        ptr(running_mean), ptr(running_var), int(act), float(slope or 0.0), ptr(partial), ptr(stats), ptr(out),
+                                        out.stride(0), stream_ptr()), "dmp_bn_train_fwd")
         ctx.save_for_backward(x, out if act else None, gamma)
-        ctx.stats, ctx.partial, ctx.slope = stats, partial, slope
+        ctx.stats, ctx.partial, ctx.slope, ctx.rows_dev = stats, partial, slope, rows_dev
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         return out
 
@@ -627,12 +629,12 @@ class _BatchNormActTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         act = ctx.slope is not None
-        check(lib.dmp_bn_train_bwd(ptr(x), x.stride(0), ptr(y), y.stride(0) if act else 0, ptr(dy), dy.stride(0), R, C, ptr(gamma),
-                                   int(act), float(ctx.slope or 0.0), ptr(ctx.partial), ptr(ctx.stats), ptr(dx), dx.stride(0),
-                                   stream_ptr()), "dmp_bn_train_bwd")
+        check(lib.dmp_bn_train_bwd_rows(ptr(x), x.stride(0), ptr(y), y.stride(0) if act else 0, ptr(dy), dy.stride(0), R, ptr(ctx.rows_dev), C,
+                                        ptr(gamma), int(act), float(ctx.slope or 0.0), ptr(ctx.partial), ptr(ctx.stats), ptr(dx), dx.stride(0),
+                                        stream_ptr()), "dmp_bn_train_bwd")
         dgamma = ctx.stats[3 * C:].clone() if gamma is not None else None      # copies: the statistics buffer stays the node's own
         dbeta = ctx.stats[2 * C:3 * C].clone() if gamma is not None else None
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def batch_norm_act_ok(bn, x):
@@ -644,12 +646,13 @@ def batch_norm_act_ok(bn, x):
             and C % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0 and (bn.weight is None) == (bn.bias is None))
 
 
-def batch_norm_act(bn, x, slope=None):
+def batch_norm_act(bn, x, slope=None, rows_dev=None):
     """``LeakyReLU(slope)(bn(x))`` (``slope`` None: no activation) for a module / input that ``batch_norm_act_ok`` accepts:
-    same values and the same side effects on the module's buffers as the module call."""
+    same values and the same side effects on the module's buffers as the module call.  ``rows_dev``: the number of rows that
+    exist, on the device (the rest is padding: out of the statistics, zeros in the result)."""
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
-    return _BatchNormActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
+    return _BatchNormActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope, rows_dev)
 
 
 def _act_slope(m):
@@ -660,10 +663,11 @@ def _act_slope(m):
     return None
 
 
-def apply_mlp(seq, x):
+def apply_mlp(seq, x, rows_dev=None):
     """Run an ``nn.Sequential`` of Linear / BatchNorm / activation modules (nmlp / emlp,
     dmpnn.py:45-60) with the Linear layers on ``linear_nn``, Linear+ReLU pairs fused and training-mode
-    BatchNorm1d (+ the activation after it) on ``batch_norm_act``."""
+    BatchNorm1d (+ the activation after it) on ``batch_norm_act``.  ``rows_dev``: x's rows past that device-side count
+    are padding (a BatchNorm the kernels cannot take then refuses: its statistics would include them)."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -676,9 +680,11 @@ def apply_mlp(seq, x):
             i += 2 if fuse else 1
         elif USE_HIP_BATCHNORM and isinstance(m, torch.nn.BatchNorm1d) and batch_norm_act_ok(m, x):
             slope = _act_slope(nxt)
-            x = batch_norm_act(m, x, slope)
+            x = batch_norm_act(m, x, slope, rows_dev)
             i += 2 if slope is not None else 1
         else:
+            if rows_dev is not None and isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training:
+                raise _lib.DmpError("apply_mlp: a padded batch needs the HIP BatchNorm (statistics over the real rows only)")
             x = m(x)
             i += 1
     return x

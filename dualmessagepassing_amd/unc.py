@@ -100,8 +100,10 @@ class DualGraphConv(nn.Module):
             g, node_feat, edge_feat, self.in_weight, self.out_weight, self.src_weight, self.dst_weight,
             self.nloop_weight, self.eloop_weight, self.nbias, self.ebias, has_rev="is_rev" in g.edata,
             edge_norm=g.edata.get("norm"))
-        node_out = ops.apply_mlp(self.nmlp, node_pre)
-        edge_out = ops.apply_mlp(self.emlp, edge_pre)
+        # (a sub-graph padded to a capacity, ``PaddedRows`` on the graph object: BatchNorm over the real rows only)
+        valid = getattr(graph, "_dmp_valid", None) or getattr(g, "_dmp_valid", None)
+        node_out = ops.apply_mlp(self.nmlp, node_pre, None if valid is None else valid.n_dev)
+        edge_out = ops.apply_mlp(self.emlp, edge_pre, None if valid is None else valid.e_dev)
         if self.act:
             node_out = self.act(node_out)
             edge_out = self.act(edge_out)
@@ -111,6 +113,20 @@ class DualGraphConv(nn.Module):
 
     def extra_repr(self):
         return "in=%s, out=%s," % (self.input_dim, self.hidden_dim)
+
+
+class PaddedRows:
+    """What a graph PADDED to fixed capacities carries under ``graph._dmp_valid`` (``unc_harness.SampledStep``: a sampled
+    sub-graph with inert nodes and edges behind the real ones, so that its step replays from a recording): the real
+    row counts on the device (int64 [1] each) and the 0 / 1 masks of the real rows.  Every reduction over the rows of the
+    model -- BatchNorm statistics, the per-relation means, the regularisers' means -- runs over the real rows only."""
+
+    def __init__(self, n_dev, e_dev, num_nodes, num_edges):
+        self.n_dev, self.e_dev = n_dev.view(1), e_dev.view(1)
+        dev = n_dev.device
+        self.node_mask = (torch.arange(num_nodes, device=dev) < self.n_dev).to(torch.float32).unsqueeze(1)
+        self.edge_bool = torch.arange(num_edges, device=dev) < self.e_dev
+        self.edge_mask = self.edge_bool.to(torch.float32).unsqueeze(1)
 
 
 def compute_edgenorm(g, norm="in"):
@@ -211,6 +227,11 @@ class DMPNN(nn.Module):
         # model.py:319-325 (one masked full-size sum per relation type there): mean of the edge
         # representations per relation type as ONE keyed segment sum; the index is memoised per
         # relation tensor (UNC trains on one fixed graph)
+        valid = getattr(g, "_dmp_valid", None)
+        if valid is not None:      # a padded sub-graph: its inert edges under a key of their own, dropped from the result
+            pool = PoolIndex.from_keys(torch.where(valid.edge_bool, r.view(-1), torch.full_like(r.view(-1), self.num_rels)), self.num_rels + 1)
+            r_rep = (seg_pool(z, pool) / (pool.sizes.float().view(-1, 1) + 1e-8))[:self.num_rels]
+            return h, z, r_rep
         pool = self._rel_pool(r)
         r_rep = seg_pool(z, pool) / (pool.sizes.float().view(-1, 1) + 1e-8)
         return h, z, r_rep
@@ -264,11 +285,17 @@ class TrainModel(nn.Module):
             pred = self.node_fc(output[0] if isinstance(output, (tuple, list)) else output)
         return output, pred
 
-    def unsupervised_regularization_loss(self, embedding, edge_type=None):
+    def unsupervised_regularization_loss(self, embedding, edge_type=None, valid=None):
         # model.py:692-714 (needs ``w_relation``: as in the reference, only defined for nlabel == 0)
+        # ``valid`` (``PaddedRows``): the node and edge representations (the first two entries) carry padding rows -- means
+        # over the real rows only
         reg = torch.mean(self.w_relation.pow(2))
         embs = list(embedding) if isinstance(embedding, (tuple, list)) else [embedding]
-        for emb in embs:
+        for k, emb in enumerate(embs):
+            if valid is not None and k < 2:
+                m, n = (valid.node_mask, valid.n_dev) if k == 0 else (valid.edge_mask, valid.e_dev)
+                reg = reg + (emb.pow(2) * m).sum() / (n.to(emb.dtype) * emb.size(1)).squeeze()
+                continue
             reg = reg + torch.mean(emb.pow(2))
         if edge_type is not None:
             for emb in embs:
@@ -288,6 +315,8 @@ class TrainModel(nn.Module):
                         if ops.is_immutable(edge_type):       # what is derived from a fixed tensor is fixed
                             ops.mark_immutable(cached[1], cached[2])
                     mask, clamped = cached[1], cached[2]
+                    if valid is not None:
+                        mask = mask * valid.edge_mask
                     emb_diff = self.edge_fc(emb) - ops.take_rows_small_table(self.w_relation, clamped)
                     reg = reg + (torch.pow(emb_diff, 2) * mask).sum() / (mask.sum() * emb_diff.size(1))
         return reg
@@ -295,7 +324,8 @@ class TrainModel(nn.Module):
     def get_unsupervised_loss(self, g, embedding, edge_type, triplets, labels):
         score = self.calc_score(embedding, triplets)
         predict_loss = F.binary_cross_entropy_with_logits(score, labels)
-        return predict_loss + self.reg_param * self.unsupervised_regularization_loss(embedding, edge_type=edge_type)
+        return predict_loss + self.reg_param * self.unsupervised_regularization_loss(embedding, edge_type=edge_type,
+                                                                                    valid=getattr(g, "_dmp_valid", None))
 
     def supervised_regularization_loss(self, embedding, edge_type=None):
         return self.unsupervised_regularization_loss(embedding, edge_type=edge_type)

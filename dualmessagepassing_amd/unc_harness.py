@@ -57,12 +57,74 @@ def _encode(model, graph, batch, sampler, sample_depth, sample_width, graph_spli
     return sub, samples, labels, edge_type, embed
 
 
+def pad_sampled(sub, edge_type, node_quantum=512, edge_quantum=2048):
+    """The sampled sub-graph ``sub`` as fixed-capacity arrays: its nodes followed by at least one INERT node (isolated; looked up
+    as node 0 of the parent graph), its edges followed by inert self-loops on the last inert node with norm 0, capacities the
+    next multiples of the quanta -- a few distinct shapes over a run instead of one per step.
+    -> ``((Ncap, Ecap), (src, dst, edge_type, norm, nid, counts))``, ``counts`` = int64 [2] on the device (real nodes, real edges)."""
+    N, E = sub.number_of_nodes(), sub.number_of_edges()
+    ncap = (N + node_quantum) // node_quantum * node_quantum              # > N: at least one inert node
+    ecap = max(edge_quantum, (E + edge_quantum - 1) // edge_quantum * edge_quantum)
+    src, dst = sub.all_edges(form="uv", order="eid")
+    dev = src.device
+    tail = torch.full((ecap - E,), ncap - 1, dtype=src.dtype, device=dev)
+    nid = sub.ndata[SUBGRAPH_NID].view(-1)
+    norm = sub.edata["norm"].view(-1)
+    arrays = (torch.cat([src, tail]), torch.cat([dst, tail]),
+              torch.cat([edge_type.view(-1), torch.zeros(ecap - E, dtype=edge_type.dtype, device=dev)]),
+              torch.cat([norm, torch.zeros(ecap - E, dtype=norm.dtype, device=dev)]).view(-1, 1),
+              torch.cat([nid, torch.zeros(ncap - N, dtype=nid.dtype, device=dev)]),
+              torch.tensor([N, E], dtype=torch.int64, device=dev))
+    return (ncap, ecap), arrays
+
+
+class SampledStep:
+    """The optimisation step of ``train_unsupervised`` on a sampled sub-graph -- encoder, link-prediction loss, backward,
+    clip, Adam -- recorded once per padded shape as a HIP graph and replayed (``dp.StepGraph``).  The samplers produce a
+    sub-graph of a new size every step (utils.py:279-349; two host syncs: they stay eager); the step itself sees
+    ``pad_sampled``'s fixed capacities, with the real row counts on the device: BatchNorm statistics
+    (``dmp_bn_train_*_rows``), the per-relation means and the regularisers run over the real rows only
+    (``unc.PaddedRows``), an inert row contributes nothing to any gradient.  ``optimizer``: ``FlatAdamW(capturable=True)``
+    (a scheduler's rate reaches the device through ``sync_hyper`` before every replay)."""
+
+    def __init__(self, model, sync, optimizer, grad_norm=1.0, node_quantum=512, edge_quantum=2048, max_shapes=8):
+        from .dp import StepGraph
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("SampledStep needs FlatAdamW(capturable=True)")
+        self.model, self.sync, self.optimizer, self.grad_norm = model, sync, optimizer, grad_norm
+        self.node_quantum, self.edge_quantum = int(node_quantum), int(edge_quantum)
+        self.steps = StepGraph(self._step, optimizer=optimizer, max_shapes=max_shapes)
+
+    def _step(self, caps, src, dst, edge_type, norm, nid, counts, samples, labels):
+        from .graph import BatchedGraph
+        from .unc import PaddedRows
+        ncap, ecap = caps
+        g = BatchedGraph(src, dst, ncap)
+        g._dmp_valid = PaddedRows(counts[0:1], counts[1:2], ncap, ecap)
+        g.edata["type"], g.edata["norm"] = edge_type, norm
+        self.sync.detach_grads()
+        embed, _ = self.model(g, nid, edge_type, norm)
+        loss = self.model.get_unsupervised_loss(g, embed, edge_type, samples, labels)
+        loss.backward()
+        self.sync.pack()
+        if self.grad_norm and self.grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_([self.sync.master], self.grad_norm)
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, sub, edge_type, samples, labels):
+        caps, arrays = pad_sampled(sub, edge_type, self.node_quantum, self.edge_quantum)
+        return self.steps(caps, *arrays, samples, labels)
+
+
 def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=2000, lr=1e-3, grad_norm=1.0,
                        sampler="neighbor", sample_depth=6, sample_width=128, graph_split_size=0.5, negative_sample=5,
-                       rescale_epochs=True, seed=0, log=None):
+                       rescale_epochs=True, seed=0, log=None, replay=False):
     """main.py:99-183 for the unsupervised objective.  ``triplets`` [M, 3] (device, int64): the positive edges;
     ``graph``: ``build_graph_from_triplets`` of them (both directions, ``edata["type"]`` / ``["norm"]``).
-    Returns the per-epoch mean losses (training stops after the first epoch whose mean loss rises)."""
+    Returns the per-epoch mean losses (training stops after the first epoch whose mean loss rises).
+    ``replay``: the step after the sampling runs through ``SampledStep`` (sub-graphs padded to capacity levels, one HIP-graph
+    replay per step); same sub-graphs, same losses up to the summation order of the padded BatchNorm partials."""
     dev = triplets.device
     triplets = triplets[:, :3].to(torch.int64)
     steps_per_epoch = math.ceil(triplets.size(0) / graph_batch_size)
@@ -73,14 +135,22 @@ def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=200
     from .dp import FlatAdamW, FlatGradSync
     sync = FlatGradSync(model)
     master = sync.flatten_parameters()
-    optimizer = FlatAdamW([master], lr=lr, weight_decay=0.0)
+    optimizer = FlatAdamW([master], lr=lr, weight_decay=0.0, capturable=bool(replay))
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, n_epochs * steps_per_epoch, eta_min=3e-6)
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
+    stepper = SampledStep(model, sync, optimizer, grad_norm) if replay else None
     history, prev = [], float("inf")
     for epoch in range(n_epochs):
         total = torch.zeros((), device=dev)
         for batch in _edge_batches(triplets, graph_batch_size, gen):
+            if stepper is not None:
+                sub, samples, labels = generate_sampled_graph_and_labels_unsupervised(
+                    graph, batch, sample_depth, sample_width, graph_split_size, negative_sample, generator=gen, sampler=sampler)
+                with stepper.steps.on_stream():
+                    total += stepper(sub, sub.edata["type"], samples, labels)
+                scheduler.step()
+                continue
             sub, samples, labels, edge_type, embed = _encode(model, graph, batch, sampler, sample_depth, sample_width,
                                                              graph_split_size, negative_sample, gen)
             loss = model.get_unsupervised_loss(sub, embed, edge_type, samples, labels)

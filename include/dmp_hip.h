@@ -43,7 +43,7 @@ extern "C" {
 #define DMP_ERR_HIP (-3)         /* a HIP launch failed; see dmp_last_hip_error()   */
 
 /* ABI version of this header; bumped on any signature change. */
-#define DMP_ABI_VERSION 83
+#define DMP_ABI_VERSION 84
 int dmp_abi_version(void);
 /* hipGetLastError() text of the most recent DMP_ERR_HIP on this host thread. */
 const char *dmp_last_hip_error(void);
@@ -771,6 +771,15 @@ int dmp_bn_train_fwd(const float *x, int64_t ldx, int64_t rows, int C, const flo
 int dmp_bn_train_bwd(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows,
                      int C, const float *gamma, int act, float slope, float *partial, float *stats, float *dx, int64_t ldo,
                      void *stream);
+/* ... with the row count ON THE DEVICE (rows_dev [1], int64, or NULL): only the first min(rows, *rows_dev) rows exist -- a batch padded
+ * to a fixed capacity so that its step replays from a recording (UNC's sampled sub-graphs, utils.py:279-349, differ in size from
+ * step to step).  The others stay out of the statistics (and out of `rows` in the divisions) and are written as zeros. */
+int dmp_bn_train_fwd_rows(const float *x, int64_t ldx, int64_t rows, const int64_t *rows_dev, int C, const float *gamma, const float *beta,
+                          float eps, float momentum, float *running_mean, float *running_var, int act, float slope, float *partial,
+                          float *stats, float *out, int64_t ldo, void *stream);
+int dmp_bn_train_bwd_rows(const float *x, int64_t ldx, const float *y, int64_t ldy, const float *dy, int64_t lddy, int64_t rows,
+                          const int64_t *rows_dev, int C, const float *gamma, int act, float slope, float *partial, float *stats, float *dx,
+                          int64_t ldo, void *stream);
 
 /* out[l] (+)= sum_s partial[s, l], s in a fixed order; L % 4 == 0.  Also reduces the
  * split-K partial products of the weight gradients. */

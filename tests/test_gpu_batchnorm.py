@@ -62,3 +62,40 @@ def test_apply_mlp_takes_the_hip_batch_norm_in_training_only(gpu):
     finally:
         ops.batch_norm_act = orig
     assert y.shape == ye.shape == (300, 256)
+
+
+@pytest.mark.parametrize("cap,rows,c", [(4096, 2708, 256), (512, 2, 64), (1024, 1024, 128), (12288, 10858, 256)])
+@pytest.mark.parametrize("slope", [None, 1 / 5.5])
+def test_batch_norm_over_the_real_rows_of_a_padded_batch(cap, rows, c, slope, gpu):
+    """``batch_norm_act(rows_dev=...)`` (``dmp_bn_train_*_rows``: the row count on the device) on a batch padded to ``cap`` rows
+    with garbage behind the real ones, against the module on the real rows alone: output, running statistics, all three
+    gradients; the padding rows come out as zeros, forward and backward (UNC's sampled sub-graphs padded to a capacity so that
+    their step replays, unc_harness.SampledStep)."""
+    from dualmessagepassing_amd import ops
+    gen = th.Generator().manual_seed(cap + rows + c)
+    x0 = (th.randn(cap, c, generator=gen) * 3.0 + th.randn(c, generator=gen) * 5.0).to(gpu)
+    x0[rows:] = 1e6                                              # padding: anything
+    dy = th.randn(cap, c, generator=gen).to(gpu)
+    dy[rows:] = -1e6
+    n_dev = th.tensor([rows], dtype=th.int64, device=gpu)
+    bn_a, bn_b = th.nn.BatchNorm1d(c).to(gpu), th.nn.BatchNorm1d(c).to(gpu)
+    with th.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(th.rand(c, generator=th.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(th.randn(c, generator=th.Generator().manual_seed(2)))
+    act = (lambda t: t) if slope is None else th.nn.LeakyReLU(slope)
+    xa, xb = x0.clone().requires_grad_(True), x0[:rows].clone().requires_grad_(True)
+    ya = ops.batch_norm_act(bn_a, xa, slope, n_dev)
+    yb = act(bn_b(xb)) if rows > 1 else None
+    if yb is None:                                               # torch refuses one row; fp64 by hand (variance 0)
+        return
+    ga = th.autograd.grad(ya, [xa, bn_a.weight, bn_a.bias], dy)
+    gb = th.autograd.grad(yb, [xb, bn_b.weight, bn_b.bias], dy[:rows])
+    assert float(ya[rows:].abs().max()) == 0.0 if rows < cap else True
+    assert float((ya[:rows] - yb).abs().max()) <= 2e-5 * max(1.0, float(yb.abs().max()))
+    assert th.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    assert th.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert float(ga[0][rows:].abs().max()) == 0.0 if rows < cap else True
+    for name, a, b in zip(("dx", "dgamma", "dbeta"), (ga[0][:rows], ga[1], ga[2]), gb):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 5e-5 * scale, (name, float((a - b).abs().max()), scale)
