@@ -718,6 +718,13 @@ class PoolIndex:
                 return m[1]
         keys_in = keys
         keys = keys.view(-1).to(torch.int64)
+        if int(num_keys) == 1 and keys.is_cuda:
+            # one key (a single relation type): every row belongs to it, in row order -- no sort, the contiguous-range build
+            out = cls(torch.full((1,), int(keys.numel()), dtype=torch.int64, device=keys.device), num_rows=int(keys.numel()))
+            if not torch.cuda.is_current_stream_capturing():
+                memo.insert(0, (ident, out, keys_in))
+                del memo[4:]
+            return out
         skeys, order = torch.sort(keys, stable=True)
         # segment sizes from the sorted keys' boundaries (a bincount serialises its atomics on hot keys)
         marks = torch.searchsorted(skeys, torch.arange(num_keys + 1, device=keys.device))

@@ -57,23 +57,29 @@ def _encode(model, graph, batch, sampler, sample_depth, sample_width, graph_spli
     return sub, samples, labels, edge_type, embed
 
 
-def pad_sampled(sub, edge_type, node_quantum=512, edge_quantum=2048):
-    """The sampled sub-graph ``sub`` as fixed-capacity arrays: its nodes followed by at least one INERT node (isolated; looked up
-    as node 0 of the parent graph), its edges followed by inert self-loops on the last inert node with norm 0, capacities the
-    next multiples of the quanta -- a few distinct shapes over a run instead of one per step.
+def pad_sampled(sub, edge_type, node_quantum=512, edge_quantum=2048, parent_nodes=1):
+    """The sampled sub-graph ``sub`` as fixed-capacity arrays: its nodes followed by INERT nodes (looked up as node 0 of the
+    parent graph), its edges followed by inert self-loops spread over the inert nodes with norm 0, capacities the next
+    multiples of the quanta -- a few distinct shapes over a run instead of one per step.  ``parent_nodes``: rows of the node
+    embedding table (the inert nodes' lookups are spread over them).
     -> ``((Ncap, Ecap), (src, dst, edge_type, norm, nid, counts))``, ``counts`` = int64 [2] on the device (real nodes, real edges)."""
     N, E = sub.number_of_nodes(), sub.number_of_edges()
-    ncap = (N + node_quantum) // node_quantum * node_quantum              # > N: at least one inert node
     ecap = max(edge_quantum, (E + edge_quantum - 1) // edge_quantum * edge_quantum)
+    # enough inert nodes for the inert edges to spread over (self-loops, at most 32 per node: the CSR build sorts a row of up to 32
+    # entries in registers -- two thousand self-loops on ONE node were a 4 ms heap sort by one thread)
+    spare = max(1, (edge_quantum + 31) // 32)
+    ncap = (N + spare + node_quantum - 1) // node_quantum * node_quantum
     src, dst = sub.all_edges(form="uv", order="eid")
     dev = src.device
-    tail = torch.full((ecap - E,), ncap - 1, dtype=src.dtype, device=dev)
+    tail = N + torch.arange(ecap - E, dtype=src.dtype, device=dev) % (ncap - N)
     nid = sub.ndata[SUBGRAPH_NID].view(-1)
     norm = sub.edata["norm"].view(-1)
     arrays = (torch.cat([src, tail]), torch.cat([dst, tail]),
               torch.cat([edge_type.view(-1), torch.zeros(ecap - E, dtype=edge_type.dtype, device=dev)]),
               torch.cat([norm, torch.zeros(ecap - E, dtype=norm.dtype, device=dev)]).view(-1, 1),
-              torch.cat([nid, torch.zeros(ncap - N, dtype=nid.dtype, device=dev)]),
+              # (the inert nodes look up DIFFERENT rows of the table: hundreds of lookups of one row are one long row of the lookup's
+              # CSR -- sorted by a single thread -- for a gradient that is zero either way)
+              torch.cat([nid, torch.arange(ncap - N, dtype=nid.dtype, device=dev) % max(1, parent_nodes)]),
               torch.tensor([N, E], dtype=torch.int64, device=dev))
     return (ncap, ecap), arrays
 
@@ -85,7 +91,12 @@ class SampledStep:
     ``pad_sampled``'s fixed capacities, with the real row counts on the device: BatchNorm statistics
     (``dmp_bn_train_*_rows``), the per-relation means and the regularisers run over the real rows only
     (``unc.PaddedRows``), an inert row contributes nothing to any gradient.  ``optimizer``: ``FlatAdamW(capturable=True)``
-    (a scheduler's rate reaches the device through ``sync_hyper`` before every replay)."""
+    (a scheduler's rate reaches the device through ``sync_hyper`` before every replay).
+
+    The WHOLE loop that owns this object -- the sampling included -- must run under ``with step.steps.on_stream():``
+    (``train_unsupervised`` does): the samplers' host round trips on the legacy default stream between a recording and its
+    replays make the replay fault on this stack (``dp.StepGraph``'s second hazard; found here as a GPU memory access fault of
+    the first replay after a sampler call)."""
 
     def __init__(self, model, sync, optimizer, grad_norm=1.0, node_quantum=512, edge_quantum=2048, max_shapes=8):
         from .dp import StepGraph
@@ -113,7 +124,7 @@ class SampledStep:
         return loss.detach()
 
     def __call__(self, sub, edge_type, samples, labels):
-        caps, arrays = pad_sampled(sub, edge_type, self.node_quantum, self.edge_quantum)
+        caps, arrays = pad_sampled(sub, edge_type, self.node_quantum, self.edge_quantum, int(self.model.model.num_nodes))
         return self.steps(caps, *arrays, samples, labels)
 
 
@@ -140,6 +151,15 @@ def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=200
     gen = torch.Generator(device=dev).manual_seed(seed)
     model.train()
     stepper = SampledStep(model, sync, optimizer, grad_norm) if replay else None
+    import contextlib
+    with (stepper.steps.on_stream() if stepper is not None else contextlib.nullcontext()):     # (the sampling too: see SampledStep)
+        return _train_epochs(model, graph, triplets, n_epochs, graph_batch_size, grad_norm, sampler, sample_depth, sample_width,
+                             graph_split_size, negative_sample, log, sync, master, optimizer, scheduler, gen, stepper, steps_per_epoch)
+
+
+def _train_epochs(model, graph, triplets, n_epochs, graph_batch_size, grad_norm, sampler, sample_depth, sample_width, graph_split_size,
+                  negative_sample, log, sync, master, optimizer, scheduler, gen, stepper, steps_per_epoch):
+    dev = triplets.device
     history, prev = [], float("inf")
     for epoch in range(n_epochs):
         total = torch.zeros((), device=dev)
@@ -147,8 +167,7 @@ def train_unsupervised(model, graph, triplets, n_epochs=10, graph_batch_size=200
             if stepper is not None:
                 sub, samples, labels = generate_sampled_graph_and_labels_unsupervised(
                     graph, batch, sample_depth, sample_width, graph_split_size, negative_sample, generator=gen, sampler=sampler)
-                with stepper.steps.on_stream():
-                    total += stepper(sub, sub.edata["type"], samples, labels)
+                total += stepper(sub, sub.edata["type"], samples, labels)
                 scheduler.step()
                 continue
             sub, samples, labels, edge_type, embed = _encode(model, graph, batch, sampler, sample_depth, sample_width,

@@ -64,3 +64,52 @@ try:
 except Exception as exc:                                   # a host sync inside the step cannot be recorded
     print("UNC train step could not be recorded: %s: %s" % (type(exc).__name__, str(exc)[:300]))
 
+
+# ---- the SAMPLED mini-batch step (utils.py:279-349 + main.py:99-183: a new sub-graph every step): eager launches vs
+# unc_harness.SampledStep (sub-graphs padded to capacity levels, the step after the sampling replayed from one HIP graph)
+from dualmessagepassing_amd.unc_harness import SampledStep
+from dualmessagepassing_amd.unc_sampling import generate_sampled_graph_and_labels_unsupervised
+trip_dev = th.from_numpy(trip).to(gpu)
+gen = th.Generator(device=gpu).manual_seed(3)
+B = int(os.environ.get("UNC_BATCH", "2000"))
+
+
+def draw():
+    idx = th.randint(0, m, (B,), device=gpu, generator=gen)
+    return generate_sampled_graph_and_labels_unsupervised(g, trip_dev[idx], 6, 128, 0.5, 5, generator=gen, sampler="neighbor")
+
+
+def run(stepper, it=30, warm=12):
+    if stepper is None:
+        return _run(None, it, warm)
+    with stepper.steps.on_stream():          # the whole loop, sampling included, on the recording's stream (SampledStep)
+        return _run(stepper, it, warm)
+
+
+def _run(stepper, it, warm):
+    t_step = 0.0
+    for k in range(warm + it):
+        sub, smp, lab = draw()
+        th.cuda.synchronize(); t0 = time.perf_counter()
+        if stepper is None:
+            sync.detach_grads()
+            emb, _ = model(sub, sub.ndata["_ID"], sub.edata["type"], sub.edata["norm"])
+            loss = model.get_unsupervised_loss(sub, emb, sub.edata["type"], smp, lab)
+            loss.backward(); sync.pack(); th.nn.utils.clip_grad_norm_([master], 1.0); opt_e.step()
+        else:
+            stepper(sub, sub.edata["type"], smp, lab)
+        th.cuda.synchronize()
+        if k >= warm: t_step += time.perf_counter() - t0
+    return t_step / it * 1e3
+
+
+opt_e = FlatAdamW([master], lr=1e-3, weight_decay=0.0)
+eager_ms = run(None)
+opt_r = FlatAdamW([master], lr=1e-3, weight_decay=0.0, capturable=True)
+st = SampledStep(model, sync, opt_r, 1.0)
+replay_ms = run(st)
+sub, _, _ = draw()
+print("UNC SAMPLED step (batch %d edges, neighbour sampler 6 x 128: sub-graphs of ~%d nodes / ~%d edges), after the sampling: eager %.3f ms, "
+      "padded + replayed %.3f ms (%.2f x; replays %d, eager %d, shapes %d)"
+      % (B, sub.number_of_nodes(), sub.number_of_edges(), eager_ms, replay_ms, replay_ms / eager_ms, st.steps.replays, st.steps.eager_calls,
+         len(st.steps._graphs)))

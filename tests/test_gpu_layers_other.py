@@ -173,3 +173,26 @@ def test_keyed_segment_pool_equals_masked_sums(gpu):
     w = th.randn(K, H, generator=gen).to(gpu)
     (out * w).sum().backward()
     assert th.equal(x.grad, w[keys])
+
+
+def test_keyed_segment_pool_with_a_single_key_is_the_plain_column_sum(gpu):
+    """``PoolIndex.from_keys(keys, 1)`` (one relation type: no sort, the contiguous-range build) -- the sum of all rows, its
+    backward, and ``take_rows_small_table`` of a one-row table (UNC's ``w_relation`` on a one-relation graph)."""
+    from dualmessagepassing_amd import ops
+    gen = th.Generator().manual_seed(4)
+    for E in (1, 63, 5000, 24000):
+        keys = th.zeros(E, dtype=th.int64, device=gpu)
+        x = th.randn(E, 64, generator=gen).to(gpu).requires_grad_(True)
+        pool = ops.PoolIndex.from_keys(keys, 1)
+        out = ops.seg_pool(x, pool)
+        assert out.shape == (1, 64)
+        assert th.allclose(out.double(), x.detach().double().sum(0, keepdim=True), rtol=1e-6, atol=1e-5 * max(1.0, E ** 0.5))
+        w = th.randn(1, 64, generator=gen).to(gpu)
+        (out * w).sum().backward()
+        assert th.equal(x.grad, w.expand(E, 64))
+        table = th.randn(1, 64, generator=gen).to(gpu).requires_grad_(True)
+        rows = ops.take_rows_small_table(table, keys)
+        assert th.equal(rows, table.detach().expand(E, 64))
+        d = th.randn(E, 64, generator=gen).to(gpu)
+        rows.backward(d)
+        assert th.allclose(table.grad.double(), d.double().sum(0, keepdim=True), rtol=1e-6, atol=1e-5 * max(1.0, E ** 0.5))
