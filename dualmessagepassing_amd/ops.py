@@ -667,7 +667,7 @@ def apply_mlp(seq, x, rows_dev=None):
     """Run an ``nn.Sequential`` of Linear / BatchNorm / activation modules (nmlp / emlp,
     dmpnn.py:45-60) with the Linear layers on ``linear_nn``, Linear+ReLU pairs fused and training-mode
     BatchNorm1d (+ the activation after it) on ``batch_norm_act``.  ``rows_dev``: x's rows past that device-side count
-    are padding (a BatchNorm the kernels cannot take then refuses: its statistics would include them)."""
+    are padding (a BatchNorm the kernels cannot take then runs as ``masked_batch_norm``: tensor ops over the real rows)."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -684,10 +684,33 @@ def apply_mlp(seq, x, rows_dev=None):
             i += 2 if slope is not None else 1
         else:
             if rows_dev is not None and isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training:
-                raise _lib.DmpError("apply_mlp: a padded batch needs the HIP BatchNorm (statistics over the real rows only)")
-            x = m(x)
+                x = masked_batch_norm(m, x, rows_dev)         # a width the kernels do not take (the reference's hid 50): tensor ops
+            else:
+                x = m(x)
             i += 1
     return x
+
+
+def masked_batch_norm(bn, x, rows_dev):
+    """Training-mode ``BatchNorm1d`` over the first ``rows_dev[0]`` rows of ``x`` with tensor ops (no host sync: it records):
+    statistics and running averages from those rows only, zeros in the others -- what ``batch_norm_act(rows_dev=...)`` does
+    for the widths the HIP kernels take."""
+    R = x.size(0)
+    n = rows_dev.to(x.dtype).clamp(min=1.0)
+    m = (torch.arange(R, device=x.device) < rows_dev).to(x.dtype).unsqueeze(1)
+    mean = (x * m).sum(0) / n
+    d = (x - mean) * m
+    var = (d * d).sum(0) / n
+    y = d / torch.sqrt(var + bn.eps)
+    if bn.weight is not None:
+        y = y * bn.weight + bn.bias
+    with torch.no_grad():
+        if bn.track_running_stats and bn.running_mean is not None:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.num_batches_tracked.add_(1)
+            bn.running_mean.mul_(1 - mom).add_(mom * mean.detach())
+            bn.running_var.mul_(1 - mom).add_(mom * (var.detach() * n / (n - 1.0).clamp(min=1.0)))
+    return y * m
 
 
 # ----------------------------------------------------------------------------- per-graph pooling

@@ -99,3 +99,29 @@ def test_batch_norm_over_the_real_rows_of_a_padded_batch(cap, rows, c, slope, gp
     for name, a, b in zip(("dx", "dgamma", "dbeta"), (ga[0][:rows], ga[1], ga[2]), gb):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 5e-5 * scale, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("cap,rows,c", [(1024, 700, 50), (512, 3, 50)])
+def test_masked_batch_norm_with_tensor_ops_for_widths_the_kernels_do_not_take(cap, rows, c, gpu):
+    """``ops.masked_batch_norm`` (the reference's shipped UNC width, hid 50, is not a multiple of 4): ``apply_mlp`` of a padded
+    batch falls back to it -- against the module on the real rows alone: output, running statistics, gradients."""
+    from dualmessagepassing_amd import ops
+    gen = th.Generator().manual_seed(cap + rows)
+    x0 = (th.randn(cap, c, generator=gen) * 2.0 + 3.0).to(gpu)
+    x0[rows:] = 1e4
+    dy = th.randn(cap, c, generator=gen).to(gpu)
+    n_dev = th.tensor([rows], dtype=th.int64, device=gpu)
+    seq_a = th.nn.Sequential(th.nn.Linear(c, c), th.nn.BatchNorm1d(c), th.nn.LeakyReLU(0.2), th.nn.Linear(c, c)).to(gpu)
+    import copy
+    seq_b = copy.deepcopy(seq_a)
+    xa, xb = x0.clone().requires_grad_(True), x0[:rows].clone().requires_grad_(True)
+    ya = ops.apply_mlp(seq_a, xa, n_dev)
+    yb = seq_b(xb)
+    assert float((ya[:rows] - yb).abs().max()) <= 2e-5 * max(1.0, float(yb.abs().max()))
+    assert th.allclose(seq_a[1].running_mean, seq_b[1].running_mean, rtol=1e-5, atol=1e-6)
+    assert th.allclose(seq_a[1].running_var, seq_b[1].running_var, rtol=1e-4, atol=1e-6)
+    ga = th.autograd.grad((ya[:rows] * dy[:rows]).sum(), [xa] + list(seq_a.parameters()))
+    gb = th.autograd.grad((yb * dy[:rows]).sum(), [xb] + list(seq_b.parameters()))
+    assert float(ga[0][rows:].abs().max()) == 0.0
+    for a, b in zip([ga[0][:rows]] + list(ga[1:]), gb):
+        assert float((a - b).abs().max()) <= 5e-5 * max(1.0, float(b.abs().max())) + 1e-6
